@@ -1,0 +1,248 @@
+/*
+ * jrx.h -- C ABI of the MI355X-native pseudo-transient (PT) Stokes / heat-diffusion hot path.
+ *
+ * This is the drop-in boundary for JustRelax.jl's backend method table: a Julia extension
+ * defines solve!(::Trait, stokes, ...), heatdiffusion_PT!(::Trait, thermal, ...), flow_bcs!,
+ * thermal_bcs!, velocity2displacement!, compute_maxloc! for its trait and forwards each to one
+ * entry point below with `ccall`, passing `pointer(A)` of its ROCArray{Float64} fields
+ * (INTEGRATION.md shows the shim).  Reference seam being replaced:
+ *   src/ext/AMDGPU/3D.jl:397-407, src/ext/AMDGPU/2D.jl (forwarding methods onto _solve!),
+ *   src/stokes/Stokes3D.jl:18-23, src/stokes/Stokes2D.jl:12-17,
+ *   src/thermal_diffusion/DiffusionPT_solver.jl:11-17.
+ * All file:line citations are relative to the reference checkout (PTsolvers/JustRelax.jl v0.7.1).
+ *
+ * Conventions
+ *  - every array is device memory, fp64, dense, column-major (x fastest) -- Julia's layout; the
+ *    library never allocates, frees or re-lays-out a caller array (the caller keeps them alive
+ *    for the duration of the call: GC.@preserve);
+ *  - extents follow src/types/constructors/stokes.jl and .../heat_diffusion.jl, e.g. in 3D with
+ *    ni = (nx,ny,nz): Vx (nx+1,ny+2,nz+2), txy (nx+1,ny+1,nz), Rx (nx-1,ny,nz), T (nx+2,ny+2);
+ *  - calls are synchronous at the ABI (they return after the handle's stream has drained) except
+ *    the *_async kernels-only entry points, which only enqueue;
+ *  - every function returns a jrx_status; jrx_last_error() gives the message. Never aborts.
+ *  - a handle is bound to one GPU and is not thread-safe (one handle per GPU / per rank).
+ */
+#ifndef JRX_H
+#define JRX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JRX_VERSION 100
+
+typedef enum jrx_status {
+    JRX_OK = 0,
+    JRX_ERR_NAN = 1,        /* error("NaN(s)") -- src/stokes/Stokes3D.jl:162 */
+    JRX_ERR_HIP = 2,
+    JRX_ERR_RCCL = 3,
+    JRX_ERR_ARG = 4,
+    JRX_ERR_UNSUPPORTED = 5
+} jrx_status;
+
+/* Boundary faces: one bit per face, names as in the reference's NamedTuples
+ * (src/boundaryconditions/types.jl:108-157).  NOTE the reference's own 3D conventions, kept
+ * verbatim: free_slip! maps `top` to k = 1 and `bot` to k = end (free_slip.jl:35-50); no_slip!
+ * maps `bot` to k = 1 and `top` to k = end (no_slip.jl:44-53); periodic: bot = k = 1.
+ * In 2D: bot <-> j = 1, top <-> j = end for all three. */
+enum {
+    JRX_FACE_LEFT = 1, JRX_FACE_RIGHT = 2, JRX_FACE_FRONT = 4, JRX_FACE_BACK = 8,
+    JRX_FACE_TOP = 16, JRX_FACE_BOT = 32
+};
+
+typedef struct jrx_handle jrx_handle;
+
+/* ------------------------------------------------------------------ lifetime */
+/* Creates streams, events and reduction scratch on `device`. */
+jrx_status jrx_create(int32_t device, jrx_handle **out);
+jrx_status jrx_destroy(jrx_handle *h);
+const char *jrx_last_error(const jrx_handle *h);   /* h may be NULL: last creation error */
+int32_t jrx_version(void);
+
+/* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)
+ * ImplicitGlobalGrid semantics used by the reference: local arrays of n cells overlap
+ * the neighbour by 2 cells; an array of extent nA along a split dimension has overlap
+ * ol_A = 2 + (nA - n); update_halo! sends plane ol_A (1-based) to the left neighbour and plane
+ * nA - ol_A + 1 to the right one, and receives into planes 1 and nA. */
+typedef struct jrx_cart {
+    int32_t rank, nprocs;
+    int32_t dims[3], coords[3];
+    int32_t periods[3];
+    int32_t neighbor[3][2];     /* [dim][0=left,1=right], -1 = physical boundary */
+} jrx_cart;
+/* dims = all zeros -> balanced factorisation over the dimensions with n[d] > 1 */
+jrx_status jrx_cart_create(int32_t rank, int32_t nprocs, const int64_t n[3], const int32_t dims_in[3],
+                           const int32_t periods[3], jrx_cart *out);
+/* 0-based plane indices for an array of extent nA in a dimension of n local cells */
+jrx_status jrx_halo_planes(int64_t n, int64_t nA, int64_t *send_left, int64_t *send_right,
+                           int64_t *recv_left, int64_t *recv_right);
+int64_t jrx_n_global(int64_t n, int32_t dims, int32_t periodic);   /* nx_g() */
+
+/* RCCL communicator for the halo exchange + norm all-reduce (one rank per GPU).
+ * Rank 0 calls jrx_comm_unique_id and ships the 128 bytes to the others out of band
+ * (MPI.Bcast in Julia, torch.distributed in the Python host), then every rank calls init. */
+#define JRX_UNIQUE_ID_BYTES 128
+jrx_status jrx_comm_unique_id(uint8_t id[JRX_UNIQUE_ID_BYTES]);
+jrx_status jrx_comm_init(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], const jrx_cart *cart);
+jrx_status jrx_comm_destroy(jrx_handle *h);
+/* update_halo!(A...) for up to 8 arrays, each of extents ext[a][0..2] on a local grid of n cells
+ * (call sites: src/stokes/Stokes3D.jl:57,120; src/stokes/Stokes2D.jl:209,268;
+ * src/thermal_diffusion/DiffusionPT_solver.jl:110).  Dimension by dimension (x, y, z). */
+jrx_status jrx_update_halo(jrx_handle *h, int32_t narrays, double *const *arrays, const int64_t (*ext)[3],
+                           const int64_t n[3]);
+
+/* ------------------------------------------------------------------ 3D Stokes, isoviscous visco-elastic variant */
+typedef struct jrx_stokes3d_fields {
+    double *P, *P0, *divV, *Q;                       /* ni                         (stokes.P, P0, ∇V, Q) */
+    double *Vx, *Vy, *Vz;                            /* staggered                  (stokes.V)            */
+    double *Ux, *Uy, *Uz;                            /* as V                       (stokes.U)            */
+    double *txx, *tyy, *tzz, *tyz, *txz, *txy;       /* @stress(stokes)  -- Voigt order of src/Utils.jl:230-239 */
+    double *toxx, *toyy, *tozz, *toyz, *toxz, *toxy; /* @tensor(stokes.τ_o)                              */
+    double *exx, *eyy, *ezz, *eyz, *exz, *exy;       /* @strain(stokes)                                  */
+    double *eta;                                     /* stokes.viscosity.η, ni                           */
+    double *K, *G;                                   /* bulk / shear modulus arrays, ni (may hold Inf)   */
+    double *fx, *fy, *fz;                            /* ρg, ni                                           */
+    double *RP, *Rx, *Ry, *Rz;                       /* stokes.R                                         */
+    double *tyz_c, *txz_c, *txy_c, *toyz_c, *toxz_c, *toxy_c;  /* centre shear copies for multi_copy!, may be NULL */
+} jrx_stokes3d_fields;
+
+typedef struct jrx_stokes3d_params {
+    int64_t nx, ny, nz;            /* size(stokes.P) on this rank */
+    int64_t nxg, nyg, nzg;         /* nx_g(), ny_g(), nz_g() */
+    double _dx, _dy, _dz;          /* grid._di.center */
+    double dt;                     /* may be Inf */
+    double r, theta_dtau, eta_dtau;/* PTStokesCoeffs: r, θ_dτ, ηdτ (src/types/stokes.jl:203-229) */
+    double eps_rel, eps_abs;       /* ϵ_rel, ϵ_abs */
+    int64_t iterMax, nout;         /* kwargs of solve! (Stokes3D.jl:35-41) */
+    uint32_t free_slip, no_slip, periodic;   /* JRX_FACE_* masks of flow_bcs */
+    int32_t b_width[3];            /* boundary-slab width for comm/compute overlap (default 4,4,4) */
+    int32_t verbose;               /* print the reference's per-check line on rank 0 */
+} jrx_stokes3d_params;
+
+typedef struct jrx_solve_result {
+    int64_t iter;                  /* iterations executed */
+    int64_t nchecks;               /* entries filled in the histories below */
+    int64_t cap;                   /* capacity of each history buffer (>= iterMax/nout + 1) */
+    double *err_evo1; int64_t *err_evo2;
+    double *norm_Rx, *norm_Ry, *norm_Rz, *norm_divV;   /* norm_Rz unused in 2D */
+    double time_s, av_time_s;      /* wtime0 and wtime0/(iter-1) as in Stokes3D.jl:170,183-184 */
+} jrx_solve_result;
+
+/* solve!(stokes, pt_stokes, grid, flow_bcs, ρg, K, G, dt, igg; kwargs) -- src/stokes/Stokes3D.jl:25-186.
+ * Runs the whole PT loop on the device: compute_maxloc!(ητ, η) (+halo), then per iteration
+ * compute_∇V!, compute_P!, compute_strain_rate!, compute_τ!, compute_V!, velocity2displacement!,
+ * flow_bcs!, update_halo!(V), L2 residual norms every nout iterations, and the final τ -> τ_o copy.
+ * All outputs the reference leaves in StokesArrays after the call (∇V, ε, R, U included) are
+ * left identical. */
+jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p,
+                              jrx_solve_result *res);
+
+/* Finer-grained entry points (each mirrors reference kernels; used by the parity tests, and by
+ * callers that drive the loop themselves).  `etatau` is the ητ array of compute_maxloc!.
+ * flags for the fused sweeps: */
+enum {
+    JRX_OUT_STATE_ONLY = 0,     /* write only the state the next sweep needs (P, τ / V) */
+    JRX_OUT_DIAG = 1            /* also write ∇V, ε, RP (stress sweep) / R, U (velocity sweep) */
+};
+/* compute_∇V! + compute_P! + compute_strain_rate! + compute_τ!  (VelocityKernels.jl:3-6,59-104;
+ * PressureKernels.jl:10-15,186-195; StressKernels.jl:149-230) fused into one sweep over ni.+1 */
+jrx_status jrx_stokes3d_sweep_stress(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p,
+                                     int32_t flags);
+/* compute_V! (VelocityKernels.jl:182-242) + velocity2displacement! (types/displacement.jl:17-28) */
+jrx_status jrx_stokes3d_sweep_velocity(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
+                                       const jrx_stokes3d_params *p, int32_t flags);
+/* flow_bcs! -- BoundaryConditions.jl:86-100 (no_slip, free_slip, periodic, in that order) */
+jrx_status jrx_flow_bcs3d(jrx_handle *h, double *Vx, double *Vy, double *Vz, int64_t nx, int64_t ny, int64_t nz,
+                          uint32_t free_slip, uint32_t no_slip, uint32_t periodic);
+/* Σx² of Rx,Ry,Rz[2:end-1,2:end-1,2:end-1] and of RP (local part of norm_mpi, Stokes3D.jl:127-142) */
+jrx_status jrx_stokes3d_residual_sumsq(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p,
+                                       double out[4]);
+/* compute_maxloc!(B, A; window=(1,1,1)) -- src/Utils.jl:409-461 ; nz = 1 selects the 2D form */
+jrx_status jrx_compute_maxloc(jrx_handle *h, double *B, const double *A, int64_t nx, int64_t ny, int64_t nz);
+
+/* ------------------------------------------------------------------ 2D Stokes, visco-elastic variant */
+typedef struct jrx_stokes2d_fields {
+    double *P, *P0, *divV, *Q;
+    double *Vx, *Vy, *Ux, *Uy;
+    double *txx, *tyy, *txy, *toxx, *toyy, *toxy;
+    double *exx, *eyy, *exy;
+    double *eta, *K, *G;
+    double *fx, *fy;
+    double *RP, *Rx, *Ry;
+    double *txy_c, *toxy_c;        /* may be NULL */
+} jrx_stokes2d_fields;
+
+typedef struct jrx_stokes2d_params {
+    int64_t nx, ny, nxg, nyg;
+    double _dx, _dy;
+    double dt, r, theta_dtau, eta_dtau, eps_rel, eps_abs;
+    int64_t iterMax, nout;
+    uint32_t free_slip, no_slip, periodic;
+    int32_t verbose;
+} jrx_stokes2d_params;
+
+/* solve!(stokes, pt_stokes, grid, flow_bcs, ρg, G, K, dt, igg; kwargs) -- src/stokes/Stokes2D.jl:181-325 */
+jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const jrx_stokes2d_params *p,
+                              jrx_solve_result *res);
+jrx_status jrx_stokes2d_sweep_stress(jrx_handle *h, const jrx_stokes2d_fields *f, const double *etatau,
+                                     const jrx_stokes2d_params *p, int32_t flags);
+jrx_status jrx_stokes2d_sweep_velocity(jrx_handle *h, const jrx_stokes2d_fields *f, const double *etatau,
+                                       const jrx_stokes2d_params *p, int32_t flags);
+/* compute_Res! -- VelocityKernels.jl:246-269 */
+jrx_status jrx_stokes2d_compute_res(jrx_handle *h, const jrx_stokes2d_fields *f, const jrx_stokes2d_params *p);
+jrx_status jrx_flow_bcs2d(jrx_handle *h, double *Vx, double *Vy, int64_t nx, int64_t ny,
+                          uint32_t free_slip, uint32_t no_slip, uint32_t periodic);
+jrx_status jrx_stokes2d_residual_sumsq(jrx_handle *h, const jrx_stokes2d_fields *f, const jrx_stokes2d_params *p,
+                                       double out[3]);
+
+/* ------------------------------------------------------------------ 2D PT heat diffusion */
+typedef struct jrx_thermal2d_fields {
+    double *T, *Told, *dT;                 /* (nx+2, ny+2): thermal.T, Told, ΔT */
+    double *qTx, *qTx2;                    /* (nx+1, ny)   */
+    double *qTy, *qTy2;                    /* (nx, ny+1)   */
+    double *H, *shear_heating, *ResT;      /* (nx, ny)     */
+    double *K, *rhoCp;                     /* (nx, ny); unused (may be NULL) in the rheology form */
+    double *thetar_dtau, *dtau_rho;        /* (nx, ny): pt_thermal.θr_dτ, dτ_ρ */
+} jrx_thermal2d_fields;
+
+typedef struct jrx_thermal2d_params {
+    int64_t nx, ny;
+    double _dx, _dy;
+    double dt, eps;                        /* pt_thermal.ϵ */
+    int64_t iterMax, nout;
+    /* faces in the order left, right, top, bot (2D: bot <-> j = 1) */
+    int32_t no_flux[4];
+    int32_t constant_value_on[4]; double constant_value[4];
+    int32_t constant_flux_on[4];  double constant_flux[4];
+    int32_t periodic[4];
+    /* 0: array-coefficient form (DiffusionPT_solver.jl:34-149);
+     * 1: rheology form restricted to constant k, constant Cp, rho = rho0*(1 - alpha*(T - T0))
+     *    (DiffusionPT_solver.jl:181-305 as evaluated by test/test_diffusion2D.jl) */
+    int32_t rheology_form;
+    double k_const, Cp, rho0, alpha, T0;
+    int32_t verbose;
+} jrx_thermal2d_params;
+
+/* heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, K, ρCp | rheology, args, dt, grid; kwargs) */
+jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p,
+                                  int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms);
+/* thermal_bcs! -- BoundaryConditions.jl:39-53 */
+jrx_status jrx_thermal_bcs2d(jrx_handle *h, double *T, const jrx_thermal2d_params *p);
+/* one PT iteration: compute_flux! + update_T! + thermal_bcs! (DiffusionPT_solver.jl:236-261) */
+jrx_status jrx_thermal2d_iteration(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p);
+/* check_res! (DiffusionPT_kernels.jl:603-668) */
+jrx_status jrx_thermal2d_check_res(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p);
+
+/* ------------------------------------------------------------------ timing hooks for bench.py */
+/* Runs `iters` PT iterations of the 3D loop body (no norm checks) and returns the device time of
+ * the whole batch and of the stress / velocity sweeps alone, measured with hipEvents on the
+ * handle's stream. */
+jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
+                                      const jrx_stokes3d_params *p, int64_t iters,
+                                      double *total_ms, double *stress_ms, double *velocity_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JRX_H */

@@ -1,0 +1,171 @@
+"""ctypes binding of libjrx_hip.so (the C ABI of include/jrx.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "lib" / "libjrx_hip.so"
+HEADER = HERE.parent / "include" / "jrx.h"
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+STATUS = {0: "JRX_OK", 1: "JRX_ERR_NAN", 2: "JRX_ERR_HIP", 3: "JRX_ERR_RCCL", 4: "JRX_ERR_ARG", 5: "JRX_ERR_UNSUPPORTED"}
+FACE = dict(left=1, right=2, front=4, back=8, top=16, bot=32)
+OUT_STATE_ONLY, OUT_DIAG = 0, 1
+UNIQUE_ID_BYTES = 128
+
+F3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",
+            "txx", "tyy", "tzz", "tyz", "txz", "txy", "toxx", "toyy", "tozz", "toyz", "toxz", "toxy",
+            "exx", "eyy", "ezz", "eyz", "exz", "exy", "eta", "K", "G", "fx", "fy", "fz", "RP", "Rx", "Ry", "Rz",
+            "tyz_c", "txz_c", "txy_c", "toyz_c", "toxz_c", "toxy_c"]
+F2_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "txx", "tyy", "txy", "toxx", "toyy", "toxy",
+            "exx", "eyy", "exy", "eta", "K", "G", "fx", "fy", "RP", "Rx", "Ry", "txy_c", "toxy_c"]
+T2_NAMES = ["T", "Told", "dT", "qTx", "qTx2", "qTy", "qTy2", "H", "shear_heating", "ResT", "K", "rhoCp",
+            "thetar_dtau", "dtau_rho"]
+
+
+def _ptr_struct(name, names):
+    return type(name, (C.Structure,), {"_fields_": [(n, C.c_void_p) for n in names]})
+
+
+Stokes3DFields = _ptr_struct("Stokes3DFields", F3_NAMES)
+Stokes2DFields = _ptr_struct("Stokes2DFields", F2_NAMES)
+Thermal2DFields = _ptr_struct("Thermal2DFields", T2_NAMES)
+
+
+class Stokes3DParams(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64),
+                ("nxg", C.c_int64), ("nyg", C.c_int64), ("nzg", C.c_int64),
+                ("_dx", C.c_double), ("_dy", C.c_double), ("_dz", C.c_double),
+                ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
+                ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
+                ("b_width", C.c_int32 * 3), ("verbose", C.c_int32)]
+
+
+class Stokes2DParams(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nxg", C.c_int64), ("nyg", C.c_int64),
+                ("_dx", C.c_double), ("_dy", C.c_double),
+                ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
+                ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32), ("verbose", C.c_int32)]
+
+
+class Thermal2DParams(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("_dx", C.c_double), ("_dy", C.c_double),
+                ("dt", C.c_double), ("eps", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("no_flux", C.c_int32 * 4),
+                ("constant_value_on", C.c_int32 * 4), ("constant_value", C.c_double * 4),
+                ("constant_flux_on", C.c_int32 * 4), ("constant_flux", C.c_double * 4),
+                ("periodic", C.c_int32 * 4), ("rheology_form", C.c_int32),
+                ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double),
+                ("T0", C.c_double), ("verbose", C.c_int32)]
+
+
+class SolveResult(C.Structure):
+    _fields_ = [("iter", C.c_int64), ("nchecks", C.c_int64), ("cap", C.c_int64),
+                ("err_evo1", _dp), ("err_evo2", _ip),
+                ("norm_Rx", _dp), ("norm_Ry", _dp), ("norm_Rz", _dp), ("norm_divV", _dp),
+                ("time_s", C.c_double), ("av_time_s", C.c_double)]
+
+
+class Cart(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("nprocs", C.c_int32), ("dims", C.c_int32 * 3), ("coords", C.c_int32 * 3),
+                ("periods", C.c_int32 * 3), ("neighbor", (C.c_int32 * 2) * 3)]
+
+
+def declared_symbols() -> list:
+    """Every function include/jrx.h declares."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(jrx_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def load(check_symbols: bool = False):
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} not found: run `python justrelax.jl_amd/build.py` (hipcc, gfx950). "
+                               "There is no CPU fallback.")
+        import torch  # noqa: F401  -- loads the process-wide HIP runtime (libamdhip64.so.7) first
+        L = C.CDLL(str(LIB_PATH))
+        L.jrx_last_error.restype = C.c_char_p
+        L.jrx_last_error.argtypes = [C.c_void_p]
+        L.jrx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+        L.jrx_n_global.restype = C.c_int64
+        L.jrx_n_global.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        for name in declared_symbols():
+            fn = getattr(L, name)          # raises AttributeError if the symbol is not exported
+            if name not in ("jrx_last_error", "jrx_n_global", "jrx_version"):
+                fn.restype = C.c_int32
+        _lib = L
+    if check_symbols:
+        missing = [s for s in declared_symbols() if not hasattr(_lib, s)]
+        if missing:
+            raise RuntimeError(f"libjrx_hip.so lacks symbols declared in jrx.h: {missing}")
+    return _lib
+
+
+class JrxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS.get(status, status)}: {msg}")
+        self.status = status
+
+
+class Handle:
+    """jrx_handle: streams, events, reduction scratch, ητ, RCCL communicator.  One per GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        self._h = C.c_void_p()
+        st = self.lib.jrx_create(C.c_int32(device), C.byref(self._h))
+        if st != 0:
+            raise JrxError(st, self.lib.jrx_last_error(None).decode())
+        self.device = device
+
+    def check(self, st):
+        if st != 0:
+            raise JrxError(st, self.lib.jrx_last_error(self._h).decode())
+
+    def call(self, name, *args):
+        self.check(getattr(self.lib, name)(self._h, *args))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.jrx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_handles = {}
+
+
+def default_handle(device=None) -> Handle:
+    import torch
+    if device is None:
+        device = torch.cuda.current_device()
+    if device not in _handles:
+        _handles[device] = Handle(device)
+    return _handles[device]
+
+
+def bcmask(d) -> int:
+    m = 0
+    for k, v in (d or {}).items():
+        if v:
+            m |= FACE[k]
+    return m

@@ -1,0 +1,143 @@
+// handle.hip -- handle lifetime, error strings, and the host-only block-decomposition helpers.
+#include "jrx_internal.hpp"
+
+char g_jrx_create_err[512] = {0};
+
+jrx_status jrx_ensure_etatau(jrx_handle *h, size_t n)
+{
+    if (h->etatau_cap >= n) return JRX_OK;
+    if (h->etatau) JRX_HIP(h, hipFree(h->etatau));
+    h->etatau = nullptr;
+    h->etatau_cap = 0;
+    JRX_HIP(h, hipMalloc(&h->etatau, n * sizeof(double)));
+    h->etatau_cap = n;
+    return JRX_OK;
+}
+
+extern "C" {
+
+int32_t jrx_version(void) { return JRX_VERSION; }
+
+const char *jrx_last_error(const jrx_handle *h) { return h ? h->err : g_jrx_create_err; }
+
+jrx_status jrx_create(int32_t device, jrx_handle **out)
+{
+    if (!out) return jrx_fail(nullptr, JRX_ERR_ARG, "jrx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return jrx_fail(nullptr, JRX_ERR_HIP, "jrx_create: no HIP device visible");
+    if (device < 0 || device >= ndev) return jrx_fail(nullptr, JRX_ERR_ARG, "jrx_create: device %d out of range [0,%d)", device, ndev);
+    jrx_handle *h = new jrx_handle();
+    h->device = device;
+#define CK(call)                                                                                   \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            jrx_status st_ = jrx_fail(nullptr, JRX_ERR_HIP, "jrx_create: %s -> %s", #call, hipGetErrorString(e_)); \
+            delete h;                                                                              \
+            return st_;                                                                            \
+        }                                                                                          \
+    } while (0)
+    CK(hipSetDevice(device));
+    CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&h->halo_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) CK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));   // stream joins
+    for (int i = 3; i < 8; i++) CK(hipEventCreate(&h->ev[i]));                                    // timing
+    CK(hipMalloc(&h->d_partials, sizeof(double) * 4 * kMaxRedBlocks));
+    CK(hipMalloc(&h->d_sums, sizeof(double) * 8));
+    CK(hipHostMalloc(&h->h_sums, sizeof(double) * 8, hipHostMallocDefault));
+#undef CK
+    *out = h;
+    return JRX_OK;
+}
+
+jrx_status jrx_destroy(jrx_handle *h)
+{
+    if (!h) return JRX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->comm) (void)jrx_comm_destroy(h);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->halo_stream) (void)hipStreamSynchronize(h->halo_stream);
+    for (int i = 0; i < 8; i++)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->d_partials) (void)hipFree(h->d_partials);
+    if (h->d_sums) (void)hipFree(h->d_sums);
+    if (h->h_sums) (void)hipHostFree(h->h_sums);
+    if (h->etatau) (void)hipFree(h->etatau);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->halo_stream) (void)hipStreamDestroy(h->halo_stream);
+    delete h;
+    return JRX_OK;
+}
+
+// ---------------------------------------------------------------- block decomposition (host only)
+int64_t jrx_n_global(int64_t n, int32_t dims, int32_t periodic)
+{
+    if (n == 1) return 1;
+    return (int64_t)dims * (n - 2) + (periodic ? 0 : 2);
+}
+
+jrx_status jrx_halo_planes(int64_t n, int64_t nA, int64_t *send_left, int64_t *send_right, int64_t *recv_left, int64_t *recv_right)
+{
+    const int64_t ol = 2 + (nA - n);          // overlap of this array along the dimension
+    if (ol < 2 || nA < ol) return JRX_ERR_ARG;   // e.g. Rx (extent n-1): not exchangeable
+    if (send_left) *send_left = ol - 1;       // 1-based plane ol_A
+    if (send_right) *send_right = nA - ol;    // 1-based plane nA - ol_A + 1
+    if (recv_left) *recv_left = 0;
+    if (recv_right) *recv_right = nA - 1;
+    return JRX_OK;
+}
+
+jrx_status jrx_cart_create(int32_t rank, int32_t nprocs, const int64_t n[3], const int32_t dims_in[3],
+                           const int32_t periods[3], jrx_cart *out)
+{
+    if (!out || !n || nprocs < 1 || rank < 0 || rank >= nprocs) return JRX_ERR_ARG;
+    int32_t dims[3] = {1, 1, 1};
+    const bool fixed = dims_in && (dims_in[0] || dims_in[1] || dims_in[2]);
+    if (fixed) {
+        for (int d = 0; d < 3; d++) dims[d] = dims_in[d] ? dims_in[d] : 1;
+    } else {
+        // balanced factorisation (MPI_Dims_create): largest prime factors first onto the smallest dim
+        int idx[3], na = 0;
+        for (int d = 0; d < 3; d++)
+            if (n[d] > 1) idx[na++] = d;
+        if (na > 0) {
+            int fac[32], nf = 0, m = nprocs;
+            for (int p = 2; m > 1; p++)
+                while (m % p == 0) { fac[nf++] = p; m /= p; }
+            int v[3] = {1, 1, 1};
+            for (int q = nf - 1; q >= 0; q--) {
+                int j = 0;
+                for (int a = 1; a < na; a++)
+                    if (v[a] < v[j]) j = a;
+                v[j] *= fac[q];
+            }
+            // non-increasing order over the active dims
+            for (int a = 0; a < na; a++)
+                for (int b = a + 1; b < na; b++)
+                    if (v[b] > v[a]) { int t = v[a]; v[a] = v[b]; v[b] = t; }
+            for (int a = 0; a < na; a++) dims[idx[a]] = v[a];
+        }
+    }
+    if ((int64_t)dims[0] * dims[1] * dims[2] != nprocs) return JRX_ERR_ARG;
+    out->rank = rank; out->nprocs = nprocs;
+    int r = rank;
+    for (int d = 2; d >= 0; d--) { out->coords[d] = r % dims[d]; r /= dims[d]; }
+    for (int d = 0; d < 3; d++) { out->dims[d] = dims[d]; out->periods[d] = periods ? periods[d] : 0; }
+    for (int d = 0; d < 3; d++)
+        for (int sgn = 0; sgn < 2; sgn++) {
+            int c[3] = {out->coords[0], out->coords[1], out->coords[2]};
+            c[d] += sgn ? 1 : -1;
+            int nb = -1;
+            if (c[d] >= 0 && c[d] < dims[d]) nb = (c[0] * dims[1] + c[1]) * dims[2] + c[2];
+            else if (out->periods[d] && dims[d] > 1) {
+                c[d] = (c[d] + dims[d]) % dims[d];
+                nb = (c[0] * dims[1] + c[1]) * dims[2] + c[2];
+            }
+            out->neighbor[d][sgn] = nb;
+        }
+    return JRX_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,91 @@
+// jrx_internal.hpp -- shared internals of libjrx_hip (handle, error plumbing, index helpers).
+// gfx950 / CDNA4 only.  Not part of the public ABI (include/jrx.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include "jrx.h"
+
+struct jrx_comm_state;   // halo.hip
+
+struct jrx_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;        // compute stream
+    hipStream_t halo_stream = nullptr;   // boundary slabs + pack/unpack + RCCL
+    hipEvent_t ev[8] = {};
+    double *d_partials = nullptr;        // reduction scratch [kMaxRedBlocks][4]
+    double *d_sums = nullptr;            // [8] final sums (device)
+    double *h_sums = nullptr;            // [8] pinned host mirror
+    double *etatau = nullptr;            // library-owned ητ (capacity etatau_cap doubles)
+    size_t etatau_cap = 0;
+    jrx_comm_state *comm = nullptr;
+    char err[512] = {0};
+};
+
+static constexpr int kMaxRedBlocks = 2048;
+
+extern char g_jrx_create_err[512];
+
+static inline jrx_status jrx_fail(jrx_handle *h, jrx_status st, const char *fmt, ...)
+{
+    char *dst = h ? h->err : g_jrx_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return st;
+}
+
+#define JRX_HIP(h, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return jrx_fail((h), JRX_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,      \
+                            hipGetErrorString(e_));                                              \
+    } while (0)
+
+#define JRX_TRY(call)                          \
+    do {                                       \
+        jrx_status s_ = (call);                \
+        if (s_ != JRX_OK) return s_;           \
+    } while (0)
+
+#define JRX_LAUNCH_CHECK(h) JRX_HIP(h, hipGetLastError())
+
+// ensure the library-owned ητ scratch holds n doubles
+jrx_status jrx_ensure_etatau(jrx_handle *h, size_t n);
+
+// reduction helper: Σ over a wave64 via DPP-free shuffles
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+typedef long long i64;
+
+__device__ __forceinline__ i64 clampll(i64 v, i64 lo, i64 hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// src/rheology/StressUpdate.jl:70
+__device__ __forceinline__ double dev_dtau_r(double theta_dtau, double eta, double _Gdt)
+{
+    return 1.0 / (theta_dtau + fma(eta, _Gdt, 1.0));
+}
+// src/stokes/StressKernels.jl:2-5
+__device__ __forceinline__ double dev_stress_inc(double t, double to, double eta, double e, double _Gdt, double dtr)
+{
+    return dtr * fma(2.0 * eta, e, fma(-(t - to) * eta, _Gdt, -t));
+}
+
+// halo.hip: exchange of the velocity (or any) fields; no-op without a communicator
+jrx_status jrx_halo_exchange(jrx_handle *h, hipStream_t s, int narrays, double *const *arrays,
+                             const int64_t (*ext)[3], const int64_t n[3]);
+bool jrx_comm_active(const jrx_handle *h);
+// all-reduce (sum) of `count` doubles in place on the host values (uses RCCL when active)
+jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count);
+int jrx_comm_rank(const jrx_handle *h);

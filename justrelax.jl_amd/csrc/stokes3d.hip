@@ -1,0 +1,573 @@
+// stokes3d.hip -- 3D isoviscous visco-elastic pseudo-transient Stokes path for gfx950.
+//
+// Reference being replaced (PTsolvers/JustRelax.jl v0.7.1): src/stokes/Stokes3D.jl:25-186 and the
+// kernels it launches (VelocityKernels.jl:3-6,59-104,182-242; PressureKernels.jl:10-15,186-195;
+// StressKernels.jl:2-5,149-230; types/displacement.jl:17-28; boundaryconditions/*.jl;
+// Utils.jl:409-461,62-72).  The reference runs six separate launches per iteration; here the
+// iteration is two fused sweeps:
+//   stress sweep   (V -> ∇V, P, ε, τ)   reads V(3) P P0 Q η K G τ(6) τ_o(6), writes P τ(6)   = 28 passes
+//   velocity sweep (τ, P -> R, V)        reads P τ(6) f(3) ητ V(3),           writes V(3)      = 17 passes
+// i.e. 45 array passes * 8 B = 360 B per cell per iteration (the two-sweep floor); the diagnostic
+// outputs ∇V, ε, RP, R, U are only written on iterations whose results can be observed (norm
+// checks and the last iteration).  Pure HBM-bandwidth-bound fp64 stencils: no MFMA.
+#include "jrx_internal.hpp"
+#include "jrx_kernels.hpp"
+
+namespace {
+
+struct Dims3 {
+    int nx, ny, nz;
+};
+
+// element strides of the staggered arrays
+struct Lay3 {
+    int nx, ny, nz;
+    // row lengths (n1) and plane sizes (n1*n2)
+    int vx1, vy1, vz1;          // nx+1, nx+2, nx+2
+    i64 vxp, vyp, vzp;          // plane sizes
+    i64 cp;                     // nx*ny
+    int xy1; i64 xyp;           // (nx+1), (nx+1)*(ny+1)
+    int xz1; i64 xzp;           // (nx+1), (nx+1)*ny
+    int yz1; i64 yzp;           // nx, nx*(ny+1)
+};
+
+__host__ __device__ inline Lay3 make_lay(int nx, int ny, int nz)
+{
+    Lay3 L;
+    L.nx = nx; L.ny = ny; L.nz = nz;
+    L.vx1 = nx + 1; L.vxp = (i64)(nx + 1) * (ny + 2);
+    L.vy1 = nx + 2; L.vyp = (i64)(nx + 2) * (ny + 1);
+    L.vz1 = nx + 2; L.vzp = (i64)(nx + 2) * (ny + 2);
+    L.cp = (i64)nx * ny;
+    L.xy1 = nx + 1; L.xyp = (i64)(nx + 1) * (ny + 1);
+    L.xz1 = nx + 1; L.xzp = (i64)(nx + 1) * ny;
+    L.yz1 = nx;     L.yzp = (i64)nx * (ny + 1);
+    return L;
+}
+
+struct SweepArgs {
+    jrx_stokes3d_fields f;
+    const double *etatau;
+    double _dx, _dy, _dz, dt, r, theta_dtau, eta_dtau;
+    Lay3 L;
+    // sub-box of the launch (0-based, half-open) -- lets the driver split boundary slabs / interior
+    int i0, i1, j0, j1, k0, k1;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Stress sweep, version 1: one thread per node of the ni.+1 box, xy-plane flattened over threadIdx
+// so that rows of any length (nx, nx+1, nx+2) stay fully coalesced; blockIdx.y walks z.
+// ------------------------------------------------------------------------------------------------
+template <bool DIAG>
+__global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
+{
+    const Lay3 &L = a.L;
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    const int wi = a.i1 - a.i0;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int jj = t / wi;
+    const int i = a.i0 + (t - jj * wi);
+    const int j = a.j0 + jj;
+    const int k = a.k0 + blockIdx.y;
+    if (j >= a.j1) return;
+
+    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
+    const double *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
+    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau;
+
+#define VX(i_, j_, k_) Vx[(i_) + (i64)L.vx1 * (j_) + L.vxp * (k_)]
+#define VY(i_, j_, k_) Vy[(i_) + (i64)L.vy1 * (j_) + L.vyp * (k_)]
+#define VZ(i_, j_, k_) Vz[(i_) + (i64)L.vz1 * (j_) + L.vzp * (k_)]
+#define CC(i_, j_, k_) ((i_) + (i64)nx * (j_) + L.cp * (k_))
+
+    const bool ci = i < nx, cj = j < ny, ck = k < nz;
+
+    if (ci && cj && ck) {
+        const i64 c = CC(i, j, k);
+        // compute_∇V! (VelocityKernels.jl:3-6)
+        const double dxi = (-VX(i, j + 1, k + 1) + VX(i + 1, j + 1, k + 1)) * _dx;
+        const double dyi = (-VY(i + 1, j, k + 1) + VY(i + 1, j + 1, k + 1)) * _dy;
+        const double dzi = (-VZ(i + 1, j + 1, k) + VZ(i + 1, j + 1, k + 1)) * _dz;
+        const double divV = dxi + dyi + dzi;
+        // compute_P! (PressureKernels.jl:186-195), η (not ητ) in the 3D driver (Stokes3D.jl:85)
+        const double e = eta[c];
+        const double _Gdt = 1.0 / (G[c] * dt);
+        {
+            const double _Kdt = 1.0 / (a.f.K[c] * dt);
+            const double _dt = 1.0 / dt;
+            const double P = a.f.P[c], P0 = a.f.P0[c];
+            const double rhs = -divV + (a.f.Q[c] * _dt);
+            const double psi = 1.0 / (1.0 / e + _Gdt) * a.r / th;
+            a.f.P[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
+            if (DIAG) {
+                a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
+                a.f.divV[c] = divV;
+            }
+        }
+        // compute_strain_rate! normal components (VelocityKernels.jl:69-78)
+        const double d3 = divV * (1.0 / 3.0);
+        const double exx = dxi - d3, eyy = dyi - d3, ezz = dzi - d3;
+        if (DIAG) { a.f.exx[c] = exx; a.f.eyy[c] = eyy; a.f.ezz[c] = ezz; }
+        // compute_τ! normal components (StressKernels.jl:185-198)
+        const double dtr = dev_dtau_r(th, e, _Gdt);
+        double tv;
+        tv = a.f.txx[c]; a.f.txx[c] = tv + dev_stress_inc(tv, a.f.toxx[c], e, exx, _Gdt, dtr);
+        tv = a.f.tyy[c]; a.f.tyy[c] = tv + dev_stress_inc(tv, a.f.toyy[c], e, eyy, _Gdt, dtr);
+        tv = a.f.tzz[c]; a.f.tzz[c] = tv + dev_stress_inc(tv, a.f.tozz[c], e, ezz, _Gdt, dtr);
+    }
+
+    // clamped neighbour cell indices (MiniKernels.jl:133-147)
+    const int im = max(i - 1, 0), ip = min(i, nx - 1);
+    const int jm = max(j - 1, 0), jp = min(j, ny - 1);
+    const int km = max(k - 1, 0), kp = min(k, nz - 1);
+
+    if (ck) {   // τxy at (i,j,k) of (nx+1, ny+1, nz)   (VelocityKernels.jl:95-101, StressKernels.jl:199-208)
+        const double exy = 0.5 * (_dy * (VX(i, j + 1, k + 1) - VX(i, j, k + 1)) + _dx * (VY(i + 1, j, k + 1) - VY(i, j, k + 1)));
+        const double e = 0.25 * (eta[CC(im, jm, k)] + eta[CC(ip, jm, k)] + eta[CC(im, jp, k)] + eta[CC(ip, jp, k)]);
+        const double g = 0.25 * (G[CC(im, jm, k)] + G[CC(ip, jm, k)] + G[CC(im, jp, k)] + G[CC(ip, jp, k)]);
+        const double _Gdt = 1.0 / (g * dt);
+        const double dtr = dev_dtau_r(th, e, _Gdt);
+        const i64 c = i + (i64)L.xy1 * j + L.xyp * k;
+        const double tv = a.f.txy[c];
+        a.f.txy[c] = tv + dev_stress_inc(tv, a.f.toxy[c], e, exy, _Gdt, dtr);
+        if (DIAG) a.f.exy[c] = exy;
+    }
+    if (cj) {   // τxz at (i,j,k) of (nx+1, ny, nz+1)
+        const double exz = 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k)));
+        const double e = 0.25 * (eta[CC(im, j, km)] + eta[CC(ip, j, km)] + eta[CC(im, j, kp)] + eta[CC(ip, j, kp)]);
+        const double g = 0.25 * (G[CC(im, j, km)] + G[CC(ip, j, km)] + G[CC(im, j, kp)] + G[CC(ip, j, kp)]);
+        const double _Gdt = 1.0 / (g * dt);
+        const double dtr = dev_dtau_r(th, e, _Gdt);
+        const i64 c = i + (i64)L.xz1 * j + L.xzp * k;
+        const double tv = a.f.txz[c];
+        a.f.txz[c] = tv + dev_stress_inc(tv, a.f.toxz[c], e, exz, _Gdt, dtr);
+        if (DIAG) a.f.exz[c] = exz;
+    }
+    if (ci) {   // τyz at (i,j,k) of (nx, ny+1, nz+1)
+        const double eyz = 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k)));
+        const double e = 0.25 * (eta[CC(i, jm, km)] + eta[CC(i, jp, km)] + eta[CC(i, jm, kp)] + eta[CC(i, jp, kp)]);
+        const double g = 0.25 * (G[CC(i, jm, km)] + G[CC(i, jp, km)] + G[CC(i, jm, kp)] + G[CC(i, jp, kp)]);
+        const double _Gdt = 1.0 / (g * dt);
+        const double dtr = dev_dtau_r(th, e, _Gdt);
+        const i64 c = i + (i64)L.yz1 * j + L.yzp * k;
+        const double tv = a.f.tyz[c];
+        a.f.tyz[c] = tv + dev_stress_inc(tv, a.f.toyz[c], e, eyz, _Gdt, dtr);
+        if (DIAG) a.f.eyz[c] = eyz;
+    }
+#undef VX
+#undef VY
+#undef VZ
+}
+
+// ------------------------------------------------------------------------------------------------
+// Velocity sweep, version 1: one thread per cell; compute_V! (VelocityKernels.jl:182-242).
+// ------------------------------------------------------------------------------------------------
+template <bool DIAG>
+__global__ __launch_bounds__(256) void k_velocity3d(const SweepArgs a)
+{
+    const Lay3 &L = a.L;
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    const int wi = a.i1 - a.i0;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int jj = t / wi;
+    const int i = a.i0 + (t - jj * wi);
+    const int j = a.j0 + jj;
+    const int k = a.k0 + blockIdx.y;
+    if (j >= a.j1) return;
+
+    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, edt = a.eta_dtau;
+    const double *__restrict__ P = a.f.P, *__restrict__ et = a.etatau;
+    const double *__restrict__ txy = a.f.txy, *__restrict__ txz = a.f.txz, *__restrict__ tyz = a.f.tyz;
+#define TXY(i_, j_, k_) txy[(i_) + (i64)L.xy1 * (j_) + L.xyp * (k_)]
+#define TXZ(i_, j_, k_) txz[(i_) + (i64)L.xz1 * (j_) + L.xzp * (k_)]
+#define TYZ(i_, j_, k_) tyz[(i_) + (i64)L.yz1 * (j_) + L.yzp * (k_)]
+    const i64 c = CC(i, j, k);
+    const double Pc = P[c], ec = et[c];
+
+    if (i < nx - 1) {
+        const i64 cx = c + 1;
+        const double R = (-a.f.txx[c] + a.f.txx[cx]) * _dx + _dy * (TXY(i + 1, j + 1, k) - TXY(i + 1, j, k)) +
+                         _dz * (TXZ(i + 1, j, k + 1) - TXZ(i + 1, j, k)) - (-Pc + P[cx]) * _dx -
+                         0.5 * (a.f.fx[c] + a.f.fx[cx]);
+        const i64 v = (i + 1) + (i64)L.vx1 * (j + 1) + L.vxp * (k + 1);
+        a.f.Vx[v] += R * edt / (0.5 * (ec + et[cx]));
+        if (DIAG) a.f.Rx[i + (i64)(nx - 1) * j + (i64)(nx - 1) * ny * k] = R;
+    }
+    if (j < ny - 1) {
+        const i64 cy = c + nx;
+        const double R = _dx * (TXY(i + 1, j + 1, k) - TXY(i, j + 1, k)) + _dy * (a.f.tyy[cy] - a.f.tyy[c]) +
+                         _dz * (TYZ(i, j + 1, k + 1) - TYZ(i, j + 1, k)) - (-Pc + P[cy]) * _dy -
+                         0.5 * (a.f.fy[c] + a.f.fy[cy]);
+        const i64 v = (i + 1) + (i64)L.vy1 * (j + 1) + L.vyp * (k + 1);
+        a.f.Vy[v] += R * edt / (0.5 * (ec + et[cy]));
+        if (DIAG) a.f.Ry[i + (i64)nx * j + (i64)nx * (ny - 1) * k] = R;
+    }
+    if (k < nz - 1) {
+        const i64 cz = c + L.cp;
+        const double R = _dx * (TXZ(i + 1, j, k + 1) - TXZ(i, j, k + 1)) + _dy * (TYZ(i, j + 1, k + 1) - TYZ(i, j, k + 1)) +
+                         (-a.f.tzz[c] + a.f.tzz[cz]) * _dz - (-Pc + P[cz]) * _dz - 0.5 * (a.f.fz[c] + a.f.fz[cz]);
+        const i64 v = (i + 1) + (i64)L.vz1 * (j + 1) + L.vzp * (k + 1);
+        a.f.Vz[v] += R * edt / (0.5 * (ec + et[cz]));
+        if (DIAG) a.f.Rz[c] = R;
+    }
+#undef TXY
+#undef TXZ
+#undef TYZ
+#undef CC
+}
+
+SweepArgs make_args(const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p)
+{
+    SweepArgs a;
+    a.f = *f;
+    a.etatau = etatau;
+    a._dx = p->_dx; a._dy = p->_dy; a._dz = p->_dz;
+    a.dt = p->dt; a.r = p->r; a.theta_dtau = p->theta_dtau; a.eta_dtau = p->eta_dtau;
+    a.L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
+    a.i0 = a.j0 = a.k0 = 0;
+    a.i1 = a.j1 = a.k1 = 0;
+    return a;
+}
+
+jrx_status check_params(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!f || !p) return jrx_fail(h, JRX_ERR_ARG, "null fields/params");
+    if (p->nx < 3 || p->ny < 3 || p->nz < 3) return jrx_fail(h, JRX_ERR_ARG, "3D Stokes needs at least 3 cells per dimension");
+    const double cells = (double)(p->nx + 2) * (double)(p->ny + 2) * (double)(p->nz + 2);
+    if (cells >= 2147483647.0) return jrx_fail(h, JRX_ERR_UNSUPPORTED, "local block too large for 32-bit plane indices");
+    const void *req[] = {f->P, f->P0, f->Q, f->Vx, f->Vy, f->Vz, f->txx, f->tyy, f->tzz, f->tyz, f->txz, f->txy,
+                         f->toxx, f->toyy, f->tozz, f->toyz, f->toxz, f->toxy, f->eta, f->K, f->G, f->fx, f->fy, f->fz};
+    for (const void *q : req)
+        if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required field pointer is NULL");
+    return JRX_OK;
+}
+
+jrx_status check_diag(jrx_handle *h, const jrx_stokes3d_fields *f)
+{
+    const void *req[] = {f->divV, f->exx, f->eyy, f->ezz, f->eyz, f->exz, f->exy, f->RP, f->Rx, f->Ry, f->Rz, f->Ux, f->Uy, f->Uz};
+    for (const void *q : req)
+        if (!q) return jrx_fail(h, JRX_ERR_ARG, "a diagnostic field pointer (∇V, ε, R, U) is NULL");
+    return JRX_OK;
+}
+
+// launch the stress sweep over the sub-box [i0,i1) x [j0,j1) x [k0,k1) of the ni.+1 box
+jrx_status launch_stress(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
+{
+    if (i1 <= i0 || j1 <= j0 || k1 <= k0) return JRX_OK;
+    a.i0 = i0; a.i1 = i1; a.j0 = j0; a.j1 = j1; a.k0 = k0; a.k1 = k1;
+    const i64 plane = (i64)(i1 - i0) * (j1 - j0);
+    dim3 grid((unsigned)((plane + 255) / 256), (unsigned)(k1 - k0));
+    if (diag) hipLaunchKernelGGL(k_stress3d<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_stress3d<false>, grid, dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+jrx_status launch_velocity(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
+{
+    if (i1 <= i0 || j1 <= j0 || k1 <= k0) return JRX_OK;
+    a.i0 = i0; a.i1 = i1; a.j0 = j0; a.j1 = j1; a.k0 = k0; a.k1 = k1;
+    const i64 plane = (i64)(i1 - i0) * (j1 - j0);
+    dim3 grid((unsigned)((plane + 255) / 256), (unsigned)(k1 - k0));
+    if (diag) hipLaunchKernelGGL(k_velocity3d<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_velocity3d<false>, grid, dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+jrx_status launch_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
+{
+    const i64 n0 = (i64)(p->nx + 1) * (p->ny + 2) * (p->nz + 2), n1 = (i64)(p->nx + 2) * (p->ny + 1) * (p->nz + 2),
+              n2 = (i64)(p->nx + 2) * (p->ny + 2) * (p->nz + 1);
+    hipLaunchKernelGGL(k_scale3, dim3(2048), dim3(256), 0, s, f->Ux, f->Vx, n0, f->Uy, f->Vy, n1, f->Uz, f->Vz, n2, p->dt);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+jrx_status launch_bcs(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz,
+                      uint32_t fs, uint32_t ns, uint32_t pe)
+{
+    BcArr A[3] = {{Vx, {nx + 1, ny + 2, nz + 2}}, {Vy, {nx + 2, ny + 1, nz + 2}}, {Vz, {nx + 2, ny + 2, nz + 1}}};
+    auto run = [&](int type, int dim, bool lo, bool hi) -> jrx_status {
+        if (!lo && !hi) return JRX_OK;
+        const int d1 = dim == 0 ? 1 : 0, d2 = dim == 2 ? 1 : 2;
+        int na = 0, nb = 0;
+        for (int c = 0; c < 3; c++) { na = A[c].n[d1] > na ? A[c].n[d1] : na; nb = A[c].n[d2] > nb ? A[c].n[d2] : nb; }
+        hipLaunchKernelGGL(k_bc3d, dim3((na + 255) / 256, nb), dim3(256), 0, s, A[0], A[1], A[2], type, dim, (int)lo, (int)hi);
+        JRX_LAUNCH_CHECK(h);
+        return JRX_OK;
+    };
+    if (ns) {   // no_slip.jl:20-54 : left,right ; front,back ; bot (k=1), top (k=end)
+        JRX_TRY(run(1, 0, ns & JRX_FACE_LEFT, ns & JRX_FACE_RIGHT));
+        JRX_TRY(run(1, 1, ns & JRX_FACE_FRONT, ns & JRX_FACE_BACK));
+        JRX_TRY(run(1, 2, ns & JRX_FACE_BOT, ns & JRX_FACE_TOP));
+    }
+    if (fs) {   // free_slip.jl:15-70 : front,back ; top (k=1), bot (k=end) ; left,right
+        JRX_TRY(run(0, 1, fs & JRX_FACE_FRONT, fs & JRX_FACE_BACK));
+        JRX_TRY(run(0, 2, fs & JRX_FACE_TOP, fs & JRX_FACE_BOT));
+        JRX_TRY(run(0, 0, fs & JRX_FACE_LEFT, fs & JRX_FACE_RIGHT));
+    }
+    if (pe) {   // periodic.jl:56-98 : left,right ; front,back ; bot (k=1), top (k=end)
+        JRX_TRY(run(2, 0, pe & JRX_FACE_LEFT, pe & JRX_FACE_RIGHT));
+        JRX_TRY(run(2, 1, pe & JRX_FACE_FRONT, pe & JRX_FACE_BACK));
+        JRX_TRY(run(2, 2, pe & JRX_FACE_BOT, pe & JRX_FACE_TOP));
+    }
+    return JRX_OK;
+}
+
+jrx_status launch_sumsq(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
+{
+    const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
+    RedArr A0 = {f->Rx, {nx - 1, ny, nz}, 1}, A1 = {f->Ry, {nx, ny - 1, nz}, 1}, A2 = {f->Rz, {nx, ny, nz - 1}, 1},
+           A3 = {f->RP, {nx, ny, nz}, 0};
+    const i64 n = (i64)nx * ny * nz;
+    int nb = (int)((n + 256 * 8 - 1) / (256 * 8));
+    nb = nb < 1 ? 1 : (nb > kMaxRedBlocks ? kMaxRedBlocks : nb);
+    hipLaunchKernelGGL(k_sumsq_partial, dim3(nb), dim3(256), 0, s, A0, A1, A2, A3, h->d_partials);
+    JRX_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(256), 0, s, h->d_partials, nb, h->d_sums);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+}   // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+jrx_status jrx_stokes3d_sweep_stress(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p, int32_t flags)
+{
+    JRX_TRY(check_params(h, f, p));
+    const bool diag = flags & JRX_OUT_DIAG;
+    if (diag) JRX_TRY(check_diag(h, f));
+    SweepArgs a = make_args(f, nullptr, p);
+    JRX_TRY(launch_stress(h, h->stream, a, diag, 0, (int)p->nx + 1, 0, (int)p->ny + 1, 0, (int)p->nz + 1));
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_stokes3d_sweep_velocity(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
+                                       const jrx_stokes3d_params *p, int32_t flags)
+{
+    JRX_TRY(check_params(h, f, p));
+    if (!etatau) return jrx_fail(h, JRX_ERR_ARG, "etatau is NULL");
+    const bool diag = flags & JRX_OUT_DIAG;
+    if (diag) JRX_TRY(check_diag(h, f));
+    SweepArgs a = make_args(f, etatau, p);
+    JRX_TRY(launch_velocity(h, h->stream, a, diag, 0, (int)p->nx, 0, (int)p->ny, 0, (int)p->nz));
+    if (diag) JRX_TRY(launch_scaleU(h, h->stream, f, p));
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_flow_bcs3d(jrx_handle *h, double *Vx, double *Vy, double *Vz, int64_t nx, int64_t ny, int64_t nz,
+                          uint32_t free_slip, uint32_t no_slip, uint32_t periodic)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!Vx || !Vy || !Vz) return jrx_fail(h, JRX_ERR_ARG, "null velocity pointer");
+    JRX_TRY(launch_bcs(h, h->stream, Vx, Vy, Vz, (int)nx, (int)ny, (int)nz, free_slip, no_slip, periodic));
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_stokes3d_residual_sumsq(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p, double out[4])
+{
+    JRX_TRY(check_params(h, f, p));
+    JRX_TRY(check_diag(h, f));
+    JRX_TRY(launch_sumsq(h, h->stream, f, p));
+    JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    for (int c = 0; c < 4; c++) out[c] = h->h_sums[c];
+    return JRX_OK;
+}
+
+jrx_status jrx_compute_maxloc(jrx_handle *h, double *B, const double *A, int64_t nx, int64_t ny, int64_t nz)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!A || !B || nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "bad compute_maxloc arguments");
+    if (A == B) return jrx_fail(h, JRX_ERR_ARG, "compute_maxloc!: B must not alias A");
+    const i64 plane = (i64)nx * ny;
+    hipLaunchKernelGGL(k_maxloc, dim3((unsigned)((plane + 255) / 256), (unsigned)nz), dim3(256), 0, h->stream, B, A, (int)nx, (int)ny, (int)nz);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+// one PT iteration (Stokes3D.jl:78-121), enqueued on the handle's streams, no host sync
+static jrx_status enqueue_iteration(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
+                                    const jrx_stokes3d_params *p, bool diag)
+{
+    const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
+    SweepArgs a = make_args(f, etatau, p);
+    hipStream_t s = h->stream;
+    JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
+    if (!jrx_comm_active(h)) {
+        JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
+        if (diag) JRX_TRY(launch_scaleU(h, s, f, p));
+        JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        return JRX_OK;
+    }
+    // @hide_communication b_width (Stokes3D.jl:104-121): boundary slabs of width b first on the halo
+    // stream, then BCs + neighbour exchange there while the interior runs on the compute stream.
+    const int bx = p->b_width[0] > 0 ? p->b_width[0] : 4, by = p->b_width[1] > 0 ? p->b_width[1] : 4,
+              bz = p->b_width[2] > 0 ? p->b_width[2] : 4;
+    const int xa = bx < nx / 2 ? bx : nx / 2, ya = by < ny / 2 ? by : ny / 2, za = bz < nz / 2 ? bz : nz / 2;
+    hipStream_t hs = h->halo_stream;
+    JRX_HIP(h, hipEventRecord(h->ev[0], s));
+    JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[0], 0));
+    // six slabs (z-lo, z-hi, y-lo, y-hi, x-lo, x-hi), disjoint
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ny, 0, za));
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ny, nz - za, nz));
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ya, za, nz - za));
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, ny - ya, ny, za, nz - za));
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, xa, ya, ny - ya, za, nz - za));
+    JRX_TRY(launch_velocity(h, hs, a, diag, nx - xa, nx, ya, ny - ya, za, nz - za));
+    // interior on the compute stream, concurrently
+    JRX_TRY(launch_velocity(h, s, a, diag, xa, nx - xa, ya, ny - ya, za, nz - za));
+    if (diag) {
+        // U = V*dt needs the whole updated V: join first
+        JRX_HIP(h, hipEventRecord(h->ev[1], s));
+        JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[1], 0));
+        JRX_TRY(launch_scaleU(h, hs, f, p));
+    }
+    JRX_TRY(launch_bcs(h, hs, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+    double *arrs[3] = {f->Vx, f->Vy, f->Vz};
+    const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
+    const int64_t n[3] = {nx, ny, nz};
+    JRX_TRY(jrx_halo_exchange(h, hs, 3, arrs, ext, n));
+    JRX_HIP(h, hipEventRecord(h->ev[2], hs));
+    JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
+    return JRX_OK;
+}
+
+jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p, jrx_solve_result *res)
+{
+    JRX_TRY(check_params(h, f, p));
+    JRX_TRY(check_diag(h, f));
+    if (!res) return jrx_fail(h, JRX_ERR_ARG, "null result");
+    if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
+    const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
+    const size_t n = (size_t)nx * ny * nz;
+    hipStream_t s = h->stream;
+
+    // ητ = deepcopy(η); compute_maxloc!(ητ, η); update_halo!(ητ)   (Stokes3D.jl:55-57)
+    JRX_TRY(jrx_ensure_etatau(h, n));
+    hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, s, h->etatau, f->eta, nx, ny, nz);
+    JRX_LAUNCH_CHECK(h);
+    if (jrx_comm_active(h)) {
+        double *arrs[1] = {h->etatau};
+        const int64_t ext[1][3] = {{nx, ny, nz}};
+        const int64_t nn[3] = {nx, ny, nz};
+        JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
+    }
+
+    double err_it1 = 1.0, err = 1.0;
+    int64_t iter = 0, cont = 0;
+    res->iter = 0; res->nchecks = 0;
+    const int rank = jrx_comm_rank(h);
+    hipEvent_t t0 = h->ev[6], t1 = h->ev[7];
+    JRX_HIP(h, hipEventRecord(t0, s));
+    auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
+    while (keep_going(iter)) {
+        const int64_t it1 = iter + 1;
+        const bool check = (it1 % p->nout == 0) && it1 > 1;
+        const bool diag = check || !keep_going(it1);   // results observable after this iteration
+        JRX_TRY(enqueue_iteration(h, f, h->etatau, p, diag));
+        iter = it1;
+        if (check) {
+            JRX_TRY(launch_sumsq(h, s, f, p));
+            JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            JRX_HIP(h, hipStreamSynchronize(s));
+            double ss[4] = {h->h_sums[0], h->h_sums[1], h->h_sums[2], h->h_sums[3]};
+            JRX_TRY(jrx_allreduce_sum_host(h, ss, 4));       // norm_mpi: sqrt(Allreduce(Σx²)) (Utils.jl:698-701)
+            const double nRx = sqrt(ss[0]) / (double)((p->nxg - 2) * (p->nyg - 1) * (p->nzg - 1));
+            const double nRy = sqrt(ss[1]) / (double)((p->nxg - 1) * (p->nyg - 2) * (p->nzg - 1));
+            const double nRz = sqrt(ss[2]) / (double)((p->nxg - 1) * (p->nyg - 1) * (p->nzg - 2));
+            const double nDV = sqrt(ss[3]) / (double)(p->nxg * p->nyg * p->nzg);
+            err = fmax(fmax(nRx, nRy), fmax(nRz, nDV));
+            if (std::isnan(nRx) || std::isnan(nRy) || std::isnan(nRz) || std::isnan(nDV)) err = NAN;
+            if (cont < res->cap) {
+                if (res->norm_Rx) res->norm_Rx[cont] = nRx;
+                if (res->norm_Ry) res->norm_Ry[cont] = nRy;
+                if (res->norm_Rz) res->norm_Rz[cont] = nRz;
+                if (res->norm_divV) res->norm_divV[cont] = nDV;
+                if (res->err_evo1) res->err_evo1[cont] = err;
+                if (res->err_evo2) res->err_evo2[cont] = iter;
+            }
+            if (cont == 0) err_it1 = err;
+            cont++;
+            if (rank == 0 && ((p->verbose && (err / err_it1) > p->eps_rel && err > p->eps_abs) || iter == p->iterMax))
+                printf("iter = %lld, abs_err = %1.3e, rel_err = %1.3e [norm_Rx=%1.3e, norm_Ry=%1.3e, norm_Rz=%1.3e, norm_∇V=%1.3e] \n",
+                       (long long)iter, err, err / err_it1, nRx, nRy, nRz, nDV);
+            if (std::isnan(err)) {
+                res->iter = iter; res->nchecks = cont < res->cap ? cont : res->cap;
+                return jrx_fail(h, JRX_ERR_NAN, "NaN(s)");
+            }
+        }
+    }
+    JRX_HIP(h, hipEventRecord(t1, s));
+    // multi_copy! τ -> τ_o, staggered set then centre set (Stokes3D.jl:172-173)
+    const i64 nc = (i64)n, nyz = (i64)nx * (ny + 1) * (nz + 1), nxz = (i64)(nx + 1) * ny * (nz + 1), nxy = (i64)(nx + 1) * (ny + 1) * nz;
+    hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, s, f->toxx, f->txx, nc, f->toyy, f->tyy, nc, f->tozz, f->tzz, nc,
+                       f->toyz, f->tyz, nyz, f->toxz, f->txz, nxz, f->toxy, f->txy, nxy);
+    JRX_LAUNCH_CHECK(h);
+    if (f->tyz_c && f->toyz_c && f->txz_c && f->toxz_c && f->txy_c && f->toxy_c) {
+        hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, s, f->toyz_c, f->tyz_c, nc, f->toxz_c, f->txz_c, nc, f->toxy_c, f->txy_c, nc,
+                           (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0,
+                           (double *)nullptr, (const double *)nullptr, (i64)0);
+        JRX_LAUNCH_CHECK(h);
+    }
+    JRX_HIP(h, hipStreamSynchronize(s));
+    float ms = 0.f;
+    JRX_HIP(h, hipEventElapsedTime(&ms, t0, t1));
+    res->iter = iter;
+    res->nchecks = cont < res->cap ? cont : res->cap;
+    res->time_s = ms * 1e-3;
+    res->av_time_s = iter > 1 ? res->time_s / (double)(iter - 1) : res->time_s;
+    return JRX_OK;
+}
+
+jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
+                                      const jrx_stokes3d_params *p, int64_t iters,
+                                      double *total_ms, double *stress_ms, double *velocity_ms)
+{
+    JRX_TRY(check_params(h, f, p));
+    if (!etatau) return jrx_fail(h, JRX_ERR_ARG, "etatau is NULL");
+    hipStream_t s = h->stream;
+    const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
+    // whole loop body, back to back
+    JRX_HIP(h, hipEventRecord(h->ev[6], s));
+    for (int64_t it = 0; it < iters; it++) JRX_TRY(enqueue_iteration(h, f, etatau, p, false));
+    JRX_HIP(h, hipEventRecord(h->ev[7], s));
+    JRX_HIP(h, hipStreamSynchronize(s));
+    float ms = 0.f;
+    JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
+    if (total_ms) *total_ms = ms;
+    // per-kernel durations: events around each sweep of a few extra iterations (these also advance the state)
+    if (stress_ms || velocity_ms) {
+        SweepArgs a = make_args(f, etatau, p);
+        double sa = 0.0, sb = 0.0;
+        const int reps = 5;
+        for (int r = 0; r < reps; r++) {
+            JRX_HIP(h, hipEventRecord(h->ev[3], s));
+            JRX_TRY(launch_stress(h, s, a, false, 0, nx + 1, 0, ny + 1, 0, nz + 1));
+            JRX_HIP(h, hipEventRecord(h->ev[4], s));
+            JRX_TRY(launch_velocity(h, s, a, false, 0, nx, 0, ny, 0, nz));
+            JRX_HIP(h, hipEventRecord(h->ev[5], s));
+            JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+            JRX_HIP(h, hipStreamSynchronize(s));
+            float m1 = 0.f, m2 = 0.f;
+            JRX_HIP(h, hipEventElapsedTime(&m1, h->ev[3], h->ev[4]));
+            JRX_HIP(h, hipEventElapsedTime(&m2, h->ev[4], h->ev[5]));
+            sa += m1; sb += m2;
+        }
+        if (stress_ms) *stress_ms = sa / reps;
+        if (velocity_ms) *velocity_ms = sb / reps;
+    }
+    return JRX_OK;
+}
+
+}   // extern "C"

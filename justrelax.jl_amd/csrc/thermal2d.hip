@@ -1,0 +1,276 @@
+// thermal2d.hip -- 2D pseudo-transient heat diffusion for gfx950.
+//
+// Reference being replaced: src/thermal_diffusion/DiffusionPT_solver.jl:34-149 (array-coefficient
+// form) and :181-305 (rheology form as test/test_diffusion2D.jl evaluates it: constant k, constant
+// Cp, rho = rho0*(1 - alpha*(T - T0)) -- the PT_Density form of the un-vendored GeoParams.jl is an
+// assumption), kernels DiffusionPT_kernels.jl:327-440,519-601,603-673 and
+// thermal_bcs! (BoundaryConditions.jl:39-53; constant_value.jl:1-13; free_slip.jl:72-84; periodic.jl:1-13).
+#include "jrx_internal.hpp"
+#include "jrx_kernels.hpp"
+
+namespace {
+
+enum { TL = 0, TR = 1, TT = 2, TB = 3 };
+
+struct TArgs {
+    jrx_thermal2d_fields t;
+    jrx_thermal2d_params p;
+};
+
+__device__ __forceinline__ double rhoCp_of(const jrx_thermal2d_params &p, const double *rhoCp, i64 c, double T)
+{
+    return p.rheology_form ? p.Cp * (p.rho0 * (1.0 - p.alpha * (T - p.T0))) : rhoCp[c];
+}
+
+// compute_flux! over (nx+1, ny+1)
+__global__ __launch_bounds__(256) void k_flux2d(const TArgs a)
+{
+    const int nx = (int)a.p.nx, ny = (int)a.p.ny;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / (nx + 1), i = t - j * (nx + 1);
+    if (j > ny) return;
+    const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau;
+#define TT_(i_, j_) T[(i_) + (i64)(nx + 2) * (j_)]
+    if (j < ny) {
+        const i64 q = i + (i64)(nx + 1) * j;
+        if (i == 0 && a.p.constant_flux_on[TL]) a.t.qTx[q] = a.p.constant_flux[TL];
+        else if (i == nx && a.p.constant_flux_on[TR]) a.t.qTx[q] = a.p.constant_flux[TR];
+        else {
+            const int iL = clampi(i - 1, 0, nx - 1), iR = clampi(i, 0, nx - 1);
+            const double Kx = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[iL + (i64)nx * j] + a.t.K[iR + (i64)nx * j]) * 0.5;
+            const double thx = (th[iL + (i64)nx * j] + th[iR + (i64)nx * j]) * 0.5;
+            const double qx = -Kx * (TT_(i + 1, j + 1) - TT_(i, j + 1)) * a.p._dx;
+            a.t.qTx2[q] = qx;
+            a.t.qTx[q] = (a.t.qTx[q] * thx + qx) / (1.0 + thx);
+        }
+    }
+    if (i < nx) {
+        const i64 q = i + (i64)nx * j;
+        if (j == 0 && a.p.constant_flux_on[TB]) a.t.qTy[q] = a.p.constant_flux[TB];
+        else if (j == ny && a.p.constant_flux_on[TT]) a.t.qTy[q] = a.p.constant_flux[TT];
+        else {
+            const int jB = clampi(j - 1, 0, ny - 1), jT = clampi(j, 0, ny - 1);
+            const double Ky = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[i + (i64)nx * jB] + a.t.K[i + (i64)nx * jT]) * 0.5;
+            const double thy = (th[i + (i64)nx * jB] + th[i + (i64)nx * jT]) * 0.5;
+            const double qy = -Ky * (TT_(i + 1, j + 1) - TT_(i + 1, j)) * a.p._dy;
+            a.t.qTy2[q] = qy;
+            a.t.qTy[q] = (a.t.qTy[q] * thy + qy) / (1.0 + thy);
+        }
+    }
+}
+
+// update_T! (RES=false) / check_res! (RES=true) over ni
+template <bool RES>
+__global__ __launch_bounds__(256) void k_updateT2d(const TArgs a)
+{
+    const int nx = (int)a.p.nx, ny = (int)a.p.ny;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / nx, i = t - j * nx;
+    if (j >= ny) return;
+    const i64 c = i + (i64)nx * j, I1 = (i + 1) + (i64)(nx + 2) * (j + 1);
+    const double _dt = 1.0 / a.p.dt;
+    const double Tij = a.t.T[I1];
+    const double rcp = rhoCp_of(a.p, a.t.rhoCp, c, Tij);
+    if (RES) {
+        a.t.ResT[c] = -rcp * (Tij - a.t.Told[I1]) * _dt -
+                      ((a.t.qTx2[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx2[i + (i64)(nx + 1) * j]) * a.p._dx +
+                       (a.t.qTy2[i + (i64)nx * (j + 1)] - a.t.qTy2[c]) * a.p._dy) +
+                      a.t.H[c] + a.t.shear_heating[c];
+    } else {
+        const double dr = a.t.dtau_rho[c];
+        const double divq = (a.t.qTx[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx[i + (i64)(nx + 1) * j]) * a.p._dx +
+                            (a.t.qTy[i + (i64)nx * (j + 1)] - a.t.qTy[c]) * a.p._dy;
+        a.t.T[I1] = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+    }
+}
+
+// thermal_bcs!: step 0 constant_value, 1 no_flux, 2 periodic; dimy=1: rows j=0 / j=end (bot/top), else columns (left/right)
+__global__ __launch_bounds__(256) void k_tbc2d(double *__restrict__ T, int nx, int ny, int step, int dimy,
+                                               int lo_on, int hi_on, double lo_val, double hi_val)
+{
+    const int n1 = nx + 2, n2 = ny + 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dimy) {
+        if (t >= n1) return;
+#define T2(i_, j_) T[(i_) + (i64)n1 * (j_)]
+        if (step == 0) {
+            if (lo_on) T2(t, 0) = 2 * lo_val - T2(t, 1);
+            if (hi_on) T2(t, n2 - 1) = 2 * hi_val - T2(t, n2 - 2);
+        } else if (step == 1) {
+            if (lo_on) T2(t, 0) = T2(t, 1);
+            if (hi_on) T2(t, n2 - 1) = T2(t, n2 - 2);
+        } else {
+            if (lo_on) T2(t, 0) = T2(t, n2 - 2);
+            if (hi_on) T2(t, n2 - 1) = T2(t, 1);
+        }
+    } else {
+        if (t >= n2) return;
+        if (step == 0) {
+            if (lo_on) T2(0, t) = 2 * lo_val - T2(1, t);
+            if (hi_on) T2(n1 - 1, t) = 2 * hi_val - T2(n1 - 2, t);
+        } else if (step == 1) {
+            if (lo_on) T2(0, t) = T2(1, t);
+            if (hi_on) T2(n1 - 1, t) = T2(n1 - 2, t);
+        } else {
+            if (lo_on) T2(0, t) = T2(n1 - 2, t);
+            if (hi_on) T2(n1 - 1, t) = T2(1, t);
+        }
+#undef T2
+    }
+}
+#undef TT_
+
+__global__ __launch_bounds__(256) void k_sub(double *__restrict__ d, const double *__restrict__ a, const double *__restrict__ b, i64 n)
+{
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) d[t] = a[t] - b[t];
+}
+
+jrx_status checkT(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!t || !p) return jrx_fail(h, JRX_ERR_ARG, "null thermal fields/params");
+    if (p->nx < 2 || p->ny < 2) return jrx_fail(h, JRX_ERR_ARG, "thermal grid too small");
+    const void *req[] = {t->T, t->Told, t->dT, t->qTx, t->qTx2, t->qTy, t->qTy2, t->H, t->shear_heating, t->ResT, t->thetar_dtau, t->dtau_rho};
+    for (const void *q : req)
+        if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required thermal field pointer is NULL");
+    if (!p->rheology_form && (!t->K || !t->rhoCp)) return jrx_fail(h, JRX_ERR_ARG, "K / rhoCp arrays required in the array-coefficient form");
+    return JRX_OK;
+}
+
+jrx_status launch_tbcs(jrx_handle *h, hipStream_t s, double *T, const jrx_thermal2d_params *p)
+{
+    const int nx = (int)p->nx, ny = (int)p->ny;
+    const unsigned gy = (unsigned)((nx + 2 + 255) / 256), gx = (unsigned)((ny + 2 + 255) / 256);
+    auto any = [](const int32_t *m) { return m[0] | m[1] | m[2] | m[3]; };
+    // each reference kernel does rows (bot/top) then columns (left/right) per thread: rows first, then columns
+    if (any(p->constant_value_on)) {
+        if (p->constant_value_on[TB] | p->constant_value_on[TT]) {
+            hipLaunchKernelGGL(k_tbc2d, dim3(gy), dim3(256), 0, s, T, nx, ny, 0, 1, p->constant_value_on[TB], p->constant_value_on[TT], p->constant_value[TB], p->constant_value[TT]);
+            JRX_LAUNCH_CHECK(h);
+        }
+        if (p->constant_value_on[TL] | p->constant_value_on[TR]) {
+            hipLaunchKernelGGL(k_tbc2d, dim3(gx), dim3(256), 0, s, T, nx, ny, 0, 0, p->constant_value_on[TL], p->constant_value_on[TR], p->constant_value[TL], p->constant_value[TR]);
+            JRX_LAUNCH_CHECK(h);
+        }
+    }
+    if (any(p->no_flux)) {
+        if (p->no_flux[TB] | p->no_flux[TT]) {
+            hipLaunchKernelGGL(k_tbc2d, dim3(gy), dim3(256), 0, s, T, nx, ny, 1, 1, p->no_flux[TB], p->no_flux[TT], 0.0, 0.0);
+            JRX_LAUNCH_CHECK(h);
+        }
+        if (p->no_flux[TL] | p->no_flux[TR]) {
+            hipLaunchKernelGGL(k_tbc2d, dim3(gx), dim3(256), 0, s, T, nx, ny, 1, 0, p->no_flux[TL], p->no_flux[TR], 0.0, 0.0);
+            JRX_LAUNCH_CHECK(h);
+        }
+    }
+    if (any(p->periodic)) {
+        if (p->periodic[TB] | p->periodic[TT]) {
+            hipLaunchKernelGGL(k_tbc2d, dim3(gy), dim3(256), 0, s, T, nx, ny, 2, 1, p->periodic[TB], p->periodic[TT], 0.0, 0.0);
+            JRX_LAUNCH_CHECK(h);
+        }
+        if (p->periodic[TL] | p->periodic[TR]) {
+            hipLaunchKernelGGL(k_tbc2d, dim3(gx), dim3(256), 0, s, T, nx, ny, 2, 0, p->periodic[TL], p->periodic[TR], 0.0, 0.0);
+            JRX_LAUNCH_CHECK(h);
+        }
+    }
+    return JRX_OK;
+}
+
+jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p)
+{
+    TArgs a;
+    a.t = *t; a.p = *p;
+    const int nx = (int)p->nx, ny = (int)p->ny;
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL(k_flux2d, dim3((unsigned)(((i64)(nx + 1) * (ny + 1) + 255) / 256)), dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(k_updateT2d<false>, dim3((unsigned)(((i64)nx * ny + 255) / 256)), dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    JRX_TRY(launch_tbcs(h, s, t->T, p));
+    if (jrx_comm_active(h)) {
+        double *arrs[1] = {t->T};
+        const int64_t ext[1][3] = {{nx + 2, ny + 2, 1}};
+        const int64_t n[3] = {nx, ny, 1};
+        JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, n));
+    }
+    return JRX_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+jrx_status jrx_thermal_bcs2d(jrx_handle *h, double *T, const jrx_thermal2d_params *p)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!T || !p) return jrx_fail(h, JRX_ERR_ARG, "thermal_bcs!: null argument");
+    JRX_TRY(launch_tbcs(h, h->stream, T, p));
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_thermal2d_iteration(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p)
+{
+    JRX_TRY(checkT(h, t, p));
+    JRX_TRY(enqueue_titer(h, t, p));
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_thermal2d_check_res(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p)
+{
+    JRX_TRY(checkT(h, t, p));
+    TArgs a;
+    a.t = *t; a.p = *p;
+    hipLaunchKernelGGL(k_updateT2d<true>, dim3((unsigned)(((i64)p->nx * p->ny + 255) / 256)), dim3(256), 0, h->stream, a);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p,
+                                  int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms)
+{
+    JRX_TRY(checkT(h, t, p));
+    if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
+    const int nx = (int)p->nx, ny = (int)p->ny;
+    const i64 nT = (i64)(nx + 2) * (ny + 2), n = (i64)nx * ny;
+    hipStream_t s = h->stream;
+    const double sq = 1.0 / sqrt((double)n);
+    JRX_HIP(h, hipMemcpyAsync(t->Told, t->T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));   // @copy thermal.Told thermal.T
+    int64_t iter = 0, cnt = 0;
+    double err = 2 * p->eps;
+    TArgs a;
+    a.t = *t; a.p = *p;
+    while (err > p->eps && iter < p->iterMax) {
+        JRX_TRY(enqueue_titer(h, t, p));
+        iter++;
+        if (iter % p->nout == 0) {
+            hipLaunchKernelGGL(k_updateT2d<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+            JRX_LAUNCH_CHECK(h);
+            RedArr Z = {nullptr, {0, 0, 0}, 0}, A3 = {t->ResT, {nx, ny, 1}, 0};
+            int nb = (int)((n + 2047) / 2048);
+            nb = nb < 1 ? 1 : (nb > kMaxRedBlocks ? kMaxRedBlocks : nb);
+            hipLaunchKernelGGL(k_sumsq_partial, dim3(nb), dim3(256), 0, s, Z, Z, Z, A3, h->d_partials);
+            JRX_LAUNCH_CHECK(h);
+            hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(256), 0, s, h->d_partials, nb, h->d_sums);
+            JRX_LAUNCH_CHECK(h);
+            JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            JRX_HIP(h, hipStreamSynchronize(s));
+            err = sqrt(h->h_sums[3]) * sq;          // norm(ResT) * _sq_len_RT : local norm, no reduction across ranks (:131)
+            if (cnt < cap) {
+                if (norm_ResT) norm_ResT[cnt] = err;
+                if (iter_count) iter_count[cnt] = iter;
+            }
+            cnt++;
+            if (p->verbose) printf("iter = %lld, err = %1.3e \n", (long long)iter, err);
+        }
+    }
+    hipLaunchKernelGGL(k_sub, dim3(256), dim3(256), 0, s, t->dT, (const double *)t->T, (const double *)t->Told, nT);   // update_ΔT!
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(s));
+    if (nnorms) *nnorms = cnt < cap ? cnt : cap;
+    return JRX_OK;
+}
+
+}   // extern "C"

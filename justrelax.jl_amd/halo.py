@@ -1,0 +1,69 @@
+"""Multi-GPU plumbing: one process per GPU, RCCL communicator inside the native handle.
+
+update_halo_ mirrors ImplicitGlobalGrid.update_halo! at the reference's call sites
+(src/stokes/Stokes3D.jl:57,120 ...).  torch.distributed is used only to ship the 128-byte RCCL
+unique id from rank 0 to the other ranks (what MPI.Bcast would do in the Julia shim).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .arrays import ptr
+from .grid import global_grid
+
+
+def make_cart(gg=None) -> _lib.Cart:
+    """jrx_cart_create from the current global grid (host logic only; works without a GPU)."""
+    gg = gg or global_grid()
+    L = _lib.load()
+    cart = _lib.Cart()
+    n = (C.c_int64 * 3)(*gg.nxyz)
+    dims = (C.c_int32 * 3)(*gg.dims)
+    per = (C.c_int32 * 3)(*gg.periods)
+    st = L.jrx_cart_create(C.c_int32(gg.me), C.c_int32(gg.nprocs), n, dims, per, C.byref(cart))
+    if st != 0:
+        raise _lib.JrxError(st, "jrx_cart_create failed")
+    return cart
+
+
+def init_comm(handle=None, group=None):
+    """Create the RCCL communicator of `handle` for the ranks of the torch.distributed group."""
+    import torch.distributed as dist
+    h = handle or _lib.default_handle()
+    gg = global_grid()
+    cart = make_cart(gg)
+    if gg.nprocs == 1:
+        h.call("jrx_comm_init", None, C.byref(cart))
+        return h
+    uid = (C.c_uint8 * _lib.UNIQUE_ID_BYTES)()
+    if gg.me == 0:
+        st = h.lib.jrx_comm_unique_id(uid)
+        if st != 0:
+            raise _lib.JrxError(st, h.lib.jrx_last_error(None).decode())
+    obj = [bytes(uid) if gg.me == 0 else None]
+    dist.broadcast_object_list(obj, src=0, group=group)
+    uid = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(obj[0])
+    h.call("jrx_comm_init", uid, C.byref(cart))
+    return h
+
+
+def update_halo_(*fields, ni=None, handle=None):
+    """update_halo!(A...) on device arrays (up to 8 per call); `ni` = local cell counts (defaults to the global grid's)."""
+    h = handle or _lib.default_handle(fields[0].device.index)
+    gg = global_grid()
+    ni = tuple(ni or gg.nxyz)
+    ni = ni + (1,) * (3 - len(ni))
+    na = len(fields)
+    arrs = (C.c_void_p * na)(*[ptr(f) for f in fields])
+    ext = ((C.c_int64 * 3) * na)()
+    for a, f in enumerate(fields):
+        shp = tuple(f.shape) + (1,) * (3 - f.dim())
+        for d in range(3):
+            ext[a][d] = shp[d]
+    n = (C.c_int64 * 3)(*ni)
+    torch.cuda.current_stream(fields[0].device).synchronize()
+    h.call("jrx_update_halo", C.c_int32(na), arrs, ext, n)

@@ -1,0 +1,128 @@
+"""2D Stokes benchmark inputs (visco-elastic driver, Stokes2D.jl:181-325).
+
+solcx2d           -- miniapps/benchmarks/stokes2D/solcx/SolCx.jl:54-140
+solkz2d           -- miniapps/benchmarks/stokes2D/solkz/SolKz.jl:47-125
+elastic_buildup2d -- miniapps/benchmarks/stokes2D/elastic_buildup/Elastic_BuildUp.jl:16-116
+random_fields2d   -- kernel-parity inputs with finite dt, G, K.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from ..arrays import PTStokesCoeffs, VelocityBoundaryConditions
+from ..grid import Geometry, init_global_grid, nx_g, ny_g
+from .common import Setup, alloc_stokes
+
+_F4 = ("left", "right", "top", "bot")
+
+
+def _smooth2d(A2, A, fact=1.0):
+    """@inn(A2) = @inn(A) + 1.0/4.1/fact*(@d2_xi(A)+@d2_yi(A))   (SolCx.jl:6-11)"""
+    c = A[1:-1, 1:-1]
+    d2x = (A[2:, 1:-1] - c) - (c - A[:-2, 1:-1])
+    d2y = (A[1:-1, 2:] - c) - (c - A[1:-1, :-2])
+    A2[1:-1, 1:-1] = c + 1.0 / 4.1 / fact * (d2x + d2y)
+
+
+def _free_slip2d_host(arr):
+    Vx, Vy = arr["Vx"], arr["Vy"]
+    Vx[:, 0] = Vx[:, 1]; Vx[:, -1] = Vx[:, -2]
+    Vy[0, :] = Vy[1, :]; Vy[-1, :] = Vy[-2, :]
+
+
+def solcx2d(n=32, *, Δη=1.0e6, iterMax=500_000, nout=5000) -> Setup:
+    ni = (n, n)
+    init_global_grid(n, n, 1)
+    li = (1.0, 1.0)
+    di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g())))
+    grid = Geometry(ni, li, origin=(0.0, 0.0))
+    arr = alloc_stokes(ni)
+    pt = PTStokesCoeffs(li, di, CFL=1 / math.sqrt(2.1), ϵ_abs=1.0e-8, ϵ_rel=1.0e-9)
+    xc, yc = grid.xci
+    X, Y = np.meshgrid(xc, yc, indexing="ij")
+    eta_stokes = np.asfortranarray(np.where(X <= 0.5, 1.0, Δη))       # solCx_viscosity :13-33
+    arr["fy"][...] = -np.sin(math.pi * Y) * np.cos(math.pi * X) * 1    # solCx_density :35-52, g = 1
+    arr["G"][...] = np.inf
+    arr["K"][...] = np.inf
+    # 5 ping-pong smoothing passes; the array the solver sees (stokes.viscosity.η) ends up with the
+    # 4x-smoothed field (SolCx.jl:88-109)
+    a, b = eta_stokes, eta_stokes.copy(order="F")       # a is "η" (aliases stokes.viscosity.η), b is η2
+    for _ in range(5):
+        _smooth2d(b, a, 1.0)
+        b[0, :] = b[1, :]; b[-1, :] = b[-2, :]; b[:, 0] = b[:, 1]; b[:, -1] = b[:, -2]
+        a, b = b, a
+    arr["eta"][...] = eta_stokes
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F4})
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=0.1, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
+
+
+def solkz2d(n=32, *, Δη=1.0e6, iterMax=150_000, nout=1000) -> Setup:
+    ni = (n, n)
+    init_global_grid(n, n, 1)
+    li = (1.0, 1.0)
+    di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g())))
+    grid = Geometry(ni, li, origin=(0.0, 0.0))
+    arr = alloc_stokes(ni)
+    pt = PTStokesCoeffs(li, di, Re=5 * math.pi, CFL=1 / math.sqrt(2.1))
+    xc, yc = grid.xci
+    X, Y = np.meshgrid(xc, yc, indexing="ij")
+    arr["eta"][...] = np.exp(math.log(Δη) * Y)
+    arr["fy"][...] = -np.sin(2 * Y) * np.cos(3 * math.pi * X) * 1
+    arr["G"][...] = np.inf
+    arr["K"][...] = np.inf
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F4})
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=0.1, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
+
+
+def elastic_buildup2d(n=32, *, lx=100.0e3, ly=100.0e3, η0=1.0e21, εbg=1.0e-14, G=10.0e9,
+                      iterMax=150_000, nout=1000) -> Setup:
+    """One Setup; the caller advances time with dt = 0.05 kyr (t < 10 kyr) else 1 kyr."""
+    ni = (n, n)
+    li = (lx, ly)
+    di = tuple(l / m for l, m in zip(li, ni))
+    init_global_grid(n, n, 1)
+    grid = Geometry(ni, li, origin=(0.0, 0.0))
+    arr = alloc_stokes(ni)
+    pt = PTStokesCoeffs(li, di, ϵ_abs=1.0e-6, ϵ_rel=1.0e-6, CFL=1 / math.sqrt(2.1))
+    arr["eta"][...] = η0
+    arr["G"][...] = G
+    arr["K"][...] = np.inf
+    xc, yc = grid.xci
+    xv, yv = grid.xvi
+    arr["Vx"][:, 1:-1] = (εbg * xv)[:, None] * np.ones((1, len(yc)))       # pure_shear.jl:1-8
+    arr["Vy"][1:-1, :] = (-εbg * yv)[None, :] * np.ones((len(xc), 1))
+    _free_slip2d_host(arr)
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F4})
+    kyr = 1.0e3 * 365.25 * 3600 * 24
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=0.05 * kyr, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False),
+                 extra=dict(li=li, di=di, kyr=kyr, η0=η0, εbg=εbg, G=G))
+
+
+def random_fields2d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nout=5, bcs="free_slip") -> Setup:
+    ni = tuple(ni)
+    init_global_grid(ni[0], ni[1], 1)
+    rng = np.random.default_rng(seed)
+    arr = alloc_stokes(ni)
+    for k, a in arr.items():
+        if k not in ("eta", "K", "G"):
+            a[...] = rng.uniform(-1.0, 1.0, size=a.shape)
+    arr["Q"][...] = rng.uniform(-0.1, 0.1, size=ni)
+    arr["eta"][...] = 10.0 ** rng.uniform(-3.0, 0.0, size=ni)
+    arr["G"][...] = G * (1.0 + 0.5 * rng.uniform(0.0, 1.0, size=ni))
+    arr["K"][...] = K * (1.0 + 0.5 * rng.uniform(0.0, 1.0, size=ni))
+    li = (1.0, 1.3)
+    di = tuple(l / n for l, n in zip(li, ni))
+    pt = PTStokesCoeffs(li, di)
+    on, off = {f: True for f in _F4}, {f: False for f in _F4}
+    b = {"free_slip": VelocityBoundaryConditions(free_slip=on, no_slip=off),
+         "no_slip": VelocityBoundaryConditions(free_slip=off, no_slip=on),
+         "periodic": VelocityBoundaryConditions(free_slip=off, no_slip=off, periodic=on),
+         "none": VelocityBoundaryConditions(free_slip=off, no_slip=off)}[bcs]
+    grid = Geometry(ni, li)
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=dt, flow_bcs=b,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))

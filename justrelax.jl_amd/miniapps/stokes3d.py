@@ -1,0 +1,230 @@
+"""3D Stokes benchmark inputs.
+
+solvi3d        -- miniapps/benchmarks/stokes3D/solvi/SolVi3D.jl:14-102 (spherical weak inclusion, pure shear)
+taylor_green3d -- miniapps/benchmarks/stokes3D/taylor_green/TaylorGreen.jl:11-136 (analytic body force)
+random_fields3d -- kernel-parity inputs with finite dt, G, K so that every elastic / compressible
+                   term is exercised (SolVi/Taylor-Green have dt = Inf).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from ..arrays import PTStokesCoeffs, VelocityBoundaryConditions
+from ..grid import Geometry, global_grid, init_global_grid, nx_g, ny_g, nz_g, OVERLAP
+from .common import Setup, alloc_stokes
+
+_F6 = ("left", "right", "front", "back", "top", "bot")
+
+
+def _smooth3d(A2, A, fact=1.0):
+    """@inn(A2) = @inn(A) + 1/6.1/fact*(@d2_xi(A)+@d2_yi(A)+@d2_zi(A))  (SolVi3D.jl:9-12;
+    ParallelStencil.FiniteDifferences3D: d2_xi = (A[i+1]-A[i]) - (A[i]-A[i-1]) on inner points)."""
+    c = A[1:-1, 1:-1, 1:-1]
+    d2x = (A[2:, 1:-1, 1:-1] - c) - (c - A[:-2, 1:-1, 1:-1])
+    d2y = (A[1:-1, 2:, 1:-1] - c) - (c - A[1:-1, :-2, 1:-1])
+    d2z = (A[1:-1, 1:-1, 2:] - c) - (c - A[1:-1, 1:-1, :-2])
+    A2[1:-1, 1:-1, 1:-1] = c + 1.0 / 6.1 / fact * (d2x + d2y + d2z)
+
+
+def solvi_viscosity(ni, di, li, rc, η0, ηi, update_halo=None):
+    """SolVi3D.jl:14-43.  The reference places the inclusion with *local* indices; here the rank
+    offset coord*(n-2) is added so that a decomposed run sees one global inclusion (identical on
+    one rank)."""
+    gg = global_grid()
+    off = [gg.coords[d] * (ni[d] - OVERLAP) if gg.initialized else 0 for d in range(3)]
+    ix = [(np.arange(ni[d]) + off[d]) * di[d] + 0.5 * di[d] - 0.5 * li[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*ix, indexing="ij")
+    η = np.full(ni, η0, dtype=np.float64, order="F")
+    η[np.sqrt(X ** 2 + Y ** 2 + Z ** 2) <= rc] = ηi
+    η2 = η.copy(order="F")
+    for _ in range(10):
+        _smooth3d(η2, η, 1.0)
+        η, η2 = η2, η
+        if update_halo is not None:
+            update_halo(η)
+    return η
+
+
+def pureshear_bc3d(arr, xci, xvi, εbg):
+    """src/boundaryconditions/pure_shear.jl:10-30 (note: Vy takes its y-coordinate from xv and
+    Vz its y from xc -- reference quirk, exact for cubic domains)."""
+    xv, yv, zv = xvi
+    xc, yc, zc = xci
+    arr["Vx"][:, 1:-1, 1:-1] = (εbg * xv)[:, None, None] * np.ones((1, len(yc), len(zc)))
+    arr["Vy"][1:-1, :, 1:-1] = (εbg * xv)[None, :, None] * np.ones((len(xc), 1, len(zc)))
+    arr["Vz"][1:-1, 1:-1, :] = (-εbg * zv)[None, None, :] * np.ones((len(xc), len(xc), 1))
+
+
+def _free_slip3d_host(arr):
+    """flow_bcs!(free_slip all faces) on host arrays -- face groups in the reference's source
+    order (free_slip.jl:15-70): front/back, top/bot (k=1/k=end), left/right."""
+    Vx, Vy, Vz = arr["Vx"], arr["Vy"], arr["Vz"]
+    Vx[:, 0, :] = Vx[:, 1, :]; Vz[:, 0, :] = Vz[:, 1, :]
+    Vx[:, -1, :] = Vx[:, -2, :]; Vz[:, -1, :] = Vz[:, -2, :]
+    Vx[:, :, 0] = Vx[:, :, 1]; Vy[:, :, 0] = Vy[:, :, 1]
+    Vx[:, :, -1] = Vx[:, :, -2]; Vy[:, :, -1] = Vy[:, :, -2]
+    Vy[0, :, :] = Vy[1, :, :]; Vz[0, :, :] = Vz[1, :, :]
+    Vy[-1, :, :] = Vy[-2, :, :]; Vz[-1, :, :] = Vz[-2, :, :]
+
+
+def solvi3d(n=16, *, Δη=1.0e-3, lx=10.0, ly=10.0, lz=10.0, rc=1.0, εbg=1.0, iterMax=5000, nout=100,
+            init_grid=True) -> Setup:
+    """solVi3D(; nx, ny, nz, ...) -- SolVi3D.jl:45-129.  `n` is the *local* cell count per dim."""
+    ni = (n, n, n) if isinstance(n, int) else tuple(n)
+    if init_grid:
+        init_global_grid(*ni)
+    li = (lx, ly, lz)
+    di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g(), nz_g())))
+    grid = Geometry(ni, li, origin=(0.0, 0.0, 0.0))
+    arr = alloc_stokes(ni)
+    pt = PTStokesCoeffs(li, di, CFL=1 / math.sqrt(3))
+    arr["eta"][...] = solvi_viscosity(ni, di, li, rc, 1.0, Δη)
+    arr["G"][...] = 1.0
+    arr["K"][...] = np.inf
+    pureshear_bc3d(arr, grid.xci, grid.xvi, εbg)
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F6}, no_slip={f: False for f in _F6})
+    gg = global_grid()
+    if gg.nprocs == 1:
+        _free_slip3d_host(arr)
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=float("inf"), flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
+
+
+def taylor_green3d(n=16, *, iterMax=100_000, nout=1000, init_grid=True) -> Setup:
+    """taylorGreen(; nx, ny, nz) -- TaylorGreen.jl:80-152."""
+    ni = (n, n, n)
+    if init_grid:
+        init_global_grid(*ni)
+    li = (1.0, 1.0, 1.0)
+    di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g(), nz_g())))
+    grid = Geometry(ni, li, origin=(0.0, 0.0, 0.0))
+    arr = alloc_stokes(ni)
+    pt = PTStokesCoeffs(li, di, CFL=1 / math.sqrt(3))
+    arr["eta"][...] = 1.0
+    xc, yc, zc = grid.xci
+    X, Y, Z = np.meshgrid(xc, yc, zc, indexing="ij")
+    arr["fx"][...] = 36 * math.pi ** 2 * np.cos(2 * math.pi * X) * np.sin(2 * math.pi * Y) * np.sin(2 * math.pi * Z)
+    arr["G"][...] = np.inf
+    arr["K"][...] = np.inf
+    # velocity!(stokes, xci, xvi): analytic velocity on every outer plane, zero inside (TaylorGreen.jl:25-78)
+    xv, yv, zv = grid.xvi
+    d = [c[1] - c[0] for c in grid.xci]
+    xce, yce, zce = [np.linspace(c[0] - dd, c[-1] + dd, len(c) + 2) for c, dd in zip(grid.xci, d)]
+    vx = lambda x, y, z: -2 * np.cos(2 * math.pi * x) * np.sin(2 * math.pi * y) * np.sin(2 * math.pi * z)
+    vy = lambda x, y, z: np.sin(2 * math.pi * x) * np.cos(2 * math.pi * y) * np.sin(2 * math.pi * z)
+    vz = lambda x, y, z: np.sin(2 * math.pi * x) * np.sin(2 * math.pi * y) * np.cos(2 * math.pi * z)
+    for name, fn, cs in (("Vx", vx, (xv, yce, zce)), ("Vy", vy, (xce, yv, zce)), ("Vz", vz, (xce, yce, zv))):
+        A = arr[name]
+        full = fn(*np.meshgrid(*cs, indexing="ij"))
+        mask = np.zeros(A.shape, dtype=bool)
+        mask[0], mask[-1], mask[:, 0], mask[:, -1], mask[:, :, 0], mask[:, :, -1] = (True,) * 6
+        A[...] = np.where(mask, full, 0.0)
+    none = {f: False for f in _F6}
+    bcs = VelocityBoundaryConditions(free_slip=dict(none), no_slip=dict(none))
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=float("inf"), flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
+
+
+def taylor_green_error_norms(arr, grid):
+    """error_norms -- vizTaylorGreen.jl:100-119 : sqrt(Σ e² ΔV), pressures with mean removed."""
+    xc, yc, zc = grid.xci
+    xv, yv, zv = grid.xvi
+    dV = float(np.prod(grid.di["center"]))
+    s, c = lambda a: np.sin(2 * math.pi * a), lambda a: np.cos(2 * math.pi * a)
+    m = lambda *cs: np.meshgrid(*cs, indexing="ij")
+    X, Y, Z = m(xv, yc, zc); vx = -2 * c(X) * s(Y) * s(Z)
+    X, Y, Z = m(xc, yv, zc); vy = s(X) * c(Y) * s(Z)
+    X, Y, Z = m(xc, yc, zv); vz = s(X) * s(Y) * c(Z)
+    X, Y, Z = m(xc, yc, zc); p = -6 * math.pi * s(X) * s(Y) * s(Z)
+    L2 = lambda e: math.sqrt(float(np.sum(e * e)) * dV)
+    P = arr["P"]
+    return (L2((P - P.mean()) - (p - p.mean())), L2(arr["Vx"][:, 1:-1, 1:-1] - vx),
+            L2(arr["Vy"][1:-1, :, 1:-1] - vy), L2(arr["Vz"][1:-1, 1:-1, :] - vz))
+
+
+def random_fields3d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nout=5,
+                    bcs="free_slip") -> Setup:
+    """Kernel-parity inputs: fields ~U(-1,1), η = 10^U(-3,0), G, K finite, finite dt,
+    Q ~ U(-0.1,0.1).  Every array the kernels read is non-trivial."""
+    ni = tuple(ni)
+    init_global_grid(*ni)
+    rng = np.random.default_rng(seed)
+    arr = alloc_stokes(ni)
+    for k, a in arr.items():
+        if k in ("eta", "K", "G"):
+            continue
+        a[...] = rng.uniform(-1.0, 1.0, size=a.shape)
+    arr["Q"][...] = rng.uniform(-0.1, 0.1, size=ni)
+    arr["eta"][...] = 10.0 ** rng.uniform(-3.0, 0.0, size=ni)
+    arr["G"][...] = G * (1.0 + 0.5 * rng.uniform(0.0, 1.0, size=ni))
+    arr["K"][...] = K * (1.0 + 0.5 * rng.uniform(0.0, 1.0, size=ni))
+    li = (1.0, 1.3, 0.9)
+    di = tuple(l / n for l, n in zip(li, ni))
+    pt = PTStokesCoeffs(li, di)
+    on = {f: True for f in _F6}
+    off = {f: False for f in _F6}
+    if bcs == "free_slip":
+        b = VelocityBoundaryConditions(free_slip=on, no_slip=off)
+    elif bcs == "no_slip":
+        b = VelocityBoundaryConditions(free_slip=off, no_slip=on)
+    elif bcs == "periodic":
+        b = VelocityBoundaryConditions(free_slip=off, no_slip=off, periodic=on)
+    elif bcs == "mixed":
+        b = VelocityBoundaryConditions(free_slip=dict(off, left=True, right=True), no_slip=dict(off, top=True, bot=True),
+                                       periodic=dict(off, front=True, back=True))
+    else:
+        b = VelocityBoundaryConditions(free_slip=off, no_slip=off)
+    grid = Geometry(ni, li)
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=dt, flow_bcs=b,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
+
+
+def solvi3d_device(n, backend_tag, *, Δη=1.0e-3, li=(10.0, 10.0, 10.0), rc=1.0, εbg=1.0, update_halo=None):
+    """SolVi3D built directly in device memory (for sizes whose host copy would not fit: 512³ needs
+    ≈48 GB of fields).  Same construction as `solvi3d` (torch elementwise ops instead of numpy);
+    returns (stokes, ρg, K, G, pt, grid, flow_bcs, dt).  Call init_global_grid first for N > 1."""
+    import torch
+    from ..arrays import StokesArrays, fzeros
+    from ..backend import device_of
+    from ..grid import grid_is_initialized
+    ni = (n, n, n) if isinstance(n, int) else tuple(n)
+    if not grid_is_initialized():
+        init_global_grid(*ni)
+    dev = device_of(backend_tag)
+    di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g(), nz_g())))
+    grid = Geometry(ni, li, origin=(0.0, 0.0, 0.0))
+    pt = PTStokesCoeffs(li, di, CFL=1 / math.sqrt(3))
+    stokes = StokesArrays(backend_tag, ni)
+    gg = global_grid()
+    off = [gg.coords[d] * (ni[d] - OVERLAP) for d in range(3)]
+    ax = [(torch.arange(ni[d], device=dev, dtype=torch.float64) + off[d]) * di[d] + 0.5 * di[d] - 0.5 * li[d] for d in range(3)]
+    η, η2 = stokes.viscosity.η, fzeros(ni, dev)
+    r2 = ax[0][:, None, None] ** 2 + ax[1][None, :, None] ** 2 + ax[2][None, None, :] ** 2
+    η.fill_(1.0)
+    η[torch.sqrt(r2) <= rc] = Δη
+    del r2
+    η2.copy_(η)
+    a, b = η, η2
+    for _ in range(10):            # 10 even ping-pong passes: the result ends in `a` == stokes.viscosity.η
+        c = a[1:-1, 1:-1, 1:-1]
+        lap = ((a[2:, 1:-1, 1:-1] - c) - (c - a[:-2, 1:-1, 1:-1])) + ((a[1:-1, 2:, 1:-1] - c) - (c - a[1:-1, :-2, 1:-1]))
+        lap = lap + ((a[1:-1, 1:-1, 2:] - c) - (c - a[1:-1, 1:-1, :-2]))
+        b[1:-1, 1:-1, 1:-1] = c + 1.0 / 6.1 / 1.0 * lap
+        del lap
+        a, b = b, a
+        if update_halo is not None:
+            update_halo(a)
+    assert a is η
+    del η2
+    G = fzeros(ni, dev, 1.0)
+    K = fzeros(ni, dev, float("inf"))
+    ρg = tuple(fzeros(ni, dev) for _ in range(3))
+    xv = torch.as_tensor(grid.xvi[0], device=dev)
+    zv = torch.as_tensor(grid.xvi[2], device=dev)
+    stokes.V.Vx[:, 1:-1, 1:-1] = (εbg * xv)[:, None, None]
+    stokes.V.Vy[1:-1, :, 1:-1] = (εbg * xv)[None, :, None]
+    stokes.V.Vz[1:-1, 1:-1, :] = (-εbg * zv)[None, None, :]
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F6}, no_slip={f: False for f in _F6})
+    return stokes, ρg, K, G, pt, grid, bcs, float("inf")

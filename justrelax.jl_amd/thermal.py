@@ -1,0 +1,111 @@
+"""Operator API of the PT heat-diffusion path: heatdiffusion_PT_, thermal_bcs_.
+
+Reference: src/thermal_diffusion/DiffusionPT_solver.jl:11-17 (dispatch), :34-149 (array form),
+:181-305 (rheology form); src/boundaryconditions/BoundaryConditions.jl:39-53.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+from .arrays import ptr
+from .grid import Geometry, legacy_uniform_grid
+from .stokes import _require_gpu
+
+_ORDER = ("left", "right", "top", "bot")
+
+
+def thermal_params2d(ni, grid, thermal_bc, dt, ϵ, *, iterMax=50_000, nout=1000, verbose=True, rheology=None, **_):
+    _di = grid._di["center"]
+    p = _lib.Thermal2DParams()
+    p.nx, p.ny, p._dx, p._dy, p.dt, p.eps = ni[0], ni[1], _di[0], _di[1], float(dt), float(ϵ)
+    p.iterMax, p.nout, p.verbose = int(iterMax), int(nout), int(bool(verbose))
+    for i, k in enumerate(_ORDER):
+        p.no_flux[i] = int(bool(thermal_bc.no_flux.get(k, False)))
+        p.periodic[i] = int(bool(thermal_bc.periodic.get(k, False)))
+        v = thermal_bc.constant_value.get(k, False)
+        p.constant_value_on[i] = int(v is not False and v is not None)         # `bc.bot === false ? ... : 2*bc.bot - T`
+        p.constant_value[i] = float(v) if p.constant_value_on[i] else 0.0
+        v = thermal_bc.constant_flux.get(k, False)
+        on = not isinstance(v, bool) and v is not None                         # `!isa(bc_flux.left, Bool)`
+        p.constant_flux_on[i] = int(on)
+        p.constant_flux[i] = float(v) if on else 0.0
+    if rheology is not None:
+        p.rheology_form = 1
+        p.k_const, p.Cp, p.rho0, p.alpha, p.T0 = (rheology["k"], rheology["Cp"], rheology["rho0"], rheology["alpha"],
+                                                   rheology.get("T0", 0.0))
+    return p
+
+
+def thermal_fields2d(thermal, pt_thermal, K=None, ρCp=None):
+    f = _lib.Thermal2DFields()
+    vals = dict(T=thermal.T, Told=thermal.Told, dT=thermal.ΔT, qTx=thermal.qTx, qTx2=thermal.qTx2, qTy=thermal.qTy,
+                qTy2=thermal.qTy2, H=thermal.H, shear_heating=thermal.shear_heating, ResT=thermal.ResT, K=K, rhoCp=ρCp,
+                thetar_dtau=pt_thermal.θr_dτ, dtau_rho=pt_thermal.dτ_ρ)
+    for n in _lib.T2_NAMES:
+        setattr(f, n, ptr(vals.get(n)))
+    f._keep = vals
+    return f
+
+
+def heatdiffusion_PT_(thermal, pt_thermal, thermal_bc, A, B, dt, grid_or_di, *, kwargs=None, handle=None):
+    """heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, K, ρCp, dt, grid; kwargs)          [array form]
+       heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, rheology, args, dt, grid; kwargs)  [rheology form]
+
+    In the rheology form `A` is a dict(k, Cp, rho0, alpha, T0) (constant conductivity / heat capacity and a
+    PT_Density) and `B` the reference's `args` (ignored: T is thermal.T, P does not enter with β = 0).
+    Returns (iter_count, norm_ResT) like DiffusionPT_solver.jl:148."""
+    _require_gpu(thermal)
+    kw = dict(kwargs or {})
+    ni = thermal._ni
+    if len(ni) != 2:
+        raise NotImplementedError("3D heatdiffusion_PT! is not part of this round (SURVEY §8f rank 3)")
+    grid = grid_or_di if isinstance(grid_or_di, Geometry) else legacy_uniform_grid(ni, grid_or_di)
+    h = handle or _lib.default_handle(thermal.T.device.index)
+    if isinstance(A, dict):
+        p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, rheology=A, **kw)
+        f = thermal_fields2d(thermal, pt_thermal)
+    else:
+        p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, **kw)
+        f = thermal_fields2d(thermal, pt_thermal, A, B)
+    cap = int(p.iterMax // p.nout + 2)
+    it, nr, nn = np.zeros(cap, dtype=np.int64), np.zeros(cap), C.c_int64(0)
+    torch.cuda.current_stream(thermal.T.device).synchronize()
+    h.call("jrx_heatdiffusion_PT2d", C.byref(f), C.byref(p), it.ctypes.data_as(C.POINTER(C.c_int64)),
+           nr.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(cap), C.byref(nn))
+    return SimpleNamespace(iter_count=it[: nn.value].copy(), norm_ResT=nr[: nn.value].copy())
+
+
+def thermal_bcs_(thermal_or_T, thermal_bc, *, handle=None):
+    """thermal_bcs!(thermal, bcs) -- BoundaryConditions.jl:39-53"""
+    T = thermal_or_T.T if hasattr(thermal_or_T, "Told") else thermal_or_T
+    _require_gpu(T)
+    if T.dim() != 2:
+        raise NotImplementedError("3D thermal_bcs! is not part of this round")
+    h = handle or _lib.default_handle(T.device.index)
+    ni = (T.shape[0] - 2, T.shape[1] - 2)
+    fake = SimpleNamespace(_di=dict(center=(1.0, 1.0)))
+    p = thermal_params2d(ni, fake, thermal_bc, 1.0, 0.0)
+    torch.cuda.current_stream(T.device).synchronize()
+    h.call("jrx_thermal_bcs2d", C.c_void_p(ptr(T)), C.byref(p))
+
+
+def thermal_iteration_(thermal, pt_thermal, thermal_bc, A, B, dt, grid, *, check_res=False, handle=None):
+    """One PT iteration (compute_flux! + update_T! + thermal_bcs!), optionally followed by check_res!."""
+    _require_gpu(thermal)
+    h = handle or _lib.default_handle(thermal.T.device.index)
+    ni = thermal._ni
+    if isinstance(A, dict):
+        p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, rheology=A)
+        f = thermal_fields2d(thermal, pt_thermal)
+    else:
+        p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ)
+        f = thermal_fields2d(thermal, pt_thermal, A, B)
+    torch.cuda.current_stream(thermal.T.device).synchronize()
+    h.call("jrx_thermal2d_iteration", C.byref(f), C.byref(p))
+    if check_res:
+        h.call("jrx_thermal2d_check_res", C.byref(f), C.byref(p))

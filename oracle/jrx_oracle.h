@@ -1,0 +1,164 @@
+/*
+ * jrx_oracle.h -- CPU restatement ("oracle") of the JustRelax.jl pseudo-transient hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (justrelax.jl_amd/, include/) may
+ * include, link, import or call this code.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and there only as the checker / CPU baseline.
+ *
+ * Parity status: the reference is pure Julia and cannot be run in the build container
+ * (no julia binary, no network).  The restatement is pinned by the reference's own
+ * known-answer tests (test/test_mini_kernels.jl, test/test_Utils.jl, test/test_types.jl,
+ * analytic benchmark thresholds of test_stokes_taylor_green.jl / test_stokes_solvi3D.jl /
+ * test_stokes_solcx.jl / test_stokes_elastic_buildup.jl / test_diffusion2D.jl) -- see
+ * tests/test_oracle_*.py.  It has never been diffed against outputs of the Julia code.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it follows.
+ * One loop nest per reference kernel, no fusion, outer-loop OpenMP threading (this mirrors
+ * ParallelStencil's Threads backend and is what bench.py times as cpu_baseline kind="port").
+ * Arrays are dense, column-major (x fastest), fp64 -- Julia's layout.
+ * Build with -ffp-contract=off: fma() appears exactly where the reference has fma/muladd.
+ */
+#ifndef JRX_ORACLE_H
+#define JRX_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- MiniKernels.jl scalar helpers (1-based i,j,k exactly as in the reference tests) ---- */
+double orc_mini2(const char *name, const double *A, int n1, int n2, double d, int i, int j);
+double orc_mini3(const char *name, const double *A, int n1, int n2, int n3, double d, int i, int j, int k);
+double orc_div2(const double *Ax, const double *Ay, int n1, int n2, double _dx, double _dy, int i, int j);
+double orc_div3(const double *Ax, const double *Ay, const double *Az, int n1, int n2, int n3,
+                double _dx, double _dy, double _dz, int i, int j, int k);
+double orc_mysum(int use_inv, const double *A, int n1, int n2, int n3,
+                 int i0, int i1, int j0, int j1, int k0, int k1);
+double orc_compute_dtau_r(double theta_dtau, double eta, double _Gdt);
+
+/* ---- 3D Stokes fields (all pointers host memory) ---- */
+typedef struct orc_fields3d {
+    double *P, *P0, *divV, *Q;
+    double *Vx, *Vy, *Vz;
+    double *Ux, *Uy, *Uz;
+    double *txx, *tyy, *tzz, *tyz, *txz, *txy;
+    double *toxx, *toyy, *tozz, *toyz, *toxz, *toxy;
+    double *exx, *eyy, *ezz, *eyz, *exz, *exy;
+    double *eta, *K, *G;
+    double *fx, *fy, *fz;
+    double *RP, *Rx, *Ry, *Rz;
+    /* centre copies of the shear stresses (xx/yy/zz alias the staggered ones); may be NULL */
+    double *tyz_c, *txz_c, *txy_c, *toyz_c, *toxz_c, *toxy_c;
+} orc_fields3d;
+
+typedef struct orc_params3d {
+    int64_t nx, ny, nz;          /* local cell counts = size(stokes.P) */
+    int64_t nxg, nyg, nzg;       /* nx_g(), ny_g(), nz_g() (== nx,ny,nz on one rank) */
+    double _dx, _dy, _dz;        /* inverse spacings */
+    double dt, r, theta_dtau, eta_dtau;
+    double eps_rel, eps_abs;
+    int64_t iterMax, nout;
+    uint32_t free_slip, no_slip, periodic; /* bit per face, see JRX_FACE_* in include/jrx.h */
+} orc_params3d;
+
+typedef struct orc_result {
+    int64_t iter;
+    int64_t nchecks;
+    int32_t status;              /* 0 ok, 1 NaN residual */
+    double *err_evo1; int64_t *err_evo2;   /* capacity cap */
+    double *norm_Rx, *norm_Ry, *norm_Rz, *norm_divV;
+    int64_t cap;
+    double time_s;
+} orc_result;
+
+/* single kernels, one per reference kernel */
+void orc_compute_divV3d(double *divV, const double *Vx, const double *Vy, const double *Vz,
+                        int64_t nx, int64_t ny, int64_t nz, double _dx, double _dy, double _dz);
+void orc_compute_P3d(double *P, const double *P0, double *RP, const double *divV, const double *Q,
+                     const double *eta, const double *K, const double *G, int64_t n,
+                     double dt, double r, double theta_dtau);
+void orc_compute_strain_rate3d(const orc_fields3d *f, const orc_params3d *p);
+void orc_compute_tau3d(const orc_fields3d *f, const orc_params3d *p);
+void orc_compute_V3d(const orc_fields3d *f, const double *etatau, const orc_params3d *p);
+void orc_velocity2displacement3d(const orc_fields3d *f, const orc_params3d *p);
+void orc_flow_bcs3d(double *Vx, double *Vy, double *Vz, int64_t nx, int64_t ny, int64_t nz,
+                    uint32_t free_slip, uint32_t no_slip, uint32_t periodic);
+void orc_compute_maxloc3d(double *B, const double *A, int64_t nx, int64_t ny, int64_t nz);
+void orc_compute_maxloc2d(double *B, const double *A, int64_t nx, int64_t ny);
+/* sums of squares: Rx/Ry/Rz interior slice [2:end-1]^3, RP whole -- Stokes3D.jl:127-142 */
+void orc_residual_sumsq3d(const orc_fields3d *f, const orc_params3d *p, double out[4]);
+/* one PT iteration = Stokes3D.jl:78-121 (no halo exchange: single rank) */
+void orc_stokes3d_iteration(const orc_fields3d *f, const double *etatau, const orc_params3d *p);
+/* full driver = Stokes3D.jl:25-186 */
+int32_t orc_stokes3d_solve(const orc_fields3d *f, const orc_params3d *p, orc_result *res);
+
+/* ---- 2D Stokes (visco-elastic variant, Stokes2D.jl:181-325) ---- */
+typedef struct orc_fields2d {
+    double *P, *P0, *divV, *Q;
+    double *Vx, *Vy, *Ux, *Uy;
+    double *txx, *tyy, *txy, *toxx, *toyy, *toxy;
+    double *exx, *eyy, *exy;
+    double *eta, *K, *G;
+    double *fx, *fy;
+    double *RP, *Rx, *Ry;
+    double *txy_c, *toxy_c;      /* may be NULL */
+} orc_fields2d;
+
+typedef struct orc_params2d {
+    int64_t nx, ny, nxg, nyg;
+    double _dx, _dy;
+    double dt, r, theta_dtau, eta_dtau, eps_rel, eps_abs;
+    int64_t iterMax, nout;
+    uint32_t free_slip, no_slip, periodic;
+} orc_params2d;
+
+void orc_compute_divV2d(double *divV, const double *Vx, const double *Vy, int64_t nx, int64_t ny,
+                        double _dx, double _dy);
+void orc_compute_strain_rate2d(const orc_fields2d *f, const orc_params2d *p);
+void orc_compute_tau2d(const orc_fields2d *f, const orc_params2d *p);
+void orc_compute_V2d(const orc_fields2d *f, const double *etatau, const orc_params2d *p);
+void orc_compute_Res2d(const orc_fields2d *f, const orc_params2d *p);
+void orc_velocity2displacement2d(const orc_fields2d *f, const orc_params2d *p);
+void orc_flow_bcs2d(double *Vx, double *Vy, int64_t nx, int64_t ny,
+                    uint32_t free_slip, uint32_t no_slip, uint32_t periodic);
+void orc_residual_sumsq2d(const orc_fields2d *f, const orc_params2d *p, double out[3]);
+void orc_stokes2d_iteration(const orc_fields2d *f, const double *etatau, const orc_params2d *p);
+int32_t orc_stokes2d_solve(const orc_fields2d *f, const orc_params2d *p, orc_result *res);
+
+/* ---- 2D PT heat diffusion (DiffusionPT_solver.jl / DiffusionPT_kernels.jl) ---- */
+typedef struct orc_thermal2d {
+    double *T, *Told, *dT;        /* (nx+2, ny+2) ; dT = ΔT */
+    double *qTx, *qTx2;           /* (nx+1, ny)   */
+    double *qTy, *qTy2;           /* (nx, ny+1)   */
+    double *H, *shear_heating, *ResT;   /* (nx, ny) */
+    double *K, *rhoCp;            /* (nx, ny) array-coefficient form; may be NULL in rheology form */
+    double *thetar_dtau, *dtau_rho;     /* (nx, ny) PTThermalCoeffs */
+} orc_thermal2d;
+
+typedef struct orc_thermal_params2d {
+    int64_t nx, ny;
+    double _dx, _dy;
+    double dt, eps;
+    int64_t iterMax, nout;
+    /* thermal BCs, faces in order left,right,top,bot (2D naming of the reference) */
+    int32_t no_flux[4];
+    int32_t constant_value_on[4]; double constant_value[4];
+    int32_t constant_flux_on[4];  double constant_flux[4];
+    int32_t periodic[4];
+    /* rheology form (test_diffusion2D.jl): constant conductivity, Cp, PT_Density(rho0, alpha), H */
+    int32_t rheology_form;
+    double k_const, Cp, rho0, alpha, T0, H_const;
+} orc_thermal_params2d;
+
+void orc_thermal_bcs2d(double *T, const orc_thermal_params2d *p);
+void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d *p);
+void orc_thermal2d_check_res(const orc_thermal2d *t, const orc_thermal_params2d *p);
+int32_t orc_heatdiffusion_PT2d(const orc_thermal2d *t, const orc_thermal_params2d *p,
+                               int64_t *iter_out, double *norm_ResT, int64_t cap, int64_t *nnorms);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,349 @@
+"""ctypes binding of the CPU oracle (oracle/libjrx_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/jrx_oracle.h.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product path never does.
+
+All arrays are numpy float64, Fortran order (Julia's dense column-major layout).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "libjrx_oracle.so"
+
+FACE = dict(left=1, right=2, front=4, back=8, top=16, bot=32)
+
+
+def build(force: bool = False) -> Path:
+    """Compile the C restatement with gcc (see oracle/Makefile)."""
+    if force or not _LIB_PATH.exists():
+        subprocess.check_call(["make", "-C", str(_HERE)] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_dp = C.POINTER(C.c_double)
+
+F3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",
+            "txx", "tyy", "tzz", "tyz", "txz", "txy",
+            "toxx", "toyy", "tozz", "toyz", "toxz", "toxy",
+            "exx", "eyy", "ezz", "eyz", "exz", "exy",
+            "eta", "K", "G", "fx", "fy", "fz", "RP", "Rx", "Ry", "Rz",
+            "tyz_c", "txz_c", "txy_c", "toyz_c", "toxz_c", "toxy_c"]
+
+F2_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy",
+            "txx", "tyy", "txy", "toxx", "toyy", "toxy", "exx", "eyy", "exy",
+            "eta", "K", "G", "fx", "fy", "RP", "Rx", "Ry", "txy_c", "toxy_c"]
+
+T2_NAMES = ["T", "Told", "dT", "qTx", "qTx2", "qTy", "qTy2", "H", "shear_heating", "ResT",
+            "K", "rhoCp", "thetar_dtau", "dtau_rho"]
+
+
+def shapes3d(nx, ny, nz):
+    """Array extents of StokesArrays in 3D (src/types/constructors/stokes.jl:27-34,196-212,241-247)."""
+    c = (nx, ny, nz)
+    s = {n: c for n in F3_NAMES}
+    s.update(Vx=(nx + 1, ny + 2, nz + 2), Vy=(nx + 2, ny + 1, nz + 2), Vz=(nx + 2, ny + 2, nz + 1))
+    s.update(Ux=s["Vx"], Uy=s["Vy"], Uz=s["Vz"])
+    for p in ("t", "to", "e"):
+        s[p + "xy"] = (nx + 1, ny + 1, nz)
+        s[p + "yz"] = (nx, ny + 1, nz + 1)
+        s[p + "xz"] = (nx + 1, ny, nz + 1)
+    s.update(Rx=(nx - 1, ny, nz), Ry=(nx, ny - 1, nz), Rz=(nx, ny, nz - 1))
+    return s
+
+
+def shapes2d(nx, ny):
+    c = (nx, ny)
+    s = {n: c for n in F2_NAMES}
+    s.update(Vx=(nx + 1, ny + 2), Vy=(nx + 2, ny + 1))
+    s.update(Ux=s["Vx"], Uy=s["Vy"])
+    for p in ("t", "to", "e"):
+        s[p + "xy"] = (nx + 1, ny + 1)
+    s.update(Rx=(nx - 1, ny), Ry=(nx, ny - 1))
+    return s
+
+
+def shapes_thermal2d(nx, ny):
+    c = (nx, ny)
+    s = {n: c for n in T2_NAMES}
+    s.update(T=(nx + 2, ny + 2), Told=(nx + 2, ny + 2), dT=(nx + 2, ny + 2),
+             qTx=(nx + 1, ny), qTx2=(nx + 1, ny), qTy=(nx, ny + 1), qTy2=(nx, ny + 1))
+    return s
+
+
+def alloc(shapes: dict) -> dict:
+    return {k: np.zeros(v, dtype=np.float64, order="F") for k, v in shapes.items()}
+
+
+def _mkstruct(name, names):
+    return type(name, (C.Structure,), {"_fields_": [(n, _dp) for n in names]})
+
+
+Fields3D = _mkstruct("Fields3D", F3_NAMES)
+Fields2D = _mkstruct("Fields2D", F2_NAMES)
+Thermal2D = _mkstruct("Thermal2D", T2_NAMES)
+
+
+class Params3D(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64),
+                ("nxg", C.c_int64), ("nyg", C.c_int64), ("nzg", C.c_int64),
+                ("_dx", C.c_double), ("_dy", C.c_double), ("_dz", C.c_double),
+                ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
+                ("eps_rel", C.c_double), ("eps_abs", C.c_double),
+                ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32)]
+
+
+class Params2D(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nxg", C.c_int64), ("nyg", C.c_int64),
+                ("_dx", C.c_double), ("_dy", C.c_double),
+                ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
+                ("eps_rel", C.c_double), ("eps_abs", C.c_double),
+                ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32)]
+
+
+class ThermalParams2D(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("_dx", C.c_double), ("_dy", C.c_double),
+                ("dt", C.c_double), ("eps", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("no_flux", C.c_int32 * 4),
+                ("constant_value_on", C.c_int32 * 4), ("constant_value", C.c_double * 4),
+                ("constant_flux_on", C.c_int32 * 4), ("constant_flux", C.c_double * 4),
+                ("periodic", C.c_int32 * 4),
+                ("rheology_form", C.c_int32),
+                ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double),
+                ("T0", C.c_double), ("H_const", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [("iter", C.c_int64), ("nchecks", C.c_int64), ("status", C.c_int32),
+                ("err_evo1", _dp), ("err_evo2", C.POINTER(C.c_int64)),
+                ("norm_Rx", _dp), ("norm_Ry", _dp), ("norm_Rz", _dp), ("norm_divV", _dp),
+                ("cap", C.c_int64), ("time_s", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(str(_LIB_PATH))
+        L.orc_mini2.restype = C.c_double
+        L.orc_mini2.argtypes = [C.c_char_p, _dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+        L.orc_mini3.restype = C.c_double
+        L.orc_mini3.argtypes = [C.c_char_p, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.orc_div2.restype = C.c_double
+        L.orc_div2.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.orc_div3.restype = C.c_double
+        L.orc_div3.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                               C.c_int, C.c_int, C.c_int]
+        L.orc_mysum.restype = C.c_double
+        L.orc_mysum.argtypes = [C.c_int, _dp] + [C.c_int] * 9
+        L.orc_compute_dtau_r.restype = C.c_double
+        L.orc_compute_dtau_r.argtypes = [C.c_double] * 3
+        L.orc_num_threads.restype = C.c_int
+        L.orc_stokes3d_solve.restype = C.c_int32
+        L.orc_stokes2d_solve.restype = C.c_int32
+        L.orc_heatdiffusion_PT2d.restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return _dp()
+    assert a.dtype == np.float64 and a.flags.f_contiguous, "oracle arrays must be float64, Fortran order"
+    return a.ctypes.data_as(_dp)
+
+
+def fields3d(arr: dict) -> Fields3D:
+    f = Fields3D()
+    for n in F3_NAMES:
+        setattr(f, n, _p(arr.get(n)))
+    return f
+
+
+def fields2d(arr: dict) -> Fields2D:
+    f = Fields2D()
+    for n in F2_NAMES:
+        setattr(f, n, _p(arr.get(n)))
+    return f
+
+
+def thermal2d(arr: dict) -> Thermal2D:
+    f = Thermal2D()
+    for n in T2_NAMES:
+        setattr(f, n, _p(arr.get(n)))
+    return f
+
+
+def bcmask(d) -> int:
+    m = 0
+    for k, v in (d or {}).items():
+        if v:
+            m |= FACE[k]
+    return m
+
+
+def params3d(ni, _di, dt, pt, *, iterMax=10_000, nout=500, free_slip=None, no_slip=None, periodic=None,
+             ni_g=None) -> Params3D:
+    """pt = dict(r, theta_dtau, eta_dtau, eps_rel, eps_abs)"""
+    ni_g = ni_g or ni
+    return Params3D(ni[0], ni[1], ni[2], ni_g[0], ni_g[1], ni_g[2], _di[0], _di[1], _di[2],
+                    dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"], pt["eps_rel"], pt["eps_abs"],
+                    int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic))
+
+
+def params2d(ni, _di, dt, pt, *, iterMax=10_000, nout=500, free_slip=None, no_slip=None, periodic=None,
+             ni_g=None) -> Params2D:
+    ni_g = ni_g or ni
+    return Params2D(ni[0], ni[1], ni_g[0], ni_g[1], _di[0], _di[1],
+                    dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"], pt["eps_rel"], pt["eps_abs"],
+                    int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic))
+
+
+class _Res:
+    def __init__(self, cap):
+        self.cap = cap
+        self.e1 = np.zeros(cap)
+        self.e2 = np.zeros(cap, dtype=np.int64)
+        self.n = [np.zeros(cap) for _ in range(4)]
+        self.c = Result(0, 0, 0, _p(self.e1), self.e2.ctypes.data_as(C.POINTER(C.c_int64)),
+                        _p(self.n[0]), _p(self.n[1]), _p(self.n[2]), _p(self.n[3]), cap, 0.0)
+
+    def asdict(self, dim):
+        k = self.c.nchecks
+        d = dict(iter=self.c.iter, status=self.c.status, err_evo1=self.e1[:k].copy(), err_evo2=self.e2[:k].copy(),
+                 norm_Rx=self.n[0][:k].copy(), norm_Ry=self.n[1][:k].copy(), norm_divV=self.n[3][:k].copy(),
+                 time=self.c.time_s)
+        if dim == 3:
+            d["norm_Rz"] = self.n[2][:k].copy()
+        return d
+
+
+def stokes3d_solve(arr: dict, p: Params3D) -> dict:
+    res = _Res(int(p.iterMax // p.nout + 2))
+    f = fields3d(arr)
+    lib().orc_stokes3d_solve(C.byref(f), C.byref(p), C.byref(res.c))
+    return res.asdict(3)
+
+
+def stokes2d_solve(arr: dict, p: Params2D) -> dict:
+    res = _Res(int(p.iterMax // p.nout + 2))
+    f = fields2d(arr)
+    lib().orc_stokes2d_solve(C.byref(f), C.byref(p), C.byref(res.c))
+    return res.asdict(2)
+
+
+def stokes3d_iteration(arr: dict, etatau, p: Params3D):
+    f = fields3d(arr)
+    lib().orc_stokes3d_iteration(C.byref(f), _p(etatau), C.byref(p))
+
+
+def stokes2d_iteration(arr: dict, etatau, p: Params2D):
+    f = fields2d(arr)
+    lib().orc_stokes2d_iteration(C.byref(f), _p(etatau), C.byref(p))
+
+
+def call3d(fn: str, arr: dict, p: Params3D, *extra):
+    """Call one of the single-kernel entry points taking (fields*, [extra...], params*)."""
+    f = fields3d(arr)
+    getattr(lib(), fn)(C.byref(f), *extra, C.byref(p))
+
+
+def call2d(fn: str, arr: dict, p: Params2D, *extra):
+    f = fields2d(arr)
+    getattr(lib(), fn)(C.byref(f), *extra, C.byref(p))
+
+
+def compute_maxloc(A):
+    B = np.zeros_like(A, order="F")
+    if A.ndim == 3:
+        lib().orc_compute_maxloc3d(_p(B), _p(A), *[C.c_int64(n) for n in A.shape])
+    else:
+        lib().orc_compute_maxloc2d(_p(B), _p(A), *[C.c_int64(n) for n in A.shape])
+    return B
+
+
+def flow_bcs3d(Vx, Vy, Vz, ni, free_slip=None, no_slip=None, periodic=None):
+    lib().orc_flow_bcs3d(_p(Vx), _p(Vy), _p(Vz), *[C.c_int64(n) for n in ni],
+                         C.c_uint32(bcmask(free_slip)), C.c_uint32(bcmask(no_slip)), C.c_uint32(bcmask(periodic)))
+
+
+def flow_bcs2d(Vx, Vy, ni, free_slip=None, no_slip=None, periodic=None):
+    lib().orc_flow_bcs2d(_p(Vx), _p(Vy), *[C.c_int64(n) for n in ni],
+                         C.c_uint32(bcmask(free_slip)), C.c_uint32(bcmask(no_slip)), C.c_uint32(bcmask(periodic)))
+
+
+def residual_sumsq3d(arr, p):
+    out = (C.c_double * 4)()
+    f = fields3d(arr)
+    lib().orc_residual_sumsq3d(C.byref(f), C.byref(p), out)
+    return np.array(out[:])
+
+
+def residual_sumsq2d(arr, p):
+    out = (C.c_double * 3)()
+    f = fields2d(arr)
+    lib().orc_residual_sumsq2d(C.byref(f), C.byref(p), out)
+    return np.array(out[:])
+
+
+def thermal_params2d(ni, _di, dt, eps, *, iterMax=50_000, nout=1000, no_flux=None, constant_value=None,
+                     constant_flux=None, periodic=None, rheology=None) -> ThermalParams2D:
+    """BC dicts use the reference's 2D face names left/right/top/bot; a value of False/None disables."""
+    order = ("left", "right", "top", "bot")
+    p = ThermalParams2D()
+    p.nx, p.ny, p._dx, p._dy, p.dt, p.eps, p.iterMax, p.nout = ni[0], ni[1], _di[0], _di[1], dt, eps, int(iterMax), int(nout)
+    for i, k in enumerate(order):
+        p.no_flux[i] = int(bool((no_flux or {}).get(k, False)))
+        p.periodic[i] = int(bool((periodic or {}).get(k, False)))
+        v = (constant_value or {}).get(k, False)
+        p.constant_value_on[i] = int(v is not False and v is not None)
+        p.constant_value[i] = float(v) if p.constant_value_on[i] else 0.0
+        v = (constant_flux or {}).get(k, False)
+        on = not isinstance(v, bool) and v is not None      # `!isa(bc_flux.left, Bool)` in the reference
+        p.constant_flux_on[i] = int(on)
+        p.constant_flux[i] = float(v) if on else 0.0
+    if rheology:
+        p.rheology_form = 1
+        p.k_const, p.Cp, p.rho0, p.alpha, p.T0 = (rheology["k"], rheology["Cp"], rheology["rho0"],
+                                                   rheology["alpha"], rheology.get("T0", 0.0))
+    return p
+
+
+def thermal_bcs2d(T, p: ThermalParams2D):
+    lib().orc_thermal_bcs2d(_p(T), C.byref(p))
+
+
+def heatdiffusion_PT2d(arr: dict, p: ThermalParams2D) -> dict:
+    cap = int(p.iterMax // p.nout + 2)
+    it = np.zeros(cap, dtype=np.int64)
+    nr = np.zeros(cap)
+    nn = C.c_int64(0)
+    t = thermal2d(arr)
+    lib().orc_heatdiffusion_PT2d(C.byref(t), C.byref(p), it.ctypes.data_as(C.POINTER(C.c_int64)), _p(nr),
+                                 C.c_int64(cap), C.byref(nn))
+    return dict(iter_count=it[:nn.value].copy(), norm_ResT=nr[:nn.value].copy())
+
+
+def thermal2d_iteration(arr: dict, p: ThermalParams2D):
+    t = thermal2d(arr)
+    lib().orc_thermal2d_iteration(C.byref(t), C.byref(p))
+
+
+def thermal2d_check_res(arr: dict, p: ThermalParams2D):
+    t = thermal2d(arr)
+    lib().orc_thermal2d_check_res(C.byref(t), C.byref(p))
+
+
+def num_threads() -> int:
+    return lib().orc_num_threads()

@@ -1,0 +1,25 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def jr():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as orc
+    orc.lib()
+    return orc
