@@ -23,6 +23,8 @@ from . import miniapps  # noqa: F401
 def __getattr__(name):
     # the operator API is imported lazily: it loads the HIP shared library and fails loudly if absent
     import importlib
+    if name.startswith("_") or name in ("stokes", "thermal", "halo", "checks", "build", "arrays", "grid", "backend"):
+        raise AttributeError(name)
     for sub in ("stokes", "thermal", "halo"):
         mod = importlib.import_module(f"{__name__}.{sub}")
         if hasattr(mod, name):

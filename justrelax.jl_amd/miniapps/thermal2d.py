@@ -47,7 +47,7 @@ def diffusion2d(n=32, *, lx=100.0e3, ly=100.0e3, ρ0=3.3e3, Cp0=1.2e3, K0=3.0, i
     arr["thetar_dtau"][...] = th
     arr["dtau_rho"][...] = dr
     rheology = dict(k=K0, Cp=Cp0, rho0=3.1e3, alpha=1.5e-5, T0=0.0)   # PT_Density(ρ0=3.1e3, β=0, T0=0, α=1.5e-5)
-    return Setup(ni=ni, arrays=arr, grid=grid, pt=dict(ϵ=1.0e-8, CFL=0.95 / math.sqrt(2.1)), dt=dt, flow_bcs=bc,
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=dict(eps=1.0e-8, CFL=0.95 / math.sqrt(2.1)), dt=dt, flow_bcs=bc,
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False),
                  extra=dict(li=li, di=di, rheology=rheology, nt=int(math.ceil(1.0e3 * kyr / dt)),
                             perturbation=dict(δT=100.0, r=10.0e3, xc=lx / 2, yc=-ly / 2)))

@@ -1,0 +1,221 @@
+"""Pins the CPU oracle against the reference's own known-answer tests (no GPU needed).
+
+Each assertion cites the reference test it restates (paths relative to the reference checkout).
+The oracle cannot be diffed against the Julia code itself (no julia in the build container); these
+golden values are what anchors it.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+
+def harmonic(*x):
+    return len(x) / sum(1.0 / v for v in x)
+
+
+@pytest.fixture(scope="module")
+def mk(oracle):
+    A2 = np.asfortranarray(np.arange(1.0, 17.0).reshape(4, 4, order="F"))
+    A3 = np.asfortranarray(np.arange(1.0, 65.0).reshape(4, 4, 4, order="F"))
+    L = oracle.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    m2 = lambda name, A, d, i, j: L.orc_mini2(name.encode(), dp(A), 4, 4, d, i, j)
+    m3 = lambda name, A, d, i, j, k: L.orc_mini3(name.encode(), dp(A), 4, 4, 4, d, i, j, k)
+    return A2, A3, m2, m3, L, dp
+
+
+def test_mini_kernels_accessors(mk):
+    """test/test_mini_kernels.jl:11-23"""
+    A2, A3, m2, m3, *_ = mk
+    assert [m2(n, A2, 0.0, 2, 2) for n in ("center", "next", "left", "right", "back", "front")] == [6.0, 11.0, 5.0, 7.0, 2.0, 10.0]
+    assert [m3(n, A3, 0.0, 2, 2, 2) for n in ("left", "right", "back", "front", "bot", "top")] == [21.0, 23.0, 18.0, 26.0, 6.0, 38.0]
+
+
+def test_mini_kernels_differences(mk):
+    """test/test_mini_kernels.jl:25-47"""
+    A2, A3, m2, m3, L, dp = mk
+    dx, dy, dz = 2.0, 3.0, 4.0
+    assert m2("_d_xa", A2, dx, 2, 2) == 2.0 and m2("_d_ya", A2, dy, 2, 2) == 12.0
+    assert m3("_d_za", A3, dz, 2, 2, 2) == 64.0
+    assert m2("_d_xi", A2, dx, 2, 2) == 2.0 and m2("_d_yi", A2, dy, 2, 2) == 12.0
+    assert m3("_d_xi", A3, dx, 2, 2, 2) == 2.0 and m3("_d_yi", A3, dy, 2, 2, 2) == 12.0 and m3("_d_zi", A3, dz, 2, 2, 2) == 64.0
+    Ay = np.asfortranarray(A2 * 2.0)
+    assert L.orc_div2(dp(A2), dp(Ay), 4, 4, dx, dy, 2, 2) == 26.0
+    Ay3, Az3 = np.asfortranarray(A3 * 2.0), np.asfortranarray(A3 * 3.0)
+    assert L.orc_div3(dp(A3), dp(Ay3), dp(Az3), 4, 4, 4, dx, dy, dz, 2, 2, 2) == 218.0
+
+
+def test_mini_kernels_averages(mk):
+    """test/test_mini_kernels.jl:49-75"""
+    A2, A3, m2, m3, *_ = mk
+    want2 = dict(_av=13.5, _av_a=8.5, _av_xa=6.5, _av_ya=8.0, _av_xi=10.5, _av_yi=9.0)
+    for k, v in want2.items():
+        assert m2(k, A2, 0.0, 2, 2) == v, k
+    assert m2("_harm", A2, 0.0, 2, 2) == pytest.approx(harmonic(11.0, 12.0, 15.0, 16.0), rel=1e-15)
+    assert m2("_harm_a", A2, 0.0, 2, 2) == pytest.approx(harmonic(6.0, 7.0, 10.0, 11.0), rel=1e-15)
+    assert m2("_harm_xa", A2, 0.0, 2, 2) == pytest.approx(harmonic(6.0, 7.0), rel=1e-15)
+    assert m2("_harm_ya", A2, 0.0, 2, 2) == pytest.approx(harmonic(6.0, 10.0), rel=1e-15)
+    want3 = dict(_av=32.5, _av_x=22.5, _av_y=24.0, _av_z=30.0, _av_xy=24.5, _av_xz=30.5, _av_yz=32.0,
+                 _av_xyi=19.5, _av_xzi=13.5, _av_yzi=12.0, _current=22.0)
+    for k, v in want3.items():
+        assert m3(k, A3, 0.0, 2, 2, 2) == v, k
+    wanth = dict(_harm_x=(22.0, 23.0), _harm_y=(22.0, 26.0), _harm_z=(22.0, 38.0), _harm_xy=(22.0, 23.0, 26.0, 27.0),
+                 _harm_xz=(22.0, 23.0, 38.0, 39.0), _harm_yz=(22.0, 26.0, 38.0, 42.0), _harm_xyi=(17.0, 18.0, 21.0, 22.0),
+                 _harm_xzi=(5.0, 6.0, 21.0, 22.0), _harm_yzi=(2.0, 6.0, 18.0, 22.0))
+    for k, v in wanth.items():
+        assert m3(k, A3, 0.0, 2, 2, 2) == pytest.approx(harmonic(*v), rel=1e-15), k
+
+
+def test_mini_kernels_clamped(mk):
+    """test/test_mini_kernels.jl:84-102 -- the stencils compute_τ! uses for the shear viscosity"""
+    A2, A3, m2, m3, *_ = mk
+    assert m2("_av_ai_clamped", A2, 0.0, 2, 2) == m2("_av_a", A2, 0.0, 1, 1)
+    assert m2("_av_ai_clamped", A2, 0.0, 1, 1) == A2[0, 0]
+    for n in ("xy", "xz", "yz"):
+        assert m3(f"_av_{n}i_clamped", A3, 0.0, 2, 2, 2) == m3(f"_av_{n}i", A3, 0.0, 2, 2, 2)
+        assert m3(f"_harm_{n}i_clamped", A3, 0.0, 2, 2, 2) == pytest.approx(m3(f"_harm_{n}i", A3, 0.0, 2, 2, 2), rel=1e-15)
+    k = 2
+    assert m3("_av_xyi_clamped", A3, 0.0, 1, 2, k) == 0.5 * (A3[0, 0, k - 1] + A3[0, 1, k - 1])
+    assert m3("_harm_xyi_clamped", A3, 0.0, 1, 2, k) == pytest.approx(harmonic(A3[0, 0, k - 1], A3[0, 1, k - 1]), rel=1e-15)
+    assert m3("_av_xzi_clamped", A3, 0.0, 2, 2, 1) == 0.5 * (A3[0, 1, 0] + A3[1, 1, 0])
+    assert m3("_harm_yzi_clamped", A3, 0.0, 2, 1, 1) == pytest.approx(A3[1, 0, 0], rel=1e-15)
+
+
+def test_mysum(mk):
+    """test/test_mini_kernels.jl:110-116 (accumulation order k -> j -> i from 0.0)"""
+    A2, A3, m2, m3, L, dp = mk
+    v = np.arange(1.0, 6.0)
+    assert L.orc_mysum(0, dp(v), 5, 1, 1, 2, 4, 1, 1, 1, 1) == 9.0
+    assert L.orc_mysum(1, dp(v), 5, 1, 1, 2, 4, 1, 1, 1, 1) == 1.0833333333333333
+    assert L.orc_mysum(0, dp(A2), 4, 4, 1, 2, 3, 2, 3, 1, 1) == 34.0
+    assert L.orc_mysum(1, dp(A2), 4, 4, 1, 2, 3, 2, 3, 1, 1) == 0.5004329004329005
+    assert L.orc_mysum(0, dp(A3), 4, 4, 4, 2, 3, 2, 3, 2, 3) == 260.0
+    assert L.orc_mysum(1, dp(A3), 4, 4, 4, 2, 3, 2, 3, 2, 3) == 0.2634535347004082
+
+
+def test_utils_known_answers(oracle):
+    """test/test_Utils.jl:170-174,236-239 (norm_mpi), :387-396 (compute_maxloc!), :470 (compute_dτ_r)"""
+    L = oracle.lib()
+    assert L.orc_compute_dtau_r(1.0, 1.0, 1.0) == pytest.approx(1 / 3, rel=1e-15)
+    A2 = np.zeros((5, 5), order="F")
+    A2[2, 2] = 7.0
+    B2 = oracle.compute_maxloc(A2)
+    assert B2.max() == 7.0 and (B2[1:4, 1:4] == 7.0).all() and B2[0, 0] == 0.0 and B2[4, 4] == 0.0
+    # norm_mpi(ones(4,4)) === 4.0 ; norm_mpi(ones(4,4,4)) === 8.0 : sqrt(Σ x²) of the RP-style full reduction
+    arr = oracle.alloc(oracle.shapes3d(4, 4, 4))
+    arr["RP"][...] = 1.0
+    p = oracle.params3d((4, 4, 4), (1, 1, 1), 1.0, dict(r=0.7, theta_dtau=1, eta_dtau=1, eps_rel=1e-6, eps_abs=1e-12))
+    assert math.sqrt(oracle.residual_sumsq3d(arr, p)[3]) == 8.0
+    arr2 = oracle.alloc(oracle.shapes2d(4, 4))
+    arr2["RP"][...] = 1.0
+    p2 = oracle.params2d((4, 4), (1, 1), 1.0, dict(r=0.7, theta_dtau=1, eta_dtau=1, eps_rel=1e-6, eps_abs=1e-12))
+    assert math.sqrt(oracle.residual_sumsq2d(arr2, p2)[2]) == 4.0
+
+
+def test_array_extents(oracle, jr):
+    """test/test_types.jl:28-199 -- staggered extents of StokesArrays / ThermalArrays"""
+    nx, ny, nz = 5, 6, 7
+    s3 = oracle.shapes3d(nx, ny, nz)
+    assert s3["Vx"] == (nx + 1, ny + 2, nz + 2) and s3["Vy"] == (nx + 2, ny + 1, nz + 2) and s3["Vz"] == (nx + 2, ny + 2, nz + 1)
+    assert s3["txy"] == (nx + 1, ny + 1, nz) and s3["tyz"] == (nx, ny + 1, nz + 1) and s3["txz"] == (nx + 1, ny, nz + 1)
+    assert s3["Rx"] == (nx - 1, ny, nz) and s3["Ry"] == (nx, ny - 1, nz) and s3["Rz"] == (nx, ny, nz - 1) and s3["RP"] == (nx, ny, nz)
+    st = jr.StokesArrays(jr.CPUBackend, (nx, ny, nz))
+    assert tuple(st.V.Vx.shape) == s3["Vx"] and tuple(st.τ.xy.shape) == s3["txy"] and tuple(st.R.Rz.shape) == s3["Rz"]
+    assert tuple(st.τ.xx_v.shape) == (nx + 1, ny + 1, nz + 1) and tuple(st.viscosity.η.shape) == (nx, ny, nz)
+    assert float(st.viscosity.η.min()) == 1.0
+    s2 = oracle.shapes2d(nx, ny)
+    assert s2["Vx"] == (nx + 1, ny + 2) and s2["Vy"] == (nx + 2, ny + 1) and s2["txy"] == (nx + 1, ny + 1) and s2["Rx"] == (nx - 1, ny)
+    th = jr.ThermalArrays(jr.CPUBackend, (nx, ny))
+    assert tuple(th.T.shape) == (nx + 2, ny + 2) and tuple(th.qTx.shape) == (nx + 1, ny) and tuple(th.qTy.shape) == (nx, ny + 1)
+    with pytest.raises(ValueError):
+        jr.StokesArrays(jr.CPUBackend, (1.5, 2.0))
+
+
+def test_pt_coefficients(jr):
+    """PTStokesCoeffs (src/types/stokes.jl:203-229): derived constants of SURVEY App. E"""
+    pt = jr.PTStokesCoeffs((10.0, 10.0, 10.0), (10 / 16,) * 3, CFL=1 / math.sqrt(3))
+    assert (pt.Vpdτ, pt.θ_dτ, pt.ηdτ) == pytest.approx((0.36084391824351614, 5.978855577018544, 0.38286728848735563), rel=1e-15)
+    pt2 = jr.PTStokesCoeffs((1.0, 1.0), (1 / 32,) * 2, CFL=1 / math.sqrt(2.1))
+    assert (pt2.Vpdτ, pt2.θ_dτ, pt2.ηdτ) == pytest.approx((0.021564548729448567, 10.004538931423484, 0.0022880696838918605), rel=1e-15)
+    assert jr.PTStokesCoeffs((1.0, 1.0), (0.1, 0.1)).CFL == 0.9 / math.sqrt(2.1)
+    assert jr.PTStokesCoeffs((1.0, 1.0, 1.0), (0.1, 0.1, 0.1)).CFL == 0.9 / math.sqrt(3.1)
+
+
+def _solve3d(orc, s):
+    from justrelax_jl_amd import checks
+    return orc.stokes3d_solve(s.arrays, checks.oracle_params3d(orc, s))
+
+
+def _solve2d(orc, s, **over):
+    from justrelax_jl_amd import checks
+    return orc.stokes2d_solve(s.arrays, checks.oracle_params2d(orc, s, **over))
+
+
+def test_solvi3d(oracle, jr):
+    """test/test_stokes_solvi3D.jl:25-55 : 16^3, iterMax=5000, nout=100 => norm_Rx[end] < 1e-8"""
+    r = _solve3d(oracle, jr.miniapps.solvi3d(16))
+    assert r["norm_Rx"][-1] < 1.0e-8
+    assert r["iter"] == 5001            # non-solenoidal BCs: norm_∇V never converges
+
+
+def test_taylor_green(oracle, jr):
+    """test/test_stokes_taylor_green.jl:29-41 : err < 1e-8 ; order > 1.7 ; L2_v < 5e-3 ; L2_p < 1.5e-1"""
+    from justrelax_jl_amd.miniapps.stokes3d import taylor_green_error_norms
+    errs = []
+    for n in (8, 16):
+        s = jr.miniapps.taylor_green3d(n)
+        r = _solve3d(oracle, s)
+        assert r["err_evo1"][-1] < 1.0e-8
+        errs.append(taylor_green_error_norms(s.arrays, s.grid))
+    order = np.log2(np.array(errs[0]) / np.array(errs[1]))
+    assert (order > 1.7).all(), order
+    L2_p, L2_vx, L2_vy, L2_vz = errs[1]
+    assert max(L2_vx, L2_vy, L2_vz) < 5.0e-3 and L2_p < 1.5e-1
+
+
+def test_solcx(oracle, jr):
+    """test/test_stokes_solcx.jl:26-37 : 32^2, Δη = 1e6 => err_evo1[end] < 1e-8"""
+    r = _solve2d(oracle, jr.miniapps.solcx2d(32))
+    assert r["err_evo1"][-1] < 1.0e-8
+
+
+def test_solkz(oracle, jr):
+    """test/test_stokes_solkz.jl:27-37 : 32^2 => err_evo1[end] < 1e-8"""
+    r = _solve2d(oracle, jr.miniapps.solkz2d(32))
+    assert r["err_evo1"][-1] < 1.0e-8
+
+
+def test_elastic_buildup(oracle, jr):
+    """test/test_stokes_elastic_buildup.jl:26-55 : mean relative error of max|τyy| vs 2εη(1-exp(-Gt/η)) <= 5e-3"""
+    s = jr.miniapps.elastic_buildup2d(32)
+    kyr, η0, εbg, G = (s.extra[k] for k in ("kyr", "η0", "εbg", "G"))
+    t, errs = 0.0, []
+    while t < 10 * kyr:
+        dt = 0.05 * kyr if t < 10 * kyr else 1.0 * kyr
+        s.dt = dt
+        _solve2d(oracle, s)
+        t += dt
+        sol = 2 * εbg * η0 * (1 - math.exp(-G * t / η0))
+        errs.append(abs(np.abs(s.arrays["tyy"]).max() - sol) / sol)
+    assert len(errs) == 200
+    assert sum(errs) / len(errs) <= 5.0e-3
+
+
+def test_diffusion2d(oracle, jr):
+    """test/test_diffusion2D.jl:127-135 : T[18,18] ≈ 1817.9448461176817, T[17,17] ≈ 1827.4674313638786 (atol 0.1)"""
+    from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+    s = jr.miniapps.diffusion2d(32)
+    b = s.flow_bcs
+    p = oracle.thermal_params2d(s.ni, s.grid._di["center"], s.dt, s.pt["eps"], iterMax=s.kwargs["iterMax"], nout=s.kwargs["nout"],
+                                no_flux=b.no_flux, constant_value=b.constant_value, constant_flux=b.constant_flux,
+                                periodic=b.periodic, rheology=s.extra["rheology"])
+    oracle.thermal_bcs2d(s.arrays["T"], p)
+    add_perturbation(s.arrays["T"], s.grid, **s.extra["perturbation"])
+    for _ in range(s.extra["nt"]):
+        r = oracle.heatdiffusion_PT2d(s.arrays, p)
+        assert r["norm_ResT"][-1] <= 1e-8
+    T = s.arrays["T"]
+    assert T[17, 17] == pytest.approx(1817.9448461176817, abs=1.0e-1)     # Julia T[18,18]
+    assert T[16, 16] == pytest.approx(1827.4674313638786, abs=1.0e-1)     # Julia T[17,17]
