@@ -12,209 +12,9 @@
 // checks and the last iteration).  Pure HBM-bandwidth-bound fp64 stencils: no MFMA.
 #include "jrx_internal.hpp"
 #include "jrx_kernels.hpp"
+#include "stokes3d_kernels.hpp"
 
 namespace {
-
-struct Dims3 {
-    int nx, ny, nz;
-};
-
-// element strides of the staggered arrays
-struct Lay3 {
-    int nx, ny, nz;
-    // row lengths (n1) and plane sizes (n1*n2)
-    int vx1, vy1, vz1;          // nx+1, nx+2, nx+2
-    i64 vxp, vyp, vzp;          // plane sizes
-    i64 cp;                     // nx*ny
-    int xy1; i64 xyp;           // (nx+1), (nx+1)*(ny+1)
-    int xz1; i64 xzp;           // (nx+1), (nx+1)*ny
-    int yz1; i64 yzp;           // nx, nx*(ny+1)
-};
-
-__host__ __device__ inline Lay3 make_lay(int nx, int ny, int nz)
-{
-    Lay3 L;
-    L.nx = nx; L.ny = ny; L.nz = nz;
-    L.vx1 = nx + 1; L.vxp = (i64)(nx + 1) * (ny + 2);
-    L.vy1 = nx + 2; L.vyp = (i64)(nx + 2) * (ny + 1);
-    L.vz1 = nx + 2; L.vzp = (i64)(nx + 2) * (ny + 2);
-    L.cp = (i64)nx * ny;
-    L.xy1 = nx + 1; L.xyp = (i64)(nx + 1) * (ny + 1);
-    L.xz1 = nx + 1; L.xzp = (i64)(nx + 1) * ny;
-    L.yz1 = nx;     L.yzp = (i64)nx * (ny + 1);
-    return L;
-}
-
-struct SweepArgs {
-    jrx_stokes3d_fields f;
-    const double *etatau;
-    double _dx, _dy, _dz, dt, r, theta_dtau, eta_dtau;
-    Lay3 L;
-    // sub-box of the launch (0-based, half-open) -- lets the driver split boundary slabs / interior
-    int i0, i1, j0, j1, k0, k1;
-};
-
-// ------------------------------------------------------------------------------------------------
-// Stress sweep, version 1: one thread per node of the ni.+1 box, xy-plane flattened over threadIdx
-// so that rows of any length (nx, nx+1, nx+2) stay fully coalesced; blockIdx.y walks z.
-// ------------------------------------------------------------------------------------------------
-template <bool DIAG>
-__global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
-{
-    const Lay3 &L = a.L;
-    const int nx = L.nx, ny = L.ny, nz = L.nz;
-    const int wi = a.i1 - a.i0;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int jj = t / wi;
-    const int i = a.i0 + (t - jj * wi);
-    const int j = a.j0 + jj;
-    const int k = a.k0 + blockIdx.y;
-    if (j >= a.j1) return;
-
-    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
-    const double *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
-    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau;
-
-#define VX(i_, j_, k_) Vx[(i_) + (i64)L.vx1 * (j_) + L.vxp * (k_)]
-#define VY(i_, j_, k_) Vy[(i_) + (i64)L.vy1 * (j_) + L.vyp * (k_)]
-#define VZ(i_, j_, k_) Vz[(i_) + (i64)L.vz1 * (j_) + L.vzp * (k_)]
-#define CC(i_, j_, k_) ((i_) + (i64)nx * (j_) + L.cp * (k_))
-
-    const bool ci = i < nx, cj = j < ny, ck = k < nz;
-
-    if (ci && cj && ck) {
-        const i64 c = CC(i, j, k);
-        // compute_∇V! (VelocityKernels.jl:3-6)
-        const double dxi = (-VX(i, j + 1, k + 1) + VX(i + 1, j + 1, k + 1)) * _dx;
-        const double dyi = (-VY(i + 1, j, k + 1) + VY(i + 1, j + 1, k + 1)) * _dy;
-        const double dzi = (-VZ(i + 1, j + 1, k) + VZ(i + 1, j + 1, k + 1)) * _dz;
-        const double divV = dxi + dyi + dzi;
-        // compute_P! (PressureKernels.jl:186-195), η (not ητ) in the 3D driver (Stokes3D.jl:85)
-        const double e = eta[c];
-        const double _Gdt = 1.0 / (G[c] * dt);
-        {
-            const double _Kdt = 1.0 / (a.f.K[c] * dt);
-            const double _dt = 1.0 / dt;
-            const double P = a.f.P[c], P0 = a.f.P0[c];
-            const double rhs = -divV + (a.f.Q[c] * _dt);
-            const double psi = 1.0 / (1.0 / e + _Gdt) * a.r / th;
-            a.f.P[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
-            if (DIAG) {
-                a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
-                a.f.divV[c] = divV;
-            }
-        }
-        // compute_strain_rate! normal components (VelocityKernels.jl:69-78)
-        const double d3 = divV * (1.0 / 3.0);
-        const double exx = dxi - d3, eyy = dyi - d3, ezz = dzi - d3;
-        if (DIAG) { a.f.exx[c] = exx; a.f.eyy[c] = eyy; a.f.ezz[c] = ezz; }
-        // compute_τ! normal components (StressKernels.jl:185-198)
-        const double dtr = dev_dtau_r(th, e, _Gdt);
-        double tv;
-        tv = a.f.txx[c]; a.f.txx[c] = tv + dev_stress_inc(tv, a.f.toxx[c], e, exx, _Gdt, dtr);
-        tv = a.f.tyy[c]; a.f.tyy[c] = tv + dev_stress_inc(tv, a.f.toyy[c], e, eyy, _Gdt, dtr);
-        tv = a.f.tzz[c]; a.f.tzz[c] = tv + dev_stress_inc(tv, a.f.tozz[c], e, ezz, _Gdt, dtr);
-    }
-
-    // clamped neighbour cell indices (MiniKernels.jl:133-147)
-    const int im = max(i - 1, 0), ip = min(i, nx - 1);
-    const int jm = max(j - 1, 0), jp = min(j, ny - 1);
-    const int km = max(k - 1, 0), kp = min(k, nz - 1);
-
-    if (ck) {   // τxy at (i,j,k) of (nx+1, ny+1, nz)   (VelocityKernels.jl:95-101, StressKernels.jl:199-208)
-        const double exy = 0.5 * (_dy * (VX(i, j + 1, k + 1) - VX(i, j, k + 1)) + _dx * (VY(i + 1, j, k + 1) - VY(i, j, k + 1)));
-        const double e = 0.25 * (eta[CC(im, jm, k)] + eta[CC(ip, jm, k)] + eta[CC(im, jp, k)] + eta[CC(ip, jp, k)]);
-        const double g = 0.25 * (G[CC(im, jm, k)] + G[CC(ip, jm, k)] + G[CC(im, jp, k)] + G[CC(ip, jp, k)]);
-        const double _Gdt = 1.0 / (g * dt);
-        const double dtr = dev_dtau_r(th, e, _Gdt);
-        const i64 c = i + (i64)L.xy1 * j + L.xyp * k;
-        const double tv = a.f.txy[c];
-        a.f.txy[c] = tv + dev_stress_inc(tv, a.f.toxy[c], e, exy, _Gdt, dtr);
-        if (DIAG) a.f.exy[c] = exy;
-    }
-    if (cj) {   // τxz at (i,j,k) of (nx+1, ny, nz+1)
-        const double exz = 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k)));
-        const double e = 0.25 * (eta[CC(im, j, km)] + eta[CC(ip, j, km)] + eta[CC(im, j, kp)] + eta[CC(ip, j, kp)]);
-        const double g = 0.25 * (G[CC(im, j, km)] + G[CC(ip, j, km)] + G[CC(im, j, kp)] + G[CC(ip, j, kp)]);
-        const double _Gdt = 1.0 / (g * dt);
-        const double dtr = dev_dtau_r(th, e, _Gdt);
-        const i64 c = i + (i64)L.xz1 * j + L.xzp * k;
-        const double tv = a.f.txz[c];
-        a.f.txz[c] = tv + dev_stress_inc(tv, a.f.toxz[c], e, exz, _Gdt, dtr);
-        if (DIAG) a.f.exz[c] = exz;
-    }
-    if (ci) {   // τyz at (i,j,k) of (nx, ny+1, nz+1)
-        const double eyz = 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k)));
-        const double e = 0.25 * (eta[CC(i, jm, km)] + eta[CC(i, jp, km)] + eta[CC(i, jm, kp)] + eta[CC(i, jp, kp)]);
-        const double g = 0.25 * (G[CC(i, jm, km)] + G[CC(i, jp, km)] + G[CC(i, jm, kp)] + G[CC(i, jp, kp)]);
-        const double _Gdt = 1.0 / (g * dt);
-        const double dtr = dev_dtau_r(th, e, _Gdt);
-        const i64 c = i + (i64)L.yz1 * j + L.yzp * k;
-        const double tv = a.f.tyz[c];
-        a.f.tyz[c] = tv + dev_stress_inc(tv, a.f.toyz[c], e, eyz, _Gdt, dtr);
-        if (DIAG) a.f.eyz[c] = eyz;
-    }
-#undef VX
-#undef VY
-#undef VZ
-}
-
-// ------------------------------------------------------------------------------------------------
-// Velocity sweep, version 1: one thread per cell; compute_V! (VelocityKernels.jl:182-242).
-// ------------------------------------------------------------------------------------------------
-template <bool DIAG>
-__global__ __launch_bounds__(256) void k_velocity3d(const SweepArgs a)
-{
-    const Lay3 &L = a.L;
-    const int nx = L.nx, ny = L.ny, nz = L.nz;
-    const int wi = a.i1 - a.i0;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int jj = t / wi;
-    const int i = a.i0 + (t - jj * wi);
-    const int j = a.j0 + jj;
-    const int k = a.k0 + blockIdx.y;
-    if (j >= a.j1) return;
-
-    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, edt = a.eta_dtau;
-    const double *__restrict__ P = a.f.P, *__restrict__ et = a.etatau;
-    const double *__restrict__ txy = a.f.txy, *__restrict__ txz = a.f.txz, *__restrict__ tyz = a.f.tyz;
-#define TXY(i_, j_, k_) txy[(i_) + (i64)L.xy1 * (j_) + L.xyp * (k_)]
-#define TXZ(i_, j_, k_) txz[(i_) + (i64)L.xz1 * (j_) + L.xzp * (k_)]
-#define TYZ(i_, j_, k_) tyz[(i_) + (i64)L.yz1 * (j_) + L.yzp * (k_)]
-    const i64 c = CC(i, j, k);
-    const double Pc = P[c], ec = et[c];
-
-    if (i < nx - 1) {
-        const i64 cx = c + 1;
-        const double R = (-a.f.txx[c] + a.f.txx[cx]) * _dx + _dy * (TXY(i + 1, j + 1, k) - TXY(i + 1, j, k)) +
-                         _dz * (TXZ(i + 1, j, k + 1) - TXZ(i + 1, j, k)) - (-Pc + P[cx]) * _dx -
-                         0.5 * (a.f.fx[c] + a.f.fx[cx]);
-        const i64 v = (i + 1) + (i64)L.vx1 * (j + 1) + L.vxp * (k + 1);
-        a.f.Vx[v] += R * edt / (0.5 * (ec + et[cx]));
-        if (DIAG) a.f.Rx[i + (i64)(nx - 1) * j + (i64)(nx - 1) * ny * k] = R;
-    }
-    if (j < ny - 1) {
-        const i64 cy = c + nx;
-        const double R = _dx * (TXY(i + 1, j + 1, k) - TXY(i, j + 1, k)) + _dy * (a.f.tyy[cy] - a.f.tyy[c]) +
-                         _dz * (TYZ(i, j + 1, k + 1) - TYZ(i, j + 1, k)) - (-Pc + P[cy]) * _dy -
-                         0.5 * (a.f.fy[c] + a.f.fy[cy]);
-        const i64 v = (i + 1) + (i64)L.vy1 * (j + 1) + L.vyp * (k + 1);
-        a.f.Vy[v] += R * edt / (0.5 * (ec + et[cy]));
-        if (DIAG) a.f.Ry[i + (i64)nx * j + (i64)nx * (ny - 1) * k] = R;
-    }
-    if (k < nz - 1) {
-        const i64 cz = c + L.cp;
-        const double R = _dx * (TXZ(i + 1, j, k + 1) - TXZ(i, j, k + 1)) + _dy * (TYZ(i, j + 1, k + 1) - TYZ(i, j, k + 1)) +
-                         (-a.f.tzz[c] + a.f.tzz[cz]) * _dz - (-Pc + P[cz]) * _dz - 0.5 * (a.f.fz[c] + a.f.fz[cz]);
-        const i64 v = (i + 1) + (i64)L.vz1 * (j + 1) + L.vzp * (k + 1);
-        a.f.Vz[v] += R * edt / (0.5 * (ec + et[cz]));
-        if (DIAG) a.f.Rz[c] = R;
-    }
-#undef TXY
-#undef TXZ
-#undef TYZ
-#undef CC
-}
 
 SweepArgs make_args(const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p)
 {

@@ -1,0 +1,227 @@
+// kbench.hip -- kernel micro-benchmark / A-B harness for the 3D Stokes sweeps (development tool).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I justrelax.jl_amd/csrc scripts/kbench.hip -o scripts/kbench
+//   ./scripts/kbench [n=512] [reps=10]
+// Every variant is checked bit-for-bit against the parity-tested v1 kernels on the same inputs,
+// then timed with hipEvents; plus pure streaming kernels (R read + W write streams) that give the
+// practical HBM ceiling for this many concurrent streams.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+#include "jrx_internal.hpp"
+#include "stokes3d_kernels.hpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void k_fill(double *p, i64 n, unsigned seed, double lo, double hi, int expo)
+{
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        unsigned long long x = (unsigned long long)t * 6364136223846793005ULL + seed * 1442695040888963407ULL + 1013904223ULL;
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+        double v = lo + (hi - lo) * u;
+        p[t] = expo ? pow(10.0, v) : v;
+    }
+}
+
+__global__ void k_maxdiff(const double *a, const double *b, i64 n, unsigned long long *out)
+{
+    unsigned long long m = 0;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        unsigned long long x = __double_as_longlong(a[t]), y = __double_as_longlong(b[t]);
+        if (x != y) m += 1;
+    }
+    if (m) atomicAdd(out, m);
+}
+
+template <int NR, int NW, int VEC>
+struct StreamArgs { const double *r[NR > 0 ? NR : 1]; double *w[NW > 0 ? NW : 1]; i64 n; };
+
+template <int NR, int NW, int VEC>
+__global__ __launch_bounds__(256) void k_stream(StreamArgs<NR, NW, VEC> a)
+{
+    const i64 t = ((i64)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (t + VEC > a.n) return;
+    double acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) acc[v] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        if (VEC == 2) {
+            double2 x = *reinterpret_cast<const double2 *>(a.r[q] + t);
+            acc[0] += x.x; acc[1] += x.y;
+        } else {
+            acc[0] += a.r[q][t];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NW; q++) {
+        if (VEC == 2) *reinterpret_cast<double2 *>(a.w[q] + t) = make_double2(acc[0] + q, acc[1] + q);
+        else a.w[q][t] = acc[0] + q;
+    }
+}
+
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
+    template <class F> double run(int reps, F f)
+    {
+        f();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a, 0));
+        for (int r = 0; r < reps; r++) f();
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        return ms / reps;
+    }
+};
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 512;
+    const int reps = argc > 2 ? atoi(argv[2]) : 10;
+    const int nx = n, ny = n, nz = n;
+    const double cells = (double)nx * ny * nz;
+    printf("kbench n=%d reps=%d\n", n, reps);
+
+    jrx_stokes3d_fields f;
+    memset(&f, 0, sizeof(f));
+    struct Ent { double **p; i64 n; double lo, hi; int expo; };
+    const i64 nc = (i64)nx * ny * nz, nvx = (i64)(nx + 1) * (ny + 2) * (nz + 2), nvy = (i64)(nx + 2) * (ny + 1) * (nz + 2),
+              nvz = (i64)(nx + 2) * (ny + 2) * (nz + 1), nxy = (i64)(nx + 1) * (ny + 1) * nz, nyz = (i64)nx * (ny + 1) * (nz + 1),
+              nxz = (i64)(nx + 1) * ny * (nz + 1);
+    std::vector<Ent> ents = {
+        {&f.P, nc, -1, 1, 0}, {&f.P0, nc, -1, 1, 0}, {&f.divV, nc, 0, 0, 0}, {&f.Q, nc, -0.1, 0.1, 0},
+        {&f.Vx, nvx, -1, 1, 0}, {&f.Vy, nvy, -1, 1, 0}, {&f.Vz, nvz, -1, 1, 0},
+        {&f.txx, nc, -1, 1, 0}, {&f.tyy, nc, -1, 1, 0}, {&f.tzz, nc, -1, 1, 0}, {&f.tyz, nyz, -1, 1, 0}, {&f.txz, nxz, -1, 1, 0}, {&f.txy, nxy, -1, 1, 0},
+        {&f.toxx, nc, -1, 1, 0}, {&f.toyy, nc, -1, 1, 0}, {&f.tozz, nc, -1, 1, 0}, {&f.toyz, nyz, -1, 1, 0}, {&f.toxz, nxz, -1, 1, 0}, {&f.toxy, nxy, -1, 1, 0},
+        {&f.exx, nc, 0, 0, 0}, {&f.eyy, nc, 0, 0, 0}, {&f.ezz, nc, 0, 0, 0}, {&f.eyz, nyz, 0, 0, 0}, {&f.exz, nxz, 0, 0, 0}, {&f.exy, nxy, 0, 0, 0},
+        {&f.eta, nc, -3, 0, 1}, {&f.K, nc, 1, 3, 0}, {&f.G, nc, 1, 2, 0},
+        {&f.fx, nc, -1, 1, 0}, {&f.fy, nc, -1, 1, 0}, {&f.fz, nc, -1, 1, 0},
+        {&f.RP, nc, 0, 0, 0}, {&f.Rx, nc, 0, 0, 0}, {&f.Ry, nc, 0, 0, 0}, {&f.Rz, nc, 0, 0, 0}};
+    unsigned seed = 1;
+    for (auto &e : ents) {
+        CK(hipMalloc(e.p, e.n * sizeof(double)));
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, *e.p, e.n, seed++, e.lo, e.hi, e.expo);
+    }
+    double *etatau;
+    CK(hipMalloc(&etatau, nc * sizeof(double)));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, etatau, nc, 99u, 0.5, 1.5, 0);
+    CK(hipDeviceSynchronize());
+
+    jrx_stokes3d_params p;
+    memset(&p, 0, sizeof(p));
+    p.nx = nx; p.ny = ny; p.nz = nz; p._dx = 51.2; p._dy = 49.0; p._dz = 47.5; p.dt = 0.25; p.r = 0.7; p.theta_dtau = 191.3; p.eta_dtau = 0.0119;
+    SweepArgs a;
+    a.f = f; a.etatau = etatau; a._dx = p._dx; a._dy = p._dy; a._dz = p._dz; a.dt = p.dt; a.r = p.r; a.theta_dtau = p.theta_dtau; a.eta_dtau = p.eta_dtau;
+    a.L = make_lay(nx, ny, nz);
+    a.i0 = a.j0 = a.k0 = 0;
+
+    // state snapshots for A/B equality
+    struct St { double **p; i64 n; double *bak, *ref; };
+    std::vector<St> sA = {{&f.P, nc}, {&f.txx, nc}, {&f.tyy, nc}, {&f.tzz, nc}, {&f.tyz, nyz}, {&f.txz, nxz}, {&f.txy, nxy}};
+    std::vector<St> sB = {{&f.Vx, nvx}, {&f.Vy, nvy}, {&f.Vz, nvz}};
+    for (auto *v : {&sA, &sB})
+        for (auto &s : *v) {
+            CK(hipMalloc(&s.bak, s.n * sizeof(double)));
+            CK(hipMalloc(&s.ref, s.n * sizeof(double)));
+            CK(hipMemcpy(s.bak, *s.p, s.n * sizeof(double), hipMemcpyDeviceToDevice));
+        }
+    unsigned long long *d_cnt;
+    CK(hipMalloc(&d_cnt, 8));
+    auto restore = [&](std::vector<St> &v) { for (auto &s : v) CK(hipMemcpy(*s.p, s.bak, s.n * sizeof(double), hipMemcpyDeviceToDevice)); };
+    auto saveref = [&](std::vector<St> &v) { for (auto &s : v) CK(hipMemcpy(s.ref, *s.p, s.n * sizeof(double), hipMemcpyDeviceToDevice)); };
+    auto ndiff = [&](std::vector<St> &v) {
+        unsigned long long tot = 0;
+        for (auto &s : v) {
+            CK(hipMemset(d_cnt, 0, 8));
+            hipLaunchKernelGGL(k_maxdiff, dim3(4096), dim3(256), 0, 0, *s.p, s.ref, s.n, d_cnt);
+            unsigned long long c;
+            CK(hipMemcpy(&c, d_cnt, 8, hipMemcpyDeviceToHost));
+            tot += c;
+        }
+        return tot;
+    };
+    Timer T;
+    auto report = [&](const char *name, double ms, double bytes_per_cell, unsigned long long nd) {
+        printf("%-44s %8.3f ms  %7.1f GB/s(alg)  frac8T %.3f  mismatches %llu\n", name, ms, bytes_per_cell * cells / (ms * 1e-3) / 1e9,
+               bytes_per_cell * cells / (ms * 1e-3) / 1e9 / 8000.0, nd);
+        fflush(stdout);
+    };
+
+    // ---------------- streaming ceilings
+    {
+        std::vector<double *> pool;
+        for (auto &e : ents) if (e.n >= nc) pool.push_back(*e.p);
+#define STREAM(NR, NW, VEC)                                                                                         \
+    {                                                                                                               \
+        StreamArgs<NR, NW, VEC> sa;                                                                                 \
+        for (int q = 0; q < NR; q++) sa.r[q] = pool[q];                                                             \
+        for (int q = 0; q < NW; q++) sa.w[q] = pool[NR + q];                                                        \
+        sa.n = nc;                                                                                                  \
+        dim3 g((unsigned)((nc / VEC + 255) / 256));                                                                 \
+        double ms = T.run(reps, [&] { hipLaunchKernelGGL((k_stream<NR, NW, VEC>), g, dim3(256), 0, 0, sa); });      \
+        char nm[64];                                                                                                \
+        snprintf(nm, 64, "stream %dR+%dW x %dB/lane", NR, NW, VEC * 8);                                             \
+        report(nm, ms, (NR + NW) * 8.0, 0);                                                                         \
+    }
+        STREAM(1, 1, 1) STREAM(1, 1, 2) STREAM(8, 2, 1) STREAM(8, 2, 2) STREAM(21, 7, 1) STREAM(21, 7, 2) STREAM(14, 3, 1) STREAM(14, 3, 2)
+    }
+    // re-fill (streams clobbered the pool)
+    seed = 1;
+    for (auto &e : ents) hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, *e.p, e.n, seed++, e.lo, e.hi, e.expo);
+    CK(hipDeviceSynchronize());
+    for (auto *v : {&sA, &sB}) for (auto &s : *v) CK(hipMemcpy(s.bak, *s.p, s.n * sizeof(double), hipMemcpyDeviceToDevice));
+
+    // ---------------- stress sweep
+    auto stress_v1 = [&] {
+        SweepArgs b = a; b.i1 = nx + 1; b.j1 = ny + 1; b.k1 = nz + 1;
+        dim3 g((unsigned)(((i64)(nx + 1) * (ny + 1) + 255) / 256), nz + 1);
+        hipLaunchKernelGGL(k_stress3d<false>, g, dim3(256), 0, 0, b);
+    };
+    stress_v1(); CK(hipDeviceSynchronize()); saveref(sA);
+    report("stress v1 (flat xy, 1 node/thread)", T.run(reps, stress_v1), 224.0, 0);
+#define STRESS_ZM(TX, TY, KZ)                                                                                       \
+    {                                                                                                               \
+        auto fn = [&] {                                                                                             \
+            dim3 g((nx + TX - 1) / TX, (ny + TY - 1) / TY, (nz + KZ - 1) / KZ);                                     \
+            hipLaunchKernelGGL((k_stress3d_zm<false, TX, TY, KZ>), g, dim3(TX, TY), 0, 0, a);                       \
+        };                                                                                                          \
+        restore(sA); fn(); CK(hipDeviceSynchronize());                                                              \
+        unsigned long long nd = ndiff(sA);                                                                          \
+        char nm[64];                                                                                                \
+        snprintf(nm, 64, "stress zm %dx%dx%d", TX, TY, KZ);                                                         \
+        report(nm, T.run(reps, fn), 224.0, nd);                                                                     \
+    }
+    STRESS_ZM(64, 4, 16) STRESS_ZM(64, 4, 32) STRESS_ZM(64, 4, 64) STRESS_ZM(64, 2, 32) STRESS_ZM(64, 8, 32) STRESS_ZM(32, 8, 32)
+    STRESS_ZM(64, 4, 128) STRESS_ZM(128, 2, 32) STRESS_ZM(64, 1, 32)
+    restore(sA);
+
+    // ---------------- velocity sweep
+    auto vel_v1 = [&] {
+        SweepArgs b = a; b.i1 = nx; b.j1 = ny; b.k1 = nz;
+        dim3 g((unsigned)(((i64)nx * ny + 255) / 256), nz);
+        hipLaunchKernelGGL(k_velocity3d<false>, g, dim3(256), 0, 0, b);
+    };
+    vel_v1(); CK(hipDeviceSynchronize()); saveref(sB);
+    report("velocity v1 (flat xy, 1 cell/thread)", T.run(reps, vel_v1), 136.0, 0);
+#define VEL_ZM(TX, TY, KZ)                                                                                          \
+    {                                                                                                               \
+        auto fn = [&] {                                                                                             \
+            SweepArgs b = a; b.i1 = nx; b.j1 = ny; b.k1 = nz;                                                       \
+            dim3 g((nx + TX - 1) / TX, (ny + TY - 1) / TY, (nz + KZ - 1) / KZ);                                     \
+            hipLaunchKernelGGL((k_velocity3d_zm<false, TX, TY, KZ>), g, dim3(TX, TY), 0, 0, b);                     \
+        };                                                                                                          \
+        restore(sB); fn(); CK(hipDeviceSynchronize());                                                              \
+        unsigned long long nd = ndiff(sB);                                                                          \
+        char nm[64];                                                                                                \
+        snprintf(nm, 64, "velocity zm %dx%dx%d", TX, TY, KZ);                                                       \
+        report(nm, T.run(reps, fn), 136.0, nd);                                                                     \
+    }
+    VEL_ZM(64, 4, 16) VEL_ZM(64, 4, 32) VEL_ZM(64, 4, 64) VEL_ZM(64, 2, 32) VEL_ZM(64, 8, 32) VEL_ZM(64, 4, 128) VEL_ZM(128, 2, 32)
+    printf("done\n");
+    return 0;
+}
