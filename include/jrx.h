@@ -60,6 +60,10 @@ jrx_status jrx_destroy(jrx_handle *h);
 const char *jrx_last_error(const jrx_handle *h);   /* h may be NULL: last creation error */
 int32_t jrx_version(void);
 
+/* Tuning / debugging knobs.  Keys: "kernel_variant" (0 = automatic choice, default; 1 = force the
+ * simple one-thread-per-node kernels -- both produce bit-identical results). */
+jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
+
 /* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)
  * ImplicitGlobalGrid semantics used by the reference: local arrays of n cells overlap
  * the neighbour by 2 cells; an array of extent nA along a split dimension has overlap

@@ -22,6 +22,7 @@ struct jrx_handle {
     double *etatau = nullptr;            // library-owned ητ (capacity etatau_cap doubles)
     size_t etatau_cap = 0;
     jrx_comm_state *comm = nullptr;
+    int kernel_variant = 0;              // 0 auto (z-marching sweeps where they apply), 1 force the per-node v1 kernels
     char err[512] = {0};
 };
 

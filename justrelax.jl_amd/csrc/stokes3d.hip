@@ -10,6 +10,7 @@
 // i.e. 45 array passes * 8 B = 360 B per cell per iteration (the two-sweep floor); the diagnostic
 // outputs ∇V, ε, RP, R, U are only written on iterations whose results can be observed (norm
 // checks and the last iteration).  Pure HBM-bandwidth-bound fp64 stencils: no MFMA.
+#include <vector>
 #include "jrx_internal.hpp"
 #include "jrx_kernels.hpp"
 #include "stokes3d_kernels.hpp"
@@ -52,7 +53,7 @@ jrx_status check_diag(jrx_handle *h, const jrx_stokes3d_fields *f)
 }
 
 // launch the stress sweep over the sub-box [i0,i1) x [j0,j1) x [k0,k1) of the ni.+1 box
-jrx_status launch_stress(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
+jrx_status launch_stress_v1(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
 {
     if (i1 <= i0 || j1 <= j0 || k1 <= k0) return JRX_OK;
     a.i0 = i0; a.i1 = i1; a.j0 = j0; a.j1 = j1; a.k0 = k0; a.k1 = k1;
@@ -64,7 +65,7 @@ jrx_status launch_stress(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, i
     return JRX_OK;
 }
 
-jrx_status launch_velocity(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
+jrx_status launch_velocity_v1(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
 {
     if (i1 <= i0 || j1 <= j0 || k1 <= k0) return JRX_OK;
     a.i0 = i0; a.i1 = i1; a.j0 = j0; a.j1 = j1; a.k0 = k0; a.k1 = k1;
@@ -74,6 +75,65 @@ jrx_status launch_velocity(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag,
     else hipLaunchKernelGGL(k_velocity3d<false>, grid, dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
+}
+
+// every array of the block addressable with a 32-bit byte offset (needed by the z-marching kernels)
+bool fits_u32(const Lay3 &L)
+{
+    const double m = (double)(L.nx + 2) * (double)(L.ny + 2) * (double)(L.nz + 2) * 8.0;
+    return m < 4294967296.0;
+}
+
+template <int TX, int TY, int KZ>
+jrx_status launch_stress_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag)
+{
+    const TileMap tm = make_tilemap(a.L.nx, a.L.ny, a.L.nz, TX, TY, KZ);
+    if (diag) hipLaunchKernelGGL((k_stress3d_zb<true, TX, TY, KZ, 4, false, false>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, false>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+template <int TX, int TY, int KZ>
+jrx_status launch_velocity_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag)
+{
+    const TileMap tm = make_tilemap(a.i1 - a.i0, a.j1 - a.j0, a.k1 - a.k0, TX, TY, KZ);
+    if (diag) hipLaunchKernelGGL((k_velocity3d_zb<true, TX, TY, KZ, 4, false>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, 4, false>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+// Stress sweep over the whole ni.+1 node box.  Wide grids: z-marching kernel over the cell box
+// (tile = one or two full-width row segments: measured best for DRAM page locality)
+// plus three thin launches of the per-node kernel for the upper boundary planes i = nx, j = ny,
+// k = nz that no cell column owns.
+jrx_status launch_stress(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
+{
+    const int nx = a.L.nx, ny = a.L.ny, nz = a.L.nz;
+    const bool full = i0 == 0 && j0 == 0 && k0 == 0 && i1 == nx + 1 && j1 == ny + 1 && k1 == nz + 1;
+    if (h->kernel_variant == 1 || !full || !fits_u32(a.L) || nx < 48) return launch_stress_v1(h, s, a, diag, i0, i1, j0, j1, k0, k1);
+    a.i0 = a.j0 = a.k0 = 0; a.i1 = nx; a.j1 = ny; a.k1 = nz;
+    if (nx > 384) JRX_TRY((launch_stress_zb<512, 1, 4>(h, s, a, diag)));
+    else if (nx > 192) JRX_TRY((launch_stress_zb<256, 1, 8>(h, s, a, diag)));
+    else if (nx > 96) JRX_TRY((launch_stress_zb<128, 2, 8>(h, s, a, diag)));
+    else JRX_TRY((launch_stress_zb<64, 4, 8>(h, s, a, diag)));
+    JRX_TRY(launch_stress_v1(h, s, a, diag, nx, nx + 1, 0, ny + 1, 0, nz + 1));
+    JRX_TRY(launch_stress_v1(h, s, a, diag, 0, nx, ny, ny + 1, 0, nz + 1));
+    JRX_TRY(launch_stress_v1(h, s, a, diag, 0, nx, 0, ny, nz, nz + 1));
+    return JRX_OK;
+}
+
+jrx_status launch_velocity(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
+{
+    if (i1 <= i0 || j1 <= j0 || k1 <= k0) return JRX_OK;
+    const int w = i1 - i0;
+    if (h->kernel_variant == 1 || !fits_u32(a.L) || w < 48 || (k1 - k0) < 4) return launch_velocity_v1(h, s, a, diag, i0, i1, j0, j1, k0, k1);
+    a.i0 = i0; a.i1 = i1; a.j0 = j0; a.j1 = j1; a.k0 = k0; a.k1 = k1;
+    if (w > 384) return launch_velocity_zb<512, 1, 4>(h, s, a, diag);
+    if (w > 192) return launch_velocity_zb<256, 1, 8>(h, s, a, diag);
+    if (w > 96) return launch_velocity_zb<128, 2, 8>(h, s, a, diag);
+    return launch_velocity_zb<64, 4, 8>(h, s, a, diag);
 }
 
 jrx_status launch_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
@@ -184,6 +244,14 @@ jrx_status jrx_stokes3d_residual_sumsq(jrx_handle *h, const jrx_stokes3d_fields 
     return JRX_OK;
 }
 
+jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!key) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: key is NULL");
+    if (strcmp(key, "kernel_variant") == 0) { h->kernel_variant = (int)value; return JRX_OK; }
+    return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: unknown key '%s'", key);
+}
+
 jrx_status jrx_compute_maxloc(jrx_handle *h, double *B, const double *A, int64_t nx, int64_t ny, int64_t nz)
 {
     if (!h) return JRX_ERR_ARG;
@@ -198,14 +266,17 @@ jrx_status jrx_compute_maxloc(jrx_handle *h, double *B, const double *A, int64_t
 
 // one PT iteration (Stokes3D.jl:78-121), enqueued on the handle's streams, no host sync
 static jrx_status enqueue_iteration(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
-                                    const jrx_stokes3d_params *p, bool diag)
+                                    const jrx_stokes3d_params *p, bool diag, hipEvent_t *tev = nullptr)
 {
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
     SweepArgs a = make_args(f, etatau, p);
     hipStream_t s = h->stream;
+    if (tev) JRX_HIP(h, hipEventRecord(tev[0], s));
     JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
+    if (tev) JRX_HIP(h, hipEventRecord(tev[1], s));
     if (!jrx_comm_active(h)) {
         JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
+        if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
         if (diag) JRX_TRY(launch_scaleU(h, s, f, p));
         JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
         return JRX_OK;
@@ -336,37 +407,36 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
 {
     JRX_TRY(check_params(h, f, p));
     if (!etatau) return jrx_fail(h, JRX_ERR_ARG, "etatau is NULL");
+    if (iters < 1) return jrx_fail(h, JRX_ERR_ARG, "iters must be >= 1");
     hipStream_t s = h->stream;
-    const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
-    // whole loop body, back to back
+    // hipEvents around each sweep of sampled iterations *inside* the timed batch (on the stream the
+    // kernels run on); at most 256 samples so that event bookkeeping stays negligible
+    const bool sample = (stress_ms || velocity_ms);
+    const int64_t stride = iters > 256 ? (iters + 255) / 256 : 1;
+    const int nsamp = sample ? (int)((iters + stride - 1) / stride) : 0;
+    std::vector<hipEvent_t> evs((size_t)nsamp * 3);
+    for (auto &e : evs) JRX_HIP(h, hipEventCreate(&e));
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
-    for (int64_t it = 0; it < iters; it++) JRX_TRY(enqueue_iteration(h, f, etatau, p, false));
+    for (int64_t it = 0; it < iters; it++) {
+        hipEvent_t *tev = (sample && it % stride == 0) ? &evs[(size_t)(it / stride) * 3] : nullptr;
+        JRX_TRY(enqueue_iteration(h, f, etatau, p, false, tev));
+    }
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_HIP(h, hipStreamSynchronize(s));
     float ms = 0.f;
     JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
     if (total_ms) *total_ms = ms;
-    // per-kernel durations: events around each sweep of a few extra iterations (these also advance the state)
-    if (stress_ms || velocity_ms) {
-        SweepArgs a = make_args(f, etatau, p);
-        double sa = 0.0, sb = 0.0;
-        const int reps = 5;
-        for (int r = 0; r < reps; r++) {
-            JRX_HIP(h, hipEventRecord(h->ev[3], s));
-            JRX_TRY(launch_stress(h, s, a, false, 0, nx + 1, 0, ny + 1, 0, nz + 1));
-            JRX_HIP(h, hipEventRecord(h->ev[4], s));
-            JRX_TRY(launch_velocity(h, s, a, false, 0, nx, 0, ny, 0, nz));
-            JRX_HIP(h, hipEventRecord(h->ev[5], s));
-            JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
-            JRX_HIP(h, hipStreamSynchronize(s));
-            float m1 = 0.f, m2 = 0.f;
-            JRX_HIP(h, hipEventElapsedTime(&m1, h->ev[3], h->ev[4]));
-            JRX_HIP(h, hipEventElapsedTime(&m2, h->ev[4], h->ev[5]));
-            sa += m1; sb += m2;
-        }
-        if (stress_ms) *stress_ms = sa / reps;
-        if (velocity_ms) *velocity_ms = sb / reps;
+    double sa = 0.0, sb = 0.0;
+    const bool split = sample && !jrx_comm_active(h);
+    for (int q = 0; q < nsamp && split; q++) {
+        float m1 = 0.f, m2 = 0.f;
+        JRX_HIP(h, hipEventElapsedTime(&m1, evs[(size_t)q * 3], evs[(size_t)q * 3 + 1]));
+        JRX_HIP(h, hipEventElapsedTime(&m2, evs[(size_t)q * 3 + 1], evs[(size_t)q * 3 + 2]));
+        sa += m1; sb += m2;
     }
+    for (auto &e : evs) (void)hipEventDestroy(e);
+    if (stress_ms) *stress_ms = split ? sa / nsamp : 0.0;
+    if (velocity_ms) *velocity_ms = split ? sb / nsamp : 0.0;
     return JRX_OK;
 }
 

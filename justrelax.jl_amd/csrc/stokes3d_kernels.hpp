@@ -452,4 +452,225 @@ __global__ __launch_bounds__(TX *TY) void k_velocity3d_zm(const SweepArgs a)
 }
 #undef CC3
 
+// ================================================================================================
+// Version 3 ("zb"): the z-marching sweeps with (a) 32-bit byte offsets against SGPR base pointers
+// (global_load saddr form: one VGPR of address state per array class instead of a 64-bit pointer
+// per array -- v2 needed 256 VGPRs and ran at one wave per SIMD), and (b) an XCD-aware tile order:
+// workgroups are dealt round-robin over the 8 XCDs, so workgroup b is mapped to logical tile
+// (b % 8) * (tiles/8) + b / 8 -- each XCD walks one contiguous run of tiles, x/y-adjacent tiles
+// share that XCD's L2 and are resident together.  Arrays must be < 4 GiB each (n <= ~800).
+// ================================================================================================
+typedef unsigned int u32;
+#define LDB(p, off) (*(const double *)((const char *)(p) + (off)))
+#define STB(p, off, v) (*(double *)((char *)(p) + (off)) = (v))
+
+struct TileMap {
+    int ntx, nty, ntz, ntiles, per;     // per = ceil(ntiles / 8)
+};
+__host__ __device__ inline TileMap make_tilemap(int ex, int ey, int ez, int TX, int TY, int KZ)
+{
+    TileMap m;
+    m.ntx = (ex + TX - 1) / TX; m.nty = (ey + TY - 1) / TY; m.ntz = (ez + KZ - 1) / KZ;
+    m.ntiles = m.ntx * m.nty * m.ntz;
+    m.per = (m.ntiles + 7) / 8;
+    return m;
+}
+template <bool XCD>
+__device__ __forceinline__ bool tile_of_block(const TileMap &m, int &tx, int &ty, int &tz)
+{
+    const int b = blockIdx.x;
+    const int lb = XCD ? (b & 7) * m.per + (b >> 3) : b;
+    if (lb >= m.ntiles) return false;
+    tx = lb % m.ntx;
+    const int r = lb / m.ntx;
+    ty = r % m.nty;
+    tz = r / m.nty;
+    return true;
+}
+
+template <bool DIAG, int TX, int TY, int KZ, int MINW, bool EDGES, bool XCD = true>
+__global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a, const TileMap tm)
+{
+    const Lay3 &L = a.L;
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    int tx, ty, tz;
+    if (!tile_of_block<XCD>(tm, tx, ty, tz)) return;
+    const int i = tx * TX + (int)(threadIdx.x % TX);
+    const int j = ty * TY + (int)(threadIdx.x / TX);
+    const int kb = tz * KZ;
+    if (i >= nx || j >= ny) return;
+    const int kend = min(kb + KZ, nz);
+    const int im = max(i - 1, 0), jm = max(j - 1, 0);
+    const bool xhi = (i == nx - 1), yhi = (j == ny - 1);
+    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau, _dt = 1.0 / dt, rr = a.r;
+    const jrx_stokes3d_fields &f = a.f;
+
+    // byte strides (uniform)
+    const u32 sc = (u32)L.cp * 8u, svx = (u32)L.vxp * 8u, svy = (u32)L.vyp * 8u, svz = (u32)L.vzp * 8u;
+    const u32 sxy = (u32)L.xyp * 8u, sxz = (u32)L.xzp * 8u, syz = (u32)L.yzp * 8u;
+    const u32 rvx = (u32)L.vx1 * 8u, rvy = (u32)L.vy1 * 8u, rvz = (u32)L.vz1 * 8u;
+    // running byte offsets
+    u32 oc = 8u * (u32)(i + nx * j) + sc * (u32)kb;
+    const u32 dcx = 8u * (u32)(i - im), dcy = 8u * (u32)(nx * (j - jm));     // distance to the clamped x / y neighbour cell
+    u32 ovx = 8u * (u32)(i + L.vx1 * (j + 1)) + svx * (u32)(kb + 1);
+    u32 ovy = 8u * (u32)((i + 1) + L.vy1 * j) + svy * (u32)(kb + 1);
+    u32 ovz = 8u * (u32)((i + 1) + L.vz1 * (j + 1)) + svz * (u32)(kb + 1);
+    u32 oxy = 8u * (u32)(i + L.xy1 * j) + sxy * (u32)kb;
+    u32 oxz = 8u * (u32)(i + L.xz1 * j) + sxz * (u32)kb;
+    u32 oyz = 8u * (u32)(i + L.yz1 * j) + syz * (u32)kb;
+
+    double a_p = LDB(f.Vx, ovx - svx), b_p = LDB(f.Vy, ovy - svy);
+    double c_p = LDB(f.Vz, ovz - svz), cx_p = LDB(f.Vz, ovz - svz - 8u), cy_p = LDB(f.Vz, ovz - svz - rvz);
+    const u32 back = kb > 0 ? sc : 0u;
+    double e_p = LDB(f.eta, oc - back), ex_p = LDB(f.eta, oc - back - dcx), ey_p = LDB(f.eta, oc - back - dcy);
+    double g_p = LDB(f.G, oc - back), gx_p = LDB(f.G, oc - back - dcx), gy_p = LDB(f.G, oc - back - dcy);
+
+    for (int k = kb; k < kend; ++k) {
+        const double va = LDB(f.Vx, ovx), vax = LDB(f.Vx, ovx + 8u), vay = LDB(f.Vx, ovx - rvx);
+        const double vb = LDB(f.Vy, ovy), vby = LDB(f.Vy, ovy + rvy), vbx = LDB(f.Vy, ovy - 8u);
+        const double vc = LDB(f.Vz, ovz), vcx = LDB(f.Vz, ovz - 8u), vcy = LDB(f.Vz, ovz - rvz);
+        const double e = LDB(f.eta, oc), ex = LDB(f.eta, oc - dcx), ey = LDB(f.eta, oc - dcy), exy_ = LDB(f.eta, oc - dcx - dcy);
+        const double g = LDB(f.G, oc), gx = LDB(f.G, oc - dcx), gy = LDB(f.G, oc - dcy), gxy = LDB(f.G, oc - dcx - dcy);
+        // issue the remaining independent loads of this plane early
+        const double P = LDB(f.P, oc), P0 = LDB(f.P0, oc), Kc = LDB(f.K, oc), Qc = LDB(f.Q, oc);
+        const double txx = LDB(f.txx, oc), tyy = LDB(f.tyy, oc), tzz = LDB(f.tzz, oc);
+        const double toxx = LDB(f.toxx, oc), toyy = LDB(f.toyy, oc), tozz = LDB(f.tozz, oc);
+        const double txy = LDB(f.txy, oxy), toxy = LDB(f.toxy, oxy);
+        const double txz = LDB(f.txz, oxz), toxz = LDB(f.toxz, oxz);
+        const double tyz = LDB(f.tyz, oyz), toyz = LDB(f.toyz, oyz);
+
+        {   // centre (i,j,k)
+            const double dxi = (-va + vax) * _dx;
+            const double dyi = (-vb + vby) * _dy;
+            const double dzi = (-c_p + vc) * _dz;
+            const double divV = dxi + dyi + dzi;
+            const double _Gdt = 1.0 / (g * dt);
+            const double _Kdt = 1.0 / (Kc * dt);
+            const double rhs = -divV + (Qc * _dt);
+            const double psi = 1.0 / (1.0 / e + _Gdt) * rr / th;
+            STB(f.P, oc, (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi));
+            const double d3 = divV * (1.0 / 3.0);
+            const double exx = dxi - d3, eyy = dyi - d3, ezz = dzi - d3;
+            if (DIAG) {
+                STB(f.RP, oc, fma(-(P - P0), _Kdt, rhs));
+                STB(f.divV, oc, divV);
+                STB(f.exx, oc, exx); STB(f.eyy, oc, eyy); STB(f.ezz, oc, ezz);
+            }
+            const double dtr = dev_dtau_r(th, e, _Gdt);
+            STB(f.txx, oc, txx + dev_stress_inc(txx, toxx, e, exx, _Gdt, dtr));
+            STB(f.tyy, oc, tyy + dev_stress_inc(tyy, toyy, e, eyy, _Gdt, dtr));
+            STB(f.tzz, oc, tzz + dev_stress_inc(tzz, tozz, e, ezz, _Gdt, dtr));
+        }
+        {   // τxy (i,j,k)
+            const double s_ = 0.5 * (_dy * (va - vay) + _dx * (vb - vbx));
+            const double ee = 0.25 * (exy_ + ey + ex + e);
+            const double gg = 0.25 * (gxy + gy + gx + g);
+            const double _Gdt = 1.0 / (gg * dt);
+            const double dtr = dev_dtau_r(th, ee, _Gdt);
+            STB(f.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
+            if (DIAG) STB(f.exy, oxy, s_);
+        }
+        {   // τxz (i,j,k)
+            const double s_ = 0.5 * (_dz * (va - a_p) + _dx * (c_p - cx_p));
+            const double ee = 0.25 * (ex_p + e_p + ex + e);
+            const double gg = 0.25 * (gx_p + g_p + gx + g);
+            const double _Gdt = 1.0 / (gg * dt);
+            const double dtr = dev_dtau_r(th, ee, _Gdt);
+            STB(f.txz, oxz, txz + dev_stress_inc(txz, toxz, ee, s_, _Gdt, dtr));
+            if (DIAG) STB(f.exz, oxz, s_);
+        }
+        {   // τyz (i,j,k)
+            const double s_ = 0.5 * (_dz * (vb - b_p) + _dy * (c_p - cy_p));
+            const double ee = 0.25 * (ey_p + e_p + ey + e);
+            const double gg = 0.25 * (gy_p + g_p + gy + g);
+            const double _Gdt = 1.0 / (gg * dt);
+            const double dtr = dev_dtau_r(th, ee, _Gdt);
+            STB(f.tyz, oyz, tyz + dev_stress_inc(tyz, toyz, ee, s_, _Gdt, dtr));
+            if (DIAG) STB(f.eyz, oyz, s_);
+        }
+        if (EDGES) {
+            if (xhi) { node_xy<DIAG>(a, nx, j, k); node_xz<DIAG>(a, nx, j, k); }
+            if (yhi) { node_xy<DIAG>(a, i, ny, k); node_yz<DIAG>(a, i, ny, k); }
+            if (xhi && yhi) node_xy<DIAG>(a, nx, ny, k);
+        }
+
+        a_p = va; b_p = vb; c_p = vc; cx_p = vcx; cy_p = vcy;
+        e_p = e; ex_p = ex; ey_p = ey; g_p = g; gx_p = gx; gy_p = gy;
+        oc += sc; ovx += svx; ovy += svy; ovz += svz; oxy += sxy; oxz += sxz; oyz += syz;
+    }
+    if (EDGES && kend == nz) {
+        node_xz<DIAG>(a, i, j, nz);
+        node_yz<DIAG>(a, i, j, nz);
+        if (xhi) node_xz<DIAG>(a, nx, j, nz);
+        if (yhi) node_yz<DIAG>(a, i, ny, nz);
+    }
+}
+
+template <bool DIAG, int TX, int TY, int KZ, int MINW, bool XCD = true>
+__global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs a, const TileMap tm)
+{
+    const Lay3 &L = a.L;
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    int tx, ty, tz;
+    if (!tile_of_block<XCD>(tm, tx, ty, tz)) return;
+    const int i = a.i0 + tx * TX + (int)(threadIdx.x % TX);
+    const int j = a.j0 + ty * TY + (int)(threadIdx.x / TX);
+    const int kb = a.k0 + tz * KZ;
+    if (i >= a.i1 || j >= a.j1) return;
+    const int kend = min(kb + KZ, a.k1);
+    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, edt = a.eta_dtau;
+    const bool hx = i < nx - 1, hy = j < ny - 1;
+    const jrx_stokes3d_fields &f = a.f;
+    const double *et = a.etatau;
+
+    const u32 sc = (u32)L.cp * 8u, svx = (u32)L.vxp * 8u, svy = (u32)L.vyp * 8u, svz = (u32)L.vzp * 8u;
+    const u32 sxy = (u32)L.xyp * 8u, sxz = (u32)L.xzp * 8u, syz = (u32)L.yzp * 8u;
+    const u32 rc = (u32)nx * 8u, rxy = (u32)L.xy1 * 8u, ryz = (u32)L.yz1 * 8u;
+    const u32 srx = (u32)(nx - 1) * (u32)ny * 8u, sry = (u32)nx * (u32)(ny - 1) * 8u;
+    u32 oc = 8u * (u32)(i + nx * j) + sc * (u32)kb;
+    u32 oxy = 8u * (u32)(i + L.xy1 * j) + sxy * (u32)kb;
+    u32 oxz = 8u * (u32)(i + L.xz1 * j) + sxz * (u32)(kb + 1);
+    u32 oyz = 8u * (u32)(i + L.yz1 * j) + syz * (u32)(kb + 1);
+    u32 ovx = 8u * (u32)((i + 1) + L.vx1 * (j + 1)) + svx * (u32)(kb + 1);
+    u32 ovy = 8u * (u32)((i + 1) + L.vy1 * (j + 1)) + svy * (u32)(kb + 1);
+    u32 ovz = 8u * (u32)((i + 1) + L.vz1 * (j + 1)) + svz * (u32)(kb + 1);
+    u32 orx = 8u * (u32)(i + (nx - 1) * j) + srx * (u32)kb;
+    u32 ory = 8u * (u32)(i + nx * j) + sry * (u32)kb;
+    // x / y upper-neighbour distance, 0 on the last cell (value then unused but address stays in range)
+    const u32 dx1 = hx ? 8u : 0u, dy1 = hy ? rc : 0u;
+
+    double Pc = LDB(f.P, oc), ec = LDB(et, oc), tzz_c = LDB(f.tzz, oc), fz_c = LDB(f.fz, oc);
+    double s10 = LDB(f.txz, oxz + 8u - sxz), r10 = LDB(f.tyz, oyz + ryz - syz);
+
+    for (int k = kb; k < kend; ++k) {
+        const bool hz = k < nz - 1;
+        const u32 dz1 = hz ? sc : 0u;
+        const double q11 = LDB(f.txy, oxy + 8u + rxy), q10 = LDB(f.txy, oxy + 8u), q01 = LDB(f.txy, oxy + rxy);
+        const double s11 = LDB(f.txz, oxz + 8u), s01 = LDB(f.txz, oxz);
+        const double r11 = LDB(f.tyz, oyz + ryz), r01 = LDB(f.tyz, oyz);
+        const double Pz = LDB(f.P, oc + dz1), ez = LDB(et, oc + dz1), tzz_z = LDB(f.tzz, oc + dz1), fz_z = LDB(f.fz, oc + dz1);
+        const double Px = LDB(f.P, oc + dx1), Py = LDB(f.P, oc + dy1), ex = LDB(et, oc + dx1), ey = LDB(et, oc + dy1);
+        const double txx_c = LDB(f.txx, oc), txx_x = LDB(f.txx, oc + dx1), tyy_c = LDB(f.tyy, oc), tyy_y = LDB(f.tyy, oc + dy1);
+        const double fx_c = LDB(f.fx, oc), fx_x = LDB(f.fx, oc + dx1), fy_c = LDB(f.fy, oc), fy_y = LDB(f.fy, oc + dy1);
+        const double vx = LDB(f.Vx, ovx), vy = LDB(f.Vy, ovy), vz = LDB(f.Vz, ovz);
+        if (hx) {
+            const double R = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx - 0.5 * (fx_c + fx_x);
+            STB(f.Vx, ovx, vx + R * edt / (0.5 * (ec + ex)));
+            if (DIAG) STB(f.Rx, orx, R);
+        }
+        if (hy) {
+            const double R = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy - 0.5 * (fy_c + fy_y);
+            STB(f.Vy, ovy, vy + R * edt / (0.5 * (ec + ey)));
+            if (DIAG) STB(f.Ry, ory, R);
+        }
+        if (hz) {
+            const double R = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz - 0.5 * (fz_c + fz_z);
+            STB(f.Vz, ovz, vz + R * edt / (0.5 * (ec + ez)));
+            if (DIAG) STB(f.Rz, oc, R);
+        }
+        Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11;
+        oc += sc; oxy += sxy; oxz += sxz; oyz += syz; ovx += svx; ovy += svy; ovz += svz; orx += srx; ory += sry;
+    }
+}
+
 }   // namespace

@@ -196,8 +196,33 @@ int main(int argc, char **argv)
         snprintf(nm, 64, "stress zm %dx%dx%d", TX, TY, KZ);                                                         \
         report(nm, T.run(reps, fn), 224.0, nd);                                                                     \
     }
-    STRESS_ZM(64, 4, 16) STRESS_ZM(64, 4, 32) STRESS_ZM(64, 4, 64) STRESS_ZM(64, 2, 32) STRESS_ZM(64, 8, 32) STRESS_ZM(32, 8, 32)
-    STRESS_ZM(64, 4, 128) STRESS_ZM(128, 2, 32) STRESS_ZM(64, 1, 32)
+    STRESS_ZM(64, 4, 32)
+#define STRESS_ZB(TX, TY, KZ, MW, ED, XM)                                                                              \
+    {                                                                                                               \
+        TileMap tm = make_tilemap(nx, ny, nz, TX, TY, KZ);                                                          \
+        auto fn = [&] {                                                                                             \
+            hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, MW, ED, XM>), dim3(tm.per * 8), dim3(TX * TY), 0, 0, a, tm); \
+            if (!ED) {                                                                                              \
+                SweepArgs b = a;                                                                                    \
+                b.i0 = nx; b.i1 = nx + 1; b.j0 = 0; b.j1 = ny + 1; b.k0 = 0; b.k1 = nz + 1;                         \
+                hipLaunchKernelGGL(k_stress3d<false>, dim3((ny + 1 + 255) / 256, nz + 1), dim3(256), 0, 0, b);      \
+                b.i0 = 0; b.i1 = nx; b.j0 = ny; b.j1 = ny + 1;                                                      \
+                hipLaunchKernelGGL(k_stress3d<false>, dim3((nx + 255) / 256, nz + 1), dim3(256), 0, 0, b);          \
+                b.j0 = 0; b.j1 = ny; b.k0 = nz; b.k1 = nz + 1;                                                      \
+                hipLaunchKernelGGL(k_stress3d<false>, dim3((unsigned)(((i64)nx * ny + 255) / 256), 1), dim3(256), 0, 0, b); \
+            }                                                                                                       \
+        };                                                                                                          \
+        restore(sA); fn(); CK(hipDeviceSynchronize());                                                              \
+        unsigned long long nd = ndiff(sA);                                                                          \
+        char nm[64];                                                                                                \
+        snprintf(nm, 64, "stress zb %dx%dx%d minw%d e%d xcd%d", TX, TY, KZ, MW, (int)ED, (int)XM);                            \
+        report(nm, T.run(reps, fn), 224.0, nd);                                                                     \
+    }
+    STRESS_ZB(128, 2, 32, 4, false, true) STRESS_ZB(128, 2, 32, 4, false, false) STRESS_ZB(128, 2, 16, 4, false, true) STRESS_ZB(128, 2, 8, 4, false, true)
+    STRESS_ZB(128, 2, 8, 4, false, false) STRESS_ZB(256, 1, 16, 4, false, true) STRESS_ZB(256, 1, 16, 4, false, false) STRESS_ZB(256, 2, 16, 4, false, true)
+    STRESS_ZB(256, 2, 16, 4, false, false) STRESS_ZB(512, 1, 16, 4, false, true) STRESS_ZB(512, 1, 16, 4, false, false) STRESS_ZB(256, 4, 16, 4, false, true)
+    STRESS_ZB(512, 2, 16, 4, false, true) STRESS_ZB(256, 1, 8, 4, false, true) STRESS_ZB(256, 1, 4, 4, false, true) STRESS_ZB(128, 1, 8, 4, false, true)
+    STRESS_ZB(512, 1, 8, 4, false, false) STRESS_ZB(512, 1, 4, 4, false, false) STRESS_ZB(512, 1, 32, 4, false, false) STRESS_ZB(512, 2, 8, 4, false, false)
     restore(sA);
 
     // ---------------- velocity sweep
@@ -221,7 +246,24 @@ int main(int argc, char **argv)
         snprintf(nm, 64, "velocity zm %dx%dx%d", TX, TY, KZ);                                                       \
         report(nm, T.run(reps, fn), 136.0, nd);                                                                     \
     }
-    VEL_ZM(64, 4, 16) VEL_ZM(64, 4, 32) VEL_ZM(64, 4, 64) VEL_ZM(64, 2, 32) VEL_ZM(64, 8, 32) VEL_ZM(64, 4, 128) VEL_ZM(128, 2, 32)
+    VEL_ZM(64, 4, 16) VEL_ZM(128, 2, 32)
+#define VEL_ZB(TX, TY, KZ, MW, XM)                                                                                     \
+    {                                                                                                               \
+        TileMap tm = make_tilemap(nx, ny, nz, TX, TY, KZ);                                                          \
+        auto fn = [&] {                                                                                             \
+            SweepArgs b = a; b.i1 = nx; b.j1 = ny; b.k1 = nz;                                                       \
+            hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, MW, XM>), dim3(tm.per * 8), dim3(TX * TY), 0, 0, b, tm); \
+        };                                                                                                          \
+        restore(sB); fn(); CK(hipDeviceSynchronize());                                                              \
+        unsigned long long nd = ndiff(sB);                                                                          \
+        char nm[64];                                                                                                \
+        snprintf(nm, 64, "velocity zb %dx%dx%d minw%d xcd%d", TX, TY, KZ, MW, (int)XM);                                           \
+        report(nm, T.run(reps, fn), 136.0, nd);                                                                     \
+    }
+    VEL_ZB(128, 2, 32, 4, true) VEL_ZB(128, 2, 32, 4, false) VEL_ZB(128, 2, 8, 4, true) VEL_ZB(128, 2, 8, 4, false)
+    VEL_ZB(256, 1, 16, 4, true) VEL_ZB(256, 1, 16, 4, false) VEL_ZB(256, 2, 16, 4, true) VEL_ZB(256, 2, 16, 4, false)
+    VEL_ZB(512, 1, 16, 4, true) VEL_ZB(512, 1, 16, 4, false) VEL_ZB(256, 4, 16, 4, false) VEL_ZB(512, 2, 16, 4, false)
+    VEL_ZB(256, 1, 8, 4, false) VEL_ZB(512, 1, 8, 4, false) VEL_ZB(512, 1, 4, 4, false) VEL_ZB(512, 1, 32, 4, false) VEL_ZB(256, 1, 4, 4, false)
     printf("done\n");
     return 0;
 }

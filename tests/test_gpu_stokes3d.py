@@ -28,7 +28,8 @@ def env(jr, oracle):
     return dict(jr=jr, orc=oracle, checks=checks, st=stokes, up=upload_stokes, down=download_stokes)
 
 
-@pytest.mark.parametrize("ni", [(17, 19, 23), (32, 32, 32), (5, 4, 3), (64, 9, 7)])
+# wide grids take the z-marching kernels (tile widths 64/128/256/512), narrow ones the per-node kernels
+@pytest.mark.parametrize("ni", [(17, 19, 23), (32, 32, 32), (5, 4, 3), (64, 9, 7), (70, 21, 20), (130, 37, 19), (200, 10, 9), (400, 8, 11)])
 def test_stress_sweep_matches_reference_kernels(env, ni):
     jr, orc, ck, st = env["jr"], env["orc"], env["checks"], env["st"]
     s = jr.miniapps.random_fields3d(ni)
@@ -67,7 +68,7 @@ def test_stress_sweep_state_only_writes_only_state(env):
         assert np.array_equal(db[k], s.arrays[k]), k      # diagnostics not written in state-only mode
 
 
-@pytest.mark.parametrize("ni", [(17, 19, 23), (32, 32, 32), (3, 3, 3)])
+@pytest.mark.parametrize("ni", [(17, 19, 23), (32, 32, 32), (3, 3, 3), (70, 21, 20), (130, 37, 19), (200, 10, 9), (400, 8, 11)])
 def test_velocity_sweep_matches_compute_V(env, ni):
     jr, orc, ck, st = env["jr"], env["orc"], env["checks"], env["st"]
     s = jr.miniapps.random_fields3d(ni, seed=7)
@@ -121,7 +122,7 @@ def test_residual_sumsq(env):
 
 
 @pytest.mark.parametrize("ni,bcs", [((17, 19, 23), "free_slip"), ((12, 12, 12), "no_slip"), ((10, 9, 8), "mixed"),
-                                    ((16, 16, 16), "none")])
+                                    ((16, 16, 16), "none"), ((100, 12, 10), "free_slip"), ((260, 9, 8), "no_slip")])
 def test_solve_matches_oracle_over_iterations(env, ni, bcs):
     """Finite dt, G, K: every elastic/compressible term active.  21 iterations, checks every 5."""
     jr, orc, ck = env["jr"], env["orc"], env["checks"]
@@ -196,3 +197,22 @@ def test_cpu_arrays_are_refused(jr):
     stokes, ρg, K, G = upload_stokes(s, jr.CPUBackend)
     with pytest.raises(NotImplementedError):
         jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+
+
+def test_kernel_variants_are_bit_identical(env):
+    """The z-marching sweeps and the per-node kernels must agree bit for bit (same operation order)."""
+    import ctypes as C
+    jr = env["jr"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields3d((130, 20, 17), iterMax=10, nout=5)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    outs = []
+    h = _lib.default_handle()
+    for variant in (0, 1):
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
+        stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+        jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+        outs.append(env["down"](stokes))
+    h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
