@@ -1,0 +1,190 @@
+"""GPU parity tests: 2D visco-elastic Stokes (Stokes2D.jl:181-325) and 2D PT heat diffusion
+(DiffusionPT_solver.jl) through the C ABI vs the CPU oracle.  Tolerances as in test_gpu_stokes3d.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL_SWEEP, TOL_ITERS = 1e-12, 1e-9
+
+
+def _cp(arrs):
+    return {k: v.copy(order="F") for k, v in arrs.items()}
+
+
+@pytest.fixture(scope="module")
+def env(jr, oracle):
+    import torch
+    assert torch.cuda.is_available()
+    from justrelax_jl_amd import checks, stokes, thermal
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    return dict(jr=jr, orc=oracle, ck=checks, st=stokes, th=thermal, up=upload_stokes, down=download_stokes)
+
+
+@pytest.mark.parametrize("ni", [(17, 19), (64, 33), (3, 3), (130, 7)])
+def test_2d_sweeps_match_reference_kernels(env, ni):
+    jr, orc, ck, st = env["jr"], env["orc"], env["ck"], env["st"]
+    s = jr.miniapps.random_fields2d(ni)
+    ref = _cp(s.arrays)
+    p = ck.oracle_params2d(orc, s)
+    et = orc.compute_maxloc(ref["eta"])
+    L = orc.lib()
+    f = orc.fields2d(ref)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    L.orc_compute_divV2d(f.divV, f.Vx, f.Vy, C.c_int64(ni[0]), C.c_int64(ni[1]), C.c_double(p._dx), C.c_double(p._dy))
+    L.orc_compute_P3d(f.P, f.P0, f.RP, f.divV, f.Q, dp(et), f.K, f.G, C.c_int64(ni[0] * ni[1]), C.c_double(s.dt),
+                      C.c_double(s.pt.r), C.c_double(s.pt.θ_dτ))           # ητ, not η, in the 2D driver (Stokes2D.jl:232)
+    orc.call2d("orc_compute_strain_rate2d", ref, p)
+    orc.call2d("orc_compute_tau2d", ref, p)
+    stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+    etd = jr.fzeros(ni, stokes.P.device)
+    jr.compute_maxloc_(etd, stokes.viscosity.η)
+    assert np.array_equal(jr.to_numpy(etd), et)
+    st.sweep_stress_(stokes, s.pt, s.grid, K, G, s.dt, ητ=etd, diag=True)
+    dev = env["down"](stokes)
+    d = ck.compare_stokes(dev, ref, ["divV", "P", "RP", "exx", "eyy", "exy", "txx", "tyy", "txy"])
+    assert max(d.values()) <= TOL_SWEEP, d
+    # velocity sweep + compute_Res!
+    orc.call2d("orc_compute_V2d", ref, p, dp(et))
+    orc.call2d("orc_velocity2displacement2d", ref, p)
+    orc.call2d("orc_compute_Res2d", ref, p)
+    st.compute_Res_(stokes, s.pt, s.grid, ρg)
+    st.sweep_velocity_(stokes, s.pt, s.grid, ρg, etd, s.dt, diag=True)
+    dev = env["down"](stokes)
+    d = ck.compare_stokes(dev, ref, ["Vx", "Vy", "Ux", "Uy", "Rx", "Ry"])
+    assert max(d.values()) <= TOL_SWEEP, d
+    assert np.allclose(st.residual_sumsq(stokes, s.pt, s.grid), orc.residual_sumsq2d(ref, p), rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("kind", ["free_slip", "no_slip", "periodic"])
+def test_flow_bcs2d(env, kind):
+    jr, orc = env["jr"], env["orc"]
+    ni = (7, 5)
+    s = jr.miniapps.random_fields2d(ni, bcs=kind, seed=3)
+    ref = _cp(s.arrays)
+    b = s.flow_bcs
+    orc.flow_bcs2d(ref["Vx"], ref["Vy"], ni, b.free_slip, b.no_slip, b.periodic)
+    stokes, *_ = env["up"](s, jr.AMDGPUBackend)
+    jr.flow_bcs_(stokes, b)
+    dev = env["down"](stokes)
+    assert np.array_equal(dev["Vx"], ref["Vx"]) and np.array_equal(dev["Vy"], ref["Vy"])
+
+
+@pytest.mark.parametrize("ni,bcs", [((17, 19), "free_slip"), ((32, 32), "no_slip"), ((40, 9), "periodic")])
+def test_2d_solve_matches_oracle(env, ni, bcs):
+    jr, orc, ck = env["jr"], env["orc"], env["ck"]
+    s = jr.miniapps.random_fields2d(ni, bcs=bcs, iterMax=20, nout=5)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    ref = _cp(s.arrays)
+    r_ref = orc.stokes2d_solve(ref, ck.oracle_params2d(orc, s))
+    stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, G, K, s.dt, None, kwargs=s.kwargs)     # 2D order: ρg, G, K
+    assert r.iter == r_ref["iter"] == 21
+    for k in ("norm_Rx", "norm_Ry", "norm_divV", "err_evo1"):
+        assert np.allclose(getattr(r, k), r_ref[k], rtol=1e-10, atol=0), k
+    d = ck.compare_stokes(env["down"](stokes), ref)
+    assert max(d.values()) <= TOL_ITERS, d
+
+
+def test_solcx_reference_test(env):
+    """test/test_stokes_solcx.jl:26-37 : err_evo1[end] < 1e-8 at 32^2, Δη = 1e6"""
+    jr, orc, ck = env["jr"], env["orc"], env["ck"]
+    s = jr.miniapps.solcx2d(32)
+    ref = _cp(s.arrays)
+    r_ref = orc.stokes2d_solve(ref, ck.oracle_params2d(orc, s))
+    stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+    iters = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, G, K, s.dt, None, kwargs=s.kwargs)
+    assert iters.err_evo1[-1] < 1.0e-8
+    assert iters.iter == r_ref["iter"]
+    dev = env["down"](stokes)
+    for k in ("Vx", "Vy", "P"):
+        assert ck.max_rel_diff(dev[k], ref[k]) < 1e-6, k
+
+
+def test_elastic_buildup_reference_test(env):
+    """test/test_stokes_elastic_buildup.jl:26-55 with finite dt and G: pins the τ_o / G·dt terms on the GPU"""
+    import math
+    jr = env["jr"]
+    s = jr.miniapps.elastic_buildup2d(32)
+    kyr, η0, εbg, Gv = (s.extra[k] for k in ("kyr", "η0", "εbg", "G"))
+    stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+    t, errs = 0.0, []
+    for _ in range(40):               # first 2 kyr of the reference's 10 kyr (the full run is pinned on the oracle)
+        dt = 0.05 * kyr
+        jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, G, K, dt, None, kwargs=s.kwargs)
+        t += dt
+        sol = 2 * εbg * η0 * (1 - math.exp(-Gv * t / η0))
+        errs.append(abs(float(stokes.τ.yy.abs().max()) - sol) / sol)
+    assert sum(errs) / len(errs) <= 5.0e-3
+
+
+def _thermal_setup(jr, th, s):
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy
+    dev = torch.device("cuda", torch.cuda.current_device())
+    thermal = jr.ThermalArrays(jr.AMDGPUBackend, s.ni)
+    for name, attr in (("T", "T"), ("Told", "Told"), ("H", "H"), ("qTx", "qTx"), ("qTy", "qTy"), ("qTx2", "qTx2"), ("qTy2", "qTy2"),
+                       ("shear_heating", "shear_heating")):
+        getattr(thermal, attr).copy_(from_numpy(s.arrays[name], dev))
+    K, ρCp = from_numpy(s.arrays["K"], dev), from_numpy(s.arrays["rhoCp"], dev)
+    pt = jr.PTThermalCoeffs(jr.AMDGPUBackend, K, ρCp, s.dt, s.extra["di"], s.extra["li"], CFL=s.pt["CFL"], ϵ=s.pt["eps"])
+    return thermal, pt, K, ρCp
+
+
+def test_thermal_coefficients_and_bcs(env):
+    jr, orc, th = env["jr"], env["orc"], env["th"]
+    s = jr.miniapps.diffusion2d(32)
+    thermal, pt, K, ρCp = _thermal_setup(jr, th, s)
+    assert np.allclose(jr.to_numpy(pt.θr_dτ), s.arrays["thetar_dtau"], rtol=1e-14)
+    assert np.allclose(jr.to_numpy(pt.dτ_ρ), s.arrays["dtau_rho"], rtol=1e-14)
+    assert float(pt.θr_dτ[0, 0]) == pytest.approx(0.5156700149045073, rel=1e-12)
+    assert float(pt.dτ_ρ[0, 0]) == pytest.approx(721404.061959508, rel=1e-12)
+    b = s.flow_bcs
+    p = orc.thermal_params2d(s.ni, s.grid._di["center"], s.dt, 1e-8, no_flux=b.no_flux, constant_value=b.constant_value,
+                             constant_flux=b.constant_flux, periodic=b.periodic)
+    Tref = s.arrays["T"].copy(order="F")
+    orc.thermal_bcs2d(Tref, p)
+    th.thermal_bcs_(thermal, b)
+    assert np.array_equal(jr.to_numpy(thermal.T), Tref)
+
+
+@pytest.mark.parametrize("form", ["array", "rheology"])
+def test_thermal_iterations_match_oracle(env, form):
+    jr, orc, th = env["jr"], env["orc"], env["th"]
+    from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+    s = jr.miniapps.diffusion2d(24, iterMax=300, nout=100)
+    b = s.flow_bcs
+    rheo = s.extra["rheology"] if form == "rheology" else None
+    p = orc.thermal_params2d(s.ni, s.grid._di["center"], s.dt, 1e-30, iterMax=300, nout=100, no_flux=b.no_flux,
+                             constant_value=b.constant_value, constant_flux=b.constant_flux, periodic=b.periodic, rheology=rheo)
+    orc.thermal_bcs2d(s.arrays["T"], p)
+    add_perturbation(s.arrays["T"], s.grid, **s.extra["perturbation"])
+    thermal, pt, K, ρCp = _thermal_setup(jr, th, s)
+    pt.ϵ = 1e-30
+    ref = _cp(s.arrays)
+    r_ref = orc.heatdiffusion_PT2d(ref, p)
+    A, B = (rheo, None) if form == "rheology" else (K, ρCp)
+    r = jr.heatdiffusion_PT_(thermal, pt, b, A, B, s.dt, s.grid, kwargs=dict(iterMax=300, nout=100, verbose=False))
+    assert list(r.iter_count) == list(r_ref["iter_count"]) == [100, 200, 300]
+    assert np.allclose(r.norm_ResT, r_ref["norm_ResT"], rtol=1e-9)
+    for name, t in (("T", thermal.T), ("Told", thermal.Told), ("dT", thermal.ΔT), ("qTx", thermal.qTx), ("qTy2", thermal.qTy2), ("ResT", thermal.ResT)):
+        assert env["ck"].max_rel_diff(jr.to_numpy(t), ref[name]) <= TOL_ITERS, name
+
+
+def test_diffusion2d_reference_test(env):
+    """test/test_diffusion2D.jl:127-135 on the GPU: 20 steps of 50 kyr, T[18,18] / T[17,17] within atol 0.1"""
+    jr, orc, th = env["jr"], env["orc"], env["th"]
+    from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+    s = jr.miniapps.diffusion2d(32)
+    b = s.flow_bcs
+    p = orc.thermal_params2d(s.ni, s.grid._di["center"], s.dt, 1e-8, no_flux=b.no_flux, constant_value=b.constant_value,
+                             constant_flux=b.constant_flux, periodic=b.periodic)
+    orc.thermal_bcs2d(s.arrays["T"], p)            # host-side setup, as the reference's test does before the time loop
+    add_perturbation(s.arrays["T"], s.grid, **s.extra["perturbation"])
+    thermal, pt, K, ρCp = _thermal_setup(jr, th, s)
+    for _ in range(s.extra["nt"]):
+        jr.heatdiffusion_PT_(thermal, pt, b, s.extra["rheology"], None, s.dt, s.grid, kwargs=dict(verbose=False))
+    T = jr.to_numpy(thermal.T)
+    assert T[17, 17] == pytest.approx(1817.9448461176817, abs=1.0e-1)
+    assert T[16, 16] == pytest.approx(1827.4674313638786, abs=1.0e-1)
