@@ -1,0 +1,146 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/jrx.h declares, the
+host-side block-decomposition logic, and the mirror of the reference's traits / BC structs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(jr):
+    from justrelax_jl_amd import _lib
+    syms = _lib.declared_symbols()
+    assert len(syms) >= 28 and "jrx_stokes3d_solve" in syms and "jrx_heatdiffusion_PT2d" in syms
+    L = _lib.load(check_symbols=True)
+    for s in syms:
+        assert hasattr(L, s), s
+    L.jrx_version.restype = C.c_int32
+    assert L.jrx_version() == 100
+
+
+def test_no_gpu_means_loud_failure(jr):
+    """Without a HIP device the product path raises; it never computes on the CPU."""
+    import torch
+    from justrelax_jl_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.JrxError):
+        _lib.Handle(0)
+    with pytest.raises(RuntimeError):
+        jr.StokesArrays(jr.AMDGPUBackend, (4, 4, 4))
+
+
+def test_halo_planes_follow_igg_semantics(jr):
+    """ol_A = 2 + (nA - n): send plane ol_A / nA-ol_A+1 (1-based), receive into 1 / nA."""
+    from justrelax_jl_amd import _lib
+    L = _lib.load()
+    n = 10
+    want = {n: (1, 8, 0, 9), n + 1: (2, 8, 0, 10), n + 2: (3, 8, 0, 11)}     # 0-based (send_l, send_r, recv_l, recv_r)
+    for nA, w in want.items():
+        v = [C.c_int64() for _ in range(4)]
+        assert L.jrx_halo_planes(C.c_int64(n), C.c_int64(nA), *[C.byref(x) for x in v]) == 0
+        assert tuple(x.value for x in v) == w
+    assert L.jrx_halo_planes(C.c_int64(n), C.c_int64(n - 1), None, None, None, None) != 0      # Rx-like arrays are not exchangeable
+    assert L.jrx_n_global(512, 2, 0) == 1022 and L.jrx_n_global(512, 1, 0) == 512 and L.jrx_n_global(1, 4, 0) == 1
+
+
+@pytest.mark.parametrize("nprocs,dims", [(1, (1, 1, 1)), (2, (2, 1, 1)), (4, (2, 2, 1)), (8, (2, 2, 2)), (6, (3, 2, 1)), (12, (3, 2, 2))])
+def test_cart_create_matches_python_grid(jr, nprocs, dims):
+    from justrelax_jl_amd import _lib, grid, halo
+    for rank in range(nprocs):
+        grid.init_global_grid(16, 16, 16, rank=rank, nprocs=nprocs)
+        gg = grid.global_grid()
+        assert tuple(gg.dims) == dims
+        cart = _lib.Cart()
+        n = (C.c_int64 * 3)(16, 16, 16)
+        assert _lib.load().jrx_cart_create(rank, nprocs, n, None, None, C.byref(cart)) == 0      # library's own factorisation
+        assert tuple(cart.dims) == dims and tuple(cart.coords) == tuple(gg.coords)
+        nb = grid.neighbors(gg.coords, gg.dims)
+        assert [tuple(x) for x in cart.neighbor] == nb
+        for d in range(3):                                   # neighbour relation is symmetric
+            for side in (0, 1):
+                o = cart.neighbor[d][side]
+                if o >= 0:
+                    oc = grid.cart_coords(o, dims)
+                    assert grid.neighbors(oc, dims)[d][1 - side] == rank
+    grid.init_global_grid(16, 16, 1, rank=0, nprocs=4)
+    assert tuple(grid.global_grid().dims) == (2, 2, 1)       # 2D problems never split z
+    grid.finalize_global_grid()
+
+
+def test_global_grid_coordinates(jr):
+    """nx_g = dims*(nx-2)+2 and x_g offsets of src/grid/Utils.jl:24-40; Geometry of src/grid/Grid.jl:56-143"""
+    from justrelax_jl_amd import grid
+    grid.init_global_grid(10, 9, 8, rank=1, nprocs=2)
+    assert (grid.nx_g(), grid.ny_g(), grid.nz_g()) == (18, 9, 8)
+    g = jr.Geometry((10, 9, 8), (18.0, 9.0, 8.0))
+    assert g.di["center"] == (1.0, 1.0, 1.0)
+    assert g.xvi[0][0] == 8.0 and g.xvi[0][-1] == 18.0 and g.xci[0][0] == 8.5      # rank 1 starts at cell 8 = 1*(10-2)
+    grid.finalize_global_grid()
+    g = jr.Geometry((4, 4), (2.0, 1.0), origin=(0.0, -1.0))
+    assert np.allclose(g.xci[1], [-0.875, -0.625, -0.375, -0.125]) and g._di["center"] == (2.0, 4.0)
+
+
+def test_traits_and_backends(jr):
+    """test/test_traits.jl:49-95"""
+    import torch
+    st = jr.StokesArrays(jr.CPUBackend, (4, 4))
+    assert isinstance(jr.backend(st), jr.CPUBackendTrait) and isinstance(jr.backend(st.P), jr.CPUBackendTrait)
+    assert isinstance(jr.backend(jr.ThermalArrays(jr.CPUBackend, (4, 4))), jr.CPUBackendTrait)
+    assert issubclass(jr.AMDGPUBackendTrait, jr.GPUBackendTrait) and issubclass(jr.GPUBackendTrait, jr.BackendTrait)
+    with pytest.raises(ValueError):
+        jr.backend(3.0)
+    with pytest.raises(ValueError):
+        jr.PTArray(int)
+    a = jr.PTArray(jr.CPUBackend)(np.ones((2, 3)))
+    assert isinstance(a, torch.Tensor) and a.dtype == torch.float64
+
+
+def test_boundary_condition_structs(jr):
+    """src/boundaryconditions/types.jl:108-195 ; test_boundary_conditions2D/3D.jl error cases"""
+    f6 = ("left", "right", "front", "back", "top", "bot")
+    on, off = {k: True for k in f6}, {k: False for k in f6}
+    with pytest.raises(ValueError, match="Incompatible"):
+        jr.VelocityBoundaryConditions(no_slip=on, free_slip=dict(off, right=True))
+    b = jr.VelocityBoundaryConditions(no_slip=off, free_slip=off)
+    assert b.nD == 3 and not any(b.free_slip.values())
+    with pytest.raises(ValueError, match="Periodic boundary conditions must be paired"):
+        jr.VelocityBoundaryConditions(no_slip=off, free_slip=off, periodic=dict(off, front=True))
+    b2 = jr.VelocityBoundaryConditions()
+    assert b2.nD == 2 and all(b2.free_slip.values())
+    with pytest.raises(ValueError):
+        jr.VelocityBoundaryConditions(free_slip=dict(left=False, right=False, top=False, bot=False),
+                                      periodic=dict(left=False, right=False, top=True, bot=True), free_surface=True)
+    t = jr.TemperatureBoundaryConditions(no_flux=dict(left=True, right=True, top=False, bot=False),
+                                         constant_value=dict(left=True, right=True, top=300.0, bot=3500.0))
+    assert t.nD == 2 and t.constant_value["top"] == 300.0 and t.constant_flux["left"] is False
+    with pytest.raises(ValueError):
+        jr.TemperatureBoundaryConditions(no_flux=dict(left=False, right=False, top=False, bot=False),
+                                         periodic=dict(left=False, right=False, front=True, back=False, top=False, bot=False))
+    with pytest.raises(ValueError):
+        jr.TemperatureBoundaryConditions(no_flux=dict(left=True, right=True, top=False, bot=False),
+                                         periodic=dict(left=True, right=True, top=False, bot=False))
+
+
+def test_column_major_layout(jr):
+    import torch
+    from justrelax_jl_amd.arrays import is_fortran
+    t = jr.fzeros((3, 4, 5), torch.device("cpu"))
+    assert tuple(t.shape) == (3, 4, 5) and t.stride() == (1, 3, 12) and is_fortran(t)
+    a = np.arange(60, dtype=np.float64).reshape(3, 4, 5, order="F")
+    t = jr.from_numpy(a, torch.device("cpu"))
+    assert is_fortran(t) and float(t[1, 2, 3]) == a[1, 2, 3]
+    assert np.array_equal(jr.to_numpy(t), a) and jr.to_numpy(t).flags.f_contiguous
+
+
+def test_device_builder_matches_host_builder_on_cpu(jr):
+    """solvi3d_device (torch ops, used by bench.py at 512^3) == solvi3d (numpy) on the same grid."""
+    from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
+    import justrelax_jl_amd.grid as g
+    g.finalize_global_grid()
+    st, ρg, K, G, pt, grid, bcs, dt = solvi3d_device(12, jr.CPUBackend)
+    g.finalize_global_grid()
+    s = jr.miniapps.solvi3d(12)
+    assert np.allclose(jr.to_numpy(st.viscosity.η), s.arrays["eta"], rtol=1e-14, atol=0)
+    Vx = jr.to_numpy(st.V.Vx)
+    assert np.array_equal(Vx[:, 1:-1, 1:-1], s.arrays["Vx"][:, 1:-1, 1:-1])
+    assert pt.θ_dτ == s.pt.θ_dτ and dt == s.dt
