@@ -109,18 +109,19 @@ def main():
         run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    tot_ms, sa_ms, sb_ms = _timed = run_timed(stokes, st, pt, geo, bcs, ρg, K, G, ητ, dt, args.steps, h)
+    tot_ms, sa_ms, sb_ms, sf_ms = run_timed(stokes, st, pt, geo, bcs, ρg, K, G, ητ, dt, args.steps, h)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
     if world > 1:
-        t = torch.tensor([el, tot_ms, sa_ms, sb_ms], dtype=torch.float64)
+        t = torch.tensor([el, tot_ms, sa_ms, sb_ms, sf_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, tot_ms, sa_ms, sb_ms = t.tolist()
+        el, tot_ms, sa_ms, sb_ms, sf_ms = t.tolist()
 
     if rank == 0:
         cells = float(n) ** 3
-        split = sa_ms > 0.0       # N > 1: sweeps overlap with the halo exchange on two streams; price the whole iteration
+        fused = sf_ms > 0.0
+        split = sa_ms > 0.0 and sb_ms > 0.0 and not fused       # N > 1: sweeps overlap with the halo exchange on two streams; price the whole iteration
         it_per_s = args.steps / el                       # PT iterations/s of the (global) problem
         value = world * it_per_s                         # n^3-block iterations/s summed over GPUs
         eff_gbs = A_ALG * cells * value / 1e9            # aggregate effective GB/s at 360 B/cell
@@ -139,7 +140,14 @@ def main():
             "roofline": None,
         }
         it_gbs = A_ALG * cells * (args.steps / (tot_ms * 1e-3)) / 1e9
-        if split:
+        if fused:
+            g = A_ALG * cells / (sf_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm",
+                               "kernel": "fused PT iteration = k_fused3d (velocity sweep m + BCs + stress sweep m+1) + 3 BC + 3 boundary-plane "
+                                         "launches; algorithmic 360 B/cell per launch group (it moves 35 array passes = 280 B/cell)",
+                               "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_ms": sf_ms, "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
+        elif split:
             out["roofline"] = {"bound": "hbm",
                                "kernel": "stress sweep = k_stress3d_zb + 3 boundary-plane launches (21 array reads + 7 writes = 224 B/cell)",
                                "achieved": A_STRESS * cells / (sa_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

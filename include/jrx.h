@@ -60,8 +60,9 @@ jrx_status jrx_destroy(jrx_handle *h);
 const char *jrx_last_error(const jrx_handle *h);   /* h may be NULL: last creation error */
 int32_t jrx_version(void);
 
-/* Tuning / debugging knobs.  Keys: "kernel_variant" (0 = automatic choice, default; 1 = force the
- * simple one-thread-per-node kernels -- both produce bit-identical results). */
+/* Tuning / debugging knobs.  Keys: "kernel_variant" (0 = automatic, default: fused iteration kernel where it
+ * applies, z-marching sweeps otherwise; 1 = simple one-thread-per-node kernels; 2 = z-marching sweeps, no fusion
+ * -- all three produce bit-identical results). */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)
@@ -239,12 +240,12 @@ jrx_status jrx_thermal2d_iteration(jrx_handle *h, const jrx_thermal2d_fields *t,
 jrx_status jrx_thermal2d_check_res(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p);
 
 /* ------------------------------------------------------------------ timing hooks for bench.py */
-/* Runs `iters` PT iterations of the 3D loop body (no norm checks) and returns the device time of
- * the whole batch and of the stress / velocity sweeps alone, measured with hipEvents on the
- * handle's stream. */
+/* Runs `iters` PT iterations of the 3D loop body back to back (no norm checks) and reports device times
+ * measured with hipEvents on the handle's stream inside that batch:
+ *   times_ms[0] whole batch; [1] mean stand-alone stress sweep; [2] mean stand-alone velocity sweep;
+ *   [3] mean fused launch group (velocity sweep m + BCs + stress sweep m+1), 0 when nothing was fused. */
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
-                                      const jrx_stokes3d_params *p, int64_t iters,
-                                      double *total_ms, double *stress_ms, double *velocity_ms);
+                                      const jrx_stokes3d_params *p, int64_t iters, double times_ms[4]);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,8 @@ jrx_status jrx_destroy(jrx_handle *h)
     if (h->d_sums) (void)hipFree(h->d_sums);
     if (h->h_sums) (void)hipHostFree(h->h_sums);
     if (h->etatau) (void)hipFree(h->etatau);
+    for (int q = 0; q < 10; q++)
+        if (h->scratch[q]) (void)hipFree(h->scratch[q]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->halo_stream) (void)hipStreamDestroy(h->halo_stream);
     delete h;

@@ -22,7 +22,9 @@ struct jrx_handle {
     double *etatau = nullptr;            // library-owned ητ (capacity etatau_cap doubles)
     size_t etatau_cap = 0;
     jrx_comm_state *comm = nullptr;
-    int kernel_variant = 0;              // 0 auto (z-marching sweeps where they apply), 1 force the per-node v1 kernels
+    double *scratch[10] = {};            // ping-pong set for the fused iteration kernel (P, τ(6), V(3))
+    int scratch_dims[3] = {0, 0, 0};
+    int kernel_variant = 0;              // 0 auto (fused iteration kernel + z-marching sweeps), 1 per-node v1 kernels, 2 z-marching sweeps without fusion
     char err[512] = {0};
 };
 

@@ -21,6 +21,7 @@ SweepArgs make_args(const jrx_stokes3d_fields *f, const double *etatau, const jr
 {
     SweepArgs a;
     a.f = *f;
+    a.o = Out10{f->P, f->txx, f->tyy, f->tzz, f->tyz, f->txz, f->txy, f->Vx, f->Vy, f->Vz};
     a.etatau = etatau;
     a._dx = p->_dx; a._dy = p->_dy; a._dz = p->_dz;
     a.dt = p->dt; a.r = p->r; a.theta_dtau = p->theta_dtau; a.eta_dtau = p->eta_dtau;
@@ -264,16 +265,122 @@ jrx_status jrx_compute_maxloc(jrx_handle *h, double *B, const double *A, int64_t
     return JRX_OK;
 }
 
-// one PT iteration (Stokes3D.jl:78-121), enqueued on the handle's streams, no host sync
-static jrx_status enqueue_iteration(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
-                                    const jrx_stokes3d_params *p, bool diag, hipEvent_t *tev = nullptr)
+}   // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Iteration driver shared by jrx_stokes3d_solve and jrx_stokes3d_iterate_timed.
+// One PT iteration m (Stokes3D.jl:78-121) = A_m (stress sweep), B_m (velocity sweep), BCs, halo.
+// When nothing observes iteration m's diagnostics and iteration m+1 is certain to run, B_m is fused
+// with A_{m+1} (k_fused3d), ping-ponging the state arrays P, τ(6), V(3) between the caller's arrays
+// and the handle's scratch set; whatever set is current at the end is copied back.
+// ------------------------------------------------------------------------------------------------
+struct Iter3D {
+    jrx_handle *h;
+    const jrx_stokes3d_params *p;
+    const double *etatau;
+    jrx_stokes3d_fields cur;      // caller's fields with the 10 state pointers of the current set
+    Out10 setU, setS;             // caller's arrays / scratch arrays
+    bool cur_is_user = true;
+    bool stress_done = false;     // A of the upcoming iteration already applied (by a fused launch)
+    bool fusable = false;
+};
+
+static Out10 out_of(const jrx_stokes3d_fields &f) { return Out10{f.P, f.txx, f.tyy, f.tzz, f.tyz, f.txz, f.txy, f.Vx, f.Vy, f.Vz}; }
+static void set_state(jrx_stokes3d_fields &f, const Out10 &o)
 {
+    f.P = o.P; f.txx = o.txx; f.tyy = o.tyy; f.tzz = o.tzz; f.tyz = o.tyz; f.txz = o.txz; f.txy = o.txy; f.Vx = o.Vx; f.Vy = o.Vy; f.Vz = o.Vz;
+}
+
+static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
+{
+    const size_t n[10] = {(size_t)nx * ny * nz, (size_t)nx * ny * nz, (size_t)nx * ny * nz, (size_t)nx * ny * nz,
+                          (size_t)nx * (ny + 1) * (nz + 1), (size_t)(nx + 1) * ny * (nz + 1), (size_t)(nx + 1) * (ny + 1) * nz,
+                          (size_t)(nx + 1) * (ny + 2) * (nz + 2), (size_t)(nx + 2) * (ny + 1) * (nz + 2), (size_t)(nx + 2) * (ny + 2) * (nz + 1)};
+    if (h->scratch_dims[0] == nx && h->scratch_dims[1] == ny && h->scratch_dims[2] == nz && h->scratch[0]) return JRX_OK;
+    for (int q = 0; q < 10; q++) {
+        if (h->scratch[q]) JRX_HIP(h, hipFree(h->scratch[q]));
+        h->scratch[q] = nullptr;
+    }
+    h->scratch_dims[0] = h->scratch_dims[1] = h->scratch_dims[2] = 0;
+    for (int q = 0; q < 10; q++) JRX_HIP(h, hipMalloc(&h->scratch[q], n[q] * sizeof(double)));
+    h->scratch_dims[0] = nx; h->scratch_dims[1] = ny; h->scratch_dims[2] = nz;
+    return JRX_OK;
+}
+
+static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p)
+{
+    I.h = h; I.p = p; I.etatau = etatau;
+    I.cur = *f;
+    I.setU = out_of(*f);
+    I.cur_is_user = true; I.stress_done = false;
+    const Lay3 L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
+    I.fusable = h->kernel_variant == 0 && !jrx_comm_active(h) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
+    if (I.fusable) {
+        JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
+        double **S = h->scratch;
+        I.setS = Out10{S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8], S[9]};
+        // the scratch V needs the planes no kernel ever writes (prescribed normal velocities): copy V once
+        const i64 n0 = (i64)(p->nx + 1) * (p->ny + 2) * (p->nz + 2), n1 = (i64)(p->nx + 2) * (p->ny + 1) * (p->nz + 2),
+                  n2 = (i64)(p->nx + 2) * (p->ny + 2) * (p->nz + 1);
+        hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, h->stream, I.setS.Vx, (const double *)f->Vx, n0, I.setS.Vy, (const double *)f->Vy, n1,
+                           I.setS.Vz, (const double *)f->Vz, n2, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr,
+                           (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
+        JRX_LAUNCH_CHECK(h);
+    }
+    return JRX_OK;
+}
+
+template <int TX, int TY, int KZ>
+static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc)
+{
+    const int ntx = (a.L.nx + TX - 2) / (TX - 1), nty = (a.L.ny + TY - 2) / (TY - 1), ntz = (a.L.nz + KZ - 1) / KZ;
+    hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+// tev (optional): events recorded around the sweeps: [0] start, [1] after stress (or after the fused
+// launch incl. its BC / boundary-plane launches), [2] after velocity
+static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *tev, int *was_fused)
+{
+    jrx_handle *h = I.h;
+    const jrx_stokes3d_params *p = I.p;
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
-    SweepArgs a = make_args(f, etatau, p);
     hipStream_t s = h->stream;
+    SweepArgs a = make_args(&I.cur, I.etatau, p);
+    if (was_fused) *was_fused = 0;
     if (tev) JRX_HIP(h, hipEventRecord(tev[0], s));
-    JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
+    if (!I.stress_done) JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
+    I.stress_done = false;
     if (tev) JRX_HIP(h, hipEventRecord(tev[1], s));
+
+    if (I.fusable && fuse_next && !diag) {
+        // B_m + BCs + A_{m+1}: src = current set, dst = the other set
+        const Out10 dst = I.cur_is_user ? I.setS : I.setU;
+        a.o = dst;
+        FusedBC bc;
+        const uint32_t fs = p->free_slip, ns = p->no_slip;
+        bc.fsL = !!(fs & JRX_FACE_LEFT); bc.nsL = !!(ns & JRX_FACE_LEFT); bc.fsF = !!(fs & JRX_FACE_FRONT); bc.nsF = !!(ns & JRX_FACE_FRONT);
+        bc.fsK0 = !!(fs & JRX_FACE_TOP);  bc.nsK0 = !!(ns & JRX_FACE_BOT);     // k = 1: free_slip `top`, no_slip `bot` (reference naming)
+        bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
+        if (nx > 96) JRX_TRY((launch_fused<128, 8, 16>(h, s, a, bc)));
+        else JRX_TRY((launch_fused<64, 8, 16>(h, s, a, bc)));
+        JRX_TRY(launch_bcs(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        // stress nodes on the planes i = nx, j = ny, k = nz: old τ from the current set, new V from dst
+        SweepArgs e = a;
+        e.f.Vx = dst.Vx; e.f.Vy = dst.Vy; e.f.Vz = dst.Vz;
+        JRX_TRY(launch_stress_v1(h, s, e, false, nx, nx + 1, 0, ny + 1, 0, nz + 1));
+        JRX_TRY(launch_stress_v1(h, s, e, false, 0, nx, ny, ny + 1, 0, nz + 1));
+        JRX_TRY(launch_stress_v1(h, s, e, false, 0, nx, 0, ny, nz, nz + 1));
+        set_state(I.cur, dst);
+        I.cur_is_user = !I.cur_is_user;
+        I.stress_done = true;
+        if (was_fused) *was_fused = 1;
+        if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
+        return JRX_OK;
+    }
+
+    const jrx_stokes3d_fields *f = &I.cur;
     if (!jrx_comm_active(h)) {
         JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
         if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
@@ -314,6 +421,31 @@ static jrx_status enqueue_iteration(jrx_handle *h, const jrx_stokes3d_fields *f,
     return JRX_OK;
 }
 
+// leave the results in the caller's arrays
+static jrx_status iter_end(Iter3D &I)
+{
+    jrx_handle *h = I.h;
+    if (I.stress_done) return jrx_fail(h, JRX_ERR_ARG, "internal: iteration pipeline ended with a pending fused stress sweep");
+    if (I.cur_is_user) return JRX_OK;
+    const jrx_stokes3d_params *p = I.p;
+    const i64 nc = (i64)p->nx * p->ny * p->nz, nyz = (i64)p->nx * (p->ny + 1) * (p->nz + 1), nxz = (i64)(p->nx + 1) * p->ny * (p->nz + 1),
+              nxy = (i64)(p->nx + 1) * (p->ny + 1) * p->nz, n0 = (i64)(p->nx + 1) * (p->ny + 2) * (p->nz + 2),
+              n1 = (i64)(p->nx + 2) * (p->ny + 1) * (p->nz + 2), n2 = (i64)(p->nx + 2) * (p->ny + 2) * (p->nz + 1);
+    const Out10 &S = I.setS, &U = I.setU;
+    hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, h->stream, U.P, (const double *)S.P, nc, U.txx, (const double *)S.txx, nc, U.tyy,
+                       (const double *)S.tyy, nc, U.tzz, (const double *)S.tzz, nc, U.tyz, (const double *)S.tyz, nyz, U.txz, (const double *)S.txz, nxz);
+    JRX_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, h->stream, U.txy, (const double *)S.txy, nxy, U.Vx, (const double *)S.Vx, n0, U.Vy,
+                       (const double *)S.Vy, n1, U.Vz, (const double *)S.Vz, n2, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr,
+                       (const double *)nullptr, (i64)0);
+    JRX_LAUNCH_CHECK(h);
+    set_state(I.cur, U);
+    I.cur_is_user = true;
+    return JRX_OK;
+}
+
+extern "C" {
+
 jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p, jrx_solve_result *res)
 {
     JRX_TRY(check_params(h, f, p));
@@ -340,16 +472,21 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
     res->iter = 0; res->nchecks = 0;
     const int rank = jrx_comm_rank(h);
     hipEvent_t t0 = h->ev[6], t1 = h->ev[7];
+    Iter3D I;
+    JRX_TRY(iter_begin(I, h, f, h->etatau, p));
     JRX_HIP(h, hipEventRecord(t0, s));
     auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
+    auto is_check = [&](int64_t it1) { return (it1 % p->nout == 0) && it1 > 1; };
     while (keep_going(iter)) {
         const int64_t it1 = iter + 1;
-        const bool check = (it1 % p->nout == 0) && it1 > 1;
+        const bool check = is_check(it1);
         const bool diag = check || !keep_going(it1);   // results observable after this iteration
-        JRX_TRY(enqueue_iteration(h, f, h->etatau, p, diag));
+        // iteration it1+1 certainly runs and is not observable either -> its stress sweep can ride on this velocity sweep
+        const bool fuse_next = !diag && keep_going(it1) && !(is_check(it1 + 1) || !keep_going(it1 + 1));
+        JRX_TRY(iter_step(I, diag, fuse_next, nullptr, nullptr));
         iter = it1;
         if (check) {
-            JRX_TRY(launch_sumsq(h, s, f, p));
+            JRX_TRY(launch_sumsq(h, s, &I.cur, p));
             JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
             JRX_HIP(h, hipStreamSynchronize(s));
             double ss[4] = {h->h_sums[0], h->h_sums[1], h->h_sums[2], h->h_sums[3]};
@@ -375,20 +512,24 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
                        (long long)iter, err, err / err_it1, nRx, nRy, nRz, nDV);
             if (std::isnan(err)) {
                 res->iter = iter; res->nchecks = cont < res->cap ? cont : res->cap;
+                (void)iter_end(I);
+                (void)hipStreamSynchronize(s);
                 return jrx_fail(h, JRX_ERR_NAN, "NaN(s)");
             }
         }
     }
     JRX_HIP(h, hipEventRecord(t1, s));
+    JRX_TRY(iter_end(I));
     // multi_copy! τ -> τ_o, staggered set then centre set (Stokes3D.jl:172-173)
     const i64 nc = (i64)n, nyz = (i64)nx * (ny + 1) * (nz + 1), nxz = (i64)(nx + 1) * ny * (nz + 1), nxy = (i64)(nx + 1) * (ny + 1) * nz;
-    hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, s, f->toxx, f->txx, nc, f->toyy, f->tyy, nc, f->tozz, f->tzz, nc,
-                       f->toyz, f->tyz, nyz, f->toxz, f->txz, nxz, f->toxy, f->txy, nxy);
+    hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, s, f->toxx, (const double *)f->txx, nc, f->toyy, (const double *)f->tyy, nc, f->tozz,
+                       (const double *)f->tzz, nc, f->toyz, (const double *)f->tyz, nyz, f->toxz, (const double *)f->txz, nxz, f->toxy,
+                       (const double *)f->txy, nxy);
     JRX_LAUNCH_CHECK(h);
     if (f->tyz_c && f->toyz_c && f->txz_c && f->toxz_c && f->txy_c && f->toxy_c) {
-        hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, s, f->toyz_c, f->tyz_c, nc, f->toxz_c, f->txz_c, nc, f->toxy_c, f->txy_c, nc,
-                           (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0,
-                           (double *)nullptr, (const double *)nullptr, (i64)0);
+        hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, s, f->toyz_c, (const double *)f->tyz_c, nc, f->toxz_c, (const double *)f->txz_c, nc,
+                           f->toxy_c, (const double *)f->txy_c, nc, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr,
+                           (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
         JRX_LAUNCH_CHECK(h);
     }
     JRX_HIP(h, hipStreamSynchronize(s));
@@ -402,41 +543,49 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
 }
 
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
-                                      const jrx_stokes3d_params *p, int64_t iters,
-                                      double *total_ms, double *stress_ms, double *velocity_ms)
+                                      const jrx_stokes3d_params *p, int64_t iters, double times_ms[4])
 {
     JRX_TRY(check_params(h, f, p));
     if (!etatau) return jrx_fail(h, JRX_ERR_ARG, "etatau is NULL");
     if (iters < 1) return jrx_fail(h, JRX_ERR_ARG, "iters must be >= 1");
+    if (!times_ms) return jrx_fail(h, JRX_ERR_ARG, "times_ms is NULL");
     hipStream_t s = h->stream;
-    // hipEvents around each sweep of sampled iterations *inside* the timed batch (on the stream the
+    // hipEvents around the launches of sampled iterations *inside* the timed batch (on the stream the
     // kernels run on); at most 256 samples so that event bookkeeping stays negligible
-    const bool sample = (stress_ms || velocity_ms);
     const int64_t stride = iters > 256 ? (iters + 255) / 256 : 1;
-    const int nsamp = sample ? (int)((iters + stride - 1) / stride) : 0;
+    const int nsamp = (int)((iters + stride - 1) / stride);
     std::vector<hipEvent_t> evs((size_t)nsamp * 3);
+    std::vector<int> fused((size_t)nsamp, 0);
     for (auto &e : evs) JRX_HIP(h, hipEventCreate(&e));
+    Iter3D I;
+    JRX_TRY(iter_begin(I, h, f, etatau, p));
+    JRX_HIP(h, hipStreamSynchronize(s));
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
     for (int64_t it = 0; it < iters; it++) {
-        hipEvent_t *tev = (sample && it % stride == 0) ? &evs[(size_t)(it / stride) * 3] : nullptr;
-        JRX_TRY(enqueue_iteration(h, f, etatau, p, false, tev));
+        const bool samp = it % stride == 0;
+        JRX_TRY(iter_step(I, false, it + 1 < iters, samp ? &evs[(size_t)(it / stride) * 3] : nullptr, samp ? &fused[(size_t)(it / stride)] : nullptr));
     }
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
+    JRX_TRY(iter_end(I));
     JRX_HIP(h, hipStreamSynchronize(s));
     float ms = 0.f;
     JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
-    if (total_ms) *total_ms = ms;
-    double sa = 0.0, sb = 0.0;
-    const bool split = sample && !jrx_comm_active(h);
+    times_ms[0] = ms; times_ms[1] = times_ms[2] = times_ms[3] = 0.0;
+    double sa = 0.0, sb = 0.0, sf = 0.0;
+    int na = 0, nb = 0, nf = 0;
+    const bool split = !jrx_comm_active(h);
     for (int q = 0; q < nsamp && split; q++) {
         float m1 = 0.f, m2 = 0.f;
         JRX_HIP(h, hipEventElapsedTime(&m1, evs[(size_t)q * 3], evs[(size_t)q * 3 + 1]));
         JRX_HIP(h, hipEventElapsedTime(&m2, evs[(size_t)q * 3 + 1], evs[(size_t)q * 3 + 2]));
-        sa += m1; sb += m2;
+        if (fused[q]) { sf += m2; nf++; }
+        else { sb += m2; nb++; }
+        if (m1 > 1e-3f) { sa += m1; na++; }      // a stress sweep ran as its own launch in this iteration
     }
     for (auto &e : evs) (void)hipEventDestroy(e);
-    if (stress_ms) *stress_ms = split ? sa / nsamp : 0.0;
-    if (velocity_ms) *velocity_ms = split ? sb / nsamp : 0.0;
+    if (na) times_ms[1] = sa / na;
+    if (nb) times_ms[2] = sb / nb;
+    if (nf) times_ms[3] = sf / nf;
     return JRX_OK;
 }
 

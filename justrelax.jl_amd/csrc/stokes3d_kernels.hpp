@@ -35,8 +35,15 @@ __host__ __device__ inline Lay3 make_lay(int nx, int ny, int nz)
     return L;
 }
 
+// destination of the state arrays a sweep updates.  Equal to the source arrays for in-place
+// sweeps; the fused iteration kernel ping-pongs between the caller's arrays and a scratch set.
+struct Out10 {
+    double *P, *txx, *tyy, *tzz, *tyz, *txz, *txy, *Vx, *Vy, *Vz;
+};
+
 struct SweepArgs {
     jrx_stokes3d_fields f;
+    Out10 o;
     const double *etatau;
     double _dx, _dy, _dz, dt, r, theta_dtau, eta_dtau;
     Lay3 L;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
             const double P = a.f.P[c], P0 = a.f.P0[c];
             const double rhs = -divV + (a.f.Q[c] * _dt);
             const double psi = 1.0 / (1.0 / e + _Gdt) * a.r / th;
-            a.f.P[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
+            a.o.P[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
             if (DIAG) {
                 a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
                 a.f.divV[c] = divV;
@@ -101,9 +108,9 @@ __global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
         // compute_τ! normal components (StressKernels.jl:185-198)
         const double dtr = dev_dtau_r(th, e, _Gdt);
         double tv;
-        tv = a.f.txx[c]; a.f.txx[c] = tv + dev_stress_inc(tv, a.f.toxx[c], e, exx, _Gdt, dtr);
-        tv = a.f.tyy[c]; a.f.tyy[c] = tv + dev_stress_inc(tv, a.f.toyy[c], e, eyy, _Gdt, dtr);
-        tv = a.f.tzz[c]; a.f.tzz[c] = tv + dev_stress_inc(tv, a.f.tozz[c], e, ezz, _Gdt, dtr);
+        tv = a.f.txx[c]; a.o.txx[c] = tv + dev_stress_inc(tv, a.f.toxx[c], e, exx, _Gdt, dtr);
+        tv = a.f.tyy[c]; a.o.tyy[c] = tv + dev_stress_inc(tv, a.f.toyy[c], e, eyy, _Gdt, dtr);
+        tv = a.f.tzz[c]; a.o.tzz[c] = tv + dev_stress_inc(tv, a.f.tozz[c], e, ezz, _Gdt, dtr);
     }
 
     // clamped neighbour cell indices (MiniKernels.jl:133-147)
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
         const double dtr = dev_dtau_r(th, e, _Gdt);
         const i64 c = i + (i64)L.xy1 * j + L.xyp * k;
         const double tv = a.f.txy[c];
-        a.f.txy[c] = tv + dev_stress_inc(tv, a.f.toxy[c], e, exy, _Gdt, dtr);
+        a.o.txy[c] = tv + dev_stress_inc(tv, a.f.toxy[c], e, exy, _Gdt, dtr);
         if (DIAG) a.f.exy[c] = exy;
     }
     if (cj) {   // τxz at (i,j,k) of (nx+1, ny, nz+1)
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
         const double dtr = dev_dtau_r(th, e, _Gdt);
         const i64 c = i + (i64)L.xz1 * j + L.xzp * k;
         const double tv = a.f.txz[c];
-        a.f.txz[c] = tv + dev_stress_inc(tv, a.f.toxz[c], e, exz, _Gdt, dtr);
+        a.o.txz[c] = tv + dev_stress_inc(tv, a.f.toxz[c], e, exz, _Gdt, dtr);
         if (DIAG) a.f.exz[c] = exz;
     }
     if (ci) {   // τyz at (i,j,k) of (nx, ny+1, nz+1)
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
         const double dtr = dev_dtau_r(th, e, _Gdt);
         const i64 c = i + (i64)L.yz1 * j + L.yzp * k;
         const double tv = a.f.tyz[c];
-        a.f.tyz[c] = tv + dev_stress_inc(tv, a.f.toyz[c], e, eyz, _Gdt, dtr);
+        a.o.tyz[c] = tv + dev_stress_inc(tv, a.f.toyz[c], e, eyz, _Gdt, dtr);
         if (DIAG) a.f.eyz[c] = eyz;
     }
 #undef VX
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(256) void k_velocity3d(const SweepArgs a)
                          _dz * (TXZ(i + 1, j, k + 1) - TXZ(i + 1, j, k)) - (-Pc + P[cx]) * _dx -
                          0.5 * (a.f.fx[c] + a.f.fx[cx]);
         const i64 v = (i + 1) + (i64)L.vx1 * (j + 1) + L.vxp * (k + 1);
-        a.f.Vx[v] += R * edt / (0.5 * (ec + et[cx]));
+        a.o.Vx[v] = a.f.Vx[v] + R * edt / (0.5 * (ec + et[cx]));
         if (DIAG) a.f.Rx[i + (i64)(nx - 1) * j + (i64)(nx - 1) * ny * k] = R;
     }
     if (j < ny - 1) {
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256) void k_velocity3d(const SweepArgs a)
                          _dz * (TYZ(i, j + 1, k + 1) - TYZ(i, j + 1, k)) - (-Pc + P[cy]) * _dy -
                          0.5 * (a.f.fy[c] + a.f.fy[cy]);
         const i64 v = (i + 1) + (i64)L.vy1 * (j + 1) + L.vyp * (k + 1);
-        a.f.Vy[v] += R * edt / (0.5 * (ec + et[cy]));
+        a.o.Vy[v] = a.f.Vy[v] + R * edt / (0.5 * (ec + et[cy]));
         if (DIAG) a.f.Ry[i + (i64)nx * j + (i64)nx * (ny - 1) * k] = R;
     }
     if (k < nz - 1) {
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(256) void k_velocity3d(const SweepArgs a)
         const double R = _dx * (TXZ(i + 1, j, k + 1) - TXZ(i, j, k + 1)) + _dy * (TYZ(i, j + 1, k + 1) - TYZ(i, j, k + 1)) +
                          (-a.f.tzz[c] + a.f.tzz[cz]) * _dz - (-Pc + P[cz]) * _dz - 0.5 * (a.f.fz[c] + a.f.fz[cz]);
         const i64 v = (i + 1) + (i64)L.vz1 * (j + 1) + L.vzp * (k + 1);
-        a.f.Vz[v] += R * edt / (0.5 * (ec + et[cz]));
+        a.o.Vz[v] = a.f.Vz[v] + R * edt / (0.5 * (ec + et[cz]));
         if (DIAG) a.f.Rz[c] = R;
     }
 #undef TXY
@@ -208,11 +215,12 @@ __global__ __launch_bounds__(256) void k_velocity3d(const SweepArgs a)
 
 
 // ================================================================================================
-// Version 2 ("zm"): 2.5D z-marching sweeps.  A block owns a TX x TY tile of cell columns and walks
-// KZ planes in z; the values that the next plane needs again (the k+1 velocity plane, the k plane
-// of η and G, the upper τ/P/f/ητ plane of the velocity sweep) stay in registers instead of being
-// re-read, x/y neighbours of the same plane are served by L1 (same or adjacent wave), so HBM sees
-// each array plane once per sweep apart from tile halos.
+// 2.5D z-marching sweeps.  A block owns a TX x TY tile of cell columns and walks KZ planes in z;
+// the values that the next plane needs again (the k+1 velocity plane, the k plane of η and G, the
+// upper τ/P/f/ητ plane of the velocity sweep) stay in registers instead of being re-read, x/y
+// neighbours of the same plane are served by L1 (same or adjacent wave), so HBM sees each array
+// plane once per sweep apart from tile halos.  (A first version with 64-bit indices needed 256
+// VGPRs -- one live pointer per array after loop strength reduction -- and ran at 1 wave/SIMD.)
 // ================================================================================================
 #define CC3(i_, j_, k_) ((i_) + (i64)nx * (j_) + L.cp * (k_))
 
@@ -233,7 +241,7 @@ __device__ __forceinline__ void node_xy(const SweepArgs &a, int I, int J, int k)
     const double dtr = dev_dtau_r(a.theta_dtau, e, _Gdt);
     const i64 c = I + (i64)L.xy1 * J + L.xyp * k;
     const double tv = a.f.txy[c];
-    a.f.txy[c] = tv + dev_stress_inc(tv, a.f.toxy[c], e, exy, _Gdt, dtr);
+    a.o.txy[c] = tv + dev_stress_inc(tv, a.f.toxy[c], e, exy, _Gdt, dtr);
     if (DIAG) a.f.exy[c] = exy;
 }
 template <bool DIAG>
@@ -251,7 +259,7 @@ __device__ __forceinline__ void node_xz(const SweepArgs &a, int I, int j, int Kk
     const double dtr = dev_dtau_r(a.theta_dtau, e, _Gdt);
     const i64 c = I + (i64)L.xz1 * j + L.xzp * Kk;
     const double tv = a.f.txz[c];
-    a.f.txz[c] = tv + dev_stress_inc(tv, a.f.toxz[c], e, exz, _Gdt, dtr);
+    a.o.txz[c] = tv + dev_stress_inc(tv, a.f.toxz[c], e, exz, _Gdt, dtr);
     if (DIAG) a.f.exz[c] = exz;
 }
 template <bool DIAG>
@@ -269,188 +277,10 @@ __device__ __forceinline__ void node_yz(const SweepArgs &a, int i, int J, int Kk
     const double dtr = dev_dtau_r(a.theta_dtau, e, _Gdt);
     const i64 c = i + (i64)L.yz1 * J + L.yzp * Kk;
     const double tv = a.f.tyz[c];
-    a.f.tyz[c] = tv + dev_stress_inc(tv, a.f.toyz[c], e, eyz, _Gdt, dtr);
+    a.o.tyz[c] = tv + dev_stress_inc(tv, a.f.toyz[c], e, eyz, _Gdt, dtr);
     if (DIAG) a.f.eyz[c] = eyz;
 }
 
-template <bool DIAG, int TX, int TY, int KZ>
-__global__ __launch_bounds__(TX *TY) void k_stress3d_zm(const SweepArgs a)
-{
-    const Lay3 &L = a.L;
-    const int nx = L.nx, ny = L.ny, nz = L.nz;
-    const int i = blockIdx.x * TX + threadIdx.x;
-    const int j = blockIdx.y * TY + threadIdx.y;
-    const int kb = blockIdx.z * KZ;
-    if (i >= nx || j >= ny) return;
-    const int kend = min(kb + KZ, nz);
-    const int im = max(i - 1, 0), jm = max(j - 1, 0);
-    const bool xhi = (i == nx - 1), yhi = (j == ny - 1);
-    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau, _dt = 1.0 / dt, rr = a.r;
-
-    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
-    const double *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
-
-    // running offsets (advance by one plane per step)
-    i64 oc = CC3(i, j, kb);                                             // centre arrays, level k
-    i64 ocx = CC3(im, j, kb), ocy = CC3(i, jm, kb), ocxy = CC3(im, jm, kb);
-    i64 ovx = i + (i64)L.vx1 * (j + 1) + L.vxp * (kb + 1);            // Vx[i, j+1, k+1]
-    i64 ovy = (i + 1) + (i64)L.vy1 * j + L.vyp * (kb + 1);            // Vy[i+1, j, k+1]
-    i64 ovz = (i + 1) + (i64)L.vz1 * (j + 1) + L.vzp * (kb + 1);      // Vz[i+1, j+1, k+1]
-    i64 oxy = i + (i64)L.xy1 * j + L.xyp * kb;
-    i64 oxz = i + (i64)L.xz1 * j + L.xzp * kb;
-    i64 oyz = i + (i64)L.yz1 * j + L.yzp * kb;
-
-    // carried values: level k of V, level k-1 (clamped) of η, G
-    double a_p = Vx[ovx - L.vxp], b_p = Vy[ovy - L.vyp];
-    double c_p = Vz[ovz - L.vzp], cx_p = Vz[ovz - L.vzp - 1], cy_p = Vz[ovz - L.vzp - L.vz1];
-    const i64 back = kb > 0 ? L.cp : 0;
-    double e_p = eta[oc - back], ex_p = eta[ocx - back], ey_p = eta[ocy - back];
-    double g_p = G[oc - back], gx_p = G[ocx - back], gy_p = G[ocy - back];
-
-    for (int k = kb; k < kend; ++k) {
-        // level k+1 velocities
-        const double va = Vx[ovx], vax = Vx[ovx + 1], vay = Vx[ovx - L.vx1];
-        const double vb = Vy[ovy], vby = Vy[ovy + L.vy1], vbx = Vy[ovy - 1];
-        const double vc = Vz[ovz], vcx = Vz[ovz - 1], vcy = Vz[ovz - L.vz1];
-        // level k material
-        const double e = eta[oc], ex = eta[ocx], ey = eta[ocy], exy_ = eta[ocxy];
-        const double g = G[oc], gx = G[ocx], gy = G[ocy], gxy = G[ocxy];
-
-        {   // centre (i,j,k)
-            const double dxi = (-va + vax) * _dx;
-            const double dyi = (-vb + vby) * _dy;
-            const double dzi = (-c_p + vc) * _dz;
-            const double divV = dxi + dyi + dzi;
-            const double _Gdt = 1.0 / (g * dt);
-            const double _Kdt = 1.0 / (a.f.K[oc] * dt);
-            const double P = a.f.P[oc], P0 = a.f.P0[oc];
-            const double rhs = -divV + (a.f.Q[oc] * _dt);
-            const double psi = 1.0 / (1.0 / e + _Gdt) * rr / th;
-            a.f.P[oc] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
-            const double d3 = divV * (1.0 / 3.0);
-            const double exx = dxi - d3, eyy = dyi - d3, ezz = dzi - d3;
-            if (DIAG) {
-                a.f.RP[oc] = fma(-(P - P0), _Kdt, rhs);
-                a.f.divV[oc] = divV;
-                a.f.exx[oc] = exx; a.f.eyy[oc] = eyy; a.f.ezz[oc] = ezz;
-            }
-            const double dtr = dev_dtau_r(th, e, _Gdt);
-            double tv;
-            tv = a.f.txx[oc]; a.f.txx[oc] = tv + dev_stress_inc(tv, a.f.toxx[oc], e, exx, _Gdt, dtr);
-            tv = a.f.tyy[oc]; a.f.tyy[oc] = tv + dev_stress_inc(tv, a.f.toyy[oc], e, eyy, _Gdt, dtr);
-            tv = a.f.tzz[oc]; a.f.tzz[oc] = tv + dev_stress_inc(tv, a.f.tozz[oc], e, ezz, _Gdt, dtr);
-        }
-        {   // τxy (i,j,k)
-            const double sxy = 0.5 * (_dy * (va - vay) + _dx * (vb - vbx));
-            const double ee = 0.25 * (exy_ + ey + ex + e);
-            const double gg = 0.25 * (gxy + gy + gx + g);
-            const double _Gdt = 1.0 / (gg * dt);
-            const double dtr = dev_dtau_r(th, ee, _Gdt);
-            const double tv = a.f.txy[oxy];
-            a.f.txy[oxy] = tv + dev_stress_inc(tv, a.f.toxy[oxy], ee, sxy, _Gdt, dtr);
-            if (DIAG) a.f.exy[oxy] = sxy;
-        }
-        {   // τxz (i,j,k)
-            const double sxz = 0.5 * (_dz * (va - a_p) + _dx * (c_p - cx_p));
-            const double ee = 0.25 * (ex_p + e_p + ex + e);
-            const double gg = 0.25 * (gx_p + g_p + gx + g);
-            const double _Gdt = 1.0 / (gg * dt);
-            const double dtr = dev_dtau_r(th, ee, _Gdt);
-            const double tv = a.f.txz[oxz];
-            a.f.txz[oxz] = tv + dev_stress_inc(tv, a.f.toxz[oxz], ee, sxz, _Gdt, dtr);
-            if (DIAG) a.f.exz[oxz] = sxz;
-        }
-        {   // τyz (i,j,k)
-            const double syz = 0.5 * (_dz * (vb - b_p) + _dy * (c_p - cy_p));
-            const double ee = 0.25 * (ey_p + e_p + ey + e);
-            const double gg = 0.25 * (gy_p + g_p + gy + g);
-            const double _Gdt = 1.0 / (gg * dt);
-            const double dtr = dev_dtau_r(th, ee, _Gdt);
-            const double tv = a.f.tyz[oyz];
-            a.f.tyz[oyz] = tv + dev_stress_inc(tv, a.f.toyz[oyz], ee, syz, _Gdt, dtr);
-            if (DIAG) a.f.eyz[oyz] = syz;
-        }
-        // upper boundary planes i = nx, j = ny (one extra node column per boundary thread)
-        if (xhi) { node_xy<DIAG>(a, nx, j, k); node_xz<DIAG>(a, nx, j, k); }
-        if (yhi) { node_xy<DIAG>(a, i, ny, k); node_yz<DIAG>(a, i, ny, k); }
-        if (xhi && yhi) node_xy<DIAG>(a, nx, ny, k);
-
-        a_p = va; b_p = vb; c_p = vc; cx_p = vcx; cy_p = vcy;
-        e_p = e; ex_p = ex; ey_p = ey; g_p = g; gx_p = gx; gy_p = gy;
-        oc += L.cp; ocx += L.cp; ocy += L.cp; ocxy += L.cp;
-        ovx += L.vxp; ovy += L.vyp; ovz += L.vzp;
-        oxy += L.xyp; oxz += L.xzp; oyz += L.yzp;
-    }
-    if (kend == nz) {   // top plane k = nz of the xz / yz nodes
-        node_xz<DIAG>(a, i, j, nz);
-        node_yz<DIAG>(a, i, j, nz);
-        if (xhi) node_xz<DIAG>(a, nx, j, nz);
-        if (yhi) node_yz<DIAG>(a, i, ny, nz);
-    }
-}
-
-// Velocity sweep, z-marching.  Sub-box [i0,i1) x [j0,j1) x [k0,k1) of the cell box.
-template <bool DIAG, int TX, int TY, int KZ>
-__global__ __launch_bounds__(TX *TY) void k_velocity3d_zm(const SweepArgs a)
-{
-    const Lay3 &L = a.L;
-    const int nx = L.nx, ny = L.ny, nz = L.nz;
-    const int i = a.i0 + blockIdx.x * TX + threadIdx.x;
-    const int j = a.j0 + blockIdx.y * TY + threadIdx.y;
-    const int kb = a.k0 + blockIdx.z * KZ;
-    if (i >= a.i1 || j >= a.j1) return;
-    const int kend = min(kb + KZ, a.k1);
-    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, edt = a.eta_dtau;
-    const bool hx = i < nx - 1, hy = j < ny - 1;
-    const double *__restrict__ P = a.f.P, *__restrict__ et = a.etatau;
-    const double *__restrict__ txy = a.f.txy, *__restrict__ txz = a.f.txz, *__restrict__ tyz = a.f.tyz;
-
-    i64 oc = CC3(i, j, kb);
-    i64 oxy = i + (i64)L.xy1 * j + L.xyp * kb;          // τxy(i, j, k)
-    i64 oxz = i + (i64)L.xz1 * j + L.xzp * (kb + 1);    // τxz(i, j, k+1)
-    i64 oyz = i + (i64)L.yz1 * j + L.yzp * (kb + 1);    // τyz(i, j, k+1)
-    i64 ovx = (i + 1) + (i64)L.vx1 * (j + 1) + L.vxp * (kb + 1);
-    i64 ovy = (i + 1) + (i64)L.vy1 * (j + 1) + L.vyp * (kb + 1);
-    i64 ovz = (i + 1) + (i64)L.vz1 * (j + 1) + L.vzp * (kb + 1);
-    i64 orx = i + (i64)(nx - 1) * j + (i64)(nx - 1) * ny * kb;
-    i64 ory = i + (i64)nx * j + (i64)nx * (ny - 1) * kb;
-
-    // carried: level-k values that were the "upper" loads of the previous step
-    double Pc = P[oc], ec = et[oc], tzz_c = a.f.tzz[oc], fz_c = a.f.fz[oc];
-    double s10 = txz[oxz + 1 - L.xzp];      // τxz(i+1, j, k)
-    double r10 = tyz[oyz + L.yz1 - L.yzp];  // τyz(i, j+1, k)
-
-    for (int k = kb; k < kend; ++k) {
-        const bool hz = k < nz - 1;
-        const double q11 = txy[oxy + 1 + L.xy1], q10 = txy[oxy + 1], q01 = txy[oxy + L.xy1];
-        const double s11 = txz[oxz + 1], s01 = txz[oxz];
-        const double r11 = tyz[oyz + L.yz1], r01 = tyz[oyz];
-        double Pz = 0.0, ez = 0.0, tzz_z = 0.0, fz_z = 0.0;
-        if (hz) { Pz = P[oc + L.cp]; ez = et[oc + L.cp]; tzz_z = a.f.tzz[oc + L.cp]; fz_z = a.f.fz[oc + L.cp]; }
-        if (hx) {
-            const double R = (-a.f.txx[oc] + a.f.txx[oc + 1]) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + P[oc + 1]) * _dx -
-                             0.5 * (a.f.fx[oc] + a.f.fx[oc + 1]);
-            a.f.Vx[ovx] += R * edt / (0.5 * (ec + et[oc + 1]));
-            if (DIAG) a.f.Rx[orx] = R;
-        }
-        if (hy) {
-            const double R = _dx * (q11 - q01) + _dy * (a.f.tyy[oc + nx] - a.f.tyy[oc]) + _dz * (r11 - r10) - (-Pc + P[oc + nx]) * _dy -
-                             0.5 * (a.f.fy[oc] + a.f.fy[oc + nx]);
-            a.f.Vy[ovy] += R * edt / (0.5 * (ec + et[oc + nx]));
-            if (DIAG) a.f.Ry[ory] = R;
-        }
-        if (hz) {
-            const double R = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz - 0.5 * (fz_c + fz_z);
-            a.f.Vz[ovz] += R * edt / (0.5 * (ec + ez));
-            if (DIAG) a.f.Rz[oc] = R;
-        }
-        Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11;
-        oc += L.cp; oxy += L.xyp; oxz += L.xzp; oyz += L.yzp;
-        ovx += L.vxp; ovy += L.vyp; ovz += L.vzp;
-        orx += (i64)(nx - 1) * ny; ory += (i64)nx * (ny - 1);
-    }
-}
-#undef CC3
 
 // ================================================================================================
 // Version 3 ("zb"): the z-marching sweeps with (a) 32-bit byte offsets against SGPR base pointers
@@ -548,7 +378,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
             const double _Kdt = 1.0 / (Kc * dt);
             const double rhs = -divV + (Qc * _dt);
             const double psi = 1.0 / (1.0 / e + _Gdt) * rr / th;
-            STB(f.P, oc, (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi));
+            STB(a.o.P, oc, (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi));
             const double d3 = divV * (1.0 / 3.0);
             const double exx = dxi - d3, eyy = dyi - d3, ezz = dzi - d3;
             if (DIAG) {
@@ -557,9 +387,9 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
                 STB(f.exx, oc, exx); STB(f.eyy, oc, eyy); STB(f.ezz, oc, ezz);
             }
             const double dtr = dev_dtau_r(th, e, _Gdt);
-            STB(f.txx, oc, txx + dev_stress_inc(txx, toxx, e, exx, _Gdt, dtr));
-            STB(f.tyy, oc, tyy + dev_stress_inc(tyy, toyy, e, eyy, _Gdt, dtr));
-            STB(f.tzz, oc, tzz + dev_stress_inc(tzz, tozz, e, ezz, _Gdt, dtr));
+            STB(a.o.txx, oc, txx + dev_stress_inc(txx, toxx, e, exx, _Gdt, dtr));
+            STB(a.o.tyy, oc, tyy + dev_stress_inc(tyy, toyy, e, eyy, _Gdt, dtr));
+            STB(a.o.tzz, oc, tzz + dev_stress_inc(tzz, tozz, e, ezz, _Gdt, dtr));
         }
         {   // τxy (i,j,k)
             const double s_ = 0.5 * (_dy * (va - vay) + _dx * (vb - vbx));
@@ -567,7 +397,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
             const double gg = 0.25 * (gxy + gy + gx + g);
             const double _Gdt = 1.0 / (gg * dt);
             const double dtr = dev_dtau_r(th, ee, _Gdt);
-            STB(f.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
+            STB(a.o.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
             if (DIAG) STB(f.exy, oxy, s_);
         }
         {   // τxz (i,j,k)
@@ -576,7 +406,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
             const double gg = 0.25 * (gx_p + g_p + gx + g);
             const double _Gdt = 1.0 / (gg * dt);
             const double dtr = dev_dtau_r(th, ee, _Gdt);
-            STB(f.txz, oxz, txz + dev_stress_inc(txz, toxz, ee, s_, _Gdt, dtr));
+            STB(a.o.txz, oxz, txz + dev_stress_inc(txz, toxz, ee, s_, _Gdt, dtr));
             if (DIAG) STB(f.exz, oxz, s_);
         }
         {   // τyz (i,j,k)
@@ -585,7 +415,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
             const double gg = 0.25 * (gy_p + g_p + gy + g);
             const double _Gdt = 1.0 / (gg * dt);
             const double dtr = dev_dtau_r(th, ee, _Gdt);
-            STB(f.tyz, oyz, tyz + dev_stress_inc(tyz, toyz, ee, s_, _Gdt, dtr));
+            STB(a.o.tyz, oyz, tyz + dev_stress_inc(tyz, toyz, ee, s_, _Gdt, dtr));
             if (DIAG) STB(f.eyz, oyz, s_);
         }
         if (EDGES) {
@@ -655,21 +485,219 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs 
         const double vx = LDB(f.Vx, ovx), vy = LDB(f.Vy, ovy), vz = LDB(f.Vz, ovz);
         if (hx) {
             const double R = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx - 0.5 * (fx_c + fx_x);
-            STB(f.Vx, ovx, vx + R * edt / (0.5 * (ec + ex)));
+            STB(a.o.Vx, ovx, vx + R * edt / (0.5 * (ec + ex)));
             if (DIAG) STB(f.Rx, orx, R);
         }
         if (hy) {
             const double R = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy - 0.5 * (fy_c + fy_y);
-            STB(f.Vy, ovy, vy + R * edt / (0.5 * (ec + ey)));
+            STB(a.o.Vy, ovy, vy + R * edt / (0.5 * (ec + ey)));
             if (DIAG) STB(f.Ry, ory, R);
         }
         if (hz) {
             const double R = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz - 0.5 * (fz_c + fz_z);
-            STB(f.Vz, ovz, vz + R * edt / (0.5 * (ec + ez)));
+            STB(a.o.Vz, ovz, vz + R * edt / (0.5 * (ec + ez)));
             if (DIAG) STB(f.Rz, oc, R);
         }
         Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11;
         oc += sc; oxy += sxy; oxz += sxz; oyz += syz; ovx += svx; ovy += svy; ovz += svz; orx += srx; ory += sry;
+    }
+}
+
+// ================================================================================================
+// Fused iteration kernel: velocity sweep of iteration m + flow BCs (low faces) + stress sweep of
+// iteration m+1 in one pass over memory.
+//
+//   reads  (src set)  P τ(6) V(3) f(3) ητ | P0 Q η K G τ_o(6)      = 25 array passes
+//   writes (dst set)  V(3) P τ(6)                                    = 10 array passes
+//
+// i.e. 35 instead of the 45 passes of the two separate sweeps: P and τ(6) are not re-read and the new
+// V(3) goes from the velocity update to the strain rates through LDS.  src and dst are different
+// buffers (ping-pong between the caller's arrays and a library-owned scratch set): the velocity update
+// of a neighbouring tile still needs the old P, τ while this tile already writes the new ones.
+//
+// Tiles overlap by one cell row/column on the low side: a block of TX x TY threads updates the
+// velocities of TX x TY cell columns ("B cells") and the stresses of the (TX-1) x (TY-1) columns
+// whose low-side neighbours it has ("A cells"): stress at cell (i,j,k) needs the new velocities of
+// the cells (i,j,k) (i-1,j,k) (i,j-1,k) (i-1,j-1,k) (i-1,j,k-1) (i,j-1,k-1) (i,j,k-1) only.
+// The block marches KZ planes in z (plus one prologue plane below the chunk); per plane: B phase
+// -> new V into LDS (+ global for the cells the block owns) -> __syncthreads -> A phase.
+// Ghost / boundary-plane velocities on the LOW faces are produced on the fly from the boundary
+// condition of that face (free slip: copy, no slip: negate / zero, none: the prescribed value in
+// memory); the high-face planes i = nx, j = ny, k = nz are finished by the per-node kernel after the
+// regular BC kernels have run on the new V.  Periodic faces and multi-rank halos are not fused.
+// ================================================================================================
+struct FusedBC {
+    // low faces: free-slip / no-slip flags; high faces: only "normal velocity = 0" matters here
+    int fsL, nsL, fsF, nsF, fsK0, nsK0, nsR, nsBk, nsK1;
+};
+
+template <int TX, int TY, int KZ, int MINW>
+__global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty)
+{
+    __shared__ double sV[2][3][TY][TX];
+    const Lay3 &L = a.L;
+    const int nx = L.nx, ny = L.ny, nz = L.nz;
+    const jrx_stokes3d_fields &f = a.f;
+    const double *et = a.etatau;
+    const int tx = (int)(threadIdx.x % TX), ty = (int)(threadIdx.x / TX);
+    const int tile = blockIdx.x;
+    const int tix = tile % ntx, tr = tile / ntx, tiy = tr % nty, tiz = tr / nty;
+    const int i = tix * (TX - 1) - 1 + tx;      // cell column of this thread
+    const int j = tiy * (TY - 1) - 1 + ty;
+    const int kb = tiz * KZ;
+    const int kend = min(kb + KZ, nz);
+    const bool bvalid = i >= 0 && j >= 0 && i < nx && j < ny;
+    const bool avalid = bvalid && tx >= 1 && ty >= 1;
+    const bool hx = i < nx - 1, hy = j < ny - 1;
+    const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau, _dt = 1.0 / dt, rr = a.r, edt = a.eta_dtau;
+
+    const u32 sc = (u32)L.cp * 8u, svx = (u32)L.vxp * 8u, svy = (u32)L.vyp * 8u, svz = (u32)L.vzp * 8u;
+    const u32 sxy = (u32)L.xyp * 8u, sxz = (u32)L.xzp * 8u, syz = (u32)L.yzp * 8u;
+    const u32 rc = (u32)nx * 8u, rxy = (u32)L.xy1 * 8u, ryz = (u32)L.yz1 * 8u;
+    const u32 rvx = (u32)L.vx1 * 8u, rvy = (u32)L.vy1 * 8u, rvz = (u32)L.vz1 * 8u;
+    const int ic = bvalid ? i : 0, jc = bvalid ? j : 0;          // keep addresses in range for idle threads
+    const int kfirst = kb > 0 ? kb - 1 : 0;
+    u32 oc = 8u * (u32)(ic + nx * jc) + sc * (u32)kfirst;
+    u32 oxy = 8u * (u32)(ic + L.xy1 * jc) + sxy * (u32)kfirst;
+    u32 oxz = 8u * (u32)(ic + L.xz1 * jc) + sxz * (u32)(kfirst + 1);
+    u32 oyz = 8u * (u32)(ic + L.yz1 * jc) + syz * (u32)(kfirst + 1);
+    u32 ovx = 8u * (u32)((ic + 1) + L.vx1 * (jc + 1)) + svx * (u32)(kfirst + 1);   // Vx[i+1, j+1, k+1]
+    u32 ovy = 8u * (u32)((ic + 1) + L.vy1 * (jc + 1)) + svy * (u32)(kfirst + 1);
+    u32 ovz = 8u * (u32)((ic + 1) + L.vz1 * (jc + 1)) + svz * (u32)(kfirst + 1);
+    const u32 dx1 = hx ? 8u : 0u, dy1 = hy ? rc : 0u;
+    const int im = max(ic - 1, 0), jm = max(jc - 1, 0);
+    const u32 dcx = 8u * (u32)(ic - im), dcy = rc * (u32)(jc - jm);
+
+    // velocity-sweep carries (plane k values that were the upper loads of the previous plane)
+    double Pc = 0, ec = 0, tzz_c = 0, fz_c = 0, s10 = 0, r10 = 0, s01p = 0, r01p = 0;
+    if (bvalid) {
+        Pc = LDB(f.P, oc); ec = LDB(et, oc); tzz_c = LDB(f.tzz, oc); fz_c = LDB(f.fz, oc);
+        s10 = LDB(f.txz, oxz + 8u - sxz); r10 = LDB(f.tyz, oyz + ryz - syz);
+        s01p = LDB(f.txz, oxz - sxz); r01p = LDB(f.tyz, oyz - syz);
+    }
+    // stress-sweep carries
+    double a_p = 0, b_p = 0, c_p = 0, cx_p = 0, cy_p = 0, e_p = 0, ex_p = 0, ey_p = 0, g_p = 0, gx_p = 0, gy_p = 0;
+
+    for (int k = kfirst; k < kend; ++k) {
+        const bool hz = k < nz - 1;
+        const bool live = k >= kb;                 // false only on the prologue plane below the chunk
+        const int slot = k & 1;
+        double vxn = 0, vyn = 0, vzn = 0, txx_c = 0, tyy_c = 0, P_k = Pc, tzz_k = tzz_c, s01k = s01p, r01k = r01p;
+        // stress-sweep operands that do not depend on the new velocities: issued before the barrier so that
+        // one memory round trip per plane serves both phases
+        double e = 0, ex = 0, ey = 0, exy_ = 0, g = 0, gx = 0, gy = 0, gxy = 0, P0 = 0, Kc = 0, Qc = 0;
+        double toxx = 0, toyy = 0, tozz = 0, txy = 0, toxy = 0, toxz = 0, toyz = 0;
+        if (avalid) {
+            e = LDB(f.eta, oc); ex = LDB(f.eta, oc - dcx); ey = LDB(f.eta, oc - dcy);
+            g = LDB(f.G, oc); gx = LDB(f.G, oc - dcx); gy = LDB(f.G, oc - dcy);
+            if (live) {
+                exy_ = LDB(f.eta, oc - dcx - dcy); gxy = LDB(f.G, oc - dcx - dcy);
+                P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
+                toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
+                txy = LDB(f.txy, oxy); toxy = LDB(f.toxy, oxy);
+                toxz = LDB(f.toxz, oxz - sxz); toyz = LDB(f.toyz, oyz - syz);
+            }
+        }
+        if (bvalid) {
+            const u32 dz1 = hz ? sc : 0u;
+            const double q11 = LDB(f.txy, oxy + 8u + rxy), q10 = LDB(f.txy, oxy + 8u), q01 = LDB(f.txy, oxy + rxy);
+            const double s11 = LDB(f.txz, oxz + 8u), s01 = LDB(f.txz, oxz);
+            const double r11 = LDB(f.tyz, oyz + ryz), r01 = LDB(f.tyz, oyz);
+            const double Pz = LDB(f.P, oc + dz1), ez = LDB(et, oc + dz1), tzz_z = LDB(f.tzz, oc + dz1), fz_z = LDB(f.fz, oc + dz1);
+            const double Px = LDB(f.P, oc + dx1), Py = LDB(f.P, oc + dy1), ex = LDB(et, oc + dx1), ey = LDB(et, oc + dy1);
+            txx_c = LDB(f.txx, oc); tyy_c = LDB(f.tyy, oc);
+            const double txx_x = LDB(f.txx, oc + dx1), tyy_y = LDB(f.tyy, oc + dy1);
+            const double fx_c = LDB(f.fx, oc), fx_x = LDB(f.fx, oc + dx1), fy_c = LDB(f.fy, oc), fy_y = LDB(f.fy, oc + dy1);
+            const double vx = LDB(f.Vx, ovx), vy = LDB(f.Vy, ovy), vz = LDB(f.Vz, ovz);
+            const bool own = avalid && live;
+            if (hx) {
+                const double R = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx - 0.5 * (fx_c + fx_x);
+                vxn = vx + R * edt / (0.5 * (ec + ex));
+                if (own) STB(a.o.Vx, ovx, vxn);
+            } else vxn = bc.nsR ? 0.0 : vx;
+            if (hy) {
+                const double R = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy - 0.5 * (fy_c + fy_y);
+                vyn = vy + R * edt / (0.5 * (ec + ey));
+                if (own) STB(a.o.Vy, ovy, vyn);
+            } else vyn = bc.nsBk ? 0.0 : vy;
+            if (hz) {
+                const double R = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz - 0.5 * (fz_c + fz_z);
+                vzn = vz + R * edt / (0.5 * (ec + ez));
+                if (own) STB(a.o.Vz, ovz, vzn);
+            } else vzn = bc.nsK1 ? 0.0 : vz;
+            Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11; s01p = s01; r01p = r01;
+            sV[slot][0][ty][tx] = vxn; sV[slot][1][ty][tx] = vyn; sV[slot][2][ty][tx] = vzn;
+        }
+        __syncthreads();
+        if (avalid) {
+            // ---- new velocities around cell (i,j,k): LDS, own registers, or the low-face boundary rule
+            double va, vay, vb, vbx, vcx, vcy;
+            const double vax = vxn, vby = vyn, vc = vzn;
+            const u32 gvx = ovx - 8u, gvy = ovy - rvy, gvz = ovz;       // Vx[i,j+1,k+1], Vy[i+1,j,k+1], Vz[i+1,j+1,k+1]
+            va = i > 0 ? sV[slot][0][ty][tx - 1] : (bc.nsL ? 0.0 : LDB(f.Vx, gvx));
+            if (j > 0) vay = i > 0 ? sV[slot][0][ty - 1][tx - 1] : (bc.nsL ? 0.0 : LDB(f.Vx, gvx - rvx));
+            else vay = bc.fsF ? va : (bc.nsF ? -va : LDB(f.Vx, gvx - rvx));
+            vb = j > 0 ? sV[slot][1][ty - 1][tx] : (bc.nsF ? 0.0 : LDB(f.Vy, gvy));
+            if (i > 0) vbx = j > 0 ? sV[slot][1][ty - 1][tx - 1] : (bc.nsF ? 0.0 : LDB(f.Vy, gvy - 8u));
+            else vbx = bc.fsL ? vb : (bc.nsL ? -vb : LDB(f.Vy, gvy - 8u));
+            vcx = i > 0 ? sV[slot][2][ty][tx - 1] : (bc.fsL ? vc : (bc.nsL ? -vc : LDB(f.Vz, gvz - 8u)));
+            vcy = j > 0 ? sV[slot][2][ty - 1][tx] : (bc.fsF ? vc : (bc.nsF ? -vc : LDB(f.Vz, gvz - rvz)));
+            if (k == 0) {
+                // plane K = 0 of V: ghost of Vx, Vy (tangential), boundary plane of Vz (normal)
+                a_p = bc.fsK0 ? va : (bc.nsK0 ? -va : LDB(f.Vx, gvx - svx));
+                b_p = bc.fsK0 ? vb : (bc.nsK0 ? -vb : LDB(f.Vy, gvy - svy));
+                c_p = bc.nsK0 ? 0.0 : LDB(f.Vz, gvz - svz);
+                cx_p = i > 0 ? (bc.nsK0 ? 0.0 : LDB(f.Vz, gvz - svz - 8u)) : (bc.fsL ? c_p : (bc.nsL ? -c_p : LDB(f.Vz, gvz - svz - 8u)));
+                cy_p = j > 0 ? (bc.nsK0 ? 0.0 : LDB(f.Vz, gvz - svz - rvz)) : (bc.fsF ? c_p : (bc.nsF ? -c_p : LDB(f.Vz, gvz - svz - rvz)));
+                e_p = e; ex_p = ex; ey_p = ey; g_p = g; gx_p = gx; gy_p = gy;
+            }
+            if (live) {
+                {   // centre
+                    const double dxi = (-va + vax) * _dx;
+                    const double dyi = (-vb + vby) * _dy;
+                    const double dzi = (-c_p + vc) * _dz;
+                    const double divV = dxi + dyi + dzi;
+                    const double _Gdt = 1.0 / (g * dt);
+                    const double _Kdt = 1.0 / (Kc * dt);
+                    const double rhs = -divV + (Qc * _dt);
+                    const double psi = 1.0 / (1.0 / e + _Gdt) * rr / th;
+                    STB(a.o.P, oc, (fma(P0, _Kdt, rhs) * psi + P_k) / (1.0 + _Kdt * psi));
+                    const double d3 = divV * (1.0 / 3.0);
+                    const double exx = dxi - d3, eyy = dyi - d3, ezz = dzi - d3;
+                    const double dtr = dev_dtau_r(th, e, _Gdt);
+                    STB(a.o.txx, oc, txx_c + dev_stress_inc(txx_c, toxx, e, exx, _Gdt, dtr));
+                    STB(a.o.tyy, oc, tyy_c + dev_stress_inc(tyy_c, toyy, e, eyy, _Gdt, dtr));
+                    STB(a.o.tzz, oc, tzz_k + dev_stress_inc(tzz_k, tozz, e, ezz, _Gdt, dtr));
+                }
+                {   // τxy (i,j,k)
+                    const double s_ = 0.5 * (_dy * (va - vay) + _dx * (vb - vbx));
+                    const double ee = 0.25 * (exy_ + ey + ex + e);
+                    const double gg = 0.25 * (gxy + gy + gx + g);
+                    const double _Gdt = 1.0 / (gg * dt);
+                    const double dtr = dev_dtau_r(th, ee, _Gdt);
+                    STB(a.o.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
+                }
+                {   // τxz (i,j,k)
+                    const double s_ = 0.5 * (_dz * (va - a_p) + _dx * (c_p - cx_p));
+                    const double ee = 0.25 * (ex_p + e_p + ex + e);
+                    const double gg = 0.25 * (gx_p + g_p + gx + g);
+                    const double _Gdt = 1.0 / (gg * dt);
+                    const double dtr = dev_dtau_r(th, ee, _Gdt);
+                    STB(a.o.txz, oxz - sxz, s01k + dev_stress_inc(s01k, toxz, ee, s_, _Gdt, dtr));
+                }
+                {   // τyz (i,j,k)
+                    const double s_ = 0.5 * (_dz * (vb - b_p) + _dy * (c_p - cy_p));
+                    const double ee = 0.25 * (ey_p + e_p + ey + e);
+                    const double gg = 0.25 * (gy_p + g_p + gy + g);
+                    const double _Gdt = 1.0 / (gg * dt);
+                    const double dtr = dev_dtau_r(th, ee, _Gdt);
+                    STB(a.o.tyz, oyz - syz, r01k + dev_stress_inc(r01k, toyz, ee, s_, _Gdt, dtr));
+                }
+            }
+            a_p = va; b_p = vb; c_p = vc; cx_p = vcx; cy_p = vcy;
+            e_p = e; ex_p = ex; ey_p = ey; g_p = g; gx_p = gx; gy_p = gy;
+        }
+        oc += sc; oxy += sxy; oxz += sxz; oyz += syz; ovx += svx; ovy += svy; ovz += svz;
     }
 }
 

@@ -199,20 +199,53 @@ def test_cpu_arrays_are_refused(jr):
         jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
 
 
-def test_kernel_variants_are_bit_identical(env):
-    """The z-marching sweeps and the per-node kernels must agree bit for bit (same operation order)."""
+@pytest.mark.parametrize("ni,bcs", [((130, 20, 17), "free_slip"), ((70, 12, 9), "free_slip"), ((130, 17, 20), "no_slip"),
+                                    ((97, 9, 33), "none"), ((64, 16, 40), "no_slip"), ((200, 8, 8), "free_slip")])
+def test_kernel_variants_are_bit_identical(env, ni, bcs):
+    """Fused iteration kernel (0), per-node kernels (1) and unfused z-marching sweeps (2) must agree bit for bit:
+    same operation order, and the fused kernel's on-the-fly low-face boundary rules reproduce flow_bcs!."""
     import ctypes as C
     jr = env["jr"]
     from justrelax_jl_amd import _lib
-    s = jr.miniapps.random_fields3d((130, 20, 17), iterMax=10, nout=5)
+    s = jr.miniapps.random_fields3d(ni, bcs=bcs, iterMax=23, nout=7)
     s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
-    outs = []
+    outs, its = [], []
     h = _lib.default_handle()
-    for variant in (0, 1):
-        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
-        stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
-        jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
-        outs.append(env["down"](stokes))
-    h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
-    for k in outs[0]:
-        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    try:
+        for variant in (0, 1, 2):
+            h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+            its.append((r.iter, tuple(r.err_evo1)))
+            outs.append(env["down"](stokes))
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
+    assert its[0] == its[1] == its[2] and its[0][0] == 24
+    for v in (1, 2):
+        for k in outs[0]:
+            m = env["checks"].interior_mask3d(k, outs[0][k].shape)
+            assert np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)
+
+
+def test_iterate_timed_leaves_state_in_user_arrays(env):
+    """bench hook: K back-to-back iterations through the fused pipeline == K iterations of the per-node kernels."""
+    import ctypes as C
+    jr, st = env["jr"], env["st"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields3d((130, 16, 12), iterMax=5, nout=100)
+    h = _lib.default_handle()
+    outs = []
+    try:
+        for variant in (0, 1):
+            h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            et = jr.fzeros(s.ni, stokes.P.device)
+            jr.compute_maxloc_(et, stokes.viscosity.η)
+            t = st.iterate_timed_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, et, s.dt, 9)
+            assert t[0] > 0 and (t[3] > 0) == (variant == 0)
+            outs.append(env["down"](stokes))
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
+    for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy"):
+        m = env["checks"].interior_mask3d(k, outs[0][k].shape)
+        assert np.array_equal(outs[0][k][m], outs[1][k][m]), k
