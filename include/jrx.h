@@ -60,9 +60,9 @@ jrx_status jrx_destroy(jrx_handle *h);
 const char *jrx_last_error(const jrx_handle *h);   /* h may be NULL: last creation error */
 int32_t jrx_version(void);
 
-/* Tuning / debugging knobs.  Keys: "kernel_variant" (0 = automatic, default: fused iteration kernel where it
- * applies, z-marching sweeps otherwise; 1 = simple one-thread-per-node kernels; 2 = z-marching sweeps, no fusion
- * -- all three produce bit-identical results). */
+/* Tuning / debugging knobs.  Keys: "kernel_variant": 0 = default (z-marching fused sweeps, two per iteration);
+ * 1 = simple one-thread-per-node kernels; 3 = experimental single fused iteration kernel (velocity sweep m + BCs +
+ * stress sweep m+1 with ping-pong state; same results, currently not faster).  All produce bit-identical results. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)

@@ -89,8 +89,8 @@ template <int TX, int TY, int KZ>
 jrx_status launch_stress_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag)
 {
     const TileMap tm = make_tilemap(a.L.nx, a.L.ny, a.L.nz, TX, TY, KZ);
-    if (diag) hipLaunchKernelGGL((k_stress3d_zb<true, TX, TY, KZ, 4, false, false>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
-    else hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, false>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    if (diag) hipLaunchKernelGGL((k_stress3d_zb<true, TX, TY, KZ, 4, false, 8>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, 8>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -99,8 +99,8 @@ template <int TX, int TY, int KZ>
 jrx_status launch_velocity_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag)
 {
     const TileMap tm = make_tilemap(a.i1 - a.i0, a.j1 - a.j0, a.k1 - a.k0, TX, TY, KZ);
-    if (diag) hipLaunchKernelGGL((k_velocity3d_zb<true, TX, TY, KZ, 4, false>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
-    else hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, 4, false>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    if (diag) hipLaunchKernelGGL((k_velocity3d_zb<true, TX, TY, KZ, 4, 8>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, 4, 8>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -314,7 +314,7 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     I.setU = out_of(*f);
     I.cur_is_user = true; I.stress_done = false;
     const Lay3 L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
-    I.fusable = h->kernel_variant == 0 && !jrx_comm_active(h) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
+    I.fusable = h->kernel_variant == 3 && !jrx_comm_active(h) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable) {
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
         double **S = h->scratch;
@@ -363,8 +363,8 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.fsL = !!(fs & JRX_FACE_LEFT); bc.nsL = !!(ns & JRX_FACE_LEFT); bc.fsF = !!(fs & JRX_FACE_FRONT); bc.nsF = !!(ns & JRX_FACE_FRONT);
         bc.fsK0 = !!(fs & JRX_FACE_TOP);  bc.nsK0 = !!(ns & JRX_FACE_BOT);     // k = 1: free_slip `top`, no_slip `bot` (reference naming)
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
-        if (nx > 96) JRX_TRY((launch_fused<128, 8, 16>(h, s, a, bc)));
-        else JRX_TRY((launch_fused<64, 8, 16>(h, s, a, bc)));
+        // 64 x 4 threads (A tile 63 x 3), 16 planes per chunk: best of the measured tile shapes (148 VGPRs -> 3 blocks/CU)
+        JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc)));
         JRX_TRY(launch_bcs(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
         // stress nodes on the planes i = nx, j = ny, k = nz: old τ from the current set, new V from dst
         SweepArgs e = a;
