@@ -25,6 +25,10 @@ A_ALG = 360.0            # algorithmic bytes per cell per PT iteration (SURVEY Â
 A_STRESS = 28 * 8.0      # stress sweep: 21 reads + 7 writes
 A_VELOCITY = 17 * 8.0    # velocity sweep: 14 reads + 3 writes
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# L2<->fabric bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+# correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernel at
+# n = 512: profiles/r01_pmc_v3_fused_traffic.txt  (k_stress3d_zb<512,1,4>: FETCH_SIZE 15456777 KB, WRITE_SIZE 7410160 KB)
+PMC_TRAFFIC_STRESS_512 = (2 * 15456777.0 + 7410160.0) * 1024.0
 
 
 def cpu_baseline(n_cpu: int, budget_s: float):
@@ -151,7 +155,9 @@ def main():
             out["roofline"] = {"bound": "hbm",
                                "kernel": "stress sweep = k_stress3d_zb + 3 boundary-plane launches (21 array reads + 7 writes = 224 B/cell)",
                                "achieved": A_STRESS * cells / (sa_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": A_STRESS * cells / (sa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sa_ms,
+                               "frac": A_STRESS * cells / (sa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "traffic": PMC_TRAFFIC_STRESS_512 if n == 512 else None, "traffic_unit": "bytes per launch (PMC, offline)",
+                               "algorithmic_bytes_per_launch": A_STRESS * cells, "avg_launch_ms": sa_ms,
                                "velocity_sweep": {"achieved": A_VELOCITY * cells / (sb_ms * 1e-3) / 1e9, "avg_launch_ms": sb_ms},
                                "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
         else:
