@@ -201,6 +201,58 @@ jrx_status jrx_flow_bcs2d(jrx_handle *h, double *Vx, double *Vy, int64_t nx, int
 jrx_status jrx_stokes2d_residual_sumsq(jrx_handle *h, const jrx_stokes2d_fields *f, const jrx_stokes2d_params *p,
                                        double out[3]);
 
+/* ------------------------------------------------------------------ 2D multiphase visco-elasto-plastic Stokes (config 5)
+ * solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs)
+ * -- src/stokes/Stokes2D.jl:577-866 with update_stresses_center_vertex_ps! (src/stokes/StressKernels.jl:992-1144),
+ * compute_P! phase-ratio form (PressureKernels.jl:47-106), update_viscosity_τII! (rheology/Viscosity.jl:67-106,382-418)
+ * and the post-loop epilogue (vorticity, shear2center!, accumulate_tensor!, accumulate_vol!, multi_copy!).
+ * The rheology is passed as a table instead of GeoParams objects: per phase a LinearViscous viscosity, ConstantElasticity
+ * (G, Kb) and an optional DruckerPrager_regularised(C, ϕ, ψ, η_vp) -- what test/test_shearband2D.jl uses.  Phase ratios
+ * are JustPIC's CellArray layout: phase index fastest, [nphase][nx][ny] at centres and [nphase][nx+1][ny+1] at vertices. */
+#define JRX_MAXPHASE 8
+typedef struct jrx_rheology {
+    int32_t nphase;
+    double eta[JRX_MAXPHASE], G[JRX_MAXPHASE], Kb[JRX_MAXPHASE];
+    int32_t is_pl[JRX_MAXPHASE];
+    double C[JRX_MAXPHASE], sinphi[JRX_MAXPHASE], cosphi[JRX_MAXPHASE], sinpsi[JRX_MAXPHASE], eta_vp[JRX_MAXPHASE];
+} jrx_rheology;
+
+typedef struct jrx_vep2d_fields {
+    double *P, *P0, *divV, *Q;                     /* stokes.P, P0, ∇V, Q */
+    double *Vx, *Vy, *Ux, *Uy;
+    double *exx, *eyy, *exy, *exy_c;               /* stokes.ε: xx, yy (centres), xy (vertices), xy_c */
+    double *eplxx, *eplyy, *eplxy, *eplxy_c;       /* stokes.ε_pl */
+    double *dexy_c, *dexy;                         /* stokes.Δε.xy_c, .xy (shear2center! only; may be NULL) */
+    double *txx, *tyy, *txy, *txy_c, *tII;         /* stokes.τ: xx, yy, xy (vertices), xy_c, II */
+    double *toxx, *toyy, *toxy, *toxy_c;           /* stokes.τ_o */
+    double *eta, *eta_v, *eta_vep;                 /* stokes.viscosity.η, ηv (may be NULL), η_vep */
+    double *EII_pl, *evol_pl, *EVol_pl;            /* stokes.EII_pl, ε_vol_pl, EVol_pl */
+    double *fx, *fy;                               /* ρg */
+    double *RP, *Rx, *Ry;
+    double *omega_xy;                              /* stokes.ω.xy (may be NULL) */
+    double *phase_c, *phase_v;                     /* phase_ratios.center / .vertex */
+} jrx_vep2d_fields;
+
+typedef struct jrx_vep2d_params {
+    int64_t nx, ny, nxg, nyg;
+    double _dx, _dy;
+    double dt, r, theta_dtau, eta_dtau, eps_rel, eps_abs;
+    int64_t iterMax, iterMin, nout;                /* kwargs (Stokes2D.jl:588-599): iterMax=50e3, iterMin=100, nout=500 */
+    uint32_t free_slip, no_slip, periodic;
+    double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
+    int32_t verbose;
+} jrx_vep2d_params;
+
+jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p,
+                                  jrx_solve_result *res);
+/* update_stresses_center_vertex_ps! alone (θ, λ, λv are caller arrays of extents ni, ni, ni.+1) -- for parity tests */
+jrx_status jrx_vep2d_update_stresses(jrx_handle *h, const jrx_vep2d_fields *f, const double *theta, double *lambda, double *lambda_v,
+                                     const jrx_rheology *rh, const jrx_vep2d_params *p);
+/* tensor_invariant!(A): II = second_invariant_staggered(xx, yy, gather(xy)) -- StressKernels.jl:443-470 */
+jrx_status jrx_tensor_invariant2d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny);
+/* compute_viscosity!/update_viscosity_τII! for the table rheology: η <- ν·η_phase + (1-ν)·η, clamped to the cutoff */
+jrx_status jrx_vep2d_compute_viscosity(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p, double nu);
+
 /* ------------------------------------------------------------------ 2D PT heat diffusion */
 typedef struct jrx_thermal2d_fields {
     double *T, *Told, *dT;                 /* (nx+2, ny+2): thermal.T, Told, ΔT */

@@ -12,7 +12,7 @@ Julia's `f!` is spelled `f_` here.
 """
 from .backend import (AMDGPUBackend, AMDGPUBackendTrait, BackendTrait, CPUBackend, CPUBackendTrait,  # noqa: F401
                       GPUBackendTrait, NonCPUBackendTrait, PTArray, backend)
-from .arrays import (DisplacementBoundaryConditions, PTStokesCoeffs, PTThermalCoeffs, StokesArrays,  # noqa: F401
+from .arrays import (DisplacementBoundaryConditions, PhaseRatios, PTStokesCoeffs, PTThermalCoeffs, StokesArrays,  # noqa: F401
                      SymmetricTensor, TemperatureBoundaryConditions, ThermalArrays, VelocityBoundaryConditions,
                      from_numpy, fzeros, to_numpy)
 from .grid import (IGG, Geometry, finalize_global_grid, init_global_grid, legacy_uniform_grid,  # noqa: F401

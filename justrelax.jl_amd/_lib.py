@@ -68,6 +68,27 @@ class Thermal2DParams(C.Structure):
                 ("T0", C.c_double), ("verbose", C.c_int32)]
 
 
+VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
+             "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
+             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v"]
+VEP2DFields = _ptr_struct("VEP2DFields", VEP_NAMES)
+MAXPHASE = 8
+
+
+class Rheology(C.Structure):
+    _fields_ = [("nphase", C.c_int32)] + [(k, C.c_double * MAXPHASE) for k in ("eta", "G", "Kb")] + [("is_pl", C.c_int32 * MAXPHASE)] + \
+               [(k, C.c_double * MAXPHASE) for k in ("C", "sinphi", "cosphi", "sinpsi", "eta_vp")]
+
+
+class VEP2DParams(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nxg", C.c_int64), ("nyg", C.c_int64), ("_dx", C.c_double), ("_dy", C.c_double),
+                ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
+                ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("iterMin", C.c_int64), ("nout", C.c_int64),
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
+                ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
+                ("verbose", C.c_int32)]
+
+
 class SolveResult(C.Structure):
     _fields_ = [("iter", C.c_int64), ("nchecks", C.c_int64), ("cap", C.c_int64),
                 ("err_evo1", _dp), ("err_evo2", _ip),

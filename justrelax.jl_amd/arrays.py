@@ -107,6 +107,42 @@ def residual_shapes(ni):
     return dict(RP=ni, Rx=(nx - 1, ny, nz), Ry=(nx, ny - 1, nz), Rz=(nx, ny, nz - 1))
 
 
+class _Lazy(SimpleNamespace):
+    """namespace whose arrays are allocated on first access"""
+
+    def __init__(self, device, shapes, fill=0.0):
+        super().__init__()
+        self.__dict__["_shapes"], self.__dict__["_device"], self.__dict__["_fill"] = dict(shapes), device, fill
+
+    def __getattr__(self, k):
+        shp = self.__dict__["_shapes"].get(k)
+        if shp is None:
+            raise AttributeError(k)
+        t = fzeros(shp, self.__dict__["_device"], self.__dict__["_fill"])
+        setattr(self, k, t)
+        return t
+
+
+class _Viscosity(_Lazy):
+    """Viscosity(ni): η, η_vep, ητ (centres), ηv (vertices), all @ones -- constructors/stokes.jl:113-119"""
+
+    def __init__(self, ni, device):
+        super().__init__(device, dict(η_vep=ni, ητ=ni, ηv=tuple(n + 1 for n in ni)), fill=1.0)
+        self.η = fzeros(ni, device, 1.0)
+
+
+class PhaseRatios:
+    """JustPIC.PhaseRatios(backend, nphases, ni): `center` (nphase, ni...) and `vertex` (nphase, ni.+1 ...) arrays in
+    CellArray layout (phase index fastest)."""
+
+    def __init__(self, backend_tag, nphases, ni):
+        dev = device_of(backend_tag)
+        ni = tuple(int(n) for n in ni)
+        self.nphases = int(nphases)
+        self.center = fzeros((self.nphases,) + ni, dev)
+        self.vertex = fzeros((self.nphases,) + tuple(n + 1 for n in ni), dev)
+
+
 class StokesArrays:
     """StokesArrays(backend, ni) -- src/types/constructors/stokes.jl:279-303.
 
@@ -129,7 +165,8 @@ class StokesArrays:
         self.τ = SymmetricTensor(ni, dev, lazy=self._LAZY_T)
         self.τ_o = SymmetricTensor(ni, dev, lazy=self._LAZY_T)
         self.ε = SymmetricTensor(ni, dev, lazy=self._LAZY_T + tuple(k for k in _tensor_shapes(ni) if k.endswith("_c")))
-        self.viscosity = SimpleNamespace(η=fzeros(ni, dev, 1.0))     # Viscosity: η = @ones (constructors/stokes.jl:113-119)
+        self.viscosity = _Viscosity(ni, dev)                           # Viscosity: η = @ones (constructors/stokes.jl:113-119)
+        self.ω = _Lazy(dev, {("xy" if len(ni) == 2 else k): tuple(n + 1 for n in ni) for k in (("xy",) if len(ni) == 2 else ("yz", "xz", "xy"))})
         self.R = SimpleNamespace(**{k: fzeros(s, dev) for k, s in residual_shapes(ni).items()})
 
     # ASCII aliases
@@ -278,6 +315,6 @@ class TemperatureBoundaryConditions:
                 raise ValueError(f"Incompatible boundary conditions on the {k} boundary")
 
 
-__all__ = ["StokesArrays", "PTStokesCoeffs", "ThermalArrays", "PTThermalCoeffs", "SymmetricTensor",
+__all__ = ["PhaseRatios", "StokesArrays", "PTStokesCoeffs", "ThermalArrays", "PTThermalCoeffs", "SymmetricTensor",
            "VelocityBoundaryConditions", "DisplacementBoundaryConditions", "TemperatureBoundaryConditions",
            "fzeros", "from_numpy", "to_numpy", "ptr", "is_fortran", "AMDGPUBackend", "CPUBackend"]

@@ -324,3 +324,439 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
 }
 
 }   // extern "C"
+
+
+// ================================================================================================
+// 2D multiphase visco-elasto-plastic driver (config 5: shear band) -- src/stokes/Stokes2D.jl:577-866
+// ================================================================================================
+namespace {
+
+struct VepArgs {
+    jrx_vep2d_fields f;
+    jrx_rheology rh;
+    const double *theta, *etatau, *Kc, *Gc;
+    double *lam, *lamv;
+    double _dx, _dy, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
+    int nx, ny;
+};
+
+__device__ __forceinline__ double sinv2(double xx, double yy, double xy) { return sqrt(0.5 * (xx * xx + yy * yy) + xy * xy); }
+// GeoParams second_invariant_staggered: the shear slot enters as the mean of the squared vertex values
+// (pinned by the extrema of test/test_shearband2D.jl:198-199: mean-then-square misses them by 2.8e-3)
+__device__ __forceinline__ double sinv_stag(double xx, double yy, double a, double b, double c, double d)
+{
+    return sqrt(0.5 * (xx * xx + yy * yy) + 0.25 * (a * a + b * b + c * c + d * d));
+}
+__device__ __forceinline__ double ratio_avg(const double *val, const double *r, int n)
+{   // fn_ratio, src/phases/phases.jl:6-15
+    double x = 0.0;
+    for (int q = 0; q < n; q++) x += (r[q] == 0.0) ? 0.0 : val[q] * r[q];
+    return x;
+}
+__device__ __forceinline__ void plastic_params(const jrx_rheology &rh, const double *r, bool &is_pl, double &eta_reg)
+{   // plastic_params_phase, rheology/StressUpdate.jl:152-176
+    is_pl = false; eta_reg = 0.0;
+    for (int q = 0; q < rh.nphase; q++)
+        if (rh.is_pl[q]) { is_pl = true; eta_reg += rh.eta_vp[q] * r[q]; }
+}
+__device__ __forceinline__ double yield_F(const jrx_rheology &rh, const double *r, double P, double tII)
+{   // compute_yieldfunction_phase, StressUpdate.jl:399-410 ; DP: F = τII - cosϕ C - sinϕ P
+    double F = 0.0;
+    for (int q = 0; q < rh.nphase; q++) {
+        if (r[q] == 0.0) continue;
+        const double Fq = rh.is_pl[q] ? (tII - rh.cosphi[q] * rh.C[q] - rh.sinphi[q] * P) : tII;
+        F += r[q] * Fq;
+    }
+    return F;
+}
+__device__ __forceinline__ void plastic_grad(const jrx_rheology &rh, const double *r, const double t[3], double dQdt[3], double &dQdP, double &dFdP)
+{   // compute_plastic_gradients_phase, StressUpdate.jl:476-495 ; ∂Q/∂τ = τ/(2 τII), ∂Q/∂P = -sinψ, ∂F/∂P = -sinϕ
+    dQdt[0] = dQdt[1] = dQdt[2] = 0.0; dQdP = 0.0; dFdP = 0.0;
+    const double tII = sinv2(t[0], t[1], t[2]);
+    for (int q = 0; q < rh.nphase; q++) {
+        if (r[q] == 0.0 || !rh.is_pl[q]) continue;
+        const double g0 = 0.5 * t[0] / tII, g1 = 0.5 * t[1] / tII, g2 = 0.5 * (t[2] / tII);
+        dQdt[0] = fma(r[q], g0, dQdt[0]); dQdt[1] = fma(r[q], g1, dQdt[1]); dQdt[2] = fma(r[q], g2, dQdt[2]);
+        dQdP = fma(r[q], -rh.sinpsi[q], dQdP);
+        dFdP = fma(r[q], -rh.sinphi[q], dFdP);
+    }
+}
+
+#define C2(A, i_, j_) (A)[(i_) + (i64)nx * (j_)]
+#define V2(A, i_, j_) (A)[(i_) + (i64)(nx + 1) * (j_)]
+
+// compute_∇V! + compute_P! (phase form: K, G phase-averaged once per solve; writes θ) + compute_strain_rate!
+__global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__restrict__ theta)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / (nx + 1), i = t - j * (nx + 1);
+    if (j > ny) return;
+    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy;
+#define VX(i_, j_) Vx[(i_) + (i64)(nx + 1) * (j_)]
+#define VY(i_, j_) Vy[(i_) + (i64)(nx + 2) * (j_)]
+    if (i < nx && j < ny) {
+        const i64 c = i + (i64)nx * j;
+        const double dxi = (-VX(i, j + 1) + VX(i + 1, j + 1)) * a._dx;
+        const double dyi = (-VY(i + 1, j) + VY(i + 1, j + 1)) * a._dy;
+        const double divV = dxi + dyi;
+        a.f.divV[c] = divV;
+        const double _Kdt = 1.0 / (a.Kc[c] * a.dt), _Gdt = 1.0 / (a.Gc[c] * a.dt), _dt = 1.0 / a.dt;
+        const double P = theta[c], P0 = a.f.P0[c];
+        const double rhs = -divV + (a.f.Q[c] * _dt);
+        a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
+        const double psi = 1.0 / (1.0 / a.etatau[c] + _Gdt) * a.r / a.theta_dtau;
+        theta[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
+        const double d3 = divV * (1.0 / 3.0);
+        a.f.exx[c] = dxi - d3;
+        a.f.eyy[c] = dyi - d3;
+    }
+    a.f.exy[i + (i64)(nx + 1) * j] = 0.5 * (a._dy * (VX(i, j + 1) - VX(i, j)) + a._dx * (VY(i + 1, j) - VY(i, j)));
+#undef VX
+#undef VY
+}
+
+// update_stresses_center_vertex_ps! -- vertex half.  Runs before the centre half so that the vertex averages
+// see the old centre stresses (the reference's single launch races on them).
+__global__ __launch_bounds__(256) void k_vep_vertex(const VepArgs a)
+{
+    const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / (nx + 1), i = t - j * (nx + 1);
+    if (j > ny) return;
+    const int i0 = clampi(i - 1, 0, nx - 1), ic = clampi(i, 0, nx - 1), j0 = clampi(j - 1, 0, ny - 1), jc = clampi(j, 0, ny - 1);
+#define AVC(A) (0.25 * (C2(A, i0, j0) + C2(A, ic, jc) + C2(A, i0, jc) + C2(A, ic, j0)))
+    const double Pv = AVC(a.theta), exxv = AVC(a.f.exx), eyyv = AVC(a.f.eyy), txxv = AVC(a.f.txx), tyyv = AVC(a.f.tyy);
+    const double toxxv = AVC(a.f.toxx), toyyv = AVC(a.f.toyy);
+#undef AVC
+    const i64 v = i + (i64)(nx + 1) * j;
+    const double *rv = a.f.phase_v + (i64)np * v;
+    bool is_pl; double eta_reg;
+    plastic_params(a.rh, rv, is_pl, eta_reg);
+    const double _Gdt = 1.0 / (ratio_avg(a.rh.G, rv, np) * a.dt);
+    const double Kv = ratio_avg(a.rh.Kb, rv, np);
+    const double etav = 4.0 / (1.0 / C2(a.f.eta, i0, j0) + 1.0 / C2(a.f.eta, ic, jc) + 1.0 / C2(a.f.eta, i0, jc) + 1.0 / C2(a.f.eta, ic, j0));
+    const double dtr = 1.0 / (a.theta_dtau + etav * _Gdt + 1.0);
+    const double txy = a.f.txy[v];
+    const double dxx = dev_stress_inc(txxv, toxxv, etav, exxv, _Gdt, dtr);
+    const double dyy = dev_stress_inc(tyyv, toyyv, etav, eyyv, _Gdt, dtr);
+    const double dxy = dev_stress_inc(txy, a.f.toxy[v], etav, a.f.exy[v], _Gdt, dtr);
+    const double tt[3] = {txxv + dxx, tyyv + dyy, txy + dxy};
+    const double tIIv = sinv2(dxx + txxv, dyy + tyyv, dxy + txy);
+    double dQdt[3], dQdP, dFdP;
+    plastic_grad(a.rh, rv, tt, dQdt, dQdP, dFdP);
+    const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
+    const double F = yield_F(a.rh, rv, Pv, tIIv);
+    if (is_pl && tIIv != 0.0 && F > 0) {
+        const double l = fma(1.0 - a.rel, a.lamv[v], a.rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol)));
+        a.lamv[v] = l;
+        const double epl = l * dQdt[2];
+        a.f.txy[v] = txy + fma(-2.0 * etav * epl, dtr, dxy);
+        a.f.eplxy[v] = epl;
+    } else {
+        a.f.txy[v] = txy + dxy;
+        a.f.eplxy[v] = 0.0;
+    }
+}
+
+// update_stresses_center_vertex_ps! -- centre half (+ Pr_c, τII, η_vep)
+__global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
+{
+    const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / nx, i = t - j * nx;
+    if (j >= ny) return;
+    const i64 c = i + (i64)nx * j;
+    const double *rc = a.f.phase_c + (i64)np * c;
+    const double _Gdt = 1.0 / (ratio_avg(a.rh.G, rc, np) * a.dt);
+    bool is_pl; double eta_reg;
+    plastic_params(a.rh, rc, is_pl, eta_reg);
+    const double K = ratio_avg(a.rh.Kb, rc, np);
+    const double e = a.f.eta[c];
+    const double dtr = 1.0 / (a.theta_dtau + e * _Gdt + 1.0);
+    const double exyc = (V2(a.f.exy, i, j) + V2(a.f.exy, i + 1, j) + V2(a.f.exy, i, j + 1) + V2(a.f.exy, i + 1, j + 1)) / 4;
+    const double eij[3] = {a.f.exx[c], a.f.eyy[c], exyc};
+    double tij[3] = {a.f.txx[c], a.f.tyy[c], a.f.txy_c[c]};
+    const double toij[3] = {a.f.toxx[c], a.f.toyy[c], a.f.toxy_c[c]};
+    double d[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) d[q] = dev_stress_inc(tij[q], toij[q], e, eij[q], _Gdt, dtr);
+    double tII = sinv2(d[0] + tij[0], d[1] + tij[1], d[2] + tij[2]);
+    const double tt[3] = {tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]};
+    double dQdt[3], dQdP, dFdP;
+    plastic_grad(a.rh, rc, tt, dQdt, dQdP, dFdP);
+    const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
+    const double Pr = a.theta[c];
+    const double F = yield_F(a.rh, rc, Pr, tII);
+    double l = a.lam[c];
+    if (is_pl && tII != 0.0 && F > 0) {
+        l = fma(1.0 - a.rel, l, a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol)));
+        a.lam[c] = l;
+        double epl[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { epl[q] = l * dQdt[q]; d[q] = fma(-2.0 * e * epl[q], dtr, d[q]); tij[q] = d[q] + tij[q]; }
+        a.f.evol_pl[c] = -l * dQdP;
+        a.f.txx[c] = tij[0]; a.f.tyy[c] = tij[1]; a.f.txy_c[c] = tij[2];
+        a.f.eplxx[c] = epl[0]; a.f.eplyy[c] = epl[1];
+        tII = sinv2(tij[0], tij[1], tij[2]);
+    } else {
+        a.f.evol_pl[c] = 0.0;
+        a.f.txx[c] = d[0] + tij[0]; a.f.tyy[c] = d[1] + tij[1]; a.f.txy_c[c] = d[2] + tij[2];
+        a.f.eplxx[c] = 0.0; a.f.eplyy[c] = 0.0;
+    }
+    a.f.tII[c] = tII;
+    a.f.eta_vep[c] = tII * 0.5 * (1.0 / sinv2(eij[0], eij[1], eij[2]));
+    a.f.P[c] = Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP);
+}
+
+__device__ __forceinline__ double phase_viscosity(const jrx_rheology &rh, const double *r)
+{   // compute_phase_viscosity, rheology/Viscosity.jl:605-625 (LinearViscous elements)
+    for (int q = 0; q < rh.nphase; q++)
+        if (r[q] > 0.999) return rh.eta[q];
+    double s = 0.0;
+    for (int q = 0; q < rh.nphase; q++)
+        if (r[q] != 0.0) s += (1.0 / rh.eta[q]) * r[q];
+    return 1.0 / s;
+}
+__global__ __launch_bounds__(256) void k_vep_visc(const VepArgs a)
+{
+    const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (i64)nx * ny) {
+        double e = phase_viscosity(a.rh, a.f.phase_c + np * t);
+        e = e * a.nu + a.f.eta[t] * (1.0 - a.nu);
+        a.f.eta[t] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+    }
+    if (a.f.eta_v && t < (i64)(nx + 1) * (ny + 1)) {
+        double e = phase_viscosity(a.rh, a.f.phase_v + np * t);
+        e = e * a.nu + a.f.eta_v[t] * (1.0 - a.nu);
+        a.f.eta_v[t] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const VepArgs a)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (i64)a.nx * a.ny) return;
+    Kc[t] = ratio_avg(a.rh.Kb, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
+    Gc[t] = ratio_avg(a.rh.G, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
+}
+
+__global__ __launch_bounds__(256) void k_tensor_invariant2d(double *__restrict__ II, const double *__restrict__ xx, const double *__restrict__ yy,
+                                                           const double *__restrict__ xy, int nx, int ny)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / nx, i = t - j * nx;
+    if (j >= ny) return;
+    II[t] = sinv_stag(xx[t], yy[t], V2(xy, i, j), V2(xy, i + 1, j), V2(xy, i, j + 1), V2(xy, i + 1, j + 1));
+}
+
+// post-loop epilogue: compute_vorticity!, shear2center! x3, accumulate_tensor!, accumulate_vol! (Stokes2D.jl:831-843)
+__global__ __launch_bounds__(256) void k_vep_epilogue(const VepArgs a)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / (nx + 1), i = t - j * (nx + 1);
+    if (j > ny) return;
+    if (a.f.omega_xy)
+        V2(a.f.omega_xy, i, j) = 0.5 * ((-a.f.Vy[i + (i64)(nx + 2) * j] + a.f.Vy[(i + 1) + (i64)(nx + 2) * j]) * a._dx -
+                                        (-a.f.Vx[i + (i64)(nx + 1) * j] + a.f.Vx[i + (i64)(nx + 1) * (j + 1)]) * a._dy);
+    if (i < nx && j < ny) {
+        const i64 c = i + (i64)nx * j;
+#define S2C(V) (0.25 * (V2(V, i, j) + V2(V, i + 1, j) + V2(V, i, j + 1) + V2(V, i + 1, j + 1)))
+        if (a.f.exy_c) a.f.exy_c[c] = S2C(a.f.exy);
+        if (a.f.eplxy_c) a.f.eplxy_c[c] = S2C(a.f.eplxy);
+        if (a.f.dexy_c && a.f.dexy) a.f.dexy_c[c] = S2C(a.f.dexy);
+#undef S2C
+        a.f.EII_pl[c] += sinv_stag(a.f.eplxx[c], a.f.eplyy[c], V2(a.f.eplxy, i, j), V2(a.f.eplxy, i + 1, j), V2(a.f.eplxy, i, j + 1),
+                                   V2(a.f.eplxy, i + 1, j + 1)) * a.dt;
+        a.f.EVol_pl[c] += a.dt * a.f.evol_pl[c];
+    }
+}
+#undef C2
+#undef V2
+
+jrx_status check_vep(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!f || !rh || !p) return jrx_fail(h, JRX_ERR_ARG, "null VEP argument");
+    if (p->nx < 3 || p->ny < 3) return jrx_fail(h, JRX_ERR_ARG, "2D Stokes needs at least 3 cells per dimension");
+    if (rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "nphase must be in 1..%d", JRX_MAXPHASE);
+    const void *req[] = {f->P, f->P0, f->divV, f->Q, f->Vx, f->Vy, f->Ux, f->Uy, f->exx, f->eyy, f->exy, f->eplxx, f->eplyy, f->eplxy, f->eplxy_c,
+                         f->txx, f->tyy, f->txy, f->txy_c, f->tII, f->toxx, f->toyy, f->toxy, f->toxy_c, f->eta, f->eta_vep, f->EII_pl, f->evol_pl,
+                         f->EVol_pl, f->fx, f->fy, f->RP, f->Rx, f->Ry, f->phase_c, f->phase_v};
+    for (const void *q : req)
+        if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required VEP field pointer is NULL");
+    return JRX_OK;
+}
+
+VepArgs make_vep(const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p)
+{
+    VepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.f = *f; a.rh = *rh;
+    a._dx = p->_dx; a._dy = p->_dy; a.dt = p->dt; a.r = p->r; a.theta_dtau = p->theta_dtau; a.rel = p->lambda_relaxation;
+    a.nu = p->viscosity_relaxation; a.cut_lo = p->cutoff_lo; a.cut_hi = p->cutoff_hi;
+    a.nx = (int)p->nx; a.ny = (int)p->ny;
+    return a;
+}
+
+// the velocity / residual kernels of the visco-elastic path work on this view (P = stokes.P = Pr_c, τxy at vertices)
+jrx_stokes2d_fields view2d(const jrx_vep2d_fields *f)
+{
+    jrx_stokes2d_fields g;
+    memset(&g, 0, sizeof(g));
+    g.P = f->P; g.P0 = f->P0; g.divV = f->divV; g.Q = f->Q; g.Vx = f->Vx; g.Vy = f->Vy; g.Ux = f->Ux; g.Uy = f->Uy;
+    g.txx = f->txx; g.tyy = f->tyy; g.txy = f->txy; g.exx = f->exx; g.eyy = f->eyy; g.exy = f->exy; g.eta = f->eta;
+    g.fx = f->fx; g.fy = f->fy; g.RP = f->RP; g.Rx = f->Rx; g.Ry = f->Ry;
+    return g;
+}
+
+}   // namespace
+
+extern "C" {
+
+jrx_status jrx_tensor_invariant2d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!II || !xx || !yy || !xy || nx < 1 || ny < 1) return jrx_fail(h, JRX_ERR_ARG, "tensor_invariant!: bad argument");
+    hipLaunchKernelGGL(k_tensor_invariant2d, dim3((unsigned)((nx * ny + 255) / 256)), dim3(256), 0, h->stream, II, xx, yy, xy, (int)nx, (int)ny);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_vep2d_compute_viscosity(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p, double nu)
+{
+    JRX_TRY(check_vep(h, f, rh, p));
+    VepArgs a = make_vep(f, rh, p);
+    a.nu = nu;
+    hipLaunchKernelGGL(k_vep_visc, dim3((unsigned)(((p->nx + 1) * (p->ny + 1) + 255) / 256)), dim3(256), 0, h->stream, a);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_vep2d_update_stresses(jrx_handle *h, const jrx_vep2d_fields *f, const double *theta, double *lambda, double *lambda_v,
+                                     const jrx_rheology *rh, const jrx_vep2d_params *p)
+{
+    JRX_TRY(check_vep(h, f, rh, p));
+    if (!theta || !lambda || !lambda_v) return jrx_fail(h, JRX_ERR_ARG, "θ / λ / λv is NULL");
+    VepArgs a = make_vep(f, rh, p);
+    a.theta = theta; a.lam = lambda; a.lamv = lambda_v;
+    const unsigned gv = (unsigned)(((p->nx + 1) * (p->ny + 1) + 255) / 256), gc = (unsigned)((p->nx * p->ny + 255) / 256);
+    hipLaunchKernelGGL(k_vep_vertex, dim3(gv), dim3(256), 0, h->stream, a);
+    JRX_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(k_vep_centre, dim3(gc), dim3(256), 0, h->stream, a);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p,
+                                  jrx_solve_result *res)
+{
+    JRX_TRY(check_vep(h, f, rh, p));
+    if (!res) return jrx_fail(h, JRX_ERR_ARG, "null result");
+    if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
+    if (jrx_comm_active(h)) return jrx_fail(h, JRX_ERR_UNSUPPORTED, "multi-rank VEP solve is not implemented");
+    const int nx = (int)p->nx, ny = (int)p->ny;
+    const size_t n = (size_t)nx * ny, nv = (size_t)(nx + 1) * (ny + 1);
+    hipStream_t s = h->stream;
+    // library scratch: ητ, θ, λ, K, G (centre) and λv (vertex), carved out of one allocation
+    JRX_TRY(jrx_ensure_etatau(h, 5 * n + nv));
+    double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n, *lamv = Gc + n;
+    VepArgs a = make_vep(f, rh, p);
+    a.theta = theta; a.etatau = etatau; a.Kc = Kc; a.Gc = Gc; a.lam = lam; a.lamv = lamv;
+    jrx_stokes2d_fields g = view2d(f);
+    jrx_stokes2d_params q;
+    memset(&q, 0, sizeof(q));
+    q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
+    q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
+    Args2 b = make_args2(&g, etatau, &q);
+    const unsigned gv = (unsigned)((nv + 255) / 256), gc = (unsigned)((n + 255) / 256);
+
+    JRX_HIP(h, hipMemcpyAsync(f->P0, f->P, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // @copy stokes.P0 stokes.P
+    JRX_HIP(h, hipMemcpyAsync(theta, f->P, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // θ = deepcopy(stokes.P)
+    JRX_HIP(h, hipMemsetAsync(lam, 0, n * sizeof(double), s));
+    JRX_HIP(h, hipMemsetAsync(lamv, 0, nv * sizeof(double), s));
+    JRX_HIP(h, hipMemsetAsync(f->eplxx, 0, n * sizeof(double), s));                                 // @tensor_center(ε_pl) .= 0
+    JRX_HIP(h, hipMemsetAsync(f->eplyy, 0, n * sizeof(double), s));
+    JRX_HIP(h, hipMemsetAsync(f->eplxy_c, 0, n * sizeof(double), s));
+    hipLaunchKernelGGL(k_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a);
+    JRX_LAUNCH_CHECK(h);
+
+    double err_it1 = 1.0, err = 1.0;
+    int64_t iter = 0, cont = 0;
+    JRX_HIP(h, hipEventRecord(h->ev[6], s));
+    while (iter <= p->iterMax) {
+        if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;          // Stokes2D.jl:650-651
+        hipLaunchKernelGGL(k_maxloc, dim3(gc, 1), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, 1);
+        JRX_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL(k_vep_pre, dim3(gv), dim3(256), 0, s, a, theta);
+        JRX_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL(k_vep_vertex, dim3(gv), dim3(256), 0, s, a);
+        JRX_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL(k_vep_centre, dim3(gc), dim3(256), 0, s, a);
+        JRX_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL(k_vep_visc, dim3(gv), dim3(256), 0, s, a);
+        JRX_LAUNCH_CHECK(h);
+        hipLaunchKernelGGL(k_velocity2d<false>, dim3(gc), dim3(256), 0, s, b);     // compute_V! (free-surface form with dt*free_surface = 0)
+        JRX_LAUNCH_CHECK(h);
+        iter += 1;
+        const bool check = (iter % p->nout == 0) && iter > 1;
+        // the loop can stop after this iteration if it is a check, the last allowed one, or already converged
+        const bool last = check || iter > p->iterMax || (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs));
+        if (last) {   // U = V*dt is only observable after an iteration the loop can stop at
+            hipLaunchKernelGGL(k_scale3, dim3(256), dim3(256), 0, s, f->Ux, (const double *)f->Vx, (i64)(nx + 1) * (ny + 2), f->Uy,
+                               (const double *)f->Vy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, p->dt);
+            JRX_LAUNCH_CHECK(h);
+        }
+        JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+        if (check) {
+            hipLaunchKernelGGL(k_velocity2d<true>, dim3(gc), dim3(256), 0, s, b);  // compute_Res!
+            JRX_LAUNCH_CHECK(h);
+            JRX_TRY(launch_sumsq2(h, s, &g, &q));
+            JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            JRX_HIP(h, hipStreamSynchronize(s));
+            const double nRx = sqrt(h->h_sums[0]) / sqrt((double)((p->nxg - 2) * (p->nyg - 1)));
+            const double nRy = sqrt(h->h_sums[1]) / sqrt((double)((p->nxg - 1) * (p->nyg - 2)));
+            const double nDV = sqrt(h->h_sums[3]) / sqrt((double)(p->nxg * p->nyg));
+            err = fmax(nRx, fmax(nRy, nDV));
+            if (std::isnan(nRx) || std::isnan(nRy) || std::isnan(nDV)) err = NAN;
+            if (cont < res->cap) {
+                if (res->norm_Rx) res->norm_Rx[cont] = nRx;
+                if (res->norm_Ry) res->norm_Ry[cont] = nRy;
+                if (res->norm_divV) res->norm_divV[cont] = nDV;
+                if (res->err_evo1) res->err_evo1[cont] = err;
+                if (res->err_evo2) res->err_evo2[cont] = iter;
+            }
+            if (cont == 0) err_it1 = err;
+            cont++;
+            if (p->verbose)
+                printf("Total steps = %lld, abs_err = %1.3e , rel_err = %1.3e [norm_Rx=%1.3e, norm_Ry=%1.3e, norm_∇V=%1.3e] \n",
+                       (long long)iter, err, err / err_it1, nRx, nRy, nDV);
+            if (std::isnan(err)) {
+                res->iter = iter; res->nchecks = cont < res->cap ? cont : res->cap;
+                return jrx_fail(h, JRX_ERR_NAN, "NaN(s)");
+            }
+        }
+    }
+    JRX_HIP(h, hipEventRecord(h->ev[7], s));
+    hipLaunchKernelGGL(k_vep_epilogue, dim3(gv), dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(k_copy6, dim3(256), dim3(256), 0, s, f->toxx, (const double *)f->txx, (i64)n, f->toyy, (const double *)f->tyy, (i64)n,
+                       f->toxy, (const double *)f->txy, (i64)nv, f->toxy_c, (const double *)f->txy_c, (i64)n, (double *)nullptr,
+                       (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(s));
+    float ms = 0.f;
+    JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
+    res->iter = iter;
+    res->nchecks = cont < res->cap ? cont : res->cap;
+    res->time_s = ms * 1e-3;
+    res->av_time_s = iter > 1 ? res->time_s / (double)(iter - 1) : res->time_s;
+    return JRX_OK;
+}
+
+}   // extern "C"

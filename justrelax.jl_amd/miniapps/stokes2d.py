@@ -126,3 +126,44 @@ def random_fields2d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nou
     grid = Geometry(ni, li)
     return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=dt, flow_bcs=b,
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
+
+
+def shearband2d(n=32, *, iterMax=50_000, nout=100) -> Setup:
+    """ShearBand2D -- test/test_shearband2D.jl:61-175 (BASELINE config 5): two phases (matrix G0 = 1, circular inclusion
+    Gi = 0.5 of radius 0.1), LinearViscous eta = 1, Kb = 4, DruckerPrager_regularised(C = 1.6/cos30, phi = 30, psi = 0,
+    eta_vp = 8e-3), pure shear eps_bg = 1, free slip, dt = eta0/G0/4.  Array names follow oracle.VEP_NAMES / jrx_vep2d_fields."""
+    nx = ny = n
+    ni, li = (nx, ny), (1.0, 1.0)
+    init_global_grid(nx, ny, 1)
+    di = tuple(l / m for l, m in zip(li, ni))
+    grid = Geometry(ni, li, origin=(0.0, 0.0))
+    τ_y, ϕ, η0, G0, εbg, η_reg = 1.6, 30.0, 1.0, 1.0, 1.0, 8.0e-3
+    Gi = G0 / (6.0 - 4.0)
+    dt = η0 / G0 / 4.0
+    Cgp = τ_y / math.cos(math.radians(ϕ))
+    phases = [dict(eta=η0, G=G0, Kb=4.0, C=Cgp, phi_deg=ϕ, psi_deg=0.0, eta_vp=η_reg),
+              dict(eta=η0, G=Gi, Kb=4.0, C=Cgp, phi_deg=ϕ, psi_deg=0.0, eta_vp=η_reg)]
+    c, v = (nx, ny), (nx + 1, ny + 1)
+    shapes = {k: c for k in ("P", "P0", "divV", "Q", "exx", "eyy", "exy_c", "eplxx", "eplyy", "eplxy_c", "dexy_c", "txx", "tyy", "txy_c", "tII",
+                             "toxx", "toyy", "toxy_c", "eta", "eta_vep", "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP")}
+    shapes.update({k: v for k in ("exy", "eplxy", "dexy", "txy", "toxy", "eta_v", "omega_xy")})
+    shapes.update(Vx=(nx + 1, ny + 2), Vy=(nx + 2, ny + 1), Ux=(nx + 1, ny + 2), Uy=(nx + 2, ny + 1), Rx=(nx - 1, ny), Ry=(nx, ny - 1),
+                  phase_c=(2, nx, ny), phase_v=(2, nx + 1, ny + 1))
+    arr = {k: np.zeros(s, dtype=np.float64, order="F") for k, s in shapes.items()}
+    radius, ox, oy = 0.1, 0.5, 0.5
+    for name, (xs, ys) in (("phase_c", grid.xci), ("phase_v", grid.xvi)):       # init_phases! :37-58
+        X, Y = np.meshgrid(xs, ys, indexing="ij")
+        outside = ((X - ox) ** 2 + (Y - oy) ** 2) > radius ** 2
+        arr[name][0] = np.where(outside, 1.0, 0.0)
+        arr[name][1] = np.where(outside, 0.0, 1.0)
+    arr["eta"][...] = η0                                                      # compute_viscosity!: linear viscous
+    arr["eta_v"][...] = η0
+    xv, yv = grid.xvi
+    arr["Vx"][...] = (xv * εbg)[:, None] * np.ones((1, ny + 2))               # :145-146 (ghost rows included)
+    arr["Vy"][...] = (-yv * εbg)[None, :] * np.ones((nx + 2, 1))
+    _free_slip2d_host(arr)
+    pt = PTStokesCoeffs(li, di, ϵ_rel=1.0e-6, CFL=0.75 / math.sqrt(2.1))
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F4}, no_slip={f: False for f in _F4})
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=dt, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False, viscosity_cutoff=(-np.inf, np.inf)),
+                 extra=dict(li=li, di=di, phases=phases, εbg=εbg, G0=G0, η0=η0))

@@ -142,9 +142,107 @@ class _Hist:
         return r
 
 
-def solve_(stokes, pt_stokes, grid_or_di, flow_bcs, ρg, A, B, dt, igg=None, *, kwargs=None, handle=None):
+def rheology_table(phases) -> _lib.Rheology:
+    """Per-phase material table for the C ABI.  `phases`: sequence of dict(eta, G, Kb[, C, phi_deg, psi_deg, eta_vp]) -- the
+    LinearViscous / ConstantElasticity / DruckerPrager_regularised parameters of each GeoParams MaterialParams
+    (C is GeoParams' cohesion parameter, i.e. τ_y / cos ϕ in test_shearband2D.jl)."""
+    import math
+    if isinstance(phases, _lib.Rheology):
+        return phases
+    r = _lib.Rheology()
+    r.nphase = len(phases)
+    if not 1 <= r.nphase <= _lib.MAXPHASE:
+        raise ValueError(f"1..{_lib.MAXPHASE} phases supported")
+    for q, ph in enumerate(phases):
+        r.eta[q], r.G[q], r.Kb[q] = ph["eta"], ph["G"], ph["Kb"]
+        pl = ph.get("C") is not None
+        r.is_pl[q] = int(pl)
+        if pl:
+            r.C[q], r.eta_vp[q] = ph["C"], ph.get("eta_vp", 0.0)
+            r.sinphi[q], r.cosphi[q] = math.sin(math.radians(ph["phi_deg"])), math.cos(math.radians(ph["phi_deg"]))
+            r.sinpsi[q] = math.sin(math.radians(ph.get("psi_deg", 0.0)))
+    return r
+
+
+def vep_fields2d(stokes, ρg, phase_ratios) -> _lib.VEP2DFields:
+    s = stokes
+    vals = dict(P=s.P, P0=s.P0, divV=s.divV, Q=s.Q, Vx=s.V.Vx, Vy=s.V.Vy, Ux=s.U.Ux, Uy=s.U.Uy,
+                exx=s.ε.xx, eyy=s.ε.yy, exy=s.ε.xy, exy_c=s.ε.xy_c,
+                eplxx=s.ε_pl.xx, eplyy=s.ε_pl.yy, eplxy=s.ε_pl.xy, eplxy_c=s.ε_pl.xy_c, dexy_c=s.Δε.xy_c, dexy=s.Δε.xy,
+                txx=s.τ.xx, tyy=s.τ.yy, txy=s.τ.xy, txy_c=s.τ.xy_c, tII=s.τ.II,
+                toxx=s.τ_o.xx, toyy=s.τ_o.yy, toxy=s.τ_o.xy, toxy_c=s.τ_o.xy_c,
+                eta=s.viscosity.η, eta_v=s.viscosity.ηv, eta_vep=s.viscosity.η_vep,
+                EII_pl=s.EII_pl, evol_pl=s.ε_vol_pl, EVol_pl=s.EVol_pl, fx=ρg[0], fy=ρg[1], RP=s.R.RP, Rx=s.R.Rx, Ry=s.R.Ry,
+                omega_xy=s.ω.xy, phase_c=phase_ratios.center, phase_v=phase_ratios.vertex)
+    f = _lib.VEP2DFields()
+    for n in _lib.VEP_NAMES:
+        setattr(f, n, ptr(vals.get(n)))
+    f._keep = vals
+    return f
+
+
+def vep_params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=50.0e3, iterMin=1.0e2, nout=500, verbose=True, λ_relaxation=0.2,
+                 viscosity_relaxation=1.0e-2, viscosity_cutoff=(-float("inf"), float("inf")), strain_increment=False,
+                 free_surface=False, **_):
+    if strain_increment or free_surface:
+        raise NotImplementedError("strain_increment / free_surface variants of the VEP driver are not built (SURVEY §8f)")
+    ni = stokes._ni
+    _di = _center_inv(grid)
+    p = _lib.VEP2DParams()
+    p.nx, p.ny = ni
+    p.nxg, p.nyg = [(_ng(d) or ni[d]) for d in range(2)]
+    p._dx, p._dy = _di
+    p.dt, p.r, p.theta_dtau, p.eta_dtau, p.eps_rel, p.eps_abs = float(dt), pt.r, pt.θ_dτ, pt.ηdτ, pt.ϵ_rel, pt.ϵ_abs
+    p.iterMax, p.iterMin, p.nout = int(iterMax), int(iterMin), int(nout)
+    if flow_bcs is not None:
+        p.free_slip, p.no_slip, p.periodic = (_lib.bcmask(flow_bcs.free_slip), _lib.bcmask(flow_bcs.no_slip), _lib.bcmask(flow_bcs.periodic))
+    p.lambda_relaxation, p.viscosity_relaxation = float(λ_relaxation), float(viscosity_relaxation)
+    p.cutoff_lo, p.cutoff_hi = float(viscosity_cutoff[0]), float(viscosity_cutoff[1])
+    p.verbose = int(bool(verbose))
+    return p
+
+
+def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h):
+    """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs) -- Stokes2D.jl:577-866"""
+    if len(stokes._ni) != 2:
+        raise NotImplementedError("3D multiphase VEP driver is not built (SURVEY §8f rank 1)")
+    p = vep_params2d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
+    f = vep_fields2d(stokes, ρg, phase_ratios)
+    rh = rheology_table(rheology)
+    hist = _Hist(int(p.iterMax // p.nout + 2))
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    h.call("jrx_stokes2d_vep_solve", C.byref(f), C.byref(rh), C.byref(p), C.byref(hist.c))
+    return hist.result(2)
+
+
+def tensor_invariant_(A, *, handle=None):
+    """tensor_invariant!(A::SymmetricTensor) (2D) -- StressKernels.jl:443-470"""
+    _require_gpu(A.xx)
+    if A.xx.dim() != 2:
+        raise NotImplementedError("3D tensor_invariant! is not built")
+    h = handle or _lib.default_handle(A.xx.device.index)
+    torch.cuda.current_stream(A.xx.device).synchronize()
+    h.call("jrx_tensor_invariant2d", C.c_void_p(ptr(A.II)), C.c_void_p(ptr(A.xx)), C.c_void_p(ptr(A.yy)), C.c_void_p(ptr(A.xy)),
+           C.c_int64(A.xx.shape[0]), C.c_int64(A.xx.shape[1]))
+
+
+def compute_viscosity_(stokes, phase_ratios, args, rheology, cutoff=(-float("inf"), float("inf")), *, relaxation=1.0, handle=None):
+    """compute_viscosity!(stokes, phase_ratios, args, rheology, cutoff) for the table rheology (rheology/Viscosity.jl:203-216)"""
+    _require_gpu(stokes)
+    h = handle or _lib.default_handle(stokes.P.device.index)
+    pt = SimpleNamespace(r=0.0, θ_dτ=1.0, ηdτ=1.0, ϵ_rel=0.0, ϵ_abs=0.0)
+    fake = SimpleNamespace(_di=dict(center=(1.0, 1.0)))
+    p = vep_params2d(stokes, pt, fake, None, 1.0, viscosity_cutoff=cutoff)
+    f = vep_fields2d(stokes, (stokes.P, stokes.P), phase_ratios)
+    rh = rheology_table(rheology)
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    h.call("jrx_vep2d_compute_viscosity", C.byref(f), C.byref(rh), C.byref(p), C.c_double(float(relaxation)))
+
+
+def solve_(stokes, pt_stokes, grid_or_di, flow_bcs, ρg, *rest, kwargs=None, handle=None):
     """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, K, G, dt, igg; kwargs)   [3D, Stokes3D.jl:25-186]
        solve!(stokes, pt_stokes, grid, flow_bcs, ρg, G, K, dt, igg; kwargs)   [2D, Stokes2D.jl:181-325]
+       solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs)   [2D VEP, Stokes2D.jl:577-866]
 
     `kwargs` is the reference's required keyword holding iterMax, nout, b_width, verbose.
     Returns the reference's NamedTuple as a namespace (iter, err_evo1, err_evo2, norm_Rx, ...).
@@ -155,6 +253,13 @@ def solve_(stokes, pt_stokes, grid_or_di, flow_bcs, ρg, A, B, dt, igg=None, *, 
     grid = _as_grid(stokes, grid_or_di)
     ni, dev = stokes._ni, stokes.P.device
     nD = len(ni)
+    from .arrays import PhaseRatios
+    if rest and isinstance(rest[0], PhaseRatios):          # (phase_ratios, rheology, args, dt[, igg]) -> multiphase VEP variant
+        phase_ratios, rheology, args, dt = rest[:4]
+        return _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h)
+    if len(rest) < 3:
+        raise TypeError("solve_: expected (K, G, dt[, igg]) / (G, K, dt[, igg]) or (phase_ratios, rheology, args, dt[, igg])")
+    A, B, dt = rest[:3]
     if nD == 3:
         K, G = _as_field(A, ni, dev), _as_field(B, ni, dev)
         p = params3d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)

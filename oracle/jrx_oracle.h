@@ -156,6 +156,51 @@ void orc_thermal2d_check_res(const orc_thermal2d *t, const orc_thermal_params2d 
 int32_t orc_heatdiffusion_PT2d(const orc_thermal2d *t, const orc_thermal_params2d *p,
                                int64_t *iter_out, double *norm_ResT, int64_t cap, int64_t *nnorms);
 
+/* ---- 2D multiphase visco-elasto-plastic Stokes (Stokes2D.jl:577-866; BASELINE config 5: shear band) ----
+ * Restricted to what test/test_shearband2D.jl evaluates: per-phase LinearViscous eta, ConstantElasticity (G, Kb),
+ * DruckerPrager_regularised (C, phi, psi, eta_vp), constant density (rho*g given as arrays).  GeoParams is not
+ * vendored in the reference; the forms used are stated at each function (ASSUMED where marked). */
+#define ORC_MAXPHASE 8
+typedef struct orc_rheology {
+    int32_t nphase;
+    double eta[ORC_MAXPHASE], G[ORC_MAXPHASE], Kb[ORC_MAXPHASE];
+    int32_t is_pl[ORC_MAXPHASE];
+    double C[ORC_MAXPHASE], sinphi[ORC_MAXPHASE], cosphi[ORC_MAXPHASE], sinpsi[ORC_MAXPHASE], eta_vp[ORC_MAXPHASE];
+} orc_rheology;
+
+typedef struct orc_vep2d {
+    double *P, *P0, *divV, *Q;              /* ni */
+    double *Vx, *Vy, *Ux, *Uy;
+    double *exx, *eyy, *exy, *exy_c;        /* strain rate: centre, centre, vertex, centre copy */
+    double *eplxx, *eplyy, *eplxy, *eplxy_c;/* plastic strain rate */
+    double *dexy_c;                         /* Δε.xy_c (shear2center! of a zero tensor here) and its vertex source */
+    double *dexy;
+    double *txx, *tyy, *txy, *txy_c, *tII;  /* τ: centre, centre, vertex, centre shear, invariant */
+    double *toxx, *toyy, *toxy, *toxy_c;
+    double *eta, *eta_v, *eta_vep;          /* ni, ni.+1, ni */
+    double *EII_pl, *evol_pl, *EVol_pl;     /* ni */
+    double *fx, *fy;                        /* ρg */
+    double *RP, *Rx, *Ry;
+    double *omega_xy;                       /* ni.+1 */
+    double *phase_c, *phase_v;              /* [nphase][nx][ny] and [nphase][nx+1][ny+1], phase index fastest (CellArray) */
+} orc_vep2d;
+
+typedef struct orc_vep_params2d {
+    int64_t nx, ny, nxg, nyg;
+    double _dx, _dy;
+    double dt, r, theta_dtau, eta_dtau, eps_rel, eps_abs;
+    int64_t iterMax, iterMin, nout;
+    uint32_t free_slip, no_slip, periodic;
+    double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
+    int32_t staggered_invariant_mean_of_squares;  /* 0: (mean xy)^2 ; 1: mean(xy^2)  -- GeoParams second_invariant_staggered */
+} orc_vep_params2d;
+
+int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res);
+void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, double *lamv, const orc_rheology *rh,
+                      const orc_vep_params2d *p);
+void orc_tensor_invariant2d(double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny, int32_t mode);
+void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -347,3 +347,84 @@ def thermal2d_check_res(arr: dict, p: ThermalParams2D):
 
 def num_threads() -> int:
     return lib().orc_num_threads()
+
+
+# ---------------------------------------------------------------- 2D multiphase VEP (shear band)
+VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
+             "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
+             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v"]
+VEP2D = _mkstruct("VEP2D", VEP_NAMES)
+MAXPHASE = 8
+
+
+class Rheology(C.Structure):
+    _fields_ = [("nphase", C.c_int32)] + [(k, C.c_double * MAXPHASE) for k in ("eta", "G", "Kb")] + [("is_pl", C.c_int32 * MAXPHASE)] + \
+               [(k, C.c_double * MAXPHASE) for k in ("C", "sinphi", "cosphi", "sinpsi", "eta_vp")]
+
+
+class VEPParams2D(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nxg", C.c_int64), ("nyg", C.c_int64), ("_dx", C.c_double), ("_dy", C.c_double),
+                ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
+                ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("iterMin", C.c_int64), ("nout", C.c_int64),
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
+                ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
+                ("staggered_invariant_mean_of_squares", C.c_int32)]
+
+
+def vep_shapes2d(nx, ny, nphase):
+    c, v = (nx, ny), (nx + 1, ny + 1)
+    s = {n: c for n in VEP_NAMES}
+    s.update(Vx=(nx + 1, ny + 2), Vy=(nx + 2, ny + 1), Ux=(nx + 1, ny + 2), Uy=(nx + 2, ny + 1), exy=v, eplxy=v, dexy=v, txy=v, toxy=v,
+             eta_v=v, omega_xy=v, Rx=(nx - 1, ny), Ry=(nx, ny - 1), phase_c=(nphase, nx, ny), phase_v=(nphase, nx + 1, ny + 1))
+    return s
+
+
+def rheology_struct(phases: list) -> Rheology:
+    """phases: list of dict(eta, G, Kb, C, phi_deg, psi_deg, eta_vp) -- C is the GeoParams cohesion parameter"""
+    import math
+    r = Rheology()
+    r.nphase = len(phases)
+    for q, ph in enumerate(phases):
+        r.eta[q], r.G[q], r.Kb[q] = ph["eta"], ph["G"], ph["Kb"]
+        pl = "C" in ph and ph["C"] is not None
+        r.is_pl[q] = int(pl)
+        if pl:
+            r.C[q], r.eta_vp[q] = ph["C"], ph.get("eta_vp", 0.0)
+            r.sinphi[q], r.cosphi[q] = math.sin(math.radians(ph["phi_deg"])), math.cos(math.radians(ph["phi_deg"]))
+            r.sinpsi[q] = math.sin(math.radians(ph.get("psi_deg", 0.0)))
+    return r
+
+
+def vep_params2d(ni, _di, dt, pt, *, iterMax=50_000, iterMin=100, nout=500, free_slip=None, no_slip=None, periodic=None,
+                 lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), stag_mode=0, ni_g=None) -> VEPParams2D:
+    ni_g = ni_g or ni
+    return VEPParams2D(ni[0], ni[1], ni_g[0], ni_g[1], _di[0], _di[1], dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"], pt["eps_rel"],
+                       pt["eps_abs"], int(iterMax), int(iterMin), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic),
+                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1], stag_mode)
+
+
+def vep2d(arr: dict) -> VEP2D:
+    f = VEP2D()
+    for n in VEP_NAMES:
+        setattr(f, n, _p(arr.get(n)))
+    return f
+
+
+def stokes2d_vep_solve(arr: dict, rh: Rheology, p: VEPParams2D) -> dict:
+    res = _Res(int(p.iterMax // p.nout + 2))
+    f = vep2d(arr)
+    L = lib()
+    L.orc_stokes2d_vep_solve.restype = C.c_int32
+    L.orc_stokes2d_vep_solve(C.byref(f), C.byref(rh), C.byref(p), C.byref(res.c))
+    return res.asdict(2)
+
+
+def tensor_invariant2d(xx, yy, xy, mode=0):
+    II = np.zeros_like(xx, order="F")
+    lib().orc_tensor_invariant2d(_p(II), _p(xx), _p(yy), _p(xy), C.c_int64(xx.shape[0]), C.c_int64(xx.shape[1]), C.c_int32(mode))
+    return II
+
+
+def compute_viscosity2d(arr, rh, p, nu=1.0):
+    f = vep2d(arr)
+    lib().orc_compute_viscosity2d(C.byref(f), C.byref(rh), C.byref(p), C.c_double(nu))

@@ -1,0 +1,285 @@
+/* oracle/stokes2d_vep.c -- TEST INFRASTRUCTURE ONLY (see jrx_oracle.h).
+ * CPU restatement of the 2D multiphase visco-elasto-plastic PT Stokes driver of JustRelax.jl
+ * (src/stokes/Stokes2D.jl:577-866) as test/test_shearband2D.jl exercises it.
+ *
+ * Third-party arithmetic (GeoParams.jl >= 0.7.19, not vendored) restated from the reference's call sites and docs
+ * (docs/src/man/constitutive_equations.md:23,87,93) -- ASSUMED forms:
+ *   second_invariant(xx,yy,xy)            = sqrt(0.5*(xx^2+yy^2) + xy^2)
+ *   DruckerPrager_regularised: F          = tauII - cos(phi)*C - sin(phi)*P          (lambda-term handled by the caller)
+ *                              dQ/dtau_ij = 0.5*tau_ij/tauII (shear slot already halved by StressUpdate.jl:448-452)
+ *                              dQ/dP = -sin(psi),  dF/dP = -sin(phi)
+ *   compute_viscosity_tauII(CompositeRheology(visc, el, pl)) with dt = Inf (Viscosity.jl:599-603): the linear viscosity
+ *   second_invariant_staggered(xx,yy,(xy1..4)): selectable, see orc_vep_params2d
+ * Pinned only by the regression scalars of test/test_shearband2D.jl:197-201 (tests/test_oracle_golden.py).
+ *
+ * The reference's stress kernel (StressKernels.jl:992-1144) reads neighbouring centre stresses for the vertex update
+ * while other threads overwrite them in the same launch (a data race); here the vertex pass runs first on the old
+ * centre stresses, then the centre pass (what a GPU launch does when all loads precede the stores). */
+#include "jrx_oracle.h"
+#include "common.h"
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+#define C2(A, i, j) (A)[IDX2(nx, i, j)]
+#define V2(A, i, j) (A)[IDX2(nx + 1, i, j)]
+
+static inline double sinv2(double xx, double yy, double xy) { return sqrt(0.5 * (xx * xx + yy * yy) + xy * xy); }
+
+static inline double sinv_stag(double xx, double yy, double a, double b, double c, double d, int mode)
+{
+    if (mode) return sqrt(0.5 * (xx * xx + yy * yy) + 0.25 * (a * a + b * b + c * c + d * d));
+    double m = 0.25 * (a + b + c + d);
+    return sqrt(0.5 * (xx * xx + yy * yy) + m * m);
+}
+
+/* fn_ratio (src/phases/phases.jl:6-15) */
+static inline double ratio_avg(const double *val, const double *r, int n)
+{
+    double x = 0.0;
+    for (int q = 0; q < n; q++) x += (r[q] == 0.0) ? 0.0 : val[q] * r[q];
+    return x;
+}
+
+/* plastic_params_phase (StressUpdate.jl:152-176): ratio-weighted parameters; is_pl if any phase is plastic */
+static inline void plastic_params(const orc_rheology *rh, const double *r, int *is_pl, double *eta_reg)
+{
+    *is_pl = 0; *eta_reg = 0.0;
+    for (int q = 0; q < rh->nphase; q++) {
+        if (rh->is_pl[q]) { *is_pl = 1; *eta_reg += rh->eta_vp[q] * r[q]; }
+    }
+}
+
+/* compute_yieldfunction_phase (StressUpdate.jl:399-410): sum_i r_i F_i, non-plastic phases contribute tauII */
+static inline double yield_F(const orc_rheology *rh, const double *r, double P, double tII)
+{
+    double F = 0.0;
+    for (int q = 0; q < rh->nphase; q++) {
+        if (r[q] == 0.0) continue;
+        double Fq = rh->is_pl[q] ? (tII - rh->cosphi[q] * rh->C[q] - rh->sinphi[q] * P) : tII;
+        F += r[q] * Fq;
+    }
+    return F;
+}
+
+/* compute_plastic_gradients_phase (StressUpdate.jl:476-495) */
+static inline void plastic_grad(const orc_rheology *rh, const double *r, const double t[3], double dQdt[3], double *dQdP, double *dFdP)
+{
+    dQdt[0] = dQdt[1] = dQdt[2] = 0.0; *dQdP = 0.0; *dFdP = 0.0;
+    const double tII = sinv2(t[0], t[1], t[2]);
+    for (int q = 0; q < rh->nphase; q++) {
+        if (r[q] == 0.0 || !rh->is_pl[q]) continue;
+        const double g0 = 0.5 * t[0] / tII, g1 = 0.5 * t[1] / tII, g2 = 0.5 * (t[2] / tII);
+        dQdt[0] = fma(r[q], g0, dQdt[0]); dQdt[1] = fma(r[q], g1, dQdt[1]); dQdt[2] = fma(r[q], g2, dQdt[2]);
+        *dQdP = fma(r[q], -rh->sinpsi[q], *dQdP);
+        *dFdP = fma(r[q], -rh->sinphi[q], *dFdP);
+    }
+}
+
+/* update_stresses_center_vertex_ps! 2D (StressKernels.jl:992-1144) */
+void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, double *lamv, const orc_rheology *rh,
+                      const orc_vep_params2d *p)
+{
+    const int64_t nx = p->nx, ny = p->ny;
+    const int np = rh->nphase;
+    const double dt = p->dt, th = p->theta_dtau, rel = p->lambda_relaxation;
+    /* vertex pass */
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < ny + 1; j++)
+        for (int64_t i = 0; i < nx + 1; i++) {
+            const int64_t i0 = clampi(i - 1, 0, nx - 1), ic = clampi(i, 0, nx - 1), j0 = clampi(j - 1, 0, ny - 1), jc = clampi(j, 0, ny - 1);
+#define AVC(A) (0.25 * (C2(A, i0, j0) + C2(A, ic, jc) + C2(A, i0, jc) + C2(A, ic, j0)))   /* av_clamped :1311-1313 */
+            const double Pv = AVC(theta), exxv = AVC(f->exx), eyyv = AVC(f->eyy), txxv = AVC(f->txx), tyyv = AVC(f->tyy);
+            const double toxxv = AVC(f->toxx), toyyv = AVC(f->toyy);
+            const double *rv = f->phase_v + (size_t)np * IDX2(nx + 1, i, j);
+            int is_pl; double eta_reg;
+            plastic_params(rh, rv, &is_pl, &eta_reg);
+            const double _Gdt = inv(ratio_avg(rh->G, rv, np) * dt);
+            const double Kv = ratio_avg(rh->Kb, rv, np);
+            const double etav = 4.0 / (1.0 / C2(f->eta, i0, j0) + 1.0 / C2(f->eta, ic, jc) + 1.0 / C2(f->eta, i0, jc) + 1.0 / C2(f->eta, ic, j0));
+            const double dtr = inv(th + etav * _Gdt + 1.0);
+            const size_t v = IDX2(nx + 1, i, j);
+            const double txy = f->txy[v];
+            const double dxx = stress_increment(txxv, toxxv, etav, exxv, _Gdt, dtr);
+            const double dyy = stress_increment(tyyv, toyyv, etav, eyyv, _Gdt, dtr);
+            const double dxy = stress_increment(txy, f->toxy[v], etav, f->exy[v], _Gdt, dtr);
+            const double tt[3] = {txxv + dxx, tyyv + dyy, txy + dxy};
+            const double tIIv = sinv2(dxx + txxv, dyy + tyyv, dxy + txy);
+            double dQdt[3], dQdP, dFdP;
+            plastic_grad(rh, rv, tt, dQdt, &dQdP, &dFdP);
+            const double vol = isinf(Kv) ? 0.0 : Kv * dt * dFdP * dQdP;
+            const double F = yield_F(rh, rv, Pv, tIIv);
+            if (is_pl && tIIv != 0.0 && F > 0) {
+                lamv[v] = fma(1.0 - rel, lamv[v], rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol)));
+                const double epl = lamv[v] * dQdt[2];
+                f->txy[v] = txy + fma(-2.0 * etav * epl, dtr, dxy);
+                f->eplxy[v] = epl;
+            } else {
+                f->txy[v] = txy + dxy;
+                f->eplxy[v] = 0.0;
+            }
+        }
+    /* centre pass */
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < ny; j++)
+        for (int64_t i = 0; i < nx; i++) {
+            const size_t c = IDX2(nx, i, j);
+            const double *rc = f->phase_c + (size_t)np * c;
+            const double _Gdt = inv(ratio_avg(rh->G, rc, np) * dt);
+            int is_pl; double eta_reg;
+            plastic_params(rh, rc, &is_pl, &eta_reg);
+            const double K = ratio_avg(rh->Kb, rc, np);
+            const double e = f->eta[c];
+            const double dtr = 1.0 / (th + e * _Gdt + 1.0);
+            const double exyc = (V2(f->exy, i, j) + V2(f->exy, i + 1, j) + V2(f->exy, i, j + 1) + V2(f->exy, i + 1, j + 1)) / 4;   /* cache_tensors :208-222 */
+            const double eij[3] = {f->exx[c], f->eyy[c], exyc};
+            double tij[3] = {f->txx[c], f->tyy[c], f->txy_c[c]};
+            const double toij[3] = {f->toxx[c], f->toyy[c], f->toxy_c[c]};
+            double d[3];
+            for (int q = 0; q < 3; q++) d[q] = stress_increment(tij[q], toij[q], e, eij[q], _Gdt, dtr);
+            double tII = sinv2(d[0] + tij[0], d[1] + tij[1], d[2] + tij[2]);
+            const double tt[3] = {tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]};
+            double dQdt[3], dQdP, dFdP;
+            plastic_grad(rh, rc, tt, dQdt, &dQdP, &dFdP);
+            const double vol = isinf(K) ? 0.0 : K * dt * dFdP * dQdP;
+            const double Pr = theta[c];
+            const double F = yield_F(rh, rc, Pr, tII);
+            if (is_pl && tII != 0.0 && F > 0) {
+                lam[c] = fma(1.0 - rel, lam[c], rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol)));
+                double epl[3];
+                for (int q = 0; q < 3; q++) { epl[q] = lam[c] * dQdt[q]; d[q] = fma(-2.0 * e * epl[q], dtr, d[q]); tij[q] = d[q] + tij[q]; }
+                f->evol_pl[c] = -lam[c] * dQdP;
+                f->txx[c] = tij[0]; f->tyy[c] = tij[1]; f->txy_c[c] = tij[2];
+                f->eplxx[c] = epl[0]; f->eplyy[c] = epl[1];
+                tII = sinv2(tij[0], tij[1], tij[2]);
+            } else {
+                f->evol_pl[c] = 0.0;
+                f->txx[c] = d[0] + tij[0]; f->tyy[c] = d[1] + tij[1]; f->txy_c[c] = d[2] + tij[2];
+                f->eplxx[c] = 0.0; f->eplyy[c] = 0.0;
+            }
+            f->tII[c] = tII;
+            f->eta_vep[c] = tII * 0.5 * inv(sinv2(eij[0], eij[1], eij[2]));
+            f->P[c] = Pr - (isinf(K) ? 0.0 : K * dt * lam[c] * dQdP);
+        }
+}
+
+/* update_viscosity_τII! (rheology/Viscosity.jl:67-106,382-418): centre and vertex viscosities relaxed towards the
+ * per-phase value; with LinearViscous + dt = Inf the composite viscosity is the linear one (ASSUMED, see header) */
+static inline double phase_viscosity(const orc_rheology *rh, const double *r)
+{
+    for (int q = 0; q < rh->nphase; q++)
+        if (r[q] > 0.999) return rh->eta[q];
+    double s = 0.0;
+    for (int q = 0; q < rh->nphase; q++)
+        if (r[q] != 0.0) s += inv(rh->eta[q]) * r[q];
+    return inv(s);
+}
+void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu)
+{
+    const int64_t nx = p->nx, ny = p->ny;
+    const int np = rh->nphase;
+    for (int64_t c = 0; c < nx * ny; c++) {
+        double e = phase_viscosity(rh, f->phase_c + (size_t)np * c);
+        e = e * nu + f->eta[c] * (1.0 - nu);                        /* continuation_linear */
+        f->eta[c] = fmin(fmax(e, p->cutoff_lo), p->cutoff_hi);
+    }
+    if (f->eta_v)
+        for (int64_t v = 0; v < (nx + 1) * (ny + 1); v++) {
+            double e = phase_viscosity(rh, f->phase_v + (size_t)np * v);
+            e = e * nu + f->eta_v[v] * (1.0 - nu);
+            f->eta_v[v] = fmin(fmax(e, p->cutoff_lo), p->cutoff_hi);
+        }
+}
+
+/* tensor_invariant_kernel! 2D (StressKernels.jl:458-470) */
+void orc_tensor_invariant2d(double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny, int32_t mode)
+{
+    for (int64_t j = 0; j < ny; j++)
+        for (int64_t i = 0; i < nx; i++)
+            II[IDX2(nx, i, j)] = sinv_stag(xx[IDX2(nx, i, j)], yy[IDX2(nx, i, j)], V2(xy, i, j), V2(xy, i + 1, j), V2(xy, i, j + 1), V2(xy, i + 1, j + 1), mode);
+}
+
+static void shear2center(double *c, const double *v, int64_t nx, int64_t ny)
+{   /* Interpolations.jl:304-309 */
+    if (!c || !v) return;
+    for (int64_t j = 0; j < ny; j++)
+        for (int64_t i = 0; i < nx; i++) c[IDX2(nx, i, j)] = 0.25 * (V2(v, i, j) + V2(v, i + 1, j) + V2(v, i, j + 1) + V2(v, i + 1, j + 1));
+}
+
+int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res)
+{
+    const int64_t nx = p->nx, ny = p->ny;
+    const size_t n = (size_t)nx * ny, nv = (size_t)(nx + 1) * (ny + 1);
+    const int np = rh->nphase;
+    double *etatau = malloc(n * 8), *theta = malloc(n * 8), *lam = calloc(n, 8), *lamv = calloc(nv, 8), *Kc = malloc(n * 8), *Gc = malloc(n * 8);
+    memcpy(f->P0, f->P, n * 8);                      /* @copy stokes.P0 stokes.P :608 */
+    orc_compute_maxloc2d(etatau, f->eta, nx, ny);
+    memcpy(theta, f->P, n * 8);                      /* θ = deepcopy(stokes.P) :635 */
+    memset(f->eplxx, 0, n * 8); memset(f->eplyy, 0, n * 8); memset(f->eplxy_c, 0, n * 8);   /* :641-643 */
+    for (size_t c = 0; c < n; c++) { Kc[c] = ratio_avg(rh->Kb, f->phase_c + np * c, np); Gc[c] = ratio_avg(rh->G, f->phase_c + np * c, np); }
+
+    /* views of this problem for the shared 2D kernels */
+    orc_fields2d g;
+    memset(&g, 0, sizeof(g));
+    g.P = f->P; g.P0 = f->P0; g.divV = f->divV; g.Q = f->Q; g.Vx = f->Vx; g.Vy = f->Vy; g.Ux = f->Ux; g.Uy = f->Uy;
+    g.txx = f->txx; g.tyy = f->tyy; g.txy = f->txy; g.exx = f->exx; g.eyy = f->eyy; g.exy = f->exy;
+    g.eta = f->eta; g.fx = f->fx; g.fy = f->fy; g.RP = f->RP; g.Rx = f->Rx; g.Ry = f->Ry;
+    orc_params2d q;
+    memset(&q, 0, sizeof(q));
+    q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
+    q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
+
+    double err_it1 = 1.0, err = 1.0;
+    int64_t iter = 0, cont = 0;
+    res->status = 0;
+    while (iter <= p->iterMax) {
+        if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;    /* :650-651 */
+        orc_compute_maxloc2d(etatau, f->eta, nx, ny);
+        orc_compute_divV2d(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy);
+        orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :663-676 */
+        orc_compute_strain_rate2d(&g, &q);
+        orc_vep2d_stress(f, theta, lam, lamv, rh, p);
+        orc_compute_viscosity2d(f, rh, p, p->viscosity_relaxation);
+        orc_compute_V2d(&g, etatau, &q);             /* free-surface form with dt*free_surface = 0 reduces to the plain one */
+        orc_velocity2displacement2d(&g, &q);
+        orc_flow_bcs2d(f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic);
+        iter += 1;
+        if (iter % p->nout == 0 && iter > 1) {
+            orc_compute_Res2d(&g, &q);
+            double s[3];
+            orc_residual_sumsq2d(&g, &q, s);
+            const double nRx = sqrt(s[0]) / sqrt((double)((p->nxg - 2) * (p->nyg - 1)));
+            const double nRy = sqrt(s[1]) / sqrt((double)((p->nxg - 1) * (p->nyg - 2)));
+            const double nDV = sqrt(s[2]) / sqrt((double)(p->nxg * p->nyg));
+            err = fmax(nRx, fmax(nRy, nDV));
+            if (isnan(nRx) || isnan(nRy) || isnan(nDV)) err = NAN;
+            if (cont < res->cap) { res->norm_Rx[cont] = nRx; res->norm_Ry[cont] = nRy; res->norm_divV[cont] = nDV; res->err_evo1[cont] = err; res->err_evo2[cont] = iter; }
+            if (cont == 0) err_it1 = err;
+            cont++;
+            if (isnan(err)) { res->status = 1; break; }
+        }
+    }
+    res->iter = iter;
+    res->nchecks = cont < res->cap ? cont : res->cap;
+    if (res->status == 0) {
+        if (f->omega_xy)                                /* compute_vorticity! :831-833 */
+            for (int64_t j = 0; j < ny + 1; j++)
+                for (int64_t i = 0; i < nx + 1; i++)
+                    V2(f->omega_xy, i, j) = 0.5 * ((-f->Vy[IDX2(nx + 2, i, j)] + f->Vy[IDX2(nx + 2, i + 1, j)]) * p->_dx -
+                                                   (-f->Vx[IDX2(nx + 1, i, j)] + f->Vx[IDX2(nx + 1, i, j + 1)]) * p->_dy);
+        shear2center(f->exy_c, f->exy, nx, ny);
+        shear2center(f->eplxy_c, f->eplxy, nx, ny);
+        shear2center(f->dexy_c, f->dexy, nx, ny);
+        for (int64_t j = 0; j < ny; j++)                /* accumulate_tensor! / accumulate_vol! :842-843 */
+            for (int64_t i = 0; i < nx; i++) {
+                const size_t c = IDX2(nx, i, j);
+                f->EII_pl[c] += sinv_stag(f->eplxx[c], f->eplyy[c], V2(f->eplxy, i, j), V2(f->eplxy, i + 1, j), V2(f->eplxy, i, j + 1),
+                                          V2(f->eplxy, i + 1, j + 1), p->staggered_invariant_mean_of_squares) * p->dt;
+                f->EVol_pl[c] += p->dt * f->evol_pl[c];
+            }
+        memcpy(f->toxx, f->txx, n * 8); memcpy(f->toyy, f->tyy, n * 8); memcpy(f->toxy, f->txy, nv * 8);    /* multi_copy! :845-846 */
+        memcpy(f->toxy_c, f->txy_c, n * 8);
+    }
+    free(etatau); free(theta); free(lam); free(lamv); free(Kc); free(Gc);
+    return res->status;
+}

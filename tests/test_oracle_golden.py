@@ -219,3 +219,35 @@ def test_diffusion2d(oracle, jr):
     T = s.arrays["T"]
     assert T[17, 17] == pytest.approx(1817.9448461176817, abs=1.0e-1)     # Julia T[18,18]
     assert T[16, 16] == pytest.approx(1827.4674313638786, abs=1.0e-1)     # Julia T[17,17]
+
+
+def _vep_params(oracle, s, **over):
+    pt, b = s.pt, s.flow_bcs
+    kw = dict(iterMax=s.kwargs["iterMax"], nout=s.kwargs["nout"], stag_mode=1)
+    kw.update(over)
+    return oracle.vep_params2d(s.ni, s.grid._di["center"], s.dt, dict(r=pt.r, theta_dtau=pt.θ_dτ, eta_dtau=pt.ηdτ, eps_rel=pt.ϵ_rel,
+                               eps_abs=pt.ϵ_abs), free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic, **kw)
+
+
+def test_shearband2d(oracle, jr):
+    """test/test_shearband2D.jl:194-202 (BASELINE config 5): 10 steps, err < 1e-6;
+    extrema(τII) ≈ (1.5128689768248313, 1.6415759440014273) atol 1e-3; τII[end] ≈ 1.6376258215356436 atol 1e-4.
+    This is what pins the ASSUMED GeoParams forms (Drucker-Prager F, ∂Q/∂τ, second_invariant_staggered)."""
+    s = jr.miniapps.shearband2d(32)
+    assert (s.pt.Vpdτ, s.pt.θ_dτ, s.pt.ηdτ) == pytest.approx((0.016173411547086427, 13.339385241897977, 0.0017160522629188955), rel=1e-15)
+    rh = oracle.rheology_struct(s.extra["phases"])
+    p = _vep_params(oracle, s)
+    tII, t, sol = [], 0.0, []
+    for _ in range(10):
+        r = oracle.stokes2d_vep_solve(s.arrays, rh, p)
+        tII.append(s.arrays["txx"].max())
+        t += s.dt
+        sol.append(2 * s.extra["εbg"] * s.extra["η0"] * (1 - math.exp(-s.extra["G0"] * t / s.extra["η0"])))
+    assert r["err_evo1"][-1] < 1.0e-6
+    II = oracle.tensor_invariant2d(s.arrays["txx"], s.arrays["tyy"], s.arrays["txy"], 1)
+    assert II.min() == pytest.approx(1.5128689768248313, abs=1.0e-3)
+    assert II.max() == pytest.approx(1.6415759440014273, abs=1.0e-3)
+    assert tII[-1] == pytest.approx(1.6376258215356436, abs=1.0e-4)
+    assert sol[-1] == pytest.approx(1.8358, abs=1.0e-4)
+    # the other reading of second_invariant_staggered ((mean xy)^2) misses the lower extremum: it is not what GeoParams does
+    assert abs(oracle.tensor_invariant2d(s.arrays["txx"], s.arrays["tyy"], s.arrays["txy"], 0).min() - 1.5128689768248313) > 1.0e-3
