@@ -36,7 +36,7 @@ def _as_field(x, ni, dev):
 
 
 def _center_inv(grid):
-    _di = grid._di if isinstance(grid, Geometry) else None
+    _di = getattr(grid, "_di", None)
     return _di["center"] if isinstance(_di, dict) else _di
 
 
