@@ -26,9 +26,12 @@ A_STRESS = 28 * 8.0      # stress sweep: 21 reads + 7 writes
 A_VELOCITY = 17 * 8.0    # velocity sweep: 14 reads + 3 writes
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # L2<->fabric bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-# correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernel at
-# n = 512: profiles/r01_pmc_v3_fused_traffic.txt  (k_stress3d_zb<512,1,4>: FETCH_SIZE 15456777 KB, WRITE_SIZE 7410160 KB)
-PMC_TRAFFIC_STRESS_512 = (2 * 15456777.0 + 7410160.0) * 1024.0
+# correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
+# n = 512: profiles/r01_pmc_xcd_banded_traffic.txt
+#   k_stress3d_zb<512,1,4,xcd8>: FETCH_SIZE 13048845 KB, WRITE_SIZE 7410032 KB   (algorithmic: 21 + 7 passes of 1.074 GB)
+#   k_fused3d<64,4,16,xg8>:      FETCH_SIZE 19537921 KB, WRITE_SIZE 11148566 KB  (needs 25 + 10 passes)
+PMC_TRAFFIC_STRESS_512 = (2 * 13048845.0 + 7410032.0) * 1024.0
+PMC_TRAFFIC_FUSED_512 = (2 * 19537921.0 + 11148566.0) * 1024.0
 
 
 def cpu_baseline(n_cpu: int, budget_s: float):
@@ -113,14 +116,14 @@ def main():
         run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    tot_ms, sa_ms, sb_ms, sf_ms = run_timed(stokes, st, pt, geo, bcs, ρg, K, G, ητ, dt, args.steps, h)
+    tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, _ = run_timed(stokes, st, pt, geo, bcs, ρg, K, G, ητ, dt, args.steps, h)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
     if world > 1:
-        t = torch.tensor([el, tot_ms, sa_ms, sb_ms, sf_ms], dtype=torch.float64)
+        t = torch.tensor([el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, tot_ms, sa_ms, sb_ms, sf_ms = t.tolist()
+        el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms = t.tolist()
 
     if rank == 0:
         cells = float(n) ** 3
@@ -145,12 +148,16 @@ def main():
         }
         it_gbs = A_ALG * cells * (args.steps / (tot_ms * 1e-3)) / 1e9
         if fused:
-            g = A_ALG * cells / (sf_ms * 1e-3) / 1e9
+            g = A_ALG * cells / (sk_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm",
-                               "kernel": "fused PT iteration = k_fused3d (velocity sweep m + BCs + stress sweep m+1) + 3 BC + 3 boundary-plane "
-                                         "launches; algorithmic 360 B/cell per launch group (it moves 35 array passes = 280 B/cell)",
-                               "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "traffic": None,
-                               "avg_launch_ms": sf_ms, "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
+                               "kernel": "k_fused3d: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong "
+                                         "state); algorithmic 360 B/cell per launch (2-sweep floor of SURVEY 8d; the kernel itself needs "
+                                         "25 reads + 10 writes = 280 B/cell)",
+                               "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                               "traffic": PMC_TRAFFIC_FUSED_512 if n == 512 else None, "traffic_unit": "bytes per launch (PMC, offline)",
+                               "algorithmic_bytes_per_launch": A_ALG * cells, "avg_launch_ms": sk_ms,
+                               "launch_group_ms": sf_ms,
+                               "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
         elif split:
             out["roofline"] = {"bound": "hbm",
                                "kernel": "stress sweep = k_stress3d_zb + 3 boundary-plane launches (21 array reads + 7 writes = 224 B/cell)",

@@ -60,9 +60,13 @@ jrx_status jrx_destroy(jrx_handle *h);
 const char *jrx_last_error(const jrx_handle *h);   /* h may be NULL: last creation error */
 int32_t jrx_version(void);
 
-/* Tuning / debugging knobs.  Keys: "kernel_variant": 0 = default (z-marching fused sweeps, two per iteration);
- * 1 = simple one-thread-per-node kernels; 3 = experimental single fused iteration kernel (velocity sweep m + BCs +
- * stress sweep m+1 with ping-pong state; same results, currently not faster).  All produce bit-identical results. */
+/* Tuning / debugging knobs.  Keys: "kernel_variant" (3D Stokes):
+ *   0 = default: fused PT pipeline where it applies (single rank, no periodic_boundary! faces, nx >= 48, ny, nz >= 8,
+ *       and nx fills its 63-column tiles to >= 87 %): one kernel runs velocity sweep m + BCs + stress sweep m+1 with
+ *       ping-pong state arrays (the handle then owns a second set of the 10 state arrays); otherwise, and on
+ *       iterations whose results are observed, the two z-marching sweeps;
+ *   1 = simple one-thread-per-node kernels;  2 = z-marching sweeps only (two launches per iteration, no ping-pong set);
+ *   3 = fused pipeline wherever it is legal (ignores the tile-fill rule).  All variants produce bit-identical results. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)
@@ -74,7 +78,7 @@ typedef struct jrx_cart {
     int32_t rank, nprocs;
     int32_t dims[3], coords[3];
     int32_t periods[3];
-    int32_t neighbor[3][2];     /* [dim][0=left,1=right], -1 = physical boundary */
+    int32_t neighbor[3][2];     /* [dim][0=left,1=right], -1 = physical boundary; == rank for a periodic dim with dims[d]==1 */
 } jrx_cart;
 /* dims = all zeros -> balanced factorisation over the dimensions with n[d] > 1 */
 jrx_status jrx_cart_create(int32_t rank, int32_t nprocs, const int64_t n[3], const int32_t dims_in[3],
@@ -295,9 +299,10 @@ jrx_status jrx_thermal2d_check_res(jrx_handle *h, const jrx_thermal2d_fields *t,
 /* Runs `iters` PT iterations of the 3D loop body back to back (no norm checks) and reports device times
  * measured with hipEvents on the handle's stream inside that batch:
  *   times_ms[0] whole batch; [1] mean stand-alone stress sweep; [2] mean stand-alone velocity sweep;
- *   [3] mean fused launch group (velocity sweep m + BCs + stress sweep m+1), 0 when nothing was fused. */
+ *   [3] mean fused launch group (k_fused3d = velocity sweep m + BCs + stress sweep m+1, then the ghost-plane and
+ *   boundary-plane launches), 0 when nothing was fused; [4] mean k_fused3d launch alone; [5] reserved (0). */
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
-                                      const jrx_stokes3d_params *p, int64_t iters, double times_ms[4]);
+                                      const jrx_stokes3d_params *p, int64_t iters, double times_ms[6]);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 // dlopen'ed on first use so that single-GPU users never load it.
 #include "jrx_internal.hpp"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <rccl/rccl.h>
 
 struct jrx_comm_state {
@@ -27,6 +28,7 @@ struct jrx_comm_state {
     double *sbuf[2] = {nullptr, nullptr}, *rbuf[2] = {nullptr, nullptr};
     size_t cap = 0;     // doubles per buffer
     double *d_red = nullptr;
+    bool self_through_rccl = false;   // JRX_HALO_SELF_RCCL=1: route self-neighbour planes through ncclSend/ncclRecv (test hook)
 };
 
 namespace {
@@ -103,12 +105,23 @@ __global__ __launch_bounds__(256) void k_planes(PlaneSet S, int dir)
 
 }   // namespace
 
-bool jrx_comm_active(const jrx_handle *h) { return h && h->comm && h->comm->comm && h->comm->cart.nprocs > 1; }
+static bool has_self_neighbor(const jrx_cart &c)
+{
+    for (int d = 0; d < 3; d++)
+        if (c.neighbor[d][0] == c.rank || c.neighbor[d][1] == c.rank) return true;
+    return false;
+}
+// true when update_halo! has something to do: other ranks (RCCL) or a periodic dimension held by this rank alone
+bool jrx_comm_active(const jrx_handle *h)
+{
+    if (!h || !h->comm) return false;
+    return (h->comm->comm && h->comm->cart.nprocs > 1) || has_self_neighbor(h->comm->cart);
+}
 int jrx_comm_rank(const jrx_handle *h) { return (h && h->comm) ? h->comm->cart.rank : 0; }
 
 jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count)
 {
-    if (!jrx_comm_active(h)) return JRX_OK;
+    if (!jrx_comm_active(h) || !h->comm->comm || h->comm->cart.nprocs == 1) return JRX_OK;
     jrx_comm_state *c = h->comm;
     if (count > 8) return jrx_fail(h, JRX_ERR_ARG, "allreduce of more than 8 values");
     JRX_HIP(h, hipMemcpyAsync(c->d_red, vals, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -128,7 +141,6 @@ jrx_status jrx_halo_exchange(jrx_handle *h, hipStream_t s, int narrays, double *
     for (int dim = 0; dim < 3; dim++) {
         const int left = c->cart.neighbor[dim][0], right = c->cart.neighbor[dim][1];
         if (left < 0 && right < 0) continue;
-        if (c->cart.periods[dim]) return jrx_fail(h, JRX_ERR_UNSUPPORTED, "periodic halo exchange across ranks is not implemented");
         PlaneSet S;
         memset(&S, 0, sizeof(S));
         S.dim = dim;
@@ -168,15 +180,24 @@ jrx_status jrx_halo_exchange(jrx_handle *h, hipStream_t s, int narrays, double *
         S.buf[0] = c->sbuf[0]; S.buf[1] = c->sbuf[1];
         hipLaunchKernelGGL(k_planes, dim3(gx, na * 2), dim3(256), 0, s, S, 0);
         JRX_LAUNCH_CHECK(h);
+        const bool self = left == c->cart.rank && right == c->cart.rank;
+        if (self && !(c->comm && c->self_through_rccl)) {
+            // periodic dimension owned by this rank alone: the left ghost plane takes the right send plane and
+            // vice versa (ImplicitGlobalGrid copies locally in this case)
+            S.buf[0] = c->sbuf[1]; S.buf[1] = c->sbuf[0];
+            hipLaunchKernelGGL(k_planes, dim3(gx, na * 2), dim3(256), 0, s, S, 1);
+            JRX_LAUNCH_CHECK(h);
+            continue;
+        }
+        if (!c->comm) return jrx_fail(h, JRX_ERR_RCCL, "update_halo!: no RCCL communicator (jrx_comm_init not called?)");
+        // Sends first (left, right), then receives in the order right, left: when both neighbours are the same
+        // rank (periodic, 2 ranks in this dimension, or the rank itself) the k-th send to a peer is matched by that
+        // peer's k-th receive, and a left-going plane must land in the peer's right ghost plane.
         JRX_NCCL(h, c, c->GroupStart());
-        if (left >= 0) {
-            JRX_NCCL(h, c, c->Send(c->sbuf[0], (size_t)total, ncclDouble, left, c->comm, s));
-            JRX_NCCL(h, c, c->Recv(c->rbuf[0], (size_t)total, ncclDouble, left, c->comm, s));
-        }
-        if (right >= 0) {
-            JRX_NCCL(h, c, c->Send(c->sbuf[1], (size_t)total, ncclDouble, right, c->comm, s));
-            JRX_NCCL(h, c, c->Recv(c->rbuf[1], (size_t)total, ncclDouble, right, c->comm, s));
-        }
+        if (left >= 0) JRX_NCCL(h, c, c->Send(c->sbuf[0], (size_t)total, ncclDouble, left, c->comm, s));
+        if (right >= 0) JRX_NCCL(h, c, c->Send(c->sbuf[1], (size_t)total, ncclDouble, right, c->comm, s));
+        if (right >= 0) JRX_NCCL(h, c, c->Recv(c->rbuf[1], (size_t)total, ncclDouble, right, c->comm, s));
+        if (left >= 0) JRX_NCCL(h, c, c->Recv(c->rbuf[0], (size_t)total, ncclDouble, left, c->comm, s));
         JRX_NCCL(h, c, c->GroupEnd());
         S.buf[0] = c->rbuf[0]; S.buf[1] = c->rbuf[1];
         hipLaunchKernelGGL(k_planes, dim3(gx, na * 2), dim3(256), 0, s, S, 1);
@@ -207,7 +228,9 @@ jrx_status jrx_comm_init(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], c
     jrx_comm_state *c = new jrx_comm_state();
     c->cart = *cart;
     h->comm = c;
-    if (cart->nprocs == 1) return JRX_OK;      // nothing to exchange; norms are local
+    const char *env = getenv("JRX_HALO_SELF_RCCL");
+    c->self_through_rccl = env && env[0] == '1';
+    if (cart->nprocs == 1 && !(c->self_through_rccl && id)) return JRX_OK;      // no other rank; norms are local
     if (!id) return jrx_fail(h, JRX_ERR_ARG, "jrx_comm_init: id is NULL");
     JRX_TRY(load_rccl(h, c));
     JRX_HIP(h, hipSetDevice(h->device));

@@ -133,7 +133,7 @@ jrx_status jrx_cart_create(int32_t rank, int32_t nprocs, const int64_t n[3], con
             c[d] += sgn ? 1 : -1;
             int nb = -1;
             if (c[d] >= 0 && c[d] < dims[d]) nb = (c[0] * dims[1] + c[1]) * dims[2] + c[2];
-            else if (out->periods[d] && dims[d] > 1) {
+            else if (out->periods[d]) {            // dims[d] == 1: the rank is its own neighbour (IGG local copy)
                 c[d] = (c[d] + dims[d]) % dims[d];
                 nb = (c[0] * dims[1] + c[1]) * dims[2] + c[2];
             }

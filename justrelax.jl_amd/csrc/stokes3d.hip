@@ -314,7 +314,13 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     I.setU = out_of(*f);
     I.cur_is_user = true; I.stress_done = false;
     const Lay3 L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
-    I.fusable = h->kernel_variant == 3 && !jrx_comm_active(h) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
+    I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && !jrx_comm_active(h) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
+    if (I.fusable && h->kernel_variant == 0) {
+        // auto: the fused kernel covers a row with ceil(nx/63) 64-lane tiles (one halo column each); when that
+        // quantisation idles more than 15 % of the lanes (e.g. nx = 256: 5 tiles, 25 %) the two sweeps are faster
+        const i64 ntx = (p->nx + 62) / 63;
+        if (ntx * 64 * 100 > (i64)p->nx * 115) I.fusable = false;
+    }
     if (I.fusable) {
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
         double **S = h->scratch;
@@ -333,14 +339,17 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
 template <int TX, int TY, int KZ>
 static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc)
 {
+    // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
+    // fetched array passes per launch at 512^3)
     const int ntx = (a.L.nx + TX - 2) / (TX - 1), nty = (a.L.ny + TY - 2) / (TY - 1), ntz = (a.L.nz + KZ - 1) / KZ;
-    hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
+    hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
 
-// tev (optional): events recorded around the sweeps: [0] start, [1] after stress (or after the fused
-// launch incl. its BC / boundary-plane launches), [2] after velocity
+// tev (optional): events recorded around the sweeps: [0] start, [1] after the stress sweep (if one was launched),
+// [2] after the velocity sweep or after the fused launch group (k_fused3d + BCs + boundary planes),
+// [3] (fused only) directly after k_fused3d, so that [1] -> [3] is that kernel alone
 static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *tev, int *was_fused)
 {
     jrx_handle *h = I.h;
@@ -365,6 +374,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
         // 64 x 4 threads (A tile 63 x 3), 16 planes per chunk: best of the measured tile shapes (148 VGPRs -> 3 blocks/CU)
         JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc)));
+        if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
         JRX_TRY(launch_bcs(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
         // stress nodes on the planes i = nx, j = ny, k = nz: old τ from the current set, new V from dst
         SweepArgs e = a;
@@ -543,7 +553,7 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
 }
 
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
-                                      const jrx_stokes3d_params *p, int64_t iters, double times_ms[4])
+                                      const jrx_stokes3d_params *p, int64_t iters, double times_ms[6])
 {
     JRX_TRY(check_params(h, f, p));
     if (!etatau) return jrx_fail(h, JRX_ERR_ARG, "etatau is NULL");
@@ -554,7 +564,7 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     // kernels run on); at most 256 samples so that event bookkeeping stays negligible
     const int64_t stride = iters > 256 ? (iters + 255) / 256 : 1;
     const int nsamp = (int)((iters + stride - 1) / stride);
-    std::vector<hipEvent_t> evs((size_t)nsamp * 3);
+    std::vector<hipEvent_t> evs((size_t)nsamp * 4);
     std::vector<int> fused((size_t)nsamp, 0);
     for (auto &e : evs) JRX_HIP(h, hipEventCreate(&e));
     Iter3D I;
@@ -563,29 +573,33 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
     for (int64_t it = 0; it < iters; it++) {
         const bool samp = it % stride == 0;
-        JRX_TRY(iter_step(I, false, it + 1 < iters, samp ? &evs[(size_t)(it / stride) * 3] : nullptr, samp ? &fused[(size_t)(it / stride)] : nullptr));
+        JRX_TRY(iter_step(I, false, it + 1 < iters, samp ? &evs[(size_t)(it / stride) * 4] : nullptr, samp ? &fused[(size_t)(it / stride)] : nullptr));
     }
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_TRY(iter_end(I));
     JRX_HIP(h, hipStreamSynchronize(s));
     float ms = 0.f;
     JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
-    times_ms[0] = ms; times_ms[1] = times_ms[2] = times_ms[3] = 0.0;
-    double sa = 0.0, sb = 0.0, sf = 0.0;
+    times_ms[0] = ms; times_ms[1] = times_ms[2] = times_ms[3] = times_ms[4] = times_ms[5] = 0.0;
+    double sa = 0.0, sb = 0.0, sf = 0.0, sk = 0.0;
     int na = 0, nb = 0, nf = 0;
     const bool split = !jrx_comm_active(h);
     for (int q = 0; q < nsamp && split; q++) {
         float m1 = 0.f, m2 = 0.f;
-        JRX_HIP(h, hipEventElapsedTime(&m1, evs[(size_t)q * 3], evs[(size_t)q * 3 + 1]));
-        JRX_HIP(h, hipEventElapsedTime(&m2, evs[(size_t)q * 3 + 1], evs[(size_t)q * 3 + 2]));
-        if (fused[q]) { sf += m2; nf++; }
+        JRX_HIP(h, hipEventElapsedTime(&m1, evs[(size_t)q * 4], evs[(size_t)q * 4 + 1]));
+        JRX_HIP(h, hipEventElapsedTime(&m2, evs[(size_t)q * 4 + 1], evs[(size_t)q * 4 + 2]));
+        if (fused[q]) {
+            float m3 = 0.f;
+            JRX_HIP(h, hipEventElapsedTime(&m3, evs[(size_t)q * 4 + 1], evs[(size_t)q * 4 + 3]));
+            sf += m2; sk += m3; nf++;
+        }
         else { sb += m2; nb++; }
         if (m1 > 1e-3f) { sa += m1; na++; }      // a stress sweep ran as its own launch in this iteration
     }
     for (auto &e : evs) (void)hipEventDestroy(e);
     if (na) times_ms[1] = sa / na;
     if (nb) times_ms[2] = sb / nb;
-    if (nf) times_ms[3] = sf / nf;
+    if (nf) { times_ms[3] = sf / nf; times_ms[4] = sk / nf; }
     return JRX_OK;
 }
 

@@ -548,23 +548,37 @@ struct FusedBC {
     int fsL, nsL, fsF, nsF, fsK0, nsK0, nsR, nsBk, nsK1;
 };
 
-template <int TX, int TY, int KZ, int MINW>
+// OVX: x-overlap of neighbouring tiles in cells (1, or 16 = one 128-B line so that row segments stay line-aligned; only
+// the last overlap column is computed).  LOWREG: the previous velocity plane is re-read from a third LDS slot and the
+// previous η/G plane is carried as two partial sums instead of 11 carried doubles.
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false>
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty)
 {
-    __shared__ double sV[2][3][TY][TX];
+    constexpr int NS = LOWREG ? 3 : 2;
+    __shared__ double sV[NS][3][TY][TX];
     const Lay3 &L = a.L;
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     const jrx_stokes3d_fields &f = a.f;
     const double *et = a.etatau;
     const int tx = (int)(threadIdx.x % TX), ty = (int)(threadIdx.x / TX);
-    const int tile = blockIdx.x;
+    int tile = blockIdx.x;
+    if (XG > 0) {
+        // XCD-banded order (blocks are dealt round-robin to the 8 XCDs): XCD q takes XG consecutive tile rows
+        // q*XG .. q*XG+XG-1 of every group of 8*XG rows (rows run over y, then z), so the y-halo rows of
+        // neighbouring tiles are served by the same L2; the tail that does not fill a group keeps plain order
+        const int full = ((nty * (int)(gridDim.x / (unsigned)(ntx * nty))) / (8 * XG)) * (8 * XG) * ntx;
+        if (tile < full) {
+            const int q = tile & 7, r = tile >> 3, r2 = r / ntx;
+            tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
+        }
+    }
     const int tix = tile % ntx, tr = tile / ntx, tiy = tr % nty, tiz = tr / nty;
-    const int i = tix * (TX - 1) - 1 + tx;      // cell column of this thread
+    const int i = tix * (TX - OVX) - OVX + tx;  // cell column of this thread
     const int j = tiy * (TY - 1) - 1 + ty;
     const int kb = tiz * KZ;
     const int kend = min(kb + KZ, nz);
-    const bool bvalid = i >= 0 && j >= 0 && i < nx && j < ny;
-    const bool avalid = bvalid && tx >= 1 && ty >= 1;
+    const bool bvalid = tx >= OVX - 1 && i >= 0 && j >= 0 && i < nx && j < ny;
+    const bool avalid = bvalid && tx >= OVX && ty >= 1;
     const bool hx = i < nx - 1, hy = j < ny - 1;
     const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau, _dt = 1.0 / dt, rr = a.r, edt = a.eta_dtau;
 
@@ -594,27 +608,31 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     }
     // stress-sweep carries
     double a_p = 0, b_p = 0, c_p = 0, cx_p = 0, cy_p = 0, e_p = 0, ex_p = 0, ey_p = 0, g_p = 0, gx_p = 0, gy_p = 0;
+    double exe_p = 0, eye_p = 0, gxg_p = 0, gyg_p = 0;      // LOWREG: (ex_p + e_p), (ey_p + e_p), same for G
 
     for (int k = kfirst; k < kend; ++k) {
         const bool hz = k < nz - 1;
         const bool live = k >= kb;                 // false only on the prologue plane below the chunk
-        const int slot = k & 1;
+        const int slot = LOWREG ? k % 3 : (k & 1);
         double vxn = 0, vyn = 0, vzn = 0, txx_c = 0, tyy_c = 0, P_k = Pc, tzz_k = tzz_c, s01k = s01p, r01k = r01p;
         // stress-sweep operands that do not depend on the new velocities: issued before the barrier so that
         // one memory round trip per plane serves both phases
         double e = 0, ex = 0, ey = 0, exy_ = 0, g = 0, gx = 0, gy = 0, gxy = 0, P0 = 0, Kc = 0, Qc = 0;
         double toxx = 0, toyy = 0, tozz = 0, txy = 0, toxy = 0, toxz = 0, toyz = 0;
-        if (avalid) {
-            e = LDB(f.eta, oc); ex = LDB(f.eta, oc - dcx); ey = LDB(f.eta, oc - dcy);
-            g = LDB(f.G, oc); gx = LDB(f.G, oc - dcx); gy = LDB(f.G, oc - dcy);
-            if (live) {
-                exy_ = LDB(f.eta, oc - dcx - dcy); gxy = LDB(f.G, oc - dcx - dcy);
-                P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
-                toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
-                txy = LDB(f.txy, oxy); toxy = LDB(f.toxy, oxy);
-                toxz = LDB(f.toxz, oxz - sxz); toyz = LDB(f.toyz, oyz - syz);
+        auto preload_stress = [&]() {
+            if (avalid) {
+                e = LDB(f.eta, oc); ex = LDB(f.eta, oc - dcx); ey = LDB(f.eta, oc - dcy);
+                g = LDB(f.G, oc); gx = LDB(f.G, oc - dcx); gy = LDB(f.G, oc - dcy);
+                if (live) {
+                    exy_ = LDB(f.eta, oc - dcx - dcy); gxy = LDB(f.G, oc - dcx - dcy);
+                    P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
+                    toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
+                    txy = LDB(f.txy, oxy); toxy = LDB(f.toxy, oxy);
+                    toxz = LDB(f.toxz, oxz - sxz); toyz = LDB(f.toyz, oyz - syz);
+                }
             }
-        }
+        };
+        if (!LATEA) preload_stress();
         if (bvalid) {
             const u32 dz1 = hz ? sc : 0u;
             const double q11 = LDB(f.txy, oxy + 8u + rxy), q10 = LDB(f.txy, oxy + 8u), q01 = LDB(f.txy, oxy + rxy);
@@ -645,6 +663,12 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11; s01p = s01; r01p = r01;
             sV[slot][0][ty][tx] = vxn; sV[slot][1][ty][tx] = vyn; sV[slot][2][ty][tx] = vzn;
         }
+        if (LATEA) {
+            // lower register peak (4 waves/SIMD): the stress operands are requested only once the velocity
+            // operands are consumed; their round trip overlaps the barrier
+            __builtin_amdgcn_sched_barrier(0);
+            preload_stress();
+        }
         __syncthreads();
         if (avalid) {
             // ---- new velocities around cell (i,j,k): LDS, own registers, or the low-face boundary rule
@@ -659,6 +683,14 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             else vbx = bc.fsL ? vb : (bc.nsL ? -vb : LDB(f.Vy, gvy - 8u));
             vcx = i > 0 ? sV[slot][2][ty][tx - 1] : (bc.fsL ? vc : (bc.nsL ? -vc : LDB(f.Vz, gvz - 8u)));
             vcy = j > 0 ? sV[slot][2][ty - 1][tx] : (bc.fsF ? vc : (bc.nsF ? -vc : LDB(f.Vz, gvz - rvz)));
+            if (LOWREG && k > 0 && live) {
+                const int ps = (k + 2) % 3;       // slot of plane k-1
+                a_p = i > 0 ? sV[ps][0][ty][tx - 1] : (bc.nsL ? 0.0 : LDB(f.Vx, gvx - svx));
+                b_p = j > 0 ? sV[ps][1][ty - 1][tx] : (bc.nsF ? 0.0 : LDB(f.Vy, gvy - svy));
+                c_p = sV[ps][2][ty][tx];
+                cx_p = i > 0 ? sV[ps][2][ty][tx - 1] : (bc.fsL ? c_p : (bc.nsL ? -c_p : LDB(f.Vz, gvz - svz - 8u)));
+                cy_p = j > 0 ? sV[ps][2][ty - 1][tx] : (bc.fsF ? c_p : (bc.nsF ? -c_p : LDB(f.Vz, gvz - svz - rvz)));
+            }
             if (k == 0) {
                 // plane K = 0 of V: ghost of Vx, Vy (tangential), boundary plane of Vz (normal)
                 a_p = bc.fsK0 ? va : (bc.nsK0 ? -va : LDB(f.Vx, gvx - svx));
@@ -667,6 +699,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 cx_p = i > 0 ? (bc.nsK0 ? 0.0 : LDB(f.Vz, gvz - svz - 8u)) : (bc.fsL ? c_p : (bc.nsL ? -c_p : LDB(f.Vz, gvz - svz - 8u)));
                 cy_p = j > 0 ? (bc.nsK0 ? 0.0 : LDB(f.Vz, gvz - svz - rvz)) : (bc.fsF ? c_p : (bc.nsF ? -c_p : LDB(f.Vz, gvz - svz - rvz)));
                 e_p = e; ex_p = ex; ey_p = ey; g_p = g; gx_p = gx; gy_p = gy;
+                exe_p = ex + e; eye_p = ey + e; gxg_p = gx + g; gyg_p = gy + g;
             }
             if (live) {
                 {   // centre
@@ -696,23 +729,26 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 }
                 {   // τxz (i,j,k)
                     const double s_ = 0.5 * (_dz * (va - a_p) + _dx * (c_p - cx_p));
-                    const double ee = 0.25 * (ex_p + e_p + ex + e);
-                    const double gg = 0.25 * (gx_p + g_p + gx + g);
+                    const double ee = 0.25 * ((LOWREG ? exe_p : ex_p + e_p) + ex + e);
+                    const double gg = 0.25 * ((LOWREG ? gxg_p : gx_p + g_p) + gx + g);
                     const double _Gdt = 1.0 / (gg * dt);
                     const double dtr = dev_dtau_r(th, ee, _Gdt);
                     STB(a.o.txz, oxz - sxz, s01k + dev_stress_inc(s01k, toxz, ee, s_, _Gdt, dtr));
                 }
                 {   // τyz (i,j,k)
                     const double s_ = 0.5 * (_dz * (vb - b_p) + _dy * (c_p - cy_p));
-                    const double ee = 0.25 * (ey_p + e_p + ey + e);
-                    const double gg = 0.25 * (gy_p + g_p + gy + g);
+                    const double ee = 0.25 * ((LOWREG ? eye_p : ey_p + e_p) + ey + e);
+                    const double gg = 0.25 * ((LOWREG ? gyg_p : gy_p + g_p) + gy + g);
                     const double _Gdt = 1.0 / (gg * dt);
                     const double dtr = dev_dtau_r(th, ee, _Gdt);
                     STB(a.o.tyz, oyz - syz, r01k + dev_stress_inc(r01k, toyz, ee, s_, _Gdt, dtr));
                 }
             }
-            a_p = va; b_p = vb; c_p = vc; cx_p = vcx; cy_p = vcy;
-            e_p = e; ex_p = ex; ey_p = ey; g_p = g; gx_p = gx; gy_p = gy;
+            if (LOWREG) { exe_p = ex + e; eye_p = ey + e; gxg_p = gx + g; gyg_p = gy + g; }
+            else {
+                a_p = va; b_p = vb; c_p = vc; cx_p = vcx; cy_p = vcy;
+                e_p = e; ex_p = ex; ey_p = ey; g_p = g; gx_p = gx; gy_p = gy;
+            }
         }
         oc += sc; oxy += sxy; oxz += sxz; oyz += syz; ovx += svx; ovy += svy; ovz += svz;
     }

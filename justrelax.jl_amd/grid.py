@@ -96,7 +96,7 @@ def neighbors(coords, dims, periods=(0, 0, 0)):
             c[d] += s
             if 0 <= c[d] < dims[d]:
                 pair.append(cart_rank(c, dims))
-            elif periods[d] and dims[d] > 1:
+            elif periods[d]:
                 c[d] %= dims[d]
                 pair.append(cart_rank(c, dims))
             else:

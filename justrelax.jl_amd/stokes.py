@@ -361,11 +361,12 @@ def residual_sumsq(stokes, pt, grid, *, handle=None):
 
 
 def iterate_timed_(stokes, pt, grid, flow_bcs, ρg, K, G, ητ, dt, iters, *, handle=None):
-    """bench hook: `iters` PT iterations of the 3D loop body; returns (total_ms, stress_ms, velocity_ms, fused_ms)."""
+    """bench hook: `iters` PT iterations of the 3D loop body; returns
+    (total_ms, stress_ms, velocity_ms, fused_group_ms, fused_kernel_ms, 0)."""
     _require_gpu(stokes)
     h = handle or _lib.default_handle(stokes.P.device.index)
     torch.cuda.current_stream(stokes.P.device).synchronize()
     f, p = fields3d(stokes, ρg, K, G), params3d(stokes, pt, grid, flow_bcs, dt)
-    t = (C.c_double * 4)()
+    t = (C.c_double * 6)()
     h.call("jrx_stokes3d_iterate_timed", C.byref(f), C.c_void_p(ptr(ητ)), C.byref(p), C.c_int64(int(iters)), t)
     return tuple(t[:])

@@ -103,8 +103,14 @@ int main(int argc, char **argv)
         {&f.fx, nc, -1, 1, 0}, {&f.fy, nc, -1, 1, 0}, {&f.fz, nc, -1, 1, 0},
         {&f.RP, nc, 0, 0, 0}, {&f.Rx, nc, 0, 0, 0}, {&f.Ry, nc, 0, 0, 0}, {&f.Rz, nc, 0, 0, 0}};
     unsigned seed = 1;
+    // KB_SKEW: byte offset added per array (array q starts q*skew bytes into its allocation) to decorrelate the
+    // HBM channel/bank mapping of equally sized arrays
+    const i64 skew = getenv("KB_SKEW") ? atoll(getenv("KB_SKEW")) : 0;
+    int qidx = 0;
     for (auto &e : ents) {
-        CK(hipMalloc(e.p, e.n * sizeof(double)));
+        char *base;
+        CK(hipMalloc(&base, e.n * sizeof(double) + 64 * skew));
+        *e.p = (double *)(base + (qidx++) * skew);
         hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, *e.p, e.n, seed++, e.lo, e.hi, e.expo);
     }
     double *etatau;
@@ -252,6 +258,16 @@ int main(int argc, char **argv)
         report(nm, T.run(reps, fn), 360.0, 0);                                                                      \
     }
         FUSED(64, 4, 16, 2)
+#define FUSED2(TX, TY, KZ, MW, OV, LR, XG, LA)                                                                      \
+    {                                                                                                               \
+        const int ntx = (nx + TX - OV - 1) / (TX - OV), nty = (ny + TY - 2) / (TY - 1), ntz = (nz + KZ - 1) / KZ;     \
+        auto fn = [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, OV, LR, XG, LA>), dim3(ntx * nty * ntz), dim3(TX * TY), 0, 0, b, bc, ntx, nty); }; \
+        char nm[80];                                                                                                \
+        snprintf(nm, 80, "fused %dx%dx%d minw%d ovx%d lowreg%d xg%d latea%d", TX, TY, KZ, MW, OV, (int)LR, XG, (int)LA); \
+        report(nm, T.run(reps, fn), 360.0, 0);                                                                      \
+    }
+        FUSED2(64, 4, 16, 2, 1, false, 8, false) FUSED2(64, 4, 16, 2, 1, false, 8, true) FUSED2(64, 4, 16, 4, 1, false, 8, true) FUSED2(64, 4, 16, 4, 1, true, 8, true)
+        FUSED2(64, 4, 16, 3, 1, true, 8, true) FUSED2(64, 8, 16, 4, 1, true, 8, true) FUSED2(64, 4, 8, 4, 1, true, 8, true) FUSED2(64, 4, 32, 4, 1, true, 8, true)
     }
     printf("done\n");
     return 0;

@@ -202,7 +202,7 @@ def test_cpu_arrays_are_refused(jr):
 @pytest.mark.parametrize("ni,bcs", [((130, 20, 17), "free_slip"), ((70, 12, 9), "free_slip"), ((130, 17, 20), "no_slip"),
                                     ((97, 9, 33), "none"), ((64, 16, 40), "no_slip"), ((200, 8, 8), "free_slip")])
 def test_kernel_variants_are_bit_identical(env, ni, bcs):
-    """z-marching sweeps (0), per-node kernels (1) and the experimental fused iteration kernel (3) must agree bit for bit:
+    """auto (0), per-node kernels (1), the two z-marching sweeps (2) and the fused PT pipeline (3) must agree bit for bit:
     same operation order, and the fused kernel's on-the-fly low-face boundary rules reproduce flow_bcs!."""
     import ctypes as C
     jr = env["jr"]
@@ -212,7 +212,7 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
     outs, its = [], []
     h = _lib.default_handle()
     try:
-        for variant in (0, 1, 3):
+        for variant in (0, 1, 2, 3):
             h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
             stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
             r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
@@ -220,8 +220,8 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
             outs.append(env["down"](stokes))
     finally:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
-    assert its[0] == its[1] == its[2] and its[0][0] == 24
-    for v in (1, 2):
+    assert its[0] == its[1] == its[2] == its[3] and its[0][0] == 24
+    for v in (1, 2, 3):
         for k in outs[0]:
             m = env["checks"].interior_mask3d(k, outs[0][k].shape)
             assert np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)
@@ -236,16 +236,16 @@ def test_iterate_timed_leaves_state_in_user_arrays(env):
     h = _lib.default_handle()
     outs = []
     try:
-        for variant in (3, 1):
+        for variant in (3, 1, 2):
             h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
             stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
             et = jr.fzeros(s.ni, stokes.P.device)
             jr.compute_maxloc_(et, stokes.viscosity.η)
             t = st.iterate_timed_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, et, s.dt, 9)
-            assert t[0] > 0 and (t[3] > 0) == (variant == 3)
+            assert t[0] > 0 and (t[3] > 0) == (variant == 3) and (t[4] > 0) == (variant == 3) and t[4] <= t[3]
             outs.append(env["down"](stokes))
     finally:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
     for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy"):
         m = env["checks"].interior_mask3d(k, outs[0][k].shape)
-        assert np.array_equal(outs[0][k][m], outs[1][k][m]), k
+        assert np.array_equal(outs[0][k][m], outs[1][k][m]) and np.array_equal(outs[0][k][m], outs[2][k][m]), k
