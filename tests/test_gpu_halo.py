@@ -69,3 +69,75 @@ def test_periodic_self_exchange(jr, through_rccl, periods):
         assert np.array_equal(a, b), f"halo mismatch for array of shape {s}, periods {periods}, rccl={through_rccl}"
         # interior untouched
     assert any(not np.array_equal(a, b) for a, b in zip(got, host))
+
+
+@pytest.mark.parametrize("through_rccl", [False, True])
+def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracle, through_rccl):
+    """The N > 1 code path of jrx_stokes3d_solve (boundary slabs first on the halo stream, interior concurrently on the
+    compute stream, BCs + update_halo! behind the slabs, norms of the global count: Stokes3D.jl:104-142) on one GPU:
+    the grid is IGG-periodic in x and z, so the rank is its own neighbour.  Expected = the CPU oracle's iteration
+    followed by the same plane copies in numpy.  Tolerance 1e-12 of each field's max (observed: bit-identical)."""
+    import torch
+    from justrelax_jl_amd import _lib, checks, halo
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    import justrelax_jl_amd.grid as g
+    orc = oracle
+    L = _lib.load()
+    n = (70, 13, 12)
+    periods = (1, 0, 1)
+    iters = 8
+    s = jr.miniapps.random_fields3d(n, seed=11, iterMax=iters - 1, nout=4)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    g.init_global_grid(*n, periodx=periods[0], periody=periods[1], periodz=periods[2], rank=0, nprocs=1)
+    ng = (g.nx_g(), g.ny_g(), g.nz_g())
+    assert ng == (n[0] - 2, n[1], n[2] - 2)
+    old = os.environ.get("JRX_HALO_SELF_RCCL")
+    h = _lib.default_handle()
+    try:
+        if through_rccl:
+            os.environ["JRX_HALO_SELF_RCCL"] = "1"
+        halo.init_comm(h)
+        stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
+        r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+        got = download_stokes(stokes)
+    finally:
+        if old is None:
+            os.environ.pop("JRX_HALO_SELF_RCCL", None)
+        else:
+            os.environ["JRX_HALO_SELF_RCCL"] = old
+        g.finalize_global_grid()
+        g.init_global_grid(*n, rank=0, nprocs=1)
+        halo.init_comm(h)          # back to a plain single-rank handle for the other tests
+        g.finalize_global_grid()
+    assert r.iter == iters
+
+    ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    b = s.flow_bcs
+    pl = orc.params3d(n, s.grid._di["center"], s.dt, dict(r=s.pt.r, theta_dtau=s.pt.θ_dτ, eta_dtau=s.pt.ηdτ, eps_rel=1e-30, eps_abs=1e-30),
+                      iterMax=iters - 1, nout=4, free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic, ni_g=ng)
+
+    def self_halo(arrs):
+        new = _expected(arrs, n, periods, L)
+        for a, m in zip(arrs, new):
+            a[...] = m
+
+    et = orc.compute_maxloc(ref["eta"])
+    self_halo([et])
+    errs = []
+    for it in range(1, iters + 1):
+        orc.stokes3d_iteration(ref, et, pl)
+        self_halo([ref["Vx"], ref["Vy"], ref["Vz"]])
+        if it % 4 == 0:
+            ss = orc.residual_sumsq3d(ref, pl)
+            cnt = [(ng[0] - 2) * (ng[1] - 1) * (ng[2] - 1), (ng[0] - 1) * (ng[1] - 2) * (ng[2] - 1), (ng[0] - 1) * (ng[1] - 1) * (ng[2] - 2),
+                   ng[0] * ng[1] * ng[2]]
+            errs.append(max(np.sqrt(ss[q]) / cnt[q] for q in range(4)))
+    assert np.allclose(np.asarray(r.err_evo1), errs, rtol=1e-12), (r.err_evo1, errs)
+    for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "txy", "txz", "tyz"):
+        m = checks.interior_mask3d(k, ref[k].shape)
+        scale = np.abs(ref[k]).max()
+        d = np.abs(got[k] - ref[k])[m].max()
+        assert d <= 1e-12 * scale, (k, d, scale)
+    # ghost planes of V hold the wrapped interior planes
+    for k in ("Vx", "Vz"):
+        assert np.abs(got[k][0] - ref[k][0]).max() <= 1e-12 * np.abs(ref[k]).max()
