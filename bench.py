@@ -69,7 +69,16 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--self-halo", action="store_true",
+                    help="diagnostic (1 GPU): IGG-periodic grid whose only neighbour is the rank itself, planes routed through a "
+                         "one-rank RCCL communicator -- times the N > 1 code path (slabs, halo stream, pack/send/recv/unpack) on one device")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line (rank 0): native libraries that print banners on fd 1 (RCCL's version block
+    # at communicator creation) are sent to stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -92,18 +101,23 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     n = args.n
-    grid.init_global_grid(n, n, n, rank=rank, nprocs=world)
+    self_halo = args.self_halo and world == 1
+    if self_halo:
+        os.environ["JRX_HALO_SELF_RCCL"] = "1"
+        grid.init_global_grid(n, n, n, rank=0, nprocs=1, periodx=1, periody=1, periodz=1)
+    else:
+        grid.init_global_grid(n, n, n, rank=rank, nprocs=world)
     h = _lib.default_handle(local_rank)
-    if world > 1:
+    if world > 1 or self_halo:
         halo.init_comm(h)
-    uh = (lambda a: halo.update_halo_(a, ni=(n, n, n), handle=h)) if world > 1 else None
+    uh = (lambda a: halo.update_halo_(a, ni=(n, n, n), handle=h)) if (world > 1 or self_halo) else None
     st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend, update_halo=uh)
     jr.flow_bcs_(st, bcs, handle=h)
-    if world > 1:
+    if world > 1 or self_halo:
         halo.update_halo_(st.V.Vx, st.V.Vy, st.V.Vz, ni=(n, n, n), handle=h)
     ητ = jr.fzeros((n, n, n), dev)
     jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
-    if world > 1:
+    if world > 1 or self_halo:
         halo.update_halo_(ητ, ni=(n, n, n), handle=h)
 
     def barrier():
@@ -140,7 +154,7 @@ def main():
             "config": {"workload": f"SolVi3D {n}^3 per GPU (configs[{'3' if n == 512 else '2' if n == 256 else '?'}]): "
                                    "eta inclusion 1e-3, G=1, K=Inf, dt=Inf, free-slip, pure shear",
                        "local_grid": [n, n, n], "global_grid": [grid.nx_g(), grid.ny_g(), grid.nz_g()],
-                       "decomposition": list(grid.global_grid().dims), "halo": "RCCL send/recv" if world > 1 else "none"},
+                       "decomposition": list(grid.global_grid().dims), "halo": "RCCL send/recv" if world > 1 else ("diagnostic: periodic self-neighbour through RCCL" if self_halo else "none")},
             "global_iterations_per_s": it_per_s,
             "effective_GBps_at_360B_per_cell": eff_gbs,
             "device_ms_per_step": tot_ms / args.steps,
@@ -178,7 +192,7 @@ def main():
                                              f"{secs:.1f} s, scaled by cell count to a {n}^3 block",
                                    "cell_updates_per_s": cps,
                                    "effective_GBps_at_600B_as_written": cps * 600.0 / 1e9}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
