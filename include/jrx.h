@@ -252,6 +252,15 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
 /* update_stresses_center_vertex_ps! alone (θ, λ, λv are caller arrays of extents ni, ni, ni.+1) -- for parity tests */
 jrx_status jrx_vep2d_update_stresses(jrx_handle *h, const jrx_vep2d_fields *f, const double *theta, double *lambda, double *lambda_v,
                                      const jrx_rheology *rh, const jrx_vep2d_params *p);
+/* compute_τ_nonlinear! 2D alone: single phase (multiphase = 0; StressKernels.jl:266-307, uses rheology phase 0) or phases at
+ * the cell centres (multiphase = 1; :310-351) with _compute_τ_nonlinear! (rheology/StressUpdate.jl:2-57).  Centre-only
+ * visco-elasto-plastic update: writes τ.xx, τ.yy, τ.xy_c, τ.II, η_vep, ε_pl.xx, ε_pl.yy, ε_pl.xy[i,j], λ and θ (caller
+ * arrays of extent ni).  τ_o.xy and ε_pl.xy are the vertex arrays addressed with the centre index, as the reference's
+ * caller passes them (Stokes2D.jl:442-458).  Softening laws are not modelled (NoSoftening). */
+jrx_status jrx_compute_tau_nonlinear2d(jrx_handle *h, const jrx_vep2d_fields *f, double *theta, double *lambda, const jrx_rheology *rh,
+                                       const jrx_vep2d_params *p, int32_t multiphase);
+/* center2vertex!(vertex, center) 2D (Interpolations.jl:101-114): vertex is (nx+1, ny+1), center (nx, ny) */
+jrx_status jrx_center2vertex2d(jrx_handle *h, double *vertex, const double *center, int64_t nx, int64_t ny);
 /* tensor_invariant!(A): II = second_invariant_staggered(xx, yy, gather(xy)) -- StressKernels.jl:443-470 */
 jrx_status jrx_tensor_invariant2d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny);
 /* compute_viscosity!/update_viscosity_τII! for the table rheology: η <- ν·η_phase + (1-ν)·η, clamped to the cutoff */

@@ -509,6 +509,83 @@ __global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
     a.f.P[c] = Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP);
 }
 
+// compute_τ_nonlinear! 2D: single phase (StressKernels.jl:266-307) / phases at the cell centres (:310-351) with
+// _compute_τ_nonlinear! (rheology/StressUpdate.jl:2-57).  Centre-only; τ_old.xy and ε_pl.xy are the vertex arrays
+// addressed with the centre's [i,j], as the reference's caller passes them (Stokes2D.jl:442-458).
+template <bool MULTI>
+__global__ __launch_bounds__(256) void k_tau_nonlinear2d(const VepArgs a, double *__restrict__ theta_out)
+{
+    const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / nx, i = t - j * nx;
+    if (j >= ny) return;
+    const i64 c = i + (i64)nx * j;
+    const double one = 1.0;
+    const double *r = MULTI ? a.f.phase_c + (i64)np * c : &one;
+    const int n = MULTI ? np : 1;
+    const double e = a.f.eta[c], dt = a.dt;
+    const double _Gdt = 1.0 / ((MULTI ? ratio_avg(a.rh.G, r, n) : a.rh.G[0]) * dt);
+    const double dtr = dev_dtau_r(a.theta_dtau, e, _Gdt);
+    bool is_pl = false;
+    double C = 0.0, sinphi = 0.0, cosphi = 0.0, sinpsi = 0.0, eta_reg = 0.0;
+    for (int q = 0; q < n; q++) {
+        if (r[q] == 0.0 || !a.rh.is_pl[q]) continue;
+        is_pl = true;
+        C += a.rh.C[q] * r[q]; sinphi += a.rh.sinphi[q] * r[q]; cosphi += a.rh.cosphi[q] * r[q];
+        sinpsi += a.rh.sinpsi[q] * r[q]; eta_reg += a.rh.eta_vp[q] * r[q];
+    }
+    const double K = MULTI ? ratio_avg(a.rh.Kb, r, n) : a.rh.Kb[0];
+    const double volume = isinf(K) ? 0.0 : K * dt * sinphi * sinpsi;
+    const double eij[3] = {a.f.exx[c], a.f.eyy[c], (V2(a.f.exy, i, j) + V2(a.f.exy, i + 1, j) + V2(a.f.exy, i, j + 1) + V2(a.f.exy, i + 1, j + 1)) / 4};
+    const double tij[3] = {a.f.txx[c], a.f.tyy[c], a.f.txy_c[c]};
+    const double toij[3] = {a.f.toxx[c], a.f.toyy[c], V2(a.f.toxy, i, j)};
+    const double P = a.f.P[c];
+    double d[3], ldq[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 3; q++) d[q] = dev_stress_inc(tij[q], toij[q], e, eij[q], _Gdt, dtr);
+    const double tII_trial = sinv2(tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]);
+    const double ty = fmax(C * cosphi + P * sinphi, 0.0);
+    double l = a.lam[c];
+    if (is_pl && tII_trial > ty) {
+        const double F = tII_trial - ty;
+        l = 0.5 * l + (1 - 0.5) * (F > 0.0 ? 1.0 : 0.0) * F * (1.0 / (e * dtr + eta_reg + volume));
+        const double l_tII = l * 0.5 * (1.0 / tII_trial);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            ldq[q] = (tij[q] + d[q]) * l_tII;
+            d[q] = fma(-dtr * 2.0, e * ldq[q], d[q]);
+        }
+        a.lam[c] = l;
+    }
+    a.f.eplxx[c] = isinf(ldq[0]) ? 0.0 : ldq[0];
+    a.f.eplyy[c] = isinf(ldq[1]) ? 0.0 : ldq[1];
+    V2(a.f.eplxy, i, j) = isinf(ldq[2]) ? 0.0 : ldq[2];
+    a.f.txx[c] = tij[0] + d[0]; a.f.tyy[c] = tij[1] + d[1]; a.f.txy_c[c] = tij[2] + d[2];
+    const double tII = sinv2(tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]);
+    a.f.tII[c] = tII;
+    a.f.eta_vep[c] = tII * 0.5 * (1.0 / sinv2(eij[0], eij[1], eij[2]));
+    theta_out[c] = P + (isinf(K) ? 0.0 : K * dt * l * sinpsi);
+}
+
+// center2vertex! 2D (Interpolations.jl:101-114): pass 0 inner vertices, pass 1 the x-edge rows, pass 2 the y-edge columns
+__global__ __launch_bounds__(256) void k_center2vertex2d(double *__restrict__ v, const double *__restrict__ cc, int nx, int ny, int pass)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pass == 0) {
+        const int j = t / (nx + 1), i = t - j * (nx + 1);
+        if (j > ny || i < 1 || i >= nx || j < 1 || j >= ny) return;
+        v[i + (i64)(nx + 1) * j] = 0.25 * (cc[(i - 1) + (i64)nx * (j - 1)] + cc[i + (i64)nx * (j - 1)] + cc[(i - 1) + (i64)nx * j] + cc[i + (i64)nx * j]);
+    } else if (pass == 1) {
+        if (t > ny) return;
+        v[0 + (i64)(nx + 1) * t] = v[1 + (i64)(nx + 1) * t];
+        v[nx + (i64)(nx + 1) * t] = v[nx - 1 + (i64)(nx + 1) * t];
+    } else {
+        if (t > nx) return;
+        v[t] = v[t + (i64)(nx + 1)];
+        v[t + (i64)(nx + 1) * ny] = v[t + (i64)(nx + 1) * (ny - 1)];
+    }
+}
+
 __device__ __forceinline__ double phase_viscosity(const jrx_rheology &rh, const double *r)
 {   // compute_phase_viscosity, rheology/Viscosity.jl:605-625 (LinearViscous elements)
     for (int q = 0; q < rh.nphase; q++)
@@ -648,6 +725,41 @@ jrx_status jrx_vep2d_update_stresses(jrx_handle *h, const jrx_vep2d_fields *f, c
     hipLaunchKernelGGL(k_vep_vertex, dim3(gv), dim3(256), 0, h->stream, a);
     JRX_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(k_vep_centre, dim3(gc), dim3(256), 0, h->stream, a);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_compute_tau_nonlinear2d(jrx_handle *h, const jrx_vep2d_fields *f, double *theta, double *lambda, const jrx_rheology *rh,
+                                       const jrx_vep2d_params *p, int32_t multiphase)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!f || !rh || !p) return jrx_fail(h, JRX_ERR_ARG, "null VEP argument");
+    if (p->nx < 1 || p->ny < 1) return jrx_fail(h, JRX_ERR_ARG, "compute_τ_nonlinear!: empty grid");
+    if (rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "nphase must be in 1..%d", JRX_MAXPHASE);
+    if (!theta || !lambda) return jrx_fail(h, JRX_ERR_ARG, "θ / λ is NULL");
+    const void *req[] = {f->P, f->exx, f->eyy, f->exy, f->eplxx, f->eplyy, f->eplxy, f->txx, f->tyy, f->txy_c, f->tII, f->toxx, f->toyy,
+                         f->toxy, f->eta, f->eta_vep, multiphase ? (const void *)f->phase_c : (const void *)f->P};
+    for (const void *q : req)
+        if (!q) return jrx_fail(h, JRX_ERR_ARG, "compute_τ_nonlinear!: a required field pointer is NULL");
+    VepArgs a = make_vep(f, rh, p);
+    a.lam = lambda;
+    const unsigned gc = (unsigned)((p->nx * p->ny + 255) / 256);
+    if (multiphase) hipLaunchKernelGGL(k_tau_nonlinear2d<true>, dim3(gc), dim3(256), 0, h->stream, a, theta);
+    else hipLaunchKernelGGL(k_tau_nonlinear2d<false>, dim3(gc), dim3(256), 0, h->stream, a, theta);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_center2vertex2d(jrx_handle *h, double *vertex, const double *center, int64_t nx, int64_t ny)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!vertex || !center || nx < 2 || ny < 2) return jrx_fail(h, JRX_ERR_ARG, "center2vertex!: bad argument");
+    const i64 nv = (nx + 1) * (ny + 1);
+    hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, h->stream, vertex, center, (int)nx, (int)ny, 0);
+    hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((ny + 1 + 255) / 256)), dim3(256), 0, h->stream, vertex, center, (int)nx, (int)ny, 1);
+    hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((nx + 1 + 255) / 256)), dim3(256), 0, h->stream, vertex, center, (int)nx, (int)ny, 2);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;

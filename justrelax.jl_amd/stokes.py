@@ -215,6 +215,34 @@ def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology,
     return hist.result(2)
 
 
+def compute_τ_nonlinear_(stokes, θ, λ, rheology, dt, pt_stokes, *, phase_ratios=None, handle=None):
+    """compute_τ_nonlinear!(@tensor_center(τ), τ.II, @tensor(τ_o), @strain, @plastic_strain, EII_pl, P, θ, η, η_vep, λ,
+    rheology, dt, θ_dτ, args) -- StressKernels.jl:266-307 (single phase: `phase_ratios=None`, rheology phase 1) or
+    :310-351 (phases at the cell centres).  2D only."""
+    _require_gpu(stokes)
+    if len(stokes._ni) != 2:
+        raise NotImplementedError("3D compute_τ_nonlinear! is not built")
+    h = handle or _lib.default_handle(stokes.P.device.index)
+    fake = SimpleNamespace(_di=dict(center=(1.0, 1.0)))
+    p = vep_params2d(stokes, pt_stokes, fake, None, dt)
+    pr = phase_ratios or SimpleNamespace(center=None, vertex=None)
+    f = vep_fields2d(stokes, (stokes.P, stokes.P), pr)
+    rh = rheology_table(rheology)
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    h.call("jrx_compute_tau_nonlinear2d", C.byref(f), C.c_void_p(ptr(θ)), C.c_void_p(ptr(λ)), C.byref(rh), C.byref(p),
+           C.c_int32(0 if phase_ratios is None else 1))
+
+
+def center2vertex_(vertex, center, *, handle=None):
+    """center2vertex!(vertex, center) 2D -- Interpolations.jl:101-114"""
+    _require_gpu(vertex)
+    if vertex.dim() != 2:
+        raise NotImplementedError("3D center2vertex! is not built")
+    h = handle or _lib.default_handle(vertex.device.index)
+    torch.cuda.current_stream(vertex.device).synchronize()
+    h.call("jrx_center2vertex2d", C.c_void_p(ptr(vertex)), C.c_void_p(ptr(center)), C.c_int64(center.shape[0]), C.c_int64(center.shape[1]))
+
+
 def tensor_invariant_(A, *, handle=None):
     """tensor_invariant!(A::SymmetricTensor) (2D) -- StressKernels.jl:443-470"""
     _require_gpu(A.xx)

@@ -198,6 +198,9 @@ typedef struct orc_vep_params2d {
 int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res);
 void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, double *lamv, const orc_rheology *rh,
                       const orc_vep_params2d *p);
+void orc_compute_tau_nonlinear2d(const orc_vep2d *f, double *theta, double *lam, const orc_rheology *rh, const orc_vep_params2d *p,
+                                 int32_t multiphase);
+void orc_center2vertex2d(double *v, const double *c, int64_t nx, int64_t ny);
 void orc_tensor_invariant2d(double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny, int32_t mode);
 void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu);
 

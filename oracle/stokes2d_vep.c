@@ -163,6 +163,80 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
         }
 }
 
+/* compute_τ_nonlinear! 2D: single phase (StressKernels.jl:266-307) and phases at cell centres (:310-351), with
+ * _compute_τ_nonlinear! (rheology/StressUpdate.jl:2-57), compute_stress_increment_and_trial (:72-81), compute_dτ_pl
+ * (:83-105), isyielding (:68), cache_tensors (:190-222), plastic_params_phase (:146-176; NoSoftening only).
+ * Centre-only update.  As the reference's only caller passes them (Stokes2D.jl:442-458): τ = (xx, yy, xy_c),
+ * τ_old = @tensor(τ_o) = (xx, yy, xy) whose shear member is the VERTEX array read at the centre's index [i,j],
+ * ε_pl = (xx, yy, xy) whose shear member is likewise the vertex array written at [i,j].
+ * PARITY UNPINNED: no test of the reference reaches this kernel (its 2D driver indexes scalar K, G per cell). */
+void orc_compute_tau_nonlinear2d(const orc_vep2d *f, double *theta, double *lam, const orc_rheology *rh, const orc_vep_params2d *p,
+                                 int32_t multiphase)
+{
+    const int64_t nx = p->nx, ny = p->ny;
+    const int np = rh->nphase;
+    const double dt = p->dt, th = p->theta_dtau, one = 1.0;
+    for (int64_t j = 0; j < ny; j++)
+        for (int64_t i = 0; i < nx; i++) {
+            const size_t c = IDX2(nx, i, j);
+            const double *r = multiphase ? f->phase_c + (size_t)np * c : &one;
+            const int n = multiphase ? np : 1;
+            const double eta = f->eta[c];
+            const double _Gdt = inv((multiphase ? ratio_avg(rh->G, r, n) : rh->G[0]) * dt);
+            const double dtr = inv(th + fma(eta, _Gdt, 1.0));                       /* compute_dτ_r, StressUpdate.jl:70 */
+            int is_pl = 0;
+            double C = 0.0, sinphi = 0.0, cosphi = 0.0, sinpsi = 0.0, eta_reg = 0.0;
+            for (int q = 0; q < n; q++) {
+                if (r[q] == 0.0 || !rh->is_pl[q]) continue;                         /* empty_args for absent / non-plastic phases */
+                is_pl = 1;
+                C += rh->C[q] * r[q]; sinphi += rh->sinphi[q] * r[q]; cosphi += rh->cosphi[q] * r[q];
+                sinpsi += rh->sinpsi[q] * r[q]; eta_reg += rh->eta_vp[q] * r[q];
+            }
+            const double K = multiphase ? ratio_avg(rh->Kb, r, n) : rh->Kb[0];
+            const double volume = isinf(K) ? 0.0 : K * dt * sinphi * sinpsi;
+            const double eij[3] = {f->exx[c], f->eyy[c],
+                                   (V2(f->exy, i, j) + V2(f->exy, i + 1, j) + V2(f->exy, i, j + 1) + V2(f->exy, i + 1, j + 1)) / 4};
+            const double tij[3] = {f->txx[c], f->tyy[c], f->txy_c[c]};
+            const double toij[3] = {f->toxx[c], f->toyy[c], V2(f->toxy, i, j)};
+            double d[3];
+            for (int q = 0; q < 3; q++) d[q] = dtr * fma(2.0 * eta, eij[q], fma(-((tij[q] - toij[q])) * eta, _Gdt, -tij[q]));
+            const double tII_trial = sinv2(tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]);
+            const double ty = fmax(C * cosphi + f->P[c] * sinphi, 0.0);
+            double ldq[3] = {0.0, 0.0, 0.0};
+            if (is_pl && tII_trial > ty) {
+                const double F = tII_trial - ty;
+                const double l = 0.5 * lam[c] + (1 - 0.5) * (F > 0.0 ? 1.0 : 0.0) * F * inv(eta * dtr + eta_reg + volume);
+                const double l_tII = l * 0.5 * inv(tII_trial);
+                double dpl[3];
+                for (int q = 0; q < 3; q++) {
+                    ldq[q] = (tij[q] + d[q]) * l_tII;
+                    dpl[q] = fma(-dtr * 2.0, eta * ldq[q], d[q]);
+                }
+                for (int q = 0; q < 3; q++) d[q] = dpl[q];
+                lam[c] = l;
+            }
+            f->eplxx[c] = isinf(ldq[0]) ? 0.0 : ldq[0];
+            f->eplyy[c] = isinf(ldq[1]) ? 0.0 : ldq[1];
+            V2(f->eplxy, i, j) = isinf(ldq[2]) ? 0.0 : ldq[2];
+            f->txx[c] = tij[0] + d[0]; f->tyy[c] = tij[1] + d[1]; f->txy_c[c] = tij[2] + d[2];
+            const double tII = sinv2(tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]);
+            f->tII[c] = tII;
+            f->eta_vep[c] = tII * 0.5 * inv(sinv2(eij[0], eij[1], eij[2]));
+            theta[c] = f->P[c] + (isinf(K) ? 0.0 : K * dt * lam[c] * sinpsi);
+        }
+}
+
+/* center2vertex!(vertex, center) 2D (Interpolations.jl:101-114): inner vertices = mean of the 4 cells, then the edge
+ * rows/columns copy their inner neighbour (rows first, then columns, so corners take the column copy) */
+void orc_center2vertex2d(double *v, const double *c, int64_t nx, int64_t ny)
+{
+    for (int64_t j = 1; j < ny; j++)
+        for (int64_t i = 1; i < nx; i++)
+            V2(v, i, j) = 0.25 * (C2(c, i - 1, j - 1) + C2(c, i, j - 1) + C2(c, i - 1, j) + C2(c, i, j));
+    for (int64_t j = 0; j <= ny; j++) { V2(v, 0, j) = V2(v, 1, j); V2(v, nx, j) = V2(v, nx - 1, j); }
+    for (int64_t i = 0; i <= nx; i++) { V2(v, i, 0) = V2(v, i, 1); V2(v, i, ny) = V2(v, i, ny - 1); }
+}
+
 /* update_viscosity_τII! (rheology/Viscosity.jl:67-106,382-418): centre and vertex viscosities relaxed towards the
  * per-phase value; with LinearViscous + dt = Inf the composite viscosity is the linear one (ASSUMED, see header) */
 static inline double phase_viscosity(const orc_rheology *rh, const double *r)

@@ -131,3 +131,59 @@ def test_shearband2d_reference_test(jr, oracle):
     assert II.max() == pytest.approx(1.6415759440014273, abs=1.0e-3)
     assert tII[-1] == pytest.approx(1.6376258215356436, abs=1.0e-4)
     assert max_rel_diff(jr.to_numpy(stokes.EII_pl), s.arrays["EII_pl"]) < 1e-6
+
+
+@pytest.mark.parametrize("multiphase", [False, True])
+def test_compute_tau_nonlinear_matches_oracle(jr, oracle, multiphase):
+    """compute_τ_nonlinear! 2D (StressKernels.jl:266-351 + rheology/StressUpdate.jl:2-105) on random states, both the
+    single-phase and the phase-ratio form; yielding and non-yielding cells.  Tolerance 1e-12 (observed: bit-identical)."""
+    from justrelax_jl_amd import stokes as st_mod
+    from justrelax_jl_amd.arrays import from_numpy
+    from justrelax_jl_amd.checks import max_rel_diff
+    s = jr.miniapps.shearband2d(24)
+    _randomize(s, seed=12)
+    phases = [dict(ph) for ph in s.extra["phases"]]
+    for ph in phases:
+        ph["psi_deg"] = 7.0              # exercise the dilatant terms (volume, θ)
+        ph["Kb"] = 3.0
+    rh = oracle.rheology_struct(phases)
+    p = _vep_params(oracle, s)
+    ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    rng = np.random.default_rng(5)
+    lam = np.asfortranarray(rng.uniform(0, 0.1, size=s.ni))
+    lam_r = lam.copy(order="F")
+    theta_r = np.zeros(s.ni, order="F")
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    f = oracle.vep2d(ref)
+    oracle.lib().orc_compute_tau_nonlinear2d(C.byref(f), dp(theta_r), dp(lam_r), C.byref(rh), C.byref(p), C.c_int32(int(multiphase)))
+    stokes, pr, ρg = _upload(jr, s)
+    dev = stokes.P.device
+    lam_d, th_d = from_numpy(lam, dev), jr.fzeros(s.ni, dev)
+    st_mod.compute_τ_nonlinear_(stokes, th_d, lam_d, phases, s.dt, s.pt, phase_ratios=pr if multiphase else None)
+    out = _download(jr, stokes)
+    assert (lam_r != lam).any() and (lam_r == lam).any()                  # yielding and elastic cells
+    for k in ("txx", "tyy", "txy_c", "tII", "eta_vep", "eplxx", "eplyy", "eplxy"):
+        assert max_rel_diff(out[k], ref[k]) <= 1e-12, k
+    for k in ("txy", "P", "toxy", "exy"):                                  # untouched
+        assert np.array_equal(out[k], s.arrays[k]), k
+    assert max_rel_diff(jr.to_numpy(lam_d), lam_r) <= 1e-12 and max_rel_diff(jr.to_numpy(th_d), theta_r) <= 1e-12
+    assert np.abs(theta_r - ref["P"]).max() > 0
+
+
+@pytest.mark.parametrize("ni", [(24, 17), (3, 5), (130, 64)])
+def test_center2vertex_matches_oracle(jr, oracle, ni):
+    """center2vertex!(τ.xy, τ.xy_c) (Interpolations.jl:101-114), bit-exact incl. the edge copies"""
+    import torch
+    from justrelax_jl_amd import stokes as st_mod
+    from justrelax_jl_amd.arrays import from_numpy
+    rng = np.random.default_rng(2)
+    c = np.asfortranarray(rng.standard_normal(ni))
+    v = np.asfortranarray(rng.standard_normal((ni[0] + 1, ni[1] + 1)))
+    v_ref = v.copy(order="F")
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    oracle.lib().orc_center2vertex2d(dp(v_ref), dp(c), C.c_int64(ni[0]), C.c_int64(ni[1]))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    vd, cd = from_numpy(v, dev), from_numpy(c, dev)
+    st_mod.center2vertex_(vd, cd)
+    assert np.array_equal(jr.to_numpy(vd), v_ref)
+    assert np.array_equal(v_ref[0, 1:-1], v_ref[1, 1:-1]) and np.array_equal(v_ref[:, 0], v_ref[:, 1])
