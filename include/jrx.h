@@ -266,6 +266,53 @@ jrx_status jrx_tensor_invariant2d(jrx_handle *h, double *II, const double *xx, c
 /* compute_viscosity!/update_viscosity_τII! for the table rheology: η <- ν·η_phase + (1-ν)·η, clamped to the cutoff */
 jrx_status jrx_vep2d_compute_viscosity(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p, double nu);
 
+/* ------------------------------------------------------------------ 3D multiphase visco-elasto-plastic Stokes
+ * solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs) for 3D grids --
+ * src/stokes/Stokes3D.jl:447-668 with update_stresses_center_vertex_ps! 3D (src/stokes/StressKernels.jl:604-989), as
+ * test/test_shearband3D_MPI.jl drives it.  Same rheology table as the 2D driver.  Extents: centres ni; edge arrays
+ * yz (nx, ny+1, nz+1), xz (nx+1, ny, nz+1), xy (nx+1, ny+1, nz); phase arrays [nphase][extent] with the phase index
+ * fastest (JustPIC CellArray).  Pointers marked optional may be NULL. */
+typedef struct jrx_vep3d_fields {
+    double *P, *P0, *divV, *Q;
+    double *Vx, *Vy, *Vz, *Ux, *Uy, *Uz;
+    double *exx, *eyy, *ezz, *eyz, *exz, *exy;            /* ε: normals at centres, shear on edges */
+    double *eyz_c, *exz_c, *exy_c;                        /* optional: shear2center!(stokes.ε) targets */
+    double *eplxx, *eplyy, *eplzz, *eplyz, *eplxz, *eplxy;/* ε_pl */
+    double *eplyz_c, *eplxz_c, *eplxy_c;                  /* optional */
+    double *deyz, *dexz, *dexy, *deyz_c, *dexz_c, *dexy_c;/* optional: Δε shear and its centre copies */
+    double *txx, *tyy, *tzz, *tyz, *txz, *txy;            /* τ: normals at centres, shear on edges */
+    double *tyz_c, *txz_c, *txy_c, *tII;                  /* τ shear at centres, second invariant */
+    double *toxx, *toyy, *tozz, *toyz, *toxz, *toxy, *toyz_c, *toxz_c, *toxy_c;
+    double *eta, *eta_vep;
+    double *EII_pl, *evol_pl, *EVol_pl;
+    double *fx, *fy, *fz;                                 /* ρg */
+    double *RP, *Rx, *Ry, *Rz;
+    double *omega_yz, *omega_xz, *omega_xy;               /* optional: vorticity on the edges */
+    const double *phase_c, *phase_yz, *phase_xz, *phase_xy;
+} jrx_vep3d_fields;
+
+typedef struct jrx_vep3d_params {
+    int64_t nx, ny, nz, nxg, nyg, nzg;
+    double _dx, _dy, _dz;
+    double dt, r, theta_dtau, eta_dtau, eps_rel, eps_abs;
+    int64_t iterMax, nout;
+    uint32_t free_slip, no_slip, periodic;
+    double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
+    int32_t verbose;
+} jrx_vep3d_params;
+
+jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p,
+                                  jrx_solve_result *res);
+/* update_stresses_center_vertex_ps! 3D alone (θ, λ of extent ni; λv = {yz, xz, xy} edge arrays) -- for parity tests.
+ * Every update reads the stresses of the previous call (the reference's single launch races on neighbouring values). */
+jrx_status jrx_vep3d_update_stresses(jrx_handle *h, const jrx_vep3d_fields *f, const double *theta, double *lambda, double *const lambda_v[3],
+                                     const jrx_rheology *rh, const jrx_vep3d_params *p);
+/* compute_viscosity!/update_viscosity_τII! 3D for the table rheology: η <- ν·η_phase + (1-ν)·η, clamped to the cutoff */
+jrx_status jrx_vep3d_compute_viscosity(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p, double nu);
+/* tensor_invariant!(A) 3D -- StressKernels.jl:472-487 */
+jrx_status jrx_tensor_invariant3d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *zz, const double *yz,
+                                  const double *xz, const double *xy, int64_t nx, int64_t ny, int64_t nz);
+
 /* ------------------------------------------------------------------ 2D PT heat diffusion */
 typedef struct jrx_thermal2d_fields {
     double *T, *Told, *dT;                 /* (nx+2, ny+2): thermal.T, Told, ΔT */

@@ -89,6 +89,27 @@ class VEP2DParams(C.Structure):
                 ("verbose", C.c_int32)]
 
 
+VEP3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",
+              "exx", "eyy", "ezz", "eyz", "exz", "exy", "eyz_c", "exz_c", "exy_c",
+              "eplxx", "eplyy", "eplzz", "eplyz", "eplxz", "eplxy", "eplyz_c", "eplxz_c", "eplxy_c",
+              "deyz", "dexz", "dexy", "deyz_c", "dexz_c", "dexy_c",
+              "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII",
+              "toxx", "toyy", "tozz", "toyz", "toxz", "toxy", "toyz_c", "toxz_c", "toxy_c",
+              "eta", "eta_vep", "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "fz", "RP", "Rx", "Ry", "Rz",
+              "omega_yz", "omega_xz", "omega_xy", "phase_c", "phase_yz", "phase_xz", "phase_xy"]
+VEP3DFields = _ptr_struct("VEP3DFields", VEP3_NAMES)
+
+
+class VEP3DParams(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64), ("nxg", C.c_int64), ("nyg", C.c_int64), ("nzg", C.c_int64),
+                ("_dx", C.c_double), ("_dy", C.c_double), ("_dz", C.c_double),
+                ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
+                ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
+                ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
+                ("verbose", C.c_int32)]
+
+
 class SolveResult(C.Structure):
     _fields_ = [("iter", C.c_int64), ("nchecks", C.c_int64), ("cap", C.c_int64),
                 ("err_evo1", _dp), ("err_evo2", _ip),

@@ -132,8 +132,8 @@ class _Viscosity(_Lazy):
 
 
 class PhaseRatios:
-    """JustPIC.PhaseRatios(backend, nphases, ni): `center` (nphase, ni...) and `vertex` (nphase, ni.+1 ...) arrays in
-    CellArray layout (phase index fastest)."""
+    """JustPIC.PhaseRatios(backend, nphases, ni): `center` (nphase, ni...) and `vertex` (nphase, ni.+1 ...) arrays, in 3D also
+    `yz`, `xz`, `xy` on the edges, in CellArray layout (phase index fastest)."""
 
     def __init__(self, backend_tag, nphases, ni):
         dev = device_of(backend_tag)
@@ -141,6 +141,9 @@ class PhaseRatios:
         self.nphases = int(nphases)
         self.center = fzeros((self.nphases,) + ni, dev)
         self.vertex = fzeros((self.nphases,) + tuple(n + 1 for n in ni), dev)
+        if len(ni) == 3:               # phase ratios at the shear-stress locations (edges), 3D only
+            ts = _tensor_shapes(ni)
+            self.yz, self.xz, self.xy = (fzeros((self.nphases,) + ts[k], dev) for k in ("yz", "xz", "xy"))
 
 
 class StokesArrays:
@@ -166,7 +169,8 @@ class StokesArrays:
         self.τ_o = SymmetricTensor(ni, dev, lazy=self._LAZY_T)
         self.ε = SymmetricTensor(ni, dev, lazy=self._LAZY_T + tuple(k for k in _tensor_shapes(ni) if k.endswith("_c")))
         self.viscosity = _Viscosity(ni, dev)                           # Viscosity: η = @ones (constructors/stokes.jl:113-119)
-        self.ω = _Lazy(dev, {("xy" if len(ni) == 2 else k): tuple(n + 1 for n in ni) for k in (("xy",) if len(ni) == 2 else ("yz", "xz", "xy"))})
+        # Vorticity (constructors/stokes.jl:79-100): 2D xy at the vertices; 3D yz, xz, xy at their staggered (edge) locations
+        self.ω = _Lazy(dev, {"xy": tuple(n + 1 for n in ni)} if len(ni) == 2 else {k: _tensor_shapes(ni)[k] for k in ("yz", "xz", "xy")})
         self.R = SimpleNamespace(**{k: fzeros(s, dev) for k, s in residual_shapes(ni).items()})
 
     # ASCII aliases

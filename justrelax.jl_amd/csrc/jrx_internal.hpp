@@ -92,3 +92,10 @@ bool jrx_comm_active(const jrx_handle *h);
 // all-reduce (sum) of `count` doubles in place on the host values (uses RCCL when active)
 jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count);
 int jrx_comm_rank(const jrx_handle *h);
+
+// stokes3d.hip: pieces of the 3D visco-elastic path that the 3D VEP driver (stokes3d_vep.hip) reuses.  Asynchronous on `s`.
+// velocity sweep = compute_V! 3D (+ residuals when diag); sumsq leaves Σx² of Rx, Ry, Rz (interior slices) and RP in h->d_sums
+jrx_status jrx3d_velocity_sweep(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag);
+jrx_status jrx3d_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p);
+jrx_status jrx3d_bcs(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz, uint32_t fs, uint32_t ns, uint32_t pe);
+jrx_status jrx3d_sumsq(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p);

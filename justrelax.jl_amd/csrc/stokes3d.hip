@@ -194,6 +194,18 @@ jrx_status launch_sumsq(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields 
 
 }   // namespace
 
+jrx_status jrx3d_velocity_sweep(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag)
+{
+    if (diag && (!f->Rx || !f->Ry || !f->Rz)) return jrx_fail(h, JRX_ERR_ARG, "residual arrays are NULL");
+    return launch_velocity(h, s, make_args(f, etatau, p), diag, 0, (int)p->nx, 0, (int)p->ny, 0, (int)p->nz);
+}
+jrx_status jrx3d_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p) { return launch_scaleU(h, s, f, p); }
+jrx_status jrx3d_bcs(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz, uint32_t fs, uint32_t ns, uint32_t pe)
+{
+    return launch_bcs(h, s, Vx, Vy, Vz, nx, ny, nz, fs, ns, pe);
+}
+jrx_status jrx3d_sumsq(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p) { return launch_sumsq(h, s, f, p); }
+
 // ================================================================================================
 // C ABI
 // ================================================================================================

@@ -1,0 +1,574 @@
+// stokes3d_vep.hip -- 3D multiphase visco-elasto-plastic pseudo-transient Stokes driver for gfx950.
+//
+// Reference being replaced (PTsolvers/JustRelax.jl): src/stokes/Stokes3D.jl:447-668 (driver),
+// src/stokes/StressKernels.jl:604-989 (update_stresses_center_vertex_ps! 3D + clamped stencils),
+// PressureKernels.jl:47-106 (compute_P! with phase ratios), rheology/Viscosity.jl:67-106,282-300
+// (update_viscosity_τII!), rheology/StressUpdate.jl:146-176,435-550 (plastic parameters, yield function, gradients),
+// stress_rotation_particles.jl:31-50 (vorticity), Interpolations.jl:314-323 (shear2center!),
+// StressKernels.jl:394-431 (accumulate_tensor!, accumulate_vol!), as test/test_shearband3D_MPI.jl drives them.
+// Rheology table as in the 2D driver (stokes2d.hip): per-phase LinearViscous η, ConstantElasticity (G, Kb),
+// DruckerPrager_regularised (C, ϕ, ψ, η_vp); constant densities (ρg given).
+//
+// Per PT iteration: k_vep3_pre (∇V, θ, RP, ε(6)) -> k_vep3_visc -> 3 edge kernels (yz, xz, xy; new edge stresses to
+// temporaries: every update reads last iteration's stresses, where the reference's single launch races) -> commit ->
+// k_vep3_centre -> velocity sweep of the visco-elastic path (compute_V! is the same kernel) -> BCs.
+// HBM-bound fp64 stencils with branches; no MFMA.
+#include "jrx_internal.hpp"
+#include "jrx_kernels.hpp"
+
+namespace {
+
+struct Vep3Args {
+    jrx_vep3d_fields f;
+    jrx_rheology rh;
+    const double *etatau, *Kc, *Gc;
+    double *theta, *lam;
+    double *lamv[3], *tnew[3];
+    double _dx, _dy, _dz, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ int clampi3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ double sinv3(const double t[6])
+{
+    return sqrt(0.5 * (t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + t[3] * t[3] + t[4] * t[4] + t[5] * t[5]);
+}
+__device__ __forceinline__ double ratio_avg3(const double *val, const double *r, int n)
+{   // fn_ratio, src/phases/phases.jl:6-15
+    double x = 0.0;
+    for (int q = 0; q < n; q++) x += (r[q] == 0.0) ? 0.0 : val[q] * r[q];
+    return x;
+}
+__device__ __forceinline__ void plastic_params3(const jrx_rheology &rh, const double *r, bool &is_pl, double &eta_reg)
+{   // plastic_params_phase, rheology/StressUpdate.jl:152-176
+    is_pl = false; eta_reg = 0.0;
+    for (int q = 0; q < rh.nphase; q++)
+        if (rh.is_pl[q]) { is_pl = true; eta_reg += rh.eta_vp[q] * r[q]; }
+}
+__device__ __forceinline__ double yield_F3(const jrx_rheology &rh, const double *r, double P, double tII)
+{   // compute_yieldfunction_phase, StressUpdate.jl:435-452 ; DP: F = τII - cosϕ C - sinϕ P
+    double F = 0.0;
+    for (int q = 0; q < rh.nphase; q++) {
+        if (r[q] == 0.0) continue;
+        const double Fq = rh.is_pl[q] ? (tII - rh.cosphi[q] * rh.C[q] - rh.sinphi[q] * P) : tII;
+        F += r[q] * Fq;
+    }
+    return F;
+}
+__device__ __forceinline__ void plastic_grad3(const jrx_rheology &rh, const double *r, const double t[6], double dQdt[6], double &dQdP, double &dFdP)
+{   // compute_plastic_gradients_phase, StressUpdate.jl:463-550 (shear slots halved once, :466-472)
+#pragma unroll
+    for (int q = 0; q < 6; q++) dQdt[q] = 0.0;
+    dQdP = 0.0; dFdP = 0.0;
+    const double tII = sinv3(t);
+    for (int q = 0; q < rh.nphase; q++) {
+        if (r[q] == 0.0 || !rh.is_pl[q]) continue;
+#pragma unroll
+        for (int s = 0; s < 3; s++) dQdt[s] = fma(r[q], 0.5 * t[s] / tII, dQdt[s]);
+#pragma unroll
+        for (int s = 3; s < 6; s++) dQdt[s] = fma(r[q], 0.5 * (t[s] / tII), dQdt[s]);
+        dQdP = fma(r[q], -rh.sinpsi[q], dQdP);
+        dFdP = fma(r[q], -rh.sinphi[q], dFdP);
+    }
+}
+
+#define C3(A, i, j, k) (A)[(i) + (i64)nx * ((j) + (i64)ny * (k))]
+#define EYZ(A, i, j, k) (A)[(i) + (i64)nx * ((j) + (i64)(ny + 1) * (k))]
+#define EXZ(A, i, j, k) (A)[(i) + (i64)(nx + 1) * ((j) + (i64)ny * (k))]
+#define EXY(A, i, j, k) (A)[(i) + (i64)(nx + 1) * ((j) + (i64)(ny + 1) * (k))]
+
+// compute_∇V!, compute_P! (phase form: K, G per cell, η = ητ, P = θ) and compute_strain_rate! 3D over the ni.+1 box
+// (VelocityKernels.jl:3-6,59-104; PressureKernels.jl:47-106,186-195)
+__global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i > nx) return;
+    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
+    const double _dx = a._dx, _dy = a._dy, _dz = a._dz;
+#define VX(i_, j_, k_) Vx[(i_) + (i64)(nx + 1) * ((j_) + (i64)(ny + 2) * (k_))]
+#define VY(i_, j_, k_) Vy[(i_) + (i64)(nx + 2) * ((j_) + (i64)(ny + 1) * (k_))]
+#define VZ(i_, j_, k_) Vz[(i_) + (i64)(nx + 2) * ((j_) + (i64)(ny + 2) * (k_))]
+    if (i < nx && j < ny && k < nz) {
+        const i64 c = i + (i64)nx * (j + (i64)ny * k);
+        const double dxi = (-VX(i, j + 1, k + 1) + VX(i + 1, j + 1, k + 1)) * _dx;
+        const double dyi = (-VY(i + 1, j, k + 1) + VY(i + 1, j + 1, k + 1)) * _dy;
+        const double dzi = (-VZ(i + 1, j + 1, k) + VZ(i + 1, j + 1, k + 1)) * _dz;
+        const double divV = dxi + dyi + dzi;
+        a.f.divV[c] = divV;
+        const double _Kdt = 1.0 / (a.Kc[c] * a.dt), _Gdt = 1.0 / (a.Gc[c] * a.dt), _dt = 1.0 / a.dt;
+        const double P = a.theta[c], P0 = a.f.P0[c];
+        const double rhs = -divV + (a.f.Q[c] * _dt);
+        a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
+        const double psi = 1.0 / (1.0 / a.etatau[c] + _Gdt) * a.r / a.theta_dtau;
+        a.theta[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
+        const double d3 = divV * (1.0 / 3.0);
+        a.f.exx[c] = dxi - d3;
+        a.f.eyy[c] = dyi - d3;
+        a.f.ezz[c] = dzi - d3;
+    }
+    if (i < nx) EYZ(a.f.eyz, i, j, k) = 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k)));
+    if (j < ny) EXZ(a.f.exz, i, j, k) = 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k)));
+    if (k < nz) EXY(a.f.exy, i, j, k) = 0.5 * (_dy * (VX(i, j + 1, k + 1) - VX(i, j, k + 1)) + _dx * (VY(i + 1, j, k + 1) - VY(i, j, k + 1)));
+}
+
+// update_viscosity_τII! / compute_viscosity! for the table rheology (rheology/Viscosity.jl:282-300, 599-625)
+__global__ __launch_bounds__(256) void k_vep3_visc(const Vep3Args a, double nu)
+{
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (i64)a.nx * a.ny * a.nz) return;
+    const int np = a.rh.nphase;
+    const double *r = a.f.phase_c + np * c;
+    double e = 0.0;
+    bool pure = false;
+    for (int q = 0; q < np; q++)
+        if (r[q] > 0.999) { e = a.rh.eta[q]; pure = true; break; }
+    if (!pure) {
+        double s = 0.0;
+        for (int q = 0; q < np; q++)
+            if (r[q] != 0.0) s += (1.0 / a.rh.eta[q]) * r[q];
+        e = 1.0 / s;
+    }
+    e = e * nu + a.f.eta[c] * (1.0 - nu);
+    a.f.eta[c] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+}
+
+__global__ __launch_bounds__(256) void k_vep3_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const Vep3Args a)
+{
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (i64)a.nx * a.ny * a.nz) return;
+    const double *r = a.f.phase_c + (i64)a.rh.nphase * c;
+    Kc[c] = ratio_avg3(a.rh.Kb, r, a.rh.nphase);
+    Gc[c] = ratio_avg3(a.rh.G, r, a.rh.nphase);
+}
+
+// Stencil tables of StressKernels.jl:604-668 for the edge families T = 0 (yz), 1 (xz), 2 (xy): entries pick the
+// clamped index {0: n-1, 1: n, 2: n+1} per direction, in the reference's order of summation.
+__device__ const int CEN3[3][4][3] = {
+    {{1, 0, 0}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}},
+    {{0, 1, 0}, {1, 1, 0}, {0, 1, 1}, {1, 1, 1}},
+    {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}}};
+__device__ const int OTH3[3][3][4][3] = {
+    {{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {{1, 0, 1}, {2, 0, 1}, {1, 1, 1}, {2, 1, 1}}, {{1, 1, 0}, {2, 1, 0}, {1, 1, 1}, {2, 1, 1}}},
+    {{{0, 1, 1}, {1, 1, 1}, {1, 2, 1}, {0, 2, 1}}, {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {{1, 1, 0}, {1, 2, 0}, {1, 1, 1}, {1, 2, 1}}},
+    {{{0, 1, 1}, {1, 1, 1}, {0, 1, 2}, {1, 1, 2}}, {{1, 0, 1}, {1, 1, 1}, {1, 0, 2}, {1, 1, 2}}, {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}}};
+
+// update_stresses_center_vertex_ps! 3D -- one edge family (StressKernels.jl:707-903)
+template <int T>
+__global__ __launch_bounds__(256) void k_vep3_edge(const Vep3Args a)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
+    const int n1 = nx + (T != 0), n2 = ny + (T != 1), n3 = nz + (T != 2);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= n1 || j >= n2 || k >= n3) return;
+    const int ci[3] = {clampi3(i - 1, 0, nx - 1), clampi3(i, 0, nx - 1), clampi3(i + 1, 0, nx - 1)};
+    const int cj[3] = {clampi3(j - 1, 0, ny - 1), clampi3(j, 0, ny - 1), clampi3(j + 1, 0, ny - 1)};
+    const int ck[3] = {clampi3(k - 1, 0, nz - 1), clampi3(k, 0, nz - 1), clampi3(k + 1, 0, nz - 1)};
+    i64 cidx[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) cidx[q] = ci[CEN3[T][q][0]] + (i64)nx * (cj[CEN3[T][q][1]] + (i64)ny * ck[CEN3[T][q][2]]);
+#define AVC(A) (0.25 * ((A)[cidx[0]] + (A)[cidx[1]] + (A)[cidx[2]] + (A)[cidx[3]]))
+    const double etav = 4 / (1 / a.f.eta[cidx[0]] + 1 / a.f.eta[cidx[1]] + 1 / a.f.eta[cidx[2]] + 1 / a.f.eta[cidx[3]]);
+    const double Pv = AVC(a.theta);
+    const i64 v = i + (i64)n1 * (j + (i64)n2 * k);
+    double *const tsh[3] = {a.f.tyz, a.f.txz, a.f.txy};
+    const double *const tosh[3] = {a.f.toyz, a.f.toxz, a.f.toxy};
+    const double *const esh[3] = {a.f.eyz, a.f.exz, a.f.exy};
+    double *const eplsh[3] = {a.f.eplyz, a.f.eplxz, a.f.eplxy};
+    const double *const phsh[3] = {a.f.phase_yz, a.f.phase_xz, a.f.phase_xy};
+    const double *const en[3] = {a.f.exx, a.f.eyy, a.f.ezz};
+    const double *const tn[3] = {a.f.txx, a.f.tyy, a.f.tzz};
+    const double *const ton[3] = {a.f.toxx, a.f.toyy, a.f.tozz};
+    double eij[6], tij[6], toij[6];
+#pragma unroll
+    for (int s = 0; s < 3; s++) { eij[s] = AVC(en[s]); tij[s] = AVC(tn[s]); toij[s] = AVC(ton[s]); }
+#undef AVC
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        if (s == T) { eij[3 + s] = esh[s][v]; tij[3 + s] = tsh[s][v]; toij[3 + s] = tosh[s][v]; continue; }
+        const int m1 = nx + (s != 0), m2 = ny + (s != 1);
+        i64 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) o[q] = ci[OTH3[T][s][q][0]] + (i64)m1 * (cj[OTH3[T][s][q][1]] + (i64)m2 * ck[OTH3[T][s][q][2]]);
+        eij[3 + s] = 0.25 * (esh[s][o[0]] + esh[s][o[1]] + esh[s][o[2]] + esh[s][o[3]]);
+        tij[3 + s] = 0.25 * (tsh[s][o[0]] + tsh[s][o[1]] + tsh[s][o[2]] + tsh[s][o[3]]);
+        toij[3 + s] = 0.25 * (tosh[s][o[0]] + tosh[s][o[1]] + tosh[s][o[2]] + tosh[s][o[3]]);
+    }
+    const double *rv = phsh[T] + (i64)np * v;
+    bool is_pl; double eta_reg;
+    plastic_params3(a.rh, rv, is_pl, eta_reg);
+    const double _Gdt = 1.0 / (ratio_avg3(a.rh.G, rv, np) * a.dt);
+    const double Kv = ratio_avg3(a.rh.Kb, rv, np);
+    const double dtr = 1.0 / (a.theta_dtau + etav * _Gdt + 1.0);
+    double d[6], tt[6];
+#pragma unroll
+    for (int s = 0; s < 6; s++) { d[s] = dev_stress_inc(tij[s], toij[s], etav, eij[s], _Gdt, dtr); tt[s] = tij[s] + d[s]; }
+    const double tIIv = sinv3(tt);
+    double dQdt[6], dQdP, dFdP;
+    plastic_grad3(a.rh, rv, tt, dQdt, dQdP, dFdP);
+    const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
+    const double F = yield_F3(a.rh, rv, Pv, tIIv);
+    constexpr int own = 3 + T;
+    if (is_pl && tIIv != 0.0 && F > 0) {
+        const double l = (1.0 - a.rel) * a.lamv[T][v] + a.rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol));
+        a.lamv[T][v] = l;
+        const double epl = l * dQdt[own];
+        a.tnew[T][v] = tij[own] + fma(-(2.0 * etav * epl), dtr, d[own]);
+        eplsh[T][v] = epl;
+    } else {
+        a.tnew[T][v] = tij[own] + d[own];
+        eplsh[T][v] = 0.0;
+    }
+}
+
+// update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
+__global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= nx || j >= ny || k >= nz) return;
+    const i64 c = i + (i64)nx * (j + (i64)ny * k);
+    const double *rc = a.f.phase_c + (i64)np * c;
+    const double _Gdt = 1.0 / (ratio_avg3(a.rh.G, rc, np) * a.dt);
+    bool is_pl; double eta_reg;
+    plastic_params3(a.rh, rc, is_pl, eta_reg);
+    const double K = ratio_avg3(a.rh.Kb, rc, np);
+    const double e = a.f.eta[c];
+    const double dtr = 1.0 / (a.theta_dtau + e * _Gdt + 1.0);
+    double eij[6] = {a.f.exx[c], a.f.eyy[c], a.f.ezz[c], 0, 0, 0};
+    // _av_yz/_av_xz/_av_xy = 0.25 * mysum (MiniKernels.jl:116-121, 228-236): s = 0.0, then k-outer, j, i-inner adds
+    eij[3] = 0.25 * ((((0.0 + EYZ(a.f.eyz, i, j, k)) + EYZ(a.f.eyz, i, j + 1, k)) + EYZ(a.f.eyz, i, j, k + 1)) + EYZ(a.f.eyz, i, j + 1, k + 1));
+    eij[4] = 0.25 * ((((0.0 + EXZ(a.f.exz, i, j, k)) + EXZ(a.f.exz, i + 1, j, k)) + EXZ(a.f.exz, i, j, k + 1)) + EXZ(a.f.exz, i + 1, j, k + 1));
+    eij[5] = 0.25 * ((((0.0 + EXY(a.f.exy, i, j, k)) + EXY(a.f.exy, i + 1, j, k)) + EXY(a.f.exy, i, j + 1, k)) + EXY(a.f.exy, i + 1, j + 1, k));
+    double *const tc[6] = {a.f.txx, a.f.tyy, a.f.tzz, a.f.tyz_c, a.f.txz_c, a.f.txy_c};
+    const double *const toc[6] = {a.f.toxx, a.f.toyy, a.f.tozz, a.f.toyz_c, a.f.toxz_c, a.f.toxy_c};
+    double tij[6], d[6], tt[6];
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        tij[s] = tc[s][c];
+        const double to = toc[s][c];
+        d[s] = (-(tij[s] - to) * e * _Gdt - tij[s] + 2.0 * e * eij[s]) * dtr;       // :926, plain arithmetic
+        tt[s] = tij[s] + d[s];
+    }
+    double tII;
+    {
+        double q6[6];
+#pragma unroll
+        for (int s = 0; s < 6; s++) q6[s] = d[s] + tij[s];
+        tII = sinv3(q6);
+    }
+    double dQdt[6], dQdP, dFdP;
+    plastic_grad3(a.rh, rc, tt, dQdt, dQdP, dFdP);
+    const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
+    const double Pr = a.theta[c];
+    const double F = yield_F3(a.rh, rc, Pr, tII);
+    double l = a.lam[c];
+    if (is_pl && tII != 0.0 && F > 0) {
+        l = (1.0 - a.rel) * l + a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol));
+        a.lam[c] = l;
+        double epl[6];
+#pragma unroll
+        for (int s = 0; s < 6; s++) { epl[s] = l * dQdt[s]; d[s] = d[s] - 2.0 * e * epl[s] * dtr; tij[s] = d[s] + tij[s]; }
+        a.f.evol_pl[c] = -l * dQdP;
+#pragma unroll
+        for (int s = 0; s < 6; s++) tc[s][c] = tij[s];
+        a.f.eplxx[c] = epl[0]; a.f.eplyy[c] = epl[1]; a.f.eplzz[c] = epl[2];
+        tII = sinv3(tij);
+    } else {
+        a.f.evol_pl[c] = 0.0;
+#pragma unroll
+        for (int s = 0; s < 6; s++) tc[s][c] = d[s] + tij[s];
+        a.f.eplxx[c] = 0.0; a.f.eplyy[c] = 0.0; a.f.eplzz[c] = 0.0;
+    }
+    a.f.tII[c] = tII;
+    a.f.eta_vep[c] = tII * 0.5 * (1.0 / sinv3(eij));
+    a.f.P[c] = Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP);
+}
+
+__device__ __forceinline__ double sinv_stag3(const double *xx, const double *yy, const double *zz, const double *yz, const double *xz, const double *xy,
+                                             int nx, int ny, int i, int j, int k)
+{   // second_invariant_staggered on the gathers of MiniKernels.jl:196-204 (mean of the squared edge values, as pinned in 2D)
+    const i64 c = i + (i64)nx * (j + (i64)ny * k);
+    const double a0 = EYZ(yz, i, j, k), a1 = EYZ(yz, i, j + 1, k), a2 = EYZ(yz, i, j, k + 1), a3 = EYZ(yz, i, j + 1, k + 1);
+    const double b0 = EXZ(xz, i, j, k), b1 = EXZ(xz, i + 1, j, k), b2 = EXZ(xz, i, j, k + 1), b3 = EXZ(xz, i + 1, j, k + 1);
+    const double c0 = EXY(xy, i, j, k), c1 = EXY(xy, i + 1, j, k), c2 = EXY(xy, i, j + 1, k), c3 = EXY(xy, i + 1, j + 1, k);
+    const double syz = 0.25 * (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
+    const double sxz = 0.25 * (b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3);
+    const double sxy = 0.25 * (c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3);
+    return sqrt(0.5 * (xx[c] * xx[c] + yy[c] * yy[c] + zz[c] * zz[c]) + syz + sxz + sxy);
+}
+
+// tensor_invariant_kernel! 3D (StressKernels.jl:472-487)
+__global__ __launch_bounds__(256) void k_tensor_invariant3d(double *__restrict__ II, const double *xx, const double *yy, const double *zz,
+                                                            const double *yz, const double *xz, const double *xy, int nx, int ny, int nz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= nx) return;
+    II[i + (i64)nx * (j + (i64)ny * k)] = sinv_stag3(xx, yy, zz, yz, xz, xy, nx, ny, i, j, k);
+}
+
+// shear2center_kernel! 3D (Interpolations.jl:314-323)
+__global__ __launch_bounds__(256) void k_shear2center3d(double *__restrict__ yz_c, double *__restrict__ xz_c, double *__restrict__ xy_c,
+                                                        const double *yz, const double *xz, const double *xy, int nx, int ny, int nz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= nx) return;
+    const i64 c = i + (i64)nx * (j + (i64)ny * k);
+    yz_c[c] = 0.25 * (EYZ(yz, i, j, k) + EYZ(yz, i, j + 1, k) + EYZ(yz, i, j, k + 1) + EYZ(yz, i, j + 1, k + 1));
+    xz_c[c] = 0.25 * (EXZ(xz, i, j, k) + EXZ(xz, i + 1, j, k) + EXZ(xz, i, j, k + 1) + EXZ(xz, i + 1, j, k + 1));
+    xy_c[c] = 0.25 * (EXY(xy, i, j, k) + EXY(xy, i + 1, j, k) + EXY(xy, i, j + 1, k) + EXY(xy, i + 1, j + 1, k));
+}
+
+// compute_vorticity!(ωyz, ωxz, ωxy, V..., _di) (stress_rotation_particles.jl:31-50) over the ni.+1 box
+__global__ __launch_bounds__(256) void k_vorticity3d(double *__restrict__ wyz, double *__restrict__ wxz, double *__restrict__ wxy, const double *Vx,
+                                                     const double *Vy, const double *Vz, int nx, int ny, int nz, double _dx, double _dy, double _dz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i > nx) return;
+    if (i < nx) EYZ(wyz, i, j, k) = 0.5 * ((-VZ(i, j, k) + VZ(i, j + 1, k)) * _dy - (-VY(i, j, k) + VY(i, j, k + 1)) * _dz);
+    if (j < ny) EXZ(wxz, i, j, k) = 0.5 * ((-VX(i, j, k) + VX(i, j, k + 1)) * _dz - (-VZ(i, j, k) + VZ(i + 1, j, k)) * _dx);
+    if (k < nz) EXY(wxy, i, j, k) = 0.5 * ((-VY(i, j, k) + VY(i + 1, j, k)) * _dx - (-VX(i, j, k) + VX(i, j + 1, k)) * _dy);
+}
+
+// accumulate_tensor! + accumulate_vol! (StressKernels.jl:394-431)
+__global__ __launch_bounds__(256) void k_vep3_accumulate(const Vep3Args a)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= nx) return;
+    const i64 c = i + (i64)nx * (j + (i64)ny * k);
+    a.f.EII_pl[c] += sinv_stag3(a.f.eplxx, a.f.eplyy, a.f.eplzz, a.f.eplyz, a.f.eplxz, a.f.eplxy, nx, ny, i, j, k) * a.dt;
+    a.f.EVol_pl[c] += a.dt * a.f.evol_pl[c];
+}
+#undef VX
+#undef VY
+#undef VZ
+
+jrx_status check_vep3(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!f || !rh || !p) return jrx_fail(h, JRX_ERR_ARG, "null VEP argument");
+    if (p->nx < 3 || p->ny < 3 || p->nz < 3) return jrx_fail(h, JRX_ERR_ARG, "3D Stokes needs at least 3 cells per dimension");
+    if ((double)(p->nx + 2) * (double)(p->ny + 2) * (double)(p->nz + 2) >= 2147483647.0)
+        return jrx_fail(h, JRX_ERR_UNSUPPORTED, "local block too large for 32-bit plane indices");
+    if (rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "nphase must be in 1..%d", JRX_MAXPHASE);
+    const void *req[] = {f->P, f->P0, f->divV, f->Q, f->Vx, f->Vy, f->Vz, f->Ux, f->Uy, f->Uz, f->exx, f->eyy, f->ezz, f->eyz, f->exz, f->exy,
+                         f->eplxx, f->eplyy, f->eplzz, f->eplyz, f->eplxz, f->eplxy, f->txx, f->tyy, f->tzz, f->tyz, f->txz, f->txy,
+                         f->tyz_c, f->txz_c, f->txy_c, f->tII, f->toxx, f->toyy, f->tozz, f->toyz, f->toxz, f->toxy, f->toyz_c, f->toxz_c,
+                         f->toxy_c, f->eta, f->eta_vep, f->EII_pl, f->evol_pl, f->EVol_pl, f->fx, f->fy, f->fz, f->RP, f->Rx, f->Ry, f->Rz,
+                         f->phase_c, f->phase_yz, f->phase_xz, f->phase_xy};
+    for (const void *q : req)
+        if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required 3D VEP field pointer is NULL");
+    return JRX_OK;
+}
+
+Vep3Args make_vep3(const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p)
+{
+    Vep3Args a;
+    memset(&a, 0, sizeof(a));
+    a.f = *f; a.rh = *rh;
+    a._dx = p->_dx; a._dy = p->_dy; a._dz = p->_dz; a.dt = p->dt; a.r = p->r; a.theta_dtau = p->theta_dtau; a.rel = p->lambda_relaxation;
+    a.nu = p->viscosity_relaxation; a.cut_lo = p->cutoff_lo; a.cut_hi = p->cutoff_hi;
+    a.nx = (int)p->nx; a.ny = (int)p->ny; a.nz = (int)p->nz;
+    return a;
+}
+
+struct EdgeN { i64 yz, xz, xy; };
+EdgeN edge_counts(const jrx_vep3d_params *p)
+{
+    return EdgeN{(i64)p->nx * (p->ny + 1) * (p->nz + 1), (i64)(p->nx + 1) * p->ny * (p->nz + 1), (i64)(p->nx + 1) * (p->ny + 1) * p->nz};
+}
+
+// the three edge passes, the commit of the new edge stresses, then the centre pass
+jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const unsigned gx1 = (unsigned)((nx + 1 + 255) / 256), gx0 = (unsigned)((nx + 255) / 256);
+    hipLaunchKernelGGL(k_vep3_edge<0>, dim3(gx0, ny + 1, nz + 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_vep3_edge<1>, dim3(gx1, ny, nz + 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_vep3_edge<2>, dim3(gx1, ny + 1, nz), dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    const EdgeN n = edge_counts(p);
+    hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, a.f.tyz, (const double *)a.tnew[0], n.yz, a.f.txz, (const double *)a.tnew[1], n.xz, a.f.txy,
+                       (const double *)a.tnew[2], n.xy, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr,
+                       (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
+    JRX_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(k_vep3_centre, dim3(gx0, ny, nz), dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+jrx_stokes3d_fields view3d(const jrx_vep3d_fields *f)
+{
+    jrx_stokes3d_fields g;
+    memset(&g, 0, sizeof(g));
+    g.P = f->P; g.P0 = f->P0; g.divV = f->divV; g.Q = f->Q; g.Vx = f->Vx; g.Vy = f->Vy; g.Vz = f->Vz; g.Ux = f->Ux; g.Uy = f->Uy; g.Uz = f->Uz;
+    g.txx = f->txx; g.tyy = f->tyy; g.tzz = f->tzz; g.tyz = f->tyz; g.txz = f->txz; g.txy = f->txy;
+    g.toxx = f->toxx; g.toyy = f->toyy; g.tozz = f->tozz; g.toyz = f->toyz; g.toxz = f->toxz; g.toxy = f->toxy;
+    g.exx = f->exx; g.eyy = f->eyy; g.ezz = f->ezz; g.eyz = f->eyz; g.exz = f->exz; g.exy = f->exy;
+    g.eta = f->eta; g.K = f->eta; g.G = f->eta;      // K, G are not read by the velocity sweep
+    g.fx = f->fx; g.fy = f->fy; g.fz = f->fz; g.RP = f->RP; g.Rx = f->Rx; g.Ry = f->Ry; g.Rz = f->Rz;
+    return g;
+}
+
+}   // namespace
+
+extern "C" {
+
+jrx_status jrx_vep3d_update_stresses(jrx_handle *h, const jrx_vep3d_fields *f, const double *theta, double *lambda, double *const lambda_v[3],
+                                     const jrx_rheology *rh, const jrx_vep3d_params *p)
+{
+    JRX_TRY(check_vep3(h, f, rh, p));
+    if (!theta || !lambda || !lambda_v || !lambda_v[0] || !lambda_v[1] || !lambda_v[2]) return jrx_fail(h, JRX_ERR_ARG, "θ / λ / λv is NULL");
+    const EdgeN n = edge_counts(p);
+    JRX_TRY(jrx_ensure_etatau(h, (size_t)(n.yz + n.xz + n.xy)));
+    Vep3Args a = make_vep3(f, rh, p);
+    a.theta = const_cast<double *>(theta); a.lam = lambda;
+    for (int t = 0; t < 3; t++) a.lamv[t] = lambda_v[t];
+    a.tnew[0] = h->etatau; a.tnew[1] = a.tnew[0] + n.yz; a.tnew[2] = a.tnew[1] + n.xz;
+    JRX_TRY(launch_vep3_stress(h, h->stream, a, p));
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_vep3d_compute_viscosity(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p, double nu)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!f || !rh || !p || !f->eta || !f->phase_c) return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: null argument");
+    Vep3Args a = make_vep3(f, rh, p);
+    const i64 n = (i64)p->nx * p->ny * p->nz;
+    hipLaunchKernelGGL(k_vep3_visc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a, nu);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_tensor_invariant3d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *zz, const double *yz,
+                                  const double *xz, const double *xy, int64_t nx, int64_t ny, int64_t nz)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!II || !xx || !yy || !zz || !yz || !xz || !xy || nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "tensor_invariant!: bad argument");
+    hipLaunchKernelGGL(k_tensor_invariant3d, dim3((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)nz), dim3(256), 0, h->stream, II, xx, yy, zz, yz, xz,
+                       xy, (int)nx, (int)ny, (int)nz);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p,
+                                  jrx_solve_result *res)
+{
+    JRX_TRY(check_vep3(h, f, rh, p));
+    if (!res) return jrx_fail(h, JRX_ERR_ARG, "null result");
+    if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
+    if (jrx_comm_active(h)) return jrx_fail(h, JRX_ERR_UNSUPPORTED, "multi-rank 3D VEP solve is not implemented");
+    const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
+    const size_t n = (size_t)nx * ny * nz;
+    const EdgeN ne = edge_counts(p);
+    hipStream_t s = h->stream;
+    // library scratch: ητ, θ, λ, K, G (centres), λv and the new edge stresses (edges), carved out of one allocation
+    JRX_TRY(jrx_ensure_etatau(h, 5 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
+    double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n;
+    Vep3Args a = make_vep3(f, rh, p);
+    a.theta = theta; a.etatau = etatau; a.Kc = Kc; a.Gc = Gc; a.lam = lam;
+    a.lamv[0] = Gc + n; a.lamv[1] = a.lamv[0] + ne.yz; a.lamv[2] = a.lamv[1] + ne.xz;
+    a.tnew[0] = a.lamv[2] + ne.xy; a.tnew[1] = a.tnew[0] + ne.yz; a.tnew[2] = a.tnew[1] + ne.xz;
+    jrx_stokes3d_fields g = view3d(f);
+    jrx_stokes3d_params q;
+    memset(&q, 0, sizeof(q));
+    q.nx = nx; q.ny = ny; q.nz = nz; q.nxg = p->nxg; q.nyg = p->nyg; q.nzg = p->nzg; q._dx = p->_dx; q._dy = p->_dy; q._dz = p->_dz;
+    q.dt = p->dt; q.r = p->r; q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau;
+    q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
+    const unsigned gc = (unsigned)((n + 255) / 256), gx1 = (unsigned)((nx + 1 + 255) / 256), gx0 = (unsigned)((nx + 255) / 256);
+
+    JRX_HIP(h, hipMemcpyAsync(f->P0, f->P, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // @copy stokes.P0 stokes.P
+    JRX_HIP(h, hipMemcpyAsync(theta, f->P, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // θ = deepcopy(stokes.P)
+    JRX_HIP(h, hipMemsetAsync(lam, 0, n * sizeof(double), s));
+    JRX_HIP(h, hipMemsetAsync(a.lamv[0], 0, (size_t)(ne.yz + ne.xz + ne.xy) * sizeof(double), s));
+    hipLaunchKernelGGL(k_vep3_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a);
+    hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, 1.0);                              // compute_viscosity! :507
+    JRX_LAUNCH_CHECK(h);
+
+    double err_it1 = 1.0, err = INFINITY;
+    int64_t iter = 0, cont = 0;
+    res->iter = 0; res->nchecks = 0;
+    hipEvent_t t0 = h->ev[6], t1 = h->ev[7];
+    JRX_HIP(h, hipEventRecord(t0, s));
+    auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
+    while (keep_going(iter)) {
+        const int64_t it1 = iter + 1;
+        const bool check = (it1 % p->nout == 0) && it1 > 1;
+        const bool diag = check || !keep_going(it1);      // R and U are only observable after such an iteration
+        hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, nz);
+        hipLaunchKernelGGL(k_vep3_pre, dim3(gx1, ny + 1, nz + 1), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, p->viscosity_relaxation);
+        JRX_LAUNCH_CHECK(h);
+        JRX_TRY(launch_vep3_stress(h, s, a, p));
+        JRX_TRY(jrx3d_velocity_sweep(h, s, &g, etatau, &q, diag));
+        if (diag) JRX_TRY(jrx3d_scaleU(h, s, &g, &q));
+        JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        iter = it1;
+        if (check) {
+            JRX_TRY(jrx3d_sumsq(h, s, &g, &q));
+            JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            JRX_HIP(h, hipStreamSynchronize(s));
+            const double den = (double)((p->nxg - 1) * (p->nyg - 1) * (p->nzg - 1));                  // Stokes3D.jl:607-612
+            const double nRx = sqrt(h->h_sums[0]) / den, nRy = sqrt(h->h_sums[1]) / den, nRz = sqrt(h->h_sums[2]) / den;
+            const double nDV = sqrt(h->h_sums[3]) / (double)n;                                        // norm_mpi(RP) / length(RP)
+            err = fmax(fmax(nRx, nRy), fmax(nRz, nDV));
+            if (std::isnan(nRx) || std::isnan(nRy) || std::isnan(nRz) || std::isnan(nDV)) err = NAN;
+            if (cont < res->cap) {
+                if (res->norm_Rx) res->norm_Rx[cont] = nRx;
+                if (res->norm_Ry) res->norm_Ry[cont] = nRy;
+                if (res->norm_Rz) res->norm_Rz[cont] = nRz;
+                if (res->norm_divV) res->norm_divV[cont] = nDV;
+                if (res->err_evo1) res->err_evo1[cont] = err;
+                if (res->err_evo2) res->err_evo2[cont] = iter;
+            }
+            if (cont == 0) err_it1 = err;
+            cont++;
+            if ((p->verbose && (err / err_it1) > p->eps_rel && err > p->eps_abs) || iter == p->iterMax)
+                printf("iter = %lld, abs_err = %1.3e, rel_err = %1.3e [norm_Rx=%1.3e, norm_Ry=%1.3e, norm_Rz=%1.3e, norm_∇V=%1.3e] \n", (long long)iter,
+                       err, err / err_it1, nRx, nRy, nRz, nDV);
+            if (std::isnan(err)) {
+                res->iter = iter; res->nchecks = cont < res->cap ? cont : res->cap;
+                (void)hipStreamSynchronize(s);
+                return jrx_fail(h, JRX_ERR_NAN, "NaN(s)");
+            }
+        }
+    }
+    JRX_HIP(h, hipEventRecord(t1, s));
+    // epilogue: vorticity, shear2center!, accumulate_tensor!/accumulate_vol!, τ -> τ_o (Stokes3D.jl:640-658)
+    if (f->omega_yz && f->omega_xz && f->omega_xy)
+        hipLaunchKernelGGL(k_vorticity3d, dim3(gx1, ny + 1, nz + 1), dim3(256), 0, s, f->omega_yz, f->omega_xz, f->omega_xy, (const double *)f->Vx,
+                           (const double *)f->Vy, (const double *)f->Vz, nx, ny, nz, p->_dx, p->_dy, p->_dz);
+    if (f->eyz_c && f->exz_c && f->exy_c)
+        hipLaunchKernelGGL(k_shear2center3d, dim3(gx0, ny, nz), dim3(256), 0, s, f->eyz_c, f->exz_c, f->exy_c, (const double *)f->eyz, (const double *)f->exz,
+                           (const double *)f->exy, nx, ny, nz);
+    if (f->eplyz_c && f->eplxz_c && f->eplxy_c)
+        hipLaunchKernelGGL(k_shear2center3d, dim3(gx0, ny, nz), dim3(256), 0, s, f->eplyz_c, f->eplxz_c, f->eplxy_c, (const double *)f->eplyz,
+                           (const double *)f->eplxz, (const double *)f->eplxy, nx, ny, nz);
+    if (f->deyz_c && f->dexz_c && f->dexy_c && f->deyz && f->dexz && f->dexy)
+        hipLaunchKernelGGL(k_shear2center3d, dim3(gx0, ny, nz), dim3(256), 0, s, f->deyz_c, f->dexz_c, f->dexy_c, (const double *)f->deyz, (const double *)f->dexz,
+                           (const double *)f->dexy, nx, ny, nz);
+    hipLaunchKernelGGL(k_vep3_accumulate, dim3(gx0, ny, nz), dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    const i64 nc = (i64)n;
+    hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, f->toxx, (const double *)f->txx, nc, f->toyy, (const double *)f->tyy, nc, f->tozz,
+                       (const double *)f->tzz, nc, f->toyz, (const double *)f->tyz, ne.yz, f->toxz, (const double *)f->txz, ne.xz, f->toxy,
+                       (const double *)f->txy, ne.xy);
+    hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, f->toyz_c, (const double *)f->tyz_c, nc, f->toxz_c, (const double *)f->txz_c, nc, f->toxy_c,
+                       (const double *)f->txy_c, nc, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0,
+                       (double *)nullptr, (const double *)nullptr, (i64)0);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(s));
+    float ms = 0.f;
+    JRX_HIP(h, hipEventElapsedTime(&ms, t0, t1));
+    res->iter = iter;
+    res->nchecks = cont < res->cap ? cont : res->cap;
+    res->time_s = ms * 1e-3;
+    res->av_time_s = iter > 1 ? res->time_s / (double)(iter - 1) : res->time_s;
+    return JRX_OK;
+}
+
+}   // extern "C"

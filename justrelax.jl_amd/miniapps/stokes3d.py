@@ -181,6 +181,61 @@ def random_fields3d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nou
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
 
 
+def vep_shapes3d(ni, nphase=2):
+    """array name -> extent for the 3D VEP problem (names follow jrx_vep3d_fields / oracle.VEP3_NAMES)"""
+    nx, ny, nz = ni
+    c = tuple(ni)
+    yz, xz, xy = (nx, ny + 1, nz + 1), (nx + 1, ny, nz + 1), (nx + 1, ny + 1, nz)
+    names = ["P", "P0", "divV", "Q", "exx", "eyy", "ezz", "eyz_c", "exz_c", "exy_c", "eplxx", "eplyy", "eplzz", "eplyz_c", "eplxz_c", "eplxy_c",
+             "deyz_c", "dexz_c", "dexy_c", "txx", "tyy", "tzz", "tyz_c", "txz_c", "txy_c", "tII", "toxx", "toyy", "tozz", "toyz_c", "toxz_c", "toxy_c",
+             "eta", "eta_vep", "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "fz", "RP"]
+    s = {k: c for k in names}
+    for pre in ("e", "epl", "de", "t", "to", "omega_"):
+        s[pre + "yz"], s[pre + "xz"], s[pre + "xy"] = yz, xz, xy
+    s.update(Vx=(nx + 1, ny + 2, nz + 2), Vy=(nx + 2, ny + 1, nz + 2), Vz=(nx + 2, ny + 2, nz + 1),
+             Ux=(nx + 1, ny + 2, nz + 2), Uy=(nx + 2, ny + 1, nz + 2), Uz=(nx + 2, ny + 2, nz + 1),
+             Rx=(nx - 1, ny, nz), Ry=(nx, ny - 1, nz), Rz=(nx, ny, nz - 1),
+             phase_c=(nphase,) + c, phase_yz=(nphase,) + yz, phase_xz=(nphase,) + xz, phase_xy=(nphase,) + xy)
+    return s
+
+
+def shearband3d(n=16, *, iterMax=150_000, nout=1000) -> Setup:
+    """ShearBand3D -- test/test_shearband3D_MPI.jl:68-168: matrix (η0 = 1, G0 = 1) with a spherical inclusion (η0/10, Gi = 0.5) of
+    radius 0.1, ν = 0.5 (Kb = Inf), DruckerPrager_regularised(C = 1.6/cos30, ϕ = 30, ψ = 0, η_vp = 1.25e-2), pure shear in x-z
+    (εbg = 1), free slip, dt = η0/G0/4, PTStokesCoeffs(ϵ_rel = 1e-5, Re = 3, r = 0.7, CFL = 0.9/√3.1)."""
+    ni = (n, n, n) if isinstance(n, int) else tuple(n)
+    nx, ny, nz = ni
+    li = (1.0, 1.0, 1.0)
+    init_global_grid(nx, ny, nz)
+    di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g(), nz_g())))
+    grid = Geometry(ni, li, origin=(0.0, 0.0, 0.0))
+    τ_y, ϕ, η0, G0, εbg, η_reg = 1.6, 30.0, 1.0, 1.0, 1.0, 1.25e-2
+    Gi = G0 / (6.0 - 4.0)
+    dt = η0 / G0 / 4.0
+    Cgp = τ_y / math.cos(math.radians(ϕ))
+    inf = float("inf")
+    phases = [dict(eta=η0, G=G0, Kb=inf, C=Cgp, phi_deg=ϕ, psi_deg=0.0, eta_vp=η_reg),
+              dict(eta=η0 / 10, G=Gi, Kb=inf, C=Cgp, phi_deg=ϕ, psi_deg=0.0, eta_vp=η_reg)]
+    arr = {k: np.zeros(s, dtype=np.float64, order="F") for k, s in vep_shapes3d(ni).items()}
+    radius, o = 0.1, (0.5, 0.5, 0.5)
+    (xc, yc, zc), (xv, yv, zv) = grid.xci, grid.xvi
+    for name, (xs, ys, zs) in (("phase_c", (xc, yc, zc)), ("phase_yz", (xc, yv, zv)), ("phase_xz", (xv, yc, zv)), ("phase_xy", (xv, yv, zc))):
+        X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")                       # init_phases! :41-65, evaluated at the node itself
+        outside = ((X - o[0]) ** 2 + (Y - o[1]) ** 2 + (Z - o[2]) ** 2) > radius ** 2
+        arr[name][0] = np.where(outside, 1.0, 0.0)
+        arr[name][1] = np.where(outside, 0.0, 1.0)
+    arr["eta"][...] = np.where(arr["phase_c"][0] > 0.5, η0, η0 / 10)           # compute_viscosity!: linear viscous
+    arr["Vx"][...] = (xv * εbg)[:, None, None] * np.ones((1, ny + 2, nz + 2))   # :146-147
+    arr["Vz"][...] = (-zv * εbg)[None, None, :] * np.ones((nx + 2, ny + 2, 1))
+    _free_slip3d_host(arr)
+    pt = PTStokesCoeffs(li, di, ϵ_rel=1.0e-5, Re=3.0, r=0.7, CFL=0.9 / math.sqrt(3.1))
+    on = {f: True for f in _F6}
+    bcs = VelocityBoundaryConditions(free_slip=on, no_slip={f: False for f in _F6})
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=dt, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False, viscosity_cutoff=(-np.inf, np.inf)),
+                 extra=dict(li=li, di=di, phases=phases, εbg=εbg, G0=G0, η0=η0))
+
+
 def solvi3d_device(n, backend_tag, *, Δη=1.0e-3, li=(10.0, 10.0, 10.0), rc=1.0, εbg=1.0, update_halo=None):
     """SolVi3D built directly in device memory (for sizes whose host copy would not fit: 512³ needs
     ≈48 GB of fields).  Same construction as `solvi3d` (torch elementwise ops instead of numpy);

@@ -204,8 +204,8 @@ def vep_params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=50.0e3, iterMin=1.0e
 
 def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h):
     """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs) -- Stokes2D.jl:577-866"""
-    if len(stokes._ni) != 2:
-        raise NotImplementedError("3D multiphase VEP driver is not built (SURVEY §8f rank 1)")
+    if len(stokes._ni) == 3:
+        return _solve_vep3d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h)
     p = vep_params2d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
     f = vep_fields2d(stokes, ρg, phase_ratios)
     rh = rheology_table(rheology)
@@ -213,6 +213,56 @@ def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology,
     torch.cuda.current_stream(stokes.P.device).synchronize()
     h.call("jrx_stokes2d_vep_solve", C.byref(f), C.byref(rh), C.byref(p), C.byref(hist.c))
     return hist.result(2)
+
+
+def vep_fields3d(stokes, ρg, phase_ratios) -> _lib.VEP3DFields:
+    s = stokes
+    vals = dict(P=s.P, P0=s.P0, divV=s.divV, Q=s.Q, Vx=s.V.Vx, Vy=s.V.Vy, Vz=s.V.Vz, Ux=s.U.Ux, Uy=s.U.Uy, Uz=s.U.Uz,
+                eta=s.viscosity.η, eta_vep=s.viscosity.η_vep, EII_pl=s.EII_pl, evol_pl=s.ε_vol_pl, EVol_pl=s.EVol_pl,
+                fx=ρg[0], fy=ρg[1], fz=ρg[2], RP=s.R.RP, Rx=s.R.Rx, Ry=s.R.Ry, Rz=s.R.Rz,
+                omega_yz=s.ω.yz, omega_xz=s.ω.xz, omega_xy=s.ω.xy, tII=s.τ.II,
+                phase_c=phase_ratios.center, phase_yz=phase_ratios.yz, phase_xz=phase_ratios.xz, phase_xy=phase_ratios.xy)
+    for pre, T in (("e", s.ε), ("epl", s.ε_pl), ("t", s.τ), ("to", s.τ_o)):
+        for c in ("xx", "yy", "zz", "yz", "xz", "xy"):
+            vals[pre + c] = getattr(T, c)
+        for c in ("yz", "xz", "xy"):
+            vals[pre + c + "_c"] = getattr(T, c + "_c")
+    for c in ("yz", "xz", "xy"):
+        vals["de" + c], vals["de" + c + "_c"] = getattr(s.Δε, c), getattr(s.Δε, c + "_c")
+    f = _lib.VEP3DFields()
+    for n in _lib.VEP3_NAMES:
+        setattr(f, n, ptr(vals.get(n)))
+    f._keep = vals
+    return f
+
+
+def vep_params3d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10.0e3, nout=500, verbose=True, λ_relaxation=0.2, viscosity_relaxation=1.0e-2,
+                 viscosity_cutoff=(-float("inf"), float("inf")), b_width=(4, 4, 4), **_):
+    ni = stokes._ni
+    _di = _center_inv(grid)
+    p = _lib.VEP3DParams()
+    p.nx, p.ny, p.nz = ni
+    p.nxg, p.nyg, p.nzg = [(_ng(d) or ni[d]) for d in range(3)]
+    p._dx, p._dy, p._dz = _di
+    p.dt, p.r, p.theta_dtau, p.eta_dtau, p.eps_rel, p.eps_abs = float(dt), pt.r, pt.θ_dτ, pt.ηdτ, pt.ϵ_rel, pt.ϵ_abs
+    p.iterMax, p.nout = int(iterMax), int(nout)
+    if flow_bcs is not None:
+        p.free_slip, p.no_slip, p.periodic = (_lib.bcmask(flow_bcs.free_slip), _lib.bcmask(flow_bcs.no_slip), _lib.bcmask(flow_bcs.periodic))
+    p.lambda_relaxation, p.viscosity_relaxation = float(λ_relaxation), float(viscosity_relaxation)
+    p.cutoff_lo, p.cutoff_hi = float(viscosity_cutoff[0]), float(viscosity_cutoff[1])
+    p.verbose = int(bool(verbose))
+    return p
+
+
+def _solve_vep3d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h):
+    """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs) in 3D -- Stokes3D.jl:447-668"""
+    p = vep_params3d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
+    f = vep_fields3d(stokes, ρg, phase_ratios)
+    rh = rheology_table(rheology)
+    hist = _Hist(int(p.iterMax // p.nout + 2))
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    h.call("jrx_stokes3d_vep_solve", C.byref(f), C.byref(rh), C.byref(p), C.byref(hist.c))
+    return hist.result(3)
 
 
 def compute_τ_nonlinear_(stokes, θ, λ, rheology, dt, pt_stokes, *, phase_ratios=None, handle=None):
@@ -244,12 +294,14 @@ def center2vertex_(vertex, center, *, handle=None):
 
 
 def tensor_invariant_(A, *, handle=None):
-    """tensor_invariant!(A::SymmetricTensor) (2D) -- StressKernels.jl:443-470"""
+    """tensor_invariant!(A::SymmetricTensor) -- StressKernels.jl:443-487"""
     _require_gpu(A.xx)
-    if A.xx.dim() != 2:
-        raise NotImplementedError("3D tensor_invariant! is not built")
     h = handle or _lib.default_handle(A.xx.device.index)
     torch.cuda.current_stream(A.xx.device).synchronize()
+    if A.xx.dim() == 3:         # StressKernels.jl:472-487
+        h.call("jrx_tensor_invariant3d", *[C.c_void_p(ptr(getattr(A, k))) for k in ("II", "xx", "yy", "zz", "yz", "xz", "xy")],
+               *[C.c_int64(n) for n in A.xx.shape])
+        return
     h.call("jrx_tensor_invariant2d", C.c_void_p(ptr(A.II)), C.c_void_p(ptr(A.xx)), C.c_void_p(ptr(A.yy)), C.c_void_p(ptr(A.xy)),
            C.c_int64(A.xx.shape[0]), C.c_int64(A.xx.shape[1]))
 
@@ -259,6 +311,13 @@ def compute_viscosity_(stokes, phase_ratios, args, rheology, cutoff=(-float("inf
     _require_gpu(stokes)
     h = handle or _lib.default_handle(stokes.P.device.index)
     pt = SimpleNamespace(r=0.0, θ_dτ=1.0, ηdτ=1.0, ϵ_rel=0.0, ϵ_abs=0.0)
+    if len(stokes._ni) == 3:
+        fake = SimpleNamespace(_di=dict(center=(1.0, 1.0, 1.0)))
+        p = vep_params3d(stokes, pt, fake, None, 1.0, viscosity_cutoff=cutoff)
+        f = vep_fields3d(stokes, (stokes.P, stokes.P, stokes.P), phase_ratios)
+        torch.cuda.current_stream(stokes.P.device).synchronize()
+        h.call("jrx_vep3d_compute_viscosity", C.byref(f), C.byref(rheology_table(rheology)), C.byref(p), C.c_double(float(relaxation)))
+        return
     fake = SimpleNamespace(_di=dict(center=(1.0, 1.0)))
     p = vep_params2d(stokes, pt, fake, None, 1.0, viscosity_cutoff=cutoff)
     f = vep_fields2d(stokes, (stokes.P, stokes.P), phase_ratios)

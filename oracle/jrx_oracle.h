@@ -204,6 +204,43 @@ void orc_center2vertex2d(double *v, const double *c, int64_t nx, int64_t ny);
 void orc_tensor_invariant2d(double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny, int32_t mode);
 void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu);
 
+/* ---- 3D multiphase visco-elasto-plastic Stokes (Stokes3D.jl:447-668; test/test_shearband3D_MPI.jl) ---- */
+typedef struct orc_vep3d {
+    double *P, *P0, *divV, *Q;                          /* ni */
+    double *Vx, *Vy, *Vz, *Ux, *Uy, *Uz;
+    double *exx, *eyy, *ezz, *eyz, *exz, *exy;          /* strain rate: centres, then edges yz (nx,ny+1,nz+1), xz (nx+1,ny,nz+1), xy (nx+1,ny+1,nz) */
+    double *eyz_c, *exz_c, *exy_c;                      /* shear2center! targets (ni) */
+    double *eplxx, *eplyy, *eplzz, *eplyz, *eplxz, *eplxy, *eplyz_c, *eplxz_c, *eplxy_c;
+    double *deyz, *dexz, *dexy, *deyz_c, *dexz_c, *dexy_c;    /* Δε shear (may be NULL) */
+    double *txx, *tyy, *tzz, *tyz, *txz, *txy, *tyz_c, *txz_c, *txy_c, *tII;
+    double *toxx, *toyy, *tozz, *toyz, *toxz, *toxy, *toyz_c, *toxz_c, *toxy_c;
+    double *eta, *eta_vep;                              /* ni */
+    double *EII_pl, *evol_pl, *EVol_pl;                 /* ni */
+    double *fx, *fy, *fz;                               /* ρg */
+    double *RP, *Rx, *Ry, *Rz;
+    double *omega_yz, *omega_xz, *omega_xy;             /* edge extents */
+    double *phase_c, *phase_yz, *phase_xz, *phase_xy;   /* [nphase][extent], phase index fastest (CellArray) */
+} orc_vep3d;
+
+typedef struct orc_vep_params3d {
+    int64_t nx, ny, nz, nxg, nyg, nzg;
+    double _dx, _dy, _dz;
+    double dt, r, theta_dtau, eta_dtau, eps_rel, eps_abs;
+    int64_t iterMax, nout;
+    uint32_t free_slip, no_slip, periodic;
+    double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
+} orc_vep_params3d;
+
+int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, orc_result *res);
+void orc_vep3d_stress(const orc_vep3d *f, const double *theta, double *lam, double *const lamv[3], const orc_rheology *rh,
+                      const orc_vep_params3d *p);
+void orc_compute_viscosity3d(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, double nu);
+void orc_tensor_invariant3d(double *II, const double *xx, const double *yy, const double *zz, const double *yz, const double *xz, const double *xy,
+                            int64_t nx, int64_t ny, int64_t nz);
+void orc_shear2center3d(double *yz_c, double *xz_c, double *xy_c, const double *yz, const double *xz, const double *xy, int64_t nx, int64_t ny, int64_t nz);
+void orc_compute_vorticity3d(double *wyz, double *wxz, double *wxy, const double *Vx, const double *Vy, const double *Vz,
+                             int64_t nx, int64_t ny, int64_t nz, double _dx, double _dy, double _dz);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -428,3 +428,68 @@ def tensor_invariant2d(xx, yy, xy, mode=0):
 def compute_viscosity2d(arr, rh, p, nu=1.0):
     f = vep2d(arr)
     lib().orc_compute_viscosity2d(C.byref(f), C.byref(rh), C.byref(p), C.c_double(nu))
+
+
+# ---- 3D multiphase VEP (oracle/stokes3d_vep.c) ----
+VEP3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",
+              "exx", "eyy", "ezz", "eyz", "exz", "exy", "eyz_c", "exz_c", "exy_c",
+              "eplxx", "eplyy", "eplzz", "eplyz", "eplxz", "eplxy", "eplyz_c", "eplxz_c", "eplxy_c",
+              "deyz", "dexz", "dexy", "deyz_c", "dexz_c", "dexy_c",
+              "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII",
+              "toxx", "toyy", "tozz", "toyz", "toxz", "toxy", "toyz_c", "toxz_c", "toxy_c",
+              "eta", "eta_vep", "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "fz", "RP", "Rx", "Ry", "Rz",
+              "omega_yz", "omega_xz", "omega_xy", "phase_c", "phase_yz", "phase_xz", "phase_xy"]
+VEP3D = _mkstruct("VEP3D", VEP3_NAMES)
+
+
+class VEPParams3D(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64), ("nxg", C.c_int64), ("nyg", C.c_int64), ("nzg", C.c_int64),
+                ("_dx", C.c_double), ("_dy", C.c_double), ("_dz", C.c_double),
+                ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
+                ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
+                ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double)]
+
+
+def vep_shapes3d(nx, ny, nz, nphase):
+    c = (nx, ny, nz)
+    yz, xz, xy = (nx, ny + 1, nz + 1), (nx + 1, ny, nz + 1), (nx + 1, ny + 1, nz)
+    s = {n: c for n in VEP3_NAMES}
+    for pre in ("e", "epl", "de", "t", "to"):
+        s[pre + "yz"], s[pre + "xz"], s[pre + "xy"] = yz, xz, xy
+    s.update(Vx=(nx + 1, ny + 2, nz + 2), Vy=(nx + 2, ny + 1, nz + 2), Vz=(nx + 2, ny + 2, nz + 1),
+             Ux=(nx + 1, ny + 2, nz + 2), Uy=(nx + 2, ny + 1, nz + 2), Uz=(nx + 2, ny + 2, nz + 1),
+             Rx=(nx - 1, ny, nz), Ry=(nx, ny - 1, nz), Rz=(nx, ny, nz - 1), omega_yz=yz, omega_xz=xz, omega_xy=xy,
+             phase_c=(nphase,) + c, phase_yz=(nphase,) + yz, phase_xz=(nphase,) + xz, phase_xy=(nphase,) + xy)
+    return s
+
+
+def vep_params3d(ni, _di, dt, pt, *, iterMax=10_000, nout=500, free_slip=None, no_slip=None, periodic=None,
+                 lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), ni_g=None) -> VEPParams3D:
+    ni_g = ni_g or ni
+    return VEPParams3D(ni[0], ni[1], ni[2], ni_g[0], ni_g[1], ni_g[2], _di[0], _di[1], _di[2], dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"],
+                       pt["eps_rel"], pt["eps_abs"], int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic),
+                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1])
+
+
+def vep3d(arr: dict) -> VEP3D:
+    f = VEP3D()
+    for n in VEP3_NAMES:
+        setattr(f, n, _p(arr.get(n)))
+    return f
+
+
+def stokes3d_vep_solve(arr: dict, rh: Rheology, p: VEPParams3D) -> dict:
+    res = _Res(int(p.iterMax // p.nout + 2))
+    f = vep3d(arr)
+    L = lib()
+    L.orc_stokes3d_vep_solve.restype = C.c_int32
+    L.orc_stokes3d_vep_solve(C.byref(f), C.byref(rh), C.byref(p), C.byref(res.c))
+    return res.asdict(3)
+
+
+def vep3d_stress(arr: dict, theta, lam, lamv, rh: Rheology, p: VEPParams3D):
+    """update_stresses_center_vertex_ps! 3D; lamv = (λv_yz, λv_xz, λv_xy)"""
+    f = vep3d(arr)
+    lv = (_dp * 3)(*[_p(a) for a in lamv])
+    lib().orc_vep3d_stress(C.byref(f), _p(theta), _p(lam), lv, C.byref(rh), C.byref(p))

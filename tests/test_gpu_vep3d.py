@@ -1,0 +1,152 @@
+"""GPU parity tests, 3D multiphase visco-elasto-plastic Stokes (Stokes3D.jl:447-668) vs the CPU oracle.
+Tolerance 1e-12 of each field's max for one kernel call (observed: bit-identical), 1e-9 after tens of PT iterations."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_T = {"e": "ε", "epl": "ε_pl", "de": "Δε", "t": "τ", "to": "τ_o"}
+VEP3_MAP = dict(P="P", P0="P0", divV="divV", Q="Q", Vx="V.Vx", Vy="V.Vy", Vz="V.Vz", Ux="U.Ux", Uy="U.Uy", Uz="U.Uz", tII="τ.II",
+                eta="viscosity.η", eta_vep="viscosity.η_vep", EII_pl="EII_pl", evol_pl="ε_vol_pl", EVol_pl="EVol_pl",
+                RP="R.RP", Rx="R.Rx", Ry="R.Ry", Rz="R.Rz", omega_yz="ω.yz", omega_xz="ω.xz", omega_xy="ω.xy")
+for _pre, _t in _T.items():
+    for _c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):
+        if _pre == "de" and _c in ("xx", "yy", "zz"):
+            continue
+        VEP3_MAP[_pre + _c] = f"{_t}.{_c}"
+
+
+def _get(o, path):
+    for p in path.split("."):
+        o = getattr(o, p)
+    return o
+
+
+def _upload(jr, s):
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+    for k, path in VEP3_MAP.items():
+        _get(st, path).copy_(from_numpy(s.arrays[k], dev))
+    pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, s.ni)
+    for k, name in (("phase_c", "center"), ("phase_yz", "yz"), ("phase_xz", "xz"), ("phase_xy", "xy")):
+        getattr(pr, name).copy_(from_numpy(s.arrays[k], dev))
+    ρg = tuple(from_numpy(s.arrays[k], dev) for k in ("fx", "fy", "fz"))
+    return st, pr, ρg
+
+
+def _download(jr, st):
+    return {k: jr.to_numpy(_get(st, path)) for k, path in VEP3_MAP.items()}
+
+
+def _params(orc, s, **over):
+    pt, b = s.pt, s.flow_bcs
+    kw = dict(iterMax=s.kwargs["iterMax"], nout=s.kwargs["nout"])
+    kw.update(over)
+    return orc.vep_params3d(s.ni, s.grid._di["center"], s.dt, dict(r=pt.r, theta_dtau=pt.θ_dτ, eta_dtau=pt.ηdτ, eps_rel=pt.ϵ_rel, eps_abs=pt.ϵ_abs),
+                            free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic, **kw)
+
+
+def _randomize(s, seed=4, Kb=3.0, psi=6.0):
+    rng = np.random.default_rng(seed)
+    a = s.arrays
+    for pre in ("e", "t", "to"):
+        for c in ("xx", "yy", "zz", "yz", "xz", "xy"):
+            a[pre + c][...] = rng.uniform(-2.0, 2.0, size=a[pre + c].shape)
+    for k in ("P", "tyz_c", "txz_c", "txy_c", "toyz_c", "toxz_c", "toxy_c"):
+        a[k][...] = rng.uniform(-2.0, 2.0, size=a[k].shape)
+    a["eta"][...] = 10.0 ** rng.uniform(-1.0, 0.5, size=a["eta"].shape)
+    for k in ("phase_c", "phase_yz", "phase_xz", "phase_xy"):
+        r = rng.uniform(0.0, 1.0, size=a[k].shape[1:])
+        r[rng.uniform(size=r.shape) < 0.3] = 0.0
+        r[rng.uniform(size=r.shape) < 0.3] = 1.0
+        a[k][0], a[k][1] = r, 1.0 - r
+    return [dict(ph, Kb=Kb, psi_deg=psi) for ph in s.extra["phases"]]
+
+
+@pytest.mark.parametrize("ni", [(13, 9, 7), (70, 5, 6)])
+def test_update_stresses_3d_matches_oracle(jr, oracle, ni):
+    """update_stresses_center_vertex_ps! 3D (StressKernels.jl:671-989) on random states: yielding and elastic nodes, mixed
+    phase ratios, dilatant plasticity with finite bulk modulus"""
+    from justrelax_jl_amd import _lib, stokes as st_mod
+    from justrelax_jl_amd.arrays import from_numpy
+    from justrelax_jl_amd.checks import max_rel_diff
+    s = jr.miniapps.shearband3d(ni)
+    phases = _randomize(s)
+    rh = oracle.rheology_struct(phases)
+    p = _params(oracle, s)
+    ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    rng = np.random.default_rng(9)
+    theta = np.asfortranarray(rng.uniform(-1, 1, size=s.ni))
+    lam = np.asfortranarray(rng.uniform(0, 0.1, size=s.ni))
+    lamv = [np.asfortranarray(rng.uniform(0, 0.1, size=s.arrays[k].shape)) for k in ("tyz", "txz", "txy")]
+    lam_r, lamv_r = lam.copy(order="F"), [x.copy(order="F") for x in lamv]
+    oracle.vep3d_stress(ref, theta, lam_r, lamv_r, rh, p)
+    stokes, pr, ρg = _upload(jr, s)
+    dev = stokes.P.device
+    th_d, lam_d = from_numpy(theta, dev), from_numpy(lam, dev)
+    lamv_d = [from_numpy(x, dev) for x in lamv]
+    h = _lib.default_handle()
+    fd = st_mod.vep_fields3d(stokes, ρg, pr)
+    pd = st_mod.vep_params3d(stokes, s.pt, s.grid, s.flow_bcs, s.dt)
+    lv = (C.c_void_p * 3)(*[x.data_ptr() for x in lamv_d])
+    h.call("jrx_vep3d_update_stresses", C.byref(fd), C.c_void_p(th_d.data_ptr()), C.c_void_p(lam_d.data_ptr()), lv,
+           C.byref(st_mod.rheology_table(phases)), C.byref(pd))
+    out = _download(jr, stokes)
+    assert (lam_r != lam).any() and (lam_r == lam).any() and (ref["eplxz"] != 0).any() and (ref["eplxz"] == 0).any()
+    for k in ("txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII", "eta_vep", "P", "eplxx", "eplyy", "eplzz", "eplyz", "eplxz",
+              "eplxy", "evol_pl"):
+        assert max_rel_diff(out[k], ref[k]) <= 1e-12, k
+    assert max_rel_diff(jr.to_numpy(lam_d), lam_r) <= 1e-12
+    for a, b in zip(lamv_d, lamv_r):
+        assert max_rel_diff(jr.to_numpy(a), b) <= 1e-12
+
+
+def test_vep3d_solve_matches_oracle_over_iterations(jr, oracle):
+    """the whole driver (pressure with phase ratios, viscosity relaxation, stress kernel, velocity sweep, BCs, norms, epilogue)
+    for a fixed number of iterations on a yielding state"""
+    from justrelax_jl_amd.checks import max_rel_diff
+    s = jr.miniapps.shearband3d((20, 12, 10), iterMax=39, nout=10)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    rng = np.random.default_rng(3)
+    for c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):     # pre-stress close to yield so that plasticity is active
+        s.arrays["to" + c][...] = rng.uniform(-1.5, 1.5, size=s.arrays["to" + c].shape)
+        s.arrays["t" + c][...] = s.arrays["to" + c]
+    s.arrays["EII_pl"][...] = rng.uniform(0, 0.1, size=s.ni)
+    ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    r_ref = oracle.stokes3d_vep_solve(ref, oracle.rheology_struct(s.extra["phases"]), _params(oracle, s))
+    stokes, pr, ρg = _upload(jr, s)
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=s.kwargs)
+    out = _download(jr, stokes)
+    assert r.iter == r_ref["iter"] == 40
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-9) and np.allclose(r.norm_Rz, r_ref["norm_Rz"], rtol=1e-9)
+    assert (ref["eplxx"] != 0).any()
+    from justrelax_jl_amd.checks import interior_mask3d
+    for k in ("P", "P0", "Vx", "Vy", "Vz", "Ux", "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "tII", "eta", "eta_vep", "exx", "exz", "eplzz",
+              "eplxy", "EII_pl", "EVol_pl", "Rx", "Rz", "RP", "toxx", "toxz", "toxy_c", "omega_yz", "omega_xz", "omega_xy", "exz_c", "eplyz_c"):
+        m = interior_mask3d(k, ref[k].shape)
+        scale = max(np.abs(ref[k]).max(), 1e-300)
+        assert np.abs(out[k] - ref[k])[m].max() <= 1e-9 * scale, k
+
+
+def test_tensor_invariant_and_viscosity_3d(jr, oracle):
+    import torch
+    from justrelax_jl_amd import stokes as st_mod
+    from justrelax_jl_amd.checks import max_rel_diff
+    s = jr.miniapps.shearband3d((9, 8, 7))
+    phases = _randomize(s, seed=7)
+    stokes, pr, ρg = _upload(jr, s)
+    st_mod.tensor_invariant_(stokes.τ)
+    want = np.zeros(s.ni, order="F")
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    a = s.arrays
+    oracle.lib().orc_tensor_invariant3d(dp(want), *[dp(a[k]) for k in ("txx", "tyy", "tzz", "tyz", "txz", "txy")], *[C.c_int64(n) for n in s.ni])
+    assert max_rel_diff(jr.to_numpy(stokes.τ.II), want) <= 1e-14
+    st_mod.compute_viscosity_(stokes, pr, None, phases, relaxation=0.3)
+    ref = {k: v.copy(order="F") for k, v in a.items()}
+    f = oracle.vep3d(ref)
+    oracle.lib().orc_compute_viscosity3d(C.byref(f), C.byref(oracle.rheology_struct(phases)), C.byref(_params(oracle, s)), C.c_double(0.3))
+    assert max_rel_diff(jr.to_numpy(stokes.viscosity.η), ref["eta"]) <= 1e-14
