@@ -351,6 +351,41 @@ jrx_status jrx_thermal2d_iteration(jrx_handle *h, const jrx_thermal2d_fields *t,
 /* check_res! (DiffusionPT_kernels.jl:603-668) */
 jrx_status jrx_thermal2d_check_res(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p);
 
+/* ------------------------------------------------------------------ 3D PT heat diffusion
+ * heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, K, ρCp | rheology, args, dt, grid; kwargs) for 3D grids --
+ * src/thermal_diffusion/DiffusionPT_solver.jl:34-149,181-305 with the 3D kernels DiffusionPT_kernels.jl:6-61,160-199,250-282.
+ * Faces in the order left, right, front, back, top, bot; 3D thermal naming: bot <-> k = 1, top <-> k = end
+ * (constant_value.jl:15-33) -- the opposite of the 3D velocity free-slip naming. */
+typedef struct jrx_thermal3d_fields {
+    double *T, *Told, *dT;                 /* (nx+2, ny+2, nz+2): thermal.T, Told, ΔT */
+    double *qTx, *qTx2;                    /* (nx+1, ny, nz) */
+    double *qTy, *qTy2;                    /* (nx, ny+1, nz) */
+    double *qTz, *qTz2;                    /* (nx, ny, nz+1) */
+    double *H, *shear_heating, *ResT;      /* ni */
+    const double *K, *rhoCp;               /* ni: array-coefficient form; NULL in the rheology form */
+    const double *thetar_dtau, *dtau_rho;  /* ni: PTThermalCoeffs */
+} jrx_thermal3d_fields;
+
+typedef struct jrx_thermal3d_params {
+    int64_t nx, ny, nz;
+    double _dx, _dy, _dz;
+    double dt, eps;
+    int64_t iterMax, nout;
+    int32_t no_flux[6];
+    int32_t constant_value_on[6]; double constant_value[6];
+    int32_t constant_flux_on[6];  double constant_flux[6];
+    int32_t periodic[6];
+    int32_t rheology_form;                 /* 1: k_const, Cp, PT_Density(rho0, alpha, T0) as in test/test_diffusion3D.jl */
+    double k_const, Cp, rho0, alpha, T0;
+    int32_t verbose;
+} jrx_thermal3d_params;
+
+jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, int64_t *iter_count, double *norm_ResT,
+                                  int64_t cap, int64_t *nnorms);
+jrx_status jrx_thermal_bcs3d(jrx_handle *h, double *T, const jrx_thermal3d_params *p);
+jrx_status jrx_thermal3d_iteration(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p);
+jrx_status jrx_thermal3d_check_res(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p);
+
 /* ------------------------------------------------------------------ timing hooks for bench.py */
 /* Runs `iters` PT iterations of the 3D loop body back to back (no norm checks) and reports device times
  * measured with hipEvents on the handle's stream inside that batch:

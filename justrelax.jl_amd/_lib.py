@@ -68,6 +68,21 @@ class Thermal2DParams(C.Structure):
                 ("T0", C.c_double), ("verbose", C.c_int32)]
 
 
+T3_NAMES = ["T", "Told", "dT", "qTx", "qTx2", "qTy", "qTy2", "qTz", "qTz2", "H", "shear_heating", "ResT", "K", "rhoCp", "thetar_dtau", "dtau_rho"]
+Thermal3DFields = _ptr_struct("Thermal3DFields", T3_NAMES)
+
+
+class Thermal3DParams(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64), ("_dx", C.c_double), ("_dy", C.c_double), ("_dz", C.c_double),
+                ("dt", C.c_double), ("eps", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("no_flux", C.c_int32 * 6),
+                ("constant_value_on", C.c_int32 * 6), ("constant_value", C.c_double * 6),
+                ("constant_flux_on", C.c_int32 * 6), ("constant_flux", C.c_double * 6),
+                ("periodic", C.c_int32 * 6), ("rheology_form", C.c_int32),
+                ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double), ("T0", C.c_double),
+                ("verbose", C.c_int32)]
+
+
 VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
              "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
              "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v"]

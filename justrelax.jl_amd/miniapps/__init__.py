@@ -8,3 +8,4 @@ from .common import Setup, upload_stokes, download_stokes  # noqa: F401
 from .stokes3d import solvi3d, taylor_green3d, random_fields3d, shearband3d, vep_shapes3d  # noqa: F401
 from .stokes2d import solcx2d, solkz2d, elastic_buildup2d, random_fields2d, shearband2d  # noqa: F401
 from .thermal2d import diffusion2d  # noqa: F401
+from .thermal3d import diffusion3d  # noqa: F401

@@ -19,12 +19,22 @@ from .stokes import _require_gpu
 _ORDER = ("left", "right", "top", "bot")
 
 
+_ORDER3 = ("left", "right", "front", "back", "top", "bot")
+
+
 def thermal_params2d(ni, grid, thermal_bc, dt, ϵ, *, iterMax=50_000, nout=1000, verbose=True, rheology=None, **_):
+    """jrx_thermal2d_params / jrx_thermal3d_params (by len(ni)) from the reference's keyword arguments"""
     _di = grid._di["center"]
-    p = _lib.Thermal2DParams()
-    p.nx, p.ny, p._dx, p._dy, p.dt, p.eps = ni[0], ni[1], _di[0], _di[1], float(dt), float(ϵ)
+    if len(ni) == 3:
+        p = _lib.Thermal3DParams()
+        p.nx, p.ny, p.nz, p._dx, p._dy, p._dz, p.dt, p.eps = ni[0], ni[1], ni[2], _di[0], _di[1], _di[2], float(dt), float(ϵ)
+        order = _ORDER3
+    else:
+        p = _lib.Thermal2DParams()
+        p.nx, p.ny, p._dx, p._dy, p.dt, p.eps = ni[0], ni[1], _di[0], _di[1], float(dt), float(ϵ)
+        order = _ORDER
     p.iterMax, p.nout, p.verbose = int(iterMax), int(nout), int(bool(verbose))
-    for i, k in enumerate(_ORDER):
+    for i, k in enumerate(order):
         p.no_flux[i] = int(bool(thermal_bc.no_flux.get(k, False)))
         p.periodic[i] = int(bool(thermal_bc.periodic.get(k, False)))
         v = thermal_bc.constant_value.get(k, False)
@@ -42,11 +52,15 @@ def thermal_params2d(ni, grid, thermal_bc, dt, ϵ, *, iterMax=50_000, nout=1000,
 
 
 def thermal_fields2d(thermal, pt_thermal, K=None, ρCp=None):
-    f = _lib.Thermal2DFields()
+    """jrx_thermal2d_fields / jrx_thermal3d_fields (by the dimension of `thermal`)"""
+    three = len(thermal._ni) == 3
+    f = _lib.Thermal3DFields() if three else _lib.Thermal2DFields()
     vals = dict(T=thermal.T, Told=thermal.Told, dT=thermal.ΔT, qTx=thermal.qTx, qTx2=thermal.qTx2, qTy=thermal.qTy,
                 qTy2=thermal.qTy2, H=thermal.H, shear_heating=thermal.shear_heating, ResT=thermal.ResT, K=K, rhoCp=ρCp,
                 thetar_dtau=pt_thermal.θr_dτ, dtau_rho=pt_thermal.dτ_ρ)
-    for n in _lib.T2_NAMES:
+    if three:
+        vals.update(qTz=thermal.qTz, qTz2=thermal.qTz2)
+    for n in (_lib.T3_NAMES if three else _lib.T2_NAMES):
         setattr(f, n, ptr(vals.get(n)))
     f._keep = vals
     return f
@@ -62,8 +76,6 @@ def heatdiffusion_PT_(thermal, pt_thermal, thermal_bc, A, B, dt, grid_or_di, *, 
     _require_gpu(thermal)
     kw = dict(kwargs or {})
     ni = thermal._ni
-    if len(ni) != 2:
-        raise NotImplementedError("3D heatdiffusion_PT! is not part of this round (SURVEY §8f rank 3)")
     grid = grid_or_di if isinstance(grid_or_di, Geometry) else legacy_uniform_grid(ni, grid_or_di)
     h = handle or _lib.default_handle(thermal.T.device.index)
     if isinstance(A, dict):
@@ -75,7 +87,7 @@ def heatdiffusion_PT_(thermal, pt_thermal, thermal_bc, A, B, dt, grid_or_di, *, 
     cap = int(p.iterMax // p.nout + 2)
     it, nr, nn = np.zeros(cap, dtype=np.int64), np.zeros(cap), C.c_int64(0)
     torch.cuda.current_stream(thermal.T.device).synchronize()
-    h.call("jrx_heatdiffusion_PT2d", C.byref(f), C.byref(p), it.ctypes.data_as(C.POINTER(C.c_int64)),
+    h.call("jrx_heatdiffusion_PT3d" if len(ni) == 3 else "jrx_heatdiffusion_PT2d", C.byref(f), C.byref(p), it.ctypes.data_as(C.POINTER(C.c_int64)),
            nr.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(cap), C.byref(nn))
     return SimpleNamespace(iter_count=it[: nn.value].copy(), norm_ResT=nr[: nn.value].copy())
 
@@ -84,14 +96,12 @@ def thermal_bcs_(thermal_or_T, thermal_bc, *, handle=None):
     """thermal_bcs!(thermal, bcs) -- BoundaryConditions.jl:39-53"""
     T = thermal_or_T.T if hasattr(thermal_or_T, "Told") else thermal_or_T
     _require_gpu(T)
-    if T.dim() != 2:
-        raise NotImplementedError("3D thermal_bcs! is not part of this round")
     h = handle or _lib.default_handle(T.device.index)
-    ni = (T.shape[0] - 2, T.shape[1] - 2)
-    fake = SimpleNamespace(_di=dict(center=(1.0, 1.0)))
+    ni = tuple(n - 2 for n in T.shape)
+    fake = SimpleNamespace(_di=dict(center=(1.0,) * T.dim()))
     p = thermal_params2d(ni, fake, thermal_bc, 1.0, 0.0)
     torch.cuda.current_stream(T.device).synchronize()
-    h.call("jrx_thermal_bcs2d", C.c_void_p(ptr(T)), C.byref(p))
+    h.call("jrx_thermal_bcs3d" if T.dim() == 3 else "jrx_thermal_bcs2d", C.c_void_p(ptr(T)), C.byref(p))
 
 
 def thermal_iteration_(thermal, pt_thermal, thermal_bc, A, B, dt, grid, *, check_res=False, handle=None):
@@ -106,6 +116,7 @@ def thermal_iteration_(thermal, pt_thermal, thermal_bc, A, B, dt, grid, *, check
         p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ)
         f = thermal_fields2d(thermal, pt_thermal, A, B)
     torch.cuda.current_stream(thermal.T.device).synchronize()
-    h.call("jrx_thermal2d_iteration", C.byref(f), C.byref(p))
+    d = "3d" if len(ni) == 3 else "2d"
+    h.call(f"jrx_thermal{d}_iteration", C.byref(f), C.byref(p))
     if check_res:
-        h.call("jrx_thermal2d_check_res", C.byref(f), C.byref(p))
+        h.call(f"jrx_thermal{d}_check_res", C.byref(f), C.byref(p))

@@ -156,6 +156,37 @@ void orc_thermal2d_check_res(const orc_thermal2d *t, const orc_thermal_params2d 
 int32_t orc_heatdiffusion_PT2d(const orc_thermal2d *t, const orc_thermal_params2d *p,
                                int64_t *iter_out, double *norm_ResT, int64_t cap, int64_t *nnorms);
 
+/* ---- 3D PT heat diffusion (DiffusionPT_kernels.jl:6-61,160-199,250-282; test/test_diffusion3D.jl) ---- */
+typedef struct orc_thermal3d {
+    double *T, *Told, *dT;              /* (nx+2, ny+2, nz+2) */
+    double *qTx, *qTx2;                 /* (nx+1, ny, nz) */
+    double *qTy, *qTy2;                 /* (nx, ny+1, nz) */
+    double *qTz, *qTz2;                 /* (nx, ny, nz+1) */
+    double *H, *shear_heating, *ResT;   /* ni */
+    double *K, *rhoCp;                  /* ni; may be NULL in the rheology form */
+    double *thetar_dtau, *dtau_rho;     /* ni */
+} orc_thermal3d;
+
+typedef struct orc_thermal_params3d {
+    int64_t nx, ny, nz;
+    double _dx, _dy, _dz;
+    double dt, eps;
+    int64_t iterMax, nout;
+    /* faces in order left,right,front,back,top,bot ; 3D thermal naming: bot <-> k = 1, top <-> k = end */
+    int32_t no_flux[6];
+    int32_t constant_value_on[6]; double constant_value[6];
+    int32_t constant_flux_on[6];  double constant_flux[6];
+    int32_t periodic[6];
+    int32_t rheology_form;
+    double k_const, Cp, rho0, alpha, T0;
+} orc_thermal_params3d;
+
+void orc_thermal_bcs3d(double *T, const orc_thermal_params3d *p);
+void orc_thermal3d_iteration(const orc_thermal3d *t, const orc_thermal_params3d *p);
+void orc_thermal3d_check_res(const orc_thermal3d *t, const orc_thermal_params3d *p);
+int32_t orc_heatdiffusion_PT3d(const orc_thermal3d *t, const orc_thermal_params3d *p, int64_t *iter_out, double *norm_ResT, int64_t cap,
+                               int64_t *nnorms);
+
 /* ---- 2D multiphase visco-elasto-plastic Stokes (Stokes2D.jl:577-866; BASELINE config 5: shear band) ----
  * Restricted to what test/test_shearband2D.jl evaluates: per-phase LinearViscous eta, ConstantElasticity (G, Kb),
  * DruckerPrager_regularised (C, phi, psi, eta_vp), constant density (rho*g given as arrays).  GeoParams is not

@@ -493,3 +493,76 @@ def vep3d_stress(arr: dict, theta, lam, lamv, rh: Rheology, p: VEPParams3D):
     f = vep3d(arr)
     lv = (_dp * 3)(*[_p(a) for a in lamv])
     lib().orc_vep3d_stress(C.byref(f), _p(theta), _p(lam), lv, C.byref(rh), C.byref(p))
+
+
+# ---- 3D PT heat diffusion (oracle/thermal3d.c) ----
+T3_NAMES = ["T", "Told", "dT", "qTx", "qTx2", "qTy", "qTy2", "qTz", "qTz2", "H", "shear_heating", "ResT", "K", "rhoCp", "thetar_dtau", "dtau_rho"]
+Thermal3D = _mkstruct("Thermal3D", T3_NAMES)
+THERMAL_FACES3 = ("left", "right", "front", "back", "top", "bot")
+
+
+class ThermalParams3D(C.Structure):
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nz", C.c_int64), ("_dx", C.c_double), ("_dy", C.c_double), ("_dz", C.c_double),
+                ("dt", C.c_double), ("eps", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
+                ("no_flux", C.c_int32 * 6),
+                ("constant_value_on", C.c_int32 * 6), ("constant_value", C.c_double * 6),
+                ("constant_flux_on", C.c_int32 * 6), ("constant_flux", C.c_double * 6),
+                ("periodic", C.c_int32 * 6),
+                ("rheology_form", C.c_int32),
+                ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double), ("T0", C.c_double)]
+
+
+def thermal_shapes3d(nx, ny, nz):
+    c, g = (nx, ny, nz), (nx + 2, ny + 2, nz + 2)
+    s = {k: c for k in ("H", "shear_heating", "ResT", "K", "rhoCp", "thetar_dtau", "dtau_rho")}
+    s.update(T=g, Told=g, dT=g, qTx=(nx + 1, ny, nz), qTx2=(nx + 1, ny, nz), qTy=(nx, ny + 1, nz), qTy2=(nx, ny + 1, nz),
+             qTz=(nx, ny, nz + 1), qTz2=(nx, ny, nz + 1))
+    return s
+
+
+def thermal_params3d(ni, _di, dt, eps, *, iterMax=50_000, nout=1000, no_flux=None, constant_value=None, constant_flux=None, periodic=None,
+                     rheology=None) -> ThermalParams3D:
+    """BC dicts use the reference's 3D face names left/right/front/back/top/bot; False/None disables; `True` in constant_value
+    counts as the number 1 exactly as `2 * bc.left - T` does in the reference."""
+    p = ThermalParams3D()
+    p.nx, p.ny, p.nz, p._dx, p._dy, p._dz = ni[0], ni[1], ni[2], _di[0], _di[1], _di[2]
+    p.dt, p.eps, p.iterMax, p.nout = dt, eps, int(iterMax), int(nout)
+    for i, k in enumerate(THERMAL_FACES3):
+        p.no_flux[i] = int(bool((no_flux or {}).get(k, False)))
+        p.periodic[i] = int(bool((periodic or {}).get(k, False)))
+        v = (constant_value or {}).get(k, False)
+        p.constant_value_on[i] = int(v is not False and v is not None)
+        p.constant_value[i] = float(v) if p.constant_value_on[i] else 0.0
+        v = (constant_flux or {}).get(k, False)
+        on = not isinstance(v, bool) and v is not None
+        p.constant_flux_on[i] = int(on)
+        p.constant_flux[i] = float(v) if on else 0.0
+    if rheology:
+        p.rheology_form = 1
+        p.k_const, p.Cp, p.rho0, p.alpha, p.T0 = (rheology["k"], rheology["Cp"], rheology["rho0"], rheology["alpha"], rheology.get("T0", 0.0))
+    return p
+
+
+def thermal3d(arr: dict) -> Thermal3D:
+    f = Thermal3D()
+    for n in T3_NAMES:
+        setattr(f, n, _p(arr.get(n)))
+    return f
+
+
+def heatdiffusion_PT3d(arr: dict, p: ThermalParams3D) -> dict:
+    cap = int(p.iterMax // p.nout + 2)
+    it, nr, nn = np.zeros(cap, dtype=np.int64), np.zeros(cap), C.c_int64(0)
+    t = thermal3d(arr)
+    lib().orc_heatdiffusion_PT3d(C.byref(t), C.byref(p), it.ctypes.data_as(C.POINTER(C.c_int64)), _p(nr), C.c_int64(cap), C.byref(nn))
+    return dict(iter_count=it[:nn.value].copy(), norm_ResT=nr[:nn.value].copy())
+
+
+def thermal3d_iteration(arr: dict, p: ThermalParams3D):
+    t = thermal3d(arr)
+    lib().orc_thermal3d_iteration(C.byref(t), C.byref(p))
+
+
+def thermal3d_check_res(arr: dict, p: ThermalParams3D):
+    t = thermal3d(arr)
+    lib().orc_thermal3d_check_res(C.byref(t), C.byref(p))
