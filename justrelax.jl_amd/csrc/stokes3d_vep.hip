@@ -28,6 +28,13 @@ struct Vep3Args {
     int nx, ny, nz;
 };
 
+// node (i, j, k) of an (n1, n2, n3) box: xy flattened over blockIdx.x (no nearly empty blocks when n1 = nx + 1), k = blockIdx.y
+#define NODE_IJK(n1_, n2_)                                              \
+    const int t_ = blockIdx.x * blockDim.x + threadIdx.x;               \
+    const int j = t_ / (n1_), i = t_ - j * (n1_), k = blockIdx.y;       \
+    if (j >= (n2_)) return;
+#define GRID_IJK(n1_, n2_, n3_) dim3((unsigned)(((i64)(n1_) * (n2_) + 255) / 256), (unsigned)(n3_))
+
 __device__ __forceinline__ int clampi3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ double sinv3(const double t[6])
 {
@@ -82,8 +89,7 @@ __device__ __forceinline__ void plastic_grad3(const jrx_rheology &rh, const doub
 __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i > nx) return;
+    NODE_IJK(nx + 1, ny + 1)
     const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
     const double _dx = a._dx, _dy = a._dy, _dz = a._dz;
 #define VX(i_, j_, k_) Vx[(i_) + (i64)(nx + 1) * ((j_) + (i64)(ny + 2) * (k_))]
@@ -159,8 +165,8 @@ __global__ __launch_bounds__(256) void k_vep3_edge(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
     const int n1 = nx + (T != 0), n2 = ny + (T != 1), n3 = nz + (T != 2);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= n1 || j >= n2 || k >= n3) return;
+    NODE_IJK(n1, n2)
+    if (k >= n3) return;
     const int ci[3] = {clampi3(i - 1, 0, nx - 1), clampi3(i, 0, nx - 1), clampi3(i + 1, 0, nx - 1)};
     const int cj[3] = {clampi3(j - 1, 0, ny - 1), clampi3(j, 0, ny - 1), clampi3(j + 1, 0, ny - 1)};
     const int ck[3] = {clampi3(k - 1, 0, nz - 1), clampi3(k, 0, nz - 1), clampi3(k + 1, 0, nz - 1)};
@@ -225,8 +231,8 @@ __global__ __launch_bounds__(256) void k_vep3_edge(const Vep3Args a)
 __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= nx || j >= ny || k >= nz) return;
+    NODE_IJK(nx, ny)
+    if (k >= nz) return;
     const i64 c = i + (i64)nx * (j + (i64)ny * k);
     const double *rc = a.f.phase_c + (i64)np * c;
     const double _Gdt = 1.0 / (ratio_avg3(a.rh.G, rc, np) * a.dt);
@@ -302,8 +308,7 @@ __device__ __forceinline__ double sinv_stag3(const double *xx, const double *yy,
 __global__ __launch_bounds__(256) void k_tensor_invariant3d(double *__restrict__ II, const double *xx, const double *yy, const double *zz,
                                                             const double *yz, const double *xz, const double *xy, int nx, int ny, int nz)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= nx) return;
+    NODE_IJK(nx, ny)
     II[i + (i64)nx * (j + (i64)ny * k)] = sinv_stag3(xx, yy, zz, yz, xz, xy, nx, ny, i, j, k);
 }
 
@@ -311,8 +316,7 @@ __global__ __launch_bounds__(256) void k_tensor_invariant3d(double *__restrict__
 __global__ __launch_bounds__(256) void k_shear2center3d(double *__restrict__ yz_c, double *__restrict__ xz_c, double *__restrict__ xy_c,
                                                         const double *yz, const double *xz, const double *xy, int nx, int ny, int nz)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= nx) return;
+    NODE_IJK(nx, ny)
     const i64 c = i + (i64)nx * (j + (i64)ny * k);
     yz_c[c] = 0.25 * (EYZ(yz, i, j, k) + EYZ(yz, i, j + 1, k) + EYZ(yz, i, j, k + 1) + EYZ(yz, i, j + 1, k + 1));
     xz_c[c] = 0.25 * (EXZ(xz, i, j, k) + EXZ(xz, i + 1, j, k) + EXZ(xz, i, j, k + 1) + EXZ(xz, i + 1, j, k + 1));
@@ -323,8 +327,7 @@ __global__ __launch_bounds__(256) void k_shear2center3d(double *__restrict__ yz_
 __global__ __launch_bounds__(256) void k_vorticity3d(double *__restrict__ wyz, double *__restrict__ wxz, double *__restrict__ wxy, const double *Vx,
                                                      const double *Vy, const double *Vz, int nx, int ny, int nz, double _dx, double _dy, double _dz)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i > nx) return;
+    NODE_IJK(nx + 1, ny + 1)
     if (i < nx) EYZ(wyz, i, j, k) = 0.5 * ((-VZ(i, j, k) + VZ(i, j + 1, k)) * _dy - (-VY(i, j, k) + VY(i, j, k + 1)) * _dz);
     if (j < ny) EXZ(wxz, i, j, k) = 0.5 * ((-VX(i, j, k) + VX(i, j, k + 1)) * _dz - (-VZ(i, j, k) + VZ(i + 1, j, k)) * _dx);
     if (k < nz) EXY(wxy, i, j, k) = 0.5 * ((-VY(i, j, k) + VY(i + 1, j, k)) * _dx - (-VX(i, j, k) + VX(i, j + 1, k)) * _dy);
@@ -334,8 +337,7 @@ __global__ __launch_bounds__(256) void k_vorticity3d(double *__restrict__ wyz, d
 __global__ __launch_bounds__(256) void k_vep3_accumulate(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= nx) return;
+    NODE_IJK(nx, ny)
     const i64 c = i + (i64)nx * (j + (i64)ny * k);
     a.f.EII_pl[c] += sinv_stag3(a.f.eplxx, a.f.eplyy, a.f.eplzz, a.f.eplyz, a.f.eplxz, a.f.eplxy, nx, ny, i, j, k) * a.dt;
     a.f.EVol_pl[c] += a.dt * a.f.evol_pl[c];
@@ -383,17 +385,16 @@ EdgeN edge_counts(const jrx_vep3d_params *p)
 jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    const unsigned gx1 = (unsigned)((nx + 1 + 255) / 256), gx0 = (unsigned)((nx + 255) / 256);
-    hipLaunchKernelGGL(k_vep3_edge<0>, dim3(gx0, ny + 1, nz + 1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_vep3_edge<1>, dim3(gx1, ny, nz + 1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_vep3_edge<2>, dim3(gx1, ny + 1, nz), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_vep3_edge<0>, GRID_IJK(nx, ny + 1, nz + 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_vep3_edge<1>, GRID_IJK(nx + 1, ny, nz + 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_vep3_edge<2>, GRID_IJK(nx + 1, ny + 1, nz), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     const EdgeN n = edge_counts(p);
     hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, a.f.tyz, (const double *)a.tnew[0], n.yz, a.f.txz, (const double *)a.tnew[1], n.xz, a.f.txy,
                        (const double *)a.tnew[2], n.xy, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr,
                        (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
     JRX_LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(k_vep3_centre, dim3(gx0, ny, nz), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_vep3_centre, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -448,7 +449,7 @@ jrx_status jrx_tensor_invariant3d(jrx_handle *h, double *II, const double *xx, c
 {
     if (!h) return JRX_ERR_ARG;
     if (!II || !xx || !yy || !zz || !yz || !xz || !xy || nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "tensor_invariant!: bad argument");
-    hipLaunchKernelGGL(k_tensor_invariant3d, dim3((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)nz), dim3(256), 0, h->stream, II, xx, yy, zz, yz, xz,
+    hipLaunchKernelGGL(k_tensor_invariant3d, GRID_IJK(nx, ny, nz), dim3(256), 0, h->stream, II, xx, yy, zz, yz, xz,
                        xy, (int)nx, (int)ny, (int)nz);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
@@ -479,7 +480,8 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     q.nx = nx; q.ny = ny; q.nz = nz; q.nxg = p->nxg; q.nyg = p->nyg; q.nzg = p->nzg; q._dx = p->_dx; q._dy = p->_dy; q._dz = p->_dz;
     q.dt = p->dt; q.r = p->r; q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau;
     q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
-    const unsigned gc = (unsigned)((n + 255) / 256), gx1 = (unsigned)((nx + 1 + 255) / 256), gx0 = (unsigned)((nx + 255) / 256);
+    const unsigned gc = (unsigned)((n + 255) / 256);
+    const dim3 gv = GRID_IJK(nx + 1, ny + 1, nz + 1), g0 = GRID_IJK(nx, ny, nz);
 
     JRX_HIP(h, hipMemcpyAsync(f->P0, f->P, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // @copy stokes.P0 stokes.P
     JRX_HIP(h, hipMemcpyAsync(theta, f->P, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // θ = deepcopy(stokes.P)
@@ -500,7 +502,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);      // R and U are only observable after such an iteration
         hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, nz);
-        hipLaunchKernelGGL(k_vep3_pre, dim3(gx1, ny + 1, nz + 1), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_vep3_pre, gv, dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, p->viscosity_relaxation);
         JRX_LAUNCH_CHECK(h);
         JRX_TRY(launch_vep3_stress(h, s, a, p));
@@ -540,18 +542,18 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     JRX_HIP(h, hipEventRecord(t1, s));
     // epilogue: vorticity, shear2center!, accumulate_tensor!/accumulate_vol!, τ -> τ_o (Stokes3D.jl:640-658)
     if (f->omega_yz && f->omega_xz && f->omega_xy)
-        hipLaunchKernelGGL(k_vorticity3d, dim3(gx1, ny + 1, nz + 1), dim3(256), 0, s, f->omega_yz, f->omega_xz, f->omega_xy, (const double *)f->Vx,
+        hipLaunchKernelGGL(k_vorticity3d, gv, dim3(256), 0, s, f->omega_yz, f->omega_xz, f->omega_xy, (const double *)f->Vx,
                            (const double *)f->Vy, (const double *)f->Vz, nx, ny, nz, p->_dx, p->_dy, p->_dz);
     if (f->eyz_c && f->exz_c && f->exy_c)
-        hipLaunchKernelGGL(k_shear2center3d, dim3(gx0, ny, nz), dim3(256), 0, s, f->eyz_c, f->exz_c, f->exy_c, (const double *)f->eyz, (const double *)f->exz,
+        hipLaunchKernelGGL(k_shear2center3d, g0, dim3(256), 0, s, f->eyz_c, f->exz_c, f->exy_c, (const double *)f->eyz, (const double *)f->exz,
                            (const double *)f->exy, nx, ny, nz);
     if (f->eplyz_c && f->eplxz_c && f->eplxy_c)
-        hipLaunchKernelGGL(k_shear2center3d, dim3(gx0, ny, nz), dim3(256), 0, s, f->eplyz_c, f->eplxz_c, f->eplxy_c, (const double *)f->eplyz,
+        hipLaunchKernelGGL(k_shear2center3d, g0, dim3(256), 0, s, f->eplyz_c, f->eplxz_c, f->eplxy_c, (const double *)f->eplyz,
                            (const double *)f->eplxz, (const double *)f->eplxy, nx, ny, nz);
     if (f->deyz_c && f->dexz_c && f->dexy_c && f->deyz && f->dexz && f->dexy)
-        hipLaunchKernelGGL(k_shear2center3d, dim3(gx0, ny, nz), dim3(256), 0, s, f->deyz_c, f->dexz_c, f->dexy_c, (const double *)f->deyz, (const double *)f->dexz,
+        hipLaunchKernelGGL(k_shear2center3d, g0, dim3(256), 0, s, f->deyz_c, f->dexz_c, f->dexy_c, (const double *)f->deyz, (const double *)f->dexz,
                            (const double *)f->dexy, nx, ny, nz);
-    hipLaunchKernelGGL(k_vep3_accumulate, dim3(gx0, ny, nz), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_vep3_accumulate, g0, dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     const i64 nc = (i64)n;
     hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, f->toxx, (const double *)f->txx, nc, f->toyy, (const double *)f->tyy, nc, f->tozz,

@@ -22,6 +22,11 @@ __device__ __forceinline__ double rhoCp3_of(const jrx_thermal3d_params &p, const
     return p.rheology_form ? p.Cp * (p.rho0 * (1.0 - p.alpha * (T - p.T0))) : rhoCp[c];
 }
 
+#define NODE_IJK(n1_, n2_)                                              \
+    const int t_ = blockIdx.x * blockDim.x + threadIdx.x;               \
+    const int j = t_ / (n1_), i = t_ - j * (n1_), k = blockIdx.y;       \
+    if (j >= (n2_)) return;
+#define GRID_IJK(n1_, n2_, n3_) dim3((unsigned)(((i64)(n1_) * (n2_) + 255) / 256), (unsigned)(n3_))
 #define T3_(i_, j_, k_) T[(i_) + (i64)(nx + 2) * ((j_) + (i64)(ny + 2) * (k_))]
 #define CC_(A, i_, j_, k_) (A)[(i_) + (i64)nx * ((j_) + (i64)ny * (k_))]
 
@@ -29,8 +34,7 @@ __device__ __forceinline__ double rhoCp3_of(const jrx_thermal3d_params &p, const
 __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
 {
     const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i > nx) return;
+    NODE_IJK(nx + 1, ny + 1)
     const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau;
     const double kc = (a.p.k_const + a.p.k_const) * 0.5;
     if (j < ny && k < nz) {
@@ -79,8 +83,8 @@ template <bool RES>
 __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a)
 {
     const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
-    if (i >= nx || j >= ny || k >= nz) return;
+    NODE_IJK(nx, ny)
+    if (k >= nz) return;
     const i64 c = i + (i64)nx * (j + (i64)ny * k), I1 = (i + 1) + (i64)(nx + 2) * ((j + 1) + (i64)(ny + 2) * (k + 1));
     const double _dt = 1.0 / a.p.dt;
     const double Tc = a.t.T[I1];
@@ -168,9 +172,9 @@ jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jr
     a.t = *t; a.p = *p;
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
     hipStream_t s = h->stream;
-    hipLaunchKernelGGL(k_flux3d, dim3((unsigned)((nx + 1 + 255) / 256), ny + 1, nz + 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_flux3d, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(k_updateT3d<false>, dim3((unsigned)((nx + 255) / 256), ny, nz), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_updateT3d<false>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     JRX_TRY(launch_tbcs3(h, s, t->T, p));
     if (jrx_comm_active(h)) {
@@ -208,7 +212,7 @@ jrx_status jrx_thermal3d_check_res(jrx_handle *h, const jrx_thermal3d_fields *t,
     JRX_TRY(checkT3(h, t, p));
     T3Args a;
     a.t = *t; a.p = *p;
-    hipLaunchKernelGGL(k_updateT3d<true>, dim3((unsigned)((p->nx + 255) / 256), (unsigned)p->ny, (unsigned)p->nz), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(k_updateT3d<true>, GRID_IJK(p->nx, p->ny, p->nz), dim3(256), 0, h->stream, a);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
@@ -232,7 +236,7 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
         JRX_TRY(enqueue_titer3(h, t, p));
         iter++;
         if (iter % p->nout == 0) {
-            hipLaunchKernelGGL(k_updateT3d<true>, dim3((unsigned)((nx + 255) / 256), ny, nz), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_updateT3d<true>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
             JRX_LAUNCH_CHECK(h);
             RedArr Z = {nullptr, {0, 0, 0}, 0}, A3 = {t->ResT, {nx, ny, nz}, 0};
             int nb = (int)((n + 2047) / 2048);

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""it/s of the 3D paths next to the headline one on one GPU: 3D multiphase VEP shear band (Stokes3D.jl:447-668) and 3D PT heat
+diffusion.  Fixed iteration counts (convergence disabled); prints one JSON line per case.  usage: bench3d_extra.py [n_vep] [n_thermal]"""
+import json, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import torch
+from __graft_entry__ import load_package
+jr = load_package()
+from justrelax_jl_amd.arrays import from_numpy
+
+dev = torch.device("cuda", 0)
+
+
+def timed(fn, warm, iters):
+    fn(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = fn(iters)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0), r
+
+
+def shearband3d(n=256, iters=100):
+    s = jr.miniapps.shearband3d(n, iterMax=iters - 1, nout=10 ** 9)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+    st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+    for k, path in dict(Vx="V.Vx", Vy="V.Vy", Vz="V.Vz", eta="viscosity.η").items():
+        o = st
+        for p in path.split("."):
+            o = getattr(o, p)
+        o.copy_(from_numpy(s.arrays[k], dev))
+    pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, s.ni)
+    for k, name in (("phase_c", "center"), ("phase_yz", "yz"), ("phase_xz", "xz"), ("phase_xy", "xy")):
+        getattr(pr, name).copy_(from_numpy(s.arrays[k], dev))
+    del s.arrays
+    ρg = tuple(jr.fzeros(s.ni, dev) for _ in range(3))
+    def run(k):
+        return jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=dict(iterMax=k - 1, nout=10 ** 9, verbose=False))
+    el, r = timed(run, 5, iters)
+    cells = float(np.prod(s.ni))
+    # as written: stress kernel reads ~70 array values per cell (3 edge families + centre), pressure/strain 14, viscosity 2, velocity 17, + phase arrays
+    print(json.dumps(dict(config="shear band 3D multiphase VEP", n=n, iters=r.iter, it_per_s=r.iter / el, ms_per_it=el / r.iter * 1e3,
+                          Mcell_updates_per_s=cells * r.iter / el / 1e6)))
+
+
+def thermal3d(n=256, iters=400):
+    s = jr.miniapps.diffusion3d(n, iterMax=iters, nout=10 ** 9)
+    thermal = jr.ThermalArrays(jr.AMDGPUBackend, s.ni)
+    thermal.T.copy_(from_numpy(s.arrays["T"], dev)); thermal.H.fill_(1e-6)
+    K, ρCp = from_numpy(s.arrays["K"], dev), from_numpy(s.arrays["rhoCp"], dev)
+    pt = jr.PTThermalCoeffs(jr.AMDGPUBackend, K, ρCp, s.dt, s.extra["di"], s.extra["li"], CFL=s.pt["CFL"], ϵ=1e-300)
+    def run(k):
+        jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, K, ρCp, s.dt, s.grid, kwargs=dict(iterMax=k, nout=10 ** 9, verbose=False))
+        return k
+    el, k = timed(run, 20, iters)
+    cells = float(np.prod(s.ni))
+    # algorithmic: flux R(T,K,θ,q(3)) W(q(3),q2(3)) = 12 ; update R(q(3),Told,ρCp,dτ_ρ,H,SH,T) W(T) = 10 -> 22 passes = 176 B/cell
+    print(json.dumps(dict(config="thermal diffusion 3D (array form)", n=n, iters=k, it_per_s=k / el, ms_per_it=el / k * 1e3,
+                          eff_GBps_at_176B=176.0 * cells * k / el / 1e9)))
+
+
+if __name__ == "__main__":
+    nv = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    nt = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    thermal3d(nt)
+    shearband3d(nv)
