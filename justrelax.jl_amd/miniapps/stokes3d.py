@@ -181,6 +181,84 @@ def random_fields3d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nou
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
 
 
+def burstedde3d(n=16, *, β=10.0, iterMax=100_000, nout=1000) -> Setup:
+    """Burstedde et al. (2013) manufactured solution -- miniapps/benchmarks/stokes3D/burstedde/Burstedde.jl:10-215
+    (test/test_stokes_burstedde.jl): η = exp(1 − β Σ x(1−x)), analytical body forces, the analytical velocity prescribed on
+    every face (no free-slip / no-slip face), net boundary flux removed; K = G = Inf, dt = Inf, CFL = 1/√3."""
+    ni = (n, n, n)
+    li = (1.0, 1.0, 1.0)
+    init_global_grid(n, n, n)
+    di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g(), nz_g())))
+    grid = Geometry(ni, li, origin=(0.0, 0.0, 0.0))
+    arr = alloc_stokes(ni)
+    xc, yc, zc = grid.xci
+    X, Y, Z = np.meshgrid(xc, yc, zc, indexing="ij")
+    η = np.exp(1 - β * (X * (1 - X) + Y * (1 - Y) + Z * (1 - Z)))               # _viscosity! :10-14
+    arr["eta"][...] = η
+    dηdx, dηdy, dηdz = -β * (1 - 2 * X) * η, -β * (1 - 2 * Y) * η, -β * (1 - 2 * Z) * η
+    x, y, z = X, Y, Z                                                            # body_forces :22-44
+    fx = ((y * z + 3 * x**2 * y**3 * z) - η * (2 + 6 * x * y)) - dηdx * (2 + 4 * x + 2 * y + 6 * x**2 * y) - dηdy * (x + x**3 + y + 2 * x * y**2) \
+        - dηdz * (-3 * z - 10 * x * y * z)
+    fy = ((x * z + 3 * x**3 * y**2 * z) - η * (2 + 2 * x**2 + 2 * y**2)) - dηdx * (x + x**3 + y + 2 * x * y**2) \
+        - dηdy * (2 + 2 * x + 4 * y + 4 * x**2 * y) - dηdz * (-3 * z - 5 * x**2 * z)
+    fz = ((x * y + x**3 * y**3) - η * (-10 * y * z)) - dηdx * (-3 * z - 10 * x * y * z) - dηdy * (-3 * z - 5 * x**2 * z) \
+        - dηdz * (-4 - 6 * x - 6 * y - 10 * x**2 * y)
+    arr["fx"][...], arr["fy"][...], arr["fz"][...] = -fx, -fy, -fz
+    arr["K"][...] = np.inf
+    arr["G"][...] = np.inf
+    # velocity! :46-104: analytical values on the outermost planes of every V array, zero inside
+    xv, yv, zv = grid.xvi
+    ext = lambda c, d: np.linspace(c[0] - d, c[-1] + d, len(c) + 2)
+    dd = [c[1] - c[0] for c in grid.xci]
+    xg, yg, zg = ext(xc, dd[0]), ext(yc, dd[1]), ext(zc, dd[2])
+    vx = lambda x_, y_: x_ + x_**2 + x_ * y_ + x_**3 * y_
+    vy = lambda x_, y_: y_ + x_ * y_ + y_**2 + x_**2 * y_**2
+    vz = lambda x_, y_, z_: -2 * z_ - 3 * x_ * z_ - 3 * y_ * z_ - 5 * x_**2 * y_ * z_
+
+    def shell(A, full):
+        m = np.zeros(A.shape, dtype=bool)
+        for d in range(3):
+            idx = [slice(None)] * 3
+            for e in (0, A.shape[d] - 1):
+                idx[d] = e
+                m[tuple(idx)] = True
+        A[...] = np.where(m, full, 0.0)
+    Xa, Ya, _ = np.meshgrid(xv, yg, zg, indexing="ij")
+    shell(arr["Vx"], vx(Xa, Ya))
+    Xa, Ya, _ = np.meshgrid(xg, yv, zg, indexing="ij")
+    shell(arr["Vy"], vy(Xa, Ya))
+    Xa, Ya, Za = np.meshgrid(xg, yg, zv, indexing="ij")
+    shell(arr["Vz"], vz(Xa, Ya, Za))
+    # remove_net_flux! :106-139
+    Vx, Vy, Vz = arr["Vx"], arr["Vy"], arr["Vz"]
+    Ax, Ay, Az = di[1] * di[2], di[0] * di[2], di[0] * di[1]
+    flux = ((Vx[-1, 1:-1, 1:-1].sum() - Vx[0, 1:-1, 1:-1].sum()) * Ax + (Vy[1:-1, -1, 1:-1].sum() - Vy[1:-1, 0, 1:-1].sum()) * Ay
+            + (Vz[1:-1, 1:-1, -1].sum() - Vz[1:-1, 1:-1, 0].sum()) * Az)
+    δ = flux / (2 * (ni[1] * ni[2] * Ax + ni[0] * ni[2] * Ay + ni[0] * ni[1] * Az))
+    Vx[0] += δ; Vx[-1] -= δ; Vy[:, 0] += δ; Vy[:, -1] -= δ; Vz[:, :, 0] += δ; Vz[:, :, -1] -= δ
+    pt = PTStokesCoeffs(li, di, CFL=1 / math.sqrt(3))
+    off = {f: False for f in _F6}
+    bcs = VelocityBoundaryConditions(free_slip=off, no_slip=dict(off))
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=float("inf"), flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di, β=β))
+
+
+def burstedde_error_norms(arr, grid, di):
+    """error_norms (vizBurstedde.jl:96-117): (L2_p, L2_vx, L2_vy, L2_vz), each sqrt(Σ e² ΔV); pressures with their means removed"""
+    (xc, yc, zc), (xv, yv, zv) = grid.xci, grid.xvi
+    dV = float(np.prod(di))
+    L2 = lambda e: math.sqrt(float((e * e).sum()) * dV)
+    X, Y, Z = np.meshgrid(xv, yc, zc, indexing="ij")
+    e_vx = arr["Vx"][:, 1:-1, 1:-1] - (X + X**2 + X * Y + X**3 * Y)
+    X, Y, Z = np.meshgrid(xc, yv, zc, indexing="ij")
+    e_vy = arr["Vy"][1:-1, :, 1:-1] - (Y + X * Y + Y**2 + X**2 * Y**2)
+    X, Y, Z = np.meshgrid(xc, yc, zv, indexing="ij")
+    e_vz = arr["Vz"][1:-1, 1:-1, :] - (-2 * Z - 3 * X * Z - 3 * Y * Z - 5 * X**2 * Y * Z)
+    X, Y, Z = np.meshgrid(xc, yc, zc, indexing="ij")
+    p = X * Y * Z + X**3 * Y**3 * Z - 5 / 32
+    return L2((arr["P"] - arr["P"].mean()) - (p - p.mean())), L2(e_vx), L2(e_vy), L2(e_vz)
+
+
 def vep_shapes3d(ni, nphase=2):
     """array name -> extent for the 3D VEP problem (names follow jrx_vep3d_fields / oracle.VEP3_NAMES)"""
     nx, ny, nz = ni

@@ -179,6 +179,29 @@ def test_taylor_green_reference_test(env):
     assert max(L2_vx, L2_vy, L2_vz) < 5.0e-3 and L2_p < 1.5e-1
 
 
+def test_burstedde_reference_test(env):
+    """test/test_stokes_burstedde.jl:29-46 on the device (variable viscosity, body forces, velocity prescribed on all faces):
+    PT err < 1e-8, velocity orders > 1.4, max L2_v < 3e-2, L2_p < 2e-1; and the fields agree with the oracle's converged ones."""
+    jr, orc, ck = env["jr"], env["orc"], env["checks"]
+    errors = []
+    for n in (8, 16):
+        s = jr.miniapps.burstedde3d(n)
+        stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+        iters = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+        assert iters.err_evo1[-1] < 1.0e-8
+        dev = env["down"](stokes)
+        errors.append(jr.miniapps.burstedde_error_norms(dev, s.grid, s.extra["di"]))
+        ref = _cp(s.arrays)
+        r = orc.stokes3d_solve(ref, ck.oracle_params3d(orc, s))
+        assert r["iter"] == iters.iter
+        for k in ("Vx", "Vy", "Vz", "P", "txx", "txy"):
+            assert ck.max_rel_diff(dev[k], ref[k]) <= 1e-9, k
+    L2_p, L2_vx, L2_vy, L2_vz = errors[-1]
+    order = np.log2(np.array(errors[0]) / np.array(errors[1]))
+    assert (order[1:] > 1.4).all(), order
+    assert max(L2_vx, L2_vy, L2_vz) < 3.0e-2 and L2_p < 2.0e-1
+
+
 def test_nan_is_reported_like_the_reference(env):
     """error("NaN(s)") at a check iteration (Stokes3D.jl:162) -> JRX_ERR_NAN."""
     jr = env["jr"]

@@ -175,6 +175,21 @@ def test_taylor_green(oracle, jr):
     assert max(L2_vx, L2_vy, L2_vz) < 5.0e-3 and L2_p < 1.5e-1
 
 
+def test_burstedde(oracle, jr):
+    """test/test_stokes_burstedde.jl:29-46 (variable viscosity η = exp(1 − 10 Σx(1−x)), analytical body forces, velocity prescribed on
+    every face): PT err < 1e-8 at 8^3 and 16^3; velocity orders > 1.4; max L2_v < 3e-2; L2_p < 2e-1"""
+    errs = []
+    for n in (8, 16):
+        s = jr.miniapps.burstedde3d(n)
+        r = _solve3d(oracle, s)
+        assert r["err_evo1"][-1] < 1.0e-8, (n, r["err_evo1"][-1])
+        errs.append(jr.miniapps.burstedde_error_norms(s.arrays, s.grid, s.extra["di"]))
+    order = np.log2(np.array(errs[0]) / np.array(errs[1]))
+    assert (order[1:] > 1.4).all(), order
+    L2_p, L2_vx, L2_vy, L2_vz = errs[1]
+    assert max(L2_vx, L2_vy, L2_vz) < 3.0e-2 and L2_p < 2.0e-1, errs[1]
+
+
 def test_solcx(oracle, jr):
     """test/test_stokes_solcx.jl:26-37 : 32^2, Δη = 1e6 => err_evo1[end] < 1e-8"""
     r = _solve2d(oracle, jr.miniapps.solcx2d(32))
