@@ -159,14 +159,13 @@ __device__ const int OTH3[3][3][4][3] = {
     {{{0, 1, 1}, {1, 1, 1}, {1, 2, 1}, {0, 2, 1}}, {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {{1, 1, 0}, {1, 2, 0}, {1, 1, 1}, {1, 2, 1}}},
     {{{0, 1, 1}, {1, 1, 1}, {0, 1, 2}, {1, 1, 2}}, {{1, 0, 1}, {1, 1, 1}, {1, 0, 2}, {1, 1, 2}}, {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}}};
 
-// update_stresses_center_vertex_ps! 3D -- one edge family (StressKernels.jl:707-903)
+// update_stresses_center_vertex_ps! 3D -- one edge family at node (i, j, k) (StressKernels.jl:707-903)
 template <int T>
-__global__ __launch_bounds__(256) void k_vep3_edge(const Vep3Args a)
+__device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, int k)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
     const int n1 = nx + (T != 0), n2 = ny + (T != 1), n3 = nz + (T != 2);
-    NODE_IJK(n1, n2)
-    if (k >= n3) return;
+    if (i >= n1 || j >= n2 || k >= n3) return;
     const int ci[3] = {clampi3(i - 1, 0, nx - 1), clampi3(i, 0, nx - 1), clampi3(i + 1, 0, nx - 1)};
     const int cj[3] = {clampi3(j - 1, 0, ny - 1), clampi3(j, 0, ny - 1), clampi3(j + 1, 0, ny - 1)};
     const int ck[3] = {clampi3(k - 1, 0, nz - 1), clampi3(k, 0, nz - 1), clampi3(k + 1, 0, nz - 1)};
@@ -225,6 +224,18 @@ __global__ __launch_bounds__(256) void k_vep3_edge(const Vep3Args a)
         a.tnew[T][v] = tij[own] + d[own];
         eplsh[T][v] = 0.0;
     }
+}
+
+// The three edge families of one node in one thread, as in the reference's kernel: they share the clamped centre stencils
+// (η, θ, the normal components) and each other's shear components, so the second and third family mostly hit in L1/L2.
+// New edge stresses go to a.tnew (committed by the caller), so every read sees last iteration's values.
+__global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
+{
+    const int nx = a.nx, ny = a.ny;
+    NODE_IJK(nx + 1, ny + 1)
+    vep3_edge_body<0>(a, i, j, k);
+    vep3_edge_body<1>(a, i, j, k);
+    vep3_edge_body<2>(a, i, j, k);
 }
 
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
@@ -385,9 +396,7 @@ EdgeN edge_counts(const jrx_vep3d_params *p)
 jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    hipLaunchKernelGGL(k_vep3_edge<0>, GRID_IJK(nx, ny + 1, nz + 1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_vep3_edge<1>, GRID_IJK(nx + 1, ny, nz + 1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_vep3_edge<2>, GRID_IJK(nx + 1, ny + 1, nz), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_vep3_edges, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     const EdgeN n = edge_counts(p);
     hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, a.f.tyz, (const double *)a.tnew[0], n.yz, a.f.txz, (const double *)a.tnew[1], n.xz, a.f.txy,

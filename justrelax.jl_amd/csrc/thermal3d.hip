@@ -30,7 +30,9 @@ __device__ __forceinline__ double rhoCp3_of(const jrx_thermal3d_params &p, const
 #define T3_(i_, j_, k_) T[(i_) + (i64)(nx + 2) * ((j_) + (i64)(ny + 2) * (k_))]
 #define CC_(A, i_, j_, k_) (A)[(i_) + (i64)nx * ((j_) + (i64)ny * (k_))]
 
-// compute_flux! over (nx+1, ny+1, nz+1)
+// compute_flux! over (nx+1, ny+1, nz+1).  Q2 = false skips the stores of qT*2 (the un-relaxed flux is only read by check_res!,
+// DiffusionPT_solver.jl:113-126, so it is written on the iterations a check follows)
+template <bool Q2>
 __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
 {
     const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
             const double K = a.p.rheology_form ? kc : (CC_(a.t.K, l, j, k) + CC_(a.t.K, r, j, k)) * 0.5;
             const double t = (CC_(th, l, j, k) + CC_(th, r, j, k)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i, j + 1, k + 1)) * a.p._dx;
-            a.t.qTx2[q] = qv;
+            if (Q2) a.t.qTx2[q] = qv;
             a.t.qTx[q] = (a.t.qTx[q] * t + qv) / (1.0 + t);
         }
     }
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
             const double K = a.p.rheology_form ? kc : (CC_(a.t.K, i, l, k) + CC_(a.t.K, i, r, k)) * 0.5;
             const double t = (CC_(th, i, l, k) + CC_(th, i, r, k)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i + 1, j, k + 1)) * a.p._dy;
-            a.t.qTy2[q] = qv;
+            if (Q2) a.t.qTy2[q] = qv;
             a.t.qTy[q] = (a.t.qTy[q] * t + qv) / (1.0 + t);
         }
     }
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
             const double K = a.p.rheology_form ? kc : (CC_(a.t.K, i, j, l) + CC_(a.t.K, i, j, r)) * 0.5;
             const double t = (CC_(th, i, j, l) + CC_(th, i, j, r)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i + 1, j + 1, k)) * a.p._dz;
-            a.t.qTz2[q] = qv;
+            if (Q2) a.t.qTz2[q] = qv;
             a.t.qTz[q] = (a.t.qTz[q] * t + qv) / (1.0 + t);
         }
     }
@@ -166,13 +168,14 @@ jrx_status launch_tbcs3(jrx_handle *h, hipStream_t s, double *T, const jrx_therm
     return JRX_OK;
 }
 
-jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p)
+jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, bool q2 = true)
 {
     T3Args a;
     a.t = *t; a.p = *p;
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
     hipStream_t s = h->stream;
-    hipLaunchKernelGGL(k_flux3d, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    if (q2) hipLaunchKernelGGL(k_flux3d<true>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_flux3d<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(k_updateT3d<false>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
@@ -233,7 +236,9 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
     T3Args a;
     a.t = *t; a.p = *p;
     while (err > p->eps && iter < p->iterMax) {
-        JRX_TRY(enqueue_titer3(h, t, p));
+        // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one
+        const bool q2 = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
+        JRX_TRY(enqueue_titer3(h, t, p, q2));
         iter++;
         if (iter % p->nout == 0) {
             hipLaunchKernelGGL(k_updateT3d<true>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
