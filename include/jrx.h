@@ -351,6 +351,24 @@ jrx_status jrx_thermal2d_iteration(jrx_handle *h, const jrx_thermal2d_fields *t,
 /* check_res! (DiffusionPT_kernels.jl:603-668) */
 jrx_status jrx_thermal2d_check_res(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p);
 
+/* ------------------------------------------------------------------ post-loop epilogue operators, stand-alone
+ * The VEP drivers run these themselves (Stokes2D.jl:831-846, Stokes3D.jl:640-658); time-stepping scripts also call them directly. */
+/* shear2center!(A): shear components averaged to the cell centres -- Interpolations.jl:291-323 */
+jrx_status jrx_shear2center2d(jrx_handle *h, double *xy_c, const double *xy, int64_t nx, int64_t ny);
+jrx_status jrx_shear2center3d(jrx_handle *h, double *yz_c, double *xz_c, double *xy_c, const double *yz, const double *xz, const double *xy,
+                              int64_t nx, int64_t ny, int64_t nz);
+/* accumulate_tensor!(II, A, dt): II += second_invariant_staggered(A) * dt -- StressKernels.jl:364-408 */
+jrx_status jrx_accumulate_tensor2d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *xy, double dt, int64_t nx, int64_t ny);
+jrx_status jrx_accumulate_tensor3d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *zz, const double *yz, const double *xz,
+                                   const double *xy, double dt, int64_t nx, int64_t ny, int64_t nz);
+/* accumulate_vol!(EVol_pl, ε_vol_pl, dt): EVol_pl += dt * ε_vol_pl over n cells -- StressKernels.jl:410-431 */
+jrx_status jrx_accumulate_vol(jrx_handle *h, double *EVol, const double *evol, double dt, int64_t n);
+/* compute_vorticity! as the drivers call it -- stress_rotation_particles.jl:17-50 (2D at the vertices with the velocity-node
+ * spacings; 3D on the edges, forward differences at the un-shifted velocity index exactly as the reference's `_di` method) */
+jrx_status jrx_compute_vorticity2d(jrx_handle *h, double *wxy, const double *Vx, const double *Vy, int64_t nx, int64_t ny, double _dx, double _dy);
+jrx_status jrx_compute_vorticity3d(jrx_handle *h, double *wyz, double *wxz, double *wxy, const double *Vx, const double *Vy, const double *Vz,
+                                   int64_t nx, int64_t ny, int64_t nz, double _dx, double _dy, double _dz);
+
 /* ------------------------------------------------------------------ 3D PT heat diffusion
  * heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, K, ρCp | rheology, args, dt, grid; kwargs) for 3D grids --
  * src/thermal_diffusion/DiffusionPT_solver.jl:34-149,181-305 with the 3D kernels DiffusionPT_kernels.jl:6-61,160-199,250-282.

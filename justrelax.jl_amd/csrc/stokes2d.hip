@@ -628,6 +628,32 @@ __global__ __launch_bounds__(256) void k_tensor_invariant2d(double *__restrict__
     II[t] = sinv_stag(xx[t], yy[t], V2(xy, i, j), V2(xy, i + 1, j), V2(xy, i, j + 1), V2(xy, i + 1, j + 1));
 }
 
+__global__ __launch_bounds__(256) void k_axpy_dt(double *__restrict__ y, const double *__restrict__ x, double dt, i64 n)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) y[t] += dt * x[t];
+}
+
+// the epilogue operators alone: mode 0 shear2center_kernel! (Interpolations.jl:306-311), 1 accumulate_tensor_kernel!
+// (StressKernels.jl:379-392), 2 compute_vorticity! (stress_rotation_particles.jl:17-29; over the vertices)
+__global__ __launch_bounds__(256) void k_epilogue_op2d(int mode, double *__restrict__ out, const double *A, const double *B, const double *Cv, double s1,
+                                                       double s2, int nx, int ny)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 2) {
+        const int j = t / (nx + 1), i = t - j * (nx + 1);
+        if (j > ny) return;
+        // A = Vx (nx+1, ny+2), B = Vy (nx+2, ny+1); s1 = _dx, s2 = _dy
+        V2(out, i, j) = 0.5 * ((-B[i + (i64)(nx + 2) * j] + B[(i + 1) + (i64)(nx + 2) * j]) * s1 - (-A[i + (i64)(nx + 1) * j] + A[i + (i64)(nx + 1) * (j + 1)]) * s2);
+        return;
+    }
+    const int j = t / nx, i = t - j * nx;
+    if (j >= ny) return;
+    const i64 c = i + (i64)nx * j;
+    if (mode == 0) out[c] = 0.25 * (V2(Cv, i, j) + V2(Cv, i + 1, j) + V2(Cv, i, j + 1) + V2(Cv, i + 1, j + 1));
+    else out[c] += sinv_stag(A[c], B[c], V2(Cv, i, j), V2(Cv, i + 1, j), V2(Cv, i, j + 1), V2(Cv, i + 1, j + 1)) * s1;
+}
+
 // post-loop epilogue: compute_vorticity!, shear2center! x3, accumulate_tensor!, accumulate_vol! (Stokes2D.jl:831-843)
 __global__ __launch_bounds__(256) void k_vep_epilogue(const VepArgs a)
 {
@@ -725,6 +751,49 @@ jrx_status jrx_vep2d_update_stresses(jrx_handle *h, const jrx_vep2d_fields *f, c
     hipLaunchKernelGGL(k_vep_vertex, dim3(gv), dim3(256), 0, h->stream, a);
     JRX_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(k_vep_centre, dim3(gc), dim3(256), 0, h->stream, a);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_shear2center2d(jrx_handle *h, double *xy_c, const double *xy, int64_t nx, int64_t ny)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!xy_c || !xy || nx < 1 || ny < 1) return jrx_fail(h, JRX_ERR_ARG, "shear2center!: bad argument");
+    hipLaunchKernelGGL(k_epilogue_op2d, dim3((unsigned)((nx * ny + 255) / 256)), dim3(256), 0, h->stream, 0, xy_c, (const double *)nullptr,
+                       (const double *)nullptr, xy, 0.0, 0.0, (int)nx, (int)ny);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_accumulate_tensor2d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *xy, double dt, int64_t nx, int64_t ny)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!II || !xx || !yy || !xy || nx < 1 || ny < 1) return jrx_fail(h, JRX_ERR_ARG, "accumulate_tensor!: bad argument");
+    hipLaunchKernelGGL(k_epilogue_op2d, dim3((unsigned)((nx * ny + 255) / 256)), dim3(256), 0, h->stream, 1, II, xx, yy, xy, dt, 0.0, (int)nx, (int)ny);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_compute_vorticity2d(jrx_handle *h, double *wxy, const double *Vx, const double *Vy, int64_t nx, int64_t ny, double _dx, double _dy)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!wxy || !Vx || !Vy || nx < 1 || ny < 1) return jrx_fail(h, JRX_ERR_ARG, "compute_vorticity!: bad argument");
+    hipLaunchKernelGGL(k_epilogue_op2d, dim3((unsigned)(((nx + 1) * (ny + 1) + 255) / 256)), dim3(256), 0, h->stream, 2, wxy, Vx, Vy, (const double *)nullptr,
+                       _dx, _dy, (int)nx, (int)ny);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+// accumulate_vol!(EVol_pl, ε_vol_pl, dt): EVol_pl += dt * ε_vol_pl (StressKernels.jl:410-431), any dimension
+jrx_status jrx_accumulate_vol(jrx_handle *h, double *EVol, const double *evol, double dt, int64_t n)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!EVol || !evol || n < 1) return jrx_fail(h, JRX_ERR_ARG, "accumulate_vol!: bad argument");
+    hipLaunchKernelGGL(k_axpy_dt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, EVol, evol, dt, (i64)n);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;

@@ -344,6 +344,14 @@ __global__ __launch_bounds__(256) void k_vorticity3d(double *__restrict__ wyz, d
     if (k < nz) EXY(wxy, i, j, k) = 0.5 * ((-VY(i, j, k) + VY(i + 1, j, k)) * _dx - (-VX(i, j, k) + VX(i, j + 1, k)) * _dy);
 }
 
+// accumulate_tensor_kernel! 3D alone (StressKernels.jl:394-408)
+__global__ __launch_bounds__(256) void k_accumulate_tensor3d(double *__restrict__ II, const double *xx, const double *yy, const double *zz,
+                                                             const double *yz, const double *xz, const double *xy, double dt, int nx, int ny, int nz)
+{
+    NODE_IJK(nx, ny)
+    II[i + (i64)nx * (j + (i64)ny * k)] += sinv_stag3(xx, yy, zz, yz, xz, xy, nx, ny, i, j, k) * dt;
+}
+
 // accumulate_tensor! + accumulate_vol! (StressKernels.jl:394-431)
 __global__ __launch_bounds__(256) void k_vep3_accumulate(const Vep3Args a)
 {
@@ -460,6 +468,40 @@ jrx_status jrx_tensor_invariant3d(jrx_handle *h, double *II, const double *xx, c
     if (!II || !xx || !yy || !zz || !yz || !xz || !xy || nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "tensor_invariant!: bad argument");
     hipLaunchKernelGGL(k_tensor_invariant3d, GRID_IJK(nx, ny, nz), dim3(256), 0, h->stream, II, xx, yy, zz, yz, xz,
                        xy, (int)nx, (int)ny, (int)nz);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_shear2center3d(jrx_handle *h, double *yz_c, double *xz_c, double *xy_c, const double *yz, const double *xz, const double *xy,
+                              int64_t nx, int64_t ny, int64_t nz)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!yz_c || !xz_c || !xy_c || !yz || !xz || !xy || nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "shear2center!: bad argument");
+    hipLaunchKernelGGL(k_shear2center3d, GRID_IJK(nx, ny, nz), dim3(256), 0, h->stream, yz_c, xz_c, xy_c, yz, xz, xy, (int)nx, (int)ny, (int)nz);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_accumulate_tensor3d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *zz, const double *yz, const double *xz,
+                                   const double *xy, double dt, int64_t nx, int64_t ny, int64_t nz)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!II || !xx || !yy || !zz || !yz || !xz || !xy || nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "accumulate_tensor!: bad argument");
+    hipLaunchKernelGGL(k_accumulate_tensor3d, GRID_IJK(nx, ny, nz), dim3(256), 0, h->stream, II, xx, yy, zz, yz, xz, xy, dt, (int)nx, (int)ny, (int)nz);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+
+jrx_status jrx_compute_vorticity3d(jrx_handle *h, double *wyz, double *wxz, double *wxy, const double *Vx, const double *Vy, const double *Vz,
+                                   int64_t nx, int64_t ny, int64_t nz, double _dx, double _dy, double _dz)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!wyz || !wxz || !wxy || !Vx || !Vy || !Vz || nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "compute_vorticity!: bad argument");
+    hipLaunchKernelGGL(k_vorticity3d, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, h->stream, wyz, wxz, wxy, Vx, Vy, Vz, (int)nx, (int)ny, (int)nz, _dx, _dy,
+                       _dz);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;

@@ -293,6 +293,52 @@ def center2vertex_(vertex, center, *, handle=None):
     h.call("jrx_center2vertex2d", C.c_void_p(ptr(vertex)), C.c_void_p(ptr(center)), C.c_int64(center.shape[0]), C.c_int64(center.shape[1]))
 
 
+def shear2center_(A, *, handle=None):
+    """shear2center!(A::SymmetricTensor) -- Interpolations.jl:291-323"""
+    _require_gpu(A.xx)
+    h = handle or _lib.default_handle(A.xx.device.index)
+    torch.cuda.current_stream(A.xx.device).synchronize()
+    n = [C.c_int64(m) for m in A.xx.shape]
+    if A.xx.dim() == 3:
+        h.call("jrx_shear2center3d", *[C.c_void_p(ptr(getattr(A, k))) for k in ("yz_c", "xz_c", "xy_c", "yz", "xz", "xy")], *n)
+    else:
+        h.call("jrx_shear2center2d", C.c_void_p(ptr(A.xy_c)), C.c_void_p(ptr(A.xy)), *n)
+
+
+def accumulate_tensor_(II, A, dt, *, handle=None):
+    """accumulate_tensor!(II, A::SymmetricTensor, dt): II += second_invariant_staggered(A) * dt -- StressKernels.jl:364-408"""
+    _require_gpu(II)
+    h = handle or _lib.default_handle(II.device.index)
+    torch.cuda.current_stream(II.device).synchronize()
+    n = [C.c_int64(m) for m in II.shape]
+    comps = ("xx", "yy", "zz", "yz", "xz", "xy") if II.dim() == 3 else ("xx", "yy", "xy")
+    h.call("jrx_accumulate_tensor3d" if II.dim() == 3 else "jrx_accumulate_tensor2d", C.c_void_p(ptr(II)),
+           *[C.c_void_p(ptr(getattr(A, k))) for k in comps], C.c_double(float(dt)), *n)
+
+
+def accumulate_vol_(EVol_pl, ε_vol_pl, dt, *, handle=None):
+    """accumulate_vol!(EVol_pl, ε_vol_pl, dt) -- StressKernels.jl:410-431"""
+    _require_gpu(EVol_pl)
+    h = handle or _lib.default_handle(EVol_pl.device.index)
+    torch.cuda.current_stream(EVol_pl.device).synchronize()
+    h.call("jrx_accumulate_vol", C.c_void_p(ptr(EVol_pl)), C.c_void_p(ptr(ε_vol_pl)), C.c_double(float(dt)), C.c_int64(EVol_pl.numel()))
+
+
+def compute_vorticity_(stokes, grid_or_di, *, handle=None):
+    """compute_vorticity!(stokes.ω..., @velocity(stokes)..., _di) as the VEP drivers call it -- stress_rotation_particles.jl:17-50"""
+    _require_gpu(stokes)
+    h = handle or _lib.default_handle(stokes.P.device.index)
+    _di = _center_inv(_as_grid(stokes, grid_or_di))
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    n = [C.c_int64(m) for m in stokes._ni]
+    V = stokes.V
+    if len(stokes._ni) == 3:
+        h.call("jrx_compute_vorticity3d", *[C.c_void_p(ptr(x)) for x in (stokes.ω.yz, stokes.ω.xz, stokes.ω.xy, V.Vx, V.Vy, V.Vz)], *n,
+               *[C.c_double(d) for d in _di])
+    else:
+        h.call("jrx_compute_vorticity2d", *[C.c_void_p(ptr(x)) for x in (stokes.ω.xy, V.Vx, V.Vy)], *n, *[C.c_double(d) for d in _di])
+
+
 def tensor_invariant_(A, *, handle=None):
     """tensor_invariant!(A::SymmetricTensor) -- StressKernels.jl:443-487"""
     _require_gpu(A.xx)

@@ -187,3 +187,27 @@ def test_center2vertex_matches_oracle(jr, oracle, ni):
     st_mod.center2vertex_(vd, cd)
     assert np.array_equal(jr.to_numpy(vd), v_ref)
     assert np.array_equal(v_ref[0, 1:-1], v_ref[1, 1:-1]) and np.array_equal(v_ref[:, 0], v_ref[:, 1])
+
+
+def test_epilogue_operators_2d(jr, oracle):
+    """shear2center!, accumulate_tensor!, compute_vorticity! 2D as stand-alone operators, vs numpy restatements (bit-exact)"""
+    from justrelax_jl_amd import stokes as st_mod
+    s = jr.miniapps.shearband2d(20)
+    _randomize(s, seed=6)
+    rng = np.random.default_rng(1)
+    a = s.arrays
+    for k in ("Vx", "Vy", "eplxx", "eplyy", "eplxy", "EII_pl"):
+        a[k][...] = rng.uniform(-1, 1, size=a[k].shape)
+    stokes, pr, ρg = _upload(jr, s)
+    st_mod.shear2center_(stokes.ε)
+    v = a["exy"]
+    assert np.array_equal(jr.to_numpy(stokes.ε.xy_c), 0.25 * (v[:-1, :-1] + v[1:, :-1] + v[:-1, 1:] + v[1:, 1:]))
+    st_mod.accumulate_tensor_(stokes.EII_pl, stokes.ε_pl, 0.25)
+    II = oracle.tensor_invariant2d(a["eplxx"], a["eplyy"], a["eplxy"], mode=1)
+    assert np.array_equal(jr.to_numpy(stokes.EII_pl), a["EII_pl"] + II * 0.25)
+    st_mod.compute_vorticity_(stokes, s.grid)
+    _dx, _dy = s.grid._di["center"]
+    Vx, Vy = a["Vx"], a["Vy"]
+    nx, ny = s.ni
+    want = 0.5 * ((-Vy[:nx + 1, :ny + 1] + Vy[1:nx + 2, :ny + 1]) * _dx - (-Vx[:nx + 1, :ny + 1] + Vx[:nx + 1, 1:ny + 2]) * _dy)
+    assert np.array_equal(jr.to_numpy(stokes.ω.xy), want)

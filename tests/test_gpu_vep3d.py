@@ -150,3 +150,38 @@ def test_tensor_invariant_and_viscosity_3d(jr, oracle):
     f = oracle.vep3d(ref)
     oracle.lib().orc_compute_viscosity3d(C.byref(f), C.byref(oracle.rheology_struct(phases)), C.byref(_params(oracle, s)), C.c_double(0.3))
     assert max_rel_diff(jr.to_numpy(stokes.viscosity.η), ref["eta"]) <= 1e-14
+
+
+def test_epilogue_operators_3d(jr, oracle):
+    """shear2center!, accumulate_tensor!, accumulate_vol!, compute_vorticity! 3D as stand-alone operators, bit-exact"""
+    from justrelax_jl_amd import stokes as st_mod
+    s = jr.miniapps.shearband3d((11, 7, 6))
+    _randomize(s, seed=2)
+    rng = np.random.default_rng(8)
+    a = s.arrays
+    for k in ("Vx", "Vy", "Vz", "eplxx", "eplyy", "eplzz", "eplyz", "eplxz", "eplxy", "EII_pl", "EVol_pl", "evol_pl"):
+        a[k][...] = rng.uniform(-1, 1, size=a[k].shape)
+    stokes, pr, ρg = _upload(jr, s)
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    n = [C.c_int64(m) for m in s.ni]
+    L = oracle.lib()
+    # shear2center!
+    st_mod.shear2center_(stokes.ε)
+    want = [np.zeros(s.ni, order="F") for _ in range(3)]
+    L.orc_shear2center3d(*[dp(w) for w in want], dp(a["eyz"]), dp(a["exz"]), dp(a["exy"]), *n)
+    for w, k in zip(want, ("yz_c", "xz_c", "xy_c")):
+        assert np.array_equal(jr.to_numpy(getattr(stokes.ε, k)), w), k
+    # accumulate_tensor! / accumulate_vol!
+    II = np.zeros(s.ni, order="F")
+    L.orc_tensor_invariant3d(dp(II), *[dp(a[k]) for k in ("eplxx", "eplyy", "eplzz", "eplyz", "eplxz", "eplxy")], *n)
+    st_mod.accumulate_tensor_(stokes.EII_pl, stokes.ε_pl, 0.37)
+    st_mod.accumulate_vol_(stokes.EVol_pl, stokes.ε_vol_pl, 0.37)
+    assert np.array_equal(jr.to_numpy(stokes.EII_pl), a["EII_pl"] + II * 0.37)
+    assert np.array_equal(jr.to_numpy(stokes.EVol_pl), a["EVol_pl"] + 0.37 * a["evol_pl"])
+    # compute_vorticity!
+    st_mod.compute_vorticity_(stokes, s.grid)
+    w = [np.zeros(a[k].shape, order="F") for k in ("tyz", "txz", "txy")]
+    _di = s.grid._di["center"]
+    L.orc_compute_vorticity3d(*[dp(x) for x in w], dp(a["Vx"]), dp(a["Vy"]), dp(a["Vz"]), *n, *[C.c_double(d) for d in _di])
+    for x, k in zip(w, ("yz", "xz", "xy")):
+        assert np.array_equal(jr.to_numpy(getattr(stokes.ω, k)), x), k
