@@ -283,3 +283,22 @@ def test_shearband2d(oracle, jr):
     assert sol[-1] == pytest.approx(1.8358, abs=1.0e-4)
     # the other reading of second_invariant_staggered ((mean xy)^2) misses the lower extremum: it is not what GeoParams does
     assert abs(oracle.tensor_invariant2d(s.arrays["txx"], s.arrays["tyy"], s.arrays["txy"], 0).min() - 1.5128689768248313) > 1.0e-3
+
+
+def test_shearband2d_softening_script_elastic_stage(oracle, jr):
+    """test/test_shearband2D_softening.jl:199-205: the same shear-band set-up with dt/5, 5 steps (t = 0.25): err < 1e-6,
+    maximum(τxx) ≈ 0.466 atol 1e-3, analytic build-up 0.4423.  The stress stays far below yield (τII ≤ 0.47 < C·cosϕ), so the
+    NonLinearSoftening law of that script never acts and the test pins the multi-step visco-elastic VEP driver with the weak
+    inclusion, not a softening formula."""
+    s = jr.miniapps.shearband2d(32, nout=100)
+    s.dt = s.dt / 5
+    rh = oracle.rheology_struct(s.extra["phases"])
+    p = _vep_params(oracle, s)
+    t = 0.0
+    for _ in range(5):
+        r = oracle.stokes2d_vep_solve(s.arrays, rh, p)
+        t += s.dt
+    assert r["err_evo1"][-1] < 1.0e-6
+    assert s.arrays["txx"].max() == pytest.approx(0.466, abs=1.0e-3)
+    assert 2 * s.extra["εbg"] * s.extra["η0"] * (1 - math.exp(-s.extra["G0"] * t / s.extra["η0"])) == pytest.approx(0.4423, abs=1.0e-4)
+    assert not s.arrays["eplxx"].any() and s.arrays["tII"].max() < 0.5
