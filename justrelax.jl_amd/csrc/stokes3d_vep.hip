@@ -149,15 +149,24 @@ __global__ __launch_bounds__(256) void k_vep3_phase_avg(double *__restrict__ Kc,
 }
 
 // Stencil tables of StressKernels.jl:604-668 for the edge families T = 0 (yz), 1 (xz), 2 (xy): entries pick the
-// clamped index {0: n-1, 1: n, 2: n+1} per direction, in the reference's order of summation.
-__device__ const int CEN3[3][4][3] = {
-    {{1, 0, 0}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}},
-    {{0, 1, 0}, {1, 1, 0}, {0, 1, 1}, {1, 1, 1}},
-    {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}}};
-__device__ const int OTH3[3][3][4][3] = {
-    {{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {{1, 0, 1}, {2, 0, 1}, {1, 1, 1}, {2, 1, 1}}, {{1, 1, 0}, {2, 1, 0}, {1, 1, 1}, {2, 1, 1}}},
-    {{{0, 1, 1}, {1, 1, 1}, {1, 2, 1}, {0, 2, 1}}, {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {{1, 1, 0}, {1, 2, 0}, {1, 1, 1}, {1, 2, 1}}},
-    {{{0, 1, 1}, {1, 1, 1}, {0, 1, 2}, {1, 1, 2}}, {{1, 0, 1}, {1, 1, 1}, {1, 0, 2}, {1, 1, 2}}, {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}}};
+// clamped index {0: n-1, 1: n, 2: n+1} per direction, in the reference's order of summation.  constexpr functions so that the
+// unrolled loops fold every table entry into the address arithmetic.
+__host__ __device__ constexpr int cen3(int t, int q, int d)
+{
+    constexpr int T[3][4][3] = {
+        {{1, 0, 0}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}},
+        {{0, 1, 0}, {1, 1, 0}, {0, 1, 1}, {1, 1, 1}},
+        {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}}};
+    return T[t][q][d];
+}
+__host__ __device__ constexpr int oth3(int t, int s, int q, int d)
+{
+    constexpr int T[3][3][4][3] = {
+        {{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {{1, 0, 1}, {2, 0, 1}, {1, 1, 1}, {2, 1, 1}}, {{1, 1, 0}, {2, 1, 0}, {1, 1, 1}, {2, 1, 1}}},
+        {{{0, 1, 1}, {1, 1, 1}, {1, 2, 1}, {0, 2, 1}}, {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, {{1, 1, 0}, {1, 2, 0}, {1, 1, 1}, {1, 2, 1}}},
+        {{{0, 1, 1}, {1, 1, 1}, {0, 1, 2}, {1, 1, 2}}, {{1, 0, 1}, {1, 1, 1}, {1, 0, 2}, {1, 1, 2}}, {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}}};
+    return T[t][s][q][d];
+}
 
 // update_stresses_center_vertex_ps! 3D -- one edge family at node (i, j, k) (StressKernels.jl:707-903)
 template <int T>
@@ -169,12 +178,17 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
     const int ci[3] = {clampi3(i - 1, 0, nx - 1), clampi3(i, 0, nx - 1), clampi3(i + 1, 0, nx - 1)};
     const int cj[3] = {clampi3(j - 1, 0, ny - 1), clampi3(j, 0, ny - 1), clampi3(j + 1, 0, ny - 1)};
     const int ck[3] = {clampi3(k - 1, 0, nz - 1), clampi3(k, 0, nz - 1), clampi3(k + 1, 0, nz - 1)};
-    i64 cidx[4];
+    // 32-bit byte offsets on the (uniform) array bases: every array is < 4 GiB (check_vep3), and the loads become
+    // base-in-SGPR + 32-bit VGPR offset instead of a 64-bit address per access
+    typedef unsigned int u32;
+#define LB(p, off) (*(const double *)((const char *)(p) + (off)))
+    u32 cb[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) cidx[q] = ci[CEN3[T][q][0]] + (i64)nx * (cj[CEN3[T][q][1]] + (i64)ny * ck[CEN3[T][q][2]]);
-#define AVC(A) (0.25 * ((A)[cidx[0]] + (A)[cidx[1]] + (A)[cidx[2]] + (A)[cidx[3]]))
-    const double etav = 4 / (1 / a.f.eta[cidx[0]] + 1 / a.f.eta[cidx[1]] + 1 / a.f.eta[cidx[2]] + 1 / a.f.eta[cidx[3]]);
+    for (int q = 0; q < 4; q++) cb[q] = 8u * (u32)(ci[cen3(T, q, 0)] + nx * (cj[cen3(T, q, 1)] + ny * ck[cen3(T, q, 2)]));
+#define AVC(A) (0.25 * (LB(A, cb[0]) + LB(A, cb[1]) + LB(A, cb[2]) + LB(A, cb[3])))
+    const double etav = 4 / (1 / LB(a.f.eta, cb[0]) + 1 / LB(a.f.eta, cb[1]) + 1 / LB(a.f.eta, cb[2]) + 1 / LB(a.f.eta, cb[3]));
     const double Pv = AVC(a.theta);
+    const u32 vb = 8u * (u32)(i + n1 * (j + n2 * k));
     const i64 v = i + (i64)n1 * (j + (i64)n2 * k);
     double *const tsh[3] = {a.f.tyz, a.f.txz, a.f.txy};
     const double *const tosh[3] = {a.f.toyz, a.f.toxz, a.f.toxy};
@@ -190,15 +204,16 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
 #undef AVC
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-        if (s == T) { eij[3 + s] = esh[s][v]; tij[3 + s] = tsh[s][v]; toij[3 + s] = tosh[s][v]; continue; }
+        if (s == T) { eij[3 + s] = LB(esh[s], vb); tij[3 + s] = LB(tsh[s], vb); toij[3 + s] = LB(tosh[s], vb); continue; }
         const int m1 = nx + (s != 0), m2 = ny + (s != 1);
-        i64 o[4];
+        u32 o[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) o[q] = ci[OTH3[T][s][q][0]] + (i64)m1 * (cj[OTH3[T][s][q][1]] + (i64)m2 * ck[OTH3[T][s][q][2]]);
-        eij[3 + s] = 0.25 * (esh[s][o[0]] + esh[s][o[1]] + esh[s][o[2]] + esh[s][o[3]]);
-        tij[3 + s] = 0.25 * (tsh[s][o[0]] + tsh[s][o[1]] + tsh[s][o[2]] + tsh[s][o[3]]);
-        toij[3 + s] = 0.25 * (tosh[s][o[0]] + tosh[s][o[1]] + tosh[s][o[2]] + tosh[s][o[3]]);
+        for (int q = 0; q < 4; q++) o[q] = 8u * (u32)(ci[oth3(T, s, q, 0)] + m1 * (cj[oth3(T, s, q, 1)] + m2 * ck[oth3(T, s, q, 2)]));
+        eij[3 + s] = 0.25 * (LB(esh[s], o[0]) + LB(esh[s], o[1]) + LB(esh[s], o[2]) + LB(esh[s], o[3]));
+        tij[3 + s] = 0.25 * (LB(tsh[s], o[0]) + LB(tsh[s], o[1]) + LB(tsh[s], o[2]) + LB(tsh[s], o[3]));
+        toij[3 + s] = 0.25 * (LB(tosh[s], o[0]) + LB(tosh[s], o[1]) + LB(tosh[s], o[2]) + LB(tosh[s], o[3]));
     }
+#undef LB
     const double *rv = phsh[T] + (i64)np * v;
     bool is_pl; double eta_reg;
     plastic_params3(a.rh, rv, is_pl, eta_reg);
@@ -370,8 +385,8 @@ jrx_status check_vep3(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheolo
     if (!h) return JRX_ERR_ARG;
     if (!f || !rh || !p) return jrx_fail(h, JRX_ERR_ARG, "null VEP argument");
     if (p->nx < 3 || p->ny < 3 || p->nz < 3) return jrx_fail(h, JRX_ERR_ARG, "3D Stokes needs at least 3 cells per dimension");
-    if ((double)(p->nx + 2) * (double)(p->ny + 2) * (double)(p->nz + 2) >= 2147483647.0)
-        return jrx_fail(h, JRX_ERR_UNSUPPORTED, "local block too large for 32-bit plane indices");
+    if ((double)(p->nx + 2) * (double)(p->ny + 2) * (double)(p->nz + 2) >= 536870912.0)
+        return jrx_fail(h, JRX_ERR_UNSUPPORTED, "local block too large: every array must stay below 4 GiB (32-bit byte offsets)");
     if (rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "nphase must be in 1..%d", JRX_MAXPHASE);
     const void *req[] = {f->P, f->P0, f->divV, f->Q, f->Vx, f->Vy, f->Vz, f->Ux, f->Uy, f->Uz, f->exx, f->eyy, f->ezz, f->eyz, f->exz, f->exy,
                          f->eplxx, f->eplyy, f->eplzz, f->eplyz, f->eplxz, f->eplxy, f->txx, f->tyy, f->tzz, f->tyz, f->txz, f->txy,
