@@ -141,3 +141,45 @@ def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracl
     # ghost planes of V hold the wrapped interior planes
     for k in ("Vx", "Vz"):
         assert np.abs(got[k][0] - ref[k][0]).max() <= 1e-12 * np.abs(ref[k]).max()
+
+
+def test_thermal3d_iterations_with_periodic_halo_match_oracle(jr, oracle):
+    """update_halo!(thermal.T) inside the 3D heat-diffusion loop (DiffusionPT_solver.jl:110) on an IGG-periodic grid held by one rank:
+    device iterations == oracle iteration + the same plane copies in numpy"""
+    import torch
+    from justrelax_jl_amd import _lib, halo, thermal as th
+    from justrelax_jl_amd.arrays import from_numpy
+    import justrelax_jl_amd.grid as g
+    L = _lib.load()
+    s = jr.miniapps.diffusion3d((14, 10, 9), iterMax=40, nout=20)
+    n, periods = s.ni, (1, 1, 0)
+    b = s.flow_bcs
+    p = oracle.thermal_params3d(n, s.grid._di["center"], s.dt, 1e-30, iterMax=40, nout=20, no_flux=b.no_flux, constant_value=b.constant_value,
+                                constant_flux=b.constant_flux, periodic=b.periodic)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    thermal = jr.ThermalArrays(jr.AMDGPUBackend, n)
+    for name in ("T", "H"):
+        getattr(thermal, name).copy_(from_numpy(s.arrays[name], dev))
+    K, ρCp = from_numpy(s.arrays["K"], dev), from_numpy(s.arrays["rhoCp"], dev)
+    pt = jr.PTThermalCoeffs(jr.AMDGPUBackend, K, ρCp, s.dt, s.extra["di"], s.extra["li"], CFL=s.pt["CFL"], ϵ=1e-30)
+    g.init_global_grid(*n, periodx=periods[0], periody=periods[1], periodz=periods[2], rank=0, nprocs=1)
+    h = _lib.default_handle()
+    try:
+        halo.init_comm(h)
+        r = jr.heatdiffusion_PT_(thermal, pt, b, K, ρCp, s.dt, s.grid, kwargs=dict(iterMax=40, nout=20, verbose=False))
+    finally:
+        g.finalize_global_grid()
+        g.init_global_grid(*n, rank=0, nprocs=1)
+        halo.init_comm(h)
+        g.finalize_global_grid()
+    ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    ref["Told"][...] = ref["T"]
+    for it in range(40):
+        oracle.thermal3d_iteration(ref, p)
+        ref["T"][...] = _expected([ref["T"]], n, periods, L)[0]
+    assert list(r.iter_count) == [20, 40]
+    T = jr.to_numpy(thermal.T)
+    inner = (slice(1, -1),) * 3
+    assert np.abs(T[inner] - ref["T"][inner]).max() <= 1e-9 * np.abs(ref["T"]).max()
+    assert np.abs(T[0, 1:-1, 1:-1] - ref["T"][0, 1:-1, 1:-1]).max() <= 1e-9 * np.abs(ref["T"]).max()       # x ghost plane: received, not a BC value
+    assert np.abs(ref["T"][0, 1:-1, 1:-1] - ref["T"][1, 1:-1, 1:-1]).max() > 0.0                          # (no_flux would have copied plane 1)
