@@ -840,8 +840,9 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     JRX_TRY(check_vep(h, f, rh, p));
     if (!res) return jrx_fail(h, JRX_ERR_ARG, "null result");
     if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
-    if (jrx_comm_active(h)) return jrx_fail(h, JRX_ERR_UNSUPPORTED, "multi-rank VEP solve is not implemented");
+    const bool comm = jrx_comm_active(h);
     const int nx = (int)p->nx, ny = (int)p->ny;
+    const int64_t nn[3] = {nx, ny, 1};
     const size_t n = (size_t)nx * ny, nv = (size_t)(nx + 1) * (ny + 1);
     hipStream_t s = h->stream;
     // library scratch: ητ, θ, λ, K, G (centre) and λv (vertex), carved out of one allocation
@@ -874,12 +875,22 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
         if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;          // Stokes2D.jl:650-651
         hipLaunchKernelGGL(k_maxloc, dim3(gc, 1), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, 1);
         JRX_LAUNCH_CHECK(h);
+        if (comm) {   // update_halo!(ητ) (Stokes2D.jl:655)
+            double *arrs[1] = {etatau};
+            const int64_t ext[1][3] = {{nx, ny, 1}};
+            JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
+        }
         hipLaunchKernelGGL(k_vep_pre, dim3(gv), dim3(256), 0, s, a, theta);
         JRX_LAUNCH_CHECK(h);
         hipLaunchKernelGGL(k_vep_vertex, dim3(gv), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
         hipLaunchKernelGGL(k_vep_centre, dim3(gc), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
+        if (comm) {   // update_halo!(stokes.τ.xy) (Stokes2D.jl:757)
+            double *arrs[1] = {f->txy};
+            const int64_t ext[1][3] = {{nx + 1, ny + 1, 1}};
+            JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
+        }
         hipLaunchKernelGGL(k_vep_visc, dim3(gv), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
         hipLaunchKernelGGL(k_velocity2d<false>, dim3(gc), dim3(256), 0, s, b);     // compute_V! (free-surface form with dt*free_surface = 0)
@@ -894,15 +905,22 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             JRX_LAUNCH_CHECK(h);
         }
         JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+        if (comm) {   // update_halo!(@velocity(stokes)...) (Stokes2D.jl:784)
+            double *arrs[2] = {f->Vx, f->Vy};
+            const int64_t ext[2][3] = {{nx + 1, ny + 2, 1}, {nx + 2, ny + 1, 1}};
+            JRX_TRY(jrx_halo_exchange(h, s, 2, arrs, ext, nn));
+        }
         if (check) {
             hipLaunchKernelGGL(k_velocity2d<true>, dim3(gc), dim3(256), 0, s, b);  // compute_Res!
             JRX_LAUNCH_CHECK(h);
             JRX_TRY(launch_sumsq2(h, s, &g, &q));
             JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
             JRX_HIP(h, hipStreamSynchronize(s));
-            const double nRx = sqrt(h->h_sums[0]) / sqrt((double)((p->nxg - 2) * (p->nyg - 1)));
-            const double nRy = sqrt(h->h_sums[1]) / sqrt((double)((p->nxg - 1) * (p->nyg - 2)));
-            const double nDV = sqrt(h->h_sums[3]) / sqrt((double)(p->nxg * p->nyg));
+            double ss[3] = {h->h_sums[0], h->h_sums[1], h->h_sums[3]};
+            JRX_TRY(jrx_allreduce_sum_host(h, ss, 3));                                   // norm_mpi (Stokes2D.jl:803-808)
+            const double nRx = sqrt(ss[0]) / sqrt((double)((p->nxg - 2) * (p->nyg - 1)));
+            const double nRy = sqrt(ss[1]) / sqrt((double)((p->nxg - 1) * (p->nyg - 2)));
+            const double nDV = sqrt(ss[2]) / sqrt((double)(p->nxg * p->nyg));
             err = fmax(nRx, fmax(nRy, nDV));
             if (std::isnan(nRx) || std::isnan(nRy) || std::isnan(nDV)) err = NAN;
             if (cont < res->cap) {

@@ -528,7 +528,6 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     JRX_TRY(check_vep3(h, f, rh, p));
     if (!res) return jrx_fail(h, JRX_ERR_ARG, "null result");
     if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
-    if (jrx_comm_active(h)) return jrx_fail(h, JRX_ERR_UNSUPPORTED, "multi-rank 3D VEP solve is not implemented");
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
     const size_t n = (size_t)nx * ny * nz;
     const EdgeN ne = edge_counts(p);
@@ -560,6 +559,9 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     double err_it1 = 1.0, err = INFINITY;
     int64_t iter = 0, cont = 0;
     res->iter = 0; res->nchecks = 0;
+    const bool comm = jrx_comm_active(h);
+    const int64_t nn[3] = {nx, ny, nz};
+    const int rank = jrx_comm_rank(h);
     hipEvent_t t0 = h->ev[6], t1 = h->ev[7];
     JRX_HIP(h, hipEventRecord(t0, s));
     auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
@@ -568,21 +570,38 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);      // R and U are only observable after such an iteration
         hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, nz);
+        if (comm) {   // update_halo!(ητ) (Stokes3D.jl:515)
+            double *arrs[1] = {etatau};
+            const int64_t ext[1][3] = {{nx, ny, nz}};
+            JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
+        }
         hipLaunchKernelGGL(k_vep3_pre, gv, dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, p->viscosity_relaxation);
         JRX_LAUNCH_CHECK(h);
         JRX_TRY(launch_vep3_stress(h, s, a, p));
+        if (comm) {   // update_halo!(τ.yz), (τ.xz), (τ.xy) (Stokes3D.jl:578-580)
+            double *arrs[3] = {f->tyz, f->txz, f->txy};
+            const int64_t ext[3][3] = {{nx, ny + 1, nz + 1}, {nx + 1, ny, nz + 1}, {nx + 1, ny + 1, nz}};
+            JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, nn));
+        }
         JRX_TRY(jrx3d_velocity_sweep(h, s, &g, etatau, &q, diag));
         if (diag) JRX_TRY(jrx3d_scaleU(h, s, &g, &q));
         JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        if (comm) {   // update_halo!(@velocity(stokes)...) (Stokes3D.jl:596); no overlap with the sweep in this driver yet
+            double *arrs[3] = {f->Vx, f->Vy, f->Vz};
+            const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
+            JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, nn));
+        }
         iter = it1;
         if (check) {
             JRX_TRY(jrx3d_sumsq(h, s, &g, &q));
             JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
             JRX_HIP(h, hipStreamSynchronize(s));
+            double ss[4] = {h->h_sums[0], h->h_sums[1], h->h_sums[2], h->h_sums[3]};
+            JRX_TRY(jrx_allreduce_sum_host(h, ss, 4));                                                // norm_mpi
             const double den = (double)((p->nxg - 1) * (p->nyg - 1) * (p->nzg - 1));                  // Stokes3D.jl:607-612
-            const double nRx = sqrt(h->h_sums[0]) / den, nRy = sqrt(h->h_sums[1]) / den, nRz = sqrt(h->h_sums[2]) / den;
-            const double nDV = sqrt(h->h_sums[3]) / (double)n;                                        // norm_mpi(RP) / length(RP)
+            const double nRx = sqrt(ss[0]) / den, nRy = sqrt(ss[1]) / den, nRz = sqrt(ss[2]) / den;
+            const double nDV = sqrt(ss[3]) / (double)n;                                               // norm_mpi(RP) / length(RP): local length
             err = fmax(fmax(nRx, nRy), fmax(nRz, nDV));
             if (std::isnan(nRx) || std::isnan(nRy) || std::isnan(nRz) || std::isnan(nDV)) err = NAN;
             if (cont < res->cap) {
@@ -595,7 +614,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             }
             if (cont == 0) err_it1 = err;
             cont++;
-            if ((p->verbose && (err / err_it1) > p->eps_rel && err > p->eps_abs) || iter == p->iterMax)
+            if (rank == 0 && ((p->verbose && (err / err_it1) > p->eps_rel && err > p->eps_abs) || iter == p->iterMax))
                 printf("iter = %lld, abs_err = %1.3e, rel_err = %1.3e [norm_Rx=%1.3e, norm_Ry=%1.3e, norm_Rz=%1.3e, norm_∇V=%1.3e] \n", (long long)iter,
                        err, err / err_it1, nRx, nRy, nRz, nDV);
             if (std::isnan(err)) {

@@ -272,6 +272,10 @@ void orc_shear2center3d(double *yz_c, double *xz_c, double *xy_c, const double *
 void orc_compute_vorticity3d(double *wyz, double *wxz, double *wxy, const double *Vx, const double *Vy, const double *Vz,
                              int64_t nx, int64_t ny, int64_t nz, double _dx, double _dy, double _dz);
 
+/* test hook: periodic self-neighbour update_halo! inside the VEP drivers (see stokes3d_vep.c) */
+void orc_set_self_halo(int px, int py, int pz);
+void orc_self_halo(double *A, const int64_t ext[3], const int64_t n[3]);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

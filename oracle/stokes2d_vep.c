@@ -309,14 +309,20 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
     while (iter <= p->iterMax) {
         if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;    /* :650-651 */
         orc_compute_maxloc2d(etatau, f->eta, nx, ny);
+        { const int64_t e[3] = {nx, ny, 1}; orc_self_halo(etatau, e, e); }                               /* update_halo!(ητ) :655 */
         orc_compute_divV2d(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy);
         orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :663-676 */
         orc_compute_strain_rate2d(&g, &q);
         orc_vep2d_stress(f, theta, lam, lamv, rh, p);
+        { const int64_t e[3] = {nx + 1, ny + 1, 1}, nn[3] = {nx, ny, 1}; orc_self_halo(f->txy, e, nn); }    /* update_halo!(τ.xy) :757 */
         orc_compute_viscosity2d(f, rh, p, p->viscosity_relaxation);
         orc_compute_V2d(&g, etatau, &q);             /* free-surface form with dt*free_surface = 0 reduces to the plain one */
         orc_velocity2displacement2d(&g, &q);
         orc_flow_bcs2d(f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic);
+        {   /* update_halo!(@velocity(stokes)...) :784 */
+            const int64_t nn[3] = {nx, ny, 1}, ex[3] = {nx + 1, ny + 2, 1}, ey[3] = {nx + 2, ny + 1, 1};
+            orc_self_halo(f->Vx, ex, nn); orc_self_halo(f->Vy, ey, nn);
+        }
         iter += 1;
         if (iter % p->nout == 0 && iter > 1) {
             orc_compute_Res2d(&g, &q);

@@ -21,6 +21,30 @@
 #include <string.h>
 #include <omp.h>
 
+/* update_halo!(A) on a grid that is IGG-periodic in the flagged dimensions and held by ONE rank (the rank is its own neighbour):
+ * per dimension x -> y -> z the left ghost plane takes the right send plane and vice versa (overlap ol_A = 2 + size_A - n).
+ * Test hook for the multi-rank code path of the device drivers; off by default. */
+static int g_self_periods[3] = {0, 0, 0};
+void orc_set_self_halo(int px, int py, int pz) { g_self_periods[0] = px; g_self_periods[1] = py; g_self_periods[2] = pz; }
+void orc_self_halo(double *A, const int64_t ext[3], const int64_t n[3])
+{
+    const int64_t s[3] = {1, ext[0], ext[0] * ext[1]};
+    for (int d = 0; d < 3; d++) {
+        if (!g_self_periods[d]) continue;
+        const int64_t nA = ext[d], ol = 2 + (nA - n[d]);
+        if (ol < 2 || nA < ol) continue;
+        const int d1 = d == 0 ? 1 : 0, d2 = d == 2 ? 1 : 2;
+        const int64_t sl = ol - 1, sr = nA - ol;
+        for (int64_t v = 0; v < ext[d2]; v++)
+            for (int64_t u = 0; u < ext[d1]; u++) {
+                const int64_t base = u * s[d1] + v * s[d2];
+                const double left_going = A[base + sl * s[d]], right_going = A[base + sr * s[d]];
+                A[base + (nA - 1) * s[d]] = left_going;
+                A[base] = right_going;
+            }
+    }
+}
+
 static inline double sinv3(const double t[6])
 {
     return sqrt(0.5 * (t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + t[3] * t[3] + t[4] * t[4] + t[5] * t[5]);
@@ -342,14 +366,25 @@ int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const
     res->status = 0;
     while (iter < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && iter <= p->iterMax)) {      /* :513 */
         orc_compute_maxloc3d(etatau, f->eta, nx, ny, nz);
+        { const int64_t e[3] = {nx, ny, nz}; orc_self_halo(etatau, e, e); }                               /* update_halo!(ητ) :515 */
         orc_compute_divV3d(f->divV, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->_dx, p->_dy, p->_dz);
         orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :520-533 */
         orc_compute_strain_rate3d(&g, &q);
         orc_compute_viscosity3d(f, rh, p, p->viscosity_relaxation);
         orc_vep3d_stress(f, theta, lam, lamv, rh, p);
+        {   /* update_halo!(τ.yz), (τ.xz), (τ.xy) :578-580 */
+            const int64_t nn[3] = {nx, ny, nz};
+            const int64_t eyz[3] = {nx, ny + 1, nz + 1}, exz[3] = {nx + 1, ny, nz + 1}, exy[3] = {nx + 1, ny + 1, nz};
+            orc_self_halo(f->tyz, eyz, nn); orc_self_halo(f->txz, exz, nn); orc_self_halo(f->txy, exy, nn);
+        }
         orc_compute_V3d(&g, etatau, &q);
         orc_velocity2displacement3d(&g, &q);
         orc_flow_bcs3d(f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic);
+        {   /* update_halo!(@velocity(stokes)...) :596 */
+            const int64_t nn[3] = {nx, ny, nz};
+            const int64_t ex[3] = {nx + 1, ny + 2, nz + 2}, ey[3] = {nx + 2, ny + 1, nz + 2}, ez[3] = {nx + 2, ny + 2, nz + 1};
+            orc_self_halo(f->Vx, ex, nn); orc_self_halo(f->Vy, ey, nn); orc_self_halo(f->Vz, ez, nn);
+        }
         iter += 1;
         if (iter % p->nout == 0 && iter > 1) {
             double s[4];
