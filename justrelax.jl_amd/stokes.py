@@ -411,8 +411,14 @@ def solve_(stokes, pt_stokes, grid_or_di, flow_bcs, ρg, *rest, kwargs=None, han
 
 
 def flow_bcs_(stokes_or_V, bcs, *, handle=None):
-    """flow_bcs!(stokes, bcs) -- BoundaryConditions.jl:65-100"""
-    V = stokes_or_V.V if hasattr(stokes_or_V, "V") else stokes_or_V
+    """flow_bcs!(stokes, bcs) -- BoundaryConditions.jl:65-100.  VelocityBoundaryConditions act on @velocity(stokes),
+    DisplacementBoundaryConditions on @displacement(stokes) (BoundaryConditions.jl:71-78); the kernels are the same."""
+    from .arrays import DisplacementBoundaryConditions
+    if isinstance(bcs, DisplacementBoundaryConditions) and hasattr(stokes_or_V, "U"):
+        U = stokes_or_V.U
+        V = SimpleNamespace(Vx=U.Ux, Vy=U.Uy, Vz=getattr(U, "Uz", None))
+    else:
+        V = stokes_or_V.V if hasattr(stokes_or_V, "V") else stokes_or_V
     _require_gpu(V.Vx)
     h = handle or _lib.default_handle(V.Vx.device.index)
     torch.cuda.current_stream(V.Vx.device).synchronize()
