@@ -232,6 +232,11 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
 void orc_compute_tau_nonlinear2d(const orc_vep2d *f, double *theta, double *lam, const orc_rheology *rh, const orc_vep_params2d *p,
                                  int32_t multiphase);
 void orc_center2vertex2d(double *v, const double *c, int64_t nx, int64_t ny);
+double orc_yieldfunction_phase(const orc_rheology *rh, const double *ratio, double P, double tII);
+void orc_plastic_gradients_phase2d(const orc_rheology *rh, const double *ratio, const double t[3], double dQdt[3], double *dQdP, double *dFdP);
+int32_t orc_isyielding(int32_t is_pl, double tII_trial, double ty);
+double orc_compute_dtau_pl(const double tij[3], const double dtij[3], double ty, double tII_trial, double eta, double lam0, double eta_reg,
+                           double dtr, double volume, double dtau_pl[3], double ldq[3]);
 void orc_tensor_invariant2d(double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny, int32_t mode);
 void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu);
 

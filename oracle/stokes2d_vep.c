@@ -237,6 +237,27 @@ void orc_center2vertex2d(double *v, const double *c, int64_t nx, int64_t ny)
     for (int64_t i = 0; i <= nx; i++) { V2(v, i, 0) = V2(v, i, 1); V2(v, i, ny) = V2(v, i, ny - 1); }
 }
 
+/* scalar entry points for the known-answer tests of test/test_Utils.jl:399-470 */
+double orc_yieldfunction_phase(const orc_rheology *rh, const double *ratio, double P, double tII) { return yield_F(rh, ratio, P, tII); }
+void orc_plastic_gradients_phase2d(const orc_rheology *rh, const double *ratio, const double t[3], double dQdt[3], double *dQdP, double *dFdP)
+{
+    plastic_grad(rh, ratio, t, dQdt, dQdP, dFdP);
+}
+int32_t orc_isyielding(int32_t is_pl, double tII_trial, double ty) { return is_pl * (tII_trial > ty); }   /* StressUpdate.jl:68 */
+/* compute_dτ_pl (StressUpdate.jl:83-105), N = 3; returns λ */
+double orc_compute_dtau_pl(const double tij[3], const double dtij[3], double ty, double tII_trial, double eta, double lam0, double eta_reg,
+                           double dtr, double volume, double dtau_pl[3], double ldq[3])
+{
+    const double F = tII_trial - ty;
+    const double l = 0.5 * lam0 + (1 - 0.5) * (F > 0.0 ? 1.0 : 0.0) * F * inv(eta * dtr + eta_reg + volume);
+    const double l_tII = l * 0.5 * inv(tII_trial);
+    for (int q = 0; q < 3; q++) {
+        ldq[q] = (tij[q] + dtij[q]) * l_tII;
+        dtau_pl[q] = fma(-dtr * 2.0, eta * ldq[q], dtij[q]);
+    }
+    return l;
+}
+
 /* update_viscosity_τII! (rheology/Viscosity.jl:67-106,382-418): centre and vertex viscosities relaxed towards the
  * per-phase value; with LinearViscous + dt = Inf the composite viscosity is the linear one (ASSUMED, see header) */
 static inline double phase_viscosity(const orc_rheology *rh, const double *r)

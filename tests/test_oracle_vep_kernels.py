@@ -106,3 +106,31 @@ def test_center2vertex(oracle):
     w[0, :] = w[1, :]; w[-1, :] = w[-2, :]; w[:, 0] = w[:, 1]; w[:, -1] = w[:, -2]
     assert np.array_equal(v[1:-1, 1:-1], w[1:-1, 1:-1])
     assert np.array_equal(v, w)
+
+
+def test_yield_function_gradients_and_dtau_pl_known_answers(oracle):
+    """test/test_Utils.jl:399-470: DruckerPrager_regularised(C = 1, ϕ = 30, η_vp = 1e-3, Ψ = 0), G = Kb = 1, η = 1"""
+    L = oracle.lib()
+    L.orc_yieldfunction_phase.restype = C.c_double
+    L.orc_compute_dtau_pl.restype = C.c_double
+    rh = oracle.rheology_struct([dict(eta=1.0, G=1.0, Kb=1.0, C=1.0, phi_deg=30.0, psi_deg=0.0, eta_vp=1e-3)])
+    one = (C.c_double * 1)(1.0)
+    F_above = L.orc_yieldfunction_phase(C.byref(rh), one, C.c_double(0.0), C.c_double(5.0))
+    F_below = L.orc_yieldfunction_phase(C.byref(rh), one, C.c_double(0.0), C.c_double(0.1))
+    assert F_above > 0.0 and F_below < 0.0
+    assert F_above == pytest.approx(5.0 - np.cos(np.radians(30.0)))                 # F = τII − C cosϕ − P sinϕ
+    t = (C.c_double * 3)(1.0, -1.0, 0.5)
+    dQ, dQdP, dFdP = (C.c_double * 3)(), C.c_double(), C.c_double()
+    L.orc_plastic_gradients_phase2d(C.byref(rh), one, t, dQ, C.byref(dQdP), C.byref(dFdP))
+    tII = np.sqrt(0.5 * (1 + 1) + 0.25)
+    assert np.allclose(dQ[:], [0.5 * 1.0 / tII, -0.5 / tII, 0.5 * 0.5 / tII]) and dQdP.value == 0.0 and dFdP.value == pytest.approx(-0.5)
+    tij, dtij = (C.c_double * 3)(1.0, 2.0, 0.5), (C.c_double * 3)(0.1, 0.2, 0.05)
+    dpl, ldq = (C.c_double * 3)(), (C.c_double * 3)()
+    lam = L.orc_compute_dtau_pl(tij, dtij, C.c_double(1.0), C.c_double(2.5), C.c_double(1e21), C.c_double(0.0), C.c_double(1e18), C.c_double(1e-22),
+                                C.c_double(0.0), dpl, ldq)
+    assert lam > 0.0 and lam == pytest.approx(0.5 * 1.5 / (0.1 + 1e18))
+    lam2 = L.orc_compute_dtau_pl(tij, dtij, C.c_double(10.0), C.c_double(0.5), C.c_double(1e21), C.c_double(0.0), C.c_double(1e18), C.c_double(1e-22),
+                                 C.c_double(0.0), dpl, ldq)
+    assert lam2 == 0.0
+    assert L.orc_isyielding(1, C.c_double(2.0), C.c_double(1.0)) == 1 and L.orc_isyielding(1, C.c_double(0.5), C.c_double(1.0)) == 0
+    assert L.orc_isyielding(0, C.c_double(2.0), C.c_double(1.0)) == 0
