@@ -351,6 +351,14 @@ jrx_status jrx_thermal2d_iteration(jrx_handle *h, const jrx_thermal2d_fields *t,
 /* check_res! (DiffusionPT_kernels.jl:603-668) */
 jrx_status jrx_thermal2d_check_res(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p);
 
+/* ------------------------------------------------------------------ small backend generics of the method table
+ * (src/ext/AMDGPU/3D.jl:205-239): velocity2displacement!, displacement2velocity! (types/displacement.jl:2-60), compute_dt (Utils.jl:492-519).
+ * Arrays in the order x, y, z with n[d] elements each; the third pointer may be NULL in 2D. */
+jrx_status jrx_velocity2displacement(jrx_handle *h, double *const U[3], const double *const V[3], const int64_t n[3], double dt);
+jrx_status jrx_displacement2velocity(jrx_handle *h, double *const V[3], const double *const U[3], const int64_t n[3], double dt);
+/* dt = min(dt_diff, 0.9 * min_d(di[d] / max|V_d|)); max over all ranks when a communicator is active; dt_diff = INFINITY to ignore */
+jrx_status jrx_compute_dt(jrx_handle *h, const double *const V[3], const int64_t n[3], const double di[3], int32_t ndim, double dt_diff, double *dt_out);
+
 /* ------------------------------------------------------------------ post-loop epilogue operators, stand-alone
  * The VEP drivers run these themselves (Stokes2D.jl:831-846, Stokes3D.jl:640-658); time-stepping scripts also call them directly. */
 /* shear2center!(A): shear components averaged to the cell centres -- Interpolations.jl:291-323 */

@@ -119,13 +119,16 @@ bool jrx_comm_active(const jrx_handle *h)
 }
 int jrx_comm_rank(const jrx_handle *h) { return (h && h->comm) ? h->comm->cart.rank : 0; }
 
-jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count)
+jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count) { return jrx_allreduce_host(h, vals, count, 0); }
+
+// op: 0 sum (norm_mpi), 1 max (maximum_mpi)
+jrx_status jrx_allreduce_host(jrx_handle *h, double *vals, int count, int op)
 {
     if (!jrx_comm_active(h) || !h->comm->comm || h->comm->cart.nprocs == 1) return JRX_OK;
     jrx_comm_state *c = h->comm;
     if (count > 8) return jrx_fail(h, JRX_ERR_ARG, "allreduce of more than 8 values");
     JRX_HIP(h, hipMemcpyAsync(c->d_red, vals, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    JRX_NCCL(h, c, c->AllReduce(c->d_red, c->d_red, (size_t)count, ncclDouble, ncclSum, c->comm, h->stream));
+    JRX_NCCL(h, c, c->AllReduce(c->d_red, c->d_red, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, h->stream));
     JRX_HIP(h, hipMemcpyAsync(h->h_sums, c->d_red, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < count; i++) vals[i] = h->h_sums[i];

@@ -91,6 +91,7 @@ jrx_status jrx_halo_exchange(jrx_handle *h, hipStream_t s, int narrays, double *
 bool jrx_comm_active(const jrx_handle *h);
 // all-reduce (sum) of `count` doubles in place on the host values (uses RCCL when active)
 jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count);
+jrx_status jrx_allreduce_host(jrx_handle *h, double *vals, int count, int op);   // op: 0 sum, 1 max
 int jrx_comm_rank(const jrx_handle *h);
 
 // stokes3d.hip: pieces of the 3D visco-elastic path that the 3D VEP driver (stokes3d_vep.hip) reuses.  Asynchronous on `s`.

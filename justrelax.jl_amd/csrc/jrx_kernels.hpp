@@ -157,6 +157,58 @@ __global__ __launch_bounds__(256) void k_sumsq_final(const double *__restrict__ 
     }
 }
 
+// max |x| of up to three arrays (compute_dt, Utils.jl:512-519): per-block partial maxima [block][4], then one block reduces them
+__global__ __launch_bounds__(256) void k_maxabs_partial(const double *__restrict__ A0, i64 n0, const double *__restrict__ A1, i64 n1,
+                                                        const double *__restrict__ A2, i64 n2, double *__restrict__ partials)
+{
+    __shared__ double sm[3][4];
+    const double *A[3] = {A0, A1, A2};
+    const i64 n[3] = {n0, n1, n2};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double m = 0.0;
+        if (A[c])
+            for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n[c]; t += stride) {
+                const double v = fabs(A[c][t]);
+                m = (v > m || v != v) ? v : m;          // NaN propagates, as maximum(abs.(x)) does
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_down(m, off, 64);
+            m = (o > m || o != o) ? o : m;
+        }
+        if (lane == 0) sm[c][wave] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        double m = sm[c][0];
+        for (int w = 1; w < 4; w++) m = (sm[c][w] > m || sm[c][w] != sm[c][w]) ? sm[c][w] : m;
+        partials[(i64)blockIdx.x * 4 + c] = m;
+    }
+}
+__global__ __launch_bounds__(256) void k_maxabs_final(const double *__restrict__ partials, int nblocks, double *__restrict__ out)
+{
+    __shared__ double sm[3][256];
+    for (int c = 0; c < 3; c++) {
+        double m = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+            const double v = partials[(i64)b * 4 + c];
+            m = (v > m || v != v) ? v : m;
+        }
+        sm[c][threadIdx.x] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        double m = 0.0;
+        for (int t = 0; t < 256; t++) m = (sm[c][t] > m || sm[c][t] != sm[c][t]) ? sm[c][t] : m;
+        out[c] = m;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy6(double *d0, const double *s0, i64 n0, double *d1, const double *s1, i64 n1,
                                                double *d2, const double *s2, i64 n2, double *d3, const double *s3, i64 n3,
                                                double *d4, const double *s4, i64 n4, double *d5, const double *s5, i64 n5)

@@ -265,6 +265,46 @@ jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value)
     return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: unknown key '%s'", key);
 }
 
+// velocity2displacement!(stokes, dt): U = V * dt ; displacement2velocity!(stokes, dt): V = U * inv(dt)   (types/displacement.jl:2-60)
+jrx_status jrx_velocity2displacement(jrx_handle *h, double *const U[3], const double *const V[3], const int64_t n[3], double dt)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!U || !V || !n || !U[0] || !U[1] || !V[0] || !V[1]) return jrx_fail(h, JRX_ERR_ARG, "velocity2displacement!: null argument");
+    hipLaunchKernelGGL(k_scale3, dim3(2048), dim3(256), 0, h->stream, U[0], V[0], (i64)n[0], U[1], V[1], (i64)n[1], U[2], V[2], (i64)(U[2] ? n[2] : 0), dt);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+jrx_status jrx_displacement2velocity(jrx_handle *h, double *const V[3], const double *const U[3], const int64_t n[3], double dt)
+{
+    return jrx_velocity2displacement(h, V, U, n, 1.0 / dt);
+}
+
+// compute_dt(stokes, di[, dt_diff][, igg]) = min(dt_diff, 0.9 * min_d(di[d] * inv(max|V_d|)))   (Utils.jl:492-519); the maximum is
+// all-reduced over the ranks when a communicator is active (maximum_mpi)
+jrx_status jrx_compute_dt(jrx_handle *h, const double *const V[3], const int64_t n[3], const double di[3], int32_t ndim, double dt_diff, double *dt_out)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!V || !n || !di || !dt_out || ndim < 2 || ndim > 3 || !V[0] || !V[1] || (ndim == 3 && !V[2])) return jrx_fail(h, JRX_ERR_ARG, "compute_dt: bad argument");
+    i64 nmax = 0;
+    for (int d = 0; d < ndim; d++) nmax = n[d] > nmax ? (i64)n[d] : nmax;
+    int nb = (int)((nmax + 2047) / 2048);
+    nb = nb < 1 ? 1 : (nb > kMaxRedBlocks ? kMaxRedBlocks : nb);
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL(k_maxabs_partial, dim3(nb), dim3(256), 0, s, V[0], (i64)n[0], V[1], (i64)n[1], ndim == 3 ? V[2] : (const double *)nullptr,
+                       (i64)(ndim == 3 ? n[2] : 0), h->d_partials);
+    hipLaunchKernelGGL(k_maxabs_final, dim3(1), dim3(256), 0, s, h->d_partials, nb, h->d_sums);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    JRX_HIP(h, hipStreamSynchronize(s));
+    double m[3] = {h->h_sums[0], h->h_sums[1], h->h_sums[2]};
+    JRX_TRY(jrx_allreduce_host(h, m, ndim, 1));
+    double dt_adv = INFINITY;
+    for (int d = 0; d < ndim; d++) dt_adv = fmin(dt_adv, di[d] * (1.0 / m[d]));
+    *dt_out = fmin(dt_diff, dt_adv * 0.9);
+    return JRX_OK;
+}
+
 jrx_status jrx_compute_maxloc(jrx_handle *h, double *B, const double *A, int64_t nx, int64_t ny, int64_t nz)
 {
     if (!h) return JRX_ERR_ARG;

@@ -293,6 +293,53 @@ def center2vertex_(vertex, center, *, handle=None):
     h.call("jrx_center2vertex2d", C.c_void_p(ptr(vertex)), C.c_void_p(ptr(center)), C.c_int64(center.shape[0]), C.c_int64(center.shape[1]))
 
 
+def _vel_triplets(stokes):
+    V, U = stokes.V, stokes.U
+    three = len(stokes._ni) == 3
+    vs = [V.Vx, V.Vy] + ([V.Vz] if three else [None])
+    us = [U.Ux, U.Uy] + ([U.Uz] if three else [None])
+    arr = lambda ts: (C.c_void_p * 3)(*[ptr(t) for t in ts])
+    n = (C.c_int64 * 3)(*[(t.numel() if t is not None else 0) for t in vs])
+    return arr(vs), arr(us), n
+
+
+def velocity2displacement_(stokes, dt, *, handle=None):
+    """velocity2displacement!(stokes, dt): U = V·dt -- types/displacement.jl:2-28"""
+    _require_gpu(stokes)
+    h = handle or _lib.default_handle(stokes.P.device.index)
+    v, u, n = _vel_triplets(stokes)
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    h.call("jrx_velocity2displacement", u, v, n, C.c_double(float(dt)))
+
+
+def displacement2velocity_(stokes, dt, bcs=None, *, handle=None):
+    """displacement2velocity!(stokes, dt[, flow_bcs]): V = U·inv(dt); a no-op for VelocityBoundaryConditions -- types/displacement.jl:32-70"""
+    from .arrays import DisplacementBoundaryConditions, VelocityBoundaryConditions
+    if isinstance(bcs, VelocityBoundaryConditions):
+        return
+    if bcs is not None and not isinstance(bcs, DisplacementBoundaryConditions):
+        raise TypeError(f"Unknown boundary conditions type: {type(bcs).__name__}")
+    _require_gpu(stokes)
+    h = handle or _lib.default_handle(stokes.P.device.index)
+    v, u, n = _vel_triplets(stokes)
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    h.call("jrx_displacement2velocity", v, u, n, C.c_double(float(dt)))
+
+
+def compute_dt_(stokes, di, dt_diff=float("inf"), igg=None, *, handle=None):
+    """compute_dt(stokes, di[, dt_diff][, igg]) = min(dt_diff, 0.9·min_d(di[d]/max|V_d|)) -- Utils.jl:492-519 (the maximum is taken over all
+    ranks whenever the handle has a communicator, i.e. the `igg` forms)"""
+    _require_gpu(stokes)
+    h = handle or _lib.default_handle(stokes.P.device.index)
+    v, _, n = _vel_triplets(stokes)
+    nd = len(stokes._ni)
+    d = (C.c_double * 3)(*[float(x) for x in tuple(di)[:nd]], *([0.0] * (3 - nd)))
+    out = C.c_double(0.0)
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    h.call("jrx_compute_dt", v, n, d, C.c_int32(nd), C.c_double(float(dt_diff)), C.byref(out))
+    return out.value
+
+
 def shear2center_(A, *, handle=None):
     """shear2center!(A::SymmetricTensor) -- Interpolations.jl:291-323"""
     _require_gpu(A.xx)

@@ -196,3 +196,31 @@ def test_diffusion2d_reference_test(env):
     T = jr.to_numpy(thermal.T)
     assert T[17, 17] == pytest.approx(1817.9448461176817, abs=1.0e-1)
     assert T[16, 16] == pytest.approx(1827.4674313638786, abs=1.0e-1)
+
+
+def test_compute_dt_and_displacement_conversions_known_answers(env):
+    """test/test_Utils.jl:145-149: ni = (4, 4), li = (1, 1), Vy = 10 everywhere: compute_dt(stokes, di, 0.1[, igg]) === 0.022500000000000003,
+    compute_dt(stokes, di) ≈ the same; velocity2displacement! / displacement2velocity! (types/displacement.jl:2-60) are exact scalings"""
+    jr, st = env["jr"], env["st"]
+    stokes = jr.StokesArrays(jr.AMDGPUBackend, (4, 4))
+    stokes.V.Vy.fill_(10.0)
+    di = (0.25, 0.25)
+    assert st.compute_dt_(stokes, di, 0.1) == 0.022500000000000003
+    assert st.compute_dt_(stokes, di, 0.1, igg=object()) == 0.022500000000000003
+    assert st.compute_dt_(stokes, di) == pytest.approx(0.022500000000000003)
+    assert st.compute_dt_(stokes, di, 0.01) == 0.01
+    rng = np.random.default_rng(0)
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy
+    vx, vy = rng.standard_normal((5, 6)), rng.standard_normal((6, 5))
+    stokes.V.Vx.copy_(from_numpy(vx, stokes.P.device)); stokes.V.Vy.copy_(from_numpy(vy, stokes.P.device))
+    st.velocity2displacement_(stokes, 0.3)
+    assert np.array_equal(jr.to_numpy(stokes.U.Ux), vx * 0.3) and np.array_equal(jr.to_numpy(stokes.U.Uy), vy * 0.3)
+    stokes.V.Vx.zero_(); stokes.V.Vy.zero_()
+    st.displacement2velocity_(stokes, 0.3, jr.VelocityBoundaryConditions())            # no-op for velocity BCs
+    assert not jr.to_numpy(stokes.V.Vx).any()
+    st.displacement2velocity_(stokes, 0.3, jr.DisplacementBoundaryConditions())
+    assert np.array_equal(jr.to_numpy(stokes.V.Vx), (vx * 0.3) * (1.0 / 0.3))
+    s3 = jr.StokesArrays(jr.AMDGPUBackend, (4, 5, 6))
+    s3.V.Vz.fill_(-2.0); s3.V.Vx[2, 3, 1] = 8.0
+    assert st.compute_dt_(s3, (0.5, 0.5, 0.1)) == min(0.5 * (1.0 / 8.0), 0.1 * (1.0 / 2.0)) * 0.9
