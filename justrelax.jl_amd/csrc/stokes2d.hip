@@ -15,6 +15,7 @@ struct Args2 {
     const double *etatau;
     double _dx, _dy, dt, r, theta_dtau, eta_dtau;
     int nx, ny;
+    unsigned fs, ns;      // free_slip / no_slip face masks for the velocity kernel's fused ghost update (BCF)
 };
 
 #define VX(i_, j_) Vx[(i_) + (i64)(nx + 1) * (j_)]
@@ -68,8 +69,11 @@ __global__ __launch_bounds__(256) void k_stress2d(const Args2 a)
     }
 }
 
-// compute_V! (VelocityKernels.jl:108-131); RES additionally stores compute_Res! (:246-269) values
-template <bool RES_ONLY>
+// compute_V! (VelocityKernels.jl:108-131); RES_ONLY stores compute_Res! (:246-269) values instead.
+// BCF: the thread that updates a velocity node next to a free-slip / no-slip face also refreshes that node's ghost copy
+// (free_slip.jl:1-13, no_slip.jl:1-18), which is all flow_bcs! changes once it has been applied in full one time: the other ghost
+// and boundary values it writes are copies of nodes compute_V! never updates.  Saves the flow_bcs! launches of the launch-bound loop.
+template <bool RES_ONLY, bool BCF = false>
 __global__ __launch_bounds__(256) void k_velocity2d(const Args2 a)
 {
     const int nx = a.nx, ny = a.ny;
@@ -84,13 +88,29 @@ __global__ __launch_bounds__(256) void k_velocity2d(const Args2 a)
         const double dP = (-P[c] + P[c + 1]) * _dx, dT = (-a.f.txx[c] + a.f.txx[c + 1]) * _dx;
         const double dS = (-TXY(i + 1, j) + TXY(i + 1, j + 1)) * _dy, av = (a.f.fx[c] + a.f.fx[c + 1]) * 0.5;
         if (RES_ONLY) a.f.Rx[i + (i64)(nx - 1) * j] = dT + dS - dP - av;
-        else a.f.Vx[(i + 1) + (i64)(nx + 1) * (j + 1)] += (-dP + dT + dS - av) * edt / ((et[c] + et[c + 1]) * 0.5);
+        else {
+            const i64 q = (i + 1) + (i64)(nx + 1) * (j + 1);
+            const double v = a.f.Vx[q] + (-dP + dT + dS - av) * edt / ((et[c] + et[c + 1]) * 0.5);
+            a.f.Vx[q] = v;
+            if (BCF) {      // Vx ghost rows j = 0 (bot) and j = ny+1 (top)
+                if (j == 0) { if (a.fs & JRX_FACE_BOT) a.f.Vx[q - (nx + 1)] = v; else if (a.ns & JRX_FACE_BOT) a.f.Vx[q - (nx + 1)] = -v; }
+                if (j == ny - 1) { if (a.fs & JRX_FACE_TOP) a.f.Vx[q + (nx + 1)] = v; else if (a.ns & JRX_FACE_TOP) a.f.Vx[q + (nx + 1)] = -v; }
+            }
+        }
     }
     if (j < ny - 1) {
         const double dP = (-P[c] + P[c + nx]) * _dy, dT = (-a.f.tyy[c] + a.f.tyy[c + nx]) * _dy;
         const double dS = (-TXY(i, j + 1) + TXY(i + 1, j + 1)) * _dx, av = (a.f.fy[c] + a.f.fy[c + nx]) * 0.5;
         if (RES_ONLY) a.f.Ry[c] = dT + dS - dP - av;
-        else a.f.Vy[(i + 1) + (i64)(nx + 2) * (j + 1)] += (-dP + dT + dS - av) * edt / ((et[c] + et[c + nx]) * 0.5);
+        else {
+            const i64 q = (i + 1) + (i64)(nx + 2) * (j + 1);
+            const double v = a.f.Vy[q] + (-dP + dT + dS - av) * edt / ((et[c] + et[c + nx]) * 0.5);
+            a.f.Vy[q] = v;
+            if (BCF) {      // Vy ghost columns i = 0 (left) and i = nx+1 (right)
+                if (i == 0) { if (a.fs & JRX_FACE_LEFT) a.f.Vy[q - 1] = v; else if (a.ns & JRX_FACE_LEFT) a.f.Vy[q - 1] = -v; }
+                if (i == nx - 1) { if (a.fs & JRX_FACE_RIGHT) a.f.Vy[q + 1] = v; else if (a.ns & JRX_FACE_RIGHT) a.f.Vy[q + 1] = -v; }
+            }
+        }
     }
 #undef TXY
 }
@@ -104,6 +124,7 @@ Args2 make_args2(const jrx_stokes2d_fields *f, const double *etatau, const jrx_s
     a.f = *f; a.etatau = etatau;
     a._dx = p->_dx; a._dy = p->_dy; a.dt = p->dt; a.r = p->r; a.theta_dtau = p->theta_dtau; a.eta_dtau = p->eta_dtau;
     a.nx = (int)p->nx; a.ny = (int)p->ny;
+    a.fs = p->free_slip; a.ns = p->no_slip;
     return a;
 }
 
@@ -160,7 +181,10 @@ jrx_status launch_sumsq2(jrx_handle *h, hipStream_t s, const jrx_stokes2d_fields
     return JRX_OK;
 }
 
-jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const double *etatau, const jrx_stokes2d_params *p, bool diag)
+// fuse_bc: flow_bcs! has already been applied in full once in this solve, nothing observes U in this iteration and no face is
+// periodic, so the velocity kernel refreshes the ghosts itself
+jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const double *etatau, const jrx_stokes2d_params *p, bool diag,
+                              bool fuse_bc = false)
 {
     const int nx = (int)p->nx, ny = (int)p->ny;
     Args2 a = make_args2(f, etatau, p);
@@ -169,6 +193,11 @@ jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const
     if (diag) hipLaunchKernelGGL(k_stress2d<true>, dim3(gA), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_stress2d<false>, dim3(gA), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
+    if (fuse_bc && !diag && p->periodic == 0 && !jrx_comm_active(h)) {
+        hipLaunchKernelGGL((k_velocity2d<false, true>), dim3(gB), dim3(256), 0, s, a);
+        JRX_LAUNCH_CHECK(h);
+        return JRX_OK;
+    }
     hipLaunchKernelGGL(k_velocity2d<false>, dim3(gB), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     if (diag) {
@@ -278,7 +307,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
         const int64_t it1 = iter + 1;
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);
-        JRX_TRY(enqueue_iteration2(h, f, h->etatau, p, diag));
+        JRX_TRY(enqueue_iteration2(h, f, h->etatau, p, diag, iter >= 1));
         iter = it1;
         if (check) {
             hipLaunchKernelGGL(k_velocity2d<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);   // compute_Res! (Stokes2D.jl:274-276)
@@ -893,7 +922,15 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
         }
         hipLaunchKernelGGL(k_vep_visc, dim3(gv), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
-        hipLaunchKernelGGL(k_velocity2d<false>, dim3(gc), dim3(256), 0, s, b);     // compute_V! (free-surface form with dt*free_surface = 0)
+        const bool bcf = iter >= 1 && p->periodic == 0 && !comm;      // flow_bcs! applied in full by iteration 1: refresh ghosts in-kernel
+        bool used_bcf = false;
+        {
+            const bool next_check = ((iter + 1) % p->nout == 0) && iter + 1 > 1;
+            const bool next_last = next_check || iter + 1 > p->iterMax || (p->iterMin < iter + 1 && ((err / err_it1) < p->eps_rel || err < p->eps_abs));
+            used_bcf = bcf && !next_last;
+            if (used_bcf) hipLaunchKernelGGL((k_velocity2d<false, true>), dim3(gc), dim3(256), 0, s, b);
+            else hipLaunchKernelGGL(k_velocity2d<false>, dim3(gc), dim3(256), 0, s, b);     // compute_V! (free-surface form with dt*free_surface = 0)
+        }
         JRX_LAUNCH_CHECK(h);
         iter += 1;
         const bool check = (iter % p->nout == 0) && iter > 1;
@@ -904,7 +941,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                                (const double *)f->Vy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, p->dt);
             JRX_LAUNCH_CHECK(h);
         }
-        JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+        if (!used_bcf) JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
         if (comm) {   // update_halo!(@velocity(stokes)...) (Stokes2D.jl:784)
             double *arrs[2] = {f->Vx, f->Vy};
             const int64_t ext[2][3] = {{nx + 1, ny + 2, 1}, {nx + 2, ny + 1, 1}};

@@ -11,6 +11,7 @@
 // outputs ∇V, ε, RP, R, U are only written on iterations whose results can be observed (norm
 // checks and the last iteration).  Pure HBM-bandwidth-bound fp64 stencils: no MFMA.
 #include <vector>
+#include <cstdlib>
 #include "jrx_internal.hpp"
 #include "jrx_kernels.hpp"
 #include "stokes3d_kernels.hpp"
@@ -452,8 +453,9 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
     }
     // @hide_communication b_width (Stokes3D.jl:104-121): boundary slabs of width b first on the halo
     // stream, then BCs + neighbour exchange there while the interior runs on the compute stream.
-    const int bx = p->b_width[0] > 0 ? p->b_width[0] : 4, by = p->b_width[1] > 0 ? p->b_width[1] : 4,
-              bz = p->b_width[2] > 0 ? p->b_width[2] : 4;
+    int bx = p->b_width[0] > 0 ? p->b_width[0] : 4, by = p->b_width[1] > 0 ? p->b_width[1] : 4,
+        bz = p->b_width[2] > 0 ? p->b_width[2] : 4;
+    if (const char *e = getenv("JRX_BWIDTH")) sscanf(e, "%d,%d,%d", &bx, &by, &bz);       // tuning override (the split does not change results)
     const int xa = bx < nx / 2 ? bx : nx / 2, ya = by < ny / 2 ? by : ny / 2, za = bz < nz / 2 ? bz : nz / 2;
     hipStream_t hs = h->halo_stream;
     JRX_HIP(h, hipEventRecord(h->ev[0], s));

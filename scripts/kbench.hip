@@ -266,8 +266,8 @@ int main(int argc, char **argv)
         snprintf(nm, 80, "fused %dx%dx%d minw%d ovx%d lowreg%d xg%d latea%d", TX, TY, KZ, MW, OV, (int)LR, XG, (int)LA); \
         report(nm, T.run(reps, fn), 360.0, 0);                                                                      \
     }
-        FUSED2(64, 4, 16, 2, 1, false, 8, false) FUSED2(64, 4, 16, 2, 1, false, 8, true) FUSED2(64, 4, 16, 4, 1, false, 8, true) FUSED2(64, 4, 16, 4, 1, true, 8, true)
-        FUSED2(64, 4, 16, 3, 1, true, 8, true) FUSED2(64, 8, 16, 4, 1, true, 8, true) FUSED2(64, 4, 8, 4, 1, true, 8, true) FUSED2(64, 4, 32, 4, 1, true, 8, true)
+        FUSED2(64, 4, 16, 2, 1, false, 8, false) FUSED2(128, 8, 16, 4, 16, true, 8, true) FUSED2(128, 4, 16, 4, 16, true, 8, true) FUSED2(128, 8, 16, 4, 1, true, 8, true)
+        FUSED2(128, 4, 16, 4, 1, true, 8, true) FUSED2(64, 8, 16, 4, 1, true, 8, true) FUSED2(256, 4, 16, 4, 16, true, 8, true) FUSED2(128, 8, 8, 4, 16, true, 8, true)
     }
     printf("done\n");
     return 0;
