@@ -59,8 +59,33 @@ __global__ __launch_bounds__(256) void k_flux2d(const TArgs a)
     }
 }
 
-// update_T! (RES=false) / check_res! (RES=true) over ni
-template <bool RES>
+// thermal_bcs! restricted to the ghost cells next to one interior cell: the reference's statement order (constant_value rows, columns;
+// no_flux rows, columns -- BoundaryConditions.jl:46-54, constant_value.jl:1-13, free_slip.jl:72-84) replayed on the 2 x 2 patch
+// {corner ghost c, row ghost r, column ghost l, interior m}.  xs/ys: which column / row face the cell touches (0 low, 1 high, -1 none).
+__device__ __forceinline__ void thermal_ghosts2d(const jrx_thermal2d_params &p, double *__restrict__ T, int n1, i64 I1, int xs, int ys, double m)
+{
+    const int fx = xs < 0 ? -1 : (xs == 0 ? TL : TR), fy = ys < 0 ? -1 : (ys == 0 ? TB : TT);
+    const i64 dl = xs == 0 ? -1 : 1, dr = ys == 0 ? -(i64)n1 : (i64)n1;      // offsets to the column ghost / row ghost
+    double l = fx >= 0 ? T[I1 + dl] : 0.0, r = fy >= 0 ? T[I1 + dr] : 0.0, c = (fx >= 0 && fy >= 0) ? T[I1 + dl + dr] : 0.0;
+    bool wl = false, wr = false, wc = false;
+    for (int step = 0; step < 2; step++) {
+        const int32_t *on = step == 0 ? p.constant_value_on : p.no_flux;
+        if (fy >= 0 && on[fy]) {         // rows (bot / top): T[i, ghost] for every i, including the ghost column
+            if (fx >= 0) { c = step == 0 ? 2 * p.constant_value[fy] - l : l; wc = true; }
+            r = step == 0 ? 2 * p.constant_value[fy] - m : m; wr = true;
+        }
+        if (fx >= 0 && on[fx]) {         // columns (left / right): T[ghost, j] for every j, including the ghost row
+            if (fy >= 0) { c = step == 0 ? 2 * p.constant_value[fx] - r : r; wc = true; }
+            l = step == 0 ? 2 * p.constant_value[fx] - m : m; wl = true;
+        }
+    }
+    if (wl) T[I1 + dl] = l;
+    if (wr) T[I1 + dr] = r;
+    if (wc) T[I1 + dl + dr] = c;
+}
+
+// update_T! (RES=false) / check_res! (RES=true) over ni; BCF: cells next to a face also apply thermal_bcs! to their ghosts
+template <bool RES, bool BCF = false>
 __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a)
 {
     const int nx = (int)a.p.nx, ny = (int)a.p.ny;
@@ -80,7 +105,12 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a)
         const double dr = a.t.dtau_rho[c];
         const double divq = (a.t.qTx[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx[i + (i64)(nx + 1) * j]) * a.p._dx +
                             (a.t.qTy[i + (i64)nx * (j + 1)] - a.t.qTy[c]) * a.p._dy;
-        a.t.T[I1] = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+        const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+        a.t.T[I1] = Tn;
+        if (BCF) {
+            const int xs = i == 0 ? 0 : (i == nx - 1 ? 1 : -1), ys = j == 0 ? 0 : (j == ny - 1 ? 1 : -1);
+            if (xs >= 0 || ys >= 0) thermal_ghosts2d(a.p, a.t.T, nx + 2, I1, xs, ys, Tn);
+        }
     }
 }
 
@@ -176,7 +206,8 @@ jrx_status launch_tbcs(jrx_handle *h, hipStream_t s, double *T, const jrx_therma
     return JRX_OK;
 }
 
-jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p)
+// fuse_bc: thermal_bcs! refreshed by the update kernel itself (no periodic face, no neighbour rank, grid at least 2 cells wide)
+jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p, bool fuse_bc = false)
 {
     TArgs a;
     a.t = *t; a.p = *p;
@@ -184,6 +215,12 @@ jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx
     hipStream_t s = h->stream;
     hipLaunchKernelGGL(k_flux2d, dim3((unsigned)(((i64)(nx + 1) * (ny + 1) + 255) / 256)), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
+    const bool any_periodic = p->periodic[0] | p->periodic[1] | p->periodic[2] | p->periodic[3];
+    if (fuse_bc && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2) {
+        hipLaunchKernelGGL((k_updateT2d<false, true>), dim3((unsigned)(((i64)nx * ny + 255) / 256)), dim3(256), 0, s, a);
+        JRX_LAUNCH_CHECK(h);
+        return JRX_OK;
+    }
     hipLaunchKernelGGL(k_updateT2d<false>, dim3((unsigned)(((i64)nx * ny + 255) / 256)), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     JRX_TRY(launch_tbcs(h, s, t->T, p));
@@ -243,7 +280,7 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
     TArgs a;
     a.t = *t; a.p = *p;
     while (err > p->eps && iter < p->iterMax) {
-        JRX_TRY(enqueue_titer(h, t, p));
+        JRX_TRY(enqueue_titer(h, t, p, true));
         iter++;
         if (iter % p->nout == 0) {
             hipLaunchKernelGGL(k_updateT2d<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
