@@ -80,8 +80,41 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
     }
 }
 
-// update_T! (RES=false) / check_res! (RES=true) over ni
-template <bool RES>
+// thermal_bcs! 3D restricted to the ghost cells around one interior cell that touches faces in the dimensions of `mask` (bit d): the
+// reference's statement order (per BC type: z faces, x faces, y faces -- constant_value.jl:15-33, free_slip.jl:86-103) replayed on the
+// 2 x 2 x 2 patch v[b], b = ghost bits (x, y, z); v[0] is the interior value.  side[d]: 0 low face, 1 high face.
+__device__ __forceinline__ void thermal_ghosts3d(const jrx_thermal3d_params &p, double *__restrict__ T, const i64 st[3], i64 I1, int mask, const int side[3], double m)
+{
+    const int face[3] = {side[0] ? XR : XL, side[1] ? YB : YF, side[2] ? ZT : ZB};
+    const i64 off[3] = {side[0] ? st[0] : -st[0], side[1] ? st[1] : -st[1], side[2] ? st[2] : -st[2]};
+    double v[8];
+    bool w[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        w[b] = false;
+        v[b] = m;
+        if (b != 0 && (b & ~mask) == 0) v[b] = T[I1 + ((b & 1) ? off[0] : 0) + ((b & 2) ? off[1] : 0) + ((b & 4) ? off[2] : 0)];
+    }
+    const int order[3] = {2, 0, 1};
+    for (int step = 0; step < 2; step++) {
+        const int32_t *on = step == 0 ? p.constant_value_on : p.no_flux;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int d = order[q];
+            if (!((mask >> d) & 1) || !on[face[d]]) continue;
+            const double cv2 = 2 * p.constant_value[face[d]];
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+                if (((b >> d) & 1) && (b & ~mask) == 0) { const double src = v[b ^ (1 << d)]; v[b] = step == 0 ? cv2 - src : src; w[b] = true; }
+        }
+    }
+#pragma unroll
+    for (int b = 1; b < 8; b++)
+        if (w[b]) T[I1 + ((b & 1) ? off[0] : 0) + ((b & 2) ? off[1] : 0) + ((b & 4) ? off[2] : 0)] = v[b];
+}
+
+// update_T! (RES=false) / check_res! (RES=true) over ni; BCF: cells next to a face also apply thermal_bcs! to their ghosts
+template <bool RES, bool BCF = false>
 __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a)
 {
     const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
@@ -99,7 +132,16 @@ __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a)
         a.t.ResT[c] = -rcp * (Tc - a.t.Told[I1]) * _dt - divq + a.t.H[c] + a.t.shear_heating[c];
     } else {
         const double dr = a.t.dtau_rho[c];
-        a.t.T[I1] = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+        const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+        a.t.T[I1] = Tn;
+        if (BCF) {
+            const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
+            const int mask = ((i == 0 || i == nx - 1) ? 1 : 0) | ((j == 0 || j == ny - 1) ? 2 : 0) | ((k == 0 || k == nz - 1) ? 4 : 0);
+            if (mask) {
+                const i64 st[3] = {1, nx + 2, (i64)(nx + 2) * (ny + 2)};
+                thermal_ghosts3d(a.p, a.t.T, st, I1, mask, side, Tn);
+            }
+        }
     }
 }
 
@@ -168,7 +210,7 @@ jrx_status launch_tbcs3(jrx_handle *h, hipStream_t s, double *T, const jrx_therm
     return JRX_OK;
 }
 
-jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, bool q2 = true)
+jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, bool q2 = true, bool fuse_bc = false)
 {
     T3Args a;
     a.t = *t; a.p = *p;
@@ -177,6 +219,13 @@ jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jr
     if (q2) hipLaunchKernelGGL(k_flux3d<true>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_flux3d<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
+    bool any_periodic = false;
+    for (int q = 0; q < 6; q++) any_periodic |= p->periodic[q] != 0;
+    if (fuse_bc && !any_periodic && !jrx_comm_active(h)) {        // thermal_bcs! refreshed by the update kernel itself
+        hipLaunchKernelGGL((k_updateT3d<false, true>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
+        JRX_LAUNCH_CHECK(h);
+        return JRX_OK;
+    }
     hipLaunchKernelGGL(k_updateT3d<false>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     JRX_TRY(launch_tbcs3(h, s, t->T, p));
@@ -238,7 +287,7 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
     while (err > p->eps && iter < p->iterMax) {
         // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one
         const bool q2 = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
-        JRX_TRY(enqueue_titer3(h, t, p, q2));
+        JRX_TRY(enqueue_titer3(h, t, p, q2, true));
         iter++;
         if (iter % p->nout == 0) {
             hipLaunchKernelGGL(k_updateT3d<true>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);

@@ -76,10 +76,9 @@ def test_thermal3d_iterations_match_oracle(jr, oracle, form):
     r = jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, A, B, s.dt, s.grid, kwargs=dict(iterMax=300, nout=100, verbose=False))
     assert list(r.iter_count) == list(r_ref["iter_count"]) == [100, 200, 300]
     assert np.allclose(r.norm_ResT, r_ref["norm_ResT"], rtol=1e-9)
-    m = _face_mask(ref["T"].shape)
     for name, t in (("T", thermal.T), ("Told", thermal.Told), ("dT", thermal.ΔT)):
-        got = jr.to_numpy(t)
-        assert np.abs(got - ref[name])[m].max() <= TOL_ITERS * np.abs(ref[name]).max(), name
+        got = jr.to_numpy(t)          # whole arrays: the in-kernel BC replay must reproduce the ghost edges and corners as well
+        assert np.abs(got - ref[name]).max() <= TOL_ITERS * np.abs(ref[name]).max(), name
     for name, t in (("qTx", thermal.qTx), ("qTy", thermal.qTy), ("qTz", thermal.qTz), ("qTz2", thermal.qTz2), ("ResT", thermal.ResT)):
         assert max_rel_diff(jr.to_numpy(t), ref[name]) <= TOL_ITERS, name
 
