@@ -278,7 +278,7 @@ int main(int argc, char **argv)
         snprintf(nm, 64, "fused 64x4x16 xg8 ablation EXP=%d", EX);                                                  \
         report(nm, T.run(reps, fn), 360.0, 0);                                                                      \
     }
-        FEXP(0) FEXP(1) FEXP(2) FEXP(3) FEXP(16) FEXP(32) FEXP(48) FEXP(0)
+        FEXP(0) FEXP(64) FEXP(128) FEXP(192) FEXP(1) FEXP(0)
     }
     printf("done\n");
     return 0;
