@@ -369,9 +369,9 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     const Lay3 L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
     I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && !jrx_comm_active(h) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable && h->kernel_variant == 0) {
-        // auto: the fused kernel covers a row with ceil(nx/63) 64-lane tiles (one halo column each); when that
+        // auto: the fused kernel covers a row with ceil(nx/62) 64-lane tiles (one halo and one feeder lane each); when that
         // quantisation idles more than 15 % of the lanes (e.g. nx = 256: 5 tiles, 25 %) the two sweeps are faster
-        const i64 ntx = (p->nx + 62) / 63;
+        const i64 ntx = (p->nx + 61) / 62;
         if (ntx * 64 * 100 > (i64)p->nx * 115) I.fusable = false;
     }
     if (I.fusable) {
@@ -394,8 +394,9 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
 {
     // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
     // fetched array passes per launch at 512^3)
-    const int ntx = (a.L.nx + TX - 2) / (TX - 1), nty = (a.L.ny + TY - 2) / (TY - 1), ntz = (a.L.nz + KZ - 1) / KZ;
-    hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
+    // lane-shuffle form: 62 stress columns per 64-lane tile row (one halo lane on the left, one feeder lane on the right)
+    const int ntx = (a.L.nx + TX - 3) / (TX - 2), nty = (a.L.ny + TY - 2) / (TY - 1), ntz = (a.L.nz + KZ - 1) / KZ;
+    hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }

@@ -278,7 +278,16 @@ int main(int argc, char **argv)
         snprintf(nm, 64, "fused 64x4x16 xg8 ablation EXP=%d", EX);                                                  \
         report(nm, T.run(reps, fn), 360.0, 0);                                                                      \
     }
-        FEXP(0) FEXP(64) FEXP(128) FEXP(192) FEXP(1) FEXP(0)
+        FEXP(0)
+        {
+            const int ntx = (nx + 61) / 62, nty = (ny + 2) / 3, ntz = (nz + 15) / 16;
+            auto fn = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 8, false, true>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 xg8 SHFL (lane shuffles for x-neighbours)", T.run(reps, fn), 360.0, 0);
+            const int nty8 = (ny + 6) / 7;
+            auto fn8 = [&] { hipLaunchKernelGGL((k_fused3d<64, 8, 16, 2, 1, false, 8, false, true>), dim3(ntx * nty8 * ntz), dim3(512), 0, 0, b, bc, ntx, nty8); };
+            report("fused 64x8x16 xg8 SHFL", T.run(reps, fn8), 360.0, 0);
+        }
+        FEXP(0)
     }
     printf("done\n");
     return 0;
