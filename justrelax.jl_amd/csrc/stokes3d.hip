@@ -90,8 +90,8 @@ template <int TX, int TY, int KZ>
 jrx_status launch_stress_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag)
 {
     const TileMap tm = make_tilemap(a.L.nx, a.L.ny, a.L.nz, TX, TY, KZ);
-    if (diag) hipLaunchKernelGGL((k_stress3d_zb<true, TX, TY, KZ, 4, false, 8>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
-    else hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, 8>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    if (diag) hipLaunchKernelGGL((k_stress3d_zb<true, TX, TY, KZ, 4, false, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -100,8 +100,8 @@ template <int TX, int TY, int KZ>
 jrx_status launch_velocity_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag)
 {
     const TileMap tm = make_tilemap(a.i1 - a.i0, a.j1 - a.j0, a.k1 - a.k0, TX, TY, KZ);
-    if (diag) hipLaunchKernelGGL((k_velocity3d_zb<true, TX, TY, KZ, 4, 8>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
-    else hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, 4, 8>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    if (diag) hipLaunchKernelGGL((k_velocity3d_zb<true, TX, TY, KZ, 4, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, 4, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }

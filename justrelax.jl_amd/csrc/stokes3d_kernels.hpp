@@ -335,9 +335,12 @@ __device__ __forceinline__ bool tile_of_block(const TileMap &m, int &tx, int &ty
     return true;
 }
 
-template <bool DIAG, int TX, int TY, int KZ, int MINW, bool EDGES, int XCD = 0>
+// SHF: the x-neighbour operands (Vx at i+1; Vy, Vz, η, G at i-1) come from the adjacent lane; only the first / last lane of a
+// wave (and the last cell column) load them
+template <bool DIAG, int TX, int TY, int KZ, int MINW, bool EDGES, int XCD = 0, bool SHF = false>
 __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a, const TileMap tm)
 {
+    static_assert(!SHF || (TX % 64 == 0 && !EDGES), "SHF needs whole waves per row");
     const Lay3 &L = a.L;
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     int tx, ty, tz;
@@ -373,11 +376,26 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
     double g_p = LDB(f.G, oc - back), gx_p = LDB(f.G, oc - back - dcx), gy_p = LDB(f.G, oc - back - dcy);
 
     for (int k = kb; k < kend; ++k) {
-        const double va = LDB(f.Vx, ovx), vax = LDB(f.Vx, ovx + 8u), vay = LDB(f.Vx, ovx - rvx);
-        const double vb = LDB(f.Vy, ovy), vby = LDB(f.Vy, ovy + rvy), vbx = LDB(f.Vy, ovy - 8u);
-        const double vc = LDB(f.Vz, ovz), vcx = LDB(f.Vz, ovz - 8u), vcy = LDB(f.Vz, ovz - rvz);
-        const double e = LDB(f.eta, oc), ex = LDB(f.eta, oc - dcx), ey = LDB(f.eta, oc - dcy), exy_ = LDB(f.eta, oc - dcx - dcy);
-        const double g = LDB(f.G, oc), gx = LDB(f.G, oc - dcx), gy = LDB(f.G, oc - dcy), gxy = LDB(f.G, oc - dcx - dcy);
+        const double va = LDB(f.Vx, ovx), vay = LDB(f.Vx, ovx - rvx);
+        const double vb = LDB(f.Vy, ovy), vby = LDB(f.Vy, ovy + rvy);
+        const double vc = LDB(f.Vz, ovz), vcy = LDB(f.Vz, ovz - rvz);
+        const double e = LDB(f.eta, oc), ey = LDB(f.eta, oc - dcy);
+        const double g = LDB(f.G, oc), gy = LDB(f.G, oc - dcy);
+        double vax, vbx, vcx, ex, exy_, gx, gxy;
+        if (SHF) {
+            const int lane = (int)(threadIdx.x & 63);
+            vax = __shfl_down(va, 1, 64);
+            vbx = __shfl_up(vb, 1, 64); vcx = __shfl_up(vc, 1, 64);
+            ex = __shfl_up(e, 1, 64); exy_ = __shfl_up(ey, 1, 64); gx = __shfl_up(g, 1, 64); gxy = __shfl_up(gy, 1, 64);
+            if (lane == 63 || xhi) vax = LDB(f.Vx, ovx + 8u);
+            if (lane == 0) {
+                vbx = LDB(f.Vy, ovy - 8u); vcx = LDB(f.Vz, ovz - 8u);
+                ex = LDB(f.eta, oc - dcx); exy_ = LDB(f.eta, oc - dcx - dcy); gx = LDB(f.G, oc - dcx); gxy = LDB(f.G, oc - dcx - dcy);
+            }
+        } else {
+            vax = LDB(f.Vx, ovx + 8u); vbx = LDB(f.Vy, ovy - 8u); vcx = LDB(f.Vz, ovz - 8u);
+            ex = LDB(f.eta, oc - dcx); exy_ = LDB(f.eta, oc - dcx - dcy); gx = LDB(f.G, oc - dcx); gxy = LDB(f.G, oc - dcx - dcy);
+        }
         // issue the remaining independent loads of this plane early
         const double P = LDB(f.P, oc), P0 = LDB(f.P0, oc), Kc = LDB(f.K, oc), Qc = LDB(f.Q, oc);
         const double txx = LDB(f.txx, oc), tyy = LDB(f.tyy, oc), tzz = LDB(f.tzz, oc);
@@ -453,9 +471,12 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
     }
 }
 
-template <bool DIAG, int TX, int TY, int KZ, int MINW, int XCD = 0>
+// SHF: the operands at i+1 that the right-hand lane holds as its own (τxy(·,j+1), τxz, P, ητ, τxx, fx) come by lane shuffle; the last
+// lane of a wave and the last column of the (sub-)box load them
+template <bool DIAG, int TX, int TY, int KZ, int MINW, int XCD = 0, bool SHF = false>
 __global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs a, const TileMap tm)
 {
+    static_assert(!SHF || TX % 64 == 0, "SHF needs whole waves per row");
     const Lay3 &L = a.L;
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     int tx, ty, tz;
@@ -492,14 +513,26 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs 
     for (int k = kb; k < kend; ++k) {
         const bool hz = k < nz - 1;
         const u32 dz1 = hz ? sc : 0u;
-        const double q11 = LDB(f.txy, oxy + 8u + rxy), q10 = LDB(f.txy, oxy + 8u), q01 = LDB(f.txy, oxy + rxy);
-        const double s11 = LDB(f.txz, oxz + 8u), s01 = LDB(f.txz, oxz);
+        const double q10 = LDB(f.txy, oxy + 8u), q01 = LDB(f.txy, oxy + rxy);
+        const double s01 = LDB(f.txz, oxz);
         const double r11 = LDB(f.tyz, oyz + ryz), r01 = LDB(f.tyz, oyz);
         const double Pz = LDB(f.P, oc + dz1), ez = LDB(et, oc + dz1), tzz_z = LDB(f.tzz, oc + dz1), fz_z = LDB(f.fz, oc + dz1);
-        const double Px = LDB(f.P, oc + dx1), Py = LDB(f.P, oc + dy1), ex = LDB(et, oc + dx1), ey = LDB(et, oc + dy1);
-        const double txx_c = LDB(f.txx, oc), txx_x = LDB(f.txx, oc + dx1), tyy_c = LDB(f.tyy, oc), tyy_y = LDB(f.tyy, oc + dy1);
-        const double fx_c = LDB(f.fx, oc), fx_x = LDB(f.fx, oc + dx1), fy_c = LDB(f.fy, oc), fy_y = LDB(f.fy, oc + dy1);
+        const double Py = LDB(f.P, oc + dy1), ey = LDB(et, oc + dy1);
+        const double txx_c = LDB(f.txx, oc), tyy_c = LDB(f.tyy, oc), tyy_y = LDB(f.tyy, oc + dy1);
+        const double fx_c = LDB(f.fx, oc), fy_c = LDB(f.fy, oc), fy_y = LDB(f.fy, oc + dy1);
         const double vx = LDB(f.Vx, ovx), vy = LDB(f.Vy, ovy), vz = LDB(f.Vz, ovz);
+        double q11, s11, Px, ex, txx_x, fx_x;
+        if (SHF) {
+            q11 = __shfl_down(q01, 1, 64); s11 = __shfl_down(s01, 1, 64);
+            Px = __shfl_down(Pc, 1, 64); ex = __shfl_down(ec, 1, 64); txx_x = __shfl_down(txx_c, 1, 64); fx_x = __shfl_down(fx_c, 1, 64);
+            if ((threadIdx.x & 63) == 63 || i == a.i1 - 1) {
+                q11 = LDB(f.txy, oxy + 8u + rxy); s11 = LDB(f.txz, oxz + 8u);
+                Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = LDB(f.fx, oc + dx1);
+            }
+        } else {
+            q11 = LDB(f.txy, oxy + 8u + rxy); s11 = LDB(f.txz, oxz + 8u);
+            Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = LDB(f.fx, oc + dx1);
+        }
         if (hx) {
             const double R = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx - 0.5 * (fx_c + fx_x);
             STB(a.o.Vx, ovx, vx + R * edt / (0.5 * (ec + ex)));

@@ -194,11 +194,12 @@ int main(int argc, char **argv)
     };
     stress_v1(); CK(hipDeviceSynchronize()); saveref(sA);
     report("stress v1 (flat xy, 1 node/thread)", T.run(reps, stress_v1), 224.0, 0);
-#define STRESS_ZB(TX, TY, KZ, MW, ED, XM)                                                                              \
+#define STRESS_ZB(TX, TY, KZ, MW, ED, XM) STRESS_ZB2(TX, TY, KZ, MW, ED, XM, false)
+#define STRESS_ZB2(TX, TY, KZ, MW, ED, XM, SH)                                                                              \
     {                                                                                                               \
         TileMap tm = make_tilemap(nx, ny, nz, TX, TY, KZ);                                                          \
         auto fn = [&] {                                                                                             \
-            hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, MW, ED, XM>), dim3(tm.per * 8), dim3(TX * TY), 0, 0, a, tm); \
+            hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, MW, ED, XM, SH>), dim3(tm.per * 8), dim3(TX * TY), 0, 0, a, tm); \
             if (!ED) {                                                                                              \
                 SweepArgs b = a;                                                                                    \
                 b.i0 = nx; b.i1 = nx + 1; b.j0 = 0; b.j1 = ny + 1; b.k0 = 0; b.k1 = nz + 1;                         \
@@ -212,10 +213,10 @@ int main(int argc, char **argv)
         restore(sA); fn(); CK(hipDeviceSynchronize());                                                              \
         unsigned long long nd = ndiff(sA);                                                                          \
         char nm[64];                                                                                                \
-        snprintf(nm, 64, "stress zb %dx%dx%d minw%d e%d xcd%d", TX, TY, KZ, MW, (int)ED, (int)XM);                            \
+        snprintf(nm, 64, "stress zb %dx%dx%d minw%d e%d xcd%d shf%d", TX, TY, KZ, MW, (int)ED, (int)XM, (int)SH);                            \
         report(nm, T.run(reps, fn), 224.0, nd);                                                                     \
     }
-    STRESS_ZB(512, 1, 4, 4, false, 0) STRESS_ZB(512, 1, 4, 4, false, 8) STRESS_ZB(512, 1, 4, 4, false, 4) STRESS_ZB(512, 1, 4, 4, false, 16) STRESS_ZB(512, 1, 4, 4, false, 2)
+    STRESS_ZB(512, 1, 4, 4, false, 0) STRESS_ZB(512, 1, 4, 4, false, 8) STRESS_ZB2(512, 1, 4, 4, false, 8, true) STRESS_ZB2(256, 1, 8, 4, false, 8, true) STRESS_ZB(512, 1, 4, 4, false, 8) STRESS_ZB2(512, 1, 4, 4, false, 8, true)  STRESS_ZB(512, 1, 4, 4, false, 4) STRESS_ZB(512, 1, 4, 4, false, 16) STRESS_ZB(512, 1, 4, 4, false, 2)
     STRESS_ZB(512, 1, 8, 4, false, 8) STRESS_ZB(512, 1, 16, 4, false, 8) STRESS_ZB(256, 1, 8, 4, false, 0) STRESS_ZB(256, 1, 8, 4, false, 8) STRESS_ZB(256, 1, 16, 4, false, 8)
     STRESS_ZB(128, 2, 8, 4, false, 8) STRESS_ZB(128, 2, 16, 4, false, 4) STRESS_ZB(512, 1, 32, 4, false, 8)
     restore(sA);
@@ -228,20 +229,21 @@ int main(int argc, char **argv)
     };
     vel_v1(); CK(hipDeviceSynchronize()); saveref(sB);
     report("velocity v1 (flat xy, 1 cell/thread)", T.run(reps, vel_v1), 136.0, 0);
-#define VEL_ZB(TX, TY, KZ, MW, XM)                                                                                     \
+#define VEL_ZB(TX, TY, KZ, MW, XM) VEL_ZB2(TX, TY, KZ, MW, XM, false)
+#define VEL_ZB2(TX, TY, KZ, MW, XM, SH)                                                                                     \
     {                                                                                                               \
         TileMap tm = make_tilemap(nx, ny, nz, TX, TY, KZ);                                                          \
         auto fn = [&] {                                                                                             \
             SweepArgs b = a; b.i1 = nx; b.j1 = ny; b.k1 = nz;                                                       \
-            hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, MW, XM>), dim3(tm.per * 8), dim3(TX * TY), 0, 0, b, tm); \
+            hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, MW, XM, SH>), dim3(tm.per * 8), dim3(TX * TY), 0, 0, b, tm); \
         };                                                                                                          \
         restore(sB); fn(); CK(hipDeviceSynchronize());                                                              \
         unsigned long long nd = ndiff(sB);                                                                          \
         char nm[64];                                                                                                \
-        snprintf(nm, 64, "velocity zb %dx%dx%d minw%d xcd%d", TX, TY, KZ, MW, (int)XM);                                           \
+        snprintf(nm, 64, "velocity zb %dx%dx%d minw%d xcd%d shf%d", TX, TY, KZ, MW, (int)XM, (int)SH);                                           \
         report(nm, T.run(reps, fn), 136.0, nd);                                                                     \
     }
-    VEL_ZB(512, 1, 4, 4, 0) VEL_ZB(512, 1, 4, 4, 8) VEL_ZB(512, 1, 4, 4, 4) VEL_ZB(512, 1, 4, 4, 16) VEL_ZB(512, 1, 8, 4, 8) VEL_ZB(512, 1, 16, 4, 8)
+    VEL_ZB(512, 1, 4, 4, 0) VEL_ZB(512, 1, 4, 4, 8) VEL_ZB2(512, 1, 4, 4, 8, true) VEL_ZB2(256, 1, 8, 4, 8, true) VEL_ZB(512, 1, 4, 4, 8) VEL_ZB2(512, 1, 4, 4, 8, true)  VEL_ZB(512, 1, 4, 4, 4) VEL_ZB(512, 1, 4, 4, 16) VEL_ZB(512, 1, 8, 4, 8) VEL_ZB(512, 1, 16, 4, 8)
     VEL_ZB(256, 1, 8, 4, 0) VEL_ZB(256, 1, 8, 4, 8) VEL_ZB(256, 1, 16, 4, 8) VEL_ZB(128, 2, 8, 4, 8) VEL_ZB(512, 1, 32, 4, 8)
     // ---------------- fused iteration kernel (timing only; bit-exactness is covered by tests/test_gpu_stokes3d.py)
     {
