@@ -69,9 +69,15 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=128)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--self-halo", action="store_true",
-                    help="diagnostic (1 GPU): IGG-periodic grid whose only neighbour is the rank itself, planes routed through a "
-                         "one-rank RCCL communicator -- times the N > 1 code path (slabs, halo stream, pack/send/recv/unpack) on one device")
+    ap.add_argument("--variant", type=int, default=0, help="jrx_set_option kernel_variant (0 auto, 1 per-node, 2 z-marching sweeps, 3 fused wherever legal): tuning A/B only")
+    ap.add_argument("--self-halo", nargs="?", const="yz", default=None, metavar="DIMS",
+                    help="diagnostic (1 GPU): IGG-periodic grid in DIMS (default yz; xyz = all faces) whose only neighbour is the rank "
+                         "itself, planes routed through a one-rank RCCL communicator -- times the N > 1 code path (halo pack/send/recv/"
+                         "unpack, shell fix-up) on one device")
+    ap.add_argument("--dims", default="yz", choices=["yz", "balanced"],
+                    help="process grid for N > 1: yz = (1, a, b) with x, the contiguous direction, never split (x faces are strided "
+                         "planes: their pack/unpack and stress fix-up cost several times a y or z face); balanced = IGG's default "
+                         "MPI_Dims_create factorisation")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line (rank 0): native libraries that print banners on fd 1 (RCCL's version block
@@ -101,13 +107,20 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     n = args.n
-    self_halo = args.self_halo and world == 1
+    self_halo = bool(args.self_halo) and world == 1
     if self_halo:
         os.environ["JRX_HALO_SELF_RCCL"] = "1"
-        grid.init_global_grid(n, n, n, rank=0, nprocs=1, periodx=1, periody=1, periodz=1)
+        grid.init_global_grid(n, n, n, rank=0, nprocs=1, periodx=int("x" in args.self_halo), periody=int("y" in args.self_halo),
+                              periodz=int("z" in args.self_halo))
+    elif world > 1 and args.dims == "yz":
+        dy = {2: 1, 4: 2, 8: 2, 16: 4}.get(world, 1)
+        grid.init_global_grid(n, n, n, rank=rank, nprocs=world, dimx=1, dimy=dy, dimz=world // dy)
     else:
         grid.init_global_grid(n, n, n, rank=rank, nprocs=world)
     h = _lib.default_handle(local_rank)
+    if args.variant:
+        import ctypes as C
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(args.variant))
     if world > 1 or self_halo:
         halo.init_comm(h)
     uh = (lambda a: halo.update_halo_(a, ni=(n, n, n), handle=h)) if (world > 1 or self_halo) else None
@@ -154,7 +167,7 @@ def main():
             "config": {"workload": f"SolVi3D {n}^3 per GPU (configs[{'3' if n == 512 else '2' if n == 256 else '?'}]): "
                                    "eta inclusion 1e-3, G=1, K=Inf, dt=Inf, free-slip, pure shear",
                        "local_grid": [n, n, n], "global_grid": [grid.nx_g(), grid.ny_g(), grid.nz_g()],
-                       "decomposition": list(grid.global_grid().dims), "halo": "RCCL send/recv" if world > 1 else ("diagnostic: periodic self-neighbour through RCCL" if self_halo else "none")},
+                       "decomposition": list(grid.global_grid().dims), "halo": "RCCL send/recv" if world > 1 else (f"diagnostic: periodic self-neighbour in {args.self_halo} through RCCL" if self_halo else "none")},
             "global_iterations_per_s": it_per_s,
             "effective_GBps_at_360B_per_cell": eff_gbs,
             "device_ms_per_step": tot_ms / args.steps,

@@ -118,6 +118,8 @@ bool jrx_comm_active(const jrx_handle *h)
     return (h->comm->comm && h->comm->cart.nprocs > 1) || has_self_neighbor(h->comm->cart);
 }
 int jrx_comm_rank(const jrx_handle *h) { return (h && h->comm) ? h->comm->cart.rank : 0; }
+// does update_halo! overwrite the boundary plane of dimension d on side 0 (low) / 1 (high)?
+bool jrx_comm_has_neighbor(const jrx_handle *h, int d, int side) { return jrx_comm_active(h) && h->comm->cart.neighbor[d][side] >= 0; }
 
 jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count) { return jrx_allreduce_host(h, vals, count, 0); }
 

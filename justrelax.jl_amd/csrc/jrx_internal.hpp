@@ -93,6 +93,7 @@ bool jrx_comm_active(const jrx_handle *h);
 jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count);
 jrx_status jrx_allreduce_host(jrx_handle *h, double *vals, int count, int op);   // op: 0 sum, 1 max
 int jrx_comm_rank(const jrx_handle *h);
+bool jrx_comm_has_neighbor(const jrx_handle *h, int d, int side);   // the halo exchange receives into that boundary plane
 
 // stokes3d.hip: pieces of the 3D visco-elastic path that the 3D VEP driver (stokes3d_vep.hip) reuses.  Asynchronous on `s`.
 // velocity sweep = compute_V! 3D (+ residuals when diag); sumsq leaves Σx² of Rx, Ry, Rz (interior slices) and RP in h->d_sums

@@ -367,12 +367,15 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     I.setU = out_of(*f);
     I.cur_is_user = true; I.stress_done = false;
     const Lay3 L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
-    I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && !jrx_comm_active(h) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
+    // JRX_FUSED_COMM=0 keeps the split sweeps + hidden communication on multi-rank runs (A/B switch; same results)
+    static const bool fused_comm = [] { const char *e = getenv("JRX_FUSED_COMM"); return !(e && e[0] == '0'); }();
+    I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && (fused_comm || !jrx_comm_active(h)) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable && h->kernel_variant == 0) {
         // auto: the fused kernel covers a row with ceil(nx/62) 64-lane tiles (one halo and one feeder lane each); when that
-        // quantisation idles more than 15 % of the lanes (e.g. nx = 256: 5 tiles, 25 %) the two sweeps are faster
+        // quantisation idles too many lanes the two sweeps are faster (measured: nx = 256, 5 tiles, 25 % idle: fused +4 %;
+        // nx = 320: +25 %; nx = 384: +18 %; nx = 128, 3 tiles, 50 % idle: fused -28 %)
         const i64 ntx = (p->nx + 61) / 62;
-        if (ntx * 64 * 100 > (i64)p->nx * 115) I.fusable = false;
+        if (ntx * 64 * 100 > (i64)p->nx * 130) I.fusable = false;
     }
     if (I.fusable) {
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
@@ -396,7 +399,12 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
     // fetched array passes per launch at 512^3)
     // lane-shuffle form: 62 stress columns per 64-lane tile row (one halo lane on the left, one feeder lane on the right)
     const int ntx = (a.L.nx + TX - 3) / (TX - 2), nty = (a.L.ny + TY - 2) / (TY - 1), ntz = (a.L.nz + KZ - 1) / KZ;
-    hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
+    // y-neighbour operands through LDS (measured 8.62 -> 7.94 ms at 512^3); JRX_FUSED_YLDS=0 keeps the lane-shuffle-only form for A/B runs
+    static const bool ylds = [] { const char *e = getenv("JRX_FUSED_YLDS"); return !(e && e[0] == '0'); }();
+    if (ylds)
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
+    else
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -430,12 +438,28 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc)));
         if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
         JRX_TRY(launch_bcs(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
-        // stress nodes on the planes i = nx, j = ny, k = nz: old τ from the current set, new V from dst
+        bool nb[3][2] = {};
+        if (jrx_comm_active(h)) {
+            // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
+            double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
+            const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
+            const int64_t n[3] = {nx, ny, nz};
+            JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, n));
+            for (int d = 0; d < 3; d++) { nb[d][0] = jrx_comm_has_neighbor(h, d, 0); nb[d][1] = jrx_comm_has_neighbor(h, d, 1); }
+        }
+        // Stress nodes whose stencil reads a velocity plane that only now has its final value are redone from the old τ of the
+        // current set and the new V of dst: always the planes i = nx, j = ny, k = nz (high-face BC planes); on a face with a
+        // neighbour also the first layer (reads the received plane 0) and the last cell layer (reads the received plane n).
         SweepArgs e = a;
         e.f.Vx = dst.Vx; e.f.Vy = dst.Vy; e.f.Vz = dst.Vz;
-        JRX_TRY(launch_stress_v1(h, s, e, false, nx, nx + 1, 0, ny + 1, 0, nz + 1));
-        JRX_TRY(launch_stress_v1(h, s, e, false, 0, nx, ny, ny + 1, 0, nz + 1));
-        JRX_TRY(launch_stress_v1(h, s, e, false, 0, nx, 0, ny, nz, nz + 1));
+        const int ilo = nb[0][0] ? 1 : 0, ihi = nb[0][1] ? nx - 1 : nx, jlo = nb[1][0] ? 1 : 0, jhi = nb[1][1] ? ny - 1 : ny,
+                  klo = nb[2][0] ? 1 : 0, khi = nb[2][1] ? nz - 1 : nz;
+        if (ilo) JRX_TRY(launch_stress_v1(h, s, e, false, 0, ilo, 0, ny + 1, 0, nz + 1));
+        JRX_TRY(launch_stress_v1(h, s, e, false, ihi, nx + 1, 0, ny + 1, 0, nz + 1));
+        if (jlo) JRX_TRY(launch_stress_v1(h, s, e, false, ilo, ihi, 0, jlo, 0, nz + 1));
+        JRX_TRY(launch_stress_v1(h, s, e, false, ilo, ihi, jhi, ny + 1, 0, nz + 1));
+        if (klo) JRX_TRY(launch_stress_v1(h, s, e, false, ilo, ihi, jlo, jhi, 0, klo));
+        JRX_TRY(launch_stress_v1(h, s, e, false, ilo, ihi, jlo, jhi, khi, nz + 1));
         set_state(I.cur, dst);
         I.cur_is_user = !I.cur_is_user;
         I.stress_done = true;
@@ -638,8 +662,10 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     times_ms[0] = ms; times_ms[1] = times_ms[2] = times_ms[3] = times_ms[4] = times_ms[5] = 0.0;
     double sa = 0.0, sb = 0.0, sf = 0.0, sk = 0.0;
     int na = 0, nb = 0, nf = 0;
-    const bool split = !jrx_comm_active(h);
-    for (int q = 0; q < nsamp && split; q++) {
+    // with a communicator the un-fused iterations run on two streams (no per-sweep events); fused ones stay on `s`
+    const bool comm = jrx_comm_active(h);
+    for (int q = 0; q < nsamp; q++) {
+        if (comm && !fused[q]) continue;
         float m1 = 0.f, m2 = 0.f;
         JRX_HIP(h, hipEventElapsedTime(&m1, evs[(size_t)q * 4], evs[(size_t)q * 4 + 1]));
         JRX_HIP(h, hipEventElapsedTime(&m2, evs[(size_t)q * 4 + 1], evs[(size_t)q * 4 + 2]));

@@ -587,12 +587,17 @@ struct FusedBC {
 // SHFL: x-neighbour operands come from the adjacent lane instead of a second load of the same array (7 velocity-phase loads at i+1, 4
 // stress-phase loads at i-1): fewer vector-memory instructions through the L1/TA path (measured -4.7 %).  Lane TX-1 then only feeds
 // its left neighbour (tile stride TX - OVX - 1), and the lanes left of the stress tile also load η, G for theirs.
-template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false>
+// YLDS (with SHFL): y-neighbour operands come from the adjacent row of the tile through LDS: every lane publishes P, ητ, τyy, fy, τxy, τyz
+// (the row below reads them as its j+1 operands) and η, G (the row above reads them as its j-1 operands); only the top row of the tile
+// and the row on the domain's back face still load the j+1 operands from memory.  One more barrier per plane, 8 fewer loads per lane.
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0>
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty)
 {
     static_assert(!(SHFL && (LATEA || LOWREG || TX != 64)), "SHFL is implemented for the default register layout and 64-lane rows");
+    static_assert(!YLDS || SHFL, "YLDS builds on the SHFL operand layout");
     constexpr int NS = LOWREG ? 3 : 2;
     __shared__ double sV[NS][3][TY][TX];
+    __shared__ double sY[YLDS ? 8 : 1][YLDS ? TY : 1][YLDS ? TX : 1];
     const Lay3 &L = a.L;
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     const jrx_stokes3d_fields &f = a.f;
@@ -659,12 +664,14 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
         auto preload_stress = [&]() {
             if (SHFL) {
                 // η, G of the own column for every lane that has one; the i-1 column arrives by lane shuffle (clamped at i = 0)
-                if (bvalid) {
+                if (YLDS) {
+                    if (bvalid) { e = LDB(f.eta, oc); g = LDB(f.G, oc); }
+                } else if (bvalid) {
                     e = LDB(f.eta, oc); ey = LDB(f.eta, oc - dcy); g = LDB(f.G, oc); gy = LDB(f.G, oc - dcy);
                     const double e_l = __shfl_up(e, 1, 64), g_l = __shfl_up(g, 1, 64), ey_l = __shfl_up(ey, 1, 64), gy_l = __shfl_up(gy, 1, 64);
                     ex = i > 0 ? e_l : e; gx = i > 0 ? g_l : g; exy_ = i > 0 ? ey_l : ey; gxy = i > 0 ? gy_l : gy;
                 }
-                if (avalid && live) {
+                if (YLDS != 2 && avalid && live) {
                     P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
                     toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
                     toxy = LDB(f.toxy, oxy);
@@ -685,21 +692,61 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             }
         };
         if (!LATEA) preload_stress();
+        // velocity-phase operands
+        double q01 = 0, s01 = 0, r11 = 0, r01 = 0, Pz = 0, ez = 0, tzz_z = 0, fz_z = 0, Py = 0, eyb = 0, tyy_y = 0;
+        double fx_c = 0, fy_c = 0, fy_y = 0, vx = 0, vy = 0, vz = 0, txy_own = 0;
+        const bool yrow = YLDS && ty < TY - 1 && hy;     // the j+1 operands are the next row's own operands (row = wave: uniform)
         if (bvalid) {
             const u32 dz1 = hz ? sc : 0u;
-            const double q01 = LDB(f.txy, oxy + rxy), s01 = LDB(f.txz, oxz);
-            const double r11 = LDB(f.tyz, oyz + ryz), r01 = LDB(f.tyz, oyz);
-            const double Pz = LDB(f.P, oc + dz1), ez = LDB(et, oc + dz1), tzz_z = LDB(f.tzz, oc + dz1), fz_z = LDB(f.fz, oc + dz1);
-            const double Py = LDB(f.P, oc + dy1), ey = LDB(et, oc + dy1);
-            txx_c = LDB(f.txx, oc); tyy_c = LDB(f.tyy, oc);
-            const double tyy_y = LDB(f.tyy, oc + dy1);
-            const double fx_c = LDB(f.fx, oc), fy_c = LDB(f.fy, oc), fy_y = LDB(f.fy, oc + dy1);
-            const double vx = LDB(f.Vx, ovx), vy = LDB(f.Vy, ovy), vz = LDB(f.Vz, ovz);
+            if (YLDS) {
+                // published operands first (loads return in order), then the rest
+                tyy_c = LDB(f.tyy, oc); fy_c = LDB(f.fy, oc); txy_own = LDB(f.txy, oxy); r01 = LDB(f.tyz, oyz);
+                if (!yrow) {
+                    q01 = LDB(f.txy, oxy + rxy); r11 = LDB(f.tyz, oyz + ryz);
+                    if (hy) { Py = LDB(f.P, oc + rc); eyb = LDB(et, oc + rc); tyy_y = LDB(f.tyy, oc + rc); fy_y = LDB(f.fy, oc + rc); }
+                }
+                s01 = LDB(f.txz, oxz);
+                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDB(f.fz, oc + dz1);
+                txx_c = LDB(f.txx, oc); fx_c = LDB(f.fx, oc);
+                vx = LDB(f.Vx, ovx); vy = LDB(f.Vy, ovy); vz = LDB(f.Vz, ovz);
+                if (YLDS == 2 && avalid && live) {
+                    // the stress phase's remaining operands queue behind the published ones
+                    P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
+                    toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
+                    toxy = LDB(f.toxy, oxy);
+                    toxz = LDB(f.toxz, oxz - sxz); toyz = LDB(f.toyz, oyz - syz);
+                }
+                sY[0][ty][tx] = Pc; sY[1][ty][tx] = ec; sY[2][ty][tx] = tyy_c; sY[3][ty][tx] = fy_c; sY[4][ty][tx] = txy_own; sY[5][ty][tx] = r01;
+                sY[6][ty][tx] = e; sY[7][ty][tx] = g;
+            } else {
+                q01 = LDB(f.txy, oxy + rxy); s01 = LDB(f.txz, oxz);
+                r11 = LDB(f.tyz, oyz + ryz); r01 = LDB(f.tyz, oyz);
+                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDB(f.fz, oc + dz1);
+                Py = LDB(f.P, oc + dy1); eyb = LDB(et, oc + dy1);
+                txx_c = LDB(f.txx, oc); tyy_c = LDB(f.tyy, oc);
+                tyy_y = LDB(f.tyy, oc + dy1);
+                fx_c = LDB(f.fx, oc); fy_c = LDB(f.fy, oc); fy_y = LDB(f.fy, oc + dy1);
+                vx = LDB(f.Vx, ovx); vy = LDB(f.Vy, ovy); vz = LDB(f.Vz, ovz);
+            }
+        }
+        if (YLDS) __syncthreads();
+        if (bvalid) {
+            if (YLDS) {
+                if (yrow) {
+                    Py = sY[0][ty + 1][tx]; eyb = sY[1][ty + 1][tx]; tyy_y = sY[2][ty + 1][tx]; fy_y = sY[3][ty + 1][tx];
+                    q01 = sY[4][ty + 1][tx]; r11 = sY[5][ty + 1][tx];
+                }
+                // stress phase: η, G at j-1 from the row below (clamped at j = 0), then the i-1 column by lane shuffle (clamped at i = 0)
+                if (ty > 0 && j > 0) { ey = sY[6][ty - 1][tx]; gy = sY[7][ty - 1][tx]; }
+                else { ey = e; gy = g; }
+                const double e_l = __shfl_up(e, 1, 64), g_l = __shfl_up(g, 1, 64), ey_l = __shfl_up(ey, 1, 64), gy_l = __shfl_up(gy, 1, 64);
+                ex = i > 0 ? e_l : e; gx = i > 0 ? g_l : g; exy_ = i > 0 ? ey_l : ey; gxy = i > 0 ? gy_l : gy;
+            }
             double q11, q10, s11, Px, ex, txx_x, fx_x;
             if (SHFL) {
                 // the operands at i+1 are the right-hand lane's operands at i (every lane of the row holds them, incl. the feeder lane TX-1);
                 // they are only used where hx, i.e. where that lane exists
-                const double txy_own = LDB(f.txy, oxy);
+                if (!YLDS) txy_own = LDB(f.txy, oxy);
                 txy = txy_own;                                  // also the stress phase's own τxy
                 q11 = __shfl_down(q01, 1, 64); q10 = __shfl_down(txy_own, 1, 64); s11 = __shfl_down(s01, 1, 64);
                 Px = __shfl_down(Pc, 1, 64); ex = __shfl_down(ec, 1, 64); txx_x = __shfl_down(txx_c, 1, 64); fx_x = __shfl_down(fx_c, 1, 64);
@@ -718,7 +765,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             } else vxn = bc.nsR ? 0.0 : vx;
             if (hy) {
                 const double R = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy - 0.5 * (fy_c + fy_y);
-                vyn = vy + R * edt / (0.5 * (ec + ey));
+                vyn = vy + R * edt / (0.5 * (ec + eyb));
                 if (own) STB(a.o.Vy, ovy, vyn);
             } else vyn = bc.nsBk ? 0.0 : vy;
             if (hz) {

@@ -288,6 +288,28 @@ int main(int argc, char **argv)
             const int nty8 = (ny + 6) / 7;
             auto fn8 = [&] { hipLaunchKernelGGL((k_fused3d<64, 8, 16, 2, 1, false, 8, false, true>), dim3(ntx * nty8 * ntz), dim3(512), 0, 0, b, bc, ntx, nty8); };
             report("fused 64x8x16 xg8 SHFL", T.run(reps, fn8), 360.0, 0);
+            auto fy = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 8, false, true, 1>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 xg8 SHFL+YLDS", T.run(reps, fy), 360.0, 0);
+            auto fy8 = [&] { hipLaunchKernelGGL((k_fused3d<64, 8, 16, 2, 1, false, 8, false, true, 1>), dim3(ntx * nty8 * ntz), dim3(512), 0, 0, b, bc, ntx, nty8); };
+            report("fused 64x8x16 xg8 SHFL+YLDS", T.run(reps, fy8), 360.0, 0);
+            const int nty6 = (ny + 4) / 5;
+            auto fy6 = [&] { hipLaunchKernelGGL((k_fused3d<64, 6, 16, 2, 1, false, 8, false, true, 1>), dim3(ntx * nty6 * ntz), dim3(384), 0, 0, b, bc, ntx, nty6); };
+            report("fused 64x6x16 xg8 SHFL+YLDS", T.run(reps, fy6), 360.0, 0);
+            auto fy2 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 8, false, true, 2>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 xg8 SHFL+YLDS2 (stress operands queued last)", T.run(reps, fy2), 360.0, 0);
+            const int ntz32 = (nz + 31) / 32, ntz24 = (nz + 23) / 24, ntz8 = (nz + 7) / 8;
+            auto fz32 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 32, 2, 1, false, 8, false, true, 1>), dim3(ntx * nty * ntz32), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x32 xg8 SHFL+YLDS", T.run(reps, fz32), 360.0, 0);
+            auto fz24 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 24, 2, 1, false, 8, false, true, 1>), dim3(ntx * nty * ntz24), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x24 xg8 SHFL+YLDS", T.run(reps, fz24), 360.0, 0);
+            auto fz8 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 8, 2, 1, false, 8, false, true, 1>), dim3(ntx * nty * ntz8), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x8 xg8 SHFL+YLDS", T.run(reps, fz8), 360.0, 0);
+            auto fx4 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 4, false, true, 1>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 xg4 SHFL+YLDS", T.run(reps, fx4), 360.0, 0);
+            auto fx16 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 16, false, true, 1>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 xg16 SHFL+YLDS", T.run(reps, fx16), 360.0, 0);
+            report("fused 64x4x16 xg8 SHFL+YLDS (again)", T.run(reps, fy), 360.0, 0);
+            report("fused 64x4x16 xg8 SHFL (again)", T.run(reps, fn), 360.0, 0);
         }
         FEXP(0)
     }

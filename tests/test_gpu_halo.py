@@ -71,12 +71,15 @@ def test_periodic_self_exchange(jr, through_rccl, periods):
     assert any(not np.array_equal(a, b) for a, b in zip(got, host))
 
 
-@pytest.mark.parametrize("through_rccl", [False, True])
-def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracle, through_rccl):
-    """The N > 1 code path of jrx_stokes3d_solve (boundary slabs first on the halo stream, interior concurrently on the
-    compute stream, BCs + update_halo! behind the slabs, norms of the global count: Stokes3D.jl:104-142) on one GPU:
-    the grid is IGG-periodic in x and z, so the rank is its own neighbour.  Expected = the CPU oracle's iteration
-    followed by the same plane copies in numpy.  Tolerance 1e-12 of each field's max (observed: bit-identical)."""
+@pytest.mark.parametrize("through_rccl,variant,periods", [(False, 2, (1, 0, 1)), (True, 2, (1, 0, 1)), (False, 3, (1, 0, 1)),
+                                                          (True, 3, (1, 1, 1)), (False, 3, (0, 1, 0))])
+def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracle, through_rccl, variant, periods):
+    """The N > 1 code path of jrx_stokes3d_solve on one GPU: the grid is IGG-periodic in some dimensions, so the rank is its own
+    neighbour there.  variant 2: split sweeps (boundary slabs first on the halo stream, interior concurrently on the compute stream,
+    BCs + update_halo! behind the slabs; Stokes3D.jl:104-142).  variant 3: fused velocity+stress kernel, BCs, update_halo!, then the
+    stress nodes next to a received plane redone.  Norms of the global count.  Expected = the CPU oracle's iteration followed by
+    the same plane copies in numpy.  Tolerance 1e-12 of each field's max (observed: bit-identical)."""
+    import ctypes as C
     import torch
     from justrelax_jl_amd import _lib, checks, halo
     from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
@@ -84,23 +87,24 @@ def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracl
     orc = oracle
     L = _lib.load()
     n = (70, 13, 12)
-    periods = (1, 0, 1)
     iters = 8
     s = jr.miniapps.random_fields3d(n, seed=11, iterMax=iters - 1, nout=4)
     s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
     g.init_global_grid(*n, periodx=periods[0], periody=periods[1], periodz=periods[2], rank=0, nprocs=1)
     ng = (g.nx_g(), g.ny_g(), g.nz_g())
-    assert ng == (n[0] - 2, n[1], n[2] - 2)
+    assert ng == tuple(n[d] - 2 * periods[d] for d in range(3))
     old = os.environ.get("JRX_HALO_SELF_RCCL")
     h = _lib.default_handle()
     try:
         if through_rccl:
             os.environ["JRX_HALO_SELF_RCCL"] = "1"
         halo.init_comm(h)
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
         stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
         r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
         got = download_stokes(stokes)
     finally:
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
         if old is None:
             os.environ.pop("JRX_HALO_SELF_RCCL", None)
         else:
@@ -139,7 +143,7 @@ def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracl
         d = np.abs(got[k] - ref[k])[m].max()
         assert d <= 1e-12 * scale, (k, d, scale)
     # ghost planes of V hold the wrapped interior planes
-    for k in ("Vx", "Vz"):
+    for k in ("Vx", "Vz") if periods[0] else ():
         assert np.abs(got[k][0] - ref[k][0]).max() <= 1e-12 * np.abs(ref[k]).max()
 
 
