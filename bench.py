@@ -70,14 +70,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="jrx_set_option kernel_variant (0 auto, 1 per-node, 2 z-marching sweeps, 3 fused wherever legal): tuning A/B only")
-    ap.add_argument("--self-halo", nargs="?", const="yz", default=None, metavar="DIMS",
-                    help="diagnostic (1 GPU): IGG-periodic grid in DIMS (default yz; xyz = all faces) whose only neighbour is the rank "
+    ap.add_argument("--self-halo", nargs="?", const="xyz", default=None, metavar="DIMS",
+                    help="diagnostic (1 GPU): IGG-periodic grid in DIMS (default xyz = all six faces) whose only neighbour is the rank "
                          "itself, planes routed through a one-rank RCCL communicator -- times the N > 1 code path (halo pack/send/recv/"
                          "unpack, shell fix-up) on one device")
-    ap.add_argument("--dims", default="yz", choices=["yz", "balanced"],
-                    help="process grid for N > 1: yz = (1, a, b) with x, the contiguous direction, never split (x faces are strided "
-                         "planes: their pack/unpack and stress fix-up cost several times a y or z face); balanced = IGG's default "
-                         "MPI_Dims_create factorisation")
+    ap.add_argument("--dims", default="balanced", choices=["balanced", "yz"],
+                    help="process grid for N > 1: balanced = IGG's default MPI_Dims_create factorisation ((2,2,2) for 8 GPUs, SURVEY 8e); "
+                         "yz = (1, a, b) with x, the contiguous direction, never split (x faces are strided planes: their pack/unpack "
+                         "and stress fix-up cost several times a y or z face) -- tuning option")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line (rank 0): native libraries that print banners on fd 1 (RCCL's version block

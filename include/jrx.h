@@ -61,12 +61,15 @@ const char *jrx_last_error(const jrx_handle *h);   /* h may be NULL: last creati
 int32_t jrx_version(void);
 
 /* Tuning / debugging knobs.  Keys: "kernel_variant" (3D Stokes):
- *   0 = default: fused PT pipeline where it applies (single rank, no periodic_boundary! faces, nx >= 48, ny, nz >= 8,
- *       and nx fills its 63-column tiles to >= 87 %): one kernel runs velocity sweep m + BCs + stress sweep m+1 with
- *       ping-pong state arrays (the handle then owns a second set of the 10 state arrays); otherwise, and on
- *       iterations whose results are observed, the two z-marching sweeps;
+ *   0 = default: fused PT pipeline where it applies (no periodic_boundary! faces, nx >= 48, ny, nz >= 8, and nx fills
+ *       its 62-column tiles to >= 77 %): one kernel runs velocity sweep m + BCs + stress sweep m+1 with ping-pong
+ *       state arrays (the handle then owns a second set of the 10 state arrays); with a communicator the exchange
+ *       of V follows and the stress nodes next to a received plane are redone; otherwise, and on iterations whose
+ *       results are observed, the two z-marching sweeps;
  *   1 = simple one-thread-per-node kernels;  2 = z-marching sweeps only (two launches per iteration, no ping-pong set);
- *   3 = fused pipeline wherever it is legal (ignores the tile-fill rule).  All variants produce bit-identical results. */
+ *   3 = fused pipeline wherever it is legal (ignores the tile-fill rule).  All variants produce bit-identical results.
+ * "fused_overlap" (0/1, default 0): multi-rank fused pipeline with the shell of tiles, BCs and exchange on a second
+ *   stream while the interior tiles run (same results). */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)

@@ -41,7 +41,12 @@ jrx_status jrx_create(int32_t device, jrx_handle **out)
     } while (0)
     CK(hipSetDevice(device));
     CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&h->halo_stream, hipStreamNonBlocking));
+    {
+        // the boundary work (slabs / shell tiles, BCs, pack, send/recv, unpack) should win the dispatch race against the interior
+        int lo = 0, hi = 0;
+        CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        CK(hipStreamCreateWithPriority(&h->halo_stream, hipStreamNonBlocking, hi));
+    }
     for (int i = 0; i < 3; i++) CK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));   // stream joins
     for (int i = 3; i < 8; i++) CK(hipEventCreate(&h->ev[i]));                                    // timing
     CK(hipMalloc(&h->d_partials, sizeof(double) * 4 * kMaxRedBlocks));

@@ -263,6 +263,7 @@ jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value)
     if (!h) return JRX_ERR_ARG;
     if (!key) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: key is NULL");
     if (strcmp(key, "kernel_variant") == 0) { h->kernel_variant = (int)value; return JRX_OK; }
+    if (strcmp(key, "fused_overlap") == 0) { h->fused_overlap = value != 0; return JRX_OK; }
     return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: unknown key '%s'", key);
 }
 
@@ -392,19 +393,29 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     return JRX_OK;
 }
 
+// tile counts of the fused kernel: lane-shuffle form, 62 stress columns per 64-lane tile row (one halo lane on the left, one feeder
+// lane on the right), TY-1 rows, KZ planes
 template <int TX, int TY, int KZ>
-static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc)
+static void fused_tiles(const Lay3 &L, int nt[3])
+{
+    nt[0] = (L.nx + TX - 3) / (TX - 2); nt[1] = (L.ny + TY - 2) / (TY - 1); nt[2] = (L.nz + KZ - 1) / KZ;
+}
+
+// launch the fused kernel over the box of tiles [b[0], b[1]) x [b[2], b[3]) x [b[4], b[5])
+template <int TX, int TY, int KZ>
+static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6])
 {
     // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
     // fetched array passes per launch at 512^3)
-    // lane-shuffle form: 62 stress columns per 64-lane tile row (one halo lane on the left, one feeder lane on the right)
-    const int ntx = (a.L.nx + TX - 3) / (TX - 2), nty = (a.L.ny + TY - 2) / (TY - 1), ntz = (a.L.nz + KZ - 1) / KZ;
+    const int ntx = b[1] - b[0], nty = b[3] - b[2], ntz = b[5] - b[4];
+    if (ntx <= 0 || nty <= 0 || ntz <= 0) return JRX_OK;
     // y-neighbour operands through LDS (measured 8.62 -> 7.94 ms at 512^3); JRX_FUSED_YLDS=0 keeps the lane-shuffle-only form for A/B runs
     static const bool ylds = [] { const char *e = getenv("JRX_FUSED_YLDS"); return !(e && e[0] == '0'); }();
     if (ylds)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
+        // + non-temporal stores: the written set is not read again before the next iteration (PMC: 35.7 -> 34.2 fetched passes, -0.5 .. -1.6 % time)
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true, 1, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty);
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -434,17 +445,56 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.fsL = !!(fs & JRX_FACE_LEFT); bc.nsL = !!(ns & JRX_FACE_LEFT); bc.fsF = !!(fs & JRX_FACE_FRONT); bc.nsF = !!(ns & JRX_FACE_FRONT);
         bc.fsK0 = !!(fs & JRX_FACE_TOP);  bc.nsK0 = !!(ns & JRX_FACE_BOT);     // k = 1: free_slip `top`, no_slip `bot` (reference naming)
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
-        // 64 x 4 threads (A tile 63 x 3), 16 planes per chunk: best of the measured tile shapes (148 VGPRs -> 3 blocks/CU)
-        JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc)));
-        if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
-        JRX_TRY(launch_bcs(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        // 64 x 4 threads (stress tile 62 x 3), 16 planes per chunk: best of the measured tile shapes (145 VGPRs -> 3 blocks/CU)
+        int nt[3];
+        fused_tiles<64, 4, 16>(a.L, nt);
+        const bool comm = jrx_comm_active(h);
+        hipStream_t bs = s;            // stream of the boundary work
         bool nb[3][2] = {};
-        if (jrx_comm_active(h)) {
+        // option "fused_overlap" / JRX_FUSED_OVERLAP=1: shell of tiles + BCs + exchange on the halo stream, interior tiles concurrently (see below).  Off by
+        // default: measured on one device (periodic self neighbour through RCCL, profiles/r01_selfhalo_overlap_*.txt) the RCCL
+        // send/recv kernel does not finish before the interior kernel drains, so nothing is hidden and the six small shell launches
+        // cost more than they save when an x face is involved (10.7 vs 9.1 ms); to be revisited with real neighbours / DMA copies.
+        static const bool overlap_env = [] { const char *e = getenv("JRX_FUSED_OVERLAP"); return e && e[0] == '1'; }();
+        const bool overlap = overlap_env || h->fused_overlap;
+        if (!comm || !overlap) {
+            const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
+            JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc, all)));
+            if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
+            JRX_TRY(launch_bcs(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+            if (comm) {
+                // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
+                double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
+                const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
+                const int64_t n[3] = {nx, ny, nz};
+                JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, n));
+                for (int d = 0; d < 3; d++) { nb[d][0] = jrx_comm_has_neighbor(h, d, 0); nb[d][1] = jrx_comm_has_neighbor(h, d, 1); }
+            }
+        } else {
+            // The role of @hide_communication (Stokes3D.jl:104-121) for the fused kernel: the shell of tiles that touches a face of
+            // the block runs first on the halo stream, followed there by the BCs, update_halo!(V) and the stress fix-up below, while
+            // the interior tiles run on the compute stream.  No tile reads what another tile of the same launch writes (ping-pong).
+            bs = h->halo_stream;
+            JRX_HIP(h, hipEventRecord(h->ev[0], s));
+            JRX_HIP(h, hipStreamWaitEvent(bs, h->ev[0], 0));
+            int lo[3][2], mid[3][2], hi[3][2];
+            for (int d = 0; d < 3; d++) {
+                lo[d][0] = 0; lo[d][1] = 1;
+                hi[d][0] = nt[d] > 1 ? nt[d] - 1 : 1; hi[d][1] = nt[d];
+                mid[d][0] = 1; mid[d][1] = hi[d][0];
+            }
+            const int boxes[6][6] = {{0, nt[0], 0, nt[1], lo[2][0], lo[2][1]},  {0, nt[0], 0, nt[1], hi[2][0], hi[2][1]},
+                                     {0, nt[0], lo[1][0], lo[1][1], mid[2][0], mid[2][1]}, {0, nt[0], hi[1][0], hi[1][1], mid[2][0], mid[2][1]},
+                                     {lo[0][0], lo[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]}, {hi[0][0], hi[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]}};
+            for (int q = 0; q < 6; q++) JRX_TRY((launch_fused<64, 4, 16>(h, bs, a, bc, boxes[q])));
+            const int inner[6] = {mid[0][0], mid[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]};
+            JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc, inner)));
+            JRX_TRY(launch_bcs(h, bs, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
             // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
             double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
             const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
             const int64_t n[3] = {nx, ny, nz};
-            JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, n));
+            JRX_TRY(jrx_halo_exchange(h, bs, 3, arrs, ext, n));
             for (int d = 0; d < 3; d++) { nb[d][0] = jrx_comm_has_neighbor(h, d, 0); nb[d][1] = jrx_comm_has_neighbor(h, d, 1); }
         }
         // Stress nodes whose stencil reads a velocity plane that only now has its final value are redone from the old τ of the
@@ -454,12 +504,17 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         e.f.Vx = dst.Vx; e.f.Vy = dst.Vy; e.f.Vz = dst.Vz;
         const int ilo = nb[0][0] ? 1 : 0, ihi = nb[0][1] ? nx - 1 : nx, jlo = nb[1][0] ? 1 : 0, jhi = nb[1][1] ? ny - 1 : ny,
                   klo = nb[2][0] ? 1 : 0, khi = nb[2][1] ? nz - 1 : nz;
-        if (ilo) JRX_TRY(launch_stress_v1(h, s, e, false, 0, ilo, 0, ny + 1, 0, nz + 1));
-        JRX_TRY(launch_stress_v1(h, s, e, false, ihi, nx + 1, 0, ny + 1, 0, nz + 1));
-        if (jlo) JRX_TRY(launch_stress_v1(h, s, e, false, ilo, ihi, 0, jlo, 0, nz + 1));
-        JRX_TRY(launch_stress_v1(h, s, e, false, ilo, ihi, jhi, ny + 1, 0, nz + 1));
-        if (klo) JRX_TRY(launch_stress_v1(h, s, e, false, ilo, ihi, jlo, jhi, 0, klo));
-        JRX_TRY(launch_stress_v1(h, s, e, false, ilo, ihi, jlo, jhi, khi, nz + 1));
+        if (ilo) JRX_TRY(launch_stress_v1(h, bs, e, false, 0, ilo, 0, ny + 1, 0, nz + 1));
+        JRX_TRY(launch_stress_v1(h, bs, e, false, ihi, nx + 1, 0, ny + 1, 0, nz + 1));
+        if (jlo) JRX_TRY(launch_stress_v1(h, bs, e, false, ilo, ihi, 0, jlo, 0, nz + 1));
+        JRX_TRY(launch_stress_v1(h, bs, e, false, ilo, ihi, jhi, ny + 1, 0, nz + 1));
+        if (klo) JRX_TRY(launch_stress_v1(h, bs, e, false, ilo, ihi, jlo, jhi, 0, klo));
+        JRX_TRY(launch_stress_v1(h, bs, e, false, ilo, ihi, jlo, jhi, khi, nz + 1));
+        if (bs != s) {
+            JRX_HIP(h, hipEventRecord(h->ev[2], bs));
+            JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
+            if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));     // two streams: only the whole group can be timed
+        }
         set_state(I.cur, dst);
         I.cur_is_user = !I.cur_is_user;
         I.stress_done = true;

@@ -293,6 +293,18 @@ __device__ __forceinline__ void node_yz(const SweepArgs &a, int i, int J, int Kk
 typedef unsigned int u32;
 #define LDB(p, off) (*(const double *)((const char *)(p) + (off)))
 #define STB(p, off, v) (*(double *)((char *)(p) + (off)) = (v))
+// the same with an optional non-temporal (streaming) hint
+template <bool NT> __device__ __forceinline__ double LDN(const double *p, u32 off)
+{
+    const double *q = (const double *)((const char *)p + off);
+    return NT ? __builtin_nontemporal_load(q) : *q;
+}
+template <bool NT> __device__ __forceinline__ void STN(double *p, u32 off, double v)
+{
+    double *q = (double *)((char *)p + off);
+    if (NT) __builtin_nontemporal_store(v, q);
+    else *q = v;
+}
 
 struct TileMap {
     int ntx, nty, ntz, ntiles, per;     // per = ceil(ntiles / 8)
@@ -590,9 +602,10 @@ struct FusedBC {
 // YLDS (with SHFL): y-neighbour operands come from the adjacent row of the tile through LDS: every lane publishes P, ητ, τyy, fy, τxy, τyz
 // (the row below reads them as its j+1 operands) and η, G (the row above reads them as its j-1 operands); only the top row of the tile
 // and the row on the domain's back face still load the j+1 operands from memory.  One more barrier per plane, 8 fewer loads per lane.
-template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0>
-__global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty)
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0>
+__global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0)
 {
+    // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
     static_assert(!(SHFL && (LATEA || LOWREG || TX != 64)), "SHFL is implemented for the default register layout and 64-lane rows");
     static_assert(!YLDS || SHFL, "YLDS builds on the SHFL operand layout");
     constexpr int NS = LOWREG ? 3 : 2;
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
         }
     }
-    const int tix = tile % ntx, tr = tile / ntx, tiy = tr % nty, tiz = tr / nty;
+    const int tr = tile / ntx, tix = tx0 + tile % ntx, tiy = ty0 + tr % nty, tiz = tz0 + tr / nty;
     const int i = tix * (TX - OVX - (SHFL ? 1 : 0)) - OVX + tx;  // cell column of this thread
     const int j = tiy * (TY - 1) - 1 + ty;
     const int kb = tiz * KZ;
@@ -644,7 +657,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     // velocity-sweep carries (plane k values that were the upper loads of the previous plane)
     double Pc = 0, ec = 0, tzz_c = 0, fz_c = 0, s10 = 0, r10 = 0, s01p = 0, r01p = 0;
     if (bvalid) {
-        Pc = LDB(f.P, oc); ec = LDB(et, oc); tzz_c = LDB(f.tzz, oc); fz_c = LDB(f.fz, oc);
+        Pc = LDB(f.P, oc); ec = LDB(et, oc); tzz_c = LDB(f.tzz, oc); fz_c = LDN<(NT & 2) != 0>(f.fz, oc);
         s10 = LDB(f.txz, oxz + 8u - sxz); r10 = LDB(f.tyz, oyz + ryz - syz);
         s01p = LDB(f.txz, oxz - sxz); r01p = LDB(f.tyz, oyz - syz);
     }
@@ -672,10 +685,10 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     ex = i > 0 ? e_l : e; gx = i > 0 ? g_l : g; exy_ = i > 0 ? ey_l : ey; gxy = i > 0 ? gy_l : gy;
                 }
                 if (YLDS != 2 && avalid && live) {
-                    P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
-                    toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
-                    toxy = LDB(f.toxy, oxy);
-                    toxz = LDB(f.toxz, oxz - sxz); toyz = LDB(f.toyz, oyz - syz);
+                    P0 = LDN<(NT & 2) != 0>(f.P0, oc); Kc = LDN<(NT & 2) != 0>(f.K, oc); Qc = LDN<(NT & 2) != 0>(f.Q, oc);
+                    toxx = LDN<(NT & 2) != 0>(f.toxx, oc); toyy = LDN<(NT & 2) != 0>(f.toyy, oc); tozz = LDN<(NT & 2) != 0>(f.tozz, oc);
+                    toxy = LDN<(NT & 2) != 0>(f.toxy, oxy);
+                    toxz = LDN<(NT & 2) != 0>(f.toxz, oxz - sxz); toyz = LDN<(NT & 2) != 0>(f.toyz, oyz - syz);
                 }
                 return;
             }
@@ -684,10 +697,10 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 g = LDB(f.G, oc); gx = LDB(f.G, oc - dcx); gy = LDB(f.G, oc - dcy);
                 if (live) {
                     exy_ = LDB(f.eta, oc - dcx - dcy); gxy = LDB(f.G, oc - dcx - dcy);
-                    P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
-                    toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
-                    txy = LDB(f.txy, oxy); toxy = LDB(f.toxy, oxy);
-                    toxz = LDB(f.toxz, oxz - sxz); toyz = LDB(f.toyz, oyz - syz);
+                    P0 = LDN<(NT & 2) != 0>(f.P0, oc); Kc = LDN<(NT & 2) != 0>(f.K, oc); Qc = LDN<(NT & 2) != 0>(f.Q, oc);
+                    toxx = LDN<(NT & 2) != 0>(f.toxx, oc); toyy = LDN<(NT & 2) != 0>(f.toyy, oc); tozz = LDN<(NT & 2) != 0>(f.tozz, oc);
+                    txy = LDB(f.txy, oxy); toxy = LDN<(NT & 2) != 0>(f.toxy, oxy);
+                    toxz = LDN<(NT & 2) != 0>(f.toxz, oxz - sxz); toyz = LDN<(NT & 2) != 0>(f.toyz, oyz - syz);
                 }
             }
         };
@@ -700,32 +713,32 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             const u32 dz1 = hz ? sc : 0u;
             if (YLDS) {
                 // published operands first (loads return in order), then the rest
-                tyy_c = LDB(f.tyy, oc); fy_c = LDB(f.fy, oc); txy_own = LDB(f.txy, oxy); r01 = LDB(f.tyz, oyz);
+                tyy_c = LDB(f.tyy, oc); fy_c = LDN<(NT & 2) != 0>(f.fy, oc); txy_own = LDB(f.txy, oxy); r01 = LDB(f.tyz, oyz);
                 if (!yrow) {
                     q01 = LDB(f.txy, oxy + rxy); r11 = LDB(f.tyz, oyz + ryz);
-                    if (hy) { Py = LDB(f.P, oc + rc); eyb = LDB(et, oc + rc); tyy_y = LDB(f.tyy, oc + rc); fy_y = LDB(f.fy, oc + rc); }
+                    if (hy) { Py = LDB(f.P, oc + rc); eyb = LDB(et, oc + rc); tyy_y = LDB(f.tyy, oc + rc); fy_y = LDN<(NT & 2) != 0>(f.fy, oc + rc); }
                 }
                 s01 = LDB(f.txz, oxz);
-                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDB(f.fz, oc + dz1);
-                txx_c = LDB(f.txx, oc); fx_c = LDB(f.fx, oc);
+                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDN<(NT & 2) != 0>(f.fz, oc + dz1);
+                txx_c = LDB(f.txx, oc); fx_c = LDN<(NT & 2) != 0>(f.fx, oc);
                 vx = LDB(f.Vx, ovx); vy = LDB(f.Vy, ovy); vz = LDB(f.Vz, ovz);
                 if (YLDS == 2 && avalid && live) {
                     // the stress phase's remaining operands queue behind the published ones
-                    P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
-                    toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
-                    toxy = LDB(f.toxy, oxy);
-                    toxz = LDB(f.toxz, oxz - sxz); toyz = LDB(f.toyz, oyz - syz);
+                    P0 = LDN<(NT & 2) != 0>(f.P0, oc); Kc = LDN<(NT & 2) != 0>(f.K, oc); Qc = LDN<(NT & 2) != 0>(f.Q, oc);
+                    toxx = LDN<(NT & 2) != 0>(f.toxx, oc); toyy = LDN<(NT & 2) != 0>(f.toyy, oc); tozz = LDN<(NT & 2) != 0>(f.tozz, oc);
+                    toxy = LDN<(NT & 2) != 0>(f.toxy, oxy);
+                    toxz = LDN<(NT & 2) != 0>(f.toxz, oxz - sxz); toyz = LDN<(NT & 2) != 0>(f.toyz, oyz - syz);
                 }
                 sY[0][ty][tx] = Pc; sY[1][ty][tx] = ec; sY[2][ty][tx] = tyy_c; sY[3][ty][tx] = fy_c; sY[4][ty][tx] = txy_own; sY[5][ty][tx] = r01;
                 sY[6][ty][tx] = e; sY[7][ty][tx] = g;
             } else {
                 q01 = LDB(f.txy, oxy + rxy); s01 = LDB(f.txz, oxz);
                 r11 = LDB(f.tyz, oyz + ryz); r01 = LDB(f.tyz, oyz);
-                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDB(f.fz, oc + dz1);
+                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDN<(NT & 2) != 0>(f.fz, oc + dz1);
                 Py = LDB(f.P, oc + dy1); eyb = LDB(et, oc + dy1);
                 txx_c = LDB(f.txx, oc); tyy_c = LDB(f.tyy, oc);
                 tyy_y = LDB(f.tyy, oc + dy1);
-                fx_c = LDB(f.fx, oc); fy_c = LDB(f.fy, oc); fy_y = LDB(f.fy, oc + dy1);
+                fx_c = LDN<(NT & 2) != 0>(f.fx, oc); fy_c = LDN<(NT & 2) != 0>(f.fy, oc); fy_y = LDN<(NT & 2) != 0>(f.fy, oc + dy1);
                 vx = LDB(f.Vx, ovx); vy = LDB(f.Vy, ovy); vz = LDB(f.Vz, ovz);
             }
         }
@@ -755,23 +768,23 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 if (!hx) { q11 = LDB(f.txy, oxy + 8u + rxy); s11 = LDB(f.txz, oxz + 8u); }
             } else {
                 q11 = LDB(f.txy, oxy + 8u + rxy); q10 = LDB(f.txy, oxy + 8u); s11 = LDB(f.txz, oxz + 8u);
-                Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = LDB(f.fx, oc + dx1);
+                Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = LDN<(NT & 2) != 0>(f.fx, oc + dx1);
             }
             const bool own = avalid && live;
             if (hx) {
                 const double R = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx - 0.5 * (fx_c + fx_x);
                 vxn = vx + R * edt / (0.5 * (ec + ex));
-                if (own) STB(a.o.Vx, ovx, vxn);
+                if (own) STN<(NT & 1) != 0>(a.o.Vx, ovx, vxn);
             } else vxn = bc.nsR ? 0.0 : vx;
             if (hy) {
                 const double R = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy - 0.5 * (fy_c + fy_y);
                 vyn = vy + R * edt / (0.5 * (ec + eyb));
-                if (own) STB(a.o.Vy, ovy, vyn);
+                if (own) STN<(NT & 1) != 0>(a.o.Vy, ovy, vyn);
             } else vyn = bc.nsBk ? 0.0 : vy;
             if (hz) {
                 const double R = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz - 0.5 * (fz_c + fz_z);
                 vzn = vz + R * edt / (0.5 * (ec + ez));
-                if (own) STB(a.o.Vz, ovz, vzn);
+                if (own) STN<(NT & 1) != 0>(a.o.Vz, ovz, vzn);
             } else vzn = bc.nsK1 ? 0.0 : vz;
             Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11; s01p = s01; r01p = r01;
             sV[slot][0][ty][tx] = vxn; sV[slot][1][ty][tx] = vyn; sV[slot][2][ty][tx] = vzn;
@@ -824,13 +837,13 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double _Kdt = 1.0 / (Kc * dt);
                     const double rhs = -divV + (Qc * _dt);
                     const double psi = 1.0 / (1.0 / e + _Gdt) * rr / th;
-                    STB(a.o.P, oc, (fma(P0, _Kdt, rhs) * psi + P_k) / (1.0 + _Kdt * psi));
+                    STN<(NT & 1) != 0>(a.o.P, oc, (fma(P0, _Kdt, rhs) * psi + P_k) / (1.0 + _Kdt * psi));
                     const double d3 = divV * (1.0 / 3.0);
                     const double exx = dxi - d3, eyy = dyi - d3, ezz = dzi - d3;
                     const double dtr = dev_dtau_r(th, e, _Gdt);
-                    STB(a.o.txx, oc, txx_c + dev_stress_inc(txx_c, toxx, e, exx, _Gdt, dtr));
-                    STB(a.o.tyy, oc, tyy_c + dev_stress_inc(tyy_c, toyy, e, eyy, _Gdt, dtr));
-                    STB(a.o.tzz, oc, tzz_k + dev_stress_inc(tzz_k, tozz, e, ezz, _Gdt, dtr));
+                    STN<(NT & 1) != 0>(a.o.txx, oc, txx_c + dev_stress_inc(txx_c, toxx, e, exx, _Gdt, dtr));
+                    STN<(NT & 1) != 0>(a.o.tyy, oc, tyy_c + dev_stress_inc(tyy_c, toyy, e, eyy, _Gdt, dtr));
+                    STN<(NT & 1) != 0>(a.o.tzz, oc, tzz_k + dev_stress_inc(tzz_k, tozz, e, ezz, _Gdt, dtr));
                 }
                 {   // τxy (i,j,k)
                     const double s_ = 0.5 * (_dy * (va - vay) + _dx * (vb - vbx));
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double gg = 0.25 * (gxy + gy + gx + g);
                     const double _Gdt = 1.0 / (gg * dt);
                     const double dtr = dev_dtau_r(th, ee, _Gdt);
-                    STB(a.o.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
+                    STN<(NT & 1) != 0>(a.o.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
                 }
                 {   // τxz (i,j,k)
                     const double s_ = 0.5 * (_dz * (va - a_p) + _dx * (c_p - cx_p));
@@ -846,7 +859,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double gg = 0.25 * ((LOWREG ? gxg_p : gx_p + g_p) + gx + g);
                     const double _Gdt = 1.0 / (gg * dt);
                     const double dtr = dev_dtau_r(th, ee, _Gdt);
-                    STB(a.o.txz, oxz - sxz, s01k + dev_stress_inc(s01k, toxz, ee, s_, _Gdt, dtr));
+                    STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01k + dev_stress_inc(s01k, toxz, ee, s_, _Gdt, dtr));
                 }
                 {   // τyz (i,j,k)
                     const double s_ = 0.5 * (_dz * (vb - b_p) + _dy * (c_p - cy_p));
@@ -854,7 +867,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double gg = 0.25 * ((LOWREG ? gyg_p : gy_p + g_p) + gy + g);
                     const double _Gdt = 1.0 / (gg * dt);
                     const double dtr = dev_dtau_r(th, ee, _Gdt);
-                    STB(a.o.tyz, oyz - syz, r01k + dev_stress_inc(r01k, toyz, ee, s_, _Gdt, dtr));
+                    STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01k + dev_stress_inc(r01k, toyz, ee, s_, _Gdt, dtr));
                 }
             }
             if (LOWREG) { exe_p = ex + e; eye_p = ey + e; gxg_p = gx + g; gyg_p = gy + g; }

@@ -308,6 +308,32 @@ int main(int argc, char **argv)
             report("fused 64x4x16 xg4 SHFL+YLDS", T.run(reps, fx4), 360.0, 0);
             auto fx16 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 16, false, true, 1>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
             report("fused 64x4x16 xg16 SHFL+YLDS", T.run(reps, fx16), 360.0, 0);
+            auto fnt1 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 xg8 SHFL+YLDS nt-stores", T.run(reps, fnt1), 360.0, 0);
+            auto fnt2 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 8, false, true, 1, 2>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 xg8 SHFL+YLDS nt-loads(streaming arrays)", T.run(reps, fnt2), 360.0, 0);
+            auto fnt3 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 2, 1, false, 8, false, true, 1, 3>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 xg8 SHFL+YLDS nt-both", T.run(reps, fnt3), 360.0, 0);
+            const int nty5 = (ny + 3) / 4, nty3 = (ny + 1) / 2;
+            auto f5 = [&] { hipLaunchKernelGGL((k_fused3d<64, 5, 16, 2, 1, false, 8, false, true, 1>), dim3(ntx * nty5 * ntz), dim3(320), 0, 0, b, bc, ntx, nty5); };
+            report("fused 64x5x16 xg8 SHFL+YLDS", T.run(reps, f5), 360.0, 0);
+            auto f3 = [&] { hipLaunchKernelGGL((k_fused3d<64, 3, 16, 2, 1, false, 8, false, true, 1>), dim3(ntx * nty3 * ntz), dim3(192), 0, 0, b, bc, ntx, nty3); };
+            report("fused 64x3x16 xg8 SHFL+YLDS", T.run(reps, f3), 360.0, 0);
+            auto g4 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 16, 4, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty * ntz), dim3(256), 0, 0, b, bc, ntx, nty); };
+            report("fused 64x4x16 minw4 YLDS nt-stores", T.run(reps, g4), 360.0, 0);
+            auto g6 = [&] { hipLaunchKernelGGL((k_fused3d<64, 6, 16, 4, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty6 * ntz), dim3(384), 0, 0, b, bc, ntx, nty6); };
+            report("fused 64x6x16 minw4 YLDS nt-stores", T.run(reps, g6), 360.0, 0);
+            auto g8 = [&] { hipLaunchKernelGGL((k_fused3d<64, 8, 16, 4, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty8 * ntz), dim3(512), 0, 0, b, bc, ntx, nty8); };
+            report("fused 64x8x16 minw4 YLDS nt-stores", T.run(reps, g8), 360.0, 0);
+            auto g88 = [&] { hipLaunchKernelGGL((k_fused3d<64, 8, 8, 4, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty8 * ntz8), dim3(512), 0, 0, b, bc, ntx, nty8); };
+            report("fused 64x8x8 minw4 YLDS nt-stores", T.run(reps, g88), 360.0, 0);
+            const int nty12 = (ny + 10) / 11;
+            auto h12 = [&] { hipLaunchKernelGGL((k_fused3d<64, 12, 16, 1, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty12 * ntz), dim3(768), 0, 0, b, bc, ntx, nty12); };
+            report("fused 64x12x16 minw1 YLDS nt-stores", T.run(reps, h12), 360.0, 0);
+            auto h128 = [&] { hipLaunchKernelGGL((k_fused3d<64, 12, 8, 1, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty12 * ntz8), dim3(768), 0, 0, b, bc, ntx, nty12); };
+            report("fused 64x12x8 minw1 YLDS nt-stores", T.run(reps, h128), 360.0, 0);
+            auto h1232 = [&] { hipLaunchKernelGGL((k_fused3d<64, 12, 32, 1, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty12 * ntz32), dim3(768), 0, 0, b, bc, ntx, nty12); };
+            report("fused 64x12x32 minw1 YLDS nt-stores", T.run(reps, h1232), 360.0, 0);
             report("fused 64x4x16 xg8 SHFL+YLDS (again)", T.run(reps, fy), 360.0, 0);
             report("fused 64x4x16 xg8 SHFL (again)", T.run(reps, fn), 360.0, 0);
         }

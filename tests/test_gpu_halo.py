@@ -71,13 +71,18 @@ def test_periodic_self_exchange(jr, through_rccl, periods):
     assert any(not np.array_equal(a, b) for a, b in zip(got, host))
 
 
-@pytest.mark.parametrize("through_rccl,variant,periods", [(False, 2, (1, 0, 1)), (True, 2, (1, 0, 1)), (False, 3, (1, 0, 1)),
-                                                          (True, 3, (1, 1, 1)), (False, 3, (0, 1, 0))])
-def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracle, through_rccl, variant, periods):
+@pytest.mark.parametrize("through_rccl,variant,periods,n", [(False, 2, (1, 0, 1), (70, 13, 12)), (True, 2, (1, 0, 1), (70, 13, 12)),
+                                                            (False, 3, (1, 0, 1), (70, 13, 12)), (True, 3, (1, 1, 1), (70, 13, 12)),
+                                                            (False, 3, (0, 1, 0), (70, 13, 12)),
+                                                            # 3 x 5 x 3 tiles of the fused kernel: all six shell boxes + an interior box
+                                                            (True, 3, (1, 1, 1), (130, 14, 40)), (False, 0, (1, 0, 1), (130, 14, 40)),
+                                                            # 13 = variant 3 with option fused_overlap (shell on the halo stream)
+                                                            (True, 13, (1, 1, 1), (130, 14, 40)), (False, 13, (0, 1, 1), (70, 13, 12))])
+def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracle, through_rccl, variant, periods, n):
     """The N > 1 code path of jrx_stokes3d_solve on one GPU: the grid is IGG-periodic in some dimensions, so the rank is its own
     neighbour there.  variant 2: split sweeps (boundary slabs first on the halo stream, interior concurrently on the compute stream,
-    BCs + update_halo! behind the slabs; Stokes3D.jl:104-142).  variant 3: fused velocity+stress kernel, BCs, update_halo!, then the
-    stress nodes next to a received plane redone.  Norms of the global count.  Expected = the CPU oracle's iteration followed by
+    BCs + update_halo! behind the slabs; Stokes3D.jl:104-142).  variant 3: fused velocity+stress kernel (shell of tiles first on the halo stream, interior tiles concurrently on the
+    compute stream), BCs, update_halo!, then the stress nodes next to a received plane redone.  Norms of the global count.  Expected = the CPU oracle's iteration followed by
     the same plane copies in numpy.  Tolerance 1e-12 of each field's max (observed: bit-identical)."""
     import ctypes as C
     import torch
@@ -86,7 +91,6 @@ def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracl
     import justrelax_jl_amd.grid as g
     orc = oracle
     L = _lib.load()
-    n = (70, 13, 12)
     iters = 8
     s = jr.miniapps.random_fields3d(n, seed=11, iterMax=iters - 1, nout=4)
     s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
@@ -99,12 +103,14 @@ def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracl
         if through_rccl:
             os.environ["JRX_HALO_SELF_RCCL"] = "1"
         halo.init_comm(h)
-        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant % 10))
+        h.call("jrx_set_option", C.c_char_p(b"fused_overlap"), C.c_int64(variant // 10))
         stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
         r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
         got = download_stokes(stokes)
     finally:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
+        h.call("jrx_set_option", C.c_char_p(b"fused_overlap"), C.c_int64(0))
         if old is None:
             os.environ.pop("JRX_HALO_SELF_RCCL", None)
         else:
