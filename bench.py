@@ -27,11 +27,11 @@ A_VELOCITY = 17 * 8.0    # velocity sweep: 14 reads + 3 writes
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # L2<->fabric bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
 # correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
-# n = 512: profiles/r01_pmc_xcd_banded_traffic.txt
+# n = 512: profiles/r01_pmc_xcd_banded_traffic.txt, profiles/r01_pmc_fused_ylds_traffic.txt
 #   k_stress3d_zb<512,1,4,xcd8>: FETCH_SIZE 13048845 KB, WRITE_SIZE 7410032 KB   (algorithmic: 21 + 7 passes of 1.074 GB)
-#   k_fused3d<64,4,16,xg8>:      FETCH_SIZE 19537921 KB, WRITE_SIZE 11148566 KB  (needs 25 + 10 passes)
+#   k_fused3d<64,4,16,xg8,shfl,ylds,nt>: FETCH_SIZE 17936302 KB, WRITE_SIZE 11036094 KB  (needs 25 + 10 passes; fetched 34.2 + written 10.5)
 PMC_TRAFFIC_STRESS_512 = (2 * 13048845.0 + 7410032.0) * 1024.0
-PMC_TRAFFIC_FUSED_512 = (2 * 19537921.0 + 11148566.0) * 1024.0
+PMC_TRAFFIC_FUSED_512 = (2 * 17936302.0 + 11036094.0) * 1024.0
 
 
 def cpu_baseline(n_cpu: int, budget_s: float):
