@@ -413,7 +413,9 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
     static const bool ylds = [] { const char *e = getenv("JRX_FUSED_YLDS"); return !(e && e[0] == '0'); }();
     if (ylds)
         // + non-temporal stores: the written set is not read again before the next iteration (PMC: 35.7 -> 34.2 fetched passes, -0.5 .. -1.6 % time)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true, 1, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        // + register diet to 128 VGPRs without spills (4 waves/SIMD): previous velocity plane re-read from a third LDS slot, previous η/G
+        //   plane carried as partial sums, the nine stress-only operands requested after the velocity phase (-1 .. -5 %)
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 8, false, true, 3, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     JRX_LAUNCH_CHECK(h);

@@ -606,7 +606,7 @@ template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, in
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0)
 {
     // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
-    static_assert(!(SHFL && (LATEA || LOWREG || TX != 64)), "SHFL is implemented for the default register layout and 64-lane rows");
+    static_assert(!(SHFL && (LATEA || TX != 64)), "SHFL is implemented for 64-lane rows");
     static_assert(!YLDS || SHFL, "YLDS builds on the SHFL operand layout");
     constexpr int NS = LOWREG ? 3 : 2;
     __shared__ double sV[NS][3][TY][TX];
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double e_l = __shfl_up(e, 1, 64), g_l = __shfl_up(g, 1, 64), ey_l = __shfl_up(ey, 1, 64), gy_l = __shfl_up(gy, 1, 64);
                     ex = i > 0 ? e_l : e; gx = i > 0 ? g_l : g; exy_ = i > 0 ? ey_l : ey; gxy = i > 0 ? gy_l : gy;
                 }
-                if (YLDS != 2 && avalid && live) {
+                if (YLDS < 2 && avalid && live) {
                     P0 = LDN<(NT & 2) != 0>(f.P0, oc); Kc = LDN<(NT & 2) != 0>(f.K, oc); Qc = LDN<(NT & 2) != 0>(f.Q, oc);
                     toxx = LDN<(NT & 2) != 0>(f.toxx, oc); toyy = LDN<(NT & 2) != 0>(f.toyy, oc); tozz = LDN<(NT & 2) != 0>(f.tozz, oc);
                     toxy = LDN<(NT & 2) != 0>(f.toxy, oxy);
@@ -788,6 +788,13 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             } else vzn = bc.nsK1 ? 0.0 : vz;
             Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11; s01p = s01; r01p = r01;
             sV[slot][0][ty][tx] = vxn; sV[slot][1][ty][tx] = vyn; sV[slot][2][ty][tx] = vzn;
+        }
+        if (YLDS == 3 && avalid && live) {
+            // lower register peak: the stress-only operands are requested once the velocity operands are consumed
+            P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
+            toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
+            toxy = LDB(f.toxy, oxy);
+            toxz = LDB(f.toxz, oxz - sxz); toyz = LDB(f.toyz, oyz - syz);
         }
         if (LATEA) {
             // lower register peak (4 waves/SIMD): the stress operands are requested only once the velocity

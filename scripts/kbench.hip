@@ -334,6 +334,17 @@ int main(int argc, char **argv)
             report("fused 64x12x8 minw1 YLDS nt-stores", T.run(reps, h128), 360.0, 0);
             auto h1232 = [&] { hipLaunchKernelGGL((k_fused3d<64, 12, 32, 1, 1, false, 8, false, true, 1, 1>), dim3(ntx * nty12 * ntz32), dim3(768), 0, 0, b, bc, ntx, nty12); };
             report("fused 64x12x32 minw1 YLDS nt-stores", T.run(reps, h1232), 360.0, 0);
+#define FV(TY_, MW_, LR_, YL_, NTY_, NM_)                                                                                                    \
+            {                                                                                                                                    \
+                auto f_ = [&] { hipLaunchKernelGGL((k_fused3d<64, TY_, 16, MW_, 1, LR_, 8, false, true, YL_, 1>), dim3(ntx * NTY_ * ntz), dim3(64 * TY_), 0, 0, b, bc, ntx, NTY_); }; \
+                report(NM_, T.run(reps, f_), 360.0, 0);                                                                                          \
+            }
+            FV(4, 2, true, 1, nty, "fused 64x4 lowreg ylds1 minw2")
+            FV(4, 2, false, 3, nty, "fused 64x4 ylds3(late stress operands) minw2")
+            FV(4, 2, true, 3, nty, "fused 64x4 lowreg ylds3 minw2")
+            FV(4, 4, true, 3, nty, "fused 64x4 lowreg ylds3 minw4")
+            FV(8, 4, true, 3, nty8, "fused 64x8 lowreg ylds3 minw4")
+            FV(8, 2, true, 3, nty8, "fused 64x8 lowreg ylds3 minw2")
             report("fused 64x4x16 xg8 SHFL+YLDS (again)", T.run(reps, fy), 360.0, 0);
             report("fused 64x4x16 xg8 SHFL (again)", T.run(reps, fn), 360.0, 0);
         }
