@@ -68,6 +68,40 @@ __global__ __launch_bounds__(256) void k_bc3d(BcArr A0, BcArr A1, BcArr A2, int 
     }
 }
 
+// free_slip / no_slip on all six faces in ONE launch (blockIdx.z = dimension; tlo/thi: 0 none, 1 free slip, 2 no slip).
+// Every ghost entry that lies on exactly one ghost plane gets the value the ordered passes above give it; entries on two or three
+// ghost planes (edge / corner ghosts) depend on the pass order there and are left racy here -- no stencil of the Stokes kernels
+// reads them.  Used between fused iterations only; the ordered passes run before results are handed back.
+__global__ __launch_bounds__(256) void k_bc3d_faces(BcArr A0, BcArr A1, BcArr A2, int tlo0, int thi0, int tlo1, int thi1, int tlo2, int thi2)
+{
+    const BcArr arrs[3] = {A0, A1, A2};
+    const int dim = blockIdx.z;
+    const int tlo = dim == 0 ? tlo0 : (dim == 1 ? tlo1 : tlo2), thi = dim == 0 ? thi0 : (dim == 1 ? thi1 : thi2);
+    if (!tlo && !thi) return;
+    const int d1 = dim == 0 ? 1 : 0, d2 = dim == 2 ? 1 : 2;
+    const int ta = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tb = blockIdx.y;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const BcArr &A = arrs[c];
+        if (ta >= A.n[d1] || tb >= A.n[d2]) continue;
+        const bool normal = (c == dim);
+        const i64 s[3] = {1, A.n[0], (i64)A.n[0] * A.n[1]};
+        const i64 base = ta * s[d1] + tb * s[d2];
+        const int e = A.n[dim];
+        double *p = A.p;
+        if (normal) {
+            if (tlo == 2) p[base] = 0.0;
+            if (thi == 2) p[base + (e - 1) * s[dim]] = 0.0;
+        } else {
+            if (tlo == 1) p[base] = p[base + s[dim]];
+            else if (tlo == 2) p[base] = -p[base + s[dim]];
+            if (thi == 1) p[base + (e - 1) * s[dim]] = p[base + (e - 2) * s[dim]];
+            else if (thi == 2) p[base + (e - 1) * s[dim]] = -p[base + (e - 2) * s[dim]];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // compute_maxloc! (Utils.jl:409-461), clamped 3x3x3 (or 3x3 when nz == 1) window maximum
 // ------------------------------------------------------------------------------------------------

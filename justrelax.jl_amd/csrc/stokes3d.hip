@@ -178,6 +178,44 @@ jrx_status launch_bcs(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, doub
     return JRX_OK;
 }
 
+// free_slip / no_slip of all faces in one launch: equal to launch_bcs on every entry a Stokes stencil reads once the ordered passes
+// have run at least once on the same arrays (normal planes of no-slip faces are then already zero); see k_bc3d_faces
+static jrx_status launch_bcs_faces(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz, uint32_t fs, uint32_t ns)
+{
+    BcArr A[3] = {{Vx, {nx + 1, ny + 2, nz + 2}}, {Vy, {nx + 2, ny + 1, nz + 2}}, {Vz, {nx + 2, ny + 2, nz + 1}}};
+    // 3D naming of the reference: free_slip `top` <-> k = 1, no_slip `bot` <-> k = 1 (App. C.4)
+    auto ty = [&](uint32_t fsbit, uint32_t nsbit) { return (ns & nsbit) ? 2 : ((fs & fsbit) ? 1 : 0); };
+    const int t[6] = {ty(JRX_FACE_LEFT, JRX_FACE_LEFT), ty(JRX_FACE_RIGHT, JRX_FACE_RIGHT), ty(JRX_FACE_FRONT, JRX_FACE_FRONT),
+                      ty(JRX_FACE_BACK, JRX_FACE_BACK), ty(JRX_FACE_TOP, JRX_FACE_BOT), ty(JRX_FACE_BOT, JRX_FACE_TOP)};
+    if (!(t[0] | t[1] | t[2] | t[3] | t[4] | t[5])) return JRX_OK;
+    const int na = (nx > ny ? nx : ny) + 2, nb = (ny > nz ? ny : nz) + 2;      // in-plane extents never exceed these
+    hipLaunchKernelGGL(k_bc3d_faces, dim3((na + 255) / 256, nb, 3), dim3(256), 0, s, A[0], A[1], A[2], t[0], t[1], t[2], t[3], t[4], t[5]);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
+// the stress sweep over up to six disjoint node boxes in one launch
+static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepArgs &a, const int (*box)[6], int nbox)
+{
+    StressBoxes B = {};
+    int tot = 0;
+    for (int q = 0; q < nbox; q++) {
+        const int *b = box[q];
+        if (b[1] <= b[0] || b[3] <= b[2] || b[5] <= b[4]) continue;
+        const i64 plane = (i64)(b[1] - b[0]) * (b[3] - b[2]);
+        for (int c = 0; c < 6; c++) B.box[B.n][c] = b[c];
+        B.per_plane[B.n] = (int)((plane + 255) / 256);
+        B.start[B.n] = tot;
+        tot += B.per_plane[B.n] * (b[5] - b[4]);
+        B.n++;
+    }
+    if (!B.n) return JRX_OK;
+    B.start[B.n] = tot;
+    hipLaunchKernelGGL(k_stress3d_boxes, dim3((unsigned)tot), dim3(256), 0, s, a, B);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
+
 jrx_status launch_sumsq(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
 {
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
@@ -337,6 +375,7 @@ struct Iter3D {
     bool cur_is_user = true;
     bool stress_done = false;     // A of the upcoming iteration already applied (by a fused launch)
     bool fusable = false;
+    bool bcs_ordered[2] = {false, false};   // flow_bcs! has run with the reference's pass order on the V of set U / set S
 };
 
 static Out10 out_of(const jrx_stokes3d_fields &f) { return Out10{f.P, f.txx, f.tyy, f.tzz, f.tyz, f.txz, f.txy, f.Vx, f.Vy, f.Vz}; }
@@ -452,6 +491,13 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         fused_tiles<64, 4, 16>(a.L, nt);
         const bool comm = jrx_comm_active(h);
         hipStream_t bs = s;            // stream of the boundary work
+        // flow_bcs! on the new V: the reference's ordered passes the first time a set is written, one launch for all faces afterwards
+        bool &ordered = I.bcs_ordered[I.cur_is_user ? 1 : 0];
+        auto fused_bcs = [&](hipStream_t st) -> jrx_status {
+            if (ordered) return launch_bcs_faces(h, st, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip);
+            ordered = true;
+            return launch_bcs(h, st, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic);
+        };
         bool nb[3][2] = {};
         // option "fused_overlap" / JRX_FUSED_OVERLAP=1: shell of tiles + BCs + exchange on the halo stream, interior tiles concurrently (see below).  Off by
         // default: measured on one device (periodic self neighbour through RCCL, profiles/r01_selfhalo_overlap_*.txt) the RCCL
@@ -463,7 +509,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
             JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc, all)));
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
-            JRX_TRY(launch_bcs(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+            JRX_TRY(fused_bcs(s));
             if (comm) {
                 // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
                 double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
@@ -491,7 +537,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             for (int q = 0; q < 6; q++) JRX_TRY((launch_fused<64, 4, 16>(h, bs, a, bc, boxes[q])));
             const int inner[6] = {mid[0][0], mid[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]};
             JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc, inner)));
-            JRX_TRY(launch_bcs(h, bs, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+            JRX_TRY(fused_bcs(bs));
             // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
             double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
             const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
@@ -506,12 +552,9 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         e.f.Vx = dst.Vx; e.f.Vy = dst.Vy; e.f.Vz = dst.Vz;
         const int ilo = nb[0][0] ? 1 : 0, ihi = nb[0][1] ? nx - 1 : nx, jlo = nb[1][0] ? 1 : 0, jhi = nb[1][1] ? ny - 1 : ny,
                   klo = nb[2][0] ? 1 : 0, khi = nb[2][1] ? nz - 1 : nz;
-        if (ilo) JRX_TRY(launch_stress_v1(h, bs, e, false, 0, ilo, 0, ny + 1, 0, nz + 1));
-        JRX_TRY(launch_stress_v1(h, bs, e, false, ihi, nx + 1, 0, ny + 1, 0, nz + 1));
-        if (jlo) JRX_TRY(launch_stress_v1(h, bs, e, false, ilo, ihi, 0, jlo, 0, nz + 1));
-        JRX_TRY(launch_stress_v1(h, bs, e, false, ilo, ihi, jhi, ny + 1, 0, nz + 1));
-        if (klo) JRX_TRY(launch_stress_v1(h, bs, e, false, ilo, ihi, jlo, jhi, 0, klo));
-        JRX_TRY(launch_stress_v1(h, bs, e, false, ilo, ihi, jlo, jhi, khi, nz + 1));
+        const int fix[6][6] = {{0, ilo, 0, ny + 1, 0, nz + 1}, {ihi, nx + 1, 0, ny + 1, 0, nz + 1}, {ilo, ihi, 0, jlo, 0, nz + 1},
+                               {ilo, ihi, jhi, ny + 1, 0, nz + 1}, {ilo, ihi, jlo, jhi, 0, klo}, {ilo, ihi, jlo, jhi, khi, nz + 1}};
+        JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6));
         if (bs != s) {
             JRX_HIP(h, hipEventRecord(h->ev[2], bs));
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
@@ -707,9 +750,13 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     JRX_TRY(iter_begin(I, h, f, etatau, p));
     JRX_HIP(h, hipStreamSynchronize(s));
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
+    // every fused step flips the ping-pong set: with an odd number of them the first step stays un-fused (one extra sweep pair,
+    // ~1 ms at 512^3) so that the batch ends in the caller's arrays instead of paying the copy-back of ten arrays (~4 ms)
+    const bool first_unfused = I.fusable && iters >= 2 && ((iters - 1) % 2 == 1);
     for (int64_t it = 0; it < iters; it++) {
         const bool samp = it % stride == 0;
-        JRX_TRY(iter_step(I, false, it + 1 < iters, samp ? &evs[(size_t)(it / stride) * 4] : nullptr, samp ? &fused[(size_t)(it / stride)] : nullptr));
+        const bool fuse_next = it + 1 < iters && !(first_unfused && it == 0);
+        JRX_TRY(iter_step(I, false, fuse_next, samp ? &evs[(size_t)(it / stride) * 4] : nullptr, samp ? &fused[(size_t)(it / stride)] : nullptr));
     }
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_TRY(iter_end(I));

@@ -56,17 +56,10 @@ struct SweepArgs {
 // so that rows of any length (nx, nx+1, nx+2) stay fully coalesced; blockIdx.y walks z.
 // ------------------------------------------------------------------------------------------------
 template <bool DIAG>
-__global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
+__device__ __forceinline__ void stress3d_node(const SweepArgs &a, const int i, const int j, const int k)
 {
     const Lay3 &L = a.L;
     const int nx = L.nx, ny = L.ny, nz = L.nz;
-    const int wi = a.i1 - a.i0;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int jj = t / wi;
-    const int i = a.i0 + (t - jj * wi);
-    const int j = a.j0 + jj;
-    const int k = a.k0 + blockIdx.y;
-    if (j >= a.j1) return;
 
     const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
     const double *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
@@ -154,6 +147,39 @@ __global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
 #undef VX
 #undef VY
 #undef VZ
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(256) void k_stress3d(const SweepArgs a)
+{
+    const int wi = a.i1 - a.i0;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int jj = t / wi;
+    const int j = a.j0 + jj;
+    if (j >= a.j1) return;
+    stress3d_node<DIAG>(a, a.i0 + (t - jj * wi), j, a.k0 + (int)blockIdx.y);
+}
+
+// the same over up to six disjoint node boxes in one launch (the thin boundary layers behind the fused kernel):
+// blocks [start[b], start[b+1]) belong to box b, each covering 256 nodes of one xy-plane of the box
+struct StressBoxes {
+    int n;
+    int box[6][6];        // i0, i1, j0, j1, k0, k1
+    int start[7];         // first block of each box; start[n] = total
+    int per_plane[6];     // blocks per xy-plane of the box
+};
+__global__ __launch_bounds__(256) void k_stress3d_boxes(const SweepArgs a, const StressBoxes B)
+{
+    int b = 0;
+    while (b + 1 < B.n && (int)blockIdx.x >= B.start[b + 1]) b++;
+    const int lb = (int)blockIdx.x - B.start[b];
+    const int kz = lb / B.per_plane[b], bx = lb - kz * B.per_plane[b];
+    const int wi = B.box[b][1] - B.box[b][0];
+    const int t = bx * 256 + (int)threadIdx.x;
+    const int jj = t / wi;
+    const int j = B.box[b][2] + jj;
+    if (j >= B.box[b][3]) return;
+    stress3d_node<false>(a, B.box[b][0] + (t - jj * wi), j, B.box[b][4] + kz);
 }
 
 // ------------------------------------------------------------------------------------------------
