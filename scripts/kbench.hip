@@ -11,6 +11,7 @@
 #include <string>
 #include "jrx_internal.hpp"
 #include "stokes3d_kernels.hpp"
+#include "fused_ws.hpp"
 namespace {
 #include "fused_exp.hpp"
 }
