@@ -34,6 +34,13 @@ struct Vep3Args {
     const int j = t_ / (n1_), i = t_ - j * (n1_), k = blockIdx.y;       \
     if (j >= (n2_)) return;
 #define GRID_IJK(n1_, n2_, n3_) dim3((unsigned)(((i64)(n1_) * (n2_) + 255) / 256), (unsigned)(n3_))
+// block = 64 consecutive nodes of the flattened xy plane x 4 consecutive planes (one plane per wave): the k-1 / k+1 operands of the
+// gathering kernels are the neighbouring waves' k operands and meet in the CU's L1 (JRX_VEP_MAP=0 keeps the one-plane blocks)
+#define NODE_IJK4(n1_, n2_, n3_)                                                     \
+    const int t_ = blockIdx.x * 64 + (threadIdx.x & 63);                             \
+    const int j = t_ / (n1_), i = t_ - j * (n1_), k = blockIdx.y * 4 + (threadIdx.x >> 6); \
+    if (j >= (n2_) || k >= (n3_)) return;
+#define GRID_IJK4(n1_, n2_, n3_) dim3((unsigned)(((i64)(n1_) * (n2_) + 63) / 64), (unsigned)(((n3_) + 3) / 4))
 
 __device__ __forceinline__ int clampi3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ double sinv3(const double t[6])
@@ -168,26 +175,21 @@ __host__ __device__ constexpr int oth3(int t, int s, int q, int d)
     return T[t][s][q][d];
 }
 
-// update_stresses_center_vertex_ps! 3D -- one edge family at node (i, j, k) (StressKernels.jl:707-903)
+// update_stresses_center_vertex_ps! 3D -- one edge family at node (i, j, k) (StressKernels.jl:707-903).
+// cen[s][T]: the clamped 4-cell averages of the normal components (s = 0..2: ε, 3..5: τ, 6..8: τ_o) for family T, etav / Pv: harmonic η
+// and average θ, gathered once per node for the three families (vep3_gather_centres)
+struct CenAvg {
+    double v[9][3], etav[3], Pv[3];
+};
 template <int T>
-__device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, int k)
+__device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, int k, const int ci[3], const int cj[3], const int ck[3], const CenAvg &C)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
     const int n1 = nx + (T != 0), n2 = ny + (T != 1), n3 = nz + (T != 2);
     if (i >= n1 || j >= n2 || k >= n3) return;
-    const int ci[3] = {clampi3(i - 1, 0, nx - 1), clampi3(i, 0, nx - 1), clampi3(i + 1, 0, nx - 1)};
-    const int cj[3] = {clampi3(j - 1, 0, ny - 1), clampi3(j, 0, ny - 1), clampi3(j + 1, 0, ny - 1)};
-    const int ck[3] = {clampi3(k - 1, 0, nz - 1), clampi3(k, 0, nz - 1), clampi3(k + 1, 0, nz - 1)};
-    // 32-bit byte offsets on the (uniform) array bases: every array is < 4 GiB (check_vep3), and the loads become
-    // base-in-SGPR + 32-bit VGPR offset instead of a 64-bit address per access
     typedef unsigned int u32;
 #define LB(p, off) (*(const double *)((const char *)(p) + (off)))
-    u32 cb[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) cb[q] = 8u * (u32)(ci[cen3(T, q, 0)] + nx * (cj[cen3(T, q, 1)] + ny * ck[cen3(T, q, 2)]));
-#define AVC(A) (0.25 * (LB(A, cb[0]) + LB(A, cb[1]) + LB(A, cb[2]) + LB(A, cb[3])))
-    const double etav = 4 / (1 / LB(a.f.eta, cb[0]) + 1 / LB(a.f.eta, cb[1]) + 1 / LB(a.f.eta, cb[2]) + 1 / LB(a.f.eta, cb[3]));
-    const double Pv = AVC(a.theta);
+    const double etav = C.etav[T], Pv = C.Pv[T];
     const u32 vb = 8u * (u32)(i + n1 * (j + n2 * k));
     const i64 v = i + (i64)n1 * (j + (i64)n2 * k);
     double *const tsh[3] = {a.f.tyz, a.f.txz, a.f.txy};
@@ -195,13 +197,9 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
     const double *const esh[3] = {a.f.eyz, a.f.exz, a.f.exy};
     double *const eplsh[3] = {a.f.eplyz, a.f.eplxz, a.f.eplxy};
     const double *const phsh[3] = {a.f.phase_yz, a.f.phase_xz, a.f.phase_xy};
-    const double *const en[3] = {a.f.exx, a.f.eyy, a.f.ezz};
-    const double *const tn[3] = {a.f.txx, a.f.tyy, a.f.tzz};
-    const double *const ton[3] = {a.f.toxx, a.f.toyy, a.f.tozz};
     double eij[6], tij[6], toij[6];
 #pragma unroll
-    for (int s = 0; s < 3; s++) { eij[s] = AVC(en[s]); tij[s] = AVC(tn[s]); toij[s] = AVC(ton[s]); }
-#undef AVC
+    for (int s = 0; s < 3; s++) { eij[s] = C.v[s][T]; tij[s] = C.v[3 + s][T]; toij[s] = C.v[6 + s][T]; }
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         if (s == T) { eij[3 + s] = LB(esh[s], vb); tij[3 + s] = LB(tsh[s], vb); toij[3 + s] = LB(tosh[s], vb); continue; }
@@ -241,16 +239,68 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
     }
 }
 
+// The clamped centre stencils of the three families lie in the 2 x 2 x 2 cube of cells below the node (cen3: bit = 1 own index,
+// 0 index - 1) and share 7 of its 8 cells: every centre array is read 7 times per node instead of 12, in the reference's order of
+// summation per family.
+__device__ __forceinline__ void vep3_gather_centres(const Vep3Args &a, const int ci[3], const int cj[3], const int ck[3], CenAvg &C)
+{
+    typedef unsigned int u32;
+    const int nx = a.nx, ny = a.ny;
+    u32 cb[8];
+#pragma unroll
+    for (int b = 1; b < 8; b++) cb[b] = 8u * (u32)(ci[b & 1] + nx * (cj[(b >> 1) & 1] + ny * ck[(b >> 2) & 1]));
+#define LB(p, off) (*(const double *)((const char *)(p) + (off)))
+#define CIDX(T, q) (cen3(T, q, 0) + 2 * cen3(T, q, 1) + 4 * cen3(T, q, 2))
+    const double *const arr[9] = {a.f.exx, a.f.eyy, a.f.ezz, a.f.txx, a.f.tyy, a.f.tzz, a.f.toxx, a.f.toyy, a.f.tozz};
+#pragma unroll
+    for (int s = 0; s < 9; s++) {
+        double v[8];
+#pragma unroll
+        for (int b = 1; b < 8; b++) v[b] = LB(arr[s], cb[b]);
+#pragma unroll
+        for (int T = 0; T < 3; T++) C.v[s][T] = 0.25 * (v[CIDX(T, 0)] + v[CIDX(T, 1)] + v[CIDX(T, 2)] + v[CIDX(T, 3)]);
+    }
+    {
+        double v[8];
+#pragma unroll
+        for (int b = 1; b < 8; b++) v[b] = LB(a.theta, cb[b]);
+#pragma unroll
+        for (int T = 0; T < 3; T++) C.Pv[T] = 0.25 * (v[CIDX(T, 0)] + v[CIDX(T, 1)] + v[CIDX(T, 2)] + v[CIDX(T, 3)]);
+#pragma unroll
+        for (int b = 1; b < 8; b++) v[b] = 1 / LB(a.f.eta, cb[b]);
+#pragma unroll
+        for (int T = 0; T < 3; T++) C.etav[T] = 4 / (v[CIDX(T, 0)] + v[CIDX(T, 1)] + v[CIDX(T, 2)] + v[CIDX(T, 3)]);
+    }
+#undef CIDX
+#undef LB
+}
+
 // The three edge families of one node in one thread, as in the reference's kernel: they share the clamped centre stencils
 // (η, θ, the normal components) and each other's shear components, so the second and third family mostly hit in L1/L2.
 // New edge stresses go to a.tnew (committed by the caller), so every read sees last iteration's values.
+template <bool P4>
 __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny;
-    NODE_IJK(nx + 1, ny + 1)
-    vep3_edge_body<0>(a, i, j, k);
-    vep3_edge_body<1>(a, i, j, k);
-    vep3_edge_body<2>(a, i, j, k);
+    int i, j, k;
+    if (P4) {
+        const int t_ = blockIdx.x * 64 + (threadIdx.x & 63);
+        j = t_ / (nx + 1); i = t_ - j * (nx + 1); k = blockIdx.y * 4 + (threadIdx.x >> 6);
+        if (j >= ny + 1 || k >= a.nz + 1) return;
+    } else {
+        const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
+        j = t_ / (nx + 1); i = t_ - j * (nx + 1); k = blockIdx.y;
+        if (j >= ny + 1) return;
+    }
+    const int nz = a.nz;
+    const int ci[3] = {clampi3(i - 1, 0, nx - 1), clampi3(i, 0, nx - 1), clampi3(i + 1, 0, nx - 1)};
+    const int cj[3] = {clampi3(j - 1, 0, ny - 1), clampi3(j, 0, ny - 1), clampi3(j + 1, 0, ny - 1)};
+    const int ck[3] = {clampi3(k - 1, 0, nz - 1), clampi3(k, 0, nz - 1), clampi3(k + 1, 0, nz - 1)};
+    CenAvg C;
+    vep3_gather_centres(a, ci, cj, ck, C);
+    vep3_edge_body<0>(a, i, j, k, ci, cj, ck, C);
+    vep3_edge_body<1>(a, i, j, k, ci, cj, ck, C);
+    vep3_edge_body<2>(a, i, j, k, ci, cj, ck, C);
 }
 
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
@@ -419,7 +469,9 @@ EdgeN edge_counts(const jrx_vep3d_params *p)
 jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    hipLaunchKernelGGL(k_vep3_edges, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    static const bool p4 = [] { const char *e = getenv("JRX_VEP_MAP"); return !(e && e[0] == '0'); }();
+    if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     const EdgeN n = edge_counts(p);
     hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, a.f.tyz, (const double *)a.tnew[0], n.yz, a.f.txz, (const double *)a.tnew[1], n.xz, a.f.txy,

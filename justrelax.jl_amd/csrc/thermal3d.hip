@@ -145,6 +145,152 @@ __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One PT iteration in one launch: compute_flux! + update_T! + thermal_bcs! (DiffusionPT_solver.jl:104-111) for iterations nobody
+// observes.  A block is a row segment of TX cells (whole waves) marching KZ planes; a thread owns cell (i, j, k) and stores the fluxes
+// on its three low faces (plus the high face where that is a domain face).  For its own update it also needs the new fluxes on its
+// high faces: x from the next lane (shuffle; the last lane of a wave computes it itself), y computed redundantly from the row above,
+// z computed here and carried to the next plane.  Because neighbouring blocks recompute fluxes that another block stores, fluxes and
+// T are read from one set (T, qT) and written to the other (ping-pong): 11 array reads + 4 writes per cell instead of 15 + 4
+// (6 + 3 and 9 + 1 for the two kernels).  No LDS, no barrier.  Same arithmetic, in the same order, as k_flux3d / k_updateT3d.
+// ------------------------------------------------------------------------------------------------
+struct TSet { double *T, *qx, *qy, *qz; };
+// R = rows per thread: the thread owns cells (i, j0 .. j0+R-1, k); the y fluxes between its rows are computed once, and only the
+// two rows j0-1 and j0+R are re-read from what neighbouring blocks own ((R+2)/R row reads of T, K, θ per cell instead of 3).
+// Shipped with R = 1: more rows per thread cost more in registers / occupancy than they save in re-reads (measured).
+template <int TX, int KZ, int XG, int R>
+__global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TSet dst, int ntx, int nty)
+{
+    const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
+    int tile = blockIdx.x;
+    {
+        // XCD-banded order (blocks are dealt round-robin to the 8 XCDs): XCD q takes XG consecutive row groups of every 8*XG, so that the
+        // rows j0-1 / j0+R a block re-reads were fetched by the same L2
+        const int rows = (int)(gridDim.x / (unsigned)ntx);          // nty * number of z chunks
+        const int full = (rows / (8 * XG)) * (8 * XG) * ntx;
+        if (tile < full) {
+            const int q = tile & 7, r = tile >> 3, r2 = r / ntx;
+            tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
+        }
+    }
+    const int tix = tile % ntx, tr = tile / ntx, j0 = (tr % nty) * R, tiz = tr / nty;
+    const int i = tix * TX + (int)threadIdx.x;
+    const int kb = tiz * KZ, kend = min(kb + KZ, nz);
+    // whole waves beyond the row end leave; lanes beyond it inside a live wave idle but stay for the shuffles
+    if (i >= nx && (i & ~63) >= nx) return;
+    const bool cell = i < nx;
+    const int ic = cell ? i : nx - 1;
+    const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau, *__restrict__ Kk = a.t.K;
+    const double kc = (a.p.k_const + a.p.k_const) * 0.5;
+    const bool rf = a.p.rheology_form != 0;
+    const double _dt = 1.0 / a.p.dt, _dx = a.p._dx, _dy = a.p._dy, _dz = a.p._dz;
+    const i64 sT1 = nx + 2, sT2 = (i64)(nx + 2) * (ny + 2), sC2 = (i64)nx * ny;
+    const int im = max(ic - 1, 0), ip = min(ic + 1, nx - 1);
+    const bool edge = (threadIdx.x & 63) == 63 || i == nx - 1;      // no lane to the right holds cell i+1
+    const bool cfxl = a.p.constant_flux_on[XL] != 0, cfxr = a.p.constant_flux_on[XR] != 0, cfyf = a.p.constant_flux_on[YF] != 0,
+               cfyb = a.p.constant_flux_on[YB] != 0, cfzb = a.p.constant_flux_on[ZB] != 0, cfzt = a.p.constant_flux_on[ZT] != 0;
+    // relaxed flux across a face: K and θ averaged over the two cells (clamped at the domain faces), T difference over the face
+    auto relax = [&](double qold, double Kl, double Kr, double tl, double tr_, double Thi, double Tlo, double _d) -> double {
+        const double K = rf ? kc : (Kl + Kr) * 0.5;
+        const double t = (tl + tr_) * 0.5;
+        const double qv = -K * (Thi - Tlo) * _d;
+        return (qold * t + qv) / (1.0 + t);
+    };
+    // plane-k operands of the own cells, carried upward: T (ghost-indexed k+1), K, θ and the flux on the low z face
+    double Tc[R], Kc_[R], tc[R], qz_lo[R];
+    bool rok[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        rok[r] = j0 + r < ny;
+        const int j = rok[r] ? j0 + r : ny - 1;
+        const i64 c = ic + (i64)nx * j + sC2 * kb, I1 = (ic + 1) + sT1 * (j + 1) + sT2 * (kb + 1);
+        Tc[r] = T[I1]; Kc_[r] = rf ? 0.0 : Kk[c]; tc[r] = th[c];
+        if (kb == 0 && cfzb) qz_lo[r] = a.p.constant_flux[ZB];
+        else {
+            const i64 cl = kb > 0 ? c - sC2 : c;
+            qz_lo[r] = relax(a.t.qTz[c], rf ? 0.0 : Kk[cl], Kc_[r], th[cl], tc[r], Tc[r], T[I1 - sT2], _dz);
+        }
+        if (kb == 0 && cell && rok[r]) dst.qz[c] = qz_lo[r];        // face 0 has no chunk below that would own it
+    }
+    const int jlo = max(j0 - 1, 0);                                   // clamped row of the K / θ average on the lowest y face
+    for (int k = kb; k < kend; ++k) {
+        // ---- y fluxes on the faces j0 .. j0+R of this column
+        double qy[R + 1];
+        {
+            // low halo row j0-1 (T ghost row when j0 = 0)
+            const i64 cl = ic + (i64)nx * jlo + sC2 * k;
+            const i64 q0 = ic + (i64)nx * (j0 + (i64)(ny + 1) * k);
+            if (j0 == 0 && cfyf) qy[0] = a.p.constant_flux[YF];
+            else qy[0] = relax(a.t.qTy[q0], rf ? 0.0 : Kk[cl], Kc_[0], th[cl], tc[0], Tc[0], T[(ic + 1) + sT1 * j0 + sT2 * (k + 1)], _dy);
+            if (cell) dst.qy[q0] = qy[0];
+#pragma unroll
+            for (int f = 1; f <= R; f++) {
+                const int jf = j0 + f;                                // face index; exists while jf <= ny
+                if (jf > ny) { qy[f] = 0.0; continue; }
+                const i64 q = q0 + (i64)nx * f;
+                if (jf == ny && cfyb) qy[f] = a.p.constant_flux[YB];
+                else if (f < R && rok[f]) qy[f] = relax(a.t.qTy[q], Kc_[f - 1], Kc_[f], tc[f - 1], tc[f], Tc[f], Tc[f - 1], _dy);
+                else {
+                    // upper cell is the row above this thread's rows, or the T ghost row behind the back face (K, θ clamped)
+                    const int ju = jf < ny ? jf : ny - 1;
+                    const i64 cu = ic + (i64)nx * ju + sC2 * k;
+                    qy[f] = relax(a.t.qTy[q], Kc_[f - 1], rf ? 0.0 : Kk[cu], tc[f - 1], th[cu], T[(ic + 1) + sT1 * (jf + 1) + sT2 * (k + 1)], Tc[f - 1], _dy);
+                }
+                if (cell && ((f < R && rok[f]) || jf == ny)) dst.qy[q] = qy[f];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (!rok[r]) continue;                                    // uniform over the block
+            const int j = j0 + r;
+            const i64 c = ic + (i64)nx * j + sC2 * k, I1 = (ic + 1) + sT1 * (j + 1) + sT2 * (k + 1);
+            // ---- x: low face i (own), high face i+1 from the next lane
+            double qx_lo;
+            {
+                const i64 q = ic + (i64)(nx + 1) * (j + (i64)ny * k);
+                if (ic == 0 && cfxl) qx_lo = a.p.constant_flux[XL];
+                else {
+                    const i64 cl = c - (ic - im);
+                    qx_lo = relax(a.t.qTx[q], rf ? 0.0 : Kk[cl], Kc_[r], th[cl], tc[r], Tc[r], T[I1 - 1], _dx);
+                }
+                if (cell) dst.qx[q] = qx_lo;
+            }
+            double qx_hi = __shfl_down(qx_lo, 1, 64);
+            if (edge) {
+                const i64 q = (ic + 1) + (i64)(nx + 1) * (j + (i64)ny * k);
+                if (ic + 1 == nx && cfxr) qx_hi = a.p.constant_flux[XR];
+                else {
+                    const i64 cr = c + (ip - ic);
+                    qx_hi = relax(a.t.qTx[q], Kc_[r], rf ? 0.0 : Kk[cr], tc[r], th[cr], T[I1 + 1], Tc[r], _dx);
+                }
+                if (cell && ic + 1 == nx) dst.qx[q] = qx_hi;           // the domain's right face belongs to no cell's low face
+            }
+            // ---- z: high face k+1 (owned here), becomes the low face of the next plane
+            double qz_hi, Kn_ = 0.0;
+            const i64 cr = k + 1 < nz ? c + sC2 : c;
+            const double Tn_c = T[I1 + sT2], tn = th[cr];
+            if (!rf) Kn_ = Kk[cr];
+            if (k + 1 == nz && cfzt) qz_hi = a.p.constant_flux[ZT];
+            else qz_hi = relax(a.t.qTz[c + sC2], Kc_[r], Kn_, tc[r], tn, Tn_c, Tc[r], _dz);
+            if (cell) dst.qz[c + sC2] = qz_hi;
+            if (cell) {
+                const double rcp = rhoCp3_of(a.p, a.t.rhoCp, c, Tc[r]);
+                const double divq = (qx_hi - qx_lo) * _dx + (qy[r + 1] - qy[r]) * _dy + (qz_hi - qz_lo[r]) * _dz;
+                const double dr = a.t.dtau_rho[c];
+                const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc[r]) / (1.0 + dr * rcp * _dt);
+                dst.T[I1] = Tn;
+                const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
+                const int mask = ((i == 0 || i == nx - 1) ? 1 : 0) | ((j == 0 || j == ny - 1) ? 2 : 0) | ((k == 0 || k == nz - 1) ? 4 : 0);
+                if (mask) {
+                    const i64 st[3] = {1, sT1, sT2};
+                    thermal_ghosts3d(a.p, dst.T, st, I1, mask, side, Tn);
+                }
+            }
+            qz_lo[r] = qz_hi; Tc[r] = Tn_c; Kc_[r] = Kn_; tc[r] = tn;
+        }
+    }
+}
+
 // thermal_bcs! 3D: one launch per (step, dim); step 0 constant_value, 1 no_flux, 2 periodic; dim = direction normal to the face pair
 __global__ __launch_bounds__(256) void k_tbc3d(double *__restrict__ T, int nx, int ny, int nz, int step, int dim, int lo_on, int hi_on, double lo_val,
                                                double hi_val)
@@ -207,6 +353,20 @@ jrx_status launch_tbcs3(jrx_handle *h, hipStream_t s, double *T, const jrx_therm
             JRX_LAUNCH_CHECK(h);
         }
     }
+    return JRX_OK;
+}
+
+static jrx_status ensure_tscratch(jrx_handle *h, int nx, int ny, int nz)
+{
+    if (h->tscratch[0] && h->tscratch_dims[0] == nx && h->tscratch_dims[1] == ny && h->tscratch_dims[2] == nz) return JRX_OK;
+    for (int q = 0; q < 4; q++) {
+        if (h->tscratch[q]) JRX_HIP(h, hipFree(h->tscratch[q]));
+        h->tscratch[q] = nullptr;
+    }
+    h->tscratch_dims[0] = h->tscratch_dims[1] = h->tscratch_dims[2] = 0;
+    const size_t n[4] = {(size_t)(nx + 2) * (ny + 2) * (nz + 2), (size_t)(nx + 1) * ny * nz, (size_t)nx * (ny + 1) * nz, (size_t)nx * ny * (nz + 1)};
+    for (int q = 0; q < 4; q++) JRX_HIP(h, hipMalloc(&h->tscratch[q], n[q] * sizeof(double)));
+    h->tscratch_dims[0] = nx; h->tscratch_dims[1] = ny; h->tscratch_dims[2] = nz;
     return JRX_OK;
 }
 
@@ -284,10 +444,44 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
     double err = 2 * p->eps;
     T3Args a;
     a.t = *t; a.p = *p;
+    // Iterations nobody observes run as one fused launch that ping-pongs (T, qT) between the caller's arrays and a library-owned set
+    // (JRX_THERMAL_FUSED=0: always the two kernels); observed ones (check / last) run the two kernels in place on the current set.
+    bool any_periodic = false;
+    for (int q = 0; q < 6; q++) any_periodic |= p->periodic[q] != 0;
+    static const bool fused_env = [] { const char *e = getenv("JRX_THERMAL_FUSED"); return !(e && e[0] == '0'); }();
+    const bool fusable = fused_env && !any_periodic && !jrx_comm_active(h);
+    const TSet user = {t->T, t->qTx, t->qTy, t->qTz};
+    TSet cur = user, oth = user;
+    if (fusable) {
+        JRX_TRY(ensure_tscratch(h, nx, ny, nz));
+        oth = TSet{h->tscratch[0], h->tscratch[1], h->tscratch[2], h->tscratch[3]};
+        // ghosts that no BC rewrites (prescribed values) must exist in both sets
+        JRX_HIP(h, hipMemcpyAsync(oth.T, t->T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    // tile = TX cells of R rows, KZ planes deep; JRX_TH_CFG = R*10000 + (TX/64)*100 + KZ overrides (tuning)
+    static const int cfg = [] { const char *e = getenv("JRX_TH_CFG"); return e ? atoi(e) : 0; }();
+    const int FR = cfg ? cfg / 10000 : 1, FTX = cfg ? ((cfg / 100) % 100) * 64 : (nx > 128 ? 256 : (nx > 64 ? 128 : 64)), FKZ = cfg ? cfg % 100 : 4;
+    const int ntx = (nx + FTX - 1) / FTX, nty = (ny + FR - 1) / FR, ntz = (nz + FKZ - 1) / FKZ;
     while (err > p->eps && iter < p->iterMax) {
         // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one
         const bool q2 = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
-        JRX_TRY(enqueue_titer3(h, t, p, q2, true));
+        a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy; a.t.qTz = cur.qz;
+        if (fusable && !q2) {
+#define THL(TX_, KZ_, R_)                                                                                                          \
+    if (FTX == TX_ && FKZ == KZ_ && FR == R_) {                                                                                    \
+        hipLaunchKernelGGL((k_thermal3d_fused<TX_, KZ_, 8, R_>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX_), 0, s, a, oth, ntx, nty); \
+        launched = true;                                                                                                           \
+    }
+            bool launched = false;
+            // measured at 256^3 (profiles/r01_thermal3d_fused_sweep.txt): one row per thread 2289 it/s, two rows 1526, four rows 1301
+            THL(256, 4, 1) THL(128, 4, 1) THL(64, 4, 1) THL(256, 8, 1) THL(256, 4, 2)
+            if (!launched) return jrx_fail(h, JRX_ERR_ARG, "JRX_TH_CFG: no such configuration");
+#undef THL
+            JRX_LAUNCH_CHECK(h);
+            const TSet tmp = cur; cur = oth; oth = tmp;
+        } else {
+            JRX_TRY(enqueue_titer3(h, &a.t, p, q2, true));
+        }
         iter++;
         if (iter % p->nout == 0) {
             hipLaunchKernelGGL(k_updateT3d<true>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
@@ -309,6 +503,12 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
             cnt++;
             if (p->verbose) printf("iter = %lld, err = %1.3e \n", (long long)iter, err);
         }
+    }
+    if (cur.T != user.T) {      // leave the results in the caller's arrays
+        JRX_HIP(h, hipMemcpyAsync(user.T, cur.T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(user.qx, cur.qx, (size_t)(nx + 1) * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(user.qy, cur.qy, (size_t)nx * (ny + 1) * nz * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(user.qz, cur.qz, (size_t)nx * ny * (nz + 1) * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     hipLaunchKernelGGL(k_sub3, dim3(1024), dim3(256), 0, s, t->dT, (const double *)t->T, (const double *)t->Told, nT);   // update_ΔT!
     JRX_LAUNCH_CHECK(h);

@@ -65,5 +65,7 @@ def thermal3d(n=256, iters=400):
 if __name__ == "__main__":
     nv = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     nt = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    thermal3d(nt)
-    shearband3d(nv)
+    if nt > 0:
+        thermal3d(nt)
+    if nv > 0:
+        shearband3d(nv)

@@ -62,10 +62,12 @@ def test_thermal_bcs_3d_all_kinds(jr, oracle):
         assert not np.array_equal(Tref, T0)
 
 
-@pytest.mark.parametrize("form", ["array", "rheology"])
-def test_thermal3d_iterations_match_oracle(jr, oracle, form):
+@pytest.mark.parametrize("form,ni", [("array", (20, 14, 12)), ("rheology", (20, 14, 12)), ("array", (70, 17, 20)), ("rheology", (130, 9, 35))])
+def test_thermal3d_iterations_match_oracle(jr, oracle, form, ni):
+    """jrx_heatdiffusion_PT3d (fused flux + update + BC kernel on the unobserved iterations, the two kernels in place on check / last
+    iterations, ping-pong (T, qT) sets; the larger grids span several tiles and z chunks) against the oracle's loop"""
     from justrelax_jl_amd.checks import max_rel_diff
-    s = jr.miniapps.diffusion3d((20, 14, 12), iterMax=300, nout=100)
+    s = jr.miniapps.diffusion3d(ni, iterMax=300, nout=100)
     rheo = s.extra["rheology"] if form == "rheology" else None
     p = _params(oracle, s, 1e-30, iterMax=300, nout=100, rheology=rheo)
     thermal, pt, K, ρCp = _setup(jr, s)
@@ -79,8 +81,10 @@ def test_thermal3d_iterations_match_oracle(jr, oracle, form):
     for name, t in (("T", thermal.T), ("Told", thermal.Told), ("dT", thermal.ΔT)):
         got = jr.to_numpy(t)          # whole arrays: the in-kernel BC replay must reproduce the ghost edges and corners as well
         assert np.abs(got - ref[name]).max() <= TOL_ITERS * np.abs(ref[name]).max(), name
-    for name, t in (("qTx", thermal.qTx), ("qTy", thermal.qTy), ("qTz", thermal.qTz), ("qTz2", thermal.qTz2), ("ResT", thermal.ResT)):
+    for name, t in (("qTx", thermal.qTx), ("qTy", thermal.qTy), ("qTz", thermal.qTz), ("qTz2", thermal.qTz2)):
         assert max_rel_diff(jr.to_numpy(t), ref[name]) <= TOL_ITERS, name
+    # the residual of a converged run is rounding noise of its terms (H = 1e-6 among them): absolute comparison on that scale
+    assert np.abs(jr.to_numpy(thermal.ResT) - ref["ResT"]).max() <= TOL_ITERS * max(np.abs(ref["ResT"]).max(), 1e-6)
 
 
 def test_diffusion3d_reference_numbers_on_the_gpu(jr, oracle):
