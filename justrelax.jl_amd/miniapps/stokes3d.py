@@ -171,6 +171,8 @@ def random_fields3d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nou
         b = VelocityBoundaryConditions(free_slip=off, no_slip=on)
     elif bcs == "periodic":
         b = VelocityBoundaryConditions(free_slip=off, no_slip=off, periodic=on)
+    elif bcs == "slip_mix":      # free slip and no slip on different faces, one face left alone (prescribed values), nothing periodic
+        b = VelocityBoundaryConditions(free_slip=dict(off, left=True, right=True, front=True), no_slip=dict(off, top=True, bot=True))
     elif bcs == "mixed":
         b = VelocityBoundaryConditions(free_slip=dict(off, left=True, right=True), no_slip=dict(off, top=True, bot=True),
                                        periodic=dict(off, front=True, back=True))

@@ -223,7 +223,8 @@ def test_cpu_arrays_are_refused(jr):
 
 
 @pytest.mark.parametrize("ni,bcs", [((130, 20, 17), "free_slip"), ((70, 12, 9), "free_slip"), ((130, 17, 20), "no_slip"),
-                                    ((97, 9, 33), "none"), ((64, 16, 40), "no_slip"), ((200, 8, 8), "free_slip")])
+                                    ((97, 9, 33), "none"), ((64, 16, 40), "no_slip"), ((200, 8, 8), "free_slip"),
+                                    ((130, 18, 19), "slip_mix"), ((66, 9, 35), "slip_mix")])
 def test_kernel_variants_are_bit_identical(env, ni, bcs):
     """auto (0), per-node kernels (1), the two z-marching sweeps (2) and the fused PT pipeline (3) must agree bit for bit:
     same operation order, and the fused kernel's on-the-fly low-face boundary rules reproduce flow_bcs!."""
