@@ -19,4 +19,5 @@ tail -3 $OUT/bench_$N.err
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --n $N --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof.log 2>&1
 cd $GRAFT_REPO_ROOT
+grep -o '{"metric".*' $OUT/prof.log | tail -1 > $OUT/bench_${N}_profiled_run.json     # the bench line of the profiled process itself
 find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -12
