@@ -103,6 +103,9 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane only (unique-id broadcast, barrier, max of the timings): gloo over loopback -- all ranks are on one node and the
+        # container hostname may not resolve; the data path is the library's own RCCL communicator
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
