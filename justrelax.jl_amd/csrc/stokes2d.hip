@@ -73,13 +73,10 @@ __global__ __launch_bounds__(256) void k_stress2d(const Args2 a)
 // BCF: the thread that updates a velocity node next to a free-slip / no-slip face also refreshes that node's ghost copy
 // (free_slip.jl:1-13, no_slip.jl:1-18), which is all flow_bcs! changes once it has been applied in full one time: the other ghost
 // and boundary values it writes are copies of nodes compute_V! never updates.  Saves the flow_bcs! launches of the launch-bound loop.
-template <bool RES_ONLY, bool BCF = false>
-__global__ __launch_bounds__(256) void k_velocity2d(const Args2 a)
+template <bool RES_ONLY, bool BCF>
+__device__ __forceinline__ void velocity2d_cell(const Args2 &a, const int i, const int j)
 {
     const int nx = a.nx, ny = a.ny;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = t / nx, i = t - j * nx;
-    if (j >= ny) return;
     const double _dx = a._dx, _dy = a._dy, edt = a.eta_dtau;
     const double *__restrict__ P = a.f.P, *__restrict__ txy = a.f.txy, *__restrict__ et = a.etatau;
 #define TXY(i_, j_) txy[(i_) + (i64)(nx + 1) * (j_)]
@@ -113,6 +110,15 @@ __global__ __launch_bounds__(256) void k_velocity2d(const Args2 a)
         }
     }
 #undef TXY
+}
+
+template <bool RES_ONLY, bool BCF = false>
+__global__ __launch_bounds__(256) void k_velocity2d(const Args2 a)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / a.nx, i = t - j * a.nx;
+    if (j >= a.ny) return;
+    velocity2d_cell<RES_ONLY, BCF>(a, i, j);
 }
 #undef VX
 #undef VY
@@ -415,6 +421,9 @@ __device__ __forceinline__ void plastic_grad(const jrx_rheology &rh, const doubl
 #define V2(A, i_, j_) (A)[(i_) + (i64)(nx + 1) * (j_)]
 
 // compute_∇V! + compute_P! (phase form: K, G phase-averaged once per solve; writes θ) + compute_strain_rate!
+// ML: compute_maxloc!(ητ, η) of the own cell first (clamped 3 x 3 window, same comparison order as k_maxloc) and store it: saves the
+// separate launch of the launch-bound 2D loop
+template <bool ML>
 __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__restrict__ theta)
 {
     const int nx = a.nx, ny = a.ny;
@@ -434,7 +443,19 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
         const double P = theta[c], P0 = a.f.P0[c];
         const double rhs = -divV + (a.f.Q[c] * _dt);
         a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
-        const double psi = 1.0 / (1.0 / a.etatau[c] + _Gdt) * a.r / a.theta_dtau;
+        double et;
+        if (ML) {
+            et = -INFINITY;
+            for (int jj = j - 1; jj <= j + 1; jj++) {
+                const int jc = clampi(jj, 0, ny - 1);
+                for (int ii = i - 1; ii <= i + 1; ii++) {
+                    const double v = a.f.eta[clampi(ii, 0, nx - 1) + (i64)nx * jc];
+                    if (v > et) et = v;
+                }
+            }
+            const_cast<double *>(a.etatau)[c] = et;
+        } else et = a.etatau[c];
+        const double psi = 1.0 / (1.0 / et + _Gdt) * a.r / a.theta_dtau;
         theta[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
         const double d3 = divV * (1.0 / 3.0);
         a.f.exx[c] = dxi - d3;
@@ -624,10 +645,9 @@ __device__ __forceinline__ double phase_viscosity(const jrx_rheology &rh, const 
         if (r[q] != 0.0) s += (1.0 / rh.eta[q]) * r[q];
     return 1.0 / s;
 }
-__global__ __launch_bounds__(256) void k_vep_visc(const VepArgs a)
+__device__ __forceinline__ void vep_visc_at(const VepArgs &a, const i64 t)
 {
     const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
-    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < (i64)nx * ny) {
         double e = phase_viscosity(a.rh, a.f.phase_c + np * t);
         e = e * a.nu + a.f.eta[t] * (1.0 - a.nu);
@@ -638,6 +658,16 @@ __global__ __launch_bounds__(256) void k_vep_visc(const VepArgs a)
         e = e * a.nu + a.f.eta_v[t] * (1.0 - a.nu);
         a.f.eta_v[t] = fmin(fmax(e, a.cut_lo), a.cut_hi);
     }
+}
+__global__ __launch_bounds__(256) void k_vep_visc(const VepArgs a) { vep_visc_at(a, (i64)blockIdx.x * blockDim.x + threadIdx.x); }
+// compute_viscosity! and compute_V! in one launch: the velocity update reads ητ (already taken from the previous η), P, τ, ρg, never η
+template <bool BCF>
+__global__ __launch_bounds__(256) void k_vep_visc_velocity(const VepArgs a, const Args2 b)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    vep_visc_at(a, t);
+    const int j = (int)(t / b.nx), i = (int)(t - (i64)j * b.nx);
+    if (j < b.ny) velocity2d_cell<false, BCF>(b, i, j);
 }
 
 __global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const VepArgs a)
@@ -902,14 +932,15 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
     while (iter <= p->iterMax) {
         if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;          // Stokes2D.jl:650-651
-        hipLaunchKernelGGL(k_maxloc, dim3(gc, 1), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, 1);
-        JRX_LAUNCH_CHECK(h);
-        if (comm) {   // update_halo!(ητ) (Stokes2D.jl:655)
+        if (comm) {
+            hipLaunchKernelGGL(k_maxloc, dim3(gc, 1), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, 1);
+            JRX_LAUNCH_CHECK(h);
+            // update_halo!(ητ) (Stokes2D.jl:655)
             double *arrs[1] = {etatau};
             const int64_t ext[1][3] = {{nx, ny, 1}};
             JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
-        }
-        hipLaunchKernelGGL(k_vep_pre, dim3(gv), dim3(256), 0, s, a, theta);
+            hipLaunchKernelGGL(k_vep_pre<false>, dim3(gv), dim3(256), 0, s, a, theta);
+        } else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, a, theta);      // compute_maxloc! folded in
         JRX_LAUNCH_CHECK(h);
         hipLaunchKernelGGL(k_vep_vertex, dim3(gv), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
@@ -920,16 +951,15 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             const int64_t ext[1][3] = {{nx + 1, ny + 1, 1}};
             JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
         }
-        hipLaunchKernelGGL(k_vep_visc, dim3(gv), dim3(256), 0, s, a);
-        JRX_LAUNCH_CHECK(h);
         const bool bcf = iter >= 1 && p->periodic == 0 && !comm;      // flow_bcs! applied in full by iteration 1: refresh ghosts in-kernel
         bool used_bcf = false;
         {
             const bool next_check = ((iter + 1) % p->nout == 0) && iter + 1 > 1;
             const bool next_last = next_check || iter + 1 > p->iterMax || (p->iterMin < iter + 1 && ((err / err_it1) < p->eps_rel || err < p->eps_abs));
             used_bcf = bcf && !next_last;
-            if (used_bcf) hipLaunchKernelGGL((k_velocity2d<false, true>), dim3(gc), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL(k_velocity2d<false>, dim3(gc), dim3(256), 0, s, b);     // compute_V! (free-surface form with dt*free_surface = 0)
+            // compute_viscosity! + compute_V! (free-surface form with dt*free_surface = 0) in one launch
+            if (used_bcf) hipLaunchKernelGGL(k_vep_visc_velocity<true>, dim3(gv), dim3(256), 0, s, a, b);
+            else hipLaunchKernelGGL(k_vep_visc_velocity<false>, dim3(gv), dim3(256), 0, s, a, b);
         }
         JRX_LAUNCH_CHECK(h);
         iter += 1;
