@@ -17,7 +17,7 @@ out = "$OUT"
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        res[r["Kernel_Name"][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        res[r["Kernel_Name"][:130]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(res.items()):
     print(k, {c: round(sum(v)/len(v)) for c, v in d.items()})
 PY
