@@ -62,7 +62,7 @@ int32_t jrx_version(void);
 
 /* Tuning / debugging knobs.  Keys: "kernel_variant" (3D Stokes):
  *   0 = default: fused PT pipeline where it applies (no periodic_boundary! faces, nx >= 48, ny, nz >= 8, and nx fills
- *       its 62-column tiles to >= 77 %): one kernel runs velocity sweep m + BCs + stress sweep m+1 with ping-pong
+ *       its 62-column tiles to >= 71 %): one kernel runs velocity sweep m + BCs + stress sweep m+1 with ping-pong
  *       state arrays (the handle then owns a second set of the 10 state arrays); with a communicator the exchange
  *       of V follows and the stress nodes next to a received plane are redone; otherwise, and on iterations whose
  *       results are observed, the two z-marching sweeps;

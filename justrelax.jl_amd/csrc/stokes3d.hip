@@ -412,10 +412,10 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && (fused_comm || !jrx_comm_active(h)) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable && h->kernel_variant == 0) {
         // auto: the fused kernel covers a row with ceil(nx/62) 64-lane tiles (one halo and one feeder lane each); when that
-        // quantisation idles too many lanes the two sweeps are faster (measured: nx = 256, 5 tiles, 25 % idle: fused +4 %;
-        // nx = 320: +25 %; nx = 384: +18 %; nx = 128, 3 tiles, 50 % idle: fused -28 %)
+        // quantisation idles too many lanes the two sweeps are faster (measured, profiles/r01_bench_sizes.txt: nx = 192, 4 tiles, 33 % idle:
+        // fused +21 %; nx = 96, 2 tiles, 33 %: equal; nx = 256: +4 %; nx = 320: +25 %; nx = 128, 3 tiles, 50 % idle: fused -21 %)
         const i64 ntx = (p->nx + 61) / 62;
-        if (ntx * 64 * 100 > (i64)p->nx * 130) I.fusable = false;
+        if (ntx * 64 * 100 > (i64)p->nx * 140) I.fusable = false;
     }
     if (I.fusable) {
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
