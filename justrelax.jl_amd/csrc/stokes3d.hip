@@ -106,6 +106,8 @@ jrx_status launch_velocity_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, 
     return JRX_OK;
 }
 
+static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepArgs &a, const int (*box)[6], int nbox, bool diag);
+
 // Stress sweep over the whole ni.+1 node box.  Wide grids: z-marching kernel over the cell box
 // (tile = one or two full-width row segments: measured best for DRAM page locality)
 // plus three thin launches of the per-node kernel for the upper boundary planes i = nx, j = ny,
@@ -120,10 +122,9 @@ jrx_status launch_stress(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, i
     else if (nx > 192) JRX_TRY((launch_stress_zb<256, 1, 8>(h, s, a, diag)));
     else if (nx > 96) JRX_TRY((launch_stress_zb<128, 2, 8>(h, s, a, diag)));
     else JRX_TRY((launch_stress_zb<64, 4, 8>(h, s, a, diag)));
-    JRX_TRY(launch_stress_v1(h, s, a, diag, nx, nx + 1, 0, ny + 1, 0, nz + 1));
-    JRX_TRY(launch_stress_v1(h, s, a, diag, 0, nx, ny, ny + 1, 0, nz + 1));
-    JRX_TRY(launch_stress_v1(h, s, a, diag, 0, nx, 0, ny, nz, nz + 1));
-    return JRX_OK;
+    // the upper boundary planes i = nx, j = ny, k = nz in one launch of the per-node kernel over three disjoint boxes
+    const int planes[3][6] = {{nx, nx + 1, 0, ny + 1, 0, nz + 1}, {0, nx, ny, ny + 1, 0, nz + 1}, {0, nx, 0, ny, nz, nz + 1}};
+    return launch_stress_boxes(h, s, a, planes, 3, diag);
 }
 
 jrx_status launch_velocity(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
@@ -195,7 +196,7 @@ static jrx_status launch_bcs_faces(jrx_handle *h, hipStream_t s, double *Vx, dou
 }
 
 // the stress sweep over up to six disjoint node boxes in one launch
-static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepArgs &a, const int (*box)[6], int nbox)
+static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepArgs &a, const int (*box)[6], int nbox, bool diag)
 {
     StressBoxes B = {};
     int tot = 0;
@@ -211,7 +212,8 @@ static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepA
     }
     if (!B.n) return JRX_OK;
     B.start[B.n] = tot;
-    hipLaunchKernelGGL(k_stress3d_boxes, dim3((unsigned)tot), dim3(256), 0, s, a, B);
+    if (diag) hipLaunchKernelGGL(k_stress3d_boxes<true>, dim3((unsigned)tot), dim3(256), 0, s, a, B);
+    else hipLaunchKernelGGL(k_stress3d_boxes<false>, dim3((unsigned)tot), dim3(256), 0, s, a, B);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -416,6 +418,8 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
         // fused +21 %; nx = 96, 2 tiles, 33 %: equal; nx = 256: +4 %; nx = 320: +25 %; nx = 128, 3 tiles, 50 % idle: fused -21 %)
         const i64 ntx = (p->nx + 61) / 62;
         if (ntx * 64 * 100 > (i64)p->nx * 140) I.fusable = false;
+        // ... and below ~6 tiles per CU the 17-plane-deep tiles leave the chip idle (96^3, 384 tiles: 6.8 k it/s fused, 9.2 k with the sweeps)
+        if (ntx * ((p->ny + 2) / 3) * ((p->nz + 15) / 16) < 1536) I.fusable = false;
     }
     if (I.fusable) {
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
@@ -554,7 +558,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                   klo = nb[2][0] ? 1 : 0, khi = nb[2][1] ? nz - 1 : nz;
         const int fix[6][6] = {{0, ilo, 0, ny + 1, 0, nz + 1}, {ihi, nx + 1, 0, ny + 1, 0, nz + 1}, {ilo, ihi, 0, jlo, 0, nz + 1},
                                {ilo, ihi, jhi, ny + 1, 0, nz + 1}, {ilo, ihi, jlo, jhi, 0, klo}, {ilo, ihi, jlo, jhi, khi, nz + 1}};
-        JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6));
+        JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false));
         if (bs != s) {
             JRX_HIP(h, hipEventRecord(h->ev[2], bs));
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
@@ -573,7 +577,14 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
         if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
         if (diag) JRX_TRY(launch_scaleU(h, s, f, p));
-        JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        // flow_bcs!: the reference's ordered passes on observable iterations and the first time a set is written, otherwise all faces in
+        // one launch (same values wherever a stencil reads them)
+        bool &ordered = I.bcs_ordered[I.cur_is_user ? 0 : 1];
+        if (!diag && ordered && p->periodic == 0) JRX_TRY(launch_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
+        else {
+            JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+            ordered = true;
+        }
         return JRX_OK;
     }
     // @hide_communication b_width (Stokes3D.jl:104-121): boundary slabs of width b first on the halo

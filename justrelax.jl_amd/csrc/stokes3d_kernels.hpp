@@ -168,6 +168,7 @@ struct StressBoxes {
     int start[7];         // first block of each box; start[n] = total
     int per_plane[6];     // blocks per xy-plane of the box
 };
+template <bool DIAG>
 __global__ __launch_bounds__(256) void k_stress3d_boxes(const SweepArgs a, const StressBoxes B)
 {
     int b = 0;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void k_stress3d_boxes(const SweepArgs a, const
     const int jj = t / wi;
     const int j = B.box[b][2] + jj;
     if (j >= B.box[b][3]) return;
-    stress3d_node<false>(a, B.box[b][0] + (t - jj * wi), j, B.box[b][4] + kz);
+    stress3d_node<DIAG>(a, B.box[b][0] + (t - jj * wi), j, B.box[b][4] + kz);
 }
 
 // ------------------------------------------------------------------------------------------------
