@@ -69,7 +69,9 @@ int32_t jrx_version(void);
  *   1 = simple one-thread-per-node kernels;  2 = z-marching sweeps only (two launches per iteration, no ping-pong set);
  *   3 = fused pipeline wherever it is legal (ignores the tile-fill rule).  All variants produce bit-identical results.
  * "fused_overlap" (0/1, default 0): multi-rank fused pipeline with the shell of tiles, BCs and exchange on a second
- *   stream while the interior tiles run (same results). */
+ *   stream while the interior tiles run (same results).
+ * "thermal_fused" (0/1, default 1): jrx_heatdiffusion_PT3d runs unobserved iterations as one fused launch with a
+ *   library-owned second (T, qT) set; 0 = always compute_flux! and update_T! as two launches (same results). */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 
 /* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)

@@ -304,6 +304,7 @@ jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value)
     if (!key) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: key is NULL");
     if (strcmp(key, "kernel_variant") == 0) { h->kernel_variant = (int)value; return JRX_OK; }
     if (strcmp(key, "fused_overlap") == 0) { h->fused_overlap = value != 0; return JRX_OK; }
+    if (strcmp(key, "thermal_fused") == 0) { h->thermal_fused = value != 0; return JRX_OK; }
     return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: unknown key '%s'", key);
 }
 

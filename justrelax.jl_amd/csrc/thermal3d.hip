@@ -449,7 +449,7 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
     bool any_periodic = false;
     for (int q = 0; q < 6; q++) any_periodic |= p->periodic[q] != 0;
     static const bool fused_env = [] { const char *e = getenv("JRX_THERMAL_FUSED"); return !(e && e[0] == '0'); }();
-    const bool fusable = fused_env && !any_periodic && !jrx_comm_active(h);
+    const bool fusable = fused_env && h->thermal_fused && !any_periodic && !jrx_comm_active(h);
     const TSet user = {t->T, t->qTx, t->qTy, t->qTz};
     TSet cur = user, oth = user;
     if (fusable) {

@@ -98,3 +98,31 @@ def test_diffusion3d_reference_numbers_on_the_gpu(jr, oracle):
     T = jr.to_numpy(thermal.T)
     assert T[15, 15, 15] == pytest.approx(1813.2470160788096, rel=1.0e-12)
     assert T[16, 16, 16] == pytest.approx(1831.2568044653274, rel=1.0e-12)
+
+
+@pytest.mark.parametrize("ni", [(256, 256, 256), (200, 96, 70)])
+def test_fused_and_two_kernel_iterations_agree_at_full_size(jr, ni):
+    """BASELINE-size property check (no oracle at this size): 60 iterations of jrx_heatdiffusion_PT3d with the fused one-launch
+    iteration (ping-pong (T, qT) sets, BC ghost replay in-kernel) and with compute_flux! / update_T! as two launches give the same
+    T, qT and residual history bit for bit -- same arithmetic in the same order."""
+    import ctypes as C
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.diffusion3d(ni, iterMax=60, nout=20)
+    h = _lib.default_handle()
+    outs = []
+    try:
+        for fused in (1, 0):
+            h.call("jrx_set_option", C.c_char_p(b"thermal_fused"), C.c_int64(fused))
+            thermal, pt, K, ρCp = _setup(jr, s)
+            pt.ϵ = 1e-30
+            r = jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, K, ρCp, s.dt, s.grid, kwargs=dict(iterMax=60, nout=20, verbose=False))
+            outs.append((list(r.iter_count), list(r.norm_ResT), {k: jr.to_numpy(getattr(thermal, k)) for k in ("T", "qTx", "qTy", "qTz", "ResT")}))
+            del thermal, pt, K, ρCp
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"thermal_fused"), C.c_int64(1))
+    assert outs[0][0] == outs[1][0] == [20, 40, 60]
+    assert outs[0][1] == outs[1][1]
+    for k in outs[0][2]:
+        assert np.array_equal(outs[0][2][k], outs[1][2][k]), k
+    T = outs[0][2]["T"]
+    assert np.isfinite(T).all() and T.max() > 1500.0
