@@ -93,6 +93,8 @@ __device__ __forceinline__ void plastic_grad3(const jrx_rheology &rh, const doub
 
 // compute_∇V!, compute_P! (phase form: K, G per cell, η = ητ, P = θ) and compute_strain_rate! 3D over the ni.+1 box
 // (VelocityKernels.jl:3-6,59-104; PressureKernels.jl:47-106,186-195)
+// ML: compute_maxloc!(ητ, η) of the own cell first (clamped 3 x 3 x 3 window, the comparison order of k_maxloc) and store it
+template <bool ML>
 __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
@@ -113,7 +115,22 @@ __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
         const double P = a.theta[c], P0 = a.f.P0[c];
         const double rhs = -divV + (a.f.Q[c] * _dt);
         a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
-        const double psi = 1.0 / (1.0 / a.etatau[c] + _Gdt) * a.r / a.theta_dtau;
+        double et;
+        if (ML) {
+            et = -INFINITY;
+            for (int kk = k - 1; kk <= k + 1; kk++) {
+                const int kc = clampi3(kk, 0, nz - 1);
+                for (int jj = j - 1; jj <= j + 1; jj++) {
+                    const int jc = clampi3(jj, 0, ny - 1);
+                    for (int ii = i - 1; ii <= i + 1; ii++) {
+                        const double v = a.f.eta[clampi3(ii, 0, nx - 1) + (i64)nx * (jc + (i64)ny * kc)];
+                        if (v > et) et = v;
+                    }
+                }
+            }
+            const_cast<double *>(a.etatau)[c] = et;
+        } else et = a.etatau[c];
+        const double psi = 1.0 / (1.0 / et + _Gdt) * a.r / a.theta_dtau;
         a.theta[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
         const double d3 = divV * (1.0 / 3.0);
         a.f.exx[c] = dxi - d3;
@@ -466,7 +483,8 @@ EdgeN edge_counts(const jrx_vep3d_params *p)
 }
 
 // the three edge passes, the commit of the new edge stresses, then the centre pass
-jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p)
+// commit = false: the caller adopts a.tnew as the current edge-stress arrays (pointer swap) instead of copying them back
+jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p, bool commit = true)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     static const bool p4 = [] { const char *e = getenv("JRX_VEP_MAP"); return !(e && e[0] == '0'); }();
@@ -474,10 +492,12 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
     else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     const EdgeN n = edge_counts(p);
-    hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, a.f.tyz, (const double *)a.tnew[0], n.yz, a.f.txz, (const double *)a.tnew[1], n.xz, a.f.txy,
-                       (const double *)a.tnew[2], n.xy, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr,
-                       (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
-    JRX_LAUNCH_CHECK(h);
+    if (commit) {
+        hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, a.f.tyz, (const double *)a.tnew[0], n.yz, a.f.txz, (const double *)a.tnew[1], n.xz, a.f.txy,
+                           (const double *)a.tnew[2], n.xy, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr,
+                           (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
+        JRX_LAUNCH_CHECK(h);
+    }
     hipLaunchKernelGGL(k_vep3_centre, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
@@ -621,18 +641,24 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         const int64_t it1 = iter + 1;
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);      // R and U are only observable after such an iteration
-        hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, nz);
-        if (comm) {   // update_halo!(ητ) (Stokes3D.jl:515)
+        if (comm) {
+            hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, nz);
+            // update_halo!(ητ) (Stokes3D.jl:515)
             double *arrs[1] = {etatau};
             const int64_t ext[1][3] = {{nx, ny, nz}};
             JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
-        }
-        hipLaunchKernelGGL(k_vep3_pre, gv, dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_vep3_pre<false>, gv, dim3(256), 0, s, a);
+        } else hipLaunchKernelGGL(k_vep3_pre<true>, gv, dim3(256), 0, s, a);        // compute_maxloc! folded in
         hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, p->viscosity_relaxation);
         JRX_LAUNCH_CHECK(h);
-        JRX_TRY(launch_vep3_stress(h, s, a, p));
+        JRX_TRY(launch_vep3_stress(h, s, a, p, false));
+        // the new edge stresses become the current ones: swap the pointers instead of copying three arrays back
+        { double *t0_ = a.f.tyz; a.f.tyz = a.tnew[0]; a.tnew[0] = t0_; }
+        { double *t1_ = a.f.txz; a.f.txz = a.tnew[1]; a.tnew[1] = t1_; }
+        { double *t2_ = a.f.txy; a.f.txy = a.tnew[2]; a.tnew[2] = t2_; }
+        g.tyz = a.f.tyz; g.txz = a.f.txz; g.txy = a.f.txy;
         if (comm) {   // update_halo!(τ.yz), (τ.xz), (τ.xy) (Stokes3D.jl:578-580)
-            double *arrs[3] = {f->tyz, f->txz, f->txy};
+            double *arrs[3] = {a.f.tyz, a.f.txz, a.f.txy};
             const int64_t ext[3][3] = {{nx, ny + 1, nz + 1}, {nx + 1, ny, nz + 1}, {nx + 1, ny + 1, nz}};
             JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, nn));
         }
@@ -677,6 +703,14 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         }
     }
     JRX_HIP(h, hipEventRecord(t1, s));
+    if (a.f.tyz != f->tyz) {       // odd number of swaps: leave the edge stresses in the caller's arrays
+        JRX_HIP(h, hipMemcpyAsync(f->tyz, a.f.tyz, (size_t)ne.yz * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(f->txz, a.f.txz, (size_t)ne.xz * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(f->txy, a.f.txy, (size_t)ne.xy * sizeof(double), hipMemcpyDeviceToDevice, s));
+        a.tnew[0] = a.f.tyz; a.tnew[1] = a.f.txz; a.tnew[2] = a.f.txy;
+        a.f.tyz = f->tyz; a.f.txz = f->txz; a.f.txy = f->txy;
+        g.tyz = f->tyz; g.txz = f->txz; g.txy = f->txy;
+    }
     // epilogue: vorticity, shear2center!, accumulate_tensor!/accumulate_vol!, τ -> τ_o (Stokes3D.jl:640-658)
     if (f->omega_yz && f->omega_xz && f->omega_xy)
         hipLaunchKernelGGL(k_vorticity3d, gv, dim3(256), 0, s, f->omega_yz, f->omega_xz, f->omega_xy, (const double *)f->Vx,
