@@ -420,7 +420,7 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
         const i64 ntx = (p->nx + 61) / 62;
         if (ntx * 64 * 100 > (i64)p->nx * 140) I.fusable = false;
         // ... and below ~6 tiles per CU the 17-plane-deep tiles leave the chip idle (96^3, 384 tiles: 6.8 k it/s fused, 9.2 k with the sweeps)
-        if (ntx * ((p->ny + 2) / 3) * ((p->nz + 15) / 16) < 1536) I.fusable = false;
+        if (ntx * ((p->ny + 2) / 3) * ((p->nz + 15) / 16) < 1536) I.fusable = false;     // counted in 16-plane units as measured
     }
     if (I.fusable) {
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
@@ -459,7 +459,9 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
         // + non-temporal stores: the written set is not read again before the next iteration (PMC: 35.7 -> 34.2 fetched passes, -0.5 .. -1.6 % time)
         // + register diet to 128 VGPRs without spills (4 waves/SIMD): previous velocity plane re-read from a third LDS slot, previous η/G
         //   plane carried as partial sums, the nine stress-only operands requested after the velocity phase (-1 .. -5 %)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 8, false, true, 3, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        // + 8-plane chunks and tile rows dealt round-robin to the XCDs (XG = 1: the eight XCDs work on eight adjacent tile rows at a time;
+        //   kbench 512^3, same box: 8.65 ms with 16 planes / 8-row bands -> 8.04 ms; 256^3: 1.106 -> 1.04 ms)
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     JRX_LAUNCH_CHECK(h);
@@ -491,9 +493,9 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.fsL = !!(fs & JRX_FACE_LEFT); bc.nsL = !!(ns & JRX_FACE_LEFT); bc.fsF = !!(fs & JRX_FACE_FRONT); bc.nsF = !!(ns & JRX_FACE_FRONT);
         bc.fsK0 = !!(fs & JRX_FACE_TOP);  bc.nsK0 = !!(ns & JRX_FACE_BOT);     // k = 1: free_slip `top`, no_slip `bot` (reference naming)
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
-        // 64 x 4 threads (stress tile 62 x 3), 16 planes per chunk: best of the measured tile shapes (145 VGPRs -> 3 blocks/CU)
+        // 64 x 4 threads (stress tile 62 x 3), 8 planes per chunk: best of the measured tile shapes (128 VGPRs -> 4 blocks/CU)
         int nt[3];
-        fused_tiles<64, 4, 16>(a.L, nt);
+        fused_tiles<64, 4, 8>(a.L, nt);
         const bool comm = jrx_comm_active(h);
         hipStream_t bs = s;            // stream of the boundary work
         // flow_bcs! on the new V: the reference's ordered passes the first time a set is written, one launch for all faces afterwards
@@ -512,7 +514,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         const bool overlap = overlap_env || h->fused_overlap;
         if (!comm || !overlap) {
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
-            JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc, all)));
+            JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, all)));
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
             JRX_TRY(fused_bcs(s));
             if (comm) {
@@ -539,9 +541,9 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             const int boxes[6][6] = {{0, nt[0], 0, nt[1], lo[2][0], lo[2][1]},  {0, nt[0], 0, nt[1], hi[2][0], hi[2][1]},
                                      {0, nt[0], lo[1][0], lo[1][1], mid[2][0], mid[2][1]}, {0, nt[0], hi[1][0], hi[1][1], mid[2][0], mid[2][1]},
                                      {lo[0][0], lo[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]}, {hi[0][0], hi[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]}};
-            for (int q = 0; q < 6; q++) JRX_TRY((launch_fused<64, 4, 16>(h, bs, a, bc, boxes[q])));
+            for (int q = 0; q < 6; q++) JRX_TRY((launch_fused<64, 4, 8>(h, bs, a, bc, boxes[q])));
             const int inner[6] = {mid[0][0], mid[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]};
-            JRX_TRY((launch_fused<64, 4, 16>(h, s, a, bc, inner)));
+            JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, inner)));
             JRX_TRY(fused_bcs(bs));
             // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
             double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};

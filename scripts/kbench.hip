@@ -346,6 +346,44 @@ int main(int argc, char **argv)
             FV(4, 4, true, 3, nty, "fused 64x4 lowreg ylds3 minw4")
             FV(8, 4, true, 3, nty8, "fused 64x8 lowreg ylds3 minw4")
             FV(8, 2, true, 3, nty8, "fused 64x8 lowreg ylds3 minw2")
+#define FVK(KZ_, XG_, NM_)                                                                                                               \
+            {                                                                                                                                    \
+                const int ntzk = (nz + KZ_ - 1) / KZ_;                                                                                           \
+                auto f_ = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, KZ_, 4, 1, true, XG_, false, true, 3, 1>), dim3(ntx * nty * ntzk), dim3(256), 0, 0, b, bc, ntx, nty); }; \
+                report(NM_, T.run(reps, f_), 360.0, 0);                                                                                          \
+            }
+            FVK(16, 8, "shipped: 64x4x16 xg8 lowreg ylds3 minw4 nt")
+            FVK(8, 8, "64x4x8 xg8 lowreg ylds3 minw4 nt")
+            FVK(12, 8, "64x4x12 xg8 lowreg ylds3 minw4 nt")
+            FVK(24, 8, "64x4x24 xg8 lowreg ylds3 minw4 nt")
+            FVK(32, 8, "64x4x32 xg8 lowreg ylds3 minw4 nt")
+            FVK(16, 4, "64x4x16 xg4 lowreg ylds3 minw4 nt")
+            FVK(16, 16, "64x4x16 xg16 lowreg ylds3 minw4 nt")
+            FVK(16, 32, "64x4x16 xg32 lowreg ylds3 minw4 nt")
+            FVK(8, 4, "64x4x8 xg4 lowreg ylds3 minw4 nt")
+            FVK(8, 2, "64x4x8 xg2 lowreg ylds3 minw4 nt")
+            FVK(8, 16, "64x4x8 xg16 lowreg ylds3 minw4 nt")
+            FVK(12, 4, "64x4x12 xg4 lowreg ylds3 minw4 nt")
+            FVK(6, 4, "64x4x6 xg4 lowreg ylds3 minw4 nt")
+            FVK(16, 2, "64x4x16 xg2 lowreg ylds3 minw4 nt")
+            FVK(8, 1, "64x4x8 xg1 lowreg ylds3 minw4 nt")
+            FVK(6, 1, "64x4x6 xg1 lowreg ylds3 minw4 nt")
+            FVK(12, 1, "64x4x12 xg1 lowreg ylds3 minw4 nt")
+            FVK(16, 1, "64x4x16 xg1 lowreg ylds3 minw4 nt")
+            FVK(4, 2, "64x4x4 xg2 lowreg ylds3 minw4 nt")
+            FVK(6, 2, "64x4x6 xg2 lowreg ylds3 minw4 nt")
+            FVK(10, 2, "64x4x10 xg2 lowreg ylds3 minw4 nt")
+            FVK(12, 2, "64x4x12 xg2 lowreg ylds3 minw4 nt")
+            FVK(8, 3, "64x4x8 xg3 lowreg ylds3 minw4 nt")
+            FVK(4, 1, "64x4x4 xg1 lowreg ylds3 minw4 nt")
+            FVK(5, 1, "64x4x5 xg1 lowreg ylds3 minw4 nt")
+            FVK(7, 1, "64x4x7 xg1 lowreg ylds3 minw4 nt")
+            FVK(6, 0, "64x4x6 xg0(plain order) lowreg ylds3 minw4 nt")
+            FVK(8, 0, "64x4x8 xg0(plain order) lowreg ylds3 minw4 nt")
+            FVK(16, 0, "64x4x16 xg0(plain order) lowreg ylds3 minw4 nt")
+            FVK(6, 1, "64x4x6 xg1 again")
+            FVK(8, 2, "64x4x8 xg2 again")
+            FVK(16, 8, "shipped again")
             report("fused 64x4x16 xg8 SHFL+YLDS (again)", T.run(reps, fy), 360.0, 0);
             report("fused 64x4x16 xg8 SHFL (again)", T.run(reps, fn), 360.0, 0);
         }
