@@ -461,20 +461,23 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
     // tile = TX cells of R rows, KZ planes deep; JRX_TH_CFG = R*10000 + (TX/64)*100 + KZ overrides (tuning)
     static const int cfg = [] { const char *e = getenv("JRX_TH_CFG"); return e ? atoi(e) : 0; }();
     const int FR = cfg ? cfg / 10000 : 1, FTX = cfg ? ((cfg / 100) % 100) * 64 : (nx > 128 ? 256 : (nx > 64 ? 128 : 64)), FKZ = cfg ? cfg % 100 : 4;
+    static const int xgenv = [] { const char *e = getenv("JRX_TH_XG"); return e ? atoi(e) : 8; }();
+    const int FXG = xgenv;
     const int ntx = (nx + FTX - 1) / FTX, nty = (ny + FR - 1) / FR, ntz = (nz + FKZ - 1) / FKZ;
     while (err > p->eps && iter < p->iterMax) {
         // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one
         const bool q2 = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
         a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy; a.t.qTz = cur.qz;
         if (fusable && !q2) {
-#define THL(TX_, KZ_, R_)                                                                                                          \
-    if (FTX == TX_ && FKZ == KZ_ && FR == R_) {                                                                                    \
-        hipLaunchKernelGGL((k_thermal3d_fused<TX_, KZ_, 8, R_>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX_), 0, s, a, oth, ntx, nty); \
+#define THL(TX_, KZ_, R_, XG_)                                                                                                      \
+    if (FTX == TX_ && FKZ == KZ_ && FR == R_ && FXG == XG_) {                                                                       \
+        hipLaunchKernelGGL((k_thermal3d_fused<TX_, KZ_, XG_, R_>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX_), 0, s, a, oth, ntx, nty); \
         launched = true;                                                                                                           \
     }
             bool launched = false;
             // measured at 256^3 (profiles/r01_thermal3d_fused_sweep.txt): one row per thread 2289 it/s, two rows 1526, four rows 1301
-            THL(256, 4, 1) THL(128, 4, 1) THL(64, 4, 1) THL(256, 8, 1) THL(256, 4, 2)
+            THL(256, 4, 1, 8) THL(128, 4, 1, 8) THL(64, 4, 1, 8) THL(256, 8, 1, 8) THL(256, 4, 2, 8)
+            THL(256, 4, 1, 1) THL(256, 4, 1, 2) THL(256, 4, 1, 4) THL(256, 2, 1, 1) THL(256, 2, 1, 2) THL(256, 8, 1, 1) THL(128, 4, 1, 1) THL(64, 4, 1, 1)
             if (!launched) return jrx_fail(h, JRX_ERR_ARG, "JRX_TH_CFG: no such configuration");
 #undef THL
             JRX_LAUNCH_CHECK(h);
