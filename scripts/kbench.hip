@@ -381,6 +381,17 @@ int main(int argc, char **argv)
             FVK(6, 0, "64x4x6 xg0(plain order) lowreg ylds3 minw4 nt")
             FVK(8, 0, "64x4x8 xg0(plain order) lowreg ylds3 minw4 nt")
             FVK(16, 0, "64x4x16 xg0(plain order) lowreg ylds3 minw4 nt")
+#define FVK8(KZ_, XG_, NM_)                                                                                                              \
+            {                                                                                                                                    \
+                const int ntzk = (nz + KZ_ - 1) / KZ_;                                                                                           \
+                auto f_ = [&] { hipLaunchKernelGGL((k_fused3d<64, 8, KZ_, 4, 1, true, XG_, false, true, 3, 1>), dim3(ntx * nty8 * ntzk), dim3(512), 0, 0, b, bc, ntx, nty8); }; \
+                report(NM_, T.run(reps, f_), 360.0, 0);                                                                                          \
+            }
+            FVK8(8, 1, "64x8x8 xg1 lowreg ylds3 minw4 nt")
+            FVK8(6, 1, "64x8x6 xg1 lowreg ylds3 minw4 nt")
+            FVK8(8, 2, "64x8x8 xg2 lowreg ylds3 minw4 nt")
+            FVK8(12, 1, "64x8x12 xg1 lowreg ylds3 minw4 nt")
+            FVK(8, 1, "64x4x8 xg1 (shipped now)")
             FVK(6, 1, "64x4x6 xg1 again")
             FVK(8, 2, "64x4x8 xg2 again")
             FVK(16, 8, "shipped again")
