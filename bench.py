@@ -29,10 +29,11 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measure
 # correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
 # n = 512: profiles/r01_pmc_xcd_banded_traffic.txt, profiles/r01_pmc_fused_ylds_traffic.txt
 #   k_stress3d_zb<512,1,4,xcd8>: FETCH_SIZE 13048845 KB, WRITE_SIZE 7410032 KB   (algorithmic: 21 + 7 passes of 1.074 GB)
-#   k_fused3d<64,4,16,minw4,lowreg,xg8,shfl,ylds3,nt>: FETCH_SIZE 18222939 KB, WRITE_SIZE 11020122 KB  (needs 25 + 10 passes; fetched 34.8 + written 10.5;
-#   profiles/r01_pmc_fused_regdiet_traffic.txt)
+#   k_fused3d<64,4,8,minw4,lowreg,xg1,shfl,ylds3,nt>: FETCH_SIZE 20010734 KB, WRITE_SIZE 11054315 KB  (needs 25 + 10 passes; fetched 38.2 + written 10.5;
+#   profiles/r01_pmc_fused_final_traffic.txt; the 16-plane / 8-row-band form fetched 34.8 passes and was slower: part of the surplus is
+#   served by the Infinity Cache, which FETCH_SIZE cannot tell from HBM)
 PMC_TRAFFIC_STRESS_512 = (2 * 13048845.0 + 7410032.0) * 1024.0
-PMC_TRAFFIC_FUSED_512 = (2 * 18222939.0 + 11020122.0) * 1024.0
+PMC_TRAFFIC_FUSED_512 = (2 * 20010734.0 + 11054315.0) * 1024.0
 
 
 def cpu_baseline(n_cpu: int, budget_s: float):
