@@ -295,14 +295,24 @@ __device__ __forceinline__ void vep3_gather_centres(const Vep3Args &a, const int
 // The three edge families of one node in one thread, as in the reference's kernel: they share the clamped centre stencils
 // (η, θ, the normal components) and each other's shear components, so the second and third family mostly hit in L1/L2.
 // New edge stresses go to a.tnew (committed by the caller), so every read sees last iteration's values.
-template <bool P4>
+// XS: blocks are dealt round-robin to the 8 XCDs; give XCD q the q-th eighth of the (flattened xy, z) block sequence instead, so that the
+// rows j +- 1 and planes k +- 1 a block gathers from were fetched by the same L2
+template <bool P4, bool XS = false>
 __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny;
     int i, j, k;
     if (P4) {
-        const int t_ = blockIdx.x * 64 + (threadIdx.x & 63);
-        j = t_ / (nx + 1); i = t_ - j * (nx + 1); k = blockIdx.y * 4 + (threadIdx.x >> 6);
+        unsigned bx = blockIdx.x, by = blockIdx.y;
+        if (XS) {
+            const unsigned L = by * gridDim.x + bx, T = gridDim.x * gridDim.y, per = T / 8;
+            if (L < per * 8) {
+                const unsigned Ln = (L & 7u) * per + (L >> 3);
+                bx = Ln % gridDim.x; by = Ln / gridDim.x;
+            }
+        }
+        const int t_ = bx * 64 + (threadIdx.x & 63);
+        j = t_ / (nx + 1); i = t_ - j * (nx + 1); k = by * 4 + (threadIdx.x >> 6);
         if (j >= ny + 1 || k >= a.nz + 1) return;
     } else {
         const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
@@ -488,7 +498,9 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     static const bool p4 = [] { const char *e = getenv("JRX_VEP_MAP"); return !(e && e[0] == '0'); }();
-    if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    static const bool xs = [] { const char *e = getenv("JRX_VEP_XCD"); return !(e && e[0] == '0'); }();   // +1-2 % measured
+    if (p4 && xs) hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    else if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     const EdgeN n = edge_counts(p);
