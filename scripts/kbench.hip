@@ -391,6 +391,17 @@ int main(int argc, char **argv)
             FVK8(6, 1, "64x8x6 xg1 lowreg ylds3 minw4 nt")
             FVK8(8, 2, "64x8x8 xg2 lowreg ylds3 minw4 nt")
             FVK8(12, 1, "64x8x12 xg1 lowreg ylds3 minw4 nt")
+            {
+                const int ntzk = (nz + 7) / 8;
+                auto f1 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 8, 2, 1, false, 1, false, true, 1, 1>), dim3(ntx * nty * ntzk), dim3(256), 0, 0, b, bc, ntx, nty); };
+                report("64x4x8 xg1 ylds1 minw2 (145 VGPRs, carried planes) nt", T.run(reps, f1), 360.0, 0);
+                auto f2 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 8, 3, 1, true, 1, false, true, 3, 1>), dim3(ntx * nty * ntzk), dim3(256), 0, 0, b, bc, ntx, nty); };
+                report("64x4x8 xg1 lowreg ylds3 minw3 nt", T.run(reps, f2), 360.0, 0);
+                auto f3 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 8, 4, 1, true, 1, false, true, 3, 0>), dim3(ntx * nty * ntzk), dim3(256), 0, 0, b, bc, ntx, nty); };
+                report("64x4x8 xg1 lowreg ylds3 minw4 (temporal stores)", T.run(reps, f3), 360.0, 0);
+                auto f4 = [&] { hipLaunchKernelGGL((k_fused3d<64, 4, 8, 4, 1, true, 1, false, true, 1, 1>), dim3(ntx * nty * ntzk), dim3(256), 0, 0, b, bc, ntx, nty); };
+                report("64x4x8 xg1 lowreg ylds1 minw4 nt", T.run(reps, f4), 360.0, 0);
+            }
             FVK(8, 1, "64x4x8 xg1 (shipped now)")
             FVK(6, 1, "64x4x6 xg1 again")
             FVK(8, 2, "64x4x8 xg2 again")
