@@ -371,6 +371,7 @@ struct VepArgs {
     jrx_rheology rh;
     const double *theta, *etatau, *Kc, *Gc;
     double *lam, *lamv;
+    double *txx_out = nullptr, *tyy_out = nullptr;      // where the centre half writes τxx, τyy (nullptr: in place)
     double _dx, _dy, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
     int nx, ny;
 };
@@ -468,12 +469,9 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
 
 // update_stresses_center_vertex_ps! -- vertex half.  Runs before the centre half so that the vertex averages
 // see the old centre stresses (the reference's single launch races on them).
-__global__ __launch_bounds__(256) void k_vep_vertex(const VepArgs a)
+__device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, const int j)
 {
     const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = t / (nx + 1), i = t - j * (nx + 1);
-    if (j > ny) return;
     const int i0 = clampi(i - 1, 0, nx - 1), ic = clampi(i, 0, nx - 1), j0 = clampi(j - 1, 0, ny - 1), jc = clampi(j, 0, ny - 1);
 #define AVC(A) (0.25 * (C2(A, i0, j0) + C2(A, ic, jc) + C2(A, i0, jc) + C2(A, ic, j0)))
     const double Pv = AVC(a.theta), exxv = AVC(a.f.exx), eyyv = AVC(a.f.eyy), txxv = AVC(a.f.txx), tyyv = AVC(a.f.tyy);
@@ -509,14 +507,20 @@ __global__ __launch_bounds__(256) void k_vep_vertex(const VepArgs a)
     }
 }
 
-// update_stresses_center_vertex_ps! -- centre half (+ Pr_c, τII, η_vep)
-__global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
+__global__ __launch_bounds__(256) void k_vep_vertex(const VepArgs a)
 {
-    const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = t / nx, i = t - j * nx;
-    if (j >= ny) return;
+    const int j = t / (a.nx + 1), i = t - j * (a.nx + 1);
+    if (j > a.ny) return;
+    vep_vertex_at(a, i, j);
+}
+
+// update_stresses_center_vertex_ps! -- centre half (+ Pr_c, τII, η_vep)
+__device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, const int j)
+{
+    const int nx = a.nx, np = a.rh.nphase;
     const i64 c = i + (i64)nx * j;
+    double *__restrict__ txx_o = a.txx_out ? a.txx_out : a.f.txx, *__restrict__ tyy_o = a.tyy_out ? a.tyy_out : a.f.tyy;
     const double *rc = a.f.phase_c + (i64)np * c;
     const double _Gdt = 1.0 / (ratio_avg(a.rh.G, rc, np) * a.dt);
     bool is_pl; double eta_reg;
@@ -546,17 +550,34 @@ __global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
 #pragma unroll
         for (int q = 0; q < 3; q++) { epl[q] = l * dQdt[q]; d[q] = fma(-2.0 * e * epl[q], dtr, d[q]); tij[q] = d[q] + tij[q]; }
         a.f.evol_pl[c] = -l * dQdP;
-        a.f.txx[c] = tij[0]; a.f.tyy[c] = tij[1]; a.f.txy_c[c] = tij[2];
+        txx_o[c] = tij[0]; tyy_o[c] = tij[1]; a.f.txy_c[c] = tij[2];
         a.f.eplxx[c] = epl[0]; a.f.eplyy[c] = epl[1];
         tII = sinv2(tij[0], tij[1], tij[2]);
     } else {
         a.f.evol_pl[c] = 0.0;
-        a.f.txx[c] = d[0] + tij[0]; a.f.tyy[c] = d[1] + tij[1]; a.f.txy_c[c] = d[2] + tij[2];
+        txx_o[c] = d[0] + tij[0]; tyy_o[c] = d[1] + tij[1]; a.f.txy_c[c] = d[2] + tij[2];
         a.f.eplxx[c] = 0.0; a.f.eplyy[c] = 0.0;
     }
     a.f.tII[c] = tII;
     a.f.eta_vep[c] = tII * 0.5 * (1.0 / sinv2(eij[0], eij[1], eij[2]));
     a.f.P[c] = Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP);
+}
+__global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / a.nx, i = t - j * a.nx;
+    if (j >= a.ny) return;
+    vep_centre_at(a, i, j);
+}
+// both halves in one launch: the vertex half averages the OLD centre stresses, so the centre half must write τxx, τyy elsewhere
+// (a.txx_out / a.tyy_out; the caller then swaps the pointers)
+__global__ __launch_bounds__(256) void k_vep_stress2d(const VepArgs a)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / (a.nx + 1), i = t - j * (a.nx + 1);
+    if (j > a.ny) return;
+    vep_vertex_at(a, i, j);
+    if (i < a.nx && j < a.ny) vep_centre_at(a, i, j);
 }
 
 // compute_τ_nonlinear! 2D: single phase (StressKernels.jl:266-307) / phases at the cell centres (:310-351) with
@@ -904,11 +925,12 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     const int64_t nn[3] = {nx, ny, 1};
     const size_t n = (size_t)nx * ny, nv = (size_t)(nx + 1) * (ny + 1);
     hipStream_t s = h->stream;
-    // library scratch: ητ, θ, λ, K, G (centre) and λv (vertex), carved out of one allocation
-    JRX_TRY(jrx_ensure_etatau(h, 5 * n + nv));
+    // library scratch: ητ, θ, λ, K, G (centre), λv (vertex) and the second set of τxx, τyy, carved out of one allocation
+    JRX_TRY(jrx_ensure_etatau(h, 7 * n + nv));
     double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n, *lamv = Gc + n;
     VepArgs a = make_vep(f, rh, p);
     a.theta = theta; a.etatau = etatau; a.Kc = Kc; a.Gc = Gc; a.lam = lam; a.lamv = lamv;
+    a.txx_out = lamv + nv; a.tyy_out = a.txx_out + n;
     jrx_stokes2d_fields g = view2d(f);
     jrx_stokes2d_params q;
     memset(&q, 0, sizeof(q));
@@ -942,10 +964,12 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             hipLaunchKernelGGL(k_vep_pre<false>, dim3(gv), dim3(256), 0, s, a, theta);
         } else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, a, theta);      // compute_maxloc! folded in
         JRX_LAUNCH_CHECK(h);
-        hipLaunchKernelGGL(k_vep_vertex, dim3(gv), dim3(256), 0, s, a);
+        // update_stresses_center_vertex_ps!: vertex and centre halves in one launch; the new τxx, τyy go to the other set, then swap
+        hipLaunchKernelGGL(k_vep_stress2d, dim3(gv), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
-        hipLaunchKernelGGL(k_vep_centre, dim3(gc), dim3(256), 0, s, a);
-        JRX_LAUNCH_CHECK(h);
+        { double *t_ = a.f.txx; a.f.txx = a.txx_out; a.txx_out = t_; }
+        { double *t_ = a.f.tyy; a.f.tyy = a.tyy_out; a.tyy_out = t_; }
+        b.f.txx = a.f.txx; b.f.tyy = a.f.tyy; g.txx = a.f.txx; g.tyy = a.f.tyy;
         if (comm) {   // update_halo!(stokes.τ.xy) (Stokes2D.jl:757)
             double *arrs[1] = {f->txy};
             const int64_t ext[1][3] = {{nx + 1, ny + 1, 1}};
@@ -1009,6 +1033,12 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
         }
     }
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
+    if (a.f.txx != f->txx) {      // odd number of swaps: leave τxx, τyy in the caller's arrays
+        JRX_HIP(h, hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        a.f.txx = f->txx; a.f.tyy = f->tyy; b.f.txx = f->txx; b.f.tyy = f->tyy; g.txx = f->txx; g.tyy = f->tyy;
+    }
+    a.txx_out = a.tyy_out = nullptr;
     hipLaunchKernelGGL(k_vep_epilogue, dim3(gv), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     hipLaunchKernelGGL(k_copy6, dim3(256), dim3(256), 0, s, f->toxx, (const double *)f->txx, (i64)n, f->toyy, (const double *)f->tyy, (i64)n,
