@@ -144,3 +144,25 @@ def test_device_builder_matches_host_builder_on_cpu(jr):
     Vx = jr.to_numpy(st.V.Vx)
     assert np.array_equal(Vx[:, 1:-1, 1:-1], s.arrays["Vx"][:, 1:-1, 1:-1])
     assert pt.θ_dτ == s.pt.θ_dτ and dt == s.dt
+
+
+def test_header_is_c99_and_callable_from_c(tmp_path):
+    """The boundary is a C ABI: include/jrx.h compiles as strict C99, and a plain-C program linked against libjrx_hip.so calls the
+    host-only entry points (block decomposition, halo planes: ImplicitGlobalGrid's arithmetic) without a GPU."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc not found"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", str(root / "include" / "jrx.h")], check=True)
+    libdir = root / "justrelax.jl_amd" / "lib"
+    assert (libdir / "libjrx_hip.so").exists(), "build the library first (__graft_entry__.build())"
+    exe = tmp_path / "c_abi_smoke"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-I", str(root / "include"), str(root / "tests" / "c_abi_smoke.c"), "-L", str(libdir),
+                    "-ljrx_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == "dims 2 2 2 coords 1 0 1"            # rank 5 of 2 x 2 x 2 = (1*2 + 0)*2 + 1: MPI_Cart_create's row-major order, as IGG uses
+    assert out[1] == "neighbors 1 -1 -1 7 4 -1"           # x-left (0,0,1) = 1, y-right (1,1,1) = 7, z-left (1,0,0) = 4; -1 = physical boundary
+    assert out[2] == "halo planes 2 510 0 512"
+    assert out[3] == "nx_g 1022"
