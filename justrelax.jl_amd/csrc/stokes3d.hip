@@ -106,7 +106,8 @@ jrx_status launch_velocity_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, 
     return JRX_OK;
 }
 
-static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepArgs &a, const int (*box)[6], int nbox, bool diag);
+static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepArgs &a, const int (*box)[6], int nbox, bool diag,
+                                      const GhostRule *rule = nullptr);
 
 // Stress sweep over the whole ni.+1 node box.  Wide grids: z-marching kernel over the cell box
 // (tile = one or two full-width row segments: measured best for DRAM page locality)
@@ -196,7 +197,8 @@ static jrx_status launch_bcs_faces(jrx_handle *h, hipStream_t s, double *Vx, dou
 }
 
 // the stress sweep over up to six disjoint node boxes in one launch
-static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepArgs &a, const int (*box)[6], int nbox, bool diag)
+// rule != nullptr: the boundary entries of V are derived by the flow_bcs! rules instead of being read (no flow_bcs! launch needed before)
+static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepArgs &a, const int (*box)[6], int nbox, bool diag, const GhostRule *rule)
 {
     StressBoxes B = {};
     int tot = 0;
@@ -212,8 +214,10 @@ static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepA
     }
     if (!B.n) return JRX_OK;
     B.start[B.n] = tot;
-    if (diag) hipLaunchKernelGGL(k_stress3d_boxes<true>, dim3((unsigned)tot), dim3(256), 0, s, a, B);
-    else hipLaunchKernelGGL(k_stress3d_boxes<false>, dim3((unsigned)tot), dim3(256), 0, s, a, B);
+    const GhostRule none = {{0, 0, 0, 0, 0, 0}};
+    if (rule) hipLaunchKernelGGL((k_stress3d_boxes<false, true>), dim3((unsigned)tot), dim3(256), 0, s, a, B, *rule);
+    else if (diag) hipLaunchKernelGGL(k_stress3d_boxes<true>, dim3((unsigned)tot), dim3(256), 0, s, a, B, none);
+    else hipLaunchKernelGGL(k_stress3d_boxes<false>, dim3((unsigned)tot), dim3(256), 0, s, a, B, none);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -379,6 +383,7 @@ struct Iter3D {
     bool stress_done = false;     // A of the upcoming iteration already applied (by a fused launch)
     bool fusable = false;
     bool bcs_ordered[2] = {false, false};   // flow_bcs! has run with the reference's pass order on the V of set U / set S
+    bool ghosts_stale = false;              // the last fused step left flow_bcs! of its new V to be applied lazily
 };
 
 static Out10 out_of(const jrx_stokes3d_fields &f) { return Out10{f.P, f.txx, f.tyy, f.tzz, f.tyz, f.txz, f.txy, f.Vx, f.Vy, f.Vz}; }
@@ -516,7 +521,11 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
             JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, all)));
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
-            JRX_TRY(fused_bcs(s));
+            // Without neighbours no flow_bcs! launch is needed here: the fused kernel and the boundary-layer launch below derive the
+            // boundary entries of V by rule, and every path that reads them from memory (un-fused sweeps, results handed back) is
+            // preceded by a flow_bcs! launch of its own.  With neighbours the exchange ships those entries, so they must be in memory.
+            if (comm) JRX_TRY(fused_bcs(s));
+            else I.ghosts_stale = true;
             if (comm) {
                 // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
                 double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
@@ -561,7 +570,14 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                   klo = nb[2][0] ? 1 : 0, khi = nb[2][1] ? nz - 1 : nz;
         const int fix[6][6] = {{0, ilo, 0, ny + 1, 0, nz + 1}, {ihi, nx + 1, 0, ny + 1, 0, nz + 1}, {ilo, ihi, 0, jlo, 0, nz + 1},
                                {ilo, ihi, jhi, ny + 1, 0, nz + 1}, {ilo, ihi, jlo, jhi, 0, klo}, {ilo, ihi, jlo, jhi, khi, nz + 1}};
-        JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false));
+        GhostRule gr;
+        {
+            auto ty = [&](uint32_t fsbit, uint32_t nsbit) { return (p->no_slip & nsbit) ? 2 : ((p->free_slip & fsbit) ? 1 : 0); };
+            const int t6[6] = {ty(JRX_FACE_LEFT, JRX_FACE_LEFT), ty(JRX_FACE_RIGHT, JRX_FACE_RIGHT), ty(JRX_FACE_FRONT, JRX_FACE_FRONT),
+                               ty(JRX_FACE_BACK, JRX_FACE_BACK), ty(JRX_FACE_TOP, JRX_FACE_BOT), ty(JRX_FACE_BOT, JRX_FACE_TOP)};
+            for (int q = 0; q < 6; q++) gr.t[q] = t6[q];
+        }
+        JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false, comm ? nullptr : &gr));
         if (bs != s) {
             JRX_HIP(h, hipEventRecord(h->ev[2], bs));
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
@@ -577,6 +593,13 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
 
     const jrx_stokes3d_fields *f = &I.cur;
     if (!jrx_comm_active(h)) {
+        if (I.ghosts_stale && diag) {
+            // U = V dt below copies the boundary entries of V as flow_bcs! of the previous iteration left them (the reference applies
+            // flow_bcs! after velocity2displacement!): apply that pending flow_bcs! now, before V is updated
+            JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+            I.bcs_ordered[I.cur_is_user ? 0 : 1] = true;
+        }
+        I.ghosts_stale = false;
         JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
         if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
         if (diag) JRX_TRY(launch_scaleU(h, s, f, p));

@@ -55,8 +55,40 @@ struct SweepArgs {
 // Stress sweep, version 1: one thread per node of the ni.+1 box, xy-plane flattened over threadIdx
 // so that rows of any length (nx, nx+1, nx+2) stay fully coalesced; blockIdx.y walks z.
 // ------------------------------------------------------------------------------------------------
-template <bool DIAG>
-__device__ __forceinline__ void stress3d_node(const SweepArgs &a, const int i, const int j, const int k)
+// flow_bcs! by rule instead of by memory: what free_slip! / no_slip! leave in the boundary entries of V, derived from the interior on the
+// fly.  t[face]: 0 none (memory holds the prescribed value), 1 free slip, 2 no slip; faces x-lo, x-hi, y-lo, y-hi, z-lo (k = 1), z-hi.
+// Exact wherever a Stokes stencil reads (entries on at most one ghost plane); used by the boundary-layer launch behind the fused
+// kernel so that it does not have to wait for -- or need at all -- a flow_bcs! launch on the new velocities.
+struct GhostRule { int t[6]; };
+__device__ __forceinline__ void ghost_tan(int &idx, double &sgn, const int n, const int tlo, const int thi)
+{
+    if (idx == 0 && tlo) { idx = 1; if (tlo == 2) sgn = -sgn; }
+    else if (idx == n + 1 && thi) { idx = n; if (thi == 2) sgn = -sgn; }
+}
+__device__ __forceinline__ double vx_rule(const double *__restrict__ Vx, const Lay3 &L, const GhostRule &g, int i, int j, int k)
+{
+    if ((i == 0 && g.t[0] == 2) || (i == L.nx && g.t[1] == 2)) return 0.0;
+    double sgn = 1.0;
+    ghost_tan(j, sgn, L.ny, g.t[2], g.t[3]); ghost_tan(k, sgn, L.nz, g.t[4], g.t[5]);
+    return sgn * Vx[i + (i64)L.vx1 * j + L.vxp * k];
+}
+__device__ __forceinline__ double vy_rule(const double *__restrict__ Vy, const Lay3 &L, const GhostRule &g, int i, int j, int k)
+{
+    if ((j == 0 && g.t[2] == 2) || (j == L.ny && g.t[3] == 2)) return 0.0;
+    double sgn = 1.0;
+    ghost_tan(i, sgn, L.nx, g.t[0], g.t[1]); ghost_tan(k, sgn, L.nz, g.t[4], g.t[5]);
+    return sgn * Vy[i + (i64)L.vy1 * j + L.vyp * k];
+}
+__device__ __forceinline__ double vz_rule(const double *__restrict__ Vz, const Lay3 &L, const GhostRule &g, int i, int j, int k)
+{
+    if ((k == 0 && g.t[4] == 2) || (k == L.nz && g.t[5] == 2)) return 0.0;
+    double sgn = 1.0;
+    ghost_tan(i, sgn, L.nx, g.t[0], g.t[1]); ghost_tan(j, sgn, L.ny, g.t[2], g.t[3]);
+    return sgn * Vz[i + (i64)L.vz1 * j + L.vzp * k];
+}
+
+template <bool DIAG, bool GH = false>
+__device__ __forceinline__ void stress3d_node(const SweepArgs &a, const int i, const int j, const int k, const GhostRule *gr = nullptr)
 {
     const Lay3 &L = a.L;
     const int nx = L.nx, ny = L.ny, nz = L.nz;
@@ -65,9 +97,9 @@ __device__ __forceinline__ void stress3d_node(const SweepArgs &a, const int i, c
     const double *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
     const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau;
 
-#define VX(i_, j_, k_) Vx[(i_) + (i64)L.vx1 * (j_) + L.vxp * (k_)]
-#define VY(i_, j_, k_) Vy[(i_) + (i64)L.vy1 * (j_) + L.vyp * (k_)]
-#define VZ(i_, j_, k_) Vz[(i_) + (i64)L.vz1 * (j_) + L.vzp * (k_)]
+#define VX(i_, j_, k_) (GH ? vx_rule(Vx, L, *gr, (i_), (j_), (k_)) : Vx[(i_) + (i64)L.vx1 * (j_) + L.vxp * (k_)])
+#define VY(i_, j_, k_) (GH ? vy_rule(Vy, L, *gr, (i_), (j_), (k_)) : Vy[(i_) + (i64)L.vy1 * (j_) + L.vyp * (k_)])
+#define VZ(i_, j_, k_) (GH ? vz_rule(Vz, L, *gr, (i_), (j_), (k_)) : Vz[(i_) + (i64)L.vz1 * (j_) + L.vzp * (k_)])
 #define CC(i_, j_, k_) ((i_) + (i64)nx * (j_) + L.cp * (k_))
 
     const bool ci = i < nx, cj = j < ny, ck = k < nz;
@@ -168,8 +200,8 @@ struct StressBoxes {
     int start[7];         // first block of each box; start[n] = total
     int per_plane[6];     // blocks per xy-plane of the box
 };
-template <bool DIAG>
-__global__ __launch_bounds__(256) void k_stress3d_boxes(const SweepArgs a, const StressBoxes B)
+template <bool DIAG, bool GH = false>
+__global__ __launch_bounds__(256) void k_stress3d_boxes(const SweepArgs a, const StressBoxes B, const GhostRule gr)
 {
     int b = 0;
     while (b + 1 < B.n && (int)blockIdx.x >= B.start[b + 1]) b++;
@@ -180,7 +212,7 @@ __global__ __launch_bounds__(256) void k_stress3d_boxes(const SweepArgs a, const
     const int jj = t / wi;
     const int j = B.box[b][2] + jj;
     if (j >= B.box[b][3]) return;
-    stress3d_node<DIAG>(a, B.box[b][0] + (t - jj * wi), j, B.box[b][4] + kz);
+    stress3d_node<DIAG, GH>(a, B.box[b][0] + (t - jj * wi), j, B.box[b][4] + kz, &gr);
 }
 
 // ------------------------------------------------------------------------------------------------
