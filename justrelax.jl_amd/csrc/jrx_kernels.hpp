@@ -68,6 +68,26 @@ __global__ __launch_bounds__(256) void k_bc3d(BcArr A0, BcArr A1, BcArr A2, int 
     }
 }
 
+// copy of the outer shell (every entry with an index on the first or last plane of a dimension) of three arrays:
+// blockIdx.y = face (2 * dim + side), blockIdx.z = array
+struct CBcArr {
+    const double *p;
+    int n[3];
+};
+__global__ __launch_bounds__(256) void k_copy_shell3(BcArr D0, BcArr D1, BcArr D2, CBcArr S0, CBcArr S1, CBcArr S2)
+{
+    const BcArr D = blockIdx.z == 0 ? D0 : (blockIdx.z == 1 ? D1 : D2);
+    const CBcArr S = blockIdx.z == 0 ? S0 : (blockIdx.z == 1 ? S1 : S2);
+    const int dim = blockIdx.y >> 1, side = blockIdx.y & 1;
+    const int d1 = dim == 0 ? 1 : 0, d2 = dim == 2 ? 1 : 2;
+    const i64 u = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= (i64)D.n[d1] * D.n[d2]) return;
+    const int a = (int)(u % D.n[d1]), b = (int)(u / D.n[d1]);
+    const i64 s[3] = {1, D.n[0], (i64)D.n[0] * D.n[1]};
+    const i64 idx = a * s[d1] + b * s[d2] + (side ? (i64)(D.n[dim] - 1) * s[dim] : 0);
+    D.p[idx] = S.p[idx];
+}
+
 // free_slip / no_slip on all six faces in ONE launch (blockIdx.z = dimension; tlo/thi: 0 none, 1 free slip, 2 no slip).
 // Every ghost entry that lies on exactly one ghost plane gets the value the ordered passes above give it; entries on two or three
 // ghost planes (edge / corner ghosts) depend on the pass order there and are left racy here -- no stencil of the Stokes kernels

@@ -431,12 +431,13 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
         double **S = h->scratch;
         I.setS = Out10{S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], S[8], S[9]};
-        // the scratch V needs the planes no kernel ever writes (prescribed normal velocities): copy V once
-        const i64 n0 = (i64)(p->nx + 1) * (p->ny + 2) * (p->nz + 2), n1 = (i64)(p->nx + 2) * (p->ny + 1) * (p->nz + 2),
-                  n2 = (i64)(p->nx + 2) * (p->ny + 2) * (p->nz + 1);
-        hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, h->stream, I.setS.Vx, (const double *)f->Vx, n0, I.setS.Vy, (const double *)f->Vy, n1,
-                           I.setS.Vz, (const double *)f->Vz, n2, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr,
-                           (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
+        // the scratch V needs the entries no kernel of the fused pipeline writes -- the outer shell of each array (boundary planes with the
+        // prescribed normal velocities, ghost planes): copy the shell once
+        const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
+        const BcArr D[3] = {{I.setS.Vx, {nx + 1, ny + 2, nz + 2}}, {I.setS.Vy, {nx + 2, ny + 1, nz + 2}}, {I.setS.Vz, {nx + 2, ny + 2, nz + 1}}};
+        const CBcArr S3[3] = {{f->Vx, {nx + 1, ny + 2, nz + 2}}, {f->Vy, {nx + 2, ny + 1, nz + 2}}, {f->Vz, {nx + 2, ny + 2, nz + 1}}};
+        const int m1 = (nx > ny ? nx : ny) + 2, m2 = (ny > nz ? ny : nz) + 2;
+        hipLaunchKernelGGL(k_copy_shell3, dim3((unsigned)(((i64)m1 * m2 + 255) / 256), 6, 3), dim3(256), 0, h->stream, D[0], D[1], D[2], S3[0], S3[1], S3[2]);
         JRX_LAUNCH_CHECK(h);
     }
     return JRX_OK;
