@@ -70,7 +70,7 @@ int32_t jrx_version(void);
  *   3 = fused pipeline wherever it is legal (ignores the tile-fill rule).  All variants produce bit-identical results.
  * "fused_overlap" (0/1, default 0): multi-rank fused pipeline with the shell of tiles, BCs and exchange on a second
  *   stream while the interior tiles run (same results).
- * "thermal_fused" (0/1, default 1): jrx_heatdiffusion_PT3d runs unobserved iterations as one fused launch with a
+ * "thermal_fused" (0/1, default 1): jrx_heatdiffusion_PT2d / _PT3d run unobserved iterations as one fused launch with a
  *   library-owned second (T, qT) set; 0 = always compute_flux! and update_T! as two launches (same results). */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 

@@ -74,6 +74,8 @@ jrx_status jrx_destroy(jrx_handle *h)
         if (h->scratch[q]) (void)hipFree(h->scratch[q]);
     for (int q = 0; q < 4; q++)
         if (h->tscratch[q]) (void)hipFree(h->tscratch[q]);
+    for (int q = 0; q < 3; q++)
+        if (h->tscratch2[q]) (void)hipFree(h->tscratch2[q]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->halo_stream) (void)hipStreamDestroy(h->halo_stream);
     delete h;

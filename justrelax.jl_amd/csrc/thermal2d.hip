@@ -114,6 +114,87 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One PT iteration in one launch (compute_flux! + update_T! + thermal_bcs!, DiffusionPT_solver.jl:104-111) for iterations nobody
+// observes -- the 2D loop is launch-bound, so this halves its cost.  A thread owns cell (i, j): it stores the fluxes on its two low
+// faces (and on the domain's high faces), takes the x flux of its high face from the next lane (wave-edge lanes compute it), recomputes
+// the y one; (T, qT) are read from one set and written to the other because neighbouring threads recompute what another thread
+// stores.  The un-relaxed fluxes qT*2 are not written (only check_res! reads them: observed iterations run the two kernels).
+// Same arithmetic, in the same order, as k_flux2d / k_updateT2d.
+// ------------------------------------------------------------------------------------------------
+struct TSet2 { double *T, *qx, *qy; };
+template <int TX>
+__global__ __launch_bounds__(TX) void k_thermal2d_fused(const TArgs a, const TSet2 dst, int ntx)
+{
+    const int nx = (int)a.p.nx, ny = (int)a.p.ny;
+    const int tix = blockIdx.x % ntx, j = blockIdx.x / ntx;
+    const int i = tix * TX + (int)threadIdx.x;
+    if (i >= nx && (i & ~63) >= nx) return;            // whole waves beyond the row end; idle lanes of a live wave stay for the shuffle
+    const bool cell = i < nx;
+    const int ic = cell ? i : nx - 1;
+    const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau, *__restrict__ Kk = a.t.K;
+    const bool rf = a.p.rheology_form != 0;
+    const double kc = (a.p.k_const + a.p.k_const) * 0.5;
+    const i64 n1 = nx + 2;
+    const i64 c = ic + (i64)nx * j, I1 = (ic + 1) + n1 * (j + 1);
+    const int im = max(ic - 1, 0), ip = min(ic + 1, nx - 1), jm = max(j - 1, 0), jp = min(j + 1, ny - 1);
+    auto relax = [&](double qold, double Kl, double Kr, double tl, double tr_, double Thi, double Tlo, double _d) -> double {
+        const double K = rf ? kc : (Kl + Kr) * 0.5;
+        const double t = (tl + tr_) * 0.5;
+        const double qv = -K * (Thi - Tlo) * _d;
+        return (qold * t + qv) / (1.0 + t);
+    };
+    const double Tc = T[I1], Kc_ = rf ? 0.0 : Kk[c], tc = th[c];
+    // x: low face i (own), high face i+1 from the next lane
+    double qx_lo;
+    {
+        const i64 q = ic + (i64)(nx + 1) * j;
+        if (ic == 0 && a.p.constant_flux_on[TL]) qx_lo = a.p.constant_flux[TL];
+        else {
+            const i64 cl = c - (ic - im);
+            qx_lo = relax(a.t.qTx[q], rf ? 0.0 : Kk[cl], Kc_, th[cl], tc, Tc, T[I1 - 1], a.p._dx);
+        }
+        if (cell) dst.qx[q] = qx_lo;
+    }
+    double qx_hi = __shfl_down(qx_lo, 1, 64);
+    if ((threadIdx.x & 63) == 63 || i == nx - 1) {
+        const i64 q = (ic + 1) + (i64)(nx + 1) * j;
+        if (ic + 1 == nx && a.p.constant_flux_on[TR]) qx_hi = a.p.constant_flux[TR];
+        else {
+            const i64 cr = c + (ip - ic);
+            qx_hi = relax(a.t.qTx[q], Kc_, rf ? 0.0 : Kk[cr], tc, th[cr], T[I1 + 1], Tc, a.p._dx);
+        }
+        if (cell && ic + 1 == nx) dst.qx[q] = qx_hi;
+    }
+    // y: low face j (own), high face j+1 recomputed (owned by the row above, or by this row on the top face)
+    double qy_lo, qy_hi;
+    {
+        const i64 q = ic + (i64)nx * j;
+        if (j == 0 && a.p.constant_flux_on[TB]) qy_lo = a.p.constant_flux[TB];
+        else {
+            const i64 cl = c - (i64)nx * (j - jm);
+            qy_lo = relax(a.t.qTy[q], rf ? 0.0 : Kk[cl], Kc_, th[cl], tc, Tc, T[I1 - n1], a.p._dy);
+        }
+        if (cell) dst.qy[q] = qy_lo;
+        if (j + 1 == ny && a.p.constant_flux_on[TT]) qy_hi = a.p.constant_flux[TT];
+        else {
+            const i64 cr = c + (i64)nx * (jp - j);
+            qy_hi = relax(a.t.qTy[q + nx], Kc_, rf ? 0.0 : Kk[cr], tc, th[cr], T[I1 + n1], Tc, a.p._dy);
+        }
+        if (cell && j + 1 == ny) dst.qy[q + nx] = qy_hi;
+    }
+    if (cell) {
+        const double _dt = 1.0 / a.p.dt;
+        const double rcp = rhoCp_of(a.p, a.t.rhoCp, c, Tc);
+        const double dr = a.t.dtau_rho[c];
+        const double divq = (qx_hi - qx_lo) * a.p._dx + (qy_hi - qy_lo) * a.p._dy;
+        const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+        dst.T[I1] = Tn;
+        const int xs = i == 0 ? 0 : (i == nx - 1 ? 1 : -1), ys = j == 0 ? 0 : (j == ny - 1 ? 1 : -1);
+        if (xs >= 0 || ys >= 0) thermal_ghosts2d(a.p, dst.T, nx + 2, I1, xs, ys, Tn);
+    }
+}
+
 // thermal_bcs!: step 0 constant_value, 1 no_flux, 2 periodic; dimy=1: rows j=0 / j=end (bot/top), else columns (left/right)
 __global__ __launch_bounds__(256) void k_tbc2d(double *__restrict__ T, int nx, int ny, int step, int dimy,
                                                int lo_on, int hi_on, double lo_val, double hi_val)
@@ -279,8 +360,37 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
     double err = 2 * p->eps;
     TArgs a;
     a.t = *t; a.p = *p;
+    // iterations nobody observes: one fused launch, ping-pong between the caller's (T, qT) and a library-owned set (option thermal_fused)
+    const bool any_periodic = p->periodic[0] | p->periodic[1] | p->periodic[2] | p->periodic[3];
+    const bool fusable = h->thermal_fused && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
+    const TSet2 user = {t->T, t->qTx, t->qTy};
+    TSet2 cur = user, oth = user;
+    if (fusable) {
+        if (!(h->tscratch2[0] && h->tscratch2_dims[0] == nx && h->tscratch2_dims[1] == ny)) {
+            for (int q = 0; q < 3; q++) { if (h->tscratch2[q]) JRX_HIP(h, hipFree(h->tscratch2[q])); h->tscratch2[q] = nullptr; }
+            h->tscratch2_dims[0] = h->tscratch2_dims[1] = 0;
+            const size_t sz[3] = {(size_t)nT, (size_t)(nx + 1) * ny, (size_t)nx * (ny + 1)};
+            for (int q = 0; q < 3; q++) JRX_HIP(h, hipMalloc(&h->tscratch2[q], sz[q] * sizeof(double)));
+            h->tscratch2_dims[0] = nx; h->tscratch2_dims[1] = ny;
+        }
+        oth = TSet2{h->tscratch2[0], h->tscratch2[1], h->tscratch2[2]};
+        JRX_HIP(h, hipMemcpyAsync(oth.T, t->T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));    // ghosts no BC rewrites
+    }
+    const int FTX = nx > 128 ? 256 : (nx > 64 ? 128 : 64), ntx = (nx + FTX - 1) / FTX;
+    jrx_thermal2d_fields tc = *t;
     while (err > p->eps && iter < p->iterMax) {
-        JRX_TRY(enqueue_titer(h, t, p, true));
+        const bool observed = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
+        a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy;
+        if (fusable && !observed) {
+            if (FTX == 256) hipLaunchKernelGGL(k_thermal2d_fused<256>, dim3((unsigned)(ntx * ny)), dim3(256), 0, s, a, oth, ntx);
+            else if (FTX == 128) hipLaunchKernelGGL(k_thermal2d_fused<128>, dim3((unsigned)(ntx * ny)), dim3(128), 0, s, a, oth, ntx);
+            else hipLaunchKernelGGL(k_thermal2d_fused<64>, dim3((unsigned)(ntx * ny)), dim3(64), 0, s, a, oth, ntx);
+            JRX_LAUNCH_CHECK(h);
+            const TSet2 tmp = cur; cur = oth; oth = tmp;
+        } else {
+            tc.T = cur.T; tc.qTx = cur.qx; tc.qTy = cur.qy;
+            JRX_TRY(enqueue_titer(h, &tc, p, true));
+        }
         iter++;
         if (iter % p->nout == 0) {
             hipLaunchKernelGGL(k_updateT2d<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
@@ -302,6 +412,11 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
             cnt++;
             if (p->verbose) printf("iter = %lld, err = %1.3e \n", (long long)iter, err);
         }
+    }
+    if (cur.T != user.T) {      // leave the results in the caller's arrays
+        JRX_HIP(h, hipMemcpyAsync(user.T, cur.T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(user.qx, cur.qx, (size_t)(nx + 1) * ny * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(user.qy, cur.qy, (size_t)nx * (ny + 1) * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     hipLaunchKernelGGL(k_sub, dim3(256), dim3(256), 0, s, t->dT, (const double *)t->T, (const double *)t->Told, nT);   // update_ΔT!
     JRX_LAUNCH_CHECK(h);
