@@ -76,6 +76,8 @@ jrx_status jrx_destroy(jrx_handle *h)
         if (h->tscratch[q]) (void)hipFree(h->tscratch[q]);
     for (int q = 0; q < 3; q++)
         if (h->tscratch2[q]) (void)hipFree(h->tscratch2[q]);
+    for (int q = 0; q < 6; q++)
+        if (h->scratch2d[q]) (void)hipFree(h->scratch2d[q]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->halo_stream) (void)hipStreamDestroy(h->halo_stream);
     delete h;

@@ -26,6 +26,8 @@ struct jrx_handle {
     int scratch_dims[3] = {0, 0, 0};
     double *tscratch[4] = {};            // ping-pong set of the fused 3D heat-diffusion kernel (T, qTx, qTy, qTz)
     int tscratch_dims[3] = {0, 0, 0};
+    double *scratch2d[6] = {};           // ping-pong set of the fused 2D Stokes kernel (P, τxx, τyy, τxy, Vx, Vy)
+    int scratch2d_dims[2] = {0, 0};
     double *tscratch2[3] = {};           // the same for the 2D loop (T, qTx, qTy)
     int tscratch2_dims[2] = {0, 0};
     bool thermal_fused = true;           // 3D heat diffusion: one fused launch per unobserved iteration (option "thermal_fused")

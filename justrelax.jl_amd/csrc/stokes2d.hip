@@ -120,6 +120,108 @@ __global__ __launch_bounds__(256) void k_velocity2d(const Args2 a)
     if (j >= a.ny) return;
     velocity2d_cell<RES_ONLY, BCF>(a, i, j);
 }
+
+// ------------------------------------------------------------------------------------------------
+// One PT iteration in one launch for iterations nobody observes (the 2D loop is launch-bound): compute_V! of iteration m, flow_bcs! by
+// rule, and compute_∇V! / compute_P! / compute_strain_rate! / compute_τ! of iteration m+1, reading the state (P, τ, V) from one set and
+// writing it to the other.  A thread owns node (i, j) of the (nx+1) x (ny+1) node grid: it computes the new velocities of its cell and
+// of the cell below (the row below recomputes them for itself), takes those of the column to its left from the neighbouring lane
+// (waves overlap by one lane: lane 0 only feeds lane 1), derives boundary and ghost entries from the flow_bcs! rules, and then does
+// the stress update of its cell centre and its vertex exactly as k_stress2d does.  Same arithmetic, in the same order.
+// ------------------------------------------------------------------------------------------------
+struct Out6_2d { double *P, *txx, *tyy, *txy, *Vx, *Vy; };
+struct BC2 { int tL, tR, tB, tT; };      // 0 none (memory holds the prescribed value), 1 free slip, 2 no slip; B: j = 1, T: j = end
+__global__ __launch_bounds__(256) void k_fused2d(const Args2 a, const Out6_2d o, const BC2 bc, const int nwx)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int wg = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int j = wg / nwx, i = (wg - j * nwx) * 63 + lane - 1;
+    if (j > ny) return;
+    const double _dx = a._dx, _dy = a._dy, edt = a.eta_dtau, dt = a.dt, th = a.theta_dtau;
+    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ P = a.f.P, *__restrict__ et = a.etatau;
+    const double *__restrict__ txy = a.f.txy, *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
+#define TXY(i_, j_) txy[(i_) + (i64)(nx + 1) * (j_)]
+    // compute_V! of cell (ci, cj): the new Vx[ci+1, cj+1] and Vy[ci+1, cj+1]; nodes on the right / top boundary planes keep their value
+    auto Bcell = [&](const int ci, const int cj, double &vx_, double &vy_) {
+        const i64 c = CC(ci, cj);
+        const double Pc = P[c], ec = et[c];
+        if (ci < nx - 1) {
+            const double dP = (-Pc + P[c + 1]) * _dx, dT = (-a.f.txx[c] + a.f.txx[c + 1]) * _dx;
+            const double dS = (-TXY(ci + 1, cj) + TXY(ci + 1, cj + 1)) * _dy, av = (a.f.fx[c] + a.f.fx[c + 1]) * 0.5;
+            vx_ = VX(ci + 1, cj + 1) + (-dP + dT + dS - av) * edt / ((ec + et[c + 1]) * 0.5);
+        } else vx_ = bc.tR == 2 ? 0.0 : VX(nx, cj + 1);
+        if (cj < ny - 1) {
+            const double dP = (-Pc + P[c + nx]) * _dy, dT = (-a.f.tyy[c] + a.f.tyy[c + nx]) * _dy;
+            const double dS = (-TXY(ci, cj + 1) + TXY(ci + 1, cj + 1)) * _dx, av = (a.f.fy[c] + a.f.fy[c + nx]) * 0.5;
+            vy_ = VY(ci + 1, cj + 1) + (-dP + dT + dS - av) * edt / ((ec + et[c + nx]) * 0.5);
+        } else vy_ = bc.tT == 2 ? 0.0 : VY(ci + 1, ny);
+    };
+    auto rule = [](const int t, const double v, const double mem) { return t == 1 ? v : (t == 2 ? -v : mem); };
+    const bool col = i >= 0 && i < nx;                 // this lane has a cell column
+    double vxn = 0.0, vyn = 0.0, vxb = 0.0, vyb = 0.0;   // new Vx[i+1, j+1], Vy[i+1, j+1] (own row) and Vx[i+1, j], Vy[i+1, j] (row below)
+    if (col) {
+        if (j < ny) Bcell(i, j, vxn, vyn);
+        if (j >= 1) Bcell(i, j - 1, vxb, vyb);
+        else {
+            vxb = rule(bc.tB, vxn, VX(i + 1, 0));                 // ghost row below the bottom face
+            vyb = bc.tB == 2 ? 0.0 : VY(i + 1, 0);                // Vy on the bottom face
+        }
+        if (j == ny) vxn = rule(bc.tT, vxb, VX(i + 1, ny + 1));   // ghost row above the top face
+    }
+    const double Lvxn = __shfl_up(vxn, 1, 64), Lvxb = __shfl_up(vxb, 1, 64), Lvyb = __shfl_up(vyb, 1, 64);
+    if (lane == 0 || i < 0 || i > nx) return;          // feeder lane / beyond the row
+    // new velocities on the left of the node: Vx[i, j+1], Vx[i, j], Vy[i, j]
+    double X1, X0, Y0;
+    if (i >= 1) { X1 = Lvxn; X0 = Lvxb; Y0 = Lvyb; }
+    else {
+        // left boundary plane of Vx (ghost rows by the bottom / top rule) and ghost column of Vy
+        auto VxL = [&](const int jr) -> double {
+            const double lo = bc.tL == 2 ? 0.0 : VX(0, 1), hi = bc.tL == 2 ? 0.0 : VX(0, ny);
+            if (jr == 0) return rule(bc.tB, lo, VX(0, 0));
+            if (jr == ny + 1) return rule(bc.tT, hi, VX(0, ny + 1));
+            return bc.tL == 2 ? 0.0 : VX(0, jr);
+        };
+        X1 = VxL(j + 1); X0 = VxL(j);
+        Y0 = rule(bc.tL, vyb, VY(0, j));
+    }
+    const double Yr = i < nx ? vyb : rule(bc.tR, Lvyb, VY(nx + 1, j));        // Vy[i+1, j]; beyond the right face: ghost column
+    if (i < nx && j < ny) {
+        const i64 c = CC(i, j);
+        const double dxi = (-X1 + vxn) * _dx;
+        const double dyi = (-vyb + vyn) * _dy;
+        const double divV = dxi + dyi;
+        const double _Gdt = 1.0 / (G[c] * dt);
+        {   // compute_P! with ητ (Stokes2D.jl:231-233)
+            const double _Kdt = 1.0 / (a.f.K[c] * dt);
+            const double _dt = 1.0 / dt;
+            const double Pc = P[c], P0 = a.f.P0[c];
+            const double rhs = -divV + (a.f.Q[c] * _dt);
+            const double psi = 1.0 / (1.0 / et[c] + _Gdt) * a.r / th;
+            o.P[c] = (fma(P0, _Kdt, rhs) * psi + Pc) / (1.0 + _Kdt * psi);
+        }
+        const double d3 = divV * (1.0 / 3.0);
+        const double exx = dxi - d3, eyy = dyi - d3;
+        const double e = eta[c];
+        const double dtr = dev_dtau_r(th, e, _Gdt);
+        double tv;
+        tv = a.f.txx[c]; o.txx[c] = tv + dev_stress_inc(tv, a.f.toxx[c], e, exx, _Gdt, dtr);
+        tv = a.f.tyy[c]; o.tyy[c] = tv + dev_stress_inc(tv, a.f.toyy[c], e, eyy, _Gdt, dtr);
+        if (i < nx - 1) o.Vx[(i + 1) + (i64)(nx + 1) * (j + 1)] = vxn;
+        if (j < ny - 1) o.Vy[(i + 1) + (i64)(nx + 2) * (j + 1)] = vyn;
+    }
+    {   // vertex (i, j)
+        const int im = max(i - 1, 0), ip = min(i, nx - 1), jm = max(j - 1, 0), jp = min(j, ny - 1);
+        const double exy = 0.5 * (_dy * (X1 - X0) + _dx * (Yr - Y0));
+        const double e = 0.25 * (eta[CC(im, jm)] + eta[CC(ip, jm)] + eta[CC(im, jp)] + eta[CC(ip, jp)]);
+        const double g = 0.25 * (G[CC(im, jm)] + G[CC(ip, jm)] + G[CC(im, jp)] + G[CC(ip, jp)]);
+        const double _Gdt = 1.0 / (g * dt);
+        const double dtr = dev_dtau_r(th, e, _Gdt);
+        const i64 v = i + (i64)(nx + 1) * j;
+        const double tv = txy[v];
+        o.txy[v] = tv + dev_stress_inc(tv, a.f.toxy[v], e, exy, _Gdt, dtr);
+    }
+#undef TXY
+}
 #undef VX
 #undef VY
 #undef CC
@@ -190,15 +292,26 @@ jrx_status launch_sumsq2(jrx_handle *h, hipStream_t s, const jrx_stokes2d_fields
 // fuse_bc: flow_bcs! has already been applied in full once in this solve, nothing observes U in this iteration and no face is
 // periodic, so the velocity kernel refreshes the ghosts itself
 jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const double *etatau, const jrx_stokes2d_params *p, bool diag,
+                              bool fuse_bc, bool skip_stress, bool *bcs_full_done);
+jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const double *etatau, const jrx_stokes2d_params *p, bool diag,
                               bool fuse_bc = false)
+{
+    return enqueue_iteration2(h, f, etatau, p, diag, fuse_bc, false, nullptr);
+}
+// skip_stress: the stress sweep of this iteration has already been applied (by a fused launch); bcs_full_done (optional): set when
+// flow_bcs! has been launched in full
+jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const double *etatau, const jrx_stokes2d_params *p, bool diag,
+                              bool fuse_bc, bool skip_stress, bool *bcs_full_done)
 {
     const int nx = (int)p->nx, ny = (int)p->ny;
     Args2 a = make_args2(f, etatau, p);
     hipStream_t s = h->stream;
     const unsigned gA = (unsigned)(((i64)(nx + 1) * (ny + 1) + 255) / 256), gB = (unsigned)(((i64)nx * ny + 255) / 256);
-    if (diag) hipLaunchKernelGGL(k_stress2d<true>, dim3(gA), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_stress2d<false>, dim3(gA), dim3(256), 0, s, a);
-    JRX_LAUNCH_CHECK(h);
+    if (!skip_stress) {
+        if (diag) hipLaunchKernelGGL(k_stress2d<true>, dim3(gA), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_stress2d<false>, dim3(gA), dim3(256), 0, s, a);
+        JRX_LAUNCH_CHECK(h);
+    }
     if (fuse_bc && !diag && p->periodic == 0 && !jrx_comm_active(h)) {
         hipLaunchKernelGGL((k_velocity2d<false, true>), dim3(gB), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
@@ -212,6 +325,7 @@ jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const
         JRX_LAUNCH_CHECK(h);
     }
     JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+    if (bcs_full_done) *bcs_full_done = true;
     if (jrx_comm_active(h)) {
         double *arrs[2] = {f->Vx, f->Vy};
         const int64_t ext[2][3] = {{nx + 1, ny + 2, 1}, {nx + 2, ny + 1, 1}};
@@ -308,14 +422,72 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     const int rank = jrx_comm_rank(h);
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
     auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
-    Args2 a = make_args2(f, h->etatau, p);
+    auto is_check = [&](int64_t i1) { return (i1 % p->nout == 0) && i1 > 1; };
+    // Fused pipeline (as in 3D): when nothing observes iteration it1 and iteration it1+1 certainly runs unobserved, compute_V! of it1,
+    // flow_bcs! (by rule) and the stress sweep of it1+1 run as one launch that ping-pongs (P, τ, V) between the caller's arrays and a
+    // library-owned set; flow_bcs! itself is applied lazily before anything reads the boundary entries of V from memory.
+    static const bool fused2d_env = [] { const char *e = getenv("JRX_FUSED2D"); return !(e && e[0] == '0'); }();
+    // measured (SolCx, profiles/r01_bench2d.txt): 64^2 +16 %, 128^2 +15 %, 256^2 -3 %, 512^2 and 1024^2 +-1 % -- the kernels stop being
+    // launch-bound around 200^2 nodes and the fused kernel's redundant velocity updates then cost what the saved launch gave
+    const bool fusable = fused2d_env && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 40000)) &&
+                         !jrx_comm_active(h) && p->periodic == 0 && nx >= 2 && ny >= 2;
+    const size_t nvx = (size_t)(nx + 1) * (ny + 2), nvy = (size_t)(nx + 2) * (ny + 1), nvt = (size_t)(nx + 1) * (ny + 1);
+    Out6_2d setU = {f->P, f->txx, f->tyy, f->txy, f->Vx, f->Vy}, setS = setU;
+    if (fusable) {
+        if (!(h->scratch2d[0] && h->scratch2d_dims[0] == nx && h->scratch2d_dims[1] == ny)) {
+            for (int q = 0; q < 6; q++) { if (h->scratch2d[q]) JRX_HIP(h, hipFree(h->scratch2d[q])); h->scratch2d[q] = nullptr; }
+            h->scratch2d_dims[0] = h->scratch2d_dims[1] = 0;
+            const size_t sz[6] = {n, n, n, nvt, nvx, nvy};
+            for (int q = 0; q < 6; q++) JRX_HIP(h, hipMalloc(&h->scratch2d[q], sz[q] * sizeof(double)));
+            h->scratch2d_dims[0] = nx; h->scratch2d_dims[1] = ny;
+        }
+        double **S = h->scratch2d;
+        setS = Out6_2d{S[0], S[1], S[2], S[3], S[4], S[5]};
+        // boundary and ghost entries of V that no fused launch writes
+        JRX_HIP(h, hipMemcpyAsync(setS.Vx, f->Vx, nvx * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(setS.Vy, f->Vy, nvy * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    BC2 bc2;
+    {
+        auto ty = [&](uint32_t bit) { return (p->no_slip & bit) ? 2 : ((p->free_slip & bit) ? 1 : 0); };
+        bc2.tL = ty(JRX_FACE_LEFT); bc2.tR = ty(JRX_FACE_RIGHT); bc2.tB = ty(JRX_FACE_BOT); bc2.tT = ty(JRX_FACE_TOP);
+    }
+    jrx_stokes2d_fields cur = *f;
+    bool cur_is_user = true, stress_done = false, ghosts_stale = false;
+    bool bcs_full_done[2] = {false, false};      // flow_bcs! launched in full on the V of the caller's set / the second set
+    const int nwx = (nx + 1 + 62) / 63;
+    Args2 a = make_args2(&cur, h->etatau, p);
     while (keep_going(iter)) {
         const int64_t it1 = iter + 1;
-        const bool check = (it1 % p->nout == 0) && it1 > 1;
+        const bool check = is_check(it1);
         const bool diag = check || !keep_going(it1);
-        JRX_TRY(enqueue_iteration2(h, f, h->etatau, p, diag, iter >= 1));
+        const bool fuse_next = fusable && !diag && keep_going(it1) && !(is_check(it1 + 1) || !keep_going(it1 + 1));
+        a = make_args2(&cur, h->etatau, p);
+        if (fuse_next) {
+            if (!stress_done) {
+                hipLaunchKernelGGL(k_stress2d<false>, dim3((unsigned)((nvt + 255) / 256)), dim3(256), 0, s, a);
+                JRX_LAUNCH_CHECK(h);
+            }
+            const Out6_2d dst = cur_is_user ? setS : setU;
+            hipLaunchKernelGGL(k_fused2d, dim3((unsigned)((nwx * (ny + 1) + 3) / 4)), dim3(256), 0, s, a, dst, bc2, nwx);
+            JRX_LAUNCH_CHECK(h);
+            cur.P = dst.P; cur.txx = dst.txx; cur.tyy = dst.tyy; cur.txy = dst.txy; cur.Vx = dst.Vx; cur.Vy = dst.Vy;
+            cur_is_user = !cur_is_user;
+            stress_done = true; ghosts_stale = true;
+        } else {
+            if (ghosts_stale && diag) {
+                // U = V dt copies the boundary entries of V as flow_bcs! of the previous iteration left them: apply the pending flow_bcs! now
+                JRX_TRY(launch_bcs2(h, s, cur.Vx, cur.Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+                bcs_full_done[cur_is_user ? 0 : 1] = true;
+            }
+            ghosts_stale = false;
+            bool &full = bcs_full_done[cur_is_user ? 0 : 1];
+            JRX_TRY(enqueue_iteration2(h, &cur, h->etatau, p, diag, full && iter >= 1, stress_done, &full));
+            stress_done = false;
+        }
         iter = it1;
         if (check) {
+            a = make_args2(&cur, h->etatau, p);
             hipLaunchKernelGGL(k_velocity2d<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);   // compute_Res! (Stokes2D.jl:274-276)
             JRX_LAUNCH_CHECK(h);
             JRX_TRY(launch_sumsq2(h, s, f, p));
@@ -343,6 +515,14 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
         }
     }
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
+    if (!cur_is_user) {       // leave the state in the caller's arrays
+        JRX_HIP(h, hipMemcpyAsync(setU.P, setS.P, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(setU.txx, setS.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(setU.tyy, setS.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(setU.txy, setS.txy, nvt * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(setU.Vx, setS.Vx, nvx * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(setU.Vy, setS.Vy, nvy * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     // multi_copy! (Stokes2D.jl:308-309)
     hipLaunchKernelGGL(k_copy6, dim3(256), dim3(256), 0, s, f->toxx, f->txx, (i64)n, f->toyy, f->tyy, (i64)n, f->toxy, f->txy, (i64)(nx + 1) * (ny + 1),
                        (f->txy_c && f->toxy_c) ? f->toxy_c : nullptr, (const double *)f->txy_c, (i64)n, (double *)nullptr, (const double *)nullptr,
