@@ -4,16 +4,31 @@
     python bench.py --gpus N --steps K --warmup W [--n 512]
 
 One "step" = one PT iteration (stress sweep + velocity sweep + boundary conditions [+ halo exchange])
-over one n^3 block per GPU, inputs resident in HBM.  N > 1: weak scaling, one process per GPU
-(launched by torch.distributed.run), IGG-style block decomposition with RCCL halo exchange inside the
-native library; torch.distributed (gloo) only carries the RCCL unique id, the barriers and the max-reduce.
-Prints ONE JSON line on rank 0.
+over one n^3 block per GPU, inputs resident in HBM.  N > 1: weak scaling, one process per GPU, IGG-style
+block decomposition with RCCL halo exchange inside the native library; torch.distributed (gloo) only
+carries the RCCL unique id, the barriers and the max-reduce.  Rank 0 prints ONE JSON line.
+
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself: the parent makes no GPU call (the device count is taken by a short-lived child), starts N child
+processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what
+`mpiexec -n N` does for the reference, test/runtests.jl:73-90), relays rank 0's JSON line and exits with
+the children's return code.  Started by `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` it finds WORLD_SIZE set and runs as one rank.
+
+Besides the headline line (BASELINE.json's metric/config) the same JSON carries, on one GPU:
+  solve_path     jrx_stokes3d_solve on the same 512^3 problem with the reference's cadence
+                 (iterMax = 399, nout = 100: norm checks, un-fused check iterations, host syncs included)
+  other_configs  the other BASELINE configs at their stated sizes (SolVi3D 256^3, SolCx 512^2, shear band
+                 1024^2, thermal diffusion 256^2), each a short fixed-iteration run
+  cpu_baseline   the oracle's six-kernel OpenMP iteration on the host cores at 128^3 and 256^3 (unscaled)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -27,19 +42,105 @@ A_VELOCITY = 17 * 8.0    # velocity sweep: 14 reads + 3 writes
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # L2<->fabric bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
 # correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
-# n = 512: profiles/r01_pmc_xcd_banded_traffic.txt, profiles/r01_pmc_fused_ylds_traffic.txt
-#   k_stress3d_zb<512,1,4,xcd8>: FETCH_SIZE 13048845 KB, WRITE_SIZE 7410032 KB   (algorithmic: 21 + 7 passes of 1.074 GB)
-#   k_fused3d<64,4,8,minw4,lowreg,xg1,shfl,ylds3,nt>: FETCH_SIZE 20010734 KB, WRITE_SIZE 11054315 KB  (needs 25 + 10 passes; fetched 38.2 + written 10.5;
-#   profiles/r01_pmc_fused_final_traffic.txt; the 16-plane / 8-row-band form fetched 34.8 passes and was slower: part of the surplus is
-#   served by the Infinity Cache, which FETCH_SIZE cannot tell from HBM)
+# n = 512 (profiles/*pmc*traffic.txt; the file names are in PMC_SOURCE)
 PMC_TRAFFIC_STRESS_512 = (2 * 13048845.0 + 7410032.0) * 1024.0
 PMC_TRAFFIC_FUSED_512 = (2 * 20010734.0 + 11054315.0) * 1024.0
+PMC_SOURCE = {"stress": "profiles/r01_pmc_xcd_banded_traffic.txt", "fused": "profiles/r01_pmc_fused_final_traffic.txt"}
 
 
+# ------------------------------------------------------------------------------------------------ launching
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=512, help="local cells per dimension per GPU")
+    ap.add_argument("--cpu-n", type=int, nargs="*", default=[128, 256], help="oracle sizes of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU budget per oracle size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip solve_path and other_configs")
+    ap.add_argument("--solve-iters", type=int, default=399, help="iterMax of the solve_path leg (nout = 100)")
+    ap.add_argument("--variant", type=int, default=0, help="jrx_set_option kernel_variant (0 auto, 1 per-node, 2 z-marching sweeps, 3 fused wherever legal): tuning A/B only")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="jrx_set_option(KEY, INT) before the run (tuning A/B)")
+    ap.add_argument("--self-halo", nargs="?", const="xyz", default=None, metavar="DIMS",
+                    help="diagnostic (1 GPU): IGG-periodic grid in DIMS (default xyz = all six faces) whose only neighbour is the rank "
+                         "itself, planes routed through a one-rank RCCL communicator -- times the N > 1 code path (halo pack/send/recv/"
+                         "unpack, shell fix-up) on one device")
+    ap.add_argument("--dims", default="balanced", choices=["balanced", "yz"],
+                    help="process grid for N > 1: balanced = IGG's default MPI_Dims_create factorisation ((2,2,2) for 8 GPUs, SURVEY 8e); "
+                         "yz = (1, a, b) with x, the contiguous direction, never split -- tuning option")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="test hook: the ranks only report their launch environment (no GPU is touched, the device-count check is skipped)")
+    return ap.parse_args(argv)
+
+
+def visible_gpus() -> int:
+    """Number of HIP devices, counted in a short-lived child so that this process never initialises the GPU."""
+    code = "import torch; print(torch.cuda.device_count())"
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """Parent of a `python bench.py --gpus N` call: start the N ranks as child processes, relay rank 0's JSON line."""
+    n = args.gpus
+    if not args.dry_launch:
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write(f"bench.py: {n} GPUs requested, {have} visible\n")
+            return 2
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("MASTER_PORT", str(free_port()))
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    # rank 0's stdout is drained by a thread while all children are polled: a rank that dies takes the others down with it
+    # (they would otherwise wait for it in a collective for ever); only the exact processes started here are ever killed
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and failed is None:
+            failed = time.time()
+        if failed is not None and time.time() - failed > 10.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    rd.join(timeout=10.0)
+    out0 = buf[0] if buf else ""
+    rcs = [p.returncode for p in procs]
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    rc = next((c for c in rcs if c != 0), 0)
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(n_cpu: int, budget_s: float):
     """The oracle (CPU restatement, 6 unfused kernels, OpenMP) timed on this host's cores."""
     sys.path.insert(0, str(ROOT / "oracle"))
-    import numpy as np
     import oracle as orc
     from __graft_entry__ import load_package
     jr = load_package()
@@ -57,30 +158,152 @@ def cpu_baseline(n_cpu: int, budget_s: float):
         el = time.perf_counter() - t0
         if (el > budget_s and it >= 3) or it >= 2000:
             break
-    cells_per_s = it * n_cpu ** 3 / el
     g.finalize_global_grid()
-    return cells_per_s, it, el, orc.num_threads()
+    return it / el, it, el, orc.num_threads()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=512, help="local cells per dimension per GPU")
-    ap.add_argument("--cpu-n", type=int, default=128)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="jrx_set_option kernel_variant (0 auto, 1 per-node, 2 z-marching sweeps, 3 fused wherever legal): tuning A/B only")
-    ap.add_argument("--self-halo", nargs="?", const="xyz", default=None, metavar="DIMS",
-                    help="diagnostic (1 GPU): IGG-periodic grid in DIMS (default xyz = all six faces) whose only neighbour is the rank "
-                         "itself, planes routed through a one-rank RCCL communicator -- times the N > 1 code path (halo pack/send/recv/"
-                         "unpack, shell fix-up) on one device")
-    ap.add_argument("--dims", default="balanced", choices=["balanced", "yz"],
-                    help="process grid for N > 1: balanced = IGG's default MPI_Dims_create factorisation ((2,2,2) for 8 GPUs, SURVEY 8e); "
-                         "yz = (1, a, b) with x, the contiguous direction, never split (x faces are strided planes: their pack/unpack "
-                         "and stress fix-up cost several times a y or z face) -- tuning option")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ extra legs (one GPU)
+def solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, iters, n):
+    """jrx_stokes3d_solve itself with the reference's cadence (SolVi3D.jl:119-120: nout = 100): compute_maxloc!, the norm checks with
+    their Σx² reductions and host syncs, the un-fused observable iterations and the τ -> τ_o copy are all inside the timed call."""
+    import torch
+    pt.ϵ_rel = pt.ϵ_abs = 1e-300       # never converge: exactly iterMax + 1 iterations
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = jr.solve_(st, pt, geo, bcs, ρg, K, G, dt, None, kwargs=dict(iterMax=iters, nout=100, verbose=False), handle=h)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    cells = float(n) ** 3
+    return {"entry": "jrx_stokes3d_solve", "iterMax": iters, "nout": 100, "iterations": int(r.iter), "checks": int(len(r.err_evo1)),
+            "it_per_s": r.iter / el, "ms_per_iteration": el / r.iter * 1e3, "device_loop_s": r.time,
+            "effective_GBps_at_360B_per_cell": A_ALG * cells * r.iter / el / 1e9,
+            "frac_of_peak": A_ALG * cells * r.iter / el / 1e9 / HBM_PEAK_GBS,
+            "norm_Rx_last": float(r.norm_Rx[-1]) if len(r.norm_Rx) else None}
+
+
+def cfg_solvi(jr, h, n, steps, warm):
+    """SolVi3D at n^3 through the same timed batch as the headline (BASELINE configs[2] at n = 256)."""
+    import torch
+    import justrelax_jl_amd.grid as grid
+    from justrelax_jl_amd import stokes
+    from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
+    grid.finalize_global_grid()
+    grid.init_global_grid(n, n, n, rank=0, nprocs=1)
+    st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
+    jr.flow_bcs_(st, bcs, handle=h)
+    ητ = jr.fzeros((n, n, n), st.P.device)
+    jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
+    run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
+    run(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot_ms, sa, sb, sf, sk, _ = run(steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    cells = float(n) ** 3
+    out = {"workload": f"SolVi3D {n}^3", "steps": steps, "it_per_s": steps / el, "ms_per_step": el / steps * 1e3,
+           "frac_whole_iteration": A_ALG * cells * steps / el / 1e9 / HBM_PEAK_GBS}
+    if sk > 0:
+        out["kernel"] = "k_fused3d"
+        out["avg_launch_ms"] = sk
+        out["frac_kernel"] = A_ALG * cells / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS
+    grid.finalize_global_grid()
+    return out
+
+
+def _timed(fn, warm, iters):
+    import torch
+    fn(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = fn(iters)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, r
+
+
+def cfg_solcx(jr, h, n=512, iters=2000):
+    """SolCx 2D visco-elastic (BASELINE configs[1]); floor 30 passes = 240 B/cell-iteration."""
+    from justrelax_jl_amd.miniapps.common import upload_stokes
+    s = jr.miniapps.solcx2d(n, iterMax=iters - 1, nout=10 ** 9)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+    st, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
+    run = lambda k: jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, G, K, s.dt, None, kwargs=dict(iterMax=k - 1, nout=10 ** 9, verbose=False), handle=h)
+    el, r = _timed(run, 50, iters)
+    return {"workload": f"SolCx {n}^2 (2D visco-elastic)", "iterations": int(r.iter), "it_per_s": r.iter / el,
+            "effective_GBps_at_240B_per_cell": 240.0 * n * n * r.iter / el / 1e9}
+
+
+def cfg_shearband(jr, h, n=1024, iters=600):
+    """2D multiphase visco-elasto-plastic shear band (BASELINE configs[4]); as written ~88 passes = 700 B/cell-iteration."""
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s = jr.miniapps.shearband2d(n, iterMax=iters - 1, nout=10 ** 9)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+    st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+    st.V.Vx.copy_(from_numpy(s.arrays["Vx"], dev)); st.V.Vy.copy_(from_numpy(s.arrays["Vy"], dev))
+    st.viscosity.η.copy_(from_numpy(s.arrays["eta"], dev))
+    pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, s.ni)
+    pr.center.copy_(from_numpy(s.arrays["phase_c"], dev)); pr.vertex.copy_(from_numpy(s.arrays["phase_v"], dev))
+    ρg = (jr.fzeros(s.ni, dev), jr.fzeros(s.ni, dev))
+    run = lambda k: jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None,
+                              kwargs=dict(iterMax=k - 1, nout=10 ** 9, iterMin=10 ** 9, verbose=False), handle=h)
+    el, r = _timed(run, 30, iters)
+    return {"workload": f"shear band {n}^2 (2D multiphase VEP)", "iterations": int(r.iter), "it_per_s": r.iter / el,
+            "effective_GBps_at_700B_per_cell_as_written": 700.0 * n * n * r.iter / el / 1e9}
+
+
+def cfg_thermal2d(jr, h, n=256, iters=4000):
+    """2D PT heat diffusion, array-coefficient form (BASELINE configs[0]); 18 passes = 144 B/cell-iteration."""
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy
+    from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s = jr.miniapps.diffusion2d(n, iterMax=iters, nout=10 ** 9)
+    th = jr.ThermalArrays(jr.AMDGPUBackend, s.ni)
+    add_perturbation(s.arrays["T"], s.grid, **s.extra["perturbation"])
+    th.T.copy_(from_numpy(s.arrays["T"], dev)); th.H.copy_(from_numpy(s.arrays["H"], dev))
+    K, ρCp = from_numpy(s.arrays["K"], dev), from_numpy(s.arrays["rhoCp"], dev)
+    pt = jr.PTThermalCoeffs(jr.AMDGPUBackend, K, ρCp, s.dt, s.extra["di"], s.extra["li"], CFL=s.pt["CFL"], ϵ=1e-300)
+
+    def run(k):
+        jr.heatdiffusion_PT_(th, pt, s.flow_bcs, K, ρCp, s.dt, s.grid, kwargs=dict(iterMax=k, nout=10 ** 9, verbose=False), handle=h)
+        return k
+    el, k = _timed(run, 100, iters)
+    return {"workload": f"thermal diffusion {n}^2 (2D PT, array form)", "iterations": k, "it_per_s": k / el,
+            "effective_GBps_at_144B_per_cell": 144.0 * n * n * k / el / 1e9}
+
+
+def other_configs(jr, h):
+    import justrelax_jl_amd.grid as grid
+    out = {}
+    for key, fn in (("solvi3d_256", lambda: cfg_solvi(jr, h, 256, 200, 20)), ("solcx_512", lambda: cfg_solcx(jr, h)),
+                    ("shearband_1024", lambda: cfg_shearband(jr, h)), ("thermal2d_256", lambda: cfg_thermal2d(jr, h))):
+        try:
+            grid.finalize_global_grid()
+            out[key] = fn()
+        except Exception as e:      # a failing side leg must not lose the headline line; it is reported, not hidden
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    grid.finalize_global_grid()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args) -> int:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_launch:
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "world": world, "rank": rank, "local_rank": local_rank,
+                              "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+        else:
+            sys.stderr.write(f"dry-launch rank {rank}/{world} local_rank {local_rank}\n")
+        marker = os.environ.get("JRX_DRY_LAUNCH_DIR")
+        if marker:
+            Path(marker, f"rank{rank}.json").write_text(json.dumps({k: os.environ.get(k) for k in
+                                                                    ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        return 0
 
     # stdout carries exactly one JSON line (rank 0): native libraries that print banners on fd 1 (RCCL's version block
     # at communicator creation) are sent to stderr for the life of the process
@@ -88,6 +311,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    import ctypes as C
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
@@ -96,12 +320,10 @@ def main():
     from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
     import justrelax_jl_amd.grid as grid
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, {torch.cuda.device_count()} visible")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (unique-id broadcast, barrier, max of the timings): gloo over loopback -- all ranks are on one node and the
@@ -114,7 +336,6 @@ def main():
     n = args.n
     self_halo = bool(args.self_halo) and world == 1
     if self_halo:
-        os.environ["JRX_HALO_SELF_RCCL"] = "1"
         grid.init_global_grid(n, n, n, rank=0, nprocs=1, periodx=int("x" in args.self_halo), periody=int("y" in args.self_halo),
                               periodz=int("z" in args.self_halo))
     elif world > 1 and args.dims == "yz":
@@ -124,10 +345,18 @@ def main():
         grid.init_global_grid(n, n, n, rank=rank, nprocs=world)
     h = _lib.default_handle(local_rank)
     if args.variant:
-        import ctypes as C
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(args.variant))
+    for kv in args.option:
+        k, v = kv.split("=")
+        h.call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(int(v)))
+    rccl_ranks = 0
     if world > 1 or self_halo:
-        halo.init_comm(h)
+        halo.init_comm(h, self_rccl=self_halo)
+        cnt = C.c_int32(0)
+        h.call("jrx_comm_count", C.byref(cnt))
+        rccl_ranks = cnt.value
+        if world > 1 and rccl_ranks != world:
+            raise SystemExit(f"bench.py: RCCL communicator has {rccl_ranks} ranks, expected {world}")
     uh = (lambda a: halo.update_halo_(a, ni=(n, n, n), handle=h)) if (world > 1 or self_halo) else None
     st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend, update_halo=uh)
     jr.flow_bcs_(st, bcs, handle=h)
@@ -148,7 +377,7 @@ def main():
         run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, _ = run_timed(stokes, st, pt, geo, bcs, ρg, K, G, ητ, dt, args.steps, h)
+    tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, _ = run(args.steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
@@ -173,6 +402,7 @@ def main():
                                    "eta inclusion 1e-3, G=1, K=Inf, dt=Inf, free-slip, pure shear",
                        "local_grid": [n, n, n], "global_grid": [grid.nx_g(), grid.ny_g(), grid.nz_g()],
                        "decomposition": list(grid.global_grid().dims), "halo": "RCCL send/recv" if world > 1 else (f"diagnostic: periodic self-neighbour in {args.self_halo} through RCCL" if self_halo else "none")},
+            "rccl_ranks": rccl_ranks,
             "global_iterations_per_s": it_per_s,
             "effective_GBps_at_360B_per_cell": eff_gbs,
             "device_ms_per_step": tot_ms / args.steps,
@@ -187,6 +417,7 @@ def main():
                                          "25 reads + 10 writes = 280 B/cell)",
                                "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
                                "traffic": PMC_TRAFFIC_FUSED_512 if n == 512 else None, "traffic_unit": "bytes per launch (PMC, offline)",
+                               "traffic_source": PMC_SOURCE["fused"],
                                "algorithmic_bytes_per_launch": A_ALG * cells, "avg_launch_ms": sk_ms,
                                "launch_group_ms": sf_ms,
                                "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
@@ -196,29 +427,48 @@ def main():
                                "achieved": A_STRESS * cells / (sa_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": A_STRESS * cells / (sa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "traffic": PMC_TRAFFIC_STRESS_512 if n == 512 else None, "traffic_unit": "bytes per launch (PMC, offline)",
+                               "traffic_source": PMC_SOURCE["stress"],
                                "algorithmic_bytes_per_launch": A_STRESS * cells, "avg_launch_ms": sa_ms,
                                "velocity_sweep": {"achieved": A_VELOCITY * cells / (sb_ms * 1e-3) / 1e9, "avg_launch_ms": sb_ms},
                                "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
         else:
             out["roofline"] = {"bound": "hbm", "kernel": "whole PT iteration per GPU (360 B/cell; sweeps overlap the halo exchange)",
                                "achieved": it_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_gbs / HBM_PEAK_GBS, "traffic": None}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not self_halo and not args.no_extras:
+            try:
+                out["solve_path"] = solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, args.solve_iters, n)
+            except Exception as e:
+                out["solve_path"] = {"error": f"{type(e).__name__}: {e}"}
             del st, ρg, K, G, ητ
-            cps, it, secs, thr = cpu_baseline(args.cpu_n, args.cpu_seconds)
-            out["cpu_baseline"] = {"value": cps / cells, "unit": "it/s", "cores": thr, "kind": "port",
-                                   "sample": f"oracle (6 unfused OpenMP kernels) on SolVi3D {args.cpu_n}^3, {it} iterations in "
-                                             f"{secs:.1f} s, scaled by cell count to a {n}^3 block",
-                                   "cell_updates_per_s": cps,
-                                   "effective_GBps_at_600B_as_written": cps * 600.0 / 1e9}
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(jr, h)
+        if world == 1 and not args.no_cpu_baseline:
+            st = ρg = K = G = ητ = None
+            runs = []
+            for nc in args.cpu_n:
+                ips, it, secs, thr = cpu_baseline(nc, args.cpu_seconds)
+                runs.append({"n": nc, "it_per_s": ips, "iterations": it, "seconds": secs, "cell_updates_per_s": ips * nc ** 3,
+                             "effective_GBps_at_600B_as_written": ips * nc ** 3 * 600.0 / 1e9})
+            big = runs[-1]
+            out["cpu_baseline"] = {"value": big["cell_updates_per_s"] / cells, "unit": "it/s", "cores": thr, "kind": "port",
+                                   "sample": f"oracle (6 unfused OpenMP kernels, {thr} threads) on SolVi3D {big['n']}^3: {big['iterations']} iterations in "
+                                             f"{big['seconds']:.1f} s = {big['it_per_s']:.3f} it/s measured at that size; `value` is that rate scaled by "
+                                             f"cell count to a {n}^3 block (a {n}^3 host copy of the fields does not fit the CPU leg's time budget)",
+                                   "measured": runs}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-def run_timed(stokes, st, pt, geo, bcs, ρg, K, G, ητ, dt, steps, h):
-    return stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, steps, handle=h)
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

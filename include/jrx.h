@@ -71,8 +71,16 @@ int32_t jrx_version(void);
  * "fused_overlap" (0/1, default 0): multi-rank fused pipeline with the shell of tiles, BCs and exchange on a second
  *   stream while the interior tiles run (same results).
  * "thermal_fused" (0/1, default 1): jrx_heatdiffusion_PT2d / _PT3d run unobserved iterations as one fused launch with a
- *   library-owned second (T, qT) set; 0 = always compute_flux! and update_T! as two launches (same results). */
+ *   library-owned second (T, qT) set; 0 = always compute_flux! and update_T! as two launches (same results).
+ * "scratch_sets" (0/1, default 1): 0 forbids every library-owned second state set (3D fused pipeline: + 10 arrays, i.e.
+ *   + 10.8 GB at 512^3; 2D fused loop; fused heat diffusion) -- the un-fused kernels then run; same results, less memory.
+ * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
+ * "fused_ylds", "fused2d", "vep3_map", "vep3_xcd", "thermal_cfg", "thermal_xg", "b_width_x/y/z": kernel-form / tile-shape A/B
+ *   switches used by the measurements in profiles/ (results never change); "halo_self_rccl" (0/1): test hook, a rank that is its
+ *   own periodic neighbour routes its planes through ncclSend/ncclRecv on a one-rank communicator.
+ * The library never reads the process environment: every switch is an option of the handle. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
+jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value);
 
 /* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)
  * ImplicitGlobalGrid semantics used by the reference: local arrays of n cells overlap
@@ -100,6 +108,8 @@ int64_t jrx_n_global(int64_t n, int32_t dims, int32_t periodic);   /* nx_g() */
 jrx_status jrx_comm_unique_id(uint8_t id[JRX_UNIQUE_ID_BYTES]);
 jrx_status jrx_comm_init(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], const jrx_cart *cart);
 jrx_status jrx_comm_destroy(jrx_handle *h);
+/* ncclCommCount of the handle's communicator: the number of ranks RCCL itself reports (0 = no RCCL communicator) */
+jrx_status jrx_comm_count(jrx_handle *h, int32_t *count);
 /* update_halo!(A...) for up to 8 arrays, each of extents ext[a][0..2] on a local grid of n cells
  * (call sites: src/stokes/Stokes3D.jl:57,120; src/stokes/Stokes2D.jl:209,268;
  * src/thermal_diffusion/DiffusionPT_solver.jl:110).  Dimension by dimension (x, y, z). */

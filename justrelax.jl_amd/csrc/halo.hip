@@ -25,10 +25,11 @@ struct jrx_comm_state {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     double *sbuf[2] = {nullptr, nullptr}, *rbuf[2] = {nullptr, nullptr};
     size_t cap = 0;     // doubles per buffer
     double *d_red = nullptr;
-    bool self_through_rccl = false;   // JRX_HALO_SELF_RCCL=1: route self-neighbour planes through ncclSend/ncclRecv (test hook)
+    bool self_through_rccl = false;   // option halo_self_rccl = 1: route self-neighbour planes through ncclSend/ncclRecv (test hook)
 };
 
 namespace {
@@ -56,7 +57,8 @@ jrx_status load_rccl(jrx_handle *h, jrx_comm_state *c)
     bool ok = sym(g_rccl, "ncclGetUniqueId", c->GetUniqueId) && sym(g_rccl, "ncclCommInitRank", c->CommInitRank) &&
               sym(g_rccl, "ncclCommDestroy", c->CommDestroy) && sym(g_rccl, "ncclSend", c->Send) && sym(g_rccl, "ncclRecv", c->Recv) &&
               sym(g_rccl, "ncclGroupStart", c->GroupStart) && sym(g_rccl, "ncclGroupEnd", c->GroupEnd) &&
-              sym(g_rccl, "ncclAllReduce", c->AllReduce) && sym(g_rccl, "ncclGetErrorString", c->GetErrorString);
+              sym(g_rccl, "ncclAllReduce", c->AllReduce) && sym(g_rccl, "ncclGetErrorString", c->GetErrorString) &&
+              sym(g_rccl, "ncclCommCount", c->CommCount);
     if (!ok) return jrx_fail(h, JRX_ERR_RCCL, "librccl is missing a required symbol");
     return JRX_OK;
 }
@@ -233,8 +235,7 @@ jrx_status jrx_comm_init(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], c
     jrx_comm_state *c = new jrx_comm_state();
     c->cart = *cart;
     h->comm = c;
-    const char *env = getenv("JRX_HALO_SELF_RCCL");
-    c->self_through_rccl = env && env[0] == '1';
+    c->self_through_rccl = h->halo_self_rccl;      // option "halo_self_rccl" (test hook)
     if (cart->nprocs == 1 && !(c->self_through_rccl && id)) return JRX_OK;      // no other rank; norms are local
     if (!id) return jrx_fail(h, JRX_ERR_ARG, "jrx_comm_init: id is NULL");
     JRX_TRY(load_rccl(h, c));
@@ -243,6 +244,18 @@ jrx_status jrx_comm_init(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], c
     memcpy(&uid, id, JRX_UNIQUE_ID_BYTES);
     JRX_NCCL(h, c, c->CommInitRank(&c->comm, cart->nprocs, uid, cart->rank));
     JRX_HIP(h, hipMalloc(&c->d_red, 8 * sizeof(double)));
+    return JRX_OK;
+}
+
+jrx_status jrx_comm_count(jrx_handle *h, int32_t *count)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!count) return jrx_fail(h, JRX_ERR_ARG, "jrx_comm_count: count is NULL");
+    *count = 0;
+    if (!h->comm || !h->comm->comm) return JRX_OK;
+    int n = 0;
+    JRX_NCCL(h, h->comm, h->comm->CommCount(h->comm->comm, &n));
+    *count = n;
     return JRX_OK;
 }
 

@@ -84,6 +84,45 @@ jrx_status jrx_destroy(jrx_handle *h)
     return JRX_OK;
 }
 
+// ---------------------------------------------------------------- options
+namespace {
+struct OptRef { const char *key; int kind; void *p; };     // kind 0: bool, 1: int
+int find_opt(jrx_handle *h, const char *key, OptRef *out)
+{
+    const OptRef tab[] = {
+        {"kernel_variant", 1, &h->kernel_variant}, {"fused_overlap", 0, &h->fused_overlap}, {"thermal_fused", 0, &h->thermal_fused},
+        {"fused_comm", 0, &h->fused_comm}, {"fused_ylds", 0, &h->fused_ylds},
+        {"b_width_x", 1, &h->b_width_opt[0]}, {"b_width_y", 1, &h->b_width_opt[1]}, {"b_width_z", 1, &h->b_width_opt[2]},
+        {"halo_self_rccl", 0, &h->halo_self_rccl}, {"thermal_cfg", 1, &h->thermal_cfg}, {"thermal_xg", 1, &h->thermal_xg},
+        {"fused2d", 0, &h->fused2d}, {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"scratch_sets", 0, &h->scratch_sets},
+    };
+    for (const OptRef &o : tab)
+        if (strcmp(o.key, key) == 0) { *out = o; return 1; }
+    return 0;
+}
+}   // namespace
+
+jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!key) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: key is NULL");
+    OptRef o;
+    if (!find_opt(h, key, &o)) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: unknown key '%s'", key);
+    if (o.kind == 0) *(bool *)o.p = value != 0;
+    else *(int *)o.p = (int)value;
+    return JRX_OK;
+}
+
+jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!key || !value) return jrx_fail(h, JRX_ERR_ARG, "jrx_get_option: null argument");
+    OptRef o;
+    if (!find_opt(h, key, &o)) return jrx_fail(h, JRX_ERR_ARG, "jrx_get_option: unknown key '%s'", key);
+    *value = o.kind == 0 ? (int64_t)*(bool *)o.p : (int64_t)*(int *)o.p;
+    return JRX_OK;
+}
+
 // ---------------------------------------------------------------- block decomposition (host only)
 int64_t jrx_n_global(int64_t n, int32_t dims, int32_t periodic)
 {

@@ -30,9 +30,18 @@ struct jrx_handle {
     int scratch2d_dims[2] = {0, 0};
     double *tscratch2[3] = {};           // the same for the 2D loop (T, qTx, qTy)
     int tscratch2_dims[2] = {0, 0};
-    bool thermal_fused = true;           // 3D heat diffusion: one fused launch per unobserved iteration (option "thermal_fused")
+    // ---- options (jrx_set_option; nothing in the library reads the process environment)
+    bool thermal_fused = true;           // heat diffusion: one fused launch per unobserved iteration (option "thermal_fused")
     bool fused_overlap = false;          // multi-rank fused pipeline: shell tiles + exchange on the halo stream, interior tiles concurrently
     int kernel_variant = 0;              // 0 auto (fused PT pipeline where it pays), 1 per-node v1 kernels, 2 z-marching sweeps only, 3 fused wherever legal
+    bool fused_comm = true;              // multi-rank runs use the fused pipeline (0: split sweeps + hidden communication)
+    bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)
+    int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)
+    bool halo_self_rccl = false;         // test hook: a rank that is its own periodic neighbour routes the planes through ncclSend/ncclRecv
+    int thermal_cfg = 0, thermal_xg = 8; // fused 3D heat-diffusion tile shape / XCD band override (tuning)
+    bool fused2d = true;                 // 2D visco-elastic loop: one-launch iterations on launch-bound grids
+    bool vep3_map = true, vep3_xcd = true;   // 3D VEP edge kernel thread mapping / XCD slab order (A/B)
+    bool scratch_sets = true;            // the fused pipelines may allocate their library-owned second state set (0: never -- un-fused paths)
     char err[512] = {0};
 };
 

@@ -426,10 +426,9 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     // Fused pipeline (as in 3D): when nothing observes iteration it1 and iteration it1+1 certainly runs unobserved, compute_V! of it1,
     // flow_bcs! (by rule) and the stress sweep of it1+1 run as one launch that ping-pongs (P, τ, V) between the caller's arrays and a
     // library-owned set; flow_bcs! itself is applied lazily before anything reads the boundary entries of V from memory.
-    static const bool fused2d_env = [] { const char *e = getenv("JRX_FUSED2D"); return !(e && e[0] == '0'); }();
     // measured (SolCx, profiles/r01_bench2d.txt): 64^2 +16 %, 128^2 +15 %, 256^2 -3 %, 512^2 and 1024^2 +-1 % -- the kernels stop being
     // launch-bound around 200^2 nodes and the fused kernel's redundant velocity updates then cost what the saved launch gave
-    const bool fusable = fused2d_env && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 40000)) &&
+    const bool fusable = h->fused2d && h->scratch_sets && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 40000)) &&
                          !jrx_comm_active(h) && p->periodic == 0 && nx >= 2 && ny >= 2;
     const size_t nvx = (size_t)(nx + 1) * (ny + 2), nvy = (size_t)(nx + 2) * (ny + 1), nvt = (size_t)(nx + 1) * (ny + 1);
     Out6_2d setU = {f->P, f->txx, f->tyy, f->txy, f->Vx, f->Vy}, setS = setU;

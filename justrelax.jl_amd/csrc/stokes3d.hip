@@ -302,16 +302,6 @@ jrx_status jrx_stokes3d_residual_sumsq(jrx_handle *h, const jrx_stokes3d_fields 
     return JRX_OK;
 }
 
-jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value)
-{
-    if (!h) return JRX_ERR_ARG;
-    if (!key) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: key is NULL");
-    if (strcmp(key, "kernel_variant") == 0) { h->kernel_variant = (int)value; return JRX_OK; }
-    if (strcmp(key, "fused_overlap") == 0) { h->fused_overlap = value != 0; return JRX_OK; }
-    if (strcmp(key, "thermal_fused") == 0) { h->thermal_fused = value != 0; return JRX_OK; }
-    return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: unknown key '%s'", key);
-}
-
 // velocity2displacement!(stokes, dt): U = V * dt ; displacement2velocity!(stokes, dt): V = U * inv(dt)   (types/displacement.jl:2-60)
 jrx_status jrx_velocity2displacement(jrx_handle *h, double *const U[3], const double *const V[3], const int64_t n[3], double dt)
 {
@@ -415,9 +405,9 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     I.setU = out_of(*f);
     I.cur_is_user = true; I.stress_done = false;
     const Lay3 L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
-    // JRX_FUSED_COMM=0 keeps the split sweeps + hidden communication on multi-rank runs (A/B switch; same results)
-    static const bool fused_comm = [] { const char *e = getenv("JRX_FUSED_COMM"); return !(e && e[0] == '0'); }();
-    I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && (fused_comm || !jrx_comm_active(h)) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
+    // option "fused_comm" = 0 keeps the split sweeps + hidden communication on multi-rank runs (A/B switch; same results);
+    // option "scratch_sets" = 0 refuses the library-owned second state set the fused pipeline needs
+    I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && h->scratch_sets && (h->fused_comm || !jrx_comm_active(h)) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable && h->kernel_variant == 0) {
         // auto: the fused kernel covers a row with ceil(nx/62) 64-lane tiles (one halo and one feeder lane each); when that
         // quantisation idles too many lanes the two sweeps are faster (measured, profiles/r01_bench_sizes.txt: nx = 192, 4 tiles, 33 % idle:
@@ -459,9 +449,8 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
     // fetched array passes per launch at 512^3)
     const int ntx = b[1] - b[0], nty = b[3] - b[2], ntz = b[5] - b[4];
     if (ntx <= 0 || nty <= 0 || ntz <= 0) return JRX_OK;
-    // y-neighbour operands through LDS (measured 8.62 -> 7.94 ms at 512^3); JRX_FUSED_YLDS=0 keeps the lane-shuffle-only form for A/B runs
-    static const bool ylds = [] { const char *e = getenv("JRX_FUSED_YLDS"); return !(e && e[0] == '0'); }();
-    if (ylds)
+    // y-neighbour operands through LDS (measured 8.62 -> 7.94 ms at 512^3); option "fused_ylds" = 0 keeps the lane-shuffle-only form for A/B runs
+    if (h->fused_ylds)
         // + non-temporal stores: the written set is not read again before the next iteration (PMC: 35.7 -> 34.2 fetched passes, -0.5 .. -1.6 % time)
         // + register diet to 128 VGPRs without spills (4 waves/SIMD): previous velocity plane re-read from a third LDS slot, previous η/G
         //   plane carried as partial sums, the nine stress-only operands requested after the velocity phase (-1 .. -5 %)
@@ -512,12 +501,11 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             return launch_bcs(h, st, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic);
         };
         bool nb[3][2] = {};
-        // option "fused_overlap" / JRX_FUSED_OVERLAP=1: shell of tiles + BCs + exchange on the halo stream, interior tiles concurrently (see below).  Off by
+        // option "fused_overlap" = 1: shell of tiles + BCs + exchange on the halo stream, interior tiles concurrently (see below).  Off by
         // default: measured on one device (periodic self neighbour through RCCL, profiles/r01_selfhalo_overlap_*.txt) the RCCL
         // send/recv kernel does not finish before the interior kernel drains, so nothing is hidden and the six small shell launches
         // cost more than they save when an x face is involved (10.7 vs 9.1 ms); to be revisited with real neighbours / DMA copies.
-        static const bool overlap_env = [] { const char *e = getenv("JRX_FUSED_OVERLAP"); return e && e[0] == '1'; }();
-        const bool overlap = overlap_env || h->fused_overlap;
+        const bool overlap = h->fused_overlap;
         if (!comm || !overlap) {
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
             JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, all)));
@@ -618,7 +606,9 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
     // stream, then BCs + neighbour exchange there while the interior runs on the compute stream.
     int bx = p->b_width[0] > 0 ? p->b_width[0] : 4, by = p->b_width[1] > 0 ? p->b_width[1] : 4,
         bz = p->b_width[2] > 0 ? p->b_width[2] : 4;
-    if (const char *e = getenv("JRX_BWIDTH")) sscanf(e, "%d,%d,%d", &bx, &by, &bz);       // tuning override (the split does not change results)
+    if (h->b_width_opt[0] > 0) bx = h->b_width_opt[0];       // options "b_width_x/y/z": tuning override (the split does not change results)
+    if (h->b_width_opt[1] > 0) by = h->b_width_opt[1];
+    if (h->b_width_opt[2] > 0) bz = h->b_width_opt[2];
     const int xa = bx < nx / 2 ? bx : nx / 2, ya = by < ny / 2 ? by : ny / 2, za = bz < nz / 2 ? bz : nz / 2;
     hipStream_t hs = h->halo_stream;
     JRX_HIP(h, hipEventRecord(h->ev[0], s));

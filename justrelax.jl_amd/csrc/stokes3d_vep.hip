@@ -497,8 +497,7 @@ EdgeN edge_counts(const jrx_vep3d_params *p)
 jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p, bool commit = true)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    static const bool p4 = [] { const char *e = getenv("JRX_VEP_MAP"); return !(e && e[0] == '0'); }();
-    static const bool xs = [] { const char *e = getenv("JRX_VEP_XCD"); return !(e && e[0] == '0'); }();   // +1-2 % measured
+    const bool p4 = h->vep3_map, xs = h->vep3_xcd;     // options "vep3_map", "vep3_xcd" (XCD slab order: +1-2 % measured)
     if (p4 && xs) hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);

@@ -445,11 +445,10 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
     T3Args a;
     a.t = *t; a.p = *p;
     // Iterations nobody observes run as one fused launch that ping-pongs (T, qT) between the caller's arrays and a library-owned set
-    // (JRX_THERMAL_FUSED=0: always the two kernels); observed ones (check / last) run the two kernels in place on the current set.
+    // (option "thermal_fused" = 0: always the two kernels); observed ones (check / last) run the two kernels in place on the current set.
     bool any_periodic = false;
     for (int q = 0; q < 6; q++) any_periodic |= p->periodic[q] != 0;
-    static const bool fused_env = [] { const char *e = getenv("JRX_THERMAL_FUSED"); return !(e && e[0] == '0'); }();
-    const bool fusable = fused_env && h->thermal_fused && !any_periodic && !jrx_comm_active(h);
+    const bool fusable = h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h);
     const TSet user = {t->T, t->qTx, t->qTy, t->qTz};
     TSet cur = user, oth = user;
     if (fusable) {
@@ -458,11 +457,10 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
         // ghosts that no BC rewrites (prescribed values) must exist in both sets
         JRX_HIP(h, hipMemcpyAsync(oth.T, t->T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
-    // tile = TX cells of R rows, KZ planes deep; JRX_TH_CFG = R*10000 + (TX/64)*100 + KZ overrides (tuning)
-    static const int cfg = [] { const char *e = getenv("JRX_TH_CFG"); return e ? atoi(e) : 0; }();
+    // tile = TX cells of R rows, KZ planes deep; option "thermal_cfg" = R*10000 + (TX/64)*100 + KZ overrides (tuning)
+    const int cfg = h->thermal_cfg;
     const int FR = cfg ? cfg / 10000 : 1, FTX = cfg ? ((cfg / 100) % 100) * 64 : (nx > 128 ? 256 : (nx > 64 ? 128 : 64)), FKZ = cfg ? cfg % 100 : 4;
-    static const int xgenv = [] { const char *e = getenv("JRX_TH_XG"); return e ? atoi(e) : 8; }();
-    const int FXG = xgenv;
+    const int FXG = h->thermal_xg;
     const int ntx = (nx + FTX - 1) / FTX, nty = (ny + FR - 1) / FR, ntz = (nz + FKZ - 1) / FKZ;
     while (err > p->eps && iter < p->iterMax) {
         // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one

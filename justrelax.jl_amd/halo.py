@@ -30,14 +30,15 @@ def make_cart(gg=None) -> _lib.Cart:
     return cart
 
 
-def init_comm(handle=None, group=None):
-    """Create the RCCL communicator of `handle` for the ranks of the torch.distributed group."""
+def init_comm(handle=None, group=None, self_rccl=False):
+    """Create the RCCL communicator of `handle` for the ranks of the torch.distributed group.
+    `self_rccl` (test hook, one rank): a periodic dimension held by the rank alone is exchanged through ncclSend/ncclRecv on a
+    one-rank communicator instead of the local copy."""
     import torch.distributed as dist
     h = handle or _lib.default_handle()
     gg = global_grid()
     cart = make_cart(gg)
-    import os
-    self_rccl = os.environ.get("JRX_HALO_SELF_RCCL", "") == "1"     # test hook: 1-rank communicator, self send/recv
+    h.call("jrx_set_option", C.c_char_p(b"halo_self_rccl"), C.c_int64(int(bool(self_rccl))))
     if gg.nprocs == 1 and not self_rccl:
         # a periodic dimension held by one rank is exchanged by a local copy inside the library
         h.call("jrx_comm_init", None, C.byref(cart))

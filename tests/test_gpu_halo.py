@@ -2,7 +2,7 @@
 
 A 1-GPU box has no neighbour rank, so the exchange is exercised through periodic dimensions held by the rank
 itself (IGG copies locally in that case): once through the library's local-copy path and once, with the test hook
-JRX_HALO_SELF_RCCL=1, through a one-rank RCCL communicator -- the same pack kernel -> grouped ncclSend/ncclRecv ->
+option halo_self_rccl = 1, through a one-rank RCCL communicator -- the same pack kernel -> grouped ncclSend/ncclRecv ->
 unpack kernel sequence that carries the planes between GPUs (src/stokes/Stokes3D.jl:57,120 call sites).
 The expectation is computed in numpy from jrx_halo_planes (x, then y, then z).  Bit-exact.
 """
@@ -47,21 +47,14 @@ def test_periodic_self_exchange(jr, through_rccl, periods):
     shapes = [(n[0] + 1, n[1] + 2, n[2] + 2), (n[0] + 2, n[1] + 1, n[2] + 2), (n[0] + 2, n[1] + 2, n[2] + 1), n]
     host = [np.asfortranarray(rng.standard_normal(s)) for s in shapes]
     g.init_global_grid(*n, periodx=periods[0], periody=periods[1], periodz=periods[2], rank=0, nprocs=1)
-    old = os.environ.get("JRX_HALO_SELF_RCCL")
     h = _lib.Handle(torch.cuda.current_device())
     try:
-        if through_rccl:
-            os.environ["JRX_HALO_SELF_RCCL"] = "1"
-        halo.init_comm(h)
+        halo.init_comm(h, self_rccl=through_rccl)
         dev = [from_numpy(a, torch.device('cuda', torch.cuda.current_device())) for a in host]
         halo.update_halo_(*dev, ni=n, handle=h)
         torch.cuda.synchronize()
         got = [to_numpy(d) for d in dev]
     finally:
-        if old is None:
-            os.environ.pop("JRX_HALO_SELF_RCCL", None)
-        else:
-            os.environ["JRX_HALO_SELF_RCCL"] = old
         h.close()
         g.finalize_global_grid()
     exp = _expected(host, n, periods, L)
@@ -97,12 +90,9 @@ def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracl
     g.init_global_grid(*n, periodx=periods[0], periody=periods[1], periodz=periods[2], rank=0, nprocs=1)
     ng = (g.nx_g(), g.ny_g(), g.nz_g())
     assert ng == tuple(n[d] - 2 * periods[d] for d in range(3))
-    old = os.environ.get("JRX_HALO_SELF_RCCL")
     h = _lib.default_handle()
     try:
-        if through_rccl:
-            os.environ["JRX_HALO_SELF_RCCL"] = "1"
-        halo.init_comm(h)
+        halo.init_comm(h, self_rccl=through_rccl)
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant % 10))
         h.call("jrx_set_option", C.c_char_p(b"fused_overlap"), C.c_int64(variant // 10))
         stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
@@ -111,10 +101,6 @@ def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracl
     finally:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
         h.call("jrx_set_option", C.c_char_p(b"fused_overlap"), C.c_int64(0))
-        if old is None:
-            os.environ.pop("JRX_HALO_SELF_RCCL", None)
-        else:
-            os.environ["JRX_HALO_SELF_RCCL"] = old
         g.finalize_global_grid()
         g.init_global_grid(*n, rank=0, nprocs=1)
         halo.init_comm(h)          # back to a plain single-rank handle for the other tests
