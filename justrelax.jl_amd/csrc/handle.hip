@@ -86,7 +86,7 @@ jrx_status jrx_destroy(jrx_handle *h)
 
 // ---------------------------------------------------------------- options
 namespace {
-struct OptRef { const char *key; int kind; void *p; };     // kind 0: bool, 1: int
+struct OptRef { const char *key; int kind; void *p; };     // kind 0: bool, 1: int, 2: read-only int64 counter
 int find_opt(jrx_handle *h, const char *key, OptRef *out)
 {
     const OptRef tab[] = {
@@ -95,6 +95,8 @@ int find_opt(jrx_handle *h, const char *key, OptRef *out)
         {"b_width_x", 1, &h->b_width_opt[0]}, {"b_width_y", 1, &h->b_width_opt[1]}, {"b_width_z", 1, &h->b_width_opt[2]},
         {"halo_self_rccl", 0, &h->halo_self_rccl}, {"thermal_cfg", 1, &h->thermal_cfg}, {"thermal_xg", 1, &h->thermal_xg},
         {"fused2d", 0, &h->fused2d}, {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"scratch_sets", 0, &h->scratch_sets},
+        {"stat_fused3d", 2, &h->stat_fused3d}, {"stat_fused2d", 2, &h->stat_fused2d}, {"stat_thermal_fused", 2, &h->stat_thermal_fused},
+        {"stat_vep3_fused", 2, &h->stat_vep3_fused},
     };
     for (const OptRef &o : tab)
         if (strcmp(o.key, key) == 0) { *out = o; return 1; }
@@ -108,6 +110,7 @@ jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value)
     if (!key) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: key is NULL");
     OptRef o;
     if (!find_opt(h, key, &o)) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: unknown key '%s'", key);
+    if (o.kind == 2) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: '%s' is a read-only counter", key);
     if (o.kind == 0) *(bool *)o.p = value != 0;
     else *(int *)o.p = (int)value;
     return JRX_OK;
@@ -119,7 +122,7 @@ jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value)
     if (!key || !value) return jrx_fail(h, JRX_ERR_ARG, "jrx_get_option: null argument");
     OptRef o;
     if (!find_opt(h, key, &o)) return jrx_fail(h, JRX_ERR_ARG, "jrx_get_option: unknown key '%s'", key);
-    *value = o.kind == 0 ? (int64_t)*(bool *)o.p : (int64_t)*(int *)o.p;
+    *value = o.kind == 0 ? (int64_t)*(bool *)o.p : (o.kind == 1 ? (int64_t)*(int *)o.p : *(int64_t *)o.p);
     return JRX_OK;
 }
 

@@ -42,6 +42,9 @@ struct jrx_handle {
     bool fused2d = true;                 // 2D visco-elastic loop: one-launch iterations on launch-bound grids
     bool vep3_map = true, vep3_xcd = true;   // 3D VEP edge kernel thread mapping / XCD slab order (A/B)
     bool scratch_sets = true;            // the fused pipelines may allocate their library-owned second state set (0: never -- un-fused paths)
+    // ---- read-only counters (jrx_get_option "stat_*"): launches of the fused kernels since jrx_create, so that tests and the bench can
+    //      prove which kernel path ran
+    int64_t stat_fused3d = 0, stat_fused2d = 0, stat_thermal_fused = 0, stat_vep3_fused = 0;
     char err[512] = {0};
 };
 

@@ -469,6 +469,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
             }
             const Out6_2d dst = cur_is_user ? setS : setU;
             hipLaunchKernelGGL(k_fused2d, dim3((unsigned)((nwx * (ny + 1) + 3) / 4)), dim3(256), 0, s, a, dst, bc2, nwx);
+            h->stat_fused2d++;
             JRX_LAUNCH_CHECK(h);
             cur.P = dst.P; cur.txx = dst.txx; cur.tyy = dst.tyy; cur.txy = dst.txy; cur.Vx = dst.Vx; cur.Vy = dst.Vy;
             cur_is_user = !cur_is_user;

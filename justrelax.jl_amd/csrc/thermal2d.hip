@@ -362,7 +362,7 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
     a.t = *t; a.p = *p;
     // iterations nobody observes: one fused launch, ping-pong between the caller's (T, qT) and a library-owned set (option thermal_fused)
     const bool any_periodic = p->periodic[0] | p->periodic[1] | p->periodic[2] | p->periodic[3];
-    const bool fusable = h->thermal_fused && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
+    const bool fusable = h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
     const TSet2 user = {t->T, t->qTx, t->qTy};
     TSet2 cur = user, oth = user;
     if (fusable) {
@@ -385,6 +385,7 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
             if (FTX == 256) hipLaunchKernelGGL(k_thermal2d_fused<256>, dim3((unsigned)(ntx * ny)), dim3(256), 0, s, a, oth, ntx);
             else if (FTX == 128) hipLaunchKernelGGL(k_thermal2d_fused<128>, dim3((unsigned)(ntx * ny)), dim3(128), 0, s, a, oth, ntx);
             else hipLaunchKernelGGL(k_thermal2d_fused<64>, dim3((unsigned)(ntx * ny)), dim3(64), 0, s, a, oth, ntx);
+            h->stat_thermal_fused++;
             JRX_LAUNCH_CHECK(h);
             const TSet2 tmp = cur; cur = oth; oth = tmp;
         } else {

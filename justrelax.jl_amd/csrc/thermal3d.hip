@@ -470,7 +470,7 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
 #define THL(TX_, KZ_, R_, XG_)                                                                                                      \
     if (FTX == TX_ && FKZ == KZ_ && FR == R_ && FXG == XG_) {                                                                       \
         hipLaunchKernelGGL((k_thermal3d_fused<TX_, KZ_, XG_, R_>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX_), 0, s, a, oth, ntx, nty); \
-        launched = true;                                                                                                           \
+        launched = true; h->stat_thermal_fused++;                                                                                                         \
     }
             bool launched = false;
             // measured at 256^3 (profiles/r01_thermal3d_fused_sweep.txt): one row per thread 2289 it/s, two rows 1526, four rows 1301

@@ -58,6 +58,19 @@ def _build(jr, n, seed=1234):
     return st, ρg, K, G, pt, grid, bcs, ητ
 
 
+def _build_solvi(jr, n):
+    """SolVi3D (the bench workload, SolVi3D.jl:45-129) built in device memory; dt = Inf as in the script"""
+    import justrelax_jl_amd.grid as g
+    from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
+    g.finalize_global_grid()
+    g.init_global_grid(n, n, n, rank=0, nprocs=1)
+    st, ρg, K, G, pt, grid, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
+    jr.flow_bcs_(st, bcs)
+    ητ = jr.fzeros((n, n, n), st.P.device)
+    jr.compute_maxloc_(ητ, st.viscosity.η)
+    return st, ρg, K, G, pt, grid, bcs, ητ
+
+
 STATE = ("P", "τ.xx", "τ.yy", "τ.zz", "τ.yz", "τ.xz", "τ.xy", "V.Vx", "V.Vy", "V.Vz")
 
 
@@ -84,12 +97,16 @@ def _observable(name, t):
     return out
 
 
-@pytest.mark.parametrize("n", [256, 512])
-def test_full_size_kernel_paths_agree_and_iteration_is_homogeneous(jr, n):
+@pytest.mark.parametrize("n,kind", [(256, "random"), (512, "random"), (256, "solvi"), (512, "solvi")])
+def test_full_size_kernel_paths_agree_and_iteration_is_homogeneous(jr, n, kind):
     import torch
     from justrelax_jl_amd import _lib, stokes
-    st, ρg, K, G, pt, grid, bcs, ητ = _build(jr, n)
-    dt, iters = 0.25, 4
+    if kind == "solvi":
+        st, ρg, K, G, pt, grid, bcs, ητ = _build_solvi(jr, n)
+        dt, iters = float("inf"), 6
+    else:
+        st, ρg, K, G, pt, grid, bcs, ητ = _build(jr, n)
+        dt, iters = 0.25, 4
     h = _lib.default_handle()
     init = {k: _get(st, k).clone() for k in STATE}
 
