@@ -197,7 +197,7 @@ def cfg_solvi(jr, h, n, steps, warm):
     run(warm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tot_ms, sa, sb, sf, sk, _ = run(steps)
+    tot_ms, sa, sb, sf, sk, kcells = run(steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     cells = float(n) ** 3
@@ -206,7 +206,8 @@ def cfg_solvi(jr, h, n, steps, warm):
     if sk > 0:
         out["kernel"] = "k_fused3d"
         out["avg_launch_ms"] = sk
-        out["frac_kernel"] = A_ALG * cells / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["kernel_cells_per_launch"] = kcells
+        out["frac_kernel"] = A_ALG * kcells / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS
     grid.finalize_global_grid()
     return out
 
@@ -377,14 +378,14 @@ def run_rank(args) -> int:
         run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, _ = run(args.steps)
+    tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = run(args.steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
     if world > 1:
-        t = torch.tensor([el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms], dtype=torch.float64)
+        t = torch.tensor([el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms = t.tolist()
+        el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = t.tolist()
 
     if rank == 0:
         cells = float(n) ** 3
@@ -410,15 +411,21 @@ def run_rank(args) -> int:
         }
         it_gbs = A_ALG * cells * (args.steps / (tot_ms * 1e-3)) / 1e9
         if fused:
-            g = A_ALG * cells / (sk_ms * 1e-3) / 1e9
+            kcells = kcells or cells
+            g = A_ALG * kcells / (sk_ms * 1e-3) / 1e9
+            whole = kcells == cells
             out["roofline"] = {"bound": "hbm",
-                               "kernel": "k_fused3d: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong "
+                               "kernel": "k_fused3d<...,TAG=0>: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong "
                                          "state); algorithmic 360 B/cell per launch (2-sweep floor of SURVEY 8d; the kernel itself needs "
-                                         "25 reads + 10 writes = 280 B/cell)",
+                                         "25 reads + 10 writes = 280 B/cell)" + ("" if whole else
+                                         f"; this launch covers the {kcells:.0f} cells of the tiles that touch no high face ({kcells / cells:.4f} of the block), "
+                                         "the high-face tiles (k_fused3d<...,TAG=1>) and the boundary stress layers run beside it on a second stream"),
                                "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
-                               "traffic": PMC_TRAFFIC_FUSED_512 if n == 512 else None, "traffic_unit": "bytes per launch (PMC, offline)",
+                               "traffic": (PMC_TRAFFIC_FUSED_512 * kcells / cells) if n == 512 else None,
+                               "traffic_unit": "bytes per launch (PMC, offline, whole-block launch scaled by the cell share of this launch)",
                                "traffic_source": PMC_SOURCE["fused"],
-                               "algorithmic_bytes_per_launch": A_ALG * cells, "avg_launch_ms": sk_ms,
+                               "cells_per_launch": kcells,
+                               "algorithmic_bytes_per_launch": A_ALG * kcells, "avg_launch_ms": sk_ms,
                                "launch_group_ms": sf_ms,
                                "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
         elif split:

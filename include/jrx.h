@@ -432,7 +432,9 @@ jrx_status jrx_thermal3d_check_res(jrx_handle *h, const jrx_thermal3d_fields *t,
  * measured with hipEvents on the handle's stream inside that batch:
  *   times_ms[0] whole batch; [1] mean stand-alone stress sweep; [2] mean stand-alone velocity sweep;
  *   [3] mean fused launch group (k_fused3d = velocity sweep m + BCs + stress sweep m+1, then the ghost-plane and
- *   boundary-plane launches), 0 when nothing was fused; [4] mean k_fused3d launch alone; [5] reserved (0). */
+ *   boundary-plane launches), 0 when nothing was fused; [4] mean k_fused3d launch alone (without neighbours: the launch over the
+ *   interior tiles, while the high-face tiles and the boundary layers run beside it on the halo stream); [5] the number of cells
+ *   whose stresses the launch timed in [4] updates (its units; 0 when nothing was fused). */
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
                                       const jrx_stokes3d_params *p, int64_t iters, double times_ms[6]);
 

@@ -443,14 +443,16 @@ static void fused_tiles(const Lay3 &L, int nt[3])
 
 // launch the fused kernel over the box of tiles [b[0], b[1]) x [b[2], b[3]) x [b[4], b[5])
 template <int TX, int TY, int KZ>
-static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6])
+static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false)
 {
     // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
     // fetched array passes per launch at 512^3)
     const int ntx = b[1] - b[0], nty = b[3] - b[2], ntz = b[5] - b[4];
     if (ntx <= 0 || nty <= 0 || ntz <= 0) return JRX_OK;
     // y-neighbour operands through LDS (measured 8.62 -> 7.94 ms at 512^3); option "fused_ylds" = 0 keeps the lane-shuffle-only form for A/B runs
-    if (h->fused_ylds)
+    if (h->fused_ylds && hiface)
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+    else if (h->fused_ylds)
         // + non-temporal stores: the written set is not read again before the next iteration (PMC: 35.7 -> 34.2 fetched passes, -0.5 .. -1.6 % time)
         // + register diet to 128 VGPRs without spills (4 waves/SIMD): previous velocity plane re-read from a third LDS slot, previous η/G
         //   plane carried as partial sums, the nine stress-only operands requested after the velocity phase (-1 .. -5 %)
@@ -467,7 +469,9 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
 // tev (optional): events recorded around the sweeps: [0] start, [1] after the stress sweep (if one was launched),
 // [2] after the velocity sweep or after the fused launch group (k_fused3d + BCs + boundary planes),
 // [3] (fused only) directly after k_fused3d, so that [1] -> [3] is that kernel alone
-static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *tev, int *was_fused)
+static inline int imin(int a, int b) { return a < b ? a : b; }
+// ncells_timed (optional): the number of cells whose stresses the launch timed by tev[1] -> tev[3] updates
+static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *tev, int *was_fused, double *ncells_timed = nullptr)
 {
     jrx_handle *h = I.h;
     const jrx_stokes3d_params *p = I.p;
@@ -475,6 +479,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
     hipStream_t s = h->stream;
     SweepArgs a = make_args(&I.cur, I.etatau, p);
     if (was_fused) *was_fused = 0;
+    if (ncells_timed) *ncells_timed = (double)nx * ny * nz;
     if (tev) JRX_HIP(h, hipEventRecord(tev[0], s));
     if (!I.stress_done) JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
     I.stress_done = false;
@@ -507,7 +512,32 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         // send/recv kernel does not finish before the interior kernel drains, so nothing is hidden and the six small shell launches
         // cost more than they save when an x face is involved (10.7 vs 9.1 ms); to be revisited with real neighbours / DMA copies.
         const bool overlap = h->fused_overlap;
-        if (!comm || !overlap) {
+        const bool split = !comm && h->fused_split && nt[0] > 1 && nt[1] > 1 && nt[2] > 1;
+        if (split) {
+            // Without neighbours the only work behind the fused kernel is the stress update of the high-face node layers (i = nx, j = ny,
+            // k = nz): thin, strided (the x face touches one cache line per node and array) and latency-bound -- 0.11 ms at 512^3, 7 % of
+            // an iteration at 256^3.  Only the tiles that touch a high face read those nodes in the next iteration, so the iteration is
+            // forked: the interior tiles run on the compute stream; the high-face tiles (three disjoint boxes) and, behind them, the
+            // boundary layers run on the (high-priority) halo stream; both join before the next iteration.  No tile reads what another
+            // tile of the same iteration writes (ping-pong), the boundary layers read new velocities that only high-face tiles produce,
+            // and the old stresses they read are never written by a tile: results are those of the single launch, bit for bit.
+            // Measured (profiles/r02_ab_fused_split.txt, same box, alternating): 512^3 119.5 / 112.5 it/s forked vs 118.4 / 121.7 single launch,
+            // 256^3 822 / 819 vs 847 / 862 -- the interior launch alone takes as long as the launch over all tiles (the high-face column of
+            // tiles sweeps every plane of every array beside it and breaks the DRAM page locality of the sweep): option "fused_split", off.
+            bs = h->halo_stream;
+            JRX_HIP(h, hipEventRecord(h->ev[0], s));
+            JRX_HIP(h, hipStreamWaitEvent(bs, h->ev[0], 0));
+            const int inner[6] = {0, nt[0] - 1, 0, nt[1] - 1, 0, nt[2] - 1};
+            JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, inner)));
+            if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
+            const int hx[6] = {nt[0] - 1, nt[0], 0, nt[1], 0, nt[2]}, hy[6] = {0, nt[0] - 1, nt[1] - 1, nt[1], 0, nt[2]},
+                      hz[6] = {0, nt[0] - 1, 0, nt[1] - 1, nt[2] - 1, nt[2]};
+            JRX_TRY((launch_fused<64, 4, 8>(h, bs, a, bc, hx, true)));
+            JRX_TRY((launch_fused<64, 4, 8>(h, bs, a, bc, hy, true)));
+            JRX_TRY((launch_fused<64, 4, 8>(h, bs, a, bc, hz, true)));
+            I.ghosts_stale = true;
+            if (ncells_timed) *ncells_timed = (double)imin(nx, (nt[0] - 1) * 62) * (double)imin(ny, (nt[1] - 1) * 3) * (double)imin(nz, (nt[2] - 1) * 8);
+        } else if (!comm || !overlap) {
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
             JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, all)));
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
@@ -571,7 +601,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         if (bs != s) {
             JRX_HIP(h, hipEventRecord(h->ev[2], bs));
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
-            if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));     // two streams: only the whole group can be timed
+            if (tev && !split) JRX_HIP(h, hipEventRecord(tev[3], s));     // shell/interior overlap with neighbours: only the whole group can be timed
         }
         set_state(I.cur, dst);
         I.cur_is_user = !I.cur_is_user;
@@ -774,6 +804,10 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     const int nsamp = (int)((iters + stride - 1) / stride);
     std::vector<hipEvent_t> evs((size_t)nsamp * 4);
     std::vector<int> fused((size_t)nsamp, 0);
+    std::vector<double> ncell((size_t)nsamp, 0.0);
+    // the events are destroyed on every exit path
+    struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (auto &e : v) if (e) (void)hipEventDestroy(e); } } guard{evs};
+    for (auto &e : evs) e = nullptr;
     for (auto &e : evs) JRX_HIP(h, hipEventCreate(&e));
     Iter3D I;
     JRX_TRY(iter_begin(I, h, f, etatau, p));
@@ -785,7 +819,8 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     for (int64_t it = 0; it < iters; it++) {
         const bool samp = it % stride == 0;
         const bool fuse_next = it + 1 < iters && !(first_unfused && it == 0);
-        JRX_TRY(iter_step(I, false, fuse_next, samp ? &evs[(size_t)(it / stride) * 4] : nullptr, samp ? &fused[(size_t)(it / stride)] : nullptr));
+        JRX_TRY(iter_step(I, false, fuse_next, samp ? &evs[(size_t)(it / stride) * 4] : nullptr, samp ? &fused[(size_t)(it / stride)] : nullptr,
+                          samp ? &ncell[(size_t)(it / stride)] : nullptr));
     }
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_TRY(iter_end(I));
@@ -793,7 +828,7 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     float ms = 0.f;
     JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
     times_ms[0] = ms; times_ms[1] = times_ms[2] = times_ms[3] = times_ms[4] = times_ms[5] = 0.0;
-    double sa = 0.0, sb = 0.0, sf = 0.0, sk = 0.0;
+    double sa = 0.0, sb = 0.0, sf = 0.0, sk = 0.0, sc = 0.0;
     int na = 0, nb = 0, nf = 0;
     // with a communicator the un-fused iterations run on two streams (no per-sweep events); fused ones stay on `s`
     const bool comm = jrx_comm_active(h);
@@ -805,15 +840,14 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
         if (fused[q]) {
             float m3 = 0.f;
             JRX_HIP(h, hipEventElapsedTime(&m3, evs[(size_t)q * 4 + 1], evs[(size_t)q * 4 + 3]));
-            sf += m2; sk += m3; nf++;
+            sf += m2; sk += m3; sc += ncell[q]; nf++;
         }
         else { sb += m2; nb++; }
         if (m1 > 1e-3f) { sa += m1; na++; }      // a stress sweep ran as its own launch in this iteration
     }
-    for (auto &e : evs) (void)hipEventDestroy(e);
     if (na) times_ms[1] = sa / na;
     if (nb) times_ms[2] = sb / nb;
-    if (nf) { times_ms[3] = sf / nf; times_ms[4] = sk / nf; }
+    if (nf) { times_ms[3] = sf / nf; times_ms[4] = sk / nf; times_ms[5] = sc / nf; }
     return JRX_OK;
 }
 
