@@ -36,6 +36,7 @@ struct jrx_handle {
     int kernel_variant = 0;              // 0 auto (fused PT pipeline where it pays), 1 per-node v1 kernels, 2 z-marching sweeps only, 3 fused wherever legal
     bool fused_split = false;            // no neighbours: high-face tiles + boundary stress layers on the halo stream, interior tiles concurrently
                                          // (measured slower, profiles/r02_ab_fused_split.txt: off)
+    int fused_tile = 0;                  // fused kernel tile: 0 = 64 x 4 threads (a row per wave), 1 = 32 x 8 (two rows per wave)
     bool fused_comm = true;              // multi-rank runs use the fused pipeline (0: split sweeps + hidden communication)
     bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)

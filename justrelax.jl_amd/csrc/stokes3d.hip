@@ -356,6 +356,15 @@ jrx_status jrx_compute_maxloc(jrx_handle *h, double *B, const double *A, int64_t
 
 }   // extern "C"
 
+// Tile shape of the fused kernel (lane-shuffle form): TX - 2 stress columns per TX-lane tile row (one halo lane on the left, one feeder
+// lane on the right), TY - 1 stress rows, KZ planes per chunk.  Option "fused_tile": 0 = 64 x 4 (a row per wave), 1 = 32 x 8 (two rows per wave).
+struct FusedShape { int tx, ty, kz; };
+static FusedShape fused_shape(const jrx_handle *h) { return h->fused_tile == 0 ? FusedShape{64, 4, 8} : FusedShape{32, 8, 8}; }
+static void fused_tiles(const Lay3 &L, const FusedShape S, int nt[3])
+{
+    nt[0] = (L.nx + S.tx - 3) / (S.tx - 2); nt[1] = (L.ny + S.ty - 2) / (S.ty - 1); nt[2] = (L.nz + S.kz - 1) / S.kz;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Iteration driver shared by jrx_stokes3d_solve and jrx_stokes3d_iterate_timed.
 // One PT iteration m (Stokes3D.jl:78-121) = A_m (stress sweep), B_m (velocity sweep), BCs, halo.
@@ -409,13 +418,15 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     // option "scratch_sets" = 0 refuses the library-owned second state set the fused pipeline needs
     I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && h->scratch_sets && (h->fused_comm || !jrx_comm_active(h)) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable && h->kernel_variant == 0) {
-        // auto: the fused kernel covers a row with ceil(nx/62) 64-lane tiles (one halo and one feeder lane each); when that
-        // quantisation idles too many lanes the two sweeps are faster (measured, profiles/r01_bench_sizes.txt: nx = 192, 4 tiles, 33 % idle:
-        // fused +21 %; nx = 96, 2 tiles, 33 %: equal; nx = 256: +4 %; nx = 320: +25 %; nx = 128, 3 tiles, 50 % idle: fused -21 %)
-        const i64 ntx = (p->nx + 61) / 62;
-        if (ntx * 64 * 100 > (i64)p->nx * 140) I.fusable = false;
-        // ... and below ~6 tiles per CU the 17-plane-deep tiles leave the chip idle (96^3, 384 tiles: 6.8 k it/s fused, 9.2 k with the sweeps)
-        if (ntx * ((p->ny + 2) / 3) * ((p->nz + 15) / 16) < 1536) I.fusable = false;     // counted in 16-plane units as measured
+        // auto: the fused kernel covers a row with ceil(nx / (TX - 2)) TX-lane tiles (one halo and one feeder lane each); when that
+        // quantisation idles too many lanes the two sweeps are faster (measured with 64-lane rows, profiles/r01_bench_sizes.txt: nx = 192,
+        // 4 tiles, 33 % idle: fused +21 %; nx = 96, 2 tiles, 33 %: equal; nx = 256: +4 %; nx = 320: +25 %; nx = 128, 3 tiles, 50 % idle: fused -21 %)
+        const FusedShape S = fused_shape(h);
+        int nt[3];
+        fused_tiles(L, S, nt);
+        if ((i64)nt[0] * S.tx * 100 > (i64)p->nx * 140) I.fusable = false;
+        // ... and below ~6 tiles per CU the deep tiles leave the chip idle (96^3 with 64 x 4 tiles, 384 16-plane units: 6.8 k it/s fused, 9.2 k with the sweeps)
+        if ((i64)nt[0] * nt[1] * ((p->nz + 15) / 16) * (S.ty - 1) < 1536 * 3) I.fusable = false;     // counted in units of 3 rows x 16 planes as measured
     }
     if (I.fusable) {
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
@@ -433,17 +444,9 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     return JRX_OK;
 }
 
-// tile counts of the fused kernel: lane-shuffle form, 62 stress columns per 64-lane tile row (one halo lane on the left, one feeder
-// lane on the right), TY-1 rows, KZ planes
-template <int TX, int TY, int KZ>
-static void fused_tiles(const Lay3 &L, int nt[3])
-{
-    nt[0] = (L.nx + TX - 3) / (TX - 2); nt[1] = (L.ny + TY - 2) / (TY - 1); nt[2] = (L.nz + KZ - 1) / KZ;
-}
-
 // launch the fused kernel over the box of tiles [b[0], b[1]) x [b[2], b[3]) x [b[4], b[5])
 template <int TX, int TY, int KZ>
-static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false)
+static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface)
 {
     // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
     // fetched array passes per launch at 512^3)
@@ -464,6 +467,11 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
     JRX_LAUNCH_CHECK(h);
     h->stat_fused3d++;
     return JRX_OK;
+}
+static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false)
+{
+    if (h->fused_tile == 0) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface);
+    return launch_fused_t<32, 8, 8>(h, s, a, bc, b, hiface);
 }
 
 // tev (optional): events recorded around the sweeps: [0] start, [1] after the stress sweep (if one was launched),
@@ -494,9 +502,10 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.fsL = !!(fs & JRX_FACE_LEFT); bc.nsL = !!(ns & JRX_FACE_LEFT); bc.fsF = !!(fs & JRX_FACE_FRONT); bc.nsF = !!(ns & JRX_FACE_FRONT);
         bc.fsK0 = !!(fs & JRX_FACE_TOP);  bc.nsK0 = !!(ns & JRX_FACE_BOT);     // k = 1: free_slip `top`, no_slip `bot` (reference naming)
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
-        // 64 x 4 threads (stress tile 62 x 3), 8 planes per chunk: best of the measured tile shapes (128 VGPRs -> 4 blocks/CU)
+        // 256 threads per tile, 8 planes per chunk (128 VGPRs -> 4 blocks/CU)
         int nt[3];
-        fused_tiles<64, 4, 8>(a.L, nt);
+        const FusedShape S = fused_shape(h);
+        fused_tiles(a.L, S, nt);
         const bool comm = jrx_comm_active(h);
         hipStream_t bs = s;            // stream of the boundary work
         // flow_bcs! on the new V: the reference's ordered passes the first time a set is written, one launch for all faces afterwards
@@ -528,18 +537,18 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             JRX_HIP(h, hipEventRecord(h->ev[0], s));
             JRX_HIP(h, hipStreamWaitEvent(bs, h->ev[0], 0));
             const int inner[6] = {0, nt[0] - 1, 0, nt[1] - 1, 0, nt[2] - 1};
-            JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, inner)));
+            JRX_TRY(launch_fused(h, s, a, bc, inner));
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
             const int hx[6] = {nt[0] - 1, nt[0], 0, nt[1], 0, nt[2]}, hy[6] = {0, nt[0] - 1, nt[1] - 1, nt[1], 0, nt[2]},
                       hz[6] = {0, nt[0] - 1, 0, nt[1] - 1, nt[2] - 1, nt[2]};
-            JRX_TRY((launch_fused<64, 4, 8>(h, bs, a, bc, hx, true)));
-            JRX_TRY((launch_fused<64, 4, 8>(h, bs, a, bc, hy, true)));
-            JRX_TRY((launch_fused<64, 4, 8>(h, bs, a, bc, hz, true)));
+            JRX_TRY(launch_fused(h, bs, a, bc, hx, true));
+            JRX_TRY(launch_fused(h, bs, a, bc, hy, true));
+            JRX_TRY(launch_fused(h, bs, a, bc, hz, true));
             I.ghosts_stale = true;
-            if (ncells_timed) *ncells_timed = (double)imin(nx, (nt[0] - 1) * 62) * (double)imin(ny, (nt[1] - 1) * 3) * (double)imin(nz, (nt[2] - 1) * 8);
+            if (ncells_timed) *ncells_timed = (double)imin(nx, (nt[0] - 1) * (S.tx - 2)) * (double)imin(ny, (nt[1] - 1) * (S.ty - 1)) * (double)imin(nz, (nt[2] - 1) * S.kz);
         } else if (!comm || !overlap) {
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
-            JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, all)));
+            JRX_TRY(launch_fused(h, s, a, bc, all));
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
             // Without neighbours no flow_bcs! launch is needed here: the fused kernel and the boundary-layer launch below derive the
             // boundary entries of V by rule, and every path that reads them from memory (un-fused sweeps, results handed back) is
@@ -570,9 +579,9 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             const int boxes[6][6] = {{0, nt[0], 0, nt[1], lo[2][0], lo[2][1]},  {0, nt[0], 0, nt[1], hi[2][0], hi[2][1]},
                                      {0, nt[0], lo[1][0], lo[1][1], mid[2][0], mid[2][1]}, {0, nt[0], hi[1][0], hi[1][1], mid[2][0], mid[2][1]},
                                      {lo[0][0], lo[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]}, {hi[0][0], hi[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]}};
-            for (int q = 0; q < 6; q++) JRX_TRY((launch_fused<64, 4, 8>(h, bs, a, bc, boxes[q])));
+            for (int q = 0; q < 6; q++) JRX_TRY(launch_fused(h, bs, a, bc, boxes[q]));
             const int inner[6] = {mid[0][0], mid[0][1], mid[1][0], mid[1][1], mid[2][0], mid[2][1]};
-            JRX_TRY((launch_fused<64, 4, 8>(h, s, a, bc, inner)));
+            JRX_TRY(launch_fused(h, s, a, bc, inner));
             JRX_TRY(fused_bcs(bs));
             // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
             double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};

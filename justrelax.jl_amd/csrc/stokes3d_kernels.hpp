@@ -658,6 +658,9 @@ struct FusedBC {
 // SHFL: x-neighbour operands come from the adjacent lane instead of a second load of the same array (7 velocity-phase loads at i+1, 4
 // stress-phase loads at i-1): fewer vector-memory instructions through the L1/TA path (measured -4.7 %).  Lane TX-1 then only feeds
 // its left neighbour (tile stride TX - OVX - 1), and the lanes left of the stress tile also load η, G for theirs.
+// TX = 32 (with SHFL): a wave holds two rows of the tile (lane shuffles of width 32), so that 256 threads form a 32 x 8 tile with 30 x 7
+// stress columns (82 % of the threads) instead of 64 x 4 with 62 x 3 (73 %), and rows quantise in steps of 30 columns (nx = 256: 9 half-wave
+// tiles = 288 lanes instead of 5 x 64 = 320).
 // YLDS (with SHFL): y-neighbour operands come from the adjacent row of the tile through LDS: every lane publishes P, ητ, τyy, fy, τxy, τyz
 // (the row below reads them as its j+1 operands) and η, G (the row above reads them as its j-1 operands); only the top row of the tile
 // and the row on the domain's back face still load the j+1 operands from memory.  One more barrier per plane, 8 fewer loads per lane.
@@ -667,7 +670,7 @@ template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, in
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0)
 {
     // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
-    static_assert(!(SHFL && (LATEA || TX != 64)), "SHFL is implemented for 64-lane rows");
+    static_assert(!(SHFL && (LATEA || (TX != 64 && TX != 32))), "SHFL is implemented for rows of one wave or half a wave");
     static_assert(!YLDS || SHFL, "YLDS builds on the SHFL operand layout");
     constexpr int NS = LOWREG ? 3 : 2;
     __shared__ double sV[NS][3][TY][TX];
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     if (bvalid) { e = LDB(f.eta, oc); g = LDB(f.G, oc); }
                 } else if (bvalid) {
                     e = LDB(f.eta, oc); ey = LDB(f.eta, oc - dcy); g = LDB(f.G, oc); gy = LDB(f.G, oc - dcy);
-                    const double e_l = __shfl_up(e, 1, 64), g_l = __shfl_up(g, 1, 64), ey_l = __shfl_up(ey, 1, 64), gy_l = __shfl_up(gy, 1, 64);
+                    const double e_l = __shfl_up(e, 1, TX), g_l = __shfl_up(g, 1, TX), ey_l = __shfl_up(ey, 1, TX), gy_l = __shfl_up(gy, 1, TX);
                     ex = i > 0 ? e_l : e; gx = i > 0 ? g_l : g; exy_ = i > 0 ? ey_l : ey; gxy = i > 0 ? gy_l : gy;
                 }
                 if (YLDS < 2 && avalid && live) {
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 // stress phase: η, G at j-1 from the row below (clamped at j = 0), then the i-1 column by lane shuffle (clamped at i = 0)
                 if (ty > 0 && j > 0) { ey = sY[6][ty - 1][tx]; gy = sY[7][ty - 1][tx]; }
                 else { ey = e; gy = g; }
-                const double e_l = __shfl_up(e, 1, 64), g_l = __shfl_up(g, 1, 64), ey_l = __shfl_up(ey, 1, 64), gy_l = __shfl_up(gy, 1, 64);
+                const double e_l = __shfl_up(e, 1, TX), g_l = __shfl_up(g, 1, TX), ey_l = __shfl_up(ey, 1, TX), gy_l = __shfl_up(gy, 1, TX);
                 ex = i > 0 ? e_l : e; gx = i > 0 ? g_l : g; exy_ = i > 0 ? ey_l : ey; gxy = i > 0 ? gy_l : gy;
             }
             double q11, q10, s11, Px, ex, txx_x, fx_x;
@@ -822,8 +825,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 // they are only used where hx, i.e. where that lane exists
                 if (!YLDS) txy_own = LDB(f.txy, oxy);
                 txy = txy_own;                                  // also the stress phase's own τxy
-                q11 = __shfl_down(q01, 1, 64); q10 = __shfl_down(txy_own, 1, 64); s11 = __shfl_down(s01, 1, 64);
-                Px = __shfl_down(Pc, 1, 64); ex = __shfl_down(ec, 1, 64); txx_x = __shfl_down(txx_c, 1, 64); fx_x = __shfl_down(fx_c, 1, 64);
+                q11 = __shfl_down(q01, 1, TX); q10 = __shfl_down(txy_own, 1, TX); s11 = __shfl_down(s01, 1, TX);
+                Px = __shfl_down(Pc, 1, TX); ex = __shfl_down(ec, 1, TX); txx_x = __shfl_down(txx_c, 1, TX); fx_x = __shfl_down(fx_c, 1, TX);
                 // the last cell column has no lane to its right, but its y- and z-momentum still need the shear stresses on the
                 // domain's right face (τxy, τxz have nx+1 columns)
                 if (!hx) { q11 = LDB(f.txy, oxy + 8u + rxy); s11 = LDB(f.txz, oxz + 8u); }

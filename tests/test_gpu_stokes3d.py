@@ -236,16 +236,21 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
     outs, its = [], []
     h = _lib.default_handle()
     try:
-        for variant in (0, 1, 2, 3):
-            h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
+        # variant 13 / 3: the fused pipeline with the other tile shape (option fused_tile: 64 x 4 / 32 x 8 threads)
+        tile0 = C.c_int64(0)
+        h.call("jrx_get_option", C.c_char_p(b"fused_tile"), C.byref(tile0))
+        for variant in (0, 1, 2, 3, 13):
+            h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant % 10))
+            h.call("jrx_set_option", C.c_char_p(b"fused_tile"), C.c_int64(1 - tile0.value if variant >= 10 else tile0.value))
             stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
             r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
             its.append((r.iter, tuple(r.err_evo1)))
             outs.append(env["down"](stokes))
     finally:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
-    assert its[0] == its[1] == its[2] == its[3] and its[0][0] == 24
-    for v in (1, 2, 3):
+        h.call("jrx_set_option", C.c_char_p(b"fused_tile"), tile0)
+    assert its[0] == its[1] == its[2] == its[3] == its[4] and its[0][0] == 24
+    for v in (1, 2, 3, 4):
         for k in outs[0]:
             m = env["checks"].interior_mask3d(k, outs[0][k].shape)
             assert np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)
