@@ -234,6 +234,27 @@ typedef struct jrx_rheology {
     double eta[JRX_MAXPHASE], G[JRX_MAXPHASE], Kb[JRX_MAXPHASE];
     int32_t is_pl[JRX_MAXPHASE];
     double C[JRX_MAXPHASE], sinphi[JRX_MAXPHASE], cosphi[JRX_MAXPHASE], sinpsi[JRX_MAXPHASE], eta_vp[JRX_MAXPHASE];
+    /* ---- appended in round 2; a zero-initialised tail gives the round-1 behaviour (LinearViscous, NoSoftening, ρg owned by the caller) ----
+     * Density and gravity -- compute_ρg! / update_ρg! (rheology/BuoyancyForces.jl:37-60,153-167).  has_density = 0: the ρg arrays
+     * are the caller's and never recomputed.  rho_kind: 0 ConstantDensity(rho0), 1 PT_Density rho0 (1 - alpha (T - T0) + beta (P - P0)),
+     * 2 T_Density rho0 (1 - alpha (T - T0)), 3 Compressible_Density rho0 exp(beta (P - P0)) [GeoParams forms, assumed].
+     * gravity = compute_gravity(first(rheology)): a scalar, it fills the last component of ρg (BuoyancyForces.jl:69-70). */
+    int32_t has_density;
+    int32_t rho_kind[JRX_MAXPHASE];
+    double rho0[JRX_MAXPHASE], alpha[JRX_MAXPHASE], beta[JRX_MAXPHASE], T0[JRX_MAXPHASE], P0[JRX_MAXPHASE];
+    double gravity;
+    /* Strain softening of the cohesion and of the friction angle, evaluated at the accumulated plastic strain EII_pl (the EII keyword
+     * of compute_yieldfunction_phase, StressKernels.jl:1053-1105; GeoParams softening_C / softening_ϕ, forms assumed):
+     * kind 0 NoSoftening, 1 LinearSoftening((a = min, b = max), (c = lo, d = hi)): b for EII <= lo, a for EII >= hi, linear between;
+     * 2 NonLinearSoftening(a = ξ₀, b = Δ, c = μ, d = σ) = ξ₀ - Δ/2 erfc(-(EII - μ)/σ).  phi_deg is the unsoftened friction angle. */
+    int32_t softC_kind[JRX_MAXPHASE], softphi_kind[JRX_MAXPHASE];
+    double softC_a[JRX_MAXPHASE], softC_b[JRX_MAXPHASE], softC_c[JRX_MAXPHASE], softC_d[JRX_MAXPHASE];
+    double softphi_a[JRX_MAXPHASE], softphi_b[JRX_MAXPHASE], softphi_c[JRX_MAXPHASE], softphi_d[JRX_MAXPHASE], phi_deg[JRX_MAXPHASE];
+    /* Creep law of the viscous element for compute_viscosity! / compute_viscosity_τII! with dt = Inf (rheology/Viscosity.jl:142-167):
+     * visc_kind 0 LinearViscous(eta); 1 Arrhenius: eta exp((Ea + P Va)/(Rgas T) - Ea/(Rgas Tref)), clamped to [visc_lo, visc_hi]
+     * (the CustomRheology of test/test_WENO5.jl:37-42 with depth = 0) */
+    int32_t visc_kind[JRX_MAXPHASE];
+    double Ea[JRX_MAXPHASE], Va[JRX_MAXPHASE], Tref[JRX_MAXPHASE], Rgas[JRX_MAXPHASE], visc_lo[JRX_MAXPHASE], visc_hi[JRX_MAXPHASE];
 } jrx_rheology;
 
 typedef struct jrx_vep2d_fields {
@@ -250,6 +271,7 @@ typedef struct jrx_vep2d_fields {
     double *RP, *Rx, *Ry;
     double *omega_xy;                              /* stokes.ω.xy (may be NULL) */
     double *phase_c, *phase_v;                     /* phase_ratios.center / .vertex */
+    const double *T;                               /* args.T at the cell centres (ni) for the density laws; may be NULL (T = 0) */
 } jrx_vep2d_fields;
 
 typedef struct jrx_vep2d_params {
@@ -260,6 +282,8 @@ typedef struct jrx_vep2d_params {
     uint32_t free_slip, no_slip, periodic;
     double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
     int32_t verbose;
+    int32_t free_surface;                          /* kwarg free_surface: compute_V! / compute_Res! get dt * free_surface (Stokes2D.jl:773,797) */
+    int32_t displacement_bcs;                      /* flow_bcs is a DisplacementBoundaryConditions: V = U / dt first, flow_bcs! acts on U */
 } jrx_vep2d_params;
 
 jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p,
@@ -304,6 +328,7 @@ typedef struct jrx_vep3d_fields {
     double *RP, *Rx, *Ry, *Rz;
     double *omega_yz, *omega_xz, *omega_xy;               /* optional: vorticity on the edges */
     const double *phase_c, *phase_yz, *phase_xz, *phase_xy;
+    const double *T;                                      /* args.T at the cell centres (ni); may be NULL (T = 0) */
 } jrx_vep3d_fields;
 
 typedef struct jrx_vep3d_params {
@@ -314,6 +339,7 @@ typedef struct jrx_vep3d_params {
     uint32_t free_slip, no_slip, periodic;
     double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
     int32_t verbose;
+    int32_t displacement_bcs;
 } jrx_vep3d_params;
 
 jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p,

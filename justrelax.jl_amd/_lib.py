@@ -85,14 +85,20 @@ class Thermal3DParams(C.Structure):
 
 VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
              "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
-             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v"]
+             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v", "T"]
 VEP2DFields = _ptr_struct("VEP2DFields", VEP_NAMES)
 MAXPHASE = 8
 
 
 class Rheology(C.Structure):
     _fields_ = [("nphase", C.c_int32)] + [(k, C.c_double * MAXPHASE) for k in ("eta", "G", "Kb")] + [("is_pl", C.c_int32 * MAXPHASE)] + \
-               [(k, C.c_double * MAXPHASE) for k in ("C", "sinphi", "cosphi", "sinpsi", "eta_vp")]
+               [(k, C.c_double * MAXPHASE) for k in ("C", "sinphi", "cosphi", "sinpsi", "eta_vp")] + \
+               [("has_density", C.c_int32), ("rho_kind", C.c_int32 * MAXPHASE)] + \
+               [(k, C.c_double * MAXPHASE) for k in ("rho0", "alpha", "beta", "T0", "P0")] + [("gravity", C.c_double)] + \
+               [("softC_kind", C.c_int32 * MAXPHASE), ("softphi_kind", C.c_int32 * MAXPHASE)] + \
+               [(k, C.c_double * MAXPHASE) for k in ("softC_a", "softC_b", "softC_c", "softC_d", "softphi_a", "softphi_b", "softphi_c",
+                                                     "softphi_d", "phi_deg")] + \
+               [("visc_kind", C.c_int32 * MAXPHASE)] + [(k, C.c_double * MAXPHASE) for k in ("Ea", "Va", "Tref", "Rgas", "visc_lo", "visc_hi")]
 
 
 class VEP2DParams(C.Structure):
@@ -101,7 +107,7 @@ class VEP2DParams(C.Structure):
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("iterMin", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
-                ("verbose", C.c_int32)]
+                ("verbose", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32)]
 
 
 VEP3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",
@@ -111,7 +117,7 @@ VEP3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",
               "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII",
               "toxx", "toyy", "tozz", "toyz", "toxz", "toxy", "toyz_c", "toxz_c", "toxy_c",
               "eta", "eta_vep", "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "fz", "RP", "Rx", "Ry", "Rz",
-              "omega_yz", "omega_xz", "omega_xy", "phase_c", "phase_yz", "phase_xz", "phase_xy"]
+              "omega_yz", "omega_xz", "omega_xy", "phase_c", "phase_yz", "phase_xz", "phase_xy", "T"]
 VEP3DFields = _ptr_struct("VEP3DFields", VEP3_NAMES)
 
 
@@ -122,7 +128,7 @@ class VEP3DParams(C.Structure):
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
-                ("verbose", C.c_int32)]
+                ("verbose", C.c_int32), ("displacement_bcs", C.c_int32)]
 
 
 class SolveResult(C.Structure):

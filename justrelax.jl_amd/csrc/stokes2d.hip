@@ -7,6 +7,7 @@
 // so these kernels are launch/latency bound rather than HBM bound.
 #include "jrx_internal.hpp"
 #include "jrx_kernels.hpp"
+#include "jrx_material.hpp"
 
 namespace {
 
@@ -16,6 +17,7 @@ struct Args2 {
     double _dx, _dy, dt, r, theta_dtau, eta_dtau;
     int nx, ny;
     unsigned fs, ns;      // free_slip / no_slip face masks for the velocity kernel's fused ghost update (BCF)
+    double fs_dt = 0.0;   // dt * free_surface of the free-surface forms of compute_V! / compute_Res! (VelocityKernels.jl:134-180,271-307)
 };
 
 #define VX(i_, j_) Vx[(i_) + (i64)(nx + 1) * (j_)]
@@ -98,10 +100,19 @@ __device__ __forceinline__ void velocity2d_cell(const Args2 &a, const int i, con
     if (j < ny - 1) {
         const double dP = (-P[c] + P[c + nx]) * _dy, dT = (-a.f.tyy[c] + a.f.tyy[c + nx]) * _dy;
         const double dS = (-TXY(i, j + 1) + TXY(i + 1, j + 1)) * _dx, av = (a.f.fy[c] + a.f.fy[c + nx]) * 0.5;
-        if (RES_ONLY) a.f.Ry[c] = dT + dS - dP - av;
+        double corr = 0.0;
+        const bool fsurf = a.fs_dt != 0.0;
+        if (fsurf) {      // ρg_correction = Vy ∂(ρg_y)/∂y θ dt with θ = 1, j_N = min(j + 1, ny)
+            const int jN = min(j + 1, ny - 1);
+            const double drg = (a.f.fy[i + (i64)nx * jN] - a.f.fy[c]) * _dy;
+            const double vy0 = a.f.Vy[(i + 1) + (i64)(nx + 2) * (j + 1)];
+            corr = RES_ONLY ? (vy0 * drg) * 1.0 * a.fs_dt : vy0 * drg * 1.0 * a.fs_dt;
+        }
+        if (RES_ONLY) a.f.Ry[c] = fsurf ? dT + dS - dP - av + corr : dT + dS - dP - av;
         else {
             const i64 q = (i + 1) + (i64)(nx + 2) * (j + 1);
-            const double v = a.f.Vy[q] + (-dP + dT + dS - av) * edt / ((et[c] + et[c + nx]) * 0.5);
+            const double rhs = fsurf ? -dP + dT + dS - av + corr : -dP + dT + dS - av;
+            const double v = a.f.Vy[q] + rhs * edt / ((et[c] + et[c + nx]) * 0.5);
             a.f.Vy[q] = v;
             if (BCF) {      // Vy ghost columns i = 0 (left) and i = nx+1 (right)
                 if (i == 0) { if (a.fs & JRX_FACE_LEFT) a.f.Vy[q - 1] = v; else if (a.ns & JRX_FACE_LEFT) a.f.Vy[q - 1] = -v; }
@@ -554,6 +565,7 @@ struct VepArgs {
     double *txx_out = nullptr, *tyy_out = nullptr;      // where the centre half writes τxx, τyy (nullptr: in place)
     double _dx, _dy, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
     int nx, ny;
+    bool soft;            // some phase has a softening law (EII_pl is then read by the yield function)
 };
 
 __device__ __forceinline__ double sinv2(double xx, double yy, double xy) { return sqrt(0.5 * (xx * xx + yy * yy) + xy * xy); }
@@ -575,12 +587,17 @@ __device__ __forceinline__ void plastic_params(const jrx_rheology &rh, const dou
     for (int q = 0; q < rh.nphase; q++)
         if (rh.is_pl[q]) { is_pl = true; eta_reg += rh.eta_vp[q] * r[q]; }
 }
-__device__ __forceinline__ double yield_F(const jrx_rheology &rh, const double *r, double P, double tII)
-{   // compute_yieldfunction_phase, StressUpdate.jl:399-410 ; DP: F = τII - cosϕ C - sinϕ P
+__device__ __forceinline__ double yield_F(const jrx_rheology &rh, const double *r, double P, double tII, double EII)
+{   // compute_yieldfunction_phase, StressUpdate.jl:399-410 ; DP: F = τII - cosϕ(EII) C(EII) - sinϕ(EII) P (softening at the EII keyword)
     double F = 0.0;
     for (int q = 0; q < rh.nphase; q++) {
         if (r[q] == 0.0) continue;
-        const double Fq = rh.is_pl[q] ? (tII - rh.cosphi[q] * rh.C[q] - rh.sinphi[q] * P) : tII;
+        double Fq = tII;
+        if (rh.is_pl[q]) {
+            double sp, cp;
+            mat_friction(rh, q, EII, sp, cp);
+            Fq = tII - cp * mat_cohesion(rh, q, EII) - sp * P;
+        }
         F += r[q] * Fq;
     }
     return F;
@@ -604,7 +621,8 @@ __device__ __forceinline__ void plastic_grad(const jrx_rheology &rh, const doubl
 // compute_∇V! + compute_P! (phase form: K, G phase-averaged once per solve; writes θ) + compute_strain_rate!
 // ML: compute_maxloc!(ητ, η) of the own cell first (clamped 3 x 3 window, same comparison order as k_maxloc) and store it: saves the
 // separate launch of the launch-bound 2D loop
-template <bool ML>
+// RHO: update_ρg! of the own cell (args.T, args.P = stokes.P; phase-ratio density times the scalar gravity, into the last component of ρg)
+template <bool ML, bool RHO = false>
 __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__restrict__ theta)
 {
     const int nx = a.nx, ny = a.ny;
@@ -641,6 +659,7 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
         const double d3 = divV * (1.0 / 3.0);
         a.f.exx[c] = dxi - d3;
         a.f.eyy[c] = dyi - d3;
+        if (RHO) a.f.fy[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)a.rh.nphase * c, a.f.T ? a.f.T[c] : 0.0, a.f.P[c]) * a.rh.gravity;
     }
     a.f.exy[i + (i64)(nx + 1) * j] = 0.5 * (a._dy * (VX(i, j + 1) - VX(i, j)) + a._dx * (VY(i + 1, j) - VY(i, j)));
 #undef VX
@@ -656,6 +675,7 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
 #define AVC(A) (0.25 * (C2(A, i0, j0) + C2(A, ic, jc) + C2(A, i0, jc) + C2(A, ic, j0)))
     const double Pv = AVC(a.theta), exxv = AVC(a.f.exx), eyyv = AVC(a.f.eyy), txxv = AVC(a.f.txx), tyyv = AVC(a.f.tyy);
     const double toxxv = AVC(a.f.toxx), toyyv = AVC(a.f.toyy);
+    const double EIIv = a.soft ? AVC(a.f.EII_pl) : 0.0;      // EIIv_ij = av_clamped(EII, Ic...) (StressKernels.jl:1030); only softening laws read it
 #undef AVC
     const i64 v = i + (i64)(nx + 1) * j;
     const double *rv = a.f.phase_v + (i64)np * v;
@@ -674,7 +694,7 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
     double dQdt[3], dQdP, dFdP;
     plastic_grad(a.rh, rv, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
-    const double F = yield_F(a.rh, rv, Pv, tIIv);
+    const double F = yield_F(a.rh, rv, Pv, tIIv, EIIv);
     if (is_pl && tIIv != 0.0 && F > 0) {
         const double l = fma(1.0 - a.rel, a.lamv[v], a.rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol)));
         a.lamv[v] = l;
@@ -721,7 +741,7 @@ __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, con
     plastic_grad(a.rh, rc, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
     const double Pr = a.theta[c];
-    const double F = yield_F(a.rh, rc, Pr, tII);
+    const double F = yield_F(a.rh, rc, Pr, tII, a.soft ? a.f.EII_pl[c] : 0.0);
     double l = a.lam[c];
     if (is_pl && tII != 0.0 && F > 0) {
         l = fma(1.0 - a.rel, l, a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol)));
@@ -871,12 +891,14 @@ __global__ __launch_bounds__(256) void k_vep_visc_velocity(const VepArgs a, cons
     if (j < b.ny) velocity2d_cell<false, BCF>(b, i, j);
 }
 
-__global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const VepArgs a)
+// rho: also compute_ρg!(ρg, phase_ratios, rheology, args) (Stokes2D.jl:646)
+__global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const VepArgs a, const bool rho)
 {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (i64)a.nx * a.ny) return;
     Kc[t] = ratio_avg(a.rh.Kb, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
     Gc[t] = ratio_avg(a.rh.G, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
+    if (rho) a.f.fy[t] = mat_density_ratio(a.rh, a.f.phase_c + a.rh.nphase * t, a.f.T ? a.f.T[t] : 0.0, a.f.P[t]) * a.rh.gravity;
 }
 
 __global__ __launch_bounds__(256) void k_tensor_invariant2d(double *__restrict__ II, const double *__restrict__ xx, const double *__restrict__ yy,
@@ -961,6 +983,7 @@ VepArgs make_vep(const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_ve
     a._dx = p->_dx; a._dy = p->_dy; a.dt = p->dt; a.r = p->r; a.theta_dtau = p->theta_dtau; a.rel = p->lambda_relaxation;
     a.nu = p->viscosity_relaxation; a.cut_lo = p->cutoff_lo; a.cut_hi = p->cutoff_hi;
     a.nx = (int)p->nx; a.ny = (int)p->ny;
+    a.soft = mat_has_softening(rh);
     return a;
 }
 
@@ -1126,8 +1149,16 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     JRX_HIP(h, hipMemsetAsync(f->eplxx, 0, n * sizeof(double), s));                                 // @tensor_center(ε_pl) .= 0
     JRX_HIP(h, hipMemsetAsync(f->eplyy, 0, n * sizeof(double), s));
     JRX_HIP(h, hipMemsetAsync(f->eplxy_c, 0, n * sizeof(double), s));
-    hipLaunchKernelGGL(k_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a);
+    hipLaunchKernelGGL(k_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a, rh->has_density != 0);
     JRX_LAUNCH_CHECK(h);
+    const bool upd_rho = rh->has_density && !mat_density_is_constant(rh);       // update_ρg!: a no-op for constant densities
+    const bool ubc = p->displacement_bcs != 0;
+    if (ubc) {    // displacement2velocity!(stokes, dt, flow_bcs) (Stokes2D.jl:647): V = U * inv(dt)
+        hipLaunchKernelGGL(k_scale3, dim3(256), dim3(256), 0, s, f->Vx, (const double *)f->Ux, (i64)(nx + 1) * (ny + 2), f->Vy,
+                           (const double *)f->Uy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, 1.0 / p->dt);
+        JRX_LAUNCH_CHECK(h);
+    }
+    b.fs_dt = p->dt * (double)(p->free_surface != 0);
 
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
@@ -1141,8 +1172,10 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             double *arrs[1] = {etatau};
             const int64_t ext[1][3] = {{nx, ny, 1}};
             JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
-            hipLaunchKernelGGL(k_vep_pre<false>, dim3(gv), dim3(256), 0, s, a, theta);
-        } else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, a, theta);      // compute_maxloc! folded in
+            if (upd_rho) hipLaunchKernelGGL((k_vep_pre<false, true>), dim3(gv), dim3(256), 0, s, a, theta);
+            else hipLaunchKernelGGL(k_vep_pre<false>, dim3(gv), dim3(256), 0, s, a, theta);
+        } else if (upd_rho) hipLaunchKernelGGL((k_vep_pre<true, true>), dim3(gv), dim3(256), 0, s, a, theta);
+        else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, a, theta);      // compute_maxloc! folded in
         JRX_LAUNCH_CHECK(h);
         // update_stresses_center_vertex_ps!: vertex and centre halves in one launch; the new τxx, τyy go to the other set, then swap
         hipLaunchKernelGGL(k_vep_stress2d, dim3(gv), dim3(256), 0, s, a);
@@ -1155,7 +1188,8 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             const int64_t ext[1][3] = {{nx + 1, ny + 1, 1}};
             JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
         }
-        const bool bcf = iter >= 1 && p->periodic == 0 && !comm;      // flow_bcs! applied in full by iteration 1: refresh ghosts in-kernel
+        // flow_bcs! applied in full by iteration 1: refresh ghosts in-kernel (never with DisplacementBoundaryConditions: flow_bcs! then acts on U)
+        const bool bcf = iter >= 1 && p->periodic == 0 && !comm && !ubc;
         bool used_bcf = false;
         {
             const bool next_check = ((iter + 1) % p->nout == 0) && iter + 1 > 1;
@@ -1175,7 +1209,9 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                                (const double *)f->Vy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, p->dt);
             JRX_LAUNCH_CHECK(h);
         }
-        if (!used_bcf) JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+        if (ubc) {    // flow_bcs!(stokes, ::DisplacementBoundaryConditions) acts on U = V dt, which the next iteration overwrites: only the last one is observable
+            if (last) JRX_TRY(launch_bcs2(h, s, f->Ux, f->Uy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+        } else if (!used_bcf) JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
         if (comm) {   // update_halo!(@velocity(stokes)...) (Stokes2D.jl:784)
             double *arrs[2] = {f->Vx, f->Vy};
             const int64_t ext[2][3] = {{nx + 1, ny + 2, 1}, {nx + 2, ny + 1, 1}};
@@ -1203,11 +1239,21 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             }
             if (cont == 0) err_it1 = err;
             cont++;
-            if (p->verbose)
+            if (p->verbose && jrx_comm_rank(h) == 0)      // igg.me == 0 (Stokes2D.jl:814)
                 printf("Total steps = %lld, abs_err = %1.3e , rel_err = %1.3e [norm_Rx=%1.3e, norm_Ry=%1.3e, norm_∇V=%1.3e] \n",
                        (long long)iter, err, err / err_it1, nRx, nRy, nDV);
             if (std::isnan(err)) {
+                // error("NaN(s)"): leave the caller's arrays consistent (the current τxx, τyy may live in the second set) and the stream drained
+                if (a.f.txx != f->txx) {
+                    (void)hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+                    (void)hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+                }
+                (void)hipEventRecord(h->ev[7], s);
+                (void)hipStreamSynchronize(s);
+                float msn = 0.f;
+                (void)hipEventElapsedTime(&msn, h->ev[6], h->ev[7]);
                 res->iter = iter; res->nchecks = cont < res->cap ? cont : res->cap;
+                res->time_s = msn * 1e-3; res->av_time_s = iter > 1 ? res->time_s / (double)(iter - 1) : res->time_s;
                 return jrx_fail(h, JRX_ERR_NAN, "NaN(s)");
             }
         }

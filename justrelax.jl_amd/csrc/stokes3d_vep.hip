@@ -15,6 +15,7 @@
 // HBM-bound fp64 stencils with branches; no MFMA.
 #include "jrx_internal.hpp"
 #include "jrx_kernels.hpp"
+#include "jrx_material.hpp"
 
 namespace {
 
@@ -26,6 +27,7 @@ struct Vep3Args {
     double *lamv[3], *tnew[3];
     double _dx, _dy, _dz, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
     int nx, ny, nz;
+    bool soft;            // some phase has a softening law: the yield function then reads EII_pl
 };
 
 // node (i, j, k) of an (n1, n2, n3) box: xy flattened over blockIdx.x (no nearly empty blocks when n1 = nx + 1), k = blockIdx.y
@@ -59,12 +61,17 @@ __device__ __forceinline__ void plastic_params3(const jrx_rheology &rh, const do
     for (int q = 0; q < rh.nphase; q++)
         if (rh.is_pl[q]) { is_pl = true; eta_reg += rh.eta_vp[q] * r[q]; }
 }
-__device__ __forceinline__ double yield_F3(const jrx_rheology &rh, const double *r, double P, double tII)
-{   // compute_yieldfunction_phase, StressUpdate.jl:435-452 ; DP: F = τII - cosϕ C - sinϕ P
+__device__ __forceinline__ double yield_F3(const jrx_rheology &rh, const double *r, double P, double tII, double EII)
+{   // compute_yieldfunction_phase, StressUpdate.jl:435-452 ; DP: F = τII - cosϕ(EII) C(EII) - sinϕ(EII) P (softening at the EII keyword)
     double F = 0.0;
     for (int q = 0; q < rh.nphase; q++) {
         if (r[q] == 0.0) continue;
-        const double Fq = rh.is_pl[q] ? (tII - rh.cosphi[q] * rh.C[q] - rh.sinphi[q] * P) : tII;
+        double Fq = tII;
+        if (rh.is_pl[q]) {
+            double sp, cp;
+            mat_friction(rh, q, EII, sp, cp);
+            Fq = tII - cp * mat_cohesion(rh, q, EII) - sp * P;
+        }
         F += r[q] * Fq;
     }
     return F;
@@ -94,7 +101,8 @@ __device__ __forceinline__ void plastic_grad3(const jrx_rheology &rh, const doub
 // compute_∇V!, compute_P! (phase form: K, G per cell, η = ητ, P = θ) and compute_strain_rate! 3D over the ni.+1 box
 // (VelocityKernels.jl:3-6,59-104; PressureKernels.jl:47-106,186-195)
 // ML: compute_maxloc!(ητ, η) of the own cell first (clamped 3 x 3 x 3 window, the comparison order of k_maxloc) and store it
-template <bool ML>
+// RHO: update_ρg! of the own cell (phase-ratio density at args.T, args.P = stokes.P, times the scalar gravity, into ρg_z)
+template <bool ML, bool RHO = false>
 __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
         a.f.exx[c] = dxi - d3;
         a.f.eyy[c] = dyi - d3;
         a.f.ezz[c] = dzi - d3;
+        if (RHO) a.f.fz[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)a.rh.nphase * c, a.f.T ? a.f.T[c] : 0.0, a.f.P[c]) * a.rh.gravity;
     }
     if (i < nx) EYZ(a.f.eyz, i, j, k) = 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k)));
     if (j < ny) EXZ(a.f.exz, i, j, k) = 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k)));
@@ -163,13 +172,15 @@ __global__ __launch_bounds__(256) void k_vep3_visc(const Vep3Args a, double nu)
     a.f.eta[c] = fmin(fmax(e, a.cut_lo), a.cut_hi);
 }
 
-__global__ __launch_bounds__(256) void k_vep3_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const Vep3Args a)
+// rho: also compute_ρg!(ρg, phase_ratios, rheology, args) (Stokes3D.jl:505)
+__global__ __launch_bounds__(256) void k_vep3_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const Vep3Args a, const bool rho)
 {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (i64)a.nx * a.ny * a.nz) return;
     const double *r = a.f.phase_c + (i64)a.rh.nphase * c;
     Kc[c] = ratio_avg3(a.rh.Kb, r, a.rh.nphase);
     Gc[c] = ratio_avg3(a.rh.G, r, a.rh.nphase);
+    if (rho) a.f.fz[c] = mat_density_ratio(a.rh, r, a.f.T ? a.f.T[c] : 0.0, a.f.P[c]) * a.rh.gravity;
 }
 
 // Stencil tables of StressKernels.jl:604-668 for the edge families T = 0 (yz), 1 (xz), 2 (xy): entries pick the
@@ -196,7 +207,7 @@ __host__ __device__ constexpr int oth3(int t, int s, int q, int d)
 // cen[s][T]: the clamped 4-cell averages of the normal components (s = 0..2: ε, 3..5: τ, 6..8: τ_o) for family T, etav / Pv: harmonic η
 // and average θ, gathered once per node for the three families (vep3_gather_centres)
 struct CenAvg {
-    double v[9][3], etav[3], Pv[3];
+    double v[9][3], etav[3], Pv[3], EIIv[3];      // EIIv: av_clamped_yz/xz/xy(EII_pl) (StressKernels.jl:710,783,854), only gathered for softening laws
 };
 template <int T>
 __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, int k, const int ci[3], const int cj[3], const int ck[3], const CenAvg &C)
@@ -242,7 +253,7 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
     double dQdt[6], dQdP, dFdP;
     plastic_grad3(a.rh, rv, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
-    const double F = yield_F3(a.rh, rv, Pv, tIIv);
+    const double F = yield_F3(a.rh, rv, Pv, tIIv, C.EIIv[T]);
     constexpr int own = 3 + T;
     if (is_pl && tIIv != 0.0 && F > 0) {
         const double l = (1.0 - a.rel) * a.lamv[T][v] + a.rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol));
@@ -287,6 +298,13 @@ __device__ __forceinline__ void vep3_gather_centres(const Vep3Args &a, const int
         for (int b = 1; b < 8; b++) v[b] = 1 / LB(a.f.eta, cb[b]);
 #pragma unroll
         for (int T = 0; T < 3; T++) C.etav[T] = 4 / (v[CIDX(T, 0)] + v[CIDX(T, 1)] + v[CIDX(T, 2)] + v[CIDX(T, 3)]);
+        C.EIIv[0] = C.EIIv[1] = C.EIIv[2] = 0.0;
+        if (a.soft) {
+#pragma unroll
+            for (int b = 1; b < 8; b++) v[b] = LB(a.f.EII_pl, cb[b]);
+#pragma unroll
+            for (int T = 0; T < 3; T++) C.EIIv[T] = 0.25 * (v[CIDX(T, 0)] + v[CIDX(T, 1)] + v[CIDX(T, 2)] + v[CIDX(T, 3)]);
+        }
     }
 #undef CIDX
 #undef LB
@@ -370,7 +388,7 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
     plastic_grad3(a.rh, rc, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
     const double Pr = a.theta[c];
-    const double F = yield_F3(a.rh, rc, Pr, tII);
+    const double F = yield_F3(a.rh, rc, Pr, tII, a.soft ? a.f.EII_pl[c] : 0.0);
     double l = a.lam[c];
     if (is_pl && tII != 0.0 && F > 0) {
         l = (1.0 - a.rel) * l + a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol));
@@ -483,6 +501,7 @@ Vep3Args make_vep3(const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_
     a._dx = p->_dx; a._dy = p->_dy; a._dz = p->_dz; a.dt = p->dt; a.r = p->r; a.theta_dtau = p->theta_dtau; a.rel = p->lambda_relaxation;
     a.nu = p->viscosity_relaxation; a.cut_lo = p->cutoff_lo; a.cut_hi = p->cutoff_hi;
     a.nx = (int)p->nx; a.ny = (int)p->ny; a.nz = (int)p->nz;
+    a.soft = mat_has_softening(rh);
     return a;
 }
 
@@ -635,9 +654,17 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     JRX_HIP(h, hipMemcpyAsync(theta, f->P, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // θ = deepcopy(stokes.P)
     JRX_HIP(h, hipMemsetAsync(lam, 0, n * sizeof(double), s));
     JRX_HIP(h, hipMemsetAsync(a.lamv[0], 0, (size_t)(ne.yz + ne.xz + ne.xy) * sizeof(double), s));
-    hipLaunchKernelGGL(k_vep3_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a);
+    hipLaunchKernelGGL(k_vep3_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a, rh->has_density != 0);
     hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, 1.0);                              // compute_viscosity! :507
     JRX_LAUNCH_CHECK(h);
+    const bool upd_rho = rh->has_density && !mat_density_is_constant(rh);       // update_ρg!: a no-op for constant densities
+    const bool ubc = p->displacement_bcs != 0;
+    if (ubc) {    // displacement2velocity!(stokes, dt, flow_bcs) (Stokes3D.jl:509): V = U * inv(dt)
+        hipLaunchKernelGGL(k_scale3, dim3(2048), dim3(256), 0, s, f->Vx, (const double *)f->Ux, (i64)(nx + 1) * (ny + 2) * (nz + 2), f->Vy,
+                           (const double *)f->Uy, (i64)(nx + 2) * (ny + 1) * (nz + 2), f->Vz, (const double *)f->Uz, (i64)(nx + 2) * (ny + 2) * (nz + 1),
+                           1.0 / p->dt);
+        JRX_LAUNCH_CHECK(h);
+    }
 
     double err_it1 = 1.0, err = INFINITY;
     int64_t iter = 0, cont = 0;
@@ -658,8 +685,10 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             double *arrs[1] = {etatau};
             const int64_t ext[1][3] = {{nx, ny, nz}};
             JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
-            hipLaunchKernelGGL(k_vep3_pre<false>, gv, dim3(256), 0, s, a);
-        } else hipLaunchKernelGGL(k_vep3_pre<true>, gv, dim3(256), 0, s, a);        // compute_maxloc! folded in
+            if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<false, true>), gv, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(k_vep3_pre<false>, gv, dim3(256), 0, s, a);
+        } else if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true>), gv, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_vep3_pre<true>, gv, dim3(256), 0, s, a);        // compute_maxloc! folded in
         hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, p->viscosity_relaxation);
         JRX_LAUNCH_CHECK(h);
         JRX_TRY(launch_vep3_stress(h, s, a, p, false));
@@ -675,7 +704,9 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         }
         JRX_TRY(jrx3d_velocity_sweep(h, s, &g, etatau, &q, diag));
         if (diag) JRX_TRY(jrx3d_scaleU(h, s, &g, &q));
-        JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        // flow_bcs!: on V, or -- DisplacementBoundaryConditions -- on U = V dt, which the next iteration overwrites (only observable when U is)
+        if (!ubc) JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        else if (diag) JRX_TRY(jrx3d_bcs(h, s, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
         if (comm) {   // update_halo!(@velocity(stokes)...) (Stokes3D.jl:596); no overlap with the sweep in this driver yet
             double *arrs[3] = {f->Vx, f->Vy, f->Vz};
             const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
@@ -707,8 +738,18 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                 printf("iter = %lld, abs_err = %1.3e, rel_err = %1.3e [norm_Rx=%1.3e, norm_Ry=%1.3e, norm_Rz=%1.3e, norm_∇V=%1.3e] \n", (long long)iter,
                        err, err / err_it1, nRx, nRy, nRz, nDV);
             if (std::isnan(err)) {
-                res->iter = iter; res->nchecks = cont < res->cap ? cont : res->cap;
+                // error("NaN(s)"): the current edge stresses may live in the second set -- leave them in the caller's arrays, drain the stream
+                if (a.f.tyz != f->tyz) {
+                    (void)hipMemcpyAsync(f->tyz, a.f.tyz, (size_t)ne.yz * sizeof(double), hipMemcpyDeviceToDevice, s);
+                    (void)hipMemcpyAsync(f->txz, a.f.txz, (size_t)ne.xz * sizeof(double), hipMemcpyDeviceToDevice, s);
+                    (void)hipMemcpyAsync(f->txy, a.f.txy, (size_t)ne.xy * sizeof(double), hipMemcpyDeviceToDevice, s);
+                }
+                (void)hipEventRecord(t1, s);
                 (void)hipStreamSynchronize(s);
+                float msn = 0.f;
+                (void)hipEventElapsedTime(&msn, t0, t1);
+                res->iter = iter; res->nchecks = cont < res->cap ? cont : res->cap;
+                res->time_s = msn * 1e-3; res->av_time_s = iter > 1 ? res->time_s / (double)(iter - 1) : res->time_s;
                 return jrx_fail(h, JRX_ERR_NAN, "NaN(s)");
             }
         }

@@ -145,7 +145,9 @@ class _Hist:
 def rheology_table(phases) -> _lib.Rheology:
     """Per-phase material table for the C ABI.  `phases`: sequence of dict(eta, G, Kb[, C, phi_deg, psi_deg, eta_vp]) -- the
     LinearViscous / ConstantElasticity / DruckerPrager_regularised parameters of each GeoParams MaterialParams
-    (C is GeoParams' cohesion parameter, i.e. τ_y / cos ϕ in test_shearband2D.jl)."""
+    (C is GeoParams' cohesion parameter, i.e. τ_y / cos ϕ in test_shearband2D.jl) -- plus, optionally, `density` (ConstantDensity,
+    PT_Density, T_Density, Compressible_Density) and `g` (gravity of the first phase), `softening_C` / `softening_phi`
+    (LinearSoftening, NonLinearSoftening) and `creep` (Arrhenius law on top of eta): see jrx_rheology in include/jrx.h."""
     import math
     if isinstance(phases, _lib.Rheology):
         return phases
@@ -161,10 +163,55 @@ def rheology_table(phases) -> _lib.Rheology:
             r.C[q], r.eta_vp[q] = ph["C"], ph.get("eta_vp", 0.0)
             r.sinphi[q], r.cosphi[q] = math.sin(math.radians(ph["phi_deg"])), math.cos(math.radians(ph["phi_deg"]))
             r.sinpsi[q] = math.sin(math.radians(ph.get("psi_deg", 0.0)))
+        # density / gravity (compute_ρg!): ph["density"] = dict(kind="constant"|"PT"|"T"|"compressible", rho0[, alpha, beta, T0, P0]); ph["g"]
+        d = ph.get("density")
+        if d is not None:
+            r.has_density = 1
+            r.rho_kind[q] = {"constant": 0, "PT": 1, "T": 2, "compressible": 3}[d.get("kind", "constant")]
+            r.rho0[q], r.alpha[q], r.beta[q] = d["rho0"], d.get("alpha", 0.0), d.get("beta", 0.0)
+            r.T0[q], r.P0[q] = d.get("T0", 0.0), d.get("P0", 0.0)
+        if q == 0:
+            r.gravity = float(ph.get("g", 0.0))
+        # strain softening of C and ϕ: dict(kind="linear", min, max, lo, hi) | dict(kind="nonlinear", xi0, Delta[, mu=1, sigma=0.5])
+        r.phi_deg[q] = float(ph.get("phi_deg", 0.0))
+        for key, pre in (("softening_C", "softC_"), ("softening_phi", "softphi_")):
+            sft = ph.get(key)
+            if sft is None:
+                continue
+            if sft["kind"] == "linear":
+                vals = (1, sft["min"], sft["max"], sft["lo"], sft["hi"])
+            elif sft["kind"] == "nonlinear":
+                vals = (2, sft["xi0"], sft["Delta"], sft.get("mu", 1.0), sft.get("sigma", 0.5))
+            else:
+                raise ValueError(f"unknown softening law {sft['kind']!r}")
+            getattr(r, pre + "kind")[q] = vals[0]
+            for name, v in zip("abcd", vals[1:]):
+                getattr(r, pre + name)[q] = float(v)
+        # creep law: dict(kind="arrhenius", Ea, Va, T0, R, cutoff=(lo, hi)) on top of eta (= η0)
+        cr = ph.get("creep")
+        if cr is not None:
+            if cr.get("kind") != "arrhenius":
+                raise ValueError(f"unknown creep law {cr.get('kind')!r}")
+            r.visc_kind[q] = 1
+            r.Ea[q], r.Va[q], r.Tref[q], r.Rgas[q] = cr["Ea"], cr["Va"], cr["T0"], cr.get("R", 8.3145)
+            lo, hi = cr.get("cutoff", (0.0, float("inf")))
+            r.visc_lo[q], r.visc_hi[q] = lo, hi
     return r
 
 
-def vep_fields2d(stokes, ρg, phase_ratios) -> _lib.VEP2DFields:
+def _args_T(args):
+    """args.T of the reference's `args` NamedTuple (dict or namespace here); None when absent"""
+    if args is None:
+        return None
+    return args.get("T") if isinstance(args, dict) else getattr(args, "T", None)
+
+
+def _is_displacement(flow_bcs):
+    from .arrays import DisplacementBoundaryConditions
+    return isinstance(flow_bcs, DisplacementBoundaryConditions)
+
+
+def vep_fields2d(stokes, ρg, phase_ratios, args=None) -> _lib.VEP2DFields:
     s = stokes
     vals = dict(P=s.P, P0=s.P0, divV=s.divV, Q=s.Q, Vx=s.V.Vx, Vy=s.V.Vy, Ux=s.U.Ux, Uy=s.U.Uy,
                 exx=s.ε.xx, eyy=s.ε.yy, exy=s.ε.xy, exy_c=s.ε.xy_c,
@@ -173,7 +220,9 @@ def vep_fields2d(stokes, ρg, phase_ratios) -> _lib.VEP2DFields:
                 toxx=s.τ_o.xx, toyy=s.τ_o.yy, toxy=s.τ_o.xy, toxy_c=s.τ_o.xy_c,
                 eta=s.viscosity.η, eta_v=s.viscosity.ηv, eta_vep=s.viscosity.η_vep,
                 EII_pl=s.EII_pl, evol_pl=s.ε_vol_pl, EVol_pl=s.EVol_pl, fx=ρg[0], fy=ρg[1], RP=s.R.RP, Rx=s.R.Rx, Ry=s.R.Ry,
-                omega_xy=s.ω.xy, phase_c=phase_ratios.center, phase_v=phase_ratios.vertex)
+                omega_xy=s.ω.xy, phase_c=phase_ratios.center, phase_v=phase_ratios.vertex, T=_args_T(args))
+    if vals["T"] is not None and tuple(vals["T"].shape) != tuple(s._ni):
+        raise ValueError(f"args.T must be cell-centred {tuple(s._ni)} (thermal.Tc), got {tuple(vals['T'].shape)}")
     f = _lib.VEP2DFields()
     for n in _lib.VEP_NAMES:
         setattr(f, n, ptr(vals.get(n)))
@@ -184,8 +233,8 @@ def vep_fields2d(stokes, ρg, phase_ratios) -> _lib.VEP2DFields:
 def vep_params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=50.0e3, iterMin=1.0e2, nout=500, verbose=True, λ_relaxation=0.2,
                  viscosity_relaxation=1.0e-2, viscosity_cutoff=(-float("inf"), float("inf")), strain_increment=False,
                  free_surface=False, **_):
-    if strain_increment or free_surface:
-        raise NotImplementedError("strain_increment / free_surface variants of the VEP driver are not built (SURVEY §8f)")
+    if strain_increment:
+        raise NotImplementedError("the strain_increment variant of the VEP driver is not built (SURVEY §8f)")
     ni = stokes._ni
     _di = _center_inv(grid)
     p = _lib.VEP2DParams()
@@ -199,6 +248,8 @@ def vep_params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=50.0e3, iterMin=1.0e
     p.lambda_relaxation, p.viscosity_relaxation = float(λ_relaxation), float(viscosity_relaxation)
     p.cutoff_lo, p.cutoff_hi = float(viscosity_cutoff[0]), float(viscosity_cutoff[1])
     p.verbose = int(bool(verbose))
+    p.free_surface = int(bool(free_surface))
+    p.displacement_bcs = int(_is_displacement(flow_bcs))
     return p
 
 
@@ -207,7 +258,7 @@ def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology,
     if len(stokes._ni) == 3:
         return _solve_vep3d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h)
     p = vep_params2d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
-    f = vep_fields2d(stokes, ρg, phase_ratios)
+    f = vep_fields2d(stokes, ρg, phase_ratios, args)
     rh = rheology_table(rheology)
     hist = _Hist(int(p.iterMax // p.nout + 2))
     torch.cuda.current_stream(stokes.P.device).synchronize()
@@ -215,13 +266,13 @@ def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology,
     return hist.result(2)
 
 
-def vep_fields3d(stokes, ρg, phase_ratios) -> _lib.VEP3DFields:
+def vep_fields3d(stokes, ρg, phase_ratios, args=None) -> _lib.VEP3DFields:
     s = stokes
     vals = dict(P=s.P, P0=s.P0, divV=s.divV, Q=s.Q, Vx=s.V.Vx, Vy=s.V.Vy, Vz=s.V.Vz, Ux=s.U.Ux, Uy=s.U.Uy, Uz=s.U.Uz,
                 eta=s.viscosity.η, eta_vep=s.viscosity.η_vep, EII_pl=s.EII_pl, evol_pl=s.ε_vol_pl, EVol_pl=s.EVol_pl,
                 fx=ρg[0], fy=ρg[1], fz=ρg[2], RP=s.R.RP, Rx=s.R.Rx, Ry=s.R.Ry, Rz=s.R.Rz,
                 omega_yz=s.ω.yz, omega_xz=s.ω.xz, omega_xy=s.ω.xy, tII=s.τ.II,
-                phase_c=phase_ratios.center, phase_yz=phase_ratios.yz, phase_xz=phase_ratios.xz, phase_xy=phase_ratios.xy)
+                phase_c=phase_ratios.center, phase_yz=phase_ratios.yz, phase_xz=phase_ratios.xz, phase_xy=phase_ratios.xy, T=_args_T(args))
     for pre, T in (("e", s.ε), ("epl", s.ε_pl), ("t", s.τ), ("to", s.τ_o)):
         for c in ("xx", "yy", "zz", "yz", "xz", "xy"):
             vals[pre + c] = getattr(T, c)
@@ -251,13 +302,14 @@ def vep_params3d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10.0e3, nout=500, ve
     p.lambda_relaxation, p.viscosity_relaxation = float(λ_relaxation), float(viscosity_relaxation)
     p.cutoff_lo, p.cutoff_hi = float(viscosity_cutoff[0]), float(viscosity_cutoff[1])
     p.verbose = int(bool(verbose))
+    p.displacement_bcs = int(_is_displacement(flow_bcs))
     return p
 
 
 def _solve_vep3d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h):
     """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs) in 3D -- Stokes3D.jl:447-668"""
     p = vep_params3d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
-    f = vep_fields3d(stokes, ρg, phase_ratios)
+    f = vep_fields3d(stokes, ρg, phase_ratios, args)
     rh = rheology_table(rheology)
     hist = _Hist(int(p.iterMax // p.nout + 2))
     torch.cuda.current_stream(stokes.P.device).synchronize()

@@ -118,6 +118,8 @@ void orc_compute_strain_rate2d(const orc_fields2d *f, const orc_params2d *p);
 void orc_compute_tau2d(const orc_fields2d *f, const orc_params2d *p);
 void orc_compute_V2d(const orc_fields2d *f, const double *etatau, const orc_params2d *p);
 void orc_compute_Res2d(const orc_fields2d *f, const orc_params2d *p);
+void orc_compute_V2d_fs(const orc_fields2d *f, const double *etatau, const orc_params2d *p, double fs_dt);
+void orc_compute_Res2d_fs(const orc_fields2d *f, const orc_params2d *p, double fs_dt);
 void orc_velocity2displacement2d(const orc_fields2d *f, const orc_params2d *p);
 void orc_flow_bcs2d(double *Vx, double *Vy, int64_t nx, int64_t ny,
                     uint32_t free_slip, uint32_t no_slip, uint32_t periodic);
@@ -197,6 +199,27 @@ typedef struct orc_rheology {
     double eta[ORC_MAXPHASE], G[ORC_MAXPHASE], Kb[ORC_MAXPHASE];
     int32_t is_pl[ORC_MAXPHASE];
     double C[ORC_MAXPHASE], sinphi[ORC_MAXPHASE], cosphi[ORC_MAXPHASE], sinpsi[ORC_MAXPHASE], eta_vp[ORC_MAXPHASE];
+    /* ---- appended in round 2; a zero-initialised tail gives the round-1 behaviour (LinearViscous, NoSoftening, ρg owned by the caller) ----
+     * Density and gravity -- compute_ρg! / update_ρg! (rheology/BuoyancyForces.jl:37-60,153-167).  has_density = 0: the ρg arrays
+     * are the caller's and never recomputed.  rho_kind: 0 ConstantDensity(rho0), 1 PT_Density rho0 (1 - alpha (T - T0) + beta (P - P0)),
+     * 2 T_Density rho0 (1 - alpha (T - T0)), 3 Compressible_Density rho0 exp(beta (P - P0)) [GeoParams forms, assumed].
+     * gravity = compute_gravity(first(rheology)): a scalar, it fills the last component of ρg (BuoyancyForces.jl:69-70). */
+    int32_t has_density;
+    int32_t rho_kind[ORC_MAXPHASE];
+    double rho0[ORC_MAXPHASE], alpha[ORC_MAXPHASE], beta[ORC_MAXPHASE], T0[ORC_MAXPHASE], P0[ORC_MAXPHASE];
+    double gravity;
+    /* Strain softening of the cohesion and of the friction angle, evaluated at the accumulated plastic strain EII_pl (the EII keyword
+     * of compute_yieldfunction_phase, StressKernels.jl:1053-1105; GeoParams softening_C / softening_ϕ, forms assumed):
+     * kind 0 NoSoftening, 1 LinearSoftening((a = min, b = max), (c = lo, d = hi)): b for EII <= lo, a for EII >= hi, linear between;
+     * 2 NonLinearSoftening(a = ξ₀, b = Δ, c = μ, d = σ) = ξ₀ - Δ/2 erfc(-(EII - μ)/σ).  phi_deg is the unsoftened friction angle. */
+    int32_t softC_kind[ORC_MAXPHASE], softphi_kind[ORC_MAXPHASE];
+    double softC_a[ORC_MAXPHASE], softC_b[ORC_MAXPHASE], softC_c[ORC_MAXPHASE], softC_d[ORC_MAXPHASE];
+    double softphi_a[ORC_MAXPHASE], softphi_b[ORC_MAXPHASE], softphi_c[ORC_MAXPHASE], softphi_d[ORC_MAXPHASE], phi_deg[ORC_MAXPHASE];
+    /* Creep law of the viscous element for compute_viscosity! / compute_viscosity_τII! with dt = Inf (rheology/Viscosity.jl:142-167):
+     * visc_kind 0 LinearViscous(eta); 1 Arrhenius: eta exp((Ea + P Va)/(Rgas T) - Ea/(Rgas Tref)), clamped to [visc_lo, visc_hi]
+     * (the CustomRheology of test/test_WENO5.jl:37-42 with depth = 0) */
+    int32_t visc_kind[ORC_MAXPHASE];
+    double Ea[ORC_MAXPHASE], Va[ORC_MAXPHASE], Tref[ORC_MAXPHASE], Rgas[ORC_MAXPHASE], visc_lo[ORC_MAXPHASE], visc_hi[ORC_MAXPHASE];
 } orc_rheology;
 
 typedef struct orc_vep2d {
@@ -214,6 +237,7 @@ typedef struct orc_vep2d {
     double *RP, *Rx, *Ry;
     double *omega_xy;                       /* ni.+1 */
     double *phase_c, *phase_v;              /* [nphase][nx][ny] and [nphase][nx+1][ny+1], phase index fastest (CellArray) */
+    const double *T;                        /* args.T at the cell centres (ni) for the density laws; may be NULL (T = 0) */
 } orc_vep2d;
 
 typedef struct orc_vep_params2d {
@@ -224,6 +248,8 @@ typedef struct orc_vep_params2d {
     uint32_t free_slip, no_slip, periodic;
     double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
     int32_t staggered_invariant_mean_of_squares;  /* 0: (mean xy)^2 ; 1: mean(xy^2)  -- GeoParams second_invariant_staggered */
+    int32_t free_surface;                         /* kwarg free_surface: compute_V! / compute_Res! get dt * free_surface (Stokes2D.jl:773,797) */
+    int32_t displacement_bcs;                     /* flow_bcs is a DisplacementBoundaryConditions: V = U / dt first, flow_bcs! acts on U (BoundaryConditions.jl:71-78) */
 } orc_vep_params2d;
 
 int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res);
@@ -256,6 +282,7 @@ typedef struct orc_vep3d {
     double *RP, *Rx, *Ry, *Rz;
     double *omega_yz, *omega_xz, *omega_xy;             /* edge extents */
     double *phase_c, *phase_yz, *phase_xz, *phase_xy;   /* [nphase][extent], phase index fastest (CellArray) */
+    const double *T;                                    /* args.T at the cell centres (ni); may be NULL (T = 0) */
 } orc_vep3d;
 
 typedef struct orc_vep_params3d {
@@ -265,6 +292,7 @@ typedef struct orc_vep_params3d {
     int64_t iterMax, nout;
     uint32_t free_slip, no_slip, periodic;
     double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
+    int32_t displacement_bcs;
 } orc_vep_params3d;
 
 int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, orc_result *res);

@@ -352,14 +352,20 @@ def num_threads() -> int:
 # ---------------------------------------------------------------- 2D multiphase VEP (shear band)
 VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
              "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
-             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v"]
+             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v", "T"]
 VEP2D = _mkstruct("VEP2D", VEP_NAMES)
 MAXPHASE = 8
 
 
 class Rheology(C.Structure):
     _fields_ = [("nphase", C.c_int32)] + [(k, C.c_double * MAXPHASE) for k in ("eta", "G", "Kb")] + [("is_pl", C.c_int32 * MAXPHASE)] + \
-               [(k, C.c_double * MAXPHASE) for k in ("C", "sinphi", "cosphi", "sinpsi", "eta_vp")]
+               [(k, C.c_double * MAXPHASE) for k in ("C", "sinphi", "cosphi", "sinpsi", "eta_vp")] + \
+               [("has_density", C.c_int32), ("rho_kind", C.c_int32 * MAXPHASE)] + \
+               [(k, C.c_double * MAXPHASE) for k in ("rho0", "alpha", "beta", "T0", "P0")] + [("gravity", C.c_double)] + \
+               [("softC_kind", C.c_int32 * MAXPHASE), ("softphi_kind", C.c_int32 * MAXPHASE)] + \
+               [(k, C.c_double * MAXPHASE) for k in ("softC_a", "softC_b", "softC_c", "softC_d", "softphi_a", "softphi_b", "softphi_c",
+                                                     "softphi_d", "phi_deg")] + \
+               [("visc_kind", C.c_int32 * MAXPHASE)] + [(k, C.c_double * MAXPHASE) for k in ("Ea", "Va", "Tref", "Rgas", "visc_lo", "visc_hi")]
 
 
 class VEPParams2D(C.Structure):
@@ -368,7 +374,7 @@ class VEPParams2D(C.Structure):
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("iterMin", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
-                ("staggered_invariant_mean_of_squares", C.c_int32)]
+                ("staggered_invariant_mean_of_squares", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32)]
 
 
 def vep_shapes2d(nx, ny, nphase):
@@ -392,15 +398,49 @@ def rheology_struct(phases: list) -> Rheology:
             r.C[q], r.eta_vp[q] = ph["C"], ph.get("eta_vp", 0.0)
             r.sinphi[q], r.cosphi[q] = math.sin(math.radians(ph["phi_deg"])), math.cos(math.radians(ph["phi_deg"]))
             r.sinpsi[q] = math.sin(math.radians(ph.get("psi_deg", 0.0)))
+        # density / gravity (compute_ρg!): ph["density"] = dict(kind="constant"|"PT"|"T"|"compressible", rho0[, alpha, beta, T0, P0]); ph["g"]
+        d = ph.get("density")
+        if d is not None:
+            r.has_density = 1
+            r.rho_kind[q] = {"constant": 0, "PT": 1, "T": 2, "compressible": 3}[d.get("kind", "constant")]
+            r.rho0[q], r.alpha[q], r.beta[q] = d["rho0"], d.get("alpha", 0.0), d.get("beta", 0.0)
+            r.T0[q], r.P0[q] = d.get("T0", 0.0), d.get("P0", 0.0)
+        if q == 0:
+            r.gravity = float(ph.get("g", 0.0))
+        # strain softening of C and ϕ: dict(kind="linear", min, max, lo, hi) | dict(kind="nonlinear", xi0, Delta[, mu=1, sigma=0.5])
+        r.phi_deg[q] = float(ph.get("phi_deg", 0.0))
+        for key, pre in (("softening_C", "softC_"), ("softening_phi", "softphi_")):
+            sft = ph.get(key)
+            if sft is None:
+                continue
+            if sft["kind"] == "linear":
+                vals = (1, sft["min"], sft["max"], sft["lo"], sft["hi"])
+            elif sft["kind"] == "nonlinear":
+                vals = (2, sft["xi0"], sft["Delta"], sft.get("mu", 1.0), sft.get("sigma", 0.5))
+            else:
+                raise ValueError(f"unknown softening law {sft['kind']!r}")
+            getattr(r, pre + "kind")[q] = vals[0]
+            for name, v in zip("abcd", vals[1:]):
+                getattr(r, pre + name)[q] = float(v)
+        # creep law: dict(kind="arrhenius", Ea, Va, T0, R, cutoff=(lo, hi)) on top of eta (= η0)
+        cr = ph.get("creep")
+        if cr is not None:
+            if cr.get("kind") != "arrhenius":
+                raise ValueError(f"unknown creep law {cr.get('kind')!r}")
+            r.visc_kind[q] = 1
+            r.Ea[q], r.Va[q], r.Tref[q], r.Rgas[q] = cr["Ea"], cr["Va"], cr["T0"], cr.get("R", 8.3145)
+            lo, hi = cr.get("cutoff", (0.0, float("inf")))
+            r.visc_lo[q], r.visc_hi[q] = lo, hi
     return r
 
 
 def vep_params2d(ni, _di, dt, pt, *, iterMax=50_000, iterMin=100, nout=500, free_slip=None, no_slip=None, periodic=None,
-                 lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), stag_mode=0, ni_g=None) -> VEPParams2D:
+                 lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), stag_mode=0, ni_g=None, free_surface=False,
+                 displacement_bcs=False) -> VEPParams2D:
     ni_g = ni_g or ni
     return VEPParams2D(ni[0], ni[1], ni_g[0], ni_g[1], _di[0], _di[1], dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"], pt["eps_rel"],
                        pt["eps_abs"], int(iterMax), int(iterMin), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic),
-                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1], stag_mode)
+                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1], stag_mode, int(bool(free_surface)), int(bool(displacement_bcs)))
 
 
 def vep2d(arr: dict) -> VEP2D:
@@ -438,7 +478,7 @@ VEP3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",
               "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII",
               "toxx", "toyy", "tozz", "toyz", "toxz", "toxy", "toyz_c", "toxz_c", "toxy_c",
               "eta", "eta_vep", "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "fz", "RP", "Rx", "Ry", "Rz",
-              "omega_yz", "omega_xz", "omega_xy", "phase_c", "phase_yz", "phase_xz", "phase_xy"]
+              "omega_yz", "omega_xz", "omega_xy", "phase_c", "phase_yz", "phase_xz", "phase_xy", "T"]
 VEP3D = _mkstruct("VEP3D", VEP3_NAMES)
 
 
@@ -448,7 +488,8 @@ class VEPParams3D(C.Structure):
                 ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
-                ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double)]
+                ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
+                ("displacement_bcs", C.c_int32)]
 
 
 def vep_shapes3d(nx, ny, nz, nphase):
@@ -465,11 +506,11 @@ def vep_shapes3d(nx, ny, nz, nphase):
 
 
 def vep_params3d(ni, _di, dt, pt, *, iterMax=10_000, nout=500, free_slip=None, no_slip=None, periodic=None,
-                 lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), ni_g=None) -> VEPParams3D:
+                 lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), ni_g=None, displacement_bcs=False) -> VEPParams3D:
     ni_g = ni_g or ni
     return VEPParams3D(ni[0], ni[1], ni[2], ni_g[0], ni_g[1], ni_g[2], _di[0], _di[1], _di[2], dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"],
                        pt["eps_rel"], pt["eps_abs"], int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic),
-                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1])
+                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1], int(bool(displacement_bcs)))
 
 
 def vep3d(arr: dict) -> VEP3D:

@@ -74,7 +74,10 @@ void orc_compute_tau2d(const orc_fields2d *f, const orc_params2d *p)
 }
 
 /* src/stokes/VelocityKernels.jl:108-131 */
-void orc_compute_V2d(const orc_fields2d *f, const double *etatau, const orc_params2d *p)
+void orc_compute_V2d(const orc_fields2d *f, const double *etatau, const orc_params2d *p) { orc_compute_V2d_fs(f, etatau, p, 0.0); }
+
+/* free-surface form (VelocityKernels.jl:134-180): fs_dt = dt * free_surface; the vertical momentum gets Vy ∂(ρg_y)/∂y θ dt (θ = 1) */
+void orc_compute_V2d_fs(const orc_fields2d *f, const double *etatau, const orc_params2d *p, double fs_dt)
 {
     const int64_t nx = p->nx, ny = p->ny;
     const double _dx = p->_dx, _dy = p->_dy, edt = p->eta_dtau;
@@ -93,13 +96,21 @@ void orc_compute_V2d(const orc_fields2d *f, const double *etatau, const orc_para
                 double r = -((-C(P, i, j) + C(P, i, j + 1)) * _dy) + (-C(f->tyy, i, j) + C(f->tyy, i, j + 1)) * _dy +
                            (-XY(f->txy, i, j + 1) + XY(f->txy, i + 1, j + 1)) * _dx -
                            (C(f->fy, i, j) + C(f->fy, i, j + 1)) * 0.5;
+                if (fs_dt != 0.0) {
+                    const int64_t jN = j + 1 < ny - 1 ? j + 1 : ny - 1;            /* j_N = min(j + 1, ny) */
+                    const double drg = (C(f->fy, i, jN) - C(f->fy, i, j)) * _dy;
+                    r += VY(i + 1, j + 1) * drg * 1.0 * fs_dt;
+                }
                 VY(i + 1, j + 1) += r * edt / ((C(etatau, i, j) + C(etatau, i, j + 1)) * 0.5);
             }
         }
 }
 
 /* src/stokes/VelocityKernels.jl:246-269 */
-void orc_compute_Res2d(const orc_fields2d *f, const orc_params2d *p)
+void orc_compute_Res2d(const orc_fields2d *f, const orc_params2d *p) { orc_compute_Res2d_fs(f, p, 0.0); }
+
+/* free-surface form (VelocityKernels.jl:271-307) */
+void orc_compute_Res2d_fs(const orc_fields2d *f, const orc_params2d *p, double fs_dt)
 {
     const int64_t nx = p->nx, ny = p->ny;
     const double _dx = p->_dx, _dy = p->_dy;
@@ -111,10 +122,17 @@ void orc_compute_Res2d(const orc_fields2d *f, const orc_params2d *p)
                 f->Rx[IDX2(nx - 1, i, j)] = (-C(f->txx, i, j) + C(f->txx, i + 1, j)) * _dx +
                                             (-XY(f->txy, i + 1, j) + XY(f->txy, i + 1, j + 1)) * _dy -
                                             (-C(P, i, j) + C(P, i + 1, j)) * _dx - (C(f->fx, i, j) + C(f->fx, i + 1, j)) * 0.5;
-            if (j < ny - 1)
-                f->Ry[IDX2(nx, i, j)] = (-C(f->tyy, i, j) + C(f->tyy, i, j + 1)) * _dy +
-                                        (-XY(f->txy, i, j + 1) + XY(f->txy, i + 1, j + 1)) * _dx -
-                                        (-C(P, i, j) + C(P, i, j + 1)) * _dy - (C(f->fy, i, j) + C(f->fy, i, j + 1)) * 0.5;
+            if (j < ny - 1) {
+                double r = (-C(f->tyy, i, j) + C(f->tyy, i, j + 1)) * _dy +
+                           (-XY(f->txy, i, j + 1) + XY(f->txy, i + 1, j + 1)) * _dx -
+                           (-C(P, i, j) + C(P, i, j + 1)) * _dy - (C(f->fy, i, j) + C(f->fy, i, j + 1)) * 0.5;
+                if (fs_dt != 0.0) {
+                    const int64_t jN = j + 1 < ny - 1 ? j + 1 : ny - 1;
+                    const double drg = (C(f->fy, i, jN) - C(f->fy, i, j)) * _dy;
+                    r += (f->Vy[IDX2(nx + 2, i + 1, j + 1)] * drg) * 1.0 * fs_dt;
+                }
+                f->Ry[IDX2(nx, i, j)] = r;
+            }
         }
 }
 

@@ -17,6 +17,7 @@
  * centre stresses, then the centre pass (what a GPU launch does when all loads precede the stores). */
 #include "jrx_oracle.h"
 #include "common.h"
+#include "material.h"
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
@@ -51,12 +52,17 @@ static inline void plastic_params(const orc_rheology *rh, const double *r, int *
 }
 
 /* compute_yieldfunction_phase (StressUpdate.jl:399-410): sum_i r_i F_i, non-plastic phases contribute tauII */
-static inline double yield_F(const orc_rheology *rh, const double *r, double P, double tII)
+static inline double yield_F(const orc_rheology *rh, const double *r, double P, double tII, double EII)
 {
     double F = 0.0;
     for (int q = 0; q < rh->nphase; q++) {
         if (r[q] == 0.0) continue;
-        double Fq = rh->is_pl[q] ? (tII - rh->cosphi[q] * rh->C[q] - rh->sinphi[q] * P) : tII;
+        double Fq = tII;
+        if (rh->is_pl[q]) {
+            double sp, cp;
+            mat_friction(rh, q, EII, &sp, &cp);                       /* softening_ϕ / softening_C at the EII keyword */
+            Fq = tII - cp * mat_cohesion(rh, q, EII) - sp * P;
+        }
         F += r[q] * Fq;
     }
     return F;
@@ -108,7 +114,8 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
             double dQdt[3], dQdP, dFdP;
             plastic_grad(rh, rv, tt, dQdt, &dQdP, &dFdP);
             const double vol = isinf(Kv) ? 0.0 : Kv * dt * dFdP * dQdP;
-            const double F = yield_F(rh, rv, Pv, tIIv);
+            const double EIIv = AVC(f->EII_pl);                        /* EIIv_ij = av_clamped(EII, Ic...) :1030 */
+            const double F = yield_F(rh, rv, Pv, tIIv, EIIv);
             if (is_pl && tIIv != 0.0 && F > 0) {
                 lamv[v] = fma(1.0 - rel, lamv[v], rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol)));
                 const double epl = lamv[v] * dQdt[2];
@@ -143,7 +150,7 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
             plastic_grad(rh, rc, tt, dQdt, &dQdP, &dFdP);
             const double vol = isinf(K) ? 0.0 : K * dt * dFdP * dQdP;
             const double Pr = theta[c];
-            const double F = yield_F(rh, rc, Pr, tII);
+            const double F = yield_F(rh, rc, Pr, tII, f->EII_pl[c]);
             if (is_pl && tII != 0.0 && F > 0) {
                 lam[c] = fma(1.0 - rel, lam[c], rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol)));
                 double epl[3];
@@ -238,7 +245,7 @@ void orc_center2vertex2d(double *v, const double *c, int64_t nx, int64_t ny)
 }
 
 /* scalar entry points for the known-answer tests of test/test_Utils.jl:399-470 */
-double orc_yieldfunction_phase(const orc_rheology *rh, const double *ratio, double P, double tII) { return yield_F(rh, ratio, P, tII); }
+double orc_yieldfunction_phase(const orc_rheology *rh, const double *ratio, double P, double tII) { return yield_F(rh, ratio, P, tII, 0.0); }
 void orc_plastic_gradients_phase2d(const orc_rheology *rh, const double *ratio, const double t[3], double dQdt[3], double *dQdP, double *dFdP)
 {
     plastic_grad(rh, ratio, t, dQdt, dQdP, dFdP);
@@ -324,6 +331,18 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
     q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
     q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
 
+    /* compute_ρg!(ρg, phase_ratios, rheology, args) :646 -- scalar gravity fills the last component (BuoyancyForces.jl:69-70) */
+    const int upd_rho = rh->has_density && !mat_density_is_constant(rh);
+    if (rh->has_density)
+        for (size_t c = 0; c < n; c++) f->fy[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
+    /* displacement2velocity!(stokes, dt, flow_bcs) :647 -- V = U * inv(dt) for DisplacementBoundaryConditions only */
+    if (p->displacement_bcs) {
+        const double _dt = inv(p->dt);
+        for (size_t c = 0; c < (size_t)(nx + 1) * (ny + 2); c++) f->Vx[c] = f->Ux[c] * _dt;
+        for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 1); c++) f->Vy[c] = f->Uy[c] * _dt;
+    }
+    const double fs_dt = p->dt * (double)(p->free_surface != 0);
+
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
     res->status = 0;
@@ -333,20 +352,23 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
         { const int64_t e[3] = {nx, ny, 1}; orc_self_halo(etatau, e, e); }                               /* update_halo!(ητ) :655 */
         orc_compute_divV2d(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy);
         orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :663-676 */
+        if (upd_rho)                                    /* update_ρg!(ρg, phase_ratios, rheology, args) :678 ; args.P is stokes.P */
+            for (size_t c = 0; c < n; c++) f->fy[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
         orc_compute_strain_rate2d(&g, &q);
         orc_vep2d_stress(f, theta, lam, lamv, rh, p);
         { const int64_t e[3] = {nx + 1, ny + 1, 1}, nn[3] = {nx, ny, 1}; orc_self_halo(f->txy, e, nn); }    /* update_halo!(τ.xy) :757 */
         orc_compute_viscosity2d(f, rh, p, p->viscosity_relaxation);
-        orc_compute_V2d(&g, etatau, &q);             /* free-surface form with dt*free_surface = 0 reduces to the plain one */
+        orc_compute_V2d_fs(&g, etatau, &q, fs_dt);   /* free-surface form; with dt*free_surface = 0 it reduces to the plain one */
         orc_velocity2displacement2d(&g, &q);
-        orc_flow_bcs2d(f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic);
+        if (p->displacement_bcs) orc_flow_bcs2d(f->Ux, f->Uy, nx, ny, p->free_slip, p->no_slip, p->periodic);   /* flow_bcs! on @displacement */
+        else orc_flow_bcs2d(f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic);
         {   /* update_halo!(@velocity(stokes)...) :784 */
             const int64_t nn[3] = {nx, ny, 1}, ex[3] = {nx + 1, ny + 2, 1}, ey[3] = {nx + 2, ny + 1, 1};
             orc_self_halo(f->Vx, ex, nn); orc_self_halo(f->Vy, ey, nn);
         }
         iter += 1;
         if (iter % p->nout == 0 && iter > 1) {
-            orc_compute_Res2d(&g, &q);
+            orc_compute_Res2d_fs(&g, &q, fs_dt);
             double s[3];
             orc_residual_sumsq2d(&g, &q, s);
             const double nRx = sqrt(s[0]) / sqrt((double)((p->nxg - 2) * (p->nyg - 1)));
@@ -384,3 +406,6 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
     free(etatau); free(theta); free(lam); free(lamv); free(Kc); free(Gc);
     return res->status;
 }
+
+/* test hook: the softening laws of material.h */
+double orc_soften(int32_t kind, double a, double b, double c, double d, double EII, double v0) { return mat_soften(kind, a, b, c, d, EII, v0); }

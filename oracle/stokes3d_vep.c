@@ -17,6 +17,7 @@
  * the three edge passes, and the centre pass runs last. */
 #include "jrx_oracle.h"
 #include "common.h"
+#include "material.h"
 #include <stdlib.h>
 #include <string.h>
 #include <omp.h>
@@ -62,12 +63,17 @@ static inline void plastic_params(const orc_rheology *rh, const double *r, int *
     for (int q = 0; q < rh->nphase; q++)
         if (rh->is_pl[q]) { *is_pl = 1; *eta_reg += rh->eta_vp[q] * r[q]; }
 }
-static inline double yield_F(const orc_rheology *rh, const double *r, double P, double tII)
-{   /* compute_yieldfunction_phase (StressUpdate.jl:435-452) */
+static inline double yield_F(const orc_rheology *rh, const double *r, double P, double tII, double EII)
+{   /* compute_yieldfunction_phase (StressUpdate.jl:435-452); softening laws evaluated at the EII keyword */
     double F = 0.0;
     for (int q = 0; q < rh->nphase; q++) {
         if (r[q] == 0.0) continue;
-        double Fq = rh->is_pl[q] ? (tII - rh->cosphi[q] * rh->C[q] - rh->sinphi[q] * P) : tII;
+        double Fq = tII;
+        if (rh->is_pl[q]) {
+            double sp, cp;
+            mat_friction(rh, q, EII, &sp, &cp);
+            Fq = tII - cp * mat_cohesion(rh, q, EII) - sp * P;
+        }
         F += r[q] * Fq;
     }
     return F;
@@ -165,7 +171,7 @@ void orc_vep3d_stress(const orc_vep3d *f, const double *theta, double *lam, doub
                     double dQdt[6], dQdP, dFdP;
                     plastic_grad(rh, rv, tt, dQdt, &dQdP, &dFdP);
                     const double vol = isinf(Kv) ? 0.0 : Kv * dt * dFdP * dQdP;
-                    const double F = yield_F(rh, rv, Pv, tIIv);
+                    const double F = yield_F(rh, rv, Pv, tIIv, AVC(f->EII_pl));      /* EIIv_ij = av_clamped_yz/xz/xy(EII, Ic...) :710,783,854 */
                     const int own = 3 + t;
                     if (is_pl && tIIv != 0.0 && F > 0) {
                         lamv[t][v] = (1.0 - rel) * lamv[t][v] + rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol));
@@ -229,7 +235,7 @@ void orc_vep3d_stress(const orc_vep3d *f, const double *theta, double *lam, doub
                 plastic_grad(rh, rc, tt, dQdt, &dQdP, &dFdP);
                 const double vol = isinf(K) ? 0.0 : K * dt * dFdP * dQdP;
                 const double Pr = theta[c];
-                const double F = yield_F(rh, rc, Pr, tII);
+                const double F = yield_F(rh, rc, Pr, tII, f->EII_pl[c]);
                 if (is_pl && tII != 0.0 && F > 0) {
                     lam[c] = (1.0 - rel) * lam[c] + rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol));
                     double epl[6];
@@ -347,7 +353,17 @@ int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const
     memcpy(f->P0, f->P, n * 8);                       /* @copy stokes.P0 stokes.P :494 */
     memcpy(theta, f->P, n * 8);                       /* θ = deepcopy(stokes.P) :495 */
     for (size_t c = 0; c < n; c++) { Kc[c] = ratio_avg(rh->Kb, f->phase_c + np * c, np); Gc[c] = ratio_avg(rh->G, f->phase_c + np * c, np); }
+    /* compute_ρg!(ρg, phase_ratios, rheology, args) :505 -- the scalar gravity fills the last component (BuoyancyForces.jl:69-70) */
+    const int upd_rho = rh->has_density && !mat_density_is_constant(rh);
+    if (rh->has_density)
+        for (size_t c = 0; c < n; c++) f->fz[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
     orc_compute_viscosity3d(f, rh, p, 1.0);           /* compute_viscosity!(stokes, phase_ratios, args, rheology, cutoff) :507 */
+    if (p->displacement_bcs) {                        /* displacement2velocity!(stokes, dt, flow_bcs) :509 */
+        const double _dt = inv(p->dt);
+        for (size_t c = 0; c < (size_t)(nx + 1) * (ny + 2) * (nz + 2); c++) f->Vx[c] = f->Ux[c] * _dt;
+        for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 1) * (nz + 2); c++) f->Vy[c] = f->Uy[c] * _dt;
+        for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 2) * (nz + 1); c++) f->Vz[c] = f->Uz[c] * _dt;
+    }
 
     orc_fields3d g;
     memset(&g, 0, sizeof(g));
@@ -370,6 +386,8 @@ int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const
         orc_compute_divV3d(f->divV, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->_dx, p->_dy, p->_dz);
         orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :520-533 */
         orc_compute_strain_rate3d(&g, &q);
+        if (upd_rho)                                  /* update_ρg!(ρg, phase_ratios, rheology, args) :538 ; args.P is stokes.P */
+            for (size_t c = 0; c < n; c++) f->fz[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
         orc_compute_viscosity3d(f, rh, p, p->viscosity_relaxation);
         orc_vep3d_stress(f, theta, lam, lamv, rh, p);
         {   /* update_halo!(τ.yz), (τ.xz), (τ.xy) :578-580 */
@@ -379,7 +397,8 @@ int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const
         }
         orc_compute_V3d(&g, etatau, &q);
         orc_velocity2displacement3d(&g, &q);
-        orc_flow_bcs3d(f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic);
+        if (p->displacement_bcs) orc_flow_bcs3d(f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic);   /* flow_bcs! on @displacement */
+        else orc_flow_bcs3d(f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic);
         {   /* update_halo!(@velocity(stokes)...) :596 */
             const int64_t nn[3] = {nx, ny, nz};
             const int64_t ex[3] = {nx + 1, ny + 2, nz + 2}, ey[3] = {nx + 2, ny + 1, nz + 2}, ez[3] = {nx + 2, ny + 2, nz + 1};

@@ -1,0 +1,154 @@
+"""GPU parity tests of the round-2 extensions of the VEP drivers against the CPU oracle:
+  * compute_ρg! / update_ρg! with T- and P-dependent densities (rheology/BuoyancyForces.jl:37-60,153-167; Stokes2D.jl:646,678; Stokes3D.jl:505,538)
+  * strain softening of C and ϕ at EII_pl (rheology/StressUpdate.jl:305-381; the EII keyword of StressKernels.jl:1053-1105)
+  * DisplacementBoundaryConditions (displacement2velocity! at the start, flow_bcs! on U; BoundaryConditions.jl:71-78)
+  * the free_surface form of compute_V! / compute_Res! (VelocityKernels.jl:134-180,271-307)
+The GeoParams forms behind density and softening are ASSUMED (include/jrx.h): these tests pin HIP path == oracle, not the formulas.
+Tolerance 1e-9 after tens of iterations (exp / erfc / sin of the device library differ from glibc in the last bits)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cp(a):
+    return {k: v.copy(order="F") for k, v in a.items()}
+
+
+def _phases_rho(phases, *, g=9.81):
+    out = [dict(p) for p in phases]
+    out[0].update(density=dict(kind="PT", rho0=3.3, alpha=2.0e-2, beta=1.0e-2, T0=0.5, P0=0.1), g=g)
+    out[1].update(density=dict(kind="compressible", rho0=2.7, beta=3.0e-2, P0=0.0))
+    return out
+
+
+def _phases_soft(phases):
+    out = [dict(p) for p in phases]
+    out[0].update(softening_C=dict(kind="linear", min=0.4 * out[0]["C"], max=out[0]["C"], lo=0.02, hi=0.3),
+                  softening_phi=dict(kind="nonlinear", xi0=30.0, Delta=10.0, mu=0.2, sigma=0.1))
+    out[1].update(softening_C=dict(kind="nonlinear", xi0=out[1]["C"], Delta=0.5 * out[1]["C"], mu=0.1, sigma=0.05))
+    return out
+
+
+def test_vep2d_density_update_matches_oracle(jr, oracle):
+    from justrelax_jl_amd.checks import max_rel_diff
+    from justrelax_jl_amd.arrays import from_numpy
+    from test_gpu_vep2d import _download, _upload, _vep_params
+    s = jr.miniapps.shearband2d(40, iterMax=60, nout=20)
+    s.kwargs.update(iterMin=10)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    rng = np.random.default_rng(5)
+    s.arrays["T"] = np.asfortranarray(rng.uniform(0.0, 2.0, size=s.ni))
+    s.arrays["fy"][...] = 123.0                     # compute_ρg! must overwrite the caller's values
+    phases = _phases_rho(s.extra["phases"], g=0.3)
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes2d_vep_solve(ref, oracle.rheology_struct(phases), _vep_params(oracle, s, iterMin=10))
+    stokes, pr, ρg = _upload(jr, s)
+    T = from_numpy(s.arrays["T"], stokes.P.device)
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, phases, dict(T=T, P=stokes.P), s.dt, None, kwargs=s.kwargs)
+    assert r.iter == r_ref["iter"] == 61
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-9)
+    assert np.ptp(ref["fy"]) > 0 and not (ref["fy"] == 123.0).any()          # the density really varies and was recomputed
+    assert max_rel_diff(jr.to_numpy(ρg[1]), ref["fy"]) <= 1e-12
+    out = _download(jr, stokes)
+    for k in out:
+        assert max_rel_diff(out[k], ref[k]) <= 1e-9, k
+
+
+def test_vep2d_softening_stress_update_matches_oracle(jr, oracle):
+    """update_stresses_center_vertex_ps! with LinearSoftening / NonLinearSoftening laws and a non-trivial EII_pl field"""
+    import torch
+    from justrelax_jl_amd import _lib, stokes as st_mod
+    from justrelax_jl_amd.arrays import from_numpy
+    from justrelax_jl_amd.checks import max_rel_diff
+    from test_gpu_vep2d import _download, _randomize, _upload, _vep_params
+    s = jr.miniapps.shearband2d(24)
+    _randomize(s)
+    rng = np.random.default_rng(11)
+    s.arrays["EII_pl"][...] = rng.uniform(0.0, 0.4, size=s.ni)
+    phases = _phases_soft(s.extra["phases"])
+    rh, p = oracle.rheology_struct(phases), _vep_params(oracle, s)
+    ref = _cp(s.arrays)
+    theta = np.asfortranarray(rng.uniform(-1, 1, size=s.ni))
+    lam = np.asfortranarray(rng.uniform(0, 0.1, size=s.ni))
+    lamv = np.asfortranarray(rng.uniform(0, 0.1, size=(s.ni[0] + 1, s.ni[1] + 1)))
+    lam_r, lamv_r = lam.copy(order="F"), lamv.copy(order="F")
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    f = oracle.vep2d(ref)
+    oracle.lib().orc_vep2d_stress(C.byref(f), dp(theta), dp(lam_r), dp(lamv_r), C.byref(rh), C.byref(p))
+    # the same call without softening gives different stresses: the laws act
+    ref0, lam0, lamv0 = _cp(s.arrays), lam.copy(order="F"), lamv.copy(order="F")
+    f0 = oracle.vep2d(ref0)
+    oracle.lib().orc_vep2d_stress(C.byref(f0), dp(theta), dp(lam0), dp(lamv0), C.byref(oracle.rheology_struct(s.extra["phases"])), C.byref(p))
+    assert np.abs(ref["txx"] - ref0["txx"]).max() > 1e-3
+    stokes, pr, ρg = _upload(jr, s)
+    dev = stokes.P.device
+    th_d, lam_d, lamv_d = from_numpy(theta, dev), from_numpy(lam, dev), from_numpy(lamv, dev)
+    h = _lib.default_handle()
+    fd = st_mod.vep_fields2d(stokes, ρg, pr)
+    pd = st_mod.vep_params2d(stokes, s.pt, s.grid, s.flow_bcs, s.dt)
+    h.call("jrx_vep2d_update_stresses", C.byref(fd), C.c_void_p(th_d.data_ptr()), C.c_void_p(lam_d.data_ptr()), C.c_void_p(lamv_d.data_ptr()),
+           C.byref(st_mod.rheology_table(phases)), C.byref(pd))
+    out = _download(jr, stokes)
+    for k in ("txx", "tyy", "txy", "txy_c", "tII", "eta_vep", "P", "eplxx", "eplyy", "eplxy", "evol_pl"):
+        assert max_rel_diff(out[k], ref[k]) <= 1e-11, k
+    assert max_rel_diff(jr.to_numpy(lam_d), lam_r) <= 1e-11 and max_rel_diff(jr.to_numpy(lamv_d), lamv_r) <= 1e-11
+
+
+@pytest.mark.parametrize("free_surface", [False, True])
+def test_vep2d_displacement_bcs_and_free_surface_match_oracle(jr, oracle, free_surface):
+    from justrelax_jl_amd.arrays import DisplacementBoundaryConditions
+    from justrelax_jl_amd.checks import max_rel_diff
+    from test_gpu_vep2d import _download, _upload, _vep_params
+    s = jr.miniapps.shearband2d(24, iterMax=45, nout=15)
+    s.kwargs.update(iterMin=10, free_surface=free_surface)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    rng = np.random.default_rng(2)
+    s.arrays["fy"][...] = rng.uniform(-1.0, 1.0, size=s.ni)          # a density gradient for the free-surface term
+    # the caller holds displacements: U = V dt; V itself starts as garbage and must be rebuilt by displacement2velocity!
+    s.arrays["Ux"][...] = s.arrays["Vx"] * s.dt
+    s.arrays["Uy"][...] = s.arrays["Vy"] * s.dt
+    s.arrays["Vx"][...] = 7.0
+    s.arrays["Vy"][...] = -3.0
+    b = s.flow_bcs
+    dbc = DisplacementBoundaryConditions(free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic)
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes2d_vep_solve(ref, oracle.rheology_struct(s.extra["phases"]),
+                                      _vep_params(oracle, s, iterMin=10, free_surface=free_surface, displacement_bcs=True))
+    stokes, pr, ρg = _upload(jr, s)
+    r = jr.solve_(stokes, s.pt, s.grid, dbc, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=s.kwargs)
+    assert r.iter == r_ref["iter"] == 46
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-9)
+    out = _download(jr, stokes)
+    for k in out:
+        assert max_rel_diff(out[k], ref[k]) <= 1e-9, k
+
+
+def test_vep3d_density_softening_displacement_match_oracle(jr, oracle):
+    from justrelax_jl_amd.arrays import DisplacementBoundaryConditions, from_numpy
+    from justrelax_jl_amd.checks import max_rel_diff
+    from test_gpu_vep3d import _download, _params, _upload
+    s = jr.miniapps.shearband3d((14, 10, 9), iterMax=24, nout=8)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    rng = np.random.default_rng(8)
+    s.arrays["T"] = np.asfortranarray(rng.uniform(0.0, 2.0, size=s.ni))
+    s.arrays["EII_pl"][...] = rng.uniform(0.0, 0.4, size=s.ni)
+    for k, v in (("Ux", "Vx"), ("Uy", "Vy"), ("Uz", "Vz")):
+        s.arrays[k][...] = s.arrays[v] * s.dt
+        s.arrays[v][...] = 1.0
+    phases = _phases_soft(_phases_rho([dict(ph, Kb=3.0, psi_deg=5.0) for ph in s.extra["phases"]], g=0.2))
+    b = s.flow_bcs
+    dbc = DisplacementBoundaryConditions(free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic)
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes3d_vep_solve(ref, oracle.rheology_struct(phases), _params(oracle, s, displacement_bcs=True))
+    stokes, pr, ρg = _upload(jr, s)
+    T = from_numpy(s.arrays["T"], stokes.P.device)
+    r = jr.solve_(stokes, s.pt, s.grid, dbc, ρg, pr, phases, dict(T=T), s.dt, None, kwargs=s.kwargs)
+    assert r.iter == r_ref["iter"] == 25
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-9)
+    assert max_rel_diff(jr.to_numpy(ρg[2]), ref["fz"]) <= 1e-12 and np.ptp(ref["fz"]) > 0
+    out = _download(jr, stokes)
+    for k in out:
+        assert max_rel_diff(out[k], ref[k]) <= 1e-9, k

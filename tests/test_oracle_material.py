@@ -1,0 +1,77 @@
+"""CPU tests of the material laws the round-2 rheology table adds to the oracle (density, softening) and of the host-side table builders.
+The GeoParams forms are ASSUMED (oracle/material.h); what is checked here is that oracle and product tables are built identically and
+that the laws have the documented limits."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+
+def _phases():
+    return [dict(eta=1.0, G=1.0, Kb=4.0, C=1.8, phi_deg=30.0, psi_deg=3.0, eta_vp=1e-2, g=9.81,
+                 density=dict(kind="PT", rho0=3300.0, alpha=3e-5, beta=1e-11, T0=273.0, P0=1e5),
+                 softening_C=dict(kind="linear", min=0.5, max=1.8, lo=0.1, hi=0.5),
+                 softening_phi=dict(kind="nonlinear", xi0=30.0, Delta=10.0, mu=1.0, sigma=0.5)),
+            dict(eta=0.1, G=0.5, Kb=float("inf"), density=dict(kind="constant", rho0=2700.0),
+                 creep=dict(kind="arrhenius", Ea=200e3, Va=2.6e-6, T0=1.6e3, R=8.3145, cutoff=(1e16, 1e25)))]
+
+
+def test_product_and_oracle_tables_are_identical(jr, oracle):
+    from justrelax_jl_amd import _lib, stokes
+    a, b = stokes.rheology_table(_phases()), oracle.rheology_struct(_phases())
+    assert C.sizeof(a) == C.sizeof(b) == C.sizeof(_lib.Rheology)
+    assert bytes(a) == bytes(b)
+    assert [f[0] for f in _lib.Rheology._fields_] == [f[0] for f in oracle.Rheology._fields_]
+    assert a.has_density == 1 and a.gravity == 9.81 and a.rho_kind[0] == 1 and a.rho_kind[1] == 0
+    assert a.softC_kind[0] == 1 and a.softphi_kind[0] == 2 and a.visc_kind[1] == 1
+
+
+def test_density_in_the_vep_driver(jr, oracle):
+    """one VEP solve with has_density: ρg_y = Σ ratio ρ_phase(T, P) g with the PT_Density / ConstantDensity forms"""
+    from test_oracle_golden import _vep_params
+    s = jr.miniapps.shearband2d(12, iterMax=10, nout=5)
+    s.kwargs.update(iterMin=1)
+    T = np.asfortranarray(np.random.default_rng(0).uniform(300.0, 1600.0, size=s.ni))
+    s.arrays["T"] = T
+    phases = [dict(s.extra["phases"][0], g=9.81, density=dict(kind="PT", rho0=3300.0, alpha=3e-5, beta=0.0, T0=273.0)),
+              dict(s.extra["phases"][1], density=dict(kind="constant", rho0=2700.0))]
+    r = oracle.stokes2d_vep_solve(s.arrays, oracle.rheology_struct(phases), _vep_params(oracle, s, iterMin=1))
+    ph = s.arrays["phase_c"]
+    want = (ph[0] * 3300.0 * (1.0 - 3e-5 * (T - 273.0)) + ph[1] * 2700.0) * 9.81
+    assert np.allclose(s.arrays["fy"], want, rtol=1e-14)
+    assert r["iter"] >= 2
+
+
+def test_softening_laws_limits(oracle):
+    """LinearSoftening: max below lo, min above hi, linear in between; NonLinearSoftening: ξ₀ far below μ, ξ₀ - Δ far above"""
+    L = oracle.lib()
+    L.orc_soften.restype = C.c_double
+    L.orc_soften.argtypes = [C.c_int32] + [C.c_double] * 6
+    lin = lambda e: L.orc_soften(1, 0.5, 1.8, 0.1, 0.5, e, 1.8)
+    assert lin(0.0) == 1.8 and lin(0.1) == 1.8 and lin(0.5) == 0.5 and lin(3.0) == 0.5
+    assert lin(0.3) == pytest.approx(1.15, rel=1e-14)
+    non = lambda e: L.orc_soften(2, 30.0, 10.0, 1.0, 0.5, e, 30.0)
+    assert non(-50.0) == pytest.approx(30.0, abs=1e-12) and non(50.0) == pytest.approx(20.0, abs=1e-12)
+    assert non(1.0) == pytest.approx(30.0 - 5.0 * math.erfc(0.0), rel=1e-14) == pytest.approx(25.0)
+    assert L.orc_soften(0, 1.0, 2.0, 3.0, 4.0, 0.7, 42.0) == 42.0          # NoSoftening
+
+
+def test_shearband_with_softening_yields_earlier(jr, oracle):
+    """The shear-band script run into the plastic stage (unpinned by the reference, whose softening test stops in the elastic stage):
+    with a cohesion that softens with accumulated plastic strain the maximum stress ends lower than without."""
+    from test_oracle_golden import _vep_params
+    outs = {}
+    for soft in (False, True):
+        s = jr.miniapps.shearband2d(16, nout=100)
+        phases = [dict(p) for p in s.extra["phases"]]
+        if soft:
+            for p in phases:
+                p["softening_C"] = dict(kind="linear", min=0.5 * p["C"], max=p["C"], lo=0.0, hi=0.05)
+        rh, prm = oracle.rheology_struct(phases), _vep_params(oracle, s)
+        for _ in range(12):
+            r = oracle.stokes2d_vep_solve(s.arrays, rh, prm)
+        outs[soft] = (float(s.arrays["tII"].max()), float(s.arrays["EII_pl"].max()), r["err_evo1"][-1])
+    assert outs[False][1] > 0 and outs[True][1] > 0                 # both runs yield
+    assert outs[True][0] < outs[False][0] - 1e-2                    # the softened run carries less stress
+    assert outs[False][2] < 1e-5 and outs[True][2] < 1e-5
