@@ -284,10 +284,18 @@ typedef struct jrx_vep2d_params {
     int32_t verbose;
     int32_t free_surface;                          /* kwarg free_surface: compute_V! / compute_Res! get dt * free_surface (Stokes2D.jl:773,797) */
     int32_t displacement_bcs;                      /* flow_bcs is a DisplacementBoundaryConditions: V = U / dt first, flow_bcs! acts on U */
+    int32_t T_ghosted;                             /* single-phase driver: args.T is thermal.T (nx+2, ny+2), indexed as the reference does */
 } jrx_vep2d_params;
 
 jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p,
                                   jrx_solve_result *res);
+/* solve!(stokes, pt_stokes, grid, flow_bcs, ρg, rheology::MaterialParams, args, dt, igg; kwargs) -- src/stokes/Stokes2D.jl:345-557: the 2D
+ * single-phase visco-elasto-plastic driver built on compute_τ_nonlinear! and center2vertex! (test/test_WENO5.jl:226-291).  The rheology is
+ * phase 0 of the table (creep law, ConstantElasticity, optional DruckerPrager_regularised, density); phase_c / phase_v are not read.
+ * f->T = args.T: cell-centred (ni), or thermal.T (ni.+2) with p->T_ghosted = 1 -- then read at [i, j] by the density and at [i+1, j+1]
+ * by the viscosity, as the reference's two argument helpers do. */
+jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p,
+                                        jrx_solve_result *res);
 /* update_stresses_center_vertex_ps! alone (θ, λ, λv are caller arrays of extents ni, ni, ni.+1) -- for parity tests */
 jrx_status jrx_vep2d_update_stresses(jrx_handle *h, const jrx_vep2d_fields *f, const double *theta, double *lambda, double *lambda_v,
                                      const jrx_rheology *rh, const jrx_vep2d_params *p);

@@ -802,7 +802,10 @@ __global__ __launch_bounds__(256) void k_tau_nonlinear2d(const VepArgs a, double
     for (int q = 0; q < n; q++) {
         if (r[q] == 0.0 || !a.rh.is_pl[q]) continue;
         is_pl = true;
-        C += a.rh.C[q] * r[q]; sinphi += a.rh.sinphi[q] * r[q]; cosphi += a.rh.cosphi[q] * r[q];
+        const double EII = a.soft ? a.f.EII_pl[c] : 0.0;         // soften_cohesion / soften_friction_angle at EII[I...] (StressUpdate.jl:305-381)
+        double sp, cp;
+        mat_friction(a.rh, q, EII, sp, cp);
+        C += mat_cohesion(a.rh, q, EII) * r[q]; sinphi += sp * r[q]; cosphi += cp * r[q];
         sinpsi += a.rh.sinpsi[q] * r[q]; eta_reg += a.rh.eta_vp[q] * r[q];
     }
     const double K = MULTI ? ratio_avg(a.rh.Kb, r, n) : a.rh.Kb[0];
@@ -899,6 +902,34 @@ __global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, doub
     Kc[t] = ratio_avg(a.rh.Kb, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
     Gc[t] = ratio_avg(a.rh.G, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
     if (rho) a.f.fy[t] = mat_density_ratio(a.rh, a.f.phase_c + a.rh.nphase * t, a.f.T ? a.f.T[t] : 0.0, a.f.P[t]) * a.rh.gravity;
+}
+
+// Single-phase driver (Stokes2D.jl:345-557): compute_ρg!/update_ρg!(ρg[2], rheology, args) and compute_viscosity!/compute_viscosity_τII!
+// (Viscosity.jl:142-167) for creep laws without strain-rate dependence: η <- clamp((1 - ν) η + ν η_creep(T, P), cutoff).
+// args.T: cell-centred (nx, ny), or -- tg -- thermal.T (nx+2, ny+2) indexed as the reference does: density at [i, j]
+// (getindex_NamedTuple(args, I...), BuoyancyForces.jl:17), viscosity at [i+1, j+1] (local_viscosity_args, Viscosity.jl:513-523).
+__global__ __launch_bounds__(256) void k_single_material(const VepArgs a, const double nu, const bool rho, const bool visc, const bool tg)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / nx, i = t - j * nx;
+    if (j >= ny) return;
+    const i64 c = i + (i64)nx * j;
+    const double P = a.f.P[c];
+    if (rho) {
+        const double T = !a.f.T ? 0.0 : (tg ? a.f.T[i + (i64)(nx + 2) * j] : a.f.T[c]);
+        a.f.fy[c] = mat_density(a.rh, 0, T, P) * a.rh.gravity;
+    }
+    if (visc) {
+        const double T = !a.f.T ? 0.0 : (tg ? a.f.T[(i + 1) + (i64)(nx + 2) * (j + 1)] : a.f.T[c]);
+        const double e = (1 - nu) * a.f.eta[c] + nu * mat_creep_viscosity(a.rh, 0, T, P);
+        a.f.eta[c] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+    }
+}
+__global__ __launch_bounds__(256) void k_fill2(double *__restrict__ A, double va, double *__restrict__ B, double vb, i64 n)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { A[t] = va; B[t] = vb; }
 }
 
 __global__ __launch_bounds__(256) void k_tensor_invariant2d(double *__restrict__ II, const double *__restrict__ xx, const double *__restrict__ yy,
@@ -1264,6 +1295,153 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
         JRX_HIP(h, hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s));
         a.f.txx = f->txx; a.f.tyy = f->tyy; b.f.txx = f->txx; b.f.tyy = f->tyy; g.txx = f->txx; g.tyy = f->tyy;
     }
+    a.txx_out = a.tyy_out = nullptr;
+    hipLaunchKernelGGL(k_vep_epilogue, dim3(gv), dim3(256), 0, s, a);
+    JRX_LAUNCH_CHECK(h);
+    hipLaunchKernelGGL(k_copy6, dim3(256), dim3(256), 0, s, f->toxx, (const double *)f->txx, (i64)n, f->toyy, (const double *)f->tyy, (i64)n,
+                       f->toxy, (const double *)f->txy, (i64)nv, f->toxy_c, (const double *)f->txy_c, (i64)n, (double *)nullptr,
+                       (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(s));
+    float ms = 0.f;
+    JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
+    res->iter = iter;
+    res->nchecks = cont < res->cap ? cont : res->cap;
+    res->time_s = ms * 1e-3;
+    res->av_time_s = iter > 1 ? res->time_s / (double)(iter - 1) : res->time_s;
+    return JRX_OK;
+}
+
+
+// solve!(stokes, pt_stokes, grid, flow_bcs, ρg, rheology::MaterialParams, args, dt, igg; kwargs) -- src/stokes/Stokes2D.jl:345-557: the
+// single-phase visco-elasto-plastic driver, the caller of compute_τ_nonlinear! and center2vertex! (test/test_WENO5.jl:226-291).
+// rheology = phase 0 of the table.  compute_P! takes η (not ητ) and updates stokes.P in place (:418-420); θ = P + K dt λ sinψ only
+// replaces P after the loop (:523).  The first compute_maxloc! of an iteration (:413) is dead (ητ is recomputed at :437 before its
+// only reader, compute_V!) and is not launched.
+jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p,
+                                        jrx_solve_result *res)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!f || !rh || !p || !res) return jrx_fail(h, JRX_ERR_ARG, "null argument");
+    if (p->nx < 3 || p->ny < 3) return jrx_fail(h, JRX_ERR_ARG, "2D Stokes needs at least 3 cells per dimension");
+    if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
+    if (rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "nphase must be in 1..%d", JRX_MAXPHASE);
+    const void *req[] = {f->P, f->P0, f->divV, f->Q, f->Vx, f->Vy, f->Ux, f->Uy, f->exx, f->eyy, f->exy, f->eplxx, f->eplyy, f->eplxy, f->eplxy_c,
+                         f->txx, f->tyy, f->txy, f->txy_c, f->tII, f->toxx, f->toyy, f->toxy, f->toxy_c, f->eta, f->eta_vep, f->EII_pl, f->evol_pl,
+                         f->EVol_pl, f->fx, f->fy, f->RP, f->Rx, f->Ry};
+    for (const void *q : req)
+        if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required field pointer is NULL");
+    const bool comm = jrx_comm_active(h);
+    const int nx = (int)p->nx, ny = (int)p->ny;
+    const int64_t nn[3] = {nx, ny, 1};
+    const size_t n = (size_t)nx * ny, nv = (size_t)(nx + 1) * (ny + 1);
+    hipStream_t s = h->stream;
+    JRX_TRY(jrx_ensure_etatau(h, 5 * n));
+    double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n;
+    VepArgs a = make_vep(f, rh, p);
+    a.theta = f->P; a.etatau = f->eta; a.Kc = Kc; a.Gc = Gc; a.lam = lam;          // the view compute_P! works on: P in place, η instead of ητ
+    jrx_stokes2d_fields g = view2d(f);
+    jrx_stokes2d_params q;
+    memset(&q, 0, sizeof(q));
+    q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
+    q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
+    Args2 b = make_args2(&g, etatau, &q);
+    b.fs_dt = p->dt * (double)(p->free_surface != 0);
+    const unsigned gv = (unsigned)((nv + 255) / 256), gc = (unsigned)((n + 255) / 256);
+    const bool tg = p->T_ghosted != 0, ubc = p->displacement_bcs != 0;
+    const bool upd_rho = rh->has_density && rh->rho_kind[0] != 0;
+
+    JRX_HIP(h, hipMemsetAsync(theta, 0, n * sizeof(double), s));                                    // θ = @zeros(ni...) :398
+    JRX_HIP(h, hipMemsetAsync(lam, 0, n * sizeof(double), s));
+    JRX_HIP(h, hipMemsetAsync(f->eplxx, 0, n * sizeof(double), s));                                 // @tensor_center(ε_pl) .= 0 :391-393
+    JRX_HIP(h, hipMemsetAsync(f->eplyy, 0, n * sizeof(double), s));
+    JRX_HIP(h, hipMemsetAsync(f->eplxy_c, 0, n * sizeof(double), s));
+    hipLaunchKernelGGL(k_fill2, dim3(gc), dim3(256), 0, s, Kc, rh->Kb[0], Gc, rh->G[0], (i64)n);      // Kb = get_Kb(rheology); G = get_G(rheology)
+    // compute_ρg!(ρg[end], rheology, args); compute_viscosity!(stokes, args, rheology, cutoff) :406-407
+    hipLaunchKernelGGL(k_single_material, dim3(gc), dim3(256), 0, s, a, 1.0, rh->has_density != 0, true, tg);
+    JRX_LAUNCH_CHECK(h);
+    if (ubc) {    // displacement2velocity!(stokes, dt, flow_bcs) :410
+        hipLaunchKernelGGL(k_scale3, dim3(256), dim3(256), 0, s, f->Vx, (const double *)f->Ux, (i64)(nx + 1) * (ny + 2), f->Vy,
+                           (const double *)f->Uy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, 1.0 / p->dt);
+        JRX_LAUNCH_CHECK(h);
+    }
+    double err_it1 = 1.0, err = 1.0;
+    int64_t iter = 0, cont = 0;
+    res->iter = 0; res->nchecks = 0;
+    JRX_HIP(h, hipEventRecord(h->ev[6], s));
+    auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
+    while (keep_going(iter)) {
+        const int64_t it1 = iter + 1;
+        const bool check = (it1 % p->nout == 0) && it1 > 1;
+        const bool diag = check || !keep_going(it1);      // U is only observable after such an iteration
+        hipLaunchKernelGGL(k_vep_pre<false>, dim3(gv), dim3(256), 0, s, a, f->P);                    // compute_∇V!, compute_P!, compute_strain_rate!
+        hipLaunchKernelGGL(k_single_material, dim3(gc), dim3(256), 0, s, a, p->viscosity_relaxation, upd_rho, true, tg);   // update_ρg!, compute_viscosity_τII!
+        hipLaunchKernelGGL(k_maxloc, dim3(gc, 1), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, 1);            // compute_maxloc!(ητ, η) :437
+        JRX_LAUNCH_CHECK(h);
+        if (comm) {
+            double *arrs[1] = {etatau};
+            const int64_t ext[1][3] = {{nx, ny, 1}};
+            JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
+        }
+        hipLaunchKernelGGL(k_tau_nonlinear2d<false>, dim3(gc), dim3(256), 0, s, a, theta);           // compute_τ_nonlinear! :440-458
+        hipLaunchKernelGGL(k_center2vertex2d, dim3(gv), dim3(256), 0, s, f->txy, (const double *)f->txy_c, nx, ny, 0);   // center2vertex! :459
+        hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((ny + 1 + 255) / 256)), dim3(256), 0, s, f->txy, (const double *)f->txy_c, nx, ny, 1);
+        hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((nx + 1 + 255) / 256)), dim3(256), 0, s, f->txy, (const double *)f->txy_c, nx, ny, 2);
+        JRX_LAUNCH_CHECK(h);
+        if (comm) {   // update_halo!(stokes.τ.xy) :460
+            double *arrs[1] = {f->txy};
+            const int64_t ext[1][3] = {{nx + 1, ny + 1, 1}};
+            JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
+        }
+        hipLaunchKernelGGL(k_velocity2d<false>, dim3(gc), dim3(256), 0, s, b);                       // compute_V! (free-surface form) :463-474
+        JRX_LAUNCH_CHECK(h);
+        if (diag) {
+            hipLaunchKernelGGL(k_scale3, dim3(256), dim3(256), 0, s, f->Ux, (const double *)f->Vx, (i64)(nx + 1) * (ny + 2), f->Uy,
+                               (const double *)f->Vy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, p->dt);
+            JRX_LAUNCH_CHECK(h);
+        }
+        if (!ubc) JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+        else if (diag) JRX_TRY(launch_bcs2(h, s, f->Ux, f->Uy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+        if (comm) {
+            double *arrs[2] = {f->Vx, f->Vy};
+            const int64_t ext[2][3] = {{nx + 1, ny + 2, 1}, {nx + 2, ny + 1, 1}};
+            JRX_TRY(jrx_halo_exchange(h, s, 2, arrs, ext, nn));
+        }
+        iter = it1;
+        if (check) {
+            hipLaunchKernelGGL(k_velocity2d<true>, dim3(gc), dim3(256), 0, s, b);                    // compute_Res! :479-490
+            JRX_LAUNCH_CHECK(h);
+            JRX_TRY(launch_sumsq2(h, s, &g, &q));
+            JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            JRX_HIP(h, hipStreamSynchronize(s));
+            double ss[3] = {h->h_sums[0], h->h_sums[1], h->h_sums[3]};
+            JRX_TRY(jrx_allreduce_sum_host(h, ss, 3));
+            const double nRx = sqrt(ss[0]) / sqrt((double)((p->nxg - 2) * (p->nyg - 1)));
+            const double nRy = sqrt(ss[1]) / sqrt((double)((p->nxg - 1) * (p->nyg - 2)));
+            const double nDV = sqrt(ss[2]) / sqrt((double)(p->nxg * p->nyg));
+            err = fmax(nRx, fmax(nRy, nDV));
+            if (std::isnan(nRx) || std::isnan(nRy) || std::isnan(nDV)) err = NAN;
+            if (cont < res->cap) {
+                if (res->norm_Rx) res->norm_Rx[cont] = nRx;
+                if (res->norm_Ry) res->norm_Ry[cont] = nRy;
+                if (res->norm_divV) res->norm_divV[cont] = nDV;
+                if (res->err_evo1) res->err_evo1[cont] = err;
+                if (res->err_evo2) res->err_evo2[cont] = iter;
+            }
+            if (cont == 0) err_it1 = err;
+            cont++;
+            if (jrx_comm_rank(h) == 0 && ((p->verbose && (err / err_it1) > p->eps_rel && err > p->eps_abs) || iter == p->iterMax))
+                printf("Total steps = %lld, abs_err = %1.3e , rel_err = %1.3e [norm_Rx=%1.3e, norm_Ry=%1.3e, norm_∇V=%1.3e] \n",
+                       (long long)iter, err, err / err_it1, nRx, nRy, nDV);
+            if (std::isnan(err)) {
+                res->iter = iter; res->nchecks = cont < res->cap ? cont : res->cap;
+                (void)hipStreamSynchronize(s);
+                return jrx_fail(h, JRX_ERR_NAN, "NaN(s)");
+            }
+        }
+    }
+    JRX_HIP(h, hipEventRecord(h->ev[7], s));
+    JRX_HIP(h, hipMemcpyAsync(f->P, theta, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // stokes.P .= θ :523
     a.txx_out = a.tyy_out = nullptr;
     hipLaunchKernelGGL(k_vep_epilogue, dim3(gv), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);

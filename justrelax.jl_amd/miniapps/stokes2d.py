@@ -167,3 +167,85 @@ def shearband2d(n=32, *, iterMax=50_000, nout=100) -> Setup:
     return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=dt, flow_bcs=bcs,
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False, viscosity_cutoff=(-np.inf, np.inf)),
                  extra=dict(li=li, di=di, phases=phases, εbg=εbg, G0=G0, η0=η0))
+
+
+def _thermal_bcs_host(T, bc):
+    """thermal_bcs!(T, bc) on a host array (BoundaryConditions.jl:39-53): constant value (constant_value.jl:1-13; `2*true - T` for a
+    face given as `true`), then no-flux copies (free_slip.jl:72-84); 2D: bot <-> j = 1"""
+    cv, nf = bc.constant_value, bc.no_flux
+    on = lambda v: v is not False and v is not None
+    if on(cv.get("bot")): T[:, 0] = 2 * float(cv["bot"]) - T[:, 1]
+    if on(cv.get("top")): T[:, -1] = 2 * float(cv["top"]) - T[:, -2]
+    if on(cv.get("left")): T[0, :] = 2 * float(cv["left"]) - T[1, :]
+    if on(cv.get("right")): T[-1, :] = 2 * float(cv["right"]) - T[-2, :]
+    if nf.get("bot"): T[:, 0] = T[:, 1]
+    if nf.get("top"): T[:, -1] = T[:, -2]
+    if nf.get("left"): T[0, :] = T[1, :]
+    if nf.get("right"): T[-1, :] = T[-2, :]
+
+
+def thermal_convection2d(n=32, *, ar=8, iterMax=150_000, nout=1000) -> Setup:
+    """The Stokes problem of test/test_WENO5.jl:105-245 (thermal_convection2D, `thermal_perturbation = :circular`): a 2890 km deep box of
+    aspect ratio `ar`, half-space-cooling temperature with a +10 % circular anomaly, a single MaterialParams with an Arrhenius
+    CustomRheology (test_WENO5.jl:25-42, depth = 0) + elasticity (G = 70 GPa, ν = 0.5), PT_Density(ρ0 = 3100, α = 1.5e-5, β = 0),
+    g = 9.81, lithostatic initial pressure, free slip.  This is the input of the single-phase solve! (Stokes2D.jl:345-557); the WENO
+    advection and the heat-diffusion step of the script are not part of it.  arrays["T"] is thermal.T (ghosted)."""
+    from ..arrays import TemperatureBoundaryConditions
+    nx = ny = n
+    ly = 2890.0e3
+    lx = ly * ar
+    ni, li = (nx, ny), (lx, ly)
+    init_global_grid(nx, ny, 1)
+    di = tuple(l / m for l, m in zip(li, ni))
+    grid = Geometry(ni, li, origin=(0.0, -ly))
+    xc, yc = grid.xci
+    v_args = dict(η0=5.0e20, Ea=200.0e3, Va=2.6e-6, T0=1.6e3, R=8.3145, cutoff=(1.0e16, 1.0e25))
+    G0 = 70.0e9
+    phase = dict(eta=v_args["η0"], G=G0, Kb=float("inf"), g=9.81,
+                 density=dict(kind="PT", rho0=3.1e3, alpha=1.5e-5, beta=0.0, T0=0.0),
+                 creep=dict(kind="arrhenius", Ea=v_args["Ea"], Va=v_args["Va"], T0=v_args["T0"], R=v_args["R"], cutoff=v_args["cutoff"]))
+    κ = 3.0 / (1.2e3 * 3.1e3)
+    dt = 0.5 * min(di) ** 2 / κ / 2.01
+    # temperature: init_T! (:60-70), thermal_bcs!, circular_perturbation! (:72-84)
+    adiabat, Tp = 0.3, 1900.0
+    Tm = Tp + adiabat * 2890
+    Tmin, Tmax = 300.0, 3.5e3
+    T = np.zeros((nx + 2, ny + 2), order="F")
+    yr = 3600 * 24 * 365.25
+    z = np.abs(yc)
+    Ti = Tp + (Tm - Tp) / 2890.0e3 * z
+    Ths = Tmin + (Tm - Tmin) * np.array([math.erf(v * 0.5 / (κ * (100.0e6 * yr)) ** 0.5) for v in z])
+    T[1:-1, 1:-1] = np.minimum(Ti, Ths)[None, :]
+    tbc = TemperatureBoundaryConditions(no_flux=dict(left=True, right=True, top=False, bot=False),
+                                        constant_value=dict(left=True, right=True, top=Tmin, bot=Tmax))
+    _thermal_bcs_host(T, tbc)
+    X, Y = np.meshgrid(xc, yc, indexing="ij")
+    T[1:-1, 1:-1][((X - 0.5 * lx) ** 2 + (Y + 0.75 * ly) ** 2) <= 150.0e3 ** 2] *= 10.0 / 100 + 1
+    arr = {k: np.zeros(s, dtype=np.float64, order="F") for k, s in _vep_shapes2d(nx, ny, 1).items()}
+    arr["T"] = T
+    # compute_ρg!(ρg[2], rheology, args) reads args.T at [i, j] of the ghosted array (no shift), then init_P! (:52-55)
+    rho = 3.1e3 * (1.0 - 1.5e-5 * (T[:nx, :ny] - 0.0) + 0.0 * (0.0 - 0.0))
+    arr["fy"][...] = rho * 9.81
+    arr["P"][...] = arr["fy"] * np.abs(yc)[None, :]
+    # compute_viscosity!(stokes, args, rheology, (1e16, 1e24)): T at [i+1, j+1], P at [i, j]
+    cutoff = (1.0e16, 1.0e24)
+    Tc, P = T[1:-1, 1:-1], arr["P"]
+    η = v_args["η0"] * np.exp((v_args["Ea"] + P * v_args["Va"]) / (v_args["R"] * Tc) - v_args["Ea"] / (v_args["R"] * v_args["T0"]))
+    arr["eta"][...] = np.clip(np.clip(η, *v_args["cutoff"]), *cutoff)
+    arr["phase_c"][...] = 1.0
+    arr["phase_v"][...] = 1.0
+    pt = PTStokesCoeffs(li, di, ϵ_rel=1.0e-4, CFL=0.8 / math.sqrt(2.1))
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F4}, no_slip={f: False for f in _F4})
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=dt, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False, viscosity_cutoff=cutoff),
+                 extra=dict(li=li, di=di, rheology=phase, thermal_bc=tbc))
+
+
+def _vep_shapes2d(nx, ny, nphase):
+    c, v = (nx, ny), (nx + 1, ny + 1)
+    shapes = {k: c for k in ("P", "P0", "divV", "Q", "exx", "eyy", "exy_c", "eplxx", "eplyy", "eplxy_c", "dexy_c", "txx", "tyy", "txy_c", "tII",
+                             "toxx", "toyy", "toxy_c", "eta", "eta_vep", "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP")}
+    shapes.update({k: v for k in ("exy", "eplxy", "dexy", "txy", "toxy", "eta_v", "omega_xy")})
+    shapes.update(Vx=(nx + 1, ny + 2), Vy=(nx + 2, ny + 1), Ux=(nx + 1, ny + 2), Uy=(nx + 2, ny + 1), Rx=(nx - 1, ny), Ry=(nx, ny - 1),
+                  phase_c=(nphase, nx, ny), phase_v=(nphase, nx + 1, ny + 1))
+    return shapes

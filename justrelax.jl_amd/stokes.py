@@ -211,7 +211,7 @@ def _is_displacement(flow_bcs):
     return isinstance(flow_bcs, DisplacementBoundaryConditions)
 
 
-def vep_fields2d(stokes, ρg, phase_ratios, args=None) -> _lib.VEP2DFields:
+def vep_fields2d(stokes, ρg, phase_ratios, args=None, allow_ghosted_T=False) -> _lib.VEP2DFields:
     s = stokes
     vals = dict(P=s.P, P0=s.P0, divV=s.divV, Q=s.Q, Vx=s.V.Vx, Vy=s.V.Vy, Ux=s.U.Ux, Uy=s.U.Uy,
                 exx=s.ε.xx, eyy=s.ε.yy, exy=s.ε.xy, exy_c=s.ε.xy_c,
@@ -221,7 +221,7 @@ def vep_fields2d(stokes, ρg, phase_ratios, args=None) -> _lib.VEP2DFields:
                 eta=s.viscosity.η, eta_v=s.viscosity.ηv, eta_vep=s.viscosity.η_vep,
                 EII_pl=s.EII_pl, evol_pl=s.ε_vol_pl, EVol_pl=s.EVol_pl, fx=ρg[0], fy=ρg[1], RP=s.R.RP, Rx=s.R.Rx, Ry=s.R.Ry,
                 omega_xy=s.ω.xy, phase_c=phase_ratios.center, phase_v=phase_ratios.vertex, T=_args_T(args))
-    if vals["T"] is not None and tuple(vals["T"].shape) != tuple(s._ni):
+    if vals["T"] is not None and tuple(vals["T"].shape) != tuple(s._ni) and not allow_ghosted_T:
         raise ValueError(f"args.T must be cell-centred {tuple(s._ni)} (thermal.Tc), got {tuple(vals['T'].shape)}")
     f = _lib.VEP2DFields()
     for n in _lib.VEP_NAMES:
@@ -263,6 +263,31 @@ def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology,
     hist = _Hist(int(p.iterMax // p.nout + 2))
     torch.cuda.current_stream(stokes.P.device).synchronize()
     h.call("jrx_stokes2d_vep_solve", C.byref(f), C.byref(rh), C.byref(p), C.byref(hist.c))
+    return hist.result(2)
+
+
+def _solve_nonlinear2d(stokes, pt_stokes, grid, flow_bcs, ρg, rheology, args, dt, kw, h):
+    """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, rheology::MaterialParams, args, dt, igg; kwargs) -- Stokes2D.jl:345-557 (single phase:
+    compute_τ_nonlinear! + center2vertex!).  `rheology` is one phase dict of the table; `args.T` may be thermal.T (ghosted)."""
+    if len(stokes._ni) != 2:
+        raise NotImplementedError("the single-phase MaterialParams variant is 2D only here; the reference's 3D one (Stokes3D.jl:206-445) does not "
+                                  "run as written (it references an undefined phase_ratios, :258-259)")
+    kw = dict(kw)
+    kw.setdefault("iterMax", 10.0e3)
+    kw.pop("iterMin", None)
+    p = vep_params2d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
+    none_pr = SimpleNamespace(center=None, vertex=None)
+    f = vep_fields2d(stokes, ρg, none_pr, args, allow_ghosted_T=True)
+    T = _args_T(args)
+    if T is not None:
+        if tuple(T.shape) == tuple(n + 2 for n in stokes._ni):
+            p.T_ghosted = 1
+        elif tuple(T.shape) != tuple(stokes._ni):
+            raise ValueError(f"args.T must be thermal.T {tuple(n + 2 for n in stokes._ni)} or cell-centred {tuple(stokes._ni)}")
+    rh = rheology_table([rheology] if isinstance(rheology, dict) else rheology)
+    hist = _Hist(int(p.iterMax // p.nout + 2))
+    torch.cuda.current_stream(stokes.P.device).synchronize()
+    h.call("jrx_stokes2d_nonlinear_solve", C.byref(f), C.byref(rh), C.byref(p), C.byref(hist.c))
     return hist.result(2)
 
 
@@ -474,7 +499,8 @@ def compute_viscosity_(stokes, phase_ratios, args, rheology, cutoff=(-float("inf
 def solve_(stokes, pt_stokes, grid_or_di, flow_bcs, ρg, *rest, kwargs=None, handle=None):
     """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, K, G, dt, igg; kwargs)   [3D, Stokes3D.jl:25-186]
        solve!(stokes, pt_stokes, grid, flow_bcs, ρg, G, K, dt, igg; kwargs)   [2D, Stokes2D.jl:181-325]
-       solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs)   [2D VEP, Stokes2D.jl:577-866]
+       solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs)   [2D VEP, Stokes2D.jl:577-866; 3D, Stokes3D.jl:447-668]
+       solve!(stokes, pt_stokes, grid, flow_bcs, ρg, rheology, args, dt, igg; kwargs)   [2D single phase, Stokes2D.jl:345-557; rheology = one phase dict]
 
     `kwargs` is the reference's required keyword holding iterMax, nout, b_width, verbose.
     Returns the reference's NamedTuple as a namespace (iter, err_evo1, err_evo2, norm_Rx, ...).
@@ -489,6 +515,9 @@ def solve_(stokes, pt_stokes, grid_or_di, flow_bcs, ρg, *rest, kwargs=None, han
     if rest and isinstance(rest[0], PhaseRatios):          # (phase_ratios, rheology, args, dt[, igg]) -> multiphase VEP variant
         phase_ratios, rheology, args, dt = rest[:4]
         return _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h)
+    if rest and isinstance(rest[0], dict):                   # (rheology::MaterialParams, args, dt[, igg]) -> single-phase VEP variant
+        rheology, args, dt = rest[:3]
+        return _solve_nonlinear2d(stokes, pt_stokes, grid, flow_bcs, ρg, rheology, args, dt, kw, h)
     if len(rest) < 3:
         raise TypeError("solve_: expected (K, G, dt[, igg]) / (G, K, dt[, igg]) or (phase_ratios, rheology, args, dt[, igg])")
     A, B, dt = rest[:3]

@@ -250,9 +250,11 @@ typedef struct orc_vep_params2d {
     int32_t staggered_invariant_mean_of_squares;  /* 0: (mean xy)^2 ; 1: mean(xy^2)  -- GeoParams second_invariant_staggered */
     int32_t free_surface;                         /* kwarg free_surface: compute_V! / compute_Res! get dt * free_surface (Stokes2D.jl:773,797) */
     int32_t displacement_bcs;                     /* flow_bcs is a DisplacementBoundaryConditions: V = U / dt first, flow_bcs! acts on U (BoundaryConditions.jl:71-78) */
+    int32_t T_ghosted;                            /* single-phase driver: args.T is thermal.T (nx+2, ny+2), indexed as the reference does */
 } orc_vep_params2d;
 
 int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res);
+int32_t orc_stokes2d_nonlinear_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res);
 void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, double *lamv, const orc_rheology *rh,
                       const orc_vep_params2d *p);
 void orc_compute_tau_nonlinear2d(const orc_vep2d *f, double *theta, double *lam, const orc_rheology *rh, const orc_vep_params2d *p,

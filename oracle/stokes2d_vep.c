@@ -176,7 +176,8 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
  * Centre-only update.  As the reference's only caller passes them (Stokes2D.jl:442-458): τ = (xx, yy, xy_c),
  * τ_old = @tensor(τ_o) = (xx, yy, xy) whose shear member is the VERTEX array read at the centre's index [i,j],
  * ε_pl = (xx, yy, xy) whose shear member is likewise the vertex array written at [i,j].
- * PARITY UNPINNED: no test of the reference reaches this kernel (its 2D driver indexes scalar K, G per cell). */
+ * PARITY UNPINNED in its plastic branch: the only test that reaches this kernel (test/test_WENO5.jl:226-291, through the single-phase
+ * driver below) uses a non-plastic rheology and asserts convergence only. */
 void orc_compute_tau_nonlinear2d(const orc_vep2d *f, double *theta, double *lam, const orc_rheology *rh, const orc_vep_params2d *p,
                                  int32_t multiphase)
 {
@@ -196,7 +197,9 @@ void orc_compute_tau_nonlinear2d(const orc_vep2d *f, double *theta, double *lam,
             for (int q = 0; q < n; q++) {
                 if (r[q] == 0.0 || !rh->is_pl[q]) continue;                         /* empty_args for absent / non-plastic phases */
                 is_pl = 1;
-                C += rh->C[q] * r[q]; sinphi += rh->sinphi[q] * r[q]; cosphi += rh->cosphi[q] * r[q];
+                double sp, cp;
+                mat_friction(rh, q, f->EII_pl[c], &sp, &cp);                          /* soften_friction_angle / soften_cohesion at EII[I...] */
+                C += mat_cohesion(rh, q, f->EII_pl[c]) * r[q]; sinphi += sp * r[q]; cosphi += cp * r[q];
                 sinpsi += rh->sinpsi[q] * r[q]; eta_reg += rh->eta_vp[q] * r[q];
             }
             const double K = multiphase ? ratio_avg(rh->Kb, r, n) : rh->Kb[0];
@@ -409,3 +412,126 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
 
 /* test hook: the softening laws of material.h */
 double orc_soften(int32_t kind, double a, double b, double c, double d, double EII, double v0) { return mat_soften(kind, a, b, c, d, EII, v0); }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * 2D single-phase visco-elasto-plastic driver: solve!(stokes, pt_stokes, grid, flow_bcs, ρg, rheology::MaterialParams, args, dt, igg)
+ * -- src/stokes/Stokes2D.jl:345-557, the only caller of compute_τ_nonlinear! + center2vertex!; reached by test/test_WENO5.jl:226-291.
+ * The rheology is phase 0 of the table.  args = (; T, P = stokes.P): with T_ghosted the temperature is thermal.T (nx+2, ny+2) and is
+ * indexed as the reference does -- compute_ρg! at [i, j] (getindex_NamedTuple(args, I...), BuoyancyForces.jl:17) but the viscosity at
+ * [i+1, j+1] (local_viscosity_args, Viscosity.jl:513-523); otherwise T is cell-centred (nx, ny).
+ * compute_viscosity! / compute_viscosity_τII! (Viscosity.jl:142-167) for creep laws without strain-rate dependence:
+ * η <- clamp((1 - ν) η + ν η_creep(T, P), cutoff). */
+static inline double T_at(const orc_vep2d *f, const orc_vep_params2d *p, int64_t i, int64_t j, int shift)
+{
+    if (!f->T) return 0.0;
+    if (p->T_ghosted) return f->T[IDX2(p->nx + 2, i + shift, j + shift)];
+    return f->T[IDX2(p->nx, i, j)];
+}
+static void visc_single(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu)
+{
+    const int64_t nx = p->nx, ny = p->ny;
+    for (int64_t j = 0; j < ny; j++)
+        for (int64_t i = 0; i < nx; i++) {
+            const size_t c = IDX2(nx, i, j);
+            const double en = mat_creep_viscosity(rh, 0, T_at(f, p, i, j, 1), f->P[c]);
+            const double e = (1 - nu) * f->eta[c] + nu * en;                        /* continuation_linear, Utils.jl:662 */
+            f->eta[c] = fmin(fmax(e, p->cutoff_lo), p->cutoff_hi);
+        }
+}
+static void rhog_single(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p)
+{
+    const int64_t nx = p->nx, ny = p->ny;
+    for (int64_t j = 0; j < ny; j++)
+        for (int64_t i = 0; i < nx; i++) {
+            const size_t c = IDX2(nx, i, j);
+            f->fy[c] = mat_density(rh, 0, T_at(f, p, i, j, 0), f->P[c]) * rh->gravity;     /* compute_buoyancy(rheology, args_ijk) */
+        }
+}
+
+int32_t orc_stokes2d_nonlinear_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res)
+{
+    const int64_t nx = p->nx, ny = p->ny;
+    const size_t n = (size_t)nx * ny, nv = (size_t)(nx + 1) * (ny + 1);
+    double *etatau = malloc(n * 8), *theta = calloc(n, 8), *lam = calloc(n, 8), *Kc = malloc(n * 8), *Gc = malloc(n * 8);
+    orc_compute_maxloc2d(etatau, f->eta, nx, ny);                                   /* :372-375 */
+    for (size_t c = 0; c < n; c++) { Kc[c] = rh->Kb[0]; Gc[c] = rh->G[0]; }         /* Kb = get_Kb(rheology); G = get_G(rheology) :378-379 */
+    memset(f->eplxx, 0, n * 8); memset(f->eplyy, 0, n * 8); memset(f->eplxy_c, 0, n * 8);   /* :391-393 */
+    const int upd_rho = rh->has_density && rh->rho_kind[0] != 0;
+    if (rh->has_density) rhog_single(f, rh, p);                                    /* compute_ρg!(ρg[end], rheology, args) :406 */
+    visc_single(f, rh, p, 1.0);                                                     /* compute_viscosity!(stokes, args, rheology, cutoff) :407 */
+    if (p->displacement_bcs) {                                                      /* displacement2velocity! :410 */
+        const double _dt = inv(p->dt);
+        for (size_t c = 0; c < (size_t)(nx + 1) * (ny + 2); c++) f->Vx[c] = f->Ux[c] * _dt;
+        for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 1); c++) f->Vy[c] = f->Uy[c] * _dt;
+    }
+    const double fs_dt = p->dt * (double)(p->free_surface != 0);
+
+    orc_fields2d g;
+    memset(&g, 0, sizeof(g));
+    g.P = f->P; g.P0 = f->P0; g.divV = f->divV; g.Q = f->Q; g.Vx = f->Vx; g.Vy = f->Vy; g.Ux = f->Ux; g.Uy = f->Uy;
+    g.txx = f->txx; g.tyy = f->tyy; g.txy = f->txy; g.exx = f->exx; g.eyy = f->eyy; g.exy = f->exy;
+    g.eta = f->eta; g.fx = f->fx; g.fy = f->fy; g.RP = f->RP; g.Rx = f->Rx; g.Ry = f->Ry;
+    orc_params2d q;
+    memset(&q, 0, sizeof(q));
+    q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
+    q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
+
+    double err_it1 = 1.0, err = 1.0;
+    int64_t iter = 0, cont = 0;
+    res->status = 0;
+    while (iter < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && iter <= p->iterMax)) {      /* :412 */
+        orc_compute_maxloc2d(etatau, f->eta, nx, ny);
+        orc_compute_divV2d(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy);
+        orc_compute_P3d(f->P, f->P0, f->RP, f->divV, f->Q, f->eta, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* with η, in place :418-420 */
+        if (upd_rho) rhog_single(f, rh, p);                                        /* update_ρg!(ρg[2], rheology, args) :422 */
+        orc_compute_strain_rate2d(&g, &q);
+        visc_single(f, rh, p, p->viscosity_relaxation);                            /* compute_viscosity_τII! :433-435 */
+        orc_compute_maxloc2d(etatau, f->eta, nx, ny);                              /* :437-438 */
+        orc_compute_tau_nonlinear2d(f, theta, lam, rh, p, 0);                      /* :440-458 */
+        orc_center2vertex2d(f->txy, f->txy_c, nx, ny);                             /* :459 */
+        orc_compute_V2d_fs(&g, etatau, &q, fs_dt);                                 /* :463-474 */
+        orc_velocity2displacement2d(&g, &q);
+        if (p->displacement_bcs) orc_flow_bcs2d(f->Ux, f->Uy, nx, ny, p->free_slip, p->no_slip, p->periodic);
+        else orc_flow_bcs2d(f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic);
+        iter += 1;
+        if (iter % p->nout == 0 && iter > 1) {
+            orc_compute_Res2d_fs(&g, &q, fs_dt);
+            double s[3];
+            orc_residual_sumsq2d(&g, &q, s);
+            const double nRx = sqrt(s[0]) / sqrt((double)((p->nxg - 2) * (p->nyg - 1)));
+            const double nRy = sqrt(s[1]) / sqrt((double)((p->nxg - 1) * (p->nyg - 2)));
+            const double nDV = sqrt(s[2]) / sqrt((double)(p->nxg * p->nyg));
+            err = fmax(nRx, fmax(nRy, nDV));
+            if (isnan(nRx) || isnan(nRy) || isnan(nDV)) err = NAN;
+            if (cont < res->cap) { res->norm_Rx[cont] = nRx; res->norm_Ry[cont] = nRy; res->norm_divV[cont] = nDV; res->err_evo1[cont] = err; res->err_evo2[cont] = iter; }
+            if (cont == 0) err_it1 = err;
+            cont++;
+            if (isnan(err)) { res->status = 1; break; }
+        }
+    }
+    res->iter = iter;
+    res->nchecks = cont < res->cap ? cont : res->cap;
+    if (res->status == 0) {
+        memcpy(f->P, theta, n * 8);                                                 /* stokes.P .= θ :523 */
+        if (f->omega_xy)
+            for (int64_t j = 0; j < ny + 1; j++)
+                for (int64_t i = 0; i < nx + 1; i++)
+                    V2(f->omega_xy, i, j) = 0.5 * ((-f->Vy[IDX2(nx + 2, i, j)] + f->Vy[IDX2(nx + 2, i + 1, j)]) * p->_dx -
+                                                   (-f->Vx[IDX2(nx + 1, i, j)] + f->Vx[IDX2(nx + 1, i, j + 1)]) * p->_dy);
+        shear2center(f->exy_c, f->exy, nx, ny);
+        shear2center(f->eplxy_c, f->eplxy, nx, ny);
+        shear2center(f->dexy_c, f->dexy, nx, ny);
+        for (int64_t j = 0; j < ny; j++)
+            for (int64_t i = 0; i < nx; i++) {
+                const size_t c = IDX2(nx, i, j);
+                f->EII_pl[c] += sinv_stag(f->eplxx[c], f->eplyy[c], V2(f->eplxy, i, j), V2(f->eplxy, i + 1, j), V2(f->eplxy, i, j + 1),
+                                          V2(f->eplxy, i + 1, j + 1), p->staggered_invariant_mean_of_squares) * p->dt;
+                f->EVol_pl[c] += p->dt * f->evol_pl[c];
+            }
+        memcpy(f->toxx, f->txx, n * 8); memcpy(f->toyy, f->tyy, n * 8); memcpy(f->toxy, f->txy, nv * 8);
+        memcpy(f->toxy_c, f->txy_c, n * 8);
+    }
+    free(etatau); free(theta); free(lam); free(Kc); free(Gc);
+    return res->status;
+}

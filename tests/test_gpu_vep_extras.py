@@ -152,3 +152,44 @@ def test_vep3d_density_softening_displacement_match_oracle(jr, oracle):
     out = _download(jr, stokes)
     for k in out:
         assert max_rel_diff(out[k], ref[k]) <= 1e-9, k
+
+
+def _nl_params(oracle, s, **over):
+    pt, b = s.pt, s.flow_bcs
+    kw = dict(iterMax=s.kwargs["iterMax"], nout=s.kwargs["nout"], stag_mode=1, cutoff=s.kwargs["viscosity_cutoff"], T_ghosted=True)
+    kw.update(over)
+    return oracle.vep_params2d(s.ni, s.grid._di["center"], s.dt, dict(r=pt.r, theta_dtau=pt.θ_dτ, eta_dtau=pt.ηdτ, eps_rel=pt.ϵ_rel, eps_abs=pt.ϵ_abs),
+                               free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic, **kw)
+
+
+@pytest.mark.parametrize("plastic", [False, True])
+def test_single_phase_driver_matches_oracle(jr, oracle, plastic):
+    """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, rheology::MaterialParams, args, dt, igg) (Stokes2D.jl:345-557) on the Stokes problem of
+    test/test_WENO5.jl (aspect ratio 1, so that the thermal anomaly is resolved): T-dependent Arrhenius viscosity with relaxation,
+    PT_Density buoyancy, compute_τ_nonlinear! + center2vertex!; `plastic` adds the script's DruckerPrager_regularised (rheology_plastic)."""
+    from justrelax_jl_amd.arrays import from_numpy
+    from justrelax_jl_amd.checks import max_rel_diff
+    from test_gpu_vep2d import VEP_MAP, _get
+    import torch
+    s = jr.miniapps.thermal_convection2d(32, ar=1, iterMax=299, nout=100)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+    ph = dict(s.extra["rheology"])
+    if plastic:      # the script's regularisation viscosity; cohesion chosen so that about half of the cells yield within the 300 iterations
+        ph.update(C=8.0e6, phi_deg=0.0, psi_deg=0.0, eta_vp=1.0e16)
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes2d_nonlinear_solve(ref, oracle.rheology_struct([ph]), _nl_params(oracle, s))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+    for k, path in VEP_MAP.items():
+        _get(st, path).copy_(from_numpy(s.arrays[k], dev))
+    ρg = (from_numpy(s.arrays["fx"], dev), from_numpy(s.arrays["fy"], dev))
+    T = from_numpy(s.arrays["T"], dev)
+    r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, ph, dict(T=T, P=st.P), s.dt, None, kwargs=s.kwargs)
+    assert r.iter == r_ref["iter"] == 300
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-8)
+    if plastic:
+        assert 100 < (ref["eplxx"] != 0).sum() < ref["eplxx"].size
+    out = {k: jr.to_numpy(_get(st, path)) for k, path in VEP_MAP.items()}
+    for k in out:
+        assert max_rel_diff(out[k], ref[k]) <= 1e-8, k
+    assert max_rel_diff(jr.to_numpy(ρg[1]), ref["fy"]) <= 1e-12

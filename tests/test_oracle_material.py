@@ -75,3 +75,22 @@ def test_shearband_with_softening_yields_earlier(jr, oracle):
     assert outs[False][1] > 0 and outs[True][1] > 0                 # both runs yield
     assert outs[True][0] < outs[False][0] - 1e-2                    # the softened run carries less stress
     assert outs[False][2] < 1e-5 and outs[True][2] < 1e-5
+
+
+def test_weno5_stokes_problem_converges_through_the_single_phase_driver(jr, oracle):
+    """test/test_WENO5.jl:226-291 drives solve!(..., rheology::MaterialParams, args, dt, igg) (Stokes2D.jl:345-557) and asserts
+    iters.err_evo1[end] < 5e-4.  The Stokes problem of that script (32 x 32 cells, aspect ratio 8, its tolerances and iteration budget)
+    through the oracle's restatement of that driver; at aspect ratio 8 no cell centre falls inside the 150-km anomaly, so the state is
+    lithostatic; at aspect ratio 1 the anomaly is resolved and drives convection at cm/yr."""
+    yr = 3600 * 24 * 365.25
+    for ar, moving in ((8, False), (1, True)):
+        s = jr.miniapps.thermal_convection2d(32, ar=ar)
+        pt, b = s.pt, s.flow_bcs
+        p = oracle.vep_params2d(s.ni, s.grid._di["center"], s.dt, dict(r=pt.r, theta_dtau=pt.θ_dτ, eta_dtau=pt.ηdτ, eps_rel=pt.ϵ_rel, eps_abs=pt.ϵ_abs),
+                                free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic, iterMax=s.kwargs["iterMax"], nout=s.kwargs["nout"],
+                                stag_mode=1, cutoff=s.kwargs["viscosity_cutoff"], T_ghosted=True)
+        r = oracle.stokes2d_nonlinear_solve(s.arrays, oracle.rheology_struct([s.extra["rheology"]]), p)
+        assert r["err_evo1"][-1] < 5.0e-4 and r["iter"] < s.kwargs["iterMax"]
+        vmax = max(np.abs(s.arrays["Vx"]).max(), np.abs(s.arrays["Vy"]).max()) * yr * 100          # cm / yr
+        assert (0.1 < vmax < 100.0) if moving else vmax < 1e-6
+        assert 1e16 <= s.arrays["eta"].min() and s.arrays["eta"].max() <= 1e24
