@@ -142,6 +142,7 @@ typedef struct jrx_stokes3d_params {
     uint32_t free_slip, no_slip, periodic;   /* JRX_FACE_* masks of flow_bcs */
     int32_t b_width[3];            /* boundary-slab width for comm/compute overlap (default 4,4,4) */
     int32_t verbose;               /* print the reference's per-check line on rank 0 */
+    int32_t displacement_bcs;      /* flow_bcs is a DisplacementBoundaryConditions: displacement2velocity! first (Stokes3D.jl:72), flow_bcs! on U */
 } jrx_stokes3d_params;
 
 typedef struct jrx_solve_result {
@@ -204,6 +205,7 @@ typedef struct jrx_stokes2d_params {
     int64_t iterMax, nout;
     uint32_t free_slip, no_slip, periodic;
     int32_t verbose;
+    int32_t displacement_bcs;      /* as in jrx_stokes3d_params (Stokes2D.jl:223) */
 } jrx_stokes2d_params;
 
 /* solve!(stokes, pt_stokes, grid, flow_bcs, ρg, G, K, dt, igg; kwargs) -- src/stokes/Stokes2D.jl:181-325 */

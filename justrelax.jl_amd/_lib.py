@@ -46,7 +46,7 @@ class Stokes3DParams(C.Structure):
                 ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
-                ("b_width", C.c_int32 * 3), ("verbose", C.c_int32)]
+                ("b_width", C.c_int32 * 3), ("verbose", C.c_int32), ("displacement_bcs", C.c_int32)]
 
 
 class Stokes2DParams(C.Structure):
@@ -54,7 +54,8 @@ class Stokes2DParams(C.Structure):
                 ("_dx", C.c_double), ("_dy", C.c_double),
                 ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
-                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32), ("verbose", C.c_int32)]
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32), ("verbose", C.c_int32),
+                ("displacement_bcs", C.c_int32)]
 
 
 class Thermal2DParams(C.Structure):

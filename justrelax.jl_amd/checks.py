@@ -16,7 +16,8 @@ def oracle_params3d(orc, setup, **over):
     b = setup.flow_bcs
     return orc.params3d(setup.ni, setup.grid._di["center"], setup.dt,
                         dict(r=pt.r, theta_dtau=pt.θ_dτ, eta_dtau=pt.ηdτ, eps_rel=pt.ϵ_rel, eps_abs=pt.ϵ_abs),
-                        iterMax=kw["iterMax"], nout=kw["nout"], free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic)
+                        iterMax=kw["iterMax"], nout=kw["nout"], free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic,
+                        displacement_bcs=type(b).__name__ == "DisplacementBoundaryConditions")
 
 
 def oracle_params2d(orc, setup, **over):
@@ -26,7 +27,8 @@ def oracle_params2d(orc, setup, **over):
     b = setup.flow_bcs
     return orc.params2d(setup.ni, setup.grid._di["center"], setup.dt,
                         dict(r=pt.r, theta_dtau=pt.θ_dτ, eta_dtau=pt.ηdτ, eps_rel=pt.ϵ_rel, eps_abs=pt.ϵ_abs),
-                        iterMax=kw["iterMax"], nout=kw["nout"], free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic)
+                        iterMax=kw["iterMax"], nout=kw["nout"], free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic,
+                        displacement_bcs=type(b).__name__ == "DisplacementBoundaryConditions")
 
 
 def max_rel_diff(a: np.ndarray, b: np.ndarray) -> float:

@@ -323,7 +323,7 @@ jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const
         else hipLaunchKernelGGL(k_stress2d<false>, dim3(gA), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
     }
-    if (fuse_bc && !diag && p->periodic == 0 && !jrx_comm_active(h)) {
+    if (fuse_bc && !diag && p->periodic == 0 && !jrx_comm_active(h) && !p->displacement_bcs) {
         hipLaunchKernelGGL((k_velocity2d<false, true>), dim3(gB), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
         return JRX_OK;
@@ -335,8 +335,12 @@ jrx_status enqueue_iteration2(jrx_handle *h, const jrx_stokes2d_fields *f, const
                            (double *)nullptr, (const double *)nullptr, (i64)0, p->dt);
         JRX_LAUNCH_CHECK(h);
     }
-    JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
-    if (bcs_full_done) *bcs_full_done = true;
+    if (p->displacement_bcs) {    // flow_bcs! on U = V dt (overwritten by the next iteration: only observable ones matter); V's ghosts stay as they are
+        if (diag) JRX_TRY(launch_bcs2(h, s, f->Ux, f->Uy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+    } else {
+        JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+        if (bcs_full_done) *bcs_full_done = true;
+    }
     if (jrx_comm_active(h)) {
         double *arrs[2] = {f->Vx, f->Vy};
         const int64_t ext[2][3] = {{nx + 1, ny + 2, 1}, {nx + 2, ny + 1, 1}};
@@ -428,6 +432,11 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
         const int64_t nn[3] = {nx, ny, 1};
         JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
     }
+    if (p->displacement_bcs) {    // displacement2velocity!(stokes, dt, flow_bcs) (Stokes2D.jl:223)
+        hipLaunchKernelGGL(k_scale3, dim3(256), dim3(256), 0, s, f->Vx, (const double *)f->Ux, (i64)(nx + 1) * (ny + 2), f->Vy,
+                           (const double *)f->Uy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, 1.0 / p->dt);
+        JRX_LAUNCH_CHECK(h);
+    }
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
     const int rank = jrx_comm_rank(h);
@@ -439,7 +448,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     // library-owned set; flow_bcs! itself is applied lazily before anything reads the boundary entries of V from memory.
     // measured (SolCx, profiles/r01_bench2d.txt): 64^2 +16 %, 128^2 +15 %, 256^2 -3 %, 512^2 and 1024^2 +-1 % -- the kernels stop being
     // launch-bound around 200^2 nodes and the fused kernel's redundant velocity updates then cost what the saved launch gave
-    const bool fusable = h->fused2d && h->scratch_sets && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 40000)) &&
+    const bool fusable = !p->displacement_bcs && h->fused2d && h->scratch_sets && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 40000)) &&
                          !jrx_comm_active(h) && p->periodic == 0 && nx >= 2 && ny >= 2;
     const size_t nvx = (size_t)(nx + 1) * (ny + 2), nvy = (size_t)(nx + 2) * (ny + 1), nvt = (size_t)(nx + 1) * (ny + 1);
     Out6_2d setU = {f->P, f->txx, f->tyy, f->txy, f->Vx, f->Vy}, setS = setU;

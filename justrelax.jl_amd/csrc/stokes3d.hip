@@ -416,7 +416,8 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     const Lay3 L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
     // option "fused_comm" = 0 keeps the split sweeps + hidden communication on multi-rank runs (A/B switch; same results);
     // option "scratch_sets" = 0 refuses the library-owned second state set the fused pipeline needs
-    I.fusable = (h->kernel_variant == 0 || h->kernel_variant == 3) && h->scratch_sets && (h->fused_comm || !jrx_comm_active(h)) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
+    // DisplacementBoundaryConditions: flow_bcs! acts on U, the ghosts of V are never refreshed -- the fused kernel's in-kernel BC rules do not apply
+    I.fusable = !p->displacement_bcs && (h->kernel_variant == 0 || h->kernel_variant == 3) && h->scratch_sets && (h->fused_comm || !jrx_comm_active(h)) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable && h->kernel_variant == 0) {
         // auto: the fused kernel covers a row with ceil(nx / (TX - 2)) TX-lane tiles (one halo and one feeder lane each); when that
         // quantisation idles too many lanes the two sweeps are faster (measured with 64-lane rows, profiles/r01_bench_sizes.txt: nx = 192,
@@ -632,6 +633,11 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
         if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
         if (diag) JRX_TRY(launch_scaleU(h, s, f, p));
+        if (p->displacement_bcs) {
+            // flow_bcs!(stokes, ::DisplacementBoundaryConditions) acts on U = V dt, which the next iteration overwrites: only observable ones matter
+            if (diag) JRX_TRY(launch_bcs(h, s, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+            return JRX_OK;
+        }
         // flow_bcs!: the reference's ordered passes on observable iterations and the first time a set is written, otherwise all faces in
         // one launch (same values wherever a stencil reads them)
         bool &ordered = I.bcs_ordered[I.cur_is_user ? 0 : 1];
@@ -668,7 +674,8 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[1], 0));
         JRX_TRY(launch_scaleU(h, hs, f, p));
     }
-    JRX_TRY(launch_bcs(h, hs, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+    if (!p->displacement_bcs) JRX_TRY(launch_bcs(h, hs, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+    else if (diag) JRX_TRY(launch_bcs(h, hs, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
     double *arrs[3] = {f->Vx, f->Vy, f->Vz};
     const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
     const int64_t n[3] = {nx, ny, nz};
@@ -724,6 +731,12 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
         JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
     }
 
+    if (p->displacement_bcs) {    // displacement2velocity!(stokes, dt, flow_bcs) (Stokes3D.jl:72): V = U * inv(dt)
+        hipLaunchKernelGGL(k_scale3, dim3(2048), dim3(256), 0, s, f->Vx, (const double *)f->Ux, (i64)(nx + 1) * (ny + 2) * (nz + 2), f->Vy,
+                           (const double *)f->Uy, (i64)(nx + 2) * (ny + 1) * (nz + 2), f->Vz, (const double *)f->Uz, (i64)(nx + 2) * (ny + 2) * (nz + 1),
+                           1.0 / p->dt);
+        JRX_LAUNCH_CHECK(h);
+    }
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
     res->iter = 0; res->nchecks = 0;

@@ -88,6 +88,11 @@ def _ng(d):
     return gg.n_g(d) if gg.initialized else None
 
 
+def _is_displacement(flow_bcs):
+    from .arrays import DisplacementBoundaryConditions
+    return isinstance(flow_bcs, DisplacementBoundaryConditions)
+
+
 def params3d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10_000, nout=500, b_width=(4, 4, 4), verbose=True, **_):
     ni = stokes._ni
     _di = _center_inv(grid)
@@ -103,6 +108,7 @@ def params3d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10_000, nout=500, b_widt
                                               _lib.bcmask(flow_bcs.periodic))
     p.b_width[0], p.b_width[1], p.b_width[2] = [int(b) for b in b_width]
     p.verbose = int(bool(verbose))
+    p.displacement_bcs = int(_is_displacement(flow_bcs))
     return p
 
 
@@ -120,6 +126,7 @@ def params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10_000, nout=500, verbos
         p.free_slip, p.no_slip, p.periodic = (_lib.bcmask(flow_bcs.free_slip), _lib.bcmask(flow_bcs.no_slip),
                                               _lib.bcmask(flow_bcs.periodic))
     p.verbose = int(bool(verbose))
+    p.displacement_bcs = int(_is_displacement(flow_bcs))
     return p
 
 
@@ -204,11 +211,6 @@ def _args_T(args):
     if args is None:
         return None
     return args.get("T") if isinstance(args, dict) else getattr(args, "T", None)
-
-
-def _is_displacement(flow_bcs):
-    from .arrays import DisplacementBoundaryConditions
-    return isinstance(flow_bcs, DisplacementBoundaryConditions)
 
 
 def vep_fields2d(stokes, ρg, phase_ratios, args=None, allow_ghosted_T=False) -> _lib.VEP2DFields:

@@ -59,6 +59,7 @@ typedef struct orc_params3d {
     double eps_rel, eps_abs;
     int64_t iterMax, nout;
     uint32_t free_slip, no_slip, periodic; /* bit per face, see JRX_FACE_* in include/jrx.h */
+    int32_t displacement_bcs;    /* DisplacementBoundaryConditions: V = U / dt first (Stokes3D.jl:72), flow_bcs! acts on U (BoundaryConditions.jl:71-78) */
 } orc_params3d;
 
 typedef struct orc_result {
@@ -110,6 +111,7 @@ typedef struct orc_params2d {
     double dt, r, theta_dtau, eta_dtau, eps_rel, eps_abs;
     int64_t iterMax, nout;
     uint32_t free_slip, no_slip, periodic;
+    int32_t displacement_bcs;    /* as in orc_params3d (Stokes2D.jl:223) */
 } orc_params2d;
 
 void orc_compute_divV2d(double *divV, const double *Vx, const double *Vy, int64_t nx, int64_t ny,

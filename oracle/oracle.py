@@ -97,7 +97,7 @@ class Params3D(C.Structure):
                 ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double),
                 ("iterMax", C.c_int64), ("nout", C.c_int64),
-                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32)]
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32), ("displacement_bcs", C.c_int32)]
 
 
 class Params2D(C.Structure):
@@ -106,7 +106,7 @@ class Params2D(C.Structure):
                 ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double),
                 ("iterMax", C.c_int64), ("nout", C.c_int64),
-                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32)]
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32), ("displacement_bcs", C.c_int32)]
 
 
 class ThermalParams2D(C.Structure):
@@ -194,20 +194,20 @@ def bcmask(d) -> int:
 
 
 def params3d(ni, _di, dt, pt, *, iterMax=10_000, nout=500, free_slip=None, no_slip=None, periodic=None,
-             ni_g=None) -> Params3D:
+             ni_g=None, displacement_bcs=False) -> Params3D:
     """pt = dict(r, theta_dtau, eta_dtau, eps_rel, eps_abs)"""
     ni_g = ni_g or ni
     return Params3D(ni[0], ni[1], ni[2], ni_g[0], ni_g[1], ni_g[2], _di[0], _di[1], _di[2],
                     dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"], pt["eps_rel"], pt["eps_abs"],
-                    int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic))
+                    int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic), int(bool(displacement_bcs)))
 
 
 def params2d(ni, _di, dt, pt, *, iterMax=10_000, nout=500, free_slip=None, no_slip=None, periodic=None,
-             ni_g=None) -> Params2D:
+             ni_g=None, displacement_bcs=False) -> Params2D:
     ni_g = ni_g or ni
     return Params2D(ni[0], ni[1], ni_g[0], ni_g[1], _di[0], _di[1],
                     dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"], pt["eps_rel"], pt["eps_abs"],
-                    int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic))
+                    int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic), int(bool(displacement_bcs)))
 
 
 class _Res:

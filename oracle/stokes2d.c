@@ -221,7 +221,8 @@ void orc_stokes2d_iteration(const orc_fields2d *f, const double *etatau, const o
     orc_compute_tau2d(f, p);
     orc_compute_V2d(f, etatau, p);
     orc_velocity2displacement2d(f, p);
-    orc_flow_bcs2d(f->Vx, f->Vy, p->nx, p->ny, p->free_slip, p->no_slip, p->periodic);
+    if (p->displacement_bcs) orc_flow_bcs2d(f->Ux, f->Uy, p->nx, p->ny, p->free_slip, p->no_slip, p->periodic);
+    else orc_flow_bcs2d(f->Vx, f->Vy, p->nx, p->ny, p->free_slip, p->no_slip, p->periodic);
 }
 
 /* src/stokes/Stokes2D.jl:181-325 */
@@ -231,6 +232,11 @@ int32_t orc_stokes2d_solve(const orc_fields2d *f, const orc_params2d *p, orc_res
     const size_t n = (size_t)nx * ny;
     double *etatau = (double *)malloc(n * sizeof(double));
     orc_compute_maxloc2d(etatau, f->eta, nx, ny);   /* :208-209 */
+    if (p->displacement_bcs) {                      /* displacement2velocity!(stokes, dt, flow_bcs) :223 */
+        const double _dt = 1.0 / p->dt;
+        for (size_t c = 0; c < (size_t)(nx + 1) * (ny + 2); c++) f->Vx[c] = f->Ux[c] * _dt;
+        for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 1); c++) f->Vy[c] = f->Uy[c] * _dt;
+    }
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
     res->status = 0;

@@ -391,7 +391,8 @@ void orc_stokes3d_iteration(const orc_fields3d *f, const double *etatau, const o
     orc_compute_tau3d(f, p);
     orc_compute_V3d(f, etatau, p);
     orc_velocity2displacement3d(f, p);
-    orc_flow_bcs3d(f->Vx, f->Vy, f->Vz, p->nx, p->ny, p->nz, p->free_slip, p->no_slip, p->periodic);
+    if (p->displacement_bcs) orc_flow_bcs3d(f->Ux, f->Uy, f->Uz, p->nx, p->ny, p->nz, p->free_slip, p->no_slip, p->periodic);
+    else orc_flow_bcs3d(f->Vx, f->Vy, f->Vz, p->nx, p->ny, p->nz, p->free_slip, p->no_slip, p->periodic);
 }
 
 /* src/stokes/Stokes3D.jl:25-186 */
@@ -401,6 +402,12 @@ int32_t orc_stokes3d_solve(const orc_fields3d *f, const orc_params3d *p, orc_res
     const size_t n = (size_t)nx * ny * nz;
     double *etatau = (double *)malloc(n * sizeof(double));
     orc_compute_maxloc3d(etatau, f->eta, nx, ny, nz);     /* :55-57 */
+    if (p->displacement_bcs) {                            /* displacement2velocity!(stokes, dt, flow_bcs) :72 */
+        const double _dt = 1.0 / p->dt;
+        for (size_t c = 0; c < (size_t)(nx + 1) * (ny + 2) * (nz + 2); c++) f->Vx[c] = f->Ux[c] * _dt;
+        for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 1) * (nz + 2); c++) f->Vy[c] = f->Uy[c] * _dt;
+        for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 2) * (nz + 1); c++) f->Vz[c] = f->Uz[c] * _dt;
+    }
 
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;

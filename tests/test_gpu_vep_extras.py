@@ -193,3 +193,31 @@ def test_single_phase_driver_matches_oracle(jr, oracle, plastic):
     for k in out:
         assert max_rel_diff(out[k], ref[k]) <= 1e-8, k
     assert max_rel_diff(jr.to_numpy(ρg[1]), ref["fy"]) <= 1e-12
+
+
+@pytest.mark.parametrize("nd", [3, 2])
+def test_visco_elastic_drivers_with_displacement_bcs_match_oracle(jr, oracle, nd):
+    """solve!(…, flow_bcs::DisplacementBoundaryConditions, …) of the visco-elastic drivers: displacement2velocity! first (Stokes3D.jl:72,
+    Stokes2D.jl:223), flow_bcs! on @displacement afterwards (BoundaryConditions.jl:71-78) -- the ghosts of V are never refreshed."""
+    from justrelax_jl_amd import checks
+    from justrelax_jl_amd.arrays import DisplacementBoundaryConditions
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    s = jr.miniapps.random_fields3d((70, 9, 11), iterMax=20, nout=5) if nd == 3 else jr.miniapps.random_fields2d((33, 17), iterMax=20, nout=5)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    b = s.flow_bcs
+    s.flow_bcs = DisplacementBoundaryConditions(free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic)
+    for u, v in (("Ux", "Vx"), ("Uy", "Vy"), ("Uz", "Vz"))[:nd]:
+        s.arrays[u][...] = s.arrays[v] * s.dt
+        s.arrays[v][...] = 5.0
+    ref = _cp(s.arrays)
+    if nd == 3:
+        r_ref = oracle.stokes3d_solve(ref, checks.oracle_params3d(oracle, s))
+    else:
+        r_ref = oracle.stokes2d_solve(ref, checks.oracle_params2d(oracle, s))
+    stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
+    mats = (K, G) if nd == 3 else (G, K)
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, *mats, s.dt, None, kwargs=s.kwargs)
+    assert r.iter == r_ref["iter"] == 21
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-10)
+    d = checks.compare_stokes(download_stokes(stokes), ref)
+    assert max(d.values()) <= 1e-9, d
