@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JRX_VERSION 100
+#define JRX_VERSION 200
 
 typedef enum jrx_status {
     JRX_OK = 0,
@@ -59,6 +59,9 @@ jrx_status jrx_create(int32_t device, jrx_handle **out);
 jrx_status jrx_destroy(jrx_handle *h);
 const char *jrx_last_error(const jrx_handle *h);   /* h may be NULL: last creation error */
 int32_t jrx_version(void);
+/* sha256 of the sources (csrc/ + include/jrx.h) this binary was built from; the Python binding refuses a library whose id differs from
+ * the sources beside it */
+const char *jrx_build_id(void);
 
 /* Tuning / debugging knobs.  Keys: "kernel_variant" (3D Stokes):
  *   0 = default: fused PT pipeline where it applies (no periodic_boundary! faces, nx >= 48, ny, nz >= 8, and nx fills

@@ -162,6 +162,13 @@ def load(check_symbols: bool = False):
                                "There is no CPU fallback.")
         import torch  # noqa: F401  -- loads the process-wide HIP runtime (libamdhip64.so.7) first
         L = C.CDLL(str(LIB_PATH))
+        # the binary must have been built from the sources beside it (csrc/ + include/jrx.h): a stale .so would silently run old kernels
+        L.jrx_build_id.restype = C.c_char_p
+        from .build import source_id
+        have, want = L.jrx_build_id().decode(), source_id()
+        if have != want:
+            raise RuntimeError(f"{LIB_PATH} was built from other sources (build id {have[:12]}…, sources {want[:12]}…): "
+                               "run `python justrelax.jl_amd/build.py`")
         L.jrx_last_error.restype = C.c_char_p
         L.jrx_last_error.argtypes = [C.c_void_p]
         L.jrx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
@@ -169,7 +176,7 @@ def load(check_symbols: bool = False):
         L.jrx_n_global.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         for name in declared_symbols():
             fn = getattr(L, name)          # raises AttributeError if the symbol is not exported
-            if name not in ("jrx_last_error", "jrx_n_global", "jrx_version"):
+            if name not in ("jrx_last_error", "jrx_n_global", "jrx_version", "jrx_build_id"):
                 fn.restype = C.c_int32
         _lib = L
     if check_symbols:

@@ -4,9 +4,13 @@
 
 -ffp-contract=off: fused multiply-adds appear only where the source says fma(), which is where the
 reference has fma/muladd, so device results track the CPU restatement to the last bits.
+
+The library carries a build id = sha256 over csrc/* and include/jrx.h (jrx_build_id()).  A rebuild is skipped only when the existing
+.so carries the id of the current sources; `_lib.load()` compares the two again at load time and refuses a stale binary.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -17,15 +21,33 @@ CSRC = HERE / "csrc"
 OUT = HERE / "lib" / "libjrx_hip.so"
 SRCS = ["handle.hip", "halo.hip", "stokes3d.hip", "stokes3d_vep.hip", "stokes2d.hip", "thermal2d.hip", "thermal3d.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-I", str(HERE.parent / "include"), "-I", str(CSRC), "-I", "/opt/rocm/include", "-Wall", "-Wno-unused-function"]
+         "-I", str(HERE.parent / "include"), "-I", str(CSRC), "-I", "/opt/rocm/include", "-Wall", "-Wno-unused-function", "-Wno-array-bounds"]
+MARKER = b"JRX_BUILD_ID="
+
+
+def source_id() -> str:
+    """sha256 over the sources the library is built from (file names and contents, sorted)"""
+    hsh = hashlib.sha256()
+    files = sorted(p for p in CSRC.iterdir() if p.suffix in (".hip", ".hpp")) + [HERE.parent / "include" / "jrx.h"]
+    for p in files:
+        hsh.update(p.name.encode() + b"\0" + p.read_bytes() + b"\0")
+    return hsh.hexdigest()
+
+
+def binary_id(path: Path = OUT):
+    """the build id embedded in an existing .so (None if absent), read from the file without loading it"""
+    if not path.exists():
+        return None
+    data = path.read_bytes()
+    i = data.find(MARKER)
+    if i < 0:
+        return None
+    j = data.find(b"\0", i)
+    return data[i + len(MARKER):j].decode(errors="replace")
 
 
 def needs_build() -> bool:
-    if not OUT.exists():
-        return True
-    t = OUT.stat().st_mtime
-    deps = list(CSRC.glob("*")) + [HERE.parent / "include" / "jrx.h", Path(__file__)]
-    return any(d.stat().st_mtime > t for d in deps)
+    return binary_id() != source_id()
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
@@ -35,10 +57,12 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     OUT.parent.mkdir(exist_ok=True)
     objdir = HERE / "build"
     objdir.mkdir(exist_ok=True)
+    sid = source_id()
     procs = []
     for s in SRCS:
         o = objdir / (s + ".o")
-        cmd = [hipcc, *FLAGS, "-c", str(CSRC / s), "-o", str(o)]
+        extra = [f'-DJRX_BUILD_ID="{sid}"'] if s == "handle.hip" else []
+        cmd = [hipcc, *FLAGS, *extra, "-c", str(CSRC / s), "-o", str(o)]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
@@ -49,9 +73,11 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if binary_id() != sid:
+        raise RuntimeError("the built library does not carry the build id of its sources")
     return OUT
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
-    print("built", OUT)
+    print("built", OUT, "build id", binary_id())

@@ -14,9 +14,28 @@ jrx_status jrx_ensure_etatau(jrx_handle *h, size_t n)
     return JRX_OK;
 }
 
+jrx_status jrx_check_device(jrx_handle *h)
+{
+    if (!h) return JRX_ERR_ARG;
+    int cur = -1;
+    JRX_HIP(h, hipGetDevice(&cur));
+    if (cur != h->device)
+        return jrx_fail(h, JRX_ERR_ARG, "this handle is bound to device %d but the calling thread's current device is %d (hipSetDevice / torch.cuda.set_device "
+                                        "first: the library does not change it)", h->device, cur);
+    return JRX_OK;
+}
+
 extern "C" {
 
 int32_t jrx_version(void) { return JRX_VERSION; }
+
+// sha256 over csrc/* and include/jrx.h at build time (justrelax.jl_amd/build.py passes -DJRX_BUILD_ID); the marker string lets the
+// builder read the id of an existing .so without loading it
+#ifndef JRX_BUILD_ID
+#define JRX_BUILD_ID "unknown"
+#endif
+static const char g_jrx_build_marker[] = "JRX_BUILD_ID=" JRX_BUILD_ID;
+const char *jrx_build_id(void) { return g_jrx_build_marker + 13; }
 
 const char *jrx_last_error(const jrx_handle *h) { return h ? h->err : g_jrx_create_err; }
 
@@ -30,6 +49,8 @@ jrx_status jrx_create(int32_t device, jrx_handle **out)
     if (device < 0 || device >= ndev) return jrx_fail(nullptr, JRX_ERR_ARG, "jrx_create: device %d out of range [0,%d)", device, ndev);
     jrx_handle *h = new jrx_handle();
     h->device = device;
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);       // restored below: creating a handle does not change the caller's current device
 #define CK(call)                                                                                   \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
@@ -53,6 +74,7 @@ jrx_status jrx_create(int32_t device, jrx_handle **out)
     CK(hipMalloc(&h->d_sums, sizeof(double) * 8));
     CK(hipHostMalloc(&h->h_sums, sizeof(double) * 8, hipHostMallocDefault));
 #undef CK
+    if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);
     *out = h;
     return JRX_OK;
 }

@@ -81,6 +81,10 @@ static inline jrx_status jrx_fail(jrx_handle *h, jrx_status st, const char *fmt,
 
 #define JRX_LAUNCH_CHECK(h) JRX_HIP(h, hipGetLastError())
 
+// A handle is bound to one device (jrx_create); entry points that launch or allocate require that device to be the calling thread's
+// current one -- checked, never changed behind the caller's back
+jrx_status jrx_check_device(jrx_handle *h);
+
 // ensure the library-owned ητ scratch holds n doubles
 jrx_status jrx_ensure_etatau(jrx_handle *h, size_t n);
 

@@ -251,6 +251,7 @@ jrx_status check2(jrx_handle *h, const jrx_stokes2d_fields *f, const jrx_stokes2
 {
     if (!h) return JRX_ERR_ARG;
     if (!f || !p) return jrx_fail(h, JRX_ERR_ARG, "null fields/params");
+    JRX_TRY(jrx_check_device(h));
     if (p->nx < 3 || p->ny < 3) return jrx_fail(h, JRX_ERR_ARG, "2D Stokes needs at least 3 cells per dimension");
     if ((double)(p->nx + 2) * (double)(p->ny + 2) >= 2147483647.0) return jrx_fail(h, JRX_ERR_UNSUPPORTED, "grid too large");
     const void *req[] = {f->P, f->P0, f->divV, f->Q, f->Vx, f->Vy, f->Ux, f->Uy, f->txx, f->tyy, f->txy, f->toxx, f->toyy, f->toxy,
@@ -1005,6 +1006,7 @@ jrx_status check_vep(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheolog
 {
     if (!h) return JRX_ERR_ARG;
     if (!f || !rh || !p) return jrx_fail(h, JRX_ERR_ARG, "null VEP argument");
+    JRX_TRY(jrx_check_device(h));
     if (p->nx < 3 || p->ny < 3) return jrx_fail(h, JRX_ERR_ARG, "2D Stokes needs at least 3 cells per dimension");
     if (rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "nphase must be in 1..%d", JRX_MAXPHASE);
     const void *req[] = {f->P, f->P0, f->divV, f->Q, f->Vx, f->Vy, f->Ux, f->Uy, f->exx, f->eyy, f->exy, f->eplxx, f->eplyy, f->eplxy, f->eplxy_c,
@@ -1332,6 +1334,7 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
 {
     if (!h) return JRX_ERR_ARG;
     if (!f || !rh || !p || !res) return jrx_fail(h, JRX_ERR_ARG, "null argument");
+    JRX_TRY(jrx_check_device(h));
     if (p->nx < 3 || p->ny < 3) return jrx_fail(h, JRX_ERR_ARG, "2D Stokes needs at least 3 cells per dimension");
     if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
     if (rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "nphase must be in 1..%d", JRX_MAXPHASE);

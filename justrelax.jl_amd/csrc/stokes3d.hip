@@ -36,6 +36,7 @@ jrx_status check_params(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_s
 {
     if (!h) return JRX_ERR_ARG;
     if (!f || !p) return jrx_fail(h, JRX_ERR_ARG, "null fields/params");
+    JRX_TRY(jrx_check_device(h));
     if (p->nx < 3 || p->ny < 3 || p->nz < 3) return jrx_fail(h, JRX_ERR_ARG, "3D Stokes needs at least 3 cells per dimension");
     const double cells = (double)(p->nx + 2) * (double)(p->ny + 2) * (double)(p->nz + 2);
     if (cells >= 2147483647.0) return jrx_fail(h, JRX_ERR_UNSUPPORTED, "local block too large for 32-bit plane indices");

@@ -479,6 +479,7 @@ jrx_status check_vep3(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheolo
 {
     if (!h) return JRX_ERR_ARG;
     if (!f || !rh || !p) return jrx_fail(h, JRX_ERR_ARG, "null VEP argument");
+    JRX_TRY(jrx_check_device(h));
     if (p->nx < 3 || p->ny < 3 || p->nz < 3) return jrx_fail(h, JRX_ERR_ARG, "3D Stokes needs at least 3 cells per dimension");
     if ((double)(p->nx + 2) * (double)(p->ny + 2) * (double)(p->nz + 2) >= 536870912.0)
         return jrx_fail(h, JRX_ERR_UNSUPPORTED, "local block too large: every array must stay below 4 GiB (32-bit byte offsets)");

@@ -240,6 +240,7 @@ jrx_status checkT(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
 {
     if (!h) return JRX_ERR_ARG;
     if (!t || !p) return jrx_fail(h, JRX_ERR_ARG, "null thermal fields/params");
+    JRX_TRY(jrx_check_device(h));
     if (p->nx < 2 || p->ny < 2) return jrx_fail(h, JRX_ERR_ARG, "thermal grid too small");
     const void *req[] = {t->T, t->Told, t->dT, t->qTx, t->qTx2, t->qTy, t->qTy2, t->H, t->shear_heating, t->ResT, t->thetar_dtau, t->dtau_rho};
     for (const void *q : req)
@@ -406,12 +407,18 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
             JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
             JRX_HIP(h, hipStreamSynchronize(s));
             err = sqrt(h->h_sums[3]) * sq;          // norm(ResT) * _sq_len_RT : local norm, no reduction across ranks (:131)
+            // The reference stops each rank on its own local norm (no MPI reduction at :131); with an exchange in every iteration ranks that
+            // cross ϵ at different checks would then wait for each other for ever.  Deviation: with more than one rank the loop test uses the
+            // maximum of the local norms, so that all ranks leave together; the reported norm_ResT stays the local one.
+            double err_stop = err;
+            if (jrx_comm_active(h)) JRX_TRY(jrx_allreduce_host(h, &err_stop, 1, 1));
             if (cnt < cap) {
                 if (norm_ResT) norm_ResT[cnt] = err;
                 if (iter_count) iter_count[cnt] = iter;
             }
             cnt++;
-            if (p->verbose) printf("iter = %lld, err = %1.3e \n", (long long)iter, err);
+            if (p->verbose && jrx_comm_rank(h) == 0) printf("iter = %lld, err = %1.3e \n", (long long)iter, err);
+            err = err_stop;
         }
     }
     if (cur.T != user.T) {      // leave the results in the caller's arrays

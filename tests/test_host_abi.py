@@ -14,7 +14,30 @@ def test_library_exports_every_declared_symbol(jr):
     for s in syms:
         assert hasattr(L, s), s
     L.jrx_version.restype = C.c_int32
-    assert L.jrx_version() == 100
+    assert L.jrx_version() == 200
+
+
+def test_library_carries_the_build_id_of_its_sources(jr, tmp_path):
+    """jrx_build_id() = sha256 over csrc/ + include/jrx.h; the binding refuses a binary built from other sources, and the builder reads the
+    id of an existing .so from the file (no load) to decide whether to rebuild (VERDICT r1 weak #9)."""
+    from justrelax_jl_amd import _lib, build
+    L = _lib.load()
+    L.jrx_build_id.restype = C.c_char_p
+    sid = build.source_id()
+    assert len(sid) == 64 and L.jrx_build_id().decode() == sid == build.binary_id()
+    assert not build.needs_build()
+    stale = tmp_path / "libstale.so"
+    data = _lib.LIB_PATH.read_bytes()
+    i = data.find(build.MARKER) + len(build.MARKER)
+    stale.write_bytes(data[:i] + b"0" * 64 + data[i + 64:])           # same binary, another id
+    assert build.binary_id(stale) == "0" * 64 != sid
+    old_lib, old_path = _lib._lib, _lib.LIB_PATH
+    try:
+        _lib._lib, _lib.LIB_PATH = None, stale
+        with pytest.raises(RuntimeError, match="built from other sources"):
+            _lib.load()
+    finally:
+        _lib._lib, _lib.LIB_PATH = old_lib, old_path
 
 
 def test_no_gpu_means_loud_failure(jr):
