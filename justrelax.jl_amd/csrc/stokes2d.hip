@@ -597,6 +597,8 @@ __device__ __forceinline__ void plastic_params(const jrx_rheology &rh, const dou
     for (int q = 0; q < rh.nphase; q++)
         if (rh.is_pl[q]) { is_pl = true; eta_reg += rh.eta_vp[q] * r[q]; }
 }
+// SOFT: some phase has a softening law (compiled out otherwise)
+template <bool SOFT>
 __device__ __forceinline__ double yield_F(const jrx_rheology &rh, const double *r, double P, double tII, double EII)
 {   // compute_yieldfunction_phase, StressUpdate.jl:399-410 ; DP: F = τII - cosϕ(EII) C(EII) - sinϕ(EII) P (softening at the EII keyword)
     double F = 0.0;
@@ -604,9 +606,11 @@ __device__ __forceinline__ double yield_F(const jrx_rheology &rh, const double *
         if (r[q] == 0.0) continue;
         double Fq = tII;
         if (rh.is_pl[q]) {
-            double sp, cp;
-            mat_friction(rh, q, EII, sp, cp);
-            Fq = tII - cp * mat_cohesion(rh, q, EII) - sp * P;
+            if (SOFT) {
+                double sp, cp;
+                mat_friction(rh, q, EII, sp, cp);
+                Fq = tII - cp * mat_cohesion(rh, q, EII) - sp * P;
+            } else Fq = tII - rh.cosphi[q] * rh.C[q] - rh.sinphi[q] * P;
         }
         F += r[q] * Fq;
     }
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
 
 // update_stresses_center_vertex_ps! -- vertex half.  Runs before the centre half so that the vertex averages
 // see the old centre stresses (the reference's single launch races on them).
+template <bool SOFT>
 __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, const int j)
 {
     const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
@@ -685,7 +690,7 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
 #define AVC(A) (0.25 * (C2(A, i0, j0) + C2(A, ic, jc) + C2(A, i0, jc) + C2(A, ic, j0)))
     const double Pv = AVC(a.theta), exxv = AVC(a.f.exx), eyyv = AVC(a.f.eyy), txxv = AVC(a.f.txx), tyyv = AVC(a.f.tyy);
     const double toxxv = AVC(a.f.toxx), toyyv = AVC(a.f.toyy);
-    const double EIIv = a.soft ? AVC(a.f.EII_pl) : 0.0;      // EIIv_ij = av_clamped(EII, Ic...) (StressKernels.jl:1030); only softening laws read it
+    const double EIIv = SOFT ? AVC(a.f.EII_pl) : 0.0;      // EIIv_ij = av_clamped(EII, Ic...) (StressKernels.jl:1030); only softening laws read it
 #undef AVC
     const i64 v = i + (i64)(nx + 1) * j;
     const double *rv = a.f.phase_v + (i64)np * v;
@@ -704,7 +709,7 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
     double dQdt[3], dQdP, dFdP;
     plastic_grad(a.rh, rv, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
-    const double F = yield_F(a.rh, rv, Pv, tIIv, EIIv);
+    const double F = yield_F<SOFT>(a.rh, rv, Pv, tIIv, EIIv);
     if (is_pl && tIIv != 0.0 && F > 0) {
         const double l = fma(1.0 - a.rel, a.lamv[v], a.rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol)));
         a.lamv[v] = l;
@@ -722,10 +727,12 @@ __global__ __launch_bounds__(256) void k_vep_vertex(const VepArgs a)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / (a.nx + 1), i = t - j * (a.nx + 1);
     if (j > a.ny) return;
-    vep_vertex_at(a, i, j);
+    if (a.soft) vep_vertex_at<true>(a, i, j);
+    else vep_vertex_at<false>(a, i, j);
 }
 
 // update_stresses_center_vertex_ps! -- centre half (+ Pr_c, τII, η_vep)
+template <bool SOFT>
 __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, const int j)
 {
     const int nx = a.nx, np = a.rh.nphase;
@@ -751,7 +758,7 @@ __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, con
     plastic_grad(a.rh, rc, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
     const double Pr = a.theta[c];
-    const double F = yield_F(a.rh, rc, Pr, tII, a.soft ? a.f.EII_pl[c] : 0.0);
+    const double F = yield_F<SOFT>(a.rh, rc, Pr, tII, SOFT ? a.f.EII_pl[c] : 0.0);
     double l = a.lam[c];
     if (is_pl && tII != 0.0 && F > 0) {
         l = fma(1.0 - a.rel, l, a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol)));
@@ -777,17 +784,19 @@ __global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / a.nx, i = t - j * a.nx;
     if (j >= a.ny) return;
-    vep_centre_at(a, i, j);
+    if (a.soft) vep_centre_at<true>(a, i, j);
+    else vep_centre_at<false>(a, i, j);
 }
 // both halves in one launch: the vertex half averages the OLD centre stresses, so the centre half must write τxx, τyy elsewhere
 // (a.txx_out / a.tyy_out; the caller then swaps the pointers)
+template <bool SOFT>
 __global__ __launch_bounds__(256) void k_vep_stress2d(const VepArgs a)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / (a.nx + 1), i = t - j * (a.nx + 1);
     if (j > a.ny) return;
-    vep_vertex_at(a, i, j);
-    if (i < a.nx && j < a.ny) vep_centre_at(a, i, j);
+    vep_vertex_at<SOFT>(a, i, j);
+    if (i < a.nx && j < a.ny) vep_centre_at<SOFT>(a, i, j);
 }
 
 // compute_τ_nonlinear! 2D: single phase (StressKernels.jl:266-307) / phases at the cell centres (:310-351) with
@@ -1220,7 +1229,8 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
         else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, a, theta);      // compute_maxloc! folded in
         JRX_LAUNCH_CHECK(h);
         // update_stresses_center_vertex_ps!: vertex and centre halves in one launch; the new τxx, τyy go to the other set, then swap
-        hipLaunchKernelGGL(k_vep_stress2d, dim3(gv), dim3(256), 0, s, a);
+        if (a.soft) hipLaunchKernelGGL(k_vep_stress2d<true>, dim3(gv), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_vep_stress2d<false>, dim3(gv), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
         { double *t_ = a.f.txx; a.f.txx = a.txx_out; a.txx_out = t_; }
         { double *t_ = a.f.tyy; a.f.tyy = a.tyy_out; a.tyy_out = t_; }

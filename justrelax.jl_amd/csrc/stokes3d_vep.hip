@@ -61,6 +61,8 @@ __device__ __forceinline__ void plastic_params3(const jrx_rheology &rh, const do
     for (int q = 0; q < rh.nphase; q++)
         if (rh.is_pl[q]) { is_pl = true; eta_reg += rh.eta_vp[q] * r[q]; }
 }
+// SOFT: some phase has a softening law (compiled out otherwise: the erfc / sincos paths cost the edge kernel its second wave per SIMD)
+template <bool SOFT>
 __device__ __forceinline__ double yield_F3(const jrx_rheology &rh, const double *r, double P, double tII, double EII)
 {   // compute_yieldfunction_phase, StressUpdate.jl:435-452 ; DP: F = τII - cosϕ(EII) C(EII) - sinϕ(EII) P (softening at the EII keyword)
     double F = 0.0;
@@ -68,9 +70,11 @@ __device__ __forceinline__ double yield_F3(const jrx_rheology &rh, const double 
         if (r[q] == 0.0) continue;
         double Fq = tII;
         if (rh.is_pl[q]) {
-            double sp, cp;
-            mat_friction(rh, q, EII, sp, cp);
-            Fq = tII - cp * mat_cohesion(rh, q, EII) - sp * P;
+            if (SOFT) {
+                double sp, cp;
+                mat_friction(rh, q, EII, sp, cp);
+                Fq = tII - cp * mat_cohesion(rh, q, EII) - sp * P;
+            } else Fq = tII - rh.cosphi[q] * rh.C[q] - rh.sinphi[q] * P;
         }
         F += r[q] * Fq;
     }
@@ -209,7 +213,7 @@ __host__ __device__ constexpr int oth3(int t, int s, int q, int d)
 struct CenAvg {
     double v[9][3], etav[3], Pv[3], EIIv[3];      // EIIv: av_clamped_yz/xz/xy(EII_pl) (StressKernels.jl:710,783,854), only gathered for softening laws
 };
-template <int T>
+template <int T, bool SOFT>
 __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, int k, const int ci[3], const int cj[3], const int ck[3], const CenAvg &C)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
@@ -253,7 +257,7 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
     double dQdt[6], dQdP, dFdP;
     plastic_grad3(a.rh, rv, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
-    const double F = yield_F3(a.rh, rv, Pv, tIIv, C.EIIv[T]);
+    const double F = yield_F3<SOFT>(a.rh, rv, Pv, tIIv, SOFT ? C.EIIv[T] : 0.0);
     constexpr int own = 3 + T;
     if (is_pl && tIIv != 0.0 && F > 0) {
         const double l = (1.0 - a.rel) * a.lamv[T][v] + a.rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol));
@@ -270,6 +274,7 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
 // The clamped centre stencils of the three families lie in the 2 x 2 x 2 cube of cells below the node (cen3: bit = 1 own index,
 // 0 index - 1) and share 7 of its 8 cells: every centre array is read 7 times per node instead of 12, in the reference's order of
 // summation per family.
+template <bool SOFT>
 __device__ __forceinline__ void vep3_gather_centres(const Vep3Args &a, const int ci[3], const int cj[3], const int ck[3], CenAvg &C)
 {
     typedef unsigned int u32;
@@ -299,7 +304,7 @@ __device__ __forceinline__ void vep3_gather_centres(const Vep3Args &a, const int
 #pragma unroll
         for (int T = 0; T < 3; T++) C.etav[T] = 4 / (v[CIDX(T, 0)] + v[CIDX(T, 1)] + v[CIDX(T, 2)] + v[CIDX(T, 3)]);
         C.EIIv[0] = C.EIIv[1] = C.EIIv[2] = 0.0;
-        if (a.soft) {
+        if (SOFT) {
 #pragma unroll
             for (int b = 1; b < 8; b++) v[b] = LB(a.f.EII_pl, cb[b]);
 #pragma unroll
@@ -315,7 +320,7 @@ __device__ __forceinline__ void vep3_gather_centres(const Vep3Args &a, const int
 // New edge stresses go to a.tnew (committed by the caller), so every read sees last iteration's values.
 // XS: blocks are dealt round-robin to the 8 XCDs; give XCD q the q-th eighth of the (flattened xy, z) block sequence instead, so that the
 // rows j +- 1 and planes k +- 1 a block gathers from were fetched by the same L2
-template <bool P4, bool XS = false>
+template <bool P4, bool XS = false, bool SOFT = false>
 __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny;
@@ -342,13 +347,14 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
     const int cj[3] = {clampi3(j - 1, 0, ny - 1), clampi3(j, 0, ny - 1), clampi3(j + 1, 0, ny - 1)};
     const int ck[3] = {clampi3(k - 1, 0, nz - 1), clampi3(k, 0, nz - 1), clampi3(k + 1, 0, nz - 1)};
     CenAvg C;
-    vep3_gather_centres(a, ci, cj, ck, C);
-    vep3_edge_body<0>(a, i, j, k, ci, cj, ck, C);
-    vep3_edge_body<1>(a, i, j, k, ci, cj, ck, C);
-    vep3_edge_body<2>(a, i, j, k, ci, cj, ck, C);
+    vep3_gather_centres<SOFT>(a, ci, cj, ck, C);
+    vep3_edge_body<0, SOFT>(a, i, j, k, ci, cj, ck, C);
+    vep3_edge_body<1, SOFT>(a, i, j, k, ci, cj, ck, C);
+    vep3_edge_body<2, SOFT>(a, i, j, k, ci, cj, ck, C);
 }
 
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
+template <bool SOFT>
 __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
     plastic_grad3(a.rh, rc, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
     const double Pr = a.theta[c];
-    const double F = yield_F3(a.rh, rc, Pr, tII, a.soft ? a.f.EII_pl[c] : 0.0);
+    const double F = yield_F3<SOFT>(a.rh, rc, Pr, tII, SOFT ? a.f.EII_pl[c] : 0.0);
     double l = a.lam[c];
     if (is_pl && tII != 0.0 && F > 0) {
         l = (1.0 - a.rel) * l + a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol));
@@ -518,7 +524,8 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const bool p4 = h->vep3_map, xs = h->vep3_xcd;     // options "vep3_map", "vep3_xcd" (XCD slab order: +1-2 % measured)
-    if (p4 && xs) hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    else if (p4 && xs) hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
@@ -529,7 +536,8 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
                            (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
         JRX_LAUNCH_CHECK(h);
     }
-    hipLaunchKernelGGL(k_vep3_centre, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
+    if (a.soft) hipLaunchKernelGGL(k_vep3_centre<true>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_vep3_centre<false>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
