@@ -443,7 +443,7 @@ typedef struct jrx_thermal3d_fields {
     double *qTz, *qTz2;                    /* (nx, ny, nz+1) */
     double *H, *shear_heating, *ResT;      /* ni */
     const double *K, *rhoCp;               /* ni: array-coefficient form; NULL in the rheology form */
-    const double *thetar_dtau, *dtau_rho;  /* ni: PTThermalCoeffs */
+    const double *thetar_dtau, *dtau_rho;  /* ni: PTThermalCoeffs (rewritten every iteration by jrx_heatdiffusion_PT3d_phases) */
 } jrx_thermal3d_fields;
 
 typedef struct jrx_thermal3d_params {
@@ -465,6 +465,36 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
 jrx_status jrx_thermal_bcs3d(jrx_handle *h, double *T, const jrx_thermal3d_params *p);
 jrx_status jrx_thermal3d_iteration(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p);
 jrx_status jrx_thermal3d_check_res(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p);
+
+/* ------------------------------------------------------------------ phase-ratio form of the heat-diffusion path
+ * heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, rheology, args, dt, grid; kwargs = (phase = phase_ratios, ...)) --
+ * src/thermal_diffusion/DiffusionPT_solver.jl:181-305 with phase !== nothing: update_pt_thermal_arrays! every iteration
+ * (DiffusionPT_coefficients.jl:105-136), conductivity from the face phase ratios (DiffusionPT_kernels.jl:366-440 / :62-158), ρCp and
+ * radioactive heat from the centre ratios (:553-601, :631-668 / :200-249, :283-325).  Per phase: ConstantConductivity k,
+ * ConstantHeatCapacity Cp, ConstantRadioactiveHeat H_r and a density law (rho_kind as in jrx_rheology: 0 constant, 1 PT_Density,
+ * 2 T_Density, 3 Compressible_Density).  p->rheology_form is ignored (set to 2 internally); t->K / t->rhoCp are not read. */
+typedef struct jrx_thermal_phases {
+    int32_t nphase;
+    double k[JRX_MAXPHASE], Cp[JRX_MAXPHASE], Hr[JRX_MAXPHASE];
+    int32_t rho_kind[JRX_MAXPHASE];
+    double rho0[JRX_MAXPHASE], alpha[JRX_MAXPHASE], beta[JRX_MAXPHASE], T0[JRX_MAXPHASE], P0[JRX_MAXPHASE];
+    double max_lxyz, Vpdtau;               /* pt_thermal.max_lxyz, pt_thermal.Vpdτ */
+} jrx_thermal_phases;
+
+typedef struct jrx_thermal_phase_fields {
+    const double *P;                       /* args.P (ni) */
+    const double *phase_c;                 /* phase_ratios.center [nphase][ni], phase index fastest */
+    const double *phase_qx, *phase_qy, *phase_qz;   /* phase_ratios.Vx (nx+1, ny[, nz]), .Vy (nx, ny+1[, nz]), .Vz (nx, ny, nz+1); qz NULL in 2D */
+} jrx_thermal_phase_fields;
+
+jrx_status jrx_heatdiffusion_PT2d_phases(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p, const jrx_thermal_phases *ph,
+                                         const jrx_thermal_phase_fields *pf, int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms);
+jrx_status jrx_heatdiffusion_PT3d_phases(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, const jrx_thermal_phases *ph,
+                                         const jrx_thermal_phase_fields *pf, int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms);
+/* update_pt_thermal_arrays!(pt_thermal, phase_ratios, rheology, args, _dt) -- DiffusionPT_coefficients.jl:105-136: writes thetar_dtau, dtau_rho (ni)
+ * from T (ni.+2, read at Idx.+1), P and the centre ratios; n = {nx, ny, nz} (nz = 1 in 2D) */
+jrx_status jrx_update_pt_thermal_arrays(jrx_handle *h, double *thetar_dtau, double *dtau_rho, const double *T, const int64_t n[3], int32_t ndim, double dt,
+                                        const jrx_thermal_phases *ph, const jrx_thermal_phase_fields *pf);
 
 /* ------------------------------------------------------------------ timing hooks for bench.py */
 /* Runs `iters` PT iterations of the 3D loop body back to back (no norm checks) and reports device times

@@ -84,6 +84,15 @@ class Thermal3DParams(C.Structure):
                 ("verbose", C.c_int32)]
 
 
+class ThermalPhases(C.Structure):
+    _fields_ = [("nphase", C.c_int32)] + [(k, C.c_double * 8) for k in ("k", "Cp", "Hr")] + [("rho_kind", C.c_int32 * 8)] + \
+               [(k, C.c_double * 8) for k in ("rho0", "alpha", "beta", "T0", "P0")] + [("max_lxyz", C.c_double), ("Vpdtau", C.c_double)]
+
+
+TPH_NAMES = ["P", "phase_c", "phase_qx", "phase_qy", "phase_qz"]
+ThermalPhaseFields = _ptr_struct("ThermalPhaseFields", TPH_NAMES)
+
+
 VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
              "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
              "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v", "T"]

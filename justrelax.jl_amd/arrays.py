@@ -141,6 +141,9 @@ class PhaseRatios:
         self.nphases = int(nphases)
         self.center = fzeros((self.nphases,) + ni, dev)
         self.vertex = fzeros((self.nphases,) + tuple(n + 1 for n in ni), dev)
+        # ratios at the velocity nodes (the heat-flux locations): Vx (nx+1, ny[, nz]), Vy (nx, ny+1[, nz]), Vz (nx, ny, nz+1)
+        for d, name in enumerate(("Vx", "Vy", "Vz")[: len(ni)]):
+            setattr(self, name, fzeros((self.nphases,) + tuple(n + (1 if e == d else 0) for e, n in enumerate(ni)), dev))
         if len(ni) == 3:               # phase ratios at the shear-stress locations (edges), 3D only
             ts = _tensor_shapes(ni)
             self.yz, self.xz, self.xy = (fzeros((self.nphases,) + ts[k], dev) for k in ("yz", "xz", "xy"))
@@ -246,6 +249,8 @@ class PTThermalCoeffs:
     """
 
     def __init__(self, backend_tag, K, ρCp, dt, di, li, *, ϵ=1.0e-8, CFL=0.9 / math.sqrt(3)):
+        if isinstance(K, (list, tuple)):
+            raise TypeError("multi-phase rheology: use PTThermalCoeffs.from_phases(backend, rheology, phase_ratios, args, dt, ni, di, li)")
         Vpdτ = min(di) * CFL
         max_lxyz = max(li)
         max_lxyz2 = max_lxyz ** 2
@@ -253,6 +258,18 @@ class PTThermalCoeffs:
         self.CFL, self.ϵ, self.max_lxyz, self.max_lxyz2, self.Vpdτ = CFL, ϵ, max_lxyz, max_lxyz2, Vpdτ
         self.θr_dτ = max_lxyz / Vpdτ / Re
         self.dτ_ρ = Vpdτ * max_lxyz / K / Re
+
+    @classmethod
+    def from_phases(cls, backend_tag, rheology, phase_ratios, args, dt, ni, di, li, *, ϵ=1.0e-8, CFL=0.9 / math.sqrt(3)):
+        """PTThermalCoeffs(backend, rheology, phase_ratios, args, dt, ni, di, li; ϵ, CFL) -- DiffusionPT_coefficients.jl:39-66:
+        the arrays are filled on the device by update_pt_thermal_arrays! (jrx_update_pt_thermal_arrays)."""
+        from .thermal import update_pt_thermal_arrays_
+        self = cls.__new__(cls)
+        dev = device_of(backend_tag)
+        self.CFL, self.ϵ, self.max_lxyz, self.max_lxyz2, self.Vpdτ = CFL, ϵ, max(li), max(li) ** 2, min(di) * CFL
+        self.θr_dτ, self.dτ_ρ = fzeros(tuple(ni), dev), fzeros(tuple(ni), dev)
+        update_pt_thermal_arrays_(self, phase_ratios, rheology, args, 1.0 / dt)
+        return self
 
 
 # ----------------------------------------------------------------------------- boundary conditions

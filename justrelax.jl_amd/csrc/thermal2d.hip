@@ -7,6 +7,7 @@
 // thermal_bcs! (BoundaryConditions.jl:39-53; constant_value.jl:1-13; free_slip.jl:72-84; periodic.jl:1-13).
 #include "jrx_internal.hpp"
 #include "jrx_kernels.hpp"
+#include "jrx_thermal_phases.hpp"
 
 namespace {
 
@@ -22,9 +23,11 @@ __device__ __forceinline__ double rhoCp_of(const jrx_thermal2d_params &p, const 
     return p.rheology_form ? p.Cp * (p.rho0 * (1.0 - p.alpha * (T - p.T0))) : rhoCp[c];
 }
 
-// compute_flux! over (nx+1, ny+1)
-__global__ __launch_bounds__(256) void k_flux2d(const TArgs a)
+// compute_flux! over (nx+1, ny+1); PHT = TPh: conductivity from the face phase ratios
+template <class PHT>
+__global__ __launch_bounds__(256) void k_flux2d(const TArgs a, const PHT ph)
 {
+    constexpr bool PH = is_tph<PHT>::value;
     const int nx = (int)a.p.nx, ny = (int)a.p.ny;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / (nx + 1), i = t - j * (nx + 1);
@@ -37,7 +40,9 @@ __global__ __launch_bounds__(256) void k_flux2d(const TArgs a)
         else if (i == nx && a.p.constant_flux_on[TR]) a.t.qTx[q] = a.p.constant_flux[TR];
         else {
             const int iL = clampi(i - 1, 0, nx - 1), iR = clampi(i, 0, nx - 1);
-            const double Kx = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[iL + (i64)nx * j] + a.t.K[iR + (i64)nx * j]) * 0.5;
+            double Kx;
+            if constexpr (PH) Kx = (tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (iL + (i64)(nx + 1) * j)) + tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (iR + (i64)(nx + 1) * j))) * 0.5;
+            else Kx = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[iL + (i64)nx * j] + a.t.K[iR + (i64)nx * j]) * 0.5;
             const double thx = (th[iL + (i64)nx * j] + th[iR + (i64)nx * j]) * 0.5;
             const double qx = -Kx * (TT_(i + 1, j + 1) - TT_(i, j + 1)) * a.p._dx;
             a.t.qTx2[q] = qx;
@@ -50,7 +55,9 @@ __global__ __launch_bounds__(256) void k_flux2d(const TArgs a)
         else if (j == ny && a.p.constant_flux_on[TT]) a.t.qTy[q] = a.p.constant_flux[TT];
         else {
             const int jB = clampi(j - 1, 0, ny - 1), jT = clampi(j, 0, ny - 1);
-            const double Ky = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[i + (i64)nx * jB] + a.t.K[i + (i64)nx * jT]) * 0.5;
+            double Ky;
+            if constexpr (PH) Ky = (tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * jB)) + tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * jT))) * 0.5;
+            else Ky = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[i + (i64)nx * jB] + a.t.K[i + (i64)nx * jT]) * 0.5;
             const double thy = (th[i + (i64)nx * jB] + th[i + (i64)nx * jT]) * 0.5;
             const double qy = -Ky * (TT_(i + 1, j + 1) - TT_(i + 1, j)) * a.p._dy;
             a.t.qTy2[q] = qy;
@@ -85,9 +92,10 @@ __device__ __forceinline__ void thermal_ghosts2d(const jrx_thermal2d_params &p, 
 }
 
 // update_T! (RES=false) / check_res! (RES=true) over ni; BCF: cells next to a face also apply thermal_bcs! to their ghosts
-template <bool RES, bool BCF = false>
-__global__ __launch_bounds__(256) void k_updateT2d(const TArgs a)
+template <bool RES, bool BCF, class PHT>
+__global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
 {
+    constexpr bool PH = is_tph<PHT>::value;
     const int nx = (int)a.p.nx, ny = (int)a.p.ny;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / nx, i = t - j * nx;
@@ -95,17 +103,24 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a)
     const i64 c = i + (i64)nx * j, I1 = (i + 1) + (i64)(nx + 2) * (j + 1);
     const double _dt = 1.0 / a.p.dt;
     const double Tij = a.t.T[I1];
-    const double rcp = rhoCp_of(a.p, a.t.rhoCp, c, Tij);
+    double rcp, Hr = 0.0;
+    if constexpr (PH) {
+        const double *rc = ph.f.phase_c + ph.m.nphase * c;
+        rcp = tph_rhoCp(ph.m, rc, Tij, ph.f.P[c]);
+        Hr = tph_Hr(ph.m, rc);
+    } else rcp = rhoCp_of(a.p, a.t.rhoCp, c, Tij);
     if (RES) {
-        a.t.ResT[c] = -rcp * (Tij - a.t.Told[I1]) * _dt -
-                      ((a.t.qTx2[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx2[i + (i64)(nx + 1) * j]) * a.p._dx +
-                       (a.t.qTy2[i + (i64)nx * (j + 1)] - a.t.qTy2[c]) * a.p._dy) +
-                      a.t.H[c] + a.t.shear_heating[c];
+        const double dq = (a.t.qTx2[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx2[i + (i64)(nx + 1) * j]) * a.p._dx +
+                          (a.t.qTy2[i + (i64)nx * (j + 1)] - a.t.qTy2[c]) * a.p._dy;
+        if constexpr (PH) a.t.ResT[c] = -rcp * (Tij - a.t.Told[I1]) * _dt - dq + Hr + a.t.H[c] + a.t.shear_heating[c];
+        else a.t.ResT[c] = -rcp * (Tij - a.t.Told[I1]) * _dt - dq + a.t.H[c] + a.t.shear_heating[c];
     } else {
         const double dr = a.t.dtau_rho[c];
         const double divq = (a.t.qTx[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx[i + (i64)(nx + 1) * j]) * a.p._dx +
                             (a.t.qTy[i + (i64)nx * (j + 1)] - a.t.qTy[c]) * a.p._dy;
-        const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+        double Tn;
+        if constexpr (PH) Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+        else Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
         a.t.T[I1] = Tn;
         if (BCF) {
             const int xs = i == 0 ? 0 : (i == nx - 1 ? 1 : -1), ys = j == 0 ? 0 : (j == ny - 1 ? 1 : -1);
@@ -236,6 +251,21 @@ __global__ __launch_bounds__(256) void k_sub(double *__restrict__ d, const doubl
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) d[t] = a[t] - b[t];
 }
 
+// update_pt_thermal_arrays! (DiffusionPT_coefficients.jl:105-136) over ni of a 2D or 3D grid (nz = 1 in 2D): T read at Idx .+ 1
+__global__ __launch_bounds__(256) void k_pt_thermal_arrays(double *__restrict__ th, double *__restrict__ dr, const double *__restrict__ T, int nx, int ny, int nz,
+                                                           int ndim, double _dt, const TPh ph)
+{
+    const i64 n = (i64)nx * ny * nz;
+    for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (i64)gridDim.x * blockDim.x) {
+        const int k = (int)(c / ((i64)nx * ny)), j = (int)((c - (i64)k * nx * ny) / nx), i = (int)(c - (i64)k * nx * ny - (i64)j * nx);
+        const i64 I1 = ndim == 3 ? (i + 1) + (i64)(nx + 2) * ((j + 1) + (i64)(ny + 2) * (k + 1)) : (i + 1) + (i64)(nx + 2) * (j + 1);
+        double a, b;
+        tph_pt_coeffs(ph.m, ph.f.phase_c + ph.m.nphase * c, T[I1], ph.f.P[c], _dt, a, b);
+        th[c] = a;
+        dr[c] = b;
+    }
+}
+
 jrx_status checkT(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p)
 {
     if (!h) return JRX_ERR_ARG;
@@ -246,6 +276,7 @@ jrx_status checkT(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
     for (const void *q : req)
         if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required thermal field pointer is NULL");
     if (!p->rheology_form && (!t->K || !t->rhoCp)) return jrx_fail(h, JRX_ERR_ARG, "K / rhoCp arrays required in the array-coefficient form");
+    if (p->rheology_form != 0 && p->rheology_form != 1) return jrx_fail(h, JRX_ERR_ARG, "rheology_form must be 0 or 1 (phase-ratio form: jrx_heatdiffusion_PT2d_phases)");
     return JRX_OK;
 }
 
@@ -289,21 +320,22 @@ jrx_status launch_tbcs(jrx_handle *h, hipStream_t s, double *T, const jrx_therma
 }
 
 // fuse_bc: thermal_bcs! refreshed by the update kernel itself (no periodic face, no neighbour rank, grid at least 2 cells wide)
-jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p, bool fuse_bc = false)
+template <class PHT>
+jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p, const PHT &ph, bool fuse_bc = false)
 {
     TArgs a;
     a.t = *t; a.p = *p;
     const int nx = (int)p->nx, ny = (int)p->ny;
     hipStream_t s = h->stream;
-    hipLaunchKernelGGL(k_flux2d, dim3((unsigned)(((i64)(nx + 1) * (ny + 1) + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_flux2d<PHT>, dim3((unsigned)(((i64)(nx + 1) * (ny + 1) + 255) / 256)), dim3(256), 0, s, a, ph);
     JRX_LAUNCH_CHECK(h);
     const bool any_periodic = p->periodic[0] | p->periodic[1] | p->periodic[2] | p->periodic[3];
     if (fuse_bc && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2) {
-        hipLaunchKernelGGL((k_updateT2d<false, true>), dim3((unsigned)(((i64)nx * ny + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_updateT2d<false, true, PHT>), dim3((unsigned)(((i64)nx * ny + 255) / 256)), dim3(256), 0, s, a, ph);
         JRX_LAUNCH_CHECK(h);
         return JRX_OK;
     }
-    hipLaunchKernelGGL(k_updateT2d<false>, dim3((unsigned)(((i64)nx * ny + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_updateT2d<false, false, PHT>), dim3((unsigned)(((i64)nx * ny + 255) / 256)), dim3(256), 0, s, a, ph);
     JRX_LAUNCH_CHECK(h);
     JRX_TRY(launch_tbcs(h, s, t->T, p));
     if (jrx_comm_active(h)) {
@@ -316,6 +348,15 @@ jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx
 }
 
 }   // namespace
+
+jrx_status jrx_enqueue_pt_thermal_arrays(jrx_handle *h, hipStream_t s, double *th, double *dr, const double *T, int nx, int ny, int nz, int ndim, double _dt, const TPh &ph)
+{
+    const i64 n = (i64)nx * ny * nz;
+    const i64 nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_pt_thermal_arrays, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, s, th, dr, T, nx, ny, nz, ndim, _dt, ph);
+    JRX_LAUNCH_CHECK(h);
+    return JRX_OK;
+}
 
 extern "C" {
 
@@ -331,7 +372,7 @@ jrx_status jrx_thermal_bcs2d(jrx_handle *h, double *T, const jrx_thermal2d_param
 jrx_status jrx_thermal2d_iteration(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p)
 {
     JRX_TRY(checkT(h, t, p));
-    JRX_TRY(enqueue_titer(h, t, p));
+    JRX_TRY(enqueue_titer(h, t, p, NoPh{}));
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
 }
@@ -341,16 +382,20 @@ jrx_status jrx_thermal2d_check_res(jrx_handle *h, const jrx_thermal2d_fields *t,
     JRX_TRY(checkT(h, t, p));
     TArgs a;
     a.t = *t; a.p = *p;
-    hipLaunchKernelGGL(k_updateT2d<true>, dim3((unsigned)(((i64)p->nx * p->ny + 255) / 256)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((k_updateT2d<true, false, NoPh>), dim3((unsigned)(((i64)p->nx * p->ny + 255) / 256)), dim3(256), 0, h->stream, a, NoPh{});
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
 }
 
-jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p,
-                                  int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms)
+}   // extern "C"
+
+namespace {
+template <class PHT>
+jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p, const PHT &ph,
+                  int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms)
 {
-    JRX_TRY(checkT(h, t, p));
+    constexpr bool PH = is_tph<PHT>::value;
     if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
     const int nx = (int)p->nx, ny = (int)p->ny;
     const i64 nT = (i64)(nx + 2) * (ny + 2), n = (i64)nx * ny;
@@ -363,7 +408,7 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
     a.t = *t; a.p = *p;
     // iterations nobody observes: one fused launch, ping-pong between the caller's (T, qT) and a library-owned set (option thermal_fused)
     const bool any_periodic = p->periodic[0] | p->periodic[1] | p->periodic[2] | p->periodic[3];
-    const bool fusable = h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
+    const bool fusable = !PH && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
     const TSet2 user = {t->T, t->qTx, t->qTy};
     TSet2 cur = user, oth = user;
     if (fusable) {
@@ -382,6 +427,9 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
     while (err > p->eps && iter < p->iterMax) {
         const bool observed = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
         a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy;
+        if constexpr (PH) {      // update_pt_thermal_arrays!(pt_thermal, phase, rheology, args, _dt) -- DiffusionPT_solver.jl:233-234
+            JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, s, t->thetar_dtau, t->dtau_rho, cur.T, nx, ny, 1, 2, 1.0 / p->dt, ph));
+        }
         if (fusable && !observed) {
             if (FTX == 256) hipLaunchKernelGGL(k_thermal2d_fused<256>, dim3((unsigned)(ntx * ny)), dim3(256), 0, s, a, oth, ntx);
             else if (FTX == 128) hipLaunchKernelGGL(k_thermal2d_fused<128>, dim3((unsigned)(ntx * ny)), dim3(128), 0, s, a, oth, ntx);
@@ -391,11 +439,11 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
             const TSet2 tmp = cur; cur = oth; oth = tmp;
         } else {
             tc.T = cur.T; tc.qTx = cur.qx; tc.qTy = cur.qy;
-            JRX_TRY(enqueue_titer(h, &tc, p, true));
+            JRX_TRY(enqueue_titer(h, &tc, p, ph, true));
         }
         iter++;
         if (iter % p->nout == 0) {
-            hipLaunchKernelGGL(k_updateT2d<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_updateT2d<true, false, PHT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, ph);
             JRX_LAUNCH_CHECK(h);
             RedArr Z = {nullptr, {0, 0, 0}, 0}, A3 = {t->ResT, {nx, ny, 1}, 0};
             int nb = (int)((n + 2047) / 2048);
@@ -430,6 +478,45 @@ jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, 
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(s));
     if (nnorms) *nnorms = cnt < cap ? cnt : cap;
+    return JRX_OK;
+}
+}   // namespace
+
+extern "C" {
+
+jrx_status jrx_heatdiffusion_PT2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p,
+                                  int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms)
+{
+    JRX_TRY(checkT(h, t, p));
+    return heat2d(h, t, p, NoPh{}, iter_count, norm_ResT, cap, nnorms);
+}
+
+jrx_status jrx_heatdiffusion_PT2d_phases(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p, const jrx_thermal_phases *ph,
+                                         const jrx_thermal_phase_fields *pf, int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!p) return jrx_fail(h, JRX_ERR_ARG, "null thermal params");
+    jrx_thermal2d_params q = *p;
+    q.rheology_form = 1;                        // K / rhoCp arrays are not read
+    JRX_TRY(checkT(h, t, &q));
+    JRX_TRY(tph_check(h, ph, pf, false));
+    q.rheology_form = 2;
+    TPh x;
+    x.m = *ph; x.f = *pf;
+    return heat2d(h, t, &q, x, iter_count, norm_ResT, cap, nnorms);
+}
+
+jrx_status jrx_update_pt_thermal_arrays(jrx_handle *h, double *thetar_dtau, double *dtau_rho, const double *T, const int64_t n[3], int32_t ndim, double dt,
+                                        const jrx_thermal_phases *ph, const jrx_thermal_phase_fields *pf)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!thetar_dtau || !dtau_rho || !T || !n || (ndim != 2 && ndim != 3)) return jrx_fail(h, JRX_ERR_ARG, "update_pt_thermal_arrays!: bad argument");
+    JRX_TRY(jrx_check_device(h));
+    if (!ph || !pf || !pf->P || !pf->phase_c) return jrx_fail(h, JRX_ERR_ARG, "update_pt_thermal_arrays!: phases, args.P and the centre ratios are required");
+    TPh x;
+    x.m = *ph; x.f = *pf;
+    JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, h->stream, thetar_dtau, dtau_rho, T, (int)n[0], (int)n[1], ndim == 3 ? (int)n[2] : 1, (int)ndim, 1.0 / dt, x));
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
 }
 

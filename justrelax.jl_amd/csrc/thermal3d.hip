@@ -7,6 +7,7 @@
 // 3D thermal face names: bot <-> k = 1, top <-> k = end.  HBM-bound fp64 stencils (20 array passes per iteration).
 #include "jrx_internal.hpp"
 #include "jrx_kernels.hpp"
+#include "jrx_thermal_phases.hpp"
 
 namespace {
 
@@ -32,9 +33,10 @@ __device__ __forceinline__ double rhoCp3_of(const jrx_thermal3d_params &p, const
 
 // compute_flux! over (nx+1, ny+1, nz+1).  Q2 = false skips the stores of qT*2 (the un-relaxed flux is only read by check_res!,
 // DiffusionPT_solver.jl:113-126, so it is written on the iterations a check follows)
-template <bool Q2>
-__global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
+template <bool Q2, class PHT>
+__global__ __launch_bounds__(256) void k_flux3d(const T3Args a, const PHT ph)
 {
+    constexpr bool PH = is_tph<PHT>::value;
     const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
     NODE_IJK(nx + 1, ny + 1)
     const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau;
@@ -45,7 +47,10 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
         else if (i == nx && a.p.constant_flux_on[XR]) a.t.qTx[q] = a.p.constant_flux[XR];
         else {
             const int l = clampi(i - 1, 0, nx - 1), r = clampi(i, 0, nx - 1);
-            const double K = a.p.rheology_form ? kc : (CC_(a.t.K, l, j, k) + CC_(a.t.K, r, j, k)) * 0.5;
+            double K;
+            if constexpr (PH) K = (tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (l + (i64)(nx + 1) * (j + (i64)ny * k))) +
+                                   tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (r + (i64)(nx + 1) * (j + (i64)ny * k)))) * 0.5;
+            else K = a.p.rheology_form ? kc : (CC_(a.t.K, l, j, k) + CC_(a.t.K, r, j, k)) * 0.5;
             const double t = (CC_(th, l, j, k) + CC_(th, r, j, k)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i, j + 1, k + 1)) * a.p._dx;
             if (Q2) a.t.qTx2[q] = qv;
@@ -58,7 +63,10 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
         else if (j == ny && a.p.constant_flux_on[YB]) a.t.qTy[q] = a.p.constant_flux[YB];
         else {
             const int l = clampi(j - 1, 0, ny - 1), r = clampi(j, 0, ny - 1);
-            const double K = a.p.rheology_form ? kc : (CC_(a.t.K, i, l, k) + CC_(a.t.K, i, r, k)) * 0.5;
+            double K;
+            if constexpr (PH) K = (tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * (l + (i64)(ny + 1) * k))) +
+                                   tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * (r + (i64)(ny + 1) * k)))) * 0.5;
+            else K = a.p.rheology_form ? kc : (CC_(a.t.K, i, l, k) + CC_(a.t.K, i, r, k)) * 0.5;
             const double t = (CC_(th, i, l, k) + CC_(th, i, r, k)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i + 1, j, k + 1)) * a.p._dy;
             if (Q2) a.t.qTy2[q] = qv;
@@ -71,7 +79,10 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a)
         else if (k == nz && a.p.constant_flux_on[ZT]) a.t.qTz[q] = a.p.constant_flux[ZT];
         else {
             const int l = clampi(k - 1, 0, nz - 1), r = clampi(k, 0, nz - 1);
-            const double K = a.p.rheology_form ? kc : (CC_(a.t.K, i, j, l) + CC_(a.t.K, i, j, r)) * 0.5;
+            double K;
+            if constexpr (PH) K = (tph_cond(ph.m, ph.f.phase_qz + ph.m.nphase * (i + (i64)nx * (j + (i64)ny * l))) +
+                                   tph_cond(ph.m, ph.f.phase_qz + ph.m.nphase * (i + (i64)nx * (j + (i64)ny * r)))) * 0.5;
+            else K = a.p.rheology_form ? kc : (CC_(a.t.K, i, j, l) + CC_(a.t.K, i, j, r)) * 0.5;
             const double t = (CC_(th, i, j, l) + CC_(th, i, j, r)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i + 1, j + 1, k)) * a.p._dz;
             if (Q2) a.t.qTz2[q] = qv;
@@ -114,25 +125,34 @@ __device__ __forceinline__ void thermal_ghosts3d(const jrx_thermal3d_params &p, 
 }
 
 // update_T! (RES=false) / check_res! (RES=true) over ni; BCF: cells next to a face also apply thermal_bcs! to their ghosts
-template <bool RES, bool BCF = false>
-__global__ __launch_bounds__(256) void k_updateT3d(const T3Args a)
+template <bool RES, bool BCF, class PHT>
+__global__ __launch_bounds__(256) void k_updateT3d(const T3Args a, const PHT ph)
 {
+    constexpr bool PH = is_tph<PHT>::value;
     const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
     NODE_IJK(nx, ny)
     if (k >= nz) return;
     const i64 c = i + (i64)nx * (j + (i64)ny * k), I1 = (i + 1) + (i64)(nx + 2) * ((j + 1) + (i64)(ny + 2) * (k + 1));
     const double _dt = 1.0 / a.p.dt;
     const double Tc = a.t.T[I1];
-    const double rcp = rhoCp3_of(a.p, a.t.rhoCp, c, Tc);
+    double rcp, Hr = 0.0;
+    if constexpr (PH) {
+        const double *rc = ph.f.phase_c + ph.m.nphase * c;
+        rcp = tph_rhoCp(ph.m, rc, Tc, ph.f.P[c]);
+        Hr = tph_Hr(ph.m, rc);
+    } else rcp = rhoCp3_of(a.p, a.t.rhoCp, c, Tc);
     const double *qx = RES ? a.t.qTx2 : a.t.qTx, *qy = RES ? a.t.qTy2 : a.t.qTy, *qz = RES ? a.t.qTz2 : a.t.qTz;
     const double divq = (qx[(i + 1) + (i64)(nx + 1) * (j + (i64)ny * k)] - qx[i + (i64)(nx + 1) * (j + (i64)ny * k)]) * a.p._dx +
                         (qy[i + (i64)nx * ((j + 1) + (i64)(ny + 1) * k)] - qy[i + (i64)nx * (j + (i64)(ny + 1) * k)]) * a.p._dy +
                         (qz[i + (i64)nx * (j + (i64)ny * (k + 1))] - qz[c]) * a.p._dz;
     if (RES) {
-        a.t.ResT[c] = -rcp * (Tc - a.t.Told[I1]) * _dt - divq + a.t.H[c] + a.t.shear_heating[c];
+        if constexpr (PH) a.t.ResT[c] = -rcp * (Tc - a.t.Told[I1]) * _dt - divq + Hr + a.t.H[c] + a.t.shear_heating[c];
+        else a.t.ResT[c] = -rcp * (Tc - a.t.Told[I1]) * _dt - divq + a.t.H[c] + a.t.shear_heating[c];
     } else {
         const double dr = a.t.dtau_rho[c];
-        const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+        double Tn;
+        if constexpr (PH) Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+        else Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
         a.t.T[I1] = Tn;
         if (BCF) {
             const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
@@ -334,6 +354,7 @@ jrx_status checkT3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therm
     for (const void *q : req)
         if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required thermal field pointer is NULL");
     if (!p->rheology_form && (!t->K || !t->rhoCp)) return jrx_fail(h, JRX_ERR_ARG, "K / rhoCp arrays required in the array-coefficient form");
+    if (p->rheology_form != 0 && p->rheology_form != 1) return jrx_fail(h, JRX_ERR_ARG, "rheology_form must be 0 or 1 (phase-ratio form: jrx_heatdiffusion_PT3d_phases)");
     return JRX_OK;
 }
 
@@ -371,23 +392,24 @@ static jrx_status ensure_tscratch(jrx_handle *h, int nx, int ny, int nz)
     return JRX_OK;
 }
 
-jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, bool q2 = true, bool fuse_bc = false)
+template <class PHT>
+jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, const PHT &ph, bool q2 = true, bool fuse_bc = false)
 {
     T3Args a;
     a.t = *t; a.p = *p;
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
     hipStream_t s = h->stream;
-    if (q2) hipLaunchKernelGGL(k_flux3d<true>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_flux3d<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    if (q2) hipLaunchKernelGGL((k_flux3d<true, PHT>), GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, ph);
+    else hipLaunchKernelGGL((k_flux3d<false, PHT>), GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, ph);
     JRX_LAUNCH_CHECK(h);
     bool any_periodic = false;
     for (int q = 0; q < 6; q++) any_periodic |= p->periodic[q] != 0;
     if (fuse_bc && !any_periodic && !jrx_comm_active(h)) {        // thermal_bcs! refreshed by the update kernel itself
-        hipLaunchKernelGGL((k_updateT3d<false, true>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_updateT3d<false, true, PHT>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a, ph);
         JRX_LAUNCH_CHECK(h);
         return JRX_OK;
     }
-    hipLaunchKernelGGL(k_updateT3d<false>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_updateT3d<false, false, PHT>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a, ph);
     JRX_LAUNCH_CHECK(h);
     JRX_TRY(launch_tbcs3(h, s, t->T, p));
     if (jrx_comm_active(h)) {
@@ -415,7 +437,7 @@ jrx_status jrx_thermal_bcs3d(jrx_handle *h, double *T, const jrx_thermal3d_param
 jrx_status jrx_thermal3d_iteration(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p)
 {
     JRX_TRY(checkT3(h, t, p));
-    JRX_TRY(enqueue_titer3(h, t, p));
+    JRX_TRY(enqueue_titer3(h, t, p, NoPh{}));
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
 }
@@ -425,16 +447,20 @@ jrx_status jrx_thermal3d_check_res(jrx_handle *h, const jrx_thermal3d_fields *t,
     JRX_TRY(checkT3(h, t, p));
     T3Args a;
     a.t = *t; a.p = *p;
-    hipLaunchKernelGGL(k_updateT3d<true>, GRID_IJK(p->nx, p->ny, p->nz), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL((k_updateT3d<true, false, NoPh>), GRID_IJK(p->nx, p->ny, p->nz), dim3(256), 0, h->stream, a, NoPh{});
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
 }
 
-jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, int64_t *iter_count, double *norm_ResT,
-                                  int64_t cap, int64_t *nnorms)
+}   // extern "C"
+
+namespace {
+template <class PHT>
+jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, const PHT &ph, int64_t *iter_count, double *norm_ResT,
+                  int64_t cap, int64_t *nnorms)
 {
-    JRX_TRY(checkT3(h, t, p));
+    constexpr bool PH = is_tph<PHT>::value;
     if (p->nout < 1) return jrx_fail(h, JRX_ERR_ARG, "nout must be >= 1");
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
     const i64 nT = (i64)(nx + 2) * (ny + 2) * (nz + 2), n = (i64)nx * ny * nz;
@@ -449,7 +475,7 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
     // (option "thermal_fused" = 0: always the two kernels); observed ones (check / last) run the two kernels in place on the current set.
     bool any_periodic = false;
     for (int q = 0; q < 6; q++) any_periodic |= p->periodic[q] != 0;
-    const bool fusable = h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h);
+    const bool fusable = !PH && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h);
     const TSet user = {t->T, t->qTx, t->qTy, t->qTz};
     TSet cur = user, oth = user;
     if (fusable) {
@@ -467,6 +493,8 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
         // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one
         const bool q2 = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
         a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy; a.t.qTz = cur.qz;
+        if constexpr (PH)      // update_pt_thermal_arrays!(pt_thermal, phase, rheology, args, _dt) -- DiffusionPT_solver.jl:233-234
+            JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, s, const_cast<double *>(t->thetar_dtau), const_cast<double *>(t->dtau_rho), cur.T, nx, ny, nz, 3, 1.0 / p->dt, ph));
         if (fusable && !q2) {
 #define THL(TX_, KZ_, R_, XG_)                                                                                                      \
     if (FTX == TX_ && FKZ == KZ_ && FR == R_ && FXG == XG_) {                                                                       \
@@ -482,11 +510,11 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
             JRX_LAUNCH_CHECK(h);
             const TSet tmp = cur; cur = oth; oth = tmp;
         } else {
-            JRX_TRY(enqueue_titer3(h, &a.t, p, q2, true));
+            JRX_TRY(enqueue_titer3(h, &a.t, p, ph, q2, true));
         }
         iter++;
         if (iter % p->nout == 0) {
-            hipLaunchKernelGGL(k_updateT3d<true>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_updateT3d<true, false, PHT>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a, ph);
             JRX_LAUNCH_CHECK(h);
             RedArr Z = {nullptr, {0, 0, 0}, 0}, A3 = {t->ResT, {nx, ny, nz}, 0};
             int nb = (int)((n + 2047) / 2048);
@@ -523,6 +551,31 @@ jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, 
     JRX_HIP(h, hipStreamSynchronize(s));
     if (nnorms) *nnorms = cnt < cap ? cnt : cap;
     return JRX_OK;
+}
+}   // namespace
+
+extern "C" {
+
+jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, int64_t *iter_count, double *norm_ResT,
+                                  int64_t cap, int64_t *nnorms)
+{
+    JRX_TRY(checkT3(h, t, p));
+    return heat3d(h, t, p, NoPh{}, iter_count, norm_ResT, cap, nnorms);
+}
+
+jrx_status jrx_heatdiffusion_PT3d_phases(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, const jrx_thermal_phases *ph,
+                                         const jrx_thermal_phase_fields *pf, int64_t *iter_count, double *norm_ResT, int64_t cap, int64_t *nnorms)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!p) return jrx_fail(h, JRX_ERR_ARG, "null thermal params");
+    jrx_thermal3d_params q = *p;
+    q.rheology_form = 1;                        // K / rhoCp arrays are not read
+    JRX_TRY(checkT3(h, t, &q));
+    JRX_TRY(tph_check(h, ph, pf, true));
+    q.rheology_form = 2;
+    TPh x;
+    x.m = *ph; x.f = *pf;
+    return heat3d(h, t, &q, x, iter_count, norm_ResT, cap, nnorms);
 }
 
 }   // extern "C"

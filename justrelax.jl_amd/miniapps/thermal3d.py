@@ -49,3 +49,16 @@ def diffusion3d(n=32, *, lx=100.0e3, ly=100.0e3, lz=100.0e3, ρ0=3.3e3, Cp0=1.2e
     arr["T"][1:-1, 1:-1, 1:-1][((X - lx / 2) ** 2 + (Y - ly / 2) ** 2 + (Z + lz / 2) ** 2) <= 10.0e3 ** 2] += 100.0
     return Setup(ni=ni, arrays=arr, grid=grid, pt=dict(eps=1.0e-8, CFL=CFL), dt=dt, flow_bcs=bc,
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di, rheology=rheology, nt=10))
+
+
+def diffusion3d_multiphase(n=32, *, iterMax=10_000, nout=100, sharp=False) -> Setup:
+    """diffusion_3D of test/test_diffusion3D_multiphase.jl:83-207: the input of diffusion3d (H = 1e-6, ϵ = 1e-8, pt_thermal from the K / ρCp arrays)
+    solved in the phase-ratio form with the two phases of the 2D multiphase test (ball = phase 2); 10 steps of 50 kyr, iterMax = 1e4, nout = 100."""
+    from .thermal2d import MULTIPHASE_RHEOLOGY, ball_phase_ratios
+    s = diffusion3d(n, iterMax=iterMax, nout=nout)
+    lx, ly, lz = s.extra["li"]
+    ph = ball_phase_ratios(s.grid, (lx / 2, ly / 2, -lz / 2), 10.0e3, s=1 if sharp else 4)
+    s.arrays["P"] = np.zeros(s.ni, order="F")
+    s.pt.update(max_lxyz=max(s.extra["li"]), Vpdtau=min(s.extra["di"]) * s.pt["CFL"])
+    s.extra.update(rheology=MULTIPHASE_RHEOLOGY, phase_ratios=ph)
+    return s

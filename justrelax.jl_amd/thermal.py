@@ -66,18 +66,85 @@ def thermal_fields2d(thermal, pt_thermal, K=None, ρCp=None):
     return f
 
 
+_RHO_KINDS = {"constant": 0, "PT": 1, "T": 2, "compressible": 3}
+
+
+def thermal_phases(rheology, pt_thermal):
+    """jrx_thermal_phases from the per-phase material table: a sequence of dict(k, Cp, Hr=0, density=dict(kind, rho0, alpha, beta, T0, P0))
+    (ConstantConductivity, ConstantHeatCapacity, ConstantRadioactiveHeat and a density law per phase) plus pt_thermal.max_lxyz / Vpdτ"""
+    if len(rheology) > _lib.MAXPHASE:
+        raise ValueError(f"at most {_lib.MAXPHASE} phases")
+    m = _lib.ThermalPhases()
+    m.nphase = len(rheology)
+    for q, ph in enumerate(rheology):
+        m.k[q], m.Cp[q], m.Hr[q] = float(ph["k"]), float(ph["Cp"]), float(ph.get("Hr", 0.0))
+        d = ph.get("density", {})
+        m.rho_kind[q] = _RHO_KINDS[d.get("kind", "constant")]
+        m.rho0[q], m.alpha[q], m.beta[q], m.T0[q], m.P0[q] = (float(d.get(k, 0.0)) for k in ("rho0", "alpha", "beta", "T0", "P0"))
+    m.max_lxyz, m.Vpdtau = float(pt_thermal.max_lxyz), float(pt_thermal.Vpdτ)
+    return m
+
+
+def thermal_phase_fields(phase_ratios, args, ni):
+    """jrx_thermal_phase_fields: args.P and phase_ratios.center / .Vx / .Vy [/ .Vz]"""
+    P = args["P"] if isinstance(args, dict) else args.P
+    if tuple(P.shape) != tuple(ni):
+        raise ValueError(f"args.P must have the shape of the cell centres {tuple(ni)}")
+    f = _lib.ThermalPhaseFields()
+    vals = dict(P=P, phase_c=phase_ratios.center, phase_qx=phase_ratios.Vx, phase_qy=phase_ratios.Vy,
+                phase_qz=getattr(phase_ratios, "Vz", None) if len(ni) == 3 else None)
+    for n in _lib.TPH_NAMES:
+        setattr(f, n, ptr(vals[n]))
+    f._keep = vals
+    return f
+
+
+def update_pt_thermal_arrays_(pt_thermal, phase_ratios, rheology, args, _dt, *, handle=None):
+    """update_pt_thermal_arrays!(pt_thermal, phase_ratios, rheology, args, _dt) -- DiffusionPT_coefficients.jl:105-121"""
+    T = args["T"] if isinstance(args, dict) else args.T
+    _require_gpu(T)
+    ni = tuple(pt_thermal.θr_dτ.shape)
+    if tuple(T.shape) != tuple(n + 2 for n in ni):
+        raise ValueError("args.T must be thermal.T (ni .+ 2)")
+    h = handle or _lib.default_handle(T.device.index)
+    m, f = thermal_phases(rheology, pt_thermal), thermal_phase_fields(phase_ratios, args, ni)
+    n3 = (C.c_int64 * 3)(*(tuple(ni) + (1,) * (3 - len(ni))))
+    torch.cuda.current_stream(T.device).synchronize()
+    h.call("jrx_update_pt_thermal_arrays", C.c_void_p(ptr(pt_thermal.θr_dτ)), C.c_void_p(ptr(pt_thermal.dτ_ρ)), C.c_void_p(ptr(T)), n3,
+           C.c_int32(len(ni)), C.c_double(1.0 / _dt), C.byref(m), C.byref(f))
+
+
 def heatdiffusion_PT_(thermal, pt_thermal, thermal_bc, A, B, dt, grid_or_di, *, kwargs=None, handle=None):
     """heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, K, ρCp, dt, grid; kwargs)          [array form]
        heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, rheology, args, dt, grid; kwargs)  [rheology form]
 
     In the rheology form `A` is a dict(k, Cp, rho0, alpha, T0) (constant conductivity / heat capacity and a
     PT_Density) and `B` the reference's `args` (ignored: T is thermal.T, P does not enter with β = 0).
+    With kwargs["phase"] = PhaseRatios, `A` is the per-phase table (see thermal_phases) and `B` = args with P (ni) and T = thermal.T.
     Returns (iter_count, norm_ResT) like DiffusionPT_solver.jl:148."""
     _require_gpu(thermal)
     kw = dict(kwargs or {})
     ni = thermal._ni
     grid = grid_or_di if isinstance(grid_or_di, Geometry) else legacy_uniform_grid(ni, grid_or_di)
     h = handle or _lib.default_handle(thermal.T.device.index)
+    phase = kw.pop("phase", None)
+    if phase is not None:
+        if isinstance(A, dict):
+            A = [A]
+        T = B["T"] if isinstance(B, dict) else B.T
+        if T.data_ptr() != thermal.T.data_ptr():
+            raise ValueError("args.T must be thermal.T in the phase-ratio form")
+        m, pf = thermal_phases(A, pt_thermal), thermal_phase_fields(phase, B, ni)
+        p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, **kw)
+        f = thermal_fields2d(thermal, pt_thermal)
+        cap = int(p.iterMax // p.nout + 2)
+        it, nr, nn = np.zeros(cap, dtype=np.int64), np.zeros(cap), C.c_int64(0)
+        torch.cuda.current_stream(thermal.T.device).synchronize()
+        h.call("jrx_heatdiffusion_PT3d_phases" if len(ni) == 3 else "jrx_heatdiffusion_PT2d_phases", C.byref(f), C.byref(p), C.byref(m), C.byref(pf),
+               it.ctypes.data_as(C.POINTER(C.c_int64)), nr.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(cap), C.byref(nn))
+        return SimpleNamespace(iter_count=it[: nn.value].copy(), norm_ResT=nr[: nn.value].copy())
+    if isinstance(A, (list, tuple)):
+        raise ValueError("a multi-phase rheology needs kwargs['phase'] = PhaseRatios")
     if isinstance(A, dict):
         p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, rheology=A, **kw)
         f = thermal_fields2d(thermal, pt_thermal)

@@ -129,6 +129,7 @@ void orc_residual_sumsq2d(const orc_fields2d *f, const orc_params2d *p, double o
 void orc_stokes2d_iteration(const orc_fields2d *f, const double *etatau, const orc_params2d *p);
 int32_t orc_stokes2d_solve(const orc_fields2d *f, const orc_params2d *p, orc_result *res);
 
+#define ORC_MAXPHASE8 8
 /* ---- 2D PT heat diffusion (DiffusionPT_solver.jl / DiffusionPT_kernels.jl) ---- */
 typedef struct orc_thermal2d {
     double *T, *Told, *dT;        /* (nx+2, ny+2) ; dT = ΔT */
@@ -153,6 +154,21 @@ typedef struct orc_thermal_params2d {
     int32_t rheology_form;
     double k_const, Cp, rho0, alpha, T0, H_const;
 } orc_thermal_params2d;
+
+/* phase-ratio form (rheology_form = 2): per-phase thermal properties + the arrays heatdiffusion_PT!(...; phase = phase_ratios) reads */
+typedef struct orc_thermal_phases {
+    int32_t nphase;
+    double k[ORC_MAXPHASE8], Cp[ORC_MAXPHASE8], Hr[ORC_MAXPHASE8];
+    int32_t rho_kind[ORC_MAXPHASE8];
+    double rho0[ORC_MAXPHASE8], alpha[ORC_MAXPHASE8], beta[ORC_MAXPHASE8], T0[ORC_MAXPHASE8], P0[ORC_MAXPHASE8];
+    double max_lxyz, Vpdtau;      /* pt_thermal.max_lxyz, pt_thermal.Vpdτ */
+} orc_thermal_phases;
+typedef struct orc_thermal_phase_fields {
+    const double *P;              /* args.P, ni */
+    const double *phase_c;        /* phase_ratios.center [nphase][ni] */
+    const double *phase_qx, *phase_qy, *phase_qz;   /* phase_ratios.Vx (nx+1, ny[, nz]), .Vy, .Vz; phase index fastest */
+} orc_thermal_phase_fields;
+void orc_thermal_set_phases(const orc_thermal_phases *ph, const orc_thermal_phase_fields *pf);   /* NULL, NULL to clear */
 
 void orc_thermal_bcs2d(double *T, const orc_thermal_params2d *p);
 void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d *p);

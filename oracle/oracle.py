@@ -617,3 +617,48 @@ def thermal3d_iteration(arr: dict, p: ThermalParams3D):
 def thermal3d_check_res(arr: dict, p: ThermalParams3D):
     t = thermal3d(arr)
     lib().orc_thermal3d_check_res(C.byref(t), C.byref(p))
+
+
+# ---- phase-ratio form of the heat-diffusion path (oracle/thermal_phases.h) ----
+class ThermalPhases(C.Structure):
+    _fields_ = [("nphase", C.c_int32)] + [(k, C.c_double * 8) for k in ("k", "Cp", "Hr")] + [("rho_kind", C.c_int32 * 8)] + \
+               [(k, C.c_double * 8) for k in ("rho0", "alpha", "beta", "T0", "P0")] + [("max_lxyz", C.c_double), ("Vpdtau", C.c_double)]
+
+
+class ThermalPhaseFields(C.Structure):
+    _fields_ = [(k, _dp) for k in ("P", "phase_c", "phase_qx", "phase_qy", "phase_qz")]
+
+
+RHO_KINDS = {"constant": 0, "PT": 1, "T": 2, "compressible": 3}
+
+
+def thermal_phases(phases: list, max_lxyz: float, Vpdtau: float) -> ThermalPhases:
+    """phases: list of dict(k, Cp, Hr=0, density=dict(kind, rho0, alpha, beta, T0, P0))"""
+    m = ThermalPhases()
+    m.nphase = len(phases)
+    for q, ph in enumerate(phases):
+        m.k[q], m.Cp[q], m.Hr[q] = ph["k"], ph["Cp"], ph.get("Hr", 0.0)
+        d = ph.get("density", {})
+        m.rho_kind[q] = RHO_KINDS[d.get("kind", "constant")]
+        m.rho0[q], m.alpha[q], m.beta[q], m.T0[q], m.P0[q] = d.get("rho0", 0.0), d.get("alpha", 0.0), d.get("beta", 0.0), d.get("T0", 0.0), d.get("P0", 0.0)
+    m.max_lxyz, m.Vpdtau = float(max_lxyz), float(Vpdtau)
+    return m
+
+
+def _phase_fields(ph: dict) -> ThermalPhaseFields:
+    f = ThermalPhaseFields()
+    for k in ("P", "phase_c", "phase_qx", "phase_qy", "phase_qz"):
+        setattr(f, k, _p(ph.get(k)))
+    return f
+
+
+def heatdiffusion_PT_phases(arr: dict, p, m: ThermalPhases, ph: dict) -> dict:
+    """heatdiffusion_PT!(...; kwargs = (phase = phase_ratios, ...)), 2D or 3D by the type of p; ph: dict(P, phase_c, phase_qx, phase_qy[, phase_qz])"""
+    three = isinstance(p, ThermalParams3D)
+    f = _phase_fields(ph)
+    p.rheology_form = 2
+    lib().orc_thermal_set_phases(C.byref(m), C.byref(f))
+    try:
+        return heatdiffusion_PT3d(arr, p) if three else heatdiffusion_PT2d(arr, p)
+    finally:
+        lib().orc_thermal_set_phases(None, None)

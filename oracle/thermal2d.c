@@ -53,6 +53,11 @@ void orc_thermal_bcs2d(double *T, const orc_thermal_params2d *p)
     }
 }
 
+#include "thermal_phases.h"
+const orc_thermal_phases *g_tph = NULL;              /* phase-ratio form (rheology_form = 2): set by orc_thermal_set_phases */
+const orc_thermal_phase_fields *g_tpf = NULL;
+void orc_thermal_set_phases(const orc_thermal_phases *ph, const orc_thermal_phase_fields *pf) { g_tph = ph; g_tpf = pf; }
+
 static inline double rhoCp_rheology(const orc_thermal_params2d *p, double T)
 {   /* DiffusionPT_GeoParams.jl:97-104 : compute_heatcapacity * compute_density */
     return p->Cp * (p->rho0 * (1.0 - p->alpha * (T - p->T0)));
@@ -74,8 +79,10 @@ void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d 
                 else if (i == nx && p->constant_flux_on[TR]) t->qTx[q] = p->constant_flux[TR];
                 else {
                     int64_t iL = clampi(i - 1, 0, nx - 1), iR = clampi(i, 0, nx - 1);
-                    double Kx = p->rheology_form ? (p->k_const + p->k_const) * 0.5
-                                                 : (t->K[IDX2(nx, iL, j)] + t->K[IDX2(nx, iR, j)]) * 0.5;
+                    double Kx = p->rheology_form == 2 ? (tph_cond(g_tph, g_tpf->phase_qx + g_tph->nphase * IDX2(nx + 1, iL, j)) +
+                                                         tph_cond(g_tph, g_tpf->phase_qx + g_tph->nphase * IDX2(nx + 1, iR, j))) * 0.5
+                                : p->rheology_form ? (p->k_const + p->k_const) * 0.5
+                                                   : (t->K[IDX2(nx, iL, j)] + t->K[IDX2(nx, iR, j)]) * 0.5;
                     double th = (t->thetar_dtau[IDX2(nx, iL, j)] + t->thetar_dtau[IDX2(nx, iR, j)]) * 0.5;
                     double qx = -Kx * (TT_(i + 1, j + 1) - TT_(i, j + 1)) * _dx;
                     t->qTx2[q] = qx;
@@ -88,8 +95,10 @@ void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d 
                 else if (j == ny && p->constant_flux_on[TT]) t->qTy[q] = p->constant_flux[TT];
                 else {
                     int64_t jB = clampi(j - 1, 0, ny - 1), jT = clampi(j, 0, ny - 1);
-                    double Ky = p->rheology_form ? (p->k_const + p->k_const) * 0.5
-                                                 : (t->K[IDX2(nx, i, jB)] + t->K[IDX2(nx, i, jT)]) * 0.5;
+                    double Ky = p->rheology_form == 2 ? (tph_cond(g_tph, g_tpf->phase_qy + g_tph->nphase * IDX2(nx, i, jB)) +
+                                                         tph_cond(g_tph, g_tpf->phase_qy + g_tph->nphase * IDX2(nx, i, jT))) * 0.5
+                                : p->rheology_form ? (p->k_const + p->k_const) * 0.5
+                                                   : (t->K[IDX2(nx, i, jB)] + t->K[IDX2(nx, i, jT)]) * 0.5;
                     double th = (t->thetar_dtau[IDX2(nx, i, jB)] + t->thetar_dtau[IDX2(nx, i, jT)]) * 0.5;
                     double qy = -Ky * (TT_(i + 1, j + 1) - TT_(i + 1, j)) * _dy;
                     t->qTy2[q] = qy;
@@ -102,11 +111,13 @@ void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d 
         for (int64_t i = 0; i < nx; i++) {
             size_t c = IDX2(nx, i, j), I1 = IDX2(nx + 2, i + 1, j + 1);
             double Tij = T[I1];
-            double rcp = p->rheology_form ? rhoCp_rheology(p, Tij) : t->rhoCp[c];
+            const double *rc = p->rheology_form == 2 ? g_tpf->phase_c + g_tph->nphase * c : NULL;
+            double rcp = rc ? tph_rhoCp(g_tph, rc, Tij, g_tpf->P[c]) : p->rheology_form ? rhoCp_rheology(p, Tij) : t->rhoCp[c];
             double dr = t->dtau_rho[c];
             double divq = (t->qTx[IDX2(nx + 1, i + 1, j)] - t->qTx[IDX2(nx + 1, i, j)]) * _dx +
                           (t->qTy[IDX2(nx, i, j + 1)] - t->qTy[IDX2(nx, i, j)]) * _dy;
-            T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + t->H[c] + t->shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+            if (rc) T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+            else T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + t->H[c] + t->shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
         }
     orc_thermal_bcs2d(T, p);
 }
@@ -120,11 +131,12 @@ void orc_thermal2d_check_res(const orc_thermal2d *t, const orc_thermal_params2d 
     for (int64_t j = 0; j < ny; j++)
         for (int64_t i = 0; i < nx; i++) {
             size_t c = IDX2(nx, i, j), I1 = IDX2(nx + 2, i + 1, j + 1);
-            double rcp = p->rheology_form ? rhoCp_rheology(p, t->T[I1]) : t->rhoCp[c];
-            t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt -
-                         ((t->qTx2[IDX2(nx + 1, i + 1, j)] - t->qTx2[IDX2(nx + 1, i, j)]) * _dx +
-                          (t->qTy2[IDX2(nx, i, j + 1)] - t->qTy2[IDX2(nx, i, j)]) * _dy) +
-                         t->H[c] + t->shear_heating[c];
+            const double *rc = p->rheology_form == 2 ? g_tpf->phase_c + g_tph->nphase * c : NULL;
+            double rcp = rc ? tph_rhoCp(g_tph, rc, t->T[I1], g_tpf->P[c]) : p->rheology_form ? rhoCp_rheology(p, t->T[I1]) : t->rhoCp[c];
+            const double dq = (t->qTx2[IDX2(nx + 1, i + 1, j)] - t->qTx2[IDX2(nx + 1, i, j)]) * _dx +
+                              (t->qTy2[IDX2(nx, i, j + 1)] - t->qTy2[IDX2(nx, i, j)]) * _dy;
+            if (rc) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c];
+            else t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + t->H[c] + t->shear_heating[c];
         }
 }
 
@@ -139,6 +151,13 @@ int32_t orc_heatdiffusion_PT2d(const orc_thermal2d *t, const orc_thermal_params2
     int64_t iter = 0, cnt = 0;
     double err = 2 * p->eps;
     while (err > p->eps && iter < p->iterMax) {
+        if (p->rheology_form == 2)      /* update_pt_thermal_arrays!(pt_thermal, phase, rheology, args, _dt) :233-234 ; T at Idx .+ 1 */
+            for (int64_t j = 0; j < ny; j++)
+                for (int64_t i = 0; i < nx; i++) {
+                    const size_t c = IDX2(nx, i, j);
+                    tph_pt_coeffs(g_tph, g_tpf->phase_c + g_tph->nphase * c, t->T[IDX2(nx + 2, i + 1, j + 1)], g_tpf->P[c], inv(p->dt),
+                                  &t->thetar_dtau[c], &t->dtau_rho[c]);
+                }
         orc_thermal2d_iteration(t, p);
         iter += 1;
         if (iter % p->nout == 0) {

@@ -50,6 +50,10 @@ static inline double rhoCp3(const orc_thermal_params3d *p, double T)
     return p->Cp * (p->rho0 * (1.0 - p->alpha * (T - p->T0)));
 }
 
+#include "thermal_phases.h"
+extern const orc_thermal_phases *g_tph;
+extern const orc_thermal_phase_fields *g_tpf;
+
 void orc_thermal3d_iteration(const orc_thermal3d *t, const orc_thermal_params3d *p)
 {
     const int64_t nx = p->nx, ny = p->ny, nz = p->nz;
@@ -66,7 +70,8 @@ void orc_thermal3d_iteration(const orc_thermal3d *t, const orc_thermal_params3d 
                     else if (i == nx && p->constant_flux_on[XR]) t->qTx[q] = p->constant_flux[XR];
                     else {
                         const int64_t a = clampi(i - 1, 0, nx - 1), b = clampi(i, 0, nx - 1);
-                        const double Kx = p->rheology_form ? (p->k_const + p->k_const) * 0.5 : (CC(t->K, a, j, k) + CC(t->K, b, j, k)) * 0.5;
+                        const double Kx = p->rheology_form == 2 ? (tph_cond(g_tph, g_tpf->phase_qx + g_tph->nphase * IDX3(nx + 1, ny, a, j, k)) + tph_cond(g_tph, g_tpf->phase_qx + g_tph->nphase * IDX3(nx + 1, ny, b, j, k))) * 0.5
+                                        : p->rheology_form ? (p->k_const + p->k_const) * 0.5 : (CC(t->K, a, j, k) + CC(t->K, b, j, k)) * 0.5;
                         const double th = (CC(t->thetar_dtau, a, j, k) + CC(t->thetar_dtau, b, j, k)) * 0.5;
                         const double qx = -Kx * (T3(i + 1, j + 1, k + 1) - T3(i, j + 1, k + 1)) * _dx;
                         t->qTx2[q] = qx;
@@ -79,7 +84,8 @@ void orc_thermal3d_iteration(const orc_thermal3d *t, const orc_thermal_params3d 
                     else if (j == ny && p->constant_flux_on[YB]) t->qTy[q] = p->constant_flux[YB];
                     else {
                         const int64_t a = clampi(j - 1, 0, ny - 1), b = clampi(j, 0, ny - 1);
-                        const double Ky = p->rheology_form ? (p->k_const + p->k_const) * 0.5 : (CC(t->K, i, a, k) + CC(t->K, i, b, k)) * 0.5;
+                        const double Ky = p->rheology_form == 2 ? (tph_cond(g_tph, g_tpf->phase_qy + g_tph->nphase * IDX3(nx, ny + 1, i, a, k)) + tph_cond(g_tph, g_tpf->phase_qy + g_tph->nphase * IDX3(nx, ny + 1, i, b, k))) * 0.5
+                                        : p->rheology_form ? (p->k_const + p->k_const) * 0.5 : (CC(t->K, i, a, k) + CC(t->K, i, b, k)) * 0.5;
                         const double th = (CC(t->thetar_dtau, i, a, k) + CC(t->thetar_dtau, i, b, k)) * 0.5;
                         const double qy = -Ky * (T3(i + 1, j + 1, k + 1) - T3(i + 1, j, k + 1)) * _dy;
                         t->qTy2[q] = qy;
@@ -92,7 +98,8 @@ void orc_thermal3d_iteration(const orc_thermal3d *t, const orc_thermal_params3d 
                     else if (k == nz && p->constant_flux_on[ZT]) t->qTz[q] = p->constant_flux[ZT];
                     else {
                         const int64_t a = clampi(k - 1, 0, nz - 1), b = clampi(k, 0, nz - 1);
-                        const double Kz = p->rheology_form ? (p->k_const + p->k_const) * 0.5 : (CC(t->K, i, j, a) + CC(t->K, i, j, b)) * 0.5;
+                        const double Kz = p->rheology_form == 2 ? (tph_cond(g_tph, g_tpf->phase_qz + g_tph->nphase * IDX3(nx, ny, i, j, a)) + tph_cond(g_tph, g_tpf->phase_qz + g_tph->nphase * IDX3(nx, ny, i, j, b))) * 0.5
+                                        : p->rheology_form ? (p->k_const + p->k_const) * 0.5 : (CC(t->K, i, j, a) + CC(t->K, i, j, b)) * 0.5;
                         const double th = (CC(t->thetar_dtau, i, j, a) + CC(t->thetar_dtau, i, j, b)) * 0.5;
                         const double qz = -Kz * (T3(i + 1, j + 1, k + 1) - T3(i + 1, j + 1, k)) * _dz;
                         t->qTz2[q] = qz;
@@ -106,12 +113,14 @@ void orc_thermal3d_iteration(const orc_thermal3d *t, const orc_thermal_params3d 
             for (int64_t i = 0; i < nx; i++) {
                 const size_t c = IDX3(nx, ny, i, j, k), I1 = IDX3(nx + 2, ny + 2, i + 1, j + 1, k + 1);
                 const double Tc = T[I1];
-                const double rcp = p->rheology_form ? rhoCp3(p, Tc) : t->rhoCp[c];
+                const double *rc = p->rheology_form == 2 ? g_tpf->phase_c + g_tph->nphase * c : NULL;
+                const double rcp = rc ? tph_rhoCp(g_tph, rc, Tc, g_tpf->P[c]) : p->rheology_form ? rhoCp3(p, Tc) : t->rhoCp[c];
                 const double dr = t->dtau_rho[c];
                 const double divq = (t->qTx[IDX3(nx + 1, ny, i + 1, j, k)] - t->qTx[IDX3(nx + 1, ny, i, j, k)]) * _dx +
                                     (t->qTy[IDX3(nx, ny + 1, i, j + 1, k)] - t->qTy[IDX3(nx, ny + 1, i, j, k)]) * _dy +
                                     (t->qTz[IDX3(nx, ny, i, j, k + 1)] - t->qTz[IDX3(nx, ny, i, j, k)]) * _dz;
-                T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + t->H[c] + t->shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+                if (rc) T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+                else T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + t->H[c] + t->shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
             }
     orc_thermal_bcs3d(T, p);
 }
@@ -125,12 +134,13 @@ void orc_thermal3d_check_res(const orc_thermal3d *t, const orc_thermal_params3d 
         for (int64_t j = 0; j < ny; j++)
             for (int64_t i = 0; i < nx; i++) {
                 const size_t c = IDX3(nx, ny, i, j, k), I1 = IDX3(nx + 2, ny + 2, i + 1, j + 1, k + 1);
-                const double rcp = p->rheology_form ? rhoCp3(p, t->T[I1]) : t->rhoCp[c];
-                t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt -
-                             ((t->qTx2[IDX3(nx + 1, ny, i + 1, j, k)] - t->qTx2[IDX3(nx + 1, ny, i, j, k)]) * _dx +
-                              (t->qTy2[IDX3(nx, ny + 1, i, j + 1, k)] - t->qTy2[IDX3(nx, ny + 1, i, j, k)]) * _dy +
-                              (t->qTz2[IDX3(nx, ny, i, j, k + 1)] - t->qTz2[IDX3(nx, ny, i, j, k)]) * _dz) +
-                             t->H[c] + t->shear_heating[c];
+                const double *rc = p->rheology_form == 2 ? g_tpf->phase_c + g_tph->nphase * c : NULL;
+                const double rcp = rc ? tph_rhoCp(g_tph, rc, t->T[I1], g_tpf->P[c]) : p->rheology_form ? rhoCp3(p, t->T[I1]) : t->rhoCp[c];
+                const double dq = (t->qTx2[IDX3(nx + 1, ny, i + 1, j, k)] - t->qTx2[IDX3(nx + 1, ny, i, j, k)]) * _dx +
+                                  (t->qTy2[IDX3(nx, ny + 1, i, j + 1, k)] - t->qTy2[IDX3(nx, ny + 1, i, j, k)]) * _dy +
+                                  (t->qTz2[IDX3(nx, ny, i, j, k + 1)] - t->qTz2[IDX3(nx, ny, i, j, k)]) * _dz;
+                if (rc) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c];
+                else t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + t->H[c] + t->shear_heating[c];
             }
 }
 
@@ -144,6 +154,14 @@ int32_t orc_heatdiffusion_PT3d(const orc_thermal3d *t, const orc_thermal_params3
     int64_t iter = 0, cnt = 0;
     double err = 2 * p->eps;
     while (err > p->eps && iter < p->iterMax) {
+        if (p->rheology_form == 2)      /* update_pt_thermal_arrays! (DiffusionPT_solver.jl:233-234) */
+            for (int64_t k = 0; k < nz; k++)
+                for (int64_t j = 0; j < ny; j++)
+                    for (int64_t i = 0; i < nx; i++) {
+                        const size_t c = IDX3(nx, ny, i, j, k);
+                        tph_pt_coeffs(g_tph, g_tpf->phase_c + g_tph->nphase * c, t->T[IDX3(nx + 2, ny + 2, i + 1, j + 1, k + 1)], g_tpf->P[c], inv(p->dt),
+                                      &t->thetar_dtau[c], &t->dtau_rho[c]);
+                    }
         orc_thermal3d_iteration(t, p);
         iter += 1;
         if (iter % p->nout == 0) {

@@ -310,3 +310,75 @@ def test_shearband2d_softening_script_elastic_stage(oracle, jr):
     assert s.arrays["txx"].max() == pytest.approx(0.466, abs=1.0e-3)
     assert 2 * s.extra["εbg"] * s.extra["η0"] * (1 - math.exp(-s.extra["G0"] * t / s.extra["η0"])) == pytest.approx(0.4423, abs=1.0e-4)
     assert not s.arrays["eplxx"].any() and s.arrays["tII"].max() < 0.5
+
+
+def _multiphase_inputs(oracle, s):
+    pr = s.extra["phase_ratios"]
+    m = oracle.thermal_phases(list(s.extra["rheology"]), s.pt["max_lxyz"], s.pt["Vpdtau"])
+    ph = dict(P=s.arrays["P"], phase_c=pr["center"], phase_qx=pr["Vx"], phase_qy=pr["Vy"], phase_qz=pr.get("Vz"))
+    return m, ph
+
+
+@pytest.mark.parametrize("sharp", [False, True])
+def test_diffusion2d_multiphase(oracle, jr, sharp):
+    """test/test_diffusion2D_multiphase.jl:186-200: T[18,18] ≈ 1814.029, T[17,17] ≈ 1823.548 (atol 0.1), phase-ratio form of heatdiffusion_PT!.
+    The reference seeds its particles at random; area-fraction ratios of the disc land within 0.03 K of its numbers, sharp 0/1 ratios within 0.09 K."""
+    from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+    s = jr.miniapps.diffusion2d_multiphase(32, sharp=sharp)
+    b = s.flow_bcs
+    p = oracle.thermal_params2d(s.ni, s.grid._di["center"], s.dt, s.pt["eps"], iterMax=s.kwargs["iterMax"], nout=s.kwargs["nout"],
+                                no_flux=b.no_flux, constant_value=b.constant_value, constant_flux=b.constant_flux, periodic=b.periodic)
+    oracle.thermal_bcs2d(s.arrays["T"], p)
+    add_perturbation(s.arrays["T"], s.grid, **s.extra["perturbation"])
+    m, ph = _multiphase_inputs(oracle, s)
+    for _ in range(s.extra["nt"]):
+        r = oracle.heatdiffusion_PT_phases(s.arrays, p, m, ph)
+        assert r["norm_ResT"][-1] <= s.pt["eps"]
+    T, g = s.arrays["T"], KA["diffusion2D_multiphase"]
+    assert T[17, 17] == pytest.approx(g["T_18_18"], abs=g["atol"])
+    assert T[16, 16] == pytest.approx(g["T_17_17"], abs=g["atol"])
+    if not sharp:
+        assert T[17, 17] == pytest.approx(g["T_18_18"], abs=0.03) and T[16, 16] == pytest.approx(g["T_17_17"], abs=0.03)
+
+
+def test_diffusion3d_multiphase(oracle, jr):
+    """test/test_diffusion3D_multiphase.jl:207-219: T[16,16,16] ≈ 1816.8262937737384, interior view [16,16,16] ≈ 1834.4197141500213 (rtol 1e-3);
+    with volume-fraction ratios of the ball the restatement agrees to 1e-5."""
+    s = jr.miniapps.diffusion3d_multiphase(32)
+    b = s.flow_bcs
+    p = oracle.thermal_params3d(s.ni, s.grid._di["center"], s.dt, s.pt["eps"], iterMax=s.kwargs["iterMax"], nout=s.kwargs["nout"],
+                                no_flux=b.no_flux, constant_value=b.constant_value, constant_flux=b.constant_flux, periodic=b.periodic)
+    m, ph = _multiphase_inputs(oracle, s)
+    for _ in range(s.extra["nt"]):
+        r = oracle.heatdiffusion_PT_phases(s.arrays, p, m, ph)
+        assert r["norm_ResT"][-1] <= 1e-8
+    T, g = s.arrays["T"], KA["diffusion3D_multiphase"]
+    assert T[15, 15, 15] == pytest.approx(g["T_16_16_16"], rel=2.0e-5)
+    assert T[16, 16, 16] == pytest.approx(g["Tinterior_16_16_16"], rel=2.0e-5)
+
+
+def test_thermal_phase_helpers_known_answers(oracle):
+    """fn_ratio forms (phases.jl:6-30): a pure phase returns its own value; mixtures are the weighted sum; the PT coefficients follow
+    DiffusionPT_coefficients.jl:123-136 -- checked through one 2 x 2 solve-free call of the coefficient update inside the driver."""
+    rheo = [dict(k=2.0, Cp=1000.0, Hr=1e-6, density=dict(kind="PT", rho0=3000.0, alpha=1e-5, beta=1e-11, T0=100.0, P0=1e5)),
+            dict(k=4.0, Cp=800.0, Hr=3e-6, density=dict(kind="constant", rho0=2500.0))]
+    ni, di, dt = (2, 2), (0.5, 0.5), 0.1
+    L, Vp = 1.0, 0.5 * 0.3
+    m = oracle.thermal_phases(rheo, L, Vp)
+    shp = oracle.shapes_thermal2d(*ni)
+    arr = {k: np.zeros(v, order="F") for k, v in shp.items()}
+    arr["T"][...] = 500.0
+    P = np.full(ni, 2.0e5, order="F")
+    rc = np.zeros((2,) + ni, order="F")
+    rc[0], rc[1] = [[1.0, 0.25], [0.0, 0.5]], [[0.0, 0.75], [1.0, 0.5]]
+    ph = dict(P=P, phase_c=rc, phase_qx=np.ones((2, 3, 2), order="F") * 0.5, phase_qy=np.ones((2, 2, 3), order="F") * 0.5)
+    p = oracle.thermal_params2d(ni, (1 / di[0], 1 / di[1]), dt, 1e-30, iterMax=1, nout=1)
+    oracle.heatdiffusion_PT_phases(arr, p, m, ph)
+    rho1 = 3000.0 * (1 - 1e-5 * (500.0 - 100.0) + 1e-11 * (2.0e5 - 1e5))
+    for (i, j) in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        r1, r2 = rc[0, i, j], rc[1, i, j]
+        rcp = r1 * 1000.0 * rho1 + r2 * 800.0 * 2500.0
+        k = r1 * 2.0 + r2 * 4.0
+        Re = math.pi + math.sqrt(math.pi ** 2 + rcp * L * L / k / dt)
+        assert arr["thetar_dtau"][i, j] == pytest.approx(L / Vp / Re, rel=1e-14)
+        assert arr["dtau_rho"][i, j] == pytest.approx(Vp * L / k / Re, rel=1e-14)
