@@ -36,6 +36,18 @@ struct Vep3Args {
     const int j = t_ / (n1_), i = t_ - j * (n1_), k = blockIdx.y;       \
     if (j >= (n2_)) return;
 #define GRID_IJK(n1_, n2_, n3_) dim3((unsigned)(((i64)(n1_) * (n2_) + 255) / 256), (unsigned)(n3_))
+// the same box, XCD-aware: blocks are dealt round-robin to the 8 XCDs (each with its own L2), so block L of the launch is mapped to position
+// (L % 8) * (T / 8) + L / 8 of the (flattened xy, z) sequence -- every XCD then works on one contiguous slab of planes and finds the rows j +- 1 and
+// planes k +- 1 of its stencils in its own L2 (measured on k_vep3_pre at 256^3: 26 array passes fetched from HBM without, ~11 with)
+#define NODE_IJK_XS(n1_, n2_)                                                         \
+    unsigned bx_ = blockIdx.x, by_ = blockIdx.y;                                      \
+    {                                                                                 \
+        const unsigned L_ = by_ * gridDim.x + bx_, per_ = (gridDim.x * gridDim.y) / 8u; \
+        if (L_ < per_ * 8u) { const unsigned Ln_ = (L_ & 7u) * per_ + (L_ >> 3); bx_ = Ln_ % gridDim.x; by_ = Ln_ / gridDim.x; } \
+    }                                                                                 \
+    const int t_ = bx_ * blockDim.x + threadIdx.x;                                    \
+    const int j = t_ / (n1_), i = t_ - j * (n1_), k = by_;                            \
+    if (j >= (n2_)) return;
 // block = 64 consecutive nodes of the flattened xy plane x 4 consecutive planes (one plane per wave): the k-1 / k+1 operands of the
 // gathering kernels are the neighbouring waves' k operands and meet in the CU's L1 (JRX_VEP_MAP=0 keeps the one-plane blocks)
 #define NODE_IJK4(n1_, n2_, n3_)                                                     \
@@ -52,21 +64,28 @@ __device__ __forceinline__ double sinv3(const double t[6])
 __device__ __forceinline__ double ratio_avg3(const double *val, const double *r, int n)
 {   // fn_ratio, src/phases/phases.jl:6-15
     double x = 0.0;
+#pragma unroll
     for (int q = 0; q < n; q++) x += (r[q] == 0.0) ? 0.0 : val[q] * r[q];
     return x;
 }
+// NP > 0: the number of phases as a compile-time constant (the phase loops unroll), else rh.nphase
+template <int NP = 0>
 __device__ __forceinline__ void plastic_params3(const jrx_rheology &rh, const double *r, bool &is_pl, double &eta_reg)
 {   // plastic_params_phase, rheology/StressUpdate.jl:152-176
     is_pl = false; eta_reg = 0.0;
-    for (int q = 0; q < rh.nphase; q++)
+    const int np = NP > 0 ? NP : rh.nphase;
+#pragma unroll
+    for (int q = 0; q < np; q++)
         if (rh.is_pl[q]) { is_pl = true; eta_reg += rh.eta_vp[q] * r[q]; }
 }
 // SOFT: some phase has a softening law (compiled out otherwise: the erfc / sincos paths cost the edge kernel its second wave per SIMD)
-template <bool SOFT>
+template <bool SOFT, int NP = 0>
 __device__ __forceinline__ double yield_F3(const jrx_rheology &rh, const double *r, double P, double tII, double EII)
 {   // compute_yieldfunction_phase, StressUpdate.jl:435-452 ; DP: F = τII - cosϕ(EII) C(EII) - sinϕ(EII) P (softening at the EII keyword)
     double F = 0.0;
-    for (int q = 0; q < rh.nphase; q++) {
+    const int np = NP > 0 ? NP : rh.nphase;
+#pragma unroll
+    for (int q = 0; q < np; q++) {
         if (r[q] == 0.0) continue;
         double Fq = tII;
         if (rh.is_pl[q]) {
@@ -80,13 +99,16 @@ __device__ __forceinline__ double yield_F3(const jrx_rheology &rh, const double 
     }
     return F;
 }
+template <int NP = 0>
 __device__ __forceinline__ void plastic_grad3(const jrx_rheology &rh, const double *r, const double t[6], double dQdt[6], double &dQdP, double &dFdP)
 {   // compute_plastic_gradients_phase, StressUpdate.jl:463-550 (shear slots halved once, :466-472)
 #pragma unroll
     for (int q = 0; q < 6; q++) dQdt[q] = 0.0;
     dQdP = 0.0; dFdP = 0.0;
     const double tII = sinv3(t);
-    for (int q = 0; q < rh.nphase; q++) {
+    const int np = NP > 0 ? NP : rh.nphase;
+#pragma unroll
+    for (int q = 0; q < np; q++) {
         if (r[q] == 0.0 || !rh.is_pl[q]) continue;
 #pragma unroll
         for (int s = 0; s < 3; s++) dQdt[s] = fma(r[q], 0.5 * t[s] / tII, dQdt[s]);
@@ -110,7 +132,7 @@ template <bool ML, bool RHO = false>
 __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    NODE_IJK(nx + 1, ny + 1)
+    NODE_IJK_XS(nx + 1, ny + 1)
     const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
     const double _dx = a._dx, _dy = a._dy, _dz = a._dz;
 #define VX(i_, j_, k_) Vx[(i_) + (i64)(nx + 1) * ((j_) + (i64)(ny + 2) * (k_))]
@@ -207,6 +229,57 @@ __host__ __device__ constexpr int oth3(int t, int s, int q, int d)
     return T[t][s][q][d];
 }
 
+// return mapping of one edge node of family T (StressKernels.jl:724-779 and the two sibling blocks), in two steps so that the z-marching
+// kernel can reduce its operands to the trial stress early: edge_mat (phase-ratio material values of the node), then vep3_edge_plastic on
+// the trial stress tt = τ + dτ (order xx, yy, zz, yz, xz, xy), the family's own component before the increment (tij_own) and its
+// increment (d_own), etav the harmonic viscosity, Pv the averaged θ, EIIv the averaged EII_pl (softening laws only)
+struct EdgeMat { double _Gdt, Kv, eta_reg; bool is_pl; };
+template <int NP = 0>
+__device__ __forceinline__ EdgeMat edge_mat(const Vep3Args &a, const double *rv)
+{
+    EdgeMat m;
+    const int np = NP > 0 ? NP : a.rh.nphase;
+    plastic_params3<NP>(a.rh, rv, m.is_pl, m.eta_reg);
+    m._Gdt = 1.0 / (ratio_avg3(a.rh.G, rv, np) * a.dt);
+    m.Kv = ratio_avg3(a.rh.Kb, rv, np);
+    return m;
+}
+template <int T, bool SOFT, int NP = 0>
+__device__ __forceinline__ void vep3_edge_plastic(const Vep3Args &a, i64 v, const double *rv, const EdgeMat &m, const double tt[6], double tij_own, double d_own,
+                                                  double etav, double Pv, double dtr, double EIIv)
+{
+    double *const eplsh[3] = {a.f.eplyz, a.f.eplxz, a.f.eplxy};
+    const double tIIv = sinv3(tt);
+    double dQdt[6], dQdP, dFdP;
+    plastic_grad3<NP>(a.rh, rv, tt, dQdt, dQdP, dFdP);
+    const double vol = isinf(m.Kv) ? 0.0 : m.Kv * a.dt * dFdP * dQdP;
+    const double F = yield_F3<SOFT, NP>(a.rh, rv, Pv, tIIv, SOFT ? EIIv : 0.0);
+    constexpr int own = 3 + T;
+    if (m.is_pl && tIIv != 0.0 && F > 0) {
+        const double l = (1.0 - a.rel) * a.lamv[T][v] + a.rel * (fmax(F, 0.0) / (etav * dtr + m.eta_reg + vol));
+        a.lamv[T][v] = l;
+        const double epl = l * dQdt[own];
+        a.tnew[T][v] = tij_own + fma(-(2.0 * etav * epl), dtr, d_own);
+        eplsh[T][v] = epl;
+    } else {
+        a.tnew[T][v] = tij_own + d_own;
+        eplsh[T][v] = 0.0;
+    }
+}
+template <int T, bool SOFT>
+__device__ __forceinline__ void vep3_edge_finish(const Vep3Args &a, i64 v, const double eij[6], const double tij[6], const double toij[6], double etav, double Pv,
+                                                 double EIIv)
+{
+    const double *const phsh[3] = {a.f.phase_yz, a.f.phase_xz, a.f.phase_xy};
+    const double *rv = phsh[T] + (i64)a.rh.nphase * v;
+    const EdgeMat m = edge_mat(a, rv);
+    const double dtr = 1.0 / (a.theta_dtau + etav * m._Gdt + 1.0);
+    double d[6], tt[6];
+#pragma unroll
+    for (int s = 0; s < 6; s++) { d[s] = dev_stress_inc(tij[s], toij[s], etav, eij[s], m._Gdt, dtr); tt[s] = tij[s] + d[s]; }
+    vep3_edge_plastic<T, SOFT>(a, v, rv, m, tt, tij[3 + T], d[3 + T], etav, Pv, dtr, EIIv);
+}
+
 // update_stresses_center_vertex_ps! 3D -- one edge family at node (i, j, k) (StressKernels.jl:707-903).
 // cen[s][T]: the clamped 4-cell averages of the normal components (s = 0..2: ε, 3..5: τ, 6..8: τ_o) for family T, etav / Pv: harmonic η
 // and average θ, gathered once per node for the three families (vep3_gather_centres)
@@ -216,7 +289,7 @@ struct CenAvg {
 template <int T, bool SOFT>
 __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, int k, const int ci[3], const int cj[3], const int ck[3], const CenAvg &C)
 {
-    const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
     const int n1 = nx + (T != 0), n2 = ny + (T != 1), n3 = nz + (T != 2);
     if (i >= n1 || j >= n2 || k >= n3) return;
     typedef unsigned int u32;
@@ -227,8 +300,6 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
     double *const tsh[3] = {a.f.tyz, a.f.txz, a.f.txy};
     const double *const tosh[3] = {a.f.toyz, a.f.toxz, a.f.toxy};
     const double *const esh[3] = {a.f.eyz, a.f.exz, a.f.exy};
-    double *const eplsh[3] = {a.f.eplyz, a.f.eplxz, a.f.eplxy};
-    const double *const phsh[3] = {a.f.phase_yz, a.f.phase_xz, a.f.phase_xy};
     double eij[6], tij[6], toij[6];
 #pragma unroll
     for (int s = 0; s < 3; s++) { eij[s] = C.v[s][T]; tij[s] = C.v[3 + s][T]; toij[s] = C.v[6 + s][T]; }
@@ -244,31 +315,7 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
         toij[3 + s] = 0.25 * (LB(tosh[s], o[0]) + LB(tosh[s], o[1]) + LB(tosh[s], o[2]) + LB(tosh[s], o[3]));
     }
 #undef LB
-    const double *rv = phsh[T] + (i64)np * v;
-    bool is_pl; double eta_reg;
-    plastic_params3(a.rh, rv, is_pl, eta_reg);
-    const double _Gdt = 1.0 / (ratio_avg3(a.rh.G, rv, np) * a.dt);
-    const double Kv = ratio_avg3(a.rh.Kb, rv, np);
-    const double dtr = 1.0 / (a.theta_dtau + etav * _Gdt + 1.0);
-    double d[6], tt[6];
-#pragma unroll
-    for (int s = 0; s < 6; s++) { d[s] = dev_stress_inc(tij[s], toij[s], etav, eij[s], _Gdt, dtr); tt[s] = tij[s] + d[s]; }
-    const double tIIv = sinv3(tt);
-    double dQdt[6], dQdP, dFdP;
-    plastic_grad3(a.rh, rv, tt, dQdt, dQdP, dFdP);
-    const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
-    const double F = yield_F3<SOFT>(a.rh, rv, Pv, tIIv, SOFT ? C.EIIv[T] : 0.0);
-    constexpr int own = 3 + T;
-    if (is_pl && tIIv != 0.0 && F > 0) {
-        const double l = (1.0 - a.rel) * a.lamv[T][v] + a.rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol));
-        a.lamv[T][v] = l;
-        const double epl = l * dQdt[own];
-        a.tnew[T][v] = tij[own] + fma(-(2.0 * etav * epl), dtr, d[own]);
-        eplsh[T][v] = epl;
-    } else {
-        a.tnew[T][v] = tij[own] + d[own];
-        eplsh[T][v] = 0.0;
-    }
+    vep3_edge_finish<T, SOFT>(a, v, eij, tij, toij, etav, Pv, C.EIIv[T]);
 }
 
 // The clamped centre stencils of the three families lie in the 2 x 2 x 2 cube of cells below the node (cen3: bit = 1 own index,
@@ -353,12 +400,201 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
     vep3_edge_body<2, SOFT>(a, i, j, k, ci, cj, ck, C);
 }
 
+// ------------------------------------------------------------------------------------------------
+// z-marching form of the edge pass (option "vep3_edges" = 1, the default when no phase has a softening law).  A wave owns the nodes
+// (i0 .. i0+61, j) -- lane l sits on node i = i0 - 1 + l, lanes 0 and 63 only feed their neighbours -- and walks KZ node planes.  Per plane
+// it loads its own cell column of the centre arrays in rows j-1 and j (2 loads per array instead of 7): the i-1 operands come from
+// the neighbouring lane, the k-1 ones are carried as the partial sums the reference's order of summation starts with, ((a + b) + c) + d:
+//   yz: a, b = (i, j-1, k-1), (i, j, k-1)   xz: a, b = (i-1, j, k-1), (i, j, k-1)   xy: all four cells in plane k
+// The 4-point stencils of the other families' shear components work the same way: rows j-1 / j / j+1 are loaded, i +- 1 comes from the
+// neighbouring lanes, plane k-1 (xy) is carried and plane k+1 (yz, xz) is loaded one step ahead.  Operands are reduced to the trial stress
+// as soon as they arrive (centre phase, shear phase, then the return mapping), results are bit-identical to k_vep3_edges (same operands,
+// same order of summation).  One wave updating all three families needs ~335 VGPRs (1 wave/SIMD: 2.63 ms at 256^3, no faster than the
+// gathering kernel's 2.68 ms, profiles/r02_vep3_zmarching.txt), so a wave updates ONE family (~170 VGPRs, 3 waves/SIMD, ~34 loads per node
+// and family instead of ~60) and the three waves of a tile are scheduled on the same XCD so that they share their operands in its L2.
+// Index clamps are the reference's (cell range [0, n-1] for every array, StressKernels.jl:604-668): lane values are the clamped-own
+// ones, so "i-1" / "i+1" degenerate to the own value on the domain faces.
+// ------------------------------------------------------------------------------------------------
+// FAM: bit T set = family T (0 yz, 1 xz, 2 xy) is updated by this launch; what the other families alone need (loads, lane exchanges, carried
+// sums) is dead code then
+template <int KZ, int NP, int FAM>
+__device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int seg, const int j, const int zchunk)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP;
+    const int lane = threadIdx.x & 63;
+    if (j > ny) return;                                  // whole waves; the kernel has no barrier
+    const int i = seg * 62 - 1 + lane;
+    const bool useful = lane >= 1 && lane <= 62 && i <= nx;
+    const int kb = zchunk * KZ, ke = min(kb + KZ, nz + 1);
+    const int ic = clampi3(i, 0, nx - 1), ir = clampi3(i, 0, nx);
+    const int cj0 = clampi3(j - 1, 0, ny - 1), cj1 = clampi3(j, 0, ny - 1), cj2 = clampi3(j + 1, 0, ny - 1);
+    const bool lo_i = i >= 1, hi_i = i < nx - 1;
+    auto up = [&](double v) { const double u = __shfl_up(v, 1, 64); return lo_i ? u : v; };      // value at clamp(i - 1)
+    auto dn = [&](double v) { const double u = __shfl_down(v, 1, 64); return hi_i ? u : v; };    // value at clamp(i + 1)
+    // centre arrays in the order they are consumed: 1/η, θ, then the (ε, τ, τ_o) triple of each normal component
+    const double *const cen[11] = {a.f.eta, a.theta, a.f.exx, a.f.txx, a.f.toxx, a.f.eyy, a.f.tyy, a.f.toyy, a.f.ezz, a.f.tzz, a.f.tozz};
+    const double *const Yp[3] = {a.f.eyz, a.f.tyz, a.f.toyz}, *const Xp[3] = {a.f.exz, a.f.txz, a.f.toxz}, *const Zp[3] = {a.f.exy, a.f.txy, a.f.toxy};
+    // row offsets inside one plane of each array family
+    // byte offsets (32-bit: every array is below 4 GiB, check_vep3) = lane part inside one plane + uniform plane part
+    typedef unsigned int u32;
+#define LB(p, off) (*(const double *)((const char *)(p) + (off)))
+    const u32 oc0 = 8u * (u32)(ic + nx * cj0), oc1 = 8u * (u32)(ic + nx * cj1);                     // centres (nx, ny)
+    const u32 oy1 = oc1, oy2 = 8u * (u32)(ic + nx * cj2);                                           // yz (nx, ny+1): rows clamp(j), clamp(j+1)
+    const u32 ox0 = 8u * (u32)(ic + (nx + 1) * cj0), ox1 = 8u * (u32)(ic + (nx + 1) * cj1);         // xz (nx+1, ny): rows clamp(j-1), clamp(j)
+    const u32 oz1 = ox1, oz2 = 8u * (u32)(ic + (nx + 1) * cj2);                                     // xy (nx+1, ny+1): rows clamp(j), clamp(j+1)
+    const u32 pc = 8u * (u32)(nx * ny), py = 8u * (u32)(nx * (ny + 1)), px = 8u * (u32)((nx + 1) * ny), pz = 8u * (u32)((nx + 1) * (ny + 1));
+    const bool act0 = useful && i < nx, act1 = useful && j < ny;             // yz / xz edge exists at this (i, j); xy: useful && k < nz
+    double pyz[11], pxz[11], Yn[3][2], Xn[3][2], Zc[3][2];
+    {
+        const u32 kc = (u32)clampi3(kb - 1, 0, nz - 1);
+#pragma unroll
+        for (int s = 0; s < 11; s++) {
+            double v0 = LB(cen[s], oc0 + pc * kc), v1 = LB(cen[s], oc1 + pc * kc);
+            if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
+            const double u1 = up(v1);
+            pyz[s] = v0 + v1;
+            pxz[s] = u1 + v1;
+        }
+        const u32 k1 = (u32)clampi3(kb, 0, nz - 1);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            Yn[q][0] = LB(Yp[q], oy1 + py * k1); Yn[q][1] = LB(Yp[q], oy2 + py * k1);
+            Xn[q][0] = LB(Xp[q], ox0 + px * k1); Xn[q][1] = LB(Xp[q], ox1 + px * k1);
+            Zc[q][0] = LB(Zp[q], oz1 + pz * kc); Zc[q][1] = LB(Zp[q], oz2 + pz * kc);
+        }
+    }
+#pragma unroll 1
+    for (int k = kb; k < ke; k++) {
+        const u32 k1 = (u32)clampi3(k, 0, nz - 1), k2 = (u32)clampi3(k + 1, 0, nz - 1);
+        const bool act2 = useful && k < nz;
+        const i64 vi[3] = {i + (i64)nx * (j + (i64)(ny + 1) * k), i + (i64)(nx + 1) * (j + (i64)ny * k), i + (i64)(nx + 1) * (j + (i64)(ny + 1) * k)};
+        const double *const rv[3] = {a.f.phase_yz + (act0 ? np * vi[0] : 0), a.f.phase_xz + (act1 ? np * vi[1] : 0), a.f.phase_xy + (act2 ? np * vi[2] : 0)};
+        // the four cells of array s around the node, in plane clamp(k): sums of the three families, then the carried partial sums of the next plane
+        auto sums = [&](int s, double S[3]) {
+            double v0 = LB(cen[s], oc0 + pc * k1), v1 = LB(cen[s], oc1 + pc * k1);
+            if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
+            const double u0 = up(v0), u1 = up(v1);
+            S[0] = (pyz[s] + v0) + v1;
+            S[1] = (pxz[s] + u1) + v1;
+            S[2] = ((u0 + v0) + u1) + v1;
+            pyz[s] = v0 + v1;
+            pxz[s] = u1 + v1;
+        };
+        EdgeMat m[3];
+        double etav[3], Pv[3], dtr[3], tt[3][6], S[3][3];
+        sums(0, S[0]);
+        sums(1, S[1]);
+#pragma unroll
+        for (int T = 0; T < 3; T++) {
+            if (!((FAM >> T) & 1)) continue;
+            m[T] = edge_mat<NP>(a, rv[T]);
+            etav[T] = 4 / S[0][T];
+            Pv[T] = 0.25 * S[1][T];
+            dtr[T] = 1.0 / (a.theta_dtau + etav[T] * m[T]._Gdt + 1.0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            sums(2 + 3 * c, S[0]);
+            sums(3 + 3 * c, S[1]);
+            sums(4 + 3 * c, S[2]);
+#pragma unroll
+            for (int T = 0; T < 3; T++) {
+                if (!((FAM >> T) & 1)) continue;
+                const double t = 0.25 * S[1][T];
+                tt[T][c] = t + dev_stress_inc(t, 0.25 * S[2][T], etav[T], 0.25 * S[0][T], m[T]._Gdt, dtr[T]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // shear components: yz, xz at planes clamp(k) (carried) and clamp(k+1) (loaded here); xy at clamp(k-1) (carried) and clamp(k)
+        double Yc[3][2], Xc[3][2], Zq[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            Yc[q][0] = Yn[q][0]; Yc[q][1] = Yn[q][1]; Xc[q][0] = Xn[q][0]; Xc[q][1] = Xn[q][1]; Zq[q][0] = Zc[q][0]; Zq[q][1] = Zc[q][1];
+            Yn[q][0] = LB(Yp[q], oy1 + py * k2); Yn[q][1] = LB(Yp[q], oy2 + py * k2);
+            Xn[q][0] = LB(Xp[q], ox0 + px * k2); Xn[q][1] = LB(Xp[q], ox1 + px * k2);
+            Zc[q][0] = LB(Zp[q], oz1 + pz * k1); Zc[q][1] = LB(Zp[q], oz2 + pz * k1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double own_t[3], own_d[3];
+        auto trial = [&](int T, const double o[3]) { return o[1] + dev_stress_inc(o[1], o[2], etav[T], o[0], m[T]._Gdt, dtr[T]); };
+        if constexpr ((FAM & 1) != 0) {   // yz edge: own (i, j, k); xz at (i, i+1) x (j-1, j); xy at (i, i+1) x planes (k-1, k)
+            double own[3], ox[3], oz[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                own[q] = Yc[q][0];
+                if (j == ny || k == nz) own[q] = LB(Yp[q], 8u * (u32)(ic + nx * j) + py * (u32)k);
+                ox[q] = 0.25 * (((Xc[q][0] + dn(Xc[q][0])) + Xc[q][1]) + dn(Xc[q][1]));
+                oz[q] = 0.25 * (((Zq[q][0] + dn(Zq[q][0])) + Zc[q][0]) + dn(Zc[q][0]));
+            }
+            own_t[0] = own[1];
+            own_d[0] = dev_stress_inc(own[1], own[2], etav[0], own[0], m[0]._Gdt, dtr[0]);
+            tt[0][3] = own_t[0] + own_d[0]; tt[0][4] = trial(0, ox); tt[0][5] = trial(0, oz);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((FAM & 2) != 0) {   // xz edge: own (i, j, k); yz at (i-1, i) x (j, j+1); xy at (j, j+1) x planes (k-1, k)
+            double own[3], oy[3], oz[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                own[q] = Xc[q][1];
+                if (i >= nx || k == nz) own[q] = LB(Xp[q], 8u * (u32)(ir + (nx + 1) * cj1) + px * (u32)k);
+                oy[q] = 0.25 * (((up(Yc[q][0]) + Yc[q][0]) + Yc[q][1]) + up(Yc[q][1]));
+                oz[q] = 0.25 * (((Zq[q][0] + Zq[q][1]) + Zc[q][0]) + Zc[q][1]);
+            }
+            own_t[1] = own[1];
+            own_d[1] = dev_stress_inc(own[1], own[2], etav[1], own[0], m[1]._Gdt, dtr[1]);
+            tt[1][3] = trial(1, oy); tt[1][4] = own_t[1] + own_d[1]; tt[1][5] = trial(1, oz);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((FAM & 4) != 0) {   // xy edge: own (i, j, k); yz at (i-1, i) x planes (k, k+1); xz at (j-1, j) x planes (k, k+1)
+            double own[3], oy[3], ox[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                own[q] = Zc[q][0];
+                if (i >= nx || j == ny) own[q] = LB(Zp[q], 8u * (u32)(ir + (nx + 1) * j) + pz * k1);
+                oy[q] = 0.25 * (((up(Yc[q][0]) + Yc[q][0]) + up(Yn[q][0])) + Yn[q][0]);
+                ox[q] = 0.25 * (((Xc[q][0] + Xc[q][1]) + Xn[q][0]) + Xn[q][1]);
+            }
+            own_t[2] = own[1];
+            own_d[2] = dev_stress_inc(own[1], own[2], etav[2], own[0], m[2]._Gdt, dtr[2]);
+            tt[2][3] = trial(2, oy); tt[2][4] = trial(2, ox); tt[2][5] = own_t[2] + own_d[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((FAM & 1) != 0) if (act0) vep3_edge_plastic<0, false, NP>(a, vi[0], rv[0], m[0], tt[0], own_t[0], own_d[0], etav[0], Pv[0], dtr[0], 0.0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((FAM & 2) != 0) if (act1) vep3_edge_plastic<1, false, NP>(a, vi[1], rv[1], m[1], tt[1], own_t[1], own_d[1], etav[1], Pv[1], dtr[1], 0.0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((FAM & 4) != 0) if (act2) vep3_edge_plastic<2, false, NP>(a, vi[2], rv[2], m[2], tt[2], own_t[2], own_d[2], etav[2], Pv[2], dtr[2], 0.0);
+    }
+}
+#undef LB
+template <int KZ, int NP, int FAM>
+__global__ __launch_bounds__(256) void k_vep3_edges_z(const Vep3Args a, int nseg)
+{
+    vep3_edges_z_tile<KZ, NP, FAM>(a, blockIdx.x % nseg, (blockIdx.x / nseg) * 4 + (int)(threadIdx.x >> 6), blockIdx.y);
+}
+// One launch, one family per block: the three blocks of a tile (same nodes, families yz / xz / xy) sit next to each other in the block sequence
+// of ONE XCD (blocks are dealt round-robin to the 8 XCDs), so that the operands they share are fetched from HBM once and found in that XCD's L2 by
+// the other two; per block only one family's state lives in registers.
+template <int KZ, int NP, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_vep3_edges_zf(const Vep3Args a, int nseg, int ntile_xy, int ntiles)
+{
+    const unsigned L = blockIdx.x, xcd = L & 7u, q = L >> 3;            // q-th block of this XCD
+    const unsigned per = ((unsigned)ntiles + 7u) / 8u;                  // XCD x works on the tiles [x * per, (x + 1) * per): a slab of z chunks
+    const unsigned fam = q % 3u, t = xcd * per + q / 3u;                // tile index over (xy tiles fastest, z chunks)
+    if (q / 3u >= per || t >= (unsigned)ntiles) return;
+    const int txy = (int)(t % (unsigned)ntile_xy), zc = (int)(t / (unsigned)ntile_xy);
+    const int j = (txy / nseg) * 4 + (int)(threadIdx.x >> 6);
+    if (fam == 0) vep3_edges_z_tile<KZ, NP, 1>(a, txy % nseg, j, zc);
+    else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2>(a, txy % nseg, j, zc);
+    else vep3_edges_z_tile<KZ, NP, 4>(a, txy % nseg, j, zc);
+}
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
 template <bool SOFT>
 __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
-    NODE_IJK(nx, ny)
+    NODE_IJK_XS(nx, ny)
     if (k >= nz) return;
     const i64 c = i + (i64)nx * (j + (i64)ny * k);
     const double *rc = a.f.phase_c + (i64)np * c;
@@ -524,7 +760,30 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const bool p4 = h->vep3_map, xs = h->vep3_xcd;     // options "vep3_map", "vep3_xcd" (XCD slab order: +1-2 % measured)
-    if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    if (!a.soft && h->vep3_edges >= 1 && a.rh.nphase <= 4) {
+        // option "vep3_edges": 0 one node per thread (k_vep3_edges; also the form softening laws and more than 4 phases use), 1 (default) the z-marching
+        // kernel with one family per block and the three blocks of a tile on one XCD, 2 the same kernel as one launch per family (A/B: the L2 sharing)
+        const int cfg = h->vep3_cfg ? h->vep3_cfg : 163;           // option "vep3_cfg" = KZ * 10 + min blocks per CU (tuning)
+        const int kz = cfg / 10, mb = cfg % 10, np_ = a.rh.nphase;
+        const int nseg = (nx + 1 + 61) / 62, ntxy = nseg * ((ny + 1 + 3) / 4), nzc = (nz + 1 + kz - 1) / kz, nt = ntxy * nzc;
+        bool ok = false;
+        if (h->vep3_edges == 2) {
+            const dim3 g((unsigned)ntxy, (unsigned)nzc);
+#define EZ(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 1>), g, dim3(256), 0, s, a, nseg); \
+                hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 2>), g, dim3(256), 0, s, a, nseg); \
+                hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 4>), g, dim3(256), 0, s, a, nseg); ok = true; }
+            EZ(1) EZ(2) EZ(3) EZ(4)
+#undef EZ
+        } else {
+            const dim3 gf((unsigned)(((nt + 7) / 8) * 8 * 3));
+#define EZG(KZ_, NP_, MB_) if (kz == KZ_ && mb == MB_ && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<KZ_, NP_, MB_>), gf, dim3(256), 0, s, a, nseg, ntxy, nt); ok = true; }
+#define EZN(KZ_, MB_) EZG(KZ_, 1, MB_) EZG(KZ_, 2, MB_) EZG(KZ_, 3, MB_) EZG(KZ_, 4, MB_)
+            EZN(16, 3) EZN(8, 3) EZN(32, 3) EZN(16, 2)
+#undef EZN
+#undef EZG
+        }
+        if (!ok) return jrx_fail(h, JRX_ERR_ARG, "vep3_cfg: no such configuration");
+    } else if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else if (p4 && xs) hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """it/s of the 3D paths next to the headline one on one GPU: 3D multiphase VEP shear band (Stokes3D.jl:447-668) and 3D PT heat
-diffusion.  Fixed iteration counts (convergence disabled); prints one JSON line per case.  usage: bench3d_extra.py [n_vep] [n_thermal]"""
+diffusion.  Fixed iteration counts (convergence disabled); prints one JSON line per case.  usage: bench3d_extra.py [n_vep] [n_thermal] [KEY=INT ...]"""
 import json, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -65,6 +65,12 @@ def thermal3d(n=256, iters=400):
 if __name__ == "__main__":
     nv = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     nt = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    for kv in sys.argv[3:]:                     # library options, KEY=INT
+        import ctypes as C
+        from justrelax_jl_amd import _lib
+        k, v = kv.split("=")
+        _lib.default_handle(0).call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(int(v)))
+        print(f"# option {k} = {v}")
     if nt > 0:
         thermal3d(nt)
     if nv > 0:

@@ -3,7 +3,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmcx}
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $OUT/sq -- python3 $GRAFT_REPO_ROOT/scripts/bench3d_extra.py ${2:-192} ${3:-192} > $OUT/sq.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $OUT/sq -- python3 $GRAFT_REPO_ROOT/scripts/bench3d_extra.py ${2:-192} ${3:-192} ${@:4} > $OUT/sq.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
 import csv, glob, collections
