@@ -19,7 +19,8 @@ Besides the headline line (BASELINE.json's metric/config) the same JSON carries,
   solve_path     jrx_stokes3d_solve on the same 512^3 problem with the reference's cadence
                  (iterMax = 399, nout = 100: norm checks, un-fused check iterations, host syncs included)
   other_configs  the other BASELINE configs at their stated sizes (SolVi3D 256^3, SolCx 512^2, shear band
-                 1024^2, thermal diffusion 256^2), each a short fixed-iteration run
+                 1024^2, thermal diffusion 256^2) and the 3D VEP / 3D thermal paths at 256^3, each a short
+                 fixed-iteration run
   cpu_baseline   the oracle's six-kernel OpenMP iteration on the host cores at 128^3 and 256^3 (unscaled)
 """
 from __future__ import annotations
@@ -43,9 +44,9 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measure
 # L2<->fabric bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
 # correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
 # n = 512 (profiles/*pmc*traffic.txt; the file names are in PMC_SOURCE)
-PMC_TRAFFIC_STRESS_512 = (2 * 13048845.0 + 7410032.0) * 1024.0
-PMC_TRAFFIC_FUSED_512 = (2 * 20010734.0 + 11054315.0) * 1024.0
-PMC_SOURCE = {"stress": "profiles/r01_pmc_xcd_banded_traffic.txt", "fused": "profiles/r01_pmc_fused_final_traffic.txt"}
+PMC_TRAFFIC_STRESS_512 = 32.545e9       # k_stress3d_zb: 24.965 GB fetched (x2 applied) + 7.580 GB written
+PMC_TRAFFIC_FUSED_512 = 52.364e9        # k_fused3d:     41.050 GB fetched (x2 applied) + 11.314 GB written (38.2 + 10.5 array passes)
+PMC_SOURCE = {"stress": "profiles/r02_pmc_bench_traffic.txt", "fused": "profiles/r02_pmc_bench_traffic.txt"}
 
 
 # ------------------------------------------------------------------------------------------------ launching
@@ -275,11 +276,59 @@ def cfg_thermal2d(jr, h, n=256, iters=4000):
             "effective_GBps_at_144B_per_cell": 144.0 * n * n * k / el / 1e9}
 
 
+def cfg_shearband3d(jr, h, n=256, iters=60):
+    """3D multiphase visco-elasto-plastic shear band (Stokes3D.jl:447-668 as test/test_shearband3D_MPI.jl drives it).  Algorithmic traffic of
+    one iteration in the reference's kernel decomposition = 114 array passes = 912 B/cell (DESIGN.md, 3D VEP table)."""
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s = jr.miniapps.shearband3d(n, iterMax=iters - 1, nout=10 ** 9)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+    st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+    for k, t in dict(Vx=st.V.Vx, Vy=st.V.Vy, Vz=st.V.Vz, eta=st.viscosity.η).items():
+        t.copy_(from_numpy(s.arrays[k], dev))
+    pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, s.ni)
+    for k, name in (("phase_c", "center"), ("phase_yz", "yz"), ("phase_xz", "xz"), ("phase_xy", "xy")):
+        getattr(pr, name).copy_(from_numpy(s.arrays[k], dev))
+    phases, grid_, pt, bcs, dt = s.extra["phases"], s.grid, s.pt, s.flow_bcs, s.dt
+    del s
+    ρg = tuple(jr.fzeros(st._ni, dev) for _ in range(3))
+    run = lambda k: jr.solve_(st, pt, grid_, bcs, ρg, pr, phases, None, dt, None, kwargs=dict(iterMax=k - 1, nout=10 ** 9, verbose=False), handle=h)
+    el, r = _timed(run, 5, iters)
+    gbps = 912.0 * n ** 3 * r.iter / el / 1e9
+    return {"workload": f"shear band {n}^3 (3D multiphase VEP)", "iterations": int(r.iter), "it_per_s": r.iter / el,
+            "effective_GBps_at_912B_per_cell": gbps, "frac_of_8TBps": gbps / 8000.0}
+
+
+def cfg_thermal3d(jr, h, n=256, iters=400):
+    """3D PT heat diffusion, array-coefficient form (DiffusionPT_solver.jl:34-149); 22 passes = 176 B/cell-iteration as the reference's two kernels move
+    them (flux: R T, K, θ, q(3) W q(3), q2(3); update: R q(3), Told, ρCp, dτ_ρ, H, SH, T W T)."""
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s = jr.miniapps.diffusion3d(n, iterMax=iters, nout=10 ** 9)
+    th = jr.ThermalArrays(jr.AMDGPUBackend, s.ni)
+    th.T.copy_(from_numpy(s.arrays["T"], dev)); th.H.fill_(1.0e-6)
+    K, ρCp = from_numpy(s.arrays["K"], dev), from_numpy(s.arrays["rhoCp"], dev)
+    pt = jr.PTThermalCoeffs(jr.AMDGPUBackend, K, ρCp, s.dt, s.extra["di"], s.extra["li"], CFL=s.pt["CFL"], ϵ=1e-300)
+    bcs, dt, grid_ = s.flow_bcs, s.dt, s.grid
+    del s
+
+    def run(k):
+        jr.heatdiffusion_PT_(th, pt, bcs, K, ρCp, dt, grid_, kwargs=dict(iterMax=k, nout=10 ** 9, verbose=False), handle=h)
+        return k
+    el, k = _timed(run, 20, iters)
+    gbps = 176.0 * n ** 3 * k / el / 1e9
+    return {"workload": f"thermal diffusion {n}^3 (3D PT, array form)", "iterations": k, "it_per_s": k / el,
+            "effective_GBps_at_176B_per_cell": gbps, "frac_of_8TBps": gbps / 8000.0}
+
+
 def other_configs(jr, h):
     import justrelax_jl_amd.grid as grid
     out = {}
     for key, fn in (("solvi3d_256", lambda: cfg_solvi(jr, h, 256, 200, 20)), ("solcx_512", lambda: cfg_solcx(jr, h)),
-                    ("shearband_1024", lambda: cfg_shearband(jr, h)), ("thermal2d_256", lambda: cfg_thermal2d(jr, h))):
+                    ("shearband_1024", lambda: cfg_shearband(jr, h)), ("thermal2d_256", lambda: cfg_thermal2d(jr, h)),
+                    ("shearband3d_256", lambda: cfg_shearband3d(jr, h)), ("thermal3d_256", lambda: cfg_thermal3d(jr, h))):
         try:
             grid.finalize_global_grid()
             out[key] = fn()
