@@ -418,7 +418,7 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     // option "fused_comm" = 0 keeps the split sweeps + hidden communication on multi-rank runs (A/B switch; same results);
     // option "scratch_sets" = 0 refuses the library-owned second state set the fused pipeline needs
     // DisplacementBoundaryConditions: flow_bcs! acts on U, the ghosts of V are never refreshed -- the fused kernel's in-kernel BC rules do not apply
-    I.fusable = !p->displacement_bcs && (h->kernel_variant == 0 || h->kernel_variant == 3) && h->scratch_sets && (h->fused_comm || !jrx_comm_active(h)) && p->periodic == 0 && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
+    I.fusable = !p->displacement_bcs && (h->kernel_variant == 0 || h->kernel_variant == 3) && h->scratch_sets && (h->fused_comm || !jrx_comm_active(h)) && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable && h->kernel_variant == 0) {
         // auto: the fused kernel covers a row with ceil(nx / (TX - 2)) TX-lane tiles (one halo and one feeder lane each); when that
         // quantisation idles too many lanes the two sweeps are faster (measured with 64-lane rows, profiles/r01_bench_sizes.txt: nx = 192,
@@ -509,11 +509,14 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         const FusedShape S = fused_shape(h);
         fused_tiles(a.L, S, nt);
         const bool comm = jrx_comm_active(h);
+        // periodic_boundary! faces (periodic.jl:56-98) are this block's own neighbour: their planes of V are filled by flow_bcs! after the fused
+        // launch, and the stress nodes that read them are redone below exactly like the nodes next to a received halo plane
+        const bool per = p->periodic != 0;
         hipStream_t bs = s;            // stream of the boundary work
         // flow_bcs! on the new V: the reference's ordered passes the first time a set is written, one launch for all faces afterwards
         bool &ordered = I.bcs_ordered[I.cur_is_user ? 1 : 0];
         auto fused_bcs = [&](hipStream_t st) -> jrx_status {
-            if (ordered) return launch_bcs_faces(h, st, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip);
+            if (ordered && !per) return launch_bcs_faces(h, st, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip);
             ordered = true;
             return launch_bcs(h, st, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic);
         };
@@ -523,7 +526,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         // send/recv kernel does not finish before the interior kernel drains, so nothing is hidden and the six small shell launches
         // cost more than they save when an x face is involved (10.7 vs 9.1 ms); to be revisited with real neighbours / DMA copies.
         const bool overlap = h->fused_overlap;
-        const bool split = !comm && h->fused_split && nt[0] > 1 && nt[1] > 1 && nt[2] > 1;
+        const bool split = !comm && !per && h->fused_split && nt[0] > 1 && nt[1] > 1 && nt[2] > 1;
         if (split) {
             // Without neighbours the only work behind the fused kernel is the stress update of the high-face node layers (i = nx, j = ny,
             // k = nz): thin, strided (the x face touches one cache line per node and array) and latency-bound -- 0.11 ms at 512^3, 7 % of
@@ -555,15 +558,19 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             // Without neighbours no flow_bcs! launch is needed here: the fused kernel and the boundary-layer launch below derive the
             // boundary entries of V by rule, and every path that reads them from memory (un-fused sweeps, results handed back) is
             // preceded by a flow_bcs! launch of its own.  With neighbours the exchange ships those entries, so they must be in memory.
-            if (comm) JRX_TRY(fused_bcs(s));
+            if (comm || per) JRX_TRY(fused_bcs(s));
             else I.ghosts_stale = true;
+            if (per) {
+                const uint32_t lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_BOT}, hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_TOP};
+                for (int d = 0; d < 3; d++) { nb[d][0] = (p->periodic & lo[d]) != 0; nb[d][1] = (p->periodic & hi[d]) != 0; }
+            }
             if (comm) {
                 // update_halo!(V) after the BCs (Stokes3D.jl:117-120): the neighbours' new velocities land in the boundary planes of dst
                 double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
                 const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
                 const int64_t n[3] = {nx, ny, nz};
                 JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, n));
-                for (int d = 0; d < 3; d++) { nb[d][0] = jrx_comm_has_neighbor(h, d, 0); nb[d][1] = jrx_comm_has_neighbor(h, d, 1); }
+                for (int d = 0; d < 3; d++) { nb[d][0] |= jrx_comm_has_neighbor(h, d, 0); nb[d][1] |= jrx_comm_has_neighbor(h, d, 1); }
             }
         } else {
             // The role of @hide_communication (Stokes3D.jl:104-121) for the fused kernel: the shell of tiles that touches a face of
@@ -591,6 +598,10 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             const int64_t n[3] = {nx, ny, nz};
             JRX_TRY(jrx_halo_exchange(h, bs, 3, arrs, ext, n));
             for (int d = 0; d < 3; d++) { nb[d][0] = jrx_comm_has_neighbor(h, d, 0); nb[d][1] = jrx_comm_has_neighbor(h, d, 1); }
+            if (per) {
+                const uint32_t lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_BOT}, hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_TOP};
+                for (int d = 0; d < 3; d++) { nb[d][0] |= (p->periodic & lo[d]) != 0; nb[d][1] |= (p->periodic & hi[d]) != 0; }
+            }
         }
         // Stress nodes whose stencil reads a velocity plane that only now has its final value are redone from the old τ of the
         // current set and the new V of dst: always the planes i = nx, j = ny, k = nz (high-face BC planes); on a face with a
@@ -608,7 +619,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                                ty(JRX_FACE_BACK, JRX_FACE_BACK), ty(JRX_FACE_TOP, JRX_FACE_BOT), ty(JRX_FACE_BOT, JRX_FACE_TOP)};
             for (int q = 0; q < 6; q++) gr.t[q] = t6[q];
         }
-        JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false, comm ? nullptr : &gr));
+        JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false, (comm || per) ? nullptr : &gr));
         if (bs != s) {
             JRX_HIP(h, hipEventRecord(h->ev[2], bs));
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));

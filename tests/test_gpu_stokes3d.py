@@ -224,7 +224,8 @@ def test_cpu_arrays_are_refused(jr):
 
 @pytest.mark.parametrize("ni,bcs", [((130, 20, 17), "free_slip"), ((70, 12, 9), "free_slip"), ((130, 17, 20), "no_slip"),
                                     ((97, 9, 33), "none"), ((64, 16, 40), "no_slip"), ((200, 8, 8), "free_slip"),
-                                    ((130, 18, 19), "slip_mix"), ((66, 9, 35), "slip_mix")])
+                                    ((130, 18, 19), "slip_mix"), ((66, 9, 35), "slip_mix"), ((130, 12, 17), "periodic"), ((70, 20, 9), "mixed"),
+                                    ((130, 9, 24), "mixed")])
 def test_kernel_variants_are_bit_identical(env, ni, bcs):
     """auto (0), per-node kernels (1), the two z-marching sweeps (2) and the fused PT pipeline (3) must agree bit for bit:
     same operation order, and the fused kernel's on-the-fly low-face boundary rules reproduce flow_bcs!."""
@@ -243,7 +244,12 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
             h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant % 10))
             h.call("jrx_set_option", C.c_char_p(b"fused_tile"), C.c_int64(1 - tile0.value if variant >= 10 else tile0.value))
             stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            n0, n1 = C.c_int64(0), C.c_int64(0)
+            h.call("jrx_get_option", C.c_char_p(b"stat_fused3d"), C.byref(n0))
             r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+            h.call("jrx_get_option", C.c_char_p(b"stat_fused3d"), C.byref(n1))
+            if variant % 10 == 3:
+                assert n1.value > n0.value, "the fused pipeline did not run (periodic faces included)"
             its.append((r.iter, tuple(r.err_evo1)))
             outs.append(env["down"](stokes))
     finally:
