@@ -280,6 +280,7 @@ typedef struct jrx_vep2d_fields {
     double *omega_xy;                              /* stokes.ω.xy (may be NULL) */
     double *phase_c, *phase_v;                     /* phase_ratios.center / .vertex */
     const double *T;                               /* args.T at the cell centres (ni) for the density laws; may be NULL (T = 0) */
+    double *dexx, *deyy, *divU;                    /* strain_increment variant: Δε.xx, Δε.yy, stokes.∇U (ni); may be NULL otherwise */
 } jrx_vep2d_fields;
 
 typedef struct jrx_vep2d_params {
@@ -293,6 +294,8 @@ typedef struct jrx_vep2d_params {
     int32_t free_surface;                          /* kwarg free_surface: compute_V! / compute_Res! get dt * free_surface (Stokes2D.jl:773,797) */
     int32_t displacement_bcs;                      /* flow_bcs is a DisplacementBoundaryConditions: V = U / dt first, flow_bcs! acts on U */
     int32_t T_ghosted;                             /* single-phase driver: args.T is thermal.T (nx+2, ny+2), indexed as the reference does */
+    int32_t strain_increment;                      /* kwarg strain_increment (jrx_stokes2d_vep_solve only; Stokes2D.jl:588,659-734, StressKernels.jl:1147-1302): strains
+                                                    * from the displacement increments U = V dt, Δε form of the stress update; U and its BCs are refreshed every iteration */
 } jrx_vep2d_params;
 
 jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p,

@@ -95,7 +95,7 @@ ThermalPhaseFields = _ptr_struct("ThermalPhaseFields", TPH_NAMES)
 
 VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
              "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
-             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v", "T"]
+             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v", "T", "dexx", "deyy", "divU"]
 VEP2DFields = _ptr_struct("VEP2DFields", VEP_NAMES)
 MAXPHASE = 8
 
@@ -117,7 +117,7 @@ class VEP2DParams(C.Structure):
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("iterMin", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
-                ("verbose", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32)]
+                ("verbose", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32), ("strain_increment", C.c_int32)]
 
 
 VEP3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",

@@ -576,6 +576,7 @@ struct VepArgs {
     double _dx, _dy, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
     int nx, ny;
     bool soft;            // some phase has a softening law (EII_pl is then read by the yield function)
+    bool si;              // strain_increment variant
 };
 
 __device__ __forceinline__ double sinv2(double xx, double yy, double xy) { return sqrt(0.5 * (xx * xx + yy * yy) + xy * xy); }
@@ -680,15 +681,51 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
 #undef VY
 }
 
+// strain_increment variant (Stokes2D.jl:659-661, 680-692): ∇U and Δε from the displacements (compute_∇V!, compute_strain_rate! on U), then
+// ε = Δε * _dt (compute_strain_rate_from_increment!, VelocityKernels.jl:46-57) -- overwrites the ε that k_vep_pre derived from V
+__global__ __launch_bounds__(256) void k_vep_strain_inc(const VepArgs a)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / (nx + 1), i = t - j * (nx + 1);
+    if (j > ny) return;
+    const double *__restrict__ Ux = a.f.Ux, *__restrict__ Uy = a.f.Uy;
+    const double _dt = 1.0 / a.dt;
+#define UX(i_, j_) Ux[(i_) + (i64)(nx + 1) * (j_)]
+#define UY(i_, j_) Uy[(i_) + (i64)(nx + 2) * (j_)]
+    if (i < nx && j < ny) {
+        const i64 c = i + (i64)nx * j;
+        const double dxi = (-UX(i, j + 1) + UX(i + 1, j + 1)) * a._dx;
+        const double dyi = (-UY(i + 1, j) + UY(i + 1, j + 1)) * a._dy;
+        const double divU = dxi + dyi;
+        a.f.divU[c] = divU;
+        const double d3 = divU * (1.0 / 3.0);
+        const double dexx = dxi - d3, deyy = dyi - d3;
+        a.f.dexx[c] = dexx; a.f.deyy[c] = deyy;
+        a.f.exx[c] = dexx * _dt; a.f.eyy[c] = deyy * _dt;
+    }
+    const double dexy = 0.5 * (a._dy * (UX(i, j + 1) - UX(i, j)) + a._dx * (UY(i + 1, j) - UY(i, j)));
+    a.f.dexy[i + (i64)(nx + 1) * j] = dexy;
+    a.f.exy[i + (i64)(nx + 1) * j] = dexy * _dt;
+#undef UX
+#undef UY
+}
+// compute_stress_increment(τ, τ_o, η, Δε, _G, dτ_r, dt) -- StressKernels.jl:18-21
+__device__ __forceinline__ double dev_stress_inc_dt(double t, double to, double eta, double de, double _G, double dtr, double dt)
+{
+    return dtr * fma(2.0 * eta, de, fma(-(t - to) * eta, _G, -t * dt));
+}
+
 // update_stresses_center_vertex_ps! -- vertex half.  Runs before the centre half so that the vertex averages
 // see the old centre stresses (the reference's single launch races on them).
-template <bool SOFT>
+// SI: strain_increment form (StressKernels.jl:1147-1302): Δε instead of ε, _G and dτ_r = inv(θ_dτ dt + η _G + dt), plastic terms times dt
+template <bool SOFT, bool SI = false>
 __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, const int j)
 {
     const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
     const int i0 = clampi(i - 1, 0, nx - 1), ic = clampi(i, 0, nx - 1), j0 = clampi(j - 1, 0, ny - 1), jc = clampi(j, 0, ny - 1);
 #define AVC(A) (0.25 * (C2(A, i0, j0) + C2(A, ic, jc) + C2(A, i0, jc) + C2(A, ic, j0)))
-    const double Pv = AVC(a.theta), exxv = AVC(a.f.exx), eyyv = AVC(a.f.eyy), txxv = AVC(a.f.txx), tyyv = AVC(a.f.tyy);
+    const double Pv = AVC(a.theta), exxv = SI ? AVC(a.f.dexx) : AVC(a.f.exx), eyyv = SI ? AVC(a.f.deyy) : AVC(a.f.eyy), txxv = AVC(a.f.txx), tyyv = AVC(a.f.tyy);
     const double toxxv = AVC(a.f.toxx), toyyv = AVC(a.f.toyy);
     const double EIIv = SOFT ? AVC(a.f.EII_pl) : 0.0;      // EIIv_ij = av_clamped(EII, Ic...) (StressKernels.jl:1030); only softening laws read it
 #undef AVC
@@ -696,14 +733,14 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
     const double *rv = a.f.phase_v + (i64)np * v;
     bool is_pl; double eta_reg;
     plastic_params(a.rh, rv, is_pl, eta_reg);
-    const double _Gdt = 1.0 / (ratio_avg(a.rh.G, rv, np) * a.dt);
+    const double _Gdt = SI ? 1.0 / ratio_avg(a.rh.G, rv, np) : 1.0 / (ratio_avg(a.rh.G, rv, np) * a.dt);      // SI: _Gv
     const double Kv = ratio_avg(a.rh.Kb, rv, np);
     const double etav = 4.0 / (1.0 / C2(a.f.eta, i0, j0) + 1.0 / C2(a.f.eta, ic, jc) + 1.0 / C2(a.f.eta, i0, jc) + 1.0 / C2(a.f.eta, ic, j0));
-    const double dtr = 1.0 / (a.theta_dtau + etav * _Gdt + 1.0);
+    const double dtr = SI ? 1.0 / (a.theta_dtau * a.dt + etav * _Gdt + a.dt) : 1.0 / (a.theta_dtau + etav * _Gdt + 1.0);
     const double txy = a.f.txy[v];
-    const double dxx = dev_stress_inc(txxv, toxxv, etav, exxv, _Gdt, dtr);
-    const double dyy = dev_stress_inc(tyyv, toyyv, etav, eyyv, _Gdt, dtr);
-    const double dxy = dev_stress_inc(txy, a.f.toxy[v], etav, a.f.exy[v], _Gdt, dtr);
+    const double dxx = SI ? dev_stress_inc_dt(txxv, toxxv, etav, exxv, _Gdt, dtr, a.dt) : dev_stress_inc(txxv, toxxv, etav, exxv, _Gdt, dtr);
+    const double dyy = SI ? dev_stress_inc_dt(tyyv, toyyv, etav, eyyv, _Gdt, dtr, a.dt) : dev_stress_inc(tyyv, toyyv, etav, eyyv, _Gdt, dtr);
+    const double dxy = SI ? dev_stress_inc_dt(txy, a.f.toxy[v], etav, a.f.dexy[v], _Gdt, dtr, a.dt) : dev_stress_inc(txy, a.f.toxy[v], etav, a.f.exy[v], _Gdt, dtr);
     const double tt[3] = {txxv + dxx, tyyv + dyy, txy + dxy};
     const double tIIv = sinv2(dxx + txxv, dyy + tyyv, dxy + txy);
     double dQdt[3], dQdP, dFdP;
@@ -711,10 +748,10 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
     const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
     const double F = yield_F<SOFT>(a.rh, rv, Pv, tIIv, EIIv);
     if (is_pl && tIIv != 0.0 && F > 0) {
-        const double l = fma(1.0 - a.rel, a.lamv[v], a.rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol)));
+        const double l = fma(1.0 - a.rel, a.lamv[v], a.rel * (fmax(F, 0.0) / (SI ? etav * dtr * a.dt + eta_reg + vol : etav * dtr + eta_reg + vol)));
         a.lamv[v] = l;
         const double epl = l * dQdt[2];
-        a.f.txy[v] = txy + fma(-2.0 * etav * epl, dtr, dxy);
+        a.f.txy[v] = txy + (SI ? fma(-2.0 * etav * a.dt * epl, dtr, dxy) : fma(-2.0 * etav * epl, dtr, dxy));
         a.f.eplxy[v] = epl;
     } else {
         a.f.txy[v] = txy + dxy;
@@ -727,31 +764,39 @@ __global__ __launch_bounds__(256) void k_vep_vertex(const VepArgs a)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / (a.nx + 1), i = t - j * (a.nx + 1);
     if (j > a.ny) return;
-    if (a.soft) vep_vertex_at<true>(a, i, j);
+    if (a.si) { if (a.soft) vep_vertex_at<true, true>(a, i, j); else vep_vertex_at<false, true>(a, i, j); }
+    else if (a.soft) vep_vertex_at<true>(a, i, j);
     else vep_vertex_at<false>(a, i, j);
 }
 
 // update_stresses_center_vertex_ps! -- centre half (+ Pr_c, τII, η_vep)
-template <bool SOFT>
+template <bool SOFT, bool SI = false>
 __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, const int j)
 {
     const int nx = a.nx, np = a.rh.nphase;
     const i64 c = i + (i64)nx * j;
     double *__restrict__ txx_o = a.txx_out ? a.txx_out : a.f.txx, *__restrict__ tyy_o = a.tyy_out ? a.tyy_out : a.f.tyy;
     const double *rc = a.f.phase_c + (i64)np * c;
-    const double _Gdt = 1.0 / (ratio_avg(a.rh.G, rc, np) * a.dt);
+    const double _Gdt = SI ? 1.0 / ratio_avg(a.rh.G, rc, np) : 1.0 / (ratio_avg(a.rh.G, rc, np) * a.dt);
     bool is_pl; double eta_reg;
     plastic_params(a.rh, rc, is_pl, eta_reg);
     const double K = ratio_avg(a.rh.Kb, rc, np);
     const double e = a.f.eta[c];
-    const double dtr = 1.0 / (a.theta_dtau + e * _Gdt + 1.0);
+    const double dtr = SI ? 1.0 / (a.theta_dtau * a.dt + e * _Gdt + a.dt) : 1.0 / (a.theta_dtau + e * _Gdt + 1.0);
     const double exyc = (V2(a.f.exy, i, j) + V2(a.f.exy, i + 1, j) + V2(a.f.exy, i, j + 1) + V2(a.f.exy, i + 1, j + 1)) / 4;
     const double eij[3] = {a.f.exx[c], a.f.eyy[c], exyc};
     double tij[3] = {a.f.txx[c], a.f.tyy[c], a.f.txy_c[c]};
     const double toij[3] = {a.f.toxx[c], a.f.toyy[c], a.f.toxy_c[c]};
     double d[3];
+    if (SI) {      // Δεij = (Δε.xx, Δε.yy, av_shear(Δε.xy)) -- cache_tensors, StressUpdate.jl:226-246
+        const double dexyc = (V2(a.f.dexy, i, j) + V2(a.f.dexy, i + 1, j) + V2(a.f.dexy, i, j + 1) + V2(a.f.dexy, i + 1, j + 1)) / 4;
+        const double deij[3] = {a.f.dexx[c], a.f.deyy[c], dexyc};
 #pragma unroll
-    for (int q = 0; q < 3; q++) d[q] = dev_stress_inc(tij[q], toij[q], e, eij[q], _Gdt, dtr);
+        for (int q = 0; q < 3; q++) d[q] = dev_stress_inc_dt(tij[q], toij[q], e, deij[q], _Gdt, dtr, a.dt);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; q++) d[q] = dev_stress_inc(tij[q], toij[q], e, eij[q], _Gdt, dtr);
+    }
     double tII = sinv2(d[0] + tij[0], d[1] + tij[1], d[2] + tij[2]);
     const double tt[3] = {tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]};
     double dQdt[3], dQdP, dFdP;
@@ -761,11 +806,15 @@ __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, con
     const double F = yield_F<SOFT>(a.rh, rc, Pr, tII, SOFT ? a.f.EII_pl[c] : 0.0);
     double l = a.lam[c];
     if (is_pl && tII != 0.0 && F > 0) {
-        l = fma(1.0 - a.rel, l, a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol)));
+        l = fma(1.0 - a.rel, l, a.rel * (fmax(F, 0.0) / (SI ? e * dtr * a.dt + eta_reg + vol : e * dtr + eta_reg + vol)));
         a.lam[c] = l;
         double epl[3];
 #pragma unroll
-        for (int q = 0; q < 3; q++) { epl[q] = l * dQdt[q]; d[q] = fma(-2.0 * e * epl[q], dtr, d[q]); tij[q] = d[q] + tij[q]; }
+        for (int q = 0; q < 3; q++) {
+            epl[q] = l * dQdt[q];
+            d[q] = SI ? fma(-2.0 * e * a.dt * epl[q], dtr, d[q]) : fma(-2.0 * e * epl[q], dtr, d[q]);
+            tij[q] = d[q] + tij[q];
+        }
         a.f.evol_pl[c] = -l * dQdP;
         txx_o[c] = tij[0]; tyy_o[c] = tij[1]; a.f.txy_c[c] = tij[2];
         a.f.eplxx[c] = epl[0]; a.f.eplyy[c] = epl[1];
@@ -784,19 +833,20 @@ __global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / a.nx, i = t - j * a.nx;
     if (j >= a.ny) return;
-    if (a.soft) vep_centre_at<true>(a, i, j);
+    if (a.si) { if (a.soft) vep_centre_at<true, true>(a, i, j); else vep_centre_at<false, true>(a, i, j); }
+    else if (a.soft) vep_centre_at<true>(a, i, j);
     else vep_centre_at<false>(a, i, j);
 }
 // both halves in one launch: the vertex half averages the OLD centre stresses, so the centre half must write τxx, τyy elsewhere
 // (a.txx_out / a.tyy_out; the caller then swaps the pointers)
-template <bool SOFT>
+template <bool SOFT, bool SI = false>
 __global__ __launch_bounds__(256) void k_vep_stress2d(const VepArgs a)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / (a.nx + 1), i = t - j * (a.nx + 1);
     if (j > a.ny) return;
-    vep_vertex_at<SOFT>(a, i, j);
-    if (i < a.nx && j < a.ny) vep_centre_at<SOFT>(a, i, j);
+    vep_vertex_at<SOFT, SI>(a, i, j);
+    if (i < a.nx && j < a.ny) vep_centre_at<SOFT, SI>(a, i, j);
 }
 
 // compute_τ_nonlinear! 2D: single phase (StressKernels.jl:266-307) / phases at the cell centres (:310-351) with
@@ -1023,6 +1073,8 @@ jrx_status check_vep(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheolog
                          f->EVol_pl, f->fx, f->fy, f->RP, f->Rx, f->Ry, f->phase_c, f->phase_v};
     for (const void *q : req)
         if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required VEP field pointer is NULL");
+    if (p->strain_increment && (!f->dexx || !f->deyy || !f->dexy || !f->divU))
+        return jrx_fail(h, JRX_ERR_ARG, "strain_increment: the Δε (xx, yy, xy) and ∇U arrays are required");
     return JRX_OK;
 }
 
@@ -1035,6 +1087,7 @@ VepArgs make_vep(const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_ve
     a.nu = p->viscosity_relaxation; a.cut_lo = p->cutoff_lo; a.cut_hi = p->cutoff_hi;
     a.nx = (int)p->nx; a.ny = (int)p->ny;
     a.soft = mat_has_softening(rh);
+    a.si = p->strain_increment != 0;
     return a;
 }
 
@@ -1228,8 +1281,15 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
         } else if (upd_rho) hipLaunchKernelGGL((k_vep_pre<true, true>), dim3(gv), dim3(256), 0, s, a, theta);
         else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, a, theta);      // compute_maxloc! folded in
         JRX_LAUNCH_CHECK(h);
+        if (a.si) {
+            hipLaunchKernelGGL(k_vep_strain_inc, dim3(gv), dim3(256), 0, s, a);
+            JRX_LAUNCH_CHECK(h);
+        }
         // update_stresses_center_vertex_ps!: vertex and centre halves in one launch; the new τxx, τyy go to the other set, then swap
-        if (a.soft) hipLaunchKernelGGL(k_vep_stress2d<true>, dim3(gv), dim3(256), 0, s, a);
+        if (a.si) {
+            if (a.soft) hipLaunchKernelGGL((k_vep_stress2d<true, true>), dim3(gv), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_vep_stress2d<false, true>), dim3(gv), dim3(256), 0, s, a);
+        } else if (a.soft) hipLaunchKernelGGL(k_vep_stress2d<true>, dim3(gv), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_vep_stress2d<false>, dim3(gv), dim3(256), 0, s, a);
         JRX_LAUNCH_CHECK(h);
         { double *t_ = a.f.txx; a.f.txx = a.txx_out; a.txx_out = t_; }
@@ -1241,7 +1301,8 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
         }
         // flow_bcs! applied in full by iteration 1: refresh ghosts in-kernel (never with DisplacementBoundaryConditions: flow_bcs! then acts on U)
-        const bool bcf = iter >= 1 && p->periodic == 0 && !comm && !ubc;
+        // (nor with strain_increment: U = V dt must copy the ghosts of V as the previous flow_bcs! left them)
+        const bool bcf = iter >= 1 && p->periodic == 0 && !comm && !ubc && !a.si;
         bool used_bcf = false;
         {
             const bool next_check = ((iter + 1) % p->nout == 0) && iter + 1 > 1;
@@ -1256,13 +1317,13 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
         const bool check = (iter % p->nout == 0) && iter > 1;
         // the loop can stop after this iteration if it is a check, the last allowed one, or already converged
         const bool last = check || iter > p->iterMax || (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs));
-        if (last) {   // U = V*dt is only observable after an iteration the loop can stop at
+        if (last || a.si) {   // U = V*dt is only observable after an iteration the loop can stop at -- or every iteration when the strains are taken from U
             hipLaunchKernelGGL(k_scale3, dim3(256), dim3(256), 0, s, f->Ux, (const double *)f->Vx, (i64)(nx + 1) * (ny + 2), f->Uy,
                                (const double *)f->Vy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, p->dt);
             JRX_LAUNCH_CHECK(h);
         }
         if (ubc) {    // flow_bcs!(stokes, ::DisplacementBoundaryConditions) acts on U = V dt, which the next iteration overwrites: only the last one is observable
-            if (last) JRX_TRY(launch_bcs2(h, s, f->Ux, f->Uy, nx, ny, p->free_slip, p->no_slip, p->periodic));
+            if (last || a.si) JRX_TRY(launch_bcs2(h, s, f->Ux, f->Uy, nx, ny, p->free_slip, p->no_slip, p->periodic));
         } else if (!used_bcf) JRX_TRY(launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic));
         if (comm) {   // update_halo!(@velocity(stokes)...) (Stokes2D.jl:784)
             double *arrs[2] = {f->Vx, f->Vy};

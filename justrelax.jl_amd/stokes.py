@@ -213,7 +213,7 @@ def _args_T(args):
     return args.get("T") if isinstance(args, dict) else getattr(args, "T", None)
 
 
-def vep_fields2d(stokes, ρg, phase_ratios, args=None, allow_ghosted_T=False) -> _lib.VEP2DFields:
+def vep_fields2d(stokes, ρg, phase_ratios, args=None, allow_ghosted_T=False, strain_increment=False) -> _lib.VEP2DFields:
     s = stokes
     vals = dict(P=s.P, P0=s.P0, divV=s.divV, Q=s.Q, Vx=s.V.Vx, Vy=s.V.Vy, Ux=s.U.Ux, Uy=s.U.Uy,
                 exx=s.ε.xx, eyy=s.ε.yy, exy=s.ε.xy, exy_c=s.ε.xy_c,
@@ -223,6 +223,8 @@ def vep_fields2d(stokes, ρg, phase_ratios, args=None, allow_ghosted_T=False) ->
                 eta=s.viscosity.η, eta_v=s.viscosity.ηv, eta_vep=s.viscosity.η_vep,
                 EII_pl=s.EII_pl, evol_pl=s.ε_vol_pl, EVol_pl=s.EVol_pl, fx=ρg[0], fy=ρg[1], RP=s.R.RP, Rx=s.R.Rx, Ry=s.R.Ry,
                 omega_xy=s.ω.xy, phase_c=phase_ratios.center, phase_v=phase_ratios.vertex, T=_args_T(args))
+    if strain_increment:      # Δε.xx, Δε.yy and ∇U are allocated on first use
+        vals.update(dexx=s.Δε.xx, deyy=s.Δε.yy, divU=getattr(s, "∇U"))      # "∇" is not a Python identifier character
     if vals["T"] is not None and tuple(vals["T"].shape) != tuple(s._ni) and not allow_ghosted_T:
         raise ValueError(f"args.T must be cell-centred {tuple(s._ni)} (thermal.Tc), got {tuple(vals['T'].shape)}")
     f = _lib.VEP2DFields()
@@ -235,8 +237,6 @@ def vep_fields2d(stokes, ρg, phase_ratios, args=None, allow_ghosted_T=False) ->
 def vep_params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=50.0e3, iterMin=1.0e2, nout=500, verbose=True, λ_relaxation=0.2,
                  viscosity_relaxation=1.0e-2, viscosity_cutoff=(-float("inf"), float("inf")), strain_increment=False,
                  free_surface=False, **_):
-    if strain_increment:
-        raise NotImplementedError("the strain_increment variant of the VEP driver is not built (SURVEY §8f)")
     ni = stokes._ni
     _di = _center_inv(grid)
     p = _lib.VEP2DParams()
@@ -252,15 +252,18 @@ def vep_params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=50.0e3, iterMin=1.0e
     p.verbose = int(bool(verbose))
     p.free_surface = int(bool(free_surface))
     p.displacement_bcs = int(_is_displacement(flow_bcs))
+    p.strain_increment = int(bool(strain_increment))
     return p
 
 
 def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h):
     """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs) -- Stokes2D.jl:577-866"""
     if len(stokes._ni) == 3:
+        if kw.get("strain_increment"):
+            raise NotImplementedError("the reference's 3D VEP driver has no strain_increment variant (Stokes3D.jl:447-668)")
         return _solve_vep3d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h)
     p = vep_params2d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
-    f = vep_fields2d(stokes, ρg, phase_ratios, args)
+    f = vep_fields2d(stokes, ρg, phase_ratios, args, strain_increment=bool(p.strain_increment))
     rh = rheology_table(rheology)
     hist = _Hist(int(p.iterMax // p.nout + 2))
     torch.cuda.current_stream(stokes.P.device).synchronize()

@@ -22,6 +22,11 @@ static inline double compute_dtau_r(double theta_dtau, double eta, double _Gdt)
     return inv(theta_dtau + fma(eta, _Gdt, 1.0));
 }
 /* src/stokes/StressKernels.jl:2-5 */
+/* compute_stress_increment(τ, τ_o, η, Δε, _G, dτ_r, dt) -- StressKernels.jl:18-21 (strain-increment form) */
+static inline double stress_increment_dt(double t, double to, double eta, double de, double _G, double dtau_r, double dt)
+{
+    return dtau_r * fma(2.0 * eta, de, fma(-(t - to) * eta, _G, -t * dt));
+}
 static inline double stress_increment(double t, double to, double eta, double e, double _Gdt, double dtau_r)
 {
     return dtau_r * fma(2.0 * eta, e, fma(-(t - to) * eta, _Gdt, -t));

@@ -256,6 +256,7 @@ typedef struct orc_vep2d {
     double *omega_xy;                       /* ni.+1 */
     double *phase_c, *phase_v;              /* [nphase][nx][ny] and [nphase][nx+1][ny+1], phase index fastest (CellArray) */
     const double *T;                        /* args.T at the cell centres (ni) for the density laws; may be NULL (T = 0) */
+    double *dexx, *deyy, *divU;             /* strain_increment variant: Δε.xx, Δε.yy (ni), stokes.∇U (ni); may be NULL otherwise */
 } orc_vep2d;
 
 typedef struct orc_vep_params2d {
@@ -269,6 +270,7 @@ typedef struct orc_vep_params2d {
     int32_t free_surface;                         /* kwarg free_surface: compute_V! / compute_Res! get dt * free_surface (Stokes2D.jl:773,797) */
     int32_t displacement_bcs;                     /* flow_bcs is a DisplacementBoundaryConditions: V = U / dt first, flow_bcs! acts on U (BoundaryConditions.jl:71-78) */
     int32_t T_ghosted;                            /* single-phase driver: args.T is thermal.T (nx+2, ny+2), indexed as the reference does */
+    int32_t strain_increment;                     /* kwarg strain_increment (Stokes2D.jl:588,659-734): strains from the displacement increments, Δε form of the stress update */
 } orc_vep_params2d;
 
 int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res);

@@ -352,7 +352,7 @@ def num_threads() -> int:
 # ---------------------------------------------------------------- 2D multiphase VEP (shear band)
 VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
              "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
-             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v", "T"]
+             "EII_pl", "evol_pl", "EVol_pl", "fx", "fy", "RP", "Rx", "Ry", "omega_xy", "phase_c", "phase_v", "T", "dexx", "deyy", "divU"]
 VEP2D = _mkstruct("VEP2D", VEP_NAMES)
 MAXPHASE = 8
 
@@ -374,7 +374,8 @@ class VEPParams2D(C.Structure):
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("iterMin", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
-                ("staggered_invariant_mean_of_squares", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32)]
+                ("staggered_invariant_mean_of_squares", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32),
+                ("strain_increment", C.c_int32)]
 
 
 def vep_shapes2d(nx, ny, nphase):
@@ -436,11 +437,12 @@ def rheology_struct(phases: list) -> Rheology:
 
 def vep_params2d(ni, _di, dt, pt, *, iterMax=50_000, iterMin=100, nout=500, free_slip=None, no_slip=None, periodic=None,
                  lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), stag_mode=0, ni_g=None, free_surface=False,
-                 displacement_bcs=False, T_ghosted=False) -> VEPParams2D:
+                 displacement_bcs=False, T_ghosted=False, strain_increment=False) -> VEPParams2D:
     ni_g = ni_g or ni
     return VEPParams2D(ni[0], ni[1], ni_g[0], ni_g[1], _di[0], _di[1], dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"], pt["eps_rel"],
                        pt["eps_abs"], int(iterMax), int(iterMin), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic),
-                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1], stag_mode, int(bool(free_surface)), int(bool(displacement_bcs)), int(bool(T_ghosted)))
+                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1], stag_mode, int(bool(free_surface)), int(bool(displacement_bcs)), int(bool(T_ghosted)),
+                       int(bool(strain_increment)))
 
 
 def vep2d(arr: dict) -> VEP2D:

@@ -89,6 +89,9 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
     const int64_t nx = p->nx, ny = p->ny;
     const int np = rh->nphase;
     const double dt = p->dt, th = p->theta_dtau, rel = p->lambda_relaxation;
+    /* strain_increment variant (StressKernels.jl:1147-1302): the increments Δε replace ε in the stress increment, which is written in its dt-multiplied
+     * form (compute_stress_increment(τ, τ_o, η, Δε, _G, dτ_r, dt) :18-21, dτ_r = inv(θ_dτ dt + η _G + dt)); plastic terms carry the factor dt */
+    const int si = p->strain_increment != 0;
     /* vertex pass */
 #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < ny + 1; j++)
@@ -100,15 +103,24 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
             const double *rv = f->phase_v + (size_t)np * IDX2(nx + 1, i, j);
             int is_pl; double eta_reg;
             plastic_params(rh, rv, &is_pl, &eta_reg);
-            const double _Gdt = inv(ratio_avg(rh->G, rv, np) * dt);
+            const double _Gdt = si ? inv(ratio_avg(rh->G, rv, np)) : inv(ratio_avg(rh->G, rv, np) * dt);      /* si: _Gv */
             const double Kv = ratio_avg(rh->Kb, rv, np);
             const double etav = 4.0 / (1.0 / C2(f->eta, i0, j0) + 1.0 / C2(f->eta, ic, jc) + 1.0 / C2(f->eta, i0, jc) + 1.0 / C2(f->eta, ic, j0));
-            const double dtr = inv(th + etav * _Gdt + 1.0);
+            const double dtr = si ? inv(th * dt + etav * _Gdt + dt) : inv(th + etav * _Gdt + 1.0);
             const size_t v = IDX2(nx + 1, i, j);
             const double txy = f->txy[v];
-            const double dxx = stress_increment(txxv, toxxv, etav, exxv, _Gdt, dtr);
-            const double dyy = stress_increment(tyyv, toyyv, etav, eyyv, _Gdt, dtr);
-            const double dxy = stress_increment(txy, f->toxy[v], etav, f->exy[v], _Gdt, dtr);
+            double dxx, dyy, dxy;
+            if (si) {
+                const double dexxv = AVC(f->dexx), deyyv = AVC(f->deyy);
+                dxx = stress_increment_dt(txxv, toxxv, etav, dexxv, _Gdt, dtr, dt);
+                dyy = stress_increment_dt(tyyv, toyyv, etav, deyyv, _Gdt, dtr, dt);
+                dxy = stress_increment_dt(txy, f->toxy[v], etav, f->dexy[v], _Gdt, dtr, dt);
+                (void)exxv; (void)eyyv;
+            } else {
+                dxx = stress_increment(txxv, toxxv, etav, exxv, _Gdt, dtr);
+                dyy = stress_increment(tyyv, toyyv, etav, eyyv, _Gdt, dtr);
+                dxy = stress_increment(txy, f->toxy[v], etav, f->exy[v], _Gdt, dtr);
+            }
             const double tt[3] = {txxv + dxx, tyyv + dyy, txy + dxy};
             const double tIIv = sinv2(dxx + txxv, dyy + tyyv, dxy + txy);
             double dQdt[3], dQdP, dFdP;
@@ -117,9 +129,9 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
             const double EIIv = AVC(f->EII_pl);                        /* EIIv_ij = av_clamped(EII, Ic...) :1030 */
             const double F = yield_F(rh, rv, Pv, tIIv, EIIv);
             if (is_pl && tIIv != 0.0 && F > 0) {
-                lamv[v] = fma(1.0 - rel, lamv[v], rel * (fmax(F, 0.0) / (etav * dtr + eta_reg + vol)));
+                lamv[v] = fma(1.0 - rel, lamv[v], rel * (fmax(F, 0.0) / (si ? etav * dtr * dt + eta_reg + vol : etav * dtr + eta_reg + vol)));
                 const double epl = lamv[v] * dQdt[2];
-                f->txy[v] = txy + fma(-2.0 * etav * epl, dtr, dxy);
+                f->txy[v] = txy + (si ? fma(-2.0 * etav * dt * epl, dtr, dxy) : fma(-2.0 * etav * epl, dtr, dxy));
                 f->eplxy[v] = epl;
             } else {
                 f->txy[v] = txy + dxy;
@@ -132,18 +144,23 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
         for (int64_t i = 0; i < nx; i++) {
             const size_t c = IDX2(nx, i, j);
             const double *rc = f->phase_c + (size_t)np * c;
-            const double _Gdt = inv(ratio_avg(rh->G, rc, np) * dt);
+            const double _Gdt = si ? inv(ratio_avg(rh->G, rc, np)) : inv(ratio_avg(rh->G, rc, np) * dt);
             int is_pl; double eta_reg;
             plastic_params(rh, rc, &is_pl, &eta_reg);
             const double K = ratio_avg(rh->Kb, rc, np);
             const double e = f->eta[c];
-            const double dtr = 1.0 / (th + e * _Gdt + 1.0);
+            const double dtr = si ? 1.0 / (th * dt + e * _Gdt + dt) : 1.0 / (th + e * _Gdt + 1.0);
             const double exyc = (V2(f->exy, i, j) + V2(f->exy, i + 1, j) + V2(f->exy, i, j + 1) + V2(f->exy, i + 1, j + 1)) / 4;   /* cache_tensors :208-222 */
             const double eij[3] = {f->exx[c], f->eyy[c], exyc};
             double tij[3] = {f->txx[c], f->tyy[c], f->txy_c[c]};
             const double toij[3] = {f->toxx[c], f->toyy[c], f->toxy_c[c]};
             double d[3];
-            for (int q = 0; q < 3; q++) d[q] = stress_increment(tij[q], toij[q], e, eij[q], _Gdt, dtr);
+            if (si) {      /* Δεij = (Δε.xx, Δε.yy, av_shear(Δε.xy)) -- cache_tensors :226-246 */
+                const double dexyc = (V2(f->dexy, i, j) + V2(f->dexy, i + 1, j) + V2(f->dexy, i, j + 1) + V2(f->dexy, i + 1, j + 1)) / 4;
+                const double deij[3] = {f->dexx[c], f->deyy[c], dexyc};
+                for (int q = 0; q < 3; q++) d[q] = stress_increment_dt(tij[q], toij[q], e, deij[q], _Gdt, dtr, dt);
+            } else
+                for (int q = 0; q < 3; q++) d[q] = stress_increment(tij[q], toij[q], e, eij[q], _Gdt, dtr);
             double tII = sinv2(d[0] + tij[0], d[1] + tij[1], d[2] + tij[2]);
             const double tt[3] = {tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]};
             double dQdt[3], dQdP, dFdP;
@@ -152,9 +169,13 @@ void orc_vep2d_stress(const orc_vep2d *f, const double *theta, double *lam, doub
             const double Pr = theta[c];
             const double F = yield_F(rh, rc, Pr, tII, f->EII_pl[c]);
             if (is_pl && tII != 0.0 && F > 0) {
-                lam[c] = fma(1.0 - rel, lam[c], rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol)));
+                lam[c] = fma(1.0 - rel, lam[c], rel * (fmax(F, 0.0) / (si ? e * dtr * dt + eta_reg + vol : e * dtr + eta_reg + vol)));
                 double epl[3];
-                for (int q = 0; q < 3; q++) { epl[q] = lam[c] * dQdt[q]; d[q] = fma(-2.0 * e * epl[q], dtr, d[q]); tij[q] = d[q] + tij[q]; }
+                for (int q = 0; q < 3; q++) {
+                    epl[q] = lam[c] * dQdt[q];
+                    d[q] = si ? fma(-2.0 * e * dt * epl[q], dtr, d[q]) : fma(-2.0 * e * epl[q], dtr, d[q]);
+                    tij[q] = d[q] + tij[q];
+                }
                 f->evol_pl[c] = -lam[c] * dQdP;
                 f->txx[c] = tij[0]; f->tyy[c] = tij[1]; f->txy_c[c] = tij[2];
                 f->eplxx[c] = epl[0]; f->eplyy[c] = epl[1];
@@ -357,7 +378,16 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
         orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :663-676 */
         if (upd_rho)                                    /* update_ρg!(ρg, phase_ratios, rheology, args) :678 ; args.P is stokes.P */
             for (size_t c = 0; c < n; c++) f->fy[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
-        orc_compute_strain_rate2d(&g, &q);
+        if (p->strain_increment) {
+            /* ∇U, Δε from the displacements (:659-661, :680-688), then ε = Δε * _dt (compute_strain_rate_from_increment!, VelocityKernels.jl:46-57) */
+            orc_fields2d gu = g;
+            gu.Vx = f->Ux; gu.Vy = f->Uy; gu.divV = f->divU; gu.exx = f->dexx; gu.eyy = f->deyy; gu.exy = f->dexy;
+            orc_compute_divV2d(f->divU, f->Ux, f->Uy, nx, ny, p->_dx, p->_dy);
+            orc_compute_strain_rate2d(&gu, &q);
+            const double _dt = inv(p->dt);
+            for (size_t c = 0; c < n; c++) { f->exx[c] = f->dexx[c] * _dt; f->eyy[c] = f->deyy[c] * _dt; }
+            for (size_t v = 0; v < nv; v++) f->exy[v] = f->dexy[v] * _dt;
+        } else orc_compute_strain_rate2d(&g, &q);
         orc_vep2d_stress(f, theta, lam, lamv, rh, p);
         { const int64_t e[3] = {nx + 1, ny + 1, 1}, nn[3] = {nx, ny, 1}; orc_self_halo(f->txy, e, nn); }    /* update_halo!(τ.xy) :757 */
         orc_compute_viscosity2d(f, rh, p, p->viscosity_relaxation);

@@ -3,6 +3,7 @@
   * strain softening of C and ϕ at EII_pl (rheology/StressUpdate.jl:305-381; the EII keyword of StressKernels.jl:1053-1105)
   * DisplacementBoundaryConditions (displacement2velocity! at the start, flow_bcs! on U; BoundaryConditions.jl:71-78)
   * the free_surface form of compute_V! / compute_Res! (VelocityKernels.jl:134-180,271-307)
+  * the strain_increment variant of the 2D VEP driver (Stokes2D.jl:659-734; StressKernels.jl:1147-1302)
 The GeoParams forms behind density and softening are ASSUMED (include/jrx.h): these tests pin HIP path == oracle, not the formulas.
 Tolerance 1e-9 after tens of iterations (exp / erfc / sin of the device library differ from glibc in the last bits)."""
 import ctypes as C
@@ -221,3 +222,44 @@ def test_visco_elastic_drivers_with_displacement_bcs_match_oracle(jr, oracle, nd
     assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-10)
     d = checks.compare_stokes(download_stokes(stokes), ref)
     assert max(d.values()) <= 1e-9, d
+
+
+@pytest.mark.parametrize("displacement,soft", [(False, False), (True, False), (True, True)])
+def test_vep2d_strain_increment_matches_oracle(jr, oracle, displacement, soft):
+    """strain_increment = true: ∇U / Δε from U = V dt every iteration, Δε form of update_stresses_center_vertex_ps!, flow_bcs! on U or V as the
+    boundary-condition type says; yielding state (pre-stress near yield), dt not a power of two"""
+    from justrelax_jl_amd.arrays import DisplacementBoundaryConditions
+    from justrelax_jl_amd.checks import max_rel_diff
+    from test_gpu_vep2d import _download, _upload, _vep_params
+    s = jr.miniapps.shearband2d(24, iterMax=45, nout=15)
+    s.kwargs.update(iterMin=10, strain_increment=True)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    s.dt = 0.3
+    rng = np.random.default_rng(8)
+    for c in ("xx", "yy", "xy", "xy_c"):
+        s.arrays["to" + c][...] = rng.uniform(-1.2, 1.2, size=s.arrays["to" + c].shape)
+        s.arrays["t" + c][...] = s.arrays["to" + c]
+    s.arrays["EII_pl"][...] = rng.uniform(0, 0.2, size=s.ni)
+    s.arrays["Ux"][...] = s.arrays["Vx"] * s.dt
+    s.arrays["Uy"][...] = s.arrays["Vy"] * s.dt
+    for k in ("dexx", "deyy", "divU"):
+        s.arrays[k] = np.zeros(s.ni, order="F")
+    phases = _phases_soft(s.extra["phases"]) if soft else s.extra["phases"]
+    b = s.flow_bcs
+    bcs = DisplacementBoundaryConditions(free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic) if displacement else b
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes2d_vep_solve(ref, oracle.rheology_struct(phases), _vep_params(oracle, s, iterMin=10, strain_increment=True, displacement_bcs=displacement))
+    stokes, pr, ρg = _upload(jr, s)
+    r = jr.solve_(stokes, s.pt, s.grid, bcs, ρg, pr, phases, None, s.dt, None, kwargs=s.kwargs)
+    assert r.iter == r_ref["iter"] == 46
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-9)
+    assert (ref["eplxx"] != 0).any() and np.abs(ref["dexx"]).max() > 0
+    out = _download(jr, stokes)
+    for k in out:
+        assert max_rel_diff(out[k], ref[k]) <= 1e-9, k
+    for k, t in (("dexx", stokes.Δε.xx), ("deyy", stokes.Δε.yy), ("divU", getattr(stokes, "∇U"))):
+        assert max_rel_diff(jr.to_numpy(t), ref[k]) <= 1e-9, k
+    # and it is not the plain variant in disguise: the same call without the flag gives different stresses
+    ref0 = _cp(s.arrays)
+    oracle.stokes2d_vep_solve(ref0, oracle.rheology_struct(phases), _vep_params(oracle, s, iterMin=10, displacement_bcs=displacement))
+    assert np.abs(ref0["txx"] - ref["txx"]).max() > 1e-12

@@ -382,3 +382,37 @@ def test_thermal_phase_helpers_known_answers(oracle):
         Re = math.pi + math.sqrt(math.pi ** 2 + rcp * L * L / k / dt)
         assert arr["thetar_dtau"][i, j] == pytest.approx(L / Vp / Re, rel=1e-14)
         assert arr["dtau_rho"][i, j] == pytest.approx(Vp * L / k / Re, rel=1e-14)
+
+
+@pytest.mark.parametrize("displacement", [False, True])
+def test_shearband2d_strain_increment_variant(oracle, jr, displacement):
+    """kwargs strain_increment = true (Stokes2D.jl:659-734, StressKernels.jl:1147-1302; used by miniapps/…/ShearBand2D_strain_increment.jl, no reference
+    test): the same equations multiplied by dt, so the run must land on the numbers test_shearband2D.jl pins for the plain variant.  With
+    DisplacementBoundaryConditions (flow_bcs! refreshes the ghosts of U, from which the strains are taken) and dt a power of two (0.25 here) every
+    scaled operation is exact, and the run agrees bit for bit with the plain variant under VelocityBoundaryConditions."""
+    s = jr.miniapps.shearband2d(32)
+    assert s.dt == 0.25
+    rh = oracle.rheology_struct(s.extra["phases"])
+    for k in ("dexx", "deyy", "divU"):
+        s.arrays[k] = np.zeros(s.ni, order="F")
+    s.arrays["Ux"][...] = s.arrays["Vx"] * s.dt
+    s.arrays["Uy"][...] = s.arrays["Vy"] * s.dt
+    plain = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    p = _vep_params(oracle, s, strain_increment=True, displacement_bcs=displacement)
+    p0 = _vep_params(oracle, s)
+    for _ in range(10):
+        r = oracle.stokes2d_vep_solve(s.arrays, rh, p)
+        r0 = oracle.stokes2d_vep_solve(plain, rh, p0)
+    g = KA["shearband2D"]
+    assert r["err_evo1"][-1] < g["err_max"]
+    II = oracle.tensor_invariant2d(s.arrays["txx"], s.arrays["tyy"], s.arrays["txy"], 1)
+    assert II.min() == pytest.approx(g["tauII_min"], abs=g["tauII_extrema_atol"])
+    assert II.max() == pytest.approx(g["tauII_max"], abs=g["tauII_extrema_atol"])
+    assert s.arrays["txx"].max() == pytest.approx(g["max_txx_last"], abs=g["max_txx_last_atol"])
+    assert np.abs(s.arrays["dexx"]).max() > 0 and np.allclose(s.arrays["exx"], s.arrays["dexx"] / s.dt, rtol=0, atol=0)
+    if displacement:
+        assert r["iter"] == r0["iter"]
+        for k in ("txx", "tyy", "txy", "P", "EII_pl", "tII", "eplxx"):      # V, U differ only in ghost entries that one of the two never refreshes
+            assert np.array_equal(s.arrays[k], plain[k]), k
+    else:       # velocity BCs: the ghosts of U lag those of V by one iteration, the converged fields agree to the solver tolerance
+        assert np.abs(s.arrays["txx"] - plain["txx"]).max() < 1e-5
