@@ -11,6 +11,14 @@ jr = load_package()
 from justrelax_jl_amd import _lib
 
 if __name__ == "__main__":
+    # usage: bench2d.py [solcx|shearband|thermal ...] [KEY=INT ...]   (library options; default: all three configs)
+    import ctypes as C
     h = _lib.default_handle(0)
-    for fn in (bench.cfg_solcx, bench.cfg_shearband, bench.cfg_thermal2d):
-        print(json.dumps(fn(jr, h)), flush=True)
+    table = dict(solcx=bench.cfg_solcx, shearband=bench.cfg_shearband, thermal=bench.cfg_thermal2d)
+    names = [a for a in sys.argv[1:] if "=" not in a] or list(table)
+    for kv in (a for a in sys.argv[1:] if "=" in a):
+        k, v = kv.split("=")
+        h.call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(int(v)))
+        print(f"# option {k} = {v}", flush=True)
+    for n in names:
+        print(json.dumps(table[n](jr, h)), flush=True)
