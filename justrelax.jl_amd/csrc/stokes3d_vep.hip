@@ -517,7 +517,6 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             Pv[T] = 0.25 * S[1][T];
             dtr[T] = 1.0 / (a.theta_dtau + etav[T] * m[T]._Gdt + 1.0);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             sums(2 + 3 * c, S[0]);
@@ -529,8 +528,7 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
                 const double t = 0.25 * S[1][T];
                 tt[T][c] = t + dev_stress_inc(t, 0.25 * S[2][T], etav[T], 0.25 * S[0][T], m[T]._Gdt, dtr[T]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            }
         // shear components: yz, xz at planes clamp(k) (carried) and clamp(k+1) (loaded here); xy at clamp(k-1) (carried) and clamp(k)
         double Yc[3][2], Xc[3][2], Zq[3][2];
 #pragma unroll
@@ -540,7 +538,6 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             Xn[q][0] = LB(Xp[q], ox0 + px * k2); Xn[q][1] = LB(Xp[q], ox1 + px * k2);
             Zc[q][0] = LB(Zp[q], oz1 + pz * k1); Zc[q][1] = LB(Zp[q], oz2 + pz * k1);
         }
-        __builtin_amdgcn_sched_barrier(0);
         double own_t[3], own_d[3];
         auto trial = [&](int T, const double o[3]) { return o[1] + dev_stress_inc(o[1], o[2], etav[T], o[0], m[T]._Gdt, dtr[T]); };
         if constexpr ((FAM & 1) != 0) {   // yz edge: own (i, j, k); xz at (i, i+1) x (j-1, j); xy at (i, i+1) x planes (k-1, k)
@@ -556,7 +553,6 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             own_d[0] = dev_stress_inc(own[1], own[2], etav[0], own[0], m[0]._Gdt, dtr[0]);
             tt[0][3] = own_t[0] + own_d[0]; tt[0][4] = trial(0, ox); tt[0][5] = trial(0, oz);
         }
-        __builtin_amdgcn_sched_barrier(0);
         if constexpr ((FAM & 2) != 0) {   // xz edge: own (i, j, k); yz at (i-1, i) x (j, j+1); xy at (j, j+1) x planes (k-1, k)
             double own[3], oy[3], oz[3];
 #pragma unroll
@@ -570,7 +566,6 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             own_d[1] = dev_stress_inc(own[1], own[2], etav[1], own[0], m[1]._Gdt, dtr[1]);
             tt[1][3] = trial(1, oy); tt[1][4] = own_t[1] + own_d[1]; tt[1][5] = trial(1, oz);
         }
-        __builtin_amdgcn_sched_barrier(0);
         if constexpr ((FAM & 4) != 0) {   // xy edge: own (i, j, k); yz at (i-1, i) x planes (k, k+1); xz at (j-1, j) x planes (k, k+1)
             double own[3], oy[3], ox[3];
 #pragma unroll
@@ -584,11 +579,8 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             own_d[2] = dev_stress_inc(own[1], own[2], etav[2], own[0], m[2]._Gdt, dtr[2]);
             tt[2][3] = trial(2, oy); tt[2][4] = trial(2, ox); tt[2][5] = own_t[2] + own_d[2];
         }
-        __builtin_amdgcn_sched_barrier(0);
         if constexpr ((FAM & 1) != 0) if (act0) vep3_edge_plastic<0, false, NP>(a, vi[0], rv[0], m[0], tt[0], own_t[0], own_d[0], etav[0], Pv[0], dtr[0], 0.0);
-        __builtin_amdgcn_sched_barrier(0);
         if constexpr ((FAM & 2) != 0) if (act1) vep3_edge_plastic<1, false, NP>(a, vi[1], rv[1], m[1], tt[1], own_t[1], own_d[1], etav[1], Pv[1], dtr[1], 0.0);
-        __builtin_amdgcn_sched_barrier(0);
         if constexpr ((FAM & 4) != 0) if (act2) vep3_edge_plastic<2, false, NP>(a, vi[2], rv[2], m[2], tt[2], own_t[2], own_d[2], etav[2], Pv[2], dtr[2], 0.0);
     }
 }
@@ -788,7 +780,7 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
     if (!a.soft && h->vep3_edges >= 1 && a.rh.nphase <= 4) {
         // option "vep3_edges": 0 one node per thread (k_vep3_edges; also the form softening laws and more than 4 phases use), 1 (default) the z-marching
         // kernel with one family per block and the three blocks of a tile on one XCD, 2 the same kernel as one launch per family (A/B: the L2 sharing)
-        const int cfg = h->vep3_cfg ? h->vep3_cfg : 163;           // option "vep3_cfg" = KZ * 10 + min blocks per CU (tuning)
+        const int cfg = h->vep3_cfg ? h->vep3_cfg : 162;           // option "vep3_cfg" = KZ * 10 + min blocks per CU (tuning)
         const int kz = cfg / 10, mb = cfg % 10, np_ = a.rh.nphase;
         const int nseg = (nx + 1 + 61) / 62, ntxy = nseg * ((ny + 1 + 3) / 4), nzc = (nz + 1 + kz - 1) / kz, nt = ntxy * nzc;
         bool ok = false;
