@@ -442,9 +442,10 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
 // ------------------------------------------------------------------------------------------------
 // FAM: bit T set = family T (0 yz, 1 xz, 2 xy) is updated by this launch; what the other families alone need (loads, lane exchanges, carried
 // sums) is dead code then
-template <int KZ, int NP, int FAM>
+template <int KZ, int NP, int FAM, bool SOFT = false>
 __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int seg, const int j, const int zchunk)
 {
+    constexpr int NC = SOFT ? 12 : 11;          // centre arrays averaged to the edges; softening laws add EII_pl (StressKernels.jl:710,783,854)
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP;
     const int lane = threadIdx.x & 63;
     if (j > ny) return;                                  // whole waves; the kernel has no barrier
@@ -457,7 +458,7 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
     auto up = [&](double v) { const double u = __shfl_up(v, 1, 64); return lo_i ? u : v; };      // value at clamp(i - 1)
     auto dn = [&](double v) { const double u = __shfl_down(v, 1, 64); return hi_i ? u : v; };    // value at clamp(i + 1)
     // centre arrays in the order they are consumed: 1/η, θ, then the (ε, τ, τ_o) triple of each normal component
-    const double *const cen[11] = {a.f.eta, a.theta, a.f.exx, a.f.txx, a.f.toxx, a.f.eyy, a.f.tyy, a.f.toyy, a.f.ezz, a.f.tzz, a.f.tozz};
+    const double *const cen[12] = {a.f.eta, a.theta, a.f.exx, a.f.txx, a.f.toxx, a.f.eyy, a.f.tyy, a.f.toyy, a.f.ezz, a.f.tzz, a.f.tozz, a.f.EII_pl};
     const double *const Yp[3] = {a.f.eyz, a.f.tyz, a.f.toyz}, *const Xp[3] = {a.f.exz, a.f.txz, a.f.toxz}, *const Zp[3] = {a.f.exy, a.f.txy, a.f.toxy};
     // row offsets inside one plane of each array family
     // byte offsets (32-bit: every array is below 4 GiB, check_vep3) = lane part inside one plane + uniform plane part
@@ -469,11 +470,11 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
     const u32 oz1 = ox1, oz2 = 8u * (u32)(ic + (nx + 1) * cj2);                                     // xy (nx+1, ny+1): rows clamp(j), clamp(j+1)
     const u32 pc = 8u * (u32)(nx * ny), py = 8u * (u32)(nx * (ny + 1)), px = 8u * (u32)((nx + 1) * ny), pz = 8u * (u32)((nx + 1) * (ny + 1));
     const bool act0 = useful && i < nx, act1 = useful && j < ny;             // yz / xz edge exists at this (i, j); xy: useful && k < nz
-    double pyz[11], pxz[11], Yn[3][2], Xn[3][2], Zc[3][2];
+    double pyz[NC], pxz[NC], Yn[3][2], Xn[3][2], Zc[3][2];
     {
         const u32 kc = (u32)clampi3(kb - 1, 0, nz - 1);
 #pragma unroll
-        for (int s = 0; s < 11; s++) {
+        for (int s = 0; s < NC; s++) {
             double v0 = LB(cen[s], oc0 + pc * kc), v1 = LB(cen[s], oc1 + pc * kc);
             if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
             const double u1 = up(v1);
@@ -506,7 +507,12 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             pxz[s] = u1 + v1;
         };
         EdgeMat m[3];
-        double etav[3], Pv[3], dtr[3], tt[3][6], S[3][3];
+        double etav[3], Pv[3], dtr[3], tt[3][6], S[3][3], EIIv[3] = {0.0, 0.0, 0.0};
+        if constexpr (SOFT) {
+            sums(11, S[0]);
+#pragma unroll
+            for (int T = 0; T < 3; T++) EIIv[T] = 0.25 * S[0][T];
+        }
         sums(0, S[0]);
         sums(1, S[1]);
 #pragma unroll
@@ -579,9 +585,9 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             own_d[2] = dev_stress_inc(own[1], own[2], etav[2], own[0], m[2]._Gdt, dtr[2]);
             tt[2][3] = trial(2, oy); tt[2][4] = trial(2, ox); tt[2][5] = own_t[2] + own_d[2];
         }
-        if constexpr ((FAM & 1) != 0) if (act0) vep3_edge_plastic<0, false, NP>(a, vi[0], rv[0], m[0], tt[0], own_t[0], own_d[0], etav[0], Pv[0], dtr[0], 0.0);
-        if constexpr ((FAM & 2) != 0) if (act1) vep3_edge_plastic<1, false, NP>(a, vi[1], rv[1], m[1], tt[1], own_t[1], own_d[1], etav[1], Pv[1], dtr[1], 0.0);
-        if constexpr ((FAM & 4) != 0) if (act2) vep3_edge_plastic<2, false, NP>(a, vi[2], rv[2], m[2], tt[2], own_t[2], own_d[2], etav[2], Pv[2], dtr[2], 0.0);
+        if constexpr ((FAM & 1) != 0) if (act0) vep3_edge_plastic<0, SOFT, NP>(a, vi[0], rv[0], m[0], tt[0], own_t[0], own_d[0], etav[0], Pv[0], dtr[0], EIIv[0]);
+        if constexpr ((FAM & 2) != 0) if (act1) vep3_edge_plastic<1, SOFT, NP>(a, vi[1], rv[1], m[1], tt[1], own_t[1], own_d[1], etav[1], Pv[1], dtr[1], EIIv[1]);
+        if constexpr ((FAM & 4) != 0) if (act2) vep3_edge_plastic<2, SOFT, NP>(a, vi[2], rv[2], m[2], tt[2], own_t[2], own_d[2], etav[2], Pv[2], dtr[2], EIIv[2]);
     }
 }
 #undef LB
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(256) void k_vep3_edges_z(const Vep3Args a, int nseg
 // One launch, one family per block: the three blocks of a tile (same nodes, families yz / xz / xy) sit next to each other in the block sequence
 // of ONE XCD (blocks are dealt round-robin to the 8 XCDs), so that the operands they share are fetched from HBM once and found in that XCD's L2 by
 // the other two; per block only one family's state lives in registers.
-template <int KZ, int NP, int MINB>
+template <int KZ, int NP, int MINB, bool SOFT = false>
 __global__ __launch_bounds__(256, MINB) void k_vep3_edges_zf(const Vep3Args a, int nseg, int ntile_xy, int ntiles)
 {
     const unsigned L = blockIdx.x, xcd = L & 7u, q = L >> 3;            // q-th block of this XCD
@@ -602,9 +608,9 @@ __global__ __launch_bounds__(256, MINB) void k_vep3_edges_zf(const Vep3Args a, i
     if (q / 3u >= per || t >= (unsigned)ntiles) return;
     const int txy = (int)(t % (unsigned)ntile_xy), zc = (int)(t / (unsigned)ntile_xy);
     const int j = (txy / nseg) * 4 + (int)(threadIdx.x >> 6);
-    if (fam == 0) vep3_edges_z_tile<KZ, NP, 1>(a, txy % nseg, j, zc);
-    else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2>(a, txy % nseg, j, zc);
-    else vep3_edges_z_tile<KZ, NP, 4>(a, txy % nseg, j, zc);
+    if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT>(a, txy % nseg, j, zc);
+    else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT>(a, txy % nseg, j, zc);
+    else vep3_edges_z_tile<KZ, NP, 4, SOFT>(a, txy % nseg, j, zc);
 }
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
 template <bool SOFT>
@@ -777,14 +783,19 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const bool p4 = h->vep3_map, xs = h->vep3_xcd;     // options "vep3_map", "vep3_xcd" (XCD slab order: +1-2 % measured)
-    if (!a.soft && h->vep3_edges >= 1 && a.rh.nphase <= 4) {
-        // option "vep3_edges": 0 one node per thread (k_vep3_edges; also the form softening laws and more than 4 phases use), 1 (default) the z-marching
+    if (h->vep3_edges >= 1 && a.rh.nphase <= 4) {
+        // option "vep3_edges": 0 one node per thread (k_vep3_edges; also the form more than 4 phases use), 1 (default) the z-marching
         // kernel with one family per block and the three blocks of a tile on one XCD, 2 the same kernel as one launch per family (A/B: the L2 sharing)
         const int cfg = h->vep3_cfg ? h->vep3_cfg : 162;           // option "vep3_cfg" = KZ * 10 + min blocks per CU (tuning)
         const int kz = cfg / 10, mb = cfg % 10, np_ = a.rh.nphase;
         const int nseg = (nx + 1 + 61) / 62, ntxy = nseg * ((ny + 1 + 3) / 4), nzc = (nz + 1 + kz - 1) / kz, nt = ntxy * nzc;
         bool ok = false;
-        if (h->vep3_edges == 2) {
+        if (a.soft) {       // softening laws: the yield function also reads the edge average of EII_pl
+            const dim3 gf((unsigned)(((nt + 7) / 8) * 8 * 3));
+#define EZS(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<16, NP_, 2, true>), gf, dim3(256), 0, s, a, nseg, ntxy, nt); ok = true; }
+            EZS(1) EZS(2) EZS(3) EZS(4)
+#undef EZS
+        } else if (h->vep3_edges == 2) {
             const dim3 g((unsigned)ntxy, (unsigned)nzc);
 #define EZ(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 1>), g, dim3(256), 0, s, a, nseg); \
                 hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 2>), g, dim3(256), 0, s, a, nseg); \
@@ -795,7 +806,7 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
             const dim3 gf((unsigned)(((nt + 7) / 8) * 8 * 3));
 #define EZG(KZ_, NP_, MB_) if (kz == KZ_ && mb == MB_ && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<KZ_, NP_, MB_>), gf, dim3(256), 0, s, a, nseg, ntxy, nt); ok = true; }
 #define EZN(KZ_, MB_) EZG(KZ_, 1, MB_) EZG(KZ_, 2, MB_) EZG(KZ_, 3, MB_) EZG(KZ_, 4, MB_)
-            EZN(16, 3) EZN(8, 3) EZN(32, 3) EZN(16, 2)
+            EZN(16, 2) EZN(16, 3) EZN(8, 2)
 #undef EZN
 #undef EZG
         }

@@ -23,8 +23,13 @@ def timed(fn, warm, iters):
     return (time.perf_counter() - t0), r
 
 
-def shearband3d(n=256, iters=100):
+def shearband3d(n=256, iters=100, soft=False):
     s = jr.miniapps.shearband3d(n, iterMax=iters - 1, nout=10 ** 9)
+    if soft:      # a softening law on C and phi of the matrix phase: the yield function then reads EII_pl
+        ph = [dict(p) for p in s.extra["phases"]]
+        ph[0].update(softening_C=dict(kind="linear", min=0.5 * ph[0]["C"], max=ph[0]["C"], lo=0.0, hi=0.1),
+                     softening_phi=dict(kind="nonlinear", xi0=30.0, Delta=10.0, mu=0.2, sigma=0.1))
+        s.extra["phases"] = ph
     s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
     st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
     for k, path in dict(Vx="V.Vx", Vy="V.Vy", Vz="V.Vz", eta="viscosity.η").items():
@@ -42,7 +47,7 @@ def shearband3d(n=256, iters=100):
     el, r = timed(run, 5, iters)
     cells = float(np.prod(s.ni))
     # as written: stress kernel reads ~70 array values per cell (3 edge families + centre), pressure/strain 14, viscosity 2, velocity 17, + phase arrays
-    print(json.dumps(dict(config="shear band 3D multiphase VEP", n=n, iters=r.iter, it_per_s=r.iter / el, ms_per_it=el / r.iter * 1e3,
+    print(json.dumps(dict(config="shear band 3D multiphase VEP" + (" with softening laws" if soft else ""), n=n, iters=r.iter, it_per_s=r.iter / el, ms_per_it=el / r.iter * 1e3,
                           Mcell_updates_per_s=cells * r.iter / el / 1e6)))
 
 
@@ -65,7 +70,8 @@ def thermal3d(n=256, iters=400):
 if __name__ == "__main__":
     nv = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     nt = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    for kv in sys.argv[3:]:                     # library options, KEY=INT
+    soft = "soft" in sys.argv[3:]
+    for kv in (a for a in sys.argv[3:] if "=" in a):                     # library options, KEY=INT
         import ctypes as C
         from justrelax_jl_amd import _lib
         k, v = kv.split("=")
@@ -74,4 +80,4 @@ if __name__ == "__main__":
     if nt > 0:
         thermal3d(nt)
     if nv > 0:
-        shearband3d(nv)
+        shearband3d(nv, soft=soft)
