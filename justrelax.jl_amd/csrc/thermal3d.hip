@@ -28,6 +28,18 @@ __device__ __forceinline__ double rhoCp3_of(const jrx_thermal3d_params &p, const
     const int j = t_ / (n1_), i = t_ - j * (n1_), k = blockIdx.y;       \
     if (j >= (n2_)) return;
 #define GRID_IJK(n1_, n2_, n3_) dim3((unsigned)(((i64)(n1_) * (n2_) + 255) / 256), (unsigned)(n3_))
+// the same box in XCD slab order: block L of the launch takes position (L % 8) * (T / 8) + L / 8 of the (flattened xy, z) sequence, so that each of the
+// 8 XCDs (blocks are dealt to them round-robin, each has its own L2) works on a contiguous slab of planes and finds the rows j +- 1 / planes k +- 1 of
+// its stencils in its own L2 (k_flux3d, phase-ratio form at 256^3: 21.6 array passes fetched without, see profiles/r02_thermal3d_phases.txt)
+#define NODE_IJK_XS(n1_, n2_)                                                         \
+    unsigned bx_ = blockIdx.x, by_ = blockIdx.y;                                      \
+    {                                                                                 \
+        const unsigned L_ = by_ * gridDim.x + bx_, per_ = (gridDim.x * gridDim.y) / 8u; \
+        if (L_ < per_ * 8u) { const unsigned Ln_ = (L_ & 7u) * per_ + (L_ >> 3); bx_ = Ln_ % gridDim.x; by_ = Ln_ / gridDim.x; } \
+    }                                                                                 \
+    const int t_ = bx_ * blockDim.x + threadIdx.x;                                    \
+    const int j = t_ / (n1_), i = t_ - j * (n1_), k = by_;                            \
+    if (j >= (n2_)) return;
 #define T3_(i_, j_, k_) T[(i_) + (i64)(nx + 2) * ((j_) + (i64)(ny + 2) * (k_))]
 #define CC_(A, i_, j_, k_) (A)[(i_) + (i64)nx * ((j_) + (i64)ny * (k_))]
 
@@ -38,7 +50,7 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a, const PHT ph)
 {
     constexpr bool PH = is_tph<PHT>::value;
     const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
-    NODE_IJK(nx + 1, ny + 1)
+    NODE_IJK_XS(nx + 1, ny + 1)
     const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau;
     const double kc = (a.p.k_const + a.p.k_const) * 0.5;
     if (j < ny && k < nz) {
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a, const PHT ph)
 {
     constexpr bool PH = is_tph<PHT>::value;
     const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
-    NODE_IJK(nx, ny)
+    NODE_IJK_XS(nx, ny)
     if (k >= nz) return;
     const i64 c = i + (i64)nx * (j + (i64)ny * k), I1 = (i + 1) + (i64)(nx + 2) * ((j + 1) + (i64)(ny + 2) * (k + 1));
     const double _dt = 1.0 / a.p.dt;

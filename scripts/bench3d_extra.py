@@ -67,6 +67,27 @@ def thermal3d(n=256, iters=400):
                           eff_GBps_at_176B=176.0 * cells * k / el / 1e9)))
 
 
+def thermal3d_phases(n=256, iters=200):
+    """phase-ratio form of the 3D heat-diffusion path (two phases, ball in the middle): update_pt_thermal_arrays! + compute_flux! + update_T! per iteration"""
+    from types import SimpleNamespace
+    s = jr.miniapps.diffusion3d_multiphase(n, iterMax=iters, nout=10 ** 9)
+    thermal = jr.ThermalArrays(jr.AMDGPUBackend, s.ni)
+    thermal.T.copy_(from_numpy(s.arrays["T"], dev)); thermal.H.fill_(1e-6)
+    pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, s.ni)
+    for k, v in s.extra["phase_ratios"].items():
+        getattr(pr, k).copy_(from_numpy(v, dev))
+    args = SimpleNamespace(P=jr.fzeros(s.ni, dev), T=thermal.T)
+    pt = jr.PTThermalCoeffs.from_phases(jr.AMDGPUBackend, s.extra["rheology"], pr, args, s.dt, s.ni, s.extra["di"], s.extra["li"], ϵ=1e-300, CFL=s.pt["CFL"])
+    def run(k):
+        jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, s.extra["rheology"], args, s.dt, s.grid, kwargs=dict(phase=pr, iterMax=k, nout=10 ** 9, verbose=False))
+        return k
+    el, k = timed(run, 10, iters)
+    cells = float(np.prod(s.ni))
+    # algorithmic: coefficients R(T, P, phase_c(2)) W(θ, dτ_ρ) = 6; flux R(T, θ, q(3), face ratios 3 x 2) W(q(3), q2(3)) = 17; update R(q(3), Told, T, P, phase_c(2), dτ_ρ, H, SH) W(T) = 12
+    print(json.dumps(dict(config="thermal diffusion 3D (phase-ratio form, 2 phases)", n=n, iters=k, it_per_s=k / el, ms_per_it=el / k * 1e3,
+                          eff_GBps_at_280B=280.0 * cells * k / el / 1e9)))
+
+
 if __name__ == "__main__":
     nv = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     nt = int(sys.argv[2]) if len(sys.argv) > 2 else 256
@@ -77,7 +98,9 @@ if __name__ == "__main__":
         k, v = kv.split("=")
         _lib.default_handle(0).call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(int(v)))
         print(f"# option {k} = {v}")
-    if nt > 0:
+    if nt > 0 and "phases" in sys.argv[3:]:
+        thermal3d_phases(nt)
+    elif nt > 0:
         thermal3d(nt)
     if nv > 0:
         shearband3d(nv, soft=soft)
