@@ -177,3 +177,58 @@ def test_taylor_green_converges_through_the_fused_pipeline():
     assert (order > 1.7).all(), (order, errors, its)
     L2_p, L2_vx, L2_vy, L2_vz = errors[-1]
     assert max(L2_vx, L2_vy, L2_vz) < 1.0e-4 and L2_p < 1.0e-2, errors[-1]
+
+
+def _build_vep3(jr, ni, seed=77):
+    """3D shear-band set-up (two phases, Drucker-Prager) with a random pre-stress near yield, built in device memory"""
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s = jr.miniapps.shearband3d(ni, iterMax=2, nout=10 ** 9)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+    st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+    for k, t in dict(Vx=st.V.Vx, Vy=st.V.Vy, Vz=st.V.Vz, eta=st.viscosity.η).items():
+        t.copy_(from_numpy(s.arrays[k], dev))
+    pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, s.ni)
+    for k, name in (("phase_c", "center"), ("phase_yz", "yz"), ("phase_xz", "xz"), ("phase_xy", "xy")):
+        getattr(pr, name).copy_(from_numpy(s.arrays[k], dev))
+    del s.arrays
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    for c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):
+        t = getattr(st.τ_o, c)
+        flat = torch.empty(t.numel(), device=dev, dtype=torch.float64).uniform_(-1.5, 1.5, generator=gen)
+        t.copy_(flat.view(*reversed(t.shape)).permute(*range(t.dim() - 1, -1, -1)))
+        getattr(st.τ, c).copy_(t)
+        del flat
+    ρg = tuple(jr.fzeros(s.ni, dev) for _ in range(3))
+    return s, st, pr, ρg
+
+
+@pytest.mark.parametrize("ni", [(256, 256, 256), (200, 96, 70)])
+def test_vep3d_edge_kernel_forms_agree_at_full_size(jr, ni):
+    """the z-marching edge kernel of the 3D visco-elasto-plastic stress update (one family per block, 62-node lane segments, 16-plane chunks, XCD-grouped
+    tiles) and the one-node-per-thread kernel the oracle checks at small sizes must leave bit-identical states after three yielding PT iterations"""
+    import torch
+    from justrelax_jl_amd import _lib
+    h = _lib.default_handle()
+    outs = []
+    try:
+        for edges in (0, 1):
+            h.call("jrx_set_option", C.c_char_p(b"vep3_edges"), C.c_int64(edges))
+            s, st, pr, ρg = _build_vep3(jr, ni)
+            r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=dict(iterMax=2, nout=10 ** 9, verbose=False))
+            assert r.iter == 3
+            keep = {"P": st.P, "Vx": st.V.Vx, "Vz": st.V.Vz, "EII_pl": st.EII_pl}
+            for c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):
+                keep["t" + c] = getattr(st.τ, c)
+            for c in ("yz", "xz", "xy", "xx"):
+                keep["epl" + c] = getattr(st.ε_pl, c)
+            outs.append({k: v.clone() for k, v in keep.items()})
+            del st, pr, ρg, keep
+            torch.cuda.empty_cache()
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"vep3_edges"), C.c_int64(1))
+    assert float(outs[0]["eplyz"].abs().max()) > 0.0 and bool((outs[0]["eplyz"] == 0).any())      # yielding and elastic edges both occur
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
