@@ -23,12 +23,20 @@ struct Args2 {
 #define VX(i_, j_) Vx[(i_) + (i64)(nx + 1) * (j_)]
 #define VY(i_, j_) Vy[(i_) + (i64)(nx + 2) * (j_)]
 #define CC(i_, j_) ((i_) + (i64)nx * (j_))
+// Blocks are dealt round-robin to the 8 XCDs, each with its own L2: block L of a 1D launch takes position (L % 8) * (T / 8) + L / 8 of the flattened
+// (x fastest) node sequence, so that every XCD works on a contiguous band of rows and finds the rows j +- 1 of its stencils in its own L2
+// (shear band 1024^2: k_vep_stress2d fetched 37.8 array passes from HBM for 19 needed, profiles/r02_bench2d_xcd_slabs.txt)
+__device__ __forceinline__ unsigned xcd_slab_block()
+{
+    const unsigned L = blockIdx.x, per = gridDim.x / 8u;
+    return L < per * 8u ? (L & 7u) * per + (L >> 3) : L;
+}
 
 template <bool DIAG>
 __global__ __launch_bounds__(256) void k_stress2d(const Args2 a)
 {
     const int nx = a.nx, ny = a.ny;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
     const int j = t / (nx + 1), i = t - j * (nx + 1);
     if (j > ny) return;
     const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
@@ -126,7 +134,7 @@ __device__ __forceinline__ void velocity2d_cell(const Args2 &a, const int i, con
 template <bool RES_ONLY, bool BCF = false>
 __global__ __launch_bounds__(256) void k_velocity2d(const Args2 a)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
     const int j = t / a.nx, i = t - j * a.nx;
     if (j >= a.ny) return;
     velocity2d_cell<RES_ONLY, BCF>(a, i, j);
@@ -145,7 +153,7 @@ struct BC2 { int tL, tR, tB, tT; };      // 0 none (memory holds the prescribed 
 __global__ __launch_bounds__(256) void k_fused2d(const Args2 a, const Out6_2d o, const BC2 bc, const int nwx)
 {
     const int nx = a.nx, ny = a.ny;
-    const int wg = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int wg = (int)xcd_slab_block() * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int j = wg / nwx, i = (wg - j * nwx) * 63 + lane - 1;
     if (j > ny) return;
     const double _dx = a._dx, _dy = a._dy, edt = a.eta_dtau, dt = a.dt, th = a.theta_dtau;
@@ -447,9 +455,9 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     // Fused pipeline (as in 3D): when nothing observes iteration it1 and iteration it1+1 certainly runs unobserved, compute_V! of it1,
     // flow_bcs! (by rule) and the stress sweep of it1+1 run as one launch that ping-pongs (P, τ, V) between the caller's arrays and a
     // library-owned set; flow_bcs! itself is applied lazily before anything reads the boundary entries of V from memory.
-    // measured (SolCx, profiles/r01_bench2d.txt): 64^2 +16 %, 128^2 +15 %, 256^2 -3 %, 512^2 and 1024^2 +-1 % -- the kernels stop being
-    // launch-bound around 200^2 nodes and the fused kernel's redundant velocity updates then cost what the saved launch gave
-    const bool fusable = !p->displacement_bcs && h->fused2d && h->scratch_sets && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 40000)) &&
+    // measured with the XCD slab block order (SolCx, profiles/r02_bench2d_xcd_slabs.txt; it/s two kernels vs fused): 128^2 175.9 k / 176.2 k, 256^2 135.2 k /
+    // 144.2 k, 384^2 101.5 k / 106.7 k, 512^2 79.1 k / 73.6 k, 768^2 40.1 k / 38.8 k, 1024^2 equal -- fused up to 200,000 nodes (~ 440^2)
+    const bool fusable = !p->displacement_bcs && h->fused2d && h->scratch_sets && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 200000)) &&
                          !jrx_comm_active(h) && p->periodic == 0 && nx >= 2 && ny >= 2;
     const size_t nvx = (size_t)(nx + 1) * (ny + 2), nvy = (size_t)(nx + 2) * (ny + 1), nvt = (size_t)(nx + 1) * (ny + 1);
     Out6_2d setU = {f->P, f->txx, f->tyy, f->txy, f->Vx, f->Vy}, setS = setU;
@@ -641,7 +649,7 @@ template <bool ML, bool RHO = false>
 __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__restrict__ theta)
 {
     const int nx = a.nx, ny = a.ny;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
     const int j = t / (nx + 1), i = t - j * (nx + 1);
     if (j > ny) return;
     const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy;
@@ -842,7 +850,7 @@ __global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
 template <bool SOFT, bool SI = false>
 __global__ __launch_bounds__(256) void k_vep_stress2d(const VepArgs a)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
     const int j = t / (a.nx + 1), i = t - j * (a.nx + 1);
     if (j > a.ny) return;
     vep_vertex_at<SOFT, SI>(a, i, j);
@@ -957,7 +965,7 @@ __global__ __launch_bounds__(256) void k_vep_visc(const VepArgs a) { vep_visc_at
 template <bool BCF>
 __global__ __launch_bounds__(256) void k_vep_visc_velocity(const VepArgs a, const Args2 b)
 {
-    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 t = (i64)xcd_slab_block() * blockDim.x + threadIdx.x;
     vep_visc_at(a, t);
     const int j = (int)(t / b.nx), i = (int)(t - (i64)j * b.nx);
     if (j < b.ny) velocity2d_cell<false, BCF>(b, i, j);

@@ -23,13 +23,21 @@ __device__ __forceinline__ double rhoCp_of(const jrx_thermal2d_params &p, const 
     return p.rheology_form ? p.Cp * (p.rho0 * (1.0 - p.alpha * (T - p.T0))) : rhoCp[c];
 }
 
+// blocks are dealt round-robin to the 8 XCDs (own L2 each): block L works on position (L % 8) * (T / 8) + L / 8 of the flattened node sequence, so that
+// an XCD owns a contiguous band of rows and the rows j +- 1 of its stencils are in its own L2
+__device__ __forceinline__ unsigned xcd_slab_block()
+{
+    const unsigned L = blockIdx.x, per = gridDim.x / 8u;
+    return L < per * 8u ? (L & 7u) * per + (L >> 3) : L;
+}
+
 // compute_flux! over (nx+1, ny+1); PHT = TPh: conductivity from the face phase ratios
 template <class PHT>
 __global__ __launch_bounds__(256) void k_flux2d(const TArgs a, const PHT ph)
 {
     constexpr bool PH = is_tph<PHT>::value;
     const int nx = (int)a.p.nx, ny = (int)a.p.ny;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
     const int j = t / (nx + 1), i = t - j * (nx + 1);
     if (j > ny) return;
     const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
 {
     constexpr bool PH = is_tph<PHT>::value;
     const int nx = (int)a.p.nx, ny = (int)a.p.ny;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
     const int j = t / nx, i = t - j * nx;
     if (j >= ny) return;
     const i64 c = i + (i64)nx * j, I1 = (i + 1) + (i64)(nx + 2) * (j + 1);
@@ -142,7 +150,8 @@ template <int TX>
 __global__ __launch_bounds__(TX) void k_thermal2d_fused(const TArgs a, const TSet2 dst, int ntx)
 {
     const int nx = (int)a.p.nx, ny = (int)a.p.ny;
-    const int tix = blockIdx.x % ntx, j = blockIdx.x / ntx;
+    const unsigned bid = xcd_slab_block();
+    const int tix = bid % ntx, j = bid / ntx;
     const int i = tix * TX + (int)threadIdx.x;
     if (i >= nx && (i & ~63) >= nx) return;            // whole waves beyond the row end; idle lanes of a live wave stay for the shuffle
     const bool cell = i < nx;
