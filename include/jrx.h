@@ -381,6 +381,11 @@ typedef struct jrx_thermal2d_fields {
     double *H, *shear_heating, *ResT;      /* (nx, ny)     */
     double *K, *rhoCp;                     /* (nx, ny); unused (may be NULL) in the rheology form */
     double *thetar_dtau, *dtau_rho;        /* (nx, ny): pt_thermal.θr_dτ, dτ_ρ */
+    /* optional (NULL = absent; the one-launch iterations are not used when any is given) */
+    const double *adiabatic;               /* (nx, ny): thermal.adiabatic, the term + adiabatic * T of the rheology forms (DiffusionPT_kernels.jl:553-601,631-668) */
+    const double *dirichlet_mask;          /* (nx+2, ny+2): thermal_bc.dirichlet.mask -- cells with mask != 0 take T = (1 - m) T + m value instead of the update
+                                            * and have ResT = 0 (Dirichlet.jl:72-105, mask/mask.jl:47-50) */
+    const double *dirichlet_value;         /* (nx+2, ny+2) values; NULL with a ConstantDirichletBoundaryCondition (params.dirichlet_const) */
 } jrx_thermal2d_fields;
 
 typedef struct jrx_thermal2d_params {
@@ -399,6 +404,7 @@ typedef struct jrx_thermal2d_params {
     int32_t rheology_form;
     double k_const, Cp, rho0, alpha, T0;
     int32_t verbose;
+    double dirichlet_const;                /* value of a ConstantDirichletBoundaryCondition (read where dirichlet_mask != 0 and dirichlet_value is NULL) */
 } jrx_thermal2d_params;
 
 /* heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, K, ρCp | rheology, args, dt, grid; kwargs) */
@@ -450,6 +456,7 @@ typedef struct jrx_thermal3d_fields {
     double *H, *shear_heating, *ResT;      /* ni */
     const double *K, *rhoCp;               /* ni: array-coefficient form; NULL in the rheology form */
     const double *thetar_dtau, *dtau_rho;  /* ni: PTThermalCoeffs (rewritten every iteration by jrx_heatdiffusion_PT3d_phases) */
+    const double *adiabatic, *dirichlet_mask, *dirichlet_value;   /* optional, as in jrx_thermal2d_fields; mask / value (nx+2, ny+2, nz+2) */
 } jrx_thermal3d_fields;
 
 typedef struct jrx_thermal3d_params {
@@ -464,6 +471,7 @@ typedef struct jrx_thermal3d_params {
     int32_t rheology_form;                 /* 1: k_const, Cp, PT_Density(rho0, alpha, T0) as in test/test_diffusion3D.jl */
     double k_const, Cp, rho0, alpha, T0;
     int32_t verbose;
+    double dirichlet_const;
 } jrx_thermal3d_params;
 
 jrx_status jrx_heatdiffusion_PT3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, int64_t *iter_count, double *norm_ResT,
@@ -501,6 +509,10 @@ jrx_status jrx_heatdiffusion_PT3d_phases(jrx_handle *h, const jrx_thermal3d_fiel
  * from T (ni.+2, read at Idx.+1), P and the centre ratios; n = {nx, ny, nz} (nz = 1 in 2D) */
 jrx_status jrx_update_pt_thermal_arrays(jrx_handle *h, double *thetar_dtau, double *dtau_rho, const double *T, const int64_t n[3], int32_t ndim, double dt,
                                         const jrx_thermal_phases *ph, const jrx_thermal_phase_fields *pf);
+/* adiabatic_heating!(thermal, stokes, rheology, phases, _dt) -- DiffusionPT_kernels.jl:720-746: A = (P - P0) * α * _dt over ncells cells, α the phase-weighted thermal
+ * expansivity of the density laws (PT_Density, T_Density: α; otherwise 0 -- ASSUMED form of GeoParams' compute_α); phase_c NULL: phase 0 alone */
+jrx_status jrx_adiabatic_heating(jrx_handle *h, double *adiabatic, const double *P, const double *P0, int64_t ncells, double dt, const jrx_thermal_phases *ph,
+                                 const double *phase_c);
 
 /* ------------------------------------------------------------------ timing hooks for bench.py */
 /* Runs `iters` PT iterations of the 3D loop body back to back (no norm checks) and reports device times

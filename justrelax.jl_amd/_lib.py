@@ -26,6 +26,7 @@ F3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",
             "tyz_c", "txz_c", "txy_c", "toyz_c", "toxz_c", "toxy_c"]
 F2_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "txx", "tyy", "txy", "toxx", "toyy", "toxy",
             "exx", "eyy", "exy", "eta", "K", "G", "fx", "fy", "RP", "Rx", "Ry", "txy_c", "toxy_c"]
+T_OPT = ["adiabatic", "dirichlet_mask", "dirichlet_value"]          # optional members of the thermal field structs (NULL = absent)
 T2_NAMES = ["T", "Told", "dT", "qTx", "qTx2", "qTy", "qTy2", "H", "shear_heating", "ResT", "K", "rhoCp",
             "thetar_dtau", "dtau_rho"]
 
@@ -36,7 +37,7 @@ def _ptr_struct(name, names):
 
 Stokes3DFields = _ptr_struct("Stokes3DFields", F3_NAMES)
 Stokes2DFields = _ptr_struct("Stokes2DFields", F2_NAMES)
-Thermal2DFields = _ptr_struct("Thermal2DFields", T2_NAMES)
+Thermal2DFields = _ptr_struct("Thermal2DFields", T2_NAMES + T_OPT)
 
 
 class Stokes3DParams(C.Structure):
@@ -66,11 +67,11 @@ class Thermal2DParams(C.Structure):
                 ("constant_flux_on", C.c_int32 * 4), ("constant_flux", C.c_double * 4),
                 ("periodic", C.c_int32 * 4), ("rheology_form", C.c_int32),
                 ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double),
-                ("T0", C.c_double), ("verbose", C.c_int32)]
+                ("T0", C.c_double), ("verbose", C.c_int32), ("dirichlet_const", C.c_double)]
 
 
 T3_NAMES = ["T", "Told", "dT", "qTx", "qTx2", "qTy", "qTy2", "qTz", "qTz2", "H", "shear_heating", "ResT", "K", "rhoCp", "thetar_dtau", "dtau_rho"]
-Thermal3DFields = _ptr_struct("Thermal3DFields", T3_NAMES)
+Thermal3DFields = _ptr_struct("Thermal3DFields", T3_NAMES + T_OPT)
 
 
 class Thermal3DParams(C.Structure):
@@ -81,7 +82,7 @@ class Thermal3DParams(C.Structure):
                 ("constant_flux_on", C.c_int32 * 6), ("constant_flux", C.c_double * 6),
                 ("periodic", C.c_int32 * 6), ("rheology_form", C.c_int32),
                 ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double), ("T0", C.c_double),
-                ("verbose", C.c_int32)]
+                ("verbose", C.c_int32), ("dirichlet_const", C.c_double)]
 
 
 class ThermalPhases(C.Structure):

@@ -320,7 +320,9 @@ class DisplacementBoundaryConditions(_FlowBCs):
 class TemperatureBoundaryConditions:
     """src/boundaryconditions/types.jl:65-106"""
 
-    def __init__(self, *, no_flux=None, constant_flux=None, constant_value=None, periodic=None):
+    def __init__(self, *, no_flux=None, constant_flux=None, constant_value=None, periodic=None, dirichlet=None):
+        # dirichlet = dict(constant=number | None, mask=array of the shape of thermal.T | None) -- Dirichlet(constant, mask), Dirichlet.jl:131-135
+        self.dirichlet = dict(dirichlet) if dirichlet else dict(constant=None, mask=None)
         d2 = dict(left=False, right=False, top=False, bot=False)
         no_flux = no_flux if no_flux is not None else dict(d2, left=True)
         given = [no_flux] + [d for d in (constant_flux, constant_value, periodic) if d is not None]

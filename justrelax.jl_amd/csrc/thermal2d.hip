@@ -117,18 +117,28 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
         rcp = tph_rhoCp(ph.m, rc, Tij, ph.f.P[c]);
         Hr = tph_Hr(ph.m, rc);
     } else rcp = rhoCp_of(a.p, a.t.rhoCp, c, Tij);
+    // optional terms: + adiabatic * T in the rheology forms; Dirichlet cells (mask != 0) take (1 - m) T + m value and have no residual
+    const bool hasadi = a.p.rheology_form != 0 && a.t.adiabatic != nullptr;
+    const double adi = hasadi ? a.t.adiabatic[c] * Tij : 0.0;
+    const double dm = a.t.dirichlet_mask ? a.t.dirichlet_mask[I1] : 0.0;
     if (RES) {
         const double dq = (a.t.qTx2[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx2[i + (i64)(nx + 1) * j]) * a.p._dx +
                           (a.t.qTy2[i + (i64)nx * (j + 1)] - a.t.qTy2[c]) * a.p._dy;
-        if constexpr (PH) a.t.ResT[c] = -rcp * (Tij - a.t.Told[I1]) * _dt - dq + Hr + a.t.H[c] + a.t.shear_heating[c];
-        else a.t.ResT[c] = -rcp * (Tij - a.t.Told[I1]) * _dt - dq + a.t.H[c] + a.t.shear_heating[c];
+        if (dm != 0.0) a.t.ResT[c] = 0.0;
+        else if constexpr (PH) a.t.ResT[c] = hasadi ? -rcp * (Tij - a.t.Told[I1]) * _dt - dq + Hr + a.t.H[c] + a.t.shear_heating[c] + adi
+                                                 : -rcp * (Tij - a.t.Told[I1]) * _dt - dq + Hr + a.t.H[c] + a.t.shear_heating[c];
+        else a.t.ResT[c] = hasadi ? -rcp * (Tij - a.t.Told[I1]) * _dt - dq + a.t.H[c] + a.t.shear_heating[c] + adi
+                                  : -rcp * (Tij - a.t.Told[I1]) * _dt - dq + a.t.H[c] + a.t.shear_heating[c];
     } else {
         const double dr = a.t.dtau_rho[c];
         const double divq = (a.t.qTx[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx[i + (i64)(nx + 1) * j]) * a.p._dx +
                             (a.t.qTy[i + (i64)nx * (j + 1)] - a.t.qTy[c]) * a.p._dy;
         double Tn;
-        if constexpr (PH) Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
-        else Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+        if (dm != 0.0) Tn = (1 - dm) * Tij + dm * (a.t.dirichlet_value ? a.t.dirichlet_value[I1] : a.p.dirichlet_const);
+        else if constexpr (PH) Tn = hasadi ? (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c] + adi) + Tij) / (1.0 + dr * rcp * _dt)
+                                           : (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+        else Tn = hasadi ? (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c] + adi) + Tij) / (1.0 + dr * rcp * _dt)
+                         : (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
         a.t.T[I1] = Tn;
         if (BCF) {
             const int xs = i == 0 ? 0 : (i == nx - 1 ? 1 : -1), ys = j == 0 ? 0 : (j == ny - 1 ? 1 : -1);
@@ -275,6 +285,20 @@ __global__ __launch_bounds__(256) void k_pt_thermal_arrays(double *__restrict__ 
     }
 }
 
+// adiabatic_heating! (DiffusionPT_kernels.jl:720-729): A = (P - P0) * α * _dt, α = phase-weighted expansivity of the density laws
+__global__ __launch_bounds__(256) void k_adiabatic(double *__restrict__ A, const double *__restrict__ P, const double *__restrict__ P0, i64 n, double _dt, const TPh ph)
+{
+    for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (i64)gridDim.x * blockDim.x) {
+        double al = 0.0;
+        for (int q = 0; q < ph.m.nphase; q++) {
+            const double r = ph.f.phase_c ? ph.f.phase_c[(i64)ph.m.nphase * c + q] : (q == 0 ? 1.0 : 0.0);
+            const double aq = (ph.m.rho_kind[q] == 1 || ph.m.rho_kind[q] == 2) ? ph.m.alpha[q] : 0.0;
+            al += (r == 0.0) ? 0.0 : aq * r;
+        }
+        A[c] = (P[c] - P0[c]) * al * _dt;
+    }
+}
+
 jrx_status checkT(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p)
 {
     if (!h) return JRX_ERR_ARG;
@@ -417,7 +441,7 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
     a.t = *t; a.p = *p;
     // iterations nobody observes: one fused launch, ping-pong between the caller's (T, qT) and a library-owned set (option thermal_fused)
     const bool any_periodic = p->periodic[0] | p->periodic[1] | p->periodic[2] | p->periodic[3];
-    const bool fusable = !PH && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
+    const bool fusable = !PH && !t->adiabatic && !t->dirichlet_mask && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
     const TSet2 user = {t->T, t->qTx, t->qTy};
     TSet2 cur = user, oth = user;
     if (fusable) {
@@ -513,6 +537,23 @@ jrx_status jrx_heatdiffusion_PT2d_phases(jrx_handle *h, const jrx_thermal2d_fiel
     TPh x;
     x.m = *ph; x.f = *pf;
     return heat2d(h, t, &q, x, iter_count, norm_ResT, cap, nnorms);
+}
+
+jrx_status jrx_adiabatic_heating(jrx_handle *h, double *adiabatic, const double *P, const double *P0, int64_t ncells, double dt, const jrx_thermal_phases *ph,
+                                 const double *phase_c)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!adiabatic || !P || !P0 || !ph || ncells < 1) return jrx_fail(h, JRX_ERR_ARG, "adiabatic_heating!: bad argument");
+    if (ph->nphase < 1 || ph->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "adiabatic_heating!: nphase out of range");
+    JRX_TRY(jrx_check_device(h));
+    TPh x;
+    memset(&x, 0, sizeof(x));
+    x.m = *ph; x.f.phase_c = phase_c;
+    const i64 nb = (ncells + 255) / 256;
+    hipLaunchKernelGGL(k_adiabatic, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, h->stream, adiabatic, P, P0, (i64)ncells, 1.0 / dt, x);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
 }
 
 jrx_status jrx_update_pt_thermal_arrays(jrx_handle *h, double *thetar_dtau, double *dtau_rho, const double *T, const int64_t n[3], int32_t ndim, double dt,

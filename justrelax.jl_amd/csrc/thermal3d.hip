@@ -157,14 +157,24 @@ __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a, const PHT ph)
     const double divq = (qx[(i + 1) + (i64)(nx + 1) * (j + (i64)ny * k)] - qx[i + (i64)(nx + 1) * (j + (i64)ny * k)]) * a.p._dx +
                         (qy[i + (i64)nx * ((j + 1) + (i64)(ny + 1) * k)] - qy[i + (i64)nx * (j + (i64)(ny + 1) * k)]) * a.p._dy +
                         (qz[i + (i64)nx * (j + (i64)ny * (k + 1))] - qz[c]) * a.p._dz;
+    // optional terms: + adiabatic * T in the rheology forms; Dirichlet cells (mask != 0) take (1 - m) T + m value and have no residual
+    const bool hasadi = a.p.rheology_form != 0 && a.t.adiabatic != nullptr;
+    const double adi = hasadi ? a.t.adiabatic[c] * Tc : 0.0;
+    const double dm = a.t.dirichlet_mask ? a.t.dirichlet_mask[I1] : 0.0;
     if (RES) {
-        if constexpr (PH) a.t.ResT[c] = -rcp * (Tc - a.t.Told[I1]) * _dt - divq + Hr + a.t.H[c] + a.t.shear_heating[c];
-        else a.t.ResT[c] = -rcp * (Tc - a.t.Told[I1]) * _dt - divq + a.t.H[c] + a.t.shear_heating[c];
+        if (dm != 0.0) a.t.ResT[c] = 0.0;
+        else if constexpr (PH) a.t.ResT[c] = hasadi ? -rcp * (Tc - a.t.Told[I1]) * _dt - divq + Hr + a.t.H[c] + a.t.shear_heating[c] + adi
+                                                 : -rcp * (Tc - a.t.Told[I1]) * _dt - divq + Hr + a.t.H[c] + a.t.shear_heating[c];
+        else a.t.ResT[c] = hasadi ? -rcp * (Tc - a.t.Told[I1]) * _dt - divq + a.t.H[c] + a.t.shear_heating[c] + adi
+                                  : -rcp * (Tc - a.t.Told[I1]) * _dt - divq + a.t.H[c] + a.t.shear_heating[c];
     } else {
         const double dr = a.t.dtau_rho[c];
         double Tn;
-        if constexpr (PH) Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
-        else Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+        if (dm != 0.0) Tn = (1 - dm) * Tc + dm * (a.t.dirichlet_value ? a.t.dirichlet_value[I1] : a.p.dirichlet_const);
+        else if constexpr (PH) Tn = hasadi ? (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c] + adi) + Tc) / (1.0 + dr * rcp * _dt)
+                                           : (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+        else Tn = hasadi ? (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c] + adi) + Tc) / (1.0 + dr * rcp * _dt)
+                         : (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
         a.t.T[I1] = Tn;
         if (BCF) {
             const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
@@ -487,7 +497,7 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
     // (option "thermal_fused" = 0: always the two kernels); observed ones (check / last) run the two kernels in place on the current set.
     bool any_periodic = false;
     for (int q = 0; q < 6; q++) any_periodic |= p->periodic[q] != 0;
-    const bool fusable = !PH && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h);
+    const bool fusable = !PH && !t->adiabatic && !t->dirichlet_mask && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h);
     const TSet user = {t->T, t->qTx, t->qTy, t->qTz};
     TSet cur = user, oth = user;
     if (fusable) {

@@ -44,6 +44,9 @@ def thermal_params2d(ni, grid, thermal_bc, dt, ϵ, *, iterMax=50_000, nout=1000,
         on = not isinstance(v, bool) and v is not None                         # `!isa(bc_flux.left, Bool)`
         p.constant_flux_on[i] = int(on)
         p.constant_flux[i] = float(v) if on else 0.0
+    dbc = getattr(thermal_bc, "dirichlet", None)
+    if dbc is not None and dbc.get("constant") is not None:
+        p.dirichlet_const = float(dbc["constant"])
     if rheology is not None:
         p.rheology_form = 1
         p.k_const, p.Cp, p.rho0, p.alpha, p.T0 = (rheology["k"], rheology["Cp"], rheology["rho0"], rheology["alpha"],
@@ -51,7 +54,25 @@ def thermal_params2d(ni, grid, thermal_bc, dt, ϵ, *, iterMax=50_000, nout=1000,
     return p
 
 
-def thermal_fields2d(thermal, pt_thermal, K=None, ρCp=None):
+def _dirichlet_arrays(thermal, thermal_bc):
+    """(mask, value) of thermal_bc.dirichlet = dict(constant=number | None, mask=array (ni .+ 2)) -- Dirichlet(constant, mask), Dirichlet.jl:131-135:
+    with constant = None the array holds the values and its non-zero entries are the mask (DirichletBoundaryCondition(A), :15-20)"""
+    dbc = getattr(thermal_bc, "dirichlet", None) if thermal_bc is not None else None
+    if not dbc or dbc.get("mask") is None:
+        return None, None
+    m = dbc["mask"]
+    if tuple(m.shape) != tuple(thermal.T.shape):
+        raise ValueError(f"the Dirichlet mask must have the shape of thermal.T {tuple(thermal.T.shape)}")
+    if dbc.get("constant") is not None:
+        return m, None
+    if "_mask01" not in dbc:                       # Mask(copy(A)) filled with T.(.!iszero.(A))
+        t = torch.empty_like(m)                    # keeps the column-major strides
+        t.copy_((m != 0).to(m.dtype))
+        dbc["_mask01"] = t
+    return dbc["_mask01"], m
+
+
+def thermal_fields2d(thermal, pt_thermal, K=None, ρCp=None, thermal_bc=None, adiabatic=None):
     """jrx_thermal2d_fields / jrx_thermal3d_fields (by the dimension of `thermal`)"""
     three = len(thermal._ni) == 3
     f = _lib.Thermal3DFields() if three else _lib.Thermal2DFields()
@@ -60,7 +81,9 @@ def thermal_fields2d(thermal, pt_thermal, K=None, ρCp=None):
                 thetar_dtau=pt_thermal.θr_dτ, dtau_rho=pt_thermal.dτ_ρ)
     if three:
         vals.update(qTz=thermal.qTz, qTz2=thermal.qTz2)
-    for n in (_lib.T3_NAMES if three else _lib.T2_NAMES):
+    dm, dv = _dirichlet_arrays(thermal, thermal_bc)
+    vals.update(adiabatic=adiabatic, dirichlet_mask=dm, dirichlet_value=dv)
+    for n in (_lib.T3_NAMES if three else _lib.T2_NAMES) + _lib.T_OPT:
         setattr(f, n, ptr(vals.get(n)))
     f._keep = vals
     return f
@@ -128,6 +151,16 @@ def heatdiffusion_PT_(thermal, pt_thermal, thermal_bc, A, B, dt, grid_or_di, *, 
     grid = grid_or_di if isinstance(grid_or_di, Geometry) else legacy_uniform_grid(ni, grid_or_di)
     h = handle or _lib.default_handle(thermal.T.device.index)
     phase = kw.pop("phase", None)
+    stokes = kw.pop("stokes", None)
+    adiabatic = None
+    if stokes is not None and isinstance(A, (dict, list, tuple)):
+        # adiabatic_heating!(thermal, stokes, rheology, phases, _dt) (DiffusionPT_solver.jl:211-213): thermal.adiabatic = (P - P0) α / dt
+        table = [dict(k=A["k"], Cp=A["Cp"], density=dict(kind="PT", rho0=A["rho0"], alpha=A["alpha"], T0=A.get("T0", 0.0)))] if isinstance(A, dict) else list(A)
+        m_ad = thermal_phases(table, SimpleNamespace(max_lxyz=1.0, Vpdτ=1.0))
+        torch.cuda.current_stream(thermal.T.device).synchronize()
+        h.call("jrx_adiabatic_heating", C.c_void_p(ptr(thermal.adiabatic)), C.c_void_p(ptr(stokes.P)), C.c_void_p(ptr(stokes.P0)),
+               C.c_int64(int(np.prod(ni))), C.c_double(float(dt)), C.byref(m_ad), C.c_void_p(ptr(phase.center) if phase is not None else 0))
+        adiabatic = thermal.adiabatic
     if phase is not None:
         if isinstance(A, dict):
             A = [A]
@@ -136,7 +169,7 @@ def heatdiffusion_PT_(thermal, pt_thermal, thermal_bc, A, B, dt, grid_or_di, *, 
             raise ValueError("args.T must be thermal.T in the phase-ratio form")
         m, pf = thermal_phases(A, pt_thermal), thermal_phase_fields(phase, B, ni)
         p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, **kw)
-        f = thermal_fields2d(thermal, pt_thermal)
+        f = thermal_fields2d(thermal, pt_thermal, thermal_bc=thermal_bc, adiabatic=adiabatic)
         cap = int(p.iterMax // p.nout + 2)
         it, nr, nn = np.zeros(cap, dtype=np.int64), np.zeros(cap), C.c_int64(0)
         torch.cuda.current_stream(thermal.T.device).synchronize()
@@ -147,10 +180,10 @@ def heatdiffusion_PT_(thermal, pt_thermal, thermal_bc, A, B, dt, grid_or_di, *, 
         raise ValueError("a multi-phase rheology needs kwargs['phase'] = PhaseRatios")
     if isinstance(A, dict):
         p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, rheology=A, **kw)
-        f = thermal_fields2d(thermal, pt_thermal)
+        f = thermal_fields2d(thermal, pt_thermal, thermal_bc=thermal_bc, adiabatic=adiabatic)
     else:
         p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, **kw)
-        f = thermal_fields2d(thermal, pt_thermal, A, B)
+        f = thermal_fields2d(thermal, pt_thermal, A, B, thermal_bc=thermal_bc)
     cap = int(p.iterMax // p.nout + 2)
     it, nr, nn = np.zeros(cap, dtype=np.int64), np.zeros(cap), C.c_int64(0)
     torch.cuda.current_stream(thermal.T.device).synchronize()
@@ -178,10 +211,10 @@ def thermal_iteration_(thermal, pt_thermal, thermal_bc, A, B, dt, grid, *, check
     ni = thermal._ni
     if isinstance(A, dict):
         p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ, rheology=A)
-        f = thermal_fields2d(thermal, pt_thermal)
+        f = thermal_fields2d(thermal, pt_thermal, thermal_bc=thermal_bc)
     else:
         p = thermal_params2d(ni, grid, thermal_bc, dt, pt_thermal.ϵ)
-        f = thermal_fields2d(thermal, pt_thermal, A, B)
+        f = thermal_fields2d(thermal, pt_thermal, A, B, thermal_bc=thermal_bc)
     torch.cuda.current_stream(thermal.T.device).synchronize()
     d = "3d" if len(ni) == 3 else "2d"
     h.call(f"jrx_thermal{d}_iteration", C.byref(f), C.byref(p))

@@ -138,6 +138,9 @@ typedef struct orc_thermal2d {
     double *H, *shear_heating, *ResT;   /* (nx, ny) */
     double *K, *rhoCp;            /* (nx, ny) array-coefficient form; may be NULL in rheology form */
     double *thetar_dtau, *dtau_rho;     /* (nx, ny) PTThermalCoeffs */
+    const double *adiabatic;            /* (nx, ny) thermal.adiabatic of the rheology forms (adiabatic_heating!, DiffusionPT_kernels.jl:720-746); NULL = absent */
+    const double *dirichlet_mask;       /* (nx+2, ny+2) thermal_bc.dirichlet.mask (Dirichlet.jl, mask/mask.jl); NULL = none */
+    const double *dirichlet_value;      /* (nx+2, ny+2) values, or NULL with dirichlet_const (ConstantDirichletBoundaryCondition) */
 } orc_thermal2d;
 
 typedef struct orc_thermal_params2d {
@@ -153,6 +156,7 @@ typedef struct orc_thermal_params2d {
     /* rheology form (test_diffusion2D.jl): constant conductivity, Cp, PT_Density(rho0, alpha), H */
     int32_t rheology_form;
     double k_const, Cp, rho0, alpha, T0, H_const;
+    double dirichlet_const;             /* value of a ConstantDirichletBoundaryCondition (used when dirichlet_value is NULL) */
 } orc_thermal_params2d;
 
 /* phase-ratio form (rheology_form = 2): per-phase thermal properties + the arrays heatdiffusion_PT!(...; phase = phase_ratios) reads */
@@ -169,6 +173,9 @@ typedef struct orc_thermal_phase_fields {
     const double *phase_qx, *phase_qy, *phase_qz;   /* phase_ratios.Vx (nx+1, ny[, nz]), .Vy, .Vz; phase index fastest */
 } orc_thermal_phase_fields;
 void orc_thermal_set_phases(const orc_thermal_phases *ph, const orc_thermal_phase_fields *pf);   /* NULL, NULL to clear */
+/* adiabatic_heating!(thermal, stokes, rheology, phases, _dt) -- DiffusionPT_kernels.jl:720-746: A = (P - P0) * α * _dt with α the phase-weighted thermal
+ * expansivity of the density laws (PT_Density, T_Density: α; otherwise 0 -- ASSUMED compute_α of GeoParams); phase_c NULL: phase 0 alone */
+void orc_adiabatic_heating(double *A, const double *P, const double *P0, int64_t n, const orc_thermal_phases *ph, const double *phase_c, double _dt);
 
 void orc_thermal_bcs2d(double *T, const orc_thermal_params2d *p);
 void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d *p);
@@ -185,6 +192,7 @@ typedef struct orc_thermal3d {
     double *H, *shear_heating, *ResT;   /* ni */
     double *K, *rhoCp;                  /* ni; may be NULL in the rheology form */
     double *thetar_dtau, *dtau_rho;     /* ni */
+    const double *adiabatic, *dirichlet_mask, *dirichlet_value;      /* as in orc_thermal2d; mask / value (nx+2, ny+2, nz+2) */
 } orc_thermal3d;
 
 typedef struct orc_thermal_params3d {
@@ -199,6 +207,7 @@ typedef struct orc_thermal_params3d {
     int32_t periodic[6];
     int32_t rheology_form;
     double k_const, Cp, rho0, alpha, T0;
+    double dirichlet_const;
 } orc_thermal_params3d;
 
 void orc_thermal_bcs3d(double *T, const orc_thermal_params3d *p);

@@ -87,7 +87,8 @@ def _mkstruct(name, names):
 
 Fields3D = _mkstruct("Fields3D", F3_NAMES)
 Fields2D = _mkstruct("Fields2D", F2_NAMES)
-Thermal2D = _mkstruct("Thermal2D", T2_NAMES)
+T_OPT = ["adiabatic", "dirichlet_mask", "dirichlet_value"]     # optional: NULL when the dict has no such entry
+Thermal2D = _mkstruct("Thermal2D", T2_NAMES + T_OPT)
 
 
 class Params3D(C.Structure):
@@ -118,7 +119,7 @@ class ThermalParams2D(C.Structure):
                 ("periodic", C.c_int32 * 4),
                 ("rheology_form", C.c_int32),
                 ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double),
-                ("T0", C.c_double), ("H_const", C.c_double)]
+                ("T0", C.c_double), ("H_const", C.c_double), ("dirichlet_const", C.c_double)]
 
 
 class Result(C.Structure):
@@ -180,7 +181,7 @@ def fields2d(arr: dict) -> Fields2D:
 
 def thermal2d(arr: dict) -> Thermal2D:
     f = Thermal2D()
-    for n in T2_NAMES:
+    for n in T2_NAMES + T_OPT:
         setattr(f, n, _p(arr.get(n)))
     return f
 
@@ -550,7 +551,7 @@ def vep3d_stress(arr: dict, theta, lam, lamv, rh: Rheology, p: VEPParams3D):
 
 # ---- 3D PT heat diffusion (oracle/thermal3d.c) ----
 T3_NAMES = ["T", "Told", "dT", "qTx", "qTx2", "qTy", "qTy2", "qTz", "qTz2", "H", "shear_heating", "ResT", "K", "rhoCp", "thetar_dtau", "dtau_rho"]
-Thermal3D = _mkstruct("Thermal3D", T3_NAMES)
+Thermal3D = _mkstruct("Thermal3D", T3_NAMES + T_OPT)
 THERMAL_FACES3 = ("left", "right", "front", "back", "top", "bot")
 
 
@@ -562,7 +563,8 @@ class ThermalParams3D(C.Structure):
                 ("constant_flux_on", C.c_int32 * 6), ("constant_flux", C.c_double * 6),
                 ("periodic", C.c_int32 * 6),
                 ("rheology_form", C.c_int32),
-                ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double), ("T0", C.c_double)]
+                ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double), ("T0", C.c_double),
+                ("dirichlet_const", C.c_double)]
 
 
 def thermal_shapes3d(nx, ny, nz):
@@ -598,7 +600,7 @@ def thermal_params3d(ni, _di, dt, eps, *, iterMax=50_000, nout=1000, no_flux=Non
 
 def thermal3d(arr: dict) -> Thermal3D:
     f = Thermal3D()
-    for n in T3_NAMES:
+    for n in T3_NAMES + T_OPT:
         setattr(f, n, _p(arr.get(n)))
     return f
 
@@ -664,3 +666,8 @@ def heatdiffusion_PT_phases(arr: dict, p, m: ThermalPhases, ph: dict) -> dict:
         return heatdiffusion_PT3d(arr, p) if three else heatdiffusion_PT2d(arr, p)
     finally:
         lib().orc_thermal_set_phases(None, None)
+
+
+def adiabatic_heating(A, P, P0, m: "ThermalPhases", phase_c, _dt):
+    """adiabatic_heating!(thermal, stokes, rheology, phases, _dt) -- DiffusionPT_kernels.jl:720-746; phase_c None: phase 0 alone"""
+    lib().orc_adiabatic_heating(_p(A), _p(P), _p(P0), C.c_int64(A.size), C.byref(m), _p(phase_c), C.c_double(_dt))

@@ -58,6 +58,19 @@ const orc_thermal_phases *g_tph = NULL;              /* phase-ratio form (rheolo
 const orc_thermal_phase_fields *g_tpf = NULL;
 void orc_thermal_set_phases(const orc_thermal_phases *ph, const orc_thermal_phase_fields *pf) { g_tph = ph; g_tpf = pf; }
 
+void orc_adiabatic_heating(double *A, const double *P, const double *P0, int64_t n, const orc_thermal_phases *ph, const double *phase_c, double _dt)
+{
+    for (int64_t c = 0; c < n; c++) {
+        double al = 0.0;
+        for (int q = 0; q < ph->nphase; q++) {
+            const double r = phase_c ? phase_c[(size_t)ph->nphase * c + q] : (q == 0 ? 1.0 : 0.0);
+            const double aq = (ph->rho_kind[q] == 1 || ph->rho_kind[q] == 2) ? ph->alpha[q] : 0.0;
+            al += (r == 0.0) ? 0.0 : aq * r;
+        }
+        A[c] = (P[c] - P0[c]) * al * _dt;
+    }
+}
+
 static inline double rhoCp_rheology(const orc_thermal_params2d *p, double T)
 {   /* DiffusionPT_GeoParams.jl:97-104 : compute_heatcapacity * compute_density */
     return p->Cp * (p->rho0 * (1.0 - p->alpha * (T - p->T0)));
@@ -116,7 +129,12 @@ void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d 
             double dr = t->dtau_rho[c];
             double divq = (t->qTx[IDX2(nx + 1, i + 1, j)] - t->qTx[IDX2(nx + 1, i, j)]) * _dx +
                           (t->qTy[IDX2(nx, i, j + 1)] - t->qTy[IDX2(nx, i, j)]) * _dy;
-            if (rc) T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
+            const double adi = (p->rheology_form && t->adiabatic) ? t->adiabatic[c] * Tij : 0.0;        /* + adiabatic[i, j] * T[I1...] of the rheology forms */
+            if (t->dirichlet_mask && t->dirichlet_mask[I1] != 0.0) {      /* isdirichlet -> apply_dirichlet!: A = inv(m) A + m B (mask/mask.jl:49-50) */
+                const double m = t->dirichlet_mask[I1], B = t->dirichlet_value ? t->dirichlet_value[I1] : p->dirichlet_const;
+                T[I1] = (1 - m) * Tij + m * B;
+            } else if (rc) T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c] + adi) + Tij) / (1.0 + dr * rcp * _dt);
+            else if (p->rheology_form && t->adiabatic) T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + t->H[c] + t->shear_heating[c] + adi) + Tij) / (1.0 + dr * rcp * _dt);
             else T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + t->H[c] + t->shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
         }
     orc_thermal_bcs2d(T, p);
@@ -135,7 +153,10 @@ void orc_thermal2d_check_res(const orc_thermal2d *t, const orc_thermal_params2d 
             double rcp = rc ? tph_rhoCp(g_tph, rc, t->T[I1], g_tpf->P[c]) : p->rheology_form ? rhoCp_rheology(p, t->T[I1]) : t->rhoCp[c];
             const double dq = (t->qTx2[IDX2(nx + 1, i + 1, j)] - t->qTx2[IDX2(nx + 1, i, j)]) * _dx +
                               (t->qTy2[IDX2(nx, i, j + 1)] - t->qTy2[IDX2(nx, i, j)]) * _dy;
-            if (rc) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c];
+            const double adi = (p->rheology_form && t->adiabatic) ? t->adiabatic[c] * t->T[I1] : 0.0;
+            if (t->dirichlet_mask && t->dirichlet_mask[I1] != 0.0) t->ResT[c] = 0.0;        /* isNotDirichlet(dirichlet.mask, I1...) ? ... : zero(_T) */
+            else if (rc) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c] + adi;
+            else if (p->rheology_form && t->adiabatic) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + t->H[c] + t->shear_heating[c] + adi;
             else t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + t->H[c] + t->shear_heating[c];
         }
 }

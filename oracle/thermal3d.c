@@ -119,7 +119,12 @@ void orc_thermal3d_iteration(const orc_thermal3d *t, const orc_thermal_params3d 
                 const double divq = (t->qTx[IDX3(nx + 1, ny, i + 1, j, k)] - t->qTx[IDX3(nx + 1, ny, i, j, k)]) * _dx +
                                     (t->qTy[IDX3(nx, ny + 1, i, j + 1, k)] - t->qTy[IDX3(nx, ny + 1, i, j, k)]) * _dy +
                                     (t->qTz[IDX3(nx, ny, i, j, k + 1)] - t->qTz[IDX3(nx, ny, i, j, k)]) * _dz;
-                if (rc) T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+                const double adi = (p->rheology_form && t->adiabatic) ? t->adiabatic[c] * Tc : 0.0;        /* + adiabatic[i, j] * T[I1...] of the rheology forms */
+                if (t->dirichlet_mask && t->dirichlet_mask[I1] != 0.0) {      /* isdirichlet -> apply_dirichlet!: A = inv(m) A + m B (mask/mask.jl:49-50) */
+                    const double m = t->dirichlet_mask[I1], B = t->dirichlet_value ? t->dirichlet_value[I1] : p->dirichlet_const;
+                    T[I1] = (1 - m) * Tc + m * B;
+                } else if (rc) T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c] + adi) + Tc) / (1.0 + dr * rcp * _dt);
+                else if (p->rheology_form && t->adiabatic) T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + t->H[c] + t->shear_heating[c] + adi) + Tc) / (1.0 + dr * rcp * _dt);
                 else T[I1] = (dr * (-divq + t->Told[I1] * rcp * _dt + t->H[c] + t->shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
             }
     orc_thermal_bcs3d(T, p);
@@ -139,7 +144,10 @@ void orc_thermal3d_check_res(const orc_thermal3d *t, const orc_thermal_params3d 
                 const double dq = (t->qTx2[IDX3(nx + 1, ny, i + 1, j, k)] - t->qTx2[IDX3(nx + 1, ny, i, j, k)]) * _dx +
                                   (t->qTy2[IDX3(nx, ny + 1, i, j + 1, k)] - t->qTy2[IDX3(nx, ny + 1, i, j, k)]) * _dy +
                                   (t->qTz2[IDX3(nx, ny, i, j, k + 1)] - t->qTz2[IDX3(nx, ny, i, j, k)]) * _dz;
-                if (rc) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c];
+                const double adi = (p->rheology_form && t->adiabatic) ? t->adiabatic[c] * t->T[I1] : 0.0;
+                if (t->dirichlet_mask && t->dirichlet_mask[I1] != 0.0) t->ResT[c] = 0.0;        /* isNotDirichlet(dirichlet.mask, I1...) ? ... : zero(_T) */
+                else if (rc) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c] + adi;
+                else if (p->rheology_form && t->adiabatic) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + t->H[c] + t->shear_heating[c] + adi;
                 else t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + t->H[c] + t->shear_heating[c];
             }
 }

@@ -125,3 +125,95 @@ def test_phase_form_argument_errors(jr):
     bad = SimpleNamespace(P=args.P, T=thermal.Told)
     with pytest.raises(ValueError):      # args.T must be thermal.T
         jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, s.extra["rheology"], bad, s.dt, s.grid, kwargs=dict(phase=pr, verbose=False))
+
+
+@pytest.mark.parametrize("dim,form", [(2, "array"), (2, "rheology"), (2, "phases"), (3, "array"), (3, "phases")])
+def test_dirichlet_mask_and_adiabatic_heating_match_oracle(jr, oracle, dim, form):
+    """inner Dirichlet cells (constant and array forms, incl. a fractional mask) in every form of heatdiffusion_PT!, and the adiabatic term of the rheology /
+    phase-ratio forms fed by kwargs.stokes (adiabatic_heating!)"""
+    import torch
+    from justrelax_jl_amd.arrays import from_numpy, TemperatureBoundaryConditions
+    from justrelax_jl_amd.checks import max_rel_diff
+    ni = (30, 22) if dim == 2 else (18, 14, 12)
+    if form == "phases":
+        s = jr.miniapps.diffusion2d_multiphase(ni, iterMax=60, nout=20) if dim == 2 else jr.miniapps.diffusion3d_multiphase(ni, iterMax=60, nout=20)
+        _randomise(s, 3)
+    else:
+        s = jr.miniapps.diffusion2d(ni[0], iterMax=60, nout=20) if dim == 2 else jr.miniapps.diffusion3d(ni, iterMax=60, nout=20)
+    ni = s.ni
+    rng = np.random.default_rng(21)
+    gsh = tuple(n + 2 for n in ni)
+    const = form != "array"                     # constant value with a 0/1 + one fractional mask; or a value array whose non-zeros are the mask
+    if const:
+        mask = np.zeros(gsh, order="F")
+        mask[(slice(3, 6),) * dim] = 1.0
+        mask[(8,) * dim] = 0.5
+        dbc = dict(constant=1400.0, mask=mask)
+        omask, oval = mask, None
+    else:
+        vals = np.zeros(gsh, order="F")
+        vals[(slice(4, 7),) * dim] = rng.uniform(1000.0, 2000.0, size=(3,) * dim)
+        dbc = dict(constant=None, mask=vals)
+        omask, oval = np.asfortranarray((vals != 0).astype(float)), vals
+    b = s.flow_bcs
+    dev = torch.device("cuda", torch.cuda.current_device())
+    bc = TemperatureBoundaryConditions(no_flux=b.no_flux, constant_value=b.constant_value, constant_flux=b.constant_flux, periodic=b.periodic,
+                                       dirichlet=dict(constant=dbc["constant"], mask=from_numpy(dbc["mask"], dev)))
+    mk = oracle.thermal_params3d if dim == 3 else oracle.thermal_params2d
+    kw = dict(rheology=s.extra["rheology"]) if form == "rheology" else {}
+    p = mk(ni, s.grid._di["center"], s.dt, 1e-30, iterMax=60, nout=20, no_flux=b.no_flux, constant_value=b.constant_value, constant_flux=b.constant_flux,
+           periodic=b.periodic, **kw)
+    p.dirichlet_const = 1400.0
+    ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    ref["dirichlet_mask"] = omask
+    if oval is not None:
+        ref["dirichlet_value"] = oval
+    # stokes.P, P0 for the adiabatic term of the rheology forms
+    P = np.asfortranarray(rng.uniform(1e8, 3e8, size=ni))
+    P0 = np.asfortranarray(rng.uniform(1e8, 3e8, size=ni))
+    stokes = SimpleNamespace(P=from_numpy(P, dev), P0=from_numpy(P0, dev))
+    thermal = jr.ThermalArrays(jr.AMDGPUBackend, ni)
+    for name in ("T", "Told", "H", "shear_heating"):
+        getattr(thermal, name).copy_(from_numpy(s.arrays[name], dev))
+    kwargs = dict(iterMax=60, nout=20, verbose=False)
+    if form == "phases":
+        pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, ni)
+        for k, v in s.extra["phase_ratios"].items():
+            getattr(pr, k).copy_(from_numpy(v, dev))
+        args = SimpleNamespace(P=from_numpy(s.arrays["P"], dev), T=thermal.T)
+        pt = jr.PTThermalCoeffs.from_phases(jr.AMDGPUBackend, s.extra["rheology"], pr, args, s.dt, ni, s.extra["di"], s.extra["li"], ϵ=1e-30, CFL=s.pt["CFL"])
+        _, m, ph = _oracle_inputs(oracle, s, 1e-30, iterMax=60, nout=20)
+        ph["P"] = ref["P"]
+        ref["adiabatic"] = np.zeros(ni, order="F")
+        oracle.adiabatic_heating(ref["adiabatic"], P, P0, m, s.extra["phase_ratios"]["center"], 1.0 / s.dt)
+        r_ref = oracle.heatdiffusion_PT_phases(ref, p, m, ph)
+        r = jr.heatdiffusion_PT_(thermal, pt, bc, s.extra["rheology"], args, s.dt, s.grid, kwargs=dict(kwargs, phase=pr, stokes=stokes))
+    else:
+        K, ρCp = from_numpy(s.arrays["K"], dev), from_numpy(s.arrays["rhoCp"], dev)
+        pt = jr.PTThermalCoeffs(jr.AMDGPUBackend, K, ρCp, s.dt, s.extra["di"], s.extra["li"], CFL=s.pt["CFL"], ϵ=1e-30)
+        solve = oracle.heatdiffusion_PT3d if dim == 3 else oracle.heatdiffusion_PT2d
+        if form == "rheology":
+            rh = s.extra["rheology"]
+            m = oracle.thermal_phases([dict(k=rh["k"], Cp=rh["Cp"], density=dict(kind="PT", rho0=rh["rho0"], alpha=rh["alpha"], T0=rh.get("T0", 0.0)))], 1.0, 1.0)
+            ref["adiabatic"] = np.zeros(ni, order="F")
+            oracle.adiabatic_heating(ref["adiabatic"], P, P0, m, None, 1.0 / s.dt)
+            r_ref = solve(ref, p)
+            r = jr.heatdiffusion_PT_(thermal, pt, bc, rh, None, s.dt, s.grid, kwargs=dict(kwargs, stokes=stokes))
+        else:
+            r_ref = solve(ref, p)
+            r = jr.heatdiffusion_PT_(thermal, pt, bc, K, ρCp, s.dt, s.grid, kwargs=kwargs)
+    assert list(r.iter_count) == list(r_ref["iter_count"]) == [20, 40, 60]
+    assert np.allclose(r.norm_ResT, r_ref["norm_ResT"], rtol=1e-9)
+    T = jr.to_numpy(thermal.T)
+    assert np.abs(T - ref["T"]).max() <= 1e-9 * np.abs(ref["T"]).max()
+    res = jr.to_numpy(thermal.ResT)
+    scale = max(np.abs(ref["ResT"]).max(), 1e-7)
+    assert np.abs(res - ref["ResT"]).max() <= 1e-7 * scale
+    inner = tuple(slice(1, -1) for _ in range(dim))
+    assert (res[omask[inner] != 0] == 0.0).all()
+    if const:
+        assert (T[(slice(3, 6),) * dim] == 1400.0).all()
+    else:
+        assert np.array_equal(T[(slice(4, 7),) * dim], oval[(slice(4, 7),) * dim])
+    if form != "array":
+        assert max_rel_diff(jr.to_numpy(thermal.adiabatic), ref["adiabatic"]) <= 1e-14 and np.abs(ref["adiabatic"]).max() > 0

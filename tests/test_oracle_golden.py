@@ -416,3 +416,52 @@ def test_shearband2d_strain_increment_variant(oracle, jr, displacement):
             assert np.array_equal(s.arrays[k], plain[k]), k
     else:       # velocity BCs: the ghosts of U lag those of V by one iteration, the converged fields agree to the solver tolerance
         assert np.abs(s.arrays["txx"] - plain["txx"]).max() < 1e-5
+
+
+def test_thermal_dirichlet_mask_and_adiabatic_term(oracle, jr):
+    """Inner Dirichlet cells (thermal_bc.dirichlet, Dirichlet.jl:72-135 / mask/mask.jl:47-50; known answers of test_boundary_conditions2D.jl:280-320: masked
+    entries take the value, the others keep theirs) and the adiabatic term of the rheology forms (DiffusionPT_kernels.jl:553-601, 720-729)."""
+    from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+    s = jr.miniapps.diffusion2d(24, iterMax=400, nout=50)
+    b = s.flow_bcs
+    p = oracle.thermal_params2d(s.ni, s.grid._di["center"], s.dt, 1e-30, iterMax=400, nout=50, no_flux=b.no_flux, constant_value=b.constant_value,
+                                constant_flux=b.constant_flux, periodic=b.periodic)
+    oracle.thermal_bcs2d(s.arrays["T"], p)
+    base = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    # constant Dirichlet block (ConstantDirichletBoundaryCondition(5, mask) of the reference test, here 1234 K on cells 4:7 x 4:7 of the ghosted array)
+    mask = np.zeros_like(s.arrays["T"], order="F")
+    mask[3:7, 3:7] = 1.0
+    a = {k: v.copy(order="F") for k, v in base.items()}
+    a["dirichlet_mask"] = mask
+    p.dirichlet_const = 1234.0
+    oracle.heatdiffusion_PT2d(a, p)
+    assert (a["T"][3:7, 3:7] == 1234.0).all() and (a["ResT"][2:6, 2:6] == 0.0).all()
+    free = {k: v.copy(order="F") for k, v in base.items()}
+    oracle.heatdiffusion_PT2d(free, p)
+    assert np.abs(a["T"][7, 5] - free["T"][7, 5]) > 1.0 and np.abs(a["T"][20, 20] - free["T"][20, 20]) < 1e-3       # the block cools the cells next to it only
+    # value array: DirichletBoundaryCondition(A) -- the non-zero entries of A are the mask
+    vals = np.zeros_like(mask, order="F")
+    vals[10:12, 5:9] = np.linspace(1500.0, 1600.0, 8).reshape(2, 4)
+    c = {k: v.copy(order="F") for k, v in base.items()}
+    c["dirichlet_mask"], c["dirichlet_value"] = np.asfortranarray((vals != 0).astype(float)), vals
+    oracle.heatdiffusion_PT2d(c, p)
+    assert np.array_equal(c["T"][10:12, 5:9], vals[10:12, 5:9])
+    # a fractional mask blends: T <- (1 - m) T + m value in every iteration (mask/mask.jl:49-50)
+    d = {k: v.copy(order="F") for k, v in base.items()}
+    half = np.zeros_like(mask, order="F")
+    half[15, 15] = 0.5
+    d["dirichlet_mask"] = half
+    T0 = d["T"][15, 15]
+    p.iterMax, p.nout = 3, 1
+    oracle.heatdiffusion_PT2d(d, p)
+    assert d["T"][15, 15] == pytest.approx(1234.0 + (T0 - 1234.0) * 0.5 ** 3, rel=1e-14)
+    # adiabatic heating: A = (P - P0) * alpha / dt, phase weighted; only PT_Density / T_Density carry an alpha
+    rheo = [dict(k=3.0, Cp=1e3, density=dict(kind="PT", rho0=3e3, alpha=2e-5)), dict(k=3.0, Cp=1e3, density=dict(kind="constant", rho0=3e3))]
+    m = oracle.thermal_phases(rheo, 1.0, 1.0)
+    n = 6
+    P, P0 = np.linspace(1e8, 2e8, n), np.full(n, 0.5e8)
+    r = np.zeros((2, n), order="F")
+    r[0], r[1] = [1, 0, 0.25, 0.5, 1, 0], [0, 1, 0.75, 0.5, 0, 1]
+    A = np.zeros(n)
+    oracle.adiabatic_heating(A, P, P0, m, r, 1.0 / 50.0)
+    assert np.allclose(A, (P - P0) * (2e-5 * r[0]) / 50.0, rtol=1e-15)
