@@ -65,11 +65,9 @@ def _dirichlet_arrays(thermal, thermal_bc):
         raise ValueError(f"the Dirichlet mask must have the shape of thermal.T {tuple(thermal.T.shape)}")
     if dbc.get("constant") is not None:
         return m, None
-    if "_mask01" not in dbc:                       # Mask(copy(A)) filled with T.(.!iszero.(A))
-        t = torch.empty_like(m)                    # keeps the column-major strides
-        t.copy_((m != 0).to(m.dtype))
-        dbc["_mask01"] = t
-    return dbc["_mask01"], m
+    t = torch.empty_like(m)                        # Mask(copy(A)) filled with T.(.!iszero.(A)); keeps the column-major strides
+    t.copy_((m != 0).to(m.dtype))
+    return t, m
 
 
 def thermal_fields2d(thermal, pt_thermal, K=None, ρCp=None, thermal_bc=None, adiabatic=None):
