@@ -16,6 +16,7 @@ enum { TL = 0, TR = 1, TT = 2, TB = 3 };
 struct TArgs {
     jrx_thermal2d_fields t;
     jrx_thermal2d_params p;
+    bool wpt = false;      // phase-ratio form: update_T! also writes next iteration's θr_dτ, dτ_ρ (update_pt_thermal_arrays! folded in)
 };
 
 __device__ __forceinline__ double rhoCp_of(const jrx_thermal2d_params &p, const double *rhoCp, i64 c, double T)
@@ -140,6 +141,14 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
         else Tn = hasadi ? (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c] + adi) + Tij) / (1.0 + dr * rcp * _dt)
                          : (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tij) / (1.0 + dr * rcp * _dt);
         a.t.T[I1] = Tn;
+        if constexpr (PH) {
+            if (a.wpt) {      // update_pt_thermal_arrays! of the next iteration (DiffusionPT_coefficients.jl:123-136) from the new T of this cell
+                double th_, dr_;
+                tph_pt_coeffs(ph.m, ph.f.phase_c + ph.m.nphase * c, Tn, ph.f.P[c], _dt, th_, dr_);
+                a.t.thetar_dtau[c] = th_;
+                a.t.dtau_rho[c] = dr_;
+            }
+        }
         if (BCF) {
             const int xs = i == 0 ? 0 : (i == nx - 1 ? 1 : -1), ys = j == 0 ? 0 : (j == ny - 1 ? 1 : -1);
             if (xs >= 0 || ys >= 0) thermal_ghosts2d(a.p, a.t.T, nx + 2, I1, xs, ys, Tn);
@@ -354,10 +363,10 @@ jrx_status launch_tbcs(jrx_handle *h, hipStream_t s, double *T, const jrx_therma
 
 // fuse_bc: thermal_bcs! refreshed by the update kernel itself (no periodic face, no neighbour rank, grid at least 2 cells wide)
 template <class PHT>
-jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p, const PHT &ph, bool fuse_bc = false)
+jrx_status enqueue_titer(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_thermal2d_params *p, const PHT &ph, bool fuse_bc = false, bool wpt = false)
 {
     TArgs a;
-    a.t = *t; a.p = *p;
+    a.t = *t; a.p = *p; a.wpt = wpt;
     const int nx = (int)p->nx, ny = (int)p->ny;
     hipStream_t s = h->stream;
     hipLaunchKernelGGL(k_flux2d<PHT>, dim3((unsigned)(((i64)(nx + 1) * (ny + 1) + 255) / 256)), dim3(256), 0, s, a, ph);
@@ -437,6 +446,7 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
     JRX_HIP(h, hipMemcpyAsync(t->Told, t->T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));   // @copy thermal.Told thermal.T
     int64_t iter = 0, cnt = 0;
     double err = 2 * p->eps;
+    bool pt_fresh = false;
     TArgs a;
     a.t = *t; a.p = *p;
     // iterations nobody observes: one fused launch, ping-pong between the caller's (T, qT) and a library-owned set (option thermal_fused)
@@ -461,7 +471,10 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
         const bool observed = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
         a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy;
         if constexpr (PH) {      // update_pt_thermal_arrays!(pt_thermal, phase, rheology, args, _dt) -- DiffusionPT_solver.jl:233-234
-            JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, s, t->thetar_dtau, t->dtau_rho, cur.T, nx, ny, 1, 2, 1.0 / p->dt, ph));
+            // on unobserved iterations update_T! writes the coefficients of the next iteration itself (same values: they depend on the cell's own new T
+            // only); observed iterations leave pt_thermal as the reference does, and the stand-alone kernel runs before the following iteration
+            if (!pt_fresh) JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, s, t->thetar_dtau, t->dtau_rho, cur.T, nx, ny, 1, 2, 1.0 / p->dt, ph));
+            pt_fresh = !observed;
         }
         if (fusable && !observed) {
             if (FTX == 256) hipLaunchKernelGGL(k_thermal2d_fused<256>, dim3((unsigned)(ntx * ny)), dim3(256), 0, s, a, oth, ntx);
@@ -472,7 +485,7 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
             const TSet2 tmp = cur; cur = oth; oth = tmp;
         } else {
             tc.T = cur.T; tc.qTx = cur.qx; tc.qTy = cur.qy;
-            JRX_TRY(enqueue_titer(h, &tc, p, ph, true));
+            JRX_TRY(enqueue_titer(h, &tc, p, ph, true, PH && pt_fresh));
         }
         iter++;
         if (iter % p->nout == 0) {

@@ -16,6 +16,7 @@ enum { XL = 0, XR = 1, YF = 2, YB = 3, ZT = 4, ZB = 5 };
 struct T3Args {
     jrx_thermal3d_fields t;
     jrx_thermal3d_params p;
+    bool wpt = false;      // phase-ratio form: update_T! also writes next iteration's θr_dτ, dτ_ρ (update_pt_thermal_arrays! folded in)
 };
 
 __device__ __forceinline__ double rhoCp3_of(const jrx_thermal3d_params &p, const double *rhoCp, i64 c, double T)
@@ -176,6 +177,14 @@ __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a, const PHT ph)
         else Tn = hasadi ? (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c] + adi) + Tc) / (1.0 + dr * rcp * _dt)
                          : (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
         a.t.T[I1] = Tn;
+        if constexpr (PH) {
+            if (a.wpt) {      // update_pt_thermal_arrays! of the next iteration (DiffusionPT_coefficients.jl:123-136) from the new T of this cell
+                double th_, dr_;
+                tph_pt_coeffs(ph.m, ph.f.phase_c + ph.m.nphase * c, Tn, ph.f.P[c], _dt, th_, dr_);
+                const_cast<double *>(a.t.thetar_dtau)[c] = th_;
+                const_cast<double *>(a.t.dtau_rho)[c] = dr_;
+            }
+        }
         if (BCF) {
             const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
             const int mask = ((i == 0 || i == nx - 1) ? 1 : 0) | ((j == 0 || j == ny - 1) ? 2 : 0) | ((k == 0 || k == nz - 1) ? 4 : 0);
@@ -415,10 +424,10 @@ static jrx_status ensure_tscratch(jrx_handle *h, int nx, int ny, int nz)
 }
 
 template <class PHT>
-jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, const PHT &ph, bool q2 = true, bool fuse_bc = false)
+jrx_status enqueue_titer3(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_thermal3d_params *p, const PHT &ph, bool q2 = true, bool fuse_bc = false, bool wpt = false)
 {
     T3Args a;
-    a.t = *t; a.p = *p;
+    a.t = *t; a.p = *p; a.wpt = wpt;
     const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
     hipStream_t s = h->stream;
     if (q2) hipLaunchKernelGGL((k_flux3d<true, PHT>), GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, ph);
@@ -491,6 +500,7 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
     JRX_HIP(h, hipMemcpyAsync(t->Told, t->T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));   // @copy thermal.Told thermal.T
     int64_t iter = 0, cnt = 0;
     double err = 2 * p->eps;
+    bool pt_fresh = false;
     T3Args a;
     a.t = *t; a.p = *p;
     // Iterations nobody observes run as one fused launch that ping-pongs (T, qT) between the caller's arrays and a library-owned set
@@ -515,8 +525,13 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
         // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one
         const bool q2 = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
         a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy; a.t.qTz = cur.qz;
-        if constexpr (PH)      // update_pt_thermal_arrays!(pt_thermal, phase, rheology, args, _dt) -- DiffusionPT_solver.jl:233-234
-            JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, s, const_cast<double *>(t->thetar_dtau), const_cast<double *>(t->dtau_rho), cur.T, nx, ny, nz, 3, 1.0 / p->dt, ph));
+        if constexpr (PH) {    // update_pt_thermal_arrays!(pt_thermal, phase, rheology, args, _dt) -- DiffusionPT_solver.jl:233-234
+            // on unobserved iterations update_T! writes the coefficients of the next iteration itself (same values: they depend on the cell's own new T
+            // only); observed iterations leave pt_thermal as the reference does, and the stand-alone kernel runs before the following iteration
+            if (!pt_fresh) JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, s, const_cast<double *>(t->thetar_dtau), const_cast<double *>(t->dtau_rho), cur.T, nx, ny, nz, 3, 1.0 / p->dt, ph));
+            pt_fresh = !q2;
+            a.wpt = pt_fresh;
+        }
         if (fusable && !q2) {
 #define THL(TX_, KZ_, R_, XG_)                                                                                                      \
     if (FTX == TX_ && FKZ == KZ_ && FR == R_ && FXG == XG_) {                                                                       \
@@ -532,7 +547,7 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
             JRX_LAUNCH_CHECK(h);
             const TSet tmp = cur; cur = oth; oth = tmp;
         } else {
-            JRX_TRY(enqueue_titer3(h, &a.t, p, ph, q2, true));
+            JRX_TRY(enqueue_titer3(h, &a.t, p, ph, q2, true, a.wpt));
         }
         iter++;
         if (iter % p->nout == 0) {
