@@ -777,9 +777,32 @@ __global__ __launch_bounds__(256) void k_vep_vertex(const VepArgs a)
     else vep_vertex_at<false>(a, i, j);
 }
 
+// operands of the centre half, loaded up front: in the merged launch they are requested BEFORE the vertex half stores anything (the compiler cannot move
+// loads above stores through unrelated pointers), so that the two halves' memory round trips overlap
+struct CentreOps { double e, exyc, exx, eyy, txx, tyy, txyc, toxx, toyy, toxyc, theta, lam, EII, dexx, deyy, dexyc; };
+template <bool SOFT, bool SI>
+__device__ __forceinline__ CentreOps vep_centre_load(const VepArgs &a, const int i, const int j)
+{
+    const int nx = a.nx;
+    const i64 c = i + (i64)nx * j;
+    CentreOps o;
+    o.e = a.f.eta[c];
+    o.exyc = (V2(a.f.exy, i, j) + V2(a.f.exy, i + 1, j) + V2(a.f.exy, i, j + 1) + V2(a.f.exy, i + 1, j + 1)) / 4;
+    o.exx = a.f.exx[c]; o.eyy = a.f.eyy[c];
+    o.txx = a.f.txx[c]; o.tyy = a.f.tyy[c]; o.txyc = a.f.txy_c[c];
+    o.toxx = a.f.toxx[c]; o.toyy = a.f.toyy[c]; o.toxyc = a.f.toxy_c[c];
+    o.theta = a.theta[c]; o.lam = a.lam[c];
+    o.EII = SOFT ? a.f.EII_pl[c] : 0.0;
+    if (SI) {      // Δεij = (Δε.xx, Δε.yy, av_shear(Δε.xy)) -- cache_tensors, StressUpdate.jl:226-246
+        o.dexyc = (V2(a.f.dexy, i, j) + V2(a.f.dexy, i + 1, j) + V2(a.f.dexy, i, j + 1) + V2(a.f.dexy, i + 1, j + 1)) / 4;
+        o.dexx = a.f.dexx[c]; o.deyy = a.f.deyy[c];
+    } else o.dexyc = o.dexx = o.deyy = 0.0;
+    return o;
+}
+
 // update_stresses_center_vertex_ps! -- centre half (+ Pr_c, τII, η_vep)
 template <bool SOFT, bool SI = false>
-__device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, const int j)
+__device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, const int j, const CentreOps &o)
 {
     const int nx = a.nx, np = a.rh.nphase;
     const i64 c = i + (i64)nx * j;
@@ -789,16 +812,14 @@ __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, con
     bool is_pl; double eta_reg;
     plastic_params(a.rh, rc, is_pl, eta_reg);
     const double K = ratio_avg(a.rh.Kb, rc, np);
-    const double e = a.f.eta[c];
+    const double e = o.e;
     const double dtr = SI ? 1.0 / (a.theta_dtau * a.dt + e * _Gdt + a.dt) : 1.0 / (a.theta_dtau + e * _Gdt + 1.0);
-    const double exyc = (V2(a.f.exy, i, j) + V2(a.f.exy, i + 1, j) + V2(a.f.exy, i, j + 1) + V2(a.f.exy, i + 1, j + 1)) / 4;
-    const double eij[3] = {a.f.exx[c], a.f.eyy[c], exyc};
-    double tij[3] = {a.f.txx[c], a.f.tyy[c], a.f.txy_c[c]};
-    const double toij[3] = {a.f.toxx[c], a.f.toyy[c], a.f.toxy_c[c]};
+    const double eij[3] = {o.exx, o.eyy, o.exyc};
+    double tij[3] = {o.txx, o.tyy, o.txyc};
+    const double toij[3] = {o.toxx, o.toyy, o.toxyc};
     double d[3];
-    if (SI) {      // Δεij = (Δε.xx, Δε.yy, av_shear(Δε.xy)) -- cache_tensors, StressUpdate.jl:226-246
-        const double dexyc = (V2(a.f.dexy, i, j) + V2(a.f.dexy, i + 1, j) + V2(a.f.dexy, i, j + 1) + V2(a.f.dexy, i + 1, j + 1)) / 4;
-        const double deij[3] = {a.f.dexx[c], a.f.deyy[c], dexyc};
+    if (SI) {
+        const double deij[3] = {o.dexx, o.deyy, o.dexyc};
 #pragma unroll
         for (int q = 0; q < 3; q++) d[q] = dev_stress_inc_dt(tij[q], toij[q], e, deij[q], _Gdt, dtr, a.dt);
     } else {
@@ -810,9 +831,9 @@ __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, con
     double dQdt[3], dQdP, dFdP;
     plastic_grad(a.rh, rc, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
-    const double Pr = a.theta[c];
-    const double F = yield_F<SOFT>(a.rh, rc, Pr, tII, SOFT ? a.f.EII_pl[c] : 0.0);
-    double l = a.lam[c];
+    const double Pr = o.theta;
+    const double F = yield_F<SOFT>(a.rh, rc, Pr, tII, o.EII);
+    double l = o.lam;
     if (is_pl && tII != 0.0 && F > 0) {
         l = fma(1.0 - a.rel, l, a.rel * (fmax(F, 0.0) / (SI ? e * dtr * a.dt + eta_reg + vol : e * dtr + eta_reg + vol)));
         a.lam[c] = l;
@@ -841,9 +862,9 @@ __global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t / a.nx, i = t - j * a.nx;
     if (j >= a.ny) return;
-    if (a.si) { if (a.soft) vep_centre_at<true, true>(a, i, j); else vep_centre_at<false, true>(a, i, j); }
-    else if (a.soft) vep_centre_at<true>(a, i, j);
-    else vep_centre_at<false>(a, i, j);
+    if (a.si) { if (a.soft) vep_centre_at<true, true>(a, i, j, vep_centre_load<true, true>(a, i, j)); else vep_centre_at<false, true>(a, i, j, vep_centre_load<false, true>(a, i, j)); }
+    else if (a.soft) vep_centre_at<true>(a, i, j, vep_centre_load<true, false>(a, i, j));
+    else vep_centre_at<false>(a, i, j, vep_centre_load<false, false>(a, i, j));
 }
 // both halves in one launch: the vertex half averages the OLD centre stresses, so the centre half must write τxx, τyy elsewhere
 // (a.txx_out / a.tyy_out; the caller then swaps the pointers)
@@ -853,8 +874,11 @@ __global__ __launch_bounds__(256) void k_vep_stress2d(const VepArgs a)
     const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
     const int j = t / (a.nx + 1), i = t - j * (a.nx + 1);
     if (j > a.ny) return;
+    const bool cell = i < a.nx && j < a.ny;
+    CentreOps o = {};
+    if (cell) o = vep_centre_load<SOFT, SI>(a, i, j);          // before the vertex half's stores
     vep_vertex_at<SOFT, SI>(a, i, j);
-    if (i < a.nx && j < a.ny) vep_centre_at<SOFT, SI>(a, i, j);
+    if (cell) vep_centre_at<SOFT, SI>(a, i, j, o);
 }
 
 // compute_τ_nonlinear! 2D: single phase (StressKernels.jl:266-307) / phases at the cell centres (:310-351) with
