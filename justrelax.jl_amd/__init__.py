@@ -17,13 +17,14 @@ from .arrays import (DisplacementBoundaryConditions, PhaseRatios, PTStokesCoeffs
                      from_numpy, fzeros, to_numpy)
 from .grid import (IGG, Geometry, finalize_global_grid, init_global_grid, legacy_uniform_grid,  # noqa: F401
                    nx_g, ny_g, nz_g)
+from .convert import Array_, PTArray_, checkpointing_npz, copy_, load_checkpoint_npz  # noqa: F401
 from . import miniapps  # noqa: F401
 
 
 def __getattr__(name):
     # the operator API is imported lazily: it loads the HIP shared library and fails loudly if absent
     import importlib
-    if name.startswith("_") or name in ("stokes", "thermal", "halo", "checks", "build", "arrays", "grid", "backend"):
+    if name.startswith("_") or name in ("stokes", "thermal", "halo", "checks", "build", "arrays", "grid", "backend", "convert"):
         raise AttributeError(name)
     for sub in ("stokes", "thermal", "halo"):
         mod = importlib.import_module(f"{__name__}.{sub}")
