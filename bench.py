@@ -139,10 +139,24 @@ def launch_ranks(args, argv) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max = "quota period"; the GPU boxes give a 16-CPU quota on
+    a 256-thread host, where 128 OpenMP threads time-slice and run 8x slower than 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(n_cpu: int, budget_s: float):
     """The oracle (CPU restatement, 6 unfused kernels, OpenMP) timed on this host's cores."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as orc
+    orc.set_num_threads(usable_cpus())
     from __graft_entry__ import load_package
     jr = load_package()
     from justrelax_jl_amd import checks
@@ -151,6 +165,11 @@ def cpu_baseline(n_cpu: int, budget_s: float):
     s = jr.miniapps.solvi3d(n_cpu)
     p = checks.oracle_params3d(orc, s)
     et = orc.compute_maxloc(s.arrays["eta"])
+    # NUMA placement: every array re-allocated and first touched by the OpenMP threads that work on its z slabs (numpy had placed all pages
+    # on the node of the main thread: 31 GB/s on a 128-thread host instead of what its memory system gives)
+    for k in list(s.arrays):
+        s.arrays[k] = orc.first_touch(s.arrays[k])
+    et = orc.first_touch(et)
     orc.stokes3d_iteration(s.arrays, et, p)          # warm
     t0, it = time.perf_counter(), 0
     while True:
@@ -506,8 +525,8 @@ def run_rank(args) -> int:
                 runs.append({"n": nc, "it_per_s": ips, "iterations": it, "seconds": secs, "cell_updates_per_s": ips * nc ** 3,
                              "effective_GBps_at_600B_as_written": ips * nc ** 3 * 600.0 / 1e9})
             big = runs[-1]
-            out["cpu_baseline"] = {"value": big["cell_updates_per_s"] / cells, "unit": "it/s", "cores": thr, "kind": "port",
-                                   "sample": f"oracle (6 unfused OpenMP kernels, {thr} threads) on SolVi3D {big['n']}^3: {big['iterations']} iterations in "
+            out["cpu_baseline"] = {"value": big["cell_updates_per_s"] / cells, "unit": "it/s", "cores": thr, "host_logical_cpus": os.cpu_count(), "kind": "port",
+                                   "sample": f"oracle (6 unfused OpenMP kernels, {thr} threads = the CPUs this job may use: affinity mask capped by the cgroup quota) on SolVi3D {big['n']}^3: {big['iterations']} iterations in "
                                              f"{big['seconds']:.1f} s = {big['it_per_s']:.3f} it/s measured at that size; `value` is that rate scaled by "
                                              f"cell count to a {n}^3 block (a {n}^3 host copy of the fields does not fit the CPU leg's time budget)",
                                    "measured": runs}

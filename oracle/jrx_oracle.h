@@ -341,6 +341,8 @@ void orc_set_self_halo(int px, int py, int pz);
 void orc_self_halo(double *A, const int64_t ext[3], const int64_t n[3]);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
+void orc_first_touch_copy(double *dst, const double *src, int64_t slab, int64_t nslab);
 
 #ifdef __cplusplus
 }

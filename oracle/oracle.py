@@ -350,6 +350,10 @@ def num_threads() -> int:
     return lib().orc_num_threads()
 
 
+def set_num_threads(n: int):
+    lib().orc_set_num_threads(C.c_int(int(n)))
+
+
 # ---------------------------------------------------------------- 2D multiphase VEP (shear band)
 VEP_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Ux", "Uy", "exx", "eyy", "exy", "exy_c", "eplxx", "eplyy", "eplxy", "eplxy_c",
              "dexy_c", "dexy", "txx", "tyy", "txy", "txy_c", "tII", "toxx", "toyy", "toxy", "toxy_c", "eta", "eta_v", "eta_vep",
@@ -671,3 +675,13 @@ def heatdiffusion_PT_phases(arr: dict, p, m: ThermalPhases, ph: dict) -> dict:
 def adiabatic_heating(A, P, P0, m: "ThermalPhases", phase_c, _dt):
     """adiabatic_heating!(thermal, stokes, rheology, phases, _dt) -- DiffusionPT_kernels.jl:720-746; phase_c None: phase 0 alone"""
     lib().orc_adiabatic_heating(_p(A), _p(P), _p(P0), C.c_int64(A.size), C.byref(m), _p(phase_c), C.c_double(_dt))
+
+
+def first_touch(a: np.ndarray) -> np.ndarray:
+    """a copy of the Fortran-ordered array `a` whose pages are first touched by the OpenMP threads that own the corresponding slabs of the slowest index
+    (NUMA placement for the timed CPU baseline of bench.py)"""
+    assert a.flags.f_contiguous and a.dtype == np.float64
+    out = np.empty(a.shape, dtype=np.float64, order="F")
+    nslab = a.shape[-1]
+    lib().orc_first_touch_copy(_p(out), _p(a), C.c_int64(a.size // nslab), C.c_int64(nslab))
+    return out

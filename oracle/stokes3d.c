@@ -8,6 +8,16 @@
 #include <omp.h>
 
 int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+
+/* NUMA placement for the timed CPU baseline (bench.py cpu_baseline): copies `nslab` contiguous slabs of `slab` doubles with the static schedule over the
+ * slowest index that every kernel of this file uses, so that a freshly allocated `dst` is first touched -- and therefore placed -- by the thread that
+ * will work on it.  Values are unchanged. */
+void orc_first_touch_copy(double *dst, const double *src, int64_t slab, int64_t nslab)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nslab; c++) memcpy(dst + (size_t)c * (size_t)slab, src + (size_t)c * (size_t)slab, (size_t)slab * sizeof(double));
+}
 
 /* array extents (src/types/constructors/stokes.jl:27-34,196-212,241-247) */
 #define NVX1 (nx + 1)
