@@ -139,24 +139,11 @@ def launch_ranks(args, argv) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def usable_cpus() -> int:
-    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max = "quota period"; the GPU boxes give a 16-CPU quota on
-    a 256-thread host, where 128 OpenMP threads time-slice and run 8x slower than 16)"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
-        if q != "max":
-            n = min(n, max(1, int(int(q) / int(per))))
-    except Exception:
-        pass
-    return max(1, n)
-
-
 def cpu_baseline(n_cpu: int, budget_s: float):
     """The oracle (CPU restatement, 6 unfused kernels, OpenMP) timed on this host's cores."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as orc
-    orc.set_num_threads(usable_cpus())
+    orc.set_num_threads(orc.usable_cpus())      # affinity mask capped by the cgroup CPU quota (16 CPUs on the GPU boxes' 256-thread hosts)
     from __graft_entry__ import load_package
     jr = load_package()
     from justrelax_jl_amd import checks

@@ -132,6 +132,20 @@ class Result(C.Structure):
 _lib = None
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max = "quota period").  The GPU boxes give a 16-CPU quota
+    on a 256-thread host, where OpenMP's default of one thread per logical CPU time-slices and runs ~8x slower than 16 threads."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -154,6 +168,9 @@ def lib():
         L.orc_stokes3d_solve.restype = C.c_int32
         L.orc_stokes2d_solve.restype = C.c_int32
         L.orc_heatdiffusion_PT2d.restype = C.c_int32
+        import os
+        if "OMP_NUM_THREADS" not in os.environ:          # default: as many threads as the job has CPUs
+            L.orc_set_num_threads(C.c_int(usable_cpus()))
         _lib = L
     return _lib
 
