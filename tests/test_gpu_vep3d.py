@@ -138,6 +138,32 @@ def test_vep3d_solve_matches_oracle_over_iterations(jr, oracle):
         assert np.abs(out[k] - ref[k])[m].max() <= 1e-9 * scale, k
 
 
+@pytest.mark.parametrize("ni,iters", [((96, 80, 72), 12), ((160, 160, 160), 6), ((256, 256, 256), 4)])
+def test_vep3d_solve_matches_oracle_on_a_multi_tile_grid(jr, oracle, ni, iters):
+    """the whole 3D VEP driver on grids that span several 62-node lane segments, row blocks, 16-plane chunks of the z-marching edge kernel and z chunks of
+    the pre kernel (160^3 and 256^3: more tiles than fit on the chip at once, every XCD slab populated; 256^3 is the size the bench quotes), yielding state, two checks"""
+    from justrelax_jl_amd.checks import interior_mask3d
+    s = jr.miniapps.shearband3d(ni, iterMax=iters - 1, nout=iters // 2)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    rng = np.random.default_rng(13)
+    for c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):
+        s.arrays["to" + c][...] = rng.uniform(-1.5, 1.5, size=s.arrays["to" + c].shape)
+        s.arrays["t" + c][...] = s.arrays["to" + c]
+    ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    r_ref = oracle.stokes3d_vep_solve(ref, oracle.rheology_struct(s.extra["phases"]), _params(oracle, s))
+    stokes, pr, ρg = _upload(jr, s)
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=s.kwargs)
+    out = _download(jr, stokes)
+    assert r.iter == r_ref["iter"] == iters
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-9)
+    assert (ref["eplyz"] != 0).any() and (ref["eplyz"] == 0).any()
+    for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII", "eta", "eta_vep", "eplxx", "eplyz", "eplxz",
+              "eplxy", "EII_pl", "EVol_pl", "Rx", "Ry", "Rz", "RP"):
+        m = interior_mask3d(k, ref[k].shape)
+        scale = max(np.abs(ref[k]).max(), 1e-300)
+        assert np.abs(out[k] - ref[k])[m].max() <= 1e-9 * scale, k
+
+
 def test_tensor_invariant_and_viscosity_3d(jr, oracle):
     import torch
     from justrelax_jl_amd import stokes as st_mod
