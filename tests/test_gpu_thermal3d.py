@@ -62,7 +62,8 @@ def test_thermal_bcs_3d_all_kinds(jr, oracle):
         assert not np.array_equal(Tref, T0)
 
 
-@pytest.mark.parametrize("form,ni", [("array", (20, 14, 12)), ("rheology", (20, 14, 12)), ("array", (70, 17, 20)), ("rheology", (130, 9, 35))])
+@pytest.mark.parametrize("form,ni", [("array", (20, 14, 12)), ("rheology", (20, 14, 12)), ("array", (70, 17, 20)), ("rheology", (130, 9, 35)),
+                                     ("array", (256, 256, 256)), ("rheology", (192, 160, 128))])
 def test_thermal3d_iterations_match_oracle(jr, oracle, form, ni):
     """jrx_heatdiffusion_PT3d (fused flux + update + BC kernel on the unobserved iterations, the two kernels in place on check / last
     iterations, ping-pong (T, qT) sets; the larger grids span several tiles and z chunks) against the oracle's loop"""
