@@ -5,6 +5,7 @@ these are direct parity tests at the sizes the bench quotes (the kernel choice i
 256^3, the two-kernel 2D loop above 200^2 nodes), not only size-independent properties:
 
   configs[2]  SolVi3D 256^3 (miniapps/benchmarks/stokes3D/solvi/SolVi3D.jl:45-129)  -- jrx_stokes3d_solve, 25 iterations, 2 checks
+  configs[3]  SolVi3D 512^3 per GPU (the headline's block)                          -- jrx_stokes3d_solve, 9 iterations, 2 checks (one 48 GB host copy)
   configs[1]  SolCx 512^2 (miniapps/benchmarks/stokes2D/solcx/SolCx.jl:54-116)      -- jrx_stokes2d_solve, 200 iterations vs oracle,
               then the reference's convergence assertion err_evo1[end] < 1e-8 (test/test_stokes_solcx.jl:26-37) at full size
   configs[4]  shear band 1024^2 (test/test_shearband2D.jl:61-145)                   -- jrx_stokes2d_vep_solve, 61 iterations
@@ -51,6 +52,35 @@ def test_solvi3d_256_matches_oracle(jr, oracle):
     d = checks.compare_stokes(dev, ref, names)
     assert max(d.values()) <= 1e-9, d
     del stokes
+    torch.cuda.empty_cache()
+
+
+def test_solvi3d_512_matches_oracle(jr, oracle):
+    """configs[3]'s block size (the headline's): 9 iterations of jrx_stokes3d_solve at 512^3 against the oracle.  Memory: one host copy of the 45 fields
+    (48 GB) -- it is uploaded first, then the oracle advances it in place, and the device result is brought back one field at a time."""
+    import torch
+    from justrelax_jl_amd import _lib, checks
+    from justrelax_jl_amd.arrays import to_numpy
+    from justrelax_jl_amd.miniapps.common import upload_stokes, _get, stokes_field_names
+    n = 512
+    s = jr.miniapps.solvi3d(n, iterMax=8, nout=4)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+    stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
+    h = _lib.default_handle()
+    before = _stat(h, "stat_fused3d")
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+    assert _stat(h, "stat_fused3d") > before
+    r_ref = oracle.stokes3d_solve(s.arrays, checks.oracle_params3d(oracle, s))        # in place on the host copy
+    assert r.iter == r_ref["iter"] == 9
+    for k in ("norm_Rx", "norm_Ry", "norm_Rz", "norm_divV", "err_evo1"):
+        assert np.allclose(getattr(r, k), r_ref[k], rtol=1e-10, atol=0), k
+    paths = stokes_field_names(3)
+    for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy", "Rx", "Rz", "RP"):
+        got = to_numpy(_get(stokes, paths[k]))
+        d = checks.compare_stokes({k: got}, {k: s.arrays[k]}, [k])
+        assert d[k] <= 1e-9, (k, d[k])
+        del got
+    del stokes, ρg, K, G
     torch.cuda.empty_cache()
 
 
