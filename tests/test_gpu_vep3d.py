@@ -138,6 +138,61 @@ def test_vep3d_solve_matches_oracle_over_iterations(jr, oracle):
         assert np.abs(out[k] - ref[k])[m].max() <= 1e-9 * scale, k
 
 
+@pytest.mark.parametrize("nphase", [1, 3, 4, 5])
+def test_update_stresses_3d_other_phase_counts(jr, oracle, nphase):
+    """the z-marching edge kernel is instantiated per phase count (1..4, unrolled phase loops); five phases take the one-node-per-thread kernel"""
+    from justrelax_jl_amd import _lib, stokes as st_mod
+    from justrelax_jl_amd.arrays import from_numpy
+    from justrelax_jl_amd.checks import max_rel_diff
+    import torch
+    ni = (66, 7, 19)
+    s = jr.miniapps.shearband3d(ni)
+    _randomize(s)
+    rng = np.random.default_rng(40 + nphase)
+    base = s.extra["phases"]
+    phases = []
+    for q in range(nphase):
+        ph = dict(base[q % 2], Kb=3.0 + 0.5 * q, psi_deg=4.0 + q)
+        ph["eta"] = ph["eta"] * (1.0 + 0.3 * q)
+        ph["C"] = ph["C"] * (1.0 - 0.1 * q)
+        ph["G"] = ph["G"] * (1.0 + 0.2 * q)
+        phases.append(ph)
+    for k in ("phase_c", "phase_yz", "phase_xz", "phase_xy"):
+        shp = s.arrays[k].shape[1:]
+        r = rng.dirichlet(np.ones(nphase), size=shp)                      # ratios sum to 1
+        r[rng.uniform(size=shp) < 0.3] = np.eye(nphase)[rng.integers(nphase)]    # some pure cells
+        s.arrays[k] = np.asfortranarray(np.moveaxis(r, -1, 0))
+    rh = oracle.rheology_struct(phases)
+    p = _params(oracle, s)
+    ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+    theta = np.asfortranarray(rng.uniform(-1, 1, size=s.ni))
+    lam = np.asfortranarray(rng.uniform(0, 0.1, size=s.ni))
+    lamv = [np.asfortranarray(rng.uniform(0, 0.1, size=s.arrays[k].shape)) for k in ("tyz", "txz", "txy")]
+    lam_r, lamv_r = lam.copy(order="F"), [x.copy(order="F") for x in lamv]
+    oracle.vep3d_stress(ref, theta, lam_r, lamv_r, rh, p)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stokes = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+    for k, path in VEP3_MAP.items():
+        _get(stokes, path).copy_(from_numpy(s.arrays[k], dev))
+    pr = jr.PhaseRatios(jr.AMDGPUBackend, nphase, s.ni)
+    for k, name in (("phase_c", "center"), ("phase_yz", "yz"), ("phase_xz", "xz"), ("phase_xy", "xy")):
+        getattr(pr, name).copy_(from_numpy(s.arrays[k], dev))
+    ρg = tuple(from_numpy(s.arrays[k], dev) for k in ("fx", "fy", "fz"))
+    th_d, lam_d = from_numpy(theta, dev), from_numpy(lam, dev)
+    lamv_d = [from_numpy(x, dev) for x in lamv]
+    h = _lib.default_handle()
+    fd = st_mod.vep_fields3d(stokes, ρg, pr)
+    pd = st_mod.vep_params3d(stokes, s.pt, s.grid, s.flow_bcs, s.dt)
+    lv = (C.c_void_p * 3)(*[x.data_ptr() for x in lamv_d])
+    h.call("jrx_vep3d_update_stresses", C.byref(fd), C.c_void_p(th_d.data_ptr()), C.c_void_p(lam_d.data_ptr()), lv, C.byref(st_mod.rheology_table(phases)), C.byref(pd))
+    out = _download(jr, stokes)
+    assert (ref["eplxz"] != 0).any() and (ref["eplxz"] == 0).any()
+    for k in ("txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII", "eta_vep", "P", "eplxx", "eplyz", "eplxz", "eplxy", "evol_pl"):
+        assert max_rel_diff(out[k], ref[k]) <= 1e-12, k
+    for a, b in zip(lamv_d, lamv_r):
+        assert max_rel_diff(jr.to_numpy(a), b) <= 1e-12
+
+
 @pytest.mark.parametrize("ni,iters", [((96, 80, 72), 12), ((160, 160, 160), 6), ((256, 256, 256), 4)])
 def test_vep3d_solve_matches_oracle_on_a_multi_tile_grid(jr, oracle, ni, iters):
     """the whole 3D VEP driver on grids that span several 62-node lane segments, row blocks, 16-plane chunks of the z-marching edge kernel and z chunks of
