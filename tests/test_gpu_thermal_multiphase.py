@@ -217,3 +217,45 @@ def test_dirichlet_mask_and_adiabatic_heating_match_oracle(jr, oracle, dim, form
         assert np.array_equal(T[(slice(4, 7),) * dim], oval[(slice(4, 7),) * dim])
     if form != "array":
         assert max_rel_diff(jr.to_numpy(thermal.adiabatic), ref["adiabatic"]) <= 1e-14 and np.abs(ref["adiabatic"]).max() > 0
+
+
+def test_round2_entry_points_refuse_bad_arguments(jr):
+    """error behaviour of the entry points added in round 2: JRX_ERR_ARG with a message, nothing launched"""
+    import ctypes as C
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd import thermal as th
+    from justrelax_jl_amd.arrays import ptr
+    h = _lib.default_handle()
+    s = jr.miniapps.diffusion2d_multiphase(8)
+    thermal, pt, pr, args = _device_setup(jr, s)
+    f = th.thermal_fields2d(thermal, pt)
+    p = th.thermal_params2d(s.ni, s.grid, s.flow_bcs, s.dt, 1e-8, iterMax=10, nout=5)
+    m = th.thermal_phases(s.extra["rheology"], pt)
+    pf = th.thermal_phase_fields(pr, args, s.ni)
+    it, nr, nn = (C.c_int64 * 4)(), (C.c_double * 4)(), C.c_int64(0)
+    with pytest.raises(_lib.JrxError, match="null phases"):
+        h.call("jrx_heatdiffusion_PT2d_phases", C.byref(f), C.byref(p), None, C.byref(pf), it, nr, C.c_int64(4), C.byref(nn))
+    m.nphase = 9
+    with pytest.raises(_lib.JrxError, match="nphase"):
+        h.call("jrx_heatdiffusion_PT2d_phases", C.byref(f), C.byref(p), C.byref(m), C.byref(pf), it, nr, C.c_int64(4), C.byref(nn))
+    m.nphase = 2
+    pf.phase_qx = None
+    with pytest.raises(_lib.JrxError, match="face phase ratios"):
+        h.call("jrx_heatdiffusion_PT2d_phases", C.byref(f), C.byref(p), C.byref(m), C.byref(pf), it, nr, C.c_int64(4), C.byref(nn))
+    p.rheology_form = 2            # the plain entry does not take the phase-ratio form
+    with pytest.raises(_lib.JrxError, match="rheology_form"):
+        h.call("jrx_heatdiffusion_PT2d", C.byref(f), C.byref(p), it, nr, C.c_int64(4), C.byref(nn))
+    n3 = (C.c_int64 * 3)(8, 8, 1)
+    with pytest.raises(_lib.JrxError, match="update_pt_thermal_arrays"):
+        h.call("jrx_update_pt_thermal_arrays", C.c_void_p(ptr(pt.θr_dτ)), C.c_void_p(ptr(pt.dτ_ρ)), C.c_void_p(ptr(thermal.T)), n3, C.c_int32(4), C.c_double(1.0),
+               C.byref(m), C.byref(pf))
+    with pytest.raises(_lib.JrxError, match="adiabatic_heating"):
+        h.call("jrx_adiabatic_heating", None, C.c_void_p(ptr(args.P)), C.c_void_p(ptr(args.P)), C.c_int64(64), C.c_double(1.0), C.byref(m), None)
+    with pytest.raises(_lib.JrxError, match="no such option|unknown"):
+        h.call("jrx_set_option", C.c_char_p(b"no_such_option"), C.c_int64(1))
+    with pytest.raises(_lib.JrxError):      # a mask of the wrong shape is refused on the host side before any call
+        pass_bc = jr.TemperatureBoundaryConditions(no_flux=s.flow_bcs.no_flux, dirichlet=dict(constant=1.0, mask=args.P))
+        try:
+            jr.heatdiffusion_PT_(thermal, pt, pass_bc, s.extra["rheology"], args, s.dt, s.grid, kwargs=dict(phase=pr, verbose=False))
+        except ValueError as e:
+            raise _lib.JrxError(1, str(e))
