@@ -80,7 +80,8 @@ const char *jrx_build_id(void);
  * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
  * "vep3_edges" (0/1/2, default 1): edge pass of the 3D visco-elasto-plastic stress update: 1 = z-marching kernel, one edge family per
  *   block, the three blocks of a tile on one XCD; 2 = the same kernel as one launch per family; 0 = one node per thread (always used with
- *   more than 4 phases).  Same results.  "vep3_cfg" = KZ * 10 + min blocks per CU (tuning).
+ *   more than 4 phases).  Same results.  "vep3_cfg" = KZ * 10 + min blocks per CU (tuning).  "vep3_peel" (default 1): a last lane segment of the z-marching
+ *   launch that would be less than 40 % full goes to the node kernel in a thin launch of its own (0 = launch it anyway; same results).
  * "fused_ylds", "fused2d", "vep3_map", "vep3_xcd", "thermal_cfg", "thermal_xg", "b_width_x/y/z": kernel-form / tile-shape A/B
  *   switches used by the measurements in profiles/ (results never change); "halo_self_rccl" (0/1): test hook, a rank that is its
  *   own periodic neighbour routes its planes through ncclSend/ncclRecv on a one-rank communicator.

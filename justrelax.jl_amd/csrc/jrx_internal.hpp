@@ -43,6 +43,7 @@ struct jrx_handle {
     bool halo_self_rccl = false;         // test hook: a rank that is its own periodic neighbour routes the planes through ncclSend/ncclRecv
     int thermal_cfg = 0, thermal_xg = 8; // fused 3D heat-diffusion tile shape / XCD band override (tuning)
     bool fused2d = true;                 // 2D visco-elastic loop: one-launch iterations on launch-bound grids
+    bool vep3_peel = true;                   // z-marching edge kernel: a nearly empty last lane segment goes to the node kernel (A/B)
     int vep3_cfg = 0;                        // z-marching edge kernel: KZ * 10 + min blocks per CU, 0 = default
     int vep3_edges = 1;                      // 3D VEP edge pass: 1 z-marching kernel (2: one launch per family), 0 one node per thread (A/B; the form softening laws use)
     bool vep3_map = true, vep3_xcd = true;   // 3D VEP edge kernel thread mapping / XCD slab order (A/B)

@@ -392,8 +392,9 @@ __device__ __forceinline__ void vep3_gather_centres(const Vep3Args &a, const int
 // New edge stresses go to a.tnew (committed by the caller), so every read sees last iteration's values.
 // XS: blocks are dealt round-robin to the 8 XCDs; give XCD q the q-th eighth of the (flattened xy, z) block sequence instead, so that the
 // rows j +- 1 and planes k +- 1 a block gathers from were fetched by the same L2
+// i0, iw: the launch covers the node columns i0 .. i0 + iw - 1 (the whole box: 0, nx + 1)
 template <bool P4, bool XS = false, bool SOFT = false>
-__global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
+__global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a, const int i0, const int iw)
 {
     const int nx = a.nx, ny = a.ny;
     int i, j, k;
@@ -407,11 +408,11 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
             }
         }
         const int t_ = bx * 64 + (threadIdx.x & 63);
-        j = t_ / (nx + 1); i = t_ - j * (nx + 1); k = by * 4 + (threadIdx.x >> 6);
+        j = t_ / iw; i = i0 + t_ - j * iw; k = by * 4 + (threadIdx.x >> 6);
         if (j >= ny + 1 || k >= a.nz + 1) return;
     } else {
         const int t_ = blockIdx.x * blockDim.x + threadIdx.x;
-        j = t_ / (nx + 1); i = t_ - j * (nx + 1); k = blockIdx.y;
+        j = t_ / iw; i = i0 + t_ - j * iw; k = blockIdx.y;
         if (j >= ny + 1) return;
     }
     const int nz = a.nz;
@@ -442,15 +443,16 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a)
 // ------------------------------------------------------------------------------------------------
 // FAM: bit T set = family T (0 yz, 1 xz, 2 xy) is updated by this launch; what the other families alone need (loads, lane exchanges, carried
 // sums) is dead code then
+// ilim: the node columns i >= ilim are left to another launch (the last, nearly empty lane segment of a row is given to the one-node-per-thread kernel)
 template <int KZ, int NP, int FAM, bool SOFT = false>
-__device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int seg, const int j, const int zchunk)
+__device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int seg, const int j, const int zchunk, const int ilim)
 {
     constexpr int NC = SOFT ? 12 : 11;          // centre arrays averaged to the edges; softening laws add EII_pl (StressKernels.jl:710,783,854)
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP;
     const int lane = threadIdx.x & 63;
     if (j > ny) return;                                  // whole waves; the kernel has no barrier
     const int i = seg * 62 - 1 + lane;
-    const bool useful = lane >= 1 && lane <= 62 && i <= nx;
+    const bool useful = lane >= 1 && lane <= 62 && i <= nx && i < ilim;
     const int kb = zchunk * KZ, ke = min(kb + KZ, nz + 1);
     const int ic = clampi3(i, 0, nx - 1), ir = clampi3(i, 0, nx);
     const int cj0 = clampi3(j - 1, 0, ny - 1), cj1 = clampi3(j, 0, ny - 1), cj2 = clampi3(j + 1, 0, ny - 1);
@@ -592,15 +594,15 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
 }
 #undef LB
 template <int KZ, int NP, int FAM>
-__global__ __launch_bounds__(256) void k_vep3_edges_z(const Vep3Args a, int nseg)
+__global__ __launch_bounds__(256) void k_vep3_edges_z(const Vep3Args a, int nseg, int ilim)
 {
-    vep3_edges_z_tile<KZ, NP, FAM>(a, blockIdx.x % nseg, (blockIdx.x / nseg) * 4 + (int)(threadIdx.x >> 6), blockIdx.y);
+    vep3_edges_z_tile<KZ, NP, FAM>(a, blockIdx.x % nseg, (blockIdx.x / nseg) * 4 + (int)(threadIdx.x >> 6), blockIdx.y, ilim);
 }
 // One launch, one family per block: the three blocks of a tile (same nodes, families yz / xz / xy) sit next to each other in the block sequence
 // of ONE XCD (blocks are dealt round-robin to the 8 XCDs), so that the operands they share are fetched from HBM once and found in that XCD's L2 by
 // the other two; per block only one family's state lives in registers.
 template <int KZ, int NP, int MINB, bool SOFT = false>
-__global__ __launch_bounds__(256, MINB) void k_vep3_edges_zf(const Vep3Args a, int nseg, int ntile_xy, int ntiles)
+__global__ __launch_bounds__(256, MINB) void k_vep3_edges_zf(const Vep3Args a, int nseg, int ntile_xy, int ntiles, int ilim)
 {
     const unsigned L = blockIdx.x, xcd = L & 7u, q = L >> 3;            // q-th block of this XCD
     const unsigned per = ((unsigned)ntiles + 7u) / 8u;                  // XCD x works on the tiles [x * per, (x + 1) * per): a slab of z chunks
@@ -608,9 +610,9 @@ __global__ __launch_bounds__(256, MINB) void k_vep3_edges_zf(const Vep3Args a, i
     if (q / 3u >= per || t >= (unsigned)ntiles) return;
     const int txy = (int)(t % (unsigned)ntile_xy), zc = (int)(t / (unsigned)ntile_xy);
     const int j = (txy / nseg) * 4 + (int)(threadIdx.x >> 6);
-    if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT>(a, txy % nseg, j, zc);
-    else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT>(a, txy % nseg, j, zc);
-    else vep3_edges_z_tile<KZ, NP, 4, SOFT>(a, txy % nseg, j, zc);
+    if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT>(a, txy % nseg, j, zc, ilim);
+    else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT>(a, txy % nseg, j, zc, ilim);
+    else vep3_edges_z_tile<KZ, NP, 4, SOFT>(a, txy % nseg, j, zc, ilim);
 }
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
 template <bool SOFT>
@@ -788,33 +790,43 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
         // kernel with one family per block and the three blocks of a tile on one XCD, 2 the same kernel as one launch per family (A/B: the L2 sharing)
         const int cfg = h->vep3_cfg ? h->vep3_cfg : 162;           // option "vep3_cfg" = KZ * 10 + min blocks per CU (tuning)
         const int kz = cfg / 10, mb = cfg % 10, np_ = a.rh.nphase;
-        const int nseg = (nx + 1 + 61) / 62, ntxy = nseg * ((ny + 1 + 3) / 4), nzc = (nz + 1 + kz - 1) / kz, nt = ntxy * nzc;
+        // lane segments of 62 node columns; a last segment that would be less than 40 % full (256^3: 257 = 4 x 62 + 9) is not launched -- its node columns
+        // go to the one-node-per-thread kernel in a thin launch of their own (the two launches write disjoint nodes and read old values only)
+        const int nfull = (nx + 1) / 62, rem = (nx + 1) - 62 * nfull;
+        const bool peel = nfull >= 1 && rem > 0 && rem <= 24 && h->vep3_peel;
+        const int nseg = peel ? nfull : (nx + 1 + 61) / 62, ilim = peel ? 62 * nfull : nx + 1;
+        const int ntxy = nseg * ((ny + 1 + 3) / 4), nzc = (nz + 1 + kz - 1) / kz, nt = ntxy * nzc;
         bool ok = false;
+        if (peel) {
+            const dim3 gp((unsigned)(((i64)rem * (ny + 1) + 63) / 64), (unsigned)((nz + 1 + 3) / 4));
+            if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, false, true>), gp, dim3(256), 0, s, a, ilim, rem);
+            else hipLaunchKernelGGL((k_vep3_edges<true, false, false>), gp, dim3(256), 0, s, a, ilim, rem);
+        }
         if (a.soft) {       // softening laws: the yield function also reads the edge average of EII_pl
             const dim3 gf((unsigned)(((nt + 7) / 8) * 8 * 3));
-#define EZS(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<16, NP_, 2, true>), gf, dim3(256), 0, s, a, nseg, ntxy, nt); ok = true; }
+#define EZS(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<16, NP_, 2, true>), gf, dim3(256), 0, s, a, nseg, ntxy, nt, ilim); ok = true; }
             EZS(1) EZS(2) EZS(3) EZS(4)
 #undef EZS
         } else if (h->vep3_edges == 2) {
             const dim3 g((unsigned)ntxy, (unsigned)nzc);
-#define EZ(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 1>), g, dim3(256), 0, s, a, nseg); \
-                hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 2>), g, dim3(256), 0, s, a, nseg); \
-                hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 4>), g, dim3(256), 0, s, a, nseg); ok = true; }
+#define EZ(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 1>), g, dim3(256), 0, s, a, nseg, ilim); \
+                hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 2>), g, dim3(256), 0, s, a, nseg, ilim); \
+                hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 4>), g, dim3(256), 0, s, a, nseg, ilim); ok = true; }
             EZ(1) EZ(2) EZ(3) EZ(4)
 #undef EZ
         } else {
             const dim3 gf((unsigned)(((nt + 7) / 8) * 8 * 3));
-#define EZG(KZ_, NP_, MB_) if (kz == KZ_ && mb == MB_ && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<KZ_, NP_, MB_>), gf, dim3(256), 0, s, a, nseg, ntxy, nt); ok = true; }
+#define EZG(KZ_, NP_, MB_) if (kz == KZ_ && mb == MB_ && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<KZ_, NP_, MB_>), gf, dim3(256), 0, s, a, nseg, ntxy, nt, ilim); ok = true; }
 #define EZN(KZ_, MB_) EZG(KZ_, 1, MB_) EZG(KZ_, 2, MB_) EZG(KZ_, 3, MB_) EZG(KZ_, 4, MB_)
             EZN(16, 2) EZN(16, 3) EZN(8, 2)
 #undef EZN
 #undef EZG
         }
         if (!ok) return jrx_fail(h, JRX_ERR_ARG, "vep3_cfg: no such configuration");
-    } else if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
-    else if (p4 && xs) hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
-    else if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a);
+    } else if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
+    else if (p4 && xs) hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
+    else if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
+    else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
     JRX_LAUNCH_CHECK(h);
     const EdgeN n = edge_counts(p);
     if (commit) {
