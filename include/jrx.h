@@ -515,6 +515,39 @@ jrx_status jrx_update_pt_thermal_arrays(jrx_handle *h, double *thetar_dtau, doub
 jrx_status jrx_adiabatic_heating(jrx_handle *h, double *adiabatic, const double *P, const double *P0, int64_t ncells, double dt, const jrx_thermal_phases *ph,
                                  const double *phase_c);
 
+/* ------------------------------------------------------------------ grid operators of a time step, either side of solve! / heatdiffusion_PT! */
+/* The methods the reference's AMDGPU extension forwards to the generic kernels (src/ext/AMDGPU/2D.jl:301-352, 3D.jl:311-362).  Shapes as in
+ * StokesArrays: Vx (nx+1, ny+2[, nz+2]), Vy (nx+2, ny+1[, nz+2]), Vz (nx+2, ny+2, nz+1); shear yz (nx, ny+1, nz+1), xz (nx+1, ny, nz+1), xy (nx+1, ny+1[, nz]).
+ * velocity2vertex!(Vx_v, Vy_v[, Vz_v], Vx, Vy[, Vz]) -- Interpolations.jl:212-249: the kernel runs over size(Vx_v) = (mx, my[, mz]) <= ni .+ 1 (the caller's
+ *   choice, as in the reference: ni .+ 1 in the miniapps, ni in test/test_Interpolations.jl:150-164);
+ * velocity2center! -- :257-289, outputs ni;
+ * vertex2center!(center, vertex; ghost_x, ghost_y, ghost_z) -- :72-96: over size(vertex) .- 1, written at I .+ ghost of a centre array of extents cdim;
+ * center2vertex_harm! -- :116-137 (2D, clamped harmonic mean; vertex (nx+1, ny+1));
+ * center2vertex!(vertex_yz, vertex_xz, vertex_xy, center_yz, center_xz, center_xy) -- :139-178 (3D; boundary edges are not written).
+ * The 2D center2vertex!(vertex, center) is jrx_center2vertex2d above. */
+jrx_status jrx_velocity2vertex2d(jrx_handle *h, double *Vx_v, double *Vy_v, const double *Vx, const double *Vy, int64_t nx, int64_t ny, int64_t mx, int64_t my);
+jrx_status jrx_velocity2vertex3d(jrx_handle *h, double *Vx_v, double *Vy_v, double *Vz_v, const double *Vx, const double *Vy, const double *Vz, int64_t nx,
+                                 int64_t ny, int64_t nz, int64_t mx, int64_t my, int64_t mz);
+jrx_status jrx_velocity2center2d(jrx_handle *h, double *Vx_c, double *Vy_c, const double *Vx, const double *Vy, int64_t nx, int64_t ny);
+jrx_status jrx_velocity2center3d(jrx_handle *h, double *Vx_c, double *Vy_c, double *Vz_c, const double *Vx, const double *Vy, const double *Vz, int64_t nx,
+                                 int64_t ny, int64_t nz);
+jrx_status jrx_vertex2center(jrx_handle *h, double *center, const double *vertex, const int64_t vdim[3], const int64_t cdim[3], int32_t ndim, int32_t ghost_x,
+                             int32_t ghost_y, int32_t ghost_z);
+jrx_status jrx_center2vertex_harm2d(jrx_handle *h, double *vertex, const double *center, int64_t nx, int64_t ny);
+jrx_status jrx_center2vertex3d(jrx_handle *h, double *vertex_yz, double *vertex_xz, double *vertex_xy, const double *center_yz, const double *center_xz,
+                               const double *center_xy, int64_t nx, int64_t ny, int64_t nz);
+/* compute_ρg!(ρg[end], [phase_ratios,] rheology, (; T, P)) -- rheology/BuoyancyForces.jl:6-60, the scalar-gravity form: rhog = density * gravity of the first
+ * phase over ncells cells (the density laws of jrx_rheology; has_density must be set).  phase_c NULL: single-phase form (phase 0); T, P (ni) may be NULL (= 0). */
+jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh, const double *phase_c, const double *T, const double *P, int64_t ncells);
+/* compute_shear_heating!(thermal, stokes, [phase_ratios,] rheology, dt) -- thermal_diffusion/ShearHeating.jl:14-71:
+ * shear_heating = max(0, Χ τ : (ε - ε_el)), ε_el = (τ - τ_o) / (2 G dt), at the cell centres.  tau, tau_o: @tensor_center(stokes.τ / τ_o) in Voigt order
+ * (2D: xx, yy, xy_c; 3D: xx, yy, zz, yz_c, xz_c, xy_c), eps: @strain(stokes) (shear components on their edges, averaged to the centre as cache_tensors does).
+ * G from rh (fn_ratio(get_shear_modulus, ...) with phase_c, phase 0 without); chi[q] = Χ of phase q's ConstantShearheating (0: no law).
+ * [compute_shearheating is GeoParams': Χ Σ τ_ij (ε_ij - ε_el_ij) with the shear terms of the Voigt tuple counted twice -- form ASSUMED, parity unpinned.]
+ * n = {nx, ny, nz}; ndim 2 or 3. */
+jrx_status jrx_compute_shear_heating(jrx_handle *h, double *shear_heating, const double *const *tau, const double *const *tau_o, const double *const *eps,
+                                     const double *phase_c, const jrx_rheology *rh, const double *chi, double dt, const int64_t n[3], int32_t ndim);
+
 /* ------------------------------------------------------------------ timing hooks for bench.py */
 /* Runs `iters` PT iterations of the 3D loop body back to back (no norm checks) and reports device times
  * measured with hipEvents on the handle's stream inside that batch:

@@ -6,7 +6,7 @@ The directory name contains a dot, so import it through `__graft_entry__.load_pa
 
 Layout: csrc/ (hand-written HIP kernels for gfx950 + the C ABI declared in include/jrx.h),
 arrays.py / backend.py / grid.py (host-side mirror of the reference's types and traits),
-stokes.py / thermal.py / halo.py (the operator API: solve_, heatdiffusion_PT_, flow_bcs_, ...),
+stokes.py / thermal.py / halo.py / gridops.py (the operator API: solve_, heatdiffusion_PT_, flow_bcs_, velocity2vertex_, ...),
 miniapps/ (synthetic-input builders restating the reference's benchmark scripts).
 Julia's `f!` is spelled `f_` here.
 """
@@ -24,9 +24,9 @@ from . import miniapps  # noqa: F401
 def __getattr__(name):
     # the operator API is imported lazily: it loads the HIP shared library and fails loudly if absent
     import importlib
-    if name.startswith("_") or name in ("stokes", "thermal", "halo", "checks", "build", "arrays", "grid", "backend", "convert"):
+    if name.startswith("_") or name in ("stokes", "thermal", "halo", "checks", "build", "arrays", "grid", "backend", "convert", "gridops"):
         raise AttributeError(name)
-    for sub in ("stokes", "thermal", "halo"):
+    for sub in ("stokes", "thermal", "halo", "gridops"):
         mod = importlib.import_module(f"{__name__}.{sub}")
         if hasattr(mod, name):
             return getattr(mod, name)

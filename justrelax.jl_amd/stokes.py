@@ -365,11 +365,14 @@ def compute_τ_nonlinear_(stokes, θ, λ, rheology, dt, pt_stokes, *, phase_rati
            C.c_int32(0 if phase_ratios is None else 1))
 
 
-def center2vertex_(vertex, center, *, handle=None):
-    """center2vertex!(vertex, center) 2D -- Interpolations.jl:101-114"""
+def center2vertex_(vertex, center, *more, handle=None):
+    """center2vertex!(vertex, center) 2D -- Interpolations.jl:101-114; with six arrays the 3D form (Interpolations.jl:139-178)"""
+    if more:
+        from .gridops import center2vertex3d_
+        return center2vertex3d_(vertex, center, *more, handle=handle)
     _require_gpu(vertex)
     if vertex.dim() != 2:
-        raise NotImplementedError("3D center2vertex! is not built")
+        raise TypeError("3D: center2vertex!(vertex_yz, vertex_xz, vertex_xy, center_yz, center_xz, center_xy) -- center2vertex3d_")
     h = handle or _lib.default_handle(vertex.device.index)
     torch.cuda.current_stream(vertex.device).synchronize()
     h.call("jrx_center2vertex2d", C.c_void_p(ptr(vertex)), C.c_void_p(ptr(center)), C.c_int64(center.shape[0]), C.c_int64(center.shape[1]))

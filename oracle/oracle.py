@@ -702,3 +702,78 @@ def first_touch(a: np.ndarray) -> np.ndarray:
     nslab = a.shape[-1]
     lib().orc_first_touch_copy(_p(out), _p(a), C.c_int64(a.size // nslab), C.c_int64(nslab))
     return out
+
+
+# ----------------------------------------------------------------------------- grid operators either side of the solves (gridops.c)
+def _i64s(*ns):
+    return [C.c_int64(int(n)) for n in ns]
+
+
+def velocity2vertex(Vx, Vy, Vz=None, out_shape=None):
+    """velocity2vertex!(Vx_v, Vy_v[, Vz_v], Vx, Vy[, Vz]) -- Interpolations.jl:212-249; returns the outputs (shape out_shape, default ni .+ 1)"""
+    if Vz is None:
+        nx, ny = Vx.shape[0] - 1, Vx.shape[1] - 2
+        m = tuple(out_shape or (nx + 1, ny + 1))
+        o = [np.zeros(m, order="F") for _ in range(2)]
+        lib().orc_velocity2vertex2d(_p(o[0]), _p(o[1]), _p(Vx), _p(Vy), *_i64s(nx, ny, *m))
+    else:
+        nx, ny, nz = Vx.shape[0] - 1, Vx.shape[1] - 2, Vx.shape[2] - 2
+        m = tuple(out_shape or (nx + 1, ny + 1, nz + 1))
+        o = [np.zeros(m, order="F") for _ in range(3)]
+        lib().orc_velocity2vertex3d(_p(o[0]), _p(o[1]), _p(o[2]), _p(Vx), _p(Vy), _p(Vz), *_i64s(nx, ny, nz, *m))
+    return o
+
+
+def velocity2center(Vx, Vy, Vz=None):
+    """velocity2center! -- Interpolations.jl:257-289"""
+    if Vz is None:
+        nx, ny = Vx.shape[0] - 1, Vx.shape[1] - 2
+        o = [np.zeros((nx, ny), order="F") for _ in range(2)]
+        lib().orc_velocity2center2d(_p(o[0]), _p(o[1]), _p(Vx), _p(Vy), *_i64s(nx, ny))
+    else:
+        nx, ny, nz = Vx.shape[0] - 1, Vx.shape[1] - 2, Vx.shape[2] - 2
+        o = [np.zeros((nx, ny, nz), order="F") for _ in range(3)]
+        lib().orc_velocity2center3d(_p(o[0]), _p(o[1]), _p(o[2]), _p(Vx), _p(Vy), _p(Vz), *_i64s(nx, ny, nz))
+    return o
+
+
+def vertex2center(center, vertex, ghost=(False, False, False)):
+    """vertex2center!(center, vertex; ghost_x, ghost_y, ghost_z) in place -- Interpolations.jl:72-96"""
+    nd = vertex.ndim
+    vd = (C.c_int64 * 3)(*vertex.shape, *([1] * (3 - nd)))
+    cd = (C.c_int64 * 3)(*center.shape, *([1] * (3 - nd)))
+    g = list(ghost) + [False] * (3 - len(ghost))
+    lib().orc_vertex2center(_p(center), _p(vertex), vd, cd, C.c_int32(nd), *[C.c_int32(bool(x)) for x in g])
+
+
+def center2vertex_harm(center):
+    """center2vertex_harm! -- Interpolations.jl:116-137"""
+    nx, ny = center.shape
+    v = np.zeros((nx + 1, ny + 1), order="F")
+    lib().orc_center2vertex_harm2d(_p(v), _p(center), *_i64s(nx, ny))
+    return v
+
+
+def center2vertex3d(vyz, vxz, vxy, cyz, cxz, cxy):
+    """center2vertex!(vertex_yz, vertex_xz, vertex_xy, center_yz, center_xz, center_xy) in place -- Interpolations.jl:139-178"""
+    lib().orc_center2vertex3d(_p(vyz), _p(vxz), _p(vxy), _p(cyz), _p(cxz), _p(cxy), *_i64s(*cyz.shape))
+
+
+def compute_rhog(rh: "Rheology", T, P, phase_c=None, shape=None):
+    """compute_ρg!(ρg[end], [phase_ratios,] rheology, (; T, P)) -- BuoyancyForces.jl:6-60"""
+    shape = shape or (T if T is not None else P).shape
+    out = np.zeros(shape, order="F")
+    lib().orc_compute_rhog(_p(out), C.byref(rh), _p(phase_c), _p(T), _p(P), C.c_int64(out.size))
+    return out
+
+
+def compute_shear_heating(tau, tau_o, eps, rh: "Rheology", chi, dt, phase_c=None):
+    """compute_shear_heating! -- ShearHeating.jl:14-71; tau, tau_o: centre arrays in Voigt order, eps: staggered strain rates; chi: Χ per phase"""
+    ni = tau[0].shape
+    nd = len(ni)
+    out = np.zeros(ni, order="F")
+    arr = lambda ts: (_dp * 6)(*[_p(t) for t in ts])
+    x = (C.c_double * MAXPHASE)(*[float(c) for c in chi])
+    n = (C.c_int64 * 3)(*ni, *([1] * (3 - nd)))
+    lib().orc_compute_shear_heating(_p(out), arr(tau), arr(tau_o), arr(eps), _p(phase_c), C.byref(rh), x, C.c_double(dt), n, C.c_int32(nd))
+    return out
