@@ -537,8 +537,11 @@ jrx_status jrx_center2vertex_harm2d(jrx_handle *h, double *vertex, const double 
 jrx_status jrx_center2vertex3d(jrx_handle *h, double *vertex_yz, double *vertex_xz, double *vertex_xy, const double *center_yz, const double *center_xz,
                                const double *center_xy, int64_t nx, int64_t ny, int64_t nz);
 /* compute_ρg!(ρg[end], [phase_ratios,] rheology, (; T, P)) -- rheology/BuoyancyForces.jl:6-60, the scalar-gravity form: rhog = density * gravity of the first
- * phase over ncells cells (the density laws of jrx_rheology; has_density must be set).  phase_c NULL: single-phase form (phase 0); T, P (ni) may be NULL (= 0). */
-jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh, const double *phase_c, const double *T, const double *P, int64_t ncells);
+ * phase over the n = {nx, ny[, nz]} cells (the density laws of jrx_rheology; has_density must be set).  phase_c NULL: single-phase form (phase 0); T, P may be
+ * NULL (= 0); P has the extents n.  tdim: the extents of args.T (NULL: n) -- T is read at the cell's own [i, j, k] of that array, so a ghosted thermal.T passed
+ * as args.T is read without the shift to the centres, as the reference's getindex_NamedTuple(args, I...) does (test/test_WENO5.jl:208-214). */
+jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh, const double *phase_c, const double *T, const double *P, const int64_t n[3],
+                            const int64_t tdim[3], int32_t ndim);
 /* compute_shear_heating!(thermal, stokes, [phase_ratios,] rheology, dt) -- thermal_diffusion/ShearHeating.jl:14-71:
  * shear_heating = max(0, Χ τ : (ε - ε_el)), ε_el = (τ - τ_o) / (2 G dt), at the cell centres.  tau, tau_o: @tensor_center(stokes.τ / τ_o) in Voigt order
  * (2D: xx, yy, xy_c; 3D: xx, yy, zz, yz_c, xz_c, xy_c), eps: @strain(stokes) (shear components on their edges, averaged to the centre as cache_tensors does).

@@ -103,14 +103,16 @@ __global__ __launch_bounds__(256) void k_center2vertex3d(double *__restrict__ vy
     if (i1 && j1) vxy[(i + 1) + (i64)(nx + 1) * ((j + 1) + (i64)(ny + 1) * k)] = 0.25 * (cxy[c] + cxy[c + 1] + cxy[c + nx] + cxy[c + 1 + nx]);
 }
 
-// compute_ρg_kernel! (BuoyancyForces.jl:17-21,50-54): ρg = density(T, P[, ratios]) * gravity of the first phase
+// compute_ρg_kernel! (BuoyancyForces.jl:17-21,50-54): ρg = density(T, P[, ratios]) * gravity of the first phase.  args.T is indexed with the cell's own
+// [i, j, k] in T's extents (t1, t2): a ghosted thermal.T passed as args.T is read WITHOUT the shift to the cell centre, exactly as getindex_NamedTuple does
+// in the reference (test/test_WENO5.jl:208-214 calls it that way)
 template <bool PH>
 __global__ __launch_bounds__(256) void k_compute_rhog(double *__restrict__ rhog, const jrx_rheology rh, const double *__restrict__ phase_c,
-                                                      const double *__restrict__ T, const double *__restrict__ P, i64 n)
+                                                      const double *__restrict__ T, const double *__restrict__ P, int nx, int ny, int t1, int t2)
 {
-    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const double t = T ? T[c] : 0.0, p = P ? P[c] : 0.0;
+    OUT_IJK(nx, ny)
+    const i64 c = i + (i64)nx * (j + (i64)ny * k);
+    const double t = T ? T[i + (i64)t1 * (j + (i64)t2 * k)] : 0.0, p = P ? P[c] : 0.0;
     rhog[c] = (PH ? mat_density_ratio(rh, phase_c + (i64)rh.nphase * c, t, p) : mat_density(rh, 0, t, p)) * rh.gravity;
 }
 
@@ -261,15 +263,23 @@ jrx_status jrx_center2vertex3d(jrx_handle *h, double *vertex_yz, double *vertex_
     return done(h);
 }
 
-jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh, const double *phase_c, const double *T, const double *P, int64_t ncells)
+jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh, const double *phase_c, const double *T, const double *P, const int64_t n[3],
+                            const int64_t tdim[3], int32_t ndim)
 {
     if (!h) return JRX_ERR_ARG;
     JRX_TRY(jrx_check_device(h));
-    if (!rhog || !rh || ncells < 1 || rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "compute_ρg!: bad argument");
+    if (!rhog || !rh || !n || (ndim != 2 && ndim != 3) || rh->nphase < 1 || rh->nphase > JRX_MAXPHASE) return jrx_fail(h, JRX_ERR_ARG, "compute_ρg!: bad argument");
     if (!rh->has_density) return jrx_fail(h, JRX_ERR_ARG, "compute_ρg!: the rheology table carries no density law (has_density = 0)");
-    const dim3 g((unsigned)((ncells + 255) / 256));
-    if (phase_c) hipLaunchKernelGGL(k_compute_rhog<true>, g, dim3(256), 0, h->stream, rhog, *rh, phase_c, T, P, (i64)ncells);
-    else hipLaunchKernelGGL(k_compute_rhog<false>, g, dim3(256), 0, h->stream, rhog, *rh, phase_c, T, P, (i64)ncells);
+    const int nx = (int)n[0], ny = (int)n[1], nz = ndim == 3 ? (int)n[2] : 1;
+    if (nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "compute_ρg!: bad size");
+    int t1 = nx, t2 = ny;
+    if (tdim) {
+        for (int d = 0; d < ndim; d++)
+            if (tdim[d] < n[d]) return jrx_fail(h, JRX_ERR_ARG, "compute_ρg!: args.T is smaller than ρg along dimension %d", d + 1);
+        t1 = (int)tdim[0]; t2 = (int)tdim[1];
+    }
+    if (phase_c) hipLaunchKernelGGL(k_compute_rhog<true>, OUT_GRID(nx, ny, nz), dim3(256), 0, h->stream, rhog, *rh, phase_c, T, P, nx, ny, t1, t2);
+    else hipLaunchKernelGGL(k_compute_rhog<false>, OUT_GRID(nx, ny, nz), dim3(256), 0, h->stream, rhog, *rh, phase_c, T, P, nx, ny, t1, t2);
     return done(h);
 }
 

@@ -128,15 +128,19 @@ def compute_ρg_(ρg, *rest, handle=None):
     out = ρg[-1] if isinstance(ρg, (tuple, list)) else ρg
     rh = rheology_table([rheology] if isinstance(rheology, dict) else rheology)
     T, P = _args_get(args, "T"), _args_get(args, "P")
-    for nm, t in (("T", T), ("P", P)):
-        if t is not None and tuple(t.shape) != tuple(out.shape):
-            raise ValueError(f"args.{nm} must have the shape of ρg (cell centres)")
+    nd = out.dim()
+    if P is not None and tuple(P.shape) != tuple(out.shape):
+        raise ValueError("args.P must have the shape of ρg (cell centres)")
+    if T is not None and (T.dim() != nd or any(a < b for a, b in zip(T.shape, out.shape))):
+        raise ValueError("args.T must be at least as large as ρg (a ghosted thermal.T is read at [i, j, k] without a shift, as in the reference)")
     pc = None
     if pr is not None:
         pc = pr.center
         if tuple(pc.shape) != (rh.nphase, *out.shape):
             raise ValueError("phase_ratios.center must be (nphase, ni...)")
-    _h(out, handle).call("jrx_compute_rhog", *_p(out), C.byref(rh), *_p(pc, T, P), C.c_int64(out.numel()))
+    n = (C.c_int64 * 3)(*out.shape, *([1] * (3 - nd)))
+    td = (C.c_int64 * 3)(*(T.shape if T is not None else out.shape), *([1] * (3 - nd)))
+    _h(out, handle).call("jrx_compute_rhog", *_p(out), C.byref(rh), *_p(pc, T, P), n, td, C.c_int32(nd))
 
 
 def compute_shear_heating_(thermal, stokes, *rest, handle=None):

@@ -107,13 +107,19 @@ void orc_center2vertex3d(double *vyz, double *vxz, double *vxy, const double *cy
 #undef C_
 }
 
-/* compute_ρg_kernel! (BuoyancyForces.jl:17-21,50-54): the scalar-gravity form, one array (the caller passes the last component of ρg) */
-void orc_compute_rhog(double *rhog, const orc_rheology *rh, const double *phase_c, const double *T, const double *P, int64_t n)
+/* compute_ρg_kernel! (BuoyancyForces.jl:17-21,50-54): the scalar-gravity form, one array (the caller passes the last component of ρg).  args.T is read at the
+ * cell's own [i, j, k] of an array of extents tdim (getindex_NamedTuple(args, I...): no shift for a ghosted thermal.T) */
+void orc_compute_rhog(double *rhog, const orc_rheology *rh, const double *phase_c, const double *T, const double *P, const int64_t n[3], const int64_t tdim[3],
+                      int32_t ndim)
 {
-    for (int64_t c = 0; c < n; c++) {
-        const double t = T ? T[c] : 0.0, p = P ? P[c] : 0.0;
-        rhog[c] = (phase_c ? mat_density_ratio(rh, phase_c + (size_t)rh->nphase * c, t, p) : mat_density(rh, 0, t, p)) * rh->gravity;
-    }
+    const int64_t nx = n[0], ny = n[1], nz = ndim == 3 ? n[2] : 1, t1 = tdim ? tdim[0] : nx, t2 = tdim ? tdim[1] : ny;
+    for (int64_t k = 0; k < nz; k++)
+        for (int64_t j = 0; j < ny; j++)
+            for (int64_t i = 0; i < nx; i++) {
+                const size_t c = IDX3(nx, ny, i, j, k);
+                const double t = T ? T[IDX3(t1, t2, i, j, k)] : 0.0, p = P ? P[c] : 0.0;
+                rhog[c] = (phase_c ? mat_density_ratio(rh, phase_c + (size_t)rh->nphase * c, t, p) : mat_density(rh, 0, t, p)) * rh->gravity;
+            }
 }
 
 /* fn_ratio(fn, rheology, ratio) (src/phases/phases.jl:6-15) */

@@ -356,7 +356,8 @@ void orc_velocity2center3d(double *Vxc, double *Vyc, double *Vzc, const double *
 void orc_vertex2center(double *cen, const double *ver, const int64_t vdim[3], const int64_t cdim[3], int32_t ndim, int32_t gx, int32_t gy, int32_t gz);
 void orc_center2vertex_harm2d(double *ver, const double *cen, int64_t nx, int64_t ny);
 void orc_center2vertex3d(double *vyz, double *vxz, double *vxy, const double *cyz, const double *cxz, const double *cxy, int64_t nx, int64_t ny, int64_t nz);
-void orc_compute_rhog(double *rhog, const orc_rheology *rh, const double *phase_c, const double *T, const double *P, int64_t n);
+void orc_compute_rhog(double *rhog, const orc_rheology *rh, const double *phase_c, const double *T, const double *P, const int64_t n[3], const int64_t tdim[3],
+                      int32_t ndim);
 void orc_compute_shear_heating(double *sh, const double *const *tau, const double *const *tau_o, const double *const *eps, const double *phase_c,
                                const orc_rheology *rh, const double *chi, double dt, const int64_t n[3], int32_t ndim);
 

@@ -760,10 +760,13 @@ def center2vertex3d(vyz, vxz, vxy, cyz, cxz, cxy):
 
 
 def compute_rhog(rh: "Rheology", T, P, phase_c=None, shape=None):
-    """compute_ρg!(ρg[end], [phase_ratios,] rheology, (; T, P)) -- BuoyancyForces.jl:6-60"""
-    shape = shape or (T if T is not None else P).shape
+    """compute_ρg!(ρg[end], [phase_ratios,] rheology, (; T, P)) -- BuoyancyForces.jl:6-60; T may be larger than ρg (read at [i, j, k] without a shift)"""
+    shape = tuple(shape or (P if P is not None else T).shape)
+    nd = len(shape)
     out = np.zeros(shape, order="F")
-    lib().orc_compute_rhog(_p(out), C.byref(rh), _p(phase_c), _p(T), _p(P), C.c_int64(out.size))
+    n = (C.c_int64 * 3)(*shape, *([1] * (3 - nd)))
+    td = (C.c_int64 * 3)(*(T.shape if T is not None else shape), *([1] * (3 - nd)))
+    lib().orc_compute_rhog(_p(out), C.byref(rh), _p(phase_c), _p(T), _p(P), n, td, C.c_int32(nd))
     return out
 
 

@@ -141,8 +141,20 @@ def test_compute_rhog_vs_oracle(jr, oracle, ni):
     assert np.all(_dn(one) == 3300.0 * (1 - 3e-5 * (0.0 - 273.0) + 1e-11 * 0.0) * 9.81)
     with pytest.raises(RuntimeError, match="no density law"):
         jr.compute_ρg_(one, dict(eta=1.0, G=1.0, Kb=1.0), args)
+    Tg = np.asfortranarray(RNG.random(tuple(n + 2 for n in ni)) * 1500)     # ghosted thermal.T as args.T: read at [i, j, k] without a shift
+    jr.compute_ρg_(one, PHASES[0], dict(T=_up(Tg), P=_up(P)))
+    np.testing.assert_array_equal(_dn(one), oracle.compute_rhog(oracle.rheology_struct(PHASES[:1]), Tg, P))
     with pytest.raises(ValueError):
-        jr.compute_ρg_(one, PHASES[0], dict(T=jr.fzeros(tuple(n + 2 for n in ni), _dev()), P=None))
+        jr.compute_ρg_(one, PHASES[0], dict(T=jr.fzeros(tuple(n - 1 for n in ni), _dev()), P=None))
+
+
+def test_compute_rhog_reproduces_the_convection_setup(jr):
+    """thermal_convection2D of test/test_WENO5.jl:208-214: compute_ρg!(ρg[2], rheology, (; T = thermal.T, P = stokes.P)) -- the miniapp builder's host
+    arithmetic (ρ0 (1 - α T[i, j]) g on the ghosted T) equals the device operator"""
+    s = jr.miniapps.thermal_convection2d(32, ar=1)
+    out = jr.fzeros(s.ni, _dev())
+    jr.compute_ρg_((jr.fzeros(s.ni, _dev()), out), s.extra["rheology"], dict(T=_up(s.arrays["T"]), P=_up(np.zeros(s.ni, order="F"))))
+    np.testing.assert_allclose(_dn(out), s.arrays["fy"], rtol=1e-15)
 
 
 @pytest.mark.parametrize("ni", [(37, 21), (20, 14, 12), (70, 17, 20)])

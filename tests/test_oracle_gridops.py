@@ -88,6 +88,9 @@ def test_compute_rhog_and_shear_heating(oracle):
     d0 = 3300.0 * (1 - 3e-5 * (T - 273.0) + 1e-11 * P)
     np.testing.assert_allclose(oracle.compute_rhog(rh, T, P), d0 * 9.81, rtol=1e-14)                      # BuoyancyForces.jl:17-21
     np.testing.assert_allclose(oracle.compute_rhog(rh, T, P, pc), (d0 * r + 2700.0 * (1 - r)) * 9.81, rtol=1e-14)   # :50-54, fn_ratio
+    # a ghosted thermal.T as args.T is read at [i, j] without the shift to the centres (getindex_NamedTuple; test/test_WENO5.jl:208-214)
+    Tg = np.asfortranarray(RNG.random((ni[0] + 2, ni[1] + 2)) * 1500)
+    np.testing.assert_allclose(oracle.compute_rhog(rh, Tg, P), 3300.0 * (1 - 3e-5 * (Tg[:ni[0], :ni[1]] - 273.0) + 1e-11 * P) * 9.81, rtol=1e-14)
     # shear heating, 2D: Χ (τxx (εxx - εel_xx) + τyy (...) + 2 τxy (av(εxy) - εel_xy)), clipped at 0
     nx, ny = ni
     tau, tau_o = [F(*ni) - 0.5 for _ in range(3)], [F(*ni) - 0.5 for _ in range(3)]
