@@ -18,6 +18,7 @@ from .arrays import (DisplacementBoundaryConditions, PhaseRatios, PTStokesCoeffs
 from .grid import (IGG, Geometry, finalize_global_grid, init_global_grid, legacy_uniform_grid,  # noqa: F401
                    nx_g, ny_g, nz_g)
 from .convert import Array_, PTArray_, checkpointing_npz, copy_, load_checkpoint_npz  # noqa: F401
+from .vtk import pack_velocity, save_vtk  # noqa: F401
 from . import miniapps  # noqa: F401
 
 
