@@ -130,4 +130,6 @@ bool jrx_comm_has_neighbor(const jrx_handle *h, int d, int side);   // the halo 
 jrx_status jrx3d_velocity_sweep(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag);
 jrx_status jrx3d_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p);
 jrx_status jrx3d_bcs(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz, uint32_t fs, uint32_t ns, uint32_t pe);
+// all free-slip / no-slip faces in one launch: equal to jrx3d_bcs on every entry a Stokes stencil reads once jrx3d_bcs has run on the same arrays
+jrx_status jrx3d_bcs_faces(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz, uint32_t fs, uint32_t ns);
 jrx_status jrx3d_sumsq(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p);

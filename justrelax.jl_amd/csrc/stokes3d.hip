@@ -251,6 +251,10 @@ jrx_status jrx3d_bcs(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, doubl
     return launch_bcs(h, s, Vx, Vy, Vz, nx, ny, nz, fs, ns, pe);
 }
 jrx_status jrx3d_sumsq(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p) { return launch_sumsq(h, s, f, p); }
+jrx_status jrx3d_bcs_faces(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz, uint32_t fs, uint32_t ns)
+{
+    return launch_bcs_faces(h, s, Vx, Vy, Vz, nx, ny, nz, fs, ns);
+}
 
 // ================================================================================================
 // C ABI

@@ -978,6 +978,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
 
     double err_it1 = 1.0, err = INFINITY;
     int64_t iter = 0, cont = 0;
+    bool bcs_ordered = false;        // the reference's ordered flow_bcs! passes have run on V at least once
     res->iter = 0; res->nchecks = 0;
     const bool comm = jrx_comm_active(h);
     const int64_t nn[3] = {nx, ny, nz};
@@ -1015,7 +1016,8 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         JRX_TRY(jrx3d_velocity_sweep(h, s, &g, etatau, &q, diag));
         if (diag) JRX_TRY(jrx3d_scaleU(h, s, &g, &q));
         // flow_bcs!: on V, or -- DisplacementBoundaryConditions -- on U = V dt, which the next iteration overwrites (only observable when U is)
-        if (!ubc) JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        if (!ubc && !diag && bcs_ordered && p->periodic == 0) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
+        else if (!ubc) { JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic)); bcs_ordered = true; }
         else if (diag) JRX_TRY(jrx3d_bcs(h, s, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
         if (comm) {   // update_halo!(@velocity(stokes)...) (Stokes3D.jl:596); no overlap with the sweep in this driver yet
             double *arrs[3] = {f->Vx, f->Vy, f->Vz};
