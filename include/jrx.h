@@ -542,6 +542,12 @@ jrx_status jrx_center2vertex3d(jrx_handle *h, double *vertex_yz, double *vertex_
  * as args.T is read without the shift to the centres, as the reference's getindex_NamedTuple(args, I...) does (test/test_WENO5.jl:208-214). */
 jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh, const double *phase_c, const double *T, const double *P, const int64_t n[3],
                             const int64_t tdim[3], int32_t ndim);
+/* compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation = ν) -- rheology/Viscosity.jl:118-167, for the creep laws of the rheology table
+ * (phase 0: LinearViscous or the Arrhenius table; they do not depend on the strain rate): eta <- clamp(ν η_creep(T, P) + (1 - ν) eta, cutoff).  args.T has the
+ * extents tdim: ni .+ 2 (the ghosted thermal.T, read at I .+ 1 as local_viscosity_args does, Viscosity.jl:513-523) or ni / NULL (cell centres); P: ni or NULL.
+ * The phase-ratio form is jrx_vep{2d,3d}_compute_viscosity. */
+jrx_status jrx_compute_viscosity_single(jrx_handle *h, double *eta, const jrx_rheology *rh, const double *T, const double *P, const int64_t n[3],
+                                        const int64_t tdim[3], int32_t ndim, double nu, double cutoff_lo, double cutoff_hi);
 /* compute_shear_heating!(thermal, stokes, [phase_ratios,] rheology, dt) -- thermal_diffusion/ShearHeating.jl:14-71:
  * shear_heating = max(0, Χ τ : (ε - ε_el)), ε_el = (τ - τ_o) / (2 G dt), at the cell centres.  tau, tau_o: @tensor_center(stokes.τ / τ_o) in Voigt order
  * (2D: xx, yy, xy_c; 3D: xx, yy, zz, yz_c, xz_c, xy_c), eps: @strain(stokes) (shear components on their edges, averaged to the centre as cache_tensors does).

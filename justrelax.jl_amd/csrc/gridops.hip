@@ -116,6 +116,19 @@ __global__ __launch_bounds__(256) void k_compute_rhog(double *__restrict__ rhog,
     rhog[c] = (PH ? mat_density_ratio(rh, phase_c + (i64)rh.nphase * c, t, p) : mat_density(rh, 0, t, p)) * rh.gravity;
 }
 
+// compute_viscosity_kernel! for ONE MaterialParams (rheology/Viscosity.jl:136-167) with the table's creep laws (LinearViscous, Arrhenius: no strain-rate
+// dependence, so the strain-rate operands drop out): η <- clamp(ν η_creep(T, P) + (1 - ν) η, cutoff).  args.T is read at I .+ 1 (local_viscosity_args,
+// Viscosity.jl:513-523: the ghosted thermal.T) when sh = 1, at the cell's own index otherwise; args.P at I
+__global__ __launch_bounds__(256) void k_viscosity_single(double *__restrict__ eta, const jrx_rheology rh, const double *__restrict__ T, const double *__restrict__ P,
+                                                          int nx, int ny, int t1, int t2, int sh, int shk, double nu, double lo, double hi)
+{
+    OUT_IJK(nx, ny)
+    const i64 c = i + (i64)nx * (j + (i64)ny * k);
+    const double t = T ? T[(i + sh) + (i64)t1 * ((j + sh) + (i64)t2 * (k + shk))] : 0.0, p = P ? P[c] : 0.0;
+    const double e = (1 - nu) * eta[c] + nu * mat_creep_viscosity(rh, 0, t, p);
+    eta[c] = fmin(fmax(e, lo), hi);
+}
+
 struct ShArgs {
     double *sh;
     const double *t[6], *to[6], *e[6];      // Voigt order: 2D xx, yy, xy; 3D xx, yy, zz, yz, xz, xy.  τ, τ_o at the centres; ε shear on its edges
@@ -280,6 +293,26 @@ jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh,
     }
     if (phase_c) hipLaunchKernelGGL(k_compute_rhog<true>, OUT_GRID(nx, ny, nz), dim3(256), 0, h->stream, rhog, *rh, phase_c, T, P, nx, ny, t1, t2);
     else hipLaunchKernelGGL(k_compute_rhog<false>, OUT_GRID(nx, ny, nz), dim3(256), 0, h->stream, rhog, *rh, phase_c, T, P, nx, ny, t1, t2);
+    return done(h);
+}
+
+jrx_status jrx_compute_viscosity_single(jrx_handle *h, double *eta, const jrx_rheology *rh, const double *T, const double *P, const int64_t n[3],
+                                        const int64_t tdim[3], int32_t ndim, double nu, double cutoff_lo, double cutoff_hi)
+{
+    if (!h) return JRX_ERR_ARG;
+    JRX_TRY(jrx_check_device(h));
+    if (!eta || !rh || !n || (ndim != 2 && ndim != 3) || rh->nphase < 1) return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: bad argument");
+    const int nx = (int)n[0], ny = (int)n[1], nz = ndim == 3 ? (int)n[2] : 1;
+    if (nx < 1 || ny < 1 || nz < 1) return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: bad size");
+    int t1 = nx, t2 = ny, sh = 0;
+    if (T && tdim) {
+        bool same = true, ghosted = true;
+        for (int d = 0; d < ndim; d++) { same = same && tdim[d] == n[d]; ghosted = ghosted && tdim[d] == n[d] + 2; }
+        if (!same && !ghosted) return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: args.T must be ni (cell centres) or ni .+ 2 (thermal.T, read at I .+ 1)");
+        t1 = (int)tdim[0]; t2 = (int)tdim[1]; sh = ghosted ? 1 : 0;
+    }
+    hipLaunchKernelGGL(k_viscosity_single, OUT_GRID(nx, ny, nz), dim3(256), 0, h->stream, eta, *rh, T, P, nx, ny, t1, t2, sh, ndim == 3 ? sh : 0, nu, cutoff_lo,
+                       cutoff_hi);
     return done(h);
 }
 

@@ -484,10 +484,30 @@ def tensor_invariant_(A, *, handle=None):
            C.c_int64(A.xx.shape[0]), C.c_int64(A.xx.shape[1]))
 
 
-def compute_viscosity_(stokes, phase_ratios, args, rheology, cutoff=(-float("inf"), float("inf")), *, relaxation=1.0, handle=None):
-    """compute_viscosity!(stokes, phase_ratios, args, rheology, cutoff) for the table rheology (rheology/Viscosity.jl:203-216)"""
+def compute_viscosity_(stokes, *rest, relaxation=1.0, handle=None):
+    """compute_viscosity!(stokes, phase_ratios, args, rheology, cutoff; relaxation) for the table rheology (rheology/Viscosity.jl:203-216), or -- without
+    phase ratios -- compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation) (Viscosity.jl:118-167; args.T is thermal.T, read at I .+ 1)"""
     _require_gpu(stokes)
     h = handle or _lib.default_handle(stokes.P.device.index)
+    from .arrays import PhaseRatios
+    if not rest or not (isinstance(rest[0], PhaseRatios) or hasattr(rest[0], "center")):
+        args, rheology = rest[0], rest[1]
+        cutoff = rest[2] if len(rest) > 2 else (-float("inf"), float("inf"))
+        if isinstance(rheology, (list, tuple)):
+            raise TypeError("several MaterialParams need phase ratios: compute_viscosity!(stokes, phase_ratios, args, rheology, cutoff)")
+        rh = rheology_table([rheology])
+        get = (lambda k: args.get(k)) if isinstance(args, dict) else (lambda k: getattr(args, k, None))
+        T, P = (get("T"), get("P")) if args is not None else (None, None)
+        η = stokes.viscosity.η
+        nd = η.dim()
+        n = (C.c_int64 * 3)(*η.shape, *([1] * (3 - nd)))
+        td = (C.c_int64 * 3)(*(T.shape if T is not None else η.shape), *([1] * (3 - nd)))
+        torch.cuda.current_stream(η.device).synchronize()
+        h.call("jrx_compute_viscosity_single", C.c_void_p(ptr(η)), C.byref(rh), C.c_void_p(ptr(T)), C.c_void_p(ptr(P)), n, td, C.c_int32(nd),
+               C.c_double(float(relaxation)), C.c_double(float(cutoff[0])), C.c_double(float(cutoff[1])))
+        return
+    phase_ratios, args, rheology = rest[0], rest[1], rest[2]
+    cutoff = rest[3] if len(rest) > 3 else (-float("inf"), float("inf"))
     pt = SimpleNamespace(r=0.0, θ_dτ=1.0, ηdτ=1.0, ϵ_rel=0.0, ϵ_abs=0.0)
     if len(stokes._ni) == 3:
         fake = SimpleNamespace(_di=dict(center=(1.0, 1.0, 1.0)))

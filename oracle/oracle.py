@@ -770,6 +770,14 @@ def compute_rhog(rh: "Rheology", T, P, phase_c=None, shape=None):
     return out
 
 
+def compute_viscosity_single(eta, rh: "Rheology", T, P, cutoff=(-np.inf, np.inf), nu=1.0):
+    """compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation) in place on eta -- rheology/Viscosity.jl:118-167 (T: ni or ni .+ 2)"""
+    nd = eta.ndim
+    n = (C.c_int64 * 3)(*eta.shape, *([1] * (3 - nd)))
+    td = (C.c_int64 * 3)(*(T.shape if T is not None else eta.shape), *([1] * (3 - nd)))
+    lib().orc_compute_viscosity_single(_p(eta), C.byref(rh), _p(T), _p(P), n, td, C.c_int32(nd), C.c_double(nu), C.c_double(cutoff[0]), C.c_double(cutoff[1]))
+
+
 def compute_shear_heating(tau, tau_o, eps, rh: "Rheology", chi, dt, phase_c=None):
     """compute_shear_heating! -- ShearHeating.jl:14-71; tau, tau_o: centre arrays in Voigt order, eps: staggered strain rates; chi: Χ per phase"""
     ni = tau[0].shape

@@ -184,6 +184,29 @@ def test_compute_shear_heating_vs_oracle(jr, oracle, ni):
     np.testing.assert_array_equal(_dn(thermal.shear_heating), oracle.compute_shear_heating(tau, tau_o, eps, oracle.rheology_struct(PHASES[:1]), chi[:1], dt))
 
 
+@pytest.mark.parametrize("nd", [2, 3])
+def test_compute_viscosity_single_vs_oracle(jr, oracle, nd):
+    """compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation): Arrhenius table, ghosted and cell-centred T, relaxation, cutoff"""
+    ni = (37, 21) if nd == 2 else (20, 14, 12)
+    ph = dict(eta=5.0e20, G=70e9, Kb=float("inf"), creep=dict(kind="arrhenius", Ea=200.0e3, Va=2.6e-6, T0=1.6e3, R=8.3145, cutoff=(1.0e16, 1.0e25)))
+    rh = oracle.rheology_struct([ph])
+    stokes = jr.StokesArrays(jr.AMDGPUBackend, ni)
+    Tg = np.asfortranarray(300.0 + RNG.random(tuple(n + 2 for n in ni)) * 3000.0)
+    P = np.asfortranarray(RNG.random(ni) * 1.0e10)
+    eta0 = np.asfortranarray(10.0 ** (18 + 6 * RNG.random(ni)))
+    for T, nu, cut in ((Tg, 1.0, (1e16, 1e24)), (Tg, 0.01, (1e19, 1e22)), (np.asfortranarray(Tg[(slice(1, -1),) * nd]), 0.5, (-np.inf, np.inf))):
+        ref = eta0.copy(order="F")
+        oracle.compute_viscosity_single(ref, rh, T, P, cutoff=cut, nu=nu)
+        stokes.viscosity.η.copy_(_up(eta0))
+        jr.compute_viscosity_(stokes, dict(T=_up(T), P=_up(P)), ph, cut, relaxation=nu)
+        np.testing.assert_allclose(_dn(stokes.viscosity.η), ref, rtol=1e-13)
+        assert np.ptp(np.log10(ref)) > 1.0
+    with pytest.raises(RuntimeError, match="ni .\\+ 2"):
+        jr.compute_viscosity_(stokes, dict(T=jr.fzeros(tuple(n + 1 for n in ni), _dev()), P=None), ph, (0.0, 1.0))
+    with pytest.raises(TypeError):
+        jr.compute_viscosity_(stokes, dict(T=None, P=None), [ph, ph], (0.0, 1.0))
+
+
 def test_argument_errors(jr):
     d = _dev()
     with pytest.raises(AssertionError):                      # Interpolations.jl:238 @assert size(Vx_v) == size(Vy_v)

@@ -74,7 +74,8 @@ def test_the_extension_covers_the_reference_method_table():
                            "jrx_tensor_invariant2d", "jrx_tensor_invariant3d", "jrx_shear2center2d", "jrx_shear2center3d", "jrx_accumulate_tensor2d",
                            "jrx_accumulate_tensor3d", "jrx_accumulate_vol", "jrx_compute_maxloc", "jrx_center2vertex2d", "jrx_compute_vorticity2d",
                            "jrx_compute_vorticity3d", "jrx_velocity2vertex2d", "jrx_velocity2vertex3d", "jrx_velocity2center2d", "jrx_velocity2center3d",
-                           "jrx_vertex2center", "jrx_center2vertex3d", "jrx_center2vertex_harm2d", "jrx_compute_rhog", "jrx_compute_shear_heating"]
+                           "jrx_vertex2center", "jrx_center2vertex3d", "jrx_center2vertex_harm2d", "jrx_compute_rhog", "jrx_compute_shear_heating", "jrx_compute_viscosity_single",
+                           "jrx_vep2d_compute_viscosity", "jrx_vep3d_compute_viscosity"]
     missing = [f for f in needed_entry_points if f not in calls]
     assert not missing, missing
     # the generics the reference's AMDGPU extension adds methods to (src/ext/AMDGPU/2D.jl:48-403, 3D.jl:46-412, ext/JustRelaxAMDGPUExt.jl:5-10)
@@ -83,7 +84,7 @@ def test_the_extension_covers_the_reference_method_table():
                 r"JR3D\.ThermalArrays\(::Type\{AMDGPUBackend\}", r"JR2D\.PTThermalCoeffs\(::Type\{AMDGPUBackend\}", r"JR3D\.PTThermalCoeffs\(::Type\{AMDGPUBackend\}",
                 r"JR2D\.heatdiffusion_PT!\(::Trait", r"JR3D\.heatdiffusion_PT!\(::Trait", r"JR2D\.thermal_bcs!\(::Trait", r"JR3D\.thermal_bcs!\(::Trait",
                 r"JR2D\.center2vertex!", r"JR3D\.center2vertex!", r"JR2D\.velocity2vertex!", r"JR3D\.velocity2vertex!", r"JR2D\.velocity2center!",
-                r"JR3D\.velocity2center!", r"JR2D\.vertex2center!", r"JR3D\.vertex2center!", r"\$JR\.compute_ρg!", r"\$JR\.compute_shear_heating!\(::Trait"):
+                r"JR3D\.velocity2center!", r"JR2D\.vertex2center!", r"JR3D\.vertex2center!", r"\$JR\.compute_ρg!", r"\$JR\.compute_shear_heating!\(::Trait", r"\$JR\.compute_viscosity!\(::Trait"):
         assert re.search(pat, txt), pat
     assert len(re.findall(r"function JR2D\.solve!\(::Trait", txt)) == 3          # G, K | phase_ratios | MaterialParams
     assert len(re.findall(r"function JR3D\.solve!\(::Trait", txt)) == 2          # K, G | phase_ratios

@@ -119,3 +119,25 @@ def test_compute_rhog_and_shear_heating(oracle):
     ref = sum((1 if q < 3 else 2) * tau3[q] * (av[q] - 0.5 * (tau3[q] - tau3o[q]) / (1e10 * 2.0)) for q in range(6))
     out = oracle.compute_shear_heating(tau3, tau3o, eps3, rh, chi, 2.0)
     np.testing.assert_allclose(out, np.maximum(0.0, 0.7 * ref), rtol=1e-12, atol=1e-15)
+
+
+def test_compute_viscosity_single(oracle):
+    """compute_viscosity!(stokes, args, rheology, cutoff) of test/test_WENO5.jl:196 (Arrhenius CustomRheology :25-42, T = thermal.T read at I .+ 1): the
+    miniapp builder's host arithmetic is the closed form"""
+    from __graft_entry__ import load_package
+    jr = load_package()
+    s = jr.miniapps.thermal_convection2d(32, ar=1)
+    rh = oracle.rheology_struct([s.extra["rheology"]])
+    eta = np.full(s.ni, 1.0e30, order="F")
+    oracle.compute_viscosity_single(eta, rh, s.arrays["T"], s.arrays["P"], cutoff=s.kwargs["viscosity_cutoff"])
+    np.testing.assert_allclose(eta, s.arrays["eta"], rtol=1e-13)
+    before = eta.copy(order="F")
+    s.arrays["T"][...] *= 1.05
+    oracle.compute_viscosity_single(eta, rh, s.arrays["T"], s.arrays["P"], cutoff=s.kwargs["viscosity_cutoff"], nu=0.25)      # continuation_linear
+    full = before.copy(order="F")
+    oracle.compute_viscosity_single(full, rh, s.arrays["T"], s.arrays["P"], cutoff=s.kwargs["viscosity_cutoff"])
+    np.testing.assert_allclose(eta, np.clip(0.75 * before + 0.25 * full, *s.kwargs["viscosity_cutoff"]), rtol=1e-13)
+    Tc = np.asfortranarray(s.arrays["T"][1:-1, 1:-1])                                    # cell-centred T gives the same numbers without the shift
+    e2 = before.copy(order="F")
+    oracle.compute_viscosity_single(e2, rh, Tc, s.arrays["P"], cutoff=s.kwargs["viscosity_cutoff"])
+    assert np.array_equal(e2, full)
