@@ -511,7 +511,8 @@ jrx_status jrx_heatdiffusion_PT3d_phases(jrx_handle *h, const jrx_thermal3d_fiel
 jrx_status jrx_update_pt_thermal_arrays(jrx_handle *h, double *thetar_dtau, double *dtau_rho, const double *T, const int64_t n[3], int32_t ndim, double dt,
                                         const jrx_thermal_phases *ph, const jrx_thermal_phase_fields *pf);
 /* adiabatic_heating!(thermal, stokes, rheology, phases, _dt) -- DiffusionPT_kernels.jl:720-746: A = (P - P0) * α * _dt over ncells cells, α the phase-weighted thermal
- * expansivity of the density laws (PT_Density, T_Density: α; otherwise 0 -- ASSUMED form of GeoParams' compute_α); phase_c NULL: phase 0 alone */
+ * expansivity of the density laws (PT_Density, T_Density: α; ConstantDensity: 0 -- the values test/test_rheology.jl:57-64 asserts of get_α; Compressible_Density: 0,
+ * assumed); phase_c NULL: phase 0 alone */
 jrx_status jrx_adiabatic_heating(jrx_handle *h, double *adiabatic, const double *P, const double *P0, int64_t ncells, double dt, const jrx_thermal_phases *ph,
                                  const double *phase_c);
 
