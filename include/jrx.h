@@ -213,6 +213,11 @@ typedef struct jrx_stokes2d_params {
     uint32_t free_slip, no_slip, periodic;
     int32_t verbose;
     int32_t displacement_bcs;      /* as in jrx_stokes3d_params (Stokes2D.jl:223) */
+    /* Non-uniform Geometry (Geometry(xvi...), src/grid/Cartesian.jl:77-100): device arrays of INVERSE spacings, all six NULL on a uniform grid (then _dx, _dy
+     * apply).  [0] _di.vertex[1] (nx), [1] _di.vertex[2] (ny), [2] _di.center[1] (nx-1), [3] _di.center[2] (ny-1), [4] _di.velocity[1][2] (y spacing of
+     * the Vx grid, ny+1), [5] _di.velocity[2][1] (x spacing of the Vy grid, nx+1).  Each stencil takes the array the reference's kernel takes
+     * (VelocityKernels.jl:3-44,108-180,246-307).  2D drivers only; the one-launch iteration (k_fused2d) is not used on such a grid. */
+    const double *inv_spacing[6];
 } jrx_stokes2d_params;
 
 /* solve!(stokes, pt_stokes, grid, flow_bcs, ρg, G, K, dt, igg; kwargs) -- src/stokes/Stokes2D.jl:181-325 */
@@ -297,6 +302,7 @@ typedef struct jrx_vep2d_params {
     int32_t T_ghosted;                             /* single-phase driver: args.T is thermal.T (nx+2, ny+2), indexed as the reference does */
     int32_t strain_increment;                      /* kwarg strain_increment (jrx_stokes2d_vep_solve only; Stokes2D.jl:588,659-734, StressKernels.jl:1147-1302): strains
                                                     * from the displacement increments U = V dt, Δε form of the stress update; U and its BCs are refreshed every iteration */
+    const double *inv_spacing[6];                  /* non-uniform Geometry: as in jrx_stokes2d_params (all NULL: uniform); not with strain_increment */
 } jrx_vep2d_params;
 
 jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p,

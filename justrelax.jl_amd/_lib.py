@@ -56,7 +56,7 @@ class Stokes2DParams(C.Structure):
                 ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32), ("verbose", C.c_int32),
-                ("displacement_bcs", C.c_int32)]
+                ("displacement_bcs", C.c_int32), ("inv_spacing", C.c_void_p * 6)]
 
 
 class Thermal2DParams(C.Structure):
@@ -118,7 +118,8 @@ class VEP2DParams(C.Structure):
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("iterMin", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
-                ("verbose", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32), ("strain_increment", C.c_int32)]
+                ("verbose", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32), ("strain_increment", C.c_int32),
+                ("inv_spacing", C.c_void_p * 6)]
 
 
 VEP3_NAMES = ["P", "P0", "divV", "Q", "Vx", "Vy", "Vz", "Ux", "Uy", "Uz",

@@ -11,9 +11,17 @@
 
 namespace {
 
+// inverse spacings of a non-uniform Geometry (src/grid/Cartesian.jl:77-100): device arrays, all NULL on a uniform grid (then the scalars _dx, _dy apply).
+// vx, vy = _di.vertex (nx | ny entries: cell sizes), cx, cy = _di.center (nx-1 | ny-1: distances of the cell centres), vxy = _di.velocity[1][2] (y spacing of the
+// Vx grid with its ghost rows, ny+1), vyx = _di.velocity[2][1] (x spacing of the Vy grid, nx+1).  Which one a stencil takes is the reference's choice, kernel by
+// kernel (VelocityKernels.jl:3-44,108-180,246-307, stress_rotation_particles.jl:17-29).
+struct Sp2 { const double *vx, *vy, *cx, *cy, *vxy, *vyx; };
+__device__ __forceinline__ double spc(const double *a, const int i, const double u) { return a ? a[i] : u; }
+
 struct Args2 {
     jrx_stokes2d_fields f;
     const double *etatau;
+    Sp2 sp;
     double _dx, _dy, dt, r, theta_dtau, eta_dtau;
     int nx, ny;
     unsigned fs, ns;      // free_slip / no_slip face masks for the velocity kernel's fused ghost update (BCF)
@@ -40,11 +48,11 @@ __global__ __launch_bounds__(256) void k_stress2d(const Args2 a)
     const int j = t / (nx + 1), i = t - j * (nx + 1);
     if (j > ny) return;
     const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
-    const double _dx = a._dx, _dy = a._dy, dt = a.dt, th = a.theta_dtau;
+    const double dt = a.dt, th = a.theta_dtau;
     if (i < nx && j < ny) {
         const i64 c = CC(i, j);
-        const double dxi = (-VX(i, j + 1) + VX(i + 1, j + 1)) * _dx;
-        const double dyi = (-VY(i + 1, j) + VY(i + 1, j + 1)) * _dy;
+        const double dxi = (-VX(i, j + 1) + VX(i + 1, j + 1)) * spc(a.sp.vx, i, a._dx);
+        const double dyi = (-VY(i + 1, j) + VY(i + 1, j + 1)) * spc(a.sp.vy, j, a._dy);
         const double divV = dxi + dyi;
         const double _Gdt = 1.0 / (G[c] * dt);
         {   // compute_P! with ητ (Stokes2D.jl:231-233)
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256) void k_stress2d(const Args2 a)
     }
     {   // vertex (i,j) of (nx+1, ny+1)
         const int im = max(i - 1, 0), ip = min(i, nx - 1), jm = max(j - 1, 0), jp = min(j, ny - 1);
-        const double exy = 0.5 * (_dy * (VX(i, j + 1) - VX(i, j)) + _dx * (VY(i + 1, j) - VY(i, j)));
+        const double exy = 0.5 * (spc(a.sp.vxy, j, a._dy) * (VX(i, j + 1) - VX(i, j)) + spc(a.sp.vyx, i, a._dx) * (VY(i + 1, j) - VY(i, j)));
         const double e = 0.25 * (eta[CC(im, jm)] + eta[CC(ip, jm)] + eta[CC(im, jp)] + eta[CC(ip, jp)]);
         const double g = 0.25 * (G[CC(im, jm)] + G[CC(ip, jm)] + G[CC(im, jp)] + G[CC(ip, jp)]);
         const double _Gdt = 1.0 / (g * dt);
@@ -87,11 +95,12 @@ template <bool RES_ONLY, bool BCF>
 __device__ __forceinline__ void velocity2d_cell(const Args2 &a, const int i, const int j)
 {
     const int nx = a.nx, ny = a.ny;
-    const double _dx = a._dx, _dy = a._dy, edt = a.eta_dtau;
+    const double edt = a.eta_dtau;
     const double *__restrict__ P = a.f.P, *__restrict__ txy = a.f.txy, *__restrict__ et = a.etatau;
 #define TXY(i_, j_) txy[(i_) + (i64)(nx + 1) * (j_)]
     const i64 c = CC(i, j);
     if (i < nx - 1) {
+        const double _dx = spc(a.sp.cx, i, a._dx), _dy = spc(a.sp.vy, j, a._dy);        // _dx_c, _dy_v
         const double dP = (-P[c] + P[c + 1]) * _dx, dT = (-a.f.txx[c] + a.f.txx[c + 1]) * _dx;
         const double dS = (-TXY(i + 1, j) + TXY(i + 1, j + 1)) * _dy, av = (a.f.fx[c] + a.f.fx[c + 1]) * 0.5;
         if (RES_ONLY) a.f.Rx[i + (i64)(nx - 1) * j] = dT + dS - dP - av;
@@ -106,6 +115,7 @@ __device__ __forceinline__ void velocity2d_cell(const Args2 &a, const int i, con
         }
     }
     if (j < ny - 1) {
+        const double _dx = spc(a.sp.vx, i, a._dx), _dy = spc(a.sp.cy, j, a._dy);        // _dx_v, _dy_c
         const double dP = (-P[c] + P[c + nx]) * _dy, dT = (-a.f.tyy[c] + a.f.tyy[c + nx]) * _dy;
         const double dS = (-TXY(i, j + 1) + TXY(i + 1, j + 1)) * _dx, av = (a.f.fy[c] + a.f.fy[c + nx]) * 0.5;
         double corr = 0.0;
@@ -252,7 +262,16 @@ Args2 make_args2(const jrx_stokes2d_fields *f, const double *etatau, const jrx_s
     a._dx = p->_dx; a._dy = p->_dy; a.dt = p->dt; a.r = p->r; a.theta_dtau = p->theta_dtau; a.eta_dtau = p->eta_dtau;
     a.nx = (int)p->nx; a.ny = (int)p->ny;
     a.fs = p->free_slip; a.ns = p->no_slip;
+    a.sp = Sp2{p->inv_spacing[0], p->inv_spacing[1], p->inv_spacing[2], p->inv_spacing[3], p->inv_spacing[4], p->inv_spacing[5]};
     return a;
+}
+
+// the six inverse-spacing arrays of a non-uniform grid come together or not at all
+bool spacing_ok(const double *const sp[6])
+{
+    int n = 0;
+    for (int q = 0; q < 6; q++) n += sp[q] != nullptr;
+    return n == 0 || n == 6;
 }
 
 jrx_status check2(jrx_handle *h, const jrx_stokes2d_fields *f, const jrx_stokes2d_params *p)
@@ -266,6 +285,7 @@ jrx_status check2(jrx_handle *h, const jrx_stokes2d_fields *f, const jrx_stokes2
                          f->exx, f->eyy, f->exy, f->eta, f->K, f->G, f->fx, f->fy, f->RP, f->Rx, f->Ry};
     for (const void *q : req)
         if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required 2D field pointer is NULL");
+    if (!spacing_ok(p->inv_spacing)) return jrx_fail(h, JRX_ERR_ARG, "non-uniform grid: all six inverse-spacing arrays are required");
     return JRX_OK;
 }
 
@@ -458,7 +478,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     // measured with the XCD slab block order (SolCx, profiles/r02_bench2d_xcd_slabs.txt; it/s two kernels vs fused): 128^2 175.9 k / 176.2 k, 256^2 135.2 k /
     // 144.2 k, 384^2 101.5 k / 106.7 k, 512^2 79.1 k / 73.6 k, 768^2 40.1 k / 38.8 k, 1024^2 equal -- fused up to 200,000 nodes (~ 440^2)
     const bool fusable = !p->displacement_bcs && h->fused2d && h->scratch_sets && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 200000)) &&
-                         !jrx_comm_active(h) && p->periodic == 0 && nx >= 2 && ny >= 2;
+                         !jrx_comm_active(h) && p->periodic == 0 && nx >= 2 && ny >= 2 && !p->inv_spacing[0];
     const size_t nvx = (size_t)(nx + 1) * (ny + 2), nvy = (size_t)(nx + 2) * (ny + 1), nvt = (size_t)(nx + 1) * (ny + 1);
     Out6_2d setU = {f->P, f->txx, f->tyy, f->txy, f->Vx, f->Vy}, setS = setU;
     if (fusable) {
@@ -581,6 +601,7 @@ struct VepArgs {
     const double *theta, *etatau, *Kc, *Gc;
     double *lam, *lamv;
     double *txx_out = nullptr, *tyy_out = nullptr;      // where the centre half writes τxx, τyy (nullptr: in place)
+    Sp2 sp;                                             // non-uniform grid: inverse spacing arrays (all NULL: _dx, _dy)
     double _dx, _dy, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
     int nx, ny;
     bool soft;            // some phase has a softening law (EII_pl is then read by the yield function)
@@ -657,8 +678,8 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
 #define VY(i_, j_) Vy[(i_) + (i64)(nx + 2) * (j_)]
     if (i < nx && j < ny) {
         const i64 c = i + (i64)nx * j;
-        const double dxi = (-VX(i, j + 1) + VX(i + 1, j + 1)) * a._dx;
-        const double dyi = (-VY(i + 1, j) + VY(i + 1, j + 1)) * a._dy;
+        const double dxi = (-VX(i, j + 1) + VX(i + 1, j + 1)) * spc(a.sp.vx, i, a._dx);
+        const double dyi = (-VY(i + 1, j) + VY(i + 1, j + 1)) * spc(a.sp.vy, j, a._dy);
         const double divV = dxi + dyi;
         a.f.divV[c] = divV;
         const double _Kdt = 1.0 / (a.Kc[c] * a.dt), _Gdt = 1.0 / (a.Gc[c] * a.dt), _dt = 1.0 / a.dt;
@@ -684,7 +705,7 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
         a.f.eyy[c] = dyi - d3;
         if (RHO) a.f.fy[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)a.rh.nphase * c, a.f.T ? a.f.T[c] : 0.0, a.f.P[c]) * a.rh.gravity;
     }
-    a.f.exy[i + (i64)(nx + 1) * j] = 0.5 * (a._dy * (VX(i, j + 1) - VX(i, j)) + a._dx * (VY(i + 1, j) - VY(i, j)));
+    a.f.exy[i + (i64)(nx + 1) * j] = 0.5 * (spc(a.sp.vxy, j, a._dy) * (VX(i, j + 1) - VX(i, j)) + spc(a.sp.vyx, i, a._dx) * (VY(i + 1, j) - VY(i, j)));
 #undef VX
 #undef VY
 }
@@ -1076,8 +1097,8 @@ __global__ __launch_bounds__(256) void k_vep_epilogue(const VepArgs a)
     const int j = t / (nx + 1), i = t - j * (nx + 1);
     if (j > ny) return;
     if (a.f.omega_xy)
-        V2(a.f.omega_xy, i, j) = 0.5 * ((-a.f.Vy[i + (i64)(nx + 2) * j] + a.f.Vy[(i + 1) + (i64)(nx + 2) * j]) * a._dx -
-                                        (-a.f.Vx[i + (i64)(nx + 1) * j] + a.f.Vx[i + (i64)(nx + 1) * (j + 1)]) * a._dy);
+        V2(a.f.omega_xy, i, j) = 0.5 * ((-a.f.Vy[i + (i64)(nx + 2) * j] + a.f.Vy[(i + 1) + (i64)(nx + 2) * j]) * spc(a.sp.vyx, i, a._dx) -
+                                        (-a.f.Vx[i + (i64)(nx + 1) * j] + a.f.Vx[i + (i64)(nx + 1) * (j + 1)]) * spc(a.sp.vxy, j, a._dy));
     if (i < nx && j < ny) {
         const i64 c = i + (i64)nx * j;
 #define S2C(V) (0.25 * (V2(V, i, j) + V2(V, i + 1, j) + V2(V, i, j + 1) + V2(V, i + 1, j + 1)))
@@ -1107,6 +1128,9 @@ jrx_status check_vep(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheolog
         if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required VEP field pointer is NULL");
     if (p->strain_increment && (!f->dexx || !f->deyy || !f->dexy || !f->divU))
         return jrx_fail(h, JRX_ERR_ARG, "strain_increment: the Δε (xx, yy, xy) and ∇U arrays are required");
+    if (!spacing_ok(p->inv_spacing)) return jrx_fail(h, JRX_ERR_ARG, "non-uniform grid: all six inverse-spacing arrays are required");
+    if (p->inv_spacing[0] && p->strain_increment)
+        return jrx_fail(h, JRX_ERR_UNSUPPORTED, "strain_increment on a non-uniform grid is not built (the reference's own kernel indexes _di.center beyond its extent there)");
     return JRX_OK;
 }
 
@@ -1120,6 +1144,7 @@ VepArgs make_vep(const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_ve
     a.nx = (int)p->nx; a.ny = (int)p->ny;
     a.soft = mat_has_softening(rh);
     a.si = p->strain_increment != 0;
+    a.sp = Sp2{p->inv_spacing[0], p->inv_spacing[1], p->inv_spacing[2], p->inv_spacing[3], p->inv_spacing[4], p->inv_spacing[5]};
     return a;
 }
 
@@ -1275,6 +1300,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     memset(&q, 0, sizeof(q));
     q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
     q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
+    for (int d = 0; d < 6; d++) q.inv_spacing[d] = p->inv_spacing[d];
     Args2 b = make_args2(&g, etatau, &q);
     const unsigned gv = (unsigned)((nv + 255) / 256), gc = (unsigned)((n + 255) / 256);
 
@@ -1460,6 +1486,7 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
     memset(&q, 0, sizeof(q));
     q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
     q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
+    for (int d = 0; d < 6; d++) q.inv_spacing[d] = p->inv_spacing[d];
     Args2 b = make_args2(&g, etatau, &q);
     b.fs_dt = p->dt * (double)(p->free_surface != 0);
     const unsigned gv = (unsigned)((nv + 255) / 256), gc = (unsigned)((n + 255) / 256);

@@ -176,7 +176,46 @@ class IGG:
 
 
 class Geometry:
-    """Geometry(ni, li; origin) -- src/grid/Cartesian.jl:42-58, src/grid/Grid.jl:56-143."""
+    """Geometry(ni, li; origin) -- src/grid/Cartesian.jl:42-58, src/grid/Grid.jl:56-143; Geometry.from_vertices(xvi) is the non-uniform constructor
+    Geometry(xvi::NTuple) (Cartesian.jl:77-100)."""
+
+    nonuniform = False
+
+    @classmethod
+    def from_vertices(cls, xvi):
+        """Geometry(TA, xvi...) / Geometry(xvi::NTuple) -- src/grid/Cartesian.jl:77-100: a staggered grid from explicit vertex coordinates; spacings are
+        vectors: di.vertex = diff(xvi) (n), di.center = diff(xci) (n - 1), di.velocity[i][d] = diff of the ghosted velocity grids (Grid.jl:171-215)"""
+        xvi = tuple(np.asarray(x, dtype=np.float64) for x in xvi)
+        nD = len(xvi)
+        g = cls.__new__(cls)
+        g.nonuniform = True
+        g.ni = tuple(len(x) - 1 for x in xvi)
+        g.xvi = xvi
+        g.xci = tuple((x[:-1] + x[1:]) / 2 for x in xvi)
+        g.li = tuple(float(x.max() - x.min()) for x in xvi)
+        g.origin = tuple(float(x.min()) for x in xvi)
+        g.max_li = max(g.li)
+        dv, dc = tuple(np.diff(x) for x in xvi), tuple(np.diff(x) for x in g.xci)
+        ghost = tuple(np.concatenate(([c[0] - d[0]], c, [c[-1] + d[-1]])) for c, d in zip(g.xci, dc))      # velocity_grids, Grid.jl:171-182,202-215
+        g.xi_vel = tuple(tuple(xvi[d] if d == i else ghost[d] for d in range(nD)) for i in range(nD))
+        dvel = tuple(tuple(np.diff(x) for x in gv) for gv in g.xi_vel)
+        g.di = dict(center=dc, vertex=dv, velocity=dvel)
+        g._di = dict(center=tuple(1.0 / x for x in dc), vertex=tuple(1.0 / x for x in dv), velocity=tuple(tuple(1.0 / x for x in gv) for gv in dvel))
+        g._dev = {}
+        return g
+
+    def inv_spacing2d(self, device):
+        """the six inverse-spacing arrays of the 2D C ABI (jrx_stokes2d_params.inv_spacing) as device tensors, cached per device"""
+        import torch
+        if device not in self._dev:
+            d = self._di
+            host = (d["vertex"][0], d["vertex"][1], d["center"][0], d["center"][1], d["velocity"][0][1], d["velocity"][1][0])
+            self._dev[device] = tuple(torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device) for a in host)
+        return self._dev[device]
+
+    def inv_spacing2d_host(self):
+        d = self._di
+        return (d["vertex"][0], d["vertex"][1], d["center"][0], d["center"][1], d["velocity"][0][1], d["velocity"][1][0])
 
     def __init__(self, ni, li, origin=None):
         nD = len(ni)

@@ -37,7 +37,19 @@ def _as_field(x, ni, dev):
 
 def _center_inv(grid):
     _di = getattr(grid, "_di", None)
+    if getattr(grid, "nonuniform", False):          # the scalars are unused then (every stencil reads its spacing array); keep them finite
+        return tuple(float(n) / float(l) for n, l in zip(grid.ni, grid.li))
     return _di["center"] if isinstance(_di, dict) else _di
+
+
+def _set_spacing2d(p, grid, stokes):
+    """non-uniform Geometry: hand the six inverse-spacing arrays to the C ABI (kept alive on the params object)"""
+    if not getattr(grid, "nonuniform", False):
+        return
+    arrs = grid.inv_spacing2d(stokes.P.device)
+    p._spacing_keepalive = arrs
+    for q, a in enumerate(arrs):
+        p.inv_spacing[q] = a.data_ptr()
 
 
 def _as_grid(stokes, grid_or_di):
@@ -109,6 +121,8 @@ def params3d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10_000, nout=500, b_widt
     p.b_width[0], p.b_width[1], p.b_width[2] = [int(b) for b in b_width]
     p.verbose = int(bool(verbose))
     p.displacement_bcs = int(_is_displacement(flow_bcs))
+    if getattr(grid, "nonuniform", False):
+        raise NotImplementedError("non-uniform grids are built for the 2D drivers only")
     return p
 
 
@@ -127,6 +141,7 @@ def params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10_000, nout=500, verbos
                                               _lib.bcmask(flow_bcs.periodic))
     p.verbose = int(bool(verbose))
     p.displacement_bcs = int(_is_displacement(flow_bcs))
+    _set_spacing2d(p, grid, stokes)
     return p
 
 
@@ -253,6 +268,7 @@ def vep_params2d(stokes, pt, grid, flow_bcs, dt, *, iterMax=50.0e3, iterMin=1.0e
     p.free_surface = int(bool(free_surface))
     p.displacement_bcs = int(_is_displacement(flow_bcs))
     p.strain_increment = int(bool(strain_increment))
+    _set_spacing2d(p, grid, stokes)
     return p
 
 

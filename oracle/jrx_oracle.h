@@ -112,8 +112,12 @@ typedef struct orc_params2d {
     int64_t iterMax, nout;
     uint32_t free_slip, no_slip, periodic;
     int32_t displacement_bcs;    /* as in orc_params3d (Stokes2D.jl:223) */
+    /* non-uniform Geometry (src/grid/Cartesian.jl:77-100): inverse spacings, all NULL on a uniform grid: [0] _di.vertex[1] (nx), [1] _di.vertex[2] (ny),
+     * [2] _di.center[1] (nx-1), [3] _di.center[2] (ny-1), [4] _di.velocity[1][2] (ny+1), [5] _di.velocity[2][1] (nx+1) */
+    const double *inv_spacing[6];
 } orc_params2d;
 
+void orc_compute_divV2d_sp(double *divV, const double *Vx, const double *Vy, int64_t nx, int64_t ny, double _dx, double _dy, const double *const *sp);
 void orc_compute_divV2d(double *divV, const double *Vx, const double *Vy, int64_t nx, int64_t ny,
                         double _dx, double _dy);
 void orc_compute_strain_rate2d(const orc_fields2d *f, const orc_params2d *p);
@@ -280,6 +284,7 @@ typedef struct orc_vep_params2d {
     int32_t displacement_bcs;                     /* flow_bcs is a DisplacementBoundaryConditions: V = U / dt first, flow_bcs! acts on U (BoundaryConditions.jl:71-78) */
     int32_t T_ghosted;                            /* single-phase driver: args.T is thermal.T (nx+2, ny+2), indexed as the reference does */
     int32_t strain_increment;                     /* kwarg strain_increment (Stokes2D.jl:588,659-734): strains from the displacement increments, Δε form of the stress update */
+    const double *inv_spacing[6];                 /* as in orc_params2d */
 } orc_vep_params2d;
 
 int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, orc_result *res);

@@ -107,7 +107,19 @@ class Params2D(C.Structure):
                 ("dt", C.c_double), ("r", C.c_double), ("theta_dtau", C.c_double), ("eta_dtau", C.c_double),
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double),
                 ("iterMax", C.c_int64), ("nout", C.c_int64),
-                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32), ("displacement_bcs", C.c_int32)]
+                ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32), ("displacement_bcs", C.c_int32),
+                ("inv_spacing", C.POINTER(C.c_double) * 6)]
+
+
+def set_spacing2d(p, inv_spacing):
+    """non-uniform Geometry: the six inverse-spacing arrays (_di.vertex x / y, _di.center x / y, _di.velocity[1][2], _di.velocity[2][1]) of Params2D / VEPParams2D;
+    the arrays are kept alive on the params object"""
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in inv_spacing]
+    assert len(arrs) == 6
+    p._spacing_keepalive = arrs
+    for q, a in enumerate(arrs):
+        p.inv_spacing[q] = a.ctypes.data_as(C.POINTER(C.c_double))
+    return p
 
 
 class ThermalParams2D(C.Structure):
@@ -397,7 +409,7 @@ class VEPParams2D(C.Structure):
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
                 ("staggered_invariant_mean_of_squares", C.c_int32), ("free_surface", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32),
-                ("strain_increment", C.c_int32)]
+                ("strain_increment", C.c_int32), ("inv_spacing", C.POINTER(C.c_double) * 6)]
 
 
 def vep_shapes2d(nx, ny, nphase):

@@ -17,10 +17,17 @@
 void orc_compute_divV2d(double *divV, const double *Vx, const double *Vy, int64_t nx, int64_t ny,
                         double _dx, double _dy)
 {
+    orc_compute_divV2d_sp(divV, Vx, Vy, nx, ny, _dx, _dy, NULL);
+}
+/* the same on a non-uniform grid: compute_∇V!(∇V, V, _di.vertex) (Stokes2D.jl:229); sp = the six inverse-spacing arrays of orc_params2d or NULL */
+#define SPC(arr, idx, uni) ((arr) ? (arr)[idx] : (uni))
+void orc_compute_divV2d_sp(double *divV, const double *Vx, const double *Vy, int64_t nx, int64_t ny, double _dx, double _dy, const double *const *sp)
+{
+    const double *vx = sp ? sp[0] : NULL, *vy = sp ? sp[1] : NULL;
 #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < ny; j++)
         for (int64_t i = 0; i < nx; i++)
-            divV[IDX2(nx, i, j)] = (-VX(i, j + 1) + VX(i + 1, j + 1)) * _dx + (-VY(i + 1, j) + VY(i + 1, j + 1)) * _dy;
+            divV[IDX2(nx, i, j)] = (-VX(i, j + 1) + VX(i + 1, j + 1)) * SPC(vx, i, _dx) + (-VY(i + 1, j) + VY(i + 1, j + 1)) * SPC(vy, j, _dy);
 }
 
 /* src/stokes/VelocityKernels.jl:10-44 ; launch box ni.+1 */
@@ -28,16 +35,17 @@ void orc_compute_strain_rate2d(const orc_fields2d *f, const orc_params2d *p)
 {
     const int64_t nx = p->nx, ny = p->ny;
     const double _dx = p->_dx, _dy = p->_dy;
+    const double *const *sp = p->inv_spacing;       /* _di.vertex for the normal components, _di.velocity[1][2] / [2][1] for the shear one (VelocityKernels.jl:22,33-34) */
     const double *Vx = f->Vx, *Vy = f->Vy;
 #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < ny + 1; j++)
         for (int64_t i = 0; i < nx + 1; i++) {
             if (i < nx && j < ny) {
                 double d3 = C(f->divV, i, j) * inv(3.0);
-                C(f->exx, i, j) = (-VX(i, j + 1) + VX(i + 1, j + 1)) * _dx - d3;
-                C(f->eyy, i, j) = (-VY(i + 1, j) + VY(i + 1, j + 1)) * _dy - d3;
+                C(f->exx, i, j) = (-VX(i, j + 1) + VX(i + 1, j + 1)) * SPC(sp[0], i, _dx) - d3;
+                C(f->eyy, i, j) = (-VY(i + 1, j) + VY(i + 1, j + 1)) * SPC(sp[1], j, _dy) - d3;
             }
-            XY(f->exy, i, j) = 0.5 * (_dy * (VX(i, j + 1) - VX(i, j)) + _dx * (VY(i + 1, j) - VY(i, j)));
+            XY(f->exy, i, j) = 0.5 * (SPC(sp[4], j, _dy) * (VX(i, j + 1) - VX(i, j)) + SPC(sp[5], i, _dx) * (VY(i + 1, j) - VY(i, j)));
         }
 }
 
@@ -80,19 +88,22 @@ void orc_compute_V2d(const orc_fields2d *f, const double *etatau, const orc_para
 void orc_compute_V2d_fs(const orc_fields2d *f, const double *etatau, const orc_params2d *p, double fs_dt)
 {
     const int64_t nx = p->nx, ny = p->ny;
-    const double _dx = p->_dx, _dy = p->_dy, edt = p->eta_dtau;
+    const double edt = p->eta_dtau;
+    const double *const *sp = p->inv_spacing;
     double *Vx = f->Vx, *Vy = f->Vy;
     const double *P = f->P;
 #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < ny; j++)
         for (int64_t i = 0; i < nx; i++) {
             if (i < nx - 1) { /* all((i,j) .< size(Vx) .- 1) : i <= nx-1, j <= ny (1-based) */
+                const double _dx = SPC(sp[2], i, p->_dx), _dy = SPC(sp[1], j, p->_dy);      /* _dx_c, _dy_v (VelocityKernels.jl:115-116) */
                 double r = -((-C(P, i, j) + C(P, i + 1, j)) * _dx) + (-C(f->txx, i, j) + C(f->txx, i + 1, j)) * _dx +
                            (-XY(f->txy, i + 1, j) + XY(f->txy, i + 1, j + 1)) * _dy -
                            (C(f->fx, i, j) + C(f->fx, i + 1, j)) * 0.5;
                 VX(i + 1, j + 1) += r * edt / ((C(etatau, i, j) + C(etatau, i + 1, j)) * 0.5);
             }
             if (j < ny - 1) {
+                const double _dx = SPC(sp[0], i, p->_dx), _dy = SPC(sp[3], j, p->_dy);      /* _dx_v, _dy_c (:123-124) */
                 double r = -((-C(P, i, j) + C(P, i, j + 1)) * _dy) + (-C(f->tyy, i, j) + C(f->tyy, i, j + 1)) * _dy +
                            (-XY(f->txy, i, j + 1) + XY(f->txy, i + 1, j + 1)) * _dx -
                            (C(f->fy, i, j) + C(f->fy, i, j + 1)) * 0.5;
@@ -113,16 +124,19 @@ void orc_compute_Res2d(const orc_fields2d *f, const orc_params2d *p) { orc_compu
 void orc_compute_Res2d_fs(const orc_fields2d *f, const orc_params2d *p, double fs_dt)
 {
     const int64_t nx = p->nx, ny = p->ny;
-    const double _dx = p->_dx, _dy = p->_dy;
+    const double *const *sp = p->inv_spacing;
     const double *P = f->P;
 #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < ny; j++)
         for (int64_t i = 0; i < nx; i++) {
-            if (i < nx - 1)
+            if (i < nx - 1) {
+                const double _dx = SPC(sp[2], i, p->_dx), _dy = SPC(sp[1], j, p->_dy);
                 f->Rx[IDX2(nx - 1, i, j)] = (-C(f->txx, i, j) + C(f->txx, i + 1, j)) * _dx +
                                             (-XY(f->txy, i + 1, j) + XY(f->txy, i + 1, j + 1)) * _dy -
                                             (-C(P, i, j) + C(P, i + 1, j)) * _dx - (C(f->fx, i, j) + C(f->fx, i + 1, j)) * 0.5;
+            }
             if (j < ny - 1) {
+                const double _dx = SPC(sp[0], i, p->_dx), _dy = SPC(sp[3], j, p->_dy);
                 double r = (-C(f->tyy, i, j) + C(f->tyy, i, j + 1)) * _dy +
                            (-XY(f->txy, i, j + 1) + XY(f->txy, i + 1, j + 1)) * _dx -
                            (-C(P, i, j) + C(P, i, j + 1)) * _dy - (C(f->fy, i, j) + C(f->fy, i, j + 1)) * 0.5;
@@ -215,7 +229,7 @@ void orc_residual_sumsq2d(const orc_fields2d *f, const orc_params2d *p, double o
 /* src/stokes/Stokes2D.jl:229-269 ; note compute_P! receives ητ here (App. C #3) */
 void orc_stokes2d_iteration(const orc_fields2d *f, const double *etatau, const orc_params2d *p)
 {
-    orc_compute_divV2d(f->divV, f->Vx, f->Vy, p->nx, p->ny, p->_dx, p->_dy);
+    orc_compute_divV2d_sp(f->divV, f->Vx, f->Vy, p->nx, p->ny, p->_dx, p->_dy, p->inv_spacing);
     orc_compute_P3d(f->P, f->P0, f->RP, f->divV, f->Q, etatau, f->K, f->G, p->nx * p->ny, p->dt, p->r, p->theta_dtau);
     orc_compute_strain_rate2d(f, p);
     orc_compute_tau2d(f, p);

@@ -353,6 +353,7 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
     orc_params2d q;
     memset(&q, 0, sizeof(q));
     q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
+    for (int d_ = 0; d_ < 6; d_++) q.inv_spacing[d_] = p->inv_spacing[d_];
     q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
 
     /* compute_ρg!(ρg, phase_ratios, rheology, args) :646 -- scalar gravity fills the last component (BuoyancyForces.jl:69-70) */
@@ -374,7 +375,7 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
         if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;    /* :650-651 */
         orc_compute_maxloc2d(etatau, f->eta, nx, ny);
         { const int64_t e[3] = {nx, ny, 1}; orc_self_halo(etatau, e, e); }                               /* update_halo!(ητ) :655 */
-        orc_compute_divV2d(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy);
+        orc_compute_divV2d_sp(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy, p->inv_spacing);
         orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :663-676 */
         if (upd_rho)                                    /* update_ρg!(ρg, phase_ratios, rheology, args) :678 ; args.P is stokes.P */
             for (size_t c = 0; c < n; c++) f->fy[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
@@ -421,8 +422,8 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
         if (f->omega_xy)                                /* compute_vorticity! :831-833 */
             for (int64_t j = 0; j < ny + 1; j++)
                 for (int64_t i = 0; i < nx + 1; i++)
-                    V2(f->omega_xy, i, j) = 0.5 * ((-f->Vy[IDX2(nx + 2, i, j)] + f->Vy[IDX2(nx + 2, i + 1, j)]) * p->_dx -
-                                                   (-f->Vx[IDX2(nx + 1, i, j)] + f->Vx[IDX2(nx + 1, i, j + 1)]) * p->_dy);
+                    V2(f->omega_xy, i, j) = 0.5 * ((-f->Vy[IDX2(nx + 2, i, j)] + f->Vy[IDX2(nx + 2, i + 1, j)]) * (p->inv_spacing[5] ? p->inv_spacing[5][i] : p->_dx) -
+                                                   (-f->Vx[IDX2(nx + 1, i, j)] + f->Vx[IDX2(nx + 1, i, j + 1)]) * (p->inv_spacing[4] ? p->inv_spacing[4][j] : p->_dy));
         shear2center(f->exy_c, f->exy, nx, ny);
         shear2center(f->eplxy_c, f->eplxy, nx, ny);
         shear2center(f->dexy_c, f->dexy, nx, ny);
@@ -505,6 +506,7 @@ int32_t orc_stokes2d_nonlinear_solve(const orc_vep2d *f, const orc_rheology *rh,
     orc_params2d q;
     memset(&q, 0, sizeof(q));
     q.nx = nx; q.ny = ny; q.nxg = p->nxg; q.nyg = p->nyg; q._dx = p->_dx; q._dy = p->_dy; q.dt = p->dt; q.r = p->r;
+    for (int d_ = 0; d_ < 6; d_++) q.inv_spacing[d_] = p->inv_spacing[d_];
     q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
 
     double err_it1 = 1.0, err = 1.0;
@@ -512,7 +514,7 @@ int32_t orc_stokes2d_nonlinear_solve(const orc_vep2d *f, const orc_rheology *rh,
     res->status = 0;
     while (iter < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && iter <= p->iterMax)) {      /* :412 */
         orc_compute_maxloc2d(etatau, f->eta, nx, ny);
-        orc_compute_divV2d(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy);
+        orc_compute_divV2d_sp(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy, p->inv_spacing);
         orc_compute_P3d(f->P, f->P0, f->RP, f->divV, f->Q, f->eta, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* with η, in place :418-420 */
         if (upd_rho) rhog_single(f, rh, p);                                        /* update_ρg!(ρg[2], rheology, args) :422 */
         orc_compute_strain_rate2d(&g, &q);
@@ -547,8 +549,8 @@ int32_t orc_stokes2d_nonlinear_solve(const orc_vep2d *f, const orc_rheology *rh,
         if (f->omega_xy)
             for (int64_t j = 0; j < ny + 1; j++)
                 for (int64_t i = 0; i < nx + 1; i++)
-                    V2(f->omega_xy, i, j) = 0.5 * ((-f->Vy[IDX2(nx + 2, i, j)] + f->Vy[IDX2(nx + 2, i + 1, j)]) * p->_dx -
-                                                   (-f->Vx[IDX2(nx + 1, i, j)] + f->Vx[IDX2(nx + 1, i, j + 1)]) * p->_dy);
+                    V2(f->omega_xy, i, j) = 0.5 * ((-f->Vy[IDX2(nx + 2, i, j)] + f->Vy[IDX2(nx + 2, i + 1, j)]) * (p->inv_spacing[5] ? p->inv_spacing[5][i] : p->_dx) -
+                                                   (-f->Vx[IDX2(nx + 1, i, j)] + f->Vx[IDX2(nx + 1, i, j + 1)]) * (p->inv_spacing[4] ? p->inv_spacing[4][j] : p->_dy));
         shear2center(f->exy_c, f->exy, nx, ny);
         shear2center(f->eplxy_c, f->eplxy, nx, ny);
         shear2center(f->dexy_c, f->dexy, nx, ny);

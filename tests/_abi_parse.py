@@ -66,7 +66,10 @@ def julia_structs(path: Path = JULIA_EXT) -> dict:
             fname, ty = mm.group(1), mm.group(2).strip()
             pm = re.match(r"Ptr\{(\w+)\}$", ty)
             tm = re.match(r"NTuple\{\s*(\d+)\s*,\s*(\w+)\s*\}$", ty)
-            if pm:
+            tp = re.match(r"NTuple\{\s*(\d+)\s*,\s*Ptr\{(\w+)\}\s*\}$", ty)          # array of pointers: const double *a[6]
+            if tp:
+                fields.append((fname, tp.group(2), True, int(tp.group(1))))
+            elif pm:
                 fields.append((fname, pm.group(1), True, 1))
             elif tm:
                 fields.append((fname, tm.group(2), False, int(tm.group(1))))

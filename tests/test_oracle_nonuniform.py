@@ -1,0 +1,100 @@
+"""CPU: non-uniform grids of the 2D drivers.  Geometry(xvi...) against the reference's own assertions (test/test_grid2D.jl:38-57), and the oracle's spacing-array
+form of the 2D kernels (VelocityKernels.jl:3-44,108-131,246-269 with _di.vertex / _di.center / _di.velocity as the reference passes them, Stokes2D.jl:229-275):
+identical to the scalar form when the arrays hold the uniform value, exact on fields the stencils differentiate exactly, converging on a refined grid."""
+import numpy as np
+import pytest
+
+
+def _cp(a):
+    return {k: (v.copy(order="F") if isinstance(v, np.ndarray) else v) for k, v in a.items()}
+
+
+def stretched(n, lo=0.0, hi=1.0, k=2.5):
+    """vertices refined towards the middle of [lo, hi] (the kind of grid miniapps/benchmarks/stokes2D/shear_band/ShearBand2D_refined.jl builds)"""
+    s = np.linspace(-1.0, 1.0, n + 1)
+    x = np.sinh(k * s) / np.sinh(k)
+    return lo + (hi - lo) * (x + 1.0) / 2.0
+
+
+def test_geometry_from_vertices_reference_assertions(jr):
+    """test/test_grid2D.jl:38-57"""
+    xv1 = np.linspace(0.0, 1.0, 5)
+    xv2 = np.array([0.0, 0.4, 0.7, 0.9, 1.0])
+    g = jr.Geometry.from_vertices((xv1, xv2))
+    assert g.ni == (4, 4) and g.li == (1.0, 1.0) and g.origin == (0.0, 0.0) and g.max_li == 1.0
+    assert len(g.xci[0]) == 4 and len(g.xvi[0]) == 5
+    assert np.array_equal(g.xci[1], (xv2[:-1] + xv2[1:]) / 2)
+    assert np.array_equal(g.di["vertex"][1], np.diff(xv2))
+    assert len(g.xi_vel[0][1]) == len(g.xci[1]) + 2 and len(g.xi_vel[1][0]) == len(g.xci[0]) + 2
+    # spacing arrays of the C ABI: vertex (n), centre (n - 1), velocity grids with their ghost points (n + 1)
+    sp = g.inv_spacing2d_host()
+    assert [len(a) for a in sp] == [4, 4, 3, 3, 5, 5]
+    assert np.allclose(1.0 / sp[3], np.diff(g.xci[1])) and np.allclose(1.0 / sp[4][1:-1], np.diff(g.xci[1]))
+    assert 1.0 / sp[4][0] == pytest.approx(np.diff(g.xci[1])[0]) and 1.0 / sp[4][-1] == pytest.approx(np.diff(g.xci[1])[-1])      # ghost offsets dyW, dyE (Grid.jl:172-176)
+
+
+def _uniform_spacing(ni, _di):
+    nx, ny = ni
+    return (np.full(nx, _di[0]), np.full(ny, _di[1]), np.full(nx - 1, _di[0]), np.full(ny - 1, _di[1]), np.full(ny + 1, _di[1]), np.full(nx + 1, _di[0]))
+
+
+def test_spacing_arrays_of_a_uniform_grid_reproduce_the_scalar_path(jr, oracle):
+    from justrelax_jl_amd import checks
+    s = jr.miniapps.random_fields2d((33, 17), iterMax=20, nout=5)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    a, b = _cp(s.arrays), _cp(s.arrays)
+    ra = oracle.stokes2d_solve(a, checks.oracle_params2d(oracle, s))
+    p = oracle.set_spacing2d(checks.oracle_params2d(oracle, s), _uniform_spacing(s.ni, s.grid._di["center"]))
+    rb = oracle.stokes2d_solve(b, p)
+    assert ra["iter"] == rb["iter"] == 21 and np.array_equal(ra["err_evo1"], rb["err_evo1"])
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+    # the visco-elasto-plastic driver
+
+
+def test_kernels_are_exact_on_a_stretched_grid(jr, oracle):
+    """Vx = a x + b y, Vy = c x + d y sampled on the staggered nodes of a stretched grid: the differences over the reference's spacing arrays return
+    ∂xVx = a, ∂yVy = d exactly (to rounding) at the centres and ∂yVx + ∂xVy = b + c at the vertices -- with the scalar spacing they would not"""
+    from justrelax_jl_amd import checks
+    nx, ny = 24, 18
+    g = jr.Geometry.from_vertices((stretched(nx), stretched(ny, -1.0, 0.0, 1.5)))
+    a_, b_, c_, d_ = 0.7, -0.3, 0.45, 1.1
+    s = jr.miniapps.random_fields2d((nx, ny), iterMax=1, nout=1)
+    (xvx, yvx), (xvy, yvy) = g.xi_vel
+    s.arrays["Vx"][...] = a_ * xvx[:, None] + b_ * yvx[None, :]
+    s.arrays["Vy"][...] = c_ * xvy[:, None] + d_ * yvy[None, :]
+    p = oracle.set_spacing2d(checks.oracle_params2d(oracle, s), g.inv_spacing2d_host())
+    f = oracle.fields2d(s.arrays)
+    import ctypes as C
+    oracle.lib().orc_compute_divV2d_sp(f.divV, f.Vx, f.Vy, C.c_int64(nx), C.c_int64(ny), C.c_double(1.0), C.c_double(1.0), p.inv_spacing)
+    oracle.lib().orc_compute_strain_rate2d(C.byref(f), C.byref(p))
+    div = a_ + d_
+    assert np.allclose(s.arrays["divV"], div, rtol=1e-12)
+    assert np.allclose(s.arrays["exx"], a_ - div / 3, rtol=1e-11) and np.allclose(s.arrays["eyy"], d_ - div / 3, rtol=1e-11)
+    assert np.allclose(s.arrays["exy"], 0.5 * (b_ + c_), rtol=1e-11)
+    # momentum residual of a linear pressure field: P = x + 2 y at the centres, no stress, no body force: Rx = -1, Ry = -2 exactly
+    for k in ("txx", "tyy", "txy", "fx", "fy"):
+        s.arrays[k][...] = 0.0
+    s.arrays["P"][...] = g.xci[0][:, None] + 2.0 * g.xci[1][None, :]
+    oracle.lib().orc_compute_Res2d(C.byref(f), C.byref(p))
+    assert np.allclose(s.arrays["Rx"], -1.0, rtol=1e-11) and np.allclose(s.arrays["Ry"], -2.0, rtol=1e-11)
+
+
+def test_solcx_converges_on_a_refined_grid(jr, oracle):
+    """SolCx (test/test_stokes_solcx.jl) with the vertices refined towards the viscosity jump at x = 0.5: the same convergence assertion err < 1e-8"""
+    from justrelax_jl_amd import checks
+    n = 32
+    s = jr.miniapps.solcx2d(n)
+    g = jr.Geometry.from_vertices((stretched(n, 0.0, 1.0, 1.5), np.linspace(0.0, 1.0, n + 1)))
+    xc, yc = g.xci
+    # rebuild the inputs on the refined centres: η = 1 | 1e6 across x = 0.5, ρg_y = -sin(π y) cos(π x) (SolCx.jl:13-31,70-77), unsmoothed
+    s.arrays["eta"][...] = np.where(xc[:, None] <= 0.5, 1.0, 1.0e6) * np.ones((1, n))
+    s.arrays["fy"][...] = -np.sin(np.pi * yc[None, :]) * np.cos(np.pi * xc[:, None])
+    p = oracle.set_spacing2d(checks.oracle_params2d(oracle, s), g.inv_spacing2d_host())
+    # PT coefficients from the smallest cell (PTStokesCoeffs takes min(di...), types/stokes.jl:225)
+    pt = jr.PTStokesCoeffs(g.li, (float(np.min(g.di["vertex"][0])), float(np.min(g.di["vertex"][1]))), ϵ_abs=1e-8, ϵ_rel=1e-9, CFL=1 / np.sqrt(2.1))
+    p.theta_dtau, p.eta_dtau, p.r = pt.θ_dτ, pt.ηdτ, pt.r
+    r = oracle.stokes2d_solve(s.arrays, p)
+    assert r["err_evo1"][-1] < 1.0e-8, r["err_evo1"][-3:]
+    assert np.abs(s.arrays["Vy"]).max() > 1e-4
