@@ -336,6 +336,8 @@ def vep_fields3d(stokes, ρg, phase_ratios, args=None) -> _lib.VEP3DFields:
 def vep_params3d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10.0e3, nout=500, verbose=True, λ_relaxation=0.2, viscosity_relaxation=1.0e-2,
                  viscosity_cutoff=(-float("inf"), float("inf")), b_width=(4, 4, 4), **_):
     ni = stokes._ni
+    if getattr(grid, "nonuniform", False):
+        raise NotImplementedError("non-uniform grids are built for the 2D drivers only")
     _di = _center_inv(grid)
     p = _lib.VEP3DParams()
     p.nx, p.ny, p.nz = ni
@@ -476,6 +478,8 @@ def compute_vorticity_(stokes, grid_or_di, *, handle=None):
     """compute_vorticity!(stokes.ω..., @velocity(stokes)..., _di) as the VEP drivers call it -- stress_rotation_particles.jl:17-50"""
     _require_gpu(stokes)
     h = handle or _lib.default_handle(stokes.P.device.index)
+    if getattr(grid_or_di, "nonuniform", False):
+        raise NotImplementedError("compute_vorticity! alone takes a uniform grid (inside the 2D solves the spacing vectors are used)")
     _di = _center_inv(_as_grid(stokes, grid_or_di))
     torch.cuda.current_stream(stokes.P.device).synchronize()
     n = [C.c_int64(m) for m in stokes._ni]

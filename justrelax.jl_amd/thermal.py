@@ -24,6 +24,8 @@ _ORDER3 = ("left", "right", "front", "back", "top", "bot")
 
 def thermal_params2d(ni, grid, thermal_bc, dt, ϵ, *, iterMax=50_000, nout=1000, verbose=True, rheology=None, **_):
     """jrx_thermal2d_params / jrx_thermal3d_params (by len(ni)) from the reference's keyword arguments"""
+    if getattr(grid, "nonuniform", False):
+        raise NotImplementedError("non-uniform grids are built for the 2D Stokes drivers only; the heat solver takes a uniform Geometry")
     _di = grid._di["center"]
     if len(ni) == 3:
         p = _lib.Thermal3DParams()
