@@ -412,6 +412,10 @@ typedef struct jrx_thermal2d_params {
     double k_const, Cp, rho0, alpha, T0;
     int32_t verbose;
     double dirichlet_const;                /* value of a ConstantDirichletBoundaryCondition (read where dirichlet_mask != 0 and dirichlet_value is NULL) */
+    /* Non-uniform Geometry (device arrays of inverse spacings, all four NULL on a uniform grid): [0], [1] = _di.center x (nx-1), y (ny-1): compute_flux! reads them
+     * at clamp(i, 1, nx-1) (DiffusionPT_kernels.jl:338,354,405,433,482,510); [2], [3] = _di.vertex x (nx), y (ny): update_T! of the rheology / phase forms and
+     * check_res! (:579-580,616,647-648).  Not with the array form (K, ρCp arrays): its update_T! indexes _di.center beyond its extent in the reference (:532). */
+    const double *inv_spacing[4];
 } jrx_thermal2d_params;
 
 /* heatdiffusion_PT!(thermal, pt_thermal, thermal_bc, K, ρCp | rheology, args, dt, grid; kwargs) */

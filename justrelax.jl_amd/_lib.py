@@ -67,7 +67,7 @@ class Thermal2DParams(C.Structure):
                 ("constant_flux_on", C.c_int32 * 4), ("constant_flux", C.c_double * 4),
                 ("periodic", C.c_int32 * 4), ("rheology_form", C.c_int32),
                 ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double),
-                ("T0", C.c_double), ("verbose", C.c_int32), ("dirichlet_const", C.c_double)]
+                ("T0", C.c_double), ("verbose", C.c_int32), ("dirichlet_const", C.c_double), ("inv_spacing", C.c_void_p * 4)]
 
 
 T3_NAMES = ["T", "Told", "dT", "qTx", "qTx2", "qTy", "qTy2", "qTz", "qTz2", "H", "shear_heating", "ResT", "K", "rhoCp", "thetar_dtau", "dtau_rho"]

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_flux2d(const TArgs a, const PHT ph)
             if constexpr (PH) Kx = (tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (iL + (i64)(nx + 1) * j)) + tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (iR + (i64)(nx + 1) * j))) * 0.5;
             else Kx = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[iL + (i64)nx * j] + a.t.K[iR + (i64)nx * j]) * 0.5;
             const double thx = (th[iL + (i64)nx * j] + th[iR + (i64)nx * j]) * 0.5;
-            const double qx = -Kx * (TT_(i + 1, j + 1) - TT_(i, j + 1)) * a.p._dx;
+            const double qx = -Kx * (TT_(i + 1, j + 1) - TT_(i, j + 1)) * (a.p.inv_spacing[0] ? a.p.inv_spacing[0][clampi(i, 0, nx - 2)] : a.p._dx);
             a.t.qTx2[q] = qx;
             a.t.qTx[q] = (a.t.qTx[q] * thx + qx) / (1.0 + thx);
         }
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_flux2d(const TArgs a, const PHT ph)
             if constexpr (PH) Ky = (tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * jB)) + tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * jT))) * 0.5;
             else Ky = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[i + (i64)nx * jB] + a.t.K[i + (i64)nx * jT]) * 0.5;
             const double thy = (th[i + (i64)nx * jB] + th[i + (i64)nx * jT]) * 0.5;
-            const double qy = -Ky * (TT_(i + 1, j + 1) - TT_(i + 1, j)) * a.p._dy;
+            const double qy = -Ky * (TT_(i + 1, j + 1) - TT_(i + 1, j)) * (a.p.inv_spacing[1] ? a.p.inv_spacing[1][clampi(j, 0, ny - 2)] : a.p._dy);
             a.t.qTy2[q] = qy;
             a.t.qTy[q] = (a.t.qTy[q] * thy + qy) / (1.0 + thy);
         }
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
     if (j >= ny) return;
     const i64 c = i + (i64)nx * j, I1 = (i + 1) + (i64)(nx + 2) * (j + 1);
     const double _dt = 1.0 / a.p.dt;
+    const double _dx = a.p.inv_spacing[2] ? a.p.inv_spacing[2][i] : a.p._dx, _dy = a.p.inv_spacing[3] ? a.p.inv_spacing[3][j] : a.p._dy;      // _di.vertex on a non-uniform grid
     const double Tij = a.t.T[I1];
     double rcp, Hr = 0.0;
     if constexpr (PH) {
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
     const double adi = hasadi ? a.t.adiabatic[c] * Tij : 0.0;
     const double dm = a.t.dirichlet_mask ? a.t.dirichlet_mask[I1] : 0.0;
     if (RES) {
-        const double dq = (a.t.qTx2[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx2[i + (i64)(nx + 1) * j]) * a.p._dx +
-                          (a.t.qTy2[i + (i64)nx * (j + 1)] - a.t.qTy2[c]) * a.p._dy;
+        const double dq = (a.t.qTx2[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx2[i + (i64)(nx + 1) * j]) * _dx +
+                          (a.t.qTy2[i + (i64)nx * (j + 1)] - a.t.qTy2[c]) * _dy;
         if (dm != 0.0) a.t.ResT[c] = 0.0;
         else if constexpr (PH) a.t.ResT[c] = hasadi ? -rcp * (Tij - a.t.Told[I1]) * _dt - dq + Hr + a.t.H[c] + a.t.shear_heating[c] + adi
                                                  : -rcp * (Tij - a.t.Told[I1]) * _dt - dq + Hr + a.t.H[c] + a.t.shear_heating[c];
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
                                   : -rcp * (Tij - a.t.Told[I1]) * _dt - dq + a.t.H[c] + a.t.shear_heating[c];
     } else {
         const double dr = a.t.dtau_rho[c];
-        const double divq = (a.t.qTx[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx[i + (i64)(nx + 1) * j]) * a.p._dx +
-                            (a.t.qTy[i + (i64)nx * (j + 1)] - a.t.qTy[c]) * a.p._dy;
+        const double divq = (a.t.qTx[(i + 1) + (i64)(nx + 1) * j] - a.t.qTx[i + (i64)(nx + 1) * j]) * _dx +
+                            (a.t.qTy[i + (i64)nx * (j + 1)] - a.t.qTy[c]) * _dy;
         double Tn;
         if (dm != 0.0) Tn = (1 - dm) * Tij + dm * (a.t.dirichlet_value ? a.t.dirichlet_value[I1] : a.p.dirichlet_const);
         else if constexpr (PH) Tn = hasadi ? (dr * (-divq + a.t.Told[I1] * rcp * _dt + Hr + a.t.H[c] + a.t.shear_heating[c] + adi) + Tij) / (1.0 + dr * rcp * _dt)
@@ -318,6 +319,13 @@ jrx_status checkT(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
     for (const void *q : req)
         if (!q) return jrx_fail(h, JRX_ERR_ARG, "a required thermal field pointer is NULL");
     if (!p->rheology_form && (!t->K || !t->rhoCp)) return jrx_fail(h, JRX_ERR_ARG, "K / rhoCp arrays required in the array-coefficient form");
+    {
+        int nsp = 0;
+        for (int q = 0; q < 4; q++) nsp += p->inv_spacing[q] != nullptr;
+        if (nsp != 0 && nsp != 4) return jrx_fail(h, JRX_ERR_ARG, "non-uniform grid: all four inverse-spacing arrays are required");
+        if (nsp && !p->rheology_form)
+            return jrx_fail(h, JRX_ERR_UNSUPPORTED, "non-uniform grid with the array form (K, ρCp): the reference's update_T! indexes _di.center beyond its extent there; use the rheology form");
+    }
     if (p->rheology_form != 0 && p->rheology_form != 1) return jrx_fail(h, JRX_ERR_ARG, "rheology_form must be 0 or 1 (phase-ratio form: jrx_heatdiffusion_PT2d_phases)");
     return JRX_OK;
 }
@@ -451,7 +459,7 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
     a.t = *t; a.p = *p;
     // iterations nobody observes: one fused launch, ping-pong between the caller's (T, qT) and a library-owned set (option thermal_fused)
     const bool any_periodic = p->periodic[0] | p->periodic[1] | p->periodic[2] | p->periodic[3];
-    const bool fusable = !PH && !t->adiabatic && !t->dirichlet_mask && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
+    const bool fusable = !PH && !t->adiabatic && !t->dirichlet_mask && !p->inv_spacing[0] && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2;
     const TSet2 user = {t->T, t->qTx, t->qTy};
     TSet2 cur = user, oth = user;
     if (fusable) {

@@ -24,9 +24,10 @@ _ORDER3 = ("left", "right", "front", "back", "top", "bot")
 
 def thermal_params2d(ni, grid, thermal_bc, dt, ϵ, *, iterMax=50_000, nout=1000, verbose=True, rheology=None, **_):
     """jrx_thermal2d_params / jrx_thermal3d_params (by len(ni)) from the reference's keyword arguments"""
-    if getattr(grid, "nonuniform", False):
-        raise NotImplementedError("non-uniform grids are built for the 2D Stokes drivers only; the heat solver takes a uniform Geometry")
-    _di = grid._di["center"]
+    nonuni = getattr(grid, "nonuniform", False)
+    if nonuni and len(ni) == 3:
+        raise NotImplementedError("non-uniform grids are built for the 2D drivers only")
+    _di = tuple(float(n) / float(l) for n, l in zip(grid.ni, grid.li)) if nonuni else grid._di["center"]      # scalars unused on a non-uniform grid
     if len(ni) == 3:
         p = _lib.Thermal3DParams()
         p.nx, p.ny, p.nz, p._dx, p._dy, p._dz, p.dt, p.eps = ni[0], ni[1], ni[2], _di[0], _di[1], _di[2], float(dt), float(ϵ)
@@ -53,6 +54,14 @@ def thermal_params2d(ni, grid, thermal_bc, dt, ϵ, *, iterMax=50_000, nout=1000,
         p.rheology_form = 1
         p.k_const, p.Cp, p.rho0, p.alpha, p.T0 = (rheology["k"], rheology["Cp"], rheology["rho0"], rheology["alpha"],
                                                    rheology.get("T0", 0.0))
+    if nonuni:          # _di.center for compute_flux!, _di.vertex for update_T! / check_res! (DiffusionPT_solver.jl:243-282)
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d = grid._di
+        arrs = tuple(torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev) for a in (d["center"][0], d["center"][1], d["vertex"][0], d["vertex"][1]))
+        p._spacing_keepalive = arrs
+        for q, a in enumerate(arrs):
+            p.inv_spacing[q] = a.data_ptr()
     return p
 
 

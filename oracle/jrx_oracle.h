@@ -161,6 +161,7 @@ typedef struct orc_thermal_params2d {
     int32_t rheology_form;
     double k_const, Cp, rho0, alpha, T0, H_const;
     double dirichlet_const;             /* value of a ConstantDirichletBoundaryCondition (used when dirichlet_value is NULL) */
+    const double *inv_spacing[4];   /* non-uniform Geometry: _di.center x (nx-1), y (ny-1), _di.vertex x (nx), y (ny); all NULL: uniform */
 } orc_thermal_params2d;
 
 /* phase-ratio form (rheology_form = 2): per-phase thermal properties + the arrays heatdiffusion_PT!(...; phase = phase_ratios) reads */

@@ -131,7 +131,16 @@ class ThermalParams2D(C.Structure):
                 ("periodic", C.c_int32 * 4),
                 ("rheology_form", C.c_int32),
                 ("k_const", C.c_double), ("Cp", C.c_double), ("rho0", C.c_double), ("alpha", C.c_double),
-                ("T0", C.c_double), ("H_const", C.c_double), ("dirichlet_const", C.c_double)]
+                ("T0", C.c_double), ("H_const", C.c_double), ("dirichlet_const", C.c_double), ("inv_spacing", C.POINTER(C.c_double) * 4)]
+
+
+def set_spacing_thermal2d(p, grid_inv):
+    """non-uniform Geometry for the 2D heat solver: grid_inv = grid._di (dict with 'center', 'vertex'); arrays kept alive on the params object"""
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (grid_inv["center"][0], grid_inv["center"][1], grid_inv["vertex"][0], grid_inv["vertex"][1])]
+    p._spacing_keepalive = arrs
+    for q, a in enumerate(arrs):
+        p.inv_spacing[q] = a.ctypes.data_as(C.POINTER(C.c_double))
+    return p
 
 
 class Result(C.Structure):

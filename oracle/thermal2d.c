@@ -97,7 +97,7 @@ void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d 
                                 : p->rheology_form ? (p->k_const + p->k_const) * 0.5
                                                    : (t->K[IDX2(nx, iL, j)] + t->K[IDX2(nx, iR, j)]) * 0.5;
                     double th = (t->thetar_dtau[IDX2(nx, iL, j)] + t->thetar_dtau[IDX2(nx, iR, j)]) * 0.5;
-                    double qx = -Kx * (TT_(i + 1, j + 1) - TT_(i, j + 1)) * _dx;
+                    double qx = -Kx * (TT_(i + 1, j + 1) - TT_(i, j + 1)) * (p->inv_spacing[0] ? p->inv_spacing[0][clampi(i, 0, nx - 2)] : _dx);   /* @dx(_di_center, clamp(i, 1, nx - 1)) */
                     t->qTx2[q] = qx;
                     t->qTx[q] = (t->qTx[q] * th + qx) / (1.0 + th);
                 }
@@ -113,7 +113,7 @@ void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d 
                                 : p->rheology_form ? (p->k_const + p->k_const) * 0.5
                                                    : (t->K[IDX2(nx, i, jB)] + t->K[IDX2(nx, i, jT)]) * 0.5;
                     double th = (t->thetar_dtau[IDX2(nx, i, jB)] + t->thetar_dtau[IDX2(nx, i, jT)]) * 0.5;
-                    double qy = -Ky * (TT_(i + 1, j + 1) - TT_(i + 1, j)) * _dy;
+                    double qy = -Ky * (TT_(i + 1, j + 1) - TT_(i + 1, j)) * (p->inv_spacing[1] ? p->inv_spacing[1][clampi(j, 0, ny - 2)] : _dy);
                     t->qTy2[q] = qy;
                     t->qTy[q] = (t->qTy[q] * th + qy) / (1.0 + th);
                 }
@@ -127,8 +127,8 @@ void orc_thermal2d_iteration(const orc_thermal2d *t, const orc_thermal_params2d 
             const double *rc = p->rheology_form == 2 ? g_tpf->phase_c + g_tph->nphase * c : NULL;
             double rcp = rc ? tph_rhoCp(g_tph, rc, Tij, g_tpf->P[c]) : p->rheology_form ? rhoCp_rheology(p, Tij) : t->rhoCp[c];
             double dr = t->dtau_rho[c];
-            double divq = (t->qTx[IDX2(nx + 1, i + 1, j)] - t->qTx[IDX2(nx + 1, i, j)]) * _dx +
-                          (t->qTy[IDX2(nx, i, j + 1)] - t->qTy[IDX2(nx, i, j)]) * _dy;
+            double divq = (t->qTx[IDX2(nx + 1, i + 1, j)] - t->qTx[IDX2(nx + 1, i, j)]) * (p->inv_spacing[2] ? p->inv_spacing[2][i] : _dx) +     /* _di.vertex (:579-580) */
+                          (t->qTy[IDX2(nx, i, j + 1)] - t->qTy[IDX2(nx, i, j)]) * (p->inv_spacing[3] ? p->inv_spacing[3][j] : _dy);
             const double adi = (p->rheology_form && t->adiabatic) ? t->adiabatic[c] * Tij : 0.0;        /* + adiabatic[i, j] * T[I1...] of the rheology forms */
             if (t->dirichlet_mask && t->dirichlet_mask[I1] != 0.0) {      /* isdirichlet -> apply_dirichlet!: A = inv(m) A + m B (mask/mask.jl:49-50) */
                 const double m = t->dirichlet_mask[I1], B = t->dirichlet_value ? t->dirichlet_value[I1] : p->dirichlet_const;
@@ -151,8 +151,8 @@ void orc_thermal2d_check_res(const orc_thermal2d *t, const orc_thermal_params2d 
             size_t c = IDX2(nx, i, j), I1 = IDX2(nx + 2, i + 1, j + 1);
             const double *rc = p->rheology_form == 2 ? g_tpf->phase_c + g_tph->nphase * c : NULL;
             double rcp = rc ? tph_rhoCp(g_tph, rc, t->T[I1], g_tpf->P[c]) : p->rheology_form ? rhoCp_rheology(p, t->T[I1]) : t->rhoCp[c];
-            const double dq = (t->qTx2[IDX2(nx + 1, i + 1, j)] - t->qTx2[IDX2(nx + 1, i, j)]) * _dx +
-                              (t->qTy2[IDX2(nx, i, j + 1)] - t->qTy2[IDX2(nx, i, j)]) * _dy;
+            const double dq = (t->qTx2[IDX2(nx + 1, i + 1, j)] - t->qTx2[IDX2(nx + 1, i, j)]) * (p->inv_spacing[2] ? p->inv_spacing[2][i] : _dx) +
+                              (t->qTy2[IDX2(nx, i, j + 1)] - t->qTy2[IDX2(nx, i, j)]) * (p->inv_spacing[3] ? p->inv_spacing[3][j] : _dy);
             const double adi = (p->rheology_form && t->adiabatic) ? t->adiabatic[c] * t->T[I1] : 0.0;
             if (t->dirichlet_mask && t->dirichlet_mask[I1] != 0.0) t->ResT[c] = 0.0;        /* isNotDirichlet(dirichlet.mask, I1...) ? ... : zero(_T) */
             else if (rc) t->ResT[c] = -rcp * (t->T[I1] - t->Told[I1]) * _dt - dq + tph_Hr(g_tph, rc) + t->H[c] + t->shear_heating[c] + adi;

@@ -132,3 +132,54 @@ def test_what_is_not_built_refuses(jr):
     res = _lib.SolveResult()
     with pytest.raises(_lib.JrxError, match="all six inverse-spacing arrays"):
         _lib.default_handle(0).call("jrx_stokes2d_solve", C.byref(f), C.byref(p), C.byref(res))
+
+
+@pytest.mark.parametrize("form", ["rheology", "phases"])
+def test_heat_diffusion_on_a_stretched_grid(jr, oracle, form):
+    """heatdiffusion_PT! (rheology form, and the phase-ratio form GlobalConvection2D_DYREL_refined.jl calls on its refined grid) with the spacing vectors vs the oracle"""
+    from justrelax_jl_amd.checks import max_rel_diff
+    if form == "rheology":
+        from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+        from test_gpu_stokes2d_thermal import _thermal_setup
+        import justrelax_jl_amd.thermal as th
+        s = jr.miniapps.diffusion2d(24, iterMax=300, nout=100)
+        b = s.flow_bcs
+        nx, ny = s.ni
+        g = jr.Geometry.from_vertices((stretched(nx, 0.0, 100e3, 1.2), stretched(ny, -100e3, 0.0, 1.6)))
+        p = oracle.thermal_params2d(s.ni, s.grid._di["center"], s.dt, 1e-30, iterMax=300, nout=100, no_flux=b.no_flux, constant_value=b.constant_value,
+                                    constant_flux=b.constant_flux, periodic=b.periodic, rheology=s.extra["rheology"])
+        oracle.thermal_bcs2d(s.arrays["T"], p)
+        add_perturbation(s.arrays["T"], s.grid, **s.extra["perturbation"])
+        thermal, pt, K, ρCp = _thermal_setup(jr, th, s)
+        pt.ϵ = 1e-30
+        ref = _cp(s.arrays)
+        r_ref = oracle.heatdiffusion_PT2d(ref, oracle.set_spacing_thermal2d(p, g._di))
+        uni = _cp(s.arrays)
+        oracle.heatdiffusion_PT2d(uni, oracle.thermal_params2d(s.ni, s.grid._di["center"], s.dt, 1e-30, iterMax=300, nout=100, no_flux=b.no_flux,
+                                                                constant_value=b.constant_value, constant_flux=b.constant_flux, periodic=b.periodic,
+                                                                rheology=s.extra["rheology"]))
+        assert max_rel_diff(ref["T"], uni["T"]) > 1e-4                      # a different problem than the uniform grid
+        r = jr.heatdiffusion_PT_(thermal, pt, b, s.extra["rheology"], None, s.dt, g, kwargs=dict(iterMax=300, nout=100, verbose=False))
+        assert list(r.iter_count) == list(r_ref["iter_count"]) == [100, 200, 300]
+        assert np.allclose(r.norm_ResT, r_ref["norm_ResT"], rtol=1e-9)
+        for name, t in (("T", thermal.T), ("qTx", thermal.qTx), ("qTy2", thermal.qTy2), ("ResT", thermal.ResT)):
+            assert max_rel_diff(jr.to_numpy(t), ref[name]) <= 1e-9, name
+        # the array form is refused on such a grid
+        with pytest.raises(RuntimeError, match="array form"):
+            jr.heatdiffusion_PT_(thermal, pt, b, K, ρCp, s.dt, g, kwargs=dict(iterMax=3, nout=1, verbose=False))
+        return
+    from test_gpu_thermal_multiphase import _device_setup, _oracle_inputs, _randomise
+    s = jr.miniapps.diffusion2d_multiphase((37, 21), iterMax=60, nout=20)
+    _randomise(s, 5)
+    nx, ny = s.ni
+    (x0, x1), (y0, y1) = [(float(v[0]), float(v[-1])) for v in s.grid.xvi]
+    g = jr.Geometry.from_vertices((stretched(nx, x0, x1, 1.4), stretched(ny, y0, y1, 1.1)))
+    thermal, pt, pr, args = _device_setup(jr, s, eps=1e-30)
+    ref = _cp(s.arrays)
+    p, m, ph = _oracle_inputs(oracle, s, 1e-30, iterMax=60, nout=20)
+    r_ref = oracle.heatdiffusion_PT_phases(ref, oracle.set_spacing_thermal2d(p, g._di), m, ph)
+    r = jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, s.extra["rheology"], args, s.dt, g, kwargs=dict(phase=pr, iterMax=60, nout=20, verbose=False))
+    assert list(r.iter_count) == list(r_ref["iter_count"])
+    assert np.allclose(r.norm_ResT, r_ref["norm_ResT"], rtol=1e-8)
+    for name, t in (("T", thermal.T), ("qTx", thermal.qTx), ("qTy", thermal.qTy), ("ResT", thermal.ResT)):
+        assert max_rel_diff(jr.to_numpy(t), ref[name]) <= 1e-9, name

@@ -98,3 +98,45 @@ def test_solcx_converges_on_a_refined_grid(jr, oracle):
     r = oracle.stokes2d_solve(s.arrays, p)
     assert r["err_evo1"][-1] < 1.0e-8, r["err_evo1"][-3:]
     assert np.abs(s.arrays["Vy"]).max() > 1e-4
+
+
+def test_heat_diffusion_on_a_stretched_grid(jr, oracle):
+    """rheology form of heatdiffusion_PT! with the spacing vectors (compute_flux! takes _di.center at clamp(i, 1, nx - 1), update_T! / check_res! _di.vertex,
+    DiffusionPT_kernels.jl:405,433,579-580,647-648): uniform vectors reproduce the scalar path bit for bit; on a stretched grid with constant conductivity
+    and no sources the solve relaxes to the linear conduction profile between the two Dirichlet faces whatever the spacing"""
+    from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+    s = jr.miniapps.diffusion2d(24, iterMax=300, nout=100)
+    b = s.flow_bcs
+    mk = lambda **kw: oracle.thermal_params2d(s.ni, s.grid._di["center"], s.dt, 1e-30, iterMax=300, nout=100, no_flux=b.no_flux, constant_value=b.constant_value,
+                                              constant_flux=b.constant_flux, periodic=b.periodic, rheology=s.extra["rheology"], **kw)
+    p0 = mk()
+    oracle.thermal_bcs2d(s.arrays["T"], p0)
+    add_perturbation(s.arrays["T"], s.grid, **s.extra["perturbation"])
+    a, c = _cp(s.arrays), _cp(s.arrays)
+    oracle.heatdiffusion_PT2d(a, p0)
+    d = s.grid._di["center"]
+    nx, ny = s.ni
+    uni = dict(center=(np.full(nx - 1, d[0]), np.full(ny - 1, d[1])), vertex=(np.full(nx, d[0]), np.full(ny, d[1])))
+    oracle.heatdiffusion_PT2d(c, oracle.set_spacing_thermal2d(mk(), uni))
+    for k in ("T", "qTx", "qTy", "qTx2", "ResT"):
+        assert np.array_equal(a[k], c[k]), k
+    # stretched in y: steady conduction between T = 300 (top) and 3500 (bottom) is linear in y at the cell centres
+    g = jr.Geometry.from_vertices((np.linspace(0.0, 100e3, nx + 1), stretched(ny, -100e3, 0.0, 1.6)))
+    e = _cp(s.arrays)
+    e["H"][...] = 0.0
+    e["shear_heating"][...] = 0.0
+    p = oracle.set_spacing_thermal2d(mk(), g._di)
+    p.dt, p.iterMax, p.nout, p.eps = 1.0e18, 40000, 1000, 1.0e-9          # a huge time step: the steady state
+    rh = dict(s.extra["rheology"], alpha=0.0)
+    p.alpha = 0.0
+    r = oracle.heatdiffusion_PT2d(e, p)
+    yc = g.xci[1]
+    # ghost rows hold 2 Tbc - T: the Dirichlet values sit on the faces y = -100 km (3500) and y = 0 (300)
+    want = 3500.0 + (300.0 - 3500.0) * (yc - (-100e3)) / 100e3
+    got = e["T"][1:-1, 1:-1]
+    assert r["norm_ResT"][-1] < 1e-6
+    # the flux stencil takes _di.center[clamp(i)] (one cell off, as the reference does), so the discrete steady state is the linear profile only to
+    # O(stretching * h): 3.6 % of the 3200 K range on this grid; monotonic between the two face values
+    assert np.abs(got - want[None, :]).max() < 0.05 * 3200.0
+    assert np.all(np.diff(got[0]) < 0.0) and 300.0 < got[0, -1] < got[0, 0] < 3500.0
+    assert np.abs(np.diff(got, axis=0)).max() < 1e-2                         # and it is independent of x (to the residual left)
