@@ -329,12 +329,41 @@ def cfg_thermal3d(jr, h, n=256, iters=400):
             "effective_GBps_at_176B_per_cell": gbps, "frac_of_8TBps": gbps / 8000.0}
 
 
+def cfg_thermal3d_phases(jr, h, n=256, iters=200):
+    """3D PT heat diffusion, phase-ratio form (heatdiffusion_PT!(...; kwargs = (phase = phase_ratios, ...)), DiffusionPT_solver.jl:181-305, two phases): per
+    iteration update_pt_thermal_arrays! + compute_flux! + update_T!; 35 passes = 280 B/cell-iteration as those three kernels move them (coefficients: R T, P,
+    ratios(2) W θ, dτ_ρ; flux: R T, θ, q(3), face ratios 3 x 2 W q(3), q2(3); update: R q(3), Told, T, P, ratios(2), dτ_ρ, H, SH W T)."""
+    import torch
+    from types import SimpleNamespace
+    from justrelax_jl_amd.arrays import from_numpy
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s = jr.miniapps.diffusion3d_multiphase(n, iterMax=iters, nout=10 ** 9)
+    th = jr.ThermalArrays(jr.AMDGPUBackend, s.ni)
+    th.T.copy_(from_numpy(s.arrays["T"], dev)); th.H.fill_(1.0e-6)
+    pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, s.ni)
+    for k, v in s.extra["phase_ratios"].items():
+        getattr(pr, k).copy_(from_numpy(v, dev))
+    args = SimpleNamespace(P=jr.fzeros(s.ni, dev), T=th.T)
+    pt = jr.PTThermalCoeffs.from_phases(jr.AMDGPUBackend, s.extra["rheology"], pr, args, s.dt, s.ni, s.extra["di"], s.extra["li"], ϵ=1e-300, CFL=s.pt["CFL"])
+    bcs, dt, grid_, rheo = s.flow_bcs, s.dt, s.grid, s.extra["rheology"]
+    del s
+
+    def run(k):
+        jr.heatdiffusion_PT_(th, pt, bcs, rheo, args, dt, grid_, kwargs=dict(phase=pr, iterMax=k, nout=10 ** 9, verbose=False), handle=h)
+        return k
+    el, k = _timed(run, 10, iters)
+    gbps = 280.0 * n ** 3 * k / el / 1e9
+    return {"workload": f"thermal diffusion {n}^3 (3D PT, phase-ratio form, 2 phases)", "iterations": k, "it_per_s": k / el,
+            "effective_GBps_at_280B_per_cell": gbps, "frac_of_8TBps": gbps / 8000.0}
+
+
 def other_configs(jr, h):
     import justrelax_jl_amd.grid as grid
     out = {}
     for key, fn in (("solvi3d_256", lambda: cfg_solvi(jr, h, 256, 200, 20)), ("solcx_512", lambda: cfg_solcx(jr, h)),
                     ("shearband_1024", lambda: cfg_shearband(jr, h)), ("thermal2d_256", lambda: cfg_thermal2d(jr, h)),
-                    ("shearband3d_256", lambda: cfg_shearband3d(jr, h)), ("thermal3d_256", lambda: cfg_thermal3d(jr, h))):
+                    ("shearband3d_256", lambda: cfg_shearband3d(jr, h)), ("thermal3d_256", lambda: cfg_thermal3d(jr, h)),
+                    ("thermal3d_phases_256", lambda: cfg_thermal3d_phases(jr, h))):
         try:
             grid.finalize_global_grid()
             out[key] = fn()
