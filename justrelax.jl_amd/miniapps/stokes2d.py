@@ -128,15 +128,19 @@ def random_fields2d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nou
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
 
 
-def shearband2d(n=32, *, iterMax=50_000, nout=100) -> Setup:
+def shearband2d(n=32, *, iterMax=50_000, nout=100, xvi=None) -> Setup:
     """ShearBand2D -- test/test_shearband2D.jl:61-175 (BASELINE config 5): two phases (matrix G0 = 1, circular inclusion
     Gi = 0.5 of radius 0.1), LinearViscous eta = 1, Kb = 4, DruckerPrager_regularised(C = 1.6/cos30, phi = 30, psi = 0,
-    eta_vp = 8e-3), pure shear eps_bg = 1, free slip, dt = eta0/G0/4.  Array names follow oracle.VEP_NAMES / jrx_vep2d_fields."""
+    eta_vp = 8e-3), pure shear eps_bg = 1, free slip, dt = eta0/G0/4.  Array names follow oracle.VEP_NAMES / jrx_vep2d_fields.
+    xvi = (xv, yv): the same problem on the non-uniform grid of these vertices (miniapps/benchmarks/stokes2D/shear_band/ShearBand2D_refined.jl:43-52:
+    grid = Geometry(xvi...), while di = li ./ ni still feeds PTStokesCoeffs, :50,110)."""
     nx = ny = n
     ni, li = (nx, ny), (1.0, 1.0)
     init_global_grid(nx, ny, 1)
     di = tuple(l / m for l, m in zip(li, ni))
-    grid = Geometry(ni, li, origin=(0.0, 0.0))
+    grid = Geometry(ni, li, origin=(0.0, 0.0)) if xvi is None else Geometry.from_vertices(xvi)
+    if xvi is not None and grid.ni != ni:
+        raise ValueError("xvi must hold n + 1 vertices per dimension")
     τ_y, ϕ, η0, G0, εbg, η_reg = 1.6, 30.0, 1.0, 1.0, 1.0, 8.0e-3
     Gi = G0 / (6.0 - 4.0)
     dt = η0 / G0 / 4.0

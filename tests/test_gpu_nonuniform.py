@@ -183,3 +183,25 @@ def test_heat_diffusion_on_a_stretched_grid(jr, oracle, form):
     assert np.allclose(r.norm_ResT, r_ref["norm_ResT"], rtol=1e-8)
     for name, t in (("T", thermal.T), ("qTx", thermal.qTx), ("qTy", thermal.qTy), ("ResT", thermal.ResT)):
         assert max_rel_diff(jr.to_numpy(t), ref[name]) <= 1e-9, name
+
+
+def test_refined_shear_band_first_step(jr):
+    """ShearBand2D_refined.jl through solve!: one time step on vertices refined towards the inclusion.  The reference's own convergence assertion of the
+    uniform case (test_shearband2D.jl:194: err < 1e-6) holds, and the stress level is the visco-elastic build-up
+    2 ε η (1 - exp(-G t / η)) of the matrix (Elastic_BuildUp.jl:4) whatever the spacing"""
+    import math
+    from test_gpu_vep2d import _upload
+    n = 32
+    xv = stretched(n, 0.0, 1.0, 1.8)
+    s = jr.miniapps.shearband2d(n, iterMax=50_000, nout=500, xvi=(xv, np.linspace(0.0, 1.0, n + 1)))
+    assert s.grid.nonuniform and np.ptp(np.diff(xv)) > 0.5 * np.diff(xv).min()
+    st, pr, ρg = _upload(jr, s)
+    r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=s.kwargs)
+    assert r.err_evo1[-1] < 1.0e-6 and r.iter < 50_000
+    jr.tensor_invariant_(st.τ)
+    τII = jr.to_numpy(st.τ.II)
+    want = 2.0 * 1.0 * 1.0 * (1.0 - math.exp(-1.0 * s.dt / 1.0))
+    # (the weak inclusion unloads the corners by a few per cent; the largest stress in the box stays within 6 % of the build-up value at this resolution (0.4 % at n = 64) -- the uniform-grid
+    # run of test/test_shearband2D_softening.jl:199-205 asserts the same 0.4423 at t = 0.25)
+    assert τII.max() == pytest.approx(want, rel=6e-2) and τII.min() > 0.25 * want
+    assert τII.max() < 1.6                                    # below yield after the first step
