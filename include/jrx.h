@@ -299,7 +299,7 @@ typedef struct jrx_vep2d_params {
     int32_t verbose;
     int32_t free_surface;                          /* kwarg free_surface: compute_V! / compute_Res! get dt * free_surface (Stokes2D.jl:773,797) */
     int32_t displacement_bcs;                      /* flow_bcs is a DisplacementBoundaryConditions: V = U / dt first, flow_bcs! acts on U */
-    int32_t T_ghosted;                             /* single-phase driver: args.T is thermal.T (nx+2, ny+2), indexed as the reference does */
+    int32_t T_ghosted;                             /* args.T is thermal.T (nx+2, ny+2), indexed as the reference does (densities at the cell's own [i, j]) */
     int32_t strain_increment;                      /* kwarg strain_increment (jrx_stokes2d_vep_solve only; Stokes2D.jl:588,659-734, StressKernels.jl:1147-1302): strains
                                                     * from the displacement increments U = V dt, Δε form of the stress update; U and its BCs are refreshed every iteration */
     const double *inv_spacing[6];                  /* non-uniform Geometry: as in jrx_stokes2d_params (all NULL: uniform); not with strain_increment */

@@ -606,6 +606,7 @@ struct VepArgs {
     int nx, ny;
     bool soft;            // some phase has a softening law (EII_pl is then read by the yield function)
     bool si;              // strain_increment variant
+    bool tg;              // args.T is the ghosted thermal.T (nx+2, ny+2): densities read it at the cell's own [i, j], unshifted (BuoyancyForces.jl:52)
 };
 
 __device__ __forceinline__ double sinv2(double xx, double yy, double xy) { return sqrt(0.5 * (xx * xx + yy * yy) + xy * xy); }
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
         const double d3 = divV * (1.0 / 3.0);
         a.f.exx[c] = dxi - d3;
         a.f.eyy[c] = dyi - d3;
-        if (RHO) a.f.fy[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)a.rh.nphase * c, a.f.T ? a.f.T[c] : 0.0, a.f.P[c]) * a.rh.gravity;
+        if (RHO) a.f.fy[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)a.rh.nphase * c, !a.f.T ? 0.0 : (a.tg ? a.f.T[i + (i64)(nx + 2) * j] : a.f.T[c]), a.f.P[c]) * a.rh.gravity;
     }
     a.f.exy[i + (i64)(nx + 1) * j] = 0.5 * (spc(a.sp.vxy, j, a._dy) * (VX(i, j + 1) - VX(i, j)) + spc(a.sp.vyx, i, a._dx) * (VY(i + 1, j) - VY(i, j)));
 #undef VX
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, doub
     if (t >= (i64)a.nx * a.ny) return;
     Kc[t] = ratio_avg(a.rh.Kb, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
     Gc[t] = ratio_avg(a.rh.G, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
-    if (rho) a.f.fy[t] = mat_density_ratio(a.rh, a.f.phase_c + a.rh.nphase * t, a.f.T ? a.f.T[t] : 0.0, a.f.P[t]) * a.rh.gravity;
+    if (rho) a.f.fy[t] = mat_density_ratio(a.rh, a.f.phase_c + a.rh.nphase * t, !a.f.T ? 0.0 : (a.tg ? a.f.T[(t % a.nx) + (i64)(a.nx + 2) * (t / a.nx)] : a.f.T[t]), a.f.P[t]) * a.rh.gravity;
 }
 
 // Single-phase driver (Stokes2D.jl:345-557): compute_ρg!/update_ρg!(ρg[2], rheology, args) and compute_viscosity!/compute_viscosity_τII!
@@ -1144,6 +1145,7 @@ VepArgs make_vep(const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_ve
     a.nx = (int)p->nx; a.ny = (int)p->ny;
     a.soft = mat_has_softening(rh);
     a.si = p->strain_increment != 0;
+    a.tg = p->T_ghosted != 0;
     a.sp = Sp2{p->inv_spacing[0], p->inv_spacing[1], p->inv_spacing[2], p->inv_spacing[3], p->inv_spacing[4], p->inv_spacing[5]};
     return a;
 }

@@ -173,6 +173,52 @@ def shearband2d(n=32, *, iterMax=50_000, nout=100, xvi=None) -> Setup:
                  extra=dict(li=li, di=di, phases=phases, εbg=εbg, G0=G0, η0=η0))
 
 
+def sinking_block2d(n=32, *, iterMax=150_000, nout=1000, sub=16) -> Setup:
+    """Sinking_Block2D -- test/test_sinking_block.jl:93-203: a 500 km box, a 100 km square block (LinearViscous 1e23, ρ = 3300) at 400 km height in a mantle
+    (1e21, ρ = 3200), g = 9.81, no elasticity, free slip, lithostatic initial pressure, dt = 1; the multiphase visco-elasto-plastic 2D solve! with a purely
+    viscous table.  The reference seeds particles to get the phase ratios; here they are the area fractions of the block in each cell / around each vertex
+    (sub x sub sampling)."""
+    nx = ny = n
+    ly = 500.0e3
+    ni, li = (nx, ny), (ly, ly)
+    init_global_grid(nx, ny, 1)
+    di = tuple(l / m for l, m in zip(li, ni))
+    grid = Geometry(ni, li, origin=(0.0, -ly))
+    phases = [dict(eta=1.0e21, G=float("inf"), Kb=float("inf"), g=9.81, density=dict(kind="constant", rho0=3.2e3)),
+              dict(eta=1.0e23, G=float("inf"), Kb=float("inf"), density=dict(kind="constant", rho0=3.3e3))]
+    arr = {k: np.zeros(shp, dtype=np.float64, order="F") for k, shp in _vep_shapes2d(nx, ny, 2).items()}
+    xc0, depth0, r = 250.0e3, 100.0e3, 50.0e3        # (x - xc)^2 <= r^2 and (depth - yc)^2 <= r^2 with yc = |-(ly - 400 km)| (:139-146, :66)
+
+    def frac(lo_x, hi_x, lo_y, hi_y):
+        t = (np.arange(sub) + 0.5) / sub
+        X = lo_x[:, None] + (hi_x - lo_x)[:, None] * t[None, :]                 # (n, sub)
+        Y = lo_y[:, None] + (hi_y - lo_y)[:, None] * t[None, :]
+        inx = ((X - xc0) ** 2 <= r ** 2).mean(axis=1)
+        iny = ((-Y - depth0) ** 2 <= r ** 2).mean(axis=1)
+        return inx[:, None] * iny[None, :]
+    xv, yv = grid.xvi
+    fc = frac(xv[:-1], xv[1:], yv[:-1], yv[1:])
+    hx, hy = 0.5 * di[0], 0.5 * di[1]
+    fv = frac(np.maximum(xv - hx, xv[0]), np.minimum(xv + hx, xv[-1]), np.maximum(yv - hy, yv[0]), np.minimum(yv + hy, yv[-1]))
+    arr["phase_c"][0], arr["phase_c"][1] = 1.0 - fc, fc
+    arr["phase_v"][0], arr["phase_v"][1] = 1.0 - fv, fv
+    # compute_ρg!(ρg[2], phase_ratios, rheology, args) (:155), init_P! (:86-89,156), compute_viscosity! (:162: harmonic mean of the phase viscosities)
+    arr["fy"][...] = (3.2e3 * arr["phase_c"][0] + 3.3e3 * arr["phase_c"][1]) * 9.81
+    arr["P"][...] = arr["fy"] * np.abs(grid.xci[1])[None, :]
+    def visc(r2):
+        e = 1.0 / (r2[0] / 1.0e21 + r2[1] / 1.0e23)
+        e[r2[0] > 0.999] = 1.0e21
+        e[r2[1] > 0.999] = 1.0e23
+        return e
+    arr["eta"][...] = visc(arr["phase_c"])
+    arr["eta_v"][...] = visc(arr["phase_v"])
+    pt = PTStokesCoeffs(li, di, ϵ_rel=1.0e-5, CFL=0.95 / math.sqrt(2.1))
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F4}, no_slip={f: False for f in _F4})
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=1.0, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False, viscosity_cutoff=(-np.inf, np.inf)),
+                 extra=dict(li=li, di=di, phases=phases))
+
+
 def _thermal_bcs_host(T, bc):
     """thermal_bcs!(T, bc) on a host array (BoundaryConditions.jl:39-53): constant value (constant_value.jl:1-13; `2*true - T` for a
     face given as `true`), then no-flux copies (free_slip.jl:72-84); 2D: bot <-> j = 1"""

@@ -279,7 +279,12 @@ def _solve_vep2d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology,
             raise NotImplementedError("the reference's 3D VEP driver has no strain_increment variant (Stokes3D.jl:447-668)")
         return _solve_vep3d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, kw, h)
     p = vep_params2d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
-    f = vep_fields2d(stokes, ρg, phase_ratios, args, strain_increment=bool(p.strain_increment))
+    f = vep_fields2d(stokes, ρg, phase_ratios, args, allow_ghosted_T=True, strain_increment=bool(p.strain_increment))
+    T = _args_T(args)
+    if T is not None and tuple(T.shape) != tuple(stokes._ni):      # args.T = thermal.T (ghosted): update_ρg! reads it at [i, j], as the reference does
+        if tuple(T.shape) != tuple(n + 2 for n in stokes._ni):
+            raise ValueError(f"args.T must be ni {tuple(stokes._ni)} (thermal.Tc) or ni .+ 2 (thermal.T), got {tuple(T.shape)}")
+        p.T_ghosted = 1
     rh = rheology_table(rheology)
     hist = _Hist(int(p.iterMax // p.nout + 2))
     torch.cuda.current_stream(stokes.P.device).synchronize()

@@ -359,7 +359,8 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
     /* compute_ρg!(ρg, phase_ratios, rheology, args) :646 -- scalar gravity fills the last component (BuoyancyForces.jl:69-70) */
     const int upd_rho = rh->has_density && !mat_density_is_constant(rh);
     if (rh->has_density)
-        for (size_t c = 0; c < n; c++) f->fy[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
+        for (size_t c = 0; c < n; c++)      /* T_ghosted: args.T = thermal.T (nx+2, ny+2), read at the cell's own [i, j], unshifted (getindex_NamedTuple, BuoyancyForces.jl:52) */
+                f->fy[c] = mat_density_ratio(rh, f->phase_c + np * c, !f->T ? 0.0 : (p->T_ghosted ? f->T[IDX2(nx + 2, c % (size_t)nx, c / (size_t)nx)] : f->T[c]), f->P[c]) * rh->gravity;
     /* displacement2velocity!(stokes, dt, flow_bcs) :647 -- V = U * inv(dt) for DisplacementBoundaryConditions only */
     if (p->displacement_bcs) {
         const double _dt = inv(p->dt);
@@ -378,7 +379,8 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
         orc_compute_divV2d_sp(f->divV, f->Vx, f->Vy, nx, ny, p->_dx, p->_dy, p->inv_spacing);
         orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :663-676 */
         if (upd_rho)                                    /* update_ρg!(ρg, phase_ratios, rheology, args) :678 ; args.P is stokes.P */
-            for (size_t c = 0; c < n; c++) f->fy[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
+            for (size_t c = 0; c < n; c++)      /* T_ghosted: args.T = thermal.T (nx+2, ny+2), read at the cell's own [i, j], unshifted (getindex_NamedTuple, BuoyancyForces.jl:52) */
+                f->fy[c] = mat_density_ratio(rh, f->phase_c + np * c, !f->T ? 0.0 : (p->T_ghosted ? f->T[IDX2(nx + 2, c % (size_t)nx, c / (size_t)nx)] : f->T[c]), f->P[c]) * rh->gravity;
         if (p->strain_increment) {
             /* ∇U, Δε from the displacements (:659-661, :680-688), then ε = Δε * _dt (compute_strain_rate_from_increment!, VelocityKernels.jl:46-57) */
             orc_fields2d gu = g;

@@ -33,7 +33,10 @@ def _phases_soft(phases):
     return out
 
 
-def test_vep2d_density_update_matches_oracle(jr, oracle):
+@pytest.mark.parametrize("ghosted", [False, True])
+def test_vep2d_density_update_matches_oracle(jr, oracle, ghosted):
+    """update_ρg! inside the multiphase solve!: args.T cell-centred (thermal.Tc), or -- ghosted -- thermal.T (ni .+ 2), which the reference reads at the cell's own
+    [i, j] without a shift (getindex_NamedTuple(args, I...), BuoyancyForces.jl:52; test/test_sinking_block.jl:155,160 passes such an array)"""
     from justrelax_jl_amd.checks import max_rel_diff
     from justrelax_jl_amd.arrays import from_numpy
     from test_gpu_vep2d import _download, _upload, _vep_params
@@ -41,11 +44,11 @@ def test_vep2d_density_update_matches_oracle(jr, oracle):
     s.kwargs.update(iterMin=10)
     s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
     rng = np.random.default_rng(5)
-    s.arrays["T"] = np.asfortranarray(rng.uniform(0.0, 2.0, size=s.ni))
+    s.arrays["T"] = np.asfortranarray(rng.uniform(0.0, 2.0, size=tuple(n + 2 for n in s.ni) if ghosted else s.ni))
     s.arrays["fy"][...] = 123.0                     # compute_ρg! must overwrite the caller's values
     phases = _phases_rho(s.extra["phases"], g=0.3)
     ref = _cp(s.arrays)
-    r_ref = oracle.stokes2d_vep_solve(ref, oracle.rheology_struct(phases), _vep_params(oracle, s, iterMin=10))
+    r_ref = oracle.stokes2d_vep_solve(ref, oracle.rheology_struct(phases), _vep_params(oracle, s, iterMin=10, T_ghosted=ghosted))
     stokes, pr, ρg = _upload(jr, s)
     T = from_numpy(s.arrays["T"], stokes.P.device)
     r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, phases, dict(T=T, P=stokes.P), s.dt, None, kwargs=s.kwargs)
@@ -263,3 +266,46 @@ def test_vep2d_strain_increment_matches_oracle(jr, oracle, displacement, soft):
     ref0 = _cp(s.arrays)
     oracle.stokes2d_vep_solve(ref0, oracle.rheology_struct(phases), _vep_params(oracle, s, iterMin=10, displacement_bcs=displacement))
     assert np.abs(ref0["txx"] - ref["txx"]).max() > 1e-12
+
+
+def test_sinking_block_reference_test_on_the_device(jr, oracle):
+    """test/test_sinking_block.jl:93-209 through the operator API as the script chains it: compute_ρg!(ρg[2], phase_ratios, rheology, args), init_P!,
+    compute_viscosity!(stokes, phase_ratios, args, rheology, cutoff), flow_bcs!, solve!, compute_dt, velocity2vertex! -- err_evo1[end] < 1e-5, the velocity
+    the reference's test prints (within 6 %), and every field equal to the oracle's solve"""
+    import json
+    from pathlib import Path
+    import torch
+    from justrelax_jl_amd.checks import max_rel_diff
+    from test_gpu_vep2d import _download, _upload, _vep_params
+    ka = json.loads((Path(__file__).parent / "golden" / "reference_known_answers.json").read_text())["sinking_block2D"]
+    s = jr.miniapps.sinking_block2d(32)
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes2d_vep_solve(ref, oracle.rheology_struct(s.extra["phases"]), _vep_params(oracle, s, iterMin=100))
+    # device: start from velocities / stresses only, derive ρg, P and η with the operators
+    host_fy, host_P, host_eta = s.arrays["fy"].copy(), s.arrays["P"].copy(), s.arrays["eta"].copy()
+    s.arrays["fy"][...] = 0.0
+    s.arrays["P"][...] = 0.0
+    s.arrays["eta"][...] = 1.0
+    s.arrays["eta_v"][...] = 1.0
+    st, pr, ρg = _upload(jr, s)
+    dev = st.P.device
+    args = dict(T=jr.fzeros(tuple(n + 2 for n in s.ni), dev, 1.0), P=st.P)
+    jr.compute_ρg_(ρg, pr, s.extra["phases"], args)                                        # :155 (args.T ghosted, read unshifted; constant densities ignore it)
+    assert np.array_equal(jr.to_numpy(ρg[1]), host_fy)
+    st.P.copy_(ρg[1] * torch.tensor(np.abs(s.grid.xci[1]), device=dev)[None, :])          # init_P! :86-89
+    jr.compute_viscosity_(st, pr, args, s.extra["phases"], (-np.inf, np.inf))              # :162
+    assert np.allclose(jr.to_numpy(st.viscosity.η), host_eta, rtol=1e-14) and np.allclose(jr.to_numpy(st.P), host_P, rtol=1e-15)
+    jr.flow_bcs_(st, s.flow_bcs)
+    r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], args, s.dt, None, kwargs=s.kwargs)
+    assert r.iter == r_ref["iter"] and r.err_evo1[-1] < ka["err_evo1_last_below"]
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-6)
+    dt = jr.compute_dt_(st, s.extra["di"])
+    assert dt == pytest.approx(0.9 * min(s.extra["di"][0] / np.abs(ref["Vx"]).max(), s.extra["di"][1] / np.abs(ref["Vy"]).max()), rel=1e-6)
+    n = s.ni[0]
+    Vx_v, Vy_v = jr.fzeros((n + 1, n + 1), dev), jr.fzeros((n + 1, n + 1), dev)
+    jr.velocity2vertex_(Vx_v, Vy_v, st.V.Vx, st.V.Vy)
+    vmax = float(torch.sqrt(Vx_v ** 2 + Vy_v ** 2).max())
+    assert vmax == pytest.approx(ka["max_velocity"], rel=6e-2)
+    out = _download(jr, st)
+    for k in ("P", "Vx", "Vy", "txx", "tyy", "txy", "exx", "exy", "tII", "eta_vep"):
+        assert max_rel_diff(out[k], ref[k]) <= 1e-6, k
