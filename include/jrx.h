@@ -553,6 +553,10 @@ jrx_status jrx_center2vertex3d(jrx_handle *h, double *vertex_yz, double *vertex_
  * as args.T is read without the shift to the centres, as the reference's getindex_NamedTuple(args, I...) does (test/test_WENO5.jl:208-214). */
 jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh, const double *phase_c, const double *T, const double *P, const int64_t n[3],
                             const int64_t tdim[3], int32_t ndim);
+/* compute_lithostatic_pressure!(P, ρg, dz) -- src/Utils.jl:521-573: P[j] = Σ_{k>j} ρg[k] dz[k] + ρg[j] dz[j] / 2 down the columns of the last dimension (the
+ * vertical, pointing up); dz_cells: one height per cell of that dimension, or NULL for the constant height dz.  n = {nx, ny[, nz]}.  The four-argument IGG
+ * form (weight of the ranks stacked above) is not built: refused when the handle's communicator splits the vertical direction. */
+jrx_status jrx_compute_lithostatic_pressure(jrx_handle *h, double *P, const double *rhog, double dz, const double *dz_cells, const int64_t n[3], int32_t ndim);
 /* compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation = ν) -- rheology/Viscosity.jl:118-167, for the creep laws of the rheology table
  * (phase 0: LinearViscous or the Arrhenius table; they do not depend on the strain rate): eta <- clamp(ν η_creep(T, P) + (1 - ν) eta, cutoff).  args.T has the
  * extents tdim: ni .+ 2 (the ghosted thermal.T, read at I .+ 1 as local_viscosity_args does, Viscosity.jl:513-523) or ni / NULL (cell centres); P: ni or NULL.

@@ -129,6 +129,22 @@ __global__ __launch_bounds__(256) void k_viscosity_single(double *__restrict__ e
     eta[c] = fmin(fmax(e, lo), hi);
 }
 
+// compute_lithostatic_pressure!(P, ρg, dz) (src/Utils.jl:541-573): P[j] = Σ_{k>j} ρg[k] dz[k] + ρg[j] dz[j] / 2 down every column of the last dimension -- the
+// reference's reverse(cumsum(reverse(w))) - w / 2 accumulated from the top cell downwards.  One thread per column, x fastest across the lanes.
+__global__ __launch_bounds__(256) void k_lithostatic(double *__restrict__ P, const double *__restrict__ rhog, const double *__restrict__ dzv, const double dz,
+                                                     const i64 ncol, const int nlast)
+{
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double acc = 0.0;
+    for (int k = nlast - 1; k >= 0; k--) {
+        const i64 q = c + ncol * k;
+        const double w = rhog[q] * (dzv ? dzv[k] : dz);
+        acc += w;
+        P[q] = acc - w / 2;
+    }
+}
+
 struct ShArgs {
     double *sh;
     const double *t[6], *to[6], *e[6];      // Voigt order: 2D xx, yy, xy; 3D xx, yy, zz, yz, xz, xy.  τ, τ_o at the centres; ε shear on its edges
@@ -293,6 +309,21 @@ jrx_status jrx_compute_rhog(jrx_handle *h, double *rhog, const jrx_rheology *rh,
     }
     if (phase_c) hipLaunchKernelGGL(k_compute_rhog<true>, OUT_GRID(nx, ny, nz), dim3(256), 0, h->stream, rhog, *rh, phase_c, T, P, nx, ny, t1, t2);
     else hipLaunchKernelGGL(k_compute_rhog<false>, OUT_GRID(nx, ny, nz), dim3(256), 0, h->stream, rhog, *rh, phase_c, T, P, nx, ny, t1, t2);
+    return done(h);
+}
+
+jrx_status jrx_compute_lithostatic_pressure(jrx_handle *h, double *P, const double *rhog, double dz, const double *dz_cells, const int64_t n[3], int32_t ndim)
+{
+    if (!h) return JRX_ERR_ARG;
+    JRX_TRY(jrx_check_device(h));
+    if (!P || !rhog || !n || (ndim != 2 && ndim != 3)) return jrx_fail(h, JRX_ERR_ARG, "compute_lithostatic_pressure!: bad argument");
+    for (int d = 0; d < ndim; d++)
+        if (n[d] < 1) return jrx_fail(h, JRX_ERR_ARG, "compute_lithostatic_pressure!: bad size");
+    if (jrx_comm_active(h) && (jrx_comm_has_neighbor(h, ndim - 1, 0) || jrx_comm_has_neighbor(h, ndim - 1, 1)))
+        return jrx_fail(h, JRX_ERR_UNSUPPORTED, "compute_lithostatic_pressure!: the vertical direction is split across ranks (the IGG form that gathers the weight of the "
+                                                "ranks above is not built)");
+    const i64 ncol = ndim == 3 ? (i64)n[0] * n[1] : (i64)n[0];
+    hipLaunchKernelGGL(k_lithostatic, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, h->stream, P, rhog, dz_cells, dz, ncol, (int)n[ndim - 1]);
     return done(h);
 }
 

@@ -143,6 +143,25 @@ def compute_ρg_(ρg, *rest, handle=None):
     _h(out, handle).call("jrx_compute_rhog", *_p(out), C.byref(rh), *_p(pc, T, P), n, td, C.c_int32(nd))
 
 
+def compute_lithostatic_pressure_(P, ρg, dz, igg=None, *, handle=None):
+    """compute_lithostatic_pressure!(P, ρg, dz[, igg]) -- src/Utils.jl:521-573: integrate ρg down the columns of the last dimension, P[j] = Σ_{k>j} ρg[k] dz[k] +
+    ρg[j] dz[j] / 2; dz a number or one height per cell of that dimension.  With `igg` the result is the same as long as the vertical direction is not split
+    across ranks (refused otherwise)."""
+    if tuple(P.shape) != tuple(ρg.shape):
+        raise ValueError(f"`P` and `ρg` must span the same cells, got {tuple(P.shape)} and {tuple(ρg.shape)}")          # DimensionMismatch, Utils.jl:562-566
+    nd = P.dim()
+    n = (C.c_int64 * 3)(*P.shape, *([1] * (3 - nd)))
+    dzv = None
+    if not isinstance(dz, (int, float)):
+        import numpy as np
+        host = np.ascontiguousarray(dz.detach().cpu().numpy() if isinstance(dz, torch.Tensor) else dz, dtype=np.float64)
+        if host.shape != (P.shape[-1],):
+            raise ValueError(f"`dz` must hold one height per cell, got {host.size} heights for {P.shape[-1]} cells")              # Utils.jl:612-616
+        dzv = torch.tensor(host, dtype=torch.float64, device=P.device)
+    _h(P, handle).call("jrx_compute_lithostatic_pressure", *_p(P, ρg), C.c_double(0.0 if dzv is not None else float(dz)), *_p(dzv), n, C.c_int32(nd))
+    return P
+
+
 def compute_shear_heating_(thermal, stokes, *rest, handle=None):
     """compute_shear_heating!(thermal, stokes, rheology, dt) / (thermal, stokes, phase_ratios, rheology, dt) -- thermal_diffusion/ShearHeating.jl:14-71.
     Each phase's table entry may carry `shear_heat` = Χ of its ConstantShearheating (absent: 0)."""

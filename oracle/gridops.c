@@ -139,6 +139,20 @@ void orc_compute_viscosity_single(double *eta, const orc_rheology *rh, const dou
             }
 }
 
+/* compute_lithostatic_pressure!(P, ρg, dz) (src/Utils.jl:541-573): reverse(cumsum(reverse(w))) - w / 2 with w = ρg .* dz, accumulated from the top cell */
+void orc_compute_lithostatic_pressure(double *P, const double *rhog, double dz, const double *dz_cells, const int64_t n[3], int32_t ndim)
+{
+    const int64_t ncol = ndim == 3 ? n[0] * n[1] : n[0], nlast = n[ndim - 1];
+    for (int64_t c = 0; c < ncol; c++) {
+        double acc = 0.0;
+        for (int64_t k = nlast - 1; k >= 0; k--) {
+            const double w = rhog[c + ncol * k] * (dz_cells ? dz_cells[k] : dz);
+            acc += w;
+            P[c + ncol * k] = acc - w / 2;
+        }
+    }
+}
+
 /* fn_ratio(fn, rheology, ratio) (src/phases/phases.jl:6-15) */
 static double ratio_sum(const double *val, const double *r, int n)
 {

@@ -364,6 +364,7 @@ void orc_center2vertex_harm2d(double *ver, const double *cen, int64_t nx, int64_
 void orc_center2vertex3d(double *vyz, double *vxz, double *vxy, const double *cyz, const double *cxz, const double *cxy, int64_t nx, int64_t ny, int64_t nz);
 void orc_compute_rhog(double *rhog, const orc_rheology *rh, const double *phase_c, const double *T, const double *P, const int64_t n[3], const int64_t tdim[3],
                       int32_t ndim);
+void orc_compute_lithostatic_pressure(double *P, const double *rhog, double dz, const double *dz_cells, const int64_t n[3], int32_t ndim);
 void orc_compute_viscosity_single(double *eta, const orc_rheology *rh, const double *T, const double *P, const int64_t n[3], const int64_t tdim[3], int32_t ndim,
                                   double nu, double lo, double hi);
 void orc_compute_shear_heating(double *sh, const double *const *tau, const double *const *tau_o, const double *const *eps, const double *phase_c,

@@ -791,6 +791,16 @@ def compute_rhog(rh: "Rheology", T, P, phase_c=None, shape=None):
     return out
 
 
+def compute_lithostatic_pressure(rhog, dz):
+    """compute_lithostatic_pressure!(P, ρg, dz) -- src/Utils.jl:541-573; dz: a number or one height per cell of the last dimension"""
+    nd = rhog.ndim
+    P = np.zeros(rhog.shape, order="F")
+    n = (C.c_int64 * 3)(*rhog.shape, *([1] * (3 - nd)))
+    vec = None if np.isscalar(dz) else np.ascontiguousarray(dz, dtype=np.float64)
+    lib().orc_compute_lithostatic_pressure(_p(P), _p(rhog), C.c_double(float(dz) if vec is None else 0.0), vec.ctypes.data_as(_dp) if vec is not None else _dp(), n, C.c_int32(nd))
+    return P
+
+
 def compute_viscosity_single(eta, rh: "Rheology", T, P, cutoff=(-np.inf, np.inf), nu=1.0):
     """compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation) in place on eta -- rheology/Viscosity.jl:118-167 (T: ni or ni .+ 2)"""
     nd = eta.ndim

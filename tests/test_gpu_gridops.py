@@ -207,6 +207,31 @@ def test_compute_viscosity_single_vs_oracle(jr, oracle, nd):
         jr.compute_viscosity_(stokes, dict(T=None, P=None), [ph, ph], (0.0, 1.0))
 
 
+def test_lithostatic_pressure_vs_oracle_and_reference_formula(jr, oracle):
+    """compute_lithostatic_pressure!(P, ρg, dz[, igg]) -- test/test_lithostatic_pressure2D_MPI.jl:104-126 on the device, and bit-identity with the oracle's top-down
+    accumulation on random 2D / 3D columns with a constant and a per-cell height"""
+    from test_oracle_gridops import _P_global
+    nx, ny = 4, 8
+    rhog = np.asfortranarray(np.tile(1 + 0.25 * np.arange(1, ny + 1)[None, :], (nx, 1)))
+    P = jr.fzeros((nx, ny), _dev())
+    jr.compute_lithostatic_pressure_(P, _up(rhog), 0.5)
+    for j in range(1, ny + 1):
+        assert np.allclose(_dn(P)[:, j - 1], _P_global(j, ny, 0.5), rtol=1e-14)
+    jr.compute_lithostatic_pressure_(P, _up(rhog), 0.1 * np.arange(1, ny + 1))
+    for j in range(1, ny + 1):
+        assert np.allclose(_dn(P)[:, j - 1], _P_global(j, ny, None), rtol=1e-14)
+    for shape in ((300, 70), (33, 20, 41)):
+        r = np.asfortranarray(RNG.random(shape) * 3.0e4)
+        for dz in (1.5e3, RNG.random(shape[-1]) * 2.0e3 + 100.0):
+            Pd = jr.fzeros(shape, _dev())
+            jr.compute_lithostatic_pressure_(Pd, _up(r), dz)
+            np.testing.assert_array_equal(_dn(Pd), oracle.compute_lithostatic_pressure(r, dz))
+    with pytest.raises(ValueError, match="same cells"):
+        jr.compute_lithostatic_pressure_(jr.fzeros((4, 8), _dev()), jr.fzeros((4, 9), _dev()), 1.0)
+    with pytest.raises(ValueError, match="one height per cell"):
+        jr.compute_lithostatic_pressure_(jr.fzeros((4, 8), _dev()), jr.fzeros((4, 8), _dev()), np.ones(7))
+
+
 def test_argument_errors(jr):
     d = _dev()
     with pytest.raises(AssertionError):                      # Interpolations.jl:238 @assert size(Vx_v) == size(Vy_v)

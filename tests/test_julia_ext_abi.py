@@ -75,7 +75,7 @@ def test_the_extension_covers_the_reference_method_table():
                            "jrx_accumulate_tensor3d", "jrx_accumulate_vol", "jrx_compute_maxloc", "jrx_center2vertex2d", "jrx_compute_vorticity2d",
                            "jrx_compute_vorticity3d", "jrx_velocity2vertex2d", "jrx_velocity2vertex3d", "jrx_velocity2center2d", "jrx_velocity2center3d",
                            "jrx_vertex2center", "jrx_center2vertex3d", "jrx_center2vertex_harm2d", "jrx_compute_rhog", "jrx_compute_shear_heating", "jrx_compute_viscosity_single",
-                           "jrx_vep2d_compute_viscosity", "jrx_vep3d_compute_viscosity"]
+                           "jrx_vep2d_compute_viscosity", "jrx_vep3d_compute_viscosity", "jrx_compute_lithostatic_pressure"]
     missing = [f for f in needed_entry_points if f not in calls]
     assert not missing, missing
     # the generics the reference's AMDGPU extension adds methods to (src/ext/AMDGPU/2D.jl:48-403, 3D.jl:46-412, ext/JustRelaxAMDGPUExt.jl:5-10)

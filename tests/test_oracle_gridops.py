@@ -141,3 +141,30 @@ def test_compute_viscosity_single(oracle):
     e2 = before.copy(order="F")
     oracle.compute_viscosity_single(e2, rh, Tc, s.arrays["P"], cutoff=s.kwargs["viscosity_cutoff"])
     assert np.array_equal(e2, full)
+
+
+def _P_global(j, nyg, dz):
+    """test/test_lithostatic_pressure2D_MPI.jl:42-49 (1-based j): pressure at cell j of a column of nyg cells, ρg_global(j) = 1 + 0.25 j, dz_global(j) = 0.1 j"""
+    rg = lambda k: 1 + 0.25 * k
+    if dz is None:
+        return sum(rg(k) * 0.1 * k for k in range(j + 1, nyg + 1)) + rg(j) * 0.1 * j / 2
+    return sum(rg(k) for k in range(j + 1, nyg + 1)) * dz + rg(j) * dz / 2
+
+
+def test_lithostatic_pressure_reference_formulas(oracle):
+    """compute_lithostatic_pressure!(P, ρg, dz): the single-subdomain case of test/test_lithostatic_pressure2D_MPI.jl:104-126 (nx, ny = 4, 8; constant and per-cell
+    heights) and a 3D column"""
+    nx, ny = 4, 8
+    rhog = np.asfortranarray(np.tile(1 + 0.25 * np.arange(1, ny + 1)[None, :], (nx, 1)))
+    P = oracle.compute_lithostatic_pressure(rhog, 0.5)
+    for j in range(1, ny + 1):
+        assert np.allclose(P[:, j - 1], _P_global(j, ny, 0.5), rtol=1e-14)
+    P = oracle.compute_lithostatic_pressure(rhog, 0.1 * np.arange(1, ny + 1))
+    for j in range(1, ny + 1):
+        assert np.allclose(P[:, j - 1], _P_global(j, ny, None), rtol=1e-14)
+    r3 = np.asfortranarray(RNG.random((5, 4, 6)) + 1.0)
+    dz = RNG.random(6) + 0.5
+    P3 = oracle.compute_lithostatic_pressure(r3, dz)
+    w = r3 * dz[None, None, :]
+    want = np.flip(np.cumsum(np.flip(w, axis=2), axis=2), axis=2) - w / 2           # Utils.jl:571
+    np.testing.assert_allclose(P3, want, rtol=1e-14)
