@@ -237,6 +237,9 @@ class Geometry:
             xci = [np.linspace(origin[d] + di[d] / 2, origin[d] + self.li[d] - di[d] / 2, self.ni[d]) for d in range(nD)]
             xvi = [np.linspace(origin[d], origin[d] + self.li[d], self.ni[d] + 1) for d in range(nD)]
         self.xci, self.xvi = tuple(xci), tuple(xvi)
+        # velocity_grids (Grid.jl:161-169,184-200): the grid of V_i is the vertices along i and the centres, with one ghost point either side, along the others
+        ghost = tuple(np.linspace(xci[d][0] - di[d], xci[d][-1] + di[d], self.ni[d] + 2) for d in range(nD))
+        self.xi_vel = tuple(tuple(self.xvi[d] if d == i else ghost[d] for d in range(nD)) for i in range(nD))
         inv = tuple(1.0 / d for d in di)
         self.di = dict(center=di, vertex=di, velocity=tuple(di for _ in range(nD)))
         self._di = dict(center=inv, vertex=inv, velocity=tuple(inv for _ in range(nD)))

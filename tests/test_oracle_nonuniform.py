@@ -140,3 +140,25 @@ def test_heat_diffusion_on_a_stretched_grid(jr, oracle):
     assert np.abs(got - want[None, :]).max() < 0.05 * 3200.0
     assert np.all(np.diff(got[0]) < 0.0) and 300.0 < got[0, -1] < got[0, 0] < 3500.0
     assert np.abs(np.diff(got, axis=0)).max() < 1e-2                         # and it is independent of x (to the residual left)
+
+
+def test_uniform_geometry_reference_assertions(jr):
+    """test/test_grid2D.jl:10-36 and the geometry_nonMPI testset of test/test_Utils.jl:473-496"""
+    import justrelax_jl_amd.grid as G
+    G.finalize_global_grid()
+    n = 4
+    origin = (0.0, -1.0)
+    g = jr.Geometry((n, n), (1.0, 1.0), origin=origin)
+    di = (0.25, 0.25)
+    assert g.origin == origin
+    for i in range(2):
+        assert g.xvi[i][0] == origin[i] and g.xci[i][0] == origin[i] + di[i] / 2
+    assert g.xi_vel[0][1][0] == origin[1] - di[0] / 2 and g.xi_vel[1][0][0] == origin[0] - di[1] / 2      # test_grid2D.jl:34-35
+    assert g.li == (1.0, 1.0) and g.max_li == 1.0 and g.di["center"] == di and len(g.xci[0]) == 4 and len(g.xvi[0]) == 5 and len(g.xi_vel) == 2
+    g3 = jr.Geometry((4, 4, 4), (1.0, 2.0, 3.0), origin=(0.0, 0.0, 0.0))
+    assert g3.li == (1.0, 2.0, 3.0) and g3.max_li == 3.0 and g3.di["center"] == (0.25, 0.5, 0.75) and len(g3.xi_vel) == 3
+    assert [len(a) for a in g3.xi_vel[0]] == [5, 6, 6] and [len(a) for a in g3.xi_vel[2]] == [6, 6, 5]
+    leg = jr.legacy_uniform_grid((n, n), di)                                                              # test_grid2D.jl:60-68
+    assert leg.ni == (n, n) and leg.li == (1.0, 1.0)
+    leg = jr.legacy_uniform_grid((n, n), g.di)
+    assert leg.ni == (n, n) and leg.li == (1.0, 1.0)
