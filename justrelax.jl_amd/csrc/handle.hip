@@ -116,7 +116,7 @@ int find_opt(jrx_handle *h, const char *key, OptRef *out)
         {"fused_comm", 0, &h->fused_comm}, {"fused_split", 0, &h->fused_split}, {"fused_tile", 1, &h->fused_tile}, {"fused_ylds", 0, &h->fused_ylds},
         {"b_width_x", 1, &h->b_width_opt[0]}, {"b_width_y", 1, &h->b_width_opt[1]}, {"b_width_z", 1, &h->b_width_opt[2]},
         {"halo_self_rccl", 0, &h->halo_self_rccl}, {"thermal_cfg", 1, &h->thermal_cfg}, {"thermal_xg", 1, &h->thermal_xg},
-        {"fused2d", 0, &h->fused2d}, {"vep3_edges", 1, &h->vep3_edges}, {"vep3_cfg", 1, &h->vep3_cfg}, {"vep3_peel", 0, &h->vep3_peel}, {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"scratch_sets", 0, &h->scratch_sets},
+        {"fused2d", 0, &h->fused2d}, {"loop_graphs", 0, &h->loop_graphs}, {"vep3_edges", 1, &h->vep3_edges}, {"vep3_cfg", 1, &h->vep3_cfg}, {"vep3_peel", 0, &h->vep3_peel}, {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"scratch_sets", 0, &h->scratch_sets},
         {"stat_fused3d", 2, &h->stat_fused3d}, {"stat_fused2d", 2, &h->stat_fused2d}, {"stat_thermal_fused", 2, &h->stat_thermal_fused},
         {"stat_vep3_fused", 2, &h->stat_vep3_fused},
     };

@@ -31,6 +31,7 @@ struct jrx_handle {
     double *tscratch2[3] = {};           // the same for the 2D loop (T, qTx, qTy)
     int tscratch2_dims[2] = {0, 0};
     // ---- options (jrx_set_option; nothing in the library reads the process environment)
+    bool loop_graphs = true;             // launch-bound 2D loops: runs of unobserved iterations replay as captured hipGraphs (option "loop_graphs")
     bool thermal_fused = true;           // heat diffusion: one fused launch per unobserved iteration (option "thermal_fused")
     bool fused_overlap = false;          // multi-rank fused pipeline: shell tiles + exchange on the halo stream, interior tiles concurrently
     int kernel_variant = 0;              // 0 auto (fused PT pipeline where it pays), 1 per-node v1 kernels, 2 z-marching sweeps only, 3 fused wherever legal

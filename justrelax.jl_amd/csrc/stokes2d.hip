@@ -505,7 +505,57 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     bool bcs_full_done[2] = {false, false};      // flow_bcs! launched in full on the V of the caller's set / the second set
     const int nwx = (nx + 1 + 62) / 63;
     Args2 a = make_args2(&cur, h->etatau, p);
+    // Runs of unobserved iterations in the steady state of the loop replay as a captured graph of GIT iterations (the gap between dependent launches is shorter
+    // inside a graph: scripts/graph_probe.hip, 4.6 vs 5.7 - 6.1 us per pair of short kernels): GIT x k_fused2d (an even count, so that the ping-pong sets end where
+    // they started; one graph per parity) on the grids that run the one-launch iteration (SolCx 128^2 173 k -> 184 k it/s, 256^2 143 k -> 150 k).  The two-kernel form
+    // of the larger grids gains nothing from it (512^2: 77.9 k plain, 76.7 k replayed) and keeps plain launches.  Option "loop_graphs" = 0: plain launches everywhere.
+    constexpr int GIT = 32;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    bool graphs = h->loop_graphs && fusable;
+    auto capture = [&](hipGraphExec_t *out, auto &&body) -> bool {
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) { body(); ok = hipStreamEndCapture(s, &g) == hipSuccess && g != nullptr; }
+        if (ok) ok = hipGraphInstantiate(out, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok) { (void)hipGetLastError(); *out = nullptr; }
+        return ok;
+    };
     while (keep_going(iter)) {
+        if (graphs && iter >= 2) {
+            // observed iterations: the multiples of nout and iteration iterMax + 1 (Stokes2D.jl:265,312); between them err does not change, so keep_going holds
+            int64_t nxt = ((iter / p->nout) + 1) * p->nout;
+            if (nxt > p->iterMax + 1) nxt = p->iterMax + 1;
+            int64_t run = nxt - 1 - iter;                     // unobserved iterations from here
+            if (fusable) {
+                int64_t frun = run - 1;                       // the last unobserved iteration before an observed one is not fused with it
+                if (stress_done && frun >= GIT) {
+                    const int par = cur_is_user ? 0 : 1;
+                    if (!gexec[par]) {
+                        const bool ok = capture(&gexec[par], [&]() {
+                            jrx_stokes2d_fields c = cur;
+                            bool cu = cur_is_user;
+                            for (int q = 0; q < GIT; q++) {
+                                const Args2 aa = make_args2(&c, h->etatau, p);
+                                const Out6_2d dst = cu ? setS : setU;
+                                hipLaunchKernelGGL(k_fused2d, dim3((unsigned)((nwx * (ny + 1) + 3) / 4)), dim3(256), 0, s, aa, dst, bc2, nwx);
+                                c.P = dst.P; c.txx = dst.txx; c.tyy = dst.tyy; c.txy = dst.txy; c.Vx = dst.Vx; c.Vy = dst.Vy;
+                                cu = !cu;
+                            }
+                        });
+                        if (!ok) graphs = false;
+                    }
+                    if (gexec[par]) {
+                        while (frun >= GIT) {
+                            JRX_HIP(h, hipGraphLaunch(gexec[par], s));
+                            iter += GIT; frun -= GIT;
+                            h->stat_fused2d += GIT;
+                        }
+                        continue;
+                    }
+                }
+            }
+        }
         const int64_t it1 = iter + 1;
         const bool check = is_check(it1);
         const bool diag = check || !keep_going(it1);
@@ -563,6 +613,8 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
                        (long long)iter, err, err / err_it1, nRx, nRy, nDV);
         }
     }
+    for (int q = 0; q < 2; q++)
+        if (gexec[q]) (void)hipGraphExecDestroy(gexec[q]);
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     if (!cur_is_user) {       // leave the state in the caller's arrays
         JRX_HIP(h, hipMemcpyAsync(setU.P, setS.P, n * sizeof(double), hipMemcpyDeviceToDevice, s));

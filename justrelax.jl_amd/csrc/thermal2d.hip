@@ -475,7 +475,51 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
     }
     const int FTX = nx > 128 ? 256 : (nx > 64 ? 128 : 64), ntx = (nx + FTX - 1) / FTX;
     jrx_thermal2d_fields tc = *t;
+    auto fused_launch = [&](const TArgs &aa, const TSet2 &dst) {
+        if (FTX == 256) hipLaunchKernelGGL(k_thermal2d_fused<256>, dim3((unsigned)(ntx * ny)), dim3(256), 0, s, aa, dst, ntx);
+        else if (FTX == 128) hipLaunchKernelGGL(k_thermal2d_fused<128>, dim3((unsigned)(ntx * ny)), dim3(128), 0, s, aa, dst, ntx);
+        else hipLaunchKernelGGL(k_thermal2d_fused<64>, dim3((unsigned)(ntx * ny)), dim3(64), 0, s, aa, dst, ntx);
+    };
+    // Runs of unobserved fused iterations replay as a captured graph of GIT iterations (an even count: the ping-pong sets end where they started): on these
+    // launch-bound grids the gap between dependent launches is shorter inside a graph (scripts/graph_probe.hip: 4.6 vs 5.7 - 6.1 us per pair of short kernels).
+    // One graph per parity of the current set, built on first use, destroyed at the end; option "loop_graphs" = 0 keeps plain launches.
+    constexpr int GIT = 32;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    bool graphs = fusable && h->loop_graphs;
+    auto destroy_graphs = [&]() { for (int q = 0; q < 2; q++) if (gexec[q]) { (void)hipGraphExecDestroy(gexec[q]); gexec[q] = nullptr; } };
     while (err > p->eps && iter < p->iterMax) {
+        if (graphs) {
+            const int64_t nxt = std::min<int64_t>(((iter / p->nout) + 1) * p->nout, p->iterMax);      // 1-based number of the next observed iteration
+            int64_t run = nxt - 1 - iter;                                                              // unobserved iterations from here
+            if (run >= GIT) {
+                const int par = cur.T == user.T ? 0 : 1;
+                if (!gexec[par]) {
+                    hipGraph_t g = nullptr;
+                    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        TSet2 c = cur, o = oth;
+                        for (int q = 0; q < GIT; q++) {
+                            TArgs aa = a;
+                            aa.t.T = c.T; aa.t.qTx = c.qx; aa.t.qTy = c.qy;
+                            fused_launch(aa, o);
+                            const TSet2 tmp = c; c = o; o = tmp;
+                        }
+                        ok = hipStreamEndCapture(s, &g) == hipSuccess && g != nullptr;
+                    }
+                    if (ok) ok = hipGraphInstantiate(&gexec[par], g, nullptr, nullptr, 0) == hipSuccess;
+                    if (g) (void)hipGraphDestroy(g);
+                    if (!ok) { (void)hipGetLastError(); gexec[par] = nullptr; graphs = false; }
+                }
+                if (gexec[par]) {
+                    while (run >= GIT) {
+                        JRX_HIP(h, hipGraphLaunch(gexec[par], s));
+                        iter += GIT; run -= GIT;
+                        h->stat_thermal_fused += GIT;
+                    }
+                    continue;
+                }
+            }
+        }
         const bool observed = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
         a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy;
         if constexpr (PH) {      // update_pt_thermal_arrays!(pt_thermal, phase, rheology, args, _dt) -- DiffusionPT_solver.jl:233-234
@@ -485,9 +529,7 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
             pt_fresh = !observed;
         }
         if (fusable && !observed) {
-            if (FTX == 256) hipLaunchKernelGGL(k_thermal2d_fused<256>, dim3((unsigned)(ntx * ny)), dim3(256), 0, s, a, oth, ntx);
-            else if (FTX == 128) hipLaunchKernelGGL(k_thermal2d_fused<128>, dim3((unsigned)(ntx * ny)), dim3(128), 0, s, a, oth, ntx);
-            else hipLaunchKernelGGL(k_thermal2d_fused<64>, dim3((unsigned)(ntx * ny)), dim3(64), 0, s, a, oth, ntx);
+            fused_launch(a, oth);
             h->stat_thermal_fused++;
             JRX_LAUNCH_CHECK(h);
             const TSet2 tmp = cur; cur = oth; oth = tmp;
@@ -523,6 +565,7 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
             err = err_stop;
         }
     }
+    destroy_graphs();
     if (cur.T != user.T) {      // leave the results in the caller's arrays
         JRX_HIP(h, hipMemcpyAsync(user.T, cur.T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));
         JRX_HIP(h, hipMemcpyAsync(user.qx, cur.qx, (size_t)(nx + 1) * ny * sizeof(double), hipMemcpyDeviceToDevice, s));

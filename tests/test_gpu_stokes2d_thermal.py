@@ -256,3 +256,51 @@ def test_2d_kernel_variants_are_bit_identical(env, ni, bcs):
                 for c in ((0, 0), (0, -1), (-1, 0), (-1, -1)):
                     a[c] = b[c]
             assert np.array_equal(a, b, equal_nan=True), (v, k)
+
+
+def test_graph_replay_of_unobserved_iterations_changes_nothing(env):
+    """option loop_graphs: runs of unobserved one-launch iterations of the 2D visco-elastic loop and of the 2D heat-diffusion loop replay as captured hipGraphs
+    (32 iterations each); results, iteration counts and the fused-launch counters equal those of plain launches"""
+    import ctypes as C
+    jr, orc, th = env["jr"], env["orc"], env["th"]
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    from justrelax_jl_amd.miniapps.thermal2d import add_perturbation
+    h = _lib.default_handle(0)
+
+    def opt(k, v=None):
+        if v is not None:
+            h.call("jrx_set_option", C.c_char_p(k), C.c_int64(v))
+        out = C.c_int64(0)
+        h.call("jrx_get_option", C.c_char_p(k), C.byref(out))
+        return out.value
+    outs = []
+    try:
+        for g in (0, 1):
+            opt(b"loop_graphs", g)
+            s = jr.miniapps.solcx2d(64, iterMax=399, nout=200)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+            stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
+            c0 = opt(b"stat_fused2d")
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, G, K, s.dt, None, kwargs=s.kwargs)
+            fused = opt(b"stat_fused2d") - c0
+            st = download_stokes(stokes)
+            s2 = jr.miniapps.diffusion2d(64, iterMax=500, nout=250)
+            b = s2.flow_bcs
+            p = orc.thermal_params2d(s2.ni, s2.grid._di["center"], s2.dt, 1e-30, no_flux=b.no_flux, constant_value=b.constant_value, constant_flux=b.constant_flux,
+                                     periodic=b.periodic)
+            orc.thermal_bcs2d(s2.arrays["T"], p)
+            add_perturbation(s2.arrays["T"], s2.grid, **s2.extra["perturbation"])
+            thermal, pt, Kt, ρCp = _thermal_setup(jr, th, s2)
+            pt.ϵ = 1e-30
+            c1 = opt(b"stat_thermal_fused")
+            rt = jr.heatdiffusion_PT_(thermal, pt, b, Kt, ρCp, s2.dt, s2.grid, kwargs=dict(iterMax=500, nout=250, verbose=False))
+            outs.append((r.iter, list(r.err_evo1), fused, st, list(rt.norm_ResT), opt(b"stat_thermal_fused") - c1, jr.to_numpy(thermal.T), jr.to_numpy(thermal.qTx)))
+    finally:
+        opt(b"loop_graphs", 1)
+    a, b_ = outs
+    assert a[0] == b_[0] == 400 and a[1] == b_[1] and a[2] == b_[2] > 300
+    for k in a[3]:
+        assert np.array_equal(a[3][k], b_[3][k], equal_nan=True), k
+    assert a[4] == b_[4] and a[5] == b_[5] > 400
+    assert np.array_equal(a[6], b_[6]) and np.array_equal(a[7], b_[7])
