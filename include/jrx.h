@@ -82,8 +82,8 @@ const char *jrx_build_id(void);
  *   block, the three blocks of a tile on one XCD; 2 = the same kernel as one launch per family; 0 = one node per thread (always used with
  *   more than 4 phases).  Same results.  "vep3_cfg" = KZ * 10 + min blocks per CU (tuning).  "vep3_peel" (default 1): a last lane segment of the z-marching
  *   launch that would be less than 40 % full goes to the node kernel in a thin launch of its own (0 = launch it anyway; same results).
- * "loop_graphs" (0/1, default 1): runs of unobserved one-launch iterations of the launch-bound 2D loops (2D heat diffusion, 2D visco-elastic Stokes on the
- *   grids that use k_fused2d) replay as captured hipGraphs of 32 iterations; same results, shorter gaps between dependent launches.
+ * "loop_graphs" (0/1, default 1): runs of unobserved iterations of the launch-bound 2D loops (2D heat diffusion, 2D visco-elastic Stokes on the grids that use
+ *   k_fused2d, 2D visco-elasto-plastic Stokes below 300 k nodes) replay as captured hipGraphs of 32 iterations; same results, shorter gaps between launches.
  * "fused_ylds", "fused2d", "vep3_map", "vep3_xcd", "thermal_cfg", "thermal_xg", "b_width_x/y/z": kernel-form / tile-shape A/B
  *   switches used by the measurements in profiles/ (results never change); "halo_self_rccl" (0/1): test hook, a rank that is its
  *   own periodic neighbour routes its planes through ncclSend/ncclRecv on a one-rank communicator.

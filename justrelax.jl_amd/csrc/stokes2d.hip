@@ -1379,8 +1379,52 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
+    // Runs of unobserved iterations replay as a captured graph of GIT iterations (three launches each: at the sizes where the loop is launch-bound -- 17 - 18 us
+    // per iteration up to 256^2 -- the gap between dependent launches is shorter inside a graph).  An even count, so that the (τxx, τyy) sets end where they
+    // started.  Only in the plain steady state: one rank, no periodic face, velocity boundary conditions, strain-rate form.  Option "loop_graphs" = 0: plain launches.
+    constexpr int GIT = 32;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    bool graphs = h->loop_graphs && !comm && !ubc && !a.si && p->periodic == 0 && (i64)(nx + 1) * (ny + 1) <= 300000;
     while (iter <= p->iterMax) {
         if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;          // Stokes2D.jl:650-651
+        if (graphs && iter >= 1 && !((err / err_it1) < p->eps_rel || err < p->eps_abs)) {
+            // observed iterations (checks: multiples of nout; the last one: iterMax + 1) end a run; err does not change inside one
+            int64_t nxt = ((iter / p->nout) + 1) * p->nout;
+            if (nxt > p->iterMax + 1) nxt = p->iterMax + 1;
+            int64_t run = nxt - 1 - iter;
+            if (run >= GIT) {
+                const int par = a.f.txx == f->txx ? 0 : 1;
+                if (!gexec[par]) {
+                    hipGraph_t gr = nullptr;
+                    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        VepArgs aa = a;
+                        Args2 bb = b;
+                        for (int q = 0; q < GIT; q++) {
+                            if (upd_rho) hipLaunchKernelGGL((k_vep_pre<true, true>), dim3(gv), dim3(256), 0, s, aa, theta);
+                            else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, aa, theta);
+                            if (aa.soft) hipLaunchKernelGGL(k_vep_stress2d<true>, dim3(gv), dim3(256), 0, s, aa);
+                            else hipLaunchKernelGGL(k_vep_stress2d<false>, dim3(gv), dim3(256), 0, s, aa);
+                            { double *t_ = aa.f.txx; aa.f.txx = aa.txx_out; aa.txx_out = t_; }
+                            { double *t_ = aa.f.tyy; aa.f.tyy = aa.tyy_out; aa.tyy_out = t_; }
+                            bb.f.txx = aa.f.txx; bb.f.tyy = aa.f.tyy;
+                            hipLaunchKernelGGL(k_vep_visc_velocity<true>, dim3(gv), dim3(256), 0, s, aa, bb);
+                        }
+                        ok = hipStreamEndCapture(s, &gr) == hipSuccess && gr != nullptr;
+                    }
+                    if (ok) ok = hipGraphInstantiate(&gexec[par], gr, nullptr, nullptr, 0) == hipSuccess;
+                    if (gr) (void)hipGraphDestroy(gr);
+                    if (!ok) { (void)hipGetLastError(); gexec[par] = nullptr; graphs = false; }
+                }
+                if (gexec[par]) {
+                    while (run >= GIT) {
+                        JRX_HIP(h, hipGraphLaunch(gexec[par], s));
+                        iter += GIT; run -= GIT;
+                    }
+                    continue;
+                }
+            }
+        }
         if (comm) {
             hipLaunchKernelGGL(k_maxloc, dim3(gc, 1), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, 1);
             JRX_LAUNCH_CHECK(h);
@@ -1469,6 +1513,8 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                        (long long)iter, err, err / err_it1, nRx, nRy, nDV);
             if (std::isnan(err)) {
                 // error("NaN(s)"): leave the caller's arrays consistent (the current τxx, τyy may live in the second set) and the stream drained
+                for (int q = 0; q < 2; q++)
+                    if (gexec[q]) (void)hipGraphExecDestroy(gexec[q]);
                 if (a.f.txx != f->txx) {
                     (void)hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s);
                     (void)hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s);
@@ -1483,6 +1529,8 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             }
         }
     }
+    for (int q = 0; q < 2; q++)
+        if (gexec[q]) (void)hipGraphExecDestroy(gexec[q]);
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     if (a.f.txx != f->txx) {      // odd number of swaps: leave τxx, τyy in the caller's arrays
         JRX_HIP(h, hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s));

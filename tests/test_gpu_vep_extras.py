@@ -309,3 +309,38 @@ def test_sinking_block_reference_test_on_the_device(jr, oracle):
     out = _download(jr, st)
     for k in ("P", "Vx", "Vy", "txx", "tyy", "txy", "exx", "exy", "tII", "eta_vep"):
         assert max_rel_diff(out[k], ref[k]) <= 1e-6, k
+
+
+@pytest.mark.parametrize("rho", [False, True])
+def test_vep2d_graph_replay_changes_nothing(jr, rho):
+    """option loop_graphs: runs of unobserved iterations of the 2D visco-elasto-plastic loop replay as captured hipGraphs of 32 iterations (three launches each,
+    the (τxx, τyy) sets ping-pong inside); every field, the iteration count and the error history equal those of plain launches -- yielding state, with and without
+    the in-loop density update"""
+    import ctypes as C
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.arrays import from_numpy
+    from test_gpu_vep2d import _download, _upload
+    h = _lib.default_handle(0)
+    outs = []
+    try:
+        for g in (0, 1):
+            h.call("jrx_set_option", C.c_char_p(b"loop_graphs"), C.c_int64(g))
+            s = jr.miniapps.shearband2d(48, iterMax=299, nout=150)
+            s.kwargs.update(iterMin=10)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+            rng = np.random.default_rng(8)
+            for c in ("xx", "yy", "xy", "xy_c"):
+                s.arrays["to" + c][...] = rng.uniform(-1.2, 1.2, size=s.arrays["to" + c].shape)
+                s.arrays["t" + c][...] = s.arrays["to" + c]
+            phases = _phases_rho(s.extra["phases"], g=0.3) if rho else s.extra["phases"]
+            st, pr, ρg = _upload(jr, s)
+            args = dict(T=from_numpy(np.asfortranarray(rng.uniform(0.0, 2.0, size=s.ni)), st.P.device), P=st.P) if rho else None
+            r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, phases, args, s.dt, None, kwargs=s.kwargs)
+            outs.append((r.iter, list(r.err_evo1), _download(jr, st), jr.to_numpy(ρg[1])))
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"loop_graphs"), C.c_int64(1))
+    a, b = outs
+    assert a[0] == b[0] == 300 and a[1] == b[1]
+    for k in a[2]:
+        assert np.array_equal(a[2][k], b[2][k], equal_nan=True), k
+    assert np.array_equal(a[3], b[3]) and (a[2]["eplxx"] != 0).any()
