@@ -1384,7 +1384,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     // started.  Only in the plain steady state: one rank, no periodic face, velocity boundary conditions, strain-rate form.  Option "loop_graphs" = 0: plain launches.
     constexpr int GIT = 32;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
-    bool graphs = h->loop_graphs && !comm && !ubc && !a.si && p->periodic == 0 && (i64)(nx + 1) * (ny + 1) <= 300000;
+    bool graphs = h->loop_graphs && !comm && !ubc && !a.si && p->periodic == 0 && (i64)(nx + 1) * (ny + 1) <= 200000;
     while (iter <= p->iterMax) {
         if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;          // Stokes2D.jl:650-651
         if (graphs && iter >= 1 && !((err / err_it1) < p->eps_rel || err < p->eps_abs)) {

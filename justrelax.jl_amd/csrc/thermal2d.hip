@@ -486,6 +486,8 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
     constexpr int GIT = 32;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     bool graphs = fusable && h->loop_graphs;
+    // the forms that keep the two kernels (phase ratios, adiabatic term, Dirichlet cells) replay compute_flux! + update_T! pairs the same way, in place
+    bool graphs2 = !fusable && h->loop_graphs && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2 && n <= 200000;
     auto destroy_graphs = [&]() { for (int q = 0; q < 2; q++) if (gexec[q]) { (void)hipGraphExecDestroy(gexec[q]); gexec[q] = nullptr; } };
     while (err > p->eps && iter < p->iterMax) {
         if (graphs) {
@@ -515,6 +517,35 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
                         JRX_HIP(h, hipGraphLaunch(gexec[par], s));
                         iter += GIT; run -= GIT;
                         h->stat_thermal_fused += GIT;
+                    }
+                    continue;
+                }
+            }
+        }
+        if (graphs2 && (!PH || pt_fresh)) {
+            const int64_t nxt = std::min<int64_t>(((iter / p->nout) + 1) * p->nout, p->iterMax);
+            int64_t run = nxt - 1 - iter;
+            if (run >= GIT) {
+                if (!gexec[0]) {
+                    hipGraph_t g = nullptr;
+                    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        TArgs aa = a;
+                        aa.t.T = cur.T; aa.t.qTx = cur.qx; aa.t.qTy = cur.qy; aa.wpt = PH;
+                        for (int q = 0; q < GIT; q++) {
+                            hipLaunchKernelGGL(k_flux2d<PHT>, dim3((unsigned)(((i64)(nx + 1) * (ny + 1) + 255) / 256)), dim3(256), 0, s, aa, ph);
+                            hipLaunchKernelGGL((k_updateT2d<false, true, PHT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, aa, ph);
+                        }
+                        ok = hipStreamEndCapture(s, &g) == hipSuccess && g != nullptr;
+                    }
+                    if (ok) ok = hipGraphInstantiate(&gexec[0], g, nullptr, nullptr, 0) == hipSuccess;
+                    if (g) (void)hipGraphDestroy(g);
+                    if (!ok) { (void)hipGetLastError(); gexec[0] = nullptr; graphs2 = false; }
+                }
+                if (gexec[0]) {
+                    while (run >= GIT) {
+                        JRX_HIP(h, hipGraphLaunch(gexec[0], s));
+                        iter += GIT; run -= GIT;
                     }
                     continue;
                 }

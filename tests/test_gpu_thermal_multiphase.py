@@ -259,3 +259,34 @@ def test_round2_entry_points_refuse_bad_arguments(jr):
             jr.heatdiffusion_PT_(thermal, pt, pass_bc, s.extra["rheology"], args, s.dt, s.grid, kwargs=dict(phase=pr, verbose=False))
         except ValueError as e:
             raise _lib.JrxError(1, str(e))
+
+
+@pytest.mark.parametrize("form", ["phases", "adiabatic"])
+def test_graph_replay_of_the_two_kernel_2d_forms_changes_nothing(jr, form):
+    """option loop_graphs: the 2D forms that keep compute_flux! + update_T! as two launches (phase ratios; adiabatic term / Dirichlet cells) replay runs of unobserved
+    iterations as captured hipGraphs; T, the fluxes, the PT coefficients and the residual history equal those of plain launches"""
+    import ctypes as C
+    from justrelax_jl_amd import _lib
+    h = _lib.default_handle(0)
+    outs = []
+    try:
+        for g in (0, 1):
+            h.call("jrx_set_option", C.c_char_p(b"loop_graphs"), C.c_int64(g))
+            s = jr.miniapps.diffusion2d_multiphase((48, 40), iterMax=300, nout=150)
+            _randomise(s, 9)
+            thermal, pt, pr, args = _device_setup(jr, s, eps=1e-30)
+            kw = dict(phase=pr, iterMax=300, nout=150, verbose=False)
+            if form == "adiabatic":       # kwargs.stokes: adiabatic_heating! feeds update_T!
+                stokes = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+                stokes.P.copy_(args.P)
+                stokes.P0.copy_(args.P * 0.9)
+                kw["stokes"] = stokes
+            r = jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, s.extra["rheology"], args, s.dt, s.grid, kwargs=kw)
+            outs.append((list(r.iter_count), list(r.norm_ResT), jr.to_numpy(thermal.T), jr.to_numpy(thermal.qTx), jr.to_numpy(thermal.qTy2), jr.to_numpy(pt.θr_dτ),
+                         jr.to_numpy(pt.dτ_ρ)))
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"loop_graphs"), C.c_int64(1))
+    a, b = outs
+    assert a[0] == b[0] == [150, 300] and a[1] == b[1]
+    for x, y in zip(a[2:], b[2:]):
+        assert np.array_equal(x, y)
