@@ -83,7 +83,7 @@ const char *jrx_build_id(void);
  *   more than 4 phases).  Same results.  "vep3_cfg" = KZ * 10 + min blocks per CU (tuning).  "vep3_peel" (default 1): a last lane segment of the z-marching
  *   launch that would be less than 40 % full goes to the node kernel in a thin launch of its own (0 = launch it anyway; same results).
  * "loop_graphs" (0/1, default 1): runs of unobserved iterations of the launch-bound 2D loops (2D heat diffusion, 2D visco-elastic Stokes on the grids that use
- *   k_fused2d, 2D visco-elasto-plastic Stokes and the two-kernel forms of 2D heat diffusion below 200 k nodes) replay as captured hipGraphs of 32 iterations; same results, shorter gaps between launches.
+ *   k_fused2d, 2D visco-elasto-plastic Stokes and the two-kernel forms of 2D heat diffusion below 200 k nodes, the single-phase non-linear 2D driver) replay as captured hipGraphs of 32 iterations; same results, shorter gaps between launches.
  * "fused_ylds", "fused2d", "vep3_map", "vep3_xcd", "thermal_cfg", "thermal_xg", "b_width_x/y/z": kernel-form / tile-shape A/B
  *   switches used by the measurements in profiles/ (results never change); "halo_self_rccl" (0/1): test hook, a rank that is its
  *   own periodic neighbour routes its planes through ncclSend/ncclRecv on a one-rank communicator.

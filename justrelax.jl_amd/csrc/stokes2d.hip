@@ -1016,11 +1016,17 @@ __global__ __launch_bounds__(256) void k_tau_nonlinear2d(const VepArgs a, double
     theta_out[c] = P + (isinf(K) ? 0.0 : K * dt * l * sinpsi);
 }
 
-// center2vertex! 2D (Interpolations.jl:101-114): pass 0 inner vertices, pass 1 the x-edge rows, pass 2 the y-edge columns
+// center2vertex! 2D (Interpolations.jl:101-114): pass 0 inner vertices, pass 1 the x-edge rows, pass 2 the y-edge columns; pass 3 = the three at once: after
+// them every edge / corner vertex is a copy of the inner vertex its indices clamp to, so each thread evaluates that one
 __global__ __launch_bounds__(256) void k_center2vertex2d(double *__restrict__ v, const double *__restrict__ cc, int nx, int ny, int pass)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pass == 0) {
+    if (pass == 3) {
+        const int j = t / (nx + 1), i = t - j * (nx + 1);
+        if (j > ny) return;
+        const int ii = clampi(i, 1, nx - 1), jj = clampi(j, 1, ny - 1);
+        v[i + (i64)(nx + 1) * j] = 0.25 * (cc[(ii - 1) + (i64)nx * (jj - 1)] + cc[ii + (i64)nx * (jj - 1)] + cc[(ii - 1) + (i64)nx * jj] + cc[ii + (i64)nx * jj]);
+    } else if (pass == 0) {
         const int j = t / (nx + 1), i = t - j * (nx + 1);
         if (j > ny || i < 1 || i >= nx || j < 1 || j >= ny) return;
         v[i + (i64)(nx + 1) * j] = 0.25 * (cc[(i - 1) + (i64)nx * (j - 1)] + cc[i + (i64)nx * (j - 1)] + cc[(i - 1) + (i64)nx * j] + cc[i + (i64)nx * j]);
@@ -1614,7 +1620,51 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
     res->iter = 0; res->nchecks = 0;
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
     auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
+    // Runs of unobserved iterations (ten short launches each as the reference orders them, every argument constant: the loop is launch-bound at any 2D size,
+    // 38 us per iteration) replay as a captured graph of GIT iterations of six launches (center2vertex! in one pass, flow_bcs! folded into compute_V!); one rank,
+    // velocity boundary conditions.  Option "loop_graphs" = 0: plain launches.
+    constexpr int GIT = 16;
+    hipGraphExec_t gexec = nullptr;
+    bool graphs = h->loop_graphs && !comm && !ubc;
+    auto unobserved_iteration = [&]() {
+        hipLaunchKernelGGL(k_vep_pre<false>, dim3(gv), dim3(256), 0, s, a, f->P);
+        hipLaunchKernelGGL(k_single_material, dim3(gc), dim3(256), 0, s, a, p->viscosity_relaxation, upd_rho, true, tg);
+        hipLaunchKernelGGL(k_maxloc, dim3(gc, 1), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, 1);
+        hipLaunchKernelGGL(k_tau_nonlinear2d<false>, dim3(gc), dim3(256), 0, s, a, theta);
+        hipLaunchKernelGGL(k_center2vertex2d, dim3(gv), dim3(256), 0, s, f->txy, (const double *)f->txy_c, nx, ny, 3);        // the three passes of center2vertex! in one
+        if (p->periodic == 0) {      // flow_bcs! has been applied in full by now (iter >= 2): the velocity kernel refreshes the ghosts next to what it updates
+            hipLaunchKernelGGL((k_velocity2d<false, true>), dim3(gc), dim3(256), 0, s, b);
+            return JRX_OK;
+        }
+        hipLaunchKernelGGL(k_velocity2d<false>, dim3(gc), dim3(256), 0, s, b);
+        return launch_bcs2(h, s, f->Vx, f->Vy, nx, ny, p->free_slip, p->no_slip, p->periodic);
+    };
     while (keep_going(iter)) {
+        if (graphs && iter >= 2) {
+            int64_t nxt = ((iter / p->nout) + 1) * p->nout;        // observed: the multiples of nout and iteration iterMax + 1
+            if (nxt > p->iterMax + 1) nxt = p->iterMax + 1;
+            int64_t run = nxt - 1 - iter;
+            if (run >= GIT) {
+                if (!gexec) {
+                    hipGraph_t gr = nullptr;
+                    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                    if (ok) {
+                        for (int q = 0; q < GIT && ok; q++) ok = unobserved_iteration() == JRX_OK;
+                        ok = (hipStreamEndCapture(s, &gr) == hipSuccess && gr != nullptr) && ok;
+                    }
+                    if (ok) ok = hipGraphInstantiate(&gexec, gr, nullptr, nullptr, 0) == hipSuccess;
+                    if (gr) (void)hipGraphDestroy(gr);
+                    if (!ok) { (void)hipGetLastError(); gexec = nullptr; graphs = false; }
+                }
+                if (gexec) {
+                    while (run >= GIT) {
+                        JRX_HIP(h, hipGraphLaunch(gexec, s));
+                        iter += GIT; run -= GIT;
+                    }
+                    continue;
+                }
+            }
+        }
         const int64_t it1 = iter + 1;
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);      // U is only observable after such an iteration
@@ -1684,6 +1734,7 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
             }
         }
     }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_HIP(h, hipMemcpyAsync(f->P, theta, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // stokes.P .= θ :523
     a.txx_out = a.tyy_out = nullptr;

@@ -344,3 +344,35 @@ def test_vep2d_graph_replay_changes_nothing(jr, rho):
     for k in a[2]:
         assert np.array_equal(a[2][k], b[2][k], equal_nan=True), k
     assert np.array_equal(a[3], b[3]) and (a[2]["eplxx"] != 0).any()
+
+
+def test_single_phase_driver_graph_replay_changes_nothing(jr):
+    """option loop_graphs in the single-phase non-linear driver: the replayed iteration (center2vertex! in one pass, flow_bcs! folded into compute_V!, 16
+    iterations per graph) leaves every array, ghost entries included, and the error history as the plain launches do"""
+    import ctypes as C
+    import torch
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.arrays import from_numpy
+    from test_gpu_vep2d import VEP_MAP, _get
+    h = _lib.default_handle(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    outs = []
+    try:
+        for g in (0, 1):
+            h.call("jrx_set_option", C.c_char_p(b"loop_graphs"), C.c_int64(g))
+            s = jr.miniapps.thermal_convection2d(40, ar=1, iterMax=299, nout=100)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+            ph = dict(s.extra["rheology"], C=8.0e6, phi_deg=0.0, psi_deg=0.0, eta_vp=1.0e16)
+            st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+            for k, path in VEP_MAP.items():
+                _get(st, path).copy_(from_numpy(s.arrays[k], dev))
+            ρg = (from_numpy(s.arrays["fx"], dev), from_numpy(s.arrays["fy"], dev))
+            r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, ph, dict(T=from_numpy(s.arrays["T"], dev), P=st.P), s.dt, None, kwargs=s.kwargs)
+            outs.append((r.iter, list(r.err_evo1), {k: jr.to_numpy(_get(st, path)) for k, path in VEP_MAP.items()}, jr.to_numpy(ρg[1])))
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"loop_graphs"), C.c_int64(1))
+    a, b = outs
+    assert a[0] == b[0] == 300 and a[1] == b[1]
+    for k in a[2]:
+        assert np.array_equal(a[2][k], b[2][k], equal_nan=True), k
+    assert np.array_equal(a[3], b[3])
