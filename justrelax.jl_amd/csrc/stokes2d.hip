@@ -1330,9 +1330,7 @@ jrx_status jrx_center2vertex2d(jrx_handle *h, double *vertex, const double *cent
     if (!h) return JRX_ERR_ARG;
     if (!vertex || !center || nx < 2 || ny < 2) return jrx_fail(h, JRX_ERR_ARG, "center2vertex!: bad argument");
     const i64 nv = (nx + 1) * (ny + 1);
-    hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, h->stream, vertex, center, (int)nx, (int)ny, 0);
-    hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((ny + 1 + 255) / 256)), dim3(256), 0, h->stream, vertex, center, (int)nx, (int)ny, 1);
-    hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((nx + 1 + 255) / 256)), dim3(256), 0, h->stream, vertex, center, (int)nx, (int)ny, 2);
+    hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, h->stream, vertex, center, (int)nx, (int)ny, 3);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
@@ -1678,9 +1676,7 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
             JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
         }
         hipLaunchKernelGGL(k_tau_nonlinear2d<false>, dim3(gc), dim3(256), 0, s, a, theta);           // compute_τ_nonlinear! :440-458
-        hipLaunchKernelGGL(k_center2vertex2d, dim3(gv), dim3(256), 0, s, f->txy, (const double *)f->txy_c, nx, ny, 0);   // center2vertex! :459
-        hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((ny + 1 + 255) / 256)), dim3(256), 0, s, f->txy, (const double *)f->txy_c, nx, ny, 1);
-        hipLaunchKernelGGL(k_center2vertex2d, dim3((unsigned)((nx + 1 + 255) / 256)), dim3(256), 0, s, f->txy, (const double *)f->txy_c, nx, ny, 2);
+        hipLaunchKernelGGL(k_center2vertex2d, dim3(gv), dim3(256), 0, s, f->txy, (const double *)f->txy_c, nx, ny, 3);   // center2vertex! :459, its three passes in one
         JRX_LAUNCH_CHECK(h);
         if (comm) {   // update_halo!(stokes.τ.xy) :460
             double *arrs[1] = {f->txy};
