@@ -28,6 +28,7 @@ struct Vep3Args {
     double _dx, _dy, _dz, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
     int nx, ny, nz;
     bool soft;            // some phase has a softening law: the yield function then reads EII_pl
+    bool tg;              // args.T is the ghosted thermal.T (ni .+ 2): densities read it at the cell's own [i, j, k], unshifted
 };
 
 // node (i, j, k) of an (n1, n2, n3) box: xy flattened over blockIdx.x (no nearly empty blocks when n1 = nx + 1), k = blockIdx.y
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
             a.f.exx[c] = dxi - d3;
             a.f.eyy[c] = dyi - d3;
             a.f.ezz[c] = dzi - d3;
-            if (RHO) a.f.fz[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)a.rh.nphase * c, a.f.T ? a.f.T[c] : 0.0, a.f.P[c]) * a.rh.gravity;
+            if (RHO) a.f.fz[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)a.rh.nphase * c,
+                                                   !a.f.T ? 0.0 : (a.tg ? a.f.T[i + (i64)(nx + 2) * (j + (i64)(ny + 2) * k)] : a.f.T[c]), a.f.P[c]) * a.rh.gravity;
         }
         if (i < nx) EYZ(a.f.eyz, i, j, k) = 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k)));
         if (j < ny) EXZ(a.f.exz, i, j, k) = 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k)));
@@ -231,7 +233,11 @@ __global__ __launch_bounds__(256) void k_vep3_phase_avg(double *__restrict__ Kc,
     const double *r = a.f.phase_c + (i64)a.rh.nphase * c;
     Kc[c] = ratio_avg3(a.rh.Kb, r, a.rh.nphase);
     Gc[c] = ratio_avg3(a.rh.G, r, a.rh.nphase);
-    if (rho) a.f.fz[c] = mat_density_ratio(a.rh, r, a.f.T ? a.f.T[c] : 0.0, a.f.P[c]) * a.rh.gravity;
+    if (rho) {
+        const int k = (int)(c / ((i64)a.nx * a.ny)), j = (int)((c - (i64)k * a.nx * a.ny) / a.nx), i = (int)(c - (i64)k * a.nx * a.ny - (i64)j * a.nx);
+        const double T = !a.f.T ? 0.0 : (a.tg ? a.f.T[i + (i64)(a.nx + 2) * (j + (i64)(a.ny + 2) * k)] : a.f.T[c]);
+        a.f.fz[c] = mat_density_ratio(a.rh, r, T, a.f.P[c]) * a.rh.gravity;
+    }
 }
 
 // Stencil tables of StressKernels.jl:604-668 for the edge families T = 0 (yz), 1 (xz), 2 (xy): entries pick the
@@ -770,6 +776,7 @@ Vep3Args make_vep3(const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_
     a.nu = p->viscosity_relaxation; a.cut_lo = p->cutoff_lo; a.cut_hi = p->cutoff_hi;
     a.nx = (int)p->nx; a.ny = (int)p->ny; a.nz = (int)p->nz;
     a.soft = mat_has_softening(rh);
+    a.tg = p->T_ghosted != 0;
     return a;
 }
 

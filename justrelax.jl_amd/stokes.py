@@ -363,6 +363,11 @@ def _solve_vep3d(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology,
     """solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs) in 3D -- Stokes3D.jl:447-668"""
     p = vep_params3d(stokes, pt_stokes, grid, flow_bcs, dt, **kw)
     f = vep_fields3d(stokes, ρg, phase_ratios, args)
+    T = _args_T(args)
+    if T is not None and tuple(T.shape) != tuple(stokes._ni):      # args.T = thermal.T (ghosted), as the miniapps pass it: update_ρg! reads it at [i, j, k]
+        if tuple(T.shape) != tuple(n + 2 for n in stokes._ni):
+            raise ValueError(f"args.T must be ni {tuple(stokes._ni)} or ni .+ 2 (thermal.T), got {tuple(T.shape)}")
+        p.T_ghosted = 1
     rh = rheology_table(rheology)
     hist = _Hist(int(p.iterMax // p.nout + 2))
     torch.cuda.current_stream(stokes.P.device).synchronize()

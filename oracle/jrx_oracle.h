@@ -330,6 +330,7 @@ typedef struct orc_vep_params3d {
     uint32_t free_slip, no_slip, periodic;
     double lambda_relaxation, viscosity_relaxation, cutoff_lo, cutoff_hi;
     int32_t displacement_bcs;
+    int32_t T_ghosted;           /* args.T is thermal.T (ni .+ 2), read by the density at the cell's own [i, j, k] (BuoyancyForces.jl:52) */
 } orc_vep_params3d;
 
 int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, orc_result *res);

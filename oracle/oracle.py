@@ -544,7 +544,7 @@ class VEPParams3D(C.Structure):
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
-                ("displacement_bcs", C.c_int32)]
+                ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32)]
 
 
 def vep_shapes3d(nx, ny, nz, nphase):
@@ -561,11 +561,11 @@ def vep_shapes3d(nx, ny, nz, nphase):
 
 
 def vep_params3d(ni, _di, dt, pt, *, iterMax=10_000, nout=500, free_slip=None, no_slip=None, periodic=None,
-                 lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), ni_g=None, displacement_bcs=False) -> VEPParams3D:
+                 lambda_relaxation=0.2, viscosity_relaxation=1e-2, cutoff=(-np.inf, np.inf), ni_g=None, displacement_bcs=False, T_ghosted=False) -> VEPParams3D:
     ni_g = ni_g or ni
     return VEPParams3D(ni[0], ni[1], ni[2], ni_g[0], ni_g[1], ni_g[2], _di[0], _di[1], _di[2], dt, pt["r"], pt["theta_dtau"], pt["eta_dtau"],
                        pt["eps_rel"], pt["eps_abs"], int(iterMax), int(nout), bcmask(free_slip), bcmask(no_slip), bcmask(periodic),
-                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1], int(bool(displacement_bcs)))
+                       lambda_relaxation, viscosity_relaxation, cutoff[0], cutoff[1], int(bool(displacement_bcs)), int(bool(T_ghosted)))
 
 
 def vep3d(arr: dict) -> VEP3D:

@@ -307,6 +307,16 @@ void orc_tensor_invariant3d(double *II, const double *xx, const double *yy, cons
             for (int64_t i = 0; i < nx; i++) II[IDX3(nx, ny, i, j, k)] = sinv_stag3(xx, yy, zz, yz, xz, xy, nx, ny, i, j, k);
 }
 
+/* args.T at cell c for the density laws: cell-centred (ni), or -- T_ghosted -- thermal.T (ni .+ 2) read at the cell's own [i, j, k] without a shift, as
+ * getindex_NamedTuple(args, I...) does in compute_ρg! (BuoyancyForces.jl:52; miniapps/convection/RisingBlob3D/Blob3D.jl:355-356 passes thermal.T) */
+static inline double T_of(const orc_vep3d *f, const orc_vep_params3d *p, size_t c)
+{
+    if (!f->T) return 0.0;
+    if (!p->T_ghosted) return f->T[c];
+    const size_t nx = (size_t)p->nx, ny = (size_t)p->ny, k = c / (nx * ny), j = (c - k * nx * ny) / nx, i = c - k * nx * ny - j * nx;
+    return f->T[IDX3(nx + 2, ny + 2, i, j, k)];
+}
+
 /* shear2center_kernel! 3D (Interpolations.jl:314-323) */
 void orc_shear2center3d(double *yz_c, double *xz_c, double *xy_c, const double *yz, const double *xz, const double *xy, int64_t nx, int64_t ny, int64_t nz)
 {
@@ -356,7 +366,7 @@ int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const
     /* compute_ρg!(ρg, phase_ratios, rheology, args) :505 -- the scalar gravity fills the last component (BuoyancyForces.jl:69-70) */
     const int upd_rho = rh->has_density && !mat_density_is_constant(rh);
     if (rh->has_density)
-        for (size_t c = 0; c < n; c++) f->fz[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
+        for (size_t c = 0; c < n; c++) f->fz[c] = mat_density_ratio(rh, f->phase_c + np * c, T_of(f, p, c), f->P[c]) * rh->gravity;
     orc_compute_viscosity3d(f, rh, p, 1.0);           /* compute_viscosity!(stokes, phase_ratios, args, rheology, cutoff) :507 */
     if (p->displacement_bcs) {                        /* displacement2velocity!(stokes, dt, flow_bcs) :509 */
         const double _dt = inv(p->dt);
@@ -387,7 +397,7 @@ int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const
         orc_compute_P3d(theta, f->P0, f->RP, f->divV, f->Q, etatau, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* :520-533 */
         orc_compute_strain_rate3d(&g, &q);
         if (upd_rho)                                  /* update_ρg!(ρg, phase_ratios, rheology, args) :538 ; args.P is stokes.P */
-            for (size_t c = 0; c < n; c++) f->fz[c] = mat_density_ratio(rh, f->phase_c + np * c, f->T ? f->T[c] : 0.0, f->P[c]) * rh->gravity;
+            for (size_t c = 0; c < n; c++) f->fz[c] = mat_density_ratio(rh, f->phase_c + np * c, T_of(f, p, c), f->P[c]) * rh->gravity;
         orc_compute_viscosity3d(f, rh, p, p->viscosity_relaxation);
         orc_vep3d_stress(f, theta, lam, lamv, rh, p);
         {   /* update_halo!(τ.yz), (τ.xz), (τ.xy) :578-580 */

@@ -130,14 +130,16 @@ def test_vep2d_displacement_bcs_and_free_surface_match_oracle(jr, oracle, free_s
         assert max_rel_diff(out[k], ref[k]) <= 1e-9, k
 
 
-def test_vep3d_density_softening_displacement_match_oracle(jr, oracle):
+@pytest.mark.parametrize("ghosted", [False, True])
+def test_vep3d_density_softening_displacement_match_oracle(jr, oracle, ghosted):
     from justrelax_jl_amd.arrays import DisplacementBoundaryConditions, from_numpy
     from justrelax_jl_amd.checks import max_rel_diff
     from test_gpu_vep3d import _download, _params, _upload
     s = jr.miniapps.shearband3d((14, 10, 9), iterMax=24, nout=8)
     s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
     rng = np.random.default_rng(8)
-    s.arrays["T"] = np.asfortranarray(rng.uniform(0.0, 2.0, size=s.ni))
+    # args.T: cell-centred, or -- ghosted -- thermal.T (ni .+ 2) as the 3D miniapps pass it (RisingBlob3D/Blob3D.jl:355), read by update_ρg! at the cell's own index
+    s.arrays["T"] = np.asfortranarray(rng.uniform(0.0, 2.0, size=tuple(n + 2 for n in s.ni) if ghosted else s.ni))
     s.arrays["EII_pl"][...] = rng.uniform(0.0, 0.4, size=s.ni)
     for k, v in (("Ux", "Vx"), ("Uy", "Vy"), ("Uz", "Vz")):
         s.arrays[k][...] = s.arrays[v] * s.dt
@@ -146,7 +148,7 @@ def test_vep3d_density_softening_displacement_match_oracle(jr, oracle):
     b = s.flow_bcs
     dbc = DisplacementBoundaryConditions(free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic)
     ref = _cp(s.arrays)
-    r_ref = oracle.stokes3d_vep_solve(ref, oracle.rheology_struct(phases), _params(oracle, s, displacement_bcs=True))
+    r_ref = oracle.stokes3d_vep_solve(ref, oracle.rheology_struct(phases), _params(oracle, s, displacement_bcs=True, T_ghosted=ghosted))
     stokes, pr, ρg = _upload(jr, s)
     T = from_numpy(s.arrays["T"], stokes.P.device)
     r = jr.solve_(stokes, s.pt, s.grid, dbc, ρg, pr, phases, dict(T=T), s.dt, None, kwargs=s.kwargs)
