@@ -81,7 +81,7 @@ def test_the_extension_covers_the_reference_method_table():
     # the generics the reference's AMDGPU extension adds methods to (src/ext/AMDGPU/2D.jl:48-403, 3D.jl:46-412, ext/JustRelaxAMDGPUExt.jl:5-10)
     for pat in (r"PTArray\(::Type\{AMDGPUBackend\}\)\s*=\s*ROCArray", r"backend\(::ROCArray\)\s*=\s*AMDGPUBackendTrait\(\)",
                 r"JR2D\.StokesArrays\(::Type\{AMDGPUBackend\}", r"JR3D\.StokesArrays\(::Type\{AMDGPUBackend\}", r"JR2D\.ThermalArrays\(::Type\{AMDGPUBackend\}",
-                r"JR3D\.ThermalArrays\(::Type\{AMDGPUBackend\}", r"JR2D\.PTThermalCoeffs\(::Type\{AMDGPUBackend\}", r"JR3D\.PTThermalCoeffs\(::Type\{AMDGPUBackend\}",
+                r"JR3D\.ThermalArrays\(::Type\{AMDGPUBackend\}", r"JR2D\.PTThermalCoeffs\(::Type\{AMDGPUBackend\}", r"JR3D\.PTThermalCoeffs\(::Type\{AMDGPUBackend\}", r"\$JR\.PTThermalCoeffs\(::Type\{AMDGPUBackend\}, rheology, phase_ratios",
                 r"JR2D\.heatdiffusion_PT!\(::Trait", r"JR3D\.heatdiffusion_PT!\(::Trait", r"JR2D\.thermal_bcs!\(::Trait", r"JR3D\.thermal_bcs!\(::Trait",
                 r"JR2D\.center2vertex!", r"JR3D\.center2vertex!", r"JR2D\.velocity2vertex!", r"JR3D\.velocity2vertex!", r"JR2D\.velocity2center!",
                 r"JR3D\.velocity2center!", r"JR2D\.vertex2center!", r"JR3D\.vertex2center!", r"\$JR\.compute_ρg!", r"\$JR\.compute_shear_heating!\(::Trait", r"\$JR\.compute_viscosity!\(::Trait"):
