@@ -268,9 +268,17 @@ typedef struct jrx_rheology {
     double softphi_a[JRX_MAXPHASE], softphi_b[JRX_MAXPHASE], softphi_c[JRX_MAXPHASE], softphi_d[JRX_MAXPHASE], phi_deg[JRX_MAXPHASE];
     /* Creep law of the viscous element for compute_viscosity! / compute_viscosity_τII! with dt = Inf (rheology/Viscosity.jl:142-167):
      * visc_kind 0 LinearViscous(eta); 1 Arrhenius: eta exp((Ea + P Va)/(Rgas T) - Ea/(Rgas Tref)), clamped to [visc_lo, visc_hi]
-     * (the CustomRheology of test/test_WENO5.jl:37-42 with depth = 0) */
+     * (the CustomRheology of test/test_WENO5.jl:37-42 with depth = 0);
+     * 2 power-law creep (GeoParams DislocationCreep with r = 0; DiffusionCreep is n = 1 with the grain-size factor folded into A):
+     *   compute_εII: ε = creep_A (τII creep_FT)^creep_n exp(-(Ea + P Va)/(Rgas T)) / creep_FE
+     *   compute_τII: τ = creep_A^(-1/n) (εII creep_FE)^(1/n) exp((Ea + P Va)/(n Rgas T)) / creep_FT
+     *   compute_viscosity_τII = τII / (2 ε(τII)),  compute_viscosity_εII = τ(εII) / (2 εII)      [forms ASSUMED, parity unpinned]
+     * FT, FE: GeoParams' apparatus corrections (AxialCompression √3, 2/√3; SimpleShear 2, 2; Invariant 1, 1).  One creep element per phase.
+     * The invariant a law of kind 2 is evaluated at is the one the reference's kernels form (Viscosity.jl:382-418,455-503): compute_viscosity! from the strain
+     * rate, update_viscosity_τII! from the stress, eps() on the normal components of an all-zero tensor. */
     int32_t visc_kind[JRX_MAXPHASE];
     double Ea[JRX_MAXPHASE], Va[JRX_MAXPHASE], Tref[JRX_MAXPHASE], Rgas[JRX_MAXPHASE], visc_lo[JRX_MAXPHASE], visc_hi[JRX_MAXPHASE];
+    double creep_A[JRX_MAXPHASE], creep_n[JRX_MAXPHASE], creep_FT[JRX_MAXPHASE], creep_FE[JRX_MAXPHASE];      /* visc_kind 2 */
 } jrx_rheology;
 
 typedef struct jrx_vep2d_fields {
@@ -330,8 +338,12 @@ jrx_status jrx_compute_tau_nonlinear2d(jrx_handle *h, const jrx_vep2d_fields *f,
 jrx_status jrx_center2vertex2d(jrx_handle *h, double *vertex, const double *center, int64_t nx, int64_t ny);
 /* tensor_invariant!(A): II = second_invariant_staggered(xx, yy, gather(xy)) -- StressKernels.jl:443-470 */
 jrx_status jrx_tensor_invariant2d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny);
-/* compute_viscosity!/update_viscosity_τII! for the table rheology: η <- ν·η_phase + (1-ν)·η, clamped to the cutoff */
+/* compute_viscosity! (fn_viscosity = compute_viscosity_εII) for the table rheology: η <- ν·η_phase + (1-ν)·η, clamped to the cutoff; creep laws that read
+ * fields take T (f->T with p->T_ghosted as in the solve), P = f->P and the invariant of @strain_center as the reference's kernel does (Viscosity.jl:382-418) */
 jrx_status jrx_vep2d_compute_viscosity(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p, double nu);
+/* the same with fn_viscosity = compute_viscosity_τII (update_viscosity_τII!, Viscosity.jl:67-106): a power-law creep is evaluated at the invariant of
+ * @stress_center (vertices: τ.xy alone, the PT solvers leave τ.xx_v, τ.yy_v zero) instead of the strain rate's; identical for the other creep laws */
+jrx_status jrx_vep2d_compute_viscosity_tauII(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p, double nu);
 
 /* ------------------------------------------------------------------ 3D multiphase visco-elasto-plastic Stokes
  * solve!(stokes, pt_stokes, grid, flow_bcs, ρg, phase_ratios, rheology, args, dt, igg; kwargs) for 3D grids --
@@ -378,8 +390,10 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
  * Every update reads the stresses of the previous call (the reference's single launch races on neighbouring values). */
 jrx_status jrx_vep3d_update_stresses(jrx_handle *h, const jrx_vep3d_fields *f, const double *theta, double *lambda, double *const lambda_v[3],
                                      const jrx_rheology *rh, const jrx_vep3d_params *p);
-/* compute_viscosity!/update_viscosity_τII! 3D for the table rheology: η <- ν·η_phase + (1-ν)·η, clamped to the cutoff */
+/* compute_viscosity! 3D (εII form; ..._tauII: update_viscosity_τII!) for the table rheology: η <- ν·η_phase + (1-ν)·η, clamped to the cutoff; creep laws that
+ * read fields: T, P at the cell, invariant of @strain / @stress with the edge components gathered (Viscosity.jl:455-503) */
 jrx_status jrx_vep3d_compute_viscosity(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p, double nu);
+jrx_status jrx_vep3d_compute_viscosity_tauII(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p, double nu);
 /* tensor_invariant!(A) 3D -- StressKernels.jl:472-487 */
 jrx_status jrx_tensor_invariant3d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *zz, const double *yz,
                                   const double *xz, const double *xy, int64_t nx, int64_t ny, int64_t nz);
@@ -566,7 +580,9 @@ jrx_status jrx_compute_lithostatic_pressure(jrx_handle *h, double *P, const doub
  * extents tdim: ni .+ 2 (the ghosted thermal.T, read at I .+ 1 as local_viscosity_args does, Viscosity.jl:513-523) or ni / NULL (cell centres); P: ni or NULL.
  * The phase-ratio form is jrx_vep{2d,3d}_compute_viscosity. */
 jrx_status jrx_compute_viscosity_single(jrx_handle *h, double *eta, const jrx_rheology *rh, const double *T, const double *P, const int64_t n[3],
-                                        const int64_t tdim[3], int32_t ndim, double nu, double cutoff_lo, double cutoff_hi);
+                                        const int64_t tdim[3], int32_t ndim, double nu, double cutoff_lo, double cutoff_hi, const double *AII, int32_t tau_form);
+/* AII (ni, or NULL): the invariant array of compute_viscosity_εII! / compute_viscosity_τII!(η, ν, AII, args, rheology, cutoff) (Viscosity.jl:169-196);
+ * tau_form: AII is a stress invariant.  A power-law creep (visc_kind 2) needs AII here; the 2D single-material driver forms it from @strain(stokes) itself. */
 /* compute_shear_heating!(thermal, stokes, [phase_ratios,] rheology, dt) -- thermal_diffusion/ShearHeating.jl:14-71:
  * shear_heating = max(0, Χ τ : (ε - ε_el)), ε_el = (τ - τ_o) / (2 G dt), at the cell centres.  tau, tau_o: @tensor_center(stokes.τ / τ_o) in Voigt order
  * (2D: xx, yy, xy_c; 3D: xx, yy, zz, yz_c, xz_c, xy_c), eps: @strain(stokes) (shear components on their edges, averaged to the centre as cache_tensors does).

@@ -109,7 +109,8 @@ class Rheology(C.Structure):
                [("softC_kind", C.c_int32 * MAXPHASE), ("softphi_kind", C.c_int32 * MAXPHASE)] + \
                [(k, C.c_double * MAXPHASE) for k in ("softC_a", "softC_b", "softC_c", "softC_d", "softphi_a", "softphi_b", "softphi_c",
                                                      "softphi_d", "phi_deg")] + \
-               [("visc_kind", C.c_int32 * MAXPHASE)] + [(k, C.c_double * MAXPHASE) for k in ("Ea", "Va", "Tref", "Rgas", "visc_lo", "visc_hi")]
+               [("visc_kind", C.c_int32 * MAXPHASE)] + [(k, C.c_double * MAXPHASE) for k in ("Ea", "Va", "Tref", "Rgas", "visc_lo", "visc_hi", "creep_A", "creep_n",
+                                                                                        "creep_FT", "creep_FE")]
 
 
 class VEP2DParams(C.Structure):

@@ -120,12 +120,13 @@ __global__ __launch_bounds__(256) void k_compute_rhog(double *__restrict__ rhog,
 // dependence, so the strain-rate operands drop out): η <- clamp(ν η_creep(T, P) + (1 - ν) η, cutoff).  args.T is read at I .+ 1 (local_viscosity_args,
 // Viscosity.jl:513-523: the ghosted thermal.T) when sh = 1, at the cell's own index otherwise; args.P at I
 __global__ __launch_bounds__(256) void k_viscosity_single(double *__restrict__ eta, const jrx_rheology rh, const double *__restrict__ T, const double *__restrict__ P,
-                                                          int nx, int ny, int t1, int t2, int sh, int shk, double nu, double lo, double hi)
+                                                          int nx, int ny, int t1, int t2, int sh, int shk, double nu, double lo, double hi,
+                                                          const double *__restrict__ AII, bool tau)
 {
     OUT_IJK(nx, ny)
     const i64 c = i + (i64)nx * (j + (i64)ny * k);
     const double t = T ? T[(i + sh) + (i64)t1 * ((j + sh) + (i64)t2 * (k + shk))] : 0.0, p = P ? P[c] : 0.0;
-    const double e = (1 - nu) * eta[c] + nu * mat_creep_viscosity(rh, 0, t, p);
+    const double e = (1 - nu) * eta[c] + nu * mat_viscosity(rh, 0, AII ? AII[c] : 0.0, t, p, tau);
     eta[c] = fmin(fmax(e, lo), hi);
 }
 
@@ -328,7 +329,7 @@ jrx_status jrx_compute_lithostatic_pressure(jrx_handle *h, double *P, const doub
 }
 
 jrx_status jrx_compute_viscosity_single(jrx_handle *h, double *eta, const jrx_rheology *rh, const double *T, const double *P, const int64_t n[3],
-                                        const int64_t tdim[3], int32_t ndim, double nu, double cutoff_lo, double cutoff_hi)
+                                        const int64_t tdim[3], int32_t ndim, double nu, double cutoff_lo, double cutoff_hi, const double *AII, int32_t tau_form)
 {
     if (!h) return JRX_ERR_ARG;
     JRX_TRY(jrx_check_device(h));
@@ -342,8 +343,10 @@ jrx_status jrx_compute_viscosity_single(jrx_handle *h, double *eta, const jrx_rh
         if (!same && !ghosted) return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: args.T must be ni (cell centres) or ni .+ 2 (thermal.T, read at I .+ 1)");
         t1 = (int)tdim[0]; t2 = (int)tdim[1]; sh = ghosted ? 1 : 0;
     }
+    if (rh->visc_kind[0] == 2 && !AII)
+        return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: a power-law creep needs the invariant array (compute_viscosity_εII!(η, ν, εII, args, rheology, cutoff))");
     hipLaunchKernelGGL(k_viscosity_single, OUT_GRID(nx, ny, nz), dim3(256), 0, h->stream, eta, *rh, T, P, nx, ny, t1, t2, sh, ndim == 3 ? sh : 0, nu, cutoff_lo,
-                       cutoff_hi);
+                       cutoff_hi, AII, tau_form != 0);
     return done(h);
 }
 

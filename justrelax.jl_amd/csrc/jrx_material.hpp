@@ -66,3 +66,45 @@ __device__ __forceinline__ double mat_creep_viscosity(const jrx_rheology &rh, in
     }
     return rh.eta[q];
 }
+// fn_viscosity(rheology[q].CompositeRheology[1], AII, args): AII is a stress invariant (compute_viscosity_τII, tau = true) or a strain-rate invariant
+// (compute_viscosity_εII); only the power-law creep (visc_kind 2) reads it
+__device__ __forceinline__ double mat_viscosity(const jrx_rheology &rh, int q, double AII, double T, double P, bool tau)
+{
+    if (rh.visc_kind[q] != 2) return mat_creep_viscosity(rh, q, T, P);
+    const double n = rh.creep_n[q], H = rh.Ea[q] + P * rh.Va[q], RT = rh.Rgas[q] * T;
+    if (tau) {
+        const double eps = rh.creep_A[q] * pow(AII * rh.creep_FT[q], n) * exp(-H / RT) / rh.creep_FE[q];
+        return 0.5 * AII / eps;
+    }
+    const double t = pow(rh.creep_A[q], -1.0 / n) * pow(AII * rh.creep_FE[q], 1.0 / n) * exp(H / (n * RT)) / rh.creep_FT[q];
+    return 0.5 * t / AII;
+}
+// compute_phase_viscosity (rheology/Viscosity.jl:599-619): a phase above 0.999 alone, else the ratio-weighted harmonic mean
+__device__ __forceinline__ double mat_phase_viscosity(const jrx_rheology &rh, const double *r, double AII, double T, double P, bool tau)
+{
+    for (int q = 0; q < rh.nphase; q++)
+        if (r[q] > 0.999) return mat_viscosity(rh, q, AII, T, P, tau);
+    double s = 0.0;
+    for (int q = 0; q < rh.nphase; q++)
+        if (r[q] != 0.0) s += (1.0 / mat_viscosity(rh, q, AII, T, P, tau)) * r[q];
+    return 1.0 / s;
+}
+// the invariant the viscosity kernels form from (xx, yy, xy) (Viscosity.jl:394-404): eps() on the normal components of an all-zero tensor
+__device__ __forceinline__ double mat_visc_invariant2(double xx, double yy, double xy)
+{
+    const double a0 = (xx == 0.0 && yy == 0.0 && xy == 0.0) ? 2.220446049250313e-16 : 0.0;
+    const double x = a0 + xx, y = -a0 + yy;
+    return sqrt(0.5 * (x * x + y * y) + xy * xy);
+}
+__host__ __device__ static inline bool mat_viscosity_reads_fields(const jrx_rheology *rh)
+{
+    for (int q = 0; q < rh->nphase; q++)
+        if (rh->visc_kind[q] != 0) return true;
+    return false;
+}
+__host__ __device__ static inline bool mat_viscosity_reads_invariant(const jrx_rheology *rh)
+{
+    for (int q = 0; q < rh->nphase; q++)
+        if (rh->visc_kind[q] == 2) return true;
+    return false;
+}

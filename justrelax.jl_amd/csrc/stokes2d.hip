@@ -659,6 +659,8 @@ struct VepArgs {
     bool soft;            // some phase has a softening law (EII_pl is then read by the yield function)
     bool si;              // strain_increment variant
     bool tg;              // args.T is the ghosted thermal.T (nx+2, ny+2): densities read it at the cell's own [i, j], unshifted (BuoyancyForces.jl:52)
+    bool vfields;         // some phase's creep law reads T, P or the invariant (visc_kind != 0)
+    bool vtau;            // the viscosity is taken from the stress (update_viscosity_τII!, the in-loop form) rather than from the strain rate (compute_viscosity!)
 };
 
 __device__ __forceinline__ double sinv2(double xx, double yy, double xy) { return sqrt(0.5 * (xx * xx + yy * yy) + xy * xy); }
@@ -1050,9 +1052,43 @@ __device__ __forceinline__ double phase_viscosity(const jrx_rheology &rh, const 
         if (r[q] != 0.0) s += (1.0 / rh.eta[q]) * r[q];
     return 1.0 / s;
 }
+// compute_viscosity_kernel! at a centre / a vertex for creep laws that read fields (rheology/Viscosity.jl:382-418): the invariant of @stress_center /
+// @strain_center, args at the cell (T at I .+ 1 of the ghosted thermal.T, local_viscosity_args :513-523); at a vertex (xx_v, yy_v, xy) -- the PT solvers
+// never write xx_v, yy_v: zero -- and args averaged over the clamped surrounding centres, T over its 2 x 2 nodes (local_viscosity_args_vertex :528-552)
+__device__ __forceinline__ double vep_visc_fields_centre(const VepArgs &a, const i64 t)
+{
+    const int nx = a.nx, j = (int)(t / nx), i = (int)(t - (i64)j * nx);
+    const double AII = a.vtau ? mat_visc_invariant2(a.f.txx[t], a.f.tyy[t], a.f.txy_c[t]) : mat_visc_invariant2(a.f.exx[t], a.f.eyy[t], a.f.exy_c[t]);
+    const double T = !a.f.T ? 0.0 : (a.tg ? a.f.T[(i + 1) + (i64)(nx + 2) * (j + 1)] : a.f.T[t]);
+    return mat_phase_viscosity(a.rh, a.f.phase_c + (i64)a.rh.nphase * t, AII, T, a.f.P[t], a.vtau);
+}
+__device__ __forceinline__ double vep_visc_fields_vertex(const VepArgs &a, const i64 t)
+{
+    const int nx = a.nx, ny = a.ny, j = (int)(t / (nx + 1)), i = (int)(t - (i64)j * (nx + 1));
+    const int il = max(i - 1, 0), ir = min(i, nx - 1), jb = max(j - 1, 0), jt = min(j, ny - 1);
+    const double AII = mat_visc_invariant2(0.0, 0.0, a.vtau ? a.f.txy[t] : a.f.exy[t]);
+    const double P = 0.25 * (a.f.P[il + (i64)nx * jb] + a.f.P[ir + (i64)nx * jb] + a.f.P[il + (i64)nx * jt] + a.f.P[ir + (i64)nx * jt]);
+    double T = 0.0;
+    if (a.f.T && a.tg) {
+        const double *q = a.f.T + i + (i64)(nx + 2) * j;
+        T = 0.25 * (q[0] + q[1] + q[nx + 2] + q[nx + 3]);
+    } else if (a.f.T) T = 0.25 * (a.f.T[il + (i64)nx * jb] + a.f.T[ir + (i64)nx * jb] + a.f.T[il + (i64)nx * jt] + a.f.T[ir + (i64)nx * jt]);
+    return mat_phase_viscosity(a.rh, a.f.phase_v + (i64)a.rh.nphase * t, AII, T, P, a.vtau);
+}
 __device__ __forceinline__ void vep_visc_at(const VepArgs &a, const i64 t)
 {
     const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
+    if (a.vfields) {
+        if (t < (i64)nx * ny) {
+            const double e = vep_visc_fields_centre(a, t) * a.nu + a.f.eta[t] * (1.0 - a.nu);
+            a.f.eta[t] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+        }
+        if (a.f.eta_v && t < (i64)(nx + 1) * (ny + 1)) {
+            const double e = vep_visc_fields_vertex(a, t) * a.nu + a.f.eta_v[t] * (1.0 - a.nu);
+            a.f.eta_v[t] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+        }
+        return;
+    }
     if (t < (i64)nx * ny) {
         double e = phase_viscosity(a.rh, a.f.phase_c + np * t);
         e = e * a.nu + a.f.eta[t] * (1.0 - a.nu);
@@ -1089,6 +1125,8 @@ __global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, doub
 // (Viscosity.jl:142-167) for creep laws without strain-rate dependence: η <- clamp((1 - ν) η + ν η_creep(T, P), cutoff).
 // args.T: cell-centred (nx, ny), or -- tg -- thermal.T (nx+2, ny+2) indexed as the reference does: density at [i, j]
 // (getindex_NamedTuple(args, I...), BuoyancyForces.jl:17), viscosity at [i+1, j+1] (local_viscosity_args, Viscosity.jl:513-523).
+// A power-law creep takes its invariant from @strain(stokes) = (ε.xx, ε.yy, ε.xy[i, j] -- the vertex array at the cell's index) in both forms, as
+// _compute_viscosity!(stokes, ν, args, rheology, cutoff, fn_viscosity) does (Viscosity.jl:136-167); a.vtau: fn_viscosity is compute_viscosity_τII.
 __global__ __launch_bounds__(256) void k_single_material(const VepArgs a, const double nu, const bool rho, const bool visc, const bool tg)
 {
     const int nx = a.nx, ny = a.ny;
@@ -1103,7 +1141,8 @@ __global__ __launch_bounds__(256) void k_single_material(const VepArgs a, const 
     }
     if (visc) {
         const double T = !a.f.T ? 0.0 : (tg ? a.f.T[(i + 1) + (i64)(nx + 2) * (j + 1)] : a.f.T[c]);
-        const double e = (1 - nu) * a.f.eta[c] + nu * mat_creep_viscosity(a.rh, 0, T, P);
+        const double AII = a.rh.visc_kind[0] == 2 ? mat_visc_invariant2(a.f.exx[c], a.f.eyy[c], a.f.exy[i + (i64)(nx + 1) * j]) : 0.0;
+        const double e = (1 - nu) * a.f.eta[c] + nu * mat_viscosity(a.rh, 0, AII, T, P, a.vtau);
         a.f.eta[c] = fmin(fmax(e, a.cut_lo), a.cut_hi);
     }
 }
@@ -1204,6 +1243,7 @@ VepArgs make_vep(const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_ve
     a.soft = mat_has_softening(rh);
     a.si = p->strain_increment != 0;
     a.tg = p->T_ghosted != 0;
+    a.vfields = mat_viscosity_reads_fields(rh); a.vtau = true;
     a.sp = Sp2{p->inv_spacing[0], p->inv_spacing[1], p->inv_spacing[2], p->inv_spacing[3], p->inv_spacing[4], p->inv_spacing[5]};
     return a;
 }
@@ -1237,7 +1277,17 @@ jrx_status jrx_vep2d_compute_viscosity(jrx_handle *h, const jrx_vep2d_fields *f,
 {
     JRX_TRY(check_vep(h, f, rh, p));
     VepArgs a = make_vep(f, rh, p);
-    a.nu = nu;
+    a.nu = nu; a.vtau = false;
+    hipLaunchKernelGGL(k_vep_visc, dim3((unsigned)(((p->nx + 1) * (p->ny + 1) + 255) / 256)), dim3(256), 0, h->stream, a);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipStreamSynchronize(h->stream));
+    return JRX_OK;
+}
+jrx_status jrx_vep2d_compute_viscosity_tauII(jrx_handle *h, const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_vep2d_params *p, double nu)
+{
+    JRX_TRY(check_vep(h, f, rh, p));
+    VepArgs a = make_vep(f, rh, p);
+    a.nu = nu; a.vtau = true;
     hipLaunchKernelGGL(k_vep_visc, dim3((unsigned)(((p->nx + 1) * (p->ny + 1) + 255) / 256)), dim3(256), 0, h->stream, a);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
@@ -1606,7 +1656,11 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
     JRX_HIP(h, hipMemsetAsync(f->eplxy_c, 0, n * sizeof(double), s));
     hipLaunchKernelGGL(k_fill2, dim3(gc), dim3(256), 0, s, Kc, rh->Kb[0], Gc, rh->G[0], (i64)n);      // Kb = get_Kb(rheology); G = get_G(rheology)
     // compute_ρg!(ρg[end], rheology, args); compute_viscosity!(stokes, args, rheology, cutoff) :406-407
-    hipLaunchKernelGGL(k_single_material, dim3(gc), dim3(256), 0, s, a, 1.0, rh->has_density != 0, true, tg);
+    {
+        VepArgs a0 = a;
+        a0.vtau = false;                    // compute_viscosity! is the εII form; the in-loop compute_viscosity_τII! the τII one
+        hipLaunchKernelGGL(k_single_material, dim3(gc), dim3(256), 0, s, a0, 1.0, rh->has_density != 0, true, tg);
+    }
     JRX_LAUNCH_CHECK(h);
     if (ubc) {    // displacement2velocity!(stokes, dt, flow_bcs) :410
         hipLaunchKernelGGL(k_scale3, dim3(256), dim3(256), 0, s, f->Vx, (const double *)f->Ux, (i64)(nx + 1) * (ny + 2), f->Vy,

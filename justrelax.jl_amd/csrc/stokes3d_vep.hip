@@ -205,10 +205,37 @@ __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
 }
 
 // update_viscosity_τII! / compute_viscosity! for the table rheology (rheology/Viscosity.jl:282-300, 599-625)
+// creep laws that read fields (Viscosity.jl:455-503): invariant of @stress / @strain with the shear components gathered from the cell's edges, eps() on the
+// normal components when those vanish; args at the cell, T at I .+ 1 of the ghosted thermal.T (local_viscosity_args :513-523)
+__device__ __forceinline__ double vep3_visc_fields(const Vep3Args &a, const i64 c, const bool tau)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int k = (int)(c / ((i64)nx * ny)), j = (int)((c - (i64)k * nx * ny) / nx), i = (int)(c - (i64)nx * (j + (i64)ny * k));
+    double AII = 0.0;
+    if (mat_viscosity_reads_invariant(&a.rh)) {
+        const double *xx = tau ? a.f.txx : a.f.exx, *yy = tau ? a.f.tyy : a.f.eyy, *zz = tau ? a.f.tzz : a.f.ezz;
+        const double *yz = tau ? a.f.tyz : a.f.eyz, *xz = tau ? a.f.txz : a.f.exz, *xy = tau ? a.f.txy : a.f.exy;
+        const double a0 = (xx[c] == 0.0 && yy[c] == 0.0 && zz[c] == 0.0) ? 2.220446049250313e-16 : 0.0;
+        const double x = xx[c] + a0, y = yy[c] + -a0 * 0.5, z = zz[c] + -a0 * 0.5;
+        const double p0 = EYZ(yz, i, j, k), p1 = EYZ(yz, i, j + 1, k), p2 = EYZ(yz, i, j, k + 1), p3 = EYZ(yz, i, j + 1, k + 1);
+        const double q0 = EXZ(xz, i, j, k), q1 = EXZ(xz, i + 1, j, k), q2 = EXZ(xz, i, j, k + 1), q3 = EXZ(xz, i + 1, j, k + 1);
+        const double r0 = EXY(xy, i, j, k), r1 = EXY(xy, i + 1, j, k), r2 = EXY(xy, i, j + 1, k), r3 = EXY(xy, i + 1, j + 1, k);
+        AII = sqrt(0.5 * (x * x + y * y + z * z) + 0.25 * (p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3) + 0.25 * (q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3) +
+                   0.25 * (r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3));
+    }
+    const double T = !a.f.T ? 0.0 : (a.tg ? a.f.T[(i + 1) + (i64)(nx + 2) * ((j + 1) + (i64)(ny + 2) * (k + 1))] : a.f.T[c]);
+    return mat_phase_viscosity(a.rh, a.f.phase_c + (i64)a.rh.nphase * c, AII, T, a.f.P[c], tau);
+}
+template <bool FIELDS, bool TAU>
 __global__ __launch_bounds__(256) void k_vep3_visc(const Vep3Args a, double nu)
 {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (i64)a.nx * a.ny * a.nz) return;
+    if (FIELDS) {
+        const double e = vep3_visc_fields(a, c, TAU) * nu + a.f.eta[c] * (1.0 - nu);
+        a.f.eta[c] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+        return;
+    }
     const int np = a.rh.nphase;
     const double *r = a.f.phase_c + np * c;
     double e = 0.0;
@@ -748,6 +775,13 @@ __global__ __launch_bounds__(256) void k_vep3_accumulate(const Vep3Args a)
 #undef VY
 #undef VZ
 
+void launch_vep3_visc(hipStream_t s, unsigned gc, const Vep3Args &a, double nu, bool tau)
+{
+    if (!mat_viscosity_reads_fields(&a.rh)) hipLaunchKernelGGL((k_vep3_visc<false, false>), dim3(gc), dim3(256), 0, s, a, nu);
+    else if (tau) hipLaunchKernelGGL((k_vep3_visc<true, true>), dim3(gc), dim3(256), 0, s, a, nu);
+    else hipLaunchKernelGGL((k_vep3_visc<true, false>), dim3(gc), dim3(256), 0, s, a, nu);
+}
+
 jrx_status check_vep3(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p)
 {
     if (!h) return JRX_ERR_ARG;
@@ -881,16 +915,29 @@ jrx_status jrx_vep3d_update_stresses(jrx_handle *h, const jrx_vep3d_fields *f, c
     return JRX_OK;
 }
 
-jrx_status jrx_vep3d_compute_viscosity(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p, double nu)
+static jrx_status vep3_viscosity(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p, double nu, bool tau)
 {
     if (!h) return JRX_ERR_ARG;
     if (!f || !rh || !p || !f->eta || !f->phase_c) return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: null argument");
+    if (mat_viscosity_reads_invariant(rh)) {
+        const void *need[] = {f->exx, f->eyy, f->ezz, f->eyz, f->exz, f->exy, f->txx, f->tyy, f->tzz, f->tyz, f->txz, f->txy, f->P};
+        for (const void *q : need)
+            if (!q) return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: a power-law creep reads stokes.ε / stokes.τ and P");
+    } else if (mat_viscosity_reads_fields(rh) && !f->P) return jrx_fail(h, JRX_ERR_ARG, "compute_viscosity!: the creep law reads P");
     Vep3Args a = make_vep3(f, rh, p);
     const i64 n = (i64)p->nx * p->ny * p->nz;
-    hipLaunchKernelGGL(k_vep3_visc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a, nu);
+    launch_vep3_visc(h->stream, (unsigned)((n + 255) / 256), a, nu, tau);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
+}
+jrx_status jrx_vep3d_compute_viscosity(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p, double nu)
+{
+    return vep3_viscosity(h, f, rh, p, nu, false);
+}
+jrx_status jrx_vep3d_compute_viscosity_tauII(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p, double nu)
+{
+    return vep3_viscosity(h, f, rh, p, nu, true);
 }
 
 jrx_status jrx_tensor_invariant3d(jrx_handle *h, double *II, const double *xx, const double *yy, const double *zz, const double *yz,
@@ -972,7 +1019,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     JRX_HIP(h, hipMemsetAsync(lam, 0, n * sizeof(double), s));
     JRX_HIP(h, hipMemsetAsync(a.lamv[0], 0, (size_t)(ne.yz + ne.xz + ne.xy) * sizeof(double), s));
     hipLaunchKernelGGL(k_vep3_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a, rh->has_density != 0);
-    hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, 1.0);                              // compute_viscosity! :507
+    launch_vep3_visc(s, gc, a, 1.0, false);                                                          // compute_viscosity! :507 (εII form)
     JRX_LAUNCH_CHECK(h);
     const bool upd_rho = rh->has_density && !mat_density_is_constant(rh);       // update_ρg!: a no-op for constant densities
     const bool ubc = p->displacement_bcs != 0;
@@ -1007,7 +1054,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             else hipLaunchKernelGGL((k_vep3_pre<false, false, PRE_KZ>), gpre, dim3(256), 0, s, a);
         } else if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_vep3_pre<true, false, PRE_KZ>), gpre, dim3(256), 0, s, a);        // compute_maxloc! folded in
-        hipLaunchKernelGGL(k_vep3_visc, dim3(gc), dim3(256), 0, s, a, p->viscosity_relaxation);
+        launch_vep3_visc(s, gc, a, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
         JRX_LAUNCH_CHECK(h);
         JRX_TRY(launch_vep3_stress(h, s, a, p, false));
         // the new edge stresses become the current ones: swap the pointers instead of copying three arrays back

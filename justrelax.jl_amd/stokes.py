@@ -211,7 +211,13 @@ def rheology_table(phases) -> _lib.Rheology:
                 getattr(r, pre + name)[q] = float(v)
         # creep law: dict(kind="arrhenius", Ea, Va, T0, R, cutoff=(lo, hi)) on top of eta (= η0)
         cr = ph.get("creep")
-        if cr is not None:
+        if cr is not None and cr.get("kind") in ("dislocation", "powerlaw"):
+            # DislocationCreep(A, n, E, V, R) with r = 0; apparatus = "AxialCompression" (FT = √3, FE = 2/√3) | "SimpleShear" (2, 2) | "Invariant" (1, 1)
+            FT, FE = {"AxialCompression": (3.0 ** 0.5, 2.0 / 3.0 ** 0.5), "SimpleShear": (2.0, 2.0), "Invariant": (1.0, 1.0)}[cr.get("apparatus", "AxialCompression")]
+            r.visc_kind[q] = 2
+            r.creep_A[q], r.creep_n[q], r.creep_FT[q], r.creep_FE[q] = cr["A"], cr["n"], cr.get("FT", FT), cr.get("FE", FE)
+            r.Ea[q], r.Va[q], r.Rgas[q] = cr.get("E", 0.0), cr.get("V", 0.0), cr.get("R", 8.3145)
+        elif cr is not None:
             if cr.get("kind") != "arrhenius":
                 raise ValueError(f"unknown creep law {cr.get('kind')!r}")
             r.visc_kind[q] = 1
@@ -514,9 +520,26 @@ def tensor_invariant_(A, *, handle=None):
            C.c_int64(A.xx.shape[0]), C.c_int64(A.xx.shape[1]))
 
 
-def compute_viscosity_(stokes, *rest, relaxation=1.0, handle=None):
+def _ghosted_T_flag(stokes, T):
+    if T is None or tuple(T.shape) == tuple(stokes._ni):
+        return 0
+    if tuple(T.shape) != tuple(n + 2 for n in stokes._ni):
+        raise ValueError(f"args.T must be ni {tuple(stokes._ni)} or ni .+ 2 (thermal.T), got {tuple(T.shape)}")
+    return 1
+
+
+def compute_viscosity_τII_(stokes, *rest, relaxation=1.0, handle=None):
+    """compute_viscosity_τII!(stokes, phase_ratios, args, rheology, cutoff; relaxation) / update_viscosity_τII! (rheology/Viscosity.jl:67-106,198-216)"""
+    return compute_viscosity_(stokes, *rest, relaxation=relaxation, handle=handle, fn="τII")
+
+
+def compute_viscosity_(stokes, *rest, relaxation=1.0, handle=None, fn="εII", AII=None):
     """compute_viscosity!(stokes, phase_ratios, args, rheology, cutoff; relaxation) for the table rheology (rheology/Viscosity.jl:203-216), or -- without
-    phase ratios -- compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation) (Viscosity.jl:118-167; args.T is thermal.T, read at I .+ 1)"""
+    phase ratios -- compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation) (Viscosity.jl:118-167; args.T is thermal.T, read at I .+ 1).
+    fn: "εII" (compute_viscosity!) or "τII" (compute_viscosity_τII! / update_viscosity_τII!): the invariant a power-law creep is evaluated at.
+    AII (single-material form): the invariant array of compute_viscosity_εII! / _τII!(η, ν, AII, args, rheology, cutoff) (Viscosity.jl:169-196)"""
+    if fn not in ("εII", "τII"):
+        raise ValueError("fn must be 'εII' or 'τII'")
     _require_gpu(stokes)
     h = handle or _lib.default_handle(stokes.P.device.index)
     from .arrays import PhaseRatios
@@ -534,24 +557,27 @@ def compute_viscosity_(stokes, *rest, relaxation=1.0, handle=None):
         td = (C.c_int64 * 3)(*(T.shape if T is not None else η.shape), *([1] * (3 - nd)))
         torch.cuda.current_stream(η.device).synchronize()
         h.call("jrx_compute_viscosity_single", C.c_void_p(ptr(η)), C.byref(rh), C.c_void_p(ptr(T)), C.c_void_p(ptr(P)), n, td, C.c_int32(nd),
-               C.c_double(float(relaxation)), C.c_double(float(cutoff[0])), C.c_double(float(cutoff[1])))
+               C.c_double(float(relaxation)), C.c_double(float(cutoff[0])), C.c_double(float(cutoff[1])), C.c_void_p(ptr(AII)), C.c_int32(int(fn == "τII")))
         return
     phase_ratios, args, rheology = rest[0], rest[1], rest[2]
     cutoff = rest[3] if len(rest) > 3 else (-float("inf"), float("inf"))
+    sfx = "_tauII" if fn == "τII" else ""
     pt = SimpleNamespace(r=0.0, θ_dτ=1.0, ηdτ=1.0, ϵ_rel=0.0, ϵ_abs=0.0)
     if len(stokes._ni) == 3:
         fake = SimpleNamespace(_di=dict(center=(1.0, 1.0, 1.0)))
         p = vep_params3d(stokes, pt, fake, None, 1.0, viscosity_cutoff=cutoff)
-        f = vep_fields3d(stokes, (stokes.P, stokes.P, stokes.P), phase_ratios)
+        f = vep_fields3d(stokes, (stokes.P, stokes.P, stokes.P), phase_ratios, args)
+        p.T_ghosted = _ghosted_T_flag(stokes, _args_T(args))
         torch.cuda.current_stream(stokes.P.device).synchronize()
-        h.call("jrx_vep3d_compute_viscosity", C.byref(f), C.byref(rheology_table(rheology)), C.byref(p), C.c_double(float(relaxation)))
+        h.call("jrx_vep3d_compute_viscosity" + sfx, C.byref(f), C.byref(rheology_table(rheology)), C.byref(p), C.c_double(float(relaxation)))
         return
     fake = SimpleNamespace(_di=dict(center=(1.0, 1.0)))
     p = vep_params2d(stokes, pt, fake, None, 1.0, viscosity_cutoff=cutoff)
-    f = vep_fields2d(stokes, (stokes.P, stokes.P), phase_ratios)
+    f = vep_fields2d(stokes, (stokes.P, stokes.P), phase_ratios, args, allow_ghosted_T=True)
+    p.T_ghosted = _ghosted_T_flag(stokes, _args_T(args))
     rh = rheology_table(rheology)
     torch.cuda.current_stream(stokes.P.device).synchronize()
-    h.call("jrx_vep2d_compute_viscosity", C.byref(f), C.byref(rh), C.byref(p), C.c_double(float(relaxation)))
+    h.call("jrx_vep2d_compute_viscosity" + sfx, C.byref(f), C.byref(rh), C.byref(p), C.c_double(float(relaxation)))
 
 
 def solve_(stokes, pt_stokes, grid_or_di, flow_bcs, ρg, *rest, kwargs=None, handle=None):

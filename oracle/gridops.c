@@ -125,7 +125,7 @@ void orc_compute_rhog(double *rhog, const orc_rheology *rh, const double *phase_
 /* compute_viscosity_kernel! for one MaterialParams (rheology/Viscosity.jl:136-167), creep laws of the table (no strain-rate dependence):
  * η <- clamp(continuation_linear(η_creep(T[I .+ 1] | T[I], P[I]), η, ν), cutoff) */
 void orc_compute_viscosity_single(double *eta, const orc_rheology *rh, const double *T, const double *P, const int64_t n[3], const int64_t tdim[3], int32_t ndim,
-                                  double nu, double lo, double hi)
+                                  double nu, double lo, double hi, const double *AII, int32_t tau)
 {
     const int64_t nx = n[0], ny = n[1], nz = ndim == 3 ? n[2] : 1, t1 = tdim ? tdim[0] : nx, t2 = tdim ? tdim[1] : ny;
     const int64_t sh = (tdim && tdim[0] == nx + 2) ? 1 : 0, shk = ndim == 3 ? sh : 0;
@@ -134,7 +134,8 @@ void orc_compute_viscosity_single(double *eta, const orc_rheology *rh, const dou
             for (int64_t i = 0; i < nx; i++) {
                 const size_t c = IDX3(nx, ny, i, j, k);
                 const double t = T ? T[IDX3(t1, t2, i + sh, j + sh, k + shk)] : 0.0, p = P ? P[c] : 0.0;
-                const double e = (1 - nu) * eta[c] + nu * mat_creep_viscosity(rh, 0, t, p);
+                /* array form compute_viscosity_εII! / compute_viscosity_τII!(η, ν, AII, args, rheology, cutoff) (Viscosity.jl:169-196) when AII is given */
+                const double e = (1 - nu) * eta[c] + nu * mat_viscosity(rh, 0, AII ? AII[c] : 0.0, t, p, tau);
                 eta[c] = fmin(fmax(e, lo), hi);
             }
 }

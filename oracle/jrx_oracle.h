@@ -249,9 +249,13 @@ typedef struct orc_rheology {
     double softphi_a[ORC_MAXPHASE], softphi_b[ORC_MAXPHASE], softphi_c[ORC_MAXPHASE], softphi_d[ORC_MAXPHASE], phi_deg[ORC_MAXPHASE];
     /* Creep law of the viscous element for compute_viscosity! / compute_viscosity_τII! with dt = Inf (rheology/Viscosity.jl:142-167):
      * visc_kind 0 LinearViscous(eta); 1 Arrhenius: eta exp((Ea + P Va)/(Rgas T) - Ea/(Rgas Tref)), clamped to [visc_lo, visc_hi]
-     * (the CustomRheology of test/test_WENO5.jl:37-42 with depth = 0) */
+     * (the CustomRheology of test/test_WENO5.jl:37-42 with depth = 0);
+     * 2 power-law creep (GeoParams DislocationCreep, r = 0; forms ASSUMED, parity unpinned):
+     *   compute_εII = creep_A (τII FT)^n exp(-(Ea + P Va)/(Rgas T)) / FE;  compute_τII = creep_A^(-1/n) (εII FE)^(1/n) exp((Ea + P Va)/(n Rgas T)) / FT;
+     *   compute_viscosity_τII = τII / (2 ε(τII)), compute_viscosity_εII = τ(εII) / (2 εII) */
     int32_t visc_kind[ORC_MAXPHASE];
     double Ea[ORC_MAXPHASE], Va[ORC_MAXPHASE], Tref[ORC_MAXPHASE], Rgas[ORC_MAXPHASE], visc_lo[ORC_MAXPHASE], visc_hi[ORC_MAXPHASE];
+    double creep_A[ORC_MAXPHASE], creep_n[ORC_MAXPHASE], creep_FT[ORC_MAXPHASE], creep_FE[ORC_MAXPHASE];
 } orc_rheology;
 
 typedef struct orc_vep2d {
@@ -301,7 +305,8 @@ int32_t orc_isyielding(int32_t is_pl, double tII_trial, double ty);
 double orc_compute_dtau_pl(const double tij[3], const double dtij[3], double ty, double tII_trial, double eta, double lam0, double eta_reg,
                            double dtr, double volume, double dtau_pl[3], double ldq[3]);
 void orc_tensor_invariant2d(double *II, const double *xx, const double *yy, const double *xy, int64_t nx, int64_t ny, int32_t mode);
-void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu);
+void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu);      /* compute_viscosity!: εII form */
+void orc_compute_viscosity2d_form(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu, int32_t tau);
 
 /* ---- 3D multiphase visco-elasto-plastic Stokes (Stokes3D.jl:447-668; test/test_shearband3D_MPI.jl) ---- */
 typedef struct orc_vep3d {
@@ -337,6 +342,7 @@ int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const
 void orc_vep3d_stress(const orc_vep3d *f, const double *theta, double *lam, double *const lamv[3], const orc_rheology *rh,
                       const orc_vep_params3d *p);
 void orc_compute_viscosity3d(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, double nu);
+void orc_compute_viscosity3d_form(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, double nu, int32_t tau);
 void orc_tensor_invariant3d(double *II, const double *xx, const double *yy, const double *zz, const double *yz, const double *xz, const double *xy,
                             int64_t nx, int64_t ny, int64_t nz);
 void orc_shear2center3d(double *yz_c, double *xz_c, double *xy_c, const double *yz, const double *xz, const double *xy, int64_t nx, int64_t ny, int64_t nz);
@@ -367,7 +373,7 @@ void orc_compute_rhog(double *rhog, const orc_rheology *rh, const double *phase_
                       int32_t ndim);
 void orc_compute_lithostatic_pressure(double *P, const double *rhog, double dz, const double *dz_cells, const int64_t n[3], int32_t ndim);
 void orc_compute_viscosity_single(double *eta, const orc_rheology *rh, const double *T, const double *P, const int64_t n[3], const int64_t tdim[3], int32_t ndim,
-                                  double nu, double lo, double hi);
+                                  double nu, double lo, double hi, const double *AII, int32_t tau);
 void orc_compute_shear_heating(double *sh, const double *const *tau, const double *const *tau_o, const double *const *eps, const double *phase_c,
                                const orc_rheology *rh, const double *chi, double dt, const int64_t n[3], int32_t ndim);
 

@@ -408,7 +408,8 @@ class Rheology(C.Structure):
                [("softC_kind", C.c_int32 * MAXPHASE), ("softphi_kind", C.c_int32 * MAXPHASE)] + \
                [(k, C.c_double * MAXPHASE) for k in ("softC_a", "softC_b", "softC_c", "softC_d", "softphi_a", "softphi_b", "softphi_c",
                                                      "softphi_d", "phi_deg")] + \
-               [("visc_kind", C.c_int32 * MAXPHASE)] + [(k, C.c_double * MAXPHASE) for k in ("Ea", "Va", "Tref", "Rgas", "visc_lo", "visc_hi")]
+               [("visc_kind", C.c_int32 * MAXPHASE)] + [(k, C.c_double * MAXPHASE) for k in ("Ea", "Va", "Tref", "Rgas", "visc_lo", "visc_hi", "creep_A", "creep_n",
+                                                                                        "creep_FT", "creep_FE")]
 
 
 class VEPParams2D(C.Structure):
@@ -468,7 +469,13 @@ def rheology_struct(phases: list) -> Rheology:
                 getattr(r, pre + name)[q] = float(v)
         # creep law: dict(kind="arrhenius", Ea, Va, T0, R, cutoff=(lo, hi)) on top of eta (= η0)
         cr = ph.get("creep")
-        if cr is not None:
+        if cr is not None and cr.get("kind") in ("dislocation", "powerlaw"):
+            # DislocationCreep(A, n, E, V, R) with r = 0; apparatus = "AxialCompression" (FT = √3, FE = 2/√3) | "SimpleShear" (2, 2) | "Invariant" (1, 1)
+            FT, FE = {"AxialCompression": (3.0 ** 0.5, 2.0 / 3.0 ** 0.5), "SimpleShear": (2.0, 2.0), "Invariant": (1.0, 1.0)}[cr.get("apparatus", "AxialCompression")]
+            r.visc_kind[q] = 2
+            r.creep_A[q], r.creep_n[q], r.creep_FT[q], r.creep_FE[q] = cr["A"], cr["n"], cr.get("FT", FT), cr.get("FE", FE)
+            r.Ea[q], r.Va[q], r.Rgas[q] = cr.get("E", 0.0), cr.get("V", 0.0), cr.get("R", 8.3145)
+        elif cr is not None:
             if cr.get("kind") != "arrhenius":
                 raise ValueError(f"unknown creep law {cr.get('kind')!r}")
             r.visc_kind[q] = 1
@@ -520,9 +527,14 @@ def tensor_invariant2d(xx, yy, xy, mode=0):
     return II
 
 
-def compute_viscosity2d(arr, rh, p, nu=1.0):
+def compute_viscosity2d(arr, rh, p, nu=1.0, tau=False):
     f = vep2d(arr)
-    lib().orc_compute_viscosity2d(C.byref(f), C.byref(rh), C.byref(p), C.c_double(nu))
+    lib().orc_compute_viscosity2d_form(C.byref(f), C.byref(rh), C.byref(p), C.c_double(nu), C.c_int32(int(tau)))
+
+
+def compute_viscosity3d(arr, rh, p, nu=1.0, tau=False):
+    f = vep3d(arr)
+    lib().orc_compute_viscosity3d_form(C.byref(f), C.byref(rh), C.byref(p), C.c_double(nu), C.c_int32(int(tau)))
 
 
 # ---- 3D multiphase VEP (oracle/stokes3d_vep.c) ----
@@ -801,12 +813,13 @@ def compute_lithostatic_pressure(rhog, dz):
     return P
 
 
-def compute_viscosity_single(eta, rh: "Rheology", T, P, cutoff=(-np.inf, np.inf), nu=1.0):
+def compute_viscosity_single(eta, rh: "Rheology", T, P, cutoff=(-np.inf, np.inf), nu=1.0, AII=None, tau=False):
     """compute_viscosity!(stokes, args, rheology::MaterialParams, cutoff; relaxation) in place on eta -- rheology/Viscosity.jl:118-167 (T: ni or ni .+ 2)"""
     nd = eta.ndim
     n = (C.c_int64 * 3)(*eta.shape, *([1] * (3 - nd)))
     td = (C.c_int64 * 3)(*(T.shape if T is not None else eta.shape), *([1] * (3 - nd)))
-    lib().orc_compute_viscosity_single(_p(eta), C.byref(rh), _p(T), _p(P), n, td, C.c_int32(nd), C.c_double(nu), C.c_double(cutoff[0]), C.c_double(cutoff[1]))
+    lib().orc_compute_viscosity_single(_p(eta), C.byref(rh), _p(T), _p(P), n, td, C.c_int32(nd), C.c_double(nu), C.c_double(cutoff[0]), C.c_double(cutoff[1]),
+                                       _p(AII), C.c_int32(int(tau)))
 
 
 def compute_shear_heating(tau, tau_o, eps, rh: "Rheology", chi, dt, phase_c=None):

@@ -300,10 +300,44 @@ static inline double phase_viscosity(const orc_rheology *rh, const double *r)
         if (r[q] != 0.0) s += inv(rh->eta[q]) * r[q];
     return inv(s);
 }
-void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu)
+/* creep laws that read fields: compute_viscosity_kernel! with local_viscosity_args / local_viscosity_args_vertex (Viscosity.jl:382-418, 513-552);
+ * centre: invariant of @stress_center / @strain_center, T at I .+ 1 of the ghosted thermal.T; vertex: (xx_v, yy_v, xy) with xx_v = yy_v = 0 (never written by
+ * the PT solvers), args averaged over the clamped surrounding centres, T over its 2 x 2 nodes */
+static void viscosity2d_fields(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu, int tau)
 {
     const int64_t nx = p->nx, ny = p->ny;
     const int np = rh->nphase;
+    for (int64_t j = 0; j < ny; j++)
+        for (int64_t i = 0; i < nx; i++) {
+            const size_t c = IDX2(nx, i, j);
+            const double AII = tau ? mat_visc_invariant2(f->txx[c], f->tyy[c], f->txy_c[c]) : mat_visc_invariant2(f->exx[c], f->eyy[c], f->exy_c[c]);
+            const double T = !f->T ? 0.0 : (p->T_ghosted ? f->T[IDX2(nx + 2, i + 1, j + 1)] : f->T[c]);
+            double e = mat_phase_viscosity(rh, f->phase_c + (size_t)np * c, AII, T, f->P[c], tau);
+            e = e * nu + f->eta[c] * (1.0 - nu);
+            f->eta[c] = fmin(fmax(e, p->cutoff_lo), p->cutoff_hi);
+        }
+    if (!f->eta_v) return;
+    for (int64_t j = 0; j <= ny; j++)
+        for (int64_t i = 0; i <= nx; i++) {
+            const size_t v = IDX2(nx + 1, i, j);
+            const int64_t il = i > 0 ? i - 1 : 0, ir = i < nx ? i : nx - 1, jb = j > 0 ? j - 1 : 0, jt = j < ny ? j : ny - 1;
+            const double AII = mat_visc_invariant2(0.0, 0.0, tau ? f->txy[v] : f->exy[v]);
+            const double P = 0.25 * (f->P[IDX2(nx, il, jb)] + f->P[IDX2(nx, ir, jb)] + f->P[IDX2(nx, il, jt)] + f->P[IDX2(nx, ir, jt)]);
+            double T = 0.0;
+            if (f->T && p->T_ghosted)
+                T = 0.25 * (f->T[IDX2(nx + 2, i, j)] + f->T[IDX2(nx + 2, i + 1, j)] + f->T[IDX2(nx + 2, i, j + 1)] + f->T[IDX2(nx + 2, i + 1, j + 1)]);
+            else if (f->T) T = 0.25 * (f->T[IDX2(nx, il, jb)] + f->T[IDX2(nx, ir, jb)] + f->T[IDX2(nx, il, jt)] + f->T[IDX2(nx, ir, jt)]);
+            double e = mat_phase_viscosity(rh, f->phase_v + (size_t)np * v, AII, T, P, tau);
+            e = e * nu + f->eta_v[v] * (1.0 - nu);
+            f->eta_v[v] = fmin(fmax(e, p->cutoff_lo), p->cutoff_hi);
+        }
+}
+void orc_compute_viscosity2d(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu) { orc_compute_viscosity2d_form(f, rh, p, nu, 0); }
+void orc_compute_viscosity2d_form(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu, int32_t tau)
+{
+    const int64_t nx = p->nx, ny = p->ny;
+    const int np = rh->nphase;
+    if (mat_viscosity_reads_fields(rh)) { viscosity2d_fields(f, rh, p, nu, tau); return; }
     for (int64_t c = 0; c < nx * ny; c++) {
         double e = phase_viscosity(rh, f->phase_c + (size_t)np * c);
         e = e * nu + f->eta[c] * (1.0 - nu);                        /* continuation_linear */
@@ -393,7 +427,7 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
         } else orc_compute_strain_rate2d(&g, &q);
         orc_vep2d_stress(f, theta, lam, lamv, rh, p);
         { const int64_t e[3] = {nx + 1, ny + 1, 1}, nn[3] = {nx, ny, 1}; orc_self_halo(f->txy, e, nn); }    /* update_halo!(τ.xy) :757 */
-        orc_compute_viscosity2d(f, rh, p, p->viscosity_relaxation);
+        orc_compute_viscosity2d_form(f, rh, p, p->viscosity_relaxation, 1);         /* update_viscosity_τII! */
         orc_compute_V2d_fs(&g, etatau, &q, fs_dt);   /* free-surface form; with dt*free_surface = 0 it reduces to the plain one */
         orc_velocity2displacement2d(&g, &q);
         if (p->displacement_bcs) orc_flow_bcs2d(f->Ux, f->Uy, nx, ny, p->free_slip, p->no_slip, p->periodic);   /* flow_bcs! on @displacement */
@@ -461,13 +495,16 @@ static inline double T_at(const orc_vep2d *f, const orc_vep_params2d *p, int64_t
     if (p->T_ghosted) return f->T[IDX2(p->nx + 2, i + shift, j + shift)];
     return f->T[IDX2(p->nx, i, j)];
 }
-static void visc_single(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu)
+/* a power-law creep takes its invariant from @strain(stokes) = (ε.xx, ε.yy, ε.xy[i, j]: the vertex array at the cell's index) whatever fn_viscosity is
+ * (_compute_viscosity!(stokes, ν, args, rheology, cutoff, fn_viscosity), Viscosity.jl:136-167) */
+static void visc_single(const orc_vep2d *f, const orc_rheology *rh, const orc_vep_params2d *p, double nu, int tau)
 {
     const int64_t nx = p->nx, ny = p->ny;
     for (int64_t j = 0; j < ny; j++)
         for (int64_t i = 0; i < nx; i++) {
             const size_t c = IDX2(nx, i, j);
-            const double en = mat_creep_viscosity(rh, 0, T_at(f, p, i, j, 1), f->P[c]);
+            const double AII = rh->visc_kind[0] == 2 ? mat_visc_invariant2(f->exx[c], f->eyy[c], f->exy[IDX2(nx + 1, i, j)]) : 0.0;
+            const double en = mat_viscosity(rh, 0, AII, T_at(f, p, i, j, 1), f->P[c], tau);
             const double e = (1 - nu) * f->eta[c] + nu * en;                        /* continuation_linear, Utils.jl:662 */
             f->eta[c] = fmin(fmax(e, p->cutoff_lo), p->cutoff_hi);
         }
@@ -492,7 +529,7 @@ int32_t orc_stokes2d_nonlinear_solve(const orc_vep2d *f, const orc_rheology *rh,
     memset(f->eplxx, 0, n * 8); memset(f->eplyy, 0, n * 8); memset(f->eplxy_c, 0, n * 8);   /* :391-393 */
     const int upd_rho = rh->has_density && rh->rho_kind[0] != 0;
     if (rh->has_density) rhog_single(f, rh, p);                                    /* compute_ρg!(ρg[end], rheology, args) :406 */
-    visc_single(f, rh, p, 1.0);                                                     /* compute_viscosity!(stokes, args, rheology, cutoff) :407 */
+    visc_single(f, rh, p, 1.0, 0);                                                     /* compute_viscosity!(stokes, args, rheology, cutoff) :407 */
     if (p->displacement_bcs) {                                                      /* displacement2velocity! :410 */
         const double _dt = inv(p->dt);
         for (size_t c = 0; c < (size_t)(nx + 1) * (ny + 2); c++) f->Vx[c] = f->Ux[c] * _dt;
@@ -520,7 +557,7 @@ int32_t orc_stokes2d_nonlinear_solve(const orc_vep2d *f, const orc_rheology *rh,
         orc_compute_P3d(f->P, f->P0, f->RP, f->divV, f->Q, f->eta, Kc, Gc, (int64_t)n, p->dt, p->r, p->theta_dtau);   /* with η, in place :418-420 */
         if (upd_rho) rhog_single(f, rh, p);                                        /* update_ρg!(ρg[2], rheology, args) :422 */
         orc_compute_strain_rate2d(&g, &q);
-        visc_single(f, rh, p, p->viscosity_relaxation);                            /* compute_viscosity_τII! :433-435 */
+        visc_single(f, rh, p, p->viscosity_relaxation, 1);                            /* compute_viscosity_τII! :433-435 */
         orc_compute_maxloc2d(etatau, f->eta, nx, ny);                              /* :437-438 */
         orc_compute_tau_nonlinear2d(f, theta, lam, rh, p, 0);                      /* :440-458 */
         orc_center2vertex2d(f->txy, f->txy_c, nx, ny);                             /* :459 */

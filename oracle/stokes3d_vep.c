@@ -256,10 +256,36 @@ void orc_vep3d_stress(const orc_vep3d *f, const double *theta, double *lam, doub
 }
 
 /* update_viscosity_τII! 3D (rheology/Viscosity.jl:67-106,282-300): centre viscosity relaxed towards the phase value */
-void orc_compute_viscosity3d(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, double nu)
+/* creep laws that read fields (Viscosity.jl:455-503): invariant of @stress / @strain with the shear components gathered from the cell's four edges (mean of
+ * squares, second_invariant_staggered), eps() on the normal components when those vanish; T at I .+ 1 of the ghosted thermal.T */
+static void viscosity3d_fields(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, double nu, int tau)
+{
+    const int64_t nx = p->nx, ny = p->ny, nz = p->nz;
+    const double *xx = tau ? f->txx : f->exx, *yy = tau ? f->tyy : f->eyy, *zz = tau ? f->tzz : f->ezz;
+    const double *yz = tau ? f->tyz : f->eyz, *xz = tau ? f->txz : f->exz, *xy = tau ? f->txy : f->exy;
+    for (int64_t k = 0; k < nz; k++)
+        for (int64_t j = 0; j < ny; j++)
+            for (int64_t i = 0; i < nx; i++) {
+                const size_t c = IDX3(nx, ny, i, j, k);
+                const double a0 = (xx[c] == 0.0 && yy[c] == 0.0 && zz[c] == 0.0) ? 2.220446049250313e-16 : 0.0;
+                const double x = xx[c] + a0, y = yy[c] + -a0 * 0.5, z = zz[c] + -a0 * 0.5;
+                const double p0 = yz[IDX3(nx, ny + 1, i, j, k)], p1 = yz[IDX3(nx, ny + 1, i, j + 1, k)], p2 = yz[IDX3(nx, ny + 1, i, j, k + 1)], p3 = yz[IDX3(nx, ny + 1, i, j + 1, k + 1)];
+                const double q0 = xz[IDX3(nx + 1, ny, i, j, k)], q1 = xz[IDX3(nx + 1, ny, i + 1, j, k)], q2 = xz[IDX3(nx + 1, ny, i, j, k + 1)], q3 = xz[IDX3(nx + 1, ny, i + 1, j, k + 1)];
+                const double r0 = xy[IDX3(nx + 1, ny + 1, i, j, k)], r1 = xy[IDX3(nx + 1, ny + 1, i + 1, j, k)], r2 = xy[IDX3(nx + 1, ny + 1, i, j + 1, k)], r3 = xy[IDX3(nx + 1, ny + 1, i + 1, j + 1, k)];
+                const double AII = sqrt(0.5 * (x * x + y * y + z * z) + 0.25 * (p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3) + 0.25 * (q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3) +
+                                        0.25 * (r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3));
+                const double T = !f->T ? 0.0 : (p->T_ghosted ? f->T[IDX3(nx + 2, ny + 2, i + 1, j + 1, k + 1)] : f->T[c]);
+                double e = mat_phase_viscosity(rh, f->phase_c + (size_t)rh->nphase * c, AII, T, f->P[c], tau);
+                e = e * nu + f->eta[c] * (1.0 - nu);
+                f->eta[c] = fmin(fmax(e, p->cutoff_lo), p->cutoff_hi);
+            }
+}
+void orc_compute_viscosity3d(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, double nu) { orc_compute_viscosity3d_form(f, rh, p, nu, 0); }
+void orc_compute_viscosity3d_form(const orc_vep3d *f, const orc_rheology *rh, const orc_vep_params3d *p, double nu, int32_t tau)
 {
     const int64_t n = p->nx * p->ny * p->nz;
     const int np = rh->nphase;
+    if (mat_viscosity_reads_fields(rh)) { viscosity3d_fields(f, rh, p, nu, tau); return; }
     for (int64_t c = 0; c < n; c++) {
         const double *r = f->phase_c + (size_t)np * c;
         double e = 0.0;
@@ -398,7 +424,7 @@ int32_t orc_stokes3d_vep_solve(const orc_vep3d *f, const orc_rheology *rh, const
         orc_compute_strain_rate3d(&g, &q);
         if (upd_rho)                                  /* update_ρg!(ρg, phase_ratios, rheology, args) :538 ; args.P is stokes.P */
             for (size_t c = 0; c < n; c++) f->fz[c] = mat_density_ratio(rh, f->phase_c + np * c, T_of(f, p, c), f->P[c]) * rh->gravity;
-        orc_compute_viscosity3d(f, rh, p, p->viscosity_relaxation);
+        orc_compute_viscosity3d_form(f, rh, p, p->viscosity_relaxation, 1);        /* update_viscosity_τII! */
         orc_vep3d_stress(f, theta, lam, lamv, rh, p);
         {   /* update_halo!(τ.yz), (τ.xz), (τ.xy) :578-580 */
             const int64_t nn[3] = {nx, ny, nz};

@@ -1,0 +1,130 @@
+"""Power-law creep (visc_kind 2 of the rheology table: GeoParams DislocationCreep with r = 0) in the CPU oracle: the viscosity kernels of
+rheology/Viscosity.jl:382-418 (2D centre + vertex), :455-503 (3D), :169-196 (array form) against an independent numpy restatement of the stated forms
+    compute_εII = A (τII FT)^n exp(-(E + P V)/(R T)) / FE          compute_τII = A^(-1/n) (εII FE)^(1/n) exp((E + P V)/(n R T)) / FT
+    compute_viscosity_τII = τII / (2 ε(τII))                        compute_viscosity_εII = τ(εII) / (2 εII)
+The GeoParams forms are ASSUMED (parity unpinned: the reference holds no known answer for them); what is pinned here is that the oracle evaluates the stated
+forms at the operands the reference's kernels select (invariant, T at I .+ 1 of the ghosted thermal.T, clamped vertex averages, eps() for a zero tensor)."""
+import numpy as np
+import pytest
+
+EPS = np.finfo(float).eps
+CREEP = [dict(kind="dislocation", A=0.5, n=3.0, E=1.0, V=0.1, R=1.0), dict(kind="dislocation", A=2.0, n=3.3, E=0.6, V=0.0, R=1.0, apparatus="Invariant")]
+FTFE = {"AxialCompression": (3.0 ** 0.5, 2.0 / 3.0 ** 0.5), "Invariant": (1.0, 1.0)}
+
+
+def eta_np(cr, AII, T, P, tau):
+    FT, FE = FTFE[cr.get("apparatus", "AxialCompression")]
+    A, n, H = cr["A"], cr["n"], cr["E"] + P * cr["V"]
+    if tau:
+        return 0.5 * AII / (A * (AII * FT) ** n * np.exp(-H / (cr["R"] * T)) / FE)
+    return 0.5 * (A ** (-1.0 / n) * (AII * FE) ** (1.0 / n) * np.exp(H / (n * cr["R"] * T)) / FT) / AII
+
+
+def phase_eta_np(ratios, AII, T, P, tau):
+    """compute_phase_viscosity (Viscosity.jl:599-619)"""
+    out = np.empty(AII.shape)
+    for I in np.ndindex(AII.shape):
+        r = ratios[(slice(None),) + I]
+        pure = np.nonzero(r > 0.999)[0]
+        if pure.size:
+            out[I] = eta_np(CREEP[pure[0]], AII[I], T[I], P[I], tau)
+        else:
+            out[I] = 1.0 / sum(r[q] / eta_np(CREEP[q], AII[I], T[I], P[I], tau) for q in range(len(r)) if r[q] != 0)
+    return out
+
+
+def inv2(xx, yy, xy):
+    a0 = np.where((xx == 0) & (yy == 0) & (xy == 0), EPS, 0.0)
+    return np.sqrt(0.5 * ((xx + a0) ** 2 + (yy - a0) ** 2) + xy ** 2)
+
+
+def _phases(base):
+    return [dict(base[q % len(base)], creep=CREEP[q]) for q in range(2)]
+
+
+def _ratios(rng, shape):
+    r = rng.uniform(0, 1, size=shape)
+    r[rng.uniform(size=shape) < 0.3] = 1.0
+    r[rng.uniform(size=shape) < 0.1] = 0.0
+    return np.asfortranarray(np.stack([r, 1.0 - r]))
+
+
+@pytest.mark.parametrize("tau", [False, True])
+def test_array_form_and_round_trip(oracle, tau):
+    rng = np.random.default_rng(3)
+    ni = (7, 5)
+    rh = oracle.rheology_struct([dict(eta=1.0, G=1.0, Kb=1.0, creep=CREEP[0])])
+    AII = np.asfortranarray(rng.uniform(0.1, 3.0, size=ni)); P = np.asfortranarray(rng.uniform(-1, 1, size=ni))
+    Tg = np.asfortranarray(rng.uniform(0.8, 1.5, size=(9, 7)))
+    eta = np.asfortranarray(np.full(ni, 0.25))
+    oracle.compute_viscosity_single(eta, rh, Tg, P, nu=0.5, AII=AII, tau=tau, cutoff=(0.0, 50.0))
+    want = np.clip(0.5 * 0.25 + 0.5 * eta_np(CREEP[0], AII, Tg[1:-1, 1:-1], P, tau), 0.0, 50.0)
+    np.testing.assert_allclose(eta, want, rtol=1e-13)
+    # the two forms are each other's inverse: η_τ(τ = 2 η_ε(ε) ε) = η_ε(ε)
+    e_eps = eta_np(CREEP[0], AII, 1.1, 0.3, False)
+    np.testing.assert_allclose(eta_np(CREEP[0], 2 * e_eps * AII, 1.1, 0.3, True), e_eps, rtol=1e-12)
+    # Duretz et al. (2014) matrix of the reference's shear-heating tests (Shearheating_rheology.jl:6) at 673 K and the test's background strain rate
+    d = dict(kind="dislocation", A=3.2e-20, n=3.0, E=276.0e3, V=0.0, R=8.3145)
+    rhd = oracle.rheology_struct([dict(eta=1.0, G=1.0, Kb=1.0, creep=d)])
+    e = np.asfortranarray(np.zeros((1, 1))); oracle.compute_viscosity_single(e, rhd, np.full((1, 1), 673.0, order="F"), None, AII=np.full((1, 1), 5e-14, order="F"))
+    assert 1e20 < e[0, 0] < 1e24 and np.isclose(e[0, 0], eta_np(d, 5e-14, 673.0, 0.0, False), rtol=1e-13)
+
+
+@pytest.mark.parametrize("ghosted", [False, True])
+@pytest.mark.parametrize("tau", [False, True])
+def test_phase_form_2d(oracle, jr, tau, ghosted):
+    s = jr.miniapps.shearband2d(12, iterMax=1, nout=1)
+    nx, ny = s.ni
+    rng = np.random.default_rng(11)
+    a = s.arrays
+    for k in ("txx", "tyy", "txy_c", "exx", "eyy", "exy_c", "txy", "exy", "P"):
+        a[k][...] = rng.uniform(-1, 1, size=a[k].shape)
+    for k in ("txx", "tyy", "txy_c", "exx", "eyy", "exy_c"):
+        a[k][2, 3] = 0.0                                         # an all-zero tensor: AII = eps()
+    a["txy"][4, 4] = a["exy"][4, 4] = 0.0
+    a["phase_c"][...] = _ratios(rng, s.ni); a["phase_v"][...] = _ratios(rng, (nx + 1, ny + 1))
+    a["eta"][...] = 1.0; a["eta_v"] = np.asfortranarray(np.full((nx + 1, ny + 1), 2.0))
+    a["T"] = np.asfortranarray(rng.uniform(0.8, 1.5, size=(nx + 2, ny + 2) if ghosted else s.ni))
+    rh = oracle.rheology_struct(_phases(s.extra["phases"]))
+    p = oracle.vep_params2d(s.ni, s.grid._di["center"], s.dt, dict(r=0.7, theta_dtau=1.0, eta_dtau=1.0, eps_rel=0, eps_abs=0), cutoff=(1e-3, 1e3), T_ghosted=ghosted)
+    nu = 0.3
+    oracle.compute_viscosity2d(a, rh, p, nu=nu, tau=tau)
+    pre = "t" if tau else "e"
+    Tc = a["T"][1:-1, 1:-1] if ghosted else a["T"]
+    want = np.clip(nu * phase_eta_np(a["phase_c"], inv2(a[pre + "xx"], a[pre + "yy"], a[pre + "xy_c"]), Tc, a["P"], tau) + (1 - nu) * 1.0, 1e-3, 1e3)
+    np.testing.assert_allclose(a["eta"], want, rtol=1e-12)
+    # vertices: (0, 0, xy), args averaged over the clamped surrounding centres, T over the 2 x 2 nodes of the ghosted array
+    il, ir = np.maximum(np.arange(nx + 1) - 1, 0), np.minimum(np.arange(nx + 1), nx - 1)
+    jb, jt = np.maximum(np.arange(ny + 1) - 1, 0), np.minimum(np.arange(ny + 1), ny - 1)
+    av = lambda A: 0.25 * (A[np.ix_(il, jb)] + A[np.ix_(ir, jb)] + A[np.ix_(il, jt)] + A[np.ix_(ir, jt)])
+    Tv = 0.25 * (a["T"][:-1, :-1] + a["T"][1:, :-1] + a["T"][:-1, 1:] + a["T"][1:, 1:]) if ghosted else av(a["T"])
+    z = np.zeros((nx + 1, ny + 1))
+    wantv = np.clip(nu * phase_eta_np(a["phase_v"], inv2(z, z, a[pre + "xy"]), Tv, av(a["P"]), tau) + (1 - nu) * 2.0, 1e-3, 1e3)
+    np.testing.assert_allclose(a["eta_v"], wantv, rtol=1e-12)
+    assert np.isfinite(a["eta"]).all() and np.isfinite(a["eta_v"]).all()
+
+
+@pytest.mark.parametrize("tau", [False, True])
+def test_phase_form_3d(oracle, jr, tau):
+    s = jr.miniapps.shearband3d((6, 5, 4), iterMax=1, nout=1)
+    nx, ny, nz = s.ni
+    rng = np.random.default_rng(12)
+    a = s.arrays
+    pre = "t" if tau else "e"
+    for k in ("xx", "yy", "zz", "yz", "xz", "xy"):
+        a[pre + k][...] = rng.uniform(-1, 1, size=a[pre + k].shape)
+    for k in ("xx", "yy", "zz"):
+        a[pre + k][1, 2, 3] = 0.0
+    a["P"][...] = rng.uniform(-1, 1, size=s.ni)
+    a["phase_c"][...] = _ratios(rng, s.ni); a["eta"][...] = 1.0
+    a["T"] = np.asfortranarray(rng.uniform(0.8, 1.5, size=(nx + 2, ny + 2, nz + 2)))
+    rh = oracle.rheology_struct(_phases(s.extra["phases"]))
+    p = oracle.vep_params3d(s.ni, s.grid._di["center"], s.dt, dict(r=0.7, theta_dtau=1.0, eta_dtau=1.0, eps_rel=0, eps_abs=0), cutoff=(1e-3, 1e3), T_ghosted=True)
+    oracle.compute_viscosity3d(a, rh, p, nu=1.0, tau=tau)
+    xx, yy, zz, yz, xz, xy = (a[pre + k] for k in ("xx", "yy", "zz", "yz", "xz", "xy"))
+    a0 = np.where((xx == 0) & (yy == 0) & (zz == 0), EPS, 0.0)
+    g = lambda A, ax: 0.25 * sum(np.take(np.take(A, range(o1, o1 + A.shape[ax[0]] - 1), ax[0]), range(o2, o2 + A.shape[ax[1]] - 1), ax[1]) ** 2 for o1 in (0, 1) for o2 in (0, 1))
+    AII = np.sqrt(0.5 * ((xx + a0) ** 2 + (yy - a0 / 2) ** 2 + (zz - a0 / 2) ** 2) + g(yz, (1, 2)) + g(xz, (0, 2)) + g(xy, (0, 1)))
+    lo, hi = p.cutoff_lo, p.cutoff_hi
+    want = np.clip(phase_eta_np(a["phase_c"], AII, a["T"][1:-1, 1:-1, 1:-1], a["P"], tau), lo, hi)
+    np.testing.assert_allclose(a["eta"], want, rtol=1e-12)
