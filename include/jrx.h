@@ -273,6 +273,7 @@ typedef struct jrx_rheology {
      *   compute_εII: ε = creep_A (τII creep_FT)^creep_n exp(-(Ea + P Va)/(Rgas T)) / creep_FE
      *   compute_τII: τ = creep_A^(-1/n) (εII creep_FE)^(1/n) exp((Ea + P Va)/(n Rgas T)) / creep_FT
      *   compute_viscosity_τII = τII / (2 ε(τII)),  compute_viscosity_εII = τ(εII) / (2 εII)      [forms ASSUMED, parity unpinned]
+     * (the 2D single-material driver hands its in-loop compute_viscosity_τII! the strain-rate invariant, as the reference's _compute_viscosity! does.)
      * FT, FE: GeoParams' apparatus corrections (AxialCompression √3, 2/√3; SimpleShear 2, 2; Invariant 1, 1).  One creep element per phase.
      * The invariant a law of kind 2 is evaluated at is the one the reference's kernels form (Viscosity.jl:382-418,455-503): compute_viscosity! from the strain
      * rate, update_viscosity_τII! from the stress, eps() on the normal components of an all-zero tensor. */
