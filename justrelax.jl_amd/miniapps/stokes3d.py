@@ -316,6 +316,54 @@ def shearband3d(n=16, *, iterMax=150_000, nout=1000) -> Setup:
                  extra=dict(li=li, di=di, phases=phases, εbg=εbg, G0=G0, η0=η0))
 
 
+def shearheating3d(n=16, *, iterMax=100_000, nout=1000) -> Setup:
+    """Shearheating3D -- test/test_shearheating3D.jl:62-162 without the particles (phase ratios from 4^3 sample points per node volume): 70 x 70 x 40 km box, dislocation-creep
+    matrix and inclusion of Duretz et al. 2014 (miniapps/benchmarks/stokes3D/shear_heating/Shearheating_rheology.jl:6-7: no elastic, no plastic element), sphere of
+    radius 3 km at 40 km depth, T = 673 K, lithostatic initial pressure (init_P! :55-58), compression at εbg = 5e-14 / s, free slip, solve! with dt = Inf,
+    ϵ_rel = 1e-4, viscosity_cutoff = (1e18, 1e22).  args.T is the ghosted thermal.T (arrays["T"], ni .+ 2)."""
+    ni = (n, n, n) if isinstance(n, int) else tuple(n)
+    nx, ny, nz = ni
+    li = (70.0e3, 70.0e3, 40.0e3)
+    init_global_grid(nx, ny, nz)
+    di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g(), nz_g())))
+    grid = Geometry(ni, li, origin=(0.0, 0.0, -li[2]))
+    inf = float("inf")
+    common = dict(eta=1.0e20, G=inf, Kb=inf, density=dict(kind="constant", rho0=2700.0), conductivity=2.5, heat_capacity=1050.0, shear_heat=1.0)
+    phases = [dict(common, g=9.81, creep=dict(kind="dislocation", A=3.2e-20, n=3.0, E=276.0e3, V=0.0, R=8.3145)),
+              dict(common, creep=dict(kind="dislocation", A=3.16e-26, n=3.3, E=186.0e3, V=0.0, R=8.3145))]
+    arr = {k: np.zeros(s, dtype=np.float64, order="F") for k, s in vep_shapes3d(ni).items()}
+    o, radius = (li[0] / 2, li[1] / 2, 40.0e3), 3.0e3
+    (xc, yc, zc), (xv, yv, zv) = grid.xci, grid.xvi
+    for name, (xs, ys, zs) in (("phase_c", (xc, yc, zc)), ("phase_yz", (xc, yv, zv)), ("phase_xz", (xv, yc, zv)), ("phase_xy", (xv, yv, zc))):
+        X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")                       # init_phases! (Shearheating_rheology.jl:58-80): depth = -z
+        # the reference marks ~100 particles per cell and update_phase_ratios! counts them; here 4^3 sample points of the node's own cell-sized volume
+        frac, sub = np.zeros(X.shape), (np.arange(4) + 0.5) / 4 - 0.5
+        for a in sub:
+            for b in sub:
+                for c in sub:
+                    frac += ((X + a * di[0] - o[0]) ** 2 + (Y + b * di[1] - o[1]) ** 2 + (-(Z + c * di[2]) - o[2]) ** 2) <= radius ** 2
+        frac /= 64.0
+        arr[name][0] = 1.0 - frac
+        arr[name][1] = frac
+    arr["T"] = np.asfortranarray(np.full((nx + 2, ny + 2, nz + 2), 273.0 + 400.0))
+    arr["fz"][...] = 2700.0 * 9.81                                              # compute_ρg!(ρg[3], phase_ratios, rheology, args) :122
+    arr["P"][...] = np.abs(arr["fz"] * zc[None, None, :]) * (zc < 0.0)[None, None, :]
+    εbg = 5.0e-14
+    arr["Vx"][...] = (-(xv - li[0] / 2) * εbg)[:, None, None] * np.ones((1, ny + 2, nz + 2))       # :142-144
+    arr["Vy"][...] = (-(yv - li[1] / 2) * εbg)[None, :, None] * np.ones((nx + 2, 1, nz + 2))
+    arr["Vz"][...] = ((li[2] - np.abs(zv)) * εbg)[None, None, :] * np.ones((nx + 2, ny + 2, 1))
+    _free_slip3d_host(arr)
+    arr["eta"][...] = 1.0e20             # overwritten by compute_viscosity!(stokes, phase_ratios, args, rheology, (-Inf, Inf)) :127
+    pt = PTStokesCoeffs(li, di, ϵ_rel=1.0e-4, CFL=0.9 / math.sqrt(3.1))
+    on = {f: True for f in _F6}
+    bcs = VelocityBoundaryConditions(free_slip=on, no_slip={f: False for f in _F6})
+    κ = 4.0 / (1050.0 * 2700.0)
+    dt_diff = 0.5 * min(di) ** 3 / κ / 3.01                                     # :79 (as written)
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=inf, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False, viscosity_cutoff=(1.0e18, 1.0e22)),
+                 extra=dict(li=li, di=di, phases=phases, εbg=εbg, dt_diff=dt_diff))
+
+
 def solvi3d_device(n, backend_tag, *, Δη=1.0e-3, li=(10.0, 10.0, 10.0), rc=1.0, εbg=1.0, update_halo=None):
     """SolVi3D built directly in device memory (for sizes whose host copy would not fit: 512³ needs
     ≈48 GB of fields).  Same construction as `solvi3d` (torch elementwise ops instead of numpy);

@@ -181,3 +181,31 @@ def test_single_material_driver_with_power_law_creep_matches_oracle(jr, oracle):
     out = {k: jr.to_numpy(_get(st, path)) for k, path in VEP_MAP.items()}
     for k in out:
         assert max_rel_diff(out[k], ref[k]) <= 1e-7, k
+
+
+def test_shearheating3d_reference_test_on_the_device(jr, oracle):
+    """test/test_shearheating3D.jl:237-252 (particle-free restatement, jr.miniapps.shearheating3d): solve! with dt = Inf on the Duretz et al. dislocation-creep
+    phases -> tensor_invariant! -> compute_dt -> compute_shear_heating!; the reference asserts `iters.err_evo1[end] < 1e-4` and a non-negative shear heating.
+    The converged state is also compared with the oracle's (1e-6: two thousand iterations of a solve whose viscosity follows its own stress)."""
+    from justrelax_jl_amd.arrays import from_numpy
+    from justrelax_jl_amd.checks import max_rel_diff
+    from test_gpu_vep3d import _download, _params, _upload
+    s = jr.miniapps.shearheating3d(16)
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes3d_vep_solve(ref, oracle.rheology_struct(s.extra["phases"]), _params(oracle, s, T_ghosted=True, cutoff=s.kwargs["viscosity_cutoff"]))
+    stokes, pr, ρg = _upload(jr, s)
+    T = from_numpy(s.arrays["T"], stokes.P.device)
+    phases = s.extra["phases"]
+    jr.compute_viscosity_(stokes, pr, dict(T=T, P=stokes.P), phases, (-np.inf, np.inf))          # :127 (the solve repeats it with its cutoff)
+    assert np.isfinite(jr.to_numpy(stokes.viscosity.η)).all()
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, phases, dict(T=T, P=stokes.P), s.dt, None, kwargs=s.kwargs)
+    assert r.err_evo1[-1] < 1e-4 and r.iter == r_ref["iter"]
+    out = _download(jr, stokes)
+    for k in ("Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy", "eta", "P"):
+        assert max_rel_diff(out[k], ref[k]) <= 1e-6, k
+    jr.tensor_invariant_(stokes.ε)
+    dt = jr.compute_dt_(stokes, s.extra["di"], s.extra["dt_diff"]) * 0.1
+    thermal = jr.ThermalArrays(jr.AMDGPUBackend, s.ni)
+    jr.compute_shear_heating_(thermal, stokes, pr, phases, dt)
+    sh = jr.to_numpy(thermal.shear_heating)
+    assert (sh >= 0).all() and sh.max() > 0                                                        # :251

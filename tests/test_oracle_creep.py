@@ -128,3 +128,17 @@ def test_phase_form_3d(oracle, jr, tau):
     lo, hi = p.cutoff_lo, p.cutoff_hi
     want = np.clip(phase_eta_np(a["phase_c"], AII, a["T"][1:-1, 1:-1, 1:-1], a["P"], tau), lo, hi)
     np.testing.assert_allclose(a["eta"], want, rtol=1e-12)
+
+
+def test_shearheating3d_setup_converges_as_the_reference_test_requires(oracle, jr):
+    """test/test_shearheating3D.jl:250: `iters.err_evo1[end] < 1e-4` for the Stokes solve of the dislocation-creep setup (particle-free restatement of the script)"""
+    s = jr.miniapps.shearheating3d(16)
+    a = s.arrays
+    assert 0 < a["phase_c"][1].sum() < 8 and np.allclose(a["phase_c"].sum(axis=0), 1.0)          # the 3 km inclusion covers a few bottom cells partially
+    pt, b = s.pt, s.flow_bcs
+    p = oracle.vep_params3d(s.ni, s.grid._di["center"], s.dt, dict(r=pt.r, theta_dtau=pt.θ_dτ, eta_dtau=pt.ηdτ, eps_rel=pt.ϵ_rel, eps_abs=pt.ϵ_abs),
+                            free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic, iterMax=s.kwargs["iterMax"], nout=s.kwargs["nout"],
+                            cutoff=s.kwargs["viscosity_cutoff"], T_ghosted=True)
+    r = oracle.stokes3d_vep_solve(a, oracle.rheology_struct(s.extra["phases"]), p)
+    assert r["iter"] < 20_000 and r["err_evo1"][-1] < 1e-4
+    assert a["eta"].min() >= 1e18 and a["eta"].max() <= 1e22 and np.ptp(np.log10(a["eta"])) > 0.5      # weak inclusion, cutoff respected
