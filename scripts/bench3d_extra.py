@@ -23,13 +23,19 @@ def timed(fn, warm, iters):
     return (time.perf_counter() - t0), r
 
 
-def shearband3d(n=256, iters=100, soft=False):
+def shearband3d(n=256, iters=100, soft=False, creep=False):
     s = jr.miniapps.shearband3d(n, iterMax=iters - 1, nout=10 ** 9)
     if soft:      # a softening law on C and phi of the matrix phase: the yield function then reads EII_pl
         ph = [dict(p) for p in s.extra["phases"]]
         ph[0].update(softening_C=dict(kind="linear", min=0.5 * ph[0]["C"], max=ph[0]["C"], lo=0.0, hi=0.1),
                      softening_phi=dict(kind="nonlinear", xi0=30.0, Delta=10.0, mu=0.2, sigma=0.1))
         s.extra["phases"] = ph
+    if creep:     # power-law (dislocation) creep on both phases: update_viscosity_τII! then reads the stress tensor (normals + 12 gathered edge values) every iteration
+        ph = [dict(p) for p in s.extra["phases"]]
+        ph[0].update(creep=dict(kind="dislocation", A=0.5, n=3.0, E=1.0, V=0.1, R=1.0))
+        ph[1].update(creep=dict(kind="dislocation", A=2.0, n=3.3, E=0.6, V=0.0, R=1.0, apparatus="Invariant"))
+        s.extra["phases"] = ph
+        s.kwargs["viscosity_cutoff"] = (1e-2, 1e2)
     s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
     st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
     for k, path in dict(Vx="V.Vx", Vy="V.Vy", Vz="V.Vz", eta="viscosity.η").items():
@@ -42,12 +48,16 @@ def shearband3d(n=256, iters=100, soft=False):
         getattr(pr, name).copy_(from_numpy(s.arrays[k], dev))
     del s.arrays
     ρg = tuple(jr.fzeros(s.ni, dev) for _ in range(3))
+    args = dict(T=jr.fzeros(tuple(n_ + 2 for n_ in s.ni), dev, 1.1), P=st.P) if creep else None
     def run(k):
-        return jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=dict(iterMax=k - 1, nout=10 ** 9, verbose=False))
+        kw = dict(iterMax=k - 1, nout=10 ** 9, verbose=False)
+        if creep:
+            kw.update(viscosity_cutoff=(1e-2, 1e2), viscosity_relaxation=0.1)
+        return jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], args, s.dt, None, kwargs=kw)
     el, r = timed(run, 5, iters)
     cells = float(np.prod(s.ni))
     # as written: stress kernel reads ~70 array values per cell (3 edge families + centre), pressure/strain 14, viscosity 2, velocity 17, + phase arrays
-    print(json.dumps(dict(config="shear band 3D multiphase VEP" + (" with softening laws" if soft else ""), n=n, iters=r.iter, it_per_s=r.iter / el, ms_per_it=el / r.iter * 1e3,
+    print(json.dumps(dict(config="shear band 3D multiphase VEP" + (" with softening laws" if soft else "") + (" with power-law creep" if creep else ""), n=n, iters=r.iter, it_per_s=r.iter / el, ms_per_it=el / r.iter * 1e3,
                           Mcell_updates_per_s=cells * r.iter / el / 1e6)))
 
 
@@ -103,4 +113,4 @@ if __name__ == "__main__":
     elif nt > 0:
         thermal3d(nt)
     if nv > 0:
-        shearband3d(nv, soft=soft)
+        shearband3d(nv, soft=soft, creep="creep" in sys.argv[3:])
