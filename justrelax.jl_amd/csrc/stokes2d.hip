@@ -1428,7 +1428,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                            (const double *)f->Uy, (i64)(nx + 2) * (ny + 1), (double *)nullptr, (const double *)nullptr, (i64)0, 1.0 / p->dt);
         JRX_LAUNCH_CHECK(h);
     }
-    b.fs_dt = p->dt * (double)(p->free_surface != 0);
+    b.fs_dt = p->free_surface ? p->dt : 0.0;      // dt * free_surface with a Bool: Inf * false == 0.0 in Julia (solve! with dt = Inf)
 
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
@@ -1644,7 +1644,7 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
     q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau; q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
     for (int d = 0; d < 6; d++) q.inv_spacing[d] = p->inv_spacing[d];
     Args2 b = make_args2(&g, etatau, &q);
-    b.fs_dt = p->dt * (double)(p->free_surface != 0);
+    b.fs_dt = p->free_surface ? p->dt : 0.0;      // dt * free_surface with a Bool: Inf * false == 0.0 in Julia (solve! with dt = Inf)
     const unsigned gv = (unsigned)((nv + 255) / 256), gc = (unsigned)((n + 255) / 256);
     const bool tg = p->T_ghosted != 0, ubc = p->displacement_bcs != 0;
     const bool upd_rho = rh->has_density && rh->rho_kind[0] != 0;

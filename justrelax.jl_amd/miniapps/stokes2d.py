@@ -173,6 +173,52 @@ def shearband2d(n=32, *, iterMax=50_000, nout=100, xvi=None) -> Setup:
                  extra=dict(li=li, di=di, phases=phases, εbg=εbg, G0=G0, η0=η0))
 
 
+def shearheating2d(n=32, *, iterMax=75_000, nout=1000) -> Setup:
+    """Shearheating2D -- test/test_shearheating2D.jl:66-232 without the particles (phase ratios from 8 x 8 sample points per cell / vertex area): 70 x 40 km box,
+    dislocation-creep matrix and inclusion of Duretz et al. 2014 (Shearheating_rheology.jl:6-7; no elastic or plastic element), disc of radius 3 km at 40 km depth,
+    T = 673 K, lithostatic initial pressure (:60-63), compression at εbg = 5e-14 / s, free slip, solve! with dt = Inf, ϵ_abs = ϵ_rel = 1e-5,
+    viscosity_cutoff = (-Inf, Inf).  args.T is the ghosted thermal.T (arrays["T"], ni .+ 2)."""
+    nx = ny = n
+    ni, li = (nx, ny), (70.0e3, 40.0e3)
+    init_global_grid(nx, ny, 1)
+    di = tuple(l / m for l, m in zip(li, ni))
+    grid = Geometry(ni, li, origin=(0.0, -li[1]))
+    inf = float("inf")
+    common = dict(eta=1.0e20, G=inf, Kb=inf, density=dict(kind="constant", rho0=2700.0), conductivity=2.5, heat_capacity=1050.0, shear_heat=1.0)
+    phases = [dict(common, g=9.81, creep=dict(kind="dislocation", A=3.2e-20, n=3.0, E=276.0e3, V=0.0, R=8.3145)),
+              dict(common, creep=dict(kind="dislocation", A=3.16e-26, n=3.3, E=186.0e3, V=0.0, R=8.3145))]
+    arr = {k: np.zeros(shp, dtype=np.float64, order="F") for k, shp in _vep_shapes2d(nx, ny, 2).items()}
+    ox, depth0, radius = li[0] / 2, 40.0e3, 3.0e3
+    sub = (np.arange(8) + 0.5) / 8 - 0.5
+    for name, (xs, ys) in (("phase_c", grid.xci), ("phase_v", grid.xvi)):
+        X, Y = np.meshgrid(xs, ys, indexing="ij")
+        frac = np.zeros(X.shape)
+        for a in sub:
+            for b in sub:
+                frac += ((X + a * di[0] - ox) ** 2 + (-(Y + b * di[1]) - depth0) ** 2) <= radius ** 2
+        frac /= 64.0
+        arr[name][0] = 1.0 - frac
+        arr[name][1] = frac
+    arr["T"] = np.asfortranarray(np.full((nx + 2, ny + 2), 273.0 + 400.0))
+    yc = grid.xci[1]
+    arr["fy"][...] = 2700.0 * 9.81                                             # compute_ρg!(ρg[2], phase_ratios, rheology, args) :118
+    arr["P"][...] = np.abs(arr["fy"] * yc[None, :]) * (yc < 0.0)[None, :]
+    εbg = 5.0e-14
+    xv, yv = grid.xvi
+    arr["Vx"][...] = (-(xv - li[0] / 2) * εbg)[:, None] * np.ones((1, ny + 2))                 # :134-135
+    arr["Vy"][...] = ((li[1] - np.abs(yv)) * εbg)[None, :] * np.ones((nx + 2, 1))
+    _free_slip2d_host(arr)
+    arr["eta"][...] = 1.0e20             # overwritten by compute_viscosity!(stokes, phase_ratios, args, rheology, (-Inf, Inf)) :122
+    arr["eta_v"][...] = 1.0e20
+    pt = PTStokesCoeffs(li, di, ϵ_abs=1.0e-5, ϵ_rel=1.0e-5, CFL=0.9 / math.sqrt(2.1))
+    bcs = VelocityBoundaryConditions(free_slip={f: True for f in _F4}, no_slip={f: False for f in _F4})
+    κ = 4.0 / (1050.0 * 2700.0)
+    dt_diff = 0.5 * min(di) ** 2 / κ / 2.01
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=pt, dt=inf, flow_bcs=bcs,
+                 kwargs=dict(iterMax=iterMax, nout=nout, verbose=False, viscosity_cutoff=(-np.inf, np.inf)),           # :172
+                 extra=dict(li=li, di=di, phases=phases, εbg=εbg, dt_diff=dt_diff))
+
+
 def sinking_block2d(n=32, *, iterMax=150_000, nout=1000, sub=16) -> Setup:
     """Sinking_Block2D -- test/test_sinking_block.jl:93-203: a 500 km box, a 100 km square block (LinearViscous 1e23, ρ = 3300) at 400 km height in a mantle
     (1e21, ρ = 3200), g = 9.81, no elasticity, free slip, lithostatic initial pressure, dt = 1; the multiphase visco-elasto-plastic 2D solve! with a purely

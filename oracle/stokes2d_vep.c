@@ -401,7 +401,7 @@ int32_t orc_stokes2d_vep_solve(const orc_vep2d *f, const orc_rheology *rh, const
         for (size_t c = 0; c < (size_t)(nx + 1) * (ny + 2); c++) f->Vx[c] = f->Ux[c] * _dt;
         for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 1); c++) f->Vy[c] = f->Uy[c] * _dt;
     }
-    const double fs_dt = p->dt * (double)(p->free_surface != 0);
+    const double fs_dt = p->free_surface ? p->dt : 0.0;      /* dt * free_surface with a Bool: Julia's false is a strong zero, Inf * false == 0.0 */
 
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
@@ -535,7 +535,7 @@ int32_t orc_stokes2d_nonlinear_solve(const orc_vep2d *f, const orc_rheology *rh,
         for (size_t c = 0; c < (size_t)(nx + 1) * (ny + 2); c++) f->Vx[c] = f->Ux[c] * _dt;
         for (size_t c = 0; c < (size_t)(nx + 2) * (ny + 1); c++) f->Vy[c] = f->Uy[c] * _dt;
     }
-    const double fs_dt = p->dt * (double)(p->free_surface != 0);
+    const double fs_dt = p->free_surface ? p->dt : 0.0;      /* dt * free_surface with a Bool: Julia's false is a strong zero, Inf * false == 0.0 */
 
     orc_fields2d g;
     memset(&g, 0, sizeof(g));

@@ -209,3 +209,30 @@ def test_shearheating3d_reference_test_on_the_device(jr, oracle):
     jr.compute_shear_heating_(thermal, stokes, pr, phases, dt)
     sh = jr.to_numpy(thermal.shear_heating)
     assert (sh >= 0).all() and sh.max() > 0                                                        # :251
+
+
+def test_shearheating2d_reference_script_on_the_device(jr, oracle):
+    """test/test_shearheating2D.jl:66-190 (particle-free, jr.miniapps.shearheating2d): 2D multiphase solve! with dt = Inf and dislocation-creep phases ->
+    tensor_invariant! -> compute_dt -> compute_shear_heating! >= 0 (:246); state compared with the oracle's run of the same script."""
+    from justrelax_jl_amd.arrays import from_numpy
+    from justrelax_jl_amd.checks import max_rel_diff
+    from test_gpu_vep2d import _download, _upload, _vep_params
+    s = jr.miniapps.shearheating2d(32)
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes2d_vep_solve(ref, oracle.rheology_struct(s.extra["phases"]), _vep_params(oracle, s, T_ghosted=True, cutoff=s.kwargs["viscosity_cutoff"]))
+    stokes, pr, ρg = _upload(jr, s)
+    stokes.viscosity.ηv.fill_(1.0e20)
+    T = from_numpy(s.arrays["T"], stokes.P.device)
+    phases = s.extra["phases"]
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, phases, dict(T=T, P=stokes.P), s.dt, None, kwargs=s.kwargs)
+    assert r.iter == r_ref["iter"] and np.isfinite(r.err_evo1).all()
+    assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-5)
+    out = _download(jr, stokes)
+    for k in ("Vx", "Vy", "txx", "tyy", "txy", "eta", "P"):
+        assert max_rel_diff(out[k], ref[k]) <= 1e-6, k
+    jr.tensor_invariant_(stokes.ε)
+    dt = jr.compute_dt_(stokes, s.extra["di"], s.extra["dt_diff"]) * 0.1
+    thermal = jr.ThermalArrays(jr.AMDGPUBackend, s.ni)
+    jr.compute_shear_heating_(thermal, stokes, pr, phases, dt)
+    sh = jr.to_numpy(thermal.shear_heating)
+    assert (sh >= 0).all() and sh.max() > 0
