@@ -433,7 +433,7 @@ def run_rank(args) -> int:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(args.variant))
     for kv in args.option:
         k, v = kv.split("=")
-        h.call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(int(v)))
+        h.set_option(k, int(v))
     rccl_ranks = 0
     if world > 1 or self_halo:
         halo.init_comm(h, self_rccl=self_halo)

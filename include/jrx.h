@@ -63,7 +63,9 @@ int32_t jrx_version(void);
  * the sources beside it */
 const char *jrx_build_id(void);
 
-/* Tuning / debugging knobs.  Keys: "kernel_variant" (3D Stokes):
+/* Options of the handle: what a caller of solve! may want to choose.  (The A/B switches of the measurements in profiles/ and the test
+ * hooks are NOT part of this ABI: include/jrx_tuning.h.)  The library never reads the process environment.  Keys:
+ * "kernel_variant" (3D Stokes):
  *   0 = default: fused PT pipeline where it applies (no periodic_boundary! faces, nx >= 48, ny, nz >= 8, and nx fills
  *       its 62-column tiles to >= 71 %): one kernel runs velocity sweep m + BCs + stress sweep m+1 with ping-pong
  *       state arrays (the handle then owns a second set of the 10 state arrays); with a communicator the exchange
@@ -71,23 +73,17 @@ const char *jrx_build_id(void);
  *       results are observed, the two z-marching sweeps;
  *   1 = simple one-thread-per-node kernels;  2 = z-marching sweeps only (two launches per iteration, no ping-pong set);
  *   3 = fused pipeline wherever it is legal (ignores the tile-fill rule).  All variants produce bit-identical results.
+ * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
  * "fused_overlap" (0/1, default 0): multi-rank fused pipeline with the shell of tiles, BCs and exchange on a second
  *   stream while the interior tiles run (same results).
  * "thermal_fused" (0/1, default 1): jrx_heatdiffusion_PT2d / _PT3d run unobserved iterations as one fused launch with a
  *   library-owned second (T, qT) set; 0 = always compute_flux! and update_T! as two launches (same results).
  * "scratch_sets" (0/1, default 1): 0 forbids every library-owned second state set (3D fused pipeline: + 10 arrays, i.e.
  *   + 10.8 GB at 512^3; 2D fused loop; fused heat diffusion) -- the un-fused kernels then run; same results, less memory.
- * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
- * "vep3_edges" (0/1/2, default 1): edge pass of the 3D visco-elasto-plastic stress update: 1 = z-marching kernel, one edge family per
- *   block, the three blocks of a tile on one XCD; 2 = the same kernel as one launch per family; 0 = one node per thread (always used with
- *   more than 4 phases).  Same results.  "vep3_cfg" = KZ * 10 + min blocks per CU (tuning).  "vep3_peel" (default 1): a last lane segment of the z-marching
- *   launch that would be less than 40 % full goes to the node kernel in a thin launch of its own (0 = launch it anyway; same results).
- * "loop_graphs" (0/1, default 1): runs of unobserved iterations of the launch-bound 2D loops (2D heat diffusion, 2D visco-elastic Stokes on the grids that use
- *   k_fused2d, 2D visco-elasto-plastic Stokes and the two-kernel forms of 2D heat diffusion below 200 k nodes, the single-phase non-linear 2D driver) replay as captured hipGraphs of 32 iterations; same results, shorter gaps between launches.
- * "fused_ylds", "fused2d", "vep3_map", "vep3_xcd", "thermal_cfg", "thermal_xg", "b_width_x/y/z": kernel-form / tile-shape A/B
- *   switches used by the measurements in profiles/ (results never change); "halo_self_rccl" (0/1): test hook, a rank that is its
- *   own periodic neighbour routes its planes through ncclSend/ncclRecv on a one-rank communicator.
- * The library never reads the process environment: every switch is an option of the handle. */
+ * "loop_graphs" (0/1, default 1): runs of unobserved iterations of the launch-bound loops (the 2D loops; the 3D loops on small grids) replay as
+ *   captured hipGraphs; same results, shorter gaps between launches.
+ * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
+ *   kernels since jrx_create, "stat_graph_replays" = hipGraphLaunch calls -- so that a caller (and the tests) can prove which path ran. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value);
 
@@ -117,7 +113,16 @@ int64_t jrx_n_global(int64_t n, int32_t dims, int32_t periodic);   /* nx_g() */
 jrx_status jrx_comm_unique_id(uint8_t id[JRX_UNIQUE_ID_BYTES]);
 jrx_status jrx_comm_init(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], const jrx_cart *cart);
 jrx_status jrx_comm_destroy(jrx_handle *h);
-/* ncclCommCount of the handle's communicator: the number of ranks RCCL itself reports (0 = no RCCL communicator) */
+/* The same communicator for ranks that are handles of ONE process (in-process transport): handles[r] becomes rank r of carts[r]
+ * (carts[r].rank == r, carts[r].nprocs == n); the handles may sit on one device or on peer-accessible devices.  update_halo! then
+ * pushes the packed planes into the neighbour's receive buffer with hipMemcpyAsync / hipMemcpyPeerAsync on the exchange's stream
+ * (copy engines instead of send/recv kernels), ordered by events; norms are all-reduced on the host in rank order.  Afterwards every
+ * rank must be driven by its own host thread: the entry points that exchange (the solves, jrx_update_halo, jrx_compute_dt) meet on
+ * the host and return JRX_ERR_RCCL after 120 s if a neighbour never arrives.  Replaces the same call sites as jrx_comm_init
+ * (update_halo! / norm_mpi of src/stokes/Stokes3D.jl:57,120,127-147); jrx_comm_destroy leaves the group. */
+jrx_status jrx_comm_init_local(jrx_handle *const *handles, int32_t n, const jrx_cart *carts);
+/* the number of ranks of the handle's communicator: ncclCommCount as RCCL itself reports it, or the size of the in-process group
+ * (0 = neither) */
 jrx_status jrx_comm_count(jrx_handle *h, int32_t *count);
 /* update_halo!(A...) for up to 8 arrays, each of extents ext[a][0..2] on a local grid of n cells
  * (call sites: src/stokes/Stokes3D.jl:57,120; src/stokes/Stokes2D.jl:209,268;

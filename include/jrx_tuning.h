@@ -1,0 +1,28 @@
+/* jrx_tuning.h -- tuning / A-B / test switches of libjrx_hip.  NOT part of the drop-in ABI (include/jrx.h): nothing a caller of
+ * solve! needs is here, results never depend on any of these, and keys may change between builds.  They exist so that the
+ * measurements under profiles/ and the parity tests can select a kernel form at run time instead of rebuilding.
+ *
+ * Keys (int64 values):
+ *   "fused_ylds" (default 1)      3D fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form)
+ *   "fused_tile" (0)              3D fused kernel tile: 0 = 64 x 4 threads, 1 = 32 x 8
+ *   "fused_split" (0)             no neighbours: high-face tiles + boundary stress layers forked onto the halo stream
+ *   "b_width_x/y/z" (0)           > 0 overrides jrx_stokes3d_params.b_width of the split sweeps
+ *   "fused2d" (1)                 2D visco-elastic loop: one-launch iterations on launch-bound grids
+ *   "vep3_edges" (1)              3D VEP edge pass: 1 = z-marching kernel, one family per block; 2 = one launch per family; 0 = one node per thread
+ *   "vep3_cfg", "vep3_peel", "vep3_map", "vep3_xcd"     z-marching edge kernel: chunk depth / occupancy, peeling of a thin last segment, thread map, XCD slabs
+ *   "thermal_cfg", "thermal_xg"   fused 3D heat-diffusion tile shape / XCD band
+ *   "halo_self_rccl" (0)          test hook: a rank that is its own periodic neighbour routes its planes through ncclSend/ncclRecv
+ *   "comm_timeout_ms" (120000)    in-process transport (jrx_comm_init_local): how long a rank waits on the host for a neighbour
+ */
+#ifndef JRX_TUNING_H
+#define JRX_TUNING_H
+#include "jrx.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+jrx_status jrx_tuning_set(jrx_handle *h, const char *key, int64_t value);
+jrx_status jrx_tuning_get(jrx_handle *h, const char *key, int64_t *value);
+#ifdef __cplusplus
+}
+#endif
+#endif

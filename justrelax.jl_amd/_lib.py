@@ -156,11 +156,16 @@ class Cart(C.Structure):
                 ("periods", C.c_int32 * 3), ("neighbor", (C.c_int32 * 2) * 3)]
 
 
-def declared_symbols() -> list:
-    """Every function include/jrx.h declares."""
-    txt = HEADER.read_text()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(jrx_[A-Za-z0-9_]+)\s*\(", txt)))
+TUNING_HEADER = HERE.parent / "include" / "jrx_tuning.h"
+
+
+def declared_symbols(headers=None) -> list:
+    """Every function include/jrx.h (the drop-in ABI) and include/jrx_tuning.h (tuning / test switches) declare."""
+    out = set()
+    for hp in (headers or (HEADER, TUNING_HEADER)):
+        txt = re.sub(r"/\*.*?\*/", "", hp.read_text(), flags=re.S)
+        out |= set(re.findall(r"\b(jrx_[A-Za-z0-9_]+)\s*\(", txt))
+    return sorted(out)
 
 
 _lib = None
@@ -221,6 +226,18 @@ class Handle:
 
     def call(self, name, *args):
         self.check(getattr(self.lib, name)(self._h, *args))
+
+    def set_option(self, key: str, value: int):
+        """jrx_set_option for the keys of the public ABI, jrx_tuning_set for the tuning / test switches of include/jrx_tuning.h"""
+        k = C.c_char_p(key.encode())
+        if self.lib.jrx_set_option(self._h, k, C.c_int64(int(value))) != 0:
+            self.check(self.lib.jrx_tuning_set(self._h, k, C.c_int64(int(value))))
+
+    def get_option(self, key: str) -> int:
+        k, v = C.c_char_p(key.encode()), C.c_int64()
+        if self.lib.jrx_get_option(self._h, k, C.byref(v)) != 0:
+            self.check(self.lib.jrx_tuning_get(self._h, k, C.byref(v)))
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -7,10 +7,36 @@
 // propagate) every array's boundary plane is packed into one contiguous buffer per side, exchanged
 // with ncclSend/ncclRecv inside one group, and unpacked into the ghost plane.  librccl is
 // dlopen'ed on first use so that single-GPU users never load it.
+//
+// Second transport, "local" (jrx_comm_init_local): the ranks are handles of ONE process, each driven by its own host thread, on one
+// device or on peer-accessible devices.  The packed planes are pushed straight into the neighbour's receive buffer with
+// hipMemcpyAsync / hipMemcpyPeerAsync (copy engines: no send/recv kernel holding CUs beside the interior kernel), ordered by events:
+// the receiver's stream waits on the sender's "sent" event before unpacking, the sender's stream waits on the receiver's "unpacked"
+// event of the previous exchange before overwriting the buffer.  Which records have been issued is agreed through per-link sequence
+// numbers under the group's mutex; the host never waits for the device.  Norms are all-reduced on the host in rank order.
 #include "jrx_internal.hpp"
 #include <dlfcn.h>
 #include <cstdlib>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <rccl/rccl.h>
+
+struct jrx_comm_state;
+static constexpr int kMaxLocalRanks = 64;
+// the ranks of an in-process group (local transport)
+struct jrx_local_group {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 0;
+    jrx_comm_state *member[kMaxLocalRanks] = {};
+    int refs = 0;
+    bool failed = false;                     // a member left or timed out: every wait returns an error instead of blocking
+    double slot[2][kMaxLocalRanks][8] = {};  // host all-reduce: the values of generation g live in slot[g & 1]
+    int arrived = 0;
+    uint64_t gen = 0;
+    double timeout_s = 120.0;
+};
 
 struct jrx_comm_state {
     void *lib = nullptr;
@@ -30,6 +56,14 @@ struct jrx_comm_state {
     size_t cap = 0;     // doubles per buffer
     double *d_red = nullptr;
     bool self_through_rccl = false;   // option halo_self_rccl = 1: route self-neighbour planes through ncclSend/ncclRecv (test hook)
+    // ---- local transport (jrx_comm_init_local); sequence numbers are guarded by grp->m
+    jrx_local_group *grp = nullptr;
+    int device = 0;
+    double *lrbuf[3][2] = {};          // receive buffer per (dimension, side): written by the neighbour's copy
+    size_t lcap[3][2] = {};
+    hipEvent_t ev_sent[3][2] = {}, ev_unpacked[3][2] = {};
+    uint64_t ready[3][2] = {}, sent[3][2] = {};   // exchanges entered (buffer large enough, previous unpack recorded) / pushed, per link
+    int64_t stat_bytes_pushed = 0;
 };
 
 namespace {
@@ -117,20 +151,137 @@ static bool has_self_neighbor(const jrx_cart &c)
 bool jrx_comm_active(const jrx_handle *h)
 {
     if (!h || !h->comm) return false;
-    return (h->comm->comm && h->comm->cart.nprocs > 1) || has_self_neighbor(h->comm->cart);
+    return ((h->comm->comm || h->comm->grp) && h->comm->cart.nprocs > 1) || has_self_neighbor(h->comm->cart);
 }
 int jrx_comm_rank(const jrx_handle *h) { return (h && h->comm) ? h->comm->cart.rank : 0; }
+void jrx_comm_set_timeout(jrx_handle *h, double seconds)
+{
+    if (!h || !h->comm || !h->comm->grp) return;
+    std::lock_guard<std::mutex> lk(h->comm->grp->m);
+    h->comm->grp->timeout_s = seconds;
+}
 // does update_halo! overwrite the boundary plane of dimension d on side 0 (low) / 1 (high)?
 bool jrx_comm_has_neighbor(const jrx_handle *h, int d, int side) { return jrx_comm_active(h) && h->comm->cart.neighbor[d][side] >= 0; }
+
+
+// ------------------------------------------------------------------------------------------------ local transport
+// wait (under the group's mutex) until pred() holds; an absent peer is an error after timeout_s, never a hang
+template <class Pred>
+static jrx_status local_wait(jrx_handle *h, jrx_local_group *g, std::unique_lock<std::mutex> &lk, Pred pred, const char *what)
+{
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(g->timeout_s);
+    while (!pred()) {
+        if (g->failed) return jrx_fail(h, JRX_ERR_RCCL, "local transport: a rank of the group failed or left while this one waited for %s", what);
+        if (g->cv.wait_until(lk, deadline) == std::cv_status::timeout && !pred()) {
+            g->failed = true;
+            g->cv.notify_all();
+            return jrx_fail(h, JRX_ERR_RCCL, "local transport: timed out after %.0f s waiting for %s (every rank of the group must be driven "
+                                              "by its own host thread, all in the same call sequence)", g->timeout_s, what);
+        }
+    }
+    return JRX_OK;
+}
+
+// norm_mpi / maximum_mpi over the ranks of an in-process group: deposit, barrier, combine in rank order (every rank gets the same bits)
+static jrx_status local_allreduce(jrx_handle *h, jrx_comm_state *c, double *vals, int count, int op)
+{
+    jrx_local_group *g = c->grp;
+    std::unique_lock<std::mutex> lk(g->m);
+    if (g->failed) return jrx_fail(h, JRX_ERR_RCCL, "local transport: the group has failed");
+    const uint64_t gen = g->gen;
+    double (*slot)[8] = g->slot[gen & 1];
+    for (int i = 0; i < count; i++) slot[c->cart.rank][i] = vals[i];
+    if (++g->arrived == g->n) {
+        g->arrived = 0;
+        g->gen++;
+        g->cv.notify_all();
+    } else {
+        JRX_TRY(local_wait(h, g, lk, [&] { return g->gen != gen; }, "the all-reduce of the other ranks"));
+    }
+    // slot[gen & 1] is overwritten at generation gen + 2 at the earliest, which every rank enters only after this read (it holds the mutex)
+    for (int i = 0; i < count; i++) {
+        double acc = slot[0][i];
+        for (int r = 1; r < g->n; r++) acc = op == 1 ? fmax(acc, slot[r][i]) : acc + slot[r][i];
+        vals[i] = acc;
+    }
+    return JRX_OK;
+}
+
+// one dimension of update_halo! between handles of this process.  The send planes are already packed into c->sbuf[side] on `s`.
+static jrx_status local_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream_t s, int dim, const int nb[2], size_t total, PlaneSet &S, int gx, int na)
+{
+    jrx_local_group *g = c->grp;
+    uint64_t k[2] = {0, 0};
+    for (int side = 0; side < 2; side++) {
+        if (nb[side] < 0) continue;
+        if (c->lcap[dim][side] < total) {
+            // nobody is copying into the old buffer: its last copy was waited for by the unpack behind it on this handle's streams
+            JRX_HIP(h, hipStreamSynchronize(h->stream));
+            JRX_HIP(h, hipStreamSynchronize(h->halo_stream));
+            if (c->lrbuf[dim][side]) JRX_HIP(h, hipFree(c->lrbuf[dim][side]));
+            c->lrbuf[dim][side] = nullptr; c->lcap[dim][side] = 0;
+            JRX_HIP(h, hipMalloc(&c->lrbuf[dim][side], total * sizeof(double)));
+            c->lcap[dim][side] = total;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        for (int side = 0; side < 2; side++)
+            if (nb[side] >= 0) k[side] = ++c->ready[dim][side];
+    }
+    g->cv.notify_all();
+    // push: my send plane of `side` lands in the neighbour's receive buffer of the opposite side
+    for (int side = 0; side < 2; side++) {
+        if (nb[side] < 0) continue;
+        const int opp = 1 - side;
+        jrx_comm_state *peer = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            JRX_TRY(local_wait(h, g, lk, [&] { return g->member[nb[side]] && g->member[nb[side]]->ready[dim][opp] >= k[side]; }, "a neighbour to enter update_halo!"));
+            peer = g->member[nb[side]];
+        }
+        if (peer->lcap[dim][opp] < total) return jrx_fail(h, JRX_ERR_ARG, "local transport: the neighbour exchanges %zu values where this rank sends %zu "
+                                                                            "(the ranks of a group must call update_halo! with the same arrays)", peer->lcap[dim][opp], total);
+        if (k[side] > 1) JRX_HIP(h, hipStreamWaitEvent(s, peer->ev_unpacked[dim][opp], 0));     // its previous unpack from that buffer
+        if (peer->device == c->device) JRX_HIP(h, hipMemcpyAsync(peer->lrbuf[dim][opp], c->sbuf[side], total * sizeof(double), hipMemcpyDeviceToDevice, s));
+        else JRX_HIP(h, hipMemcpyPeerAsync(peer->lrbuf[dim][opp], peer->device, c->sbuf[side], c->device, total * sizeof(double), s));
+        JRX_HIP(h, hipEventRecord(c->ev_sent[dim][side], s));
+        c->stat_bytes_pushed += (int64_t)(total * sizeof(double));
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            c->sent[dim][side] = k[side];
+        }
+        g->cv.notify_all();
+    }
+    // receive: the neighbour's push into my buffer of `side`
+    for (int side = 0; side < 2; side++) {
+        if (nb[side] < 0) continue;
+        const int opp = 1 - side;
+        jrx_comm_state *peer = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            JRX_TRY(local_wait(h, g, lk, [&] { return g->member[nb[side]] && g->member[nb[side]]->sent[dim][opp] >= k[side]; }, "a neighbour's planes"));
+            peer = g->member[nb[side]];
+        }
+        JRX_HIP(h, hipStreamWaitEvent(s, peer->ev_sent[dim][opp], 0));
+    }
+    S.buf[0] = c->lrbuf[dim][0]; S.buf[1] = c->lrbuf[dim][1];
+    hipLaunchKernelGGL(k_planes, dim3(gx, na * 2), dim3(256), 0, s, S, 1);
+    JRX_LAUNCH_CHECK(h);
+    for (int side = 0; side < 2; side++)
+        if (nb[side] >= 0) JRX_HIP(h, hipEventRecord(c->ev_unpacked[dim][side], s));
+    return JRX_OK;
+}
 
 jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count) { return jrx_allreduce_host(h, vals, count, 0); }
 
 // op: 0 sum (norm_mpi), 1 max (maximum_mpi)
 jrx_status jrx_allreduce_host(jrx_handle *h, double *vals, int count, int op)
 {
-    if (!jrx_comm_active(h) || !h->comm->comm || h->comm->cart.nprocs == 1) return JRX_OK;
+    if (!jrx_comm_active(h) || !(h->comm->comm || h->comm->grp) || h->comm->cart.nprocs == 1) return JRX_OK;
     jrx_comm_state *c = h->comm;
     if (count > 8) return jrx_fail(h, JRX_ERR_ARG, "allreduce of more than 8 values");
+    if (c->grp) return local_allreduce(h, c, vals, count, op);
     JRX_HIP(h, hipMemcpyAsync(c->d_red, vals, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     JRX_NCCL(h, c, c->AllReduce(c->d_red, c->d_red, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, h->stream));
     JRX_HIP(h, hipMemcpyAsync(h->h_sums, c->d_red, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -171,12 +322,14 @@ jrx_status jrx_halo_exchange(jrx_handle *h, hipStream_t s, int narrays, double *
         S.narr = na;
         S.on[0] = left >= 0; S.on[1] = right >= 0;
         if ((size_t)total > c->cap) {
-            JRX_HIP(h, hipStreamSynchronize(s));
+            JRX_HIP(h, hipStreamSynchronize(h->stream));        // an earlier exchange may have run on the other stream
+            JRX_HIP(h, hipStreamSynchronize(h->halo_stream));
             for (int q = 0; q < 2; q++) {
                 if (c->sbuf[q]) JRX_HIP(h, hipFree(c->sbuf[q]));
                 if (c->rbuf[q]) JRX_HIP(h, hipFree(c->rbuf[q]));
+                c->sbuf[q] = c->rbuf[q] = nullptr;
                 JRX_HIP(h, hipMalloc(&c->sbuf[q], (size_t)total * sizeof(double)));
-                JRX_HIP(h, hipMalloc(&c->rbuf[q], (size_t)total * sizeof(double)));
+                if (!c->grp) JRX_HIP(h, hipMalloc(&c->rbuf[q], (size_t)total * sizeof(double)));    // the local transport receives per (dimension, side)
             }
             c->cap = (size_t)total;
         }
@@ -194,6 +347,11 @@ jrx_status jrx_halo_exchange(jrx_handle *h, hipStream_t s, int narrays, double *
             S.buf[0] = c->sbuf[1]; S.buf[1] = c->sbuf[0];
             hipLaunchKernelGGL(k_planes, dim3(gx, na * 2), dim3(256), 0, s, S, 1);
             JRX_LAUNCH_CHECK(h);
+            continue;
+        }
+        if (c->grp) {
+            const int nb[2] = {left, right};
+            JRX_TRY(local_exchange_dim(h, c, s, dim, nb, (size_t)total, S, gx, na));
             continue;
         }
         if (!c->comm) return jrx_fail(h, JRX_ERR_RCCL, "update_halo!: no RCCL communicator (jrx_comm_init not called?)");
@@ -247,11 +405,76 @@ jrx_status jrx_comm_init(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], c
     return JRX_OK;
 }
 
+// In-process group: handles[r] becomes rank r of carts[r] (carts[r].rank == r, .nprocs == n).  Afterwards every rank must be driven by
+// its own host thread (the entry points rendezvous on the host); devices may be the same one or peer-accessible ones.
+jrx_status jrx_comm_init_local(jrx_handle *const *handles, int32_t n, const jrx_cart *carts)
+{
+    if (!handles || !handles[0]) return JRX_ERR_ARG;
+    jrx_handle *h0 = handles[0];
+    if (!carts || n < 1 || n > kMaxLocalRanks) return jrx_fail(h0, JRX_ERR_ARG, "jrx_comm_init_local: 1..%d ranks and their carts", kMaxLocalRanks);
+    for (int r = 0; r < n; r++) {
+        if (!handles[r]) return jrx_fail(h0, JRX_ERR_ARG, "jrx_comm_init_local: handle %d is NULL", r);
+        if (carts[r].rank != r || carts[r].nprocs != n) return jrx_fail(h0, JRX_ERR_ARG, "jrx_comm_init_local: carts[%d] is rank %d of %d", r, carts[r].rank, carts[r].nprocs);
+        for (int q = 0; q < r; q++)
+            if (handles[q] == handles[r]) return jrx_fail(h0, JRX_ERR_ARG, "jrx_comm_init_local: handle %d appears twice", r);
+    }
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
+    jrx_local_group *g = new jrx_local_group();
+    g->n = n;
+    g->timeout_s = handles[0]->comm_timeout_ms * 1e-3;
+    jrx_status st = JRX_OK;
+    for (int r = 0; r < n && st == JRX_OK; r++) {
+        jrx_handle *h = handles[r];
+        if (h->comm) st = jrx_comm_destroy(h);
+        if (st != JRX_OK) break;
+        jrx_comm_state *c = new jrx_comm_state();
+        c->cart = carts[r];
+        c->grp = g;
+        c->device = h->device;
+        h->comm = c;
+        g->member[r] = c;
+        g->refs++;
+        auto hip_ok = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && st == JRX_OK) st = jrx_fail(h0, JRX_ERR_HIP, "jrx_comm_init_local: %s -> %s", what, hipGetErrorString(e));
+        };
+        hip_ok(hipSetDevice(h->device), "hipSetDevice");
+        for (int d = 0; d < 3 && st == JRX_OK; d++)
+            for (int q = 0; q < 2 && st == JRX_OK; q++) {
+                hip_ok(hipEventCreateWithFlags(&c->ev_sent[d][q], hipEventDisableTiming), "hipEventCreate");
+                hip_ok(hipEventCreateWithFlags(&c->ev_unpacked[d][q], hipEventDisableTiming), "hipEventCreate");
+            }
+        // peer access for the pushes into a neighbour on another device
+        for (int q = 0; q < r && st == JRX_OK; q++) {
+            if (handles[q]->device == h->device) continue;
+            int can = 0;
+            hip_ok(hipDeviceCanAccessPeer(&can, h->device, handles[q]->device), "hipDeviceCanAccessPeer");
+            if (!can && st == JRX_OK) st = jrx_fail(h0, JRX_ERR_UNSUPPORTED, "jrx_comm_init_local: device %d cannot access device %d", h->device, handles[q]->device);
+            hipError_t e = hipDeviceEnablePeerAccess(handles[q]->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_ok(e, "hipDeviceEnablePeerAccess");
+            (void)hipGetLastError();
+            (void)hipSetDevice(handles[q]->device);
+            e = hipDeviceEnablePeerAccess(h->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_ok(e, "hipDeviceEnablePeerAccess");
+            (void)hipGetLastError();
+            (void)hipSetDevice(h->device);
+        }
+    }
+    if (prev_device >= 0) (void)hipSetDevice(prev_device);
+    if (st != JRX_OK) {
+        for (int r = 0; r < n; r++)
+            if (handles[r]->comm && handles[r]->comm->grp == g) (void)jrx_comm_destroy(handles[r]);
+        return st;
+    }
+    return JRX_OK;
+}
+
 jrx_status jrx_comm_count(jrx_handle *h, int32_t *count)
 {
     if (!h) return JRX_ERR_ARG;
     if (!count) return jrx_fail(h, JRX_ERR_ARG, "jrx_comm_count: count is NULL");
     *count = 0;
+    if (h->comm && h->comm->grp) { *count = h->comm->grp->n; return JRX_OK; }
     if (!h->comm || !h->comm->comm) return JRX_OK;
     int n = 0;
     JRX_NCCL(h, h->comm, h->comm->CommCount(h->comm->comm, &n));
@@ -266,6 +489,25 @@ jrx_status jrx_comm_destroy(jrx_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->halo_stream) (void)hipStreamSynchronize(h->halo_stream);
     if (c->comm && c->CommDestroy) (void)c->CommDestroy(c->comm);
+    if (c->grp) {
+        // leaving breaks the group for the ranks that remain (their waits return an error); the last one out frees it
+        jrx_local_group *g = c->grp;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            g->member[c->cart.rank] = nullptr;
+            last = --g->refs == 0;
+            if (!last) g->failed = true;
+        }
+        g->cv.notify_all();
+        if (last) delete g;
+        for (int d = 0; d < 3; d++)
+            for (int q = 0; q < 2; q++) {
+                if (c->ev_sent[d][q]) (void)hipEventDestroy(c->ev_sent[d][q]);
+                if (c->ev_unpacked[d][q]) (void)hipEventDestroy(c->ev_unpacked[d][q]);
+                if (c->lrbuf[d][q]) (void)hipFree(c->lrbuf[d][q]);
+            }
+    }
     for (int q = 0; q < 2; q++) {
         if (c->sbuf[q]) (void)hipFree(c->sbuf[q]);
         if (c->rbuf[q]) (void)hipFree(c->rbuf[q]);

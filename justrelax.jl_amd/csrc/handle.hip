@@ -1,5 +1,6 @@
 // handle.hip -- handle lifetime, error strings, and the host-only block-decomposition helpers.
 #include "jrx_internal.hpp"
+#include "jrx_tuning.h"
 
 char g_jrx_create_err[512] = {0};
 
@@ -56,7 +57,8 @@ jrx_status jrx_create(int32_t device, jrx_handle **out)
         hipError_t e_ = (call);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
             jrx_status st_ = jrx_fail(nullptr, JRX_ERR_HIP, "jrx_create: %s -> %s", #call, hipGetErrorString(e_)); \
-            delete h;                                                                              \
+            (void)jrx_destroy(h);              /* streams, events and buffers created so far */    \
+            if (prev_device >= 0) (void)hipSetDevice(prev_device);                                 \
             return st_;                                                                            \
         }                                                                                          \
     } while (0)
@@ -107,46 +109,65 @@ jrx_status jrx_destroy(jrx_handle *h)
 }
 
 // ---------------------------------------------------------------- options
+// Two tables: the options of the drop-in ABI (include/jrx.h: what a caller of solve! may want to choose -- kernel path, memory, overlap --
+// and the read-only launch counters) and the tuning / test switches of the measurements in profiles/ (include/jrx_tuning.h).
 namespace {
 struct OptRef { const char *key; int kind; void *p; };     // kind 0: bool, 1: int, 2: read-only int64 counter
-int find_opt(jrx_handle *h, const char *key, OptRef *out)
+int find_opt(jrx_handle *h, const char *key, bool tuning, OptRef *out)
 {
-    const OptRef tab[] = {
+    const OptRef pub[] = {
         {"kernel_variant", 1, &h->kernel_variant}, {"fused_overlap", 0, &h->fused_overlap}, {"thermal_fused", 0, &h->thermal_fused},
-        {"fused_comm", 0, &h->fused_comm}, {"fused_split", 0, &h->fused_split}, {"fused_tile", 1, &h->fused_tile}, {"fused_ylds", 0, &h->fused_ylds},
+        {"fused_comm", 0, &h->fused_comm}, {"loop_graphs", 0, &h->loop_graphs}, {"scratch_sets", 0, &h->scratch_sets},
+        {"stat_fused3d", 2, &h->stat_fused3d}, {"stat_fused2d", 2, &h->stat_fused2d}, {"stat_thermal_fused", 2, &h->stat_thermal_fused},
+        {"stat_vep3_fused", 2, &h->stat_vep3_fused}, {"stat_graph_replays", 2, &h->stat_graph_replays},
+    };
+    const OptRef tun[] = {
+        {"fused_split", 0, &h->fused_split}, {"fused_tile", 1, &h->fused_tile}, {"fused_ylds", 0, &h->fused_ylds},
         {"b_width_x", 1, &h->b_width_opt[0]}, {"b_width_y", 1, &h->b_width_opt[1]}, {"b_width_z", 1, &h->b_width_opt[2]},
         {"halo_self_rccl", 0, &h->halo_self_rccl}, {"thermal_cfg", 1, &h->thermal_cfg}, {"thermal_xg", 1, &h->thermal_xg},
-        {"fused2d", 0, &h->fused2d}, {"loop_graphs", 0, &h->loop_graphs}, {"vep3_edges", 1, &h->vep3_edges}, {"vep3_cfg", 1, &h->vep3_cfg}, {"vep3_peel", 0, &h->vep3_peel}, {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"scratch_sets", 0, &h->scratch_sets},
-        {"stat_fused3d", 2, &h->stat_fused3d}, {"stat_fused2d", 2, &h->stat_fused2d}, {"stat_thermal_fused", 2, &h->stat_thermal_fused},
-        {"stat_vep3_fused", 2, &h->stat_vep3_fused},
+        {"fused2d", 0, &h->fused2d}, {"vep3_edges", 1, &h->vep3_edges}, {"vep3_cfg", 1, &h->vep3_cfg}, {"vep3_peel", 0, &h->vep3_peel},
+        {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"comm_timeout_ms", 1, &h->comm_timeout_ms},
     };
-    for (const OptRef &o : tab)
-        if (strcmp(o.key, key) == 0) { *out = o; return 1; }
+    if (tuning) {
+        for (const OptRef &o : tun)
+            if (strcmp(o.key, key) == 0) { *out = o; return 1; }
+    } else {
+        for (const OptRef &o : pub)
+            if (strcmp(o.key, key) == 0) { *out = o; return 1; }
+    }
     return 0;
 }
-}   // namespace
-
-jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value)
+jrx_status opt_set(jrx_handle *h, const char *key, int64_t value, bool tuning, const char *fn)
 {
     if (!h) return JRX_ERR_ARG;
-    if (!key) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: key is NULL");
+    if (!key) return jrx_fail(h, JRX_ERR_ARG, "%s: key is NULL", fn);
     OptRef o;
-    if (!find_opt(h, key, &o)) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: unknown key '%s'", key);
-    if (o.kind == 2) return jrx_fail(h, JRX_ERR_ARG, "jrx_set_option: '%s' is a read-only counter", key);
+    if (!find_opt(h, key, tuning, &o)) {
+        if (find_opt(h, key, !tuning, &o))
+            return jrx_fail(h, JRX_ERR_ARG, "%s: '%s' is %s", fn, key, tuning ? "an option of the public ABI (jrx_set_option)" : "a tuning switch (jrx_tuning_set, include/jrx_tuning.h)");
+        return jrx_fail(h, JRX_ERR_ARG, "%s: unknown key '%s'", fn, key);
+    }
+    if (o.kind == 2) return jrx_fail(h, JRX_ERR_ARG, "%s: '%s' is a read-only counter", fn, key);
     if (o.kind == 0) *(bool *)o.p = value != 0;
     else *(int *)o.p = (int)value;
+    if (strcmp(key, "comm_timeout_ms") == 0) jrx_comm_set_timeout(h, (double)value * 1e-3);
     return JRX_OK;
 }
-
-jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value)
+jrx_status opt_get(jrx_handle *h, const char *key, int64_t *value, bool tuning, const char *fn)
 {
     if (!h) return JRX_ERR_ARG;
-    if (!key || !value) return jrx_fail(h, JRX_ERR_ARG, "jrx_get_option: null argument");
+    if (!key || !value) return jrx_fail(h, JRX_ERR_ARG, "%s: null argument", fn);
     OptRef o;
-    if (!find_opt(h, key, &o)) return jrx_fail(h, JRX_ERR_ARG, "jrx_get_option: unknown key '%s'", key);
+    if (!find_opt(h, key, tuning, &o)) return jrx_fail(h, JRX_ERR_ARG, "%s: unknown key '%s'", fn, key);
     *value = o.kind == 0 ? (int64_t)*(bool *)o.p : (o.kind == 1 ? (int64_t)*(int *)o.p : *(int64_t *)o.p);
     return JRX_OK;
 }
+}   // namespace
+
+jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value) { return opt_set(h, key, value, false, "jrx_set_option"); }
+jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value) { return opt_get(h, key, value, false, "jrx_get_option"); }
+jrx_status jrx_tuning_set(jrx_handle *h, const char *key, int64_t value) { return opt_set(h, key, value, true, "jrx_tuning_set"); }
+jrx_status jrx_tuning_get(jrx_handle *h, const char *key, int64_t *value) { return opt_get(h, key, value, true, "jrx_tuning_get"); }
 
 // ---------------------------------------------------------------- block decomposition (host only)
 int64_t jrx_n_global(int64_t n, int32_t dims, int32_t periodic)

@@ -51,7 +51,8 @@ struct jrx_handle {
     bool scratch_sets = true;            // the fused pipelines may allocate their library-owned second state set (0: never -- un-fused paths)
     // ---- read-only counters (jrx_get_option "stat_*"): launches of the fused kernels since jrx_create, so that tests and the bench can
     //      prove which kernel path ran
-    int64_t stat_fused3d = 0, stat_fused2d = 0, stat_thermal_fused = 0, stat_vep3_fused = 0;
+    int64_t stat_fused3d = 0, stat_fused2d = 0, stat_thermal_fused = 0, stat_vep3_fused = 0, stat_graph_replays = 0;
+    int comm_timeout_ms = 120000;        // in-process transport: how long a rank waits on the host for a neighbour before it reports an error
     char err[512] = {0};
 };
 
@@ -124,6 +125,7 @@ bool jrx_comm_active(const jrx_handle *h);
 jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count);
 jrx_status jrx_allreduce_host(jrx_handle *h, double *vals, int count, int op);   // op: 0 sum, 1 max
 int jrx_comm_rank(const jrx_handle *h);
+void jrx_comm_set_timeout(jrx_handle *h, double seconds);          // in-process group of the handle (no-op without one)
 bool jrx_comm_has_neighbor(const jrx_handle *h, int d, int side);   // the halo exchange receives into that boundary plane
 
 // stokes3d.hip: pieces of the 3D visco-elastic path that the 3D VEP driver (stokes3d_vep.hip) reuses.  Asynchronous on `s`.

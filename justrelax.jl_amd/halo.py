@@ -38,7 +38,7 @@ def init_comm(handle=None, group=None, self_rccl=False):
     h = handle or _lib.default_handle()
     gg = global_grid()
     cart = make_cart(gg)
-    h.call("jrx_set_option", C.c_char_p(b"halo_self_rccl"), C.c_int64(int(bool(self_rccl))))
+    h.call("jrx_tuning_set", C.c_char_p(b"halo_self_rccl"), C.c_int64(int(bool(self_rccl))))
     if gg.nprocs == 1 and not self_rccl:
         # a periodic dimension held by one rank is exchanged by a local copy inside the library
         h.call("jrx_comm_init", None, C.byref(cart))
@@ -54,6 +54,51 @@ def init_comm(handle=None, group=None, self_rccl=False):
         uid = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(obj[0])
     h.call("jrx_comm_init", uid, C.byref(cart))
     return h
+
+
+def make_carts(n, dims, periods=(0, 0, 0)):
+    """The carts of every rank of a `dims` process grid of local blocks of `n` cells (host logic only)."""
+    L = _lib.load()
+    nprocs = int(np.prod(dims))
+    carts = (_lib.Cart * nprocs)()
+    for r in range(nprocs):
+        st = L.jrx_cart_create(C.c_int32(r), C.c_int32(nprocs), (C.c_int64 * 3)(*n), (C.c_int32 * 3)(*dims), (C.c_int32 * 3)(*periods), C.byref(carts[r]))
+        if st != 0:
+            raise _lib.JrxError(st, "jrx_cart_create failed")
+    return carts
+
+
+def init_comm_local(handles, carts):
+    """jrx_comm_init_local: the ranks are `handles` of this process (one device or peer-accessible devices); planes travel by
+    device-to-device copies.  Every rank must then be driven by its own host thread (`run_ranks`)."""
+    n = len(handles)
+    arr = (C.c_void_p * n)(*[h._h for h in handles])
+    st = handles[0].lib.jrx_comm_init_local(arr, C.c_int32(n), carts)
+    handles[0].check(st)
+    return handles
+
+
+def run_ranks(fns):
+    """Run one callable per rank, each on its own host thread (ctypes releases the GIL inside the library), and return their results;
+    the first exception of any rank is re-raised."""
+    import threading
+    out, err = [None] * len(fns), [None] * len(fns)
+
+    def work(r):
+        try:
+            out[r] = fns[r]()
+        except BaseException as e:       # noqa: BLE001 -- re-raised below
+            err[r] = e
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(len(fns))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
 
 
 def update_halo_(*fields, ni=None, handle=None):

@@ -18,7 +18,7 @@ if __name__ == "__main__":
     names = [a for a in sys.argv[1:] if "=" not in a] or list(table)
     for kv in (a for a in sys.argv[1:] if "=" in a):
         k, v = kv.split("=")
-        h.call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(int(v)))
+        h.set_option(k, int(v))
         print(f"# option {k} = {v}", flush=True)
     for n in names:
         print(json.dumps(table[n](jr, h)), flush=True)

@@ -106,7 +106,7 @@ if __name__ == "__main__":
         import ctypes as C
         from justrelax_jl_amd import _lib
         k, v = kv.split("=")
-        _lib.default_handle(0).call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(int(v)))
+        _lib.default_handle(0).set_option(k, int(v))
         print(f"# option {k} = {v}")
     if nt > 0 and "phases" in sys.argv[3:]:
         thermal3d_phases(nt)

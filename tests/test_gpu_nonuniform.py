@@ -50,11 +50,11 @@ def test_uniform_spacing_arrays_equal_the_scalar_path_on_the_device(jr):
         stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
         import ctypes as C
         from justrelax_jl_amd import _lib
-        _lib.default_handle(0).call("jrx_set_option", C.c_char_p(b"fused2d"), C.c_int64(0))       # the same kernel form on both sides
+        _lib.default_handle(0).call("jrx_tuning_set", C.c_char_p(b"fused2d"), C.c_int64(0))       # the same kernel form on both sides
         try:
             jr.solve_(stokes, s.pt, grid, s.flow_bcs, ρg, G, K, s.dt, None, kwargs=s.kwargs)
         finally:
-            _lib.default_handle(0).call("jrx_set_option", C.c_char_p(b"fused2d"), C.c_int64(1))
+            _lib.default_handle(0).call("jrx_tuning_set", C.c_char_p(b"fused2d"), C.c_int64(1))
         outs.append(download_stokes(stokes))
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k

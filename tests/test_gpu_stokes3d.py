@@ -239,10 +239,10 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
     try:
         # variant 13 / 3: the fused pipeline with the other tile shape (option fused_tile: 64 x 4 / 32 x 8 threads)
         tile0 = C.c_int64(0)
-        h.call("jrx_get_option", C.c_char_p(b"fused_tile"), C.byref(tile0))
+        h.call("jrx_tuning_get", C.c_char_p(b"fused_tile"), C.byref(tile0))
         for variant in (0, 1, 2, 3, 13):
             h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant % 10))
-            h.call("jrx_set_option", C.c_char_p(b"fused_tile"), C.c_int64(1 - tile0.value if variant >= 10 else tile0.value))
+            h.call("jrx_tuning_set", C.c_char_p(b"fused_tile"), C.c_int64(1 - tile0.value if variant >= 10 else tile0.value))
             stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
             n0, n1 = C.c_int64(0), C.c_int64(0)
             h.call("jrx_get_option", C.c_char_p(b"stat_fused3d"), C.byref(n0))
@@ -254,7 +254,7 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
             outs.append(env["down"](stokes))
     finally:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
-        h.call("jrx_set_option", C.c_char_p(b"fused_tile"), tile0)
+        h.call("jrx_tuning_set", C.c_char_p(b"fused_tile"), tile0)
     assert its[0] == its[1] == its[2] == its[3] == its[4] and its[0][0] == 24
     for v in (1, 2, 3, 4):
         for k in outs[0]:

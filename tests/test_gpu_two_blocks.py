@@ -1,0 +1,239 @@
+"""The N > 1 path of the HIP library with two DIFFERENT blocks, on one device.
+
+Two handles of this process are the two ranks of an ImplicitGlobalGrid decomposition (jrx_comm_init_local: the planes travel by
+device-to-device copies ordered by events -- the transport that becomes hipMemcpyPeerAsync between GPUs); each rank's solve! runs on its
+own host thread.  Reference being matched: update_halo!(V) inside @hide_communication (src/stokes/Stokes3D.jl:104-121), update_halo!(ητ)
+(:57), norm_mpi with the doubly counted overlap (:127-142), ImplicitGlobalGrid's plane selection (src/grid/Utils.jl:26-39); the reference's
+own two-rank check is test/test_periodic_boundary_conditions_MPI.jl:9-48 (restated below on the device).
+
+Expectations:
+  * uniform material: every block equals the UNDECOMPOSED device run bit for bit on every entry (the duplicated overlap cells stay
+    consistent), for the default fused pipeline, the overlapped fused pipeline and the split sweeps, split along x, y or z;
+  * SolVi-style non-uniform viscosity: the decomposed iteration is not the undecomposed one in the reference either -- compute_τ! averages
+    η, G to the shear nodes with indices clamped to the LOCAL block (src/MiniKernels.jl:133-147), so the nodes on a block face see one
+    cell twice -- hence the expectation is the CPU oracle run block by block with the same plane copies in numpy (tolerance 1e-12 of each
+    field's maximum; observed: bit-identical).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _blocks as B
+
+pytestmark = pytest.mark.gpu
+
+STATE = ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "txy", "txz", "tyz")
+PIPELINES = {"fused": dict(kernel_variant=3, fused_overlap=0, fused_comm=1), "fused_overlap": dict(kernel_variant=3, fused_overlap=1, fused_comm=1),
+             "split_sweeps": dict(kernel_variant=3, fused_overlap=0, fused_comm=0)}
+
+
+def _set(h, **opts):
+    for k, v in opts.items():
+        h.call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(v))
+
+
+def _get(h, key):
+    v = C.c_int64()
+    h.call("jrx_get_option", C.c_char_p(key.encode()), C.byref(v))
+    return v.value
+
+
+class TwoBlocks:
+    """two handles on the current device joined into a 2-rank in-process group"""
+
+    def __init__(self, n, dims, periods=(0, 0, 0)):
+        import torch
+        from justrelax_jl_amd import _lib, halo
+        self.n, self.dims, self.periods = tuple(n), tuple(dims), tuple(periods)
+        self.carts = halo.make_carts(n, dims, periods)
+        self.handles = [_lib.Handle(torch.cuda.current_device()) for _ in range(len(self.carts))]
+        halo.init_comm_local(self.handles, self.carts)
+        self.ng = B.n_global(n, dims, periods)
+
+    def close(self):
+        for h in self.handles:
+            h.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def _global_setup(jr, ng, uniform, iterMax, nout, seed=5, bcs="free_slip"):
+    S = jr.miniapps.random_fields3d(ng, seed=seed, iterMax=iterMax, nout=nout, bcs=bcs)
+    S.pt.ϵ_rel = S.pt.ϵ_abs = 1e-30
+    if uniform:
+        for k, v in (("eta", 0.7), ("G", 1.3), ("K", 2.1)):
+            S.arrays[k][...] = v
+    else:
+        # SolVi3D-like: a weak background with a stiff spherical inclusion that straddles the block faces
+        x, y, z = (np.linspace(-0.5, 0.5, m) for m in ng)
+        r2 = x[:, None, None] ** 2 + y[None, :, None] ** 2 + z[None, None, :] ** 2
+        S.arrays["eta"][...] = np.where(r2 < 0.12, 1.0, 1e-2)
+    return S
+
+
+def _solve_blocks(jr, tb, S, pipeline, iters_kw):
+    """upload every rank's block of the global setup S and run solve! on all ranks concurrently"""
+    import justrelax_jl_amd.grid as g
+    from justrelax_jl_amd import halo
+    from justrelax_jl_amd.miniapps.common import Setup, download_stokes, upload_stokes
+    n, ng = tb.n, tb.ng
+    g.init_global_grid(*n, dimx=tb.dims[0], dimy=tb.dims[1], dimz=tb.dims[2], periodx=tb.periods[0], periody=tb.periods[1], periodz=tb.periods[2],
+                       rank=0, nprocs=len(tb.handles))
+    try:
+        assert tuple(g.global_grid().n_g(d) for d in range(3)) == ng
+        grid = jr.Geometry(n, S.extra["li"])          # geometry_MPI: spacing = li / n_g
+        ups = []
+        for r, h in enumerate(tb.handles):
+            _set(h, **PIPELINES[pipeline])
+            loc = Setup(ni=n, arrays={k: B.local_block(v, n, ng, B.coords_of(tb.carts[r])) for k, v in S.arrays.items()})
+            ups.append(upload_stokes(loc, jr.AMDGPUBackend))
+        fns = [(lambda r=r: jr.solve_(ups[r][0], S.pt, grid, S.flow_bcs, ups[r][1], ups[r][2], ups[r][3], S.dt, None, kwargs=iters_kw, handle=tb.handles[r]))
+               for r in range(len(tb.handles))]
+        res = halo.run_ranks(fns)
+        return res, [download_stokes(u[0]) for u in ups]
+    finally:
+        g.finalize_global_grid()
+
+
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "split_sweeps"])
+@pytest.mark.parametrize("dims,n", [((2, 1, 1), (70, 13, 12)), ((1, 2, 1), (70, 13, 12)), ((1, 1, 2), (70, 13, 12)),
+                                    # 3 x 5 x 5 tiles of the fused kernel per block: every shell box and an interior box
+                                    ((2, 1, 1), (130, 14, 40)), ((1, 1, 2), (130, 14, 40))])
+def test_two_blocks_equal_the_undecomposed_run_bit_for_bit(jr, dims, n, pipeline):
+    """uniform material, 24 iterations with nout = 8 (checks at 8, 16, 24; the last iteration is observed)"""
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    from justrelax_jl_amd.checks import interior_mask3d
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        S = _global_setup(jr, tb.ng, True, 23, 8)
+        # the undecomposed run on the plain single-rank handle, simplest kernels
+        h0 = _lib.default_handle()
+        _set(h0, kernel_variant=1)
+        try:
+            stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+            rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw)
+            glob = download_stokes(stokes)
+        finally:
+            _set(h0, kernel_variant=0)
+        res, outs = _solve_blocks(jr, tb, S, pipeline, kw)
+        fused_launches = [_get(h, "stat_fused3d") for h in tb.handles]
+    assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    if pipeline == "split_sweeps":
+        assert fused_launches == [0, 0]
+    else:
+        assert min(fused_launches) >= 12, fused_launches       # the fused kernel really ran on both ranks
+    for r, out in enumerate(outs):
+        co = B.coords_of(tb.carts[r])
+        for k in STATE + ("Rx", "Ry", "Rz", "RP", "exx", "exy", "divV", "Ux"):
+            want = B.local_block(glob[k], n, tb.ng, co)
+            m = interior_mask3d(k, want.shape)
+            if k == "Ux":       # U = V dt is taken before flow_bcs! and update_halo! (Stokes3D.jl:116-120): its received planes hold the previous exchange
+                m &= B.owned_mask(want.shape, n, tb.carts[r])
+            assert np.array_equal(out[k][m], want[m]), (pipeline, dims, r, k, float(np.abs(out[k] - want)[m].max()))
+    # norm_mpi: Σ over the ranks of the local interior slices (the 2-cell overlap is counted twice, Stokes3D.jl:127-142) / global counts
+    ng = tb.ng
+    ss = np.zeros(4)
+    for r in range(2):
+        co = B.coords_of(tb.carts[r])
+        loc = {k: B.local_block(glob[k], n, ng, co) for k in ("Rx", "Ry", "Rz", "RP")}
+        ss += [np.sum(loc["Rx"][1:-1, 1:-1, 1:-1] ** 2), np.sum(loc["Ry"][1:-1, 1:-1, 1:-1] ** 2), np.sum(loc["Rz"][1:-1, 1:-1, 1:-1] ** 2), np.sum(loc["RP"] ** 2)]
+    cnt = [(ng[0] - 2) * (ng[1] - 1) * (ng[2] - 1), (ng[0] - 1) * (ng[1] - 2) * (ng[2] - 1), (ng[0] - 1) * (ng[1] - 1) * (ng[2] - 2), ng[0] * ng[1] * ng[2]]
+    want_err = max(np.sqrt(ss[q]) / cnt[q] for q in range(4))
+    for r in res:
+        assert list(r.err_evo2) == [8, 16, 24]
+        assert np.isclose(r.err_evo1[-1], want_err, rtol=1e-12), (r.err_evo1[-1], want_err)
+    assert list(res[0].err_evo1) == list(res[1].err_evo1)          # every rank holds the same bits (rank-ordered host all-reduce)
+    assert getattr(res[0], "norm_∇V")[-1] != getattr(rg, "norm_∇V")[-1]          # ... which are not the undecomposed norm (RP: overlap counted twice)
+
+
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "split_sweeps"])
+@pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (1, 1, 2)])
+def test_two_blocks_with_an_inclusion_match_the_oracle_block_by_block(jr, oracle, dims, pipeline):
+    """SolVi-style non-uniform η (with its ητ halo): device blocks == oracle blocks + numpy plane copies"""
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.checks import interior_mask3d
+    orc = oracle
+    L = _lib.load()
+    n = (70, 13, 12)
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        S = _global_setup(jr, tb.ng, False, 23, 8, seed=9)
+        res, outs = _solve_blocks(jr, tb, S, pipeline, kw)
+    ng = tb.ng
+    b = S.flow_bcs
+    pl = orc.params3d(n, S.grid._di["center"], S.dt, dict(r=S.pt.r, theta_dtau=S.pt.θ_dτ, eta_dtau=S.pt.ηdτ, eps_rel=1e-30, eps_abs=1e-30),
+                      iterMax=23, nout=8, free_slip=b.free_slip, no_slip=b.no_slip, periodic=b.periodic, ni_g=ng)
+    loc = [{k: B.local_block(v, n, ng, B.coords_of(tb.carts[r])) for k, v in S.arrays.items()} for r in range(2)]
+    et = [orc.compute_maxloc(l["eta"]) for l in loc]
+    B.exchange([[e] for e in et], n, tb.carts, L)
+    errs = []
+    for it in range(1, 25):
+        for r in range(2):
+            orc.stokes3d_iteration(loc[r], et[r], pl)
+        B.exchange([[l["Vx"], l["Vy"], l["Vz"]] for l in loc], n, tb.carts, L)
+        if it % 8 == 0:
+            ss = sum(orc.residual_sumsq3d(l, pl) for l in loc)
+            cnt = [(ng[0] - 2) * (ng[1] - 1) * (ng[2] - 1), (ng[0] - 1) * (ng[1] - 2) * (ng[2] - 1), (ng[0] - 1) * (ng[1] - 1) * (ng[2] - 2), ng[0] * ng[1] * ng[2]]
+            errs.append(max(np.sqrt(ss[q]) / cnt[q] for q in range(4)))
+    for r in range(2):
+        assert res[r].iter == 24
+        assert np.allclose(res[r].err_evo1, errs, rtol=1e-11), (res[r].err_evo1, errs)
+        for k in STATE:
+            m = interior_mask3d(k, loc[r][k].shape)
+            scale = np.abs(loc[r][k]).max()
+            d = np.abs(outs[r][k] - loc[r][k])[m].max()
+            assert d <= 1e-12 * scale, (pipeline, dims, r, k, d, scale)
+    # the inclusion makes the decomposed iteration differ from the undecomposed one (clamped η averages on the block face): make sure the
+    # test would notice, i.e. that the blocks really differ from slices of an undecomposed oracle run
+    glob = {k: v.copy(order="F") for k, v in S.arrays.items()}
+    from justrelax_jl_amd import checks
+    pg = checks.oracle_params3d(orc, S)
+    etg = orc.compute_maxloc(glob["eta"])
+    for it in range(24):
+        orc.stokes3d_iteration(glob, etg, pg)
+    d = max(np.abs(B.local_block(glob["Vx"], n, ng, B.coords_of(tb.carts[r])) - loc[r]["Vx"]).max() for r in range(2))
+    assert d > 1e-9
+
+
+def test_reference_two_rank_periodic_check_on_the_device(jr):
+    """test/test_periodic_boundary_conditions_MPI.jl:9-48 in 3D on two device blocks: dims = (2, 1, 1), periodic in x; every field holds
+    coords[1] + 1; after the BCs and update_halo! the first and the last x plane hold the OTHER rank's value."""
+    import torch
+    from justrelax_jl_amd import halo
+    from justrelax_jl_amd.arrays import from_numpy, to_numpy
+    n = (8, 6, 5)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    with TwoBlocks(n, (2, 1, 1), periods=(1, 0, 0)) as tb:
+        assert tb.ng[0] == 2 * (n[0] - 2)
+        shapes = [(n[0] + 1, n[1] + 2, n[2] + 2), (n[0] + 2, n[1] + 1, n[2] + 2), (n[0] + 2, n[1] + 2, n[2] + 1), (n[0] + 2, n[1] + 2, n[2] + 2)]
+        fields = [[from_numpy(np.full(s, float(r + 1), order="F"), dev) for s in shapes] for r in range(2)]
+        torch.cuda.synchronize()
+        halo.run_ranks([(lambda r=r: halo.update_halo_(*fields[r], ni=n, handle=tb.handles[r])) for r in range(2)])
+        torch.cuda.synchronize()
+        for r in range(2):
+            other = float(2 - r)
+            for f in fields[r]:
+                A = to_numpy(f)
+                assert (A[0] == other).all() and (A[-1] == other).all()
+                assert (A[1:-1] == float(r + 1)).all()
+
+
+def test_local_group_reports_an_absent_rank_instead_of_hanging(jr):
+    """a rank whose neighbour never calls: JRX_ERR_RCCL after the time-out, and the group stays failed"""
+    import torch
+    from justrelax_jl_amd import _lib, halo
+    from justrelax_jl_amd.arrays import from_numpy
+    n = (8, 6, 5)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    with TwoBlocks(n, (2, 1, 1)) as tb:
+        tb.handles[0].call("jrx_tuning_set", C.c_char_p(b"comm_timeout_ms"), C.c_int64(300))
+        A = from_numpy(np.zeros((n[0] + 1, n[1] + 2, n[2] + 2), order="F"), dev)
+        with pytest.raises(_lib.JrxError) as e:
+            halo.update_halo_(A, ni=n, handle=tb.handles[0])
+        assert e.value.status == 3 and "timed out" in str(e.value)

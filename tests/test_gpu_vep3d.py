@@ -95,12 +95,12 @@ def test_update_stresses_3d_matches_oracle(jr, oracle, edges, ni):
     fd = st_mod.vep_fields3d(stokes, ρg, pr)
     pd = st_mod.vep_params3d(stokes, s.pt, s.grid, s.flow_bcs, s.dt)
     lv = (C.c_void_p * 3)(*[x.data_ptr() for x in lamv_d])
-    h.call("jrx_set_option", C.c_char_p(b"vep3_edges"), C.c_int64(edges))
+    h.call("jrx_tuning_set", C.c_char_p(b"vep3_edges"), C.c_int64(edges))
     try:
         h.call("jrx_vep3d_update_stresses", C.byref(fd), C.c_void_p(th_d.data_ptr()), C.c_void_p(lam_d.data_ptr()), lv,
                C.byref(st_mod.rheology_table(phases)), C.byref(pd))
     finally:
-        h.call("jrx_set_option", C.c_char_p(b"vep3_edges"), C.c_int64(1))
+        h.call("jrx_tuning_set", C.c_char_p(b"vep3_edges"), C.c_int64(1))
     out = _download(jr, stokes)
     assert (lam_r != lam).any() and (lam_r == lam).any() and (ref["eplxz"] != 0).any() and (ref["eplxz"] == 0).any()
     for k in ("txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII", "eta_vep", "P", "eplxx", "eplyy", "eplzz", "eplyz", "eplxz",
