@@ -16,10 +16,11 @@ def coords_of(cart):
 
 def local_block(A, n, ng, coords):
     """the block of rank `coords` of a global array A (any staggering): extent along d = A.shape[d] - ng[d] + n[d]"""
-    idx = []
-    for d in range(A.ndim):
+    lead = A.ndim - 3           # phase-ratio arrays carry the phase index first
+    idx = [slice(None)] * lead
+    for d in range(3):
         off = coords[d] * (n[d] - 2)
-        idx.append(slice(off, off + A.shape[d] - ng[d] + n[d]))
+        idx.append(slice(off, off + A.shape[lead + d] - ng[d] + n[d]))
     return np.array(A[tuple(idx)], order="F", copy=True)      # always a copy: a z slab of an F-ordered array is contiguous, asfortranarray would alias it
 
 

@@ -237,3 +237,108 @@ def test_local_group_reports_an_absent_rank_instead_of_hanging(jr):
         with pytest.raises(_lib.JrxError) as e:
             halo.update_halo_(A, ni=n, handle=tb.handles[0])
         assert e.value.status == 3 and "timed out" in str(e.value)
+
+
+@pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (1, 1, 2)])
+def test_vep3d_two_blocks_equal_the_undecomposed_run(jr, dims):
+    """jrx_stokes3d_vep_solve on two blocks: update_halo!(ητ), update_halo!(τ.yz / τ.xz / τ.xy) and update_halo!(V) every iteration, norms over the
+    ranks (Stokes3D.jl:515,578-580,582-597,607-612).  Two phases of equal viscosity but different G and cohesion, pre-stressed to yield: with a
+    uniform η the clamped centre-to-edge averages on a block face only touch the edge nodes of the outermost plane, which the τ exchange replaces,
+    so every block must equal the undecomposed device run bit for bit on the state arrays."""
+    import test_gpu_vep3d as tv
+    import justrelax_jl_amd.grid as g
+    from justrelax_jl_amd import halo
+    from justrelax_jl_amd.checks import interior_mask3d
+    from justrelax_jl_amd.miniapps.common import Setup
+    n = (40, 13, 12)
+    kw = dict(iterMax=23, nout=8, verbose=False, viscosity_cutoff=(-np.inf, np.inf))
+    with TwoBlocks(n, dims) as tb:
+        ng = tb.ng
+        S = jr.miniapps.shearband3d(ng, iterMax=23, nout=8)
+        S.pt.ϵ_rel = S.pt.ϵ_abs = 1e-30
+        S.extra["phases"][1]["eta"] = S.extra["phases"][0]["eta"]
+        S.arrays["eta"][...] = S.extra["phases"][0]["eta"]
+        rng = np.random.default_rng(3)
+        for c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):     # pre-stress close to yield so that plasticity is active
+            S.arrays["to" + c][...] = rng.uniform(-1.5, 1.5, size=S.arrays["to" + c].shape)
+            S.arrays["t" + c][...] = S.arrays["to" + c]
+        stokes, pr, ρg = tv._upload(jr, S)
+        rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, pr, S.extra["phases"], None, S.dt, None, kwargs=kw)
+        glob = tv._download(jr, stokes)
+        g.init_global_grid(*n, dimx=dims[0], dimy=dims[1], dimz=dims[2], rank=0, nprocs=2)
+        try:
+            grid = jr.Geometry(n, S.extra["li"], origin=(0.0, 0.0, 0.0))
+            ups = []
+            for r in range(2):
+                loc = Setup(ni=n, arrays={k: B.local_block(v, n, ng, B.coords_of(tb.carts[r])) for k, v in S.arrays.items()})
+                ups.append(tv._upload(jr, loc))
+            res = halo.run_ranks([(lambda r=r: jr.solve_(ups[r][0], S.pt, grid, S.flow_bcs, ups[r][2], ups[r][1], S.extra["phases"], None, S.dt, None, kwargs=kw,
+                                                         handle=tb.handles[r])) for r in range(2)])
+            outs = [tv._download(jr, u[0]) for u in ups]
+        finally:
+            g.finalize_global_grid()
+    assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    assert (glob["eplxx"] != 0).any() and (glob["eplxx"] == 0).any()
+    assert list(res[0].err_evo1) == list(res[1].err_evo1) and len(res[0].err_evo1) == 3
+    for r in range(2):
+        co = B.coords_of(tb.carts[r])
+        for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII", "eta_vep", "eta", "exx", "exz", "eplzz",
+                  "Rx", "Rz", "RP", "toxx", "toxz", "toxy_c", "EII_pl"):
+            want = B.local_block(glob[k], n, ng, co)
+            m = interior_mask3d(k, want.shape)
+            if k == "EII_pl":     # accumulate_tensor! gathers the edge plastic strains, which nobody exchanges: the cell layer on a block face is local
+                m &= B.owned_mask(want.shape, n, tb.carts[r])
+            assert np.array_equal(outs[r][k][m], want[m]), (dims, r, k, float(np.abs(outs[r][k] - want)[m].max()))
+
+
+@pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (1, 1, 2)])
+def test_thermal3d_two_blocks_equal_the_undecomposed_run(jr, dims):
+    """jrx_heatdiffusion_PT3d on two blocks: update_halo!(thermal.T) every iteration (DiffusionPT_solver.jl:110), uniform K and ρCp"""
+    import torch
+    import justrelax_jl_amd.grid as g
+    from justrelax_jl_amd import halo
+    from justrelax_jl_amd.arrays import from_numpy
+    n = (24, 13, 12)
+    kw = dict(iterMax=40, nout=20, verbose=False)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def run(ni, arrays, grid, handle, li, di):
+        thermal = jr.ThermalArrays(jr.AMDGPUBackend, ni)
+        for name in ("T", "H"):
+            getattr(thermal, name).copy_(from_numpy(arrays[name], dev))
+        K, ρCp = from_numpy(arrays["K"], dev), from_numpy(arrays["rhoCp"], dev)
+        pt = jr.PTThermalCoeffs(jr.AMDGPUBackend, K, ρCp, S.dt, di, li, CFL=S.pt["CFL"], ϵ=1e-30)
+        return thermal, (lambda: jr.heatdiffusion_PT_(thermal, pt, S.flow_bcs, K, ρCp, S.dt, grid, kwargs=kw, handle=handle))
+
+    with TwoBlocks(n, dims) as tb:
+        ng = tb.ng
+        S = jr.miniapps.diffusion3d(ng, iterMax=40, nout=20)
+        rng = np.random.default_rng(8)
+        S.arrays["T"][...] += rng.uniform(-50.0, 50.0, size=S.arrays["T"].shape)
+        S.arrays["K"][...] = S.arrays["K"].flat[0]
+        S.arrays["rhoCp"][...] = S.arrays["rhoCp"].flat[0]
+        tg, fg = run(ng, S.arrays, S.grid, None, S.extra["li"], S.extra["di"])
+        rg = fg()
+        Tg = jr.to_numpy(tg.T)
+        g.init_global_grid(*n, dimx=dims[0], dimy=dims[1], dimz=dims[2], rank=0, nprocs=2)
+        try:
+            grid = jr.Geometry(n, S.extra["li"])
+            runs = []
+            for r in range(2):
+                co = B.coords_of(tb.carts[r])
+                loc = {k: B.local_block(S.arrays[k], n, ng, co) for k in ("T", "H", "K", "rhoCp")}
+                runs.append(run(n, loc, grid, tb.handles[r], S.extra["li"], S.extra["di"]))
+            res = halo.run_ranks([f for _, f in runs])
+            Ts = [jr.to_numpy(t.T) for t, _ in runs]
+            Rs = [jr.to_numpy(t.ResT) for t, _ in runs]
+        finally:
+            g.finalize_global_grid()
+    assert list(rg.iter_count) == [20, 40] and all(list(r.iter_count) == [20, 40] for r in res)
+    for r in range(2):
+        want = B.local_block(Tg, n, ng, B.coords_of(tb.carts[r]))
+        inner = (slice(1, -1),) * 3
+        assert np.array_equal(Ts[r][inner], want[inner]), (dims, r, float(np.abs(Ts[r] - want)[inner].max()))
+    # the reference reports each rank's LOCAL norm(ResT) * _sq_len_RT (DiffusionPT_solver.jl:131, no MPI reduction); the ranks leave together
+    for r in range(2):
+        assert np.isclose(res[r].norm_ResT[-1], np.linalg.norm(Rs[r].ravel()) / np.sqrt(Rs[r].size), rtol=1e-12)
+    assert res[0].norm_ResT[-1] != res[1].norm_ResT[-1]
