@@ -357,10 +357,85 @@ def cfg_thermal3d_phases(jr, h, n=256, iters=200):
             "effective_GBps_at_280B_per_cell": gbps, "frac_of_8TBps": gbps / 8000.0}
 
 
+def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z")):
+    """The N > 1 code path priced on ONE device: two different n^3 blocks of an IGG decomposition (two handles of this process joined by
+    jrx_comm_init_local, planes pushed by device-to-device copies, one host thread per rank) run the timed batch of the headline concurrently.
+    The same two blocks -- same allocations, the pool's boxes and allocations differ by several per cent -- are then timed again without the
+    communicator: `overhead_pct` is what the exchange (BCs in memory, pack, copies, unpack, stress fix-up next to the received planes) costs
+    on top.  The two blocks share the device's HBM, so two uncoupled blocks run at the one-block rate (also reported)."""
+    import torch
+    import justrelax_jl_amd.grid as grid
+    from justrelax_jl_amd import _lib, halo, stokes
+    from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
+    dev = torch.cuda.current_device()
+    DIMS = {"x": (2, 1, 1), "y": (1, 2, 1), "z": (1, 1, 2)}
+    out = {"workload": f"SolVi3D, two {n}^3 blocks on one device (in-process transport: hipMemcpyAsync D2D + events)", "steps": steps}
+
+    def timed(hs, blocks, k=steps):
+        fns = lambda m: [(lambda r=r: stokes.iterate_timed_(*blocks[r], m, handle=hs[r])) for r in range(len(hs))]
+        halo.run_ranks(fns(warm))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        halo.run_ranks(fns(k))
+        torch.cuda.synchronize()
+        return len(hs) * k / (time.perf_counter() - t0)
+
+    def split_leg(name, modes):
+        dims = DIMS[name]
+        hs = [_lib.Handle(dev) for _ in range(2)]
+        blocks, res = [], {}
+        try:
+            halo.init_comm_local(hs, halo.make_carts((n, n, n), dims))
+            for r in range(2):
+                grid.finalize_global_grid()
+                grid.init_global_grid(n, n, n, rank=r, nprocs=2, dimx=dims[0], dimy=dims[1], dimz=dims[2])
+                st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
+                jr.flow_bcs_(st, bcs, handle=hs[r])
+                ητ = jr.fzeros((n, n, n), st.P.device)
+                jr.compute_maxloc_(ητ, st.viscosity.η, handle=hs[r])
+                blocks.append((st, pt, geo, bcs, ρg, K, G, ητ, dt))
+            # the ghost planes of V and ητ before the first iteration (what the drivers do at their start)
+            halo.run_ranks([(lambda r=r: halo.update_halo_(blocks[r][0].V.Vx, blocks[r][0].V.Vy, blocks[r][0].V.Vz, blocks[r][7], ni=(n, n, n), handle=hs[r]))
+                            for r in range(2)])
+            for mode in modes:
+                for h in hs:
+                    h.set_option("fused_overlap", int(mode == "overlap"))
+                res[mode] = timed(hs, blocks)
+            for h in hs:
+                h.call("jrx_comm_destroy")
+            res["uncoupled"] = timed(hs, blocks)
+            res["one_block"] = timed(hs[:1], blocks[:1])
+            return res
+        finally:
+            del blocks
+            for h in hs:
+                h.close()
+            torch.cuda.empty_cache()
+            grid.finalize_global_grid()
+
+    if only:       # profiling hook (scripts/bench_multi_rank.py): one coupled leg alone, e.g. ("z", "serial")
+        return {"leg": list(only), "block_it_per_s": split_leg(only[0], [only[1]])}
+    best = None
+    for name in splits:
+        r = split_leg(name, ["serial", "overlap"])
+        leg = {"one_block_it_per_s": r["one_block"], "two_uncoupled_blocks_block_it_per_s": r["uncoupled"]}
+        for mode in ("serial", "overlap"):
+            leg[mode] = {"block_it_per_s": r[mode], "overhead_pct": (r["uncoupled"] / r[mode] - 1.0) * 100.0}
+        out[f"split_{name}"] = leg
+        cand = max(("serial", "overlap"), key=lambda m: r[m])
+        if best is None or leg[cand]["overhead_pct"] > best[1]["overhead_pct"]:
+            best = (f"split_{name}/{cand}", leg[cand])          # the headline of the leg is the WORSE split (x planes are strided)
+    out["it_per_s"] = best[1]["block_it_per_s"]
+    out["overhead_pct"] = best[1]["overhead_pct"]
+    out["quoted"] = best[0]
+    return out
+
+
 def other_configs(jr, h):
     import justrelax_jl_amd.grid as grid
     out = {}
-    for key, fn in (("solvi3d_256", lambda: cfg_solvi(jr, h, 256, 200, 20)), ("solcx_512", lambda: cfg_solcx(jr, h)),
+    for key, fn in (("multi_rank_path", lambda: cfg_multi_rank_path(jr)),
+                    ("solvi3d_256", lambda: cfg_solvi(jr, h, 256, 200, 20)), ("solcx_512", lambda: cfg_solcx(jr, h)),
                     ("shearband_1024", lambda: cfg_shearband(jr, h)), ("thermal2d_256", lambda: cfg_thermal2d(jr, h)),
                     ("shearband3d_256", lambda: cfg_shearband3d(jr, h)), ("thermal3d_256", lambda: cfg_thermal3d(jr, h)),
                     ("thermal3d_phases_256", lambda: cfg_thermal3d_phases(jr, h))):

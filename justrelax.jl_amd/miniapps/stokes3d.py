@@ -183,6 +183,35 @@ def random_fields3d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nou
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
 
 
+def plane_strain3d(s2: Setup, nz=3) -> Setup:
+    """The 3D restatement of a 2D visco-elastic setup: every field uniform along z (nz cells of the in-plane spacing), Vz = 0, the out-of-plane
+    stresses zero, free slip on the two z faces, and the 2D run's own PT coefficients.  With ∂/∂z = 0 the 3D iteration (Stokes3D.jl:78-121) is
+    algebraically the 2D one (Stokes2D.jl:229-275) -- same ∇V, the same ε_xx = ∂Vx/∂x − ∇V/3, the same clamped shear-node averages, ητ of a
+    z-uniform η -- so a 3D run must reproduce the pinned 2D run to round-off (the kernels differ in fma placement and summation order).  This is how
+    the elastic (τ_o, 1/(G dt)) and compressible (1/(K dt)) terms of the 3D kernels get a numeric anchor: every 3D test of the reference runs with
+    dt = Inf and/or G = K = Inf, the 2D elastic build-up (miniapps/benchmarks/stokes2D/elastic_buildup/Elastic_BuildUp.jl:4,55-56,75-86,
+    test/test_stokes_elastic_buildup.jl:47-54) does not."""
+    nx, ny = s2.ni
+    ni = (nx, ny, nz)
+    dz = s2.extra["di"][0]
+    li = tuple(s2.extra["li"]) + (dz * nz,)
+    init_global_grid(*ni)
+    grid = Geometry(ni, li, origin=tuple(s2.grid.origin) + (0.0,))
+    arr = alloc_stokes(ni)
+    a2 = s2.arrays
+    for k2, k3 in (("P", "P"), ("P0", "P0"), ("Q", "Q"), ("eta", "eta"), ("K", "K"), ("G", "G"), ("fx", "fx"), ("fy", "fy"), ("txx", "txx"), ("tyy", "tyy"),
+                   ("txy", "txy"), ("toxx", "toxx"), ("toyy", "toyy"), ("toxy", "toxy")):
+        arr[k3][...] = a2[k2][:, :, None]                                      # centre arrays and τxy (nx+1, ny+1, nz): uniform along z
+    arr["Vx"][...] = a2["Vx"][:, :, None]                                      # (nx+1, ny+2) -> (nx+1, ny+2, nz+2), ghost planes in z included
+    arr["Vy"][...] = a2["Vy"][:, :, None]
+    b2 = s2.flow_bcs
+    on3 = lambda d: dict({f: bool(d.get(f, False)) for f in ("left", "right")}, front=bool(d.get("bot", False)), back=bool(d.get("top", False)))
+    fs = dict(on3(b2.free_slip), top=True, bot=True)                           # 2D bot/top are j = 1 / j = end: front / back in 3D; the z faces slip freely
+    ns = dict(on3(b2.no_slip), top=False, bot=False)
+    bcs = VelocityBoundaryConditions(free_slip=fs, no_slip=ns)
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=s2.pt, dt=s2.dt, flow_bcs=bcs, kwargs=dict(s2.kwargs), extra=dict(s2.extra, li=li, di=tuple(s2.extra["di"]) + (dz,)))
+
+
 def burstedde3d(n=16, *, β=10.0, iterMax=100_000, nout=1000) -> Setup:
     """Burstedde et al. (2013) manufactured solution -- miniapps/benchmarks/stokes3D/burstedde/Burstedde.jl:10-215
     (test/test_stokes_burstedde.jl): η = exp(1 − β Σ x(1−x)), analytical body forces, the analytical velocity prescribed on

@@ -284,3 +284,67 @@ def test_iterate_timed_leaves_state_in_user_arrays(env):
     for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy"):
         m = env["checks"].interior_mask3d(k, outs[0][k].shape)
         assert np.array_equal(outs[0][k][m], outs[1][k][m]) and np.array_equal(outs[0][k][m], outs[2][k][m]), k
+
+
+def test_3d_elastic_buildup_on_the_device(jr, oracle):
+    """VERDICT r2 P1: the τ_o / 1/(G dt) terms of the 3D kernels on the device, anchored on the reference's elastic build-up (Elastic_BuildUp.jl:4,55-56,75-86;
+    test_stokes_elastic_buildup.jl:47-54) through its plane-strain restatement (tests/test_oracle_plane_strain3d.py pins the 3D oracle on the reference's
+    5e-3 bound and on the 2D run).  First 2 kyr (40 solves of 1000 iterations), step by step against the 3D oracle, the pinned 2D oracle and the analytic curve."""
+    import math
+    from justrelax_jl_amd import checks
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    orc = oracle
+    s2 = jr.miniapps.elastic_buildup2d(32)
+    s3 = jr.miniapps.plane_strain3d(s2, nz=3)
+    kyr, η0, εbg, Gv = (s2.extra[k] for k in ("kyr", "η0", "εbg", "G"))
+    ref3 = {k: v.copy(order="F") for k, v in s3.arrays.items()}
+    stokes, ρg, K, G = upload_stokes(s3, jr.AMDGPUBackend)
+    t = 0.0
+    for step in range(40):
+        dt = 0.05 * kyr
+        s2.dt = s3.dt = dt
+        r = jr.solve_(stokes, s3.pt, s3.grid, s3.flow_bcs, ρg, K, G, dt, None, kwargs=s3.kwargs)
+        r3 = orc.stokes3d_solve(ref3, checks.oracle_params3d(orc, s3))
+        orc.stokes2d_solve(s2.arrays, checks.oracle_params2d(orc, s2))
+        assert r.iter == r3["iter"] == 1000, step
+        t += dt
+        got = float(stokes.τ.yy.abs().max())
+        assert got == pytest.approx(float(np.abs(ref3["tyy"]).max()), rel=1e-9), step
+        assert got == pytest.approx(float(np.abs(s2.arrays["tyy"]).max()), rel=1e-9), step
+        sol = 2 * εbg * η0 * (1 - math.exp(-Gv * t / η0))
+        assert abs(got - sol) / sol < 1e-2
+    out = download_stokes(stokes)
+    for k in ("txx", "tyy", "txy", "toxx", "toyy", "toxy", "P", "Vx", "Vy"):
+        scale = np.abs(s2.arrays[k]).max()
+        assert np.abs(out[k] - s2.arrays[k][:, :, None]).max() <= 1e-9 * max(scale, 1e-300), k
+        assert checks.max_rel_diff(out[k], ref3[k]) <= 1e-9, k
+    assert np.abs(out["toyy"]).max() > 0.15 * 2 * εbg * η0
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_3d_compressible_iterations_on_z_uniform_fields_equal_the_2d_oracle(jr, oracle, variant):
+    """compute_P!'s 1/(K dt) term and the τ_o terms of the in-plane stresses, finite K, G, dt, random z-uniform fields: 30 device iterations of the 3D
+    path == the pinned 2D oracle on every plane (see tests/test_oracle_plane_strain3d.py)"""
+    import ctypes as C
+    from justrelax_jl_amd import _lib, checks
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    orc = oracle
+    s2 = jr.miniapps.random_fields2d((70, 14), seed=77, iterMax=29, nout=10)
+    s2.pt.ϵ_rel = s2.pt.ϵ_abs = 1e-30
+    s2.arrays["eta"][...] = 0.37
+    orc.flow_bcs2d(s2.arrays["Vx"], s2.arrays["Vy"], s2.ni, **{k: getattr(s2.flow_bcs, k) for k in ("free_slip", "no_slip", "periodic")})
+    s3 = jr.miniapps.plane_strain3d(s2, nz=9)
+    h = _lib.default_handle()
+    h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
+    try:
+        stokes, ρg, K, G = upload_stokes(s3, jr.AMDGPUBackend)
+        r = jr.solve_(stokes, s3.pt, s3.grid, s3.flow_bcs, ρg, K, G, s3.dt, None, kwargs=s3.kwargs)
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
+    r2 = orc.stokes2d_solve(s2.arrays, checks.oracle_params2d(orc, s2))
+    assert r.iter == r2["iter"] == 30
+    out = download_stokes(stokes)
+    for k in ("P", "Vx", "Vy", "txx", "tyy", "txy", "toxx", "toxy", "exx", "eyy", "exy", "RP", "Rx", "Ry", "divV"):
+        scale = max(np.abs(s2.arrays[k]).max(), 1e-300)
+        assert np.abs(out[k] - s2.arrays[k][:, :, None]).max() <= 1e-11 * scale, k
+    assert np.abs(out["tzz"]).max() > 0.0 and np.abs(out["Vz"]).max() == 0.0
