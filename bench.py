@@ -77,12 +77,17 @@ def parse_args(argv=None):
 
 def visible_gpus() -> int:
     """Number of HIP devices, counted in a short-lived child so that this process never initialises the GPU."""
-    code = "import torch; print(torch.cuda.device_count())"
+    code = "import torch; print('JRX_DEVICE_COUNT', torch.cuda.device_count())"
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-        return int(out.stdout.strip().splitlines()[-1])
-    except Exception:
-        return 0
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: device count probe timed out after 600 s\n")
+        return -1
+    for line in reversed(out.stdout.splitlines()):
+        if line.startswith("JRX_DEVICE_COUNT "):
+            return int(line.split()[1])
+    sys.stderr.write(f"bench.py: device count probe failed (rc {out.returncode}); stderr tail:\n{out.stderr[-2000:]}\n")
+    return -1
 
 
 def free_port() -> int:
@@ -96,6 +101,8 @@ def launch_ranks(args, argv) -> int:
     n = args.gpus
     if not args.dry_launch:
         have = visible_gpus()
+        if have < 0:
+            return 2                      # the probe itself failed: its message says why
         if have < n:
             sys.stderr.write(f"bench.py: {n} GPUs requested, {have} visible\n")
             return 2

@@ -86,6 +86,17 @@ static inline jrx_status jrx_fail(jrx_handle *h, jrx_status st, const char *fmt,
 
 #define JRX_LAUNCH_CHECK(h) JRX_HIP(h, hipGetLastError())
 
+// the instantiated hipGraphs of one driver call: released on every exit path (error returns included)
+struct GraphExecs {
+    hipGraphExec_t g[2] = {nullptr, nullptr};
+    GraphExecs() = default;
+    GraphExecs(const GraphExecs &) = delete;
+    GraphExecs &operator=(const GraphExecs &) = delete;
+    ~GraphExecs() { reset(); }
+    void reset() { for (auto &x : g) if (x) { (void)hipGraphExecDestroy(x); x = nullptr; } }
+    hipGraphExec_t &operator[](int i) { return g[i]; }
+};
+
 // A handle is bound to one device (jrx_create); entry points that launch or allocate require that device to be the calling thread's
 // current one -- checked, never changed behind the caller's back
 jrx_status jrx_check_device(jrx_handle *h);

@@ -510,7 +510,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     // they started; one graph per parity) on the grids that run the one-launch iteration (SolCx 128^2 173 k -> 184 k it/s, 256^2 143 k -> 150 k).  The two-kernel form
     // of the larger grids gains nothing from it (512^2: 77.9 k plain, 76.7 k replayed) and keeps plain launches.  Option "loop_graphs" = 0: plain launches everywhere.
     constexpr int GIT = 32;
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    GraphExecs gexec;        // released on every exit path
     bool graphs = h->loop_graphs && fusable;
     auto capture = [&](hipGraphExec_t *out, auto &&body) -> bool {
         hipGraph_t g = nullptr;
@@ -613,8 +613,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
                        (long long)iter, err, err / err_it1, nRx, nRy, nDV);
         }
     }
-    for (int q = 0; q < 2; q++)
-        if (gexec[q]) (void)hipGraphExecDestroy(gexec[q]);
+    gexec.reset();
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     if (!cur_is_user) {       // leave the state in the caller's arrays
         JRX_HIP(h, hipMemcpyAsync(setU.P, setS.P, n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1437,7 +1436,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     // per iteration up to 256^2 -- the gap between dependent launches is shorter inside a graph).  An even count, so that the (τxx, τyy) sets end where they
     // started.  Only in the plain steady state: one rank, no periodic face, velocity boundary conditions, strain-rate form.  Option "loop_graphs" = 0: plain launches.
     constexpr int GIT = 32;
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    GraphExecs gexec;        // released on every exit path
     bool graphs = h->loop_graphs && !comm && !ubc && !a.si && p->periodic == 0 && (i64)(nx + 1) * (ny + 1) <= 200000;
     while (iter <= p->iterMax) {
         if (p->iterMin < iter && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) break;          // Stokes2D.jl:650-651
@@ -1567,8 +1566,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                        (long long)iter, err, err / err_it1, nRx, nRy, nDV);
             if (std::isnan(err)) {
                 // error("NaN(s)"): leave the caller's arrays consistent (the current τxx, τyy may live in the second set) and the stream drained
-                for (int q = 0; q < 2; q++)
-                    if (gexec[q]) (void)hipGraphExecDestroy(gexec[q]);
+                gexec.reset();
                 if (a.f.txx != f->txx) {
                     (void)hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s);
                     (void)hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s);
@@ -1583,8 +1581,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             }
         }
     }
-    for (int q = 0; q < 2; q++)
-        if (gexec[q]) (void)hipGraphExecDestroy(gexec[q]);
+    gexec.reset();
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     if (a.f.txx != f->txx) {      // odd number of swaps: leave τxx, τyy in the caller's arrays
         JRX_HIP(h, hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1676,7 +1673,8 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
     // 38 us per iteration) replay as a captured graph of GIT iterations of six launches (center2vertex! in one pass, flow_bcs! folded into compute_V!); one rank,
     // velocity boundary conditions.  Option "loop_graphs" = 0: plain launches.
     constexpr int GIT = 16;
-    hipGraphExec_t gexec = nullptr;
+    GraphExecs gexecs;       // released on every exit path
+    hipGraphExec_t &gexec = gexecs[0];
     bool graphs = h->loop_graphs && !comm && !ubc;
     auto unobserved_iteration = [&]() {
         hipLaunchKernelGGL(k_vep_pre<false>, dim3(gv), dim3(256), 0, s, a, f->P);
@@ -1784,7 +1782,7 @@ jrx_status jrx_stokes2d_nonlinear_solve(jrx_handle *h, const jrx_vep2d_fields *f
             }
         }
     }
-    if (gexec) (void)hipGraphExecDestroy(gexec);
+    gexecs.reset();
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_HIP(h, hipMemcpyAsync(f->P, theta, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // stokes.P .= θ :523
     a.txx_out = a.tyy_out = nullptr;

@@ -484,11 +484,11 @@ jrx_status heat2d(jrx_handle *h, const jrx_thermal2d_fields *t, const jrx_therma
     // launch-bound grids the gap between dependent launches is shorter inside a graph (scripts/graph_probe.hip: 4.6 vs 5.7 - 6.1 us per pair of short kernels).
     // One graph per parity of the current set, built on first use, destroyed at the end; option "loop_graphs" = 0 keeps plain launches.
     constexpr int GIT = 32;
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    GraphExecs gexec;        // released on every exit path
     bool graphs = fusable && h->loop_graphs;
     // the forms that keep the two kernels (phase ratios, adiabatic term, Dirichlet cells) replay compute_flux! + update_T! pairs the same way, in place
     bool graphs2 = !fusable && h->loop_graphs && !any_periodic && !jrx_comm_active(h) && nx >= 2 && ny >= 2 && n <= 200000;
-    auto destroy_graphs = [&]() { for (int q = 0; q < 2; q++) if (gexec[q]) { (void)hipGraphExecDestroy(gexec[q]); gexec[q] = nullptr; } };
+    auto destroy_graphs = [&]() { gexec.reset(); };
     while (err > p->eps && iter < p->iterMax) {
         if (graphs) {
             const int64_t nxt = std::min<int64_t>(((iter / p->nout) + 1) * p->nout, p->iterMax);      // 1-based number of the next observed iteration

@@ -184,7 +184,7 @@ def shearheating2d(n=32, *, iterMax=75_000, nout=1000) -> Setup:
     di = tuple(l / m for l, m in zip(li, ni))
     grid = Geometry(ni, li, origin=(0.0, -li[1]))
     inf = float("inf")
-    common = dict(eta=1.0e20, G=inf, Kb=inf, density=dict(kind="constant", rho0=2700.0), conductivity=2.5, heat_capacity=1050.0, shear_heat=1.0)
+    common = dict(G=inf, Kb=inf, density=dict(kind="constant", rho0=2700.0), conductivity=2.5, heat_capacity=1050.0, shear_heat=1.0)
     phases = [dict(common, g=9.81, creep=dict(kind="dislocation", A=3.2e-20, n=3.0, E=276.0e3, V=0.0, R=8.3145)),
               dict(common, creep=dict(kind="dislocation", A=3.16e-26, n=3.3, E=186.0e3, V=0.0, R=8.3145))]
     arr = {k: np.zeros(shp, dtype=np.float64, order="F") for k, shp in _vep_shapes2d(nx, ny, 2).items()}

@@ -357,7 +357,7 @@ def shearheating3d(n=16, *, iterMax=100_000, nout=1000) -> Setup:
     di = tuple(l / g for l, g in zip(li, (nx_g(), ny_g(), nz_g())))
     grid = Geometry(ni, li, origin=(0.0, 0.0, -li[2]))
     inf = float("inf")
-    common = dict(eta=1.0e20, G=inf, Kb=inf, density=dict(kind="constant", rho0=2700.0), conductivity=2.5, heat_capacity=1050.0, shear_heat=1.0)
+    common = dict(G=inf, Kb=inf, density=dict(kind="constant", rho0=2700.0), conductivity=2.5, heat_capacity=1050.0, shear_heat=1.0)
     phases = [dict(common, g=9.81, creep=dict(kind="dislocation", A=3.2e-20, n=3.0, E=276.0e3, V=0.0, R=8.3145)),
               dict(common, creep=dict(kind="dislocation", A=3.16e-26, n=3.3, E=186.0e3, V=0.0, R=8.3145))]
     arr = {k: np.zeros(s, dtype=np.float64, order="F") for k, s in vep_shapes3d(ni).items()}

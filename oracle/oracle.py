@@ -436,7 +436,15 @@ def rheology_struct(phases: list) -> Rheology:
     r = Rheology()
     r.nphase = len(phases)
     for q, ph in enumerate(phases):
-        r.eta[q], r.G[q], r.Kb[q] = ph["eta"], ph["G"], ph["Kb"]
+        r.eta[q], r.G[q], r.Kb[q] = ph.get("eta", 0.0), ph["G"], ph["Kb"]
+        _cr = ph.get("creep")
+        if _cr is not None and _cr.get("kind") in ("dislocation", "powerlaw"):
+            # GeoParams sums the strain rates of the elements of a CompositeRheology; the table holds ONE viscous element per phase, so a LinearViscous
+            # element (eta) beside a DislocationCreep would be dropped silently: refuse it
+            if r.eta[q] != 0.0:
+                raise ValueError(f"phase {q}: `eta` (a LinearViscous element) in series with a dislocation creep is not built: one viscous element per phase")
+        elif "eta" not in ph:
+            raise KeyError("eta")
         pl = "C" in ph and ph["C"] is not None
         r.is_pl[q] = int(pl)
         if pl:

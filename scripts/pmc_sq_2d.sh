@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counters of the 3D VEP / thermal kernels (own --pmc pass, no tracing)
+# SQ counters of the kernels of scripts/bench2d.py (own --pmc pass, no tracing)
+#   bash scripts/pmc_sq_2d.sh <tag> [bench2d.py arguments ...]
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmcx}
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp

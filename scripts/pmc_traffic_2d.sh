@@ -1,8 +1,10 @@
 #!/bin/bash
-# HBM-side traffic (FETCH_SIZE and WRITE_SIZE, one --pmc pass each, no tracing) per kernel of scripts/bench3d_extra.py
-#   bash scripts/pmc_traffic_2d.sh <tag> <cells> 0 [config names / KEY=INT ...]
+# HBM-side traffic (FETCH_SIZE and WRITE_SIZE, one --pmc pass each, no tracing) per kernel of scripts/bench2d.py
+#   bash scripts/pmc_traffic_2d.sh <tag> <cells> [config names / KEY=INT ... forwarded to bench2d.py]
+# <cells> = cells of the grid the configs run on (e.g. 1048576 for 1024^2): the passes are bytes / (8 B x cells).
 # FETCH_SIZE is doubled on output (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md "HBM"); both are in KiB units from rocprofv3.
-TAG=${1:-pmct}; NV=${2:-256}; NT=${3:-0}; shift 3
+if [ $# -lt 2 ]; then echo "usage: $0 <tag> <cells> [bench2d.py arguments ...]" >&2; exit 2; fi
+TAG=$1; NV=$2; shift 2
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp

@@ -15,7 +15,7 @@ def _cp(a):
 
 
 def _creep_phases(base):
-    return [dict(ph, creep=CREEP[q % 2]) for q, ph in enumerate(base)]
+    return [dict({k: v for k, v in ph.items() if k != "eta"}, creep=CREEP[q % 2]) for q, ph in enumerate(base)]      # no LinearViscous element beside the creep
 
 
 def _ratios(rng, shape):
@@ -164,7 +164,7 @@ def test_single_material_driver_with_power_law_creep_matches_oracle(jr, oracle):
     # which the law then reads as a stress; mirrored as written.  A is chosen so that this evaluation lands inside the cutoff at the strain rates the
     # convection reaches (~2e-17 / s), otherwise every cell sits on the upper cutoff and the comparison would say nothing about the law.
     n, E, R, Tm = 3.0, 150e3, 8.3145, 2285.0
-    A = 0.5 * (2e-17) ** (1 - n) * np.exp(E / (R * Tm)) / ph["eta"]
+    A = 0.5 * (2e-17) ** (1 - n) * np.exp(E / (R * Tm)) / ph.pop("eta")
     ph["creep"] = dict(kind="dislocation", A=A, n=n, E=E, V=0.0, R=R, apparatus="Invariant")
     ref = _cp(s.arrays)
     r_ref = oracle.stokes2d_nonlinear_solve(ref, oracle.rheology_struct([ph]), _nl_params(oracle, s))

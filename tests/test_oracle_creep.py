@@ -4,8 +4,12 @@ rheology/Viscosity.jl:382-418 (2D centre + vertex), :455-503 (3D), :169-196 (arr
     compute_viscosity_τII = τII / (2 ε(τII))                        compute_viscosity_εII = τ(εII) / (2 εII)
 The GeoParams forms are ASSUMED (parity unpinned: the reference holds no known answer for them); what is pinned here is that the oracle evaluates the stated
 forms at the operands the reference's kernels select (invariant, T at I .+ 1 of the ghosted thermal.T, clamped vertex averages, eps() for a zero tensor)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
 
 EPS = np.finfo(float).eps
 CREEP = [dict(kind="dislocation", A=0.5, n=3.0, E=1.0, V=0.1, R=1.0), dict(kind="dislocation", A=2.0, n=3.3, E=0.6, V=0.0, R=1.0, apparatus="Invariant")]
@@ -39,7 +43,7 @@ def inv2(xx, yy, xy):
 
 
 def _phases(base):
-    return [dict(base[q % len(base)], creep=CREEP[q]) for q in range(2)]
+    return [dict({k: v for k, v in base[q % len(base)].items() if k != "eta"}, creep=CREEP[q]) for q in range(2)]      # no LinearViscous element beside the creep
 
 
 def _ratios(rng, shape):
@@ -53,7 +57,7 @@ def _ratios(rng, shape):
 def test_array_form_and_round_trip(oracle, tau):
     rng = np.random.default_rng(3)
     ni = (7, 5)
-    rh = oracle.rheology_struct([dict(eta=1.0, G=1.0, Kb=1.0, creep=CREEP[0])])
+    rh = oracle.rheology_struct([dict(G=1.0, Kb=1.0, creep=CREEP[0])])
     AII = np.asfortranarray(rng.uniform(0.1, 3.0, size=ni)); P = np.asfortranarray(rng.uniform(-1, 1, size=ni))
     Tg = np.asfortranarray(rng.uniform(0.8, 1.5, size=(9, 7)))
     eta = np.asfortranarray(np.full(ni, 0.25))
@@ -65,7 +69,7 @@ def test_array_form_and_round_trip(oracle, tau):
     np.testing.assert_allclose(eta_np(CREEP[0], 2 * e_eps * AII, 1.1, 0.3, True), e_eps, rtol=1e-12)
     # Duretz et al. (2014) matrix of the reference's shear-heating tests (Shearheating_rheology.jl:6) at 673 K and the test's background strain rate
     d = dict(kind="dislocation", A=3.2e-20, n=3.0, E=276.0e3, V=0.0, R=8.3145)
-    rhd = oracle.rheology_struct([dict(eta=1.0, G=1.0, Kb=1.0, creep=d)])
+    rhd = oracle.rheology_struct([dict(G=1.0, Kb=1.0, creep=d)])
     e = np.asfortranarray(np.zeros((1, 1))); oracle.compute_viscosity_single(e, rhd, np.full((1, 1), 673.0, order="F"), None, AII=np.full((1, 1), 5e-14, order="F"))
     assert 1e20 < e[0, 0] < 1e24 and np.isclose(e[0, 0], eta_np(d, 5e-14, 673.0, 0.0, False), rtol=1e-13)
 
@@ -159,3 +163,17 @@ def test_shearheating2d_setup_converges(oracle, jr):
     e = r["err_evo1"]
     assert np.isfinite(e).all() and r["iter"] < 20_000 and (e[-1] / e[0] < 1e-5 or e[-1] < 1e-5)
     assert np.isfinite(a["eta"]).all() and np.ptp(np.log10(a["eta"])) > 1.0
+
+
+def test_linear_viscous_beside_a_dislocation_creep_is_refused(oracle, jr):
+    """GeoParams sums the strain rates of the elements of CompositeRheology((LinearViscous, DislocationCreep)); the native table holds one viscous
+    element per phase, so the combination is refused by every table builder instead of silently dropping the linear element"""
+    from justrelax_jl_amd import stokes
+    ph = dict(eta=1.0e20, G=1.0, Kb=1.0, creep=CREEP[0])
+    with pytest.raises(ValueError, match="one viscous element per phase"):
+        oracle.rheology_struct([ph])
+    with pytest.raises(ValueError, match="one viscous element per phase"):
+        stokes.rheology_table([ph])
+    assert stokes.rheology_table([dict(G=1.0, Kb=1.0, creep=CREEP[0])]).visc_kind[0] == 2
+    txt = (ROOT / "ext" / "JustRelaxHIPNativeExt.jl").read_text()
+    assert "LinearViscous in series with DislocationCreep has no counterpart" in txt
