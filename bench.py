@@ -443,6 +443,59 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
             torch.cuda.empty_cache()
             grid.finalize_global_grid()
 
+    def vep_leg(name, nv=256, iters=40):
+        """the same measurement for jrx_stokes3d_vep_solve (three exchanges per iteration: ητ, the edge stresses, V): two nv^3 shear-band blocks"""
+        from justrelax_jl_amd.arrays import from_numpy
+        dims = DIMS[name]
+        hs = [_lib.Handle(dev) for _ in range(2)]
+        tdev = torch.device("cuda", dev)
+        blocks, res = [], {}
+        try:
+            halo.init_comm_local(hs, halo.make_carts((nv, nv, nv), dims))
+            s = jr.miniapps.shearband3d(nv, iterMax=iters - 1, nout=10 ** 9)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+            for r in range(2):
+                st = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+                for k, t in dict(Vx=st.V.Vx, Vy=st.V.Vy, Vz=st.V.Vz, eta=st.viscosity.η).items():
+                    t.copy_(from_numpy(s.arrays[k], tdev))
+                pr = jr.PhaseRatios(jr.AMDGPUBackend, 2, s.ni)
+                for k, nm in (("phase_c", "center"), ("phase_yz", "yz"), ("phase_xz", "xz"), ("phase_xy", "xy")):
+                    getattr(pr, nm).copy_(from_numpy(s.arrays[k], tdev))
+                blocks.append((st, pr, tuple(jr.fzeros(st._ni, tdev) for _ in range(3))))
+            phases, grid_, pt, bcs, dt = s.extra["phases"], s.grid, s.pt, s.flow_bcs, s.dt
+            del s
+
+            def run(nr, k):
+                fns = [(lambda r=r: jr.solve_(blocks[r][0], pt, grid_, bcs, blocks[r][2], blocks[r][1], phases, None, dt, None,
+                                              kwargs=dict(iterMax=k - 1, nout=10 ** 9, verbose=False), handle=hs[r])) for r in range(nr)]
+                halo.run_ranks(fns)
+
+            def timed_vep(nr):
+                run(nr, 5)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(nr, iters)
+                torch.cuda.synchronize()
+                return nr * iters / (time.perf_counter() - t0)
+
+            for mode, v in (("hidden", 2), ("hidden_eta_tau_only", 1), ("serial", 0)):
+                for h in hs:
+                    h.set_option("vep3_hide_comm", v)
+                res[mode] = timed_vep(2)
+            for h in hs:
+                h.call("jrx_comm_destroy")
+            res["uncoupled"] = timed_vep(2)
+            res["one_block"] = timed_vep(1)
+            return res
+        finally:
+            del blocks
+            for h in hs:
+                h.close()
+            torch.cuda.empty_cache()
+            grid.finalize_global_grid()
+
+    if only and only[0] == "vep":
+        return {"leg": list(only), "block_it_per_s": vep_leg(only[1])}
     if only:       # profiling hook (scripts/bench_multi_rank.py): one coupled leg alone, e.g. ("z", "serial")
         return {"leg": list(only), "block_it_per_s": split_leg(only[0], [only[1]])}
     best = None
@@ -458,6 +511,15 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
     out["it_per_s"] = best[1]["block_it_per_s"]
     out["overhead_pct"] = best[1]["overhead_pct"]
     out["quoted"] = best[0]
+    try:
+        r = vep_leg("z")
+        out["vep3d_256_split_z"] = {"workload": "jrx_stokes3d_vep_solve, two 256^3 shear-band blocks, exchanges of ητ, the edge stresses and V every iteration",
+                                    "one_block_it_per_s": r["one_block"], "two_uncoupled_blocks_block_it_per_s": r["uncoupled"],
+                                    "hidden": {"block_it_per_s": r["hidden"], "overhead_pct": (r["uncoupled"] / r["hidden"] - 1.0) * 100.0},
+                                    "hidden_eta_tau_only": {"block_it_per_s": r["hidden_eta_tau_only"], "overhead_pct": (r["uncoupled"] / r["hidden_eta_tau_only"] - 1.0) * 100.0},
+                                    "serial": {"block_it_per_s": r["serial"], "overhead_pct": (r["uncoupled"] / r["serial"] - 1.0) * 100.0}}
+    except Exception as e:
+        out["vep3d_256_split_z"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

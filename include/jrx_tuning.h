@@ -10,6 +10,8 @@
  *   "fused2d" (1)                 2D visco-elastic loop: one-launch iterations on launch-bound grids
  *   "vep3_edges" (1)              3D VEP edge pass: 1 = z-marching kernel, one family per block; 2 = one launch per family; 0 = one node per thread
  *   "vep3_cfg", "vep3_peel", "vep3_map", "vep3_xcd"     z-marching edge kernel: chunk depth / occupancy, peeling of a thin last segment, thread map, XCD slabs
+ *   "vep3_hide_comm" (2)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 = the first two only,
+ *                                 update_halo!(V) behind the whole velocity sweep; 0 = everything on the compute stream, in order (A/B)
  *   "thermal_cfg", "thermal_xg"   fused 3D heat-diffusion tile shape / XCD band
  *   "halo_self_rccl" (0)          test hook: a rank that is its own periodic neighbour routes its planes through ncclSend/ncclRecv
  *   "comm_timeout_ms" (120000)    in-process transport (jrx_comm_init_local): how long a rank waits on the host for a neighbour

@@ -47,6 +47,8 @@ struct jrx_handle {
     bool vep3_peel = true;                   // z-marching edge kernel: a nearly empty last lane segment goes to the node kernel (A/B)
     int vep3_cfg = 0;                        // z-marching edge kernel: KZ * 10 + min blocks per CU, 0 = default
     int vep3_edges = 1;                      // 3D VEP edge pass: 1 z-marching kernel (2: one launch per family), 0 one node per thread (A/B; the form softening laws use)
+    int vep3_hide_comm = 2;                  // multi-rank 3D VEP driver: the three exchanges of an iteration on the halo stream beside independent kernels
+                                             // (1: ητ and the edge stresses only, 0: serial; A/B)
     bool vep3_map = true, vep3_xcd = true;   // 3D VEP edge kernel thread mapping / XCD slab order (A/B)
     bool scratch_sets = true;            // the fused pipelines may allocate their library-owned second state set (0: never -- un-fused paths)
     // ---- read-only counters (jrx_get_option "stat_*"): launches of the fused kernels since jrx_create, so that tests and the bench can
@@ -142,6 +144,8 @@ bool jrx_comm_has_neighbor(const jrx_handle *h, int d, int side);   // the halo 
 // stokes3d.hip: pieces of the 3D visco-elastic path that the 3D VEP driver (stokes3d_vep.hip) reuses.  Asynchronous on `s`.
 // velocity sweep = compute_V! 3D (+ residuals when diag); sumsq leaves Σx² of Rx, Ry, Rz (interior slices) and RP in h->d_sums
 jrx_status jrx3d_velocity_sweep(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag);
+// the same sweep as @hide_communication runs it (boundary slabs, BCs and update_halo!(V) on the halo stream, interior on the compute stream); see stokes3d.hip
+jrx_status jrx3d_velocity_hidden(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag, int bc_kind);
 jrx_status jrx3d_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p);
 jrx_status jrx3d_bcs(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz, uint32_t fs, uint32_t ns, uint32_t pe);
 // all free-slip / no-slip faces in one launch: equal to jrx3d_bcs on every entry a Stokes stencil reads once jrx3d_bcs has run on the same arrays

@@ -256,6 +256,52 @@ jrx_status jrx3d_bcs_faces(jrx_handle *h, hipStream_t s, double *Vx, double *Vy,
     return launch_bcs_faces(h, s, Vx, Vy, Vz, nx, ny, nz, fs, ns);
 }
 
+// @hide_communication b_width (Stokes3D.jl:104-121, 582-597): compute_V! over the six boundary slabs of width b first, on the halo stream, followed
+// there by velocity2displacement! (observable iterations), flow_bcs! and update_halo!(V), while the interior runs on the compute stream; the two
+// streams are joined on return.  bc_kind: 0 = flow_bcs! on V in the reference's pass order, 1 = all faces of V in one launch (equal wherever a stencil
+// reads once the ordered passes have run), 2 = flow_bcs! on U (DisplacementBoundaryConditions, observable iterations), 3 = none.
+jrx_status jrx3d_velocity_hidden(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag, int bc_kind)
+{
+    if (diag && (!f->Rx || !f->Ry || !f->Rz)) return jrx_fail(h, JRX_ERR_ARG, "residual arrays are NULL");
+    const int nx = (int)p->nx, ny = (int)p->ny, nz = (int)p->nz;
+    hipStream_t s = h->stream;
+    const SweepArgs a = make_args(f, etatau, p);
+    int bx = p->b_width[0] > 0 ? p->b_width[0] : 4, by = p->b_width[1] > 0 ? p->b_width[1] : 4,
+        bz = p->b_width[2] > 0 ? p->b_width[2] : 4;
+    if (h->b_width_opt[0] > 0) bx = h->b_width_opt[0];       // tuning switches "b_width_x/y/z" (the split does not change results)
+    if (h->b_width_opt[1] > 0) by = h->b_width_opt[1];
+    if (h->b_width_opt[2] > 0) bz = h->b_width_opt[2];
+    const int xa = bx < nx / 2 ? bx : nx / 2, ya = by < ny / 2 ? by : ny / 2, za = bz < nz / 2 ? bz : nz / 2;
+    hipStream_t hs = h->halo_stream;
+    JRX_HIP(h, hipEventRecord(h->ev[0], s));
+    JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[0], 0));
+    // six slabs (z-lo, z-hi, y-lo, y-hi, x-lo, x-hi), disjoint
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ny, 0, za));
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ny, nz - za, nz));
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ya, za, nz - za));
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, ny - ya, ny, za, nz - za));
+    JRX_TRY(launch_velocity(h, hs, a, diag, 0, xa, ya, ny - ya, za, nz - za));
+    JRX_TRY(launch_velocity(h, hs, a, diag, nx - xa, nx, ya, ny - ya, za, nz - za));
+    // interior on the compute stream, concurrently
+    JRX_TRY(launch_velocity(h, s, a, diag, xa, nx - xa, ya, ny - ya, za, nz - za));
+    if (diag) {
+        // U = V*dt needs the whole updated V: join first
+        JRX_HIP(h, hipEventRecord(h->ev[1], s));
+        JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[1], 0));
+        JRX_TRY(launch_scaleU(h, hs, f, p));
+    }
+    if (bc_kind == 0) JRX_TRY(launch_bcs(h, hs, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+    else if (bc_kind == 1) JRX_TRY(launch_bcs_faces(h, hs, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
+    else if (bc_kind == 2) JRX_TRY(launch_bcs(h, hs, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+    double *arrs[3] = {f->Vx, f->Vy, f->Vz};
+    const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
+    const int64_t n[3] = {nx, ny, nz};
+    JRX_TRY(jrx_halo_exchange(h, hs, 3, arrs, ext, n));
+    JRX_HIP(h, hipEventRecord(h->ev[2], hs));
+    JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
+    return JRX_OK;
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -664,41 +710,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         }
         return JRX_OK;
     }
-    // @hide_communication b_width (Stokes3D.jl:104-121): boundary slabs of width b first on the halo
-    // stream, then BCs + neighbour exchange there while the interior runs on the compute stream.
-    int bx = p->b_width[0] > 0 ? p->b_width[0] : 4, by = p->b_width[1] > 0 ? p->b_width[1] : 4,
-        bz = p->b_width[2] > 0 ? p->b_width[2] : 4;
-    if (h->b_width_opt[0] > 0) bx = h->b_width_opt[0];       // options "b_width_x/y/z": tuning override (the split does not change results)
-    if (h->b_width_opt[1] > 0) by = h->b_width_opt[1];
-    if (h->b_width_opt[2] > 0) bz = h->b_width_opt[2];
-    const int xa = bx < nx / 2 ? bx : nx / 2, ya = by < ny / 2 ? by : ny / 2, za = bz < nz / 2 ? bz : nz / 2;
-    hipStream_t hs = h->halo_stream;
-    JRX_HIP(h, hipEventRecord(h->ev[0], s));
-    JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[0], 0));
-    // six slabs (z-lo, z-hi, y-lo, y-hi, x-lo, x-hi), disjoint
-    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ny, 0, za));
-    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ny, nz - za, nz));
-    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, 0, ya, za, nz - za));
-    JRX_TRY(launch_velocity(h, hs, a, diag, 0, nx, ny - ya, ny, za, nz - za));
-    JRX_TRY(launch_velocity(h, hs, a, diag, 0, xa, ya, ny - ya, za, nz - za));
-    JRX_TRY(launch_velocity(h, hs, a, diag, nx - xa, nx, ya, ny - ya, za, nz - za));
-    // interior on the compute stream, concurrently
-    JRX_TRY(launch_velocity(h, s, a, diag, xa, nx - xa, ya, ny - ya, za, nz - za));
-    if (diag) {
-        // U = V*dt needs the whole updated V: join first
-        JRX_HIP(h, hipEventRecord(h->ev[1], s));
-        JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[1], 0));
-        JRX_TRY(launch_scaleU(h, hs, f, p));
-    }
-    if (!p->displacement_bcs) JRX_TRY(launch_bcs(h, hs, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
-    else if (diag) JRX_TRY(launch_bcs(h, hs, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
-    double *arrs[3] = {f->Vx, f->Vy, f->Vz};
-    const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
-    const int64_t n[3] = {nx, ny, nz};
-    JRX_TRY(jrx_halo_exchange(h, hs, 3, arrs, ext, n));
-    JRX_HIP(h, hipEventRecord(h->ev[2], hs));
-    JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
-    return JRX_OK;
+    return jrx3d_velocity_hidden(h, f, I.etatau, p, diag, p->displacement_bcs ? (diag ? 2 : 3) : 0);
 }
 
 // leave the results in the caller's arrays

@@ -822,9 +822,11 @@ EdgeN edge_counts(const jrx_vep3d_params *p)
 
 // the three edge passes, the commit of the new edge stresses, then the centre pass
 // commit = false: the caller adopts a.tnew as the current edge-stress arrays (pointer swap) instead of copying them back
-jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p, bool commit = true)
+// which: 0 = both passes, 1 = the edge pass alone, 2 = the centre pass alone (the multi-rank driver exchanges the new edge stresses in between)
+jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p, bool commit = true, int which = 0)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
+    if (which != 2) {
     const bool p4 = h->vep3_map, xs = h->vep3_xcd;     // options "vep3_map", "vep3_xcd" (XCD slab order: +1-2 % measured)
     if (h->vep3_edges >= 1 && a.rh.nphase <= 4) {
         // option "vep3_edges": 0 one node per thread (k_vep3_edges; also the form more than 4 phases use), 1 (default) the z-marching
@@ -869,8 +871,10 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
     else if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
     else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
     JRX_LAUNCH_CHECK(h);
+    }
+    if (which == 1) return JRX_OK;
     const EdgeN n = edge_counts(p);
-    if (commit) {
+    if (commit && which == 0) {
         hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, a.f.tyz, (const double *)a.tnew[0], n.yz, a.f.txz, (const double *)a.tnew[1], n.xz, a.f.txy,
                            (const double *)a.tnew[2], n.xy, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr, (const double *)nullptr,
                            (i64)0, (double *)nullptr, (const double *)nullptr, (i64)0);
@@ -996,12 +1000,12 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     const size_t n = (size_t)nx * ny * nz;
     const EdgeN ne = edge_counts(p);
     hipStream_t s = h->stream;
-    // library scratch: ητ, θ, λ, K, G (centres), λv and the new edge stresses (edges), carved out of one allocation
-    JRX_TRY(jrx_ensure_etatau(h, 5 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
-    double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n;
+    // library scratch: ητ, θ, λ, K, G, a second ητ (centres), λv and the new edge stresses (edges), carved out of one allocation
+    JRX_TRY(jrx_ensure_etatau(h, 6 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
+    double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n, *etatau_next = Gc + n;
     Vep3Args a = make_vep3(f, rh, p);
     a.theta = theta; a.etatau = etatau; a.Kc = Kc; a.Gc = Gc; a.lam = lam;
-    a.lamv[0] = Gc + n; a.lamv[1] = a.lamv[0] + ne.yz; a.lamv[2] = a.lamv[1] + ne.xz;
+    a.lamv[0] = etatau_next + n; a.lamv[1] = a.lamv[0] + ne.yz; a.lamv[2] = a.lamv[1] + ne.xz;
     a.tnew[0] = a.lamv[2] + ne.xy; a.tnew[1] = a.tnew[0] + ne.yz; a.tnew[2] = a.tnew[1] + ne.xz;
     jrx_stokes3d_fields g = view3d(f);
     jrx_stokes3d_params q;
@@ -1045,14 +1049,71 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);      // R and U are only observable after such an iteration
         if (comm) {
-            hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, nz);
-            // update_halo!(ητ) (Stokes3D.jl:515)
-            double *arrs[1] = {etatau};
-            const int64_t ext[1][3] = {{nx, ny, nz}};
-            JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));
+            // Hidden communication.  The reference hides update_halo!(V) behind compute_V! (@hide_communication, Stokes3D.jl:582-597);
+            // its other two exchanges of the iteration block.  Here all three run on the halo stream beside kernels that do not depend on them:
+            //   update_halo!(ητ) of the NEXT iteration (compute_maxloc! of the η that update_viscosity_τII! has just left, into a second ητ array)
+            //                        beside the edge pass of the stress update,
+            //   update_halo!(τ.yz, τ.xz, τ.xy) beside the centre pass (which reads no edge stress),
+            //   update_halo!(V) behind the boundary slabs of compute_V!, beside its interior.
+            // Same kernels, same operands: results are those of the serial order, bit for bit (tests/test_gpu_two_blocks.py, tests/test_gpu_halo.py).
+            // tuning switch "vep3_hide_comm": 2 (default) as described; 1 = ητ and the edge stresses hidden, update_halo!(V) in order behind the whole sweep;
+            // 0 = the same sequence on the compute stream alone (A/B)
+            const bool hide = h->vep3_hide_comm >= 2;
+            hipStream_t hs = h->vep3_hide_comm >= 1 ? h->halo_stream : s;
+            if (iter == 0) {        // ητ of the first iteration: nothing to hide it behind
+                double *cur = const_cast<double *>(a.etatau);
+                hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, s, cur, (const double *)f->eta, nx, ny, nz);
+                double *arrs[1] = {cur};
+                const int64_t ext[1][3] = {{nx, ny, nz}};
+                JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));      // update_halo!(ητ) (Stokes3D.jl:515)
+            }
             if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<false, true, PRE_KZ>), gpre, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_vep3_pre<false, false, PRE_KZ>), gpre, dim3(256), 0, s, a);
-        } else if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, a);
+            launch_vep3_visc(s, gc, a, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
+            JRX_LAUNCH_CHECK(h);
+            JRX_HIP(h, hipEventRecord(h->ev[3], s));
+            JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[3], 0));
+            {
+                double *nxt = a.etatau == etatau ? etatau_next : etatau;
+                hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, hs, nxt, (const double *)f->eta, nx, ny, nz);
+                JRX_LAUNCH_CHECK(h);
+                double *arrs[1] = {nxt};
+                const int64_t ext[1][3] = {{nx, ny, nz}};
+                JRX_TRY(jrx_halo_exchange(h, hs, 1, arrs, ext, nn));     // update_halo!(ητ) of iteration it1 + 1
+            }
+            JRX_TRY(launch_vep3_stress(h, s, a, p, false, 1));           // edge pass
+            { double *t0_ = a.f.tyz; a.f.tyz = a.tnew[0]; a.tnew[0] = t0_; }
+            { double *t1_ = a.f.txz; a.f.txz = a.tnew[1]; a.tnew[1] = t1_; }
+            { double *t2_ = a.f.txy; a.f.txy = a.tnew[2]; a.tnew[2] = t2_; }
+            g.tyz = a.f.tyz; g.txz = a.f.txz; g.txy = a.f.txy;
+            JRX_HIP(h, hipEventRecord(h->ev[3], s));
+            JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[3], 0));
+            {   // update_halo!(τ.yz), (τ.xz), (τ.xy) (Stokes3D.jl:578-580)
+                double *arrs[3] = {a.f.tyz, a.f.txz, a.f.txy};
+                const int64_t ext[3][3] = {{nx, ny + 1, nz + 1}, {nx + 1, ny, nz + 1}, {nx + 1, ny + 1, nz}};
+                JRX_TRY(jrx_halo_exchange(h, hs, 3, arrs, ext, nn));
+            }
+            JRX_HIP(h, hipEventRecord(h->ev[4], hs));
+            JRX_TRY(launch_vep3_stress(h, s, a, p, false, 2));           // centre pass, beside the exchange
+            JRX_HIP(h, hipStreamWaitEvent(s, h->ev[4], 0));
+            int bc_kind = 3;
+            if (!ubc && !diag && bcs_ordered && p->periodic == 0) bc_kind = 1;
+            else if (!ubc) { bc_kind = 0; bcs_ordered = true; }
+            else if (diag) bc_kind = 2;
+            if (hide) JRX_TRY(jrx3d_velocity_hidden(h, &g, a.etatau, &q, diag, bc_kind));      // joins the two streams
+            else {
+                JRX_TRY(jrx3d_velocity_sweep(h, s, &g, a.etatau, &q, diag));
+                if (diag) JRX_TRY(jrx3d_scaleU(h, s, &g, &q));
+                if (bc_kind == 1) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
+                else if (bc_kind == 0) JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+                else if (bc_kind == 2) JRX_TRY(jrx3d_bcs(h, s, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+                double *arrs[3] = {f->Vx, f->Vy, f->Vz};
+                const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
+                JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, nn));       // update_halo!(@velocity(stokes)...) (Stokes3D.jl:596)
+            }
+            a.etatau = a.etatau == etatau ? etatau_next : etatau;
+        } else {
+        if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_vep3_pre<true, false, PRE_KZ>), gpre, dim3(256), 0, s, a);        // compute_maxloc! folded in
         launch_vep3_visc(s, gc, a, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
         JRX_LAUNCH_CHECK(h);
@@ -1062,21 +1123,12 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         { double *t1_ = a.f.txz; a.f.txz = a.tnew[1]; a.tnew[1] = t1_; }
         { double *t2_ = a.f.txy; a.f.txy = a.tnew[2]; a.tnew[2] = t2_; }
         g.tyz = a.f.tyz; g.txz = a.f.txz; g.txy = a.f.txy;
-        if (comm) {   // update_halo!(τ.yz), (τ.xz), (τ.xy) (Stokes3D.jl:578-580)
-            double *arrs[3] = {a.f.tyz, a.f.txz, a.f.txy};
-            const int64_t ext[3][3] = {{nx, ny + 1, nz + 1}, {nx + 1, ny, nz + 1}, {nx + 1, ny + 1, nz}};
-            JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, nn));
-        }
-        JRX_TRY(jrx3d_velocity_sweep(h, s, &g, etatau, &q, diag));
+        JRX_TRY(jrx3d_velocity_sweep(h, s, &g, a.etatau, &q, diag));
         if (diag) JRX_TRY(jrx3d_scaleU(h, s, &g, &q));
         // flow_bcs!: on V, or -- DisplacementBoundaryConditions -- on U = V dt, which the next iteration overwrites (only observable when U is)
         if (!ubc && !diag && bcs_ordered && p->periodic == 0) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
         else if (!ubc) { JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic)); bcs_ordered = true; }
         else if (diag) JRX_TRY(jrx3d_bcs(h, s, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
-        if (comm) {   // update_halo!(@velocity(stokes)...) (Stokes3D.jl:596); no overlap with the sweep in this driver yet
-            double *arrs[3] = {f->Vx, f->Vy, f->Vz};
-            const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
-            JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, nn));
         }
         iter = it1;
         if (check) {
