@@ -388,6 +388,7 @@ typedef struct jrx_vep3d_params {
     int32_t displacement_bcs;
     int32_t T_ghosted;             /* f->T = args.T is thermal.T (ni .+ 2), as the miniapps pass it (RisingBlob3D/Blob3D.jl:355): update_ρg! reads it at the cell's own
                                     * [i, j, k], unshifted (getindex_NamedTuple(args, I...), BuoyancyForces.jl:52); 0: cell-centred (ni) */
+    int32_t b_width[3];            /* kwargs.b_width (Stokes3D.jl:460): boundary-slab widths of the hidden update_halo!(V) (multi-rank runs; <= 0: 4) */
 } jrx_vep3d_params;
 
 jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_vep3d_params *p,

@@ -141,7 +141,7 @@ class VEP3DParams(C.Structure):
                 ("eps_rel", C.c_double), ("eps_abs", C.c_double), ("iterMax", C.c_int64), ("nout", C.c_int64),
                 ("free_slip", C.c_uint32), ("no_slip", C.c_uint32), ("periodic", C.c_uint32),
                 ("lambda_relaxation", C.c_double), ("viscosity_relaxation", C.c_double), ("cutoff_lo", C.c_double), ("cutoff_hi", C.c_double),
-                ("verbose", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32)]
+                ("verbose", C.c_int32), ("displacement_bcs", C.c_int32), ("T_ghosted", C.c_int32), ("b_width", C.c_int32 * 3)]
 
 
 class SolveResult(C.Structure):

@@ -1013,6 +1013,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     q.nx = nx; q.ny = ny; q.nz = nz; q.nxg = p->nxg; q.nyg = p->nyg; q.nzg = p->nzg; q._dx = p->_dx; q._dy = p->_dy; q._dz = p->_dz;
     q.dt = p->dt; q.r = p->r; q.theta_dtau = p->theta_dtau; q.eta_dtau = p->eta_dtau;
     q.free_slip = p->free_slip; q.no_slip = p->no_slip; q.periodic = p->periodic;
+    for (int d = 0; d < 3; d++) q.b_width[d] = p->b_width[d];
     const unsigned gc = (unsigned)((n + 255) / 256);
     const dim3 gv = GRID_IJK(nx + 1, ny + 1, nz + 1), g0 = GRID_IJK(nx, ny, nz);
     constexpr int PRE_KZ = 8;        // planes per thread of k_vep3_pre

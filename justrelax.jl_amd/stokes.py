@@ -370,6 +370,7 @@ def vep_params3d(stokes, pt, grid, flow_bcs, dt, *, iterMax=10.0e3, nout=500, ve
     p.cutoff_lo, p.cutoff_hi = float(viscosity_cutoff[0]), float(viscosity_cutoff[1])
     p.verbose = int(bool(verbose))
     p.displacement_bcs = int(_is_displacement(flow_bcs))
+    p.b_width[0], p.b_width[1], p.b_width[2] = [int(b) for b in b_width]
     return p
 
 

@@ -189,3 +189,50 @@ def test_header_is_c99_and_callable_from_c(tmp_path):
     assert out[1] == "neighbors 1 -1 -1 7 4 -1"           # x-left (0,0,1) = 1, y-right (1,1,1) = 7, z-left (1,0,0) = 4; -1 = physical boundary
     assert out[2] == "halo planes 2 510 0 512"
     assert out[3] == "nx_g 1022"
+
+
+def test_every_driver_kwarg_reaches_its_parameter_struct(jr):
+    """the kwargs the reference's drivers accept (Stokes3D.jl:25-41,447-466; Stokes2D.jl:181-196,345-362,577-599) are forwarded into the
+    parameter structs of the C ABI -- by value on the Python host, by name in the Julia extension (INTEGRATION.md, table "kwargs of the reference's drivers")"""
+    import re
+    from pathlib import Path
+    from types import SimpleNamespace
+    from justrelax_jl_amd import stokes as st
+    pt = jr.PTStokesCoeffs((1.0, 1.0, 1.0), (0.1, 0.1, 0.1))
+    grid3 = SimpleNamespace(_di=dict(center=(10.0, 10.0, 10.0)), nonuniform=False)
+    grid2 = SimpleNamespace(_di=dict(center=(10.0, 10.0)), nonuniform=False)
+    bcs3 = jr.VelocityBoundaryConditions(free_slip={f: True for f in ("left", "right", "front", "back", "top", "bot")})
+    bcs2 = jr.VelocityBoundaryConditions(free_slip={f: True for f in ("left", "right", "top", "bot")})
+    s3, s2 = SimpleNamespace(_ni=(8, 9, 10)), SimpleNamespace(_ni=(8, 9))
+    p = st.params3d(s3, pt, grid3, bcs3, 0.5, iterMax=77, nout=11, b_width=(3, 2, 5), verbose=False, viscosity_relaxation=0.3)
+    assert (p.iterMax, p.nout, tuple(p.b_width), p.verbose) == (77, 11, (3, 2, 5), 0)
+    p = st.params2d(s2, pt, grid2, bcs2, 0.5, iterMax=78, nout=12, b_width=(4, 4, 1), verbose=True)
+    assert (p.iterMax, p.nout, p.verbose) == (78, 12, 1)
+    p = st.vep_params2d(s2, pt, grid2, bcs2, 0.5, iterMax=79, iterMin=13, nout=14, verbose=False, λ_relaxation=0.3, viscosity_relaxation=0.05,
+                        viscosity_cutoff=(1e18, 1e23), strain_increment=True, free_surface=True, b_width=(4, 4, 0))
+    assert (p.iterMax, p.iterMin, p.nout, p.verbose, p.lambda_relaxation, p.viscosity_relaxation, p.cutoff_lo, p.cutoff_hi, p.strain_increment, p.free_surface) == \
+        (79, 13, 14, 0, 0.3, 0.05, 1e18, 1e23, 1, 1)
+    p = st.vep_params3d(s3, pt, grid3, bcs3, 0.5, iterMax=80, nout=15, verbose=False, λ_relaxation=0.4, viscosity_relaxation=0.06, viscosity_cutoff=(1e17, 1e24),
+                        b_width=(2, 3, 6))
+    assert (p.iterMax, p.nout, p.verbose, p.lambda_relaxation, p.viscosity_relaxation, p.cutoff_lo, p.cutoff_hi, tuple(p.b_width)) == \
+        (80, 15, 0, 0.4, 0.06, 1e17, 1e24, (2, 3, 6))
+    # the Julia extension: every solve! method reads the kwargs of its reference signature
+    txt = (Path(__file__).resolve().parent.parent / "ext" / "JustRelaxHIPNativeExt.jl").read_text()
+    methods = re.split(r"\nfunction (?=JR[23]D\.solve!\(::Trait)", txt)[1:]
+    assert len(methods) == 5
+    body = {}
+    for m in methods:
+        head = m.split("\n", 1)[0]
+        key = ("3D" if "JR3D" in head else "2D") + ("_phases" if "phase_ratios" in m.split("kwargs)")[0] else ("_material" if "MaterialParams" in m.split("kwargs)")[0] else ""))
+        body[key] = m.split("\nend\n")[0]
+    helper = txt.split("function vep_params2d(")[1].split("\nend\n")[0]
+    for k in ("iterMax", "nout", "b_width", "verbose"):
+        assert re.search(rf"kw\.{k}\b", body["3D"]), k
+    for k in ("iterMax", "nout", "verbose"):
+        assert re.search(rf"kw\.{k}\b", body["2D"]), k
+    for k in ("iterMax", "nout", "b_width", "verbose", "λ_relaxation", "viscosity_relaxation", "viscosity_cutoff"):
+        assert re.search(rf"kw\.{k}\b", body["3D_phases"]), k
+    for k in ("iterMax", "iterMin", "nout", "verbose", "λ_relaxation", "viscosity_relaxation", "viscosity_cutoff", "strain_increment", "free_surface"):
+        assert re.search(rf"\b{k}\b", helper), k
+    assert "vep_params2d(" in body["2D_phases"] and "kwargs..." in body["2D_phases"]
+    assert "vep_params2d(" in body["2D_material"] and "kwargs..." in body["2D_material"]
