@@ -99,6 +99,25 @@ struct GraphExecs {
     hipGraphExec_t &operator[](int i) { return g[i]; }
 };
 
+// Capture what `body` enqueues on stream s into an instantiated graph.  *out stays nullptr when the runtime refuses the capture (the caller then
+// keeps plain launches); an error of the body itself is returned.  Thread-local capture mode: other host threads (other handles) are not affected.
+template <class F>
+static inline jrx_status jrx_capture_graph(hipStream_t s, hipGraphExec_t *out, F &&body)
+{
+    *out = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return JRX_OK; }
+    const jrx_status st = body();
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (st == JRX_OK && e == hipSuccess && g && hipGraphInstantiate(out, g, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return st;
+}
+// grids up to this many cells run their 3D loops launch-bound (a dependent launch costs ~5 us): runs of unobserved iterations replay as graphs.
+// Measured (profiles/r03_small_grids_graphs.txt): +3 .. +8 % at 16^3 and 32^3, nothing at 64^3, -7 % for the heat loop at 96^3 -> up to 48^3 cells.
+static constexpr double kGraphCells3D = 48.0 * 48.0 * 48.0;
+
 // A handle is bound to one device (jrx_create); entry points that launch or allocate require that device to be the calling thread's
 // current one -- checked, never changed behind the caller's back
 jrx_status jrx_check_device(jrx_handle *h);

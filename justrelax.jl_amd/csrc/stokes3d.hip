@@ -775,7 +775,36 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
     JRX_HIP(h, hipEventRecord(t0, s));
     auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
     auto is_check = [&](int64_t it1) { return (it1 % p->nout == 0) && it1 > 1; };
+    // Small grids (the reference's own 3D tests run at 8^3 .. 32^3, test/test_stokes_solvi3D.jl:25-55) are launch-bound: three to four dependent launches
+    // of a few microseconds each per iteration.  Runs of unobserved iterations of the un-fused loop replay as a captured graph of GIT iterations
+    // (option "loop_graphs"; same kernels, same order: identical results; profiles/r03_small_grids_graphs.txt).
+    constexpr int GIT = 16;
+    GraphExecs gexec;
+    bool graphs = h->loop_graphs && !I.fusable && !jrx_comm_active(h) && !p->displacement_bcs && p->periodic == 0 && (double)n <= kGraphCells3D;
     while (keep_going(iter)) {
+        if (graphs && iter >= 2 && I.bcs_ordered[0] && I.cur_is_user && !I.stress_done) {
+            // observed iterations: the multiples of nout and iteration iterMax + 1; between them err does not change, so keep_going holds
+            int64_t nxt = ((iter / p->nout) + 1) * p->nout;
+            if (nxt > p->iterMax + 1) nxt = p->iterMax + 1;
+            int64_t run = nxt - 1 - iter;                     // unobserved iterations from here
+            if (run >= GIT) {
+                if (!gexec[0]) {
+                    JRX_TRY(jrx_capture_graph(s, &gexec[0], [&]() -> jrx_status {
+                        for (int q = 0; q < GIT; q++) JRX_TRY(iter_step(I, false, false, nullptr, nullptr));
+                        return JRX_OK;
+                    }));
+                    if (!gexec[0]) graphs = false;
+                }
+                if (gexec[0]) {
+                    while (run >= GIT) {
+                        JRX_HIP(h, hipGraphLaunch(gexec[0], s));
+                        iter += GIT; run -= GIT;
+                        h->stat_graph_replays++;
+                    }
+                    continue;
+                }
+            }
+        }
         const int64_t it1 = iter + 1;
         const bool check = is_check(it1);
         const bool diag = check || !keep_going(it1);   // results observable after this iteration

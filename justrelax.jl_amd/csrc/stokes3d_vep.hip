@@ -1045,7 +1045,59 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     hipEvent_t t0 = h->ev[6], t1 = h->ev[7];
     JRX_HIP(h, hipEventRecord(t0, s));
     auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
+    // one iteration without neighbours, enqueued on s; A / G: the kernel arguments and the view the velocity sweep takes (their edge-stress pointers swap)
+    auto enqueue_iteration = [&](Vep3Args &A, jrx_stokes3d_fields &G, bool diag_) -> jrx_status {
+        if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((k_vep3_pre<true, false, PRE_KZ>), gpre, dim3(256), 0, s, A);        // compute_maxloc! folded in
+        launch_vep3_visc(s, gc, A, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
+        JRX_LAUNCH_CHECK(h);
+        JRX_TRY(launch_vep3_stress(h, s, A, p, false));
+        // the new edge stresses become the current ones: swap the pointers instead of copying three arrays back
+        { double *t0_ = A.f.tyz; A.f.tyz = A.tnew[0]; A.tnew[0] = t0_; }
+        { double *t1_ = A.f.txz; A.f.txz = A.tnew[1]; A.tnew[1] = t1_; }
+        { double *t2_ = A.f.txy; A.f.txy = A.tnew[2]; A.tnew[2] = t2_; }
+        G.tyz = A.f.tyz; G.txz = A.f.txz; G.txy = A.f.txy;
+        JRX_TRY(jrx3d_velocity_sweep(h, s, &G, A.etatau, &q, diag_));
+        if (diag_) JRX_TRY(jrx3d_scaleU(h, s, &G, &q));
+        // flow_bcs!: on V, or -- DisplacementBoundaryConditions -- on U = V dt, which the next iteration overwrites (only observable when U is)
+        if (!ubc && !diag_ && bcs_ordered && p->periodic == 0) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
+        else if (!ubc) { JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic)); bcs_ordered = true; }
+        else if (diag_) JRX_TRY(jrx3d_bcs(h, s, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
+        return JRX_OK;
+    };
+    // small grids are launch-bound (seven dependent launches per iteration): runs of unobserved iterations replay as a captured graph of GIT iterations
+    // (an even count, so the swapped edge-stress pointers end where they began; one graph per parity; option "loop_graphs")
+    constexpr int GIT = 16;
+    GraphExecs gexec;
+    bool graphs = h->loop_graphs && !comm && !ubc && p->periodic == 0 && (double)n <= kGraphCells3D;
     while (keep_going(iter)) {
+        if (graphs && iter >= 2 && bcs_ordered) {
+            int64_t nxt = ((iter / p->nout) + 1) * p->nout;         // observed iterations: the multiples of nout and iteration iterMax + 1
+            if (nxt > p->iterMax + 1) nxt = p->iterMax + 1;
+            int64_t run = nxt - 1 - iter;
+            if (run >= GIT) {
+                const int par = a.f.tyz == f->tyz ? 0 : 1;
+                if (!gexec[par]) {
+                    const int64_t stat0 = h->stat_vep3_fused;
+                    JRX_TRY(jrx_capture_graph(s, &gexec[par], [&]() -> jrx_status {
+                        Vep3Args A = a;
+                        jrx_stokes3d_fields G = g;
+                        for (int r_ = 0; r_ < GIT; r_++) JRX_TRY(enqueue_iteration(A, G, false));
+                        return JRX_OK;
+                    }));
+                    h->stat_vep3_fused = stat0;
+                    if (!gexec[par]) graphs = false;
+                }
+                if (gexec[par]) {
+                    while (run >= GIT) {
+                        JRX_HIP(h, hipGraphLaunch(gexec[par], s));
+                        iter += GIT; run -= GIT;
+                        h->stat_graph_replays++;
+                    }
+                    continue;
+                }
+            }
+        }
         const int64_t it1 = iter + 1;
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);      // R and U are only observable after such an iteration
@@ -1113,24 +1165,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                 JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, nn));       // update_halo!(@velocity(stokes)...) (Stokes3D.jl:596)
             }
             a.etatau = a.etatau == etatau ? etatau_next : etatau;
-        } else {
-        if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_vep3_pre<true, false, PRE_KZ>), gpre, dim3(256), 0, s, a);        // compute_maxloc! folded in
-        launch_vep3_visc(s, gc, a, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
-        JRX_LAUNCH_CHECK(h);
-        JRX_TRY(launch_vep3_stress(h, s, a, p, false));
-        // the new edge stresses become the current ones: swap the pointers instead of copying three arrays back
-        { double *t0_ = a.f.tyz; a.f.tyz = a.tnew[0]; a.tnew[0] = t0_; }
-        { double *t1_ = a.f.txz; a.f.txz = a.tnew[1]; a.tnew[1] = t1_; }
-        { double *t2_ = a.f.txy; a.f.txy = a.tnew[2]; a.tnew[2] = t2_; }
-        g.tyz = a.f.tyz; g.txz = a.f.txz; g.txy = a.f.txy;
-        JRX_TRY(jrx3d_velocity_sweep(h, s, &g, a.etatau, &q, diag));
-        if (diag) JRX_TRY(jrx3d_scaleU(h, s, &g, &q));
-        // flow_bcs!: on V, or -- DisplacementBoundaryConditions -- on U = V dt, which the next iteration overwrites (only observable when U is)
-        if (!ubc && !diag && bcs_ordered && p->periodic == 0) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
-        else if (!ubc) { JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic)); bcs_ordered = true; }
-        else if (diag) JRX_TRY(jrx3d_bcs(h, s, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
-        }
+        } else JRX_TRY(enqueue_iteration(a, g, diag));
         iter = it1;
         if (check) {
             JRX_TRY(jrx3d_sumsq(h, s, &g, &q));

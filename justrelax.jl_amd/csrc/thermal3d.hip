@@ -521,7 +521,59 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
     const int FR = cfg ? cfg / 10000 : 1, FTX = cfg ? ((cfg / 100) % 100) * 64 : (nx > 128 ? 256 : (nx > 64 ? 128 : 64)), FKZ = cfg ? cfg % 100 : 4;
     const int FXG = h->thermal_xg;
     const int ntx = (nx + FTX - 1) / FTX, nty = (ny + FR - 1) / FR, ntz = (nz + FKZ - 1) / FKZ;
+    // launch_fused: one unobserved iteration from set c into set o (the caller swaps)
+    auto launch_fused = [&](const TSet &c, const TSet &o) -> jrx_status {
+        T3Args b = a;
+        b.t.T = c.T; b.t.qTx = c.qx; b.t.qTy = c.qy; b.t.qTz = c.qz;
+#define THL(TX_, KZ_, R_, XG_)                                                                                                      \
+    if (FTX == TX_ && FKZ == KZ_ && FR == R_ && FXG == XG_) {                                                                       \
+        hipLaunchKernelGGL((k_thermal3d_fused<TX_, KZ_, XG_, R_>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX_), 0, s, b, o, ntx, nty); \
+        launched = true; h->stat_thermal_fused++;                                                                                                         \
+    }
+        bool launched = false;
+        // measured at 256^3 (profiles/r01_thermal3d_fused_sweep.txt): one row per thread 2289 it/s, two rows 1526, four rows 1301
+        THL(256, 4, 1, 8) THL(128, 4, 1, 8) THL(64, 4, 1, 8) THL(256, 8, 1, 8) THL(256, 4, 2, 8)
+        THL(256, 4, 1, 1) THL(256, 4, 1, 2) THL(256, 4, 1, 4) THL(256, 2, 1, 1) THL(256, 2, 1, 2) THL(256, 8, 1, 1) THL(128, 4, 1, 1) THL(64, 4, 1, 1)
+        if (!launched) return jrx_fail(h, JRX_ERR_ARG, "JRX_TH_CFG: no such configuration");
+#undef THL
+        JRX_LAUNCH_CHECK(h);
+        return JRX_OK;
+    };
+    // small grids: runs of unobserved one-launch iterations replay as captured graphs of GIT iterations (an even count: the ping-pong sets end where they
+    // began; one graph per parity), as the 2D loop does (option "loop_graphs"; profiles/r03_small_grids_graphs.txt)
+    constexpr int GIT = 32;
+    GraphExecs gexec;
+    bool graphs = h->loop_graphs && fusable && (double)n <= kGraphCells3D;
     while (err > p->eps && iter < p->iterMax) {
+        if (graphs) {
+            // observed iterations (1-based number it1 = iter + 1): the multiples of nout and every it1 >= iterMax
+            int64_t nxt = ((iter / p->nout) + 1) * p->nout;
+            if (nxt > p->iterMax) nxt = p->iterMax;
+            int64_t run = nxt - 1 - iter;
+            if (run >= GIT) {
+                const int par = cur.T == user.T ? 0 : 1;
+                if (!gexec[par]) {
+                    JRX_TRY(jrx_capture_graph(s, &gexec[par], [&]() -> jrx_status {
+                        TSet c = cur, o = oth;
+                        for (int q = 0; q < GIT; q++) {
+                            JRX_TRY(launch_fused(c, o));
+                            const TSet tmp = c; c = o; o = tmp;
+                        }
+                        return JRX_OK;
+                    }));
+                    if (!gexec[par]) graphs = false;
+                    else h->stat_thermal_fused -= GIT;          // the capture counted launches that have not run
+                }
+                if (gexec[par]) {
+                    while (run >= GIT) {
+                        JRX_HIP(h, hipGraphLaunch(gexec[par], s));
+                        iter += GIT; run -= GIT;
+                        h->stat_thermal_fused += GIT; h->stat_graph_replays++;
+                    }
+                    continue;
+                }
+            }
+        }
         // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one
         const bool q2 = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
         a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy; a.t.qTz = cur.qz;
@@ -533,18 +585,7 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
             a.wpt = pt_fresh;
         }
         if (fusable && !q2) {
-#define THL(TX_, KZ_, R_, XG_)                                                                                                      \
-    if (FTX == TX_ && FKZ == KZ_ && FR == R_ && FXG == XG_) {                                                                       \
-        hipLaunchKernelGGL((k_thermal3d_fused<TX_, KZ_, XG_, R_>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX_), 0, s, a, oth, ntx, nty); \
-        launched = true; h->stat_thermal_fused++;                                                                                                         \
-    }
-            bool launched = false;
-            // measured at 256^3 (profiles/r01_thermal3d_fused_sweep.txt): one row per thread 2289 it/s, two rows 1526, four rows 1301
-            THL(256, 4, 1, 8) THL(128, 4, 1, 8) THL(64, 4, 1, 8) THL(256, 8, 1, 8) THL(256, 4, 2, 8)
-            THL(256, 4, 1, 1) THL(256, 4, 1, 2) THL(256, 4, 1, 4) THL(256, 2, 1, 1) THL(256, 2, 1, 2) THL(256, 8, 1, 1) THL(128, 4, 1, 1) THL(64, 4, 1, 1)
-            if (!launched) return jrx_fail(h, JRX_ERR_ARG, "JRX_TH_CFG: no such configuration");
-#undef THL
-            JRX_LAUNCH_CHECK(h);
+            JRX_TRY(launch_fused(cur, oth));
             const TSet tmp = cur; cur = oth; oth = tmp;
         } else {
             JRX_TRY(enqueue_titer3(h, &a.t, p, ph, q2, true, a.wpt));
