@@ -840,11 +840,21 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
         const int nseg = peel ? nfull : (nx + 1 + 61) / 62, ilim = peel ? 62 * nfull : nx + 1;
         const int ntxy = nseg * ((ny + 1 + 3) / 4), nzc = (nz + 1 + kz - 1) / kz, nt = ntxy * nzc;
         bool ok = false;
+        // the peeled columns are independent of the main launch (disjoint nodes written, only old values read); tuning switch "vep3_peel_fork" runs the thin,
+        // load-instruction-bound node kernel (0.14 ms for 3.5 % of the nodes at 256^3) on the halo stream beside the main kernel -- measured 266.1 / 267.6 it/s
+        // forked vs 269.2 / 269.8 in order (256^3, same box, alternating): off
+        const bool fork = peel && h->vep3_peel_fork && s == h->stream && !jrx_comm_active(h);      // (with neighbours the halo stream carries the exchanges)
+        hipStream_t ps = fork ? h->halo_stream : s;
+        if (fork) {
+            JRX_HIP(h, hipEventRecord(h->ev[5], s));
+            JRX_HIP(h, hipStreamWaitEvent(ps, h->ev[5], 0));
+        }
         if (peel) {
             const dim3 gp((unsigned)(((i64)rem * (ny + 1) + 63) / 64), (unsigned)((nz + 1 + 3) / 4));
-            if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, false, true>), gp, dim3(256), 0, s, a, ilim, rem);
-            else hipLaunchKernelGGL((k_vep3_edges<true, false, false>), gp, dim3(256), 0, s, a, ilim, rem);
+            if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, false, true>), gp, dim3(256), 0, ps, a, ilim, rem);
+            else hipLaunchKernelGGL((k_vep3_edges<true, false, false>), gp, dim3(256), 0, ps, a, ilim, rem);
         }
+        struct Join { jrx_handle *h; hipStream_t s, ps; bool on; ~Join() { if (on) { (void)hipEventRecord(h->ev[5], ps); (void)hipStreamWaitEvent(s, h->ev[5], 0); } } } join{h, s, ps, fork};
         if (a.soft) {       // softening laws: the yield function also reads the edge average of EII_pl
             const dim3 gf((unsigned)(((nt + 7) / 8) * 8 * 3));
 #define EZS(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<16, NP_, 2, true>), gf, dim3(256), 0, s, a, nseg, ntxy, nt, ilim); ok = true; }

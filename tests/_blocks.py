@@ -14,11 +14,11 @@ def coords_of(cart):
     return tuple(cart.coords[d] for d in range(3))
 
 
-def local_block(A, n, ng, coords):
-    """the block of rank `coords` of a global array A (any staggering): extent along d = A.shape[d] - ng[d] + n[d]"""
-    lead = A.ndim - 3           # phase-ratio arrays carry the phase index first
+def local_block(A, n, ng, coords, nd=3):
+    """the block of rank `coords` of a global array A (any staggering): extent along d = A.shape[d] - ng[d] + n[d]; nd = 2 for the 2D drivers"""
+    lead = A.ndim - nd          # phase-ratio arrays carry the phase index first
     idx = [slice(None)] * lead
-    for d in range(3):
+    for d in range(nd):
         off = coords[d] * (n[d] - 2)
         idx.append(slice(off, off + A.shape[lead + d] - ng[d] + n[d]))
     return np.array(A[tuple(idx)], order="F", copy=True)      # always a copy: a z slab of an F-ordered array is contiguous, asfortranarray would alias it
@@ -31,7 +31,7 @@ def n_global(n, dims, periods=(0, 0, 0)):
 def exchange(blocks, n, carts, L):
     """update_halo!(A...) between the blocks of one process: blocks[r] = list of that rank's arrays (same order on every rank), in place."""
     nr = len(blocks)
-    for dim in range(3):
+    for dim in range(blocks[0][0].ndim):
         if all(carts[r].neighbor[dim][0] < 0 and carts[r].neighbor[dim][1] < 0 for r in range(nr)):
             continue
         for a in range(len(blocks[0])):
@@ -45,7 +45,7 @@ def exchange(blocks, n, carts, L):
                     nb = carts[r].neighbor[dim][side]
                     if nb < 0:
                         continue
-                    idx = [slice(None)] * 3
+                    idx = [slice(None)] * blocks[r][a].ndim
                     idx[dim] = rp
                     blocks[r][a][tuple(idx)] = send[nb][1 - side]     # my left ghost plane <- the left neighbour's right-going plane
 

@@ -345,3 +345,54 @@ def test_thermal3d_two_blocks_equal_the_undecomposed_run(jr, dims):
     for r in range(2):
         assert np.isclose(res[r].norm_ResT[-1], np.linalg.norm(Rs[r].ravel()) / np.sqrt(Rs[r].size), rtol=1e-12)
     assert res[0].norm_ResT[-1] != res[1].norm_ResT[-1]
+
+
+@pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1)])
+def test_stokes2d_two_blocks_equal_the_undecomposed_run(jr, dims):
+    """jrx_stokes2d_solve on two blocks (update_halo!(ητ), update_halo!(V) every iteration, norm_mpi; Stokes2D.jl:209,268,277-300), uniform material:
+    every block equals the undecomposed device run bit for bit"""
+    import justrelax_jl_amd.grid as g
+    from justrelax_jl_amd import halo
+    from justrelax_jl_amd.miniapps.common import Setup, download_stokes, upload_stokes
+    n = (40, 23, 1)
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        ng = tb.ng
+        S = jr.miniapps.random_fields2d(ng[:2], seed=6, iterMax=23, nout=8)
+        S.pt.ϵ_rel = S.pt.ϵ_abs = 1e-30
+        for k, v in (("eta", 0.7), ("G", 1.3), ("K", 2.1)):
+            S.arrays[k][...] = v
+        stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+        rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, G, K, S.dt, None, kwargs=kw)
+        glob = download_stokes(stokes)
+        g.init_global_grid(*n, dimx=dims[0], dimy=dims[1], dimz=1, rank=0, nprocs=2)
+        try:
+            grid = jr.Geometry(n[:2], S.extra["li"])
+            ups = []
+            for r in range(2):
+                loc = Setup(ni=n[:2], arrays={k: B.local_block(v, n, ng, B.coords_of(tb.carts[r]), nd=2) for k, v in S.arrays.items()})
+                ups.append(upload_stokes(loc, jr.AMDGPUBackend))
+            res = halo.run_ranks([(lambda r=r: jr.solve_(ups[r][0], S.pt, grid, S.flow_bcs, ups[r][1], ups[r][3], ups[r][2], S.dt, None, kwargs=kw,
+                                                         handle=tb.handles[r])) for r in range(2)])
+            outs = [download_stokes(u[0]) for u in ups]
+        finally:
+            g.finalize_global_grid()
+    assert rg.iter == 24 and all(r.iter == 24 for r in res) and list(res[0].err_evo1) == list(res[1].err_evo1)
+    for r in range(2):
+        for k in ("P", "Vx", "Vy", "txx", "tyy", "txy", "Rx", "Ry", "RP", "exx", "exy"):
+            want = B.local_block(glob[k], n, ng, B.coords_of(tb.carts[r]), nd=2)
+            m = np.ones(want.shape, dtype=bool)
+            if k in ("Vx", "Vy"):       # corner ghosts are never read
+                gd = 1 if k == "Vx" else 0
+                cm = np.zeros(want.shape, dtype=int)
+                idx = [slice(None)] * 2
+                for e in (0, want.shape[gd] - 1):
+                    idx[gd] = e
+                    cm[tuple(idx)] += 1
+                od = 1 - gd
+                idx = [slice(None)] * 2
+                for e in (0, want.shape[od] - 1):
+                    idx[od] = e
+                    cm[tuple(idx)] += 1
+                m = cm < 2
+            assert np.array_equal(outs[r][k][m], want[m]), (dims, r, k, float(np.abs(outs[r][k] - want)[m].max()))
