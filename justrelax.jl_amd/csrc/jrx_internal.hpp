@@ -46,6 +46,7 @@ struct jrx_handle {
     bool fused2d = true;                 // 2D visco-elastic loop: one-launch iterations on launch-bound grids
     bool vep3_peel = true;                   // z-marching edge kernel: a nearly empty last lane segment goes to the node kernel (A/B)
     bool vep3_peel_fork = false;             // ... that thin launch on the halo stream beside the main edge kernel (measured 1 % slower at 256^3: off; A/B)
+    bool vep3_nt = false;                    // 3D VEP kernels: non-temporal stores of the outputs (measured neutral at 256^3: off; A/B)
     int vep3_cfg = 0;                        // z-marching edge kernel: KZ * 10 + min blocks per CU, 0 = default
     int vep3_edges = 1;                      // 3D VEP edge pass: 1 z-marching kernel (2: one launch per family), 0 one node per thread (A/B; the form softening laws use)
     int vep3_hide_comm = 2;                  // multi-rank 3D VEP driver: the three exchanges of an iteration on the halo stream beside independent kernels

@@ -28,6 +28,7 @@ struct Vep3Args {
     double _dx, _dy, _dz, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
     int nx, ny, nz;
     bool soft;            // some phase has a softening law: the yield function then reads EII_pl
+    bool nt;              // outputs with non-temporal stores
     bool tg;              // args.T is the ghosted thermal.T (ni .+ 2): densities read it at the cell's own [i, j, k], unshifted
 };
 
@@ -120,6 +121,9 @@ __device__ __forceinline__ void plastic_grad3(const jrx_rheology &rh, const doub
     }
 }
 
+// store of an output array that no thread of this launch reads back: non-temporal when a.nt (the lines do not displace the operands the neighbouring
+// blocks are about to re-read from L2; tuning switch "vep3_nt")
+#define VST(a_, ptr_, val_) do { double *q_ = &(ptr_); const double v_ = (val_); if ((a_).nt) __builtin_nontemporal_store(v_, q_); else *q_ = v_; } while (0)
 #define C3(A, i, j, k) (A)[(i) + (i64)nx * ((j) + (i64)ny * (k))]
 #define EYZ(A, i, j, k) (A)[(i) + (i64)nx * ((j) + (i64)(ny + 1) * (k))]
 #define EXZ(A, i, j, k) (A)[(i) + (i64)(nx + 1) * ((j) + (i64)ny * (k))]
@@ -175,11 +179,11 @@ __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
             const double dyi = (-VY(i + 1, j, k + 1) + VY(i + 1, j + 1, k + 1)) * _dy;
             const double dzi = (-VZ(i + 1, j + 1, k) + VZ(i + 1, j + 1, k + 1)) * _dz;
             const double divV = dxi + dyi + dzi;
-            a.f.divV[c] = divV;
+            VST(a, a.f.divV[c], divV);
             const double _Kdt = 1.0 / (a.Kc[c] * a.dt), _Gdt = 1.0 / (a.Gc[c] * a.dt), _dt = 1.0 / a.dt;
             const double P = a.theta[c], P0 = a.f.P0[c];
             const double rhs = -divV + (a.f.Q[c] * _dt);
-            a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
+            VST(a, a.f.RP[c], fma(-(P - P0), _Kdt, rhs));
             double et;
             if (ML) {
                 m_next = plane_max(k + 1);
@@ -192,15 +196,15 @@ __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
             const double psi = 1.0 / (1.0 / et + _Gdt) * a.r / a.theta_dtau;
             a.theta[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
             const double d3 = divV * (1.0 / 3.0);
-            a.f.exx[c] = dxi - d3;
-            a.f.eyy[c] = dyi - d3;
-            a.f.ezz[c] = dzi - d3;
+            VST(a, a.f.exx[c], dxi - d3);
+            VST(a, a.f.eyy[c], dyi - d3);
+            VST(a, a.f.ezz[c], dzi - d3);
             if (RHO) a.f.fz[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)a.rh.nphase * c,
                                                    !a.f.T ? 0.0 : (a.tg ? a.f.T[i + (i64)(nx + 2) * (j + (i64)(ny + 2) * k)] : a.f.T[c]), a.f.P[c]) * a.rh.gravity;
         }
-        if (i < nx) EYZ(a.f.eyz, i, j, k) = 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k)));
-        if (j < ny) EXZ(a.f.exz, i, j, k) = 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k)));
-        if (k < nz) EXY(a.f.exy, i, j, k) = 0.5 * (_dy * (VX(i, j + 1, k + 1) - VX(i, j, k + 1)) + _dx * (VY(i + 1, j, k + 1) - VY(i, j, k + 1)));
+        if (i < nx) VST(a, EYZ(a.f.eyz, i, j, k), 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k))));
+        if (j < ny) VST(a, EXZ(a.f.exz, i, j, k), 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k))));
+        if (k < nz) VST(a, EXY(a.f.exy, i, j, k), 0.5 * (_dy * (VX(i, j + 1, k + 1) - VX(i, j, k + 1)) + _dx * (VY(i + 1, j, k + 1) - VY(i, j, k + 1))));
     }
 }
 
@@ -317,11 +321,11 @@ __device__ __forceinline__ void vep3_edge_plastic(const Vep3Args &a, i64 v, cons
         const double l = (1.0 - a.rel) * a.lamv[T][v] + a.rel * (fmax(F, 0.0) / (etav * dtr + m.eta_reg + vol));
         a.lamv[T][v] = l;
         const double epl = l * dQdt[own];
-        a.tnew[T][v] = tij_own + fma(-(2.0 * etav * epl), dtr, d_own);
-        eplsh[T][v] = epl;
+        VST(a, a.tnew[T][v], tij_own + fma(-(2.0 * etav * epl), dtr, d_own));
+        VST(a, eplsh[T][v], epl);
     } else {
-        a.tnew[T][v] = tij_own + d_own;
-        eplsh[T][v] = 0.0;
+        VST(a, a.tnew[T][v], tij_own + d_own);
+        VST(a, eplsh[T][v], 0.0);
     }
 }
 template <int T, bool SOFT>
@@ -696,20 +700,20 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
         double epl[6];
 #pragma unroll
         for (int s = 0; s < 6; s++) { epl[s] = l * dQdt[s]; d[s] = d[s] - 2.0 * e * epl[s] * dtr; tij[s] = d[s] + tij[s]; }
-        a.f.evol_pl[c] = -l * dQdP;
+        VST(a, a.f.evol_pl[c], -l * dQdP);
 #pragma unroll
-        for (int s = 0; s < 6; s++) tc[s][c] = tij[s];
-        a.f.eplxx[c] = epl[0]; a.f.eplyy[c] = epl[1]; a.f.eplzz[c] = epl[2];
+        for (int s = 0; s < 6; s++) VST(a, tc[s][c], tij[s]);
+        VST(a, a.f.eplxx[c], epl[0]); VST(a, a.f.eplyy[c], epl[1]); VST(a, a.f.eplzz[c], epl[2]);
         tII = sinv3(tij);
     } else {
-        a.f.evol_pl[c] = 0.0;
+        VST(a, a.f.evol_pl[c], 0.0);
 #pragma unroll
-        for (int s = 0; s < 6; s++) tc[s][c] = d[s] + tij[s];
-        a.f.eplxx[c] = 0.0; a.f.eplyy[c] = 0.0; a.f.eplzz[c] = 0.0;
+        for (int s = 0; s < 6; s++) VST(a, tc[s][c], d[s] + tij[s]);
+        VST(a, a.f.eplxx[c], 0.0); VST(a, a.f.eplyy[c], 0.0); VST(a, a.f.eplzz[c], 0.0);
     }
-    a.f.tII[c] = tII;
-    a.f.eta_vep[c] = tII * 0.5 * (1.0 / sinv3(eij));
-    a.f.P[c] = Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP);
+    VST(a, a.f.tII[c], tII);
+    VST(a, a.f.eta_vep[c], tII * 0.5 * (1.0 / sinv3(eij)));
+    VST(a, a.f.P[c], Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP));
 }
 
 __device__ __forceinline__ double sinv_stag3(const double *xx, const double *yy, const double *zz, const double *yz, const double *xz, const double *xy,
@@ -811,6 +815,7 @@ Vep3Args make_vep3(const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_
     a.nx = (int)p->nx; a.ny = (int)p->ny; a.nz = (int)p->nz;
     a.soft = mat_has_softening(rh);
     a.tg = p->T_ghosted != 0;
+    a.nt = false;
     return a;
 }
 
@@ -1014,6 +1019,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     JRX_TRY(jrx_ensure_etatau(h, 6 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
     double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n, *etatau_next = Gc + n;
     Vep3Args a = make_vep3(f, rh, p);
+    a.nt = h->vep3_nt;
     a.theta = theta; a.etatau = etatau; a.Kc = Kc; a.Gc = Gc; a.lam = lam;
     a.lamv[0] = etatau_next + n; a.lamv[1] = a.lamv[0] + ne.yz; a.lamv[2] = a.lamv[1] + ne.xz;
     a.tnew[0] = a.lamv[2] + ne.xy; a.tnew[1] = a.tnew[0] + ne.yz; a.tnew[2] = a.tnew[1] + ne.xz;
