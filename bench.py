@@ -398,7 +398,7 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
     from justrelax_jl_amd import _lib, halo, stokes
     from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
     dev = torch.cuda.current_device()
-    DIMS = {"x": (2, 1, 1), "y": (1, 2, 1), "z": (1, 1, 2)}
+    DIMS = {"x": (2, 1, 1), "y": (1, 2, 1), "z": (1, 1, 2), "xyz": (2, 2, 2)}
     out = {"workload": f"SolVi3D, two {n}^3 blocks on one device (in-process transport: hipMemcpyAsync D2D + events)", "steps": steps}
 
     def timed(hs, blocks, k=steps):
@@ -410,15 +410,16 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
         torch.cuda.synchronize()
         return len(hs) * k / (time.perf_counter() - t0)
 
-    def split_leg(name, modes):
+    def split_leg(name, modes, n=n):
         dims = DIMS[name]
-        hs = [_lib.Handle(dev) for _ in range(2)]
+        nr = dims[0] * dims[1] * dims[2]
+        hs = [_lib.Handle(dev) for _ in range(nr)]
         blocks, res = [], {}
         try:
             halo.init_comm_local(hs, halo.make_carts((n, n, n), dims))
-            for r in range(2):
+            for r in range(nr):
                 grid.finalize_global_grid()
-                grid.init_global_grid(n, n, n, rank=r, nprocs=2, dimx=dims[0], dimy=dims[1], dimz=dims[2])
+                grid.init_global_grid(n, n, n, rank=r, nprocs=nr, dimx=dims[0], dimy=dims[1], dimz=dims[2])
                 st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
                 jr.flow_bcs_(st, bcs, handle=hs[r])
                 ητ = jr.fzeros((n, n, n), st.P.device)
@@ -426,7 +427,7 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
                 blocks.append((st, pt, geo, bcs, ρg, K, G, ητ, dt))
             # the ghost planes of V and ητ before the first iteration (what the drivers do at their start)
             halo.run_ranks([(lambda r=r: halo.update_halo_(blocks[r][0].V.Vx, blocks[r][0].V.Vy, blocks[r][0].V.Vz, blocks[r][7], ni=(n, n, n), handle=hs[r]))
-                            for r in range(2)])
+                            for r in range(nr)])
             for mode in modes:
                 for h in hs:
                     h.set_option("fused_overlap", int(mode == "overlap"))
@@ -497,7 +498,7 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
     if only and only[0] == "vep":
         return {"leg": list(only), "block_it_per_s": vep_leg(only[1])}
     if only:       # profiling hook (scripts/bench_multi_rank.py): one coupled leg alone, e.g. ("z", "serial")
-        return {"leg": list(only), "block_it_per_s": split_leg(only[0], [only[1]])}
+        return {"leg": list(only), "block_it_per_s": split_leg(only[0], [only[1]], n=n)}
     best = None
     for name in splits:
         r = split_leg(name, ["serial", "overlap"])

@@ -1,4 +1,4 @@
-"""two blocks on one device through the in-process transport: the bench leg `multi_rank_path` alone (python scripts/bench_multi_rank.py [n] [steps] [x|y|z serial|overlap])"""
+"""two blocks on one device through the in-process transport: the bench leg `multi_rank_path` alone (python scripts/bench_multi_rank.py [n] [steps] [x|y|z|xyz serial|overlap] | vep x|z)"""
 import json
 import sys
 from pathlib import Path

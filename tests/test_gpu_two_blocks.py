@@ -40,7 +40,7 @@ def _get(h, key):
 
 
 class TwoBlocks:
-    """two handles on the current device joined into a 2-rank in-process group"""
+    """prod(dims) handles on the current device joined into an in-process group (two ranks in most tests, 2 x 2 x 2 in the last ones)"""
 
     def __init__(self, n, dims, periods=(0, 0, 0)):
         import torch
@@ -396,3 +396,38 @@ def test_stokes2d_two_blocks_equal_the_undecomposed_run(jr, dims):
                     cm[tuple(idx)] += 1
                 m = cm < 2
             assert np.array_equal(outs[r][k][m], want[m]), (dims, r, k, float(np.abs(outs[r][k] - want)[m].max()))
+
+
+@pytest.mark.parametrize("pipeline", ["fused", "split_sweeps"])
+@pytest.mark.parametrize("dims,n", [((2, 2, 2), (70, 13, 12)), ((2, 2, 1), (70, 13, 12)), ((1, 2, 2), (130, 14, 40))])
+def test_eight_blocks_2x2x2_equal_the_undecomposed_run(jr, dims, n, pipeline):
+    """BASELINE configs[3] in miniature: the 2 x 2 x 2 block decomposition of north_star (eight ranks = eight handles of this process on ONE device,
+    each on its own host thread), where every block has three faces with a neighbour and the edge / corner values of the ghost planes only arrive through the
+    x -> y -> z order of update_halo! (a two-rank run cannot see a mistake there).  Uniform material: every block equals the undecomposed device run bit for bit."""
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    from justrelax_jl_amd.checks import interior_mask3d
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        nr = len(tb.handles)
+        assert nr == int(np.prod(dims))
+        S = _global_setup(jr, tb.ng, True, 23, 8, seed=12)
+        h0 = _lib.default_handle()
+        _set(h0, kernel_variant=1)
+        try:
+            stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+            rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw)
+            glob = download_stokes(stokes)
+        finally:
+            _set(h0, kernel_variant=0)
+        res, outs = _solve_blocks(jr, tb, S, pipeline, kw)
+        faces = [sum(1 for d in range(3) for sd in range(2) if tb.carts[r].neighbor[d][sd] >= 0) for r in range(nr)]
+    assert all(f == sum(1 for d in dims if d > 1) for f in faces)          # every block: one neighbour per split dimension
+    assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    assert all(list(r.err_evo1) == list(res[0].err_evo1) for r in res)
+    for r, out in enumerate(outs):
+        co = B.coords_of(tb.carts[r])
+        for k in STATE + ("Rx", "Ry", "Rz", "RP"):
+            want = B.local_block(glob[k], n, tb.ng, co)
+            m = interior_mask3d(k, want.shape)
+            assert np.array_equal(out[k][m], want[m]), (pipeline, dims, r, co, k, float(np.abs(out[k] - want)[m].max()))
