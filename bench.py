@@ -45,9 +45,9 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measure
 # L2<->fabric bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
 # correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
 # n = 512 (profiles/*pmc*traffic.txt; the file names are in PMC_SOURCE)
-PMC_TRAFFIC_STRESS_512 = 32.545e9       # k_stress3d_zb: 24.965 GB fetched (x2 applied) + 7.580 GB written
-PMC_TRAFFIC_FUSED_512 = 52.364e9        # k_fused3d:     41.050 GB fetched (x2 applied) + 11.314 GB written (38.2 + 10.5 array passes)
-PMC_SOURCE = {"stress": "profiles/r02_pmc_bench_traffic.txt", "fused": "profiles/r02_pmc_bench_traffic.txt"}
+PMC_TRAFFIC_STRESS_512 = 32.543e9       # k_stress3d_zb: 24.962 GB fetched (x2 applied) + 7.581 GB written
+PMC_TRAFFIC_FUSED_512 = 52.351e9        # k_fused3d:     41.035 GB fetched (x2 applied) + 11.316 GB written (38.2 + 10.5 array passes)
+PMC_SOURCE = {"stress": "profiles/r03_pmc_bench_traffic.txt", "fused": "profiles/r03_pmc_bench_traffic.txt"}
 
 
 # ------------------------------------------------------------------------------------------------ launching

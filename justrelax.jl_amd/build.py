@@ -5,7 +5,7 @@
 -ffp-contract=off: fused multiply-adds appear only where the source says fma(), which is where the
 reference has fma/muladd, so device results track the CPU restatement to the last bits.
 
-The library carries a build id = sha256 over csrc/*, include/*.h, the compiler flags, the source list and the hipcc version (jrx_build_id()).  A rebuild is skipped only when the existing
+The library carries a build id = sha256 over csrc/*, include/*.h, the compiler flags, the source list and the ROCm release of the compiler (jrx_build_id()).  A rebuild is skipped only when the existing
 .so carries the id of the current sources; `_lib.load()` compares the two again at load time and refuses a stale binary.
 """
 from __future__ import annotations
@@ -25,31 +25,26 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 MARKER = b"JRX_BUILD_ID="
 
 
-_HIPCC_VERSION = None
-
-
-def hipcc_version() -> str:
-    """first line of `hipcc --version` ("" when there is no hipcc: the GPU box only loads the prebuilt binary, and the id it checks
-    then covers sources and flags)"""
-    global _HIPCC_VERSION
-    if _HIPCC_VERSION is None:
-        try:
-            out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], capture_output=True, text=True, timeout=60).stdout
-            _HIPCC_VERSION = next((l.strip() for l in out.splitlines() if "HIP version" in l), "")
-        except Exception:
-            _HIPCC_VERSION = ""
-    return _HIPCC_VERSION
+def toolchain_version() -> str:
+    """the ROCm release the compiler belongs to, read from /opt/rocm/.info/version -- a file, not `hipcc --version`: source_id() also runs inside
+    processes that have initialised the GPU (the binding checks the id at load time), and starting a child process from such a process is refused on the
+    GPU boxes"""
+    rocm = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+    try:
+        return (rocm / ".info" / "version").read_text().strip()
+    except OSError:
+        return ""
 
 
 def source_id() -> str:
     """sha256 over everything the binary depends on: the sources (file names and contents, sorted), both headers, the compiler flags
-    (-ffp-contract=off / -fno-fast-math are what the bit-for-bit agreement with the oracle rests on), the source list and the hipcc version"""
+    (-ffp-contract=off / -fno-fast-math are what the bit-for-bit agreement with the oracle rests on), the source list and the ROCm release"""
     hsh = hashlib.sha256()
     files = sorted(p for p in CSRC.iterdir() if p.suffix in (".hip", ".hpp")) + sorted((HERE.parent / "include").glob("*.h"))
     for p in files:
         hsh.update(p.name.encode() + b"\0" + p.read_bytes() + b"\0")
     flags = [f for f in FLAGS if not f.startswith("/")]          # paths differ between the build container and the GPU box
-    hsh.update(("\0".join(flags) + "\1" + "\0".join(SRCS) + "\1" + hipcc_version()).encode())
+    hsh.update(("\0".join(flags) + "\1" + "\0".join(SRCS) + "\1" + toolchain_version()).encode())
     return hsh.hexdigest()
 
 
