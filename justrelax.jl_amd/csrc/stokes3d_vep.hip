@@ -481,8 +481,12 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a, const int 
 // FAM: bit T set = family T (0 yz, 1 xz, 2 xy) is updated by this launch; what the other families alone need (loads, lane exchanges, carried
 // sums) is dead code then
 // ilim: the node columns i >= ilim are left to another launch (the last, nearly empty lane segment of a row is given to the one-node-per-thread kernel)
-template <int KZ, int NP, int FAM, bool SOFT = false>
-__device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int seg, const int j, const int zchunk, const int ilim)
+// LDSC: the three family waves of a (row, lane segment) form ONE workgroup and share the centre operands of every plane through LDS: wave f loads the
+// arrays s with s % 3 == f (rows j-1 and j of its own column), all three read the 2 x NC values back after a barrier (two buffers, one barrier per plane) --
+// 8 instead of 22 centre loads per wave and plane, and every centre line is fetched exactly once per tile whatever the dispatcher does with the blocks.
+// sh: [2][12][2][64] doubles of the workgroup; fidx: this wave's index 0..2 among the loaders.
+template <int KZ, int NP, int FAM, bool SOFT = false, bool LDSC = false, bool LDSS = false>
+__device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int seg, const int j, const int zchunk, const int ilim, double *sh = nullptr, const int fidx = 0)
 {
     constexpr int NC = SOFT ? 12 : 11;          // centre arrays averaged to the edges; softening laws add EII_pl (StressKernels.jl:710,783,854)
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP;
@@ -510,22 +514,62 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
     const u32 pc = 8u * (u32)(nx * ny), py = 8u * (u32)(nx * (ny + 1)), px = 8u * (u32)((nx + 1) * ny), pz = 8u * (u32)((nx + 1) * (ny + 1));
     const bool act0 = useful && i < nx, act1 = useful && j < ny;             // yz / xz edge exists at this (i, j); xy: useful && k < nz
     double pyz[NC], pxz[NC], Yn[3][2], Xn[3][2], Zc[3][2];
-    {
-        const u32 kc = (u32)clampi3(kb - 1, 0, nz - 1);
+    // LDSC: publish the (row j-1, row j) values of the arrays this wave loads for plane kp into buffer b; everybody reads them back after the barrier
+    auto publish = [&](u32 kp, int b) {
 #pragma unroll
         for (int s = 0; s < NC; s++) {
-            double v0 = LB(cen[s], oc0 + pc * kc), v1 = LB(cen[s], oc1 + pc * kc);
+            if (s % 3 != fidx) continue;
+            double v0 = LB(cen[s], oc0 + pc * kp), v1 = LB(cen[s], oc1 + pc * kp);
             if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
+            sh[((b * NC + s) * 2 + 0) * 64 + lane] = v0;
+            sh[((b * NC + s) * 2 + 1) * 64 + lane] = v1;
+        }
+    };
+    // ... and the 18 shear operands of a plane step (rows of the yz / xz components at plane ky, of the xy components at plane kz), same partition
+    double *const shs = sh + 2 * NC * 2 * 64;
+    auto publish_shear = [&](u32 ky, u32 kz, int b) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if ((6 * q + 0) % 3 == fidx) shs[(b * 18 + 6 * q + 0) * 64 + lane] = LB(Yp[q], oy1 + py * ky);
+            if ((6 * q + 1) % 3 == fidx) shs[(b * 18 + 6 * q + 1) * 64 + lane] = LB(Yp[q], oy2 + py * ky);
+            if ((6 * q + 2) % 3 == fidx) shs[(b * 18 + 6 * q + 2) * 64 + lane] = LB(Xp[q], ox0 + px * ky);
+            if ((6 * q + 3) % 3 == fidx) shs[(b * 18 + 6 * q + 3) * 64 + lane] = LB(Xp[q], ox1 + px * ky);
+            if ((6 * q + 4) % 3 == fidx) shs[(b * 18 + 6 * q + 4) * 64 + lane] = LB(Zp[q], oz1 + pz * kz);
+            if ((6 * q + 5) % 3 == fidx) shs[(b * 18 + 6 * q + 5) * 64 + lane] = LB(Zp[q], oz2 + pz * kz);
+        }
+    };
+    auto read_shear = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            Yn[q][0] = shs[(b * 18 + 6 * q + 0) * 64 + lane]; Yn[q][1] = shs[(b * 18 + 6 * q + 1) * 64 + lane];
+            Xn[q][0] = shs[(b * 18 + 6 * q + 2) * 64 + lane]; Xn[q][1] = shs[(b * 18 + 6 * q + 3) * 64 + lane];
+            Zc[q][0] = shs[(b * 18 + 6 * q + 4) * 64 + lane]; Zc[q][1] = shs[(b * 18 + 6 * q + 5) * 64 + lane];
+        }
+    };
+    {
+        const u32 kc = (u32)clampi3(kb - 1, 0, nz - 1);
+        if constexpr (LDSC) { publish(kc, 0); if constexpr (LDSS) publish_shear((u32)clampi3(kb, 0, nz - 1), kc, 0); __syncthreads(); }
+#pragma unroll
+        for (int s = 0; s < NC; s++) {
+            double v0, v1;
+            if constexpr (LDSC) { v0 = sh[((0 * NC + s) * 2 + 0) * 64 + lane]; v1 = sh[((0 * NC + s) * 2 + 1) * 64 + lane]; }
+            else {
+                v0 = LB(cen[s], oc0 + pc * kc); v1 = LB(cen[s], oc1 + pc * kc);
+                if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
+            }
             const double u1 = up(v1);
             pyz[s] = v0 + v1;
             pxz[s] = u1 + v1;
         }
         const u32 k1 = (u32)clampi3(kb, 0, nz - 1);
+        if constexpr (LDSS) read_shear(0);
+        else {
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            Yn[q][0] = LB(Yp[q], oy1 + py * k1); Yn[q][1] = LB(Yp[q], oy2 + py * k1);
-            Xn[q][0] = LB(Xp[q], ox0 + px * k1); Xn[q][1] = LB(Xp[q], ox1 + px * k1);
-            Zc[q][0] = LB(Zp[q], oz1 + pz * kc); Zc[q][1] = LB(Zp[q], oz2 + pz * kc);
+            for (int q = 0; q < 3; q++) {
+                Yn[q][0] = LB(Yp[q], oy1 + py * k1); Yn[q][1] = LB(Yp[q], oy2 + py * k1);
+                Xn[q][0] = LB(Xp[q], ox0 + px * k1); Xn[q][1] = LB(Xp[q], ox1 + px * k1);
+                Zc[q][0] = LB(Zp[q], oz1 + pz * kc); Zc[q][1] = LB(Zp[q], oz2 + pz * kc);
+            }
         }
     }
 #pragma unroll 1
@@ -535,9 +579,15 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
         const i64 vi[3] = {i + (i64)nx * (j + (i64)(ny + 1) * k), i + (i64)(nx + 1) * (j + (i64)ny * k), i + (i64)(nx + 1) * (j + (i64)(ny + 1) * k)};
         const double *const rv[3] = {a.f.phase_yz + (act0 ? np * vi[0] : 0), a.f.phase_xz + (act1 ? np * vi[1] : 0), a.f.phase_xy + (act2 ? np * vi[2] : 0)};
         // the four cells of array s around the node, in plane clamp(k): sums of the three families, then the carried partial sums of the next plane
+        const int bsel = (k - kb + 1) & 1;            // the prologue used buffer 0
+        if constexpr (LDSC) { publish(k1, bsel); if constexpr (LDSS) publish_shear(k2, k1, bsel); __syncthreads(); }
         auto sums = [&](int s, double S[3]) {
-            double v0 = LB(cen[s], oc0 + pc * k1), v1 = LB(cen[s], oc1 + pc * k1);
-            if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
+            double v0, v1;
+            if constexpr (LDSC) { v0 = sh[((bsel * NC + s) * 2 + 0) * 64 + lane]; v1 = sh[((bsel * NC + s) * 2 + 1) * 64 + lane]; }
+            else {
+                v0 = LB(cen[s], oc0 + pc * k1); v1 = LB(cen[s], oc1 + pc * k1);
+                if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
+            }
             const double u0 = up(v0), u1 = up(v1);
             S[0] = (pyz[s] + v0) + v1;
             S[1] = (pxz[s] + u1) + v1;
@@ -579,10 +629,13 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             Yc[q][0] = Yn[q][0]; Yc[q][1] = Yn[q][1]; Xc[q][0] = Xn[q][0]; Xc[q][1] = Xn[q][1]; Zq[q][0] = Zc[q][0]; Zq[q][1] = Zc[q][1];
-            Yn[q][0] = LB(Yp[q], oy1 + py * k2); Yn[q][1] = LB(Yp[q], oy2 + py * k2);
-            Xn[q][0] = LB(Xp[q], ox0 + px * k2); Xn[q][1] = LB(Xp[q], ox1 + px * k2);
-            Zc[q][0] = LB(Zp[q], oz1 + pz * k1); Zc[q][1] = LB(Zp[q], oz2 + pz * k1);
+            if constexpr (!LDSS) {
+                Yn[q][0] = LB(Yp[q], oy1 + py * k2); Yn[q][1] = LB(Yp[q], oy2 + py * k2);
+                Xn[q][0] = LB(Xp[q], ox0 + px * k2); Xn[q][1] = LB(Xp[q], ox1 + px * k2);
+                Zc[q][0] = LB(Zp[q], oz1 + pz * k1); Zc[q][1] = LB(Zp[q], oz2 + pz * k1);
+            }
         }
+        if constexpr (LDSS) read_shear(bsel);
         double own_t[3], own_d[3];
         auto trial = [&](int T, const double o[3]) { return o[1] + dev_stress_inc(o[1], o[2], etav[T], o[0], m[T]._Gdt, dtr[T]); };
         if constexpr ((FAM & 1) != 0) {   // yz edge: own (i, j, k); xz at (i, i+1) x (j-1, j); xy at (i, i+1) x planes (k-1, k)
@@ -650,6 +703,21 @@ __global__ __launch_bounds__(256, MINB) void k_vep3_edges_zf(const Vep3Args a, i
     if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT>(a, txy % nseg, j, zc, ilim);
     else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT>(a, txy % nseg, j, zc, ilim);
     else vep3_edges_z_tile<KZ, NP, 4, SOFT>(a, txy % nseg, j, zc, ilim);
+}
+// The LDS-sharing form (see LDSC above): a workgroup = the three family waves of one (row, lane segment, z chunk); tiles in the XCD slab order of k_vep3_edges_zf.
+template <int KZ, int NP, bool SOFT = false, bool LDSS = false>
+__global__ __launch_bounds__(192) void k_vep3_edges_zl(const Vep3Args a, int nseg, int ntile_xy, int ntiles, int ilim)
+{
+    __shared__ double sh[2 * (SOFT ? 12 : 11) * 2 * 64 + (LDSS ? 2 * 18 * 64 : 0)];       // LDSS: 40 KB without softening laws, four workgroups (12 waves) per CU
+    const unsigned L = blockIdx.x, xcd = L & 7u, q = L >> 3;
+    const unsigned per = ((unsigned)ntiles + 7u) / 8u;
+    const unsigned t = xcd * per + q;
+    if (q >= per || t >= (unsigned)ntiles) return;                  // whole workgroups
+    const int txy = (int)(t % (unsigned)ntile_xy), zc = (int)(t / (unsigned)ntile_xy);
+    const int fam = (int)(threadIdx.x >> 6), j = txy / nseg;        // ntile_xy = nseg * (ny + 1): one row per workgroup
+    if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 0);
+    else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 1);
+    else vep3_edges_z_tile<KZ, NP, 4, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 2);
 }
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
 template <bool SOFT>
@@ -860,11 +928,26 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
             else hipLaunchKernelGGL((k_vep3_edges<true, false, false>), gp, dim3(256), 0, ps, a, ilim, rem);
         }
         struct Join { jrx_handle *h; hipStream_t s, ps; bool on; ~Join() { if (on) { (void)hipEventRecord(h->ev[5], ps); (void)hipStreamWaitEvent(s, h->ev[5], 0); } } } join{h, s, ps, fork};
-        if (a.soft) {       // softening laws: the yield function also reads the edge average of EII_pl
+        if (a.soft && h->vep3_edges == 4) {       // softening laws: the yield function also reads the edge average of EII_pl (a twelfth shared centre array);
+                                                  // measured at 256^3: 195.7 it/s through LDS vs 214.9 with one family per block (254 VGPRs either way): only on request
+            const int ntxy_l = nseg * (ny + 1), nt_l = ntxy_l * nzc;
+            const dim3 gl((unsigned)(((nt_l + 7) / 8) * 8));
+#define EZLS(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zl<16, NP_, true>), gl, dim3(192), 0, s, a, nseg, ntxy_l, nt_l, ilim); ok = true; }
+            EZLS(1) EZLS(2) EZLS(3) EZLS(4)
+#undef EZLS
+        } else if (a.soft) {
             const dim3 gf((unsigned)(((nt + 7) / 8) * 8 * 3));
 #define EZS(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<16, NP_, 2, true>), gf, dim3(256), 0, s, a, nseg, ntxy, nt, ilim); ok = true; }
             EZS(1) EZS(2) EZS(3) EZS(4)
 #undef EZS
+        } else if (h->vep3_edges == 3 || h->vep3_edges == 4) {
+            const int ntxy_l = nseg * (ny + 1), nt_l = ntxy_l * nzc;
+            const dim3 gl((unsigned)(((nt_l + 7) / 8) * 8));
+#define EZL(NP_) if (kz == 16 && np_ == NP_) { if (h->vep3_edges == 4) hipLaunchKernelGGL((k_vep3_edges_zl<16, NP_, false, true>), gl, dim3(192), 0, s, a, nseg, ntxy_l, nt_l, ilim); \
+                else hipLaunchKernelGGL((k_vep3_edges_zl<16, NP_>), gl, dim3(192), 0, s, a, nseg, ntxy_l, nt_l, ilim); ok = true; }
+            EZL(1) EZL(2) EZL(3) EZL(4)
+#undef EZL
+
         } else if (h->vep3_edges == 2) {
             const dim3 g((unsigned)ntxy, (unsigned)nzc);
 #define EZ(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 1>), g, dim3(256), 0, s, a, nseg, ilim); \

@@ -208,13 +208,13 @@ def _build_vep3(jr, ni, seed=77):
 @pytest.mark.parametrize("ni", [(256, 256, 256), (200, 96, 70)])
 def test_vep3d_edge_kernel_forms_agree_at_full_size(jr, ni):
     """the z-marching edge kernel of the 3D visco-elasto-plastic stress update (one family per block, 62-node lane segments, 16-plane chunks, XCD-grouped
-    tiles) and the one-node-per-thread kernel the oracle checks at small sizes must leave bit-identical states after three yielding PT iterations"""
+    tiles), its LDS-sharing form (the three family waves of a row as one workgroup) and the one-node-per-thread kernel the oracle checks at small sizes must leave bit-identical states after three yielding PT iterations"""
     import torch
     from justrelax_jl_amd import _lib
     h = _lib.default_handle()
     outs = []
     try:
-        for edges in (0, 1):
+        for edges in (0, 1, 3):
             h.call("jrx_tuning_set", C.c_char_p(b"vep3_edges"), C.c_int64(edges))
             s, st, pr, ρg = _build_vep3(jr, ni)
             r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=dict(iterMax=2, nout=10 ** 9, verbose=False))
@@ -228,7 +228,8 @@ def test_vep3d_edge_kernel_forms_agree_at_full_size(jr, ni):
             del st, pr, ρg, keep
             torch.cuda.empty_cache()
     finally:
-        h.call("jrx_tuning_set", C.c_char_p(b"vep3_edges"), C.c_int64(1))
+        h.call("jrx_tuning_set", C.c_char_p(b"vep3_edges"), C.c_int64(3))
     assert float(outs[0]["eplyz"].abs().max()) > 0.0 and bool((outs[0]["eplyz"] == 0).any())      # yielding and elastic edges both occur
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+        assert torch.equal(outs[0][k], outs[2][k]), k          # 3: the family waves of a row share the centre operands through LDS (the default form)
