@@ -8,8 +8,8 @@
  *   "fused_split" (0)             no neighbours: high-face tiles + boundary stress layers forked onto the halo stream
  *   "b_width_x/y/z" (0)           > 0 overrides jrx_stokes3d_params.b_width of the split sweeps
  *   "fused2d" (1)                 2D visco-elastic loop: one-launch iterations on launch-bound grids
- *   "vep3_edges" (3)              3D VEP edge pass: 3 = z-marching kernel, the three family waves of a row share the centre operands through LDS; 1 = the same,
- *                                 one family per block, no LDS; 2 = one launch per family; 4 = shear operands through LDS too; 0 = one node per thread
+ *   "vep3_edges" (4)              3D VEP edge pass: 4 = z-marching kernel, the three family waves of a row share the centre and shear operands through LDS;
+ *                                 3 = centre operands only; 1 = no LDS, one family per block; 2 = one launch per family; 0 = one node per thread
  *   "vep3_cfg", "vep3_peel", "vep3_peel_fork", "vep3_map", "vep3_xcd"     z-marching edge kernel: chunk depth / occupancy, peeling of a thin last segment, thread map, XCD slabs
  *   "vep3_hide_comm" (2)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 = the first two only,
  *                                 update_halo!(V) behind the whole velocity sweep; 0 = everything on the compute stream, in order (A/B)

@@ -48,8 +48,8 @@ struct jrx_handle {
     bool vep3_peel_fork = false;             // ... that thin launch on the halo stream beside the main edge kernel (measured 1 % slower at 256^3: off; A/B)
     bool vep3_nt = false;                    // 3D VEP kernels: non-temporal stores of the outputs (measured neutral at 256^3: off; A/B)
     int vep3_cfg = 0;                        // z-marching edge kernel: KZ * 10 + min blocks per CU, 0 = default
-    int vep3_edges = 3;                      // 3D VEP edge pass: 3 z-marching kernel, the three family waves of a row share the centre operands through LDS;
-                                             // 1 the same without LDS (one family per block), 2 one launch per family, 4 shear operands through LDS too, 0 one node per thread (A/B)
+    int vep3_edges = 4;                      // 3D VEP edge pass: 4 z-marching kernel, the three family waves of a row share the centre and shear operands through LDS;
+                                             // 3 centre operands only, 1 no LDS (one family per block), 2 one launch per family, 0 one node per thread (A/B)
     int vep3_hide_comm = 2;                  // multi-rank 3D VEP driver: the three exchanges of an iteration on the halo stream beside independent kernels
                                              // (1: ητ and the edge stresses only, 0: serial; A/B)
     bool vep3_map = true, vep3_xcd = true;   // 3D VEP edge kernel thread mapping / XCD slab order (A/B)

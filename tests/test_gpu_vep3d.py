@@ -69,12 +69,13 @@ def _randomize(s, seed=4, Kb=3.0, psi=6.0):
 
 @pytest.mark.parametrize("edges,ni", [(0, (13, 9, 7)), (0, (70, 5, 6)), (1, (13, 9, 7)), (1, (70, 5, 6)), (1, (125, 6, 18)), (1, (61, 7, 33)),
                                       (1, (62, 4, 16)), (1, (3, 3, 3)), (2, (70, 5, 6)), (2, (13, 9, 7)),
-                                      (3, (13, 9, 7)), (3, (70, 5, 6)), (3, (125, 6, 18)), (3, (61, 7, 33)), (3, (62, 4, 16)), (3, (3, 3, 3))])
+                                      (3, (13, 9, 7)), (3, (70, 5, 6)), (3, (125, 6, 18)), (3, (61, 7, 33)), (3, (62, 4, 16)), (3, (3, 3, 3)),
+                                      (4, (13, 9, 7)), (4, (70, 5, 6)), (4, (125, 6, 18)), (4, (61, 7, 33)), (4, (62, 4, 16)), (4, (3, 3, 3))])
 def test_update_stresses_3d_matches_oracle(jr, oracle, edges, ni):
     """update_stresses_center_vertex_ps! 3D (StressKernels.jl:671-989) on random states: yielding and elastic nodes, mixed
     phase ratios, dilatant plasticity with finite bulk modulus.  edges = 1: the z-marching edge kernel, one family per block (grids spanning one, two and three
     62-node lane segments and one to three z chunks), 2: the same as one launch per family, 3: the three family waves of a row as one workgroup sharing the
-    centre operands through LDS, 0: one node per thread."""
+    centre operands through LDS, 4 (default): the shear operands too, 0: one node per thread."""
     from justrelax_jl_amd import _lib, stokes as st_mod
     from justrelax_jl_amd.arrays import from_numpy
     from justrelax_jl_amd.checks import max_rel_diff
@@ -102,7 +103,7 @@ def test_update_stresses_3d_matches_oracle(jr, oracle, edges, ni):
         h.call("jrx_vep3d_update_stresses", C.byref(fd), C.c_void_p(th_d.data_ptr()), C.c_void_p(lam_d.data_ptr()), lv,
                C.byref(st_mod.rheology_table(phases)), C.byref(pd))
     finally:
-        h.call("jrx_tuning_set", C.c_char_p(b"vep3_edges"), C.c_int64(3))
+        h.call("jrx_tuning_set", C.c_char_p(b"vep3_edges"), C.c_int64(4))
     out = _download(jr, stokes)
     assert (lam_r != lam).any() and (lam_r == lam).any() and (ref["eplxz"] != 0).any() and (ref["eplxz"] == 0).any()
     for k in ("txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "txz_c", "txy_c", "tII", "eta_vep", "P", "eplxx", "eplyy", "eplzz", "eplyz", "eplxz",
