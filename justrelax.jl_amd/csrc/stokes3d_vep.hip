@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a, const int 
 // arrays s with s % 3 == f (rows j-1 and j of its own column), all three read the 2 x NC values back after a barrier (two buffers, one barrier per plane) --
 // 8 instead of 22 centre loads per wave and plane, and every centre line is fetched exactly once per tile whatever the dispatcher does with the blocks.
 // sh: [2][12][2][64] doubles of the workgroup; fidx: this wave's index 0..2 among the loaders.
-template <int KZ, int NP, int FAM, bool SOFT = false, bool LDSC = false, bool LDSS = false, bool PRE = false>
+template <int KZ, int NP, int FAM, bool SOFT = false, bool LDSC = false, bool LDSS = false>
 __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int seg, const int j, const int zchunk, const int ilim, double *sh = nullptr, const int fidx = 0)
 {
     constexpr int NC = SOFT ? 12 : 11;          // centre arrays averaged to the edges; softening laws add EII_pl (StressKernels.jl:710,783,854)
@@ -525,26 +525,6 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             sh[((b * NC + s) * 2 + 1) * 64 + lane] = v1;
         }
     };
-    // PRE: the wave's share of the centre loads is issued one plane ahead (into nv) and only stored to LDS at the top of the next plane
-    constexpr int NSH = (NC + 2) / 3;
-    double nv[NSH][2];
-    auto prefetch = [&](u32 kp) {
-#pragma unroll
-        for (int s = 0; s < NC; s++) {
-            if (s % 3 != fidx) continue;
-            nv[s / 3][0] = LB(cen[s], oc0 + pc * kp); nv[s / 3][1] = LB(cen[s], oc1 + pc * kp);
-        }
-    };
-    auto publish_pre = [&](int b) {
-#pragma unroll
-        for (int s = 0; s < NC; s++) {
-            if (s % 3 != fidx) continue;
-            double v0 = nv[s / 3][0], v1 = nv[s / 3][1];
-            if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
-            sh[((b * NC + s) * 2 + 0) * 64 + lane] = v0;
-            sh[((b * NC + s) * 2 + 1) * 64 + lane] = v1;
-        }
-    };
     // ... and the 18 shear operands of a plane step (rows of the yz / xz components at plane ky, of the xy components at plane kz), same partition
     double *const shs = sh + 2 * NC * 2 * 64;
     auto publish_shear = [&](u32 ky, u32 kz, int b) {
@@ -568,7 +548,7 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
     };
     {
         const u32 kc = (u32)clampi3(kb - 1, 0, nz - 1);
-        if constexpr (LDSC) { publish(kc, 0); if constexpr (LDSS) publish_shear((u32)clampi3(kb, 0, nz - 1), kc, 0); __syncthreads(); if constexpr (PRE) prefetch((u32)clampi3(kb, 0, nz - 1)); }
+        if constexpr (LDSC) { publish(kc, 0); if constexpr (LDSS) publish_shear((u32)clampi3(kb, 0, nz - 1), kc, 0); __syncthreads(); }
 #pragma unroll
         for (int s = 0; s < NC; s++) {
             double v0, v1;
@@ -600,7 +580,7 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
         const double *const rv[3] = {a.f.phase_yz + (act0 ? np * vi[0] : 0), a.f.phase_xz + (act1 ? np * vi[1] : 0), a.f.phase_xy + (act2 ? np * vi[2] : 0)};
         // the four cells of array s around the node, in plane clamp(k): sums of the three families, then the carried partial sums of the next plane
         const int bsel = (k - kb + 1) & 1;            // the prologue used buffer 0
-        if constexpr (LDSC) { if constexpr (PRE) publish_pre(bsel); else publish(k1, bsel); if constexpr (LDSS) publish_shear(k2, k1, bsel); __syncthreads(); if constexpr (PRE) { if (k + 1 < ke) prefetch(k2); } }
+        if constexpr (LDSC) { publish(k1, bsel); if constexpr (LDSS) publish_shear(k2, k1, bsel); __syncthreads(); }
         auto sums = [&](int s, double S[3]) {
             double v0, v1;
             if constexpr (LDSC) { v0 = sh[((bsel * NC + s) * 2 + 0) * 64 + lane]; v1 = sh[((bsel * NC + s) * 2 + 1) * 64 + lane]; }
@@ -725,7 +705,7 @@ __global__ __launch_bounds__(256, MINB) void k_vep3_edges_zf(const Vep3Args a, i
     else vep3_edges_z_tile<KZ, NP, 4, SOFT>(a, txy % nseg, j, zc, ilim);
 }
 // The LDS-sharing form (see LDSC above): a workgroup = the three family waves of one (row, lane segment, z chunk); tiles in the XCD slab order of k_vep3_edges_zf.
-template <int KZ, int NP, bool SOFT = false, bool LDSS = false, bool PRE = false>
+template <int KZ, int NP, bool SOFT = false, bool LDSS = false>
 __global__ __launch_bounds__(192, SOFT ? 2 : 3) void k_vep3_edges_zl(const Vep3Args a, int nseg, int ntile_xy, int ntiles, int ilim)
 {
     __shared__ double sh[2 * (SOFT ? 12 : 11) * 2 * 64 + (LDSS ? 2 * 18 * 64 : 0)];       // LDSS: 40 KB without softening laws, four workgroups (12 waves) per CU
@@ -735,9 +715,9 @@ __global__ __launch_bounds__(192, SOFT ? 2 : 3) void k_vep3_edges_zl(const Vep3A
     if (q >= per || t >= (unsigned)ntiles) return;                  // whole workgroups
     const int txy = (int)(t % (unsigned)ntile_xy), zc = (int)(t / (unsigned)ntile_xy);
     const int fam = (int)(threadIdx.x >> 6), j = txy / nseg;        // ntile_xy = nseg * (ny + 1): one row per workgroup
-    if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT, true, LDSS, PRE>(a, txy % nseg, j, zc, ilim, sh, 0);
-    else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT, true, LDSS, PRE>(a, txy % nseg, j, zc, ilim, sh, 1);
-    else vep3_edges_z_tile<KZ, NP, 4, SOFT, true, LDSS, PRE>(a, txy % nseg, j, zc, ilim, sh, 2);
+    if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 0);
+    else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 1);
+    else vep3_edges_z_tile<KZ, NP, 4, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 2);
 }
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
 template <bool SOFT>
