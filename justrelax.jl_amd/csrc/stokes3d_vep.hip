@@ -1147,6 +1147,9 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     // one iteration without neighbours, enqueued on s; A / G: the kernel arguments and the view the velocity sweep takes (their edge-stress pointers swap)
     auto enqueue_iteration = [&](Vep3Args &A, jrx_stokes3d_fields &G, bool diag_) -> jrx_status {
         if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, A);
+        else if (h->vep3_prekz == 16) hipLaunchKernelGGL((k_vep3_pre<true, false, 16>), dim3(gpre.x, (unsigned)((nz + 1 + 15) / 16)), dim3(256), 0, s, A);
+        else if (h->vep3_prekz == 32) hipLaunchKernelGGL((k_vep3_pre<true, false, 32>), dim3(gpre.x, (unsigned)((nz + 1 + 31) / 32)), dim3(256), 0, s, A);
+        else if (h->vep3_prekz == 4) hipLaunchKernelGGL((k_vep3_pre<true, false, 4>), dim3(gpre.x, (unsigned)((nz + 1 + 3) / 4)), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((k_vep3_pre<true, false, PRE_KZ>), gpre, dim3(256), 0, s, A);        // compute_maxloc! folded in
         launch_vep3_visc(s, gc, A, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
         JRX_LAUNCH_CHECK(h);
