@@ -74,8 +74,10 @@ const char *jrx_build_id(void);
  *   1 = simple one-thread-per-node kernels;  2 = z-marching sweeps only (two launches per iteration, no ping-pong set);
  *   3 = fused pipeline wherever it is legal (ignores the tile-fill rule).  All variants produce bit-identical results.
  * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
- * "fused_overlap" (0/1, default 0): multi-rank fused pipeline with the shell of tiles, BCs and exchange on a second
- *   stream while the interior tiles run (same results).
+ * "fused_overlap" (0/1/2, default 2): how the multi-rank fused pipeline places update_halo!(V) (same results in every mode):
+ *   2 = early exchange: the velocity phase alone over the boundary slabs of the faces with a neighbour, flow_bcs! and the whole exchange on a second
+ *       stream BESIDE the fused kernel (which recomputes those cells with the same values), then flow_bcs! on the physical faces and the fix-up;
+ *   1 = the shell of tiles, BCs and exchange on the second stream while the interior tiles run;  0 = everything behind the kernel, in order.
  * "thermal_fused" (0/1, default 1): jrx_heatdiffusion_PT2d / _PT3d run unobserved iterations as one fused launch with a
  *   library-owned second (T, qT) set; 0 = always compute_flux! and update_T! as two launches (same results).
  * "scratch_sets" (0/1, default 1): 0 forbids every library-owned second state set (3D fused pipeline: + 10 arrays, i.e.

@@ -33,7 +33,8 @@ struct jrx_handle {
     // ---- options (jrx_set_option; nothing in the library reads the process environment)
     bool loop_graphs = true;             // launch-bound 2D loops: runs of unobserved iterations replay as captured hipGraphs (option "loop_graphs")
     bool thermal_fused = true;           // heat diffusion: one fused launch per unobserved iteration (option "thermal_fused")
-    bool fused_overlap = false;          // multi-rank fused pipeline: shell tiles + exchange on the halo stream, interior tiles concurrently
+    int fused_overlap = 2;               // multi-rank fused pipeline: 0 exchange behind the kernel, in order; 1 shell tiles + exchange on the halo stream, interior tiles
+                                         // concurrently; 2 boundary slabs of the velocity phase + BCs + the whole exchange on the halo stream beside the kernel (early exchange)
     int kernel_variant = 0;              // 0 auto (fused PT pipeline where it pays), 1 per-node v1 kernels, 2 z-marching sweeps only, 3 fused wherever legal
     bool fused_split = false;            // no neighbours: high-face tiles + boundary stress layers on the halo stream, interior tiles concurrently
                                          // (measured slower, profiles/r02_ab_fused_split.txt: off)

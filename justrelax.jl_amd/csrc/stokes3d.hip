@@ -575,7 +575,8 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         // default: measured on one device (periodic self neighbour through RCCL, profiles/r01_selfhalo_overlap_*.txt) the RCCL
         // send/recv kernel does not finish before the interior kernel drains, so nothing is hidden and the six small shell launches
         // cost more than they save when an x face is involved (10.7 vs 9.1 ms); to be revisited with real neighbours / DMA copies.
-        const bool overlap = h->fused_overlap;
+        const bool overlap = h->fused_overlap == 1;
+        const bool early = h->fused_overlap == 2 && comm && !per;
         const bool split = !comm && !per && h->fused_split && nt[0] > 1 && nt[1] > 1 && nt[2] > 1;
         if (split) {
             // Without neighbours the only work behind the fused kernel is the stress update of the high-face node layers (i = nx, j = ny,
@@ -601,6 +602,55 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             JRX_TRY(launch_fused(h, bs, a, bc, hz, true));
             I.ghosts_stale = true;
             if (ncells_timed) *ncells_timed = (double)imin(nx, (nt[0] - 1) * (S.tx - 2)) * (double)imin(ny, (nt[1] - 1) * (S.ty - 1)) * (double)imin(nz, (nt[2] - 1) * S.kz);
+        } else if (early) {
+            // Early exchange (option "fused_overlap" = 2).  What the neighbours need of V_m -- the planes 2 / n - 2 (normal component) and the cell layers 2 / n - 3
+            // (tangential ones) -- lies within four cells of the face.  So the velocity phase alone runs first over the boundary slabs of the faces WITH a neighbour
+            // (the un-fused velocity kernel, into the new set), followed on the halo stream by flow_bcs! (the sent planes carry BC entries of their own rows) and the
+            // whole update_halo!(V), x then y then z, while k_fused3d runs over all tiles on the compute stream: it writes the same values to the slab cells again and
+            // never touches the planes the exchange receives into.  Behind both: flow_bcs! on the faces WITHOUT a neighbour (the received planes must survive it;
+            // where such a ghost row crosses a received plane the copy / negation of the received value is what the neighbour's own flow_bcs! had sent), then the fix-up.
+            bs = h->halo_stream;
+            JRX_HIP(h, hipEventRecord(h->ev[0], s));
+            JRX_HIP(h, hipStreamWaitEvent(bs, h->ev[0], 0));
+            {
+                const int w = 4;
+                const int xa = imin(w, nx / 2), ya = imin(w, ny / 2), za = imin(w, nz / 2);
+                const bool L0 = jrx_comm_has_neighbor(h, 0, 0), H0 = jrx_comm_has_neighbor(h, 0, 1), L1 = jrx_comm_has_neighbor(h, 1, 0), H1 = jrx_comm_has_neighbor(h, 1, 1),
+                           L2 = jrx_comm_has_neighbor(h, 2, 0), H2 = jrx_comm_has_neighbor(h, 2, 1);
+                // disjoint slabs as in jrx3d_velocity_hidden, only on faces with a neighbour
+                const int z0 = L2 ? za : 0, z1 = H2 ? nz - za : nz, y0 = L1 ? ya : 0, y1 = H1 ? ny - ya : ny;
+                if (L2) JRX_TRY(launch_velocity(h, bs, a, false, 0, nx, 0, ny, 0, za));
+                if (H2) JRX_TRY(launch_velocity(h, bs, a, false, 0, nx, 0, ny, nz - za, nz));
+                if (L1) JRX_TRY(launch_velocity(h, bs, a, false, 0, nx, 0, ya, z0, z1));
+                if (H1) JRX_TRY(launch_velocity(h, bs, a, false, 0, nx, ny - ya, ny, z0, z1));
+                if (L0) JRX_TRY(launch_velocity(h, bs, a, false, 0, xa, y0, y1, z0, z1));
+                if (H0) JRX_TRY(launch_velocity(h, bs, a, false, nx - xa, nx, y0, y1, z0, z1));
+            }
+            JRX_TRY(fused_bcs(bs));
+            {
+                double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
+                const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
+                const int64_t n[3] = {nx, ny, nz};
+                JRX_TRY(jrx_halo_exchange(h, bs, 3, arrs, ext, n));
+            }
+            const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
+            JRX_TRY(launch_fused(h, s, a, bc, all));
+            if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
+            JRX_HIP(h, hipEventRecord(h->ev[2], bs));
+            JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
+            bs = s;
+            {   // flow_bcs! of the complete new V on the faces that are physical boundaries.  3D naming of the reference (App. C.4): free_slip `top` is k = 1 and
+                // `bot` k = end, no_slip the other way round
+                const uint32_t fs_lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_TOP}, fs_hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_BOT};
+                const uint32_t ns_lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_BOT}, ns_hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_TOP};
+                uint32_t fs_keep = 0, ns_keep = 0;
+                for (int d = 0; d < 3; d++) {
+                    if (!jrx_comm_has_neighbor(h, d, 0)) { fs_keep |= fs_lo[d]; ns_keep |= ns_lo[d]; }
+                    if (!jrx_comm_has_neighbor(h, d, 1)) { fs_keep |= fs_hi[d]; ns_keep |= ns_hi[d]; }
+                }
+                JRX_TRY(launch_bcs_faces(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip & fs_keep, p->no_slip & ns_keep));
+            }
+            for (int d = 0; d < 3; d++) { nb[d][0] = jrx_comm_has_neighbor(h, d, 0); nb[d][1] = jrx_comm_has_neighbor(h, d, 1); }
         } else if (!comm || !overlap) {
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
             JRX_TRY(launch_fused(h, s, a, bc, all));

@@ -70,12 +70,14 @@ def test_periodic_self_exchange(jr, through_rccl, periods):
                                                             # 3 x 5 x 3 tiles of the fused kernel: all six shell boxes + an interior box
                                                             (True, 3, (1, 1, 1), (130, 14, 40)), (False, 0, (1, 0, 1), (130, 14, 40)),
                                                             # 13 = variant 3 with option fused_overlap (shell on the halo stream)
-                                                            (True, 13, (1, 1, 1), (130, 14, 40)), (False, 13, (0, 1, 1), (70, 13, 12))])
+                                                            (True, 13, (1, 1, 1), (130, 14, 40)), (False, 13, (0, 1, 1), (70, 13, 12)),
+                                                            # 23 = variant 3 with fused_overlap = 2 (boundary slabs, BCs and the whole exchange on the halo stream beside k_fused3d)
+                                                            (True, 23, (1, 1, 1), (130, 14, 40)), (False, 23, (0, 1, 1), (70, 13, 12)), (True, 23, (1, 0, 1), (70, 13, 12))])
 def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracle, through_rccl, variant, periods, n):
     """The N > 1 code path of jrx_stokes3d_solve on one GPU: the grid is IGG-periodic in some dimensions, so the rank is its own
     neighbour there.  variant 2: split sweeps (boundary slabs first on the halo stream, interior concurrently on the compute stream,
-    BCs + update_halo! behind the slabs; Stokes3D.jl:104-142).  variant 3: fused velocity+stress kernel (shell of tiles first on the halo stream, interior tiles concurrently on the
-    compute stream), BCs, update_halo!, then the stress nodes next to a received plane redone.  Norms of the global count.  Expected = the CPU oracle's iteration followed by
+    BCs + update_halo! behind the slabs; Stokes3D.jl:104-142).  variant 3: fused velocity+stress kernel, BCs, update_halo!, then the stress nodes next to a received plane redone (3: exchange behind the kernel;
+    13: shell of tiles first on the halo stream, interior tiles concurrently; 23: boundary slabs + BCs + exchange on the halo stream beside the kernel).  Norms of the global count.  Expected = the CPU oracle's iteration followed by
     the same plane copies in numpy.  Tolerance 1e-12 of each field's max (observed: bit-identical)."""
     import ctypes as C
     import torch
@@ -100,7 +102,7 @@ def test_solve_on_the_multi_gpu_path_matches_oracle_with_periodic_halo(jr, oracl
         got = download_stokes(stokes)
     finally:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
-        h.call("jrx_set_option", C.c_char_p(b"fused_overlap"), C.c_int64(0))
+        h.call("jrx_set_option", C.c_char_p(b"fused_overlap"), C.c_int64(2))          # the default
         g.finalize_global_grid()
         g.init_global_grid(*n, rank=0, nprocs=1)
         halo.init_comm(h)          # back to a plain single-rank handle for the other tests

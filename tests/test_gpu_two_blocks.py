@@ -8,7 +8,8 @@ own two-rank check is test/test_periodic_boundary_conditions_MPI.jl:9-48 (restat
 
 Expectations:
   * uniform material: every block equals the UNDECOMPOSED device run bit for bit on every entry (the duplicated overlap cells stay
-    consistent), for the default fused pipeline, the overlapped fused pipeline and the split sweeps, split along x, y or z;
+    consistent), for the fused pipeline in its three placements of the exchange (beside the kernel = default, behind it, shell tiles) and
+    the split sweeps, split along x, y or z;
   * SolVi-style non-uniform viscosity: the decomposed iteration is not the undecomposed one in the reference either -- compute_τ! averages
     η, G to the shear nodes with indices clamped to the LOCAL block (src/MiniKernels.jl:133-147), so the nodes on a block face see one
     cell twice -- hence the expectation is the CPU oracle run block by block with the same plane copies in numpy (tolerance 1e-12 of each
@@ -25,6 +26,7 @@ pytestmark = pytest.mark.gpu
 
 STATE = ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "txy", "txz", "tyz")
 PIPELINES = {"fused": dict(kernel_variant=3, fused_overlap=0, fused_comm=1), "fused_overlap": dict(kernel_variant=3, fused_overlap=1, fused_comm=1),
+             "fused_early": dict(kernel_variant=3, fused_overlap=2, fused_comm=1),
              "split_sweeps": dict(kernel_variant=3, fused_overlap=0, fused_comm=0)}
 
 
@@ -100,7 +102,7 @@ def _solve_blocks(jr, tb, S, pipeline, iters_kw):
         g.finalize_global_grid()
 
 
-@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "split_sweeps"])
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "split_sweeps"])
 @pytest.mark.parametrize("dims,n", [((2, 1, 1), (70, 13, 12)), ((1, 2, 1), (70, 13, 12)), ((1, 1, 2), (70, 13, 12)),
                                     # 3 x 5 x 5 tiles of the fused kernel per block: every shell box and an interior box
                                     ((2, 1, 1), (130, 14, 40)), ((1, 1, 2), (130, 14, 40))])
@@ -152,7 +154,7 @@ def test_two_blocks_equal_the_undecomposed_run_bit_for_bit(jr, dims, n, pipeline
     assert getattr(res[0], "norm_∇V")[-1] != getattr(rg, "norm_∇V")[-1]          # ... which are not the undecomposed norm (RP: overlap counted twice)
 
 
-@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "split_sweeps"])
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "split_sweeps"])
 @pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (1, 1, 2)])
 def test_two_blocks_with_an_inclusion_match_the_oracle_block_by_block(jr, oracle, dims, pipeline):
     """SolVi-style non-uniform η (with its ητ halo): device blocks == oracle blocks + numpy plane copies"""
@@ -398,7 +400,7 @@ def test_stokes2d_two_blocks_equal_the_undecomposed_run(jr, dims):
             assert np.array_equal(outs[r][k][m], want[m]), (dims, r, k, float(np.abs(outs[r][k] - want)[m].max()))
 
 
-@pytest.mark.parametrize("pipeline", ["fused", "split_sweeps"])
+@pytest.mark.parametrize("pipeline", ["fused", "fused_early", "split_sweeps"])
 @pytest.mark.parametrize("dims,n", [((2, 2, 2), (70, 13, 12)), ((2, 2, 1), (70, 13, 12)), ((1, 2, 2), (130, 14, 40))])
 def test_eight_blocks_2x2x2_equal_the_undecomposed_run(jr, dims, n, pipeline):
     """BASELINE configs[3] in miniature: the 2 x 2 x 2 block decomposition of north_star (eight ranks = eight handles of this process on ONE device,
