@@ -236,3 +236,28 @@ def test_every_driver_kwarg_reaches_its_parameter_struct(jr):
         assert re.search(rf"\b{k}\b", helper), k
     assert "vep_params2d(" in body["2D_phases"] and "kwargs..." in body["2D_phases"]
     assert "vep_params2d(" in body["2D_material"] and "kwargs..." in body["2D_material"]
+
+
+def test_carts_of_a_2x2x2_process_grid_are_mutually_consistent(jr):
+    """halo.make_carts (jrx_cart_create for every rank of the grid the in-process transport and the RCCL transport both run on): neighbour relations are symmetric,
+    a 2 x 2 x 2 block has exactly one neighbour per dimension, periodic dimensions wrap, and the plan is the one north_star names (dims = (2, 2, 2) for eight ranks)."""
+    from justrelax_jl_amd import halo, _lib
+    L = _lib.load()
+    carts = halo.make_carts((16, 16, 16), (2, 2, 2))
+    assert len(carts) == 8
+    for r, c in enumerate(carts):
+        assert (c.rank, c.nprocs, tuple(c.dims)) == (r, 8, (2, 2, 2))
+        nbs = [(d, s, c.neighbor[d][s]) for d in range(3) for s in range(2) if c.neighbor[d][s] >= 0]
+        assert len(nbs) == 3 and {d for d, _, _ in nbs} == {0, 1, 2}
+        for d, s, nb in nbs:
+            assert carts[nb].neighbor[d][1 - s] == r                       # my right neighbour's left neighbour is me
+            co, cn = tuple(c.coords), tuple(carts[nb].coords)
+            assert sum(abs(a - b) for a, b in zip(co, cn)) == 1 and cn[d] - co[d] == (1 if s else -1)
+    # balanced factorisation of eight ranks (what IGG / MPI_Dims_create gives the reference): (2, 2, 2)
+    auto = _lib.Cart()
+    import ctypes as C
+    assert L.jrx_cart_create(C.c_int32(5), C.c_int32(8), (C.c_int64 * 3)(16, 16, 16), (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(0, 0, 0), C.byref(auto)) == 0
+    assert tuple(auto.dims) == (2, 2, 2) and tuple(auto.coords) == tuple(carts[5].coords)
+    per = halo.make_carts((16, 16, 16), (2, 1, 1), periods=(1, 0, 0))
+    assert per[0].neighbor[0][0] == 1 and per[0].neighbor[0][1] == 1 and per[1].neighbor[0][0] == 0      # two ranks, periodic: both neighbours are the other rank
+    assert per[0].neighbor[1][0] == -1
