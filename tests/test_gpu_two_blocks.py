@@ -433,3 +433,73 @@ def test_eight_blocks_2x2x2_equal_the_undecomposed_run(jr, dims, n, pipeline):
             want = B.local_block(glob[k], n, tb.ng, co)
             m = interior_mask3d(k, want.shape)
             assert np.array_equal(out[k][m], want[m]), (pipeline, dims, r, co, k, float(np.abs(out[k] - want)[m].max()))
+
+
+@pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1)])
+def test_vep2d_two_blocks_equal_the_undecomposed_run(jr, dims):
+    """jrx_stokes2d_vep_solve on two blocks: update_halo!(ητ), update_halo!(τ.xy), update_halo!(V) every iteration (Stokes2D.jl:655,757,784), norm_mpi.
+    Two phases of equal viscosity (different G and cohesion), pre-stressed to yield: every block equals the undecomposed device run bit for bit on the state arrays."""
+    import test_gpu_vep2d as tv
+    import justrelax_jl_amd.grid as g
+    from justrelax_jl_amd import halo
+    from justrelax_jl_amd.miniapps.common import Setup
+    n = (34, 66, 1) if dims[0] == 2 else (66, 34, 1)            # a square 66 x 66 global grid either way
+    kw = dict(iterMax=29, nout=10, iterMin=5, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        ng = tb.ng
+        assert ng[:2] == (66, 66)
+        S = jr.miniapps.shearband2d(66, iterMax=29, nout=10)
+        S.pt.ϵ_rel = S.pt.ϵ_abs = 1e-30
+        S.extra["phases"][1]["eta"] = S.extra["phases"][0]["eta"]
+        S.arrays["eta"][...] = S.extra["phases"][0]["eta"]
+        rng = np.random.default_rng(13)
+        for c in ("xx", "yy", "xy", "xy_c"):
+            S.arrays["to" + c][...] = rng.uniform(-1.5, 1.5, size=S.arrays["to" + c].shape)
+            S.arrays["t" + c][...] = S.arrays["to" + c]
+        stokes, pr, ρg = tv._upload(jr, S)
+        rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, pr, S.extra["phases"], None, S.dt, None, kwargs=kw)
+        glob = tv._download(jr, stokes)
+        g.init_global_grid(*n, dimx=dims[0], dimy=dims[1], dimz=1, rank=0, nprocs=2)
+        try:
+            grid = jr.Geometry(n[:2], (1.0, 1.0))
+            ups = []
+            for r in range(2):
+                loc = Setup(ni=n[:2], arrays={k: B.local_block(v, n, ng, B.coords_of(tb.carts[r]), nd=2) for k, v in S.arrays.items()})
+                ups.append(tv._upload(jr, loc))
+            res = halo.run_ranks([(lambda r=r: jr.solve_(ups[r][0], S.pt, grid, S.flow_bcs, ups[r][2], ups[r][1], S.extra["phases"], None, S.dt, None, kwargs=kw,
+                                                         handle=tb.handles[r])) for r in range(2)])
+            outs = [tv._download(jr, u[0]) for u in ups]
+        finally:
+            g.finalize_global_grid()
+    assert rg.iter == res[0].iter == res[1].iter and list(res[0].err_evo1) == list(res[1].err_evo1)
+    assert (glob["eplxx"] != 0).any()
+    for r in range(2):
+        for k in ("P", "txx", "tyy", "txy", "tII", "eta_vep", "exx", "Rx", "Ry", "RP"):
+            want = B.local_block(glob[k], n, ng, B.coords_of(tb.carts[r]), nd=2)
+            d = np.abs(outs[r][k] - want)
+            bad = np.argwhere(d > 0)
+            assert np.array_equal(outs[r][k], want), (dims, r, k, float(d.max()), want.shape, bad[:6].tolist(), bad[-3:].tolist(), len(bad))
+        for k in ("Vx", "Vy"):
+            want = B.local_block(glob[k], n, ng, B.coords_of(tb.carts[r]), nd=2)
+            inner = (slice(1, -1), slice(1, -1))
+            assert np.array_equal(outs[r][k][inner], want[inner]), (dims, r, k)
+
+
+def test_compute_dt_takes_the_maximum_over_the_ranks(jr):
+    """compute_dt(stokes, di, dt_diff, igg) (Utils.jl:492-519): maximum_mpi over the group -- both ranks get the dt of the faster block"""
+    import torch
+    from justrelax_jl_amd import halo
+    n = (12, 10, 9)
+    with TwoBlocks(n, (2, 1, 1)) as tb:
+        sts = []
+        for r in range(2):
+            st = jr.StokesArrays(jr.AMDGPUBackend, n)
+            st.V.Vx.fill_(0.5 * (r + 1)); st.V.Vy.fill_(0.1); st.V.Vz.fill_(-0.2 * (r + 1))
+            sts.append(st)
+        torch.cuda.synchronize()
+        di = (0.1, 0.2, 0.3)
+        dts = halo.run_ranks([(lambda r=r: jr.compute_dt_(sts[r], di, float("inf"), None, handle=tb.handles[r])) for r in range(2)])
+        alone = jr.compute_dt_(sts[0], di, float("inf"), None)          # the plain handle: no communicator
+    want = 0.9 * min(0.1 / 1.0, 0.2 / 0.1, 0.3 / 0.4)
+    assert dts[0] == dts[1] == pytest.approx(want, rel=1e-15)
+    assert alone == pytest.approx(0.9 * min(0.1 / 0.5, 0.2 / 0.1, 0.3 / 0.2), rel=1e-15) and alone != dts[0]
