@@ -503,3 +503,35 @@ def test_compute_dt_takes_the_maximum_over_the_ranks(jr):
     want = 0.9 * min(0.1 / 1.0, 0.2 / 0.1, 0.3 / 0.4)
     assert dts[0] == dts[1] == pytest.approx(want, rel=1e-15)
     assert alone == pytest.approx(0.9 * min(0.1 / 0.5, 0.2 / 0.1, 0.3 / 0.2), rel=1e-15) and alone != dts[0]
+
+
+def test_comm_init_local_rejects_bad_arguments(jr):
+    """jrx_comm_init_local: carts must be rank r of n in order, handles distinct; a refused call leaves no communicator behind"""
+    import torch
+    from justrelax_jl_amd import _lib, halo
+    hs = [_lib.Handle(torch.cuda.current_device()) for _ in range(2)]
+    try:
+        carts = halo.make_carts((8, 6, 5), (2, 1, 1))
+        swapped = (_lib.Cart * 2)(carts[1], carts[0])
+        with pytest.raises(_lib.JrxError) as e:
+            halo.init_comm_local(hs, swapped)
+        assert e.value.status == 4 and "carts[0] is rank 1" in str(e.value)
+        with pytest.raises(_lib.JrxError) as e:
+            halo.init_comm_local([hs[0], hs[0]], carts)
+        assert e.value.status == 4 and "appears twice" in str(e.value)
+        cnt = C.c_int32(-1)
+        hs[0].call("jrx_comm_count", C.byref(cnt))
+        assert cnt.value == 0
+        halo.init_comm_local(hs, carts)
+        hs[1].call("jrx_comm_count", C.byref(cnt))
+        assert cnt.value == 2
+        # leaving the group breaks it for the rank that stays: its next exchange reports the failure at once instead of waiting for the time-out
+        hs[1].call("jrx_comm_destroy")
+        from justrelax_jl_amd.arrays import from_numpy
+        A = from_numpy(np.zeros((9, 8, 7), order="F"), torch.device("cuda", torch.cuda.current_device()))
+        with pytest.raises(_lib.JrxError) as e:
+            halo.update_halo_(A, ni=(8, 6, 5), handle=hs[0])
+        assert e.value.status == 3 and "failed or left" in str(e.value)
+    finally:
+        for h in hs:
+            h.close()
