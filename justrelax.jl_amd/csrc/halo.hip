@@ -208,9 +208,22 @@ static jrx_status local_allreduce(jrx_handle *h, jrx_comm_state *c, double *vals
 }
 
 // one dimension of update_halo! between handles of this process.  The send planes are already packed into c->sbuf[side] on `s`.
+// a rank that leaves an exchange half way (a HIP error, a size mismatch) breaks the group for everybody: the others' waits return at once instead of timing out
+struct LocalFailGuard {
+    jrx_local_group *g;
+    bool ok = false;
+    ~LocalFailGuard()
+    {
+        if (ok) return;
+        { std::lock_guard<std::mutex> lk(g->m); g->failed = true; }
+        g->cv.notify_all();
+    }
+};
+
 static jrx_status local_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream_t s, int dim, const int nb[2], size_t total, PlaneSet &S, int gx, int na)
 {
     jrx_local_group *g = c->grp;
+    LocalFailGuard guard{g};
     uint64_t k[2] = {0, 0};
     for (int side = 0; side < 2; side++) {
         if (nb[side] < 0) continue;
@@ -270,6 +283,7 @@ static jrx_status local_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream
     JRX_LAUNCH_CHECK(h);
     for (int side = 0; side < 2; side++)
         if (nb[side] >= 0) JRX_HIP(h, hipEventRecord(c->ev_unpacked[dim][side], s));
+    guard.ok = true;
     return JRX_OK;
 }
 
