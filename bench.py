@@ -15,7 +15,12 @@ processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MAS
 the children's return code.  Started by `python -m torch.distributed.run --nproc-per-node N bench.py
 --gpus N ...` it finds WORLD_SIZE set and runs as one rank.
 
+The workload hands dt = Inf (SolVi3D.jl:96), so the library's default kernel is the viscous-limit form of k_fused3d (it does not load the ten operand
+arrays whose factor is exactly 0 there; bit-identical results, tests/test_gpu_stokes3d.py::test_viscous_limit_kernel_equals_the_general_one).  That is
+the headline; its roofline is priced at 280 B/cell (see A_ALG_VISC below), and the general form at SURVEY 8d's 360 B/cell is timed beside it.
+
 Besides the headline line (BASELINE.json's metric/config) the same JSON carries, on one GPU:
+  general_kernel the same batch with option viscous_limit = 0 (the kernel for any dt, the one rounds 1-2 quoted), priced at 360 B/cell
   solve_path     jrx_stokes3d_solve on the same 512^3 problem with the reference's cadence
                  (iterMax = 399, nout = 100: norm checks, un-fused check iterations, host syncs included)
   other_configs  the other BASELINE configs at their stated sizes (SolVi3D 256^3, SolCx 512^2, shear band
@@ -39,6 +44,11 @@ sys.path.insert(0, str(ROOT))
 
 A_ALG = 360.0            # algorithmic bytes per cell per PT iteration (45 passes x 8 B)
 A_NEEDED_FUSED = 35 * 8.0   # what k_fused3d itself has to move: 25 array reads + 10 writes = 280 B/cell (V handed from the velocity to the stress phase in LDS)
+# dt = Inf (SolVi3D, the headline workload): 1/(G dt) = 1/(K dt) = 1/dt = 0 exactly, and the ten operand arrays they multiply (six old stresses, P0, K, G, Q)
+# cannot change any result; the library's default kernel for that limit does not load them (option viscous_limit).  The two sweeps of SURVEY 8d without
+# those ten arrays are 35 passes -- the figure that launch is priced at (pricing it at 360 B/cell would credit it with bytes nobody has to move).
+A_ALG_VISC = 35 * 8.0
+A_NEEDED_VISC = 25 * 8.0    # what the viscous-limit k_fused3d itself has to move: 15 array reads + 10 writes = 200 B/cell
 A_STRESS = 28 * 8.0      # stress sweep: 21 reads + 7 writes
 A_VELOCITY = 17 * 8.0    # velocity sweep: 14 reads + 3 writes
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -47,7 +57,49 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measure
 # n = 512 (profiles/*pmc*traffic.txt; the file names are in PMC_SOURCE)
 PMC_TRAFFIC_STRESS_512 = 32.543e9       # k_stress3d_zb: 24.962 GB fetched (x2 applied) + 7.581 GB written
 PMC_TRAFFIC_FUSED_512 = 52.351e9        # k_fused3d:     41.035 GB fetched (x2 applied) + 11.316 GB written (38.2 + 10.5 array passes)
-PMC_SOURCE = {"stress": "profiles/r03_pmc_bench_traffic.txt", "fused": "profiles/r03_pmc_bench_traffic.txt"}
+PMC_TRAFFIC_VISC_512 = 40.179e9         # k_fused3d, viscous-limit form: 28.851 GB fetched (x2 applied) + 11.327 GB written (26.9 + 10.5 array passes)
+PMC_SOURCE = {"stress": "profiles/r03_pmc_bench_traffic.txt", "fused": "profiles/r03_pmc_bench_traffic.txt", "visc": "profiles/r03_pmc_viscous_limit_traffic.txt"}
+
+
+def pricing(h, dt):
+    """what one launch of the fused kernel is priced at: the form of the kernel that runs (h: handle, dt: the time step handed to the solver)"""
+    import math
+    if math.isinf(dt) and h.get_option("viscous_limit") == 1 and h.get_option("fused_ylds") == 1:
+        return {"form": "viscous_limit", "alg": A_ALG_VISC, "needed": A_NEEDED_VISC, "pmc": PMC_TRAFFIC_VISC_512, "pmc_source": PMC_SOURCE["visc"],
+                "kernel": "k_fused3d<...,VISC=1,TAG=0>: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong state) in the viscous limit dt = Inf of "
+                          "the workload: algorithmic 280 B/cell per launch = SURVEY 8d's two sweeps (45 passes) less the ten operand arrays whose factor 1/(G dt), 1/(K dt), 1/dt "
+                          "is exactly 0 (old stresses, P0, K, G, Q), which this form does not load; the kernel itself needs 15 reads + 10 writes = 200 B/cell.  The general form "
+                          "priced at 360 B/cell is the `general_kernel` entry of this line"}
+    return {"form": "general", "alg": A_ALG, "needed": A_NEEDED_FUSED, "pmc": PMC_TRAFFIC_FUSED_512, "pmc_source": PMC_SOURCE["fused"],
+            "kernel": "k_fused3d<...,TAG=0>: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong "
+                      "state); algorithmic 360 B/cell per launch (2-sweep floor of SURVEY 8d; the kernel itself needs "
+                      "25 reads + 10 writes = 280 B/cell)"}
+
+
+def fused_roofline(pr, n, sk_ms, sf_ms, kcells, it_gbs=None):
+    cells = float(n) ** 3
+    kcells = kcells or cells
+    g = pr["alg"] * kcells / (sk_ms * 1e-3) / 1e9
+    whole = kcells == cells
+    tr = (pr["pmc"] * kcells / cells) if n == 512 else None
+    out = {"bound": "hbm",
+           "kernel": pr["kernel"] + ("" if whole else
+                     f"; this launch covers the {kcells:.0f} cells of the tiles that touch no high face ({kcells / cells:.4f} of the block), "
+                     "the high-face tiles (k_fused3d<...,TAG=1>) and the boundary stress layers run beside it on a second stream"),
+           "form": pr["form"], "bytes_per_cell": pr["alg"],
+           "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+           "traffic": tr,
+           "traffic_unit": "bytes per launch (PMC, offline, whole-block launch scaled by the cell share of this launch)",
+           "traffic_source": pr["pmc_source"],
+           "traffic_ratio": tr / (pr["alg"] * kcells) if tr else None,
+           "needed_bytes_per_launch": pr["needed"] * kcells,
+           "traffic_over_needed": tr / (pr["needed"] * kcells) if tr else None,
+           "cells_per_launch": kcells,
+           "algorithmic_bytes_per_launch": pr["alg"] * kcells, "avg_launch_ms": sk_ms,
+           "launch_group_ms": sf_ms}
+    if it_gbs is not None:
+        out["whole_iteration"] = {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ launching
@@ -61,6 +113,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU budget per oracle size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip solve_path and other_configs")
+    ap.add_argument("--no-general-kernel", action="store_true", help="skip the leg that times the general form of k_fused3d (option viscous_limit = 0) beside the headline")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the extra 100-step batch that follows a requested batch of fewer than 50 steps")
     ap.add_argument("--cpu-full-size", choices=["auto", "on", "off"], default="auto",
                     help="cpu_baseline also measured at the metric's own size (n^3, 5 iterations): auto = when MemAvailable >= 64 GB")
@@ -200,7 +253,7 @@ def cpu_baseline(n_cpu: int, budget_s: float, min_iters: int = 3):
 
 
 # ------------------------------------------------------------------------------------------------ extra legs (one GPU)
-def solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, iters, n):
+def solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, iters, n, pr):
     """jrx_stokes3d_solve itself with the reference's cadence (SolVi3D.jl:119-120: nout = 100): compute_maxloc!, the norm checks with
     their Σx² reductions and host syncs, the un-fused observable iterations and the τ -> τ_o copy are all inside the timed call."""
     import torch
@@ -213,8 +266,9 @@ def solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, iters, n):
     cells = float(n) ** 3
     return {"entry": "jrx_stokes3d_solve", "iterMax": iters, "nout": 100, "iterations": int(r.iter), "checks": int(len(r.err_evo1)),
             "it_per_s": r.iter / el, "ms_per_iteration": el / r.iter * 1e3, "device_loop_s": r.time,
-            "effective_GBps_at_360B_per_cell": A_ALG * cells * r.iter / el / 1e9,
-            "frac_of_peak": A_ALG * cells * r.iter / el / 1e9 / HBM_PEAK_GBS,
+            "form": pr["form"], "bytes_per_cell": pr["alg"],
+            "effective_GBps": pr["alg"] * cells * r.iter / el / 1e9,
+            "frac_of_peak": pr["alg"] * cells * r.iter / el / 1e9 / HBM_PEAK_GBS,
             "norm_Rx_last": float(r.norm_Rx[-1]) if len(r.norm_Rx) else None}
 
 
@@ -238,13 +292,14 @@ def cfg_solvi(jr, h, n, steps, warm):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     cells = float(n) ** 3
-    out = {"workload": f"SolVi3D {n}^3", "steps": steps, "it_per_s": steps / el, "ms_per_step": el / steps * 1e3,
-           "frac_whole_iteration": A_ALG * cells * steps / el / 1e9 / HBM_PEAK_GBS}
+    pr = pricing(h, dt)
+    out = {"workload": f"SolVi3D {n}^3", "form": pr["form"], "bytes_per_cell": pr["alg"], "steps": steps, "it_per_s": steps / el, "ms_per_step": el / steps * 1e3,
+           "frac_whole_iteration": pr["alg"] * cells * steps / el / 1e9 / HBM_PEAK_GBS}
     if sk > 0:
         out["kernel"] = "k_fused3d"
         out["avg_launch_ms"] = sk
         out["kernel_cells_per_launch"] = kcells
-        out["frac_kernel"] = A_ALG * kcells / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["frac_kernel"] = pr["alg"] * kcells / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS
     grid.finalize_global_grid()
     return out
 
@@ -626,6 +681,7 @@ def run_rank(args) -> int:
             dist.barrier()
 
     run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
+    pr = pricing(h, dt)
     if args.warmup > 0:
         run(args.warmup)
     barrier()
@@ -654,7 +710,7 @@ def run_rank(args) -> int:
             sel = t.item()
         steady = {"steps": 100, "value": world * 100 / sel, "ms_per_step": sel / 100 * 1e3,
                   "kernel_avg_launch_ms": sres[4] if sres[4] > 0 else None,
-                  "kernel_frac": (A_ALG * (sres[5] or float(n) ** 3) / (sres[4] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sres[4] > 0 else None}
+                  "kernel_frac": (pr["alg"] * (sres[5] or float(n) ** 3) / (sres[4] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sres[4] > 0 else None}
 
     if rank == 0:
         cells = float(n) ** 3
@@ -662,7 +718,7 @@ def run_rank(args) -> int:
         split = sa_ms > 0.0 and sb_ms > 0.0 and not fused       # N > 1: sweeps overlap with the halo exchange on two streams; price the whole iteration
         it_per_s = args.steps / el                       # PT iterations/s of the (global) problem
         value = world * it_per_s                         # n^3-block iterations/s summed over GPUs
-        eff_gbs = A_ALG * cells * value / 1e9            # aggregate effective GB/s at 360 B/cell
+        eff_gbs = pr["alg"] * cells * value / 1e9        # aggregate effective GB/s at the priced bytes per cell
         out = {
             "metric": f"PT-iterations/s (3D Stokes SolVi3D, {n}^3 fp64 block per GPU, block-iterations summed over GPUs)",
             "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -671,36 +727,18 @@ def run_rank(args) -> int:
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"SolVi3D {n}^3 per GPU (configs[{'3' if n == 512 else '2' if n == 256 else '?'}]): "
                                    "eta inclusion 1e-3, G=1, K=Inf, dt=Inf, free-slip, pure shear",
+                       "kernel_form": pr["form"],
                        "local_grid": [n, n, n], "global_grid": [grid.nx_g(), grid.ny_g(), grid.nz_g()],
                        "decomposition": list(grid.global_grid().dims), "halo": "RCCL send/recv" if world > 1 else (f"diagnostic: periodic self-neighbour in {args.self_halo} through RCCL" if self_halo else "none")},
             "rccl_ranks": rccl_ranks,
             "global_iterations_per_s": it_per_s,
-            "effective_GBps_at_360B_per_cell": eff_gbs,
+            "bytes_per_cell_priced": pr["alg"], "effective_GBps": eff_gbs,
             "device_ms_per_step": tot_ms / args.steps,
             "roofline": None,
         }
-        it_gbs = A_ALG * cells * (args.steps / (tot_ms * 1e-3)) / 1e9
+        it_gbs = pr["alg"] * cells * (args.steps / (tot_ms * 1e-3)) / 1e9
         if fused:
-            kcells = kcells or cells
-            g = A_ALG * kcells / (sk_ms * 1e-3) / 1e9
-            whole = kcells == cells
-            out["roofline"] = {"bound": "hbm",
-                               "kernel": "k_fused3d<...,TAG=0>: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong "
-                                         "state); algorithmic 360 B/cell per launch (2-sweep floor of SURVEY 8d; the kernel itself needs "
-                                         "25 reads + 10 writes = 280 B/cell)" + ("" if whole else
-                                         f"; this launch covers the {kcells:.0f} cells of the tiles that touch no high face ({kcells / cells:.4f} of the block), "
-                                         "the high-face tiles (k_fused3d<...,TAG=1>) and the boundary stress layers run beside it on a second stream"),
-                               "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
-                               "traffic": (PMC_TRAFFIC_FUSED_512 * kcells / cells) if n == 512 else None,
-                               "traffic_unit": "bytes per launch (PMC, offline, whole-block launch scaled by the cell share of this launch)",
-                               "traffic_source": PMC_SOURCE["fused"],
-                               "traffic_ratio": (PMC_TRAFFIC_FUSED_512 * kcells / cells) / (A_ALG * kcells) if n == 512 else None,
-                               "needed_bytes_per_launch": A_NEEDED_FUSED * kcells,
-                               "traffic_over_needed": (PMC_TRAFFIC_FUSED_512 * kcells / cells) / (A_NEEDED_FUSED * kcells) if n == 512 else None,
-                               "cells_per_launch": kcells,
-                               "algorithmic_bytes_per_launch": A_ALG * kcells, "avg_launch_ms": sk_ms,
-                               "launch_group_ms": sf_ms,
-                               "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
+            out["roofline"] = fused_roofline(pr, n, sk_ms, sf_ms, kcells, it_gbs)
         elif split:
             out["roofline"] = {"bound": "hbm",
                                "kernel": "stress sweep = k_stress3d_zb + 3 boundary-plane launches (21 array reads + 7 writes = 224 B/cell)",
@@ -716,9 +754,28 @@ def run_rank(args) -> int:
         else:
             out["roofline"] = {"bound": "hbm", "kernel": "whole PT iteration per GPU (360 B/cell; sweeps overlap the halo exchange)",
                                "achieved": it_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_gbs / HBM_PEAK_GBS, "traffic": None}
+        if world == 1 and not self_halo and fused and pr["form"] == "viscous_limit" and not args.no_general_kernel:
+            # the general form of the same kernel (any dt; what rounds 1-2 quoted) on the same allocations: option viscous_limit = 0
+            try:
+                h.set_option("viscous_limit", 0)
+                prg = pricing(h, dt)
+                run(max(args.warmup, 2))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                g_tot, _, _, g_sf, g_sk, g_kc = run(args.steps)
+                torch.cuda.synchronize()
+                gel = time.perf_counter() - t1
+                out["general_kernel"] = {"what": "option viscous_limit = 0: the kernel that loads and applies every operand (any dt), same problem, same allocations, same batch length; "
+                                                 "priced at SURVEY 8d's 360 B/cell like the headline of rounds 1-2",
+                                         "it_per_s": args.steps / gel, "ms_per_step": gel / args.steps * 1e3, "steps": args.steps,
+                                         "roofline": fused_roofline(prg, n, g_sk, g_sf, g_kc, prg["alg"] * cells * (args.steps / (g_tot * 1e-3)) / 1e9)}
+            except Exception as e:
+                out["general_kernel"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                h.set_option("viscous_limit", 1)
         if world == 1 and not self_halo and not args.no_extras:
             try:
-                out["solve_path"] = solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, args.solve_iters, n)
+                out["solve_path"] = solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, args.solve_iters, n, pr)
             except Exception as e:
                 out["solve_path"] = {"error": f"{type(e).__name__}: {e}"}
             del st, ρg, K, G, ητ

@@ -118,6 +118,7 @@ int find_opt(jrx_handle *h, const char *key, bool tuning, OptRef *out)
     const OptRef pub[] = {
         {"kernel_variant", 1, &h->kernel_variant}, {"fused_overlap", 1, &h->fused_overlap}, {"thermal_fused", 0, &h->thermal_fused},
         {"fused_comm", 0, &h->fused_comm}, {"loop_graphs", 0, &h->loop_graphs}, {"scratch_sets", 0, &h->scratch_sets},
+        {"viscous_limit", 0, &h->viscous_limit},
         {"stat_fused3d", 2, &h->stat_fused3d}, {"stat_fused2d", 2, &h->stat_fused2d}, {"stat_thermal_fused", 2, &h->stat_thermal_fused},
         {"stat_vep3_fused", 2, &h->stat_vep3_fused}, {"stat_graph_replays", 2, &h->stat_graph_replays},
     };

@@ -505,7 +505,15 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     const int ntx = b[1] - b[0], nty = b[3] - b[2], ntz = b[5] - b[4];
     if (ntx <= 0 || nty <= 0 || ntz <= 0) return JRX_OK;
     // y-neighbour operands through LDS (measured 8.62 -> 7.94 ms at 512^3); option "fused_ylds" = 0 keeps the lane-shuffle-only form for A/B runs
-    if (h->fused_ylds && hiface)
+    // viscous limit (dt = Inf): the operands that 1/(G dt) = 1/(K dt) = 1/dt = 0 multiply are not loaded; option "viscous_limit" = 0 keeps
+    // the general kernel.  (Its lower register need -- 111 VGPRs -- leaves room to carry the previous velocity / η planes in registers
+    // instead of the third LDS slot: LOWREG off, -1.4 %, scripts/kbench_visc.hip)
+    const bool visc = h->viscous_limit && a.dt == INFINITY && h->fused_ylds;
+    if (visc && hiface)
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 1, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+    else if (visc)
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+    else if (h->fused_ylds && hiface)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (h->fused_ylds)
         // + non-temporal stores: the written set is not read again before the next iteration (PMC: 35.7 -> 34.2 fetched passes, -0.5 .. -1.6 % time)

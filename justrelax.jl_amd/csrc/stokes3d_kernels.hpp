@@ -664,17 +664,21 @@ struct FusedBC {
 // YLDS (with SHFL): y-neighbour operands come from the adjacent row of the tile through LDS: every lane publishes P, ητ, τyy, fy, τxy, τyz
 // (the row below reads them as its j+1 operands) and η, G (the row above reads them as its j-1 operands); only the top row of the tile
 // and the row on the domain's back face still load the j+1 operands from memory.  One more barrier per plane, 8 fewer loads per lane.
+// VISC: the viscous limit dt = Inf (SolVi3D, Burstedde, TaylorGreen run there).  1/(G dt), 1/(K dt) and 1/dt are exactly 0 then, so the
+// operands they multiply -- the six old stresses, P0, K, G, Q -- cannot change the result for finite inputs and are not loaded: 15 read
+// and 10 written arrays per launch instead of 25 and 10.  The arithmetic is the general one with those factors set to 0.
 // TAG: only gives the launches over the high-face tiles (halo stream, see iter_step) a kernel name of their own, so that a profile
 // separates them from the launch over the interior tiles.
-template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0>
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false>
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0)
 {
     // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
     static_assert(!(SHFL && (LATEA || (TX != 64 && TX != 32))), "SHFL is implemented for rows of one wave or half a wave");
     static_assert(!YLDS || SHFL, "YLDS builds on the SHFL operand layout");
+    static_assert(!VISC || YLDS, "the viscous-limit form is built on the YLDS operand layout");
     constexpr int NS = LOWREG ? 3 : 2;
     __shared__ double sV[NS][3][TY][TX];
-    __shared__ double sY[YLDS ? 8 : 1][YLDS ? TY : 1][YLDS ? TX : 1];
+    __shared__ double sY[YLDS ? (VISC ? 7 : 8) : 1][YLDS ? TY : 1][YLDS ? TX : 1];
     const Lay3 &L = a.L;
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     const jrx_stokes3d_fields &f = a.f;
@@ -742,13 +746,13 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             if (SHFL) {
                 // η, G of the own column for every lane that has one; the i-1 column arrives by lane shuffle (clamped at i = 0)
                 if (YLDS) {
-                    if (bvalid) { e = LDB(f.eta, oc); g = LDB(f.G, oc); }
+                    if (bvalid) { e = LDB(f.eta, oc); if (!VISC) g = LDB(f.G, oc); }
                 } else if (bvalid) {
                     e = LDB(f.eta, oc); ey = LDB(f.eta, oc - dcy); g = LDB(f.G, oc); gy = LDB(f.G, oc - dcy);
                     const double e_l = __shfl_up(e, 1, TX), g_l = __shfl_up(g, 1, TX), ey_l = __shfl_up(ey, 1, TX), gy_l = __shfl_up(gy, 1, TX);
                     ex = i > 0 ? e_l : e; gx = i > 0 ? g_l : g; exy_ = i > 0 ? ey_l : ey; gxy = i > 0 ? gy_l : gy;
                 }
-                if (YLDS < 2 && avalid && live) {
+                if (YLDS < 2 && !VISC && avalid && live) {
                     P0 = LDN<(NT & 2) != 0>(f.P0, oc); Kc = LDN<(NT & 2) != 0>(f.K, oc); Qc = LDN<(NT & 2) != 0>(f.Q, oc);
                     toxx = LDN<(NT & 2) != 0>(f.toxx, oc); toyy = LDN<(NT & 2) != 0>(f.toyy, oc); tozz = LDN<(NT & 2) != 0>(f.tozz, oc);
                     toxy = LDN<(NT & 2) != 0>(f.toxy, oxy);
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDN<(NT & 2) != 0>(f.fz, oc + dz1);
                 txx_c = LDB(f.txx, oc); fx_c = LDN<(NT & 2) != 0>(f.fx, oc);
                 vx = LDB(f.Vx, ovx); vy = LDB(f.Vy, ovy); vz = LDB(f.Vz, ovz);
-                if (YLDS == 2 && avalid && live) {
+                if (YLDS == 2 && !VISC && avalid && live) {
                     // the stress phase's remaining operands queue behind the published ones
                     P0 = LDN<(NT & 2) != 0>(f.P0, oc); Kc = LDN<(NT & 2) != 0>(f.K, oc); Qc = LDN<(NT & 2) != 0>(f.Q, oc);
                     toxx = LDN<(NT & 2) != 0>(f.toxx, oc); toyy = LDN<(NT & 2) != 0>(f.toyy, oc); tozz = LDN<(NT & 2) != 0>(f.tozz, oc);
@@ -794,7 +798,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     toxz = LDN<(NT & 2) != 0>(f.toxz, oxz - sxz); toyz = LDN<(NT & 2) != 0>(f.toyz, oyz - syz);
                 }
                 sY[0][ty][tx] = Pc; sY[1][ty][tx] = ec; sY[2][ty][tx] = tyy_c; sY[3][ty][tx] = fy_c; sY[4][ty][tx] = txy_own; sY[5][ty][tx] = r01;
-                sY[6][ty][tx] = e; sY[7][ty][tx] = g;
+                sY[6][ty][tx] = e;
+                if (!VISC) sY[7][ty][tx] = g;
             } else {
                 q01 = LDB(f.txy, oxy + rxy); s01 = LDB(f.txz, oxz);
                 r11 = LDB(f.tyz, oyz + ryz); r01 = LDB(f.tyz, oyz);
@@ -814,10 +819,14 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     q01 = sY[4][ty + 1][tx]; r11 = sY[5][ty + 1][tx];
                 }
                 // stress phase: η, G at j-1 from the row below (clamped at j = 0), then the i-1 column by lane shuffle (clamped at i = 0)
-                if (ty > 0 && j > 0) { ey = sY[6][ty - 1][tx]; gy = sY[7][ty - 1][tx]; }
+                if (ty > 0 && j > 0) { ey = sY[6][ty - 1][tx]; if (!VISC) gy = sY[7][ty - 1][tx]; }
                 else { ey = e; gy = g; }
-                const double e_l = __shfl_up(e, 1, TX), g_l = __shfl_up(g, 1, TX), ey_l = __shfl_up(ey, 1, TX), gy_l = __shfl_up(gy, 1, TX);
-                ex = i > 0 ? e_l : e; gx = i > 0 ? g_l : g; exy_ = i > 0 ? ey_l : ey; gxy = i > 0 ? gy_l : gy;
+                const double e_l = __shfl_up(e, 1, TX), ey_l = __shfl_up(ey, 1, TX);
+                ex = i > 0 ? e_l : e; exy_ = i > 0 ? ey_l : ey;
+                if (!VISC) {
+                    const double g_l = __shfl_up(g, 1, TX), gy_l = __shfl_up(gy, 1, TX);
+                    gx = i > 0 ? g_l : g; gxy = i > 0 ? gy_l : gy;
+                }
             }
             double q11, q10, s11, Px, ex, txx_x, fx_x;
             if (SHFL) {
@@ -853,7 +862,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11; s01p = s01; r01p = r01;
             sV[slot][0][ty][tx] = vxn; sV[slot][1][ty][tx] = vyn; sV[slot][2][ty][tx] = vzn;
         }
-        if (YLDS == 3 && avalid && live) {
+        if (YLDS == 3 && !VISC && avalid && live) {
             // lower register peak: the stress-only operands are requested once the velocity operands are consumed
             P0 = LDB(f.P0, oc); Kc = LDB(f.K, oc); Qc = LDB(f.Q, oc);
             toxx = LDB(f.toxx, oc); toyy = LDB(f.toyy, oc); tozz = LDB(f.tozz, oc);
@@ -904,8 +913,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double dyi = (-vb + vby) * _dy;
                     const double dzi = (-c_p + vc) * _dz;
                     const double divV = dxi + dyi + dzi;
-                    const double _Gdt = 1.0 / (g * dt);
-                    const double _Kdt = 1.0 / (Kc * dt);
+                    const double _Gdt = VISC ? 0.0 : 1.0 / (g * dt);
+                    const double _Kdt = VISC ? 0.0 : 1.0 / (Kc * dt);
                     const double rhs = -divV + (Qc * _dt);
                     const double psi = 1.0 / (1.0 / e + _Gdt) * rr / th;
                     STN<(NT & 1) != 0>(a.o.P, oc, (fma(P0, _Kdt, rhs) * psi + P_k) / (1.0 + _Kdt * psi));
@@ -920,7 +929,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double s_ = 0.5 * (_dy * (va - vay) + _dx * (vb - vbx));
                     const double ee = 0.25 * (exy_ + ey + ex + e);
                     const double gg = 0.25 * (gxy + gy + gx + g);
-                    const double _Gdt = 1.0 / (gg * dt);
+                    const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
                     const double dtr = dev_dtau_r(th, ee, _Gdt);
                     STN<(NT & 1) != 0>(a.o.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
                 }
@@ -928,7 +937,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double s_ = 0.5 * (_dz * (va - a_p) + _dx * (c_p - cx_p));
                     const double ee = 0.25 * ((LOWREG ? exe_p : ex_p + e_p) + ex + e);
                     const double gg = 0.25 * ((LOWREG ? gxg_p : gx_p + g_p) + gx + g);
-                    const double _Gdt = 1.0 / (gg * dt);
+                    const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
                     const double dtr = dev_dtau_r(th, ee, _Gdt);
                     STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01k + dev_stress_inc(s01k, toxz, ee, s_, _Gdt, dtr));
                 }
@@ -936,7 +945,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double s_ = 0.5 * (_dz * (vb - b_p) + _dy * (c_p - cy_p));
                     const double ee = 0.25 * ((LOWREG ? eye_p : ey_p + e_p) + ey + e);
                     const double gg = 0.25 * ((LOWREG ? gyg_p : gy_p + g_p) + gy + g);
-                    const double _Gdt = 1.0 / (gg * dt);
+                    const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
                     const double dtr = dev_dtau_r(th, ee, _Gdt);
                     STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01k + dev_stress_inc(r01k, toyz, ee, s_, _Gdt, dtr));
                 }

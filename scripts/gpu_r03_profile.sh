@@ -20,15 +20,16 @@ import csv, glob, collections
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/FETCH_SIZE/*/*counter_collection.csv") + glob.glob("$OUT/WRITE_SIZE/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        res[r["Kernel_Name"].replace("(anonymous namespace)::", "")[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        res[r["Kernel_Name"].replace("(anonymous namespace)::", "")[:100]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 n = 512.0 ** 3
 print("# python3 bench.py --no-extras --no-cpu-baseline --no-steady-state --steps 20 --warmup 2 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each); FETCH_SIZE doubled")
 print("# (gfx950: 128-B read requests tallied at 64 B, MI355X_MICROARCH.md 'HBM'); rocprofv3 reports KiB; passes = bytes / (8 B x 512^3)")
+print("# k_fused3d<..., TAG, VISC>: last template argument true = viscous-limit form (the headline, dt = Inf), false = general form (the general_kernel leg)")
 for k, d in sorted(res.items()):
     if "at::" in k or "rocclr" in k: continue
     fv, wv = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
     fe = 2.0 * 1024.0 * sum(fv) / max(len(fv), 1)
     wr = 1024.0 * sum(wv) / max(len(wv), 1)
-    print(f"{k:70s} launches {len(fv):4d}  fetch {fe / 1e9:8.3f} GB ({fe / 8 / n:5.1f} passes)  write {wr / 1e9:8.3f} GB ({wr / 8 / n:5.1f} passes)  total {(fe + wr) / 1e9:8.3f} GB")
+    print(f"{k:100s} launches {len(fv):4d}  fetch {fe / 1e9:8.3f} GB ({fe / 8 / n:5.1f} passes)  write {wr / 1e9:8.3f} GB ({wr / 8 / n:5.1f} passes)  total {(fe + wr) / 1e9:8.3f} GB")
 PY
 grep -v "^#" $OUT/pmc_bench_traffic.txt | head -8

@@ -1,0 +1,145 @@
+// kbench_visc.hip -- A/B harness for the viscous-limit form of k_fused3d (development tool): tile shapes, chunk depths, XCD banding.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I justrelax.jl_amd/csrc scripts/kbench_visc.hip -o scripts/kbench_visc
+//   ./scripts/kbench_visc [n=512] [reps=20]
+// Every variant's ten output arrays are compared bit for bit with the shipped configuration's.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "jrx_internal.hpp"
+#include "stokes3d_kernels.hpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void k_fill(double *p, i64 n, unsigned seed, double lo, double hi, int expo)
+{
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        unsigned long long x = (unsigned long long)t * 6364136223846793005ULL + seed * 1442695040888963407ULL + 1013904223ULL;
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0), v = lo + (hi - lo) * u;
+        p[t] = expo ? pow(10.0, v) : v;
+    }
+}
+__global__ void k_ndiff(const double *a, const double *b, i64 n, unsigned long long *out)
+{
+    unsigned long long m = 0;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x)
+        if (__double_as_longlong(a[t]) != __double_as_longlong(b[t])) m += 1;
+    if (m) atomicAdd(out, m);
+}
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
+    template <class F> double run(int reps, F f)
+    {
+        f(); f();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a, 0));
+        for (int r = 0; r < reps; r++) f();
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        return ms / reps;
+    }
+};
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 512, reps = argc > 2 ? atoi(argv[2]) : 20;
+    const int nx = n, ny = n, nz = n;
+    const double cells = (double)nx * ny * nz;
+    jrx_stokes3d_fields f;
+    memset(&f, 0, sizeof(f));
+    struct Ent { double **p; i64 n; double lo, hi; int expo; };
+    const i64 nc = (i64)nx * ny * nz, nvx = (i64)(nx + 1) * (ny + 2) * (nz + 2), nvy = (i64)(nx + 2) * (ny + 1) * (nz + 2),
+              nvz = (i64)(nx + 2) * (ny + 2) * (nz + 1), nxy = (i64)(nx + 1) * (ny + 1) * nz, nyz = (i64)nx * (ny + 1) * (nz + 1),
+              nxz = (i64)(nx + 1) * ny * (nz + 1);
+    std::vector<Ent> ents = {
+        {&f.P, nc, -1, 1, 0}, {&f.Vx, nvx, -1, 1, 0}, {&f.Vy, nvy, -1, 1, 0}, {&f.Vz, nvz, -1, 1, 0},
+        {&f.txx, nc, -1, 1, 0}, {&f.tyy, nc, -1, 1, 0}, {&f.tzz, nc, -1, 1, 0}, {&f.tyz, nyz, -1, 1, 0}, {&f.txz, nxz, -1, 1, 0}, {&f.txy, nxy, -1, 1, 0},
+        {&f.eta, nc, -3, 0, 1}, {&f.fx, nc, -1, 1, 0}, {&f.fy, nc, -1, 1, 0}, {&f.fz, nc, -1, 1, 0}};
+    unsigned seed = 1;
+    for (auto &e : ents) {
+        CK(hipMalloc(e.p, e.n * sizeof(double)));
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, *e.p, e.n, seed++, e.lo, e.hi, e.expo);
+    }
+    // the viscous-limit form never touches these: leave them NULL so that a stray load faults
+    double *etatau;
+    CK(hipMalloc(&etatau, nc * sizeof(double)));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, etatau, nc, 99u, 0.5, 1.5, 0);
+    SweepArgs a;
+    a.f = f; a.etatau = etatau; a._dx = 51.2; a._dy = 49.0; a._dz = 47.5; a.dt = INFINITY; a.r = 0.7; a.theta_dtau = 191.3; a.eta_dtau = 0.0119;
+    a.L = make_lay(nx, ny, nz);
+    a.i0 = a.j0 = a.k0 = 0;
+    Out10 dst, ref;
+    const i64 dn[10] = {nc, nc, nc, nc, nyz, nxz, nxy, nvx, nvy, nvz};
+    double **dp[10] = {&dst.P, &dst.txx, &dst.tyy, &dst.tzz, &dst.tyz, &dst.txz, &dst.txy, &dst.Vx, &dst.Vy, &dst.Vz};
+    double **rp[10] = {&ref.P, &ref.txx, &ref.tyy, &ref.tzz, &ref.tyz, &ref.txz, &ref.txy, &ref.Vx, &ref.Vy, &ref.Vz};
+    for (int q = 0; q < 10; q++) {
+        CK(hipMalloc(dp[q], dn[q] * sizeof(double)));
+        CK(hipMalloc(rp[q], dn[q] * sizeof(double)));
+        CK(hipMemset(*dp[q], 0, dn[q] * sizeof(double)));
+        CK(hipMemset(*rp[q], 0, dn[q] * sizeof(double)));
+    }
+    unsigned long long *d_cnt;
+    CK(hipMalloc(&d_cnt, 8));
+    CK(hipDeviceSynchronize());
+    FusedBC bc;
+    memset(&bc, 0, sizeof(bc));
+    bc.fsL = bc.fsF = bc.fsK0 = 1;
+    Timer T;
+    printf("kbench_visc n=%d reps=%d   (200 B/cell needed, 280 B/cell = the two sweeps without the operands of the zero factors)\n", n, reps);
+    bool have_ref = false;
+    auto finish = [&](const char *name, double ms) {
+        unsigned long long tot = 0;
+        if (have_ref)
+            for (int q = 0; q < 10; q++) {
+                CK(hipMemset(d_cnt, 0, 8));
+                hipLaunchKernelGGL(k_ndiff, dim3(4096), dim3(256), 0, 0, *dp[q], *rp[q], dn[q], d_cnt);
+                unsigned long long c;
+                CK(hipMemcpy(&c, d_cnt, 8, hipMemcpyDeviceToHost));
+                tot += c;
+            }
+        printf("%-40s %8.3f ms  needed %6.0f GB/s  frac(280 B) %.3f  mismatches %llu\n", name, ms, 200.0 * cells / (ms * 1e-3) / 1e9, 280.0 * cells / (ms * 1e-3) / 1e9 / 8000.0, tot);
+        fflush(stdout);
+    };
+#define V(TX, TY, KZ, MW, LR, XG, YL, NT)                                                                                            \
+    {                                                                                                                                \
+        SweepArgs b = a; b.o = have_ref ? dst : ref;                                                                                 \
+        const int ntx = (nx + TX - 3) / (TX - 2), nty = (ny + TY - 2) / (TY - 1), ntz = (nz + KZ - 1) / KZ;                          \
+        auto fn = [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, LR, XG, false, true, YL, NT, 0, true>), dim3(ntx * nty * ntz), dim3(TX * TY), 0, 0, b, bc, ntx, nty, 0, 0, 0); }; \
+        const double ms = T.run(reps, fn);                                                                                           \
+        finish(#TX "x" #TY "x" #KZ " minw" #MW " lowreg=" #LR " xg" #XG " ylds" #YL " nt" #NT, ms);                                  \
+        have_ref = true;                                                                                                             \
+    }
+    V(64, 4, 8, 4, true, 1, 3, 1)      // shipped (reference for the comparisons)
+    V(64, 4, 8, 4, true, 1, 3, 1)
+    V(64, 4, 8, 4, false, 1, 3, 1)
+    V(64, 4, 8, 4, true, 1, 2, 1)
+    V(64, 4, 8, 4, true, 1, 1, 1)
+    V(64, 4, 8, 4, true, 1, 3, 3)
+    V(64, 4, 8, 4, true, 1, 3, 0)
+    V(64, 4, 16, 4, true, 1, 3, 1)
+    V(64, 4, 12, 4, true, 1, 3, 1)
+    V(64, 4, 16, 4, true, 8, 3, 1)
+    V(64, 4, 8, 4, true, 2, 3, 1)
+    V(64, 4, 8, 4, true, 8, 3, 1)
+    V(64, 6, 8, 4, true, 1, 3, 1)
+    V(64, 6, 8, 3, true, 1, 3, 1)
+    V(64, 6, 16, 4, true, 1, 3, 1)
+    V(64, 8, 8, 4, true, 1, 3, 1)
+    V(64, 8, 8, 2, true, 1, 3, 1)
+    V(64, 8, 16, 4, true, 1, 3, 1)
+    V(64, 8, 8, 4, true, 2, 3, 1)
+    V(64, 8, 8, 4, false, 1, 3, 1)
+    V(64, 12, 8, 2, true, 1, 3, 1)
+    V(64, 16, 8, 2, true, 1, 3, 1)
+    V(32, 8, 8, 4, true, 1, 3, 1)
+    V(32, 16, 8, 4, true, 1, 3, 1)
+    V(64, 4, 8, 4, true, 1, 3, 1)
+    printf("done\n");
+    return 0;
+}

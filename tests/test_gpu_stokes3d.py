@@ -262,6 +262,44 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
             assert np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)
 
 
+@pytest.mark.parametrize("ni,bcs,tile", [((130, 20, 17), "free_slip", 0), ((97, 9, 33), "none", 0), ((130, 17, 20), "no_slip", 1), ((66, 9, 35), "slip_mix", 1),
+                                         ((130, 12, 17), "periodic", 0)])
+def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
+    """dt = Inf (SolVi3D, Burstedde, TaylorGreen: SolVi3D.jl:96 hands dt = Inf): the fused kernel's viscous-limit form does not load τ_o, P0, K, G, Q
+    -- every one of them random and non-zero here -- and must equal the general fused kernel and the per-node kernels, which do."""
+    import ctypes as C
+    jr = env["jr"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields3d(ni, bcs=bcs, dt=np.inf, iterMax=23, nout=7)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    h = _lib.default_handle()
+    tile0 = C.c_int64(0)
+    h.call("jrx_tuning_get", C.c_char_p(b"fused_tile"), C.byref(tile0))
+    outs, its = [], []
+    try:
+        h.call("jrx_tuning_set", C.c_char_p(b"fused_tile"), C.c_int64(tile))
+        for variant, visc in ((3, 1), (3, 0), (1, 1)):
+            h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
+            h.call("jrx_set_option", C.c_char_p(b"viscous_limit"), C.c_int64(visc))
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            n0, n1 = C.c_int64(0), C.c_int64(0)
+            h.call("jrx_get_option", C.c_char_p(b"stat_fused3d"), C.byref(n0))
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+            h.call("jrx_get_option", C.c_char_p(b"stat_fused3d"), C.byref(n1))
+            assert (n1.value > n0.value) == (variant == 3)
+            its.append((r.iter, tuple(r.err_evo1)))
+            outs.append(env["down"](stokes))
+    finally:
+        h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
+        h.call("jrx_set_option", C.c_char_p(b"viscous_limit"), C.c_int64(1))
+        h.call("jrx_tuning_set", C.c_char_p(b"fused_tile"), tile0)
+    assert its[0] == its[1] == its[2] and its[0][0] == 24
+    for v in (1, 2):
+        for k in outs[0]:
+            m = env["checks"].interior_mask3d(k, outs[0][k].shape)
+            assert (k[0] == "U" or np.isfinite(outs[0][k][m]).all()) and np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)      # U = V dt = ±Inf, NaN where V = 0
+
+
 def test_iterate_timed_leaves_state_in_user_arrays(env):
     """bench hook: K back-to-back iterations through the fused pipeline == K iterations of the per-node kernels."""
     import ctypes as C
