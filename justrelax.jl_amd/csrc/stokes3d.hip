@@ -92,6 +92,8 @@ jrx_status launch_stress_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bo
 {
     const TileMap tm = make_tilemap(a.L.nx, a.L.ny, a.L.nz, TX, TY, KZ);
     if (diag) hipLaunchKernelGGL((k_stress3d_zb<true, TX, TY, KZ, 4, false, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else if (h->viscous_limit && a.dt == INFINITY)      // dt = Inf: τ_o, P0, K, G, Q only meet factors that are exactly 0 and are not loaded (see k_fused3d)
+        hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, 8, true, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     else hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;

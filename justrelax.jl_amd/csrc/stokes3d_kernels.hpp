@@ -408,10 +408,11 @@ __device__ __forceinline__ bool tile_of_block(const TileMap &m, int &tx, int &ty
 
 // SHF: the x-neighbour operands (Vx at i+1; Vy, Vz, η, G at i-1) come from the adjacent lane; only the first / last lane of a
 // wave (and the last cell column) load them
-template <bool DIAG, int TX, int TY, int KZ, int MINW, bool EDGES, int XCD = 0, bool SHF = false>
+template <bool DIAG, int TX, int TY, int KZ, int MINW, bool EDGES, int XCD = 0, bool SHF = false, bool VISC = false>
 __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a, const TileMap tm)
 {
     static_assert(!SHF || (TX % 64 == 0 && !EDGES), "SHF needs whole waves per row");
+    static_assert(!VISC || (!DIAG && !EDGES), "the viscous-limit form is the state-only sweep over the interior tiles");
     const Lay3 &L = a.L;
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     int tx, ty, tz;
@@ -444,44 +445,48 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
     double c_p = LDB(f.Vz, ovz - svz), cx_p = LDB(f.Vz, ovz - svz - 8u), cy_p = LDB(f.Vz, ovz - svz - rvz);
     const u32 back = kb > 0 ? sc : 0u;
     double e_p = LDB(f.eta, oc - back), ex_p = LDB(f.eta, oc - back - dcx), ey_p = LDB(f.eta, oc - back - dcy);
-    double g_p = LDB(f.G, oc - back), gx_p = LDB(f.G, oc - back - dcx), gy_p = LDB(f.G, oc - back - dcy);
+    double g_p = 1.0, gx_p = 1.0, gy_p = 1.0;     // VISC: G is only ever multiplied into 1/(G dt) = 0 (see k_fused3d)
+    if (!VISC) { g_p = LDB(f.G, oc - back); gx_p = LDB(f.G, oc - back - dcx); gy_p = LDB(f.G, oc - back - dcy); }
 
     for (int k = kb; k < kend; ++k) {
         const double va = LDB(f.Vx, ovx), vay = LDB(f.Vx, ovx - rvx);
         const double vb = LDB(f.Vy, ovy), vby = LDB(f.Vy, ovy + rvy);
         const double vc = LDB(f.Vz, ovz), vcy = LDB(f.Vz, ovz - rvz);
         const double e = LDB(f.eta, oc), ey = LDB(f.eta, oc - dcy);
-        const double g = LDB(f.G, oc), gy = LDB(f.G, oc - dcy);
-        double vax, vbx, vcx, ex, exy_, gx, gxy;
+        const double g = VISC ? 1.0 : LDB(f.G, oc), gy = VISC ? 1.0 : LDB(f.G, oc - dcy);
+        double vax, vbx, vcx, ex, exy_, gx = 1.0, gxy = 1.0;
         if (SHF) {
             const int lane = (int)(threadIdx.x & 63);
             vax = __shfl_down(va, 1, 64);
             vbx = __shfl_up(vb, 1, 64); vcx = __shfl_up(vc, 1, 64);
-            ex = __shfl_up(e, 1, 64); exy_ = __shfl_up(ey, 1, 64); gx = __shfl_up(g, 1, 64); gxy = __shfl_up(gy, 1, 64);
+            ex = __shfl_up(e, 1, 64); exy_ = __shfl_up(ey, 1, 64);
+            if (!VISC) { gx = __shfl_up(g, 1, 64); gxy = __shfl_up(gy, 1, 64); }
             if (lane == 63 || xhi) vax = LDB(f.Vx, ovx + 8u);
             if (lane == 0) {
                 vbx = LDB(f.Vy, ovy - 8u); vcx = LDB(f.Vz, ovz - 8u);
-                ex = LDB(f.eta, oc - dcx); exy_ = LDB(f.eta, oc - dcx - dcy); gx = LDB(f.G, oc - dcx); gxy = LDB(f.G, oc - dcx - dcy);
+                ex = LDB(f.eta, oc - dcx); exy_ = LDB(f.eta, oc - dcx - dcy);
+                if (!VISC) { gx = LDB(f.G, oc - dcx); gxy = LDB(f.G, oc - dcx - dcy); }
             }
         } else {
             vax = LDB(f.Vx, ovx + 8u); vbx = LDB(f.Vy, ovy - 8u); vcx = LDB(f.Vz, ovz - 8u);
-            ex = LDB(f.eta, oc - dcx); exy_ = LDB(f.eta, oc - dcx - dcy); gx = LDB(f.G, oc - dcx); gxy = LDB(f.G, oc - dcx - dcy);
+            ex = LDB(f.eta, oc - dcx); exy_ = LDB(f.eta, oc - dcx - dcy);
+            if (!VISC) { gx = LDB(f.G, oc - dcx); gxy = LDB(f.G, oc - dcx - dcy); }
         }
         // issue the remaining independent loads of this plane early
-        const double P = LDB(f.P, oc), P0 = LDB(f.P0, oc), Kc = LDB(f.K, oc), Qc = LDB(f.Q, oc);
+        const double P = LDB(f.P, oc), P0 = VISC ? 0.0 : LDB(f.P0, oc), Kc = VISC ? 1.0 : LDB(f.K, oc), Qc = VISC ? 0.0 : LDB(f.Q, oc);
         const double txx = LDB(f.txx, oc), tyy = LDB(f.tyy, oc), tzz = LDB(f.tzz, oc);
-        const double toxx = LDB(f.toxx, oc), toyy = LDB(f.toyy, oc), tozz = LDB(f.tozz, oc);
-        const double txy = LDB(f.txy, oxy), toxy = LDB(f.toxy, oxy);
-        const double txz = LDB(f.txz, oxz), toxz = LDB(f.toxz, oxz);
-        const double tyz = LDB(f.tyz, oyz), toyz = LDB(f.toyz, oyz);
+        const double toxx = VISC ? 0.0 : LDB(f.toxx, oc), toyy = VISC ? 0.0 : LDB(f.toyy, oc), tozz = VISC ? 0.0 : LDB(f.tozz, oc);
+        const double txy = LDB(f.txy, oxy), toxy = VISC ? 0.0 : LDB(f.toxy, oxy);
+        const double txz = LDB(f.txz, oxz), toxz = VISC ? 0.0 : LDB(f.toxz, oxz);
+        const double tyz = LDB(f.tyz, oyz), toyz = VISC ? 0.0 : LDB(f.toyz, oyz);
 
         {   // centre (i,j,k)
             const double dxi = (-va + vax) * _dx;
             const double dyi = (-vb + vby) * _dy;
             const double dzi = (-c_p + vc) * _dz;
             const double divV = dxi + dyi + dzi;
-            const double _Gdt = 1.0 / (g * dt);
-            const double _Kdt = 1.0 / (Kc * dt);
+            const double _Gdt = VISC ? 0.0 : 1.0 / (g * dt);
+            const double _Kdt = VISC ? 0.0 : 1.0 / (Kc * dt);
             const double rhs = -divV + (Qc * _dt);
             const double psi = 1.0 / (1.0 / e + _Gdt) * rr / th;
             STB(a.o.P, oc, (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi));
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
             const double s_ = 0.5 * (_dy * (va - vay) + _dx * (vb - vbx));
             const double ee = 0.25 * (exy_ + ey + ex + e);
             const double gg = 0.25 * (gxy + gy + gx + g);
-            const double _Gdt = 1.0 / (gg * dt);
+            const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
             const double dtr = dev_dtau_r(th, ee, _Gdt);
             STB(a.o.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
             if (DIAG) STB(f.exy, oxy, s_);
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
             const double s_ = 0.5 * (_dz * (va - a_p) + _dx * (c_p - cx_p));
             const double ee = 0.25 * (ex_p + e_p + ex + e);
             const double gg = 0.25 * (gx_p + g_p + gx + g);
-            const double _Gdt = 1.0 / (gg * dt);
+            const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
             const double dtr = dev_dtau_r(th, ee, _Gdt);
             STB(a.o.txz, oxz, txz + dev_stress_inc(txz, toxz, ee, s_, _Gdt, dtr));
             if (DIAG) STB(f.exz, oxz, s_);
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
             const double s_ = 0.5 * (_dz * (vb - b_p) + _dy * (c_p - cy_p));
             const double ee = 0.25 * (ey_p + e_p + ey + e);
             const double gg = 0.25 * (gy_p + g_p + gy + g);
-            const double _Gdt = 1.0 / (gg * dt);
+            const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
             const double dtr = dev_dtau_r(th, ee, _Gdt);
             STB(a.o.tyz, oyz, tyz + dev_stress_inc(tyz, toyz, ee, s_, _Gdt, dtr));
             if (DIAG) STB(f.eyz, oyz, s_);

@@ -29,6 +29,23 @@ __global__ void k_ndiff(const double *a, const double *b, i64 n, unsigned long l
         if (__double_as_longlong(a[t]) != __double_as_longlong(b[t])) m += 1;
     if (m) atomicAdd(out, m);
 }
+template <int NR, int NW, int NT>
+struct StreamArgs { const double *r[NR > 0 ? NR : 1]; double *w[NW > 0 ? NW : 1]; i64 n; };
+// pure streaming kernel with the stream mix of a sweep: NR arrays read, NW written, 8 B per lane, NT: non-temporal stores
+template <int NR, int NW, int NT>
+__global__ __launch_bounds__(256) void k_stream(StreamArgs<NR, NW, NT> a)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n) return;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; q++) acc += a.r[q][t];
+#pragma unroll
+    for (int q = 0; q < NW; q++) {
+        if (NT) __builtin_nontemporal_store(acc + q, a.w[q] + t);
+        else a.w[q][t] = acc + q;
+    }
+}
 struct Timer {
     hipEvent_t a, b;
     Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
@@ -92,6 +109,23 @@ int main(int argc, char **argv)
     bc.fsL = bc.fsF = bc.fsK0 = 1;
     Timer T;
     printf("kbench_visc n=%d reps=%d   (200 B/cell needed, 280 B/cell = the two sweeps without the operands of the zero factors)\n", n, reps);
+    {   // streaming ceilings for the stream mixes of the two forms (the written arrays are the ten outputs: they are rewritten by every variant below)
+        std::vector<const double *> rd;
+        for (auto &e : ents) if (e.n >= nc) rd.push_back(*e.p);
+        for (int q = 0; q < 10; q++) rd.push_back(*rp[q]);
+        rd.push_back(etatau);
+#define STREAM(NR, NW, NT)                                                                                           \
+        {                                                                                                            \
+            StreamArgs<NR, NW, NT> sa;                                                                               \
+            for (int q = 0; q < NR; q++) sa.r[q] = rd[q % rd.size()];                                                \
+            for (int q = 0; q < NW; q++) sa.w[q] = *dp[q];                                                           \
+            sa.n = nc;                                                                                               \
+            const double ms = T.run(reps, [&] { hipLaunchKernelGGL((k_stream<NR, NW, NT>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, 0, sa); }); \
+            printf("stream %2dR + %2dW nt%d                      %8.3f ms  %6.0f GB/s\n", NR, NW, NT, ms, (NR + NW) * 8.0 * cells / (ms * 1e-3) / 1e9); \
+            fflush(stdout);                                                                                          \
+        }
+        STREAM(15, 10, 1) STREAM(15, 10, 0) STREAM(25, 10, 1) STREAM(25, 10, 0) STREAM(14, 3, 1) STREAM(21, 7, 1) STREAM(25, 0, 0) STREAM(15, 0, 0) STREAM(1, 10, 1) STREAM(1, 10, 0) STREAM(1, 1, 1)
+    }
     bool have_ref = false;
     auto finish = [&](const char *name, double ms) {
         unsigned long long tot = 0;

@@ -278,7 +278,7 @@ def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
     outs, its = [], []
     try:
         h.call("jrx_tuning_set", C.c_char_p(b"fused_tile"), C.c_int64(tile))
-        for variant, visc in ((3, 1), (3, 0), (1, 1)):
+        for variant, visc in ((3, 1), (3, 0), (2, 1), (2, 0), (1, 1)):      # 2: the z-marching stress sweep has the same form
             h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
             h.call("jrx_set_option", C.c_char_p(b"viscous_limit"), C.c_int64(visc))
             stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
@@ -293,8 +293,8 @@ def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
         h.call("jrx_set_option", C.c_char_p(b"viscous_limit"), C.c_int64(1))
         h.call("jrx_tuning_set", C.c_char_p(b"fused_tile"), tile0)
-    assert its[0] == its[1] == its[2] and its[0][0] == 24
-    for v in (1, 2):
+    assert its[0] == its[1] == its[2] == its[3] == its[4] and its[0][0] == 24
+    for v in (1, 2, 3, 4):
         for k in outs[0]:
             m = env["checks"].interior_mask3d(k, outs[0][k].shape)
             assert (k[0] == "U" or np.isfinite(outs[0][k][m]).all()) and np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)      # U = V dt = ±Inf, NaN where V = 0
