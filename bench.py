@@ -56,9 +56,9 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measure
 # correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
 # n = 512 (profiles/*pmc*traffic.txt; the file names are in PMC_SOURCE)
 PMC_TRAFFIC_STRESS_512 = 32.543e9       # k_stress3d_zb: 24.962 GB fetched (x2 applied) + 7.581 GB written
-PMC_TRAFFIC_FUSED_512 = 52.351e9        # k_fused3d:     41.035 GB fetched (x2 applied) + 11.316 GB written (38.2 + 10.5 array passes)
-PMC_TRAFFIC_VISC_512 = 40.179e9         # k_fused3d, viscous-limit form: 28.851 GB fetched (x2 applied) + 11.327 GB written (26.9 + 10.5 array passes)
-PMC_SOURCE = {"stress": "profiles/r03_pmc_bench_traffic.txt", "fused": "profiles/r03_pmc_bench_traffic.txt", "visc": "profiles/r03_pmc_viscous_limit_traffic.txt"}
+PMC_TRAFFIC_FUSED_512 = 52.371e9        # k_fused3d, general form: 41.056 GB fetched (x2 applied) + 11.315 GB written (38.2 + 10.5 array passes)
+PMC_TRAFFIC_VISC_512 = 39.940e9         # k_fused3d, viscous-limit form: 28.609 GB fetched (x2 applied) + 11.331 GB written (26.6 + 10.6 array passes)
+PMC_SOURCE = {"stress": "profiles/r03_pmc_bench_traffic.txt", "fused": "profiles/r03_pmc_bench_traffic.txt", "visc": "profiles/r03_pmc_bench_traffic.txt"}
 
 
 def pricing(h, dt):

@@ -126,6 +126,7 @@ int main(int argc, char **argv)
         }
         STREAM(15, 10, 1) STREAM(15, 10, 0) STREAM(25, 10, 1) STREAM(25, 10, 0) STREAM(14, 3, 1) STREAM(21, 7, 1) STREAM(25, 0, 0) STREAM(15, 0, 0) STREAM(1, 10, 1) STREAM(1, 10, 0) STREAM(1, 1, 1)
     }
+    for (int q = 0; q < 10; q++) CK(hipMemset(*dp[q], 0, dn[q] * sizeof(double)));     // the streams wrote into them; no variant writes the outer shell of V
     bool have_ref = false;
     auto finish = [&](const char *name, double ms) {
         unsigned long long tot = 0;
