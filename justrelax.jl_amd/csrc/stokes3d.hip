@@ -218,7 +218,10 @@ static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepA
     if (!B.n) return JRX_OK;
     B.start[B.n] = tot;
     const GhostRule none = {{0, 0, 0, 0, 0, 0}};
-    if (rule) hipLaunchKernelGGL((k_stress3d_boxes<false, true>), dim3((unsigned)tot), dim3(256), 0, s, a, B, *rule);
+    const bool visc = !diag && h->viscous_limit && a.dt == INFINITY;
+    if (rule && visc) hipLaunchKernelGGL((k_stress3d_boxes<false, true, true>), dim3((unsigned)tot), dim3(256), 0, s, a, B, *rule);
+    else if (rule) hipLaunchKernelGGL((k_stress3d_boxes<false, true>), dim3((unsigned)tot), dim3(256), 0, s, a, B, *rule);
+    else if (visc) hipLaunchKernelGGL((k_stress3d_boxes<false, false, true>), dim3((unsigned)tot), dim3(256), 0, s, a, B, none);
     else if (diag) hipLaunchKernelGGL(k_stress3d_boxes<true>, dim3((unsigned)tot), dim3(256), 0, s, a, B, none);
     else hipLaunchKernelGGL(k_stress3d_boxes<false>, dim3((unsigned)tot), dim3(256), 0, s, a, B, none);
     JRX_LAUNCH_CHECK(h);

@@ -87,7 +87,8 @@ __device__ __forceinline__ double vz_rule(const double *__restrict__ Vz, const L
     return sgn * Vz[i + (i64)L.vz1 * j + L.vzp * k];
 }
 
-template <bool DIAG, bool GH = false>
+// VISC: the viscous limit dt = Inf (see k_fused3d): 1/(G dt) = 1/(K dt) = 1/dt = 0, their operands τ_o, P0, K, G, Q are not loaded
+template <bool DIAG, bool GH = false, bool VISC = false>
 __device__ __forceinline__ void stress3d_node(const SweepArgs &a, const int i, const int j, const int k, const GhostRule *gr = nullptr)
 {
     const Lay3 &L = a.L;
@@ -113,12 +114,12 @@ __device__ __forceinline__ void stress3d_node(const SweepArgs &a, const int i, c
         const double divV = dxi + dyi + dzi;
         // compute_P! (PressureKernels.jl:186-195), η (not ητ) in the 3D driver (Stokes3D.jl:85)
         const double e = eta[c];
-        const double _Gdt = 1.0 / (G[c] * dt);
+        const double _Gdt = VISC ? 0.0 : 1.0 / (G[c] * dt);
         {
-            const double _Kdt = 1.0 / (a.f.K[c] * dt);
+            const double _Kdt = VISC ? 0.0 : 1.0 / (a.f.K[c] * dt);
             const double _dt = 1.0 / dt;
-            const double P = a.f.P[c], P0 = a.f.P0[c];
-            const double rhs = -divV + (a.f.Q[c] * _dt);
+            const double P = a.f.P[c], P0 = VISC ? 0.0 : a.f.P0[c];
+            const double rhs = -divV + ((VISC ? 0.0 : a.f.Q[c]) * _dt);
             const double psi = 1.0 / (1.0 / e + _Gdt) * a.r / th;
             a.o.P[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
             if (DIAG) {
@@ -133,9 +134,9 @@ __device__ __forceinline__ void stress3d_node(const SweepArgs &a, const int i, c
         // compute_τ! normal components (StressKernels.jl:185-198)
         const double dtr = dev_dtau_r(th, e, _Gdt);
         double tv;
-        tv = a.f.txx[c]; a.o.txx[c] = tv + dev_stress_inc(tv, a.f.toxx[c], e, exx, _Gdt, dtr);
-        tv = a.f.tyy[c]; a.o.tyy[c] = tv + dev_stress_inc(tv, a.f.toyy[c], e, eyy, _Gdt, dtr);
-        tv = a.f.tzz[c]; a.o.tzz[c] = tv + dev_stress_inc(tv, a.f.tozz[c], e, ezz, _Gdt, dtr);
+        tv = a.f.txx[c]; a.o.txx[c] = tv + dev_stress_inc(tv, (VISC ? 0.0 : a.f.toxx[c]), e, exx, _Gdt, dtr);
+        tv = a.f.tyy[c]; a.o.tyy[c] = tv + dev_stress_inc(tv, (VISC ? 0.0 : a.f.toyy[c]), e, eyy, _Gdt, dtr);
+        tv = a.f.tzz[c]; a.o.tzz[c] = tv + dev_stress_inc(tv, (VISC ? 0.0 : a.f.tozz[c]), e, ezz, _Gdt, dtr);
     }
 
     // clamped neighbour cell indices (MiniKernels.jl:133-147)
@@ -146,34 +147,31 @@ __device__ __forceinline__ void stress3d_node(const SweepArgs &a, const int i, c
     if (ck) {   // τxy at (i,j,k) of (nx+1, ny+1, nz)   (VelocityKernels.jl:95-101, StressKernels.jl:199-208)
         const double exy = 0.5 * (_dy * (VX(i, j + 1, k + 1) - VX(i, j, k + 1)) + _dx * (VY(i + 1, j, k + 1) - VY(i, j, k + 1)));
         const double e = 0.25 * (eta[CC(im, jm, k)] + eta[CC(ip, jm, k)] + eta[CC(im, jp, k)] + eta[CC(ip, jp, k)]);
-        const double g = 0.25 * (G[CC(im, jm, k)] + G[CC(ip, jm, k)] + G[CC(im, jp, k)] + G[CC(ip, jp, k)]);
-        const double _Gdt = 1.0 / (g * dt);
+        const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (G[CC(im, jm, k)] + G[CC(ip, jm, k)] + G[CC(im, jp, k)] + G[CC(ip, jp, k)]) * dt);
         const double dtr = dev_dtau_r(th, e, _Gdt);
         const i64 c = i + (i64)L.xy1 * j + L.xyp * k;
         const double tv = a.f.txy[c];
-        a.o.txy[c] = tv + dev_stress_inc(tv, a.f.toxy[c], e, exy, _Gdt, dtr);
+        a.o.txy[c] = tv + dev_stress_inc(tv, (VISC ? 0.0 : a.f.toxy[c]), e, exy, _Gdt, dtr);
         if (DIAG) a.f.exy[c] = exy;
     }
     if (cj) {   // τxz at (i,j,k) of (nx+1, ny, nz+1)
         const double exz = 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k)));
         const double e = 0.25 * (eta[CC(im, j, km)] + eta[CC(ip, j, km)] + eta[CC(im, j, kp)] + eta[CC(ip, j, kp)]);
-        const double g = 0.25 * (G[CC(im, j, km)] + G[CC(ip, j, km)] + G[CC(im, j, kp)] + G[CC(ip, j, kp)]);
-        const double _Gdt = 1.0 / (g * dt);
+        const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (G[CC(im, j, km)] + G[CC(ip, j, km)] + G[CC(im, j, kp)] + G[CC(ip, j, kp)]) * dt);
         const double dtr = dev_dtau_r(th, e, _Gdt);
         const i64 c = i + (i64)L.xz1 * j + L.xzp * k;
         const double tv = a.f.txz[c];
-        a.o.txz[c] = tv + dev_stress_inc(tv, a.f.toxz[c], e, exz, _Gdt, dtr);
+        a.o.txz[c] = tv + dev_stress_inc(tv, (VISC ? 0.0 : a.f.toxz[c]), e, exz, _Gdt, dtr);
         if (DIAG) a.f.exz[c] = exz;
     }
     if (ci) {   // τyz at (i,j,k) of (nx, ny+1, nz+1)
         const double eyz = 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k)));
         const double e = 0.25 * (eta[CC(i, jm, km)] + eta[CC(i, jp, km)] + eta[CC(i, jm, kp)] + eta[CC(i, jp, kp)]);
-        const double g = 0.25 * (G[CC(i, jm, km)] + G[CC(i, jp, km)] + G[CC(i, jm, kp)] + G[CC(i, jp, kp)]);
-        const double _Gdt = 1.0 / (g * dt);
+        const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (G[CC(i, jm, km)] + G[CC(i, jp, km)] + G[CC(i, jm, kp)] + G[CC(i, jp, kp)]) * dt);
         const double dtr = dev_dtau_r(th, e, _Gdt);
         const i64 c = i + (i64)L.yz1 * j + L.yzp * k;
         const double tv = a.f.tyz[c];
-        a.o.tyz[c] = tv + dev_stress_inc(tv, a.f.toyz[c], e, eyz, _Gdt, dtr);
+        a.o.tyz[c] = tv + dev_stress_inc(tv, (VISC ? 0.0 : a.f.toyz[c]), e, eyz, _Gdt, dtr);
         if (DIAG) a.f.eyz[c] = eyz;
     }
 #undef VX
@@ -200,7 +198,7 @@ struct StressBoxes {
     int start[7];         // first block of each box; start[n] = total
     int per_plane[6];     // blocks per xy-plane of the box
 };
-template <bool DIAG, bool GH = false>
+template <bool DIAG, bool GH = false, bool VISC = false>
 __global__ __launch_bounds__(256) void k_stress3d_boxes(const SweepArgs a, const StressBoxes B, const GhostRule gr)
 {
     int b = 0;
@@ -212,7 +210,7 @@ __global__ __launch_bounds__(256) void k_stress3d_boxes(const SweepArgs a, const
     const int jj = t / wi;
     const int j = B.box[b][2] + jj;
     if (j >= B.box[b][3]) return;
-    stress3d_node<DIAG, GH>(a, B.box[b][0] + (t - jj * wi), j, B.box[b][4] + kz, &gr);
+    stress3d_node<DIAG, GH, VISC>(a, B.box[b][0] + (t - jj * wi), j, B.box[b][4] + kz, &gr);
 }
 
 // ------------------------------------------------------------------------------------------------
