@@ -66,13 +66,13 @@ const char *jrx_build_id(void);
 /* Options of the handle: what a caller of solve! may want to choose.  (The A/B switches of the measurements in profiles/ and the test
  * hooks are NOT part of this ABI: include/jrx_tuning.h.)  The library never reads the process environment.  Keys:
  * "kernel_variant" (3D Stokes):
- *   0 = default: fused PT pipeline where it applies (no periodic_boundary! faces, nx >= 48, ny, nz >= 8, and nx fills
- *       its 62-column tiles to >= 71 %): one kernel runs velocity sweep m + BCs + stress sweep m+1 with ping-pong
+ *   0 = default: fused PT pipeline where it applies (nx >= 48, ny, nz >= 8, and not one of the few nx -- 125 .. 128 -- whose last
+ *       62-column tile stays nearly empty while the sweeps' row tiles fill exactly): one kernel runs velocity sweep m + BCs + stress sweep m+1 with ping-pong
  *       state arrays (the handle then owns a second set of the 10 state arrays); with a communicator the exchange
  *       of V follows and the stress nodes next to a received plane are redone; otherwise, and on iterations whose
  *       results are observed, the two z-marching sweeps;
  *   1 = simple one-thread-per-node kernels;  2 = z-marching sweeps only (two launches per iteration, no ping-pong set);
- *   3 = fused pipeline wherever it is legal (ignores the tile-fill rule).  All variants produce bit-identical results.
+ *   3 = fused pipeline wherever it is legal (ignores that rule).  All variants produce bit-identical results.
  * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
  * "fused_overlap" (0/1/2, default 2): how the multi-rank fused pipeline places update_halo!(V) (same results in every mode):
  *   2 = early exchange: the velocity phase alone over the boundary slabs of the faces with a neighbour, flow_bcs! and the whole exchange on a second

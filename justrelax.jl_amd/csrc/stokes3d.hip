@@ -475,15 +475,18 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     // DisplacementBoundaryConditions: flow_bcs! acts on U, the ghosts of V are never refreshed -- the fused kernel's in-kernel BC rules do not apply
     I.fusable = !p->displacement_bcs && (h->kernel_variant == 0 || h->kernel_variant == 3) && h->scratch_sets && (h->fused_comm || !jrx_comm_active(h)) && fits_u32(L) && p->nx >= 48 && p->ny >= 8 && p->nz >= 8;
     if (I.fusable && h->kernel_variant == 0) {
-        // auto: the fused kernel covers a row with ceil(nx / (TX - 2)) TX-lane tiles (one halo and one feeder lane each); when that
-        // quantisation idles too many lanes the two sweeps are faster (measured with 64-lane rows, profiles/r01_bench_sizes.txt: nx = 192,
-        // 4 tiles, 33 % idle: fused +21 %; nx = 96, 2 tiles, 33 %: equal; nx = 256: +4 %; nx = 320: +25 %; nx = 128, 3 tiles, 50 % idle: fused -21 %)
+        // auto.  Round 3, with 8-plane chunks and the leaner kernels (scripts/bench_sizes_variants.py, profiles/r03_sizes_variants.txt): the fused pipeline is the
+        // faster path at every cube from 48^3 to 512^3 -- by 15 .. 66 % below 160^3, where the round-1 rules (tile fill >= 71 %, >= 1536 tiles) still kept the two
+        // sweeps -- except where its 62-column tiles leave a nearly empty last tile while the sweeps' row tiles fill exactly (nx = 125 .. 128: fused -9 %).
+        // Lanes per cell row: fused ceil(nx / (TX - 2)) TX-lane tiles with TY - 1 of TY rows updating stresses; sweeps ceil(nx / W) W-lane row tiles (W as in
+        // launch_stress); per lane the fused iteration costs 0.62 of the two sweeps (120^3: 9.0 k against 7.4 k it/s at 171 against 128 lanes).  Small grids are
+        // bound by the launch count, which favours the fused pipeline whatever the fill.
         const FusedShape S = fused_shape(h);
         int nt[3];
         fused_tiles(L, S, nt);
-        if ((i64)nt[0] * S.tx * 100 > (i64)p->nx * 140) I.fusable = false;
-        // ... and below ~6 tiles per CU the deep tiles leave the chip idle (96^3 with 64 x 4 tiles, 384 16-plane units: 6.8 k it/s fused, 9.2 k with the sweeps)
-        if ((i64)nt[0] * nt[1] * ((p->nz + 15) / 16) * (S.ty - 1) < 1536 * 3) I.fusable = false;     // counted in units of 3 rows x 16 planes as measured
+        const int W = p->nx > 384 ? 512 : (p->nx > 192 ? 256 : (p->nx > 96 ? 128 : 64));
+        const double lanes_f = (double)nt[0] * S.tx * S.ty / (S.ty - 1), lanes_s = (double)((p->nx + W - 1) / W) * W;
+        if ((double)p->nx * (double)p->ny * (double)p->nz >= 1e6 && 0.62 * lanes_f > 1.15 * lanes_s) I.fusable = false;
     }
     if (I.fusable) {
         JRX_TRY(ensure_scratch(h, (int)p->nx, (int)p->ny, (int)p->nz));
