@@ -175,6 +175,35 @@ int main(int argc, char **argv)
     V(32, 8, 8, 4, true, 1, 3, 1)
     V(32, 16, 8, 4, true, 1, 3, 1)
     V(64, 4, 8, 4, true, 1, 3, 1)
+    {   // two iterations as a wavefront of z slabs: iteration m on slab s, then iteration m+1 on slab s-1, so that what iteration m wrote is re-read while it may still be in the
+        // 256 MiB Infinity Cache (timing experiment only: the boundary-layer launches between the iterations are left out; A -> B -> A ping-pong on the harness' arrays)
+        constexpr int TX = 64, TY = 4, KZ = 8;
+        const int ntx = (nx + TX - 3) / (TX - 2), nty = (ny + TY - 2) / (TY - 1), ntz = (nz + KZ - 1) / KZ;
+        SweepArgs ab = a; ab.o = dst;                          // iteration m: harness inputs -> dst
+        SweepArgs ba = a;                                      // iteration m+1: dst -> ref (the state arrays of a.f are read-only inputs of the other variants)
+        ba.f.P = dst.P; ba.f.txx = dst.txx; ba.f.tyy = dst.tyy; ba.f.tzz = dst.tzz; ba.f.tyz = dst.tyz; ba.f.txz = dst.txz; ba.f.txy = dst.txy;
+        ba.f.Vx = dst.Vx; ba.f.Vy = dst.Vy; ba.f.Vz = dst.Vz; ba.o = ref;
+        auto full2 = [&] {
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true>), dim3(ntx * nty * ntz), dim3(TX * TY), 0, 0, ab, bc, ntx, nty, 0, 0, 0);
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true>), dim3(ntx * nty * ntz), dim3(TX * TY), 0, 0, ba, bc, ntx, nty, 0, 0, 0);
+        };
+        printf("two iterations, two full launches          %8.3f ms per iteration\n", T.run(reps, full2) / 2);
+        for (int D : {1, 2, 4, 8, 16}) {
+            auto wave = [&] {
+                for (int s0 = 0; s0 < ntz + D; s0 += D) {
+                    const int d1 = s0 < ntz ? (ntz - s0 < D ? ntz - s0 : D) : 0;
+                    if (d1 > 0) hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true>), dim3(ntx * nty * d1), dim3(TX * TY), 0, 0, ab, bc, ntx, nty, 0, 0, s0);
+                    const int t0 = s0 - D;
+                    if (t0 >= 0) {
+                        const int d2 = ntz - t0 < D ? ntz - t0 : D;
+                        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true>), dim3(ntx * nty * d2), dim3(TX * TY), 0, 0, ba, bc, ntx, nty, 0, 0, t0);
+                    }
+                }
+            };
+            printf("two iterations, wavefront of %2d-chunk slabs %8.3f ms per iteration\n", D, T.run(reps, wave) / 2);
+            fflush(stdout);
+        }
+    }
     printf("done\n");
     return 0;
 }
