@@ -55,7 +55,9 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measure
 # L2<->fabric bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
 # correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
 # n = 512 (profiles/*pmc*traffic.txt; the file names are in PMC_SOURCE)
-PMC_TRAFFIC_STRESS_512 = 32.543e9       # k_stress3d_zb: 24.962 GB fetched (x2 applied) + 7.581 GB written
+A_STRESS_VISC = 18 * 8.0  # ... in the viscous limit: 11 reads + 7 writes (no tau_o, P0, K, G, Q)
+PMC_TRAFFIC_STRESS_512 = 32.569e9       # k_stress3d_zb, general form: 24.990 GB fetched (x2 applied) + 7.580 GB written
+PMC_TRAFFIC_STRESS_VISC_512 = 20.339e9  # k_stress3d_zb, viscous-limit form: 12.767 GB fetched (x2 applied) + 7.573 GB written
 PMC_TRAFFIC_FUSED_512 = 52.371e9        # k_fused3d, general form: 41.056 GB fetched (x2 applied) + 11.315 GB written (38.2 + 10.5 array passes)
 PMC_TRAFFIC_VISC_512 = 39.940e9         # k_fused3d, viscous-limit form: 28.609 GB fetched (x2 applied) + 11.331 GB written (26.6 + 10.6 array passes)
 PMC_SOURCE = {"stress": "profiles/r03_pmc_bench_traffic.txt", "fused": "profiles/r03_pmc_bench_traffic.txt", "visc": "profiles/r03_pmc_bench_traffic.txt"}
@@ -740,15 +742,20 @@ def run_rank(args) -> int:
         if fused:
             out["roofline"] = fused_roofline(pr, n, sk_ms, sf_ms, kcells, it_gbs)
         elif split:
+            visc = pr["form"] == "viscous_limit"
+            a_st = A_STRESS_VISC if visc else A_STRESS
+            tr_st = (PMC_TRAFFIC_STRESS_VISC_512 if visc else PMC_TRAFFIC_STRESS_512) if n == 512 else None
             out["roofline"] = {"bound": "hbm",
-                               "kernel": "stress sweep = k_stress3d_zb + 3 boundary-plane launches (21 array reads + 7 writes = 224 B/cell)",
-                               "achieved": A_STRESS * cells / (sa_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": A_STRESS * cells / (sa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "traffic": PMC_TRAFFIC_STRESS_512 if n == 512 else None, "traffic_unit": "bytes per launch (PMC, offline)",
+                               "kernel": ("stress sweep = k_stress3d_zb<...,VISC=1> + the boundary-plane launch, viscous limit dt = Inf (11 array reads + 7 writes = 144 B/cell; tau_o, P0, K, G, Q not loaded)"
+                                          if visc else "stress sweep = k_stress3d_zb + the boundary-plane launch (21 array reads + 7 writes = 224 B/cell)"),
+                               "form": pr["form"], "bytes_per_cell": a_st,
+                               "achieved": a_st * cells / (sa_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": a_st * cells / (sa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "traffic": tr_st, "traffic_unit": "bytes per launch (PMC, offline)",
                                "traffic_source": PMC_SOURCE["stress"],
-                               "traffic_ratio": PMC_TRAFFIC_STRESS_512 / (A_STRESS * cells) if n == 512 else None,
-                               "needed_bytes_per_launch": A_STRESS * cells,
-                               "algorithmic_bytes_per_launch": A_STRESS * cells, "avg_launch_ms": sa_ms,
+                               "traffic_ratio": tr_st / (a_st * cells) if tr_st else None,
+                               "needed_bytes_per_launch": a_st * cells,
+                               "algorithmic_bytes_per_launch": a_st * cells, "avg_launch_ms": sa_ms,
                                "velocity_sweep": {"achieved": A_VELOCITY * cells / (sb_ms * 1e-3) / 1e9, "avg_launch_ms": sb_ms},
                                "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
         else:
