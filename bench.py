@@ -759,7 +759,7 @@ def run_rank(args) -> int:
                                "velocity_sweep": {"achieved": A_VELOCITY * cells / (sb_ms * 1e-3) / 1e9, "avg_launch_ms": sb_ms},
                                "whole_iteration": {"achieved": it_gbs, "frac": it_gbs / HBM_PEAK_GBS}}
         else:
-            out["roofline"] = {"bound": "hbm", "kernel": "whole PT iteration per GPU (360 B/cell; sweeps overlap the halo exchange)",
+            out["roofline"] = {"bound": "hbm", "kernel": f"whole PT iteration per GPU ({pr['alg']:.0f} B/cell, form: {pr['form']}; sweeps overlap the halo exchange)", "form": pr["form"], "bytes_per_cell": pr["alg"],
                                "achieved": it_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_gbs / HBM_PEAK_GBS, "traffic": None}
         if world == 1 and not self_halo and fused and pr["form"] == "viscous_limit" and not args.no_general_kernel:
             # the general form of the same kernel (any dt; what rounds 1-2 quoted) on the same allocations: option viscous_limit = 0
