@@ -415,10 +415,23 @@ jrx_status jrx_compute_maxloc(jrx_handle *h, double *B, const double *A, int64_t
 // Tile shape of the fused kernel (lane-shuffle form): TX - 2 stress columns per TX-lane tile row (one halo lane on the left, one feeder
 // lane on the right), TY - 1 stress rows, KZ planes per chunk.  Option "fused_tile": 0 = 64 x 4 (a row per wave), 1 = 32 x 8 (two rows per wave).
 struct FusedShape { int tx, ty, kz; };
-static FusedShape fused_shape(const jrx_handle *h) { return h->fused_tile == 0 ? FusedShape{64, 4, 8} : FusedShape{32, 8, 8}; }
 static void fused_tiles(const Lay3 &L, const FusedShape S, int nt[3])
 {
     nt[0] = (L.nx + S.tx - 3) / (S.tx - 2); nt[1] = (L.ny + S.ty - 2) / (S.ty - 1); nt[2] = (L.nz + S.kz - 1) / S.kz;
+}
+// Chunk depth: 8 planes where that gives the chip enough blocks; on small grids a block's chain of dependent planes is what takes the time (64^3 in 8-plane chunks is
+// 352 blocks on 256 CUs: 33 us per launch, 24 us in 4-plane chunks; 48^3: 26 -> 12 us in 2-plane chunks; from 96^3 on 8 planes are best; scripts/kbench_visc.hip,
+// profiles/r03_small_grid_chunks.txt), so the depth is halved while the launch has fewer than 512 blocks
+static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L)
+{
+    FusedShape S = h->fused_tile == 0 ? FusedShape{64, 4, 8} : FusedShape{32, 8, 8};
+    int nt[3];
+    for (int kz = 8; kz >= 2; kz /= 2) {
+        S.kz = kz;
+        fused_tiles(L, S, nt);
+        if ((long long)nt[0] * nt[1] * nt[2] >= 512) break;
+    }
+    return S;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,7 +494,7 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
         // Lanes per cell row: fused ceil(nx / (TX - 2)) TX-lane tiles with TY - 1 of TY rows updating stresses; sweeps ceil(nx / W) W-lane row tiles (W as in
         // launch_stress); per lane the fused iteration costs 0.62 of the two sweeps (120^3: 9.0 k against 7.4 k it/s at 171 against 128 lanes).  Small grids are
         // bound by the launch count, which favours the fused pipeline whatever the fill.
-        const FusedShape S = fused_shape(h);
+        const FusedShape S = fused_shape(h, L);
         int nt[3];
         fused_tiles(L, S, nt);
         const int W = p->nx > 384 ? 512 : (p->nx > 192 ? 256 : (p->nx > 96 ? 128 : 64));
@@ -538,8 +551,15 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
 }
 static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false)
 {
-    if (h->fused_tile == 0) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface);
-    return launch_fused_t<32, 8, 8>(h, s, a, bc, b, hiface);
+    const int kz = fused_shape(h, a.L).kz;
+    if (h->fused_tile == 0) {
+        if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface);
+        if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface);
+        return launch_fused_t<64, 4, 2>(h, s, a, bc, b, hiface);
+    }
+    if (kz == 8) return launch_fused_t<32, 8, 8>(h, s, a, bc, b, hiface);
+    if (kz == 4) return launch_fused_t<32, 8, 4>(h, s, a, bc, b, hiface);
+    return launch_fused_t<32, 8, 2>(h, s, a, bc, b, hiface);
 }
 
 // tev (optional): events recorded around the sweeps: [0] start, [1] after the stress sweep (if one was launched),
@@ -572,7 +592,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
         // 256 threads per tile, 8 planes per chunk (128 VGPRs -> 4 blocks/CU)
         int nt[3];
-        const FusedShape S = fused_shape(h);
+        const FusedShape S = fused_shape(h, a.L);
         fused_tiles(a.L, S, nt);
         const bool comm = jrx_comm_active(h);
         // periodic_boundary! faces (periodic.jl:56-98) are this block's own neighbour: their planes of V are filled by flow_bcs! after the fused
