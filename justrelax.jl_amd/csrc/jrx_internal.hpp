@@ -38,7 +38,7 @@ struct jrx_handle {
     int kernel_variant = 0;              // 0 auto (fused PT pipeline where it pays), 1 per-node v1 kernels, 2 z-marching sweeps only, 3 fused wherever legal
     bool fused_split = false;            // no neighbours: high-face tiles + boundary stress layers on the halo stream, interior tiles concurrently
                                          // (measured slower, profiles/r02_ab_fused_split.txt: off)
-    int fused_tile = 0;                  // fused kernel tile: 0 = 64 x 4 threads (a row per wave), 1 = 32 x 8 (two rows per wave)
+    int fused_tile = 2;                  // fused kernel tile: 0 = 64 x 4 threads, 1 = 32 x 8, 2 = by nx (32 x 8 for nx = 63 .. 90)
     bool fused_comm = true;              // multi-rank runs use the fused pipeline (0: split sweeps + hidden communication)
     bool viscous_limit = true;           // dt = Inf: the fused 3D kernel skips the operands multiplied by 1/(G dt) = 1/(K dt) = 1/dt = 0
     bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)

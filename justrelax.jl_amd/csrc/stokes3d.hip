@@ -424,7 +424,12 @@ static void fused_tiles(const Lay3 &L, const FusedShape S, int nt[3])
 // profiles/r03_small_grid_chunks.txt), so the depth is halved while the launch has fewer than 512 blocks
 static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L)
 {
-    FusedShape S = h->fused_tile == 0 ? FusedShape{64, 4, 8} : FusedShape{32, 8, 8};
+    // tile: 64 x 4 threads (a row per wave); 32 x 8 (two rows per wave, 30 stress columns per tile) costs ~20 % more per lane but quantises nx in steps of 30:
+    // it is the better shape where three 32-lane tiles replace two 64-lane ones, nx = 63 .. 90 (64^3: 25.4 k -> 30.4 k it/s, 80^3: 15.9 k -> 22.1 k, 90^3: 14.6 k -> 17.8 k;
+    // from nx = 91 on -- four 32-lane tiles -- and on every larger grid 64 x 4 is faster again: 96^3 14.3 k against 13.1 k, 130^3 6.9 k against 6.4 k, 192^3 2.6 k against 2.2 k).
+    // tuning switch "fused_tile": 2 = this rule (default), 0 / 1 force a shape
+    const bool narrow = h->fused_tile == 1 || (h->fused_tile == 2 && L.nx > 62 && L.nx <= 90);
+    FusedShape S = narrow ? FusedShape{32, 8, 8} : FusedShape{64, 4, 8};
     int nt[3];
     for (int kz = 8; kz >= 2; kz /= 2) {
         S.kz = kz;
@@ -551,8 +556,9 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
 }
 static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false)
 {
-    const int kz = fused_shape(h, a.L).kz;
-    if (h->fused_tile == 0) {
+    const FusedShape S = fused_shape(h, a.L);
+    const int kz = S.kz;
+    if (S.tx == 64) {
         if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface);
         if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface);
         return launch_fused_t<64, 4, 2>(h, s, a, bc, b, hiface);

@@ -16,6 +16,8 @@ h = _lib.default_handle(0)
 import os
 visc = int(os.environ.get("VISC", "1"))
 h.set_option("viscous_limit", visc)
+if "TILE" in os.environ:
+    h.set_option("fused_tile", int(os.environ["TILE"]))
 for n in [int(a) for a in sys.argv[1:]] or [64, 96, 128, 160, 192, 224, 256, 320, 384]:
     steps = max(60, min(2000, int(3e10 / n ** 3)))
     row = {"n": n, "viscous_limit": visc, "steps": steps}
