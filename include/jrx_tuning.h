@@ -14,6 +14,7 @@
  *   "vep3_nt" (0), "vep3_prekz" (8)   3D VEP: non-temporal stores of the edge pass; planes per block of the z-marching pre kernel (4, 8, 16, 32)
  *   "vep3_hide_comm" (2)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 = the first two only,
  *                                 update_halo!(V) behind the whole velocity sweep; 0 = everything on the compute stream, in order (A/B)
+ *   "vep_store_all" (0)           VEP loops (2D and 3D): 1 = every iteration stores ∇V, RP, ε_pl, ε_vol_pl, τII, η_vep (default: only iterations whose results can be observed)
  *   "thermal_cfg", "thermal_xg"   fused 3D heat-diffusion tile shape / XCD band
  *   "halo_self_rccl" (0)          test hook: a rank that is its own periodic neighbour routes its planes through ncclSend/ncclRecv
  *   "comm_timeout_ms" (120000)    in-process transport (jrx_comm_init_local): how long a rank waits on the host for a neighbour

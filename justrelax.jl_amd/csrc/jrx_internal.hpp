@@ -40,6 +40,7 @@ struct jrx_handle {
                                          // (measured slower, profiles/r02_ab_fused_split.txt: off)
     int fused_tile = 2;                  // fused kernel tile: 0 = 64 x 4 threads, 1 = 32 x 8, 2 = by nx (32 x 8 for nx = 63 .. 90)
     bool fused_comm = true;              // multi-rank runs use the fused pipeline (0: split sweeps + hidden communication)
+    bool vep_store_all = false;          // VEP loops: every iteration stores the output-only arrays (A/B of the skipped stores)
     bool viscous_limit = true;           // dt = Inf: the fused 3D kernel skips the operands multiplied by 1/(G dt) = 1/(K dt) = 1/dt = 0
     bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)

@@ -660,6 +660,8 @@ struct VepArgs {
     bool tg;              // args.T is the ghosted thermal.T (nx+2, ny+2): densities read it at the cell's own [i, j], unshifted (BuoyancyForces.jl:52)
     bool vfields;         // some phase's creep law reads T, P or the invariant (visc_kind != 0)
     bool vtau;            // the viscosity is taken from the stress (update_viscosity_τII!, the in-loop form) rather than from the strain rate (compute_viscosity!)
+    bool obs = true;      // the outputs nothing inside the PT loop reads -- ∇V, RP, ε_pl (3), ε_vol_pl, τII, η_vep -- are stored; the solve loop clears it on iterations whose
+                          // results cannot be observed (not a norm check, not the last one): the next iteration overwrites them anyway
 };
 
 __device__ __forceinline__ double sinv2(double xx, double yy, double xy) { return sqrt(0.5 * (xx * xx + yy * yy) + xy * xy); }
@@ -735,11 +737,11 @@ __global__ __launch_bounds__(256) void k_vep_pre(const VepArgs a, double *__rest
         const double dxi = (-VX(i, j + 1) + VX(i + 1, j + 1)) * spc(a.sp.vx, i, a._dx);
         const double dyi = (-VY(i + 1, j) + VY(i + 1, j + 1)) * spc(a.sp.vy, j, a._dy);
         const double divV = dxi + dyi;
-        a.f.divV[c] = divV;
+        if (a.obs) a.f.divV[c] = divV;
         const double _Kdt = 1.0 / (a.Kc[c] * a.dt), _Gdt = 1.0 / (a.Gc[c] * a.dt), _dt = 1.0 / a.dt;
         const double P = theta[c], P0 = a.f.P0[c];
         const double rhs = -divV + (a.f.Q[c] * _dt);
-        a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
+        if (a.obs) a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
         double et;
         if (ML) {
             et = -INFINITY;
@@ -835,10 +837,10 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
         a.lamv[v] = l;
         const double epl = l * dQdt[2];
         a.f.txy[v] = txy + (SI ? fma(-2.0 * etav * a.dt * epl, dtr, dxy) : fma(-2.0 * etav * epl, dtr, dxy));
-        a.f.eplxy[v] = epl;
+        if (a.obs) a.f.eplxy[v] = epl;
     } else {
         a.f.txy[v] = txy + dxy;
-        a.f.eplxy[v] = 0.0;
+        if (a.obs) a.f.eplxy[v] = 0.0;
     }
 }
 
@@ -919,17 +921,19 @@ __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, con
             d[q] = SI ? fma(-2.0 * e * a.dt * epl[q], dtr, d[q]) : fma(-2.0 * e * epl[q], dtr, d[q]);
             tij[q] = d[q] + tij[q];
         }
-        a.f.evol_pl[c] = -l * dQdP;
+        if (a.obs) a.f.evol_pl[c] = -l * dQdP;
         txx_o[c] = tij[0]; tyy_o[c] = tij[1]; a.f.txy_c[c] = tij[2];
-        a.f.eplxx[c] = epl[0]; a.f.eplyy[c] = epl[1];
+        if (a.obs) { a.f.eplxx[c] = epl[0]; a.f.eplyy[c] = epl[1]; }
         tII = sinv2(tij[0], tij[1], tij[2]);
     } else {
-        a.f.evol_pl[c] = 0.0;
+        if (a.obs) a.f.evol_pl[c] = 0.0;
         txx_o[c] = d[0] + tij[0]; tyy_o[c] = d[1] + tij[1]; a.f.txy_c[c] = d[2] + tij[2];
-        a.f.eplxx[c] = 0.0; a.f.eplyy[c] = 0.0;
+        if (a.obs) { a.f.eplxx[c] = 0.0; a.f.eplyy[c] = 0.0; }
     }
-    a.f.tII[c] = tII;
-    a.f.eta_vep[c] = tII * 0.5 * (1.0 / sinv2(eij[0], eij[1], eij[2]));
+    if (a.obs) {
+        a.f.tII[c] = tII;
+        a.f.eta_vep[c] = tII * 0.5 * (1.0 / sinv2(eij[0], eij[1], eij[2]));
+    }
     a.f.P[c] = Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP);
 }
 __global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
@@ -1243,6 +1247,7 @@ VepArgs make_vep(const jrx_vep2d_fields *f, const jrx_rheology *rh, const jrx_ve
     a.si = p->strain_increment != 0;
     a.tg = p->T_ghosted != 0;
     a.vfields = mat_viscosity_reads_fields(rh); a.vtau = true;
+    a.obs = true;
     a.sp = Sp2{p->inv_spacing[0], p->inv_spacing[1], p->inv_spacing[2], p->inv_spacing[3], p->inv_spacing[4], p->inv_spacing[5]};
     return a;
 }
@@ -1452,6 +1457,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                     bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
                     if (ok) {
                         VepArgs aa = a;
+                        aa.obs = h->vep_store_all;          // a run of unobserved iterations
                         Args2 bb = b;
                         for (int q = 0; q < GIT; q++) {
                             if (upd_rho) hipLaunchKernelGGL((k_vep_pre<true, true>), dim3(gv), dim3(256), 0, s, aa, theta);
@@ -1477,6 +1483,10 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                     continue;
                 }
             }
+        }
+        {   // can the loop stop after the iteration launched now (a check, the last allowed one, or already converged)?  Only then are its output-only arrays stored
+            const int64_t it1 = iter + 1;
+            a.obs = ((it1 % p->nout == 0) && it1 > 1) || it1 > p->iterMax || (p->iterMin < it1 && ((err / err_it1) < p->eps_rel || err < p->eps_abs)) || h->vep_store_all;
         }
         if (comm) {
             hipLaunchKernelGGL(k_maxloc, dim3(gc, 1), dim3(256), 0, s, etatau, (const double *)f->eta, nx, ny, 1);

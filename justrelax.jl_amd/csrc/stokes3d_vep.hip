@@ -30,6 +30,8 @@ struct Vep3Args {
     bool soft;            // some phase has a softening law: the yield function then reads EII_pl
     bool nt;              // outputs with non-temporal stores
     bool tg;              // args.T is the ghosted thermal.T (ni .+ 2): densities read it at the cell's own [i, j, k], unshifted
+    bool obs;             // the outputs nothing inside the PT loop reads -- ∇V, RP, ε_pl (6), ε_vol_pl, η_vep, τII (update_viscosity_τII! takes its invariant from the stress arrays) -- are stored; the solve loop clears it on iterations whose
+                          // results cannot be observed (not a norm check, not the last one): the next iteration overwrites them anyway (11 of 29 written passes)
 };
 
 // node (i, j, k) of an (n1, n2, n3) box: xy flattened over blockIdx.x (no nearly empty blocks when n1 = nx + 1), k = blockIdx.y
@@ -179,11 +181,11 @@ __global__ __launch_bounds__(256) void k_vep3_pre(const Vep3Args a)
             const double dyi = (-VY(i + 1, j, k + 1) + VY(i + 1, j + 1, k + 1)) * _dy;
             const double dzi = (-VZ(i + 1, j + 1, k) + VZ(i + 1, j + 1, k + 1)) * _dz;
             const double divV = dxi + dyi + dzi;
-            VST(a, a.f.divV[c], divV);
+            if (a.obs) VST(a, a.f.divV[c], divV);
             const double _Kdt = 1.0 / (a.Kc[c] * a.dt), _Gdt = 1.0 / (a.Gc[c] * a.dt), _dt = 1.0 / a.dt;
             const double P = a.theta[c], P0 = a.f.P0[c];
             const double rhs = -divV + (a.f.Q[c] * _dt);
-            VST(a, a.f.RP[c], fma(-(P - P0), _Kdt, rhs));
+            if (a.obs) VST(a, a.f.RP[c], fma(-(P - P0), _Kdt, rhs));
             double et;
             if (ML) {
                 m_next = plane_max(k + 1);
@@ -322,10 +324,10 @@ __device__ __forceinline__ void vep3_edge_plastic(const Vep3Args &a, i64 v, cons
         a.lamv[T][v] = l;
         const double epl = l * dQdt[own];
         VST(a, a.tnew[T][v], tij_own + fma(-(2.0 * etav * epl), dtr, d_own));
-        VST(a, eplsh[T][v], epl);
+        if (a.obs) VST(a, eplsh[T][v], epl);
     } else {
         VST(a, a.tnew[T][v], tij_own + d_own);
-        VST(a, eplsh[T][v], 0.0);
+        if (a.obs) VST(a, eplsh[T][v], 0.0);
     }
 }
 template <int T, bool SOFT>
@@ -768,19 +770,19 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
         double epl[6];
 #pragma unroll
         for (int s = 0; s < 6; s++) { epl[s] = l * dQdt[s]; d[s] = d[s] - 2.0 * e * epl[s] * dtr; tij[s] = d[s] + tij[s]; }
-        VST(a, a.f.evol_pl[c], -l * dQdP);
+        if (a.obs) VST(a, a.f.evol_pl[c], -l * dQdP);
 #pragma unroll
         for (int s = 0; s < 6; s++) VST(a, tc[s][c], tij[s]);
-        VST(a, a.f.eplxx[c], epl[0]); VST(a, a.f.eplyy[c], epl[1]); VST(a, a.f.eplzz[c], epl[2]);
+        if (a.obs) { VST(a, a.f.eplxx[c], epl[0]); VST(a, a.f.eplyy[c], epl[1]); VST(a, a.f.eplzz[c], epl[2]); }
         tII = sinv3(tij);
     } else {
-        VST(a, a.f.evol_pl[c], 0.0);
+        if (a.obs) VST(a, a.f.evol_pl[c], 0.0);
 #pragma unroll
         for (int s = 0; s < 6; s++) VST(a, tc[s][c], d[s] + tij[s]);
-        VST(a, a.f.eplxx[c], 0.0); VST(a, a.f.eplyy[c], 0.0); VST(a, a.f.eplzz[c], 0.0);
+        if (a.obs) { VST(a, a.f.eplxx[c], 0.0); VST(a, a.f.eplyy[c], 0.0); VST(a, a.f.eplzz[c], 0.0); }
     }
-    VST(a, a.f.tII[c], tII);
-    VST(a, a.f.eta_vep[c], tII * 0.5 * (1.0 / sinv3(eij)));
+    if (a.obs) VST(a, a.f.tII[c], tII);
+    if (a.obs) VST(a, a.f.eta_vep[c], tII * 0.5 * (1.0 / sinv3(eij)));
     VST(a, a.f.P[c], Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP));
 }
 
@@ -884,6 +886,7 @@ Vep3Args make_vep3(const jrx_vep3d_fields *f, const jrx_rheology *rh, const jrx_
     a.soft = mat_has_softening(rh);
     a.tg = p->T_ghosted != 0;
     a.nt = false;
+    a.obs = true;
     return a;
 }
 
@@ -1146,6 +1149,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
     // one iteration without neighbours, enqueued on s; A / G: the kernel arguments and the view the velocity sweep takes (their edge-stress pointers swap)
     auto enqueue_iteration = [&](Vep3Args &A, jrx_stokes3d_fields &G, bool diag_) -> jrx_status {
+        A.obs = diag_ || h->vep_store_all;
         if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, A);
         else if (h->vep3_prekz == 16) hipLaunchKernelGGL((k_vep3_pre<true, false, 16>), dim3(gpre.x, (unsigned)((nz + 1 + 15) / 16)), dim3(256), 0, s, A);
         else if (h->vep3_prekz == 32) hipLaunchKernelGGL((k_vep3_pre<true, false, 32>), dim3(gpre.x, (unsigned)((nz + 1 + 31) / 32)), dim3(256), 0, s, A);
@@ -1203,6 +1207,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         const int64_t it1 = iter + 1;
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);      // R and U are only observable after such an iteration
+        a.obs = diag || h->vep_store_all;
         if (comm) {
             // Hidden communication.  The reference hides update_halo!(V) behind compute_V! (@hide_communication, Stokes3D.jl:582-597);
             // its other two exchanges of the iteration block.  Here all three run on the halo stream beside kernels that do not depend on them:

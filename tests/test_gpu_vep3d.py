@@ -134,8 +134,9 @@ def test_vep3d_solve_matches_oracle_over_iterations(jr, oracle):
     assert np.allclose(r.err_evo1, r_ref["err_evo1"], rtol=1e-9) and np.allclose(r.norm_Rz, r_ref["norm_Rz"], rtol=1e-9)
     assert (ref["eplxx"] != 0).any()
     from justrelax_jl_amd.checks import interior_mask3d
-    for k in ("P", "P0", "Vx", "Vy", "Vz", "Ux", "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "tII", "eta", "eta_vep", "exx", "exz", "eplzz",
-              "eplxy", "EII_pl", "EVol_pl", "Rx", "Rz", "RP", "toxx", "toxz", "toxy_c", "omega_yz", "omega_xz", "omega_xy", "exz_c", "eplyz_c"):
+    # (∇V, RP, ε_pl, ε_vol_pl, η_vep are stored by observed iterations only -- the last one is: they must still be the reference's)
+    for k in ("P", "P0", "Vx", "Vy", "Vz", "Ux", "txx", "tyy", "tzz", "tyz", "txz", "txy", "tyz_c", "tII", "eta", "eta_vep", "exx", "exz", "eplxx", "eplyy", "eplzz",
+              "eplxy", "eplxz", "eplyz", "evol_pl", "divV", "EII_pl", "EVol_pl", "Rx", "Rz", "RP", "toxx", "toxz", "toxy_c", "omega_yz", "omega_xz", "omega_xy", "exz_c", "eplyz_c"):
         m = interior_mask3d(k, ref[k].shape)
         scale = max(np.abs(ref[k]).max(), 1e-300)
         assert np.abs(out[k] - ref[k])[m].max() <= 1e-9 * scale, k
