@@ -111,6 +111,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=512, help="local cells per dimension per GPU")
+    ap.add_argument("--slab-gb", type=float, default=0.0,
+                    help="experiment: reserve one device allocation of this many GB first and hand it back to torch's caching allocator, so that the arrays of the run are carved "
+                         "out of ONE hipMalloc instead of one per array (does the physical placement the process is handed explain the run-to-run spread? profiles/r03_bench512_boxes.txt)")
     ap.add_argument("--cpu-n", type=int, nargs="*", default=[128, 256], help="oracle sizes of the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU budget per oracle size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -641,6 +644,9 @@ def run_rank(args) -> int:
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
+    if args.slab_gb > 0:
+        _slab = torch.empty(int(args.slab_gb * 2 ** 30), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        del _slab            # stays in the caching allocator; the later allocations split it
     dev = torch.device("cuda", local_rank)
 
     n = args.n
