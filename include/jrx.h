@@ -84,9 +84,9 @@ const char *jrx_build_id(void);
  *   + 10.8 GB at 512^3; 2D fused loop; fused heat diffusion) -- the un-fused kernels then run; same results, less memory.
  * "loop_graphs" (0/1, default 1): runs of unobserved iterations of the launch-bound loops (the 2D loops; the 3D loops on small grids) replay as
  *   captured hipGraphs; same results, shorter gaps between launches.
- * "viscous_limit" (0/1, default 1): with dt = Inf (the reference's purely viscous runs: SolVi3D, Burstedde, TaylorGreen) the fused 3D kernel
- *   does not load the operands that 1/(G dt) = 1/(K dt) = 1/dt = 0 multiply (old stresses, P0, K, G, Q); same results for finite inputs;
- *   0 = always the general kernel.
+ * "viscous_limit" (0/1, default 1): with dt = Inf (the reference's purely viscous runs: SolVi3D, Burstedde, TaylorGreen) the 3D visco-elastic
+ *   stress kernels (fused iteration, z-marching sweep, boundary layers) do not load the operands that 1/(G dt) = 1/(K dt) = 1/dt = 0 multiply
+ *   (old stresses, P0, K, G, Q); same results for finite values in those arrays; 0 = always the general kernels.
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
  *   kernels since jrx_create, "stat_graph_replays" = hipGraphLaunch calls -- so that a caller (and the tests) can prove which path ran. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
