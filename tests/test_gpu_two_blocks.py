@@ -155,6 +155,37 @@ def test_two_blocks_equal_the_undecomposed_run_bit_for_bit(jr, dims, n, pipeline
 
 
 @pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "split_sweeps"])
+@pytest.mark.parametrize("dims,n", [((2, 1, 1), (70, 13, 12)), ((1, 1, 2), (130, 14, 40))])
+def test_two_blocks_in_the_viscous_limit_equal_the_undecomposed_general_kernels(jr, dims, n, pipeline):
+    """dt = Inf: every rank runs the viscous-limit forms (fused kernel, z-marching sweep, fix-up layers next to received planes), which do not load τ_o, P0, K, G, Q
+    -- all non-zero here; the undecomposed run uses the per-node kernels, which load and apply everything"""
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    from justrelax_jl_amd.checks import interior_mask3d
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        S = _global_setup(jr, tb.ng, True, 23, 8, seed=11)
+        S.dt = np.inf
+        h0 = _lib.default_handle()
+        _set(h0, kernel_variant=1, viscous_limit=0)
+        try:
+            stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+            rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw)
+            glob = download_stokes(stokes)
+        finally:
+            _set(h0, kernel_variant=0, viscous_limit=1)
+        res, outs = _solve_blocks(jr, tb, S, pipeline, kw)
+        assert all(_get(h, "viscous_limit") == 1 for h in tb.handles)
+    assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    for r, out in enumerate(outs):
+        co = B.coords_of(tb.carts[r])
+        for k in STATE + ("Rx", "Ry", "Rz", "RP", "exx", "exy", "divV"):
+            want = B.local_block(glob[k], n, tb.ng, co)
+            m = interior_mask3d(k, want.shape)
+            assert np.isfinite(want[m]).all() and np.array_equal(out[k][m], want[m]), (pipeline, dims, r, k, float(np.abs(out[k] - want)[m].max()))
+
+
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "split_sweeps"])
 @pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (1, 1, 2)])
 def test_two_blocks_with_an_inclusion_match_the_oracle_block_by_block(jr, oracle, dims, pipeline):
     """SolVi-style non-uniform η (with its ητ halo): device blocks == oracle blocks + numpy plane copies"""
