@@ -23,6 +23,7 @@ struct Vep3Args {
     jrx_vep3d_fields f;
     jrx_rheology rh;
     const double *etatau, *Kc, *Gc;
+    const double *eta_lin = nullptr;   // linear laws: the phase average of η (constant over a solve), precomputed by k_vep3_phase_avg; nullptr: computed per call
     double *theta, *lam;
     double *lamv[3], *tnew[3];
     double _dx, _dy, _dz, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
@@ -232,6 +233,18 @@ __device__ __forceinline__ double vep3_visc_fields(const Vep3Args &a, const i64 
     const double T = !a.f.T ? 0.0 : (a.tg ? a.f.T[(i + 1) + (i64)(nx + 2) * ((j + 1) + (i64)(ny + 2) * (k + 1))] : a.f.T[c]);
     return mat_phase_viscosity(a.rh, a.f.phase_c + (i64)a.rh.nphase * c, AII, T, a.f.P[c], tau);
 }
+// compute_viscosity of the linear laws: a pure cell takes its phase's η, a mixed one the harmonic phase average (Viscosity.jl:282-300 with constant η per phase)
+__device__ __forceinline__ double vep3_eta_linear(const Vep3Args &a, const i64 c)
+{
+    const int np = a.rh.nphase;
+    const double *r = a.f.phase_c + np * c;
+    for (int q = 0; q < np; q++)
+        if (r[q] > 0.999) return a.rh.eta[q];
+    double s = 0.0;
+    for (int q = 0; q < np; q++)
+        if (r[q] != 0.0) s += (1.0 / a.rh.eta[q]) * r[q];
+    return 1.0 / s;
+}
 template <bool FIELDS, bool TAU>
 __global__ __launch_bounds__(256) void k_vep3_visc(const Vep3Args a, double nu)
 {
@@ -242,27 +255,17 @@ __global__ __launch_bounds__(256) void k_vep3_visc(const Vep3Args a, double nu)
         a.f.eta[c] = fmin(fmax(e, a.cut_lo), a.cut_hi);
         return;
     }
-    const int np = a.rh.nphase;
-    const double *r = a.f.phase_c + np * c;
-    double e = 0.0;
-    bool pure = false;
-    for (int q = 0; q < np; q++)
-        if (r[q] > 0.999) { e = a.rh.eta[q]; pure = true; break; }
-    if (!pure) {
-        double s = 0.0;
-        for (int q = 0; q < np; q++)
-            if (r[q] != 0.0) s += (1.0 / a.rh.eta[q]) * r[q];
-        e = 1.0 / s;
-    }
+    double e = a.eta_lin ? a.eta_lin[c] : vep3_eta_linear(a, c);
     e = e * nu + a.f.eta[c] * (1.0 - nu);
     a.f.eta[c] = fmin(fmax(e, a.cut_lo), a.cut_hi);
 }
 
 // rho: also compute_ρg!(ρg, phase_ratios, rheology, args) (Stokes3D.jl:505)
-__global__ __launch_bounds__(256) void k_vep3_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const Vep3Args a, const bool rho)
+__global__ __launch_bounds__(256) void k_vep3_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const Vep3Args a, const bool rho, double *__restrict__ eta_lin = nullptr)
 {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (i64)a.nx * a.ny * a.nz) return;
+    if (eta_lin) eta_lin[c] = vep3_eta_linear(a, c);
     const double *r = a.f.phase_c + (i64)a.rh.nphase * c;
     Kc[c] = ratio_avg3(a.rh.Kb, r, a.rh.nphase);
     Gc[c] = ratio_avg3(a.rh.G, r, a.rh.nphase);
@@ -1101,13 +1104,14 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     const size_t n = (size_t)nx * ny * nz;
     const EdgeN ne = edge_counts(p);
     hipStream_t s = h->stream;
-    // library scratch: ητ, θ, λ, K, G, a second ητ (centres), λv and the new edge stresses (edges), carved out of one allocation
-    JRX_TRY(jrx_ensure_etatau(h, 6 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
+    // library scratch: ητ, θ, λ, K, G, a second ητ, the phase-averaged η of the linear laws (centres), λv and the new edge stresses (edges), carved out of one allocation
+    JRX_TRY(jrx_ensure_etatau(h, 7 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
     double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n, *etatau_next = Gc + n;
     Vep3Args a = make_vep3(f, rh, p);
     a.nt = h->vep3_nt;
     a.theta = theta; a.etatau = etatau; a.Kc = Kc; a.Gc = Gc; a.lam = lam;
-    a.lamv[0] = etatau_next + n; a.lamv[1] = a.lamv[0] + ne.yz; a.lamv[2] = a.lamv[1] + ne.xz;
+    double *eta_lin = etatau_next + n;
+    a.lamv[0] = eta_lin + n; a.lamv[1] = a.lamv[0] + ne.yz; a.lamv[2] = a.lamv[1] + ne.xz;
     a.tnew[0] = a.lamv[2] + ne.xy; a.tnew[1] = a.tnew[0] + ne.yz; a.tnew[2] = a.tnew[1] + ne.xz;
     jrx_stokes3d_fields g = view3d(f);
     jrx_stokes3d_params q;
@@ -1125,7 +1129,9 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     JRX_HIP(h, hipMemcpyAsync(theta, f->P, n * sizeof(double), hipMemcpyDeviceToDevice, s));        // θ = deepcopy(stokes.P)
     JRX_HIP(h, hipMemsetAsync(lam, 0, n * sizeof(double), s));
     JRX_HIP(h, hipMemsetAsync(a.lamv[0], 0, (size_t)(ne.yz + ne.xz + ne.xy) * sizeof(double), s));
-    hipLaunchKernelGGL(k_vep3_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a, rh->has_density != 0);
+    const bool lin = !mat_viscosity_reads_fields(rh);       // η of the laws depends on the phase ratios only: average it once per solve (update_viscosity_τII! then reads one array instead of the ratios)
+    hipLaunchKernelGGL(k_vep3_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a, rh->has_density != 0, lin ? eta_lin : (double *)nullptr);
+    if (lin) a.eta_lin = eta_lin;
     launch_vep3_visc(s, gc, a, 1.0, false);                                                          // compute_viscosity! :507 (εII form)
     JRX_LAUNCH_CHECK(h);
     const bool upd_rho = rh->has_density && !mat_density_is_constant(rh);       // update_ρg!: a no-op for constant densities
