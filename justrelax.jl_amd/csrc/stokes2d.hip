@@ -650,6 +650,7 @@ struct VepArgs {
     jrx_vep2d_fields f;
     jrx_rheology rh;
     const double *theta, *etatau, *Kc, *Gc;
+    const double *eta_lin_c, *eta_lin_v;                // linear laws: phase-averaged η at centres / vertices, computed once per solve (nullptr: from the ratios per call)
     double *lam, *lamv;
     double *txx_out = nullptr, *tyy_out = nullptr;      // where the centre half writes τxx, τyy (nullptr: in place)
     Sp2 sp;                                             // non-uniform grid: inverse spacing arrays (all NULL: _dx, _dy)
@@ -1093,12 +1094,12 @@ __device__ __forceinline__ void vep_visc_at(const VepArgs &a, const i64 t)
         return;
     }
     if (t < (i64)nx * ny) {
-        double e = phase_viscosity(a.rh, a.f.phase_c + np * t);
+        double e = a.eta_lin_c ? a.eta_lin_c[t] : phase_viscosity(a.rh, a.f.phase_c + np * t);
         e = e * a.nu + a.f.eta[t] * (1.0 - a.nu);
         a.f.eta[t] = fmin(fmax(e, a.cut_lo), a.cut_hi);
     }
     if (a.f.eta_v && t < (i64)(nx + 1) * (ny + 1)) {
-        double e = phase_viscosity(a.rh, a.f.phase_v + np * t);
+        double e = a.eta_lin_v ? a.eta_lin_v[t] : phase_viscosity(a.rh, a.f.phase_v + np * t);
         e = e * a.nu + a.f.eta_v[t] * (1.0 - a.nu);
         a.f.eta_v[t] = fmin(fmax(e, a.cut_lo), a.cut_hi);
     }
@@ -1115,10 +1116,13 @@ __global__ __launch_bounds__(256) void k_vep_visc_velocity(const VepArgs a, cons
 }
 
 // rho: also compute_ρg!(ρg, phase_ratios, rheology, args) (Stokes2D.jl:646)
-__global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const VepArgs a, const bool rho)
+__global__ __launch_bounds__(256) void k_phase_avg(double *__restrict__ Kc, double *__restrict__ Gc, const VepArgs a, const bool rho, double *__restrict__ elc = nullptr,
+                                                   double *__restrict__ elv = nullptr)
 {
     const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (elv && t < (i64)(a.nx + 1) * (a.ny + 1)) elv[t] = phase_viscosity(a.rh, a.f.phase_v + a.rh.nphase * t);
     if (t >= (i64)a.nx * a.ny) return;
+    if (elc) elc[t] = phase_viscosity(a.rh, a.f.phase_c + a.rh.nphase * t);
     Kc[t] = ratio_avg(a.rh.Kb, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
     Gc[t] = ratio_avg(a.rh.G, a.f.phase_c + a.rh.nphase * t, a.rh.nphase);
     if (rho) a.f.fy[t] = mat_density_ratio(a.rh, a.f.phase_c + a.rh.nphase * t, !a.f.T ? 0.0 : (a.tg ? a.f.T[(t % a.nx) + (i64)(a.nx + 2) * (t / a.nx)] : a.f.T[t]), a.f.P[t]) * a.rh.gravity;
@@ -1402,11 +1406,12 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     const size_t n = (size_t)nx * ny, nv = (size_t)(nx + 1) * (ny + 1);
     hipStream_t s = h->stream;
     // library scratch: ητ, θ, λ, K, G (centre), λv (vertex) and the second set of τxx, τyy, carved out of one allocation
-    JRX_TRY(jrx_ensure_etatau(h, 7 * n + nv));
+    JRX_TRY(jrx_ensure_etatau(h, 8 * n + 2 * nv));
     double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n, *lamv = Gc + n;
     VepArgs a = make_vep(f, rh, p);
     a.theta = theta; a.etatau = etatau; a.Kc = Kc; a.Gc = Gc; a.lam = lam; a.lamv = lamv;
     a.txx_out = lamv + nv; a.tyy_out = a.txx_out + n;
+    double *eta_lin_c = a.tyy_out + n, *eta_lin_v = eta_lin_c + n;
     jrx_stokes2d_fields g = view2d(f);
     jrx_stokes2d_params q;
     memset(&q, 0, sizeof(q));
@@ -1423,8 +1428,12 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
     JRX_HIP(h, hipMemsetAsync(f->eplxx, 0, n * sizeof(double), s));                                 // @tensor_center(ε_pl) .= 0
     JRX_HIP(h, hipMemsetAsync(f->eplyy, 0, n * sizeof(double), s));
     JRX_HIP(h, hipMemsetAsync(f->eplxy_c, 0, n * sizeof(double), s));
-    hipLaunchKernelGGL(k_phase_avg, dim3(gc), dim3(256), 0, s, Kc, Gc, a, rh->has_density != 0);
+    // linear laws: η of a cell / vertex depends on its phase ratios only -- averaged once per solve, compute_viscosity! then reads one array instead of the ratios
+    const bool lin = !a.vfields;
+    hipLaunchKernelGGL(k_phase_avg, dim3(lin && f->eta_v ? gv : gc), dim3(256), 0, s, Kc, Gc, a, rh->has_density != 0, lin ? eta_lin_c : (double *)nullptr,
+                       lin && f->eta_v ? eta_lin_v : (double *)nullptr);
     JRX_LAUNCH_CHECK(h);
+    if (lin) { a.eta_lin_c = eta_lin_c; a.eta_lin_v = f->eta_v ? eta_lin_v : nullptr; }
     const bool upd_rho = rh->has_density && !mat_density_is_constant(rh);       // update_ρg!: a no-op for constant densities
     const bool ubc = p->displacement_bcs != 0;
     if (ubc) {    // displacement2velocity!(stokes, dt, flow_bcs) (Stokes2D.jl:647): V = U * inv(dt)
