@@ -66,7 +66,7 @@ struct Timer {
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 512, reps = argc > 2 ? atoi(argv[2]) : 20;
-    const int nx = n, ny = n, nz = n;
+    const int nx = argc > 3 ? atoi(argv[3]) : n, ny = n, nz = n;      // optional third argument: nx alone (ragged last tile experiments)
     const double cells = (double)nx * ny * nz;
     jrx_stokes3d_fields f;
     memset(&f, 0, sizeof(f));
@@ -108,7 +108,7 @@ int main(int argc, char **argv)
     memset(&bc, 0, sizeof(bc));
     bc.fsL = bc.fsF = bc.fsK0 = 1;
     Timer T;
-    printf("kbench_visc n=%d reps=%d   (200 B/cell needed, 280 B/cell = the two sweeps without the operands of the zero factors)\n", n, reps);
+    printf("kbench_visc nx=%d n=%d reps=%d   (200 B/cell needed, 280 B/cell = the two sweeps without the operands of the zero factors)\n", nx, n, reps);
     {   // streaming ceilings for the stream mixes of the two forms (the written arrays are the ten outputs: they are rewritten by every variant below)
         std::vector<const double *> rd;
         for (auto &e : ents) if (e.n >= nc) rd.push_back(*e.p);
@@ -151,6 +151,7 @@ int main(int argc, char **argv)
         have_ref = true;                                                                                                             \
     }
     V(64, 4, 8, 4, false, 1, 3, 1)      // shipped (reference for the comparisons)
+    if (argc > 3) { V(64, 4, 8, 4, false, 1, 3, 1) V(32, 8, 8, 4, false, 1, 3, 1) printf("done\n"); return 0; }
     if (n < 200) {
         V(64, 4, 4, 4, false, 1, 3, 1)
         V(64, 4, 2, 4, false, 1, 3, 1)
