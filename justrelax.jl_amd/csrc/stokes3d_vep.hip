@@ -902,12 +902,17 @@ EdgeN edge_counts(const jrx_vep3d_params *p)
 // the three edge passes, the commit of the new edge stresses, then the centre pass
 // commit = false: the caller adopts a.tnew as the current edge-stress arrays (pointer swap) instead of copying them back
 // which: 0 = both passes, 1 = the edge pass alone, 2 = the centre pass alone (the multi-rank driver exchanges the new edge stresses in between)
-jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p, bool commit = true, int which = 0)
+// loop: called by the solve loop -- the form of the edge pass then follows the grid size (the kernel-level entry points keep the form the switch names)
+jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, const jrx_vep3d_params *p, bool commit = true, int which = 0, bool loop = false)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
+    // Small grids (the reference's own 3D tests run at 16^3 .. 32^3): the z-marching edge kernel has a few hundred blocks, each a chain of 16 dependent planes, and the
+    // one-node-per-thread kernel is the faster form -- 16^3 14.1 k -> 19.4 k it/s, 32^3 13.0 k -> 18.1 k, 48^3 10.5 k -> 12.4 k; equal at 56^3, z-marching from there on
+    // (scripts/bench_vep3d_sizes.py, profiles/r03_vep3d_small_grids.txt)
+    const int edges = (loop && h->vep3_edges == 4 && (double)(nx + 1) * (ny + 1) * (nz + 1) <= 125000.0) ? 0 : h->vep3_edges;
     if (which != 2) {
     const bool p4 = h->vep3_map, xs = h->vep3_xcd;     // options "vep3_map", "vep3_xcd" (XCD slab order: +1-2 % measured)
-    if (h->vep3_edges >= 1 && a.rh.nphase <= 4) {
+    if (edges >= 1 && a.rh.nphase <= 4) {
         // option "vep3_edges": 0 one node per thread (k_vep3_edges; also the form more than 4 phases use), 1 (default) the z-marching
         // kernel with one family per block and the three blocks of a tile on one XCD, 2 the same kernel as one launch per family (A/B: the L2 sharing)
         const int cfg = h->vep3_cfg ? h->vep3_cfg : 162;           // option "vep3_cfg" = KZ * 10 + min blocks per CU (tuning)
@@ -915,7 +920,8 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
         // lane segments of 62 node columns; a last segment that would be less than 40 % full (256^3: 257 = 4 x 62 + 9) is not launched -- its node columns
         // go to the one-node-per-thread kernel in a thin launch of their own (the two launches write disjoint nodes and read old values only)
         const int nfull = (nx + 1) / 62, rem = (nx + 1) - 62 * nfull;
-        const bool peel = nfull >= 1 && rem > 0 && rem <= 24 && h->vep3_peel;
+        // (a thin last segment is only worth a launch of its own behind at least two full ones: 72^3 6.9 k -> 7.3 k, 80^3 5.5 k -> 6.4 k it/s without it, 128^3 2.03 k with against 1.98 k without)
+        const bool peel = nfull >= 2 && rem > 0 && rem <= 24 && h->vep3_peel;
         const int nseg = peel ? nfull : (nx + 1 + 61) / 62, ilim = peel ? 62 * nfull : nx + 1;
         const int ntxy = nseg * ((ny + 1 + 3) / 4), nzc = (nz + 1 + kz - 1) / kz, nt = ntxy * nzc;
         bool ok = false;
@@ -934,7 +940,7 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
             else hipLaunchKernelGGL((k_vep3_edges<true, false, false>), gp, dim3(256), 0, ps, a, ilim, rem);
         }
         struct Join { jrx_handle *h; hipStream_t s, ps; bool on; ~Join() { if (on) { (void)hipEventRecord(h->ev[5], ps); (void)hipStreamWaitEvent(s, h->ev[5], 0); } } } join{h, s, ps, fork};
-        if (a.soft && h->vep3_edges == 5) {       // softening laws: the yield function also reads the edge average of EII_pl (a twelfth shared centre array);
+        if (a.soft && edges == 5) {       // softening laws: the yield function also reads the edge average of EII_pl (a twelfth shared centre array);
                                                   // measured at 256^3: 195.7 it/s through LDS vs 214.9 with one family per block (254 VGPRs either way): only on request
             const int ntxy_l = nseg * (ny + 1), nt_l = ntxy_l * nzc;
             const dim3 gl((unsigned)(((nt_l + 7) / 8) * 8));
@@ -946,15 +952,15 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
 #define EZS(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<16, NP_, 2, true>), gf, dim3(256), 0, s, a, nseg, ntxy, nt, ilim); ok = true; }
             EZS(1) EZS(2) EZS(3) EZS(4)
 #undef EZS
-        } else if (h->vep3_edges == 3 || h->vep3_edges == 4) {
+        } else if (edges == 3 || edges == 4) {
             const int ntxy_l = nseg * (ny + 1), nt_l = ntxy_l * nzc;
             const dim3 gl((unsigned)(((nt_l + 7) / 8) * 8));
-#define EZL(NP_) if (kz == 16 && np_ == NP_) { if (h->vep3_edges == 4) hipLaunchKernelGGL((k_vep3_edges_zl<16, NP_, false, true>), gl, dim3(192), 0, s, a, nseg, ntxy_l, nt_l, ilim); \
+#define EZL(NP_) if (kz == 16 && np_ == NP_) { if (edges == 4) hipLaunchKernelGGL((k_vep3_edges_zl<16, NP_, false, true>), gl, dim3(192), 0, s, a, nseg, ntxy_l, nt_l, ilim); \
                 else hipLaunchKernelGGL((k_vep3_edges_zl<16, NP_>), gl, dim3(192), 0, s, a, nseg, ntxy_l, nt_l, ilim); ok = true; }
             EZL(1) EZL(2) EZL(3) EZL(4)
 #undef EZL
 
-        } else if (h->vep3_edges == 2) {
+        } else if (edges == 2) {
             const dim3 g((unsigned)ntxy, (unsigned)nzc);
 #define EZ(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 1>), g, dim3(256), 0, s, a, nseg, ilim); \
                 hipLaunchKernelGGL((k_vep3_edges_z<16, NP_, 2>), g, dim3(256), 0, s, a, nseg, ilim); \
@@ -1163,7 +1169,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         else hipLaunchKernelGGL((k_vep3_pre<true, false, PRE_KZ>), gpre, dim3(256), 0, s, A);        // compute_maxloc! folded in
         launch_vep3_visc(s, gc, A, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
         JRX_LAUNCH_CHECK(h);
-        JRX_TRY(launch_vep3_stress(h, s, A, p, false));
+        JRX_TRY(launch_vep3_stress(h, s, A, p, false, 0, true));
         // the new edge stresses become the current ones: swap the pointers instead of copying three arrays back
         { double *t0_ = A.f.tyz; A.f.tyz = A.tnew[0]; A.tnew[0] = t0_; }
         { double *t1_ = A.f.txz; A.f.txz = A.tnew[1]; A.tnew[1] = t1_; }
@@ -1247,7 +1253,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                 const int64_t ext[1][3] = {{nx, ny, nz}};
                 JRX_TRY(jrx_halo_exchange(h, hs, 1, arrs, ext, nn));     // update_halo!(ητ) of iteration it1 + 1
             }
-            JRX_TRY(launch_vep3_stress(h, s, a, p, false, 1));           // edge pass
+            JRX_TRY(launch_vep3_stress(h, s, a, p, false, 1, true));     // edge pass
             { double *t0_ = a.f.tyz; a.f.tyz = a.tnew[0]; a.tnew[0] = t0_; }
             { double *t1_ = a.f.txz; a.f.txz = a.tnew[1]; a.tnew[1] = t1_; }
             { double *t2_ = a.f.txy; a.f.txy = a.tnew[2]; a.tnew[2] = t2_; }
@@ -1260,7 +1266,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                 JRX_TRY(jrx_halo_exchange(h, hs, 3, arrs, ext, nn));
             }
             JRX_HIP(h, hipEventRecord(h->ev[4], hs));
-            JRX_TRY(launch_vep3_stress(h, s, a, p, false, 2));           // centre pass, beside the exchange
+            JRX_TRY(launch_vep3_stress(h, s, a, p, false, 2, true));     // centre pass, beside the exchange
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[4], 0));
             int bc_kind = 3;
             if (!ubc && !diag && bcs_ordered && p->periodic == 0) bc_kind = 1;
