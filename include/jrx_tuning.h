@@ -11,7 +11,7 @@
  *   "vep3_edges" (4)              3D VEP edge pass: 4 = z-marching kernel, the three family waves of a row share the centre and shear operands through LDS;
  *                                 3 = centre operands only; 1 = no LDS, one family per block; 2 = one launch per family; 0 = one node per thread
  *   "vep3_cfg", "vep3_peel", "vep3_peel_fork", "vep3_map", "vep3_xcd"     z-marching edge kernel: chunk depth / occupancy, peeling of a thin last segment, thread map, XCD slabs
- *   "vep3_nt" (0), "vep3_prekz" (8)   3D VEP: non-temporal stores of the edge pass; planes per block of the z-marching pre kernel (4, 8, 16, 32)
+ *   "vep3_nt" (0), "vep3_prekz" (0)   3D VEP: non-temporal stores of the edge pass; planes per thread of the z-marching pre kernel (0 = chosen by the grid size; 1, 2, 4, 8, 16, 32)
  *   "vep3_hide_comm" (2)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 = the first two only,
  *                                 update_halo!(V) behind the whole velocity sweep; 0 = everything on the compute stream, in order (A/B)
  *   "vep_store_all" (0)           VEP loops (2D and 3D): 1 = every iteration stores ∇V, RP, ε_pl, ε_vol_pl, τII, η_vep (default: only iterations whose results can be observed)

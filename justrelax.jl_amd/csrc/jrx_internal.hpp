@@ -50,7 +50,7 @@ struct jrx_handle {
     bool vep3_peel = true;                   // z-marching edge kernel: a nearly empty last lane segment goes to the node kernel (A/B)
     bool vep3_peel_fork = false;             // ... that thin launch on the halo stream beside the main edge kernel (measured 1 % slower at 256^3: off; A/B)
     bool vep3_nt = false;                    // 3D VEP kernels: non-temporal stores of the outputs (measured neutral at 256^3: off; A/B)
-    int vep3_prekz = 8;                      // planes per thread of k_vep3_pre (A/B)
+    int vep3_prekz = 0;                      // planes per thread of k_vep3_pre: 0 = by the number of blocks (default), 1 .. 32 force a depth (A/B)
     int vep3_cfg = 0;                        // z-marching edge kernel: KZ * 10 + min blocks per CU, 0 = default
     int vep3_edges = 4;                      // 3D VEP edge pass: 4 z-marching kernel, the three family waves of a row share the centre and shear operands through LDS;
                                              // 3 centre operands only, 1 no LDS (one family per block), 2 one launch per family, 0 one node per thread (A/B)

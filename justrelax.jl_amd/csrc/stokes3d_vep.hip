@@ -1160,12 +1160,19 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     JRX_HIP(h, hipEventRecord(t0, s));
     auto keep_going = [&](int64_t it) { return it < 2 || (((err / err_it1) > p->eps_rel && err > p->eps_abs) && it <= p->iterMax); };
     // one iteration without neighbours, enqueued on s; A / G: the kernel arguments and the view the velocity sweep takes (their edge-stress pointers swap)
+    // planes per thread of k_vep3_pre: 8 where that gives the chip enough blocks, halved while the launch has fewer than 2048 (16^3: 19.3 k -> 26.0 k it/s with one plane per
+    // thread, 32^3 18.1 k -> 23.3 k, 64^3 8.2 k -> 9.0 k, 128^3 +1 % with four; 256^3: eight planes stay the best, 318 against 304 it/s with one; profiles/r03_vep3d_small_grids.txt)
+    int prekz = h->vep3_prekz;
+    if (prekz == 0)
+        for (prekz = 8; prekz > 1 && (i64)gpre.x * ((nz + prekz) / prekz) < 2048; prekz /= 2) {}
     auto enqueue_iteration = [&](Vep3Args &A, jrx_stokes3d_fields &G, bool diag_) -> jrx_status {
         A.obs = diag_ || h->vep_store_all;
         if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, A);
-        else if (h->vep3_prekz == 16) hipLaunchKernelGGL((k_vep3_pre<true, false, 16>), dim3(gpre.x, (unsigned)((nz + 1 + 15) / 16)), dim3(256), 0, s, A);
-        else if (h->vep3_prekz == 32) hipLaunchKernelGGL((k_vep3_pre<true, false, 32>), dim3(gpre.x, (unsigned)((nz + 1 + 31) / 32)), dim3(256), 0, s, A);
-        else if (h->vep3_prekz == 4) hipLaunchKernelGGL((k_vep3_pre<true, false, 4>), dim3(gpre.x, (unsigned)((nz + 1 + 3) / 4)), dim3(256), 0, s, A);
+        else if (prekz == 16) hipLaunchKernelGGL((k_vep3_pre<true, false, 16>), dim3(gpre.x, (unsigned)((nz + 1 + 15) / 16)), dim3(256), 0, s, A);
+        else if (prekz == 32) hipLaunchKernelGGL((k_vep3_pre<true, false, 32>), dim3(gpre.x, (unsigned)((nz + 1 + 31) / 32)), dim3(256), 0, s, A);
+        else if (prekz == 4) hipLaunchKernelGGL((k_vep3_pre<true, false, 4>), dim3(gpre.x, (unsigned)((nz + 1 + 3) / 4)), dim3(256), 0, s, A);
+        else if (prekz == 2) hipLaunchKernelGGL((k_vep3_pre<true, false, 2>), dim3(gpre.x, (unsigned)((nz + 1 + 1) / 2)), dim3(256), 0, s, A);
+        else if (prekz == 1) hipLaunchKernelGGL((k_vep3_pre<true, false, 1>), dim3(gpre.x, (unsigned)(nz + 1)), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((k_vep3_pre<true, false, PRE_KZ>), gpre, dim3(256), 0, s, A);        // compute_maxloc! folded in
         launch_vep3_visc(s, gc, A, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
         JRX_LAUNCH_CHECK(h);
