@@ -71,7 +71,7 @@ const char *jrx_build_id(void);
  *       state arrays (the handle then owns a second set of the 10 state arrays); with a communicator the exchange
  *       of V follows and the stress nodes next to a received plane are redone; otherwise, and on iterations whose
  *       results are observed, the two z-marching sweeps;
- *   1 = simple one-thread-per-node kernels;  2 = z-marching sweeps only (two launches per iteration, no ping-pong set);
+ *   1 = simple one-thread-per-node kernels;  2 = the two sweeps only (z-marching; per-node on blocks up to ~88^3; no ping-pong set);
  *   3 = fused pipeline wherever it is legal (ignores that rule).  All variants produce bit-identical results.
  * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
  * "fused_overlap" (0/1/2, default 2): how the multi-rank fused pipeline places update_halo!(V) (same results in every mode):

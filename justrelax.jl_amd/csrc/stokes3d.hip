@@ -120,7 +120,10 @@ jrx_status launch_stress(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, i
 {
     const int nx = a.L.nx, ny = a.L.ny, nz = a.L.nz;
     const bool full = i0 == 0 && j0 == 0 && k0 == 0 && i1 == nx + 1 && j1 == ny + 1 && k1 == nz + 1;
-    if (h->kernel_variant == 1 || !full || !fits_u32(a.L) || nx < 48) return launch_stress_v1(h, s, a, diag, i0, i1, j0, j1, k0, k1);
+    // small blocks: the z-marching kernel would have a few hundred blocks, each a chain of dependent planes; one node per thread is faster up to ~88^3 (two sweeps per iteration:
+    // 48^3 28.9 k against 19.5 k it/s, 64^3 20.5 k / 17.5 k, 80^3 14.4 k / 13.1 k; 96^3 10.0 k / 11.2 k, 128^3 5.4 k / 8.0 k)
+    const bool small = (double)nx * ny * nz <= 681472.0;
+    if (h->kernel_variant == 1 || !full || !fits_u32(a.L) || nx < 48 || small) return launch_stress_v1(h, s, a, diag, i0, i1, j0, j1, k0, k1);
     a.i0 = a.j0 = a.k0 = 0; a.i1 = nx; a.j1 = ny; a.k1 = nz;
     if (nx > 384) JRX_TRY((launch_stress_zb<512, 1, 4>(h, s, a, diag)));
     else if (nx > 192) JRX_TRY((launch_stress_zb<256, 1, 8>(h, s, a, diag)));
@@ -135,7 +138,8 @@ jrx_status launch_velocity(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag,
 {
     if (i1 <= i0 || j1 <= j0 || k1 <= k0) return JRX_OK;
     const int w = i1 - i0;
-    if (h->kernel_variant == 1 || !fits_u32(a.L) || w < 48 || (k1 - k0) < 4) return launch_velocity_v1(h, s, a, diag, i0, i1, j0, j1, k0, k1);
+    const bool small = (double)w * (j1 - j0) * (k1 - k0) <= 681472.0;          // see launch_stress
+    if (h->kernel_variant == 1 || !fits_u32(a.L) || w < 48 || (k1 - k0) < 4 || small) return launch_velocity_v1(h, s, a, diag, i0, i1, j0, j1, k0, k1);
     a.i0 = i0; a.i1 = i1; a.j0 = j0; a.j1 = j1; a.k0 = k0; a.k1 = k1;
     if (w > 384) return launch_velocity_zb<512, 1, 4>(h, s, a, diag);
     if (w > 192) return launch_velocity_zb<256, 1, 8>(h, s, a, diag);
