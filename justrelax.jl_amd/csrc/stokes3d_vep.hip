@@ -915,14 +915,19 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
     if (edges >= 1 && a.rh.nphase <= 4) {
         // option "vep3_edges": 0 one node per thread (k_vep3_edges; also the form more than 4 phases use), 1 (default) the z-marching
         // kernel with one family per block and the three blocks of a tile on one XCD, 2 the same kernel as one launch per family (A/B: the L2 sharing)
-        const int cfg = h->vep3_cfg ? h->vep3_cfg : 162;           // option "vep3_cfg" = KZ * 10 + min blocks per CU (tuning)
-        const int kz = cfg / 10, mb = cfg % 10, np_ = a.rh.nphase;
+        const int cfg = h->vep3_cfg ? h->vep3_cfg : 162;           // option "vep3_cfg" = KZ * 10 + min blocks per CU (tuning); 0: KZ by the grid size (below)
+        int kz = cfg / 10;
+        const int mb = cfg % 10, np_ = a.rh.nphase;
         // lane segments of 62 node columns; a last segment that would be less than 40 % full (256^3: 257 = 4 x 62 + 9) is not launched -- its node columns
         // go to the one-node-per-thread kernel in a thin launch of their own (the two launches write disjoint nodes and read old values only)
         const int nfull = (nx + 1) / 62, rem = (nx + 1) - 62 * nfull;
         // (a thin last segment is only worth a launch of its own behind at least two full ones: 72^3 6.9 k -> 7.3 k, 80^3 5.5 k -> 6.4 k it/s without it, 128^3 2.03 k with against 1.98 k without)
         const bool peel = nfull >= 2 && rem > 0 && rem <= 24 && h->vep3_peel;
         const int nseg = peel ? nfull : (nx + 1 + 61) / 62, ilim = peel ? 62 * nfull : nx + 1;
+        // chunk depth of the LDS-sharing form: 16 planes where that gives the chip enough blocks, halved (down to 4) while the launch has fewer than 3000 -- 56^3 12.6 k -> 15.6 k it/s,
+        // 64^3 9.6 k -> 10.7 k, 96^3 4.12 k -> 4.33 k, 128^3 +1.4 %; from 160^3 on 16 planes are the best (profiles/r03_vep3d_small_grids.txt)
+        if (!h->vep3_cfg && edges == 4 && !a.soft)
+            while (kz > 4 && (i64)nseg * (ny + 1) * ((nz + kz) / kz) < 3000) kz /= 2;
         const int ntxy = nseg * ((ny + 1 + 3) / 4), nzc = (nz + 1 + kz - 1) / kz, nt = ntxy * nzc;
         bool ok = false;
         // the peeled columns are independent of the main launch (disjoint nodes written, only old values read); tuning switch "vep3_peel_fork" runs the thin,
@@ -959,6 +964,9 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
                 else hipLaunchKernelGGL((k_vep3_edges_zl<16, NP_>), gl, dim3(192), 0, s, a, nseg, ntxy_l, nt_l, ilim); ok = true; }
             EZL(1) EZL(2) EZL(3) EZL(4)
 #undef EZL
+#define EZLK(KZ_, NP_) if (!ok && kz == KZ_ && np_ == NP_ && edges == 4) { hipLaunchKernelGGL((k_vep3_edges_zl<KZ_, NP_, false, true>), gl, dim3(192), 0, s, a, nseg, ntxy_l, nt_l, ilim); ok = true; }
+            EZLK(8, 1) EZLK(8, 2) EZLK(8, 3) EZLK(8, 4) EZLK(4, 1) EZLK(4, 2) EZLK(4, 3) EZLK(4, 4)
+#undef EZLK
 
         } else if (edges == 2) {
             const dim3 g((unsigned)ntxy, (unsigned)nzc);
