@@ -518,7 +518,13 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
     }
     // tile = TX cells of R rows, KZ planes deep; option "thermal_cfg" = R*10000 + (TX/64)*100 + KZ overrides (tuning)
     const int cfg = h->thermal_cfg;
-    const int FR = cfg ? cfg / 10000 : 1, FTX = cfg ? ((cfg / 100) % 100) * 64 : (nx > 128 ? 256 : (nx > 64 ? 128 : 64)), FKZ = cfg ? cfg % 100 : 4;
+    const int FR = cfg ? cfg / 10000 : 1, FTX = cfg ? ((cfg / 100) % 100) * 64 : (nx > 128 ? 256 : (nx > 64 ? 128 : 64));
+    // planes per block: 4, halved while the launch has fewer than 4096 waves -- a block marches its planes one after the other, and a small grid in 4-plane chunks leaves most of the
+    // chip idle (64^3: 1024 single-wave blocks): 16^3 74.7 k -> 175 k it/s, 32^3 72.4 k -> 159 k, 48^3 64.3 k -> 112 k, 64^3 52.5 k -> 101 k with one plane per block; from 96^3 on
+    // 4 planes are the better depth again (35.5 k against 33.2 k) (profiles/r03_small_grids_graphs.txt)
+    int FKZ = cfg ? cfg % 100 : 4;
+    if (!cfg)
+        while (FKZ > 1 && (i64)((nx + FTX - 1) / FTX) * (FTX / 64) * ny * ((nz + FKZ - 1) / FKZ) < 4096) FKZ /= 2;
     const int FXG = h->thermal_xg;
     const int ntx = (nx + FTX - 1) / FTX, nty = (ny + FR - 1) / FR, ntz = (nz + FKZ - 1) / FKZ;
     // launch_fused: one unobserved iteration from set c into set o (the caller swaps)
@@ -534,6 +540,7 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
         // measured at 256^3 (profiles/r01_thermal3d_fused_sweep.txt): one row per thread 2289 it/s, two rows 1526, four rows 1301
         THL(256, 4, 1, 8) THL(128, 4, 1, 8) THL(64, 4, 1, 8) THL(256, 8, 1, 8) THL(256, 4, 2, 8)
         THL(256, 4, 1, 1) THL(256, 4, 1, 2) THL(256, 4, 1, 4) THL(256, 2, 1, 1) THL(256, 2, 1, 2) THL(256, 8, 1, 1) THL(128, 4, 1, 1) THL(64, 4, 1, 1)
+        THL(64, 2, 1, 8) THL(64, 1, 1, 8) THL(128, 2, 1, 8) THL(128, 1, 1, 8) THL(256, 2, 1, 8) THL(256, 1, 1, 8)
         if (!launched) return jrx_fail(h, JRX_ERR_ARG, "JRX_TH_CFG: no such configuration");
 #undef THL
         JRX_LAUNCH_CHECK(h);
