@@ -86,9 +86,13 @@ const char *jrx_build_id(void);
  *   captured hipGraphs; same results, shorter gaps between launches.
  * "viscous_limit" (0/1, default 1): with dt = Inf (the reference's purely viscous runs: SolVi3D, Burstedde, TaylorGreen) the 3D visco-elastic
  *   stress kernels (fused iteration, z-marching sweep, boundary layers) do not load the operands that 1/(G dt) = 1/(K dt) = 1/dt = 0 multiply
- *   (old stresses, P0, K, G, Q); same results for finite values in those arrays; 0 = always the general kernels.
+ *   (old stresses, P0, K, G, Q).  Every driver call first checks those ten arrays in one streaming pass (all of tau_o, P0, Q finite; K, G neither NaN
+ *   nor 0): only then do the results equal the general kernels', and only then does this form run -- otherwise the general kernels run and a NaN
+ *   there ends the solve with JRX_ERR_NAN exactly as error("NaN(s)") of Stokes3D.jl:162 would.  0 = always the general kernels.
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
- *   kernels since jrx_create, "stat_graph_replays" = hipGraphLaunch calls -- so that a caller (and the tests) can prove which path ran. */
+ *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_visc_checks" /
+ *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
+ *   (and the tests, and bench.py for the kernel it prices) can prove which path ran. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value);
 

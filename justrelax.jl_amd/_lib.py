@@ -230,12 +230,17 @@ class Handle:
     def set_option(self, key: str, value: int):
         """jrx_set_option for the keys of the public ABI, jrx_tuning_set for the tuning / test switches of include/jrx_tuning.h"""
         k = C.c_char_p(key.encode())
-        if self.lib.jrx_set_option(self._h, k, C.c_int64(int(value))) != 0:
+        st = self.lib.jrx_set_option(self._h, k, C.c_int64(int(value)))
+        if st != 0:
+            # only a key that lives in the other table is retried there; any other failure (a read-only counter, a NULL key) is reported as it is
+            if "is a tuning switch" not in self.lib.jrx_last_error(self._h).decode():
+                self.check(st)
             self.check(self.lib.jrx_tuning_set(self._h, k, C.c_int64(int(value))))
 
     def get_option(self, key: str) -> int:
         k, v = C.c_char_p(key.encode()), C.c_int64()
-        if self.lib.jrx_get_option(self._h, k, C.byref(v)) != 0:
+        st = self.lib.jrx_get_option(self._h, k, C.byref(v))
+        if st != 0:
             self.check(self.lib.jrx_tuning_get(self._h, k, C.byref(v)))
         return v.value
 

@@ -121,6 +121,7 @@ int find_opt(jrx_handle *h, const char *key, bool tuning, OptRef *out)
         {"viscous_limit", 0, &h->viscous_limit},
         {"stat_fused3d", 2, &h->stat_fused3d}, {"stat_fused2d", 2, &h->stat_fused2d}, {"stat_thermal_fused", 2, &h->stat_thermal_fused},
         {"stat_vep3_fused", 2, &h->stat_vep3_fused}, {"stat_graph_replays", 2, &h->stat_graph_replays},
+        {"stat_fused3d_visc", 2, &h->stat_fused3d_visc}, {"stat_visc_checks", 2, &h->stat_visc_checks}, {"stat_visc_fallbacks", 2, &h->stat_visc_fallbacks},
     };
     const OptRef tun[] = {
         {"fused_split", 0, &h->fused_split}, {"fused_tile", 1, &h->fused_tile}, {"fused_ylds", 0, &h->fused_ylds},

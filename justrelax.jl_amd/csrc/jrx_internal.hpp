@@ -42,6 +42,7 @@ struct jrx_handle {
     bool fused_comm = true;              // multi-rank runs use the fused pipeline (0: split sweeps + hidden communication)
     bool vep_store_all = false;          // VEP loops: every iteration stores the output-only arrays (A/B of the skipped stores)
     bool viscous_limit = true;           // dt = Inf: the fused 3D kernel skips the operands multiplied by 1/(G dt) = 1/(K dt) = 1/dt = 0
+    bool visc_ok = false;                // set per driver call by the operand check: every τ_o, P0, Q finite and K, G neither NaN nor 0, so the viscous-limit kernels give the general ones' result
     bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)
     bool halo_self_rccl = false;         // test hook: a rank that is its own periodic neighbour routes the planes through ncclSend/ncclRecv
@@ -60,6 +61,7 @@ struct jrx_handle {
     bool scratch_sets = true;            // the fused pipelines may allocate their library-owned second state set (0: never -- un-fused paths)
     // ---- read-only counters (jrx_get_option "stat_*"): launches of the fused kernels since jrx_create, so that tests and the bench can
     //      prove which kernel path ran
+    int64_t stat_fused3d_visc = 0, stat_visc_checks = 0, stat_visc_fallbacks = 0;     // launches of the viscous-limit form of k_fused3d; operand checks run / failed
     int64_t stat_fused3d = 0, stat_fused2d = 0, stat_thermal_fused = 0, stat_vep3_fused = 0, stat_graph_replays = 0;
     int comm_timeout_ms = 120000;        // in-process transport: how long a rank waits on the host for a neighbour before it reports an error
     char err[512] = {0};

@@ -87,12 +87,54 @@ bool fits_u32(const Lay3 &L)
     return m < 4294967296.0;
 }
 
+// Viscous-limit guard.  With dt = Inf the reference still multiplies τ_o, P0, Q by an exact 0 and divides by K dt, G dt (StressKernels.jl:2-5, PressureKernels.jl:186-195):
+// a NaN / Inf in τ_o, P0 or Q, or a K or G that is NaN or 0 (0 * Inf), turns the result into NaN and the driver raises error("NaN(s)") (Stokes3D.jl:162).  The
+// viscous-limit kernels never read those ten arrays, so before they are selected one streaming pass checks that every entry is harmless; if not, the general
+// kernels run (and produce the reference's NaNs).  sets h->visc_ok.
+__global__ __launch_bounds__(256) void k_visc_operands_ok(const double *__restrict__ c0, const double *__restrict__ c1, const double *__restrict__ c2, const double *__restrict__ c3,
+                                                          const double *__restrict__ c4, i64 nc, const double *__restrict__ K, const double *__restrict__ G,
+                                                          const double *__restrict__ yz, i64 nyz, const double *__restrict__ xz, i64 nxz, const double *__restrict__ xy, i64 nxy, int *bad)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    bool b = false;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < nyz || t < nxz || t < nxy; t += stride) {
+        if (t < nc) {
+            b |= !(isfinite(c0[t]) && isfinite(c1[t]) && isfinite(c2[t]) && isfinite(c3[t]) && isfinite(c4[t]));
+            const double k = K[t], g = G[t];
+            b |= (k != k) || (g != g) || k == 0.0 || g == 0.0;
+        }
+        if (t < nyz) b |= !isfinite(yz[t]);
+        if (t < nxz) b |= !isfinite(xz[t]);
+        if (t < nxy) b |= !isfinite(xy[t]);
+    }
+    if (__any(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
+jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
+{
+    h->visc_ok = false;
+    if (!h->viscous_limit || p->dt != INFINITY) return JRX_OK;
+    const i64 nx = p->nx, ny = p->ny, nz = p->nz;
+    int *d_bad = reinterpret_cast<int *>(h->d_sums + 6), *h_bad = reinterpret_cast<int *>(h->h_sums + 6);
+    hipStream_t s = h->stream;
+    JRX_HIP(h, hipMemsetAsync(d_bad, 0, sizeof(double), s));
+    hipLaunchKernelGGL(k_visc_operands_ok, dim3(4096), dim3(256), 0, s, f->P0, f->Q, f->toxx, f->toyy, f->tozz, nx * ny * nz, f->K, f->G, f->toyz, nx * (ny + 1) * (nz + 1),
+                       f->toxz, (nx + 1) * ny * (nz + 1), f->toxy, (nx + 1) * (ny + 1) * nz, d_bad);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipMemcpyAsync(h_bad, d_bad, sizeof(double), hipMemcpyDeviceToHost, s));
+    JRX_HIP(h, hipStreamSynchronize(s));
+    h->visc_ok = (*h_bad == 0);
+    h->stat_visc_checks++;
+    if (!h->visc_ok) h->stat_visc_fallbacks++;
+    return JRX_OK;
+}
+
 template <int TX, int TY, int KZ>
 jrx_status launch_stress_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag)
 {
     const TileMap tm = make_tilemap(a.L.nx, a.L.ny, a.L.nz, TX, TY, KZ);
     if (diag) hipLaunchKernelGGL((k_stress3d_zb<true, TX, TY, KZ, 4, false, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
-    else if (h->viscous_limit && a.dt == INFINITY)      // dt = Inf: τ_o, P0, K, G, Q only meet factors that are exactly 0 and are not loaded (see k_fused3d)
+    else if (h->viscous_limit && h->visc_ok && a.dt == INFINITY)      // dt = Inf: τ_o, P0, K, G, Q only meet factors that are exactly 0 and are not loaded (see k_fused3d)
         hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, 8, true, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     else hipLaunchKernelGGL((k_stress3d_zb<false, TX, TY, KZ, 4, false, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     JRX_LAUNCH_CHECK(h);
@@ -222,7 +264,7 @@ static jrx_status launch_stress_boxes(jrx_handle *h, hipStream_t s, const SweepA
     if (!B.n) return JRX_OK;
     B.start[B.n] = tot;
     const GhostRule none = {{0, 0, 0, 0, 0, 0}};
-    const bool visc = !diag && h->viscous_limit && a.dt == INFINITY;
+    const bool visc = !diag && h->viscous_limit && h->visc_ok && a.dt == INFINITY;
     if (rule && visc) hipLaunchKernelGGL((k_stress3d_boxes<false, true, true>), dim3((unsigned)tot), dim3(256), 0, s, a, B, *rule);
     else if (rule) hipLaunchKernelGGL((k_stress3d_boxes<false, true>), dim3((unsigned)tot), dim3(256), 0, s, a, B, *rule);
     else if (visc) hipLaunchKernelGGL((k_stress3d_boxes<false, false, true>), dim3((unsigned)tot), dim3(256), 0, s, a, B, none);
@@ -322,6 +364,7 @@ jrx_status jrx_stokes3d_sweep_stress(jrx_handle *h, const jrx_stokes3d_fields *f
     const bool diag = flags & JRX_OUT_DIAG;
     if (diag) JRX_TRY(check_diag(h, f));
     SweepArgs a = make_args(f, nullptr, p);
+    JRX_TRY(visc_operands_check(h, f, p));
     JRX_TRY(launch_stress(h, h->stream, a, diag, 0, (int)p->nx + 1, 0, (int)p->ny + 1, 0, (int)p->nz + 1));
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
@@ -488,6 +531,7 @@ static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
 static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p)
 {
     I.h = h; I.p = p; I.etatau = etatau;
+    JRX_TRY(visc_operands_check(h, f, p));       // may the viscous-limit kernels stand in for the general ones? (dt = Inf only)
     I.cur = *f;
     I.setU = out_of(*f);
     I.cur_is_user = true; I.stress_done = false;
@@ -538,7 +582,7 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     // viscous limit (dt = Inf): the operands that 1/(G dt) = 1/(K dt) = 1/dt = 0 multiply are not loaded; option "viscous_limit" = 0 keeps
     // the general kernel.  (Its lower register need -- 111 VGPRs -- leaves room to carry the previous velocity / η planes in registers
     // instead of the third LDS slot: LOWREG off, -1.4 %, scripts/kbench_visc.hip)
-    const bool visc = h->viscous_limit && a.dt == INFINITY && h->fused_ylds;
+    const bool visc = h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
     if (visc && hiface)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 1, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc)
@@ -556,6 +600,7 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     JRX_LAUNCH_CHECK(h);
     h->stat_fused3d++;
+    if (visc) h->stat_fused3d_visc++;
     return JRX_OK;
 }
 static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false)

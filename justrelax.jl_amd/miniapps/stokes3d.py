@@ -183,33 +183,66 @@ def random_fields3d(ni, seed=20260821, *, dt=0.25, G=1.0, K=2.0, iterMax=20, nou
                  kwargs=dict(iterMax=iterMax, nout=nout, verbose=False), extra=dict(li=li, di=di))
 
 
-def plane_strain3d(s2: Setup, nz=3) -> Setup:
-    """The 3D restatement of a 2D visco-elastic setup: every field uniform along z (nz cells of the in-plane spacing), Vz = 0, the out-of-plane
-    stresses zero, free slip on the two z faces, and the 2D run's own PT coefficients.  With ∂/∂z = 0 the 3D iteration (Stokes3D.jl:78-121) is
-    algebraically the 2D one (Stokes2D.jl:229-275) -- same ∇V, the same ε_xx = ∂Vx/∂x − ∇V/3, the same clamped shear-node averages, ητ of a
-    z-uniform η -- so a 3D run must reproduce the pinned 2D run to round-off (the kernels differ in fma placement and summation order).  This is how
-    the elastic (τ_o, 1/(G dt)) and compressible (1/(K dt)) terms of the 3D kernels get a numeric anchor: every 3D test of the reference runs with
-    dt = Inf and/or G = K = Inf, the 2D elastic build-up (miniapps/benchmarks/stokes2D/elastic_buildup/Elastic_BuildUp.jl:4,55-56,75-86,
-    test/test_stokes_elastic_buildup.jl:47-54) does not."""
-    nx, ny = s2.ni
-    ni = (nx, ny, nz)
-    dz = s2.extra["di"][0]
-    li = tuple(s2.extra["li"]) + (dz * nz,)
+def plane_strain3d(s2: Setup, nz=3, axis=2) -> Setup:
+    """The 3D restatement of a 2D visco-elastic setup: every field uniform along the 3D axis `axis` (nz cells of the in-plane spacing there), the
+    velocity along it 0, the out-of-plane stresses zero, free slip on its two faces, and the 2D run's own PT coefficients.  The 2D x and y take the two
+    remaining 3D axes in order (axis = 2: x, y -- the fields are uniform along z; axis = 1: x, z; axis = 0: y, z), and the 2D components are renamed with
+    them (axis = 1: τxy -> τxz, τyy -> τzz, Vy -> Vz, fy -> fz; axis = 0: τxx -> τyy, τyy -> τzz, τxy -> τyz, Vx -> Vy, Vy -> Vz).
+    With ∂/∂(axis) = 0 the 3D iteration (Stokes3D.jl:78-121) is algebraically the 2D one (Stokes2D.jl:229-275) -- same ∇V, the same ε_xx = ∂Vx/∂x − ∇V/3,
+    the same clamped shear-node averages, ητ of a uniform-along-axis η -- so a 3D run must reproduce the pinned 2D run to round-off (the kernels differ in fma
+    placement and summation order; the terms that vanish are exact zeros).  This is how the elastic (τ_o, 1/(G dt)) and compressible (1/(K dt)) terms of the
+    3D kernels get a numeric anchor: every 3D test of the reference runs with dt = Inf and/or G = K = Inf, the 2D elastic build-up
+    (miniapps/benchmarks/stokes2D/elastic_buildup/Elastic_BuildUp.jl:4,55-56,75-86, test/test_stokes_elastic_buildup.jl:47-54) does not.  The three
+    orientations together anchor all six stress components -- axis = 0 and 1 put the 2D shear stress on τyz / τxz and a 2D normal stress on τzz, the
+    components the z-marching kernels carry from plane to plane."""
+    if axis not in (0, 1, 2):
+        raise ValueError("axis must be 0, 1 or 2")
+    u = axis
+    a, b = [d for d in range(3) if d != u]            # the 3D axes of the 2D x and y
+    n2 = s2.ni
+    ni = [0, 0, 0]
+    ni[a], ni[b], ni[u] = n2[0], n2[1], nz
+    ni = tuple(ni)
+    du = s2.extra["di"][0]
+    li, di, org = [0.0] * 3, [0.0] * 3, [0.0] * 3
+    li[a], li[b], li[u] = s2.extra["li"][0], s2.extra["li"][1], du * nz
+    di[a], di[b], di[u] = s2.extra["di"][0], s2.extra["di"][1], du
+    org[a], org[b] = s2.grid.origin[0], s2.grid.origin[1]
     init_global_grid(*ni)
-    grid = Geometry(ni, li, origin=tuple(s2.grid.origin) + (0.0,))
+    grid = Geometry(ni, tuple(li), origin=tuple(org))
     arr = alloc_stokes(ni)
     a2 = s2.arrays
-    for k2, k3 in (("P", "P"), ("P0", "P0"), ("Q", "Q"), ("eta", "eta"), ("K", "K"), ("G", "G"), ("fx", "fx"), ("fy", "fy"), ("txx", "txx"), ("tyy", "tyy"),
-                   ("txy", "txy"), ("toxx", "toxx"), ("toyy", "toyy"), ("toxy", "toxy")):
-        arr[k3][...] = a2[k2][:, :, None]                                      # centre arrays and τxy (nx+1, ny+1, nz): uniform along z
-    arr["Vx"][...] = a2["Vx"][:, :, None]                                      # (nx+1, ny+2) -> (nx+1, ny+2, nz+2), ghost planes in z included
-    arr["Vy"][...] = a2["Vy"][:, :, None]
+    c = "xyz"
+    nrm = lambda d: c[d] + c[d]
+    shear = {(1, 2): "yz", (0, 2): "xz", (0, 1): "xy"}[(a, b)]
+    put = lambda k3, k2: arr[k3].__setitem__(Ellipsis, np.expand_dims(a2[k2], u))     # broadcast along the uniform axis (ghost planes of V included)
+    for k in ("P", "P0", "Q", "eta", "K", "G"):
+        put(k, k)
+    for pre in ("t", "to"):
+        put(pre + nrm(a), pre + "xx")
+        put(pre + nrm(b), pre + "yy")
+        put(pre + shear, pre + "xy")
+    put("V" + c[a], "Vx"); put("V" + c[b], "Vy")
+    put("f" + c[a], "fx"); put("f" + c[b], "fy")
+    # faces: 2D left / right are x-lo / x-hi, bot / top are y-lo (j = 1) / y-hi; in 3D the x faces are left / right, the y faces front / back, and the z faces
+    # carry the reference's inconsistent names (SURVEY App. C.4): free_slip `top` is k = 1 and `bot` k = end, no_slip `bot` is k = 1 and `top` k = end
+    lohi = {"fs": ({0: "left", 1: "front", 2: "top"}, {0: "right", 1: "back", 2: "bot"}),
+            "ns": ({0: "left", 1: "front", 2: "bot"}, {0: "right", 1: "back", 2: "top"})}
     b2 = s2.flow_bcs
-    on3 = lambda d: dict({f: bool(d.get(f, False)) for f in ("left", "right")}, front=bool(d.get("bot", False)), back=bool(d.get("top", False)))
-    fs = dict(on3(b2.free_slip), top=True, bot=True)                           # 2D bot/top are j = 1 / j = end: front / back in 3D; the z faces slip freely
-    ns = dict(on3(b2.no_slip), top=False, bot=False)
+    fs = {f: False for f in _F6}
+    ns = {f: False for f in _F6}
+    for tag, tgt, src in (("fs", fs, b2.free_slip), ("ns", ns, b2.no_slip)):
+        lo, hi = lohi[tag]
+        tgt[lo[a]] = bool(src.get("left", False)); tgt[hi[a]] = bool(src.get("right", False))
+        tgt[lo[b]] = bool(src.get("bot", False)); tgt[hi[b]] = bool(src.get("top", False))
+    fs[lohi["fs"][0][u]] = fs[lohi["fs"][1][u]] = True                                  # the faces of the uniform axis slip freely
     bcs = VelocityBoundaryConditions(free_slip=fs, no_slip=ns)
-    return Setup(ni=ni, arrays=arr, grid=grid, pt=s2.pt, dt=s2.dt, flow_bcs=bcs, kwargs=dict(s2.kwargs), extra=dict(s2.extra, li=li, di=tuple(s2.extra["di"]) + (dz,)))
+    names = {"P": "P", "P0": "P0", "Q": "Q", "eta": "eta", "K": "K", "G": "G", "divV": "divV", "RP": "RP",
+             "Vx": "V" + c[a], "Vy": "V" + c[b], "Rx": "R" + c[a], "Ry": "R" + c[b], "fx": "f" + c[a], "fy": "f" + c[b]}
+    for pre in ("t", "to", "e"):
+        names[pre + "xx"], names[pre + "yy"], names[pre + "xy"] = pre + nrm(a), pre + nrm(b), pre + shear
+    return Setup(ni=ni, arrays=arr, grid=grid, pt=s2.pt, dt=s2.dt, flow_bcs=bcs, kwargs=dict(s2.kwargs),
+                 extra=dict(s2.extra, li=tuple(li), di=tuple(di), axis=u, names=names, out_of_plane=dict(V="V" + c[u], tn=nrm(u), shear=[v for v in ("yz", "xz", "xy") if v != shear])))
 
 
 def burstedde3d(n=16, *, β=10.0, iterMax=100_000, nout=1000) -> Setup:

@@ -300,6 +300,54 @@ def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
             assert (k[0] == "U" or np.isfinite(outs[0][k][m]).all()) and np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)      # U = V dt = ±Inf, NaN where V = 0
 
 
+@pytest.mark.parametrize("poison", ["toxx=nan", "toyz=inf", "P0=inf", "Q=nan", "K=0", "G=nan", "none"])
+def test_viscous_limit_falls_back_when_an_unloaded_operand_is_not_harmless(env, poison):
+    """VERDICT r3 P3.  With dt = Inf the reference still multiplies τ_o, P0, Q by 0 and divides by K dt, G dt: a NaN / Inf in one of them (or K, G = 0: 0 * Inf)
+    makes the residuals NaN and the driver raises error("NaN(s)") (Stokes3D.jl:162).  The viscous-limit kernels never read those arrays, so the library checks
+    them once per driver call and runs the general kernels when an entry is not harmless: same status, same fields as with option viscous_limit = 0, and the
+    oracle agrees that the run is NaN.  `none`: the check passes and the viscous form runs."""
+    import ctypes as C
+    jr, orc = env["jr"], env["orc"]
+    from justrelax_jl_amd import _lib, checks
+    s = jr.miniapps.random_fields3d((130, 20, 17), bcs="free_slip", dt=np.inf, iterMax=23, nout=7)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    if poison != "none":
+        name, val = poison.split("=")
+        s.arrays[name][7, 5, 3] = {"nan": np.nan, "inf": np.inf, "0": 0.0}[val]
+    h = _lib.default_handle()
+    res = []
+    try:
+        for visc in (1, 0):
+            h.set_option("kernel_variant", 3)
+            h.set_option("viscous_limit", visc)
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            c0 = [h.get_option(k) for k in ("stat_fused3d_visc", "stat_visc_checks", "stat_visc_fallbacks", "stat_fused3d")]
+            try:
+                r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+                status = ("ok", r.iter)
+            except _lib.JrxError as e:
+                status = ("error", str(e))
+            c1 = [h.get_option(k) for k in ("stat_fused3d_visc", "stat_visc_checks", "stat_visc_fallbacks", "stat_fused3d")]
+            res.append((status, env["down"](stokes), [b - a for a, b in zip(c0, c1)]))
+    finally:
+        h.set_option("kernel_variant", 0)
+        h.set_option("viscous_limit", 1)
+    (st1, out1, d1), (st0, out0, d0) = res
+    assert d0[:3] == [0, 0, 0] and d0[3] > 0                     # option off: no check, general form of the fused kernel
+    assert d1[1] == 1 and d1[3] > 0
+    if poison == "none":
+        assert st1[0] == st0[0] == "ok" and d1[0] == d1[3] and d1[2] == 0            # every fused launch was the viscous form
+    else:
+        assert d1[0] == 0 and d1[2] == 1                                                # the check failed: not one launch of the viscous form
+        assert st1[0] == st0[0] == "error" and "NaN" in st1[1] and "JRX_ERR_NAN" in st1[1], (st1, st0)
+        ref = {k: v.copy(order="F") for k, v in s.arrays.items()}
+        r_ref = orc.stokes3d_solve(ref, checks.oracle_params3d(orc, s))
+        assert np.isnan(r_ref["err_evo1"][-1])                                          # the restated reference run is NaN, too
+    for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy"):
+        m = env["checks"].interior_mask3d(k, out1[k].shape)
+        assert np.array_equal(out1[k][m], out0[k][m], equal_nan=True), k
+
+
 def test_iterate_timed_leaves_state_in_user_arrays(env):
     """bench hook: K back-to-back iterations through the fused pipeline == K iterations of the per-node kernels."""
     import ctypes as C
@@ -324,21 +372,24 @@ def test_iterate_timed_leaves_state_in_user_arrays(env):
         assert np.array_equal(outs[0][k][m], outs[1][k][m]) and np.array_equal(outs[0][k][m], outs[2][k][m]), k
 
 
-def test_3d_elastic_buildup_on_the_device(jr, oracle):
-    """VERDICT r2 P1: the τ_o / 1/(G dt) terms of the 3D kernels on the device, anchored on the reference's elastic build-up (Elastic_BuildUp.jl:4,55-56,75-86;
+@pytest.mark.parametrize("axis,steps", [(2, 40), (1, 20), (0, 20)])
+def test_3d_elastic_buildup_on_the_device(jr, oracle, axis, steps):
+    """VERDICT r2 P1 / r3 P1: the τ_o / 1/(G dt) terms of the 3D kernels on the device, anchored on the reference's elastic build-up (Elastic_BuildUp.jl:4,55-56,75-86;
     test_stokes_elastic_buildup.jl:47-54) through its plane-strain restatement (tests/test_oracle_plane_strain3d.py pins the 3D oracle on the reference's
-    5e-3 bound and on the 2D run).  First 2 kyr (40 solves of 1000 iterations), step by step against the 3D oracle, the pinned 2D oracle and the analytic curve."""
+    5e-3 bound and on the 2D run) in all three orientations: uniform along z (τxx, τyy, τxy), along y (τxx, τzz, τxz) and along x (τyy, τzz, τyz).  The first
+    solves of 1000 iterations, step by step against the 3D oracle, the pinned 2D oracle and the analytic curve."""
     import math
     from justrelax_jl_amd import checks
     from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
     orc = oracle
     s2 = jr.miniapps.elastic_buildup2d(32)
-    s3 = jr.miniapps.plane_strain3d(s2, nz=3)
+    s3 = jr.miniapps.plane_strain3d(s2, nz=3, axis=axis)
+    nm = s3.extra["names"]
     kyr, η0, εbg, Gv = (s2.extra[k] for k in ("kyr", "η0", "εbg", "G"))
     ref3 = {k: v.copy(order="F") for k, v in s3.arrays.items()}
     stokes, ρg, K, G = upload_stokes(s3, jr.AMDGPUBackend)
     t = 0.0
-    for step in range(40):
+    for step in range(steps):
         dt = 0.05 * kyr
         s2.dt = s3.dt = dt
         r = jr.solve_(stokes, s3.pt, s3.grid, s3.flow_bcs, ρg, K, G, dt, None, kwargs=s3.kwargs)
@@ -346,43 +397,57 @@ def test_3d_elastic_buildup_on_the_device(jr, oracle):
         orc.stokes2d_solve(s2.arrays, checks.oracle_params2d(orc, s2))
         assert r.iter == r3["iter"] == 1000, step
         t += dt
-        got = float(stokes.τ.yy.abs().max())
-        assert got == pytest.approx(float(np.abs(ref3["tyy"]).max()), rel=1e-9), step
+        got = float(getattr(stokes.τ, nm["tyy"][1:]).abs().max())
+        assert got == pytest.approx(float(np.abs(ref3[nm["tyy"]]).max()), rel=1e-9), step
         assert got == pytest.approx(float(np.abs(s2.arrays["tyy"]).max()), rel=1e-9), step
         sol = 2 * εbg * η0 * (1 - math.exp(-Gv * t / η0))
-        assert abs(got - sol) / sol < 1e-2
+        assert abs(got - sol) / sol < 2e-2
     out = download_stokes(stokes)
     for k in ("txx", "tyy", "txy", "toxx", "toyy", "toxy", "P", "Vx", "Vy"):
         scale = np.abs(s2.arrays[k]).max()
-        assert np.abs(out[k] - s2.arrays[k][:, :, None]).max() <= 1e-9 * max(scale, 1e-300), k
-        assert checks.max_rel_diff(out[k], ref3[k]) <= 1e-9, k
-    assert np.abs(out["toyy"]).max() > 0.15 * 2 * εbg * η0
+        assert np.abs(out[nm[k]] - np.expand_dims(s2.arrays[k], axis)).max() <= 1e-9 * max(scale, 1e-300), k
+        assert checks.max_rel_diff(out[nm[k]], ref3[nm[k]]) <= 1e-9, k
+    assert np.abs(out[nm["toyy"]]).max() > (0.15 if steps == 40 else 0.07) * 2 * εbg * η0
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_3d_compressible_iterations_on_z_uniform_fields_equal_the_2d_oracle(jr, oracle, variant):
-    """compute_P!'s 1/(K dt) term and the τ_o terms of the in-plane stresses, finite K, G, dt, random z-uniform fields: 30 device iterations of the 3D
-    path == the pinned 2D oracle on every plane (see tests/test_oracle_plane_strain3d.py)"""
+# (variant, 2D grid, cells along the uniform axis): 1 = one node per thread; 3 = the fused iteration kernel (its z-march carries the previous planes of V, η, G
+# and the k - 1 shear stresses in registers / LDS); 2 on a block large enough for the z-marching sweeps (> 681,472 cells, launch_stress)
+_PS_CASES = [(1, (70, 14), 9), (3, (70, 14), 9), (2, (96, 80), 96)]
+
+
+@pytest.mark.parametrize("axis", [2, 1, 0])
+@pytest.mark.parametrize("variant,n2,nu", _PS_CASES)
+def test_3d_compressible_iterations_on_uniform_fields_equal_the_2d_oracle(jr, oracle, variant, n2, nu, axis):
+    """compute_P!'s 1/(K dt) term and the τ_o terms of the stresses, finite K, G, dt, random fields uniform along one axis: 30 device iterations of the 3D
+    path == the pinned 2D oracle on every plane (see tests/test_oracle_plane_strain3d.py).  Uniform along z anchors τxx, τyy, τxy; along y τxx, τzz, τxz; along x
+    τyy, τzz, τyz -- the last two put a 2D stress on the components the z-marching kernels carry from plane to plane."""
     import ctypes as C
     from justrelax_jl_amd import _lib, checks
     from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
     orc = oracle
-    s2 = jr.miniapps.random_fields2d((70, 14), seed=77, iterMax=29, nout=10)
+    if axis == 0 and variant == 3:
+        n2, nu = (20, 14), 50                  # the fused kernel wants nx >= 48: the uniform axis is x here
+    s2 = jr.miniapps.random_fields2d(n2, seed=77, iterMax=29, nout=10)
     s2.pt.ϵ_rel = s2.pt.ϵ_abs = 1e-30
     s2.arrays["eta"][...] = 0.37
     orc.flow_bcs2d(s2.arrays["Vx"], s2.arrays["Vy"], s2.ni, **{k: getattr(s2.flow_bcs, k) for k in ("free_slip", "no_slip", "periodic")})
-    s3 = jr.miniapps.plane_strain3d(s2, nz=9)
+    s3 = jr.miniapps.plane_strain3d(s2, nz=nu, axis=axis)
+    nm = s3.extra["names"]
     h = _lib.default_handle()
     h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(variant))
+    fused0 = h.get_option("stat_fused3d")
     try:
         stokes, ρg, K, G = upload_stokes(s3, jr.AMDGPUBackend)
         r = jr.solve_(stokes, s3.pt, s3.grid, s3.flow_bcs, ρg, K, G, s3.dt, None, kwargs=s3.kwargs)
     finally:
         h.call("jrx_set_option", C.c_char_p(b"kernel_variant"), C.c_int64(0))
+    assert (h.get_option("stat_fused3d") > fused0) == (variant == 3)
     r2 = orc.stokes2d_solve(s2.arrays, checks.oracle_params2d(orc, s2))
     assert r.iter == r2["iter"] == 30
     out = download_stokes(stokes)
-    for k in ("P", "Vx", "Vy", "txx", "tyy", "txy", "toxx", "toxy", "exx", "eyy", "exy", "RP", "Rx", "Ry", "divV"):
+    for k in ("P", "Vx", "Vy", "txx", "tyy", "txy", "toxx", "toyy", "toxy", "exx", "eyy", "exy", "RP", "Rx", "Ry", "divV"):
         scale = max(np.abs(s2.arrays[k]).max(), 1e-300)
-        assert np.abs(out[k] - s2.arrays[k][:, :, None]).max() <= 1e-11 * scale, k
-    assert np.abs(out["tzz"]).max() > 0.0 and np.abs(out["Vz"]).max() == 0.0
+        assert np.abs(out[nm[k]] - np.expand_dims(s2.arrays[k], axis)).max() <= 1e-11 * scale, k
+    oop = s3.extra["out_of_plane"]
+    assert np.abs(out["t" + oop["tn"]]).max() > 0.0 and np.abs(out[oop["V"]]).max() == 0.0
+    assert all(np.abs(out["t" + c]).max() == 0.0 for c in oop["shear"])

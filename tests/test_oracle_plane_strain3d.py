@@ -13,20 +13,31 @@ import numpy as np
 import pytest
 
 
-def _cmp3(a3, a2, name):
-    """the k planes of a 3D array against the 2D array (ghost planes in z included)"""
+def _cmp3(s3, a2, k2):
+    """every plane (normal to the uniform axis, ghost planes included) of the 3D array that carries the 2D array `k2`, against it"""
+    a3 = s3.arrays[s3.extra["names"][k2]]
     scale = max(np.abs(a2).max(), 1e-300)
-    return float(np.abs(a3 - a2[:, :, None]).max() / scale)
+    return float(np.abs(a3 - np.expand_dims(a2, s3.extra["axis"])).max() / scale)
 
 
-def test_3d_elastic_buildup_meets_the_reference_bound_and_equals_the_2d_run(oracle, jr):
+def _out_of_plane_is_zero(s3):
+    oop = s3.extra["out_of_plane"]
+    return all(np.abs(s3.arrays[k]).max() == 0.0 for k in [oop["V"]] + ["t" + c for c in oop["shear"]])
+
+
+@pytest.mark.parametrize("axis,steps", [(2, 200), (1, 60), (0, 60)])
+def test_3d_elastic_buildup_meets_the_reference_bound_and_equals_the_2d_run(oracle, jr, axis, steps):
+    """axis = 2: the reference's whole test (200 solves, mean error <= 5e-3) on fields uniform along z -- anchors τxx, τyy, τxy, P.  axis = 1 / 0: the first 60
+    solves on fields uniform along y / x, where the 2D τyy lives on τzz and the 2D τxy on τxz / τyz -- the components whose τ_o terms had no numeric anchor
+    (VERDICT r3 P1): the same numbers as the pinned 2D run at every compared step."""
     from justrelax_jl_amd import checks
     orc = oracle
     s2 = jr.miniapps.elastic_buildup2d(32)
-    s3 = jr.miniapps.plane_strain3d(s2, nz=3)
+    s3 = jr.miniapps.plane_strain3d(s2, nz=3, axis=axis)
     kyr, η0, εbg, G = (s2.extra[k] for k in ("kyr", "η0", "εbg", "G"))
     t, errs, worst = 0.0, [], 0.0
-    for step in range(200):
+    nm = s3.extra["names"]
+    for step in range(steps):
         dt = 0.05 * kyr
         s2.dt = s3.dt = dt
         r2 = orc.stokes2d_solve(s2.arrays, checks.oracle_params2d(orc, s2))
@@ -34,20 +45,25 @@ def test_3d_elastic_buildup_meets_the_reference_bound_and_equals_the_2d_run(orac
         assert r3["iter"] == r2["iter"] == 1000, step
         t += dt
         sol = 2 * εbg * η0 * (1 - math.exp(-G * t / η0))
-        errs.append(abs(np.abs(s3.arrays["tyy"]).max() - sol) / sol)
+        errs.append(abs(np.abs(s3.arrays[nm["tyy"]]).max() - sol) / sol)
         if step % 20 == 19 or step < 3:
-            for k in ("tyy", "txx", "txy", "toyy", "P", "Vx", "Vy"):
-                worst = max(worst, _cmp3(s3.arrays[k], s2.arrays[k], k))
-    assert len(errs) == 200 and sum(errs) / len(errs) <= 5.0e-3              # test_stokes_elastic_buildup.jl:47-54
+            for k in ("tyy", "txx", "txy", "toyy", "toxx", "toxy", "P", "Vx", "Vy"):
+                worst = max(worst, _cmp3(s3, s2.arrays[k], k))
+    if steps == 200:
+        assert sum(errs) / len(errs) <= 5.0e-3                                # test_stokes_elastic_buildup.jl:47-54
+    else:
+        assert max(errs) <= 2.0e-2 and errs[-1] <= 6.0e-3                     # the first steps of the same curve (the 2D run's own errors, checked below to round-off)
     assert worst <= 1e-10, worst                                              # the pinned 2D run, to round-off
-    assert np.abs(s3.arrays["Vz"]).max() == 0.0 and np.abs(s3.arrays["txz"]).max() == 0.0 and np.abs(s3.arrays["tyz"]).max() == 0.0
-    assert np.abs(s3.arrays["toyy"]).max() > 0.5 * 2 * εbg * η0                # the elastic memory term really is in play
+    assert _out_of_plane_is_zero(s3)
+    assert np.abs(s3.arrays[nm["toyy"]]).max() > (0.5 if steps == 200 else 0.2) * 2 * εbg * η0      # the elastic memory term really is in play
 
 
+@pytest.mark.parametrize("axis", [2, 1, 0])
 @pytest.mark.parametrize("bcs", ["free_slip", "no_slip"])
-def test_3d_compressible_viscoelastic_iterations_equal_the_2d_ones_on_z_uniform_fields(oracle, jr, bcs):
+def test_3d_compressible_viscoelastic_iterations_equal_the_2d_ones_on_uniform_fields(oracle, jr, bcs, axis):
     """random V, P, τ, τ_o, Q, G, K (all finite), uniform η, finite dt: 30 PT iterations of the 3D oracle == the 2D oracle (pinned by SolCx / SolKz /
-    the elastic build-up) on every plane: pins compute_P!'s 1/(K dt) term and the τ_o terms of all four in-plane stress components in 3D"""
+    the elastic build-up) on every plane: pins compute_P!'s 1/(K dt) term and the τ_o terms of the four stress components the orientation puts in plane --
+    the three orientations together cover all six"""
     from justrelax_jl_amd import checks
     orc = oracle
     s2 = jr.miniapps.random_fields2d((19, 14), seed=77, iterMax=29, nout=10, bcs=bcs)
@@ -55,17 +71,16 @@ def test_3d_compressible_viscoelastic_iterations_equal_the_2d_ones_on_z_uniform_
     # a uniform viscosity: the 2D driver hands compute_P! ητ (Stokes2D.jl:231-233) where the 3D one hands it η (Stokes3D.jl:79-91) -- a quirk of the
     # reference that makes the two iterations differ for a variable η; with a uniform η they are the same number.  G and K stay random
     s2.arrays["eta"][...] = 0.37
-    s3 = jr.miniapps.plane_strain3d(s2, nz=4)
-    p2, p3 = checks.oracle_params2d(orc, s2), checks.oracle_params3d(orc, s3)
     orc.flow_bcs2d(s2.arrays["Vx"], s2.arrays["Vy"], s2.ni, **{k: getattr(s2.flow_bcs, k) for k in ("free_slip", "no_slip", "periodic")})
-    for k in ("Vx", "Vy"):
-        s3.arrays[k][...] = s2.arrays[k][:, :, None]
+    s3 = jr.miniapps.plane_strain3d(s2, nz=4, axis=axis)
+    p2, p3 = checks.oracle_params2d(orc, s2), checks.oracle_params3d(orc, s3)
     P_before = s2.arrays["P"].copy()
     r2 = orc.stokes2d_solve(s2.arrays, p2)
     r3 = orc.stokes3d_solve(s3.arrays, p3)
     assert r2["iter"] == r3["iter"] == 30
     assert np.isfinite(s2.arrays["K"]).all() and np.abs(s2.arrays["P"] - P_before).max() > 1e-3
-    for k in ("P", "Vx", "Vy", "txx", "tyy", "txy", "toxx", "toxy", "exx", "eyy", "exy", "RP", "Rx", "Ry", "divV"):
-        assert _cmp3(s3.arrays[k], s2.arrays[k], k) <= 1e-11, k
-    assert np.abs(s3.arrays["tzz"]).max() > 0.0          # ε_zz = −∇V/3 ≠ 0 here: the out-of-plane normal stress evolves without feeding back
-    assert np.abs(s3.arrays["Vz"]).max() == 0.0
+    for k in ("P", "Vx", "Vy", "txx", "tyy", "txy", "toxx", "toyy", "toxy", "exx", "eyy", "exy", "RP", "Rx", "Ry", "divV"):
+        assert _cmp3(s3, s2.arrays[k], k) <= 1e-11, k
+    oop = s3.extra["out_of_plane"]
+    assert np.abs(s3.arrays["t" + oop["tn"]]).max() > 0.0          # ε_uu = −∇V/3 ≠ 0 here: the out-of-plane normal stress evolves without feeding back
+    assert _out_of_plane_is_zero(s3)
