@@ -52,15 +52,31 @@ A_NEEDED_VISC = 25 * 8.0    # what the viscous-limit k_fused3d itself has to mov
 A_STRESS = 28 * 8.0      # stress sweep: 21 reads + 7 writes
 A_VELOCITY = 17 * 8.0    # velocity sweep: 14 reads + 3 writes
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# L2<->fabric bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-# correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate passes), collected offline on the same kernels at
-# n = 512 (profiles/*pmc*traffic.txt; the file names are in PMC_SOURCE)
 A_STRESS_VISC = 18 * 8.0  # ... in the viscous limit: 11 reads + 7 writes (no tau_o, P0, K, G, Q)
-PMC_TRAFFIC_STRESS_512 = 32.569e9       # k_stress3d_zb, general form: 24.990 GB fetched (x2 applied) + 7.580 GB written
-PMC_TRAFFIC_STRESS_VISC_512 = 20.339e9  # k_stress3d_zb, viscous-limit form: 12.767 GB fetched (x2 applied) + 7.573 GB written
-PMC_TRAFFIC_FUSED_512 = 52.371e9        # k_fused3d, general form: 41.056 GB fetched (x2 applied) + 11.315 GB written (38.2 + 10.5 array passes)
-PMC_TRAFFIC_VISC_512 = 39.940e9         # k_fused3d, viscous-limit form: 28.609 GB fetched (x2 applied) + 11.331 GB written (26.6 + 10.6 array passes)
-PMC_SOURCE = {"stress": "profiles/r03_pmc_bench_traffic.txt", "fused": "profiles/r03_pmc_bench_traffic.txt", "visc": "profiles/r03_pmc_bench_traffic.txt"}
+
+
+def load_pmc():
+    """L2<->fabric bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE;
+    separate passes), collected offline at n = 512 and kept in profiles/pmc_traffic.json together with the sha256 of csrc/stokes3d_kernels.hpp and the git commit they
+    were taken at (scripts/pmc_traffic.py writes the file).  A kernel source that has changed since makes the figures stale: `traffic` is then null."""
+    import hashlib
+    empty = {"k_fused3d_general": None, "k_fused3d_visc": None, "k_stress3d_zb_general": None, "k_stress3d_zb_visc": None, "source": None, "stale": True}
+    try:
+        d = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        have = hashlib.sha256((ROOT / "justrelax.jl_amd" / "csrc" / "stokes3d_kernels.hpp").read_bytes()).hexdigest()
+    except (OSError, ValueError):
+        return empty
+    if d.get("kernels_sha256") != have:
+        return dict(empty, source=f"{d.get('source')} @ {d.get('git_head')}: STALE, csrc/stokes3d_kernels.hpp has changed since")
+    return dict(d, source=f"{d.get('source')} @ {d.get('git_head')}", stale=False)
+
+
+PMC = load_pmc()
+PMC_TRAFFIC_STRESS_512 = PMC["k_stress3d_zb_general"]          # k_stress3d_zb, general form
+PMC_TRAFFIC_STRESS_VISC_512 = PMC["k_stress3d_zb_visc"]        # k_stress3d_zb, viscous-limit form
+PMC_TRAFFIC_FUSED_512 = PMC["k_fused3d_general"]               # k_fused3d, general form (38.2 + 10.5 array passes in round 3)
+PMC_TRAFFIC_VISC_512 = PMC["k_fused3d_visc"]                   # k_fused3d, viscous-limit form (26.6 + 10.6 array passes in round 3)
+PMC_SOURCE = {"stress": PMC["source"], "fused": PMC["source"], "visc": PMC["source"]}
 
 
 def pricing(h, dt):
@@ -83,7 +99,7 @@ def fused_roofline(pr, n, sk_ms, sf_ms, kcells, it_gbs=None):
     kcells = kcells or cells
     g = pr["alg"] * kcells / (sk_ms * 1e-3) / 1e9
     whole = kcells == cells
-    tr = (pr["pmc"] * kcells / cells) if n == 512 else None
+    tr = (pr["pmc"] * kcells / cells) if (n == 512 and pr["pmc"]) else None
     out = {"bound": "hbm",
            "kernel": pr["kernel"] + ("" if whole else
                      f"; this launch covers the {kcells:.0f} cells of the tiles that touch no high face ({kcells / cells:.4f} of the block), "
@@ -132,6 +148,11 @@ def parse_args(argv=None):
     ap.add_argument("--dims", default="balanced", choices=["balanced", "yz"],
                     help="process grid for N > 1: balanced = IGG's default MPI_Dims_create factorisation ((2,2,2) for 8 GPUs, SURVEY 8e); "
                          "yz = (1, a, b) with x, the contiguous direction, never split -- tuning option")
+    ap.add_argument("--leg-steps", type=int, default=60, help="N > 1: steps of every leg behind the headline (transports, other decomposition)")
+    ap.add_argument("--extras-budget", type=float, default=600.0, help="N > 1: seconds the legs behind the headline may take before rank 0 prints the line it has and every rank leaves")
+    ap.add_argument("--dry-transports", action="store_true",
+                    help="test hook: the N > 1 control flow (legs, barriers, gathers, watchdog) with sleeps instead of kernels -- no GPU is touched")
+    ap.add_argument("--ipc-helper", action="store_true", help="internal: one of the two parked rank processes of the multi_rank_path leg (see start_ipc_helpers)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="test hook: the ranks only report their launch environment (no GPU is touched, the device-count check is skipped)")
     return ap.parse_args(argv)
@@ -161,7 +182,7 @@ def free_port() -> int:
 def launch_ranks(args, argv) -> int:
     """Parent of a `python bench.py --gpus N` call: start the N ranks as child processes, relay rank 0's JSON line."""
     n = args.gpus
-    if not args.dry_launch:
+    if not (args.dry_launch or args.dry_transports):
         have = visible_gpus()
         if have < 0:
             return 2                      # the probe itself failed: its message says why
@@ -581,6 +602,10 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
                                     "serial": {"block_it_per_s": r["serial"], "overhead_pct": (r["uncoupled"] / r["serial"] - 1.0) * 100.0}}
     except Exception as e:
         out["vep3d_256_split_z"] = {"error": f"{type(e).__name__}: {e}"}
+    # the same two blocks as two PROCESSES on this device through the cross-process copy-engine transport (this process is idle meanwhile)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    out["ipc_two_processes"] = run_ipc_helpers()
     return out
 
 
@@ -601,7 +626,624 @@ def other_configs(jr, h):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ N > 1: transports and decompositions
+CHAIN_KEYS = ("k_fused3d", "slab_velocity", "flow_bcs_pre", "update_halo", "flow_bcs_post", "fixup", "step", "beyond_kernel")
+YZ_DIMS = {2: (1, 1, 2), 4: (1, 2, 2), 8: (1, 2, 4), 16: (1, 4, 4)}
+
+
+class Control:
+    """the control plane of the ranks (gloo over loopback): barriers, max-reduce, object gathers; a no-op for one rank"""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max(self, vals):
+        if self.world == 1:
+            return list(vals)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor(list(vals), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+
+def collective_leg(R, ctl, transport, steps, warm, n1_rate=None):
+    """One transport with one process per GPU, all ranks: connect, warm up, time `steps` iterations between barriers (max over ranks), then a short profiled
+    batch for the per-rank chain breakdown.  A rank that fails reports it to the others (every stage ends in a gather), so the leg ends as an error entry
+    instead of a hang."""
+    def stage(fn):
+        try:
+            r, err = fn(), None
+        except Exception as e:      # noqa: BLE001 -- reported in the JSON line
+            r, err = None, f"{type(e).__name__}: {e}"
+        errs = [e for e in ctl.gather(err) if e]
+        return r, (errs[0] if errs else None)
+
+    _, err = stage(lambda: R.connect(transport))
+    if err:
+        return {"error": f"connect: {err}"}
+    leg = {"ranks": R.comm_count(), "steps": steps}
+
+    def timed():
+        R.run(warm)
+        R.sync(); ctl.barrier()
+        t0 = time.perf_counter()
+        r = R.run(steps)
+        R.sync()
+        el = time.perf_counter() - t0
+        ctl.barrier()
+        return el, r
+    res, err = stage(timed)
+    if err:
+        leg["error"] = f"timed batch: {err}"
+        return leg
+    el = ctl.max([res[0]])[0]
+    leg.update(it_per_s=ctl.world * steps / el, ms_per_step=el / steps * 1e3, pipeline=R.pipeline())
+    if n1_rate:
+        leg["efficiency_vs_n1"] = (steps / el) / n1_rate
+    ch, err = stage(lambda: R.chain(12))
+    leg["chain_us_per_rank"] = ctl.gather(ch) if not err else {"error": err}
+    return leg
+
+
+class GpuRanks:
+    """what the legs need of one rank: the SolVi3D block of this rank on its device, a communicator of a given transport, timed batches"""
+
+    def __init__(self, args, jr, rank, world, local_rank):
+        import torch
+        from justrelax_jl_amd import _lib
+        self.args, self.jr, self.rank, self.world, self.local_rank = args, jr, rank, world, local_rank
+        self.n = args.n
+        self.dev = torch.device("cuda", local_rank)
+        self.h = _lib.default_handle(local_rank)
+        self.blk = None
+        self.transport = None
+        self.dims = None
+
+    def grid_dims(self, mode):
+        if mode in ("x", "y", "z"):
+            return tuple(self.world if c == mode else 1 for c in "xyz")
+        return YZ_DIMS.get(self.world, (1, 1, self.world)) if mode == "yz" else None
+
+    def build(self, mode):
+        """the global grid of the decomposition `mode` (balanced | yz); the communicator and the block are dropped -- the next connect() builds this rank's block of
+        SolVi3D on it (the ten smoothing passes of the viscosity exchange their halos, SolVi3D.jl:33-40, so the communicator comes first)"""
+        import justrelax_jl_amd.grid as grid
+        n = self.n
+        self.disconnect()
+        self.blk = None
+        grid.finalize_global_grid()
+        d = self.grid_dims(mode)
+        if d:
+            grid.init_global_grid(n, n, n, rank=self.rank, nprocs=self.world, dimx=d[0], dimy=d[1], dimz=d[2])
+        else:
+            grid.init_global_grid(n, n, n, rank=self.rank, nprocs=self.world)
+        self.dims = tuple(grid.global_grid().dims)
+        return self.dims
+
+    def disconnect(self):
+        if self.transport:
+            self.h.call("jrx_comm_destroy")
+            self.transport = None
+
+    def connect(self, transport):
+        from justrelax_jl_amd import halo
+        from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
+        self.disconnect()
+        self.h.set_option("comm_timeout_ms", 60000)
+        if transport == "rccl":
+            halo.init_comm(self.h)
+        elif transport == "ipc":
+            halo.init_comm_ipc(self.h)
+        else:
+            raise ValueError(transport)
+        self.transport = transport
+        n = self.n
+        if self.blk is None:
+            uh = lambda a: halo.update_halo_(a, ni=(n, n, n), handle=self.h)
+            st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, self.jr.AMDGPUBackend, update_halo=uh)
+            self.jr.flow_bcs_(st, bcs, handle=self.h)
+            ητ = self.jr.fzeros((n, n, n), self.dev)
+            self.jr.compute_maxloc_(ητ, st.viscosity.η, handle=self.h)
+            self.blk = (st, pt, geo, bcs, ρg, K, G, ητ, dt)
+        st, ητ = self.blk[0], self.blk[7]
+        halo.update_halo_(st.V.Vx, st.V.Vy, st.V.Vz, ητ, ni=(n, n, n), handle=self.h)
+
+    def comm_count(self):
+        import ctypes as C
+        cnt = C.c_int32(0)
+        self.h.call("jrx_comm_count", C.byref(cnt))
+        return cnt.value
+
+    def pipeline(self):
+        return {0: "exchange behind the kernel", 1: "shell tiles + exchange beside the interior tiles", 2: "early exchange beside the kernel"}[self.h.get_option("fused_overlap")]
+
+    def run(self, k):
+        from justrelax_jl_amd import stokes
+        return stokes.iterate_timed_(*self.blk, k, handle=self.h)
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def chain(self, k):
+        return chain_profile(self.h, lambda: self.run(k))
+
+
+def chain_profile(h, run):
+    """per-stage microseconds of a rank's fused iteration (jrx_tuning_chain_profile; hipEvents inside the library on the streams the stages run on)"""
+    import ctypes as C
+    h.set_option("chain_profile", 1)
+    try:
+        run()
+        out, ns = (C.c_double * 8)(), C.c_int64(0)
+        h.check(h.lib.jrx_tuning_chain_profile(h._h, out, C.byref(ns)))
+    finally:
+        h.set_option("chain_profile", 0)
+    d = {k: round(out[i], 1) for i, k in enumerate(CHAIN_KEYS)}
+    d["samples"] = ns.value
+    return d
+
+
+def local_peer_leg(jr, args, world, mode, steps, warm, n1_rate=None):
+    """ONE process (this one) driving `world` handles on `world` devices: jrx_comm_init_local, planes pushed by hipMemcpyPeerAsync (copy engines over xGMI),
+    one host thread per rank.  The other rank processes idle meanwhile."""
+    import torch
+    import justrelax_jl_amd.grid as grid
+    from justrelax_jl_amd import _lib, halo, stokes
+    from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
+    n = args.n
+    d = YZ_DIMS.get(world, (1, 1, world)) if mode == "yz" else None
+    cur = torch.cuda.current_device()
+    hs, blocks = [], []
+    try:
+        for r in range(world):
+            torch.cuda.set_device(r)
+            hs.append(_lib.Handle(r))
+        torch.cuda.set_device(cur)
+        grid.finalize_global_grid()
+        if d:
+            grid.init_global_grid(n, n, n, rank=0, nprocs=world, dimx=d[0], dimy=d[1], dimz=d[2])
+        else:
+            grid.init_global_grid(n, n, n, rank=0, nprocs=world)
+        dims = tuple(grid.global_grid().dims)
+        halo.init_comm_local(hs, halo.make_carts((n, n, n), dims))
+        for r in range(world):
+            torch.cuda.set_device(r)
+            grid.finalize_global_grid()
+            grid.init_global_grid(n, n, n, rank=r, nprocs=world, dimx=dims[0], dimy=dims[1], dimz=dims[2])
+            st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
+            jr.flow_bcs_(st, bcs, handle=hs[r])
+            ητ = jr.fzeros((n, n, n), st.P.device)
+            jr.compute_maxloc_(ητ, st.viscosity.η, handle=hs[r])
+            blocks.append((st, pt, geo, bcs, ρg, K, G, ητ, dt))
+
+        def on(r, fn):
+            def f():
+                torch.cuda.set_device(r)          # the current device is a property of the host thread
+                return fn()
+            return f
+        halo.run_ranks([on(r, lambda r=r: halo.update_halo_(blocks[r][0].V.Vx, blocks[r][0].V.Vy, blocks[r][0].V.Vz, blocks[r][7], ni=(n, n, n), handle=hs[r])) for r in range(world)])
+
+        def sync_all():
+            for r in range(world):
+                torch.cuda.synchronize(r)
+        batch = lambda k: halo.run_ranks([on(r, lambda r=r: stokes.iterate_timed_(*blocks[r], k, handle=hs[r])) for r in range(world)])
+        batch(warm)
+        sync_all()
+        t0 = time.perf_counter()
+        batch(steps)
+        sync_all()
+        el = time.perf_counter() - t0
+        leg = {"handles": world, "devices": list(range(world)), "steps": steps, "decomposition": list(dims), "it_per_s": world * steps / el, "ms_per_step": el / steps * 1e3,
+               "pushed_by": "hipMemcpyPeerAsync between the handles of one process, ordered by events"}
+        if n1_rate:
+            leg["efficiency_vs_n1"] = (steps / el) / n1_rate
+        for h in hs:
+            h.set_option("chain_profile", 1)
+        batch(12)
+        sync_all()
+        import ctypes as C
+        per = []
+        for h in hs:
+            out, ns = (C.c_double * 8)(), C.c_int64(0)
+            h.check(h.lib.jrx_tuning_chain_profile(h._h, out, C.byref(ns)))
+            per.append(dict({k: round(out[i], 1) for i, k in enumerate(CHAIN_KEYS)}, samples=ns.value))
+        leg["chain_us_per_rank"] = per
+        return leg
+    finally:
+        del blocks
+        for h in hs:
+            h.close()
+        torch.cuda.set_device(cur)
+        torch.cuda.empty_cache()
+        grid.finalize_global_grid()
+
+
+class Watchdog:
+    """The legs behind the headline talk to other processes; if one of them hangs, rank 0 still prints the line it has (with the leg marked) and every rank
+    leaves -- the measured headline is never lost to an extra."""
+
+    def __init__(self, seconds, rank, emit):
+        import threading
+        self.where, self.rank, self.emit = "start", rank, emit
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def fire(self):
+        sys.stderr.write(f"bench.py: rank {self.rank}: the extra legs exceeded their time budget during `{self.where}`; leaving\n")
+        if self.rank == 0:
+            self.emit(f"time budget exceeded during `{self.where}`")
+        os._exit(0)
+
+    def cancel(self):
+        self.t.cancel()
+
+
+def multi_rank_extras(R, ctl, args, out, local_peer, wd):
+    """transports x decompositions behind the headline leg (which ran on `rccl` with the balanced decomposition)"""
+    steps, warm = args.leg_steps, max(args.warmup, 4)
+    tr = out["transports"]
+    # one block alone on rank 0 (no communicator, same allocations): the N = 1 rate the efficiencies refer to
+    wd.where = "n1_reference"
+    R.disconnect()
+    n1 = None
+    if ctl.rank == 0:
+        R.run(warm); R.sync()
+        t0 = time.perf_counter()
+        R.run(steps); R.sync()
+        n1 = steps / (time.perf_counter() - t0)
+    ctl.barrier()
+    n1 = ctl.max([n1 or 0.0])[0]
+    out["n1_reference"] = {"it_per_s": n1, "what": "rank 0's block alone, no communicator, same allocations, the other ranks idle"}
+    if "it_per_s" in tr["rccl"]:
+        tr["rccl"]["efficiency_vs_n1"] = (tr["rccl"]["it_per_s"] / ctl.world) / n1
+    wd.where = "rccl chain profile"
+    try:
+        R.connect("rccl")
+        ch = R.chain(12)
+    except Exception as e:      # noqa: BLE001
+        ch = {"error": f"{type(e).__name__}: {e}"}
+    tr["rccl"]["chain_us_per_rank"] = ctl.gather(ch)
+    wd.where = "ipc"
+    tr["ipc"] = collective_leg(R, ctl, "ipc", steps, warm, n1)
+    R.disconnect()
+    ctl.barrier()
+    wd.where = "local_peer"
+    if ctl.rank == 0:
+        try:
+            tr["local_peer"] = local_peer(ctl.world, "balanced", steps, warm, n1)
+        except Exception as e:      # noqa: BLE001
+            tr["local_peer"] = {"error": f"{type(e).__name__}: {e}"}
+    ctl.barrier()
+    # the other decomposition (x, the contiguous direction, never split) on the faster of the process-per-GPU transports
+    wd.where = "alt_decomposition"
+    rate = lambda k: tr.get(k, {}).get("it_per_s", 0.0)
+    best = "ipc" if rate("ipc") > rate("rccl") else "rccl"
+    alt_mode = "balanced" if args.dims == "yz" else "yz"
+    try:
+        dims = R.build(alt_mode)
+        err = None
+    except Exception as e:      # noqa: BLE001
+        dims, err = None, f"{type(e).__name__}: {e}"
+    errs = [e for e in ctl.gather(err) if e]
+    if errs:
+        out["alt_decomposition"] = {"error": errs[0]}
+    else:
+        leg = collective_leg(R, ctl, best, steps, warm, n1)
+        leg.update(decomposition=list(dims), transport=best)
+        out["alt_decomposition"] = leg
+        R.disconnect()
+        ctl.barrier()
+        wd.where = "alt_decomposition local_peer"
+        if ctl.rank == 0:
+            try:
+                leg["local_peer"] = local_peer(ctl.world, alt_mode, steps, warm, n1)
+            except Exception as e:      # noqa: BLE001
+                leg["local_peer"] = {"error": f"{type(e).__name__}: {e}"}
+        ctl.barrier()
+
+
+# ------------------------------------------------------------------------------------------------ dry run of the N > 1 control flow (no GPU)
+class DryRanks:
+    """stands in for GpuRanks in `--dry-transports`: the legs' control flow (connects, barriers, gathers, watchdog) runs with sleeps instead of kernels, so
+    that the schema of the N > 1 line can be tested without a GPU (tests/test_bench_launch.py)"""
+
+    def __init__(self, args, rank, world):
+        self.rank, self.world, self.transport, self.dims, self.n = rank, world, None, None, args.n
+        self.fail = os.environ.get("JRX_DRY_FAIL", "")
+
+    def build(self, mode):
+        self.disconnect()
+        self.dims = YZ_DIMS.get(self.world, (1, 1, self.world)) if mode == "yz" else {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(self.world, (self.world, 1, 1))
+        return self.dims
+
+    def disconnect(self):
+        self.transport = None
+
+    def connect(self, transport):
+        if transport == self.fail and self.rank == self.world - 1:
+            raise RuntimeError(f"dry run: {transport} refused")
+        if self.fail == "hang:" + transport and self.rank == self.world - 1:
+            time.sleep(3600.0)
+        self.transport = transport
+
+    def comm_count(self):
+        return self.world
+
+    def pipeline(self):
+        return "dry"
+
+    def run(self, k):
+        time.sleep(0.001 * k)
+        return (1.0 * k, 0.0, 0.0, 1.0, 0.9, float(self.n) ** 3)
+
+    def sync(self):
+        pass
+
+    def chain(self, k):
+        return dict({key: 1.0 for key in CHAIN_KEYS}, samples=k)
+
+
+def dry_local_peer(world, mode, steps, warm, n1):
+    return {"handles": world, "devices": list(range(world)), "steps": steps, "it_per_s": 1.0, "ms_per_step": 1.0, "efficiency_vs_n1": 1.0,
+            "chain_us_per_rank": [dict({k: 1.0 for k in CHAIN_KEYS}, samples=12) for _ in range(world)]}
+
+
+# ------------------------------------------------------------------------------------------------ N = 1: two rank PROCESSES on the one device (ipc transport)
+IPC_HELPERS = []
+
+
+def start_ipc_helpers(args):
+    """Two child processes of this script (`--ipc-helper`), started before this process touches the GPU (afterwards it may not start any) and parked on their stdin until
+    the multi_rank_path leg wakes them: rank 0 and rank 1 of a two-block decomposition, both on device 0, joined by jrx_comm_init_ipc."""
+    env0 = dict(os.environ, WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", LOCAL_RANK="0")
+    for r in range(2):
+        IPC_HELPERS.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), "--ipc-helper", "--n", str(args.n), "--gpus", "2"], env=dict(env0, RANK=str(r)),
+                                            stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+
+
+def stop_ipc_helpers():
+    for p in IPC_HELPERS:
+        try:
+            if p.stdin and not p.stdin.closed:
+                p.stdin.close()
+        except OSError:
+            pass
+    t0 = time.time()
+    for p in IPC_HELPERS:
+        while p.poll() is None and time.time() - t0 < 20.0:
+            time.sleep(0.1)
+        if p.poll() is None:
+            p.kill()             # only the exact processes started above
+    IPC_HELPERS.clear()
+
+
+def run_ipc_helpers(timeout=420.0):
+    """wake the two parked rank processes, wait for rank 0's JSON line; this process must leave the GPU idle meanwhile"""
+    if not IPC_HELPERS:
+        return {"skipped": "the rank processes are only started by a one-GPU `python bench.py` run with the extra legs on"}
+    import threading
+    outs = [None, None]
+
+    def drain(i):
+        outs[i] = IPC_HELPERS[i].stdout.read()
+    ths = [threading.Thread(target=drain, args=(i,), daemon=True) for i in range(2)]
+    for t in ths:
+        t.start()
+    for p in IPC_HELPERS:
+        p.stdin.write("go\n")
+        p.stdin.flush()
+    t0 = time.time()
+    while any(p.poll() is None for p in IPC_HELPERS) and time.time() - t0 < timeout:
+        time.sleep(0.2)
+    alive = [p.poll() is None for p in IPC_HELPERS]
+    stop_ipc_helpers()
+    for t in ths:
+        t.join(timeout=5.0)
+    if any(alive):
+        return {"error": f"the rank processes did not finish within {timeout:.0f} s"}
+    lines = [l for l in (outs[0] or "").splitlines() if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else {"error": "rank 0 printed no JSON line"}
+
+
+def ipc_helper(args) -> int:
+    """One of the two parked rank processes (see start_ipc_helpers).  Measures, for a split along x and along z: two coupled n^3 blocks (early exchange = default, and the
+    exchange behind the kernel) against the same two blocks uncoupled -- what cfg_multi_rank_path measures for the in-process transport."""
+    line = sys.stdin.readline()
+    if not line.startswith("go"):
+        return 0
+    rank = int(os.environ["RANK"])
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    from datetime import timedelta
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=2, timeout=timedelta(minutes=10))
+    ctl = Control(rank, 2)
+    from __graft_entry__ import load_package
+    jr = load_package()
+    torch.cuda.set_device(0)
+    R = GpuRanks(args, jr, rank, 2, 0)
+    steps, warm = 40, 6
+    out = {"workload": f"SolVi3D, two {args.n}^3 blocks on one device, one PROCESS per block (ipc transport: hipIpcOpenMemHandle + hipMemcpyAsync, flags in shared memory)", "steps": steps}
+    try:
+        for split in ("x", "z"):
+            R.build(split)
+            leg = {}
+            for mode, ov in (("early", 2), ("serial", 0)):
+                R.h.set_option("fused_overlap", ov)
+                r = collective_leg(R, ctl, "ipc", steps, warm)
+                leg[mode] = {"block_it_per_s": r.get("it_per_s"), "chain_us_per_rank": r.get("chain_us_per_rank"), **({"error": r["error"]} if "error" in r else {})}
+            R.h.set_option("fused_overlap", 2)
+            R.disconnect()
+            R.run(warm); R.sync(); ctl.barrier()
+            t0 = time.perf_counter()
+            R.run(steps); R.sync()
+            el = ctl.max([time.perf_counter() - t0])[0]
+            ctl.barrier()
+            unc = 2 * steps / el
+            leg["two_uncoupled_blocks_block_it_per_s"] = unc
+            for mode in ("early", "serial"):
+                if leg[mode].get("block_it_per_s"):
+                    leg[mode]["overhead_pct"] = (unc / leg[mode]["block_it_per_s"] - 1.0) * 100.0
+            out[f"split_{split}"] = leg
+    except Exception as e:      # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    try:
+        R.disconnect()
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:           # noqa: BLE001
+        pass
+    return 0
+
+
 # ------------------------------------------------------------------------------------------------ one rank
+def run_multi(args, world, rank, local_rank, json_fd) -> int:
+    """N > 1 (one process per GPU).  Headline = the requested K steps on the RCCL transport with the requested decomposition (north_star's configuration); behind it,
+    in the same processes: the chain breakdown per rank, the cross-process copy-engine transport (ipc), one process driving all devices by peer copies
+    (local_peer, on rank 0 while the others idle) and the other decomposition on the faster process-per-GPU transport."""
+    from datetime import timedelta
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # control plane only (ids, barriers, max of the timings, gathers): gloo over loopback -- all ranks are on one node and the container hostname may not
+    # resolve; the data path is the library's own transport
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=timedelta(minutes=60))
+    ctl = Control(rank, world)
+    n = args.n
+    if args.dry_transports:
+        R, local_peer, jr = DryRanks(args, rank, world), dry_local_peer, None
+        pr = {"form": "dry", "alg": A_ALG_VISC, "needed": A_NEEDED_VISC, "pmc": None, "pmc_source": None, "kernel": "dry run"}
+        gg = None
+    else:
+        import torch
+        from __graft_entry__ import load_package
+        jr = load_package()
+        import justrelax_jl_amd.grid as grid
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, {torch.cuda.device_count()} visible")
+        torch.cuda.set_device(local_rank)
+        R = GpuRanks(args, jr, rank, world, local_rank)
+        if args.variant:
+            R.h.set_option("kernel_variant", args.variant)
+        for kv in args.option:
+            k, v = kv.split("=")
+            R.h.set_option(k, int(v))
+        local_peer = lambda w, mode, steps, warm, n1: local_peer_leg(jr, args, w, mode, steps, warm, n1)
+    dims = R.build(args.dims)
+    R.connect("rccl")
+    ranks = R.comm_count()
+    if ranks != world:
+        raise SystemExit(f"bench.py: RCCL communicator has {ranks} ranks, expected {world}")
+    if not args.dry_transports:
+        pr = pricing(R.h, R.blk[8])
+        f0 = [R.h.get_option("stat_fused3d"), R.h.get_option("stat_fused3d_visc")]
+    if args.warmup > 0:
+        R.run(args.warmup)
+    R.sync(); ctl.barrier()
+    t0 = time.perf_counter()
+    tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = R.run(args.steps)
+    R.sync()
+    el = time.perf_counter() - t0
+    ctl.barrier()
+    el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = ctl.max([el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells])
+    steady = None
+    if args.steps < 50 and not args.no_steady_state:
+        ctl.barrier()
+        t1 = time.perf_counter()
+        sres = R.run(100)
+        R.sync()
+        sel = time.perf_counter() - t1
+        ctl.barrier()
+        sel = ctl.max([sel])[0]
+        steady = {"steps": 100, "value": world * 100 / sel, "ms_per_step": sel / 100 * 1e3,
+                  "kernel_avg_launch_ms": sres[4] if sres[4] > 0 else None,
+                  "kernel_frac": (pr["alg"] * (sres[5] or float(n) ** 3) / (sres[4] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sres[4] > 0 else None}
+    cells = float(n) ** 3
+    it_per_s = args.steps / el
+    value = world * it_per_s
+    out = {
+        "metric": f"PT-iterations/s (3D Stokes SolVi3D, {n}^3 fp64 block per GPU, block-iterations summed over GPUs)",
+        "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "steps_effective": args.steps, "steady_state": steady,
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"SolVi3D {n}^3 per GPU (configs[3]: 512^3 per GPU, weak scaling): eta inclusion 1e-3, G=1, K=Inf, dt=Inf, free-slip, pure shear",
+                   "kernel_form": pr["form"], "local_grid": [n, n, n], "global_grid": [d * (n - 2) + 2 for d in dims], "decomposition": list(dims),
+                   "halo": "RCCL send/recv (the default transport; the others are under `transports`)"},
+        "rccl_ranks": ranks, "default_transport": "rccl",
+        "global_iterations_per_s": it_per_s,
+        "bytes_per_cell_priced": pr["alg"], "effective_GBps": pr["alg"] * cells * value / 1e9,
+        "device_ms_per_step": tot_ms / args.steps,
+        "roofline": None,
+        "transports": {"rccl": {"ranks": ranks, "steps": args.steps, "it_per_s": value, "ms_per_step": el / args.steps * 1e3, "decomposition": list(dims),
+                                "pipeline": R.pipeline(), "what": "the headline leg: one process per GPU, grouped ncclSend/ncclRecv per dimension"}},
+    }
+    it_gbs = pr["alg"] * cells * (args.steps / (tot_ms * 1e-3)) / 1e9
+    if sf_ms > 0.0:
+        out["roofline"] = fused_roofline(pr, n, sk_ms, sf_ms, kcells, it_gbs)
+    else:
+        out["roofline"] = {"bound": "hbm", "kernel": f"whole PT iteration per GPU ({pr['alg']:.0f} B/cell, form: {pr['form']}; sweeps overlap the halo exchange)", "form": pr["form"],
+                           "bytes_per_cell": pr["alg"], "achieved": it_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_gbs / HBM_PEAK_GBS, "traffic": None}
+    if not args.dry_transports:
+        check_priced_kernel(R.h, pr, f0, out)
+
+    def emit(note=None):
+        if note:
+            out["extras_incomplete"] = note
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if args.no_extras:
+        if rank == 0:
+            emit()
+    else:
+        wd = Watchdog(args.extras_budget, rank, emit)
+        try:
+            multi_rank_extras(R, ctl, args, out, local_peer, wd)
+            note = None
+        except Exception as e:      # noqa: BLE001 -- the headline is kept
+            note = f"{type(e).__name__}: {e}"
+        wd.cancel()
+        if rank == 0:
+            emit(note)
+    R.disconnect()
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:       # noqa: BLE001 -- a rank that left early must not turn a finished measurement into a failure
+        pass
+    return 0
+
+
+def check_priced_kernel(h, pr, before, out):
+    """Evidence hygiene: the kernel form the line prices must be the one that ran.  The library counts its launches of k_fused3d and, of those, the
+    launches of the viscous-limit form; the bench refuses to print a roofline for a form that did not run."""
+    d_all = h.get_option("stat_fused3d") - before[0]
+    d_visc = h.get_option("stat_fused3d_visc") - before[1]
+    out["kernel_launch_counters"] = {"k_fused3d": int(d_all), "of_which_viscous_limit_form": int(d_visc), "operand_checks_failed": int(h.get_option("stat_visc_fallbacks"))}
+    want_visc = pr["form"] == "viscous_limit"
+    if d_all <= 0 or (want_visc and d_visc != d_all) or (not want_visc and d_visc != 0):
+        raise SystemExit(f"bench.py: the line prices the `{pr['form']}` form of k_fused3d, but the library launched {d_all} fused kernels of which {d_visc} in the viscous-limit form")
+
+
 def run_rank(args) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -624,25 +1266,21 @@ def run_rank(args) -> int:
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        return run_multi(args, world, rank, local_rank, json_fd)
+
     import ctypes as C
     import torch
-    import torch.distributed as dist
     from __graft_entry__ import load_package
     jr = load_package()
     from justrelax_jl_amd import _lib, halo, stokes
     from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
     import justrelax_jl_amd.grid as grid
 
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, {torch.cuda.device_count()} visible")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # control plane only (unique-id broadcast, barrier, max of the timings): gloo over loopback -- all ranks are on one node and the
-        # container hostname may not resolve; the data path is the library's own RCCL communicator
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     if args.slab_gb > 0:
         _slab = torch.empty(int(args.slab_gb * 2 ** 30), dtype=torch.uint8, device=f"cuda:{local_rank}")
@@ -654,9 +1292,6 @@ def run_rank(args) -> int:
     if self_halo:
         grid.init_global_grid(n, n, n, rank=0, nprocs=1, periodx=int("x" in args.self_halo), periody=int("y" in args.self_halo),
                               periodz=int("z" in args.self_halo))
-    elif world > 1 and args.dims == "yz":
-        dy = {2: 1, 4: 2, 8: 2, 16: 4}.get(world, 1)
-        grid.init_global_grid(n, n, n, rank=rank, nprocs=world, dimx=1, dimy=dy, dimz=world // dy)
     else:
         grid.init_global_grid(n, n, n, rank=rank, nprocs=world)
     h = _lib.default_handle(local_rank)
@@ -671,8 +1306,6 @@ def run_rank(args) -> int:
         cnt = C.c_int32(0)
         h.call("jrx_comm_count", C.byref(cnt))
         rccl_ranks = cnt.value
-        if world > 1 and rccl_ranks != world:
-            raise SystemExit(f"bench.py: RCCL communicator has {rccl_ranks} ranks, expected {world}")
     uh = (lambda a: halo.update_halo_(a, ni=(n, n, n), handle=h)) if (world > 1 or self_halo) else None
     st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend, update_halo=uh)
     jr.flow_bcs_(st, bcs, handle=h)
@@ -685,11 +1318,10 @@ def run_rank(args) -> int:
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
 
     run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
     pr = pricing(h, dt)
+    f0 = [h.get_option("stat_fused3d"), h.get_option("stat_fused3d_visc")]
     if args.warmup > 0:
         run(args.warmup)
     barrier()
@@ -698,10 +1330,6 @@ def run_rank(args) -> int:
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
-    if world > 1:
-        t = torch.tensor([el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = t.tolist()
     # A short requested batch (the driver times 20 steps = 0.16 s) samples the box's clocks and allocation luck more than the code: a 100-step batch
     # of the same loop is timed afterwards and reported beside it as `steady_state`; `value` stays the requested batch.
     steady = None
@@ -712,10 +1340,6 @@ def run_rank(args) -> int:
         torch.cuda.synchronize()
         sel = time.perf_counter() - t1
         barrier()
-        if world > 1:
-            t = torch.tensor([sel], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sel = t.item()
         steady = {"steps": 100, "value": world * 100 / sel, "ms_per_step": sel / 100 * 1e3,
                   "kernel_avg_launch_ms": sres[4] if sres[4] > 0 else None,
                   "kernel_frac": (pr["alg"] * (sres[5] or float(n) ** 3) / (sres[4] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sres[4] > 0 else None}
@@ -747,10 +1371,12 @@ def run_rank(args) -> int:
         it_gbs = pr["alg"] * cells * (args.steps / (tot_ms * 1e-3)) / 1e9
         if fused:
             out["roofline"] = fused_roofline(pr, n, sk_ms, sf_ms, kcells, it_gbs)
+            if not self_halo and not args.variant:
+                check_priced_kernel(h, pr, f0, out)
         elif split:
             visc = pr["form"] == "viscous_limit"
             a_st = A_STRESS_VISC if visc else A_STRESS
-            tr_st = (PMC_TRAFFIC_STRESS_VISC_512 if visc else PMC_TRAFFIC_STRESS_512) if n == 512 else None
+            tr_st = ((PMC_TRAFFIC_STRESS_VISC_512 if visc else PMC_TRAFFIC_STRESS_512) if n == 512 else None) or None
             out["roofline"] = {"bound": "hbm",
                                "kernel": ("stress sweep = k_stress3d_zb<...,VISC=1> + the boundary-plane launch, viscous limit dt = Inf (11 array reads + 7 writes = 144 B/cell; tau_o, P0, K, G, Q not loaded)"
                                           if visc else "stress sweep = k_stress3d_zb + the boundary-plane launch (21 array reads + 7 writes = 224 B/cell)"),
@@ -827,18 +1453,22 @@ def run_rank(args) -> int:
                                                  f"cell count to a {n}^3 block (the {n}^3 leg was not run: --cpu-full-size {args.cpu_full_size}, MemAvailable {mem_available_gb():.0f} GB)",
                                        "measured": runs}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     return 0
 
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.ipc_helper:
+        return ipc_helper(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)
-    return run_rank(args)
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not (args.no_extras or args.dry_launch or args.dry_transports or args.self_halo):
+        start_ipc_helpers(args)
+    try:
+        return run_rank(args)
+    finally:
+        stop_ipc_helpers()
 
 
 if __name__ == "__main__":

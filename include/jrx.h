@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JRX_VERSION 200
+#define JRX_VERSION 210
 
 typedef enum jrx_status {
     JRX_OK = 0,
@@ -122,6 +122,15 @@ int64_t jrx_n_global(int64_t n, int32_t dims, int32_t periodic);   /* nx_g() */
 jrx_status jrx_comm_unique_id(uint8_t id[JRX_UNIQUE_ID_BYTES]);
 jrx_status jrx_comm_init(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], const jrx_cart *cart);
 jrx_status jrx_comm_destroy(jrx_handle *h);
+/* The same communicator between PROCESSES of one node with copy engines as transport ("ipc"; one process per rank as the reference runs --
+ * mpiexec -n N, test/runtests.jl:73-90 -- and as the Julia extension's MPI ranks would).  Every rank exports one receive buffer per (dimension, side)
+ * (hipIpcGetMemHandle), the neighbour maps it and pushes its packed planes into it with hipMemcpyAsync on the exchange's stream; sequence flags in a
+ * POSIX shared-memory segment named by `id` order the copies against the unpack kernels (device-side waits with a time-out: a neighbour that never
+ * arrives is JRX_ERR_RCCL, not a hang); norms are all-reduced through the segment in rank order.  Rank 0 calls jrx_comm_ipc_id and ships the 128
+ * bytes out of band exactly like the RCCL id; every rank then calls jrx_comm_init_ipc.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only
+ * supports dmabuf IPC.  Replaces the same call sites as jrx_comm_init. */
+jrx_status jrx_comm_ipc_id(uint8_t id[JRX_UNIQUE_ID_BYTES]);
+jrx_status jrx_comm_init_ipc(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], const jrx_cart *cart);
 /* The same communicator for ranks that are handles of ONE process (in-process transport): handles[r] becomes rank r of carts[r]
  * (carts[r].rank == r, carts[r].nprocs == n); the handles may sit on one device or on peer-accessible devices.  update_halo! then
  * pushes the packed planes into the neighbour's receive buffer with hipMemcpyAsync / hipMemcpyPeerAsync on the exchange's stream

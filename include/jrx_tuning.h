@@ -17,7 +17,9 @@
  *   "vep_store_all" (0)           VEP loops (2D and 3D): 1 = every iteration stores ∇V, RP, ε_pl, ε_vol_pl, τII, η_vep (default: only iterations whose results can be observed)
  *   "thermal_cfg", "thermal_xg"   fused 3D heat-diffusion tile shape / XCD band
  *   "halo_self_rccl" (0)          test hook: a rank that is its own periodic neighbour routes its planes through ncclSend/ncclRecv
- *   "comm_timeout_ms" (120000)    in-process transport (jrx_comm_init_local): how long a rank waits on the host for a neighbour
+ *   "comm_timeout_ms" (120000)    in-process and ipc transports (jrx_comm_init_local / _ipc): how long a rank waits for a neighbour (host waits and the device-side flag waits)
+ *   "chain_profile" (0)           jrx_stokes3d_iterate_timed on a multi-rank handle also records events around the stages of every sampled fused step; read with
+ *                                 jrx_tuning_chain_profile
  */
 #ifndef JRX_TUNING_H
 #define JRX_TUNING_H
@@ -27,6 +29,11 @@ extern "C" {
 #endif
 jrx_status jrx_tuning_set(jrx_handle *h, const char *key, int64_t value);
 jrx_status jrx_tuning_get(jrx_handle *h, const char *key, int64_t *value);
+/* what a rank's fused iteration spent where in the last jrx_stokes3d_iterate_timed call with "chain_profile" = 1, averages in microseconds over `samples` steps:
+ * [0] k_fused3d, [1] boundary-slab velocity launches of the early exchange, [2] flow_bcs! before the exchange, [3] update_halo!(V) (pack, transport, waiting for
+ * the neighbour, unpack), [4] flow_bcs! behind the join, [5] stress fix-up next to the received planes, [6] the whole step, [7] the step beyond k_fused3d.  With the
+ * early exchange [1]..[3] run on the halo stream beside [0]. */
+jrx_status jrx_tuning_chain_profile(jrx_handle *h, double out_us[8], int64_t *samples);
 #ifdef __cplusplus
 }
 #endif

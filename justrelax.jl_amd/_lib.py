@@ -157,6 +157,12 @@ class Cart(C.Structure):
 
 
 TUNING_HEADER = HERE.parent / "include" / "jrx_tuning.h"
+ABI_VERSION = 210        # JRX_VERSION this binding's structs and option keys follow (210: jrx_comm_init_ipc, viscous-limit counters; 200 -> 210 also covers round 3's b_width[3] of jrx_vep3d_params)
+
+
+def header_version() -> int:
+    m = re.search(r"#define\s+JRX_VERSION\s+(\d+)", HEADER.read_text())
+    return int(m.group(1)) if m else -1
 
 
 def declared_symbols(headers=None) -> list:
@@ -186,6 +192,10 @@ def load(check_symbols: bool = False):
         if have != want:
             raise RuntimeError(f"{LIB_PATH} was built from other sources (build id {have[:12]}…, sources {want[:12]}…): "
                                "run `python justrelax.jl_amd/build.py`")
+        # ... and speak the ABI revision this binding was written against (struct layouts, option keys): JRX_VERSION of include/jrx.h
+        L.jrx_version.restype = C.c_int32
+        if L.jrx_version() != ABI_VERSION or header_version() != ABI_VERSION:
+            raise RuntimeError(f"ABI revision mismatch: binding {ABI_VERSION}, include/jrx.h {header_version()}, {LIB_PATH.name} {L.jrx_version()}")
         L.jrx_last_error.restype = C.c_char_p
         L.jrx_last_error.argtypes = [C.c_void_p]
         L.jrx_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]

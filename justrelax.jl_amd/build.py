@@ -83,7 +83,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT)] + [str(objdir / (s + ".o")) for s in SRCS] + ["-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(OUT)] + [str(objdir / (s + ".o")) for s in SRCS] + ["-ldl", "-lrt", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -14,8 +14,22 @@
 // the receiver's stream waits on the sender's "sent" event before unpacking, the sender's stream waits on the receiver's "unpacked"
 // event of the previous exchange before overwriting the buffer.  Which records have been issued is agreed through per-link sequence
 // numbers under the group's mutex; the host never waits for the device.  Norms are all-reduced on the host in rank order.
+//
+// Third transport, "ipc" (jrx_comm_init_ipc): the same push protocol between PROCESSES of one node -- one process per rank, the reference's own model
+// (mpiexec -n N, test/runtests.jl:73-90; what the Julia extension's MPI ranks would use).  Every rank owns one receive buffer per (dimension, side) in
+// uncached device memory and exports it with hipIpcGetMemHandle; the neighbour maps it (hipIpcOpenMemHandle) and pushes its packed planes into it with
+// hipMemcpyAsync on the exchange's stream (copy engines / xGMI, no send/recv kernel beside the interior kernel).  Ordering is by sequence flags in a small
+// POSIX shared-memory segment that every rank maps and registers with HIP: the sender's stream posts `sent = k` behind its copy, the receiver's stream
+// waits for it (a one-wave kernel polling the flag, with a time-out) before it unpacks and then posts `unpacked = k`, which the sender's stream waits for
+// before it overwrites the buffer in exchange k + 1.  The host only meets the neighbour's host once per exchange (is its buffer large enough?) and never
+// waits for a device.  Norms are all-reduced through the same segment in rank order, so every rank holds the same bits.
 #include "jrx_internal.hpp"
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <time.h>
 #include <cstdlib>
 #include <chrono>
 #include <condition_variable>
@@ -37,6 +51,27 @@ struct jrx_local_group {
     uint64_t gen = 0;
     double timeout_s = 120.0;
 };
+
+// ---- ipc transport: the control segment (POSIX shared memory, mapped by every rank and registered with HIP so that device kernels can poll / post the flags)
+struct IpcLink {                 // state of rank r's face (dimension, side): its receive buffer there and its sends through it
+    uint64_t ready;              // host of r: exchanges r has entered through this face (its buffer then holds `cap` values)
+    uint64_t cap;                // host of r: capacity of the receive buffer (doubles)
+    uint64_t buf_gen;            // host of r: bumped whenever the buffer is re-allocated (the neighbour then re-opens `mem`)
+    hipIpcMemHandle_t mem;       // host of r: IPC handle of the receive buffer
+    uint64_t sent;               // stream of r: payloads of r through this face that have landed in the neighbour's buffer
+    uint64_t unpacked;           // stream of r: exchanges r has unpacked from its receive buffer of this face
+    uint64_t pad[2];
+};
+struct IpcCtl {
+    uint64_t magic;
+    uint32_t nranks, attached, failed, left;
+    uint64_t red_gen;
+    uint32_t red_arrived, pad_;
+    double red_slot[2][kMaxLocalRanks][8];
+    int32_t device[kMaxLocalRanks];
+    IpcLink link[kMaxLocalRanks][3][2];
+};
+static constexpr uint64_t kIpcMagic = 0x4a52584950433031ull;      // "JRXIPC01"
 
 struct jrx_comm_state {
     void *lib = nullptr;
@@ -64,6 +99,15 @@ struct jrx_comm_state {
     hipEvent_t ev_sent[3][2] = {}, ev_unpacked[3][2] = {};
     uint64_t ready[3][2] = {}, sent[3][2] = {};   // exchanges entered (buffer large enough, previous unpack recorded) / pushed, per link
     int64_t stat_bytes_pushed = 0;
+    // ---- ipc transport (jrx_comm_init_ipc)
+    IpcCtl *ctl = nullptr, *ctl_dev = nullptr;     // the control segment as the host / the device of this rank sees it
+    bool ctl_registered = false;
+    double *irbuf[3][2] = {};          // my receive buffers (uncached device memory, exported)
+    size_t icap[3][2] = {};
+    double *peer_buf[3][2] = {};       // the neighbour's receive buffer behind my face (dimension, side), mapped into this process
+    uint64_t peer_gen[3][2] = {};
+    uint64_t ik[3][2] = {};            // exchanges entered per face
+    double ipc_timeout_s = 120.0;
 };
 
 namespace {
@@ -151,12 +195,14 @@ static bool has_self_neighbor(const jrx_cart &c)
 bool jrx_comm_active(const jrx_handle *h)
 {
     if (!h || !h->comm) return false;
-    return ((h->comm->comm || h->comm->grp) && h->comm->cart.nprocs > 1) || has_self_neighbor(h->comm->cart);
+    return ((h->comm->comm || h->comm->grp || h->comm->ctl) && h->comm->cart.nprocs > 1) || has_self_neighbor(h->comm->cart);
 }
 int jrx_comm_rank(const jrx_handle *h) { return (h && h->comm) ? h->comm->cart.rank : 0; }
 void jrx_comm_set_timeout(jrx_handle *h, double seconds)
 {
-    if (!h || !h->comm || !h->comm->grp) return;
+    if (!h || !h->comm) return;
+    h->comm->ipc_timeout_s = seconds;
+    if (!h->comm->grp) return;
     std::lock_guard<std::mutex> lk(h->comm->grp->m);
     h->comm->grp->timeout_s = seconds;
 }
@@ -287,15 +333,218 @@ static jrx_status local_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream
     return JRX_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ ipc transport
+namespace {
+template <class T> inline T ipc_load(const T *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+template <class T> inline void ipc_store(T *p, T v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+inline double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+inline void ipc_relax(int spins)
+{
+    if (spins < 2000) { sched_yield(); return; }
+    timespec ts = {0, 50000};       // 50 us
+    nanosleep(&ts, nullptr);
+}
+// host wait on the control segment; an absent / failed peer is an error after the time-out, never a hang
+template <class Pred>
+jrx_status ipc_wait(jrx_handle *h, jrx_comm_state *c, Pred pred, const char *what)
+{
+    const double t0 = now_s();
+    for (int spins = 0; !pred(); spins++) {
+        if (ipc_load(&c->ctl->failed)) return jrx_fail(h, JRX_ERR_RCCL, "ipc transport: a rank of the group failed or timed out while this one waited for %s", what);
+        if (now_s() - t0 > c->ipc_timeout_s) {
+            ipc_store(&c->ctl->failed, 1u);
+            return jrx_fail(h, JRX_ERR_RCCL, "ipc transport: timed out after %.0f s waiting for %s (every rank must make the same sequence of calls)", c->ipc_timeout_s, what);
+        }
+        ipc_relax(spins);
+    }
+    return JRX_OK;
+}
+
+// one lane per flag: wait until *flag >= want.  The flags live in host memory shared by the processes of the node; a peer that never posts is a time-out
+// (the group is marked failed and every host call of every rank then returns an error), never a hung queue.
+__global__ void k_ipc_wait(const uint64_t *f0, uint64_t w0, const uint64_t *f1, uint64_t w1, uint32_t *failed, uint64_t timeout_ticks)
+{
+    const uint64_t *f = threadIdx.x == 0 ? f0 : f1;
+    const uint64_t w = threadIdx.x == 0 ? w0 : w1;
+    if (!f) return;
+    const uint64_t t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < w) {
+        __builtin_amdgcn_s_sleep(64);
+        if (__hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
+        if (wall_clock64() - t0 > timeout_ticks) {
+            __hip_atomic_store(failed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
+}
+// post *flag = v behind everything the stream has done so far
+__global__ void k_ipc_post(uint64_t *f0, uint64_t v0, uint64_t *f1, uint64_t v1)
+{
+    uint64_t *f = threadIdx.x == 0 ? f0 : f1;
+    const uint64_t v = threadIdx.x == 0 ? v0 : v1;
+    if (!f) return;
+    __threadfence_system();
+    __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}   // namespace
+
+static jrx_status ipc_check(jrx_handle *h, jrx_comm_state *c)
+{
+    if (c->ctl && ipc_load(&c->ctl->failed))
+        return jrx_fail(h, JRX_ERR_RCCL, "ipc transport: the group has failed (a rank left, reported an error, or a device-side wait for a neighbour's planes timed out)");
+    return JRX_OK;
+}
+struct IpcFailGuard {
+    jrx_comm_state *c;
+    bool ok = false;
+    ~IpcFailGuard() { if (!ok && c->ctl) ipc_store(&c->ctl->failed, 1u); }
+};
+
+// norm_mpi / maximum_mpi over the ranks of the node: deposit, barrier, combine in rank order (every rank gets the same bits)
+static jrx_status ipc_allreduce(jrx_handle *h, jrx_comm_state *c, double *vals, int count, int op)
+{
+    IpcCtl *ctl = c->ctl;
+    JRX_TRY(ipc_check(h, c));
+    const int n = (int)ctl->nranks, me = c->cart.rank;
+    const uint64_t gen = ipc_load(&ctl->red_gen);
+    double (*slot)[8] = ctl->red_slot[gen & 1];
+    for (int i = 0; i < count; i++) slot[me][i] = vals[i];
+    if ((int)__atomic_add_fetch(&ctl->red_arrived, 1u, __ATOMIC_ACQ_REL) == n) {
+        ipc_store(&ctl->red_arrived, 0u);
+        ipc_store(&ctl->red_gen, gen + 1);
+    } else {
+        JRX_TRY(ipc_wait(h, c, [&] { return ipc_load(&ctl->red_gen) != gen; }, "the all-reduce of the other ranks"));
+    }
+    // slot[gen & 1] is written again in generation gen + 2, which starts only after every rank has arrived in gen + 1, i.e. after this read
+    for (int i = 0; i < count; i++) {
+        double acc = slot[0][i];
+        for (int r = 1; r < n; r++) acc = op == 1 ? fmax(acc, slot[r][i]) : acc + slot[r][i];
+        vals[i] = acc;
+    }
+    return JRX_OK;
+}
+
+// one dimension of update_halo! between processes.  The send planes are already packed into c->sbuf[side] on `s`.
+static jrx_status ipc_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream_t s, int dim, const int nb[2], size_t total, PlaneSet &S, int gx, int na)
+{
+    IpcCtl *ctl = c->ctl, *dctl = c->ctl_dev;
+    const int me = c->cart.rank;
+    JRX_TRY(ipc_check(h, c));
+    IpcFailGuard guard{c};
+    uint64_t k[2] = {0, 0};
+    const uint64_t ticks = (uint64_t)(c->ipc_timeout_s * 1e8);           // wall_clock64 counts at 100 MHz
+    // 1. my receive buffers
+    for (int side = 0; side < 2; side++) {
+        if (nb[side] < 0 || c->icap[dim][side] >= total) continue;
+        // nobody copies into the old buffer any more: every copy into it was waited for by the unpack behind it on this rank's streams
+        JRX_HIP(h, hipStreamSynchronize(h->stream));
+        JRX_HIP(h, hipStreamSynchronize(h->halo_stream));
+        if (c->irbuf[dim][side]) JRX_HIP(h, hipFree(c->irbuf[dim][side]));
+        c->irbuf[dim][side] = nullptr; c->icap[dim][side] = 0;
+        // uncached (fine-grained) device memory: the planes are written by another process's copy and read here behind a flag, not behind a kernel boundary the
+        // runtime knows about -- the L2 of this device must not serve them from a stale line
+        JRX_HIP(h, hipExtMallocWithFlags((void **)&c->irbuf[dim][side], total * sizeof(double), hipDeviceMallocUncached));
+        c->icap[dim][side] = total;
+        IpcLink &L = ctl->link[me][dim][side];
+        hipIpcMemHandle_t mh;
+        JRX_HIP(h, hipIpcGetMemHandle(&mh, c->irbuf[dim][side]));
+        memcpy((void *)&L.mem, &mh, sizeof(mh));
+        ipc_store(&L.cap, (uint64_t)total);
+        ipc_store(&L.buf_gen, L.buf_gen + 1);
+    }
+    // 2. enter
+    for (int side = 0; side < 2; side++)
+        if (nb[side] >= 0) { k[side] = ++c->ik[dim][side]; ipc_store(&ctl->link[me][dim][side].ready, k[side]); }
+    // 3. push: my send plane of `side` lands in the neighbour's receive buffer of the opposite side
+    uint64_t *wf[2] = {nullptr, nullptr}, wv[2] = {0, 0};
+    for (int side = 0; side < 2; side++) {
+        if (nb[side] < 0) continue;
+        const int opp = 1 - side, peer = nb[side];
+        IpcLink &P = ctl->link[peer][dim][opp];
+        JRX_TRY(ipc_wait(h, c, [&] { return ipc_load(&P.ready) >= k[side]; }, "a neighbour to enter update_halo!"));
+        if (ipc_load(&P.cap) < total)
+            return jrx_fail(h, JRX_ERR_ARG, "ipc transport: the neighbour exchanges %llu values where this rank sends %zu (all ranks must call update_halo! with the same arrays)",
+                            (unsigned long long)ipc_load(&P.cap), total);
+        const uint64_t gen = ipc_load(&P.buf_gen);
+        if (gen != c->peer_gen[dim][side]) {
+            if (c->peer_buf[dim][side]) {
+                JRX_HIP(h, hipStreamSynchronize(h->stream));
+                JRX_HIP(h, hipStreamSynchronize(h->halo_stream));
+                JRX_HIP(h, hipIpcCloseMemHandle(c->peer_buf[dim][side]));
+                c->peer_buf[dim][side] = nullptr;
+            }
+            hipIpcMemHandle_t mh;
+            memcpy(&mh, (const void *)&P.mem, sizeof(mh));
+            void *q = nullptr;
+            JRX_HIP(h, hipIpcOpenMemHandle(&q, mh, hipIpcMemLazyEnablePeerAccess));
+            c->peer_buf[dim][side] = (double *)q;
+            c->peer_gen[dim][side] = gen;
+        }
+        if (k[side] > 1) { wf[side] = &dctl->link[peer][dim][opp].unpacked; wv[side] = k[side] - 1; }     // its previous unpack from that buffer
+    }
+    if (wf[0] || wf[1]) {
+        hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(2), 0, s, (const uint64_t *)wf[0], wv[0], (const uint64_t *)wf[1], wv[1], &dctl->failed, ticks);
+        JRX_LAUNCH_CHECK(h);
+    }
+    uint64_t *pf[2] = {nullptr, nullptr};
+    for (int side = 0; side < 2; side++) {
+        if (nb[side] < 0) continue;
+        JRX_HIP(h, hipMemcpyAsync(c->peer_buf[dim][side], c->sbuf[side], total * sizeof(double), hipMemcpyDeviceToDevice, s));
+        c->stat_bytes_pushed += (int64_t)(total * sizeof(double));
+        pf[side] = &dctl->link[me][dim][side].sent;
+    }
+    hipLaunchKernelGGL(k_ipc_post, dim3(1), dim3(2), 0, s, pf[0], k[0], pf[1], k[1]);
+    JRX_LAUNCH_CHECK(h);
+    // 4. receive: the neighbour's push into my buffer of `side`
+    for (int side = 0; side < 2; side++) {
+        wf[side] = nullptr;
+        if (nb[side] >= 0) { wf[side] = &dctl->link[nb[side]][dim][1 - side].sent; wv[side] = k[side]; }
+    }
+    hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(2), 0, s, (const uint64_t *)wf[0], wv[0], (const uint64_t *)wf[1], wv[1], &dctl->failed, ticks);
+    JRX_LAUNCH_CHECK(h);
+    S.buf[0] = c->irbuf[dim][0]; S.buf[1] = c->irbuf[dim][1];
+    hipLaunchKernelGGL(k_planes, dim3(gx, na * 2), dim3(256), 0, s, S, 1);
+    JRX_LAUNCH_CHECK(h);
+    for (int side = 0; side < 2; side++) pf[side] = nb[side] >= 0 ? &dctl->link[me][dim][side].unpacked : nullptr;
+    hipLaunchKernelGGL(k_ipc_post, dim3(1), dim3(2), 0, s, pf[0], k[0], pf[1], k[1]);
+    JRX_LAUNCH_CHECK(h);
+    guard.ok = true;
+    return JRX_OK;
+}
+
+static void ipc_teardown(jrx_comm_state *c)
+{
+    for (int d = 0; d < 3; d++)
+        for (int q = 0; q < 2; q++) {
+            if (c->peer_buf[d][q]) (void)hipIpcCloseMemHandle(c->peer_buf[d][q]);
+            if (c->irbuf[d][q]) (void)hipFree(c->irbuf[d][q]);
+            c->peer_buf[d][q] = nullptr; c->irbuf[d][q] = nullptr;
+        }
+    if (c->ctl) {
+        (void)__atomic_add_fetch(&c->ctl->left, 1u, __ATOMIC_ACQ_REL);
+        if (c->ctl_registered) (void)hipHostUnregister(c->ctl);
+        (void)munmap(c->ctl, sizeof(IpcCtl));
+        c->ctl = c->ctl_dev = nullptr;
+    }
+    (void)hipGetLastError();
+}
+
 jrx_status jrx_allreduce_sum_host(jrx_handle *h, double *vals, int count) { return jrx_allreduce_host(h, vals, count, 0); }
 
 // op: 0 sum (norm_mpi), 1 max (maximum_mpi)
 jrx_status jrx_allreduce_host(jrx_handle *h, double *vals, int count, int op)
 {
-    if (!jrx_comm_active(h) || !(h->comm->comm || h->comm->grp) || h->comm->cart.nprocs == 1) return JRX_OK;
+    if (!jrx_comm_active(h) || !(h->comm->comm || h->comm->grp || h->comm->ctl) || h->comm->cart.nprocs == 1) return JRX_OK;
     jrx_comm_state *c = h->comm;
     if (count > 8) return jrx_fail(h, JRX_ERR_ARG, "allreduce of more than 8 values");
     if (c->grp) return local_allreduce(h, c, vals, count, op);
+    if (c->ctl) return ipc_allreduce(h, c, vals, count, op);
     JRX_HIP(h, hipMemcpyAsync(c->d_red, vals, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     JRX_NCCL(h, c, c->AllReduce(c->d_red, c->d_red, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, h->stream));
     JRX_HIP(h, hipMemcpyAsync(h->h_sums, c->d_red, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -343,7 +592,7 @@ jrx_status jrx_halo_exchange(jrx_handle *h, hipStream_t s, int narrays, double *
                 if (c->rbuf[q]) JRX_HIP(h, hipFree(c->rbuf[q]));
                 c->sbuf[q] = c->rbuf[q] = nullptr;
                 JRX_HIP(h, hipMalloc(&c->sbuf[q], (size_t)total * sizeof(double)));
-                if (!c->grp) JRX_HIP(h, hipMalloc(&c->rbuf[q], (size_t)total * sizeof(double)));    // the local transport receives per (dimension, side)
+                if (!c->grp && !c->ctl) JRX_HIP(h, hipMalloc(&c->rbuf[q], (size_t)total * sizeof(double)));    // the local / ipc transports receive per (dimension, side)
             }
             c->cap = (size_t)total;
         }
@@ -366,6 +615,11 @@ jrx_status jrx_halo_exchange(jrx_handle *h, hipStream_t s, int narrays, double *
         if (c->grp) {
             const int nb[2] = {left, right};
             JRX_TRY(local_exchange_dim(h, c, s, dim, nb, (size_t)total, S, gx, na));
+            continue;
+        }
+        if (c->ctl) {
+            const int nb[2] = {left, right};
+            JRX_TRY(ipc_exchange_dim(h, c, s, dim, nb, (size_t)total, S, gx, na));
             continue;
         }
         if (!c->comm) return jrx_fail(h, JRX_ERR_RCCL, "update_halo!: no RCCL communicator (jrx_comm_init not called?)");
@@ -483,12 +737,109 @@ jrx_status jrx_comm_init_local(jrx_handle *const *handles, int32_t n, const jrx_
     return JRX_OK;
 }
 
+// id for jrx_comm_init_ipc: 128 bytes that name the group's control segment (rank 0 makes it, the others get it out of band, like the RCCL unique id)
+jrx_status jrx_comm_ipc_id(uint8_t id[JRX_UNIQUE_ID_BYTES])
+{
+    if (!id) return JRX_ERR_ARG;
+    memset(id, 0, JRX_UNIQUE_ID_BYTES);
+    int fd = open("/dev/urandom", O_RDONLY);
+    ssize_t got = fd >= 0 ? read(fd, id, 32) : -1;
+    if (fd >= 0) close(fd);
+    if (got != 32) {
+        uint64_t v[4] = {(uint64_t)getpid(), (uint64_t)time(nullptr), (uint64_t)(now_s() * 1e9), (uint64_t)(uintptr_t)id};
+        memcpy(id, v, 32);
+    }
+    return JRX_OK;
+}
+
+jrx_status jrx_comm_init_ipc(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES], const jrx_cart *cart)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!cart || !id) return jrx_fail(h, JRX_ERR_ARG, "jrx_comm_init_ipc: null argument");
+    if (cart->nprocs < 1 || cart->nprocs > kMaxLocalRanks || cart->rank < 0 || cart->rank >= cart->nprocs)
+        return jrx_fail(h, JRX_ERR_ARG, "jrx_comm_init_ipc: rank %d of %d (1..%d ranks)", cart->rank, cart->nprocs, kMaxLocalRanks);
+    JRX_TRY(jrx_check_device(h));
+    if (h->comm) JRX_TRY(jrx_comm_destroy(h));
+    jrx_comm_state *c = new jrx_comm_state();
+    c->cart = *cart;
+    c->device = h->device;
+    c->ipc_timeout_s = h->comm_timeout_ms * 1e-3;
+    h->comm = c;
+    if (cart->nprocs == 1) return JRX_OK;      // no other rank; a periodic dimension is copied locally, norms are local
+    char name[64];
+    {
+        static const char *hx = "0123456789abcdef";
+        char *q = name;
+        q += snprintf(q, 16, "/jrx_ipc_");
+        for (int i = 0; i < 16; i++) { *q++ = hx[id[i] >> 4]; *q++ = hx[id[i] & 15]; }
+        *q = 0;
+    }
+    const size_t bytes = sizeof(IpcCtl);
+    int fd = -1;
+    const double t0 = now_s();
+    auto fail = [&](const char *what) {
+        if (fd >= 0) close(fd);
+        delete c;
+        h->comm = nullptr;
+        return jrx_fail(h, JRX_ERR_RCCL, "jrx_comm_init_ipc: %s (%s): %s", what, name, strerror(errno));
+    };
+    if (cart->rank == 0) {
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fail("shm_open (create)");
+        if (ftruncate(fd, (off_t)bytes) != 0) return fail("ftruncate");
+    } else {
+        for (int spins = 0;; spins++) {
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat sb;
+                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+                close(fd); fd = -1;
+            }
+            if (now_s() - t0 > c->ipc_timeout_s) { errno = ETIMEDOUT; return fail("shm_open (rank 0 never created the segment)"); }
+            ipc_relax(spins + 2000);
+        }
+    }
+    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) return fail("mmap");
+    close(fd); fd = -1;
+    c->ctl = (IpcCtl *)m;
+    if (cart->rank == 0) {
+        memset(m, 0, bytes);
+        c->ctl->nranks = (uint32_t)cart->nprocs;
+        ipc_store(&c->ctl->magic, kIpcMagic);
+    }
+    jrx_status st = ipc_wait(h, c, [&] { return ipc_load(&c->ctl->magic) == kIpcMagic; }, "rank 0 to initialise the control segment");
+    if (st == JRX_OK && (int)c->ctl->nranks != cart->nprocs) st = jrx_fail(h, JRX_ERR_ARG, "jrx_comm_init_ipc: the segment was made for %u ranks, this cart has %d", c->ctl->nranks, cart->nprocs);
+    if (st == JRX_OK) {
+        c->ctl->device[cart->rank] = h->device;
+        (void)__atomic_add_fetch(&c->ctl->attached, 1u, __ATOMIC_ACQ_REL);
+        st = ipc_wait(h, c, [&] { return (int)ipc_load(&c->ctl->attached) >= cart->nprocs; }, "every rank to attach");
+    }
+    if (cart->rank == 0) (void)shm_unlink(name);     // every rank has it mapped (or the group failed): the name can go
+    if (st == JRX_OK) {
+        // the flags are polled and posted by device kernels: pin the segment and map it into the device's address space
+        hipError_t e = hipHostRegister(c->ctl, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+        if (e == hipSuccess) { c->ctl_registered = true; e = hipHostGetDevicePointer((void **)&c->ctl_dev, c->ctl, 0); }
+        if (e != hipSuccess) st = jrx_fail(h, JRX_ERR_HIP, "jrx_comm_init_ipc: registering the control segment with HIP -> %s", hipGetErrorString(e));
+    }
+    if (st != JRX_OK) {
+        ipc_store(&c->ctl->failed, 1u);
+        ipc_teardown(c);
+        delete c;
+        h->comm = nullptr;
+        return st;
+    }
+    return JRX_OK;
+}
+
 jrx_status jrx_comm_count(jrx_handle *h, int32_t *count)
 {
     if (!h) return JRX_ERR_ARG;
     if (!count) return jrx_fail(h, JRX_ERR_ARG, "jrx_comm_count: count is NULL");
     *count = 0;
     if (h->comm && h->comm->grp) { *count = h->comm->grp->n; return JRX_OK; }
+    if (h->comm && h->comm->ctl) { JRX_TRY(ipc_check(h, h->comm)); *count = (int32_t)ipc_load(&h->comm->ctl->attached); return JRX_OK; }
     if (!h->comm || !h->comm->comm) return JRX_OK;
     int n = 0;
     JRX_NCCL(h, h->comm, h->comm->CommCount(h->comm->comm, &n));
@@ -522,6 +873,7 @@ jrx_status jrx_comm_destroy(jrx_handle *h)
                 if (c->lrbuf[d][q]) (void)hipFree(c->lrbuf[d][q]);
             }
     }
+    if (c->ctl) ipc_teardown(c);     // the streams are idle: every copy into my buffers was unpacked, every copy of mine has completed
     for (int q = 0; q < 2; q++) {
         if (c->sbuf[q]) (void)hipFree(c->sbuf[q]);
         if (c->rbuf[q]) (void)hipFree(c->rbuf[q]);
@@ -538,6 +890,7 @@ jrx_status jrx_update_halo(jrx_handle *h, int32_t narrays, double *const *arrays
     if (!arrays || !ext || !n) return jrx_fail(h, JRX_ERR_ARG, "update_halo!: null argument");
     JRX_TRY(jrx_halo_exchange(h, h->stream, narrays, arrays, ext, n));
     JRX_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->comm && h->comm->ctl) JRX_TRY(ipc_check(h, h->comm));      // a device-side wait that timed out leaves garbage in the ghost planes
     return JRX_OK;
 }
 

@@ -128,7 +128,7 @@ int find_opt(jrx_handle *h, const char *key, bool tuning, OptRef *out)
         {"b_width_x", 1, &h->b_width_opt[0]}, {"b_width_y", 1, &h->b_width_opt[1]}, {"b_width_z", 1, &h->b_width_opt[2]},
         {"halo_self_rccl", 0, &h->halo_self_rccl}, {"thermal_cfg", 1, &h->thermal_cfg}, {"thermal_xg", 1, &h->thermal_xg},
         {"fused2d", 0, &h->fused2d}, {"vep3_edges", 1, &h->vep3_edges}, {"vep3_cfg", 1, &h->vep3_cfg}, {"vep3_peel", 0, &h->vep3_peel}, {"vep3_peel_fork", 0, &h->vep3_peel_fork}, {"vep3_nt", 0, &h->vep3_nt}, {"vep3_prekz", 1, &h->vep3_prekz},
-        {"vep3_hide_comm", 1, &h->vep3_hide_comm}, {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"comm_timeout_ms", 1, &h->comm_timeout_ms}, {"vep_store_all", 0, &h->vep_store_all},
+        {"vep3_hide_comm", 1, &h->vep3_hide_comm}, {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"comm_timeout_ms", 1, &h->comm_timeout_ms}, {"vep_store_all", 0, &h->vep_store_all}, {"chain_profile", 0, &h->chain_profile},
     };
     if (tuning) {
         for (const OptRef &o : tun)
@@ -170,6 +170,14 @@ jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value) { retur
 jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value) { return opt_get(h, key, value, false, "jrx_get_option"); }
 jrx_status jrx_tuning_set(jrx_handle *h, const char *key, int64_t value) { return opt_set(h, key, value, true, "jrx_tuning_set"); }
 jrx_status jrx_tuning_get(jrx_handle *h, const char *key, int64_t *value) { return opt_get(h, key, value, true, "jrx_tuning_get"); }
+jrx_status jrx_tuning_chain_profile(jrx_handle *h, double out_us[8], int64_t *samples)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!out_us || !samples) return jrx_fail(h, JRX_ERR_ARG, "jrx_tuning_chain_profile: null argument");
+    for (int q = 0; q < 8; q++) out_us[q] = h->chain_us[q];
+    *samples = h->chain_n;
+    return JRX_OK;
+}
 
 // ---------------------------------------------------------------- block decomposition (host only)
 int64_t jrx_n_global(int64_t n, int32_t dims, int32_t periodic)

@@ -63,6 +63,9 @@ struct jrx_handle {
     //      prove which kernel path ran
     int64_t stat_fused3d_visc = 0, stat_visc_checks = 0, stat_visc_fallbacks = 0;     // launches of the viscous-limit form of k_fused3d; operand checks run / failed
     int64_t stat_fused3d = 0, stat_fused2d = 0, stat_thermal_fused = 0, stat_vep3_fused = 0, stat_graph_replays = 0;
+    bool chain_profile = false;          // tuning switch: jrx_stokes3d_iterate_timed also times the stages of a multi-rank fused step (jrx_tuning_chain_profile)
+    double chain_us[8] = {};
+    int64_t chain_n = 0;
     int comm_timeout_ms = 120000;        // in-process transport: how long a rank waits on the host for a neighbour before it reports an error
     char err[512] = {0};
 };

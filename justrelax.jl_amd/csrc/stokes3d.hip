@@ -622,7 +622,8 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
 // [3] (fused only) directly after k_fused3d, so that [1] -> [3] is that kernel alone
 static inline int imin(int a, int b) { return a < b ? a : b; }
 // ncells_timed (optional): the number of cells whose stresses the launch timed by tev[1] -> tev[3] updates
-static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *tev, int *was_fused, double *ncells_timed = nullptr)
+// cev (optional, tuning switch "chain_profile"): six events around the stages of a multi-rank fused step, *chain_mode = 1 (exchange in order) / 2 (early exchange)
+static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *tev, int *was_fused, double *ncells_timed = nullptr, hipEvent_t *cev = nullptr, int *chain_mode = nullptr)
 {
     jrx_handle *h = I.h;
     const jrx_stokes3d_params *p = I.p;
@@ -630,6 +631,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
     hipStream_t s = h->stream;
     SweepArgs a = make_args(&I.cur, I.etatau, p);
     if (was_fused) *was_fused = 0;
+    if (chain_mode) *chain_mode = 0;
     if (ncells_timed) *ncells_timed = (double)nx * ny * nz;
     if (tev) JRX_HIP(h, hipEventRecord(tev[0], s));
     if (!I.stress_done) JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
@@ -717,13 +719,16 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                 if (L0) JRX_TRY(launch_velocity(h, bs, a, false, 0, xa, y0, y1, z0, z1));
                 if (H0) JRX_TRY(launch_velocity(h, bs, a, false, nx - xa, nx, y0, y1, z0, z1));
             }
+            if (cev) JRX_HIP(h, hipEventRecord(cev[0], bs));
             JRX_TRY(fused_bcs(bs));
+            if (cev) JRX_HIP(h, hipEventRecord(cev[1], bs));
             {
                 double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
                 const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
                 const int64_t n[3] = {nx, ny, nz};
                 JRX_TRY(jrx_halo_exchange(h, bs, 3, arrs, ext, n));
             }
+            if (cev) JRX_HIP(h, hipEventRecord(cev[2], bs));
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
             JRX_TRY(launch_fused(h, s, a, bc, all));
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
@@ -741,6 +746,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                 }
                 JRX_TRY(launch_bcs_faces(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip & fs_keep, p->no_slip & ns_keep));
             }
+            if (cev) { JRX_HIP(h, hipEventRecord(cev[3], s)); if (chain_mode) *chain_mode = 2; }
             for (int d = 0; d < 3; d++) { nb[d][0] = jrx_comm_has_neighbor(h, d, 0); nb[d][1] = jrx_comm_has_neighbor(h, d, 1); }
         } else if (!comm || !overlap) {
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
@@ -751,6 +757,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             // preceded by a flow_bcs! launch of its own.  With neighbours the exchange ships those entries, so they must be in memory.
             if (comm || per) JRX_TRY(fused_bcs(s));
             else I.ghosts_stale = true;
+            if (cev && comm) JRX_HIP(h, hipEventRecord(cev[1], s));
             if (per) {
                 const uint32_t lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_BOT}, hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_TOP};
                 for (int d = 0; d < 3; d++) { nb[d][0] = (p->periodic & lo[d]) != 0; nb[d][1] = (p->periodic & hi[d]) != 0; }
@@ -762,6 +769,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                 const int64_t n[3] = {nx, ny, nz};
                 JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, n));
                 for (int d = 0; d < 3; d++) { nb[d][0] |= jrx_comm_has_neighbor(h, d, 0); nb[d][1] |= jrx_comm_has_neighbor(h, d, 1); }
+                if (cev) { JRX_HIP(h, hipEventRecord(cev[2], s)); if (chain_mode) *chain_mode = 1; }
             }
         } else {
             // The role of @hide_communication (Stokes3D.jl:104-121) for the fused kernel: the shell of tiles that touches a face of
@@ -1022,8 +1030,9 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     // kernels run on); at most 256 samples so that event bookkeeping stays negligible
     const int64_t stride = iters > 256 ? (iters + 255) / 256 : 1;
     const int nsamp = (int)((iters + stride - 1) / stride);
-    std::vector<hipEvent_t> evs((size_t)nsamp * 4);
-    std::vector<int> fused((size_t)nsamp, 0);
+    const bool chain = h->chain_profile && jrx_comm_active(h);
+    std::vector<hipEvent_t> evs((size_t)nsamp * (chain ? 8 : 4));
+    std::vector<int> fused((size_t)nsamp, 0), cmode((size_t)nsamp, 0);
     std::vector<double> ncell((size_t)nsamp, 0.0);
     // the events are destroyed on every exit path
     struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (auto &e : v) if (e) (void)hipEventDestroy(e); } } guard{evs};
@@ -1039,8 +1048,9 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     for (int64_t it = 0; it < iters; it++) {
         const bool samp = it % stride == 0;
         const bool fuse_next = it + 1 < iters && !(first_unfused && it == 0);
-        JRX_TRY(iter_step(I, false, fuse_next, samp ? &evs[(size_t)(it / stride) * 4] : nullptr, samp ? &fused[(size_t)(it / stride)] : nullptr,
-                          samp ? &ncell[(size_t)(it / stride)] : nullptr));
+        const size_t q = (size_t)(it / stride);
+        JRX_TRY(iter_step(I, false, fuse_next, samp ? &evs[q * 4] : nullptr, samp ? &fused[q] : nullptr, samp ? &ncell[q] : nullptr,
+                          samp && chain ? &evs[(size_t)nsamp * 4 + q * 4] : nullptr, samp && chain ? &cmode[q] : nullptr));
     }
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_TRY(iter_end(I));
@@ -1064,6 +1074,29 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
         }
         else { sb += m2; nb++; }
         if (m1 > 1e-3f) { sa += m1; na++; }      // a stress sweep ran as its own launch in this iteration
+    }
+    if (chain) {
+        // the rank's chain per fused iteration, microseconds: [0] k_fused3d, [1] boundary-slab velocity launches, [2] flow_bcs! before the exchange, [3] update_halo!(V)
+        // (pack, transport, waits for the neighbour, unpack), [4] flow_bcs! behind the join, [5] stress fix-up, [6] whole step, [7] what the step takes beyond the kernel
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int nc = 0;
+        auto el = [&](hipEvent_t a, hipEvent_t b) { float m = 0.f; (void)hipEventElapsedTime(&m, a, b); return (double)m * 1e3; };
+        for (int q = 0; q < nsamp; q++) {
+            if (!fused[q] || !cmode[q]) continue;
+            hipEvent_t *t = &evs[(size_t)q * 4], *c = &evs[(size_t)nsamp * 4 + (size_t)q * 4];
+            const double step = el(t[1], t[2]), kern = el(t[1], t[3]);
+            if (cmode[q] == 2) {
+                const double post = fmin(el(t[3], c[3]), el(c[2], c[3]));       // flow_bcs! starts when both the kernel and the exchange are done
+                acc[0] += kern; acc[1] += el(t[1], c[0]); acc[2] += el(c[0], c[1]); acc[3] += el(c[1], c[2]); acc[4] += post; acc[5] += el(c[3], t[2]);
+            } else {
+                acc[0] += kern; acc[2] += el(t[3], c[1]); acc[3] += el(c[1], c[2]); acc[5] += el(c[2], t[2]);
+            }
+            acc[6] += step; acc[7] += step - kern;
+            nc++;
+        }
+        for (int q = 0; q < 8; q++) h->chain_us[q] = nc ? acc[q] / nc : 0.0;
+        h->chain_n = nc;
+        (void)hipGetLastError();
     }
     if (na) times_ms[1] = sa / na;
     if (nb) times_ms[2] = sb / nb;

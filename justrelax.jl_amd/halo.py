@@ -56,6 +56,26 @@ def init_comm(handle=None, group=None, self_rccl=False):
     return h
 
 
+def init_comm_ipc(handle=None, group=None, cart=None):
+    """jrx_comm_init_ipc: one process per rank on one node, packed planes pushed into the neighbour process's receive buffer by copy engines (IPC memory
+    handles), ordered by flags in a shared-memory segment.  The 128 bytes that name the segment travel like the RCCL id (torch.distributed here, MPI.Bcast
+    in the Julia extension).  `cart`: defaults to the current global grid's."""
+    import torch.distributed as dist
+    h = handle or _lib.default_handle()
+    cart = cart or make_cart(global_grid())
+    uid = (C.c_uint8 * _lib.UNIQUE_ID_BYTES)()
+    if cart.nprocs > 1:
+        if cart.rank == 0:
+            st = h.lib.jrx_comm_ipc_id(uid)
+            if st != 0:
+                raise _lib.JrxError(st, "jrx_comm_ipc_id failed")
+        obj = [bytes(uid) if cart.rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0, group=group)
+        uid = (C.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(obj[0])
+    h.call("jrx_comm_init_ipc", uid, C.byref(cart))
+    return h
+
+
 def make_carts(n, dims, periods=(0, 0, 0)):
     """The carts of every rank of a `dims` process grid of local blocks of `n` cells (host logic only)."""
     L = _lib.load()

@@ -3,6 +3,8 @@ MASTER_* set before anything touches a GPU, rank 0's JSON line relayed, non-zero
 Reference equivalent: `mpiexec -n 2` in test/runtests.jl:73-90."""
 import json
 import os
+
+import pytest
 import subprocess
 import sys
 from pathlib import Path
@@ -45,6 +47,75 @@ def test_rank_refuses_mismatched_world():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=120)
     # with WORLD_SIZE set the script is one rank of an externally launched job (torch.distributed.run): it does not spawn
     assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1])["world"] == 3
+
+
+def _dry_transports(extra_args=(), env_extra=None, torchrun=False, timeout=180):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    bench_args = ["--gpus", "2", "--dry-transports", "--steps", "4", "--warmup", "1", "--leg-steps", "4", *extra_args]
+    if torchrun:        # how the driver starts N > 1
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               str(ROOT / "bench.py"), *bench_args]
+    else:
+        cmd = [sys.executable, str(ROOT / "bench.py"), *bench_args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def _check_leg(leg, world=2):
+    import bench
+    assert leg["it_per_s"] > 0 and leg["ms_per_step"] > 0 and 0 < leg["efficiency_vs_n1"]
+    per = leg["chain_us_per_rank"]
+    assert len(per) == world
+    for d in per:
+        assert set(bench.CHAIN_KEYS) <= set(d) and d["samples"] > 0
+
+
+@pytest.mark.parametrize("torchrun", [False, True])
+def test_two_rank_line_carries_every_transport_and_both_decompositions(torchrun):
+    """`bench.py --gpus N` (self-launched or under torch.distributed.run, as the driver starts it) prints ONE line whose `value` is the default
+    transport (RCCL ranks) and which also carries `transports.{rccl, ipc, local_peer}` -- each with it_per_s, efficiency_vs_n1 and a per-rank chain breakdown -- and an
+    `alt_decomposition` leg on the faster process-per-GPU transport.  The control flow (connects, barriers, gathers between two gloo ranks) is the real one; the
+    kernels are sleeps (`--dry-transports`), so this runs without a GPU.  Reference: mpiexec -n 2, test/runtests.jl:73-90; docs/paper/paper.md:78-80."""
+    sys.path.insert(0, str(ROOT))
+    r, lines = _dry_transports(torchrun=torchrun)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["default_transport"] == "rccl" and out["scaling"] == "weak" and out["steps"] == 4
+    tr = out["transports"]
+    assert set(tr) == {"rccl", "ipc", "local_peer"}
+    assert tr["rccl"]["ranks"] == 2 and tr["ipc"]["ranks"] == 2 and tr["local_peer"]["handles"] == 2
+    assert tr["rccl"]["it_per_s"] == out["value"]
+    for k in tr:
+        _check_leg(tr[k])
+    alt = out["alt_decomposition"]
+    assert alt["decomposition"] == [1, 1, 2] and out["config"]["decomposition"] == [2, 1, 1] and alt["transport"] in ("rccl", "ipc")
+    _check_leg(alt)
+    _check_leg(alt["local_peer"])
+    assert out["n1_reference"]["it_per_s"] > 0 and "extras_incomplete" not in out
+
+
+def test_a_transport_that_fails_on_one_rank_becomes_an_error_entry():
+    r, lines = _dry_transports(env_extra={"JRX_DRY_FAIL": "ipc"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(lines[-1])
+    assert len(lines) == 1 and "refused" in out["transports"]["ipc"]["error"]
+    assert out["transports"]["rccl"]["it_per_s"] > 0 and out["transports"]["local_peer"]["it_per_s"] > 0 and out["alt_decomposition"]["transport"] == "rccl"
+
+
+def test_a_leg_that_hangs_does_not_lose_the_headline():
+    """the legs behind the headline run under a time budget: rank 0 prints the line it has, marked, and every rank leaves"""
+    r, lines = _dry_transports(extra_args=["--extras-budget", "6"], env_extra={"JRX_DRY_FAIL": "hang:ipc"}, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(lines[-1])
+    assert len(lines) == 1 and out["value"] > 0 and "ipc" in out["extras_incomplete"] and "ipc" not in out["transports"]
 
 
 class _FakeHandle:
