@@ -152,6 +152,10 @@ def parse_args(argv=None):
     ap.add_argument("--extras-budget", type=float, default=600.0, help="N > 1: seconds the legs behind the headline may take before rank 0 prints the line it has and every rank leaves")
     ap.add_argument("--dry-transports", action="store_true",
                     help="test hook: the N > 1 control flow (legs, barriers, gathers, watchdog) with sleeps instead of kernels -- no GPU is touched")
+    ap.add_argument("--same-device", action="store_true",
+                    help="diagnostic for one-GPU boxes: every rank of an N > 1 run uses device 0 (RCCL refuses that, so combine with --default-transport ipc); exercises the whole "
+                         "N > 1 control flow, the ipc and local_peer transports and both decompositions on one device")
+    ap.add_argument("--default-transport", choices=["rccl", "ipc"], default="rccl", help="N > 1: the transport of the headline leg (`value`); the others are reported under `transports`")
     ap.add_argument("--ipc-helper", action="store_true", help="internal: one of the two parked rank processes of the multi_rank_path leg (see start_ipc_helpers)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="test hook: the ranks only report their launch environment (no GPU is touched, the device-count check is skipped)")
@@ -186,7 +190,7 @@ def launch_ranks(args, argv) -> int:
         have = visible_gpus()
         if have < 0:
             return 2                      # the probe itself failed: its message says why
-        if have < n:
+        if have < (1 if args.same_device else n):
             sys.stderr.write(f"bench.py: {n} GPUs requested, {have} visible\n")
             return 2
     env0 = dict(os.environ)
@@ -808,11 +812,12 @@ def local_peer_leg(jr, args, world, mode, steps, warm, n1_rate=None):
     n = args.n
     d = YZ_DIMS.get(world, (1, 1, world)) if mode == "yz" else None
     cur = torch.cuda.current_device()
+    devs = [0] * world if args.same_device else list(range(world))
     hs, blocks = [], []
     try:
         for r in range(world):
-            torch.cuda.set_device(r)
-            hs.append(_lib.Handle(r))
+            torch.cuda.set_device(devs[r])
+            hs.append(_lib.Handle(devs[r]))
         torch.cuda.set_device(cur)
         grid.finalize_global_grid()
         if d:
@@ -822,7 +827,7 @@ def local_peer_leg(jr, args, world, mode, steps, warm, n1_rate=None):
         dims = tuple(grid.global_grid().dims)
         halo.init_comm_local(hs, halo.make_carts((n, n, n), dims))
         for r in range(world):
-            torch.cuda.set_device(r)
+            torch.cuda.set_device(devs[r])
             grid.finalize_global_grid()
             grid.init_global_grid(n, n, n, rank=r, nprocs=world, dimx=dims[0], dimy=dims[1], dimz=dims[2])
             st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
@@ -833,14 +838,14 @@ def local_peer_leg(jr, args, world, mode, steps, warm, n1_rate=None):
 
         def on(r, fn):
             def f():
-                torch.cuda.set_device(r)          # the current device is a property of the host thread
+                torch.cuda.set_device(devs[r])    # the current device is a property of the host thread
                 return fn()
             return f
         halo.run_ranks([on(r, lambda r=r: halo.update_halo_(blocks[r][0].V.Vx, blocks[r][0].V.Vy, blocks[r][0].V.Vz, blocks[r][7], ni=(n, n, n), handle=hs[r])) for r in range(world)])
 
         def sync_all():
-            for r in range(world):
-                torch.cuda.synchronize(r)
+            for dv in set(devs):
+                torch.cuda.synchronize(dv)
         batch = lambda k: halo.run_ranks([on(r, lambda r=r: stokes.iterate_timed_(*blocks[r], k, handle=hs[r])) for r in range(world)])
         batch(warm)
         sync_all()
@@ -848,7 +853,7 @@ def local_peer_leg(jr, args, world, mode, steps, warm, n1_rate=None):
         batch(steps)
         sync_all()
         el = time.perf_counter() - t0
-        leg = {"handles": world, "devices": list(range(world)), "steps": steps, "decomposition": list(dims), "it_per_s": world * steps / el, "ms_per_step": el / steps * 1e3,
+        leg = {"handles": world, "devices": devs, "steps": steps, "decomposition": list(dims), "it_per_s": world * steps / el, "ms_per_step": el / steps * 1e3,
                "pushed_by": "hipMemcpyPeerAsync between the handles of one process, ordered by events"}
         if n1_rate:
             leg["efficiency_vs_n1"] = (steps / el) / n1_rate
@@ -910,17 +915,19 @@ def multi_rank_extras(R, ctl, args, out, local_peer, wd):
     ctl.barrier()
     n1 = ctl.max([n1 or 0.0])[0]
     out["n1_reference"] = {"it_per_s": n1, "what": "rank 0's block alone, no communicator, same allocations, the other ranks idle"}
-    if "it_per_s" in tr["rccl"]:
-        tr["rccl"]["efficiency_vs_n1"] = (tr["rccl"]["it_per_s"] / ctl.world) / n1
-    wd.where = "rccl chain profile"
+    T0 = out["default_transport"]
+    T1 = "ipc" if T0 == "rccl" else "rccl"
+    if "it_per_s" in tr[T0]:
+        tr[T0]["efficiency_vs_n1"] = (tr[T0]["it_per_s"] / ctl.world) / n1
+    wd.where = f"{T0} chain profile"
     try:
-        R.connect("rccl")
+        R.connect(T0)
         ch = R.chain(12)
     except Exception as e:      # noqa: BLE001
         ch = {"error": f"{type(e).__name__}: {e}"}
-    tr["rccl"]["chain_us_per_rank"] = ctl.gather(ch)
-    wd.where = "ipc"
-    tr["ipc"] = collective_leg(R, ctl, "ipc", steps, warm, n1)
+    tr[T0]["chain_us_per_rank"] = ctl.gather(ch)
+    wd.where = T1
+    tr[T1] = collective_leg(R, ctl, T1, steps, warm, n1)
     R.disconnect()
     ctl.barrier()
     wd.where = "local_peer"
@@ -1139,6 +1146,8 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
         from __graft_entry__ import load_package
         jr = load_package()
         import justrelax_jl_amd.grid as grid
+        if args.same_device:
+            local_rank = 0
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit(f"bench.py: rank {rank} needs device {local_rank}, {torch.cuda.device_count()} visible")
         torch.cuda.set_device(local_rank)
@@ -1150,10 +1159,11 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
             R.h.set_option(k, int(v))
         local_peer = lambda w, mode, steps, warm, n1: local_peer_leg(jr, args, w, mode, steps, warm, n1)
     dims = R.build(args.dims)
-    R.connect("rccl")
+    T0 = args.default_transport
+    R.connect(T0)
     ranks = R.comm_count()
     if ranks != world:
-        raise SystemExit(f"bench.py: RCCL communicator has {ranks} ranks, expected {world}")
+        raise SystemExit(f"bench.py: the {T0} communicator has {ranks} ranks, expected {world}")
     if not args.dry_transports:
         pr = pricing(R.h, R.blk[8])
         f0 = [R.h.get_option("stat_fused3d"), R.h.get_option("stat_fused3d_visc")]
@@ -1189,14 +1199,16 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"SolVi3D {n}^3 per GPU (configs[3]: 512^3 per GPU, weak scaling): eta inclusion 1e-3, G=1, K=Inf, dt=Inf, free-slip, pure shear",
                    "kernel_form": pr["form"], "local_grid": [n, n, n], "global_grid": [d * (n - 2) + 2 for d in dims], "decomposition": list(dims),
-                   "halo": "RCCL send/recv (the default transport; the others are under `transports`)"},
-        "rccl_ranks": ranks, "default_transport": "rccl",
+                   "halo": {"rccl": "RCCL send/recv", "ipc": "copy engines between processes (IPC memory handles)"}[T0] + " (the default transport; the others are under `transports`)",
+                   **({"same_device": "diagnostic: every rank on device 0"} if args.same_device else {})},
+        "rccl_ranks": ranks if T0 == "rccl" else 0, "default_transport": T0,
         "global_iterations_per_s": it_per_s,
         "bytes_per_cell_priced": pr["alg"], "effective_GBps": pr["alg"] * cells * value / 1e9,
         "device_ms_per_step": tot_ms / args.steps,
         "roofline": None,
-        "transports": {"rccl": {"ranks": ranks, "steps": args.steps, "it_per_s": value, "ms_per_step": el / args.steps * 1e3, "decomposition": list(dims),
-                                "pipeline": R.pipeline(), "what": "the headline leg: one process per GPU, grouped ncclSend/ncclRecv per dimension"}},
+        "transports": {T0: {"ranks": ranks, "steps": args.steps, "it_per_s": value, "ms_per_step": el / args.steps * 1e3, "decomposition": list(dims),
+                            "pipeline": R.pipeline(), "what": "the headline leg: one process per GPU, " + {"rccl": "grouped ncclSend/ncclRecv per dimension",
+                                                                                                           "ipc": "planes pushed into the neighbour process's buffer by copy engines"}[T0]}},
     }
     it_gbs = pr["alg"] * cells * (args.steps / (tot_ms * 1e-3)) / 1e9
     if sf_ms > 0.0:

@@ -4,6 +4,8 @@
  *
  * Keys (int64 values):
  *   "fused_ylds" (default 1)      3D fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form)
+ *   "fused_hiface" (1)            3D fused kernel, viscous-limit form, no neighbours: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel
+ *                                 (0: by the boundary-layer launch behind it)
  *   "fused_tile" (2)              3D fused kernel tile: 0 = 64 x 4 threads, 1 = 32 x 8, 2 = chosen by nx (32 x 8 for nx = 63 .. 90, where three 32-lane tiles replace two 64-lane ones)
  *   "fused_split" (0)             no neighbours: high-face tiles + boundary stress layers forked onto the halo stream
  *   "b_width_x/y/z" (0)           > 0 overrides jrx_stokes3d_params.b_width of the split sweeps

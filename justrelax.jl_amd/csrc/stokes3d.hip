@@ -572,7 +572,7 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
 
 // launch the fused kernel over the box of tiles [b[0], b[1]) x [b[2], b[3]) x [b[4], b[5])
 template <int TX, int TY, int KZ>
-static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface)
+static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface, bool fold)
 {
     // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
     // fetched array passes per launch at 512^3)
@@ -583,7 +583,9 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     // the general kernel.  (Its lower register need -- 111 VGPRs -- leaves room to carry the previous velocity / η planes in registers
     // instead of the third LDS slot: LOWREG off, -1.4 %, scripts/kbench_visc.hip)
     const bool visc = h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
-    if (visc && hiface)
+    if (visc && fold)       // + the high-face node layers inside the kernel: the whole iteration in one launch
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+    else if (visc && hiface)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 1, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
@@ -603,18 +605,23 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     if (visc) h->stat_fused3d_visc++;
     return JRX_OK;
 }
-static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false)
+// can this launch also update the high-face node layers (k_fused3d<..., HIF>)?  Only the viscous-limit form over all tiles of a block without neighbours has them
+static bool fused_folds_hiface(const jrx_handle *h, const SweepArgs &a)
+{
+    return h->fused_hiface && h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
+}
+static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false, bool fold = false)
 {
     const FusedShape S = fused_shape(h, a.L);
     const int kz = S.kz;
     if (S.tx == 64) {
-        if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface);
-        if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface);
-        return launch_fused_t<64, 4, 2>(h, s, a, bc, b, hiface);
+        if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface, fold);
+        if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface, fold);
+        return launch_fused_t<64, 4, 2>(h, s, a, bc, b, hiface, fold);
     }
-    if (kz == 8) return launch_fused_t<32, 8, 8>(h, s, a, bc, b, hiface);
-    if (kz == 4) return launch_fused_t<32, 8, 4>(h, s, a, bc, b, hiface);
-    return launch_fused_t<32, 8, 2>(h, s, a, bc, b, hiface);
+    if (kz == 8) return launch_fused_t<32, 8, 8>(h, s, a, bc, b, hiface, fold);
+    if (kz == 4) return launch_fused_t<32, 8, 4>(h, s, a, bc, b, hiface, fold);
+    return launch_fused_t<32, 8, 2>(h, s, a, bc, b, hiface, fold);
 }
 
 // tev (optional): events recorded around the sweeps: [0] start, [1] after the stress sweep (if one was launched),
@@ -647,6 +654,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.fsL = !!(fs & JRX_FACE_LEFT); bc.nsL = !!(ns & JRX_FACE_LEFT); bc.fsF = !!(fs & JRX_FACE_FRONT); bc.nsF = !!(ns & JRX_FACE_FRONT);
         bc.fsK0 = !!(fs & JRX_FACE_TOP);  bc.nsK0 = !!(ns & JRX_FACE_BOT);     // k = 1: free_slip `top`, no_slip `bot` (reference naming)
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
+        bc.fsR = !!(fs & JRX_FACE_RIGHT); bc.fsBk = !!(fs & JRX_FACE_BACK); bc.fsK1 = !!(fs & JRX_FACE_BOT);       // k = end: free_slip `bot`
         // 256 threads per tile, 8 planes per chunk (128 VGPRs -> 4 blocks/CU)
         int nt[3];
         const FusedShape S = fused_shape(h, a.L);
@@ -664,6 +672,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             return launch_bcs(h, st, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic);
         };
         bool nb[3][2] = {};
+        bool folded = false;           // the kernel has updated the high-face node layers itself: nothing is left behind it
         // option "fused_overlap" = 1: shell of tiles + BCs + exchange on the halo stream, interior tiles concurrently (see below).  Off by
         // default: measured on one device (periodic self neighbour through RCCL, profiles/r01_selfhalo_overlap_*.txt) the RCCL
         // send/recv kernel does not finish before the interior kernel drains, so nothing is hidden and the six small shell launches
@@ -750,7 +759,8 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             for (int d = 0; d < 3; d++) { nb[d][0] = jrx_comm_has_neighbor(h, d, 0); nb[d][1] = jrx_comm_has_neighbor(h, d, 1); }
         } else if (!comm || !overlap) {
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
-            JRX_TRY(launch_fused(h, s, a, bc, all));
+            folded = !comm && !per && fused_folds_hiface(h, a);
+            JRX_TRY(launch_fused(h, s, a, bc, all, false, folded));
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
             // Without neighbours no flow_bcs! launch is needed here: the fused kernel and the boundary-layer launch below derive the
             // boundary entries of V by rule, and every path that reads them from memory (un-fused sweeps, results handed back) is
@@ -818,7 +828,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                                ty(JRX_FACE_BACK, JRX_FACE_BACK), ty(JRX_FACE_TOP, JRX_FACE_BOT), ty(JRX_FACE_BOT, JRX_FACE_TOP)};
             for (int q = 0; q < 6; q++) gr.t[q] = t6[q];
         }
-        JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false, (comm || per) ? nullptr : &gr));
+        if (!folded) JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false, (comm || per) ? nullptr : &gr));
         if (bs != s) {
             JRX_HIP(h, hipEventRecord(h->ev[2], bs));
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));

@@ -651,8 +651,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs 
 // regular BC kernels have run on the new V.  Periodic faces and multi-rank halos are not fused.
 // ================================================================================================
 struct FusedBC {
-    // low faces: free-slip / no-slip flags; high faces: only "normal velocity = 0" matters here
-    int fsL, nsL, fsF, nsF, fsK0, nsK0, nsR, nsBk, nsK1;
+    // low faces: free-slip / no-slip flags; high faces: "normal velocity = 0" for the cells, the free-slip flags for the folded high-face node layers (HIF)
+    int fsL, nsL, fsF, nsF, fsK0, nsK0, nsR, nsBk, nsK1, fsR, fsBk, fsK1;
 };
 
 // OVX: x-overlap of neighbouring tiles in cells (1, or 16 = one 128-B line so that row segments stay line-aligned; only
@@ -672,13 +672,17 @@ struct FusedBC {
 // and 10 written arrays per launch instead of 25 and 10.  The arithmetic is the general one with those factors set to 0.
 // TAG: only gives the launches over the high-face tiles (halo stream, see iter_step) a kernel name of their own, so that a profile
 // separates them from the launch over the interior tiles.
-template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false>
+// HIF (viscous-limit form, no neighbours): the stress nodes on the high faces i = nx, j = ny, k = nz -- which no cell column owns and which the boundary-layer launch
+// (k_stress3d_boxes with the flow_bcs! rules) otherwise updates behind this kernel -- are updated here by the threads of the last cell column / row / plane, from the
+// new velocities they hold anyway and the same rules (GhostRule), operation for operation as stress3d_node<false, true, true>: one launch per iteration.
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false>
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0)
 {
     // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
     static_assert(!(SHFL && (LATEA || (TX != 64 && TX != 32))), "SHFL is implemented for rows of one wave or half a wave");
     static_assert(!YLDS || SHFL, "YLDS builds on the SHFL operand layout");
     static_assert(!VISC || YLDS, "the viscous-limit form is built on the YLDS operand layout");
+    static_assert(!HIF || (VISC && !LOWREG && SHFL && OVX == 1), "the folded high-face layers are built for the viscous-limit form with carried planes");
     constexpr int NS = LOWREG ? 3 : 2;
     __shared__ double sV[NS][3][TY][TX];
     __shared__ double sY[YLDS ? (VISC ? 7 : 8) : 1][YLDS ? TY : 1][YLDS ? TX : 1];
@@ -735,12 +739,14 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     // stress-sweep carries
     double a_p = 0, b_p = 0, c_p = 0, cx_p = 0, cy_p = 0, e_p = 0, ex_p = 0, ey_p = 0, g_p = 0, gx_p = 0, gy_p = 0;
     double exe_p = 0, eye_p = 0, gxg_p = 0, gyg_p = 0;      // LOWREG: (ex_p + e_p), (ey_p + e_p), same for G
+    double vax_p = 0, vby_p = 0;                            // HIF: the previous plane of Vx[nx, j+1, ·] / Vy[i+1, ny, ·] (last cell column / row only)
 
     for (int k = kfirst; k < kend; ++k) {
         const bool hz = k < nz - 1;
         const bool live = k >= kb;                 // false only on the prologue plane below the chunk
         const int slot = LOWREG ? k % 3 : (k & 1);
         double vxn = 0, vyn = 0, vzn = 0, txx_c = 0, tyy_c = 0, P_k = Pc, tzz_k = tzz_c, s01k = s01p, r01k = r01p;
+        const double s10k = s10, r10k = r10;       // HIF: the old τxz[i+1, j, k] / τyz[i, j+1, k] (s10 / r10 move on to plane k + 1 in the velocity phase)
         // stress-sweep operands that do not depend on the new velocities: issued before the barrier so that
         // one memory round trip per plane serves both phases
         double e = 0, ex = 0, ey = 0, exy_ = 0, g = 0, gx = 0, gy = 0, gxy = 0, P0 = 0, Kc = 0, Qc = 0;
@@ -953,6 +959,63 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01k + dev_stress_inc(r01k, toyz, ee, s_, _Gdt, dtr));
                 }
             }
+            if (HIF) {
+                // ---- high-face node layers i = nx (last cell column) and j = ny (last cell row) of plane k; values on ghost planes by the flow_bcs! rules
+                const bool xl = i == nx - 1, yl = j == ny - 1;
+                if (k == 0) {
+                    // plane K = 0 of Vx[nx, j+1, ·] / Vy[i+1, ny, ·]: tangential ghosts of the low z face (normal planes of no-slip faces are zero before the rule's sign)
+                    if (xl) vax_p = bc.nsR ? 0.0 : (bc.fsK0 ? vax : (bc.nsK0 ? -vax : LDB(f.Vx, ovx - svx)));
+                    if (yl) vby_p = bc.nsBk ? 0.0 : (bc.fsK0 ? vby : (bc.nsK0 ? -vby : LDB(f.Vy, ovy - svy)));
+                }
+                if (live) {
+                    if (xl) {
+                        {   // τxy (nx, j, k): Vx[nx, j, k+1] is the row below's boundary value, Vy[nx+1, j, k+1] the ghost column
+                            const double vxl = j > 0 ? sV[slot][0][ty - 1][tx] : (bc.nsR ? 0.0 : (bc.fsF ? vax : (bc.nsF ? -vax : LDB(f.Vx, ovx - rvx))));
+                            const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsR ? vb : (bc.nsR ? -vb : LDB(f.Vy, ovy - rvy + 8u)));
+                            const double s_ = 0.5 * (_dy * (vax - vxl) + _dx * (vyg - vb));
+                            const double ee = 0.25 * (ey + ey + e + e);
+                            const double dtr = dev_dtau_r(th, ee, 0.0);
+                            const double t0 = LDB(f.txy, oxy + 8u);
+                            STN<(NT & 1) != 0>(a.o.txy, oxy + 8u, t0 + dev_stress_inc(t0, 0.0, ee, s_, 0.0, dtr));
+                        }
+                        {   // τxz (nx, j, k): Vz[nx+1, j+1, k] is the ghost column of the previous plane's own Vz
+                            const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : LDB(f.Vz, ovz - svz + 8u)));
+                            const double s_ = 0.5 * (_dz * (vax - vax_p) + _dx * (vzg - c_p));
+                            const double ee = 0.25 * (e_p + e_p + e + e);
+                            const double dtr = dev_dtau_r(th, ee, 0.0);
+                            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10k + dev_stress_inc(s10k, 0.0, ee, s_, 0.0, dtr));
+                        }
+                    }
+                    if (yl) {
+                        {   // τxy (i, ny, k): Vx[i, ny+1, k+1] is the ghost row, Vy[i, ny, k+1] the left neighbour's boundary value
+                            const double vxg = (i == 0 && bc.nsL) ? 0.0 : (bc.fsBk ? va : (bc.nsBk ? -va : LDB(f.Vx, ovx - 8u + rvx)));
+                            const double vyl = i > 0 ? sV[slot][1][ty][tx - 1] : (bc.nsBk ? 0.0 : (bc.fsL ? vby : (bc.nsL ? -vby : LDB(f.Vy, ovy - 8u))));
+                            const double s_ = 0.5 * (_dy * (vxg - va) + _dx * (vby - vyl));
+                            const double ee = 0.25 * (ex + e + ex + e);
+                            const double dtr = dev_dtau_r(th, ee, 0.0);
+                            const double t0 = LDB(f.txy, oxy + rxy);
+                            STN<(NT & 1) != 0>(a.o.txy, oxy + rxy, t0 + dev_stress_inc(t0, 0.0, ee, s_, 0.0, dtr));
+                        }
+                        {   // τyz (i, ny, k)
+                            const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : LDB(f.Vz, ovz - svz + rvz)));
+                            const double s_ = 0.5 * (_dz * (vby - vby_p) + _dy * (vzg - c_p));
+                            const double ee = 0.25 * (e_p + e_p + e + e);
+                            const double dtr = dev_dtau_r(th, ee, 0.0);
+                            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10k + dev_stress_inc(r10k, 0.0, ee, s_, 0.0, dtr));
+                        }
+                    }
+                    if (xl && yl) {   // τxy (nx, ny, k): both velocities on ghost lines of their own boundary values
+                        const double vxg = bc.nsR ? 0.0 : (bc.fsBk ? vax : (bc.nsBk ? -vax : LDB(f.Vx, ovx + rvx)));
+                        const double vyg = bc.nsBk ? 0.0 : (bc.fsR ? vby : (bc.nsR ? -vby : LDB(f.Vy, ovy + 8u)));
+                        const double s_ = 0.5 * (_dy * (vxg - vax) + _dx * (vyg - vby));
+                        const double ee = 0.25 * (e + e + e + e);
+                        const double dtr = dev_dtau_r(th, ee, 0.0);
+                        const double t0 = LDB(f.txy, oxy + 8u + rxy);
+                        STN<(NT & 1) != 0>(a.o.txy, oxy + 8u + rxy, t0 + dev_stress_inc(t0, 0.0, ee, s_, 0.0, dtr));
+                    }
+                }
+                vax_p = vax; vby_p = vby;
+            }
             if (LOWREG) { exe_p = ex + e; eye_p = ey + e; gxg_p = gx + g; gyg_p = gy + g; }
             else {
                 a_p = va; b_p = vb; c_p = vc; cx_p = vcx; cy_p = vcy;
@@ -960,6 +1023,42 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             }
         }
         oc += sc; oxy += sxy; oxz += sxz; oyz += syz; ovx += svx; ovy += svy; ovz += svz;
+    }
+    if (HIF && avalid && kend == nz) {
+        // ---- node plane k = nz above the last cell plane: the carried registers hold plane nz of the new V (a_p = Vx[i, j+1, nz], b_p = Vy[i+1, j, nz], c_p = Vz[i+1, j+1, nz] --
+        // the boundary plane --, cx_p / cy_p its left / front neighbours, vax_p / vby_p the boundary column / row), e_p, ex_p, ey_p plane nz - 1 of η; the byte offsets have moved
+        // on to plane nz + 1 of V and of τxz / τyz (so `- sxz` is plane nz), s10 / r10 / s01p / r01p hold the old stresses of plane nz
+        const bool xl = i == nx - 1, yl = j == ny - 1;
+        {   // τxz (i, j, nz): Vx[i, j+1, nz+1] is the ghost plane
+            const double vxg = (i == 0 && bc.nsL) ? 0.0 : (bc.fsK1 ? a_p : (bc.nsK1 ? -a_p : LDB(f.Vx, ovx - 8u)));
+            const double s_ = 0.5 * (_dz * (vxg - a_p) + _dx * (c_p - cx_p));
+            const double ee = 0.25 * (ex_p + e_p + ex_p + e_p);
+            const double dtr = dev_dtau_r(th, ee, 0.0);
+            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01p + dev_stress_inc(s01p, 0.0, ee, s_, 0.0, dtr));
+        }
+        {   // τyz (i, j, nz)
+            const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsK1 ? b_p : (bc.nsK1 ? -b_p : LDB(f.Vy, ovy - rvy)));
+            const double s_ = 0.5 * (_dz * (vyg - b_p) + _dy * (c_p - cy_p));
+            const double ee = 0.25 * (ey_p + e_p + ey_p + e_p);
+            const double dtr = dev_dtau_r(th, ee, 0.0);
+            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01p + dev_stress_inc(r01p, 0.0, ee, s_, 0.0, dtr));
+        }
+        if (xl) {   // τxz (nx, j, nz)
+            const double vxg = bc.nsR ? 0.0 : (bc.fsK1 ? vax_p : (bc.nsK1 ? -vax_p : LDB(f.Vx, ovx)));
+            const double vzg = bc.nsK1 ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : LDB(f.Vz, ovz - svz + 8u)));
+            const double s_ = 0.5 * (_dz * (vxg - vax_p) + _dx * (vzg - c_p));
+            const double ee = 0.25 * (e_p + e_p + e_p + e_p);
+            const double dtr = dev_dtau_r(th, ee, 0.0);
+            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10 + dev_stress_inc(s10, 0.0, ee, s_, 0.0, dtr));
+        }
+        if (yl) {   // τyz (i, ny, nz)
+            const double vyg = bc.nsBk ? 0.0 : (bc.fsK1 ? vby_p : (bc.nsK1 ? -vby_p : LDB(f.Vy, ovy)));
+            const double vzg = bc.nsK1 ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : LDB(f.Vz, ovz - svz + rvz)));
+            const double s_ = 0.5 * (_dz * (vyg - vby_p) + _dy * (vzg - c_p));
+            const double ee = 0.25 * (e_p + e_p + e_p + e_p);
+            const double dtr = dev_dtau_r(th, ee, 0.0);
+            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10 + dev_stress_inc(r10, 0.0, ee, s_, 0.0, dtr));
+        }
     }
 }
 
