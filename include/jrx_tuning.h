@@ -6,6 +6,8 @@
  *   "fused_ylds" (default 1)      3D fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form)
  *   "fused_hiface" (1)            3D fused kernel, viscous-limit form, no neighbours: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel
  *                                 (0: by the boundary-layer launch behind it)
+ *   "comm_bcs_lazy" (0)           multi-rank fused pipeline: 1 = flow_bcs! of the physical faces applied lazily (before anything reads those entries from memory) instead of twice per
+ *                                 iteration; the fix-up next to the received planes derives them by rule (measured 2 % slower than the two launches: off)
  *   "fused_tile" (2)              3D fused kernel tile: 0 = 64 x 4 threads, 1 = 32 x 8, 2 = chosen by nx (32 x 8 for nx = 63 .. 90, where three 32-lane tiles replace two 64-lane ones)
  *   "fused_split" (0)             no neighbours: high-face tiles + boundary stress layers forked onto the halo stream
  *   "b_width_x/y/z" (0)           > 0 overrides jrx_stokes3d_params.b_width of the split sweeps
@@ -16,6 +18,8 @@
  *   "vep3_nt" (0), "vep3_prekz" (0)   3D VEP: non-temporal stores of the edge pass; planes per thread of the z-marching pre kernel (0 = chosen by the grid size; 1, 2, 4, 8, 16, 32)
  *   "vep3_hide_comm" (2)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 = the first two only,
  *                                 update_halo!(V) behind the whole velocity sweep; 0 = everything on the compute stream, in order (A/B)
+ *   "vep3_fork" (0)               3D VEP driver without neighbours: 1 = the centre pass of update_stresses_center_vertex_ps! runs on a second stream beside the edge pass (it writes a
+ *                                 second set of τxx, τyy, τzz, adopted by pointer swap); measured equal to one pass after the other: off
  *   "vep_store_all" (0)           VEP loops (2D and 3D): 1 = every iteration stores ∇V, RP, ε_pl, ε_vol_pl, τII, η_vep (default: only iterations whose results can be observed)
  *   "thermal_cfg", "thermal_xg"   fused 3D heat-diffusion tile shape / XCD band
  *   "halo_self_rccl" (0)          test hook: a rank that is its own periodic neighbour routes its planes through ncclSend/ncclRecv

@@ -728,13 +728,14 @@ jrx_status jrx_comm_init_local(jrx_handle *const *handles, int32_t n, const jrx_
             (void)hipSetDevice(h->device);
         }
     }
-    if (prev_device >= 0) (void)hipSetDevice(prev_device);
     if (st != JRX_OK) {
+        bool joined = false;
         for (int r = 0; r < n; r++)
-            if (handles[r]->comm && handles[r]->comm->grp == g) (void)jrx_comm_destroy(handles[r]);
-        return st;
+            if (handles[r]->comm && handles[r]->comm->grp == g) { joined = true; (void)jrx_comm_destroy(handles[r]); }      // the last member out deletes the group
+        if (!joined) delete g;
     }
-    return JRX_OK;
+    if (prev_device >= 0) (void)hipSetDevice(prev_device);      // init and the destroys above select the handles' devices: the caller's current device is restored
+    return st;
 }
 
 // id for jrx_comm_init_ipc: 128 bytes that name the group's control segment (rank 0 makes it, the others get it out of band, like the RCCL unique id)
@@ -851,6 +852,8 @@ jrx_status jrx_comm_destroy(jrx_handle *h)
 {
     if (!h || !h->comm) return JRX_OK;
     jrx_comm_state *c = h->comm;
+    // the frees below belong to the handle's device; the caller's current device is put back on return
+    struct DeviceGuard { int prev = -1; DeviceGuard(int d) { (void)hipGetDevice(&prev); if (prev != d) (void)hipSetDevice(d); else prev = -1; } ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); } } guard(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->halo_stream) (void)hipStreamSynchronize(h->halo_stream);
     if (c->comm && c->CommDestroy) (void)c->CommDestroy(c->comm);

@@ -43,6 +43,9 @@ struct jrx_handle {
     bool vep_store_all = false;          // VEP loops: every iteration stores the output-only arrays (A/B of the skipped stores)
     bool viscous_limit = true;           // dt = Inf: the fused 3D kernel skips the operands multiplied by 1/(G dt) = 1/(K dt) = 1/dt = 0
     bool visc_ok = false;                // set per driver call by the operand check: every τ_o, P0, Q finite and K, G neither NaN nor 0, so the viscous-limit kernels give the general ones' result
+    bool comm_bcs_lazy = false;          // multi-rank fused pipeline: 1 = flow_bcs! of the physical faces is not applied in memory every iteration (the fix-up derives those entries by rule) but
+                                         // lazily, before anything reads them.  Measured (two 512^3 blocks, profiles/r04_comm_bcs_lazy_ab.txt): the rule form of the fix-up costs more than the two
+                                         // BC launches it saves (-2 %): off
     bool fused_hiface = true;            // viscous-limit fused kernel without neighbours: the high-face node layers inside the kernel (0: the boundary-layer launch behind it, A/B)
     bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)
@@ -58,6 +61,8 @@ struct jrx_handle {
                                              // 3 centre operands only, 1 no LDS (one family per block), 2 one launch per family, 0 one node per thread (A/B)
     int vep3_hide_comm = 2;                  // multi-rank 3D VEP driver: the three exchanges of an iteration on the halo stream beside independent kernels
                                              // (1: ητ and the edge stresses only, 0: serial; A/B)
+    bool vep3_fork = false;                  // 3D VEP driver without neighbours: the centre pass of the stress update on the halo stream beside the edge pass (second set of τxx, τyy, τzz).
+                                             // Measured 256^3 311.6 / 311.4 / 312.2 it/s forked vs 312.7 / 313.2 / 312.2 in order (profiles/r04_vep3d_fork.txt): nothing to gain, off
     bool vep3_map = true, vep3_xcd = true;   // 3D VEP edge kernel thread mapping / XCD slab order (A/B)
     bool scratch_sets = true;            // the fused pipelines may allocate their library-owned second state set (0: never -- un-fused paths)
     // ---- read-only counters (jrx_get_option "stat_*"): launches of the fused kernels since jrx_create, so that tests and the bench can

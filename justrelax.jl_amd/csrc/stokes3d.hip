@@ -624,6 +624,19 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
     return launch_fused_t<32, 8, 2>(h, s, a, bc, b, hiface, fold);
 }
 
+// the faces of this rank's block that are physical boundaries (no neighbour): the bits of free_slip / no_slip that flow_bcs! may act on once the planes of the other faces
+// hold received values.  3D naming of the reference (App. C.4): free_slip `top` is k = 1 and `bot` k = end, no_slip the other way round
+static void physical_faces(const jrx_handle *h, uint32_t *fs_keep, uint32_t *ns_keep)
+{
+    const uint32_t fs_lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_TOP}, fs_hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_BOT};
+    const uint32_t ns_lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_BOT}, ns_hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_TOP};
+    *fs_keep = *ns_keep = 0;
+    for (int d = 0; d < 3; d++) {
+        if (!jrx_comm_has_neighbor(h, d, 0)) { *fs_keep |= fs_lo[d]; *ns_keep |= ns_lo[d]; }
+        if (!jrx_comm_has_neighbor(h, d, 1)) { *fs_keep |= fs_hi[d]; *ns_keep |= ns_hi[d]; }
+    }
+}
+
 // tev (optional): events recorded around the sweeps: [0] start, [1] after the stress sweep (if one was launched),
 // [2] after the velocity sweep or after the fused launch group (k_fused3d + BCs + boundary planes),
 // [3] (fused only) directly after k_fused3d, so that [1] -> [3] is that kernel alone
@@ -673,6 +686,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         };
         bool nb[3][2] = {};
         bool folded = false;           // the kernel has updated the high-face node layers itself: nothing is left behind it
+        bool rules_with_comm = false;  // neighbours, but flow_bcs! was not applied in memory: the fix-up derives the BC entries of the physical faces by rule
         // option "fused_overlap" = 1: shell of tiles + BCs + exchange on the halo stream, interior tiles concurrently (see below).  Off by
         // default: measured on one device (periodic self neighbour through RCCL, profiles/r01_selfhalo_overlap_*.txt) the RCCL
         // send/recv kernel does not finish before the interior kernel drains, so nothing is hidden and the six small shell launches
@@ -729,7 +743,11 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                 if (H0) JRX_TRY(launch_velocity(h, bs, a, false, nx - xa, nx, y0, y1, z0, z1));
             }
             if (cev) JRX_HIP(h, hipEventRecord(cev[0], bs));
-            JRX_TRY(fused_bcs(bs));
+            // flow_bcs! in memory before the exchange (the sent planes carry BC entries of their own rows) -- not needed when nothing reads those entries from memory: the
+            // fix-up below derives them by rule, k_fused3d always did, and every path that does read them (un-fused iterations, results handed back) applies the
+            // pending flow_bcs! first (tuning switch "comm_bcs_lazy", default on)
+            const bool lazy = h->comm_bcs_lazy;
+            if (!lazy) JRX_TRY(fused_bcs(bs));
             if (cev) JRX_HIP(h, hipEventRecord(cev[1], bs));
             {
                 double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
@@ -744,15 +762,10 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             JRX_HIP(h, hipEventRecord(h->ev[2], bs));
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
             bs = s;
-            {   // flow_bcs! of the complete new V on the faces that are physical boundaries.  3D naming of the reference (App. C.4): free_slip `top` is k = 1 and
-                // `bot` k = end, no_slip the other way round
-                const uint32_t fs_lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_TOP}, fs_hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_BOT};
-                const uint32_t ns_lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_BOT}, ns_hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_TOP};
-                uint32_t fs_keep = 0, ns_keep = 0;
-                for (int d = 0; d < 3; d++) {
-                    if (!jrx_comm_has_neighbor(h, d, 0)) { fs_keep |= fs_lo[d]; ns_keep |= ns_lo[d]; }
-                    if (!jrx_comm_has_neighbor(h, d, 1)) { fs_keep |= fs_hi[d]; ns_keep |= ns_hi[d]; }
-                }
+            if (lazy) { I.ghosts_stale = true; rules_with_comm = true; }
+            else {   // flow_bcs! of the complete new V on the faces that are physical boundaries
+                uint32_t fs_keep, ns_keep;
+                physical_faces(h, &fs_keep, &ns_keep);
                 JRX_TRY(launch_bcs_faces(h, s, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip & fs_keep, p->no_slip & ns_keep));
             }
             if (cev) { JRX_HIP(h, hipEventRecord(cev[3], s)); if (chain_mode) *chain_mode = 2; }
@@ -765,8 +778,8 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             // Without neighbours no flow_bcs! launch is needed here: the fused kernel and the boundary-layer launch below derive the
             // boundary entries of V by rule, and every path that reads them from memory (un-fused sweeps, results handed back) is
             // preceded by a flow_bcs! launch of its own.  With neighbours the exchange ships those entries, so they must be in memory.
-            if (comm || per) JRX_TRY(fused_bcs(s));
-            else I.ghosts_stale = true;
+            if (per || (comm && !h->comm_bcs_lazy)) JRX_TRY(fused_bcs(s));
+            else { I.ghosts_stale = true; rules_with_comm = comm; }
             if (cev && comm) JRX_HIP(h, hipEventRecord(cev[1], s));
             if (per) {
                 const uint32_t lo[3] = {JRX_FACE_LEFT, JRX_FACE_FRONT, JRX_FACE_BOT}, hi[3] = {JRX_FACE_RIGHT, JRX_FACE_BACK, JRX_FACE_TOP};
@@ -827,8 +840,10 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             const int t6[6] = {ty(JRX_FACE_LEFT, JRX_FACE_LEFT), ty(JRX_FACE_RIGHT, JRX_FACE_RIGHT), ty(JRX_FACE_FRONT, JRX_FACE_FRONT),
                                ty(JRX_FACE_BACK, JRX_FACE_BACK), ty(JRX_FACE_TOP, JRX_FACE_BOT), ty(JRX_FACE_BOT, JRX_FACE_TOP)};
             for (int q = 0; q < 6; q++) gr.t[q] = t6[q];
+            if (rules_with_comm)       // a face with a neighbour holds received values: read them
+                for (int d = 0; d < 3; d++) { if (nb[d][0]) gr.t[2 * d] = 0; if (nb[d][1]) gr.t[2 * d + 1] = 0; }
         }
-        if (!folded) JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false, (comm || per) ? nullptr : &gr));
+        if (!folded) JRX_TRY(launch_stress_boxes(h, bs, e, fix, 6, false, ((comm || per) && !rules_with_comm) ? nullptr : &gr));
         if (bs != s) {
             JRX_HIP(h, hipEventRecord(h->ev[2], bs));
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
@@ -868,6 +883,15 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             ordered = true;
         }
         return JRX_OK;
+    }
+    if (I.ghosts_stale) {
+        // the fused steps before left flow_bcs! of the physical faces to be applied lazily: now, before U = V dt copies those entries and before anything reads them from memory
+        // (the planes of the faces with a neighbour hold received values and stay; where a ghost row crosses one, the copy / negation of the received value is what the
+        // neighbour's own flow_bcs! would have sent)
+        uint32_t fs_keep, ns_keep;
+        physical_faces(h, &fs_keep, &ns_keep);
+        JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip & fs_keep, p->no_slip & ns_keep, 0));
+        I.ghosts_stale = false;
     }
     return jrx3d_velocity_hidden(h, f, I.etatau, p, diag, p->displacement_bcs ? (diag ? 2 : 3) : 0);
 }

@@ -26,6 +26,7 @@ struct Vep3Args {
     const double *eta_lin = nullptr;   // linear laws: the phase average of η (constant over a solve), precomputed by k_vep3_phase_avg; nullptr: computed per call
     double *theta, *lam;
     double *lamv[3], *tnew[3];
+    double *cnew[3] = {nullptr, nullptr, nullptr};   // centre pass: where the new τxx, τyy, τzz go (nullptr: in place).  A second set lets the centre pass run BESIDE the edge pass, which averages the OLD normal stresses
     double _dx, _dy, _dz, dt, r, theta_dtau, rel, nu, cut_lo, cut_hi;
     int nx, ny, nz;
     bool soft;            // some phase has a softening law: the yield function then reads EII_pl
@@ -496,7 +497,7 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
     constexpr int NC = SOFT ? 12 : 11;          // centre arrays averaged to the edges; softening laws add EII_pl (StressKernels.jl:710,783,854)
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP;
     const int lane = threadIdx.x & 63;
-    if (j > ny) return;                                  // whole waves; the kernel has no barrier
+    if (j > ny) return;                                  // whole waves; in the LDS-sharing forms (barriers!) j is the workgroup's row, so the whole workgroup leaves together
     const int i = seg * 62 - 1 + lane;
     const bool useful = lane >= 1 && lane <= 62 && i <= nx && i < ilim;
     const int kb = zchunk * KZ, ke = min(kb + KZ, nz + 1);
@@ -720,6 +721,9 @@ __global__ __launch_bounds__(192, SOFT ? 2 : 3) void k_vep3_edges_zl(const Vep3A
     if (q >= per || t >= (unsigned)ntiles) return;                  // whole workgroups
     const int txy = (int)(t % (unsigned)ntile_xy), zc = (int)(t / (unsigned)ntile_xy);
     const int fam = (int)(threadIdx.x >> 6), j = txy / nseg;        // ntile_xy = nseg * (ny + 1): one row per workgroup
+    // The three family waves run three instantiations of the tile function.  Each instantiation executes the same barrier sequence -- one in the prologue, one per plane of the
+    // chunk, with loop bounds (kb, ke) that depend on the workgroup's chunk only -- and no instantiation returns early unless the whole workgroup does (row j, above): every
+    // __syncthreads() is reached by all 192 threads the same number of times, although textually from different branches
     if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 0);
     else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 1);
     else vep3_edges_z_tile<KZ, NP, 4, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 2);
@@ -745,6 +749,7 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
     eij[4] = 0.25 * ((((0.0 + EXZ(a.f.exz, i, j, k)) + EXZ(a.f.exz, i + 1, j, k)) + EXZ(a.f.exz, i, j, k + 1)) + EXZ(a.f.exz, i + 1, j, k + 1));
     eij[5] = 0.25 * ((((0.0 + EXY(a.f.exy, i, j, k)) + EXY(a.f.exy, i + 1, j, k)) + EXY(a.f.exy, i, j + 1, k)) + EXY(a.f.exy, i + 1, j + 1, k));
     double *const tc[6] = {a.f.txx, a.f.tyy, a.f.tzz, a.f.tyz_c, a.f.txz_c, a.f.txy_c};
+    double *const tw[6] = {a.cnew[0] ? a.cnew[0] : a.f.txx, a.cnew[1] ? a.cnew[1] : a.f.tyy, a.cnew[2] ? a.cnew[2] : a.f.tzz, a.f.tyz_c, a.f.txz_c, a.f.txy_c};
     const double *const toc[6] = {a.f.toxx, a.f.toyy, a.f.tozz, a.f.toyz_c, a.f.toxz_c, a.f.toxy_c};
     double tij[6], d[6], tt[6];
 #pragma unroll
@@ -775,13 +780,13 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
         for (int s = 0; s < 6; s++) { epl[s] = l * dQdt[s]; d[s] = d[s] - 2.0 * e * epl[s] * dtr; tij[s] = d[s] + tij[s]; }
         if (a.obs) VST(a, a.f.evol_pl[c], -l * dQdP);
 #pragma unroll
-        for (int s = 0; s < 6; s++) VST(a, tc[s][c], tij[s]);
+        for (int s = 0; s < 6; s++) VST(a, tw[s][c], tij[s]);
         if (a.obs) { VST(a, a.f.eplxx[c], epl[0]); VST(a, a.f.eplyy[c], epl[1]); VST(a, a.f.eplzz[c], epl[2]); }
         tII = sinv3(tij);
     } else {
         if (a.obs) VST(a, a.f.evol_pl[c], 0.0);
 #pragma unroll
-        for (int s = 0; s < 6; s++) VST(a, tc[s][c], d[s] + tij[s]);
+        for (int s = 0; s < 6; s++) VST(a, tw[s][c], d[s] + tij[s]);
         if (a.obs) { VST(a, a.f.eplxx[c], 0.0); VST(a, a.f.eplyy[c], 0.0); VST(a, a.f.eplzz[c], 0.0); }
     }
     if (a.obs) VST(a, a.f.tII[c], tII);
@@ -1119,7 +1124,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     const EdgeN ne = edge_counts(p);
     hipStream_t s = h->stream;
     // library scratch: ητ, θ, λ, K, G, a second ητ, the phase-averaged η of the linear laws (centres), λv and the new edge stresses (edges), carved out of one allocation
-    JRX_TRY(jrx_ensure_etatau(h, 7 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
+    JRX_TRY(jrx_ensure_etatau(h, 10 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
     double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n, *etatau_next = Gc + n;
     Vep3Args a = make_vep3(f, rh, p);
     a.nt = h->vep3_nt;
@@ -1127,6 +1132,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     double *eta_lin = etatau_next + n;
     a.lamv[0] = eta_lin + n; a.lamv[1] = a.lamv[0] + ne.yz; a.lamv[2] = a.lamv[1] + ne.xz;
     a.tnew[0] = a.lamv[2] + ne.xy; a.tnew[1] = a.tnew[0] + ne.yz; a.tnew[2] = a.tnew[1] + ne.xz;
+    double *const cset[3] = {a.tnew[2] + ne.xy, a.tnew[2] + ne.xy + n, a.tnew[2] + ne.xy + 2 * n};      // second set of τxx, τyy, τzz (see `fork` below)
     jrx_stokes3d_fields g = view3d(f);
     jrx_stokes3d_params q;
     memset(&q, 0, sizeof(q));
@@ -1173,6 +1179,10 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     int prekz = h->vep3_prekz;
     if (prekz == 0)
         for (prekz = 8; prekz > 1 && (i64)gpre.x * ((nz + prekz) / prekz) < 2048; prekz /= 2) {}
+    // tuning switch "vep3_fork" (default off: measured equal, profiles/r04_vep3d_fork.txt): the centre pass beside the edge pass (see enqueue_iteration); not inside captured graphs (small grids), not with neighbours
+    // (there the halo stream carries the exchanges and the centre pass already runs beside one)
+    const bool fork = h->vep3_fork && !comm && !((h->loop_graphs && !ubc && p->periodic == 0 && (double)n <= kGraphCells3D));
+    double *const user_c[3] = {f->txx, f->tyy, f->tzz};
     auto enqueue_iteration = [&](Vep3Args &A, jrx_stokes3d_fields &G, bool diag_) -> jrx_status {
         A.obs = diag_ || h->vep_store_all;
         if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, A);
@@ -1184,7 +1194,22 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         else hipLaunchKernelGGL((k_vep3_pre<true, false, PRE_KZ>), gpre, dim3(256), 0, s, A);        // compute_maxloc! folded in
         launch_vep3_visc(s, gc, A, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
         JRX_LAUNCH_CHECK(h);
-        JRX_TRY(launch_vep3_stress(h, s, A, p, false, 0, true));
+        if (fork) {
+            // Edge pass and centre pass of update_stresses_center_vertex_ps! side by side on two streams.  They are independent except that the edge pass averages the OLD
+            // τxx, τyy, τzz to its nodes while the centre pass overwrites them: the centre pass writes a second set, adopted by pointer swap like the edge stresses.  The
+            // edge kernel is latency-bound (4.0 TB/s), the centre kernel streams (5.3 TB/s): the hope was that together they would fill the memory system -- they do not (profiles/r04_vep3d_fork.txt)
+            hipStream_t hs = h->halo_stream;
+            for (int c_ = 0; c_ < 3; c_++) A.cnew[c_] = (c_ == 0 ? A.f.txx : (c_ == 1 ? A.f.tyy : A.f.tzz)) == cset[c_] ? user_c[c_] : cset[c_];
+            JRX_HIP(h, hipEventRecord(h->ev[3], s));
+            JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[3], 0));
+            JRX_TRY(launch_vep3_stress(h, hs, A, p, false, 2, true));      // centre pass
+            JRX_TRY(launch_vep3_stress(h, s, A, p, false, 1, true));       // edge pass
+            JRX_HIP(h, hipEventRecord(h->ev[4], hs));
+            JRX_HIP(h, hipStreamWaitEvent(s, h->ev[4], 0));
+            A.f.txx = A.cnew[0]; A.f.tyy = A.cnew[1]; A.f.tzz = A.cnew[2];
+            A.cnew[0] = A.cnew[1] = A.cnew[2] = nullptr;
+            G.txx = A.f.txx; G.tyy = A.f.tyy; G.tzz = A.f.tzz;
+        } else JRX_TRY(launch_vep3_stress(h, s, A, p, false, 0, true));
         // the new edge stresses become the current ones: swap the pointers instead of copying three arrays back
         { double *t0_ = A.f.tyz; A.f.tyz = A.tnew[0]; A.tnew[0] = t0_; }
         { double *t1_ = A.f.txz; A.f.txz = A.tnew[1]; A.tnew[1] = t1_; }
@@ -1327,6 +1352,11 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                        err, err / err_it1, nRx, nRy, nRz, nDV);
             if (std::isnan(err)) {
                 // error("NaN(s)"): the current edge stresses may live in the second set -- leave them in the caller's arrays, drain the stream
+                if (a.f.txx != f->txx) {
+                    (void)hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+                    (void)hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+                    (void)hipMemcpyAsync(f->tzz, a.f.tzz, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+                }
                 if (a.f.tyz != f->tyz) {
                     (void)hipMemcpyAsync(f->tyz, a.f.tyz, (size_t)ne.yz * sizeof(double), hipMemcpyDeviceToDevice, s);
                     (void)hipMemcpyAsync(f->txz, a.f.txz, (size_t)ne.xz * sizeof(double), hipMemcpyDeviceToDevice, s);
@@ -1343,6 +1373,13 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         }
     }
     JRX_HIP(h, hipEventRecord(t1, s));
+    if (a.f.txx != f->txx) {       // the same for the normal stresses of the forked centre pass
+        JRX_HIP(h, hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        JRX_HIP(h, hipMemcpyAsync(f->tzz, a.f.tzz, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        a.f.txx = f->txx; a.f.tyy = f->tyy; a.f.tzz = f->tzz;
+        g.txx = f->txx; g.tyy = f->tyy; g.tzz = f->tzz;
+    }
     if (a.f.tyz != f->tyz) {       // odd number of swaps: leave the edge stresses in the caller's arrays
         JRX_HIP(h, hipMemcpyAsync(f->tyz, a.f.tyz, (size_t)ne.yz * sizeof(double), hipMemcpyDeviceToDevice, s));
         JRX_HIP(h, hipMemcpyAsync(f->txz, a.f.txz, (size_t)ne.xz * sizeof(double), hipMemcpyDeviceToDevice, s));

@@ -523,9 +523,10 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
     // chip idle (64^3: 1024 single-wave blocks): 16^3 74.7 k -> 175 k it/s, 32^3 72.4 k -> 159 k, 48^3 64.3 k -> 112 k, 64^3 52.5 k -> 101 k with one plane per block; from 96^3 on
     // 4 planes are the better depth again (35.5 k against 33.2 k) (profiles/r03_small_grids_graphs.txt)
     int FKZ = cfg ? cfg % 100 : 4;
-    if (!cfg)
-        while (FKZ > 1 && (i64)((nx + FTX - 1) / FTX) * (FTX / 64) * ny * ((nz + FKZ - 1) / FKZ) < 4096) FKZ /= 2;
     const int FXG = h->thermal_xg;
+    // (the shallower chunks are instantiated for the default XCD band width only: with the tuning switch "thermal_xg" != 8 the depth stays 4)
+    if (!cfg && FXG == 8)
+        while (FKZ > 1 && (i64)((nx + FTX - 1) / FTX) * (FTX / 64) * ny * ((nz + FKZ - 1) / FKZ) < 4096) FKZ /= 2;
     const int ntx = (nx + FTX - 1) / FTX, nty = (ny + FR - 1) / FR, ntz = (nz + FKZ - 1) / FKZ;
     // launch_fused: one unobserved iteration from set c into set o (the caller swaps)
     auto launch_fused = [&](const TSet &c, const TSet &o) -> jrx_status {

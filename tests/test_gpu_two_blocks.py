@@ -26,13 +26,14 @@ pytestmark = pytest.mark.gpu
 
 STATE = ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "txy", "txz", "tyz")
 PIPELINES = {"fused": dict(kernel_variant=3, fused_overlap=0, fused_comm=1), "fused_overlap": dict(kernel_variant=3, fused_overlap=1, fused_comm=1),
-             "fused_early": dict(kernel_variant=3, fused_overlap=2, fused_comm=1),
+             "fused_early": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=0),
+             "fused_early_lazy_bcs": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=1),
              "split_sweeps": dict(kernel_variant=3, fused_overlap=0, fused_comm=0)}
 
 
 def _set(h, **opts):
     for k, v in opts.items():
-        h.call("jrx_set_option", C.c_char_p(k.encode()), C.c_int64(v))
+        h.set_option(k, v)          # options of the public ABI and tuning switches alike
 
 
 def _get(h, key):
@@ -102,7 +103,7 @@ def _solve_blocks(jr, tb, S, pipeline, iters_kw):
         g.finalize_global_grid()
 
 
-@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "split_sweeps"])
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "fused_early_lazy_bcs", "split_sweeps"])
 @pytest.mark.parametrize("dims,n", [((2, 1, 1), (70, 13, 12)), ((1, 2, 1), (70, 13, 12)), ((1, 1, 2), (70, 13, 12)),
                                     # 3 x 5 x 5 tiles of the fused kernel per block: every shell box and an interior box
                                     ((2, 1, 1), (130, 14, 40)), ((1, 1, 2), (130, 14, 40))])
@@ -154,7 +155,7 @@ def test_two_blocks_equal_the_undecomposed_run_bit_for_bit(jr, dims, n, pipeline
     assert getattr(res[0], "norm_∇V")[-1] != getattr(rg, "norm_∇V")[-1]          # ... which are not the undecomposed norm (RP: overlap counted twice)
 
 
-@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "split_sweeps"])
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "fused_early_lazy_bcs", "split_sweeps"])
 @pytest.mark.parametrize("dims,n", [((2, 1, 1), (70, 13, 12)), ((1, 1, 2), (130, 14, 40))])
 def test_two_blocks_in_the_viscous_limit_equal_the_undecomposed_general_kernels(jr, dims, n, pipeline):
     """dt = Inf: every rank runs the viscous-limit forms (fused kernel, z-marching sweep, fix-up layers next to received planes), which do not load τ_o, P0, K, G, Q
