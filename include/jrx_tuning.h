@@ -4,6 +4,8 @@
  *
  * Keys (int64 values):
  *   "fused_ylds" (default 1)      3D fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form)
+ *   "visc_fold" (1)               3D fused kernel, viscous-limit form: the arithmetic with its exact zeros folded away for finite η (dτ_r = 1 / (θ_dτ + 1) once per thread, Δτ = dτ_r fma(2η, ε, -τ),
+ *                                 no division by 1 + 0 ψ); same bits (0: the general expressions with zero operands)
  *   "fused_hiface" (1)            3D fused kernel, viscous-limit form, no neighbours: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel
  *                                 (0: by the boundary-layer launch behind it)
  *   "comm_bcs_lazy" (0)           multi-rank fused pipeline: 1 = flow_bcs! of the physical faces applied lazily (before anything reads those entries from memory) instead of twice per

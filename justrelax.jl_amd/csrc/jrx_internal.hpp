@@ -46,6 +46,7 @@ struct jrx_handle {
     bool comm_bcs_lazy = false;          // multi-rank fused pipeline: 1 = flow_bcs! of the physical faces is not applied in memory every iteration (the fix-up derives those entries by rule) but
                                          // lazily, before anything reads them.  Measured (two 512^3 blocks, profiles/r04_comm_bcs_lazy_ab.txt): the rule form of the fix-up costs more than the two
                                          // BC launches it saves (-2 %): off
+    bool visc_fold = true;               // viscous-limit fused kernel: the arithmetic with the exact zeros folded away (one division per thread for dτ_r, no division by 1 in compute_P!; same bits; A/B)
     bool fused_hiface = true;            // viscous-limit fused kernel without neighbours: the high-face node layers inside the kernel (0: the boundary-layer launch behind it, A/B)
     bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)

@@ -90,16 +90,16 @@ bool fits_u32(const Lay3 &L)
 // Viscous-limit guard.  With dt = Inf the reference still multiplies τ_o, P0, Q by an exact 0 and divides by K dt, G dt (StressKernels.jl:2-5, PressureKernels.jl:186-195):
 // a NaN / Inf in τ_o, P0 or Q, or a K or G that is NaN or 0 (0 * Inf), turns the result into NaN and the driver raises error("NaN(s)") (Stokes3D.jl:162).  The
 // viscous-limit kernels never read those ten arrays, so before they are selected one streaming pass checks that every entry is harmless; if not, the general
-// kernels run (and produce the reference's NaNs).  sets h->visc_ok.
+// kernels run (and produce the reference's NaNs).  η must be finite, too: the viscous-limit form of the fused kernel folds η · 0 = 0 (k_fused3d, VFOLD).  sets h->visc_ok.
 __global__ __launch_bounds__(256) void k_visc_operands_ok(const double *__restrict__ c0, const double *__restrict__ c1, const double *__restrict__ c2, const double *__restrict__ c3,
-                                                          const double *__restrict__ c4, i64 nc, const double *__restrict__ K, const double *__restrict__ G,
+                                                          const double *__restrict__ c4, const double *__restrict__ eta, i64 nc, const double *__restrict__ K, const double *__restrict__ G,
                                                           const double *__restrict__ yz, i64 nyz, const double *__restrict__ xz, i64 nxz, const double *__restrict__ xy, i64 nxy, int *bad)
 {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     bool b = false;
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < nyz || t < nxz || t < nxy; t += stride) {
         if (t < nc) {
-            b |= !(isfinite(c0[t]) && isfinite(c1[t]) && isfinite(c2[t]) && isfinite(c3[t]) && isfinite(c4[t]));
+            b |= !(isfinite(c0[t]) && isfinite(c1[t]) && isfinite(c2[t]) && isfinite(c3[t]) && isfinite(c4[t]) && isfinite(eta[t]));
             const double k = K[t], g = G[t];
             b |= (k != k) || (g != g) || k == 0.0 || g == 0.0;
         }
@@ -118,7 +118,7 @@ jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, cons
     int *d_bad = reinterpret_cast<int *>(h->d_sums + 6), *h_bad = reinterpret_cast<int *>(h->h_sums + 6);
     hipStream_t s = h->stream;
     JRX_HIP(h, hipMemsetAsync(d_bad, 0, sizeof(double), s));
-    hipLaunchKernelGGL(k_visc_operands_ok, dim3(4096), dim3(256), 0, s, f->P0, f->Q, f->toxx, f->toyy, f->tozz, nx * ny * nz, f->K, f->G, f->toyz, nx * (ny + 1) * (nz + 1),
+    hipLaunchKernelGGL(k_visc_operands_ok, dim3(4096), dim3(256), 0, s, f->P0, f->Q, f->toxx, f->toyy, f->tozz, f->eta, nx * ny * nz, f->K, f->G, f->toyz, nx * (ny + 1) * (nz + 1),
                        f->toxz, (nx + 1) * ny * (nz + 1), f->toxy, (nx + 1) * (ny + 1) * nz, d_bad);
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipMemcpyAsync(h_bad, d_bad, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -583,8 +583,13 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     // the general kernel.  (Its lower register need -- 111 VGPRs -- leaves room to carry the previous velocity / η planes in registers
     // instead of the third LDS slot: LOWREG off, -1.4 %, scripts/kbench_visc.hip)
     const bool visc = h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
-    if (visc && fold)       // + the high-face node layers inside the kernel: the whole iteration in one launch
+    const bool vf = h->visc_fold;      // tuning switch: the folded arithmetic of the viscous limit (k_fused3d, VFOLD; same bits)
+    if (visc && fold && vf)       // + the high-face node layers inside the kernel: the whole iteration in one launch
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+    else if (visc && fold)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+    else if (visc && !hiface && vf)
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc && hiface)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 1, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc)

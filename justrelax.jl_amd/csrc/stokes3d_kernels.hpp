@@ -675,7 +675,7 @@ struct FusedBC {
 // HIF (viscous-limit form, no neighbours): the stress nodes on the high faces i = nx, j = ny, k = nz -- which no cell column owns and which the boundary-layer launch
 // (k_stress3d_boxes with the flow_bcs! rules) otherwise updates behind this kernel -- are updated here by the threads of the last cell column / row / plane, from the
 // new velocities they hold anyway and the same rules (GhostRule), operation for operation as stress3d_node<false, true, true>: one launch per iteration.
-template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false>
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false, bool VFOLD = false>
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0)
 {
     // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
@@ -683,6 +683,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     static_assert(!YLDS || SHFL, "YLDS builds on the SHFL operand layout");
     static_assert(!VISC || YLDS, "the viscous-limit form is built on the YLDS operand layout");
     static_assert(!HIF || (VISC && !LOWREG && SHFL && OVX == 1), "the folded high-face layers are built for the viscous-limit form with carried planes");
+    static_assert(!VFOLD || VISC, "VFOLD simplifies the viscous-limit arithmetic");
     constexpr int NS = LOWREG ? 3 : 2;
     __shared__ double sV[NS][3][TY][TX];
     __shared__ double sY[YLDS ? (VISC ? 7 : 8) : 1][YLDS ? TY : 1][YLDS ? TX : 1];
@@ -711,6 +712,16 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     const bool avalid = bvalid && tx >= OVX && ty >= 1 && (!SHFL || tx < TX - 1);
     const bool hx = i < nx - 1, hy = j < ny - 1;
     const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau, _dt = 1.0 / dt, rr = a.r, edt = a.eta_dtau;
+    // VFOLD: what the viscous-limit arithmetic reduces to for FINITE η (the driver's operand check guarantees it), bit for bit:
+    //   dev_dtau_r(θ, η, 0) = 1 / (θ + fma(η, 0, 1)) = 1 / (θ + 1): one division per thread instead of four per cell and plane;
+    //   INC(τ, 0, η, ε, 0, dτ_r) = dτ_r fma(2η, ε, fma(-(τ - 0) η, 0, -τ)) = dτ_r fma(2η, ε, -τ)   (x · 0 = ±0, and ±0 + (-τ) = -τ, the zeros included);
+    //   compute_P!: fma(0, 0, rhs) = rhs (rhs = -∇V + 0 is never -0) and the division by 1 + 0 ψ = 1 is the identity.
+    // The fused kernel spends more than half of its time issuing fp64 VALU instructions, a good part of them division sequences (profiles/r04_temporal_blocking.txt §4).
+    const double dtr0 = VFOLD ? 1.0 / (th + 1.0) : 0.0;
+    auto DTR = [&](const double eta_, const double Gdt_) { return VFOLD ? dtr0 : dev_dtau_r(th, eta_, Gdt_); };
+    auto INC = [&](const double t_, const double to_, const double eta_, const double e_, const double Gdt_, const double dtr_) {
+        return VFOLD ? dtr_ * fma(2.0 * eta_, e_, -t_) : dev_stress_inc(t_, to_, eta_, e_, Gdt_, dtr_);
+    };
 
     const u32 sc = (u32)L.cp * 8u, svx = (u32)L.vxp * 8u, svy = (u32)L.vyp * 8u, svz = (u32)L.vzp * 8u;
     const u32 sxy = (u32)L.xyp * 8u, sxz = (u32)L.xzp * 8u, syz = (u32)L.yzp * 8u;
@@ -926,37 +937,38 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     const double _Kdt = VISC ? 0.0 : 1.0 / (Kc * dt);
                     const double rhs = -divV + (Qc * _dt);
                     const double psi = 1.0 / (1.0 / e + _Gdt) * rr / th;
-                    STN<(NT & 1) != 0>(a.o.P, oc, (fma(P0, _Kdt, rhs) * psi + P_k) / (1.0 + _Kdt * psi));
+                    if (VFOLD) STN<(NT & 1) != 0>(a.o.P, oc, rhs * psi + P_k);
+                    else STN<(NT & 1) != 0>(a.o.P, oc, (fma(P0, _Kdt, rhs) * psi + P_k) / (1.0 + _Kdt * psi));
                     const double d3 = divV * (1.0 / 3.0);
                     const double exx = dxi - d3, eyy = dyi - d3, ezz = dzi - d3;
-                    const double dtr = dev_dtau_r(th, e, _Gdt);
-                    STN<(NT & 1) != 0>(a.o.txx, oc, txx_c + dev_stress_inc(txx_c, toxx, e, exx, _Gdt, dtr));
-                    STN<(NT & 1) != 0>(a.o.tyy, oc, tyy_c + dev_stress_inc(tyy_c, toyy, e, eyy, _Gdt, dtr));
-                    STN<(NT & 1) != 0>(a.o.tzz, oc, tzz_k + dev_stress_inc(tzz_k, tozz, e, ezz, _Gdt, dtr));
+                    const double dtr = DTR(e, _Gdt);
+                    STN<(NT & 1) != 0>(a.o.txx, oc, txx_c + INC(txx_c, toxx, e, exx, _Gdt, dtr));
+                    STN<(NT & 1) != 0>(a.o.tyy, oc, tyy_c + INC(tyy_c, toyy, e, eyy, _Gdt, dtr));
+                    STN<(NT & 1) != 0>(a.o.tzz, oc, tzz_k + INC(tzz_k, tozz, e, ezz, _Gdt, dtr));
                 }
                 {   // τxy (i,j,k)
                     const double s_ = 0.5 * (_dy * (va - vay) + _dx * (vb - vbx));
                     const double ee = 0.25 * (exy_ + ey + ex + e);
                     const double gg = 0.25 * (gxy + gy + gx + g);
                     const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
-                    const double dtr = dev_dtau_r(th, ee, _Gdt);
-                    STN<(NT & 1) != 0>(a.o.txy, oxy, txy + dev_stress_inc(txy, toxy, ee, s_, _Gdt, dtr));
+                    const double dtr = DTR(ee, _Gdt);
+                    STN<(NT & 1) != 0>(a.o.txy, oxy, txy + INC(txy, toxy, ee, s_, _Gdt, dtr));
                 }
                 {   // τxz (i,j,k)
                     const double s_ = 0.5 * (_dz * (va - a_p) + _dx * (c_p - cx_p));
                     const double ee = 0.25 * ((LOWREG ? exe_p : ex_p + e_p) + ex + e);
                     const double gg = 0.25 * ((LOWREG ? gxg_p : gx_p + g_p) + gx + g);
                     const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
-                    const double dtr = dev_dtau_r(th, ee, _Gdt);
-                    STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01k + dev_stress_inc(s01k, toxz, ee, s_, _Gdt, dtr));
+                    const double dtr = DTR(ee, _Gdt);
+                    STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01k + INC(s01k, toxz, ee, s_, _Gdt, dtr));
                 }
                 {   // τyz (i,j,k)
                     const double s_ = 0.5 * (_dz * (vb - b_p) + _dy * (c_p - cy_p));
                     const double ee = 0.25 * ((LOWREG ? eye_p : ey_p + e_p) + ey + e);
                     const double gg = 0.25 * ((LOWREG ? gyg_p : gy_p + g_p) + gy + g);
                     const double _Gdt = VISC ? 0.0 : 1.0 / (gg * dt);
-                    const double dtr = dev_dtau_r(th, ee, _Gdt);
-                    STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01k + dev_stress_inc(r01k, toyz, ee, s_, _Gdt, dtr));
+                    const double dtr = DTR(ee, _Gdt);
+                    STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01k + INC(r01k, toyz, ee, s_, _Gdt, dtr));
                 }
             }
             if (HIF) {
@@ -974,16 +986,16 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                             const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsR ? vb : (bc.nsR ? -vb : LDB(f.Vy, ovy - rvy + 8u)));
                             const double s_ = 0.5 * (_dy * (vax - vxl) + _dx * (vyg - vb));
                             const double ee = 0.25 * (ey + ey + e + e);
-                            const double dtr = dev_dtau_r(th, ee, 0.0);
+                            const double dtr = DTR(ee, 0.0);
                             const double t0 = LDB(f.txy, oxy + 8u);
-                            STN<(NT & 1) != 0>(a.o.txy, oxy + 8u, t0 + dev_stress_inc(t0, 0.0, ee, s_, 0.0, dtr));
+                            STN<(NT & 1) != 0>(a.o.txy, oxy + 8u, t0 + INC(t0, 0.0, ee, s_, 0.0, dtr));
                         }
                         {   // τxz (nx, j, k): Vz[nx+1, j+1, k] is the ghost column of the previous plane's own Vz
                             const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : LDB(f.Vz, ovz - svz + 8u)));
                             const double s_ = 0.5 * (_dz * (vax - vax_p) + _dx * (vzg - c_p));
                             const double ee = 0.25 * (e_p + e_p + e + e);
-                            const double dtr = dev_dtau_r(th, ee, 0.0);
-                            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10k + dev_stress_inc(s10k, 0.0, ee, s_, 0.0, dtr));
+                            const double dtr = DTR(ee, 0.0);
+                            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10k + INC(s10k, 0.0, ee, s_, 0.0, dtr));
                         }
                     }
                     if (yl) {
@@ -992,16 +1004,16 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                             const double vyl = i > 0 ? sV[slot][1][ty][tx - 1] : (bc.nsBk ? 0.0 : (bc.fsL ? vby : (bc.nsL ? -vby : LDB(f.Vy, ovy - 8u))));
                             const double s_ = 0.5 * (_dy * (vxg - va) + _dx * (vby - vyl));
                             const double ee = 0.25 * (ex + e + ex + e);
-                            const double dtr = dev_dtau_r(th, ee, 0.0);
+                            const double dtr = DTR(ee, 0.0);
                             const double t0 = LDB(f.txy, oxy + rxy);
-                            STN<(NT & 1) != 0>(a.o.txy, oxy + rxy, t0 + dev_stress_inc(t0, 0.0, ee, s_, 0.0, dtr));
+                            STN<(NT & 1) != 0>(a.o.txy, oxy + rxy, t0 + INC(t0, 0.0, ee, s_, 0.0, dtr));
                         }
                         {   // τyz (i, ny, k)
                             const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : LDB(f.Vz, ovz - svz + rvz)));
                             const double s_ = 0.5 * (_dz * (vby - vby_p) + _dy * (vzg - c_p));
                             const double ee = 0.25 * (e_p + e_p + e + e);
-                            const double dtr = dev_dtau_r(th, ee, 0.0);
-                            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10k + dev_stress_inc(r10k, 0.0, ee, s_, 0.0, dtr));
+                            const double dtr = DTR(ee, 0.0);
+                            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10k + INC(r10k, 0.0, ee, s_, 0.0, dtr));
                         }
                     }
                     if (xl && yl) {   // τxy (nx, ny, k): both velocities on ghost lines of their own boundary values
@@ -1009,9 +1021,9 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                         const double vyg = bc.nsBk ? 0.0 : (bc.fsR ? vby : (bc.nsR ? -vby : LDB(f.Vy, ovy + 8u)));
                         const double s_ = 0.5 * (_dy * (vxg - vax) + _dx * (vyg - vby));
                         const double ee = 0.25 * (e + e + e + e);
-                        const double dtr = dev_dtau_r(th, ee, 0.0);
+                        const double dtr = DTR(ee, 0.0);
                         const double t0 = LDB(f.txy, oxy + 8u + rxy);
-                        STN<(NT & 1) != 0>(a.o.txy, oxy + 8u + rxy, t0 + dev_stress_inc(t0, 0.0, ee, s_, 0.0, dtr));
+                        STN<(NT & 1) != 0>(a.o.txy, oxy + 8u + rxy, t0 + INC(t0, 0.0, ee, s_, 0.0, dtr));
                     }
                 }
                 vax_p = vax; vby_p = vby;
@@ -1033,31 +1045,31 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             const double vxg = (i == 0 && bc.nsL) ? 0.0 : (bc.fsK1 ? a_p : (bc.nsK1 ? -a_p : LDB(f.Vx, ovx - 8u)));
             const double s_ = 0.5 * (_dz * (vxg - a_p) + _dx * (c_p - cx_p));
             const double ee = 0.25 * (ex_p + e_p + ex_p + e_p);
-            const double dtr = dev_dtau_r(th, ee, 0.0);
-            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01p + dev_stress_inc(s01p, 0.0, ee, s_, 0.0, dtr));
+            const double dtr = DTR(ee, 0.0);
+            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01p + INC(s01p, 0.0, ee, s_, 0.0, dtr));
         }
         {   // τyz (i, j, nz)
             const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsK1 ? b_p : (bc.nsK1 ? -b_p : LDB(f.Vy, ovy - rvy)));
             const double s_ = 0.5 * (_dz * (vyg - b_p) + _dy * (c_p - cy_p));
             const double ee = 0.25 * (ey_p + e_p + ey_p + e_p);
-            const double dtr = dev_dtau_r(th, ee, 0.0);
-            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01p + dev_stress_inc(r01p, 0.0, ee, s_, 0.0, dtr));
+            const double dtr = DTR(ee, 0.0);
+            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01p + INC(r01p, 0.0, ee, s_, 0.0, dtr));
         }
         if (xl) {   // τxz (nx, j, nz)
             const double vxg = bc.nsR ? 0.0 : (bc.fsK1 ? vax_p : (bc.nsK1 ? -vax_p : LDB(f.Vx, ovx)));
             const double vzg = bc.nsK1 ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : LDB(f.Vz, ovz - svz + 8u)));
             const double s_ = 0.5 * (_dz * (vxg - vax_p) + _dx * (vzg - c_p));
             const double ee = 0.25 * (e_p + e_p + e_p + e_p);
-            const double dtr = dev_dtau_r(th, ee, 0.0);
-            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10 + dev_stress_inc(s10, 0.0, ee, s_, 0.0, dtr));
+            const double dtr = DTR(ee, 0.0);
+            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10 + INC(s10, 0.0, ee, s_, 0.0, dtr));
         }
         if (yl) {   // τyz (i, ny, nz)
             const double vyg = bc.nsBk ? 0.0 : (bc.fsK1 ? vby_p : (bc.nsK1 ? -vby_p : LDB(f.Vy, ovy)));
             const double vzg = bc.nsK1 ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : LDB(f.Vz, ovz - svz + rvz)));
             const double s_ = 0.5 * (_dz * (vyg - vby_p) + _dy * (vzg - c_p));
             const double ee = 0.25 * (e_p + e_p + e_p + e_p);
-            const double dtr = dev_dtau_r(th, ee, 0.0);
-            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10 + dev_stress_inc(r10, 0.0, ee, s_, 0.0, dtr));
+            const double dtr = DTR(ee, 0.0);
+            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10 + INC(r10, 0.0, ee, s_, 0.0, dtr));
         }
     }
 }
