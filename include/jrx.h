@@ -74,7 +74,10 @@ const char *jrx_build_id(void);
  *   1 = simple one-thread-per-node kernels;  2 = the two sweeps only (z-marching; per-node on blocks up to ~88^3; no ping-pong set);
  *   3 = fused pipeline wherever it is legal (ignores that rule).  All variants produce bit-identical results.
  * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
- * "fused_overlap" (0/1/2, default 2): how the multi-rank fused pipeline places update_halo!(V) (same results in every mode):
+ * "fused_overlap" (0/1/2/3, default 3): how the multi-rank fused pipeline places update_halo!(V) (same results in every mode):
+ *   3 = neighbour faces inside the kernel (viscous-limit form, dt = Inf; other runs use 2): boundary slabs + the exchange on a second stream beside the fused kernel as in 2, but the
+ *       kernel's tiles next to a face with a neighbour are the last blocks of the launch, wait for a device-side flag posted behind the exchange and read the received planes themselves:
+ *       no flow_bcs! launch, no fix-up -- one launch per iteration and rank;
  *   2 = early exchange: the velocity phase alone over the boundary slabs of the faces with a neighbour, flow_bcs! and the whole exchange on a second
  *       stream BESIDE the fused kernel (which recomputes those cells with the same values), then flow_bcs! on the physical faces and the fix-up;
  *   1 = the shell of tiles, BCs and exchange on the second stream while the interior tiles run;  0 = everything behind the kernel, in order.
@@ -90,7 +93,7 @@ const char *jrx_build_id(void);
  *   nor 0): only then do the results equal the general kernels', and only then does this form run -- otherwise the general kernels run and a NaN
  *   there ends the solve with JRX_ERR_NAN exactly as error("NaN(s)") of Stokes3D.jl:162 would.  0 = always the general kernels.
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
- *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_visc_checks" /
+ *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_fused3d_inkernel" = those that finished the faces with a neighbour themselves ("fused_overlap" = 3), "stat_visc_checks" /
  *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
  *   (and the tests, and bench.py for the kernel it prices) can prove which path ran. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);

@@ -73,8 +73,9 @@ jrx_status jrx_create(int32_t device, jrx_handle **out)
     for (int i = 0; i < 3; i++) CK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));   // stream joins
     for (int i = 3; i < 8; i++) CK(hipEventCreate(&h->ev[i]));                                    // timing
     CK(hipMalloc(&h->d_partials, sizeof(double) * 4 * kMaxRedBlocks));
-    CK(hipMalloc(&h->d_sums, sizeof(double) * 8));
-    CK(hipHostMalloc(&h->h_sums, sizeof(double) * 8, hipHostMallocDefault));
+    CK(hipMalloc(&h->d_sums, sizeof(double) * 16));         // [0..7] reductions / flags of the drivers, [8] the halo flag of the in-kernel neighbour faces, [9] its time-out mark
+    CK(hipMemset(h->d_sums, 0, sizeof(double) * 16));
+    CK(hipHostMalloc(&h->h_sums, sizeof(double) * 16, hipHostMallocDefault));
 #undef CK
     if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);
     *out = h;
@@ -121,7 +122,7 @@ int find_opt(jrx_handle *h, const char *key, bool tuning, OptRef *out)
         {"viscous_limit", 0, &h->viscous_limit},
         {"stat_fused3d", 2, &h->stat_fused3d}, {"stat_fused2d", 2, &h->stat_fused2d}, {"stat_thermal_fused", 2, &h->stat_thermal_fused},
         {"stat_vep3_fused", 2, &h->stat_vep3_fused}, {"stat_graph_replays", 2, &h->stat_graph_replays},
-        {"stat_fused3d_visc", 2, &h->stat_fused3d_visc}, {"stat_visc_checks", 2, &h->stat_visc_checks}, {"stat_visc_fallbacks", 2, &h->stat_visc_fallbacks},
+        {"stat_fused3d_visc", 2, &h->stat_fused3d_visc}, {"stat_fused3d_inkernel", 2, &h->stat_fused3d_inkernel}, {"stat_visc_checks", 2, &h->stat_visc_checks}, {"stat_visc_fallbacks", 2, &h->stat_visc_fallbacks},
     };
     const OptRef tun[] = {
         {"fused_split", 0, &h->fused_split}, {"fused_tile", 1, &h->fused_tile}, {"fused_ylds", 0, &h->fused_ylds}, {"fused_hiface", 0, &h->fused_hiface}, {"visc_fold", 0, &h->visc_fold}, {"comm_bcs_lazy", 0, &h->comm_bcs_lazy},

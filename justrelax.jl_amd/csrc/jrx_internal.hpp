@@ -17,8 +17,9 @@ struct jrx_handle {
     hipStream_t halo_stream = nullptr;   // boundary slabs + pack/unpack + RCCL
     hipEvent_t ev[8] = {};
     double *d_partials = nullptr;        // reduction scratch [kMaxRedBlocks][4]
-    double *d_sums = nullptr;            // [8] final sums (device)
-    double *h_sums = nullptr;            // [8] pinned host mirror
+    double *d_sums = nullptr;            // [16] final sums and flags (device)
+    double *h_sums = nullptr;            // [16] pinned host mirror
+    unsigned long long halo_seq = 0;     // update_halo!(V) exchanges posted to the device-side flag d_sums[8] (in-kernel neighbour faces, fused_overlap = 3)
     double *etatau = nullptr;            // library-owned ητ (capacity etatau_cap doubles)
     size_t etatau_cap = 0;
     jrx_comm_state *comm = nullptr;
@@ -33,7 +34,8 @@ struct jrx_handle {
     // ---- options (jrx_set_option; nothing in the library reads the process environment)
     bool loop_graphs = true;             // launch-bound 2D loops: runs of unobserved iterations replay as captured hipGraphs (option "loop_graphs")
     bool thermal_fused = true;           // heat diffusion: one fused launch per unobserved iteration (option "thermal_fused")
-    int fused_overlap = 2;               // multi-rank fused pipeline: 0 exchange behind the kernel, in order; 1 shell tiles + exchange on the halo stream, interior tiles
+    int fused_overlap = 3;               // multi-rank fused pipeline: 3 (viscous-limit form) the kernel's own boundary tiles read the received planes -- they run last and wait for a device-side
+                                         // flag behind update_halo!(V) -- nothing is left behind the kernel; 0 exchange behind the kernel, in order; 1 shell tiles + exchange on the halo stream, interior tiles
                                          // concurrently; 2 boundary slabs of the velocity phase + BCs + the whole exchange on the halo stream beside the kernel (early exchange)
     int kernel_variant = 0;              // 0 auto (fused PT pipeline where it pays), 1 per-node v1 kernels, 2 z-marching sweeps only, 3 fused wherever legal
     bool fused_split = false;            // no neighbours: high-face tiles + boundary stress layers on the halo stream, interior tiles concurrently
@@ -68,6 +70,7 @@ struct jrx_handle {
     bool scratch_sets = true;            // the fused pipelines may allocate their library-owned second state set (0: never -- un-fused paths)
     // ---- read-only counters (jrx_get_option "stat_*"): launches of the fused kernels since jrx_create, so that tests and the bench can
     //      prove which kernel path ran
+    int64_t stat_fused3d_inkernel = 0;   // launches of k_fused3d that finished the neighbour faces themselves (fused_overlap = 3)
     int64_t stat_fused3d_visc = 0, stat_visc_checks = 0, stat_visc_fallbacks = 0;     // launches of the viscous-limit form of k_fused3d; operand checks run / failed
     int64_t stat_fused3d = 0, stat_fused2d = 0, stat_thermal_fused = 0, stat_vep3_fused = 0, stat_graph_replays = 0;
     bool chain_profile = false;          // tuning switch: jrx_stokes3d_iterate_timed also times the stages of a multi-rank fused step (jrx_tuning_chain_profile)

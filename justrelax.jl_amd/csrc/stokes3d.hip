@@ -110,6 +110,22 @@ __global__ __launch_bounds__(256) void k_visc_operands_ok(const double *__restri
     if (__any(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
 }
 
+// in-kernel neighbour faces (fused_overlap = 3): the halo stream posts the sequence number of the exchange it has finished; the boundary tiles of k_fused3d wait for it
+__global__ void k_post_halo_flag(unsigned long long *flag, unsigned long long seq)
+{
+    __threadfence();
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a boundary tile that waited in vain for its received planes (a neighbour that never delivered) has marked d_sums[9]: the fields are then garbage -- report it
+jrx_status check_halo_timeout(jrx_handle *h)
+{
+    if (h->halo_seq == 0) return JRX_OK;
+    unsigned int mark = 0;
+    JRX_HIP(h, hipMemcpy(&mark, reinterpret_cast<unsigned int *>(h->d_sums + 9), sizeof(mark), hipMemcpyDeviceToHost));
+    if (mark) return jrx_fail(h, JRX_ERR_RCCL, "update_halo!: the boundary tiles of the fused kernel timed out waiting for a neighbour's planes (a rank failed or left the call sequence)");
+    return JRX_OK;
+}
+
 jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
 {
     h->visc_ok = false;
@@ -572,7 +588,7 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
 
 // launch the fused kernel over the box of tiles [b[0], b[1]) x [b[2], b[3]) x [b[4], b[5])
 template <int TX, int TY, int KZ>
-static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface, bool fold)
+static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface, bool fold, const FusedShell *shell = nullptr)
 {
     // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
     // fetched array passes per launch at 512^3)
@@ -584,7 +600,12 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     // instead of the third LDS slot: LOWREG off, -1.4 %, scripts/kbench_visc.hip)
     const bool visc = h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
     const bool vf = h->visc_fold;      // tuning switch: the folded arithmetic of the viscous limit (k_fused3d, VFOLD; same bits)
-    if (visc && fold && vf)       // + the high-face node layers inside the kernel: the whole iteration in one launch
+    if (shell) {        // neighbours, one launch: interior tiles first, the tiles next to a face with a neighbour last (they wait for the exchange's flag)
+        if (!(visc && fold)) return jrx_fail(h, JRX_ERR_ARG, "internal: the in-kernel neighbour faces need the one-launch viscous-limit form");
+        const unsigned nblk = (unsigned)shell->start[shell->nbox];
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true>), dim3(nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
+        h->stat_fused3d_inkernel++;
+    } else if (visc && fold && vf)       // + the high-face node layers inside the kernel: the whole iteration in one launch
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc && fold)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
@@ -615,18 +636,18 @@ static bool fused_folds_hiface(const jrx_handle *h, const SweepArgs &a)
 {
     return h->fused_hiface && h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
 }
-static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false, bool fold = false)
+static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false, bool fold = false, const FusedShell *shell = nullptr)
 {
     const FusedShape S = fused_shape(h, a.L);
     const int kz = S.kz;
     if (S.tx == 64) {
-        if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface, fold);
-        if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface, fold);
-        return launch_fused_t<64, 4, 2>(h, s, a, bc, b, hiface, fold);
+        if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface, fold, shell);
+        if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface, fold, shell);
+        return launch_fused_t<64, 4, 2>(h, s, a, bc, b, hiface, fold, shell);
     }
-    if (kz == 8) return launch_fused_t<32, 8, 8>(h, s, a, bc, b, hiface, fold);
-    if (kz == 4) return launch_fused_t<32, 8, 4>(h, s, a, bc, b, hiface, fold);
-    return launch_fused_t<32, 8, 2>(h, s, a, bc, b, hiface, fold);
+    if (kz == 8) return launch_fused_t<32, 8, 8>(h, s, a, bc, b, hiface, fold, shell);
+    if (kz == 4) return launch_fused_t<32, 8, 4>(h, s, a, bc, b, hiface, fold, shell);
+    return launch_fused_t<32, 8, 2>(h, s, a, bc, b, hiface, fold, shell);
 }
 
 // the faces of this rank's block that are physical boundaries (no neighbour): the bits of free_slip / no_slip that flow_bcs! may act on once the planes of the other faces
@@ -673,6 +694,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.fsK0 = !!(fs & JRX_FACE_TOP);  bc.nsK0 = !!(ns & JRX_FACE_BOT);     // k = 1: free_slip `top`, no_slip `bot` (reference naming)
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
         bc.fsR = !!(fs & JRX_FACE_RIGHT); bc.fsBk = !!(fs & JRX_FACE_BACK); bc.fsK1 = !!(fs & JRX_FACE_BOT);       // k = end: free_slip `bot`
+        bc.nbL = bc.nbR = bc.nbF = bc.nbBk = bc.nbK0 = bc.nbK1 = 0;
         // 256 threads per tile, 8 planes per chunk (128 VGPRs -> 4 blocks/CU)
         int nt[3];
         const FusedShape S = fused_shape(h, a.L);
@@ -697,7 +719,10 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         // send/recv kernel does not finish before the interior kernel drains, so nothing is hidden and the six small shell launches
         // cost more than they save when an x face is involved (10.7 vs 9.1 ms); to be revisited with real neighbours / DMA copies.
         const bool overlap = h->fused_overlap == 1;
-        const bool early = h->fused_overlap == 2 && comm && !per;
+        // option "fused_overlap" = 3 (default): the viscous-limit kernel's own boundary tiles finish the cells next to the received planes (see the branch below); where that
+        // form does not run (finite dt, a failed operand check) the early exchange (2) stands in
+        const bool inkernel = h->fused_overlap == 3 && comm && !per && fused_folds_hiface(h, a) && h->visc_fold;
+        const bool early = (h->fused_overlap == 2 || (h->fused_overlap == 3 && !inkernel)) && comm && !per;
         const bool split = !comm && !per && h->fused_split && nt[0] > 1 && nt[1] > 1 && nt[2] > 1;
         if (split) {
             // Without neighbours the only work behind the fused kernel is the stress update of the high-face node layers (i = nx, j = ny,
@@ -723,6 +748,89 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             JRX_TRY(launch_fused(h, bs, a, bc, hz, true));
             I.ghosts_stale = true;
             if (ncells_timed) *ncells_timed = (double)imin(nx, (nt[0] - 1) * (S.tx - 2)) * (double)imin(ny, (nt[1] - 1) * (S.ty - 1)) * (double)imin(nz, (nt[2] - 1) * S.kz);
+        } else if (inkernel) {
+            // Neighbour faces inside the kernel (option "fused_overlap" = 3).  As with the early exchange, the velocity phase alone runs first over the boundary slabs of the
+            // faces with a neighbour and update_halo!(V) follows on the halo stream, beside k_fused3d on the compute stream.  But the kernel then needs no fix-up: its tiles
+            // next to a face with a neighbour are the LAST blocks of the launch, wait for a device-side flag that the halo stream posts behind its last unpack, and read the
+            // received planes of the new set where the other tiles apply a flow_bcs! rule -- the stress nodes next to a received plane (and the high-face node layers, HIF)
+            // come out right the first time.  flow_bcs! is not applied in memory at all (every rule is applied on the fly; the pending application happens before anything
+            // reads those entries from memory, `ghosts_stale`).  One launch per iteration and rank, whatever the decomposition; the strided x-face layers are gone.
+            bs = h->halo_stream;
+            JRX_HIP(h, hipEventRecord(h->ev[0], s));
+            JRX_HIP(h, hipStreamWaitEvent(bs, h->ev[0], 0));
+            bool nbf[3][2];
+            for (int d = 0; d < 3; d++) { nbf[d][0] = jrx_comm_has_neighbor(h, d, 0); nbf[d][1] = jrx_comm_has_neighbor(h, d, 1); }
+            {
+                const int w = 4;
+                const int xa = imin(w, nx / 2), ya = imin(w, ny / 2), za = imin(w, nz / 2);
+                const bool L0 = nbf[0][0], H0 = nbf[0][1], L1 = nbf[1][0], H1 = nbf[1][1], L2 = nbf[2][0], H2 = nbf[2][1];
+                const int z0 = L2 ? za : 0, z1 = H2 ? nz - za : nz, y0 = L1 ? ya : 0, y1 = H1 ? ny - ya : ny;
+                if (L2) JRX_TRY(launch_velocity(h, bs, a, false, 0, nx, 0, ny, 0, za));
+                if (H2) JRX_TRY(launch_velocity(h, bs, a, false, 0, nx, 0, ny, nz - za, nz));
+                if (L1) JRX_TRY(launch_velocity(h, bs, a, false, 0, nx, 0, ya, z0, z1));
+                if (H1) JRX_TRY(launch_velocity(h, bs, a, false, 0, nx, ny - ya, ny, z0, z1));
+                if (L0) JRX_TRY(launch_velocity(h, bs, a, false, 0, xa, y0, y1, z0, z1));
+                if (H0) JRX_TRY(launch_velocity(h, bs, a, false, nx - xa, nx, y0, y1, z0, z1));
+            }
+            if (cev) { JRX_HIP(h, hipEventRecord(cev[0], bs)); JRX_HIP(h, hipEventRecord(cev[1], bs)); }
+            {
+                double *arrs[3] = {dst.Vx, dst.Vy, dst.Vz};
+                const int64_t ext[3][3] = {{nx + 1, ny + 2, nz + 2}, {nx + 2, ny + 1, nz + 2}, {nx + 2, ny + 2, nz + 1}};
+                const int64_t n[3] = {nx, ny, nz};
+                JRX_TRY(jrx_halo_exchange(h, bs, 3, arrs, ext, n));
+            }
+            unsigned long long *flag = reinterpret_cast<unsigned long long *>(h->d_sums + 8);
+            hipLaunchKernelGGL(k_post_halo_flag, dim3(1), dim3(1), 0, bs, flag, ++h->halo_seq);
+            JRX_LAUNCH_CHECK(h);
+            if (cev) JRX_HIP(h, hipEventRecord(cev[2], bs));
+            FusedShell sh;
+            memset(&sh, 0, sizeof(sh));
+            int lo[3], hi[3];
+            for (int d = 0; d < 3; d++) { lo[d] = (nbf[d][0] && nt[d] > 1) ? 1 : 0; hi[d] = (nbf[d][1] && nt[d] > 1) ? nt[d] - 1 : nt[d]; if (hi[d] < lo[d]) hi[d] = lo[d]; }
+            // a dimension with a single tile and a neighbour has no interior tile at all
+            for (int d = 0; d < 3; d++) if ((nbf[d][0] || nbf[d][1]) && nt[d] == 1) { lo[d] = 0; hi[d] = 0; }
+            sh.ntx_i = hi[0] - lo[0]; sh.nty_i = hi[1] - lo[1];
+            sh.tx0_i = lo[0]; sh.ty0_i = lo[1]; sh.tz0_i = lo[2];
+            sh.n_int = sh.ntx_i * sh.nty_i * (hi[2] - lo[2]);
+            if (sh.n_int <= 0) { sh.n_int = 0; sh.ntx_i = sh.nty_i = 1; }
+            {
+                // the shell: z slabs over the whole xy extent, then y slabs over the remaining z range, then x slabs over the remaining y and z ranges -- disjoint boxes
+                const int boxes[6][6] = {{0, nt[0], 0, nt[1], 0, lo[2]}, {0, nt[0], 0, nt[1], hi[2], nt[2]},
+                                         {0, nt[0], 0, lo[1], lo[2], hi[2]}, {0, nt[0], hi[1], nt[1], lo[2], hi[2]},
+                                         {0, lo[0], lo[1], hi[1], lo[2], hi[2]}, {hi[0], nt[0], lo[1], hi[1], lo[2], hi[2]}};
+                int tot = sh.n_int;
+                for (int q = 0; q < 6; q++) {
+                    const int *b = boxes[q];
+                    const int cnt = (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]);
+                    if (b[1] <= b[0] || b[3] <= b[2] || b[5] <= b[4] || cnt <= 0) continue;
+                    for (int c = 0; c < 6; c++) sh.box[sh.nbox][c] = b[c];
+                    sh.start[sh.nbox] = tot;
+                    tot += cnt;
+                    sh.nbox++;
+                }
+                sh.start[sh.nbox] = tot;
+                if (tot != nt[0] * nt[1] * nt[2]) return jrx_fail(h, JRX_ERR_ARG, "internal: the tile classes of the fused kernel do not cover the block (%d of %d)", tot, nt[0] * nt[1] * nt[2]);
+            }
+            sh.flag = flag; sh.seq = h->halo_seq; sh.err = reinterpret_cast<unsigned int *>(h->d_sums + 9);
+            const double tmo = h->comm_timeout_ms * 1e-3 < 30.0 ? h->comm_timeout_ms * 1e-3 : 30.0;
+            sh.timeout_ticks = (unsigned long long)(tmo * 1e8);         // wall_clock64: 100 MHz
+            FusedBC bn = bc;
+            bn.nbL = nbf[0][0]; bn.nbR = nbf[0][1]; bn.nbF = nbf[1][0]; bn.nbBk = nbf[1][1]; bn.nbK0 = nbf[2][0]; bn.nbK1 = nbf[2][1];
+            if (bn.nbL) bn.fsL = bn.nsL = 0;
+            if (bn.nbR) bn.fsR = bn.nsR = 0;
+            if (bn.nbF) bn.fsF = bn.nsF = 0;
+            if (bn.nbBk) bn.fsBk = bn.nsBk = 0;
+            if (bn.nbK0) bn.fsK0 = bn.nsK0 = 0;
+            if (bn.nbK1) bn.fsK1 = bn.nsK1 = 0;
+            const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
+            JRX_TRY(launch_fused(h, s, a, bn, all, false, true, &sh));
+            if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
+            JRX_HIP(h, hipEventRecord(h->ev[2], bs));
+            JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
+            bs = s;
+            if (cev) { JRX_HIP(h, hipEventRecord(cev[3], s)); if (chain_mode) *chain_mode = 2; }
+            I.ghosts_stale = true;
+            folded = true;
         } else if (early) {
             // Early exchange (option "fused_overlap" = 2).  What the neighbours need of V_m -- the planes 2 / n - 2 (normal component) and the cell layers 2 / n - 3
             // (tangential ones) -- lies within four cells of the face.  So the velocity phase alone runs first over the boundary slabs of the faces WITH a neighbour
@@ -1005,6 +1113,7 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
             JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
             JRX_HIP(h, hipStreamSynchronize(s));
             double ss[4] = {h->h_sums[0], h->h_sums[1], h->h_sums[2], h->h_sums[3]};
+            JRX_TRY(check_halo_timeout(h));
             JRX_TRY(jrx_allreduce_sum_host(h, ss, 4));       // norm_mpi: sqrt(Allreduce(Σx²)) (Utils.jl:698-701)
             const double nRx = sqrt(ss[0]) / (double)((p->nxg - 2) * (p->nyg - 1) * (p->nzg - 1));
             const double nRy = sqrt(ss[1]) / (double)((p->nxg - 1) * (p->nyg - 2) * (p->nzg - 1));
@@ -1094,6 +1203,7 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_TRY(iter_end(I));
     JRX_HIP(h, hipStreamSynchronize(s));
+    JRX_TRY(check_halo_timeout(h));
     float ms = 0.f;
     JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
     times_ms[0] = ms; times_ms[1] = times_ms[2] = times_ms[3] = times_ms[4] = times_ms[5] = 0.0;

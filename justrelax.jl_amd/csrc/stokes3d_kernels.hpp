@@ -653,7 +653,24 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs 
 struct FusedBC {
     // low faces: free-slip / no-slip flags; high faces: "normal velocity = 0" for the cells, the free-slip flags for the folded high-face node layers (HIF)
     int fsL, nsL, fsF, nsF, fsK0, nsK0, nsR, nsBk, nsK1, fsR, fsBk, fsK1;
+    // NBR: faces with a neighbour (their fs / ns flags are cleared): the planes of the DESTINATION set there hold received velocities
+    int nbL, nbR, nbF, nbBk, nbK0, nbK1;
 };
+// NBR: the tiles of one launch in two classes -- blocks [0, n_int) are the box of tiles that touch no face with a neighbour (XCD-banded order inside the box), the blocks
+// behind them the up to six disjoint boxes of tiles that do; those wait for `*flag >= seq` (posted on the halo stream behind update_halo!(V)) before they start
+struct FusedShell {
+    int n_int, ntx_i, nty_i, tx0_i, ty0_i, tz0_i;
+    int nbox, box[6][6], start[7];
+    const unsigned long long *flag;
+    unsigned long long seq, timeout_ticks;
+    unsigned int *err;
+};
+// coherent load (device scope): a value another kernel of this device has written while this one runs
+__device__ __forceinline__ double LDC(const double *p, u32 off)
+{
+    const unsigned long long v = __hip_atomic_load((const unsigned long long *)((const char *)p + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)v);
+}
 
 // OVX: x-overlap of neighbouring tiles in cells (1, or 16 = one 128-B line so that row segments stay line-aligned; only
 // the last overlap column is computed).  LOWREG: the previous velocity plane is re-read from a third LDS slot and the
@@ -675,8 +692,8 @@ struct FusedBC {
 // HIF (viscous-limit form, no neighbours): the stress nodes on the high faces i = nx, j = ny, k = nz -- which no cell column owns and which the boundary-layer launch
 // (k_stress3d_boxes with the flow_bcs! rules) otherwise updates behind this kernel -- are updated here by the threads of the last cell column / row / plane, from the
 // new velocities they hold anyway and the same rules (GhostRule), operation for operation as stress3d_node<false, true, true>: one launch per iteration.
-template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false, bool VFOLD = false>
-__global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0)
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false, bool VFOLD = false, bool NBR = false>
+__global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0, const FusedShell sh = FusedShell{})
 {
     // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
     static_assert(!(SHFL && (LATEA || (TX != 64 && TX != 32))), "SHFL is implemented for rows of one wave or half a wave");
@@ -684,6 +701,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     static_assert(!VISC || YLDS, "the viscous-limit form is built on the YLDS operand layout");
     static_assert(!HIF || (VISC && !LOWREG && SHFL && OVX == 1), "the folded high-face layers are built for the viscous-limit form with carried planes");
     static_assert(!VFOLD || VISC, "VFOLD simplifies the viscous-limit arithmetic");
+    static_assert(!NBR || (VISC && HIF), "the in-kernel neighbour faces are built on the one-launch viscous-limit form");
     constexpr int NS = LOWREG ? 3 : 2;
     __shared__ double sV[NS][3][TY][TX];
     __shared__ double sY[YLDS ? (VISC ? 7 : 8) : 1][YLDS ? TY : 1][YLDS ? TX : 1];
@@ -691,19 +709,45 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     const int nx = L.nx, ny = L.ny, nz = L.nz;
     const jrx_stokes3d_fields &f = a.f;
     const double *et = a.etatau;
+    // a boundary entry of V read from memory: on a face with a neighbour it is in the destination set (received in this iteration), else in the source set (prescribed, static)
+#define NBV(flag_, arr_, off_) ((NBR && bc.flag_) ? LDC(a.o.arr_, (off_)) : LDB(f.arr_, (off_)))
+    // ... where such an entry also lies on the normal plane of a physical no-slip face it is zero by rule (vx_rule / vy_rule / vz_rule check that first): flow_bcs! is not applied in
+    // memory in this pipeline, so the received plane does not carry the zero.  ii_ / jj_ / kk_: the entry's index along the array's own direction
+#define NBVX(flag_, off_, ii_) ((NBR && bc.flag_) ? ((((ii_) == 0 && bc.nsL) || ((ii_) == nx && bc.nsR)) ? 0.0 : LDC(a.o.Vx, (off_))) : LDB(f.Vx, (off_)))
+#define NBVY(flag_, off_, jj_) ((NBR && bc.flag_) ? ((((jj_) == 0 && bc.nsF) || ((jj_) == ny && bc.nsBk)) ? 0.0 : LDC(a.o.Vy, (off_))) : LDB(f.Vy, (off_)))
+#define NBVZ(flag_, off_, kk_) ((NBR && bc.flag_) ? ((((kk_) == 0 && bc.nsK0) || ((kk_) == nz && bc.nsK1)) ? 0.0 : LDC(a.o.Vz, (off_))) : LDB(f.Vz, (off_)))
     const int tx = (int)(threadIdx.x % TX), ty = (int)(threadIdx.x / TX);
     int tile = blockIdx.x;
-    if (XG > 0) {
+    int nblk = (int)gridDim.x;
+    if (NBR) { ntx = sh.ntx_i; nty = sh.nty_i; tx0 = sh.tx0_i; ty0 = sh.ty0_i; tz0 = sh.tz0_i; nblk = sh.n_int; }
+    const bool shell = NBR && tile >= sh.n_int;          // a tile next to a face with a neighbour
+    if (XG > 0 && !shell) {
         // XCD-banded order (blocks are dealt round-robin to the 8 XCDs): XCD q takes XG consecutive tile rows
         // q*XG .. q*XG+XG-1 of every group of 8*XG rows (rows run over y, then z), so the y-halo rows of
         // neighbouring tiles are served by the same L2; the tail that does not fill a group keeps plain order
-        const int full = ((nty * (int)(gridDim.x / (unsigned)(ntx * nty))) / (8 * XG)) * (8 * XG) * ntx;
+        const int full = ((nty * (int)((unsigned)nblk / (unsigned)(ntx * nty))) / (8 * XG)) * (8 * XG) * ntx;
         if (tile < full) {
             const int q = tile & 7, r = tile >> 3, r2 = r / ntx;
             tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
         }
     }
-    const int tr = tile / ntx, tix = tx0 + tile % ntx, tiy = ty0 + tr % nty, tiz = tz0 + tr / nty;
+    int tr = tile / ntx, tix = tx0 + tile % ntx, tiy = ty0 + tr % nty, tiz = tz0 + tr / nty;
+    if (shell) {
+        int b = 0;
+        while (b + 1 < sh.nbox && tile >= sh.start[b + 1]) b++;
+        const int l = tile - sh.start[b], bw = sh.box[b][1] - sh.box[b][0], bh = sh.box[b][3] - sh.box[b][2];
+        tix = sh.box[b][0] + l % bw; tiy = sh.box[b][2] + (l / bw) % bh; tiz = sh.box[b][4] + l / (bw * bh);
+        // the received planes this tile reads must have landed: update_halo!(V) of this iteration runs on the halo stream beside this kernel and posts the flag behind
+        // its last unpack.  These blocks are the last of the launch, so the flag is long up when they start; a neighbour that never delivers is a time-out, not a hang
+        if (threadIdx.x == 0) {
+            const unsigned long long t0_ = wall_clock64();
+            while (__hip_atomic_load(sh.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sh.seq) {
+                __builtin_amdgcn_s_sleep(32);
+                if (wall_clock64() - t0_ > sh.timeout_ticks) { __hip_atomic_store(sh.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+    }
     const int i = tix * (TX - OVX - (SHFL ? 1 : 0)) - OVX + tx;  // cell column of this thread
     const int j = tiy * (TY - 1) - 1 + ty;
     const int kb = tiz * KZ;
@@ -810,6 +854,11 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDN<(NT & 2) != 0>(f.fz, oc + dz1);
                 txx_c = LDB(f.txx, oc); fx_c = LDN<(NT & 2) != 0>(f.fx, oc);
                 vx = LDB(f.Vx, ovx); vy = LDB(f.Vy, ovy); vz = LDB(f.Vz, ovz);
+                if (NBR) {      // the boundary planes i = nx, j = ny, k = nz of a face with a neighbour: received values
+                    if (!hx && bc.nbR) vx = LDC(a.o.Vx, ovx);
+                    if (!hy && bc.nbBk) vy = LDC(a.o.Vy, ovy);
+                    if (!hz && bc.nbK1) vz = LDC(a.o.Vz, ovz);
+                }
                 if (YLDS == 2 && !VISC && avalid && live) {
                     // the stress phase's remaining operands queue behind the published ones
                     P0 = LDN<(NT & 2) != 0>(f.P0, oc); Kc = LDN<(NT & 2) != 0>(f.K, oc); Qc = LDN<(NT & 2) != 0>(f.Q, oc);
@@ -901,14 +950,14 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             double va, vay, vb, vbx, vcx, vcy;
             const double vax = vxn, vby = vyn, vc = vzn;
             const u32 gvx = ovx - 8u, gvy = ovy - rvy, gvz = ovz;       // Vx[i,j+1,k+1], Vy[i+1,j,k+1], Vz[i+1,j+1,k+1]
-            va = i > 0 ? sV[slot][0][ty][tx - 1] : (bc.nsL ? 0.0 : LDB(f.Vx, gvx));
-            if (j > 0) vay = i > 0 ? sV[slot][0][ty - 1][tx - 1] : (bc.nsL ? 0.0 : LDB(f.Vx, gvx - rvx));
-            else vay = bc.fsF ? va : (bc.nsF ? -va : LDB(f.Vx, gvx - rvx));
-            vb = j > 0 ? sV[slot][1][ty - 1][tx] : (bc.nsF ? 0.0 : LDB(f.Vy, gvy));
-            if (i > 0) vbx = j > 0 ? sV[slot][1][ty - 1][tx - 1] : (bc.nsF ? 0.0 : LDB(f.Vy, gvy - 8u));
-            else vbx = bc.fsL ? vb : (bc.nsL ? -vb : LDB(f.Vy, gvy - 8u));
-            vcx = i > 0 ? sV[slot][2][ty][tx - 1] : (bc.fsL ? vc : (bc.nsL ? -vc : LDB(f.Vz, gvz - 8u)));
-            vcy = j > 0 ? sV[slot][2][ty - 1][tx] : (bc.fsF ? vc : (bc.nsF ? -vc : LDB(f.Vz, gvz - rvz)));
+            va = i > 0 ? sV[slot][0][ty][tx - 1] : (bc.nsL ? 0.0 : NBV(nbL, Vx, gvx));
+            if (j > 0) vay = i > 0 ? sV[slot][0][ty - 1][tx - 1] : (bc.nsL ? 0.0 : NBV(nbL, Vx, gvx - rvx));
+            else vay = bc.fsF ? va : (bc.nsF ? -va : NBVX(nbF, gvx - rvx, i));
+            vb = j > 0 ? sV[slot][1][ty - 1][tx] : (bc.nsF ? 0.0 : NBV(nbF, Vy, gvy));
+            if (i > 0) vbx = j > 0 ? sV[slot][1][ty - 1][tx - 1] : (bc.nsF ? 0.0 : NBV(nbF, Vy, gvy - 8u));
+            else vbx = bc.fsL ? vb : (bc.nsL ? -vb : NBVY(nbL, gvy - 8u, j));
+            vcx = i > 0 ? sV[slot][2][ty][tx - 1] : (bc.fsL ? vc : (bc.nsL ? -vc : NBVZ(nbL, gvz - 8u, k + 1)));
+            vcy = j > 0 ? sV[slot][2][ty - 1][tx] : (bc.fsF ? vc : (bc.nsF ? -vc : NBVZ(nbF, gvz - rvz, k + 1)));
             if (LOWREG && k > 0 && live) {
                 const int ps = (k + 2) % 3;       // slot of plane k-1
                 a_p = i > 0 ? sV[ps][0][ty][tx - 1] : (bc.nsL ? 0.0 : LDB(f.Vx, gvx - svx));
@@ -919,11 +968,11 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             }
             if (k == 0) {
                 // plane K = 0 of V: ghost of Vx, Vy (tangential), boundary plane of Vz (normal)
-                a_p = bc.fsK0 ? va : (bc.nsK0 ? -va : LDB(f.Vx, gvx - svx));
-                b_p = bc.fsK0 ? vb : (bc.nsK0 ? -vb : LDB(f.Vy, gvy - svy));
-                c_p = bc.nsK0 ? 0.0 : LDB(f.Vz, gvz - svz);
-                cx_p = i > 0 ? (bc.nsK0 ? 0.0 : LDB(f.Vz, gvz - svz - 8u)) : (bc.fsL ? c_p : (bc.nsL ? -c_p : LDB(f.Vz, gvz - svz - 8u)));
-                cy_p = j > 0 ? (bc.nsK0 ? 0.0 : LDB(f.Vz, gvz - svz - rvz)) : (bc.fsF ? c_p : (bc.nsF ? -c_p : LDB(f.Vz, gvz - svz - rvz)));
+                a_p = bc.fsK0 ? va : (bc.nsK0 ? -va : NBVX(nbK0, gvx - svx, i));
+                b_p = bc.fsK0 ? vb : (bc.nsK0 ? -vb : NBVY(nbK0, gvy - svy, j));
+                c_p = bc.nsK0 ? 0.0 : NBV(nbK0, Vz, gvz - svz);
+                cx_p = i > 0 ? (bc.nsK0 ? 0.0 : NBV(nbK0, Vz, gvz - svz - 8u)) : (bc.fsL ? c_p : (bc.nsL ? -c_p : NBVZ(nbL, gvz - svz - 8u, 0)));
+                cy_p = j > 0 ? (bc.nsK0 ? 0.0 : NBV(nbK0, Vz, gvz - svz - rvz)) : (bc.fsF ? c_p : (bc.nsF ? -c_p : NBVZ(nbF, gvz - svz - rvz, 0)));
                 e_p = e; ex_p = ex; ey_p = ey; g_p = g; gx_p = gx; gy_p = gy;
                 exe_p = ex + e; eye_p = ey + e; gxg_p = gx + g; gyg_p = gy + g;
             }
@@ -976,14 +1025,14 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 const bool xl = i == nx - 1, yl = j == ny - 1;
                 if (k == 0) {
                     // plane K = 0 of Vx[nx, j+1, ·] / Vy[i+1, ny, ·]: tangential ghosts of the low z face (normal planes of no-slip faces are zero before the rule's sign)
-                    if (xl) vax_p = bc.nsR ? 0.0 : (bc.fsK0 ? vax : (bc.nsK0 ? -vax : LDB(f.Vx, ovx - svx)));
-                    if (yl) vby_p = bc.nsBk ? 0.0 : (bc.fsK0 ? vby : (bc.nsK0 ? -vby : LDB(f.Vy, ovy - svy)));
+                    if (xl) vax_p = bc.nsR ? 0.0 : (bc.fsK0 ? vax : (bc.nsK0 ? -vax : NBV(nbK0, Vx, ovx - svx)));
+                    if (yl) vby_p = bc.nsBk ? 0.0 : (bc.fsK0 ? vby : (bc.nsK0 ? -vby : NBV(nbK0, Vy, ovy - svy)));
                 }
                 if (live) {
                     if (xl) {
                         {   // τxy (nx, j, k): Vx[nx, j, k+1] is the row below's boundary value, Vy[nx+1, j, k+1] the ghost column
-                            const double vxl = j > 0 ? sV[slot][0][ty - 1][tx] : (bc.nsR ? 0.0 : (bc.fsF ? vax : (bc.nsF ? -vax : LDB(f.Vx, ovx - rvx))));
-                            const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsR ? vb : (bc.nsR ? -vb : LDB(f.Vy, ovy - rvy + 8u)));
+                            const double vxl = j > 0 ? sV[slot][0][ty - 1][tx] : (bc.nsR ? 0.0 : (bc.fsF ? vax : (bc.nsF ? -vax : NBV(nbF, Vx, ovx - rvx))));
+                            const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsR ? vb : (bc.nsR ? -vb : NBV(nbR, Vy, ovy - rvy + 8u)));
                             const double s_ = 0.5 * (_dy * (vax - vxl) + _dx * (vyg - vb));
                             const double ee = 0.25 * (ey + ey + e + e);
                             const double dtr = DTR(ee, 0.0);
@@ -991,7 +1040,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                             STN<(NT & 1) != 0>(a.o.txy, oxy + 8u, t0 + INC(t0, 0.0, ee, s_, 0.0, dtr));
                         }
                         {   // τxz (nx, j, k): Vz[nx+1, j+1, k] is the ghost column of the previous plane's own Vz
-                            const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : LDB(f.Vz, ovz - svz + 8u)));
+                            const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : NBV(nbR, Vz, ovz - svz + 8u)));
                             const double s_ = 0.5 * (_dz * (vax - vax_p) + _dx * (vzg - c_p));
                             const double ee = 0.25 * (e_p + e_p + e + e);
                             const double dtr = DTR(ee, 0.0);
@@ -1000,8 +1049,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     }
                     if (yl) {
                         {   // τxy (i, ny, k): Vx[i, ny+1, k+1] is the ghost row, Vy[i, ny, k+1] the left neighbour's boundary value
-                            const double vxg = (i == 0 && bc.nsL) ? 0.0 : (bc.fsBk ? va : (bc.nsBk ? -va : LDB(f.Vx, ovx - 8u + rvx)));
-                            const double vyl = i > 0 ? sV[slot][1][ty][tx - 1] : (bc.nsBk ? 0.0 : (bc.fsL ? vby : (bc.nsL ? -vby : LDB(f.Vy, ovy - 8u))));
+                            const double vxg = (i == 0 && bc.nsL) ? 0.0 : (bc.fsBk ? va : (bc.nsBk ? -va : NBV(nbBk, Vx, ovx - 8u + rvx)));
+                            const double vyl = i > 0 ? sV[slot][1][ty][tx - 1] : (bc.nsBk ? 0.0 : (bc.fsL ? vby : (bc.nsL ? -vby : NBV(nbL, Vy, ovy - 8u))));
                             const double s_ = 0.5 * (_dy * (vxg - va) + _dx * (vby - vyl));
                             const double ee = 0.25 * (ex + e + ex + e);
                             const double dtr = DTR(ee, 0.0);
@@ -1009,7 +1058,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                             STN<(NT & 1) != 0>(a.o.txy, oxy + rxy, t0 + INC(t0, 0.0, ee, s_, 0.0, dtr));
                         }
                         {   // τyz (i, ny, k)
-                            const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : LDB(f.Vz, ovz - svz + rvz)));
+                            const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : NBV(nbBk, Vz, ovz - svz + rvz)));
                             const double s_ = 0.5 * (_dz * (vby - vby_p) + _dy * (vzg - c_p));
                             const double ee = 0.25 * (e_p + e_p + e + e);
                             const double dtr = DTR(ee, 0.0);
@@ -1017,8 +1066,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                         }
                     }
                     if (xl && yl) {   // τxy (nx, ny, k): both velocities on ghost lines of their own boundary values
-                        const double vxg = bc.nsR ? 0.0 : (bc.fsBk ? vax : (bc.nsBk ? -vax : LDB(f.Vx, ovx + rvx)));
-                        const double vyg = bc.nsBk ? 0.0 : (bc.fsR ? vby : (bc.nsR ? -vby : LDB(f.Vy, ovy + 8u)));
+                        const double vxg = bc.nsR ? 0.0 : (bc.fsBk ? vax : (bc.nsBk ? -vax : NBV(nbBk, Vx, ovx + rvx)));
+                        const double vyg = bc.nsBk ? 0.0 : (bc.fsR ? vby : (bc.nsR ? -vby : NBV(nbR, Vy, ovy + 8u)));
                         const double s_ = 0.5 * (_dy * (vxg - vax) + _dx * (vyg - vby));
                         const double ee = 0.25 * (e + e + e + e);
                         const double dtr = DTR(ee, 0.0);
@@ -1042,36 +1091,40 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
         // on to plane nz + 1 of V and of τxz / τyz (so `- sxz` is plane nz), s10 / r10 / s01p / r01p hold the old stresses of plane nz
         const bool xl = i == nx - 1, yl = j == ny - 1;
         {   // τxz (i, j, nz): Vx[i, j+1, nz+1] is the ghost plane
-            const double vxg = (i == 0 && bc.nsL) ? 0.0 : (bc.fsK1 ? a_p : (bc.nsK1 ? -a_p : LDB(f.Vx, ovx - 8u)));
+            const double vxg = (i == 0 && bc.nsL) ? 0.0 : (bc.fsK1 ? a_p : (bc.nsK1 ? -a_p : NBV(nbK1, Vx, ovx - 8u)));
             const double s_ = 0.5 * (_dz * (vxg - a_p) + _dx * (c_p - cx_p));
             const double ee = 0.25 * (ex_p + e_p + ex_p + e_p);
             const double dtr = DTR(ee, 0.0);
             STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01p + INC(s01p, 0.0, ee, s_, 0.0, dtr));
         }
         {   // τyz (i, j, nz)
-            const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsK1 ? b_p : (bc.nsK1 ? -b_p : LDB(f.Vy, ovy - rvy)));
+            const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsK1 ? b_p : (bc.nsK1 ? -b_p : NBV(nbK1, Vy, ovy - rvy)));
             const double s_ = 0.5 * (_dz * (vyg - b_p) + _dy * (c_p - cy_p));
             const double ee = 0.25 * (ey_p + e_p + ey_p + e_p);
             const double dtr = DTR(ee, 0.0);
             STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01p + INC(r01p, 0.0, ee, s_, 0.0, dtr));
         }
         if (xl) {   // τxz (nx, j, nz)
-            const double vxg = bc.nsR ? 0.0 : (bc.fsK1 ? vax_p : (bc.nsK1 ? -vax_p : LDB(f.Vx, ovx)));
-            const double vzg = bc.nsK1 ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : LDB(f.Vz, ovz - svz + 8u)));
+            const double vxg = bc.nsR ? 0.0 : (bc.fsK1 ? vax_p : (bc.nsK1 ? -vax_p : NBV(nbK1, Vx, ovx)));
+            const double vzg = bc.nsK1 ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : NBV(nbR, Vz, ovz - svz + 8u)));
             const double s_ = 0.5 * (_dz * (vxg - vax_p) + _dx * (vzg - c_p));
             const double ee = 0.25 * (e_p + e_p + e_p + e_p);
             const double dtr = DTR(ee, 0.0);
             STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10 + INC(s10, 0.0, ee, s_, 0.0, dtr));
         }
         if (yl) {   // τyz (i, ny, nz)
-            const double vyg = bc.nsBk ? 0.0 : (bc.fsK1 ? vby_p : (bc.nsK1 ? -vby_p : LDB(f.Vy, ovy)));
-            const double vzg = bc.nsK1 ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : LDB(f.Vz, ovz - svz + rvz)));
+            const double vyg = bc.nsBk ? 0.0 : (bc.fsK1 ? vby_p : (bc.nsK1 ? -vby_p : NBV(nbK1, Vy, ovy)));
+            const double vzg = bc.nsK1 ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : NBV(nbBk, Vz, ovz - svz + rvz)));
             const double s_ = 0.5 * (_dz * (vyg - vby_p) + _dy * (vzg - c_p));
             const double ee = 0.25 * (e_p + e_p + e_p + e_p);
             const double dtr = DTR(ee, 0.0);
             STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10 + INC(r10, 0.0, ee, s_, 0.0, dtr));
         }
     }
+#undef NBV
+#undef NBVX
+#undef NBVY
+#undef NBVZ
 }
 
 }   // namespace

@@ -23,6 +23,8 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 CASES = [((2, 1, 1), (70, 13, 12)), ((1, 1, 2), (70, 13, 12)), ((2, 1, 1), (130, 14, 40)), ((1, 1, 2), (130, 14, 40)), ((1, 2, 1), (70, 13, 12))]
 PIPES = ["fused", "fused_overlap", "fused_early", "split_sweeps"]
+# dt = Inf: the default pipeline of the viscous limit -- the kernel finishes the faces with a neighbour itself behind a device-side flag (fused_overlap = 3)
+VISC_CASES = [((2, 1, 1), (70, 13, 12)), ((1, 1, 2), (130, 14, 40)), ((1, 2, 1), (70, 40, 12))]
 
 
 def main():
@@ -70,6 +72,16 @@ def main():
             rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw, handle=h0)
             undecomposed[ng] = (S, download_stokes(stokes), int(rg.iter))
             T._set(h0, kernel_variant=0)
+            del stokes, ρg, K, G
+        for dims, n in VISC_CASES:
+            ng = B.n_global(n, dims)
+            g.finalize_global_grid()
+            S = T._global_setup(jr, ng, True, 23, 8, seed=31, dt=float("inf"))
+            T._set(h0, kernel_variant=1, viscous_limit=0)
+            stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+            rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw, handle=h0)
+            undecomposed[("visc", ng)] = (S, download_stokes(stokes), int(rg.iter))
+            T._set(h0, kernel_variant=0, viscous_limit=1)
             del stokes, ρg, K, G
         g.finalize_global_grid()
         import torch.distributed as dist
@@ -128,6 +140,32 @@ def main():
                                      "fused_launches": int(hc.get_option("stat_fused3d") - f0), "norm_Rx": [float(x) for x in r.norm_Rx]})
                 flush()
                 del st, rg_, K_, G_
+            g.finalize_global_grid()
+        for dims, n in VISC_CASES:
+            ng = B.n_global(n, dims)
+            S, glob, rg_iter = undecomposed[("visc", ng)]
+            g.finalize_global_grid()
+            g.init_global_grid(*n, rank=rank, nprocs=world, dimx=dims[0], dimy=dims[1], dimz=dims[2])
+            cart = halo.make_cart()
+            halo.init_comm_ipc(hc, cart=cart)
+            co = B.coords_of(cart)
+            grid = jr.Geometry(n, S.extra["li"])
+            T._set(hc, **T.PIPELINES["fused_inkernel"])
+            loc = Setup(ni=n, arrays={k: B.local_block(v, n, ng, co) for k, v in S.arrays.items()})
+            st, rg_, K_, G_ = upload_stokes(loc, jr.AMDGPUBackend)
+            f0 = hc.get_option("stat_fused3d_inkernel")
+            r = jr.solve_(st, S.pt, grid, S.flow_bcs, rg_, K_, G_, S.dt, None, kwargs=kw, handle=hc)
+            out = download_stokes(st)
+            bad = []
+            for k in T.STATE + ("Rx", "Ry", "Rz", "RP", "exx", "exy", "divV"):
+                want = B.local_block(glob[k], n, ng, co)
+                m = interior_mask3d(k, want.shape)
+                if not np.array_equal(out[k][m], want[m]):
+                    bad.append((k, float(np.abs(out[k] - want)[m].max())))
+            res["cases"].append({"case": f"viscous limit dims={dims} n={n} fused_inkernel", "ok": not bad and r.iter == rg_iter == 24, "bad": bad, "iter": int(r.iter),
+                                 "inkernel_launches": int(hc.get_option("stat_fused3d_inkernel") - f0), "norm_Rx": [float(x) for x in r.norm_Rx]})
+            flush()
+            del st, rg_, K_, G_
             g.finalize_global_grid()
         # every rank must hold the same norm bits
         mine = [c["norm_Rx"] for c in res["cases"] if "norm_Rx" in c]

@@ -41,6 +41,8 @@ def test_two_processes_on_one_device_equal_the_undecomposed_run():
             if "fused_launches" in c:
                 assert (c["fused_launches"] >= 12) == ("split_sweeps" not in c["case"]), c
         assert d["norm_bits_equal_across_ranks"]
+        visc = [c for c in d["cases"] if "inkernel_launches" in c]
+        assert len(visc) == 3 and all(c["inkernel_launches"] >= 12 for c in visc), visc        # dt = Inf: the kernel finished the neighbour faces itself
     # both ranks report the same norms, and both dims (2,1,1) and (1,1,2) ran in all four pipelines
     for dims in ("(2, 1, 1)", "(1, 1, 2)"):
         for pipe in ("fused", "fused_overlap", "fused_early", "split_sweeps"):

@@ -27,6 +27,7 @@ pytestmark = pytest.mark.gpu
 STATE = ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "txy", "txz", "tyz")
 PIPELINES = {"fused": dict(kernel_variant=3, fused_overlap=0, fused_comm=1), "fused_overlap": dict(kernel_variant=3, fused_overlap=1, fused_comm=1),
              "fused_early": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=0),
+             "fused_inkernel": dict(kernel_variant=3, fused_overlap=3, fused_comm=1, comm_bcs_lazy=0),      # viscous limit only (dt = Inf); the early exchange otherwise
              "fused_early_lazy_bcs": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=1),
              "split_sweeps": dict(kernel_variant=3, fused_overlap=0, fused_comm=0)}
 
@@ -65,8 +66,8 @@ class TwoBlocks:
         self.close()
 
 
-def _global_setup(jr, ng, uniform, iterMax, nout, seed=5, bcs="free_slip"):
-    S = jr.miniapps.random_fields3d(ng, seed=seed, iterMax=iterMax, nout=nout, bcs=bcs)
+def _global_setup(jr, ng, uniform, iterMax, nout, seed=5, bcs="free_slip", dt=0.25):
+    S = jr.miniapps.random_fields3d(ng, seed=seed, iterMax=iterMax, nout=nout, bcs=bcs, dt=dt)
     S.pt.ϵ_rel = S.pt.ϵ_abs = 1e-30
     if uniform:
         for k, v in (("eta", 0.7), ("G", 1.3), ("K", 2.1)):
@@ -155,7 +156,7 @@ def test_two_blocks_equal_the_undecomposed_run_bit_for_bit(jr, dims, n, pipeline
     assert getattr(res[0], "norm_∇V")[-1] != getattr(rg, "norm_∇V")[-1]          # ... which are not the undecomposed norm (RP: overlap counted twice)
 
 
-@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "fused_early_lazy_bcs", "split_sweeps"])
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "fused_early_lazy_bcs", "fused_inkernel", "split_sweeps"])
 @pytest.mark.parametrize("dims,n", [((2, 1, 1), (70, 13, 12)), ((1, 1, 2), (130, 14, 40))])
 def test_two_blocks_in_the_viscous_limit_equal_the_undecomposed_general_kernels(jr, dims, n, pipeline):
     """dt = Inf: every rank runs the viscous-limit forms (fused kernel, z-marching sweep, fix-up layers next to received planes), which do not load τ_o, P0, K, G, Q
@@ -177,6 +178,7 @@ def test_two_blocks_in_the_viscous_limit_equal_the_undecomposed_general_kernels(
             _set(h0, kernel_variant=0, viscous_limit=1)
         res, outs = _solve_blocks(jr, tb, S, pipeline, kw)
         assert all(_get(h, "viscous_limit") == 1 for h in tb.handles)
+        assert all((_get(h, "stat_fused3d_inkernel") >= 12) == (pipeline == "fused_inkernel") for h in tb.handles)
     assert rg.iter == 24 and all(r.iter == 24 for r in res)
     for r, out in enumerate(outs):
         co = B.coords_of(tb.carts[r])
@@ -184,6 +186,41 @@ def test_two_blocks_in_the_viscous_limit_equal_the_undecomposed_general_kernels(
             want = B.local_block(glob[k], n, tb.ng, co)
             m = interior_mask3d(k, want.shape)
             assert np.isfinite(want[m]).all() and np.array_equal(out[k][m], want[m]), (pipeline, dims, r, k, float(np.abs(out[k] - want)[m].max()))
+
+
+@pytest.mark.parametrize("bcs", ["free_slip", "no_slip", "slip_mix", "none"])
+@pytest.mark.parametrize("dims,n", [((2, 1, 1), (130, 14, 40)), ((1, 2, 1), (70, 13, 12)), ((1, 2, 1), (70, 40, 12)), ((1, 1, 2), (70, 13, 12)), ((2, 2, 2), (70, 13, 12)), ((2, 2, 1), (130, 14, 40)),
+                                    ((1, 2, 2), (130, 14, 40))])
+def test_blocks_in_the_viscous_limit_finish_their_neighbour_faces_inside_the_kernel(jr, dims, n, bcs):
+    """option fused_overlap = 3 (the default): with dt = Inf the fused kernel's own tiles next to a face with a neighbour wait for the exchange's device-side flag and read
+    the received planes themselves -- no flow_bcs! launch, no fix-up launch, the high-face node layers inside the kernel as well.  Two, four and eight blocks (2 x 2 x 2: every
+    block has three faces with a neighbour and three physical ones of every kind), single- and multi-tile: every block equals the undecomposed run of the per-node GENERAL
+    kernels bit for bit, residuals and strain rates of the observed iterations included."""
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    from justrelax_jl_amd.checks import interior_mask3d
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        S = _global_setup(jr, tb.ng, True, 23, 8, seed=21, bcs=bcs, dt=np.inf)
+        h0 = _lib.default_handle()
+        _set(h0, kernel_variant=1, viscous_limit=0)
+        try:
+            stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+            rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw)
+            glob = download_stokes(stokes)
+        finally:
+            _set(h0, kernel_variant=0, viscous_limit=1)
+        res, outs = _solve_blocks(jr, tb, S, "fused_inkernel", kw)
+        launches = [_get(h, "stat_fused3d_inkernel") for h in tb.handles]
+    assert min(launches) >= 12, launches
+    assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    assert all(list(r.err_evo1) == list(res[0].err_evo1) for r in res)
+    for r, out in enumerate(outs):
+        co = B.coords_of(tb.carts[r])
+        for k in STATE + ("Rx", "Ry", "Rz", "RP", "exx", "exy", "eyz", "exz", "divV"):
+            want = B.local_block(glob[k], n, tb.ng, co)
+            m = interior_mask3d(k, want.shape)
+            assert np.isfinite(want[m]).all() and np.array_equal(out[k][m], want[m]), (dims, bcs, r, co, k, float(np.abs(out[k] - want)[m].max()))
 
 
 @pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "split_sweeps"])
