@@ -515,9 +515,10 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
                             for r in range(nr)])
             for mode in modes:
                 for h in hs:
-                    h.set_option("fused_overlap", {"serial": 0, "overlap": 1, "early": 2}[mode])
+                    h.set_option("fused_overlap", {"serial": 0, "overlap": 1, "early": 2, "inkernel": 4, "default": 3}[mode])
                 res[mode] = timed(hs, blocks)
             for h in hs:
+                h.set_option("fused_overlap", 3)
                 h.call("jrx_comm_destroy")
             res["uncoupled"] = timed(hs, blocks)
             res["one_block"] = timed(hs[:1], blocks[:1])
@@ -586,12 +587,14 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
         return {"leg": list(only), "block_it_per_s": split_leg(only[0], [only[1]], n=n)}
     best = None
     for name in splits:
-        r = split_leg(name, ["serial", "early", "overlap"])
+        r = split_leg(name, ["default", "inkernel", "serial", "early", "overlap"])
         leg = {"one_block_it_per_s": r["one_block"], "two_uncoupled_blocks_block_it_per_s": r["uncoupled"]}
-        for mode in ("serial", "early", "overlap"):
+        for mode in ("default", "inkernel", "serial", "early", "overlap"):
             leg[mode] = {"block_it_per_s": r[mode], "overhead_pct": (r["uncoupled"] / r[mode] - 1.0) * 100.0}
         out[f"split_{name}"] = leg
-        cand = "early"             # the default pipeline (exchange beside the kernel) is what the leg quotes; "serial" and "overlap" (shell tiles) are the options
+        cand = "default"           # the default pipeline is what the leg quotes: the kernel's own boundary tiles read the received planes (a second launch of the kernel behind the
+                                   # exchange: no BC launch, no fix-up) on ranks without an x neighbour, "early" (exchange beside the kernel, BCs + fix-up behind it) on the others;
+                                   # "inkernel" forces the first form, "serial" and "overlap" (shell tiles) are the older options
         if best is None or leg[cand]["overhead_pct"] > best[1]["overhead_pct"]:
             best = (f"split_{name}/{cand}", leg[cand])          # the headline of the leg is the WORSE split (x planes are strided)
     out["it_per_s"] = best[1]["block_it_per_s"]
@@ -773,7 +776,9 @@ class GpuRanks:
         return cnt.value
 
     def pipeline(self):
-        return {0: "exchange behind the kernel", 1: "shell tiles + exchange beside the interior tiles", 2: "early exchange beside the kernel"}[self.h.get_option("fused_overlap")]
+        return {0: "exchange behind the kernel", 1: "shell tiles + exchange beside the interior tiles", 2: "early exchange beside the kernel, BCs + fix-up behind it",
+                3: "exchange beside the kernel; ranks without an x neighbour: the kernel's boundary tiles read the received planes (second launch behind the exchange, no BCs, no fix-up); others: BCs + fix-up behind the kernel",
+                4: "exchange beside the kernel, whose boundary tiles read the received planes (second launch behind the exchange)"}[self.h.get_option("fused_overlap")]
 
     def run(self, k):
         from justrelax_jl_amd import stokes
@@ -1093,11 +1098,11 @@ def ipc_helper(args) -> int:
         for split in ("x", "z"):
             R.build(split)
             leg = {}
-            for mode, ov in (("early", 2), ("serial", 0)):
+            for mode, ov in (("default", 3), ("inkernel", 4), ("early", 2), ("serial", 0)):
                 R.h.set_option("fused_overlap", ov)
                 r = collective_leg(R, ctl, "ipc", steps, warm)
                 leg[mode] = {"block_it_per_s": r.get("it_per_s"), "chain_us_per_rank": r.get("chain_us_per_rank"), **({"error": r["error"]} if "error" in r else {})}
-            R.h.set_option("fused_overlap", 2)
+            R.h.set_option("fused_overlap", 3)
             R.disconnect()
             R.run(warm); R.sync(); ctl.barrier()
             t0 = time.perf_counter()
@@ -1106,7 +1111,7 @@ def ipc_helper(args) -> int:
             ctl.barrier()
             unc = 2 * steps / el
             leg["two_uncoupled_blocks_block_it_per_s"] = unc
-            for mode in ("early", "serial"):
+            for mode in ("default", "inkernel", "early", "serial"):
                 if leg[mode].get("block_it_per_s"):
                     leg[mode]["overhead_pct"] = (unc / leg[mode]["block_it_per_s"] - 1.0) * 100.0
             out[f"split_{split}"] = leg

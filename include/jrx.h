@@ -74,10 +74,11 @@ const char *jrx_build_id(void);
  *   1 = simple one-thread-per-node kernels;  2 = the two sweeps only (z-marching; per-node on blocks up to ~88^3; no ping-pong set);
  *   3 = fused pipeline wherever it is legal (ignores that rule).  All variants produce bit-identical results.
  * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
- * "fused_overlap" (0/1/2/3, default 3): how the multi-rank fused pipeline places update_halo!(V) (same results in every mode):
- *   3 = neighbour faces inside the kernel (viscous-limit form, dt = Inf; other runs use 2): boundary slabs + the exchange on a second stream beside the fused kernel as in 2, but the
- *       kernel's tiles next to a face with a neighbour are the last blocks of the launch, wait for a device-side flag posted behind the exchange and read the received planes themselves:
- *       no flow_bcs! launch, no fix-up -- one launch per iteration and rank;
+ * "fused_overlap" (0/1/2/3/4, default 3): how the multi-rank fused pipeline places update_halo!(V) (same results in every mode):
+ *   3 = neighbour faces inside the kernel for ranks without an x neighbour, 2 for the others (a launch over the tiles of an x face alone is slow); 4 = inside the kernel for every rank
+ *       (viscous-limit form, dt = Inf; other runs use 2): boundary slabs + the exchange on a second stream beside the fused kernel as in 2, but the
+ *       kernel's tiles next to a face with a neighbour are launched behind the exchange (the others beside it) and read the received planes themselves: no flow_bcs! launch,
+ *       no fix-up launch;
  *   2 = early exchange: the velocity phase alone over the boundary slabs of the faces with a neighbour, flow_bcs! and the whole exchange on a second
  *       stream BESIDE the fused kernel (which recomputes those cells with the same values), then flow_bcs! on the physical faces and the fix-up;
  *   1 = the shell of tiles, BCs and exchange on the second stream while the interior tiles run;  0 = everything behind the kernel, in order.

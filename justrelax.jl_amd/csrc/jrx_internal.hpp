@@ -19,7 +19,6 @@ struct jrx_handle {
     double *d_partials = nullptr;        // reduction scratch [kMaxRedBlocks][4]
     double *d_sums = nullptr;            // [16] final sums and flags (device)
     double *h_sums = nullptr;            // [16] pinned host mirror
-    unsigned long long halo_seq = 0;     // update_halo!(V) exchanges posted to the device-side flag d_sums[8] (in-kernel neighbour faces, fused_overlap = 3)
     double *etatau = nullptr;            // library-owned ητ (capacity etatau_cap doubles)
     size_t etatau_cap = 0;
     jrx_comm_state *comm = nullptr;
@@ -34,8 +33,8 @@ struct jrx_handle {
     // ---- options (jrx_set_option; nothing in the library reads the process environment)
     bool loop_graphs = true;             // launch-bound 2D loops: runs of unobserved iterations replay as captured hipGraphs (option "loop_graphs")
     bool thermal_fused = true;           // heat diffusion: one fused launch per unobserved iteration (option "thermal_fused")
-    int fused_overlap = 3;               // multi-rank fused pipeline: 3 (viscous-limit form) the kernel's own boundary tiles read the received planes -- they run last and wait for a device-side
-                                         // flag behind update_halo!(V) -- nothing is left behind the kernel; 0 exchange behind the kernel, in order; 1 shell tiles + exchange on the halo stream, interior tiles
+    int fused_overlap = 3;               // multi-rank fused pipeline: 4 (viscous-limit form) the kernel's own boundary tiles read the received planes -- a second launch of the kernel over those
+                                         // tiles behind update_halo!(V) -- no BC launch, no fix-up; 3 = that for ranks without an x neighbour, 2 for the others; 0 exchange behind the kernel, in order; 1 shell tiles + exchange on the halo stream, interior tiles
                                          // concurrently; 2 boundary slabs of the velocity phase + BCs + the whole exchange on the halo stream beside the kernel (early exchange)
     int kernel_variant = 0;              // 0 auto (fused PT pipeline where it pays), 1 per-node v1 kernels, 2 z-marching sweeps only, 3 fused wherever legal
     bool fused_split = false;            // no neighbours: high-face tiles + boundary stress layers on the halo stream, interior tiles concurrently

@@ -110,22 +110,6 @@ __global__ __launch_bounds__(256) void k_visc_operands_ok(const double *__restri
     if (__any(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
 }
 
-// in-kernel neighbour faces (fused_overlap = 3): the halo stream posts the sequence number of the exchange it has finished; the boundary tiles of k_fused3d wait for it
-__global__ void k_post_halo_flag(unsigned long long *flag, unsigned long long seq)
-{
-    __threadfence();
-    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-// a boundary tile that waited in vain for its received planes (a neighbour that never delivered) has marked d_sums[9]: the fields are then garbage -- report it
-jrx_status check_halo_timeout(jrx_handle *h)
-{
-    if (h->halo_seq == 0) return JRX_OK;
-    unsigned int mark = 0;
-    JRX_HIP(h, hipMemcpy(&mark, reinterpret_cast<unsigned int *>(h->d_sums + 9), sizeof(mark), hipMemcpyDeviceToHost));
-    if (mark) return jrx_fail(h, JRX_ERR_RCCL, "update_halo!: the boundary tiles of the fused kernel timed out waiting for a neighbour's planes (a rank failed or left the call sequence)");
-    return JRX_OK;
-}
-
 jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
 {
     h->visc_ok = false;
@@ -602,9 +586,12 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     const bool vf = h->visc_fold;      // tuning switch: the folded arithmetic of the viscous limit (k_fused3d, VFOLD; same bits)
     if (shell) {        // neighbours, one launch: interior tiles first, the tiles next to a face with a neighbour last (they wait for the exchange's flag)
         if (!(visc && fold)) return jrx_fail(h, JRX_ERR_ARG, "internal: the in-kernel neighbour faces need the one-launch viscous-limit form");
-        const unsigned nblk = (unsigned)shell->start[shell->nbox];
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true>), dim3(nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
-        h->stat_fused3d_inkernel++;
+        // blk0 = 0: the tiles that touch no face with a neighbour; blk0 = n_int: the ones that do (launched behind the exchange)
+        const int nblk = shell->blk0 == 0 ? shell->n_int : shell->start[shell->nbox] - shell->n_int;
+        if (nblk > 0)
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
+        if (shell->blk0 != 0) h->stat_fused3d_inkernel++;
+        else { JRX_LAUNCH_CHECK(h); return JRX_OK; }       // counted once per iteration, with the second class
     } else if (visc && fold && vf)       // + the high-face node layers inside the kernel: the whole iteration in one launch
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc && fold)
@@ -721,8 +708,12 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         const bool overlap = h->fused_overlap == 1;
         // option "fused_overlap" = 3 (default): the viscous-limit kernel's own boundary tiles finish the cells next to the received planes (see the branch below); where that
         // form does not run (finite dt, a failed operand check) the early exchange (2) stands in
-        const bool inkernel = h->fused_overlap == 3 && comm && !per && fused_folds_hiface(h, a) && h->visc_fold;
-        const bool early = (h->fused_overlap == 2 || (h->fused_overlap == 3 && !inkernel)) && comm && !per;
+        // A second launch over the tiles of an x face alone is slow (a column of 64-lane tiles touches 512 B of every 4 KB row: few HBM channels carry it; two 512^3 blocks as two
+        // processes: +6.0 % against +2.6 % for the early exchange), over y and z faces it is free (-2.4 % against +2.2 %; profiles/r04_inkernel_faces.txt): 3 picks it for ranks without an
+        // x neighbour, 4 forces it
+        const bool xnb = jrx_comm_has_neighbor(h, 0, 0) || jrx_comm_has_neighbor(h, 0, 1);
+        const bool inkernel = ((h->fused_overlap == 3 && !xnb) || h->fused_overlap == 4) && comm && !per && fused_folds_hiface(h, a) && h->visc_fold;
+        const bool early = (h->fused_overlap == 2 || (h->fused_overlap >= 3 && !inkernel)) && comm && !per;
         const bool split = !comm && !per && h->fused_split && nt[0] > 1 && nt[1] > 1 && nt[2] > 1;
         if (split) {
             // Without neighbours the only work behind the fused kernel is the stress update of the high-face node layers (i = nx, j = ny,
@@ -751,10 +742,12 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         } else if (inkernel) {
             // Neighbour faces inside the kernel (option "fused_overlap" = 3).  As with the early exchange, the velocity phase alone runs first over the boundary slabs of the
             // faces with a neighbour and update_halo!(V) follows on the halo stream, beside k_fused3d on the compute stream.  But the kernel then needs no fix-up: its tiles
-            // next to a face with a neighbour are the LAST blocks of the launch, wait for a device-side flag that the halo stream posts behind its last unpack, and read the
-            // received planes of the new set where the other tiles apply a flow_bcs! rule -- the stress nodes next to a received plane (and the high-face node layers, HIF)
-            // come out right the first time.  flow_bcs! is not applied in memory at all (every rule is applied on the fly; the pending application happens before anything
-            // reads those entries from memory, `ghosts_stale`).  One launch per iteration and rank, whatever the decomposition; the strided x-face layers are gone.
+            // are launched in two classes -- the ones that touch no face with a neighbour right away, the others behind the event that marks the end of the exchange -- and
+            // the second class reads the received planes of the new set where the other tiles apply a flow_bcs! rule: the stress nodes next to a received plane (and the
+            // high-face node layers, HIF) come out right the first time.  flow_bcs! is not applied in memory at all (every rule is applied on the fly; the pending application
+            // happens before anything reads those entries from memory, `ghosts_stale`).  No BC launch, no fix-up launch, no strided x-face layers.
+            // (A first version kept ONE launch and let the boundary tiles, last in the block order, spin on a device-side flag: with two ranks on one device the spinning blocks
+            // of one rank fill the chip and starve the kernels they wait for -- the time-out fired at 512^3.  A stream dependency cannot deadlock.)
             bs = h->halo_stream;
             JRX_HIP(h, hipEventRecord(h->ev[0], s));
             JRX_HIP(h, hipStreamWaitEvent(bs, h->ev[0], 0));
@@ -779,9 +772,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                 const int64_t n[3] = {nx, ny, nz};
                 JRX_TRY(jrx_halo_exchange(h, bs, 3, arrs, ext, n));
             }
-            unsigned long long *flag = reinterpret_cast<unsigned long long *>(h->d_sums + 8);
-            hipLaunchKernelGGL(k_post_halo_flag, dim3(1), dim3(1), 0, bs, flag, ++h->halo_seq);
-            JRX_LAUNCH_CHECK(h);
+            JRX_HIP(h, hipEventRecord(h->ev[2], bs));            // update_halo!(V) has delivered
             if (cev) JRX_HIP(h, hipEventRecord(cev[2], bs));
             FusedShell sh;
             memset(&sh, 0, sizeof(sh));
@@ -811,9 +802,6 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
                 sh.start[sh.nbox] = tot;
                 if (tot != nt[0] * nt[1] * nt[2]) return jrx_fail(h, JRX_ERR_ARG, "internal: the tile classes of the fused kernel do not cover the block (%d of %d)", tot, nt[0] * nt[1] * nt[2]);
             }
-            sh.flag = flag; sh.seq = h->halo_seq; sh.err = reinterpret_cast<unsigned int *>(h->d_sums + 9);
-            const double tmo = h->comm_timeout_ms * 1e-3 < 30.0 ? h->comm_timeout_ms * 1e-3 : 30.0;
-            sh.timeout_ticks = (unsigned long long)(tmo * 1e8);         // wall_clock64: 100 MHz
             FusedBC bn = bc;
             bn.nbL = nbf[0][0]; bn.nbR = nbf[0][1]; bn.nbF = nbf[1][0]; bn.nbBk = nbf[1][1]; bn.nbK0 = nbf[2][0]; bn.nbK1 = nbf[2][1];
             if (bn.nbL) bn.fsL = bn.nsL = 0;
@@ -823,10 +811,12 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             if (bn.nbK0) bn.fsK0 = bn.nsK0 = 0;
             if (bn.nbK1) bn.fsK1 = bn.nsK1 = 0;
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
-            JRX_TRY(launch_fused(h, s, a, bn, all, false, true, &sh));
-            if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
-            JRX_HIP(h, hipEventRecord(h->ev[2], bs));
+            sh.blk0 = 0;
+            JRX_TRY(launch_fused(h, s, a, bn, all, false, true, &sh));           // the tiles that read no received plane: beside the exchange
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
+            sh.blk0 = sh.n_int;
+            JRX_TRY(launch_fused(h, s, a, bn, all, false, true, &sh));           // the tiles next to a face with a neighbour: behind it
+            if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
             bs = s;
             if (cev) { JRX_HIP(h, hipEventRecord(cev[3], s)); if (chain_mode) *chain_mode = 2; }
             I.ghosts_stale = true;
@@ -1113,7 +1103,6 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
             JRX_HIP(h, hipMemcpyAsync(h->h_sums, h->d_sums, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
             JRX_HIP(h, hipStreamSynchronize(s));
             double ss[4] = {h->h_sums[0], h->h_sums[1], h->h_sums[2], h->h_sums[3]};
-            JRX_TRY(check_halo_timeout(h));
             JRX_TRY(jrx_allreduce_sum_host(h, ss, 4));       // norm_mpi: sqrt(Allreduce(Σx²)) (Utils.jl:698-701)
             const double nRx = sqrt(ss[0]) / (double)((p->nxg - 2) * (p->nyg - 1) * (p->nzg - 1));
             const double nRy = sqrt(ss[1]) / (double)((p->nxg - 1) * (p->nyg - 2) * (p->nzg - 1));
@@ -1203,7 +1192,6 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     JRX_HIP(h, hipEventRecord(h->ev[7], s));
     JRX_TRY(iter_end(I));
     JRX_HIP(h, hipStreamSynchronize(s));
-    JRX_TRY(check_halo_timeout(h));
     float ms = 0.f;
     JRX_HIP(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
     times_ms[0] = ms; times_ms[1] = times_ms[2] = times_ms[3] = times_ms[4] = times_ms[5] = 0.0;

@@ -656,14 +656,12 @@ struct FusedBC {
     // NBR: faces with a neighbour (their fs / ns flags are cleared): the planes of the DESTINATION set there hold received velocities
     int nbL, nbR, nbF, nbBk, nbK0, nbK1;
 };
-// NBR: the tiles of one launch in two classes -- blocks [0, n_int) are the box of tiles that touch no face with a neighbour (XCD-banded order inside the box), the blocks
-// behind them the up to six disjoint boxes of tiles that do; those wait for `*flag >= seq` (posted on the halo stream behind update_halo!(V)) before they start
+// NBR: the tiles of a block in two classes -- [0, n_int) the box of tiles that touch no face with a neighbour (XCD-banded order inside the box), behind them the up to six
+// disjoint boxes of tiles that do.  Two launches of the same kernel: the first class right away, the second (blk0 = n_int) once update_halo!(V) has delivered the planes it reads
 struct FusedShell {
     int n_int, ntx_i, nty_i, tx0_i, ty0_i, tz0_i;
     int nbox, box[6][6], start[7];
-    const unsigned long long *flag;
-    unsigned long long seq, timeout_ticks;
-    unsigned int *err;
+    int blk0;
 };
 // coherent load (device scope): a value another kernel of this device has written while this one runs
 __device__ __forceinline__ double LDC(const double *p, u32 off)
@@ -717,7 +715,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
 #define NBVY(flag_, off_, jj_) ((NBR && bc.flag_) ? ((((jj_) == 0 && bc.nsF) || ((jj_) == ny && bc.nsBk)) ? 0.0 : LDC(a.o.Vy, (off_))) : LDB(f.Vy, (off_)))
 #define NBVZ(flag_, off_, kk_) ((NBR && bc.flag_) ? ((((kk_) == 0 && bc.nsK0) || ((kk_) == nz && bc.nsK1)) ? 0.0 : LDC(a.o.Vz, (off_))) : LDB(f.Vz, (off_)))
     const int tx = (int)(threadIdx.x % TX), ty = (int)(threadIdx.x / TX);
-    int tile = blockIdx.x;
+    int tile = blockIdx.x + (NBR ? sh.blk0 : 0);
     int nblk = (int)gridDim.x;
     if (NBR) { ntx = sh.ntx_i; nty = sh.nty_i; tx0 = sh.tx0_i; ty0 = sh.ty0_i; tz0 = sh.tz0_i; nblk = sh.n_int; }
     const bool shell = NBR && tile >= sh.n_int;          // a tile next to a face with a neighbour
@@ -737,16 +735,6 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
         while (b + 1 < sh.nbox && tile >= sh.start[b + 1]) b++;
         const int l = tile - sh.start[b], bw = sh.box[b][1] - sh.box[b][0], bh = sh.box[b][3] - sh.box[b][2];
         tix = sh.box[b][0] + l % bw; tiy = sh.box[b][2] + (l / bw) % bh; tiz = sh.box[b][4] + l / (bw * bh);
-        // the received planes this tile reads must have landed: update_halo!(V) of this iteration runs on the halo stream beside this kernel and posts the flag behind
-        // its last unpack.  These blocks are the last of the launch, so the flag is long up when they start; a neighbour that never delivers is a time-out, not a hang
-        if (threadIdx.x == 0) {
-            const unsigned long long t0_ = wall_clock64();
-            while (__hip_atomic_load(sh.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sh.seq) {
-                __builtin_amdgcn_s_sleep(32);
-                if (wall_clock64() - t0_ > sh.timeout_ticks) { __hip_atomic_store(sh.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        __syncthreads();
     }
     const int i = tix * (TX - OVX - (SHFL ? 1 : 0)) - OVX + tx;  // cell column of this thread
     const int j = tiy * (TY - 1) - 1 + ty;

@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 STATE = ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "txy", "txz", "tyz")
 PIPELINES = {"fused": dict(kernel_variant=3, fused_overlap=0, fused_comm=1), "fused_overlap": dict(kernel_variant=3, fused_overlap=1, fused_comm=1),
              "fused_early": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=0),
-             "fused_inkernel": dict(kernel_variant=3, fused_overlap=3, fused_comm=1, comm_bcs_lazy=0),      # viscous limit only (dt = Inf); the early exchange otherwise
+             "fused_inkernel": dict(kernel_variant=3, fused_overlap=4, fused_comm=1, comm_bcs_lazy=0),      # viscous limit only (dt = Inf); the early exchange otherwise (4: x faces too)
              "fused_early_lazy_bcs": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=1),
              "split_sweeps": dict(kernel_variant=3, fused_overlap=0, fused_comm=0)}
 
