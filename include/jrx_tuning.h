@@ -8,6 +8,8 @@
  *                                 no division by 1 + 0 ψ); same bits (0: the general expressions with zero operands)
  *   "fused_hiface" (1)            3D fused kernel, viscous-limit form, no neighbours: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel
  *                                 (0: by the boundary-layer launch behind it)
+ *   "fused_first_pct" (15)        multi-rank fused pipeline with the neighbour faces inside the kernel (fused_overlap = 3): share (%) of the interior z chunks whose tiles are launched
+ *                                 beside update_halo!(V); the rest of the block -- shell tiles among their row neighbours -- follows behind it
  *   "comm_bcs_lazy" (0)           multi-rank fused pipeline: 1 = flow_bcs! of the physical faces applied lazily (before anything reads those entries from memory) instead of twice per
  *                                 iteration; the fix-up next to the received planes derives them by rule (measured 2 % slower than the two launches: off)
  *   "fused_tile" (2)              3D fused kernel tile: 0 = 64 x 4 threads, 1 = 32 x 8, 2 = chosen by nx (32 x 8 for nx = 63 .. 90, where three 32-lane tiles replace two 64-lane ones)

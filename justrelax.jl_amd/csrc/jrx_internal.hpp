@@ -44,6 +44,7 @@ struct jrx_handle {
     bool vep_store_all = false;          // VEP loops: every iteration stores the output-only arrays (A/B of the skipped stores)
     bool viscous_limit = true;           // dt = Inf: the fused 3D kernel skips the operands multiplied by 1/(G dt) = 1/(K dt) = 1/dt = 0
     bool visc_ok = false;                // set per driver call by the operand check: every τ_o, P0, Q finite and K, G neither NaN nor 0, so the viscous-limit kernels give the general ones' result
+    int fused_first_pct = 15;            // in-kernel neighbour faces: share of the interior z chunks launched beside the exchange (the rest of the block follows behind it)
     bool comm_bcs_lazy = false;          // multi-rank fused pipeline: 1 = flow_bcs! of the physical faces is not applied in memory every iteration (the fix-up derives those entries by rule) but
                                          // lazily, before anything reads them.  Measured (two 512^3 blocks, profiles/r04_comm_bcs_lazy_ab.txt): the rule form of the fix-up costs more than the two
                                          // BC launches it saves (-2 %): off

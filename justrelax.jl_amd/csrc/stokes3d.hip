@@ -586,11 +586,11 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     const bool vf = h->visc_fold;      // tuning switch: the folded arithmetic of the viscous limit (k_fused3d, VFOLD; same bits)
     if (shell) {        // neighbours, one launch: interior tiles first, the tiles next to a face with a neighbour last (they wait for the exchange's flag)
         if (!(visc && fold)) return jrx_fail(h, JRX_ERR_ARG, "internal: the in-kernel neighbour faces need the one-launch viscous-limit form");
-        // blk0 = 0: the tiles that touch no face with a neighbour; blk0 = n_int: the ones that do (launched behind the exchange)
-        const int nblk = shell->blk0 == 0 ? shell->n_int : shell->start[shell->nbox] - shell->n_int;
+        // blk0 = 0: box 0 (tiles that touch no face with a neighbour, beside the exchange); blk0 = start[1]: everything else, behind it
+        const int nblk = shell->cls == 0 ? shell->start[1] : shell->start[shell->nbox] - shell->start[1];
         if (nblk > 0)
             hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
-        if (shell->blk0 != 0) h->stat_fused3d_inkernel++;
+        if (shell->cls != 0) h->stat_fused3d_inkernel++;
         else { JRX_LAUNCH_CHECK(h); return JRX_OK; }       // counted once per iteration, with the second class
     } else if (visc && fold && vf)       // + the high-face node layers inside the kernel: the whole iteration in one launch
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
@@ -708,11 +708,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         const bool overlap = h->fused_overlap == 1;
         // option "fused_overlap" = 3 (default): the viscous-limit kernel's own boundary tiles finish the cells next to the received planes (see the branch below); where that
         // form does not run (finite dt, a failed operand check) the early exchange (2) stands in
-        // A second launch over the tiles of an x face alone is slow (a column of 64-lane tiles touches 512 B of every 4 KB row: few HBM channels carry it; two 512^3 blocks as two
-        // processes: +6.0 % against +2.6 % for the early exchange), over y and z faces it is free (-2.4 % against +2.2 %; profiles/r04_inkernel_faces.txt): 3 picks it for ranks without an
-        // x neighbour, 4 forces it
-        const bool xnb = jrx_comm_has_neighbor(h, 0, 0) || jrx_comm_has_neighbor(h, 0, 1);
-        const bool inkernel = ((h->fused_overlap == 3 && !xnb) || h->fused_overlap == 4) && comm && !per && fused_folds_hiface(h, a) && h->visc_fold;
+        const bool inkernel = (h->fused_overlap == 3 || h->fused_overlap == 4) && comm && !per && fused_folds_hiface(h, a) && h->visc_fold;
         const bool early = (h->fused_overlap == 2 || (h->fused_overlap >= 3 && !inkernel)) && comm && !per;
         const bool split = !comm && !per && h->fused_split && nt[0] > 1 && nt[1] > 1 && nt[2] > 1;
         if (split) {
@@ -778,25 +774,30 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             memset(&sh, 0, sizeof(sh));
             int lo[3], hi[3];
             for (int d = 0; d < 3; d++) { lo[d] = (nbf[d][0] && nt[d] > 1) ? 1 : 0; hi[d] = (nbf[d][1] && nt[d] > 1) ? nt[d] - 1 : nt[d]; if (hi[d] < lo[d]) hi[d] = lo[d]; }
-            // a dimension with a single tile and a neighbour has no interior tile at all
-            for (int d = 0; d < 3; d++) if ((nbf[d][0] || nbf[d][1]) && nt[d] == 1) { lo[d] = 0; hi[d] = 0; }
-            sh.ntx_i = hi[0] - lo[0]; sh.nty_i = hi[1] - lo[1];
-            sh.tx0_i = lo[0]; sh.ty0_i = lo[1]; sh.tz0_i = lo[2];
-            sh.n_int = sh.ntx_i * sh.nty_i * (hi[2] - lo[2]);
-            if (sh.n_int <= 0) { sh.n_int = 0; sh.ntx_i = sh.nty_i = 1; }
+            for (int d = 0; d < 3; d++) if ((nbf[d][0] || nbf[d][1]) && nt[d] == 1) { lo[d] = 0; hi[d] = 0; }       // a single tile next to a neighbour: no interior tile in that dimension
+            // box 0: the first z chunks of the interior tiles -- tuning switch "fused_first_pct" (default 15 % of the interior chunks: ~0.9 ms of work at 512^3 for an exchange of ~0.3 ms);
+            // a launch over ALL interior tiles first would leave the tiles of an x face to a launch of their own, which is slow (a column of 64-lane tiles touches 512 B of every 4 KB
+            // row of every array: few HBM channels carry it; profiles/r04_inkernel_faces.txt) -- in the second launch they run among their row neighbours
+            int zs = lo[2] + ((hi[2] - lo[2]) * h->fused_first_pct + 99) / 100;
+            if (zs > hi[2]) zs = hi[2];
+            if (hi[0] <= lo[0] || hi[1] <= lo[1]) zs = lo[2];
             {
-                // the shell: z slabs over the whole xy extent, then y slabs over the remaining z range, then x slabs over the remaining y and z ranges -- disjoint boxes
-                const int boxes[6][6] = {{0, nt[0], 0, nt[1], 0, lo[2]}, {0, nt[0], 0, nt[1], hi[2], nt[2]},
-                                         {0, nt[0], 0, lo[1], lo[2], hi[2]}, {0, nt[0], hi[1], nt[1], lo[2], hi[2]},
-                                         {0, lo[0], lo[1], hi[1], lo[2], hi[2]}, {hi[0], nt[0], lo[1], hi[1], lo[2], hi[2]}};
-                int tot = sh.n_int;
-                for (int q = 0; q < 6; q++) {
+                const int boxes[7][6] = {{lo[0], hi[0], lo[1], hi[1], lo[2], zs},                                  // class 1
+                                         {0, nt[0], 0, nt[1], zs, nt[2]},                                          // class 2: the rest of the block, natural order
+                                         {0, nt[0], 0, nt[1], 0, lo[2]},                                           //          the z-lo slab of shell tiles
+                                         {0, nt[0], 0, lo[1], lo[2], zs}, {0, nt[0], hi[1], nt[1], lo[2], zs},     //          the shell tiles beside box 0: y slabs,
+                                         {0, lo[0], lo[1], hi[1], lo[2], zs}, {hi[0], nt[0], lo[1], hi[1], lo[2], zs}};   //      x slabs
+                const int band[7] = {1, 1, 1, 0, 0, 0, 0};
+                int tot = 0;
+                for (int q = 0; q < 7; q++) {
                     const int *b = boxes[q];
-                    const int cnt = (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]);
-                    if (b[1] <= b[0] || b[3] <= b[2] || b[5] <= b[4] || cnt <= 0) continue;
-                    for (int c = 0; c < 6; c++) sh.box[sh.nbox][c] = b[c];
+                    const bool empty = b[1] <= b[0] || b[3] <= b[2] || b[5] <= b[4];
+                    if (empty && q > 0) continue;
+                    for (int c = 0; c < 6; c++) sh.box[sh.nbox][c] = empty ? 0 : b[c];
+                    if (empty) { sh.box[sh.nbox][1] = sh.box[sh.nbox][3] = sh.box[sh.nbox][5] = 1; }      // (keeps the divisions of the tile map defined; no block maps to an empty box 0)
+                    sh.banded[sh.nbox] = band[q];
                     sh.start[sh.nbox] = tot;
-                    tot += cnt;
+                    tot += empty ? 0 : (b[1] - b[0]) * (b[3] - b[2]) * (b[5] - b[4]);
                     sh.nbox++;
                 }
                 sh.start[sh.nbox] = tot;
@@ -811,10 +812,10 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             if (bn.nbK0) bn.fsK0 = bn.nsK0 = 0;
             if (bn.nbK1) bn.fsK1 = bn.nsK1 = 0;
             const int all[6] = {0, nt[0], 0, nt[1], 0, nt[2]};
-            sh.blk0 = 0;
+            sh.blk0 = 0; sh.cls = 0;
             JRX_TRY(launch_fused(h, s, a, bn, all, false, true, &sh));           // the tiles that read no received plane: beside the exchange
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[2], 0));
-            sh.blk0 = sh.n_int;
+            sh.blk0 = sh.start[1]; sh.cls = 1;
             JRX_TRY(launch_fused(h, s, a, bn, all, false, true, &sh));           // the tiles next to a face with a neighbour: behind it
             if (tev) JRX_HIP(h, hipEventRecord(tev[3], s));
             bs = s;

@@ -656,12 +656,12 @@ struct FusedBC {
     // NBR: faces with a neighbour (their fs / ns flags are cleared): the planes of the DESTINATION set there hold received velocities
     int nbL, nbR, nbF, nbBk, nbK0, nbK1;
 };
-// NBR: the tiles of a block in two classes -- [0, n_int) the box of tiles that touch no face with a neighbour (XCD-banded order inside the box), behind them the up to six
-// disjoint boxes of tiles that do.  Two launches of the same kernel: the first class right away, the second (blk0 = n_int) once update_halo!(V) has delivered the planes it reads
+// NBR: the tiles of a block as a list of disjoint boxes of tiles, launched in two classes.  Box 0 = tiles that touch no face with a neighbour (a first share of them: enough work
+// to cover update_halo!(V), which runs beside it); boxes 1.. = everything else -- the rest of the block in its natural XCD-banded order, shell tiles included, plus the shell
+// tiles beside box 0 -- launched (blk0 = start[1]) once the exchange has delivered the planes they read
 struct FusedShell {
-    int n_int, ntx_i, nty_i, tx0_i, ty0_i, tz0_i;
-    int nbox, box[6][6], start[7];
-    int blk0;
+    int nbox, box[7][6], start[8], banded[7];
+    int blk0, cls;           // first block of the launch; cls (host side only): 0 = box 0, 1 = the boxes behind it
 };
 // coherent load (device scope): a value another kernel of this device has written while this one runs
 __device__ __forceinline__ double LDC(const double *p, u32 off)
@@ -715,26 +715,35 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
 #define NBVY(flag_, off_, jj_) ((NBR && bc.flag_) ? ((((jj_) == 0 && bc.nsF) || ((jj_) == ny && bc.nsBk)) ? 0.0 : LDC(a.o.Vy, (off_))) : LDB(f.Vy, (off_)))
 #define NBVZ(flag_, off_, kk_) ((NBR && bc.flag_) ? ((((kk_) == 0 && bc.nsK0) || ((kk_) == nz && bc.nsK1)) ? 0.0 : LDC(a.o.Vz, (off_))) : LDB(f.Vz, (off_)))
     const int tx = (int)(threadIdx.x % TX), ty = (int)(threadIdx.x / TX);
-    int tile = blockIdx.x + (NBR ? sh.blk0 : 0);
-    int nblk = (int)gridDim.x;
-    if (NBR) { ntx = sh.ntx_i; nty = sh.nty_i; tx0 = sh.tx0_i; ty0 = sh.ty0_i; tz0 = sh.tz0_i; nblk = sh.n_int; }
-    const bool shell = NBR && tile >= sh.n_int;          // a tile next to a face with a neighbour
-    if (XG > 0 && !shell) {
-        // XCD-banded order (blocks are dealt round-robin to the 8 XCDs): XCD q takes XG consecutive tile rows
-        // q*XG .. q*XG+XG-1 of every group of 8*XG rows (rows run over y, then z), so the y-halo rows of
-        // neighbouring tiles are served by the same L2; the tail that does not fill a group keeps plain order
-        const int full = ((nty * (int)((unsigned)nblk / (unsigned)(ntx * nty))) / (8 * XG)) * (8 * XG) * ntx;
-        if (tile < full) {
-            const int q = tile & 7, r = tile >> 3, r2 = r / ntx;
-            tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
-        }
-    }
-    int tr = tile / ntx, tix = tx0 + tile % ntx, tiy = ty0 + tr % nty, tiz = tz0 + tr / nty;
-    if (shell) {
+    int tile = blockIdx.x;
+    int tix, tiy, tiz;
+    if (NBR) {
+        tile += sh.blk0;
         int b = 0;
         while (b + 1 < sh.nbox && tile >= sh.start[b + 1]) b++;
-        const int l = tile - sh.start[b], bw = sh.box[b][1] - sh.box[b][0], bh = sh.box[b][3] - sh.box[b][2];
+        int l = tile - sh.start[b];
+        const int bw = sh.box[b][1] - sh.box[b][0], bh = sh.box[b][3] - sh.box[b][2], bd = sh.box[b][5] - sh.box[b][4];
+        if (XG > 0 && sh.banded[b]) {       // XCD-banded order inside the box (see below)
+            const int full = ((bh * bd) / (8 * XG)) * (8 * XG) * bw;
+            if (l < full) {
+                const int q = l & 7, r = l >> 3, r2 = r / bw;
+                l = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * bw + r % bw;
+            }
+        }
         tix = sh.box[b][0] + l % bw; tiy = sh.box[b][2] + (l / bw) % bh; tiz = sh.box[b][4] + l / (bw * bh);
+    } else {
+        if (XG > 0) {
+            // XCD-banded order (blocks are dealt round-robin to the 8 XCDs): XCD q takes XG consecutive tile rows
+            // q*XG .. q*XG+XG-1 of every group of 8*XG rows (rows run over y, then z), so the y-halo rows of
+            // neighbouring tiles are served by the same L2; the tail that does not fill a group keeps plain order
+            const int full = ((nty * (int)(gridDim.x / (unsigned)(ntx * nty))) / (8 * XG)) * (8 * XG) * ntx;
+            if (tile < full) {
+                const int q = tile & 7, r = tile >> 3, r2 = r / ntx;
+                tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
+            }
+        }
+        const int tr = tile / ntx;
+        tix = tx0 + tile % ntx; tiy = ty0 + tr % nty; tiz = tz0 + tr / nty;
     }
     const int i = tix * (TX - OVX - (SHFL ? 1 : 0)) - OVX + tx;  // cell column of this thread
     const int j = tiy * (TY - 1) - 1 + ty;
