@@ -1025,7 +1025,8 @@ def start_ipc_helpers(args):
     the multi_rank_path leg wakes them: rank 0 and rank 1 of a two-block decomposition, both on device 0, joined by jrx_comm_init_ipc."""
     env0 = dict(os.environ, WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", LOCAL_RANK="0")
     for r in range(2):
-        IPC_HELPERS.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), "--ipc-helper", "--n", str(args.n), "--gpus", "2"], env=dict(env0, RANK=str(r)),
+        opts = [x for kv in args.option for x in ("--option", kv)]
+        IPC_HELPERS.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), "--ipc-helper", "--n", str(args.n), "--gpus", "2", *opts], env=dict(env0, RANK=str(r)),
                                             stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
 
 
@@ -1092,6 +1093,9 @@ def ipc_helper(args) -> int:
     jr = load_package()
     torch.cuda.set_device(0)
     R = GpuRanks(args, jr, rank, 2, 0)
+    for kv in args.option:
+        k, v = kv.split("=")
+        R.h.set_option(k, int(v))
     steps, warm = 40, 6
     out = {"workload": f"SolVi3D, two {args.n}^3 blocks on one device, one PROCESS per block (ipc transport: hipIpcOpenMemHandle + hipMemcpyAsync, flags in shared memory)", "steps": steps}
     try:
