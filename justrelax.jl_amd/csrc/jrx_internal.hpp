@@ -62,8 +62,9 @@ struct jrx_handle {
     int vep3_cfg = 0;                        // z-marching edge kernel: KZ * 10 + min blocks per CU, 0 = default
     int vep3_edges = 4;                      // 3D VEP edge pass: 4 z-marching kernel, the three family waves of a row share the centre and shear operands through LDS;
                                              // 3 centre operands only, 1 no LDS (one family per block), 2 one launch per family, 0 one node per thread (A/B)
-    int vep3_hide_comm = 2;                  // multi-rank 3D VEP driver: the three exchanges of an iteration on the halo stream beside independent kernels
-                                             // (1: ητ and the edge stresses only, 0: serial; A/B)
+    int vep3_hide_comm = 1;                  // multi-rank 3D VEP driver: 2 = the three exchanges of an iteration on the halo stream beside independent kernels; 1 (default) = ητ and the
+                                             // edge stresses only, update_halo!(V) behind the whole velocity sweep; 0 = serial.  Two 256^3 blocks on one device (profiles/r04_bench_default.json): +12.2 % (2),
+                                             // +8.6 % (1), +9.6 % (0) -- the six slab launches of (2) cost more than they hide until a real link shows otherwise
     bool vep3_fork = false;                  // 3D VEP driver without neighbours: the centre pass of the stress update on the halo stream beside the edge pass (second set of τxx, τyy, τzz).
                                              // Measured 256^3 311.6 / 311.4 / 312.2 it/s forked vs 312.7 / 313.2 / 312.2 in order (profiles/r04_vep3d_fork.txt): nothing to gain, off
     bool vep3_map = true, vep3_xcd = true;   // 3D VEP edge kernel thread mapping / XCD slab order (A/B)

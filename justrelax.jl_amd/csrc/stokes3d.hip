@@ -1165,8 +1165,8 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     if (!times_ms) return jrx_fail(h, JRX_ERR_ARG, "times_ms is NULL");
     hipStream_t s = h->stream;
     // hipEvents around the launches of sampled iterations *inside* the timed batch (on the stream the
-    // kernels run on); at most 256 samples so that event bookkeeping stays negligible
-    const int64_t stride = iters > 256 ? (iters + 255) / 256 : 1;
+    // kernels run on); at most 64 samples so that event bookkeeping stays negligible (four records per sampled iteration cost 10-20 us: 2 % of a 256^3 iteration)
+    const int64_t stride = iters > 64 ? (iters + 63) / 64 : 1;
     const int nsamp = (int)((iters + stride - 1) / stride);
     const bool chain = h->chain_profile && jrx_comm_active(h);
     std::vector<hipEvent_t> evs((size_t)nsamp * (chain ? 8 : 4));

@@ -142,6 +142,32 @@ def test_bench_prices_a_launch_by_the_kernel_form_that_runs():
     cells = float(n) ** 3
     assert abs(r["achieved"] - 280.0 * cells / 6.0e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12 and r["frac"] < 1.0
     assert r["bytes_per_cell"] == 280.0 and abs(r["needed_bytes_per_launch"] - 200.0 * cells) < 1.0
-    assert abs(r["traffic_ratio"] - bench.PMC_TRAFFIC_VISC_512 / (280.0 * cells)) < 1e-12 and 1.0 < r["traffic_over_needed"] < 1.6
+    if bench.PMC["stale"]:
+        # csrc/stokes3d_kernels.hpp has changed since the PMC passes of profiles/pmc_traffic.json were taken: the line must not quote them
+        assert r["traffic"] is None and r["traffic_ratio"] is None and r["traffic_over_needed"] is None and "STALE" in r["traffic_source"]
+    else:
+        assert abs(r["traffic_ratio"] - bench.PMC_TRAFFIC_VISC_512 / (280.0 * cells)) < 1e-12 and 1.0 < r["traffic_over_needed"] < 1.6
+        assert bench.PMC["git_head"] in r["traffic_source"]
     r256 = bench.fused_roofline(g, 256, 1.0, 1.1, 0.0, None)
     assert r256["traffic"] is None and r256["traffic_ratio"] is None and r256["bytes_per_cell"] == 360.0
+
+
+def test_pmc_figures_are_dropped_when_the_kernel_source_has_changed(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json carries the sha256 of csrc/stokes3d_kernels.hpp it was measured on; another sha -> every figure None and a source that says STALE"""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    real = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+    assert len(real["kernels_sha256"]) == 64 and real["n"] == 512 and real["git_head"]
+    fake_root = tmp_path
+    (fake_root / "profiles").mkdir()
+    (fake_root / "justrelax.jl_amd" / "csrc").mkdir(parents=True)
+    (fake_root / "justrelax.jl_amd" / "csrc" / "stokes3d_kernels.hpp").write_text("// another kernel source\n")
+    (fake_root / "profiles" / "pmc_traffic.json").write_text(json.dumps(real))
+    monkeypatch.setattr(bench, "ROOT", fake_root)
+    d = bench.load_pmc()
+    assert d["stale"] and d["k_fused3d_visc"] is None and d["k_fused3d_general"] is None and "STALE" in d["source"]
+    import hashlib
+    real2 = dict(real, kernels_sha256=hashlib.sha256(b"// another kernel source\n").hexdigest())
+    (fake_root / "profiles" / "pmc_traffic.json").write_text(json.dumps(real2))
+    d = bench.load_pmc()
+    assert not d["stale"] and d["k_fused3d_visc"] == real["k_fused3d_visc"] and real["git_head"] in d["source"]
