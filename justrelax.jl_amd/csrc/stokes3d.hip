@@ -1166,7 +1166,8 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     hipStream_t s = h->stream;
     // hipEvents around the launches of sampled iterations *inside* the timed batch (on the stream the
     // kernels run on); at most 64 samples so that event bookkeeping stays negligible (four records per sampled iteration cost 10-20 us: 2 % of a 256^3 iteration)
-    const int64_t stride = iters > 64 ? (iters + 63) / 64 : 1;
+    // (an odd stride: consecutive fused iterations alternate between the two state sets, whose allocations run 1-2 % apart -- sampling every second one would see one direction only)
+    const int64_t stride = iters > 64 ? (((iters + 63) / 64) | 1) : 1;
     const int nsamp = (int)((iters + stride - 1) / stride);
     const bool chain = h->chain_profile && jrx_comm_active(h);
     std::vector<hipEvent_t> evs((size_t)nsamp * (chain ? 8 : 4));
