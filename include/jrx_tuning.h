@@ -22,6 +22,9 @@
  *   "vep3_nt" (0), "vep3_prekz" (0)   3D VEP: non-temporal stores of the edge pass; planes per thread of the z-marching pre kernel (0 = chosen by the grid size; 1, 2, 4, 8, 16, 32)
  *   "vep3_hide_comm" (1)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 (default: the fastest on one device) = the first two only,
  *                                 update_halo!(V) behind the whole velocity sweep; 0 = everything on the compute stream, in order (A/B)
+ *   "vep3_fuse_pc" (1)            3D VEP driver without neighbours, viscosity laws that read no field: compute_∇V! / compute_P! / compute_strain_rate!, update_viscosity_τII! and the centre half of
+ *                                 update_stresses_center_vertex_ps! run as ONE kernel ahead of the edge half (0 = the three kernels, centre half behind the edge half); bit-identical
+ *   "vep3_np_const" (1)           3D VEP centre pass / fused kernel: 1 = instantiations with the number of phases as a compile-time constant (1..4; 0 = the run-time loops, A/B)
  *   "vep3_fork" (0)               3D VEP driver without neighbours: 1 = the centre pass of update_stresses_center_vertex_ps! runs on a second stream beside the edge pass (it writes a
  *                                 second set of τxx, τyy, τzz, adopted by pointer swap); measured equal to one pass after the other: off
  *   "vep_store_all" (0)           VEP loops (2D and 3D): 1 = every iteration stores ∇V, RP, ε_pl, ε_vol_pl, τII, η_vep (default: only iterations whose results can be observed)

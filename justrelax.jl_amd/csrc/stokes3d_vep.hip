@@ -729,17 +729,24 @@ __global__ __launch_bounds__(192, SOFT ? 2 : 3) void k_vep3_edges_zl(const Vep3A
     else vep3_edges_z_tile<KZ, NP, 4, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 2);
 }
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
-template <bool SOFT>
+// NP > 0: the number of phases as a compile-time constant -- the cell's phase ratios are loaded once, in one batch, and the phase loops unroll (with a run-time count every
+// loop iteration of every material function is a load the next instruction waits for: ~10 dependent memory round trips per cell)
+template <bool SOFT, int NP = 0>
 __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
 {
-    const int nx = a.nx, ny = a.ny, nz = a.nz, np = a.rh.nphase;
+    const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP > 0 ? NP : a.rh.nphase;
     NODE_IJK_XS(nx, ny)
     if (k >= nz) return;
     const i64 c = i + (i64)nx * (j + (i64)ny * k);
-    const double *rc = a.f.phase_c + (i64)np * c;
+    double rcv[NP > 0 ? NP : 1];
+    if (NP > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) rcv[q] = a.f.phase_c[(i64)NP * c + q];
+    }
+    const double *rc = NP > 0 ? rcv : a.f.phase_c + (i64)np * c;
     const double _Gdt = 1.0 / (ratio_avg3(a.rh.G, rc, np) * a.dt);
     bool is_pl; double eta_reg;
-    plastic_params3(a.rh, rc, is_pl, eta_reg);
+    plastic_params3<NP>(a.rh, rc, is_pl, eta_reg);
     const double K = ratio_avg3(a.rh.Kb, rc, np);
     const double e = a.f.eta[c];
     const double dtr = 1.0 / (a.theta_dtau + e * _Gdt + 1.0);
@@ -767,10 +774,10 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
         tII = sinv3(q6);
     }
     double dQdt[6], dQdP, dFdP;
-    plastic_grad3(a.rh, rc, tt, dQdt, dQdP, dFdP);
+    plastic_grad3<NP>(a.rh, rc, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
     const double Pr = a.theta[c];
-    const double F = yield_F3<SOFT>(a.rh, rc, Pr, tII, SOFT ? a.f.EII_pl[c] : 0.0);
+    const double F = yield_F3<SOFT, NP>(a.rh, rc, Pr, tII, SOFT ? a.f.EII_pl[c] : 0.0);
     double l = a.lam[c];
     if (is_pl && tII != 0.0 && F > 0) {
         l = (1.0 - a.rel) * l + a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol));
@@ -792,6 +799,221 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
     if (a.obs) VST(a, a.f.tII[c], tII);
     if (a.obs) VST(a, a.f.eta_vep[c], tII * 0.5 * (1.0 / sinv3(eij)));
     VST(a, a.f.P[c], Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_vep3_pre + k_vep3_visc (linear laws) + k_vep3_centre as ONE kernel (option "vep3_fuse_pc", single rank): the centre pass of update_stresses_center_vertex_ps!
+// reads nothing the edge pass writes -- only the cell's own ε, τ, τ_o, θ, η, λ and the strain rates of its twelve edges -- so it can run before the edge pass, in the
+// thread that has just produced the cell's ∇V, θ and ε.  The twelve edge strain rates are recomputed from the velocities (the expressions of k_vep3_pre, so the same bits
+// as the stored arrays the edge pass reads); walking up its column the thread carries the four of plane k + 1 into the next step.  What the edge pass still has to find
+// unchanged goes to second arrays: the relaxed η (compute_maxloc! of the neighbouring cells reads the old one) to eta_out, the new τxx, τyy, τzz (the edge pass averages the
+// old ones) to a.cnew; the driver swaps the pointers.  Per iteration 16 written + ~27 fetched passes instead of (8.3 + 11.9) + (1 + 2) + (7.1 + 25.3).
+// Same arithmetic, operation for operation, as the three kernels: bit-identical (tests/test_gpu_vep3d.py::test_vep3d_fused_pre_centre_equals_the_three_kernels).
+// OBS: the launch stores the output-only arrays (a.obs as a compile-time constant: with the flag tested at run time every such store ends a basic block, and the
+// scheduler, which works one block at a time, can no longer issue the plane's loads as one batch -- seven dependent memory round trips per plane instead of two)
+template <bool SOFT, bool RHO, int NP = 0, bool OBS = true>
+__global__ __launch_bounds__(256, 3) void k_vep3_prec(const Vep3Args a, double *__restrict__ eta_out, const int KZ)
+{
+    const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP > 0 ? NP : a.rh.nphase;
+    unsigned bx_ = blockIdx.x, by_ = blockIdx.y;
+    {   // XCD slab order of the (flattened xy, z chunk) block sequence, see NODE_IJK_XS
+        const unsigned L_ = by_ * gridDim.x + bx_, per_ = (gridDim.x * gridDim.y) / 8u;
+        if (L_ < per_ * 8u) { const unsigned Ln_ = (L_ & 7u) * per_ + (L_ >> 3); bx_ = Ln_ % gridDim.x; by_ = Ln_ / gridDim.x; }
+    }
+    const int t_ = bx_ * blockDim.x + threadIdx.x;
+    const int j = t_ / (nx + 1), i = t_ - j * (nx + 1);
+    if (j >= ny + 1) return;
+    const int k0 = (int)by_ * KZ, k1 = min(k0 + KZ, nz + 1);
+    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
+    const double _dx = a._dx, _dy = a._dy, _dz = a._dz;
+#define VX(i_, j_, k_) Vx[(i_) + (i64)(nx + 1) * ((j_) + (i64)(ny + 2) * (k_))]
+#define VY(i_, j_, k_) Vy[(i_) + (i64)(nx + 2) * ((j_) + (i64)(ny + 1) * (k_))]
+#define VZ(i_, j_, k_) Vz[(i_) + (i64)(nx + 2) * ((j_) + (i64)(ny + 2) * (k_))]
+    const bool cellcol = i < nx && j < ny;
+    if (!cellcol) {     // node columns on the high faces i = nx / j = ny: their own edge strain rates only, as k_vep3_pre
+#pragma unroll 1
+        for (int k = k0; k < k1; k++) {
+            if (i < nx) VST(a, EYZ(a.f.eyz, i, j, k), 0.5 * (_dz * (VY(i + 1, j, k + 1) - VY(i + 1, j, k)) + _dy * (VZ(i + 1, j + 1, k) - VZ(i + 1, j, k))));
+            if (j < ny) VST(a, EXZ(a.f.exz, i, j, k), 0.5 * (_dz * (VX(i, j + 1, k + 1) - VX(i, j + 1, k)) + _dx * (VZ(i + 1, j + 1, k) - VZ(i, j + 1, k))));
+            if (k < nz) VST(a, EXY(a.f.exy, i, j, k), 0.5 * (_dy * (VX(i, j + 1, k + 1) - VX(i, j, k + 1)) + _dx * (VY(i + 1, j, k + 1) - VY(i, j, k + 1))));
+        }
+        return;
+    }
+    // Addressing: one 32-bit byte offset per array LAYOUT and thread (every array is below 4 GiB, check_vep3), advanced by the layout's plane stride per step; the row / plane
+    // displacements of the stencils go into uniform base pointers (SGPRs) and the x displacements into the instruction's immediate offset.  Left to itself the compiler keeps a
+    // 64-bit address per (array, displacement) pair alive across the loop: ~100 VGPRs, and with them the kernel's third wave per SIMD.
+    typedef unsigned int u32;
+#define LB(p, off) (*(const double *)((const char *)(p) + (off)))
+#define SW(p, off) (*(double *)((char *)(p) + (off)))
+    const u32 pVx = 8u * (u32)((nx + 1) * (ny + 2)), pVy = 8u * (u32)((nx + 2) * (ny + 1)), pVz = 8u * (u32)((nx + 2) * (ny + 2));
+    const u32 pC = 8u * (u32)(nx * ny), pYZ = 8u * (u32)(nx * (ny + 1)), pXZ = 8u * (u32)((nx + 1) * ny), pXY = 8u * (u32)((nx + 1) * (ny + 1));
+    u32 ovx = 8u * (u32)(i + (nx + 1) * j) + pVx * (u32)k0;          // Vx[i, j, k]
+    u32 ovy = 8u * (u32)(i + (nx + 2) * j) + pVy * (u32)k0;          // Vy[i, j, k]
+    u32 ovz = 8u * (u32)(i + (nx + 2) * j) + pVz * (u32)k0;          // Vz[i, j, k]
+    u32 oc = 8u * (u32)(i + nx * j) + pC * (u32)k0;                  // cell (i, j, k)
+    u32 oyz = 8u * (u32)(i + nx * j) + pYZ * (u32)k0, oxz = 8u * (u32)(i + (nx + 1) * j) + pXZ * (u32)k0, oxy = 8u * (u32)(i + (nx + 1) * j) + pXY * (u32)k0;
+    // uniform base pointers: X[dj][dk] = Vx displaced by dj rows and dk planes, ...
+    const i64 rX = nx + 1, qX = (i64)(nx + 1) * (ny + 2), rY = nx + 2, qY = (i64)(nx + 2) * (ny + 1), rZ = nx + 2, qZ = (i64)(nx + 2) * (ny + 2);
+    const double *const X01 = Vx + qX, *const X11 = Vx + rX + qX, *const X21 = Vx + 2 * rX + qX, *const X12 = Vx + rX + 2 * qX, *const X10 = Vx + rX;
+    const double *const Y01 = Vy + qY, *const Y11 = Vy + rY + qY, *const Y02 = Vy + 2 * qY, *const Y12 = Vy + rY + 2 * qY, *const Y00 = Vy, *const Y10 = Vy + rY;
+    const double *const Z00 = Vz, *const Z10 = Vz + rZ, *const Z20 = Vz + 2 * rZ, *const Z01 = Vz + qZ, *const Z11 = Vz + rZ + qZ, *const Z21 = Vz + 2 * rZ + qZ;
+    // clamped 3 x 3 window of η: three row offsets, the x displacements 0 on the faces
+    const u32 er[3] = {8u * (u32)(i + nx * clampi3(j - 1, 0, ny - 1)), 8u * (u32)(i + nx * j), 8u * (u32)(i + nx * clampi3(j + 1, 0, ny - 1))};
+    const u32 dxl = i > 0 ? 8u : 0u, dxr = i < nx - 1 ? 8u : 0u;
+    auto plane_max = [&](int kk) {          // clamped 3 x 3 maximum of η in plane clamp(kk), the comparison order of k_maxloc within the plane
+        const double *const ep = a.f.eta + (i64)nx * ny * clampi3(kk, 0, nz - 1);
+        double m = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const double v0 = LB(ep, er[q] - dxl), v1 = LB(ep, er[q]), v2 = LB(ep, er[q] + dxr);
+            if (v0 > m) m = v0;
+            if (v1 > m) m = v1;
+            if (v2 > m) m = v2;
+        }
+        return m;
+    };
+    double m_prev = plane_max(k0 - 1), m_cur = plane_max(k0), m_next;
+    // carried up the column: the velocities of plane k + 1 that plane k + 2's edges difference against, Vz of the cell's lower face, and the four edge strain rates of plane k
+    double vx_a = LB(X11, ovx), vx_b = LB(X11, ovx + 8u), vy_a = LB(Y01, ovy + 8u), vy_b = LB(Y11, ovy + 8u), vz_c = LB(Z10, ovz + 8u);
+    double e_yz0 = 0.5 * (_dz * (vy_a - LB(Y00, ovy + 8u)) + _dy * (vz_c - LB(Z00, ovz + 8u)));                      // eyz(i, j, k0)
+    double e_yz1 = 0.5 * (_dz * (vy_b - LB(Y10, ovy + 8u)) + _dy * (LB(Z20, ovz + 8u) - vz_c));                      // eyz(i, j+1, k0)
+    double e_xz0 = 0.5 * (_dz * (vx_a - LB(X10, ovx)) + _dx * (vz_c - LB(Z10, ovz)));                                // exz(i, j, k0)
+    double e_xz1 = 0.5 * (_dz * (vx_b - LB(X10, ovx + 8u)) + _dx * (LB(Z10, ovz + 16u) - vz_c));                     // exz(i+1, j, k0)
+    double *const tc[6] = {a.f.txx, a.f.tyy, a.f.tzz, a.f.tyz_c, a.f.txz_c, a.f.txy_c};
+    double *const tw[6] = {a.cnew[0], a.cnew[1], a.cnew[2], a.f.tyz_c, a.f.txz_c, a.f.txy_c};
+    const double *const toc[6] = {a.f.toxx, a.f.toyy, a.f.tozz, a.f.toyz_c, a.f.toxz_c, a.f.toxy_c};
+    const double _dt = 1.0 / a.dt;
+#pragma unroll 1
+    for (int k = k0; k < k1; k++, ovx += pVx, ovy += pVy, ovz += pVz, oc += pC, oyz += pYZ, oxz += pXZ, oxy += pXY) {
+        SW(a.f.eyz, oyz) = e_yz0;
+        SW(a.f.exz, oxz) = e_xz0;
+        if (k >= nz) break;               // the node plane above the last cells
+        // ---- every operand of the plane, requested before the first of them is used
+        const double z_n = LB(Z11, ovz + 8u), z_d = LB(Z01, ovz + 8u), z_u = LB(Z21, ovz + 8u), z_l = LB(Z11, ovz), z_r = LB(Z11, ovz + 16u);
+        const double x00 = LB(X01, ovx), x02 = LB(X21, ovx), x10 = LB(X01, ovx + 8u), x12 = LB(X21, ovx + 8u);
+        const double y00 = LB(Y01, ovy), y01 = LB(Y11, ovy), y20 = LB(Y01, ovy + 16u), y21 = LB(Y11, ovy + 16u);
+        const double nx_a = LB(X12, ovx), nx_b = LB(X12, ovx + 8u), ny_a = LB(Y02, ovy + 8u), ny_b = LB(Y12, ovy + 8u);
+        const double Kc_ = LB(a.Kc, oc), Gc_ = LB(a.Gc, oc), P = LB(a.theta, oc), P0 = LB(a.f.P0, oc), Q_ = LB(a.f.Q, oc);
+        double w9[9];
+        {
+            const double *const ep = a.f.eta + (i64)nx * ny * clampi3(k + 1, 0, nz - 1);
+#pragma unroll
+            for (int q = 0; q < 3; q++) { w9[3 * q] = LB(ep, er[q] - dxl); w9[3 * q + 1] = LB(ep, er[q]); w9[3 * q + 2] = LB(ep, er[q] + dxr); }
+        }
+        const double e_lin = LB(a.eta_lin, oc), e_old = LB(a.f.eta, oc), l_old = LB(a.lam, oc);
+        const i64 c = (i64)(oc >> 3);
+        double rcv[NP > 0 ? NP : 1];
+        if (NP > 0) {
+#pragma unroll
+            for (int q = 0; q < NP; q++) rcv[q] = a.f.phase_c[(i64)NP * c + q];
+        }
+        double tij[6], toij[6];
+#pragma unroll
+        for (int s = 0; s < 6; s++) { tij[s] = LB(tc[s], oc); toij[s] = LB(toc[s], oc); }
+        const double EII_ = SOFT ? LB(a.f.EII_pl, oc) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler, minimising register pressure, would sink every load to its first use again)
+        // ---- compute_∇V!, compute_P!, compute_strain_rate! (k_vep3_pre)
+        const double dxi = (-vx_a + vx_b) * _dx;
+        const double dyi = (-vy_a + vy_b) * _dy;
+        const double dzi = (-vz_c + z_n) * _dz;
+        const double divV = dxi + dyi + dzi;
+        if (OBS) SW(a.f.divV, oc) = divV;
+        const double _Kdt = 1.0 / (Kc_ * a.dt), _Gdt0 = 1.0 / (Gc_ * a.dt);
+        const double rhs = -divV + (Q_ * _dt);
+        if (OBS) SW(a.f.RP, oc) = fma(-(P - P0), _Kdt, rhs);
+        m_next = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 9; q++)
+            if (w9[q] > m_next) m_next = w9[q];         // the comparison order of plane_max
+        double et = m_prev;
+        if (m_cur > et) et = m_cur;
+        if (m_next > et) et = m_next;
+        m_prev = m_cur; m_cur = m_next;
+        SW(const_cast<double *>(a.etatau), oc) = et;
+        const double psi = 1.0 / (1.0 / et + _Gdt0) * a.r / a.theta_dtau;
+        const double Pr = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
+        SW(a.theta, oc) = Pr;
+        const double d3 = divV * (1.0 / 3.0);
+        double eij[6];
+        eij[0] = dxi - d3; eij[1] = dyi - d3; eij[2] = dzi - d3;
+        SW(a.f.exx, oc) = eij[0];
+        SW(a.f.eyy, oc) = eij[1];
+        SW(a.f.ezz, oc) = eij[2];
+        if (RHO) a.f.fz[c] = mat_density_ratio(a.rh, a.f.phase_c + (i64)np * c,
+                                               !a.f.T ? 0.0 : (a.tg ? a.f.T[i + (i64)(nx + 2) * (j + (i64)(ny + 2) * k)] : a.f.T[c]), a.f.P[c]) * a.rh.gravity;
+        // the four xy edges of the cell (plane k) and the yz / xz edges of plane k + 1
+        {
+            const double exy00 = 0.5 * (_dy * (vx_a - x00) + _dx * (vy_a - y00));
+            const double exy10 = 0.5 * (_dy * (vx_b - x10) + _dx * (y20 - vy_a));
+            const double exy01 = 0.5 * (_dy * (x02 - vx_a) + _dx * (vy_b - y01));
+            const double exy11 = 0.5 * (_dy * (x12 - vx_b) + _dx * (y21 - vy_b));
+            SW(a.f.exy, oxy) = exy00;
+            eij[5] = 0.25 * ((((0.0 + exy00) + exy10) + exy01) + exy11);
+        }
+        {
+            const double n_yz0 = 0.5 * (_dz * (ny_a - vy_a) + _dy * (z_n - z_d));
+            const double n_yz1 = 0.5 * (_dz * (ny_b - vy_b) + _dy * (z_u - z_n));
+            const double n_xz0 = 0.5 * (_dz * (nx_a - vx_a) + _dx * (z_n - z_l));
+            const double n_xz1 = 0.5 * (_dz * (nx_b - vx_b) + _dx * (z_r - z_n));
+            // _av_yz/_av_xz/_av_xy = 0.25 * mysum (MiniKernels.jl:116-121, 228-236): s = 0.0, then k-outer, j, i-inner adds
+            eij[3] = 0.25 * ((((0.0 + e_yz0) + e_yz1) + n_yz0) + n_yz1);
+            eij[4] = 0.25 * ((((0.0 + e_xz0) + e_xz1) + n_xz0) + n_xz1);
+            e_yz0 = n_yz0; e_yz1 = n_yz1; e_xz0 = n_xz0; e_xz1 = n_xz1;
+            vx_a = nx_a; vx_b = nx_b; vy_a = ny_a; vy_b = ny_b; vz_c = z_n;
+        }
+        // ---- update_viscosity_τII! of the linear laws (k_vep3_visc<false, false>)
+        double e = e_lin;
+        e = e * a.nu + e_old * (1.0 - a.nu);
+        e = fmin(fmax(e, a.cut_lo), a.cut_hi);
+        SW(eta_out, oc) = e;
+        // ---- update_stresses_center_vertex_ps!, centres (k_vep3_centre)
+        const double *rc = NP > 0 ? rcv : a.f.phase_c + (i64)np * c;
+        const double _Gdt = 1.0 / (ratio_avg3(a.rh.G, rc, np) * a.dt);
+        bool is_pl; double eta_reg;
+        plastic_params3<NP>(a.rh, rc, is_pl, eta_reg);
+        const double K = ratio_avg3(a.rh.Kb, rc, np);
+        const double dtr = 1.0 / (a.theta_dtau + e * _Gdt + 1.0);
+        double d[6], tt[6];
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+            d[s] = (-(tij[s] - toij[s]) * e * _Gdt - tij[s] + 2.0 * e * eij[s]) * dtr;       // :926, plain arithmetic
+            tt[s] = tij[s] + d[s];
+        }
+        double tII;
+        {
+            double q6[6];
+#pragma unroll
+            for (int s = 0; s < 6; s++) q6[s] = d[s] + tij[s];
+            tII = sinv3(q6);
+        }
+        double dQdt[6], dQdP, dFdP;
+        plastic_grad3<NP>(a.rh, rc, tt, dQdt, dQdP, dFdP);
+        const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
+        const double F = yield_F3<SOFT, NP>(a.rh, rc, Pr, tII, EII_);
+        double l = l_old;
+        if (is_pl && tII != 0.0 && F > 0) {
+            l = (1.0 - a.rel) * l + a.rel * (fmax(F, 0.0) / (e * dtr + eta_reg + vol));
+            SW(a.lam, oc) = l;
+            double epl[6];
+#pragma unroll
+            for (int s = 0; s < 6; s++) { epl[s] = l * dQdt[s]; d[s] = d[s] - 2.0 * e * epl[s] * dtr; tij[s] = d[s] + tij[s]; }
+            if (OBS) SW(a.f.evol_pl, oc) = -l * dQdP;
+#pragma unroll
+            for (int s = 0; s < 6; s++) SW(tw[s], oc) = tij[s];
+            if (OBS) { SW(a.f.eplxx, oc) = epl[0]; SW(a.f.eplyy, oc) = epl[1]; SW(a.f.eplzz, oc) = epl[2]; }
+            tII = sinv3(tij);
+        } else {
+            if (OBS) SW(a.f.evol_pl, oc) = 0.0;
+#pragma unroll
+            for (int s = 0; s < 6; s++) SW(tw[s], oc) = d[s] + tij[s];
+            if (OBS) { SW(a.f.eplxx, oc) = 0.0; SW(a.f.eplyy, oc) = 0.0; SW(a.f.eplzz, oc) = 0.0; }
+        }
+        if (OBS) SW(a.f.tII, oc) = tII;
+        if (OBS) SW(a.f.eta_vep, oc) = tII * 0.5 * (1.0 / sinv3(eij));
+        SW(a.f.P, oc) = Pr - (isinf(K) ? 0.0 : K * a.dt * l * dQdP);
+    }
+#undef LB
+#undef SW
 }
 
 __device__ __forceinline__ double sinv_stag3(const double *xx, const double *yy, const double *zz, const double *yz, const double *xz, const double *xy,
@@ -1004,7 +1226,13 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
         JRX_LAUNCH_CHECK(h);
     }
     if (a.soft) hipLaunchKernelGGL(k_vep3_centre<true>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_vep3_centre<false>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
+    else switch (h->vep3_np_const ? a.rh.nphase : 0) {
+    case 1: hipLaunchKernelGGL((k_vep3_centre<false, 1>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_vep3_centre<false, 2>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_vep3_centre<false, 3>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_vep3_centre<false, 4>), GRID_IJK(nx, ny, nz), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(k_vep3_centre<false>, GRID_IJK(nx, ny, nz), dim3(256), 0, s, a);
+    }
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
 }
@@ -1124,7 +1352,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     const EdgeN ne = edge_counts(p);
     hipStream_t s = h->stream;
     // library scratch: ητ, θ, λ, K, G, a second ητ, the phase-averaged η of the linear laws (centres), λv and the new edge stresses (edges), carved out of one allocation
-    JRX_TRY(jrx_ensure_etatau(h, 10 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
+    JRX_TRY(jrx_ensure_etatau(h, 11 * n + 2 * (size_t)(ne.yz + ne.xz + ne.xy)));
     double *etatau = h->etatau, *theta = etatau + n, *lam = theta + n, *Kc = lam + n, *Gc = Kc + n, *etatau_next = Gc + n;
     Vep3Args a = make_vep3(f, rh, p);
     a.nt = h->vep3_nt;
@@ -1132,7 +1360,8 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     double *eta_lin = etatau_next + n;
     a.lamv[0] = eta_lin + n; a.lamv[1] = a.lamv[0] + ne.yz; a.lamv[2] = a.lamv[1] + ne.xz;
     a.tnew[0] = a.lamv[2] + ne.xy; a.tnew[1] = a.tnew[0] + ne.yz; a.tnew[2] = a.tnew[1] + ne.xz;
-    double *const cset[3] = {a.tnew[2] + ne.xy, a.tnew[2] + ne.xy + n, a.tnew[2] + ne.xy + 2 * n};      // second set of τxx, τyy, τzz (see `fork` below)
+    double *const cset[3] = {a.tnew[2] + ne.xy, a.tnew[2] + ne.xy + n, a.tnew[2] + ne.xy + 2 * n};      // second set of τxx, τyy, τzz (see `fuse` / `fork` below)
+    double *const eta2 = cset[2] + n;                                                                   // second η (see `fuse`)
     jrx_stokes3d_fields g = view3d(f);
     jrx_stokes3d_params q;
     memset(&q, 0, sizeof(q));
@@ -1181,10 +1410,37 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         for (prekz = 8; prekz > 1 && (i64)gpre.x * ((nz + prekz) / prekz) < 2048; prekz /= 2) {}
     // tuning switch "vep3_fork" (default off: measured equal, profiles/r04_vep3d_fork.txt): the centre pass beside the edge pass (see enqueue_iteration); not inside captured graphs (small grids), not with neighbours
     // (there the halo stream carries the exchanges and the centre pass already runs beside one)
-    const bool fork = h->vep3_fork && !comm && !((h->loop_graphs && !ubc && p->periodic == 0 && (double)n <= kGraphCells3D));
+    // "vep3_fuse_pc" (default): pre, viscosity relaxation and centre pass as one kernel AHEAD of the edge pass (k_vep3_prec).  The relaxed η and the new τxx, τyy, τzz go to second arrays -- the neighbours'
+    // compute_maxloc! reads the old η, the edge pass averages the old normal stresses -- which are adopted by pointer swap like the edge stresses; every iteration swaps all of them, so the captured graphs of
+    // an even number of iterations end where they began.  Laws whose η reads fields (invariants gathered from the neighbours) and ranks with neighbours (ητ is exchanged) keep the three kernels.
+    const bool fuse = h->vep3_fuse_pc && !comm && lin && !a.soft;      // (softening laws: 255 VGPRs, one wave per SIMD -- they keep the three kernels)
+    const bool fork = !fuse && h->vep3_fork && !comm && !((h->loop_graphs && !ubc && p->periodic == 0 && (double)n <= kGraphCells3D));
     double *const user_c[3] = {f->txx, f->tyy, f->tzz};
-    auto enqueue_iteration = [&](Vep3Args &A, jrx_stokes3d_fields &G, bool diag_) -> jrx_status {
+    // ordered_: flow_bcs! in the reference's pass order (always on observed iterations; also on the iteration BEFORE one, whose ghost edges and corners velocity2displacement! copies into U --
+    // the one-launch form of the faces leaves those entries, which no stencil reads, to whichever thread wrote last)
+    auto enqueue_iteration = [&](Vep3Args &A, jrx_stokes3d_fields &G, bool diag_, bool ordered_ = false) -> jrx_status {
         A.obs = diag_ || h->vep_store_all;
+        if (fuse) {
+            for (int c_ = 0; c_ < 3; c_++) A.cnew[c_] = (c_ == 0 ? A.f.txx : (c_ == 1 ? A.f.tyy : A.f.tzz)) == cset[c_] ? user_c[c_] : cset[c_];
+            double *const eta_out = A.f.eta == f->eta ? eta2 : f->eta;
+            const dim3 gpc(gpre.x, (unsigned)((nz + 1 + prekz - 1) / prekz));
+            const int npc = (h->vep3_np_const && !upd_rho) ? A.rh.nphase : 0;
+            switch ((npc <= 4 ? npc : 0) * 2 + (A.obs ? 1 : 0) + (upd_rho ? 100 : 0)) {
+#define PREC(NP_, OBS_) case NP_ * 2 + OBS_: hipLaunchKernelGGL((k_vep3_prec<false, false, NP_, OBS_ != 0>), gpc, dim3(256), 0, s, A, eta_out, prekz); break;
+            PREC(0, 0) PREC(0, 1) PREC(1, 0) PREC(1, 1) PREC(2, 0) PREC(2, 1) PREC(3, 0) PREC(3, 1) PREC(4, 0) PREC(4, 1)
+#undef PREC
+            case 100: hipLaunchKernelGGL((k_vep3_prec<false, true, 0, false>), gpc, dim3(256), 0, s, A, eta_out, prekz); break;
+            default: hipLaunchKernelGGL((k_vep3_prec<false, true, 0, true>), gpc, dim3(256), 0, s, A, eta_out, prekz);
+            }
+            JRX_LAUNCH_CHECK(h);
+            A.f.eta = eta_out;
+            JRX_TRY(launch_vep3_stress(h, s, A, p, false, 1, true));       // edge pass: the relaxed η, the OLD normal stresses
+            A.f.txx = A.cnew[0]; A.f.tyy = A.cnew[1]; A.f.tzz = A.cnew[2];
+            A.cnew[0] = A.cnew[1] = A.cnew[2] = nullptr;
+            G.txx = A.f.txx; G.tyy = A.f.tyy; G.tzz = A.f.tzz;
+            G.eta = G.K = G.G = A.f.eta;
+            h->stat_vep3_fused++;
+        } else {
         if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<true, true, PRE_KZ>), gpre, dim3(256), 0, s, A);
         else if (prekz == 16) hipLaunchKernelGGL((k_vep3_pre<true, false, 16>), dim3(gpre.x, (unsigned)((nz + 1 + 15) / 16)), dim3(256), 0, s, A);
         else if (prekz == 32) hipLaunchKernelGGL((k_vep3_pre<true, false, 32>), dim3(gpre.x, (unsigned)((nz + 1 + 31) / 32)), dim3(256), 0, s, A);
@@ -1210,6 +1466,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             A.cnew[0] = A.cnew[1] = A.cnew[2] = nullptr;
             G.txx = A.f.txx; G.tyy = A.f.tyy; G.tzz = A.f.tzz;
         } else JRX_TRY(launch_vep3_stress(h, s, A, p, false, 0, true));
+        }
         // the new edge stresses become the current ones: swap the pointers instead of copying three arrays back
         { double *t0_ = A.f.tyz; A.f.tyz = A.tnew[0]; A.tnew[0] = t0_; }
         { double *t1_ = A.f.txz; A.f.txz = A.tnew[1]; A.tnew[1] = t1_; }
@@ -1218,7 +1475,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         JRX_TRY(jrx3d_velocity_sweep(h, s, &G, A.etatau, &q, diag_));
         if (diag_) JRX_TRY(jrx3d_scaleU(h, s, &G, &q));
         // flow_bcs!: on V, or -- DisplacementBoundaryConditions -- on U = V dt, which the next iteration overwrites (only observable when U is)
-        if (!ubc && !diag_ && bcs_ordered && p->periodic == 0) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
+        if (!ubc && !diag_ && !ordered_ && bcs_ordered && p->periodic == 0) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
         else if (!ubc) { JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic)); bcs_ordered = true; }
         else if (diag_) JRX_TRY(jrx3d_bcs(h, s, f->Ux, f->Uy, f->Uz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
         return JRX_OK;
@@ -1232,7 +1489,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         if (graphs && iter >= 2 && bcs_ordered) {
             int64_t nxt = ((iter / p->nout) + 1) * p->nout;         // observed iterations: the multiples of nout and iteration iterMax + 1
             if (nxt > p->iterMax + 1) nxt = p->iterMax + 1;
-            int64_t run = nxt - 1 - iter;
+            int64_t run = nxt - 2 - iter;                           // (the iteration before an observed one runs its boundary conditions in the reference's pass order: not part of a replay)
             if (run >= GIT) {
                 const int par = a.f.tyz == f->tyz ? 0 : 1;
                 if (!gexec[par]) {
@@ -1260,6 +1517,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         const bool check = (it1 % p->nout == 0) && it1 > 1;
         const bool diag = check || !keep_going(it1);      // R and U are only observable after such an iteration
         a.obs = diag || h->vep_store_all;
+        const bool pre_diag = ((it1 + 1) % p->nout == 0) || it1 + 1 > p->iterMax;       // the next iteration, if there is one, is observed
         if (comm) {
             // Hidden communication.  The reference hides update_halo!(V) behind compute_V! (@hide_communication, Stokes3D.jl:582-597);
             // its other two exchanges of the iteration block.  Here all three run on the halo stream beside kernels that do not depend on them:
@@ -1309,7 +1567,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             JRX_TRY(launch_vep3_stress(h, s, a, p, false, 2, true));     // centre pass, beside the exchange
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[4], 0));
             int bc_kind = 3;
-            if (!ubc && !diag && bcs_ordered && p->periodic == 0) bc_kind = 1;
+            if (!ubc && !diag && !pre_diag && bcs_ordered && p->periodic == 0) bc_kind = 1;
             else if (!ubc) { bc_kind = 0; bcs_ordered = true; }
             else if (diag) bc_kind = 2;
             if (hide) JRX_TRY(jrx3d_velocity_hidden(h, &g, a.etatau, &q, diag, bc_kind));      // joins the two streams
@@ -1324,7 +1582,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                 JRX_TRY(jrx_halo_exchange(h, s, 3, arrs, ext, nn));       // update_halo!(@velocity(stokes)...) (Stokes3D.jl:596)
             }
             a.etatau = a.etatau == etatau ? etatau_next : etatau;
-        } else JRX_TRY(enqueue_iteration(a, g, diag));
+        } else JRX_TRY(enqueue_iteration(a, g, diag, pre_diag));
         iter = it1;
         if (check) {
             JRX_TRY(jrx3d_sumsq(h, s, &g, &q));
@@ -1352,6 +1610,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                        err, err / err_it1, nRx, nRy, nRz, nDV);
             if (std::isnan(err)) {
                 // error("NaN(s)"): the current edge stresses may live in the second set -- leave them in the caller's arrays, drain the stream
+                if (a.f.eta != f->eta) (void)hipMemcpyAsync(f->eta, a.f.eta, n * sizeof(double), hipMemcpyDeviceToDevice, s);
                 if (a.f.txx != f->txx) {
                     (void)hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s);
                     (void)hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s);
@@ -1373,7 +1632,11 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         }
     }
     JRX_HIP(h, hipEventRecord(t1, s));
-    if (a.f.txx != f->txx) {       // the same for the normal stresses of the forked centre pass
+    if (a.f.eta != f->eta) {       // the relaxed η of the fused pre / centre kernel
+        JRX_HIP(h, hipMemcpyAsync(f->eta, a.f.eta, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        a.f.eta = f->eta; g.eta = g.K = g.G = f->eta;
+    }
+    if (a.f.txx != f->txx) {       // the same for the normal stresses of the fused / forked centre pass
         JRX_HIP(h, hipMemcpyAsync(f->txx, a.f.txx, n * sizeof(double), hipMemcpyDeviceToDevice, s));
         JRX_HIP(h, hipMemcpyAsync(f->tyy, a.f.tyy, n * sizeof(double), hipMemcpyDeviceToDevice, s));
         JRX_HIP(h, hipMemcpyAsync(f->tzz, a.f.tzz, n * sizeof(double), hipMemcpyDeviceToDevice, s));

@@ -276,3 +276,38 @@ def test_epilogue_operators_3d(jr, oracle):
     L.orc_compute_vorticity3d(*[dp(x) for x in w], dp(a["Vx"]), dp(a["Vy"]), dp(a["Vz"]), *n, *[C.c_double(d) for d in _di])
     for x, k in zip(w, ("yz", "xz", "xy")):
         assert np.array_equal(jr.to_numpy(getattr(stokes.ω, k)), x), k
+
+
+@pytest.mark.parametrize("ni,iters,nout,prekz", [((20, 12, 10), 7, 3, 0), ((20, 12, 10), 40, 10, 0), ((13, 9, 7), 5, 2, 1), ((70, 5, 6), 6, 5, 4), ((64, 64, 17), 4, 2, 8),
+                                                   ((63, 31, 16), 5, 4, 16), ((127, 66, 40), 6, 3, 8), ((127, 66, 40), 5, 10 ** 9, 32), ((96, 80, 72), 35, 17, 0)])
+def test_vep3d_fused_pre_centre_equals_the_three_kernels(jr, ni, iters, nout, prekz):
+    """k_vep3_prec (pre + viscosity relaxation + centre pass in one kernel ahead of the edge pass, second sets of η and τxx/τyy/τzz adopted by pointer swap; the default without
+    neighbours) against the three kernels with the centre pass behind the edge pass: every field of the solve bit for bit -- odd and even iteration counts (the copy-back of the
+    second sets), observed and unobserved iterations (the output-only arrays), chunk depths that cut the column at every place, a run long enough for the captured graphs"""
+    from justrelax_jl_amd import _lib
+    h = _lib.default_handle()
+    outs, res = [], []
+    try:
+        for fuse in (0, 1):
+            h.set_option("vep3_fuse_pc", fuse)
+            h.set_option("vep3_prekz", prekz)
+            s = jr.miniapps.shearband3d(ni, iterMax=iters - 1, nout=nout)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+            rng = np.random.default_rng(3)
+            for c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):     # pre-stress close to yield so that plasticity is active
+                s.arrays["to" + c][...] = rng.uniform(-1.5, 1.5, size=s.arrays["to" + c].shape)
+                s.arrays["t" + c][...] = s.arrays["to" + c]
+            stokes, pr, ρg = _upload(jr, s)
+            n0 = h.get_option("stat_vep3_fused")
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=s.kwargs)
+            assert r.iter == iters
+            assert (h.get_option("stat_vep3_fused") > n0) == bool(fuse)
+            outs.append(_download(jr, stokes))
+            res.append(r)
+    finally:
+        h.set_option("vep3_fuse_pc", 1)
+        h.set_option("vep3_prekz", 0)
+    assert (outs[0]["eplxx"] != 0).any() or iters < 5
+    assert np.array_equal(np.asarray(res[0].err_evo1), np.asarray(res[1].err_evo1))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
