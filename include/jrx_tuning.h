@@ -17,6 +17,8 @@
  *   "b_width_x/y/z" (0)           > 0 overrides jrx_stokes3d_params.b_width of the split sweeps
  *   "fused2d" (1)                 2D visco-elastic loop: one-launch iterations on launch-bound grids
  *   "vep3_edges" (4)              3D VEP edge pass: 4 = z-marching kernel, the three family waves of a row share the centre and shear operands through LDS;
+ *                                 6 = the same with a fourth wave per workgroup that loads and publishes every operand (phase ratios and λv included) one plane step ahead of the
+ *                                 family waves, which then have no load of their own (bit-identical; measured equal to 4, profiles/r04_vep3d_fused_pre_centre.txt);
  *                                 3 = centre operands only; 1 = no LDS, one family per block; 2 = one launch per family; 0 = one node per thread
  *   "vep3_cfg", "vep3_peel", "vep3_peel_fork", "vep3_map", "vep3_xcd"     z-marching edge kernel: chunk depth / occupancy, peeling of a thin last segment, thread map, XCD slabs
  *   "vep3_nt" (0), "vep3_prekz" (0)   3D VEP: non-temporal stores of the edge pass; planes per thread of the z-marching pre kernel (0 = chosen by the grid size; 1, 2, 4, 8, 16, 32)

@@ -113,13 +113,22 @@ __device__ __forceinline__ void plastic_grad3(const jrx_rheology &rh, const doub
     dQdP = 0.0; dFdP = 0.0;
     const double tII = sinv3(t);
     const int np = NP > 0 ? NP : rh.nphase;
+    // ∂Q/∂τ of a Drucker-Prager phase does not depend on the phase: one division per component instead of one per component and phase (the same quotient, so the same bits)
+    bool any_pl = false;
+#pragma unroll
+    for (int q = 0; q < np; q++) any_pl |= rh.is_pl[q] != 0;
+    double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (any_pl) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) g[s] = 0.5 * t[s] / tII;
+#pragma unroll
+        for (int s = 3; s < 6; s++) g[s] = 0.5 * (t[s] / tII);
+    }
 #pragma unroll
     for (int q = 0; q < np; q++) {
         if (r[q] == 0.0 || !rh.is_pl[q]) continue;
 #pragma unroll
-        for (int s = 0; s < 3; s++) dQdt[s] = fma(r[q], 0.5 * t[s] / tII, dQdt[s]);
-#pragma unroll
-        for (int s = 3; s < 6; s++) dQdt[s] = fma(r[q], 0.5 * (t[s] / tII), dQdt[s]);
+        for (int s = 0; s < 6; s++) dQdt[s] = fma(r[q], g[s], dQdt[s]);
         dQdP = fma(r[q], -rh.sinpsi[q], dQdP);
         dFdP = fma(r[q], -rh.sinphi[q], dFdP);
     }
@@ -312,9 +321,10 @@ __device__ __forceinline__ EdgeMat edge_mat(const Vep3Args &a, const double *rv)
     m.Kv = ratio_avg3(a.rh.Kb, rv, np);
     return m;
 }
-template <int T, bool SOFT, int NP = 0>
+// PRE: lam_pre is λv of the node, fetched by the caller ahead of the return mapping
+template <int T, bool SOFT, int NP = 0, bool PRE = false>
 __device__ __forceinline__ void vep3_edge_plastic(const Vep3Args &a, i64 v, const double *rv, const EdgeMat &m, const double tt[6], double tij_own, double d_own,
-                                                  double etav, double Pv, double dtr, double EIIv)
+                                                  double etav, double Pv, double dtr, double EIIv, double lam_pre = 0.0)
 {
     double *const eplsh[3] = {a.f.eplyz, a.f.eplxz, a.f.eplxy};
     const double tIIv = sinv3(tt);
@@ -324,7 +334,7 @@ __device__ __forceinline__ void vep3_edge_plastic(const Vep3Args &a, i64 v, cons
     const double F = yield_F3<SOFT, NP>(a.rh, rv, Pv, tIIv, SOFT ? EIIv : 0.0);
     constexpr int own = 3 + T;
     if (m.is_pl && tIIv != 0.0 && F > 0) {
-        const double l = (1.0 - a.rel) * a.lamv[T][v] + a.rel * (fmax(F, 0.0) / (etav * dtr + m.eta_reg + vol));
+        const double l = (1.0 - a.rel) * (PRE ? lam_pre : a.lamv[T][v]) + a.rel * (fmax(F, 0.0) / (etav * dtr + m.eta_reg + vol));
         a.lamv[T][v] = l;
         const double epl = l * dQdt[own];
         VST(a, a.tnew[T][v], tij_own + fma(-(2.0 * etav * epl), dtr, d_own));
@@ -491,7 +501,10 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a, const int 
 // arrays s with s % 3 == f (rows j-1 and j of its own column), all three read the 2 x NC values back after a barrier (two buffers, one barrier per plane) --
 // 8 instead of 22 centre loads per wave and plane, and every centre line is fetched exactly once per tile whatever the dispatcher does with the blocks.
 // sh: [2][12][2][64] doubles of the workgroup; fidx: this wave's index 0..2 among the loaders.
-template <int KZ, int NP, int FAM, bool SOFT = false, bool LDSC = false, bool LDSS = false>
+// PROD (with LDSC and LDSS): 1 = a fourth wave of the workgroup publishes ALL operands of a plane step and the family waves only read them back; 2 = that fourth wave (FAM = 0: no family of
+// its own).  Same barrier sequence as before -- publish, barrier, read back -- but the publishing wave has nothing else to do and so requests the operands of step t + 1 while the family waves
+// are still in the arithmetic of step t: the memory latency the family waves used to sit out at the top of every plane is hidden by construction instead of by occupancy.
+template <int KZ, int NP, int FAM, bool SOFT = false, bool LDSC = false, bool LDSS = false, int PROD = 0>
 __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int seg, const int j, const int zchunk, const int ilim, double *sh = nullptr, const int fidx = 0)
 {
     constexpr int NC = SOFT ? 12 : 11;          // centre arrays averaged to the edges; softening laws add EII_pl (StressKernels.jl:710,783,854)
@@ -504,8 +517,15 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
     const int ic = clampi3(i, 0, nx - 1), ir = clampi3(i, 0, nx);
     const int cj0 = clampi3(j - 1, 0, ny - 1), cj1 = clampi3(j, 0, ny - 1), cj2 = clampi3(j + 1, 0, ny - 1);
     const bool lo_i = i >= 1, hi_i = i < nx - 1;
-    auto up = [&](double v) { const double u = __shfl_up(v, 1, 64); return lo_i ? u : v; };      // value at clamp(i - 1)
-    auto dn = [&](double v) { const double u = __shfl_down(v, 1, 64); return hi_i ? u : v; };    // value at clamp(i + 1)
+    // value at clamp(i - 1) / clamp(i + 1): the neighbouring lane's, or the own one on the domain's faces and at the ends of the wave -- the clamp goes into the permute address
+    // (as a select behind __shfl_up / __shfl_down it was two v_cndmask per double: 56 of the ~430 VALU instructions of a plane step)
+    const int a_up = 4 * ((lo_i && lane > 0) ? lane - 1 : lane), a_dn = 4 * ((hi_i && lane < 63) ? lane + 1 : lane);
+    auto perm = [&](int addr, double v) {
+        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+        return __hiloint2double(hi, lo);
+    };
+    auto up = [&](double v) { return perm(a_up, v); };
+    auto dn = [&](double v) { return perm(a_dn, v); };
     // centre arrays in the order they are consumed: 1/η, θ, then the (ε, τ, τ_o) triple of each normal component
     const double *const cen[12] = {a.f.eta, a.theta, a.f.exx, a.f.txx, a.f.toxx, a.f.eyy, a.f.tyy, a.f.toyy, a.f.ezz, a.f.tzz, a.f.tozz, a.f.EII_pl};
     const double *const Yp[3] = {a.f.eyz, a.f.tyz, a.f.toyz}, *const Xp[3] = {a.f.exz, a.f.txz, a.f.toxz}, *const Zp[3] = {a.f.exy, a.f.txy, a.f.toxy};
@@ -521,27 +541,64 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
     const bool act0 = useful && i < nx, act1 = useful && j < ny;             // yz / xz edge exists at this (i, j); xy: useful && k < nz
     double pyz[NC], pxz[NC], Yn[3][2], Xn[3][2], Zc[3][2];
     // LDSC: publish the (row j-1, row j) values of the arrays this wave loads for plane kp into buffer b; everybody reads them back after the barrier
-    auto publish = [&](u32 kp, int b) {
+    // (every load of a publication is requested before the first LDS write: left to the scheduler, which sinks each load to its use, a publication becomes a chain of
+    // load - wait - write round trips -- profiles/r04_vep3d_fused_pre_centre.txt)
+    double *const shs = sh + 2 * NC * 2 * 64;
+    // kp: plane of the centre operands; ky / kz (LDSS): planes of the yz, xz / xy shear operands of the plane step
+    // kn >= 0 (publishing wave only): also the phase ratios and λv of the three families' nodes of plane kn -- the family waves then have no load left that the arithmetic of a
+    // plane waits for (the ratios were requested behind the barrier and used ~100 instructions later, λv inside the yielding branch: two exposed memory round trips per plane)
+    double *const shm = shs + 2 * 18 * 64;        // [2][3 * NP + 3][64]
+    constexpr int NM = 3 * NP + 3;
+    auto publish = [&](u32 kp, u32 ky, u32 kz, int b, int kn = -1) {
+        double v0[NC], v1[NC], w[18], pm[NM];
+        if constexpr (PROD == 2) {
+            if (kn >= 0) {
+                const bool ac[3] = {act0, act1, useful && kn < nz};
+                const i64 vn[3] = {i + (i64)nx * (j + (i64)(ny + 1) * kn), i + (i64)(nx + 1) * (j + (i64)ny * kn), i + (i64)(nx + 1) * (j + (i64)(ny + 1) * kn)};
+                const double *const phs[3] = {a.f.phase_yz, a.f.phase_xz, a.f.phase_xy};
+#pragma unroll
+                for (int T = 0; T < 3; T++) {
+#pragma unroll
+                    for (int q = 0; q < NP; q++) pm[T * NP + q] = phs[T][ac[T] ? NP * vn[T] + q : 0];
+                    pm[3 * NP + T] = a.lamv[T][ac[T] ? vn[T] : 0];
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NC; s++) {
-            if (s % 3 != fidx) continue;
-            double v0 = LB(cen[s], oc0 + pc * kp), v1 = LB(cen[s], oc1 + pc * kp);
-            if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
-            sh[((b * NC + s) * 2 + 0) * 64 + lane] = v0;
-            sh[((b * NC + s) * 2 + 1) * 64 + lane] = v1;
+            if (PROD == 1 || (PROD == 0 && s % 3 != fidx)) continue;
+            v0[s] = LB(cen[s], oc0 + pc * kp); v1[s] = LB(cen[s], oc1 + pc * kp);
         }
-    };
-    // ... and the 18 shear operands of a plane step (rows of the yz / xz components at plane ky, of the xy components at plane kz), same partition
-    double *const shs = sh + 2 * NC * 2 * 64;
-    auto publish_shear = [&](u32 ky, u32 kz, int b) {
+        if constexpr (LDSS) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            if ((6 * q + 0) % 3 == fidx) shs[(b * 18 + 6 * q + 0) * 64 + lane] = LB(Yp[q], oy1 + py * ky);
-            if ((6 * q + 1) % 3 == fidx) shs[(b * 18 + 6 * q + 1) * 64 + lane] = LB(Yp[q], oy2 + py * ky);
-            if ((6 * q + 2) % 3 == fidx) shs[(b * 18 + 6 * q + 2) * 64 + lane] = LB(Xp[q], ox0 + px * ky);
-            if ((6 * q + 3) % 3 == fidx) shs[(b * 18 + 6 * q + 3) * 64 + lane] = LB(Xp[q], ox1 + px * ky);
-            if ((6 * q + 4) % 3 == fidx) shs[(b * 18 + 6 * q + 4) * 64 + lane] = LB(Zp[q], oz1 + pz * kz);
-            if ((6 * q + 5) % 3 == fidx) shs[(b * 18 + 6 * q + 5) * 64 + lane] = LB(Zp[q], oz2 + pz * kz);
+            for (int q = 0; q < 3; q++) {
+                if (PROD == 1) continue;
+                if (PROD == 2 || (6 * q + 0) % 3 == fidx) w[6 * q + 0] = LB(Yp[q], oy1 + py * ky);
+                if (PROD == 2 || (6 * q + 1) % 3 == fidx) w[6 * q + 1] = LB(Yp[q], oy2 + py * ky);
+                if (PROD == 2 || (6 * q + 2) % 3 == fidx) w[6 * q + 2] = LB(Xp[q], ox0 + px * ky);
+                if (PROD == 2 || (6 * q + 3) % 3 == fidx) w[6 * q + 3] = LB(Xp[q], ox1 + px * ky);
+                if (PROD == 2 || (6 * q + 4) % 3 == fidx) w[6 * q + 4] = LB(Zp[q], oz1 + pz * kz);
+                if (PROD == 2 || (6 * q + 5) % 3 == fidx) w[6 * q + 5] = LB(Zp[q], oz2 + pz * kz);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NC; s++) {
+            if (PROD == 1 || (PROD == 0 && s % 3 != fidx)) continue;
+            if (s == 0) { v0[s] = 1 / v0[s]; v1[s] = 1 / v1[s]; }
+            sh[((b * NC + s) * 2 + 0) * 64 + lane] = v0[s];
+            sh[((b * NC + s) * 2 + 1) * 64 + lane] = v1[s];
+        }
+        if constexpr (LDSS) {
+#pragma unroll
+            for (int r = 0; r < 18; r++)
+                if (PROD == 2 || (PROD == 0 && r % 3 == fidx)) shs[(b * 18 + r) * 64 + lane] = w[r];
+        }
+        if constexpr (PROD == 2) {
+            if (kn >= 0) {
+#pragma unroll
+                for (int r = 0; r < NM; r++) shm[(b * NM + r) * 64 + lane] = pm[r];
+            }
         }
     };
     auto read_shear = [&](int b) {
@@ -554,16 +611,28 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
     };
     {
         const u32 kc = (u32)clampi3(kb - 1, 0, nz - 1);
-        if constexpr (LDSC) { publish(kc, 0); if constexpr (LDSS) publish_shear((u32)clampi3(kb, 0, nz - 1), kc, 0); __syncthreads(); }
+        if constexpr (LDSC) { publish(kc, (u32)clampi3(kb, 0, nz - 1), kc, 0); __syncthreads(); }
+        if constexpr (PROD == 2) {      // the publishing wave: one publication and one barrier per plane, in step with the family waves
+#pragma unroll 1
+            for (int k = kb; k < ke; k++) {
+                const u32 k1 = (u32)clampi3(k, 0, nz - 1), k2 = (u32)clampi3(k + 1, 0, nz - 1);
+                const int bsel = (k - kb + 1) & 1;
+                publish(k1, k2, k1, bsel, k);
+                __syncthreads();
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < NC; s++) {
-            double v0, v1;
-            if constexpr (LDSC) { v0 = sh[((0 * NC + s) * 2 + 0) * 64 + lane]; v1 = sh[((0 * NC + s) * 2 + 1) * 64 + lane]; }
-            else {
+            double v0, v1, u1;
+            if constexpr (LDSC) {     // (the left neighbour's value straight from the workgroup's slot: one LDS read instead of two lane permutes)
+                v0 = sh[((0 * NC + s) * 2 + 0) * 64 + lane]; v1 = sh[((0 * NC + s) * 2 + 1) * 64 + lane];
+                u1 = sh[((0 * NC + s) * 2 + 1) * 64 + (a_up >> 2)];
+            } else {
                 v0 = LB(cen[s], oc0 + pc * kc); v1 = LB(cen[s], oc1 + pc * kc);
                 if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
+                u1 = up(v1);
             }
-            const double u1 = up(v1);
             pyz[s] = v0 + v1;
             pxz[s] = u1 + v1;
         }
@@ -583,18 +652,29 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
         const u32 k1 = (u32)clampi3(k, 0, nz - 1), k2 = (u32)clampi3(k + 1, 0, nz - 1);
         const bool act2 = useful && k < nz;
         const i64 vi[3] = {i + (i64)nx * (j + (i64)(ny + 1) * k), i + (i64)(nx + 1) * (j + (i64)ny * k), i + (i64)(nx + 1) * (j + (i64)(ny + 1) * k)};
-        const double *const rv[3] = {a.f.phase_yz + (act0 ? np * vi[0] : 0), a.f.phase_xz + (act1 ? np * vi[1] : 0), a.f.phase_xy + (act2 ? np * vi[2] : 0)};
+        double rvl[PROD == 1 ? NP : 1];          // PROD == 1: the own family's phase ratios, from the publishing wave's slots (read behind the barrier below)
+        const double *const rv[3] = {PROD == 1 ? rvl : a.f.phase_yz + (act0 ? np * vi[0] : 0), PROD == 1 ? rvl : a.f.phase_xz + (act1 ? np * vi[1] : 0),
+                                     PROD == 1 ? rvl : a.f.phase_xy + (act2 ? np * vi[2] : 0)};
         // the four cells of array s around the node, in plane clamp(k): sums of the three families, then the carried partial sums of the next plane
         const int bsel = (k - kb + 1) & 1;            // the prologue used buffer 0
-        if constexpr (LDSC) { publish(k1, bsel); if constexpr (LDSS) publish_shear(k2, k1, bsel); __syncthreads(); }
+        if constexpr (LDSC) { publish(k1, k2, k1, bsel); __syncthreads(); }
+        double lam_pre = 0.0;
+        if constexpr (PROD == 1) {
+            constexpr int TF = FAM == 1 ? 0 : (FAM == 2 ? 1 : 2);
+#pragma unroll
+            for (int q = 0; q < NP; q++) rvl[q] = shm[(bsel * NM + TF * NP + q) * 64 + lane];
+            lam_pre = shm[(bsel * NM + 3 * NP + TF) * 64 + lane];
+        }
         auto sums = [&](int s, double S[3]) {
-            double v0, v1;
-            if constexpr (LDSC) { v0 = sh[((bsel * NC + s) * 2 + 0) * 64 + lane]; v1 = sh[((bsel * NC + s) * 2 + 1) * 64 + lane]; }
-            else {
+            double v0, v1, u0, u1;
+            if constexpr (LDSC) {
+                v0 = sh[((bsel * NC + s) * 2 + 0) * 64 + lane]; v1 = sh[((bsel * NC + s) * 2 + 1) * 64 + lane];
+                u0 = sh[((bsel * NC + s) * 2 + 0) * 64 + (a_up >> 2)]; u1 = sh[((bsel * NC + s) * 2 + 1) * 64 + (a_up >> 2)];
+            } else {
                 v0 = LB(cen[s], oc0 + pc * k1); v1 = LB(cen[s], oc1 + pc * k1);
                 if (s == 0) { v0 = 1 / v0; v1 = 1 / v1; }
+                u0 = up(v0); u1 = up(v1);
             }
-            const double u0 = up(v0), u1 = up(v1);
             S[0] = (pyz[s] + v0) + v1;
             S[1] = (pxz[s] + u1) + v1;
             S[2] = ((u0 + v0) + u1) + v1;
@@ -683,9 +763,9 @@ __device__ __forceinline__ void vep3_edges_z_tile(const Vep3Args &a, const int s
             own_d[2] = dev_stress_inc(own[1], own[2], etav[2], own[0], m[2]._Gdt, dtr[2]);
             tt[2][3] = trial(2, oy); tt[2][4] = trial(2, ox); tt[2][5] = own_t[2] + own_d[2];
         }
-        if constexpr ((FAM & 1) != 0) if (act0) vep3_edge_plastic<0, SOFT, NP>(a, vi[0], rv[0], m[0], tt[0], own_t[0], own_d[0], etav[0], Pv[0], dtr[0], EIIv[0]);
-        if constexpr ((FAM & 2) != 0) if (act1) vep3_edge_plastic<1, SOFT, NP>(a, vi[1], rv[1], m[1], tt[1], own_t[1], own_d[1], etav[1], Pv[1], dtr[1], EIIv[1]);
-        if constexpr ((FAM & 4) != 0) if (act2) vep3_edge_plastic<2, SOFT, NP>(a, vi[2], rv[2], m[2], tt[2], own_t[2], own_d[2], etav[2], Pv[2], dtr[2], EIIv[2]);
+        if constexpr ((FAM & 1) != 0) if (act0) vep3_edge_plastic<0, SOFT, NP, PROD == 1>(a, vi[0], rv[0], m[0], tt[0], own_t[0], own_d[0], etav[0], Pv[0], dtr[0], EIIv[0], lam_pre);
+        if constexpr ((FAM & 2) != 0) if (act1) vep3_edge_plastic<1, SOFT, NP, PROD == 1>(a, vi[1], rv[1], m[1], tt[1], own_t[1], own_d[1], etav[1], Pv[1], dtr[1], EIIv[1], lam_pre);
+        if constexpr ((FAM & 4) != 0) if (act2) vep3_edge_plastic<2, SOFT, NP, PROD == 1>(a, vi[2], rv[2], m[2], tt[2], own_t[2], own_d[2], etav[2], Pv[2], dtr[2], EIIv[2], lam_pre);
     }
 }
 #undef LB
@@ -727,6 +807,23 @@ __global__ __launch_bounds__(192, SOFT ? 2 : 3) void k_vep3_edges_zl(const Vep3A
     if (fam == 0) vep3_edges_z_tile<KZ, NP, 1, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 0);
     else if (fam == 1) vep3_edges_z_tile<KZ, NP, 2, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 1);
     else vep3_edges_z_tile<KZ, NP, 4, SOFT, true, LDSS>(a, txy % nseg, j, zc, ilim, sh, 2);
+}
+// The form with a publishing wave (see PROD above): a workgroup = the three family waves + the wave that loads for them; tiles as in k_vep3_edges_zl.
+template <int KZ, int NP>
+__global__ __launch_bounds__(256, 3) void k_vep3_edges_zp(const Vep3Args a, int nseg, int ntile_xy, int ntiles, int ilim)
+{
+    __shared__ double sh[2 * 11 * 2 * 64 + 2 * 18 * 64 + 2 * (3 * NP + 3) * 64];       // NP = 2: 50 KB, three workgroups per CU
+    const unsigned L = blockIdx.x, xcd = L & 7u, q = L >> 3;
+    const unsigned per = ((unsigned)ntiles + 7u) / 8u;
+    const unsigned t = xcd * per + q;
+    if (q >= per || t >= (unsigned)ntiles) return;                  // whole workgroups
+    const int txy = (int)(t % (unsigned)ntile_xy), zc = (int)(t / (unsigned)ntile_xy);
+    const int role = (int)(threadIdx.x >> 6), j = txy / nseg;
+    // four instantiations, one barrier sequence (see k_vep3_edges_zl)
+    if (role == 0) vep3_edges_z_tile<KZ, NP, 1, false, true, true, 1>(a, txy % nseg, j, zc, ilim, sh, 0);
+    else if (role == 1) vep3_edges_z_tile<KZ, NP, 2, false, true, true, 1>(a, txy % nseg, j, zc, ilim, sh, 1);
+    else if (role == 2) vep3_edges_z_tile<KZ, NP, 4, false, true, true, 1>(a, txy % nseg, j, zc, ilim, sh, 2);
+    else vep3_edges_z_tile<KZ, NP, 0, false, true, true, 2>(a, txy % nseg, j, zc, ilim, sh, 3);
 }
 // update_stresses_center_vertex_ps! 3D -- centres (StressKernels.jl:906-985; cache_tensors StressUpdate.jl:269-301)
 // NP > 0: the number of phases as a compile-time constant -- the cell's phase ratios are loaded once, in one batch, and the phase loops unroll (with a run-time count every
@@ -1184,6 +1281,12 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
 #define EZS(NP_) if (kz == 16 && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zf<16, NP_, 2, true>), gf, dim3(256), 0, s, a, nseg, ntxy, nt, ilim); ok = true; }
             EZS(1) EZS(2) EZS(3) EZS(4)
 #undef EZS
+        } else if (edges == 6) {
+            const int ntxy_l = nseg * (ny + 1), nt_l = ntxy_l * nzc;
+            const dim3 gl((unsigned)(((nt_l + 7) / 8) * 8));
+#define EZP(KZ_, NP_) if (kz == KZ_ && np_ == NP_) { hipLaunchKernelGGL((k_vep3_edges_zp<KZ_, NP_>), gl, dim3(256), 0, s, a, nseg, ntxy_l, nt_l, ilim); ok = true; }
+            EZP(16, 1) EZP(16, 2) EZP(16, 3) EZP(16, 4)
+#undef EZP
         } else if (edges == 3 || edges == 4) {
             const int ntxy_l = nseg * (ny + 1), nt_l = ntxy_l * nzc;
             const dim3 gl((unsigned)(((nt_l + 7) / 8) * 8));

@@ -214,7 +214,7 @@ def test_vep3d_edge_kernel_forms_agree_at_full_size(jr, ni):
     h = _lib.default_handle()
     outs = []
     try:
-        for edges in (0, 1, 3, 4):
+        for edges in (0, 1, 3, 4, 6):
             h.call("jrx_tuning_set", C.c_char_p(b"vep3_edges"), C.c_int64(edges))
             s, st, pr, ρg = _build_vep3(jr, ni)
             r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=dict(iterMax=2, nout=10 ** 9, verbose=False))
@@ -233,4 +233,5 @@ def test_vep3d_edge_kernel_forms_agree_at_full_size(jr, ni):
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
         assert torch.equal(outs[0][k], outs[2][k]), k          # 3: the family waves of a row share the centre operands through LDS
-        assert torch.equal(outs[0][k], outs[3][k]), k          # 4: ... and the shear operands (the default form)
+        assert torch.equal(outs[0][k], outs[3][k]), k          # 4: ... and the shear operands
+        assert torch.equal(outs[0][k], outs[4][k]), k          # 6: ... published by a fourth wave that runs one plane step ahead of the family waves

@@ -70,7 +70,8 @@ def _randomize(s, seed=4, Kb=3.0, psi=6.0):
 @pytest.mark.parametrize("edges,ni", [(0, (13, 9, 7)), (0, (70, 5, 6)), (1, (13, 9, 7)), (1, (70, 5, 6)), (1, (125, 6, 18)), (1, (61, 7, 33)),
                                       (1, (62, 4, 16)), (1, (3, 3, 3)), (2, (70, 5, 6)), (2, (13, 9, 7)),
                                       (3, (13, 9, 7)), (3, (70, 5, 6)), (3, (125, 6, 18)), (3, (61, 7, 33)), (3, (62, 4, 16)), (3, (3, 3, 3)),
-                                      (4, (13, 9, 7)), (4, (70, 5, 6)), (4, (125, 6, 18)), (4, (61, 7, 33)), (4, (62, 4, 16)), (4, (3, 3, 3))])
+                                      (4, (13, 9, 7)), (4, (70, 5, 6)), (4, (125, 6, 18)), (4, (61, 7, 33)), (4, (62, 4, 16)), (4, (3, 3, 3)),
+                                      (6, (13, 9, 7)), (6, (70, 5, 6)), (6, (125, 6, 18)), (6, (61, 7, 33)), (6, (62, 4, 16)), (6, (3, 3, 3))])
 def test_update_stresses_3d_matches_oracle(jr, oracle, edges, ni):
     """update_stresses_center_vertex_ps! 3D (StressKernels.jl:671-989) on random states: yielding and elastic nodes, mixed
     phase ratios, dilatant plasticity with finite bulk modulus.  edges = 1: the z-marching edge kernel, one family per block (grids spanning one, two and three
