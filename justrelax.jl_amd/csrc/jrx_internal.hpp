@@ -65,6 +65,7 @@ struct jrx_handle {
     int vep3_hide_comm = 1;                  // multi-rank 3D VEP driver: 2 = the three exchanges of an iteration on the halo stream beside independent kernels; 1 (default) = ητ and the
                                              // edge stresses only, update_halo!(V) behind the whole velocity sweep; 0 = serial.  Two 256^3 blocks on one device (profiles/r04_bench_default.json): +12.2 % (2),
                                              // +8.6 % (1), +9.6 % (0) -- the six slab launches of (2) cost more than they hide until a real link shows otherwise
+    bool thermal_np_const = true;            // phase-ratio form of the 3D heat-diffusion kernels: instantiations with the phase count as a constant (1..4)
     bool vep3_np_const = true;               // 3D VEP centre pass (and the fused pre / centre kernel): instantiations with the phase count as a constant (1..4): ratios loaded in one batch, phase loops unrolled
     bool vep3_fuse_pc = true;                // 3D VEP driver without neighbours, linear laws: k_vep3_pre + k_vep3_visc + k_vep3_centre as one kernel ahead of the edge pass (k_vep3_prec; second sets of η and τxx, τyy, τzz)
     bool vep3_fork = false;                  // 3D VEP driver without neighbours: the centre pass of the stress update on the halo stream beside the edge pass (second set of τxx, τyy, τzz).

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a, const PHT ph)
         else {
             const int l = clampi(i - 1, 0, nx - 1), r = clampi(i, 0, nx - 1);
             double K;
-            if constexpr (PH) K = (tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (l + (i64)(nx + 1) * (j + (i64)ny * k))) +
-                                   tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (r + (i64)(nx + 1) * (j + (i64)ny * k)))) * 0.5;
+            if constexpr (PH) K = (tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qx + tph_nph(ph) * (l + (i64)(nx + 1) * (j + (i64)ny * k))) +
+                                   tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qx + tph_nph(ph) * (r + (i64)(nx + 1) * (j + (i64)ny * k)))) * 0.5;
             else K = a.p.rheology_form ? kc : (CC_(a.t.K, l, j, k) + CC_(a.t.K, r, j, k)) * 0.5;
             const double t = (CC_(th, l, j, k) + CC_(th, r, j, k)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i, j + 1, k + 1)) * a.p._dx;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a, const PHT ph)
         else {
             const int l = clampi(j - 1, 0, ny - 1), r = clampi(j, 0, ny - 1);
             double K;
-            if constexpr (PH) K = (tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * (l + (i64)(ny + 1) * k))) +
-                                   tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * (r + (i64)(ny + 1) * k)))) * 0.5;
+            if constexpr (PH) K = (tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qy + tph_nph(ph) * (i + (i64)nx * (l + (i64)(ny + 1) * k))) +
+                                   tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qy + tph_nph(ph) * (i + (i64)nx * (r + (i64)(ny + 1) * k)))) * 0.5;
             else K = a.p.rheology_form ? kc : (CC_(a.t.K, i, l, k) + CC_(a.t.K, i, r, k)) * 0.5;
             const double t = (CC_(th, i, l, k) + CC_(th, i, r, k)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i + 1, j, k + 1)) * a.p._dy;
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void k_flux3d(const T3Args a, const PHT ph)
         else {
             const int l = clampi(k - 1, 0, nz - 1), r = clampi(k, 0, nz - 1);
             double K;
-            if constexpr (PH) K = (tph_cond(ph.m, ph.f.phase_qz + ph.m.nphase * (i + (i64)nx * (j + (i64)ny * l))) +
-                                   tph_cond(ph.m, ph.f.phase_qz + ph.m.nphase * (i + (i64)nx * (j + (i64)ny * r)))) * 0.5;
+            if constexpr (PH) K = (tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qz + tph_nph(ph) * (i + (i64)nx * (j + (i64)ny * l))) +
+                                   tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qz + tph_nph(ph) * (i + (i64)nx * (j + (i64)ny * r)))) * 0.5;
             else K = a.p.rheology_form ? kc : (CC_(a.t.K, i, j, l) + CC_(a.t.K, i, j, r)) * 0.5;
             const double t = (CC_(th, i, j, l) + CC_(th, i, j, r)) * 0.5;
             const double qv = -K * (T3_(i + 1, j + 1, k + 1) - T3_(i + 1, j + 1, k)) * a.p._dz;
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a, const PHT ph)
     const double Tc = a.t.T[I1];
     double rcp, Hr = 0.0;
     if constexpr (PH) {
-        const double *rc = ph.f.phase_c + ph.m.nphase * c;
-        rcp = tph_rhoCp(ph.m, rc, Tc, ph.f.P[c]);
-        Hr = tph_Hr(ph.m, rc);
+        const double *rc = ph.f.phase_c + tph_nph(ph) * c;
+        rcp = tph_rhoCp<tph_np<PHT>::value>(ph.m, rc, Tc, ph.f.P[c]);
+        Hr = tph_Hr<tph_np<PHT>::value>(ph.m, rc);
     } else rcp = rhoCp3_of(a.p, a.t.rhoCp, c, Tc);
     const double *qx = RES ? a.t.qTx2 : a.t.qTx, *qy = RES ? a.t.qTy2 : a.t.qTy, *qz = RES ? a.t.qTz2 : a.t.qTz;
     const double divq = (qx[(i + 1) + (i64)(nx + 1) * (j + (i64)ny * k)] - qx[i + (i64)(nx + 1) * (j + (i64)ny * k)]) * a.p._dx +
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_updateT3d(const T3Args a, const PHT ph)
         if constexpr (PH) {
             if (a.wpt) {      // update_pt_thermal_arrays! of the next iteration (DiffusionPT_coefficients.jl:123-136) from the new T of this cell
                 double th_, dr_;
-                tph_pt_coeffs(ph.m, ph.f.phase_c + ph.m.nphase * c, Tn, ph.f.P[c], _dt, th_, dr_);
+                tph_pt_coeffs<tph_np<PHT>::value>(ph.m, ph.f.phase_c + tph_nph(ph) * c, Tn, ph.f.P[c], _dt, th_, dr_);
                 const_cast<double *>(a.t.thetar_dtau)[c] = th_;
                 const_cast<double *>(a.t.dtau_rho)[c] = dr_;
             }
@@ -661,6 +661,13 @@ jrx_status jrx_heatdiffusion_PT3d_phases(jrx_handle *h, const jrx_thermal3d_fiel
     q.rheology_form = 2;
     TPh x;
     x.m = *ph; x.f = *pf;
+    // option "thermal_np_const" (default): the instantiations with the phase count as a constant
+    switch (h->thermal_np_const ? ph->nphase : 0) {
+#define TPN(N_) case N_: { TPhN<N_> y; y.m = *ph; y.f = *pf; return heat3d(h, t, &q, y, iter_count, norm_ResT, cap, nnorms); }
+    TPN(1) TPN(2) TPN(3) TPN(4)
+#undef TPN
+    default: break;
+    }
     return heat3d(h, t, &q, x, iter_count, norm_ResT, cap, nnorms);
 }
 
