@@ -344,18 +344,23 @@ __device__ __forceinline__ void vep3_edge_plastic(const Vep3Args &a, i64 v, cons
         if (a.obs) VST(a, eplsh[T][v], 0.0);
     }
 }
-template <int T, bool SOFT>
+template <int T, bool SOFT, int NP = 0>
 __device__ __forceinline__ void vep3_edge_finish(const Vep3Args &a, i64 v, const double eij[6], const double tij[6], const double toij[6], double etav, double Pv,
                                                  double EIIv)
 {
     const double *const phsh[3] = {a.f.phase_yz, a.f.phase_xz, a.f.phase_xy};
-    const double *rv = phsh[T] + (i64)a.rh.nphase * v;
-    const EdgeMat m = edge_mat(a, rv);
+    double rvv[NP > 0 ? NP : 1];
+    if (NP > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) rvv[q] = phsh[T][(i64)NP * v + q];
+    }
+    const double *rv = NP > 0 ? rvv : phsh[T] + (i64)a.rh.nphase * v;
+    const EdgeMat m = edge_mat<NP>(a, rv);
     const double dtr = 1.0 / (a.theta_dtau + etav * m._Gdt + 1.0);
     double d[6], tt[6];
 #pragma unroll
     for (int s = 0; s < 6; s++) { d[s] = dev_stress_inc(tij[s], toij[s], etav, eij[s], m._Gdt, dtr); tt[s] = tij[s] + d[s]; }
-    vep3_edge_plastic<T, SOFT>(a, v, rv, m, tt, tij[3 + T], d[3 + T], etav, Pv, dtr, EIIv);
+    vep3_edge_plastic<T, SOFT, NP>(a, v, rv, m, tt, tij[3 + T], d[3 + T], etav, Pv, dtr, EIIv);
 }
 
 // update_stresses_center_vertex_ps! 3D -- one edge family at node (i, j, k) (StressKernels.jl:707-903).
@@ -364,7 +369,7 @@ __device__ __forceinline__ void vep3_edge_finish(const Vep3Args &a, i64 v, const
 struct CenAvg {
     double v[9][3], etav[3], Pv[3], EIIv[3];      // EIIv: av_clamped_yz/xz/xy(EII_pl) (StressKernels.jl:710,783,854), only gathered for softening laws
 };
-template <int T, bool SOFT>
+template <int T, bool SOFT, int NP = 0>
 __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, int k, const int ci[3], const int cj[3], const int ck[3], const CenAvg &C)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz;
@@ -393,7 +398,7 @@ __device__ __forceinline__ void vep3_edge_body(const Vep3Args &a, int i, int j, 
         toij[3 + s] = 0.25 * (LB(tosh[s], o[0]) + LB(tosh[s], o[1]) + LB(tosh[s], o[2]) + LB(tosh[s], o[3]));
     }
 #undef LB
-    vep3_edge_finish<T, SOFT>(a, v, eij, tij, toij, etav, Pv, C.EIIv[T]);
+    vep3_edge_finish<T, SOFT, NP>(a, v, eij, tij, toij, etav, Pv, C.EIIv[T]);
 }
 
 // The clamped centre stencils of the three families lie in the 2 x 2 x 2 cube of cells below the node (cen3: bit = 1 own index,
@@ -446,7 +451,7 @@ __device__ __forceinline__ void vep3_gather_centres(const Vep3Args &a, const int
 // XS: blocks are dealt round-robin to the 8 XCDs; give XCD q the q-th eighth of the (flattened xy, z) block sequence instead, so that the
 // rows j +- 1 and planes k +- 1 a block gathers from were fetched by the same L2
 // i0, iw: the launch covers the node columns i0 .. i0 + iw - 1 (the whole box: 0, nx + 1)
-template <bool P4, bool XS = false, bool SOFT = false>
+template <bool P4, bool XS = false, bool SOFT = false, int NP = 0>
 __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a, const int i0, const int iw)
 {
     const int nx = a.nx, ny = a.ny;
@@ -474,9 +479,9 @@ __global__ __launch_bounds__(256) void k_vep3_edges(const Vep3Args a, const int 
     const int ck[3] = {clampi3(k - 1, 0, nz - 1), clampi3(k, 0, nz - 1), clampi3(k + 1, 0, nz - 1)};
     CenAvg C;
     vep3_gather_centres<SOFT>(a, ci, cj, ck, C);
-    vep3_edge_body<0, SOFT>(a, i, j, k, ci, cj, ck, C);
-    vep3_edge_body<1, SOFT>(a, i, j, k, ci, cj, ck, C);
-    vep3_edge_body<2, SOFT>(a, i, j, k, ci, cj, ck, C);
+    vep3_edge_body<0, SOFT, NP>(a, i, j, k, ci, cj, ck, C);
+    vep3_edge_body<1, SOFT, NP>(a, i, j, k, ci, cj, ck, C);
+    vep3_edge_body<2, SOFT, NP>(a, i, j, k, ci, cj, ck, C);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1266,7 +1271,13 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
         if (peel) {
             const dim3 gp((unsigned)(((i64)rem * (ny + 1) + 63) / 64), (unsigned)((nz + 1 + 3) / 4));
             if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, false, true>), gp, dim3(256), 0, ps, a, ilim, rem);
-            else hipLaunchKernelGGL((k_vep3_edges<true, false, false>), gp, dim3(256), 0, ps, a, ilim, rem);
+            else switch (h->vep3_np_const ? np_ : 0) {
+            case 1: hipLaunchKernelGGL((k_vep3_edges<true, false, false, 1>), gp, dim3(256), 0, ps, a, ilim, rem); break;
+            case 2: hipLaunchKernelGGL((k_vep3_edges<true, false, false, 2>), gp, dim3(256), 0, ps, a, ilim, rem); break;
+            case 3: hipLaunchKernelGGL((k_vep3_edges<true, false, false, 3>), gp, dim3(256), 0, ps, a, ilim, rem); break;
+            case 4: hipLaunchKernelGGL((k_vep3_edges<true, false, false, 4>), gp, dim3(256), 0, ps, a, ilim, rem); break;
+            default: hipLaunchKernelGGL((k_vep3_edges<true, false, false>), gp, dim3(256), 0, ps, a, ilim, rem);
+            }
         }
         struct Join { jrx_handle *h; hipStream_t s, ps; bool on; ~Join() { if (on) { (void)hipEventRecord(h->ev[5], ps); (void)hipStreamWaitEvent(s, h->ev[5], 0); } } } join{h, s, ps, fork};
         if (a.soft && edges == 5) {       // softening laws: the yield function also reads the edge average of EII_pl (a twelfth shared centre array);
@@ -1315,7 +1326,13 @@ jrx_status launch_vep3_stress(jrx_handle *h, hipStream_t s, const Vep3Args &a, c
         }
         if (!ok) return jrx_fail(h, JRX_ERR_ARG, "vep3_cfg: no such configuration");
     } else if (a.soft) hipLaunchKernelGGL((k_vep3_edges<true, true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
-    else if (p4 && xs) hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
+    else if (p4 && xs) switch (h->vep3_np_const && a.rh.nphase <= 4 ? a.rh.nphase : 0) {
+        case 1: hipLaunchKernelGGL((k_vep3_edges<true, true, false, 1>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1); break;
+        case 2: hipLaunchKernelGGL((k_vep3_edges<true, true, false, 2>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1); break;
+        case 3: hipLaunchKernelGGL((k_vep3_edges<true, true, false, 3>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1); break;
+        case 4: hipLaunchKernelGGL((k_vep3_edges<true, true, false, 4>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1); break;
+        default: hipLaunchKernelGGL((k_vep3_edges<true, true>), GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
+    }
     else if (p4) hipLaunchKernelGGL(k_vep3_edges<true>, GRID_IJK4(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
     else hipLaunchKernelGGL(k_vep3_edges<false>, GRID_IJK(nx + 1, ny + 1, nz + 1), dim3(256), 0, s, a, 0, nx + 1);
     JRX_LAUNCH_CHECK(h);
