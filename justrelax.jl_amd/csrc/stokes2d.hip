@@ -678,18 +678,24 @@ __device__ __forceinline__ double ratio_avg(const double *val, const double *r, 
     for (int q = 0; q < n; q++) x += (r[q] == 0.0) ? 0.0 : val[q] * r[q];
     return x;
 }
+// NP > 0: the number of phases as a compile-time constant (the phase loops unroll and the caller hands the ratios in registers, loaded in one batch), else rh.nphase
+template <int NP = 0>
 __device__ __forceinline__ void plastic_params(const jrx_rheology &rh, const double *r, bool &is_pl, double &eta_reg)
 {   // plastic_params_phase, rheology/StressUpdate.jl:152-176
     is_pl = false; eta_reg = 0.0;
-    for (int q = 0; q < rh.nphase; q++)
+    const int np = NP > 0 ? NP : rh.nphase;
+#pragma unroll
+    for (int q = 0; q < np; q++)
         if (rh.is_pl[q]) { is_pl = true; eta_reg += rh.eta_vp[q] * r[q]; }
 }
 // SOFT: some phase has a softening law (compiled out otherwise)
-template <bool SOFT>
+template <bool SOFT, int NP = 0>
 __device__ __forceinline__ double yield_F(const jrx_rheology &rh, const double *r, double P, double tII, double EII)
 {   // compute_yieldfunction_phase, StressUpdate.jl:399-410 ; DP: F = τII - cosϕ(EII) C(EII) - sinϕ(EII) P (softening at the EII keyword)
     double F = 0.0;
-    for (int q = 0; q < rh.nphase; q++) {
+    const int np = NP > 0 ? NP : rh.nphase;
+#pragma unroll
+    for (int q = 0; q < np; q++) {
         if (r[q] == 0.0) continue;
         double Fq = tII;
         if (rh.is_pl[q]) {
@@ -703,13 +709,21 @@ __device__ __forceinline__ double yield_F(const jrx_rheology &rh, const double *
     }
     return F;
 }
+template <int NP = 0>
 __device__ __forceinline__ void plastic_grad(const jrx_rheology &rh, const double *r, const double t[3], double dQdt[3], double &dQdP, double &dFdP)
 {   // compute_plastic_gradients_phase, StressUpdate.jl:476-495 ; ∂Q/∂τ = τ/(2 τII), ∂Q/∂P = -sinψ, ∂F/∂P = -sinϕ
     dQdt[0] = dQdt[1] = dQdt[2] = 0.0; dQdP = 0.0; dFdP = 0.0;
     const double tII = sinv2(t[0], t[1], t[2]);
-    for (int q = 0; q < rh.nphase; q++) {
+    const int np = NP > 0 ? NP : rh.nphase;
+    // (the quotients do not depend on the phase: one division per component, not one per component and phase -- the same bits)
+    bool any_pl = false;
+#pragma unroll
+    for (int q = 0; q < np; q++) any_pl |= rh.is_pl[q] != 0;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    if (any_pl) { g0 = 0.5 * t[0] / tII; g1 = 0.5 * t[1] / tII; g2 = 0.5 * (t[2] / tII); }
+#pragma unroll
+    for (int q = 0; q < np; q++) {
         if (r[q] == 0.0 || !rh.is_pl[q]) continue;
-        const double g0 = 0.5 * t[0] / tII, g1 = 0.5 * t[1] / tII, g2 = 0.5 * (t[2] / tII);
         dQdt[0] = fma(r[q], g0, dQdt[0]); dQdt[1] = fma(r[q], g1, dQdt[1]); dQdt[2] = fma(r[q], g2, dQdt[2]);
         dQdP = fma(r[q], -rh.sinpsi[q], dQdP);
         dFdP = fma(r[q], -rh.sinphi[q], dFdP);
@@ -805,10 +819,10 @@ __device__ __forceinline__ double dev_stress_inc_dt(double t, double to, double 
 // update_stresses_center_vertex_ps! -- vertex half.  Runs before the centre half so that the vertex averages
 // see the old centre stresses (the reference's single launch races on them).
 // SI: strain_increment form (StressKernels.jl:1147-1302): Δε instead of ε, _G and dτ_r = inv(θ_dτ dt + η _G + dt), plastic terms times dt
-template <bool SOFT, bool SI = false>
+template <bool SOFT, bool SI = false, int NP = 0>
 __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, const int j)
 {
-    const int nx = a.nx, ny = a.ny, np = a.rh.nphase;
+    const int nx = a.nx, ny = a.ny, np = NP > 0 ? NP : a.rh.nphase;
     const int i0 = clampi(i - 1, 0, nx - 1), ic = clampi(i, 0, nx - 1), j0 = clampi(j - 1, 0, ny - 1), jc = clampi(j, 0, ny - 1);
 #define AVC(A) (0.25 * (C2(A, i0, j0) + C2(A, ic, jc) + C2(A, i0, jc) + C2(A, ic, j0)))
     const double Pv = AVC(a.theta), exxv = SI ? AVC(a.f.dexx) : AVC(a.f.exx), eyyv = SI ? AVC(a.f.deyy) : AVC(a.f.eyy), txxv = AVC(a.f.txx), tyyv = AVC(a.f.tyy);
@@ -816,9 +830,14 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
     const double EIIv = SOFT ? AVC(a.f.EII_pl) : 0.0;      // EIIv_ij = av_clamped(EII, Ic...) (StressKernels.jl:1030); only softening laws read it
 #undef AVC
     const i64 v = i + (i64)(nx + 1) * j;
-    const double *rv = a.f.phase_v + (i64)np * v;
+    double rvv[NP > 0 ? NP : 1];
+    if (NP > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) rvv[q] = a.f.phase_v[(i64)NP * v + q];
+    }
+    const double *rv = NP > 0 ? rvv : a.f.phase_v + (i64)np * v;
     bool is_pl; double eta_reg;
-    plastic_params(a.rh, rv, is_pl, eta_reg);
+    plastic_params<NP>(a.rh, rv, is_pl, eta_reg);
     const double _Gdt = SI ? 1.0 / ratio_avg(a.rh.G, rv, np) : 1.0 / (ratio_avg(a.rh.G, rv, np) * a.dt);      // SI: _Gv
     const double Kv = ratio_avg(a.rh.Kb, rv, np);
     const double etav = 4.0 / (1.0 / C2(a.f.eta, i0, j0) + 1.0 / C2(a.f.eta, ic, jc) + 1.0 / C2(a.f.eta, i0, jc) + 1.0 / C2(a.f.eta, ic, j0));
@@ -830,9 +849,9 @@ __device__ __forceinline__ void vep_vertex_at(const VepArgs &a, const int i, con
     const double tt[3] = {txxv + dxx, tyyv + dyy, txy + dxy};
     const double tIIv = sinv2(dxx + txxv, dyy + tyyv, dxy + txy);
     double dQdt[3], dQdP, dFdP;
-    plastic_grad(a.rh, rv, tt, dQdt, dQdP, dFdP);
+    plastic_grad<NP>(a.rh, rv, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(Kv) ? 0.0 : Kv * a.dt * dFdP * dQdP;
-    const double F = yield_F<SOFT>(a.rh, rv, Pv, tIIv, EIIv);
+    const double F = yield_F<SOFT, NP>(a.rh, rv, Pv, tIIv, EIIv);
     if (is_pl && tIIv != 0.0 && F > 0) {
         const double l = fma(1.0 - a.rel, a.lamv[v], a.rel * (fmax(F, 0.0) / (SI ? etav * dtr * a.dt + eta_reg + vol : etav * dtr + eta_reg + vol)));
         a.lamv[v] = l;
@@ -879,16 +898,21 @@ __device__ __forceinline__ CentreOps vep_centre_load(const VepArgs &a, const int
 }
 
 // update_stresses_center_vertex_ps! -- centre half (+ Pr_c, τII, η_vep)
-template <bool SOFT, bool SI = false>
+template <bool SOFT, bool SI = false, int NP = 0>
 __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, const int j, const CentreOps &o)
 {
-    const int nx = a.nx, np = a.rh.nphase;
+    const int nx = a.nx, np = NP > 0 ? NP : a.rh.nphase;
     const i64 c = i + (i64)nx * j;
     double *__restrict__ txx_o = a.txx_out ? a.txx_out : a.f.txx, *__restrict__ tyy_o = a.tyy_out ? a.tyy_out : a.f.tyy;
-    const double *rc = a.f.phase_c + (i64)np * c;
+    double rcv[NP > 0 ? NP : 1];
+    if (NP > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) rcv[q] = a.f.phase_c[(i64)NP * c + q];
+    }
+    const double *rc = NP > 0 ? rcv : a.f.phase_c + (i64)np * c;
     const double _Gdt = SI ? 1.0 / ratio_avg(a.rh.G, rc, np) : 1.0 / (ratio_avg(a.rh.G, rc, np) * a.dt);
     bool is_pl; double eta_reg;
-    plastic_params(a.rh, rc, is_pl, eta_reg);
+    plastic_params<NP>(a.rh, rc, is_pl, eta_reg);
     const double K = ratio_avg(a.rh.Kb, rc, np);
     const double e = o.e;
     const double dtr = SI ? 1.0 / (a.theta_dtau * a.dt + e * _Gdt + a.dt) : 1.0 / (a.theta_dtau + e * _Gdt + 1.0);
@@ -907,10 +931,10 @@ __device__ __forceinline__ void vep_centre_at(const VepArgs &a, const int i, con
     double tII = sinv2(d[0] + tij[0], d[1] + tij[1], d[2] + tij[2]);
     const double tt[3] = {tij[0] + d[0], tij[1] + d[1], tij[2] + d[2]};
     double dQdt[3], dQdP, dFdP;
-    plastic_grad(a.rh, rc, tt, dQdt, dQdP, dFdP);
+    plastic_grad<NP>(a.rh, rc, tt, dQdt, dQdP, dFdP);
     const double vol = isinf(K) ? 0.0 : K * a.dt * dFdP * dQdP;
     const double Pr = o.theta;
-    const double F = yield_F<SOFT>(a.rh, rc, Pr, tII, o.EII);
+    const double F = yield_F<SOFT, NP>(a.rh, rc, Pr, tII, o.EII);
     double l = o.lam;
     if (is_pl && tII != 0.0 && F > 0) {
         l = fma(1.0 - a.rel, l, a.rel * (fmax(F, 0.0) / (SI ? e * dtr * a.dt + eta_reg + vol : e * dtr + eta_reg + vol)));
@@ -948,7 +972,7 @@ __global__ __launch_bounds__(256) void k_vep_centre(const VepArgs a)
 }
 // both halves in one launch: the vertex half averages the OLD centre stresses, so the centre half must write τxx, τyy elsewhere
 // (a.txx_out / a.tyy_out; the caller then swaps the pointers)
-template <bool SOFT, bool SI = false>
+template <bool SOFT, bool SI = false, int NP = 0>
 __global__ __launch_bounds__(256) void k_vep_stress2d(const VepArgs a)
 {
     const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
@@ -957,8 +981,8 @@ __global__ __launch_bounds__(256) void k_vep_stress2d(const VepArgs a)
     const bool cell = i < a.nx && j < a.ny;
     CentreOps o = {};
     if (cell) o = vep_centre_load<SOFT, SI>(a, i, j);          // before the vertex half's stores
-    vep_vertex_at<SOFT, SI>(a, i, j);
-    if (cell) vep_centre_at<SOFT, SI>(a, i, j, o);
+    vep_vertex_at<SOFT, SI, NP>(a, i, j);
+    if (cell) vep_centre_at<SOFT, SI, NP>(a, i, j, o);
 }
 
 // compute_τ_nonlinear! 2D: single phase (StressKernels.jl:266-307) / phases at the cell centres (:310-351) with
@@ -1472,7 +1496,13 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                             if (upd_rho) hipLaunchKernelGGL((k_vep_pre<true, true>), dim3(gv), dim3(256), 0, s, aa, theta);
                             else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, aa, theta);
                             if (aa.soft) hipLaunchKernelGGL(k_vep_stress2d<true>, dim3(gv), dim3(256), 0, s, aa);
-                            else hipLaunchKernelGGL(k_vep_stress2d<false>, dim3(gv), dim3(256), 0, s, aa);
+                            else switch (h->vep3_np_const ? aa.rh.nphase : 0) {
+                            case 1: hipLaunchKernelGGL((k_vep_stress2d<false, false, 1>), dim3(gv), dim3(256), 0, s, aa); break;
+                            case 2: hipLaunchKernelGGL((k_vep_stress2d<false, false, 2>), dim3(gv), dim3(256), 0, s, aa); break;
+                            case 3: hipLaunchKernelGGL((k_vep_stress2d<false, false, 3>), dim3(gv), dim3(256), 0, s, aa); break;
+                            case 4: hipLaunchKernelGGL((k_vep_stress2d<false, false, 4>), dim3(gv), dim3(256), 0, s, aa); break;
+                            default: hipLaunchKernelGGL(k_vep_stress2d<false>, dim3(gv), dim3(256), 0, s, aa);
+                            }
                             { double *t_ = aa.f.txx; aa.f.txx = aa.txx_out; aa.txx_out = t_; }
                             { double *t_ = aa.f.tyy; aa.f.tyy = aa.tyy_out; aa.tyy_out = t_; }
                             bb.f.txx = aa.f.txx; bb.f.tyy = aa.f.tyy;
@@ -1518,7 +1548,13 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             if (a.soft) hipLaunchKernelGGL((k_vep_stress2d<true, true>), dim3(gv), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_vep_stress2d<false, true>), dim3(gv), dim3(256), 0, s, a);
         } else if (a.soft) hipLaunchKernelGGL(k_vep_stress2d<true>, dim3(gv), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(k_vep_stress2d<false>, dim3(gv), dim3(256), 0, s, a);
+        else switch (h->vep3_np_const ? a.rh.nphase : 0) {
+        case 1: hipLaunchKernelGGL((k_vep_stress2d<false, false, 1>), dim3(gv), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_vep_stress2d<false, false, 2>), dim3(gv), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_vep_stress2d<false, false, 3>), dim3(gv), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_vep_stress2d<false, false, 4>), dim3(gv), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(k_vep_stress2d<false>, dim3(gv), dim3(256), 0, s, a);
+        }
         JRX_LAUNCH_CHECK(h);
         { double *t_ = a.f.txx; a.f.txx = a.txx_out; a.txx_out = t_; }
         { double *t_ = a.f.tyy; a.f.tyy = a.tyy_out; a.tyy_out = t_; }
