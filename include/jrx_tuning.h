@@ -27,7 +27,10 @@
  *   "vep3_fuse_pc" (1)            3D VEP driver without neighbours, viscosity laws that read no field: compute_∇V! / compute_P! / compute_strain_rate!, update_viscosity_τII! and the centre half of
  *                                 update_stresses_center_vertex_ps! run as ONE kernel ahead of the edge half (0 = the three kernels, centre half behind the edge half); bit-identical
  *   "vep3_np_const" (1)           3D VEP centre pass / fused kernel: 1 = instantiations with the number of phases as a compile-time constant (1..4; 0 = the run-time loops, A/B)
- *   "thermal_np_const" (1)        phase-ratio form of the 3D heat-diffusion kernels: 1 = instantiations with the number of phases as a compile-time constant (1..4; 0 = run-time loops, A/B)
+ *   "thermal_np_const" (1)        phase-ratio form of the heat-diffusion kernels (2D, 3D): 1 = instantiations with the number of phases as a compile-time constant (1..4; 0 = run-time loops, A/B)
+ *   "fused2d_batch" (1)           2D visco-elastic loop, one-launch iteration: 1 = the form that requests every operand up front (k_fused2d_b; dt = Inf: its viscous-limit instantiation,
+ *                                 which does not load τ_o, P0, K, G, Q, behind the operand check of "viscous_limit"); 0 = the control-flow form (A/B)
+ *   "fused2d_max_nodes" (1200000)  ... on grids of up to this many nodes (larger: the two-kernel iteration)
  *   "vep3_fork" (0)               3D VEP driver without neighbours: 1 = the centre pass of update_stresses_center_vertex_ps! runs on a second stream beside the edge pass (it writes a
  *                                 second set of τxx, τyy, τzz, adopted by pointer swap); measured equal to one pass after the other: off
  *   "vep_store_all" (0)           VEP loops (2D and 3D): 1 = every iteration stores ∇V, RP, ε_pl, ε_vol_pl, τII, η_vep (default: only iterations whose results can be observed)

@@ -65,7 +65,9 @@ struct jrx_handle {
     int vep3_hide_comm = 1;                  // multi-rank 3D VEP driver: 2 = the three exchanges of an iteration on the halo stream beside independent kernels; 1 (default) = ητ and the
                                              // edge stresses only, update_halo!(V) behind the whole velocity sweep; 0 = serial.  Two 256^3 blocks on one device (profiles/r04_bench_default.json): +12.2 % (2),
                                              // +8.6 % (1), +9.6 % (0) -- the six slab launches of (2) cost more than they hide until a real link shows otherwise
-    bool thermal_np_const = true;            // phase-ratio form of the 3D heat-diffusion kernels: instantiations with the phase count as a constant (1..4)
+    bool fused2d_batch = true;               // 2D one-launch iteration: the form with every operand requested up front (k_fused2d_b), and its viscous-limit instantiation for dt = Inf
+    int fused2d_max_nodes = 1200000;         // ... runs on grids of up to this many nodes (SolCx: faster than the two-kernel iteration up to 1024^2, slower at 1280^2 ... 1536^2; the control-flow form: 200,000)
+    bool thermal_np_const = true;            // phase-ratio form of the heat-diffusion kernels (2D and 3D): instantiations with the phase count as a constant (1..4)
     bool vep3_np_const = true;               // 3D VEP centre pass (and the fused pre / centre kernel): instantiations with the phase count as a constant (1..4): ratios loaded in one batch, phase loops unrolled
     bool vep3_fuse_pc = true;                // 3D VEP driver without neighbours, linear laws: k_vep3_pre + k_vep3_visc + k_vep3_centre as one kernel ahead of the edge pass (k_vep3_prec; second sets of η and τxx, τyy, τzz)
     bool vep3_fork = false;                  // 3D VEP driver without neighbours: the centre pass of the stress update on the halo stream beside the edge pass (second set of τxx, τyy, τzz).

@@ -251,6 +251,167 @@ __global__ __launch_bounds__(256) void k_fused2d(const Args2 a, const Out6_2d o,
     }
 #undef TXY
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_fused2d with every operand requested up front (option "fused2d_batch", default).  The kernel above follows the reference's control flow -- compute_V! of the own cell,
+// of the cell below, the boundary rules, compute_P!, compute_τ! of the centre, of the vertex -- and every `if` on the way ends a basic block, so its ~50 loads reach the
+// memory system as a chain of 12-14 dependent groups: on the grids this kernel runs on (everything sits in L2 / Infinity Cache) an iteration IS that chain of round trips.
+// Here the loads are unconditional (clamped indices; what a boundary lane does not use it does not use), issued as one batch and pinned ahead of the arithmetic; the
+// arithmetic is the kernel above, expression for expression, with the boundary cases as selects.  VISC (dt = Inf, SolCx and every purely viscous 2D run): the seven arrays
+// that only ever meet 1/(G dt), 1/(K dt), 1/dt -- τ_o (3), P0, K, G, Q -- are not loaded (finite operands: the driver checks them once per solve), as in 3D.
+// ------------------------------------------------------------------------------------------------
+template <bool VISC>
+__global__ __launch_bounds__(256) void k_fused2d_b(const Args2 a, const Out6_2d o, const BC2 bc, const int nwx)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int wg = (int)xcd_slab_block() * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int j = wg / nwx, i = (wg - j * nwx) * 63 + lane - 1;
+    if (j > ny) return;
+    const double _dx = a._dx, _dy = a._dy, edt = a.eta_dtau, dt = a.dt, th = a.theta_dtau;
+    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ P = a.f.P, *__restrict__ et = a.etatau;
+    const double *__restrict__ txy = a.f.txy, *__restrict__ eta = a.f.eta, *__restrict__ G = a.f.G;
+    typedef unsigned int u32;
+#define LB(p_, off_) (*(const double *)((const char *)(p_) + (off_)))
+    // clamped cell column / rows: r0 = j - 1, r1 = j, r2 = j + 1 (cells), ip = ic + 1 (cells)
+    const int ic = min(max(i, 0), nx - 1), ip = min(ic + 1, nx - 1);
+    const int r0 = min(max(j - 1, 0), ny - 1), r1 = min(j, ny - 1), r2 = min(j + 1, ny - 1);
+    const u32 c0 = 8u * (u32)(ic + nx * r0), c1 = 8u * (u32)(ic + nx * r1), c2 = 8u * (u32)(ic + nx * r2), dxp = 8u * (u32)(ip - ic);
+    // node rows of τxy (nx+1 columns, rows 0..ny): j - 1, j, j + 1 clamped; node column ic + 1 and ic
+    const int n0 = max(j - 1, 0), n2 = min(j + 1, ny);
+    const u32 t0 = 8u * (u32)(ic + (nx + 1) * n0), t1 = 8u * (u32)(ic + (nx + 1) * j), t2 = 8u * (u32)(ic + (nx + 1) * n2);
+    // Vx (nx+1 columns, rows 0..ny+1): (i+1, j), (i+1, j+1);  Vy (nx+2 columns, rows 0..ny): (i+1, j), (i+1, min(j+1, ny)).  The feeder lane of the first segment (i = -1) thereby
+    // loads the boundary column Vx[0, ·], Vy[0, ·] for the lane on the left face, and the lane on the right face (i = nx, no cell of its own) the ghost column Vy[nx+1, j]
+    const int cvx = min(max(i + 1, 0), nx), cvy = min(max(i + 1, 0), nx + 1);
+    const u32 vx0 = 8u * (u32)(cvx + (nx + 1) * j), vx1 = vx0 + 8u * (u32)(nx + 1);
+    const u32 vy0 = 8u * (u32)(cvy + (nx + 2) * j), vy1 = 8u * (u32)(cvy + (nx + 2) * n2);
+    // vertex (i, j): the four cells around it, clamped
+    const int iq = min(max(i, 0), nx - 1), jm = max(j - 1, 0), jq = min(j, ny - 1);
+    const u32 v10 = 8u * (u32)(iq + nx * jm), v11 = 8u * (u32)(iq + nx * jq);
+    const u32 vv = 8u * (u32)(min(max(i, 0), nx) + (nx + 1) * j);
+    // ---- every operand
+    const double P00 = LB(P, c0), P10 = LB(P, c0 + dxp), P01 = LB(P, c1), P11 = LB(P, c1 + dxp), P02 = LB(P, c2);
+    const double E00 = LB(et, c0), E10 = LB(et, c0 + dxp), E01 = LB(et, c1), E11 = LB(et, c1 + dxp), E02 = LB(et, c2);
+    const double X00 = LB(a.f.txx, c0), X10 = LB(a.f.txx, c0 + dxp), X01 = LB(a.f.txx, c1), X11 = LB(a.f.txx, c1 + dxp);
+    const double Y00 = LB(a.f.tyy, c0), Y01 = LB(a.f.tyy, c1), Y02 = LB(a.f.tyy, c2);
+    const double Fx00 = LB(a.f.fx, c0), Fx10 = LB(a.f.fx, c0 + dxp), Fx01 = LB(a.f.fx, c1), Fx11 = LB(a.f.fx, c1 + dxp);
+    const double Fy00 = LB(a.f.fy, c0), Fy01 = LB(a.f.fy, c1), Fy02 = LB(a.f.fy, c2);
+    const double S10 = LB(txy, t0 + 8u), S01 = LB(txy, t1), S11 = LB(txy, t1 + 8u), S02 = LB(txy, t2), S12 = LB(txy, t2 + 8u);     // τxy[ic+1, j-1], [ic, j], [ic+1, j], [ic, j+1], [ic+1, j+1]
+    const double Ux0 = LB(Vx, vx0), Ux1 = LB(Vx, vx1), Uy0 = LB(Vy, vy0), Uy1 = LB(Vy, vy1);
+    const double e10 = LB(eta, v10), e11 = LB(eta, v11);
+    double g10 = 0, g11 = 0, Gc = 0, Kc = 0, P0c = 0, Qc = 0, toxx = 0, toyy = 0, toxy = 0;
+    if (!VISC) {
+        g10 = LB(G, v10); g11 = LB(G, v11);
+        Gc = g11;          // (where the centre is updated, i < nx and j < ny, the vertex's cell (iq, jq) is the own cell)
+    }
+    const double ec1 = e11, tvv = i < nx ? S01 : S11;       // η of the own cell = the vertex's (iq, jq); τxy[i, j]: the own node column, or the last one (ic + 1 = nx)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- compute_V! of cell (ci, cj) from its operands: Pc, P[c+1], P[c+nx], ... (k_fused2d::Bcell)
+    auto Bcell = [&](const int ci, const int cj, const double Pc, const double Px, const double Py, const double ec, const double ex, const double ey, const double txc,
+                     const double txr, const double tyc, const double tyu, const double s_r0, const double s_r1, const double s_l1, const double fxc, const double fxr,
+                     const double fyc, const double fyu, const double vxo, const double vyo, double &vx_, double &vy_) {
+        if (ci < nx - 1) {
+            const double dP = (-Pc + Px) * _dx, dT = (-txc + txr) * _dx;
+            const double dS = (-s_r0 + s_r1) * _dy, av = (fxc + fxr) * 0.5;
+            vx_ = vxo + (-dP + dT + dS - av) * edt / ((ec + ex) * 0.5);
+        } else vx_ = bc.tR == 2 ? 0.0 : vxo;
+        if (cj < ny - 1) {
+            const double dP = (-Pc + Py) * _dy, dT = (-tyc + tyu) * _dy;
+            const double dS = (-s_l1 + s_r1) * _dx, av = (fyc + fyu) * 0.5;
+            vy_ = vyo + (-dP + dT + dS - av) * edt / ((ec + ey) * 0.5);
+        } else vy_ = bc.tT == 2 ? 0.0 : vyo;
+    };
+    auto rule = [](const int t, const double v, const double mem) { return t == 1 ? v : (t == 2 ? -v : mem); };
+    const bool col = i >= 0 && i < nx;
+    double vxn = 0.0, vyn = 0.0, vxb = 0.0, vyb = 0.0;
+    if (col) {
+        //                         Pc   P[c+1] P[c+nx] ec  e[c+1] e[c+nx] txx  txx+1 tyy  tyy+nx τxy[ci+1,cj] [ci+1,cj+1] [ci,cj+1]
+        if (j < ny) Bcell(i, j, P01, P11, P02, E01, E11, E02, X01, X11, Y01, Y02, S11, S12, S02, Fx01, Fx11, Fy01, Fy02, Ux1, Uy1, vxn, vyn);
+    }
+    if (!VISC) {
+        // the six operands only the stress update reads, requested once the first compute_V! has consumed its share of the batch (the register peak that decides between four
+        // and five waves per SIMD -- 512^2 is 4,617 waves for 4,096 or 5,120 slots) and pinned here: in flight under the second compute_V! and the lane exchanges
+        __builtin_amdgcn_sched_barrier(0);
+        Kc = LB(a.f.K, c1); P0c = LB(a.f.P0, c1); Qc = LB(a.f.Q, c1); toxx = LB(a.f.toxx, c1); toyy = LB(a.f.toyy, c1); toxy = LB(a.f.toxy, vv);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (col) {
+        if (j >= 1) Bcell(i, j - 1, P00, P10, P01, E00, E10, E01, X00, X10, Y00, Y01, S10, S11, S01, Fx00, Fx10, Fy00, Fy01, Ux0, Uy0, vxb, vyb);
+        else {
+            vxb = rule(bc.tB, vxn, Ux0);                 // ghost row below the bottom face: Vx[i+1, 0]
+            vyb = bc.tB == 2 ? 0.0 : Uy0;                // Vy on the bottom face: Vy[i+1, 0]
+        }
+        if (j == ny) vxn = rule(bc.tT, vxb, Ux1);        // ghost row above the top face: Vx[i+1, ny+1]
+    }
+    const double Lvxn = __shfl_up(vxn, 1, 64), Lvxb = __shfl_up(vxb, 1, 64), Lvyb = __shfl_up(vyb, 1, 64);
+    // from the lane to the left: its velocity loads (for the lane on the left face: the boundary column) and the vertex's two left-hand cells (im, jm), (im, jq) = that lane's (iq, jm), (iq, jq)
+    const double LUx0 = __shfl_up(Ux0, 1, 64), LUx1 = __shfl_up(Ux1, 1, 64), LUy0 = __shfl_up(Uy0, 1, 64);
+    const double Le10 = __shfl_up(e10, 1, 64), Le11 = __shfl_up(e11, 1, 64);
+    const double e00 = i > 0 ? Le10 : e10, e01 = i > 0 ? Le11 : e11;
+    double g00 = 0, g01 = 0;
+    if (!VISC) {
+        const double Lg10 = __shfl_up(g10, 1, 64), Lg11 = __shfl_up(g11, 1, 64);
+        g00 = i > 0 ? Lg10 : g10; g01 = i > 0 ? Lg11 : g11;
+    }
+    if (lane == 0 || i < 0 || i > nx) return;          // feeder lane / beyond the row
+    const double B0 = LUx0, B1 = LUx1, BY = i == 0 ? LUy0 : Uy0;      // i = 0: Vx[0, j], Vx[0, j+1], Vy[0, j];  i = nx: Vy[nx+1, j]
+    double X1, X0, Y0;
+    if (i >= 1) { X1 = Lvxn; X0 = Lvxb; Y0 = Lvyb; }
+    else {
+        // left boundary plane of Vx (ghost rows by the bottom / top rule) and ghost column of Vy: B0 = Vx[0, j], B1 = Vx[0, j+1], BY = Vy[0, j]
+        const double b0 = bc.tL == 2 ? 0.0 : B0, b1 = bc.tL == 2 ? 0.0 : B1;
+        X1 = (j + 1 == ny + 1) ? rule(bc.tT, b0, B1) : b1;
+        X0 = (j == 0) ? rule(bc.tB, b1, B0) : b0;
+        Y0 = rule(bc.tL, vyb, BY);
+    }
+    const double Yr = i < nx ? vyb : rule(bc.tR, Lvyb, BY);        // Vy[i+1, j]; beyond the right face: ghost column Vy[nx+1, j]
+    if (i < nx && j < ny) {
+        const double dxi = (-X1 + vxn) * _dx;
+        const double dyi = (-vyb + vyn) * _dy;
+        const double divV = dxi + dyi;
+        const double _Gdt = VISC ? 0.0 : 1.0 / (Gc * dt);
+        {   // compute_P! with ητ (Stokes2D.jl:231-233)
+            const double _Kdt = VISC ? 0.0 : 1.0 / (Kc * dt);
+            const double _dt = 1.0 / dt;
+            const double rhs = -divV + (Qc * _dt);
+            const double psi = 1.0 / (1.0 / E01 + _Gdt) * a.r / th;
+            *(double *)((char *)o.P + c1) = (fma(P0c, _Kdt, rhs) * psi + P01) / (1.0 + _Kdt * psi);
+        }
+        const double d3 = divV * (1.0 / 3.0);
+        const double exx = dxi - d3, eyy = dyi - d3;
+        const double dtr = dev_dtau_r(th, ec1, _Gdt);
+        *(double *)((char *)o.txx + c1) = X01 + dev_stress_inc(X01, toxx, ec1, exx, _Gdt, dtr);
+        *(double *)((char *)o.tyy + c1) = Y01 + dev_stress_inc(Y01, toyy, ec1, eyy, _Gdt, dtr);
+        if (i < nx - 1) o.Vx[(i + 1) + (i64)(nx + 1) * (j + 1)] = vxn;
+        if (j < ny - 1) o.Vy[(i + 1) + (i64)(nx + 2) * (j + 1)] = vyn;
+    }
+    {   // vertex (i, j)
+        const double exy = 0.5 * (_dy * (X1 - X0) + _dx * (Yr - Y0));
+        const double e = 0.25 * (e00 + e10 + e01 + e11);
+        const double g = 0.25 * (g00 + g10 + g01 + g11);
+        const double _Gdt = VISC ? 0.0 : 1.0 / (g * dt);
+        const double dtr = dev_dtau_r(th, e, _Gdt);
+        *(double *)((char *)o.txy + vv) = tvv + dev_stress_inc(tvv, toxy, e, exy, _Gdt, dtr);
+    }
+#undef LB
+}
+
+// dt = Inf (see k_fused2d_b<VISC>): one streaming pass checks that every entry of the arrays the viscous-limit form does not load is harmless -- τ_o, P0, Q finite, K and G neither
+// NaN nor 0 (0 * Inf) -- as visc_operands_check does in 3D; if not, the general form runs and produces the reference's NaNs
+__global__ __launch_bounds__(256) void k_visc_operands_ok2d(const double *__restrict__ P0, const double *__restrict__ Q, const double *__restrict__ toxx, const double *__restrict__ toyy,
+                                                            const double *__restrict__ K, const double *__restrict__ G, i64 nc, const double *__restrict__ toxy, i64 nv, int *bad)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    bool b = false;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < nv; t += stride) {
+        if (t < nc) {
+            b |= !(isfinite(P0[t]) && isfinite(Q[t]) && isfinite(toxx[t]) && isfinite(toyy[t]));
+            const double k = K[t], g = G[t];
+            b |= (k != k) || (g != g) || k == 0.0 || g == 0.0;
+        }
+        b |= !isfinite(toxy[t]);
+    }
+    if (__any(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
 #undef VX
 #undef VY
 #undef CC
@@ -477,7 +638,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     // library-owned set; flow_bcs! itself is applied lazily before anything reads the boundary entries of V from memory.
     // measured with the XCD slab block order (SolCx, profiles/r02_bench2d_xcd_slabs.txt; it/s two kernels vs fused): 128^2 175.9 k / 176.2 k, 256^2 135.2 k /
     // 144.2 k, 384^2 101.5 k / 106.7 k, 512^2 79.1 k / 73.6 k, 768^2 40.1 k / 38.8 k, 1024^2 equal -- fused up to 200,000 nodes (~ 440^2)
-    const bool fusable = !p->displacement_bcs && h->fused2d && h->scratch_sets && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= 200000)) &&
+    const bool fusable = !p->displacement_bcs && h->fused2d && h->scratch_sets && (h->kernel_variant == 3 || (h->kernel_variant == 0 && (i64)(nx + 1) * (ny + 1) <= (i64)(h->fused2d_batch ? h->fused2d_max_nodes : 200000))) &&
                          !jrx_comm_active(h) && p->periodic == 0 && nx >= 2 && ny >= 2 && !p->inv_spacing[0];
     const size_t nvx = (size_t)(nx + 1) * (ny + 2), nvy = (size_t)(nx + 2) * (ny + 1), nvt = (size_t)(nx + 1) * (ny + 1);
     Out6_2d setU = {f->P, f->txx, f->tyy, f->txy, f->Vx, f->Vy}, setS = setU;
@@ -504,6 +665,27 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
     bool cur_is_user = true, stress_done = false, ghosts_stale = false;
     bool bcs_full_done[2] = {false, false};      // flow_bcs! launched in full on the V of the caller's set / the second set
     const int nwx = (nx + 1 + 62) / 63;
+    // the one-launch iteration: "fused2d_batch" (default) = the form with every operand requested up front; its viscous-limit instantiation when dt = Inf and the operand check passed
+    bool visc2 = false;
+    if (fusable && h->fused2d_batch && h->viscous_limit && p->dt == INFINITY) {
+        int *d_bad = reinterpret_cast<int *>(h->d_sums + 6), *h_bad = reinterpret_cast<int *>(h->h_sums + 6);
+        JRX_HIP(h, hipMemsetAsync(d_bad, 0, sizeof(double), s));
+        hipLaunchKernelGGL(k_visc_operands_ok2d, dim3(1024), dim3(256), 0, s, (const double *)f->P0, (const double *)f->Q, (const double *)f->toxx, (const double *)f->toyy,
+                           (const double *)f->K, (const double *)f->G, (i64)n, (const double *)f->toxy, (i64)nvt, d_bad);
+        JRX_LAUNCH_CHECK(h);
+        JRX_HIP(h, hipMemcpyAsync(h_bad, d_bad, sizeof(double), hipMemcpyDeviceToHost, s));
+        JRX_HIP(h, hipStreamSynchronize(s));
+        visc2 = (*h_bad == 0);
+        h->stat_visc_checks++;
+        if (!visc2) h->stat_visc_fallbacks++;
+    }
+    const bool batch2 = h->fused2d_batch && (double)(nx + 2) * (double)(ny + 2) < 536870912.0;      // (32-bit byte offsets)
+    auto launch_fused2d = [&](hipStream_t st, const Args2 &aa, const Out6_2d &dst) {
+        const dim3 g((unsigned)((nwx * (ny + 1) + 3) / 4));
+        if (batch2 && visc2) hipLaunchKernelGGL(k_fused2d_b<true>, g, dim3(256), 0, st, aa, dst, bc2, nwx);
+        else if (batch2) hipLaunchKernelGGL(k_fused2d_b<false>, g, dim3(256), 0, st, aa, dst, bc2, nwx);
+        else hipLaunchKernelGGL(k_fused2d, g, dim3(256), 0, st, aa, dst, bc2, nwx);
+    };
     Args2 a = make_args2(&cur, h->etatau, p);
     // Runs of unobserved iterations in the steady state of the loop replay as a captured graph of GIT iterations (the gap between dependent launches is shorter
     // inside a graph: scripts/graph_probe.hip, 4.6 vs 5.7 - 6.1 us per pair of short kernels): GIT x k_fused2d (an even count, so that the ping-pong sets end where
@@ -538,7 +720,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
                             for (int q = 0; q < GIT; q++) {
                                 const Args2 aa = make_args2(&c, h->etatau, p);
                                 const Out6_2d dst = cu ? setS : setU;
-                                hipLaunchKernelGGL(k_fused2d, dim3((unsigned)((nwx * (ny + 1) + 3) / 4)), dim3(256), 0, s, aa, dst, bc2, nwx);
+                                launch_fused2d(s, aa, dst);
                                 c.P = dst.P; c.txx = dst.txx; c.tyy = dst.tyy; c.txy = dst.txy; c.Vx = dst.Vx; c.Vy = dst.Vy;
                                 cu = !cu;
                             }
@@ -567,7 +749,7 @@ jrx_status jrx_stokes2d_solve(jrx_handle *h, const jrx_stokes2d_fields *f, const
                 JRX_LAUNCH_CHECK(h);
             }
             const Out6_2d dst = cur_is_user ? setS : setU;
-            hipLaunchKernelGGL(k_fused2d, dim3((unsigned)((nwx * (ny + 1) + 3) / 4)), dim3(256), 0, s, a, dst, bc2, nwx);
+            launch_fused2d(s, a, dst);
             h->stat_fused2d++;
             JRX_LAUNCH_CHECK(h);
             cur.P = dst.P; cur.txx = dst.txx; cur.tyy = dst.tyy; cur.txy = dst.txy; cur.Vx = dst.Vx; cur.Vy = dst.Vy;

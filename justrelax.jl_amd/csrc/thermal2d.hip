@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_flux2d(const TArgs a, const PHT ph)
         else {
             const int iL = clampi(i - 1, 0, nx - 1), iR = clampi(i, 0, nx - 1);
             double Kx;
-            if constexpr (PH) Kx = (tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (iL + (i64)(nx + 1) * j)) + tph_cond(ph.m, ph.f.phase_qx + ph.m.nphase * (iR + (i64)(nx + 1) * j))) * 0.5;
+            if constexpr (PH) Kx = (tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qx + tph_nph(ph) * (iL + (i64)(nx + 1) * j)) + tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qx + tph_nph(ph) * (iR + (i64)(nx + 1) * j))) * 0.5;
             else Kx = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[iL + (i64)nx * j] + a.t.K[iR + (i64)nx * j]) * 0.5;
             const double thx = (th[iL + (i64)nx * j] + th[iR + (i64)nx * j]) * 0.5;
             const double qx = -Kx * (TT_(i + 1, j + 1) - TT_(i, j + 1)) * (a.p.inv_spacing[0] ? a.p.inv_spacing[0][clampi(i, 0, nx - 2)] : a.p._dx);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_flux2d(const TArgs a, const PHT ph)
         else {
             const int jB = clampi(j - 1, 0, ny - 1), jT = clampi(j, 0, ny - 1);
             double Ky;
-            if constexpr (PH) Ky = (tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * jB)) + tph_cond(ph.m, ph.f.phase_qy + ph.m.nphase * (i + (i64)nx * jT))) * 0.5;
+            if constexpr (PH) Ky = (tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qy + tph_nph(ph) * (i + (i64)nx * jB)) + tph_cond<tph_np<PHT>::value>(ph.m, ph.f.phase_qy + tph_nph(ph) * (i + (i64)nx * jT))) * 0.5;
             else Ky = a.p.rheology_form ? (a.p.k_const + a.p.k_const) * 0.5 : (a.t.K[i + (i64)nx * jB] + a.t.K[i + (i64)nx * jT]) * 0.5;
             const double thy = (th[i + (i64)nx * jB] + th[i + (i64)nx * jT]) * 0.5;
             const double qy = -Ky * (TT_(i + 1, j + 1) - TT_(i + 1, j)) * (a.p.inv_spacing[1] ? a.p.inv_spacing[1][clampi(j, 0, ny - 2)] : a.p._dy);
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
     const double Tij = a.t.T[I1];
     double rcp, Hr = 0.0;
     if constexpr (PH) {
-        const double *rc = ph.f.phase_c + ph.m.nphase * c;
-        rcp = tph_rhoCp(ph.m, rc, Tij, ph.f.P[c]);
-        Hr = tph_Hr(ph.m, rc);
+        const double *rc = ph.f.phase_c + tph_nph(ph) * c;
+        rcp = tph_rhoCp<tph_np<PHT>::value>(ph.m, rc, Tij, ph.f.P[c]);
+        Hr = tph_Hr<tph_np<PHT>::value>(ph.m, rc);
     } else rcp = rhoCp_of(a.p, a.t.rhoCp, c, Tij);
     // optional terms: + adiabatic * T in the rheology forms; Dirichlet cells (mask != 0) take (1 - m) T + m value and have no residual
     const bool hasadi = a.p.rheology_form != 0 && a.t.adiabatic != nullptr;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_updateT2d(const TArgs a, const PHT ph)
         if constexpr (PH) {
             if (a.wpt) {      // update_pt_thermal_arrays! of the next iteration (DiffusionPT_coefficients.jl:123-136) from the new T of this cell
                 double th_, dr_;
-                tph_pt_coeffs(ph.m, ph.f.phase_c + ph.m.nphase * c, Tn, ph.f.P[c], _dt, th_, dr_);
+                tph_pt_coeffs<tph_np<PHT>::value>(ph.m, ph.f.phase_c + tph_nph(ph) * c, Tn, ph.f.P[c], _dt, th_, dr_);
                 a.t.thetar_dtau[c] = th_;
                 a.t.dtau_rho[c] = dr_;
             }
@@ -631,6 +631,12 @@ jrx_status jrx_heatdiffusion_PT2d_phases(jrx_handle *h, const jrx_thermal2d_fiel
     q.rheology_form = 2;
     TPh x;
     x.m = *ph; x.f = *pf;
+    switch (h->thermal_np_const ? ph->nphase : 0) {       // option "thermal_np_const" (default): the instantiations with the phase count as a constant
+#define TPN(N_) case N_: { TPhN<N_> y; y.m = *ph; y.f = *pf; return heat2d(h, t, &q, y, iter_count, norm_ResT, cap, nnorms); }
+    TPN(1) TPN(2) TPN(3) TPN(4)
+#undef TPN
+    default: break;
+    }
     return heat2d(h, t, &q, x, iter_count, norm_ResT, cap, nnorms);
 }
 

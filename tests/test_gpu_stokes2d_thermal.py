@@ -304,3 +304,81 @@ def test_graph_replay_of_unobserved_iterations_changes_nothing(env):
         assert np.array_equal(a[3][k], b_[3][k], equal_nan=True), k
     assert a[4] == b_[4] and a[5] == b_[5] > 400
     assert np.array_equal(a[6], b_[6]) and np.array_equal(a[7], b_[7])
+
+
+@pytest.mark.parametrize("ni,bcs,dt", [((130, 67), "free_slip", 0.25), ((64, 200), "no_slip", 0.25), ((200, 33), "none", 0.25), ((17, 9), "free_slip", 0.25), ((63, 5), "no_slip", 0.25),
+                                       ((130, 67), "free_slip", np.inf), ((64, 200), "no_slip", np.inf), ((200, 33), "none", np.inf), ((126, 9), "free_slip", np.inf), ((3, 3), "free_slip", np.inf)])
+def test_2d_fused_iteration_with_batched_loads_is_bit_identical(env, ni, bcs, dt):
+    """k_fused2d_b (every operand of the one-launch iteration requested up front, boundary cases as selects; dt = Inf: its viscous-limit instantiation, which does not load
+    τ_o, P0, K, G, Q -- here random and non-zero) against the control-flow form k_fused2d and the two-kernel loop: identical fields and residual history, rows that span
+    several waves, rows of exactly one and two wave segments, the smallest grid"""
+    jr = env["jr"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields2d(ni, bcs=bcs, dt=dt, iterMax=23, nout=7)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    outs, its, used = [], [], []
+    h = _lib.default_handle()
+    try:
+        for variant, batch in ((2, 1), (3, 0), (3, 1)):
+            h.set_option("kernel_variant", variant)
+            h.set_option("fused2d_batch", batch)
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            c0 = (h.get_option("stat_fused2d"), h.get_option("stat_visc_checks"), h.get_option("stat_visc_fallbacks"))
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, G, K, s.dt, None, kwargs=s.kwargs)
+            used.append((h.get_option("stat_fused2d") - c0[0], h.get_option("stat_visc_checks") - c0[1], h.get_option("stat_visc_fallbacks") - c0[2]))
+            its.append((r.iter, tuple(r.err_evo1)))
+            outs.append(env["down"](stokes))
+    finally:
+        h.set_option("kernel_variant", 0)
+        h.set_option("fused2d_batch", 1)
+    assert used[0][0] == 0 and used[1][0] > 0 and used[2][0] == used[1][0]
+    assert used[2][1:] == ((1, 0) if np.isinf(dt) else (0, 0)) and used[1][1:] == (0, 0)       # the operand check runs once per solve of the viscous-limit form, and passes
+    assert its[0] == its[1] == its[2] and its[0][0] == 24
+    for v in (1, 2):
+        for k in outs[0]:
+            a, b = outs[0][k], outs[v][k]
+            if k in ("Vx", "Vy", "Ux", "Uy"):      # the four ghost corners are not read by any stencil
+                a, b = a.copy(), b.copy()
+                for c in ((0, 0), (0, -1), (-1, 0), (-1, -1)):
+                    a[c] = b[c]
+            assert np.array_equal(a, b, equal_nan=True), (v, k)
+
+
+@pytest.mark.parametrize("poison", ["toxx=nan", "toxy=inf", "P0=inf", "Q=nan", "K=0", "G=nan"])
+def test_2d_viscous_limit_falls_back_when_an_unloaded_operand_is_not_harmless(env, poison):
+    """as test_viscous_limit_falls_back_when_an_unloaded_operand_is_not_harmless in 3D: with dt = Inf a NaN / Inf in τ_o, P0, Q (or K, G = 0 or NaN) makes the reference's
+    run NaN; the viscous-limit form of the one-launch 2D iteration never reads them, so the operand check sends the solve to the general form: same status and fields as the
+    control-flow kernel, which loads everything"""
+    jr = env["jr"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields2d((70, 20), bcs="free_slip", dt=np.inf, iterMax=23, nout=7)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    name, val = poison.split("=")
+    s.arrays[name][7, 5] = {"nan": np.nan, "inf": np.inf, "0": 0.0}[val]
+    h = _lib.default_handle()
+    res = []
+    try:
+        for batch in (1, 0):
+            h.set_option("kernel_variant", 3)
+            h.set_option("fused2d_batch", batch)
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            c0 = (h.get_option("stat_visc_checks"), h.get_option("stat_visc_fallbacks"))
+            try:
+                r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, G, K, s.dt, None, kwargs=s.kwargs)
+                status = ("ok", r.iter)
+            except _lib.JrxError as e:
+                status = ("error", str(e))
+            res.append((status, env["down"](stokes), (h.get_option("stat_visc_checks") - c0[0], h.get_option("stat_visc_fallbacks") - c0[1])))
+    finally:
+        h.set_option("kernel_variant", 0)
+        h.set_option("fused2d_batch", 1)
+    (st1, out1, d1), (st0, out0, d0) = res
+    assert d1 == (1, 1) and d0 == (0, 0)
+    assert st1 == st0, (st1, st0)            # (the 2D visco-elastic loop leaves with NaN norms where the 3D one raises: Stokes2D.jl has no error("NaN(s)"))
+    assert np.isnan(out1["P"]).any()
+    for k in ("P", "Vx", "Vy", "txx", "tyy", "txy"):
+        a, b = out1[k].copy(), out0[k].copy()
+        if k in ("Vx", "Vy"):
+            for c in ((0, 0), (0, -1), (-1, 0), (-1, -1)):
+                a[c] = b[c]
+        assert np.array_equal(a, b, equal_nan=True), k
