@@ -613,6 +613,16 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     out["ipc_two_processes"] = run_ipc_helpers()
+    # What the leg quotes: one PROCESS per block (the deployment of the reference, test/runtests.jl:73-90 mpiexec -n 2, and of the Julia extension) when that ran; the in-process figures above
+    # come from two host threads of one interpreter and carry their scheduling noise (4 - 17 % between runs of the same pipeline)
+    try:
+        ipc = out["ipc_two_processes"]
+        worst = max(((ipc[f"split_{n_}"]["default"]["overhead_pct"], f"ipc_two_processes/split_{n_}/default", ipc[f"split_{n_}"]["default"]) for n_ in splits if f"split_{n_}" in ipc),
+                    key=lambda t: t[0])
+        out["in_process_quoted"] = {"quoted": out["quoted"], "it_per_s": out["it_per_s"], "overhead_pct": out["overhead_pct"]}
+        out["it_per_s"], out["overhead_pct"], out["quoted"] = worst[2]["block_it_per_s"], worst[0], worst[1]
+    except Exception:
+        pass
     return out
 
 
