@@ -1,0 +1,160 @@
+// kbench_int.hip -- k_fused3d on the interior box of tiles: the shipped instantiation against the one that knows it is interior (INT; development tool).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I justrelax.jl_amd/csrc scripts/kbench_int.hip -o scripts/kbench_int
+//   ./scripts/kbench_int [n=512] [reps=20]
+// Every variant's ten output arrays are compared bit for bit with the shipped configuration's.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "jrx_internal.hpp"
+#include "stokes3d_kernels.hpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void k_fill(double *p, i64 n, unsigned seed, double lo, double hi, int expo)
+{
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        unsigned long long x = (unsigned long long)t * 6364136223846793005ULL + seed * 1442695040888963407ULL + 1013904223ULL;
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0), v = lo + (hi - lo) * u;
+        p[t] = expo ? pow(10.0, v) : v;
+    }
+}
+__global__ void k_ndiff(const double *a, const double *b, i64 n, unsigned long long *out)
+{
+    unsigned long long m = 0;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x)
+        if (__double_as_longlong(a[t]) != __double_as_longlong(b[t])) m += 1;
+    if (m) atomicAdd(out, m);
+}
+template <int NR, int NW, int NT>
+struct StreamArgs { const double *r[NR > 0 ? NR : 1]; double *w[NW > 0 ? NW : 1]; i64 n; };
+// pure streaming kernel with the stream mix of a sweep: NR arrays read, NW written, 8 B per lane, NT: non-temporal stores
+template <int NR, int NW, int NT>
+__global__ __launch_bounds__(256) void k_stream(StreamArgs<NR, NW, NT> a)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n) return;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; q++) acc += a.r[q][t];
+#pragma unroll
+    for (int q = 0; q < NW; q++) {
+        if (NT) __builtin_nontemporal_store(acc + q, a.w[q] + t);
+        else a.w[q][t] = acc + q;
+    }
+}
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
+    template <class F> double run(int reps, F f)
+    {
+        f(); f();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a, 0));
+        for (int r = 0; r < reps; r++) f();
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        return ms / reps;
+    }
+};
+
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 512, reps = argc > 2 ? atoi(argv[2]) : 20;
+    const int nx = n, ny = n, nz = n;
+    const double cells = (double)nx * ny * nz;
+    jrx_stokes3d_fields f;
+    memset(&f, 0, sizeof(f));
+    struct Ent { double **p; i64 n; double lo, hi; int expo; };
+    const i64 nc = (i64)nx * ny * nz, nvx = (i64)(nx + 1) * (ny + 2) * (nz + 2), nvy = (i64)(nx + 2) * (ny + 1) * (nz + 2),
+              nvz = (i64)(nx + 2) * (ny + 2) * (nz + 1), nxy = (i64)(nx + 1) * (ny + 1) * nz, nyz = (i64)nx * (ny + 1) * (nz + 1),
+              nxz = (i64)(nx + 1) * ny * (nz + 1);
+    std::vector<Ent> ents = {
+        {&f.P, nc, -1, 1, 0}, {&f.Vx, nvx, -1, 1, 0}, {&f.Vy, nvy, -1, 1, 0}, {&f.Vz, nvz, -1, 1, 0},
+        {&f.txx, nc, -1, 1, 0}, {&f.tyy, nc, -1, 1, 0}, {&f.tzz, nc, -1, 1, 0}, {&f.tyz, nyz, -1, 1, 0}, {&f.txz, nxz, -1, 1, 0}, {&f.txy, nxy, -1, 1, 0},
+        {&f.eta, nc, -3, 0, 1}, {&f.fx, nc, -1, 1, 0}, {&f.fy, nc, -1, 1, 0}, {&f.fz, nc, -1, 1, 0},
+        {&f.toxx, nc, -1, 1, 0}, {&f.toyy, nc, -1, 1, 0}, {&f.tozz, nc, -1, 1, 0}, {&f.toyz, nyz, -1, 1, 0}, {&f.toxz, nxz, -1, 1, 0}, {&f.toxy, nxy, -1, 1, 0},
+        {&f.P0, nc, -1, 1, 0}, {&f.Q, nc, -0.1, 0.1, 0}, {&f.K, nc, 1, 2, 0}, {&f.G, nc, 1, 2, 0}};
+    unsigned seed = 1;
+    for (auto &e : ents) {
+        CK(hipMalloc(e.p, e.n * sizeof(double)));
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, *e.p, e.n, seed++, e.lo, e.hi, e.expo);
+    }
+    double *etatau;
+    CK(hipMalloc(&etatau, nc * sizeof(double)));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, etatau, nc, 99u, 0.5, 1.5, 0);
+    SweepArgs a;
+    a.f = f; a.etatau = etatau; a._dx = 51.2; a._dy = 49.0; a._dz = 47.5; a.dt = INFINITY; a.r = 0.7; a.theta_dtau = 191.3; a.eta_dtau = 0.0119;
+    a.L = make_lay(nx, ny, nz);
+    a.i0 = a.j0 = a.k0 = 0;
+    Out10 dst, ref;
+    const i64 dn[10] = {nc, nc, nc, nc, nyz, nxz, nxy, nvx, nvy, nvz};
+    double **dp[10] = {&dst.P, &dst.txx, &dst.tyy, &dst.tzz, &dst.tyz, &dst.txz, &dst.txy, &dst.Vx, &dst.Vy, &dst.Vz};
+    double **rp[10] = {&ref.P, &ref.txx, &ref.tyy, &ref.tzz, &ref.tyz, &ref.txz, &ref.txy, &ref.Vx, &ref.Vy, &ref.Vz};
+    for (int q = 0; q < 10; q++) {
+        CK(hipMalloc(dp[q], dn[q] * sizeof(double)));
+        CK(hipMalloc(rp[q], dn[q] * sizeof(double)));
+        CK(hipMemset(*dp[q], 0, dn[q] * sizeof(double)));
+        CK(hipMemset(*rp[q], 0, dn[q] * sizeof(double)));
+    }
+    unsigned long long *d_cnt;
+    CK(hipMalloc(&d_cnt, 8));
+    CK(hipDeviceSynchronize());
+    FusedBC bc;
+    memset(&bc, 0, sizeof(bc));
+    bc.fsL = bc.fsF = bc.fsK0 = bc.fsR = bc.fsBk = bc.fsK1 = 1;
+    Timer T;
+    constexpr int TX = 64, TY = 4, KZ = 8;
+    const int ntx = (nx + TX - 3) / (TX - 2), nty = (ny + TY - 2) / (TY - 1), ntz = (nz + KZ - 1) / KZ;
+    // interior box of tiles: every thread 0 < i < nx-1, 0 < j < ny-1, every plane 0 < k < nz-1
+    int bx1 = ntx - 1; while (bx1 > 1 && bx1 * (TX - 2) >= nx - 1) bx1--;          // tiles [1, bx1): max i = bx1 * 62 < nx - 1
+    int by1 = nty - 1; while (by1 > 1 && (by1 - 1) * (TY - 1) + 2 >= ny - 1) by1--; // tiles [1, by1): max j = (by1-1)*3 + 2 < ny - 1
+    int bz1 = ntz - 1; while (bz1 > 1 && bz1 * KZ >= nz - 1 + 1) bz1--;            // chunks [1, bz1): kend = bz1 * KZ < nz  ->  k <= kend - 1 < nz - 1
+    const int iw = bx1 - 1, ih = by1 - 1, id = bz1 - 1;
+    printf("kbench_int n=%d reps=%d: tiles %d x %d x %d, interior box %d x %d x %d = %.1f %% of the tiles\n", n, reps, ntx, nty, ntz, iw, ih, id, 100.0 * iw * ih * id / ((double)ntx * nty * ntz));
+    const double frac = (double)iw * ih * id / ((double)ntx * nty * ntz);
+    auto cmp = [&]() {
+        unsigned long long tot = 0;
+        for (int q = 0; q < 10; q++) {
+            CK(hipMemset(d_cnt, 0, 8));
+            hipLaunchKernelGGL(k_ndiff, dim3(4096), dim3(256), 0, 0, *dp[q], *rp[q], dn[q], d_cnt);
+            unsigned long long c;
+            CK(hipMemcpy(&c, d_cnt, 8, hipMemcpyDeviceToHost));
+            tot += c;
+        }
+        return tot;
+    };
+    for (int rep = 0; rep < 2; rep++) {
+        {   // viscous-limit form, the shipped single-rank instantiation (HIF + VFOLD)
+            SweepArgs b = a; b.o = ref;
+            const double ms_all = T.run(reps, [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3(ntx * nty * ntz), dim3(TX * TY), 0, 0, b, bc, ntx, nty, 0, 0, 0); });
+            const double ms_box = T.run(reps, [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3(iw * ih * id), dim3(TX * TY), 0, 0, b, bc, iw, ih, 1, 1, 1); });
+            SweepArgs c = a; c.o = dst;
+            for (int q = 0; q < 10; q++) CK(hipMemcpy(*dp[q], *rp[q], dn[q] * sizeof(double), hipMemcpyDeviceToDevice));
+            const double ms_int = T.run(reps, [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, false, true>), dim3(iw * ih * id), dim3(TX * TY), 0, 0, c, bc, iw, ih, 1, 1, 1); });
+            printf("viscous form: whole grid %.3f ms | interior box: shipped kernel %.3f ms, INT kernel %.3f ms (x %.3f) | mismatches %llu | projected whole grid %.3f ms (x %.3f)\n", ms_all, ms_box, ms_int,
+                   ms_box / ms_int, cmp(), ms_all - ms_box + ms_int, ms_all / (ms_all - ms_box + ms_int));
+            fflush(stdout);
+        }
+        {   // general form (finite dt), the shipped instantiation (LOWREG)
+            SweepArgs b = a; b.o = ref; b.dt = 0.37;
+            const double ms_all = T.run(reps, [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1>), dim3(ntx * nty * ntz), dim3(TX * TY), 0, 0, b, bc, ntx, nty, 0, 0, 0); });
+            const double ms_box = T.run(reps, [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1>), dim3(iw * ih * id), dim3(TX * TY), 0, 0, b, bc, iw, ih, 1, 1, 1); });
+            SweepArgs c = b; c.o = dst;
+            for (int q = 0; q < 10; q++) CK(hipMemcpy(*dp[q], *rp[q], dn[q] * sizeof(double), hipMemcpyDeviceToDevice));
+            const double ms_int = T.run(reps, [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 0, false, false, false, false, true>), dim3(iw * ih * id), dim3(TX * TY), 0, 0, c, bc, iw, ih, 1, 1, 1); });
+            printf("general form: whole grid %.3f ms | interior box: shipped kernel %.3f ms, INT kernel %.3f ms (x %.3f) | mismatches %llu | projected whole grid %.3f ms (x %.3f)\n", ms_all, ms_box, ms_int,
+                   ms_box / ms_int, cmp(), ms_all - ms_box + ms_int, ms_all / (ms_all - ms_box + ms_int));
+            fflush(stdout);
+        }
+    }
+    (void)frac; (void)cells;
+    printf("done\n");
+    return 0;
+}
