@@ -1,4 +1,6 @@
 // kbench_int.hip -- k_fused3d on the interior box of tiles: the shipped instantiation against the one that knows it is interior (INT; development tool).
+// RECORD OF AN EXPERIMENT THAT WAS NOT SHIPPED (profiles/r04_interior_tiles_kernel.txt): building it needs a 17th template parameter `bool INT` on k_fused3d that states
+//   __builtin_assume(i > 0 && i < nx - 1 && j > 0 && j < ny - 1 && kb > 0 && kb + KZ < nz) once and __builtin_assume(k > 0 && k < nz - 1) per plane; the tree does not carry it.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I justrelax.jl_amd/csrc scripts/kbench_int.hip -o scripts/kbench_int
 //   ./scripts/kbench_int [n=512] [reps=20]
 // Every variant's ten output arrays are compared bit for bit with the shipped configuration's.
