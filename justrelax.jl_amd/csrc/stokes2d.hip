@@ -993,6 +993,54 @@ __global__ __launch_bounds__(256) void k_vep_strain_inc(const VepArgs a)
 #undef UY
 }
 // compute_stress_increment(τ, τ_o, η, Δε, _G, dτ_r, dt) -- StressKernels.jl:18-21
+// k_vep_pre<ML = true> for uniform grids and constant densities with every operand requested up front (option "fused2d_batch"): the control-flow form issues its 24 loads in five
+// dependent groups (the 3 x 3 window of η compares as it loads, every `if (a.obs)` ends a basic block); same arithmetic, expression for expression.  OBS: a.obs as a constant.
+template <bool OBS>
+__global__ __launch_bounds__(256) void k_vep_pre_b(const VepArgs a, double *__restrict__ theta)
+{
+    const int nx = a.nx, ny = a.ny;
+    const int t = xcd_slab_block() * blockDim.x + threadIdx.x;
+    const int j = t / (nx + 1), i = t - j * (nx + 1);
+    if (j > ny) return;
+    const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy;
+    const bool cell = i < nx && j < ny;
+    const int ic = min(i, nx - 1), jc = min(j, ny - 1);
+    const i64 c = ic + (i64)nx * jc;
+    // velocities: Vx[i, j], Vx[i, j+1], Vx[i+1, j+1] (cells only), Vy[i, j], Vy[i+1, j], Vy[i+1, j+1] (cells only)
+    const i64 qx = i + (i64)(nx + 1) * j, qy = i + (i64)(nx + 2) * j;
+    const double x00 = Vx[qx], x01 = Vx[qx + (nx + 1)], x11 = Vx[qx + (nx + 1) + (i < nx ? 1 : 0)];
+    const double y00 = Vy[qy], y10 = Vy[qy + 1], y11 = Vy[qy + 1 + (j < ny ? nx + 2 : 0)];
+    const double Kc = a.Kc[c], Gc = a.Gc[c], P = theta[c], P0 = a.f.P0[c], Q = a.f.Q[c];
+    double w[9];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const i64 r = (i64)nx * clampi(jc + q - 1, 0, ny - 1);
+#pragma unroll
+        for (int m = 0; m < 3; m++) w[3 * q + m] = a.f.eta[clampi(ic + m - 1, 0, nx - 1) + r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (cell) {
+        const double dxi = (-x01 + x11) * a._dx;
+        const double dyi = (-y10 + y11) * a._dy;
+        const double divV = dxi + dyi;
+        if (OBS) a.f.divV[c] = divV;
+        const double _Kdt = 1.0 / (Kc * a.dt), _Gdt = 1.0 / (Gc * a.dt), _dt = 1.0 / a.dt;
+        const double rhs = -divV + (Q * _dt);
+        if (OBS) a.f.RP[c] = fma(-(P - P0), _Kdt, rhs);
+        double et = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 9; q++)
+            if (w[q] > et) et = w[q];
+        const_cast<double *>(a.etatau)[c] = et;
+        const double psi = 1.0 / (1.0 / et + _Gdt) * a.r / a.theta_dtau;
+        theta[c] = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
+        const double d3 = divV * (1.0 / 3.0);
+        a.f.exx[c] = dxi - d3;
+        a.f.eyy[c] = dyi - d3;
+    }
+    a.f.exy[qx] = 0.5 * (a._dy * (x01 - x00) + a._dx * (y10 - y00));
+}
+
 __device__ __forceinline__ double dev_stress_inc_dt(double t, double to, double eta, double de, double _G, double dtr, double dt)
 {
     return dtr * fma(2.0 * eta, de, fma(-(t - to) * eta, _G, -t * dt));
@@ -1319,6 +1367,68 @@ __global__ __launch_bounds__(256) void k_vep_visc_velocity(const VepArgs a, cons
     vep_visc_at(a, t);
     const int j = (int)(t / b.nx), i = (int)(t - (i64)j * b.nx);
     if (j < b.ny) velocity2d_cell<false, BCF>(b, i, j);
+}
+
+// k_vep_visc_velocity for laws whose η reads no field (the phase average is precomputed), uniform grids and no free surface, with every operand requested up front (option
+// "fused2d_batch").  The general kernel carries the field-reading creep laws, the non-uniform spacings and the free-surface correction as run-time branches: 3,200 ISA lines, 68
+// branches, its 48 loads in ~20 dependent groups.  Same arithmetic on the path it takes for these inputs, expression for expression.
+template <bool BCF>
+__global__ __launch_bounds__(256) void k_vep_visc_velocity_b(const VepArgs a, const Args2 b)
+{
+    const i64 t = (i64)xcd_slab_block() * blockDim.x + threadIdx.x;
+    const int nx = b.nx, ny = b.ny;
+    const i64 nc = (i64)nx * ny, nv = (i64)(nx + 1) * (ny + 1);
+    const bool cell = t < nc, vert = a.f.eta_v != nullptr && t < nv;
+    const i64 c = cell ? t : 0, tv = t < nv ? t : 0;
+    const int j = (int)(c / nx), i = (int)(c - (i64)j * nx);
+    const i64 cx = c + (i < nx - 1 ? 1 : 0), cy = c + (j < ny - 1 ? nx : 0);
+    const double *__restrict__ P = b.f.P, *__restrict__ txy = b.f.txy, *__restrict__ et = b.etatau;
+    const i64 qx = (i + 1) + (i64)(nx + 1) * (j + 1), qy = (i + 1) + (i64)(nx + 2) * (j + 1);
+    // ---- every operand
+    const double el = a.eta_lin_c[c], eo = a.f.eta[c];
+    double elv = 0.0, eov = 0.0;
+    if (a.f.eta_v) { elv = a.eta_lin_v[tv]; eov = a.f.eta_v[tv]; }
+    const double P0 = P[c], Px = P[cx], Py = P[cy], X0 = b.f.txx[c], X1 = b.f.txx[cx], Y0 = b.f.tyy[c], Y1 = b.f.tyy[cy];
+    const double S10 = txy[(i + 1) + (i64)(nx + 1) * j], S11 = txy[(i + 1) + (i64)(nx + 1) * (j + 1)], S01 = txy[i + (i64)(nx + 1) * (j + 1)];
+    const double fx0 = b.f.fx[c], fx1 = b.f.fx[cx], fy0 = b.f.fy[c], fy1 = b.f.fy[cy];
+    const double E0 = et[c], Ex = et[cx], Ey = et[cy];
+    const double vx0 = b.f.Vx[qx], vy0 = b.f.Vy[qy];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- compute_viscosity! (vep_visc_at, laws without fields)
+    if (cell) {
+        double e = el;
+        e = e * a.nu + eo * (1.0 - a.nu);
+        a.f.eta[c] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+    }
+    if (vert) {
+        double e = elv;
+        e = e * a.nu + eov * (1.0 - a.nu);
+        a.f.eta_v[tv] = fmin(fmax(e, a.cut_lo), a.cut_hi);
+    }
+    if (!cell) return;
+    // ---- compute_V! (velocity2d_cell<false, BCF>, uniform spacing, fs_dt = 0)
+    const double edt = b.eta_dtau, _dx = b._dx, _dy = b._dy;
+    if (i < nx - 1) {
+        const double dP = (-P0 + Px) * _dx, dT = (-X0 + X1) * _dx;
+        const double dS = (-S10 + S11) * _dy, av = (fx0 + fx1) * 0.5;
+        const double v = vx0 + (-dP + dT + dS - av) * edt / ((E0 + Ex) * 0.5);
+        b.f.Vx[qx] = v;
+        if (BCF) {      // Vx ghost rows j = 0 (bot) and j = ny+1 (top)
+            if (j == 0) { if (b.fs & JRX_FACE_BOT) b.f.Vx[qx - (nx + 1)] = v; else if (b.ns & JRX_FACE_BOT) b.f.Vx[qx - (nx + 1)] = -v; }
+            if (j == ny - 1) { if (b.fs & JRX_FACE_TOP) b.f.Vx[qx + (nx + 1)] = v; else if (b.ns & JRX_FACE_TOP) b.f.Vx[qx + (nx + 1)] = -v; }
+        }
+    }
+    if (j < ny - 1) {
+        const double dP = (-P0 + Py) * _dy, dT = (-Y0 + Y1) * _dy;
+        const double dS = (-S01 + S11) * _dx, av = (fy0 + fy1) * 0.5;
+        const double rhs = -dP + dT + dS - av;
+        const double v = vy0 + rhs * edt / ((E0 + Ey) * 0.5);
+        b.f.Vy[qy] = v;
+        if (BCF) {      // Vy ghost columns i = 0 (left) and i = nx+1 (right)
+            if (i == 0) { if (b.fs & JRX_FACE_LEFT) b.f.Vy[qy - 1] = v; else if (b.ns & JRX_FACE_LEFT) b.f.Vy[qy - 1] = -v; }
+            if (i == nx - 1) { if (b.fs & JRX_FACE_RIGHT) b.f.Vy[qy + 1] = v; else if (b.ns & JRX_FACE_RIGHT) b.f.Vy[qy + 1] = -v; }
+        }
+    }
 }
 
 // rho: also compute_ρg!(ρg, phase_ratios, rheology, args) (Stokes2D.jl:646)
@@ -1648,6 +1758,10 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
         JRX_LAUNCH_CHECK(h);
     }
     b.fs_dt = p->free_surface ? p->dt : 0.0;      // dt * free_surface with a Bool: Inf * false == 0.0 in Julia (solve! with dt = Inf)
+    // option "fused2d_batch" (default): the forms of the pre and viscosity + velocity kernels that request every operand up front -- uniform grids, constant densities, viscosity laws
+    // without fields (phase average precomputed), no free surface; everything else keeps the general kernels
+    const bool batch_pre = h->fused2d_batch && !p->inv_spacing[0] && !upd_rho;
+    const bool batch_vv = h->fused2d_batch && !p->inv_spacing[0] && b.fs_dt == 0.0 && !a.vfields && a.eta_lin_c != nullptr && (a.f.eta_v == nullptr || a.eta_lin_v != nullptr);
 
     double err_it1 = 1.0, err = 1.0;
     int64_t iter = 0, cont = 0;
@@ -1676,6 +1790,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                         Args2 bb = b;
                         for (int q = 0; q < GIT; q++) {
                             if (upd_rho) hipLaunchKernelGGL((k_vep_pre<true, true>), dim3(gv), dim3(256), 0, s, aa, theta);
+                            else if (batch_pre) { if (aa.obs) hipLaunchKernelGGL(k_vep_pre_b<true>, dim3(gv), dim3(256), 0, s, aa, theta); else hipLaunchKernelGGL(k_vep_pre_b<false>, dim3(gv), dim3(256), 0, s, aa, theta); }
                             else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, aa, theta);
                             if (aa.soft) hipLaunchKernelGGL(k_vep_stress2d<true>, dim3(gv), dim3(256), 0, s, aa);
                             else switch (h->vep3_np_const ? aa.rh.nphase : 0) {
@@ -1688,7 +1803,8 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
                             { double *t_ = aa.f.txx; aa.f.txx = aa.txx_out; aa.txx_out = t_; }
                             { double *t_ = aa.f.tyy; aa.f.tyy = aa.tyy_out; aa.tyy_out = t_; }
                             bb.f.txx = aa.f.txx; bb.f.tyy = aa.f.tyy;
-                            hipLaunchKernelGGL(k_vep_visc_velocity<true>, dim3(gv), dim3(256), 0, s, aa, bb);
+                            if (batch_vv) hipLaunchKernelGGL(k_vep_visc_velocity_b<true>, dim3(gv), dim3(256), 0, s, aa, bb);
+                            else hipLaunchKernelGGL(k_vep_visc_velocity<true>, dim3(gv), dim3(256), 0, s, aa, bb);
                         }
                         ok = hipStreamEndCapture(s, &gr) == hipSuccess && gr != nullptr;
                     }
@@ -1719,6 +1835,7 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             if (upd_rho) hipLaunchKernelGGL((k_vep_pre<false, true>), dim3(gv), dim3(256), 0, s, a, theta);
             else hipLaunchKernelGGL(k_vep_pre<false>, dim3(gv), dim3(256), 0, s, a, theta);
         } else if (upd_rho) hipLaunchKernelGGL((k_vep_pre<true, true>), dim3(gv), dim3(256), 0, s, a, theta);
+        else if (batch_pre) { if (a.obs) hipLaunchKernelGGL(k_vep_pre_b<true>, dim3(gv), dim3(256), 0, s, a, theta); else hipLaunchKernelGGL(k_vep_pre_b<false>, dim3(gv), dim3(256), 0, s, a, theta); }
         else hipLaunchKernelGGL(k_vep_pre<true>, dim3(gv), dim3(256), 0, s, a, theta);      // compute_maxloc! folded in
         JRX_LAUNCH_CHECK(h);
         if (a.si) {
@@ -1755,7 +1872,9 @@ jrx_status jrx_stokes2d_vep_solve(jrx_handle *h, const jrx_vep2d_fields *f, cons
             const bool next_last = next_check || iter + 1 > p->iterMax || (p->iterMin < iter + 1 && ((err / err_it1) < p->eps_rel || err < p->eps_abs));
             used_bcf = bcf && !next_last;
             // compute_viscosity! + compute_V! (free-surface form with dt*free_surface = 0) in one launch
-            if (used_bcf) hipLaunchKernelGGL(k_vep_visc_velocity<true>, dim3(gv), dim3(256), 0, s, a, b);
+            if (batch_vv && used_bcf) hipLaunchKernelGGL(k_vep_visc_velocity_b<true>, dim3(gv), dim3(256), 0, s, a, b);
+            else if (batch_vv) hipLaunchKernelGGL(k_vep_visc_velocity_b<false>, dim3(gv), dim3(256), 0, s, a, b);
+            else if (used_bcf) hipLaunchKernelGGL(k_vep_visc_velocity<true>, dim3(gv), dim3(256), 0, s, a, b);
             else hipLaunchKernelGGL(k_vep_visc_velocity<false>, dim3(gv), dim3(256), 0, s, a, b);
         }
         JRX_LAUNCH_CHECK(h);

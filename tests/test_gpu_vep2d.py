@@ -211,3 +211,36 @@ def test_epilogue_operators_2d(jr, oracle):
     nx, ny = s.ni
     want = 0.5 * ((-Vy[:nx + 1, :ny + 1] + Vy[1:nx + 2, :ny + 1]) * _dx - (-Vx[:nx + 1, :ny + 1] + Vx[:nx + 1, 1:ny + 2]) * _dy)
     assert np.array_equal(jr.to_numpy(stokes.ω.xy), want)
+
+
+@pytest.mark.parametrize("ni,iters,nout", [(32, 40, 10), (70, 37, 7), (63, 12, 5), (130, 45, 20), (256, 80, 40)])
+def test_vep2d_batched_kernels_equal_the_control_flow_kernels(jr, ni, iters, nout):
+    """option fused2d_batch: k_vep_pre_b and k_vep_visc_velocity_b (every operand requested up front; uniform grid, constant densities, viscosity laws without fields) against
+    k_vep_pre and k_vep_visc_velocity, and option vep3_np_const (the stress kernel's instantiation with the phase count as a constant) against the run-time loops: every field
+    of the solve bit for bit -- observed and unobserved iterations, graph replays at the small sizes, rows of one / several waves"""
+    from justrelax_jl_amd import _lib
+    h = _lib.default_handle()
+    outs, res = [], []
+    try:
+        for batch, npc in ((0, 0), (1, 1), (1, 0), (0, 1)):
+            h.set_option("fused2d_batch", batch)
+            h.set_option("vep3_np_const", npc)
+            s = jr.miniapps.shearband2d(ni, iterMax=iters - 1, nout=nout)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+            stokes, pr, ρg = _upload(jr, s)
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=s.kwargs)
+            outs.append(_download(jr, stokes))
+            res.append(r)
+    finally:
+        h.set_option("fused2d_batch", 1)
+        h.set_option("vep3_np_const", 1)
+    assert res[0].iter == iters
+    for v in (1, 2, 3):
+        assert res[v].iter == res[0].iter and np.array_equal(np.asarray(res[v].err_evo1), np.asarray(res[0].err_evo1))
+        for k in outs[0]:
+            a, b = outs[0][k], outs[v][k]
+            if k in ("Vx", "Vy", "Ux", "Uy"):      # the four ghost corners are not read by any stencil
+                a, b = a.copy(), b.copy()
+                for c in ((0, 0), (0, -1), (-1, 0), (-1, -1)):
+                    a[c] = b[c]
+            assert np.array_equal(a, b, equal_nan=True), (v, k)
