@@ -913,7 +913,9 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
 // Same arithmetic, operation for operation, as the three kernels: bit-identical (tests/test_gpu_vep3d.py::test_vep3d_fused_pre_centre_equals_the_three_kernels).
 // OBS: the launch stores the output-only arrays (a.obs as a compile-time constant: with the flag tested at run time every such store ends a basic block, and the
 // scheduler, which works one block at a time, can no longer issue the plane's loads as one batch -- seven dependent memory round trips per plane instead of two)
-template <bool SOFT, bool RHO, int NP = 0, bool OBS = true>
+// ML = false (ranks with neighbours): ητ arrives in a.etatau -- compute_maxloc! of the relaxed η and its update_halo! run on the halo stream beside the edge pass -- instead of being taken
+// from the 3 x 3 x 3 window of η here
+template <bool SOFT, bool RHO, int NP = 0, bool OBS = true, bool ML = true>
 __global__ __launch_bounds__(256, 3) void k_vep3_prec(const Vep3Args a, double *__restrict__ eta_out, const int KZ)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP > 0 ? NP : a.rh.nphase;
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(256, 3) void k_vep3_prec(const Vep3Args a, double *
         }
         return m;
     };
-    double m_prev = plane_max(k0 - 1), m_cur = plane_max(k0), m_next;
+    double m_prev = ML ? plane_max(k0 - 1) : 0.0, m_cur = ML ? plane_max(k0) : 0.0, m_next;
     // carried up the column: the velocities of plane k + 1 that plane k + 2's edges difference against, Vz of the cell's lower face, and the four edge strain rates of plane k
     double vx_a = LB(X11, ovx), vx_b = LB(X11, ovx + 8u), vy_a = LB(Y01, ovy + 8u), vy_b = LB(Y11, ovy + 8u), vz_c = LB(Z10, ovz + 8u);
     double e_yz0 = 0.5 * (_dz * (vy_a - LB(Y00, ovy + 8u)) + _dy * (vz_c - LB(Z00, ovz + 8u)));                      // eyz(i, j, k0)
@@ -996,12 +998,12 @@ __global__ __launch_bounds__(256, 3) void k_vep3_prec(const Vep3Args a, double *
         const double y00 = LB(Y01, ovy), y01 = LB(Y11, ovy), y20 = LB(Y01, ovy + 16u), y21 = LB(Y11, ovy + 16u);
         const double nx_a = LB(X12, ovx), nx_b = LB(X12, ovx + 8u), ny_a = LB(Y02, ovy + 8u), ny_b = LB(Y12, ovy + 8u);
         const double Kc_ = LB(a.Kc, oc), Gc_ = LB(a.Gc, oc), P = LB(a.theta, oc), P0 = LB(a.f.P0, oc), Q_ = LB(a.f.Q, oc);
-        double w9[9];
-        {
+        double w9[9], et_in = 0.0;
+        if (ML) {
             const double *const ep = a.f.eta + (i64)nx * ny * clampi3(k + 1, 0, nz - 1);
 #pragma unroll
             for (int q = 0; q < 3; q++) { w9[3 * q] = LB(ep, er[q] - dxl); w9[3 * q + 1] = LB(ep, er[q]); w9[3 * q + 2] = LB(ep, er[q] + dxr); }
-        }
+        } else et_in = LB(a.etatau, oc);
         const double e_lin = LB(a.eta_lin, oc), e_old = LB(a.f.eta, oc), l_old = LB(a.lam, oc);
         const i64 c = (i64)(oc >> 3);
         double rcv[NP > 0 ? NP : 1];
@@ -1023,15 +1025,18 @@ __global__ __launch_bounds__(256, 3) void k_vep3_prec(const Vep3Args a, double *
         const double _Kdt = 1.0 / (Kc_ * a.dt), _Gdt0 = 1.0 / (Gc_ * a.dt);
         const double rhs = -divV + (Q_ * _dt);
         if (OBS) SW(a.f.RP, oc) = fma(-(P - P0), _Kdt, rhs);
-        m_next = -INFINITY;
+        double et = et_in;
+        if (ML) {
+            m_next = -INFINITY;
 #pragma unroll
-        for (int q = 0; q < 9; q++)
-            if (w9[q] > m_next) m_next = w9[q];         // the comparison order of plane_max
-        double et = m_prev;
-        if (m_cur > et) et = m_cur;
-        if (m_next > et) et = m_next;
-        m_prev = m_cur; m_cur = m_next;
-        SW(const_cast<double *>(a.etatau), oc) = et;
+            for (int q = 0; q < 9; q++)
+                if (w9[q] > m_next) m_next = w9[q];         // the comparison order of plane_max
+            et = m_prev;
+            if (m_cur > et) et = m_cur;
+            if (m_next > et) et = m_next;
+            m_prev = m_cur; m_cur = m_next;
+            SW(const_cast<double *>(a.etatau), oc) = et;
+        }
         const double psi = 1.0 / (1.0 / et + _Gdt0) * a.r / a.theta_dtau;
         const double Pr = (fma(P0, _Kdt, rhs) * psi + P) / (1.0 + _Kdt * psi);
         SW(a.theta, oc) = Pr;
@@ -1657,15 +1662,32 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                 const int64_t ext[1][3] = {{nx, ny, nz}};
                 JRX_TRY(jrx_halo_exchange(h, s, 1, arrs, ext, nn));      // update_halo!(ητ) (Stokes3D.jl:515)
             }
+            // "vep3_fuse_pc" with neighbours: pre, viscosity relaxation and centre pass as one kernel here too (k_vep3_prec<ML = false>: ητ is the exchanged array); the centre pass then no longer
+            // runs beside update_halo!(τ.yz, τ.xz, τ.xy), which waits in line instead -- three thin planes against the ~0.3 ms the fusion saves at 256^3
+            const bool fuse_c = h->vep3_fuse_pc && lin && !a.soft && !upd_rho && h->vep3_np_const && a.rh.nphase <= 4;
+            if (fuse_c) {
+                for (int c_ = 0; c_ < 3; c_++) a.cnew[c_] = (c_ == 0 ? a.f.txx : (c_ == 1 ? a.f.tyy : a.f.tzz)) == cset[c_] ? user_c[c_] : cset[c_];
+                double *const eta_out = a.f.eta == f->eta ? eta2 : f->eta;
+                const dim3 gpc(gpre.x, (unsigned)((nz + 1 + PRE_KZ - 1) / PRE_KZ));
+                switch (a.rh.nphase * 2 + (a.obs ? 1 : 0)) {
+#define PRECC(NP_, OBS_) case NP_ * 2 + OBS_: hipLaunchKernelGGL((k_vep3_prec<false, false, NP_, OBS_ != 0, false>), gpc, dim3(256), 0, s, a, eta_out, PRE_KZ); break;
+                PRECC(1, 0) PRECC(1, 1) PRECC(2, 0) PRECC(2, 1) PRECC(3, 0) PRECC(3, 1) PRECC(4, 0) PRECC(4, 1)
+#undef PRECC
+                }
+                a.f.eta = eta_out;
+                g.eta = g.K = g.G = a.f.eta;
+                h->stat_vep3_fused++;
+            } else {
             if (upd_rho) hipLaunchKernelGGL((k_vep3_pre<false, true, PRE_KZ>), gpre, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((k_vep3_pre<false, false, PRE_KZ>), gpre, dim3(256), 0, s, a);
             launch_vep3_visc(s, gc, a, p->viscosity_relaxation, true);                               // update_viscosity_τII! :541
+            }
             JRX_LAUNCH_CHECK(h);
             JRX_HIP(h, hipEventRecord(h->ev[3], s));
             JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[3], 0));
             {
                 double *nxt = a.etatau == etatau ? etatau_next : etatau;
-                hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, hs, nxt, (const double *)f->eta, nx, ny, nz);
+                hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, hs, nxt, (const double *)a.f.eta, nx, ny, nz);
                 JRX_LAUNCH_CHECK(h);
                 double *arrs[1] = {nxt};
                 const int64_t ext[1][3] = {{nx, ny, nz}};
@@ -1684,7 +1706,11 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
                 JRX_TRY(jrx_halo_exchange(h, hs, 3, arrs, ext, nn));
             }
             JRX_HIP(h, hipEventRecord(h->ev[4], hs));
-            JRX_TRY(launch_vep3_stress(h, s, a, p, false, 2, true));     // centre pass, beside the exchange
+            if (fuse_c) {       // the centre pass ran inside k_vep3_prec: adopt its normal stresses
+                a.f.txx = a.cnew[0]; a.f.tyy = a.cnew[1]; a.f.tzz = a.cnew[2];
+                a.cnew[0] = a.cnew[1] = a.cnew[2] = nullptr;
+                g.txx = a.f.txx; g.tyy = a.f.tyy; g.tzz = a.f.tzz;
+            } else JRX_TRY(launch_vep3_stress(h, s, a, p, false, 2, true));     // centre pass, beside the exchange
             JRX_HIP(h, hipStreamWaitEvent(s, h->ev[4], 0));
             int bc_kind = 3;
             if (!ubc && !diag && !pre_diag && bcs_ordered && p->periodic == 0) bc_kind = 1;

@@ -310,14 +310,16 @@ def test_local_group_reports_an_absent_rank_instead_of_hanging(jr):
         assert e.value.status == 3 and "timed out" in str(e.value)
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("hide", [2, 1, 0])
 @pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (1, 1, 2)])
-def test_vep3d_two_blocks_equal_the_undecomposed_run(jr, dims, hide):
+def test_vep3d_two_blocks_equal_the_undecomposed_run(jr, dims, hide, fuse):
     """jrx_stokes3d_vep_solve on two blocks: update_halo!(ητ), update_halo!(τ.yz / τ.xz / τ.xy) and update_halo!(V) every iteration, norms over the
     ranks (Stokes3D.jl:515,578-580,582-597,607-612).  Two phases of equal viscosity but different G and cohesion, pre-stressed to yield: with a
     uniform η the clamped centre-to-edge averages on a block face only touch the edge nodes of the outermost plane, which the τ exchange replaces,
     so every block must equal the undecomposed device run bit for bit on the state arrays.  hide = 2 (default): the three exchanges run on the halo
-    stream beside independent kernels (@hide_communication of Stokes3D.jl:582-597 and more); hide = 1: ητ and the edge stresses only; hide = 0: in order on the compute stream."""
+    stream beside independent kernels (@hide_communication of Stokes3D.jl:582-597 and more); hide = 1: ητ and the edge stresses only; hide = 0: in order on the compute stream.
+    fuse = 1 (default): the blocks run pre, viscosity relaxation and centre pass as one kernel (k_vep3_prec<ML = false>, ητ from the exchanged array); 0: the three kernels."""
     import test_gpu_vep3d as tv
     import justrelax_jl_amd.grid as g
     from justrelax_jl_amd import halo
@@ -344,11 +346,14 @@ def test_vep3d_two_blocks_equal_the_undecomposed_run(jr, dims, hide):
             ups = []
             for r in range(2):
                 tb.handles[r].set_option("vep3_hide_comm", hide)
+                tb.handles[r].set_option("vep3_fuse_pc", fuse)
+                f0 = tb.handles[r].get_option("stat_vep3_fused")
                 loc = Setup(ni=n, arrays={k: B.local_block(v, n, ng, B.coords_of(tb.carts[r])) for k, v in S.arrays.items()})
                 ups.append(tv._upload(jr, loc))
             res = halo.run_ranks([(lambda r=r: jr.solve_(ups[r][0], S.pt, grid, S.flow_bcs, ups[r][2], ups[r][1], S.extra["phases"], None, S.dt, None, kwargs=kw,
                                                          handle=tb.handles[r])) for r in range(2)])
             outs = [tv._download(jr, u[0]) for u in ups]
+            assert (tb.handles[1].get_option("stat_vep3_fused") > f0) == bool(fuse)
         finally:
             g.finalize_global_grid()
     assert rg.iter == 24 and all(r.iter == 24 for r in res)
