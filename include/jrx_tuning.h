@@ -22,8 +22,8 @@
  *                                 3 = centre operands only; 1 = no LDS, one family per block; 2 = one launch per family; 0 = one node per thread
  *   "vep3_cfg", "vep3_peel", "vep3_peel_fork", "vep3_map", "vep3_xcd"     z-marching edge kernel: chunk depth / occupancy, peeling of a thin last segment, thread map, XCD slabs
  *   "vep3_nt" (0), "vep3_prekz" (0)   3D VEP: non-temporal stores of the edge pass; planes per thread of the z-marching pre kernel (0 = chosen by the grid size; 1, 2, 4, 8, 16, 32)
- *   "vep3_hide_comm" (1)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 (default: the fastest on one device) = the first two only,
- *                                 update_halo!(V) behind the whole velocity sweep; 0 = everything on the compute stream, in order (A/B)
+ *   "vep3_hide_comm" (0)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 = the first two only, update_halo!(V) behind the
+ *                                 whole velocity sweep; 0 (default: the fastest on one device since the pre / centre kernels are fused) = everything on the compute stream, in order
  *   "vep3_fuse_pc" (1)            3D VEP driver without neighbours, viscosity laws that read no field: compute_∇V! / compute_P! / compute_strain_rate!, update_viscosity_τII! and the centre half of
  *                                 update_stresses_center_vertex_ps! run as ONE kernel ahead of the edge half (0 = the three kernels, centre half behind the edge half); bit-identical
  *   "vep3_np_const" (1)           3D VEP centre pass / fused kernel: 1 = instantiations with the number of phases as a compile-time constant (1..4; 0 = the run-time loops, A/B)

@@ -62,9 +62,10 @@ struct jrx_handle {
     int vep3_cfg = 0;                        // z-marching edge kernel: KZ * 10 + min blocks per CU, 0 = default
     int vep3_edges = 4;                      // 3D VEP edge pass: 4 z-marching kernel, the three family waves of a row share the centre and shear operands through LDS;
                                              // 3 centre operands only, 1 no LDS (one family per block), 2 one launch per family, 0 one node per thread (A/B)
-    int vep3_hide_comm = 1;                  // multi-rank 3D VEP driver: 2 = the three exchanges of an iteration on the halo stream beside independent kernels; 1 (default) = ητ and the
-                                             // edge stresses only, update_halo!(V) behind the whole velocity sweep; 0 = serial.  Two 256^3 blocks on one device (profiles/r04_bench_default.json): +12.2 % (2),
-                                             // +8.6 % (1), +9.6 % (0) -- the six slab launches of (2) cost more than they hide until a real link shows otherwise
+    int vep3_hide_comm = 0;                  // multi-rank 3D VEP driver: 2 = the three exchanges of an iteration on the halo stream beside independent kernels; 1 = ητ and the edge stresses only,
+                                             // update_halo!(V) behind the whole velocity sweep; 0 (default) = everything in order on the compute stream.  Two 256^3 blocks on one device, with the fused
+                                             // pre / centre kernel (no centre pass left to hide the edge-stress exchange behind): +20 % (2), +17 % (1), +10 % (0) over two uncoupled blocks
+                                             // (gpurun_out/r04c; before the fusion +9.7 / +7.9 / +8.8 %) -- until a real link shows otherwise the measured-best form is the default
     bool fused2d_batch = true;               // 2D one-launch iteration: the form with every operand requested up front (k_fused2d_b), and its viscous-limit instantiation for dt = Inf
     int fused2d_max_nodes = 1200000;         // ... runs on grids of up to this many nodes (SolCx: faster than the two-kernel iteration up to 1024^2, slower at 1280^2 ... 1536^2; the control-flow form: 200,000)
     bool thermal_np_const = true;            // phase-ratio form of the heat-diffusion kernels (2D and 3D): instantiations with the phase count as a constant (1..4)
