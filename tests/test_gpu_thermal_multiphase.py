@@ -290,3 +290,26 @@ def test_graph_replay_of_the_two_kernel_2d_forms_changes_nothing(jr, form):
     assert a[0] == b[0] == [150, 300] and a[1] == b[1]
     for x, y in zip(a[2:], b[2:]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("dim,ni", [(2, (37, 21)), (2, (130, 40)), (3, (20, 14, 12)), (3, (70, 17, 20)), (3, (65, 3, 3))])
+def test_phase_count_constant_kernels_equal_the_run_time_loops(jr, dim, ni):
+    """option thermal_np_const: the phase-ratio kernels instantiated for the phase count (ratios in registers, loops unrolled; in 3D the flux kernel with every operand requested up
+    front, k_flux3d_b) against the run-time loops / the control-flow flux kernel: temperature, fluxes, residual and PT coefficients bit for bit"""
+    from justrelax_jl_amd import _lib
+    h = _lib.default_handle()
+    outs = []
+    try:
+        for const in (0, 1):
+            h.set_option("thermal_np_const", const)
+            s = jr.miniapps.diffusion2d_multiphase(ni, iterMax=60, nout=20) if dim == 2 else jr.miniapps.diffusion3d_multiphase(ni, iterMax=60, nout=20)
+            _randomise(s, 11 + dim)
+            thermal, pt, pr, args = _device_setup(jr, s, eps=1e-30)
+            r = jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, s.extra["rheology"], args, s.dt, s.grid, kwargs=dict(phase=pr, iterMax=60, nout=20, verbose=False))
+            fields = [thermal.T, thermal.Told, thermal.ΔT, thermal.qTx, thermal.qTy, thermal.qTx2, thermal.qTy2, thermal.ResT, pt.θr_dτ, pt.dτ_ρ] + ([thermal.qTz, thermal.qTz2] if dim == 3 else [])
+            outs.append((list(r.iter_count), list(r.norm_ResT), [jr.to_numpy(t) for t in fields]))
+    finally:
+        h.set_option("thermal_np_const", 1)
+    assert outs[0][0] == outs[1][0] == [20, 40, 60] and outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert np.array_equal(a, b, equal_nan=True)
