@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void k_vep3_centre(const Vep3Args a)
 // ML = false (ranks with neighbours): ητ arrives in a.etatau -- compute_maxloc! of the relaxed η and its update_halo! run on the halo stream beside the edge pass -- instead of being taken
 // from the 3 x 3 x 3 window of η here
 template <bool SOFT, bool RHO, int NP = 0, bool OBS = true, bool ML = true>
-__global__ __launch_bounds__(256, 3) void k_vep3_prec(const Vep3Args a, double *__restrict__ eta_out, const int KZ)
+__global__ __launch_bounds__(256, 3) void k_vep3_prec(const Vep3Args a, double *__restrict__ eta_out, const int KZ, const int tile_ntx = 0)
 {
     const int nx = a.nx, ny = a.ny, nz = a.nz, np = NP > 0 ? NP : a.rh.nphase;
     unsigned bx_ = blockIdx.x, by_ = blockIdx.y;
@@ -924,9 +924,16 @@ __global__ __launch_bounds__(256, 3) void k_vep3_prec(const Vep3Args a, double *
         const unsigned L_ = by_ * gridDim.x + bx_, per_ = (gridDim.x * gridDim.y) / 8u;
         if (L_ < per_ * 8u) { const unsigned Ln_ = (L_ & 7u) * per_ + (L_ >> 3); bx_ = Ln_ % gridDim.x; by_ = Ln_ / gridDim.x; }
     }
-    const int t_ = bx_ * blockDim.x + threadIdx.x;
-    const int j = t_ / (nx + 1), i = t_ - j * (nx + 1);
-    if (j >= ny + 1) return;
+    int i, j;
+    if (tile_ntx > 0) {     // 64 x 4 tiles of node columns (one wave per row): the three rows of a velocity / η window that a block's rows share are requested by waves of the same block
+        const int tyi = (int)bx_ / tile_ntx, txi = (int)bx_ - tyi * tile_ntx;
+        i = txi * 64 + (int)(threadIdx.x & 63); j = tyi * 4 + (int)(threadIdx.x >> 6);
+        if (i > nx || j > ny) return;
+    } else {
+        const int t_ = bx_ * blockDim.x + threadIdx.x;
+        j = t_ / (nx + 1); i = t_ - j * (nx + 1);
+        if (j >= ny + 1) return;
+    }
     const int k0 = (int)by_ * KZ, k1 = min(k0 + KZ, nz + 1);
     const double *__restrict__ Vx = a.f.Vx, *__restrict__ Vy = a.f.Vy, *__restrict__ Vz = a.f.Vz;
     const double _dx = a._dx, _dy = a._dy, _dz = a._dz;
@@ -1548,10 +1555,15 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         if (fuse) {
             for (int c_ = 0; c_ < 3; c_++) A.cnew[c_] = (c_ == 0 ? A.f.txx : (c_ == 1 ? A.f.tyy : A.f.tzz)) == cset[c_] ? user_c[c_] : cset[c_];
             double *const eta_out = A.f.eta == f->eta ? eta2 : f->eta;
-            const dim3 gpc(gpre.x, (unsigned)((nz + 1 + prekz - 1) / prekz));
+            // thread map of the fused kernel: 64 x 4 tiles of node columns where a plane has enough of them ("vep3_prec_tile" = 2, default: from 16,384 node columns per plane), else 256
+            // consecutive nodes of the flattened plane.  With tiles the rows of a velocity / η window that a block's rows share are requested by waves of one block: 35.4 -> 30.1 fetched passes,
+            // 256^3 350 -> 365 it/s (128^3 +3 %, 160^3 +4 %, 224^3 +5 %, 320^3 +2 %); on small planes the partly filled tiles cost more: 96^3 -7 %, 64^3 -8 %, 32^3 -6 % (gpurun_out/r04pt)
+            const bool tiled = h->vep3_prec_tile == 1 || (h->vep3_prec_tile == 2 && (i64)(nx + 1) * (ny + 1) >= 16384);
+            const int tntx = tiled ? (nx + 1 + 63) / 64 : 0;
+            const dim3 gpc(tntx ? (unsigned)(tntx * ((ny + 1 + 3) / 4)) : gpre.x, (unsigned)((nz + 1 + prekz - 1) / prekz));
             const int npc = (h->vep3_np_const && !upd_rho) ? A.rh.nphase : 0;
             switch ((npc <= 4 ? npc : 0) * 2 + (A.obs ? 1 : 0) + (upd_rho ? 100 : 0)) {
-#define PREC(NP_, OBS_) case NP_ * 2 + OBS_: hipLaunchKernelGGL((k_vep3_prec<false, false, NP_, OBS_ != 0>), gpc, dim3(256), 0, s, A, eta_out, prekz); break;
+#define PREC(NP_, OBS_) case NP_ * 2 + OBS_: hipLaunchKernelGGL((k_vep3_prec<false, false, NP_, OBS_ != 0>), gpc, dim3(256), 0, s, A, eta_out, prekz, tntx); break;
             PREC(0, 0) PREC(0, 1) PREC(1, 0) PREC(1, 1) PREC(2, 0) PREC(2, 1) PREC(3, 0) PREC(3, 1) PREC(4, 0) PREC(4, 1)
 #undef PREC
             case 100: hipLaunchKernelGGL((k_vep3_prec<false, true, 0, false>), gpc, dim3(256), 0, s, A, eta_out, prekz); break;

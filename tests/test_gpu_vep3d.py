@@ -279,9 +279,10 @@ def test_epilogue_operators_3d(jr, oracle):
         assert np.array_equal(jr.to_numpy(getattr(stokes.ω, k)), x), k
 
 
+@pytest.mark.parametrize("tile", [0, 1])
 @pytest.mark.parametrize("ni,iters,nout,prekz", [((20, 12, 10), 7, 3, 0), ((20, 12, 10), 40, 10, 0), ((13, 9, 7), 5, 2, 1), ((70, 5, 6), 6, 5, 4), ((64, 64, 17), 4, 2, 8),
                                                    ((63, 31, 16), 5, 4, 16), ((127, 66, 40), 6, 3, 8), ((127, 66, 40), 5, 10 ** 9, 32), ((96, 80, 72), 35, 17, 0)])
-def test_vep3d_fused_pre_centre_equals_the_three_kernels(jr, ni, iters, nout, prekz):
+def test_vep3d_fused_pre_centre_equals_the_three_kernels(jr, ni, iters, nout, prekz, tile):
     """k_vep3_prec (pre + viscosity relaxation + centre pass in one kernel ahead of the edge pass, second sets of η and τxx/τyy/τzz adopted by pointer swap; the default without
     neighbours) against the three kernels with the centre pass behind the edge pass: every field of the solve bit for bit -- odd and even iteration counts (the copy-back of the
     second sets), observed and unobserved iterations (the output-only arrays), chunk depths that cut the column at every place, a run long enough for the captured graphs"""
@@ -292,6 +293,7 @@ def test_vep3d_fused_pre_centre_equals_the_three_kernels(jr, ni, iters, nout, pr
         for fuse in (0, 1):
             h.set_option("vep3_fuse_pc", fuse)
             h.set_option("vep3_prekz", prekz)
+            h.set_option("vep3_prec_tile", tile)
             s = jr.miniapps.shearband3d(ni, iterMax=iters - 1, nout=nout)
             s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
             rng = np.random.default_rng(3)
@@ -308,6 +310,7 @@ def test_vep3d_fused_pre_centre_equals_the_three_kernels(jr, ni, iters, nout, pr
     finally:
         h.set_option("vep3_fuse_pc", 1)
         h.set_option("vep3_prekz", 0)
+        h.set_option("vep3_prec_tile", 2)
     assert (outs[0]["eplxx"] != 0).any() or iters < 5
     assert np.array_equal(np.asarray(res[0].err_evo1), np.asarray(res[1].err_evo1))
     for k in outs[0]:
