@@ -315,3 +315,56 @@ def test_vep3d_fused_pre_centre_equals_the_three_kernels(jr, ni, iters, nout, pr
     assert np.array_equal(np.asarray(res[0].err_evo1), np.asarray(res[1].err_evo1))
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("nphase", [1, 3, 4, 5])
+def test_vep3d_solve_with_other_phase_counts_fused_equals_unfused(jr, nphase):
+    """the whole 3D VEP solve with 1, 3, 4 (template instantiations of the fused pre / centre, centre and per-node edge kernels) and 5 phases (run-time phase loops everywhere): the
+    fused kernel against the three kernels, and the constant-phase-count instantiations against the run-time loops, every field bit for bit"""
+    import torch
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.arrays import from_numpy
+    ni = (66, 9, 19)
+    h = _lib.default_handle()
+    outs = []
+    try:
+        for fuse, npc in ((0, 0), (1, 1), (1, 0), (0, 1)):
+            h.set_option("vep3_fuse_pc", fuse)
+            h.set_option("vep3_np_const", npc)
+            s = jr.miniapps.shearband3d(ni, iterMax=11, nout=5)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+            rng = np.random.default_rng(40 + nphase)
+            for c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):
+                s.arrays["to" + c][...] = rng.uniform(-1.5, 1.5, size=s.arrays["to" + c].shape)
+                s.arrays["t" + c][...] = s.arrays["to" + c]
+            base = s.extra["phases"]
+            phases = []
+            for q in range(nphase):
+                ph = dict(base[q % 2], Kb=3.0 + 0.5 * q, psi_deg=4.0 + q)
+                ph["eta"] = ph["eta"] * (1.0 + 0.3 * q)
+                ph["C"] = ph["C"] * (1.0 - 0.1 * q)
+                ph["G"] = ph["G"] * (1.0 + 0.2 * q)
+                phases.append(ph)
+            for k in ("phase_c", "phase_yz", "phase_xz", "phase_xy"):
+                shp = s.arrays[k].shape[1:]
+                r = rng.dirichlet(np.ones(nphase), size=shp)
+                r[rng.uniform(size=shp) < 0.3] = np.eye(nphase)[rng.integers(nphase)]
+                s.arrays[k] = np.asfortranarray(np.moveaxis(r, -1, 0))
+            dev = torch.device("cuda", torch.cuda.current_device())
+            stokes = jr.StokesArrays(jr.AMDGPUBackend, s.ni)
+            for k, path in VEP3_MAP.items():
+                _get(stokes, path).copy_(from_numpy(s.arrays[k], dev))
+            pr = jr.PhaseRatios(jr.AMDGPUBackend, nphase, s.ni)
+            for k, name in (("phase_c", "center"), ("phase_yz", "yz"), ("phase_xz", "xz"), ("phase_xy", "xy")):
+                getattr(pr, name).copy_(from_numpy(s.arrays[k], dev))
+            ρg = tuple(from_numpy(s.arrays[k], dev) for k in ("fx", "fy", "fz"))
+            r_ = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, phases, None, s.dt, None, kwargs=s.kwargs)
+            assert r_.iter == 12
+            outs.append(_download(jr, stokes))
+    finally:
+        h.set_option("vep3_fuse_pc", 1)
+        h.set_option("vep3_np_const", 1)
+    assert (outs[0]["eplxx"] != 0).any()
+    for v in (1, 2, 3):
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], outs[v][k], equal_nan=True), (v, k)
