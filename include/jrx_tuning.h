@@ -32,6 +32,7 @@
  *                                 which does not load τ_o, P0, K, G, Q, behind the operand check of "viscous_limit"); 0 = the control-flow form (A/B)
  *   "fused2d_max_nodes" (1200000)  ... on grids of up to this many nodes (larger: the two-kernel iteration)
  *   "vep3_prec_tile" (2)          thread map of the fused 3D VEP pre / centre kernel: 1 = 64 x 4 tiles of node columns, 0 = 256 consecutive nodes of the flattened plane, 2 = tiles from 16,384 node columns per plane
+ *   "thermal_fused_ph" (1)        3D heat diffusion, phase-ratio form (phase count 1..4): 1 = unobserved iterations as one launch (flux + update + BCs + next PT coefficients; θr_dτ ping-pongs), 0 = two kernels
  *   "vep3_fork" (0)               3D VEP driver without neighbours: 1 = the centre pass of update_stresses_center_vertex_ps! runs on a second stream beside the edge pass (it writes a
  *                                 second set of τxx, τyy, τzz, adopted by pointer swap); measured equal to one pass after the other: off
  *   "vep_store_all" (0)           VEP loops (2D and 3D): 1 = every iteration stores ∇V, RP, ε_pl, ε_vol_pl, τII, η_vep (default: only iterations whose results can be observed)

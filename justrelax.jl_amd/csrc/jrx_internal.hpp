@@ -68,6 +68,7 @@ struct jrx_handle {
                                              // (gpurun_out/r04c; before the fusion +9.7 / +7.9 / +8.8 %) -- until a real link shows otherwise the measured-best form is the default
     bool fused2d_batch = true;               // 2D one-launch iteration: the form with every operand requested up front (k_fused2d_b), and its viscous-limit instantiation for dt = Inf
     int fused2d_max_nodes = 1200000;         // ... runs on grids of up to this many nodes (SolCx: faster than the two-kernel iteration up to 1024^2, slower at 1280^2 ... 1536^2; the control-flow form: 200,000)
+    bool thermal_fused_ph = true;            // 3D heat diffusion, phase-ratio form with a constant phase count: unobserved iterations as one launch (k_thermal3d_fused_ph)
     bool thermal_np_const = true;            // phase-ratio form of the heat-diffusion kernels (2D and 3D): instantiations with the phase count as a constant (1..4)
     int vep3_prec_tile = 2;                  // fused pre / centre kernel: 1 = 64 x 4 tiles of node columns per block, 0 = 256 consecutive nodes of the flattened plane, 2 (default) = tiles from 16,384 node columns per plane
     bool vep3_np_const = true;               // 3D VEP centre pass (and the fused pre / centre kernel): instantiations with the phase count as a constant (1..4): ratios loaded in one batch, phase loops unrolled

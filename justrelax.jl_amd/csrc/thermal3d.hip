@@ -426,6 +426,139 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TS
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_thermal3d_fused for the phase-ratio form (TPhN<NPH>: phase count as a constant), one row per thread (R = 1): compute_flux! with the conductivity of a face averaged from the
+// phase ratios at the two clamped face positions (k_flux3d, DiffusionPT_kernels.jl:366-440), update_T! with ρCp and the radiogenic heat from the centre ratios (k_updateT3d),
+// thermal_bcs! by rule, and update_pt_thermal_arrays! of the next iteration from the cell's new T (the `wpt` part of k_updateT3d).  θr_dτ is read at neighbouring cells and written
+// for the own one, so it ping-pongs like T and the fluxes (dst.th); dτ_ρ is read and written at the own cell only and stays in place.  Same arithmetic, in the same order, as
+// k_flux3d_b / k_updateT3d: 23 array passes per iteration instead of 18 + 16.
+// ------------------------------------------------------------------------------------------------
+struct TSetP { double *T, *qx, *qy, *qz, *th; };
+template <int TX, int KZ, int XG, int NPH>
+__global__ __launch_bounds__(TX) void k_thermal3d_fused_ph(const T3Args a, const TSetP dst, const TPhN<NPH> ph, int ntx, int nty)
+{
+    const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
+    int tile = blockIdx.x;
+    {
+        const int rows = (int)(gridDim.x / (unsigned)ntx);          // nty * number of z chunks
+        const int full = (rows / (8 * XG)) * (8 * XG) * ntx;
+        if (tile < full) {
+            const int q = tile & 7, r = tile >> 3, r2 = r / ntx;
+            tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
+        }
+    }
+    const int tix = tile % ntx, tr = tile / ntx, j = tr % nty, tiz = tr / nty;
+    const int i = tix * TX + (int)threadIdx.x;
+    const int kb = tiz * KZ, kend = min(kb + KZ, nz);
+    if (i >= nx && (i & ~63) >= nx) return;
+    const bool cell = i < nx;
+    const int ic = cell ? i : nx - 1;
+    const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau;
+    const double _dt = 1.0 / a.p.dt, _dx = a.p._dx, _dy = a.p._dy, _dz = a.p._dz;
+    const i64 sT1 = nx + 2, sT2 = (i64)(nx + 2) * (ny + 2), sC2 = (i64)nx * ny;
+    const int im = max(ic - 1, 0), ip = min(ic + 1, nx - 1), jl = max(j - 1, 0), ju = min(j + 1, ny - 1);
+    const bool edge = (threadIdx.x & 63) == 63 || i == nx - 1;      // no lane to the right holds cell i+1
+    const bool cfxl = a.p.constant_flux_on[XL] != 0, cfxr = a.p.constant_flux_on[XR] != 0, cfyf = a.p.constant_flux_on[YF] != 0,
+               cfyb = a.p.constant_flux_on[YB] != 0, cfzb = a.p.constant_flux_on[ZB] != 0, cfzt = a.p.constant_flux_on[ZT] != 0;
+    // tph_cond on ratios held in registers, without the early return (a select instead: same value -- the sum stops where a pure phase is found)
+    struct R { double v[NPH]; };
+    auto ld = [&](const double *__restrict__ base, i64 pos) { R r; _Pragma("unroll") for (int q = 0; q < NPH; q++) r.v[q] = base[NPH * pos + q]; return r; };
+    auto cond = [&](const R &r) {
+        double x = 0.0, pure = 0.0;
+        bool done = false;
+#pragma unroll
+        for (int q = 0; q < NPH; q++) {
+            const double rq = r.v[q], term = ph.m.k[q] * rq;
+            if (!done && rq == 1.0) { pure = term; done = true; }
+            if (!done) x += (rq == 0.0) ? 0.0 : term;
+        }
+        return done ? pure : x;
+    };
+    // relaxed flux across a face (k_flux3d): K = the mean of the conductivities at the two clamped face positions, θ the mean over the two cells
+    auto relax = [&](double qold, double Kl, double Kr, double tl, double tr_, double Thi, double Tlo, double _d) -> double {
+        const double K = (Kl + Kr) * 0.5;
+        const double t = (tl + tr_) * 0.5;
+        const double qv = -K * (Thi - Tlo) * _d;
+        return (qold * t + qv) / (1.0 + t);
+    };
+    // plane-kb operands of the own cell, carried upward: T (ghost-indexed k+1), θ, the conductivity at the z-face position k and the flux on the low z face
+    double Tc, tc, cz, qz_lo;
+    {
+        const i64 c = ic + (i64)nx * j + sC2 * kb, I1 = (ic + 1) + sT1 * (j + 1) + sT2 * (kb + 1);
+        Tc = T[I1]; tc = th[c]; cz = cond(ld(ph.f.phase_qz, c));
+        if (kb == 0 && cfzb) qz_lo = a.p.constant_flux[ZB];
+        else {
+            const i64 cl = kb > 0 ? c - sC2 : c;
+            qz_lo = relax(a.t.qTz[c], cond(ld(ph.f.phase_qz, cl)), cz, th[cl], tc, Tc, T[I1 - sT2], _dz);
+        }
+        if (kb == 0 && cell) dst.qz[c] = qz_lo;
+    }
+    for (int k = kb; k < kend; ++k) {
+        const i64 c = ic + (i64)nx * j + sC2 * k, I1 = (ic + 1) + sT1 * (j + 1) + sT2 * (k + 1);
+        const i64 q0 = ic + (i64)nx * (j + (i64)(ny + 1) * k), q1 = q0 + nx;          // y faces j, j + 1 (= positions j, j + 1 of phase_qy)
+        const i64 cl = ic + (i64)nx * jl + sC2 * k, cu = ic + (i64)nx * ju + sC2 * k, cr = k + 1 < nz ? c + sC2 : c;
+        const i64 qx = ic + (i64)(nx + 1) * (j + (i64)ny * k), qxe = qx + 1;
+        // ---- every operand of the plane, requested before the first of them is used
+        const R ry0 = ld(ph.f.phase_qy, q0), ryl = ld(ph.f.phase_qy, ic + (i64)nx * (jl + (i64)(ny + 1) * k)), ryu = ld(ph.f.phase_qy, ic + (i64)nx * (ju + (i64)(ny + 1) * k));
+        const R rxl = ld(ph.f.phase_qx, qx - (ic - im)), rx0 = ld(ph.f.phase_qx, qx), rzn = ld(ph.f.phase_qz, cr), rcc = ld(ph.f.phase_c, c);
+        const double qoy0 = a.t.qTy[q0], qoy1 = a.t.qTy[q1], qox = a.t.qTx[qx], qoz = a.t.qTz[c + sC2];
+        const double thl = th[cl], thu = th[cu], thx = th[c - (ic - im)], tn = th[cr];
+        const double Tyl = T[(ic + 1) + sT1 * j + sT2 * (k + 1)], Tyu = T[(ic + 1) + sT1 * (j + 2) + sT2 * (k + 1)], Txl = T[I1 - 1], Tn_c = T[I1 + sT2];
+        const double Pc = ph.f.P[c], dr = a.t.dtau_rho[c], Told = a.t.Told[I1], Hc = a.t.H[c], shc = a.t.shear_heating[c];
+        R rxe = rx0;
+        double qoxe = 0.0, thxe = 0.0, Txe = 0.0;
+        if (edge) { rxe = ld(ph.f.phase_qx, qxe - 1 + (ip - ic)); qoxe = a.t.qTx[qxe]; thxe = th[c + (ip - ic)]; Txe = T[I1 + 1]; }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- y: low face j, high face j + 1 (computed here as the row above computes its low face)
+        double qy_lo, qy_hi;
+        {
+            const double cy0 = cond(ry0);
+            if (j == 0 && cfyf) qy_lo = a.p.constant_flux[YF];
+            else qy_lo = relax(qoy0, cond(ryl), cy0, thl, tc, Tc, Tyl, _dy);
+            if (cell) dst.qy[q0] = qy_lo;
+            if (j + 1 == ny && cfyb) qy_hi = a.p.constant_flux[YB];
+            else qy_hi = relax(qoy1, cy0, cond(ryu), tc, thu, Tyu, Tc, _dy);
+            if (cell && j + 1 == ny) dst.qy[q1] = qy_hi;                              // the back face belongs to no cell's low face
+        }
+        // ---- x: low face i (own), high face i + 1 from the next lane
+        const double cx0 = cond(rx0);
+        double qx_lo;
+        if (ic == 0 && cfxl) qx_lo = a.p.constant_flux[XL];
+        else qx_lo = relax(qox, cond(rxl), cx0, thx, tc, Tc, Txl, _dx);
+        if (cell) dst.qx[qx] = qx_lo;
+        double qx_hi = __shfl_down(qx_lo, 1, 64);
+        if (edge) {
+            if (ic + 1 == nx && cfxr) qx_hi = a.p.constant_flux[XR];
+            else qx_hi = relax(qoxe, cx0, cond(rxe), tc, thxe, Txe, Tc, _dx);
+            if (cell && ic + 1 == nx) dst.qx[qxe] = qx_hi;
+        }
+        // ---- z: high face k + 1 (owned here), becomes the low face of the next plane
+        double qz_hi;
+        const double czn = cond(rzn);
+        if (k + 1 == nz && cfzt) qz_hi = a.p.constant_flux[ZT];
+        else qz_hi = relax(qoz, cz, czn, tc, tn, Tn_c, Tc, _dz);
+        if (cell) dst.qz[c + sC2] = qz_hi;
+        if (cell) {
+            const double rcp = tph_rhoCp<NPH>(ph.m, rcc.v, Tc, Pc);
+            const double Hr = tph_Hr<NPH>(ph.m, rcc.v);
+            const double divq = (qx_hi - qx_lo) * _dx + (qy_hi - qy_lo) * _dy + (qz_hi - qz_lo) * _dz;
+            const double Tn = (dr * (-divq + Told * rcp * _dt + Hr + Hc + shc) + Tc) / (1.0 + dr * rcp * _dt);
+            dst.T[I1] = Tn;
+            double th_, dr_;      // update_pt_thermal_arrays! of the next iteration
+            tph_pt_coeffs<NPH>(ph.m, rcc.v, Tn, Pc, _dt, th_, dr_);
+            dst.th[c] = th_;
+            const_cast<double *>(a.t.dtau_rho)[c] = dr_;
+            const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
+            const int mask = ((i == 0 || i == nx - 1) ? 1 : 0) | ((j == 0 || j == ny - 1) ? 2 : 0) | ((k == 0 || k == nz - 1) ? 4 : 0);
+            if (mask) {
+                const i64 st[3] = {1, sT1, sT2};
+                thermal_ghosts3d(a.p, dst.T, st, I1, mask, side, Tn);
+            }
+        }
+        qz_lo = qz_hi; Tc = Tn_c; tc = tn; cz = czn;
+    }
+}
+
 // thermal_bcs! 3D: one launch per (step, dim); step 0 constant_value, 1 no_flux, 2 periodic; dim = direction normal to the face pair
 __global__ __launch_bounds__(256) void k_tbc3d(double *__restrict__ T, int nx, int ny, int nz, int step, int dim, int lo_on, int hi_on, double lo_val,
                                                double hi_val)
@@ -594,14 +727,20 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
     // (option "thermal_fused" = 0: always the two kernels); observed ones (check / last) run the two kernels in place on the current set.
     bool any_periodic = false;
     for (int q = 0; q < 6; q++) any_periodic |= p->periodic[q] != 0;
-    const bool fusable = !PH && !t->adiabatic && !t->dirichlet_mask && h->thermal_fused && h->scratch_sets && !any_periodic && !jrx_comm_active(h);
+    // the phase-ratio form fuses, too, where the phase count is a template constant (k_thermal3d_fused_ph; its default tile shape only): θr_dτ then ping-pongs with T and the fluxes
+    constexpr int NPHC = tph_np<PHT>::value;
+    const bool fusable = (!PH || (NPHC > 0 && h->thermal_cfg == 0 && h->thermal_xg == 8 && h->thermal_fused_ph)) && !t->adiabatic && !t->dirichlet_mask && h->thermal_fused &&
+                         h->scratch_sets && !any_periodic && !jrx_comm_active(h);
     const TSet user = {t->T, t->qTx, t->qTy, t->qTz};
     TSet cur = user, oth = user;
+    double *const th_user = const_cast<double *>(t->thetar_dtau);
+    double *th_cur = th_user, *th_oth = th_user;
     if (fusable) {
         JRX_TRY(ensure_tscratch(h, nx, ny, nz));
         oth = TSet{h->tscratch[0], h->tscratch[1], h->tscratch[2], h->tscratch[3]};
         // ghosts that no BC rewrites (prescribed values) must exist in both sets
         JRX_HIP(h, hipMemcpyAsync(oth.T, t->T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (PH) { JRX_TRY(jrx_ensure_etatau(h, (size_t)n)); th_oth = h->etatau; }
     }
     // tile = TX cells of R rows, KZ planes deep; option "thermal_cfg" = R*10000 + (TX/64)*100 + KZ overrides (tuning)
     const int cfg = h->thermal_cfg;
@@ -616,9 +755,21 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
         while (FKZ > 1 && (i64)((nx + FTX - 1) / FTX) * (FTX / 64) * ny * ((nz + FKZ - 1) / FKZ) < 4096) FKZ /= 2;
     const int ntx = (nx + FTX - 1) / FTX, nty = (ny + FR - 1) / FR, ntz = (nz + FKZ - 1) / FKZ;
     // launch_fused: one unobserved iteration from set c into set o (the caller swaps)
-    auto launch_fused = [&](const TSet &c, const TSet &o) -> jrx_status {
+    auto launch_fused = [&](const TSet &c, const TSet &o, double *thc = nullptr, double *tho = nullptr) -> jrx_status {
         T3Args b = a;
         b.t.T = c.T; b.t.qTx = c.qx; b.t.qTy = c.qy; b.t.qTz = c.qz;
+        if constexpr (NPHC > 0) {
+            b.t.thetar_dtau = thc;
+            const TSetP op = {o.T, o.qx, o.qy, o.qz, tho};
+            bool ok = true;
+#define THP(TX_, KZ_) if (FTX == TX_ && FKZ == KZ_) hipLaunchKernelGGL((k_thermal3d_fused_ph<TX_, KZ_, 8, NPHC>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX_), 0, s, b, op, ph, ntx, nty); else
+            THP(256, 4) THP(128, 4) THP(64, 4) THP(256, 2) THP(128, 2) THP(64, 2) THP(256, 1) THP(128, 1) THP(64, 1) ok = false;
+#undef THP
+            if (!ok) return jrx_fail(h, JRX_ERR_ARG, "internal: no fused phase-ratio instantiation for this tile shape");
+            h->stat_thermal_fused++;
+            JRX_LAUNCH_CHECK(h);
+            return JRX_OK;
+        }
 #define THL(TX_, KZ_, R_, XG_)                                                                                                      \
     if (FTX == TX_ && FKZ == KZ_ && FR == R_ && FXG == XG_) {                                                                       \
         hipLaunchKernelGGL((k_thermal3d_fused<TX_, KZ_, XG_, R_>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX_), 0, s, b, o, ntx, nty); \
@@ -650,9 +801,11 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
                 if (!gexec[par]) {
                     JRX_TRY(jrx_capture_graph(s, &gexec[par], [&]() -> jrx_status {
                         TSet c = cur, o = oth;
+                        double *tc_ = th_cur, *to_ = th_oth;
                         for (int q = 0; q < GIT; q++) {
-                            JRX_TRY(launch_fused(c, o));
+                            JRX_TRY(launch_fused(c, o, tc_, to_));
                             const TSet tmp = c; c = o; o = tmp;
+                            double *tt_ = tc_; tc_ = to_; to_ = tt_;
                         }
                         return JRX_OK;
                     }));
@@ -672,16 +825,18 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
         // qT*2 is observable after the loop as well (the arrays belong to the caller): written on check iterations and on the last one
         const bool q2 = ((iter + 1) % p->nout == 0) || (iter + 1 >= p->iterMax);
         a.t.T = cur.T; a.t.qTx = cur.qx; a.t.qTy = cur.qy; a.t.qTz = cur.qz;
+        a.t.thetar_dtau = th_cur;
         if constexpr (PH) {    // update_pt_thermal_arrays!(pt_thermal, phase, rheology, args, _dt) -- DiffusionPT_solver.jl:233-234
             // on unobserved iterations update_T! writes the coefficients of the next iteration itself (same values: they depend on the cell's own new T
             // only); observed iterations leave pt_thermal as the reference does, and the stand-alone kernel runs before the following iteration
-            if (!pt_fresh) JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, s, const_cast<double *>(t->thetar_dtau), const_cast<double *>(t->dtau_rho), cur.T, nx, ny, nz, 3, 1.0 / p->dt, ph));
+            if (!pt_fresh) JRX_TRY(jrx_enqueue_pt_thermal_arrays(h, s, th_cur, const_cast<double *>(t->dtau_rho), cur.T, nx, ny, nz, 3, 1.0 / p->dt, ph));
             pt_fresh = !q2;
             a.wpt = pt_fresh;
         }
         if (fusable && !q2) {
-            JRX_TRY(launch_fused(cur, oth));
+            JRX_TRY(launch_fused(cur, oth, th_cur, th_oth));
             const TSet tmp = cur; cur = oth; oth = tmp;
+            if (PH) { double *tt_ = th_cur; th_cur = th_oth; th_oth = tt_; }
         } else {
             JRX_TRY(enqueue_titer3(h, &a.t, p, ph, q2, true, a.wpt));
         }
@@ -713,6 +868,7 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
             err = err_stop;
         }
     }
+    if (th_cur != th_user) JRX_HIP(h, hipMemcpyAsync(th_user, th_cur, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));      // ... and the PT coefficients of the phase-ratio form
     if (cur.T != user.T) {      // leave the results in the caller's arrays
         JRX_HIP(h, hipMemcpyAsync(user.T, cur.T, (size_t)nT * sizeof(double), hipMemcpyDeviceToDevice, s));
         JRX_HIP(h, hipMemcpyAsync(user.qx, cur.qx, (size_t)(nx + 1) * ny * nz * sizeof(double), hipMemcpyDeviceToDevice, s));
