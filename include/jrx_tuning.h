@@ -24,10 +24,12 @@
  *   "vep3_nt" (0), "vep3_prekz" (0)   3D VEP: non-temporal stores of the edge pass; planes per thread of the z-marching pre kernel (0 = chosen by the grid size; 1, 2, 4, 8, 16, 32)
  *   "vep3_hide_comm" (0)          multi-rank 3D VEP driver: 2 = ητ, edge-stress and V exchanges on the halo stream beside independent kernels; 1 = the first two only, update_halo!(V) behind the
  *                                 whole velocity sweep; 0 (default: the fastest on one device since the pre / centre kernels are fused) = everything on the compute stream, in order
- *   "vep3_fuse_pc" (1)            3D VEP driver without neighbours, viscosity laws that read no field: compute_∇V! / compute_P! / compute_strain_rate!, update_viscosity_τII! and the centre half of
+ *   "vep3_fuse_pc" (1)            3D VEP driver (with and without neighbours), viscosity laws that read no field, no softening law: compute_∇V! / compute_P! / compute_strain_rate!, update_viscosity_τII! and the centre half of
  *                                 update_stresses_center_vertex_ps! run as ONE kernel ahead of the edge half (0 = the three kernels, centre half behind the edge half); bit-identical
- *   "vep3_np_const" (1)           3D VEP centre pass / fused kernel: 1 = instantiations with the number of phases as a compile-time constant (1..4; 0 = the run-time loops, A/B)
- *   "thermal_np_const" (1)        phase-ratio form of the heat-diffusion kernels (2D, 3D): 1 = instantiations with the number of phases as a compile-time constant (1..4; 0 = run-time loops, A/B)
+ *   "vep3_np_const" (1)           VEP kernels, 2D and 3D (3D: centre pass, fused pre / centre kernel, per-node edge kernel; 2D: the merged stress kernel): 1 = instantiations with the number of
+ *                                 phases as a compile-time constant (1..4: ratios loaded in one batch, phase loops unrolled); 0 = the run-time loops (A/B)
+ *   "thermal_np_const" (1)        phase-ratio form of the heat-diffusion kernels (2D, 3D): 1 = instantiations with the number of phases as a compile-time constant (1..4; in 3D also the flux kernel
+ *                                 with batched loads and, with "thermal_fused_ph", the one-launch iteration); 0 = run-time loops, two kernels per iteration (A/B)
  *   "fused2d_batch" (1)           2D visco-elastic loop, one-launch iteration: 1 = the form that requests every operand up front (k_fused2d_b; dt = Inf: its viscous-limit instantiation,
  *                                 which does not load τ_o, P0, K, G, Q, behind the operand check of "viscous_limit"); 0 = the control-flow form (A/B)
  *   "fused2d_max_nodes" (1200000)  ... on grids of up to this many nodes (larger: the two-kernel iteration)
