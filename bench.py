@@ -49,6 +49,10 @@ A_NEEDED_FUSED = 35 * 8.0   # what k_fused3d itself has to move: 25 array reads 
 # those ten arrays are 35 passes -- the figure that launch is priced at (pricing it at 360 B/cell would credit it with bytes nobody has to move).
 A_ALG_VISC = 35 * 8.0
 A_NEEDED_VISC = 25 * 8.0    # what the viscous-limit k_fused3d itself has to move: 15 array reads + 10 writes = 200 B/cell
+# SolVi3D hands three body-force arrays of zeros (SolVi3D.jl:102).  The one-launch viscous-limit kernel does not load ρg arrays in which the operand pass of the driver call has
+# found nothing but +0.0 (x - 0.5 (0 + 0) = x for every x; tuning switch zero_forces): a launch of that form is priced WITHOUT those passes -- 8 B/cell less per array, 32 passes =
+# 256 B/cell for SolVi3D -- and the same kernel with the loads (280 B/cell) is timed beside it as `with_body_forces`.
+FORMS_NOF = {1: ("viscous_limit_gravity_along_z", 2), 2: ("viscous_limit_no_body_forces", 3)}
 A_STRESS = 28 * 8.0      # stress sweep: 21 reads + 7 writes
 A_VELOCITY = 17 * 8.0    # velocity sweep: 14 reads + 3 writes
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -79,16 +83,43 @@ PMC_TRAFFIC_VISC_512 = PMC["k_fused3d_visc"]                   # k_fused3d, visc
 PMC_SOURCE = {"stress": PMC["source"], "fused": PMC["source"], "visc": PMC["source"]}
 
 
-def pricing(h, dt):
-    """what one launch of the fused kernel is priced at: the form of the kernel that runs (h: handle, dt: the time step handed to the solver)"""
+NOF_COUNTERS = ("stat_fused3d", "stat_fused3d_visc", "stat_fused3d_nof1", "stat_fused3d_nof2")
+
+
+def counters(h):
+    return [h.get_option(k) for k in NOF_COUNTERS]
+
+
+def nof_ran(h, before):
+    """which body-force arrays the fused launches since `before` (= counters(h)) did not load: 0 none, 1 ρg_x and ρg_y, 2 all three -- read from the library's launch
+    counters, so that a launch is never priced at a form that did not run"""
+    d = [b - a for a, b in zip(before, counters(h))]
+    for lvl in (1, 2):
+        if d[0] > 0 and d[1 + lvl] == d[0]:
+            return lvl
+    if d[2] or d[3]:
+        raise SystemExit(f"bench.py: the fused launches of one batch ran in different forms {dict(zip(NOF_COUNTERS, d))}")
+    return 0
+
+
+def pricing(h, dt, nof=0):
+    """what one launch of the fused kernel is priced at: the form of the kernel that runs (h: handle, dt: the time step handed to the solver, nof: nof_ran() of the batch)"""
     import math
+    if math.isinf(dt) and h.get_option("viscous_limit") == 1 and h.get_option("fused_ylds") == 1 and nof:
+        form, na = FORMS_NOF[nof]
+        return {"form": form, "alg": A_ALG_VISC - 8.0 * na, "needed": A_NEEDED_VISC - 8.0 * na, "pmc": PMC.get(f"k_fused3d_visc_nof{nof}"), "pmc_source": PMC_SOURCE["visc"], "nof": nof,
+                "kernel": f"k_fused3d<...,VISC=1,HIF=1,NOF={nof}>: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1 + the high-face node layers, ping-pong state) in the "
+                          f"viscous limit dt = Inf of the workload, whose {'three body-force arrays are' if nof == 2 else 'body-force arrays ρg_x, ρg_y are'} +0.0 in every entry (SolVi3D.jl:102; "
+                          f"the operand pass of the driver call checks the bits): algorithmic {A_ALG_VISC - 8.0 * na:.0f} B/cell per launch = SURVEY 8d's two sweeps (45 passes) less the ten operand "
+                          f"arrays whose factor 1/(G dt), 1/(K dt), 1/dt is exactly 0 and less the {na} zero body-force arrays, none of which this form loads; the kernel itself needs "
+                          f"{15 - na} reads + 10 writes.  The same kernel with the body-force loads (280 B/cell) is the `with_body_forces` entry of this line, the general form (360 B/cell) `general_kernel`"}
     if math.isinf(dt) and h.get_option("viscous_limit") == 1 and h.get_option("fused_ylds") == 1:
-        return {"form": "viscous_limit", "alg": A_ALG_VISC, "needed": A_NEEDED_VISC, "pmc": PMC_TRAFFIC_VISC_512, "pmc_source": PMC_SOURCE["visc"],
+        return {"form": "viscous_limit", "nof": 0, "alg": A_ALG_VISC, "needed": A_NEEDED_VISC, "pmc": PMC_TRAFFIC_VISC_512, "pmc_source": PMC_SOURCE["visc"],
                 "kernel": "k_fused3d<...,VISC=1,TAG=0>: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong state) in the viscous limit dt = Inf of "
                           "the workload: algorithmic 280 B/cell per launch = SURVEY 8d's two sweeps (45 passes) less the ten operand arrays whose factor 1/(G dt), 1/(K dt), 1/dt "
                           "is exactly 0 (old stresses, P0, K, G, Q), which this form does not load; the kernel itself needs 15 reads + 10 writes = 200 B/cell.  The general form "
                           "priced at 360 B/cell is the `general_kernel` entry of this line"}
-    return {"form": "general", "alg": A_ALG, "needed": A_NEEDED_FUSED, "pmc": PMC_TRAFFIC_FUSED_512, "pmc_source": PMC_SOURCE["fused"],
+    return {"form": "general", "nof": 0, "alg": A_ALG, "needed": A_NEEDED_FUSED, "pmc": PMC_TRAFFIC_FUSED_512, "pmc_source": PMC_SOURCE["fused"],
             "kernel": "k_fused3d<...,TAG=0>: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong "
                       "state); algorithmic 360 B/cell per launch (2-sweep floor of SURVEY 8d; the kernel itself needs "
                       "25 reads + 10 writes = 280 B/cell)"}
@@ -317,12 +348,13 @@ def cfg_solvi(jr, h, n, steps, warm):
     run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
     run(warm)
     torch.cuda.synchronize()
+    f0 = counters(h)
     t0 = time.perf_counter()
     tot_ms, sa, sb, sf, sk, kcells = run(steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     cells = float(n) ** 3
-    pr = pricing(h, dt)
+    pr = pricing(h, dt, nof_ran(h, f0))
     out = {"workload": f"SolVi3D {n}^3", "form": pr["form"], "bytes_per_cell": pr["alg"], "steps": steps, "it_per_s": steps / el, "ms_per_step": el / steps * 1e3,
            "frac_whole_iteration": pr["alg"] * cells * steps / el / 1e9 / HBM_PEAK_GBS}
     if sk > 0:
@@ -1184,15 +1216,18 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
     if ranks != world:
         raise SystemExit(f"bench.py: the {T0} communicator has {ranks} ranks, expected {world}")
     if not args.dry_transports:
-        pr = pricing(R.h, R.blk[8])
-        f0 = [R.h.get_option("stat_fused3d"), R.h.get_option("stat_fused3d_visc")]
+        f0 = counters(R.h)
     if args.warmup > 0:
         R.run(args.warmup)
     R.sync(); ctl.barrier()
+    if not args.dry_transports:
+        f0 = counters(R.h)
     t0 = time.perf_counter()
     tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = R.run(args.steps)
     R.sync()
     el = time.perf_counter() - t0
+    if not args.dry_transports:
+        pr = pricing(R.h, R.blk[8], nof_ran(R.h, f0))
     ctl.barrier()
     el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = ctl.max([el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells])
     steady = None
@@ -1267,10 +1302,14 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
 def check_priced_kernel(h, pr, before, out):
     """Evidence hygiene: the kernel form the line prices must be the one that ran.  The library counts its launches of k_fused3d and, of those, the
     launches of the viscous-limit form; the bench refuses to print a roofline for a form that did not run."""
-    d_all = h.get_option("stat_fused3d") - before[0]
-    d_visc = h.get_option("stat_fused3d_visc") - before[1]
-    out["kernel_launch_counters"] = {"k_fused3d": int(d_all), "of_which_viscous_limit_form": int(d_visc), "operand_checks_failed": int(h.get_option("stat_visc_fallbacks"))}
-    want_visc = pr["form"] == "viscous_limit"
+    now = counters(h)
+    d_all, d_visc, d_n1, d_n2 = (b - a for a, b in zip(before[:4], now))
+    out["kernel_launch_counters"] = {"k_fused3d": int(d_all), "of_which_viscous_limit_form": int(d_visc), "of_which_without_loads_of_rho_g_x_y": int(d_n1),
+                                     "of_which_without_loads_of_any_rho_g": int(d_n2), "operand_checks_failed": int(h.get_option("stat_visc_fallbacks"))}
+    want_visc = pr["form"].startswith("viscous_limit")
+    want = {0: (0, 0), 1: (d_all, 0), 2: (0, d_all)}[pr.get("nof", 0)]
+    if (d_n1, d_n2) != want:
+        raise SystemExit(f"bench.py: the line prices the `{pr['form']}` form of k_fused3d, but the launch counters say {out['kernel_launch_counters']}")
     if d_all <= 0 or (want_visc and d_visc != d_all) or (not want_visc and d_visc != 0):
         raise SystemExit(f"bench.py: the line prices the `{pr['form']}` form of k_fused3d, but the library launched {d_all} fused kernels of which {d_visc} in the viscous-limit form")
 
@@ -1351,16 +1390,16 @@ def run_rank(args) -> int:
         torch.cuda.synchronize()
 
     run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
-    pr = pricing(h, dt)
-    f0 = [h.get_option("stat_fused3d"), h.get_option("stat_fused3d_visc")]
     if args.warmup > 0:
         run(args.warmup)
     barrier()
+    f0 = counters(h)
     t0 = time.perf_counter()
     tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = run(args.steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
+    pr = pricing(h, dt, nof_ran(h, f0))
     # A short requested batch (the driver times 20 steps = 0.16 s) samples the box's clocks and allocation luck more than the code: a 100-step batch
     # of the same loop is timed afterwards and reported beside it as `steady_state`; `value` stays the requested batch.
     steady = None
@@ -1405,7 +1444,7 @@ def run_rank(args) -> int:
             if not self_halo and not args.variant:
                 check_priced_kernel(h, pr, f0, out)
         elif split:
-            visc = pr["form"] == "viscous_limit"
+            visc = pr["form"].startswith("viscous_limit")
             a_st = A_STRESS_VISC if visc else A_STRESS
             tr_st = ((PMC_TRAFFIC_STRESS_VISC_512 if visc else PMC_TRAFFIC_STRESS_512) if n == 512 else None) or None
             out["roofline"] = {"bound": "hbm",
@@ -1424,7 +1463,27 @@ def run_rank(args) -> int:
         else:
             out["roofline"] = {"bound": "hbm", "kernel": f"whole PT iteration per GPU ({pr['alg']:.0f} B/cell, form: {pr['form']}; sweeps overlap the halo exchange)", "form": pr["form"], "bytes_per_cell": pr["alg"],
                                "achieved": it_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_gbs / HBM_PEAK_GBS, "traffic": None}
-        if world == 1 and not self_halo and fused and pr["form"] == "viscous_limit" and not args.no_general_kernel:
+        if world == 1 and not self_halo and fused and pr.get("nof") and not args.no_general_kernel:
+            # the same viscous-limit kernel WITH the loads of the body forces (any ρg; the headline of round 3 and of the first part of round 4): tuning switch zero_forces = 0
+            try:
+                h.set_option("zero_forces", 0)
+                run(max(args.warmup, 2))
+                torch.cuda.synchronize()
+                fb = counters(h)
+                t1 = time.perf_counter()
+                b_tot, _, _, b_sf, b_sk, b_kc = run(args.steps)
+                torch.cuda.synchronize()
+                bel = time.perf_counter() - t1
+                prb = pricing(h, dt, nof_ran(h, fb))
+                out["with_body_forces"] = {"what": "tuning switch zero_forces = 0: the viscous-limit kernel that loads the three body-force arrays (any ρg with dt = Inf), same problem, same "
+                                                   "allocations, same batch length; priced at 280 B/cell",
+                                           "it_per_s": args.steps / bel, "ms_per_step": bel / args.steps * 1e3, "steps": args.steps,
+                                           "roofline": fused_roofline(prb, n, b_sk, b_sf, b_kc, prb["alg"] * cells * (args.steps / (b_tot * 1e-3)) / 1e9)}
+            except Exception as e:
+                out["with_body_forces"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                h.set_option("zero_forces", 1)
+        if world == 1 and not self_halo and fused and pr["form"].startswith("viscous_limit") and not args.no_general_kernel:
             # the general form of the same kernel (any dt; what rounds 1-2 quoted) on the same allocations: option viscous_limit = 0
             try:
                 h.set_option("viscous_limit", 0)

@@ -6,6 +6,8 @@
  *   "fused_ylds" (default 1)      3D fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form)
  *   "visc_fold" (1)               3D fused kernel, viscous-limit form: the arithmetic with its exact zeros folded away for finite η (dτ_r = 1 / (θ_dτ + 1) once per thread, Δτ = dτ_r fma(2η, ε, -τ),
  *                                 no division by 1 + 0 ψ); same bits (0: the general expressions with zero operands)
+ *   "zero_forces" (1)             3D fused kernel, one-launch viscous-limit form: ρg arrays whose every entry is +0.0 (all 64 bits zero; the operand pass of the driver call looks at
+ *                                 them) are not loaded -- ρg_x and ρg_y (gravity along z), or all three (SolVi3D); x - (+0.0) = x for every x, so the bits are the same (0: always loaded)
  *   "fused_hiface" (1)            3D fused kernel, viscous-limit form, no neighbours: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel
  *                                 (0: by the boundary-layer launch behind it)
  *   "fused_first_pct" (15)        multi-rank fused pipeline with the neighbour faces inside the kernel (fused_overlap = 3): share (%) of the interior z chunks whose tiles are launched

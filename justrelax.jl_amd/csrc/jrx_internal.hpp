@@ -48,6 +48,8 @@ struct jrx_handle {
     bool comm_bcs_lazy = false;          // multi-rank fused pipeline: 1 = flow_bcs! of the physical faces is not applied in memory every iteration (the fix-up derives those entries by rule) but
                                          // lazily, before anything reads them.  Measured (two 512^3 blocks, profiles/r04_comm_bcs_lazy_ab.txt): the rule form of the fix-up costs more than the two
                                          // BC launches it saves (-2 %): off
+    bool zero_forces = true;             // viscous-limit one-launch kernel: body-force arrays whose every entry is +0.0 (all bits zero; the operand pass looks) are not loaded (k_fused3d, NOF; same bits)
+    int nof = 0;                         // set per driver call by the operand pass: 0 = every ρg array is loaded, 1 = ρg_x and ρg_y hold only +0.0, 2 = all three do
     bool visc_fold = true;               // viscous-limit fused kernel: the arithmetic with the exact zeros folded away (one division per thread for dτ_r, no division by 1 in compute_P!; same bits; A/B)
     bool fused_hiface = true;            // viscous-limit fused kernel without neighbours: the high-face node layers inside the kernel (0: the boundary-layer launch behind it, A/B)
     bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)
@@ -80,7 +82,7 @@ struct jrx_handle {
     // ---- read-only counters (jrx_get_option "stat_*"): launches of the fused kernels since jrx_create, so that tests and the bench can
     //      prove which kernel path ran
     int64_t stat_fused3d_inkernel = 0;   // launches of k_fused3d that finished the neighbour faces themselves (fused_overlap = 3)
-    int64_t stat_fused3d_visc = 0, stat_visc_checks = 0, stat_visc_fallbacks = 0;     // launches of the viscous-limit form of k_fused3d; operand checks run / failed
+    int64_t stat_fused3d_visc = 0, stat_visc_checks = 0, stat_visc_fallbacks = 0, stat_fused3d_nof1 = 0, stat_fused3d_nof2 = 0;     // launches of the viscous-limit form of k_fused3d; operand checks run / failed
     int64_t stat_fused3d = 0, stat_fused2d = 0, stat_thermal_fused = 0, stat_vep3_fused = 0, stat_graph_replays = 0;
     bool chain_profile = false;          // tuning switch: jrx_stokes3d_iterate_timed also times the stages of a multi-rank fused step (jrx_tuning_chain_profile)
     double chain_us[8] = {};

@@ -93,37 +93,48 @@ bool fits_u32(const Lay3 &L)
 // kernels run (and produce the reference's NaNs).  η must be finite, too: the viscous-limit form of the fused kernel folds η · 0 = 0 (k_fused3d, VFOLD).  sets h->visc_ok.
 __global__ __launch_bounds__(256) void k_visc_operands_ok(const double *__restrict__ c0, const double *__restrict__ c1, const double *__restrict__ c2, const double *__restrict__ c3,
                                                           const double *__restrict__ c4, const double *__restrict__ eta, i64 nc, const double *__restrict__ K, const double *__restrict__ G,
-                                                          const double *__restrict__ yz, i64 nyz, const double *__restrict__ xz, i64 nxz, const double *__restrict__ xy, i64 nxy, int *bad)
+                                                          const double *__restrict__ yz, i64 nyz, const double *__restrict__ xz, i64 nxz, const double *__restrict__ xy, i64 nxy, int *bad,
+                                                          const unsigned long long *__restrict__ fx, const unsigned long long *__restrict__ fy, const unsigned long long *__restrict__ fz)
 {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     bool b = false;
+    unsigned long long bxy = 0, bz = 0;        // fx != nullptr: the same pass ORs the bits of the body forces (bad |= 2: ρg_x or ρg_y has an entry that is not +0.0, |= 4: ρg_z has)
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < nyz || t < nxz || t < nxy; t += stride) {
         if (t < nc) {
             b |= !(isfinite(c0[t]) && isfinite(c1[t]) && isfinite(c2[t]) && isfinite(c3[t]) && isfinite(c4[t]) && isfinite(eta[t]));
             const double k = K[t], g = G[t];
             b |= (k != k) || (g != g) || k == 0.0 || g == 0.0;
+            if (fx) { bxy |= fx[t] | fy[t]; bz |= fz[t]; }
         }
         if (t < nyz) b |= !isfinite(yz[t]);
         if (t < nxz) b |= !isfinite(xz[t]);
         if (t < nxy) b |= !isfinite(xy[t]);
     }
     if (__any(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+    if (fx) {
+        const int m = (__any(bxy != 0) ? 2 : 0) | (__any(bz != 0) ? 4 : 0);
+        if (m && (threadIdx.x & 63) == 0) atomicOr(bad, m);
+    }
 }
 
 jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
 {
     h->visc_ok = false;
+    h->nof = 0;
     if (!h->viscous_limit || p->dt != INFINITY) return JRX_OK;
     const i64 nx = p->nx, ny = p->ny, nz = p->nz;
     int *d_bad = reinterpret_cast<int *>(h->d_sums + 6), *h_bad = reinterpret_cast<int *>(h->h_sums + 6);
     hipStream_t s = h->stream;
     JRX_HIP(h, hipMemsetAsync(d_bad, 0, sizeof(double), s));
     hipLaunchKernelGGL(k_visc_operands_ok, dim3(4096), dim3(256), 0, s, f->P0, f->Q, f->toxx, f->toyy, f->tozz, f->eta, nx * ny * nz, f->K, f->G, f->toyz, nx * (ny + 1) * (nz + 1),
-                       f->toxz, (nx + 1) * ny * (nz + 1), f->toxy, (nx + 1) * (ny + 1) * nz, d_bad);
+                       f->toxz, (nx + 1) * ny * (nz + 1), f->toxy, (nx + 1) * (ny + 1) * nz, d_bad,
+                       h->zero_forces ? reinterpret_cast<const unsigned long long *>(f->fx) : nullptr, reinterpret_cast<const unsigned long long *>(f->fy), reinterpret_cast<const unsigned long long *>(f->fz));
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipMemcpyAsync(h_bad, d_bad, sizeof(double), hipMemcpyDeviceToHost, s));
     JRX_HIP(h, hipStreamSynchronize(s));
-    h->visc_ok = (*h_bad == 0);
+    h->visc_ok = ((*h_bad & 1) == 0);
+    // body forces that are +0.0 throughout need not be streamed (k_fused3d, NOF): the usual 3D model has gravity along z only, SolVi3D has none
+    if (h->visc_ok && h->zero_forces && !(*h_bad & 2)) h->nof = (*h_bad & 4) ? 1 : 2;
     h->stat_visc_checks++;
     if (!h->visc_ok) h->stat_visc_fallbacks++;
     return JRX_OK;
@@ -584,16 +595,31 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     // instead of the third LDS slot: LOWREG off, -1.4 %, scripts/kbench_visc.hip)
     const bool visc = h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
     const bool vf = h->visc_fold;      // tuning switch: the folded arithmetic of the viscous limit (k_fused3d, VFOLD; same bits)
+    const int nof = (visc && fold && vf) ? h->nof : 0;     // body-force arrays that hold only +0.0 are not loaded (set by the operand pass; the one-launch form only)
     if (shell) {        // neighbours, one launch: interior tiles first, the tiles next to a face with a neighbour last (they wait for the exchange's flag)
         if (!(visc && fold)) return jrx_fail(h, JRX_ERR_ARG, "internal: the in-kernel neighbour faces need the one-launch viscous-limit form");
         // blk0 = 0: box 0 (tiles that touch no face with a neighbour, beside the exchange); blk0 = start[1]: everything else, behind it
         const int nblk = shell->cls == 0 ? shell->start[1] : shell->start[shell->nbox] - shell->start[1];
-        if (nblk > 0)
-            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
-        if (shell->cls != 0) h->stat_fused3d_inkernel++;
+        if (nblk > 0) {
+            if (nof == 2)
+                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true, 2>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
+            else if (nof == 1)
+                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true, 1>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
+            else
+                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
+        }
+        if (shell->cls != 0) { h->stat_fused3d_inkernel++; if (nof == 1) h->stat_fused3d_nof1++; else if (nof == 2) h->stat_fused3d_nof2++; }
         else { JRX_LAUNCH_CHECK(h); return JRX_OK; }       // counted once per iteration, with the second class
-    } else if (visc && fold && vf)       // + the high-face node layers inside the kernel: the whole iteration in one launch
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+    } else if (visc && fold && vf) {     // + the high-face node layers inside the kernel: the whole iteration in one launch
+        if (nof == 2) {
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+            h->stat_fused3d_nof2++;
+        } else if (nof == 1) {
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+            h->stat_fused3d_nof1++;
+        } else
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+    }
     else if (visc && fold)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc && !hiface && vf)

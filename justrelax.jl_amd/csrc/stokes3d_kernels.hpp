@@ -690,7 +690,7 @@ __device__ __forceinline__ double LDC(const double *p, u32 off)
 // HIF (viscous-limit form, no neighbours): the stress nodes on the high faces i = nx, j = ny, k = nz -- which no cell column owns and which the boundary-layer launch
 // (k_stress3d_boxes with the flow_bcs! rules) otherwise updates behind this kernel -- are updated here by the threads of the last cell column / row / plane, from the
 // new velocities they hold anyway and the same rules (GhostRule), operation for operation as stress3d_node<false, true, true>: one launch per iteration.
-template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false, bool VFOLD = false, bool NBR = false>
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false, bool VFOLD = false, bool NBR = false, int NOF = 0>
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0, const FusedShell sh = FusedShell{})
 {
     // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
@@ -714,6 +714,11 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
 #define NBVX(flag_, off_, ii_) ((NBR && bc.flag_) ? ((((ii_) == 0 && bc.nsL) || ((ii_) == nx && bc.nsR)) ? 0.0 : LDC(a.o.Vx, (off_))) : LDB(f.Vx, (off_)))
 #define NBVY(flag_, off_, jj_) ((NBR && bc.flag_) ? ((((jj_) == 0 && bc.nsF) || ((jj_) == ny && bc.nsBk)) ? 0.0 : LDC(a.o.Vy, (off_))) : LDB(f.Vy, (off_)))
 #define NBVZ(flag_, off_, kk_) ((NBR && bc.flag_) ? ((((kk_) == 0 && bc.nsK0) || ((kk_) == nz && bc.nsK1)) ? 0.0 : LDC(a.o.Vz, (off_))) : LDB(f.Vz, (off_)))
+    // NOF: body-force arrays that are +0.0 in every entry (the driver's operand pass has seen all their bits zero) are not loaded: 1 = fx, fy (gravity along z), 2 = all three
+    static_assert(NOF == 0 || (VISC && HIF && VFOLD), "the forms without body-force loads are built on the one-launch viscous-limit form");
+#define LFX(off_) (NOF >= 1 ? 0.0 : LDN<(NT & 2) != 0>(f.fx, (off_)))
+#define LFY(off_) (NOF >= 1 ? 0.0 : LDN<(NT & 2) != 0>(f.fy, (off_)))
+#define LFZ(off_) (NOF >= 2 ? 0.0 : LDN<(NT & 2) != 0>(f.fz, (off_)))
     const int tx = (int)(threadIdx.x % TX), ty = (int)(threadIdx.x / TX);
     int tile = blockIdx.x;
     int tix, tiy, tiz;
@@ -784,7 +789,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     // velocity-sweep carries (plane k values that were the upper loads of the previous plane)
     double Pc = 0, ec = 0, tzz_c = 0, fz_c = 0, s10 = 0, r10 = 0, s01p = 0, r01p = 0;
     if (bvalid) {
-        Pc = LDB(f.P, oc); ec = LDB(et, oc); tzz_c = LDB(f.tzz, oc); fz_c = LDN<(NT & 2) != 0>(f.fz, oc);
+        Pc = LDB(f.P, oc); ec = LDB(et, oc); tzz_c = LDB(f.tzz, oc); fz_c = LFZ(oc);
         s10 = LDB(f.txz, oxz + 8u - sxz); r10 = LDB(f.tyz, oyz + ryz - syz);
         s01p = LDB(f.txz, oxz - sxz); r01p = LDB(f.tyz, oyz - syz);
     }
@@ -842,14 +847,14 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             const u32 dz1 = hz ? sc : 0u;
             if (YLDS) {
                 // published operands first (loads return in order), then the rest
-                tyy_c = LDB(f.tyy, oc); fy_c = LDN<(NT & 2) != 0>(f.fy, oc); txy_own = LDB(f.txy, oxy); r01 = LDB(f.tyz, oyz);
+                tyy_c = LDB(f.tyy, oc); fy_c = LFY(oc); txy_own = LDB(f.txy, oxy); r01 = LDB(f.tyz, oyz);
                 if (!yrow) {
                     q01 = LDB(f.txy, oxy + rxy); r11 = LDB(f.tyz, oyz + ryz);
-                    if (hy) { Py = LDB(f.P, oc + rc); eyb = LDB(et, oc + rc); tyy_y = LDB(f.tyy, oc + rc); fy_y = LDN<(NT & 2) != 0>(f.fy, oc + rc); }
+                    if (hy) { Py = LDB(f.P, oc + rc); eyb = LDB(et, oc + rc); tyy_y = LDB(f.tyy, oc + rc); fy_y = LFY(oc + rc); }
                 }
                 s01 = LDB(f.txz, oxz);
-                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDN<(NT & 2) != 0>(f.fz, oc + dz1);
-                txx_c = LDB(f.txx, oc); fx_c = LDN<(NT & 2) != 0>(f.fx, oc);
+                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LFZ(oc + dz1);
+                txx_c = LDB(f.txx, oc); fx_c = LFX(oc);
                 vx = LDB(f.Vx, ovx); vy = LDB(f.Vy, ovy); vz = LDB(f.Vz, ovz);
                 if (NBR) {      // the boundary planes i = nx, j = ny, k = nz of a face with a neighbour: received values
                     if (!hx && bc.nbR) vx = LDC(a.o.Vx, ovx);
@@ -863,17 +868,17 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                     toxy = LDN<(NT & 2) != 0>(f.toxy, oxy);
                     toxz = LDN<(NT & 2) != 0>(f.toxz, oxz - sxz); toyz = LDN<(NT & 2) != 0>(f.toyz, oyz - syz);
                 }
-                sY[0][ty][tx] = Pc; sY[1][ty][tx] = ec; sY[2][ty][tx] = tyy_c; sY[3][ty][tx] = fy_c; sY[4][ty][tx] = txy_own; sY[5][ty][tx] = r01;
+                sY[0][ty][tx] = Pc; sY[1][ty][tx] = ec; sY[2][ty][tx] = tyy_c; if (NOF < 1) sY[3][ty][tx] = fy_c; sY[4][ty][tx] = txy_own; sY[5][ty][tx] = r01;
                 sY[6][ty][tx] = e;
                 if (!VISC) sY[7][ty][tx] = g;
             } else {
                 q01 = LDB(f.txy, oxy + rxy); s01 = LDB(f.txz, oxz);
                 r11 = LDB(f.tyz, oyz + ryz); r01 = LDB(f.tyz, oyz);
-                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LDN<(NT & 2) != 0>(f.fz, oc + dz1);
+                Pz = LDB(f.P, oc + dz1); ez = LDB(et, oc + dz1); tzz_z = LDB(f.tzz, oc + dz1); fz_z = LFZ(oc + dz1);
                 Py = LDB(f.P, oc + dy1); eyb = LDB(et, oc + dy1);
                 txx_c = LDB(f.txx, oc); tyy_c = LDB(f.tyy, oc);
                 tyy_y = LDB(f.tyy, oc + dy1);
-                fx_c = LDN<(NT & 2) != 0>(f.fx, oc); fy_c = LDN<(NT & 2) != 0>(f.fy, oc); fy_y = LDN<(NT & 2) != 0>(f.fy, oc + dy1);
+                fx_c = LFX(oc); fy_c = LFY(oc); fy_y = LFY(oc + dy1);
                 vx = LDB(f.Vx, ovx); vy = LDB(f.Vy, ovy); vz = LDB(f.Vz, ovz);
             }
         }
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
         if (bvalid) {
             if (YLDS) {
                 if (yrow) {
-                    Py = sY[0][ty + 1][tx]; eyb = sY[1][ty + 1][tx]; tyy_y = sY[2][ty + 1][tx]; fy_y = sY[3][ty + 1][tx];
+                    Py = sY[0][ty + 1][tx]; eyb = sY[1][ty + 1][tx]; tyy_y = sY[2][ty + 1][tx]; if (NOF < 1) fy_y = sY[3][ty + 1][tx];
                     q01 = sY[4][ty + 1][tx]; r11 = sY[5][ty + 1][tx];
                 }
                 // stress phase: η, G at j-1 from the row below (clamped at j = 0), then the i-1 column by lane shuffle (clamped at i = 0)
@@ -901,27 +906,31 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                 if (!YLDS) txy_own = LDB(f.txy, oxy);
                 txy = txy_own;                                  // also the stress phase's own τxy
                 q11 = __shfl_down(q01, 1, TX); q10 = __shfl_down(txy_own, 1, TX); s11 = __shfl_down(s01, 1, TX);
-                Px = __shfl_down(Pc, 1, TX); ex = __shfl_down(ec, 1, TX); txx_x = __shfl_down(txx_c, 1, TX); fx_x = __shfl_down(fx_c, 1, TX);
+                Px = __shfl_down(Pc, 1, TX); ex = __shfl_down(ec, 1, TX); txx_x = __shfl_down(txx_c, 1, TX); fx_x = NOF >= 1 ? 0.0 : __shfl_down(fx_c, 1, TX);
                 // the last cell column has no lane to its right, but its y- and z-momentum still need the shear stresses on the
                 // domain's right face (τxy, τxz have nx+1 columns)
                 if (!hx) { q11 = LDB(f.txy, oxy + 8u + rxy); s11 = LDB(f.txz, oxz + 8u); }
             } else {
                 q11 = LDB(f.txy, oxy + 8u + rxy); q10 = LDB(f.txy, oxy + 8u); s11 = LDB(f.txz, oxz + 8u);
-                Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = LDN<(NT & 2) != 0>(f.fx, oc + dx1);
+                Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = LFX(oc + dx1);
             }
             const bool own = avalid && live;
             if (hx) {
-                const double R = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx - 0.5 * (fx_c + fx_x);
+                // NOF: x - (+0.0) = x for every x, -0.0 and NaN included, so the term is left out when the array is known to hold nothing but +0.0
+                const double R0 = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx;
+                const double R = NOF >= 1 ? R0 : R0 - 0.5 * (fx_c + fx_x);
                 vxn = vx + R * edt / (0.5 * (ec + ex));
                 if (own) STN<(NT & 1) != 0>(a.o.Vx, ovx, vxn);
             } else vxn = bc.nsR ? 0.0 : vx;
             if (hy) {
-                const double R = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy - 0.5 * (fy_c + fy_y);
+                const double R0 = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy;
+                const double R = NOF >= 1 ? R0 : R0 - 0.5 * (fy_c + fy_y);
                 vyn = vy + R * edt / (0.5 * (ec + eyb));
                 if (own) STN<(NT & 1) != 0>(a.o.Vy, ovy, vyn);
             } else vyn = bc.nsBk ? 0.0 : vy;
             if (hz) {
-                const double R = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz - 0.5 * (fz_c + fz_z);
+                const double R0 = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz;
+                const double R = NOF >= 2 ? R0 : R0 - 0.5 * (fz_c + fz_z);
                 vzn = vz + R * edt / (0.5 * (ec + ez));
                 if (own) STN<(NT & 1) != 0>(a.o.Vz, ovz, vzn);
             } else vzn = bc.nsK1 ? 0.0 : vz;
@@ -1122,6 +1131,9 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
 #undef NBVX
 #undef NBVY
 #undef NBVZ
+#undef LFX
+#undef LFY
+#undef LFZ
 }
 
 }   // namespace

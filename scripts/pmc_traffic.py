@@ -29,7 +29,8 @@ def main():
     n = 512.0 ** 3
     lines = ["# python3 bench.py --no-extras --no-cpu-baseline --no-steady-state --steps 20 --warmup 2 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each); FETCH_SIZE doubled",
              "# (gfx950: 128-B read requests tallied at 64 B, MI355X_MICROARCH.md 'HBM'); rocprofv3 reports KiB; passes = bytes / (8 B x 512^3)",
-             "# k_fused3d<..., TAG, VISC, HIF>: VISC true = viscous-limit form (the headline, dt = Inf), false = general form (the general_kernel leg); HIF true = high-face layers inside"]
+             "# k_fused3d<..., TAG, VISC, HIF, VFOLD, NBR, NOF>: VISC true = viscous-limit form (dt = Inf), false = general form (the general_kernel leg); HIF true = high-face layers inside;",
+             "# NOF (last argument) 2 = the three zero body-force arrays of SolVi3D are not loaded (the headline), 0 = they are (the with_body_forces leg)"]
     tot = {}
     for k, d in sorted(res.items()):
         if "at::" in k or "rocclr" in k:
@@ -47,7 +48,9 @@ def main():
             return max(c) if c else None
         targs = lambda k: [a.strip() for a in k[k.index("<") + 1:k.index(">")].split(",")] if "<" in k else []
         fused = {k: v for k, v in tot.items() if "k_fused3d<" in k}
-        visc = pick(lambda k: "k_fused3d<" in k and len(targs(k)) >= 13 and targs(k)[12] == "true")
+        nof = lambda k: int(targs(k)[16]) if len(targs(k)) >= 17 else 0        # template argument NOF: body-force arrays not loaded (0 none, 1 ρg_x, ρg_y, 2 all three)
+        visc = pick(lambda k: "k_fused3d<" in k and len(targs(k)) >= 13 and targs(k)[12] == "true" and nof(k) == 0)
+        visc_n = {l: pick(lambda k: "k_fused3d<" in k and len(targs(k)) >= 13 and targs(k)[12] == "true" and nof(k) == l) for l in (1, 2)}
         gen = pick(lambda k: "k_fused3d<" in k and (len(targs(k)) < 13 or targs(k)[12] == "false"))
         zb_v = pick(lambda k: "k_stress3d_zb<" in k and targs(k)[-1] == "true")
         zb_g = pick(lambda k: "k_stress3d_zb<" in k and targs(k)[-1] == "false")
@@ -56,8 +59,8 @@ def main():
         json.dump({"what": "L2<->fabric bytes per launch of the dominant kernels at n = 512 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE doubled per the gfx950 "
                            "correction of MI355X_MICROARCH.md), written by scripts/pmc_traffic.py; bench.py prints `traffic: null` when csrc/stokes3d_kernels.hpp differs from the file these passes ran",
                    "kernels_sha256": sha, "git_head": head, "source": source, "n": 512,
-                   "k_fused3d_general": gen, "k_fused3d_visc": visc, "k_stress3d_zb_general": zb_g, "k_stress3d_zb_visc": zb_v}, open(jpath, "w"), indent=1)
-        print("wrote", jpath, "visc", visc, "general", gen)
+                   "k_fused3d_general": gen, "k_fused3d_visc": visc, "k_fused3d_visc_nof1": visc_n[1], "k_fused3d_visc_nof2": visc_n[2], "k_stress3d_zb_general": zb_g, "k_stress3d_zb_visc": zb_v}, open(jpath, "w"), indent=1)
+        print("wrote", jpath, "visc", visc, "visc without body forces", visc_n, "general", gen)
 
 
 if __name__ == "__main__":

@@ -300,6 +300,59 @@ def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
             assert (k[0] == "U" or np.isfinite(outs[0][k][m]).all()) and np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)      # U = V dt = ±Inf, NaN where V = 0
 
 
+@pytest.mark.parametrize("zero,nof", [("xy", 1), ("xyz", 2), ("xy one entry -0.0", 0), ("xy one entry 1e-300", 0), ("z", 0), ("xz", 0), ("", 0)])
+@pytest.mark.parametrize("ni,bcs,tile", [((130, 20, 17), "free_slip", 0), ((66, 9, 35), "slip_mix", 1), ((97, 9, 33), "none", 0)])
+def test_body_forces_that_are_zero_are_not_loaded_and_the_bits_stay(env, ni, bcs, tile, zero, nof):
+    """SolVi3D.jl:102 hands three ρg arrays of zeros, and every 3D model of the reference has ρg_x = ρg_y = 0 (gravity along z).  The one-launch viscous-limit kernel does not
+    load body-force arrays in which the operand pass of the driver call has found nothing but +0.0 (all 64 bits zero): x - 0.5 (0 + 0) = x for every x, -0.0 and NaN included.
+    A single -0.0 (x - (-0.0) turns x = -0.0 into +0.0) or a denormal keeps the loads.  Every case equals the per-node general kernels and the same form with the loads."""
+    jr = env["jr"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields3d(ni, bcs=bcs, dt=np.inf, iterMax=23, nout=7)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    comps = zero.split(" ")[0]
+    for c in comps:
+        s.arrays["f" + c][...] = 0.0
+    if "-0.0" in zero:
+        s.arrays["fy"][ni[0] // 2, ni[1] - 1, 3] = -0.0
+    if "1e-300" in zero:
+        s.arrays["fx"][0, 0, 0] = 1e-300
+    # velocities / stresses with zeros of both signs in them, so that a dropped "- 0.0" would show
+    s.arrays["Vx"][3:9, 2:6, 2:9] = 0.0
+    s.arrays["txx"][2:9, 2:6, 2:9] = -0.0
+    h = _lib.default_handle()
+    tile0 = h.get_option("fused_tile")
+    outs, its, cnt = [], [], []
+    try:
+        h.set_option("fused_tile", tile)
+        for variant, zf in ((3, 1), (3, 0), (1, 1)):
+            h.set_option("kernel_variant", variant)
+            h.set_option("zero_forces", zf)
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            c0 = [h.get_option(k) for k in ("stat_fused3d", "stat_fused3d_nof1", "stat_fused3d_nof2")]
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+            c1 = [h.get_option(k) for k in ("stat_fused3d", "stat_fused3d_nof1", "stat_fused3d_nof2")]
+            cnt.append([b - a for a, b in zip(c0, c1)])
+            its.append((r.iter, tuple(r.err_evo1)))
+            outs.append(env["down"](stokes))
+    finally:
+        h.set_option("kernel_variant", 0)
+        h.set_option("zero_forces", 1)
+        h.set_option("fused_tile", tile0)
+    assert cnt[0][0] > 0 and cnt[0][0] == cnt[1][0] and cnt[1][1:] == [0, 0] and cnt[2] == [0, 0, 0], cnt
+    assert cnt[0][1] == (cnt[0][0] if nof == 1 else 0) and cnt[0][2] == (cnt[0][0] if nof == 2 else 0), (cnt, nof)
+    assert its[0] == its[1] == its[2] and its[0][0] == 24
+    for v in (1, 2):
+        for k in outs[0]:
+            m = env["checks"].interior_mask3d(k, outs[0][k].shape)
+            # array_equal treats -0.0 == +0.0: compare the bit patterns
+            a, b = np.ascontiguousarray(outs[0][k][m]), np.ascontiguousarray(outs[v][k][m])
+            if k[0] == "U":      # U = V dt = ±Inf, NaN where V = 0
+                assert np.array_equal(a, b, equal_nan=True), (v, k)
+            else:
+                assert np.isfinite(a).all() and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (v, k)
+
+
 @pytest.mark.parametrize("poison", ["toxx=nan", "toyz=inf", "P0=inf", "Q=nan", "K=0", "G=nan", "none"])
 def test_viscous_limit_falls_back_when_an_unloaded_operand_is_not_harmless(env, poison):
     """VERDICT r3 P3.  With dt = Inf the reference still multiplies τ_o, P0, Q by 0 and divides by K dt, G dt: a NaN / Inf in one of them (or K, G = 0: 0 * Inf)

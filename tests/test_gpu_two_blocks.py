@@ -223,6 +223,40 @@ def test_blocks_in_the_viscous_limit_finish_their_neighbour_faces_inside_the_ker
             assert np.isfinite(want[m]).all() and np.array_equal(out[k][m], want[m]), (dims, bcs, r, co, k, float(np.abs(out[k] - want)[m].max()))
 
 
+@pytest.mark.parametrize("zero,nof", [("xy", 1), ("xyz", 2)])
+@pytest.mark.parametrize("dims,n,bcs", [((2, 1, 1), (130, 14, 40), "free_slip"), ((1, 1, 2), (70, 13, 12), "slip_mix"), ((2, 2, 2), (70, 13, 12), "no_slip")])
+def test_blocks_whose_body_forces_are_zero_do_not_load_them_and_keep_the_bits(jr, dims, n, bcs, zero, nof):
+    """ρg_x = ρg_y = +0.0 (gravity along z: every 3D model of the reference) or all three (SolVi3D.jl:102): the one-launch viscous-limit kernel with the neighbour faces inside
+    does not load those arrays (k_fused3d, NOF) -- every block still equals the undecomposed run of the per-node general kernels, which subtract the zeros, bit for bit."""
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    from justrelax_jl_amd.checks import interior_mask3d
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        S = _global_setup(jr, tb.ng, True, 23, 8, seed=22, bcs=bcs, dt=np.inf)
+        for c in zero:
+            S.arrays["f" + c][...] = 0.0
+        h0 = _lib.default_handle()
+        _set(h0, kernel_variant=1, viscous_limit=0)
+        try:
+            stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+            rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw)
+            glob = download_stokes(stokes)
+        finally:
+            _set(h0, kernel_variant=0, viscous_limit=1)
+        res, outs = _solve_blocks(jr, tb, S, "fused_inkernel", kw)
+        launches = [(_get(h, "stat_fused3d_inkernel"), _get(h, "stat_fused3d_nof1"), _get(h, "stat_fused3d_nof2")) for h in tb.handles]
+    for l in launches:
+        assert l[0] >= 12 and l[nof] == l[0] and l[3 - nof] == 0, launches
+    assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    for r, out in enumerate(outs):
+        co = B.coords_of(tb.carts[r])
+        for k in STATE + ("Rx", "Ry", "Rz", "RP"):
+            want = B.local_block(glob[k], n, tb.ng, co)
+            m = interior_mask3d(k, want.shape)
+            assert np.isfinite(want[m]).all() and np.array_equal(out[k][m], want[m]), (dims, bcs, r, co, k, float(np.abs(out[k] - want)[m].max()))
+
+
 @pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "split_sweeps"])
 @pytest.mark.parametrize("dims", [(2, 1, 1), (1, 2, 1), (1, 1, 2)])
 def test_two_blocks_with_an_inclusion_match_the_oracle_block_by_block(jr, oracle, dims, pipeline):
