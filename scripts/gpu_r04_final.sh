@@ -1,11 +1,11 @@
 #!/bin/bash
 # final evidence of round 4: GPU suite, profile (kernel stats + PMC + default bench line), the N > 1 bench control flow on one device
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04final
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r04final}
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1
 tail -3 $OUT/pytest_gpu.txt
-bash scripts/gpu_r04_profile.sh r04final
+bash scripts/gpu_r04_profile.sh ${1:-r04final}
 cd $GRAFT_REPO_ROOT
 for cfg in "2 512" "8 192"; do
   set -- $cfg
