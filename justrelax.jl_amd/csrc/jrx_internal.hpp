@@ -48,6 +48,7 @@ struct jrx_handle {
     bool comm_bcs_lazy = false;          // multi-rank fused pipeline: 1 = flow_bcs! of the physical faces is not applied in memory every iteration (the fix-up derives those entries by rule) but
                                          // lazily, before anything reads them.  Measured (two 512^3 blocks, profiles/r04_comm_bcs_lazy_ab.txt): the rule form of the fix-up costs more than the two
                                          // BC launches it saves (-2 %): off
+    bool end_flips = true;               // jrx_stokes3d_iterate_timed: a batch with an odd number of fused steps ends in the caller's arrays through out-of-place end sweeps (0: first step un-fused)
     bool zero_forces = true;             // viscous-limit one-launch kernel: body-force arrays whose every entry is +0.0 (all bits zero; the operand pass looks) are not loaded (k_fused3d, NOF; same bits)
     int nof = 0;                         // set per driver call by the operand pass: 0 = every ρg array is loaded, 1 = ρg_x and ρg_y hold only +0.0, 2 = all three do
     bool visc_fold = true;               // viscous-limit fused kernel: the arithmetic with the exact zeros folded away (one division per thread for dτ_r, no division by 1 in compute_P!; same bits; A/B)

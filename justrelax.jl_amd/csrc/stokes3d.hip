@@ -510,7 +510,12 @@ struct Iter3D {
     const double *etatau;
     jrx_stokes3d_fields cur;      // caller's fields with the 10 state pointers of the current set
     Out10 setU, setS;             // caller's arrays / scratch arrays
-    bool cur_is_user = true;
+    // where the current state lives, per group: P and the six stresses / the three velocities.  A fused step moves both groups to the other set; an un-fused stress or
+    // velocity sweep can move its own group alone (flip_A / flip_B: it writes out of place -- every sweep reads only the node's own old value of what it writes), which is how a
+    // batch with an odd number of fused steps still ends in the caller's arrays without a copy-back and without an extra un-fused iteration (jrx_stokes3d_iterate_timed)
+    bool pt_user = true, v_user = true;
+    bool flip_A = false, flip_B = false;    // the next un-fused stress sweep / velocity sweep writes its group into the other set (no communicator, no periodic faces)
+    bool all_user() const { return pt_user && v_user; }
     bool stress_done = false;     // A of the upcoming iteration already applied (by a fused launch)
     bool fusable = false;
     bool bcs_ordered[2] = {false, false};   // flow_bcs! has run with the reference's pass order on the V of set U / set S
@@ -522,6 +527,8 @@ static void set_state(jrx_stokes3d_fields &f, const Out10 &o)
 {
     f.P = o.P; f.txx = o.txx; f.tyy = o.tyy; f.tzz = o.tzz; f.tyz = o.tyz; f.txz = o.txz; f.txy = o.txy; f.Vx = o.Vx; f.Vy = o.Vy; f.Vz = o.Vz;
 }
+// P and the stresses of `pt`, the velocities of `v`
+static Out10 mix_sets(const Out10 &pt, const Out10 &v) { return Out10{pt.P, pt.txx, pt.tyy, pt.tzz, pt.tyz, pt.txz, pt.txy, v.Vx, v.Vy, v.Vz}; }
 
 static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
 {
@@ -545,7 +552,7 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
     JRX_TRY(visc_operands_check(h, f, p));       // may the viscous-limit kernels stand in for the general ones? (dt = Inf only)
     I.cur = *f;
     I.setU = out_of(*f);
-    I.cur_is_user = true; I.stress_done = false;
+    I.pt_user = I.v_user = true; I.flip_A = I.flip_B = false; I.stress_done = false;
     const Lay3 L = make_lay((int)p->nx, (int)p->ny, (int)p->nz);
     // option "fused_comm" = 0 keeps the split sweeps + hidden communication on multi-rank runs (A/B switch; same results);
     // option "scratch_sets" = 0 refuses the library-owned second state set the fused pipeline needs
@@ -693,13 +700,25 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
     if (chain_mode) *chain_mode = 0;
     if (ncells_timed) *ncells_timed = (double)nx * ny * nz;
     if (tev) JRX_HIP(h, hipEventRecord(tev[0], s));
-    if (!I.stress_done) JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
+    if (!I.stress_done) {
+        if (I.flip_A) {
+            // out of place: the new P and stresses go to the other set (the sweep writes every entry of the seven arrays), the velocities stay where they are
+            const Out10 other = mix_sets(I.pt_user ? I.setS : I.setU, I.v_user ? I.setU : I.setS);
+            a.o = other;
+            JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
+            set_state(I.cur, other);
+            I.pt_user = !I.pt_user;
+            I.flip_A = false;
+            a = make_args(&I.cur, I.etatau, p);
+        } else
+            JRX_TRY(launch_stress(h, s, a, diag, 0, nx + 1, 0, ny + 1, 0, nz + 1));
+    }
     I.stress_done = false;
     if (tev) JRX_HIP(h, hipEventRecord(tev[1], s));
 
     if (I.fusable && fuse_next && !diag) {
         // B_m + BCs + A_{m+1}: src = current set, dst = the other set
-        const Out10 dst = I.cur_is_user ? I.setS : I.setU;
+        const Out10 dst = mix_sets(I.pt_user ? I.setS : I.setU, I.v_user ? I.setS : I.setU);
         a.o = dst;
         FusedBC bc;
         const uint32_t fs = p->free_slip, ns = p->no_slip;
@@ -718,7 +737,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         const bool per = p->periodic != 0;
         hipStream_t bs = s;            // stream of the boundary work
         // flow_bcs! on the new V: the reference's ordered passes the first time a set is written, one launch for all faces afterwards
-        bool &ordered = I.bcs_ordered[I.cur_is_user ? 1 : 0];
+        bool &ordered = I.bcs_ordered[I.v_user ? 1 : 0];
         auto fused_bcs = [&](hipStream_t st) -> jrx_status {
             if (ordered && !per) return launch_bcs_faces(h, st, dst.Vx, dst.Vy, dst.Vz, nx, ny, nz, p->free_slip, p->no_slip);
             ordered = true;
@@ -980,7 +999,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             if (tev && !split) JRX_HIP(h, hipEventRecord(tev[3], s));     // shell/interior overlap with neighbours: only the whole group can be timed
         }
         set_state(I.cur, dst);
-        I.cur_is_user = !I.cur_is_user;
+        I.pt_user = !I.pt_user; I.v_user = !I.v_user;
         I.stress_done = true;
         if (was_fused) *was_fused = 1;
         if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
@@ -993,10 +1012,20 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             // U = V dt below copies the boundary entries of V as flow_bcs! of the previous iteration left them (the reference applies
             // flow_bcs! after velocity2displacement!): apply that pending flow_bcs! now, before V is updated
             JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
-            I.bcs_ordered[I.cur_is_user ? 0 : 1] = true;
+            I.bcs_ordered[I.v_user ? 0 : 1] = true;
         }
         I.ghosts_stale = false;
-        JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
+        if (I.flip_B && !p->displacement_bcs) {
+            // out of place: the new velocities go to the other set, whose boundary and ghost entries hold the caller's values (its own arrays, or their copy: k_copy_shell3);
+            // flow_bcs! below then acts on that set
+            const Out10 other = mix_sets(I.pt_user ? I.setU : I.setS, I.v_user ? I.setS : I.setU);
+            a.o = other;
+            JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
+            set_state(I.cur, other);
+            I.v_user = !I.v_user;
+        } else
+            JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
+        I.flip_B = false;
         if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
         if (diag) JRX_TRY(launch_scaleU(h, s, f, p));
         if (p->displacement_bcs) {
@@ -1006,7 +1035,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         }
         // flow_bcs!: the reference's ordered passes on observable iterations and the first time a set is written, otherwise all faces in
         // one launch (same values wherever a stencil reads them)
-        bool &ordered = I.bcs_ordered[I.cur_is_user ? 0 : 1];
+        bool &ordered = I.bcs_ordered[I.v_user ? 0 : 1];
         if (!diag && ordered && p->periodic == 0) JRX_TRY(launch_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
         else {
             JRX_TRY(launch_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));
@@ -1031,21 +1060,24 @@ static jrx_status iter_end(Iter3D &I)
 {
     jrx_handle *h = I.h;
     if (I.stress_done) return jrx_fail(h, JRX_ERR_ARG, "internal: iteration pipeline ended with a pending fused stress sweep");
-    if (I.cur_is_user) return JRX_OK;
+    if (I.all_user()) return JRX_OK;
     const jrx_stokes3d_params *p = I.p;
     const i64 nc = (i64)p->nx * p->ny * p->nz, nyz = (i64)p->nx * (p->ny + 1) * (p->nz + 1), nxz = (i64)(p->nx + 1) * p->ny * (p->nz + 1),
               nxy = (i64)(p->nx + 1) * (p->ny + 1) * p->nz, n0 = (i64)(p->nx + 1) * (p->ny + 2) * (p->nz + 2),
               n1 = (i64)(p->nx + 2) * (p->ny + 1) * (p->nz + 2), n2 = (i64)(p->nx + 2) * (p->ny + 2) * (p->nz + 1);
     const Out10 &S = I.setS, &U = I.setU;
-    hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, h->stream, U.P, (const double *)S.P, nc, U.txx, (const double *)S.txx, nc, U.tyy,
-                       (const double *)S.tyy, nc, U.tzz, (const double *)S.tzz, nc, U.tyz, (const double *)S.tyz, nyz, U.txz, (const double *)S.txz, nxz);
-    JRX_LAUNCH_CHECK(h);
-    hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, h->stream, U.txy, (const double *)S.txy, nxy, U.Vx, (const double *)S.Vx, n0, U.Vy,
-                       (const double *)S.Vy, n1, U.Vz, (const double *)S.Vz, n2, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr,
+    const i64 zp = I.pt_user ? 0 : 1, zv = I.v_user ? 0 : 1;        // a group that is in the caller's arrays already is not copied (count 0)
+    if (zp) {
+        hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, h->stream, U.P, (const double *)S.P, nc, U.txx, (const double *)S.txx, nc, U.tyy,
+                           (const double *)S.tyy, nc, U.tzz, (const double *)S.tzz, nc, U.tyz, (const double *)S.tyz, nyz, U.txz, (const double *)S.txz, nxz);
+        JRX_LAUNCH_CHECK(h);
+    }
+    hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, h->stream, U.txy, (const double *)S.txy, nxy * zp, U.Vx, (const double *)S.Vx, n0 * zv, U.Vy,
+                       (const double *)S.Vy, n1 * zv, U.Vz, (const double *)S.Vz, n2 * zv, (double *)nullptr, (const double *)nullptr, (i64)0, (double *)nullptr,
                        (const double *)nullptr, (i64)0);
     JRX_LAUNCH_CHECK(h);
     set_state(I.cur, U);
-    I.cur_is_user = true;
+    I.pt_user = I.v_user = true;
     return JRX_OK;
 }
 
@@ -1095,7 +1127,7 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
     GraphExecs gexec;
     bool graphs = h->loop_graphs && !I.fusable && !jrx_comm_active(h) && !p->displacement_bcs && p->periodic == 0 && (double)n <= kGraphCells3D;
     while (keep_going(iter)) {
-        if (graphs && iter >= 2 && I.bcs_ordered[0] && I.cur_is_user && !I.stress_done) {
+        if (graphs && iter >= 2 && I.bcs_ordered[0] && I.all_user() && !I.stress_done) {
             // observed iterations: the multiples of nout and iteration iterMax + 1; between them err does not change, so keep_going holds
             int64_t nxt = ((iter / p->nout) + 1) * p->nout;
             if (nxt > p->iterMax + 1) nxt = p->iterMax + 1;
@@ -1207,12 +1239,19 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     JRX_TRY(iter_begin(I, h, f, etatau, p));
     JRX_HIP(h, hipStreamSynchronize(s));
     JRX_HIP(h, hipEventRecord(h->ev[6], s));
-    // every fused step flips the ping-pong set: with an odd number of them the first step stays un-fused (one extra sweep pair,
-    // ~1 ms at 512^3) so that the batch ends in the caller's arrays instead of paying the copy-back of ten arrays (~4 ms)
-    const bool first_unfused = I.fusable && iters >= 2 && ((iters - 1) % 2 == 1);
+    // every fused step flips the ping-pong set of both groups (P + stresses, velocities); the batch has iters - 1 of them between the first stress sweep and the last
+    // velocity sweep.  With an odd number the batch would end in the scratch set (copy-back of ten arrays: ~4 ms at 512^3).  Instead the two un-fused sweeps at its ends
+    // write out of place: the first stress sweep puts P and the stresses into the scratch set, the last velocity sweep brings the velocities back -- every group ends
+    // in the caller's arrays, no copy, no extra launch (tuning switch end_flips = 0: the first step stays un-fused instead, one extra sweep pair, ~2 ms at 512^3).
+    // With a communicator, periodic faces or an observed batch the first step stays un-fused as before.
+    const bool odd = I.fusable && iters >= 2 && ((iters - 1) % 2 == 1);
+    const bool flips = odd && h->end_flips && !jrx_comm_active(h) && p->periodic == 0 && !p->displacement_bcs;
+    const bool first_unfused = odd && !flips;
     for (int64_t it = 0; it < iters; it++) {
         const bool samp = it % stride == 0;
         const bool fuse_next = it + 1 < iters && !(first_unfused && it == 0);
+        if (flips && it == 0) I.flip_A = true;
+        if (flips && it == iters - 1) I.flip_B = true;
         const size_t q = (size_t)(it / stride);
         JRX_TRY(iter_step(I, false, fuse_next, samp ? &evs[q * 4] : nullptr, samp ? &fused[q] : nullptr, samp ? &ncell[q] : nullptr,
                           samp && chain ? &evs[(size_t)nsamp * 4 + q * 4] : nullptr, samp && chain ? &cmode[q] : nullptr));

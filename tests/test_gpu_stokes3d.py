@@ -425,6 +425,42 @@ def test_iterate_timed_leaves_state_in_user_arrays(env):
         assert np.array_equal(outs[0][k][m], outs[1][k][m]) and np.array_equal(outs[0][k][m], outs[2][k][m]), k
 
 
+@pytest.mark.parametrize("dt", [0.25, np.inf])
+@pytest.mark.parametrize("ni,bcs,iters", [((130, 16, 12), "free_slip", 10), ((130, 16, 12), "none", 2), ((66, 9, 35), "slip_mix", 4), ((97, 9, 33), "no_slip", 20), ((130, 16, 12), "free_slip", 9)])
+def test_iterate_timed_with_an_odd_number_of_fused_steps_ends_in_the_user_arrays_without_a_copy(env, ni, bcs, iters, dt):
+    """A batch of K iterations is the first stress sweep, K - 1 fused steps and the last velocity sweep; every fused step moves the state to the other set.  With K - 1 odd the
+    two end sweeps write out of place (P and the stresses into the scratch set first, the velocities back last) so that the batch still ends in the caller's arrays -- no copy-back,
+    no extra un-fused iteration (tuning switch end_flips).  Same fields as with the switch off and as K iterations of the per-node kernels, for two different problems in a row on
+    one handle (the scratch set still holds the previous problem's state: an entry the out-of-place sweeps did not write would show)."""
+    jr, st = env["jr"], env["st"]
+    from justrelax_jl_amd import _lib
+    h = _lib.default_handle()
+    try:
+        for seed in (11, 12):
+            s = jr.miniapps.random_fields3d(ni, seed=seed, bcs=bcs, dt=dt, iterMax=5, nout=100)
+            if seed == 12:
+                s.arrays["fx"][...] = 0.0; s.arrays["fy"][...] = 0.0
+            outs, fused = [], []
+            for variant, flips in ((3, 1), (3, 0), (1, 1)):
+                h.set_option("kernel_variant", variant)
+                h.set_option("end_flips", flips)
+                stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+                et = jr.fzeros(s.ni, stokes.P.device)
+                jr.compute_maxloc_(et, stokes.viscosity.η)
+                c0 = h.get_option("stat_fused3d")
+                st.iterate_timed_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, et, s.dt, iters)
+                fused.append(h.get_option("stat_fused3d") - c0)
+                outs.append(env["down"](stokes))
+            odd = (iters - 1) % 2 == 1
+            assert fused == [iters - 1, iters - 2 if odd else iters - 1, 0], fused
+            for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy"):
+                m = env["checks"].interior_mask3d(k, outs[0][k].shape)
+                assert np.isfinite(outs[0][k][m]).all() and np.array_equal(outs[0][k][m], outs[1][k][m]) and np.array_equal(outs[0][k][m], outs[2][k][m]), (seed, k)
+    finally:
+        h.set_option("kernel_variant", 0)
+        h.set_option("end_flips", 1)
+
+
 @pytest.mark.parametrize("axis,steps", [(2, 40), (1, 20), (0, 20)])
 def test_3d_elastic_buildup_on_the_device(jr, oracle, axis, steps):
     """VERDICT r2 P1 / r3 P1: the τ_o / 1/(G dt) terms of the 3D kernels on the device, anchored on the reference's elastic build-up (Elastic_BuildUp.jl:4,55-56,75-86;
