@@ -119,6 +119,11 @@ def pricing(h, dt, nof=0):
                           "the workload: algorithmic 280 B/cell per launch = SURVEY 8d's two sweeps (45 passes) less the ten operand arrays whose factor 1/(G dt), 1/(K dt), 1/dt "
                           "is exactly 0 (old stresses, P0, K, G, Q), which this form does not load; the kernel itself needs 15 reads + 10 writes = 200 B/cell.  The general form "
                           "priced at 360 B/cell is the `general_kernel` entry of this line"}
+    if nof:
+        form, na = FORMS_NOF[nof]
+        return {"form": form.replace("viscous_limit", "general"), "nof": nof, "alg": A_ALG - 8.0 * na, "needed": A_NEEDED_FUSED - 8.0 * na, "pmc": PMC.get(f"k_fused3d_general_nof{nof}"), "pmc_source": PMC_SOURCE["fused"],
+                "kernel": f"k_fused3d<...,NOF={nof}>: the general form (any dt) of the fused iteration for a workload whose {'three body-force arrays are' if nof == 2 else 'body-force arrays ρg_x, ρg_y are'} +0.0 in "
+                          f"every entry and are not loaded: algorithmic {A_ALG - 8.0 * na:.0f} B/cell per launch = SURVEY 8d's 45 passes less those {na}; the kernel itself needs {25 - na} reads + 10 writes"}
     return {"form": "general", "nof": 0, "alg": A_ALG, "needed": A_NEEDED_FUSED, "pmc": PMC_TRAFFIC_FUSED_512, "pmc_source": PMC_SOURCE["fused"],
             "kernel": "k_fused3d<...,TAG=0>: one PT iteration per launch (velocity sweep m + BCs + stress sweep m+1, ping-pong "
                       "state); algorithmic 360 B/cell per launch (2-sweep floor of SURVEY 8d; the kernel itself needs "
@@ -1487,21 +1492,27 @@ def run_rank(args) -> int:
             # the general form of the same kernel (any dt; what rounds 1-2 quoted) on the same allocations: option viscous_limit = 0
             try:
                 h.set_option("viscous_limit", 0)
-                prg = pricing(h, dt)
-                run(max(args.warmup, 2))
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                g_tot, _, _, g_sf, g_sk, g_kc = run(args.steps)
-                torch.cuda.synchronize()
-                gel = time.perf_counter() - t1
-                out["general_kernel"] = {"what": "option viscous_limit = 0: the kernel that loads and applies every operand (any dt), same problem, same allocations, same batch length; "
-                                                 "priced at SURVEY 8d's 360 B/cell like the headline of rounds 1-2",
-                                         "it_per_s": args.steps / gel, "ms_per_step": gel / args.steps * 1e3, "steps": args.steps,
-                                         "roofline": fused_roofline(prg, n, g_sk, g_sf, g_kc, prg["alg"] * cells * (args.steps / (g_tot * 1e-3)) / 1e9)}
+                for key, zf, what in (("general_kernel", 0, "options viscous_limit = 0, zero_forces = 0: the kernel that loads and applies every operand (any dt, any ρg), same problem, same allocations, same batch "
+                                                            "length; priced at SURVEY 8d's 360 B/cell like the headline of rounds 1-2"),
+                                      ("general_kernel_zero_forces", 1, "option viscous_limit = 0 alone: the general kernel (any dt) of a workload whose body-force arrays are zeros -- they are not loaded; "
+                                                                        "priced without those passes")):
+                    h.set_option("zero_forces", zf)
+                    run(max(args.warmup, 2))
+                    torch.cuda.synchronize()
+                    fg = counters(h)
+                    t1 = time.perf_counter()
+                    g_tot, _, _, g_sf, g_sk, g_kc = run(args.steps)
+                    torch.cuda.synchronize()
+                    gel = time.perf_counter() - t1
+                    prg = pricing(h, dt, nof_ran(h, fg))
+                    out[key] = {"what": what, "it_per_s": args.steps / gel, "ms_per_step": gel / args.steps * 1e3, "steps": args.steps,
+                                "roofline": fused_roofline(prg, n, g_sk, g_sf, g_kc, prg["alg"] * cells * (args.steps / (g_tot * 1e-3)) / 1e9)}
             except Exception as e:
-                out["general_kernel"] = {"error": f"{type(e).__name__}: {e}"}
+                out.setdefault("general_kernel", {"error": f"{type(e).__name__}: {e}"})
+                out.setdefault("general_kernel_zero_forces", {"error": f"{type(e).__name__}: {e}"})
             finally:
                 h.set_option("viscous_limit", 1)
+                h.set_option("zero_forces", 1)
         if world == 1 and not self_halo and not args.no_extras:
             try:
                 out["solve_path"] = solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, args.solve_iters, n, pr)

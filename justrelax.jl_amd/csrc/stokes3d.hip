@@ -117,10 +117,36 @@ __global__ __launch_bounds__(256) void k_visc_operands_ok(const double *__restri
     }
 }
 
-jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
+// finite dt: only the bits of the three body-force arrays are looked at (bad |= 2: ρg_x or ρg_y has an entry that is not +0.0, |= 4: ρg_z has)
+__global__ __launch_bounds__(256) void k_forces_zero(const unsigned long long *__restrict__ fx, const unsigned long long *__restrict__ fy, const unsigned long long *__restrict__ fz, i64 nc, int *bad)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    unsigned long long bxy = 0, bz = 0;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < nc; t += stride) { bxy |= fx[t] | fy[t]; bz |= fz[t]; }
+    const int m = (__any(bxy != 0) ? 2 : 0) | (__any(bz != 0) ? 4 : 0);
+    if (m && (threadIdx.x & 63) == 0) atomicOr(bad, m);
+}
+
+// forces: also look at the body forces (the drivers whose fused kernels read them; the stand-alone stress sweep does not)
+jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p, bool forces = true)
 {
     h->visc_ok = false;
     h->nof = 0;
+    forces = forces && h->zero_forces && f->fx && f->fy && f->fz;
+    if ((!h->viscous_limit || p->dt != INFINITY) && forces && !p->displacement_bcs && (h->kernel_variant == 0 || h->kernel_variant == 3) && p->nx >= 48) {
+        // the general form of the fused kernel has the instantiations without body-force loads, too (every 3D model of the reference has gravity along z: ρg_x = ρg_y = 0)
+        const i64 nc = (i64)p->nx * p->ny * p->nz;
+        int *d_bad = reinterpret_cast<int *>(h->d_sums + 6), *h_bad = reinterpret_cast<int *>(h->h_sums + 6);
+        hipStream_t s = h->stream;
+        JRX_HIP(h, hipMemsetAsync(d_bad, 0, sizeof(double), s));
+        hipLaunchKernelGGL(k_forces_zero, dim3(2048), dim3(256), 0, s, reinterpret_cast<const unsigned long long *>(f->fx), reinterpret_cast<const unsigned long long *>(f->fy),
+                           reinterpret_cast<const unsigned long long *>(f->fz), nc, d_bad);
+        JRX_LAUNCH_CHECK(h);
+        JRX_HIP(h, hipMemcpyAsync(h_bad, d_bad, sizeof(double), hipMemcpyDeviceToHost, s));
+        JRX_HIP(h, hipStreamSynchronize(s));
+        if (!(*h_bad & 2)) h->nof = (*h_bad & 4) ? 1 : 2;
+        return JRX_OK;
+    }
     if (!h->viscous_limit || p->dt != INFINITY) return JRX_OK;
     const i64 nx = p->nx, ny = p->ny, nz = p->nz;
     int *d_bad = reinterpret_cast<int *>(h->d_sums + 6), *h_bad = reinterpret_cast<int *>(h->h_sums + 6);
@@ -128,13 +154,13 @@ jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, cons
     JRX_HIP(h, hipMemsetAsync(d_bad, 0, sizeof(double), s));
     hipLaunchKernelGGL(k_visc_operands_ok, dim3(4096), dim3(256), 0, s, f->P0, f->Q, f->toxx, f->toyy, f->tozz, f->eta, nx * ny * nz, f->K, f->G, f->toyz, nx * (ny + 1) * (nz + 1),
                        f->toxz, (nx + 1) * ny * (nz + 1), f->toxy, (nx + 1) * (ny + 1) * nz, d_bad,
-                       h->zero_forces ? reinterpret_cast<const unsigned long long *>(f->fx) : nullptr, reinterpret_cast<const unsigned long long *>(f->fy), reinterpret_cast<const unsigned long long *>(f->fz));
+                       forces ? reinterpret_cast<const unsigned long long *>(f->fx) : nullptr, reinterpret_cast<const unsigned long long *>(f->fy), reinterpret_cast<const unsigned long long *>(f->fz));
     JRX_LAUNCH_CHECK(h);
     JRX_HIP(h, hipMemcpyAsync(h_bad, d_bad, sizeof(double), hipMemcpyDeviceToHost, s));
     JRX_HIP(h, hipStreamSynchronize(s));
     h->visc_ok = ((*h_bad & 1) == 0);
     // body forces that are +0.0 throughout need not be streamed (k_fused3d, NOF): the usual 3D model has gravity along z only, SolVi3D has none
-    if (h->visc_ok && h->zero_forces && !(*h_bad & 2)) h->nof = (*h_bad & 4) ? 1 : 2;
+    if (h->visc_ok && forces && !(*h_bad & 2)) h->nof = (*h_bad & 4) ? 1 : 2;
     h->stat_visc_checks++;
     if (!h->visc_ok) h->stat_visc_fallbacks++;
     return JRX_OK;
@@ -375,7 +401,7 @@ jrx_status jrx_stokes3d_sweep_stress(jrx_handle *h, const jrx_stokes3d_fields *f
     const bool diag = flags & JRX_OUT_DIAG;
     if (diag) JRX_TRY(check_diag(h, f));
     SweepArgs a = make_args(f, nullptr, p);
-    JRX_TRY(visc_operands_check(h, f, p));
+    JRX_TRY(visc_operands_check(h, f, p, false));
     JRX_TRY(launch_stress(h, h->stream, a, diag, 0, (int)p->nx + 1, 0, (int)p->ny + 1, 0, (int)p->nz + 1));
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
@@ -602,7 +628,8 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     // instead of the third LDS slot: LOWREG off, -1.4 %, scripts/kbench_visc.hip)
     const bool visc = h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
     const bool vf = h->visc_fold;      // tuning switch: the folded arithmetic of the viscous limit (k_fused3d, VFOLD; same bits)
-    const int nof = (visc && fold && vf) ? h->nof : 0;     // body-force arrays that hold only +0.0 are not loaded (set by the operand pass; the one-launch form only)
+    // body-force arrays that hold only +0.0 are not loaded (set by the operand pass): the one-launch viscous-limit form and the general form have those instantiations
+    const int nof = ((visc && fold && vf) || (!visc && h->fused_ylds && !shell)) ? h->nof : 0;
     if (shell) {        // neighbours, one launch: interior tiles first, the tiles next to a face with a neighbour last (they wait for the exchange's flag)
         if (!(visc && fold)) return jrx_fail(h, JRX_ERR_ARG, "internal: the in-kernel neighbour faces need the one-launch viscous-limit form");
         // blk0 = 0: box 0 (tiles that touch no face with a neighbour, beside the exchange); blk0 = start[1]: everything else, behind it
@@ -635,9 +662,21 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 1, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc)
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
-    else if (h->fused_ylds && hiface)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
-    else if (h->fused_ylds)
+    else if (h->fused_ylds && hiface) {
+        if (nof == 2)
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1, false, false, false, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        else if (nof == 1)
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1, false, false, false, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        else
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        if (nof == 1) h->stat_fused3d_nof1++; else if (nof == 2) h->stat_fused3d_nof2++;
+    } else if (h->fused_ylds && nof == 2) {
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 0, false, false, false, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        h->stat_fused3d_nof2++;
+    } else if (h->fused_ylds && nof == 1) {
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 0, false, false, false, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        h->stat_fused3d_nof1++;
+    } else if (h->fused_ylds)
         // + non-temporal stores: the written set is not read again before the next iteration (PMC: 35.7 -> 34.2 fetched passes, -0.5 .. -1.6 % time)
         // + register diet to 128 VGPRs without spills (4 waves/SIMD): previous velocity plane re-read from a third LDS slot, previous η/G
         //   plane carried as partial sums, the nine stress-only operands requested after the velocity phase (-1 .. -5 %)

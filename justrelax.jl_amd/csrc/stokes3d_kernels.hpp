@@ -715,7 +715,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
 #define NBVY(flag_, off_, jj_) ((NBR && bc.flag_) ? ((((jj_) == 0 && bc.nsF) || ((jj_) == ny && bc.nsBk)) ? 0.0 : LDC(a.o.Vy, (off_))) : LDB(f.Vy, (off_)))
 #define NBVZ(flag_, off_, kk_) ((NBR && bc.flag_) ? ((((kk_) == 0 && bc.nsK0) || ((kk_) == nz && bc.nsK1)) ? 0.0 : LDC(a.o.Vz, (off_))) : LDB(f.Vz, (off_)))
     // NOF: body-force arrays that are +0.0 in every entry (the driver's operand pass has seen all their bits zero) are not loaded: 1 = fx, fy (gravity along z), 2 = all three
-    static_assert(NOF == 0 || (VISC && HIF && VFOLD), "the forms without body-force loads are built on the one-launch viscous-limit form");
+    static_assert(NOF == 0 || (VISC && HIF && VFOLD) || (!VISC && LOWREG && YLDS == 3), "the forms without body-force loads exist for the one-launch viscous-limit form and for the general form");
 #define LFX(off_) (NOF >= 1 ? 0.0 : LDN<(NT & 2) != 0>(f.fx, (off_)))
 #define LFY(off_) (NOF >= 1 ? 0.0 : LDN<(NT & 2) != 0>(f.fy, (off_)))
 #define LFZ(off_) (NOF >= 2 ? 0.0 : LDN<(NT & 2) != 0>(f.fz, (off_)))

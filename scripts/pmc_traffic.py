@@ -51,7 +51,8 @@ def main():
         nof = lambda k: int(targs(k)[16]) if len(targs(k)) >= 17 else 0        # template argument NOF: body-force arrays not loaded (0 none, 1 ρg_x, ρg_y, 2 all three)
         visc = pick(lambda k: "k_fused3d<" in k and len(targs(k)) >= 13 and targs(k)[12] == "true" and nof(k) == 0)
         visc_n = {l: pick(lambda k: "k_fused3d<" in k and len(targs(k)) >= 13 and targs(k)[12] == "true" and nof(k) == l) for l in (1, 2)}
-        gen = pick(lambda k: "k_fused3d<" in k and (len(targs(k)) < 13 or targs(k)[12] == "false"))
+        gen = pick(lambda k: "k_fused3d<" in k and (len(targs(k)) < 13 or targs(k)[12] == "false") and nof(k) == 0)
+        gen_n = {l: pick(lambda k: "k_fused3d<" in k and len(targs(k)) >= 13 and targs(k)[12] == "false" and nof(k) == l) for l in (1, 2)}
         zb_v = pick(lambda k: "k_stress3d_zb<" in k and targs(k)[-1] == "true")
         zb_g = pick(lambda k: "k_stress3d_zb<" in k and targs(k)[-1] == "false")
         sha = hashlib.sha256((ROOT / "justrelax.jl_amd" / "csrc" / "stokes3d_kernels.hpp").read_bytes()).hexdigest()
@@ -59,7 +60,7 @@ def main():
         json.dump({"what": "L2<->fabric bytes per launch of the dominant kernels at n = 512 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE doubled per the gfx950 "
                            "correction of MI355X_MICROARCH.md), written by scripts/pmc_traffic.py; bench.py prints `traffic: null` when csrc/stokes3d_kernels.hpp differs from the file these passes ran",
                    "kernels_sha256": sha, "git_head": head, "source": source, "n": 512,
-                   "k_fused3d_general": gen, "k_fused3d_visc": visc, "k_fused3d_visc_nof1": visc_n[1], "k_fused3d_visc_nof2": visc_n[2], "k_stress3d_zb_general": zb_g, "k_stress3d_zb_visc": zb_v}, open(jpath, "w"), indent=1)
+                   "k_fused3d_general": gen, "k_fused3d_visc": visc, "k_fused3d_visc_nof1": visc_n[1], "k_fused3d_visc_nof2": visc_n[2], "k_fused3d_general_nof1": gen_n[1], "k_fused3d_general_nof2": gen_n[2], "k_stress3d_zb_general": zb_g, "k_stress3d_zb_visc": zb_v}, open(jpath, "w"), indent=1)
         print("wrote", jpath, "visc", visc, "visc without body forces", visc_n, "general", gen)
 
 

@@ -301,14 +301,15 @@ def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
 
 
 @pytest.mark.parametrize("zero,nof", [("xy", 1), ("xyz", 2), ("xy one entry -0.0", 0), ("xy one entry 1e-300", 0), ("z", 0), ("xz", 0), ("", 0)])
-@pytest.mark.parametrize("ni,bcs,tile", [((130, 20, 17), "free_slip", 0), ((66, 9, 35), "slip_mix", 1), ((97, 9, 33), "none", 0)])
-def test_body_forces_that_are_zero_are_not_loaded_and_the_bits_stay(env, ni, bcs, tile, zero, nof):
+@pytest.mark.parametrize("ni,bcs,tile,dt", [((130, 20, 17), "free_slip", 0, np.inf), ((66, 9, 35), "slip_mix", 1, np.inf), ((97, 9, 33), "none", 0, np.inf),
+                                            ((130, 20, 17), "free_slip", 0, 0.25), ((66, 9, 35), "slip_mix", 1, 0.25), ((130, 17, 20), "no_slip", 0, 0.25)])
+def test_body_forces_that_are_zero_are_not_loaded_and_the_bits_stay(env, ni, bcs, tile, dt, zero, nof):
     """SolVi3D.jl:102 hands three ρg arrays of zeros, and every 3D model of the reference has ρg_x = ρg_y = 0 (gravity along z).  The one-launch viscous-limit kernel does not
     load body-force arrays in which the operand pass of the driver call has found nothing but +0.0 (all 64 bits zero): x - 0.5 (0 + 0) = x for every x, -0.0 and NaN included.
     A single -0.0 (x - (-0.0) turns x = -0.0 into +0.0) or a denormal keeps the loads.  Every case equals the per-node general kernels and the same form with the loads."""
     jr = env["jr"]
     from justrelax_jl_amd import _lib
-    s = jr.miniapps.random_fields3d(ni, bcs=bcs, dt=np.inf, iterMax=23, nout=7)
+    s = jr.miniapps.random_fields3d(ni, bcs=bcs, dt=dt, iterMax=23, nout=7)      # finite dt: the general form of the fused kernel has the same instantiations
     s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
     comps = zero.split(" ")[0]
     for c in comps:
@@ -349,8 +350,13 @@ def test_body_forces_that_are_zero_are_not_loaded_and_the_bits_stay(env, ni, bcs
             a, b = np.ascontiguousarray(outs[0][k][m]), np.ascontiguousarray(outs[v][k][m])
             if k[0] == "U":      # U = V dt = ±Inf, NaN where V = 0
                 assert np.array_equal(a, b, equal_nan=True), (v, k)
-            else:
+            elif v == 1 and k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy", "Rx", "Ry", "Rz", "RP"):
+                # the same kernels with the loads: every bit of the state and the residuals, the signs of zeros included
                 assert np.isfinite(a).all() and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (v, k)
+            else:
+                # the per-node kernels, and the strain rates of observed iterations: exact zeros on boundary nodes carry the sign the ghost entries on the block's edges happen to
+                # have (no-slip negates them; the one-launch flow_bcs! of unobserved iterations writes those entries from two faces), so these compare as numbers
+                assert np.isfinite(a).all() and np.array_equal(a, b), (v, k)
 
 
 @pytest.mark.parametrize("poison", ["toxx=nan", "toyz=inf", "P0=inf", "Q=nan", "K=0", "G=nan", "none"])
