@@ -10,6 +10,8 @@
  *                                 them) are not loaded -- ρg_x and ρg_y (gravity along z), or all three (SolVi3D); x - (+0.0) = x for every x, so the bits are the same (0: always loaded)
  *   "end_flips" (1)               jrx_stokes3d_iterate_timed, no neighbours: a batch whose number of fused steps is odd ends in the caller's arrays because its first stress sweep and its last
  *                                 velocity sweep write out of place into the other state set (0: the first iteration stays un-fused instead -- one more sweep pair; same results)
+ *   "scratch_stagger" (0)         bytes (multiple of 256): array q of the library's second 3D state set starts q * stagger bytes into its allocation (scripts/bench_alloc_stagger.py: the spread
+ *                                 of the 512^3 kernel between allocations does not depend on it -- it comes with the physical placement, not with the low address bits)
  *   "fused_hiface" (1)            3D fused kernel, viscous-limit form, no neighbours: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel
  *                                 (0: by the boundary-layer launch behind it)
  *   "fused_first_pct" (15)        multi-rank fused pipeline with the neighbour faces inside the kernel (fused_overlap = 3): share (%) of the interior z chunks whose tiles are launched

@@ -22,6 +22,8 @@ struct jrx_handle {
     double *etatau = nullptr;            // library-owned ητ (capacity etatau_cap doubles)
     size_t etatau_cap = 0;
     jrx_comm_state *comm = nullptr;
+    double *scratch_base[10] = {};       // what hipMalloc returned for scratch[q] (scratch[q] may start scratch_stagger * q bytes into it)
+    int scratch_stagger = 0, scratch_stagger_used = 0;   // tuning switch (bytes; see ensure_scratch) and the value the current allocation was made with
     double *scratch[10] = {};            // ping-pong set for the fused iteration kernel (P, τ(6), V(3))
     int scratch_dims[3] = {0, 0, 0};
     double *tscratch[4] = {};            // ping-pong set of the fused 3D heat-diffusion kernel (T, qTx, qTy, qTz)
