@@ -198,7 +198,9 @@ bool jrx_comm_has_neighbor(const jrx_handle *h, int d, int side);   // the halo 
 
 // stokes3d.hip: pieces of the 3D visco-elastic path that the 3D VEP driver (stokes3d_vep.hip) reuses.  Asynchronous on `s`.
 // velocity sweep = compute_V! 3D (+ residuals when diag); sumsq leaves Σx² of Rx, Ry, Rz (interior slices) and RP in h->d_sums
-jrx_status jrx3d_velocity_sweep(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag);
+// nof: body-force arrays that the caller has just seen to hold only +0.0 (jrx3d_forces_zero) and that the unobserved sweep therefore does not load (1: fx, fy; 2: all three)
+jrx_status jrx3d_velocity_sweep(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag, int nof = 0);
+jrx_status jrx3d_forces_zero(jrx_handle *h, hipStream_t s, const double *fx, const double *fy, const double *fz, int64_t nc, int *nof);
 // the same sweep as @hide_communication runs it (boundary slabs, BCs and update_halo!(V) on the halo stream, interior on the compute stream); see stokes3d.hip
 jrx_status jrx3d_velocity_hidden(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag, int bc_kind);
 jrx_status jrx3d_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p);

@@ -179,10 +179,13 @@ jrx_status launch_stress_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bo
 }
 
 template <int TX, int TY, int KZ>
-jrx_status launch_velocity_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag)
+jrx_status launch_velocity_zb(jrx_handle *h, hipStream_t s, const SweepArgs &a, bool diag, int nof = 0)
 {
+    // nof: body-force arrays the caller has just seen to hold only +0.0 (1: fx, fy; 2: all three) are not loaded by the unobserved form
     const TileMap tm = make_tilemap(a.i1 - a.i0, a.j1 - a.j0, a.k1 - a.k0, TX, TY, KZ);
-    if (diag) hipLaunchKernelGGL((k_velocity3d_zb<true, TX, TY, KZ, 4, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    if (!diag && nof == 2) hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, 4, 8, true, 2>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else if (!diag && nof == 1) hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, 4, 8, true, 1>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
+    else if (diag) hipLaunchKernelGGL((k_velocity3d_zb<true, TX, TY, KZ, 4, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     else hipLaunchKernelGGL((k_velocity3d_zb<false, TX, TY, KZ, 4, 8, true>), dim3(tm.ntiles), dim3(TX * TY), 0, s, a, tm);
     JRX_LAUNCH_CHECK(h);
     return JRX_OK;
@@ -213,17 +216,17 @@ jrx_status launch_stress(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, i
     return launch_stress_boxes(h, s, a, planes, 3, diag);
 }
 
-jrx_status launch_velocity(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1)
+jrx_status launch_velocity(jrx_handle *h, hipStream_t s, SweepArgs a, bool diag, int i0, int i1, int j0, int j1, int k0, int k1, int nof = 0)
 {
     if (i1 <= i0 || j1 <= j0 || k1 <= k0) return JRX_OK;
     const int w = i1 - i0;
     const bool small = (double)w * (j1 - j0) * (k1 - k0) <= 681472.0;          // see launch_stress
     if (h->kernel_variant == 1 || !fits_u32(a.L) || w < 48 || (k1 - k0) < 4 || small) return launch_velocity_v1(h, s, a, diag, i0, i1, j0, j1, k0, k1);
     a.i0 = i0; a.i1 = i1; a.j0 = j0; a.j1 = j1; a.k0 = k0; a.k1 = k1;
-    if (w > 384) return launch_velocity_zb<512, 1, 4>(h, s, a, diag);
-    if (w > 192) return launch_velocity_zb<256, 1, 8>(h, s, a, diag);
-    if (w > 96) return launch_velocity_zb<128, 2, 8>(h, s, a, diag);
-    return launch_velocity_zb<64, 4, 8>(h, s, a, diag);
+    if (w > 384) return launch_velocity_zb<512, 1, 4>(h, s, a, diag, nof);
+    if (w > 192) return launch_velocity_zb<256, 1, 8>(h, s, a, diag, nof);
+    if (w > 96) return launch_velocity_zb<128, 2, 8>(h, s, a, diag, nof);
+    return launch_velocity_zb<64, 4, 8>(h, s, a, diag, nof);
 }
 
 jrx_status launch_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p)
@@ -328,10 +331,25 @@ jrx_status launch_sumsq(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields 
 
 }   // namespace
 
-jrx_status jrx3d_velocity_sweep(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag)
+jrx_status jrx3d_velocity_sweep(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, bool diag, int nof)
 {
     if (diag && (!f->Rx || !f->Ry || !f->Rz)) return jrx_fail(h, JRX_ERR_ARG, "residual arrays are NULL");
-    return launch_velocity(h, s, make_args(f, etatau, p), diag, 0, (int)p->nx, 0, (int)p->ny, 0, (int)p->nz);
+    return launch_velocity(h, s, make_args(f, etatau, p), diag, 0, (int)p->nx, 0, (int)p->ny, 0, (int)p->nz, nof);
+}
+// which body-force arrays hold nothing but +0.0 right now: 0 none (or the switch zero_forces is off), 1 fx and fy, 2 all three.  One streaming pass and a host synchronisation
+jrx_status jrx3d_forces_zero(jrx_handle *h, hipStream_t s, const double *fx, const double *fy, const double *fz, int64_t nc, int *nof)
+{
+    *nof = 0;
+    if (!h->zero_forces || !fx || !fy || !fz) return JRX_OK;
+    int *d_bad = reinterpret_cast<int *>(h->d_sums + 6), *h_bad = reinterpret_cast<int *>(h->h_sums + 6);
+    JRX_HIP(h, hipMemsetAsync(d_bad, 0, sizeof(double), s));
+    hipLaunchKernelGGL(k_forces_zero, dim3(2048), dim3(256), 0, s, reinterpret_cast<const unsigned long long *>(fx), reinterpret_cast<const unsigned long long *>(fy),
+                       reinterpret_cast<const unsigned long long *>(fz), (i64)nc, d_bad);
+    JRX_LAUNCH_CHECK(h);
+    JRX_HIP(h, hipMemcpyAsync(h_bad, d_bad, sizeof(double), hipMemcpyDeviceToHost, s));
+    JRX_HIP(h, hipStreamSynchronize(s));
+    if (!(*h_bad & 2)) *nof = (*h_bad & 4) ? 1 : 2;
+    return JRX_OK;
 }
 jrx_status jrx3d_scaleU(jrx_handle *h, hipStream_t s, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p) { return launch_scaleU(h, s, f, p); }
 jrx_status jrx3d_bcs(jrx_handle *h, hipStream_t s, double *Vx, double *Vy, double *Vz, int nx, int ny, int nz, uint32_t fs, uint32_t ns, uint32_t pe)
@@ -1068,11 +1086,11 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             // flow_bcs! below then acts on that set
             const Out10 other = mix_sets(I.pt_user ? I.setU : I.setS, I.v_user ? I.setS : I.setU);
             a.o = other;
-            JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
+            JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz, h->nof));
             set_state(I.cur, other);
             I.v_user = !I.v_user;
         } else
-            JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz));
+            JRX_TRY(launch_velocity(h, s, a, diag, 0, nx, 0, ny, 0, nz, h->nof));      // h->nof: what iter_begin's pass over this call's body-force arrays has found
         I.flip_B = false;
         if (tev) JRX_HIP(h, hipEventRecord(tev[2], s));
         if (diag) JRX_TRY(launch_scaleU(h, s, f, p));

@@ -547,7 +547,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_stress3d_zb(const SweepArgs a,
 
 // SHF: the operands at i+1 that the right-hand lane holds as its own (τxy(·,j+1), τxz, P, ητ, τxx, fx) come by lane shuffle; the last
 // lane of a wave and the last column of the (sub-)box load them
-template <bool DIAG, int TX, int TY, int KZ, int MINW, int XCD = 0, bool SHF = false>
+// NOF: body-force arrays known to hold only +0.0 are not loaded (1: fx, fy; 2: all three), see k_fused3d; the caller states it per launch
+template <bool DIAG, int TX, int TY, int KZ, int MINW, int XCD = 0, bool SHF = false, int NOF = 0>
 __global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs a, const TileMap tm)
 {
     static_assert(!SHF || TX % 64 == 0, "SHF needs whole waves per row");
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs 
     // x / y upper-neighbour distance, 0 on the last cell (value then unused but address stays in range)
     const u32 dx1 = hx ? 8u : 0u, dy1 = hy ? rc : 0u;
 
-    double Pc = LDB(f.P, oc), ec = LDB(et, oc), tzz_c = LDB(f.tzz, oc), fz_c = LDB(f.fz, oc);
+    double Pc = LDB(f.P, oc), ec = LDB(et, oc), tzz_c = LDB(f.tzz, oc), fz_c = NOF >= 2 ? 0.0 : LDB(f.fz, oc);
     double s10 = LDB(f.txz, oxz + 8u - sxz), r10 = LDB(f.tyz, oyz + ryz - syz);
 
     for (int k = kb; k < kend; ++k) {
@@ -590,35 +591,38 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_velocity3d_zb(const SweepArgs 
         const double q10 = LDB(f.txy, oxy + 8u), q01 = LDB(f.txy, oxy + rxy);
         const double s01 = LDB(f.txz, oxz);
         const double r11 = LDB(f.tyz, oyz + ryz), r01 = LDB(f.tyz, oyz);
-        const double Pz = LDB(f.P, oc + dz1), ez = LDB(et, oc + dz1), tzz_z = LDB(f.tzz, oc + dz1), fz_z = LDB(f.fz, oc + dz1);
+        const double Pz = LDB(f.P, oc + dz1), ez = LDB(et, oc + dz1), tzz_z = LDB(f.tzz, oc + dz1), fz_z = NOF >= 2 ? 0.0 : LDB(f.fz, oc + dz1);
         const double Py = LDB(f.P, oc + dy1), ey = LDB(et, oc + dy1);
         const double txx_c = LDB(f.txx, oc), tyy_c = LDB(f.tyy, oc), tyy_y = LDB(f.tyy, oc + dy1);
-        const double fx_c = LDB(f.fx, oc), fy_c = LDB(f.fy, oc), fy_y = LDB(f.fy, oc + dy1);
+        const double fx_c = NOF >= 1 ? 0.0 : LDB(f.fx, oc), fy_c = NOF >= 1 ? 0.0 : LDB(f.fy, oc), fy_y = NOF >= 1 ? 0.0 : LDB(f.fy, oc + dy1);
         const double vx = LDB(f.Vx, ovx), vy = LDB(f.Vy, ovy), vz = LDB(f.Vz, ovz);
         double q11, s11, Px, ex, txx_x, fx_x;
         if (SHF) {
             q11 = __shfl_down(q01, 1, 64); s11 = __shfl_down(s01, 1, 64);
-            Px = __shfl_down(Pc, 1, 64); ex = __shfl_down(ec, 1, 64); txx_x = __shfl_down(txx_c, 1, 64); fx_x = __shfl_down(fx_c, 1, 64);
+            Px = __shfl_down(Pc, 1, 64); ex = __shfl_down(ec, 1, 64); txx_x = __shfl_down(txx_c, 1, 64); fx_x = NOF >= 1 ? 0.0 : __shfl_down(fx_c, 1, 64);
             if ((threadIdx.x & 63) == 63 || i == a.i1 - 1) {
                 q11 = LDB(f.txy, oxy + 8u + rxy); s11 = LDB(f.txz, oxz + 8u);
-                Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = LDB(f.fx, oc + dx1);
+                Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = NOF >= 1 ? 0.0 : LDB(f.fx, oc + dx1);
             }
         } else {
             q11 = LDB(f.txy, oxy + 8u + rxy); s11 = LDB(f.txz, oxz + 8u);
-            Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = LDB(f.fx, oc + dx1);
+            Px = LDB(f.P, oc + dx1); ex = LDB(et, oc + dx1); txx_x = LDB(f.txx, oc + dx1); fx_x = NOF >= 1 ? 0.0 : LDB(f.fx, oc + dx1);
         }
         if (hx) {
-            const double R = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx - 0.5 * (fx_c + fx_x);
+            const double R0 = (-txx_c + txx_x) * _dx + _dy * (q11 - q10) + _dz * (s11 - s10) - (-Pc + Px) * _dx;
+            const double R = NOF >= 1 ? R0 : R0 - 0.5 * (fx_c + fx_x);       // x - (+0.0) = x for every x
             STB(a.o.Vx, ovx, vx + R * edt / (0.5 * (ec + ex)));
             if (DIAG) STB(f.Rx, orx, R);
         }
         if (hy) {
-            const double R = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy - 0.5 * (fy_c + fy_y);
+            const double R0 = _dx * (q11 - q01) + _dy * (tyy_y - tyy_c) + _dz * (r11 - r10) - (-Pc + Py) * _dy;
+            const double R = NOF >= 1 ? R0 : R0 - 0.5 * (fy_c + fy_y);
             STB(a.o.Vy, ovy, vy + R * edt / (0.5 * (ec + ey)));
             if (DIAG) STB(f.Ry, ory, R);
         }
         if (hz) {
-            const double R = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz - 0.5 * (fz_c + fz_z);
+            const double R0 = _dx * (s11 - s01) + _dy * (r11 - r01) + (-tzz_c + tzz_z) * _dz - (-Pc + Pz) * _dz;
+            const double R = NOF >= 2 ? R0 : R0 - 0.5 * (fz_c + fz_z);
             STB(a.o.Vz, ovz, vz + R * edt / (0.5 * (ec + ez)));
             if (DIAG) STB(f.Rz, oc, R);
         }

@@ -1516,6 +1516,11 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     launch_vep3_visc(s, gc, a, 1.0, false);                                                          // compute_viscosity! :507 (εII form)
     JRX_LAUNCH_CHECK(h);
     const bool upd_rho = rh->has_density && !mat_density_is_constant(rh);       // update_ρg!: a no-op for constant densities
+    // body-force arrays that hold nothing but +0.0 (ρg_x, ρg_y of every model with gravity along z; all three in ShearBand3D.jl:114) are not loaded by the velocity sweep of
+    // unobserved iterations (k_velocity3d_zb, NOF; x - (+0.0) = x: same bits).  ρg_z is the library's to write when the rheology carries densities (compute_ρg! above, update_ρg!)
+    int vnof = 0;
+    JRX_TRY(jrx3d_forces_zero(h, s, f->fx, f->fy, f->fz, (int64_t)n, &vnof));
+    if (rh->has_density && vnof > 1) vnof = 1;
     const bool ubc = p->displacement_bcs != 0;
     if (ubc) {    // displacement2velocity!(stokes, dt, flow_bcs) (Stokes3D.jl:509): V = U * inv(dt)
         hipLaunchKernelGGL(k_scale3, dim3(2048), dim3(256), 0, s, f->Vx, (const double *)f->Ux, (i64)(nx + 1) * (ny + 2) * (nz + 2), f->Vy,
@@ -1609,7 +1614,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
         { double *t1_ = A.f.txz; A.f.txz = A.tnew[1]; A.tnew[1] = t1_; }
         { double *t2_ = A.f.txy; A.f.txy = A.tnew[2]; A.tnew[2] = t2_; }
         G.tyz = A.f.tyz; G.txz = A.f.txz; G.txy = A.f.txy;
-        JRX_TRY(jrx3d_velocity_sweep(h, s, &G, A.etatau, &q, diag_));
+        JRX_TRY(jrx3d_velocity_sweep(h, s, &G, A.etatau, &q, diag_, vnof));
         if (diag_) JRX_TRY(jrx3d_scaleU(h, s, &G, &q));
         // flow_bcs!: on V, or -- DisplacementBoundaryConditions -- on U = V dt, which the next iteration overwrites (only observable when U is)
         if (!ubc && !diag_ && !ordered_ && bcs_ordered && p->periodic == 0) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
@@ -1730,7 +1735,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             else if (diag) bc_kind = 2;
             if (hide) JRX_TRY(jrx3d_velocity_hidden(h, &g, a.etatau, &q, diag, bc_kind));      // joins the two streams
             else {
-                JRX_TRY(jrx3d_velocity_sweep(h, s, &g, a.etatau, &q, diag));
+                JRX_TRY(jrx3d_velocity_sweep(h, s, &g, a.etatau, &q, diag, vnof));
                 if (diag) JRX_TRY(jrx3d_scaleU(h, s, &g, &q));
                 if (bc_kind == 1) JRX_TRY(jrx3d_bcs_faces(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip));
                 else if (bc_kind == 0) JRX_TRY(jrx3d_bcs(h, s, f->Vx, f->Vy, f->Vz, nx, ny, nz, p->free_slip, p->no_slip, p->periodic));

@@ -317,6 +317,44 @@ def test_vep3d_fused_pre_centre_equals_the_three_kernels(jr, ni, iters, nout, pr
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize("forces", ["none", "z", "z and one denormal in x", "xyz"])
+def test_vep3d_velocity_sweep_does_not_load_body_forces_that_are_zero(jr, forces):
+    """ShearBand3D.jl:114 hands three ρg arrays of zeros, a model with gravity has them in x and y.  The 3D VEP driver looks at their bits once per solve and the z-marching velocity
+    sweep of unobserved iterations does not load the arrays that hold only +0.0 (k_velocity3d_zb, NOF; grids above 88^3 cells run that kernel) -- every field equals the run that
+    loads them (tuning switch zero_forces = 0), bit for bit."""
+    from justrelax_jl_amd import _lib
+    h = _lib.default_handle()
+    ni = (112, 88, 72)
+    outs, res = [], []
+    try:
+        for zf in (1, 0):
+            h.set_option("zero_forces", zf)
+            s = jr.miniapps.shearband3d(ni, iterMax=6, nout=3)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+            rng = np.random.default_rng(8)
+            for c in ("xx", "yy", "zz", "yz", "xz", "xy", "yz_c", "xz_c", "xy_c"):
+                s.arrays["to" + c][...] = rng.uniform(-1.5, 1.5, size=s.arrays["to" + c].shape)
+                s.arrays["t" + c][...] = s.arrays["to" + c]
+            if "z" in forces:
+                s.arrays["fz"][...] = rng.uniform(-1.0, 1.0, size=s.arrays["fz"].shape)
+            if forces == "xyz":
+                s.arrays["fx"][...] = rng.uniform(-1.0, 1.0, size=s.arrays["fx"].shape)
+                s.arrays["fy"][...] = rng.uniform(-1.0, 1.0, size=s.arrays["fy"].shape)
+            if "denormal" in forces:
+                s.arrays["fx"][5, 7, 9] = 5e-324
+            stokes, pr, ρg = _upload(jr, s)
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, pr, s.extra["phases"], None, s.dt, None, kwargs=s.kwargs)
+            assert r.iter == 7
+            outs.append(_download(jr, stokes))
+            res.append(r)
+    finally:
+        h.set_option("zero_forces", 1)
+    assert np.array_equal(np.asarray(res[0].err_evo1), np.asarray(res[1].err_evo1))
+    for k in outs[0]:
+        a, b = np.ascontiguousarray(outs[0][k]), np.ascontiguousarray(outs[1][k])
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) or (np.array_equal(a, b) and k[0] == "e"), k
+
+
 @pytest.mark.parametrize("nphase", [1, 3, 4, 5])
 def test_vep3d_solve_with_other_phase_counts_fused_equals_unfused(jr, nphase):
     """the whole 3D VEP solve with 1, 3, 4 (template instantiations of the fused pre / centre, centre and per-node edge kernels) and 5 phases (run-time phase loops everywhere): the
