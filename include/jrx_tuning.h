@@ -6,8 +6,9 @@
  *   "fused_ylds" (default 1)      3D fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form)
  *   "visc_fold" (1)               3D fused kernel, viscous-limit form: the arithmetic with its exact zeros folded away for finite η (dτ_r = 1 / (θ_dτ + 1) once per thread, Δτ = dτ_r fma(2η, ε, -τ),
  *                                 no division by 1 + 0 ψ); same bits (0: the general expressions with zero operands)
- *   "zero_forces" (1)             3D fused kernel, one-launch viscous-limit form: ρg arrays whose every entry is +0.0 (all 64 bits zero; the operand pass of the driver call looks at
- *                                 them) are not loaded -- ρg_x and ρg_y (gravity along z), or all three (SolVi3D); x - (+0.0) = x for every x, so the bits are the same (0: always loaded)
+ *   "zero_forces" (1)             3D fused kernel (one-launch viscous-limit form and general form) and z-marching velocity sweep (3D Stokes and 3D VEP drivers): ρg arrays whose every entry
+ *                                 is +0.0 (all 64 bits zero; a pass of the driver call looks at them) are not loaded -- ρg_x and ρg_y (gravity along z), or all three (SolVi3D, ShearBand3D);
+ *                                 x - (+0.0) = x for every x, so the bits are the same (0: always loaded)
  *   "end_flips" (1)               jrx_stokes3d_iterate_timed, no neighbours: a batch whose number of fused steps is odd ends in the caller's arrays because its first stress sweep and its last
  *                                 velocity sweep write out of place into the other state set (0: the first iteration stays un-fused instead -- one more sweep pair; same results)
  *   "scratch_stagger" (0)         bytes (multiple of 256): array q of the library's second 3D state set starts q * stagger bytes into its allocation (scripts/bench_alloc_stagger.py: the spread
