@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B on ONE box: the tree before the body-force forms (_old/, commit b24392c, built beside) against the current tree, headline leg alone, alternating
+# A/B on ONE box: the tree before the body-force forms (_old/, commit b24392c, built beside) against the current tree, headline leg alone, alternating.
+# _old/ is not kept in the repository:  mkdir _old && git archive b24392c | tar -x -C _old && (cd _old && python justrelax.jl_amd/build.py && python __graft_entry__.py)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r04ab}
 mkdir -p $OUT
 for r in 1 2 3; do
