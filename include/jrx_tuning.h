@@ -13,6 +13,8 @@
  *                                 velocity sweep write out of place into the other state set (0: the first iteration stays un-fused instead -- one more sweep pair; same results)
  *   "scratch_stagger" (0)         bytes (multiple of 256): array q of the library's second 3D state set starts q * stagger bytes into its allocation (scripts/bench_alloc_stagger.py: the spread
  *                                 of the 512^3 kernel between allocations does not depend on it -- it comes with the physical placement, not with the low address bits)
+ *   "scratch_contiguous" (0)      the library's second 3D state set in physically contiguous device memory (hipExtMallocWithFlags, hipDeviceMallocContiguous): the probe of
+ *                                 profiles/r04_alloc_stagger.txt -- a process whose arrays are ALL physically contiguous runs the 512^3 kernel at the slow rate, every time
  *   "fused_hiface" (1)            3D fused kernel, viscous-limit form, no neighbours: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel
  *                                 (0: by the boundary-layer launch behind it)
  *   "fused_first_pct" (15)        multi-rank fused pipeline with the neighbour faces inside the kernel (fused_overlap = 3): share (%) of the interior z chunks whose tiles are launched

@@ -125,7 +125,7 @@ int find_opt(jrx_handle *h, const char *key, bool tuning, OptRef *out)
         {"stat_fused3d_visc", 2, &h->stat_fused3d_visc}, {"stat_fused3d_inkernel", 2, &h->stat_fused3d_inkernel}, {"stat_visc_checks", 2, &h->stat_visc_checks}, {"stat_visc_fallbacks", 2, &h->stat_visc_fallbacks}, {"stat_fused3d_nof1", 2, &h->stat_fused3d_nof1}, {"stat_fused3d_nof2", 2, &h->stat_fused3d_nof2},
     };
     const OptRef tun[] = {
-        {"fused_split", 0, &h->fused_split}, {"fused_tile", 1, &h->fused_tile}, {"fused_ylds", 0, &h->fused_ylds}, {"fused_hiface", 0, &h->fused_hiface}, {"visc_fold", 0, &h->visc_fold}, {"zero_forces", 0, &h->zero_forces}, {"scratch_stagger", 1, &h->scratch_stagger}, {"end_flips", 0, &h->end_flips}, {"comm_bcs_lazy", 0, &h->comm_bcs_lazy}, {"fused_first_pct", 1, &h->fused_first_pct},
+        {"fused_split", 0, &h->fused_split}, {"fused_tile", 1, &h->fused_tile}, {"fused_ylds", 0, &h->fused_ylds}, {"fused_hiface", 0, &h->fused_hiface}, {"visc_fold", 0, &h->visc_fold}, {"zero_forces", 0, &h->zero_forces}, {"scratch_stagger", 1, &h->scratch_stagger}, {"scratch_contiguous", 0, &h->scratch_contiguous}, {"end_flips", 0, &h->end_flips}, {"comm_bcs_lazy", 0, &h->comm_bcs_lazy}, {"fused_first_pct", 1, &h->fused_first_pct},
         {"b_width_x", 1, &h->b_width_opt[0]}, {"b_width_y", 1, &h->b_width_opt[1]}, {"b_width_z", 1, &h->b_width_opt[2]},
         {"halo_self_rccl", 0, &h->halo_self_rccl}, {"thermal_cfg", 1, &h->thermal_cfg}, {"thermal_xg", 1, &h->thermal_xg},
         {"fused2d", 0, &h->fused2d}, {"vep3_edges", 1, &h->vep3_edges}, {"vep3_cfg", 1, &h->vep3_cfg}, {"vep3_peel", 0, &h->vep3_peel}, {"vep3_peel_fork", 0, &h->vep3_peel_fork}, {"vep3_nt", 0, &h->vep3_nt}, {"vep3_prekz", 1, &h->vep3_prekz},

@@ -23,6 +23,7 @@ struct jrx_handle {
     size_t etatau_cap = 0;
     jrx_comm_state *comm = nullptr;
     double *scratch_base[10] = {};       // what hipMalloc returned for scratch[q] (scratch[q] may start scratch_stagger * q bytes into it)
+    bool scratch_contiguous = false;     // tuning switch: the second 3D state set in physically contiguous device memory (hipDeviceMallocContiguous)
     int scratch_stagger = 0, scratch_stagger_used = 0;   // tuning switch (bytes; see ensure_scratch) and the value the current allocation was made with
     double *scratch[10] = {};            // ping-pong set for the fused iteration kernel (P, τ(6), V(3))
     int scratch_dims[3] = {0, 0, 0};

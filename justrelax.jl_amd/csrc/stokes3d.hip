@@ -579,7 +579,7 @@ static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
     const size_t n[10] = {(size_t)nx * ny * nz, (size_t)nx * ny * nz, (size_t)nx * ny * nz, (size_t)nx * ny * nz,
                           (size_t)nx * (ny + 1) * (nz + 1), (size_t)(nx + 1) * ny * (nz + 1), (size_t)(nx + 1) * (ny + 1) * nz,
                           (size_t)(nx + 1) * (ny + 2) * (nz + 2), (size_t)(nx + 2) * (ny + 1) * (nz + 2), (size_t)(nx + 2) * (ny + 2) * (nz + 1)};
-    if (h->scratch_dims[0] == nx && h->scratch_dims[1] == ny && h->scratch_dims[2] == nz && h->scratch[0] && h->scratch_stagger_used == h->scratch_stagger) return JRX_OK;
+    if (h->scratch_dims[0] == nx && h->scratch_dims[1] == ny && h->scratch_dims[2] == nz && h->scratch[0] && h->scratch_stagger_used == h->scratch_stagger + 1000003 * (int)h->scratch_contiguous) return JRX_OK;
     for (int q = 0; q < 10; q++) {
         if (h->scratch_base[q]) JRX_HIP(h, hipFree(h->scratch_base[q]));
         h->scratch[q] = h->scratch_base[q] = nullptr;
@@ -590,11 +590,16 @@ static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
     const size_t stg = (size_t)(h->scratch_stagger > 0 ? h->scratch_stagger : 0) & ~(size_t)255;
     for (int q = 0; q < 10; q++) {
         void *b = nullptr;
-        JRX_HIP(h, hipMalloc(&b, n[q] * sizeof(double) + (size_t)q * stg));
+        // tuning switch scratch_contiguous: physically contiguous device memory (hipDeviceMallocContiguous), plain hipMalloc when the runtime refuses
+        if (!h->scratch_contiguous || hipExtMallocWithFlags(&b, n[q] * sizeof(double) + (size_t)q * stg, hipDeviceMallocContiguous) != hipSuccess) {
+            (void)hipGetLastError();
+            b = nullptr;
+            JRX_HIP(h, hipMalloc(&b, n[q] * sizeof(double) + (size_t)q * stg));
+        }
         h->scratch_base[q] = (double *)b;
         h->scratch[q] = (double *)((char *)b + (size_t)q * stg);
     }
-    h->scratch_stagger_used = h->scratch_stagger;
+    h->scratch_stagger_used = h->scratch_stagger + 1000003 * (int)h->scratch_contiguous;
     h->scratch_dims[0] = nx; h->scratch_dims[1] = ny; h->scratch_dims[2] = nz;
     return JRX_OK;
 }
