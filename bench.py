@@ -147,6 +147,7 @@ def fused_roofline(pr, n, sk_ms, sf_ms, kcells, it_gbs=None):
            "traffic_source": pr["pmc_source"],
            "traffic_ratio": tr / (pr["alg"] * kcells) if tr else None,
            "needed_bytes_per_launch": pr["needed"] * kcells,
+           "frac_at_needed_bytes": pr["needed"] * kcells / (sk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,      # every array the kernel reads or writes counted once: the compulsory traffic of this fused form
            "traffic_over_needed": tr / (pr["needed"] * kcells) if tr else None,
            "cells_per_launch": kcells,
            "algorithmic_bytes_per_launch": pr["alg"] * kcells, "avg_launch_ms": sk_ms,
@@ -367,6 +368,8 @@ def cfg_solvi(jr, h, n, steps, warm):
         out["avg_launch_ms"] = sk
         out["kernel_cells_per_launch"] = kcells
         out["frac_kernel"] = pr["alg"] * kcells / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["needed_bytes_per_cell"] = pr["needed"]
+        out["frac_kernel_at_needed_bytes"] = pr["needed"] * kcells / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS
     grid.finalize_global_grid()
     return out
 
@@ -478,7 +481,9 @@ def cfg_thermal3d(jr, h, n=256, iters=400):
     el, k = _timed(run, 20, iters)
     gbps = 176.0 * n ** 3 * k / el / 1e9
     return {"workload": f"thermal diffusion {n}^3 (3D PT, array form)", "iterations": k, "it_per_s": k / el,
-            "effective_GBps_at_176B_per_cell": gbps, "frac_of_8TBps": gbps / 8000.0}
+            "effective_GBps_at_176B_per_cell_as_written": gbps, "frac_of_8TBps_as_written": gbps / 8000.0,
+            # the one-launch iteration needs 11 reads (T, q(3), K, θr_dτ, Told, ρCp, dτ_ρ, H, SH) + 4 writes (T, q(3)) = 120 B/cell
+            "needed_bytes_per_cell": 120.0, "frac_at_needed_bytes": 120.0 * n ** 3 * k / el / 1e9 / 8000.0}
 
 
 def cfg_thermal3d_phases(jr, h, n=256, iters=200):
@@ -506,7 +511,9 @@ def cfg_thermal3d_phases(jr, h, n=256, iters=200):
     el, k = _timed(run, 10, iters)
     gbps = 280.0 * n ** 3 * k / el / 1e9
     return {"workload": f"thermal diffusion {n}^3 (3D PT, phase-ratio form, 2 phases)", "iterations": k, "it_per_s": k / el,
-            "effective_GBps_at_280B_per_cell": gbps, "frac_of_8TBps": gbps / 8000.0}
+            "effective_GBps_at_280B_per_cell_as_written": gbps, "frac_of_8TBps_as_written": gbps / 8000.0,
+            # k_thermal3d_fused_ph, two phases: 18 reads (T, θr_dτ, q(3), P, dτ_ρ, Told, H, SH, centre and three face ratio arrays of 2 doubles each) + 6 writes (T, q(3), θr_dτ, dτ_ρ) = 192 B/cell
+            "needed_bytes_per_cell": 192.0, "frac_at_needed_bytes": 192.0 * n ** 3 * k / el / 1e9 / 8000.0}
 
 
 def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z")):
@@ -1513,6 +1520,15 @@ def run_rank(args) -> int:
             finally:
                 h.set_option("viscous_limit", 1)
                 h.set_option("zero_forces", 1)
+        if isinstance(out.get("roofline"), dict):
+            g = out.get("general_kernel")
+            if isinstance(g, dict) and isinstance(g.get("roofline"), dict):
+                gr = g["roofline"]
+                out["roofline"]["general_form"] = {"what": "the kernel that does all of SURVEY 8d's work (any dt, every operand and body-force array loaded), same process, same allocations, same batch length",
+                                                   "bytes_per_cell": gr["bytes_per_cell"], "avg_launch_ms": gr["avg_launch_ms"], "achieved": gr["achieved"], "frac": gr["frac"],
+                                                   "frac_at_needed_bytes": gr.get("frac_at_needed_bytes"), "it_per_s": g["it_per_s"], "traffic": gr.get("traffic")}
+            out["roofline"]["launch_ms_per_rank"] = [sk_ms if fused else None]      # placement probe: a process runs this kernel at one of two rates for its lifetime (DESIGN, placement)
+            out["roofline"]["field_placement"] = h.get_option("field_placement")
         if world == 1 and not self_halo and not args.no_extras:
             try:
                 out["solve_path"] = solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, args.solve_iters, n, pr)

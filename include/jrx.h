@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JRX_VERSION 210
+#define JRX_VERSION 220
 
 typedef enum jrx_status {
     JRX_OK = 0,
@@ -63,6 +63,20 @@ int32_t jrx_version(void);
  * the sources beside it */
 const char *jrx_build_id(void);
 
+/* ------------------------------------------------------------------ state arrays
+ * Device memory for the fields, handed out by the library.  Replaces the array constructor the backend owns in the reference:
+ * StokesArrays(::Type{AMDGPUBackend}, ni) / ThermalArrays(...) -> @zeros(ni...) -> ROCArray (src/ext/AMDGPU/3D.jl:46-48,
+ * src/types/constructors/stokes.jl:279-303) -- a binding wraps the pointer (Julia: unsafe_wrap(ROCArray, ptr, dims; own = false) plus a
+ * finalizer that calls jrx_field_free).  Contents are NOT initialised (the constructor fills with zeros as @zeros does).  Using it is
+ * optional: every entry point takes any device pointer.  What it buys: the option "field_placement" decides how the arrays are backed
+ * physically, which the large 3D kernels are sensitive to ("placement"); the library's own large arrays (second state sets, ητ)
+ * follow the same option.  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns unmapped spare chunks to the driver.
+ * jrx_field_stats: [0] live arrays (the library's own included), [1] their bytes, [2] physical chunks created, [3] spare chunks, [4] us in hipMemCreate, [5] us mapping. */
+jrx_status jrx_field_alloc(jrx_handle *h, int64_t count, double **out);     /* count doubles */
+jrx_status jrx_field_free(jrx_handle *h, double *p);
+jrx_status jrx_field_trim(jrx_handle *h);
+jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
+
 /* Options of the handle: what a caller of solve! may want to choose.  (The A/B switches of the measurements in profiles/ and the test
  * hooks are NOT part of this ABI: include/jrx_tuning.h.)  The library never reads the process environment.  Keys:
  * "kernel_variant" (3D Stokes):
@@ -93,6 +107,9 @@ const char *jrx_build_id(void);
  *   (old stresses, P0, K, G, Q).  Every driver call first checks those ten arrays in one streaming pass (all of tau_o, P0, Q finite; K, G neither NaN
  *   nor 0): only then do the results equal the general kernels', and only then does this form run -- otherwise the general kernels run and a NaN
  *   there ends the solve with JRX_ERR_NAN exactly as error("NaN(s)") of Stokes3D.jl:162 would.  0 = always the general kernels.
+ * "field_placement" (0/1/2, default 0): backing of the arrays of jrx_field_alloc and of the library's own large arrays: 0 = hipMalloc; 1 = physical chunks
+ *   (hipMemCreate) mapped onto one virtual range per array in a shuffled order; 2 = physically contiguous (hipDeviceMallocContiguous; the A/B reproducer of
+ *   the slow rate).  Results never depend on it.
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
  *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_fused3d_inkernel" = those that finished the faces with a neighbour themselves ("fused_overlap" = 3), "stat_visc_checks" /
  *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_graph_replays" = hipGraphLaunch calls -- so that a caller

@@ -157,7 +157,7 @@ class Cart(C.Structure):
 
 
 TUNING_HEADER = HERE.parent / "include" / "jrx_tuning.h"
-ABI_VERSION = 210        # JRX_VERSION this binding's structs and option keys follow (210: jrx_comm_init_ipc, viscous-limit counters; 200 -> 210 also covers round 3's b_width[3] of jrx_vep3d_params)
+ABI_VERSION = 220        # 220: jrx_field_alloc / _free / _trim / _stats, option field_placement; JRX_VERSION this binding's structs and option keys follow (210: jrx_comm_init_ipc, viscous-limit counters; 200 -> 210 also covers round 3's b_width[3] of jrx_vep3d_params)
 
 
 def header_version() -> int:

@@ -23,9 +23,48 @@ from .backend import AMDGPUBackend, CPUBackend, device_of
 
 
 # ----------------------------------------------------------------------------- layout helpers
+class _LibraryArray:
+    """one array of jrx_field_alloc, exposed through __cuda_array_interface__ so that torch wraps it without a copy; torch keeps this object alive for as
+    long as any tensor views the memory, and the last reference returns the array to the library"""
+
+    def __init__(self, handle, count: int):
+        import ctypes as C
+        self._handle, p = handle, C.c_void_p()
+        handle.call("jrx_field_alloc", C.c_int64(max(count, 1)), C.byref(p))
+        self._ptr = p.value
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (self._ptr, False), "version": 2}
+
+    def __del__(self):
+        try:
+            import ctypes as C
+            if self._ptr and getattr(self._handle, "_h", None) and self._handle._h.value:      # a closed handle has released its arrays itself
+                self._handle.lib.jrx_field_free(self._handle._h, C.c_void_p(self._ptr))
+            self._ptr = 0
+        except Exception:
+            pass
+
+
+_field_allocator = None      # a _lib.Handle: device arrays come from jrx_field_alloc (the backend owns the array constructor: src/ext/AMDGPU/3D.jl:46-48)
+
+
+def use_library_arrays(handle):
+    """Route the device arrays of every constructor of this package through jrx_field_alloc of `handle` (None: back to torch's allocator).  What
+    the handle's option "field_placement" selects then holds for the caller's arrays as it does for the library's own."""
+    global _field_allocator
+    _field_allocator = handle
+
+
 def fzeros(shape, device, fill: float = 0.0) -> torch.Tensor:
     """Column-major fp64 array (the layout ParallelStencil's @zeros gives on every backend)."""
     shape = tuple(int(s) for s in shape)
+    if _field_allocator is not None and torch.device(device).type == "cuda":
+        count = 1
+        for n_ in shape:
+            count *= n_
+        if count > 0:
+            t = torch.as_tensor(_LibraryArray(_field_allocator, count), device=device)
+            t.fill_(float(fill))
+            return t.view(shape[::-1]).permute(*range(len(shape) - 1, -1, -1))
     t = torch.full(shape[::-1], float(fill), dtype=torch.float64, device=device)
     return t.permute(*range(len(shape) - 1, -1, -1))
 
@@ -40,7 +79,12 @@ def is_fortran(t: torch.Tensor) -> bool:
 
 def from_numpy(a: np.ndarray, device) -> torch.Tensor:
     a = np.asarray(a, dtype=np.float64)
-    t = torch.from_numpy(np.ascontiguousarray(a.T)).to(device)
+    src = torch.from_numpy(np.ascontiguousarray(a.T))
+    if _field_allocator is not None and torch.device(device).type == "cuda" and a.size:
+        t = fzeros(a.shape, device)
+        t.permute(*range(a.ndim - 1, -1, -1)).copy_(src)
+        return t
+    t = src.to(device)
     return t.permute(*range(a.ndim - 1, -1, -1))
 
 

@@ -19,7 +19,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "lib" / "libjrx_hip.so"
-SRCS = ["handle.hip", "halo.hip", "stokes3d.hip", "stokes3d_vep.hip", "stokes2d.hip", "thermal2d.hip", "thermal3d.hip", "gridops.hip"]
+SRCS = ["handle.hip", "fieldpool.hip", "halo.hip", "stokes3d.hip", "stokes3d_vep.hip", "stokes2d.hip", "thermal2d.hip", "thermal3d.hip", "gridops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-I", str(HERE.parent / "include"), "-I", str(CSRC), "-I", "/opt/rocm/include", "-Wall", "-Wno-unused-function", "-Wno-array-bounds"]
 MARKER = b"JRX_BUILD_ID="

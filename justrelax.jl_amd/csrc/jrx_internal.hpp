@@ -10,6 +10,7 @@
 #include "jrx.h"
 
 struct jrx_comm_state;   // halo.hip
+struct jrx_field_pool;   // fieldpool.hip
 
 struct jrx_handle {
     int device = 0;
@@ -22,6 +23,10 @@ struct jrx_handle {
     double *etatau = nullptr;            // library-owned ητ (capacity etatau_cap doubles)
     size_t etatau_cap = 0;
     jrx_comm_state *comm = nullptr;
+    jrx_field_pool *pool = nullptr;      // jrx_field_alloc / jrx_field_free: the state arrays the library hands out, and its own large arrays
+    int field_placement = 0;             // option: 0 hipMalloc, 1 physical chunks mapped in shuffled order (virtual memory management), 2 physically contiguous (A/B: the slow rate)
+    int field_chunk_mib = 64, field_batch_mib = 0, field_va_align_mib = 0;   // tuning: chunk size, smallest batch of new chunks, alignment of the reserved virtual range
+    bool field_shuffle = true;           // tuning: 0 = chunks in creation order (A/B of the shuffle itself)
     double *scratch_base[10] = {};       // what hipMalloc returned for scratch[q] (scratch[q] may start scratch_stagger * q bytes into it)
     bool scratch_contiguous = false;     // tuning switch: the second 3D state set in physically contiguous device memory (hipDeviceMallocContiguous)
     int scratch_stagger = 0, scratch_stagger_used = 0;   // tuning switch (bytes; see ensure_scratch) and the value the current allocation was made with
@@ -158,6 +163,11 @@ static constexpr double kGraphCells3D = 48.0 * 48.0 * 48.0;
 // A handle is bound to one device (jrx_create); entry points that launch or allocate require that device to be the calling thread's
 // current one -- checked, never changed behind the caller's back
 jrx_status jrx_check_device(jrx_handle *h);
+
+// fieldpool.hip: where every large library-owned array comes from (the handle's placement option applies); freed with the handle at the latest
+jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out);
+jrx_status jrx_dev_free(jrx_handle *h, void *p);
+void jrx_pool_destroy(jrx_handle *h);
 
 // ensure the library-owned ητ scratch holds n doubles
 jrx_status jrx_ensure_etatau(jrx_handle *h, size_t n);

@@ -581,7 +581,7 @@ static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
                           (size_t)(nx + 1) * (ny + 2) * (nz + 2), (size_t)(nx + 2) * (ny + 1) * (nz + 2), (size_t)(nx + 2) * (ny + 2) * (nz + 1)};
     if (h->scratch_dims[0] == nx && h->scratch_dims[1] == ny && h->scratch_dims[2] == nz && h->scratch[0] && h->scratch_stagger_used == h->scratch_stagger + 1000003 * (int)h->scratch_contiguous) return JRX_OK;
     for (int q = 0; q < 10; q++) {
-        if (h->scratch_base[q]) JRX_HIP(h, hipFree(h->scratch_base[q]));
+        if (h->scratch_base[q]) JRX_TRY(jrx_dev_free(h, h->scratch_base[q]));
         h->scratch[q] = h->scratch_base[q] = nullptr;
     }
     h->scratch_dims[0] = h->scratch_dims[1] = h->scratch_dims[2] = 0;
@@ -591,11 +591,11 @@ static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
     for (int q = 0; q < 10; q++) {
         void *b = nullptr;
         // tuning switch scratch_contiguous: physically contiguous device memory (hipDeviceMallocContiguous), plain hipMalloc when the runtime refuses
-        if (!h->scratch_contiguous || hipExtMallocWithFlags(&b, n[q] * sizeof(double) + (size_t)q * stg, hipDeviceMallocContiguous) != hipSuccess) {
-            (void)hipGetLastError();
-            b = nullptr;
-            JRX_HIP(h, hipMalloc(&b, n[q] * sizeof(double) + (size_t)q * stg));
-        }
+        const int keep = h->field_placement;
+        if (h->scratch_contiguous) h->field_placement = 2;
+        const jrx_status st = jrx_dev_alloc(h, n[q] * sizeof(double) + (size_t)q * stg, &b);
+        h->field_placement = keep;
+        JRX_TRY(st);
         h->scratch_base[q] = (double *)b;
         h->scratch[q] = (double *)((char *)b + (size_t)q * stg);
     }
