@@ -89,8 +89,7 @@ jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
  *   3 = fused pipeline wherever it is legal (ignores that rule).  All variants produce bit-identical results.
  * "fused_comm" (0/1, default 1): multi-rank runs use the fused pipeline; 0 = split sweeps + hidden communication (same results).
  * "fused_overlap" (0/1/2/3/4, default 3): how the multi-rank fused pipeline places update_halo!(V) (same results in every mode):
- *   3 = neighbour faces inside the kernel for ranks without an x neighbour, 2 for the others (a launch over the tiles of an x face alone is slow); 4 = inside the kernel for every rank
- *       (viscous-limit form, dt = Inf; other runs use 2): boundary slabs + the exchange on a second stream beside the fused kernel as in 2, but the
+ *   3 = neighbour faces inside the kernel, for every rank (4 is accepted as a synonym; viscous-limit form, dt = Inf; other runs use 2): boundary slabs + the exchange on a second stream beside the fused kernel as in 2, but the
  *       kernel's tiles next to a face with a neighbour are launched behind the exchange (the others beside it) and read the received planes themselves: no flow_bcs! launch,
  *       no fix-up launch;
  *   2 = early exchange: the velocity phase alone over the boundary slabs of the faces with a neighbour, flow_bcs! and the whole exchange on a second
@@ -107,14 +106,20 @@ jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
  *   (old stresses, P0, K, G, Q).  Every driver call first checks those ten arrays in one streaming pass (all of tau_o, P0, Q finite; K, G neither NaN
  *   nor 0): only then do the results equal the general kernels', and only then does this form run -- otherwise the general kernels run and a NaN
  *   there ends the solve with JRX_ERR_NAN exactly as error("NaN(s)") of Stokes3D.jl:162 would.  0 = always the general kernels.
+ * "operand_cache" (0/1, default 0): the drivers of the 3D visco-elastic path look at their operand arrays once per call (dt = Inf: may the viscous-limit kernels stand in --
+ *   tau_o, P0, Q, eta finite, K, G neither NaN nor 0; any dt: are body-force arrays +0.0 throughout): one streaming pass and a host synchronisation, 3.6 ms at 512^3 -- nothing
+ *   inside a solve! of thousands of iterations, 3 % of a 20-iteration batch.  1 = the verdict is kept per (operand pointers, extents, dt) and reused until the caller states that
+ *   it has written to one of those arrays: jrx_fields_dirty(h).  The library's own writes (the tau -> tau_o copy at the end of solve!) invalidate it themselves.  Default 0: every call looks.
  * "field_placement" (0/1/2, default 0): backing of the arrays of jrx_field_alloc and of the library's own large arrays: 0 = hipMalloc; 1 = physical chunks
  *   (hipMemCreate) mapped onto one virtual range per array in a shuffled order; 2 = physically contiguous (hipDeviceMallocContiguous; the A/B reproducer of
  *   the slow rate).  Results never depend on it.
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
  *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_fused3d_inkernel" = those that finished the faces with a neighbour themselves ("fused_overlap" = 3), "stat_visc_checks" /
- *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
+ *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_operand_cache_hits" = driver calls that reused the operand verdict, "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
  *   (and the tests, and bench.py for the kernel it prices) can prove which path ran. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
+/* the caller has written to an operand array (tau_o, P0, Q, K, G, eta, rho g) since the last driver call: a cached verdict of the operand pass ("operand_cache") is dropped */
+jrx_status jrx_fields_dirty(jrx_handle *h);
 jrx_status jrx_get_option(jrx_handle *h, const char *key, int64_t *value);
 
 /* ------------------------------------------------------------------ block decomposition (host logic; no GPU needed)

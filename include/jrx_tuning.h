@@ -21,7 +21,8 @@
  *                                 beside update_halo!(V); the rest of the block -- shell tiles among their row neighbours -- follows behind it
  *   "comm_bcs_lazy" (0)           multi-rank fused pipeline: 1 = flow_bcs! of the physical faces applied lazily (before anything reads those entries from memory) instead of twice per
  *                                 iteration; the fix-up next to the received planes derives them by rule (measured 2 % slower than the two launches: off)
- *   "fused_tile" (2)              3D fused kernel tile: 0 = 64 x 4 threads, 1 = 32 x 8, 2 = chosen by nx (32 x 8 for nx = 63 .. 90, where three 32-lane tiles replace two 64-lane ones)
+ *   "fused_tile" (2)              3D fused kernel tile: 0 = 64 x 4 threads, 1 = 32 x 8, 3 = 64 x 8 (two 8-wave blocks per CU, XCD bands of four tile rows), 2 = chosen by the grid (32 x 8 for nx = 63 .. 90,
+ *                                 where three 32-lane tiles replace two 64-lane ones; 64 x 8 where the launch keeps >= 4,096 blocks, i.e. from ~230^3 on)
  *   "fused_split" (0)             no neighbours: high-face tiles + boundary stress layers forked onto the halo stream
  *   "b_width_x/y/z" (0)           > 0 overrides jrx_stokes3d_params.b_width of the split sweeps
  *   "fused2d" (1)                 2D visco-elastic loop: one-launch iterations on launch-bound grids

@@ -157,7 +157,7 @@ class Cart(C.Structure):
 
 
 TUNING_HEADER = HERE.parent / "include" / "jrx_tuning.h"
-ABI_VERSION = 220        # 220: jrx_field_alloc / _free / _trim / _stats, option field_placement; JRX_VERSION this binding's structs and option keys follow (210: jrx_comm_init_ipc, viscous-limit counters; 200 -> 210 also covers round 3's b_width[3] of jrx_vep3d_params)
+ABI_VERSION = 220        # 220: jrx_field_alloc / _free / _trim / _stats, option field_placement; jrx_fields_dirty, option operand_cache; JRX_VERSION this binding's structs and option keys follow (210: jrx_comm_init_ipc, viscous-limit counters; 200 -> 210 also covers round 3's b_width[3] of jrx_vep3d_params)
 
 
 def header_version() -> int:
@@ -253,6 +253,10 @@ class Handle:
         if st != 0:
             self.check(self.lib.jrx_tuning_get(self._h, k, C.byref(v)))
         return v.value
+
+    def fields_dirty(self):
+        """the caller has written to an operand array (τ_o, P0, Q, K, G, η, ρg) since the last driver call: a cached operand verdict (option operand_cache) is dropped"""
+        self.call("jrx_fields_dirty")
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -41,9 +41,9 @@ struct jrx_handle {
     // ---- options (jrx_set_option; nothing in the library reads the process environment)
     bool loop_graphs = true;             // launch-bound 2D loops: runs of unobserved iterations replay as captured hipGraphs (option "loop_graphs")
     bool thermal_fused = true;           // heat diffusion: one fused launch per unobserved iteration (option "thermal_fused")
-    int fused_overlap = 3;               // multi-rank fused pipeline: 4 (viscous-limit form) the kernel's own boundary tiles read the received planes -- a second launch of the kernel over those
-                                         // tiles behind update_halo!(V) -- no BC launch, no fix-up; 3 = that for ranks without an x neighbour, 2 for the others; 0 exchange behind the kernel, in order; 1 shell tiles + exchange on the halo stream, interior tiles
-                                         // concurrently; 2 boundary slabs of the velocity phase + BCs + the whole exchange on the halo stream beside the kernel (early exchange)
+    int fused_overlap = 3;               // multi-rank fused pipeline: 3 (= 4; viscous-limit form) the kernel's own boundary tiles read the received planes -- a second launch of the kernel over those
+                                         // tiles behind update_halo!(V) -- no BC launch, no fix-up, on every rank; 0 exchange behind the kernel, in order; 1 shell tiles + exchange on the halo stream, interior tiles
+                                         // concurrently; 2 boundary slabs of the velocity phase + BCs + the whole exchange on the halo stream beside the kernel (early exchange; what 3 falls back to for finite dt)
     int kernel_variant = 0;              // 0 auto (fused PT pipeline where it pays), 1 per-node v1 kernels, 2 z-marching sweeps only, 3 fused wherever legal
     bool fused_split = false;            // no neighbours: high-face tiles + boundary stress layers on the halo stream, interior tiles concurrently
                                          // (measured slower, profiles/r02_ab_fused_split.txt: off)
@@ -58,6 +58,11 @@ struct jrx_handle {
                                          // BC launches it saves (-2 %): off
     bool end_flips = true;               // jrx_stokes3d_iterate_timed: a batch with an odd number of fused steps ends in the caller's arrays through out-of-place end sweeps (0: first step un-fused)
     bool zero_forces = true;             // viscous-limit one-launch kernel: body-force arrays whose every entry is +0.0 (all bits zero; the operand pass looks) are not loaded (k_fused3d, NOF; same bits)
+    // option "operand_cache": the verdict of the operand pass (visc_ok, nof) is kept per set of operand pointers, extents and dt and reused by the next driver call until the caller
+    // declares the operand arrays changed (jrx_fields_dirty) or the library writes one of them itself
+    bool operand_cache = false;
+    struct { bool valid = false; const void *ptr[14] = {}; int64_t n[3] = {}; double dt = 0.0; int flags = 0; bool visc_ok = false; int nof = 0; } opv;
+    int64_t stat_operand_cache_hits = 0;
     int nof = 0;                         // set per driver call by the operand pass: 0 = every ρg array is loaded, 1 = ρg_x and ρg_y hold only +0.0, 2 = all three do
     bool visc_fold = true;               // viscous-limit fused kernel: the arithmetic with the exact zeros folded away (one division per thread for dτ_r, no division by 1 in compute_P!; same bits; A/B)
     bool fused_hiface = true;            // viscous-limit fused kernel without neighbours: the high-face node layers inside the kernel (0: the boundary-layer launch behind it, A/B)

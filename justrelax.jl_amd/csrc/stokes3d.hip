@@ -128,11 +128,45 @@ __global__ __launch_bounds__(256) void k_forces_zero(const unsigned long long *_
 }
 
 // forces: also look at the body forces (the drivers whose fused kernels read them; the stand-alone stress sweep does not)
+static jrx_status visc_operands_local(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p, bool forces);
+// ... and with neighbours every rank must pick the same kernel forms (the in-kernel neighbour faces exist for the viscous-limit form only: ranks that disagreed would run different
+// pipelines inside one exchange): the verdicts are combined over the ranks -- the viscous-limit form only if every rank's operands allow it, body-force loads dropped only where every rank's are zero
 jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p, bool forces = true)
+{
+    JRX_TRY(visc_operands_local(h, f, p, forces));
+    if (jrx_comm_active(h)) {
+        double v[2] = {h->visc_ok ? 0.0 : 1.0, (double)(2 - h->nof)};
+        JRX_TRY(jrx_allreduce_host(h, v, 2, 1));
+        h->visc_ok = v[0] == 0.0;
+        h->nof = 2 - (int)v[1];
+    }
+    return JRX_OK;
+}
+static jrx_status visc_operands_local(jrx_handle *h, const jrx_stokes3d_fields *f, const jrx_stokes3d_params *p, bool forces)
 {
     h->visc_ok = false;
     h->nof = 0;
     forces = forces && h->zero_forces && f->fx && f->fy && f->fz;
+    // option "operand_cache" = 1: the same operand arrays, extents and dt as at the last pass, and the caller has not declared them changed (jrx_fields_dirty): the verdict stands
+    // (the pass streams up to 17 arrays and ends in a host synchronisation: 3.0 + 0.6 ms at 512^3 -- nothing inside a solve!, 3 % of a 20-iteration batch)
+    const void *key[14] = {f->P0, f->Q, f->toxx, f->toyy, f->tozz, f->toyz, f->toxz, f->toxy, f->eta, f->K, f->G, f->fx, f->fy, f->fz};
+    const int kflags = (forces ? 1 : 0) | (h->viscous_limit ? 2 : 0) | (p->displacement_bcs ? 4 : 0) | (h->kernel_variant << 3);
+    if (h->operand_cache && h->opv.valid && h->opv.dt == p->dt && h->opv.flags == kflags && h->opv.n[0] == p->nx && h->opv.n[1] == p->ny && h->opv.n[2] == p->nz &&
+        memcmp(h->opv.ptr, key, sizeof(key)) == 0) {
+        h->visc_ok = h->opv.visc_ok;
+        h->nof = h->opv.nof;
+        h->stat_operand_cache_hits++;
+        return JRX_OK;
+    }
+    struct Remember {      // whatever way the pass ends, its verdict is what the next call may reuse
+        jrx_handle *h; const void *const *key; const jrx_stokes3d_params *p; int kflags; bool ok = false;
+        ~Remember() {
+            h->opv.valid = ok;
+            if (!ok) return;
+            memcpy(h->opv.ptr, key, sizeof(h->opv.ptr));
+            h->opv.n[0] = p->nx; h->opv.n[1] = p->ny; h->opv.n[2] = p->nz; h->opv.dt = p->dt; h->opv.flags = kflags; h->opv.visc_ok = h->visc_ok; h->opv.nof = h->nof;
+        }
+    } remember{h, key, p, kflags};
     if ((!h->viscous_limit || p->dt != INFINITY) && forces && !p->displacement_bcs && (h->kernel_variant == 0 || h->kernel_variant == 3) && p->nx >= 48) {
         // the general form of the fused kernel has the instantiations without body-force loads, too (every 3D model of the reference has gravity along z: ρg_x = ρg_y = 0)
         const i64 nc = (i64)p->nx * p->ny * p->nz;
@@ -145,9 +179,10 @@ jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, cons
         JRX_HIP(h, hipMemcpyAsync(h_bad, d_bad, sizeof(double), hipMemcpyDeviceToHost, s));
         JRX_HIP(h, hipStreamSynchronize(s));
         if (!(*h_bad & 2)) h->nof = (*h_bad & 4) ? 1 : 2;
+        remember.ok = true;
         return JRX_OK;
     }
-    if (!h->viscous_limit || p->dt != INFINITY) return JRX_OK;
+    if (!h->viscous_limit || p->dt != INFINITY) { remember.ok = true; return JRX_OK; }
     const i64 nx = p->nx, ny = p->ny, nz = p->nz;
     int *d_bad = reinterpret_cast<int *>(h->d_sums + 6), *h_bad = reinterpret_cast<int *>(h->h_sums + 6);
     hipStream_t s = h->stream;
@@ -163,6 +198,7 @@ jrx_status visc_operands_check(jrx_handle *h, const jrx_stokes3d_fields *f, cons
     if (h->visc_ok && forces && !(*h_bad & 2)) h->nof = (*h_bad & 4) ? 1 : 2;
     h->stat_visc_checks++;
     if (!h->visc_ok) h->stat_visc_fallbacks++;
+    remember.ok = true;
     return JRX_OK;
 }
 
@@ -419,7 +455,10 @@ jrx_status jrx_stokes3d_sweep_stress(jrx_handle *h, const jrx_stokes3d_fields *f
     const bool diag = flags & JRX_OUT_DIAG;
     if (diag) JRX_TRY(check_diag(h, f));
     SweepArgs a = make_args(f, nullptr, p);
-    JRX_TRY(visc_operands_check(h, f, p, false));
+    // one sweep: a pass over the ten operand arrays to find out whether they may stay unread costs more than reading them -- the general kernel runs, unless a verdict is
+    // already at hand (option "operand_cache")
+    if (h->operand_cache) JRX_TRY(visc_operands_check(h, f, p, false));
+    else { h->visc_ok = false; h->nof = 0; }
     JRX_TRY(launch_stress(h, h->stream, a, diag, 0, (int)p->nx + 1, 0, (int)p->ny + 1, 0, (int)p->nz + 1));
     JRX_HIP(h, hipStreamSynchronize(h->stream));
     return JRX_OK;
@@ -524,7 +563,7 @@ static void fused_tiles(const Lay3 &L, const FusedShape S, int nt[3])
 // Chunk depth: 8 planes where that gives the chip enough blocks; on small grids a block's chain of dependent planes is what takes the time (64^3 in 8-plane chunks is
 // 352 blocks on 256 CUs: 33 us per launch, 24 us in 4-plane chunks; 48^3: 26 -> 12 us in 2-plane chunks; from 96^3 on 8 planes are best; scripts/kbench_visc.hip,
 // profiles/r03_small_grid_chunks.txt), so the depth is halved while the launch has fewer than 512 blocks
-static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L)
+static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L, double dt)
 {
     // tile: 64 x 4 threads (a row per wave); 32 x 8 (two rows per wave, 30 stress columns per tile) costs ~20 % more per lane but quantises nx in steps of 30:
     // it is the better shape where three 32-lane tiles replace two 64-lane ones, nx = 63 .. 90 (64^3: 25.4 k -> 30.4 k it/s, 80^3: 15.9 k -> 22.1 k, 90^3: 14.6 k -> 17.8 k;
@@ -533,6 +572,16 @@ static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L)
     const bool narrow = h->fused_tile == 1 || (h->fused_tile == 2 && L.nx > 62 && L.nx <= 90);
     FusedShape S = narrow ? FusedShape{32, 8, 8} : FusedShape{64, 4, 8};
     int nt[3];
+    // round 5: 64 x 8 threads (seven stress rows per tile instead of three: the y halo costs 8/7 instead of 4/3 of the velocity-phase operands; two 8-wave blocks per CU, tile rows
+    // dealt to the XCDs in bands of four) where the launch still has >= 4,096 blocks: 512^3 -2.5 .. -5 % kernel time in every physical backing of the arrays (hipMalloc, shuffled
+    // 2 MiB chunks, contiguous), 256^3 -1 .. -4 % (scripts/kbench_place.hip, profiles/r05_placement_ab.txt).  "fused_tile" = 3 forces it, 0 keeps 64 x 4
+    {
+        const FusedShape T{64, 8, 8};
+        fused_tiles(L, T, nt);
+        // viscous-limit forms only: the general form needs 132 VGPRs at this shape (one 8-wave block per CU instead of two)
+        const bool visc = h->viscous_limit && h->visc_ok && dt == INFINITY && h->fused_ylds;
+        if (visc && (h->fused_tile == 3 || (h->fused_tile == 2 && !narrow && (long long)nt[0] * nt[1] * nt[2] >= 4096))) return T;
+    }
     for (int kz = 8; kz >= 2; kz /= 2) {
         S.kz = kz;
         fused_tiles(L, S, nt);
@@ -623,7 +672,7 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
         // Lanes per cell row: fused ceil(nx / (TX - 2)) TX-lane tiles with TY - 1 of TY rows updating stresses; sweeps ceil(nx / W) W-lane row tiles (W as in
         // launch_stress); per lane the fused iteration costs 0.62 of the two sweeps (120^3: 9.0 k against 7.4 k it/s at 171 against 128 lanes).  Small grids are
         // bound by the launch count, which favours the fused pipeline whatever the fill.
-        const FusedShape S = fused_shape(h, L);
+        const FusedShape S = fused_shape(h, L, p->dt);
         int nt[3];
         fused_tiles(L, S, nt);
         const int W = p->nx > 384 ? 512 : (p->nx > 192 ? 256 : (p->nx > 96 ? 128 : 64));
@@ -647,7 +696,8 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
 }
 
 // launch the fused kernel over the box of tiles [b[0], b[1]) x [b[2], b[3]) x [b[4], b[5])
-template <int TX, int TY, int KZ>
+// MW: blocks per CU the kernel is built for (a 64 x 4 block has 4 waves: 4 blocks; a 64 x 8 block 8 waves: 2 blocks -- 128 VGPRs either way); XGV: tile rows per XCD band
+template <int TX, int TY, int KZ, int MW = 4, int XGV = 1>
 static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface, bool fold, const FusedShell *shell = nullptr)
 {
     // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
@@ -668,45 +718,45 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
         const int nblk = shell->cls == 0 ? shell->start[1] : shell->start[shell->nbox] - shell->start[1];
         if (nblk > 0) {
             if (nof == 2)
-                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true, 2>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
+                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true, true, true, 2>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
             else if (nof == 1)
-                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true, 1>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
+                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true, true, true, 1>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
             else
-                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, true>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
+                hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true, true, true>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], *shell);
         }
         if (shell->cls != 0) { h->stat_fused3d_inkernel++; if (nof == 1) h->stat_fused3d_nof1++; else if (nof == 2) h->stat_fused3d_nof2++; }
         else { JRX_LAUNCH_CHECK(h); return JRX_OK; }       // counted once per iteration, with the second class
     } else if (visc && fold && vf) {     // + the high-face node layers inside the kernel: the whole iteration in one launch
         if (nof == 2) {
-            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true, true, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
             h->stat_fused3d_nof2++;
         } else if (nof == 1) {
-            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true, true, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
             h->stat_fused3d_nof1++;
         } else
-            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     }
     else if (visc && fold)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc && !hiface && vf)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc && hiface)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 1, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 1, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (visc)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, false, 1, false, true, 3, 1, 0, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else if (h->fused_ylds && hiface) {
         if (nof == 2)
-            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1, false, false, false, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, true, XGV, false, true, 3, 1, 1, false, false, false, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
         else if (nof == 1)
-            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1, false, false, false, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, true, XGV, false, true, 3, 1, 1, false, false, false, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
         else
-            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+            hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, true, XGV, false, true, 3, 1, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
         if (nof == 1) h->stat_fused3d_nof1++; else if (nof == 2) h->stat_fused3d_nof2++;
     } else if (h->fused_ylds && nof == 2) {
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 0, false, false, false, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, true, XGV, false, true, 3, 1, 0, false, false, false, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
         h->stat_fused3d_nof2++;
     } else if (h->fused_ylds && nof == 1) {
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1, 0, false, false, false, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, true, XGV, false, true, 3, 1, 0, false, false, false, false, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
         h->stat_fused3d_nof1++;
     } else if (h->fused_ylds)
         // + non-temporal stores: the written set is not read again before the next iteration (PMC: 35.7 -> 34.2 fetched passes, -0.5 .. -1.6 % time)
@@ -714,7 +764,7 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
         //   plane carried as partial sums, the nine stress-only operands requested after the velocity phase (-1 .. -5 %)
         // + 8-plane chunks and tile rows dealt round-robin to the XCDs (XG = 1: the eight XCDs work on eight adjacent tile rows at a time;
         //   kbench 512^3, same box: 8.65 ms with 16 planes / 8-row bands -> 8.04 ms; 256^3: 1.106 -> 1.04 ms)
-        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 4, 1, true, 1, false, true, 3, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
+        hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, true, XGV, false, true, 3, 1>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     else
         hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 8, false, true>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
     JRX_LAUNCH_CHECK(h);
@@ -729,8 +779,9 @@ static bool fused_folds_hiface(const jrx_handle *h, const SweepArgs &a)
 }
 static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false, bool fold = false, const FusedShell *shell = nullptr)
 {
-    const FusedShape S = fused_shape(h, a.L);
+    const FusedShape S = fused_shape(h, a.L, a.dt);
     const int kz = S.kz;
+    if (S.tx == 64 && S.ty == 8) return launch_fused_t<64, 8, 8, 2, 4>(h, s, a, bc, b, hiface, fold, shell);
     if (S.tx == 64) {
         if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface, fold, shell);
         if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface, fold, shell);
@@ -800,7 +851,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.nbL = bc.nbR = bc.nbF = bc.nbBk = bc.nbK0 = bc.nbK1 = 0;
         // 256 threads per tile, 8 planes per chunk (128 VGPRs -> 4 blocks/CU)
         int nt[3];
-        const FusedShape S = fused_shape(h, a.L);
+        const FusedShape S = fused_shape(h, a.L, a.dt);
         fused_tiles(a.L, S, nt);
         const bool comm = jrx_comm_active(h);
         // periodic_boundary! faces (periodic.jl:56-98) are this block's own neighbour: their planes of V are filled by flow_bcs! after the fused
@@ -965,7 +1016,8 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
             if (cev) JRX_HIP(h, hipEventRecord(cev[0], bs));
             // flow_bcs! in memory before the exchange (the sent planes carry BC entries of their own rows) -- not needed when nothing reads those entries from memory: the
             // fix-up below derives them by rule, k_fused3d always did, and every path that does read them (un-fused iterations, results handed back) applies the
-            // pending flow_bcs! first (tuning switch "comm_bcs_lazy", default on)
+            // pending flow_bcs! first (tuning switch "comm_bcs_lazy", default OFF: measured 2 % slower than the two BC launches it saves, profiles/r04_comm_bcs_lazy_ab.txt; a non-default A/B path
+            // covered by the `fused_early_lazy_bcs` configurations of tests/test_gpu_two_blocks.py only)
             const bool lazy = h->comm_bcs_lazy;
             if (!lazy) JRX_TRY(fused_bcs(bs));
             if (cev) JRX_HIP(h, hipEventRecord(cev[1], bs));
@@ -1263,7 +1315,8 @@ jrx_status jrx_stokes3d_solve(jrx_handle *h, const jrx_stokes3d_fields *f, const
     }
     JRX_HIP(h, hipEventRecord(t1, s));
     JRX_TRY(iter_end(I));
-    // multi_copy! τ -> τ_o, staggered set then centre set (Stokes3D.jl:172-173)
+    // multi_copy! τ -> τ_o, staggered set then centre set (Stokes3D.jl:172-173); τ_o is an operand of the next call: a cached verdict of the operand pass goes
+    h->opv.valid = false;
     const i64 nc = (i64)n, nyz = (i64)nx * (ny + 1) * (nz + 1), nxz = (i64)(nx + 1) * ny * (nz + 1), nxy = (i64)(nx + 1) * (ny + 1) * nz;
     hipLaunchKernelGGL(k_copy6, dim3(2048), dim3(256), 0, s, f->toxx, (const double *)f->txx, nc, f->toyy, (const double *)f->tyy, nc, f->tozz,
                        (const double *)f->tzz, nc, f->toyz, (const double *)f->tyz, nyz, f->toxz, (const double *)f->txz, nxz, f->toxy,

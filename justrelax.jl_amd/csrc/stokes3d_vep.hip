@@ -1830,6 +1830,7 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
     hipLaunchKernelGGL(k_vep3_accumulate, g0, dim3(256), 0, s, a);
     JRX_LAUNCH_CHECK(h);
     const i64 nc = (i64)n;
+    h->opv.valid = false;      // τ_o is written: a cached verdict of the 3D visco-elastic operand pass (option operand_cache) may describe these arrays
     hipLaunchKernelGGL(k_copy6, dim3(1024), dim3(256), 0, s, f->toxx, (const double *)f->txx, nc, f->toyy, (const double *)f->tyy, nc, f->tozz,
                        (const double *)f->tzz, nc, f->toyz, (const double *)f->tyz, ne.yz, f->toxz, (const double *)f->txz, ne.xz, f->toxy,
                        (const double *)f->txy, ne.xy);

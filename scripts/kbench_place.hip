@@ -160,16 +160,19 @@ int main(int argc, char **argv)
     V(64, 4, 8, 4, 1)      // shipped (reference for the comparisons)
     V(64, 4, 8, 4, 2)
     V(64, 4, 8, 4, 4)
-    V(64, 4, 8, 4, 8)
-    V(64, 4, 8, 4, 16)
-    V(64, 4, 16, 4, 1)
-    V(64, 4, 16, 4, 8)
-    V(64, 4, 4, 4, 8)
-    V(64, 6, 8, 2, 1)
-    V(64, 6, 8, 2, 8)
     V(64, 8, 8, 2, 1)
+    V(64, 8, 8, 2, 2)
     V(64, 8, 8, 2, 4)
-    V(64, 8, 8, 2, 8)
+    V(64, 8, 16, 2, 1)
+    V(64, 8, 16, 2, 4)
+    V(64, 8, 4, 2, 1)
+    V(64, 8, 4, 2, 4)
+    V(64, 10, 8, 1, 1)
+    V(64, 12, 8, 1, 1)
+    V(64, 12, 8, 1, 4)
+    V(64, 16, 8, 1, 1)
+    V(64, 16, 8, 1, 4)
+    V(64, 5, 8, 3, 1)
     V(64, 4, 8, 4, 1)
     }
     printf("done\n");

@@ -263,7 +263,8 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
 
 
 @pytest.mark.parametrize("ni,bcs,tile", [((130, 20, 17), "free_slip", 0), ((97, 9, 33), "none", 0), ((130, 17, 20), "no_slip", 1), ((66, 9, 35), "slip_mix", 1),
-                                         ((130, 12, 17), "periodic", 0)])
+                                         ((130, 12, 17), "periodic", 0), ((130, 20, 17), "free_slip", 3), ((97, 23, 33), "none", 3), ((130, 17, 20), "no_slip", 3),
+                                         ((70, 30, 19), "slip_mix", 3), ((130, 12, 17), "periodic", 3), ((190, 50, 9), "slip_mix", 3)])
 def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
     """dt = Inf (SolVi3D, Burstedde, TaylorGreen: SolVi3D.jl:96 hands dt = Inf): the fused kernel's viscous-limit form does not load τ_o, P0, K, G, Q
     -- every one of them random and non-zero here -- and must equal the general fused kernel and the per-node kernels, which do."""
@@ -302,7 +303,8 @@ def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
 
 @pytest.mark.parametrize("zero,nof", [("xy", 1), ("xyz", 2), ("xy one entry -0.0", 0), ("xy one entry 1e-300", 0), ("z", 0), ("xz", 0), ("", 0)])
 @pytest.mark.parametrize("ni,bcs,tile,dt", [((130, 20, 17), "free_slip", 0, np.inf), ((66, 9, 35), "slip_mix", 1, np.inf), ((97, 9, 33), "none", 0, np.inf),
-                                            ((130, 20, 17), "free_slip", 0, 0.25), ((66, 9, 35), "slip_mix", 1, 0.25), ((130, 17, 20), "no_slip", 0, 0.25)])
+                                            ((130, 20, 17), "free_slip", 0, 0.25), ((66, 9, 35), "slip_mix", 1, 0.25), ((130, 17, 20), "no_slip", 0, 0.25),
+                                            ((130, 20, 17), "free_slip", 3, np.inf), ((97, 23, 20), "none", 3, np.inf)])
 def test_body_forces_that_are_zero_are_not_loaded_and_the_bits_stay(env, ni, bcs, tile, dt, zero, nof):
     """SolVi3D.jl:102 hands three ρg arrays of zeros, and every 3D model of the reference has ρg_x = ρg_y = 0 (gravity along z).  The one-launch viscous-limit kernel does not
     load body-force arrays in which the operand pass of the driver call has found nothing but +0.0 (all 64 bits zero): x - 0.5 (0 + 0) = x for every x, -0.0 and NaN included.
@@ -405,6 +407,63 @@ def test_viscous_limit_falls_back_when_an_unloaded_operand_is_not_harmless(env, 
     for k in ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy"):
         m = env["checks"].interior_mask3d(k, out1[k].shape)
         assert np.array_equal(out1[k][m], out0[k][m], equal_nan=True), k
+
+
+def test_operand_cache_reuses_the_verdict_until_the_fields_are_declared_dirty(env):
+    """option operand_cache = 1: the operand pass of the 3D visco-elastic drivers runs once per (operand pointers, extents, dt); the next driver call on the
+    same arrays reuses its verdict -- same bits as a call that looks again -- until jrx_fields_dirty, after which a poisoned operand is found and the general kernels report the
+    reference's NaN.  solve! itself invalidates the verdict (it writes τ_o at its end)."""
+    jr, st = env["jr"], env["st"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields3d((130, 20, 17), bcs="free_slip", dt=np.inf, iterMax=23, nout=7)
+    for c in "xyz":
+        s.arrays["f" + c][...] = 0.0
+    h = _lib.default_handle()
+    keys = ("stat_visc_checks", "stat_operand_cache_hits", "stat_fused3d_visc", "stat_fused3d_nof2", "stat_fused3d")
+    cnt = lambda: [h.get_option(k) for k in keys]
+    outs = []
+    try:
+        for cache in (0, 1):
+            h.set_option("operand_cache", cache)
+            h.set_option("kernel_variant", 3)
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            ητ = jr.fzeros(s.ni, stokes.P.device)
+            jr.compute_maxloc_(ητ, stokes.viscosity.η, handle=h)
+            c0 = cnt()
+            for _ in range(3):
+                st.iterate_timed_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, ητ, s.dt, 6, handle=h)
+            d = [b - a for a, b in zip(c0, cnt())]
+            assert d[0] == (1 if cache else 3) and d[1] == (2 if cache else 0), d
+            assert d[2] == d[4] > 0 and d[3] == d[4], d                   # every fused launch in the viscous-limit form without body-force loads, cached verdict or not
+            outs.append(env["down"](stokes))
+            if cache:
+                # a NaN written behind the library's back stays unseen (that is the contract) ...
+                K[5, 5, 5] = float("nan")
+                c0 = cnt()
+                st.iterate_timed_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, ητ, s.dt, 6, handle=h)
+                d = [b - a for a, b in zip(c0, cnt())]
+                assert d[0] == 0 and d[1] == 1 and d[2] == d[4] > 0, d
+                # ... until the caller says so: the pass runs again, fails, and the general kernels run
+                h.call("jrx_fields_dirty")
+                c0 = cnt()
+                st.iterate_timed_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, ητ, s.dt, 6, handle=h)
+                d = [b - a for a, b in zip(c0, cnt())]
+                assert d[0] == 1 and d[1] == 0 and d[2] == 0 and d[4] > 0, d
+                # solve! writes τ_o at its end: the verdict it left is not reused
+                K[5, 5, 5] = 1.0
+                h.call("jrx_fields_dirty")
+                s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+                c0 = cnt()
+                jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs, handle=h)
+                jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs, handle=h)
+                d = [b - a for a, b in zip(c0, cnt())]
+                assert d[0] == 2 and d[1] == 0, d
+    finally:
+        h.set_option("operand_cache", 0)
+        h.set_option("kernel_variant", 0)
+    for k in outs[0]:
+        m = env["checks"].interior_mask3d(k, outs[0][k].shape)
+        assert np.array_equal(outs[0][k][m], outs[1][k][m], equal_nan=True), k
 
 
 def test_iterate_timed_leaves_state_in_user_arrays(env):

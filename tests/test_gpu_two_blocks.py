@@ -28,6 +28,9 @@ STATE = ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "txy", "txz", "tyz")
 PIPELINES = {"fused": dict(kernel_variant=3, fused_overlap=0, fused_comm=1), "fused_overlap": dict(kernel_variant=3, fused_overlap=1, fused_comm=1),
              "fused_early": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=0),
              "fused_inkernel": dict(kernel_variant=3, fused_overlap=4, fused_comm=1, comm_bcs_lazy=0),      # viscous limit only (dt = Inf); the early exchange otherwise (4: x faces too)
+             "fused_inkernel_tall": dict(kernel_variant=3, fused_overlap=4, fused_comm=1, comm_bcs_lazy=0, fused_tile=3),      # ... with the 64 x 8 tile (round 5: the default shape of large blocks)
+             "fused_early_tall": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=0, fused_tile=3),
+             "fused_tall": dict(kernel_variant=3, fused_overlap=0, fused_comm=1, fused_tile=3),
              "fused_early_lazy_bcs": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=1),
              "split_sweeps": dict(kernel_variant=3, fused_overlap=0, fused_comm=0)}
 
@@ -221,6 +224,37 @@ def test_blocks_in_the_viscous_limit_finish_their_neighbour_faces_inside_the_ker
             want = B.local_block(glob[k], n, tb.ng, co)
             m = interior_mask3d(k, want.shape)
             assert np.isfinite(want[m]).all() and np.array_equal(out[k][m], want[m]), (dims, bcs, r, co, k, float(np.abs(out[k] - want)[m].max()))
+
+
+@pytest.mark.parametrize("pipeline", ["fused_inkernel_tall", "fused_early_tall", "fused_tall"])
+@pytest.mark.parametrize("dims,n,bcs", [((2, 1, 1), (130, 30, 40), "free_slip"), ((1, 2, 1), (70, 40, 12), "slip_mix"), ((1, 1, 2), (70, 23, 20), "no_slip"), ((2, 2, 2), (70, 23, 20), "slip_mix")])
+def test_blocks_with_the_tall_tile_equal_the_undecomposed_general_kernels(jr, dims, n, bcs, pipeline):
+    """the 64 x 8 tile of the viscous-limit fused kernel (tuning switch fused_tile = 3; what large blocks get by default) in the three multi-rank pipelines: every block equals the
+    undecomposed run of the per-node general kernels bit for bit"""
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    from justrelax_jl_amd.checks import interior_mask3d
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        S = _global_setup(jr, tb.ng, True, 23, 8, seed=5, bcs=bcs, dt=np.inf)
+        h0 = _lib.default_handle()
+        _set(h0, kernel_variant=1, viscous_limit=0)
+        try:
+            stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+            rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw)
+            glob = download_stokes(stokes)
+        finally:
+            _set(h0, kernel_variant=0, viscous_limit=1)
+        res, outs = _solve_blocks(jr, tb, S, pipeline, kw)
+        fused = [_get(h, "stat_fused3d_visc") for h in tb.handles]
+    assert min(fused) >= 12, fused
+    assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    for r, out in enumerate(outs):
+        co = B.coords_of(tb.carts[r])
+        for k in STATE + ("Rx", "Ry", "Rz", "RP", "exx", "exy", "eyz", "exz", "divV"):
+            want = B.local_block(glob[k], n, tb.ng, co)
+            m = interior_mask3d(k, want.shape)
+            assert np.isfinite(want[m]).all() and np.array_equal(out[k][m], want[m]), (dims, bcs, pipeline, r, co, k, float(np.abs(out[k] - want)[m].max()))
 
 
 @pytest.mark.parametrize("zero,nof", [("xy", 1), ("xyz", 2)])
