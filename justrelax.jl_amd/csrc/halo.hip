@@ -24,6 +24,8 @@
 // before it overwrites the buffer in exchange k + 1.  The host only meets the neighbour's host once per exchange (is its buffer large enough?) and never
 // waits for a device.  Norms are all-reduced through the same segment in rank order, so every rank holds the same bits.
 #include "jrx_internal.hpp"
+#include "ipc_ctl.hpp"
+#include "local_group.hpp"
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -34,44 +36,22 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <vector>
 #include <rccl/rccl.h>
 
 struct jrx_comm_state;
 static constexpr int kMaxLocalRanks = 64;
-// the ranks of an in-process group (local transport)
-struct jrx_local_group {
-    std::mutex m;
-    std::condition_variable cv;
-    int n = 0;
-    jrx_comm_state *member[kMaxLocalRanks] = {};
-    int refs = 0;
-    bool failed = false;                     // a member left or timed out: every wait returns an error instead of blocking
-    double slot[2][kMaxLocalRanks][8] = {};  // host all-reduce: the values of generation g live in slot[g & 1]
-    int arrived = 0;
-    uint64_t gen = 0;
-    double timeout_s = 120.0;
-};
+// the ranks of an in-process group (local transport): local_group.hpp (free of HIP, shared with the CPU sanitizer harness)
+typedef jrx_local::Group jrx_local_group;
+static_assert(jrx_local::kMaxRanks == kMaxLocalRanks, "one rank limit");
 
-// ---- ipc transport: the control segment (POSIX shared memory, mapped by every rank and registered with HIP so that device kernels can poll / post the flags)
-struct IpcLink {                 // state of rank r's face (dimension, side): its receive buffer there and its sends through it
-    uint64_t ready;              // host of r: exchanges r has entered through this face (its buffer then holds `cap` values)
-    uint64_t cap;                // host of r: capacity of the receive buffer (doubles)
-    uint64_t buf_gen;            // host of r: bumped whenever the buffer is re-allocated (the neighbour then re-opens `mem`)
-    hipIpcMemHandle_t mem;       // host of r: IPC handle of the receive buffer
-    uint64_t sent;               // stream of r: payloads of r through this face that have landed in the neighbour's buffer
-    uint64_t unpacked;           // stream of r: exchanges r has unpacked from its receive buffer of this face
-    uint64_t pad[2];
-};
-struct IpcCtl {
-    uint64_t magic;
-    uint32_t nranks, attached, failed, left;
-    uint64_t red_gen;
-    uint32_t red_arrived, pad_;
-    double red_slot[2][kMaxLocalRanks][8];
-    int32_t device[kMaxLocalRanks];
-    IpcLink link[kMaxLocalRanks][3][2];
-};
-static constexpr uint64_t kIpcMagic = 0x4a52584950433031ull;      // "JRXIPC01"
+// ---- ipc transport: the control segment (POSIX shared memory, mapped by every rank and registered with HIP so that device kernels can poll / post the flags).
+// Its layout and the whole host-side protocol (attach, failure flag, waits with a time-out, all-reduce) live in ipc_ctl.hpp, free of HIP, so that the CPU sanitizer
+// job (tests/host/ctl_harness.cpp) builds exactly this code with -fsanitize=thread / address,undefined.
+typedef jrx_ipc::Link IpcLink;
+typedef jrx_ipc::Ctl IpcCtl;
+static_assert(sizeof(hipIpcMemHandle_t) == sizeof(IpcLink::mem), "IpcLink::mem holds a hipIpcMemHandle_t");
+static_assert(jrx_ipc::kMaxRanks == kMaxLocalRanks, "one rank limit for the in-process and the ipc transport");
 
 struct jrx_comm_state {
     void *lib = nullptr;
@@ -107,6 +87,8 @@ struct jrx_comm_state {
     double *peer_buf[3][2] = {};       // the neighbour's receive buffer behind my face (dimension, side), mapped into this process
     uint64_t peer_gen[3][2] = {};
     uint64_t ik[3][2] = {};            // exchanges entered per face
+    struct Retired { double *p; uint64_t gen; int dim, side; };
+    std::vector<Retired> retired;      // receive buffers replaced by larger ones: freed once the neighbour has closed its mapping of that generation (IpcLink::closed_gen)
     double ipc_timeout_s = 120.0;
 };
 
@@ -215,41 +197,21 @@ bool jrx_comm_has_neighbor(const jrx_handle *h, int d, int side) { return jrx_co
 template <class Pred>
 static jrx_status local_wait(jrx_handle *h, jrx_local_group *g, std::unique_lock<std::mutex> &lk, Pred pred, const char *what)
 {
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(g->timeout_s);
-    while (!pred()) {
-        if (g->failed) return jrx_fail(h, JRX_ERR_RCCL, "local transport: a rank of the group failed or left while this one waited for %s", what);
-        if (g->cv.wait_until(lk, deadline) == std::cv_status::timeout && !pred()) {
-            g->failed = true;
-            g->cv.notify_all();
-            return jrx_fail(h, JRX_ERR_RCCL, "local transport: timed out after %.0f s waiting for %s (every rank of the group must be driven "
-                                              "by its own host thread, all in the same call sequence)", g->timeout_s, what);
-        }
-    }
+    const jrx_local::Status st = jrx_local::wait(g, lk, pred);
+    if (st == jrx_local::FAILED) return jrx_fail(h, JRX_ERR_RCCL, "local transport: a rank of the group failed or left while this one waited for %s", what);
+    if (st == jrx_local::TIMEOUT)
+        return jrx_fail(h, JRX_ERR_RCCL, "local transport: timed out after %.0f s waiting for %s (every rank of the group must be driven "
+                                          "by its own host thread, all in the same call sequence)", g->timeout_s, what);
     return JRX_OK;
 }
 
-// norm_mpi / maximum_mpi over the ranks of an in-process group: deposit, barrier, combine in rank order (every rank gets the same bits)
+// norm_mpi / maximum_mpi over the ranks of an in-process group: deposit, barrier, combine in rank order (every rank gets the same bits) -- jrx_local::allreduce
 static jrx_status local_allreduce(jrx_handle *h, jrx_comm_state *c, double *vals, int count, int op)
 {
     jrx_local_group *g = c->grp;
-    std::unique_lock<std::mutex> lk(g->m);
-    if (g->failed) return jrx_fail(h, JRX_ERR_RCCL, "local transport: the group has failed");
-    const uint64_t gen = g->gen;
-    double (*slot)[8] = g->slot[gen & 1];
-    for (int i = 0; i < count; i++) slot[c->cart.rank][i] = vals[i];
-    if (++g->arrived == g->n) {
-        g->arrived = 0;
-        g->gen++;
-        g->cv.notify_all();
-    } else {
-        JRX_TRY(local_wait(h, g, lk, [&] { return g->gen != gen; }, "the all-reduce of the other ranks"));
-    }
-    // slot[gen & 1] is overwritten at generation gen + 2 at the earliest, which every rank enters only after this read (it holds the mutex)
-    for (int i = 0; i < count; i++) {
-        double acc = slot[0][i];
-        for (int r = 1; r < g->n; r++) acc = op == 1 ? fmax(acc, slot[r][i]) : acc + slot[r][i];
-        vals[i] = acc;
-    }
+    const jrx_local::Status st = jrx_local::allreduce(g, c->cart.rank, vals, count, op);
+    if (st == jrx_local::FAILED) return jrx_fail(h, JRX_ERR_RCCL, "local transport: the group has failed, or a rank left while this one waited for the all-reduce of the other ranks");
+    if (st == jrx_local::TIMEOUT) return jrx_fail(h, JRX_ERR_RCCL, "local transport: timed out after %.0f s waiting for the all-reduce of the other ranks", g->timeout_s);
     return JRX_OK;
 }
 
@@ -336,34 +298,21 @@ static jrx_status local_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream
 
 // ------------------------------------------------------------------------------------------------ ipc transport
 namespace {
-template <class T> inline T ipc_load(const T *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-template <class T> inline void ipc_store(T *p, T v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
-inline double now_s()
+using jrx_ipc::now_s;
+template <class T> inline T ipc_load(const T *p) { return jrx_ipc::ctl_load(p); }
+template <class T> inline void ipc_store(T *p, T v) { jrx_ipc::ctl_store(p, v); }
+inline void ipc_relax(int spins) { jrx_ipc::relax(spins); }
+jrx_status ipc_status(jrx_handle *h, jrx_comm_state *c, jrx_ipc::Status st, const char *what)
 {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
-}
-inline void ipc_relax(int spins)
-{
-    if (spins < 2000) { sched_yield(); return; }
-    timespec ts = {0, 50000};       // 50 us
-    nanosleep(&ts, nullptr);
+    if (st == jrx_ipc::OK) return JRX_OK;
+    if (st == jrx_ipc::FAILED) return jrx_fail(h, JRX_ERR_RCCL, "ipc transport: a rank of the group failed or timed out while this one waited for %s", what);
+    return jrx_fail(h, JRX_ERR_RCCL, "ipc transport: timed out after %.0f s waiting for %s (every rank must make the same sequence of calls)", c->ipc_timeout_s, what);
 }
 // host wait on the control segment; an absent / failed peer is an error after the time-out, never a hang
 template <class Pred>
 jrx_status ipc_wait(jrx_handle *h, jrx_comm_state *c, Pred pred, const char *what)
 {
-    const double t0 = now_s();
-    for (int spins = 0; !pred(); spins++) {
-        if (ipc_load(&c->ctl->failed)) return jrx_fail(h, JRX_ERR_RCCL, "ipc transport: a rank of the group failed or timed out while this one waited for %s", what);
-        if (now_s() - t0 > c->ipc_timeout_s) {
-            ipc_store(&c->ctl->failed, 1u);
-            return jrx_fail(h, JRX_ERR_RCCL, "ipc transport: timed out after %.0f s waiting for %s (every rank must make the same sequence of calls)", c->ipc_timeout_s, what);
-        }
-        ipc_relax(spins);
-    }
-    return JRX_OK;
+    return ipc_status(h, c, jrx_ipc::wait(c->ctl, c->ipc_timeout_s, pred), what);
 }
 
 // one lane per flag: wait until *flag >= want.  The flags live in host memory shared by the processes of the node; a peer that never posts is a time-out
@@ -406,28 +355,11 @@ struct IpcFailGuard {
     ~IpcFailGuard() { if (!ok && c->ctl) ipc_store(&c->ctl->failed, 1u); }
 };
 
-// norm_mpi / maximum_mpi over the ranks of the node: deposit, barrier, combine in rank order (every rank gets the same bits)
+// norm_mpi / maximum_mpi over the ranks of the node: deposit, barrier, combine in rank order (every rank gets the same bits) -- jrx_ipc::allreduce
 static jrx_status ipc_allreduce(jrx_handle *h, jrx_comm_state *c, double *vals, int count, int op)
 {
-    IpcCtl *ctl = c->ctl;
     JRX_TRY(ipc_check(h, c));
-    const int n = (int)ctl->nranks, me = c->cart.rank;
-    const uint64_t gen = ipc_load(&ctl->red_gen);
-    double (*slot)[8] = ctl->red_slot[gen & 1];
-    for (int i = 0; i < count; i++) slot[me][i] = vals[i];
-    if ((int)__atomic_add_fetch(&ctl->red_arrived, 1u, __ATOMIC_ACQ_REL) == n) {
-        ipc_store(&ctl->red_arrived, 0u);
-        ipc_store(&ctl->red_gen, gen + 1);
-    } else {
-        JRX_TRY(ipc_wait(h, c, [&] { return ipc_load(&ctl->red_gen) != gen; }, "the all-reduce of the other ranks"));
-    }
-    // slot[gen & 1] is written again in generation gen + 2, which starts only after every rank has arrived in gen + 1, i.e. after this read
-    for (int i = 0; i < count; i++) {
-        double acc = slot[0][i];
-        for (int r = 1; r < n; r++) acc = op == 1 ? fmax(acc, slot[r][i]) : acc + slot[r][i];
-        vals[i] = acc;
-    }
-    return JRX_OK;
+    return ipc_status(h, c, jrx_ipc::allreduce(c->ctl, c->cart.rank, vals, count, op, c->ipc_timeout_s), "the all-reduce of the other ranks");
 }
 
 // one dimension of update_halo! between processes.  The send planes are already packed into c->sbuf[side] on `s`.
@@ -445,7 +377,9 @@ static jrx_status ipc_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream_t
         // nobody copies into the old buffer any more: every copy into it was waited for by the unpack behind it on this rank's streams
         JRX_HIP(h, hipStreamSynchronize(h->stream));
         JRX_HIP(h, hipStreamSynchronize(h->halo_stream));
-        if (c->irbuf[dim][side]) JRX_HIP(h, hipFree(c->irbuf[dim][side]));
+        // the neighbour may still have the old buffer mapped (it closes the mapping when it sees the new generation): the old one is retired and freed once the
+        // neighbour has said so (closed_gen), or with the communicator
+        if (c->irbuf[dim][side]) c->retired.push_back({c->irbuf[dim][side], ipc_load(&ctl->link[me][dim][side].buf_gen), dim, side});
         c->irbuf[dim][side] = nullptr; c->icap[dim][side] = 0;
         // uncached (fine-grained) device memory: the planes are written by another process's copy and read here behind a flag, not behind a kernel boundary the
         // runtime knows about -- the L2 of this device must not serve them from a stale line
@@ -454,20 +388,23 @@ static jrx_status ipc_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream_t
         IpcLink &L = ctl->link[me][dim][side];
         hipIpcMemHandle_t mh;
         JRX_HIP(h, hipIpcGetMemHandle(&mh, c->irbuf[dim][side]));
-        memcpy((void *)&L.mem, &mh, sizeof(mh));
-        ipc_store(&L.cap, (uint64_t)total);
-        ipc_store(&L.buf_gen, L.buf_gen + 1);
+        jrx_ipc::publish_buffer(L, &mh, (uint64_t)total);
+    }
+    for (size_t q = 0; q < c->retired.size();) {          // old receive buffers whose mapping the neighbour has closed
+        const auto r = c->retired[q];
+        if (ipc_load(&ctl->link[me][r.dim][r.side].closed_gen) >= r.gen) { JRX_HIP(h, hipFree(r.p)); c->retired.erase(c->retired.begin() + (long)q); }
+        else q++;
     }
     // 2. enter
     for (int side = 0; side < 2; side++)
-        if (nb[side] >= 0) { k[side] = ++c->ik[dim][side]; ipc_store(&ctl->link[me][dim][side].ready, k[side]); }
+        if (nb[side] >= 0) { k[side] = ++c->ik[dim][side]; jrx_ipc::enter(ctl->link[me][dim][side], k[side]); }
     // 3. push: my send plane of `side` lands in the neighbour's receive buffer of the opposite side
     uint64_t *wf[2] = {nullptr, nullptr}, wv[2] = {0, 0};
     for (int side = 0; side < 2; side++) {
         if (nb[side] < 0) continue;
         const int opp = 1 - side, peer = nb[side];
         IpcLink &P = ctl->link[peer][dim][opp];
-        JRX_TRY(ipc_wait(h, c, [&] { return ipc_load(&P.ready) >= k[side]; }, "a neighbour to enter update_halo!"));
+        JRX_TRY(ipc_status(h, c, jrx_ipc::wait_entered(ctl, P, k[side], c->ipc_timeout_s), "a neighbour to enter update_halo!"));
         if (ipc_load(&P.cap) < total)
             return jrx_fail(h, JRX_ERR_ARG, "ipc transport: the neighbour exchanges %llu values where this rank sends %zu (all ranks must call update_halo! with the same arrays)",
                             (unsigned long long)ipc_load(&P.cap), total);
@@ -478,9 +415,10 @@ static jrx_status ipc_exchange_dim(jrx_handle *h, jrx_comm_state *c, hipStream_t
                 JRX_HIP(h, hipStreamSynchronize(h->halo_stream));
                 JRX_HIP(h, hipIpcCloseMemHandle(c->peer_buf[dim][side]));
                 c->peer_buf[dim][side] = nullptr;
+                ipc_store(&P.closed_gen, c->peer_gen[dim][side]);        // the owner may free that generation's buffer now
             }
             hipIpcMemHandle_t mh;
-            memcpy(&mh, (const void *)&P.mem, sizeof(mh));
+            memcpy(&mh, (const void *)P.mem, sizeof(mh));
             void *q = nullptr;
             JRX_HIP(h, hipIpcOpenMemHandle(&q, mh, hipIpcMemLazyEnablePeerAccess));
             c->peer_buf[dim][side] = (double *)q;
@@ -526,10 +464,11 @@ static void ipc_teardown(jrx_comm_state *c)
             if (c->irbuf[d][q]) (void)hipFree(c->irbuf[d][q]);
             c->peer_buf[d][q] = nullptr; c->irbuf[d][q] = nullptr;
         }
+    for (auto &r : c->retired) (void)hipFree(r.p);
+    c->retired.clear();
     if (c->ctl) {
-        (void)__atomic_add_fetch(&c->ctl->left, 1u, __ATOMIC_ACQ_REL);
         if (c->ctl_registered) (void)hipHostUnregister(c->ctl);
-        (void)munmap(c->ctl, sizeof(IpcCtl));
+        jrx_ipc::leave(c->ctl, true);
         c->ctl = c->ctl_dev = nullptr;
     }
     (void)hipGetLastError();
@@ -768,54 +707,22 @@ jrx_status jrx_comm_init_ipc(jrx_handle *h, const uint8_t id[JRX_UNIQUE_ID_BYTES
     h->comm = c;
     if (cart->nprocs == 1) return JRX_OK;      // no other rank; a periodic dimension is copied locally, norms are local
     char name[64];
-    {
-        static const char *hx = "0123456789abcdef";
-        char *q = name;
-        q += snprintf(q, 16, "/jrx_ipc_");
-        for (int i = 0; i < 16; i++) { *q++ = hx[id[i] >> 4]; *q++ = hx[id[i] & 15]; }
-        *q = 0;
-    }
+    jrx_ipc::segment_name(id, name);
     const size_t bytes = sizeof(IpcCtl);
-    int fd = -1;
-    const double t0 = now_s();
-    auto fail = [&](const char *what) {
-        if (fd >= 0) close(fd);
-        delete c;
-        h->comm = nullptr;
-        return jrx_fail(h, JRX_ERR_RCCL, "jrx_comm_init_ipc: %s (%s): %s", what, name, strerror(errno));
-    };
-    if (cart->rank == 0) {
-        (void)shm_unlink(name);
-        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0) return fail("shm_open (create)");
-        if (ftruncate(fd, (off_t)bytes) != 0) return fail("ftruncate");
-    } else {
-        for (int spins = 0;; spins++) {
-            fd = shm_open(name, O_RDWR, 0600);
-            if (fd >= 0) {
-                struct stat sb;
-                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
-                close(fd); fd = -1;
-            }
-            if (now_s() - t0 > c->ipc_timeout_s) { errno = ETIMEDOUT; return fail("shm_open (rank 0 never created the segment)"); }
-            ipc_relax(spins + 2000);
+    {
+        const char *what = "";
+        if (jrx_ipc::map_segment(name, cart->rank, c->ipc_timeout_s, &c->ctl, &what) != jrx_ipc::OK) {
+            const int e = errno;
+            delete c;
+            h->comm = nullptr;
+            return jrx_fail(h, JRX_ERR_RCCL, "jrx_comm_init_ipc: %s (%s): %s", what, name, strerror(e));
         }
     }
-    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    if (m == MAP_FAILED) return fail("mmap");
-    close(fd); fd = -1;
-    c->ctl = (IpcCtl *)m;
-    if (cart->rank == 0) {
-        memset(m, 0, bytes);
-        c->ctl->nranks = (uint32_t)cart->nprocs;
-        ipc_store(&c->ctl->magic, kIpcMagic);
-    }
-    jrx_status st = ipc_wait(h, c, [&] { return ipc_load(&c->ctl->magic) == kIpcMagic; }, "rank 0 to initialise the control segment");
-    if (st == JRX_OK && (int)c->ctl->nranks != cart->nprocs) st = jrx_fail(h, JRX_ERR_ARG, "jrx_comm_init_ipc: the segment was made for %u ranks, this cart has %d", c->ctl->nranks, cart->nprocs);
-    if (st == JRX_OK) {
-        c->ctl->device[cart->rank] = h->device;
-        (void)__atomic_add_fetch(&c->ctl->attached, 1u, __ATOMIC_ACQ_REL);
-        st = ipc_wait(h, c, [&] { return (int)ipc_load(&c->ctl->attached) >= cart->nprocs; }, "every rank to attach");
+    jrx_status st = JRX_OK;
+    {
+        const jrx_ipc::Status js = jrx_ipc::join(c->ctl, cart->rank, cart->nprocs, h->device, c->ipc_timeout_s);
+        if (js == jrx_ipc::MISMATCH) st = jrx_fail(h, JRX_ERR_ARG, "jrx_comm_init_ipc: the segment was made for %u ranks, this cart has %d", c->ctl->nranks, cart->nprocs);
+        else st = ipc_status(h, c, js, "every rank to attach to the control segment");
     }
     if (cart->rank == 0) (void)shm_unlink(name);     // every rank has it mapped (or the group failed): the name can go
     if (st == JRX_OK) {

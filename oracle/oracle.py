@@ -15,13 +15,16 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-_LIB_PATH = _HERE / "libjrx_oracle.so"
+# JRX_ORACLE_LIB: another build of the same sources (the sanitizer build of oracle/Makefile, tests/test_host_sanitizers.py); it is loaded as it is, never rebuilt here
+_LIB_PATH = Path(os.environ["JRX_ORACLE_LIB"]) if os.environ.get("JRX_ORACLE_LIB") else _HERE / "libjrx_oracle.so"
 
 FACE = dict(left=1, right=2, front=4, back=8, top=16, bot=32)
 
 
 def build(force: bool = False) -> Path:
     """Compile the C restatement with gcc (see oracle/Makefile)."""
+    if os.environ.get("JRX_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not _LIB_PATH.exists():
         subprocess.check_call(["make", "-C", str(_HERE)] + (["-B"] if force else []))
     return _LIB_PATH
