@@ -75,6 +75,12 @@ const char *jrx_build_id(void);
 jrx_status jrx_field_alloc(jrx_handle *h, int64_t count, double **out);     /* count doubles */
 jrx_status jrx_field_free(jrx_handle *h, double *p);
 jrx_status jrx_field_trim(jrx_handle *h);
+/* jrx_field_reroll: new physical backing for one chunk-backed array ("field_placement" = 1), or for all of them (p = NULL), IN PLACE -- the pointer, the contents and every
+ * other pointer into the array stay valid; the device must not be using the array meanwhile (the call synchronises the device).  Why: the rate of the large 3D kernels
+ * depends on where the arrays happen to lie physically, per set of allocations ("placement"); together with jrx_stokes3d_probe a binding can look for a good
+ * placement once, before a long run.  jrx_field_list: the live arrays of the handle (bytes[i] < 0: not chunk-backed), count = how many there are (may exceed cap). */
+jrx_status jrx_field_reroll(jrx_handle *h, double *p);
+jrx_status jrx_field_list(jrx_handle *h, int64_t cap, double **ptrs, int64_t *bytes, int64_t *count);
 jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
 
 /* Options of the handle: what a caller of solve! may want to choose.  (The A/B switches of the measurements in profiles/ and the test

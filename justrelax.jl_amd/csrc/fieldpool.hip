@@ -19,13 +19,19 @@
 #include <vector>
 
 struct jrx_field_pool {
-    struct Alloc { size_t bytes = 0, mapped = 0; int kind = 0; std::vector<hipMemGenericAllocationHandle_t> chunks; size_t chunk = 0; };
+    struct Alloc { size_t bytes = 0, mapped = 0; int kind = 0; bool in_arena = false; std::vector<hipMemGenericAllocationHandle_t> chunks; size_t chunk = 0; };
     std::map<void *, Alloc> live;
     std::vector<hipMemGenericAllocationHandle_t> spare;      // created, unmapped chunks (all of `spare_chunk` bytes)
     size_t spare_chunk = 0;
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     double create_ms = 0, map_ms = 0;
-    int64_t chunks_created = 0, bytes_live = 0;
+    int64_t chunks_created = 0, bytes_live = 0, rerolls = 0;
+    // the arena: ONE reserved virtual range in which the chunk-backed arrays are placed one behind the other, `gap` bytes apart -- the rate of the large kernels turned out to
+    // depend on the arrays' VIRTUAL addresses (re-rolling the physical chunks under fixed addresses changes nothing, new addresses do: profiles/r05_placement.txt), and this is
+    // what makes them a choice instead of a draw
+    char *arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    std::multimap<size_t, void *> arena_free;     // released sub-ranges by size, reused for arrays of exactly that size
 };
 
 namespace {
@@ -85,9 +91,27 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, void **o
     void *va = nullptr;
     size_t align = (size_t)(h->field_va_align_mib > 0 ? h->field_va_align_mib : 0) << 20;
     if (align < gran) align = gran;
-    JRX_HIP(h, hipMemAddressReserve(&va, nch * chunk, align, nullptr, 0));
+    bool in_arena = false;
+    if (h->field_arena_gib > 0) {
+        if (!P->arena) {
+            void *a = nullptr;
+            const size_t want = (size_t)h->field_arena_gib << 30;
+            if (hipMemAddressReserve(&a, want, (size_t)1 << 30, nullptr, 0) == hipSuccess) { P->arena = (char *)a; P->arena_bytes = want; P->arena_used = 0; }
+            else (void)hipGetLastError();
+        }
+        if (P->arena) {
+            auto it = P->arena_free.find(nch * chunk);
+            if (it != P->arena_free.end()) { va = it->second; P->arena_free.erase(it); in_arena = true; }
+            else {
+                const size_t gap = ((size_t)(h->field_va_gap_mib > 0 ? h->field_va_gap_mib : 0) << 20) / gran * gran;
+                size_t at = (P->arena_used + align - 1) / align * align;
+                if (at + nch * chunk <= P->arena_bytes) { va = P->arena + at; P->arena_used = at + nch * chunk + gap; in_arena = true; }
+            }
+        }
+    }
+    if (!in_arena) JRX_HIP(h, hipMemAddressReserve(&va, nch * chunk, align, nullptr, 0));
     jrx_field_pool::Alloc A;
-    A.bytes = bytes; A.kind = 1; A.chunk = chunk;
+    A.bytes = bytes; A.kind = 1; A.chunk = chunk; A.in_arena = in_arena;
     for (size_t c = 0; c < nch; c++) {
         hipMemGenericAllocationHandle_t hd = P->spare.back();
         const hipError_t e = hipMemMap((char *)va + c * chunk, chunk, 0, hd, 0);
@@ -95,7 +119,7 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, void **o
             (void)hipGetLastError();
             if (A.mapped) (void)hipMemUnmap(va, A.mapped);
             for (auto x : A.chunks) P->spare.push_back(x);
-            (void)hipMemAddressFree(va, nch * chunk);
+            if (in_arena) P->arena_free.insert({nch * chunk, va}); else (void)hipMemAddressFree(va, nch * chunk);
             return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemMap -> %s", hipGetErrorString(e));
         }
         P->spare.pop_back();
@@ -110,12 +134,65 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, void **o
         (void)hipGetLastError();
         (void)hipMemUnmap(va, A.mapped);
         for (auto x : A.chunks) P->spare.push_back(x);
-        (void)hipMemAddressFree(va, nch * chunk);
+        if (in_arena) P->arena_free.insert({nch * chunk, va}); else (void)hipMemAddressFree(va, nch * chunk);
         return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemSetAccess -> %s", hipGetErrorString(e));
     }
     P->map_ms += ms_since(t1);
     P->live[va] = std::move(A);
     *out = va;
+    return JRX_OK;
+}
+// Give one chunk-backed array new physical backing IN PLACE: its virtual range, and therefore every pointer the caller and the library hold, stays as it is.  New chunks (spare ones
+// first, in shuffled order; freshly created ones if the spare list is short) are mapped at a temporary range, the contents are copied, then the array's range is re-mapped onto them
+// and the old chunks join the spare list.  The device must be idle as far as this array is concerned (the caller's contract; the function synchronises the device itself).
+jrx_status reroll_one(jrx_handle *h, jrx_field_pool *P, void *va, jrx_field_pool::Alloc &A)
+{
+    if (A.kind != 1) return JRX_OK;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = h->device;
+    const size_t chunk = A.chunk, nch = A.chunks.size();
+    if (P->spare_chunk != chunk) { release_spare(P); P->spare_chunk = chunk; }
+    const auto t0 = Clock::now();
+    while (P->spare.size() < nch) {
+        hipMemGenericAllocationHandle_t hd;
+        const hipError_t e = hipMemCreate(&hd, chunk, &prop, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_field_reroll: hipMemCreate(%zu MiB) -> %s", chunk >> 20, hipGetErrorString(e)); }
+        P->spare.push_back(hd);
+        P->chunks_created++;
+    }
+    P->create_ms += ms_since(t0);
+    if (h->field_shuffle)
+        for (size_t i = P->spare.size(); i > 1; i--) std::swap(P->spare[i - 1], P->spare[next_rng(P->rng) % i]);
+    const auto t1 = Clock::now();
+    std::vector<hipMemGenericAllocationHandle_t> fresh(P->spare.end() - (long)nch, P->spare.end());
+    P->spare.resize(P->spare.size() - nch);
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    void *tmp = nullptr;
+    auto give_back = [&] { for (auto hd : fresh) P->spare.push_back(hd); };
+    hipError_t e = hipMemAddressReserve(&tmp, A.mapped, chunk < ((size_t)2 << 20) ? ((size_t)2 << 20) : 0, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); give_back(); return jrx_fail(h, JRX_ERR_HIP, "jrx_field_reroll: hipMemAddressReserve -> %s", hipGetErrorString(e)); }
+    size_t mapped = 0;
+    for (size_t c = 0; c < nch && e == hipSuccess; c++) { e = hipMemMap((char *)tmp + c * chunk, chunk, 0, fresh[c], 0); if (e == hipSuccess) mapped += chunk; }
+    if (e == hipSuccess) e = hipMemSetAccess(tmp, A.mapped, &acc, 1);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(tmp, va, A.bytes, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (mapped) (void)hipMemUnmap(tmp, mapped);
+    (void)hipMemAddressFree(tmp, A.mapped);
+    if (e != hipSuccess) { (void)hipGetLastError(); give_back(); return jrx_fail(h, JRX_ERR_HIP, "jrx_field_reroll: staging the new chunks -> %s", hipGetErrorString(e)); }
+    // the switch: from here on a failure leaves the array without backing, which is reported as such
+    e = hipMemUnmap(va, A.mapped);
+    for (size_t c = 0; c < nch && e == hipSuccess; c++) e = hipMemMap((char *)va + c * chunk, chunk, 0, fresh[c], 0);
+    if (e == hipSuccess) e = hipMemSetAccess(va, A.mapped, &acc, 1);
+    if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_field_reroll: re-mapping the array at %p -> %s (the array has lost its backing)", va, hipGetErrorString(e)); }
+    for (auto hd : A.chunks) P->spare.push_back(hd);
+    A.chunks = fresh;
+    P->map_ms += ms_since(t1);
+    P->rerolls++;
     return JRX_OK;
 }
 }   // namespace
@@ -157,7 +234,8 @@ jrx_status jrx_dev_free(jrx_handle *h, void *p)
         // nothing of this handle may still be using the range
         JRX_HIP(h, hipDeviceSynchronize());
         JRX_HIP(h, hipMemUnmap(p, A.mapped));
-        JRX_HIP(h, hipMemAddressFree(p, A.mapped));
+        if (A.in_arena) P->arena_free.insert({A.mapped, p});
+        else JRX_HIP(h, hipMemAddressFree(p, A.mapped));
         if (A.chunk == P->spare_chunk) for (auto hd : A.chunks) P->spare.push_back(hd);
         else for (auto hd : A.chunks) (void)hipMemRelease(hd);
     } else {
@@ -175,13 +253,14 @@ void jrx_pool_destroy(jrx_handle *h)
     for (auto &kv : P->live) {
         if (kv.second.kind == 1) {
             (void)hipMemUnmap(kv.first, kv.second.mapped);
-            (void)hipMemAddressFree(kv.first, kv.second.mapped);
+            if (!kv.second.in_arena) (void)hipMemAddressFree(kv.first, kv.second.mapped);
             for (auto hd : kv.second.chunks) (void)hipMemRelease(hd);
         } else {
             (void)hipFree(kv.first);
         }
     }
     release_spare(P);
+    if (P->arena) (void)hipMemAddressFree(P->arena, P->arena_bytes);
     delete P;
     h->pool = nullptr;
 }
@@ -202,6 +281,35 @@ jrx_status jrx_field_free(jrx_handle *h, double *p)
     if (!h) return JRX_ERR_ARG;
     JRX_TRY(jrx_check_device(h));
     return jrx_dev_free(h, p);
+}
+
+jrx_status jrx_field_reroll(jrx_handle *h, double *p)
+{
+    if (!h) return JRX_ERR_ARG;
+    JRX_TRY(jrx_check_device(h));
+    jrx_field_pool *P = pool_of(h);
+    if (p) {
+        auto it = P->live.find(p);
+        if (it == P->live.end()) return jrx_fail(h, JRX_ERR_ARG, "jrx_field_reroll: %p was not allocated by jrx_field_alloc on this handle", (void *)p);
+        return reroll_one(h, P, it->first, it->second);
+    }
+    for (auto &kv : P->live) JRX_TRY(reroll_one(h, P, kv.first, kv.second));
+    return JRX_OK;
+}
+
+jrx_status jrx_field_list(jrx_handle *h, int64_t cap, double **ptrs, int64_t *bytes, int64_t *count)
+{
+    if (!h) return JRX_ERR_ARG;
+    if (!count) return jrx_fail(h, JRX_ERR_ARG, "jrx_field_list: count is NULL");
+    jrx_field_pool *P = pool_of(h);
+    int64_t n = 0;
+    for (auto &kv : P->live) {
+        if (n < cap && ptrs) ptrs[n] = (double *)kv.first;
+        if (n < cap && bytes) bytes[n] = kv.second.kind == 1 ? (int64_t)kv.second.bytes : -(int64_t)kv.second.bytes;       // negative: not chunk-backed (cannot be re-rolled)
+        n++;
+    }
+    *count = n;
+    return JRX_OK;
 }
 
 jrx_status jrx_field_trim(jrx_handle *h)

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Placement experiments IN ONE PROCESS with jrx_field_reroll (new physical chunks under an array, same pointer): which arrays does the rate of the 512^3 kernel depend on?
+   probe_reroll2.py [n=512] [chunk_mib=64] [full_rolls=6] [greedy=1]"""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from __graft_entry__ import load_package  # noqa: E402
+jr = load_package()
+import torch  # noqa: E402
+from justrelax_jl_amd import _lib, stokes, arrays  # noqa: E402
+import justrelax_jl_amd.grid as grid  # noqa: E402
+from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+full_rolls = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+greedy = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+torch.zeros(1, device="cuda")
+h = _lib.default_handle(0)
+h.set_option("operand_cache", 1)
+h.set_option("field_placement", 1)
+h.set_option("field_chunk_mib", chunk)
+arrays.use_library_arrays(h)
+grid.init_global_grid(n, n, n, rank=0, nprocs=1)
+st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
+jr.flow_bcs_(st, bcs, handle=h)
+ητ = jr.fzeros((n, n, n), st.P.device)
+jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
+run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
+
+
+def probe():
+    run(3)
+    return run(16)[4]
+
+
+def reroll(p=None):
+    torch.cuda.synchronize()
+    h.call("jrx_field_reroll", C.c_void_p(p or 0))
+
+
+names = {}
+for nm, t in (("P", st.P), ("Vx", st.V.Vx), ("Vy", st.V.Vy), ("Vz", st.V.Vz), ("txx", st.τ.xx), ("tyy", st.τ.yy), ("tzz", st.τ.zz), ("tyz", st.τ.yz), ("txz", st.τ.xz), ("txy", st.τ.xy),
+               ("eta", st.viscosity.η), ("etatau", ητ), ("K", K), ("G", G), ("fx", ρg[0]), ("fy", ρg[1]), ("fz", ρg[2]), ("P0", st.P0), ("toxx", st.τ_o.xx), ("toxy", st.τ_o.xy)):
+    names[t.data_ptr()] = nm
+ms0 = probe()
+cnt = C.c_int64()
+ptrs, nbytes = (C.c_void_p * 256)(), (C.c_int64 * 256)()
+h.call("jrx_field_list", C.c_int64(256), ptrs, nbytes, C.byref(cnt))
+live = [(ptrs[i], nbytes[i]) for i in range(cnt.value)]
+k = 0
+for p, b in live:
+    if p not in names and b >= n ** 3 * 8:
+        names[p] = f"scratch{k}"
+        k += 1
+print(f"n {n} chunk {chunk} MiB: {cnt.value} live arrays, {sum(1 for _, b in live if b > 0)} chunk-backed; first probe {ms0:.3f} ms", flush=True)
+t0 = time.time()
+out = []
+for r in range(full_rolls):
+    reroll()
+    out.append(probe())
+print(f"full re-rolls ({(time.time() - t0) / max(1, full_rolls):.2f} s each incl. the probe): " + " ".join(f"{x:.3f}" for x in out), flush=True)
+if greedy:
+    cur = out[-1] if out else ms0
+    used = ["P", "txx", "tyy", "tzz", "tyz", "txz", "txy", "Vx", "Vy", "Vz", "eta", "etatau"] + [f"scratch{i}" for i in range(10)]
+    control = ["K", "G", "fx", "fy", "fz", "P0", "toxx", "toxy"]
+    byname = {v: k for k, v in names.items()}
+    for group, label in ((control, "arrays the kernel does not touch (control)"), (used, "arrays the kernel reads or writes"), (used, "second pass")):
+        line = []
+        for nm in group:
+            if nm not in byname:
+                continue
+            reroll(byname[nm])
+            m = probe()
+            line.append(f"{nm} {cur:.3f}->{m:.3f}")
+            cur = m
+        print(f"one array at a time, {label}: " + "  ".join(line), flush=True)
+    # greedy: keep rolling the arrays in use, one at a time, accepting what is not worse; how far down does it go?
+    best = cur
+    trace = []
+    for sweep in range(2):
+        for nm in used:
+            if nm not in byname:
+                continue
+            for attempt in range(3):
+                reroll(byname[nm])
+                m = probe()
+                if m <= best * 1.002:
+                    best = min(best, m)
+                    break
+            trace.append(f"{nm} {m:.3f}")
+    print("greedy (up to 3 rolls per array until not worse than the best so far), two sweeps: " + "  ".join(trace), flush=True)
+    print(f"final {probe():.3f} ms", flush=True)
