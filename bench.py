@@ -59,6 +59,65 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measure
 A_STRESS_VISC = 18 * 8.0  # ... in the viscous limit: 11 reads + 7 writes (no tau_o, P0, K, G, Q)
 
 
+class DeviceState:
+    """sclk / power / temperatures of this rank's device (hwmon files under /sys/class/drm/card*/device/hwmon), sampled by a thread while a batch runs.  Why it is in the line: the fused kernel
+    draws ~1.36 kW of the 1.4 kW cap, so its rate follows the clock the power management sustains (2.30 - 2.40 GHz on the boxes seen) -- the spread between boxes, processes and ranks that
+    rounds 3-4 took for a memory-placement lottery (profiles/r05_placement.txt: new physical chunks under fixed addresses, new virtual layouts, other streams, other code copies change nothing)."""
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.paths = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            hw = sorted(glob.glob(d + "/hwmon/hwmon*"))
+            if hw and os.path.exists(hw[0] + "/freq1_input"):
+                try:
+                    bus = os.path.basename(os.path.realpath(d))
+                except OSError:
+                    bus = ""
+                self.paths.append((bus, hw[0]))
+        self.want = (pci_bus_id or "").lower()
+        self.samples, self._stop, self._th = [], None, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return float("nan")
+
+    def _loop(self):
+        while not self._stop.is_set():
+            self.samples.append([(self._read(h + "/freq1_input"), self._read(h + "/power1_input"), self._read(h + "/temp2_input"), self._read(h + "/temp3_input")) for _, h in self.paths])
+            self._stop.wait(0.02)
+
+    def start(self):
+        import threading
+        self.samples, self._stop = [], threading.Event()
+        if self.paths:
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+        return self
+
+    def stop(self):
+        if self._th:
+            self._stop.set()
+            self._th.join()
+            self._th = None
+        if not self.samples:
+            return None
+        nd = len(self.paths)
+        idx = [i for i, (bus, _) in enumerate(self.paths) if self.want and bus.lower().endswith(self.want[-7:])]
+        peak = [max(smp[i][1] for smp in self.samples) for i in range(nd)]
+        me = idx[0] if idx else max(range(nd), key=lambda i: peak[i])         # by PCI address when it can be matched, else the device that drew the most
+        busy = [smp[me] for smp in self.samples if smp[me][1] >= 0.6 * peak[me]] or [smp[me] for smp in self.samples]
+        med = lambda v: sorted(v)[len(v) // 2]
+        cap = self._read(self.paths[me][1] + "/power1_cap")
+        return {"sclk_mhz": med([b[0] for b in busy]) / 1e6, "power_w": med([b[1] for b in busy]) / 1e6, "power_cap_w": cap / 1e6 if cap == cap else None,
+                "junction_c": med([b[2] for b in busy]) / 1e3, "hbm_c": med([b[3] for b in busy]) / 1e3, "samples": len(busy), "matched_by": "pci" if idx else "highest power",
+                "devices_visible": nd, "other_devices_above_600w": sum(1 for i in range(nd) if i != me and peak[i] > 600e6)}
+
+
 def load_pmc():
     """L2<->fabric bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE;
     separate passes), collected offline at n = 512 and kept in profiles/pmc_traffic.json together with the sha256 of csrc/stokes3d_kernels.hpp and the git commit they
@@ -1264,13 +1323,24 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
     R.sync(); ctl.barrier()
     if not args.dry_transports:
         f0 = counters(R.h)
+    dstate = None
+    if not args.dry_transports:
+        try:
+            import torch
+            pp = torch.cuda.get_device_properties(0 if args.same_device else local_rank)
+            dstate = DeviceState(f"{pp.pci_bus_id:02x}:{pp.pci_device_id:02x}.0").start()
+        except Exception:       # noqa: BLE001
+            dstate = DeviceState(None).start()
     t0 = time.perf_counter()
     tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = R.run(args.steps)
     R.sync()
     el = time.perf_counter() - t0
+    my_state = dstate.stop() if dstate else None
     if not args.dry_transports:
         pr = pricing(R.h, R.blk[8], nof_ran(R.h, f0))
     ctl.barrier()
+    # per rank: the launch time of the dominant kernel and the device's clock / power during the timed batch -- the slowest rank paces a weak-scaling run, and its reason should be readable
+    per_rank = ctl.gather({"rank": rank, "k_fused3d_ms": sk_ms, "device_state": my_state})
     el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = ctl.max([el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells])
     steady = None
     if args.steps < 50 and not args.no_steady_state:
@@ -1314,6 +1384,9 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
                            "bytes_per_cell": pr["alg"], "achieved": it_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_gbs / HBM_PEAK_GBS, "traffic": None}
     if not args.dry_transports:
         check_priced_kernel(R.h, pr, f0, out)
+    if isinstance(out.get("roofline"), dict) and per_rank:
+        out["roofline"]["launch_ms_per_rank"] = [p.get("k_fused3d_ms") for p in per_rank]
+        out["roofline"]["device_state_per_rank"] = [p.get("device_state") for p in per_rank]
 
     def emit(note=None):
         if note:
@@ -1439,11 +1512,18 @@ def run_rank(args) -> int:
     if args.warmup > 0:
         run(args.warmup)
     barrier()
+    try:
+        pci = torch.cuda.get_device_properties(local_rank)
+        pci = f"{pci.pci_bus_id:02x}:{pci.pci_device_id:02x}.0"
+    except Exception:       # noqa: BLE001 -- older torch: the device that draws the most is taken
+        pci = None
+    dstate = DeviceState(pci).start()
     f0 = counters(h)
     t0 = time.perf_counter()
     tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = run(args.steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    dev_state = dstate.stop()
     barrier()
     pr = pricing(h, dt, nof_ran(h, f0))
     # A short requested batch (the driver times 20 steps = 0.16 s) samples the box's clocks and allocation luck more than the code: a 100-step batch
@@ -1451,12 +1531,14 @@ def run_rank(args) -> int:
     steady = None
     if args.steps < 50 and not args.no_steady_state:
         barrier()
+        dstate.start()
         t1 = time.perf_counter()
         sres = run(100)
         torch.cuda.synchronize()
         sel = time.perf_counter() - t1
+        dev_state_steady = dstate.stop()
         barrier()
-        steady = {"steps": 100, "value": world * 100 / sel, "ms_per_step": sel / 100 * 1e3,
+        steady = {"steps": 100, "device_state": dev_state_steady, "value": world * 100 / sel, "ms_per_step": sel / 100 * 1e3,
                   "kernel_avg_launch_ms": sres[4] if sres[4] > 0 else None,
                   "kernel_frac": (pr["alg"] * (sres[5] or float(n) ** 3) / (sres[4] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sres[4] > 0 else None}
 
@@ -1561,6 +1643,7 @@ def run_rank(args) -> int:
                 out["roofline"]["general_form"] = {"what": "the kernel that does all of SURVEY 8d's work (any dt, every operand and body-force array loaded), same process, same allocations, same batch length",
                                                    "bytes_per_cell": gr["bytes_per_cell"], "avg_launch_ms": gr["avg_launch_ms"], "achieved": gr["achieved"], "frac": gr["frac"],
                                                    "frac_at_needed_bytes": gr.get("frac_at_needed_bytes"), "it_per_s": g["it_per_s"], "traffic": gr.get("traffic")}
+            out["roofline"]["device_state"] = dev_state          # sclk / power / temperatures of the device during the timed batch (see DeviceState)
             out["roofline"]["launch_ms_per_rank"] = [sk_ms if fused else None]      # placement probe: a process runs this kernel at one of two rates for its lifetime (DESIGN, placement)
             out["roofline"]["field_placement"] = h.get_option("field_placement")
         if world == 1 and not self_halo and not args.no_extras:
