@@ -1685,9 +1685,12 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             if (fuse_c) {
                 for (int c_ = 0; c_ < 3; c_++) a.cnew[c_] = (c_ == 0 ? a.f.txx : (c_ == 1 ? a.f.tyy : a.f.tzz)) == cset[c_] ? user_c[c_] : cset[c_];
                 double *const eta_out = a.f.eta == f->eta ? eta2 : f->eta;
-                const dim3 gpc(gpre.x, (unsigned)((nz + 1 + PRE_KZ - 1) / PRE_KZ));
+                // the same thread map as without neighbours: 64 x 4 tiles of node columns where a plane has enough of them ("vep3_prec_tile")
+                const bool tiled_c = h->vep3_prec_tile == 1 || (h->vep3_prec_tile == 2 && (i64)(nx + 1) * (ny + 1) >= 16384);
+                const int tntx_c = tiled_c ? (nx + 1 + 63) / 64 : 0;
+                const dim3 gpc(tntx_c ? (unsigned)(tntx_c * ((ny + 1 + 3) / 4)) : gpre.x, (unsigned)((nz + 1 + PRE_KZ - 1) / PRE_KZ));
                 switch (a.rh.nphase * 2 + (a.obs ? 1 : 0)) {
-#define PRECC(NP_, OBS_) case NP_ * 2 + OBS_: hipLaunchKernelGGL((k_vep3_prec<false, false, NP_, OBS_ != 0, false>), gpc, dim3(256), 0, s, a, eta_out, PRE_KZ); break;
+#define PRECC(NP_, OBS_) case NP_ * 2 + OBS_: hipLaunchKernelGGL((k_vep3_prec<false, false, NP_, OBS_ != 0, false>), gpc, dim3(256), 0, s, a, eta_out, PRE_KZ, tntx_c); break;
                 PRECC(1, 0) PRECC(1, 1) PRECC(2, 0) PRECC(2, 1) PRECC(3, 0) PRECC(3, 1) PRECC(4, 0) PRECC(4, 1)
 #undef PRECC
                 }
@@ -1702,13 +1705,18 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             JRX_LAUNCH_CHECK(h);
             JRX_HIP(h, hipEventRecord(h->ev[3], s));
             JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[3], 0));
+            // in-order pipeline ("vep3_hide_comm" = 0, the default): ητ of the next iteration is first read by that iteration's velocity sweep, so its planes travel with the
+            // edge stresses below -- two exchanges (pack, copies, flags, unpack each) per iteration instead of three; same values in the same places
+            const bool merged = h->vep3_hide_comm == 0;
+            double *const nxt = a.etatau == etatau ? etatau_next : etatau;
             {
-                double *nxt = a.etatau == etatau ? etatau_next : etatau;
                 hipLaunchKernelGGL(k_maxloc, dim3((unsigned)(((i64)nx * ny + 255) / 256), (unsigned)nz), dim3(256), 0, hs, nxt, (const double *)a.f.eta, nx, ny, nz);
                 JRX_LAUNCH_CHECK(h);
-                double *arrs[1] = {nxt};
-                const int64_t ext[1][3] = {{nx, ny, nz}};
-                JRX_TRY(jrx_halo_exchange(h, hs, 1, arrs, ext, nn));     // update_halo!(ητ) of iteration it1 + 1
+                if (!merged) {
+                    double *arrs[1] = {nxt};
+                    const int64_t ext[1][3] = {{nx, ny, nz}};
+                    JRX_TRY(jrx_halo_exchange(h, hs, 1, arrs, ext, nn));     // update_halo!(ητ) of iteration it1 + 1
+                }
             }
             JRX_TRY(launch_vep3_stress(h, s, a, p, false, 1, true));     // edge pass
             { double *t0_ = a.f.tyz; a.f.tyz = a.tnew[0]; a.tnew[0] = t0_; }
@@ -1717,10 +1725,10 @@ jrx_status jrx_stokes3d_vep_solve(jrx_handle *h, const jrx_vep3d_fields *f, cons
             g.tyz = a.f.tyz; g.txz = a.f.txz; g.txy = a.f.txy;
             JRX_HIP(h, hipEventRecord(h->ev[3], s));
             JRX_HIP(h, hipStreamWaitEvent(hs, h->ev[3], 0));
-            {   // update_halo!(τ.yz), (τ.xz), (τ.xy) (Stokes3D.jl:578-580)
-                double *arrs[3] = {a.f.tyz, a.f.txz, a.f.txy};
-                const int64_t ext[3][3] = {{nx, ny + 1, nz + 1}, {nx + 1, ny, nz + 1}, {nx + 1, ny + 1, nz}};
-                JRX_TRY(jrx_halo_exchange(h, hs, 3, arrs, ext, nn));
+            {   // update_halo!(τ.yz), (τ.xz), (τ.xy) (Stokes3D.jl:578-580) [+ ητ of the next iteration, see above]
+                double *arrs[4] = {a.f.tyz, a.f.txz, a.f.txy, nxt};
+                const int64_t ext[4][3] = {{nx, ny + 1, nz + 1}, {nx + 1, ny, nz + 1}, {nx + 1, ny + 1, nz}, {nx, ny, nz}};
+                JRX_TRY(jrx_halo_exchange(h, hs, merged ? 4 : 3, arrs, ext, nn));
             }
             JRX_HIP(h, hipEventRecord(h->ev[4], hs));
             if (fuse_c) {       // the centre pass ran inside k_vep3_prec: adopt its normal stresses
