@@ -578,9 +578,10 @@ static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L, double dt)
     {
         const FusedShape T{64, 8, 8};
         fused_tiles(L, T, nt);
-        // viscous-limit forms only: the general form needs 132 VGPRs at this shape (one 8-wave block per CU instead of two)
-        const bool visc = h->viscous_limit && h->visc_ok && dt == INFINITY && h->fused_ylds;
-        if (visc && (h->fused_tile == 3 || (h->fused_tile == 2 && !narrow && (long long)nt[0] * nt[1] * nt[2] >= 4096))) return T;
+        // By default for the viscous-limit forms only: the general form fits the shape as well (128 VGPRs, no spills, 70 KB of LDS per block) but gains nothing from it
+        // (512^3: 7.63 -> 7.76 ms in one process, 7.65 -> 7.65 in another; 256^3 1.064 -> 1.066; gpurun_out/r05s) -- it runs this shape only when "fused_tile" = 3 asks for it
+        const bool visc = h->viscous_limit && h->visc_ok && dt == INFINITY;
+        if (h->fused_ylds && (h->fused_tile == 3 || (visc && h->fused_tile == 2 && !narrow && (long long)nt[0] * nt[1] * nt[2] >= 4096))) return T;
     }
     for (int kz = 8; kz >= 2; kz /= 2) {
         S.kz = kz;
@@ -696,7 +697,8 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
 }
 
 // launch the fused kernel over the box of tiles [b[0], b[1]) x [b[2], b[3]) x [b[4], b[5])
-// MW: blocks per CU the kernel is built for (a 64 x 4 block has 4 waves: 4 blocks; a 64 x 8 block 8 waves: 2 blocks -- 128 VGPRs either way); XGV: tile rows per XCD band
+// MW: the second argument of __launch_bounds__, which in HIP is the least number of WAVES PER SIMD the kernel must be able to run with (not CUDA's blocks per multiprocessor): 4, i.e. at most
+// 128 VGPRs, for both tile shapes (four 4-wave blocks or two 8-wave blocks per CU); XGV: tile rows per XCD band
 template <int TX, int TY, int KZ, int MW = 4, int XGV = 1>
 static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface, bool fold, const FusedShell *shell = nullptr)
 {
@@ -781,7 +783,7 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
 {
     const FusedShape S = fused_shape(h, a.L, a.dt);
     const int kz = S.kz;
-    if (S.tx == 64 && S.ty == 8) return launch_fused_t<64, 8, 8, 2, 4>(h, s, a, bc, b, hiface, fold, shell);
+    if (S.tx == 64 && S.ty == 8) return launch_fused_t<64, 8, 8, 4, 4>(h, s, a, bc, b, hiface, fold, shell);
     if (S.tx == 64) {
         if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface, fold, shell);
         if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface, fold, shell);

@@ -12,8 +12,12 @@ import justrelax_jl_amd.grid as grid  # noqa: E402
 from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 41
+general = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # 1: the general form (viscous_limit = 0, zero_forces = 0): every operand and body force loaded
 h = _lib.default_handle(0)
 h.set_option("operand_cache", 1)
+if general:
+    h.set_option("viscous_limit", 0)
+    h.set_option("zero_forces", 0)
 grid.init_global_grid(n, n, n, rank=0, nprocs=1)
 st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
 jr.flow_bcs_(st, bcs, handle=h)
@@ -26,4 +30,4 @@ for rep in range(4):
         h.set_option("fused_tile", tile)
         run(5)
         out.append((tile, run(iters)[4]))
-print(f"n {n}: " + "  ".join(f"tile{t} {ms:.3f}" for t, ms in out), flush=True)
+print(f"n {n} {'general form' if general else 'headline form'}: " + "  ".join(f"tile{t} {ms:.3f}" for t, ms in out), flush=True)

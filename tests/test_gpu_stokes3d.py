@@ -304,7 +304,7 @@ def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
 @pytest.mark.parametrize("zero,nof", [("xy", 1), ("xyz", 2), ("xy one entry -0.0", 0), ("xy one entry 1e-300", 0), ("z", 0), ("xz", 0), ("", 0)])
 @pytest.mark.parametrize("ni,bcs,tile,dt", [((130, 20, 17), "free_slip", 0, np.inf), ((66, 9, 35), "slip_mix", 1, np.inf), ((97, 9, 33), "none", 0, np.inf),
                                             ((130, 20, 17), "free_slip", 0, 0.25), ((66, 9, 35), "slip_mix", 1, 0.25), ((130, 17, 20), "no_slip", 0, 0.25),
-                                            ((130, 20, 17), "free_slip", 3, np.inf), ((97, 23, 20), "none", 3, np.inf)])
+                                            ((130, 20, 17), "free_slip", 3, np.inf), ((97, 23, 20), "none", 3, np.inf), ((130, 20, 17), "free_slip", 3, 0.25), ((70, 30, 19), "slip_mix", 3, 0.25)])
 def test_body_forces_that_are_zero_are_not_loaded_and_the_bits_stay(env, ni, bcs, tile, dt, zero, nof):
     """SolVi3D.jl:102 hands three ρg arrays of zeros, and every 3D model of the reference has ρg_x = ρg_y = 0 (gravity along z).  The one-launch viscous-limit kernel does not
     load body-force arrays in which the operand pass of the driver call has found nothing but +0.0 (all 64 bits zero): x - 0.5 (0 + 0) = x for every x, -0.0 and NaN included.

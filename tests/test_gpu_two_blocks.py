@@ -107,7 +107,7 @@ def _solve_blocks(jr, tb, S, pipeline, iters_kw):
         g.finalize_global_grid()
 
 
-@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "fused_early_lazy_bcs", "split_sweeps"])
+@pytest.mark.parametrize("pipeline", ["fused", "fused_overlap", "fused_early", "fused_early_lazy_bcs", "split_sweeps", "fused_tall", "fused_early_tall"])
 @pytest.mark.parametrize("dims,n", [((2, 1, 1), (70, 13, 12)), ((1, 2, 1), (70, 13, 12)), ((1, 1, 2), (70, 13, 12)),
                                     # 3 x 5 x 5 tiles of the fused kernel per block: every shell box and an interior box
                                     ((2, 1, 1), (130, 14, 40)), ((1, 1, 2), (130, 14, 40))])
