@@ -575,7 +575,7 @@ def cfg_thermal3d_phases(jr, h, n=256, iters=200):
             "needed_bytes_per_cell": 192.0, "frac_at_needed_bytes": 192.0 * n ** 3 * k / el / 1e9 / 8000.0}
 
 
-def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z")):
+def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"), handle_options=None):
     """The N > 1 code path priced on ONE device: two different n^3 blocks of an IGG decomposition (two handles of this process joined by
     jrx_comm_init_local, planes pushed by device-to-device copies, one host thread per rank) run the timed batch of the headline concurrently.
     The same two blocks -- same allocations, the pool's boxes and allocations differ by several per cent -- are then timed again without the
@@ -630,6 +630,8 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
             # the final tree spanned 0.9 - 14.5 %) -- the median of the paired overheads and their spread are reported
             for h in hs + hu:
                 h.set_option("operand_cache", 1)
+                for k_, v_ in (handle_options or {}).items():
+                    h.set_option(k_, v_)
             pairs = []
             for rep in range(ALTERNATIONS if modes[0] == "default" else 1):
                 for h in hs:

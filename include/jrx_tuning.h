@@ -56,6 +56,10 @@
  *   "field_chunk_mib" (64), "field_batch_mib" (0), "field_va_align_mib" (0), "field_shuffle" (1)    jrx_field_alloc with "field_placement" = 1: size of a physical chunk, the least
  *                                 amount of new chunks created at once (the shuffle then mixes the chunks of several arrays), alignment of the reserved virtual range (0 = the
  *                                 allocation granularity), 0 = chunks in creation order
+ *   "general_hif" (0)            3D fused kernel, general form (any dt), 64 x 4 tile: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel (one launch per
+ *                                 unobserved iteration) and, with neighbours, the kernel's boundary tiles read the received planes ("fused_overlap" = 3: no flow_bcs! launch, no fix-up):
+ *                                 4 / 3 = the instantiation built for four (128 VGPRs + 28 dwords of scratch: 10.99 ms at 512^3) / three (155 VGPRs: 7.95 ms) waves per SIMD; 0 = boundary-layer launch (7.47 + 0.11 ms)
+ *                                 and early exchange (default: the faster pipeline, with and without neighbours -- profiles/r05_general_one_launch.txt)
  */
 #ifndef JRX_TUNING_H
 #define JRX_TUNING_H

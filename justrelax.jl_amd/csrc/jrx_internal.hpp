@@ -68,6 +68,9 @@ struct jrx_handle {
     bool visc_fold = true;               // viscous-limit fused kernel: the arithmetic with the exact zeros folded away (one division per thread for dτ_r, no division by 1 in compute_P!; same bits; A/B)
     bool fused_hiface = true;            // viscous-limit fused kernel without neighbours: the high-face node layers inside the kernel (0: the boundary-layer launch behind it, A/B)
     bool fused_ylds = true;              // fused kernel: y-neighbour operands through LDS (0: lane-shuffle-only form, A/B)
+    int general_hif = 0;                 // general (any dt) fused kernel, 64 x 4 tile: the high-face node layers inside the kernel and, with neighbours, the in-kernel faces: 4 / 3 = built for that many
+                                         // waves per SIMD, 0 = the boundary-layer launch behind the kernel and the early exchange (the pipeline of rounds 1-4, default: measured faster)
+    int64_t stat_fused3d_general_hif = 0;
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)
     bool halo_self_rccl = false;         // test hook: a rank that is its own periodic neighbour routes the planes through ncclSend/ncclRecv
     int thermal_cfg = 0, thermal_xg = 8; // fused 3D heat-diffusion tile shape / XCD band override (tuning)

@@ -699,7 +699,10 @@ static jrx_status iter_begin(Iter3D &I, jrx_handle *h, const jrx_stokes3d_fields
 // launch the fused kernel over the box of tiles [b[0], b[1]) x [b[2], b[3]) x [b[4], b[5])
 // MW: the second argument of __launch_bounds__, which in HIP is the least number of WAVES PER SIMD the kernel must be able to run with (not CUDA's blocks per multiprocessor): 4, i.e. at most
 // 128 VGPRs, for both tile shapes (four 4-wave blocks or two 8-wave blocks per CU); XGV: tile rows per XCD band
-template <int TX, int TY, int KZ, int MW = 4, int XGV = 1>
+static int general_hif_eff(const jrx_handle *h);
+// GH: the one-launch forms of the GENERAL kernel (any dt: high-face node layers folded in, in-kernel neighbour faces) are instantiated for this shape (tuning switch "general_hif":
+// 4 = built for four waves per SIMD -- 128 VGPRs, 28 dwords of scratch --, 3 = for three -- 155 VGPRs, no scratch --, 0 = the boundary-layer launch behind the kernel as before)
+template <int TX, int TY, int KZ, int MW = 4, int XGV = 1, bool GH = false>
 static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface, bool fold, const FusedShell *shell = nullptr)
 {
     // XCD-banded tile order (8 tile rows per XCD): y-halo rows of neighbouring tiles hit in the same L2 (PMC: 45.6 -> 37.3
@@ -713,9 +716,35 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     const bool visc = h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
     const bool vf = h->visc_fold;      // tuning switch: the folded arithmetic of the viscous limit (k_fused3d, VFOLD; same bits)
     // body-force arrays that hold only +0.0 are not loaded (set by the operand pass): the one-launch viscous-limit form and the general form have those instantiations
-    const int nof = ((visc && fold && vf) || (!visc && h->fused_ylds && !shell)) ? h->nof : 0;
+    const bool gfold = GH && fold && !visc && h->fused_ylds && general_hif_eff(h) != 0;      // the general form with its high-face node layers inside
+    const int nof = ((visc && fold && vf) || (!visc && h->fused_ylds && (!shell || gfold))) ? h->nof : 0;
+    if constexpr (GH) {
+        if (gfold) {
+            const int nblk = shell ? (shell->cls == 0 ? shell->start[1] : shell->start[shell->nbox] - shell->start[1]) : ntx * nty * ntz;
+            const FusedShell none = FusedShell{};
+            const FusedShell &sh = shell ? *shell : none;
+            if (nblk > 0) {
+#define GHL(MW_, NBR_, NOF_) hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW_, 1, false, XGV, false, true, 3, 1, 0, false, true, false, NBR_, NOF_>), dim3((unsigned)nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4], sh)
+                const int key = (general_hif_eff(h) == 3 ? 100 : 0) + (shell ? 10 : 0) + nof;
+                switch (key) {
+                case 0: GHL(4, false, 0); break; case 1: GHL(4, false, 1); break; case 2: GHL(4, false, 2); break;
+                case 10: GHL(4, true, 0); break; case 11: GHL(4, true, 1); break; case 12: GHL(4, true, 2); break;
+                case 100: GHL(3, false, 0); break; case 101: GHL(3, false, 1); break; case 102: GHL(3, false, 2); break;
+                case 110: GHL(3, true, 0); break; case 111: GHL(3, true, 1); break; default: GHL(3, true, 2); break;
+                }
+#undef GHL
+            }
+            JRX_LAUNCH_CHECK(h);
+            if (shell && shell->cls == 0) return JRX_OK;       // counted once per iteration, with the second class
+            if (shell) h->stat_fused3d_inkernel++;
+            if (nof == 1) h->stat_fused3d_nof1++; else if (nof == 2) h->stat_fused3d_nof2++;
+            h->stat_fused3d++;
+            h->stat_fused3d_general_hif++;
+            return JRX_OK;
+        }
+    }
     if (shell) {        // neighbours, one launch: interior tiles first, the tiles next to a face with a neighbour last (they wait for the exchange's flag)
-        if (!(visc && fold)) return jrx_fail(h, JRX_ERR_ARG, "internal: the in-kernel neighbour faces need the one-launch viscous-limit form");
+        if (!(visc && fold)) return jrx_fail(h, JRX_ERR_ARG, "internal: the in-kernel neighbour faces need a one-launch form of the kernel");
         // blk0 = 0: box 0 (tiles that touch no face with a neighbour, beside the exchange); blk0 = start[1]: everything else, behind it
         const int nblk = shell->cls == 0 ? shell->start[1] : shell->start[shell->nbox] - shell->start[1];
         if (nblk > 0) {
@@ -775,9 +804,19 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
     return JRX_OK;
 }
 // can this launch also update the high-face node layers (k_fused3d<..., HIF>)?  Only the viscous-limit form over all tiles of a block without neighbours has them
+static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L, double dt);
+// tuning switch "general_hif": 0 (default) = the pipeline of rounds 1-4 (kernel + boundary-layer launch; early exchange with neighbours).  Measured (gpurun_out/r05t, r05u;
+// profiles/r05_general_one_launch.txt): the one-launch instantiation needs 155 VGPRs (three waves per SIMD; built for four it spills 28 dwords: 10.99 ms) and runs at 7.95 ms where kernel +
+// boundary-layer launch take 7.47 + 0.11 ms at 512^3 (256^3: 1.178 against 1.146); with neighbours its in-kernel faces do not repay that either (two 512^3 blocks on one device, general
+// form: +16.6 % (x split) / +8.6 % (z) over uncoupled blocks against +10.5 % / +11.3 % for the early exchange).  3 / 4 select it for A/B runs and for the parity tests.
+static int general_hif_eff(const jrx_handle *h) { return h->general_hif > 0 ? h->general_hif : 0; }
 static bool fused_folds_hiface(const jrx_handle *h, const SweepArgs &a)
 {
-    return h->fused_hiface && h->viscous_limit && h->visc_ok && a.dt == INFINITY && h->fused_ylds;
+    if (!h->fused_hiface || !h->fused_ylds) return false;
+    if (h->viscous_limit && h->visc_ok && a.dt == INFINITY) return true;
+    // the general form (round 5): its one-launch instantiations exist for the 64 x 4 tile
+    const FusedShape S = fused_shape(h, a.L, a.dt);
+    return general_hif_eff(h) != 0 && S.tx == 64 && S.ty == 4;
 }
 static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a, const FusedBC &bc, const int b[6], bool hiface = false, bool fold = false, const FusedShell *shell = nullptr)
 {
@@ -785,9 +824,9 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
     const int kz = S.kz;
     if (S.tx == 64 && S.ty == 8) return launch_fused_t<64, 8, 8, 4, 4>(h, s, a, bc, b, hiface, fold, shell);
     if (S.tx == 64) {
-        if (kz == 8) return launch_fused_t<64, 4, 8>(h, s, a, bc, b, hiface, fold, shell);
-        if (kz == 4) return launch_fused_t<64, 4, 4>(h, s, a, bc, b, hiface, fold, shell);
-        return launch_fused_t<64, 4, 2>(h, s, a, bc, b, hiface, fold, shell);
+        if (kz == 8) return launch_fused_t<64, 4, 8, 4, 1, true>(h, s, a, bc, b, hiface, fold, shell);
+        if (kz == 4) return launch_fused_t<64, 4, 4, 4, 1, true>(h, s, a, bc, b, hiface, fold, shell);
+        return launch_fused_t<64, 4, 2, 4, 1, true>(h, s, a, bc, b, hiface, fold, shell);
     }
     if (kz == 8) return launch_fused_t<32, 8, 8>(h, s, a, bc, b, hiface, fold, shell);
     if (kz == 4) return launch_fused_t<32, 8, 4>(h, s, a, bc, b, hiface, fold, shell);
@@ -877,7 +916,8 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         const bool overlap = h->fused_overlap == 1;
         // option "fused_overlap" = 3 (default): the viscous-limit kernel's own boundary tiles finish the cells next to the received planes (see the branch below); where that
         // form does not run (finite dt, a failed operand check) the early exchange (2) stands in
-        const bool inkernel = (h->fused_overlap == 3 || h->fused_overlap == 4) && comm && !per && fused_folds_hiface(h, a) && h->visc_fold;
+        const bool visc_form = h->viscous_limit && h->visc_ok && a.dt == INFINITY;
+        const bool inkernel = (h->fused_overlap == 3 || h->fused_overlap == 4) && comm && !per && fused_folds_hiface(h, a) && (h->visc_fold || !visc_form);
         const bool early = (h->fused_overlap == 2 || (h->fused_overlap >= 3 && !inkernel)) && comm && !per;
         const bool split = !comm && !per && h->fused_split && nt[0] > 1 && nt[1] > 1 && nt[2] > 1;
         if (split) {

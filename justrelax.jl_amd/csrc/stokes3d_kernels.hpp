@@ -701,9 +701,9 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     static_assert(!(SHFL && (LATEA || (TX != 64 && TX != 32))), "SHFL is implemented for rows of one wave or half a wave");
     static_assert(!YLDS || SHFL, "YLDS builds on the SHFL operand layout");
     static_assert(!VISC || YLDS, "the viscous-limit form is built on the YLDS operand layout");
-    static_assert(!HIF || (VISC && !LOWREG && SHFL && OVX == 1), "the folded high-face layers are built for the viscous-limit form with carried planes");
+    static_assert(!HIF || (!LOWREG && SHFL && OVX == 1 && YLDS == 3), "the folded high-face layers are built on the forms with carried planes");
     static_assert(!VFOLD || VISC, "VFOLD simplifies the viscous-limit arithmetic");
-    static_assert(!NBR || (VISC && HIF), "the in-kernel neighbour faces are built on the one-launch viscous-limit form");
+    static_assert(!NBR || HIF, "the in-kernel neighbour faces are built on the one-launch forms");
     constexpr int NS = LOWREG ? 3 : 2;
     __shared__ double sV[NS][3][TY][TX];
     __shared__ double sY[YLDS ? (VISC ? 7 : 8) : 1][YLDS ? TY : 1][YLDS ? TX : 1];
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
 #define NBVY(flag_, off_, jj_) ((NBR && bc.flag_) ? ((((jj_) == 0 && bc.nsF) || ((jj_) == ny && bc.nsBk)) ? 0.0 : LDC(a.o.Vy, (off_))) : LDB(f.Vy, (off_)))
 #define NBVZ(flag_, off_, kk_) ((NBR && bc.flag_) ? ((((kk_) == 0 && bc.nsK0) || ((kk_) == nz && bc.nsK1)) ? 0.0 : LDC(a.o.Vz, (off_))) : LDB(f.Vz, (off_)))
     // NOF: body-force arrays that are +0.0 in every entry (the driver's operand pass has seen all their bits zero) are not loaded: 1 = fx, fy (gravity along z), 2 = all three
-    static_assert(NOF == 0 || (VISC && HIF && VFOLD) || (!VISC && LOWREG && YLDS == 3), "the forms without body-force loads exist for the one-launch viscous-limit form and for the general form");
+    static_assert(NOF == 0 || (VISC && HIF && VFOLD) || (!VISC && (LOWREG || HIF) && YLDS == 3), "the forms without body-force loads exist for the one-launch viscous-limit form and for the general forms");
 #define LFX(off_) (NOF >= 1 ? 0.0 : LDN<(NT & 2) != 0>(f.fx, (off_)))
 #define LFY(off_) (NOF >= 1 ? 0.0 : LDN<(NT & 2) != 0>(f.fy, (off_)))
 #define LFZ(off_) (NOF >= 2 ? 0.0 : LDN<(NT & 2) != 0>(f.fz, (off_)))
@@ -1045,16 +1045,20 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                             const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsR ? vb : (bc.nsR ? -vb : NBV(nbR, Vy, ovy - rvy + 8u)));
                             const double s_ = 0.5 * (_dy * (vax - vxl) + _dx * (vyg - vb));
                             const double ee = 0.25 * (ey + ey + e + e);
-                            const double dtr = DTR(ee, 0.0);
+                            const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (gy + gy + g + g) * dt);
+                            const double to_ = VISC ? 0.0 : LDB(f.toxy, oxy + 8u);
+                            const double dtr = DTR(ee, _Gdt);
                             const double t0 = LDB(f.txy, oxy + 8u);
-                            STN<(NT & 1) != 0>(a.o.txy, oxy + 8u, t0 + INC(t0, 0.0, ee, s_, 0.0, dtr));
+                            STN<(NT & 1) != 0>(a.o.txy, oxy + 8u, t0 + INC(t0, to_, ee, s_, _Gdt, dtr));
                         }
                         {   // τxz (nx, j, k): Vz[nx+1, j+1, k] is the ghost column of the previous plane's own Vz
                             const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : NBV(nbR, Vz, ovz - svz + 8u)));
                             const double s_ = 0.5 * (_dz * (vax - vax_p) + _dx * (vzg - c_p));
                             const double ee = 0.25 * (e_p + e_p + e + e);
-                            const double dtr = DTR(ee, 0.0);
-                            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10k + INC(s10k, 0.0, ee, s_, 0.0, dtr));
+                            const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (g_p + g_p + g + g) * dt);
+                            const double to_ = VISC ? 0.0 : LDB(f.toxz, oxz - sxz + 8u);
+                            const double dtr = DTR(ee, _Gdt);
+                            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10k + INC(s10k, to_, ee, s_, _Gdt, dtr));
                         }
                     }
                     if (yl) {
@@ -1063,16 +1067,20 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                             const double vyl = i > 0 ? sV[slot][1][ty][tx - 1] : (bc.nsBk ? 0.0 : (bc.fsL ? vby : (bc.nsL ? -vby : NBV(nbL, Vy, ovy - 8u))));
                             const double s_ = 0.5 * (_dy * (vxg - va) + _dx * (vby - vyl));
                             const double ee = 0.25 * (ex + e + ex + e);
-                            const double dtr = DTR(ee, 0.0);
+                            const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (gx + g + gx + g) * dt);
+                            const double to_ = VISC ? 0.0 : LDB(f.toxy, oxy + rxy);
+                            const double dtr = DTR(ee, _Gdt);
                             const double t0 = LDB(f.txy, oxy + rxy);
-                            STN<(NT & 1) != 0>(a.o.txy, oxy + rxy, t0 + INC(t0, 0.0, ee, s_, 0.0, dtr));
+                            STN<(NT & 1) != 0>(a.o.txy, oxy + rxy, t0 + INC(t0, to_, ee, s_, _Gdt, dtr));
                         }
                         {   // τyz (i, ny, k)
                             const double vzg = (k == 0 && bc.nsK0) ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : NBV(nbBk, Vz, ovz - svz + rvz)));
                             const double s_ = 0.5 * (_dz * (vby - vby_p) + _dy * (vzg - c_p));
                             const double ee = 0.25 * (e_p + e_p + e + e);
-                            const double dtr = DTR(ee, 0.0);
-                            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10k + INC(r10k, 0.0, ee, s_, 0.0, dtr));
+                            const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (g_p + g_p + g + g) * dt);
+                            const double to_ = VISC ? 0.0 : LDB(f.toyz, oyz - syz + ryz);
+                            const double dtr = DTR(ee, _Gdt);
+                            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10k + INC(r10k, to_, ee, s_, _Gdt, dtr));
                         }
                     }
                     if (xl && yl) {   // τxy (nx, ny, k): both velocities on ghost lines of their own boundary values
@@ -1080,9 +1088,11 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
                         const double vyg = bc.nsBk ? 0.0 : (bc.fsR ? vby : (bc.nsR ? -vby : NBV(nbR, Vy, ovy + 8u)));
                         const double s_ = 0.5 * (_dy * (vxg - vax) + _dx * (vyg - vby));
                         const double ee = 0.25 * (e + e + e + e);
-                        const double dtr = DTR(ee, 0.0);
+                        const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (g + g + g + g) * dt);
+                        const double to_ = VISC ? 0.0 : LDB(f.toxy, oxy + 8u + rxy);
+                        const double dtr = DTR(ee, _Gdt);
                         const double t0 = LDB(f.txy, oxy + 8u + rxy);
-                        STN<(NT & 1) != 0>(a.o.txy, oxy + 8u + rxy, t0 + INC(t0, 0.0, ee, s_, 0.0, dtr));
+                        STN<(NT & 1) != 0>(a.o.txy, oxy + 8u + rxy, t0 + INC(t0, to_, ee, s_, _Gdt, dtr));
                     }
                 }
                 vax_p = vax; vby_p = vby;
@@ -1104,31 +1114,39 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             const double vxg = (i == 0 && bc.nsL) ? 0.0 : (bc.fsK1 ? a_p : (bc.nsK1 ? -a_p : NBV(nbK1, Vx, ovx - 8u)));
             const double s_ = 0.5 * (_dz * (vxg - a_p) + _dx * (c_p - cx_p));
             const double ee = 0.25 * (ex_p + e_p + ex_p + e_p);
-            const double dtr = DTR(ee, 0.0);
-            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01p + INC(s01p, 0.0, ee, s_, 0.0, dtr));
+            const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (gx_p + g_p + gx_p + g_p) * dt);
+            const double to_ = VISC ? 0.0 : LDB(f.toxz, oxz - sxz);
+            const double dtr = DTR(ee, _Gdt);
+            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz, s01p + INC(s01p, to_, ee, s_, _Gdt, dtr));
         }
         {   // τyz (i, j, nz)
             const double vyg = (j == 0 && bc.nsF) ? 0.0 : (bc.fsK1 ? b_p : (bc.nsK1 ? -b_p : NBV(nbK1, Vy, ovy - rvy)));
             const double s_ = 0.5 * (_dz * (vyg - b_p) + _dy * (c_p - cy_p));
             const double ee = 0.25 * (ey_p + e_p + ey_p + e_p);
-            const double dtr = DTR(ee, 0.0);
-            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01p + INC(r01p, 0.0, ee, s_, 0.0, dtr));
+            const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (gy_p + g_p + gy_p + g_p) * dt);
+            const double to_ = VISC ? 0.0 : LDB(f.toyz, oyz - syz);
+            const double dtr = DTR(ee, _Gdt);
+            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz, r01p + INC(r01p, to_, ee, s_, _Gdt, dtr));
         }
         if (xl) {   // τxz (nx, j, nz)
             const double vxg = bc.nsR ? 0.0 : (bc.fsK1 ? vax_p : (bc.nsK1 ? -vax_p : NBV(nbK1, Vx, ovx)));
             const double vzg = bc.nsK1 ? 0.0 : (bc.fsR ? c_p : (bc.nsR ? -c_p : NBV(nbR, Vz, ovz - svz + 8u)));
             const double s_ = 0.5 * (_dz * (vxg - vax_p) + _dx * (vzg - c_p));
             const double ee = 0.25 * (e_p + e_p + e_p + e_p);
-            const double dtr = DTR(ee, 0.0);
-            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10 + INC(s10, 0.0, ee, s_, 0.0, dtr));
+            const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (g_p + g_p + g_p + g_p) * dt);
+            const double to_ = VISC ? 0.0 : LDB(f.toxz, oxz - sxz + 8u);
+            const double dtr = DTR(ee, _Gdt);
+            STN<(NT & 1) != 0>(a.o.txz, oxz - sxz + 8u, s10 + INC(s10, to_, ee, s_, _Gdt, dtr));
         }
         if (yl) {   // τyz (i, ny, nz)
             const double vyg = bc.nsBk ? 0.0 : (bc.fsK1 ? vby_p : (bc.nsK1 ? -vby_p : NBV(nbK1, Vy, ovy)));
             const double vzg = bc.nsK1 ? 0.0 : (bc.fsBk ? c_p : (bc.nsBk ? -c_p : NBV(nbBk, Vz, ovz - svz + rvz)));
             const double s_ = 0.5 * (_dz * (vyg - vby_p) + _dy * (vzg - c_p));
             const double ee = 0.25 * (e_p + e_p + e_p + e_p);
-            const double dtr = DTR(ee, 0.0);
-            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10 + INC(r10, 0.0, ee, s_, 0.0, dtr));
+            const double _Gdt = VISC ? 0.0 : 1.0 / (0.25 * (g_p + g_p + g_p + g_p) * dt);
+            const double to_ = VISC ? 0.0 : LDB(f.toyz, oyz - syz + ryz);
+            const double dtr = DTR(ee, _Gdt);
+            STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10 + INC(r10, to_, ee, s_, _Gdt, dtr));
         }
     }
 #undef NBV

@@ -409,6 +409,40 @@ def test_viscous_limit_falls_back_when_an_unloaded_operand_is_not_harmless(env, 
         assert np.array_equal(out1[k][m], out0[k][m], equal_nan=True), k
 
 
+@pytest.mark.parametrize("gh", [0, 3, 4])
+@pytest.mark.parametrize("ni,bcs,zero", [((130, 20, 17), "free_slip", ""), ((97, 9, 33), "none", "xy"), ((130, 17, 20), "no_slip", "xyz"), ((66, 12, 35), "slip_mix", ""), ((190, 50, 9), "slip_mix", "xy")])
+def test_general_form_folds_its_high_face_layers(env, ni, bcs, zero, gh):
+    """for any dt the fused kernel now updates the stress nodes on the high faces i = nx, j = ny, k = nz itself (one launch per unobserved iteration instead of the
+    kernel + the boundary-layer launch), built for four or three waves per SIMD (tuning switch general_hif; 0 = the launch pair of rounds 1-4).  Every form equals the per-node kernels."""
+    jr = env["jr"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields3d(ni, bcs=bcs, dt=0.25, iterMax=23, nout=7)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    for c in zero:
+        s.arrays["f" + c][...] = 0.0
+    h = _lib.default_handle()
+    outs, its, cnt = [], [], []
+    try:
+        h.set_option("general_hif", gh)
+        for variant in (3, 1):
+            h.set_option("kernel_variant", variant)
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            c0 = [h.get_option(k) for k in ("stat_fused3d", "stat_fused3d_general_hif")]
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+            cnt.append([h.get_option(k) - c for k, c in zip(("stat_fused3d", "stat_fused3d_general_hif"), c0)])
+            its.append((r.iter, tuple(r.err_evo1)))
+            outs.append(env["down"](stokes))
+    finally:
+        h.set_option("kernel_variant", 0)
+        h.set_option("general_hif", 0)
+    one_launch = gh != 0 and ni[0] > 90          # the one-launch instantiations exist for the 64 x 4 tile (nx = 63 .. 90 runs 32 x 8 tiles)
+    assert cnt[0][0] > 0 and cnt[0][1] == (cnt[0][0] if one_launch else 0) and cnt[1] == [0, 0], cnt
+    assert its[0] == its[1] and its[0][0] == 24
+    for k in outs[0]:
+        m = env["checks"].interior_mask3d(k, outs[0][k].shape)
+        assert np.array_equal(outs[0][k][m], outs[1][k][m], equal_nan=True), (gh, k)
+
+
 def test_operand_cache_reuses_the_verdict_until_the_fields_are_declared_dirty(env):
     """option operand_cache = 1: the operand pass of the 3D visco-elastic drivers runs once per (operand pointers, extents, dt); the next driver call on the
     same arrays reuses its verdict -- same bits as a call that looks again -- until jrx_fields_dirty, after which a poisoned operand is found and the general kernels report the

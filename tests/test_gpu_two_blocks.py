@@ -28,6 +28,9 @@ STATE = ("P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "txy", "txz", "tyz")
 PIPELINES = {"fused": dict(kernel_variant=3, fused_overlap=0, fused_comm=1), "fused_overlap": dict(kernel_variant=3, fused_overlap=1, fused_comm=1),
              "fused_early": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=0),
              "fused_inkernel": dict(kernel_variant=3, fused_overlap=4, fused_comm=1, comm_bcs_lazy=0),      # viscous limit only (dt = Inf); the early exchange otherwise (4: x faces too)
+             "fused_inkernel_general4": dict(kernel_variant=3, fused_overlap=3, fused_comm=1, comm_bcs_lazy=0, general_hif=4),     # finite dt: the general form's in-kernel neighbour faces (round 5)
+             "fused_inkernel_general3": dict(kernel_variant=3, fused_overlap=3, fused_comm=1, comm_bcs_lazy=0, general_hif=3),
+             "fused_early_general0": dict(kernel_variant=3, fused_overlap=3, fused_comm=1, comm_bcs_lazy=0, general_hif=0),        # ... switched off: the early exchange of rounds 3-4
              "fused_inkernel_tall": dict(kernel_variant=3, fused_overlap=4, fused_comm=1, comm_bcs_lazy=0, fused_tile=3),      # ... with the 64 x 8 tile (round 5: the default shape of large blocks)
              "fused_early_tall": dict(kernel_variant=3, fused_overlap=2, fused_comm=1, comm_bcs_lazy=0, fused_tile=3),
              "fused_tall": dict(kernel_variant=3, fused_overlap=0, fused_comm=1, fused_tile=3),
@@ -249,6 +252,46 @@ def test_blocks_with_the_tall_tile_equal_the_undecomposed_general_kernels(jr, di
         fused = [_get(h, "stat_fused3d_visc") for h in tb.handles]
     assert min(fused) >= 12, fused
     assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    for r, out in enumerate(outs):
+        co = B.coords_of(tb.carts[r])
+        for k in STATE + ("Rx", "Ry", "Rz", "RP", "exx", "exy", "eyz", "exz", "divV"):
+            want = B.local_block(glob[k], n, tb.ng, co)
+            m = interior_mask3d(k, want.shape)
+            assert np.isfinite(want[m]).all() and np.array_equal(out[k][m], want[m]), (dims, bcs, pipeline, r, co, k, float(np.abs(out[k] - want)[m].max()))
+
+
+@pytest.mark.parametrize("pipeline", ["fused_inkernel_general4", "fused_inkernel_general3", "fused_early_general0"])
+@pytest.mark.parametrize("dims,n,bcs,zero", [((2, 1, 1), (130, 14, 40), "free_slip", ""), ((1, 2, 1), (97, 40, 12), "slip_mix", "xy"), ((1, 1, 2), (70, 13, 12), "no_slip", ""), ((2, 2, 2), (130, 13, 20), "slip_mix", "xyz"),
+                                             ((2, 2, 1), (130, 14, 40), "none", "")])
+def test_blocks_with_finite_dt_finish_their_neighbour_faces_inside_the_general_kernel(jr, dims, n, bcs, zero, pipeline):
+    """the GENERAL form of the fused kernel (finite dt: old stresses, P0, K, G, Q all in play) with its high-face node layers inside and, with neighbours, its boundary
+    tiles reading the received planes -- no flow_bcs! launch, no fix-up -- built for four or three waves per SIMD (tuning switch general_hif).  Two, four and eight blocks equal the
+    undecomposed run of the per-node kernels bit for bit, residuals and strain rates of the observed iterations included; with general_hif = 0 the early exchange of rounds 3-4 runs."""
+    from justrelax_jl_amd import _lib
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    from justrelax_jl_amd.checks import interior_mask3d
+    kw = dict(iterMax=23, nout=8, verbose=False)
+    with TwoBlocks(n, dims) as tb:
+        S = _global_setup(jr, tb.ng, True, 23, 8, seed=9, bcs=bcs, dt=0.25)
+        for c in zero:
+            S.arrays["f" + c][...] = 0.0
+        h0 = _lib.default_handle()
+        _set(h0, kernel_variant=1)
+        try:
+            stokes, ρg, K, G = upload_stokes(S, jr.AMDGPUBackend)
+            rg = jr.solve_(stokes, S.pt, S.grid, S.flow_bcs, ρg, K, G, S.dt, None, kwargs=kw)
+            glob = download_stokes(stokes)
+        finally:
+            _set(h0, kernel_variant=0)
+        res, outs = _solve_blocks(jr, tb, S, pipeline, kw)
+        inkernel = [_get(h, "stat_fused3d_inkernel") for h in tb.handles]
+        ghif = [_get(h, "stat_fused3d_general_hif") for h in tb.handles]
+    if pipeline == "fused_early_general0" or n[0] <= 90:          # (nx = 63 .. 90 runs 32 x 8 tiles, for which the one-launch general form is not instantiated: early exchange)
+        assert max(inkernel) == 0 and max(ghif) == 0, (inkernel, ghif)
+    else:
+        assert min(inkernel) >= 12 and min(ghif) >= 12, (inkernel, ghif)
+    assert rg.iter == 24 and all(r.iter == 24 for r in res)
+    assert all(list(r.err_evo1) == list(res[0].err_evo1) for r in res)
     for r, out in enumerate(outs):
         co = B.coords_of(tb.carts[r])
         for k in STATE + ("Rx", "Ry", "Rz", "RP", "exx", "exy", "eyz", "exz", "divV"):
