@@ -472,7 +472,9 @@ def cfg_shearband(jr, h, n=1024, iters=600):
                               kwargs=dict(iterMax=k - 1, nout=10 ** 9, iterMin=10 ** 9, verbose=False), handle=h)
     el, r = _timed(run, 30, iters)
     return {"workload": f"shear band {n}^2 (2D multiphase VEP)", "iterations": int(r.iter), "it_per_s": r.iter / el,
-            "effective_GBps_at_700B_per_cell_as_written": 700.0 * n * n * r.iter / el / 1e9}
+            "effective_GBps_at_700B_per_cell_as_written": 700.0 * n * n * r.iter / el / 1e9,
+            "needed_bytes_per_cell": 440.0, "effective_GBps_at_needed_bytes": 440.0 * n * n * r.iter / el / 1e9,          # floor ~ 55 passes
+            "frac_at_needed_bytes": 440.0 * n * n * r.iter / el / 1e9 / 8000.0}
 
 
 def cfg_thermal2d(jr, h, n=256, iters=4000):
@@ -493,7 +495,9 @@ def cfg_thermal2d(jr, h, n=256, iters=4000):
         return k
     el, k = _timed(run, 100, iters)
     return {"workload": f"thermal diffusion {n}^2 (2D PT, array form)", "iterations": k, "it_per_s": k / el,
-            "effective_GBps_at_144B_per_cell": 144.0 * n * n * k / el / 1e9}
+            "effective_GBps_at_144B_per_cell_as_written": 144.0 * n * n * k / el / 1e9,
+            # the one-launch iteration needs 10 reads (T, q(2), K, θr_dτ, Told, ρCp, dτ_ρ, H, SH) + 3 writes = 104 B/cell; 256^2 is cache-resident: a rate, not a roofline fraction
+            "needed_bytes_per_cell": 104.0, "effective_GBps_at_needed_bytes": 104.0 * n * n * k / el / 1e9}
 
 
 def cfg_shearband3d(jr, h, n=256, iters=60):
@@ -517,7 +521,10 @@ def cfg_shearband3d(jr, h, n=256, iters=60):
     el, r = _timed(run, 5, iters)
     gbps = 912.0 * n ** 3 * r.iter / el / 1e9
     return {"workload": f"shear band {n}^3 (3D multiphase VEP)", "iterations": int(r.iter), "it_per_s": r.iter / el,
-            "effective_GBps_at_912B_per_cell": gbps, "frac_of_8TBps": gbps / 8000.0}
+            "effective_GBps_at_912B_per_cell_as_written": gbps, "frac_of_8TBps_as_written": gbps / 8000.0,
+            # what the three kernels of an unobserved iteration have to move, every array once: fused pre / centre kernel 27 reads + 16 writes, edge pass 29 reads (11 centre, 9 shear,
+            # 6 phase ratios, 3 λ) + 6 writes, velocity sweep 11 reads + 3 writes (the zero body forces are not loaded) = 92 passes
+            "needed_bytes_per_cell": 736.0, "frac_at_needed_bytes": 736.0 * n ** 3 * r.iter / el / 1e9 / 8000.0}
 
 
 def cfg_thermal3d(jr, h, n=256, iters=400):

@@ -17,5 +17,5 @@ for r in range(rounds):
     for fork in (1, 0):
         h.set_option("vep3_fork", fork)
         out = bench.cfg_shearband3d(jr, h, n=n, iters=60)
-        print(f"n={n} vep3_fork={fork}: {out['it_per_s']:.1f} it/s  frac {out['frac_of_8TBps']:.3f}", flush=True)
+        print(f"n={n} vep3_fork={fork}: {out['it_per_s']:.1f} it/s  frac {out['frac_at_needed_bytes']:.3f}", flush=True)
 h.set_option("vep3_fork", 1)
