@@ -66,6 +66,7 @@ int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 512;
     const double seconds = argc > 2 ? atof(argv[2]) : 30.0;
+    const int smooth = argc > 3 ? atoi(argv[3]) : 0;      // 1: every array a constant (the operands of a smooth model: few mantissa bits toggle), 0: random operands
     const int nx = n, ny = n, nz = n;
     jrx_stokes3d_fields f;
     memset(&f, 0, sizeof(f));
@@ -79,7 +80,7 @@ int main(int argc, char **argv)
                              {&dst.P, nc, 0, 0, 0}, {&dst.txx, nc, 0, 0, 0}, {&dst.tyy, nc, 0, 0, 0}, {&dst.tzz, nc, 0, 0, 0}, {&dst.tyz, nyz, 0, 0, 0}, {&dst.txz, nxz, 0, 0, 0}, {&dst.txy, nxy, 0, 0, 0},
                              {&dst.Vx, nvx, 0, 0, 0}, {&dst.Vy, nvy, 0, 0, 0}, {&dst.Vz, nvz, 0, 0, 0}};
     unsigned seed = 1;
-    for (auto &e : ents) { CK(hipMalloc(e.p, e.n * 8)); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, *e.p, e.n, seed++, e.lo, e.hi, e.expo); }
+    for (auto &e : ents) { CK(hipMalloc(e.p, e.n * 8)); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, *e.p, e.n, seed++, smooth ? (e.expo ? 0.0 : 0.25 * (e.lo + e.hi) + 0.125) : e.lo, smooth ? (e.expo ? 0.0 : 0.25 * (e.lo + e.hi) + 0.125) : e.hi, e.expo); }
     double *vout; CK(hipMalloc(&vout, 8));
     unsigned *perm, *cout;
     CK(hipMalloc(&perm, (size_t)4 << 26)); CK(hipMalloc(&cout, 4 * 4096));
@@ -125,7 +126,7 @@ int main(int argc, char **argv)
         CK(hipFree(w)); free(hw);
     }
     const auto t00 = std::chrono::system_clock::now();
-    printf("# unix_time  k_fused3d<64,8,8> ms   copy 1 GiB ms (GB/s)   fp64 VALU kernel ms   re-read of 128 MiB GB/s   read of 1 GiB GB/s   ns per dependent load (one lane)   (2,048 lanes)\n");
+    printf("# operands: %s\n", smooth ? "constants" : "random"); printf("# unix_time  k_fused3d<64,8,8> ms   copy 1 GiB ms (GB/s)   fp64 VALU kernel ms   re-read of 128 MiB GB/s   read of 1 GiB GB/s   ns per dependent load (one lane)   (2,048 lanes)\n");
     while (std::chrono::duration<double>(std::chrono::system_clock::now() - t00).count() < seconds) {
         CK(hipEventRecord(e0, 0));
         for (int r = 0; r < 20; r++)
