@@ -69,7 +69,7 @@ const char *jrx_build_id(void);
  * src/types/constructors/stokes.jl:279-303) -- a binding wraps the pointer (Julia: unsafe_wrap(ROCArray, ptr, dims; own = false) plus a
  * finalizer that calls jrx_field_free).  Contents are NOT initialised (the constructor fills with zeros as @zeros does).  Using it is
  * optional: every entry point takes any device pointer.  What it buys: the option "field_placement" decides how the arrays are backed
- * physically, which the large 3D kernels are sensitive to ("placement"); the library's own large arrays (second state sets, ητ)
+ * physically, which the large 3D kernels were suspected to be sensitive to (profiles/r05_placement.txt: they are not); the library's own large arrays (second state sets, ητ)
  * follow the same option.  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns unmapped spare chunks to the driver.
  * jrx_field_stats: [0] live arrays (the library's own included), [1] their bytes, [2] physical chunks created, [3] spare chunks, [4] us in hipMemCreate, [5] us mapping. */
 jrx_status jrx_field_alloc(jrx_handle *h, int64_t count, double **out);     /* count doubles */
@@ -77,8 +77,8 @@ jrx_status jrx_field_free(jrx_handle *h, double *p);
 jrx_status jrx_field_trim(jrx_handle *h);
 /* jrx_field_reroll: new physical backing for one chunk-backed array ("field_placement" = 1), or for all of them (p = NULL), IN PLACE -- the pointer, the contents and every
  * other pointer into the array stay valid; the device must not be using the array meanwhile (the call synchronises the device).  Why: the rate of the large 3D kernels
- * depends on where the arrays happen to lie physically, per set of allocations ("placement"); together with jrx_stokes3d_probe a binding can look for a good
- * placement once, before a long run.  jrx_field_list: the live arrays of the handle (bytes[i] < 0: not chunk-backed), count = how many there are (may exceed cap). */
+ * was suspected to depend on where the arrays lie physically; it is how round 5 showed that the placement is NOT what the
+ * rate depends on (profiles/r05_placement.txt); kept for A/B runs.  jrx_field_list: the live arrays of the handle (bytes[i] < 0: not chunk-backed), count = how many there are (may exceed cap). */
 jrx_status jrx_field_reroll(jrx_handle *h, double *p);
 jrx_status jrx_field_list(jrx_handle *h, int64_t cap, double **ptrs, int64_t *bytes, int64_t *count);
 jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
