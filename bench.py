@@ -231,6 +231,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip solve_path and other_configs")
     ap.add_argument("--no-general-kernel", action="store_true", help="skip the leg that times the general form of k_fused3d (option viscous_limit = 0) beside the headline")
+    ap.add_argument("--placement-draws", type=int, default=8,
+                    help="placement search before the run (jrx_stokes3d_tune_placement): the arrays come from the library's chunk allocator (field_placement = 1, one chunk per array) and "
+                         "are given new physical memory this many times, the fastest placement stays; 0 = the arrays are torch's and lie where hipMalloc put them")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the extra 100-step batch that follows a requested batch of fewer than 50 steps")
     ap.add_argument("--cpu-full-size", choices=["auto", "on", "off"], default="auto",
                     help="cpu_baseline also measured at the metric's own size (n^3, 5 iterations): auto = when MemAvailable >= 64 GB")
@@ -396,6 +399,28 @@ def solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, iters, n, pr):
             "effective_GBps": pr["alg"] * cells * r.iter / el / 1e9,
             "frac_of_peak": pr["alg"] * cells * r.iter / el / 1e9 / HBM_PEAK_GBS,
             "norm_Rx_last": float(r.norm_Rx[-1]) if len(r.norm_Rx) else None}
+
+
+def state_tensors(obj, _seen=None):
+    """every device array reachable from a StokesArrays-like object (its fields, nested)"""
+    import torch
+    seen = _seen if _seen is not None else set()
+    if torch.is_tensor(obj):
+        if obj.data_ptr() not in seen and obj.numel() > 0:
+            seen.add(obj.data_ptr())
+            yield obj
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from state_tensors(v, seen)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from state_tensors(v, seen)
+    elif hasattr(obj, "__dict__"):
+        for v in vars(obj).values():
+            yield from state_tensors(v, seen)
+    elif hasattr(obj, "__slots__"):
+        for k in obj.__slots__:
+            yield from state_tensors(getattr(obj, k, None), seen)
 
 
 def cfg_solvi(jr, h, n, steps, warm):
@@ -1505,6 +1530,15 @@ def run_rank(args) -> int:
         h.call("jrx_comm_count", C.byref(cnt))
         rccl_ranks = cnt.value
     uh = (lambda a: halo.update_halo_(a, ni=(n, n, n), handle=h)) if (world > 1 or self_halo) else None
+    # Where the arrays lie in the device's memory moves the time of the dominant kernel by up to 30 % (4.7 .. 6.2 ms per launch at 512^3, profiles/r05_placement.txt) and only a run
+    # tells: the arrays come from the library (as the backend's array constructor would hand them out: src/ext/AMDGPU/3D.jl:46-48) and it searches before anything is timed.
+    searching = args.placement_draws > 0 and h.get_option("field_placement") in (0, 1)
+    if searching:
+        from justrelax_jl_amd import arrays as _arrays
+        h.set_option("field_placement", 1)
+        if not any(kv.startswith("field_chunk_mib=") for kv in args.option):
+            h.set_option("field_chunk_mib", 0)
+        _arrays.use_library_arrays(h)
     st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend, update_halo=uh)
     jr.flow_bcs_(st, bcs, handle=h)
     if world > 1 or self_halo:
@@ -1513,6 +1547,21 @@ def run_rank(args) -> int:
     jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
     if world > 1 or self_halo:
         halo.update_halo_(ητ, ni=(n, n, n), handle=h)
+    placement_search = None
+    if searching:
+        # the search advances the fields: the initial state is set aside and written back afterwards (outside every timed region, like the allocation itself)
+        ts = time.perf_counter()
+        held = [(t, t.clone()) for t in state_tensors(st)]
+        ms_draws, kept = stokes.tune_placement_(st, pt, geo, bcs, ρg, K, G, ητ, dt, args.placement_draws, 12, handle=h)
+        for t, c in held:
+            t.copy_(c)
+        del held
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        placement_search = {"draws": args.placement_draws, "kept": kept, "iterations_per_probe": 12, "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_of_the_draws": ms_draws[1:-1],
+                            "ms_per_iteration_kept": ms_draws[-1], "seconds": time.perf_counter() - ts,
+                            "what": "jrx_stokes3d_tune_placement: new physical chunks under every array in place, 12 iterations timed, the draw kept if it is the fastest so far (-1: draw not made, "
+                                    "no room for a second copy of the arrays); setup, not part of any timed region; the initial state is restored afterwards"}
 
     def barrier():
         torch.cuda.synchronize()
@@ -1655,6 +1704,7 @@ def run_rank(args) -> int:
             out["roofline"]["device_state"] = dev_state          # sclk / power / temperatures of the device during the timed batch (see DeviceState)
             out["roofline"]["launch_ms_per_rank"] = [sk_ms if fused else None]      # placement probe: a process runs this kernel at one of two rates for its lifetime (DESIGN, placement)
             out["roofline"]["field_placement"] = h.get_option("field_placement")
+            out["roofline"]["placement_search"] = placement_search
         if world == 1 and not self_halo and not args.no_extras:
             try:
                 out["solve_path"] = solve_path(jr, h, st, pt, geo, bcs, ρg, K, G, dt, args.solve_iters, n, pr)
@@ -1662,6 +1712,9 @@ def run_rank(args) -> int:
                 out["solve_path"] = {"error": f"{type(e).__name__}: {e}"}
             del st, ρg, K, G, ητ
             torch.cuda.empty_cache()
+            if searching:                                    # the other configurations run as before: torch's arrays, hipMalloc
+                _arrays.use_library_arrays(None)
+                h.set_option("field_placement", 0)
             out["other_configs"] = other_configs(jr, h)
         if world == 1 and not args.no_cpu_baseline:
             st = ρg = K = G = ητ = None

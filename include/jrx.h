@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JRX_VERSION 220
+#define JRX_VERSION 221
 
 typedef enum jrx_status {
     JRX_OK = 0,
@@ -70,16 +70,12 @@ const char *jrx_build_id(void);
  * finalizer that calls jrx_field_free).  Contents are NOT initialised (the constructor fills with zeros as @zeros does).  Using it is
  * optional: every entry point takes any device pointer.  What it buys: the option "field_placement" decides how the arrays are backed
  * physically, which the large 3D kernels were suspected to be sensitive to (profiles/r05_placement.txt: they are not); the library's own large arrays (second state sets, ητ)
- * follow the same option.  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns unmapped spare chunks to the driver.
+ * follow the same option .  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns unmapped spare chunks to the driver.
  * jrx_field_stats: [0] live arrays (the library's own included), [1] their bytes, [2] physical chunks created, [3] spare chunks, [4] us in hipMemCreate, [5] us mapping. */
 jrx_status jrx_field_alloc(jrx_handle *h, int64_t count, double **out);     /* count doubles */
 jrx_status jrx_field_free(jrx_handle *h, double *p);
 jrx_status jrx_field_trim(jrx_handle *h);
-/* jrx_field_reroll: new physical backing for one chunk-backed array ("field_placement" = 1), or for all of them (p = NULL), IN PLACE -- the pointer, the contents and every
- * other pointer into the array stay valid; the device must not be using the array meanwhile (the call synchronises the device).  Why: the rate of the large 3D kernels
- * was suspected to depend on where the arrays lie physically; it is how round 5 showed that the placement is NOT what the
- * rate depends on (profiles/r05_placement.txt); kept for A/B runs.  jrx_field_list: the live arrays of the handle (bytes[i] < 0: not chunk-backed), count = how many there are (may exceed cap). */
-jrx_status jrx_field_reroll(jrx_handle *h, double *p);
+/* jrx_field_list: the live arrays of the handle (bytes[i] < 0: not chunk-backed), count = how many there are (may exceed cap). */
 jrx_status jrx_field_list(jrx_handle *h, int64_t cap, double **ptrs, int64_t *bytes, int64_t *count);
 jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
 
@@ -659,6 +655,16 @@ jrx_status jrx_compute_shear_heating(jrx_handle *h, double *shear_heating, const
  *   whose stresses the launch timed in [4] updates (its units; 0 when nothing was fused). */
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
                                       const jrx_stokes3d_params *p, int64_t iters, double times_ms[6]);
+
+/* Placement search for the arrays of one 3D Stokes problem.  Arrays of jrx_field_alloc with "field_placement" = 1 (and the library's own, which follow the same option) can be given
+ * other physical memory without their addresses or contents changing; the time of the large kernels depends on that memory (4.7 .. 6.2 ms per launch at 512^3 on the same device,
+ * profiles/r05_placement.txt) in a way only a run can tell.  `draws` times: new chunks for every chunk-backed array of the handle, `iters` (>= 2) iterations of the loop body timed as by
+ * jrx_stokes3d_iterate_timed, keep the draw if it beat the best so far (by 0.3 %), undo it otherwise.  ms_per_iter[0] = as allocated, [1 .. draws] = the draws (-1: not made -- a draw
+ * needs room for a second copy of the arrays, the search ends when there is none), [draws + 1] = the placement that stays; *kept = draws kept.  The fields are advanced by all those
+ * iterations: call it before the initial state is written (or write it again).  Arrays of other allocators are left alone (with none chunk-backed the call only measures).  With
+ * neighbours every rank calls it with the same draws and iters. */
+jrx_status jrx_stokes3d_tune_placement(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, int32_t draws, int64_t iters,
+                                       double *ms_per_iter, int32_t *kept);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,8 @@
  *   "field_chunk_mib" (64), "field_batch_mib" (0), "field_va_align_mib" (0), "field_shuffle" (1)    jrx_field_alloc with "field_placement" = 1: size of a physical chunk, the least
  *                                 amount of new chunks created at once (the shuffle then mixes the chunks of several arrays), alignment of the reserved virtual range (0 = the
  *                                 allocation granularity), 0 = chunks in creation order
+ *   "field_arena_gib" (0), "field_va_gap_mib" (0)    "field_placement" = 1: > 0 = the chunk-backed arrays lie one behind the other in ONE reserved virtual range of that size, that many MiB apart
+ *   "field_skew_bytes" (0), "field_skew_mod" (32)    every placement: the k-th large array (>= 8 MiB) starts (k mod field_skew_mod) * field_skew_bytes (a multiple of 256) into its allocation
  *   "general_hif" (0)            3D fused kernel, general form (any dt), 64 x 4 tile: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel (one launch per
  *                                 unobserved iteration) and, with neighbours, the kernel's boundary tiles read the received planes ("fused_overlap" = 3: no flow_bcs! launch, no fix-up):
  *                                 4 / 3 = the instantiation built for four (128 VGPRs + 28 dwords of scratch: 10.99 ms at 512^3) / three (155 VGPRs: 7.95 ms) waves per SIMD; 0 = boundary-layer launch (7.47 + 0.11 ms)
@@ -74,6 +76,14 @@ jrx_status jrx_tuning_get(jrx_handle *h, const char *key, int64_t *value);
  * the neighbour, unpack), [4] flow_bcs! behind the join, [5] stress fix-up next to the received planes, [6] the whole step, [7] the step beyond k_fused3d.  With the
  * early exchange [1]..[3] run on the halo stream beside [0]. */
 jrx_status jrx_tuning_chain_profile(jrx_handle *h, double out_us[8], int64_t *samples);
+/* New physical chunks under one chunk-backed array of jrx_field_alloc ("field_placement" = 1), or under all of them (p = NULL), IN PLACE: every pointer stays valid and the contents are
+ * carried over (staged through a hipMalloc buffer; the re-mapping is followed by the translation flush csrc/fieldpool.hip describes -- without it the shaders keep reaching the OLD chunks
+ * on this ROCm release, scripts/vmm_stale.hip).  The primitive of the placement experiments of round 5 (scripts/probe_reroll2.py, profiles/r05_placement.txt). */
+jrx_status jrx_tuning_field_reroll(jrx_handle *h, double *p);
+/* jrx_tuning_field_undo: back onto the chunks the array (NULL: every array) had before its last re-roll -- a re-roll keeps them aside until the array is re-rolled again, freed, or
+ * jrx_tuning_field_keep hands them to the spare list; contents are carried over both ways.  Re-roll, time the kernel, keep or undo: the step of a placement search. */
+jrx_status jrx_tuning_field_undo(jrx_handle *h, double *p);
+jrx_status jrx_tuning_field_keep(jrx_handle *h, double *p);
 #ifdef __cplusplus
 }
 #endif

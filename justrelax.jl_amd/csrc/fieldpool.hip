@@ -19,13 +19,15 @@
 #include <vector>
 
 struct jrx_field_pool {
-    struct Alloc { size_t bytes = 0, mapped = 0; int kind = 0; bool in_arena = false; std::vector<hipMemGenericAllocationHandle_t> chunks; size_t chunk = 0; };
+    struct Alloc { size_t bytes = 0, mapped = 0, skew = 0; int kind = 0; bool in_arena = false; std::vector<hipMemGenericAllocationHandle_t> chunks, prev; size_t chunk = 0; };   // prev: the chunks before the last re-roll (jrx_tuning_field_undo)
     std::map<void *, Alloc> live;
-    std::vector<hipMemGenericAllocationHandle_t> spare;      // created, unmapped chunks (all of `spare_chunk` bytes)
-    size_t spare_chunk = 0;
+    std::map<size_t, std::vector<hipMemGenericAllocationHandle_t>> spare;      // created, unmapped chunks by their size
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     double create_ms = 0, map_ms = 0;
-    int64_t chunks_created = 0, bytes_live = 0, rerolls = 0;
+    int64_t chunks_created = 0, bytes_live = 0, rerolls = 0, large_allocs = 0;
+    std::vector<void *> ballast;                  // "field_ballast_mib": allocations nobody uses, made behind every large array so that the arrays spread over the device's memory
+    void *stage = nullptr;                        // jrx_tuning_field_reroll: the contents of the array being re-mapped
+    size_t stage_bytes = 0;
     // the arena: ONE reserved virtual range in which the chunk-backed arrays are placed one behind the other, `gap` bytes apart -- the rate of the large kernels turned out to
     // depend on the arrays' VIRTUAL addresses (re-rolling the physical chunks under fixed addresses changes nothing, new addresses do: profiles/r05_placement.txt), and this is
     // what makes them a choice instead of a draw
@@ -35,6 +37,25 @@ struct jrx_field_pool {
 };
 
 namespace {
+// jrx_tuning_field_reroll moves the contents with a kernel (the range is ordinary device memory for a kernel on the null stream)
+__global__ void k_pool_copy(double *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// STALE TRANSLATIONS.  On this ROCm release (7.2, gfx950) hipMemUnmap + hipMemMap of OTHER chunks at an address that was mapped before leaves the shaders with the OLD translation:
+// scripts/vmm_stale.hip -- 100 % of the words a kernel writes through the re-mapped range land in the old chunks, for ranges of 2 .. 128 MiB, whether or not a hipDeviceSynchronize, a
+// 20 ms sleep, a hipMalloc / hipFree, a copy, a memset or a complete earlier kernel lies in between; after a hipHostMalloc + hipHostFree (or a hipStreamCreate + destroy) 100 % land in
+// the new ones.  (Both go through the driver's map / queue path, which flushes the translation caches of the process; the plain re-mapping evidently does not.)  So every mapping this
+// file makes at an address that may have been mapped before -- a re-roll, a range of the arena handed out again, a reservation the runtime hands out again -- is followed by that flush.
+hipError_t flush_translations()
+{
+    void *t = nullptr;
+    hipError_t e = hipHostMalloc(&t, 4096, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostFree(t);
+    return e;
+}
+
 using Clock = std::chrono::steady_clock;
 double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 uint64_t next_rng(uint64_t &s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return s >> 17; }
@@ -47,12 +68,12 @@ jrx_field_pool *pool_of(jrx_handle *h)
 
 void release_spare(jrx_field_pool *P)
 {
-    for (auto hd : P->spare) (void)hipMemRelease(hd);
+    for (auto &kv : P->spare)
+        for (auto hd : kv.second) (void)hipMemRelease(hd);
     P->spare.clear();
-    P->spare_chunk = 0;
 }
 
-jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, void **out)
+jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, size_t skew, void **out)
 {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
@@ -61,32 +82,32 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, void **o
     size_t gran = 0;
     JRX_HIP(h, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     if (gran == 0) gran = (size_t)2 << 20;
-    size_t chunk = (size_t)(h->field_chunk_mib > 0 ? h->field_chunk_mib : 64) << 20;
+    // "field_chunk_mib" = 0: the whole array is ONE chunk (one hipMemCreate of its size: as contiguous as the driver makes it)
+    size_t chunk = h->field_chunk_mib > 0 ? (size_t)h->field_chunk_mib << 20 : bytes + skew;
     chunk = (chunk + gran - 1) / gran * gran;
-    if (P->spare_chunk != chunk) release_spare(P);
-    P->spare_chunk = chunk;
-    const size_t nch = (bytes + chunk - 1) / chunk;
+    const size_t nch = (bytes + skew + chunk - 1) / chunk;
+    auto &sp = P->spare[chunk];
     // a batch of new chunks: at least what this array needs, and at least "field_batch_mib" MiB, so that the shuffle mixes the chunks of several arrays
-    if (P->spare.size() < nch) {
+    if (sp.size() < nch) {
         const size_t batch_min = ((size_t)(h->field_batch_mib > 0 ? h->field_batch_mib : 0) << 20) / chunk;
-        const size_t want = std::max(nch - P->spare.size(), batch_min);
+        const size_t want = std::max(nch - sp.size(), batch_min);
         const auto t0 = Clock::now();
         for (size_t c = 0; c < want; c++) {
             hipMemGenericAllocationHandle_t hd;
             const hipError_t e = hipMemCreate(&hd, chunk, &prop, 0);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
-                if (P->spare.size() >= nch) break;             // the batch was a wish; the array itself is covered
+                if (sp.size() >= nch) break;             // the batch was a wish; the array itself is covered
                 return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemCreate(%zu MiB) -> %s after %lld chunks", chunk >> 20, hipGetErrorString(e), (long long)P->chunks_created);
             }
-            P->spare.push_back(hd);
+            sp.push_back(hd);
             P->chunks_created++;
         }
         P->create_ms += ms_since(t0);
     }
     // Fisher-Yates over the spare list, then the array takes the tail
     if (h->field_shuffle)
-        for (size_t i = P->spare.size(); i > 1; i--) std::swap(P->spare[i - 1], P->spare[next_rng(P->rng) % i]);
+        for (size_t i = sp.size(); i > 1; i--) std::swap(sp[i - 1], sp[next_rng(P->rng) % i]);
     const auto t1 = Clock::now();
     void *va = nullptr;
     size_t align = (size_t)(h->field_va_align_mib > 0 ? h->field_va_align_mib : 0) << 20;
@@ -111,41 +132,72 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, void **o
     }
     if (!in_arena) JRX_HIP(h, hipMemAddressReserve(&va, nch * chunk, align, nullptr, 0));
     jrx_field_pool::Alloc A;
-    A.bytes = bytes; A.kind = 1; A.chunk = chunk; A.in_arena = in_arena;
+    A.bytes = bytes; A.kind = 1; A.chunk = chunk; A.in_arena = in_arena; A.skew = skew;
     for (size_t c = 0; c < nch; c++) {
-        hipMemGenericAllocationHandle_t hd = P->spare.back();
+        hipMemGenericAllocationHandle_t hd = sp.back();
         const hipError_t e = hipMemMap((char *)va + c * chunk, chunk, 0, hd, 0);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             if (A.mapped) (void)hipMemUnmap(va, A.mapped);
-            for (auto x : A.chunks) P->spare.push_back(x);
+            for (auto x : A.chunks) sp.push_back(x);
             if (in_arena) P->arena_free.insert({nch * chunk, va}); else (void)hipMemAddressFree(va, nch * chunk);
             return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemMap -> %s", hipGetErrorString(e));
         }
-        P->spare.pop_back();
+        sp.pop_back();
         A.chunks.push_back(hd);
         A.mapped += chunk;
     }
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    const hipError_t e = hipMemSetAccess(va, nch * chunk, &acc, 1);
+    hipError_t e = hipMemSetAccess(va, nch * chunk, &acc, 1);
+    if (e == hipSuccess) e = flush_translations();       // the range may have been mapped before (arena sub-range, a reservation handed out again)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipMemUnmap(va, A.mapped);
-        for (auto x : A.chunks) P->spare.push_back(x);
+        for (auto x : A.chunks) sp.push_back(x);
         if (in_arena) P->arena_free.insert({nch * chunk, va}); else (void)hipMemAddressFree(va, nch * chunk);
-        return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemSetAccess -> %s", hipGetErrorString(e));
+        return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemSetAccess / flush -> %s", hipGetErrorString(e));
     }
     P->map_ms += ms_since(t1);
-    P->live[va] = std::move(A);
-    *out = va;
+    P->live[(char *)va + skew] = std::move(A);
+    *out = (char *)va + skew;
     return JRX_OK;
 }
-// Give one chunk-backed array new physical backing IN PLACE: its virtual range, and therefore every pointer the caller and the library hold, stays as it is.  New chunks (spare ones
-// first, in shuffled order; freshly created ones if the spare list is short) are mapped at a temporary range, the contents are copied, then the array's range is re-mapped onto them
-// and the old chunks join the spare list.  The device must be idle as far as this array is concerned (the caller's contract; the function synchronises the device itself).
-jrx_status reroll_one(jrx_handle *h, jrx_field_pool *P, void *va, jrx_field_pool::Alloc &A)
+// re-map the array at `key` onto `fresh` (as many chunks as it has now), contents carried over; on failure `fresh` stays with the caller
+jrx_status remap_with(jrx_handle *h, jrx_field_pool *P, void *key, jrx_field_pool::Alloc &A, const std::vector<hipMemGenericAllocationHandle_t> &fresh)
+{
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = h->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    // The contents travel through a plain hipMalloc buffer of the pool: out of the old chunks before the range is re-mapped, into the new ones after the translations have been flushed.
+    hipError_t e = hipSuccess;
+    const size_t chunk = A.chunk, nch = fresh.size();
+    void *va = (char *)key - A.skew;              // the mapped range starts `skew` bytes before the array
+    const size_t nw = (A.bytes + 7) / 8;          // the mapped range is a whole number of chunks
+    if (P->stage_bytes < nw * 8) {
+        if (P->stage) (void)hipFree(P->stage);
+        P->stage = nullptr; P->stage_bytes = 0;
+        e = hipMalloc(&P->stage, nw * 8);
+        if (e == hipSuccess) P->stage_bytes = nw * 8;
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_pool_copy, dim3(4096), dim3(256), 0, 0, (double *)P->stage, (const double *)key, nw); e = hipDeviceSynchronize(); }
+    if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_tuning_field_reroll: staging %zu bytes -> %s", A.bytes, hipGetErrorString(e)); }
+    e = hipMemUnmap(va, A.mapped);
+    for (size_t c = 0; c < nch && e == hipSuccess; c++) e = hipMemMap((char *)va + c * chunk, chunk, 0, fresh[c], 0);
+    if (e == hipSuccess) e = hipMemSetAccess(va, A.mapped, &acc, 1);
+    if (e == hipSuccess) e = flush_translations();
+    if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_tuning_field_reroll: re-mapping the array at %p -> %s (the array has lost its backing)", va, hipGetErrorString(e)); }
+    hipLaunchKernelGGL(k_pool_copy, dim3(4096), dim3(256), 0, 0, (double *)key, (const double *)P->stage, nw);
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_tuning_field_reroll: copying the contents back -> %s", hipGetErrorString(e)); }
+    return JRX_OK;
+}
+// Give one chunk-backed array new physical backing IN PLACE: its virtual range, and therefore every pointer the caller and the library hold, stays as it is; its contents are carried over.  New chunks: spare ones first, in shuffled order; freshly created ones if the spare list is short; the old chunks join the spare list.  An experiment
+// primitive (include/jrx_tuning.h), not part of the drop-in ABI.
+jrx_status reroll_one(jrx_handle *h, jrx_field_pool *P, void *key, jrx_field_pool::Alloc &A)
 {
     if (A.kind != 1) return JRX_OK;
     hipMemAllocationProp prop = {};
@@ -153,47 +205,43 @@ jrx_status reroll_one(jrx_handle *h, jrx_field_pool *P, void *va, jrx_field_pool
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = h->device;
     const size_t chunk = A.chunk, nch = A.chunks.size();
-    if (P->spare_chunk != chunk) { release_spare(P); P->spare_chunk = chunk; }
+    auto &sp = P->spare[chunk];
     const auto t0 = Clock::now();
-    while (P->spare.size() < nch) {
+    while (sp.size() < nch) {
         hipMemGenericAllocationHandle_t hd;
         const hipError_t e = hipMemCreate(&hd, chunk, &prop, 0);
-        if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_field_reroll: hipMemCreate(%zu MiB) -> %s", chunk >> 20, hipGetErrorString(e)); }
-        P->spare.push_back(hd);
+        if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_tuning_field_reroll: hipMemCreate(%zu MiB) -> %s", chunk >> 20, hipGetErrorString(e)); }
+        sp.push_back(hd);
         P->chunks_created++;
     }
     P->create_ms += ms_since(t0);
     if (h->field_shuffle)
-        for (size_t i = P->spare.size(); i > 1; i--) std::swap(P->spare[i - 1], P->spare[next_rng(P->rng) % i]);
+        for (size_t i = sp.size(); i > 1; i--) std::swap(sp[i - 1], sp[next_rng(P->rng) % i]);
     const auto t1 = Clock::now();
-    std::vector<hipMemGenericAllocationHandle_t> fresh(P->spare.end() - (long)nch, P->spare.end());
-    P->spare.resize(P->spare.size() - nch);
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    void *tmp = nullptr;
-    auto give_back = [&] { for (auto hd : fresh) P->spare.push_back(hd); };
-    hipError_t e = hipMemAddressReserve(&tmp, A.mapped, chunk < ((size_t)2 << 20) ? ((size_t)2 << 20) : 0, nullptr, 0);
-    if (e != hipSuccess) { (void)hipGetLastError(); give_back(); return jrx_fail(h, JRX_ERR_HIP, "jrx_field_reroll: hipMemAddressReserve -> %s", hipGetErrorString(e)); }
-    size_t mapped = 0;
-    for (size_t c = 0; c < nch && e == hipSuccess; c++) { e = hipMemMap((char *)tmp + c * chunk, chunk, 0, fresh[c], 0); if (e == hipSuccess) mapped += chunk; }
-    if (e == hipSuccess) e = hipMemSetAccess(tmp, A.mapped, &acc, 1);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(tmp, va, A.bytes, hipMemcpyDeviceToDevice);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (mapped) (void)hipMemUnmap(tmp, mapped);
-    (void)hipMemAddressFree(tmp, A.mapped);
-    if (e != hipSuccess) { (void)hipGetLastError(); give_back(); return jrx_fail(h, JRX_ERR_HIP, "jrx_field_reroll: staging the new chunks -> %s", hipGetErrorString(e)); }
-    // the switch: from here on a failure leaves the array without backing, which is reported as such
-    e = hipMemUnmap(va, A.mapped);
-    for (size_t c = 0; c < nch && e == hipSuccess; c++) e = hipMemMap((char *)va + c * chunk, chunk, 0, fresh[c], 0);
-    if (e == hipSuccess) e = hipMemSetAccess(va, A.mapped, &acc, 1);
-    if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_field_reroll: re-mapping the array at %p -> %s (the array has lost its backing)", va, hipGetErrorString(e)); }
-    for (auto hd : A.chunks) P->spare.push_back(hd);
+    std::vector<hipMemGenericAllocationHandle_t> fresh(sp.end() - (long)nch, sp.end());
+    sp.resize(sp.size() - nch);
+    { const jrx_status st = remap_with(h, P, key, A, fresh); if (st != JRX_OK) { for (auto hd : fresh) sp.push_back(hd); return st; } }
+    for (auto hd : A.prev) sp.push_back(hd);       // an earlier re-roll is thereby kept
+    A.prev = std::move(A.chunks);
     A.chunks = fresh;
     P->map_ms += ms_since(t1);
     P->rerolls++;
     return JRX_OK;
+}
+// back onto the chunks the array had before its last re-roll (nothing to do if there was none, or if it has been kept since)
+jrx_status undo_one(jrx_handle *h, jrx_field_pool *P, void *key, jrx_field_pool::Alloc &A)
+{
+    if (A.kind != 1 || A.prev.empty()) return JRX_OK;
+    JRX_TRY(remap_with(h, P, key, A, A.prev));
+    for (auto hd : A.chunks) P->spare[A.chunk].push_back(hd);
+    A.chunks = std::move(A.prev);
+    A.prev.clear();
+    return JRX_OK;
+}
+void keep_one(jrx_field_pool *P, jrx_field_pool::Alloc &A)
+{
+    for (auto hd : A.prev) P->spare[A.chunk].push_back(hd);
+    A.prev.clear();
 }
 }   // namespace
 
@@ -205,18 +253,29 @@ jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out)
     jrx_field_pool *P = pool_of(h);
     // small arrays never matter for the placement and would waste a chunk each
     const int kind = (h->field_placement == 1 && bytes < ((size_t)8 << 20)) ? 0 : h->field_placement;
+    // "field_skew_bytes": the k-th large array starts (k mod "field_skew_mod") * skew bytes into its allocation, so that element i of different arrays does not sit at the same
+    // offset of a 2 MiB page (all large allocations are 2 MiB-aligned otherwise); multiples of 256 B keep every alignment the kernels rely on
+    size_t skew = 0;
+    if (h->field_skew_bytes > 0 && bytes >= ((size_t)8 << 20)) {
+        const int mod = h->field_skew_mod > 0 ? h->field_skew_mod : 32;
+        skew = (size_t)(P->large_allocs++ % mod) * ((size_t)h->field_skew_bytes / 256 * 256);
+    }
     if (kind == 1) {
-        JRX_TRY(alloc_chunks(h, P, bytes, out));
+        JRX_TRY(alloc_chunks(h, P, bytes, skew, out));
     } else {
         void *p = nullptr;
         if (kind == 2) {
-            if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+            if (hipExtMallocWithFlags(&p, bytes + skew, hipDeviceMallocContiguous) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
         }
-        if (!p) JRX_HIP(h, hipMalloc(&p, bytes));
+        if (!p) JRX_HIP(h, hipMalloc(&p, bytes + skew));
         jrx_field_pool::Alloc A;
-        A.bytes = bytes; A.kind = kind;
-        P->live[p] = std::move(A);
-        *out = p;
+        A.bytes = bytes; A.kind = kind; A.skew = skew;
+        P->live[(char *)p + skew] = std::move(A);
+        *out = (char *)p + skew;
+    }
+    if (h->field_ballast_mib > 0 && bytes >= ((size_t)8 << 20)) {
+        void *b = nullptr;
+        if (hipMalloc(&b, (size_t)h->field_ballast_mib << 20) == hipSuccess) P->ballast.push_back(b); else (void)hipGetLastError();
     }
     P->bytes_live += (int64_t)bytes;
     return JRX_OK;
@@ -233,13 +292,14 @@ jrx_status jrx_dev_free(jrx_handle *h, void *p)
     if (A.kind == 1) {
         // nothing of this handle may still be using the range
         JRX_HIP(h, hipDeviceSynchronize());
-        JRX_HIP(h, hipMemUnmap(p, A.mapped));
-        if (A.in_arena) P->arena_free.insert({A.mapped, p});
-        else JRX_HIP(h, hipMemAddressFree(p, A.mapped));
-        if (A.chunk == P->spare_chunk) for (auto hd : A.chunks) P->spare.push_back(hd);
-        else for (auto hd : A.chunks) (void)hipMemRelease(hd);
+        void *va = (char *)p - A.skew;
+        JRX_HIP(h, hipMemUnmap(va, A.mapped));
+        if (A.in_arena) P->arena_free.insert({A.mapped, va});
+        else JRX_HIP(h, hipMemAddressFree(va, A.mapped));
+        for (auto hd : A.prev) A.chunks.push_back(hd);
+        for (auto hd : A.chunks) P->spare[A.chunk].push_back(hd);
     } else {
-        JRX_HIP(h, hipFree(p));
+        JRX_HIP(h, hipFree((char *)p - A.skew));
     }
     P->live.erase(it);
     return JRX_OK;
@@ -252,14 +312,18 @@ void jrx_pool_destroy(jrx_handle *h)
     (void)hipDeviceSynchronize();
     for (auto &kv : P->live) {
         if (kv.second.kind == 1) {
-            (void)hipMemUnmap(kv.first, kv.second.mapped);
-            if (!kv.second.in_arena) (void)hipMemAddressFree(kv.first, kv.second.mapped);
+            void *va = (char *)kv.first - kv.second.skew;
+            (void)hipMemUnmap(va, kv.second.mapped);
+            if (!kv.second.in_arena) (void)hipMemAddressFree(va, kv.second.mapped);
             for (auto hd : kv.second.chunks) (void)hipMemRelease(hd);
+            for (auto hd : kv.second.prev) (void)hipMemRelease(hd);
         } else {
-            (void)hipFree(kv.first);
+            (void)hipFree((char *)kv.first - kv.second.skew);
         }
     }
     release_spare(P);
+    for (void *b : P->ballast) (void)hipFree(b);
+    if (P->stage) (void)hipFree(P->stage);
     if (P->arena) (void)hipMemAddressFree(P->arena, P->arena_bytes);
     delete P;
     h->pool = nullptr;
@@ -283,17 +347,45 @@ jrx_status jrx_field_free(jrx_handle *h, double *p)
     return jrx_dev_free(h, p);
 }
 
-jrx_status jrx_field_reroll(jrx_handle *h, double *p)
+jrx_status jrx_tuning_field_reroll(jrx_handle *h, double *p)
 {
     if (!h) return JRX_ERR_ARG;
     JRX_TRY(jrx_check_device(h));
     jrx_field_pool *P = pool_of(h);
     if (p) {
         auto it = P->live.find(p);
-        if (it == P->live.end()) return jrx_fail(h, JRX_ERR_ARG, "jrx_field_reroll: %p was not allocated by jrx_field_alloc on this handle", (void *)p);
+        if (it == P->live.end()) return jrx_fail(h, JRX_ERR_ARG, "jrx_tuning_field_reroll: %p was not allocated by jrx_field_alloc on this handle", (void *)p);
         return reroll_one(h, P, it->first, it->second);
     }
     for (auto &kv : P->live) JRX_TRY(reroll_one(h, P, kv.first, kv.second));
+    return JRX_OK;
+}
+
+jrx_status jrx_tuning_field_undo(jrx_handle *h, double *p)
+{
+    if (!h) return JRX_ERR_ARG;
+    JRX_TRY(jrx_check_device(h));
+    jrx_field_pool *P = pool_of(h);
+    if (p) {
+        auto it = P->live.find(p);
+        if (it == P->live.end()) return jrx_fail(h, JRX_ERR_ARG, "jrx_tuning_field_undo: %p was not allocated by jrx_field_alloc on this handle", (void *)p);
+        return undo_one(h, P, it->first, it->second);
+    }
+    for (auto &kv : P->live) JRX_TRY(undo_one(h, P, kv.first, kv.second));
+    return JRX_OK;
+}
+
+jrx_status jrx_tuning_field_keep(jrx_handle *h, double *p)
+{
+    if (!h) return JRX_ERR_ARG;
+    jrx_field_pool *P = pool_of(h);
+    if (p) {
+        auto it = P->live.find(p);
+        if (it == P->live.end()) return jrx_fail(h, JRX_ERR_ARG, "jrx_tuning_field_keep: %p was not allocated by jrx_field_alloc on this handle", (void *)p);
+        keep_one(P, it->second);
+        return JRX_OK;
+    }
+    for (auto &kv : P->live) keep_one(P, kv.second);
     return JRX_OK;
 }
 
@@ -316,7 +408,10 @@ jrx_status jrx_field_trim(jrx_handle *h)
 {
     if (!h) return JRX_ERR_ARG;
     JRX_TRY(jrx_check_device(h));
-    if (h->pool) release_spare(h->pool);
+    if (h->pool) {
+        release_spare(h->pool);
+        if (h->pool->stage) { (void)hipFree(h->pool->stage); h->pool->stage = nullptr; h->pool->stage_bytes = 0; }
+    }
     return JRX_OK;
 }
 
@@ -328,7 +423,8 @@ jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6])
     out[0] = (int64_t)P->live.size();
     out[1] = P->bytes_live;
     out[2] = P->chunks_created;
-    out[3] = (int64_t)P->spare.size();
+    out[3] = 0;
+    for (auto &kv : P->spare) out[3] += (int64_t)kv.second.size();
     out[4] = (int64_t)(P->create_ms * 1e3);      // microseconds spent in hipMemCreate
     out[5] = (int64_t)(P->map_ms * 1e3);         // microseconds spent reserving, mapping and setting access
     return JRX_OK;

@@ -27,6 +27,8 @@ struct jrx_handle {
     int field_placement = 0;             // option: 0 hipMalloc, 1 physical chunks mapped in shuffled order (virtual memory management), 2 physically contiguous (A/B: the slow rate)
     int field_chunk_mib = 64, field_batch_mib = 0, field_va_align_mib = 0;   // tuning: chunk size, smallest batch of new chunks, alignment of the reserved virtual range
     bool field_shuffle = true;           // tuning: 0 = chunks in creation order (A/B of the shuffle itself)
+    int field_ballast_mib = 0;                       // tuning: an unused allocation of that size behind every large array (placement experiments)
+    int field_skew_bytes = 0, field_skew_mod = 32;    // tuning: the k-th large array starts (k mod field_skew_mod) * field_skew_bytes into its allocation (csrc/fieldpool.hip)
     int field_arena_gib = 0, field_va_gap_mib = 0;   // tuning: > 0 = the chunk-backed arrays are placed in ONE reserved virtual range of that size, one behind the other, this many MiB apart
     double *scratch_base[10] = {};       // what hipMalloc returned for scratch[q] (scratch[q] may start scratch_stagger * q bytes into it)
     bool scratch_contiguous = false;     // tuning switch: the second 3D state set in physically contiguous device memory (hipDeviceMallocContiguous)

@@ -39,7 +39,7 @@ def probe():
 
 def reroll(p=None):
     torch.cuda.synchronize()
-    h.call("jrx_field_reroll", C.c_void_p(p or 0))
+    h.call("jrx_tuning_field_reroll", C.c_void_p(p or 0))
 
 
 names = {}

@@ -60,6 +60,65 @@ def test_alloc_write_read_free(jr, placement, chunk):
         h.close()
 
 
+@pytest.mark.parametrize("arena_gib,gap_mib", [(0, 0), (4, 0), (4, 6)])
+def test_reroll_keeps_pointers_and_contents_and_the_arena_places_arrays_in_one_range(jr, arena_gib, gap_mib):
+    """jrx_tuning_field_reroll gives chunk-backed arrays new physical chunks under the same pointers and carries the contents over (the experiment primitive of round 5); with
+    "field_arena_gib" the arrays lie one behind the other in ONE reserved virtual range, "field_va_gap_mib" apart; jrx_field_list names them."""
+    import torch
+    from justrelax_jl_amd import _lib, arrays
+    h = _lib.Handle(0)
+    try:
+        h.set_option("field_placement", 1)
+        h.set_option("field_chunk_mib", 2)
+        h.set_option("field_arena_gib", arena_gib)
+        h.set_option("field_va_gap_mib", gap_mib)
+        arrays.use_library_arrays(h)
+        shapes = [(257, 130, 67), (1200, 1100), (300, 300, 30)]        # 17.9, 10.6, 21.6 MB: chunk-backed
+        rng = np.random.default_rng(3)
+        ts, ref = [], []
+        for sh in shapes:
+            a = rng.standard_normal(sh)
+            t = jr.fzeros(sh, "cuda")
+            t.copy_(torch.from_numpy(a).to("cuda"))
+            ts.append(t); ref.append(a)
+        ptrs0 = [t.data_ptr() for t in ts]
+        if arena_gib:
+            sz = [-(-int(np.prod(sh)) * 8 // (2 << 20)) * (2 << 20) for sh in shapes]
+            assert ptrs0[1] - ptrs0[0] == sz[0] + (gap_mib << 20) and ptrs0[2] - ptrs0[1] == sz[1] + (gap_mib << 20), (ptrs0, sz)
+        created0 = _stats(h)[2]
+        torch.cuda.synchronize()
+        h.call("jrx_tuning_field_reroll", C.c_void_p(ptrs0[1]))          # one array
+        h.call("jrx_tuning_field_reroll", C.c_void_p(0))                # all of them
+        assert _stats(h)[2] > created0                            # new physical chunks were created for the first re-roll
+        assert [t.data_ptr() for t in ts] == ptrs0
+        for t, a in zip(ts, ref):
+            assert np.array_equal(t.cpu().numpy(), a)
+        t2 = ts[0] * 2.0                                          # the re-mapped arrays are ordinary device memory for every later kernel
+        assert np.array_equal(t2.cpu().numpy(), ref[0] * 2.0)
+        for t, a in zip(ts, ref):                                 # writes behind the re-mapping land where later reads see them (the translation flush of csrc/fieldpool.hip)
+            t.copy_(torch.from_numpy(a + 1.0).to("cuda"))
+        torch.cuda.synchronize()
+        for t, a in zip(ts, ref):
+            assert np.array_equal(t.cpu().numpy(), a + 1.0)
+        cnt, pl, nb = C.c_int64(), (C.c_void_p * 16)(), (C.c_int64 * 16)()
+        h.call("jrx_field_list", C.c_int64(16), pl, nb, C.byref(cnt))
+        assert cnt.value == 3 and sorted(pl[i] for i in range(3)) == sorted(ptrs0) and all(nb[i] > 0 for i in range(3))
+        with pytest.raises(_lib.JrxError):
+            h.call("jrx_tuning_field_reroll", C.c_void_p(ptrs0[0] + 8))
+        del ts, t, t2
+        torch.cuda.synchronize()
+        assert _stats(h)[0] == 0
+        # a freed range of the arena is handed out again to an array of the same size
+        if arena_gib:
+            t = jr.fzeros(shapes[0], "cuda", fill=3.0)
+            assert t.data_ptr() == ptrs0[0]
+            assert float(t.min()) == float(t.max()) == 3.0
+            del t
+    finally:
+        arrays.use_library_arrays(None)
+        h.close()
+
+
 def test_free_of_a_foreign_pointer_is_an_error(jr):
     import torch
     from justrelax_jl_amd import _lib
@@ -93,6 +152,50 @@ def test_solve_on_library_arrays_gives_the_same_bits(jr, placement):
             h.close()
     (ra, a, sa), (rb, b, sb) = outs
     assert sa[0] <= 11 and sb[0] > 30, (sa, sb)        # torch's arrays: only the library's own; library arrays: the caller's too
+    assert ra.iter == rb.iter and list(ra.err_evo1) == list(rb.err_evo1)
+    for k in a:
+        m = checks.interior_mask3d(k, a[k].shape)
+        assert np.array_equal(a[k][m], b[k][m], equal_nan=True), k
+
+
+def test_placement_search_keeps_addresses_and_a_restored_state_solves_to_the_same_bits(jr):
+    """jrx_stokes3d_tune_placement: draws of new physical chunks under the arrays, the loop body timed on each, the fastest kept.  Pointers stay; the fields are advanced by the probes,
+    so the initial state is written back -- and the solve that follows gives the bits of a solve on arrays that were never moved."""
+    from justrelax_jl_amd import _lib, arrays, checks, stokes
+    from justrelax_jl_amd.miniapps.common import download_stokes, stokes_field_names, upload_stokes, _get
+    from justrelax_jl_amd.arrays import from_numpy
+    outs = []
+    for tune in (False, True):
+        h = _lib.Handle(0)
+        try:
+            h.set_option("field_placement", 1)
+            h.set_option("field_chunk_mib", 0 if tune else 2)
+            arrays.use_library_arrays(h)
+            s = jr.miniapps.random_fields3d((130, 96, 100), seed=5, iterMax=40, nout=20)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+            st, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
+            if tune:
+                ητ = jr.fzeros(s.ni, st.P.device)
+                jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
+                ptr0 = [st.P.data_ptr(), st.V.Vx.data_ptr(), st.τ.xy.data_ptr(), ητ.data_ptr()]
+                created0 = _stats(h)[2]
+                ms, kept = stokes.tune_placement_(st, s.pt, s.grid, s.flow_bcs, ρg, K, G, ητ, s.dt, 3, 4, handle=h)
+                assert len(ms) == 5 and all(m > 0 for m in ms) and 0 <= kept <= 3
+                assert [st.P.data_ptr(), st.V.Vx.data_ptr(), st.τ.xy.data_ptr(), ητ.data_ptr()] == ptr0
+                assert _stats(h)[2] > created0 and _stats(h)[3] == 0        # draws were made, and the chunks of those that lost went back to the driver
+                for name, path in stokes_field_names(3).items():             # the initial state again
+                    if name in s.arrays:
+                        _get(st, path).copy_(from_numpy(s.arrays[name], st.P.device))
+                    else:
+                        _get(st, path).zero_()
+                del ητ
+            r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs, handle=h)
+            outs.append((r, download_stokes(st)))
+            del st, ρg, K, G
+        finally:
+            arrays.use_library_arrays(None)
+            h.close()
+    (ra, a), (rb, b) = outs
     assert ra.iter == rb.iter and list(ra.err_evo1) == list(rb.err_evo1)
     for k in a:
         m = checks.interior_mask3d(k, a[k].shape)
