@@ -75,6 +75,15 @@ const char *jrx_build_id(void);
 jrx_status jrx_field_alloc(jrx_handle *h, int64_t count, double **out);     /* count doubles */
 jrx_status jrx_field_free(jrx_handle *h, double *p);
 jrx_status jrx_field_trim(jrx_handle *h);
+/* jrx_field_tune: the placement search.  Chunk-backed arrays ("field_placement" = 1: the caller's from jrx_field_alloc and the library's own) can be given other physical memory
+ * without their addresses or contents changing, and the time of the large kernels depends on that memory (4.7 .. 6.2 ms for the same launch at 512^3, 0.67 / 0.79 ms at 256^3 on one
+ * device: profiles/r05_placement.txt) in a way only a run can tell.  So: `draws` times, new chunks under every chunk-backed array of the handle, probe(ctx) -- the caller runs
+ * what it is going to run and returns its time in ms (> 0) -- and the draw is kept if it beat the best so far by 0.3 %, undone otherwise.  ms[0] = as allocated, ms[1 .. draws] = the
+ * draws (-1: not made -- a draw needs room for a second copy of the arrays; the search ends when there is none), ms[draws + 1] = the placement that stays (measured again);
+ * *kept = draws kept.  Whatever the probe does to the arrays' contents is the caller's business (run it before the initial state is written, or write it again).  With neighbours
+ * every rank calls it with the same `draws` and a probe that does the same exchanges. */
+typedef double (*jrx_probe_fn)(void *ctx);
+jrx_status jrx_field_tune(jrx_handle *h, int32_t draws, jrx_probe_fn probe, void *ctx, double *ms, int32_t *kept);
 /* jrx_field_list: the live arrays of the handle (bytes[i] < 0: not chunk-backed), count = how many there are (may exceed cap). */
 jrx_status jrx_field_list(jrx_handle *h, int64_t cap, double **ptrs, int64_t *bytes, int64_t *count);
 jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
@@ -656,13 +665,8 @@ jrx_status jrx_compute_shear_heating(jrx_handle *h, double *shear_heating, const
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
                                       const jrx_stokes3d_params *p, int64_t iters, double times_ms[6]);
 
-/* Placement search for the arrays of one 3D Stokes problem.  Arrays of jrx_field_alloc with "field_placement" = 1 (and the library's own, which follow the same option) can be given
- * other physical memory without their addresses or contents changing; the time of the large kernels depends on that memory (4.7 .. 6.2 ms per launch at 512^3 on the same device,
- * profiles/r05_placement.txt) in a way only a run can tell.  `draws` times: new chunks for every chunk-backed array of the handle, `iters` (>= 2) iterations of the loop body timed as by
- * jrx_stokes3d_iterate_timed, keep the draw if it beat the best so far (by 0.3 %), undo it otherwise.  ms_per_iter[0] = as allocated, [1 .. draws] = the draws (-1: not made -- a draw
- * needs room for a second copy of the arrays, the search ends when there is none), [draws + 1] = the placement that stays; *kept = draws kept.  The fields are advanced by all those
- * iterations: call it before the initial state is written (or write it again).  Arrays of other allocators are left alone (with none chunk-backed the call only measures).  With
- * neighbours every rank calls it with the same draws and iters. */
+/* jrx_field_tune with the 3D Stokes loop body as the probe: `iters` (>= 2) iterations timed as by jrx_stokes3d_iterate_timed per draw; ms_per_iter as ms of jrx_field_tune, per
+ * iteration.  The fields are advanced by all those iterations: call it before the initial state is written (or write it again). */
 jrx_status jrx_stokes3d_tune_placement(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, int32_t draws, int64_t iters,
                                        double *ms_per_iter, int32_t *kept);
 

@@ -1,18 +1,19 @@
 // fieldpool.hip -- device memory for the state arrays, owned by the library (jrx_field_alloc / jrx_field_free).
 //
 // Replaces the array constructor the backend owns in the reference: StokesArrays(::Type{AMDGPUBackend}, ni) -> @zeros(ni...) -> ROCArray
-// (src/ext/AMDGPU/3D.jl:46-48, src/types/constructors/stokes.jl:279-303).  Why the library wants a say in it: the 512^3 kernels run at one of
-// two rates for a process's lifetime depending on how the driver happened to back the arrays physically (profiles/r04_alloc_stagger.txt;
-// contiguous backing = the slow rate).  hipMalloc gives nobody a say; the virtual-memory-management API does: an array is one reserved
-// virtual range onto which physical chunks are mapped in an order the pool chooses.
+// (src/ext/AMDGPU/3D.jl:46-48, src/types/constructors/stokes.jl:279-303).  Why the library wants a say in it: the same launch of the 512^3 kernel takes
+// 4.7 .. 6.9 ms depending on which physical pages its arrays got (profiles/r05_placement_search.txt) -- same traffic, same plain bandwidth, nothing but a
+// run tells.  hipMalloc gives nobody a say; the virtual-memory-management API does: an array is one reserved virtual range onto which physical chunks are
+// mapped, and the chunks under it can be exchanged IN PLACE (jrx_tuning_field_reroll / _undo / _keep), which is what the placement search (jrx_field_tune) does.
 //
 // Placement kinds ("field_placement"):
 //   0  hipMalloc (what a ROCArray / torch tensor gets)
 //   1  chunks: hipMemCreate handles of "field_chunk_mib" MiB, created in batches, handed to the arrays in shuffled order (a fixed LCG: the same
 //      sequence of requests gives the same chunk order), mapped with hipMemMap, one hipMemSetAccess per array
-//   2  physically contiguous (hipDeviceMallocContiguous): the reproducer of the slow rate, for A/B runs only
+//   2  physically contiguous (hipDeviceMallocContiguous): the slowest placement there is, for A/B runs only
 // Host-only code; every entry point requires the handle's device to be current.
 #include "jrx_internal.hpp"
+#include "jrx_tuning.h"
 #include <algorithm>
 #include <chrono>
 #include <map>
@@ -28,9 +29,7 @@ struct jrx_field_pool {
     std::vector<void *> ballast;                  // "field_ballast_mib": allocations nobody uses, made behind every large array so that the arrays spread over the device's memory
     void *stage = nullptr;                        // jrx_tuning_field_reroll: the contents of the array being re-mapped
     size_t stage_bytes = 0;
-    // the arena: ONE reserved virtual range in which the chunk-backed arrays are placed one behind the other, `gap` bytes apart -- the rate of the large kernels turned out to
-    // depend on the arrays' VIRTUAL addresses (re-rolling the physical chunks under fixed addresses changes nothing, new addresses do: profiles/r05_placement.txt), and this is
-    // what makes them a choice instead of a draw
+    // the arena ("field_arena_gib", an experiment knob): ONE reserved virtual range in which the chunk-backed arrays are placed one behind the other, `gap` bytes apart
     char *arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
     std::multimap<size_t, void *> arena_free;     // released sub-ranges by size, reused for arrays of exactly that size
@@ -386,6 +385,52 @@ jrx_status jrx_tuning_field_keep(jrx_handle *h, double *p)
         return JRX_OK;
     }
     for (auto &kv : P->live) keep_one(P, kv.second);
+    return JRX_OK;
+}
+
+// The placement search (include/jrx.h): draw, let the caller's probe time whatever it is going to run, keep the draw if it is the fastest so far, undo it otherwise.
+jrx_status jrx_field_tune(jrx_handle *h, int32_t draws, jrx_probe_fn probe, void *ctx, double *ms, int32_t *kept)
+{
+    if (!h) return JRX_ERR_ARG;
+    JRX_TRY(jrx_check_device(h));
+    if (draws < 0 || draws > 64) return jrx_fail(h, JRX_ERR_ARG, "jrx_field_tune: draws = %d (0 .. 64)", (int)draws);
+    if (!probe || !ms) return jrx_fail(h, JRX_ERR_ARG, "jrx_field_tune: probe / ms is NULL");
+    for (int d = 0; d <= draws + 1; d++) ms[d] = -1.0;
+    // with neighbours every rank makes the same number of probes (they may exchange halos), whatever its own draws come to: a rank that cannot draw (no room) says so to all
+    auto agree = [&](bool ok, bool *all) -> jrx_status {
+        double v = ok ? 0.0 : 1.0;
+        if (jrx_comm_active(h)) JRX_TRY(jrx_allreduce_host(h, &v, 1, 1));
+        *all = v == 0.0;
+        return JRX_OK;
+    };
+    auto run = [&](double *out) -> jrx_status {
+        const double t = probe(ctx);
+        if (!(t > 0.0)) return jrx_fail(h, JRX_ERR_ARG, "jrx_field_tune: the probe returned %g (it reports milliseconds, > 0)", t);
+        *out = t;
+        return JRX_OK;
+    };
+    double best = 0.0;
+    JRX_TRY(run(&best));
+    ms[0] = best;
+    int nk = 0;
+    for (int d = 0; d < draws; d++) {
+        const jrx_status st = jrx_tuning_field_reroll(h, nullptr);
+        bool all = false;
+        JRX_TRY(agree(st == JRX_OK, &all));
+        if (!all) {                                    // some rank could not make the draw: everybody goes back to what it had and the search ends
+            JRX_TRY(jrx_tuning_field_undo(h, nullptr));
+            break;
+        }
+        double t = 0.0;
+        const jrx_status sp = run(&t);
+        if (sp != JRX_OK) { (void)jrx_tuning_field_undo(h, nullptr); return sp; }
+        ms[d + 1] = t;
+        if (t < best * 0.997) { best = t; nk++; JRX_TRY(jrx_tuning_field_keep(h, nullptr)); }
+        else JRX_TRY(jrx_tuning_field_undo(h, nullptr));
+    }
+    JRX_TRY(jrx_field_trim(h));                        // the chunks of the draws that lost go back to the driver
+    JRX_TRY(run(&ms[draws + 1]));
+    if (kept) *kept = nk;
     return JRX_OK;
 }
 

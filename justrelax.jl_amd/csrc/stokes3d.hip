@@ -1482,46 +1482,16 @@ jrx_status jrx_stokes3d_tune_placement(jrx_handle *h, const jrx_stokes3d_fields 
                                        double *ms_per_iter, int32_t *kept)
 {
     JRX_TRY(check_params(h, f, p));
-    if (draws < 0 || draws > 64) return jrx_fail(h, JRX_ERR_ARG, "jrx_stokes3d_tune_placement: draws = %d (0 .. 64)", (int)draws);
     if (iters < 2) return jrx_fail(h, JRX_ERR_ARG, "jrx_stokes3d_tune_placement: iters must be >= 2");
-    if (!ms_per_iter) return jrx_fail(h, JRX_ERR_ARG, "jrx_stokes3d_tune_placement: ms_per_iter is NULL");
-    double t[6];
-    auto probe = [&](double *out) -> jrx_status {
-        JRX_TRY(jrx_stokes3d_iterate_timed(h, f, etatau, p, 2, t));       // the first launches behind a re-mapping also pay for the translations
-        JRX_TRY(jrx_stokes3d_iterate_timed(h, f, etatau, p, iters, t));
-        *out = t[0] / (double)iters;
-        return JRX_OK;
+    struct Ctx { jrx_handle *h; const jrx_stokes3d_fields *f; const double *etatau; const jrx_stokes3d_params *p; int64_t iters; } c{h, f, etatau, p, iters};
+    auto probe = [](void *v) -> double {
+        Ctx *c = (Ctx *)v;
+        double t[6];
+        if (jrx_stokes3d_iterate_timed(c->h, c->f, c->etatau, c->p, 2, t) != JRX_OK) return -1.0;        // the first launches behind a re-mapping also pay for the translations
+        if (jrx_stokes3d_iterate_timed(c->h, c->f, c->etatau, c->p, c->iters, t) != JRX_OK) return -1.0;
+        return t[0] / (double)c->iters;
     };
-    // with neighbours every rank makes the same number of probes (they exchange halos), whatever its own draws come to: a rank that cannot draw (out of memory) says so to all
-    auto all_ok = [&](bool ok, bool *all) -> jrx_status {
-        double v = ok ? 0.0 : 1.0;
-        if (jrx_comm_active(h)) JRX_TRY(jrx_allreduce_host(h, &v, 1, 1));
-        *all = v == 0.0;
-        return JRX_OK;
-    };
-    for (int d = 0; d <= draws + 1; d++) ms_per_iter[d] = -1.0;
-    double best = 0.0;
-    JRX_TRY(probe(&best));
-    ms_per_iter[0] = best;
-    int nk = 0;
-    for (int d = 0; d < draws; d++) {
-        const jrx_status st = jrx_tuning_field_reroll(h, nullptr);
-        bool all = false;
-        JRX_TRY(all_ok(st == JRX_OK, &all));
-        if (!all) {                                                        // some rank could not make the draw: everybody goes back to what it had and the search ends
-            JRX_TRY(jrx_tuning_field_undo(h, nullptr));
-            break;
-        }
-        double ms = 0.0;
-        JRX_TRY(probe(&ms));
-        ms_per_iter[d + 1] = ms;
-        if (ms < best * 0.997) { best = ms; nk++; JRX_TRY(jrx_tuning_field_keep(h, nullptr)); }
-        else JRX_TRY(jrx_tuning_field_undo(h, nullptr));
-    }
-    JRX_TRY(jrx_field_trim(h));                                            // the chunks of the draws that lost go back to the driver
-    JRX_TRY(probe(&ms_per_iter[draws + 1]));
-    if (kept) *kept = nk;
-    return JRX_OK;
+    return jrx_field_tune(h, draws, probe, &c, ms_per_iter, kept);
 }
 
 }   // extern "C"

@@ -123,6 +123,8 @@ def _c_param_to_julia(prm: str) -> str:
         return f"Ref{{{julia_name(m.group(1))}}}"
     if p.startswith("char *"):
         return "Cstring"
+    if p.startswith("void *") or re.match(r"jrx_\w+_fn\b", p):      # an opaque context pointer; a callback (typedef ... (*jrx_xxx_fn)(...): @cfunction pointer)
+        return "Ptr{Cvoid}"
     m = re.match(r"(double|int32_t|int64_t|uint32_t|uint8_t)\s*(.*)$", p)
     assert m, f"unparsed parameter {prm!r}"
     base, rest = C2J[m.group(1)], m.group(2).strip()
