@@ -414,7 +414,8 @@ jrx_status jrx_field_tune(jrx_handle *h, int32_t draws, jrx_probe_fn probe, void
     ms[0] = best;
     int nk = 0;
     for (int d = 0; d < draws; d++) {
-        const jrx_status st = jrx_tuning_field_reroll(h, nullptr);
+        // test switch "field_test_fail_draw" = k: this rank's k-th draw fails as if there were no room (tests/test_gpu_two_blocks.py: the ranks must stop together)
+        const jrx_status st = h->field_test_fail_draw == d + 1 ? JRX_ERR_HIP : jrx_tuning_field_reroll(h, nullptr);
         bool all = false;
         JRX_TRY(agree(st == JRX_OK, &all));
         if (!all) {                                    // some rank could not make the draw: everybody goes back to what it had and the search ends
