@@ -423,30 +423,52 @@ def state_tensors(obj, _seen=None):
             yield from state_tensors(getattr(obj, k, None), seen)
 
 
-def cfg_solvi(jr, h, n, steps, warm):
+def cfg_solvi(jr, h, n, steps, warm, draws=8):
     """SolVi3D at n^3 through the same timed batch as the headline (BASELINE configs[2] at n = 256)."""
     import torch
     import justrelax_jl_amd.grid as grid
     from justrelax_jl_amd import stokes
     from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device
+    from justrelax_jl_amd import arrays as _arrays
     grid.finalize_global_grid()
     grid.init_global_grid(n, n, n, rank=0, nprocs=1)
-    st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
-    jr.flow_bcs_(st, bcs, handle=h)
-    ητ = jr.fzeros((n, n, n), st.P.device)
-    jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
-    run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
-    run(warm)
-    torch.cuda.synchronize()
-    f0 = counters(h)
-    t0 = time.perf_counter()
-    tot_ms, sa, sb, sf, sk, kcells = run(steps)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    search = None
+    if draws > 0:                  # as the headline does: the arrays from the library's chunk allocator, the placement searched before anything is timed
+        h.set_option("field_placement", 1)
+        h.set_option("field_chunk_mib", 0)
+        _arrays.use_library_arrays(h)
+    try:
+        st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
+        jr.flow_bcs_(st, bcs, handle=h)
+        ητ = jr.fzeros((n, n, n), st.P.device)
+        jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
+        if draws > 0:
+            ts = time.perf_counter()
+            held = [(t, t.clone()) for t in state_tensors(st)]
+            ms_draws, kept = stokes.tune_placement_(st, pt, geo, bcs, ρg, K, G, ητ, dt, draws, 24, handle=h)
+            for t, c in held:
+                t.copy_(c)
+            del held
+            search = {"draws": draws, "kept": kept, "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_of_the_draws": ms_draws[1:-1], "ms_per_iteration_kept": ms_draws[-1],
+                      "seconds": time.perf_counter() - ts}
+        run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
+        run(warm)
+        torch.cuda.synchronize()
+        f0 = counters(h)
+        t0 = time.perf_counter()
+        tot_ms, sa, sb, sf, sk, kcells = run(steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        if draws > 0:
+            _arrays.use_library_arrays(None)
+            st = ρg = K = G = ητ = None
+            torch.cuda.empty_cache()
+            h.set_option("field_placement", 0)
     cells = float(n) ** 3
     pr = pricing(h, dt, nof_ran(h, f0))
     out = {"workload": f"SolVi3D {n}^3", "form": pr["form"], "bytes_per_cell": pr["alg"], "steps": steps, "it_per_s": steps / el, "ms_per_step": el / steps * 1e3,
-           "frac_whole_iteration": pr["alg"] * cells * steps / el / 1e9 / HBM_PEAK_GBS}
+           "frac_whole_iteration": pr["alg"] * cells * steps / el / 1e9 / HBM_PEAK_GBS, "placement_search": search}
     if sk > 0:
         out["kernel"] = "k_fused3d"
         out["avg_launch_ms"] = sk
