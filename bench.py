@@ -904,6 +904,7 @@ class GpuRanks:
         self.blk = None
         self.transport = None
         self.dims = None
+        self.placement_search = None
 
     def grid_dims(self, mode):
         if mode in ("x", "y", "z"):
@@ -944,15 +945,68 @@ class GpuRanks:
             raise ValueError(transport)
         self.transport = transport
         n = self.n
-        if self.blk is None:
-            uh = lambda a: halo.update_halo_(a, ni=(n, n, n), handle=self.h)
-            st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, self.jr.AMDGPUBackend, update_halo=uh)
-            self.jr.flow_bcs_(st, bcs, handle=self.h)
-            ητ = self.jr.fzeros((n, n, n), self.dev)
-            self.jr.compute_maxloc_(ητ, st.viscosity.η, handle=self.h)
+        fresh = self.blk is None
+        if fresh:
+            # as at N = 1: the block's arrays come from the library's chunk allocator and the placement is searched before anything is timed -- the slowest rank paces a weak-scaling
+            # run, and which physical pages a rank's arrays got moves its kernel by up to 30 % (profiles/r05_placement_search.txt)
+            searching = self.args.placement_draws > 0 and self.h.get_option("field_placement") in (0, 1)
+            if searching:
+                searching = self._library_arrays_everywhere()
+            try:
+                uh = lambda a: halo.update_halo_(a, ni=(n, n, n), handle=self.h)
+                st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, self.jr.AMDGPUBackend, update_halo=uh)
+                self.jr.flow_bcs_(st, bcs, handle=self.h)
+                ητ = self.jr.fzeros((n, n, n), self.dev)
+                self.jr.compute_maxloc_(ητ, st.viscosity.η, handle=self.h)
+            finally:
+                if searching:
+                    from justrelax_jl_amd import arrays as _arrays
+                    _arrays.use_library_arrays(None)
             self.blk = (st, pt, geo, bcs, ρg, K, G, ητ, dt)
         st, ητ = self.blk[0], self.blk[7]
         halo.update_halo_(st.V.Vx, st.V.Vy, st.V.Vz, ητ, ni=(n, n, n), handle=self.h)
+        if fresh and searching:
+            import torch
+            from justrelax_jl_amd import stokes
+            ts = time.perf_counter()
+            held = [(t, t.clone()) for t in state_tensors(st)]
+            ms_draws, kept = stokes.tune_placement_(*self.blk, self.args.placement_draws, 12, handle=self.h)      # every rank: the probes exchange halos, the draws are agreed on
+            for t, c in held:
+                t.copy_(c)
+            del held
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            halo.update_halo_(st.V.Vx, st.V.Vy, st.V.Vz, ητ, ni=(n, n, n), handle=self.h)
+            self.placement_search = {"draws": self.args.placement_draws, "kept": kept, "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_of_the_draws": ms_draws[1:-1],
+                                     "ms_per_iteration_kept": ms_draws[-1], "seconds": time.perf_counter() - ts}
+
+    def _library_arrays_everywhere(self):
+        """field_placement = 1 and the constructors routed through jrx_field_alloc -- on every rank or on none (a rank whose driver refuses the virtual-memory calls keeps torch's arrays,
+        and then so do all: the search is collective)"""
+        import torch
+        import torch.distributed as dist
+        from justrelax_jl_amd import arrays as _arrays
+        self.h.set_option("field_placement", 1)
+        if not any(kv.startswith("field_chunk_mib=") for kv in self.args.option):
+            self.h.set_option("field_chunk_mib", 0)
+        _arrays.use_library_arrays(self.h)
+        ok = 1.0
+        try:
+            t = self.jr.fzeros((64, 64, 600), self.dev)      # 19.7 MB: chunk-backed
+            del t
+        except Exception as e:      # noqa: BLE001
+            ok = 0.0
+            self.placement_search = {"note": f"library arrays refused ({type(e).__name__}: {e}); torch's arrays, no search"}
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            t_ok = torch.tensor([ok])
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            ok = float(t_ok.item())
+        if ok == 0.0:
+            _arrays.use_library_arrays(None)
+            self.h.set_option("field_placement", 0)
+            self.placement_search = self.placement_search or {"note": "another rank could not use library arrays; torch's arrays, no search"}
+            return False
+        return True
 
     def comm_count(self):
         import ctypes as C
@@ -1396,7 +1450,7 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
         pr = pricing(R.h, R.blk[8], nof_ran(R.h, f0))
     ctl.barrier()
     # per rank: the launch time of the dominant kernel and the device's clock / power during the timed batch -- the slowest rank paces a weak-scaling run, and its reason should be readable
-    per_rank = ctl.gather({"rank": rank, "k_fused3d_ms": sk_ms, "device_state": my_state})
+    per_rank = ctl.gather({"rank": rank, "k_fused3d_ms": sk_ms, "device_state": my_state, "placement_search": getattr(R, "placement_search", None)})
     el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells = ctl.max([el, tot_ms, sa_ms, sb_ms, sf_ms, sk_ms, kcells])
     steady = None
     if args.steps < 50 and not args.no_steady_state:
@@ -1443,6 +1497,7 @@ def run_multi(args, world, rank, local_rank, json_fd) -> int:
     if isinstance(out.get("roofline"), dict) and per_rank:
         out["roofline"]["launch_ms_per_rank"] = [p.get("k_fused3d_ms") for p in per_rank]
         out["roofline"]["device_state_per_rank"] = [p.get("device_state") for p in per_rank]
+        out["roofline"]["placement_search_per_rank"] = [p.get("placement_search") for p in per_rank]
 
     def emit(note=None):
         if note:
@@ -1561,6 +1616,27 @@ def run_rank(args) -> int:
         if not any(kv.startswith("field_chunk_mib=") for kv in args.option):
             h.set_option("field_chunk_mib", 0)
         _arrays.use_library_arrays(h)
+    placement_note = None
+    if searching:
+        # the chunk allocator needs the driver's virtual-memory-management calls: where they are refused the arrays are torch's as before (and every rank must then do the same:
+        # the ranks agree on it before anything is built)
+        ok = 1.0
+        try:
+            probe_t = jr.fzeros((64, 64, 600), dev)      # 19.7 MB: chunk-backed
+            del probe_t
+        except Exception as e:      # noqa: BLE001
+            ok, placement_note = 0.0, f"library arrays refused ({type(e).__name__}: {e}); torch's arrays, no search"
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                t_ok = torch.tensor([ok], device=dev)
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                ok = float(t_ok.item())
+        if ok == 0.0:
+            searching = False
+            placement_note = placement_note or "another rank could not use library arrays; torch's arrays, no search"
+            _arrays.use_library_arrays(None)
+            h.set_option("field_placement", 0)
     st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend, update_halo=uh)
     jr.flow_bcs_(st, bcs, handle=h)
     if world > 1 or self_halo:
@@ -1569,7 +1645,7 @@ def run_rank(args) -> int:
     jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
     if world > 1 or self_halo:
         halo.update_halo_(ητ, ni=(n, n, n), handle=h)
-    placement_search = None
+    placement_search = {"note": placement_note} if placement_note else None
     if searching:
         # the search advances the fields: the initial state is set aside and written back afterwards (outside every timed region, like the allocation itself)
         ts = time.perf_counter()
