@@ -53,7 +53,7 @@
  *   "comm_timeout_ms" (120000)    in-process and ipc transports (jrx_comm_init_local / _ipc): how long a rank waits for a neighbour (host waits and the device-side flag waits)
  *   "chain_profile" (0)           jrx_stokes3d_iterate_timed on a multi-rank handle also records events around the stages of every sampled fused step; read with
  *                                 jrx_tuning_chain_profile
- *   "field_chunk_mib" (64), "field_batch_mib" (0), "field_va_align_mib" (0), "field_shuffle" (1)    jrx_field_alloc with "field_placement" = 1: size of a physical chunk, the least
+ *   "field_chunk_mib" (64), "field_batch_mib" (0), "field_va_align_mib" (0), "field_shuffle" (1)    jrx_field_alloc with "field_placement" = 1: size of a physical chunk (0: every array is ONE chunk of its own size -- what the placement search uses), the least
  *                                 amount of new chunks created at once (the shuffle then mixes the chunks of several arrays), alignment of the reserved virtual range (0 = the
  *                                 allocation granularity), 0 = chunks in creation order
  *   "field_arena_gib" (0), "field_va_gap_mib" (0)    "field_placement" = 1: > 0 = the chunk-backed arrays lie one behind the other in ONE reserved virtual range of that size, that many MiB apart

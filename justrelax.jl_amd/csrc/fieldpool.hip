@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <vector>
 
 struct jrx_field_pool {
@@ -47,6 +48,28 @@ __global__ void k_pool_copy(double *__restrict__ dst, const double *__restrict__
 // 20 ms sleep, a hipMalloc / hipFree, a copy, a memset or a complete earlier kernel lies in between; after a hipHostMalloc + hipHostFree (or a hipStreamCreate + destroy) 100 % land in
 // the new ones.  (Both go through the driver's map / queue path, which flushes the translation caches of the process; the plain re-mapping evidently does not.)  So every mapping this
 // file makes at an address that may have been mapped before -- a re-roll, a range of the arena handed out again, a reservation the runtime hands out again -- is followed by that flush.
+// VIRTUAL RANGES ARE NEVER GIVEN BACK to the runtime.  A range that hipMemAddressFree has returned can come back from hipMalloc / hipExtMallocWithFlags, and the full GPU suite then
+// died now and then inside a later hipFree (a segmentation fault in the runtime; gpurun_out/r05y) or produced wrong bits -- the runtime's own books and the translations of such an
+// address are not to be trusted on this release.  Released ranges are parked in a process-wide list by size and handed to the next array of that size of ANY handle; address space is
+// the one thing there is plenty of (47 bits against the few hundred GiB a process ever reserves here).
+std::mutex g_va_mu;
+std::multimap<size_t, void *> g_va_free;
+hipError_t va_reserve(void **va, size_t bytes, size_t align)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_va_mu);
+        auto r = g_va_free.equal_range(bytes);
+        for (auto it = r.first; it != r.second; ++it)
+            if ((uintptr_t)it->second % align == 0) { *va = it->second; g_va_free.erase(it); return hipSuccess; }
+    }
+    return hipMemAddressReserve(va, bytes, align, nullptr, 0);
+}
+void va_release(void *va, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_va_mu);
+    g_va_free.insert({bytes, va});
+}
+
 hipError_t flush_translations()
 {
     void *t = nullptr;
@@ -116,7 +139,7 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, size_t s
         if (!P->arena) {
             void *a = nullptr;
             const size_t want = (size_t)h->field_arena_gib << 30;
-            if (hipMemAddressReserve(&a, want, (size_t)1 << 30, nullptr, 0) == hipSuccess) { P->arena = (char *)a; P->arena_bytes = want; P->arena_used = 0; }
+            if (va_reserve(&a, want, (size_t)1 << 30) == hipSuccess) { P->arena = (char *)a; P->arena_bytes = want; P->arena_used = 0; }
             else (void)hipGetLastError();
         }
         if (P->arena) {
@@ -129,7 +152,7 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, size_t s
             }
         }
     }
-    if (!in_arena) JRX_HIP(h, hipMemAddressReserve(&va, nch * chunk, align, nullptr, 0));
+    if (!in_arena) JRX_HIP(h, va_reserve(&va, nch * chunk, align));
     jrx_field_pool::Alloc A;
     A.bytes = bytes; A.kind = 1; A.chunk = chunk; A.in_arena = in_arena; A.skew = skew;
     for (size_t c = 0; c < nch; c++) {
@@ -139,7 +162,7 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, size_t s
             (void)hipGetLastError();
             if (A.mapped) (void)hipMemUnmap(va, A.mapped);
             for (auto x : A.chunks) sp.push_back(x);
-            if (in_arena) P->arena_free.insert({nch * chunk, va}); else (void)hipMemAddressFree(va, nch * chunk);
+            if (in_arena) P->arena_free.insert({nch * chunk, va}); else va_release(va, nch * chunk);
             return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemMap -> %s", hipGetErrorString(e));
         }
         sp.pop_back();
@@ -155,7 +178,7 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, size_t s
         (void)hipGetLastError();
         (void)hipMemUnmap(va, A.mapped);
         for (auto x : A.chunks) sp.push_back(x);
-        if (in_arena) P->arena_free.insert({nch * chunk, va}); else (void)hipMemAddressFree(va, nch * chunk);
+        if (in_arena) P->arena_free.insert({nch * chunk, va}); else va_release(va, nch * chunk);
         return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemSetAccess / flush -> %s", hipGetErrorString(e));
     }
     P->map_ms += ms_since(t1);
@@ -294,7 +317,7 @@ jrx_status jrx_dev_free(jrx_handle *h, void *p)
         void *va = (char *)p - A.skew;
         JRX_HIP(h, hipMemUnmap(va, A.mapped));
         if (A.in_arena) P->arena_free.insert({A.mapped, va});
-        else JRX_HIP(h, hipMemAddressFree(va, A.mapped));
+        else va_release(va, A.mapped);
         for (auto hd : A.prev) A.chunks.push_back(hd);
         for (auto hd : A.chunks) P->spare[A.chunk].push_back(hd);
     } else {
@@ -313,7 +336,7 @@ void jrx_pool_destroy(jrx_handle *h)
         if (kv.second.kind == 1) {
             void *va = (char *)kv.first - kv.second.skew;
             (void)hipMemUnmap(va, kv.second.mapped);
-            if (!kv.second.in_arena) (void)hipMemAddressFree(va, kv.second.mapped);
+            if (!kv.second.in_arena) va_release(va, kv.second.mapped);
             for (auto hd : kv.second.chunks) (void)hipMemRelease(hd);
             for (auto hd : kv.second.prev) (void)hipMemRelease(hd);
         } else {
@@ -323,7 +346,7 @@ void jrx_pool_destroy(jrx_handle *h)
     release_spare(P);
     for (void *b : P->ballast) (void)hipFree(b);
     if (P->stage) (void)hipFree(P->stage);
-    if (P->arena) (void)hipMemAddressFree(P->arena, P->arena_bytes);
+    if (P->arena) va_release(P->arena, P->arena_bytes);
     delete P;
     h->pool = nullptr;
 }
