@@ -383,6 +383,36 @@ jrx_status jrx_tuning_field_reroll(jrx_handle *h, double *p)
     return JRX_OK;
 }
 
+// One draw of the placement search: fresh chunks from the driver for every chunk-backed array (the spare list is emptied first: chunks of earlier draws would only be dealt again),
+// with `ballast` bytes of throw-away chunks created in between, one piece before each array -- what the driver hands out next depends on what is held, so the pieces push the arrays
+// apart and every draw to other places of the device's memory (pages a launch touches at the same time are best far apart: profiles/r05_placement_search.txt, sections 3 and 8).
+static jrx_status draw_spread(jrx_handle *h, size_t ballast)
+{
+    jrx_field_pool *P = pool_of(h);
+    release_spare(P);
+    size_t n = 0;
+    for (auto &kv : P->live) n += kv.second.kind == 1;
+    if (n == 0) return JRX_OK;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = h->device;
+    const size_t piece = ballast / n / ((size_t)2 << 20) * ((size_t)2 << 20);
+    std::vector<hipMemGenericAllocationHandle_t> held;
+    jrx_status st = JRX_OK;
+    for (auto &kv : P->live) {
+        if (kv.second.kind != 1) continue;
+        if (piece) {
+            hipMemGenericAllocationHandle_t b;
+            if (hipMemCreate(&b, piece, &prop, 0) == hipSuccess) held.push_back(b); else (void)hipGetLastError();
+        }
+        st = reroll_one(h, P, kv.first, kv.second);
+        if (st != JRX_OK) break;
+    }
+    for (auto b : held) (void)hipMemRelease(b);
+    return st;
+}
+
 jrx_status jrx_tuning_field_undo(jrx_handle *h, double *p)
 {
     if (!h) return JRX_ERR_ARG;
@@ -438,7 +468,17 @@ jrx_status jrx_field_tune(jrx_handle *h, int32_t draws, jrx_probe_fn probe, void
     int nk = 0;
     for (int d = 0; d < draws; d++) {
         // test switch "field_test_fail_draw" = k: this rank's k-th draw fails as if there were no room (tests/test_gpu_two_blocks.py: the ranks must stop together)
-        const jrx_status st = h->field_test_fail_draw == d + 1 ? JRX_ERR_HIP : jrx_tuning_field_reroll(h, nullptr);
+        // tuning switch "field_spread_draws" (off: measured to find nothing better -- kernel 4.76 - 4.79 ms after 8 draws either way -- at five times the cost, 21 - 25 s against
+        // 2 - 4 s, profiles/r05_placement_search.txt section 9): fresh chunks from the driver for every draw, a different share of the free memory held back meanwhile
+        size_t ballast = 0;
+        {
+            static const double share[8] = {0.0, 0.5, 0.25, 0.75, 0.125, 0.625, 0.375, 0.875};
+            size_t free_b = 0, total_b = 0, need = 0;
+            for (auto &kv : pool_of(h)->live) if (kv.second.kind == 1) need += kv.second.mapped;
+            if (h->field_spread_draws && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + ((size_t)4 << 30))
+                ballast = (size_t)((double)(free_b - need - ((size_t)4 << 30)) * share[d % 8]);
+        }
+        const jrx_status st = h->field_test_fail_draw == d + 1 ? JRX_ERR_HIP : h->field_spread_draws ? draw_spread(h, ballast) : jrx_tuning_field_reroll(h, nullptr);
         bool all = false;
         JRX_TRY(agree(st == JRX_OK, &all));
         if (!all) {                                    // some rank could not make the draw: everybody goes back to what it had and the search ends
