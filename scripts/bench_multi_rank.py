@@ -1,4 +1,5 @@
-"""two blocks on one device through the in-process transport: the bench leg `multi_rank_path` alone (python scripts/bench_multi_rank.py [n] [steps] [x|y|z|xyz serial|overlap] | vep x|z)"""
+"""two blocks on one device through the in-process transport: the bench leg `multi_rank_path` alone
+   python scripts/bench_multi_rank.py [n] [steps] [x|y|z|xyz default|serial|early|overlap] [KEY=INT ...]   |   ... vep x|z"""
 import json
 import sys
 from pathlib import Path
@@ -7,7 +8,9 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package
 import bench
 jr = load_package()
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-only = tuple(sys.argv[3:5]) if len(sys.argv) > 4 else None
-print(json.dumps(bench.cfg_multi_rank_path(jr, n=n, steps=steps, only=only), indent=1))
+args = [a for a in sys.argv[1:] if "=" not in a]
+opts = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+n = int(args[0]) if len(args) > 0 else 512
+steps = int(args[1]) if len(args) > 1 else 40
+only = tuple(args[2:4]) if len(args) > 3 else None
+print(json.dumps(bench.cfg_multi_rank_path(jr, n=n, steps=steps, only=only, handle_options=opts or None), indent=1))
