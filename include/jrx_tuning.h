@@ -57,7 +57,8 @@
  *                                 amount of new chunks created at once (the shuffle then mixes the chunks of several arrays), alignment of the reserved virtual range (0 = the
  *                                 allocation granularity), 0 = chunks in creation order
  *   "field_arena_gib" (0), "field_va_gap_mib" (0)    "field_placement" = 1: > 0 = the chunk-backed arrays lie one behind the other in ONE reserved virtual range of that size, that many MiB apart
- *   "field_spread_draws" (0)     1: the draws of jrx_field_tune take fresh chunks from the driver and hold back a varying share of the free memory (throw-away chunks between the arrays' new chunks) so that every draw lands elsewhere (five times the cost, nothing better found); 0: plain re-rolls
+ *   "field_spread_draws" (0)     the draws of jrx_field_tune: 0 = chunks of earlier draws are dealt again (cheap; in effect two candidate sets and their permutations), 2 = fresh chunks from the driver
+ *                                 for every draw (every draw a new set; 0.7 s per draw at 512^3), 1 = fresh + a varying share of the free memory held back meanwhile; measured alike in what they find
  *   "field_ballast_mib" (0)      an unused allocation of that size behind every large array (placement experiments); "field_test_fail_draw" (0): test switch, the k-th draw of jrx_field_tune fails on this handle
  *   "field_skew_bytes" (0), "field_skew_mod" (32)    every placement: the k-th large array (>= 8 MiB) starts (k mod field_skew_mod) * field_skew_bytes (a multiple of 256) into its allocation
  *   "general_hif" (0)            3D fused kernel, general form (any dt), 64 x 4 tile: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel (one launch per

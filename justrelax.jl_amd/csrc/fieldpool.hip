@@ -21,7 +21,8 @@
 #include <vector>
 
 struct jrx_field_pool {
-    struct Alloc { size_t bytes = 0, mapped = 0, skew = 0; int kind = 0; bool in_arena = false; std::vector<hipMemGenericAllocationHandle_t> chunks, prev; size_t chunk = 0; };   // prev: the chunks before the last re-roll (jrx_tuning_field_undo)
+    struct Alloc { size_t bytes = 0, mapped = 0, skew = 0; int kind = 0; bool in_arena = false, cold = false;   // cold: left alone by whole-set re-rolls (jrx_pool_mark_cold)
+                   std::vector<hipMemGenericAllocationHandle_t> chunks, prev; size_t chunk = 0; };   // prev: the chunks before the last re-roll (jrx_tuning_field_undo)
     std::map<void *, Alloc> live;
     std::map<size_t, std::vector<hipMemGenericAllocationHandle_t>> spare;      // created, unmapped chunks by their size
     uint64_t rng = 0x9E3779B97F4A7C15ull;
@@ -267,6 +268,17 @@ void keep_one(jrx_field_pool *P, jrx_field_pool::Alloc &A)
 }
 }   // namespace
 
+// internal: arrays a placement search need not move (the kernel it times does not touch them): whole-set re-rolls skip them.  Pointers the pool does not know are ignored.
+void jrx_pool_mark_cold(jrx_handle *h, const double *const *ptrs, int n, bool cold)
+{
+    jrx_field_pool *P = pool_of(h);
+    for (int i = 0; i < n; i++) {
+        if (!ptrs[i]) continue;
+        auto it = P->live.find((void *)ptrs[i]);
+        if (it != P->live.end()) it->second.cold = cold;
+    }
+}
+
 // internal: every large library-owned array (second state sets, ητ) comes from the same place as the caller's
 jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out)
 {
@@ -379,7 +391,7 @@ jrx_status jrx_tuning_field_reroll(jrx_handle *h, double *p)
         if (it == P->live.end()) return jrx_fail(h, JRX_ERR_ARG, "jrx_tuning_field_reroll: %p was not allocated by jrx_field_alloc on this handle", (void *)p);
         return reroll_one(h, P, it->first, it->second);
     }
-    for (auto &kv : P->live) JRX_TRY(reroll_one(h, P, kv.first, kv.second));
+    for (auto &kv : P->live) if (!kv.second.cold) JRX_TRY(reroll_one(h, P, kv.first, kv.second));
     return JRX_OK;
 }
 
@@ -391,7 +403,7 @@ static jrx_status draw_spread(jrx_handle *h, size_t ballast)
     jrx_field_pool *P = pool_of(h);
     release_spare(P);
     size_t n = 0;
-    for (auto &kv : P->live) n += kv.second.kind == 1;
+    for (auto &kv : P->live) n += kv.second.kind == 1 && !kv.second.cold;
     if (n == 0) return JRX_OK;
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
@@ -401,7 +413,7 @@ static jrx_status draw_spread(jrx_handle *h, size_t ballast)
     std::vector<hipMemGenericAllocationHandle_t> held;
     jrx_status st = JRX_OK;
     for (auto &kv : P->live) {
-        if (kv.second.kind != 1) continue;
+        if (kv.second.kind != 1 || kv.second.cold) continue;
         if (piece) {
             hipMemGenericAllocationHandle_t b;
             if (hipMemCreate(&b, piece, &prop, 0) == hipSuccess) held.push_back(b); else (void)hipGetLastError();
@@ -475,7 +487,7 @@ jrx_status jrx_field_tune(jrx_handle *h, int32_t draws, jrx_probe_fn probe, void
             static const double share[8] = {0.0, 0.5, 0.25, 0.75, 0.125, 0.625, 0.375, 0.875};
             size_t free_b = 0, total_b = 0, need = 0;
             for (auto &kv : pool_of(h)->live) if (kv.second.kind == 1) need += kv.second.mapped;
-            if (h->field_spread_draws && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + ((size_t)4 << 30))
+            if (h->field_spread_draws == 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + ((size_t)4 << 30))
                 ballast = (size_t)((double)(free_b - need - ((size_t)4 << 30)) * share[d % 8]);
         }
         const jrx_status st = h->field_test_fail_draw == d + 1 ? JRX_ERR_HIP : h->field_spread_draws ? draw_spread(h, ballast) : jrx_tuning_field_reroll(h, nullptr);

@@ -27,7 +27,7 @@ struct jrx_handle {
     int field_placement = 0;             // option: 0 hipMalloc, 1 physical chunks mapped in shuffled order (virtual memory management), 2 physically contiguous (A/B: the slow rate)
     int field_chunk_mib = 64, field_batch_mib = 0, field_va_align_mib = 0;   // tuning: chunk size, smallest batch of new chunks, alignment of the reserved virtual range
     bool field_shuffle = true;           // tuning: 0 = chunks in creation order (A/B of the shuffle itself)
-    int field_spread_draws = 0;                      // tuning: the draws of jrx_field_tune hold back a varying share of the free memory while their chunks are created (0: plain re-rolls)
+    int field_spread_draws = 0;                      // tuning: draws of jrx_field_tune -- 0: chunks of earlier draws are dealt again; 2: fresh chunks from the driver for every draw; 1: fresh + a varying share of the free memory held back meanwhile
     int field_test_fail_draw = 0;                    // test switch: the k-th draw of jrx_field_tune fails on this handle
     int field_ballast_mib = 0;                       // tuning: an unused allocation of that size behind every large array (placement experiments)
     int field_skew_bytes = 0, field_skew_mod = 32;    // tuning: the k-th large array starts (k mod field_skew_mod) * field_skew_bytes into its allocation (csrc/fieldpool.hip)
@@ -181,6 +181,7 @@ jrx_status jrx_check_device(jrx_handle *h);
 jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out);
 jrx_status jrx_dev_free(jrx_handle *h, void *p);
 void jrx_pool_destroy(jrx_handle *h);
+void jrx_pool_mark_cold(jrx_handle *h, const double *const *ptrs, int n, bool cold);   // arrays whole-set re-rolls leave alone (csrc/fieldpool.hip)
 
 // ensure the library-owned ητ scratch holds n doubles
 jrx_status jrx_ensure_etatau(jrx_handle *h, size_t n);

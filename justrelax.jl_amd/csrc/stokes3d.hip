@@ -1491,7 +1491,23 @@ jrx_status jrx_stokes3d_tune_placement(jrx_handle *h, const jrx_stokes3d_fields 
         if (jrx_stokes3d_iterate_timed(c->h, c->f, c->etatau, c->p, c->iters, t) != JRX_OK) return -1.0;
         return t[0] / (double)c->iters;
     };
-    return jrx_field_tune(h, draws, probe, &c, ms_per_iter, kept);
+    // arrays the loop body's dominant kernel does not touch stay where they are: a draw then moves 22 arrays instead of 55 (the strain rates, displacements, residuals and centre
+    // copies never; τ_o, P0, Q, K, G, and the body forces when the viscous-limit kernels without them stand in -- which the first probe's operand pass decides)
+    const double *never[] = {f->divV, f->Ux, f->Uy, f->Uz, f->exx, f->eyy, f->ezz, f->eyz, f->exz, f->exy, f->RP, f->Rx, f->Ry, f->Rz,
+                             f->tyz_c, f->txz_c, f->txy_c, f->toyz_c, f->toxz_c, f->toxy_c};
+    const double *visc[] = {f->P0, f->Q, f->toxx, f->toyy, f->tozz, f->toyz, f->toxz, f->toxy, f->K, f->G};
+    const double *force[] = {f->fx, f->fy, f->fz};
+    double t[6];
+    JRX_TRY(jrx_stokes3d_iterate_timed(h, f, etatau, p, 2, t));          // runs the operand pass: h->visc_ok, h->nof
+    const bool vl = std::isinf(p->dt) && h->viscous_limit && h->visc_ok;
+    jrx_pool_mark_cold(h, never, (int)(sizeof(never) / sizeof(never[0])), true);
+    if (vl) jrx_pool_mark_cold(h, visc, 10, true);
+    if (vl && h->nof == 2) jrx_pool_mark_cold(h, force, 3, true);
+    const jrx_status st = jrx_field_tune(h, draws, probe, &c, ms_per_iter, kept);
+    jrx_pool_mark_cold(h, never, (int)(sizeof(never) / sizeof(never[0])), false);
+    jrx_pool_mark_cold(h, visc, 10, false);
+    jrx_pool_mark_cold(h, force, 3, false);
+    return st;
 }
 
 }   // extern "C"
