@@ -104,5 +104,44 @@ int main(int argc, char **argv)
         return sxy / sqrt(sxx * syy + 1e-300); };
     for (int q = 0; q < 4; q++) { double lo = 1e9, hi = 0; for (double t : T[q]) { lo = std::min(lo, t); hi = std::max(hi, t); } printf("under %-6s: min %.3f max %.3f ms\n", names[probes[q]], lo, hi); }
     printf("correlation over the chunks: txx~Vx %.2f  txx~o.txx %.2f  txx~o.Vx %.2f  Vx~o.txx %.2f  o.txx~o.Vx %.2f  txx~read bandwidth %.2f\n", corr(T[0], T[1]), corr(T[0], T[2]), corr(T[0], T[3]), corr(T[1], T[2]), corr(T[2], T[3]), corr(T[0], bw));
+    // ---- is the quality additive?  Every chunk of the pool (the 22 in use, too) is timed under txx; then the arrays are put on the 22 best / the 22 worst / 22 random chunks.
+    {
+        std::vector<double> q(NC, 0.0);
+        const int R = 4;                                   // txx
+        for (int c = 0; c < NC; c++) {
+            // chunk c may be in use by another array: that array takes the chunk txx holds now (which array holds which chunk does not matter, section 11 of the record)
+            int holder = -1;
+            for (int k = 0; k < NA; k++) if (at[k] == c) holder = k;
+            if (holder == R) { q[c] = timeit(6); continue; }
+            const int mine = at[R];
+            if (holder >= 0) {
+                CK(hipDeviceSynchronize());
+                CK(hipMemUnmap(va[holder], CH)); CK(hipMemUnmap(va[R], CH));
+                CK(hipMemMap(va[holder], CH, 0, ch[mine], 0)); CK(hipMemSetAccess(va[holder], CH, &acc, 1));
+                CK(hipMemMap(va[R], CH, 0, ch[c], 0)); CK(hipMemSetAccess(va[R], CH, &acc, 1));
+                flush();
+                at[holder] = mine; at[R] = c;
+            } else put(R, c);
+            q[c] = timeit(6);
+        }
+        std::vector<int> order(NC);
+        for (int c = 0; c < NC; c++) order[c] = c;
+        std::sort(order.begin(), order.end(), [&](int a_, int b_) { return q[a_] < q[b_]; });
+        printf("# every chunk under txx: fastest %.3f ms, median %.3f, slowest %.3f\n", q[order[0]], q[order[NC / 2]], q[order[NC - 1]]);
+        auto assemble = [&](const std::vector<int> &pick) {
+            CK(hipDeviceSynchronize());
+            for (int k = 0; k < NA; k++) CK(hipMemUnmap(va[k], CH));
+            for (int k = 0; k < NA; k++) { CK(hipMemMap(va[k], CH, 0, ch[pick[k]], 0)); CK(hipMemSetAccess(va[k], CH, &acc, 1)); at[k] = pick[k]; }
+            flush();
+            return timeit(8);
+        };
+        std::vector<int> best(order.begin(), order.begin() + NA), worst(order.end() - NA, order.end()), mid(order.begin() + (NC - NA) / 2, order.begin() + (NC - NA) / 2 + NA);
+        printf("arrays on the 22 fastest chunks: %.3f ms\n", assemble(best));
+        printf("arrays on the 22 slowest chunks: %.3f ms\n", assemble(worst));
+        printf("arrays on the 22 middle chunks:  %.3f ms\n", assemble(mid));
+        std::vector<int> rev(best.rbegin(), best.rend());
+        printf("the 22 fastest again, dealt in the opposite order: %.3f ms\n", assemble(rev));
+        printf("arrays on the 22 fastest chunks: %.3f ms\n", assemble(best));
+    }
     return 0;
 }
