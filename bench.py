@@ -423,6 +423,13 @@ def state_tensors(obj, _seen=None):
             yield from state_tensors(getattr(obj, k, None), seen)
 
 
+def uniform_chunk_mib(n):
+    """one chunk size for every large array of an n^3 block: the largest of them, (n + 2)^2 (n + 1) doubles, rounded up to 2 MiB -- with every array ONE chunk of one common size the
+    placement search can deal chunks of a pool that spans the device's memory (csrc/fieldpool.hip, "field_pool_pct")"""
+    b = (n + 2) * (n + 2) * (n + 1) * 8
+    return -(-b // (2 << 20)) * 2
+
+
 def hold_state(st):
     """copies of every array of the state (to be written back after a placement search, which advances the fields) -- or None when the device has no room for them beside the
     second copy of the arrays a draw needs (the search matters more than the restored state: the timed batches do not depend on the values)"""
@@ -453,7 +460,7 @@ def cfg_solvi(jr, h, n, steps, warm, draws=8):
     search = None
     if draws > 0:                  # as the headline does: the arrays from the library's chunk allocator, the placement searched before anything is timed
         h.set_option("field_placement", 1)
-        h.set_option("field_chunk_mib", 0)
+        h.set_option("field_chunk_mib", uniform_chunk_mib(n))
         _arrays.use_library_arrays(h)
     try:
         st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
@@ -711,7 +718,7 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
                     hs[r].set_option(k_, v_)
                 if draws > 0:
                     hs[r].set_option("field_placement", 1)
-                    hs[r].set_option("field_chunk_mib", 0)
+                    hs[r].set_option("field_chunk_mib", uniform_chunk_mib(n))
                     _arrays.use_library_arrays(hs[r])
                 try:
                     st, ρg, K, G, pt, geo, bcs, dt = solvi3d_device(n, jr.AMDGPUBackend)
@@ -1034,7 +1041,7 @@ class GpuRanks:
         from justrelax_jl_amd import arrays as _arrays
         self.h.set_option("field_placement", 1)
         if not any(kv.startswith("field_chunk_mib=") for kv in self.args.option):
-            self.h.set_option("field_chunk_mib", 0)
+            self.h.set_option("field_chunk_mib", uniform_chunk_mib(self.n))
         _arrays.use_library_arrays(self.h)
         ok = 1.0
         try:
@@ -1661,7 +1668,7 @@ def run_rank(args) -> int:
         from justrelax_jl_amd import arrays as _arrays
         h.set_option("field_placement", 1)
         if not any(kv.startswith("field_chunk_mib=") for kv in args.option):
-            h.set_option("field_chunk_mib", 0)
+            h.set_option("field_chunk_mib", uniform_chunk_mib(args.n))
         _arrays.use_library_arrays(h)
     placement_note = None
     if searching:

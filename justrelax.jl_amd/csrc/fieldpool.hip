@@ -478,6 +478,40 @@ jrx_status jrx_field_tune(jrx_handle *h, int32_t draws, jrx_probe_fn probe, void
     JRX_TRY(run(&best));
     ms[0] = best;
     int nk = 0;
+    // THE POOL.  A placement is good when the chunks its arrays use at the same time lie far apart in the device's memory (profiles/r05_placement_search.txt, sections 3, 8, 12: 22 random
+    // chunks out of a pool that spans most of the memory gave 4.81 - 4.85 ms in sixteen of sixteen picks where compact sets gave 4.9 - 6.2).  So where every array that takes part is
+    // ONE chunk of one common size ("field_chunk_mib" = that size), the spare list is first filled with chunks for "field_pool_pct" % of the free memory: the draws below then deal
+    // random chunks of that pool, and what is not used goes back to the driver at the end.
+    if (draws > 0 && h->field_pool_pct > 0) {
+        jrx_field_pool *P = pool_of(h);
+        size_t S = 0, m = 0;
+        bool uniform = true;
+        for (auto &kv : P->live) {
+            const jrx_field_pool::Alloc &A = kv.second;
+            if (A.kind != 1 || A.cold) continue;
+            if (A.chunks.size() != 1 || (S && A.chunk != S)) { uniform = false; break; }
+            S = A.chunk; m++;
+        }
+        size_t free_b = 0, total_b = 0;
+        if (uniform && m > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > ((size_t)6 << 30)) {
+            const size_t pct = (size_t)(h->field_pool_pct > 90 ? 90 : h->field_pool_pct);
+            size_t want = (free_b - ((size_t)6 << 30)) / 100 * pct / S;
+            if (want > 16 * m) want = 16 * m;
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = h->device;
+            auto &sp = P->spare[S];
+            const auto t0 = Clock::now();
+            while (sp.size() < want) {
+                hipMemGenericAllocationHandle_t hd;
+                if (hipMemCreate(&hd, S, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+                sp.push_back(hd);
+                P->chunks_created++;
+            }
+            P->create_ms += ms_since(t0);
+        }
+    }
     for (int d = 0; d < draws; d++) {
         // test switch "field_test_fail_draw" = k: this rank's k-th draw fails as if there were no room (tests/test_gpu_two_blocks.py: the ranks must stop together)
         // tuning switch "field_spread_draws" (off: measured to find nothing better -- kernel 4.76 - 4.79 ms after 8 draws either way -- at five times the cost, 21 - 25 s against

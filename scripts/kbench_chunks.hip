@@ -142,6 +142,20 @@ int main(int argc, char **argv)
         std::vector<int> rev(best.rbegin(), best.rend());
         printf("the 22 fastest again, dealt in the opposite order: %.3f ms\n", assemble(rev));
         printf("arrays on the 22 fastest chunks: %.3f ms\n", assemble(best));
+        // unlike chunks on purpose: evenly spaced through the ranking / through the order of creation, and random picks
+        const int stp = NC / NA;
+        for (int off = 0; off < std::min(stp, 3); off++) {
+            std::vector<int> a1, a2;
+            for (int k = 0; k < NA; k++) { a1.push_back(order[off + k * stp]); a2.push_back(off + k * stp); }
+            printf("every %d-th chunk of the ranking (from %d): %.3f ms     every %d-th chunk in the order of creation (from %d): %.3f ms\n", stp, off, assemble(a1), stp, off, assemble(a2));
+        }
+        unsigned long long sd = 88172645463325252ull;
+        for (int r = 0; r < 4; r++) {
+            std::vector<int> all(NC); for (int c = 0; c < NC; c++) all[c] = c;
+            for (int i = NC - 1; i > 0; i--) { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; std::swap(all[i], all[sd % (i + 1)]); }
+            printf("22 random chunks: %.3f ms\n", assemble(std::vector<int>(all.begin(), all.begin() + NA)));
+        }
+        { std::vector<int> a0; for (int k = 0; k < NA; k++) a0.push_back(k); printf("the first 22 chunks in the order of creation (as at the start): %.3f ms\n", assemble(a0)); }
     }
     return 0;
 }
