@@ -158,7 +158,8 @@ def test_solve_on_library_arrays_gives_the_same_bits(jr, placement):
         assert np.array_equal(a[k][m], b[k][m], equal_nan=True), k
 
 
-def test_placement_search_keeps_addresses_and_a_restored_state_solves_to_the_same_bits(jr):
+@pytest.mark.parametrize("chunk_mib,pool_pct", [(0, 0), (10, 2)])
+def test_placement_search_keeps_addresses_and_a_restored_state_solves_to_the_same_bits(jr, chunk_mib, pool_pct):
     """jrx_stokes3d_tune_placement: draws of new physical chunks under the arrays, the loop body timed on each, the fastest kept.  Pointers stay; the fields are advanced by the probes,
     so the initial state is written back -- and the solve that follows gives the bits of a solve on arrays that were never moved."""
     from justrelax_jl_amd import _lib, arrays, checks, stokes
@@ -169,7 +170,8 @@ def test_placement_search_keeps_addresses_and_a_restored_state_solves_to_the_sam
         h = _lib.Handle(0)
         try:
             h.set_option("field_placement", 1)
-            h.set_option("field_chunk_mib", 0 if tune else 2)
+            h.set_option("field_chunk_mib", chunk_mib if tune else 2)      # 10 MiB: every array of this problem is ONE chunk of that size -> the draws deal from a pool
+            h.set_option("field_pool_pct", pool_pct)
             arrays.use_library_arrays(h)
             s = jr.miniapps.random_fields3d((130, 96, 100), seed=5, iterMax=40, nout=20)
             s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
@@ -183,6 +185,8 @@ def test_placement_search_keeps_addresses_and_a_restored_state_solves_to_the_sam
                 assert len(ms) == 5 and all(m > 0 for m in ms) and 0 <= kept <= 3
                 assert [st.P.data_ptr(), st.V.Vx.data_ptr(), st.τ.xy.data_ptr(), ητ.data_ptr()] == ptr0
                 assert _stats(h)[2] > created0 and _stats(h)[3] == 0        # draws were made, and the chunks of those that lost went back to the driver
+                if pool_pct:
+                    assert _stats(h)[2] - created0 > 3 * 40                  # the pool: many more chunks than three draws of the ~40 arrays that took part need
                 for name, path in stokes_field_names(3).items():             # the initial state again
                     if name in s.arrays:
                         _get(st, path).copy_(from_numpy(s.arrays[name], st.P.device))
