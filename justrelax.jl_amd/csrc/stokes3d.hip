@@ -577,7 +577,10 @@ static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L, double dt)
     // dealt to the XCDs in bands of four) where the launch still has >= 4,096 blocks: 512^3 -2.5 .. -5 % kernel time in every physical backing of the arrays (hipMalloc, shuffled
     // 2 MiB chunks, contiguous), 256^3 -1 .. -4 % (scripts/kbench_place.hip, profiles/r05_placement_ab.txt).  "fused_tile" = 3 forces it, 0 keeps 64 x 4
     {
-        const FusedShape T{64, 8, 8};
+        // chunk depth of the tall tile: 12 planes from nz = 384 on (a third fewer prologue planes: 512^3 4.877 -> 4.838 ms, three rounds alike, with 16 planes 4.865, with 32 4.958;
+        // 256^3 is best at 8: 0.801 against 0.813 / 0.835; scripts/kbench_kz.hip, same arrays in one process); tuning switch "fused_kz": 0 = this rule, 8 / 12 force a depth
+        const int tkz = h->fused_kz == 8 || h->fused_kz == 12 ? h->fused_kz : (L.nz >= 384 ? 12 : 8);
+        const FusedShape T{64, 8, tkz};
         fused_tiles(L, T, nt);
         // By default for the viscous-limit forms only: the general form fits the shape as well (128 VGPRs, no spills, 70 KB of LDS per block) but gains nothing from it
         // (512^3: 7.63 -> 7.76 ms in one process, 7.65 -> 7.65 in another; 256^3 1.064 -> 1.066; gpurun_out/r05s) -- it runs this shape only when "fused_tile" = 3 asks for it
@@ -823,7 +826,7 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
 {
     const FusedShape S = fused_shape(h, a.L, a.dt);
     const int kz = S.kz;
-    if (S.tx == 64 && S.ty == 8) return launch_fused_t<64, 8, 8, 4, 4>(h, s, a, bc, b, hiface, fold, shell);
+    if (S.tx == 64 && S.ty == 8) return kz == 12 ? launch_fused_t<64, 8, 12, 4, 4>(h, s, a, bc, b, hiface, fold, shell) : launch_fused_t<64, 8, 8, 4, 4>(h, s, a, bc, b, hiface, fold, shell);
     if (S.tx == 64) {
         if (kz == 8) return launch_fused_t<64, 4, 8, 4, 1, true>(h, s, a, bc, b, hiface, fold, shell);
         if (kz == 4) return launch_fused_t<64, 4, 4, 4, 1, true>(h, s, a, bc, b, hiface, fold, shell);
