@@ -29,6 +29,21 @@ __global__ __launch_bounds__(256) void k_read(const double2 *__restrict__ s, i64
 static hipMemAllocationProp prop = {};
 static hipMemAccessDesc acc = {};
 static void flush() { void *t = nullptr; CK(hipHostMalloc(&t, 4096, hipHostMallocDefault)); CK(hipHostFree(t)); }
+static hipEvent_t g_e0, g_e1;
+template <int KZ, int MW, int XG>
+static double time_variant(const SweepArgs &a, const FusedBC &bc, int ntx, int nty, int nz, int reps)
+{
+    const int ntz = (nz + KZ - 1) / KZ;
+    auto go = [&] { hipLaunchKernelGGL((k_fused3d<64, 8, KZ, MW, 1, false, XG, false, true, 3, 1, 0, true, true, true, false, 2>), dim3(ntx * nty * ntz), dim3(512), 0, 0, a, bc, ntx, nty, 0, 0, 0); };
+    go();
+    CK(hipEventRecord(g_e0, 0));
+    for (int r = 0; r < reps; r++) go();
+    CK(hipEventRecord(g_e1, 0));
+    CK(hipEventSynchronize(g_e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, g_e0, g_e1));
+    return (double)ms / reps;
+}
 int main(int argc, char **argv)
 {
     const int spares = argc > 1 ? atoi(argv[1]) : 40;
@@ -156,6 +171,20 @@ int main(int argc, char **argv)
             printf("22 random chunks: %.3f ms\n", assemble(std::vector<int>(all.begin(), all.begin() + NA)));
         }
         { std::vector<int> a0; for (int k = 0; k < NA; k++) a0.push_back(k); printf("the first 22 chunks in the order of creation (as at the start): %.3f ms\n", assemble(a0)); }
+        // kernel variants on a GOOD placement (22 random chunks of the pool): chunk depth, XCD band width, waves per SIMD -- the library runs <64, 8, 12 (8 below nz = 384), MINW 4, XG 4>
+        CK(hipEventCreate(&g_e0)); CK(hipEventCreate(&g_e1));
+        for (int r = 0; r < 2; r++) {
+            std::vector<int> all(NC); for (int c = 0; c < NC; c++) all[c] = c;
+            for (int i = NC - 1; i > 0; i--) { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; std::swap(all[i], all[sd % (i + 1)]); }
+            printf("22 random chunks: %.3f ms (the harness's own instantiation, MINW 2)\n", assemble(std::vector<int>(all.begin(), all.begin() + NA)));
+            for (int q = 0; q < 2; q++) {
+                printf("  MINW 4, XG 4: KZ 8 %.3f  KZ 10 %.3f  KZ 12 %.3f  KZ 14 %.3f  KZ 16 %.3f |", time_variant<8, 4, 4>(a, bc, ntx, nty, nz, 6), time_variant<10, 4, 4>(a, bc, ntx, nty, nz, 6),
+                       time_variant<12, 4, 4>(a, bc, ntx, nty, nz, 6), time_variant<14, 4, 4>(a, bc, ntx, nty, nz, 6), time_variant<16, 4, 4>(a, bc, ntx, nty, nz, 6));
+                printf(" KZ 12: XG 1 %.3f  XG 2 %.3f  XG 4 %.3f  XG 8 %.3f  XG 0 %.3f | MINW 2 %.3f  MINW 3 %.3f\n", time_variant<12, 4, 1>(a, bc, ntx, nty, nz, 6), time_variant<12, 4, 2>(a, bc, ntx, nty, nz, 6),
+                       time_variant<12, 4, 4>(a, bc, ntx, nty, nz, 6), time_variant<12, 4, 8>(a, bc, ntx, nty, nz, 6), time_variant<12, 4, 0>(a, bc, ntx, nty, nz, 6), time_variant<12, 2, 4>(a, bc, ntx, nty, nz, 6),
+                       time_variant<12, 3, 4>(a, bc, ntx, nty, nz, 6));
+            }
+        }
     }
     return 0;
 }

@@ -34,7 +34,7 @@ static hipEvent_t e0, e1;
 static char *blk;
 static size_t blk_bytes;
 static std::vector<i64> cnt;       // elements of the 22 arrays, in the order of `slot`
-template <int KZ>
+template <int KZ, int MW = 4, int XG = 4>
 static double time_kz(const std::vector<size_t> &off, int reps)
 {
     jrx_stokes3d_fields f;
@@ -53,7 +53,7 @@ static double time_kz(const std::vector<size_t> &off, int reps)
     bc.fsL = bc.fsF = bc.fsK0 = 1;
     constexpr int TX = 64, TY = 8;
     const int ntz_ = (nz + KZ - 1) / KZ;
-    auto go = [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, 2, 1, false, 4, false, true, 3, 1, 0, true, true, true, false, 2>), dim3(ntx * nty * ntz_), dim3(TX * TY), 0, 0, a, bc, ntx, nty, 0, 0, 0); };
+    auto go = [&] { hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XG, false, true, 3, 1, 0, true, true, true, false, 2>), dim3(ntx * nty * ntz_), dim3(TX * TY), 0, 0, a, bc, ntx, nty, 0, 0, 0); };
     go();
     CK(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; r++) go();
@@ -88,8 +88,11 @@ int main(int argc, char **argv)
     blk = base; blk_bytes = ~(size_t)0;
     CK(hipDeviceSynchronize());
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("# n %d, 64 x 8 tiles, chunk depth KZ; ms per launch, three rounds\n", n);
-    for (int r = 0; r < 3; r++)
-        printf("KZ 8: %.3f   KZ 12: %.3f   KZ 16: %.3f   KZ 32: %.3f   KZ 8: %.3f\n", time_kz<8>(off, 8), time_kz<12>(off, 8), time_kz<16>(off, 8), time_kz<32>(off, 8), time_kz<8>(off, 8));
+    printf("# n %d, 64 x 8 tiles; k_fused3d<64, 8, KZ, MINW, .., XG, ..>: ms per launch, three rounds (the library runs MINW 4, XG 4)\n", n);
+    for (int r = 0; r < 3; r++) {
+        printf("KZ 8: %.3f   KZ 10: %.3f   KZ 12: %.3f   KZ 14: %.3f   KZ 16: %.3f   KZ 8: %.3f\n", time_kz<8>(off, 8), time_kz<10>(off, 8), time_kz<12>(off, 8), time_kz<14>(off, 8), time_kz<16>(off, 8), time_kz<8>(off, 8));
+        printf("KZ 12 with XG 1: %.3f   XG 2: %.3f   XG 4: %.3f   XG 8: %.3f   XG 0 (plain block order): %.3f   MINW 2 (XG 4): %.3f   MINW 3: %.3f\n", time_kz<12, 4, 1>(off, 8), time_kz<12, 4, 2>(off, 8), time_kz<12, 4, 4>(off, 8),
+               time_kz<12, 4, 8>(off, 8), time_kz<12, 4, 0>(off, 8), time_kz<12, 2, 4>(off, 8), time_kz<12, 3, 4>(off, 8));
+    }
     return 0;
 }
