@@ -57,6 +57,7 @@
  *                                 amount of new chunks created at once (the shuffle then mixes the chunks of several arrays), alignment of the reserved virtual range (0 = the
  *                                 allocation granularity), 0 = chunks in creation order
  *   "field_arena_gib" (0), "field_va_gap_mib" (0)    "field_placement" = 1: > 0 = the chunk-backed arrays lie one behind the other in ONE reserved virtual range of that size, that many MiB apart
+ *   "scratch_poison" (0)         test switch: the library's second state set is filled with NaNs when it is allocated (what it holds before its first use must not matter)
  *   "fused_kz" (0)               chunk depth of the 64 x 8 tile of k_fused3d: 0 = 12 planes from nz = 384 on, 8 below (scripts/kbench_kz.hip); 8 / 12 force a depth
  *   "field_pool_pct" (70)         jrx_field_tune, when every array that takes part is ONE chunk of one common size ("field_chunk_mib" = the size of the largest array): the spare list is first filled
  *                                 with chunks for this share of the free memory, so that the draws deal random chunks from all over the device's memory; the rest is released at the end; 0 = off

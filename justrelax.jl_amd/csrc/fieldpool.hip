@@ -73,9 +73,13 @@ void va_release(void *va, size_t bytes)
 
 hipError_t flush_translations()
 {
+    // both of the two things that were seen to flush (300 of 300 re-mappings each, scripts/vmm_stale.hip): neither is a documented contract, and a lost flush is silent corruption
     void *t = nullptr;
     hipError_t e = hipHostMalloc(&t, 4096, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostFree(t);
+    hipStream_t s = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamDestroy(s);
     return e;
 }
 

@@ -27,6 +27,7 @@ struct jrx_handle {
     int field_placement = 0;             // option: 0 hipMalloc, 1 physical chunks mapped in shuffled order (virtual memory management), 2 physically contiguous (A/B: the slow rate)
     int field_chunk_mib = 64, field_batch_mib = 0, field_va_align_mib = 0;   // tuning: chunk size, smallest batch of new chunks, alignment of the reserved virtual range
     bool field_shuffle = true;           // tuning: 0 = chunks in creation order (A/B of the shuffle itself)
+    int scratch_poison = 0;                          // test switch: the second state set is filled with NaNs when it is allocated
     int fused_kz = 0;                                // tuning: chunk depth of the 64 x 8 tile of k_fused3d (0: 12 planes from nz = 384 on, else 8; 8 / 12 force)
     int field_pool_pct = 70;                         // tuning: jrx_field_tune first fills the spare list with chunks for that share of the free memory (arrays of ONE common chunk size only); 0 = off
     int field_spread_draws = 0;                      // tuning: draws of jrx_field_tune -- 0: chunks of earlier draws are dealt again; 2: fresh chunks from the driver for every draw; 1: fresh + a varying share of the free memory held back meanwhile

@@ -582,10 +582,10 @@ static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L, double dt)
         const int tkz = h->fused_kz == 8 || h->fused_kz == 12 ? h->fused_kz : (L.nz >= 384 ? 12 : 8);
         const FusedShape T{64, 8, tkz};
         fused_tiles(L, T, nt);
-        // By default for the viscous-limit forms only: the general form fits the shape as well (128 VGPRs, no spills, 70 KB of LDS per block) but gains nothing from it
-        // (512^3: 7.63 -> 7.76 ms in one process, 7.65 -> 7.65 in another; 256^3 1.064 -> 1.066; gpurun_out/r05s) -- it runs this shape only when "fused_tile" = 3 asks for it
+        // The general form fits the shape as well (128 VGPRs, no spills, 70 KB of LDS per block) and gains little from it: nothing at 256^3 (1.064 -> 1.066 ms), 0.7 % at 512^3 with
+        // 12-plane chunks (7.447 / 7.469 -> 7.392 / 7.418 ms, two pairs of processes on searched placements) -- it runs this shape from nz = 384 on, or when "fused_tile" = 3 asks for it
         const bool visc = h->viscous_limit && h->visc_ok && dt == INFINITY;
-        if (h->fused_ylds && (h->fused_tile == 3 || (visc && h->fused_tile == 2 && !narrow && (long long)nt[0] * nt[1] * nt[2] >= 4096))) return T;
+        if (h->fused_ylds && (h->fused_tile == 3 || ((visc || L.nz >= 384) && h->fused_tile == 2 && !narrow && (long long)nt[0] * nt[1] * nt[2] >= 4096))) return T;
     }
     for (int kz = 8; kz >= 2; kz /= 2) {
         S.kz = kz;
@@ -652,6 +652,9 @@ static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
         JRX_TRY(st);
         h->scratch_base[q] = (double *)b;
         h->scratch[q] = (double *)((char *)b + (size_t)q * stg);
+        // what the set holds before its first use must not matter (every entry a kernel reads has been written by a kernel before); test switch "scratch_poison": 1 = every byte 0xFF
+        // (NaNs) instead of whatever the allocation held (tests/test_gpu_stokes3d.py::test_the_second_state_set_may_hold_anything)
+        if (h->scratch_poison) JRX_HIP(h, hipMemset(b, 0xFF, n[q] * sizeof(double) + (size_t)q * stg));
     }
     h->scratch_stagger_used = h->scratch_stagger + 1000003 * (int)h->scratch_contiguous;
     h->scratch_dims[0] = nx; h->scratch_dims[1] = ny; h->scratch_dims[2] = nz;

@@ -78,5 +78,47 @@ int main(int argc, char **argv)
             }
         }
     }
+    // ---- how reliable is a flush?  300 re-mappings each, 6 chunks of 2 MiB, the range and both chunk sets reused every time (as a pool does)
+    {
+        const int nch = 6;
+        const size_t words = nch * CH / 4;
+        void *va = nullptr;
+        CK(hipMemAddressReserve(&va, nch * CH, 0, nullptr, 0));
+        Chunks A = create(nch), B = create(nch);
+        static char hostbuf[1 << 16];
+        const char *fn[] = {"hipHostMalloc + hipHostFree 4 KiB", "hipHostRegister + hipHostUnregister 64 KiB", "hipStreamCreate + hipStreamDestroy", "hipHostMalloc + hipHostFree of a size that changes every time"};
+        for (int F = 0; F < 4; F++) {
+            int bad = 0;
+            unsigned long long lost = 0;
+            for (int it = 0; it < 300; it++) {
+                const Chunks &X = (it & 1) ? B : A, &Y = (it & 1) ? A : B;        // X is mapped and filled, then Y takes its place
+                map_at(va, X);
+                if (it == 0) { void *t0 = nullptr; CK(hipHostMalloc(&t0, 4096)); CK(hipHostFree(t0)); }
+                k_fill<<<1024, 256>>>((unsigned *)va, words, 1u);
+                CK(hipDeviceSynchronize());
+                CK(hipMemUnmap(va, nch * CH));
+                map_at(va, Y);
+                void *t = nullptr; hipStream_t st;
+                switch (F) {
+                case 0: CK(hipHostMalloc(&t, 4096)); CK(hipHostFree(t)); break;
+                case 1: CK(hipHostRegister(hostbuf, sizeof hostbuf, hipHostRegisterDefault)); CK(hipHostUnregister(hostbuf)); break;
+                case 2: CK(hipStreamCreate(&st)); CK(hipStreamDestroy(st)); break;
+                default: CK(hipHostMalloc(&t, 4096 * (1 + it % 37))); CK(hipHostFree(t)); break;
+                }
+                k_fill<<<1024, 256>>>((unsigned *)va, words, 2u + (unsigned)it);
+                CK(hipDeviceSynchronize());
+                CK(hipMemset(d_out, 0, 8));
+                k_count<<<1024, 256>>>((const unsigned *)va, words, 2u + (unsigned)it, d_out);      // read back through the same range, as a later kernel of the application would
+                unsigned long long r = 0;
+                CK(hipMemcpy(&r, d_out, 8, hipMemcpyDeviceToHost));
+                CK(hipMemUnmap(va, nch * CH));
+                // and where did the words really go?  Y through a fresh range
+                const unsigned long long inY = count_in(Y, 2u + (unsigned)it, d_out);
+                if (inY != words) { bad++; lost += words - inY; }
+                (void)r;
+            }
+            printf("%-62s 300 re-mappings: %d with writes that did not reach the new chunks (%llu words in all)\n", fn[F], bad, lost);
+        }
+    }
     return 0;
 }

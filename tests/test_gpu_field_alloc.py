@@ -200,7 +200,5 @@ def test_placement_search_keeps_addresses_and_a_restored_state_solves_to_the_sam
             arrays.use_library_arrays(None)
             h.close()
     (ra, a), (rb, b) = outs
-    assert ra.iter == rb.iter and list(ra.err_evo1) == list(rb.err_evo1)
-    for k in a:
-        m = checks.interior_mask3d(k, a[k].shape)
-        assert np.array_equal(a[k][m], b[k][m], equal_nan=True), k
+    diff = {k: int((a[k] != b[k]).sum()) for k in a if not np.array_equal(a[k][checks.interior_mask3d(k, a[k].shape)], b[k][checks.interior_mask3d(k, a[k].shape)], equal_nan=True)}
+    assert ra.iter == rb.iter and list(ra.err_evo1) == list(rb.err_evo1) and not diff, (ra.iter, rb.iter, list(ra.err_evo1), list(rb.err_evo1), diff)

@@ -638,3 +638,28 @@ def test_3d_compressible_iterations_on_uniform_fields_equal_the_2d_oracle(jr, or
     oop = s3.extra["out_of_plane"]
     assert np.abs(out["t" + oop["tn"]]).max() > 0.0 and np.abs(out[oop["V"]]).max() == 0.0
     assert all(np.abs(out["t" + c]).max() == 0.0 for c in oop["shear"])
+
+
+@pytest.mark.parametrize("ni,dt,bcs", [((130, 96, 100), 0.25, "free_slip"), ((130, 96, 100), float("inf"), "free_slip"), ((70, 40, 36), 0.25, "no_slip"), ((200, 64, 72), float("inf"), "free_slip")])
+def test_the_second_state_set_may_hold_anything(jr, ni, dt, bcs):
+    """the fused pipeline ping-pongs between the caller's arrays and a set of the library's own: whatever that set holds when it is allocated (here: NaNs in every entry, test switch
+    "scratch_poison") must not reach a result -- every entry a kernel reads has been written by a kernel before"""
+    from justrelax_jl_amd import _lib, checks
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    outs = []
+    for poison in (0, 1):
+        h = _lib.Handle(0)
+        try:
+            h.set_option("scratch_poison", poison)
+            s = jr.miniapps.random_fields3d(ni, seed=3, iterMax=45, nout=15, bcs=bcs, dt=dt)
+            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+            st, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
+            r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs, handle=h)
+            outs.append((r, download_stokes(st)))
+        finally:
+            h.close()
+    (ra, a), (rb, b) = outs
+    assert ra.iter == rb.iter and list(ra.err_evo1) == list(rb.err_evo1), (list(ra.err_evo1), list(rb.err_evo1))
+    for k in a:
+        m = checks.interior_mask3d(k, a[k].shape)
+        assert np.array_equal(a[k][m], b[k][m], equal_nan=True), k
