@@ -1709,7 +1709,7 @@ def run_rank(args) -> int:
         restored, held = held is not None, None
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        placement_search = {"state_restored": restored, "draws": args.placement_draws, "kept": kept, "iterations_per_probe": 12, "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_of_the_draws": ms_draws[1:-1],
+        placement_search = {"state_restored": restored, "draws": args.placement_draws, "kept": kept, "iterations_per_probe": 12, "reflushes": h.get_option("stat_field_reflushes"), "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_of_the_draws": ms_draws[1:-1],
                             "ms_per_iteration_kept": ms_draws[-1], "seconds": time.perf_counter() - ts,
                             "what": "jrx_stokes3d_tune_placement: new physical chunks under every array in place, 12 iterations timed, the draw kept if it is the fastest so far (-1: draw not made, "
                                     "no room for a second copy of the arrays); setup, not part of any timed region; the initial state is restored afterwards"}

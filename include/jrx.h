@@ -126,7 +126,7 @@ jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
  *   the slow rate).  Results never depend on it.
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
  *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_fused3d_inkernel" = those that finished the faces with a neighbour themselves ("fused_overlap" = 3), "stat_visc_checks" /
- *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_operand_cache_hits" = driver calls that reused the operand verdict, "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
+ *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_operand_cache_hits" = driver calls that reused the operand verdict, "stat_field_reflushes" = re-mappings of the field pool that had to be flushed and copied again (their first copy had not reached the new chunks), "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
  *   (and the tests, and bench.py for the kernel it prices) can prove which path ran. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 /* the caller has written to an operand array (tau_o, P0, Q, K, G, eta, rho g) since the last driver call: a cached verdict of the operand pass ("operand_cache") is dropped */

@@ -27,7 +27,7 @@ struct jrx_field_pool {
     std::map<size_t, std::vector<hipMemGenericAllocationHandle_t>> spare;      // created, unmapped chunks by their size
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     double create_ms = 0, map_ms = 0;
-    int64_t chunks_created = 0, bytes_live = 0, rerolls = 0, large_allocs = 0;
+    int64_t chunks_created = 0, bytes_live = 0, rerolls = 0, large_allocs = 0, lost_remaps = 0;
     std::vector<void *> ballast;                  // "field_ballast_mib": allocations nobody uses, made behind every large array so that the arrays spread over the device's memory
     void *stage = nullptr;                        // jrx_tuning_field_reroll: the contents of the array being re-mapped
     size_t stage_bytes = 0;
@@ -42,6 +42,14 @@ namespace {
 __global__ void k_pool_copy(double *__restrict__ dst, const double *__restrict__ src, size_t n)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// remap_with checks where its writes went (see there): words of `a` (the new chunks through a range of their own) that differ from `b` (the staged contents)
+__global__ void k_pool_diff(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b, size_t n, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+    if (c) atomicAdd(out, c);
 }
 
 // STALE TRANSLATIONS.  On this ROCm release (7.2, gfx950) hipMemUnmap + hipMemMap of OTHER chunks at an address that was mapped before leaves the shaders with the OLD translation:
@@ -217,9 +225,41 @@ jrx_status remap_with(jrx_handle *h, jrx_field_pool *P, void *key, jrx_field_poo
     if (e == hipSuccess) e = hipMemSetAccess(va, A.mapped, &acc, 1);
     if (e == hipSuccess) e = flush_translations();
     if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_tuning_field_reroll: re-mapping the array at %p -> %s (the array has lost its backing)", va, hipGetErrorString(e)); }
-    hipLaunchKernelGGL(k_pool_copy, dim3(4096), dim3(256), 0, 0, (double *)key, (const double *)P->stage, nw);
-    e = hipDeviceSynchronize();
-    if (e != hipSuccess) { (void)hipGetLastError(); return jrx_fail(h, JRX_ERR_HIP, "jrx_tuning_field_reroll: copying the contents back -> %s", hipGetErrorString(e)); }
+    // DID THE COPY LAND?  The flush above is a side effect, not a contract; a lost one is silent corruption (the copy goes to the old chunks, the array then shows whatever the new ones
+    // held -- NaNs of an earlier test, in the GPU suite).  So the new chunks are mapped a second time at a range that has never been used -- no translation of it can be stale -- and
+    // compared with the staged contents there.  Not landed: flush again, copy again, up to four times; then the old chunks (which hold the contents either way: a stale copy wrote
+    // the same values back into them) are put back under the array and the re-roll fails.
+    void *alias = nullptr;
+    unsigned long long *cnt = nullptr, bad = 1;
+    // (the second range comes from the parked list when there is one of that size: a stale translation of IT makes the comparison fail, never pass, and the next round -- behind
+    // another flush -- sees the truth)
+    hipError_t ea = va_reserve(&alias, A.mapped, (size_t)2 << 20);
+    for (size_t c = 0; c < nch && ea == hipSuccess; c++) ea = hipMemMap((char *)alias + c * chunk, chunk, 0, fresh[c], 0);
+    if (ea == hipSuccess) ea = hipMemSetAccess(alias, A.mapped, &acc, 1);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&cnt, 8);
+    for (int attempt = 0; attempt < 4 && ea == hipSuccess && bad; attempt++) {
+        if (attempt) { P->lost_remaps++; h->stat_field_reflushes++; ea = flush_translations(); if (ea != hipSuccess) break; }
+        hipLaunchKernelGGL(k_pool_copy, dim3(4096), dim3(256), 0, 0, (double *)key, (const double *)P->stage, nw);
+        ea = hipMemset(cnt, 0, 8);
+        if (ea != hipSuccess) break;
+        hipLaunchKernelGGL(k_pool_diff, dim3(4096), dim3(256), 0, 0, (const unsigned long long *)((char *)alias + A.skew), (const unsigned long long *)P->stage, nw, cnt);
+        ea = hipMemcpy(&bad, cnt, 8, hipMemcpyDeviceToHost);
+    }
+    if (cnt) (void)hipFree(cnt);
+    if (alias) { (void)hipMemUnmap(alias, A.mapped); va_release(alias, A.mapped); }
+    if (ea != hipSuccess || bad) {
+        (void)hipGetLastError();
+        // back onto the chunks the array had
+        hipError_t eb = hipDeviceSynchronize();
+        if (eb == hipSuccess) eb = hipMemUnmap(va, A.mapped);
+        for (size_t c = 0; c < A.chunks.size() && eb == hipSuccess; c++) eb = hipMemMap((char *)va + c * chunk, chunk, 0, A.chunks[c], 0);
+        if (eb == hipSuccess) eb = hipMemSetAccess(va, A.mapped, &acc, 1);
+        if (eb == hipSuccess) eb = flush_translations();
+        (void)hipGetLastError();
+        if (ea != hipSuccess) return jrx_fail(h, JRX_ERR_HIP, "jrx_tuning_field_reroll: checking the re-mapped array at %p -> %s%s", va, hipGetErrorString(ea), eb == hipSuccess ? " (the array is back on its chunks)" : " (and the array has lost its backing)");
+        return jrx_fail(h, JRX_ERR_HIP, "jrx_tuning_field_reroll: %llu of %zu words written through the re-mapped range %p did not reach its new chunks after four flushes%s", bad, nw, va,
+                        eb == hipSuccess ? " (the array is back on its old chunks)" : " (and the array has lost its backing)");
+    }
     return JRX_OK;
 }
 // Give one chunk-backed array new physical backing IN PLACE: its virtual range, and therefore every pointer the caller and the library hold, stays as it is; its contents are carried over.  New chunks: spare ones first, in shuffled order; freshly created ones if the spare list is short; the old chunks join the spare list.  An experiment

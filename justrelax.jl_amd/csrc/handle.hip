@@ -115,7 +115,7 @@ int find_opt(jrx_handle *h, const char *key, bool tuning, OptRef *out)
     const OptRef pub[] = {
         {"kernel_variant", 1, &h->kernel_variant}, {"fused_overlap", 1, &h->fused_overlap}, {"thermal_fused", 0, &h->thermal_fused},
         {"fused_comm", 0, &h->fused_comm}, {"loop_graphs", 0, &h->loop_graphs}, {"scratch_sets", 0, &h->scratch_sets},
-        {"viscous_limit", 0, &h->viscous_limit}, {"field_placement", 1, &h->field_placement}, {"operand_cache", 0, &h->operand_cache}, {"stat_operand_cache_hits", 2, &h->stat_operand_cache_hits}, {"stat_fused3d_general_hif", 2, &h->stat_fused3d_general_hif},
+        {"viscous_limit", 0, &h->viscous_limit}, {"field_placement", 1, &h->field_placement}, {"operand_cache", 0, &h->operand_cache}, {"stat_operand_cache_hits", 2, &h->stat_operand_cache_hits}, {"stat_field_reflushes", 2, &h->stat_field_reflushes}, {"stat_fused3d_general_hif", 2, &h->stat_fused3d_general_hif},
         {"stat_fused3d", 2, &h->stat_fused3d}, {"stat_fused2d", 2, &h->stat_fused2d}, {"stat_thermal_fused", 2, &h->stat_thermal_fused},
         {"stat_vep3_fused", 2, &h->stat_vep3_fused}, {"stat_graph_replays", 2, &h->stat_graph_replays},
         {"stat_fused3d_visc", 2, &h->stat_fused3d_visc}, {"stat_fused3d_inkernel", 2, &h->stat_fused3d_inkernel}, {"stat_visc_checks", 2, &h->stat_visc_checks}, {"stat_visc_fallbacks", 2, &h->stat_visc_fallbacks}, {"stat_fused3d_nof1", 2, &h->stat_fused3d_nof1}, {"stat_fused3d_nof2", 2, &h->stat_fused3d_nof2},

@@ -71,6 +71,7 @@ struct jrx_handle {
     bool operand_cache = false;
     struct { bool valid = false; const void *ptr[14] = {}; int64_t n[3] = {}; double dt = 0.0; int flags = 0; bool visc_ok = false; int nof = 0; } opv;
     int64_t stat_operand_cache_hits = 0;
+    int64_t stat_field_reflushes = 0;    // re-mappings of the field pool whose copy had not landed in the new chunks at the first check (flushed and copied again)
     int nof = 0;                         // set per driver call by the operand pass: 0 = every ρg array is loaded, 1 = ρg_x and ρg_y hold only +0.0, 2 = all three do
     bool visc_fold = true;               // viscous-limit fused kernel: the arithmetic with the exact zeros folded away (one division per thread for dτ_r, no division by 1 in compute_P!; same bits; A/B)
     bool fused_hiface = true;            // viscous-limit fused kernel without neighbours: the high-face node layers inside the kernel (0: the boundary-layer launch behind it, A/B)

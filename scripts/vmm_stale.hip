@@ -78,6 +78,29 @@ int main(int argc, char **argv)
             }
         }
     }
+    {   // may one chunk set be mapped at two ranges at once?  (a second, never-used range would let the pool CHECK where its writes went)
+        const int nch = 3;
+        void *v1 = nullptr, *v2 = nullptr;
+        CK(hipMemAddressReserve(&v1, nch * CH, 0, nullptr, 0)); CK(hipMemAddressReserve(&v2, nch * CH, 0, nullptr, 0));
+        Chunks A = create(nch);
+        map_at(v1, A);
+        hipError_t e = hipSuccess;
+        for (size_t q = 0; q < A.h.size() && e == hipSuccess; q++) e = hipMemMap((char *)v2 + q * CH, CH, 0, A.h[q], 0);
+        if (e == hipSuccess) e = hipMemSetAccess(v2, nch * CH, &acc, 1);
+        if (e != hipSuccess) { (void)hipGetLastError(); printf("a second mapping of the same chunks: refused (%s)\n", hipGetErrorString(e)); }
+        else {
+            k_fill<<<1024, 256>>>((unsigned *)v1, nch * CH / 4, 77u);
+            CK(hipDeviceSynchronize());
+            CK(hipMemset(d_out, 0, 8));
+            k_count<<<1024, 256>>>((const unsigned *)v2, nch * CH / 4, 77u, d_out);
+            unsigned long long r = 0;
+            CK(hipMemcpy(&r, d_out, 8, hipMemcpyDeviceToHost));
+            printf("a second mapping of the same chunks: allowed; %.1f %% of what was written through the first range is read through the second\n", 100.0 * r / (nch * CH / 4));
+            CK(hipMemUnmap(v2, nch * CH));
+        }
+        CK(hipMemUnmap(v1, nch * CH));
+        for (auto x : A.h) CK(hipMemRelease(x));
+    }
     // ---- how reliable is a flush?  300 re-mappings each, 6 chunks of 2 MiB, the range and both chunk sets reused every time (as a pool does)
     {
         const int nch = 6;
@@ -86,8 +109,9 @@ int main(int argc, char **argv)
         CK(hipMemAddressReserve(&va, nch * CH, 0, nullptr, 0));
         Chunks A = create(nch), B = create(nch);
         static char hostbuf[1 << 16];
-        const char *fn[] = {"hipHostMalloc + hipHostFree 4 KiB", "hipHostRegister + hipHostUnregister 64 KiB", "hipStreamCreate + hipStreamDestroy", "hipHostMalloc + hipHostFree of a size that changes every time"};
-        for (int F = 0; F < 4; F++) {
+        const char *fn[] = {"hipHostMalloc + hipHostFree 4 KiB", "hipHostRegister + hipHostUnregister 64 KiB", "hipStreamCreate + hipStreamDestroy", "hipHostMalloc + hipHostFree of a size that changes every time", "hipMalloc + hipFree 256 MiB", "hipHostMalloc + hipHostFree 4 KiB with other host allocations coming and going"};
+        std::vector<void *> others;
+        for (int F = 0; F < 6; F++) {
             int bad = 0;
             unsigned long long lost = 0;
             for (int it = 0; it < 300; it++) {
@@ -103,7 +127,13 @@ int main(int argc, char **argv)
                 case 0: CK(hipHostMalloc(&t, 4096)); CK(hipHostFree(t)); break;
                 case 1: CK(hipHostRegister(hostbuf, sizeof hostbuf, hipHostRegisterDefault)); CK(hipHostUnregister(hostbuf)); break;
                 case 2: CK(hipStreamCreate(&st)); CK(hipStreamDestroy(st)); break;
-                default: CK(hipHostMalloc(&t, 4096 * (1 + it % 37))); CK(hipHostFree(t)); break;
+                case 3: CK(hipHostMalloc(&t, 4096 * (1 + it % 37))); CK(hipHostFree(t)); break;
+                case 4: CK(hipMalloc(&t, (size_t)256 << 20)); CK(hipFree(t)); break;
+                default: {      // a busy process: pinned buffers of many sizes are allocated and freed around the flush
+                    for (int q = 0; q < 3; q++) { void *o = nullptr; CK(hipHostMalloc(&o, 4096 << ((it + q) % 9))); others.push_back(o); }
+                    CK(hipHostMalloc(&t, 4096)); CK(hipHostFree(t));
+                    while (others.size() > 8) { CK(hipHostFree(others.front())); others.erase(others.begin()); }
+                } break;
                 }
                 k_fill<<<1024, 256>>>((unsigned *)va, words, 2u + (unsigned)it);
                 CK(hipDeviceSynchronize());

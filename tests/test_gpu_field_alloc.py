@@ -183,6 +183,10 @@ def test_placement_search_keeps_addresses_and_a_restored_state_solves_to_the_sam
                 created0 = _stats(h)[2]
                 ms, kept = stokes.tune_placement_(st, s.pt, s.grid, s.flow_bcs, ρg, K, G, ητ, s.dt, 3, 4, handle=h)
                 assert len(ms) == 5 and all(m > 0 for m in ms) and 0 <= kept <= 3
+                import os
+                if os.environ.get("JRX_DIAG_FILE"):          # how often a re-mapping had to be flushed and copied a second time (csrc/fieldpool.hip, remap_with)
+                    with open(os.environ["JRX_DIAG_FILE"], "a") as fdiag:
+                        fdiag.write(f"tune test chunk {chunk_mib} pool {pool_pct}: stat_field_reflushes {h.get_option('stat_field_reflushes')}\n")
                 assert [st.P.data_ptr(), st.V.Vx.data_ptr(), st.τ.xy.data_ptr(), ητ.data_ptr()] == ptr0
                 assert _stats(h)[2] > created0 and _stats(h)[3] == 0        # draws were made, and the chunks of those that lost went back to the driver
                 if pool_pct:
