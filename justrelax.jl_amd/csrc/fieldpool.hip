@@ -52,6 +52,18 @@ __global__ void k_pool_diff(const unsigned long long *__restrict__ a, const unsi
     if (c) atomicAdd(out, c);
 }
 
+// alloc_chunks checks a fresh mapping at a range that was used before (see there): one word per 2 MiB page is stamped through the range and looked for through a second mapping
+__global__ void k_pool_stamp(unsigned long long *p, size_t pages, size_t stride_words, unsigned long long nonce)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pages; i += (size_t)gridDim.x * blockDim.x) p[i * stride_words] = nonce + i;
+}
+__global__ void k_pool_stamped(const unsigned long long *p, size_t pages, size_t stride_words, unsigned long long nonce, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pages; i += (size_t)gridDim.x * blockDim.x) c += p[i * stride_words] != nonce + i;
+    if (c) atomicAdd(out, c);
+}
+
 // STALE TRANSLATIONS.  On this ROCm release (7.2, gfx950) hipMemUnmap + hipMemMap of OTHER chunks at an address that was mapped before leaves the shaders with the OLD translation:
 // scripts/vmm_stale.hip -- 100 % of the words a kernel writes through the re-mapped range land in the old chunks, for ranges of 2 .. 128 MiB, whether or not a hipDeviceSynchronize, a
 // 20 ms sleep, a hipMalloc / hipFree, a copy, a memset or a complete earlier kernel lies in between; after a hipHostMalloc + hipHostFree (or a hipStreamCreate + destroy) 100 % land in
@@ -187,12 +199,36 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, size_t s
     acc.flags = hipMemAccessFlagsProtReadWrite;
     hipError_t e = hipMemSetAccess(va, nch * chunk, &acc, 1);
     if (e == hipSuccess) e = flush_translations();       // the range may have been mapped before (arena sub-range, a reservation handed out again)
+    // ... and whether the flush took is checked (it is a side effect, not a contract; what a lost one costs: the caller's first writes go to chunks that belong to somebody else).  One
+    // word per 2 MiB page is stamped through the range and looked for through a second mapping of the same chunks; not there: flush again, up to four times.
+    if (e == hipSuccess) {
+        void *alias = nullptr;
+        unsigned long long *cnt = nullptr, bad = 1;
+        const size_t pages = nch * chunk / ((size_t)2 << 20), strw = ((size_t)2 << 20) / 8;
+        hipError_t ea = va_reserve(&alias, nch * chunk, gran);
+        for (size_t c = 0; c < nch && ea == hipSuccess; c++) ea = hipMemMap((char *)alias + c * chunk, chunk, 0, A.chunks[c], 0);
+        if (ea == hipSuccess) ea = hipMemSetAccess(alias, nch * chunk, &acc, 1);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&cnt, 8);
+        for (int attempt = 0; attempt < 4 && ea == hipSuccess && bad; attempt++) {
+            if (attempt) { h->stat_field_reflushes++; ea = flush_translations(); if (ea != hipSuccess) break; }
+            const unsigned long long nonce = 0x9E3779B97F4A7C15ull * (unsigned long long)(P->chunks_created + 7 * attempt + 1) + (unsigned long long)(uintptr_t)va;
+            hipLaunchKernelGGL(k_pool_stamp, dim3(64), dim3(256), 0, 0, (unsigned long long *)va, pages, strw, nonce);
+            ea = hipMemset(cnt, 0, 8);
+            if (ea != hipSuccess) break;
+            hipLaunchKernelGGL(k_pool_stamped, dim3(64), dim3(256), 0, 0, (const unsigned long long *)alias, pages, strw, nonce, cnt);
+            ea = hipMemcpy(&bad, cnt, 8, hipMemcpyDeviceToHost);
+        }
+        if (cnt) (void)hipFree(cnt);
+        if (alias) { (void)hipMemUnmap(alias, nch * chunk); va_release(alias, nch * chunk); }
+        if (ea != hipSuccess) { (void)hipGetLastError(); e = ea; }
+        else if (bad) e = hipErrorUnknown;
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipMemUnmap(va, A.mapped);
         for (auto x : A.chunks) sp.push_back(x);
         if (in_arena) P->arena_free.insert({nch * chunk, va}); else va_release(va, nch * chunk);
-        return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemSetAccess / flush -> %s", hipGetErrorString(e));
+        return jrx_fail(h, JRX_ERR_HIP, "jrx_field_alloc: hipMemSetAccess / flush / check of the new mapping -> %s", hipGetErrorString(e));
     }
     P->map_ms += ms_since(t1);
     P->live[(char *)va + skew] = std::move(A);

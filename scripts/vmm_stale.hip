@@ -111,6 +111,8 @@ int main(int argc, char **argv)
         static char hostbuf[1 << 16];
         const char *fn[] = {"hipHostMalloc + hipHostFree 4 KiB", "hipHostRegister + hipHostUnregister 64 KiB", "hipStreamCreate + hipStreamDestroy", "hipHostMalloc + hipHostFree of a size that changes every time", "hipMalloc + hipFree 256 MiB", "hipHostMalloc + hipHostFree 4 KiB with other host allocations coming and going"};
         std::vector<void *> others;
+        hipStream_t old_stream; CK(hipStreamCreateWithFlags(&old_stream, hipStreamNonBlocking));
+        k_fill<<<64, 256, 0, old_stream>>>((unsigned *)d_out, 0, 0u); CK(hipDeviceSynchronize());
         for (int F = 0; F < 6; F++) {
             int bad = 0;
             unsigned long long lost = 0;
@@ -135,7 +137,8 @@ int main(int argc, char **argv)
                     while (others.size() > 8) { CK(hipHostFree(others.front())); others.erase(others.begin()); }
                 } break;
                 }
-                k_fill<<<1024, 256>>>((unsigned *)va, words, 2u + (unsigned)it);
+                // the writing kernel runs on a stream that existed before the re-mapping (as the library's own stream does), a large grid so that every XCD takes part
+                hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, old_stream, (unsigned *)va, words, 2u + (unsigned)it);
                 CK(hipDeviceSynchronize());
                 CK(hipMemset(d_out, 0, 8));
                 k_count<<<1024, 256>>>((const unsigned *)va, words, 2u + (unsigned)it, d_out);      // read back through the same range, as a later kernel of the application would
