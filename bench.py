@@ -1387,8 +1387,10 @@ def ipc_helper(args) -> int:
     from __graft_entry__ import load_package
     jr = load_package()
     torch.cuda.set_device(0)
-    args.placement_draws = 0       # two processes share this device: no room for a second copy of both blocks, and the leg quotes paired overheads on the same arrays
+    # two processes share this device: a smaller pool each (a quarter of what is free) and fewer draws; where there is no room a draw is simply not made
+    args.placement_draws = min(args.placement_draws, 4)
     R = GpuRanks(args, jr, rank, 2, 0)
+    R.h.set_option("field_pool_pct", 25)
     for kv in args.option:
         k, v = kv.split("=")
         R.h.set_option(k, int(v))
