@@ -473,7 +473,7 @@ def cfg_solvi(jr, h, n, steps, warm, draws=8):
             ms_draws, kept = stokes.tune_placement_(st, pt, geo, bcs, ρg, K, G, ητ, dt, draws, 24, handle=h)
             restore_state(held)
             restored, held = held is not None, None
-            search = {"state_restored": restored, "draws": draws, "kept": kept, "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_of_the_draws": ms_draws[1:-1], "ms_per_iteration_kept": ms_draws[-1],
+            search = {"state_restored": restored, "draws": draws, "kept": kept, "ms_as_allocated": ms_draws[0], "ms_of_the_draws": ms_draws[1:-1], "ms_kept": ms_draws[-1],
                       "seconds": time.perf_counter() - ts}
         run = lambda k: stokes.iterate_timed_(st, pt, geo, bcs, ρg, K, G, ητ, dt, k, handle=h)
         run(warm)
@@ -730,7 +730,7 @@ def cfg_multi_rank_path(jr, n=512, steps=40, warm=6, only=None, splits=("x", "z"
                 blocks.append((st, pt, geo, bcs, ρg, K, G, ητ, dt))
             for r in range(nr if draws > 0 else 0):          # one block at a time: a draw needs room for a second copy of that block's arrays only
                 ms_draws, kept = stokes.tune_placement_(*blocks[r], draws, 12, handle=hs[r])
-                search.append({"kept": kept, "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_kept": ms_draws[-1]})
+                search.append({"kept": kept, "ms_as_allocated": ms_draws[0], "ms_kept": ms_draws[-1]})
             res["placement_search"] = search
             # the quoted mode against the same blocks WITHOUT the communicator, alternating: one pair is not evidence (single pairs spanned 0.9 - 14.5 %) -- the
             # median of the paired overheads and their spread are reported
@@ -1030,8 +1030,8 @@ class GpuRanks:
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
             halo.update_halo_(st.V.Vx, st.V.Vy, st.V.Vz, ητ, ni=(n, n, n), handle=self.h)
-            self.placement_search = {"state_restored": restored, "draws": self.args.placement_draws, "kept": kept, "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_of_the_draws": ms_draws[1:-1],
-                                     "ms_per_iteration_kept": ms_draws[-1], "seconds": time.perf_counter() - ts}
+            self.placement_search = {"state_restored": restored, "draws": self.args.placement_draws, "kept": kept, "ms_as_allocated": ms_draws[0], "ms_of_the_draws": ms_draws[1:-1],
+                                     "ms_kept": ms_draws[-1], "seconds": time.perf_counter() - ts}
 
     def _library_arrays_everywhere(self):
         """field_placement = 1 and the constructors routed through jrx_field_alloc -- on every rank or on none (a rank whose driver refuses the virtual-memory calls keeps torch's arrays,
@@ -1711,8 +1711,9 @@ def run_rank(args) -> int:
         restored, held = held is not None, None
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        placement_search = {"state_restored": restored, "draws": args.placement_draws, "kept": kept, "iterations_per_probe": 12, "reflushes": h.get_option("stat_field_reflushes"), "ms_per_iteration_as_allocated": ms_draws[0], "ms_per_iteration_of_the_draws": ms_draws[1:-1],
-                            "ms_per_iteration_kept": ms_draws[-1], "seconds": time.perf_counter() - ts,
+        placement_search = {"state_restored": restored, "draws": args.placement_draws, "kept": kept, "iterations_per_probe": 12, "reflushes": h.get_option("stat_field_reflushes"), "ms_as_allocated": ms_draws[0], "ms_of_the_draws": ms_draws[1:-1],
+                            "ms_kept": ms_draws[-1], "seconds": time.perf_counter() - ts,
+                            "ms_is": "mean k_fused3d launch of the probe's batch",
                             "what": "jrx_stokes3d_tune_placement: new physical chunks under every array in place, 12 iterations timed, the draw kept if it is the fastest so far (-1: draw not made, "
                                     "no room for a second copy of the arrays); setup, not part of any timed region; the initial state is restored afterwards"}
 

@@ -665,8 +665,8 @@ jrx_status jrx_compute_shear_heating(jrx_handle *h, double *shear_heating, const
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
                                       const jrx_stokes3d_params *p, int64_t iters, double times_ms[6]);
 
-/* jrx_field_tune with the 3D Stokes loop body as the probe: `iters` (>= 2) iterations timed as by jrx_stokes3d_iterate_timed per draw; ms_per_iter as ms of jrx_field_tune, per
- * iteration.  The fields are advanced by all those iterations: call it before the initial state is written (or write it again). */
+/* jrx_field_tune with the 3D Stokes loop body as the probe: `iters` (>= 2) iterations timed as by jrx_stokes3d_iterate_timed per draw; ms_per_iter as ms of jrx_field_tune: the mean
+ * launch time of the fused kernel where the batch fused (a quantity of this rank alone), the time per iteration otherwise.  The fields are advanced by all those iterations: call it before the initial state is written (or write it again). */
 jrx_status jrx_stokes3d_tune_placement(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, int32_t draws, int64_t iters,
                                        double *ms_per_iter, int32_t *kept);
 

@@ -1495,7 +1495,9 @@ jrx_status jrx_stokes3d_tune_placement(jrx_handle *h, const jrx_stokes3d_fields 
         double t[6];
         if (jrx_stokes3d_iterate_timed(c->h, c->f, c->etatau, c->p, 2, t) != JRX_OK) return -1.0;        // the first launches behind a re-mapping also pay for the translations
         if (jrx_stokes3d_iterate_timed(c->h, c->f, c->etatau, c->p, c->iters, t) != JRX_OK) return -1.0;
-        return t[0] / (double)c->iters;
+        // what is compared: the launch time of the fused kernel alone where the batch fused (a quantity of this rank: with neighbours the time of a whole iteration also holds
+        // the wait for the slowest of them, and a rank would throw a good draw away because a neighbour drew a bad one), the time per iteration otherwise
+        return t[4] > 0.0 ? t[4] : t[0] / (double)c->iters;
     };
     // arrays the loop body's dominant kernel does not touch stay where they are: a draw then moves 22 arrays instead of 55 (the strain rates, displacements, residuals and centre
     // copies never; τ_o, P0, Q, K, G, and the body forces when the viscous-limit kernels without them stand in -- which the first probe's operand pass decides)

@@ -15,5 +15,5 @@ import json
 for i in range(1, 13):
     d = json.load(open("$OUT/p%d.json" % i)); r = d["roofline"]; ps = r.get("placement_search") or {}
     print("process %2d: %6.1f it/s (20 steps) %6.1f (100 steps)  k_fused3d %.3f ms  | %s" % (i, d["value"], (d.get("steady_state") or {}).get("value") or 0.0, r["avg_launch_ms"],
-          ("search: %.3f ms per iteration as allocated -> %.3f, %d of %d draws kept, %.1f s" % (ps["ms_per_iteration_as_allocated"], ps["ms_per_iteration_kept"], ps["kept"], ps["draws"], ps["seconds"])) if ps.get("draws") else "no search (--placement-draws 0, torch's arrays)"))
+          ("search: %.3f ms as allocated -> %.3f, %d of %d draws kept, %.1f s" % (ps["ms_as_allocated"], ps["ms_kept"], ps["kept"], ps["draws"], ps["seconds"])) if ps.get("draws") else "no search (--placement-draws 0, torch's arrays)"))
 PY
