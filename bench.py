@@ -1706,14 +1706,18 @@ def run_rank(args) -> int:
         # the search advances the fields: the initial state is set aside and written back afterwards (outside every timed region, like the allocation itself)
         ts = time.perf_counter()
         held = hold_state(st)
-        ms_draws, kept = stokes.tune_placement_(st, pt, geo, bcs, ρg, K, G, ητ, dt, args.placement_draws, 12, handle=h)
+        try:
+            ms_draws, kept = stokes.tune_placement_(st, pt, geo, bcs, ρg, K, G, ητ, dt, args.placement_draws, 12, handle=h)
+            search_error = None
+        except Exception as e:      # noqa: BLE001 -- a search that fails leaves the arrays on the chunks they had (csrc/fieldpool.hip); the run goes on and says so
+            ms_draws, kept, search_error = [-1.0] * (args.placement_draws + 2), 0, f"{type(e).__name__}: {e}"
         restore_state(held)
         restored, held = held is not None, None
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         placement_search = {"state_restored": restored, "draws": args.placement_draws, "kept": kept, "iterations_per_probe": 12, "reflushes": h.get_option("stat_field_reflushes"), "ms_as_allocated": ms_draws[0], "ms_of_the_draws": ms_draws[1:-1],
                             "ms_kept": ms_draws[-1], "seconds": time.perf_counter() - ts,
-                            "ms_is": "mean k_fused3d launch of the probe's batch",
+                            "ms_is": "mean k_fused3d launch of the probe's batch", "error": search_error,
                             "what": "jrx_stokes3d_tune_placement: new physical chunks under every array in place, 12 iterations timed, the draw kept if it is the fastest so far (-1: draw not made, "
                                     "no room for a second copy of the arrays); setup, not part of any timed region; the initial state is restored afterwards"}
 
