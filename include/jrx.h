@@ -69,15 +69,17 @@ const char *jrx_build_id(void);
  * src/types/constructors/stokes.jl:279-303) -- a binding wraps the pointer (Julia: unsafe_wrap(ROCArray, ptr, dims; own = false) plus a
  * finalizer that calls jrx_field_free).  Contents are NOT initialised (the constructor fills with zeros as @zeros does).  Using it is
  * optional: every entry point takes any device pointer.  What it buys: the option "field_placement" decides how the arrays are backed
- * physically, which the large 3D kernels were suspected to be sensitive to (profiles/r05_placement.txt: they are not); the library's own large arrays (second state sets, ητ)
- * follow the same option .  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns unmapped spare chunks to the driver.
+ * physically, and the large 3D kernels are sensitive to that (the same launch takes 4.7 .. 6.9 ms at 512^3: DESIGN.md section 0, profiles/r05_placement_search.txt) -- arrays of
+ * "field_placement" = 1 can be moved to other physical memory in place, which is what jrx_field_tune below searches with; the library's own large arrays (second state sets, ητ)
+ * follow the same option.  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns unmapped spare chunks to the driver.
  * jrx_field_stats: [0] live arrays (the library's own included), [1] their bytes, [2] physical chunks created, [3] spare chunks, [4] us in hipMemCreate, [5] us mapping. */
 jrx_status jrx_field_alloc(jrx_handle *h, int64_t count, double **out);     /* count doubles */
 jrx_status jrx_field_free(jrx_handle *h, double *p);
 jrx_status jrx_field_trim(jrx_handle *h);
 /* jrx_field_tune: the placement search.  Chunk-backed arrays ("field_placement" = 1: the caller's from jrx_field_alloc and the library's own) can be given other physical memory
  * without their addresses or contents changing, and the time of the large kernels depends on that memory (4.7 .. 6.2 ms for the same launch at 512^3, 0.67 / 0.79 ms at 256^3 on one
- * device: profiles/r05_placement.txt) in a way only a run can tell.  So: `draws` times, new chunks under every chunk-backed array of the handle, probe(ctx) -- the caller runs
+ * device: profiles/r05_placement_search.txt) in a way only a run can tell.  So: `draws` times, new chunks under every chunk-backed array of the handle (random chunks of a pool that spans
+ * most of the free memory when every array is ONE chunk of one common size: tuning key "field_chunk_mib" = the largest array's size, include/jrx_tuning.h), probe(ctx) -- the caller runs
  * what it is going to run and returns its time in ms (> 0) -- and the draw is kept if it beat the best so far by 0.3 %, undone otherwise.  ms[0] = as allocated, ms[1 .. draws] = the
  * draws (-1: not made -- a draw needs room for a second copy of the arrays; the search ends when there is none), ms[draws + 1] = the placement that stays (measured again);
  * *kept = draws kept.  Whatever the probe does to the arrays' contents is the caller's business (run it before the initial state is written, or write it again).  With neighbours
@@ -122,8 +124,8 @@ jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
  *   inside a solve! of thousands of iterations, 3 % of a 20-iteration batch.  1 = the verdict is kept per (operand pointers, extents, dt) and reused until the caller states that
  *   it has written to one of those arrays: jrx_fields_dirty(h).  The library's own writes (the tau -> tau_o copy at the end of solve!) invalidate it themselves.  Default 0: every call looks.
  * "field_placement" (0/1/2, default 0): backing of the arrays of jrx_field_alloc and of the library's own large arrays: 0 = hipMalloc; 1 = physical chunks
- *   (hipMemCreate) mapped onto one virtual range per array in a shuffled order; 2 = physically contiguous (hipDeviceMallocContiguous; the A/B reproducer of
- *   the slow rate).  Results never depend on it.
+ *   (hipMemCreate) mapped onto one virtual range per array in a shuffled order; 2 = physically contiguous (hipDeviceMallocContiguous; the slowest placement there
+ *   is, for A/B runs).  Results never depend on it.
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
  *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_fused3d_inkernel" = those that finished the faces with a neighbour themselves ("fused_overlap" = 3), "stat_visc_checks" /
  *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_operand_cache_hits" = driver calls that reused the operand verdict, "stat_field_reflushes" = re-mappings of the field pool that had to be flushed and copied again (their first copy had not reached the new chunks), "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
