@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JRX_VERSION 221
+#define JRX_VERSION 230
 
 typedef enum jrx_status {
     JRX_OK = 0,
@@ -69,23 +69,15 @@ const char *jrx_build_id(void);
  * src/types/constructors/stokes.jl:279-303) -- a binding wraps the pointer (Julia: unsafe_wrap(ROCArray, ptr, dims; own = false) plus a
  * finalizer that calls jrx_field_free).  Contents are NOT initialised (the constructor fills with zeros as @zeros does).  Using it is
  * optional: every entry point takes any device pointer.  What it buys: the option "field_placement" decides how the arrays are backed
- * physically, and the large 3D kernels are sensitive to that (the same launch takes 4.7 .. 6.9 ms at 512^3: DESIGN.md section 0, profiles/r05_placement_search.txt) -- arrays of
- * "field_placement" = 1 can be moved to other physical memory in place, which is what jrx_field_tune below searches with; the library's own large arrays (second state sets, ητ)
- * follow the same option.  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns unmapped spare chunks to the driver.
+ * physically, and the large 3D kernels are sensitive to that (the same launch takes 4.7 .. 6.9 ms at 512^3: DESIGN.md section 3, profiles/r05_placement_search.txt).  With
+ * "field_placement" = 1 every large array is mapped ONCE, at a virtual range never used before, onto physical chunks picked at random from a pool that spans most of the free
+ * memory (tuning keys "field_chunk_mib", "field_pool_pct": include/jrx_tuning.h); the library's own large arrays (second state sets, ητ) follow the same option.  An array is
+ * never moved afterwards.  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns the pool's unused chunks to the driver (call it once the arrays of a
+ * run exist -- the library's second state set is made by the first driver call).
  * jrx_field_stats: [0] live arrays (the library's own included), [1] their bytes, [2] physical chunks created, [3] spare chunks, [4] us in hipMemCreate, [5] us mapping. */
 jrx_status jrx_field_alloc(jrx_handle *h, int64_t count, double **out);     /* count doubles */
 jrx_status jrx_field_free(jrx_handle *h, double *p);
 jrx_status jrx_field_trim(jrx_handle *h);
-/* jrx_field_tune: the placement search.  Chunk-backed arrays ("field_placement" = 1: the caller's from jrx_field_alloc and the library's own) can be given other physical memory
- * without their addresses or contents changing, and the time of the large kernels depends on that memory (4.7 .. 6.2 ms for the same launch at 512^3, 0.67 / 0.79 ms at 256^3 on one
- * device: profiles/r05_placement_search.txt) in a way only a run can tell.  So: `draws` times, new chunks under every chunk-backed array of the handle (random chunks of a pool that spans
- * most of the free memory when every array is ONE chunk of one common size: tuning key "field_chunk_mib" = the largest array's size, include/jrx_tuning.h), probe(ctx) -- the caller runs
- * what it is going to run and returns its time in ms (> 0) -- and the draw is kept if it beat the best so far by 0.3 %, undone otherwise.  ms[0] = as allocated, ms[1 .. draws] = the
- * draws (-1: not made -- a draw needs room for a second copy of the arrays; the search ends when there is none), ms[draws + 1] = the placement that stays (measured again);
- * *kept = draws kept.  Whatever the probe does to the arrays' contents is the caller's business (run it before the initial state is written, or write it again).  With neighbours
- * every rank calls it with the same `draws` and a probe that does the same exchanges. */
-typedef double (*jrx_probe_fn)(void *ctx);
-jrx_status jrx_field_tune(jrx_handle *h, int32_t draws, jrx_probe_fn probe, void *ctx, double *ms, int32_t *kept);
 /* jrx_field_list: the live arrays of the handle (bytes[i] < 0: not chunk-backed), count = how many there are (may exceed cap). */
 jrx_status jrx_field_list(jrx_handle *h, int64_t cap, double **ptrs, int64_t *bytes, int64_t *count);
 jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
@@ -124,11 +116,11 @@ jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
  *   inside a solve! of thousands of iterations, 3 % of a 20-iteration batch.  1 = the verdict is kept per (operand pointers, extents, dt) and reused until the caller states that
  *   it has written to one of those arrays: jrx_fields_dirty(h).  The library's own writes (the tau -> tau_o copy at the end of solve!) invalidate it themselves.  Default 0: every call looks.
  * "field_placement" (0/1/2, default 0): backing of the arrays of jrx_field_alloc and of the library's own large arrays: 0 = hipMalloc; 1 = physical chunks
- *   (hipMemCreate) mapped onto one virtual range per array in a shuffled order; 2 = physically contiguous (hipDeviceMallocContiguous; the slowest placement there
+ *   (hipMemCreate) picked at random from a pool and mapped once onto a fresh virtual range per array; 2 = physically contiguous (hipDeviceMallocContiguous; the slowest placement there
  *   is, for A/B runs).  Results never depend on it.
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
  *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_fused3d_inkernel" = those that finished the faces with a neighbour themselves ("fused_overlap" = 3), "stat_visc_checks" /
- *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_operand_cache_hits" = driver calls that reused the operand verdict, "stat_field_reflushes" = re-mappings of the field pool that had to be flushed and copied again (their first copy had not reached the new chunks), "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
+ *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_operand_cache_hits" = driver calls that reused the operand verdict, "stat_graph_replays" = hipGraphLaunch calls -- so that a caller
  *   (and the tests, and bench.py for the kernel it prices) can prove which path ran. */
 jrx_status jrx_set_option(jrx_handle *h, const char *key, int64_t value);
 /* the caller has written to an operand array (tau_o, P0, Q, K, G, eta, rho g) since the last driver call: a cached verdict of the operand pass ("operand_cache") is dropped */
@@ -666,11 +658,6 @@ jrx_status jrx_compute_shear_heating(jrx_handle *h, double *shear_heating, const
  *   whose stresses the launch timed in [4] updates (its units; 0 when nothing was fused). */
 jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau,
                                       const jrx_stokes3d_params *p, int64_t iters, double times_ms[6]);
-
-/* jrx_field_tune with the 3D Stokes loop body as the probe: `iters` (>= 2) iterations timed as by jrx_stokes3d_iterate_timed per draw; ms_per_iter as ms of jrx_field_tune: the mean
- * launch time of the fused kernel where the batch fused (a quantity of this rank alone), the time per iteration otherwise.  The fields are advanced by all those iterations: call it before the initial state is written (or write it again). */
-jrx_status jrx_stokes3d_tune_placement(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, int32_t draws, int64_t iters,
-                                       double *ms_per_iter, int32_t *kept);
 
 #ifdef __cplusplus
 }

@@ -53,18 +53,13 @@
  *   "comm_timeout_ms" (120000)    in-process and ipc transports (jrx_comm_init_local / _ipc): how long a rank waits for a neighbour (host waits and the device-side flag waits)
  *   "chain_profile" (0)           jrx_stokes3d_iterate_timed on a multi-rank handle also records events around the stages of every sampled fused step; read with
  *                                 jrx_tuning_chain_profile
- *   "field_chunk_mib" (64), "field_batch_mib" (0), "field_va_align_mib" (0), "field_shuffle" (1)    jrx_field_alloc with "field_placement" = 1: size of a physical chunk (0: every array is ONE chunk of its own size -- what the placement search uses), the least
- *                                 amount of new chunks created at once (the shuffle then mixes the chunks of several arrays), alignment of the reserved virtual range (0 = the
- *                                 allocation granularity), 0 = chunks in creation order
- *   "field_arena_gib" (0), "field_va_gap_mib" (0)    "field_placement" = 1: > 0 = the chunk-backed arrays lie one behind the other in ONE reserved virtual range of that size, that many MiB apart
- *   "scratch_poison" (0)         test switch: the library's second state set is filled with NaNs when it is allocated (what it holds before its first use must not matter)
+ *   "field_chunk_mib" (64), "field_shuffle" (1)    jrx_field_alloc with "field_placement" = 1: size of a physical chunk (0: every array is ONE chunk of its own size, no pool); a run
+ *                                 whose large arrays should be ONE chunk each sets it to the size of its largest array (bench.py does); 0 = chunks dealt in creation order (A/B of the random dealing)
+ *   "scratch_poison" (0)         test switch: every array the library allocates (second state sets, ητ, jrx_field_alloc) is filled with NaNs first (what it holds before its first use must not matter)
  *   "fused_kz" (0)               chunk depth of the 64 x 8 tile of k_fused3d: 0 = 12 planes from nz = 384 on, 8 below (scripts/kbench_kz.hip); 8 / 12 force a depth
- *   "field_pool_pct" (70)         jrx_field_tune, when every array that takes part is ONE chunk of one common size ("field_chunk_mib" = the size of the largest array): the spare list is first filled
- *                                 with chunks for this share of the free memory, so that the draws deal random chunks from all over the device's memory; the rest is released at the end; 0 = off
- *   "field_spread_draws" (0)     the draws of jrx_field_tune: 0 = chunks of earlier draws are dealt again (cheap; in effect two candidate sets and their permutations), 2 = fresh chunks from the driver
- *                                 for every draw (every draw a new set; 0.7 s per draw at 512^3), 1 = fresh + a varying share of the free memory held back meanwhile; measured alike in what they find
- *   "field_ballast_mib" (0)      an unused allocation of that size behind every large array (placement experiments); "field_test_fail_draw" (0): test switch, the k-th draw of jrx_field_tune fails on this handle
- *   "field_skew_bytes" (0), "field_skew_mod" (32)    every placement: the k-th large array (>= 8 MiB) starts (k mod field_skew_mod) * field_skew_bytes (a multiple of 256) into its allocation
+ *   "field_pool_pct" (70)         "field_placement" = 1 with chunks of >= 128 MiB: the first allocation of a chunk size creates chunks for this share of the free memory (less 6 GiB), and every
+ *                                 array takes random chunks of that pool -- chunks from all over the device's memory are what makes a placement good (profiles/r05_placement_search.txt,
+ *                                 section 13); jrx_field_trim releases what nobody took; 0 = no pool (chunks are created as needed)
  *   "general_hif" (0)            3D fused kernel, general form (any dt), 64 x 4 tile: the stress nodes on the high faces i = nx, j = ny, k = nz are updated inside the kernel (one launch per
  *                                 unobserved iteration) and, with neighbours, the kernel's boundary tiles read the received planes ("fused_overlap" = 3: no flow_bcs! launch, no fix-up):
  *                                 4 / 3 = the instantiation built for four (128 VGPRs + 28 dwords of scratch: 10.99 ms at 512^3) / three (155 VGPRs: 7.95 ms) waves per SIMD; 0 = boundary-layer launch (7.47 + 0.11 ms)
@@ -83,14 +78,6 @@ jrx_status jrx_tuning_get(jrx_handle *h, const char *key, int64_t *value);
  * the neighbour, unpack), [4] flow_bcs! behind the join, [5] stress fix-up next to the received planes, [6] the whole step, [7] the step beyond k_fused3d.  With the
  * early exchange [1]..[3] run on the halo stream beside [0]. */
 jrx_status jrx_tuning_chain_profile(jrx_handle *h, double out_us[8], int64_t *samples);
-/* New physical chunks under one chunk-backed array of jrx_field_alloc ("field_placement" = 1), or under all of them (p = NULL), IN PLACE: every pointer stays valid and the contents are
- * carried over (staged through a hipMalloc buffer; the re-mapping is followed by the translation flush csrc/fieldpool.hip describes -- without it the shaders keep reaching the OLD chunks
- * on this ROCm release, scripts/vmm_stale.hip).  The primitive of the placement experiments of round 5 (scripts/probe_reroll2.py, profiles/r05_placement.txt). */
-jrx_status jrx_tuning_field_reroll(jrx_handle *h, double *p);
-/* jrx_tuning_field_undo: back onto the chunks the array (NULL: every array) had before its last re-roll -- a re-roll keeps them aside until the array is re-rolled again, freed, or
- * jrx_tuning_field_keep hands them to the spare list; contents are carried over both ways.  Re-roll, time the kernel, keep or undo: the step of a placement search. */
-jrx_status jrx_tuning_field_undo(jrx_handle *h, double *p);
-jrx_status jrx_tuning_field_keep(jrx_handle *h, double *p);
 #ifdef __cplusplus
 }
 #endif

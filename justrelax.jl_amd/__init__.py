@@ -14,7 +14,7 @@ from .backend import (AMDGPUBackend, AMDGPUBackendTrait, BackendTrait, CPUBacken
                       GPUBackendTrait, NonCPUBackendTrait, PTArray, backend)
 from .arrays import (DisplacementBoundaryConditions, PhaseRatios, PTStokesCoeffs, PTThermalCoeffs, StokesArrays,  # noqa: F401
                      SymmetricTensor, TemperatureBoundaryConditions, ThermalArrays, VelocityBoundaryConditions,
-                     from_numpy, fzeros, to_numpy, tune_placement, use_library_arrays)
+                     from_numpy, fzeros, to_numpy, trim_library_arrays, use_library_arrays)
 from .grid import (IGG, Geometry, finalize_global_grid, init_global_grid, legacy_uniform_grid,  # noqa: F401
                    nx_g, ny_g, nz_g)
 from .convert import Array_, PTArray_, checkpointing_npz, copy_, load_checkpoint_npz  # noqa: F401

@@ -157,7 +157,7 @@ class Cart(C.Structure):
 
 
 TUNING_HEADER = HERE.parent / "include" / "jrx_tuning.h"
-ABI_VERSION = 221        # 221: jrx_stokes3d_tune_placement (jrx_field_reroll moved to jrx_tuning.h); 220: jrx_field_alloc / _free / _trim / _stats, option field_placement; jrx_fields_dirty, option operand_cache; JRX_VERSION this binding's structs and option keys follow (210: jrx_comm_init_ipc, viscous-limit counters; 200 -> 210 also covers round 3's b_width[3] of jrx_vep3d_params)
+ABI_VERSION = 230        # 230: allocation-time pool placement; jrx_field_tune, jrx_stokes3d_tune_placement and the in-place re-mapping are gone; 220: jrx_field_alloc / _free / _trim / _stats, option field_placement; jrx_fields_dirty, option operand_cache; JRX_VERSION this binding's structs and option keys follow (210: jrx_comm_init_ipc, viscous-limit counters; 200 -> 210 also covers round 3's b_width[3] of jrx_vep3d_params)
 
 
 def header_version() -> int:

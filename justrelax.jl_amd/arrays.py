@@ -54,31 +54,10 @@ def use_library_arrays(handle):
     _field_allocator = handle
 
 
-def tune_placement(handle, probe, draws: int = 8):
-    """jrx_field_tune (include/jrx.h): `draws` times new physical memory under every chunk-backed array of `handle` (option "field_placement" = 1: the arrays made while
-    use_library_arrays(handle) was in force and the library's own), `probe()` -- run what is going to be run, return its time in ms -- and the draw is kept if it is the fastest
-    so far.  Addresses and contents of the arrays stay; what the probe does to the contents is the caller's business.  Returns ([ms as allocated, ms of each draw (-1 = not made),
-    ms of the placement that stays], number of draws kept)."""
-    import ctypes as C
-    err = []
-
-    def _cb(_ctx):
-        try:
-            return float(probe())
-        except BaseException as e:      # noqa: BLE001 -- an exception must not unwind through the C frames: it is re-raised below
-            err.append(e)
-            return -1.0
-
-    cb = C.CFUNCTYPE(C.c_double, C.c_void_p)(_cb)
-    ms = (C.c_double * (int(draws) + 2))()
-    kept = C.c_int32(0)
-    try:
-        handle.call("jrx_field_tune", C.c_int32(int(draws)), cb, C.c_void_p(0), ms, C.byref(kept))
-    except Exception:
-        if err:
-            raise err[0]
-        raise
-    return list(ms), int(kept.value)
+def trim_library_arrays(handle):
+    """jrx_field_trim (include/jrx.h): the chunks of the placement pool ("field_placement" = 1) that no array took go back to the driver -- call it when the arrays of a run
+    exist (the library's second state set is made by the first driver call)."""
+    handle.call("jrx_field_trim")
 
 
 def fzeros(shape, device, fill: float = 0.0) -> torch.Tensor:

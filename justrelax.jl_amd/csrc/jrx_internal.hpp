@@ -25,16 +25,11 @@ struct jrx_handle {
     jrx_comm_state *comm = nullptr;
     jrx_field_pool *pool = nullptr;      // jrx_field_alloc / jrx_field_free: the state arrays the library hands out, and its own large arrays
     int field_placement = 0;             // option: 0 hipMalloc, 1 physical chunks mapped in shuffled order (virtual memory management), 2 physically contiguous (A/B: the slow rate)
-    int field_chunk_mib = 64, field_batch_mib = 0, field_va_align_mib = 0;   // tuning: chunk size, smallest batch of new chunks, alignment of the reserved virtual range
-    bool field_shuffle = true;           // tuning: 0 = chunks in creation order (A/B of the shuffle itself)
-    int scratch_poison = 0;                          // test switch: the second state set is filled with NaNs when it is allocated
+    int field_chunk_mib = 64;            // tuning: size of a physical chunk (0: every array ONE chunk of its own size, no pool); a run that wants the pool sets it to its largest array
+    bool field_shuffle = true;           // tuning: 0 = chunks in creation order (A/B of the random dealing itself)
+    int scratch_poison = 0;                          // test switch: every array of jrx_dev_alloc (second state sets, ητ, jrx_field_alloc) is filled with NaNs when it is allocated
     int fused_kz = 0;                                // tuning: chunk depth of the 64 x 8 tile of k_fused3d (0: 12 planes from nz = 384 on, else 8; 8 / 12 force)
-    int field_pool_pct = 70;                         // tuning: jrx_field_tune first fills the spare list with chunks for that share of the free memory (arrays of ONE common chunk size only); 0 = off
-    int field_spread_draws = 0;                      // tuning: draws of jrx_field_tune -- 0: chunks of earlier draws are dealt again; 2: fresh chunks from the driver for every draw; 1: fresh + a varying share of the free memory held back meanwhile
-    int field_test_fail_draw = 0;                    // test switch: the k-th draw of jrx_field_tune fails on this handle
-    int field_ballast_mib = 0;                       // tuning: an unused allocation of that size behind every large array (placement experiments)
-    int field_skew_bytes = 0, field_skew_mod = 32;    // tuning: the k-th large array starts (k mod field_skew_mod) * field_skew_bytes into its allocation (csrc/fieldpool.hip)
-    int field_arena_gib = 0, field_va_gap_mib = 0;   // tuning: > 0 = the chunk-backed arrays are placed in ONE reserved virtual range of that size, one behind the other, this many MiB apart
+    int field_pool_pct = 70;                         // tuning: "field_placement" = 1, chunks >= 128 MiB: the first allocation of a chunk size fills a pool of chunks for that share of the free memory, every array takes random chunks of it; 0 = off
     double *scratch_base[10] = {};       // what hipMalloc returned for scratch[q] (scratch[q] may start scratch_stagger * q bytes into it)
     bool scratch_contiguous = false;     // tuning switch: the second 3D state set in physically contiguous device memory (hipDeviceMallocContiguous)
     int scratch_stagger = 0, scratch_stagger_used = 0;   // tuning switch (bytes; see ensure_scratch) and the value the current allocation was made with
@@ -71,7 +66,6 @@ struct jrx_handle {
     bool operand_cache = false;
     struct { bool valid = false; const void *ptr[14] = {}; int64_t n[3] = {}; double dt = 0.0; int flags = 0; bool visc_ok = false; int nof = 0; } opv;
     int64_t stat_operand_cache_hits = 0;
-    int64_t stat_field_reflushes = 0;    // re-mappings of the field pool whose copy had not landed in the new chunks at the first check (flushed and copied again)
     int nof = 0;                         // set per driver call by the operand pass: 0 = every ρg array is loaded, 1 = ρg_x and ρg_y hold only +0.0, 2 = all three do
     bool visc_fold = true;               // viscous-limit fused kernel: the arithmetic with the exact zeros folded away (one division per thread for dτ_r, no division by 1 in compute_P!; same bits; A/B)
     bool fused_hiface = true;            // viscous-limit fused kernel without neighbours: the high-face node layers inside the kernel (0: the boundary-layer launch behind it, A/B)
@@ -185,7 +179,6 @@ jrx_status jrx_check_device(jrx_handle *h);
 jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out);
 jrx_status jrx_dev_free(jrx_handle *h, void *p);
 void jrx_pool_destroy(jrx_handle *h);
-void jrx_pool_mark_cold(jrx_handle *h, const double *const *ptrs, int n, bool cold);   // arrays whole-set re-rolls leave alone (csrc/fieldpool.hip)
 
 // ensure the library-owned ητ scratch holds n doubles
 jrx_status jrx_ensure_etatau(jrx_handle *h, size_t n);

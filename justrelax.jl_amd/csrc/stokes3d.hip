@@ -652,9 +652,7 @@ static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
         JRX_TRY(st);
         h->scratch_base[q] = (double *)b;
         h->scratch[q] = (double *)((char *)b + (size_t)q * stg);
-        // what the set holds before its first use must not matter (every entry a kernel reads has been written by a kernel before); test switch "scratch_poison": 1 = every byte 0xFF
-        // (NaNs) instead of whatever the allocation held (tests/test_gpu_stokes3d.py::test_the_second_state_set_may_hold_anything)
-        if (h->scratch_poison) JRX_HIP(h, hipMemset(b, 0xFF, n[q] * sizeof(double) + (size_t)q * stg));
+        // (test switch "scratch_poison": jrx_dev_alloc fills the allocation with NaNs -- what the set holds before its first use must not matter, tests/test_gpu_stokes3d.py::test_the_second_state_set_may_hold_anything)
     }
     h->scratch_stagger_used = h->scratch_stagger + 1000003 * (int)h->scratch_contiguous;
     h->scratch_dims[0] = nx; h->scratch_dims[1] = ny; h->scratch_dims[2] = nz;
@@ -1479,43 +1477,6 @@ jrx_status jrx_stokes3d_iterate_timed(jrx_handle *h, const jrx_stokes3d_fields *
     if (nb) times_ms[2] = sb / nb;
     if (nf) { times_ms[3] = sf / nf; times_ms[4] = sk / nf; times_ms[5] = sc / nf; }
     return JRX_OK;
-}
-
-// Placement search (include/jrx.h).  The time of the large kernels depends on where in the device's memory their arrays lie (profiles/r05_placement.txt: 4.7 .. 6.2 ms for the same
-// launch at 512^3), and nothing about a placement can be told without running the kernel on it -- so run it: every draw gives all chunk-backed arrays of the handle new physical
-// chunks in place (csrc/fieldpool.hip), the loop body is timed on them, and the draw is kept if it is faster than the best one so far, undone otherwise.
-jrx_status jrx_stokes3d_tune_placement(jrx_handle *h, const jrx_stokes3d_fields *f, const double *etatau, const jrx_stokes3d_params *p, int32_t draws, int64_t iters,
-                                       double *ms_per_iter, int32_t *kept)
-{
-    JRX_TRY(check_params(h, f, p));
-    if (iters < 2) return jrx_fail(h, JRX_ERR_ARG, "jrx_stokes3d_tune_placement: iters must be >= 2");
-    struct Ctx { jrx_handle *h; const jrx_stokes3d_fields *f; const double *etatau; const jrx_stokes3d_params *p; int64_t iters; } c{h, f, etatau, p, iters};
-    auto probe = [](void *v) -> double {
-        Ctx *c = (Ctx *)v;
-        double t[6];
-        if (jrx_stokes3d_iterate_timed(c->h, c->f, c->etatau, c->p, 2, t) != JRX_OK) return -1.0;        // the first launches behind a re-mapping also pay for the translations
-        if (jrx_stokes3d_iterate_timed(c->h, c->f, c->etatau, c->p, c->iters, t) != JRX_OK) return -1.0;
-        // what is compared: the launch time of the fused kernel alone where the batch fused (a quantity of this rank: with neighbours the time of a whole iteration also holds
-        // the wait for the slowest of them, and a rank would throw a good draw away because a neighbour drew a bad one), the time per iteration otherwise
-        return t[4] > 0.0 ? t[4] : t[0] / (double)c->iters;
-    };
-    // arrays the loop body's dominant kernel does not touch stay where they are: a draw then moves 22 arrays instead of 55 (the strain rates, displacements, residuals and centre
-    // copies never; τ_o, P0, Q, K, G, and the body forces when the viscous-limit kernels without them stand in -- which the first probe's operand pass decides)
-    const double *never[] = {f->divV, f->Ux, f->Uy, f->Uz, f->exx, f->eyy, f->ezz, f->eyz, f->exz, f->exy, f->RP, f->Rx, f->Ry, f->Rz,
-                             f->tyz_c, f->txz_c, f->txy_c, f->toyz_c, f->toxz_c, f->toxy_c};
-    const double *visc[] = {f->P0, f->Q, f->toxx, f->toyy, f->tozz, f->toyz, f->toxz, f->toxy, f->K, f->G};
-    const double *force[] = {f->fx, f->fy, f->fz};
-    double t[6];
-    JRX_TRY(jrx_stokes3d_iterate_timed(h, f, etatau, p, 2, t));          // runs the operand pass: h->visc_ok, h->nof
-    const bool vl = std::isinf(p->dt) && h->viscous_limit && h->visc_ok;
-    jrx_pool_mark_cold(h, never, (int)(sizeof(never) / sizeof(never[0])), true);
-    if (vl) jrx_pool_mark_cold(h, visc, 10, true);
-    if (vl && h->nof == 2) jrx_pool_mark_cold(h, force, 3, true);
-    const jrx_status st = jrx_field_tune(h, draws, probe, &c, ms_per_iter, kept);
-    jrx_pool_mark_cold(h, never, (int)(sizeof(never) / sizeof(never[0])), false);
-    jrx_pool_mark_cold(h, visc, 10, false);
-    jrx_pool_mark_cold(h, force, 3, false);
-    return st;
 }
 
 }   // extern "C"

@@ -730,17 +730,3 @@ def iterate_timed_(stokes, pt, grid, flow_bcs, ρg, K, G, ητ, dt, iters, *, ha
     t = (C.c_double * 6)()
     h.call("jrx_stokes3d_iterate_timed", C.byref(f), C.c_void_p(ptr(ητ)), C.byref(p), C.c_int64(int(iters)), t)
     return tuple(t[:])
-
-
-def tune_placement_(stokes, pt, grid, flow_bcs, ρg, K, G, ητ, dt, draws=6, iters=12, *, handle=None):
-    """jrx_stokes3d_tune_placement (include/jrx.h): `draws` times new physical memory under every chunk-backed array of the handle ("field_placement" = 1, arrays.use_library_arrays),
-    the loop body timed on it, the draw kept if it is the fastest so far.  Advances the fields: call it before the initial state is written.  Returns (ms per iteration: as allocated,
-    each draw (-1 = not made), the placement that stays; number of draws kept)."""
-    _require_gpu(stokes)
-    h = handle or _lib.default_handle(stokes.P.device.index)
-    torch.cuda.current_stream(stokes.P.device).synchronize()
-    f, p = fields3d(stokes, ρg, K, G), params3d(stokes, pt, grid, flow_bcs, dt)
-    ms = (C.c_double * (int(draws) + 2))()
-    kept = C.c_int32(0)
-    h.call("jrx_stokes3d_tune_placement", C.byref(f), C.c_void_p(ptr(ητ)), C.byref(p), C.c_int32(int(draws)), C.c_int64(int(iters)), ms, C.byref(kept))
-    return list(ms), int(kept.value)

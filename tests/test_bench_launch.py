@@ -49,11 +49,19 @@ def test_rank_refuses_mismatched_world():
     assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1])["world"] == 3
 
 
-def _dry_transports(extra_args=(), env_extra=None, torchrun=False, timeout=180):
+def _strict(line):
+    """the contract line: strict JSON (no NaN / Infinity tokens), under 4 KB"""
+    assert len(line) < 4096, len(line)
+    def no_const(c):
+        raise AssertionError(f"non-standard JSON token {c}")
+    return json.loads(line, parse_constant=no_const)
+
+
+def _dry_transports(extra_args=(), env_extra=None, torchrun=False, timeout=180, extras=True, details=None):
     env = dict(os.environ, **(env_extra or {}))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    bench_args = ["--gpus", "2", "--dry-transports", "--steps", "4", "--warmup", "1", "--leg-steps", "4", *extra_args]
+    bench_args = ["--gpus", "2", "--dry-transports", "--steps", "4", "--warmup", "1", "--leg-steps", "4", *(["--extras"] if extras else []), *(["--details", str(details)] if details else []), *extra_args]
     if torchrun:        # how the driver starts N > 1
         import socket
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -69,7 +77,7 @@ def _dry_transports(extra_args=(), env_extra=None, torchrun=False, timeout=180):
 
 
 def _check_leg(leg, world=2):
-    import bench
+    import bench_extras as bench
     assert leg["it_per_s"] > 0 and leg["ms_per_step"] > 0 and 0 < leg["efficiency_vs_n1"]
     per = leg["chain_us_per_rank"]
     assert len(per) == world
@@ -77,22 +85,41 @@ def _check_leg(leg, world=2):
         assert set(bench.CHAIN_KEYS) <= set(d) and d["samples"] > 0
 
 
+def test_default_two_rank_line_is_compact_and_strict(tmp_path):
+    """what the driver reads: ONE line, strict JSON, < 4 KB, with the contract's keys, the per-rank launch times and the name of the details file; without
+    --extras no leg behind the headline runs"""
+    r, lines = _dry_transports(extras=False, details=tmp_path / "d.json")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout
+    out = _strict(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "details"):
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak" and out["dtype"] == "f64" and out["vs_baseline"] is None
+    assert out["config"]["decomposition"] == [2, 1, 1] and "workload" in out["config"]
+    assert len(out["roofline"]["launch_ms_per_rank"]) == 2 and out["roofline"]["bound"] == "hbm"
+    assert out["details"] == "d.json"
+    full = json.loads((tmp_path / "d.json").read_text())
+    assert set(full["transports"]) == {"rccl"} and "alt_decomposition" not in full
+
+
 @pytest.mark.parametrize("torchrun", [False, True])
-def test_two_rank_line_carries_every_transport_and_both_decompositions(torchrun):
+def test_two_rank_line_carries_every_transport_and_both_decompositions(torchrun, tmp_path):
     """`bench.py --gpus N` (self-launched or under torch.distributed.run, as the driver starts it) prints ONE line whose `value` is the default
     transport (RCCL ranks) and which also carries `transports.{rccl, ipc, local_peer}` -- each with it_per_s, efficiency_vs_n1 and a per-rank chain breakdown -- and an
     `alt_decomposition` leg on the faster process-per-GPU transport.  The control flow (connects, barriers, gathers between two gloo ranks) is the real one; the
     kernels are sleeps (`--dry-transports`), so this runs without a GPU.  Reference: mpiexec -n 2, test/runtests.jl:73-90; docs/paper/paper.md:78-80."""
     sys.path.insert(0, str(ROOT))
-    r, lines = _dry_transports(torchrun=torchrun)
+    r, lines = _dry_transports(torchrun=torchrun, details=tmp_path / "d.json")
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
+    line = _strict(lines[0])
+    out = json.loads((tmp_path / "d.json").read_text())            # --extras: the legs behind the headline are in the details file, the line stays the contract
+    assert line["value"] == pytest.approx(out["value"], rel=1e-5) and "transports" not in line
     assert out["n_gpus"] == 2 and out["default_transport"] == "rccl" and out["scaling"] == "weak" and out["steps"] == 4
     tr = out["transports"]
     assert set(tr) == {"rccl", "ipc", "local_peer"}
     assert tr["rccl"]["ranks"] == 2 and tr["ipc"]["ranks"] == 2 and tr["local_peer"]["handles"] == 2
-    assert tr["rccl"]["it_per_s"] == out["value"]
+    assert tr["rccl"]["it_per_s"] == pytest.approx(out["value"], rel=1e-5)
     for k in tr:
         _check_leg(tr[k])
     alt = out["alt_decomposition"]
@@ -102,10 +129,11 @@ def test_two_rank_line_carries_every_transport_and_both_decompositions(torchrun)
     assert out["n1_reference"]["it_per_s"] > 0 and "extras_incomplete" not in out
 
 
-def test_a_transport_that_fails_on_one_rank_becomes_an_error_entry():
-    r, lines = _dry_transports(env_extra={"JRX_DRY_FAIL": "ipc"})
+def test_a_transport_that_fails_on_one_rank_becomes_an_error_entry(tmp_path):
+    r, lines = _dry_transports(env_extra={"JRX_DRY_FAIL": "ipc"}, details=tmp_path / "d.json")
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads(lines[-1])
+    _strict(lines[-1])
+    out = json.loads((tmp_path / "d.json").read_text())
     assert len(lines) == 1 and "refused" in out["transports"]["ipc"]["error"]
     assert out["transports"]["rccl"]["it_per_s"] > 0 and out["transports"]["local_peer"]["it_per_s"] > 0 and out["alt_decomposition"]["transport"] == "rccl"
 
@@ -114,8 +142,8 @@ def test_a_leg_that_hangs_does_not_lose_the_headline():
     """the legs behind the headline run under a time budget: rank 0 prints the line it has, marked, and every rank leaves"""
     r, lines = _dry_transports(extra_args=["--extras-budget", "6"], env_extra={"JRX_DRY_FAIL": "hang:ipc"}, timeout=120)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads(lines[-1])
-    assert len(lines) == 1 and out["value"] > 0 and "ipc" in out["extras_incomplete"] and "ipc" not in out["transports"]
+    out = _strict(lines[-1])
+    assert len(lines) == 1 and out["value"] > 0 and "ipc" in out["extras_incomplete"] and out["degraded"] is True
 
 
 class _FakeHandle:
@@ -142,12 +170,12 @@ def test_bench_prices_a_launch_by_the_kernel_form_that_runs():
     cells = float(n) ** 3
     assert abs(r["achieved"] - 280.0 * cells / 6.0e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12 and r["frac"] < 1.0
     assert r["bytes_per_cell"] == 280.0 and abs(r["needed_bytes_per_launch"] - 200.0 * cells) < 1.0
-    if bench.PMC["stale"]:
+    if bench.X.PMC["stale"]:
         # csrc/stokes3d_kernels.hpp has changed since the PMC passes of profiles/pmc_traffic.json were taken: the line must not quote them
         assert r["traffic"] is None and r["traffic_ratio"] is None and r["traffic_over_needed"] is None and "STALE" in r["traffic_source"]
     else:
-        assert abs(r["traffic_ratio"] - bench.PMC_TRAFFIC_VISC_512 / (280.0 * cells)) < 1e-12 and 1.0 < r["traffic_over_needed"] < 1.6
-        assert bench.PMC["git_head"] in r["traffic_source"]
+        assert abs(r["traffic_ratio"] - bench.X.PMC_TRAFFIC_VISC_512 / (280.0 * cells)) < 1e-12 and 1.0 < r["traffic_over_needed"] < 1.6
+        assert bench.X.PMC["git_head"] in r["traffic_source"]
     r256 = bench.fused_roofline(g, 256, 1.0, 1.1, 0.0, None)
     assert r256["traffic"] is None and r256["traffic_ratio"] is None and r256["bytes_per_cell"] == 360.0
 
@@ -155,7 +183,7 @@ def test_bench_prices_a_launch_by_the_kernel_form_that_runs():
 def test_pmc_figures_are_dropped_when_the_kernel_source_has_changed(tmp_path, monkeypatch):
     """profiles/pmc_traffic.json carries the sha256 of csrc/stokes3d_kernels.hpp it was measured on; another sha -> every figure None and a source that says STALE"""
     sys.path.insert(0, str(ROOT))
-    import bench
+    import bench_extras as bench
     real = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
     assert len(real["kernels_sha256"]) == 64 and real["n"] == 512 and real["git_head"]
     fake_root = tmp_path
@@ -171,3 +199,22 @@ def test_pmc_figures_are_dropped_when_the_kernel_source_has_changed(tmp_path, mo
     (fake_root / "profiles" / "pmc_traffic.json").write_text(json.dumps(real2))
     d = bench.load_pmc()
     assert not d["stale"] and d["k_fused3d_visc"] == real["k_fused3d_visc"] and real["git_head"] in d["source"]
+
+
+def test_the_contract_line_is_a_fixed_selection_under_4_kb():
+    """compact_line: whatever the full record holds (long strings, NaNs, nested legs), the line is strict JSON under 4 KB with the contract's keys"""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full = {"metric": "m", "value": 200.123456789, "unit": "it/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 5.0, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "w" * 200, "kernel_form": "viscous_limit_no_body_forces", "local_grid": [512] * 3,
+                                                                                  "global_grid": [512] * 3, "decomposition": [1, 1, 1], "halo": "none", "arrays": "pool", "operand_cache": 0},
+            "state_ok": True, "steady_state": {"steps": 100, "value": 209.0, "ms_per_step": 4.78, "kernel_avg_launch_ms": 4.7, "device_state": {"x": "y" * 5000}},
+            "roofline": {"bound": "hbm", "kernel": "k" * 3000, "kernel_name": "k_fused3d", "form": "f", "bytes_per_cell": 256.0, "avg_launch_ms": float("nan"), "achieved": 7200.0, "peak": 8000.0,
+                         "unit": "GB/s", "frac": 0.9, "traffic": None, "needed_bytes_per_launch": 2.3e10, "frac_at_needed_bytes": 0.62, "launch_ms_per_rank": [4.7],
+                         "general_form": {"bytes_per_cell": 360.0, "avg_launch_ms": 7.3, "frac": 0.82, "what": "z" * 2000}},
+            "cpu_baseline": {"value": 2.5, "unit": "it/s", "cores": 16, "kind": "port", "measured_at_n": 256, "sample": "s" * 300, "measured": [{"n": 256}] * 50},
+            "other_configs": {"a": "b" * 20000}, "details": "bench_details.json"}
+    line = bench.compact_line(full)
+    out = _strict(line)
+    assert out["roofline"]["avg_launch_ms"] is None and out["roofline"]["general_form"]["frac"] == 0.82 and "other_configs" not in out and "kernel" not in out["roofline"]
+    assert out["cpu_baseline"]["cores"] == 16 and out["state_ok"] is True and out["value"] == 200.123

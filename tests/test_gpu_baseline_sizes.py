@@ -5,6 +5,7 @@ these are direct parity tests at the sizes the bench quotes (the kernel choice i
 256^3, the two-kernel 2D loop above 200^2 nodes), not only size-independent properties:
 
   configs[2]  SolVi3D 256^3 (miniapps/benchmarks/stokes3D/solvi/SolVi3D.jl:45-129)  -- jrx_stokes3d_solve, 25 iterations, 2 checks
+  (8d)        random fields, finite dt, G, K at 256^3 (SURVEY 8d kernel-parity inputs)      -- jrx_stokes3d_solve, 17 iterations, general k_fused3d
   configs[3]  SolVi3D 512^3 per GPU (the headline's block)                          -- jrx_stokes3d_solve, 9 iterations, 2 checks (one 48 GB host copy)
   configs[1]  SolCx 512^2 (miniapps/benchmarks/stokes2D/solcx/SolCx.jl:54-116)      -- jrx_stokes2d_solve, 200 iterations vs oracle,
               then the reference's convergence assertion err_evo1[end] < 1e-8 (test/test_stokes_solcx.jl:26-37) at full size
@@ -52,6 +53,37 @@ def test_solvi3d_256_matches_oracle(jr, oracle):
     d = checks.compare_stokes(dev, ref, names)
     assert max(d.values()) <= 1e-9, d
     del stokes
+    torch.cuda.empty_cache()
+
+
+def test_random_fields_256_finite_dt_matches_oracle_general_kernel(jr, oracle):
+    """SURVEY 8(d)'s kernel-parity inputs at a BASELINE size: every field ~U(-1,1) (default_rng(20260821)), eta = 10^U(-3,0), G ~ 1, K ~ 2, dt = 0.25, Q ~ U(-0.1,0.1)
+    at 256^3 -- SolVi3D zeroes every elastic / compressible term (dt = Inf, F7), this run does not: the elastic increment of compute_tau! (StressKernels.jl:2-5,149-230:
+    (tau - tau_o) eta / (G dt), the clamped 4-cell means of eta and G at the shear nodes) and the compressible pressure update (PressureKernels.jl:186-195: P0 / (K dt),
+    Q / dt, psi / (K dt)) are compared with the oracle through jrx_stokes3d_solve, and the launch counters prove that the GENERAL form of k_fused3d ran (none of its
+    launches in the viscous-limit form)."""
+    import torch
+    from justrelax_jl_amd import _lib, checks
+    from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
+    n = 256
+    s = jr.miniapps.random_fields3d((n, n, n), seed=20260821, dt=0.25, G=1.0, K=2.0, iterMax=16, nout=8)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-300
+    ref = _cp(s.arrays)
+    r_ref = oracle.stokes3d_solve(ref, checks.oracle_params3d(oracle, s))
+    stokes, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
+    h = _lib.default_handle()
+    f0, v0 = _stat(h, "stat_fused3d"), _stat(h, "stat_fused3d_visc")
+    r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+    assert _stat(h, "stat_fused3d") - f0 >= 8, "the auto rule did not select k_fused3d at 256^3"
+    assert _stat(h, "stat_fused3d_visc") == v0, "a finite-dt run launched the viscous-limit form"
+    assert r.iter == r_ref["iter"] == 17
+    for k in ("norm_Rx", "norm_Ry", "norm_Rz", "norm_divV", "err_evo1"):
+        assert np.allclose(getattr(r, k), r_ref[k], rtol=1e-10, atol=0), k
+    dev = download_stokes(stokes)
+    names = ["P", "Vx", "Vy", "Vz", "txx", "tyy", "tzz", "tyz", "txz", "txy", "toxx", "toyy", "tozz", "toyz", "toxz", "toxy", "Rx", "Ry", "Rz", "RP", "divV", "exx", "eyy", "ezz", "eyz", "exz", "exy"]
+    d = checks.compare_stokes(dev, ref, names)
+    assert max(d.values()) <= 1e-9, d
+    del stokes, dev
     torch.cuda.empty_cache()
 
 

@@ -1,6 +1,6 @@
 """jrx_field_alloc / jrx_field_free: the library hands out the state arrays (the backend owns the array constructor in the reference:
 src/ext/AMDGPU/3D.jl:46-48 StokesArrays(::Type{AMDGPUBackend}, ni) -> @zeros(ni...)).  Whatever "field_placement" selects -- hipMalloc,
-physical chunks mapped in shuffled order, physically contiguous memory -- an array is plain device memory: a solve on library arrays gives
+physical chunks dealt at random from a pool and mapped once at a fresh virtual range, physically contiguous memory -- an array is plain device memory: a solve on library arrays gives
 the bits of the same solve on torch's arrays, and the pool accounts for every array it handed out."""
 import ctypes as C
 
@@ -47,11 +47,10 @@ def test_alloc_write_read_free(jr, placement, chunk):
         del ts, t
         torch.cuda.synchronize()
         assert _stats(h)[0] == 0 and _stats(h)[1] == 0
-        # a freed range can be handed out again (chunks come back from the spare list: no new ones)
-        created = _stats(h)[2]
+        # chunk sizes without a pool: the memory of a freed array went back to the driver, and its virtual range is never handed out again
+        assert _stats(h)[3] == 0
         t = jr.fzeros(shapes[0], "cuda")
-        assert _stats(h)[2] == created
-        assert p0 != 0 and t.data_ptr() != 0
+        assert p0 != 0 and t.data_ptr() != 0 and (placement != 1 or t.data_ptr() != p0)
         del t
         h.call("jrx_field_trim")
         assert _stats(h)[3] == 0
@@ -60,60 +59,61 @@ def test_alloc_write_read_free(jr, placement, chunk):
         h.close()
 
 
-@pytest.mark.parametrize("arena_gib,gap_mib", [(0, 0), (4, 0), (4, 6)])
-def test_reroll_keeps_pointers_and_contents_and_the_arena_places_arrays_in_one_range(jr, arena_gib, gap_mib):
-    """jrx_tuning_field_reroll gives chunk-backed arrays new physical chunks under the same pointers and carries the contents over (the experiment primitive of round 5); with
-    "field_arena_gib" the arrays lie one behind the other in ONE reserved virtual range, "field_va_gap_mib" apart; jrx_field_list names them."""
+def test_pool_placement_maps_every_array_once_at_a_range_never_used_before(jr):
+    """ "field_placement" = 1 with chunks of pool size: the first large allocation fills a pool of chunks ("field_pool_pct" of the free memory), every array takes random chunks of it,
+    a freed array's chunks go back to the pool and its virtual range is never handed out again (nothing is ever mapped at an address that was mapped before: csrc/fieldpool.hip);
+    jrx_field_trim releases what nobody took; jrx_field_list names the arrays."""
     import torch
     from justrelax_jl_amd import _lib, arrays
     h = _lib.Handle(0)
     try:
         h.set_option("field_placement", 1)
-        h.set_option("field_chunk_mib", 2)
-        h.set_option("field_arena_gib", arena_gib)
-        h.set_option("field_va_gap_mib", gap_mib)
+        h.set_option("field_chunk_mib", 128)
+        h.set_option("field_pool_pct", 1)                      # ~1 % of the free memory: a few dozen chunks of 128 MiB
+        h.set_option("scratch_poison", 1)                      # every allocation starts as NaNs: the constructor's fill is what the caller sees
         arrays.use_library_arrays(h)
-        shapes = [(257, 130, 67), (1200, 1100), (300, 300, 30)]        # 17.9, 10.6, 21.6 MB: chunk-backed
+        shapes = [(257, 130, 67), (1200, 1100), (300, 300, 30), (512, 512, 70)]        # 17.9, 10.6, 21.6 MB: one chunk each; 146.8 MB: two chunks
         rng = np.random.default_rng(3)
         ts, ref = [], []
         for sh in shapes:
             a = rng.standard_normal(sh)
             t = jr.fzeros(sh, "cuda")
+            assert float(t.abs().max()) == 0.0
             t.copy_(torch.from_numpy(a).to("cuda"))
             ts.append(t); ref.append(a)
-        ptrs0 = [t.data_ptr() for t in ts]
-        if arena_gib:
-            sz = [-(-int(np.prod(sh)) * 8 // (2 << 20)) * (2 << 20) for sh in shapes]
-            assert ptrs0[1] - ptrs0[0] == sz[0] + (gap_mib << 20) and ptrs0[2] - ptrs0[1] == sz[1] + (gap_mib << 20), (ptrs0, sz)
-        created0 = _stats(h)[2]
-        torch.cuda.synchronize()
-        h.call("jrx_tuning_field_reroll", C.c_void_p(ptrs0[1]))          # one array
-        h.call("jrx_tuning_field_reroll", C.c_void_p(0))                # all of them
-        assert _stats(h)[2] > created0                            # new physical chunks were created for the first re-roll
-        assert [t.data_ptr() for t in ts] == ptrs0
-        for t, a in zip(ts, ref):
-            assert np.array_equal(t.cpu().numpy(), a)
-        t2 = ts[0] * 2.0                                          # the re-mapped arrays are ordinary device memory for every later kernel
-        assert np.array_equal(t2.cpu().numpy(), ref[0] * 2.0)
-        for t, a in zip(ts, ref):                                 # writes behind the re-mapping land where later reads see them (the translation flush of csrc/fieldpool.hip)
-            t.copy_(torch.from_numpy(a + 1.0).to("cuda"))
-        torch.cuda.synchronize()
-        for t, a in zip(ts, ref):
-            assert np.array_equal(t.cpu().numpy(), a + 1.0)
+        st = _stats(h)
+        pool = st[2]
+        assert pool >= 12 and st[3] == pool - 5, st           # the pool was filled once; five chunks are in use
+        seen = {t.data_ptr() for t in ts}
+        assert len(seen) == 4
         cnt, pl, nb = C.c_int64(), (C.c_void_p * 16)(), (C.c_int64 * 16)()
         h.call("jrx_field_list", C.c_int64(16), pl, nb, C.byref(cnt))
-        assert cnt.value == 3 and sorted(pl[i] for i in range(3)) == sorted(ptrs0) and all(nb[i] > 0 for i in range(3))
-        with pytest.raises(_lib.JrxError):
-            h.call("jrx_tuning_field_reroll", C.c_void_p(ptrs0[0] + 8))
-        del ts, t, t2
+        assert cnt.value == 4 and sorted(pl[i] for i in range(4)) == sorted(seen) and all(nb[i] > 0 for i in range(4))
+        for t, a in zip(ts, ref):
+            assert np.array_equal(t.cpu().numpy(), a)
+        # free and allocate again, several times: chunks come from the pool (none created), addresses are always new, the other arrays keep their contents
+        for rep in range(6):
+            i = rep % 4
+            ts[i] = None
+            torch.cuda.synchronize()
+            t = jr.fzeros(shapes[i], "cuda", fill=float(rep))
+            assert t.data_ptr() not in seen, "a virtual range was handed out twice"
+            seen.add(t.data_ptr())
+            assert float(t.min()) == float(t.max()) == float(rep)
+            ref[i] = rng.standard_normal(shapes[i])
+            t.copy_(torch.from_numpy(ref[i]).to("cuda"))
+            ts[i] = t
+            for u, a in zip(ts, ref):
+                assert np.array_equal(u.cpu().numpy(), a)
+        st = _stats(h)
+        assert st[2] == pool and st[3] == pool - 5, st
+        h.call("jrx_field_trim")
+        assert _stats(h)[3] == 0
+        for u, a in zip(ts, ref):                                  # the arrays in use are untouched by the trim
+            assert np.array_equal(u.cpu().numpy(), a)
+        del ts, t, u
         torch.cuda.synchronize()
-        assert _stats(h)[0] == 0
-        # a freed range of the arena is handed out again to an array of the same size
-        if arena_gib:
-            t = jr.fzeros(shapes[0], "cuda", fill=3.0)
-            assert t.data_ptr() == ptrs0[0]
-            assert float(t.min()) == float(t.max()) == 3.0
-            del t
+        assert _stats(h)[0] == 0 and _stats(h)[3] == 0             # the pool is over: freed chunks went back to the driver
     finally:
         arrays.use_library_arrays(None)
         h.close()
@@ -128,9 +128,10 @@ def test_free_of_a_foreign_pointer_is_an_error(jr):
         h.call("jrx_field_free", C.c_void_p(t.data_ptr()))
 
 
-@pytest.mark.parametrize("placement", [1, 2])
-def test_solve_on_library_arrays_gives_the_same_bits(jr, placement):
-    """3D visco-elastic solve (fused pipeline: the library's second state set comes from the same pool) on arrays of the pool against torch's arrays"""
+@pytest.mark.parametrize("placement,chunk,poison", [(1, 2, 0), (1, 128, 1), (2, 64, 0)])
+def test_solve_on_library_arrays_gives_the_same_bits(jr, placement, chunk, poison):
+    """3D visco-elastic solve, finite dt (fused pipeline: the library's second state set comes from the same pool -- filled with NaNs first in the pool case) on arrays of the
+    pool against torch's arrays"""
     from justrelax_jl_amd import _lib, arrays, checks
     from justrelax_jl_amd.miniapps.common import download_stokes, upload_stokes
     outs = []
@@ -139,7 +140,9 @@ def test_solve_on_library_arrays_gives_the_same_bits(jr, placement):
         try:
             if lib_arrays:
                 h.set_option("field_placement", placement)
-                h.set_option("field_chunk_mib", 2)
+                h.set_option("field_chunk_mib", chunk)
+                h.set_option("field_pool_pct", 1)
+                h.set_option("scratch_poison", poison)
                 arrays.use_library_arrays(h)
             s = jr.miniapps.random_fields3d((130, 96, 100), seed=11, iterMax=60, nout=20)
             s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
@@ -156,53 +159,3 @@ def test_solve_on_library_arrays_gives_the_same_bits(jr, placement):
     for k in a:
         m = checks.interior_mask3d(k, a[k].shape)
         assert np.array_equal(a[k][m], b[k][m], equal_nan=True), k
-
-
-@pytest.mark.parametrize("chunk_mib,pool_pct", [(0, 0), (10, 2)])
-def test_placement_search_keeps_addresses_and_a_restored_state_solves_to_the_same_bits(jr, chunk_mib, pool_pct):
-    """jrx_stokes3d_tune_placement: draws of new physical chunks under the arrays, the loop body timed on each, the fastest kept.  Pointers stay; the fields are advanced by the probes,
-    so the initial state is written back -- and the solve that follows gives the bits of a solve on arrays that were never moved."""
-    from justrelax_jl_amd import _lib, arrays, checks, stokes
-    from justrelax_jl_amd.miniapps.common import download_stokes, stokes_field_names, upload_stokes, _get
-    from justrelax_jl_amd.arrays import from_numpy
-    outs = []
-    for tune in (False, True):
-        h = _lib.Handle(0)
-        try:
-            h.set_option("field_placement", 1)
-            h.set_option("field_chunk_mib", chunk_mib if tune else 2)      # 10 MiB: every array of this problem is ONE chunk of that size -> the draws deal from a pool
-            h.set_option("field_pool_pct", pool_pct)
-            arrays.use_library_arrays(h)
-            s = jr.miniapps.random_fields3d((130, 96, 100), seed=5, iterMax=40, nout=20)
-            s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
-            st, ρg, K, G = upload_stokes(s, jr.AMDGPUBackend)
-            if tune:
-                ητ = jr.fzeros(s.ni, st.P.device)
-                jr.compute_maxloc_(ητ, st.viscosity.η, handle=h)
-                ptr0 = [st.P.data_ptr(), st.V.Vx.data_ptr(), st.τ.xy.data_ptr(), ητ.data_ptr()]
-                created0 = _stats(h)[2]
-                ms, kept = stokes.tune_placement_(st, s.pt, s.grid, s.flow_bcs, ρg, K, G, ητ, s.dt, 3, 4, handle=h)
-                assert len(ms) == 5 and all(m > 0 for m in ms) and 0 <= kept <= 3
-                import os
-                if os.environ.get("JRX_DIAG_FILE"):          # how often a re-mapping had to be flushed and copied a second time (csrc/fieldpool.hip, remap_with)
-                    with open(os.environ["JRX_DIAG_FILE"], "a") as fdiag:
-                        fdiag.write(f"tune test chunk {chunk_mib} pool {pool_pct}: stat_field_reflushes {h.get_option('stat_field_reflushes')}\n")
-                assert [st.P.data_ptr(), st.V.Vx.data_ptr(), st.τ.xy.data_ptr(), ητ.data_ptr()] == ptr0
-                assert _stats(h)[2] > created0 and _stats(h)[3] == 0        # draws were made, and the chunks of those that lost went back to the driver
-                if pool_pct:
-                    assert _stats(h)[2] - created0 > 3 * 40                  # the pool: many more chunks than three draws of the ~40 arrays that took part need
-                for name, path in stokes_field_names(3).items():             # the initial state again
-                    if name in s.arrays:
-                        _get(st, path).copy_(from_numpy(s.arrays[name], st.P.device))
-                    else:
-                        _get(st, path).zero_()
-                del ητ
-            r = jr.solve_(st, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs, handle=h)
-            outs.append((r, download_stokes(st)))
-            del st, ρg, K, G
-        finally:
-            arrays.use_library_arrays(None)
-            h.close()
-    (ra, a), (rb, b) = outs
-    diff = {k: int((a[k] != b[k]).sum()) for k in a if not np.array_equal(a[k][checks.interior_mask3d(k, a[k].shape)], b[k][checks.interior_mask3d(k, a[k].shape)], equal_nan=True)}
-    assert ra.iter == rb.iter and list(ra.err_evo1) == list(rb.err_evo1) and not diff, (ra.iter, rb.iter, list(ra.err_evo1), list(rb.err_evo1), diff)

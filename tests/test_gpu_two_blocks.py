@@ -670,60 +670,39 @@ def test_vep2d_two_blocks_equal_the_undecomposed_run(jr, dims):
             assert np.array_equal(outs[r][k][inner], want[inner]), (dims, r, k)
 
 
-@pytest.mark.parametrize("fail_at", [0, 2])
-def test_two_blocks_search_their_placement_together_and_keep_the_bits(jr, fail_at):
-    """jrx_field_tune on coupled blocks: each rank draws new physical memory for its own arrays and times its own probe (a few iterations of solve!, which exchange halos), the ranks
-    make every draw together -- when one of them cannot (no room: test switch), all stop at that draw; afterwards the restored state solves to the bits of blocks that never moved."""
-    import time
-    import torch
+def test_two_blocks_on_pool_placed_library_arrays_keep_the_bits(jr):
+    """coupled blocks whose arrays (the callers' and the libraries' own second state sets, filled with NaNs first) come from the placement pool of their handles
+    ("field_placement" = 1, csrc/fieldpool.hip) solve to the bits of the same blocks on torch's arrays"""
     import justrelax_jl_amd.grid as g
     from justrelax_jl_amd import arrays, halo
-    from justrelax_jl_amd.arrays import from_numpy
-    from justrelax_jl_amd.miniapps.common import Setup, download_stokes, stokes_field_names, upload_stokes, _get as _field
+    from justrelax_jl_amd.miniapps.common import Setup, download_stokes, upload_stokes
     dims, n = (2, 1, 1), (130, 96, 100)
     kw = dict(iterMax=30, nout=10, verbose=False)
     outs = []
-    for tune in (False, True):
+    for pooled in (False, True):
         with TwoBlocks(n, dims) as tb:
             S = _global_setup(jr, tb.ng, False, 30, 10)
             g.init_global_grid(*n, dimx=dims[0], dimy=dims[1], dimz=dims[2], rank=0, nprocs=2)
             try:
                 grid = jr.Geometry(n, S.extra["li"])
-                ups, locs = [], []
+                ups = []
                 for r, h in enumerate(tb.handles):
                     _set(h, **PIPELINES["fused_early"])
-                    h.set_option("field_placement", 1)
-                    h.set_option("field_chunk_mib", 0)
-                    if tune and r == 1:
-                        h.set_option("field_test_fail_draw", fail_at)
-                    arrays.use_library_arrays(h)
+                    if pooled:
+                        h.set_option("field_placement", 1)
+                        h.set_option("field_chunk_mib", 128)
+                        h.set_option("field_pool_pct", 1)
+                        h.set_option("scratch_poison", 1)
+                        arrays.use_library_arrays(h)
                     loc = Setup(ni=n, arrays={k: B.local_block(v, n, tb.ng, B.coords_of(tb.carts[r])) for k, v in S.arrays.items()})
-                    locs.append(loc)
                     ups.append(upload_stokes(loc, jr.AMDGPUBackend))
-                arrays.use_library_arrays(None)
+                    arrays.use_library_arrays(None)
                 solve = lambda r, k: jr.solve_(ups[r][0], S.pt, grid, S.flow_bcs, ups[r][1], ups[r][2], ups[r][3], S.dt, None, kwargs=dict(kw, iterMax=k), handle=tb.handles[r])
-                if tune:
-                    def probe(r):
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        solve(r, 4)
-                        torch.cuda.synchronize()
-                        return (time.perf_counter() - t0) * 1e3
-                    ptr0 = [u[0].P.data_ptr() for u in ups]
-                    res = halo.run_ranks([(lambda r=r: arrays.tune_placement(tb.handles[r], lambda: probe(r), 3)) for r in range(2)])
-                    assert [u[0].P.data_ptr() for u in ups] == ptr0
-                    for ms, kept in res:
-                        assert ms[0] > 0 and ms[-1] > 0
-                        made = [m > 0 for m in ms[1:-1]]
-                        assert made == ([True, True, True] if fail_at == 0 else [True, False, False]), ms        # both ranks stopped at the draw one of them could not make
-                    for r in range(2):                                        # the initial state again
-                        for name, path in stokes_field_names(3).items():
-                            t = _field(ups[r][0], path)
-                            t.copy_(from_numpy(locs[r].arrays[name], t.device)) if name in locs[r].arrays else t.zero_()
                 res = halo.run_ranks([(lambda r=r: solve(r, 30)) for r in range(2)])
                 outs.append((res, [download_stokes(u[0]) for u in ups]))
                 del ups
             finally:
+                arrays.use_library_arrays(None)
                 g.finalize_global_grid()
     (ra, a), (rb, b) = outs
     for r in range(2):

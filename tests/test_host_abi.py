@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol(jr):
     for s in syms:
         assert hasattr(L, s), s
     L.jrx_version.restype = C.c_int32
-    assert L.jrx_version() == 221
+    assert L.jrx_version() == 230
 
 
 def test_library_carries_the_build_id_of_its_sources(jr, tmp_path):
