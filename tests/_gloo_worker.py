@@ -1,4 +1,4 @@
-"""Worker for tests/test_multirank_gloo.py (world_size 2, gloo, CPU only).
+"""Worker for tests/test_multirank_gloo.py (world_size 2 -> (2,1,1) and world_size 8 -> (2,2,2), gloo, CPU only).
 
 Exercises the N > 1 host logic of the product -- block decomposition (grid.init_global_grid /
 jrx_cart_create), halo plane selection (jrx_halo_planes) and the x -> y -> z exchange order -- with
@@ -7,7 +7,10 @@ pack kernels + RCCL inside libjrx_hip).  Checks, on every rank:
   1. after update_halo the ghost planes hold the neighbour's send planes;
   2. a decomposed PT run with uniform material equals the undecomposed run bit for bit on every
      cell the rank owns (IGG overlap semantics: duplicated overlap cells stay consistent);
-  3. the summed Σx² norms double-count the overlap exactly as the reference's norm_mpi does.
+  3. the summed Σx² norms double-count the overlap exactly as the reference's norm_mpi does
+     (Stokes3D.jl:127-142, nx_g = dims_x (n - 2) + 2 in every split dimension).
+With 8 ranks the x -> y -> z order is what carries edge and corner ghosts: a rank's corner entry comes from its diagonal
+neighbour in three hops, and check 2 fails on the first iteration if one of them is out of order.
 """
 import ctypes as C
 import os
@@ -65,12 +68,21 @@ def main():
     n = (10, 9, 8)
     g.init_global_grid(*n, rank=rank, nprocs=world)
     gg = g.global_grid()
-    assert tuple(gg.dims) == (2, 1, 1) and g.nx_g() == 2 * (n[0] - 2) + 2 == 18
-    cart = halo.make_cart(gg)
-    assert cart.neighbor[0][0] == (-1 if rank == 0 else 0) and cart.neighbor[0][1] == (1 if rank == 0 else -1)
+    dims = tuple(gg.dims)
+    assert dims == {2: (2, 1, 1), 8: (2, 2, 2)}[world], dims
     ng = (g.nx_g(), g.ny_g(), g.nz_g())
+    assert ng == tuple(d * (m - 2) + 2 for d, m in zip(dims, n)), ng
+    cart = halo.make_cart(gg)
+    coords = tuple(gg.coords)
+    rank_of = lambda c: g.cart_rank(c, dims)          # MPI_Cart_rank order (last dimension fastest), as IGG has it
+    assert coords == tuple(g.cart_coords(rank, dims))
+    for d in range(3):
+        for side, step in ((0, -1), (1, 1)):
+            c = list(coords); c[d] += step
+            want = rank_of(c) if 0 <= c[d] < dims[d] else -1
+            assert cart.neighbor[d][side] == want, (rank, d, side, cart.neighbor[d][side], want)
 
-    # global problem (identical on both ranks), uniform material so that the clamped shear averages
+    # global problem (identical on all ranks), uniform material so that the clamped shear averages
     # at rank-internal faces equal the global ones
     g.finalize_global_grid()
     S = jr.miniapps.random_fields3d(ng, seed=5, iterMax=12, nout=4)
@@ -78,26 +90,38 @@ def main():
     for k in ("eta", "G", "K"):
         S.arrays[k][...] = {"eta": 0.7, "G": 1.3, "K": 2.1}[k]
     g.init_global_grid(*n, rank=rank, nprocs=world)
-    off = rank * (n[0] - 2)
 
-    def local(name, A):
-        return np.asfortranarray(A[off: off + A.shape[0] - ng[0] + n[0]])
+    def block(A, c):
+        """the local block of rank coordinates c out of the global array A (any staggering: the local extent is the global one less ng - n)"""
+        sl = tuple(slice(c[d] * (n[d] - 2), c[d] * (n[d] - 2) + A.shape[d] - ng[d] + n[d]) for d in range(3))
+        return np.asfortranarray(A[sl])
+
+    local = lambda name, A: block(A, coords)
 
     loc = {k: local(k, v) for k, v in S.arrays.items()}
     shp = orc.shapes3d(*n)
     for k, v in loc.items():
         assert v.shape == shp[k], (k, v.shape, shp[k])
 
-    # 1. exchange check on a copy
+    # 1. exchange check on a copy: ghost planes poisoned, then update_halo -- faces with a neighbour hold the neighbour's values (= the global field there, edges and
+    #    corners included when all three dimensions are split), faces without one keep the poison
     V = [loc[k].copy(order="F") for k in ("Vx", "Vy", "Vz")]
     for A in V:
-        A[0], A[-1] = -777.0, -777.0
+        for d in range(3):
+            idx = [slice(None)] * 3
+            for p in (0, -1):
+                idx[d] = p
+                A[tuple(idx)] = -777.0
     update_halo_gloo(V, n, cart, L)
     for A, k in zip(V, ("Vx", "Vy", "Vz")):
-        if rank == 1:
-            assert np.array_equal(A[0], loc[k][0]) and (A[-1] == -777.0).all()
-        else:
-            assert np.array_equal(A[-1], loc[k][-1]) and (A[0] == -777.0).all()
+        inner = tuple(slice(1 if cart.neighbor[d][0] < 0 else 0, -1 if cart.neighbor[d][1] < 0 else None) for d in range(3))
+        assert np.array_equal(A[inner], loc[k][inner]), (rank, k)
+        for d in range(3):
+            for side, p in ((0, 0), (1, -1)):
+                if cart.neighbor[d][side] < 0:
+                    idx = [slice(None)] * 3
+                    idx[d] = p
+                    assert (A[tuple(idx)] == -777.0).all(), (rank, k, d, side)
 
     # 2. decomposed run == global run
     b = S.flow_bcs
@@ -126,8 +150,8 @@ def main():
     # 3. norm_mpi double counts the 2-cell overlap (Stokes3D.jl:127-142): Σ over ranks of local interior slices
     want = np.zeros(4)
     for r in range(world):
-        o = r * (n[0] - 2)
-        lr = {k: np.asfortranarray(glob[k][o: o + glob[k].shape[0] - ng[0] + n[0]]) for k in ("Rx", "Ry", "Rz", "RP")}
+        c = tuple(g.cart_coords(r, dims))
+        lr = {k: block(glob[k], c) for k in ("Rx", "Ry", "Rz", "RP")}
         full = dict(loc)
         full.update(lr)
         want += orc.residual_sumsq3d(full, pl)

@@ -57,17 +57,17 @@ def _strict(line):
     return json.loads(line, parse_constant=no_const)
 
 
-def _dry_transports(extra_args=(), env_extra=None, torchrun=False, timeout=180, extras=True, details=None):
+def _dry_transports(extra_args=(), env_extra=None, torchrun=False, timeout=180, extras=True, details=None, world=2):
     env = dict(os.environ, **(env_extra or {}))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    bench_args = ["--gpus", "2", "--dry-transports", "--steps", "4", "--warmup", "1", "--leg-steps", "4", *(["--extras"] if extras else []), *(["--details", str(details)] if details else []), *extra_args]
+    bench_args = ["--gpus", str(world), "--dry-transports", "--steps", "4", "--warmup", "1", "--leg-steps", "4", *(["--extras"] if extras else []), *(["--details", str(details)] if details else []), *extra_args]
     if torchrun:        # how the driver starts N > 1
         import socket
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
                str(ROOT / "bench.py"), *bench_args]
     else:
         cmd = [sys.executable, str(ROOT / "bench.py"), *bench_args]
@@ -100,6 +100,17 @@ def test_default_two_rank_line_is_compact_and_strict(tmp_path):
     assert out["details"] == "d.json"
     full = json.loads((tmp_path / "d.json").read_text())
     assert set(full["transports"]) == {"rccl"} and "alt_decomposition" not in full
+
+
+def test_eight_rank_line_reports_the_2x2x2_rccl_job(tmp_path):
+    """BASELINE configs[3] as the driver starts it (torch.distributed.run, 8 ranks): the line reports 8 RCCL ranks, the (2,2,2) decomposition, the 1022^3 global grid
+    (2 (512 - 2) + 2 per split dimension) and one launch time per rank -- control flow only, kernels are sleeps"""
+    r, lines = _dry_transports(extras=False, details=tmp_path / "d.json", world=8, torchrun=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout
+    out = _strict(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["config"]["decomposition"] == [2, 2, 2] and out["config"]["global_grid"] == [1022, 1022, 1022]
+    assert len(out["roofline"]["launch_ms_per_rank"]) == 8 and out["scaling"] == "weak"
 
 
 @pytest.mark.parametrize("torchrun", [False, True])

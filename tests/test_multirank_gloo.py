@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the decomposition + halo-exchange logic (see _gloo_worker.py)."""
+"""N > 1 path on CPU: world_size-2 and world_size-8 (2 x 2 x 2) gloo runs of the decomposition + halo-exchange logic (see _gloo_worker.py)."""
 import os
 import socket
 import subprocess
@@ -14,10 +14,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_halo_and_decomposition():
-    env = dict(os.environ, OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_halo_and_decomposition(world):
+    """2 ranks: (2,1,1); 8 ranks: (2,2,2), the decomposition of BASELINE configs[3] -- edge and corner ghosts through x -> y -> z, the norms' double-counted overlap in all three dimensions"""
+    env = dict(os.environ, OMP_NUM_THREADS="1" if world == 8 else "2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "tests" / "_gloo_worker.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    for k in range(world):
+        assert f"rank {k} ok" in r.stdout
