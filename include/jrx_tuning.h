@@ -55,7 +55,8 @@
  *                                 jrx_tuning_chain_profile
  *   "field_chunk_mib" (64), "field_shuffle" (1)    jrx_field_alloc with "field_placement" = 1: size of a physical chunk (0: every array is ONE chunk of its own size, no pool); a run
  *                                 whose large arrays should be ONE chunk each sets it to the size of its largest array (bench.py does); 0 = chunks dealt in creation order (A/B of the random dealing)
- *   "scratch_poison" (0)         test switch: every array the library allocates (second state sets, ητ, jrx_field_alloc) is filled with NaNs first (what it holds before its first use must not matter)
+ *   "scratch_poison" (0)         test switch, bit mask: arrays the library allocates are filled with NaNs first (what they hold before their first use must not matter): 1 = the second state sets,
+ *                                 2 = the library-owned ητ, 4 = the arrays of jrx_field_alloc
  *   "fused_kz" (0)               chunk depth of the 64 x 8 tile of k_fused3d: 0 = 12 planes from nz = 384 on, 8 below (scripts/kbench_kz.hip); 8 / 12 force a depth
  *   "field_pool_pct" (70)         "field_placement" = 1 with chunks of >= 128 MiB: the first allocation of a chunk size creates chunks for this share of the free memory (less 6 GiB), and every
  *                                 array takes random chunks of that pool -- chunks from all over the device's memory are what makes a placement good (profiles/r05_placement_search.txt,

@@ -145,7 +145,7 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, void **o
 }   // namespace
 
 // internal: every large library-owned array (second state sets, ητ) comes from the same place as the caller's
-jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out)
+jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out, int tag)
 {
     *out = nullptr;
     if (bytes == 0) bytes = 8;
@@ -172,8 +172,10 @@ jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out)
         P->live[p] = std::move(A);
         *out = p;
     }
-    // test switch "scratch_poison": what an array holds before its first use must not matter (every entry a kernel reads has been written before) -- every byte 0xFF (NaNs)
-    if (h->scratch_poison) JRX_HIP(h, hipMemset(*out, 0xFF, bytes));
+    // test switch "scratch_poison" (bit mask by `tag`): what an array holds before its first use must not matter (every entry a kernel reads has been written before) -- every byte 0xFF (NaNs)
+    // (hipMemset of device memory returns before the fill has run and the handle's streams do not wait for the null stream: without the synchronisation the fill would land
+    // on top of whatever the first kernels on those streams have written by then -- round 6 took exactly that for reads of unwritten memory in the coupled pipelines)
+    if (h->scratch_poison & tag) { JRX_HIP(h, hipMemset(*out, 0xFF, bytes)); JRX_HIP(h, hipDeviceSynchronize()); }
     P->bytes_live += (int64_t)bytes;
     return JRX_OK;
 }

@@ -27,7 +27,7 @@ struct jrx_handle {
     int field_placement = 0;             // option: 0 hipMalloc, 1 physical chunks mapped in shuffled order (virtual memory management), 2 physically contiguous (A/B: the slow rate)
     int field_chunk_mib = 64;            // tuning: size of a physical chunk (0: every array ONE chunk of its own size, no pool); a run that wants the pool sets it to its largest array
     bool field_shuffle = true;           // tuning: 0 = chunks in creation order (A/B of the random dealing itself)
-    int scratch_poison = 0;                          // test switch: every array of jrx_dev_alloc (second state sets, ητ, jrx_field_alloc) is filled with NaNs when it is allocated
+    int scratch_poison = 0;                          // test switch, bit mask: arrays of jrx_dev_alloc are filled with NaNs when they are allocated -- 1 the second state sets, 2 ητ, 4 jrx_field_alloc
     int fused_kz = 0;                                // tuning: chunk depth of the 64 x 8 tile of k_fused3d (0: 12 planes from nz = 384 on, else 8; 8 / 12 force)
     int field_pool_pct = 70;                         // tuning: "field_placement" = 1, chunks >= 128 MiB: the first allocation of a chunk size fills a pool of chunks for that share of the free memory, every array takes random chunks of it; 0 = off
     double *scratch_base[10] = {};       // what hipMalloc returned for scratch[q] (scratch[q] may start scratch_stagger * q bytes into it)
@@ -176,7 +176,7 @@ static constexpr double kGraphCells3D = 48.0 * 48.0 * 48.0;
 jrx_status jrx_check_device(jrx_handle *h);
 
 // fieldpool.hip: where every large library-owned array comes from (the handle's placement option applies); freed with the handle at the latest
-jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out);
+jrx_status jrx_dev_alloc(jrx_handle *h, size_t bytes, void **out, int tag = 4);      // tag: which bit of the test switch "scratch_poison" fills it with NaNs (1 second state sets, 2 ητ, 4 jrx_field_alloc)
 jrx_status jrx_dev_free(jrx_handle *h, void *p);
 void jrx_pool_destroy(jrx_handle *h);
 

@@ -647,7 +647,7 @@ static jrx_status ensure_scratch(jrx_handle *h, int nx, int ny, int nz)
         // tuning switch scratch_contiguous: physically contiguous device memory (hipDeviceMallocContiguous), plain hipMalloc when the runtime refuses
         const int keep = h->field_placement;
         if (h->scratch_contiguous) h->field_placement = 2;
-        const jrx_status st = jrx_dev_alloc(h, n[q] * sizeof(double) + (size_t)q * stg, &b);
+        const jrx_status st = jrx_dev_alloc(h, n[q] * sizeof(double) + (size_t)q * stg, &b, 1);
         h->field_placement = keep;
         JRX_TRY(st);
         h->scratch_base[q] = (double *)b;

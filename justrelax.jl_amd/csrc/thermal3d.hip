@@ -635,7 +635,7 @@ static jrx_status ensure_tscratch(jrx_handle *h, int nx, int ny, int nz)
     }
     h->tscratch_dims[0] = h->tscratch_dims[1] = h->tscratch_dims[2] = 0;
     const size_t n[4] = {(size_t)(nx + 2) * (ny + 2) * (nz + 2), (size_t)(nx + 1) * ny * nz, (size_t)nx * (ny + 1) * nz, (size_t)nx * ny * (nz + 1)};
-    for (int q = 0; q < 4; q++) JRX_TRY(jrx_dev_alloc(h, n[q] * sizeof(double), (void **)&h->tscratch[q]));
+    for (int q = 0; q < 4; q++) JRX_TRY(jrx_dev_alloc(h, n[q] * sizeof(double), (void **)&h->tscratch[q], 1));
     h->tscratch_dims[0] = nx; h->tscratch_dims[1] = ny; h->tscratch_dims[2] = nz;
     return JRX_OK;
 }

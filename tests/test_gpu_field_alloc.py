@@ -70,7 +70,7 @@ def test_pool_placement_maps_every_array_once_at_a_range_never_used_before(jr):
         h.set_option("field_placement", 1)
         h.set_option("field_chunk_mib", 128)
         h.set_option("field_pool_pct", 1)                      # ~1 % of the free memory: a few dozen chunks of 128 MiB
-        h.set_option("scratch_poison", 1)                      # every allocation starts as NaNs: the constructor's fill is what the caller sees
+        h.set_option("scratch_poison", 7)                      # every allocation starts as NaNs: the constructor's fill is what the caller sees
         arrays.use_library_arrays(h)
         shapes = [(257, 130, 67), (1200, 1100), (300, 300, 30), (512, 512, 70)]        # 17.9, 10.6, 21.6 MB: one chunk each; 146.8 MB: two chunks
         rng = np.random.default_rng(3)
@@ -128,7 +128,7 @@ def test_free_of_a_foreign_pointer_is_an_error(jr):
         h.call("jrx_field_free", C.c_void_p(t.data_ptr()))
 
 
-@pytest.mark.parametrize("placement,chunk,poison", [(1, 2, 0), (1, 128, 1), (2, 64, 0)])
+@pytest.mark.parametrize("placement,chunk,poison", [(1, 2, 0), (1, 128, 7), (2, 64, 0)])
 def test_solve_on_library_arrays_gives_the_same_bits(jr, placement, chunk, poison):
     """3D visco-elastic solve, finite dt (fused pipeline: the library's second state set comes from the same pool -- filled with NaNs first in the pool case) on arrays of the
     pool against torch's arrays"""

@@ -692,7 +692,7 @@ def test_two_blocks_on_pool_placed_library_arrays_keep_the_bits(jr):
                         h.set_option("field_placement", 1)
                         h.set_option("field_chunk_mib", 128)
                         h.set_option("field_pool_pct", 1)
-                        h.set_option("scratch_poison", 1)
+                        h.set_option("scratch_poison", 7)
                         arrays.use_library_arrays(h)
                     loc = Setup(ni=n, arrays={k: B.local_block(v, n, tb.ng, B.coords_of(tb.carts[r])) for k, v in S.arrays.items()})
                     ups.append(upload_stokes(loc, jr.AMDGPUBackend))
