@@ -73,6 +73,8 @@ struct jrx_handle {
     int general_hif = 0;                 // general (any dt) fused kernel, 64 x 4 tile: the high-face node layers inside the kernel and, with neighbours, the in-kernel faces: 4 / 3 = built for that many
                                          // waves per SIMD, 0 = the boundary-layer launch behind the kernel and the early exchange (the pipeline of rounds 1-4, default: measured faster)
     int64_t stat_fused3d_general_hif = 0;
+    int fused_ym = 0;                    // tuning (round 6): one-launch viscous-limit kernel, 64 x 8 tile: a block marches this many tile rows in y (0 / 1: one tile per block)
+    int64_t stat_fused3d_ym = 0;         // launches of the y-marching form
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)
     bool halo_self_rccl = false;         // test hook: a rank that is its own periodic neighbour routes the planes through ncclSend/ncclRecv
     int thermal_cfg = 0, thermal_xg = 8; // fused 3D heat-diffusion tile shape / XCD band override (tuning)

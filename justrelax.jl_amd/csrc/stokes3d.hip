@@ -585,6 +585,10 @@ static FusedShape fused_shape(const jrx_handle *h, const Lay3 &L, double dt)
         // The general form fits the shape as well (128 VGPRs, no spills, 70 KB of LDS per block) and gains little from it: nothing at 256^3 (1.064 -> 1.066 ms), 0.7 % at 512^3 with
         // 12-plane chunks (7.447 / 7.469 -> 7.392 / 7.418 ms, two pairs of processes on searched placements) -- it runs this shape from nz = 384 on, or when "fused_tile" = 3 asks for it
         const bool visc = h->viscous_limit && h->visc_ok && dt == INFINITY;
+        // round 6 A/B, "fused_tile" = 4: 64 x 16 threads -- fifteen stress rows per tile (y halo 16/15), ONE 16-wave block per CU: fetches 6 % less (16.08 against 17.16 GB per
+        // launch) and runs 8 % slower (5.14 - 5.17 against 4.74 - 4.87 ms at 512^3: one block per CU leaves nobody to run while it waits at its two barriers per plane);
+        // profiles/r06_y_halo.txt
+        if (h->fused_ylds && h->fused_tile == 4) return FusedShape{64, 16, 12};
         if (h->fused_ylds && (h->fused_tile == 3 || ((visc || L.nz >= 384) && h->fused_tile == 2 && !narrow && (long long)nt[0] * nt[1] * nt[2] >= 4096))) return T;
     }
     for (int kz = 8; kz >= 2; kz /= 2) {
@@ -762,6 +766,23 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
         }
         if (shell->cls != 0) { h->stat_fused3d_inkernel++; if (nof == 1) h->stat_fused3d_nof1++; else if (nof == 2) h->stat_fused3d_nof2++; }
         else { JRX_LAUNCH_CHECK(h); return JRX_OK; }       // counted once per iteration, with the second class
+    } else if (visc && fold && vf && TX == 64 && TY == 8 && h->fused_ym > 1) {
+        // the y march (k_fused3d, YM; tuning switch "fused_ym" = 2 / 4, round 6): a block marches that many tile rows, the y halo row is computed once per march.  Bit-identical,
+        // and SLOWER: 4.96 - 5.00 ms (2 rows) / 5.12 - 5.16 ms (4) against 4.74 - 4.79 ms at 512^3 -- the XCD-banded tile order already serves the halo row from L2, and the march
+        // fetches more through the fabric, not less (17.16 -> 18.15 / 18.60 GB per launch, PMC): profiles/r06_y_halo.txt.  Off.
+        const int ym = h->fused_ym >= 3 ? 4 : 2;
+        const unsigned nblk = (unsigned)(ntx * ((nty + ym - 1) / ym) * ntz);
+#define YML(NOF_, YM_) hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true, true, false, NOF_, YM_>), dim3(nblk), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4])
+        if constexpr (TX == 64 && TY == 8) {
+            switch (nof * 10 + (ym >= 3 ? 4 : 2)) {        // built for marches of two and of four tile rows
+            case 2: YML(0, 2); break; case 4: YML(0, 4); break;
+            case 12: YML(1, 2); break; case 14: YML(1, 4); break;
+            case 22: YML(2, 2); break; default: YML(2, 4); break;
+            }
+        }
+#undef YML
+        if (nof == 1) h->stat_fused3d_nof1++; else if (nof == 2) h->stat_fused3d_nof2++;
+        h->stat_fused3d_ym++;
     } else if (visc && fold && vf) {     // + the high-face node layers inside the kernel: the whole iteration in one launch
         if (nof == 2) {
             hipLaunchKernelGGL((k_fused3d<TX, TY, KZ, MW, 1, false, XGV, false, true, 3, 1, 0, true, true, true, false, 2>), dim3((unsigned)(ntx * nty * ntz)), dim3(TX * TY), 0, s, a, bc, ntx, nty, b[0], b[2], b[4]);
@@ -827,6 +848,7 @@ static jrx_status launch_fused(jrx_handle *h, hipStream_t s, const SweepArgs &a,
 {
     const FusedShape S = fused_shape(h, a.L, a.dt);
     const int kz = S.kz;
+    if (S.tx == 64 && S.ty == 16) return launch_fused_t<64, 16, 12, 4, 2>(h, s, a, bc, b, hiface, fold, shell);
     if (S.tx == 64 && S.ty == 8) return kz == 12 ? launch_fused_t<64, 8, 12, 4, 4>(h, s, a, bc, b, hiface, fold, shell) : launch_fused_t<64, 8, 8, 4, 4>(h, s, a, bc, b, hiface, fold, shell);
     if (S.tx == 64) {
         if (kz == 8) return launch_fused_t<64, 4, 8, 4, 1, true>(h, s, a, bc, b, hiface, fold, shell);

@@ -694,7 +694,7 @@ __device__ __forceinline__ double LDC(const double *p, u32 off)
 // HIF (viscous-limit form, no neighbours): the stress nodes on the high faces i = nx, j = ny, k = nz -- which no cell column owns and which the boundary-layer launch
 // (k_stress3d_boxes with the flow_bcs! rules) otherwise updates behind this kernel -- are updated here by the threads of the last cell column / row / plane, from the
 // new velocities they hold anyway and the same rules (GhostRule), operation for operation as stress3d_node<false, true, true>: one launch per iteration.
-template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false, bool VFOLD = false, bool NBR = false, int NOF = 0>
+template <int TX, int TY, int KZ, int MINW, int OVX = 1, bool LOWREG = false, int XG = 0, bool LATEA = false, bool SHFL = false, int YLDS = 0, int NT = 0, int TAG = 0, bool VISC = false, bool HIF = false, bool VFOLD = false, bool NBR = false, int NOF = 0, int YM = 1>
 __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, const FusedBC bc, int ntx, int nty, int tx0 = 0, int ty0 = 0, int tz0 = 0, const FusedShell sh = FusedShell{})
 {
     // the launch covers the box of tiles [tx0, tx0+ntx) x [ty0, ty0+nty) x [tz0, tz0 + gridDim.x/(ntx*nty))
@@ -704,7 +704,12 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     static_assert(!HIF || (!LOWREG && SHFL && OVX == 1 && YLDS == 3), "the folded high-face layers are built on the forms with carried planes");
     static_assert(!VFOLD || VISC, "VFOLD simplifies the viscous-limit arithmetic");
     static_assert(!NBR || HIF, "the in-kernel neighbour faces are built on the one-launch forms");
+    // YM > 1 (round 6): the block marches YM consecutive tiles in y.  Row 0 of a tile only feeds the velocity phase -- it recomputes what the top row of the tile below it
+    // computes as its own (the y halo: 1 / (TY - 1) of every velocity-phase operand is read twice) -- so the top row leaves its new velocities and its η, plane by plane, in
+    // LDS (sT) and row 0 of the next tile of the march takes them from there instead of loading anything: the halo is paid once per YM tiles.  Same values, same bits.
+    static_assert(YM == 1 || (VISC && HIF && VFOLD && !NBR && !LOWREG && YLDS == 3), "the y march is built on the one-launch viscous-limit form");
     constexpr int NS = LOWREG ? 3 : 2;
+    __shared__ double sT[YM > 1 ? KZ + 1 : 1][4][YM > 1 ? TX : 1];
     __shared__ double sV[NS][3][TY][TX];
     __shared__ double sY[YLDS ? (VISC ? 7 : 8) : 1][YLDS ? TY : 1][YLDS ? TX : 1];
     const Lay3 &L = a.L;
@@ -741,19 +746,24 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
         }
         tix = sh.box[b][0] + l % bw; tiy = sh.box[b][2] + (l / bw) % bh; tiz = sh.box[b][4] + l / (bw * bh);
     } else {
+        const int ntyS = (nty + YM - 1) / YM;      // rows of blocks: a block marches YM tile rows
         if (XG > 0) {
             // XCD-banded order (blocks are dealt round-robin to the 8 XCDs): XCD q takes XG consecutive tile rows
             // q*XG .. q*XG+XG-1 of every group of 8*XG rows (rows run over y, then z), so the y-halo rows of
             // neighbouring tiles are served by the same L2; the tail that does not fill a group keeps plain order
-            const int full = ((nty * (int)(gridDim.x / (unsigned)(ntx * nty))) / (8 * XG)) * (8 * XG) * ntx;
+            const int full = ((ntyS * (int)(gridDim.x / (unsigned)(ntx * ntyS))) / (8 * XG)) * (8 * XG) * ntx;
             if (tile < full) {
                 const int q = tile & 7, r = tile >> 3, r2 = r / ntx;
                 tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
             }
         }
         const int tr = tile / ntx;
-        tix = tx0 + tile % ntx; tiy = ty0 + tr % nty; tiz = tz0 + tr / nty;
+        tix = tx0 + tile % ntx; tiy = ty0 + (tr % ntyS) * YM; tiz = tz0 + tr / ntyS;
     }
+    const int tiy_end = NBR ? tiy + 1 : min(tiy + YM, ty0 + nty);       // the tiles [tiy, tiy_end) of the march
+    for (const int tiy_first = tiy; tiy < tiy_end; ++tiy) {
+    const bool fed = YM > 1 && tiy > tiy_first && threadIdx.x < TX;        // row 0 of a tile behind the first of the march: fed from sT (a whole wave: uniform)
+    const bool feeds = YM > 1 && tiy + 1 < tiy_end && (int)(threadIdx.x / TX) == TY - 1;     // the top row of a tile with a successor in the march
     const int i = tix * (TX - OVX - (SHFL ? 1 : 0)) - OVX + tx;  // cell column of this thread
     const int j = tiy * (TY - 1) - 1 + ty;
     const int kb = tiz * KZ;
@@ -792,7 +802,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
 
     // velocity-sweep carries (plane k values that were the upper loads of the previous plane)
     double Pc = 0, ec = 0, tzz_c = 0, fz_c = 0, s10 = 0, r10 = 0, s01p = 0, r01p = 0;
-    if (bvalid) {
+    if (bvalid && !fed) {
         Pc = LDB(f.P, oc); ec = LDB(et, oc); tzz_c = LDB(f.tzz, oc); fz_c = LFZ(oc);
         s10 = LDB(f.txz, oxz + 8u - sxz); r10 = LDB(f.tyz, oyz + ryz - syz);
         s01p = LDB(f.txz, oxz - sxz); r01p = LDB(f.tyz, oyz - syz);
@@ -816,7 +826,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             if (SHFL) {
                 // η, G of the own column for every lane that has one; the i-1 column arrives by lane shuffle (clamped at i = 0)
                 if (YLDS) {
-                    if (bvalid) { e = LDB(f.eta, oc); if (!VISC) g = LDB(f.G, oc); }
+                    if (fed) e = sT[k - kfirst][3][tx];
+                    else if (bvalid) { e = LDB(f.eta, oc); if (!VISC) g = LDB(f.G, oc); }
                 } else if (bvalid) {
                     e = LDB(f.eta, oc); ey = LDB(f.eta, oc - dcy); g = LDB(f.G, oc); gy = LDB(f.G, oc - dcy);
                     const double e_l = __shfl_up(e, 1, TX), g_l = __shfl_up(g, 1, TX), ey_l = __shfl_up(ey, 1, TX), gy_l = __shfl_up(gy, 1, TX);
@@ -847,7 +858,12 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
         double q01 = 0, s01 = 0, r11 = 0, r01 = 0, Pz = 0, ez = 0, tzz_z = 0, fz_z = 0, Py = 0, eyb = 0, tyy_y = 0;
         double fx_c = 0, fy_c = 0, fy_y = 0, vx = 0, vy = 0, vz = 0, txy_own = 0;
         const bool yrow = YLDS && ty < TY - 1 && hy;     // the j+1 operands are the next row's own operands (row = wave: uniform)
-        if (bvalid) {
+        if (fed) {
+            // the new velocities of this row and plane, as the top row of the previous tile of the march computed them (read before the barrier: that row writes this plane's
+            // entry of sT again behind it)
+            vxn = sT[k - kfirst][0][tx]; vyn = sT[k - kfirst][1][tx]; vzn = sT[k - kfirst][2][tx];
+            sY[6][ty][tx] = e;
+        } else if (bvalid) {
             const u32 dz1 = hz ? sc : 0u;
             if (YLDS) {
                 // published operands first (loads return in order), then the rest
@@ -887,7 +903,9 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             }
         }
         if (YLDS) __syncthreads();
-        if (bvalid) {
+        if (fed) {
+            sV[slot][0][ty][tx] = vxn; sV[slot][1][ty][tx] = vyn; sV[slot][2][ty][tx] = vzn;
+        } else if (bvalid) {
             if (YLDS) {
                 if (yrow) {
                     Py = sY[0][ty + 1][tx]; eyb = sY[1][ty + 1][tx]; tyy_y = sY[2][ty + 1][tx]; if (NOF < 1) fy_y = sY[3][ty + 1][tx];
@@ -940,6 +958,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             } else vzn = bc.nsK1 ? 0.0 : vz;
             Pc = Pz; ec = ez; tzz_c = tzz_z; fz_c = fz_z; s10 = s11; r10 = r11; s01p = s01; r01p = r01;
             sV[slot][0][ty][tx] = vxn; sV[slot][1][ty][tx] = vyn; sV[slot][2][ty][tx] = vzn;
+            if (feeds) { sT[k - kfirst][0][tx] = vxn; sT[k - kfirst][1][tx] = vyn; sT[k - kfirst][2][tx] = vzn; sT[k - kfirst][3][tx] = e; }
         }
         if (YLDS == 3 && !VISC && avalid && live) {
             // lower register peak: the stress-only operands are requested once the velocity operands are consumed
@@ -1149,6 +1168,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             STN<(NT & 1) != 0>(a.o.tyz, oyz - syz + ryz, r10 + INC(r10, to_, ee, s_, _Gdt, dtr));
         }
     }
+    }   // the march over tiy
 #undef NBV
 #undef NBVX
 #undef NBVY

@@ -264,7 +264,8 @@ def test_kernel_variants_are_bit_identical(env, ni, bcs):
 
 @pytest.mark.parametrize("ni,bcs,tile", [((130, 20, 17), "free_slip", 0), ((97, 9, 33), "none", 0), ((130, 17, 20), "no_slip", 1), ((66, 9, 35), "slip_mix", 1),
                                          ((130, 12, 17), "periodic", 0), ((130, 20, 17), "free_slip", 3), ((97, 23, 33), "none", 3), ((130, 17, 20), "no_slip", 3),
-                                         ((70, 30, 19), "slip_mix", 3), ((130, 12, 17), "periodic", 3), ((190, 50, 9), "slip_mix", 3)])
+                                         ((70, 30, 19), "slip_mix", 3), ((130, 12, 17), "periodic", 3), ((190, 50, 9), "slip_mix", 3),
+                                         ((130, 40, 17), "free_slip", 4), ((97, 23, 33), "none", 4), ((130, 17, 20), "no_slip", 4), ((70, 50, 19), "slip_mix", 4), ((130, 12, 17), "periodic", 4)])
 def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
     """dt = Inf (SolVi3D, Burstedde, TaylorGreen: SolVi3D.jl:96 hands dt = Inf): the fused kernel's viscous-limit form does not load τ_o, P0, K, G, Q
     -- every one of them random and non-zero here -- and must equal the general fused kernel and the per-node kernels, which do."""
@@ -301,10 +302,50 @@ def test_viscous_limit_kernel_equals_the_general_one(env, ni, bcs, tile):
             assert (k[0] == "U" or np.isfinite(outs[0][k][m]).all()) and np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)      # U = V dt = ±Inf, NaN where V = 0
 
 
+@pytest.mark.parametrize("ym", [2, 4])
+@pytest.mark.parametrize("ni,bcs,zero", [((130, 40, 17), "free_slip", "xyz"), ((97, 23, 33), "none", ""), ((70, 50, 19), "slip_mix", "xy"), ((190, 57, 9), "no_slip", "xyz"), ((130, 12, 17), "periodic", "")])
+def test_y_march_of_the_fused_kernel_keeps_the_bits(env, ni, bcs, zero, ym):
+    """round 6: a block of the one-launch viscous-limit kernel (64 x 8 tile) marches `fused_ym` tile rows in y; row 0 of every tile behind the first takes the new velocities and
+    η of its cells from LDS, where the top row of the previous tile left them, instead of recomputing them from re-loaded operands (the y halo).  Same values: every array equals
+    the one-tile-per-block form and the per-node kernels bit for bit -- for ny that fill whole marches, leave a shorter last march (ny = 23: 4 tile rows; 57: 9) or a single tile
+    row (ny = 12: no march at all)."""
+    jr = env["jr"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields3d(ni, bcs=bcs, dt=np.inf, iterMax=23, nout=7)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    for c in zero:
+        s.arrays["f" + c][...] = 0.0
+    h = _lib.default_handle()
+    tile0, ym0 = h.get_option("fused_tile"), h.get_option("fused_ym")
+    outs, its, marched = [], [], []
+    try:
+        h.set_option("fused_tile", 3)
+        for variant, m in ((3, ym), (3, 0), (1, 0)):
+            h.set_option("kernel_variant", variant)
+            h.set_option("fused_ym", m)
+            stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+            c0 = h.get_option("stat_fused3d_ym")
+            r = jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+            marched.append(h.get_option("stat_fused3d_ym") - c0)
+            its.append((r.iter, tuple(r.err_evo1)))
+            outs.append(env["down"](stokes))
+    finally:
+        h.set_option("kernel_variant", 0)
+        h.set_option("fused_tile", tile0)
+        h.set_option("fused_ym", ym0)
+    assert (marched[0] > 0) == (bcs != "periodic") and marched[1:] == [0, 0], marched       # periodic faces: the kernel is not the one-launch form
+    assert its[0] == its[1] == its[2] and its[0][0] == 24
+    for v in (1, 2):
+        for k in outs[0]:
+            m = env["checks"].interior_mask3d(k, outs[0][k].shape)
+            assert np.array_equal(outs[0][k][m], outs[v][k][m], equal_nan=True), (v, k)
+
+
 @pytest.mark.parametrize("zero,nof", [("xy", 1), ("xyz", 2), ("xy one entry -0.0", 0), ("xy one entry 1e-300", 0), ("z", 0), ("xz", 0), ("", 0)])
 @pytest.mark.parametrize("ni,bcs,tile,dt", [((130, 20, 17), "free_slip", 0, np.inf), ((66, 9, 35), "slip_mix", 1, np.inf), ((97, 9, 33), "none", 0, np.inf),
                                             ((130, 20, 17), "free_slip", 0, 0.25), ((66, 9, 35), "slip_mix", 1, 0.25), ((130, 17, 20), "no_slip", 0, 0.25),
-                                            ((130, 20, 17), "free_slip", 3, np.inf), ((97, 23, 20), "none", 3, np.inf), ((130, 20, 17), "free_slip", 3, 0.25), ((70, 30, 19), "slip_mix", 3, 0.25)])
+                                            ((130, 20, 17), "free_slip", 3, np.inf), ((97, 23, 20), "none", 3, np.inf), ((130, 20, 17), "free_slip", 3, 0.25), ((70, 30, 19), "slip_mix", 3, 0.25),
+                                            ((130, 40, 17), "free_slip", 4, np.inf), ((70, 50, 19), "slip_mix", 4, 0.25)])
 def test_body_forces_that_are_zero_are_not_loaded_and_the_bits_stay(env, ni, bcs, tile, dt, zero, nof):
     """SolVi3D.jl:102 hands three ρg arrays of zeros, and every 3D model of the reference has ρg_x = ρg_y = 0 (gravity along z).  The one-launch viscous-limit kernel does not
     load body-force arrays in which the operand pass of the driver call has found nothing but +0.0 (all 64 bits zero): x - 0.5 (0 + 0) = x for every x, -0.0 and NaN included.
