@@ -5,7 +5,7 @@ import json, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-import bench
+import bench_extras as bench
 from __graft_entry__ import load_package
 jr = load_package()
 from justrelax_jl_amd import _lib

@@ -6,7 +6,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package
-import bench
+import bench_extras as bench
 jr = load_package()
 args = [a for a in sys.argv[1:] if "=" not in a]
 opts = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}

@@ -4,7 +4,7 @@ import json, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-import bench
+import bench_extras as bench
 args = bench.parse_args(["--n", sys.argv[1] if len(sys.argv) > 1 else "512"])
 bench.start_ipc_helpers(args)
 try:

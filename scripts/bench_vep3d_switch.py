@@ -7,7 +7,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package
 jr = load_package()
 from justrelax_jl_amd import _lib
-import bench
+import bench_extras as bench
 h = _lib.default_handle(0)
 key = sys.argv[1]
 for n in [int(a) for a in sys.argv[2:]] or [16, 32, 48, 64, 96, 128]:

@@ -5,7 +5,7 @@ import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-import bench
+import bench_extras as bench
 from __graft_entry__ import load_package
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
