@@ -12,7 +12,7 @@ import torch  # noqa: E402
 from justrelax_jl_amd import _lib, stokes  # noqa: E402
 import justrelax_jl_amd.grid as grid  # noqa: E402
 from justrelax_jl_amd.miniapps.stokes3d import solvi3d_device  # noqa: E402
-import bench  # noqa: E402
+import bench_extras as bench  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 41
