@@ -118,6 +118,10 @@ jrx_status jrx_field_stats(jrx_handle *h, int64_t out[6]);
  * "field_placement" (0/1/2, default 0): backing of the arrays of jrx_field_alloc and of the library's own large arrays: 0 = hipMalloc; 1 = physical chunks
  *   (hipMemCreate) picked at random from a pool and mapped once onto a fresh virtual range per array; 2 = physically contiguous (hipDeviceMallocContiguous; the slowest placement there
  *   is, for A/B runs).  Results never depend on it.
+ * "field_chunk_mib" (default 64): size of a physical chunk of "field_placement" = 1 in MiB (0: every array ONE chunk of its own size).  The pool -- chunks for most of the free
+ *   memory, created by the first large allocation, dealt at random -- exists for chunks of >= 128 MiB; a caller sets the size of its largest array (for an (nx, ny, nz) block:
+ *   (nx + 2)(ny + 2)(nz + 2) x 8 B rounded up to 2 MiB) so that every array is ONE chunk of one common size, which is the arrangement that was measured
+ *   (profiles/r05_placement_search.txt section 13, profiles/r06_ten_processes.txt).
  * Read-only counters (jrx_get_option): "stat_fused3d", "stat_fused2d", "stat_thermal_fused", "stat_vep3_fused" = launches of the fused
  *   kernels since jrx_create, "stat_fused3d_visc" = those of "stat_fused3d" that ran the viscous-limit form, "stat_fused3d_inkernel" = those that finished the faces with a neighbour themselves ("fused_overlap" = 3), "stat_visc_checks" /
  *   "stat_visc_fallbacks" = operand checks run / failed (general kernels used), "stat_operand_cache_hits" = driver calls that reused the operand verdict, "stat_graph_replays" = hipGraphLaunch calls -- so that a caller

@@ -53,8 +53,7 @@
  *   "comm_timeout_ms" (120000)    in-process and ipc transports (jrx_comm_init_local / _ipc): how long a rank waits for a neighbour (host waits and the device-side flag waits)
  *   "chain_profile" (0)           jrx_stokes3d_iterate_timed on a multi-rank handle also records events around the stages of every sampled fused step; read with
  *                                 jrx_tuning_chain_profile
- *   "field_chunk_mib" (64), "field_shuffle" (1)    jrx_field_alloc with "field_placement" = 1: size of a physical chunk (0: every array is ONE chunk of its own size, no pool); a run
- *                                 whose large arrays should be ONE chunk each sets it to the size of its largest array (bench.py does); 0 = chunks dealt in creation order (A/B of the random dealing)
+ *   "field_shuffle" (1)          "field_placement" = 1: 0 = chunks dealt in creation order (A/B of the random dealing)
  *   "scratch_poison" (0)         test switch, bit mask: arrays the library allocates are filled with NaNs first (what they hold before their first use must not matter): 1 = the second state sets,
  *                                 2 = the library-owned ητ, 4 = the arrays of jrx_field_alloc
  *   "fused_ym" (0)               one-launch viscous-limit kernel, 64 x 8 tile: 2 / 4 = a block marches that many tile rows in y and hands the halo row on in LDS (round 6; bit-identical, measured
