@@ -427,6 +427,144 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TS
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_thermal3d_fused with the rows j - 1 / j + 1 through LDS (round 6, tuning switch "thermal_tile" = TY): a block is a tile of 64 cells x TY rows (a row per wave) marching KZ
+// planes.  The row-segment form above reads T, K, θ of the row below and T, K, θ, qTy of the row above from memory for every cell (served by L2 where the XCD band holds: 18 array
+// passes moved for 15 needed); here every row publishes its (T, K, θ) of the plane, takes the row below's from LDS for its low y face, publishes the new flux of that face, and
+// takes the row above's as the flux of its high face instead of recomputing it.  Only the bottom row of a tile loads the row below, only the top row (and the row on the domain's
+// back face) computes its high face from loaded operands.  Two barriers per plane.  Operand for operand the arithmetic of k_thermal3d_fused<., ., ., 1>: same bits.
+// ------------------------------------------------------------------------------------------------
+template <int TY, int KZ, int XG>
+__global__ __launch_bounds__(64 * TY) void k_thermal3d_fused_t(const T3Args a, const TSet dst, int ntx, int nty)
+{
+    __shared__ double sA[3][TY][64];      // T, K, θ of the own cell, plane k
+    __shared__ double sQ[TY][64];         // new flux on the low y face of the row
+    const int nx = (int)a.p.nx, ny = (int)a.p.ny, nz = (int)a.p.nz;
+    int tile = blockIdx.x;
+    {
+        const int rows = (int)(gridDim.x / (unsigned)ntx);          // nty * number of z chunks
+        const int full = (rows / (8 * XG)) * (8 * XG) * ntx;
+        if (tile < full) {
+            const int q = tile & 7, r = tile >> 3, r2 = r / ntx;
+            tile = ((r2 / XG) * (8 * XG) + q * XG + r2 % XG) * ntx + r % ntx;
+        }
+    }
+    const int lane = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
+    const int tix = tile % ntx, tr = tile / ntx, jt = (tr % nty) * TY, tiz = tr / nty;
+    const int i = tix * 64 + lane;
+    const int j = jt + ty;
+    const int kb = tiz * KZ, kend = min(kb + KZ, nz);
+    const bool rok = j < ny;                   // a whole wave
+    const bool cell = i < nx && rok;
+    const int ic = i < nx ? i : nx - 1, jc = rok ? j : ny - 1;
+    const double *__restrict__ T = a.t.T, *__restrict__ th = a.t.thetar_dtau, *__restrict__ Kk = a.t.K;
+    const double kc = (a.p.k_const + a.p.k_const) * 0.5;
+    const bool rf = a.p.rheology_form != 0;
+    const double _dt = 1.0 / a.p.dt, _dx = a.p._dx, _dy = a.p._dy, _dz = a.p._dz;
+    const i64 sT1 = nx + 2, sT2 = (i64)(nx + 2) * (ny + 2), sC2 = (i64)nx * ny;
+    const int im = max(ic - 1, 0), ip = min(ic + 1, nx - 1);
+    const bool edge = lane == 63 || i == nx - 1;      // no lane to the right holds cell i+1
+    const bool cfxl = a.p.constant_flux_on[XL] != 0, cfxr = a.p.constant_flux_on[XR] != 0, cfyf = a.p.constant_flux_on[YF] != 0,
+               cfyb = a.p.constant_flux_on[YB] != 0, cfzb = a.p.constant_flux_on[ZB] != 0, cfzt = a.p.constant_flux_on[ZT] != 0;
+    auto relax = [&](double qold, double Kl, double Kr, double tl, double tr_, double Thi, double Tlo, double _d) -> double {
+        const double K = rf ? kc : (Kl + Kr) * 0.5;
+        const double t = (tl + tr_) * 0.5;
+        const double qv = -K * (Thi - Tlo) * _d;
+        return (qold * t + qv) / (1.0 + t);
+    };
+    double Tc, Kc_, tc, qz_lo;
+    {
+        const i64 c = ic + (i64)nx * jc + sC2 * kb, I1 = (ic + 1) + sT1 * (jc + 1) + sT2 * (kb + 1);
+        Tc = T[I1]; Kc_ = rf ? 0.0 : Kk[c]; tc = th[c];
+        if (kb == 0 && cfzb) qz_lo = a.p.constant_flux[ZB];
+        else {
+            const i64 cl = kb > 0 ? c - sC2 : c;
+            qz_lo = relax(a.t.qTz[c], rf ? 0.0 : Kk[cl], Kc_, th[cl], tc, Tc, T[I1 - sT2], _dz);
+        }
+        if (kb == 0 && cell) dst.qz[c] = qz_lo;
+    }
+    const int jlo = max(j - 1, 0);
+    const bool below = ty > 0;                                       // the row below is a row of this tile
+    const bool above = ty < TY - 1 && j + 1 < ny;                    // the row above is a live row of this tile
+    for (int k = kb; k < kend; ++k) {
+        sA[0][ty][lane] = Tc; sA[1][ty][lane] = Kc_; sA[2][ty][lane] = tc;
+        __syncthreads();
+        const i64 c = ic + (i64)nx * jc + sC2 * k, I1 = (ic + 1) + sT1 * (jc + 1) + sT2 * (k + 1);
+        // ---- y: low face j of the own cell
+        double qy_lo = 0.0, qy_hi = 0.0;
+        const i64 q0 = ic + (i64)nx * (jc + (i64)(ny + 1) * k);
+        if (rok) {
+            if (j == 0 && cfyf) qy_lo = a.p.constant_flux[YF];
+            else if (below) qy_lo = relax(a.t.qTy[q0], sA[1][ty - 1][lane], Kc_, sA[2][ty - 1][lane], tc, Tc, sA[0][ty - 1][lane], _dy);
+            else {
+                const i64 cl = ic + (i64)nx * jlo + sC2 * k;
+                qy_lo = relax(a.t.qTy[q0], rf ? 0.0 : Kk[cl], Kc_, th[cl], tc, Tc, T[(ic + 1) + sT1 * j + sT2 * (k + 1)], _dy);
+            }
+            if (cell) dst.qy[q0] = qy_lo;
+        }
+        sQ[ty][lane] = qy_lo;
+        __syncthreads();
+        if (rok) {
+            // ---- y: high face j + 1: the row above's low face, or (top row of the tile, back face of the domain) computed here from loaded operands
+            if (above) qy_hi = sQ[ty + 1][lane];
+            else {
+                const int jf = j + 1;
+                const i64 q = q0 + (i64)nx;
+                if (jf == ny && cfyb) qy_hi = a.p.constant_flux[YB];
+                else {
+                    const int ju = jf < ny ? jf : ny - 1;
+                    const i64 cu = ic + (i64)nx * ju + sC2 * k;
+                    qy_hi = relax(a.t.qTy[q], Kc_, rf ? 0.0 : Kk[cu], tc, th[cu], T[(ic + 1) + sT1 * (jf + 1) + sT2 * (k + 1)], Tc, _dy);
+                }
+                if (cell && jf == ny) dst.qy[q] = qy_hi;
+            }
+            // ---- x: low face i (own), high face i+1 from the next lane
+            double qx_lo;
+            {
+                const i64 q = ic + (i64)(nx + 1) * (j + (i64)ny * k);
+                if (ic == 0 && cfxl) qx_lo = a.p.constant_flux[XL];
+                else {
+                    const i64 cl = c - (ic - im);
+                    qx_lo = relax(a.t.qTx[q], rf ? 0.0 : Kk[cl], Kc_, th[cl], tc, Tc, T[I1 - 1], _dx);
+                }
+                if (cell) dst.qx[q] = qx_lo;
+            }
+            double qx_hi = __shfl_down(qx_lo, 1, 64);
+            if (edge) {
+                const i64 q = (ic + 1) + (i64)(nx + 1) * (j + (i64)ny * k);
+                if (ic + 1 == nx && cfxr) qx_hi = a.p.constant_flux[XR];
+                else {
+                    const i64 cr = c + (ip - ic);
+                    qx_hi = relax(a.t.qTx[q], Kc_, rf ? 0.0 : Kk[cr], tc, th[cr], T[I1 + 1], Tc, _dx);
+                }
+                if (cell && ic + 1 == nx) dst.qx[q] = qx_hi;
+            }
+            // ---- z: high face k+1 (owned here), becomes the low face of the next plane
+            double qz_hi, Kn_ = 0.0;
+            const i64 cr = k + 1 < nz ? c + sC2 : c;
+            const double Tn_c = T[I1 + sT2], tn = th[cr];
+            if (!rf) Kn_ = Kk[cr];
+            if (k + 1 == nz && cfzt) qz_hi = a.p.constant_flux[ZT];
+            else qz_hi = relax(a.t.qTz[c + sC2], Kc_, Kn_, tc, tn, Tn_c, Tc, _dz);
+            if (cell) dst.qz[c + sC2] = qz_hi;
+            if (cell) {
+                const double rcp = rhoCp3_of(a.p, a.t.rhoCp, c, Tc);
+                const double divq = (qx_hi - qx_lo) * _dx + (qy_hi - qy_lo) * _dy + (qz_hi - qz_lo) * _dz;
+                const double dr = a.t.dtau_rho[c];
+                const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
+                dst.T[I1] = Tn;
+                const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
+                const int mask = ((i == 0 || i == nx - 1) ? 1 : 0) | ((j == 0 || j == ny - 1) ? 2 : 0) | ((k == 0 || k == nz - 1) ? 4 : 0);
+                if (mask) {
+                    const i64 st[3] = {1, sT1, sT2};
+                    thermal_ghosts3d(a.p, dst.T, st, I1, mask, side, Tn);
+                }
+            }
+            qz_lo = qz_hi; Tc = Tn_c; Kc_ = Kn_; tc = tn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_thermal3d_fused for the phase-ratio form (TPhN<NPH>: phase count as a constant), one row per thread (R = 1): compute_flux! with the conductivity of a face averaged from the
 // phase ratios at the two clamped face positions (k_flux3d, DiffusionPT_kernels.jl:366-440), update_T! with ρCp and the radiogenic heat from the centre ratios (k_updateT3d),
 // thermal_bcs! by rule, and update_pt_thermal_arrays! of the next iteration from the cell's new T (the `wpt` part of k_updateT3d).  θr_dτ is read at neighbouring cells and written
@@ -776,6 +914,15 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
         launched = true; h->stat_thermal_fused++;                                                                                                         \
     }
         bool launched = false;
+        if (h->thermal_tile == 4 || h->thermal_tile == 8) {        // round 6: 64 x TY tiles, y neighbours through LDS (k_thermal3d_fused_t)
+            const int TYv = h->thermal_tile, ntx_t = (nx + 63) / 64, nty_t = (ny + TYv - 1) / TYv, ntz_t = (nz + 3) / 4;
+            const unsigned nb = (unsigned)(ntx_t * nty_t * ntz_t);
+            const int xg = h->thermal_xg == 8 ? (TYv == 4 ? 2 : 1) : h->thermal_xg;      // default band: 8 rows per XCD, as the row-segment form has
+#define THT(TY_, XG_) if (TYv == TY_ && xg == XG_) { hipLaunchKernelGGL((k_thermal3d_fused_t<TY_, 4, XG_>), dim3(nb), dim3(64 * TY_), 0, s, b, o, ntx_t, nty_t); launched = true; }
+            THT(4, 1) THT(4, 2) THT(4, 4) THT(8, 1) THT(8, 2) THT(8, 4)
+#undef THT
+            if (launched) { h->stat_thermal_fused++; JRX_LAUNCH_CHECK(h); return JRX_OK; }
+        }
         // measured at 256^3 (profiles/r01_thermal3d_fused_sweep.txt): one row per thread 2289 it/s, two rows 1526, four rows 1301
         THL(256, 4, 1, 8) THL(128, 4, 1, 8) THL(64, 4, 1, 8) THL(256, 8, 1, 8) THL(256, 4, 2, 8)
         THL(256, 4, 1, 1) THL(256, 4, 1, 2) THL(256, 4, 1, 4) THL(256, 2, 1, 1) THL(256, 2, 1, 2) THL(256, 8, 1, 1) THL(128, 4, 1, 1) THL(64, 4, 1, 1)

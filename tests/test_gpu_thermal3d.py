@@ -127,3 +127,35 @@ def test_fused_and_two_kernel_iterations_agree_at_full_size(jr, ni):
         assert np.array_equal(outs[0][2][k], outs[1][2][k]), k
     T = outs[0][2]["T"]
     assert np.isfinite(T).all() and T.max() > 1500.0
+
+
+@pytest.mark.parametrize("tile", [4, 8])
+@pytest.mark.parametrize("form,ni", [("array", (70, 17, 20)), ("rheology", (130, 9, 35)), ("array", (200, 96, 70)), ("rheology", (64, 21, 13))])
+def test_tiled_fused_iteration_keeps_the_bits(jr, form, ni, tile):
+    """round 6, tuning switch "thermal_tile": the one-launch iteration on 64 x TY tiles whose rows exchange (T, K, θ) and the new y flux through LDS (k_thermal3d_fused_t) gives
+    the bits of the row-segment form and of the two-kernel iteration -- grids whose ny fills whole tiles, leaves a partial last tile (17, 21, 9 rows) and whose nx is not a
+    multiple of 64"""
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.diffusion3d(ni, iterMax=60, nout=20)
+    rheo = s.extra["rheology"] if form == "rheology" else None
+    h = _lib.default_handle()
+    outs = []
+    try:
+        for fused, tl in ((1, tile), (1, 0), (0, 0)):
+            h.set_option("thermal_fused", fused)
+            h.set_option("thermal_tile", tl)
+            thermal, pt, K, ρCp = _setup(jr, s)
+            pt.ϵ = 1e-30
+            A, B = (rheo, None) if form == "rheology" else (K, ρCp)
+            n0 = h.get_option("stat_thermal_fused")
+            r = jr.heatdiffusion_PT_(thermal, pt, s.flow_bcs, A, B, s.dt, s.grid, kwargs=dict(iterMax=60, nout=20, verbose=False))
+            assert (h.get_option("stat_thermal_fused") > n0) == bool(fused)
+            outs.append((list(r.iter_count), list(r.norm_ResT), {k: jr.to_numpy(getattr(thermal, k)) for k in ("T", "qTx", "qTy", "qTz", "ResT")}))
+            del thermal, pt, K, ρCp
+    finally:
+        h.set_option("thermal_fused", 1)
+        h.set_option("thermal_tile", 0)
+    for v in (1, 2):
+        assert outs[0][0] == outs[v][0] == [20, 40, 60] and outs[0][1] == outs[v][1]
+        for k in outs[0][2]:
+            assert np.array_equal(outs[0][2][k], outs[v][2][k]), (v, k)
