@@ -73,7 +73,8 @@ const char *jrx_build_id(void);
  * "field_placement" = 1 every large array is mapped ONCE, at a virtual range never used before, onto physical chunks picked at random from a pool that spans most of the free
  * memory (tuning keys "field_chunk_mib", "field_pool_pct": include/jrx_tuning.h); the library's own large arrays (second state sets, ητ) follow the same option.  An array is
  * never moved afterwards.  jrx_destroy releases whatever the caller has not freed.  jrx_field_trim returns the pool's unused chunks to the driver (call it once the arrays of a
- * run exist -- the library's second state set is made by the first driver call).
+ * run exist -- the library's second state set is made by the first driver call).  The pool is filled when a large array is requested while no array of that chunk size is live
+ * (the first array of a run); arrays made later get chunks created on the spot.
  * jrx_field_stats: [0] live arrays (the library's own included), [1] their bytes, [2] physical chunks created, [3] spare chunks, [4] us in hipMemCreate, [5] us mapping. */
 jrx_status jrx_field_alloc(jrx_handle *h, int64_t count, double **out);     /* count doubles */
 jrx_status jrx_field_free(jrx_handle *h, double *p);

@@ -7,10 +7,11 @@
 // memory (4.81 - 4.85 ms in sixteen of sixteen picks, where the first chunks the driver hands out give 4.95 / 5.64 ms).  That is what "field_placement" = 1 does,
 // at allocation time:
 //
-//   * the first large request of a chunk size fills a pool of hipMemCreate chunks of that size for "field_pool_pct" % of the free memory;
+//   * a large request of a chunk size of which no array is live fills a pool of hipMemCreate chunks of that size for "field_pool_pct" % of the free memory;
 //   * every array takes random chunks of the pool and maps them ONCE, at a virtual range that has NEVER been used before (a fresh hipMemAddressReserve);
 //   * a freed array's range is unmapped and retired for good (never handed out again, never given back to the runtime); its chunks return to the pool;
-//   * jrx_field_trim releases the chunks nobody uses (call it when the arrays of a run have been made).
+//   * jrx_field_trim releases the chunks nobody uses (call it when the arrays of a run have been made); arrays made later -- while arrays of the run are live -- get chunks
+//     created on the spot (no second pool: a solve! behind the trim does not spend seconds, and 70 % of the memory, on one).
 //
 // Nothing here ever maps anything at an address that has been mapped before.  Round 5's in-place re-mapping (hipMemUnmap + hipMemMap under a live array, the
 // placement search on top of it) is gone from the library: on ROCm 7.2 the shaders keep the OLD translation of a re-mapped address until some unrelated driver
@@ -34,7 +35,7 @@ struct jrx_field_pool {
     struct Alloc { size_t bytes = 0, mapped = 0, chunk = 0; int kind = 0; std::vector<hipMemGenericAllocationHandle_t> chunks; };
     std::map<void *, Alloc> live;
     std::map<size_t, std::vector<hipMemGenericAllocationHandle_t>> spare;      // created, unmapped chunks by their size: the pool
-    std::set<size_t> pooled;                      // chunk sizes whose pool has been filled (their freed chunks stay until jrx_field_trim)
+    std::set<size_t> pooled;                      // chunk sizes that have (had) a pool: their freed chunks stay in `spare` until jrx_field_trim
     std::vector<std::pair<void *, size_t>> retired;   // virtual ranges of freed arrays: never used again
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     double create_ms = 0, map_ms = 0;
@@ -61,7 +62,6 @@ void release_spare(jrx_field_pool *P)
     for (auto &kv : P->spare)
         for (auto hd : kv.second) (void)hipMemRelease(hd);
     P->spare.clear();
-    P->pooled.clear();
 }
 
 hipMemAllocationProp device_prop(const jrx_handle *h)
@@ -85,14 +85,19 @@ jrx_status alloc_chunks(jrx_handle *h, jrx_field_pool *P, size_t bytes, void **o
     const size_t nch = (bytes + chunk - 1) / chunk;
     auto &sp = P->spare[chunk];
     const auto t0 = Clock::now();
-    // the pool: once per chunk size, chunks for "field_pool_pct" % of what is free now (less a headroom)
+    // the pool: when no array of this chunk size is live (the first array of a run), chunks for "field_pool_pct" % of what is free now (less a headroom)
     size_t want = sp.size() < nch ? nch - sp.size() : 0;
-    if (h->field_chunk_mib > 0 && chunk >= kPoolChunkMin && h->field_pool_pct > 0 && !P->pooled.count(chunk)) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > kHeadroom) {
-            const size_t pct = (size_t)std::min(h->field_pool_pct, 90);
-            want = std::max(want, (free_b - kHeadroom) / 100 * pct / chunk);
-        } else (void)hipGetLastError();
+    if (h->field_chunk_mib > 0 && chunk >= kPoolChunkMin && h->field_pool_pct > 0) {
+        bool any_live = false;
+        for (auto &kv : P->live) if (kv.second.kind == 1 && kv.second.chunk == chunk) { any_live = true; break; }
+        if (!any_live) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > kHeadroom) {
+                const size_t pct = (size_t)std::min(h->field_pool_pct, 90);
+                const size_t pool = (free_b - kHeadroom) / 100 * pct / chunk;
+                if (pool > sp.size()) want = std::max(want, pool - sp.size());
+            } else (void)hipGetLastError();
+        }
         P->pooled.insert(chunk);
     }
     for (size_t c = 0; c < want; c++) {

@@ -111,9 +111,16 @@ def test_pool_placement_maps_every_array_once_at_a_range_never_used_before(jr):
         assert _stats(h)[3] == 0
         for u, a in zip(ts, ref):                                  # the arrays in use are untouched by the trim
             assert np.array_equal(u.cpu().numpy(), a)
-        del ts, t, u
+        # an array made behind the trim, while arrays of the run are live, gets chunks created on the spot -- no second pool (a solve! behind the trim must not spend seconds,
+        # and most of the memory, on one)
+        created = _stats(h)[2]
+        late = jr.fzeros(shapes[0], "cuda", fill=7.0)
+        assert _stats(h)[2] == created + 1 and _stats(h)[3] == 0 and float(late.min()) == float(late.max()) == 7.0
+        del ts, t, u, late
         torch.cuda.synchronize()
-        assert _stats(h)[0] == 0 and _stats(h)[3] == 0             # the pool is over: freed chunks went back to the driver
+        assert _stats(h)[0] == 0 and _stats(h)[3] == 6             # the freed chunks wait for the next run ...
+        h.call("jrx_field_trim")
+        assert _stats(h)[3] == 0                                   # ... or for the trim
     finally:
         arrays.use_library_arrays(None)
         h.close()
