@@ -57,7 +57,7 @@
  *   "scratch_poison" (0)         test switch, bit mask: arrays the library allocates are filled with NaNs first (what they hold before their first use must not matter): 1 = the second state sets,
  *                                 2 = the library-owned ητ, 4 = the arrays of jrx_field_alloc
  *   "fused_ym" (0)               one-launch viscous-limit kernel, 64 x 8 tile: 2 / 4 = a block marches that many tile rows in y and hands the halo row on in LDS (round 6; bit-identical, measured
- *                                 4 - 8 % slower at 512^3 and fetching more, not less: the XCD-banded tile order already serves the halo row from L2 -- profiles/r06_y_halo.txt); 0 = one tile per block.
+ *                                 4 - 8 % slower at 512^3 and fetching more, not less: the march loses the L2 sharing between concurrent y neighbours -- profiles/r06_y_halo.txt); 0 = one tile per block.
  *                                 "stat_fused3d_ym" (read-only) counts its launches.  "fused_tile" = 4: a 64 x 16 tile, one 16-wave block per CU (6 % fewer bytes fetched, 8 % slower)
  *   "fused_kz" (0)               chunk depth of the 64 x 8 tile of k_fused3d: 0 = 12 planes from nz = 384 on, 8 below (scripts/kbench_kz.hip); 8 / 12 force a depth
  *   "field_pool_pct" (70)         "field_placement" = 1 with chunks of >= 128 MiB: the first allocation of a chunk size creates chunks for this share of the free memory (less 6 GiB), and every

@@ -768,7 +768,7 @@ static jrx_status launch_fused_t(jrx_handle *h, hipStream_t s, const SweepArgs &
         else { JRX_LAUNCH_CHECK(h); return JRX_OK; }       // counted once per iteration, with the second class
     } else if (visc && fold && vf && TX == 64 && TY == 8 && h->fused_ym > 1) {
         // the y march (k_fused3d, YM; tuning switch "fused_ym" = 2 / 4, round 6): a block marches that many tile rows, the y halo row is computed once per march.  Bit-identical,
-        // and SLOWER: 4.96 - 5.00 ms (2 rows) / 5.12 - 5.16 ms (4) against 4.74 - 4.79 ms at 512^3 -- the XCD-banded tile order already serves the halo row from L2, and the march
+        // and SLOWER: 4.96 - 5.00 ms (2 rows) / 5.12 - 5.16 ms (4) against 4.74 - 4.79 ms at 512^3 -- under the XCD-banded tile order y neighbours share part of their halo rows in L2; the march gives that up and
         // fetches more through the fabric, not less (17.16 -> 18.15 / 18.60 GB per launch, PMC): profiles/r06_y_halo.txt.  Off.
         const int ym = h->fused_ym >= 3 ? 4 : 2;
         const unsigned nblk = (unsigned)(ntx * ((nty + ym - 1) / ym) * ntz);
