@@ -49,6 +49,8 @@
  *                                 second set of τxx, τyy, τzz, adopted by pointer swap); measured equal to one pass after the other: off
  *   "vep_store_all" (0)           VEP loops (2D and 3D): 1 = every iteration stores ∇V, RP, ε_pl, ε_vol_pl, τII, η_vep (default: only iterations whose results can be observed)
  *   "thermal_cfg", "thermal_xg"   fused 3D heat-diffusion tile shape / XCD band
+ *   "thermal_tile" (0), "thermal_nt" (0)   round 6 A/Bs of the fused 3D heat-diffusion iteration: 4 / 8 = 64 x TY tiles whose rows exchange (T, K, θ) and the y flux through LDS (bit-identical, 9 - 16 %
+ *                                 slower); 1 = non-temporal stores of the new (T, qT) set (neutral) -- profiles/r06_thermal3d_tile.txt
  *   "halo_self_rccl" (0)          test hook: a rank that is its own periodic neighbour routes its planes through ncclSend/ncclRecv
  *   "comm_timeout_ms" (120000)    in-process and ipc transports (jrx_comm_init_local / _ipc): how long a rank waits for a neighbour (host waits and the device-side flag waits)
  *   "chain_profile" (0)           jrx_stokes3d_iterate_timed on a multi-rank handle also records events around the stages of every sampled fused step; read with

@@ -78,6 +78,7 @@ struct jrx_handle {
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)
     bool halo_self_rccl = false;         // test hook: a rank that is its own periodic neighbour routes the planes through ncclSend/ncclRecv
     int thermal_cfg = 0, thermal_xg = 8; // fused 3D heat-diffusion tile shape / XCD band override (tuning)
+    bool thermal_nt = false;             // tuning (round 6): fused 3D heat-diffusion kernels store the new (T, qT) set with non-temporal stores
     int thermal_tile = 0;                // tuning (round 6): fused 3D heat diffusion, array / rheology form: 4 / 8 = 64 x TY tiles with the rows j +- 1 through LDS (k_thermal3d_fused_t)
     bool fused2d = true;                 // 2D visco-elastic loop: one-launch iterations on launch-bound grids
     bool vep3_peel = true;                   // z-marching edge kernel: a nearly empty last lane segment goes to the node kernel (A/B)

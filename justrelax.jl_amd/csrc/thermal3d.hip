@@ -17,7 +17,10 @@ struct T3Args {
     jrx_thermal3d_fields t;
     jrx_thermal3d_params p;
     bool wpt = false;      // phase-ratio form: update_T! also writes next iteration's θr_dτ, dτ_ρ (update_pt_thermal_arrays! folded in)
+    bool nt = false;       // fused one-launch kernels: non-temporal stores of the new (T, qT) set (nobody reads it before the next launch); tuning switch "thermal_nt"
 };
+// store of the fused kernels' outputs: streaming (non-temporal) when a.nt
+#define TST(a_, lhs_, val_) do { double *q_ = &(lhs_); const double v_ = (val_); if ((a_).nt) __builtin_nontemporal_store(v_, q_); else *q_ = v_; } while (0)
 
 __device__ __forceinline__ double rhoCp3_of(const jrx_thermal3d_params &p, const double *rhoCp, i64 c, double T)
 {
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TS
             const i64 cl = kb > 0 ? c - sC2 : c;
             qz_lo[r] = relax(a.t.qTz[c], rf ? 0.0 : Kk[cl], Kc_[r], th[cl], tc[r], Tc[r], T[I1 - sT2], _dz);
         }
-        if (kb == 0 && cell && rok[r]) dst.qz[c] = qz_lo[r];        // face 0 has no chunk below that would own it
+        if (kb == 0 && cell && rok[r]) TST(a, dst.qz[c], qz_lo[r]);        // face 0 has no chunk below that would own it
     }
     const int jlo = max(j0 - 1, 0);                                   // clamped row of the K / θ average on the lowest y face
     for (int k = kb; k < kend; ++k) {
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TS
             const i64 q0 = ic + (i64)nx * (j0 + (i64)(ny + 1) * k);
             if (j0 == 0 && cfyf) qy[0] = a.p.constant_flux[YF];
             else qy[0] = relax(a.t.qTy[q0], rf ? 0.0 : Kk[cl], Kc_[0], th[cl], tc[0], Tc[0], T[(ic + 1) + sT1 * j0 + sT2 * (k + 1)], _dy);
-            if (cell) dst.qy[q0] = qy[0];
+            if (cell) TST(a, dst.qy[q0], qy[0]);
 #pragma unroll
             for (int f = 1; f <= R; f++) {
                 const int jf = j0 + f;                                // face index; exists while jf <= ny
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TS
                     const i64 cu = ic + (i64)nx * ju + sC2 * k;
                     qy[f] = relax(a.t.qTy[q], Kc_[f - 1], rf ? 0.0 : Kk[cu], tc[f - 1], th[cu], T[(ic + 1) + sT1 * (jf + 1) + sT2 * (k + 1)], Tc[f - 1], _dy);
                 }
-                if (cell && ((f < R && rok[f]) || jf == ny)) dst.qy[q] = qy[f];
+                if (cell && ((f < R && rok[f]) || jf == ny)) TST(a, dst.qy[q], qy[f]);
             }
         }
 #pragma unroll
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TS
                     const i64 cl = c - (ic - im);
                     qx_lo = relax(a.t.qTx[q], rf ? 0.0 : Kk[cl], Kc_[r], th[cl], tc[r], Tc[r], T[I1 - 1], _dx);
                 }
-                if (cell) dst.qx[q] = qx_lo;
+                if (cell) TST(a, dst.qx[q], qx_lo);
             }
             double qx_hi = __shfl_down(qx_lo, 1, 64);
             if (edge) {
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TS
                     const i64 cr = c + (ip - ic);
                     qx_hi = relax(a.t.qTx[q], Kc_[r], rf ? 0.0 : Kk[cr], tc[r], th[cr], T[I1 + 1], Tc[r], _dx);
                 }
-                if (cell && ic + 1 == nx) dst.qx[q] = qx_hi;           // the domain's right face belongs to no cell's low face
+                if (cell && ic + 1 == nx) TST(a, dst.qx[q], qx_hi);           // the domain's right face belongs to no cell's low face
             }
             // ---- z: high face k+1 (owned here), becomes the low face of the next plane
             double qz_hi, Kn_ = 0.0;
@@ -407,13 +410,13 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused(const T3Args a, const TS
             if (!rf) Kn_ = Kk[cr];
             if (k + 1 == nz && cfzt) qz_hi = a.p.constant_flux[ZT];
             else qz_hi = relax(a.t.qTz[c + sC2], Kc_[r], Kn_, tc[r], tn, Tn_c, Tc[r], _dz);
-            if (cell) dst.qz[c + sC2] = qz_hi;
+            if (cell) TST(a, dst.qz[c + sC2], qz_hi);
             if (cell) {
                 const double rcp = rhoCp3_of(a.p, a.t.rhoCp, c, Tc[r]);
                 const double divq = (qx_hi - qx_lo) * _dx + (qy[r + 1] - qy[r]) * _dy + (qz_hi - qz_lo[r]) * _dz;
                 const double dr = a.t.dtau_rho[c];
                 const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc[r]) / (1.0 + dr * rcp * _dt);
-                dst.T[I1] = Tn;
+                TST(a, dst.T[I1], Tn);
                 const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
                 const int mask = ((i == 0 || i == nx - 1) ? 1 : 0) | ((j == 0 || j == ny - 1) ? 2 : 0) | ((k == 0 || k == nz - 1) ? 4 : 0);
                 if (mask) {
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(64 * TY) void k_thermal3d_fused_t(const T3Args a, c
             const i64 cl = kb > 0 ? c - sC2 : c;
             qz_lo = relax(a.t.qTz[c], rf ? 0.0 : Kk[cl], Kc_, th[cl], tc, Tc, T[I1 - sT2], _dz);
         }
-        if (kb == 0 && cell) dst.qz[c] = qz_lo;
+        if (kb == 0 && cell) TST(a, dst.qz[c], qz_lo);
     }
     const int jlo = max(j - 1, 0);
     const bool below = ty > 0;                                       // the row below is a row of this tile
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(64 * TY) void k_thermal3d_fused_t(const T3Args a, c
                 const i64 cl = ic + (i64)nx * jlo + sC2 * k;
                 qy_lo = relax(a.t.qTy[q0], rf ? 0.0 : Kk[cl], Kc_, th[cl], tc, Tc, T[(ic + 1) + sT1 * j + sT2 * (k + 1)], _dy);
             }
-            if (cell) dst.qy[q0] = qy_lo;
+            if (cell) TST(a, dst.qy[q0], qy_lo);
         }
         sQ[ty][lane] = qy_lo;
         __syncthreads();
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(64 * TY) void k_thermal3d_fused_t(const T3Args a, c
                     const i64 cu = ic + (i64)nx * ju + sC2 * k;
                     qy_hi = relax(a.t.qTy[q], Kc_, rf ? 0.0 : Kk[cu], tc, th[cu], T[(ic + 1) + sT1 * (jf + 1) + sT2 * (k + 1)], Tc, _dy);
                 }
-                if (cell && jf == ny) dst.qy[q] = qy_hi;
+                if (cell && jf == ny) TST(a, dst.qy[q], qy_hi);
             }
             // ---- x: low face i (own), high face i+1 from the next lane
             double qx_lo;
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(64 * TY) void k_thermal3d_fused_t(const T3Args a, c
                     const i64 cl = c - (ic - im);
                     qx_lo = relax(a.t.qTx[q], rf ? 0.0 : Kk[cl], Kc_, th[cl], tc, Tc, T[I1 - 1], _dx);
                 }
-                if (cell) dst.qx[q] = qx_lo;
+                if (cell) TST(a, dst.qx[q], qx_lo);
             }
             double qx_hi = __shfl_down(qx_lo, 1, 64);
             if (edge) {
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(64 * TY) void k_thermal3d_fused_t(const T3Args a, c
                     const i64 cr = c + (ip - ic);
                     qx_hi = relax(a.t.qTx[q], Kc_, rf ? 0.0 : Kk[cr], tc, th[cr], T[I1 + 1], Tc, _dx);
                 }
-                if (cell && ic + 1 == nx) dst.qx[q] = qx_hi;
+                if (cell && ic + 1 == nx) TST(a, dst.qx[q], qx_hi);
             }
             // ---- z: high face k+1 (owned here), becomes the low face of the next plane
             double qz_hi, Kn_ = 0.0;
@@ -545,13 +548,13 @@ __global__ __launch_bounds__(64 * TY) void k_thermal3d_fused_t(const T3Args a, c
             if (!rf) Kn_ = Kk[cr];
             if (k + 1 == nz && cfzt) qz_hi = a.p.constant_flux[ZT];
             else qz_hi = relax(a.t.qTz[c + sC2], Kc_, Kn_, tc, tn, Tn_c, Tc, _dz);
-            if (cell) dst.qz[c + sC2] = qz_hi;
+            if (cell) TST(a, dst.qz[c + sC2], qz_hi);
             if (cell) {
                 const double rcp = rhoCp3_of(a.p, a.t.rhoCp, c, Tc);
                 const double divq = (qx_hi - qx_lo) * _dx + (qy_hi - qy_lo) * _dy + (qz_hi - qz_lo) * _dz;
                 const double dr = a.t.dtau_rho[c];
                 const double Tn = (dr * (-divq + a.t.Told[I1] * rcp * _dt + a.t.H[c] + a.t.shear_heating[c]) + Tc) / (1.0 + dr * rcp * _dt);
-                dst.T[I1] = Tn;
+                TST(a, dst.T[I1], Tn);
                 const int side[3] = {i == nx - 1, j == ny - 1, k == nz - 1};
                 const int mask = ((i == 0 || i == nx - 1) ? 1 : 0) | ((j == 0 || j == ny - 1) ? 2 : 0) | ((k == 0 || k == nz - 1) ? 4 : 0);
                 if (mask) {
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused_ph(const T3Args a, const
             const i64 cl = kb > 0 ? c - sC2 : c;
             qz_lo = relax(a.t.qTz[c], cond(ld(ph.f.phase_qz, cl)), cz, th[cl], tc, Tc, T[I1 - sT2], _dz);
         }
-        if (kb == 0 && cell) dst.qz[c] = qz_lo;
+        if (kb == 0 && cell) TST(a, dst.qz[c], qz_lo);
     }
     for (int k = kb; k < kend; ++k) {
         const i64 c = ic + (i64)nx * j + sC2 * k, I1 = (ic + 1) + sT1 * (j + 1) + sT2 * (k + 1);
@@ -653,35 +656,35 @@ __global__ __launch_bounds__(TX) void k_thermal3d_fused_ph(const T3Args a, const
             const double cy0 = cond(ry0);
             if (j == 0 && cfyf) qy_lo = a.p.constant_flux[YF];
             else qy_lo = relax(qoy0, cond(ryl), cy0, thl, tc, Tc, Tyl, _dy);
-            if (cell) dst.qy[q0] = qy_lo;
+            if (cell) TST(a, dst.qy[q0], qy_lo);
             if (j + 1 == ny && cfyb) qy_hi = a.p.constant_flux[YB];
             else qy_hi = relax(qoy1, cy0, cond(ryu), tc, thu, Tyu, Tc, _dy);
-            if (cell && j + 1 == ny) dst.qy[q1] = qy_hi;                              // the back face belongs to no cell's low face
+            if (cell && j + 1 == ny) TST(a, dst.qy[q1], qy_hi);                              // the back face belongs to no cell's low face
         }
         // ---- x: low face i (own), high face i + 1 from the next lane
         const double cx0 = cond(rx0);
         double qx_lo;
         if (ic == 0 && cfxl) qx_lo = a.p.constant_flux[XL];
         else qx_lo = relax(qox, cond(rxl), cx0, thx, tc, Tc, Txl, _dx);
-        if (cell) dst.qx[qx] = qx_lo;
+        if (cell) TST(a, dst.qx[qx], qx_lo);
         double qx_hi = __shfl_down(qx_lo, 1, 64);
         if (edge) {
             if (ic + 1 == nx && cfxr) qx_hi = a.p.constant_flux[XR];
             else qx_hi = relax(qoxe, cx0, cond(rxe), tc, thxe, Txe, Tc, _dx);
-            if (cell && ic + 1 == nx) dst.qx[qxe] = qx_hi;
+            if (cell && ic + 1 == nx) TST(a, dst.qx[qxe], qx_hi);
         }
         // ---- z: high face k + 1 (owned here), becomes the low face of the next plane
         double qz_hi;
         const double czn = cond(rzn);
         if (k + 1 == nz && cfzt) qz_hi = a.p.constant_flux[ZT];
         else qz_hi = relax(qoz, cz, czn, tc, tn, Tn_c, Tc, _dz);
-        if (cell) dst.qz[c + sC2] = qz_hi;
+        if (cell) TST(a, dst.qz[c + sC2], qz_hi);
         if (cell) {
             const double rcp = tph_rhoCp<NPH>(ph.m, rcc.v, Tc, Pc);
             const double Hr = tph_Hr<NPH>(ph.m, rcc.v);
             const double divq = (qx_hi - qx_lo) * _dx + (qy_hi - qy_lo) * _dy + (qz_hi - qz_lo) * _dz;
             const double Tn = (dr * (-divq + Told * rcp * _dt + Hr + Hc + shc) + Tc) / (1.0 + dr * rcp * _dt);
-            dst.T[I1] = Tn;
+            TST(a, dst.T[I1], Tn);
             double th_, dr_;      // update_pt_thermal_arrays! of the next iteration
             tph_pt_coeffs<NPH>(ph.m, rcc.v, Tn, Pc, _dt, th_, dr_);
             dst.th[c] = th_;
@@ -861,6 +864,7 @@ jrx_status heat3d(jrx_handle *h, const jrx_thermal3d_fields *t, const jrx_therma
     bool pt_fresh = false;
     T3Args a;
     a.t = *t; a.p = *p;
+    a.nt = h->thermal_nt;
     // Iterations nobody observes run as one fused launch that ping-pongs (T, qT) between the caller's arrays and a library-owned set
     // (option "thermal_fused" = 0: always the two kernels); observed ones (check / last) run the two kernels in place on the current set.
     bool any_periodic = false;
