@@ -58,6 +58,8 @@
  *   "field_shuffle" (1)          "field_placement" = 1: 0 = chunks dealt in creation order (A/B of the random dealing)
  *   "scratch_poison" (0)         test switch, bit mask: arrays the library allocates are filled with NaNs first (what they hold before their first use must not matter): 1 = the second state sets,
  *                                 2 = the library-owned ητ, 4 = the arrays of jrx_field_alloc
+ *   "nbr_feeder" (1)             in-kernel neighbour faces ("fused_overlap" = 3), low x face: the idle feeder lane of the face's tiles holds the received plane as "column -1" (round 6: -2 % on
+ *                                 the coupled kernel, profiles/r06_low_face_feeder.txt); 0 = column 0 loads those entries itself behind the barrier (A/B)
  *   "fused_ym" (0)               one-launch viscous-limit kernel, 64 x 8 tile: 2 / 4 = a block marches that many tile rows in y and hands the halo row on in LDS (round 6; bit-identical, measured
  *                                 4 - 8 % slower at 512^3 and fetching more, not less: the march loses the L2 sharing between concurrent y neighbours -- profiles/r06_y_halo.txt); 0 = one tile per block.
  *                                 "stat_fused3d_ym" (read-only) counts its launches.  "fused_tile" = 4: a 64 x 16 tile, one 16-wave block per CU (6 % fewer bytes fetched, 8 % slower)

@@ -126,7 +126,7 @@ int find_opt(jrx_handle *h, const char *key, bool tuning, OptRef *out)
         {"halo_self_rccl", 0, &h->halo_self_rccl}, {"thermal_cfg", 1, &h->thermal_cfg}, {"thermal_xg", 1, &h->thermal_xg}, {"thermal_tile", 1, &h->thermal_tile}, {"thermal_nt", 0, &h->thermal_nt},
         {"fused2d", 0, &h->fused2d}, {"vep3_edges", 1, &h->vep3_edges}, {"vep3_cfg", 1, &h->vep3_cfg}, {"vep3_peel", 0, &h->vep3_peel}, {"vep3_peel_fork", 0, &h->vep3_peel_fork}, {"vep3_nt", 0, &h->vep3_nt}, {"vep3_prekz", 1, &h->vep3_prekz},
         {"vep3_hide_comm", 1, &h->vep3_hide_comm}, {"vep3_fork", 0, &h->vep3_fork}, {"vep3_fuse_pc", 0, &h->vep3_fuse_pc}, {"vep3_np_const", 0, &h->vep3_np_const}, {"vep3_prec_tile", 1, &h->vep3_prec_tile}, {"thermal_np_const", 0, &h->thermal_np_const}, {"thermal_fused_ph", 0, &h->thermal_fused_ph}, {"fused2d_batch", 0, &h->fused2d_batch}, {"fused2d_max_nodes", 1, &h->fused2d_max_nodes}, {"vep3_map", 0, &h->vep3_map}, {"vep3_xcd", 0, &h->vep3_xcd}, {"comm_timeout_ms", 1, &h->comm_timeout_ms}, {"vep_store_all", 0, &h->vep_store_all}, {"chain_profile", 0, &h->chain_profile},
-        {"general_hif", 1, &h->general_hif}, {"field_shuffle", 0, &h->field_shuffle}, {"field_pool_pct", 1, &h->field_pool_pct}, {"fused_kz", 1, &h->fused_kz}, {"fused_ym", 1, &h->fused_ym}, {"stat_fused3d_ym", 2, &h->stat_fused3d_ym}, {"scratch_poison", 1, &h->scratch_poison},
+        {"general_hif", 1, &h->general_hif}, {"field_shuffle", 0, &h->field_shuffle}, {"field_pool_pct", 1, &h->field_pool_pct}, {"fused_kz", 1, &h->fused_kz}, {"fused_ym", 1, &h->fused_ym}, {"nbr_feeder", 0, &h->nbr_feeder}, {"stat_fused3d_ym", 2, &h->stat_fused3d_ym}, {"scratch_poison", 1, &h->scratch_poison},
     };
     if (tuning) {
         for (const OptRef &o : tun)

@@ -73,6 +73,7 @@ struct jrx_handle {
     int general_hif = 0;                 // general (any dt) fused kernel, 64 x 4 tile: the high-face node layers inside the kernel and, with neighbours, the in-kernel faces: 4 / 3 = built for that many
                                          // waves per SIMD, 0 = the boundary-layer launch behind the kernel and the early exchange (the pipeline of rounds 1-4, default: measured faster)
     int64_t stat_fused3d_general_hif = 0;
+    bool nbr_feeder = true;              // tuning (round 6): in-kernel neighbour faces, low x face: the idle feeder lane holds the received plane (k_fused3d, feedL); 0 = column 0 loads it itself behind the barrier
     int fused_ym = 0;                    // tuning (round 6): one-launch viscous-limit kernel, 64 x 8 tile: a block marches this many tile rows in y (0 / 1: one tile per block)
     int64_t stat_fused3d_ym = 0;         // launches of the y-marching form
     int b_width_opt[3] = {0, 0, 0};      // > 0 overrides jrx_stokes3d_params.b_width (tuning; the split does not change results)

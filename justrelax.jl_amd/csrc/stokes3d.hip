@@ -917,6 +917,7 @@ static jrx_status iter_step(Iter3D &I, bool diag, bool fuse_next, hipEvent_t *te
         bc.nsR = !!(ns & JRX_FACE_RIGHT); bc.nsBk = !!(ns & JRX_FACE_BACK); bc.nsK1 = !!(ns & JRX_FACE_TOP);
         bc.fsR = !!(fs & JRX_FACE_RIGHT); bc.fsBk = !!(fs & JRX_FACE_BACK); bc.fsK1 = !!(fs & JRX_FACE_BOT);       // k = end: free_slip `bot`
         bc.nbL = bc.nbR = bc.nbF = bc.nbBk = bc.nbK0 = bc.nbK1 = 0;
+        bc.feed = h->nbr_feeder ? 1 : 0;
         // 256 threads per tile, 8 planes per chunk (128 VGPRs -> 4 blocks/CU)
         int nt[3];
         const FusedShape S = fused_shape(h, a.L, a.dt);

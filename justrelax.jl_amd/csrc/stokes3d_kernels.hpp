@@ -659,6 +659,7 @@ struct FusedBC {
     int fsL, nsL, fsF, nsF, fsK0, nsK0, nsR, nsBk, nsK1, fsR, fsBk, fsK1;
     // NBR: faces with a neighbour (their fs / ns flags are cleared): the planes of the DESTINATION set there hold received velocities
     int nbL, nbR, nbF, nbBk, nbK0, nbK1;
+    int feed;      // NBR: the idle feeder lane of the tiles on a low x face with a neighbour holds the received plane (tuning switch "nbr_feeder", default 1)
 };
 // NBR: the tiles of a block as a list of disjoint boxes of tiles, launched in two classes.  Box 0 = tiles that touch no face with a neighbour (a first share of them: enough work
 // to cover update_halo!(V), which runs beside it); boxes 1.. = everything else -- the rest of the block in its natural XCD-banded order, shell tiles included, plus the shell
@@ -770,6 +771,11 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     const int kend = min(kb + KZ, nz);
     const bool bvalid = tx >= OVX - 1 && i >= 0 && j >= 0 && i < nx && j < ny;
     const bool avalid = bvalid && tx >= OVX && ty >= 1 && (!SHFL || tx < TX - 1);
+    // NBR, a tile on the low x face of a block with a neighbour there: lane 0 sits on column i = -1 and is idle otherwise -- it holds the RECEIVED plane (Vx[0], the ghost columns
+    // Vy[0], Vz[0] of the new set) as "the velocities of column -1": loaded with the other operands of the plane, published to sV like any lane's, read by the lane of column 0
+    // through the generic i - 1 path.  (Round 6: before, column 0 fetched those entries itself behind the second barrier -- four dependent single-lane loads in the stress phase
+    // of every plane: the rank with a low x neighbour ran its kernel 6 % slower than the rank with a high one, profiles/r06_low_face_feeder.txt.)
+    const bool feedL = NBR && SHFL && OVX == 1 && YLDS && !LOWREG && bc.feed && bc.nbL && tx == 0 && i == -1 && j >= 0 && j < ny;
     const bool hx = i < nx - 1, hy = j < ny - 1;
     const double _dx = a._dx, _dy = a._dy, _dz = a._dz, dt = a.dt, th = a.theta_dtau, _dt = 1.0 / dt, rr = a.r, edt = a.eta_dtau;
     // VFOLD: what the viscous-limit arithmetic reduces to for FINITE η (the driver's operand check guarantees it), bit for bit:
@@ -787,7 +793,7 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
     const u32 sxy = (u32)L.xyp * 8u, sxz = (u32)L.xzp * 8u, syz = (u32)L.yzp * 8u;
     const u32 rc = (u32)nx * 8u, rxy = (u32)L.xy1 * 8u, ryz = (u32)L.yz1 * 8u;
     const u32 rvx = (u32)L.vx1 * 8u, rvy = (u32)L.vy1 * 8u, rvz = (u32)L.vz1 * 8u;
-    const int ic = bvalid ? i : 0, jc = bvalid ? j : 0;          // keep addresses in range for idle threads
+    const int ic = bvalid ? i : (feedL ? -1 : 0), jc = (bvalid || feedL) ? j : 0;          // keep addresses in range for idle threads (a feeder lane only uses ovx / ovy / ovz: column ic + 1 = 0)
     const int kfirst = kb > 0 ? kb - 1 : 0;
     u32 oc = 8u * (u32)(ic + nx * jc) + sc * (u32)kfirst;
     u32 oxy = 8u * (u32)(ic + L.xy1 * jc) + sxy * (u32)kfirst;
@@ -863,6 +869,8 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             // entry of sT again behind it)
             vxn = sT[k - kfirst][0][tx]; vyn = sT[k - kfirst][1][tx]; vzn = sT[k - kfirst][2][tx];
             sY[6][ty][tx] = e;
+        } else if (NBR && feedL) {
+            vx = LDC(a.o.Vx, ovx); vy = LDC(a.o.Vy, ovy); vz = LDC(a.o.Vz, ovz);
         } else if (bvalid) {
             const u32 dz1 = hz ? sc : 0u;
             if (YLDS) {
@@ -905,6 +913,9 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
         if (YLDS) __syncthreads();
         if (fed) {
             sV[slot][0][ty][tx] = vxn; sV[slot][1][ty][tx] = vyn; sV[slot][2][ty][tx] = vzn;
+        } else if (NBR && feedL) {
+            // (Vz on the normal plane k + 1 = nz of a physical no-slip face is zero by rule -- flow_bcs! is not applied in memory in this pipeline, NBVZ)
+            sV[slot][0][ty][tx] = vx; sV[slot][1][ty][tx] = vy; sV[slot][2][ty][tx] = (!hz && bc.nsK1) ? 0.0 : vz;
         } else if (bvalid) {
             if (YLDS) {
                 if (yrow) {
@@ -979,13 +990,14 @@ __global__ __launch_bounds__(TX *TY, MINW) void k_fused3d(const SweepArgs a, con
             double va, vay, vb, vbx, vcx, vcy;
             const double vax = vxn, vby = vyn, vc = vzn;
             const u32 gvx = ovx - 8u, gvy = ovy - rvy, gvz = ovz;       // Vx[i,j+1,k+1], Vy[i+1,j,k+1], Vz[i+1,j+1,k+1]
-            va = i > 0 ? sV[slot][0][ty][tx - 1] : (bc.nsL ? 0.0 : NBV(nbL, Vx, gvx));
-            if (j > 0) vay = i > 0 ? sV[slot][0][ty - 1][tx - 1] : (bc.nsL ? 0.0 : NBV(nbL, Vx, gvx - rvx));
+            const bool lx = NBR && SHFL && OVX == 1 && YLDS && !LOWREG && bc.feed && bc.nbL && i == 0;     // column 0 next to a received plane: the lane to its left is the feeder lane (feedL)
+            va = (i > 0 || lx) ? sV[slot][0][ty][tx - 1] : (bc.nsL ? 0.0 : NBV(nbL, Vx, gvx));
+            if (j > 0) vay = (i > 0 || lx) ? sV[slot][0][ty - 1][tx - 1] : (bc.nsL ? 0.0 : NBV(nbL, Vx, gvx - rvx));
             else vay = bc.fsF ? va : (bc.nsF ? -va : NBVX(nbF, gvx - rvx, i));
             vb = j > 0 ? sV[slot][1][ty - 1][tx] : (bc.nsF ? 0.0 : NBV(nbF, Vy, gvy));
             if (i > 0) vbx = j > 0 ? sV[slot][1][ty - 1][tx - 1] : (bc.nsF ? 0.0 : NBV(nbF, Vy, gvy - 8u));
-            else vbx = bc.fsL ? vb : (bc.nsL ? -vb : NBVY(nbL, gvy - 8u, j));
-            vcx = i > 0 ? sV[slot][2][ty][tx - 1] : (bc.fsL ? vc : (bc.nsL ? -vc : NBVZ(nbL, gvz - 8u, k + 1)));
+            else vbx = (lx && j > 0) ? sV[slot][1][ty - 1][tx - 1] : (bc.fsL ? vb : (bc.nsL ? -vb : NBVY(nbL, gvy - 8u, j)));
+            vcx = (i > 0 || lx) ? sV[slot][2][ty][tx - 1] : (bc.fsL ? vc : (bc.nsL ? -vc : NBVZ(nbL, gvz - 8u, k + 1)));
             vcy = j > 0 ? sV[slot][2][ty - 1][tx] : (bc.fsF ? vc : (bc.nsF ? -vc : NBVZ(nbF, gvz - rvz, k + 1)));
             if (LOWREG && k > 0 && live) {
                 const int ps = (k + 2) % 3;       // slot of plane k-1
