@@ -66,7 +66,7 @@ const char *jrx_build_id(void);
 /* ------------------------------------------------------------------ state arrays
  * Device memory for the fields, handed out by the library.  Replaces the array constructor the backend owns in the reference:
  * StokesArrays(::Type{AMDGPUBackend}, ni) / ThermalArrays(...) -> @zeros(ni...) -> ROCArray (src/ext/AMDGPU/3D.jl:46-48,
- * src/types/constructors/stokes.jl:279-303) -- a binding wraps the pointer (Julia: unsafe_wrap(ROCArray, ptr, dims; own = false) plus a
+ * src/types/constructors/stokes.jl:279-303) -- a binding wraps the pointer (Julia: unsafe_wrap(ROCArray, ptr, dims; lock = false) plus a
  * finalizer that calls jrx_field_free).  Contents are NOT initialised (the constructor fills with zeros as @zeros does).  Using it is
  * optional: every entry point takes any device pointer.  What it buys: the option "field_placement" decides how the arrays are backed
  * physically, and the large 3D kernels are sensitive to that (the same launch takes 4.7 .. 6.9 ms at 512^3: DESIGN.md section 3, profiles/r05_placement_search.txt).  With
