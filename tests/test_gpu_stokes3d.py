@@ -402,6 +402,41 @@ def test_body_forces_that_are_zero_are_not_loaded_and_the_bits_stay(env, ni, bcs
                 assert np.isfinite(a).all() and np.array_equal(a, b), (v, k)
 
 
+@pytest.mark.parametrize("name,where,val", [("P0", "first", np.nan), ("P0", "last", np.inf), ("toxy", "last", np.nan), ("toyz", "first", np.inf), ("G", "last", 0.0), ("eta", "last", np.inf),
+                                            ("fz", "last", 1e-300), ("fx", "first", -0.0)])
+def test_operand_pass_sees_the_first_and_the_last_entry_of_every_array(env, name, where, val):
+    """round 6: the operand pass streams every array on its own in 16-byte pairs; the entries outside the pairs -- the last one of an array of odd length (65 x 9 x 9 = 5,265
+    cells, 66 x 9 x 10 nodes ...) -- and the very first one are looked at all the same: a poisoned one sends the call to the general kernels, a body-force entry that is not
+    +0.0 keeps the loads"""
+    jr = env["jr"]
+    from justrelax_jl_amd import _lib
+    s = jr.miniapps.random_fields3d((65, 9, 9), bcs="free_slip", dt=np.inf, iterMax=9, nout=4)
+    s.pt.ϵ_rel = s.pt.ϵ_abs = 1e-30
+    for c in "xyz":
+        s.arrays["f" + c][...] = 0.0
+    flat = s.arrays[name].reshape(-1, order="F")
+    assert flat.base is s.arrays[name] or flat.base is s.arrays[name].base
+    flat[0 if where == "first" else -1] = val
+    h = _lib.default_handle()
+    try:
+        h.set_option("kernel_variant", 3)
+        stokes, ρg, K, G = env["up"](s, jr.AMDGPUBackend)
+        keys = ("stat_visc_checks", "stat_visc_fallbacks", "stat_fused3d", "stat_fused3d_nof1", "stat_fused3d_nof2")
+        c0 = [h.get_option(k) for k in keys]
+        try:
+            jr.solve_(stokes, s.pt, s.grid, s.flow_bcs, ρg, K, G, s.dt, None, kwargs=s.kwargs)
+        except _lib.JrxError as e:
+            assert "NaN" in str(e)
+        d = [b - a for a, b in zip(c0, [h.get_option(k) for k in keys])]
+    finally:
+        h.set_option("kernel_variant", 0)
+    assert d[0] == 1 and d[2] > 0
+    if name in ("fx", "fz"):
+        assert d[1] == 0 and d[4] == 0 and d[3] == (d[2] if name == "fz" else 0), d        # fz not zero: the x, y loads are still dropped (NOF = 1); fx not +0.0: every load stays
+    else:
+        assert d[1] == 1 and d[3] == d[4] == 0, d                                               # the check failed: general kernels
+
+
 @pytest.mark.parametrize("poison", ["toxx=nan", "toyz=inf", "P0=inf", "Q=nan", "K=0", "G=nan", "none"])
 def test_viscous_limit_falls_back_when_an_unloaded_operand_is_not_harmless(env, poison):
     """VERDICT r3 P3.  With dt = Inf the reference still multiplies τ_o, P0, Q by 0 and divides by K dt, G dt: a NaN / Inf in one of them (or K, G = 0: 0 * Inf)
